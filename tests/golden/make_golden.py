@@ -1,0 +1,160 @@
+#!/usr/bin/env python3
+"""
+Generate the golden fixtures under tests/golden/.   Run ONLY in the build container:
+
+    PYTHONDONTWRITEBYTECODE=1 python3 -B tests/golden/make_golden.py
+
+Two families, kept in separate files so it is always clear what pinned what:
+
+* ``ref_*.npz``   -- outputs of the REFERENCE'S OWN SOURCE (/root/reference/xrft) for the helpers that are
+  pure numpy/scipy and therefore runnable here: ``_freq`` (xrft.py:139-155) and ``_detrend_2d_ufunc``
+  (detrend.py:100-113).  xarray/dask are not installed, so the package is imported with throw-away stub
+  modules (SURVEY.md header note 3); only functions that never touch a DataArray are called.
+  These files pin the oracle (tests/test_oracle_golden.py).
+* ``case_*.npz``  -- seeded inputs + the ORACLE's outputs for whole-path cases (power_spectrum, cross_spectrum,
+  isotropic, dft).  They pin the HIP path against the oracle on the GPU box, where neither the reference
+  nor this generator can run, and guard the oracle against accidental edits.
+
+Fixtures are data only (inputs / expected outputs); no reference source text is stored.
+"""
+import os
+import sys
+import types
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, REPO)
+sys.dont_write_bytecode = True
+
+
+def import_reference():
+    """Import /root/reference/xrft with stub xarray/dask modules (read-only use, no bytecode written)."""
+    for name in ("xarray", "xarray.core", "xarray.core.utils", "dask", "dask.array"):
+        if name not in sys.modules:
+            sys.modules[name] = types.ModuleType(name)
+    sys.modules["xarray"].DataArray = object
+    sys.modules["xarray.core.utils"].either_dict_or_kwargs = lambda *a, **k: None
+    sys.modules["dask"].delayed = lambda *a, **k: None
+    sys.modules["dask"].array = sys.modules["dask.array"]
+    sys.path.insert(0, "/root/reference")
+    import xrft.xrft as rx  # noqa
+    import importlib
+    rd = importlib.import_module("xrft.detrend")  # (the package attribute `detrend` is the function)
+    rd = sys.modules["xrft.detrend"]
+    return rx, rd
+
+
+def gen_reference_files():
+    rx, rd = import_reference()
+    # ---- _freq
+    out = {}
+    cases = []
+    i = 0
+    for N in ([8], [9], [16], [4096], [65536], [16, 32], [9, 8], [720, 1440]):
+        for dx0 in (1.0, 0.25, 2.0e4):
+            for real in (None, "x"):
+                for shift in (False, True):
+                    dx = [dx0 * (1 + 0.5 * j) for j in range(len(N))]
+                    k = rx._freq(N, dx, real, shift)
+                    for j, kk in enumerate(k):
+                        out[f"k_{i}_{j}"] = kk
+                    cases.append((len(N),) + tuple(N) + (0,) * (2 - len(N)) + tuple(dx) + (0.0,) * (2 - len(N))
+                                 + (0 if real is None else 1, int(shift)))
+                    i += 1
+    out["cases"] = np.array(cases, dtype=np.float64)
+    np.savez_compressed(os.path.join(HERE, "ref_freq.npz"), **out)
+    # ---- _detrend_2d_ufunc
+    rng = np.random.default_rng(20260927)
+    out = {}
+    for j, shape in enumerate([(32, 16), (16, 32), (64, 48), (15, 9)]):
+        ny, nx = shape
+        ii, jj = np.meshgrid(np.arange(ny), np.arange(nx), indexing="ij")
+        arr = rng.standard_normal(shape) + 0.3 * ii - 0.7 * jj + 5.0
+        out[f"in_{j}"] = arr
+        out[f"out_{j}"] = rd._detrend_2d_ufunc(arr)
+    np.savez_compressed(os.path.join(HERE, "ref_detrend2d.npz"), **out)
+    print("reference-generated: ref_freq.npz, ref_detrend2d.npz")
+
+
+def gen_oracle_cases():
+    from oracle import xrft_oracle as o
+    import warnings
+
+    warnings.simplefilter("ignore")
+    rng = np.random.default_rng(20260927 + 1)
+
+    # (3) power_spectrum on the C1 shape family, reduced to (2, 64, 48) float64 to keep the file small
+    nt, ny, nx = 2, 64, 48
+    ii, jj = np.meshgrid(np.arange(ny), np.arange(nx), indexing="ij")
+    data = rng.standard_normal((nt, ny, nx)) + 0.01 * ii - 0.02 * jj + 3.0
+    out = {"data": data, "dy": 0.5, "dx": 2.0}
+    da = o.OArr(data, ("time", "y", "x"), {"time": np.arange(nt), "y": np.arange(ny) * 0.5, "x": np.arange(nx) * 2.0})
+    n = 0
+    combos = []
+    for det in (None, "constant", "linear"):
+        for win in (None, "hann"):
+            for scaling in ("density", "spectrum"):
+                for wc in (False, True):
+                    if wc and win is None:
+                        continue
+                    ps = o.power_spectrum(da, dim=["y", "x"], detrend=det, window=win, scaling=scaling,
+                                          window_correction=wc)
+                    out[f"ps_{n}"] = ps.values
+                    combos.append(f"{det}|{win}|{scaling}|{int(wc)}")
+                    n += 1
+    out["combos"] = np.array(combos)
+    out["freq_y"] = ps.coord("freq_y")
+    out["freq_x"] = ps.coord("freq_x")
+    np.savez_compressed(os.path.join(HERE, "case_ps2d_f64.npz"), **out)
+
+    # real_dim variant + float32 input
+    data32 = data.astype(np.float32)
+    da32 = o.OArr(data32, da.dims, da._coords_raw())
+    ps = o.power_spectrum(da32, dim=["y"], real_dim="x", detrend="linear", window="hann")
+    np.savez_compressed(os.path.join(HERE, "case_ps2d_f32_real.npz"), data=data32, ps=ps.values,
+                        freq_y=ps.coord("freq_y"), freq_x=ps.coord("freq_x"))
+
+    # (4) cross_spectrum on (2,16,16) with different coordinate origins (true-phase net factor)
+    a = rng.standard_normal((2, 16, 16))
+    b = rng.standard_normal((2, 16, 16))
+    c1 = {"t": np.arange(2), "y": np.arange(16) * 0.5 + 3.0, "x": np.arange(16) * 0.25 - 1.0}
+    c2 = {"t": np.arange(2), "y": np.arange(16) * 0.5 + 4.5, "x": np.arange(16) * 0.25 + 2.0}
+    cs = o.cross_spectrum(o.OArr(a, ("t", "y", "x"), c1), o.OArr(b, ("t", "y", "x"), c2), dim=["y", "x"],
+                          window="hann", detrend="constant")
+    cs2 = o.cross_spectrum(o.OArr(a, ("t", "y", "x"), c1), o.OArr(b, ("t", "y", "x"), c2), dim=["y", "x"],
+                           true_phase=False, scaling="spectrum")
+    np.savez_compressed(os.path.join(HERE, "case_cs2d.npz"), a=a, b=b, y1=c1["y"], x1=c1["x"], y2=c2["y"],
+                        x2=c2["x"], cs=cs.values, cs_nophase_spectrum=cs2.values)
+
+    # (5) isotropic power / cross spectrum: (16,32) random and a (64,64) red-noise field (slope -3)
+    r = rng.standard_normal((3, 16, 32))
+    dar = o.OArr(r, ("t", "y", "x"), {"t": np.arange(3), "y": np.arange(16), "x": np.arange(32)})
+    iso = o.isotropic_power_spectrum(dar, dim=["y", "x"], detrend="constant", window="hann")
+    r2 = rng.standard_normal((3, 16, 32))
+    dar2 = o.OArr(r2, dar.dims, dar._coords_raw())
+    ics = o.isotropic_cross_spectrum(dar, dar2, dim=["y", "x"], window="hann")
+    theta = np.stack([o.synthetic_field(64, 1.0, 10.0, -3.0, rng) for _ in range(2)])
+    dth = o.OArr(theta, ("d0", "y", "x"), {"d0": np.arange(2), "y": np.arange(64), "x": np.arange(64)})
+    iso2 = o.isotropic_power_spectrum(dth, dim=["y", "x"], detrend="constant", truncate=True)
+    np.savez_compressed(os.path.join(HERE, "case_iso.npz"), r=r, r2=r2, iso=iso.values, iso_kr=iso.coord("freq_r"),
+                        ics=ics.values, ics_kr=ics.coord("freq_r"), theta=theta, iso2=iso2.values,
+                        iso2_kr=iso2.coord("freq_r"))
+
+    # (6) 1-D dft: (4, 4096) float32 (the 65536-point row is exercised by seeded tests, not stored)
+    x = rng.standard_normal((4, 4096)).astype(np.float32)
+    dax = o.OArr(x, ("t", "x"), {"t": np.arange(4), "x": np.arange(4096) * 0.5})
+    ft = o.dft(dax, dim="x")
+    ft2 = o.fft(dax, dim="x", detrend="linear", window="hann")
+    np.savez_compressed(os.path.join(HERE, "case_dft1d_f32.npz"), x=x, ft=ft.values.astype(np.complex64),
+                        freq_x=ft.coord("freq_x"), ft_lin_hann=ft2.values)
+    print("oracle-generated: case_ps2d_f64.npz, case_ps2d_f32_real.npz, case_cs2d.npz, case_iso.npz, case_dft1d_f32.npz")
+
+
+if __name__ == "__main__":
+    if os.path.isdir("/root/reference/xrft"):
+        gen_reference_files()
+    else:
+        print("no /root/reference: skipping reference-generated files")
+    gen_oracle_cases()
