@@ -1,0 +1,186 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of BASELINE.json:
+    xrft.power_spectrum 2-D, detrend='linear' + Hann window, (nt, 4096, 4096) float32 per GPU.
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+One "step" = one call of ``xrft_amd.power_spectrum`` over the rank's whole (nt, ny, nx) cube, input already
+resident in HBM.  Batches shard over ranks as independent time slabs (weak scaling: nt per GPU is fixed); there is
+no data-path collective.  value = GFFT/s = 1e-9 * (points transformed by all ranks) / (max-over-ranks wall time).
+
+Extra objects on the JSON line:
+  roofline     : the dominant kernel (longest total time): achieved = 8 B/point (4 B read + 4 B
+                 written per input point) * points per launch / average launch duration, durations from HIP events
+                 recorded by the library on the launch stream inside the timed region (xrfthip_plan_set_profiling).
+                 "path" repeats the computation for the whole call (all kernels + gaps).
+  cpu_baseline : the CPU oracle (numpy/scipy restatement of the reference; the reference itself needs xarray,
+                 which the image lacks) timed on a bounded sample of the same workload, 1 thread.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+import warnings
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+if REPO not in sys.path:
+    sys.path.insert(0, REPO)
+
+HBM_PEAK = 8.0e12  # B/s, MI355X spec (MI355X_MICROARCH.md)
+BYTES_PER_POINT = 8.0  # f32 in (4 B) + f32 out (4 B) per input point
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--nt", type=int, default=64, help="time slabs per GPU")
+    ap.add_argument("--ny", type=int, default=4096)
+    ap.add_argument("--nx", type=int, default=4096)
+    ap.add_argument("--cpu-slabs", type=int, default=2, help="slabs timed through the CPU oracle (0 = skip)")
+    ap.add_argument("--no-profile", action="store_true", help="do not record per-kernel HIP events")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+
+    warnings.simplefilter("ignore")
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    assert world == max(args.gpus, 1), f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    dev = torch.device("cuda", local)
+    torch.cuda.set_device(dev)
+
+    import xrft_amd as xrft
+    from xrft_amd import _lib, api
+
+    _lib.load()  # no fallback: raises if the HIP library is missing
+    nt, ny, nx = args.nt, args.ny, args.nx
+
+    # ---- synthetic cube generated on the device: N(0,1) + plane + offset so that the linear detrend works
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(20260927 + 1000 * 3 + rank)
+    x = torch.randn((nt, ny, nx), dtype=torch.float32, device=dev, generator=gen)
+    x += (0.01 * torch.arange(ny, device=dev, dtype=torch.float32))[None, :, None]
+    x += (-0.02 * torch.arange(nx, device=dev, dtype=torch.float32) + 3.0)[None, None, :]
+    coords = {"time": np.arange(nt), "y": np.arange(ny, dtype=np.float64), "x": np.arange(nx, dtype=np.float64)}
+    da = xrft.DataArray(x, ("time", "y", "x"), coords)
+
+    def step():
+        return xrft.power_spectrum(da, dim=["y", "x"], detrend="linear", window="hann")
+
+    def barrier():
+        torch.cuda.synchronize(dev)
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    ps = None
+    for _ in range(args.warmup):
+        ps = step()
+    barrier()
+    plan = next(reversed(api._plan_cache.values())) if api._plan_cache else None
+    if plan is not None and not args.no_profile:
+        plan.set_profiling(True)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        ps = step()
+    barrier()
+    dt = time.perf_counter() - t0
+    prof = plan.read_profile() if (plan is not None and not args.no_profile) else {}
+    if plan is not None:
+        plan.set_profiling(False)
+    tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+    if dist is not None:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dt = float(tmax.item())
+
+    points_per_step = float(nt) * ny * nx * world
+    value = 1e-9 * points_per_step * args.steps / dt
+    ms_per_step = 1e3 * dt / args.steps
+
+    out = None
+    if rank == 0:
+        # ---- roofline of the dominant kernel
+        roof = None
+        if prof:
+            kern = {k: v for k, v in prof.items()}
+            dom = max(kern, key=lambda k: kern[k][1])
+            launches, total_ms = kern[dom]
+            avg_s = 1e-3 * total_ms / launches
+            launches_per_step = launches / args.steps
+            pts_per_launch = float(nt) * ny * nx / launches_per_step
+            achieved = BYTES_PER_POINT * pts_per_launch / avg_s
+            kernel_ms = sum(v[1] for v in kern.values()) / args.steps
+            roof = {
+                "bound": "hbm", "kernel": dom, "achieved": round(achieved / 1e9, 2), "peak": HBM_PEAK / 1e9,
+                "unit": "GB/s", "frac": round(achieved / HBM_PEAK, 4), "traffic": None,
+                "avg_launch_us": round(avg_s * 1e6, 2), "points_per_launch": pts_per_launch,
+                "bytes_per_point": BYTES_PER_POINT,
+                "kernels_ms_per_step": {k: round(v[1] / args.steps, 3) for k, v in kern.items()},
+                "path": {"achieved": round(BYTES_PER_POINT * value, 2), "unit": "GB/s",
+                         "frac": round(BYTES_PER_POINT * value * 1e9 / HBM_PEAK / world, 4),
+                         "sum_kernels_ms_per_step": round(kernel_ms, 3)},
+            }
+        # ---- CPU baseline (the oracle on a bounded sample, 1 thread) + parity of the same slabs
+        cpu = None
+        parity = None
+        if args.cpu_slabs > 0 and world == 1:
+            from oracle import xrft_oracle as oracle
+
+            try:
+                from threadpoolctl import threadpool_limits
+            except Exception:  # pragma: no cover
+                threadpool_limits = None
+            ns = min(args.cpu_slabs, nt)
+            sub = x[:ns].cpu().numpy()
+            oc = {"time": np.arange(ns), "y": coords["y"], "x": coords["x"]}
+            import contextlib
+
+            limiter = threadpool_limits(limits=1) if threadpool_limits else contextlib.nullcontext()
+            with limiter:
+                t0 = time.perf_counter()
+                ref = oracle.power_spectrum(oracle.OArr(sub, ("time", "y", "x"), oc), dim=["y", "x"],
+                                            detrend="linear", window="hann")
+                tc = time.perf_counter() - t0
+            cpu = {"value": round(1e-9 * ns * ny * nx / tc, 6), "unit": "GFFT/s", "cores": 1, "kind": "port",
+                   "sample": f"{ns} of {nt} slabs ({ny}x{nx} f32) through oracle.power_spectrum(detrend='linear', "
+                             f"window='hann') [numpy pocketfft + the reference's plane-fit algorithm], 1 thread, "
+                             f"{tc:.1f} s; host has {os.cpu_count()} cores"}
+            got = ps.data[:ns].cpu().numpy()
+            parity = float(np.abs(got - ref.values).max() / np.abs(ref.values).max())
+        out = {
+            "metric": "2-D power_spectrum GFFT/s (nt,4096,4096) fp32", "value": round(value, 3), "unit": "GFFT/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"xrft.power_spectrum dim=[y,x] detrend=linear window=hann on ({nt},{ny},{nx}) "
+                                   f"float32 per GPU (BASELINE.json configs[2])",
+                       "nt_per_gpu": nt, "ny": ny, "nx": nx, "parallelism": f"time-slab shards x{world}, no collective",
+                       "slabs_per_s": round(nt * world * args.steps / dt, 2)},
+            "roofline": roof, "cpu_baseline": cpu, "parity_max_rel_err_vs_oracle": parity,
+        }
+        if plan is not None:
+            out["plan"] = plan.describe().strip().split("\n")
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+
+
+if __name__ == "__main__":
+    main()

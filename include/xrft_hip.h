@@ -1,0 +1,154 @@
+/*
+ * xrft_hip.h -- C ABI of libxrft_hip.so: the MI355X (gfx950) spectral engine behind the xrft API.
+ *
+ * The reference (xgcm/xrft) is pure Python and has no FFI of its own.  The seam this library replaces is
+ * the array-backend module returned by `_fft_module` (reference xrft/xrft.py:32-36) together with the
+ * full-array numpy passes `xrft.fft` / `power_spectrum` / `cross_spectrum` / `isotropize` / `detrend`
+ * wrap around it.  One plan executes, fused on the device, what the reference does in these steps:
+ *
+ *   detrend (constant | linear)            xrft/detrend.py:54-55, 64-71, 100-113
+ *   window multiply                        xrft/xrft.py:96-103
+ *   flip + ifftshift of the input          xrft/xrft.py:436-441   (true_phase)
+ *   fftn / rfftn over the last 1-2 axes    xrft/xrft.py:439-444
+ *   fftshift                               xrft/xrft.py:446-447
+ *   x exp(-i 2 pi k lag), x prod(dx)       xrft/xrft.py:462-472
+ *   |F|^2  or  F1 conj(F2), real-dim x2,
+ *   / window correction, x prod(dk)        xrft/xrft.py:740-748, 825-833
+ *   radial bin-sum                         xrft/xrft.py:895-906, 993-1004
+ *
+ * Conventions
+ *   - every `d_*` pointer is a DEVICE pointer owned by the caller (e.g. torch tensor .data_ptr());
+ *     every `h_*` pointer is a HOST pointer, copied during the call;
+ *   - arrays are C-contiguous [batch][ny][nx] (ny == 1 for 1-D transforms); the transform runs over the
+ *     last `ndim` axes; `batch` slabs are independent;
+ *   - xrfthip_exec never allocates, never synchronises, and enqueues everything on `stream`
+ *     (a hipStream_t passed as void*; NULL = the default stream);
+ *   - all functions return 0 on success or a negative xrfthip_status; nothing throws or aborts.
+ *
+ * Python binding: xrft_amd/_lib.py (ctypes).  A reference-side binding sketch is in INTEGRATION.md.
+ */
+#ifndef XRFT_HIP_H
+#define XRFT_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define XRFTHIP_VERSION 100 /* 0.1.0 */
+
+typedef enum xrfthip_status {
+    XRFTHIP_OK = 0,
+    XRFTHIP_BAD_ARG = -1,
+    XRFTHIP_UNSUPPORTED_LENGTH = -2, /* a prime factor larger than XRFTHIP_MAX_RADIX */
+    XRFTHIP_WORKSPACE_TOO_SMALL = -3,
+    XRFTHIP_HIP_ERROR = -4, /* see xrfthip_last_hip_error() */
+    XRFTHIP_ALLOC_FAILED = -5,
+    XRFTHIP_MISSING_TABLE = -6 /* flag needs a table that was not set (window, phase, bin map) */
+} xrfthip_status;
+
+#define XRFTHIP_MAX_RADIX 128
+
+typedef enum xrfthip_dtype { /* dtype of the input array; the arithmetic runs in the matching precision */
+    XRFTHIP_F32 = 0,
+    XRFTHIP_F64 = 1,
+    XRFTHIP_C64 = 2,
+    XRFTHIP_C128 = 3
+} xrfthip_dtype;
+
+typedef enum xrfthip_out_mode {
+    XRFTHIP_OUT_COMPLEX = 0, /* F                    -> complex (c64 | c128)          xrft.fft            */
+    XRFTHIP_OUT_POWER = 1,   /* |F|^2 * scale        -> real    (f32 | f64)           xrft.power_spectrum */
+    XRFTHIP_OUT_CROSS = 2    /* F0 conj(F1) * scale  -> complex                       xrft.cross_spectrum */
+} xrfthip_out_mode;
+
+typedef enum xrfthip_detrend_kind {
+    XRFTHIP_DETREND_NONE = 0,
+    XRFTHIP_DETREND_CONSTANT = 1, /* subtract the mean over the transform axes, per slab  detrend.py:54-55 */
+    XRFTHIP_DETREND_LINEAR = 2    /* subtract the least-squares line (1-D) / plane (2-D)  detrend.py:64-113 */
+} xrfthip_detrend_kind;
+
+/* flags */
+#define XRFTHIP_HALF_X 0x001u   /* rfftn: keep only kx = 0..nx/2 along the last axis (real input only; no shift) */
+#define XRFTHIP_SHIFT_Y 0x002u  /* fftshift the output along y (xrft.py:446-447) */
+#define XRFTHIP_SHIFT_X 0x004u  /* fftshift the output along x */
+#define XRFTHIP_ISHIFT_Y 0x008u /* ifftshift the input along y (true_phase, xrft.py:440) */
+#define XRFTHIP_ISHIFT_X 0x010u /* ifftshift the input along x */
+#define XRFTHIP_FLIP_Y 0x020u   /* np.flip the input along y before the ifftshift (descending coordinate) */
+#define XRFTHIP_FLIP_X 0x040u   /* np.flip the input along x */
+#define XRFTHIP_REALDIM_X2 0x080u /* with HALF_X and POWER|CROSS: multiply by [1,2,...,2,(1)] (xrft.py:673-682) */
+#define XRFTHIP_ISO 0x100u      /* radial bin-sum of the POWER|CROSS result into d_iso (needs a bin map) */
+#define XRFTHIP_NO_SPECTRUM_OUT 0x200u /* with ISO: do not write the full spectrum (d_out may be NULL) */
+
+typedef struct xrfthip_desc {
+    uint32_t struct_size; /* = sizeof(xrfthip_desc) */
+    int32_t ndim;         /* 1 or 2: number of trailing axes transformed */
+    int64_t batch;        /* independent slabs */
+    int64_t ny;           /* 1 when ndim == 1 */
+    int64_t nx;
+    int32_t dtype;    /* xrfthip_dtype of d_in0 / d_in1 */
+    int32_t out_mode; /* xrfthip_out_mode */
+    int32_t detrend;  /* xrfthip_detrend_kind */
+    uint32_t flags;
+    double scale;            /* COMPLEX: multiplies F (prod(dx) for true_amplitude); POWER/CROSS: multiplies the product */
+    int32_t slabs_per_group; /* 0 = auto: slabs pushed through all passes together (keeps the intermediate in MALL) */
+    int32_t reserved;
+} xrfthip_desc;
+
+typedef struct xrfthip_plan xrfthip_plan;
+
+int xrfthip_version(void);
+const char* xrfthip_strerror(int status);
+int xrfthip_last_hip_error(void); /* hipError_t of the most recent XRFTHIP_HIP_ERROR on this thread */
+
+int xrfthip_plan_create(xrfthip_plan** plan, const xrfthip_desc* desc);
+int xrfthip_plan_destroy(xrfthip_plan* plan);
+
+/* axis: 0 = y, 1 = x.  h_window: n doubles (scipy.signal.windows.<name>(n, sym=False)).  NULL clears. */
+int xrfthip_plan_set_window(xrfthip_plan* plan, int axis, const double* h_window, int64_t n);
+/* h_phase: n interleaved (re,im) doubles indexed by UNSHIFTED frequency index: exp(-i 2 pi f_k lag)
+ * (for CROSS: the net factor phase0 * conj(phase1)).  NULL clears. */
+int xrfthip_plan_set_phase(xrfthip_plan* plan, int axis, const double* h_phase, int64_t n);
+/* h_binmap: [ny][nx_out] int32 bin codes indexed by UNSHIFTED frequency indices (nx_out = nx, or nx/2+1 with
+ * HALF_X); negative = not binned.  The host computes it with the reference's float64 pd.cut expression. */
+int xrfthip_plan_set_binmap(xrfthip_plan* plan, const int32_t* h_binmap, int64_t ny, int64_t nx_out, int32_t nbins);
+
+/* Per-pass timing with HIP events recorded on the exec stream around every kernel launch (bench.py's roofline
+ * figure).  enable != 0 starts a fresh record; xrfthip_plan_profile_read synchronises the recorded events and
+ * writes one line per pass: "<label> <launches> <total_ms>\n".  Off by default (no events are recorded). */
+int xrfthip_plan_set_profiling(xrfthip_plan* plan, int enable);
+int xrfthip_plan_profile_read(xrfthip_plan* plan, char* buf, size_t buflen);
+
+size_t xrfthip_workspace_bytes(const xrfthip_plan* plan);
+/* human-readable pass list (kernel, tile, grid, LDS) for logs and DESIGN.md; returns bytes written */
+int xrfthip_plan_describe(const xrfthip_plan* plan, char* buf, size_t buflen);
+
+/*
+ * d_in0 : [batch][ny][nx] input (dtype)
+ * d_in1 : second field for CROSS, else NULL
+ * d_out : COMPLEX/CROSS: complex [batch][ny][nx_out]; POWER: real [batch][ny][nx_out]; may be NULL with
+ *         XRFTHIP_NO_SPECTRUM_OUT
+ * d_iso : with XRFTHIP_ISO: float64 [batch][nbins] (POWER) or complex128 [batch][nbins] (CROSS), else NULL
+ * d_workspace / ws_bytes : >= xrfthip_workspace_bytes(plan), 256-byte aligned
+ */
+int xrfthip_exec(const xrfthip_plan* plan, const void* d_in0, const void* d_in1, void* d_out, void* d_iso,
+                 void* d_workspace, size_t ws_bytes, void* stream);
+
+/* Stand-alone detrend (xrft.detrend, detrend.py:11-97) over the last `ndim` axes: out = in - trend, same dtype.
+ * d_workspace: >= xrfthip_detrend_workspace_bytes(batch) bytes. */
+size_t xrfthip_detrend_workspace_bytes(int64_t batch);
+int xrfthip_detrend(int32_t dtype, int32_t ndim, int64_t batch, int64_t ny, int64_t nx, int32_t detrend_type,
+                    const void* d_in, void* d_out, void* d_workspace, size_t ws_bytes, void* stream);
+
+/* Stand-alone radial bin-sum of an existing spectrum (xrft.isotropize, xrft.py:948-1010):
+ * d_in [batch][ny][nx] (dtype F32|F64|C64|C128), d_binmap device int32 [ny][nx], d_iso float64|complex128
+ * [batch][nbins] (zeroed by the call). */
+int xrfthip_isotropize(int32_t dtype, int64_t batch, int64_t ny, int64_t nx, const void* d_in,
+                       const int32_t* d_binmap, int32_t nbins, void* d_iso, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* XRFT_HIP_H */

@@ -1,0 +1,110 @@
+"""CPU-side functional tests of the PRODUCT host code and kernels: the same sources as libxrft_hip.so, compiled by
+g++ against tests/emu/hip_emu.h (fibers stand in for GPU threads), driven through the same C ABI / ctypes binding
+and compared with the CPU oracle.  This exercises index arithmetic and host logic only -- it is NOT a product
+fallback and says nothing about the GPU build; the GPU parity tests are tests/test_gpu_parity.py (-m gpu)."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+sys.path.insert(0, os.path.join(os.path.dirname(__file__), "emu"))
+import build_emu  # noqa: E402
+
+from xrft_amd import _lib, api  # noqa: E402
+
+import cases  # noqa: E402
+
+
+@pytest.fixture(scope="module", autouse=True)
+def emulated_library():
+    api._plan_cache.clear()
+    _lib._load_for_testing(build_emu.build())
+    yield
+    api._plan_cache.clear()
+    _lib._state.update(dll=None, path=None, device="cuda")
+
+
+@pytest.mark.parametrize("name,dtype", cases.all_case_params())
+def test_case(name, dtype):
+    cases.run_case(name, dtype)
+
+
+@pytest.mark.parametrize("kind", cases.CROSS_KINDS)
+@pytest.mark.parametrize("dtype", ["float64", "float32"])
+def test_cross(kind, dtype):
+    cases.run_cross_case(kind, dtype)
+
+
+@pytest.mark.parametrize("dtype", ["float64", "float32"])
+def test_true_phase(dtype):
+    cases.run_true_phase_case(dtype)
+
+
+def test_golden_ps2d(golden_dir):
+    """Committed oracle fixtures (tests/golden/case_ps2d_f64.npz) through the product path."""
+    import xrft_amd as xa
+
+    z = np.load(os.path.join(golden_dir, "case_ps2d_f64.npz"))
+    data = z["data"]
+    nt, ny, nx = data.shape
+    da = xa.DataArray(data, ("time", "y", "x"), {"time": np.arange(nt), "y": np.arange(ny) * 0.5, "x": np.arange(nx) * 2.0})
+    for n, combo in enumerate(z["combos"]):
+        det, win, scaling, wc = str(combo).split("|")
+        ps = xa.power_spectrum(da, dim=["y", "x"], detrend=None if det == "None" else det,
+                               window=None if win == "None" else win, scaling=scaling, window_correction=bool(int(wc)))
+        ref = z[f"ps_{n}"]
+        assert np.abs(ps.values - ref).max() / np.abs(ref).max() < 1e-10, combo
+    assert np.array_equal(ps["freq_y"].values, z["freq_y"]) and np.array_equal(ps["freq_x"].values, z["freq_x"])
+
+
+def test_four_step_paths(monkeypatch):
+    """Force the four-step decompositions (normally only used when a sequence does not fit one LDS tile)."""
+    import xrft_amd as xa
+    from oracle import xrft_oracle as o
+
+    rng = np.random.default_rng(5)
+    monkeypatch.setenv("XRFTHIP_X_FOURSTEP_MIN", "2")
+    monkeypatch.setenv("XRFTHIP_Y_FOURSTEP_MIN", "2")
+    api._plan_cache.clear()
+    for shape, dt in [((2, 12, 60), "float64"), ((2, 16, 36), "complex128"), ((3, 1, 120), "float64")]:
+        v = rng.standard_normal(shape)
+        if dt.startswith("complex"):
+            v = v + 1j * rng.standard_normal(shape)
+        c = {"t": np.arange(shape[0]), "y": np.arange(shape[1]) * 0.5, "x": np.arange(shape[2]) * 0.25 + 1.0}
+        da, od = cases.pair(v.astype(dt), ("t", "y", "x"), c)
+        dims = ["y", "x"] if shape[1] > 1 else ["x"]
+        cases.check(xa.fft(da, dim=dims, detrend="linear", window="hann"), o.fft(od, dim=dims, detrend="linear", window="hann"), 1e-10)
+        cases.check(xa.power_spectrum(da, dim=dims), o.power_spectrum(od, dim=dims), 1e-10)
+        if dt == "float64":
+            cases.check(xa.power_spectrum(da, dim=dims[:-1], real_dim="x"), o.power_spectrum(od, dim=dims[:-1], real_dim="x"), 1e-10)
+    api._plan_cache.clear()
+
+
+def test_groups_and_batches(monkeypatch):
+    """Several slab groups per call (workspace re-use) and a batch that is not a multiple of the group size."""
+    import xrft_amd as xa
+    from oracle import xrft_oracle as o
+
+    monkeypatch.setenv("XRFTHIP_GROUP", "2")
+    api._plan_cache.clear()
+    rng = np.random.default_rng(6)
+    v = rng.standard_normal((5, 8, 12)) + np.arange(12) * 0.1
+    c = {"t": np.arange(5), "y": np.arange(8.0), "x": np.arange(12.0)}
+    da, od = cases.pair(v, ("t", "y", "x"), c)
+    cases.check(xa.power_spectrum(da, dim=["y", "x"], detrend="linear", window="hann"),
+                o.power_spectrum(od, dim=["y", "x"], detrend="linear", window="hann"), 1e-10)
+    cases.check(xa.isotropic_power_spectrum(da, dim=["y", "x"], detrend="constant"),
+                o.isotropic_power_spectrum(od, dim=["y", "x"], detrend="constant"), 1e-10)
+    da2, od2 = cases.pair(rng.standard_normal((5, 8, 12)), ("t", "y", "x"), c)
+    cases.check(xa.cross_spectrum(da, da2, dim=["y", "x"], detrend="linear"),
+                o.cross_spectrum(od, od2, dim=["y", "x"], detrend="linear"), 1e-10)
+    api._plan_cache.clear()
+
+
+def test_unsupported_length_is_loud():
+    import xrft_amd as xa
+
+    da = xa.DataArray(np.zeros((2, 131)), ("t", "x"))  # 131 is a prime > XRFTHIP_MAX_RADIX
+    with pytest.raises(xa.XrftHipError):
+        xa.fft(da, dim="x")

@@ -1,0 +1,236 @@
+"""GPU parity tests proper (-m gpu): the real libxrft_hip.so on an MI355X, called through the C ABI via the
+product API, compared with the CPU oracle on seeded inputs, with the committed golden fixtures, and -- at the
+sizes of BASELINE.json -- through size-independent properties (Parseval, linearity, Hermitian symmetry,
+sum conservation of the radial reduce).  Nothing here reads /root/reference."""
+import os
+import warnings
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+warnings.simplefilter("ignore")
+
+torch = pytest.importorskip("torch")
+
+import cases  # noqa: E402
+from oracle import xrft_oracle as o  # noqa: E402
+
+
+@pytest.fixture(scope="module", autouse=True)
+def real_library():
+    from xrft_amd import _lib, api
+
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    api._plan_cache.clear()
+    _lib._state.update(dll=None, path=None, device="cuda")
+    dll = _lib.load()  # raises XrftHipUnavailable if the HIP library is missing: no fallback
+    assert _lib._state["path"].endswith("libxrft_hip.so") and _lib.device() == "cuda"
+    assert dll.xrfthip_version() >= 100
+    yield
+    api._plan_cache.clear()
+
+
+@pytest.mark.parametrize("name,dtype", cases.all_case_params())
+def test_case(name, dtype):
+    cases.run_case(name, dtype)
+
+
+@pytest.mark.parametrize("kind", cases.CROSS_KINDS)
+@pytest.mark.parametrize("dtype", ["float64", "float32"])
+def test_cross(kind, dtype):
+    cases.run_cross_case(kind, dtype)
+
+
+@pytest.mark.parametrize("dtype", ["float64", "float32"])
+def test_true_phase(dtype):
+    cases.run_true_phase_case(dtype)
+
+
+def _da(data, dims, coords):
+    import xrft_amd as xa
+
+    return xa.DataArray(torch.from_numpy(np.ascontiguousarray(data)).cuda(), dims, coords)
+
+
+# ---------------------------------------------------------------------------------- golden fixtures
+def test_golden_fixtures(golden_dir):
+    import xrft_amd as xa
+
+    z = np.load(os.path.join(golden_dir, "case_ps2d_f64.npz"))
+    data = z["data"]
+    nt, ny, nx = data.shape
+    c = {"time": np.arange(nt), "y": np.arange(ny) * 0.5, "x": np.arange(nx) * 2.0}
+    da = _da(data, ("time", "y", "x"), c)
+    for n, combo in enumerate(z["combos"]):
+        det, win, scaling, wc = str(combo).split("|")
+        ps = xa.power_spectrum(da, dim=["y", "x"], detrend=None if det == "None" else det,
+                               window=None if win == "None" else win, scaling=scaling, window_correction=bool(int(wc)))
+        ref = z[f"ps_{n}"]
+        assert np.abs(ps.values - ref).max() / np.abs(ref).max() < 1e-10, combo
+    assert np.array_equal(ps["freq_y"].values, z["freq_y"]) and np.array_equal(ps["freq_x"].values, z["freq_x"])
+
+    z = np.load(os.path.join(golden_dir, "case_ps2d_f32_real.npz"))
+    ps = xa.power_spectrum(_da(z["data"], ("time", "y", "x"), c), dim=["y"], real_dim="x", detrend="linear", window="hann")
+    assert np.abs(ps.values - z["ps"]).max() / np.abs(z["ps"]).max() < 1e-3
+
+    z = np.load(os.path.join(golden_dir, "case_cs2d.npz"))
+    c1 = {"t": np.arange(2), "y": z["y1"], "x": z["x1"]}
+    c2 = {"t": np.arange(2), "y": z["y2"], "x": z["x2"]}
+    cs = xa.cross_spectrum(_da(z["a"], ("t", "y", "x"), c1), _da(z["b"], ("t", "y", "x"), c2), dim=["y", "x"],
+                           window="hann", detrend="constant")
+    assert np.abs(cs.values - z["cs"]).max() / np.abs(z["cs"]).max() < 1e-10
+    cs = xa.cross_spectrum(_da(z["a"], ("t", "y", "x"), c1), _da(z["b"], ("t", "y", "x"), c2), dim=["y", "x"],
+                           true_phase=False, scaling="spectrum")
+    assert np.abs(cs.values - z["cs_nophase_spectrum"]).max() / np.abs(z["cs_nophase_spectrum"]).max() < 1e-10
+
+    z = np.load(os.path.join(golden_dir, "case_iso.npz"))
+    c = {"t": np.arange(3), "y": np.arange(16), "x": np.arange(32)}
+    iso = xa.isotropic_power_spectrum(_da(z["r"], ("t", "y", "x"), c), dim=["y", "x"], detrend="constant", window="hann")
+    assert np.abs(iso.values - z["iso"]).max() / np.abs(z["iso"]).max() < 1e-10
+    np.testing.assert_allclose(iso["freq_r"].values, z["iso_kr"], rtol=1e-13)
+    ics = xa.isotropic_cross_spectrum(_da(z["r"], ("t", "y", "x"), c), _da(z["r2"], ("t", "y", "x"), c), dim=["y", "x"], window="hann")
+    assert np.abs(ics.values - z["ics"]).max() / np.abs(z["ics"]).max() < 1e-10
+    c = {"d0": np.arange(2), "y": np.arange(64), "x": np.arange(64)}
+    iso2 = xa.isotropic_power_spectrum(_da(z["theta"], ("d0", "y", "x"), c), dim=["y", "x"], detrend="constant", truncate=True)
+    assert np.abs(iso2.values - z["iso2"]).max() / np.abs(z["iso2"]).max() < 1e-10
+    np.testing.assert_allclose(iso2["freq_r"].values, z["iso2_kr"], rtol=1e-13, equal_nan=True)
+
+    z = np.load(os.path.join(golden_dir, "case_dft1d_f32.npz"))
+    c = {"t": np.arange(4), "x": np.arange(4096) * 0.5}
+    ft = xa.dft(_da(z["x"], ("t", "x"), c), dim="x")
+    assert np.abs(ft.values - z["ft"]).max() / np.abs(z["ft"]).max() < 1e-3
+    assert np.array_equal(ft["freq_x"].values, z["freq_x"])
+    ft2 = xa.fft(_da(z["x"], ("t", "x"), c), dim="x", detrend="linear", window="hann")
+    assert np.abs(ft2.values - z["ft_lin_hann"]).max() / np.abs(z["ft_lin_hann"]).max() < 1e-3
+
+
+# ---------------------------------------------------------------------------------- BASELINE.json configs vs oracle
+def test_config1_ps_256_f64():
+    import xrft_amd as xa
+
+    rng = np.random.default_rng(101)
+    v = rng.standard_normal((4, 256, 256)) + 0.01 * np.arange(256)
+    c = {"time": np.arange(4), "y": np.arange(256.0), "x": np.arange(256.0)}
+    got = xa.power_spectrum(_da(v, ("time", "y", "x"), c), dim=["y", "x"], detrend="linear", window="hann")
+    ref = o.power_spectrum(o.OArr(v, ("time", "y", "x"), c), dim=["y", "x"], detrend="linear", window="hann")
+    cases.check(got, ref, 1e-6)
+
+
+def test_config2_dft_65536_f32():
+    """1-D dft along x of (8, 65536) float32: rows do not fit one LDS tile -> four-step 256 x 256."""
+    import xrft_amd as xa
+
+    rng = np.random.default_rng(102)
+    v = rng.standard_normal((8, 65536)).astype(np.float32)
+    c = {"t": np.arange(8), "x": np.arange(65536) * 0.25}
+    got = xa.dft(_da(v, ("t", "x"), c), dim="x")
+    ref = o.dft(o.OArr(v, ("t", "x"), c), dim="x")
+    cases.check(got, ref, 1e-3)
+    assert np.array_equal(got["freq_x"].values, np.fft.fftshift(np.fft.fftfreq(65536, 0.25)))
+    got = xa.power_spectrum(_da(v.astype(np.float64), ("t", "x"), c), dim="x", real_dim="x", detrend="linear", window="hann")
+    ref = o.power_spectrum(o.OArr(v.astype(np.float64), ("t", "x"), c), dim="x", real_dim="x", detrend="linear", window="hann")
+    cases.check(got, ref, 1e-6)
+
+
+def test_config3_ps_4096_f32_vs_oracle():
+    """The headline shape, one slab against the oracle (the oracle's plane fit takes ~8 s per slab)."""
+    import xrft_amd as xa
+
+    rng = np.random.default_rng(103)
+    ny = nx = 4096
+    v = rng.standard_normal((1, ny, nx)).astype(np.float32)
+    v += (0.01 * np.arange(ny, dtype=np.float32))[None, :, None] + (-0.02 * np.arange(nx, dtype=np.float32) + 3)[None, None, :]
+    c = {"time": np.arange(1), "y": np.arange(ny, dtype=np.float64), "x": np.arange(nx, dtype=np.float64)}
+    got = xa.power_spectrum(_da(v, ("time", "y", "x"), c), dim=["y", "x"], detrend="linear", window="hann")
+    ref = o.power_spectrum(o.OArr(v, ("time", "y", "x"), c), dim=["y", "x"], detrend="linear", window="hann")
+    cases.check(got, ref, 1e-3)
+    # and tighter in a norm that does not depend on the largest bin
+    g, r = got.values.astype(np.float64), ref.values
+    assert np.abs(g - r).sum() / np.abs(r).sum() < 1e-4
+
+
+def test_config4_cross_iso_2048_f32():
+    import xrft_amd as xa
+
+    rng = np.random.default_rng(104)
+    n = 2048
+    a = rng.standard_normal((2, n, n)).astype(np.float32)
+    b = (0.5 * a + rng.standard_normal((2, n, n))).astype(np.float32)
+    c = {"t": np.arange(2), "y": np.arange(n, dtype=np.float64), "x": np.arange(n, dtype=np.float64)}
+    got = xa.cross_spectrum(_da(a, ("t", "y", "x"), c), _da(b, ("t", "y", "x"), c), dim=["y", "x"], window="hann")
+    ref = o.cross_spectrum(o.OArr(a, ("t", "y", "x"), c), o.OArr(b, ("t", "y", "x"), c), dim=["y", "x"], window="hann")
+    cases.check(got, ref, 1e-3)
+    iso = xa.isotropic_power_spectrum(_da(a, ("t", "y", "x"), c), dim=["y", "x"], window="hann")
+    iref = o.isotropic_power_spectrum(o.OArr(a, ("t", "y", "x"), c), dim=["y", "x"], window="hann")
+    cases.check(iso, iref, 1e-3)
+    ics = xa.isotropic_cross_spectrum(_da(a, ("t", "y", "x"), c), _da(b, ("t", "y", "x"), c), dim=["y", "x"], window="hann")
+    icref = o.isotropic_cross_spectrum(o.OArr(a, ("t", "y", "x"), c), o.OArr(b, ("t", "y", "x"), c), dim=["y", "x"], window="hann")
+    cases.check(ics, icref, 1e-3)
+    # sum conservation of the radial reduce (test_xrft.py:963)
+    ps = xa.power_spectrum(_da(a, ("t", "y", "x"), c), dim=["y", "x"], window="hann")
+    np.testing.assert_allclose(iso.values.sum(), ps.values.astype(np.float64).sum(), rtol=1e-5)
+
+
+def test_config5_ps_1440x720_f64():
+    """MITgcm-like cube: mixed radix 2^5 3^2 5 x 2^4 3^2 5 in float64."""
+    import xrft_amd as xa
+
+    rng = np.random.default_rng(105)
+    v = rng.standard_normal((3, 1440, 720)) + 0.002 * np.arange(720)
+    c = {"time": np.arange(3), "lat": np.arange(1440) * 0.25, "lon": np.arange(720) * 0.25}
+    got = xa.power_spectrum(_da(v, ("time", "lat", "lon"), c), dim=["lat", "lon"], detrend="constant", window="hann")
+    ref = o.power_spectrum(o.OArr(v, ("time", "lat", "lon"), c), dim=["lat", "lon"], detrend="constant", window="hann")
+    cases.check(got, ref, 1e-6)
+
+
+# ---------------------------------------------------------------------------------- full-size properties
+def test_full_size_properties_4096():
+    """(8, 4096, 4096) float32 on the device: Parseval with window + linear detrend (test_xrft.py:693-842), Hermitian
+    symmetry of the spectrum of a real field, linearity of fft, determinism."""
+    import xrft_amd as xa
+
+    nt, ny, nx = 8, 4096, 4096
+    g = torch.Generator(device="cuda").manual_seed(7)
+    x = torch.randn((nt, ny, nx), dtype=torch.float32, device="cuda", generator=g)
+    x += (0.01 * torch.arange(ny, device="cuda"))[None, :, None] + (-0.02 * torch.arange(nx, device="cuda"))[None, None, :]
+    c = {"time": np.arange(nt), "y": np.arange(ny, dtype=np.float64), "x": np.arange(nx, dtype=np.float64)}
+    da = xa.DataArray(x, ("time", "y", "x"), c)
+    ps = xa.power_spectrum(da, dim=["y", "x"], detrend="linear", window="hann")
+    det = xa.detrend(da, ["y", "x"], "linear")
+    import scipy.signal as sps
+    w = torch.from_numpy(sps.windows.hann(ny, sym=False)).cuda()
+    wx = torch.from_numpy(sps.windows.hann(nx, sym=False)).cuda()
+    lhs = ps.data.double().mean(dim=(1, 2))  # (1/dxdy) mean(ps), dx = dy = 1
+    rhs = ((det.data.double() * w[None, :, None] * wx[None, None, :]) ** 2).mean(dim=(1, 2))
+    assert torch.allclose(lhs, rhs, rtol=2e-4), (lhs, rhs)
+    # Hermitian symmetry of the shifted spectrum: ps[ky, kx] == ps[-ky, -kx]
+    p = ps.data[0]
+    assert torch.allclose(p[1:, 1:], torch.flip(p[1:, 1:], dims=(0, 1)), rtol=1e-5, atol=0)
+    assert torch.isfinite(ps.data).all()
+    # determinism
+    ps2 = xa.power_spectrum(da, dim=["y", "x"], detrend="linear", window="hann")
+    assert torch.equal(ps.data, ps2.data)
+    # linearity of the complex transform on a 2-slab subset
+    a = xa.DataArray(x[:2].contiguous(), ("time", "y", "x"), {"time": np.arange(2), "y": c["y"], "x": c["x"]})
+    b = xa.DataArray(torch.flip(x[2:4], dims=(2,)).contiguous(), a.dims, a.coords)
+    s = xa.DataArray((2.0 * a.data - 0.5 * b.data), a.dims, a.coords)
+    fa, fb, fs = (xa.fft(t, dim=["y", "x"], true_phase=False, true_amplitude=False).data for t in (a, b, s))
+    num = (fs - (2.0 * fa - 0.5 * fb)).abs().max()
+    assert float(num / fs.abs().max()) < 1e-5
+
+
+def test_isotropic_slope_minus3():
+    """test_xrft.py:995-1031: isotropic PS of a synthetic red-noise field has slope -3 (N = 512)."""
+    import xrft_amd as xa
+
+    rng = np.random.default_rng(11)
+    N = 512
+    theta = o.synthetic_field(N, 1.0, 10.0, -3.0, rng)
+    v = theta[None] + np.ones((4, 1, 1))
+    da = _da(v, ("d0", "y", "x"), {"y": np.arange(N), "x": np.arange(N)})
+    iso = xa.isotropic_power_spectrum(da, dim=["y", "x"], detrend="constant", density=True)
+    m = iso.values.mean(axis=0)
+    assert np.isfinite(m).all()
+    _, a, _ = xa.fit_loglog(iso["freq_r"].values[:-35], m[:-35])
+    np.testing.assert_allclose(a, -3.0, atol=0.06)

@@ -1,0 +1,18 @@
+"""xrft_amd -- the xrft spectral hot path (fft / dft / power_spectrum / cross_spectrum / isotropic_* / detrend)
+on AMD MI355X (gfx950): hand-written HIP kernels in libxrft_hip.so behind the reference's call signatures.
+
+    import xrft_amd as xrft
+    ps = xrft.power_spectrum(da, dim=["y", "x"], detrend="linear", window="hann")
+
+``da`` is an ``xrft_amd.DataArray`` (numpy or torch data) or, when xarray is installed, an ``xarray.DataArray``.
+There is no CPU fallback: the compute entry points raise ``XrftHipUnavailable`` if the library is not built.
+"""
+from ._lib import XrftHipError, XrftHipUnavailable  # noqa: F401
+from .labeled import Coordinate, DataArray  # noqa: F401
+from .api import (cross_spectrum, detrend, dft, fft, fit_loglog, isotropic_cross_spectrum,  # noqa: F401
+                  isotropic_power_spectrum, isotropize, power_spectrum)
+
+__version__ = "0.1.0"
+__all__ = ["DataArray", "Coordinate", "fft", "dft", "detrend", "power_spectrum", "cross_spectrum", "isotropize",
+           "isotropic_power_spectrum", "isotropic_cross_spectrum", "fit_loglog", "XrftHipError",
+           "XrftHipUnavailable"]

@@ -1,0 +1,589 @@
+"""The xrft call surface (same names, argument meaning and error behaviour as the reference's
+``xrft/xrft.py`` and ``xrft/detrend.py``), executed by the MI355X engine in libxrft_hip.so.
+
+Host side (this file): argument normalisation, coordinate validation, spacing / lag / frequency vectors,
+window vectors, the radial bin map -- all tiny float64 numpy work that must match the reference bit for bit.
+Device side (one fused plan per call): detrend, window, flip/ifftshift, FFT, fftshift, phase, scaling,
+|F|^2 / F conj(G), Hermitian mirror, radial bin-sum.
+
+Deviations from the reference, all documented in DESIGN.md:
+  * float32 input is computed and returned in float32/complex64 (the reference promotes to float64 as soon as a
+    float64 window or ``prod(dx)`` touches the data); isotropic results are returned in float64/complex128;
+  * at most two transform dimensions (the reference also offers 3-D linear detrend / N-D fftn);
+  * ``chunks_to_segments`` needs dask chunks in the reference; here it is not implemented yet.
+"""
+from __future__ import annotations
+
+import warnings
+from collections import OrderedDict
+
+import numpy as np
+import pandas as pd
+import scipy.signal as sps
+import torch
+from pandas.api.types import is_datetime64_any_dtype, is_numeric_dtype
+
+from . import _lib, engine
+from .labeled import Coordinate, DataArray, from_any, to_like
+
+__all__ = ["fft", "dft", "detrend", "power_spectrum", "cross_spectrum", "isotropize", "isotropic_power_spectrum",
+           "isotropic_cross_spectrum", "fit_loglog"]
+
+_WINDOW_NAMES = [  # xrft.py:48-72
+    "hann", "hamming", "kaiser", "tukey", "parzen", "taylor", "boxcar", "barthann", "bartlett", "blackman",
+    "blackmanharris", "bohman", "chebwin", "cosine", "dpss", "exponential", "flattop", "gaussian",
+    "general_cosine", "general_gaussian", "general_hamming", "triang", "nuttall",
+]
+_real_flag_warning = ("`real` flag will be deprecated in future version of xrft.fft and replaced by `real_dim` flag.")
+
+
+# ------------------------------------------------------------------------------------------------------
+# coordinate helpers (host, float64) -- xrft.py:139-155, 195-234, 269-304
+# ------------------------------------------------------------------------------------------------------
+def _freq(N, delta_x, real, shift):
+    if real is None:
+        fftfreq = [np.fft.fftfreq] * len(N)
+    else:
+        fftfreq = [np.fft.fftfreq] * (len(N) - 1)
+        fftfreq.append(np.fft.rfftfreq)
+    k = [f(Nx, dx) for (f, Nx, dx) in zip(fftfreq, N, delta_x)]
+    if shift:
+        k = [np.fft.fftshift(l) for l in k]
+    return k
+
+
+def _diff_coord(coord):
+    v0 = coord[0]
+    if getattr(v0, "calendar", None):
+        import cftime  # xrft.py:200-206; only reachable when cftime is installed
+
+        decoded = cftime.date2num(coord, "seconds since 1800-01-01 00:00:00", v0.calendar)
+        return np.diff(decoded)
+    if pd.api.types.is_datetime64_dtype(v0):
+        return np.diff(coord).astype("timedelta64[ns]").astype("f8") / 1e9
+    return np.diff(coord)
+
+
+def _lag_coord(coord):
+    v0 = coord[0]
+    coord_data = coord if coord[-1] > coord[0] else np.flip(coord, axis=-1)
+    lag = coord_data[len(coord) // 2]
+    if getattr(v0, "calendar", None):
+        import cftime
+
+        return cftime.date2num(lag, "seconds since 1800-01-01 00:00:00", v0.calendar)
+    if pd.api.types.is_datetime64_dtype(v0):
+        return lag.astype("timedelta64[s]").astype("f8")
+    return lag
+
+
+def _is_valid_fft_coord(coord):
+    c0 = coord[0]
+    return bool(is_numeric_dtype(coord) or is_datetime64_any_dtype(coord)
+                or bool(getattr(c0.item() if hasattr(c0, "item") else c0, "calendar", False)))
+
+
+def _get_coordinate_spacing(coord, spacing_tol, name):
+    diff = _diff_coord(coord)
+    delta = np.abs(diff[0])
+    if not np.allclose(diff, diff[0], rtol=spacing_tol):
+        raise ValueError("Can't take Fourier transform because coodinate %s is not evenly spaced" % name)
+    if delta == 0.0:
+        raise ValueError("Can't take Fourier transform because spacing in coordinate %s is zero" % name)
+    return delta
+
+
+def _move_to_end(lst, el):
+    return [i for i in lst if i != el] + [el]
+
+
+def _window_vector(window_type, n):
+    if window_type is True:  # xrft.py:42-47
+        window_type = "hann"
+        warnings.warn("Please provide the name of window adhering to scipy.signal.windows. The boolean option "
+                      "will be deprecated in future releases.", FutureWarning)
+    elif window_type not in _WINDOW_NAMES:
+        raise NotImplementedError(f"Window type {window_type} not supported. Please adhere to "
+                                  "scipy.signal.windows for naming convention.")
+    return getattr(sps.windows, window_type)(n, sym=False)
+
+
+# ------------------------------------------------------------------------------------------------------
+# device plumbing
+# ------------------------------------------------------------------------------------------------------
+_TORCH_OK = (torch.float32, torch.float64, torch.complex64, torch.complex128)
+
+
+def _to_device(data):
+    dev = _lib.device()
+    if isinstance(data, torch.Tensor):
+        t = data
+    else:
+        a = np.asarray(data)
+        if a.dtype == np.float16:
+            a = a.astype(np.float32)
+        elif a.dtype.kind in "biu":
+            a = a.astype(np.float64)  # numpy.fft promotes integers to float64
+        elif a.dtype.kind not in "fc":
+            raise TypeError(f"cannot transform data of dtype {a.dtype}")
+        elif a.dtype.itemsize > 8 and a.dtype.kind == "f" or a.dtype.itemsize > 16:
+            a = a.astype(np.complex128 if a.dtype.kind == "c" else np.float64)
+        t = torch.from_numpy(np.ascontiguousarray(a))
+    if t.dtype not in _TORCH_OK:
+        t = t.to(torch.float64 if not t.is_complex() else torch.complex128)
+    return t.to(dev)
+
+
+_plan_cache: "OrderedDict[tuple, engine.SpectralPlan]" = OrderedDict()
+_PLAN_CACHE_SIZE = 16
+
+
+def _akey(a):
+    return None if a is None else hash(np.ascontiguousarray(a).tobytes())
+
+
+def _get_plan(**kw):
+    key = tuple((k, _akey(v) if isinstance(v, np.ndarray) else v) for k, v in sorted(kw.items()))
+    p = _plan_cache.get(key)
+    if p is None:
+        p = engine.SpectralPlan(**kw)
+        _plan_cache[key] = p
+        while len(_plan_cache) > _PLAN_CACHE_SIZE:
+            _plan_cache.popitem(last=False)
+    else:
+        _plan_cache.move_to_end(key)
+    return p
+
+
+class _Ctx:
+    """Everything ``fft`` derives on the host before touching the device (xrft.py:370-433)."""
+
+
+def _analyze(da, spacing_tol, dim, real_dim, shift, detrend, window, true_phase, chunks_to_segments, prefix, real):
+    c = _Ctx()
+    if dim is None:
+        dim = list(da.dims)
+    elif isinstance(dim, str):
+        dim = [dim]
+    else:
+        dim = list(dim)
+    if real is not None:  # xrft.py:376-378
+        real_dim = real
+        warnings.warn(_real_flag_warning, FutureWarning)
+    if real_dim is not None:  # xrft.py:380-386
+        if real_dim not in da.dims:
+            raise ValueError("The dimension along which real FT is taken must be one of the existing dimensions.")
+        dim = _move_to_end(dim, real_dim)
+    for d in dim:
+        da.get_axis_num(d)
+    if not np.all([_is_valid_fft_coord(da[d].values) for d in dim]):  # xrft.py:277-281
+        raise ValueError("All transformed dimensions coordinates must be numerical or datetime.")
+    if chunks_to_segments:
+        raise NotImplementedError("chunks_to_segments relies on dask chunks in the reference; not implemented "
+                                  "in xrft_amd yet (reshape the segmented dimension explicitly instead).")
+    if real_dim is not None:
+        shift = False  # xrft.py:403
+    c.rawdims = da.dims
+    c.dim, c.real_dim, c.shift = dim, real_dim, bool(shift)
+    c.N = [da.sizes[d] for d in dim]
+    for d in dim:  # xrft.py:412-420
+        bad = [cn for cn, cv in da.coords.items() if cn != d and d in cv.dims]
+        if bad:
+            raise ValueError(f"The input array contains coordinate variable(s) ({bad}) whose dims include the "
+                             f"transform dimension(s) `{d}`. Please drop these coordinates (`.drop({bad}`) "
+                             "before invoking xrft.")
+    c.delta_x = [_get_coordinate_spacing(da[d].values, spacing_tol, d) for d in dim]  # xrft.py:422
+    c.lag_x = [_lag_coord(da[d].values) for d in dim]  # xrft.py:423
+    if detrend not in (None, "constant", "linear"):  # detrend.py:46-50
+        raise NotImplementedError("%s is not a valid detrending option. Valid options are: 'constant','linear', "
+                                  "or None." % detrend)
+    if len(dim) > 2 or len(dim) == 0:
+        raise NotImplementedError("xrft_amd transforms one or two dimensions per call (the reference's N-D fftn / "
+                                  "3-D linear detrend are outside the MI355X hot path, SURVEY.md 8f).")
+    c.detrend = {None: _lib.DETREND_NONE, "constant": _lib.DETREND_CONSTANT, "linear": _lib.DETREND_LINEAR}[detrend]
+    c.windows = None if window is None else [_window_vector(window, n) for n in c.N]
+    c.true_phase = bool(true_phase)
+    c.reversed = [bool(da[d].values[-1] < da[d].values[0]) for d in dim] if true_phase else [False] * len(dim)
+    # device axis roles: x = last listed dim when real (xrft.py:395-396), else the one stored last in memory
+    if len(dim) == 1:
+        c.ydim, c.xdim = None, dim[0]
+    elif real_dim is not None:
+        c.ydim, c.xdim = dim[0], dim[1]
+    else:
+        a0, a1 = da.get_axis_num(dim[0]), da.get_axis_num(dim[1])
+        c.ydim, c.xdim = (dim[0], dim[1]) if a0 < a1 else (dim[1], dim[0])
+    c.k = _freq(c.N, c.delta_x, real_dim, c.shift)  # xrft.py:449
+    c.k_unshifted = _freq(c.N, c.delta_x, real_dim, False)
+    c.prefix = prefix
+    c.swap = OrderedDict()
+    c.new_coords = {}
+    for d, kk in zip(dim, c.k):  # xrft.py:178-192
+        new_name = prefix + d if d[: len(prefix)] != prefix else d[len(prefix):]
+        c.swap[d] = new_name
+        c.new_coords[new_name] = Coordinate((new_name,), kk, {"spacing": kk[1] - kk[0]} if len(kk) > 1 else {}, new_name)
+    return c
+
+
+def _flags_tables(c, da, other_lag=None):
+    """Engine flags, window vectors and phase tables per device axis (y, x)."""
+    flags = 0
+    win = {"y": None, "x": None}
+    ph = {"y": None, "x": None}
+    for i, d in enumerate(c.dim):
+        ax = "x" if d == c.xdim else "y"
+        if c.shift:
+            flags |= _lib.SHIFT_X if ax == "x" else _lib.SHIFT_Y
+        if c.true_phase:
+            flags |= _lib.ISHIFT_X if ax == "x" else _lib.ISHIFT_Y
+            if c.reversed[i]:
+                flags |= _lib.FLIP_X if ax == "x" else _lib.FLIP_Y
+            # xrft.py:462-469 -- indexed by unshifted frequency; the real axis uses rfftfreq on its kept half
+            n = c.N[i]
+            f = np.fft.fftfreq(n, c.delta_x[i])
+            if c.real_dim is not None and d == c.real_dim:
+                f[: n // 2 + 1] = np.fft.rfftfreq(n, c.delta_x[i])
+            p = np.exp(-1j * 2.0 * np.pi * f * c.lag_x[i])
+            if other_lag is not None:  # cross spectrum: F1 phase * conj(F2 phase)
+                p = p * np.conj(np.exp(-1j * 2.0 * np.pi * f * other_lag[i]))
+            ph[ax] = p
+        if c.windows is not None:
+            win[ax] = c.windows[i]
+    if c.real_dim is not None:
+        flags |= _lib.HALF_X
+    return flags, win, ph
+
+
+def _arrange(c, da):
+    """Device tensor with the transform axes last: shape (*other, [ny,] nx); returns (tensor, other_dims)."""
+    t = _to_device(da.data)
+    tdims = ([c.ydim] if c.ydim is not None else []) + [c.xdim]
+    other = [d for d in da.dims if d not in tdims]
+    order = other + tdims
+    if tuple(order) != tuple(da.dims):
+        t = t.permute([da.get_axis_num(d) for d in order])
+    return t.contiguous(), other
+
+
+def _label_output(c, da, out_t, other, extra_cattrs=None, drop_transform=False):
+    """Wrap the engine output (other..., ky, kx) as a DataArray in the reference's dim order (xrft.py:451-476)."""
+    tdims = ([c.ydim] if c.ydim is not None else []) + [c.xdim]
+    cur = other + [c.swap[d] for d in tdims]
+    final = [c.swap.get(d, d) for d in c.rawdims]
+    out_t = out_t.reshape([da.sizes[d] for d in other] + list(out_t.shape[-len(tdims):]))
+    if cur != final:
+        out_t = out_t.permute([cur.index(d) for d in final])
+    coords = {k: v for k, v in da.coords.items() if k not in c.dim}
+    for name, cv in c.new_coords.items():
+        attrs = dict(cv.attrs)
+        if extra_cattrs and name in extra_cattrs:
+            attrs.update(extra_cattrs[name])
+        coords[name] = Coordinate(cv.dims, cv.values, attrs, name)
+    return DataArray(out_t, final, coords, None, None)
+
+
+def _execute(c, da, mode, scale, da2=None, c2=None, iso=None, extra_flags=0):
+    t, other = _arrange(c, da)
+    ndim = len(c.dim)
+    nx = da.sizes[c.xdim]
+    ny = da.sizes[c.ydim] if c.ydim is not None else 1
+    batch = t.numel() // max(ny * nx, 1)
+    flags, win, ph = _flags_tables(c, da, None if c2 is None else c2.lag_x)
+    if mode == _lib.OUT_POWER:
+        ph = {"y": None, "x": None}
+    flags |= extra_flags
+    t2 = None
+    if da2 is not None:
+        t2, other2 = _arrange(c2, da2)
+        if t2.shape != t.shape or other2 != other:
+            raise ValueError("The two datasets have different dimensions")
+        if t2.dtype != t.dtype:
+            dt = torch.promote_types(t.dtype, t2.dtype)
+            t, t2 = t.to(dt), t2.to(dt)
+        for i, d in enumerate(c.dim):
+            if c.true_phase and c.reversed[i] != c2.reversed[i]:
+                # The engine flips both fields alike (xrft.py:436-441 flips each by its own coordinate).  Pre-flip
+                # the second field; only exact when no (flip-asymmetric, sym=False) window is applied.
+                if c.windows is not None:
+                    raise NotImplementedError("cross_spectrum of fields whose coordinates run in opposite "
+                                              "directions combined with a window is not supported")
+                axis = t2.dim() - 1 if d == c.xdim else t2.dim() - 2
+                t2 = torch.flip(t2, dims=[axis]).contiguous()
+    kw = dict(ndim=ndim, batch=batch, ny=ny, nx=nx, dtype=t.dtype, out_mode=mode, detrend=c.detrend, flags=flags,
+              scale=float(scale), window_y=win["y"], window_x=win["x"], phase_y=ph["y"], phase_x=ph["x"])
+    if iso is not None:
+        kw.update(binmap=iso["binmap"], nbins=iso["nbins"])
+    plan = _get_plan(**kw)
+    out, iso_out = plan.execute(t, t2)
+    return out, iso_out, other
+
+
+# ------------------------------------------------------------------------------------------------------
+# public API
+# ------------------------------------------------------------------------------------------------------
+def fft(da, spacing_tol=1e-3, dim=None, real_dim=None, shift=True, detrend=None, window=None, true_phase=True,
+        true_amplitude=True, chunks_to_segments=False, prefix="freq_", real=None):
+    """Discrete Fourier transform of ``da`` along ``dim`` (reference: xrft/xrft.py:307-476; same arguments)."""
+    src = da
+    da = from_any(da)
+    c = _analyze(da, spacing_tol, dim, real_dim, shift, detrend, window, true_phase, chunks_to_segments, prefix, real)
+    scale = np.prod(c.delta_x) if true_amplitude else 1.0  # xrft.py:471-472
+    out, _, other = _execute(c, da, _lib.OUT_COMPLEX, scale)
+    extra = None
+    if c.true_phase:  # xrft.py:469
+        extra = {c.swap[d]: {"direct_lag": lag} for d, lag in zip(c.dim, c.lag_x)}
+    return to_like(_label_output(c, da, out, other, extra), src)
+
+
+def dft(da, dim=None, true_phase=False, true_amplitude=False, **kwargs):
+    """Deprecated alias of ``fft`` with numpy-like defaults (xrft/xrft.py:237-250)."""
+    warnings.warn("This function has been renamed and will disappear in the future. Please use `fft` instead",
+                  FutureWarning)
+    return fft(da, dim=dim, true_phase=true_phase, true_amplitude=true_amplitude, **kwargs)
+
+
+def detrend(da, dim, detrend_type="constant"):
+    """Remove the mean or the least-squares line / plane over ``dim`` (xrft/detrend.py:11-97)."""
+    src = da
+    da = from_any(da)
+    if dim is None:
+        dim = list(da.dims)
+    elif isinstance(dim, str):
+        dim = [dim]
+    else:
+        dim = list(dim)
+    if detrend_type not in ["constant", "linear", None]:
+        raise NotImplementedError("%s is not a valid detrending option. Valid options are: 'constant','linear', "
+                                  "or None." % detrend_type)
+    if detrend_type is None:
+        return src
+    if len(dim) not in (1, 2):
+        raise NotImplementedError("Only 1D and 2D detrending are implemented in xrft_amd.")
+    axes = [da.get_axis_num(d) for d in dim]
+    t = _to_device(da.data)
+    if len(dim) == 2 and axes[0] > axes[1]:
+        dim = dim[::-1]
+    other = [d for d in da.dims if d not in dim]
+    order = other + dim
+    if tuple(order) != tuple(da.dims):
+        t = t.permute([da.get_axis_num(d) for d in order])
+    t = t.contiguous()
+    kind = _lib.DETREND_CONSTANT if detrend_type == "constant" else _lib.DETREND_LINEAR
+    out = engine.detrend(t, len(dim), kind)
+    if tuple(order) != tuple(da.dims):
+        out = out.permute([order.index(d) for d in da.dims])
+    return to_like(DataArray(out, da.dims, da.coords, da.name, da.attrs), src)
+
+
+def _window_correction_factor(c, scaling, window):
+    """xrft.py:649-660: mean(w^2) (density) or mean(w)^2 (spectrum) of the outer-product window."""
+    if window is None:
+        raise ValueError("window_correction can only be applied when windowing is turned on.")
+    w = c.windows[0]
+    for v in c.windows[1:]:
+        w = np.multiply.outer(w, v)
+    if scaling == "density":
+        return (w ** 2).mean()
+    elif scaling == "spectrum":
+        return w.mean() ** 2
+    raise ValueError("Unknown {} scaling flag".format(scaling))
+
+
+def _psd_scaling_factor(c, scaling):
+    """xrft.py:663-670."""
+    fs = np.prod([float(c.new_coords[c.swap[d]].attrs["spacing"]) for d in c.dim])
+    if scaling == "density":
+        return fs
+    elif scaling == "spectrum":
+        return fs ** 2
+    raise ValueError("Unknown {} scaling flag".format(scaling))
+
+
+def _spectrum_scale(c, amp, scaling, window_correction, window):
+    """Everything that multiplies |F|^2 (or F1 conj F2): (prod dx)^2, / window factor, x prod(dk)^(1|2)."""
+    scale = float(amp)
+    if scaling != "false_density":  # xrft.py:745-748
+        if window_correction:
+            scale = scale / _window_correction_factor(c, scaling, window)
+        scale = scale * _psd_scaling_factor(c, scaling)
+    return scale
+
+
+def _spectrum(da, da2, dim, real_dim, scaling, window_correction, true_phase, kwargs, iso=None):
+    if "real" in kwargs:  # xrft.py:728-730 (`real` stays in kwargs and reaches fft as well)
+        real_dim = kwargs.get("real")
+        warnings.warn(_real_flag_warning, FutureWarning)
+    if "density" in kwargs:  # xrft.py:718-726
+        density = kwargs.pop("density")
+        warnings.warn("density flag will be deprecated in future version of xrft and replaced by scaling flag. "
+                      'density=True should be replaced by scaling="density" and density=False will not be '
+                      "maintained.\nscaling flag is ignored !", FutureWarning)
+        scaling = "density" if density else "false_density"
+    kw = dict(spacing_tol=1e-3, shift=True, detrend=None, window=None, chunks_to_segments=False, prefix="freq_",
+              real=None)
+    for k in list(kwargs):
+        if k in ("true_amplitude", "true_phase"):
+            kwargs.pop(k)  # overridden by the reference (xrft.py:732-734, 814)
+    unknown = set(kwargs) - set(kw)
+    if unknown:
+        raise TypeError(f"fft() got an unexpected keyword argument {sorted(unknown)[0]!r}")
+    kw.update(kwargs)
+    c = _analyze(da, kw["spacing_tol"], dim, real_dim, kw["shift"], kw["detrend"], kw["window"], true_phase,
+                 kw["chunks_to_segments"], kw["prefix"], kw["real"])
+    c2 = None
+    amp = np.prod(c.delta_x) ** 2
+    if da2 is not None:
+        c2 = _analyze(da2, kw["spacing_tol"], dim, real_dim, kw["shift"], kw["detrend"], kw["window"], true_phase,
+                      kw["chunks_to_segments"], kw["prefix"], kw["real"])
+        if [c.swap.get(d, d) for d in c.rawdims] != [c2.swap.get(d, d) for d in c2.rawdims]:  # xrft.py:819-820
+            raise ValueError("The two datasets have different dimensions")
+        if c.N != c2.N or not np.allclose(c.delta_x, c2.delta_x, rtol=1e-12):
+            raise ValueError("The two datasets have different frequency coordinates (size or spacing)")
+        amp = np.prod(c.delta_x) * np.prod(c2.delta_x)
+    scale = _spectrum_scale(c, amp, scaling, window_correction, kw["window"])
+    flags = _lib.REALDIM_X2 if c.real_dim is not None else 0  # xrft.py:742-743
+    mode = _lib.OUT_POWER if da2 is None else _lib.OUT_CROSS
+    return c, c2, mode, scale, flags
+
+
+def power_spectrum(da, dim=None, real_dim=None, scaling="density", window_correction=False, **kwargs):
+    """Power spectrum |F(da')|^2 with density / spectrum scaling (xrft/xrft.py:685-750)."""
+    src = da
+    da = from_any(da)
+    c, _, mode, scale, flags = _spectrum(da, None, dim, real_dim, scaling, window_correction, False, dict(kwargs))
+    out, _, other = _execute(c, da, mode, scale, extra_flags=flags)
+    return to_like(_label_output(c, da, out, other), src)
+
+
+def cross_spectrum(da1, da2, dim=None, real_dim=None, scaling="density", window_correction=False, true_phase=True,
+                   **kwargs):
+    """Cross spectrum F(da1') conj(F(da2')) (xrft/xrft.py:753-835)."""
+    src = da1
+    da1, da2 = from_any(da1), from_any(da2)
+    c, c2, mode, scale, flags = _spectrum(da1, da2, dim, real_dim, scaling, window_correction, true_phase, dict(kwargs))
+    out, _, other = _execute(c, da1, mode, scale, da2=da2, c2=c2, extra_flags=flags)
+    extra = None
+    if c.true_phase:  # the product keeps daft1's coordinates, including their direct_lag attribute (xrft.py:469, 825)
+        extra = {c.swap[d]: {"direct_lag": lag} for d, lag in zip(c.dim, c.lag_x)}
+    return to_like(_label_output(c, da1, out, other, extra), src)
+
+
+# ------------------------------------------------------------------------------------------------------
+# isotropic spectra (xrft.py:877-1187)
+# ------------------------------------------------------------------------------------------------------
+def _radial_bins(k, l, nfactor):
+    """Bin codes and per-bin mean radius for the grid sqrt(k^2 + l^2), dims (k, l)  (xrft.py:975-981, 910-923).
+
+    ``pd.cut`` on the float64 radii, exactly the reference's expression; the per-bin mean replaces
+    ``numpy_groupies.aggregate(func="mean", fill_value=0)``.
+    """
+    N = [k.size, l.size]
+    nbins = int(min(N) / nfactor)
+    freq_r = np.sqrt(k[:, None] ** 2 + l[None, :] ** 2)
+    binned = pd.cut(np.ravel(freq_r), nbins)
+    codes = binned.codes.reshape(freq_r.shape)
+    nb = binned.categories.size
+    valid = codes >= 0
+    cnt = np.bincount(codes[valid], minlength=nb)
+    s = np.bincount(codes[valid], weights=freq_r[valid], minlength=nb)
+    kr = np.where(cnt > 0, s / np.maximum(cnt, 1), 0.0)
+    return codes.astype(np.int32), kr, nb
+
+
+def _finish_iso(kr, k, l, truncate, iso_vals):
+    """truncate / dropna semantics of xrft.py:983-991, 1007-1010 (dropna only looks at data values)."""
+    if truncate:
+        kmax = l.max() if k.max() > l.max() else k.max()
+        kr = np.where(kr <= kmax, kr, np.nan)
+        keep = ~np.isnan(iso_vals).reshape(-1, iso_vals.shape[-1]).any(axis=0)
+        if not keep.all():
+            iso_vals, kr = iso_vals[..., keep], kr[keep]
+    else:
+        warnings.warn("Isotropic wavenumber larger than the Nyquist wavenumber may result.", FutureWarning)
+    return kr, iso_vals
+
+
+def isotropize(ps, fftdim, nfactor=4, truncate=True, complx=False):
+    """Azimuthal (radial-bin) SUM of an existing 2-D spectrum (xrft/xrft.py:948-1010)."""
+    src = ps
+    ps = from_any(ps)
+    k = np.asarray(ps[fftdim[1]].values, dtype=np.float64)
+    l = np.asarray(ps[fftdim[0]].values, dtype=np.float64)
+    codes, kr, nb = _radial_bins(k, l, nfactor)  # dims (fftdim[1], fftdim[0])
+    other = [d for d in ps.dims if d not in fftdim]
+    order = other + [fftdim[1], fftdim[0]]
+    t = _to_device(ps.data)
+    if tuple(order) != tuple(ps.dims):
+        t = t.permute([ps.get_axis_num(d) for d in order])
+    t = t.contiguous()
+    bm = torch.from_numpy(np.ascontiguousarray(codes)).to(t.device)
+    iso = engine.isotropize(t, bm, nb)
+    iso = iso.reshape([ps.sizes[d] for d in other] + [nb])
+    vals = iso.cpu().numpy()
+    kr, vals = _finish_iso(kr, k, l, truncate, vals)
+    coords = {c: v for c, v in ps.coords.items() if not (set(v.dims) & set(fftdim))}
+    coords["freq_r"] = Coordinate(("freq_r",), kr, None, "freq_r")
+    return to_like(DataArray(vals, other + ["freq_r"], coords, ps.name, ps.attrs), src)
+
+
+def _iso_spectrum(da, da2, spacing_tol, dim, shift, detrend_, scaling, window, window_correction, nfactor, truncate,
+                  kwargs):
+    if "density" in kwargs:  # xrft.py:1072-1074
+        density = kwargs.pop("density")
+        scaling = "density" if density else "false_density"
+    if dim is None:
+        dim = da.dims
+        if da2 is not None and tuple(dim) != tuple(da2.dims):
+            raise ValueError("The two datasets have different dimensions")
+    if len(dim) != 2:
+        raise ValueError("The Fourier transform should be two dimensional")
+    dim = list(dim)
+    kw = dict(kwargs, spacing_tol=spacing_tol, shift=shift, detrend=detrend_, window=window)
+    true_phase = kw.pop("true_phase", True) if da2 is not None else False
+    real_dim = kw.pop("real_dim", None)
+    c, c2, mode, scale, flags = _spectrum(da, da2, dim, real_dim, scaling, window_correction, true_phase, kw)
+    fftdim = ["freq_" + d for d in dim]  # xrft.py:1093 (hard-coded prefix, as in the reference)
+    for f in fftdim:
+        if f not in c.new_coords:
+            raise KeyError(f)
+    # bin map on the engine's (ky, kx) grid in UNSHIFTED index order; radii are order-independent
+    ky = c.k_unshifted[c.dim.index(c.ydim)]
+    kx = c.k_unshifted[c.dim.index(c.xdim)]
+    kk = c.new_coords[fftdim[1]].values
+    ll = c.new_coords[fftdim[0]].values
+    codes_yx, kr, nb = _radial_bins(ky, kx, nfactor)
+    # reference bins over (fftdim[1], fftdim[0]); the edges depend only on min/max of the same set of radii,
+    # and kr (a per-bin mean of the same multiset) is identical up to summation order
+    iso_cfg = {"binmap": codes_yx, "nbins": nb}
+    out, iso, other = _execute(c, da, mode, scale, da2=da2, c2=c2, iso=iso_cfg,
+                               extra_flags=flags | _lib.ISO | _lib.NO_SPECTRUM_OUT)
+    vals = iso.reshape([da.sizes[d] for d in other] + [nb]).cpu().numpy()
+    kr, vals = _finish_iso(kr, kk, ll, truncate, vals)
+    coords = {cn: cv for cn, cv in da.coords.items() if not (set(cv.dims) & set(dim))}
+    coords["freq_r"] = Coordinate(("freq_r",), kr, None, "freq_r")
+    return DataArray(vals, other + ["freq_r"], coords, None, None)
+
+
+def isotropic_power_spectrum(da, spacing_tol=1e-3, dim=None, shift=True, detrend=None, scaling="density",
+                             window=None, window_correction=False, nfactor=4, truncate=False, **kwargs):
+    """Isotropic (radially binned) power spectrum (xrft/xrft.py:1013-1095); spectrum and bin-sum are fused on
+    the device, the full 2-D spectrum is never written."""
+    src = da
+    da = from_any(da)
+    return to_like(_iso_spectrum(da, None, spacing_tol, dim, shift, detrend, scaling, window, window_correction,
+                                 nfactor, truncate, dict(kwargs)), src)
+
+
+def isotropic_cross_spectrum(da1, da2, spacing_tol=1e-3, dim=None, shift=True, detrend=None, scaling="density",
+                             window=None, window_correction=False, nfactor=4, truncate=False, **kwargs):
+    """Isotropic cross spectrum (xrft/xrft.py:1098-1187)."""
+    src = da1
+    da1, da2 = from_any(da1), from_any(da2)
+    return to_like(_iso_spectrum(da1, da2, spacing_tol, dim, shift, detrend, scaling, window, window_correction,
+                                 nfactor, truncate, dict(kwargs)), src)
+
+
+def fit_loglog(x, y):
+    """Least-squares line in log2-log2 space (xrft/xrft.py:1190-1214)."""
+    p = np.polyfit(np.log2(x), np.log2(y), 1)
+    y_fit = 2 ** (np.log2(x) * p[0] + p[1])
+    return y_fit, p[0], p[1]

@@ -1,0 +1,141 @@
+// aux_kernels.h -- small bandwidth-bound helper kernels around the FFT passes:
+//   slab_moments      centred first moments of every slab (for detrend)      xrft/detrend.py:54-55, 64-71, 100-113
+//   finalize_coef     moments -> trend coefficients c0 + c1*i + c2*j
+//   detrend_apply     out = in - trend                                        xrft.detrend as a stand-alone op
+//   radial_binsum     isotropize of an existing spectrum                      xrft/xrft.py:895-906, 993-1004
+#pragma once
+#include "tile_fft.h"
+
+namespace xrft {
+
+// Block-wide sum of NV doubles per thread through LDS; result valid in thread 0.
+template <int NV>
+__device__ __forceinline__ void block_sum(double* v, double* red /* >= NV*blockDim doubles */) {
+    const int tid = threadIdx.x, n = blockDim.x;
+    for (int k = 0; k < NV; ++k) red[k * n + tid] = v[k];
+    __syncthreads();
+    for (int s = n / 2; s > 0; s >>= 1) {
+        if (tid < s)
+            for (int k = 0; k < NV; ++k) red[k * n + tid] += red[k * n + tid + s];
+        __syncthreads();
+    }
+    if (tid == 0)
+        for (int k = 0; k < NV; ++k) v[k] = red[k * n];
+}
+
+// acc[slab][6] += { sum x.re, sum x.im, sum (i-ibar) x.re, .. .im, sum (j-jbar) x.re, .. .im }
+// grid = (chunks, batch); every block reduces a contiguous run of rows of one slab.
+template <typename T, bool CPLX>
+__global__ void __launch_bounds__(256) slab_moments_kernel(const void* in, long long ny, long long nx, long long slab_stride,
+                                                          long long row_stride, double* acc) {
+    XRFT_DYN_SMEM(smem_raw);
+    double* red = reinterpret_cast<double*>(smem_raw);
+    const long long b = blockIdx.y;
+    const long long total = ny * nx;
+    const long long per = (total + gridDim.x - 1) / gridDim.x;
+    const long long e0 = (long long)blockIdx.x * per;
+    long long e1 = e0 + per;
+    if (e1 > total) e1 = total;
+    const T ibar = (T)(0.5 * (double)(ny - 1)), jbar = (T)(0.5 * (double)(nx - 1));
+    double s[6] = {0, 0, 0, 0, 0, 0};
+    T p[6] = {0, 0, 0, 0, 0, 0};
+    int cnt = 0;
+    for (long long e = e0 + threadIdx.x; e < e1; e += blockDim.x) {
+        const long long i = e / nx;
+        const long long j = e - i * nx;
+        const long long off = b * slab_stride + i * row_stride + j;
+        T xr, xi = (T)0;
+        if (CPLX) { C2<T> v = reinterpret_cast<const C2<T>*>(in)[off]; xr = v.re; xi = v.im; }
+        else xr = reinterpret_cast<const T*>(in)[off];
+        const T di = (T)i - ibar, dj = (T)j - jbar;
+        p[0] += xr; p[2] += di * xr; p[4] += dj * xr;
+        if (CPLX) { p[1] += xi; p[3] += di * xi; p[5] += dj * xi; }
+        if (++cnt == 64) {  // bound the length of the working-precision partial sums
+            for (int k = 0; k < 6; ++k) { s[k] += (double)p[k]; p[k] = (T)0; }
+            cnt = 0;
+        }
+    }
+    for (int k = 0; k < 6; ++k) s[k] += (double)p[k];
+    block_sum<6>(s, red);
+    if (threadIdx.x == 0)
+        for (int k = 0; k < 6; ++k)
+            if (s[k] != 0.0) atomicAdd(&acc[b * 6 + k], s[k]);
+}
+
+// One thread per slab.  Least squares on a full regular grid: the centred regressors (i-ibar), (j-jbar) are
+// orthogonal to each other and to 1, so the plane fit of detrend.py:100-113 (normal equations on [1, i+1, j+1])
+// and the line fit of scipy.signal.detrend (detrend.py:64-71) reduce to three independent ratios.
+__global__ void finalize_coef_kernel(const double* acc, double* coef, long long batch, long long ny, long long nx, int kind) {
+    const long long b = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= batch) return;
+    const double n = (double)ny * (double)nx;
+    const double ibar = 0.5 * (double)(ny - 1), jbar = 0.5 * (double)(nx - 1);
+    const double sii = (double)nx * (double)ny * ((double)ny * (double)ny - 1.0) / 12.0;
+    const double sjj = (double)ny * (double)nx * ((double)nx * (double)nx - 1.0) / 12.0;
+    for (int c = 0; c < 2; ++c) {
+        const double mean = acc[b * 6 + c] / n;
+        double c1 = 0.0, c2 = 0.0;
+        if (kind == 2) {
+            if (ny > 1) c1 = acc[b * 6 + 2 + c] / sii;
+            if (nx > 1) c2 = acc[b * 6 + 4 + c] / sjj;
+        }
+        coef[b * 6 + c] = mean - c1 * ibar - c2 * jbar;
+        coef[b * 6 + 2 + c] = c1;
+        coef[b * 6 + 4 + c] = c2;
+    }
+}
+
+template <typename T, bool CPLX>
+__global__ void __launch_bounds__(256) detrend_apply_kernel(const void* in, void* out, long long ny, long long nx, const double* coef) {
+    const long long b = blockIdx.y;
+    const long long total = ny * nx;
+    const double* c = coef + b * 6;
+    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
+        const long long i = e / nx;
+        const long long j = e - i * nx;
+        const long long off = b * total + e;
+        if (CPLX) {
+            C2<T> v = reinterpret_cast<const C2<T>*>(in)[off];
+            v.re -= (T)(c[0] + c[2] * (double)i + c[4] * (double)j);
+            v.im -= (T)(c[1] + c[3] * (double)i + c[5] * (double)j);
+            reinterpret_cast<C2<T>*>(out)[off] = v;
+        } else {
+            T v = reinterpret_cast<const T*>(in)[off];
+            v -= (T)(c[0] + c[2] * (double)i + c[4] * (double)j);
+            reinterpret_cast<T*>(out)[off] = v;
+        }
+    }
+}
+
+// iso[slab][bin] += in[slab][e] for bin = binmap[e] >= 0 ; LDS-privatised histogram, one flush per block.
+template <typename T, bool CPLX>
+__global__ void __launch_bounds__(256) radial_binsum_kernel(const void* in, const int* binmap, long long total, int nbins, double* iso) {
+    XRFT_DYN_SMEM(smem_raw);
+    double* hist = reinterpret_cast<double*>(smem_raw);
+    const int hl = nbins * (CPLX ? 2 : 1);
+    for (int i = threadIdx.x; i < hl; i += blockDim.x) hist[i] = 0.0;
+    __syncthreads();
+    const long long b = blockIdx.y;
+    const long long per = (total + gridDim.x - 1) / gridDim.x;
+    const long long e0 = (long long)blockIdx.x * per;
+    long long e1 = e0 + per;
+    if (e1 > total) e1 = total;
+    for (long long e = e0 + threadIdx.x; e < e1; e += blockDim.x) {
+        const int bin = binmap[e];
+        if (bin < 0) continue;
+        if (CPLX) {
+            const C2<T> v = reinterpret_cast<const C2<T>*>(in)[b * total + e];
+            atomicAdd(&hist[2 * bin], (double)v.re);
+            atomicAdd(&hist[2 * bin + 1], (double)v.im);
+        } else {
+            atomicAdd(&hist[bin], (double)reinterpret_cast<const T*>(in)[b * total + e]);
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < hl; i += blockDim.x) {
+        const double v = hist[i];
+        if (v != 0.0) atomicAdd(&iso[b * hl + i], v);
+    }
+}
+
+}  // namespace xrft

@@ -1,0 +1,437 @@
+// tile_fft.h -- the generic batched tile FFT kernel (any length with prime factors <= 128).
+//
+// One workgroup owns a tile of T sequences x n complex points in LDS and runs an in-place decimation-in-
+// frequency mixed-radix FFT on it: early passes touch lane-contiguous LDS addresses, the result is left in
+// digit-reversed order and the store loop gathers it through a host-built table, so no ping-pong buffer is
+// needed and twice as many sequences fit per tile (better HBM coalescing for strided "column" passes).
+// Everything the reference does around numpy.fft is folded into the first pass' loads (detrend, window,
+// flip, ifftshift -- xrft/xrft.py:425-442) and the last pass' stores (fftshift, true-phase factor, prod(dx),
+// |F|^2 / F conj(G), real-dim doubling, window/density scaling, Hermitian mirror, radial bin-sum --
+// xrft/xrft.py:446-472, 740-748, 825-833, 993-1004), so intermediates never exist as arrays.
+//
+// The hot shape of BASELINE.json (4096 x 4096 float32) has its own specialised kernels (fft4096.h); this
+// kernel is the fallback for every other shape and the parity reference for the specialised ones.
+#pragma once
+#include "gpu_rt.h"
+
+namespace xrft {
+
+// ------------------------------------------------------------------------------------------------
+// complex arithmetic
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+struct alignas(2 * sizeof(T)) C2 {
+    T re, im;
+};
+template <typename T> __device__ __forceinline__ C2<T> mk(T a, T b) { C2<T> r; r.re = a; r.im = b; return r; }
+template <typename T> __device__ __forceinline__ C2<T> operator+(C2<T> a, C2<T> b) { return mk<T>(a.re + b.re, a.im + b.im); }
+template <typename T> __device__ __forceinline__ C2<T> operator-(C2<T> a, C2<T> b) { return mk<T>(a.re - b.re, a.im - b.im); }
+template <typename T> __device__ __forceinline__ C2<T> cmul(C2<T> a, C2<T> b) { return mk<T>(a.re * b.re - a.im * b.im, a.re * b.im + a.im * b.re); }
+template <typename T> __device__ __forceinline__ C2<T> cmulc(C2<T> a, C2<T> b) { return mk<T>(a.re * b.re + a.im * b.im, a.im * b.re - a.re * b.im); }  // a * conj(b)
+template <typename T> __device__ __forceinline__ C2<T> cscale(C2<T> a, T s) { return mk<T>(a.re * s, a.im * s); }
+template <typename T> __device__ __forceinline__ C2<T> cconj(C2<T> a) { return mk<T>(a.re, -a.im); }
+template <typename T> __device__ __forceinline__ C2<T> mul_mi(C2<T> a) { return mk<T>(a.im, -a.re); }  // a * (-i)
+template <typename T> __device__ __forceinline__ C2<T> mul_pi(C2<T> a) { return mk<T>(-a.im, a.re); }  // a * (+i)
+
+// ------------------------------------------------------------------------------------------------
+// in-register DFTs (forward, e^{-2 pi i qk/R}), natural order in and out
+// ------------------------------------------------------------------------------------------------
+template <typename T> __device__ __forceinline__ void dft2(C2<T>& a0, C2<T>& a1) { C2<T> t = a0 - a1; a0 = a0 + a1; a1 = t; }
+
+template <typename T> __device__ __forceinline__ void dft3(C2<T>* a) {
+    const T s = (T)0.86602540378443864676;
+    C2<T> t = a[1] + a[2];
+    C2<T> m = mk<T>(a[0].re - (T)0.5 * t.re, a[0].im - (T)0.5 * t.im);
+    C2<T> d = cscale(a[1] - a[2], s);
+    a[0] = a[0] + t;
+    a[1] = m + mul_mi(d);
+    a[2] = m + mul_pi(d);
+}
+
+template <typename T> __device__ __forceinline__ void dft4(C2<T>* a) {
+    C2<T> s02 = a[0] + a[2], d02 = a[0] - a[2], s13 = a[1] + a[3], d13 = a[1] - a[3];
+    a[0] = s02 + s13;
+    a[2] = s02 - s13;
+    a[1] = d02 + mul_mi(d13);
+    a[3] = d02 + mul_pi(d13);
+}
+
+template <typename T> __device__ __forceinline__ void dft5(C2<T>* a) {
+    const T c1 = (T)0.30901699437494742410, c2 = (T)-0.80901699437494742410;
+    const T s1 = (T)0.95105651629515357212, s2 = (T)0.58778525229247312917;
+    C2<T> t1 = a[1] + a[4], t2 = a[2] + a[3], t3 = a[1] - a[4], t4 = a[2] - a[3];
+    C2<T> m1 = mk<T>(a[0].re + c1 * t1.re + c2 * t2.re, a[0].im + c1 * t1.im + c2 * t2.im);
+    C2<T> m2 = mk<T>(a[0].re + c2 * t1.re + c1 * t2.re, a[0].im + c2 * t1.im + c1 * t2.im);
+    C2<T> n1 = mk<T>(s1 * t3.re + s2 * t4.re, s1 * t3.im + s2 * t4.im);
+    C2<T> n2 = mk<T>(s2 * t3.re - s1 * t4.re, s2 * t3.im - s1 * t4.im);
+    a[0] = a[0] + t1 + t2;
+    a[1] = m1 + mul_mi(n1);
+    a[4] = m1 + mul_pi(n1);
+    a[2] = m2 + mul_mi(n2);
+    a[3] = m2 + mul_pi(n2);
+}
+
+template <typename T> __device__ __forceinline__ void dft8(C2<T>* a) {
+    const T h = (T)0.70710678118654752440;
+    C2<T> u[4], v[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { u[k] = a[k] + a[k + 4]; v[k] = a[k] - a[k + 4]; }
+    // v[k] *= W8^k
+    v[1] = mk<T>(h * (v[1].re + v[1].im), h * (v[1].im - v[1].re));
+    v[2] = mul_mi(v[2]);
+    v[3] = mk<T>(h * (v[3].im - v[3].re), -h * (v[3].re + v[3].im));
+    dft4(u);
+    dft4(v);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { a[2 * k] = u[k]; a[2 * k + 1] = v[k]; }
+}
+
+template <typename T, int R> __device__ __forceinline__ void dft_r(C2<T>* a) {
+    if (R == 2) dft2(a[0], a[1]);
+    else if (R == 3) dft3(a);
+    else if (R == 4) dft4(a);
+    else if (R == 5) dft5(a);
+    else if (R == 8) dft8(a);
+}
+
+// ------------------------------------------------------------------------------------------------
+// parameter blocks (plain data, passed by value)
+// ------------------------------------------------------------------------------------------------
+#define XRFT_MAX_PASSES 24
+
+struct TileGeom {
+    int n;      // complex FFT length held in LDS per sequence
+    int n_out;  // output points per sequence (n, n/…: r2c n+1, or truncated nxh)
+    int nr;     // radix passes
+    int radix[XRFT_MAX_PASSES];
+    int T;           // sequences per tile
+    int seq_stride;  // LDS elements between sequences
+    int pad_shift;   // phys(pos) = pos + (pos >> pad_shift)
+    int r2c;         // real input packed z[m] = y[2m] + i y[2m+1]; n = n_real/2, n_out = n+1
+    int tile_axis;   // 0: a tile is T consecutive o (sequence contiguous: "row" pass); 1: T consecutive q ("column" pass)
+    int in_fast;     // lanes iterate fastest over: 0 the point index, 1 the tile axis (pick the contiguous one)
+    int out_fast;
+    long long n_outer, inner, n_tiles, tiles_per_outer;
+    // raw complex addressing (elements): o*so + q*sq + p*sp
+    long long in_so, in_sq, in_sp, out_so, out_sq, out_sp;
+    const void* in;
+    void* out;
+    const void* tw;         // W_n^k, k < n
+    const unsigned* rev;    // rev[k] = LDS position of frequency k after the DIF passes
+    const void* tw_r2c;     // W_{2n}^k, k <= n   (r2c unpack)
+    const void* tw_big;     // four-step: W_bigN^k table, k < bigN
+    long long tw_bigN, tw_qdiv, tw_qmod;  // factor = W_bigN^{((q / qdiv) % qmod) * k}
+};
+
+struct Prologue {  // first pass: xrft.py:425-442
+    int in_complex;
+    int detrend;
+    long long rows;            // rows per slab seen by this pass (ny for 2-D, 1 for 1-D): b = o / rows, i = o % rows
+    long long j_mul_p, j_mul_q;  // logical x index j = p*j_mul_p + q*j_mul_q
+    int ny, nx;
+    int flip_y, ishift_y, flip_x, ishift_x;
+    long long slab_stride, row_stride;  // source strides in elements
+    const void* in;
+    const void* win_y;
+    const void* win_x;
+    const double* coef;  // [slab][6]: c0.re c0.im c1.re c1.im c2.re c2.im ; trend = c0 + c1*i + c2*j (source indices)
+};
+
+struct Epilogue {  // last pass: xrft.py:446-472, 740-748, 825-833, 993-1004
+    int mode;      // xrfthip_out_mode
+    int p_axis;    // 0: this pass transforms x (1-D): kx = k_m, ky = 0;  1: it transforms y: ky = k_m, kx = q
+    long long odiv;  // slab b = o / odiv, r = o % odiv
+    long long r_mul, q_mul, p_mul;  // k_m = r*r_mul + q*q_mul + p*p_mul  (four-step final passes interleave k1 + n1*k2)
+    int ny, nx, nx_out;
+    int mirror;    // real input, full output: also store the Hermitian mirror (ny-ky, nx-kx)
+    int shift_y, shift_x;
+    int realdim_x2;
+    long long slab_stride, row_stride;  // output strides in elements
+    double scale;
+    void* out;  // may be null (iso only)
+    const void* ph_y;
+    const void* ph_x;
+    const void* other;  // CROSS: raw F0, complex [slab][ny][nxh], unshifted
+    long long other_slab_stride, other_row_stride;
+    const int* binmap;  // [ny][nx_out], unshifted indices
+    int nbins;
+    double* iso;  // [slab][nbins] (x2 interleaved for CROSS)
+};
+
+__device__ __forceinline__ int phys(int pos, int sh) { return pos + (pos >> sh); }
+
+__device__ __forceinline__ int map_src(int m, int n, int flip, int ishift) {
+    int t = m;
+    if (ishift) { t += n / 2; if (t >= n) t -= n; }  // ifftshift(y)[m] = y[(m + n//2) % n]
+    if (flip) t = n - 1 - t;
+    return t;
+}
+__device__ __forceinline__ int shift_dst(int k, int n, int shift) {
+    if (!shift) return k;
+    int t = k + n / 2;  // fftshift(f)[(k + n//2) % n] = f[k]
+    return t >= n ? t - n : t;
+}
+
+// ------------------------------------------------------------------------------------------------
+// first-pass element fetch: source value -> detrend -> window      (one real or complex sample)
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__device__ __forceinline__ C2<T> fetch_src(const Prologue& pr, long long b, int i, int j) {
+    const int si = map_src(i, pr.ny, pr.flip_y, pr.ishift_y);
+    const int sj = map_src(j, pr.nx, pr.flip_x, pr.ishift_x);
+    const long long off = b * pr.slab_stride + (long long)si * pr.row_stride + sj;
+    C2<T> v;
+    if (pr.in_complex) v = reinterpret_cast<const C2<T>*>(pr.in)[off];
+    else v = mk<T>(reinterpret_cast<const T*>(pr.in)[off], (T)0);
+    if (pr.detrend) {
+        const double* c = pr.coef + b * 6;
+        v.re -= (T)(c[0] + c[2] * si + c[4] * sj);
+        if (pr.in_complex) v.im -= (T)(c[1] + c[3] * si + c[5] * sj);
+    }
+    T w = (T)1;
+    if (pr.win_y) w = reinterpret_cast<const T*>(pr.win_y)[si];
+    if (pr.win_x) w *= reinterpret_cast<const T*>(pr.win_x)[sj];
+    if (pr.win_y || pr.win_x) v = cscale(v, w);
+    return v;
+}
+
+// ------------------------------------------------------------------------------------------------
+// last-pass store of one frequency sample V = F(b, ky, kx) (unshifted indices)
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__device__ __forceinline__ void emit(const Epilogue& ep, long long b, int ky, int kx, C2<T> V, bool conj_it, double* hist) {
+    // V is F (COMPLEX), or F0 conj(F1) (CROSS), or (|F|^2, 0) (POWER), before phase and scale
+    if (conj_it) V.im = -V.im;
+    if (ep.mode != 1) {
+        if (ep.ph_y) V = cmul(V, reinterpret_cast<const C2<T>*>(ep.ph_y)[ky]);
+        if (ep.ph_x) V = cmul(V, reinterpret_cast<const C2<T>*>(ep.ph_x)[kx]);
+    }
+    T s = (T)ep.scale;
+    if (ep.realdim_x2 && !(kx == 0 || ((ep.nx & 1) == 0 && kx == ep.nx / 2))) s *= (T)2;
+    V = cscale(V, s);
+    if (ep.out) {
+        const long long off = b * ep.slab_stride + (long long)shift_dst(ky, ep.ny, ep.shift_y) * ep.row_stride + shift_dst(kx, ep.nx, ep.shift_x);
+        if (ep.mode == 1) reinterpret_cast<T*>(ep.out)[off] = V.re;
+        else reinterpret_cast<C2<T>*>(ep.out)[off] = V;
+    }
+    if (hist) {
+        const int bin = ep.binmap[(long long)ky * ep.nx_out + kx];
+        if (bin >= 0) {
+            if (ep.mode == 2) { atomicAdd(&hist[2 * bin], (double)V.re); atomicAdd(&hist[2 * bin + 1], (double)V.im); }
+            else atomicAdd(&hist[bin], (double)V.re);
+        }
+    }
+}
+
+template <typename T>
+__device__ __forceinline__ void epi_store(const Epilogue& ep, long long o, long long q, int p, C2<T> F, double* hist) {
+    const long long b = o / ep.odiv;
+    const int km = (int)((o - b * ep.odiv) * ep.r_mul + q * ep.q_mul + (long long)p * ep.p_mul);
+    int ky, kx;
+    if (ep.p_axis) { ky = km; kx = (int)q; } else { ky = 0; kx = km; }
+    if (kx >= ep.nx_out && !ep.mirror) return;  // full-complex path of a real input with HALF_X
+    C2<T> V;
+    if (ep.mode == 0) V = F;
+    else if (ep.mode == 1) V = mk<T>(F.re * F.re + F.im * F.im, (T)0);
+    else {
+        const C2<T> G = reinterpret_cast<const C2<T>*>(ep.other)[b * ep.other_slab_stride + (long long)ky * ep.other_row_stride + kx];
+        V = cmulc(G, F);  // F0 * conj(F1): `other` holds field 0, this pass transforms field 1
+    }
+    emit<T>(ep, b, ky, kx, V, false, hist);
+    if (ep.mirror && kx > 0 && kx < ep.nx - kx) {
+        const int my = ky == 0 ? 0 : ep.ny - ky;
+        emit<T>(ep, b, my, ep.nx - kx, V, true, hist);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// radix passes
+// ------------------------------------------------------------------------------------------------
+template <typename T, int R>
+__device__ __forceinline__ void run_pass(C2<T>* tile, const TileGeom& g, int L, int tid, int nthreads) {
+    const int m = L / R;
+    const int per_seq = g.n / R;
+    const int nb = g.T * per_seq;
+    const int twstep = g.n / L;
+    const C2<T>* __restrict__ tw = reinterpret_cast<const C2<T>*>(g.tw);
+    for (int w = tid; w < nb; w += nthreads) {
+        const int t = w / per_seq;
+        const int gg = w - t * per_seq;
+        const int blk = gg / m;
+        const int j = gg - blk * m;
+        C2<T>* s = tile + (long long)t * g.seq_stride;
+        const int base = blk * L + j;
+        C2<T> a[R];
+#pragma unroll
+        for (int q = 0; q < R; ++q) a[q] = s[phys(base + q * m, g.pad_shift)];
+        dft_r<T, R>(a);
+        if (m > 1) {
+#pragma unroll
+            for (int k = 1; k < R; ++k) a[k] = cmul(a[k], tw[(long long)j * k * twstep]);
+        }
+#pragma unroll
+        for (int k = 0; k < R; ++k) s[phys(base + k * m, g.pad_shift)] = a[k];
+    }
+}
+
+// any radix up to XRFTHIP_MAX_RADIX (O(R^2) butterfly; operands live in scratch) -- odd lengths only
+template <typename T>
+__device__ void run_pass_generic(C2<T>* tile, const TileGeom& g, int R, int L, int tid, int nthreads) {
+    const int m = L / R;
+    const int per_seq = g.n / R;
+    const int nb = g.T * per_seq;
+    const int twstep = g.n / L;
+    const int rstep = g.n / R;
+    const C2<T>* __restrict__ tw = reinterpret_cast<const C2<T>*>(g.tw);
+    C2<T> a[128];
+    for (int w = tid; w < nb; w += nthreads) {
+        const int t = w / per_seq;
+        const int gg = w - t * per_seq;
+        const int blk = gg / m;
+        const int j = gg - blk * m;
+        C2<T>* s = tile + (long long)t * g.seq_stride;
+        const int base = blk * L + j;
+        for (int q = 0; q < R; ++q) a[q] = s[phys(base + q * m, g.pad_shift)];
+        for (int k = 0; k < R; ++k) {
+            C2<T> acc = a[0];
+            int idx = 0;
+            for (int q = 1; q < R; ++q) {
+                idx += k; if (idx >= R) idx -= R;
+                acc = acc + cmul(a[q], tw[(long long)idx * rstep]);
+            }
+            if (m > 1 && k > 0) acc = cmul(acc, tw[(long long)j * k * twstep]);
+            s[phys(base + k * m, g.pad_shift)] = acc;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// the kernel
+// ------------------------------------------------------------------------------------------------
+template <typename T, bool FIRST, bool FINAL, bool GENERIC>
+__global__ void __launch_bounds__(1024) tile_fft_kernel(TileGeom g, Prologue pr, Epilogue ep) {
+    XRFT_DYN_SMEM(smem_raw);
+    C2<T>* tile = reinterpret_cast<C2<T>*>(smem_raw);
+    const int tid = threadIdx.x, nthreads = blockDim.x;
+    double* hist = nullptr;
+    long long hist_slab = -1;
+    int hist_len = 0;
+    if (FINAL && ep.iso) {
+        size_t off = (size_t)g.T * g.seq_stride * sizeof(C2<T>);
+        off = (off + 15) & ~(size_t)15;
+        hist = reinterpret_cast<double*>(smem_raw + off);
+        hist_len = ep.nbins * (ep.mode == 2 ? 2 : 1);
+        for (int i = tid; i < hist_len; i += nthreads) hist[i] = 0.0;
+    }
+    const C2<T>* __restrict__ gin = reinterpret_cast<const C2<T>*>(g.in);
+    C2<T>* __restrict__ gout = reinterpret_cast<C2<T>*>(g.out);
+
+    for (long long tile_id = blockIdx.x; tile_id < g.n_tiles; tile_id += gridDim.x) {
+        long long o0, q0;
+        int tv;
+        if (g.tile_axis == 0) {
+            o0 = tile_id * g.T; q0 = 0;
+            long long rem = g.n_outer - o0; tv = rem < g.T ? (int)rem : g.T;
+        } else {
+            o0 = tile_id / g.tiles_per_outer;
+            q0 = (tile_id - o0 * g.tiles_per_outer) * g.T;
+            long long rem = g.inner - q0; tv = rem < g.T ? (int)rem : g.T;
+        }
+        if (hist) {  // flush the LDS histogram when this block moves on to another slab
+            const long long slab = (g.tile_axis == 0 ? o0 : o0) / ep.odiv;
+            if (hist_slab >= 0 && slab != hist_slab) {
+                __syncthreads();
+                for (int i = tid; i < hist_len; i += nthreads) {
+                    double v = hist[i];
+                    if (v != 0.0) atomicAdd(&ep.iso[hist_slab * hist_len + i], v);
+                    hist[i] = 0.0;
+                }
+            }
+            hist_slab = slab;
+        }
+        // ------------------------------------------------------------------ load
+        const int total_in = g.T * g.n;
+        for (int e = tid; e < total_in; e += nthreads) {
+            int t, p;
+            if (g.in_fast == 0) { t = e / g.n; p = e - t * g.n; } else { p = e / g.T; t = e - p * g.T; }
+            C2<T> v = mk<T>((T)0, (T)0);
+            if (t < tv) {
+                const long long o = g.tile_axis == 0 ? o0 + t : o0;
+                const long long q = g.tile_axis == 0 ? 0 : q0 + t;
+                if (FIRST) {
+                    const long long b = o / pr.rows;
+                    const int i = (int)(o - b * pr.rows);
+                    if (g.r2c) {
+                        const C2<T> e0 = fetch_src<T>(pr, b, i, 2 * p);
+                        const C2<T> e1 = fetch_src<T>(pr, b, i, 2 * p + 1);
+                        v = mk<T>(e0.re, e1.re);
+                    } else {
+                        v = fetch_src<T>(pr, b, i, (int)(p * pr.j_mul_p + q * pr.j_mul_q));
+                    }
+                } else {
+                    v = gin[o * g.in_so + q * g.in_sq + (long long)p * g.in_sp];
+                }
+            }
+            tile[(long long)t * g.seq_stride + phys(p, g.pad_shift)] = v;
+        }
+        __syncthreads();
+        // ------------------------------------------------------------------ in-place DIF passes
+        int L = g.n;
+        for (int ip = 0; ip < g.nr; ++ip) {
+            const int R = g.radix[ip];
+            switch (R) {
+                case 2: run_pass<T, 2>(tile, g, L, tid, nthreads); break;
+                case 3: run_pass<T, 3>(tile, g, L, tid, nthreads); break;
+                case 4: run_pass<T, 4>(tile, g, L, tid, nthreads); break;
+                case 5: run_pass<T, 5>(tile, g, L, tid, nthreads); break;
+                case 8: run_pass<T, 8>(tile, g, L, tid, nthreads); break;
+                default:
+                    if (GENERIC) run_pass_generic<T>(tile, g, R, L, tid, nthreads);
+                    break;
+            }
+            L /= R;
+            __syncthreads();
+        }
+        // ------------------------------------------------------------------ store
+        const int total_out = g.T * g.n_out;
+        for (int e = tid; e < total_out; e += nthreads) {
+            int t, k;
+            if (g.out_fast == 0) { t = e / g.n_out; k = e - t * g.n_out; } else { k = e / g.T; t = e - k * g.T; }
+            if (t >= tv) continue;
+            const C2<T>* s = tile + (long long)t * g.seq_stride;
+            C2<T> F;
+            if (g.r2c) {
+                const int ka = k == g.n ? 0 : k;
+                const int kb = k == 0 ? 0 : g.n - k;
+                const C2<T> zk = s[phys((int)g.rev[ka], g.pad_shift)];
+                const C2<T> zc = cconj(s[phys((int)g.rev[kb], g.pad_shift)]);
+                const C2<T> E = cscale(zk + zc, (T)0.5);
+                const C2<T> O = cscale(mul_mi(zk - zc), (T)0.5);
+                F = E + cmul(reinterpret_cast<const C2<T>*>(g.tw_r2c)[k], O);
+            } else {
+                F = s[phys((int)g.rev[k], g.pad_shift)];
+            }
+            const long long o = g.tile_axis == 0 ? o0 + t : o0;
+            const long long q = g.tile_axis == 0 ? 0 : q0 + t;
+            if (FINAL) {
+                epi_store<T>(ep, o, q, k, F, hist);
+            } else {
+                if (g.tw_big) {
+                    const long long a = (q / g.tw_qdiv) % g.tw_qmod;
+                    F = cmul(F, reinterpret_cast<const C2<T>*>(g.tw_big)[(a * k) % g.tw_bigN]);
+                }
+                gout[o * g.out_so + q * g.out_sq + (long long)k * g.out_sp] = F;
+            }
+        }
+        __syncthreads();
+    }
+    if (hist && hist_slab >= 0) {
+        __syncthreads();
+        for (int i = tid; i < hist_len; i += nthreads) {
+            double v = hist[i];
+            if (v != 0.0) atomicAdd(&ep.iso[hist_slab * hist_len + i], v);
+        }
+    }
+}
+
+}  // namespace xrft

@@ -1,0 +1,937 @@
+// xrft_hip.cpp -- plan builder, pass scheduler and the C ABI of libxrft_hip.so (see include/xrft_hip.h).
+//
+// A plan is a short list of kernel launches ("passes") per group of slabs:
+//     [slab_moments -> finalize_coef]  ->  x pass(es)  ->  y pass(es)
+// The x pass reads the user's array (detrend / window / flip / ifftshift fused into its loads) and the last
+// pass writes the user's output (fftshift / phase / scaling / |F|^2 / cross / mirror / radial bin-sum fused
+// into its stores).  The only intermediate is the half-spectrum of ONE group of slabs, sized to stay inside
+// the 256 MiB Infinity Cache, re-used for every group.  Nothing here allocates or synchronises in exec.
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../include/xrft_hip.h"
+#include "aux_kernels.h"
+#include "tile_fft.h"
+
+using namespace xrft;
+
+namespace {
+
+thread_local int g_last_hip_error = 0;
+
+#define HIP_TRY(expr)                                   \
+    do {                                                \
+        hipError_t e_ = (expr);                         \
+        if (e_ != hipSuccess) {                         \
+            g_last_hip_error = (int)e_;                 \
+            return XRFTHIP_HIP_ERROR;                   \
+        }                                               \
+    } while (0)
+
+constexpr size_t kLdsMax = 160 * 1024;  // gfx950: 160 KiB per CU, one workgroup may use all of it
+constexpr int kCUs = 256;
+
+struct DevBuf {
+    void* p = nullptr;
+    size_t bytes = 0;
+    ~DevBuf() { if (p) (void)hipFree(p); }
+    int upload(const void* host, size_t n) {
+        if (p) { (void)hipFree(p); p = nullptr; }
+        bytes = n;
+        if (hipMalloc(&p, n ? n : 16) != hipSuccess) { p = nullptr; return XRFTHIP_ALLOC_FAILED; }
+        HIP_TRY(hipMemcpy(p, host, n, hipMemcpyHostToDevice));
+        return XRFTHIP_OK;
+    }
+    void clear() { if (p) { (void)hipFree(p); p = nullptr; bytes = 0; } }
+};
+
+struct FftTables {  // per FFT length, in the plan's precision
+    int n = 0;
+    std::vector<int> radix;
+    bool generic = false;
+    DevBuf tw, rev;
+};
+
+enum BufKind { B_NONE = 0, B_IN, B_W, B_W2, B_F0, B_OUT };
+
+struct Pass {
+    TileGeom g{};
+    Prologue pr{};
+    Epilogue ep{};
+    bool first = false, final_ = false, generic = false;
+    int threads = 256;
+    size_t lds = 0;
+    int in_kind = B_NONE, out_kind = B_NONE;
+    long long outer_per_slab = 1;  // n_outer = outer_per_slab * slabs in the group
+    std::string label;
+};
+
+int factorize(long long n, std::vector<int>& out, bool& generic) {
+    // DIF order: odd radices first (their passes then run on lane-contiguous LDS), then 8, 4, 2
+    std::vector<int> odd, two;
+    long long m = n;
+    while (m % 8 == 0) { two.push_back(8); m /= 8; }
+    while (m % 4 == 0) { two.push_back(4); m /= 4; }
+    while (m % 2 == 0) { two.push_back(2); m /= 2; }
+    generic = false;
+    for (long long p = 3; m > 1; p += 2) {
+        if (p * p > m) p = m;
+        while (m % p == 0) {
+            if (p > XRFTHIP_MAX_RADIX) return XRFTHIP_UNSUPPORTED_LENGTH;
+            odd.push_back((int)p);
+            if (p != 3 && p != 5) generic = true;
+            m /= p;
+        }
+    }
+    std::sort(odd.begin(), odd.end(), [](int a, int b) { return a > b; });
+    out = odd;
+    out.insert(out.end(), two.begin(), two.end());
+    if ((int)out.size() > XRFT_MAX_PASSES) return XRFTHIP_UNSUPPORTED_LENGTH;
+    return XRFTHIP_OK;
+}
+
+template <typename T>
+int build_tables(FftTables& t, int n) {
+    t.n = n;
+    int rc = factorize(n, t.radix, t.generic);
+    if (rc) return rc;
+    std::vector<C2<T>> tw((size_t)std::max(n, 1));
+    for (int k = 0; k < n; ++k) {
+        const long double a = -2.0L * 3.14159265358979323846264338327950288L * (long double)k / (long double)n;
+        tw[k].re = (T)cosl(a);
+        tw[k].im = (T)sinl(a);
+    }
+    std::vector<unsigned> rev((size_t)std::max(n, 1));
+    for (int pos = 0; pos < n; ++pos) {  // frequency held at LDS position `pos` after the DIF passes
+        long long L = n, rem = pos, k = 0, mult = 1;
+        for (int r : t.radix) {
+            const long long m = L / r;
+            k += (rem / m) * mult;
+            rem %= m;
+            mult *= r;
+            L = m;
+        }
+        rev[(size_t)k] = (unsigned)pos;
+    }
+    rc = t.tw.upload(tw.data(), tw.size() * sizeof(C2<T>));
+    if (rc) return rc;
+    return t.rev.upload(rev.data(), rev.size() * sizeof(unsigned));
+}
+
+template <typename T>
+int build_twiddle(DevBuf& buf, long long N, long long count) {  // W_N^k, k < count
+    std::vector<C2<T>> tw((size_t)count);
+    for (long long k = 0; k < count; ++k) {
+        const long double a = -2.0L * 3.14159265358979323846264338327950288L * (long double)k / (long double)N;
+        tw[(size_t)k].re = (T)cosl(a);
+        tw[(size_t)k].im = (T)sinl(a);
+    }
+    return buf.upload(tw.data(), tw.size() * sizeof(C2<T>));
+}
+
+long long env_ll(const char* name, long long dflt) {
+    const char* e = getenv(name);
+    return e && *e ? atoll(e) : dflt;
+}
+
+}  // namespace
+
+struct xrfthip_plan {
+    xrfthip_desc d{};
+    bool dbl = false, cplx_in = false;
+    size_t rsize = 4, csize = 8;
+    long long nxh = 0, width = 0, nx_out = 0;
+    bool mirror = false;
+    int G = 1;
+    std::map<int, FftTables> tables;
+    std::vector<DevBuf*> extra;  // r2c / four-step twiddles
+    DevBuf win[2], phase[2], binmap;
+    int nbins = 0;
+    std::vector<Pass> passes;     // main pipeline (field 1 for CROSS)
+    std::vector<Pass> passes_f0;  // CROSS: field 0 -> raw F0 buffer
+    // workspace layout (byte offsets)
+    size_t off_acc = 0, off_coef = 0, off_w = 0, off_w2 = 0, off_f0 = 0, ws_bytes = 0;
+    std::string desc_text;
+    // optional per-pass event timing (bench only)
+    bool prof = false;
+    struct ProfRec { std::string label; hipEvent_t a, b; };
+    std::vector<ProfRec> prof_recs;
+    void prof_clear() { for (auto& r : prof_recs) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); } prof_recs.clear(); }
+    ~xrfthip_plan() { for (auto* b : extra) delete b; prof_clear(); }
+};
+
+namespace {
+
+struct TileChoice { int T, threads, seq_stride, pad_shift; size_t lds; };
+
+// pick sequences-per-tile for an n-point FFT; `col`: the tile axis is the contiguous one in memory, so T*csize
+// bytes per row segment should reach a 128-byte line.  Returns T = 0 if one sequence does not fit in LDS.
+TileChoice choose_tile(long long n, size_t csize, bool col, long long avail, size_t hist_bytes) {
+    TileChoice c{};
+    c.pad_shift = csize == 8 ? 4 : 3;
+    long long ss = n + (n >> c.pad_shift) + 1;
+    if ((ss & 1) == 0) ++ss;
+    c.seq_stride = (int)ss;
+    const size_t per = (size_t)ss * csize;
+    const size_t hard = kLdsMax - hist_bytes - 64;
+    const size_t soft = (size_t)env_ll("XRFTHIP_LDS_SOFT", 64 * 1024);
+    long long target = std::max<long long>(1, 8192 / std::max<long long>(n, 1));
+    if (col) target = std::max<long long>(target, (long long)(128 / csize));
+    long long T = std::min<long long>(target, (long long)(soft / per));
+    const long long want = col ? std::min<long long>(4, target) : 1;
+    if (T < want) T = std::min<long long>(target, (long long)(hard / per));
+    if (T > avail) T = avail;
+    if (T < 1) { c.T = 0; return c; }
+    if (col) { long long p2 = 1; while (p2 * 2 <= T) p2 *= 2; T = p2; }
+    c.T = (int)T;
+    long long th = (T * n + 15) / 16;
+    th = ((th + 63) / 64) * 64;
+    c.threads = (int)std::min<long long>(1024, std::max<long long>(64, th));
+    c.lds = (((size_t)T * per + 15) & ~(size_t)15) + hist_bytes;
+    return c;
+}
+
+// split n = n1 * n2 with both factors as close to sqrt(n) as the factorisation allows
+bool split_two(long long n, long long& n1, long long& n2) {
+    long long best = 0;
+    for (long long a = 1; a * a <= n; ++a)
+        if (n % a == 0) best = a;
+    if (best <= 1) return false;
+    n1 = n / best;  // n1 >= n2
+    n2 = best;
+    return true;
+}
+
+template <typename T>
+struct Builder {
+    xrfthip_plan& P;
+    explicit Builder(xrfthip_plan& p) : P(p) {}
+
+    int tables_for(int n, FftTables** out) {
+        auto it = P.tables.find(n);
+        if (it == P.tables.end()) {
+            FftTables& t = P.tables[n];
+            int rc = build_tables<T>(t, n);
+            if (rc) { P.tables.erase(n); return rc; }
+            *out = &t;
+        } else *out = &it->second;
+        return XRFTHIP_OK;
+    }
+
+    int set_fft(Pass& ps, int n) {
+        FftTables* t;
+        int rc = tables_for(n, &t);
+        if (rc) return rc;
+        ps.g.n = n;
+        ps.g.nr = (int)t->radix.size();
+        for (int i = 0; i < ps.g.nr; ++i) ps.g.radix[i] = t->radix[i];
+        ps.g.tw = t->tw.p;
+        ps.g.rev = (const unsigned*)t->rev.p;
+        ps.generic = t->generic;
+        return XRFTHIP_OK;
+    }
+
+    void apply_tile(Pass& ps, const TileChoice& c) {
+        ps.g.T = c.T;
+        ps.g.seq_stride = c.seq_stride;
+        ps.g.pad_shift = c.pad_shift;
+        ps.threads = c.threads;
+        ps.lds = c.lds;
+    }
+
+    void fill_prologue(Pass& ps, long long rows, long long jmp, long long jmq) {
+        const xrfthip_desc& d = P.d;
+        Prologue& pr = ps.pr;
+        pr.in_complex = P.cplx_in;
+        pr.detrend = d.detrend != XRFTHIP_DETREND_NONE;
+        pr.rows = rows;
+        pr.j_mul_p = jmp;
+        pr.j_mul_q = jmq;
+        pr.ny = (int)d.ny;
+        pr.nx = (int)d.nx;
+        pr.flip_y = !!(d.flags & XRFTHIP_FLIP_Y);
+        pr.ishift_y = !!(d.flags & XRFTHIP_ISHIFT_Y);
+        pr.flip_x = !!(d.flags & XRFTHIP_FLIP_X);
+        pr.ishift_x = !!(d.flags & XRFTHIP_ISHIFT_X);
+        pr.slab_stride = d.ny * d.nx;
+        pr.row_stride = d.nx;
+        ps.first = true;
+        ps.in_kind = B_IN;
+    }
+
+    // raw: final pass of the F0 pipeline of CROSS (plain complex spectrum, unshifted, into the F0 buffer)
+    void fill_epilogue(Pass& ps, bool raw, int p_axis, long long odiv) {
+        const xrfthip_desc& d = P.d;
+        Epilogue& ep = ps.ep;
+        ep.mode = raw ? 0 : d.out_mode;
+        ep.p_axis = p_axis;
+        ep.odiv = odiv;
+        ep.r_mul = odiv > 1 ? 1 : 0;
+        ep.q_mul = 0;
+        ep.p_mul = odiv;
+        ep.ny = (int)d.ny;
+        ep.nx = (int)d.nx;
+        ep.scale = raw ? 1.0 : d.scale;
+        if (raw) {
+            ep.nx_out = (int)P.width;
+            ep.mirror = 0;
+            ep.shift_y = ep.shift_x = 0;
+            ep.realdim_x2 = 0;
+            ep.slab_stride = d.ny * P.width;
+            ep.row_stride = P.width;
+            ps.out_kind = B_F0;
+        } else {
+            ep.nx_out = (int)P.nx_out;
+            ep.mirror = P.mirror;
+            ep.shift_y = !!(d.flags & XRFTHIP_SHIFT_Y);
+            ep.shift_x = !!(d.flags & XRFTHIP_SHIFT_X);
+            ep.realdim_x2 = !!(d.flags & XRFTHIP_REALDIM_X2);
+            ep.slab_stride = d.ny * P.nx_out;
+            ep.row_stride = P.nx_out;
+            ep.other_slab_stride = d.ny * P.width;
+            ep.other_row_stride = P.width;
+            ps.out_kind = B_OUT;
+        }
+        ps.final_ = true;
+    }
+
+    size_t hist_bytes(bool raw) const {
+        if (raw || !(P.d.flags & XRFTHIP_ISO)) return 0;
+        return (size_t)P.nbins * (P.d.out_mode == XRFTHIP_OUT_CROSS ? 16 : 8);
+    }
+
+    // ---------------------------------------------------------------- x passes (along the contiguous axis)
+    // rows_per_slab = ny (2-D) or 1 (1-D).  `last`: the x transform is the whole transform (1-D).
+    int build_x(std::vector<Pass>& out, bool raw) {
+        const xrfthip_desc& d = P.d;
+        const bool last = d.ndim == 1;
+        const long long rows = d.ny;
+        const bool real_in = !P.cplx_in;
+        const bool want_r2c = real_in && d.nx % 2 == 0 && d.nx >= 2 && P.width == d.nx / 2 + 1;
+        const long long n = want_r2c ? d.nx / 2 : d.nx;
+        TileChoice c = choose_tile(n, P.csize, false, std::max<long long>(1, rows * d.batch), last ? hist_bytes(raw) : 0);
+        const bool four = P.width == d.nx && (c.T == 0 || n >= env_ll("XRFTHIP_X_FOURSTEP_MIN", 1LL << 40)) && n > 1;
+        if (c.T == 0 && !four) return XRFTHIP_UNSUPPORTED_LENGTH;
+        if (!four) {
+            Pass ps;
+            ps.label = want_r2c ? "x:r2c-row" : "x:row";
+            int rc = set_fft(ps, (int)n);
+            if (rc) return rc;
+            apply_tile(ps, c);
+            ps.g.r2c = want_r2c;
+            ps.g.n_out = (int)P.width;
+            if (want_r2c) {
+                DevBuf* b = new DevBuf();
+                P.extra.push_back(b);
+                rc = build_twiddle<T>(*b, d.nx, n + 1);
+                if (rc) return rc;
+                ps.g.tw_r2c = b->p;
+            }
+            ps.g.tile_axis = 0;
+            ps.g.in_fast = 0;
+            ps.g.out_fast = 0;
+            ps.g.inner = 1;
+            ps.g.tiles_per_outer = 1;
+            ps.outer_per_slab = rows;
+            fill_prologue(ps, rows, 1, 0);
+            if (last) {
+                fill_epilogue(ps, raw, 0, 1);
+            } else {
+                ps.g.out_so = P.width;
+                ps.g.out_sq = 0;
+                ps.g.out_sp = 1;
+                ps.out_kind = B_W;
+            }
+            out.push_back(ps);
+            return XRFTHIP_OK;
+        }
+        // ---- four-step along x: nx = n1 * n2, A: FFT over i1 (stride n2) + twiddle, B: FFT over i2, transposed store
+        long long n1, n2;
+        if (!split_two(d.nx, n1, n2)) return XRFTHIP_UNSUPPORTED_LENGTH;
+        TileChoice ca = choose_tile(n1, P.csize, true, n2, 0);
+        TileChoice cb = choose_tile(n2, P.csize, true, n1, last ? hist_bytes(raw) : 0);
+        if (ca.T == 0 || cb.T == 0) return XRFTHIP_UNSUPPORTED_LENGTH;
+        DevBuf* big = new DevBuf();
+        P.extra.push_back(big);
+        int rc = build_twiddle<T>(*big, d.nx, d.nx);
+        if (rc) return rc;
+        {
+            Pass a;
+            a.label = "x:four-step-A";
+            rc = set_fft(a, (int)n1);
+            if (rc) return rc;
+            apply_tile(a, ca);
+            a.g.n_out = (int)n1;
+            a.g.tile_axis = 1;
+            a.g.in_fast = 1;
+            a.g.out_fast = 1;
+            a.g.inner = n2;
+            a.g.tiles_per_outer = (n2 + ca.T - 1) / ca.T;
+            a.outer_per_slab = rows;
+            fill_prologue(a, rows, n2, 1);
+            a.g.out_so = d.nx; a.g.out_sq = 1; a.g.out_sp = n2;
+            a.g.tw_big = big->p; a.g.tw_bigN = d.nx; a.g.tw_qdiv = 1; a.g.tw_qmod = n2;
+            a.out_kind = B_W2;
+            out.push_back(a);
+        }
+        {
+            Pass b;
+            b.label = "x:four-step-B";
+            rc = set_fft(b, (int)n2);
+            if (rc) return rc;
+            apply_tile(b, cb);
+            b.g.n_out = (int)n2;
+            b.g.tile_axis = 1;
+            b.g.in_fast = 0;
+            b.g.out_fast = 1;
+            b.g.inner = n1;
+            b.g.tiles_per_outer = (n1 + cb.T - 1) / cb.T;
+            b.outer_per_slab = rows;
+            b.in_kind = B_W2;
+            b.g.in_so = d.nx; b.g.in_sq = n2; b.g.in_sp = 1;
+            if (last) {
+                fill_epilogue(b, raw, 0, 1);
+                b.ep.q_mul = 1;  // kx = k1 + n1 * k2
+                b.ep.p_mul = n1;
+            } else {
+                b.g.out_so = d.nx; b.g.out_sq = 1; b.g.out_sp = n1;
+                b.out_kind = B_W;
+            }
+            out.push_back(b);
+        }
+        return XRFTHIP_OK;
+    }
+
+    // ---------------------------------------------------------------- y passes (strided axis of the intermediate)
+    int build_y(std::vector<Pass>& out, bool raw) {
+        const xrfthip_desc& d = P.d;
+        const long long ny = d.ny, w = P.width;
+        TileChoice c = choose_tile(ny, P.csize, true, w, hist_bytes(raw));
+        const long long min_t = std::min<long long>(env_ll("XRFTHIP_Y_MIN_T", 4), w);
+        bool four = (c.T < min_t || ny >= env_ll("XRFTHIP_Y_FOURSTEP_MIN", 1LL << 40)) && ny > 3;
+        long long n1 = 0, n2 = 0;
+        if (four && !split_two(ny, n1, n2)) four = false;
+        if (!four) {
+            if (c.T == 0) return XRFTHIP_UNSUPPORTED_LENGTH;
+            Pass ps;
+            ps.label = "y:col";
+            int rc = set_fft(ps, (int)ny);
+            if (rc) return rc;
+            apply_tile(ps, c);
+            ps.g.n_out = (int)ny;
+            ps.g.tile_axis = 1;
+            ps.g.in_fast = 1;
+            ps.g.out_fast = 1;
+            ps.g.inner = w;
+            ps.g.tiles_per_outer = (w + c.T - 1) / c.T;
+            ps.outer_per_slab = 1;
+            ps.in_kind = B_W;
+            ps.g.in_so = ny * w; ps.g.in_sq = 1; ps.g.in_sp = w;
+            fill_epilogue(ps, raw, 1, 1);
+            out.push_back(ps);
+            return XRFTHIP_OK;
+        }
+        TileChoice ca = choose_tile(n1, P.csize, true, n2 * w, 0);
+        TileChoice cb = choose_tile(n2, P.csize, true, w, hist_bytes(raw));
+        if (ca.T == 0 || cb.T == 0) return XRFTHIP_UNSUPPORTED_LENGTH;
+        DevBuf* big = new DevBuf();
+        P.extra.push_back(big);
+        int rc = build_twiddle<T>(*big, ny, ny);
+        if (rc) return rc;
+        {
+            Pass a;  // in place on W viewed as [slab][n1][n2*w]
+            a.label = "y:four-step-A";
+            rc = set_fft(a, (int)n1);
+            if (rc) return rc;
+            apply_tile(a, ca);
+            a.g.n_out = (int)n1;
+            a.g.tile_axis = 1;
+            a.g.in_fast = 1;
+            a.g.out_fast = 1;
+            a.g.inner = n2 * w;
+            a.g.tiles_per_outer = (n2 * w + ca.T - 1) / ca.T;
+            a.outer_per_slab = 1;
+            a.in_kind = B_W;
+            a.out_kind = B_W;
+            a.g.in_so = ny * w; a.g.in_sq = 1; a.g.in_sp = n2 * w;
+            a.g.out_so = ny * w; a.g.out_sq = 1; a.g.out_sp = n2 * w;
+            a.g.tw_big = big->p; a.g.tw_bigN = ny; a.g.tw_qdiv = w; a.g.tw_qmod = n2;
+            out.push_back(a);
+        }
+        {
+            Pass b;  // sequences (slab, k1, kx): o = slab*n1 + k1, q = kx, points i2 (stride w)
+            b.label = "y:four-step-B";
+            rc = set_fft(b, (int)n2);
+            if (rc) return rc;
+            apply_tile(b, cb);
+            b.g.n_out = (int)n2;
+            b.g.tile_axis = 1;
+            b.g.in_fast = 1;
+            b.g.out_fast = 1;
+            b.g.inner = w;
+            b.g.tiles_per_outer = (w + cb.T - 1) / cb.T;
+            b.outer_per_slab = n1;
+            b.in_kind = B_W;
+            b.g.in_so = n2 * w; b.g.in_sq = 1; b.g.in_sp = w;
+            fill_epilogue(b, raw, 1, n1);
+            out.push_back(b);
+        }
+        return XRFTHIP_OK;
+    }
+
+    int build_pipeline(std::vector<Pass>& out, bool raw) {
+        int rc = build_x(out, raw);
+        if (rc) return rc;
+        if (P.d.ndim == 2) rc = build_y(out, raw);
+        return rc;
+    }
+};
+
+template <typename T>
+int build_plan_t(xrfthip_plan& P) {
+    Builder<T> B(P);
+    int rc = B.build_pipeline(P.passes, false);
+    if (rc) return rc;
+    if (P.d.out_mode == XRFTHIP_OUT_CROSS) rc = B.build_pipeline(P.passes_f0, true);
+    return rc;
+}
+
+void set_kernel_attrs_once() {
+    static bool done = false;
+    if (done) return;
+    done = true;
+    const int m = (int)kLdsMax;
+#define SETA(TT, A, B, C) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&tile_fft_kernel<TT, A, B, C>), hipFuncAttributeMaxDynamicSharedMemorySize, m)
+#define SETALL(TT) SETA(TT, false, false, false); SETA(TT, false, false, true); SETA(TT, false, true, false); SETA(TT, false, true, true); \
+                   SETA(TT, true, false, false); SETA(TT, true, false, true); SETA(TT, true, true, false); SETA(TT, true, true, true)
+    SETALL(float);
+    SETALL(double);
+#undef SETALL
+#undef SETA
+}
+
+template <typename T>
+void launch_tile(const Pass& ps, int grid, hipStream_t st) {
+    const dim3 g((unsigned)grid), b((unsigned)ps.threads);
+#define L_(A, B, C) do { auto k = &tile_fft_kernel<T, A, B, C>; XRFT_LAUNCH(k, g, b, ps.lds, st, ps.g, ps.pr, ps.ep); } while (0)
+    const int sel = (ps.first ? 4 : 0) | (ps.final_ ? 2 : 0) | (ps.generic ? 1 : 0);
+    switch (sel) {
+        case 0: L_(false, false, false); break;
+        case 1: L_(false, false, true); break;
+        case 2: L_(false, true, false); break;
+        case 3: L_(false, true, true); break;
+        case 4: L_(true, false, false); break;
+        case 5: L_(true, false, true); break;
+        case 6: L_(true, true, false); break;
+        default: L_(true, true, true); break;
+    }
+#undef L_
+}
+
+void appendf(std::string& s, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    s += buf;
+}
+
+void describe_passes(std::string& s, const std::vector<Pass>& v, const char* name) {
+    for (const Pass& p : v) {
+        appendf(s, "  [%s] %-16s n=%d radix=", name, p.label.c_str(), p.g.n);
+        for (int i = 0; i < p.g.nr; ++i) appendf(s, "%s%d", i ? "x" : "", p.g.radix[i]);
+        appendf(s, " T=%d threads=%d lds=%zuB%s%s%s%s\n", p.g.T, p.threads, p.lds, p.g.r2c ? " r2c" : "",
+                p.first ? " first" : "", p.final_ ? " final" : "", p.generic ? " generic-radix" : "");
+    }
+}
+
+}  // namespace
+
+static int upload_real_table(xrfthip_plan* P, DevBuf& buf, const double* h, int64_t n, int cplx) {
+    if (!h) { buf.clear(); return XRFTHIP_OK; }
+    const size_t cnt = (size_t)n * (cplx ? 2 : 1);
+    if (P->dbl) return buf.upload(h, cnt * sizeof(double));
+    std::vector<float> f(cnt);
+    for (size_t i = 0; i < cnt; ++i) f[i] = (float)h[i];
+    return buf.upload(f.data(), cnt * sizeof(float));
+}
+
+static void layout_workspace(xrfthip_plan* P) {
+    const xrfthip_desc& d = P->d;
+    long long G = d.slabs_per_group > 0 ? d.slabs_per_group : env_ll("XRFTHIP_GROUP", 0);
+    const size_t slab_w = (size_t)d.ny * P->width * P->csize;
+    if (G <= 0) {
+        const size_t target = (size_t)env_ll("XRFTHIP_GROUP_BYTES", 64LL << 20);
+        G = (long long)std::max<size_t>(1, target / std::max<size_t>(slab_w, 1));
+    }
+    G = std::max<long long>(1, std::min<long long>(G, std::max<long long>(d.batch, 1)));
+    P->G = (int)G;
+    auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
+    const int nf = d.out_mode == XRFTHIP_OUT_CROSS ? 2 : 1;
+    size_t off = 0;
+    P->off_acc = off; off = al(off + (size_t)d.batch * 6 * sizeof(double) * nf);
+    P->off_coef = off; off = al(off + (size_t)d.batch * 6 * sizeof(double) * nf);
+    bool need_w = d.ndim == 2, need_w2 = false;
+    for (const Pass& p : P->passes) { if (p.out_kind == B_W2) need_w2 = true; if (p.out_kind == B_W) need_w = true; }
+    P->off_w = off; if (need_w) off = al(off + (size_t)G * slab_w);
+    P->off_w2 = off; if (need_w2) off = al(off + (size_t)G * d.ny * d.nx * P->csize);
+    P->off_f0 = off; if (nf == 2) off = al(off + (size_t)G * slab_w);
+    P->ws_bytes = off;
+}
+
+static xrfthip_plan::ProfRec* prof_begin(const xrfthip_plan* P, const std::string& label, hipStream_t st) {
+    if (!P->prof || P->prof_recs.size() + 1 >= P->prof_recs.capacity()) return nullptr;
+    xrfthip_plan* M = const_cast<xrfthip_plan*>(P);
+    xrfthip_plan::ProfRec r;
+    r.label = label;
+    if (hipEventCreate(&r.a) != hipSuccess || hipEventCreate(&r.b) != hipSuccess) return nullptr;
+    (void)hipEventRecord(r.a, st);
+    M->prof_recs.push_back(r);
+    return &M->prof_recs.back();
+}
+static void prof_end(xrfthip_plan::ProfRec* r, hipStream_t st) {
+    if (r) (void)hipEventRecord(r->b, st);
+}
+
+template <typename T>
+static int run_moments(const xrfthip_plan* P, const void* in, long long g0, long long gc, double* acc, double* coef, hipStream_t st) {
+    const xrfthip_desc& d = P->d;
+    const long long total = d.ny * d.nx;
+    long long chunks = std::max<long long>(1, std::min<long long>(1024, total / (256 * 64)));
+    const dim3 grid((unsigned)chunks, (unsigned)gc), block(256);
+    const size_t esz = P->cplx_in ? P->csize : P->rsize;
+    const void* src = (const char*)in + (size_t)g0 * total * esz;
+    const size_t lds = 6 * 256 * sizeof(double);
+    xrfthip_plan::ProfRec* rec = prof_begin(P, "moments", st);
+    if (P->cplx_in) { auto k = &slab_moments_kernel<T, true>; XRFT_LAUNCH(k, grid, block, lds, st, src, (long long)d.ny, (long long)d.nx, total, (long long)d.nx, acc + g0 * 6); }
+    else { auto k = &slab_moments_kernel<T, false>; XRFT_LAUNCH(k, grid, block, lds, st, src, (long long)d.ny, (long long)d.nx, total, (long long)d.nx, acc + g0 * 6); }
+    prof_end(rec, st);
+    rec = prof_begin(P, "finalize_coef", st);
+    auto kf = &finalize_coef_kernel;
+    XRFT_LAUNCH(kf, dim3((unsigned)((gc + 63) / 64)), dim3(64), 0, st, (const double*)(acc + g0 * 6), coef + g0 * 6, gc, (long long)d.ny, (long long)d.nx, (int)d.detrend);
+    prof_end(rec, st);
+    HIP_TRY(hipGetLastError());
+    return XRFTHIP_OK;
+}
+
+template <typename T>
+static int run_pipeline(const xrfthip_plan* P, const std::vector<Pass>& passes, const void* in, void* out, double* iso,
+                        char* ws, const double* coef, long long g0, long long gc, hipStream_t st) {
+    const xrfthip_desc& d = P->d;
+    const size_t in_esz = P->cplx_in ? P->csize : P->rsize;
+    for (const Pass& p0 : passes) {
+        Pass p = p0;
+        p.g.n_outer = p.outer_per_slab * gc;
+        p.g.n_tiles = p.g.tile_axis == 0 ? (p.g.n_outer + p.g.T - 1) / p.g.T : p.g.n_outer * p.g.tiles_per_outer;
+        auto buf = [&](int kind) -> void* {
+            switch (kind) {
+                case B_W: return ws + P->off_w;
+                case B_W2: return ws + P->off_w2;
+                case B_F0: return ws + P->off_f0;
+                default: return nullptr;
+            }
+        };
+        if (p.first) {
+            p.pr.in = (const char*)in + (size_t)g0 * d.ny * d.nx * in_esz;
+            p.pr.win_y = P->win[0].p;
+            p.pr.win_x = P->win[1].p;
+            p.pr.coef = coef ? coef + g0 * 6 : nullptr;
+            if (!coef) p.pr.detrend = 0;
+        } else {
+            p.g.in = buf(p.in_kind);
+        }
+        if (p.final_) {
+            if (p.out_kind == B_F0) {
+                p.ep.out = buf(B_F0);
+                p.ep.iso = nullptr;
+            } else {
+                const size_t out_esz = d.out_mode == XRFTHIP_OUT_POWER ? P->rsize : P->csize;
+                p.ep.out = out ? (char*)out + (size_t)g0 * d.ny * P->nx_out * out_esz : nullptr;
+                p.ep.ph_y = P->phase[0].p;
+                p.ep.ph_x = P->phase[1].p;
+                p.ep.other = d.out_mode == XRFTHIP_OUT_CROSS ? buf(B_F0) : nullptr;
+                if (d.flags & XRFTHIP_ISO) {
+                    p.ep.binmap = (const int*)P->binmap.p;
+                    p.ep.nbins = P->nbins;
+                    p.ep.iso = iso + (size_t)g0 * P->nbins * (d.out_mode == XRFTHIP_OUT_CROSS ? 2 : 1);
+                }
+            }
+        } else {
+            p.g.out = buf(p.out_kind);
+        }
+        if (p.g.n_tiles <= 0) continue;
+        const int grid = (int)std::min<long long>(p.g.n_tiles, env_ll("XRFTHIP_MAX_GRID", 8 * kCUs * 4));
+        xrfthip_plan::ProfRec* rec = prof_begin(P, p.label, st);
+        launch_tile<T>(p, grid, st);
+        prof_end(rec, st);
+        HIP_TRY(hipGetLastError());
+    }
+    return XRFTHIP_OK;
+}
+
+// =====================================================================================================
+// C ABI
+// =====================================================================================================
+extern "C" {
+
+int xrfthip_version(void) { return XRFTHIP_VERSION; }
+
+const char* xrfthip_strerror(int status) {
+    switch (status) {
+        case XRFTHIP_OK: return "ok";
+        case XRFTHIP_BAD_ARG: return "bad argument";
+        case XRFTHIP_UNSUPPORTED_LENGTH: return "unsupported transform length (prime factor > 128 or does not fit LDS)";
+        case XRFTHIP_WORKSPACE_TOO_SMALL: return "workspace too small";
+        case XRFTHIP_HIP_ERROR: return "HIP runtime error (see xrfthip_last_hip_error)";
+        case XRFTHIP_ALLOC_FAILED: return "device allocation failed";
+        case XRFTHIP_MISSING_TABLE: return "a required table (window / phase / bin map) was not set";
+        default: return "unknown status";
+    }
+}
+
+int xrfthip_last_hip_error(void) { return g_last_hip_error; }
+
+int xrfthip_plan_create(xrfthip_plan** plan, const xrfthip_desc* desc) {
+    if (!plan || !desc || desc->struct_size != sizeof(xrfthip_desc)) return XRFTHIP_BAD_ARG;
+    const xrfthip_desc& d = *desc;
+    if (d.ndim != 1 && d.ndim != 2) return XRFTHIP_BAD_ARG;
+    if (d.batch < 0 || d.nx < 1 || d.ny < 1 || (d.ndim == 1 && d.ny != 1)) return XRFTHIP_BAD_ARG;
+    if (d.nx > (1LL << 30) || d.ny > (1LL << 30)) return XRFTHIP_BAD_ARG;
+    if (d.dtype < XRFTHIP_F32 || d.dtype > XRFTHIP_C128) return XRFTHIP_BAD_ARG;
+    if (d.out_mode < XRFTHIP_OUT_COMPLEX || d.out_mode > XRFTHIP_OUT_CROSS) return XRFTHIP_BAD_ARG;
+    if (d.detrend < XRFTHIP_DETREND_NONE || d.detrend > XRFTHIP_DETREND_LINEAR) return XRFTHIP_BAD_ARG;
+    const bool cplx_in = d.dtype >= XRFTHIP_C64;
+    if ((d.flags & XRFTHIP_HALF_X) && cplx_in) return XRFTHIP_BAD_ARG;
+    if ((d.flags & XRFTHIP_HALF_X) && (d.flags & (XRFTHIP_SHIFT_X | XRFTHIP_SHIFT_Y))) return XRFTHIP_BAD_ARG;  // xrft.py:403
+    if ((d.flags & XRFTHIP_REALDIM_X2) && (!(d.flags & XRFTHIP_HALF_X) || d.out_mode == XRFTHIP_OUT_COMPLEX)) return XRFTHIP_BAD_ARG;
+    if ((d.flags & XRFTHIP_ISO) && (d.ndim != 2 || d.out_mode == XRFTHIP_OUT_COMPLEX)) return XRFTHIP_BAD_ARG;
+    if ((d.flags & XRFTHIP_NO_SPECTRUM_OUT) && !(d.flags & XRFTHIP_ISO)) return XRFTHIP_BAD_ARG;
+    if (d.ndim == 1 && (d.flags & (XRFTHIP_SHIFT_Y | XRFTHIP_ISHIFT_Y | XRFTHIP_FLIP_Y))) return XRFTHIP_BAD_ARG;
+
+    xrfthip_plan* P = new (std::nothrow) xrfthip_plan();
+    if (!P) return XRFTHIP_ALLOC_FAILED;
+    P->d = d;
+    P->cplx_in = cplx_in;
+    P->dbl = d.dtype == XRFTHIP_F64 || d.dtype == XRFTHIP_C128;
+    P->rsize = P->dbl ? 8 : 4;
+    P->csize = 2 * P->rsize;
+    P->nxh = cplx_in ? d.nx : d.nx / 2 + 1;
+    P->nx_out = (d.flags & XRFTHIP_HALF_X) ? d.nx / 2 + 1 : d.nx;
+    // width of the intermediate: the half spectrum for real input, unless the row does not fit one LDS tile
+    // (four-step along x computes every kx) -- decided inside build_x through P->width.
+    P->width = P->nxh;
+    if (!cplx_in) {
+        const long long n_try = (d.nx % 2 == 0 && d.nx >= 2) ? d.nx / 2 : d.nx;
+        TileChoice c = choose_tile(n_try, P->csize, false, 1LL << 40, 0);
+        if (c.T == 0 || n_try >= env_ll("XRFTHIP_X_FOURSTEP_MIN", 1LL << 40)) P->width = d.nx;
+    }
+    P->mirror = !cplx_in && !(d.flags & XRFTHIP_HALF_X) && P->width == d.nx / 2 + 1 && d.nx > 1;
+    set_kernel_attrs_once();
+    // nbins must be known before tiles are sized (the LDS histogram shares the tile's allocation): ISO plans are
+    // (re)built in xrfthip_plan_set_binmap.  Build now for everything else.
+    int rc = XRFTHIP_OK;
+    if (!(d.flags & XRFTHIP_ISO)) rc = P->dbl ? build_plan_t<double>(*P) : build_plan_t<float>(*P);
+    if (rc) { delete P; return rc; }
+    *plan = P;
+    return XRFTHIP_OK;
+}
+
+int xrfthip_plan_destroy(xrfthip_plan* plan) {
+    delete plan;
+    return XRFTHIP_OK;
+}
+
+int xrfthip_plan_set_window(xrfthip_plan* plan, int axis, const double* h_window, int64_t n) {
+    if (!plan || axis < 0 || axis > 1) return XRFTHIP_BAD_ARG;
+    if (h_window && n != (axis == 0 ? plan->d.ny : plan->d.nx)) return XRFTHIP_BAD_ARG;
+    return upload_real_table(plan, plan->win[axis], h_window, n, 0);
+}
+
+int xrfthip_plan_set_phase(xrfthip_plan* plan, int axis, const double* h_phase, int64_t n) {
+    if (!plan || axis < 0 || axis > 1) return XRFTHIP_BAD_ARG;
+    if (h_phase && n != (axis == 0 ? plan->d.ny : plan->d.nx)) return XRFTHIP_BAD_ARG;
+    return upload_real_table(plan, plan->phase[axis], h_phase, n, 1);
+}
+
+int xrfthip_plan_set_binmap(xrfthip_plan* plan, const int32_t* h_binmap, int64_t ny, int64_t nx_out, int32_t nbins) {
+    if (!plan || !h_binmap || !(plan->d.flags & XRFTHIP_ISO)) return XRFTHIP_BAD_ARG;
+    if (ny != plan->d.ny || nx_out != plan->nx_out || nbins < 1 || nbins > 4096) return XRFTHIP_BAD_ARG;
+    int rc = plan->binmap.upload(h_binmap, (size_t)ny * nx_out * sizeof(int32_t));
+    if (rc) return rc;
+    plan->nbins = nbins;
+    plan->passes.clear();
+    plan->passes_f0.clear();
+    return plan->dbl ? build_plan_t<double>(*plan) : build_plan_t<float>(*plan);
+}
+
+int xrfthip_plan_set_profiling(xrfthip_plan* plan, int enable) {
+    if (!plan) return XRFTHIP_BAD_ARG;
+    plan->prof_clear();
+    plan->prof_recs.reserve(1 << 16);  // prof_begin hands out pointers into this vector
+    plan->prof = enable != 0;
+    return XRFTHIP_OK;
+}
+
+int xrfthip_plan_profile_read(xrfthip_plan* plan, char* buf, size_t buflen) {
+    if (!plan || !buf || !buflen) return XRFTHIP_BAD_ARG;
+    std::vector<std::string> order;
+    std::map<std::string, std::pair<long long, double>> agg;
+    for (auto& r : plan->prof_recs) {
+        HIP_TRY(hipEventSynchronize(r.b));
+        float ms = 0.f;
+        HIP_TRY(hipEventElapsedTime(&ms, r.a, r.b));
+        if (!agg.count(r.label)) order.push_back(r.label);
+        agg[r.label].first += 1;
+        agg[r.label].second += ms;
+    }
+    std::string s;
+    for (auto& l : order) appendf(s, "%s %lld %.6f\n", l.c_str(), agg[l].first, agg[l].second);
+    const size_t n = std::min(buflen - 1, s.size());
+    memcpy(buf, s.data(), n);
+    buf[n] = 0;
+    return (int)n;
+}
+
+size_t xrfthip_workspace_bytes(const xrfthip_plan* plan) {
+    if (!plan) return 0;
+    layout_workspace(const_cast<xrfthip_plan*>(plan));
+    return plan->ws_bytes;
+}
+
+int xrfthip_plan_describe(const xrfthip_plan* plan, char* buf, size_t buflen) {
+    if (!plan || !buf || !buflen) return XRFTHIP_BAD_ARG;
+    layout_workspace(const_cast<xrfthip_plan*>(plan));
+    std::string s;
+    const xrfthip_desc& d = plan->d;
+    appendf(s, "xrfthip plan: ndim=%d batch=%lld ny=%lld nx=%lld dtype=%d mode=%d detrend=%d flags=0x%x width=%lld nx_out=%lld mirror=%d group=%d ws=%zuB\n",
+            d.ndim, (long long)d.batch, (long long)d.ny, (long long)d.nx, d.dtype, d.out_mode, d.detrend, d.flags,
+            plan->width, plan->nx_out, (int)plan->mirror, plan->G, plan->ws_bytes);
+    describe_passes(s, plan->passes_f0, "f0");
+    describe_passes(s, plan->passes, "main");
+    const size_t n = std::min(buflen - 1, s.size());
+    memcpy(buf, s.data(), n);
+    buf[n] = 0;
+    return (int)n;
+}
+
+int xrfthip_exec(const xrfthip_plan* plan, const void* d_in0, const void* d_in1, void* d_out, void* d_iso,
+                 void* d_workspace, size_t ws_bytes, void* stream) {
+    if (!plan || !d_in0) return XRFTHIP_BAD_ARG;
+    const xrfthip_plan* P = plan;
+    const xrfthip_desc& d = P->d;
+    const bool cross = d.out_mode == XRFTHIP_OUT_CROSS;
+    const bool iso = (d.flags & XRFTHIP_ISO) != 0;
+    if (cross && !d_in1) return XRFTHIP_BAD_ARG;
+    if (!d_out && !(d.flags & XRFTHIP_NO_SPECTRUM_OUT)) return XRFTHIP_BAD_ARG;
+    if (iso && (!d_iso || !P->binmap.p)) return d_iso ? XRFTHIP_MISSING_TABLE : XRFTHIP_BAD_ARG;
+    if (P->passes.empty()) return XRFTHIP_MISSING_TABLE;
+    layout_workspace(const_cast<xrfthip_plan*>(P));
+    if (ws_bytes < P->ws_bytes || (!d_workspace && P->ws_bytes)) return XRFTHIP_WORKSPACE_TOO_SMALL;
+    if (d.batch == 0) return XRFTHIP_OK;
+    hipStream_t st = (hipStream_t)stream;
+    char* ws = (char*)d_workspace;
+    void* out = (d.flags & XRFTHIP_NO_SPECTRUM_OUT) ? nullptr : d_out;
+    const bool det = d.detrend != XRFTHIP_DETREND_NONE;
+    double* acc = (double*)(ws + P->off_acc);
+    double* coef = (double*)(ws + P->off_coef);
+    if (det) HIP_TRY(hipMemsetAsync(acc, 0, (size_t)d.batch * 6 * sizeof(double) * (cross ? 2 : 1), st));
+    if (iso) HIP_TRY(hipMemsetAsync(d_iso, 0, (size_t)d.batch * P->nbins * (cross ? 16 : 8), st));
+    for (long long g0 = 0; g0 < d.batch; g0 += P->G) {
+        const long long gc = std::min<long long>(P->G, d.batch - g0);
+        int rc;
+        if (cross) {
+            if (det) {
+                rc = P->dbl ? run_moments<double>(P, d_in0, g0, gc, acc, coef, st) : run_moments<float>(P, d_in0, g0, gc, acc, coef, st);
+                if (rc) return rc;
+            }
+            rc = P->dbl ? run_pipeline<double>(P, P->passes_f0, d_in0, nullptr, nullptr, ws, det ? coef : nullptr, g0, gc, st)
+                        : run_pipeline<float>(P, P->passes_f0, d_in0, nullptr, nullptr, ws, det ? coef : nullptr, g0, gc, st);
+            if (rc) return rc;
+        }
+        const void* in_main = cross ? d_in1 : d_in0;
+        double* acc_m = cross ? acc + d.batch * 6 : acc;
+        double* coef_m = cross ? coef + d.batch * 6 : coef;
+        if (det) {
+            rc = P->dbl ? run_moments<double>(P, in_main, g0, gc, acc_m, coef_m, st) : run_moments<float>(P, in_main, g0, gc, acc_m, coef_m, st);
+            if (rc) return rc;
+        }
+        rc = P->dbl ? run_pipeline<double>(P, P->passes, in_main, out, (double*)d_iso, ws, det ? coef_m : nullptr, g0, gc, st)
+                    : run_pipeline<float>(P, P->passes, in_main, out, (double*)d_iso, ws, det ? coef_m : nullptr, g0, gc, st);
+        if (rc) return rc;
+    }
+    return XRFTHIP_OK;
+}
+
+size_t xrfthip_detrend_workspace_bytes(int64_t batch) { return ((size_t)std::max<int64_t>(batch, 1) * 12 * sizeof(double) + 255) & ~(size_t)255; }
+
+int xrfthip_detrend(int32_t dtype, int32_t ndim, int64_t batch, int64_t ny, int64_t nx, int32_t detrend_type,
+                    const void* d_in, void* d_out, void* d_workspace, size_t ws_bytes, void* stream) {
+    if (!d_in || !d_out || dtype < XRFTHIP_F32 || dtype > XRFTHIP_C128 || batch < 0 || ny < 1 || nx < 1) return XRFTHIP_BAD_ARG;
+    if ((ndim != 1 && ndim != 2) || (ndim == 1 && ny != 1)) return XRFTHIP_BAD_ARG;
+    if (detrend_type != XRFTHIP_DETREND_CONSTANT && detrend_type != XRFTHIP_DETREND_LINEAR) return XRFTHIP_BAD_ARG;
+    if (ws_bytes < xrfthip_detrend_workspace_bytes(batch) || !d_workspace) return XRFTHIP_WORKSPACE_TOO_SMALL;
+    if (batch == 0) return XRFTHIP_OK;
+    hipStream_t st = (hipStream_t)stream;
+    double* acc = (double*)d_workspace;
+    double* coef = acc + batch * 6;
+    HIP_TRY(hipMemsetAsync(acc, 0, (size_t)batch * 6 * sizeof(double), st));
+    const bool dbl = dtype == XRFTHIP_F64 || dtype == XRFTHIP_C128, cplx = dtype >= XRFTHIP_C64;
+    const long long total = ny * nx;
+    const long long chunks = std::max<long long>(1, std::min<long long>(1024, total / (256 * 64)));
+    const size_t esz = (dbl ? 8 : 4) * (cplx ? 2 : 1);
+    for (long long b0 = 0; b0 < batch; b0 += 32768) {  // grid.y limit
+        const long long bc = std::min<long long>(32768, batch - b0);
+        const dim3 grid((unsigned)chunks, (unsigned)bc), block(256);
+        const void* src = (const char*)d_in + (size_t)b0 * total * esz;
+        void* dst = (char*)d_out + (size_t)b0 * total * esz;
+        const size_t lds = 6 * 256 * sizeof(double);
+#define MOM(TT, CC) do { auto k = &slab_moments_kernel<TT, CC>; XRFT_LAUNCH(k, grid, block, lds, st, src, (long long)ny, (long long)nx, total, (long long)nx, acc + b0 * 6); } while (0)
+        if (dbl) { if (cplx) MOM(double, true); else MOM(double, false); } else { if (cplx) MOM(float, true); else MOM(float, false); }
+#undef MOM
+        auto kf = &finalize_coef_kernel;
+        XRFT_LAUNCH(kf, dim3((unsigned)((bc + 63) / 64)), dim3(64), 0, st, (const double*)(acc + b0 * 6), coef + b0 * 6, bc, (long long)ny, (long long)nx, (int)detrend_type);
+        const long long gx = std::max<long long>(1, std::min<long long>(2048, (total + 255) / 256));
+        const dim3 grid2((unsigned)gx, (unsigned)bc);
+#define APP(TT, CC) do { auto k = &detrend_apply_kernel<TT, CC>; XRFT_LAUNCH(k, grid2, block, 0, st, src, dst, (long long)ny, (long long)nx, (const double*)(coef + b0 * 6)); } while (0)
+        if (dbl) { if (cplx) APP(double, true); else APP(double, false); } else { if (cplx) APP(float, true); else APP(float, false); }
+#undef APP
+        HIP_TRY(hipGetLastError());
+    }
+    return XRFTHIP_OK;
+}
+
+int xrfthip_isotropize(int32_t dtype, int64_t batch, int64_t ny, int64_t nx, const void* d_in,
+                       const int32_t* d_binmap, int32_t nbins, void* d_iso, void* stream) {
+    if (!d_in || !d_binmap || !d_iso || dtype < XRFTHIP_F32 || dtype > XRFTHIP_C128 || batch < 0 || ny < 1 || nx < 1) return XRFTHIP_BAD_ARG;
+    if (nbins < 1 || nbins > 4096) return XRFTHIP_BAD_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    const bool dbl = dtype == XRFTHIP_F64 || dtype == XRFTHIP_C128, cplx = dtype >= XRFTHIP_C64;
+    HIP_TRY(hipMemsetAsync(d_iso, 0, (size_t)batch * nbins * (cplx ? 16 : 8), st));
+    if (batch == 0) return XRFTHIP_OK;
+    const long long total = ny * nx;
+    const long long chunks = std::max<long long>(1, std::min<long long>(512, total / (256 * 16)));
+    const size_t esz = (dbl ? 8 : 4) * (cplx ? 2 : 1);
+    const size_t lds = (size_t)nbins * (cplx ? 16 : 8);
+    for (long long b0 = 0; b0 < batch; b0 += 32768) {
+        const long long bc = std::min<long long>(32768, batch - b0);
+        const dim3 grid((unsigned)chunks, (unsigned)bc), block(256);
+        const void* src = (const char*)d_in + (size_t)b0 * total * esz;
+        double* dst = (double*)d_iso + (size_t)b0 * nbins * (cplx ? 2 : 1);
+#define ISO_(TT, CC) do { auto k = &radial_binsum_kernel<TT, CC>; XRFT_LAUNCH(k, grid, block, lds, st, src, (const int*)d_binmap, total, (int)nbins, dst); } while (0)
+        if (dbl) { if (cplx) ISO_(double, true); else ISO_(double, false); } else { if (cplx) ISO_(float, true); else ISO_(float, false); }
+#undef ISO_
+        HIP_TRY(hipGetLastError());
+    }
+    return XRFTHIP_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,149 @@
+"""Thin object wrapper over the C ABI: one ``SpectralPlan`` = one ``xrfthip_plan`` + its workspace.
+
+torch is used only as the owner of device memory and the provider of the current HIP stream; every
+arithmetic step runs inside libxrft_hip.so.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+
+_DTYPES = {torch.float32: _lib.F32, torch.float64: _lib.F64, torch.complex64: _lib.C64, torch.complex128: _lib.C128}
+_REAL_OF = {torch.float32: torch.float32, torch.float64: torch.float64, torch.complex64: torch.float32,
+            torch.complex128: torch.float64}
+_CPLX_OF = {torch.float32: torch.complex64, torch.float64: torch.complex128, torch.complex64: torch.complex64,
+            torch.complex128: torch.complex128}
+
+
+def _stream_handle(t):
+    if t.is_cuda:
+        return C.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
+    return C.c_void_p(0)
+
+
+def _ptr(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+
+
+class SpectralPlan:
+    """detrend -> window -> (flip, ifftshift) -> FFT over the last ``ndim`` axes -> shift/phase/scale ->
+    complex | power | cross (-> radial bin-sum), in one call on the current stream."""
+
+    def __init__(self, ndim, batch, ny, nx, dtype, out_mode=_lib.OUT_COMPLEX, detrend=_lib.DETREND_NONE, flags=0,
+                 scale=1.0, window_y=None, window_x=None, phase_y=None, phase_x=None, binmap=None, nbins=0,
+                 slabs_per_group=0):
+        self._dll = _lib.load()
+        self._h = C.c_void_p(0)
+        if dtype not in _DTYPES:
+            raise TypeError(f"unsupported dtype {dtype}")
+        self.ndim, self.batch, self.ny, self.nx = int(ndim), int(batch), int(ny), int(nx)
+        self.dtype, self.out_mode, self.flags = dtype, int(out_mode), int(flags)
+        self.nx_out = self.nx // 2 + 1 if (flags & _lib.HALF_X) else self.nx
+        self.nbins = int(nbins)
+        d = _lib.Desc(C.sizeof(_lib.Desc), self.ndim, self.batch, self.ny, self.nx, _DTYPES[dtype], self.out_mode,
+                      int(detrend), self.flags, float(scale), int(slabs_per_group), 0)
+        _lib.check(self._dll.xrfthip_plan_create(C.byref(self._h), C.byref(d)))
+        for axis, w in ((0, window_y), (1, window_x)):
+            if w is not None:
+                w = np.ascontiguousarray(w, dtype=np.float64)
+                _lib.check(self._dll.xrfthip_plan_set_window(self._h, axis, w.ctypes.data_as(C.c_void_p), w.size))
+        for axis, p in ((0, phase_y), (1, phase_x)):
+            if p is not None:
+                p = np.ascontiguousarray(p, dtype=np.complex128)
+                _lib.check(self._dll.xrfthip_plan_set_phase(self._h, axis, p.ctypes.data_as(C.c_void_p), p.size))
+        if flags & _lib.ISO:
+            bm = np.ascontiguousarray(binmap, dtype=np.int32)
+            if bm.shape != (self.ny, self.nx_out):
+                raise ValueError(f"bin map shape {bm.shape} != {(self.ny, self.nx_out)}")
+            _lib.check(self._dll.xrfthip_plan_set_binmap(self._h, bm.ctypes.data_as(C.c_void_p), self.ny,
+                                                         self.nx_out, self.nbins))
+        self._ws = None
+
+    def __del__(self):
+        try:
+            if self._h:
+                self._dll.xrfthip_plan_destroy(self._h)
+                self._h = C.c_void_p(0)
+        except Exception:
+            pass
+
+    @property
+    def workspace_bytes(self):
+        return int(self._dll.xrfthip_workspace_bytes(self._h))
+
+    def describe(self):
+        buf = C.create_string_buffer(8192)
+        self._dll.xrfthip_plan_describe(self._h, buf, len(buf))
+        return buf.value.decode()
+
+    def set_profiling(self, enable=True):
+        _lib.check(self._dll.xrfthip_plan_set_profiling(self._h, int(bool(enable))))
+
+    def read_profile(self):
+        """{label: (launches, total_ms)} from HIP events recorded around every launch since set_profiling(True)."""
+        buf = C.create_string_buffer(1 << 16)
+        n = self._dll.xrfthip_plan_profile_read(self._h, buf, len(buf))
+        if n < 0:
+            _lib.check(n)
+        out = {}
+        for line in buf.value.decode().splitlines():
+            label, cnt, ms = line.rsplit(" ", 2)
+            out[label] = (int(cnt), float(ms))
+        return out
+
+    def out_dtype(self):
+        return _REAL_OF[self.dtype] if self.out_mode == _lib.OUT_POWER else _CPLX_OF[self.dtype]
+
+    def execute(self, in0, in1=None, out=None, iso=None):
+        """``in0``/``in1``: contiguous tensors of shape (batch, ny, nx) (any leading shape that flattens to it).
+        Returns (out, iso); either may be None depending on the flags."""
+        dev = in0.device
+        if in0.dtype != self.dtype or not in0.is_contiguous() or in0.numel() != self.batch * self.ny * self.nx:
+            raise ValueError("in0 does not match the plan (dtype / contiguity / size)")
+        if self.out_mode == _lib.OUT_CROSS:
+            if in1 is None or in1.dtype != self.dtype or not in1.is_contiguous() or in1.numel() != in0.numel():
+                raise ValueError("in1 does not match the plan")
+        want_out = not (self.flags & _lib.NO_SPECTRUM_OUT)
+        if want_out and out is None:
+            out = torch.empty((self.batch, self.ny, self.nx_out), dtype=self.out_dtype(), device=dev)
+        if self.flags & _lib.ISO and iso is None:
+            iso = torch.empty((self.batch, self.nbins), device=dev,
+                              dtype=torch.complex128 if self.out_mode == _lib.OUT_CROSS else torch.float64)
+        nws = self.workspace_bytes
+        if self._ws is None or self._ws.numel() < nws or self._ws.device != dev:
+            self._ws = torch.empty(max(nws, 256), dtype=torch.uint8, device=dev)
+        _lib.check(self._dll.xrfthip_exec(self._h, _ptr(in0), _ptr(in1), _ptr(out if want_out else None), _ptr(iso),
+                                          _ptr(self._ws), self._ws.numel(), _stream_handle(in0)))
+        return (out if want_out else None), iso
+
+
+def detrend(x, ndim, kind):
+    """Stand-alone detrend over the last ``ndim`` (1|2) axes of a contiguous tensor (xrft/detrend.py:11-97)."""
+    dll = _lib.load()
+    if x.dtype not in _DTYPES or not x.is_contiguous():
+        raise ValueError("detrend needs a contiguous float/complex tensor")
+    nx = x.shape[-1]
+    ny = x.shape[-2] if ndim == 2 else 1
+    batch = x.numel() // max(ny * nx, 1)
+    out = torch.empty_like(x)
+    nws = int(dll.xrfthip_detrend_workspace_bytes(batch))
+    ws = torch.empty(nws, dtype=torch.uint8, device=x.device)
+    _lib.check(dll.xrfthip_detrend(_DTYPES[x.dtype], ndim, batch, ny, nx, kind, _ptr(x), _ptr(out), _ptr(ws), nws,
+                                   _stream_handle(x)))
+    return out
+
+
+def isotropize(x, binmap_dev, nbins):
+    """Radial bin-sum of the last two axes of ``x`` with a device int32 bin map (xrft/xrft.py:993-1004)."""
+    dll = _lib.load()
+    ny, nx = x.shape[-2], x.shape[-1]
+    batch = x.numel() // max(ny * nx, 1)
+    cplx = x.is_complex()
+    iso = torch.empty((batch, nbins), dtype=torch.complex128 if cplx else torch.float64, device=x.device)
+    _lib.check(dll.xrfthip_isotropize(_DTYPES[x.dtype], batch, ny, nx, _ptr(x), _ptr(binmap_dev), nbins, _ptr(iso),
+                                      _stream_handle(x)))
+    return iso

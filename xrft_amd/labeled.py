@@ -1,0 +1,259 @@
+"""A minimal labelled array: the subset of ``xarray.DataArray`` the xrft API surface needs.
+
+xarray is not installed in the build image nor on the GPU box, so the label logic the reference gets from
+xarray (dimension names, 1-D coordinate vectors with attrs, kept / dropped coordinates) lives in this small
+self-contained class.  When xarray *is* installed, ``xrft_amd`` functions also accept ``xarray.DataArray``
+and hand the same type back (see ``from_any`` / ``to_like``).
+
+``.data`` is whatever holds the samples (numpy array or torch tensor, possibly on the GPU);
+``.values`` always returns a host numpy array.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+try:  # torch is the device-memory carrier; the container itself also works with plain numpy
+    import torch
+except Exception:  # pragma: no cover
+    torch = None
+
+
+class Coordinate:
+    """A named coordinate variable: ``dims`` (tuple of dim names), ``values`` (numpy), ``attrs``."""
+
+    def __init__(self, dims, values, attrs=None, name=None):
+        self.dims = (dims,) if isinstance(dims, str) else tuple(dims)
+        self.values = np.asarray(values)
+        self.attrs = dict(attrs or {})
+        self.name = name
+
+    # numpy interop so that ``npt.assert_allclose(ft["freq_x"], expected)`` works as with xarray
+    def __array__(self, dtype=None, copy=None):
+        return np.asarray(self.values, dtype=dtype)
+
+    def __len__(self):
+        return len(self.values)
+
+    def __getitem__(self, i):
+        return self.values[i]
+
+    def __getattr__(self, item):  # ``ft["freq_x"].spacing`` like xarray attribute access
+        attrs = self.__dict__.get("attrs", {})
+        if item in attrs:
+            return attrs[item]
+        raise AttributeError(item)
+
+    @property
+    def data(self):
+        return self.values
+
+    @property
+    def size(self):
+        return self.values.size
+
+    def __repr__(self):
+        return f"Coordinate({self.name!r}, dims={self.dims}, n={self.values.shape}, attrs={self.attrs})"
+
+
+def _is_torch(x):
+    return torch is not None and isinstance(x, torch.Tensor)
+
+
+class DataArray:
+    def __init__(self, data, dims=None, coords=None, name=None, attrs=None):
+        if not _is_torch(data):
+            data = np.asarray(data)
+        self.data = data
+        nd = data.ndim
+        if dims is None:
+            dims = tuple(f"dim_{i}" for i in range(nd))
+        self.dims = (dims,) if isinstance(dims, str) else tuple(dims)
+        if len(self.dims) != nd:
+            raise ValueError(f"dims {self.dims} do not match data of rank {nd}")
+        self.name = name
+        self.attrs = dict(attrs or {})
+        self.coords = {}
+        if coords is not None:
+            if isinstance(coords, dict):
+                items = coords.items()
+            else:  # xarray's positional form: coords=[x, y] aligned with dims
+                items = zip(self.dims, coords)
+            for k, v in items:
+                self.coords[k] = self._as_coord(k, v)
+        for k, c in self.coords.items():
+            for d, n in zip(c.dims, c.values.shape):
+                if d not in self.dims:
+                    raise ValueError(f"coordinate {k} has dimension {d} which is not a dimension of the array")
+                if self.shape[self.dims.index(d)] != n:
+                    raise ValueError(f"coordinate {k} length {n} conflicts with dimension {d}")
+
+    @staticmethod
+    def _as_coord(name, v):
+        if isinstance(v, Coordinate):
+            return Coordinate(v.dims, v.values, v.attrs, name)
+        if isinstance(v, tuple) and len(v) in (2, 3) and (
+                isinstance(v[0], str) or (isinstance(v[0], (tuple, list)) and all(isinstance(x, str) for x in v[0]))):
+            return Coordinate(v[0], np.asarray(v[1]), v[2] if len(v) == 3 else None, name)
+        a = np.asarray(v)
+        if a.ndim == 0:
+            return Coordinate((), a, None, name)
+        return Coordinate((name,), a, None, name)
+
+    # ---------------------------------------------------------------- basic protocol
+    @property
+    def shape(self):
+        return tuple(self.data.shape)
+
+    @property
+    def ndim(self):
+        return len(self.dims)
+
+    @property
+    def sizes(self):
+        return dict(zip(self.dims, self.shape))
+
+    @property
+    def dtype(self):
+        return self.data.dtype
+
+    @property
+    def values(self):
+        d = self.data
+        if _is_torch(d):
+            d = d.detach()
+            if d.is_conj():
+                d = d.resolve_conj()
+            return d.cpu().numpy()
+        return d
+
+    def __array__(self, dtype=None, copy=None):
+        return np.asarray(self.values, dtype=dtype)
+
+    def __len__(self):
+        return self.shape[0]
+
+    def get_axis_num(self, dim):
+        if isinstance(dim, (list, tuple)):
+            return [self.get_axis_num(d) for d in dim]
+        if dim not in self.dims:
+            raise ValueError(f"{dim!r} not found in array dimensions {self.dims}")
+        return self.dims.index(dim)
+
+    def __getitem__(self, key):
+        """``da["x"]``: the coordinate of a dimension (``arange`` if it has none), or a named coordinate."""
+        if isinstance(key, str):
+            if key in self.coords:
+                return self.coords[key]
+            if key in self.dims:
+                return Coordinate((key,), np.arange(self.sizes[key]), None, key)
+            raise KeyError(key)
+        raise TypeError("only coordinate lookup by name is supported; use .isel for positional selection")
+
+    def __contains__(self, key):
+        return key in self.coords or key in self.dims
+
+    def __getattr__(self, item):  # ``da.x`` / ``ps.freq_x`` shorthand
+        d = self.__dict__
+        if "coords" in d and (item in d["coords"] or item in d.get("dims", ())):
+            return self[item]
+        raise AttributeError(item)
+
+    # ---------------------------------------------------------------- the few transformations the API needs
+    def _new(self, data, dims=None, coords=None, name=None):
+        return DataArray(data, self.dims if dims is None else dims, self.coords if coords is None else coords,
+                         self.name if name is None else name, self.attrs)
+
+    def transpose(self, *dims):
+        if not dims:
+            dims = self.dims[::-1]
+        perm = [self.get_axis_num(d) for d in dims]
+        data = self.data.permute(perm) if _is_torch(self.data) else self.data.transpose(perm)
+        return self._new(data, dims)
+
+    def isel(self, **idx):
+        data = self.data
+        dims = list(self.dims)
+        coords = dict(self.coords)
+        for d, i in idx.items():
+            ax = dims.index(d)
+            sl = [slice(None)] * len(dims)
+            sl[ax] = i
+            data = data[tuple(sl)]
+            scalar = not isinstance(i, slice)
+            new = {}
+            for k, c in coords.items():
+                if d in c.dims:
+                    cax = c.dims.index(d)
+                    csl = [slice(None)] * len(c.dims)
+                    csl[cax] = i
+                    v = c.values[tuple(csl)]
+                    cd = tuple(x for x in c.dims if x != d) if scalar else c.dims
+                    new[k] = Coordinate(cd, v, c.attrs, k)
+                else:
+                    new[k] = c
+            coords = new
+            if scalar:
+                dims.pop(ax)
+        return DataArray(data, dims, coords, self.name, self.attrs)
+
+    def mean(self, dim=None):
+        """Mean over ``dim`` (name or list of names; all dims if None) -- host-side convenience for tests/examples."""
+        v = self.values
+        if dim is None:
+            return DataArray(v.mean(), (), None, self.name, self.attrs)
+        dims = [dim] if isinstance(dim, str) else list(dim)
+        ax = tuple(self.get_axis_num(d) for d in dims)
+        keep = [d for d in self.dims if d not in dims]
+        coords = {k: c for k, c in self.coords.items() if not (set(c.dims) & set(dims))}
+        return DataArray(v.mean(axis=ax), keep, coords, self.name, self.attrs)
+
+    def sum(self, dim=None):
+        v = self.values
+        if dim is None:
+            return DataArray(v.sum(), (), None, self.name, self.attrs)
+        dims = [dim] if isinstance(dim, str) else list(dim)
+        ax = tuple(self.get_axis_num(d) for d in dims)
+        keep = [d for d in self.dims if d not in dims]
+        coords = {k: c for k, c in self.coords.items() if not (set(c.dims) & set(dims))}
+        return DataArray(v.sum(axis=ax), keep, coords, self.name, self.attrs)
+
+    def copy(self):
+        data = self.data.clone() if _is_torch(self.data) else self.data.copy()
+        return self._new(data, coords={k: Coordinate(c.dims, c.values.copy(), c.attrs, k) for k, c in self.coords.items()})
+
+    def __repr__(self):
+        kind = "torch:" + str(self.data.device) if _is_torch(self.data) else "numpy"
+        return f"<xrft_amd.DataArray {self.name or ''} {self.sizes} dtype={self.dtype} [{kind}] coords={list(self.coords)}>"
+
+    # ---------------------------------------------------------------- xarray interop (only if xarray is importable)
+    def to_xarray(self):
+        import xarray as xr
+
+        coords = {k: (c.dims, c.values, c.attrs) for k, c in self.coords.items()}
+        return xr.DataArray(self.values, dims=self.dims, coords=coords, name=self.name, attrs=self.attrs)
+
+    @classmethod
+    def from_xarray(cls, xda):
+        coords = {k: (tuple(v.dims), np.asarray(v.values), dict(v.attrs)) for k, v in xda.coords.items()}
+        return cls(np.asarray(xda.values), tuple(xda.dims), coords, xda.name, dict(xda.attrs))
+
+
+def is_xarray(obj):
+    t = type(obj)
+    return t.__module__.split(".")[0] == "xarray" and t.__name__ == "DataArray"
+
+
+def from_any(obj):
+    """Accept xrft_amd.DataArray or (if installed) xarray.DataArray."""
+    if isinstance(obj, DataArray):
+        return obj
+    if is_xarray(obj):
+        return DataArray.from_xarray(obj)
+    raise TypeError(f"expected a DataArray, got {type(obj).__name__}")
+
+
+def to_like(result, template):
+    """Return ``result`` as the array type the caller passed in."""
+    if is_xarray(template):
+        return result.to_xarray()
+    return result
