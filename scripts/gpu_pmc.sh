@@ -1,0 +1,22 @@
+#!/bin/bash
+# PMC counter passes for the bench workload (reduced to --nt 8 so every pass is short). Usage: gpu_pmc.sh <tag>
+cd "$GRAFT_REPO_ROOT" || exit 1
+TAG=${1:-r01}
+mkdir -p gpurun_out/pmc_$TAG
+export TMPDIR=/tmp
+cd /tmp
+if [ ! -f "$GRAFT_REPO_ROOT/gpurun_out/counters_list.txt" ]; then rocprofv3 -L > "$GRAFT_REPO_ROOT/gpurun_out/counters_list.txt" 2>&1; fi
+run() {  # name, counters...
+  name=$1; shift
+  timeout 600 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d "$GRAFT_REPO_ROOT/gpurun_out/pmc_$TAG/$name" -o p -- python "$GRAFT_REPO_ROOT/bench.py" --steps 1 --warmup 1 --nt 8 --cpu-slabs 0 --no-profile > "$GRAFT_REPO_ROOT/gpurun_out/pmc_$TAG/$name.log" 2>&1
+  echo "pass $name rc=$?"
+}
+run sq1 SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS
+run sq2 SQ_INSTS_VALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAIT_INST_LDS SQ_ACTIVE_INST_VMEM
+run tcc1 TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum
+run tcc2 TCC_EA0_RDREQ_sum TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum
+run fetch FETCH_SIZE
+run write WRITE_SIZE
+run grbm GRBM_GUI_ACTIVE GRBM_COUNT
+cd "$GRAFT_REPO_ROOT"
+python3 scripts/pmc_summary.py gpurun_out/pmc_$TAG | tee gpurun_out/pmc_$TAG/summary.txt

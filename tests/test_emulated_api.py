@@ -108,3 +108,36 @@ def test_unsupported_length_is_loud():
     da = xa.DataArray(np.zeros((2, 131)), ("t", "x"))  # 131 is a prime > XRFTHIP_MAX_RADIX
     with pytest.raises(xa.XrftHipError):
         xa.fft(da, dim="x")
+
+
+@pytest.mark.parametrize("shift,det,win", [(True, "linear", "hann"), (False, None, None), (False, "constant", "hamming")])
+def test_fast4096_path(shift, det, win):
+    """The specialised (4096, 4096) float32 power-spectrum kernels (fast4096.h), one slab, against numpy in float64."""
+    import scipy.signal as sps
+    import xrft_amd as xa
+
+    n = 4096
+    rng = np.random.default_rng(42)
+    v = rng.standard_normal((1, n, n)).astype(np.float32)
+    v += (0.01 * np.arange(n, dtype=np.float32))[None, :, None] + (-0.02 * np.arange(n, dtype=np.float32) + 3)[None, None, :]
+    c = {"t": np.arange(1), "y": np.arange(n) * 1.0, "x": np.arange(n) * 1.0}
+    ps = xa.power_spectrum(xa.DataArray(v, ("t", "y", "x"), c), dim=["y", "x"], detrend=det, window=win, shift=shift)
+    plan = next(reversed(api._plan_cache.values()))
+    assert "[fast4096]" in plan.describe()
+    x = v[0].astype(np.float64)
+    if det == "constant":
+        x = x - x.mean()
+    elif det == "linear":
+        ii, jj = np.meshgrid(np.arange(n) - (n - 1) / 2, np.arange(n) - (n - 1) / 2, indexing="ij")
+        den = n * n * (n * n - 1) / 12
+        x = x - (x.mean() + (ii * x).sum() / den * ii + (jj * x).sum() / den * jj)
+    if win:
+        w = getattr(sps.windows, win)(n, sym=False)
+        x = x * w[:, None] * w[None, :]
+    F = np.fft.fft2(x)
+    if shift:
+        F = np.fft.fftshift(F)
+    ref = np.abs(F) ** 2 / (n * n)
+    g = ps.values[0].astype(np.float64)
+    assert np.abs(g - ref).max() / ref.max() < 2e-5
+    assert np.abs(g - ref).sum() / ref.sum() < 5e-6

@@ -96,12 +96,12 @@ __global__ void __launch_bounds__(256) detrend_apply_kernel(const void* in, void
         const long long off = b * total + e;
         if (CPLX) {
             C2<T> v = reinterpret_cast<const C2<T>*>(in)[off];
-            v.re -= (T)(c[0] + c[2] * (double)i + c[4] * (double)j);
-            v.im -= (T)(c[1] + c[3] * (double)i + c[5] * (double)j);
+            v.re = (T)((double)v.re - (c[0] + c[2] * (double)i + c[4] * (double)j));
+            v.im = (T)((double)v.im - (c[1] + c[3] * (double)i + c[5] * (double)j));
             reinterpret_cast<C2<T>*>(out)[off] = v;
         } else {
             T v = reinterpret_cast<const T*>(in)[off];
-            v -= (T)(c[0] + c[2] * (double)i + c[4] * (double)j);
+            v = (T)((double)v - (c[0] + c[2] * (double)i + c[4] * (double)j));
             reinterpret_cast<T*>(out)[off] = v;
         }
     }

@@ -1,0 +1,333 @@
+// fast4096.h -- the specialised kernels for BASELINE.json's headline shape: 2-D power spectrum of (nt, 4096, 4096)
+// float32 with detrend + window (xrft.power_spectrum, reference xrft/xrft.py:685-750 -> fft :307-476).
+//
+// Design, from measurements on MI355X (scripts/ubench/*.hip, DESIGN.md "measurements"):
+//   * HBM streams ~6.0 TB/s read / ~5.1 TB/s write and the Infinity Cache adds almost no bandwidth on top, so the
+//     number of passes over a slab is what counts: 2 passes (rows, then columns), never 3.
+//   * scattered FULL 128-byte lines write at streaming speed -> the row pass stores the half spectrum in a tiled
+//     layout W[slab][tile = kx/4][i][kx%4] (4 rows x 4 columns x 8 B = one line per workgroup and tile), which the
+//     column pass then reads as one contiguous 128 KiB block per tile.
+//   * a 4096-point column of complex64 is 32 KiB, so only 4 columns fit one CU's LDS: the column pass writes
+//     16-byte output segments.  With the tile -> workgroup mapping arranged so that the 8 workgroups sharing a
+//     128-byte output line run on the same XCD at the same time, the XCD's L2 merges them (3.0 TB/s measured vs
+//     1.0 TB/s with the naive mapping).
+// Core: a 4096-point complex FFT by 256 threads, 16 points per thread held in registers, three radix-16 passes
+// (decimation in frequency) with two padded, bank-conflict-free LDS exchanges; twiddles W^(u k), k = 1..15, are
+// generated in registers from one table load W^u by a depth-4 product tree (no strided table gathers).
+#pragma once
+#include "aux_kernels.h"
+
+namespace xrft {
+
+typedef C2<float> cf;
+struct alignas(16) F4 { float x, y, z, w; };
+struct __attribute__((aligned(4))) F4u { float x, y, z, w; };  // 16-byte access at 4-byte alignment (mirror segments)
+
+// ------------------------------------------------------------------------------------------------
+// radix-16 butterfly, natural order in and out (4 x 4 with constant twiddles)
+// ------------------------------------------------------------------------------------------------
+template <typename T> __device__ __forceinline__ void dft16(C2<T>* a) {
+    const T c1 = (T)0.92387953251128675613, s1 = (T)0.38268343236508977173, h = (T)0.70710678118654752440;
+    C2<T> t[4][4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {  // stage 1: DFT4 over elements q, q+4, q+8, q+12  -> t[q][m]
+        C2<T> b[4] = {a[q], a[q + 4], a[q + 8], a[q + 12]};
+        dft4(b);
+#pragma unroll
+        for (int m = 0; m < 4; ++m) t[q][m] = b[m];
+    }
+    // twiddle t[q][m] *= W16^(q m)
+    t[1][1] = mk<T>(c1 * t[1][1].re + s1 * t[1][1].im, c1 * t[1][1].im - s1 * t[1][1].re);  // W16^1
+    t[1][2] = mk<T>(h * (t[1][2].re + t[1][2].im), h * (t[1][2].im - t[1][2].re));          // W16^2
+    t[1][3] = mk<T>(s1 * t[1][3].re + c1 * t[1][3].im, s1 * t[1][3].im - c1 * t[1][3].re);  // W16^3
+    t[2][1] = mk<T>(h * (t[2][1].re + t[2][1].im), h * (t[2][1].im - t[2][1].re));          // W16^2
+    t[2][2] = mul_mi(t[2][2]);                                                              // W16^4 = -i
+    t[2][3] = mk<T>(h * (t[2][3].im - t[2][3].re), -h * (t[2][3].re + t[2][3].im));         // W16^6
+    t[3][1] = mk<T>(s1 * t[3][1].re + c1 * t[3][1].im, s1 * t[3][1].im - c1 * t[3][1].re);  // W16^3
+    t[3][2] = mk<T>(h * (t[3][2].im - t[3][2].re), -h * (t[3][2].re + t[3][2].im));         // W16^6
+    t[3][3] = mk<T>(-c1 * t[3][3].re - s1 * t[3][3].im, s1 * t[3][3].re - c1 * t[3][3].im); // W16^9 = -W16^1
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {  // stage 2: DFT4 over q -> X[m + 4 p]
+        C2<T> b[4] = {t[0][m], t[1][m], t[2][m], t[3][m]};
+        dft4(b);
+#pragma unroll
+        for (int p = 0; p < 4; ++p) a[m + 4 * p] = b[p];
+    }
+}
+
+// a[k] *= w1^k for k = 1..15, powers built by a product tree of depth <= 4 (error ~ 4 ulp)
+template <typename T> __device__ __forceinline__ void twiddle16(C2<T>* a, C2<T> w1) {
+    C2<T> w2 = cmul(w1, w1), w3 = cmul(w2, w1), w4 = cmul(w2, w2);
+    C2<T> w5 = cmul(w4, w1), w6 = cmul(w4, w2), w7 = cmul(w4, w3), w8 = cmul(w4, w4);
+    a[1] = cmul(a[1], w1); a[2] = cmul(a[2], w2); a[3] = cmul(a[3], w3); a[4] = cmul(a[4], w4);
+    a[5] = cmul(a[5], w5); a[6] = cmul(a[6], w6); a[7] = cmul(a[7], w7); a[8] = cmul(a[8], w8);
+    a[9] = cmul(a[9], cmul(w8, w1)); a[10] = cmul(a[10], cmul(w8, w2)); a[11] = cmul(a[11], cmul(w8, w3));
+    a[12] = cmul(a[12], cmul(w8, w4)); a[13] = cmul(a[13], cmul(w8, w5)); a[14] = cmul(a[14], cmul(w8, w6));
+    a[15] = cmul(a[15], cmul(w8, w7));
+}
+
+// LDS elements one 4096-point sequence needs (16 blocks of 256 + 16 padding, = 16 x 16 runs of 17)
+#define XRFT_F4096_LDS 4352
+__device__ __forceinline__ int nat4096(int k) { return k + (k >> 4); }  // natural-order slot of frequency k (1 pad per 16)
+
+// 4096-point forward FFT by a 256-thread group.  In: a[q] = x[u + 256 q].  Out: a[k3] = X[k1 + 16 k2 + 256 k3] with
+// k1 = u >> 4, k2 = u & 15.  `lds` = this group's XRFT_F4096_LDS elements; every thread of the workgroup must call it
+// (it contains __syncthreads()); the buffer may be reused by the caller after the trailing barrier.
+__device__ __forceinline__ void fft4096_group(cf* a, int u, cf* lds, const cf* __restrict__ tw) {
+    dft16(a);
+    twiddle16(a, tw[u]);  // W_4096^(u k)
+#pragma unroll
+    for (int k = 0; k < 16; ++k) lds[k * 272 + u] = a[k];
+    __syncthreads();
+    const int k1 = u >> 4, v = u & 15;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) a[q] = lds[k1 * 272 + v + 16 * q];
+    __syncthreads();
+    dft16(a);
+    twiddle16(a, tw[16 * v]);  // W_256^(v k)
+#pragma unroll
+    for (int k = 0; k < 16; ++k) lds[k1 * 272 + k * 17 + v] = a[k];
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < 16; ++q) a[q] = lds[k1 * 272 + v * 17 + q];
+    dft16(a);
+    __syncthreads();
+}
+
+struct Fast4096 {  // parameters shared by the two passes
+    const float* in;         // [slab][4096][4096] float32
+    cf* w;                   // tiled intermediate [slab][513][4096][4]
+    float* pt;               // line-tiled half power spectrum [slab][ky/8 (512)][tile (513)][ky%8][4]
+    float* out;              // [slab][4096][4096] float32 power spectrum
+    const cf* tw;            // W_4096^k
+    const float* win_y;      // nullable
+    const float* win_x;      // nullable
+    const double* coef;      // [slab][6] trend coefficients (nullable)
+    int nslab;
+    int shift_y, shift_x;    // 0 or 2048
+    float scale;
+};
+
+#define XRFT_F4096_TILES 513
+
+// ------------------------------------------------------------------------------------------------
+// row pass: 512 threads = 2 groups; group g transforms rows 4w+2g (real part) and 4w+2g+1 (imaginary part) packed
+// into one complex sequence, splits the two half spectra and the workgroup stores 4 rows x 2049 columns as 513
+// full 128-byte lines of the tiled intermediate.      detrend/window: xrft.py:425-433
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(512) fast4096_rows_kernel(Fast4096 p) {
+    XRFT_DYN_SMEM(smem_raw);
+    cf* lds = reinterpret_cast<cf*>(smem_raw);
+    const int tid = threadIdx.x, g = tid >> 8, u = tid & 255;
+    const int slab = blockIdx.x >> 10, wrow = blockIdx.x & 1023;
+    const int rA = 4 * wrow + 2 * g, rB = rA + 1;
+    cf* mine = lds + g * XRFT_F4096_LDS;
+    const float* __restrict__ srcA = p.in + ((size_t)slab * 4096 + rA) * 4096;
+    const float* __restrict__ srcB = srcA + 4096;
+    // trend evaluated and subtracted in float64: a float32 evaluation of c2*j rounds identically in every row, and
+    // that column-coherent error adds up over 4096 rows into the ky = 0 bins (measured 6e-4 of max vs 4e-5)
+    double tA = 0.0, tB = 0.0, c2 = 0.0;
+    if (p.coef) {
+        const double* c = p.coef + (size_t)slab * 6;
+        tA = c[0] + c[2] * rA;
+        tB = c[0] + c[2] * rB;
+        c2 = c[4];
+    }
+    const float wA = p.win_y ? p.win_y[rA] : 1.f, wB = p.win_y ? p.win_y[rB] : 1.f;
+    cf a[16];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+        const int j = u + 256 * q;
+        float xa = srcA[j], xb = srcB[j];
+        if (p.coef) {
+            const double tr = c2 * (double)j;
+            xa = (float)((double)xa - (tA + tr));
+            xb = (float)((double)xb - (tB + tr));
+        }
+        const float wx = p.win_x ? p.win_x[j] : 1.f;
+        a[q] = mk<float>(xa * (wx * wA), xb * (wx * wB));
+    }
+    fft4096_group(a, u, mine, p.tw);
+    {
+        const int k1 = u >> 4, k2 = u & 15;
+#pragma unroll
+        for (int k3 = 0; k3 < 16; ++k3) mine[nat4096(k1 + 16 * k2 + 256 * k3)] = a[k3];
+    }
+    __syncthreads();
+    // split: Ra[k] = (Z[k] + conj Z[N-k]) / 2, Rb[k] = (Z[k] - conj Z[N-k]) / (2i), k = u + 256 q (q < 8), and k = 2048
+    cf ra[9], rb[9];
+#pragma unroll
+    for (int q = 0; q < 9; ++q) {
+        const int k = u + 256 * q;
+        if (q < 8 || u == 0) {
+            const cf zk = mine[nat4096(k & 4095)];
+            const cf zc = cconj(mine[nat4096((4096 - k) & 4095)]);
+            ra[q] = cscale(zk + zc, 0.5f);
+            rb[q] = cscale(mul_mi(zk - zc), 0.5f);
+        }
+    }
+    __syncthreads();
+    // stage the 4 x 2049 outputs as [tile][row(4)][col(4)], then write full lines
+#pragma unroll
+    for (int q = 0; q < 9; ++q) {
+        const int k = u + 256 * q;
+        if (q < 8 || u == 0) {
+            const int tl = k >> 2, sw = tl & 3;  // row slot XOR (tile & 3): 4 consecutive tiles hit 4 different bank groups
+            lds[tl * 16 + ((2 * g) ^ sw) * 4 + (k & 3)] = ra[q];
+            lds[tl * 16 + ((2 * g + 1) ^ sw) * 4 + (k & 3)] = rb[q];
+        }
+    }
+    if (tid < 12) {  // the 3 padding columns of tile 512 (kx = 2049..2051): keep the intermediate deterministic
+        const int r = tid / 3, c = 1 + tid % 3;
+        lds[512 * 16 + (r ^ 0) * 4 + c] = mk<float>(0.f, 0.f);  // tile 512: swizzle (512 & 3) = 0
+    }
+    __syncthreads();
+    F4* __restrict__ dst = reinterpret_cast<F4*>(p.w + ((size_t)slab * XRFT_F4096_TILES * 4096 + 4 * wrow) * 4);
+    const F4* stg = reinterpret_cast<const F4*>(lds);
+    for (int e = tid; e < XRFT_F4096_TILES * 8; e += 512) {
+        const int tile = e >> 3, part = e & 7;  // part = row * 2 + half
+        dst[(size_t)tile * (4096 * 2) + part] = stg[tile * 8 + ((((part >> 1) ^ (tile & 3)) << 1) | (part & 1))];  // tile stride = 4096*2 F4
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// column pass: 1024 threads = 4 groups, one column of the tile each; persistent over tiles; |F|^2 * scale is stored
+// line-tiled (full 128-byte lines); fast4096_untile_kernel turns that into the row-major, shifted, mirrored output.
+// (Writing the 16-byte-per-row segments straight into the output relies on L2 write-combining, which collapses when
+// 256 CUs x 128 KiB of partial lines = the whole L2 are in flight: measured 2.4x write amplification, 53% store stalls.)
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(1024) fast4096_cols_kernel(Fast4096 p) {
+    XRFT_DYN_SMEM(smem_raw);
+    cf* lds = reinterpret_cast<cf*>(smem_raw);
+    float* stg = reinterpret_cast<float*>(smem_raw);
+    const int tid = threadIdx.x, g = tid >> 8, u = tid & 255;
+    cf* mine = lds + g * XRFT_F4096_LDS;
+    const long long ntiles = (long long)p.nslab * XRFT_F4096_TILES;
+    // blocks b, b+8, b+16, ... sit on one XCD (round-robin dispatch): give each run of 8 of them 8 consecutive tiles
+    const int bx = blockIdx.x & 7, bj = blockIdx.x >> 3;
+    const int per_round = gridDim.x;  // multiple of 64
+    const long long first = (long long)((bj >> 3) * 8 + bx) * 8 + (bj & 7);
+    for (long long T = first; T < ntiles; T += per_round) {
+        const int slab = (int)(T / XRFT_F4096_TILES), tile = (int)(T - (long long)slab * XRFT_F4096_TILES);
+        const cf* __restrict__ src = p.w + ((size_t)slab * XRFT_F4096_TILES + tile) * 4096 * 4 + g;
+        cf a[16];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) a[q] = src[(size_t)(u + 256 * q) * 4];
+        fft4096_group(a, u, mine, p.tw);
+        {   // power, staged column-major [g][ky] with the conflict-free 17/16 padding
+            const int k1 = u >> 4, k2 = u & 15;
+#pragma unroll
+            for (int k3 = 0; k3 < 16; ++k3) {
+                const int ky = k1 + 16 * k2 + 256 * k3;
+                stg[g * XRFT_F4096_LDS + nat4096(ky)] = (a[k3].re * a[k3].re + a[k3].im * a[k3].im) * p.scale;
+            }
+        }
+        __syncthreads();
+        // line-tiled store: 8 consecutive lanes (rows ky..ky+7 of this tile) fill one 128-byte line
+        F4* __restrict__ pt = reinterpret_cast<F4*>(p.pt) + (size_t)slab * 512 * XRFT_F4096_TILES * 8;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int ky = tid + 1024 * r;
+            const int s = nat4096(ky);
+            F4 d;
+            d.x = stg[s]; d.y = stg[XRFT_F4096_LDS + s]; d.z = stg[2 * XRFT_F4096_LDS + s]; d.w = stg[3 * XRFT_F4096_LDS + s];
+            pt[((size_t)(ky >> 3) * XRFT_F4096_TILES + tile) * 8 + (ky & 7)] = d;
+        }
+        __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// untile + fftshift + Hermitian mirror: a workgroup owns 8 rows ky0..ky0+7 of the half spectrum (one contiguous
+// 65.7 KB read), writes them as the direct part of output rows ky (kx = 0..2048) and, reversed, as the mirror part
+// of output rows -ky (kx = 4095..2049); every run is contiguous, aligned quads go out as 16-byte stores.
+//   xrft.py:446-447 (fftshift); the mirror is the Hermitian symmetry of the transform of a real field.
+// ------------------------------------------------------------------------------------------------
+#define XRFT_UNTILE_LD 2052  // floats per staged row (2049 used)
+__global__ void __launch_bounds__(256) fast4096_untile_kernel(Fast4096 p) {
+    XRFT_DYN_SMEM(smem_raw);
+    float* rows = reinterpret_cast<float*>(smem_raw);
+    const int tid = threadIdx.x;
+    const int slab = blockIdx.x >> 9, kb = blockIdx.x & 511;
+    const F4* __restrict__ src = reinterpret_cast<const F4*>(p.pt) + ((size_t)slab * 512 + kb) * XRFT_F4096_TILES * 8;
+    for (int e = tid; e < XRFT_F4096_TILES * 8; e += 256) {
+        const F4 v = src[e];
+        const int tile = e >> 3, r = e & 7;
+        float* d = rows + r * XRFT_UNTILE_LD + tile * 4;
+        d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+    }
+    __syncthreads();
+    float* __restrict__ out = p.out + (size_t)slab * 4096 * 4096;
+    const int sx = p.shift_x;
+    for (int r = 0; r < 8; ++r) {
+        const int ky = kb * 8 + r;
+        const float* row = rows + r * XRFT_UNTILE_LD;
+        float* drow = out + (size_t)((ky + p.shift_y) & 4095) * 4096;
+        float* mrow = out + (size_t)(((4096 - ky) + p.shift_y) & 4095) * 4096;
+        // direct: destination column c = (kx + sx) & 4095 for kx = 0..2048
+        for (int qd = tid; qd < 512; qd += 256) {  // kx = 4 qd .. 4 qd + 3 (kx <= 2047): aligned quads on both sides
+            F4 v; v.x = row[4 * qd]; v.y = row[4 * qd + 1]; v.z = row[4 * qd + 2]; v.w = row[4 * qd + 3];
+            *reinterpret_cast<F4*>(drow + ((4 * qd + sx) & 4095)) = v;
+        }
+        if (tid == 0) drow[(2048 + sx) & 4095] = row[2048];
+        // mirror: value at kx goes to column (4096 - kx + sx) & 4095, kx = 1..2047.  Destination quads
+        // c0 = (4096 - 4 m - 3 + sx) .. +3 hold kx = 4m+3, 4m+2, 4m+1, 4m  -> aligned when taken as kx = 4m+1..4m+4 instead:
+        // columns (4096 - (4m+4) + sx) .. (4096 - (4m+1) + sx) are an aligned quad for m = 0..510 (kx <= 2044)
+        for (int m = tid; m < 511; m += 256) {
+            F4 v; v.x = row[4 * m + 4]; v.y = row[4 * m + 3]; v.z = row[4 * m + 2]; v.w = row[4 * m + 1];
+            *reinterpret_cast<F4*>(mrow + ((4096 - (4 * m + 4) + sx) & 4095)) = v;
+        }
+        if (tid < 3) { const int kx = 2045 + tid; mrow[(4096 - kx + sx) & 4095] = row[kx]; }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// moments with 16-byte loads (nx % 4 == 0): grid = (row blocks, slabs); a block reduces ROWS consecutive rows
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) slab_moments_f32x4_kernel(const float* in, int ny, int nx, int rows_per_block, double* acc) {
+    XRFT_DYN_SMEM(smem_raw);
+    double* red = reinterpret_cast<double*>(smem_raw);
+    const int b = blockIdx.y;
+    const int r0 = blockIdx.x * rows_per_block;
+    const float ibar = 0.5f * (float)(ny - 1), jbar = 0.5f * (float)(nx - 1);
+    double s[6] = {0, 0, 0, 0, 0, 0};
+    const int nq = nx / 4;
+    for (int r = r0; r < r0 + rows_per_block && r < ny; r += 4) {  // 4 rows at a time: up to 16 independent 16-byte loads in flight
+        float s0[4] = {0.f, 0.f, 0.f, 0.f}, sj[4] = {0.f, 0.f, 0.f, 0.f};
+        for (int j4 = threadIdx.x; j4 < nq; j4 += 1024) {
+            F4 v[4][4];
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) {
+                const F4* __restrict__ row = reinterpret_cast<const F4*>(in + ((size_t)b * ny + (r + rr < ny ? r + rr : r)) * nx);
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const int jj = j4 + 256 * c;
+                    F4 z; z.x = z.y = z.z = z.w = 0.f;
+                    v[rr][c] = jj < nq ? row[jj] : z;
+                }
+            }
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr)
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const float j = (float)(4 * (j4 + 256 * c)) - jbar;
+                    const F4 w = v[rr][c];
+                    s0[rr] += (w.x + w.y) + (w.z + w.w);
+                    sj[rr] += (w.x * j + w.y * (j + 1.f)) + (w.z * (j + 2.f) + w.w * (j + 3.f));
+                }
+        }
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr)
+            if (r + rr < ny && r + rr < r0 + rows_per_block) {
+                s[0] += (double)s0[rr];
+                s[2] += (double)(((float)(r + rr) - ibar) * s0[rr]);
+                s[4] += (double)sj[rr];
+            }
+    }
+    block_sum<6>(s, red);
+    if (threadIdx.x == 0)
+        for (int k = 0; k < 6; k += 2)
+            if (s[k] != 0.0) atomicAdd(&acc[(size_t)b * 6 + k], s[k]);
+}
+
+}  // namespace xrft

@@ -185,8 +185,8 @@ __device__ __forceinline__ C2<T> fetch_src(const Prologue& pr, long long b, int 
     else v = mk<T>(reinterpret_cast<const T*>(pr.in)[off], (T)0);
     if (pr.detrend) {
         const double* c = pr.coef + b * 6;
-        v.re -= (T)(c[0] + c[2] * si + c[4] * sj);
-        if (pr.in_complex) v.im -= (T)(c[1] + c[3] * si + c[5] * sj);
+        v.re = (T)((double)v.re - (c[0] + c[2] * si + c[4] * sj));
+        if (pr.in_complex) v.im = (T)((double)v.im - (c[1] + c[3] * si + c[5] * sj));
     }
     T w = (T)1;
     if (pr.win_y) w = reinterpret_cast<const T*>(pr.win_y)[si];

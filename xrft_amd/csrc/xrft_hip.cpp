@@ -19,6 +19,7 @@
 
 #include "../../include/xrft_hip.h"
 #include "aux_kernels.h"
+#include "fast4096.h"
 #include "tile_fft.h"
 
 using namespace xrft;
@@ -158,8 +159,11 @@ struct xrfthip_plan {
     std::vector<Pass> passes;     // main pipeline (field 1 for CROSS)
     std::vector<Pass> passes_f0;  // CROSS: field 0 -> raw F0 buffer
     // workspace layout (byte offsets)
-    size_t off_acc = 0, off_coef = 0, off_w = 0, off_w2 = 0, off_f0 = 0, ws_bytes = 0;
+    size_t off_acc = 0, off_coef = 0, off_w = 0, off_w2 = 0, off_f0 = 0, off_pt = 0, ws_bytes = 0;
     std::string desc_text;
+    // specialised path for (4096, 4096) float32 power spectra (fast4096.h)
+    bool fast4096 = false;
+    DevBuf tw4096;
     // optional per-pass event timing (bench only)
     bool prof = false;
     struct ProfRec { std::string label; hipEvent_t a, b; };
@@ -516,6 +520,9 @@ void set_kernel_attrs_once() {
     SETALL(double);
 #undef SETALL
 #undef SETA
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&fast4096_rows_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, m);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&fast4096_cols_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, m);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&fast4096_untile_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, m);
 }
 
 template <typename T>
@@ -568,7 +575,11 @@ static int upload_real_table(xrfthip_plan* P, DevBuf& buf, const double* h, int6
 static void layout_workspace(xrfthip_plan* P) {
     const xrfthip_desc& d = P->d;
     long long G = d.slabs_per_group > 0 ? d.slabs_per_group : env_ll("XRFTHIP_GROUP", 0);
-    const size_t slab_w = (size_t)d.ny * P->width * P->csize;
+    size_t slab_w = (size_t)d.ny * P->width * P->csize;
+    if (P->fast4096) {
+        slab_w = (size_t)XRFT_F4096_TILES * 4096 * 4 * sizeof(cf);
+        if (G <= 0) G = env_ll("XRFTHIP_FAST_GROUP", 8);
+    }
     if (G <= 0) {
         const size_t target = (size_t)env_ll("XRFTHIP_GROUP_BYTES", 64LL << 20);
         G = (long long)std::max<size_t>(1, target / std::max<size_t>(slab_w, 1));
@@ -585,6 +596,7 @@ static void layout_workspace(xrfthip_plan* P) {
     P->off_w = off; if (need_w) off = al(off + (size_t)G * slab_w);
     P->off_w2 = off; if (need_w2) off = al(off + (size_t)G * d.ny * d.nx * P->csize);
     P->off_f0 = off; if (nf == 2) off = al(off + (size_t)G * slab_w);
+    P->off_pt = off; if (P->fast4096) off = al(off + (size_t)G * 512 * XRFT_F4096_TILES * 8 * sizeof(F4));
     P->ws_bytes = off;
 }
 
@@ -620,6 +632,57 @@ static int run_moments(const xrfthip_plan* P, const void* in, long long g0, long
     XRFT_LAUNCH(kf, dim3((unsigned)((gc + 63) / 64)), dim3(64), 0, st, (const double*)(acc + g0 * 6), coef + g0 * 6, gc, (long long)d.ny, (long long)d.nx, (int)d.detrend);
     prof_end(rec, st);
     HIP_TRY(hipGetLastError());
+    return XRFTHIP_OK;
+}
+
+// (4096, 4096) float32 power spectrum: [moments -> coefficients ->] row pass -> column pass, per group of slabs
+static int run_fast4096(const xrfthip_plan* P, const float* in, float* out, char* ws, double* acc, double* coef, hipStream_t st) {
+    const xrfthip_desc& d = P->d;
+    const bool det = acc != nullptr;
+    for (long long g0 = 0; g0 < d.batch; g0 += P->G) {
+        const long long gc = std::min<long long>(P->G, d.batch - g0);
+        const float* gin = in + (size_t)g0 * 4096 * 4096;
+        if (det) {
+            const int rpb = (int)env_ll("XRFTHIP_MOMENT_ROWS", 16);
+            xrfthip_plan::ProfRec* rec = prof_begin(P, "moments", st);
+            auto km = &slab_moments_f32x4_kernel;
+            XRFT_LAUNCH(km, dim3((unsigned)((4096 + rpb - 1) / rpb), (unsigned)gc), dim3(256), 6 * 256 * sizeof(double), st, gin, 4096, 4096, rpb, acc + g0 * 6);
+            prof_end(rec, st);
+            rec = prof_begin(P, "finalize_coef", st);
+            auto kf = &finalize_coef_kernel;
+            XRFT_LAUNCH(kf, dim3((unsigned)((gc + 63) / 64)), dim3(64), 0, st, (const double*)(acc + g0 * 6), coef + g0 * 6, gc, 4096LL, 4096LL, (int)d.detrend);
+            prof_end(rec, st);
+        }
+        Fast4096 p{};
+        p.in = gin;
+        p.w = reinterpret_cast<cf*>(ws + P->off_w);
+        p.pt = reinterpret_cast<float*>(ws + P->off_pt);
+        p.out = out + (size_t)g0 * 4096 * 4096;
+        p.tw = reinterpret_cast<const cf*>(P->tw4096.p);
+        p.win_y = reinterpret_cast<const float*>(P->win[0].p);
+        p.win_x = reinterpret_cast<const float*>(P->win[1].p);
+        p.coef = det ? coef + g0 * 6 : nullptr;
+        p.nslab = (int)gc;
+        p.shift_y = (d.flags & XRFTHIP_SHIFT_Y) ? 2048 : 0;
+        p.shift_x = (d.flags & XRFTHIP_SHIFT_X) ? 2048 : 0;
+        p.scale = (float)d.scale;
+        xrfthip_plan::ProfRec* rec = prof_begin(P, "fast4096_rows", st);
+        auto kr = &fast4096_rows_kernel;
+        XRFT_LAUNCH(kr, dim3((unsigned)(1024 * gc)), dim3(512), 2 * XRFT_F4096_LDS * sizeof(cf), st, p);
+        prof_end(rec, st);
+        rec = prof_begin(P, "fast4096_cols", st);
+        auto kc = &fast4096_cols_kernel;
+        const long long ntiles = gc * XRFT_F4096_TILES;
+        long long grid = std::min<long long>(env_ll("XRFTHIP_FAST_COLS_GRID", kCUs), ((ntiles + 63) / 64) * 64);
+        grid = std::max<long long>(64, (grid / 64) * 64);
+        XRFT_LAUNCH(kc, dim3((unsigned)grid), dim3(1024), 4 * XRFT_F4096_LDS * sizeof(cf), st, p);
+        prof_end(rec, st);
+        rec = prof_begin(P, "fast4096_untile", st);
+        auto ku = &fast4096_untile_kernel;
+        XRFT_LAUNCH(ku, dim3((unsigned)(512 * gc)), dim3(256), 8 * XRFT_UNTILE_LD * sizeof(float), st, p);
+        prof_end(rec, st);
+        HIP_TRY(hipGetLastError());
+    }
     return XRFTHIP_OK;
 }
 
@@ -735,6 +798,12 @@ int xrfthip_plan_create(xrfthip_plan** plan, const xrfthip_desc* desc) {
         if (c.T == 0 || n_try >= env_ll("XRFTHIP_X_FOURSTEP_MIN", 1LL << 40)) P->width = d.nx;
     }
     P->mirror = !cplx_in && !(d.flags & XRFTHIP_HALF_X) && P->width == d.nx / 2 + 1 && d.nx > 1;
+    P->fast4096 = d.ndim == 2 && d.ny == 4096 && d.nx == 4096 && d.dtype == XRFTHIP_F32 && d.out_mode == XRFTHIP_OUT_POWER &&
+                  !(d.flags & ~(XRFTHIP_SHIFT_Y | XRFTHIP_SHIFT_X)) && !env_ll("XRFTHIP_NO_FAST", 0);
+    if (P->fast4096) {
+        int rc4 = build_twiddle<float>(P->tw4096, 4096, 4096);
+        if (rc4) { delete P; return rc4; }
+    }
     set_kernel_attrs_once();
     // nbins must be known before tiles are sized (the LDS histogram shares the tile's allocation): ISO plans are
     // (re)built in xrfthip_plan_set_binmap.  Build now for everything else.
@@ -815,6 +884,9 @@ int xrfthip_plan_describe(const xrfthip_plan* plan, char* buf, size_t buflen) {
     appendf(s, "xrfthip plan: ndim=%d batch=%lld ny=%lld nx=%lld dtype=%d mode=%d detrend=%d flags=0x%x width=%lld nx_out=%lld mirror=%d group=%d ws=%zuB\n",
             d.ndim, (long long)d.batch, (long long)d.ny, (long long)d.nx, d.dtype, d.out_mode, d.detrend, d.flags,
             plan->width, plan->nx_out, (int)plan->mirror, plan->G, plan->ws_bytes);
+    if (plan->fast4096)
+        appendf(s, "  [fast4096] moments(f32x4) -> rows: 512 thr, 2x(2 real rows -> 1 complex FFT4096 r16x16x16), lds=%zuB, tiled W[slab][513][4096][4] -> cols: 1024 thr, 4 columns/tile, lds=%zuB, persistent, line-tiled |F|^2 -> untile+shift+mirror: 256 thr, 8 rows\n",
+                2 * XRFT_F4096_LDS * sizeof(cf), 4 * XRFT_F4096_LDS * sizeof(cf));
     describe_passes(s, plan->passes_f0, "f0");
     describe_passes(s, plan->passes, "main");
     const size_t n = std::min(buflen - 1, s.size());
@@ -845,6 +917,7 @@ int xrfthip_exec(const xrfthip_plan* plan, const void* d_in0, const void* d_in1,
     double* coef = (double*)(ws + P->off_coef);
     if (det) HIP_TRY(hipMemsetAsync(acc, 0, (size_t)d.batch * 6 * sizeof(double) * (cross ? 2 : 1), st));
     if (iso) HIP_TRY(hipMemsetAsync(d_iso, 0, (size_t)d.batch * P->nbins * (cross ? 16 : 8), st));
+    if (P->fast4096) return run_fast4096(P, (const float*)d_in0, (float*)d_out, ws, det ? acc : nullptr, coef, st);
     for (long long g0 = 0; g0 < d.batch; g0 += P->G) {
         const long long gc = std::min<long long>(P->G, d.batch - g0);
         int rc;
