@@ -5,7 +5,7 @@
 //   * HBM streams ~6.0 TB/s read / ~5.1 TB/s write and the Infinity Cache adds almost no bandwidth on top, so the
 //     number of passes over a slab is what counts: 2 passes (rows, then columns), never 3.
 //   * scattered FULL 128-byte lines write at streaming speed -> the row pass stores the half spectrum in a tiled
-//     layout W[slab][tile = kx/4][i][kx%4] (4 rows x 4 columns x 8 B = one line per workgroup and tile), which the
+//     layout W[slab][tile = kx/4][i/4][kx%4][i%4] (4 columns x 4 rows x 8 B = one line per workgroup and tile), which the
 //     column pass then reads as one contiguous 128 KiB block per tile.
 //   * a 4096-point column of complex64 is 32 KiB, so only 4 columns fit one CU's LDS: the column pass writes
 //     16-byte output segments.  With the tile -> workgroup mapping arranged so that the 8 workgroups sharing a
@@ -96,7 +96,7 @@ __device__ __forceinline__ void fft4096_group(cf* a, int u, cf* lds, const cf* _
 
 struct Fast4096 {  // parameters shared by the two passes
     const float* in;         // [slab][4096][4096] float32
-    cf* w;                   // tiled intermediate [slab][513][4096][4]
+    cf* w;                   // tiled intermediate [slab][513][1024 lines][col(4)][row(4)]
     float* pt;               // line-tiled half power spectrum [slab][ky/8 (512)][tile (513)][ky%8][4]
     float* out;              // [slab][4096][4096] float32 power spectrum
     const cf* tw;            // W_4096^k
@@ -124,28 +124,34 @@ __global__ void __launch_bounds__(512) fast4096_rows_kernel(Fast4096 p) {
     cf* mine = lds + g * XRFT_F4096_LDS;
     const float* __restrict__ srcA = p.in + ((size_t)slab * 4096 + rA) * 4096;
     const float* __restrict__ srcB = srcA + 4096;
-    // trend evaluated and subtracted in float64: a float32 evaluation of c2*j rounds identically in every row, and
-    // that column-coherent error adds up over 4096 rows into the ky = 0 bins (measured 6e-4 of max vs 4e-5)
-    double tA = 0.0, tB = 0.0, c2 = 0.0;
-    if (p.coef) {
-        const double* c = p.coef + (size_t)slab * 6;
-        tA = c[0] + c[2] * rA;
-        tB = c[0] + c[2] * rB;
-        c2 = c[4];
-    }
-    const float wA = p.win_y ? p.win_y[rA] : 1.f, wB = p.win_y ? p.win_y[rB] : 1.f;
+    // Trend c0 + c1*i + c2*j subtracted in float32 with hi/lo splits whose hi parts lie on a coarse power-of-two grid G
+    // (G ~ 2^-20 of the trend's magnitude).  Then x - tAh and the FMA with the exact product c2h*j are error-free
+    // (all operands are multiples of min(ulp(x), G) and small enough), and the lo parts are applied to the already
+    // noise-sized value, so every rounding that remains depends on the data's own low bits: no error that is
+    // coherent along a row or a column (a plain float32 evaluation leaves 6e-4 of max in the ky = 0 / kx = 0 bins;
+    // this form gives 1e-6, like float64 arithmetic, at 4 float32 operations per sample).
+    // (coef / win_x / win_y are never null here: the plan passes zero coefficients / all-ones windows instead, so that
+    // the loads below are unconditional -- a nullable table costs one branch per load.)
+    const double* c = p.coef + (size_t)slab * 6;
+    int ge;
+    (void)frexp(fabs(c[0]) + (fabs(c[2]) + fabs(c[4])) * 4096.0, &ge);
+    const double G = ldexp(1.0, ge - 20), rG = ldexp(1.0, 20 - ge);
+    const double tA = c[0] + c[2] * rA, tB = c[0] + c[2] * rB;
+    const double tAq = rint(tA * rG) * G, tBq = rint(tB * rG) * G, c2q = rint(c[4] * rG) * G;
+    const float tAh = (float)tAq, tAl = (float)(tA - tAq);
+    const float tBh = (float)tBq, tBl = (float)(tB - tBq);
+    const float c2h = (float)c2q, c2l = (float)(c[4] - c2q);
+    const float wA = p.win_y[rA], wB = p.win_y[rB];
+    float xa[16], xb[16], wx[16];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) { xa[q] = srcA[u + 256 * q]; xb[q] = srcB[u + 256 * q]; wx[q] = p.win_x[u + 256 * q]; }
     cf a[16];
 #pragma unroll
     for (int q = 0; q < 16; ++q) {
-        const int j = u + 256 * q;
-        float xa = srcA[j], xb = srcB[j];
-        if (p.coef) {
-            const double tr = c2 * (double)j;
-            xa = (float)((double)xa - (tA + tr));
-            xb = (float)((double)xb - (tB + tr));
-        }
-        const float wx = p.win_x ? p.win_x[j] : 1.f;
-        a[q] = mk<float>(xa * (wx * wA), xb * (wx * wB));
+        const float jf = (float)(u + 256 * q);
+        const float va = fmaf(-c2l, jf, fmaf(-c2h, jf, xa[q] - tAh) - tAl);
+        const float vb = fmaf(-c2l, jf, fmaf(-c2h, jf, xb[q] - tBh) - tBl);
+        a[q] = mk<float>(va * (wx[q] * wA), vb * (wx[q] * wB));
     }
     fft4096_group(a, u, mine, p.tw);
     {
@@ -167,25 +173,27 @@ __global__ void __launch_bounds__(512) fast4096_rows_kernel(Fast4096 p) {
         }
     }
     __syncthreads();
-    // stage the 4 x 2049 outputs as [tile][row(4)][col(4)], then write full lines
+    // stage the 4 x 2049 outputs as [tile][col(4)][row(4)], then write full lines
 #pragma unroll
     for (int q = 0; q < 9; ++q) {
         const int k = u + 256 * q;
         if (q < 8 || u == 0) {
-            const int tl = k >> 2, sw = tl & 3;  // row slot XOR (tile & 3): 4 consecutive tiles hit 4 different bank groups
-            lds[tl * 16 + ((2 * g) ^ sw) * 4 + (k & 3)] = ra[q];
-            lds[tl * 16 + ((2 * g + 1) ^ sw) * 4 + (k & 3)] = rb[q];
+            // line layout [col(4)][row(4)]: the column pass then reads 4 consecutive rows of its column as one 32-byte sector.
+            // slot = (col ^ (tile & 3)): 4 consecutive lanes (cols of one tile) x 4 consecutive tiles hit 16 different bank pairs
+            const int tl = k >> 2, sw = tl & 3;
+            lds[tl * 16 + (((k & 3) ^ sw) << 2) + 2 * g] = ra[q];
+            lds[tl * 16 + (((k & 3) ^ sw) << 2) + 2 * g + 1] = rb[q];
         }
     }
     if (tid < 12) {  // the 3 padding columns of tile 512 (kx = 2049..2051): keep the intermediate deterministic
         const int r = tid / 3, c = 1 + tid % 3;
-        lds[512 * 16 + (r ^ 0) * 4 + c] = mk<float>(0.f, 0.f);  // tile 512: swizzle (512 & 3) = 0
+        lds[512 * 16 + c * 4 + r] = mk<float>(0.f, 0.f);  // tile 512: swizzle (512 & 3) = 0, layout [col][row]
     }
     __syncthreads();
     F4* __restrict__ dst = reinterpret_cast<F4*>(p.w + ((size_t)slab * XRFT_F4096_TILES * 4096 + 4 * wrow) * 4);
     const F4* stg = reinterpret_cast<const F4*>(lds);
     for (int e = tid; e < XRFT_F4096_TILES * 8; e += 512) {
-        const int tile = e >> 3, part = e & 7;  // part = row * 2 + half
+        const int tile = e >> 3, part = e & 7;  // part = col * 2 + (row pair)
         dst[(size_t)tile * (4096 * 2) + part] = stg[tile * 8 + ((((part >> 1) ^ (tile & 3)) << 1) | (part & 1))];  // tile stride = 4096*2 F4
     }
 }
@@ -207,12 +215,14 @@ __global__ void __launch_bounds__(1024) fast4096_cols_kernel(Fast4096 p) {
     const int bx = blockIdx.x & 7, bj = blockIdx.x >> 3;
     const int per_round = gridDim.x;  // multiple of 64
     const long long first = (long long)((bj >> 3) * 8 + bx) * 8 + (bj & 7);
+    cf a[16];
+    if (first < ntiles) {
+        const cf* __restrict__ src = p.w + (size_t)first * 4096 * 4 + (u >> 2) * 16 + g * 4 + (u & 3);
+#pragma unroll
+        for (int q = 0; q < 16; ++q) a[q] = src[q * 1024];  // row u + 256 q of column g: line (i >> 2), slot [g][i & 3]
+    }
     for (long long T = first; T < ntiles; T += per_round) {
         const int slab = (int)(T / XRFT_F4096_TILES), tile = (int)(T - (long long)slab * XRFT_F4096_TILES);
-        const cf* __restrict__ src = p.w + ((size_t)slab * XRFT_F4096_TILES + tile) * 4096 * 4 + g;
-        cf a[16];
-#pragma unroll
-        for (int q = 0; q < 16; ++q) a[q] = src[(size_t)(u + 256 * q) * 4];
         fft4096_group(a, u, mine, p.tw);
         {   // power, staged column-major [g][ky] with the conflict-free 17/16 padding
             const int k1 = u >> 4, k2 = u & 15;
@@ -221,6 +231,11 @@ __global__ void __launch_bounds__(1024) fast4096_cols_kernel(Fast4096 p) {
                 const int ky = k1 + 16 * k2 + 256 * k3;
                 stg[g * XRFT_F4096_LDS + nat4096(ky)] = (a[k3].re * a[k3].re + a[k3].im * a[k3].im) * p.scale;
             }
+        }
+        if (T + per_round < ntiles) {  // late prefetch: the FFT registers are dead; the next tile loads while this one is stored
+            const cf* __restrict__ src = p.w + (size_t)(T + per_round) * 4096 * 4 + (u >> 2) * 16 + g * 4 + (u & 3);
+#pragma unroll
+            for (int q = 0; q < 16; ++q) a[q] = src[q * 1024];
         }
         __syncthreads();
         // line-tiled store: 8 consecutive lanes (rows ky..ky+7 of this tile) fill one 128-byte line
@@ -292,12 +307,12 @@ __global__ void __launch_bounds__(256) slab_moments_f32x4_kernel(const float* in
     const float ibar = 0.5f * (float)(ny - 1), jbar = 0.5f * (float)(nx - 1);
     double s[6] = {0, 0, 0, 0, 0, 0};
     const int nq = nx / 4;
-    for (int r = r0; r < r0 + rows_per_block && r < ny; r += 4) {  // 4 rows at a time: up to 16 independent 16-byte loads in flight
-        float s0[4] = {0.f, 0.f, 0.f, 0.f}, sj[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int r = r0; r < r0 + rows_per_block && r < ny; r += 2) {  // 2 rows at a time: 8 independent 16-byte loads in flight
+        float s0[2] = {0.f, 0.f}, sj[2] = {0.f, 0.f};
         for (int j4 = threadIdx.x; j4 < nq; j4 += 1024) {
-            F4 v[4][4];
+            F4 v[2][4];
 #pragma unroll
-            for (int rr = 0; rr < 4; ++rr) {
+            for (int rr = 0; rr < 2; ++rr) {
                 const F4* __restrict__ row = reinterpret_cast<const F4*>(in + ((size_t)b * ny + (r + rr < ny ? r + rr : r)) * nx);
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
@@ -307,7 +322,7 @@ __global__ void __launch_bounds__(256) slab_moments_f32x4_kernel(const float* in
                 }
             }
 #pragma unroll
-            for (int rr = 0; rr < 4; ++rr)
+            for (int rr = 0; rr < 2; ++rr)
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
                     const float j = (float)(4 * (j4 + 256 * c)) - jbar;
@@ -317,7 +332,7 @@ __global__ void __launch_bounds__(256) slab_moments_f32x4_kernel(const float* in
                 }
         }
 #pragma unroll
-        for (int rr = 0; rr < 4; ++rr)
+        for (int rr = 0; rr < 2; ++rr)
             if (r + rr < ny && r + rr < r0 + rows_per_block) {
                 s[0] += (double)s0[rr];
                 s[2] += (double)(((float)(r + rr) - ibar) * s0[rr]);

@@ -163,7 +163,7 @@ struct xrfthip_plan {
     std::string desc_text;
     // specialised path for (4096, 4096) float32 power spectra (fast4096.h)
     bool fast4096 = false;
-    DevBuf tw4096;
+    DevBuf tw4096, ones4096, zero_coef;
     // optional per-pass event timing (bench only)
     bool prof = false;
     struct ProfRec { std::string label; hipEvent_t a, b; };
@@ -659,9 +659,9 @@ static int run_fast4096(const xrfthip_plan* P, const float* in, float* out, char
         p.pt = reinterpret_cast<float*>(ws + P->off_pt);
         p.out = out + (size_t)g0 * 4096 * 4096;
         p.tw = reinterpret_cast<const cf*>(P->tw4096.p);
-        p.win_y = reinterpret_cast<const float*>(P->win[0].p);
-        p.win_x = reinterpret_cast<const float*>(P->win[1].p);
-        p.coef = det ? coef + g0 * 6 : nullptr;
+        p.win_y = reinterpret_cast<const float*>(P->win[0].p ? P->win[0].p : P->ones4096.p);
+        p.win_x = reinterpret_cast<const float*>(P->win[1].p ? P->win[1].p : P->ones4096.p);
+        p.coef = det ? coef + g0 * 6 : reinterpret_cast<const double*>(P->zero_coef.p) + g0 * 6;
         p.nslab = (int)gc;
         p.shift_y = (d.flags & XRFTHIP_SHIFT_Y) ? 2048 : 0;
         p.shift_x = (d.flags & XRFTHIP_SHIFT_X) ? 2048 : 0;
@@ -802,6 +802,10 @@ int xrfthip_plan_create(xrfthip_plan** plan, const xrfthip_desc* desc) {
                   !(d.flags & ~(XRFTHIP_SHIFT_Y | XRFTHIP_SHIFT_X)) && !env_ll("XRFTHIP_NO_FAST", 0);
     if (P->fast4096) {
         int rc4 = build_twiddle<float>(P->tw4096, 4096, 4096);
+        std::vector<float> ones(4096, 1.0f);
+        std::vector<double> zc((size_t)std::max<int64_t>(d.batch, 1) * 6, 0.0);
+        if (!rc4) rc4 = P->ones4096.upload(ones.data(), ones.size() * sizeof(float));
+        if (!rc4) rc4 = P->zero_coef.upload(zc.data(), zc.size() * sizeof(double));
         if (rc4) { delete P; return rc4; }
     }
     set_kernel_attrs_once();
