@@ -297,47 +297,40 @@ __global__ void __launch_bounds__(256) fast4096_untile_kernel(Fast4096 p) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// moments with 16-byte loads (nx % 4 == 0): grid = (row blocks, slabs); a block reduces ROWS consecutive rows
+// moments of (4096 x 4096) float32 slabs with unconditional 16-byte loads: grid = (4096 / ROWS, slabs); a 256-thread
+// block reduces ROWS consecutive rows, two rows (8 independent loads per thread) at a time.
+// (Bounds-checked loads compile to one branch per load and run at 3.3 TB/s instead of ~5.5.)
 // ------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) slab_moments_f32x4_kernel(const float* in, int ny, int nx, int rows_per_block, double* acc) {
+__global__ void __launch_bounds__(256) slab_moments_4096_kernel(const float* in, double* acc) {
     XRFT_DYN_SMEM(smem_raw);
     double* red = reinterpret_cast<double*>(smem_raw);
     const int b = blockIdx.y;
-    const int r0 = blockIdx.x * rows_per_block;
-    const float ibar = 0.5f * (float)(ny - 1), jbar = 0.5f * (float)(nx - 1);
+    // rows are dealt to the blocks round-robin in pairs (block x takes rows 2x, 2x+1, then + 2*gridDim.x, ...), so that
+    // at any moment the resident blocks read one compact moving window of the slab: with a contiguous chunk per block the
+    // 2048 concurrent streams thrash the DRAM row buffers (3.9 TB/s instead of ~5.5)
+    const float ibar = 2047.5f, jbar = 2047.5f;
+    const F4* __restrict__ base = reinterpret_cast<const F4*>(in + (size_t)b * 4096 * 4096) + threadIdx.x;
     double s[6] = {0, 0, 0, 0, 0, 0};
-    const int nq = nx / 4;
-    for (int r = r0; r < r0 + rows_per_block && r < ny; r += 2) {  // 2 rows at a time: 8 independent 16-byte loads in flight
-        float s0[2] = {0.f, 0.f}, sj[2] = {0.f, 0.f};
-        for (int j4 = threadIdx.x; j4 < nq; j4 += 1024) {
-            F4 v[2][4];
-#pragma unroll
-            for (int rr = 0; rr < 2; ++rr) {
-                const F4* __restrict__ row = reinterpret_cast<const F4*>(in + ((size_t)b * ny + (r + rr < ny ? r + rr : r)) * nx);
-#pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    const int jj = j4 + 256 * c;
-                    F4 z; z.x = z.y = z.z = z.w = 0.f;
-                    v[rr][c] = jj < nq ? row[jj] : z;
-                }
-            }
-#pragma unroll
-            for (int rr = 0; rr < 2; ++rr)
-#pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    const float j = (float)(4 * (j4 + 256 * c)) - jbar;
-                    const F4 w = v[rr][c];
-                    s0[rr] += (w.x + w.y) + (w.z + w.w);
-                    sj[rr] += (w.x * j + w.y * (j + 1.f)) + (w.z * (j + 2.f) + w.w * (j + 3.f));
-                }
-        }
+    for (int r = 2 * blockIdx.x; r < 4096; r += 2 * gridDim.x) {
+        F4 v[2][4];
 #pragma unroll
         for (int rr = 0; rr < 2; ++rr)
-            if (r + rr < ny && r + rr < r0 + rows_per_block) {
-                s[0] += (double)s0[rr];
-                s[2] += (double)(((float)(r + rr) - ibar) * s0[rr]);
-                s[4] += (double)sj[rr];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) v[rr][c] = base[(size_t)(r + rr) * 1024 + 256 * c];
+#pragma unroll
+        for (int rr = 0; rr < 2; ++rr) {
+            float s0 = 0.f, sj = 0.f;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const float j = (float)(4 * (threadIdx.x + 256 * c)) - jbar;
+                const F4 w = v[rr][c];
+                s0 += (w.x + w.y) + (w.z + w.w);
+                sj += (w.x * j + w.y * (j + 1.f)) + (w.z * (j + 2.f) + w.w * (j + 3.f));
             }
+            s[0] += (double)s0;
+            s[2] += (double)(((float)(r + rr) - ibar) * s0);
+            s[4] += (double)sj;
+        }
     }
     block_sum<6>(s, red);
     if (threadIdx.x == 0)

@@ -643,10 +643,10 @@ static int run_fast4096(const xrfthip_plan* P, const float* in, float* out, char
         const long long gc = std::min<long long>(P->G, d.batch - g0);
         const float* gin = in + (size_t)g0 * 4096 * 4096;
         if (det) {
-            const int rpb = (int)env_ll("XRFTHIP_MOMENT_ROWS", 16);
+            const int rpb = (int)env_ll("XRFTHIP_MOMENT_ROWS", 8);  // row PAIRS per block
             xrfthip_plan::ProfRec* rec = prof_begin(P, "moments", st);
-            auto km = &slab_moments_f32x4_kernel;
-            XRFT_LAUNCH(km, dim3((unsigned)((4096 + rpb - 1) / rpb), (unsigned)gc), dim3(256), 6 * 256 * sizeof(double), st, gin, 4096, 4096, rpb, acc + g0 * 6);
+            auto km = &slab_moments_4096_kernel;
+            XRFT_LAUNCH(km, dim3((unsigned)(2048 / rpb), (unsigned)gc), dim3(256), 6 * 256 * sizeof(double), st, gin, acc + g0 * 6);
             prof_end(rec, st);
             rec = prof_begin(P, "finalize_coef", st);
             auto kf = &finalize_coef_kernel;
