@@ -102,7 +102,11 @@ struct Fast4096 {  // parameters shared by the two passes
     const cf* tw;            // W_4096^k
     const float* win_y;      // nullable
     const float* win_x;      // nullable
-    const double* coef;      // [slab][6] trend coefficients (nullable)
+    double* rowfit;          // [slab][4096][2]: per-row mean and slope found by the row pass (detrend != none), float64
+    const float* corr;       // [slab][4096][2]: wy[i] * (row fit - plane fit) as (offset, slope), from fast4096_fit_kernel
+    const cf* what0;         // FFT_x(wx)[kx], kx <= 2048 (2052 entries)
+    const cf* what1;         // FFT_x(wx * (j - 2047.5))[kx]
+    int detrend;             // 0 none, 1 constant, 2 linear
     int nslab;
     int shift_y, shift_x;    // 0 or 2048
     float scale;
@@ -124,33 +128,72 @@ __global__ void __launch_bounds__(512) fast4096_rows_kernel(Fast4096 p) {
     cf* mine = lds + g * XRFT_F4096_LDS;
     const float* __restrict__ srcA = p.in + ((size_t)slab * 4096 + rA) * 4096;
     const float* __restrict__ srcB = srcA + 4096;
-    // Trend c0 + c1*i + c2*j subtracted in float32 with hi/lo splits whose hi parts lie on a coarse power-of-two grid G
-    // (G ~ 2^-20 of the trend's magnitude).  Then x - tAh and the FMA with the exact product c2h*j are error-free
-    // (all operands are multiples of min(ulp(x), G) and small enough), and the lo parts are applied to the already
-    // noise-sized value, so every rounding that remains depends on the data's own low bits: no error that is
-    // coherent along a row or a column (a plain float32 evaluation leaves 6e-4 of max in the ky = 0 / kx = 0 bins;
-    // this form gives 1e-6, like float64 arithmetic, at 4 float32 operations per sample).
-    // (coef / win_x / win_y are never null here: the plan passes zero coefficients / all-ones windows instead, so that
-    // the loads below are unconditional -- a nullable table costs one branch per load.)
-    const double* c = p.coef + (size_t)slab * 6;
-    int ge;
-    (void)frexp(fabs(c[0]) + (fabs(c[2]) + fabs(c[4])) * 4096.0, &ge);
-    const double G = ldexp(1.0, ge - 20), rG = ldexp(1.0, 20 - ge);
-    const double tA = c[0] + c[2] * rA, tB = c[0] + c[2] * rB;
-    const double tAq = rint(tA * rG) * G, tBq = rint(tB * rG) * G, c2q = rint(c[4] * rG) * G;
-    const float tAh = (float)tAq, tAl = (float)(tA - tAq);
-    const float tBh = (float)tBq, tBl = (float)(tB - tBq);
-    const float c2h = (float)c2q, c2l = (float)(c[4] - c2q);
     const float wA = p.win_y[rA], wB = p.win_y[rB];
     float xa[16], xb[16], wx[16];
 #pragma unroll
     for (int q = 0; q < 16; ++q) { xa[q] = srcA[u + 256 * q]; xb[q] = srcB[u + 256 * q]; wx[q] = p.win_x[u + 256 * q]; }
+    // ---- detrend, fused: no pre-pass over the slab.  Every row's own least-squares line m + s*(j - 2047.5) is found
+    // here (the whole row is in this group's registers) and subtracted; it differs from the slab's plane
+    // a + b*(i - 2047.5) + c*(j - 2047.5)  (xrft/detrend.py:100-113) only by a noise-sized (offset, slope) pair per row,
+    // which the column pass adds back in the spectral domain:  wy[i] * (alpha_i * What0[kx] + gamma_i * What1[kx])
+    // with What0 = FFT(wx), What1 = FFT(wx * (j - 2047.5)).  Because the large part of the trend is removed exactly in
+    // x-space, nothing cancels catastrophically in float32; the same float32 (m, s) are used on both sides.
+    // The row sums are accumulated in float64: the lowest bins see the plane through a gain of ~1e9 (sum of the window
+    // times |What1[1]|), so the slope must be good to ~1e-11 -- float32 sums leave 5e-5 of max there, float64 1e-6.
+    float mA = 0.f, sA = 0.f, mB = 0.f, sB = 0.f;
+    if (p.detrend) {
+        double p0a = 0.0, p1a = 0.0, p0b = 0.0, p1b = 0.0;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const double jc = (double)(u + 256 * q) - 2047.5;
+            const double da = (double)xa[q], db = (double)xb[q];
+            p0a += da; p1a = fma(jc, da, p1a);
+            p0b += db; p1b = fma(jc, db, p1b);
+        }
+        struct alignas(16) D4 { double a, b, c, d; };
+        D4* red = reinterpret_cast<D4*>(mine);  // 256 + 16 entries of this group's (still unused) FFT buffer
+        D4 t; t.a = p0a; t.b = p1a; t.c = p0b; t.d = p1b;
+        red[u] = t;
+        __syncthreads();
+        if (u < 16) {
+            D4 acc; acc.a = acc.b = acc.c = acc.d = 0.0;
+#pragma unroll
+            for (int k = 0; k < 16; ++k) { const D4 v = red[u * 16 + k]; acc.a += v.a; acc.b += v.b; acc.c += v.c; acc.d += v.d; }
+            red[256 + u] = acc;
+        }
+        __syncthreads();
+        D4 tot; tot.a = tot.b = tot.c = tot.d = 0.0;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) { const D4 v = red[256 + k]; tot.a += v.a; tot.b += v.b; tot.c += v.c; tot.d += v.d; }
+        const double inv_n = 1.0 / 4096.0, inv_sjj = 1.0 / 5726622720.0;  // sum_j (j - 2047.5)^2 = n (n^2 - 1) / 12
+        const double mAd = tot.a * inv_n, mBd = tot.c * inv_n;
+        const double sAd = p.detrend == 2 ? tot.b * inv_sjj : 0.0, sBd = p.detrend == 2 ? tot.d * inv_sjj : 0.0;
+        mA = (float)mAd; mB = (float)mBd; sA = (float)sAd; sB = (float)sBd;  // the float32 values are what gets subtracted
+        if (u == 0) {
+            double* rf = p.rowfit + ((size_t)slab * 4096 + rA) * 2;
+            rf[0] = mAd; rf[1] = sAd; rf[2] = mBd; rf[3] = sBd;
+        }
+        __syncthreads();  // the reduction scratch aliases the FFT buffer written next
+    }
+    // local trend (m - s*2047.5) + s*j, subtracted in float32 with hi/lo splits whose hi parts lie on a coarse
+    // power-of-two grid G (G ~ 2^-20 of the trend's magnitude): x - th and the FMA with the exact product sh*j are then
+    // error-free, and the lo parts are applied to the already noise-sized value, so every remaining rounding depends on
+    // the data's own low bits -- no error that is coherent along a row or a column (a plain float32 evaluation leaves
+    // 6e-4 of max in the ky = 0 / kx = 0 bins; this form 1e-6, like float64, at 4 float32 operations per sample).
+    const double tA = (double)mA - (double)sA * 2047.5, tB = (double)mB - (double)sB * 2047.5;
+    int geA, geB;
+    (void)frexp(fabs(tA) + fabs((double)sA) * 4096.0, &geA);
+    (void)frexp(fabs(tB) + fabs((double)sB) * 4096.0, &geB);
+    const double GA = ldexp(1.0, geA - 20), rGA = ldexp(1.0, 20 - geA), GB = ldexp(1.0, geB - 20), rGB = ldexp(1.0, 20 - geB);
+    const double tAq = rint(tA * rGA) * GA, tBq = rint(tB * rGB) * GB, sAq = rint((double)sA * rGA) * GA, sBq = rint((double)sB * rGB) * GB;
+    const float tAh = (float)tAq, tAl = (float)(tA - tAq), sAh = (float)sAq, sAl = (float)((double)sA - sAq);
+    const float tBh = (float)tBq, tBl = (float)(tB - tBq), sBh = (float)sBq, sBl = (float)((double)sB - sBq);
     cf a[16];
 #pragma unroll
     for (int q = 0; q < 16; ++q) {
         const float jf = (float)(u + 256 * q);
-        const float va = fmaf(-c2l, jf, fmaf(-c2h, jf, xa[q] - tAh) - tAl);
-        const float vb = fmaf(-c2l, jf, fmaf(-c2h, jf, xb[q] - tBh) - tBl);
+        const float va = fmaf(-sAl, jf, fmaf(-sAh, jf, xa[q] - tAh) - tAl);
+        const float vb = fmaf(-sBl, jf, fmaf(-sBh, jf, xb[q] - tBh) - tBl);
         a[q] = mk<float>(va * (wx[q] * wA), vb * (wx[q] * wB));
     }
     fft4096_group(a, u, mine, p.tw);
@@ -223,6 +266,16 @@ __global__ void __launch_bounds__(1024) fast4096_cols_kernel(Fast4096 p) {
     }
     for (long long T = first; T < ntiles; T += per_round) {
         const int slab = (int)(T / XRFT_F4096_TILES), tile = (int)(T - (long long)slab * XRFT_F4096_TILES);
+        if (p.detrend) {  // add back wy[i] * (row fit - plane fit) in the spectral domain (see fast4096_rows_kernel)
+            const cf w0 = p.what0[4 * tile + g], w1 = p.what1[4 * tile + g];
+            const float* __restrict__ cr = p.corr + ((size_t)slab * 4096 + u) * 2;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const float al = cr[512 * q], ga = cr[512 * q + 1];
+                a[q].re = fmaf(al, w0.re, fmaf(ga, w1.re, a[q].re));
+                a[q].im = fmaf(al, w0.im, fmaf(ga, w1.im, a[q].im));
+            }
+        }
         fft4096_group(a, u, mine, p.tw);
         {   // power, staged column-major [g][ky] with the conflict-free 17/16 padding
             const int k1 = u >> 4, k2 = u & 15;
@@ -297,45 +350,36 @@ __global__ void __launch_bounds__(256) fast4096_untile_kernel(Fast4096 p) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// moments of (4096 x 4096) float32 slabs with unconditional 16-byte loads: grid = (4096 / ROWS, slabs); a 256-thread
-// block reduces ROWS consecutive rows, two rows (8 independent loads per thread) at a time.
-// (Bounds-checked loads compile to one branch per load and run at 3.3 TB/s instead of ~5.5.)
+// plane fit from the per-row fits (one 256-thread block per slab, float64): a = mean(m_i), b = slope of m_i over i,
+// c = mean(s_i)  (the centred regressors of a full grid are orthogonal, so this IS the least-squares plane of
+// xrft/detrend.py:100-113).  Output: corr[i] = wy[i] * (m_i - a - b (i - 2047.5),  s_i - c).
 // ------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) slab_moments_4096_kernel(const float* in, double* acc) {
+__global__ void __launch_bounds__(256) fast4096_fit_kernel(const double* rowfit, const float* win_y, float* corr, int detrend) {
     XRFT_DYN_SMEM(smem_raw);
     double* red = reinterpret_cast<double*>(smem_raw);
-    const int b = blockIdx.y;
-    // rows are dealt to the blocks round-robin in pairs (block x takes rows 2x, 2x+1, then + 2*gridDim.x, ...), so that
-    // at any moment the resident blocks read one compact moving window of the slab: with a contiguous chunk per block the
-    // 2048 concurrent streams thrash the DRAM row buffers (3.9 TB/s instead of ~5.5)
-    const float ibar = 2047.5f, jbar = 2047.5f;
-    const F4* __restrict__ base = reinterpret_cast<const F4*>(in + (size_t)b * 4096 * 4096) + threadIdx.x;
-    double s[6] = {0, 0, 0, 0, 0, 0};
-    for (int r = 2 * blockIdx.x; r < 4096; r += 2 * gridDim.x) {
-        F4 v[2][4];
-#pragma unroll
-        for (int rr = 0; rr < 2; ++rr)
-#pragma unroll
-            for (int c = 0; c < 4; ++c) v[rr][c] = base[(size_t)(r + rr) * 1024 + 256 * c];
-#pragma unroll
-        for (int rr = 0; rr < 2; ++rr) {
-            float s0 = 0.f, sj = 0.f;
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                const float j = (float)(4 * (threadIdx.x + 256 * c)) - jbar;
-                const F4 w = v[rr][c];
-                s0 += (w.x + w.y) + (w.z + w.w);
-                sj += (w.x * j + w.y * (j + 1.f)) + (w.z * (j + 2.f) + w.w * (j + 3.f));
-            }
-            s[0] += (double)s0;
-            s[2] += (double)(((float)(r + rr) - ibar) * s0);
-            s[4] += (double)sj;
-        }
+    const int slab = blockIdx.x, tid = threadIdx.x;
+    const double* rf = rowfit + (size_t)slab * 4096 * 2;
+    double s[3] = {0.0, 0.0, 0.0};
+    for (int i = tid; i < 4096; i += 256) {
+        const double m = rf[2 * i], sl = rf[2 * i + 1];
+        s[0] += m;
+        s[1] += ((double)i - 2047.5) * m;
+        s[2] += sl;
     }
-    block_sum<6>(s, red);
-    if (threadIdx.x == 0)
-        for (int k = 0; k < 6; k += 2)
-            if (s[k] != 0.0) atomicAdd(&acc[(size_t)b * 6 + k], s[k]);
+    block_sum<3>(s, red);
+    __syncthreads();
+    if (tid == 0) { red[0] = s[0]; red[1] = s[1]; red[2] = s[2]; }
+    __syncthreads();
+    const double a = red[0] / 4096.0;
+    const double b = detrend == 2 ? red[1] / 5726622720.0 : 0.0;
+    const double c = detrend == 2 ? red[2] / 4096.0 : 0.0;
+    float* out = corr + (size_t)slab * 4096 * 2;
+    for (int i = tid; i < 4096; i += 256) {
+        const double wy = win_y[i];
+        // what the row pass subtracted is the float32-rounded row fit; what must be subtracted is the plane
+        out[2 * i] = (float)(wy * ((double)(float)rf[2 * i] - a - b * ((double)i - 2047.5)));
+        out[2 * i + 1] = (float)(wy * ((double)(float)rf[2 * i + 1] - c));
+    }
 }
 
 }  // namespace xrft

@@ -159,11 +159,13 @@ struct xrfthip_plan {
     std::vector<Pass> passes;     // main pipeline (field 1 for CROSS)
     std::vector<Pass> passes_f0;  // CROSS: field 0 -> raw F0 buffer
     // workspace layout (byte offsets)
-    size_t off_acc = 0, off_coef = 0, off_w = 0, off_w2 = 0, off_f0 = 0, off_pt = 0, ws_bytes = 0;
+    size_t off_acc = 0, off_coef = 0, off_w = 0, off_w2 = 0, off_f0 = 0, off_pt = 0, off_rowfit = 0, off_corr = 0, ws_bytes = 0;
     std::string desc_text;
     // specialised path for (4096, 4096) float32 power spectra (fast4096.h)
     bool fast4096 = false;
-    DevBuf tw4096, ones4096, zero_coef;
+    DevBuf tw4096, ones4096, what0, what1;
+    bool what_dirty = true;
+    std::vector<double> host_win_x;
     // optional per-pass event timing (bench only)
     bool prof = false;
     struct ProfRec { std::string label; hipEvent_t a, b; };
@@ -597,6 +599,8 @@ static void layout_workspace(xrfthip_plan* P) {
     P->off_w2 = off; if (need_w2) off = al(off + (size_t)G * d.ny * d.nx * P->csize);
     P->off_f0 = off; if (nf == 2) off = al(off + (size_t)G * slab_w);
     P->off_pt = off; if (P->fast4096) off = al(off + (size_t)G * 512 * XRFT_F4096_TILES * 8 * sizeof(F4));
+    P->off_rowfit = off; if (P->fast4096) off = al(off + (size_t)G * 4096 * 2 * sizeof(double));
+    P->off_corr = off; if (P->fast4096) off = al(off + (size_t)G * 4096 * 2 * sizeof(float));
     P->ws_bytes = off;
 }
 
@@ -635,33 +639,66 @@ static int run_moments(const xrfthip_plan* P, const void* in, long long g0, long
     return XRFTHIP_OK;
 }
 
-// (4096, 4096) float32 power spectrum: [moments -> coefficients ->] row pass -> column pass, per group of slabs
-static int run_fast4096(const xrfthip_plan* P, const float* in, float* out, char* ws, double* acc, double* coef, hipStream_t st) {
+// host-side radix-2 FFT (float64) for the two 4096-point window spectra the fused detrend needs
+static void host_fft_pow2(std::vector<double>& re, std::vector<double>& im) {
+    const size_t n = re.size();
+    for (size_t i = 1, j = 0; i < n; ++i) {
+        size_t bit = n >> 1;
+        for (; j & bit; bit >>= 1) j ^= bit;
+        j ^= bit;
+        if (i < j) { std::swap(re[i], re[j]); std::swap(im[i], im[j]); }
+    }
+    for (size_t len = 2; len <= n; len <<= 1) {
+        const double ang = -2.0 * 3.14159265358979323846264338327950288 / (double)len;
+        for (size_t i = 0; i < n; i += len)
+            for (size_t k = 0; k < len / 2; ++k) {
+                const double wr = cos(ang * (double)k), wi = sin(ang * (double)k);
+                const size_t a = i + k, b = i + k + len / 2;
+                const double xr = re[b] * wr - im[b] * wi, xi = re[b] * wi + im[b] * wr;
+                re[b] = re[a] - xr; im[b] = im[a] - xi;
+                re[a] += xr; im[a] += xi;
+            }
+    }
+}
+
+static int fast4096_window_spectra(xrfthip_plan* P) {
+    std::vector<double> r0(4096), i0(4096, 0.0), r1(4096), i1(4096, 0.0);
+    for (int j = 0; j < 4096; ++j) {
+        const double w = P->host_win_x.empty() ? 1.0 : P->host_win_x[(size_t)j];
+        r0[j] = w;
+        r1[j] = w * ((double)j - 2047.5);
+    }
+    host_fft_pow2(r0, i0);
+    host_fft_pow2(r1, i1);
+    std::vector<cf> h0(2052), h1(2052);
+    for (int k = 0; k < 2052; ++k) {
+        h0[k].re = k <= 2048 ? (float)r0[k] : 0.f; h0[k].im = k <= 2048 ? (float)i0[k] : 0.f;
+        h1[k].re = k <= 2048 ? (float)r1[k] : 0.f; h1[k].im = k <= 2048 ? (float)i1[k] : 0.f;
+    }
+    int rc = P->what0.upload(h0.data(), h0.size() * sizeof(cf));
+    if (!rc) rc = P->what1.upload(h1.data(), h1.size() * sizeof(cf));
+    if (!rc) P->what_dirty = false;
+    return rc;
+}
+
+// (4096, 4096) float32 power spectrum: row pass (detrend fused) -> [plane fit] -> column pass -> untile, per group of slabs
+static int run_fast4096(const xrfthip_plan* P, const float* in, float* out, char* ws, hipStream_t st) {
     const xrfthip_desc& d = P->d;
-    const bool det = acc != nullptr;
     for (long long g0 = 0; g0 < d.batch; g0 += P->G) {
         const long long gc = std::min<long long>(P->G, d.batch - g0);
-        const float* gin = in + (size_t)g0 * 4096 * 4096;
-        if (det) {
-            const int rpb = (int)env_ll("XRFTHIP_MOMENT_ROWS", 8);  // row PAIRS per block
-            xrfthip_plan::ProfRec* rec = prof_begin(P, "moments", st);
-            auto km = &slab_moments_4096_kernel;
-            XRFT_LAUNCH(km, dim3((unsigned)(2048 / rpb), (unsigned)gc), dim3(256), 6 * 256 * sizeof(double), st, gin, acc + g0 * 6);
-            prof_end(rec, st);
-            rec = prof_begin(P, "finalize_coef", st);
-            auto kf = &finalize_coef_kernel;
-            XRFT_LAUNCH(kf, dim3((unsigned)((gc + 63) / 64)), dim3(64), 0, st, (const double*)(acc + g0 * 6), coef + g0 * 6, gc, 4096LL, 4096LL, (int)d.detrend);
-            prof_end(rec, st);
-        }
         Fast4096 p{};
-        p.in = gin;
+        p.in = in + (size_t)g0 * 4096 * 4096;
         p.w = reinterpret_cast<cf*>(ws + P->off_w);
         p.pt = reinterpret_cast<float*>(ws + P->off_pt);
         p.out = out + (size_t)g0 * 4096 * 4096;
         p.tw = reinterpret_cast<const cf*>(P->tw4096.p);
         p.win_y = reinterpret_cast<const float*>(P->win[0].p ? P->win[0].p : P->ones4096.p);
         p.win_x = reinterpret_cast<const float*>(P->win[1].p ? P->win[1].p : P->ones4096.p);
-        p.coef = det ? coef + g0 * 6 : reinterpret_cast<const double*>(P->zero_coef.p) + g0 * 6;
+        p.rowfit = reinterpret_cast<double*>(ws + P->off_rowfit);
+        p.corr = reinterpret_cast<const float*>(ws + P->off_corr);
+        p.what0 = reinterpret_cast<const cf*>(P->what0.p);
+        p.what1 = reinterpret_cast<const cf*>(P->what1.p);
+        p.detrend = d.detrend;
         p.nslab = (int)gc;
         p.shift_y = (d.flags & XRFTHIP_SHIFT_Y) ? 2048 : 0;
         p.shift_x = (d.flags & XRFTHIP_SHIFT_X) ? 2048 : 0;
@@ -670,6 +707,12 @@ static int run_fast4096(const xrfthip_plan* P, const float* in, float* out, char
         auto kr = &fast4096_rows_kernel;
         XRFT_LAUNCH(kr, dim3((unsigned)(1024 * gc)), dim3(512), 2 * XRFT_F4096_LDS * sizeof(cf), st, p);
         prof_end(rec, st);
+        if (d.detrend) {
+            rec = prof_begin(P, "fast4096_fit", st);
+            auto kf = &fast4096_fit_kernel;
+            XRFT_LAUNCH(kf, dim3((unsigned)gc), dim3(256), 3 * 256 * sizeof(double), st, (const double*)p.rowfit, p.win_y, (float*)(ws + P->off_corr), (int)d.detrend);
+            prof_end(rec, st);
+        }
         rec = prof_begin(P, "fast4096_cols", st);
         auto kc = &fast4096_cols_kernel;
         const long long ntiles = gc * XRFT_F4096_TILES;
@@ -803,9 +846,7 @@ int xrfthip_plan_create(xrfthip_plan** plan, const xrfthip_desc* desc) {
     if (P->fast4096) {
         int rc4 = build_twiddle<float>(P->tw4096, 4096, 4096);
         std::vector<float> ones(4096, 1.0f);
-        std::vector<double> zc((size_t)std::max<int64_t>(d.batch, 1) * 6, 0.0);
         if (!rc4) rc4 = P->ones4096.upload(ones.data(), ones.size() * sizeof(float));
-        if (!rc4) rc4 = P->zero_coef.upload(zc.data(), zc.size() * sizeof(double));
         if (rc4) { delete P; return rc4; }
     }
     set_kernel_attrs_once();
@@ -826,6 +867,10 @@ int xrfthip_plan_destroy(xrfthip_plan* plan) {
 int xrfthip_plan_set_window(xrfthip_plan* plan, int axis, const double* h_window, int64_t n) {
     if (!plan || axis < 0 || axis > 1) return XRFTHIP_BAD_ARG;
     if (h_window && n != (axis == 0 ? plan->d.ny : plan->d.nx)) return XRFTHIP_BAD_ARG;
+    if (axis == 1) {
+        plan->host_win_x.assign(h_window ? h_window : nullptr, h_window ? h_window + n : nullptr);
+        plan->what_dirty = true;
+    }
     return upload_real_table(plan, plan->win[axis], h_window, n, 0);
 }
 
@@ -889,7 +934,7 @@ int xrfthip_plan_describe(const xrfthip_plan* plan, char* buf, size_t buflen) {
             d.ndim, (long long)d.batch, (long long)d.ny, (long long)d.nx, d.dtype, d.out_mode, d.detrend, d.flags,
             plan->width, plan->nx_out, (int)plan->mirror, plan->G, plan->ws_bytes);
     if (plan->fast4096)
-        appendf(s, "  [fast4096] moments(f32x4) -> rows: 512 thr, 2x(2 real rows -> 1 complex FFT4096 r16x16x16), lds=%zuB, tiled W[slab][513][4096][4] -> cols: 1024 thr, 4 columns/tile, lds=%zuB, persistent, line-tiled |F|^2 -> untile+shift+mirror: 256 thr, 8 rows\n",
+        appendf(s, "  [fast4096] rows: 512 thr (row-local detrend fused), 2x(2 real rows -> 1 complex FFT4096 r16x16x16), lds=%zuB, tiled W[slab][513][4096][4] -> cols: 1024 thr, 4 columns/tile, lds=%zuB, persistent, line-tiled |F|^2 -> untile+shift+mirror: 256 thr, 8 rows\n",
                 2 * XRFT_F4096_LDS * sizeof(cf), 4 * XRFT_F4096_LDS * sizeof(cf));
     describe_passes(s, plan->passes_f0, "f0");
     describe_passes(s, plan->passes, "main");
@@ -921,7 +966,10 @@ int xrfthip_exec(const xrfthip_plan* plan, const void* d_in0, const void* d_in1,
     double* coef = (double*)(ws + P->off_coef);
     if (det) HIP_TRY(hipMemsetAsync(acc, 0, (size_t)d.batch * 6 * sizeof(double) * (cross ? 2 : 1), st));
     if (iso) HIP_TRY(hipMemsetAsync(d_iso, 0, (size_t)d.batch * P->nbins * (cross ? 16 : 8), st));
-    if (P->fast4096) return run_fast4096(P, (const float*)d_in0, (float*)d_out, ws, det ? acc : nullptr, coef, st);
+    if (P->fast4096) {
+        if (P->what_dirty) { int rcw = fast4096_window_spectra(const_cast<xrfthip_plan*>(P)); if (rcw) return rcw; }
+        return run_fast4096(P, (const float*)d_in0, (float*)d_out, ws, st);
+    }
     for (long long g0 = 0; g0 < d.batch; g0 += P->G) {
         const long long gc = std::min<long long>(P->G, d.batch - g0);
         int rc;
