@@ -61,7 +61,8 @@ typedef enum xrfthip_dtype { /* dtype of the input array; the arithmetic runs in
 typedef enum xrfthip_out_mode {
     XRFTHIP_OUT_COMPLEX = 0, /* F                    -> complex (c64 | c128)          xrft.fft            */
     XRFTHIP_OUT_POWER = 1,   /* |F|^2 * scale        -> real    (f32 | f64)           xrft.power_spectrum */
-    XRFTHIP_OUT_CROSS = 2    /* F0 conj(F1) * scale  -> complex                       xrft.cross_spectrum */
+    XRFTHIP_OUT_CROSS = 2,   /* F0 conj(F1) * scale  -> complex                       xrft.cross_spectrum */
+    XRFTHIP_OUT_PHASE = 3    /* arg(F0 conj(F1))     -> real, in [-pi, pi]            xrft.cross_phase (xrft.py:838-874) */
 } xrfthip_out_mode;
 
 typedef enum xrfthip_detrend_kind {
@@ -81,6 +82,10 @@ typedef enum xrfthip_detrend_kind {
 #define XRFTHIP_REALDIM_X2 0x080u /* with HALF_X and POWER|CROSS: multiply by [1,2,...,2,(1)] (xrft.py:673-682) */
 #define XRFTHIP_ISO 0x100u      /* radial bin-sum of the POWER|CROSS result into d_iso (needs a bin map) */
 #define XRFTHIP_NO_SPECTRUM_OUT 0x200u /* with ISO: do not write the full spectrum (d_out may be NULL) */
+/* inverse transforms (xrft.ifft, xrft.py:479-646); complex input, out_mode COMPLEX */
+#define XRFTHIP_INVERSE 0x400u   /* ifftn: conj(FFT(conj(z))); the caller folds 1/prod(N) into `scale` */
+#define XRFTHIP_C2R_X 0x800u     /* irfftn: d_in0 is [batch][ny][nx/2+1] complex, Hermitian-extended on the fly; d_out is REAL [batch][ny][nx] */
+#define XRFTHIP_PHASE_IN 0x1000u /* the phase tables multiply the INPUT (indexed by source position) instead of the output (xrft.py:574-576) */
 
 typedef struct xrfthip_desc {
     uint32_t struct_size; /* = sizeof(xrfthip_desc) */

@@ -47,7 +47,10 @@ import scipy.signal as sps
 __all__ = [
     "OArr",
     "fft",
+    "ifft",
     "dft",
+    "idft",
+    "cross_phase",
     "detrend",
     "power_spectrum",
     "cross_spectrum",
@@ -69,7 +72,8 @@ class OArr:
     ``arange(n)`` (cf. ``test_xrft.py:34-45`` "nocoords").
     """
 
-    def __init__(self, values, dims, coords=None, attrs=None, coord_attrs=None, name=None):
+    def __init__(self, values, dims, coords=None, attrs=None, coord_attrs=None, name=None, chunks=None):
+        self.chunks = chunks  # {dim: tuple of chunk lengths} -- stands in for dask chunking (metadata only)
         self.values = np.asarray(values)
         self.dims = tuple(dims)
         assert self.values.ndim == len(self.dims), (self.values.shape, self.dims)
@@ -108,7 +112,18 @@ class OArr:
 
     def replace(self, values=None, dims=None):
         return OArr(self.values if values is None else values, self.dims if dims is None else dims,
-                    self._coords_raw(), self.attrs, self.coord_attrs, self.name)
+                    self._coords_raw(), self.attrs, self.coord_attrs, self.name, self.chunks)
+
+    def chunk(self, spec):
+        """``da.chunk({dim: n})``: record equal-ish chunks of length n along dim (metadata only, like dask)."""
+        ch = dict(self.chunks or {})
+        for d, n in spec.items():
+            N = self.shape[self.get_axis_num(d)]
+            n = int(n)
+            ch[d] = tuple([n] * (N // n) + ([N % n] if N % n else []))
+        r = self.replace()
+        r.chunks = ch
+        return r
 
     def __repr__(self):
         return f"OArr(shape={self.shape}, dims={self.dims}, coords={list(self.coords)})"
@@ -164,6 +179,43 @@ def _freq(N, delta_x, real, shift):
     if shift:
         k = [np.fft.fftshift(l) for l in k]
     return k
+
+
+def _ifreq(N, delta_x, real, shift):
+    """xrft.py:158-175."""
+    if real is None:
+        fftfreq = [np.fft.fftfreq] * len(N)
+    else:
+        irfftfreq = lambda Nx, dx: np.fft.fftfreq(2 * (Nx - 1), dx)
+        fftfreq = [np.fft.fftfreq] * (len(N) - 1)
+        fftfreq.append(irfftfreq)
+    k = [f(Nx, dx) for (f, Nx, dx) in zip(fftfreq, N, delta_x)]
+    if shift:
+        k = [np.fft.fftshift(l) for l in k]
+    return k
+
+
+def _stack_chunks(da, dim, suffix="_segment"):
+    """xrft.py:106-136: reshape every chunked transform dimension d into (d_segment, d)."""
+    newdims, newshape, newcoords = [], [], {}
+    for d in da.dims:
+        if d in dim:
+            ch = (da.chunks or {}).get(d) or (da.shape[da.get_axis_num(d)],)
+            if np.diff(ch).sum() != 0:
+                raise ValueError("Chunk lengths need to be the same.")
+            n = len(da.coord(d))
+            chunklen = ch[0]
+            coord_rs = da.coord(d).reshape((int(n / chunklen), int(chunklen)))
+            newdims += [d + suffix, d]
+            newshape += [int(n / chunklen), int(chunklen)]
+            newcoords[d + suffix] = np.arange(int(n / chunklen))
+            newcoords[d] = coord_rs[0]
+        else:
+            newdims.append(d)
+            newshape.append(da.shape[da.get_axis_num(d)])
+            if d in da.coords:
+                newcoords[d] = da.coords[d][1]
+    return OArr(da.values.reshape(newshape), newdims, newcoords, da.attrs)
 
 
 def _diff_coord(coord):
@@ -262,8 +314,8 @@ def detrend(da, dim, detrend_type="constant"):
 # fft / dft  (reference: xrft/xrft.py:237-250, 307-476)
 # --------------------------------------------------------------------------------------------------
 def fft(da, spacing_tol=1e-3, dim=None, real_dim=None, shift=True, detrend=None, window=None,
-        true_phase=True, true_amplitude=True, prefix="freq_", real=None):
-    """xrft.py:307-476, without the dask-only ``chunks_to_segments`` branch."""
+        true_phase=True, true_amplitude=True, chunks_to_segments=False, prefix="freq_", real=None):
+    """xrft.py:307-476 (``chunks_to_segments`` uses the chunk metadata of OArr.chunk())."""
     _detrend_kind = detrend
     if dim is None:
         dim = list(da.dims)
@@ -283,6 +335,11 @@ def fft(da, spacing_tol=1e-3, dim=None, real_dim=None, shift=True, detrend=None,
 
     if not np.all([_is_valid_fft_coord(da.coord(d)) for d in dim]):  # xrft.py:277-281
         raise ValueError("All transformed dimensions coordinates must be numerical or datetime.")
+
+    if chunks_to_segments:  # xrft.py:390-391
+        da = _stack_chunks(da, dim)
+    elif da.chunks and any(len(da.chunks.get(d, (0,))) > 1 for d in dim):
+        raise ValueError("dask.array.fft refuses to transform along an axis that has more than one chunk")
 
     rawdims = da.dims
     if real_dim is not None:  # xrft.py:395-396
@@ -363,6 +420,96 @@ def dft(da, dim=None, true_phase=False, true_amplitude=False, **kwargs):
     warnings.warn("This function has been renamed and will disappear in the future. Please use `fft` instead",
                   FutureWarning)
     return fft(da, dim=dim, true_phase=true_phase, true_amplitude=true_amplitude, **kwargs)
+
+
+def ifft(daft, spacing_tol=1e-3, dim=None, real_dim=None, shift=True, true_phase=True, true_amplitude=True,
+         chunks_to_segments=False, prefix="freq_", lag=None, real=None):
+    """xrft.py:479-646."""
+    if dim is None:
+        dim = list(daft.dims)
+    elif isinstance(dim, str):
+        dim = [dim]
+    else:
+        dim = list(dim)
+    if real is not None:
+        real_dim = real
+        warnings.warn("`real` flag will be deprecated", FutureWarning)
+    if real_dim is not None:
+        if real_dim not in daft.dims:
+            raise ValueError("The dimension along which real IFT is taken must be one of the existing dimensions.")
+        dim = move_to_end(dim, real_dim)
+    if not np.all([_is_valid_fft_coord(daft.coord(d)) for d in dim]):
+        raise ValueError("All transformed dimensions coordinates must be numerical or datetime.")
+    if lag is None:  # xrft.py:557-560
+        lag = [daft.coord_attrs.get(d, {}).get("direct_lag", 0.0) for d in dim]
+        warnings.warn("Default ifft's behaviour (lag=None) changed!", FutureWarning)
+    else:
+        if isinstance(lag, float) or isinstance(lag, int):
+            lag = [lag]
+        if len(dim) != len(lag):
+            raise ValueError("dim and lag must have the same length.")
+        if not true_phase:
+            warnings.warn("Setting lag with true_phase=False does not guarantee accurate ifft.", Warning)
+        lag = [daft.coord_attrs.get(d, {}).get("direct_lag") if l is None else l for d, l in zip(dim, lag)]
+    v = daft.values
+    if true_phase:  # xrft.py:574-576
+        for d, l in zip(dim, lag):
+            v = v * _broadcast_1d(np.exp(1j * 2.0 * np.pi * daft.coord(d) * l), daft, d)
+        daft = daft.replace(values=v)
+    if chunks_to_segments:
+        daft = _stack_chunks(daft, dim)
+    rawdims = daft.dims
+    if real_dim is not None:
+        daft = daft.transpose(*move_to_end(list(daft.dims), real_dim))
+    fft_fn = np.fft.ifftn if real_dim is None else np.fft.irfftn
+    axis_num = [daft.get_axis_num(d) for d in dim]
+    N = [daft.shape[n] for n in axis_num]
+    # daft.sortby(dim): sort by the coordinates (handles fftshifted grids), xrft.py:598
+    vals = daft.values
+    coords = daft._coords_raw()
+    for d in dim:
+        order = np.argsort(daft.coord(d), kind="stable")
+        vals = np.take(vals, order, axis=daft.get_axis_num(d))
+        coords[d] = ((d,), daft.coord(d)[order])
+    daft = OArr(vals, daft.dims, coords, daft.attrs, daft.coord_attrs, daft.name)
+    delta_x = [_get_coordinate_spacing(daft.coord(d), spacing_tol, d) for d in dim]
+    for d in dim:  # xrft.py:600-606
+        l = _lag_coord(daft.coord(d)) if d is not real_dim else daft.coord(d)[0]
+        if np.abs(l) > spacing_tol:
+            raise ValueError("Inverse Fourier Transform can not be computed because coordinate %s is not centered "
+                             "on zero frequency" % d)
+    axis_shift = [daft.get_axis_num(d) for d in dim if d is not real_dim]
+    f = np.fft.ifftshift(daft.values, axes=axis_shift)
+    f = fft_fn(f, axes=axis_num)
+    if not true_phase:
+        f = np.fft.ifftshift(f, axes=axis_num)
+    if shift:
+        f = np.fft.fftshift(f, axes=axis_num)
+    k = _ifreq(N, delta_x, real_dim, shift)
+    swap, new_coords, cattrs = {}, {}, {}
+    for d, kk in zip(dim, k):
+        new_name = prefix + d if d[: len(prefix)] != prefix else d[len(prefix):]
+        swap[d] = new_name
+        new_coords[new_name] = kk
+        cattrs[new_name] = {"spacing": kk[1] - kk[0]}
+    out_dims = tuple(swap.get(d, d) for d in daft.dims)
+    kept = {c: (tuple(swap.get(x, x) for x in cd), cv) for c, (cd, cv) in daft.coords.items() if c not in dim}
+    for d, l in zip(dim, lag):  # xrft.py:634-639
+        tfd = swap[d]
+        kept[tfd] = ((tfd,), new_coords[tfd] + l)
+    if true_amplitude:  # xrft.py:641-642
+        f = f / np.prod([float(cattrs[up]["spacing"]) for up in swap.values()])
+    other_attrs = {c: a for c, a in daft.coord_attrs.items() if c not in dim}
+    other_attrs.update(cattrs)
+    da = OArr(f, out_dims, kept, None, other_attrs, None)
+    return da.transpose(*[swap.get(d, d) for d in rawdims])
+
+
+def idft(daft, dim=None, true_phase=False, true_amplitude=False, **kwargs):
+    """xrft.py:253-266."""
+    warnings.warn("This function has been renamed and will disappear in the future. Please use `ifft` instead",
+                  FutureWarning)
+    return ifft(daft, dim=dim, true_phase=true_phase, true_amplitude=true_amplitude, **kwargs)
 
 
 # --------------------------------------------------------------------------------------------------
@@ -450,6 +597,15 @@ def cross_spectrum(da1, da2, dim=None, real_dim=None, scaling="density", window_
     updated_dims = [d for d in daft1.dims if (d not in da1.dims and "segment" not in d)]
     cs = daft1.replace(values=daft1.values * np.conj(daft2.values))  # xrft.py:825
     return _spectrum_tail(da1, cs, dim, real_dim, scaling, window_correction, kwargs.get("window"), updated_dims)
+
+
+def cross_phase(da1, da2, dim=None, true_phase=True, **kwargs):
+    """xrft.py:838-874."""
+    cs = cross_spectrum(da1, da2, dim=dim, true_phase=true_phase, **kwargs)
+    cp = cs.replace(values=np.angle(cs.values))
+    if da1.name and da2.name:
+        cp.name = "{}_{}_phase".format(da1.name, da2.name)
+    return cp
 
 
 # --------------------------------------------------------------------------------------------------

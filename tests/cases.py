@@ -208,3 +208,105 @@ def run_true_phase_case(dtype, seed=2):
     da, od = pair(v2, ("y", "x"), c)
     e2 = check(xa.fft(da), o.fft(od), TOL[dtype])
     return max(e1, e2)
+
+
+# ---- widened rows: ifft / idft, cross_phase, chunks_to_segments ---------------------------------
+def run_inverse_cases(dtype="float64"):
+    """xrft.ifft / idft against the oracle (xrft.py:479-646) and as round trips (test_xrft.py:1253-1312)."""
+    cdt = "complex128" if dtype == "float64" else "complex64"
+    tol = TOL[dtype]
+    rng = np.random.default_rng(8)
+    errs = []
+    # 1-D complex round trip, shifted and unshifted spectra (test_ifft_fft)
+    N = 20
+    v = (rng.random(N) + 1j * rng.random(N)).astype(cdt)
+    s, so = pair(v, ("x",), {"x": np.arange(0, N)})
+    for sh in (True, False):
+        F, Fo = xa.fft(s, shift=sh), o.fft(so, shift=sh)
+        errs.append(check(xa.ifft(F, shift=True), o.ifft(Fo, shift=True), tol))
+        assert np.abs(xa.ifft(F, shift=True).values - v).max() < 50 * tol
+    # idft(dft) with explicit and automatic lag (test_idft_dft)
+    N, dx = 40, 0.37
+    v = (rng.random(N) + 1j * rng.random(N)).astype(cdt)
+    x = dx * (np.arange(-N // 2, -N // 2 + N) + 7)
+    s, so = pair(v, ("x",), {"x": x})
+    F, Fo = xa.dft(s, true_phase=True, true_amplitude=True), o.dft(so, true_phase=True, true_amplitude=True)
+    lagv = float(x[N // 2])
+    errs.append(check(xa.idft(F, shift=True, true_phase=True, true_amplitude=True, lag=lagv),
+                      o.idft(Fo, shift=True, true_phase=True, true_amplitude=True, lag=lagv), tol))
+    back = xa.idft(F, shift=True, true_phase=True, true_amplitude=True)
+    assert np.abs(back.values - v).max() < 50 * tol and np.allclose(back["x"].values, x)
+    # 2-D complex, batch, odd x odd sizes, default arguments
+    v = (rng.standard_normal((3, 9, 15)) + 1j * rng.standard_normal((3, 9, 15))).astype(cdt)
+    c = {"t": np.arange(3), "y": np.arange(9) * 0.5 - 2, "x": np.arange(15) * 0.25 + 1}
+    s, so = pair(v, ("t", "y", "x"), c)
+    F, Fo = xa.fft(s, dim=["y", "x"]), o.fft(so, dim=["y", "x"])
+    errs.append(check(xa.ifft(F, dim=["freq_y", "freq_x"]), o.ifft(Fo, dim=["freq_y", "freq_x"]), tol))
+    assert np.abs(xa.ifft(F, dim=["freq_y", "freq_x"]).values - v).max() < 100 * tol
+    # real_dim: rfft -> irfft (the half spectrum is Hermitian-extended on the device)
+    v = rng.standard_normal((2, 8, 12)).astype(dtype)
+    c = {"t": np.arange(2), "y": np.arange(8) * 0.5, "x": np.arange(12) * 0.25}
+    s, so = pair(v, ("t", "y", "x"), c)
+    F, Fo = (f(a, dim=["y"], real_dim="x", true_phase=False, true_amplitude=False) for f, a in ((xa.fft, s), (o.fft, so)))
+    kw = dict(dim=["freq_y"], real_dim="freq_x", true_phase=False, true_amplitude=False, lag=[0.0, 0.0], shift=True)
+    errs.append(check(xa.ifft(F, **kw), o.ifft(Fo, **kw), tol))
+    assert np.abs(xa.ifft(F, **kw).values - v).max() < 100 * tol
+    # not centred on zero frequency -> ValueError (test_idft_centered_coordinates)
+    import pytest
+    bad, _ = pair((rng.random(20) + 0j).astype(cdt), ("freq_x",), {"freq_x": np.arange(-10, 10) + 2})
+    with pytest.raises(ValueError):
+        xa.idft(bad)
+    return max(errs)
+
+
+def run_cross_phase_cases(dtype="float64"):
+    """xrft.cross_phase (xrft.py:838-874; test_xrft.py:606-690)."""
+    tol = 1e-9 if dtype == "float64" else 2e-3  # the angle of a near-zero cross spectrum amplifies rounding
+    N = 32
+    x = np.linspace(0, 1, num=N, endpoint=False)
+    f, po = 6, np.pi / 2
+    a1 = xa.DataArray(np.cos(2 * np.pi * f * x).astype(dtype), ("x",), {"x": x}, name="a")
+    a2 = xa.DataArray(np.cos(2 * np.pi * f * x - po).astype(dtype), ("x",), {"x": x}, name="b")
+    cp = xa.cross_phase(a1, a2, dim=["x"])
+    assert cp.name == "a_b_phase" and cp.dims == ("freq_x",)
+    i = int(np.argmin(np.abs(cp["freq_x"].values - f)))
+    assert abs(float(cp.values[i]) - po) < (1e-6 if dtype == "float64" else 1e-3)
+    rng = np.random.default_rng(4)
+    shape = (2, 12, 10)
+    v1, v2 = rng.standard_normal(shape).astype(dtype), rng.standard_normal(shape).astype(dtype)
+    c1 = _coords3(shape)
+    c2 = _coords3(shape, y0=1.5, x0=-4.0)
+    d1, o1 = pair(v1, D3, c1)
+    d2, o2 = pair(v2, D3, c2)
+    got = xa.cross_phase(d1, d2, dim=["y", "x"], true_phase=True, window="hann")
+    ref = o.cross_phase(o1, o2, dim=["y", "x"], true_phase=True, window="hann")
+    assert got.dims == ref.dims
+    d = np.angle(np.exp(1j * (got.values - ref.values)))  # compare angles modulo 2 pi
+    assert np.abs(d).max() < tol, np.abs(d).max()
+    return float(np.abs(d).max())
+
+
+def run_segment_cases(dtype="float64"):
+    """chunks_to_segments (xrft.py:106-136, 390-391; test_xrft.py:273-337): the chunk length is metadata here."""
+    import pytest
+    tol = TOL[dtype]
+    rng = np.random.default_rng(12)
+    N = 32
+    v = rng.random((N, N, N)).astype(dtype)
+    c = {"time": np.arange(N), "y": np.arange(N), "x": np.arange(N)}
+    da, od = pair(v, D3, c)
+    ft = xa.fft(da.chunk({"time": 16}), dim=["time"], shift=False, chunks_to_segments=True)
+    assert ft.dims == ("time_segment", "freq_time", "y", "x")
+    e1 = check(ft, o.fft(od.chunk({"time": 16}), dim=["time"], shift=False, chunks_to_segments=True), tol)
+    ft2 = xa.fft(da.chunk({"y": 16, "x": 16}), dim=["y", "x"], shift=False, chunks_to_segments=True)
+    assert ft2.dims == ("time", "y_segment", "freq_y", "x_segment", "freq_x")
+    e2 = check(ft2, o.fft(od.chunk({"y": 16, "x": 16}), dim=["y", "x"], shift=False, chunks_to_segments=True), tol)
+    ps = xa.power_spectrum(da.chunk({"y": 16, "x": 16}), dim=["y", "x"], window="hann", window_correction=True,
+                           chunks_to_segments=True)
+    e3 = check(ps, o.power_spectrum(od.chunk({"y": 16, "x": 16}), dim=["y", "x"], window="hann", window_correction=True,
+                                    chunks_to_segments=True), tol)
+    with pytest.raises(ValueError):
+        xa.fft(da.chunk({"time": 20}), dim=["time"], detrend="linear", chunks_to_segments=True)
+    with pytest.raises(ValueError):  # several chunks along a transform dim without chunks_to_segments (test_xrft.py:166-170)
+        xa.fft(da.chunk({"x": 1}), dim=["x"])
+    return max(e1, e2, e3)

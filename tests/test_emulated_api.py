@@ -141,3 +141,18 @@ def test_fast4096_path(shift, det, win):
     g = ps.values[0].astype(np.float64)
     assert np.abs(g - ref).max() / ref.max() < 2e-5
     assert np.abs(g - ref).sum() / ref.sum() < 5e-6
+
+
+@pytest.mark.parametrize("dtype", ["float64", "float32"])
+def test_inverse_transforms(dtype):
+    cases.run_inverse_cases(dtype)
+
+
+@pytest.mark.parametrize("dtype", ["float64", "float32"])
+def test_cross_phase(dtype):
+    cases.run_cross_phase_cases(dtype)
+
+
+@pytest.mark.parametrize("dtype", ["float64", "float32"])
+def test_chunks_to_segments(dtype):
+    cases.run_segment_cases(dtype)

@@ -235,3 +235,18 @@ def test_isotropic_slope_minus3():
     assert np.isfinite(m).all()
     _, a, _ = xa.fit_loglog(iso["freq_r"].values[:-35], m[:-35])
     np.testing.assert_allclose(a, -3.0, atol=0.06)
+
+
+@pytest.mark.parametrize("dtype", ["float64", "float32"])
+def test_inverse_transforms(dtype):
+    cases.run_inverse_cases(dtype)
+
+
+@pytest.mark.parametrize("dtype", ["float64", "float32"])
+def test_cross_phase(dtype):
+    cases.run_cross_phase_cases(dtype)
+
+
+@pytest.mark.parametrize("dtype", ["float64", "float32"])
+def test_chunks_to_segments(dtype):
+    cases.run_segment_cases(dtype)

@@ -349,3 +349,47 @@ def test_detrend_removes_injected_trend():
     npt.assert_allclose(l1, sps.detrend(noise, axis=2))
     with pytest.raises(NotImplementedError):
         o.detrend(da0, ["y", "x"], "quadratic")
+
+
+def test_ifft_round_trips():
+    """test_xrft.py:1253-1312"""
+    rng = np.random.default_rng(21)
+    N = 20
+    s = o.OArr(rng.random(N) + 1j * rng.random(N), ("x",), {"x": np.arange(0, N)})
+    for sh in (True, False):
+        npt.assert_allclose(o.ifft(o.fft(s, shift=sh), shift=True).values, s.values, atol=1e-14)
+    N, dx = 40, 0.37
+    x = dx * (np.arange(-N // 2, -N // 2 + N) + 7)
+    s = o.OArr(rng.random(N) + 1j * rng.random(N), ("x",), {"x": x})
+    F = o.dft(s, true_phase=True, true_amplitude=True)
+    for lag in (float(x[N // 2]), None):
+        kw = {} if lag is None else {"lag": lag}
+        back = o.idft(F, shift=True, true_phase=True, true_amplitude=True, **kw)
+        npt.assert_allclose(back.values, s.values, atol=1e-13)
+        npt.assert_allclose(back.coord("x"), x, atol=1e-12)
+    with pytest.raises(ValueError):
+        o.idft(o.OArr(rng.random(20) + 0j, ("freq_x",), {"freq_x": np.arange(-10, 10) + 2}))
+
+
+def test_cross_phase_and_segments():
+    """test_xrft.py:606-634, 273-337"""
+    N = 32
+    x = np.linspace(0, 1, num=N, endpoint=False)
+    f, po = 6, np.pi / 2
+    a = o.OArr(np.cos(2 * np.pi * f * x), ("x",), {"x": x}, name="a")
+    b = o.OArr(np.cos(2 * np.pi * f * x - po), ("x",), {"x": x}, name="b")
+    cp = o.cross_phase(a, b, dim=["x"])
+    npt.assert_almost_equal(cp.values[np.argmin(np.abs(cp.coord("freq_x") - f))], po)
+    assert cp.name == "a_b_phase"
+    rng = np.random.default_rng(22)
+    da = o.OArr(rng.random((N, N, N)), ("time", "y", "x"), {"time": np.arange(N), "y": np.arange(N), "x": np.arange(N)})
+    ft = o.fft(da.chunk({"time": 16}), dim=["time"], shift=False, chunks_to_segments=True)
+    assert ft.dims == ("time_segment", "freq_time", "y", "x")
+    npt.assert_almost_equal(ft.values, np.fft.fftn(da.values.reshape((2, 16, N, N)), axes=[1]), decimal=7)
+    ft = o.fft(da.chunk({"y": 16, "x": 16}), dim=["y", "x"], shift=False, chunks_to_segments=True)
+    assert ft.dims == ("time", "y_segment", "freq_y", "x_segment", "freq_x")
+    npt.assert_almost_equal(ft.values, np.fft.fftn(da.values.reshape((N, 2, 16, 2, 16)), axes=[2, 4]), decimal=7)
+    ps = o.power_spectrum(da.chunk({"y": 16, "x": 16}), dim=["y", "x"], shift=False, density=False, chunks_to_segments=True)
+    npt.assert_almost_equal(ps.values, (ft.values * np.conj(ft.values)).real)
+    with pytest.raises(ValueError):
+        o.fft(da.chunk({"time": 20}), dim=["time"], detrend="linear", chunks_to_segments=True)

@@ -10,7 +10,7 @@ Deviations from the reference, all documented in DESIGN.md:
   * float32 input is computed and returned in float32/complex64 (the reference promotes to float64 as soon as a
     float64 window or ``prod(dx)`` touches the data); isotropic results are returned in float64/complex128;
   * at most two transform dimensions (the reference also offers 3-D linear detrend / N-D fftn);
-  * ``chunks_to_segments`` needs dask chunks in the reference; here it is not implemented yet.
+  * ``chunks_to_segments`` takes its segment length from ``DataArray.chunk({dim: n})`` metadata (no dask here).
 """
 from __future__ import annotations
 
@@ -26,8 +26,8 @@ from pandas.api.types import is_datetime64_any_dtype, is_numeric_dtype
 from . import _lib, engine
 from .labeled import Coordinate, DataArray, from_any, to_like
 
-__all__ = ["fft", "dft", "detrend", "power_spectrum", "cross_spectrum", "isotropize", "isotropic_power_spectrum",
-           "isotropic_cross_spectrum", "fit_loglog"]
+__all__ = ["fft", "ifft", "dft", "idft", "detrend", "power_spectrum", "cross_spectrum", "cross_phase", "isotropize",
+           "isotropic_power_spectrum", "isotropic_cross_spectrum", "fit_loglog"]
 
 _WINDOW_NAMES = [  # xrft.py:48-72
     "hann", "hamming", "kaiser", "tukey", "parzen", "taylor", "boxcar", "barthann", "bartlett", "blackman",
@@ -50,6 +50,46 @@ def _freq(N, delta_x, real, shift):
     if shift:
         k = [np.fft.fftshift(l) for l in k]
     return k
+
+
+def _ifreq(N, delta_x, real, shift):
+    """xrft.py:158-175."""
+    if real is None:
+        fftfreq = [np.fft.fftfreq] * len(N)
+    else:
+        fftfreq = [np.fft.fftfreq] * (len(N) - 1)
+        fftfreq.append(lambda Nx, dx: np.fft.fftfreq(2 * (Nx - 1), dx))
+    k = [f(Nx, dx) for (f, Nx, dx) in zip(fftfreq, N, delta_x)]
+    if shift:
+        k = [np.fft.fftshift(l) for l in k]
+    return k
+
+
+def _stack_chunks(da, dim, suffix="_segment"):
+    """xrft.py:106-136: reshape every chunked transform dimension d into (d_segment, d) -- a view, no copy."""
+    newdims, newshape, newcoords = [], [], {}
+    chunks = da._chunks or {}
+    for d in da.dims:
+        if d in dim:
+            ch = chunks.get(d) or (da.sizes[d],)
+            if np.diff(ch).sum() != 0:
+                raise ValueError("Chunk lengths need to be the same.")
+            n = da.sizes[d]
+            chunklen = int(ch[0])
+            coord_rs = np.asarray(da[d].values).reshape((int(n / chunklen), chunklen))
+            newdims += [d + suffix, d]
+            newshape += [int(n / chunklen), chunklen]
+            newcoords[d + suffix] = np.arange(int(n / chunklen))
+            newcoords[d] = coord_rs[0]
+        else:
+            newdims.append(d)
+            newshape.append(da.sizes[d])
+            if d in da.coords:
+                newcoords[d] = da.coords[d]
+    data = da.data
+    if isinstance(data, torch.Tensor) and not data.is_contiguous():
+        data = data.contiguous()
+    return DataArray(data.reshape(newshape), newdims, newcoords, da.name, da.attrs)
 
 
 def _diff_coord(coord):
@@ -178,9 +218,13 @@ def _analyze(da, spacing_tol, dim, real_dim, shift, detrend, window, true_phase,
         da.get_axis_num(d)
     if not np.all([_is_valid_fft_coord(da[d].values) for d in dim]):  # xrft.py:277-281
         raise ValueError("All transformed dimensions coordinates must be numerical or datetime.")
-    if chunks_to_segments:
-        raise NotImplementedError("chunks_to_segments relies on dask chunks in the reference; not implemented "
-                                  "in xrft_amd yet (reshape the segmented dimension explicitly instead).")
+    c.corr_N = [da.sizes[d] for d in dim]  # window_correction uses the UNsegmented lengths (xrft.py:747 -> :654)
+    if chunks_to_segments:  # xrft.py:390-391
+        da = _stack_chunks(da, dim)
+    elif da._chunks and any(len(da._chunks.get(d, (0,))) > 1 for d in dim):
+        raise ValueError("The transform dimension(s) are split into several chunks; dask.array.fft refuses that "
+                         "(use chunks_to_segments=True or rechunk).")
+    c.da = da
     if real_dim is not None:
         shift = False  # xrft.py:403
     c.rawdims = da.dims
@@ -326,6 +370,7 @@ def fft(da, spacing_tol=1e-3, dim=None, real_dim=None, shift=True, detrend=None,
     src = da
     da = from_any(da)
     c = _analyze(da, spacing_tol, dim, real_dim, shift, detrend, window, true_phase, chunks_to_segments, prefix, real)
+    da = c.da
     scale = np.prod(c.delta_x) if true_amplitude else 1.0  # xrft.py:471-472
     out, _, other = _execute(c, da, _lib.OUT_COMPLEX, scale)
     extra = None
@@ -339,6 +384,170 @@ def dft(da, dim=None, true_phase=False, true_amplitude=False, **kwargs):
     warnings.warn("This function has been renamed and will disappear in the future. Please use `fft` instead",
                   FutureWarning)
     return fft(da, dim=dim, true_phase=true_phase, true_amplitude=true_amplitude, **kwargs)
+
+
+def ifft(daft, spacing_tol=1e-3, dim=None, real_dim=None, shift=True, true_phase=True, true_amplitude=True,
+         chunks_to_segments=False, prefix="freq_", lag=None, real=None):
+    """Inverse discrete Fourier transform (reference: xrft/xrft.py:479-646; same arguments).  The input phase factor,
+    the coordinate sort / ifftshift, the conjugate-FFT-conjugate inverse, the 1/N and 1/prod(dk) factors and (for
+    ``real_dim``) the Hermitian extension of the half spectrum are fused into one device plan."""
+    src = daft
+    daft = from_any(daft)
+    if dim is None:
+        dim = list(daft.dims)
+    elif isinstance(dim, str):
+        dim = [dim]
+    else:
+        dim = list(dim)
+    if real is not None:
+        real_dim = real
+        warnings.warn(_real_flag_warning, FutureWarning)
+    if real_dim is not None:
+        if real_dim not in daft.dims:
+            raise ValueError("The dimension along which real IFT is taken must be one of the existing dimensions.")
+        dim = _move_to_end(dim, real_dim)
+    for d in dim:
+        daft.get_axis_num(d)
+    if not np.all([_is_valid_fft_coord(daft[d].values) for d in dim]):
+        raise ValueError("All transformed dimensions coordinates must be numerical or datetime.")
+    if lag is None:  # xrft.py:557-560
+        lag = [daft[d].attrs.get("direct_lag", 0.0) for d in dim]
+        warnings.warn("Default ifft's behaviour (lag=None) changed! Default value of lag was zero (centered output "
+                      "coordinates) and is now set to transformed coordinate's attribute: 'direct_lag'.", FutureWarning)
+    else:
+        if isinstance(lag, float) or isinstance(lag, int):
+            lag = [lag]
+        if len(dim) != len(lag):
+            raise ValueError("dim and lag must have the same length.")
+        if not true_phase:
+            warnings.warn("Setting lag with true_phase=False does not guarantee accurate ifft.", Warning)
+        lag = [daft[d].attrs.get("direct_lag") if l is None else l for d, l in zip(dim, lag)]
+    if len(dim) > 2 or len(dim) == 0:
+        raise NotImplementedError("xrft_amd transforms one or two dimensions per call")
+    # input phase factors, indexed by SOURCE position (xrft.py:574-576; applied before any reordering)
+    phase = {d: (np.exp(1j * 2.0 * np.pi * np.asarray(daft[d].values, dtype=np.float64) * l) if true_phase else None)
+             for d, l in zip(dim, lag)}
+    if chunks_to_segments:
+        daft = _stack_chunks(daft, dim)
+    rawdims = daft.dims
+    N = [daft.sizes[d] for d in dim]
+    # sortby(dim) + ifftshift (xrft.py:598, 612-614) expressed as an index map of the engine: ascending coordinates ->
+    # ISHIFT, descending -> FLIP + ISHIFT, the unshifted layout (fftshift(sort) == identity) -> nothing
+    coords_sorted, maps = {}, {}
+    for d, n in zip(dim, N):
+        cv = np.asarray(daft[d].values)
+        order = np.argsort(cv, kind="stable")
+        coords_sorted[d] = cv[order]
+        if d == real_dim:
+            if not np.array_equal(order, np.arange(n)):
+                raise ValueError("the real dimension's frequency coordinate must be ascending (rfftfreq order)")
+            maps[d] = "none"
+            continue
+        want = order[(np.arange(n) + n // 2) % n]  # source index feeding unshifted position m
+        if np.array_equal(want, np.arange(n)):
+            maps[d] = "none"
+        elif np.array_equal(order, np.arange(n)):
+            maps[d] = "ishift"
+        elif np.array_equal(order, np.arange(n)[::-1]):
+            maps[d] = "flip_ishift"
+        else:
+            maps[d] = want  # arbitrary permutation: gather on the device first
+    delta_x = [_get_coordinate_spacing(coords_sorted[d], spacing_tol, d) for d in dim]
+    for d in dim:  # xrft.py:600-606
+        l = _lag_coord(coords_sorted[d]) if d is not real_dim else coords_sorted[d][0]
+        if np.abs(l) > spacing_tol:
+            raise ValueError("Inverse Fourier Transform can not be computed because coordinate %s is not centered on "
+                             "zero frequency" % d)
+    k = _ifreq(N, delta_x, real_dim, shift)  # xrft.py:623
+    swap, new_coords = OrderedDict(), {}
+    for d, kk in zip(dim, k):
+        new_name = prefix + d if d[: len(prefix)] != prefix else d[len(prefix):]
+        swap[d] = new_name
+        new_coords[new_name] = Coordinate((new_name,), kk, {"spacing": kk[1] - kk[0]} if len(kk) > 1 else {}, new_name)
+    # device layout: x = real dim if given, else the later axis
+    if len(dim) == 1:
+        ydim, xdim = None, dim[0]
+    elif real_dim is not None:
+        ydim, xdim = dim[0], dim[1]
+    else:
+        a0, a1 = daft.get_axis_num(dim[0]), daft.get_axis_num(dim[1])
+        ydim, xdim = (dim[0], dim[1]) if a0 < a1 else (dim[1], dim[0])
+    t = _to_device(daft.data)
+    if not t.is_complex():
+        t = t.to(torch.complex64 if t.dtype == torch.float32 else torch.complex128)
+    tdims = ([ydim] if ydim is not None else []) + [xdim]
+    other = [d for d in daft.dims if d not in tdims]
+    order_dims = other + tdims
+    if tuple(order_dims) != tuple(daft.dims):
+        t = t.permute([daft.get_axis_num(d) for d in order_dims])
+    flags = _lib.INVERSE
+    ph = {"y": None, "x": None}
+    for d in dim:
+        ax = "x" if d == xdim else "y"
+        m = maps[d]
+        p = phase[d]
+        if isinstance(m, np.ndarray):  # gather to the unshifted layout on the device; the phase follows the data
+            axis = t.dim() - 1 if ax == "x" else t.dim() - 2
+            idx = torch.from_numpy(m.astype(np.int64)).to(t.device)
+            t = torch.index_select(t, axis, idx)
+            p = None if p is None else p[m]
+        elif m == "ishift":
+            flags |= _lib.ISHIFT_X if ax == "x" else _lib.ISHIFT_Y
+        elif m == "flip_ishift":
+            flags |= (_lib.ISHIFT_X | _lib.FLIP_X) if ax == "x" else (_lib.ISHIFT_Y | _lib.FLIP_Y)
+        if p is not None:
+            ph[ax] = p
+            flags |= _lib.PHASE_IN
+        # output: "if not true_phase: ifftshift" then "if shift: fftshift" (xrft.py:617-621) -- for even N the two cancel;
+        # the engine's output shift is fftshift, so the remaining cases are: only fftshift, or only ifftshift (odd N differs)
+    t = t.contiguous()
+    out_shift = {}
+    post_roll = []
+    for d, n in zip(dim, N if real_dim is None else N[:-1] + [2 * (N[-1] - 1)]):
+        ax = "x" if d == xdim else "y"
+        if true_phase:
+            if shift:
+                flags |= _lib.SHIFT_X if ax == "x" else _lib.SHIFT_Y
+        else:
+            if shift and n % 2 == 0:
+                pass  # ifftshift followed by fftshift is the identity for even n
+            elif shift:
+                pass  # odd n: roll(-(n//2)) then roll(+n//2) is also the identity
+            else:
+                post_roll.append((ax, -(n // 2)))  # only the ifftshift remains
+    nx_in = daft.sizes[xdim]
+    nx = 2 * (nx_in - 1) if real_dim is not None else nx_in
+    ny = daft.sizes[ydim] if ydim is not None else 1
+    if real_dim is not None:
+        flags |= _lib.C2R_X
+    batch = t.numel() // max(ny * nx_in, 1)
+    nprod = float(nx) * float(ny)
+    scale = 1.0 / nprod
+    if true_amplitude:  # xrft.py:641-642
+        scale = scale / np.prod([float(new_coords[swap[d]].attrs["spacing"]) for d in dim])
+    plan = _get_plan(ndim=len(dim), batch=batch, ny=ny, nx=nx, dtype=t.dtype, out_mode=_lib.OUT_COMPLEX,
+                     detrend=_lib.DETREND_NONE, flags=flags, scale=float(scale), window_y=None, window_x=None,
+                     phase_y=ph["y"], phase_x=ph["x"])
+    out, _ = plan.execute(t)
+    out = out.reshape([daft.sizes[d] for d in other] + list(out.shape[-len(tdims):]))
+    for ax, sh in post_roll:
+        out = torch.roll(out, shifts=sh, dims=out.dim() - 1 if ax == "x" else out.dim() - 2)
+    cur = other + [swap[d] for d in tdims]
+    final = [swap.get(d, d) for d in rawdims]
+    if cur != final:
+        out = out.permute([cur.index(d) for d in final])
+    coords = {kname: v for kname, v in daft.coords.items() if kname not in dim}
+    for d, l in zip(dim, lag):  # xrft.py:634-639 (keep_attrs: the spacing attribute survives the shift by lag)
+        cv = new_coords[swap[d]]
+        coords[swap[d]] = Coordinate(cv.dims, cv.values + l, cv.attrs, swap[d])
+    return to_like(DataArray(out, final, coords, None, None), src)
+
+
+def idft(daft, dim=None, true_phase=False, true_amplitude=False, **kwargs):
+    """Deprecated alias of ``ifft`` with numpy-like defaults (xrft/xrft.py:253-266)."""
+    warnings.warn("This function has been renamed and will disappear in the future. Please use `ifft` instead",
+                  FutureWarning)
+    return ifft(daft, dim=dim, true_phase=true_phase, true_amplitude=true_amplitude, **kwargs)
 
 
 def detrend(da, dim, detrend_type="constant"):
@@ -378,8 +587,9 @@ def _window_correction_factor(c, scaling, window):
     """xrft.py:649-660: mean(w^2) (density) or mean(w)^2 (spectrum) of the outer-product window."""
     if window is None:
         raise ValueError("window_correction can only be applied when windowing is turned on.")
-    w = c.windows[0]
-    for v in c.windows[1:]:
+    vecs = [_window_vector(window, n) for n in c.corr_N]
+    w = vecs[0]
+    for v in vecs[1:]:
         w = np.multiply.outer(w, v)
     if scaling == "density":
         return (w ** 2).mean()
@@ -450,8 +660,8 @@ def power_spectrum(da, dim=None, real_dim=None, scaling="density", window_correc
     src = da
     da = from_any(da)
     c, _, mode, scale, flags = _spectrum(da, None, dim, real_dim, scaling, window_correction, False, dict(kwargs))
-    out, _, other = _execute(c, da, mode, scale, extra_flags=flags)
-    return to_like(_label_output(c, da, out, other), src)
+    out, _, other = _execute(c, c.da, mode, scale, extra_flags=flags)
+    return to_like(_label_output(c, c.da, out, other), src)
 
 
 def cross_spectrum(da1, da2, dim=None, real_dim=None, scaling="density", window_correction=False, true_phase=True,
@@ -460,11 +670,31 @@ def cross_spectrum(da1, da2, dim=None, real_dim=None, scaling="density", window_
     src = da1
     da1, da2 = from_any(da1), from_any(da2)
     c, c2, mode, scale, flags = _spectrum(da1, da2, dim, real_dim, scaling, window_correction, true_phase, dict(kwargs))
-    out, _, other = _execute(c, da1, mode, scale, da2=da2, c2=c2, extra_flags=flags)
+    return to_like(_cross_result(c, c2, mode, scale, flags), src)
+
+
+def _cross_result(c, c2, mode, scale, flags):
+    out, _, other = _execute(c, c.da, mode, scale, da2=c2.da, c2=c2, extra_flags=flags)
     extra = None
     if c.true_phase:  # the product keeps daft1's coordinates, including their direct_lag attribute (xrft.py:469, 825)
         extra = {c.swap[d]: {"direct_lag": lag} for d, lag in zip(c.dim, c.lag_x)}
-    return to_like(_label_output(c, da1, out, other, extra), src)
+    return _label_output(c, c.da, out, other, extra)
+
+
+def cross_phase(da1, da2, dim=None, true_phase=True, **kwargs):
+    """Cross phase arg(F(da1') conj(F(da2'))) in [-pi, pi] (xrft/xrft.py:838-874); the angle is taken in the
+    epilogue of the cross-spectrum kernel, the complex cross spectrum is never written."""
+    src = da1
+    da1, da2 = from_any(da1), from_any(da2)
+    kw = dict(kwargs)
+    real_dim = kw.pop("real_dim", None)
+    scaling = kw.pop("scaling", "density")
+    window_correction = kw.pop("window_correction", False)
+    c, c2, mode, scale, flags = _spectrum(da1, da2, dim, real_dim, scaling, window_correction, true_phase, kw)
+    cp = _cross_result(c, c2, _lib.OUT_PHASE, abs(scale) if scale != 0 else 1.0, flags & ~_lib.REALDIM_X2)
+    if da1.name and da2.name:
+        cp.name = "{}_{}_phase".format(da1.name, da2.name)
+    return to_like(cp, src)
 
 
 # ------------------------------------------------------------------------------------------------------
@@ -554,7 +784,8 @@ def _iso_spectrum(da, da2, spacing_tol, dim, shift, detrend_, scaling, window, w
     # reference bins over (fftdim[1], fftdim[0]); the edges depend only on min/max of the same set of radii,
     # and kr (a per-bin mean of the same multiset) is identical up to summation order
     iso_cfg = {"binmap": codes_yx, "nbins": nb}
-    out, iso, other = _execute(c, da, mode, scale, da2=da2, c2=c2, iso=iso_cfg,
+    da = c.da
+    out, iso, other = _execute(c, da, mode, scale, da2=None if c2 is None else c2.da, c2=c2, iso=iso_cfg,
                                extra_flags=flags | _lib.ISO | _lib.NO_SPECTRUM_OUT)
     vals = iso.reshape([da.sizes[d] for d in other] + [nb]).cpu().numpy()
     kr, vals = _finish_iso(kr, kk, ll, truncate, vals)

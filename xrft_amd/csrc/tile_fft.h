@@ -135,6 +135,11 @@ struct Prologue {  // first pass: xrft.py:425-442
     const void* win_y;
     const void* win_x;
     const double* coef;  // [slab][6]: c0.re c0.im c1.re c1.im c2.re c2.im ; trend = c0 + c1*i + c2*j (source indices)
+    // inverse transforms (xrft.ifft): complex input only
+    const void* ph_y;    // complex tables multiplying the input, indexed by source position (nullable)
+    const void* ph_x;
+    int conj_in;         // conjugate after the phase multiply (ifft = conj(FFT(conj z)) / N)
+    int herm_nxh;        // > 0: the source row holds only kx = 0..herm_nxh-1; kx >= herm_nxh is conj(src[-ky][nx-kx]) (irfftn)
 };
 
 struct Epilogue {  // last pass: xrft.py:446-472, 740-748, 825-833, 993-1004
@@ -146,6 +151,7 @@ struct Epilogue {  // last pass: xrft.py:446-472, 740-748, 825-833, 993-1004
     int mirror;    // real input, full output: also store the Hermitian mirror (ny-ky, nx-kx)
     int shift_y, shift_x;
     int realdim_x2;
+    int conj_out, real_out;  // inverse transforms: conjugate the result / store only its real part
     long long slab_stride, row_stride;  // output strides in elements
     double scale;
     void* out;  // may be null (iso only)
@@ -177,8 +183,14 @@ __device__ __forceinline__ int shift_dst(int k, int n, int shift) {
 // ------------------------------------------------------------------------------------------------
 template <typename T>
 __device__ __forceinline__ C2<T> fetch_src(const Prologue& pr, long long b, int i, int j) {
+    bool herm = false;
+    if (pr.herm_nxh > 0 && j >= pr.herm_nxh) {  // irfftn: F[ky, kx] = conj(F[-ky, nx - kx]) for the half that is not stored
+        j = pr.nx - j;
+        i = i == 0 ? 0 : pr.ny - i;
+        herm = true;
+    }
     const int si = map_src(i, pr.ny, pr.flip_y, pr.ishift_y);
-    const int sj = map_src(j, pr.nx, pr.flip_x, pr.ishift_x);
+    const int sj = map_src(j, pr.herm_nxh > 0 ? pr.herm_nxh : pr.nx, pr.flip_x, pr.ishift_x);
     const long long off = b * pr.slab_stride + (long long)si * pr.row_stride + sj;
     C2<T> v;
     if (pr.in_complex) v = reinterpret_cast<const C2<T>*>(pr.in)[off];
@@ -192,6 +204,9 @@ __device__ __forceinline__ C2<T> fetch_src(const Prologue& pr, long long b, int 
     if (pr.win_y) w = reinterpret_cast<const T*>(pr.win_y)[si];
     if (pr.win_x) w *= reinterpret_cast<const T*>(pr.win_x)[sj];
     if (pr.win_y || pr.win_x) v = cscale(v, w);
+    if (pr.ph_y) v = cmul(v, reinterpret_cast<const C2<T>*>(pr.ph_y)[si]);
+    if (pr.ph_x) v = cmul(v, reinterpret_cast<const C2<T>*>(pr.ph_x)[sj]);
+    if (herm != (pr.conj_in != 0)) v.im = -v.im;
     return v;
 }
 
@@ -209,9 +224,11 @@ __device__ __forceinline__ void emit(const Epilogue& ep, long long b, int ky, in
     T s = (T)ep.scale;
     if (ep.realdim_x2 && !(kx == 0 || ((ep.nx & 1) == 0 && kx == ep.nx / 2))) s *= (T)2;
     V = cscale(V, s);
+    if (ep.conj_out) V.im = -V.im;
     if (ep.out) {
         const long long off = b * ep.slab_stride + (long long)shift_dst(ky, ep.ny, ep.shift_y) * ep.row_stride + shift_dst(kx, ep.nx, ep.shift_x);
-        if (ep.mode == 1) reinterpret_cast<T*>(ep.out)[off] = V.re;
+        if (ep.mode == 3) reinterpret_cast<T*>(ep.out)[off] = (T)atan2((double)V.im, (double)V.re);  // np.angle
+        else if (ep.mode == 1 || ep.real_out) reinterpret_cast<T*>(ep.out)[off] = V.re;
         else reinterpret_cast<C2<T>*>(ep.out)[off] = V;
     }
     if (hist) {
@@ -233,7 +250,7 @@ __device__ __forceinline__ void epi_store(const Epilogue& ep, long long o, long 
     C2<T> V;
     if (ep.mode == 0) V = F;
     else if (ep.mode == 1) V = mk<T>(F.re * F.re + F.im * F.im, (T)0);
-    else {
+    else {  // CROSS (2) and PHASE (3)
         const C2<T> G = reinterpret_cast<const C2<T>*>(ep.other)[b * ep.other_slab_stride + (long long)ky * ep.other_row_stride + kx];
         V = cmulc(G, F);  // F0 * conj(F1): `other` holds field 0, this pass transforms field 1
     }

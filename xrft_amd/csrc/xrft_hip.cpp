@@ -269,6 +269,12 @@ struct Builder {
         pr.ishift_x = !!(d.flags & XRFTHIP_ISHIFT_X);
         pr.slab_stride = d.ny * d.nx;
         pr.row_stride = d.nx;
+        pr.conj_in = !!(d.flags & XRFTHIP_INVERSE);
+        if (d.flags & XRFTHIP_C2R_X) {
+            pr.herm_nxh = (int)(d.nx / 2 + 1);
+            pr.row_stride = d.nx / 2 + 1;
+            pr.slab_stride = d.ny * (d.nx / 2 + 1);
+        }
         ps.first = true;
         ps.in_kind = B_IN;
     }
@@ -300,6 +306,8 @@ struct Builder {
             ep.shift_y = !!(d.flags & XRFTHIP_SHIFT_Y);
             ep.shift_x = !!(d.flags & XRFTHIP_SHIFT_X);
             ep.realdim_x2 = !!(d.flags & XRFTHIP_REALDIM_X2);
+            ep.conj_out = !!(d.flags & XRFTHIP_INVERSE);
+            ep.real_out = !!(d.flags & XRFTHIP_C2R_X);
             ep.slab_stride = d.ny * P.nx_out;
             ep.row_stride = P.nx_out;
             ep.other_slab_stride = d.ny * P.width;
@@ -506,7 +514,7 @@ int build_plan_t(xrfthip_plan& P) {
     Builder<T> B(P);
     int rc = B.build_pipeline(P.passes, false);
     if (rc) return rc;
-    if (P.d.out_mode == XRFTHIP_OUT_CROSS) rc = B.build_pipeline(P.passes_f0, true);
+    if (P.d.out_mode == XRFTHIP_OUT_CROSS || P.d.out_mode == XRFTHIP_OUT_PHASE) rc = B.build_pipeline(P.passes_f0, true);
     return rc;
 }
 
@@ -580,7 +588,7 @@ static void layout_workspace(xrfthip_plan* P) {
     size_t slab_w = (size_t)d.ny * P->width * P->csize;
     if (P->fast4096) {
         slab_w = (size_t)XRFT_F4096_TILES * 4096 * 4 * sizeof(cf);
-        if (G <= 0) G = env_ll("XRFTHIP_FAST_GROUP", 8);
+        if (G <= 0) G = env_ll("XRFTHIP_FAST_GROUP", 32);  // measured 8: 197, 16: 210, 32: 214 GFFT/s (tails and launch gaps amortise)
     }
     if (G <= 0) {
         const size_t target = (size_t)env_ll("XRFTHIP_GROUP_BYTES", 64LL << 20);
@@ -589,7 +597,7 @@ static void layout_workspace(xrfthip_plan* P) {
     G = std::max<long long>(1, std::min<long long>(G, std::max<long long>(d.batch, 1)));
     P->G = (int)G;
     auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
-    const int nf = d.out_mode == XRFTHIP_OUT_CROSS ? 2 : 1;
+    const int nf = (d.out_mode == XRFTHIP_OUT_CROSS || d.out_mode == XRFTHIP_OUT_PHASE) ? 2 : 1;
     size_t off = 0;
     P->off_acc = off; off = al(off + (size_t)d.batch * 6 * sizeof(double) * nf);
     P->off_coef = off; off = al(off + (size_t)d.batch * 6 * sizeof(double) * nf);
@@ -747,11 +755,12 @@ static int run_pipeline(const xrfthip_plan* P, const std::vector<Pass>& passes, 
             }
         };
         if (p.first) {
-            p.pr.in = (const char*)in + (size_t)g0 * d.ny * d.nx * in_esz;
+            p.pr.in = (const char*)in + (size_t)g0 * d.ny * ((d.flags & XRFTHIP_C2R_X) ? d.nx / 2 + 1 : d.nx) * in_esz;
             p.pr.win_y = P->win[0].p;
             p.pr.win_x = P->win[1].p;
             p.pr.coef = coef ? coef + g0 * 6 : nullptr;
             if (!coef) p.pr.detrend = 0;
+            if (d.flags & XRFTHIP_PHASE_IN) { p.pr.ph_y = P->phase[0].p; p.pr.ph_x = P->phase[1].p; }
         } else {
             p.g.in = buf(p.in_kind);
         }
@@ -760,11 +769,10 @@ static int run_pipeline(const xrfthip_plan* P, const std::vector<Pass>& passes, 
                 p.ep.out = buf(B_F0);
                 p.ep.iso = nullptr;
             } else {
-                const size_t out_esz = d.out_mode == XRFTHIP_OUT_POWER ? P->rsize : P->csize;
+                const size_t out_esz = (d.out_mode == XRFTHIP_OUT_POWER || d.out_mode == XRFTHIP_OUT_PHASE || (d.flags & XRFTHIP_C2R_X)) ? P->rsize : P->csize;
                 p.ep.out = out ? (char*)out + (size_t)g0 * d.ny * P->nx_out * out_esz : nullptr;
-                p.ep.ph_y = P->phase[0].p;
-                p.ep.ph_x = P->phase[1].p;
-                p.ep.other = d.out_mode == XRFTHIP_OUT_CROSS ? buf(B_F0) : nullptr;
+                if (!(d.flags & XRFTHIP_PHASE_IN)) { p.ep.ph_y = P->phase[0].p; p.ep.ph_x = P->phase[1].p; }
+                p.ep.other = (d.out_mode == XRFTHIP_OUT_CROSS || d.out_mode == XRFTHIP_OUT_PHASE) ? buf(B_F0) : nullptr;
                 if (d.flags & XRFTHIP_ISO) {
                     p.ep.binmap = (const int*)P->binmap.p;
                     p.ep.nbins = P->nbins;
@@ -813,7 +821,9 @@ int xrfthip_plan_create(xrfthip_plan** plan, const xrfthip_desc* desc) {
     if (d.batch < 0 || d.nx < 1 || d.ny < 1 || (d.ndim == 1 && d.ny != 1)) return XRFTHIP_BAD_ARG;
     if (d.nx > (1LL << 30) || d.ny > (1LL << 30)) return XRFTHIP_BAD_ARG;
     if (d.dtype < XRFTHIP_F32 || d.dtype > XRFTHIP_C128) return XRFTHIP_BAD_ARG;
-    if (d.out_mode < XRFTHIP_OUT_COMPLEX || d.out_mode > XRFTHIP_OUT_CROSS) return XRFTHIP_BAD_ARG;
+    if (d.out_mode < XRFTHIP_OUT_COMPLEX || d.out_mode > XRFTHIP_OUT_PHASE) return XRFTHIP_BAD_ARG;
+    if ((d.flags & (XRFTHIP_INVERSE | XRFTHIP_C2R_X | XRFTHIP_PHASE_IN)) && (d.dtype < XRFTHIP_C64 || d.out_mode != XRFTHIP_OUT_COMPLEX || d.detrend)) return XRFTHIP_BAD_ARG;
+    if ((d.flags & XRFTHIP_C2R_X) && (!(d.flags & XRFTHIP_INVERSE) || (d.nx & 1) || (d.flags & (XRFTHIP_ISHIFT_X | XRFTHIP_FLIP_X)))) return XRFTHIP_BAD_ARG;
     if (d.detrend < XRFTHIP_DETREND_NONE || d.detrend > XRFTHIP_DETREND_LINEAR) return XRFTHIP_BAD_ARG;
     const bool cplx_in = d.dtype >= XRFTHIP_C64;
     if ((d.flags & XRFTHIP_HALF_X) && cplx_in) return XRFTHIP_BAD_ARG;
@@ -949,7 +959,7 @@ int xrfthip_exec(const xrfthip_plan* plan, const void* d_in0, const void* d_in1,
     if (!plan || !d_in0) return XRFTHIP_BAD_ARG;
     const xrfthip_plan* P = plan;
     const xrfthip_desc& d = P->d;
-    const bool cross = d.out_mode == XRFTHIP_OUT_CROSS;
+    const bool cross = d.out_mode == XRFTHIP_OUT_CROSS || d.out_mode == XRFTHIP_OUT_PHASE;
     const bool iso = (d.flags & XRFTHIP_ISO) != 0;
     if (cross && !d_in1) return XRFTHIP_BAD_ARG;
     if (!d_out && !(d.flags & XRFTHIP_NO_SPECTRUM_OUT)) return XRFTHIP_BAD_ARG;

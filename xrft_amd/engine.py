@@ -96,15 +96,17 @@ class SpectralPlan:
         return out
 
     def out_dtype(self):
-        return _REAL_OF[self.dtype] if self.out_mode == _lib.OUT_POWER else _CPLX_OF[self.dtype]
+        real = self.out_mode in (_lib.OUT_POWER, _lib.OUT_PHASE) or (self.flags & _lib.C2R_X)
+        return _REAL_OF[self.dtype] if real else _CPLX_OF[self.dtype]
 
     def execute(self, in0, in1=None, out=None, iso=None):
         """``in0``/``in1``: contiguous tensors of shape (batch, ny, nx) (any leading shape that flattens to it).
         Returns (out, iso); either may be None depending on the flags."""
         dev = in0.device
-        if in0.dtype != self.dtype or not in0.is_contiguous() or in0.numel() != self.batch * self.ny * self.nx:
+        nx_in = self.nx // 2 + 1 if (self.flags & _lib.C2R_X) else self.nx
+        if in0.dtype != self.dtype or not in0.is_contiguous() or in0.numel() != self.batch * self.ny * nx_in:
             raise ValueError("in0 does not match the plan (dtype / contiguity / size)")
-        if self.out_mode == _lib.OUT_CROSS:
+        if self.out_mode in (_lib.OUT_CROSS, _lib.OUT_PHASE):
             if in1 is None or in1.dtype != self.dtype or not in1.is_contiguous() or in1.numel() != in0.numel():
                 raise ValueError("in1 does not match the plan")
         want_out = not (self.flags & _lib.NO_SPECTRUM_OUT)

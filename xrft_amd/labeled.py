@@ -72,6 +72,7 @@ class DataArray:
             raise ValueError(f"dims {self.dims} do not match data of rank {nd}")
         self.name = name
         self.attrs = dict(attrs or {})
+        self._chunks = None  # {dim: tuple of chunk lengths}: metadata only (see .chunk)
         self.coords = {}
         if coords is not None:
             if isinstance(coords, dict):
@@ -160,8 +161,11 @@ class DataArray:
 
     # ---------------------------------------------------------------- the few transformations the API needs
     def _new(self, data, dims=None, coords=None, name=None):
-        return DataArray(data, self.dims if dims is None else dims, self.coords if coords is None else coords,
-                         self.name if name is None else name, self.attrs)
+        out = DataArray(data, self.dims if dims is None else dims, self.coords if coords is None else coords,
+                        self.name if name is None else name, self.attrs)
+        if self._chunks and (dims is None or set(out.dims) == set(self.dims)):
+            out._chunks = dict(self._chunks)
+        return out
 
     def transpose(self, *dims):
         if not dims:
@@ -216,6 +220,27 @@ class DataArray:
         keep = [d for d in self.dims if d not in dims]
         coords = {k: c for k, c in self.coords.items() if not (set(c.dims) & set(dims))}
         return DataArray(v.sum(axis=ax), keep, coords, self.name, self.attrs)
+
+    # ---------------------------------------------------------------- chunk metadata (stands in for dask chunking)
+    @property
+    def chunks(self):
+        """None, or per-axis tuples of chunk lengths like a dask-backed xarray.DataArray."""
+        if not self._chunks:
+            return None
+        return tuple(self._chunks.get(d, (n,)) for d, n in zip(self.dims, self.shape))
+
+    def chunk(self, chunks=None):
+        """``da.chunk({dim: n})`` records equal chunks of length n along dim.  xrft uses dask chunks only to define
+        Bartlett/Welch segments (``chunks_to_segments``) and to refuse transforms across chunk boundaries; the data
+        stay where they are."""
+        out = self._new(self.data)
+        ch = dict(self._chunks or {})
+        for d, n in (chunks or {}).items():
+            N = self.sizes[d]
+            n = N if n is None else int(n)
+            ch[d] = tuple([n] * (N // n) + ([N % n] if N % n else []))
+        out._chunks = ch or {d: (n,) for d, n in zip(self.dims, self.shape)}
+        return out
 
     def copy(self):
         data = self.data.clone() if _is_torch(self.data) else self.data.copy()
