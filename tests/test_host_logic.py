@@ -112,7 +112,7 @@ def test_radial_bins_match_pandas_cut():
 
     k = np.fft.fftshift(np.fft.fftfreq(32, 1.0))
     l = np.fft.fftshift(np.fft.fftfreq(16, 1.0))
-    codes, kr, nb = api._radial_bins(k, l, 4)
+    codes, kr, nb, _ = api._radial_bins(k, l, 4)
     r = np.sqrt(k[:, None] ** 2 + l[None, :] ** 2)
     ref = pd.cut(r.ravel(), 4)
     assert nb == 4 and np.array_equal(codes.ravel(), ref.codes)

@@ -182,8 +182,10 @@ def _akey(a):
     return None if a is None else hash(np.ascontiguousarray(a).tobytes())
 
 
-def _get_plan(**kw):
-    key = tuple((k, _akey(v) if isinstance(v, np.ndarray) else v) for k, v in sorted(kw.items()))
+def _get_plan(binmap_key=None, **kw):
+    # the bin map can be 16M entries: it is identified by the key of the (cached) host computation, not by its bytes
+    key = tuple((k, (binmap_key if k == "binmap" else _akey(v)) if isinstance(v, np.ndarray) else v)
+                for k, v in sorted(kw.items()))
     p = _plan_cache.get(key)
     if p is None:
         p = engine.SpectralPlan(**kw)
@@ -354,9 +356,11 @@ def _execute(c, da, mode, scale, da2=None, c2=None, iso=None, extra_flags=0):
                 t2 = torch.flip(t2, dims=[axis]).contiguous()
     kw = dict(ndim=ndim, batch=batch, ny=ny, nx=nx, dtype=t.dtype, out_mode=mode, detrend=c.detrend, flags=flags,
               scale=float(scale), window_y=win["y"], window_x=win["x"], phase_y=ph["y"], phase_x=ph["x"])
+    bkey = None
     if iso is not None:
         kw.update(binmap=iso["binmap"], nbins=iso["nbins"])
-    plan = _get_plan(**kw)
+        bkey = iso.get("binmap_key")
+    plan = _get_plan(binmap_key=bkey, **kw)
     out, iso_out = plan.execute(t, t2)
     return out, iso_out, other
 
@@ -700,12 +704,29 @@ def cross_phase(da1, da2, dim=None, true_phase=True, **kwargs):
 # ------------------------------------------------------------------------------------------------------
 # isotropic spectra (xrft.py:877-1187)
 # ------------------------------------------------------------------------------------------------------
+_bins_cache: "OrderedDict[tuple, tuple]" = OrderedDict()
+
+
 def _radial_bins(k, l, nfactor):
     """Bin codes and per-bin mean radius for the grid sqrt(k^2 + l^2), dims (k, l)  (xrft.py:975-981, 910-923).
 
     ``pd.cut`` on the float64 radii, exactly the reference's expression; the per-bin mean replaces
-    ``numpy_groupies.aggregate(func="mean", fill_value=0)``.
+    ``numpy_groupies.aggregate(func="mean", fill_value=0)``.  The result depends only on the two frequency vectors
+    and nfactor, and costs seconds of host time at 4096^2, so it is cached (the reference recomputes it per call).
     """
+    key = (k.size, l.size, hash(np.ascontiguousarray(k).tobytes()), hash(np.ascontiguousarray(l).tobytes()), nfactor)
+    hit = _bins_cache.get(key)
+    if hit is not None:
+        _bins_cache.move_to_end(key)
+        return hit
+    res = _radial_bins_uncached(k, l, nfactor) + (key,)
+    _bins_cache[key] = res
+    while len(_bins_cache) > 8:
+        _bins_cache.popitem(last=False)
+    return res
+
+
+def _radial_bins_uncached(k, l, nfactor):
     N = [k.size, l.size]
     nbins = int(min(N) / nfactor)
     freq_r = np.sqrt(k[:, None] ** 2 + l[None, :] ** 2)
@@ -738,7 +759,7 @@ def isotropize(ps, fftdim, nfactor=4, truncate=True, complx=False):
     ps = from_any(ps)
     k = np.asarray(ps[fftdim[1]].values, dtype=np.float64)
     l = np.asarray(ps[fftdim[0]].values, dtype=np.float64)
-    codes, kr, nb = _radial_bins(k, l, nfactor)  # dims (fftdim[1], fftdim[0])
+    codes, kr, nb, _ = _radial_bins(k, l, nfactor)  # dims (fftdim[1], fftdim[0])
     other = [d for d in ps.dims if d not in fftdim]
     order = other + [fftdim[1], fftdim[0]]
     t = _to_device(ps.data)
@@ -780,10 +801,10 @@ def _iso_spectrum(da, da2, spacing_tol, dim, shift, detrend_, scaling, window, w
     kx = c.k_unshifted[c.dim.index(c.xdim)]
     kk = c.new_coords[fftdim[1]].values
     ll = c.new_coords[fftdim[0]].values
-    codes_yx, kr, nb = _radial_bins(ky, kx, nfactor)
+    codes_yx, kr, nb, bkey = _radial_bins(ky, kx, nfactor)
     # reference bins over (fftdim[1], fftdim[0]); the edges depend only on min/max of the same set of radii,
     # and kr (a per-bin mean of the same multiset) is identical up to summation order
-    iso_cfg = {"binmap": codes_yx, "nbins": nb}
+    iso_cfg = {"binmap": codes_yx, "nbins": nb, "binmap_key": bkey}
     da = c.da
     out, iso, other = _execute(c, da, mode, scale, da2=None if c2 is None else c2.da, c2=c2, iso=iso_cfg,
                                extra_flags=flags | _lib.ISO | _lib.NO_SPECTRUM_OUT)

@@ -115,6 +115,8 @@ class SpectralPlan:
         if self.flags & _lib.ISO and iso is None:
             iso = torch.empty((self.batch, self.nbins), device=dev,
                               dtype=torch.complex128 if self.out_mode == _lib.OUT_CROSS else torch.float64)
+        if self.batch == 0:  # nothing to transform: empty outputs, no device call
+            return (out if want_out else None), iso
         nws = self.workspace_bytes
         if self._ws is None or self._ws.numel() < nws or self._ws.device != dev:
             self._ws = torch.empty(max(nws, 256), dtype=torch.uint8, device=dev)
