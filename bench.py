@@ -132,9 +132,20 @@ def main():
             pts_per_launch = float(nt) * ny * nx / launches_per_step
             achieved = BYTES_PER_POINT * pts_per_launch / avg_s
             kernel_ms = sum(v[1] for v in kern.values()) / args.steps
+            # HBM traffic of the dominant kernel from the committed PMC profile of this same command (rocprofv3 cannot run
+            # inside the timed process): bytes per slab x slabs per launch
+            traffic = None
+            try:
+                with open(os.path.join(REPO, "profiles", "r01_traffic.json")) as fh:
+                    tj = json.load(fh)
+                traffic = tj["kernels"][dom]["hbm_bytes_per_slab"] * (pts_per_launch / (ny * nx))
+            except Exception:
+                traffic = None
             roof = {
                 "bound": "hbm", "kernel": dom, "achieved": round(achieved / 1e9, 2), "peak": HBM_PEAK / 1e9,
-                "unit": "GB/s", "frac": round(achieved / HBM_PEAK, 4), "traffic": None,
+                "unit": "GB/s", "frac": round(achieved / HBM_PEAK, 4), "traffic": traffic,
+                "traffic_note": "HBM bytes per launch from profiles/r01_traffic.json (rocprofv3 --pmc FETCH_SIZE x2 + "
+                                "WRITE_SIZE, separate passes); algorithmic bytes per launch = 8 B x points_per_launch",
                 "avg_launch_us": round(avg_s * 1e6, 2), "points_per_launch": pts_per_launch,
                 "bytes_per_point": BYTES_PER_POINT,
                 "kernels_ms_per_step": {k: round(v[1] / args.steps, 3) for k, v in kern.items()},
