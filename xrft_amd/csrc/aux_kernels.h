@@ -31,31 +31,29 @@ __global__ void __launch_bounds__(256) slab_moments_kernel(const void* in, long 
     XRFT_DYN_SMEM(smem_raw);
     double* red = reinterpret_cast<double*>(smem_raw);
     const long long b = blockIdx.y;
-    const long long total = ny * nx;
-    const long long per = (total + gridDim.x - 1) / gridDim.x;
-    const long long e0 = (long long)blockIdx.x * per;
-    long long e1 = e0 + per;
-    if (e1 > total) e1 = total;
     const T ibar = (T)(0.5 * (double)(ny - 1)), jbar = (T)(0.5 * (double)(nx - 1));
     double s[6] = {0, 0, 0, 0, 0, 0};
-    T p[6] = {0, 0, 0, 0, 0, 0};
-    int cnt = 0;
-    for (long long e = e0 + threadIdx.x; e < e1; e += blockDim.x) {
-        const long long i = e / nx;
-        const long long j = e - i * nx;
-        const long long off = b * slab_stride + i * row_stride + j;
-        T xr, xi = (T)0;
-        if (CPLX) { C2<T> v = reinterpret_cast<const C2<T>*>(in)[off]; xr = v.re; xi = v.im; }
-        else xr = reinterpret_cast<const T*>(in)[off];
-        const T di = (T)i - ibar, dj = (T)j - jbar;
-        p[0] += xr; p[2] += di * xr; p[4] += dj * xr;
-        if (CPLX) { p[1] += xi; p[3] += di * xi; p[5] += dj * xi; }
-        if (++cnt == 64) {  // bound the length of the working-precision partial sums
-            for (int k = 0; k < 6; ++k) { s[k] += (double)p[k]; p[k] = (T)0; }
-            cnt = 0;
+    // rows are dealt round-robin to the blocks of a slab; inside a row lanes stride along j (no integer division)
+    for (long long i = blockIdx.x; i < ny; i += gridDim.x) {
+        const long long base = b * slab_stride + i * row_stride;
+        T p0r = 0, p0i = 0, pjr = 0, pji = 0;
+        int cnt = 0;
+        for (long long j = threadIdx.x; j < nx; j += blockDim.x) {
+            T xr, xi = (T)0;
+            if (CPLX) { C2<T> v = reinterpret_cast<const C2<T>*>(in)[base + j]; xr = v.re; xi = v.im; }
+            else xr = reinterpret_cast<const T*>(in)[base + j];
+            const T dj = (T)j - jbar;
+            p0r += xr; pjr += dj * xr;
+            if (CPLX) { p0i += xi; pji += dj * xi; }
+            if (++cnt == 64) {  // bound the length of the working-precision partial sums
+                s[0] += (double)p0r; s[1] += (double)p0i; s[4] += (double)pjr; s[5] += (double)pji;
+                s[2] += (double)(((T)i - ibar) * p0r); s[3] += (double)(((T)i - ibar) * p0i);
+                p0r = p0i = pjr = pji = (T)0; cnt = 0;
+            }
         }
+        s[0] += (double)p0r; s[1] += (double)p0i; s[4] += (double)pjr; s[5] += (double)pji;
+        s[2] += (double)(((T)i - ibar) * p0r); s[3] += (double)(((T)i - ibar) * p0i);
     }
-    for (int k = 0; k < 6; ++k) s[k] += (double)p[k];
     block_sum<6>(s, red);
     if (threadIdx.x == 0)
         for (int k = 0; k < 6; ++k)

@@ -23,38 +23,6 @@ typedef C2<float> cf;
 struct alignas(16) F4 { float x, y, z, w; };
 struct __attribute__((aligned(4))) F4u { float x, y, z, w; };  // 16-byte access at 4-byte alignment (mirror segments)
 
-// ------------------------------------------------------------------------------------------------
-// radix-16 butterfly, natural order in and out (4 x 4 with constant twiddles)
-// ------------------------------------------------------------------------------------------------
-template <typename T> __device__ __forceinline__ void dft16(C2<T>* a) {
-    const T c1 = (T)0.92387953251128675613, s1 = (T)0.38268343236508977173, h = (T)0.70710678118654752440;
-    C2<T> t[4][4];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {  // stage 1: DFT4 over elements q, q+4, q+8, q+12  -> t[q][m]
-        C2<T> b[4] = {a[q], a[q + 4], a[q + 8], a[q + 12]};
-        dft4(b);
-#pragma unroll
-        for (int m = 0; m < 4; ++m) t[q][m] = b[m];
-    }
-    // twiddle t[q][m] *= W16^(q m)
-    t[1][1] = mk<T>(c1 * t[1][1].re + s1 * t[1][1].im, c1 * t[1][1].im - s1 * t[1][1].re);  // W16^1
-    t[1][2] = mk<T>(h * (t[1][2].re + t[1][2].im), h * (t[1][2].im - t[1][2].re));          // W16^2
-    t[1][3] = mk<T>(s1 * t[1][3].re + c1 * t[1][3].im, s1 * t[1][3].im - c1 * t[1][3].re);  // W16^3
-    t[2][1] = mk<T>(h * (t[2][1].re + t[2][1].im), h * (t[2][1].im - t[2][1].re));          // W16^2
-    t[2][2] = mul_mi(t[2][2]);                                                              // W16^4 = -i
-    t[2][3] = mk<T>(h * (t[2][3].im - t[2][3].re), -h * (t[2][3].re + t[2][3].im));         // W16^6
-    t[3][1] = mk<T>(s1 * t[3][1].re + c1 * t[3][1].im, s1 * t[3][1].im - c1 * t[3][1].re);  // W16^3
-    t[3][2] = mk<T>(h * (t[3][2].im - t[3][2].re), -h * (t[3][2].re + t[3][2].im));         // W16^6
-    t[3][3] = mk<T>(-c1 * t[3][3].re - s1 * t[3][3].im, s1 * t[3][3].re - c1 * t[3][3].im); // W16^9 = -W16^1
-#pragma unroll
-    for (int m = 0; m < 4; ++m) {  // stage 2: DFT4 over q -> X[m + 4 p]
-        C2<T> b[4] = {t[0][m], t[1][m], t[2][m], t[3][m]};
-        dft4(b);
-#pragma unroll
-        for (int p = 0; p < 4; ++p) a[m + 4 * p] = b[p];
-    }
-}
-
 // a[k] *= w1^k for k = 1..15, powers built by a product tree of depth <= 4 (error ~ 4 ulp)
 template <typename T> __device__ __forceinline__ void twiddle16(C2<T>* a, C2<T> w1) {
     C2<T> w2 = cmul(w1, w1), w3 = cmul(w2, w1), w4 = cmul(w2, w2);

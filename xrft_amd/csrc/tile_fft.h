@@ -86,12 +86,45 @@ template <typename T> __device__ __forceinline__ void dft8(C2<T>* a) {
     for (int k = 0; k < 4; ++k) { a[2 * k] = u[k]; a[2 * k + 1] = v[k]; }
 }
 
+// ------------------------------------------------------------------------------------------------
+// radix-16 butterfly, natural order in and out (4 x 4 with constant twiddles)
+// ------------------------------------------------------------------------------------------------
+template <typename T> __device__ __forceinline__ void dft16(C2<T>* a) {
+    const T c1 = (T)0.92387953251128675613, s1 = (T)0.38268343236508977173, h = (T)0.70710678118654752440;
+    C2<T> t[4][4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {  // stage 1: DFT4 over elements q, q+4, q+8, q+12  -> t[q][m]
+        C2<T> b[4] = {a[q], a[q + 4], a[q + 8], a[q + 12]};
+        dft4(b);
+#pragma unroll
+        for (int m = 0; m < 4; ++m) t[q][m] = b[m];
+    }
+    // twiddle t[q][m] *= W16^(q m)
+    t[1][1] = mk<T>(c1 * t[1][1].re + s1 * t[1][1].im, c1 * t[1][1].im - s1 * t[1][1].re);  // W16^1
+    t[1][2] = mk<T>(h * (t[1][2].re + t[1][2].im), h * (t[1][2].im - t[1][2].re));          // W16^2
+    t[1][3] = mk<T>(s1 * t[1][3].re + c1 * t[1][3].im, s1 * t[1][3].im - c1 * t[1][3].re);  // W16^3
+    t[2][1] = mk<T>(h * (t[2][1].re + t[2][1].im), h * (t[2][1].im - t[2][1].re));          // W16^2
+    t[2][2] = mul_mi(t[2][2]);                                                              // W16^4 = -i
+    t[2][3] = mk<T>(h * (t[2][3].im - t[2][3].re), -h * (t[2][3].re + t[2][3].im));         // W16^6
+    t[3][1] = mk<T>(s1 * t[3][1].re + c1 * t[3][1].im, s1 * t[3][1].im - c1 * t[3][1].re);  // W16^3
+    t[3][2] = mk<T>(h * (t[3][2].im - t[3][2].re), -h * (t[3][2].re + t[3][2].im));         // W16^6
+    t[3][3] = mk<T>(-c1 * t[3][3].re - s1 * t[3][3].im, s1 * t[3][3].re - c1 * t[3][3].im); // W16^9 = -W16^1
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {  // stage 2: DFT4 over q -> X[m + 4 p]
+        C2<T> b[4] = {t[0][m], t[1][m], t[2][m], t[3][m]};
+        dft4(b);
+#pragma unroll
+        for (int p = 0; p < 4; ++p) a[m + 4 * p] = b[p];
+    }
+}
+
 template <typename T, int R> __device__ __forceinline__ void dft_r(C2<T>* a) {
     if (R == 2) dft2(a[0], a[1]);
     else if (R == 3) dft3(a);
     else if (R == 4) dft4(a);
     else if (R == 5) dft5(a);
     else if (R == 8) dft8(a);
+    else if (R == 16) dft16(a);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -117,6 +150,8 @@ struct TileGeom {
     const void* in;
     void* out;
     const void* tw;         // W_n^k, k < n
+    int tw_lds;             // 1: the kernel copies the table into LDS behind the tile (7 twiddle loads per radix-8 butterfly
+                            // from global memory made the passes load-issue bound)
     const unsigned* rev;    // rev[k] = LDS position of frequency k after the DIF passes
     const void* tw_r2c;     // W_{2n}^k, k <= n   (r2c unpack)
     const void* tw_big;     // four-step: W_bigN^k table, k < bigN
@@ -240,10 +275,15 @@ __device__ __forceinline__ void emit(const Epilogue& ep, long long b, int ky, in
     }
 }
 
+// (b0, r0) = (o0 / odiv, o0 % odiv) of the tile's first sequence, dt = sequence offset inside the tile: the only division
+// per element is a 32-bit one (64-bit integer division costs >100 instructions on the GPU)
 template <typename T>
-__device__ __forceinline__ void epi_store(const Epilogue& ep, long long o, long long q, int p, C2<T> F, double* hist) {
-    const long long b = o / ep.odiv;
-    const int km = (int)((o - b * ep.odiv) * ep.r_mul + q * ep.q_mul + (long long)p * ep.p_mul);
+__device__ __forceinline__ void epi_store(const Epilogue& ep, long long b0, int r0, int dt, int q, int p, C2<T> F, double* hist) {
+    const unsigned rr = (unsigned)(r0 + dt), od = (unsigned)ep.odiv;
+    const unsigned db = od == 1 ? rr : rr / od;
+    const long long b = b0 + db;
+    const int r = (int)(rr - db * od);
+    const int km = (int)(r * (int)ep.r_mul + q * (int)ep.q_mul + p * (int)ep.p_mul);
     int ky, kx;
     if (ep.p_axis) { ky = km; kx = (int)q; } else { ky = 0; kx = km; }
     if (kx >= ep.nx_out && !ep.mirror) return;  // full-complex path of a real input with HALF_X
@@ -264,13 +304,12 @@ __device__ __forceinline__ void epi_store(const Epilogue& ep, long long o, long 
 // ------------------------------------------------------------------------------------------------
 // radix passes
 // ------------------------------------------------------------------------------------------------
-template <typename T, int R>
-__device__ __forceinline__ void run_pass(C2<T>* tile, const TileGeom& g, int L, int tid, int nthreads) {
+template <typename T, int R, typename TWP>
+__device__ __forceinline__ void run_pass(C2<T>* tile, const TileGeom& g, int L, int tid, int nthreads, TWP tw) {
     const int m = L / R;
     const int per_seq = g.n / R;
     const int nb = g.T * per_seq;
     const int twstep = g.n / L;
-    const C2<T>* __restrict__ tw = reinterpret_cast<const C2<T>*>(g.tw);
     for (int w = tid; w < nb; w += nthreads) {
         const int t = w / per_seq;
         const int gg = w - t * per_seq;
@@ -284,7 +323,7 @@ __device__ __forceinline__ void run_pass(C2<T>* tile, const TileGeom& g, int L, 
         dft_r<T, R>(a);
         if (m > 1) {
 #pragma unroll
-            for (int k = 1; k < R; ++k) a[k] = cmul(a[k], tw[(long long)j * k * twstep]);
+            for (int k = 1; k < R; ++k) a[k] = cmul(a[k], tw[j * k * twstep]);
         }
 #pragma unroll
         for (int k = 0; k < R; ++k) s[phys(base + k * m, g.pad_shift)] = a[k];
@@ -342,6 +381,16 @@ __global__ void __launch_bounds__(1024) tile_fft_kernel(TileGeom g, Prologue pr,
     }
     const C2<T>* __restrict__ gin = reinterpret_cast<const C2<T>*>(g.in);
     C2<T>* __restrict__ gout = reinterpret_cast<C2<T>*>(g.out);
+    const C2<T>* __restrict__ twg = reinterpret_cast<const C2<T>*>(g.tw);
+    C2<T>* twl = nullptr;
+    if (g.tw_lds) {
+        size_t off = (size_t)g.T * g.seq_stride * sizeof(C2<T>);
+        off = (off + 15) & ~(size_t)15;
+        if (FINAL && ep.iso) off += (size_t)ep.nbins * (ep.mode == 2 ? 16 : 8);
+        off = (off + 15) & ~(size_t)15;
+        twl = reinterpret_cast<C2<T>*>(smem_raw + off);
+        for (int i = tid; i < g.n; i += nthreads) twl[i] = twg[i];
+    }
 
     for (long long tile_id = blockIdx.x; tile_id < g.n_tiles; tile_id += gridDim.x) {
         long long o0, q0;
@@ -354,8 +403,13 @@ __global__ void __launch_bounds__(1024) tile_fft_kernel(TileGeom g, Prologue pr,
             q0 = (tile_id - o0 * g.tiles_per_outer) * g.T;
             long long rem = g.inner - q0; tv = rem < g.T ? (int)rem : g.T;
         }
+        // per-tile 64-bit divisions (once); everything per element is 32-bit
+        long long pb0 = 0, eb0 = 0;
+        int pi0 = 0, er0 = 0;
+        if (FIRST) { pb0 = o0 / pr.rows; pi0 = (int)(o0 - pb0 * pr.rows); }
+        if (FINAL) { eb0 = o0 / ep.odiv; er0 = (int)(o0 - eb0 * ep.odiv); }
         if (hist) {  // flush the LDS histogram when this block moves on to another slab
-            const long long slab = (g.tile_axis == 0 ? o0 : o0) / ep.odiv;
+            const long long slab = eb0;
             if (hist_slab >= 0 && slab != hist_slab) {
                 __syncthreads();
                 for (int i = tid; i < hist_len; i += nthreads) {
@@ -376,8 +430,10 @@ __global__ void __launch_bounds__(1024) tile_fft_kernel(TileGeom g, Prologue pr,
                 const long long o = g.tile_axis == 0 ? o0 + t : o0;
                 const long long q = g.tile_axis == 0 ? 0 : q0 + t;
                 if (FIRST) {
-                    const long long b = o / pr.rows;
-                    const int i = (int)(o - b * pr.rows);
+                    const unsigned ii = (unsigned)(pi0 + (g.tile_axis == 0 ? t : 0)), rws = (unsigned)pr.rows;
+                    const unsigned db = rws == 1 ? ii : ii / rws;
+                    const long long b = pb0 + db;
+                    const int i = (int)(ii - db * rws);
                     if (g.r2c) {
                         const C2<T> e0 = fetch_src<T>(pr, b, i, 2 * p);
                         const C2<T> e1 = fetch_src<T>(pr, b, i, 2 * p + 1);
@@ -396,15 +452,31 @@ __global__ void __launch_bounds__(1024) tile_fft_kernel(TileGeom g, Prologue pr,
         int L = g.n;
         for (int ip = 0; ip < g.nr; ++ip) {
             const int R = g.radix[ip];
-            switch (R) {
-                case 2: run_pass<T, 2>(tile, g, L, tid, nthreads); break;
-                case 3: run_pass<T, 3>(tile, g, L, tid, nthreads); break;
-                case 4: run_pass<T, 4>(tile, g, L, tid, nthreads); break;
-                case 5: run_pass<T, 5>(tile, g, L, tid, nthreads); break;
-                case 8: run_pass<T, 8>(tile, g, L, tid, nthreads); break;
-                default:
-                    if (GENERIC) run_pass_generic<T>(tile, g, R, L, tid, nthreads);
-                    break;
+            if (twl) {
+                const C2<T>* tw = twl;
+                switch (R) {
+                    case 2: run_pass<T, 2>(tile, g, L, tid, nthreads, tw); break;
+                    case 3: run_pass<T, 3>(tile, g, L, tid, nthreads, tw); break;
+                    case 4: run_pass<T, 4>(tile, g, L, tid, nthreads, tw); break;
+                    case 5: run_pass<T, 5>(tile, g, L, tid, nthreads, tw); break;
+                    case 8: run_pass<T, 8>(tile, g, L, tid, nthreads, tw); break;
+                    case 16: run_pass<T, 16>(tile, g, L, tid, nthreads, tw); break;
+                    default:
+                        if (GENERIC) run_pass_generic<T>(tile, g, R, L, tid, nthreads);
+                        break;
+                }
+            } else {
+                switch (R) {
+                    case 2: run_pass<T, 2>(tile, g, L, tid, nthreads, twg); break;
+                    case 3: run_pass<T, 3>(tile, g, L, tid, nthreads, twg); break;
+                    case 4: run_pass<T, 4>(tile, g, L, tid, nthreads, twg); break;
+                    case 5: run_pass<T, 5>(tile, g, L, tid, nthreads, twg); break;
+                    case 8: run_pass<T, 8>(tile, g, L, tid, nthreads, twg); break;
+                    case 16: run_pass<T, 16>(tile, g, L, tid, nthreads, twg); break;
+                    default:
+                        if (GENERIC) run_pass_generic<T>(tile, g, R, L, tid, nthreads);
+                        break;
+                }
             }
             L /= R;
             __syncthreads();
@@ -431,11 +503,11 @@ __global__ void __launch_bounds__(1024) tile_fft_kernel(TileGeom g, Prologue pr,
             const long long o = g.tile_axis == 0 ? o0 + t : o0;
             const long long q = g.tile_axis == 0 ? 0 : q0 + t;
             if (FINAL) {
-                epi_store<T>(ep, o, q, k, F, hist);
+                epi_store<T>(ep, eb0, er0, g.tile_axis == 0 ? t : 0, (int)q, k, F, hist);
             } else {
                 if (g.tw_big) {
-                    const long long a = (q / g.tw_qdiv) % g.tw_qmod;
-                    F = cmul(F, reinterpret_cast<const C2<T>*>(g.tw_big)[(a * k) % g.tw_bigN]);
+                    const unsigned a = ((unsigned)q / (unsigned)g.tw_qdiv) % (unsigned)g.tw_qmod;
+                    F = cmul(F, reinterpret_cast<const C2<T>*>(g.tw_big)[(long long)a * k]);  // a*k < bigN by construction
                 }
                 gout[o * g.out_so + q * g.out_sq + (long long)k * g.out_sp] = F;
             }

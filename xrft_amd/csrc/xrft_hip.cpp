@@ -75,10 +75,16 @@ struct Pass {
     std::string label;
 };
 
+long long env_ll(const char* name, long long dflt) {
+    const char* e = getenv(name);
+    return e && *e ? atoll(e) : dflt;
+}
+
 int factorize(long long n, std::vector<int>& out, bool& generic) {
     // DIF order: odd radices first (their passes then run on lane-contiguous LDS), then 8, 4, 2
     std::vector<int> odd, two;
     long long m = n;
+    while (m % 16 == 0 && env_ll("XRFTHIP_RADIX16", 1)) { two.push_back(16); m /= 16; }
     while (m % 8 == 0) { two.push_back(8); m /= 8; }
     while (m % 4 == 0) { two.push_back(4); m /= 4; }
     while (m % 2 == 0) { two.push_back(2); m /= 2; }
@@ -136,11 +142,6 @@ int build_twiddle(DevBuf& buf, long long N, long long count) {  // W_N^k, k < co
         tw[(size_t)k].im = (T)sinl(a);
     }
     return buf.upload(tw.data(), tw.size() * sizeof(C2<T>));
-}
-
-long long env_ll(const char* name, long long dflt) {
-    const char* e = getenv(name);
-    return e && *e ? atoll(e) : dflt;
 }
 
 }  // namespace
@@ -251,6 +252,12 @@ struct Builder {
         ps.g.pad_shift = c.pad_shift;
         ps.threads = c.threads;
         ps.lds = c.lds;
+        // twiddle table of this pass' FFT length in LDS when it fits next to the tile
+        const size_t twb = (size_t)ps.g.n * P.csize + 32;
+        if (ps.g.n > 1 && twb <= 48 * 1024 && ps.lds + twb <= kLdsMax && env_ll("XRFTHIP_TW_LDS", 1)) {
+            ps.g.tw_lds = 1;
+            ps.lds += twb;
+        }
     }
 
     void fill_prologue(Pass& ps, long long rows, long long jmp, long long jmq) {
@@ -591,7 +598,8 @@ static void layout_workspace(xrfthip_plan* P) {
         if (G <= 0) G = env_ll("XRFTHIP_FAST_GROUP", 32);  // measured 8: 197, 16: 210, 32: 214 GFFT/s (tails and launch gaps amortise)
     }
     if (G <= 0) {
-        const size_t target = (size_t)env_ll("XRFTHIP_GROUP_BYTES", 64LL << 20);
+        // the Infinity Cache adds no bandwidth, so groups are sized for launch efficiency, not residency
+        const size_t target = (size_t)env_ll("XRFTHIP_GROUP_BYTES", 512LL << 20);
         G = (long long)std::max<size_t>(1, target / std::max<size_t>(slab_w, 1));
     }
     G = std::max<long long>(1, std::min<long long>(G, std::max<long long>(d.batch, 1)));
@@ -630,7 +638,7 @@ template <typename T>
 static int run_moments(const xrfthip_plan* P, const void* in, long long g0, long long gc, double* acc, double* coef, hipStream_t st) {
     const xrfthip_desc& d = P->d;
     const long long total = d.ny * d.nx;
-    long long chunks = std::max<long long>(1, std::min<long long>(1024, total / (256 * 64)));
+    long long chunks = std::max<long long>(1, std::min<long long>(d.ny, std::max<long long>(1, (2048 + gc - 1) / gc)));
     const dim3 grid((unsigned)chunks, (unsigned)gc), block(256);
     const size_t esz = P->cplx_in ? P->csize : P->rsize;
     const void* src = (const char*)in + (size_t)g0 * total * esz;
@@ -819,7 +827,7 @@ int xrfthip_plan_create(xrfthip_plan** plan, const xrfthip_desc* desc) {
     const xrfthip_desc& d = *desc;
     if (d.ndim != 1 && d.ndim != 2) return XRFTHIP_BAD_ARG;
     if (d.batch < 0 || d.nx < 1 || d.ny < 1 || (d.ndim == 1 && d.ny != 1)) return XRFTHIP_BAD_ARG;
-    if (d.nx > (1LL << 30) || d.ny > (1LL << 30)) return XRFTHIP_BAD_ARG;
+    if (d.nx > (1LL << 30) || d.ny > (1LL << 30) || d.nx * d.ny > (1LL << 31) - 1) return XRFTHIP_BAD_ARG;  // per-element index math is 32-bit
     if (d.dtype < XRFTHIP_F32 || d.dtype > XRFTHIP_C128) return XRFTHIP_BAD_ARG;
     if (d.out_mode < XRFTHIP_OUT_COMPLEX || d.out_mode > XRFTHIP_OUT_PHASE) return XRFTHIP_BAD_ARG;
     if ((d.flags & (XRFTHIP_INVERSE | XRFTHIP_C2R_X | XRFTHIP_PHASE_IN)) && (d.dtype < XRFTHIP_C64 || d.out_mode != XRFTHIP_OUT_COMPLEX || d.detrend)) return XRFTHIP_BAD_ARG;
@@ -1021,7 +1029,7 @@ int xrfthip_detrend(int32_t dtype, int32_t ndim, int64_t batch, int64_t ny, int6
     HIP_TRY(hipMemsetAsync(acc, 0, (size_t)batch * 6 * sizeof(double), st));
     const bool dbl = dtype == XRFTHIP_F64 || dtype == XRFTHIP_C128, cplx = dtype >= XRFTHIP_C64;
     const long long total = ny * nx;
-    const long long chunks = std::max<long long>(1, std::min<long long>(1024, total / (256 * 64)));
+    const long long chunks = std::max<long long>(1, std::min<long long>(ny, 64));
     const size_t esz = (dbl ? 8 : 4) * (cplx ? 2 : 1);
     for (long long b0 = 0; b0 < batch; b0 += 32768) {  // grid.y limit
         const long long bc = std::min<long long>(32768, batch - b0);
