@@ -30,7 +30,7 @@ t = timeit(lambda: xrft.dft(da, dim="x")); rows.append(("C2 dft 1-D (1024,65536)
 # C3 variants on the generic path
 x = cube((8, 4096, 4096), torch.float32); c = {"y": np.arange(4096.), "x": np.arange(4096.)}
 da = xrft.DataArray(x, ("t", "y", "x"), c)
-t = timeit(lambda: xrft.power_spectrum(da, dim=["y", "x"], detrend="linear", window="hann")); rows.append(("C3 PS (8,4096,4096) f32 [fast4096]", x.numel() / t / 1e9, t))
+t = timeit(lambda: xrft.power_spectrum(da, dim=["y", "x"], detrend="linear", window="hann")); rows.append(("C3 PS (8,4096,4096) f32 [fastp2]", x.numel() / t / 1e9, t))
 t = timeit(lambda: xrft.fft(da, dim=["y", "x"], detrend="linear", window="hann")); rows.append(("   fft complex out (8,4096,4096) f32 [generic]", x.numel() / t / 1e9, t))
 t = timeit(lambda: xrft.isotropic_power_spectrum(da, dim=["y", "x"], detrend="linear", window="hann")); rows.append(("   isotropic PS (8,4096,4096) f32 [generic]", x.numel() / t / 1e9, t))
 # C4: cross + isotropic on two (16,2048,2048) f32
@@ -39,6 +39,10 @@ d1 = xrft.DataArray(a, ("t", "y", "x"), c); d2 = xrft.DataArray(b, ("t", "y", "x
 t = timeit(lambda: xrft.cross_spectrum(d1, d2, dim=["y", "x"], window="hann")); rows.append(("C4 cross_spectrum 2x(16,2048,2048) f32", a.numel() / t / 1e9, t))
 t = timeit(lambda: xrft.isotropic_cross_spectrum(d1, d2, dim=["y", "x"], window="hann")); rows.append(("C4 isotropic_cross_spectrum", a.numel() / t / 1e9, t))
 t = timeit(lambda: xrft.isotropic_power_spectrum(d1, dim=["y", "x"], window="hann")); rows.append(("C4 isotropic_power_spectrum", a.numel() / t / 1e9, t))
+t = timeit(lambda: xrft.power_spectrum(d1, dim=["y", "x"], detrend="linear", window="hann")); rows.append(("   PS (16,2048,2048) f32 [fastp2]", a.numel() / t / 1e9, t))
+x = cube((64, 1024, 1024), torch.float32); c = {"y": np.arange(1024.), "x": np.arange(1024.)}
+da = xrft.DataArray(x, ("t", "y", "x"), c)
+t = timeit(lambda: xrft.power_spectrum(da, dim=["y", "x"], detrend="linear", window="hann")); rows.append(("   PS (64,1024,1024) f32 [fastp2]", x.numel() / t / 1e9, t))
 # C5: PS (64,1440,720) f64
 x = cube((64, 1440, 720), torch.float64); da = xrft.DataArray(x, ("t", "lat", "lon"), {"lat": np.arange(1440) * .25, "lon": np.arange(720) * .25})
 t = timeit(lambda: xrft.power_spectrum(da, dim=["lat", "lon"], detrend="constant", window="hann")); rows.append(("C5 PS (64,1440,720) f64", x.numel() / t / 1e9, t))

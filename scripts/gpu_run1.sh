@@ -14,3 +14,4 @@ f=$(find gpurun_out/prof_r01 -name "*kernel_stats.csv" | head -1); [ -n "$f" ] &
 # keep the merged-back payload small
 find gpurun_out/prof_r01 -name "*kernel_trace.csv" -size +20M -delete
 du -sh gpurun_out
+echo "== other configs"; timeout 600 python scripts/bench_configs.py 2>&1 | tee gpurun_out/bench_configs.log | tail -20

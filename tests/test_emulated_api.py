@@ -110,37 +110,46 @@ def test_unsupported_length_is_loud():
         xa.fft(da, dim="x")
 
 
-@pytest.mark.parametrize("shift,det,win", [(True, "linear", "hann"), (False, None, None), (False, "constant", "hamming")])
-def test_fast4096_path(shift, det, win):
-    """The specialised (4096, 4096) float32 power-spectrum kernels (fast4096.h), one slab, against numpy in float64."""
+@pytest.mark.parametrize("ny,nx,nt,shift,det,win", [
+    (4096, 4096, 1, True, "linear", "hann"),
+    (4096, 4096, 1, False, None, None),
+    (1024, 1024, 3, True, "linear", "hann"),
+    (1024, 2048, 2, False, "constant", "hamming"),
+    (2048, 1024, 2, True, "linear", None),
+    (2048, 2048, 1, True, None, "hann"),
+    (1024, 4096, 1, True, "linear", "hann"),
+    (4096, 1024, 1, False, "linear", "hann"),
+])
+def test_fastp2_path(ny, nx, nt, shift, det, win):
+    """The specialised power-of-two float32 power-spectrum kernels (fastp2.h) against numpy in float64."""
     import scipy.signal as sps
     import xrft_amd as xa
 
-    n = 4096
     rng = np.random.default_rng(42)
-    v = rng.standard_normal((1, n, n)).astype(np.float32)
-    v += (0.01 * np.arange(n, dtype=np.float32))[None, :, None] + (-0.02 * np.arange(n, dtype=np.float32) + 3)[None, None, :]
-    c = {"t": np.arange(1), "y": np.arange(n) * 1.0, "x": np.arange(n) * 1.0}
+    v = rng.standard_normal((nt, ny, nx)).astype(np.float32)
+    v += (0.01 * np.arange(ny, dtype=np.float32))[None, :, None] + (-0.02 * np.arange(nx, dtype=np.float32) + 3)[None, None, :]
+    v *= (1 + np.arange(nt, dtype=np.float32))[:, None, None]
+    c = {"t": np.arange(nt), "y": np.arange(ny) * 1.0, "x": np.arange(nx) * 1.0}
     ps = xa.power_spectrum(xa.DataArray(v, ("t", "y", "x"), c), dim=["y", "x"], detrend=det, window=win, shift=shift)
     plan = next(reversed(api._plan_cache.values()))
-    assert "[fast4096]" in plan.describe()
-    x = v[0].astype(np.float64)
-    if det == "constant":
-        x = x - x.mean()
-    elif det == "linear":
-        ii, jj = np.meshgrid(np.arange(n) - (n - 1) / 2, np.arange(n) - (n - 1) / 2, indexing="ij")
-        den = n * n * (n * n - 1) / 12
-        x = x - (x.mean() + (ii * x).sum() / den * ii + (jj * x).sum() / den * jj)
-    if win:
-        w = getattr(sps.windows, win)(n, sym=False)
-        x = x * w[:, None] * w[None, :]
-    F = np.fft.fft2(x)
-    if shift:
-        F = np.fft.fftshift(F)
-    ref = np.abs(F) ** 2 / (n * n)
-    g = ps.values[0].astype(np.float64)
-    assert np.abs(g - ref).max() / ref.max() < 2e-5
-    assert np.abs(g - ref).sum() / ref.sum() < 5e-6
+    assert "[fastp2]" in plan.describe()
+    for t in range(nt):
+        x = v[t].astype(np.float64)
+        if det == "constant":
+            x = x - x.mean()
+        elif det == "linear":
+            ii, jj = np.meshgrid(np.arange(ny) - (ny - 1) / 2, np.arange(nx) - (nx - 1) / 2, indexing="ij")
+            x = x - (x.mean() + (ii * x).sum() / (ii * ii).sum() * ii + (jj * x).sum() / (jj * jj).sum() * jj)
+        if win:
+            x = x * getattr(sps.windows, win)(ny, sym=False)[:, None] * getattr(sps.windows, win)(nx, sym=False)[None, :]
+        F = np.fft.fft2(x)
+        if shift:
+            F = np.fft.fftshift(F)
+        ref = np.abs(F) ** 2 / (ny * nx)
+        g = ps.values[t].astype(np.float64)
+        assert np.abs(g - ref).max() / ref.max() < 2e-5
+        assert np.abs(g - ref).sum() / ref.sum() < 5e-6
+    api._plan_cache.clear()
 
 
 @pytest.mark.parametrize("dtype", ["float64", "float32"])

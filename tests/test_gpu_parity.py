@@ -150,6 +150,34 @@ def test_config3_ps_4096_f32_vs_oracle():
     assert np.abs(g - r).sum() / np.abs(r).sum() < 1e-4
 
 
+@pytest.mark.parametrize("ny,nx,nt,det,win,shift", [
+    (1024, 1024, 5, "linear", "hann", True),
+    (2048, 2048, 3, "linear", "hann", True),
+    (1024, 2048, 3, "constant", "hamming", False),
+    (2048, 1024, 2, None, None, True),
+    (4096, 1024, 2, "linear", None, True),
+    (1024, 4096, 2, "linear", "hann", False),
+])
+def test_fastp2_shapes_vs_oracle(ny, nx, nt, det, win, shift):
+    """Every power-of-two shape the specialised kernels take (fastp2.h) against the oracle, several slabs."""
+    import xrft_amd as xa
+    from xrft_amd import api
+
+    rng = np.random.default_rng(ny + nx)
+    v = rng.standard_normal((nt, ny, nx)).astype(np.float32)
+    v += (0.01 * np.arange(ny, dtype=np.float32))[None, :, None] + (-0.02 * np.arange(nx, dtype=np.float32) + 3)[None, None, :]
+    v *= (1 + np.arange(nt, dtype=np.float32))[:, None, None]
+    c = {"time": np.arange(nt), "y": np.arange(ny) * 0.5, "x": np.arange(nx) * 2.0}
+    got = xa.power_spectrum(_da(v, ("time", "y", "x"), c), dim=["y", "x"], detrend=det, window=win, shift=shift)
+    assert "[fastp2]" in next(reversed(api._plan_cache.values())).describe()
+    ref = o.power_spectrum(o.OArr(v, ("time", "y", "x"), c), dim=["y", "x"], detrend=det, window=win, shift=shift)
+    cases.check(got, ref, 1e-3)
+    g, r = got.values.astype(np.float64), ref.values
+    for t in range(nt):
+        assert np.abs(g[t] - r[t]).max() / r[t].max() < 2e-5
+        assert np.abs(g[t] - r[t]).sum() / np.abs(r[t]).sum() < 1e-4
+
+
 def test_config4_cross_iso_2048_f32():
     import xrft_amd as xa
 

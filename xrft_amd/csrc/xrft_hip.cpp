@@ -19,7 +19,7 @@
 
 #include "../../include/xrft_hip.h"
 #include "aux_kernels.h"
-#include "fast4096.h"
+#include "fastp2.h"
 #include "tile_fft.h"
 
 using namespace xrft;
@@ -162,9 +162,10 @@ struct xrfthip_plan {
     // workspace layout (byte offsets)
     size_t off_acc = 0, off_coef = 0, off_w = 0, off_w2 = 0, off_f0 = 0, off_pt = 0, off_rowfit = 0, off_corr = 0, ws_bytes = 0;
     std::string desc_text;
-    // specialised path for (4096, 4096) float32 power spectra (fast4096.h)
-    bool fast4096 = false;
-    DevBuf tw4096, ones4096, what0, what1;
+    // specialised path for float32 power spectra of power-of-two slabs, 1024..4096 per axis (fastp2.h)
+    bool fast4096 = false;  // (the flag keeps its first name: the headline shape is where the path started)
+    int fast_ntile = 0, fast_ntile_pad = 0;
+    DevBuf tw_fx, tw_fy, ones4096, what0, what1;
     bool what_dirty = true;
     std::vector<double> host_win_x;
     // optional per-pass event timing (bench only)
@@ -537,9 +538,11 @@ void set_kernel_attrs_once() {
     SETALL(double);
 #undef SETALL
 #undef SETA
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&fast4096_rows_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, m);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&fast4096_cols_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, m);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&fast4096_untile_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, m);
+#define SETF(K) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&K), hipFuncAttributeMaxDynamicSharedMemorySize, m)
+    SETF((fastp2_rows_kernel<4096, 512>)); SETF((fastp2_rows_kernel<2048, 512>)); SETF((fastp2_rows_kernel<1024, 256>));
+    SETF((fastp2_cols_kernel<4096>)); SETF((fastp2_cols_kernel<2048>)); SETF((fastp2_cols_kernel<1024>));
+    SETF(fastp2_untile_kernel);
+#undef SETF
 }
 
 template <typename T>
@@ -594,8 +597,8 @@ static void layout_workspace(xrfthip_plan* P) {
     long long G = d.slabs_per_group > 0 ? d.slabs_per_group : env_ll("XRFTHIP_GROUP", 0);
     size_t slab_w = (size_t)d.ny * P->width * P->csize;
     if (P->fast4096) {
-        slab_w = (size_t)XRFT_F4096_TILES * 4096 * 4 * sizeof(cf);
-        if (G <= 0) G = env_ll("XRFTHIP_FAST_GROUP", 32);  // measured 8: 197, 16: 210, 32: 214 GFFT/s (tails and launch gaps amortise)
+        slab_w = (size_t)P->fast_ntile_pad * d.ny * 4 * sizeof(cf);
+        if (G <= 0) G = env_ll("XRFTHIP_FAST_GROUP", std::max<long long>(1, (32LL * 4096 * 4096) / (d.ny * d.nx)));  // measured 8: 197, 16: 210, 32: 214 GFFT/s (tails and launch gaps amortise)
     }
     if (G <= 0) {
         // the Infinity Cache adds no bandwidth, so groups are sized for launch efficiency, not residency
@@ -614,9 +617,9 @@ static void layout_workspace(xrfthip_plan* P) {
     P->off_w = off; if (need_w) off = al(off + (size_t)G * slab_w);
     P->off_w2 = off; if (need_w2) off = al(off + (size_t)G * d.ny * d.nx * P->csize);
     P->off_f0 = off; if (nf == 2) off = al(off + (size_t)G * slab_w);
-    P->off_pt = off; if (P->fast4096) off = al(off + (size_t)G * 512 * XRFT_F4096_TILES * 8 * sizeof(F4));
-    P->off_rowfit = off; if (P->fast4096) off = al(off + (size_t)G * 4096 * 2 * sizeof(double));
-    P->off_corr = off; if (P->fast4096) off = al(off + (size_t)G * 4096 * 2 * sizeof(float));
+    P->off_pt = off; if (P->fast4096) off = al(off + (size_t)G * (d.ny / 8) * P->fast_ntile_pad * 8 * sizeof(F4));
+    P->off_rowfit = off; if (P->fast4096) off = al(off + (size_t)G * d.ny * 2 * sizeof(double));
+    P->off_corr = off; if (P->fast4096) off = al(off + (size_t)G * d.ny * 2 * sizeof(float));
     P->ws_bytes = off;
 }
 
@@ -678,18 +681,20 @@ static void host_fft_pow2(std::vector<double>& re, std::vector<double>& im) {
 }
 
 static int fast4096_window_spectra(xrfthip_plan* P) {
-    std::vector<double> r0(4096), i0(4096, 0.0), r1(4096), i1(4096, 0.0);
-    for (int j = 0; j < 4096; ++j) {
+    const int nx = (int)P->d.nx, nxh = nx / 2;
+    std::vector<double> r0((size_t)nx), i0((size_t)nx, 0.0), r1((size_t)nx), i1((size_t)nx, 0.0);
+    for (int j = 0; j < nx; ++j) {
         const double w = P->host_win_x.empty() ? 1.0 : P->host_win_x[(size_t)j];
-        r0[j] = w;
-        r1[j] = w * ((double)j - 2047.5);
+        r0[(size_t)j] = w;
+        r1[(size_t)j] = w * ((double)j - 0.5 * (nx - 1));
     }
     host_fft_pow2(r0, i0);
     host_fft_pow2(r1, i1);
-    std::vector<cf> h0(2052), h1(2052);
-    for (int k = 0; k < 2052; ++k) {
-        h0[k].re = k <= 2048 ? (float)r0[k] : 0.f; h0[k].im = k <= 2048 ? (float)i0[k] : 0.f;
-        h1[k].re = k <= 2048 ? (float)r1[k] : 0.f; h1[k].im = k <= 2048 ? (float)i1[k] : 0.f;
+    const int nent = 4 * P->fast_ntile_pad;
+    std::vector<cf> h0((size_t)nent), h1((size_t)nent);
+    for (int k = 0; k < nent; ++k) {
+        h0[(size_t)k].re = k <= nxh ? (float)r0[(size_t)k] : 0.f; h0[(size_t)k].im = k <= nxh ? (float)i0[(size_t)k] : 0.f;
+        h1[(size_t)k].re = k <= nxh ? (float)r1[(size_t)k] : 0.f; h1[(size_t)k].im = k <= nxh ? (float)i1[(size_t)k] : 0.f;
     }
     int rc = P->what0.upload(h0.data(), h0.size() * sizeof(cf));
     if (!rc) rc = P->what1.upload(h1.data(), h1.size() * sizeof(cf));
@@ -697,48 +702,70 @@ static int fast4096_window_spectra(xrfthip_plan* P) {
     return rc;
 }
 
-// (4096, 4096) float32 power spectrum: row pass (detrend fused) -> [plane fit] -> column pass -> untile, per group of slabs
+static int fast_rows_threads(long long nx) { return nx == 1024 ? 256 : 512; }
+static size_t fast_rows_lds(long long nx) {
+    const int thr = fast_rows_threads(nx), gx = thr / (int)(nx / 16), lb = 2 * gx / 4, ntile = (int)(nx / 8 + 1);
+    return std::max<size_t>((size_t)gx * (nx + 256), (size_t)ntile * lb * 16) * sizeof(cf);
+}
+static size_t fast_cols_lds(long long ny) { return (size_t)(16384 / ny) * (ny + 256) * sizeof(cf); }
+
+// float32 power spectrum of a power-of-two slab: row pass (detrend fused) -> [plane fit] -> column pass -> untile, per group of slabs
 static int run_fast4096(const xrfthip_plan* P, const float* in, float* out, char* ws, hipStream_t st) {
     const xrfthip_desc& d = P->d;
+    const size_t slab_pts = (size_t)d.ny * d.nx;
     for (long long g0 = 0; g0 < d.batch; g0 += P->G) {
         const long long gc = std::min<long long>(P->G, d.batch - g0);
-        Fast4096 p{};
-        p.in = in + (size_t)g0 * 4096 * 4096;
+        FastP2 p{};
+        p.in = in + (size_t)g0 * slab_pts;
         p.w = reinterpret_cast<cf*>(ws + P->off_w);
         p.pt = reinterpret_cast<float*>(ws + P->off_pt);
-        p.out = out + (size_t)g0 * 4096 * 4096;
-        p.tw = reinterpret_cast<const cf*>(P->tw4096.p);
+        p.out = out + (size_t)g0 * slab_pts;
+        p.tw_x = reinterpret_cast<const cf*>(P->tw_fx.p);
+        p.tw_y = reinterpret_cast<const cf*>(P->tw_fy.p);
         p.win_y = reinterpret_cast<const float*>(P->win[0].p ? P->win[0].p : P->ones4096.p);
         p.win_x = reinterpret_cast<const float*>(P->win[1].p ? P->win[1].p : P->ones4096.p);
         p.rowfit = reinterpret_cast<double*>(ws + P->off_rowfit);
         p.corr = reinterpret_cast<const float*>(ws + P->off_corr);
         p.what0 = reinterpret_cast<const cf*>(P->what0.p);
         p.what1 = reinterpret_cast<const cf*>(P->what1.p);
+        p.ny = (int)d.ny; p.nx = (int)d.nx;
+        p.ntile = P->fast_ntile; p.ntile_pad = P->fast_ntile_pad;
         p.detrend = d.detrend;
         p.nslab = (int)gc;
-        p.shift_y = (d.flags & XRFTHIP_SHIFT_Y) ? 2048 : 0;
-        p.shift_x = (d.flags & XRFTHIP_SHIFT_X) ? 2048 : 0;
+        p.shift_y = (d.flags & XRFTHIP_SHIFT_Y) ? (int)(d.ny / 2) : 0;
+        p.shift_x = (d.flags & XRFTHIP_SHIFT_X) ? (int)(d.nx / 2) : 0;
         p.scale = (float)d.scale;
-        xrfthip_plan::ProfRec* rec = prof_begin(P, "fast4096_rows", st);
-        auto kr = &fast4096_rows_kernel;
-        XRFT_LAUNCH(kr, dim3((unsigned)(1024 * gc)), dim3(512), 2 * XRFT_F4096_LDS * sizeof(cf), st, p);
+        xrfthip_plan::ProfRec* rec = prof_begin(P, "fastp2_rows", st);
+        {
+            const int thr = fast_rows_threads(d.nx), rw = 2 * thr / (int)(d.nx / 16);
+            const dim3 grid((unsigned)(gc * (d.ny / rw))), blk((unsigned)thr);
+            const size_t lds = fast_rows_lds(d.nx);
+            if (d.nx == 4096) { auto k = &fastp2_rows_kernel<4096, 512>; XRFT_LAUNCH(k, grid, blk, lds, st, p); }
+            else if (d.nx == 2048) { auto k = &fastp2_rows_kernel<2048, 512>; XRFT_LAUNCH(k, grid, blk, lds, st, p); }
+            else { auto k = &fastp2_rows_kernel<1024, 256>; XRFT_LAUNCH(k, grid, blk, lds, st, p); }
+        }
         prof_end(rec, st);
         if (d.detrend) {
-            rec = prof_begin(P, "fast4096_fit", st);
-            auto kf = &fast4096_fit_kernel;
-            XRFT_LAUNCH(kf, dim3((unsigned)gc), dim3(256), 3 * 256 * sizeof(double), st, (const double*)p.rowfit, p.win_y, (float*)(ws + P->off_corr), (int)d.detrend);
+            rec = prof_begin(P, "fastp2_fit", st);
+            auto kf = &fastp2_fit_kernel;
+            XRFT_LAUNCH(kf, dim3((unsigned)gc), dim3(256), 3 * 256 * sizeof(double), st, (const double*)p.rowfit, p.win_y, (float*)(ws + P->off_corr), (int)d.ny, (int)d.detrend);
             prof_end(rec, st);
         }
-        rec = prof_begin(P, "fast4096_cols", st);
-        auto kc = &fast4096_cols_kernel;
-        const long long ntiles = gc * XRFT_F4096_TILES;
-        long long grid = std::min<long long>(env_ll("XRFTHIP_FAST_COLS_GRID", kCUs), ((ntiles + 63) / 64) * 64);
-        grid = std::max<long long>(64, (grid / 64) * 64);
-        XRFT_LAUNCH(kc, dim3((unsigned)grid), dim3(1024), 4 * XRFT_F4096_LDS * sizeof(cf), st, p);
+        rec = prof_begin(P, "fastp2_cols", st);
+        {
+            const long long tpu = (16384 / d.ny) / 4;
+            const long long nunits = gc * (P->fast_ntile_pad / tpu);
+            long long grid = std::min<long long>(env_ll("XRFTHIP_FAST_COLS_GRID", kCUs), ((nunits + 63) / 64) * 64);
+            grid = std::max<long long>(64, (grid / 64) * 64);
+            const size_t lds = fast_cols_lds(d.ny);
+            if (d.ny == 4096) { auto k = &fastp2_cols_kernel<4096>; XRFT_LAUNCH(k, dim3((unsigned)grid), dim3(1024), lds, st, p); }
+            else if (d.ny == 2048) { auto k = &fastp2_cols_kernel<2048>; XRFT_LAUNCH(k, dim3((unsigned)grid), dim3(1024), lds, st, p); }
+            else { auto k = &fastp2_cols_kernel<1024>; XRFT_LAUNCH(k, dim3((unsigned)grid), dim3(1024), lds, st, p); }
+        }
         prof_end(rec, st);
-        rec = prof_begin(P, "fast4096_untile", st);
-        auto ku = &fast4096_untile_kernel;
-        XRFT_LAUNCH(ku, dim3((unsigned)(512 * gc)), dim3(256), 8 * XRFT_UNTILE_LD * sizeof(float), st, p);
+        rec = prof_begin(P, "fastp2_untile", st);
+        auto ku = &fastp2_untile_kernel;
+        XRFT_LAUNCH(ku, dim3((unsigned)((d.ny / 8) * gc)), dim3(256), (size_t)8 * (d.nx / 2 + 4) * sizeof(float), st, p);
         prof_end(rec, st);
         HIP_TRY(hipGetLastError());
     }
@@ -859,11 +886,16 @@ int xrfthip_plan_create(xrfthip_plan** plan, const xrfthip_desc* desc) {
         if (c.T == 0 || n_try >= env_ll("XRFTHIP_X_FOURSTEP_MIN", 1LL << 40)) P->width = d.nx;
     }
     P->mirror = !cplx_in && !(d.flags & XRFTHIP_HALF_X) && P->width == d.nx / 2 + 1 && d.nx > 1;
-    P->fast4096 = d.ndim == 2 && d.ny == 4096 && d.nx == 4096 && d.dtype == XRFTHIP_F32 && d.out_mode == XRFTHIP_OUT_POWER &&
+    auto fast_len = [](long long n) { return n == 1024 || n == 2048 || n == 4096; };
+    P->fast4096 = d.ndim == 2 && fast_len(d.ny) && fast_len(d.nx) && d.dtype == XRFTHIP_F32 && d.out_mode == XRFTHIP_OUT_POWER &&
                   !(d.flags & ~(XRFTHIP_SHIFT_Y | XRFTHIP_SHIFT_X)) && !env_ll("XRFTHIP_NO_FAST", 0);
     if (P->fast4096) {
-        int rc4 = build_twiddle<float>(P->tw4096, 4096, 4096);
-        std::vector<float> ones(4096, 1.0f);
+        const int tpu = (int)(16384 / d.ny) / 4;  // tiles one column workgroup covers
+        P->fast_ntile = (int)(d.nx / 8 + 1);
+        P->fast_ntile_pad = (P->fast_ntile + tpu - 1) / tpu * tpu;
+        int rc4 = build_twiddle<float>(P->tw_fx, d.nx, d.nx);
+        if (!rc4) rc4 = build_twiddle<float>(P->tw_fy, d.ny, d.ny);
+        std::vector<float> ones((size_t)std::max(d.ny, d.nx), 1.0f);
         if (!rc4) rc4 = P->ones4096.upload(ones.data(), ones.size() * sizeof(float));
         if (rc4) { delete P; return rc4; }
     }
@@ -951,9 +983,12 @@ int xrfthip_plan_describe(const xrfthip_plan* plan, char* buf, size_t buflen) {
     appendf(s, "xrfthip plan: ndim=%d batch=%lld ny=%lld nx=%lld dtype=%d mode=%d detrend=%d flags=0x%x width=%lld nx_out=%lld mirror=%d group=%d ws=%zuB\n",
             d.ndim, (long long)d.batch, (long long)d.ny, (long long)d.nx, d.dtype, d.out_mode, d.detrend, d.flags,
             plan->width, plan->nx_out, (int)plan->mirror, plan->G, plan->ws_bytes);
-    if (plan->fast4096)
-        appendf(s, "  [fast4096] rows: 512 thr (row-local detrend fused), 2x(2 real rows -> 1 complex FFT4096 r16x16x16), lds=%zuB, tiled W[slab][513][4096][4] -> cols: 1024 thr, 4 columns/tile, lds=%zuB, persistent, line-tiled |F|^2 -> untile+shift+mirror: 256 thr, 8 rows\n",
-                2 * XRFT_F4096_LDS * sizeof(cf), 4 * XRFT_F4096_LDS * sizeof(cf));
+    if (plan->fast4096) {
+        const long long nx = plan->d.nx, ny = plan->d.ny;
+        appendf(s, "  [fastp2] rows: %d thr (row-local detrend fused), %dx(2 real rows -> 1 complex FFT%lld r16x16x%lld), lds=%zuB, tiled W[slab][%d][%lld][4] -> cols: 1024 thr, %lld columns/unit (FFT%lld r16x16x%lld), lds=%zuB, persistent, line-tiled |F|^2 -> untile+shift+mirror: 256 thr, 8 rows\n",
+                fast_rows_threads(nx), fast_rows_threads(nx) / (int)(nx / 16), nx, nx / 256, fast_rows_lds(nx), plan->fast_ntile_pad, ny,
+                16384 / ny, ny, ny / 256, fast_cols_lds(ny));
+    }
     describe_passes(s, plan->passes_f0, "f0");
     describe_passes(s, plan->passes, "main");
     const size_t n = std::min(buflen - 1, s.size());
