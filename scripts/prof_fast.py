@@ -1,0 +1,27 @@
+#!/usr/bin/env python3
+"""Per-kernel HIP-event timings (us per slab) of the specialised path for several shapes/modes.  Run on the GPU box."""
+import os, sys, time, warnings
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+import xrft_amd as xrft
+from xrft_amd import api
+warnings.simplefilter("ignore")
+def prof(name, fn, nslab):
+    fn(); fn(); torch.cuda.synchronize()
+    plan = [p for p in api._plan_cache.values()][-1]
+    t0 = time.perf_counter()
+    for _ in range(3): fn()
+    torch.cuda.synchronize(); wall = (time.perf_counter() - t0) / 3
+    plan.set_profiling(True)
+    for _ in range(3): fn()
+    torch.cuda.synchronize()
+    p = plan.read_profile(); plan.set_profiling(False)
+    tot = sum(ms for c, ms in p.values()) / 3 * 1e3 / nslab
+    print(f"{name:34s}", " | ".join(f"{k} {ms/3*1e3/nslab:.1f}" for k, (c, ms) in p.items()), f"|| kernels {tot:.1f} us/slab, wall {wall*1e6/nslab:.1f} us/slab")
+for (nt, n) in ((32, 4096), (64, 2048), (128, 1024)):
+    a = torch.randn((nt, n, n), dtype=torch.float32, device="cuda"); c = {"y": np.arange(float(n)), "x": np.arange(float(n))}
+    d1 = xrft.DataArray(a, ("t", "y", "x"), c)
+    prof(f"PS linear+hann ({nt},{n},{n})", lambda: xrft.power_spectrum(d1, dim=["y", "x"], detrend="linear", window="hann"), nt)
+    prof(f"isoPS linear+hann ({nt},{n},{n})", lambda: xrft.isotropic_power_spectrum(d1, dim=["y", "x"], detrend="linear", window="hann"), nt)
+    del a, d1
+    torch.cuda.empty_cache()

@@ -152,6 +152,25 @@ def test_fastp2_path(ny, nx, nt, shift, det, win):
     api._plan_cache.clear()
 
 
+@pytest.mark.parametrize("ny,nx,nt,det,win,truncate", [(1024, 1024, 3, "linear", "hann", True), (1024, 2048, 2, None, None, False),
+                                                     (2048, 1024, 1, "constant", "hann", True)])
+def test_fastp2_isotropic(ny, nx, nt, det, win, truncate):
+    """isotropic_power_spectrum through the specialised kernels: radial sums taken inside the column pass."""
+    import xrft_amd as xa
+    from oracle import xrft_oracle as o
+
+    rng = np.random.default_rng(7)
+    v = rng.standard_normal((nt, ny, nx)).astype(np.float32)
+    v += (0.01 * np.arange(ny, dtype=np.float32))[None, :, None] + (-0.02 * np.arange(nx, dtype=np.float32) + 3)[None, None, :]
+    v *= (1 + np.arange(nt, dtype=np.float32))[:, None, None]
+    c = {"t": np.arange(nt), "y": np.arange(ny) * 1.0, "x": np.arange(nx) * 1.0}
+    got = xa.isotropic_power_spectrum(xa.DataArray(v, ("t", "y", "x"), c), dim=["y", "x"], detrend=det, window=win, truncate=truncate)
+    assert any("[fastp2]" in p.describe() for p in api._plan_cache.values())
+    ref = o.isotropic_power_spectrum(o.OArr(v, ("t", "y", "x"), c), dim=["y", "x"], detrend=det, window=win, truncate=truncate)
+    cases.check(got, ref, 3e-4)
+    api._plan_cache.clear()
+
+
 @pytest.mark.parametrize("dtype", ["float64", "float32"])
 def test_inverse_transforms(dtype):
     cases.run_inverse_cases(dtype)

@@ -178,6 +178,24 @@ def test_fastp2_shapes_vs_oracle(ny, nx, nt, det, win, shift):
         assert np.abs(g[t] - r[t]).sum() / np.abs(r[t]).sum() < 1e-4
 
 
+@pytest.mark.parametrize("ny,nx,nt,det,win", [(1024, 1024, 5, "linear", "hann"), (2048, 2048, 3, "linear", "hann"),
+                                            (2048, 1024, 2, None, None), (4096, 4096, 2, "linear", "hann")])
+def test_fastp2_isotropic_vs_oracle(ny, nx, nt, det, win):
+    """isotropic_power_spectrum with the radial sums taken inside the specialised column pass (no full spectrum written)."""
+    import xrft_amd as xa
+    from xrft_amd import api
+
+    rng = np.random.default_rng(ny * 3 + nx)
+    v = rng.standard_normal((nt, ny, nx)).astype(np.float32)
+    v += (0.01 * np.arange(ny, dtype=np.float32))[None, :, None] + (-0.02 * np.arange(nx, dtype=np.float32) + 3)[None, None, :]
+    v *= (1 + np.arange(nt, dtype=np.float32))[:, None, None]
+    c = {"time": np.arange(nt), "y": np.arange(ny) * 0.5, "x": np.arange(nx) * 0.5}
+    got = xa.isotropic_power_spectrum(_da(v, ("time", "y", "x"), c), dim=["y", "x"], detrend=det, window=win, truncate=True)
+    assert any("[fastp2]" in p.describe() for p in api._plan_cache.values())
+    ref = o.isotropic_power_spectrum(o.OArr(v, ("time", "y", "x"), c), dim=["y", "x"], detrend=det, window=win, truncate=True)
+    cases.check(got, ref, 3e-4)
+
+
 def test_config4_cross_iso_2048_f32():
     import xrft_amd as xa
 

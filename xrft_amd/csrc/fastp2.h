@@ -86,6 +86,9 @@ struct FastP2 {  // parameters shared by the passes
     const float* corr;       // [slab][ny][2]: wy[i] * (row fit - plane fit) as (offset, slope), from fastp2_fit_kernel
     const cf* what0;         // FFT_x(wx)[kx], kx <= nx/2, zero-padded to 4 * ntile_pad entries
     const cf* what1;         // FFT_x(wx * (j - (nx-1)/2))[kx]
+    const unsigned* tcodes;  // radial bins in the column pass's own order [unit][slot(16)][column][u]: (direct + 1) | (mirror + 1) << 16
+    double* iso;             // [slab][nbins] per-bin sums (ISO), zeroed by the caller
+    int nbins;
     int ny, nx;
     int ntile;               // nx/8 + 1 tiles of 4 columns hold kx = 0..nx/2
     int ntile_pad;           // ntile rounded up to what one column workgroup covers
@@ -232,15 +235,16 @@ __global__ void __launch_bounds__(THR) fastp2_rows_kernel(FastP2 p) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// column pass: 1024 threads = GY groups, one column each (GY/4 tiles, one contiguous read); persistent over tile
+// column pass: THR threads (1024; 768 when the 1024-point pass also needs room for the histogram) = GY groups, one column
+// each (GY/4 tiles, one contiguous read); persistent over tile
 // groups; adds the residual trend back in the spectral domain; |F|^2 * scale is stored line-tiled (full 128-byte lines).
 // (Writing 16-byte-per-row segments straight into the output relies on L2 write-combining, which collapses when
 // 256 CUs x 128 KiB of partial lines = the whole L2 are in flight: measured 2.4x write amplification, 53% store stalls.)
 // ------------------------------------------------------------------------------------------------
-template <int NY>
-__global__ void __launch_bounds__(1024) fastp2_cols_kernel(FastP2 p) {
+template <int NY, int THR, bool ISO>
+__global__ void __launch_bounds__(THR) fastp2_cols_kernel(FastP2 p) {
     typedef P2<NY> G;
-    constexpr int NT = G::NT, GY = 1024 / NT, TPU = GY / 4;  // tiles per unit of work
+    constexpr int NT = G::NT, GY = THR / NT, TPU = GY / 4;  // tiles per unit of work
     XRFT_DYN_SMEM(smem_raw);
     cf* lds = reinterpret_cast<cf*>(smem_raw);
     float* stg = reinterpret_cast<float*>(smem_raw);
@@ -254,6 +258,10 @@ __global__ void __launch_bounds__(1024) fastp2_cols_kernel(FastP2 p) {
     const long long first = (long long)((bj >> 3) * 8 + bx) * 8 + (bj & 7);
     // unit U = tiles TPU*U .. of the [slab][ntile_pad] sequence; row i of column g: tile g>>2, line i>>2, slot [g&3][i&3]
     const size_t lane_off = (size_t)(g >> 2) * NY * 4 + (u >> 2) * 16 + (g & 3) * 4 + (u & 3);
+    // radial sums (xrft.py:895-906): per-workgroup float64 histogram behind the FFT buffers, flushed when the slab changes
+    double* hist = reinterpret_cast<double*>(lds + GY * G::LDS);
+    int cur_slab = -1;
+    if (ISO) for (int i = tid; i < p.nbins; i += THR) hist[i] = 0.0;  // ordered before the first add by the FFT's barriers
     cf a[16];
     if (first < nunits) {
         const cf* __restrict__ src = p.w + (size_t)first * TPU * NY * 4 + lane_off;
@@ -261,7 +269,18 @@ __global__ void __launch_bounds__(1024) fastp2_cols_kernel(FastP2 p) {
         for (int q = 0; q < 16; ++q) a[q] = src[q * NT * 4];
     }
     for (long long U = first; U < nunits; U += per_round) {
-        const int slab = (int)(U / upr), tile0 = (int)(U - (long long)slab * upr) * TPU;
+        const int slab = (int)(U / upr), unit = (int)(U - (long long)slab * upr), tile0 = unit * TPU;
+        if (ISO && slab != cur_slab) {
+            if (cur_slab >= 0) {
+                __syncthreads();
+                for (int i = tid; i < p.nbins; i += THR) {
+                    const double v = hist[i];
+                    if (v != 0.0) { atomicAdd(&p.iso[(size_t)cur_slab * p.nbins + i], v); hist[i] = 0.0; }
+                }
+                __syncthreads();
+            }
+            cur_slab = slab;
+        }
         if (p.detrend) {  // add back wy[i] * (row fit - plane fit) in the spectral domain (see fastp2_rows_kernel)
             const cf w0 = p.what0[4 * tile0 + g], w1 = p.what1[4 * tile0 + g];
             const float* __restrict__ cr = p.corr + ((size_t)slab * NY + u) * 2;
@@ -273,7 +292,25 @@ __global__ void __launch_bounds__(1024) fastp2_cols_kernel(FastP2 p) {
             }
         }
         fft_p2_group<NY>(a, u, mine, p.tw_y);
+        if (ISO) {  // value at (ky, kx) goes to its bin, and once more to the bin of (-ky, -kx) (Hermitian mirror of a real field)
+            const unsigned* __restrict__ tc = p.tcodes + ((size_t)unit * 16 * GY + g) * NT + u;
+            unsigned code[16];
+#pragma unroll
+            for (int sl = 0; sl < 16; ++sl) code[sl] = tc[sl * GY * NT];
+#pragma unroll
+            for (int sl = 0; sl < 16; ++sl) {
+                const float v = (a[sl].re * a[sl].re + a[sl].im * a[sl].im) * p.scale;
+                const unsigned cd = code[sl] & 0xffffu, cm = code[sl] >> 16;
+                if (cd == cm) { if (cd) atomicAdd(&hist[cd - 1], 2.0 * (double)v); }
+                else {
+                    if (cd) atomicAdd(&hist[cd - 1], (double)v);
+                    if (cm) atomicAdd(&hist[cm - 1], (double)v);
+                }
+            }
+        }
+        const bool want_p = !ISO || p.pt != nullptr;
         // power, staged column-major [g][ky] with the conflict-free 17/16 padding
+        if (want_p) {
 #pragma unroll
         for (int b = 0; b < G::NB; ++b) {
             const int pr = u + NT * b;
@@ -283,23 +320,32 @@ __global__ void __launch_bounds__(1024) fastp2_cols_kernel(FastP2 p) {
                 stg[g * G::LDS + nat16((pr >> 4) + 16 * (pr & 15) + 256 * k3)] = (v.re * v.re + v.im * v.im) * p.scale;
             }
         }
+        }
         if (U + per_round < nunits) {  // late prefetch: the FFT registers are dead; the next unit loads while this one is stored
             const cf* __restrict__ src = p.w + (size_t)(U + per_round) * TPU * NY * 4 + lane_off;
 #pragma unroll
             for (int q = 0; q < 16; ++q) a[q] = src[q * NT * 4];
         }
+        if (!want_p) continue;
         __syncthreads();
         // line-tiled store: 8 consecutive lanes (rows ky..ky+7 of one tile) fill one 128-byte line
         F4* __restrict__ pt = reinterpret_cast<F4*>(p.pt) + (size_t)slab * (NY / 8) * p.ntile_pad * 8;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const int item = tid + 1024 * r, ky = item % NY, wt = item / NY;
+            const int item = tid + THR * r, ky = item % NY, wt = item / NY;
             const float* s = stg + (4 * wt) * G::LDS + nat16(ky);
             F4 d;
             d.x = s[0]; d.y = s[G::LDS]; d.z = s[2 * G::LDS]; d.w = s[3 * G::LDS];
             pt[((size_t)(ky >> 3) * p.ntile_pad + tile0 + wt) * 8 + (ky & 7)] = d;
         }
         __syncthreads();
+    }
+    if (ISO && cur_slab >= 0) {
+        __syncthreads();
+        for (int i = tid; i < p.nbins; i += THR) {
+            const double v = hist[i];
+            if (v != 0.0) atomicAdd(&p.iso[(size_t)cur_slab * p.nbins + i], v);
+        }
     }
 }
 

@@ -165,7 +165,7 @@ struct xrfthip_plan {
     // specialised path for float32 power spectra of power-of-two slabs, 1024..4096 per axis (fastp2.h)
     bool fast4096 = false;  // (the flag keeps its first name: the headline shape is where the path started)
     int fast_ntile = 0, fast_ntile_pad = 0;
-    DevBuf tw_fx, tw_fy, ones4096, what0, what1;
+    DevBuf tw_fx, tw_fy, ones4096, what0, what1, tcodes;
     bool what_dirty = true;
     std::vector<double> host_win_x;
     // optional per-pass event timing (bench only)
@@ -540,7 +540,8 @@ void set_kernel_attrs_once() {
 #undef SETA
 #define SETF(K) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&K), hipFuncAttributeMaxDynamicSharedMemorySize, m)
     SETF((fastp2_rows_kernel<4096, 512>)); SETF((fastp2_rows_kernel<2048, 512>)); SETF((fastp2_rows_kernel<1024, 256>));
-    SETF((fastp2_cols_kernel<4096>)); SETF((fastp2_cols_kernel<2048>)); SETF((fastp2_cols_kernel<1024>));
+    SETF((fastp2_cols_kernel<4096, 1024, false>)); SETF((fastp2_cols_kernel<2048, 1024, false>)); SETF((fastp2_cols_kernel<1024, 1024, false>));
+    SETF((fastp2_cols_kernel<4096, 1024, true>)); SETF((fastp2_cols_kernel<2048, 1024, true>)); SETF((fastp2_cols_kernel<1024, 768, true>));
     SETF(fastp2_untile_kernel);
 #undef SETF
 }
@@ -617,7 +618,7 @@ static void layout_workspace(xrfthip_plan* P) {
     P->off_w = off; if (need_w) off = al(off + (size_t)G * slab_w);
     P->off_w2 = off; if (need_w2) off = al(off + (size_t)G * d.ny * d.nx * P->csize);
     P->off_f0 = off; if (nf == 2) off = al(off + (size_t)G * slab_w);
-    P->off_pt = off; if (P->fast4096) off = al(off + (size_t)G * (d.ny / 8) * P->fast_ntile_pad * 8 * sizeof(F4));
+    P->off_pt = off; if (P->fast4096 && !(d.flags & XRFTHIP_NO_SPECTRUM_OUT)) off = al(off + (size_t)G * (d.ny / 8) * P->fast_ntile_pad * 8 * sizeof(F4));
     P->off_rowfit = off; if (P->fast4096) off = al(off + (size_t)G * d.ny * 2 * sizeof(double));
     P->off_corr = off; if (P->fast4096) off = al(off + (size_t)G * d.ny * 2 * sizeof(float));
     P->ws_bytes = off;
@@ -707,10 +708,13 @@ static size_t fast_rows_lds(long long nx) {
     const int thr = fast_rows_threads(nx), gx = thr / (int)(nx / 16), lb = 2 * gx / 4, ntile = (int)(nx / 8 + 1);
     return std::max<size_t>((size_t)gx * (nx + 256), (size_t)ntile * lb * 16) * sizeof(cf);
 }
-static size_t fast_cols_lds(long long ny) { return (size_t)(16384 / ny) * (ny + 256) * sizeof(cf); }
+// the 1024-point column pass fills the whole LDS with 16 columns: with a histogram it runs 12 columns (768 threads)
+static int fast_cols_threads(long long ny, bool iso) { return (iso && ny == 1024) ? 768 : 1024; }
+static int fast_cols_gy(long long ny, bool iso) { return fast_cols_threads(ny, iso) / (int)(ny / 16); }
+static size_t fast_cols_lds(long long ny, bool iso) { return (size_t)fast_cols_gy(ny, iso) * (ny + 256) * sizeof(cf); }
 
 // float32 power spectrum of a power-of-two slab: row pass (detrend fused) -> [plane fit] -> column pass -> untile, per group of slabs
-static int run_fast4096(const xrfthip_plan* P, const float* in, float* out, char* ws, hipStream_t st) {
+static int run_fast4096(const xrfthip_plan* P, const float* in, float* out, double* iso, char* ws, hipStream_t st) {
     const xrfthip_desc& d = P->d;
     const size_t slab_pts = (size_t)d.ny * d.nx;
     for (long long g0 = 0; g0 < d.batch; g0 += P->G) {
@@ -718,8 +722,13 @@ static int run_fast4096(const xrfthip_plan* P, const float* in, float* out, char
         FastP2 p{};
         p.in = in + (size_t)g0 * slab_pts;
         p.w = reinterpret_cast<cf*>(ws + P->off_w);
-        p.pt = reinterpret_cast<float*>(ws + P->off_pt);
-        p.out = out + (size_t)g0 * slab_pts;
+        const bool want_out = !(d.flags & XRFTHIP_NO_SPECTRUM_OUT);
+        const bool iso_on = (d.flags & XRFTHIP_ISO) != 0;
+        p.pt = want_out ? reinterpret_cast<float*>(ws + P->off_pt) : nullptr;
+        p.out = want_out ? out + (size_t)g0 * slab_pts : nullptr;
+        p.tcodes = reinterpret_cast<const unsigned*>(P->tcodes.p);
+        p.iso = iso_on ? iso + (size_t)g0 * P->nbins : nullptr;
+        p.nbins = P->nbins;
         p.tw_x = reinterpret_cast<const cf*>(P->tw_fx.p);
         p.tw_y = reinterpret_cast<const cf*>(P->tw_fy.p);
         p.win_y = reinterpret_cast<const float*>(P->win[0].p ? P->win[0].p : P->ones4096.p);
@@ -753,20 +762,24 @@ static int run_fast4096(const xrfthip_plan* P, const float* in, float* out, char
         }
         rec = prof_begin(P, "fastp2_cols", st);
         {
-            const long long tpu = (16384 / d.ny) / 4;
+            const long long tpu = fast_cols_gy(d.ny, iso_on) / 4;
+            const int cthr = fast_cols_threads(d.ny, iso_on);
             const long long nunits = gc * (P->fast_ntile_pad / tpu);
             long long grid = std::min<long long>(env_ll("XRFTHIP_FAST_COLS_GRID", kCUs), ((nunits + 63) / 64) * 64);
             grid = std::max<long long>(64, (grid / 64) * 64);
-            const size_t lds = fast_cols_lds(d.ny);
-            if (d.ny == 4096) { auto k = &fastp2_cols_kernel<4096>; XRFT_LAUNCH(k, dim3((unsigned)grid), dim3(1024), lds, st, p); }
-            else if (d.ny == 2048) { auto k = &fastp2_cols_kernel<2048>; XRFT_LAUNCH(k, dim3((unsigned)grid), dim3(1024), lds, st, p); }
-            else { auto k = &fastp2_cols_kernel<1024>; XRFT_LAUNCH(k, dim3((unsigned)grid), dim3(1024), lds, st, p); }
+            const size_t lds = fast_cols_lds(d.ny, iso_on) + (iso_on ? (size_t)P->nbins * sizeof(double) : 0);
+#define COLS_(NN, TT, II) do { auto k = &fastp2_cols_kernel<NN, TT, II>; XRFT_LAUNCH(k, dim3((unsigned)grid), dim3((unsigned)cthr), lds, st, p); } while (0)
+            if (iso_on) { if (d.ny == 4096) COLS_(4096, 1024, true); else if (d.ny == 2048) COLS_(2048, 1024, true); else COLS_(1024, 768, true); }
+            else { if (d.ny == 4096) COLS_(4096, 1024, false); else if (d.ny == 2048) COLS_(2048, 1024, false); else COLS_(1024, 1024, false); }
+#undef COLS_
         }
         prof_end(rec, st);
-        rec = prof_begin(P, "fastp2_untile", st);
-        auto ku = &fastp2_untile_kernel;
-        XRFT_LAUNCH(ku, dim3((unsigned)((d.ny / 8) * gc)), dim3(256), (size_t)8 * (d.nx / 2 + 4) * sizeof(float), st, p);
-        prof_end(rec, st);
+        if (want_out) {
+            rec = prof_begin(P, "fastp2_untile", st);
+            auto ku = &fastp2_untile_kernel;
+            XRFT_LAUNCH(ku, dim3((unsigned)((d.ny / 8) * gc)), dim3(256), (size_t)8 * (d.nx / 2 + 4) * sizeof(float), st, p);
+            prof_end(rec, st);
+        }
         HIP_TRY(hipGetLastError());
     }
     return XRFTHIP_OK;
@@ -888,9 +901,9 @@ int xrfthip_plan_create(xrfthip_plan** plan, const xrfthip_desc* desc) {
     P->mirror = !cplx_in && !(d.flags & XRFTHIP_HALF_X) && P->width == d.nx / 2 + 1 && d.nx > 1;
     auto fast_len = [](long long n) { return n == 1024 || n == 2048 || n == 4096; };
     P->fast4096 = d.ndim == 2 && fast_len(d.ny) && fast_len(d.nx) && d.dtype == XRFTHIP_F32 && d.out_mode == XRFTHIP_OUT_POWER &&
-                  !(d.flags & ~(XRFTHIP_SHIFT_Y | XRFTHIP_SHIFT_X)) && !env_ll("XRFTHIP_NO_FAST", 0);
+                  !(d.flags & ~(XRFTHIP_SHIFT_Y | XRFTHIP_SHIFT_X | XRFTHIP_ISO | XRFTHIP_NO_SPECTRUM_OUT)) && !env_ll("XRFTHIP_NO_FAST", 0);
     if (P->fast4096) {
-        const int tpu = (int)(16384 / d.ny) / 4;  // tiles one column workgroup covers
+        const int tpu = fast_cols_gy(d.ny, (d.flags & XRFTHIP_ISO) != 0) / 4;  // tiles one column workgroup covers
         P->fast_ntile = (int)(d.nx / 8 + 1);
         P->fast_ntile_pad = (P->fast_ntile + tpu - 1) / tpu * tpu;
         int rc4 = build_twiddle<float>(P->tw_fx, d.nx, d.nx);
@@ -930,12 +943,46 @@ int xrfthip_plan_set_phase(xrfthip_plan* plan, int axis, const double* h_phase, 
     return upload_real_table(plan, plan->phase[axis], h_phase, n, 1);
 }
 
+// the bin map re-ordered the way the column pass holds its results (fastp2_cols_kernel): [unit][slot][column][u],
+// value = (bin of (ky, kx) + 1) | (bin of the Hermitian mirror (-ky, -kx) + 1) << 16, 0 = not counted
+static int fast_build_tcodes(xrfthip_plan* P, const int32_t* bm) {
+    const int ny = (int)P->d.ny, nx = (int)P->d.nx, nt = ny / 16, r3 = ny / 256, gy = fast_cols_gy(ny, true), tpu = gy / 4;
+    const int units = P->fast_ntile_pad / tpu;
+    const long long w = P->nx_out;
+    std::vector<uint32_t> t((size_t)units * 16 * gy * nt);
+    for (int un = 0; un < units; ++un)
+        for (int sl = 0; sl < 16; ++sl) {
+            const int b = sl / r3, k3 = sl % r3;
+            for (int g = 0; g < gy; ++g)
+                for (int u = 0; u < nt; ++u) {
+                    const int pr = u + nt * b, ky = (pr >> 4) + 16 * (pr & 15) + 256 * k3, kx = 4 * un * tpu + g;
+                    uint32_t v = 0;
+                    if (kx <= nx / 2) {
+                        const int32_t cd = bm[(size_t)ky * w + kx];
+                        if (cd >= 0) v |= (uint32_t)(cd + 1);
+                        if (kx > 0 && kx < nx - kx) {
+                            const int32_t cm = bm[(size_t)(ky == 0 ? 0 : ny - ky) * w + (nx - kx)];
+                            if (cm >= 0) v |= (uint32_t)(cm + 1) << 16;
+                        }
+                    }
+                    t[(((size_t)un * 16 + sl) * gy + g) * nt + u] = v;
+                }
+        }
+    return P->tcodes.upload(t.data(), t.size() * sizeof(uint32_t));
+}
+
 int xrfthip_plan_set_binmap(xrfthip_plan* plan, const int32_t* h_binmap, int64_t ny, int64_t nx_out, int32_t nbins) {
     if (!plan || !h_binmap || !(plan->d.flags & XRFTHIP_ISO)) return XRFTHIP_BAD_ARG;
     if (ny != plan->d.ny || nx_out != plan->nx_out || nbins < 1 || nbins > 4096) return XRFTHIP_BAD_ARG;
     int rc = plan->binmap.upload(h_binmap, (size_t)ny * nx_out * sizeof(int32_t));
     if (rc) return rc;
     plan->nbins = nbins;
+    if (plan->fast4096) {
+        int rcf = XRFTHIP_OK;
+        if (nbins > 2048) plan->fast4096 = false;  // the histogram must fit behind the column pass's FFT buffers
+        else rcf = fast_build_tcodes(plan, h_binmap);
+        if (rcf) return rcf;
+    }
     plan->passes.clear();
     plan->passes_f0.clear();
     return plan->dbl ? build_plan_t<double>(*plan) : build_plan_t<float>(*plan);
@@ -985,9 +1032,9 @@ int xrfthip_plan_describe(const xrfthip_plan* plan, char* buf, size_t buflen) {
             plan->width, plan->nx_out, (int)plan->mirror, plan->G, plan->ws_bytes);
     if (plan->fast4096) {
         const long long nx = plan->d.nx, ny = plan->d.ny;
-        appendf(s, "  [fastp2] rows: %d thr (row-local detrend fused), %dx(2 real rows -> 1 complex FFT%lld r16x16x%lld), lds=%zuB, tiled W[slab][%d][%lld][4] -> cols: 1024 thr, %lld columns/unit (FFT%lld r16x16x%lld), lds=%zuB, persistent, line-tiled |F|^2 -> untile+shift+mirror: 256 thr, 8 rows\n",
+        appendf(s, "  [fastp2] rows: %d thr (row-local detrend fused), %dx(2 real rows -> 1 complex FFT%lld r16x16x%lld), lds=%zuB, tiled W[slab][%d][%lld][4] -> cols: %lld columns/unit (FFT%lld r16x16x%lld), lds=%zuB, persistent, line-tiled |F|^2 -> untile+shift+mirror: 256 thr, 8 rows\n",
                 fast_rows_threads(nx), fast_rows_threads(nx) / (int)(nx / 16), nx, nx / 256, fast_rows_lds(nx), plan->fast_ntile_pad, ny,
-                16384 / ny, ny, ny / 256, fast_cols_lds(ny));
+                (long long)fast_cols_gy(ny, (plan->d.flags & XRFTHIP_ISO) != 0), ny, ny / 256, fast_cols_lds(ny, (plan->d.flags & XRFTHIP_ISO) != 0));
     }
     describe_passes(s, plan->passes_f0, "f0");
     describe_passes(s, plan->passes, "main");
@@ -1021,7 +1068,7 @@ int xrfthip_exec(const xrfthip_plan* plan, const void* d_in0, const void* d_in1,
     if (iso) HIP_TRY(hipMemsetAsync(d_iso, 0, (size_t)d.batch * P->nbins * (cross ? 16 : 8), st));
     if (P->fast4096) {
         if (P->what_dirty) { int rcw = fast4096_window_spectra(const_cast<xrfthip_plan*>(P)); if (rcw) return rcw; }
-        return run_fast4096(P, (const float*)d_in0, (float*)d_out, ws, st);
+        return run_fast4096(P, (const float*)d_in0, (float*)out, (double*)d_iso, ws, st);
     }
     for (long long g0 = 0; g0 < d.batch; g0 += P->G) {
         const long long gc = std::min<long long>(P->G, d.batch - g0);
