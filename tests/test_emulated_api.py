@@ -171,6 +171,67 @@ def test_fastp2_isotropic(ny, nx, nt, det, win, truncate):
     api._plan_cache.clear()
 
 
+def _p2_fields(ny, nx, nt, seed, dx=1.0, x0=0.0):
+    import xrft_amd as xa
+    from oracle import xrft_oracle as o
+
+    rng = np.random.default_rng(seed)
+    v = rng.standard_normal((nt, ny, nx)).astype(np.float32)
+    v += (0.01 * np.arange(ny, dtype=np.float32))[None, :, None] + (-0.02 * np.arange(nx, dtype=np.float32) + 3)[None, None, :]
+    v *= (1 + np.arange(nt, dtype=np.float32))[:, None, None]
+    c = {"t": np.arange(nt), "y": np.arange(ny) * dx + x0, "x": np.arange(nx) * 2 * dx - x0}
+    return xa.DataArray(v, ("t", "y", "x"), c), o.OArr(v, ("t", "y", "x"), c)
+
+
+@pytest.mark.parametrize("ny,nx,kw", [
+    (1024, 1024, dict(detrend="linear", window="hann")),                      # true_phase=True: ifftshift sign + phase tables
+    (1024, 2048, dict(true_phase=False, detrend="constant")),
+    (2048, 1024, dict(shift=False, window="hamming", true_phase=True)),
+])
+def test_fastp2_complex_fft(ny, nx, kw):
+    """xrft.fft of a real float32 slab through the specialised kernels (complex result, Hermitian half mirrored)."""
+    import xrft_amd as xa
+    from oracle import xrft_oracle as o
+
+    da, od = _p2_fields(ny, nx, 2, 11, x0=3.0)
+    got = xa.fft(da, dim=["y", "x"], **kw)
+    assert any("[fastp2]" in p.describe() for p in api._plan_cache.values())
+    cases.check(got, o.fft(od, dim=["y", "x"], **kw), 3e-4)
+    api._plan_cache.clear()
+
+
+@pytest.mark.parametrize("ny,nx,kw", [
+    (1024, 1024, dict(detrend="linear", window="hann")),
+    (2048, 1024, dict(true_phase=False)),
+])
+def test_fastp2_cross_spectrum(ny, nx, kw):
+    import xrft_amd as xa
+    from oracle import xrft_oracle as o
+
+    da, od = _p2_fields(ny, nx, 2, 12)
+    db, ob = _p2_fields(ny, nx, 2, 13)
+    got = xa.cross_spectrum(da, db, dim=["y", "x"], **kw)
+    assert any("[fastp2]" in p.describe() for p in api._plan_cache.values())
+    cases.check(got, o.cross_spectrum(od, ob, dim=["y", "x"], **kw), 3e-4)
+    api._plan_cache.clear()
+
+
+@pytest.mark.parametrize("ny,nx,kw", [
+    (1024, 1024, dict(detrend="linear", window="hann", truncate=True)),
+    (1024, 2048, dict(window="hann", truncate=False)),
+])
+def test_fastp2_isotropic_cross(ny, nx, kw):
+    import xrft_amd as xa
+    from oracle import xrft_oracle as o
+
+    da, od = _p2_fields(ny, nx, 2, 14)
+    db, ob = _p2_fields(ny, nx, 2, 15)
+    got = xa.isotropic_cross_spectrum(da, db, dim=["y", "x"], **kw)
+    assert any("[fastp2]" in p.describe() for p in api._plan_cache.values())
+    cases.check(got, o.isotropic_cross_spectrum(od, ob, dim=["y", "x"], **kw), 3e-4)
+    api._plan_cache.clear()
+
+
 @pytest.mark.parametrize("dtype", ["float64", "float32"])
 def test_inverse_transforms(dtype):
     cases.run_inverse_cases(dtype)

@@ -196,6 +196,58 @@ def test_fastp2_isotropic_vs_oracle(ny, nx, nt, det, win):
     cases.check(got, ref, 3e-4)
 
 
+def _p2_pair(ny, nx, nt, seed, x0=0.0):
+    rng = np.random.default_rng(seed)
+    v = rng.standard_normal((nt, ny, nx)).astype(np.float32)
+    v += (0.01 * np.arange(ny, dtype=np.float32))[None, :, None] + (-0.02 * np.arange(nx, dtype=np.float32) + 3)[None, None, :]
+    v *= (1 + np.arange(nt, dtype=np.float32))[:, None, None]
+    c = {"time": np.arange(nt), "y": np.arange(ny) * 0.5 + x0, "x": np.arange(nx) * 0.5 - x0}
+    return _da(v, ("time", "y", "x"), c), o.OArr(v, ("time", "y", "x"), c)
+
+
+def _assert_fast():
+    from xrft_amd import api
+
+    assert any("[fastp2]" in p.describe() for p in api._plan_cache.values())
+    api._plan_cache.clear()
+
+
+@pytest.mark.parametrize("ny,nx,nt,kw", [
+    (1024, 1024, 3, dict(detrend="linear", window="hann")),
+    (2048, 2048, 2, dict(detrend="linear", window="hann")),
+    (1024, 2048, 2, dict(true_phase=False, detrend="constant")),
+    (2048, 1024, 2, dict(shift=False, window="hamming")),
+    (4096, 4096, 1, dict(detrend="linear", window="hann")),
+])
+def test_fastp2_complex_fft_vs_oracle(ny, nx, nt, kw):
+    """xrft.fft of real float32 power-of-two slabs on the specialised path (true-phase factors, ifftshift sign, mirror)."""
+    import xrft_amd as xa
+
+    da, od = _p2_pair(ny, nx, nt, 21, x0=3.0)
+    got = xa.fft(da, dim=["y", "x"], **kw)
+    _assert_fast()
+    cases.check(got, o.fft(od, dim=["y", "x"], **kw), 3e-4)
+
+
+@pytest.mark.parametrize("ny,nx,nt,kw", [
+    (1024, 1024, 3, dict(detrend="linear", window="hann")),
+    (2048, 2048, 2, dict(window="hann")),
+    (2048, 1024, 2, dict(true_phase=False, detrend="constant")),
+    (4096, 4096, 1, dict(detrend="linear", window="hann")),
+])
+def test_fastp2_cross_vs_oracle(ny, nx, nt, kw):
+    import xrft_amd as xa
+
+    da, od = _p2_pair(ny, nx, nt, 22)
+    db, ob = _p2_pair(ny, nx, nt, 23)
+    got = xa.cross_spectrum(da, db, dim=["y", "x"], **kw)
+    _assert_fast()
+    cases.check(got, o.cross_spectrum(od, ob, dim=["y", "x"], **kw), 3e-4)
+    got = xa.isotropic_cross_spectrum(da, db, dim=["y", "x"], truncate=True, **{k: v for k, v in kw.items() if k != "true_phase"})
+    _assert_fast()
+    cases.check(got, o.isotropic_cross_spectrum(od, ob, dim=["y", "x"], truncate=True, **{k: v for k, v in kw.items() if k != "true_phase"}), 3e-4)
+
+
 def test_config4_cross_iso_2048_f32():
     import xrft_amd as xa
 

@@ -86,6 +86,8 @@ struct FastP2 {  // parameters shared by the passes
     const float* corr;       // [slab][ny][2]: wy[i] * (row fit - plane fit) as (offset, slope), from fastp2_fit_kernel
     const cf* what0;         // FFT_x(wx)[kx], kx <= nx/2, zero-padded to 4 * ntile_pad entries
     const cf* what1;         // FFT_x(wx * (j - (nx-1)/2))[kx]
+    const cf* ph_y;          // complex modes: true-phase factor per unshifted ky (times (-1)^ky for an ifftshifted input), never null
+    const cf* ph_x;
     const unsigned* tcodes;  // radial bins in the column pass's own order [unit][slot(16)][column][u]: (direct + 1) | (mirror + 1) << 16
     double* iso;             // [slab][nbins] per-bin sums (ISO), zeroed by the caller
     int nbins;
@@ -241,8 +243,13 @@ __global__ void __launch_bounds__(THR) fastp2_rows_kernel(FastP2 p) {
 // (Writing 16-byte-per-row segments straight into the output relies on L2 write-combining, which collapses when
 // 256 CUs x 128 KiB of partial lines = the whole L2 are in flight: measured 2.4x write amplification, 53% store stalls.)
 // ------------------------------------------------------------------------------------------------
-template <int NY, int THR, bool ISO>
+// MODE 1: |F|^2 * scale (float).  MODE 0: F * scale (complex; the true-phase factors are applied by the untile kernel).
+// MODE 2: cross spectrum, second of two passes -- the field-0 pass (MODE 0, scale 1) left F0 in `pt`; this pass transforms
+// field 1 and replaces F0 by F0 conj(F1) * scale in place (xrft.py:825).  ISO: radial sums, MODE 1 in transform order
+// straight from the registers, MODE 2 in the store loop (complex bins; the mirror contributes the conjugate).
+template <int NY, int THR, int MODE, bool ISO>
 __global__ void __launch_bounds__(THR) fastp2_cols_kernel(FastP2 p) {
+    static_assert(MODE == 1 || !ISO || MODE == 2, "complex output has no radial reduce");
     typedef P2<NY> G;
     constexpr int NT = G::NT, GY = THR / NT, TPU = GY / 4;  // tiles per unit of work
     XRFT_DYN_SMEM(smem_raw);
@@ -261,7 +268,8 @@ __global__ void __launch_bounds__(THR) fastp2_cols_kernel(FastP2 p) {
     // radial sums (xrft.py:895-906): per-workgroup float64 histogram behind the FFT buffers, flushed when the slab changes
     double* hist = reinterpret_cast<double*>(lds + GY * G::LDS);
     int cur_slab = -1;
-    if (ISO) for (int i = tid; i < p.nbins; i += THR) hist[i] = 0.0;  // ordered before the first add by the FFT's barriers
+    constexpr int HW = MODE == 2 ? 2 : 1;  // doubles per bin
+    if (ISO) for (int i = tid; i < p.nbins * HW; i += THR) hist[i] = 0.0;  // ordered before the first add by the FFT's barriers
     cf a[16];
     if (first < nunits) {
         const cf* __restrict__ src = p.w + (size_t)first * TPU * NY * 4 + lane_off;
@@ -273,9 +281,9 @@ __global__ void __launch_bounds__(THR) fastp2_cols_kernel(FastP2 p) {
         if (ISO && slab != cur_slab) {
             if (cur_slab >= 0) {
                 __syncthreads();
-                for (int i = tid; i < p.nbins; i += THR) {
+                for (int i = tid; i < p.nbins * HW; i += THR) {
                     const double v = hist[i];
-                    if (v != 0.0) { atomicAdd(&p.iso[(size_t)cur_slab * p.nbins + i], v); hist[i] = 0.0; }
+                    if (v != 0.0) { atomicAdd(&p.iso[(size_t)cur_slab * p.nbins * HW + i], v); hist[i] = 0.0; }
                 }
                 __syncthreads();
             }
@@ -292,59 +300,111 @@ __global__ void __launch_bounds__(THR) fastp2_cols_kernel(FastP2 p) {
             }
         }
         fft_p2_group<NY>(a, u, mine, p.tw_y);
-        if (ISO) {  // value at (ky, kx) goes to its bin, and once more to the bin of (-ky, -kx) (Hermitian mirror of a real field)
-            const unsigned* __restrict__ tc = p.tcodes + ((size_t)unit * 16 * GY + g) * NT + u;
-            unsigned code[16];
+        if constexpr (MODE == 1) {
+            if (ISO) {  // value at (ky, kx) goes to its bin, and once more to the bin of (-ky, -kx) (Hermitian mirror of a real field)
+                const unsigned* __restrict__ tc = p.tcodes + ((size_t)unit * 16 * GY + g) * NT + u;
+                unsigned code[16];
 #pragma unroll
-            for (int sl = 0; sl < 16; ++sl) code[sl] = tc[sl * GY * NT];
+                for (int sl = 0; sl < 16; ++sl) code[sl] = tc[sl * GY * NT];
 #pragma unroll
-            for (int sl = 0; sl < 16; ++sl) {
-                const float v = (a[sl].re * a[sl].re + a[sl].im * a[sl].im) * p.scale;
-                const unsigned cd = code[sl] & 0xffffu, cm = code[sl] >> 16;
-                if (cd == cm) { if (cd) atomicAdd(&hist[cd - 1], 2.0 * (double)v); }
-                else {
-                    if (cd) atomicAdd(&hist[cd - 1], (double)v);
-                    if (cm) atomicAdd(&hist[cm - 1], (double)v);
+                for (int sl = 0; sl < 16; ++sl) {
+                    const float v = (a[sl].re * a[sl].re + a[sl].im * a[sl].im) * p.scale;
+                    const unsigned cd = code[sl] & 0xffffu, cm = code[sl] >> 16;
+                    if (cd == cm) { if (cd) atomicAdd(&hist[cd - 1], 2.0 * (double)v); }
+                    else {
+                        if (cd) atomicAdd(&hist[cd - 1], (double)v);
+                        if (cm) atomicAdd(&hist[cm - 1], (double)v);
+                    }
                 }
             }
-        }
-        const bool want_p = !ISO || p.pt != nullptr;
-        // power, staged column-major [g][ky] with the conflict-free 17/16 padding
-        if (want_p) {
+            const bool want_p = !ISO || p.pt != nullptr;
+            // power, staged column-major [g][ky] with the conflict-free 17/16 padding
+            if (want_p) {
 #pragma unroll
-        for (int b = 0; b < G::NB; ++b) {
-            const int pr = u + NT * b;
+                for (int b = 0; b < G::NB; ++b) {
+                    const int pr = u + NT * b;
 #pragma unroll
-            for (int k3 = 0; k3 < G::R3; ++k3) {
-                const cf v = a[b * G::R3 + k3];
-                stg[g * G::LDS + nat16((pr >> 4) + 16 * (pr & 15) + 256 * k3)] = (v.re * v.re + v.im * v.im) * p.scale;
+                    for (int k3 = 0; k3 < G::R3; ++k3) {
+                        const cf v = a[b * G::R3 + k3];
+                        stg[g * G::LDS + nat16((pr >> 4) + 16 * (pr & 15) + 256 * k3)] = (v.re * v.re + v.im * v.im) * p.scale;
+                    }
+                }
             }
-        }
-        }
-        if (U + per_round < nunits) {  // late prefetch: the FFT registers are dead; the next unit loads while this one is stored
-            const cf* __restrict__ src = p.w + (size_t)(U + per_round) * TPU * NY * 4 + lane_off;
+            if (U + per_round < nunits) {  // late prefetch: the FFT registers are dead; the next unit loads while this one is stored
+                const cf* __restrict__ src = p.w + (size_t)(U + per_round) * TPU * NY * 4 + lane_off;
 #pragma unroll
-            for (int q = 0; q < 16; ++q) a[q] = src[q * NT * 4];
-        }
-        if (!want_p) continue;
-        __syncthreads();
-        // line-tiled store: 8 consecutive lanes (rows ky..ky+7 of one tile) fill one 128-byte line
-        F4* __restrict__ pt = reinterpret_cast<F4*>(p.pt) + (size_t)slab * (NY / 8) * p.ntile_pad * 8;
+                for (int q = 0; q < 16; ++q) a[q] = src[q * NT * 4];
+            }
+            if (!want_p) continue;
+            __syncthreads();
+            // line-tiled store: 8 consecutive lanes (rows ky..ky+7 of one tile) fill one 128-byte line
+            F4* __restrict__ pt = reinterpret_cast<F4*>(p.pt) + (size_t)slab * (NY / 8) * p.ntile_pad * 8;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int item = tid + THR * r, ky = item % NY, wt = item / NY;
-            const float* s = stg + (4 * wt) * G::LDS + nat16(ky);
-            F4 d;
-            d.x = s[0]; d.y = s[G::LDS]; d.z = s[2 * G::LDS]; d.w = s[3 * G::LDS];
-            pt[((size_t)(ky >> 3) * p.ntile_pad + tile0 + wt) * 8 + (ky & 7)] = d;
+            for (int r = 0; r < 4; ++r) {
+                const int item = tid + THR * r, ky = item % NY, wt = item / NY;
+                const float* s = stg + (4 * wt) * G::LDS + nat16(ky);
+                F4 d;
+                d.x = s[0]; d.y = s[G::LDS]; d.z = s[2 * G::LDS]; d.w = s[3 * G::LDS];
+                pt[((size_t)(ky >> 3) * p.ntile_pad + tile0 + wt) * 8 + (ky & 7)] = d;
+            }
+            __syncthreads();
+        } else {
+            // complex result, staged in the group's own FFT buffer in natural order
+            const float sc0 = MODE == 0 ? p.scale : 1.0f;
+#pragma unroll
+            for (int b = 0; b < G::NB; ++b) {
+                const int pr = u + NT * b;
+#pragma unroll
+                for (int k3 = 0; k3 < G::R3; ++k3)
+                    mine[nat16((pr >> 4) + 16 * (pr & 15) + 256 * k3)] = cscale(a[b * G::R3 + k3], sc0);
+            }
+            if (U + per_round < nunits) {
+                const cf* __restrict__ src = p.w + (size_t)(U + per_round) * TPU * NY * 4 + lane_off;
+#pragma unroll
+                for (int q = 0; q < 16; ++q) a[q] = src[q * NT * 4];
+            }
+            __syncthreads();
+            // line-tiled store, 32 bytes per row and tile: 8 consecutive lanes fill two 128-byte lines
+            F4* __restrict__ pt = reinterpret_cast<F4*>(p.pt) + (size_t)slab * (NY / 8) * p.ntile_pad * 16;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int item = tid + THR * r, ky = item % NY, wt = item / NY;
+                const cf* s = lds + (4 * wt) * G::LDS + nat16(ky);
+                cf v[4];
+                v[0] = s[0]; v[1] = s[G::LDS]; v[2] = s[2 * G::LDS]; v[3] = s[3 * G::LDS];
+                F4* dst = pt + (((size_t)(ky >> 3) * p.ntile_pad + tile0 + wt) * 8 + (ky & 7)) * 2;
+                if constexpr (MODE == 2) {
+                    const F4 o0 = dst[0], o1 = dst[1];
+                    v[0] = cscale(cmulc(mk<float>(o0.x, o0.y), v[0]), p.scale); v[1] = cscale(cmulc(mk<float>(o0.z, o0.w), v[1]), p.scale);
+                    v[2] = cscale(cmulc(mk<float>(o1.x, o1.y), v[2]), p.scale); v[3] = cscale(cmulc(mk<float>(o1.z, o1.w), v[3]), p.scale);
+                    if (ISO) {
+                        const unsigned* __restrict__ tc = p.tcodes + ((size_t)unit * (NY * TPU) + item) * 4;
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) {
+                            const unsigned code = tc[c], cd = code & 0xffffu, cm = code >> 16;
+                            if (cd == cm) { if (cd) atomicAdd(&hist[2 * (cd - 1)], 2.0 * (double)v[c].re); }  // V + conj V
+                            else {
+                                if (cd) { atomicAdd(&hist[2 * (cd - 1)], (double)v[c].re); atomicAdd(&hist[2 * (cd - 1) + 1], (double)v[c].im); }
+                                if (cm) { atomicAdd(&hist[2 * (cm - 1)], (double)v[c].re); atomicAdd(&hist[2 * (cm - 1) + 1], -(double)v[c].im); }
+                            }
+                        }
+                    }
+                }
+                if (MODE == 0 || p.out != nullptr) {
+                    F4 d0, d1;
+                    d0.x = v[0].re; d0.y = v[0].im; d0.z = v[1].re; d0.w = v[1].im;
+                    d1.x = v[2].re; d1.y = v[2].im; d1.z = v[3].re; d1.w = v[3].im;
+                    dst[0] = d0; dst[1] = d1;
+                }
+            }
+            __syncthreads();
         }
-        __syncthreads();
     }
     if (ISO && cur_slab >= 0) {
         __syncthreads();
-        for (int i = tid; i < p.nbins; i += THR) {
+        for (int i = tid; i < p.nbins * HW; i += THR) {
             const double v = hist[i];
-            if (v != 0.0) atomicAdd(&p.iso[(size_t)cur_slab * p.nbins + i], v);
+            if (v != 0.0) atomicAdd(&p.iso[(size_t)cur_slab * p.nbins * HW + i], v);
         }
     }
 }
@@ -390,6 +450,50 @@ __global__ void __launch_bounds__(256) fastp2_untile_kernel(FastP2 p) {
             *reinterpret_cast<F4*>(mrow + ((nx - (4 * m + 4) + sx) & mx)) = v;
         }
         if (tid < 3) { const int kx = nxh - 3 + tid; mrow[(nx - kx + sx) & mx] = row[kx]; }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// complex variant (fft / cross_spectrum): a workgroup owns 4 rows (half of an 8-row group of the line-tiled
+// intermediate, still full 128-byte lines); the mirror half is the conjugate; the true-phase factors
+// exp(-i 2 pi k lag) (xrft.py:462-469) are applied here, to direct and mirrored samples alike.
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) fastp2_untile_c_kernel(FastP2 p) {
+    XRFT_DYN_SMEM(smem_raw);
+    cf* rows = reinterpret_cast<cf*>(smem_raw);
+    const int tid = threadIdx.x;
+    const int nx = p.nx, ny = p.ny, nxh = nx >> 1, ld = nxh + 4, mx = nx - 1, my = ny - 1;
+    const int gpr = ny >> 2;  // 4-row groups per slab
+    const int slab = blockIdx.x / gpr, kq = blockIdx.x % gpr, kb = kq >> 1, half = kq & 1;
+    const F4* __restrict__ src = reinterpret_cast<const F4*>(p.pt) + ((size_t)slab * (ny >> 3) + kb) * p.ntile_pad * 16 + half * 8;
+    for (int e = tid; e < p.ntile * 8; e += 256) {
+        const int tile = e >> 3, j = e & 7;  // j = row * 2 + column pair
+        const F4 v = src[tile * 16 + j];
+        cf* d = rows + (j >> 1) * ld + tile * 4 + 2 * (j & 1);
+        d[0] = mk<float>(v.x, v.y); d[1] = mk<float>(v.z, v.w);
+    }
+    __syncthreads();
+    cf* __restrict__ out = reinterpret_cast<cf*>(p.out) + (size_t)slab * ny * nx;
+    const int sx = p.shift_x;
+    for (int r = 0; r < 4; ++r) {
+        const int ky = kb * 8 + half * 4 + r, nky = (ny - ky) & my;
+        const cf* row = rows + r * ld;
+        const cf py = p.ph_y[ky], pmy = p.ph_y[nky];
+        cf* drow = out + (size_t)((ky + p.shift_y) & my) * nx;
+        cf* mrow = out + (size_t)((nky + p.shift_y) & my) * nx;
+        for (int m = tid; m < (nxh >> 1); m += 256) {  // direct, kx = 2m, 2m+1: one aligned 16-byte store
+            const cf v0 = cmul(cmul(row[2 * m], py), p.ph_x[2 * m]), v1 = cmul(cmul(row[2 * m + 1], py), p.ph_x[2 * m + 1]);
+            F4 o; o.x = v0.re; o.y = v0.im; o.z = v1.re; o.w = v1.im;
+            *reinterpret_cast<F4*>(drow + ((2 * m + sx) & mx)) = o;
+        }
+        if (tid == 0) drow[(nxh + sx) & mx] = cmul(cmul(row[nxh], py), p.ph_x[nxh]);
+        for (int m = tid; m < (nxh >> 1) - 1; m += 256) {  // mirror of kx = 2m+2, 2m+1 at columns nx - kx: again an aligned pair
+            const cf v2 = cmul(cmul(cconj(row[2 * m + 2]), pmy), p.ph_x[nx - (2 * m + 2)]);
+            const cf v1 = cmul(cmul(cconj(row[2 * m + 1]), pmy), p.ph_x[nx - (2 * m + 1)]);
+            F4 o; o.x = v2.re; o.y = v2.im; o.z = v1.re; o.w = v1.im;
+            *reinterpret_cast<F4*>(mrow + ((nx - (2 * m + 2) + sx) & mx)) = o;
+        }
+        if (tid == 0) { const int kx = nxh - 1; mrow[(nx - kx + sx) & mx] = cmul(cmul(cconj(row[kx]), pmy), p.ph_x[nx - kx]); }
     }
 }
 

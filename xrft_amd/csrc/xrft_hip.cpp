@@ -165,7 +165,9 @@ struct xrfthip_plan {
     // specialised path for float32 power spectra of power-of-two slabs, 1024..4096 per axis (fastp2.h)
     bool fast4096 = false;  // (the flag keeps its first name: the headline shape is where the path started)
     int fast_ntile = 0, fast_ntile_pad = 0;
-    DevBuf tw_fx, tw_fy, ones4096, what0, what1, tcodes;
+    DevBuf tw_fx, tw_fy, ones4096, what0, what1, tcodes, fph[2];
+    std::vector<double> host_phase[2];  // complex, as handed to xrfthip_plan_set_phase (empty = none)
+    bool fph_dirty = true;
     bool what_dirty = true;
     std::vector<double> host_win_x;
     // optional per-pass event timing (bench only)
@@ -540,9 +542,11 @@ void set_kernel_attrs_once() {
 #undef SETA
 #define SETF(K) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&K), hipFuncAttributeMaxDynamicSharedMemorySize, m)
     SETF((fastp2_rows_kernel<4096, 512>)); SETF((fastp2_rows_kernel<2048, 512>)); SETF((fastp2_rows_kernel<1024, 256>));
-    SETF((fastp2_cols_kernel<4096, 1024, false>)); SETF((fastp2_cols_kernel<2048, 1024, false>)); SETF((fastp2_cols_kernel<1024, 1024, false>));
-    SETF((fastp2_cols_kernel<4096, 1024, true>)); SETF((fastp2_cols_kernel<2048, 1024, true>)); SETF((fastp2_cols_kernel<1024, 768, true>));
-    SETF(fastp2_untile_kernel);
+#define SETC(M, I, T1) SETF((fastp2_cols_kernel<4096, 1024, M, I>)); SETF((fastp2_cols_kernel<2048, 1024, M, I>)); SETF((fastp2_cols_kernel<1024, T1, M, I>))
+    SETC(1, false, 1024); SETC(1, true, 768); SETC(0, false, 1024); SETC(2, false, 1024); SETC(2, true, 768);
+    SETF((fastp2_cols_kernel<1024, 768, 0, false>));
+#undef SETC
+    SETF(fastp2_untile_kernel); SETF(fastp2_untile_c_kernel);
 #undef SETF
 }
 
@@ -593,11 +597,14 @@ static int upload_real_table(xrfthip_plan* P, DevBuf& buf, const double* h, int6
     return buf.upload(f.data(), cnt * sizeof(float));
 }
 
+static bool fast_on(const xrfthip_plan* P);
+
 static void layout_workspace(xrfthip_plan* P) {
     const xrfthip_desc& d = P->d;
+    const bool fast = fast_on(P);
     long long G = d.slabs_per_group > 0 ? d.slabs_per_group : env_ll("XRFTHIP_GROUP", 0);
     size_t slab_w = (size_t)d.ny * P->width * P->csize;
-    if (P->fast4096) {
+    if (fast) {
         slab_w = (size_t)P->fast_ntile_pad * d.ny * 4 * sizeof(cf);
         if (G <= 0) G = env_ll("XRFTHIP_FAST_GROUP", std::max<long long>(1, (32LL * 4096 * 4096) / (d.ny * d.nx)));  // measured 8: 197, 16: 210, 32: 214 GFFT/s (tails and launch gaps amortise)
     }
@@ -617,10 +624,14 @@ static void layout_workspace(xrfthip_plan* P) {
     for (const Pass& p : P->passes) { if (p.out_kind == B_W2) need_w2 = true; if (p.out_kind == B_W) need_w = true; }
     P->off_w = off; if (need_w) off = al(off + (size_t)G * slab_w);
     P->off_w2 = off; if (need_w2) off = al(off + (size_t)G * d.ny * d.nx * P->csize);
-    P->off_f0 = off; if (nf == 2) off = al(off + (size_t)G * slab_w);
-    P->off_pt = off; if (P->fast4096 && !(d.flags & XRFTHIP_NO_SPECTRUM_OUT)) off = al(off + (size_t)G * (d.ny / 8) * P->fast_ntile_pad * 8 * sizeof(F4));
-    P->off_rowfit = off; if (P->fast4096) off = al(off + (size_t)G * d.ny * 2 * sizeof(double));
-    P->off_corr = off; if (P->fast4096) off = al(off + (size_t)G * d.ny * 2 * sizeof(float));
+    P->off_f0 = off; if (nf == 2 && !fast) off = al(off + (size_t)G * slab_w);
+    if (fast) {  // line-tiled result: float (power; not needed without a spectrum output) or complex (fft, cross)
+        const bool pw = d.out_mode == XRFTHIP_OUT_POWER;
+        P->off_pt = off;
+        if (!pw || !(d.flags & XRFTHIP_NO_SPECTRUM_OUT)) off = al(off + (size_t)G * (d.ny / 8) * P->fast_ntile_pad * 8 * sizeof(F4) * (pw ? 1 : 2));
+    }
+    P->off_rowfit = off; if (fast) off = al(off + (size_t)G * d.ny * 2 * sizeof(double));
+    P->off_corr = off; if (fast) off = al(off + (size_t)G * d.ny * 2 * sizeof(float));
     P->ws_bytes = off;
 }
 
@@ -714,20 +725,100 @@ static int fast_cols_gy(long long ny, bool iso) { return fast_cols_threads(ny, i
 static size_t fast_cols_lds(long long ny, bool iso) { return (size_t)fast_cols_gy(ny, iso) * (ny + 256) * sizeof(cf); }
 
 // float32 power spectrum of a power-of-two slab: row pass (detrend fused) -> [plane fit] -> column pass -> untile, per group of slabs
-static int run_fast4096(const xrfthip_plan* P, const float* in, float* out, double* iso, char* ws, hipStream_t st) {
+// combined per-axis factors of the complex modes: the true-phase table (or 1) times (-1)^k for an ifftshifted input
+// (rolling the input by n/2 -- xrft.py:436-441 -- is that sign in the spectrum; in a cross spectrum the two signs cancel)
+static int fast_phase_tables(xrfthip_plan* P) {
+    const xrfthip_desc& d = P->d;
+    for (int ax = 0; ax < 2; ++ax) {
+        const long long n = ax == 0 ? d.ny : d.nx;
+        const bool sign = d.out_mode == XRFTHIP_OUT_COMPLEX && (d.flags & (ax == 0 ? XRFTHIP_ISHIFT_Y : XRFTHIP_ISHIFT_X));
+        std::vector<cf> t((size_t)n);
+        for (long long k = 0; k < n; ++k) {
+            double re = 1.0, im = 0.0;
+            if (!P->host_phase[ax].empty()) { re = P->host_phase[ax][(size_t)(2 * k)]; im = P->host_phase[ax][(size_t)(2 * k + 1)]; }
+            if (sign && (k & 1)) { re = -re; im = -im; }
+            t[(size_t)k].re = (float)re; t[(size_t)k].im = (float)im;
+        }
+        int rc = P->fph[ax].upload(t.data(), t.size() * sizeof(cf));
+        if (rc) return rc;
+    }
+    P->fph_dirty = false;
+    return XRFTHIP_OK;
+}
+
+static bool phase_nontrivial(const xrfthip_plan* P) {
+    for (int ax = 0; ax < 2; ++ax)
+        for (size_t k = 0; k + 1 < P->host_phase[ax].size(); k += 2)
+            if (std::fabs(P->host_phase[ax][k] - 1.0) > 1e-12 || std::fabs(P->host_phase[ax][k + 1]) > 1e-12) return true;
+    return false;
+}
+
+// the specialised path is taken unless an isotropic cross spectrum carries a true-phase factor that is not 1 (two
+// fields with different lags): its radial sums would need the factor per sample inside the column pass
+static bool fast_on(const xrfthip_plan* P) {
+    if (!P->fast4096) return false;
+    if (P->d.out_mode == XRFTHIP_OUT_CROSS && (P->d.flags & XRFTHIP_ISO) && phase_nontrivial(P)) return false;
+    return true;
+}
+
+static void fast_launch_rows(const xrfthip_plan* P, const FastP2& p, long long gc, hipStream_t st) {
+    const xrfthip_desc& d = P->d;
+    xrfthip_plan::ProfRec* rec = prof_begin(P, "fastp2_rows", st);
+    const int thr = fast_rows_threads(d.nx), rw = 2 * thr / (int)(d.nx / 16);
+    const dim3 grid((unsigned)(gc * (d.ny / rw))), blk((unsigned)thr);
+    const size_t lds = fast_rows_lds(d.nx);
+    if (d.nx == 4096) { auto k = &fastp2_rows_kernel<4096, 512>; XRFT_LAUNCH(k, grid, blk, lds, st, p); }
+    else if (d.nx == 2048) { auto k = &fastp2_rows_kernel<2048, 512>; XRFT_LAUNCH(k, grid, blk, lds, st, p); }
+    else { auto k = &fastp2_rows_kernel<1024, 256>; XRFT_LAUNCH(k, grid, blk, lds, st, p); }
+    prof_end(rec, st);
+    if (d.detrend) {
+        rec = prof_begin(P, "fastp2_fit", st);
+        auto kf = &fastp2_fit_kernel;
+        XRFT_LAUNCH(kf, dim3((unsigned)gc), dim3(256), 3 * 256 * sizeof(double), st, (const double*)p.rowfit, p.win_y, const_cast<float*>(p.corr), (int)d.ny, (int)d.detrend);
+        prof_end(rec, st);
+    }
+}
+
+template <int MODE, bool ISO>
+static void fast_launch_cols(const xrfthip_plan* P, const FastP2& p, long long gc, hipStream_t st) {
+    const xrfthip_desc& d = P->d;
+    const bool iso_plan = (d.flags & XRFTHIP_ISO) != 0;  // decides the unit size (plan-wide: the tile padding depends on it)
+    xrfthip_plan::ProfRec* rec = prof_begin(P, MODE == 0 && d.out_mode == XRFTHIP_OUT_CROSS ? "fastp2_cols_f0" : "fastp2_cols", st);
+    const long long tpu = fast_cols_gy(d.ny, iso_plan) / 4;
+    const int cthr = fast_cols_threads(d.ny, iso_plan);
+    const long long nunits = gc * (P->fast_ntile_pad / tpu);
+    long long grid = std::min<long long>(env_ll("XRFTHIP_FAST_COLS_GRID", kCUs), ((nunits + 63) / 64) * 64);
+    grid = std::max<long long>(64, (grid / 64) * 64);
+    const size_t lds = fast_cols_lds(d.ny, iso_plan) + (ISO ? (size_t)P->nbins * sizeof(double) * (MODE == 2 ? 2 : 1) : 0);
+#define COLS_(NN, TT) do { auto k = &fastp2_cols_kernel<NN, TT, MODE, ISO>; XRFT_LAUNCH(k, dim3((unsigned)grid), dim3((unsigned)cthr), lds, st, p); } while (0)
+    if (d.ny == 4096) COLS_(4096, 1024);
+    else if (d.ny == 2048) COLS_(2048, 1024);
+    else if (cthr == 768) { if constexpr (ISO || MODE == 0) COLS_(1024, 768); }  // (the field-0 pass of an isotropic cross spectrum)
+    else { if constexpr (!ISO) COLS_(1024, 1024); }
+#undef COLS_
+    prof_end(rec, st);
+}
+
+// float32 spectra of a power-of-two slab, per group of slabs:  rows (detrend fused) -> [plane fit] -> columns -> untile.
+// A cross spectrum runs rows + columns for field 0 (complex, left line-tiled), then rows + columns for field 1, whose
+// column pass multiplies in place.
+static int run_fast4096(const xrfthip_plan* P, const float* in, const float* in1, void* out, double* iso, char* ws, hipStream_t st) {
     const xrfthip_desc& d = P->d;
     const size_t slab_pts = (size_t)d.ny * d.nx;
+    const bool want_out = !(d.flags & XRFTHIP_NO_SPECTRUM_OUT);
+    const bool iso_on = (d.flags & XRFTHIP_ISO) != 0;
+    const bool power = d.out_mode == XRFTHIP_OUT_POWER, cross = d.out_mode == XRFTHIP_OUT_CROSS;
     for (long long g0 = 0; g0 < d.batch; g0 += P->G) {
         const long long gc = std::min<long long>(P->G, d.batch - g0);
         FastP2 p{};
         p.in = in + (size_t)g0 * slab_pts;
         p.w = reinterpret_cast<cf*>(ws + P->off_w);
-        const bool want_out = !(d.flags & XRFTHIP_NO_SPECTRUM_OUT);
-        const bool iso_on = (d.flags & XRFTHIP_ISO) != 0;
-        p.pt = want_out ? reinterpret_cast<float*>(ws + P->off_pt) : nullptr;
-        p.out = want_out ? out + (size_t)g0 * slab_pts : nullptr;
+        p.pt = (!power || want_out) ? reinterpret_cast<float*>(ws + P->off_pt) : nullptr;
+        p.out = !want_out ? nullptr : power ? (float*)out + (size_t)g0 * slab_pts : (float*)((cf*)out + (size_t)g0 * slab_pts);
+        p.ph_y = reinterpret_cast<const cf*>(P->fph[0].p);
+        p.ph_x = reinterpret_cast<const cf*>(P->fph[1].p);
         p.tcodes = reinterpret_cast<const unsigned*>(P->tcodes.p);
-        p.iso = iso_on ? iso + (size_t)g0 * P->nbins : nullptr;
+        p.iso = iso_on ? iso + (size_t)g0 * P->nbins * (cross ? 2 : 1) : nullptr;
         p.nbins = P->nbins;
         p.tw_x = reinterpret_cast<const cf*>(P->tw_fx.p);
         p.tw_y = reinterpret_cast<const cf*>(P->tw_fy.p);
@@ -744,40 +835,28 @@ static int run_fast4096(const xrfthip_plan* P, const float* in, float* out, doub
         p.shift_y = (d.flags & XRFTHIP_SHIFT_Y) ? (int)(d.ny / 2) : 0;
         p.shift_x = (d.flags & XRFTHIP_SHIFT_X) ? (int)(d.nx / 2) : 0;
         p.scale = (float)d.scale;
-        xrfthip_plan::ProfRec* rec = prof_begin(P, "fastp2_rows", st);
-        {
-            const int thr = fast_rows_threads(d.nx), rw = 2 * thr / (int)(d.nx / 16);
-            const dim3 grid((unsigned)(gc * (d.ny / rw))), blk((unsigned)thr);
-            const size_t lds = fast_rows_lds(d.nx);
-            if (d.nx == 4096) { auto k = &fastp2_rows_kernel<4096, 512>; XRFT_LAUNCH(k, grid, blk, lds, st, p); }
-            else if (d.nx == 2048) { auto k = &fastp2_rows_kernel<2048, 512>; XRFT_LAUNCH(k, grid, blk, lds, st, p); }
-            else { auto k = &fastp2_rows_kernel<1024, 256>; XRFT_LAUNCH(k, grid, blk, lds, st, p); }
+        fast_launch_rows(P, p, gc, st);
+        if (power) {
+            if (iso_on) fast_launch_cols<1, true>(P, p, gc, st); else fast_launch_cols<1, false>(P, p, gc, st);
+        } else if (!cross) {
+            fast_launch_cols<0, false>(P, p, gc, st);
+        } else {
+            FastP2 p0 = p;
+            p0.scale = 1.0f;
+            fast_launch_cols<0, false>(P, p0, gc, st);
+            p.in = in1 + (size_t)g0 * slab_pts;
+            fast_launch_rows(P, p, gc, st);
+            if (iso_on) fast_launch_cols<2, true>(P, p, gc, st); else fast_launch_cols<2, false>(P, p, gc, st);
         }
-        prof_end(rec, st);
-        if (d.detrend) {
-            rec = prof_begin(P, "fastp2_fit", st);
-            auto kf = &fastp2_fit_kernel;
-            XRFT_LAUNCH(kf, dim3((unsigned)gc), dim3(256), 3 * 256 * sizeof(double), st, (const double*)p.rowfit, p.win_y, (float*)(ws + P->off_corr), (int)d.ny, (int)d.detrend);
-            prof_end(rec, st);
-        }
-        rec = prof_begin(P, "fastp2_cols", st);
-        {
-            const long long tpu = fast_cols_gy(d.ny, iso_on) / 4;
-            const int cthr = fast_cols_threads(d.ny, iso_on);
-            const long long nunits = gc * (P->fast_ntile_pad / tpu);
-            long long grid = std::min<long long>(env_ll("XRFTHIP_FAST_COLS_GRID", kCUs), ((nunits + 63) / 64) * 64);
-            grid = std::max<long long>(64, (grid / 64) * 64);
-            const size_t lds = fast_cols_lds(d.ny, iso_on) + (iso_on ? (size_t)P->nbins * sizeof(double) : 0);
-#define COLS_(NN, TT, II) do { auto k = &fastp2_cols_kernel<NN, TT, II>; XRFT_LAUNCH(k, dim3((unsigned)grid), dim3((unsigned)cthr), lds, st, p); } while (0)
-            if (iso_on) { if (d.ny == 4096) COLS_(4096, 1024, true); else if (d.ny == 2048) COLS_(2048, 1024, true); else COLS_(1024, 768, true); }
-            else { if (d.ny == 4096) COLS_(4096, 1024, false); else if (d.ny == 2048) COLS_(2048, 1024, false); else COLS_(1024, 1024, false); }
-#undef COLS_
-        }
-        prof_end(rec, st);
         if (want_out) {
-            rec = prof_begin(P, "fastp2_untile", st);
-            auto ku = &fastp2_untile_kernel;
-            XRFT_LAUNCH(ku, dim3((unsigned)((d.ny / 8) * gc)), dim3(256), (size_t)8 * (d.nx / 2 + 4) * sizeof(float), st, p);
+            xrfthip_plan::ProfRec* rec = prof_begin(P, "fastp2_untile", st);
+            if (power) {
+                auto ku = &fastp2_untile_kernel;
+                XRFT_LAUNCH(ku, dim3((unsigned)((d.ny / 8) * gc)), dim3(256), (size_t)8 * (d.nx / 2 + 4) * sizeof(float), st, p);
+            } else {
+                auto ku = &fastp2_untile_c_kernel;
+                XRFT_LAUNCH(ku, dim3((unsigned)((d.ny / 4) * gc)), dim3(256), (size_t)4 * (d.nx / 2 + 4) * sizeof(cf), st, p);
+            }
             prof_end(rec, st);
         }
         HIP_TRY(hipGetLastError());
@@ -900,8 +979,13 @@ int xrfthip_plan_create(xrfthip_plan** plan, const xrfthip_desc* desc) {
     }
     P->mirror = !cplx_in && !(d.flags & XRFTHIP_HALF_X) && P->width == d.nx / 2 + 1 && d.nx > 1;
     auto fast_len = [](long long n) { return n == 1024 || n == 2048 || n == 4096; };
-    P->fast4096 = d.ndim == 2 && fast_len(d.ny) && fast_len(d.nx) && d.dtype == XRFTHIP_F32 && d.out_mode == XRFTHIP_OUT_POWER &&
-                  !(d.flags & ~(XRFTHIP_SHIFT_Y | XRFTHIP_SHIFT_X | XRFTHIP_ISO | XRFTHIP_NO_SPECTRUM_OUT)) && !env_ll("XRFTHIP_NO_FAST", 0);
+    {
+        const uint32_t shifts = XRFTHIP_SHIFT_Y | XRFTHIP_SHIFT_X, ish = XRFTHIP_ISHIFT_Y | XRFTHIP_ISHIFT_X, isof = XRFTHIP_ISO | XRFTHIP_NO_SPECTRUM_OUT;
+        const uint32_t allowed = d.out_mode == XRFTHIP_OUT_POWER ? (shifts | isof) : d.out_mode == XRFTHIP_OUT_COMPLEX ? (shifts | ish)
+                                 : d.out_mode == XRFTHIP_OUT_CROSS ? (shifts | ish | isof) : 0u;
+        P->fast4096 = d.ndim == 2 && fast_len(d.ny) && fast_len(d.nx) && d.dtype == XRFTHIP_F32 && d.out_mode != XRFTHIP_OUT_PHASE &&
+                      !(d.flags & ~allowed) && !env_ll("XRFTHIP_NO_FAST", 0);
+    }
     if (P->fast4096) {
         const int tpu = fast_cols_gy(d.ny, (d.flags & XRFTHIP_ISO) != 0) / 4;  // tiles one column workgroup covers
         P->fast_ntile = (int)(d.nx / 8 + 1);
@@ -940,6 +1024,8 @@ int xrfthip_plan_set_window(xrfthip_plan* plan, int axis, const double* h_window
 int xrfthip_plan_set_phase(xrfthip_plan* plan, int axis, const double* h_phase, int64_t n) {
     if (!plan || axis < 0 || axis > 1) return XRFTHIP_BAD_ARG;
     if (h_phase && n != (axis == 0 ? plan->d.ny : plan->d.nx)) return XRFTHIP_BAD_ARG;
+    plan->host_phase[axis].assign(h_phase ? h_phase : nullptr, h_phase ? h_phase + 2 * n : nullptr);
+    plan->fph_dirty = true;
     return upload_real_table(plan, plan->phase[axis], h_phase, n, 1);
 }
 
@@ -949,25 +1035,35 @@ static int fast_build_tcodes(xrfthip_plan* P, const int32_t* bm) {
     const int ny = (int)P->d.ny, nx = (int)P->d.nx, nt = ny / 16, r3 = ny / 256, gy = fast_cols_gy(ny, true), tpu = gy / 4;
     const int units = P->fast_ntile_pad / tpu;
     const long long w = P->nx_out;
-    std::vector<uint32_t> t((size_t)units * 16 * gy * nt);
-    for (int un = 0; un < units; ++un)
-        for (int sl = 0; sl < 16; ++sl) {
-            const int b = sl / r3, k3 = sl % r3;
-            for (int g = 0; g < gy; ++g)
-                for (int u = 0; u < nt; ++u) {
-                    const int pr = u + nt * b, ky = (pr >> 4) + 16 * (pr & 15) + 256 * k3, kx = 4 * un * tpu + g;
-                    uint32_t v = 0;
-                    if (kx <= nx / 2) {
-                        const int32_t cd = bm[(size_t)ky * w + kx];
-                        if (cd >= 0) v |= (uint32_t)(cd + 1);
-                        if (kx > 0 && kx < nx - kx) {
-                            const int32_t cm = bm[(size_t)(ky == 0 ? 0 : ny - ky) * w + (nx - kx)];
-                            if (cm >= 0) v |= (uint32_t)(cm + 1) << 16;
-                        }
-                    }
-                    t[(((size_t)un * 16 + sl) * gy + g) * nt + u] = v;
-                }
+    auto code = [&](int ky, int kx) -> uint32_t {
+        uint32_t v = 0;
+        if (kx <= nx / 2) {
+            const int32_t cd = bm[(size_t)ky * w + kx];
+            if (cd >= 0) v |= (uint32_t)(cd + 1);
+            if (kx > 0 && kx < nx - kx) {
+                const int32_t cm = bm[(size_t)(ky == 0 ? 0 : ny - ky) * w + (nx - kx)];
+                if (cm >= 0) v |= (uint32_t)(cm + 1) << 16;
+            }
         }
+        return v;
+    };
+    std::vector<uint32_t> t((size_t)units * 16 * gy * nt);
+    if (P->d.out_mode == XRFTHIP_OUT_CROSS) {  // the cross pass bins in its store loop: [unit][item = tile * ny + ky][column of the tile]
+        for (int un = 0; un < units; ++un)
+            for (int wt = 0; wt < tpu; ++wt)
+                for (int ky = 0; ky < ny; ++ky)
+                    for (int c = 0; c < 4; ++c) t[(((size_t)un * tpu + wt) * ny + ky) * 4 + c] = code(ky, 4 * (un * tpu + wt) + c);
+    } else {
+        for (int un = 0; un < units; ++un)
+            for (int sl = 0; sl < 16; ++sl) {
+                const int b = sl / r3, k3 = sl % r3;
+                for (int g = 0; g < gy; ++g)
+                    for (int u = 0; u < nt; ++u) {
+                        const int pr = u + nt * b, ky = (pr >> 4) + 16 * (pr & 15) + 256 * k3;
+                        t[(((size_t)un * 16 + sl) * gy + g) * nt + u] = code(ky, 4 * un * tpu + g);
+                    }
+            }
+    }
     return P->tcodes.upload(t.data(), t.size() * sizeof(uint32_t));
 }
 
@@ -979,7 +1075,8 @@ int xrfthip_plan_set_binmap(xrfthip_plan* plan, const int32_t* h_binmap, int64_t
     plan->nbins = nbins;
     if (plan->fast4096) {
         int rcf = XRFTHIP_OK;
-        if (nbins > 2048) plan->fast4096 = false;  // the histogram must fit behind the column pass's FFT buffers
+        const size_t hist_bytes = (size_t)nbins * sizeof(double) * (plan->d.out_mode == XRFTHIP_OUT_CROSS ? 2 : 1);
+        if (nbins > 65534 || fast_cols_lds(plan->d.ny, true) + hist_bytes > kLdsMax) plan->fast4096 = false;  // the histogram sits behind the column pass's FFT buffers
         else rcf = fast_build_tcodes(plan, h_binmap);
         if (rcf) return rcf;
     }
@@ -1030,7 +1127,7 @@ int xrfthip_plan_describe(const xrfthip_plan* plan, char* buf, size_t buflen) {
     appendf(s, "xrfthip plan: ndim=%d batch=%lld ny=%lld nx=%lld dtype=%d mode=%d detrend=%d flags=0x%x width=%lld nx_out=%lld mirror=%d group=%d ws=%zuB\n",
             d.ndim, (long long)d.batch, (long long)d.ny, (long long)d.nx, d.dtype, d.out_mode, d.detrend, d.flags,
             plan->width, plan->nx_out, (int)plan->mirror, plan->G, plan->ws_bytes);
-    if (plan->fast4096) {
+    if (fast_on(plan)) {
         const long long nx = plan->d.nx, ny = plan->d.ny;
         appendf(s, "  [fastp2] rows: %d thr (row-local detrend fused), %dx(2 real rows -> 1 complex FFT%lld r16x16x%lld), lds=%zuB, tiled W[slab][%d][%lld][4] -> cols: %lld columns/unit (FFT%lld r16x16x%lld), lds=%zuB, persistent, line-tiled |F|^2 -> untile+shift+mirror: 256 thr, 8 rows\n",
                 fast_rows_threads(nx), fast_rows_threads(nx) / (int)(nx / 16), nx, nx / 256, fast_rows_lds(nx), plan->fast_ntile_pad, ny,
@@ -1066,9 +1163,10 @@ int xrfthip_exec(const xrfthip_plan* plan, const void* d_in0, const void* d_in1,
     double* coef = (double*)(ws + P->off_coef);
     if (det) HIP_TRY(hipMemsetAsync(acc, 0, (size_t)d.batch * 6 * sizeof(double) * (cross ? 2 : 1), st));
     if (iso) HIP_TRY(hipMemsetAsync(d_iso, 0, (size_t)d.batch * P->nbins * (cross ? 16 : 8), st));
-    if (P->fast4096) {
+    if (fast_on(P)) {
         if (P->what_dirty) { int rcw = fast4096_window_spectra(const_cast<xrfthip_plan*>(P)); if (rcw) return rcw; }
-        return run_fast4096(P, (const float*)d_in0, (float*)out, (double*)d_iso, ws, st);
+        if (P->fph_dirty && d.out_mode != XRFTHIP_OUT_POWER) { int rcp = fast_phase_tables(const_cast<xrfthip_plan*>(P)); if (rcp) return rcp; }
+        return run_fast4096(P, (const float*)d_in0, (const float*)d_in1, out, (double*)d_iso, ws, st);
     }
     for (long long g0 = 0; g0 < d.batch; g0 += P->G) {
         const long long gc = std::min<long long>(P->G, d.batch - g0);
