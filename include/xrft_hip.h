@@ -147,6 +147,16 @@ size_t xrfthip_detrend_workspace_bytes(int64_t batch);
 int xrfthip_detrend(int32_t dtype, int32_t ndim, int64_t batch, int64_t ny, int64_t nx, int32_t detrend_type,
                     const void* d_in, void* d_out, void* d_workspace, size_t ws_bytes, void* stream);
 
+/* The same over the last THREE axes (n0, n1, n2) of [batch][n0][n1][n2]: mean, or the least-squares hyperplane
+ * a0 + a1 i + a2 j + a3 k of xrft/detrend.py:116-138 (_detrend_3d_ufunc).  Same workspace size as xrfthip_detrend. */
+int xrfthip_detrend3(int32_t dtype, int64_t batch, int64_t n0, int64_t n1, int64_t n2, int32_t detrend_type,
+                     const void* d_in, void* d_out, void* d_workspace, size_t ws_bytes, void* stream);
+
+/* Tail of power_spectrum / cross_spectrum (xrft.py:740, 825) on already transformed fields, for transforms over more
+ * than two axes that are composed of several plans: d_out[e] = |d_a[e]|^2 * scale (real, d_b NULL) or
+ * d_a[e] * conj(d_b[e]) * scale (complex).  dtype = XRFTHIP_C64 | XRFTHIP_C128 (type of d_a / d_b). */
+int xrfthip_spectrum_tail(int32_t dtype, int64_t n, const void* d_a, const void* d_b, void* d_out, double scale, void* stream);
+
 /* Stand-alone radial bin-sum of an existing spectrum (xrft.isotropize, xrft.py:948-1010):
  * d_in [batch][ny][nx] (dtype F32|F64|C64|C128), d_binmap device int32 [ny][nx], d_iso float64|complex128
  * [batch][nbins] (zeroed by the call). */

@@ -283,8 +283,20 @@ def _detrend_2d_ufunc(arr):
     return arr - np.reshape(d_est, N)
 
 
+def _detrend_3d_ufunc(arr):
+    """detrend.py:116-138 restated: hyperplane a0 + a1(i+1) + a2(j+1) + a3(k+1) by numpy.linalg.lstsq."""
+    assert arr.ndim == 3
+    N0, N1, N2 = arr.shape
+    i = np.repeat(np.arange(N0), N1 * N2) + 1
+    j = np.tile(np.repeat(np.arange(N1), N2), N0) + 1
+    k = np.tile(np.arange(N2), N0 * N1) + 1
+    G = np.stack([np.ones(N0 * N1 * N2), i, j, k], axis=1)
+    m_est, _, _, _ = np.linalg.lstsq(G, arr.reshape(-1, 1), rcond=None)
+    return arr - (G @ m_est).reshape(N0, N1, N2)
+
+
 def detrend(da, dim, detrend_type="constant"):
-    """detrend.py:11-97 (constant, linear 1-D, linear 2-D; 3-D is out of scope)."""
+    """detrend.py:11-97 (constant over any dims; linear 1-D, 2-D, 3-D)."""
     if dim is None:
         dim = list(da.dims)
     elif isinstance(dim, str):
@@ -307,7 +319,67 @@ def detrend(da, dim, detrend_type="constant"):
         other = [d for d in da.dims if d not in dim]
         res = OArr(out, tuple(other) + tuple(dim), da._coords_raw(), da.attrs, da.coord_attrs, da.name)
         return res  # NB: core dims are last, as with apply_ufunc; fft() transposes back (xrft.py:427-428)
-    raise NotImplementedError("Only 1D and 2D detrending are restated in the oracle.")
+    if len(dim) == 3:  # detrend.py:82-91
+        v = np.moveaxis(da.values, axis_num, [-3, -2, -1])
+        out = np.empty(v.shape, dtype=da.values.dtype)
+        for idx in np.ndindex(*v.shape[:-3]):
+            out[idx] = _detrend_3d_ufunc(v[idx])
+        other = [d for d in da.dims if d not in dim]
+        return OArr(out, tuple(other) + tuple(dim), da._coords_raw(), da.attrs, da.coord_attrs, da.name)
+    raise NotImplementedError("Only 1D, 2D, and 3D detrending are implemented so far.")
+
+
+# --------------------------------------------------------------------------------------------------
+# pad / unpad  (reference: xrft/padding.py)
+# --------------------------------------------------------------------------------------------------
+def _pad_coordinates_callback(vector, iaxis_pad_width, iaxis, kwargs):
+    """padding.py:277-323."""
+    spacing = kwargs["spacing"]
+    n_start, n_end = iaxis_pad_width[:]
+    vmin, vmax = vector[n_start], vector[-(n_end + 1)]
+    vector[:n_start] = vmin - n_start * spacing + np.linspace(0, spacing * (n_start - 1), n_start)
+    vector[len(vector) - n_end:] = vmax + spacing + np.linspace(0, spacing * (n_end - 1), n_end)
+    return vector
+
+
+def pad(da, pad_width=None, mode="constant", constant_values=0, **pad_width_kwargs):
+    """padding.py:11-193 for the gather / constant modes: numpy.pad on the values (what xarray's .pad does), linear
+    extrapolation of the coordinates, ``pad_width`` attribute on every padded coordinate."""
+    pad_width = dict(pad_width or {}, **pad_width_kwargs)
+    full = [(0, 0)] * da.values.ndim
+    for d, w in pad_width.items():
+        full[da.get_axis_num(d)] = (w, w) if isinstance(w, int) else tuple(w)
+    kw = {"constant_values": constant_values} if mode == "constant" else {}
+    values = np.pad(da.values, full, mode=mode, **kw)
+    coords = dict(da._coords_raw())
+    cattrs = {k: dict(v) for k, v in da.coord_attrs.items()}
+    for d, w in pad_width.items():
+        c = np.asarray(da.coord(d))
+        spacing = np.diff(c)[0]
+        coords[d] = np.pad(c, full[da.get_axis_num(d)], mode=_pad_coordinates_callback, spacing=spacing)
+        cattrs.setdefault(d, {})["pad_width"] = w
+    return OArr(values, da.dims, coords, da.attrs, cattrs, da.name)
+
+
+def unpad(da, pad_width=None, **pad_width_kwargs):
+    """padding.py:326-446."""
+    if pad_width is None and not pad_width_kwargs:
+        pad_width = {d: a["pad_width"] for d, a in da.coord_attrs.items() if "pad_width" in a}
+        if not pad_width:
+            raise ValueError("The passed array doesn't seem to be a padded one")
+    else:
+        pad_width = dict(pad_width or {}, **pad_width_kwargs)
+    values = da.values
+    coords = dict(da._coords_raw())
+    cattrs = {k: dict(v) for k, v in da.coord_attrs.items()}
+    for d, w in pad_width.items():
+        w = (w, w) if isinstance(w, int) else tuple(w)
+        ax = da.get_axis_num(d)
+        sl = slice(w[0], values.shape[ax] - w[1])
+        values = values[(slice(None),) * ax + (sl,)]
+        coords[d] = np.asarray(da.coord(d))[sl]
+        cattrs.get(d, {}).pop("pad_width", None)
+    return OArr(values, da.dims, coords, da.attrs, cattrs, da.name)
 
 
 # --------------------------------------------------------------------------------------------------

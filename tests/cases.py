@@ -10,6 +10,8 @@ the tests assert much tighter float64 agreement (1e-10).
 import warnings
 
 import numpy as np
+import numpy.testing as npt
+import pytest
 
 import xrft_amd as xa
 from oracle import xrft_oracle as o
@@ -310,3 +312,98 @@ def run_segment_cases(dtype="float64"):
     with pytest.raises(ValueError):  # several chunks along a transform dim without chunks_to_segments (test_xrft.py:166-170)
         xa.fft(da.chunk({"x": 1}), dim=["x"])
     return max(e1, e2, e3)
+
+
+# ---------------------------------------------------------------------------------- SURVEY 8 f4
+def run_nd_cases(dtype):
+    """Transforms over three and four axes (the reference hands all axes to fftn at once, xrft.py:439-447)."""
+    tol = TOL[dtype]
+    rng = np.random.default_rng(77)
+    shape = (2, 6, 8, 10)
+    v = rng.standard_normal(shape).astype(dtype)
+    ii, jj, kk = np.meshgrid(np.arange(6), np.arange(8), np.arange(10), indexing="ij")
+    v = v + (0.3 * ii - 0.2 * jj + 0.1 * kk + 2.0).astype(dtype)[None]
+    coords = {"t": np.arange(2), "z": np.arange(6) * 0.5 + 1.0, "y": np.arange(8) * 2.0 - 3.0, "x": np.arange(10) * 0.25}
+    da, od = pair(v, ("t", "z", "y", "x"), coords)
+    d3 = ["z", "y", "x"]
+    for kw in (dict(), dict(detrend="linear", window="hann"), dict(true_phase=False, shift=False, detrend="constant"),
+               dict(true_amplitude=False, window="hamming")):
+        check(xa.fft(da, dim=d3, **kw), o.fft(od, dim=d3, **kw), tol)
+    check(xa.fft(da, dim=["x", "z", "y"], detrend="linear"), o.fft(od, dim=["x", "z", "y"], detrend="linear"), tol)
+    check(xa.fft(da, dim=d3, real_dim="x", window="hann"), o.fft(od, dim=d3, real_dim="x", window="hann"), tol)
+    check(xa.fft(da, detrend="constant"), o.fft(od, detrend="constant"), tol)  # all four axes
+    for kw in (dict(), dict(detrend="linear", window="hann", window_correction=True), dict(scaling="spectrum", window="hann", window_correction=True),
+               dict(scaling="false_density", detrend="constant")):
+        check(xa.power_spectrum(da, dim=d3, **kw), o.power_spectrum(od, dim=d3, **kw), tol)
+    w = rng.standard_normal(shape).astype(dtype)
+    c2 = dict(coords, z=coords["z"] + 0.5)
+    db, ob = pair(w, ("t", "z", "y", "x"), c2)
+    for kw in (dict(), dict(detrend="linear", window="hann"), dict(true_phase=False)):
+        check(xa.cross_spectrum(da, db, dim=d3, **kw), o.cross_spectrum(od, ob, dim=d3, **kw), tol)
+    with pytest.raises(NotImplementedError):
+        xa.fft(da, detrend="linear")  # 4-D linear detrend: "Only 1D, 2D, and 3D detrending"
+
+
+def run_detrend3_cases(dtype):
+    tol = TOL["float32" if dtype == "float32" else "float64"]
+    rng = np.random.default_rng(78)
+    for shape, dims in (((3, 6, 5, 4), ["z", "y", "x"]), ((2, 9, 16, 12), ["x", "z", "y"]), ((4, 1, 7, 3), ["z", "y", "x"])):
+        v = rng.standard_normal(shape)
+        ii, jj, kk = np.meshgrid(*[np.arange(n) for n in shape[1:]], indexing="ij")
+        v = v + (0.3 * ii - 0.7 * jj + 0.11 * kk + 5.0)[None]
+        if dtype.startswith("complex"):
+            v = v + 1j * (rng.standard_normal(shape) - 0.2 * ii[None] + 0.05 * kk[None])
+        v = v.astype(dtype)
+        da, od = pair(v, ("t", "z", "y", "x"))
+        for kind in ("constant", "linear"):
+            if dtype.startswith("complex") and kind == "linear":
+                ref = o.detrend(o.OArr(v.real, od.dims), dims, kind).transpose("t", "z", "y", "x").values + 1j * o.detrend(
+                    o.OArr(v.imag, od.dims), dims, kind).transpose("t", "z", "y", "x").values
+            else:
+                r = o.detrend(od, dims, kind)
+                ref = r.transpose("t", "z", "y", "x").values if r.dims != od.dims else r.values
+            got = xa.detrend(da, dims, kind)
+            assert tuple(got.dims) == ("t", "z", "y", "x")
+            err = np.abs(got.values - ref).max() / max(np.abs(ref).max(), 1e-300)
+            assert err < tol, (shape, dims, kind, err)
+
+
+def run_pad_cases():
+    rng = np.random.default_rng(79)
+    v = rng.standard_normal((3, 5, 6))
+    coords = {"t": np.arange(3), "y": np.arange(5) * 0.5 - 1.0, "x": np.arange(6) * 2.0 + 10.0}
+    for data in (v, None):
+        if data is None:
+            import torch
+
+            arr = xa.DataArray(torch.from_numpy(v.copy()), ("t", "y", "x"), coords)
+        else:
+            arr = xa.DataArray(v, ("t", "y", "x"), coords)
+        od = o.OArr(v, ("t", "y", "x"), coords)
+        for kw, mode in ((dict(x=2, y=1), "constant"), (dict(x=(1, 4)), "constant"), (dict(y=(0, 3), x=(2, 0)), "edge"),
+                         (dict(x=3), "wrap"), (dict(y=2, x=2), "reflect"), (dict(x=(2, 1)), "symmetric")):
+            got = xa.pad(arr, mode=mode, **kw)
+            ref = o.pad(od, mode=mode, **kw)
+            npt.assert_array_equal(got.values, ref.values)
+            for d in ("y", "x"):
+                npt.assert_array_equal(got[d].values, ref.coord(d))
+                if d in kw:
+                    assert got[d].attrs["pad_width"] == kw[d]
+            back = xa.unpad(got)
+            npt.assert_array_equal(back.values, v)
+            for d in ("y", "x"):
+                npt.assert_array_equal(back[d].values, coords[d])
+                assert "pad_width" not in back[d].attrs
+        got = xa.pad(arr, x=2, constant_values=7.5)
+        npt.assert_array_equal(got.values, o.pad(od, x=2, constant_values=7.5).values)
+        npt.assert_array_equal(xa.unpad(xa.pad(arr, x=2, y=1), x=1, y=1).values, np.pad(v, ((0, 0), (0, 0), (1, 1))))
+        npt.assert_array_equal(xa.pad(arr, x=2, mode="mean").values, np.pad(v, ((0, 0), (0, 0), (2, 2)), mode="mean"))
+        npt.assert_array_equal(xa.pad(arr, x=2, mode="linear_ramp", end_values=1.0).values,
+                               np.pad(v, ((0, 0), (0, 0), (2, 2)), mode="linear_ramp", end_values=1.0))
+    # the padded array transforms like any other (test_padding.py:207-235: fft of a padded array, unpad after ifft)
+    da1 = xa.DataArray(v[0, 0], ("x",), {"x": coords["x"]})
+    p = xa.pad(da1, x=4)
+    ft = xa.fft(p, true_phase=True)
+    back = xa.unpad(xa.ifft(ft, lag=[ft["freq_x"].attrs["direct_lag"]]), x=4)
+    npt.assert_allclose(back.values.real, v[0, 0], atol=1e-12)
+    npt.assert_allclose(back["x"].values, coords["x"], atol=1e-12)

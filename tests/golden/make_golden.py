@@ -78,6 +78,50 @@ def gen_reference_files():
     print("reference-generated: ref_freq.npz, ref_detrend2d.npz")
 
 
+def gen_reference_misc():
+    """More helpers run from the reference's own source: _ifreq (xrft.py:158-175), fit_loglog (:1190-1210),
+    _detrend_3d_ufunc (detrend.py:116-138), padding helpers (padding.py:277-323, 425-446)."""
+    rx, rd = import_reference()
+    import importlib
+    sys.modules.setdefault("xrft.utils", types.ModuleType("xrft.utils")).get_spacing = lambda c: None
+    rp = importlib.import_module("xrft.padding")
+    out = {}
+    cases = []
+    i = 0
+    for N in ([8], [9], [16, 9], [6, 5]):
+        for real in (None, "x"):
+            for shift in (False, True):
+                dx = [0.5 * (1 + j) for j in range(len(N))]
+                k = rx._ifreq(N, dx, real, shift)
+                for j, kk in enumerate(k):
+                    out[f"ik_{i}_{j}"] = kk
+                cases.append((len(N),) + tuple(N) + (0,) * (2 - len(N)) + tuple(dx) + (0.0,) * (2 - len(N))
+                             + (0 if real is None else 1, int(shift)))
+                i += 1
+    out["ifreq_cases"] = np.array(cases, dtype=np.float64)
+    rng = np.random.default_rng(20260927 + 7)
+    x = np.arange(1, 200, dtype=np.float64) * 0.01
+    y = 3.5 * x ** -2.7 * np.exp(0.05 * rng.standard_normal(x.size))
+    out["loglog_x"], out["loglog_y"] = x, y
+    fit = rx.fit_loglog(x, y)  # (y_fit, a, b)
+    out["loglog_yfit"], out["loglog_ab"] = np.asarray(fit[0], dtype=np.float64), np.array([fit[1], fit[2]], dtype=np.float64)
+    for j, shape in enumerate([(6, 5, 4), (9, 16, 12), (3, 32, 8)]):
+        ii, jj, kk = np.meshgrid(*[np.arange(n) for n in shape], indexing="ij")
+        arr = rng.standard_normal(shape) + 0.3 * ii - 0.7 * jj + 0.11 * kk + 5.0
+        out[f"d3_in_{j}"] = arr
+        out[f"d3_out_{j}"] = rd._detrend_3d_ufunc(arr)
+    pcs = []
+    for j, (c0, n, sp, pw) in enumerate([(0.0, 3, 1.0, (2, 2)), (-5.0, 7, 0.25, (1, 4)), (10.0, 5, -2.0, (3, 0)), (1e3, 16, 1e-3, (0, 5))]):
+        coord = c0 + sp * np.arange(n)
+        out[f"pad_in_{j}"] = coord
+        out[f"pad_out_{j}"] = np.pad(coord, pad_width=pw, mode=rp._pad_coordinates_callback, spacing=sp)
+        sl = rp._pad_width_to_slice(pw, n + sum(pw))
+        pcs.append((sp, pw[0], pw[1], sl.start, sl.stop))
+    out["pad_cases"] = np.array(pcs, dtype=np.float64)
+    np.savez_compressed(os.path.join(HERE, "ref_misc.npz"), **out)
+    print("reference-generated: ref_misc.npz")
+
+
 def gen_oracle_cases():
     from oracle import xrft_oracle as o
     import warnings
@@ -152,9 +196,15 @@ def gen_oracle_cases():
     print("oracle-generated: case_ps2d_f64.npz, case_ps2d_f32_real.npz, case_cs2d.npz, case_iso.npz, case_dft1d_f32.npz")
 
 
+if __name__ == "__main__" and "--misc-only" in sys.argv:
+    gen_reference_misc()
+    sys.exit(0)
+
 if __name__ == "__main__":
     if os.path.isdir("/root/reference/xrft"):
         gen_reference_files()
     else:
         print("no /root/reference: skipping reference-generated files")
+    if os.path.isdir("/root/reference/xrft"):
+        gen_reference_misc()
     gen_oracle_cases()

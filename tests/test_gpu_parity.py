@@ -348,3 +348,32 @@ def test_cross_phase(dtype):
 @pytest.mark.parametrize("dtype", ["float64", "float32"])
 def test_chunks_to_segments(dtype):
     cases.run_segment_cases(dtype)
+
+
+# ---------------------------------------------------------------------------------- SURVEY 8 f4
+@pytest.mark.parametrize("dtype", ["float64", "float32"])
+def test_nd_transforms(dtype):
+    cases.run_nd_cases(dtype)
+
+
+@pytest.mark.parametrize("dtype", ["float64", "float32", "complex128"])
+def test_detrend3(dtype):
+    cases.run_detrend3_cases(dtype)
+
+
+def test_pad_unpad():
+    cases.run_pad_cases()
+
+
+def test_nd_larger_block_f32():
+    """(2, 32, 64, 128) float32 over three axes with linear detrend + Hann: 3-D detrend kernel + composed plans."""
+    import xrft_amd as xa
+
+    rng = np.random.default_rng(5)
+    v = rng.standard_normal((2, 32, 64, 128)).astype(np.float32)
+    ii, jj, kk = np.meshgrid(np.arange(32), np.arange(64), np.arange(128), indexing="ij")
+    v += (0.05 * ii - 0.02 * jj + 0.01 * kk + 1.0).astype(np.float32)[None]
+    c = {"t": np.arange(2), "z": np.arange(32) * 1.0, "y": np.arange(64) * 0.5, "x": np.arange(128) * 0.25}
+    got = xa.power_spectrum(_da(v, ("t", "z", "y", "x"), c), dim=["z", "y", "x"], detrend="linear", window="hann")
+    ref = o.power_spectrum(o.OArr(v, ("t", "z", "y", "x"), c), dim=["z", "y", "x"], detrend="linear", window="hann")
+    cases.check(got, ref, 3e-4)

@@ -366,6 +366,108 @@ def _execute(c, da, mode, scale, da2=None, c2=None, iso=None, extra_flags=0):
 
 
 # ------------------------------------------------------------------------------------------------------
+# more than two transform axes: numpy's fftn is separable, so the reference's N-D transform
+# (xrft.py:439-447) is the fused two-axis plan over the last two listed dims followed by one- or two-axis plans over
+# the remaining ones; detrending needs the whole block and runs first as its own device pass; windows, shifts, phase
+# factors and the dx amplitude factor are per-axis and travel with the stage that transforms the axis.
+# ------------------------------------------------------------------------------------------------------
+def _nd_dims(da, dim, real_dim, real):
+    """The normalised dim list if it has more than two entries, else None."""
+    if dim is None:
+        dims = list(da.dims)
+    elif isinstance(dim, str):
+        return None
+    else:
+        dims = list(dim)
+    if len(dims) <= 2:
+        return None
+    rd = real if real is not None else real_dim
+    if rd is not None:
+        if rd not in da.dims:
+            raise ValueError("The dimension along which real FT is taken must be one of the existing dimensions.")
+        dims = _move_to_end(dims, rd)
+    for d in dims:
+        da.get_axis_num(d)
+    return dims
+
+
+def _fft_nd(da, dims, spacing_tol, real_dim, shift, detrend_, window, true_phase, true_amplitude, chunks_to_segments,
+            prefix):
+    if chunks_to_segments:
+        raise NotImplementedError("chunks_to_segments is implemented for one or two transform dimensions.")
+    if detrend_ not in (None, "constant", "linear"):
+        raise NotImplementedError("%s is not a valid detrending option. Valid options are: 'constant','linear', "
+                                  "or None." % detrend_)
+    cur = da
+    if detrend_ is not None:
+        cur = from_any(detrend(cur, dims, detrend_))
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore", FutureWarning)
+        cur = fft(cur, spacing_tol=spacing_tol, dim=dims[-2:], real_dim=real_dim, shift=shift, detrend=None,
+                  window=window, true_phase=true_phase, true_amplitude=true_amplitude, prefix=prefix)
+        rest = dims[:-2]
+        sh = False if real_dim is not None else shift  # xrft.py:403: a real transform switches every shift off
+        while rest:
+            grp, rest = rest[-2:], rest[:-2]
+            cur = fft(cur, spacing_tol=spacing_tol, dim=grp, shift=sh, detrend=None, window=window,
+                      true_phase=true_phase, true_amplitude=true_amplitude, prefix=prefix)
+    return cur
+
+
+def _spectrum_nd(da, da2, dims, real_dim, scaling, window_correction, true_phase, kwargs):
+    """power_spectrum / cross_spectrum over more than two axes: N-D transform(s), then the elementwise tail."""
+    if "density" in kwargs:
+        scaling = "density" if kwargs.pop("density") else "false_density"
+    if real_dim is not None or kwargs.get("real") is not None:
+        raise NotImplementedError("real_dim with more than two transform dimensions is not implemented in xrft_amd.")
+    for k in ("true_amplitude", "true_phase"):
+        kwargs.pop(k, None)
+    kw = dict(spacing_tol=1e-3, shift=True, detrend=None, window=None, chunks_to_segments=False, prefix="freq_")
+    unknown = set(kwargs) - set(kw) - {"real"}
+    if unknown:
+        raise TypeError(f"fft() got an unexpected keyword argument {sorted(unknown)[0]!r}")
+    kw.update({k: v for k, v in kwargs.items() if k != "real"})
+    f1 = _fft_nd(da, dims, kw["spacing_tol"], None, kw["shift"], kw["detrend"], kw["window"], true_phase, True,
+                 kw["chunks_to_segments"], kw["prefix"])
+    f2 = None
+    if da2 is not None:
+        f2 = _fft_nd(da2, dims, kw["spacing_tol"], None, kw["shift"], kw["detrend"], kw["window"], true_phase, True,
+                     kw["chunks_to_segments"], kw["prefix"])
+        if tuple(f1.dims) != tuple(f2.dims):
+            raise ValueError("The two datasets have different dimensions")
+    pf = kw["prefix"]
+    new = [pf + d if d[: len(pf)] != pf else d[len(pf):] for d in dims]  # xrft.py:186
+    scale = 1.0
+    if scaling != "false_density":
+        if window_correction:
+            if kw["window"] is None:
+                raise ValueError("window_correction can only be applied when windowing is turned on.")
+            vecs = [_window_vector(kw["window"], da.sizes[d]) for d in dims]
+            if scaling == "density":
+                scale /= float(np.prod([(v ** 2).mean() for v in vecs]))
+            elif scaling == "spectrum":
+                scale /= float(np.prod([v.mean() for v in vecs])) ** 2
+            else:
+                raise ValueError("Unknown {} scaling flag".format(scaling))
+        fs = float(np.prod([float(f1[n].attrs["spacing"]) for n in new]))
+        if scaling == "density":
+            scale *= fs
+        elif scaling == "spectrum":
+            scale *= fs ** 2
+        else:
+            raise ValueError("Unknown {} scaling flag".format(scaling))
+    a = _to_device(f1.data).contiguous()
+    b = None
+    if f2 is not None:
+        b = _to_device(f2.data).contiguous()
+        if b.dtype != a.dtype:
+            dt = torch.promote_types(a.dtype, b.dtype)
+            a, b = a.to(dt), b.to(dt)
+    out = engine.spectrum_tail(a, b, scale)
+    return DataArray(out, f1.dims, f1.coords, None, None)
+
+
+# ------------------------------------------------------------------------------------------------------
 # public API
 # ------------------------------------------------------------------------------------------------------
 def fft(da, spacing_tol=1e-3, dim=None, real_dim=None, shift=True, detrend=None, window=None, true_phase=True,
@@ -373,6 +475,10 @@ def fft(da, spacing_tol=1e-3, dim=None, real_dim=None, shift=True, detrend=None,
     """Discrete Fourier transform of ``da`` along ``dim`` (reference: xrft/xrft.py:307-476; same arguments)."""
     src = da
     da = from_any(da)
+    nd = _nd_dims(da, dim, real_dim, real)
+    if nd is not None:
+        return to_like(_fft_nd(da, nd, spacing_tol, real_dim if real is None else real, shift, detrend, window,
+                               true_phase, true_amplitude, chunks_to_segments, prefix), src)
     c = _analyze(da, spacing_tol, dim, real_dim, shift, detrend, window, true_phase, chunks_to_segments, prefix, real)
     da = c.da
     scale = np.prod(c.delta_x) if true_amplitude else 1.0  # xrft.py:471-472
@@ -569,19 +675,23 @@ def detrend(da, dim, detrend_type="constant"):
                                   "or None." % detrend_type)
     if detrend_type is None:
         return src
-    if len(dim) not in (1, 2):
-        raise NotImplementedError("Only 1D and 2D detrending are implemented in xrft_amd.")
+    if detrend_type == "linear" and len(dim) > 3:
+        raise NotImplementedError("Only 1D, 2D, and 3D detrending are implemented so far.")
     axes = [da.get_axis_num(d) for d in dim]
     t = _to_device(da.data)
-    if len(dim) == 2 and axes[0] > axes[1]:
-        dim = dim[::-1]
+    dim = [d for _, d in sorted(zip(axes, dim))]  # memory order: the fit does not depend on the order of the axes
     other = [d for d in da.dims if d not in dim]
     order = other + dim
     if tuple(order) != tuple(da.dims):
         t = t.permute([da.get_axis_num(d) for d in order])
     t = t.contiguous()
     kind = _lib.DETREND_CONSTANT if detrend_type == "constant" else _lib.DETREND_LINEAR
-    out = engine.detrend(t, len(dim), kind)
+    if len(dim) > 3 or (len(dim) == 3 and detrend_type == "constant"):
+        # the mean over any number of trailing axes is the mean of the flattened block
+        nblk = int(np.prod([da.sizes[d] for d in dim]))
+        out = engine.detrend(t.reshape(-1, nblk), 1, kind).reshape(t.shape)
+    else:
+        out = engine.detrend(t, len(dim), kind)
     if tuple(order) != tuple(da.dims):
         out = out.permute([order.index(d) for d in da.dims])
     return to_like(DataArray(out, da.dims, da.coords, da.name, da.attrs), src)
@@ -663,6 +773,9 @@ def power_spectrum(da, dim=None, real_dim=None, scaling="density", window_correc
     """Power spectrum |F(da')|^2 with density / spectrum scaling (xrft/xrft.py:685-750)."""
     src = da
     da = from_any(da)
+    nd = _nd_dims(da, dim, real_dim, kwargs.get("real"))
+    if nd is not None:
+        return to_like(_spectrum_nd(da, None, nd, real_dim, scaling, window_correction, False, dict(kwargs)), src)
     c, _, mode, scale, flags = _spectrum(da, None, dim, real_dim, scaling, window_correction, False, dict(kwargs))
     out, _, other = _execute(c, c.da, mode, scale, extra_flags=flags)
     return to_like(_label_output(c, c.da, out, other), src)
@@ -673,6 +786,9 @@ def cross_spectrum(da1, da2, dim=None, real_dim=None, scaling="density", window_
     """Cross spectrum F(da1') conj(F(da2')) (xrft/xrft.py:753-835)."""
     src = da1
     da1, da2 = from_any(da1), from_any(da2)
+    nd = _nd_dims(da1, dim, real_dim, kwargs.get("real"))
+    if nd is not None:
+        return to_like(_spectrum_nd(da1, da2, nd, real_dim, scaling, window_correction, true_phase, dict(kwargs)), src)
     c, c2, mode, scale, flags = _spectrum(da1, da2, dim, real_dim, scaling, window_correction, true_phase, dict(kwargs))
     return to_like(_cross_result(c, c2, mode, scale, flags), src)
 

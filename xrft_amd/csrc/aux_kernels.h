@@ -105,6 +105,98 @@ __global__ void __launch_bounds__(256) detrend_apply_kernel(const void* in, void
     }
 }
 
+// ---- 3-D blocks (xrft/detrend.py:116-138: least-squares hyperplane a0 + a1 i + a2 j + a3 k over a (n0, n1, n2) block).
+// acc[block][8] += { sum x, sum (i-ibar) x, sum (j-jbar) x, sum (k-kbar) x } as (re, im) pairs; rows r = i*n1 + j of
+// length n2 are dealt round-robin to the blocks of the grid's x dimension.
+template <typename T, bool CPLX>
+__global__ void __launch_bounds__(256) block3_moments_kernel(const void* in, long long n0, long long n1, long long n2, double* acc) {
+    XRFT_DYN_SMEM(smem_raw);
+    double* red = reinterpret_cast<double*>(smem_raw);
+    const long long b = blockIdx.y, rows = n0 * n1;
+    const double ibar = 0.5 * (double)(n0 - 1), jbar = 0.5 * (double)(n1 - 1);
+    const T kbar = (T)(0.5 * (double)(n2 - 1));
+    double s[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (long long r = blockIdx.x; r < rows; r += gridDim.x) {
+        const long long i = r / n1, j = r - i * n1;
+        const long long base = (b * rows + r) * n2;
+        T p0r = 0, p0i = 0, pkr = 0, pki = 0;
+        double q0r = 0, q0i = 0;
+        int cnt = 0;
+        for (long long k = threadIdx.x; k < n2; k += blockDim.x) {
+            T xr, xi = (T)0;
+            if (CPLX) { C2<T> v = reinterpret_cast<const C2<T>*>(in)[base + k]; xr = v.re; xi = v.im; }
+            else xr = reinterpret_cast<const T*>(in)[base + k];
+            const T dk = (T)k - kbar;
+            p0r += xr; pkr += dk * xr;
+            if (CPLX) { p0i += xi; pki += dk * xi; }
+            if (++cnt == 64) {
+                q0r += (double)p0r; q0i += (double)p0i; s[6] += (double)pkr; s[7] += (double)pki;
+                p0r = p0i = pkr = pki = (T)0; cnt = 0;
+            }
+        }
+        q0r += (double)p0r; q0i += (double)p0i; s[6] += (double)pkr; s[7] += (double)pki;
+        s[0] += q0r; s[1] += q0i;
+        s[2] += ((double)i - ibar) * q0r; s[3] += ((double)i - ibar) * q0i;
+        s[4] += ((double)j - jbar) * q0r; s[5] += ((double)j - jbar) * q0i;
+    }
+    block_sum<8>(s, red);
+    if (threadIdx.x == 0)
+        for (int k = 0; k < 8; ++k)
+            if (s[k] != 0.0) atomicAdd(&acc[b * 8 + k], s[k]);
+}
+
+// the centred regressors of a full grid are mutually orthogonal: four independent ratios (constant: only the mean)
+__global__ void finalize_coef3_kernel(const double* acc, double* coef, long long batch, long long n0, long long n1, long long n2, int kind) {
+    const long long b = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= batch) return;
+    const double n = (double)n0 * (double)n1 * (double)n2;
+    const double bar[3] = {0.5 * (double)(n0 - 1), 0.5 * (double)(n1 - 1), 0.5 * (double)(n2 - 1)};
+    const double len[3] = {(double)n0, (double)n1, (double)n2};
+    for (int c = 0; c < 2; ++c) {
+        double c0 = acc[b * 8 + c] / n;
+        for (int a = 0; a < 3; ++a) {
+            double sl = 0.0;
+            if (kind == 2 && len[a] > 1.0) sl = acc[b * 8 + 2 + 2 * a + c] / (n * (len[a] * len[a] - 1.0) / 12.0);
+            coef[b * 8 + 2 + 2 * a + c] = sl;
+            c0 -= sl * bar[a];
+        }
+        coef[b * 8 + c] = c0;
+    }
+}
+
+template <typename T, bool CPLX>
+__global__ void __launch_bounds__(256) detrend3_apply_kernel(const void* in, void* out, long long n0, long long n1, long long n2, const double* coef) {
+    const long long b = blockIdx.y, rows = n0 * n1;
+    const double* c = coef + b * 8;
+    for (long long r = blockIdx.x; r < rows; r += gridDim.x) {
+        const long long i = r / n1, j = r - i * n1;
+        const double tr = c[0] + c[2] * (double)i + c[4] * (double)j, ti = c[1] + c[3] * (double)i + c[5] * (double)j;
+        const long long base = (b * rows + r) * n2;
+        for (long long k = threadIdx.x; k < n2; k += blockDim.x) {
+            if (CPLX) {
+                C2<T> v = reinterpret_cast<const C2<T>*>(in)[base + k];
+                v.re = (T)((double)v.re - (tr + c[6] * (double)k));
+                v.im = (T)((double)v.im - (ti + c[7] * (double)k));
+                reinterpret_cast<C2<T>*>(out)[base + k] = v;
+            } else {
+                const T v = reinterpret_cast<const T*>(in)[base + k];
+                reinterpret_cast<T*>(out)[base + k] = (T)((double)v - (tr + c[6] * (double)k));
+            }
+        }
+    }
+}
+
+// |a|^2 * scale (real result) or a * conj(b) * scale (complex result) of already transformed fields: the tail of
+// power_spectrum / cross_spectrum (xrft.py:740, 825) for transforms composed of several plans (more than two axes)
+template <typename T, bool CROSS>
+__global__ void __launch_bounds__(256) spectrum_tail_kernel(const C2<T>* a, const C2<T>* b, void* out, long long n, double scale) {
+    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (long long)gridDim.x * blockDim.x) {
+        const C2<T> x = a[e];
+        if (CROSS) reinterpret_cast<C2<T>*>(out)[e] = cscale(cmulc(x, b[e]), (T)scale);
+        else reinterpret_cast<T*>(out)[e] = (x.re * x.re + x.im * x.im) * (T)scale;
+    }
+}
+
 // iso[slab][bin] += in[slab][e] for bin = binmap[e] >= 0 ; LDS-privatised histogram, one flush per block.
 template <typename T, bool CPLX>
 __global__ void __launch_bounds__(256) radial_binsum_kernel(const void* in, const int* binmap, long long total, int nbins, double* iso) {

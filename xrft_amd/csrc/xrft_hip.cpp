@@ -1194,7 +1194,7 @@ int xrfthip_exec(const xrfthip_plan* plan, const void* d_in0, const void* d_in1,
     return XRFTHIP_OK;
 }
 
-size_t xrfthip_detrend_workspace_bytes(int64_t batch) { return ((size_t)std::max<int64_t>(batch, 1) * 12 * sizeof(double) + 255) & ~(size_t)255; }
+size_t xrfthip_detrend_workspace_bytes(int64_t batch) { return ((size_t)std::max<int64_t>(batch, 1) * 16 * sizeof(double) + 255) & ~(size_t)255; }
 
 int xrfthip_detrend(int32_t dtype, int32_t ndim, int64_t batch, int64_t ny, int64_t nx, int32_t detrend_type,
                     const void* d_in, void* d_out, void* d_workspace, size_t ws_bytes, void* stream) {
@@ -1229,6 +1229,53 @@ int xrfthip_detrend(int32_t dtype, int32_t ndim, int64_t batch, int64_t ny, int6
 #undef APP
         HIP_TRY(hipGetLastError());
     }
+    return XRFTHIP_OK;
+}
+
+int xrfthip_detrend3(int32_t dtype, int64_t batch, int64_t n0, int64_t n1, int64_t n2, int32_t detrend_type,
+                     const void* d_in, void* d_out, void* d_workspace, size_t ws_bytes, void* stream) {
+    if (!d_in || !d_out || dtype < XRFTHIP_F32 || dtype > XRFTHIP_C128 || batch < 0 || n0 < 1 || n1 < 1 || n2 < 1) return XRFTHIP_BAD_ARG;
+    if (detrend_type != XRFTHIP_DETREND_CONSTANT && detrend_type != XRFTHIP_DETREND_LINEAR) return XRFTHIP_BAD_ARG;
+    if (ws_bytes < xrfthip_detrend_workspace_bytes(batch) || !d_workspace) return XRFTHIP_WORKSPACE_TOO_SMALL;
+    if (batch == 0) return XRFTHIP_OK;
+    hipStream_t st = (hipStream_t)stream;
+    double* acc = (double*)d_workspace;
+    double* coef = acc + batch * 8;
+    HIP_TRY(hipMemsetAsync(acc, 0, (size_t)batch * 8 * sizeof(double), st));
+    const bool dbl = dtype == XRFTHIP_F64 || dtype == XRFTHIP_C128, cplx = dtype >= XRFTHIP_C64;
+    const long long rows = n0 * n1, total = rows * n2;
+    const size_t esz = (dbl ? 8 : 4) * (cplx ? 2 : 1);
+    for (long long b0 = 0; b0 < batch; b0 += 32768) {  // grid.y limit
+        const long long bc = std::min<long long>(32768, batch - b0);
+        const long long gx = std::max<long long>(1, std::min<long long>(rows, std::max<long long>(8, 4096 / bc)));
+        const dim3 grid((unsigned)gx, (unsigned)bc), block(256);
+        const void* src = (const char*)d_in + (size_t)b0 * total * esz;
+        void* dst = (char*)d_out + (size_t)b0 * total * esz;
+        const size_t lds = 8 * 256 * sizeof(double);
+#define MOM(TT, CC) do { auto k = &block3_moments_kernel<TT, CC>; XRFT_LAUNCH(k, grid, block, lds, st, src, (long long)n0, (long long)n1, (long long)n2, acc + b0 * 8); } while (0)
+        if (dbl) { if (cplx) MOM(double, true); else MOM(double, false); } else { if (cplx) MOM(float, true); else MOM(float, false); }
+#undef MOM
+        auto kf = &finalize_coef3_kernel;
+        XRFT_LAUNCH(kf, dim3((unsigned)((bc + 63) / 64)), dim3(64), 0, st, (const double*)(acc + b0 * 8), coef + b0 * 8, bc, (long long)n0, (long long)n1, (long long)n2, (int)detrend_type);
+        const dim3 grid2((unsigned)std::max<long long>(1, std::min<long long>(rows, 4096)), (unsigned)bc);
+#define APP(TT, CC) do { auto k = &detrend3_apply_kernel<TT, CC>; XRFT_LAUNCH(k, grid2, block, 0, st, src, dst, (long long)n0, (long long)n1, (long long)n2, (const double*)(coef + b0 * 8)); } while (0)
+        if (dbl) { if (cplx) APP(double, true); else APP(double, false); } else { if (cplx) APP(float, true); else APP(float, false); }
+#undef APP
+        HIP_TRY(hipGetLastError());
+    }
+    return XRFTHIP_OK;
+}
+
+int xrfthip_spectrum_tail(int32_t dtype, int64_t n, const void* d_a, const void* d_b, void* d_out, double scale, void* stream) {
+    if (!d_a || !d_out || n < 0 || (dtype != XRFTHIP_C64 && dtype != XRFTHIP_C128)) return XRFTHIP_BAD_ARG;
+    if (n == 0) return XRFTHIP_OK;
+    hipStream_t st = (hipStream_t)stream;
+    const dim3 grid((unsigned)std::max<long long>(1, std::min<long long>(16384, (n + 255) / 256))), block(256);
+#define TAIL(TT, CC) do { auto k = &spectrum_tail_kernel<TT, CC>; XRFT_LAUNCH(k, grid, block, 0, st, (const C2<TT>*)d_a, (const C2<TT>*)d_b, d_out, (long long)n, scale); } while (0)
+    if (dtype == XRFTHIP_C128) { if (d_b) TAIL(double, true); else TAIL(double, false); }
+    else { if (d_b) TAIL(float, true); else TAIL(float, false); }
+#undef TAIL
+    HIP_TRY(hipGetLastError());
     return XRFTHIP_OK;
 }
 

@@ -126,10 +126,19 @@ class SpectralPlan:
 
 
 def detrend(x, ndim, kind):
-    """Stand-alone detrend over the last ``ndim`` (1|2) axes of a contiguous tensor (xrft/detrend.py:11-97)."""
+    """Stand-alone detrend over the last ``ndim`` (1|2|3) axes of a contiguous tensor (xrft/detrend.py:11-138)."""
     dll = _lib.load()
     if x.dtype not in _DTYPES or not x.is_contiguous():
         raise ValueError("detrend needs a contiguous float/complex tensor")
+    if ndim == 3:
+        n0, n1, n2 = x.shape[-3:]
+        batch = x.numel() // max(n0 * n1 * n2, 1)
+        out = torch.empty_like(x)
+        nws = int(dll.xrfthip_detrend_workspace_bytes(batch))
+        ws = torch.empty(nws, dtype=torch.uint8, device=x.device)
+        _lib.check(dll.xrfthip_detrend3(_DTYPES[x.dtype], batch, n0, n1, n2, kind, _ptr(x), _ptr(out), _ptr(ws), nws,
+                                        _stream_handle(x)))
+        return out
     nx = x.shape[-1]
     ny = x.shape[-2] if ndim == 2 else 1
     batch = x.numel() // max(ny * nx, 1)
@@ -138,6 +147,18 @@ def detrend(x, ndim, kind):
     ws = torch.empty(nws, dtype=torch.uint8, device=x.device)
     _lib.check(dll.xrfthip_detrend(_DTYPES[x.dtype], ndim, batch, ny, nx, kind, _ptr(x), _ptr(out), _ptr(ws), nws,
                                    _stream_handle(x)))
+    return out
+
+
+def spectrum_tail(a, b, scale):
+    """|a|^2 * scale (real) or a * conj(b) * scale (complex) of transformed fields (xrft.py:740, 825)."""
+    dll = _lib.load()
+    if not a.is_complex() or not a.is_contiguous() or (b is not None and (b.dtype != a.dtype or b.shape != a.shape or not b.is_contiguous())):
+        raise ValueError("spectrum_tail needs contiguous complex tensors of one shape and dtype")
+    real_dt = torch.float32 if a.dtype == torch.complex64 else torch.float64
+    out = torch.empty(a.shape, dtype=a.dtype if b is not None else real_dt, device=a.device)
+    _lib.check(dll.xrfthip_spectrum_tail(_DTYPES[a.dtype], a.numel(), _ptr(a), _ptr(b), _ptr(out), float(scale),
+                                         _stream_handle(a)))
     return out
 
 
