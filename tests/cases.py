@@ -407,3 +407,27 @@ def run_pad_cases():
     back = xa.unpad(xa.ifft(ft, lag=[ft["freq_x"].attrs["direct_lag"]]), x=4)
     npt.assert_allclose(back.values.real, v[0, 0], atol=1e-12)
     npt.assert_allclose(back["x"].values, coords["x"], atol=1e-12)
+
+
+def run_bluestein_cases(dtype):
+    """Lengths with a prime factor above 128 (chirp-z inside the tile kernel); numpy's pocketfft takes any length."""
+    tol = TOL[dtype]
+    rng = np.random.default_rng(131)
+    for n in (131, 257, 262, 1801):
+        v = rng.standard_normal((3, n)).astype(dtype) + 0.01 * np.arange(n, dtype=dtype)[None]
+        da, od = pair(v, ("t", "x"), {"t": np.arange(3), "x": np.arange(n) * 0.5 + 2.0})
+        for kw in (dict(), dict(detrend="linear", window="hann"), dict(true_phase=False, shift=False)):
+            check(xa.fft(da, dim="x", **kw), o.fft(od, dim="x", **kw), tol)
+        check(xa.power_spectrum(da, dim="x", window="hann"), o.power_spectrum(od, dim="x", window="hann"), tol)
+        check(xa.fft(da, dim="x", real_dim="x"), o.fft(od, dim="x", real_dim="x"), tol)
+    z = (rng.standard_normal((2, 139)) + 1j * rng.standard_normal((2, 139))).astype("complex128" if dtype == "float64" else "complex64")
+    da, od = pair(z, ("t", "x"), {"t": np.arange(2), "x": np.arange(139) * 1.0})
+    check(xa.fft(da, dim="x"), o.fft(od, dim="x"), tol)
+    check(xa.ifft(xa.fft(da, dim="x"), dim="freq_x"), o.ifft(o.fft(od, dim="x"), dim="freq_x"), tol)
+    for shape in ((2, 131, 24), (2, 20, 262), (1, 149, 137)):
+        v = rng.standard_normal(shape).astype(dtype)
+        c = {"t": np.arange(shape[0]), "y": np.arange(shape[1]) * 1.0, "x": np.arange(shape[2]) * 2.0}
+        da, od = pair(v, ("t", "y", "x"), c)
+        check(xa.power_spectrum(da, dim=["y", "x"], detrend="linear", window="hann"),
+              o.power_spectrum(od, dim=["y", "x"], detrend="linear", window="hann"), tol)
+        check(xa.fft(da, dim=["y", "x"]), o.fft(od, dim=["y", "x"]), tol)

@@ -105,7 +105,7 @@ def test_groups_and_batches(monkeypatch):
 def test_unsupported_length_is_loud():
     import xrft_amd as xa
 
-    da = xa.DataArray(np.zeros((2, 131)), ("t", "x"))  # 131 is a prime > XRFTHIP_MAX_RADIX
+    da = xa.DataArray(np.zeros((2, 10007)), ("t", "x"))  # a prime whose Bluestein transform (32768 points) does not fit the LDS
     with pytest.raises(xa.XrftHipError):
         xa.fft(da, dim="x")
 
@@ -230,6 +230,11 @@ def test_fastp2_isotropic_cross(ny, nx, kw):
     assert any("[fastp2]" in p.describe() for p in api._plan_cache.values())
     cases.check(got, o.isotropic_cross_spectrum(od, ob, dim=["y", "x"], **kw), 3e-4)
     api._plan_cache.clear()
+
+
+@pytest.mark.parametrize("dtype", ["float64", "float32"])
+def test_bluestein_lengths(dtype):
+    cases.run_bluestein_cases(dtype)
 
 
 @pytest.mark.parametrize("dtype", ["float64", "float32"])

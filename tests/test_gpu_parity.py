@@ -377,3 +377,8 @@ def test_nd_larger_block_f32():
     got = xa.power_spectrum(_da(v, ("t", "z", "y", "x"), c), dim=["z", "y", "x"], detrend="linear", window="hann")
     ref = o.power_spectrum(o.OArr(v, ("t", "z", "y", "x"), c), dim=["z", "y", "x"], detrend="linear", window="hann")
     cases.check(got, ref, 3e-4)
+
+
+@pytest.mark.parametrize("dtype", ["float64", "float32"])
+def test_bluestein_lengths(dtype):
+    cases.run_bluestein_cases(dtype)

@@ -154,6 +154,11 @@ struct TileGeom {
                             // from global memory made the passes load-issue bound)
     const unsigned* rev;    // rev[k] = LDS position of frequency k after the DIF passes
     const void* tw_r2c;     // W_{2n}^k, k <= n   (r2c unpack)
+    // Bluestein: blue_n > 0 is the logical sequence length; n (a power of two >= 2 blue_n - 1) is what the LDS passes run.
+    //   x[p] conj(c[p]) zero-padded -> forward passes -> * blue_b -> inverse passes -> * conj(c[k]),  c[k] = exp(i pi k^2 / blue_n)
+    int blue_n;
+    const void* blue_c;
+    const void* blue_b;     // FFT_n(chirp) / n at the LDS position the forward passes leave each frequency
     const void* tw_big;     // four-step: W_bigN^k table, k < bigN
     long long tw_bigN, tw_qdiv, tw_qmod;  // factor = W_bigN^{((q / qdiv) % qmod) * k}
 };
@@ -330,6 +335,34 @@ __device__ __forceinline__ void run_pass(C2<T>* tile, const TileGeom& g, int L, 
     }
 }
 
+// exact inverse of run_pass up to the factor R (used by the Bluestein convolution, whose transform length is a power of
+// two): undo the twiddles with their conjugates, then the unnormalised inverse butterfly
+template <typename T, int R, typename TWP>
+__device__ __forceinline__ void run_pass_inv(C2<T>* tile, const TileGeom& g, int L, int tid, int nthreads, TWP tw) {
+    const int m = L / R;
+    const int per_seq = g.n / R;
+    const int nb = g.T * per_seq;
+    const int twstep = g.n / L;
+    for (int w = tid; w < nb; w += nthreads) {
+        const int t = w / per_seq;
+        const int gg = w - t * per_seq;
+        const int blk = gg / m;
+        const int j = gg - blk * m;
+        C2<T>* s = tile + (long long)t * g.seq_stride;
+        const int base = blk * L + j;
+        C2<T> a[R];
+#pragma unroll
+        for (int k = 0; k < R; ++k) a[k] = cconj(s[phys(base + k * m, g.pad_shift)]);
+        if (m > 1) {
+#pragma unroll
+            for (int k = 1; k < R; ++k) a[k] = cmul(a[k], tw[j * k * twstep]);  // conj(a conj(w)) = conj(a) w
+        }
+        dft_r<T, R>(a);
+#pragma unroll
+        for (int q = 0; q < R; ++q) s[phys(base + q * m, g.pad_shift)] = cconj(a[q]);
+    }
+}
+
 // any radix up to XRFTHIP_MAX_RADIX (O(R^2) butterfly; operands live in scratch) -- odd lengths only
 template <typename T>
 __device__ void run_pass_generic(C2<T>* tile, const TileGeom& g, int R, int L, int tid, int nthreads) {
@@ -426,7 +459,7 @@ __global__ void __launch_bounds__(1024) tile_fft_kernel(TileGeom g, Prologue pr,
             int t, p;
             if (g.in_fast == 0) { t = e / g.n; p = e - t * g.n; } else { p = e / g.T; t = e - p * g.T; }
             C2<T> v = mk<T>((T)0, (T)0);
-            if (t < tv) {
+            if (t < tv && (g.blue_n == 0 || p < g.blue_n)) {
                 const long long o = g.tile_axis == 0 ? o0 + t : o0;
                 const long long q = g.tile_axis == 0 ? 0 : q0 + t;
                 if (FIRST) {
@@ -444,6 +477,7 @@ __global__ void __launch_bounds__(1024) tile_fft_kernel(TileGeom g, Prologue pr,
                 } else {
                     v = gin[o * g.in_so + q * g.in_sq + (long long)p * g.in_sp];
                 }
+                if (g.blue_n) v = cmulc(v, reinterpret_cast<const C2<T>*>(g.blue_c)[p]);
             }
             tile[(long long)t * g.seq_stride + phys(p, g.pad_shift)] = v;
         }
@@ -481,7 +515,47 @@ __global__ void __launch_bounds__(1024) tile_fft_kernel(TileGeom g, Prologue pr,
             L /= R;
             __syncthreads();
         }
+        if (g.blue_n) {  // circular convolution with the chirp: * B, inverse passes in reverse order, * conj(c)
+            const C2<T>* __restrict__ bh = reinterpret_cast<const C2<T>*>(g.blue_b);
+            const C2<T>* __restrict__ ch = reinterpret_cast<const C2<T>*>(g.blue_c);
+            for (int e = tid; e < total_in; e += nthreads) {
+                const int t = e / g.n, p = e - t * g.n;
+                C2<T>* x = tile + (long long)t * g.seq_stride + phys(p, g.pad_shift);
+                *x = cmul(*x, bh[p]);
+            }
+            __syncthreads();
+            int Li = 1;
+            for (int ip = g.nr - 1; ip >= 0; --ip) {
+                const int R = g.radix[ip];
+                Li *= R;
+                if (twl) {
+                    const C2<T>* tw = twl;
+                    switch (R) {
+                        case 2: run_pass_inv<T, 2>(tile, g, Li, tid, nthreads, tw); break;
+                        case 4: run_pass_inv<T, 4>(tile, g, Li, tid, nthreads, tw); break;
+                        case 8: run_pass_inv<T, 8>(tile, g, Li, tid, nthreads, tw); break;
+                        default: run_pass_inv<T, 16>(tile, g, Li, tid, nthreads, tw); break;
+                    }
+                } else {
+                    switch (R) {
+                        case 2: run_pass_inv<T, 2>(tile, g, Li, tid, nthreads, twg); break;
+                        case 4: run_pass_inv<T, 4>(tile, g, Li, tid, nthreads, twg); break;
+                        case 8: run_pass_inv<T, 8>(tile, g, Li, tid, nthreads, twg); break;
+                        default: run_pass_inv<T, 16>(tile, g, Li, tid, nthreads, twg); break;
+                    }
+                }
+                __syncthreads();
+            }
+            const int tot_b = g.T * g.blue_n;
+            for (int e = tid; e < tot_b; e += nthreads) {
+                const int t = e / g.blue_n, k = e - t * g.blue_n;
+                C2<T>* x = tile + (long long)t * g.seq_stride + phys(k, g.pad_shift);
+                *x = cmulc(*x, ch[k]);
+            }
+            __syncthreads();
+        }
         // ------------------------------------------------------------------ store
+        const int nl = g.blue_n ? g.blue_n : g.n;  // logical transform length
         const int total_out = g.T * g.n_out;
         for (int e = tid; e < total_out; e += nthreads) {
             int t, k;
@@ -490,15 +564,15 @@ __global__ void __launch_bounds__(1024) tile_fft_kernel(TileGeom g, Prologue pr,
             const C2<T>* s = tile + (long long)t * g.seq_stride;
             C2<T> F;
             if (g.r2c) {
-                const int ka = k == g.n ? 0 : k;
-                const int kb = k == 0 ? 0 : g.n - k;
-                const C2<T> zk = s[phys((int)g.rev[ka], g.pad_shift)];
-                const C2<T> zc = cconj(s[phys((int)g.rev[kb], g.pad_shift)]);
+                const int ka = k == nl ? 0 : k;
+                const int kb = k == 0 ? 0 : nl - k;
+                const C2<T> zk = s[phys(g.blue_n ? ka : (int)g.rev[ka], g.pad_shift)];
+                const C2<T> zc = cconj(s[phys(g.blue_n ? kb : (int)g.rev[kb], g.pad_shift)]);
                 const C2<T> E = cscale(zk + zc, (T)0.5);
                 const C2<T> O = cscale(mul_mi(zk - zc), (T)0.5);
                 F = E + cmul(reinterpret_cast<const C2<T>*>(g.tw_r2c)[k], O);
             } else {
-                F = s[phys((int)g.rev[k], g.pad_shift)];
+                F = s[phys(g.blue_n ? k : (int)g.rev[k], g.pad_shift)];
             }
             const long long o = g.tile_axis == 0 ? o0 + t : o0;
             const long long q = g.tile_axis == 0 ? 0 : q0 + t;

@@ -59,6 +59,10 @@ struct FftTables {  // per FFT length, in the plan's precision
     std::vector<int> radix;
     bool generic = false;
     DevBuf tw, rev;
+    // Bluestein (a prime factor above XRFTHIP_MAX_RADIX): the LDS transform has blue_m = 2^k >= 2n-1 points;
+    // blue_c[k] = exp(+i pi k^2 / n), blue_b = FFT_m(chirp kernel) / m in the order the DIF passes leave it
+    int blue_m = 0;
+    DevBuf blue_c, blue_b;
 };
 
 enum BufKind { B_NONE = 0, B_IN, B_W, B_W2, B_F0, B_OUT };
@@ -105,9 +109,44 @@ int factorize(long long n, std::vector<int>& out, bool& generic) {
     return XRFTHIP_OK;
 }
 
+// length of the transform actually run in LDS for an n-point sequence: n, or the Bluestein length when n has a prime
+// factor the radix passes do not take
+long long lds_fft_len(long long n) {
+    std::vector<int> r;
+    bool g;
+    if (n < 2 || factorize(n, r, g) == XRFTHIP_OK) return n;
+    long long m = 1;
+    while (m < 2 * n - 1) m *= 2;
+    return m;
+}
+
+// host-side radix-2 FFT (float64) for the two 4096-point window spectra the fused detrend needs
+static void host_fft_pow2(std::vector<double>& re, std::vector<double>& im) {
+    const size_t n = re.size();
+    for (size_t i = 1, j = 0; i < n; ++i) {
+        size_t bit = n >> 1;
+        for (; j & bit; bit >>= 1) j ^= bit;
+        j ^= bit;
+        if (i < j) { std::swap(re[i], re[j]); std::swap(im[i], im[j]); }
+    }
+    for (size_t len = 2; len <= n; len <<= 1) {
+        const double ang = -2.0 * 3.14159265358979323846264338327950288 / (double)len;
+        for (size_t i = 0; i < n; i += len)
+            for (size_t k = 0; k < len / 2; ++k) {
+                const double wr = cos(ang * (double)k), wi = sin(ang * (double)k);
+                const size_t a = i + k, b = i + k + len / 2;
+                const double xr = re[b] * wr - im[b] * wi, xi = re[b] * wi + im[b] * wr;
+                re[b] = re[a] - xr; im[b] = im[a] - xi;
+                re[a] += xr; im[a] += xi;
+            }
+    }
+}
+
 template <typename T>
-int build_tables(FftTables& t, int n) {
-    t.n = n;
+int build_tables(FftTables& t, int n_logical) {
+    t.n = n_logical;
+    const int n = (int)lds_fft_len(n_logical);
+    t.blue_m = n != n_logical ? n : 0;
     int rc = factorize(n, t.radix, t.generic);
     if (rc) return rc;
     std::vector<C2<T>> tw((size_t)std::max(n, 1));
@@ -130,6 +169,28 @@ int build_tables(FftTables& t, int n) {
     }
     rc = t.tw.upload(tw.data(), tw.size() * sizeof(C2<T>));
     if (rc) return rc;
+    if (t.blue_m) {
+        const long long N = n_logical;
+        const long double pi = 3.14159265358979323846264338327950288L;
+        std::vector<C2<T>> c((size_t)N);
+        std::vector<double> br((size_t)n, 0.0), bi((size_t)n, 0.0);
+        for (long long k = 0; k < N; ++k) {
+            const long double a = pi * (long double)((k * k) % (2 * N)) / (long double)N;  // k^2 mod 2N keeps the angle small
+            const long double cr = cosl(a), ci = sinl(a);
+            c[(size_t)k].re = (T)cr; c[(size_t)k].im = (T)ci;
+            br[(size_t)k] = (double)cr; bi[(size_t)k] = (double)ci;
+            if (k) { br[(size_t)(n - k)] = (double)cr; bi[(size_t)(n - k)] = (double)ci; }
+        }
+        host_fft_pow2(br, bi);
+        std::vector<C2<T>> bh((size_t)n);
+        for (int k = 0; k < n; ++k) {
+            bh[(size_t)rev[(size_t)k]].re = (T)(br[(size_t)k] / n);
+            bh[(size_t)rev[(size_t)k]].im = (T)(bi[(size_t)k] / n);
+        }
+        rc = t.blue_c.upload(c.data(), c.size() * sizeof(C2<T>));
+        if (!rc) rc = t.blue_b.upload(bh.data(), bh.size() * sizeof(C2<T>));
+        if (rc) return rc;
+    }
     return t.rev.upload(rev.data(), rev.size() * sizeof(unsigned));
 }
 
@@ -184,7 +245,8 @@ struct TileChoice { int T, threads, seq_stride, pad_shift; size_t lds; };
 
 // pick sequences-per-tile for an n-point FFT; `col`: the tile axis is the contiguous one in memory, so T*csize
 // bytes per row segment should reach a 128-byte line.  Returns T = 0 if one sequence does not fit in LDS.
-TileChoice choose_tile(long long n, size_t csize, bool col, long long avail, size_t hist_bytes) {
+TileChoice choose_tile(long long n_logical, size_t csize, bool col, long long avail, size_t hist_bytes) {
+    const long long n = lds_fft_len(n_logical);
     TileChoice c{};
     c.pad_shift = csize == 8 ? 4 : 3;
     long long ss = n + (n >> c.pad_shift) + 1;
@@ -240,7 +302,10 @@ struct Builder {
         FftTables* t;
         int rc = tables_for(n, &t);
         if (rc) return rc;
-        ps.g.n = n;
+        ps.g.n = t->blue_m ? t->blue_m : n;
+        ps.g.blue_n = t->blue_m ? n : 0;
+        ps.g.blue_c = t->blue_c.p;
+        ps.g.blue_b = t->blue_b.p;
         ps.g.nr = (int)t->radix.size();
         for (int i = 0; i < ps.g.nr; ++i) ps.g.radix[i] = t->radix[i];
         ps.g.tw = t->tw.p;
@@ -670,27 +735,6 @@ static int run_moments(const xrfthip_plan* P, const void* in, long long g0, long
     return XRFTHIP_OK;
 }
 
-// host-side radix-2 FFT (float64) for the two 4096-point window spectra the fused detrend needs
-static void host_fft_pow2(std::vector<double>& re, std::vector<double>& im) {
-    const size_t n = re.size();
-    for (size_t i = 1, j = 0; i < n; ++i) {
-        size_t bit = n >> 1;
-        for (; j & bit; bit >>= 1) j ^= bit;
-        j ^= bit;
-        if (i < j) { std::swap(re[i], re[j]); std::swap(im[i], im[j]); }
-    }
-    for (size_t len = 2; len <= n; len <<= 1) {
-        const double ang = -2.0 * 3.14159265358979323846264338327950288 / (double)len;
-        for (size_t i = 0; i < n; i += len)
-            for (size_t k = 0; k < len / 2; ++k) {
-                const double wr = cos(ang * (double)k), wi = sin(ang * (double)k);
-                const size_t a = i + k, b = i + k + len / 2;
-                const double xr = re[b] * wr - im[b] * wi, xi = re[b] * wi + im[b] * wr;
-                re[b] = re[a] - xr; im[b] = im[a] - xi;
-                re[a] += xr; im[a] += xi;
-            }
-    }
-}
 
 static int fast4096_window_spectra(xrfthip_plan* P) {
     const int nx = (int)P->d.nx, nxh = nx / 2;
