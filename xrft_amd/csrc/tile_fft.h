@@ -153,6 +153,7 @@ struct TileGeom {
     int tw_lds;             // 1: the kernel copies the table into LDS behind the tile (7 twiddle loads per radix-8 butterfly
                             // from global memory made the passes load-issue bound)
     const unsigned* rev;    // rev[k] = LDS position of frequency k after the DIF passes
+    int rev_lds;            // 1: staged in LDS behind the twiddles (the store loop's lookups are on its critical path)
     const void* tw_r2c;     // W_{2n}^k, k <= n   (r2c unpack)
     // Bluestein: blue_n > 0 is the logical sequence length; n (a power of two >= 2 blue_n - 1) is what the LDS passes run.
     //   x[p] conj(c[p]) zero-padded -> forward passes -> * blue_b -> inverse passes -> * conj(c[k]),  c[k] = exp(i pi k^2 / blue_n)
@@ -205,6 +206,11 @@ struct Epilogue {  // last pass: xrft.py:446-472, 740-748, 825-833, 993-1004
 };
 
 __device__ __forceinline__ int phys(int pos, int sh) { return pos + (pos >> sh); }
+
+// x / d for 0 <= x < 2^22 with inv = 1.0f / d: (x + 0.5) / d is at least 0.5 / d away from an integer and the float
+// evaluation is off by at most (x + 0.5) / d * 2^-23, so the truncation is exact.  Every per-element index of a tile
+// (< 20 K elements) goes through this instead of a ~30-instruction integer division by a runtime divisor.
+__device__ __forceinline__ int fdiv(int x, float inv) { return (int)(((float)x + 0.5f) * inv); }
 
 __device__ __forceinline__ int map_src(int m, int n, int flip, int ishift) {
     int t = m;
@@ -284,10 +290,11 @@ __device__ __forceinline__ void emit(const Epilogue& ep, long long b, int ky, in
 // per element is a 32-bit one (64-bit integer division costs >100 instructions on the GPU)
 template <typename T>
 __device__ __forceinline__ void epi_store(const Epilogue& ep, long long b0, int r0, int dt, int q, int p, C2<T> F, double* hist) {
-    const unsigned rr = (unsigned)(r0 + dt), od = (unsigned)ep.odiv;
-    const unsigned db = od == 1 ? rr : rr / od;
+    unsigned rr = (unsigned)(r0 + dt), db = 0;
+    const unsigned od = (unsigned)ep.odiv;
+    if (od == 1) { db = rr; rr = 0; } else { while (rr >= od) { rr -= od; ++db; } }  // r0 < od, dt < T: a step or two
     const long long b = b0 + db;
-    const int r = (int)(rr - db * od);
+    const int r = (int)rr;
     const int km = (int)(r * (int)ep.r_mul + q * (int)ep.q_mul + p * (int)ep.p_mul);
     int ky, kx;
     if (ep.p_axis) { ky = km; kx = (int)q; } else { ky = 0; kx = km; }
@@ -315,12 +322,13 @@ __device__ __forceinline__ void run_pass(C2<T>* tile, const TileGeom& g, int L, 
     const int per_seq = g.n / R;
     const int nb = g.T * per_seq;
     const int twstep = g.n / L;
+    const float inv_ps = 1.0f / (float)per_seq, inv_m = 1.0f / (float)m;
     for (int w = tid; w < nb; w += nthreads) {
-        const int t = w / per_seq;
+        const int t = fdiv(w, inv_ps);
         const int gg = w - t * per_seq;
-        const int blk = gg / m;
+        const int blk = fdiv(gg, inv_m);
         const int j = gg - blk * m;
-        C2<T>* s = tile + (long long)t * g.seq_stride;
+        C2<T>* s = tile + t * g.seq_stride;
         const int base = blk * L + j;
         C2<T> a[R];
 #pragma unroll
@@ -343,12 +351,13 @@ __device__ __forceinline__ void run_pass_inv(C2<T>* tile, const TileGeom& g, int
     const int per_seq = g.n / R;
     const int nb = g.T * per_seq;
     const int twstep = g.n / L;
+    const float inv_ps = 1.0f / (float)per_seq, inv_m = 1.0f / (float)m;
     for (int w = tid; w < nb; w += nthreads) {
-        const int t = w / per_seq;
+        const int t = fdiv(w, inv_ps);
         const int gg = w - t * per_seq;
-        const int blk = gg / m;
+        const int blk = fdiv(gg, inv_m);
         const int j = gg - blk * m;
-        C2<T>* s = tile + (long long)t * g.seq_stride;
+        C2<T>* s = tile + t * g.seq_stride;
         const int base = blk * L + j;
         C2<T> a[R];
 #pragma unroll
@@ -372,13 +381,14 @@ __device__ void run_pass_generic(C2<T>* tile, const TileGeom& g, int R, int L, i
     const int twstep = g.n / L;
     const int rstep = g.n / R;
     const C2<T>* __restrict__ tw = reinterpret_cast<const C2<T>*>(g.tw);
+    const float inv_ps = 1.0f / (float)per_seq, inv_m = 1.0f / (float)m;
     C2<T> a[128];
     for (int w = tid; w < nb; w += nthreads) {
-        const int t = w / per_seq;
+        const int t = fdiv(w, inv_ps);
         const int gg = w - t * per_seq;
-        const int blk = gg / m;
+        const int blk = fdiv(gg, inv_m);
         const int j = gg - blk * m;
-        C2<T>* s = tile + (long long)t * g.seq_stride;
+        C2<T>* s = tile + t * g.seq_stride;
         const int base = blk * L + j;
         for (int q = 0; q < R; ++q) a[q] = s[phys(base + q * m, g.pad_shift)];
         for (int k = 0; k < R; ++k) {
@@ -416,13 +426,22 @@ __global__ void __launch_bounds__(1024) tile_fft_kernel(TileGeom g, Prologue pr,
     C2<T>* __restrict__ gout = reinterpret_cast<C2<T>*>(g.out);
     const C2<T>* __restrict__ twg = reinterpret_cast<const C2<T>*>(g.tw);
     C2<T>* twl = nullptr;
-    if (g.tw_lds) {
+    unsigned* revl = nullptr;
+    if (g.tw_lds || g.rev_lds) {
         size_t off = (size_t)g.T * g.seq_stride * sizeof(C2<T>);
         off = (off + 15) & ~(size_t)15;
         if (FINAL && ep.iso) off += (size_t)ep.nbins * (ep.mode == 2 ? 16 : 8);
         off = (off + 15) & ~(size_t)15;
-        twl = reinterpret_cast<C2<T>*>(smem_raw + off);
-        for (int i = tid; i < g.n; i += nthreads) twl[i] = twg[i];
+        if (g.tw_lds) {
+            twl = reinterpret_cast<C2<T>*>(smem_raw + off);
+            for (int i = tid; i < g.n; i += nthreads) twl[i] = twg[i];
+            off += (size_t)g.n * sizeof(C2<T>);
+            off = (off + 15) & ~(size_t)15;
+        }
+        if (g.rev_lds) {
+            revl = reinterpret_cast<unsigned*>(smem_raw + off);
+            for (int i = tid; i < g.n; i += nthreads) revl[i] = g.rev[i];
+        }
     }
 
     for (long long tile_id = blockIdx.x; tile_id < g.n_tiles; tile_id += gridDim.x) {
@@ -455,31 +474,49 @@ __global__ void __launch_bounds__(1024) tile_fft_kernel(TileGeom g, Prologue pr,
         }
         // ------------------------------------------------------------------ load
         const int total_in = g.T * g.n;
-        for (int e = tid; e < total_in; e += nthreads) {
-            int t, p;
-            if (g.in_fast == 0) { t = e / g.n; p = e - t * g.n; } else { p = e / g.T; t = e - p * g.T; }
-            C2<T> v = mk<T>((T)0, (T)0);
-            if (t < tv && (g.blue_n == 0 || p < g.blue_n)) {
-                const long long o = g.tile_axis == 0 ? o0 + t : o0;
-                const long long q = g.tile_axis == 0 ? 0 : q0 + t;
-                if (FIRST) {
-                    const unsigned ii = (unsigned)(pi0 + (g.tile_axis == 0 ? t : 0)), rws = (unsigned)pr.rows;
-                    const unsigned db = rws == 1 ? ii : ii / rws;
-                    const long long b = pb0 + db;
-                    const int i = (int)(ii - db * rws);
-                    if (g.r2c) {
-                        const C2<T> e0 = fetch_src<T>(pr, b, i, 2 * p);
-                        const C2<T> e1 = fetch_src<T>(pr, b, i, 2 * p + 1);
-                        v = mk<T>(e0.re, e1.re);
-                    } else {
-                        v = fetch_src<T>(pr, b, i, (int)(p * pr.j_mul_p + q * pr.j_mul_q));
+        const float inv_n = 1.0f / (float)g.n, inv_T = 1.0f / (float)g.T;
+        // U independent elements per thread and trip: all their global loads are in flight before the first LDS store
+        constexpr int U = 4;
+        for (int e0 = tid; e0 < total_in; e0 += U * nthreads) {
+            C2<T> vv[U];
+            int dst[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int e = e0 + u * nthreads;
+                vv[u] = mk<T>((T)0, (T)0);
+                dst[u] = -1;
+                if (e < total_in) {
+                    int t, p;
+                    if (g.in_fast == 0) { t = fdiv(e, inv_n); p = e - t * g.n; } else { p = fdiv(e, inv_T); t = e - p * g.T; }
+                    dst[u] = t * g.seq_stride + phys(p, g.pad_shift);
+                    if (t < tv && (g.blue_n == 0 || p < g.blue_n)) {
+                        const long long o = g.tile_axis == 0 ? o0 + t : o0;
+                        const long long q = g.tile_axis == 0 ? 0 : q0 + t;
+                        C2<T> v;
+                        if (FIRST) {
+                            unsigned ii = (unsigned)(pi0 + (g.tile_axis == 0 ? t : 0)), db = 0;
+                            const unsigned rws = (unsigned)pr.rows;
+                            if (rws == 1) { db = ii; ii = 0; } else { while (ii >= rws) { ii -= rws; ++db; } }  // t < T: a step or two
+                            const long long b = pb0 + db;
+                            const int i = (int)ii;
+                            if (g.r2c) {
+                                const C2<T> x0 = fetch_src<T>(pr, b, i, 2 * p);
+                                const C2<T> x1 = fetch_src<T>(pr, b, i, 2 * p + 1);
+                                v = mk<T>(x0.re, x1.re);
+                            } else {
+                                v = fetch_src<T>(pr, b, i, (int)(p * pr.j_mul_p + q * pr.j_mul_q));
+                            }
+                        } else {
+                            v = gin[o * g.in_so + q * g.in_sq + (long long)p * g.in_sp];
+                        }
+                        if (g.blue_n) v = cmulc(v, reinterpret_cast<const C2<T>*>(g.blue_c)[p]);
+                        vv[u] = v;
                     }
-                } else {
-                    v = gin[o * g.in_so + q * g.in_sq + (long long)p * g.in_sp];
                 }
-                if (g.blue_n) v = cmulc(v, reinterpret_cast<const C2<T>*>(g.blue_c)[p]);
             }
-            tile[(long long)t * g.seq_stride + phys(p, g.pad_shift)] = v;
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+                if (dst[u] >= 0) tile[dst[u]] = vv[u];
         }
         __syncthreads();
         // ------------------------------------------------------------------ in-place DIF passes
@@ -519,8 +556,8 @@ __global__ void __launch_bounds__(1024) tile_fft_kernel(TileGeom g, Prologue pr,
             const C2<T>* __restrict__ bh = reinterpret_cast<const C2<T>*>(g.blue_b);
             const C2<T>* __restrict__ ch = reinterpret_cast<const C2<T>*>(g.blue_c);
             for (int e = tid; e < total_in; e += nthreads) {
-                const int t = e / g.n, p = e - t * g.n;
-                C2<T>* x = tile + (long long)t * g.seq_stride + phys(p, g.pad_shift);
+                const int t = fdiv(e, inv_n), p = e - t * g.n;
+                C2<T>* x = tile + t * g.seq_stride + phys(p, g.pad_shift);
                 *x = cmul(*x, bh[p]);
             }
             __syncthreads();
@@ -547,9 +584,10 @@ __global__ void __launch_bounds__(1024) tile_fft_kernel(TileGeom g, Prologue pr,
                 __syncthreads();
             }
             const int tot_b = g.T * g.blue_n;
+            const float inv_bn = 1.0f / (float)g.blue_n;
             for (int e = tid; e < tot_b; e += nthreads) {
-                const int t = e / g.blue_n, k = e - t * g.blue_n;
-                C2<T>* x = tile + (long long)t * g.seq_stride + phys(k, g.pad_shift);
+                const int t = fdiv(e, inv_bn), k = e - t * g.blue_n;
+                C2<T>* x = tile + t * g.seq_stride + phys(k, g.pad_shift);
                 *x = cmulc(*x, ch[k]);
             }
             __syncthreads();
@@ -557,33 +595,58 @@ __global__ void __launch_bounds__(1024) tile_fft_kernel(TileGeom g, Prologue pr,
         // ------------------------------------------------------------------ store
         const int nl = g.blue_n ? g.blue_n : g.n;  // logical transform length
         const int total_out = g.T * g.n_out;
-        for (int e = tid; e < total_out; e += nthreads) {
-            int t, k;
-            if (g.out_fast == 0) { t = e / g.n_out; k = e - t * g.n_out; } else { k = e / g.T; t = e - k * g.T; }
-            if (t >= tv) continue;
-            const C2<T>* s = tile + (long long)t * g.seq_stride;
-            C2<T> F;
-            if (g.r2c) {
-                const int ka = k == nl ? 0 : k;
-                const int kb = k == 0 ? 0 : nl - k;
-                const C2<T> zk = s[phys(g.blue_n ? ka : (int)g.rev[ka], g.pad_shift)];
-                const C2<T> zc = cconj(s[phys(g.blue_n ? kb : (int)g.rev[kb], g.pad_shift)]);
-                const C2<T> E = cscale(zk + zc, (T)0.5);
-                const C2<T> O = cscale(mul_mi(zk - zc), (T)0.5);
-                F = E + cmul(reinterpret_cast<const C2<T>*>(g.tw_r2c)[k], O);
-            } else {
-                F = s[phys(g.blue_n ? k : (int)g.rev[k], g.pad_shift)];
-            }
-            const long long o = g.tile_axis == 0 ? o0 + t : o0;
-            const long long q = g.tile_axis == 0 ? 0 : q0 + t;
-            if (FINAL) {
-                epi_store<T>(ep, eb0, er0, g.tile_axis == 0 ? t : 0, (int)q, k, F, hist);
-            } else {
-                if (g.tw_big) {
-                    const unsigned a = ((unsigned)q / (unsigned)g.tw_qdiv) % (unsigned)g.tw_qmod;
-                    F = cmul(F, reinterpret_cast<const C2<T>*>(g.tw_big)[(long long)a * k]);  // a*k < bigN by construction
+        const float inv_no = 1.0f / (float)g.n_out;
+        // V independent results per thread and trip: table lookups and LDS reads of all of them overlap
+        constexpr int V = 4;
+        for (int e0 = tid; e0 < total_out; e0 += V * nthreads) {
+            C2<T> FF[V];
+            int tt[V], kk[V];
+#pragma unroll
+            for (int u = 0; u < V; ++u) {
+                const int e = e0 + u * nthreads;
+                tt[u] = -1; kk[u] = 0;
+                FF[u] = mk<T>((T)0, (T)0);
+                if (e < total_out) {
+                    int t, k;
+                    if (g.out_fast == 0) { t = fdiv(e, inv_no); k = e - t * g.n_out; } else { k = fdiv(e, inv_T); t = e - k * g.T; }
+                    if (t < tv) {
+                        tt[u] = t; kk[u] = k;
+                        const C2<T>* s = tile + t * g.seq_stride;
+                        if (g.r2c) {
+                            const int ka = k == nl ? 0 : k;
+                            const int kb = k == 0 ? 0 : nl - k;
+                            int pa, pb;
+                            if (g.blue_n) { pa = ka; pb = kb; }
+                            else if (revl) { pa = (int)revl[ka]; pb = (int)revl[kb]; }
+                            else { pa = (int)g.rev[ka]; pb = (int)g.rev[kb]; }
+                            const C2<T> zk = s[phys(pa, g.pad_shift)];
+                            const C2<T> zc = cconj(s[phys(pb, g.pad_shift)]);
+                            const C2<T> E = cscale(zk + zc, (T)0.5);
+                            const C2<T> O = cscale(mul_mi(zk - zc), (T)0.5);
+                            FF[u] = E + cmul(reinterpret_cast<const C2<T>*>(g.tw_r2c)[k], O);
+                        } else {
+                            const int pk = g.blue_n ? k : (revl ? (int)revl[k] : (int)g.rev[k]);
+                            FF[u] = s[phys(pk, g.pad_shift)];
+                        }
+                    }
                 }
-                gout[o * g.out_so + q * g.out_sq + (long long)k * g.out_sp] = F;
+            }
+#pragma unroll
+            for (int u = 0; u < V; ++u) {
+                if (tt[u] < 0) continue;
+                const int t = tt[u], k = kk[u];
+                C2<T> F = FF[u];
+                const long long o = g.tile_axis == 0 ? o0 + t : o0;
+                const long long q = g.tile_axis == 0 ? 0 : q0 + t;
+                if (FINAL) {
+                    epi_store<T>(ep, eb0, er0, g.tile_axis == 0 ? t : 0, (int)q, k, F, hist);
+                } else {
+                    if (g.tw_big) {
+                        const unsigned a = ((unsigned)q / (unsigned)g.tw_qdiv) % (unsigned)g.tw_qmod;
+                        F = cmul(F, reinterpret_cast<const C2<T>*>(g.tw_big)[(long long)a * k]);  // a*k < bigN by construction
+                    }
+                    gout[o * g.out_so + q * g.out_sq + (long long)k * g.out_sp] = F;
+                }
             }
         }
         __syncthreads();

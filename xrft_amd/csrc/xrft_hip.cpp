@@ -326,6 +326,11 @@ struct Builder {
             ps.g.tw_lds = 1;
             ps.lds += twb;
         }
+        const size_t rvb = (size_t)ps.g.n * sizeof(unsigned) + 32;
+        if (ps.g.n > 1 && !ps.g.blue_n && rvb <= 32 * 1024 && ps.lds + rvb <= kLdsMax && env_ll("XRFTHIP_REV_LDS", 1)) {
+            ps.g.rev_lds = 1;
+            ps.lds += rvb;
+        }
     }
 
     void fill_prologue(Pass& ps, long long rows, long long jmp, long long jmq) {
