@@ -114,7 +114,8 @@ int xrfthip_plan_destroy(xrfthip_plan* plan);
 /* axis: 0 = y, 1 = x.  h_window: n doubles (scipy.signal.windows.<name>(n, sym=False)).  NULL clears. */
 int xrfthip_plan_set_window(xrfthip_plan* plan, int axis, const double* h_window, int64_t n);
 /* h_phase: n interleaved (re,im) doubles indexed by UNSHIFTED frequency index: exp(-i 2 pi f_k lag)
- * (for CROSS: the net factor phase0 * conj(phase1)).  NULL clears. */
+ * (for CROSS: the net factor phase0 * conj(phase1)).  With XRFTHIP_PHASE_IN (inverse transforms) the table multiplies
+ * the INPUT and is indexed by source position; a C2R_X plan then takes nx/2 + 1 entries on axis 1.  NULL clears. */
 int xrfthip_plan_set_phase(xrfthip_plan* plan, int axis, const double* h_phase, int64_t n);
 /* h_binmap: [ny][nx_out] int32 bin codes indexed by UNSHIFTED frequency indices (nx_out = nx, or nx/2+1 with
  * HALF_X); negative = not binned.  The host computes it with the reference's float64 pd.cut expression. */

@@ -253,6 +253,12 @@ def run_inverse_cases(dtype="float64"):
     kw = dict(dim=["freq_y"], real_dim="freq_x", true_phase=False, true_amplitude=False, lag=[0.0, 0.0], shift=True)
     errs.append(check(xa.ifft(F, **kw), o.ifft(Fo, **kw), tol))
     assert np.abs(xa.ifft(F, **kw).values - v).max() < 100 * tol
+    # the same with the default true phase / amplitude (input phase table on the stored half of the real axis)
+    F, Fo = xa.fft(s, dim=["y"], real_dim="x"), o.fft(so, dim=["y"], real_dim="x")
+    errs.append(check(xa.ifft(F, dim=["freq_y"], real_dim="freq_x"), o.ifft(Fo, dim=["freq_y"], real_dim="freq_x"), tol))
+    assert np.abs(xa.ifft(F, dim=["freq_y"], real_dim="freq_x").values - v).max() < 100 * tol
+    F1, F1o = xa.fft(s, dim="x", real_dim="x"), o.fft(so, dim="x", real_dim="x")
+    errs.append(check(xa.ifft(F1, dim="freq_x", real_dim="freq_x"), o.ifft(F1o, dim="freq_x", real_dim="freq_x"), tol))
     # not centred on zero frequency -> ValueError (test_idft_centered_coordinates)
     import pytest
     bad, _ = pair((rng.random(20) + 0j).astype(cdt), ("freq_x",), {"freq_x": np.arange(-10, 10) + 2})
@@ -342,6 +348,17 @@ def run_nd_cases(dtype):
         check(xa.cross_spectrum(da, db, dim=d3, **kw), o.cross_spectrum(od, ob, dim=d3, **kw), tol)
     with pytest.raises(NotImplementedError):
         xa.fft(da, detrend="linear")  # 4-D linear detrend: "Only 1D, 2D, and 3D detrending"
+    # real_dim in spectra over three axes, inverse transforms over three axes
+    check(xa.power_spectrum(da, dim=d3, real_dim="x", window="hann"), o.power_spectrum(od, dim=d3, real_dim="x", window="hann"), tol)
+    check(xa.cross_spectrum(da, db, dim=d3, real_dim="x"), o.cross_spectrum(od, ob, dim=d3, real_dim="x"), tol)
+    fd = ["freq_z", "freq_y", "freq_x"]
+    ft, oft = xa.fft(da, dim=d3), o.fft(od, dim=d3)
+    check(xa.ifft(ft, dim=fd), o.ifft(oft, dim=fd), tol)
+    check(xa.ifft(ft, dim=fd, true_phase=False, shift=True, lag=[0.0, 0.0, 0.0]), o.ifft(oft, dim=fd, true_phase=False, shift=True, lag=[0.0, 0.0, 0.0]), tol)
+    ft, oft = xa.fft(da, dim=d3, real_dim="x"), o.fft(od, dim=d3, real_dim="x")
+    check(xa.ifft(ft, dim=fd, real_dim="freq_x"), o.ifft(oft, dim=fd, real_dim="freq_x"), tol)
+    back = xa.ifft(xa.fft(da, dim=d3), dim=fd)
+    assert np.abs(back.values.real - v).max() < (1e-10 if dtype == "float64" else 2e-4)
 
 
 def run_detrend3_cases(dtype):

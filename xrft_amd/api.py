@@ -418,8 +418,8 @@ def _spectrum_nd(da, da2, dims, real_dim, scaling, window_correction, true_phase
     """power_spectrum / cross_spectrum over more than two axes: N-D transform(s), then the elementwise tail."""
     if "density" in kwargs:
         scaling = "density" if kwargs.pop("density") else "false_density"
-    if real_dim is not None or kwargs.get("real") is not None:
-        raise NotImplementedError("real_dim with more than two transform dimensions is not implemented in xrft_amd.")
+    if kwargs.get("real") is not None:
+        real_dim = kwargs.get("real")
     for k in ("true_amplitude", "true_phase"):
         kwargs.pop(k, None)
     kw = dict(spacing_tol=1e-3, shift=True, detrend=None, window=None, chunks_to_segments=False, prefix="freq_")
@@ -427,11 +427,11 @@ def _spectrum_nd(da, da2, dims, real_dim, scaling, window_correction, true_phase
     if unknown:
         raise TypeError(f"fft() got an unexpected keyword argument {sorted(unknown)[0]!r}")
     kw.update({k: v for k, v in kwargs.items() if k != "real"})
-    f1 = _fft_nd(da, dims, kw["spacing_tol"], None, kw["shift"], kw["detrend"], kw["window"], true_phase, True,
+    f1 = _fft_nd(da, dims, kw["spacing_tol"], real_dim, kw["shift"], kw["detrend"], kw["window"], true_phase, True,
                  kw["chunks_to_segments"], kw["prefix"])
     f2 = None
     if da2 is not None:
-        f2 = _fft_nd(da2, dims, kw["spacing_tol"], None, kw["shift"], kw["detrend"], kw["window"], true_phase, True,
+        f2 = _fft_nd(da2, dims, kw["spacing_tol"], real_dim, kw["shift"], kw["detrend"], kw["window"], true_phase, True,
                      kw["chunks_to_segments"], kw["prefix"])
         if tuple(f1.dims) != tuple(f2.dims):
             raise ValueError("The two datasets have different dimensions")
@@ -464,6 +464,15 @@ def _spectrum_nd(da, da2, dims, real_dim, scaling, window_correction, true_phase
             dt = torch.promote_types(a.dtype, b.dtype)
             a, b = a.to(dt), b.to(dt)
     out = engine.spectrum_tail(a, b, scale)
+    if real_dim is not None:  # xrft.py:673-682: the kept half of the real axis counts twice, except k = 0 and Nyquist
+        nreal = da.sizes[real_dim]
+        fac = np.full(out.shape[f1.get_axis_num(new[-1])], 2.0)
+        fac[0] = 1.0
+        if nreal % 2 == 0:
+            fac[-1] = 1.0
+        shp = [1] * out.ndim
+        shp[f1.get_axis_num(new[-1])] = fac.size
+        out = out * torch.from_numpy(fac).to(device=out.device, dtype=out.real.dtype if out.is_complex() else out.dtype).reshape(shp)
     return DataArray(out, f1.dims, f1.coords, None, None)
 
 
@@ -532,8 +541,25 @@ def ifft(daft, spacing_tol=1e-3, dim=None, real_dim=None, shift=True, true_phase
         if not true_phase:
             warnings.warn("Setting lag with true_phase=False does not guarantee accurate ifft.", Warning)
         lag = [daft[d].attrs.get("direct_lag") if l is None else l for d, l in zip(dim, lag)]
-    if len(dim) > 2 or len(dim) == 0:
-        raise NotImplementedError("xrft_amd transforms one or two dimensions per call")
+    if len(dim) == 0:
+        raise NotImplementedError("xrft_amd needs at least one transform dimension")
+    if len(dim) > 2:
+        # ifftn / irfftn over more than two axes (xrft.py:612-621) is separable: complex stages over the leading dims
+        # first, the stage holding the real dimension (whose c2r step must come last) at the end
+        if chunks_to_segments:
+            raise NotImplementedError("chunks_to_segments is implemented for one or two transform dimensions.")
+        cur = daft
+        lag_of = dict(zip(dim, lag))
+        rest = list(dim)
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            while rest:
+                last = len(rest) <= 2
+                grp, rest = (rest, []) if last else (rest[:2], rest[2:])
+                cur = ifft(cur, spacing_tol=spacing_tol, dim=grp, real_dim=real_dim if (last and real_dim in grp) else None,
+                           shift=shift, true_phase=true_phase, true_amplitude=true_amplitude, prefix=prefix,
+                           lag=[lag_of[d] for d in grp])
+        return to_like(from_any(cur), src)
     # input phase factors, indexed by SOURCE position (xrft.py:574-576; applied before any reordering)
     phase = {d: (np.exp(1j * 2.0 * np.pi * np.asarray(daft[d].values, dtype=np.float64) * l) if true_phase else None)
              for d, l in zip(dim, lag)}

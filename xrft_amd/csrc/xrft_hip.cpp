@@ -1072,7 +1072,9 @@ int xrfthip_plan_set_window(xrfthip_plan* plan, int axis, const double* h_window
 
 int xrfthip_plan_set_phase(xrfthip_plan* plan, int axis, const double* h_phase, int64_t n) {
     if (!plan || axis < 0 || axis > 1) return XRFTHIP_BAD_ARG;
-    if (h_phase && n != (axis == 0 ? plan->d.ny : plan->d.nx)) return XRFTHIP_BAD_ARG;
+    // an input phase of a c2r transform covers the stored half of the x axis only
+    const int64_t want = axis == 0 ? plan->d.ny : ((plan->d.flags & XRFTHIP_C2R_X) ? plan->d.nx / 2 + 1 : plan->d.nx);
+    if (h_phase && n != want) return XRFTHIP_BAD_ARG;
     plan->host_phase[axis].assign(h_phase ? h_phase : nullptr, h_phase ? h_phase + 2 * n : nullptr);
     plan->fph_dirty = true;
     return upload_real_table(plan, plan->phase[axis], h_phase, n, 1);
