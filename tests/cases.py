@@ -448,3 +448,21 @@ def run_bluestein_cases(dtype):
         check(xa.power_spectrum(da, dim=["y", "x"], detrend="linear", window="hann"),
               o.power_spectrum(od, dim=["y", "x"], detrend="linear", window="hann"), tol)
         check(xa.fft(da, dim=["y", "x"]), o.fft(od, dim=["y", "x"]), tol)
+
+
+def run_composite_lengths(dtype):
+    """Lengths whose factorisation uses every in-register butterfly (2, 3, 4, 5, 6, 8, 9, 10, 12, 15, 16) and a prime one (7, 11)."""
+    tol = TOL[dtype]
+    rng = np.random.default_rng(15)
+    cdt = "complex128" if dtype == "float64" else "complex64"
+    for n in (6, 9, 10, 12, 15, 18, 36, 45, 60, 90, 100, 120, 144, 150, 225, 360, 720, 1440, 2160, 77, 1155):
+        z = (rng.standard_normal((2, n)) + 1j * rng.standard_normal((2, n))).astype(cdt)
+        da, od = pair(z, ("t", "x"), {"t": np.arange(2), "x": np.arange(n) * 0.5})
+        check(xa.fft(da, dim="x", true_phase=False), o.fft(od, dim="x", true_phase=False), tol)
+        r = rng.standard_normal((2, n)).astype(dtype)
+        da, od = pair(r, ("t", "x"), {"t": np.arange(2), "x": np.arange(n) * 0.5})
+        check(xa.power_spectrum(da, dim="x", window="hann"), o.power_spectrum(od, dim="x", window="hann"), tol)
+    v = rng.standard_normal((2, 90, 120)).astype(dtype)
+    da, od = pair(v, ("t", "y", "x"), {"t": np.arange(2), "y": np.arange(90) * 0.25, "x": np.arange(120) * 0.25})
+    check(xa.power_spectrum(da, dim=["y", "x"], detrend="constant", window="hann"),
+          o.power_spectrum(od, dim=["y", "x"], detrend="constant", window="hann"), tol)

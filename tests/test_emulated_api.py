@@ -233,6 +233,11 @@ def test_fastp2_isotropic_cross(ny, nx, kw):
 
 
 @pytest.mark.parametrize("dtype", ["float64", "float32"])
+def test_composite_radix_lengths(dtype):
+    cases.run_composite_lengths(dtype)
+
+
+@pytest.mark.parametrize("dtype", ["float64", "float32"])
 def test_bluestein_lengths(dtype):
     cases.run_bluestein_cases(dtype)
 

@@ -382,3 +382,8 @@ def test_nd_larger_block_f32():
 @pytest.mark.parametrize("dtype", ["float64", "float32"])
 def test_bluestein_lengths(dtype):
     cases.run_bluestein_cases(dtype)
+
+
+@pytest.mark.parametrize("dtype", ["float64", "float32"])
+def test_composite_radix_lengths(dtype):
+    cases.run_composite_lengths(dtype)

@@ -118,12 +118,67 @@ template <typename T> __device__ __forceinline__ void dft16(C2<T>* a) {
     }
 }
 
+template <typename T, int R> __device__ __forceinline__ void dft_r(C2<T>* a);
+
+// Composite radices with coprime factors (6, 10, 12, 15) by the prime-factor (Good-Thomas) mapping: no twiddles at all,
+//   n = (B n1 + A n2) mod AB,   k = k1 mod A, k = k2 mod B (CRT);  every index is a compile-time constant.
+constexpr int xrft_modinv(int a, int m) { for (int x = 1; x < m; ++x) if ((a * x) % m == 1) return x; return 0; }
+template <typename T, int A, int B> __device__ __forceinline__ void dft_pfa(C2<T>* a) {
+    constexpr int N = A * B, EB = B * xrft_modinv(B % A, A), EA = A * xrft_modinv(A % B, B);  // k = (k1 EB + k2 EA) mod N
+    C2<T> y[N];
+#pragma unroll
+    for (int n2 = 0; n2 < B; ++n2) {
+        C2<T> t[A];
+#pragma unroll
+        for (int n1 = 0; n1 < A; ++n1) t[n1] = a[(B * n1 + A * n2) % N];
+        dft_r<T, A>(t);
+#pragma unroll
+        for (int k1 = 0; k1 < A; ++k1) y[k1 * B + n2] = t[k1];
+    }
+#pragma unroll
+    for (int k1 = 0; k1 < A; ++k1) {
+        C2<T> t[B];
+#pragma unroll
+        for (int n2 = 0; n2 < B; ++n2) t[n2] = y[k1 * B + n2];
+        dft_r<T, B>(t);
+#pragma unroll
+        for (int k2 = 0; k2 < B; ++k2) a[(k1 * EB + k2 * EA) % N] = t[k2];
+    }
+}
+
+// radix 9 = 3 x 3 (Cooley-Tukey, constant twiddles W9^1, W9^2, W9^4)
+template <typename T> __device__ __forceinline__ void dft9(C2<T>* a) {
+    const C2<T> w1 = mk<T>((T)0.76604444311897803520, (T)-0.64278760968653932632);
+    const C2<T> w2 = mk<T>((T)0.17364817766693034885, (T)-0.98480775301220805937);
+    const C2<T> w4 = mk<T>((T)-0.93969262078590838405, (T)-0.34202014332566873304);
+    C2<T> y[3][3];
+#pragma unroll
+    for (int n2 = 0; n2 < 3; ++n2) {  // n = 3 n1 + n2
+        C2<T> t[3] = {a[n2], a[3 + n2], a[6 + n2]};
+        dft3(t);
+        y[0][n2] = t[0]; y[1][n2] = t[1]; y[2][n2] = t[2];
+    }
+    y[1][1] = cmul(y[1][1], w1); y[1][2] = cmul(y[1][2], w2);
+    y[2][1] = cmul(y[2][1], w2); y[2][2] = cmul(y[2][2], w4);
+#pragma unroll
+    for (int k1 = 0; k1 < 3; ++k1) {  // k = k1 + 3 k2
+        C2<T> t[3] = {y[k1][0], y[k1][1], y[k1][2]};
+        dft3(t);
+        a[k1] = t[0]; a[k1 + 3] = t[1]; a[k1 + 6] = t[2];
+    }
+}
+
 template <typename T, int R> __device__ __forceinline__ void dft_r(C2<T>* a) {
     if (R == 2) dft2(a[0], a[1]);
     else if (R == 3) dft3(a);
     else if (R == 4) dft4(a);
     else if (R == 5) dft5(a);
+    else if (R == 6) dft_pfa<T, 2, 3>(a);
     else if (R == 8) dft8(a);
+    else if (R == 9) dft9(a);
+    else if (R == 10) dft_pfa<T, 2, 5>(a);
+    else if (R == 12) dft_pfa<T, 4, 3>(a);
+    else if (R == 15) dft_pfa<T, 3, 5>(a);
     else if (R == 16) dft16(a);
 }
 
@@ -157,6 +212,9 @@ struct TileGeom {
     const void* tw_r2c;     // W_{2n}^k, k <= n   (r2c unpack)
     // Bluestein: blue_n > 0 is the logical sequence length; n (a power of two >= 2 blue_n - 1) is what the LDS passes run.
     //   x[p] conj(c[p]) zero-padded -> forward passes -> * blue_b -> inverse passes -> * conj(c[k]),  c[k] = exp(i pi k^2 / blue_n)
+    int rowc_off;           // > 0: byte offset of T per-row constant records in LDS; the first pass over contiguous rows of
+                            // real input then takes the lean loader (see tile_fft_kernel)
+    int dbg;                // ablation switches for profiling (XRFTHIP_DBG): 1 skip the passes, 2 skip the store, 4 skip the load
     int blue_n;
     const void* blue_c;
     const void* blue_b;     // FFT_n(chirp) / n at the LDS position the forward passes leave each frequency
@@ -475,9 +533,81 @@ __global__ void __launch_bounds__(1024) tile_fft_kernel(TileGeom g, Prologue pr,
         // ------------------------------------------------------------------ load
         const int total_in = g.T * g.n;
         const float inv_n = 1.0f / (float)g.n, inv_T = 1.0f / (float)g.T;
+        bool loaded = false;
+        if (FIRST && g.rowc_off > 0 && pr.ph_y == nullptr && pr.ph_x == nullptr && !(g.dbg & 4)) {
+            // lean loader for rows of real samples (xrft.py:425-442 without flips / input phases): everything that is
+            // constant along a row -- slab, source row, trend at j = 0, trend slope, y window -- is computed once per tile
+            // by T lanes and read back from LDS; per sample: one address, the trend FMA in float64, the x window.
+            struct RowC { long long base; double t0, t1, wy; };
+            RowC* rc = reinterpret_cast<RowC*>(smem_raw + g.rowc_off);
+            for (int rt = tid; rt < g.T; rt += nthreads) {
+                unsigned ii = (unsigned)(pi0 + rt), db = 0;
+                const unsigned rws = (unsigned)pr.rows;
+                if (rws == 1) { db = ii; ii = 0; } else { while (ii >= rws) { ii -= rws; ++db; } }
+                const long long b = pb0 + db;
+                const int si = map_src((int)ii, pr.ny, pr.flip_y, pr.ishift_y);
+                RowC r;
+                r.base = b * pr.slab_stride + (long long)si * pr.row_stride;
+                r.t0 = 0.0; r.t1 = 0.0;
+                if (pr.detrend && rt < tv) { const double* c = pr.coef + b * 6; r.t0 = c[0] + c[2] * si; r.t1 = c[4]; }
+                r.wy = pr.win_y ? (double)reinterpret_cast<const T*>(pr.win_y)[si] : 1.0;
+                rc[rt] = r;
+            }
+            __syncthreads();
+            const T* __restrict__ src = reinterpret_cast<const T*>(pr.in);
+            const T* __restrict__ wx = reinterpret_cast<const T*>(pr.win_x);
+            const C2<T>* __restrict__ chirp = reinterpret_cast<const C2<T>*>(g.blue_c);
+            const int nx = pr.nx, hx = pr.ishift_x ? nx / 2 : 0, nlog = g.blue_n ? g.blue_n : g.n;
+            const bool det = pr.detrend != 0, r2c = g.r2c != 0;
+            constexpr int UR = 4;
+            for (int e0 = tid; e0 < total_in; e0 += UR * nthreads) {
+                T x0[UR], x1[UR], w0[UR], w1[UR];
+                int dst[UR], sj0[UR], sj1[UR], tt[UR], pp[UR];
+#pragma unroll
+                for (int u = 0; u < UR; ++u) {
+                    const int e = e0 + u * nthreads;
+                    dst[u] = -1; tt[u] = -1; pp[u] = 0; sj0[u] = sj1[u] = 0;
+                    x0[u] = x1[u] = (T)0; w0[u] = w1[u] = (T)1;
+                    if (e < total_in) {
+                        const int t = fdiv(e, inv_n), p = e - t * g.n;
+                        dst[u] = t * g.seq_stride + phys(p, g.pad_shift);
+                        if (t < tv && p < nlog) {
+                            tt[u] = t; pp[u] = p;
+                            int a = (r2c ? 2 * p : p) + hx;
+                            if (a >= nx) a -= nx;
+                            int b1 = a + 1;
+                            if (b1 >= nx) b1 -= nx;
+                            sj0[u] = a; sj1[u] = b1;
+                            const long long base = rc[t].base;
+                            x0[u] = src[base + a];
+                            if (r2c) x1[u] = src[base + b1];
+                            if (wx) { w0[u] = wx[a]; if (r2c) w1[u] = wx[b1]; }
+                        }
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < UR; ++u) {
+                    if (dst[u] < 0) continue;
+                    C2<T> v = mk<T>((T)0, (T)0);
+                    if (tt[u] >= 0) {
+                        const RowC r = rc[tt[u]];
+                        T a0 = x0[u], a1 = x1[u];
+                        if (det) {
+                            a0 = (T)((double)a0 - (r.t0 + r.t1 * (double)sj0[u]));
+                            if (r2c) a1 = (T)((double)a1 - (r.t0 + r.t1 * (double)sj1[u]));
+                        }
+                        const T wy = (T)r.wy;
+                        v = mk<T>(a0 * (w0[u] * wy), r2c ? a1 * (w1[u] * wy) : (T)0);
+                        if (g.blue_n) v = cmulc(v, chirp[pp[u]]);
+                    }
+                    tile[dst[u]] = v;
+                }
+            }
+            loaded = true;
+        }
         // U independent elements per thread and trip: all their global loads are in flight before the first LDS store
         constexpr int U = 4;
-        for (int e0 = tid; e0 < total_in; e0 += U * nthreads) {
+        for (int e0 = tid; e0 < ((loaded || (g.dbg & 4)) ? 0 : total_in); e0 += U * nthreads) {
             C2<T> vv[U];
             int dst[U];
 #pragma unroll
@@ -521,7 +651,7 @@ __global__ void __launch_bounds__(1024) tile_fft_kernel(TileGeom g, Prologue pr,
         __syncthreads();
         // ------------------------------------------------------------------ in-place DIF passes
         int L = g.n;
-        for (int ip = 0; ip < g.nr; ++ip) {
+        for (int ip = 0; ip < ((g.dbg & 1) ? 0 : g.nr); ++ip) {
             const int R = g.radix[ip];
             if (twl) {
                 const C2<T>* tw = twl;
@@ -530,7 +660,12 @@ __global__ void __launch_bounds__(1024) tile_fft_kernel(TileGeom g, Prologue pr,
                     case 3: run_pass<T, 3>(tile, g, L, tid, nthreads, tw); break;
                     case 4: run_pass<T, 4>(tile, g, L, tid, nthreads, tw); break;
                     case 5: run_pass<T, 5>(tile, g, L, tid, nthreads, tw); break;
+                    case 6: run_pass<T, 6>(tile, g, L, tid, nthreads, tw); break;
                     case 8: run_pass<T, 8>(tile, g, L, tid, nthreads, tw); break;
+                    case 9: run_pass<T, 9>(tile, g, L, tid, nthreads, tw); break;
+                    case 10: run_pass<T, 10>(tile, g, L, tid, nthreads, tw); break;
+                    case 12: run_pass<T, 12>(tile, g, L, tid, nthreads, tw); break;
+                    case 15: run_pass<T, 15>(tile, g, L, tid, nthreads, tw); break;
                     case 16: run_pass<T, 16>(tile, g, L, tid, nthreads, tw); break;
                     default:
                         if (GENERIC) run_pass_generic<T>(tile, g, R, L, tid, nthreads);
@@ -542,7 +677,12 @@ __global__ void __launch_bounds__(1024) tile_fft_kernel(TileGeom g, Prologue pr,
                     case 3: run_pass<T, 3>(tile, g, L, tid, nthreads, twg); break;
                     case 4: run_pass<T, 4>(tile, g, L, tid, nthreads, twg); break;
                     case 5: run_pass<T, 5>(tile, g, L, tid, nthreads, twg); break;
+                    case 6: run_pass<T, 6>(tile, g, L, tid, nthreads, twg); break;
                     case 8: run_pass<T, 8>(tile, g, L, tid, nthreads, twg); break;
+                    case 9: run_pass<T, 9>(tile, g, L, tid, nthreads, twg); break;
+                    case 10: run_pass<T, 10>(tile, g, L, tid, nthreads, twg); break;
+                    case 12: run_pass<T, 12>(tile, g, L, tid, nthreads, twg); break;
+                    case 15: run_pass<T, 15>(tile, g, L, tid, nthreads, twg); break;
                     case 16: run_pass<T, 16>(tile, g, L, tid, nthreads, twg); break;
                     default:
                         if (GENERIC) run_pass_generic<T>(tile, g, R, L, tid, nthreads);
@@ -598,7 +738,7 @@ __global__ void __launch_bounds__(1024) tile_fft_kernel(TileGeom g, Prologue pr,
         const float inv_no = 1.0f / (float)g.n_out;
         // V independent results per thread and trip: table lookups and LDS reads of all of them overlap
         constexpr int V = 4;
-        for (int e0 = tid; e0 < total_out; e0 += V * nthreads) {
+        for (int e0 = tid; e0 < ((g.dbg & 2) ? 0 : total_out); e0 += V * nthreads) {
             C2<T> FF[V];
             int tt[V], kk[V];
 #pragma unroll

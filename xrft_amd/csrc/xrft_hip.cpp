@@ -7,6 +7,7 @@
 // into its stores).  The only intermediate is the half-spectrum of ONE group of slabs, sized to stay inside
 // the 256 MiB Infinity Cache, re-used for every group.  Nothing here allocates or synchronises in exec.
 #include <algorithm>
+#include <functional>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -85,25 +86,50 @@ long long env_ll(const char* name, long long dflt) {
 }
 
 int factorize(long long n, std::vector<int>& out, bool& generic) {
-    // DIF order: odd radices first (their passes then run on lane-contiguous LDS), then 8, 4, 2
-    std::vector<int> odd, two;
+    // prime factors first: anything above XRFTHIP_MAX_RADIX is refused here (Bluestein takes over, see lds_fft_len)
+    std::vector<int> big;  // primes other than 2, 3, 5: O(r^2) butterflies of their own
     long long m = n;
-    while (m % 16 == 0 && env_ll("XRFTHIP_RADIX16", 1)) { two.push_back(16); m /= 16; }
-    while (m % 8 == 0) { two.push_back(8); m /= 8; }
-    while (m % 4 == 0) { two.push_back(4); m /= 4; }
-    while (m % 2 == 0) { two.push_back(2); m /= 2; }
-    generic = false;
-    for (long long p = 3; m > 1; p += 2) {
+    int c2 = 0, c3 = 0, c5 = 0;
+    while (m % 2 == 0) { ++c2; m /= 2; }
+    while (m % 3 == 0) { ++c3; m /= 3; }
+    while (m % 5 == 0) { ++c5; m /= 5; }
+    for (long long p = 7; m > 1; p += 2) {
         if (p * p > m) p = m;
         while (m % p == 0) {
             if (p > XRFTHIP_MAX_RADIX) return XRFTHIP_UNSUPPORTED_LENGTH;
-            odd.push_back((int)p);
-            if (p != 3 && p != 5) generic = true;
+            big.push_back((int)p);
             m /= p;
         }
     }
-    std::sort(odd.begin(), odd.end(), [](int a, int b) { return a > b; });
-    out = odd;
+    generic = !big.empty();
+    std::sort(big.begin(), big.end(), [](int a, int b) { return a > b; });
+    // 2^a 3^b 5^c into as few passes as possible with the in-register butterflies 16, 15, 12, 10, 9, 8, 6, 5, 4, 3, 2
+    // (every pass is one trip of every point through LDS): exhaustive search, the exponents are small
+    static const int R[] = {16, 15, 12, 10, 9, 8, 6, 5, 4, 3, 2};
+    static const int E2[] = {4, 0, 2, 1, 0, 3, 1, 0, 2, 0, 1}, E3[] = {0, 1, 1, 0, 2, 0, 1, 0, 0, 1, 0}, E5[] = {0, 1, 0, 1, 0, 0, 0, 1, 0, 0, 0};
+    const bool comp = env_ll("XRFTHIP_COMPOSITE", 1) != 0, r16 = env_ll("XRFTHIP_RADIX16", 1) != 0;
+    std::vector<int> best, cur;
+    std::function<void(int, int, int, int)> dfs = [&](int a2, int a3, int a5, int from) {
+        if (a2 == 0 && a3 == 0 && a5 == 0) {
+            if (best.empty() || cur.size() < best.size()) best = cur;
+            return;
+        }
+        if (!best.empty() && cur.size() + 1 >= best.size()) return;
+        for (int i = from; i < 11; ++i) {  // non-increasing radices: each multiset once, big radices tried first
+            if (E2[i] > a2 || E3[i] > a3 || E5[i] > a5) continue;
+            if (!comp && (R[i] == 15 || R[i] == 12 || R[i] == 10 || R[i] == 9 || R[i] == 6)) continue;
+            if (!r16 && R[i] == 16) continue;
+            cur.push_back(R[i]);
+            dfs(a2 - E2[i], a3 - E3[i], a5 - E5[i], i);
+            cur.pop_back();
+        }
+    };
+    if (c2 || c3 || c5) dfs(c2, c3, c5, 0);
+    // DIF order: odd and composite radices first (their passes then run on lane-contiguous LDS), powers of two last
+    std::vector<int> odd, two;
+    for (int r : best) ((r & (r - 1)) == 0 ? two : odd).push_back(r);
+    out = big;
+    out.insert(out.end(), odd.begin(), odd.end());
     out.insert(out.end(), two.begin(), two.end());
     if ((int)out.size() > XRFT_MAX_PASSES) return XRFTHIP_UNSUPPORTED_LENGTH;
     return XRFTHIP_OK;
@@ -316,6 +342,7 @@ struct Builder {
 
     void apply_tile(Pass& ps, const TileChoice& c) {
         ps.g.T = c.T;
+        ps.g.dbg = (int)env_ll("XRFTHIP_DBG", 0);
         ps.g.seq_stride = c.seq_stride;
         ps.g.pad_shift = c.pad_shift;
         ps.threads = c.threads;
@@ -436,6 +463,11 @@ struct Builder {
             ps.g.tiles_per_outer = 1;
             ps.outer_per_slab = rows;
             fill_prologue(ps, rows, 1, 0);
+            if (real_in && !(d.flags & (XRFTHIP_FLIP_X | XRFTHIP_C2R_X | XRFTHIP_INVERSE)) && env_ll("XRFTHIP_LEAN_ROWS", 1) &&
+                ps.lds + 32 * (size_t)c.T + 32 <= kLdsMax) {  // lean row loader: per-row constants behind everything else
+                ps.g.rowc_off = (int)((ps.lds + 15) & ~(size_t)15);
+                ps.lds = (size_t)ps.g.rowc_off + 32 * (size_t)c.T;
+            }
             if (last) {
                 fill_epilogue(ps, raw, 0, 1);
             } else {
