@@ -214,6 +214,13 @@ struct TileGeom {
     //   x[p] conj(c[p]) zero-padded -> forward passes -> * blue_b -> inverse passes -> * conj(c[k]),  c[k] = exp(i pi k^2 / blue_n)
     int rowc_off;           // > 0: byte offset of T per-row constant records in LDS; the first pass over contiguous rows of
                             // real input then takes the lean loader (see tile_fft_kernel)
+    // tiled intermediate between a row pass and a column pass of Tc = til columns per tile: W[slab][kx / Tc][i][kx % Tc].
+    // The column pass then reads each of its tiles as ONE contiguous block (reading Tc-column strips out of row-major rows
+    // fetched every 128-byte line twice or more), the row pass writes Tc-element chunks.
+    int out_tiled, in_tiled;      // Tc (a power of two) or 0
+    long long til_stride;         // ny * Tc: elements between column tiles
+    long long til_slab;           // (padded width / Tc) * ny * Tc: elements per slab
+    int til_ny;
     int dbg;                // ablation switches for profiling (XRFTHIP_DBG): 1 skip the passes, 2 skip the store, 4 skip the load
     int blue_n;
     const void* blue_c;
@@ -534,12 +541,11 @@ __global__ void __launch_bounds__(1024) tile_fft_kernel(TileGeom g, Prologue pr,
         const int total_in = g.T * g.n;
         const float inv_n = 1.0f / (float)g.n, inv_T = 1.0f / (float)g.T;
         bool loaded = false;
-        if (FIRST && g.rowc_off > 0 && pr.ph_y == nullptr && pr.ph_x == nullptr && !(g.dbg & 4)) {
-            // lean loader for rows of real samples (xrft.py:425-442 without flips / input phases): everything that is
-            // constant along a row -- slab, source row, trend at j = 0, trend slope, y window -- is computed once per tile
-            // by T lanes and read back from LDS; per sample: one address, the trend FMA in float64, the x window.
-            struct RowC { long long base; double t0, t1, wy; };
-            RowC* rc = reinterpret_cast<RowC*>(smem_raw + g.rowc_off);
+        // everything that is constant along a row of a row tile -- slab, source row, trend at j = 0, trend slope, y window,
+        // base of the row in the (tiled) intermediate -- is computed once per tile by T lanes and read back from LDS
+        struct RowC { long long base, obase; double t0, t1, wy, pad_; };
+        RowC* rc = reinterpret_cast<RowC*>(smem_raw + (g.rowc_off > 0 ? g.rowc_off : 0));
+        if (FIRST && g.rowc_off > 0) {
             for (int rt = tid; rt < g.T; rt += nthreads) {
                 unsigned ii = (unsigned)(pi0 + rt), db = 0;
                 const unsigned rws = (unsigned)pr.rows;
@@ -548,12 +554,17 @@ __global__ void __launch_bounds__(1024) tile_fft_kernel(TileGeom g, Prologue pr,
                 const int si = map_src((int)ii, pr.ny, pr.flip_y, pr.ishift_y);
                 RowC r;
                 r.base = b * pr.slab_stride + (long long)si * pr.row_stride;
-                r.t0 = 0.0; r.t1 = 0.0;
+                r.obase = g.out_tiled ? b * g.til_slab + (long long)ii * g.out_tiled : 0;
+                r.t0 = 0.0; r.t1 = 0.0; r.pad_ = 0.0;
                 if (pr.detrend && rt < tv) { const double* c = pr.coef + b * 6; r.t0 = c[0] + c[2] * si; r.t1 = c[4]; }
                 r.wy = pr.win_y ? (double)reinterpret_cast<const T*>(pr.win_y)[si] : 1.0;
                 rc[rt] = r;
             }
             __syncthreads();
+        }
+        if (FIRST && g.rowc_off > 0 && pr.ph_y == nullptr && pr.ph_x == nullptr && !(g.dbg & 4)) {
+            // lean loader for rows of real samples (xrft.py:425-442 without flips / input phases): per sample one
+            // address, the trend FMA in float64, the x window
             const T* __restrict__ src = reinterpret_cast<const T*>(pr.in);
             const T* __restrict__ wx = reinterpret_cast<const T*>(pr.win_x);
             const C2<T>* __restrict__ chirp = reinterpret_cast<const C2<T>*>(g.blue_c);
@@ -607,6 +618,39 @@ __global__ void __launch_bounds__(1024) tile_fft_kernel(TileGeom g, Prologue pr,
         }
         // U independent elements per thread and trip: all their global loads are in flight before the first LDS store
         constexpr int U = 4;
+        if (!FIRST && g.in_tiled && !(g.dbg & 4)) {  // one contiguous block: element e of the tile is element e of the block
+            const int tsh = 31 - __builtin_clz((unsigned)g.T);
+            const C2<T>* __restrict__ blk = gin + o0 * g.til_slab + (q0 >> tsh) * g.til_stride;
+            const int nlog = g.blue_n ? g.blue_n : g.n;
+            const int tot = nlog * g.T;
+            constexpr int UT = 8;
+            for (int e0 = tid; e0 < tot; e0 += UT * nthreads) {
+                C2<T> vv[UT];
+#pragma unroll
+                for (int u = 0; u < UT; ++u) {
+                    const int e = e0 + u * nthreads;
+                    vv[u] = mk<T>((T)0, (T)0);
+                    if (e < tot && (e & (g.T - 1)) < tv) vv[u] = blk[e];
+                }
+#pragma unroll
+                for (int u = 0; u < UT; ++u) {
+                    const int e = e0 + u * nthreads;
+                    if (e < tot) {
+                        const int p = e >> tsh, t = e & (g.T - 1);
+                        C2<T> v = vv[u];
+                        if (g.blue_n) v = cmulc(v, reinterpret_cast<const C2<T>*>(g.blue_c)[p]);
+                        tile[t * g.seq_stride + phys(p, g.pad_shift)] = v;
+                    }
+                }
+            }
+            if (g.blue_n) {  // zero padding of the Bluestein transform
+                for (int e = tot + tid; e < total_in; e += nthreads) {
+                    const int p = e >> tsh, t = e & (g.T - 1);
+                    tile[t * g.seq_stride + phys(p, g.pad_shift)] = mk<T>((T)0, (T)0);
+                }
+            }
+            loaded = true;
+        }
         for (int e0 = tid; e0 < ((loaded || (g.dbg & 4)) ? 0 : total_in); e0 += U * nthreads) {
             C2<T> vv[U];
             int dst[U];
@@ -785,7 +829,12 @@ __global__ void __launch_bounds__(1024) tile_fft_kernel(TileGeom g, Prologue pr,
                         const unsigned a = ((unsigned)q / (unsigned)g.tw_qdiv) % (unsigned)g.tw_qmod;
                         F = cmul(F, reinterpret_cast<const C2<T>*>(g.tw_big)[(long long)a * k]);  // a*k < bigN by construction
                     }
-                    gout[o * g.out_so + q * g.out_sq + (long long)k * g.out_sp] = F;
+                    if (g.out_tiled) {
+                        const int tsh = 31 - __builtin_clz((unsigned)g.out_tiled);
+                        gout[rc[t].obase + (long long)(k >> tsh) * g.til_stride + (k & (g.out_tiled - 1))] = F;
+                    } else {
+                        gout[o * g.out_so + q * g.out_sq + (long long)k * g.out_sp] = F;
+                    }
                 }
             }
         }

@@ -237,7 +237,7 @@ struct xrfthip_plan {
     xrfthip_desc d{};
     bool dbl = false, cplx_in = false;
     size_t rsize = 4, csize = 8;
-    long long nxh = 0, width = 0, nx_out = 0;
+    long long nxh = 0, width = 0, nx_out = 0, w_cols = 0;  // w_cols: columns of the row->column intermediate incl. tile padding
     bool mirror = false;
     int G = 1;
     std::map<int, FftTables> tables;
@@ -464,9 +464,9 @@ struct Builder {
             ps.outer_per_slab = rows;
             fill_prologue(ps, rows, 1, 0);
             if (real_in && !(d.flags & (XRFTHIP_FLIP_X | XRFTHIP_C2R_X | XRFTHIP_INVERSE)) && env_ll("XRFTHIP_LEAN_ROWS", 1) &&
-                ps.lds + 32 * (size_t)c.T + 32 <= kLdsMax) {  // lean row loader: per-row constants behind everything else
+                ps.lds + 48 * (size_t)c.T + 32 <= kLdsMax) {  // lean row loader: per-row constants behind everything else
                 ps.g.rowc_off = (int)((ps.lds + 15) & ~(size_t)15);
-                ps.lds = (size_t)ps.g.rowc_off + 32 * (size_t)c.T;
+                ps.lds = (size_t)ps.g.rowc_off + 48 * (size_t)c.T;
             }
             if (last) {
                 fill_epilogue(ps, raw, 0, 1);
@@ -617,13 +617,28 @@ struct Builder {
         int rc = build_x(out, raw);
         if (rc) return rc;
         if (P.d.ndim == 2) rc = build_y(out, raw);
-        return rc;
+        if (rc) return rc;
+        // one row pass feeding one column pass: hand the intermediate over in tiles of the column pass's T columns
+        if (out.size() == 2 && out[0].g.rowc_off > 0 && out[0].out_kind == B_W && out[1].in_kind == B_W && out[1].g.tile_axis == 1 &&
+            out[1].g.T >= 2 && (out[1].g.T & (out[1].g.T - 1)) == 0 && env_ll("XRFTHIP_TILED_W", 1)) {
+            const int tc = out[1].g.T;
+            const long long wc = (P.width + tc - 1) / tc * tc;
+            if (P.w_cols == 0 || P.w_cols == wc) {  // (the F0 pipeline of a cross spectrum picks the same T)
+                P.w_cols = wc;
+                out[0].g.out_tiled = tc; out[1].g.in_tiled = tc;
+                out[0].g.til_stride = out[1].g.til_stride = P.d.ny * tc;
+                out[0].g.til_slab = out[1].g.til_slab = (wc / tc) * P.d.ny * tc;
+                out[0].g.til_ny = out[1].g.til_ny = (int)P.d.ny;
+            }
+        }
+        return XRFTHIP_OK;
     }
 };
 
 template <typename T>
 int build_plan_t(xrfthip_plan& P) {
     Builder<T> B(P);
+    P.w_cols = 0;
     int rc = B.build_pipeline(P.passes, false);
     if (rc) return rc;
     if (P.d.out_mode == XRFTHIP_OUT_CROSS || P.d.out_mode == XRFTHIP_OUT_PHASE) rc = B.build_pipeline(P.passes_f0, true);
@@ -705,7 +720,7 @@ static void layout_workspace(xrfthip_plan* P) {
     const xrfthip_desc& d = P->d;
     const bool fast = fast_on(P);
     long long G = d.slabs_per_group > 0 ? d.slabs_per_group : env_ll("XRFTHIP_GROUP", 0);
-    size_t slab_w = (size_t)d.ny * P->width * P->csize;
+    size_t slab_w = (size_t)d.ny * std::max(P->width, P->w_cols) * P->csize;
     if (fast) {
         slab_w = (size_t)P->fast_ntile_pad * d.ny * 4 * sizeof(cf);
         if (G <= 0) G = env_ll("XRFTHIP_FAST_GROUP", std::max<long long>(1, (32LL * 4096 * 4096) / (d.ny * d.nx)));  // measured 8: 197, 16: 210, 32: 214 GFFT/s (tails and launch gaps amortise)
