@@ -221,6 +221,7 @@ struct TileGeom {
     long long til_stride;         // ny * Tc: elements between column tiles
     long long til_slab;           // (padded width / Tc) * ny * Tc: elements per slab
     int til_ny;
+    int lean_final;         // 1: plain column pass writing |F|^2 or F: the lean epilogue applies (host-checked, see tile_fft_kernel)
     int dbg;                // ablation switches for profiling (XRFTHIP_DBG): 1 skip the passes, 2 skip the store, 4 skip the load
     int blue_n;
     const void* blue_c;
@@ -778,11 +779,70 @@ __global__ void __launch_bounds__(1024) tile_fft_kernel(TileGeom g, Prologue pr,
         }
         // ------------------------------------------------------------------ store
         const int nl = g.blue_n ? g.blue_n : g.n;  // logical transform length
+        bool stored = false;
+        if (FINAL && g.lean_final && hist == nullptr && ep.out != nullptr && !(g.dbg & 2)) {
+            // lean epilogue of a plain column pass (xrft.py:446-472, 740-748): T is a power of two dividing the block size,
+            // so a lane keeps its column for the whole tile -- column index, shifted destination column, mirror column,
+            // x phase factors and the scale are per-lane constants; per sample: one LDS read, the y factors, two stores.
+            const int tsh = 31 - __builtin_clz((unsigned)g.T);
+            const int t = tid & (g.T - 1), kx = (int)q0 + t;
+            const bool col_ok = t < tv && (kx < ep.nx_out || ep.mirror);
+            const bool has_m = ep.mirror && kx > 0 && kx < ep.nx - kx;
+            const bool direct_ok = kx < ep.nx_out;
+            const int mkx = ep.nx - kx;
+            const long long dcol = shift_dst(kx < ep.nx ? kx : 0, ep.nx, ep.shift_x), mcol = has_m ? shift_dst(mkx, ep.nx, ep.shift_x) : 0;
+            T sc = (T)ep.scale;
+            if (ep.realdim_x2 && !(kx == 0 || ((ep.nx & 1) == 0 && kx == ep.nx / 2))) sc *= (T)2;
+            const bool cplx = ep.mode == 0;
+            const C2<T>* __restrict__ phy = reinterpret_cast<const C2<T>*>(ep.ph_y);
+            const C2<T>* __restrict__ phx = reinterpret_cast<const C2<T>*>(ep.ph_x);
+            C2<T> px = mk<T>(sc, (T)0), pxm = mk<T>(sc, (T)0);  // scale folded into the x factor
+            if (cplx && phx && col_ok) {
+                px = cscale(phx[kx < ep.nx ? kx : 0], sc);
+                if (has_m) pxm = cscale(phx[mkx], sc);
+            }
+            const long long slab_off = eb0 * ep.slab_stride;
+            const C2<T>* s = tile + t * g.seq_stride;
+            const int kstep = nthreads >> tsh;
+            constexpr int VL = 4;
+            for (int k0 = tid >> tsh; k0 < nl; k0 += VL * kstep) {
+                C2<T> FF[VL];
+#pragma unroll
+                for (int u = 0; u < VL; ++u) {
+                    const int k = k0 + u * kstep;
+                    FF[u] = mk<T>((T)0, (T)0);
+                    if (k < nl && col_ok) {
+                        const int pk = g.blue_n ? k : (revl ? (int)revl[k] : (int)g.rev[k]);
+                        FF[u] = s[phys(pk, g.pad_shift)];
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < VL; ++u) {
+                    const int k = k0 + u * kstep;
+                    if (k >= nl || !col_ok) continue;
+                    const C2<T> F = FF[u];
+                    const long long drow = slab_off + (long long)shift_dst(k, ep.ny, ep.shift_y) * ep.row_stride;
+                    const int mk_ = k == 0 ? 0 : ep.ny - k;
+                    const long long mrow = slab_off + (long long)shift_dst(mk_, ep.ny, ep.shift_y) * ep.row_stride;
+                    if (cplx) {
+                        C2<T> vd = cmul(F, px), vm = cmul(cconj(F), pxm);
+                        if (phy) { vd = cmul(vd, phy[k]); if (has_m) vm = cmul(vm, phy[mk_]); }
+                        if (direct_ok) reinterpret_cast<C2<T>*>(ep.out)[drow + dcol] = vd;
+                        if (has_m) reinterpret_cast<C2<T>*>(ep.out)[mrow + mcol] = vm;
+                    } else {
+                        const T v = (F.re * F.re + F.im * F.im) * sc;
+                        if (direct_ok) reinterpret_cast<T*>(ep.out)[drow + dcol] = v;
+                        if (has_m) reinterpret_cast<T*>(ep.out)[mrow + mcol] = v;
+                    }
+                }
+            }
+            stored = true;
+        }
         const int total_out = g.T * g.n_out;
         const float inv_no = 1.0f / (float)g.n_out;
         // V independent results per thread and trip: table lookups and LDS reads of all of them overlap
         constexpr int V = 4;
-        for (int e0 = tid; e0 < ((g.dbg & 2) ? 0 : total_out); e0 += V * nthreads) {
+        for (int e0 = tid; e0 < ((stored || (g.dbg & 2)) ? 0 : total_out); e0 += V * nthreads) {
             C2<T> FF[V];
             int tt[V], kk[V];
 #pragma unroll

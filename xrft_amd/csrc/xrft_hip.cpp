@@ -280,7 +280,9 @@ TileChoice choose_tile(long long n_logical, size_t csize, bool col, long long av
     c.seq_stride = (int)ss;
     const size_t per = (size_t)ss * csize;
     const size_t hard = kLdsMax - hist_bytes - 64;
-    const size_t soft = (size_t)env_ll("XRFTHIP_LDS_SOFT", 64 * 1024);
+    // measured (scripts/prof_generic3.py): for long sequences larger tiles (wider chunks, more threads) beat two small
+    // workgroups per CU; short ones already get 8+ sequences into 64 KiB
+    const size_t soft = (size_t)env_ll("XRFTHIP_LDS_SOFT", (64 * 1024) / per < 8 ? 144 * 1024 : 64 * 1024);
     long long target = std::max<long long>(1, 8192 / std::max<long long>(n, 1));
     if (col) target = std::max<long long>(target, (long long)(128 / csize));
     long long T = std::min<long long>(target, (long long)(soft / per));
@@ -562,6 +564,9 @@ struct Builder {
             ps.in_kind = B_W;
             ps.g.in_so = ny * w; ps.g.in_sq = 1; ps.g.in_sp = w;
             fill_epilogue(ps, raw, 1, 1);
+            if ((ps.ep.mode == 0 || ps.ep.mode == 1) && !ps.ep.conj_out && !ps.ep.real_out && c.T >= 1 && c.T <= 64 &&
+                (c.T & (c.T - 1)) == 0 && ps.threads % c.T == 0 && env_ll("XRFTHIP_LEAN_FINAL", 1))
+                ps.g.lean_final = 1;
             out.push_back(ps);
             return XRFTHIP_OK;
         }
