@@ -222,6 +222,8 @@ struct TileGeom {
     long long til_slab;           // (padded width / Tc) * ny * Tc: elements per slab
     int til_ny;
     int lean_final;         // 1: plain column pass writing |F|^2 or F: the lean epilogue applies (host-checked, see tile_fft_kernel)
+                            // 2: last pass of a four-step transform along x (kx = q + q_mul' ... see there)
+    int lean_col;           // column tiles of a four-step first pass: bit 0 = lean loader (real 1-D input), bit 1 = lean store
     int dbg;                // ablation switches for profiling (XRFTHIP_DBG): 1 skip the passes, 2 skip the store, 4 skip the load
     int blue_n;
     const void* blue_c;
@@ -473,8 +475,10 @@ __device__ void run_pass_generic(C2<T>* tile, const TileGeom& g, int R, int L, i
 // ------------------------------------------------------------------------------------------------
 // the kernel
 // ------------------------------------------------------------------------------------------------
-template <typename T, bool FIRST, bool FINAL, bool GENERIC>
-__global__ void __launch_bounds__(1024) tile_fft_kernel(TileGeom g, Prologue pr, Epilogue ep) {
+// MAXT: the largest block the instantiation is launched with -- 512 leaves the register allocator 256 VGPRs per lane
+// (the float64 radix-16 butterfly alone holds 64), 1024 caps it at 128
+template <typename T, bool FIRST, bool FINAL, bool GENERIC, int MAXT>
+__global__ void __launch_bounds__(MAXT) tile_fft_kernel(TileGeom g, Prologue pr, Epilogue ep) {
     XRFT_DYN_SMEM(smem_raw);
     C2<T>* tile = reinterpret_cast<C2<T>*>(smem_raw);
     const int tid = threadIdx.x, nthreads = blockDim.x;
@@ -619,6 +623,51 @@ __global__ void __launch_bounds__(1024) tile_fft_kernel(TileGeom g, Prologue pr,
         }
         // U independent elements per thread and trip: all their global loads are in flight before the first LDS store
         constexpr int U = 4;
+        if (FIRST && (g.lean_col & 1) && pr.ph_x == nullptr && !(g.dbg & 4)) {
+            // four-step first pass over a real 1-D series: the tile is T consecutive columns q of the row viewed as
+            // [n1][n2]; a lane keeps its column, per sample: j = p n2 + q, one load, trend, window
+            const int tsh = 31 - __builtin_clz((unsigned)g.T);
+            const int t = tid & (g.T - 1);
+            const long long q = q0 + t;
+            const bool ok = t < tv;
+            const T* __restrict__ src = reinterpret_cast<const T*>(pr.in) + o0 * pr.slab_stride;
+            const T* __restrict__ wx = reinterpret_cast<const T*>(pr.win_x);
+            const int nx = pr.nx, hx = pr.ishift_x ? nx / 2 : 0, nlog = g.blue_n ? g.blue_n : g.n;
+            double t0 = 0.0, t1 = 0.0;
+            if (pr.detrend) { const double* c = pr.coef + o0 * 6; t0 = c[0]; t1 = c[4]; }
+            const int pstep = nthreads >> tsh, jq = (int)(q * pr.j_mul_q), jp = (int)pr.j_mul_p;
+            constexpr int UC = 8;
+            for (int p0 = tid >> tsh; p0 < g.n; p0 += UC * pstep) {
+                T xv[UC], wv[UC];
+                int sjv[UC];
+#pragma unroll
+                for (int u = 0; u < UC; ++u) {
+                    const int p = p0 + u * pstep;
+                    xv[u] = (T)0; wv[u] = (T)1; sjv[u] = 0;
+                    if (p < nlog && ok) {
+                        int a = p * jp + jq + hx;
+                        if (a >= nx) a -= nx;
+                        sjv[u] = a;
+                        xv[u] = src[a];
+                        if (wx) wv[u] = wx[a];
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < UC; ++u) {
+                    const int p = p0 + u * pstep;
+                    if (p >= g.n) continue;
+                    C2<T> v = mk<T>((T)0, (T)0);
+                    if (p < nlog && ok) {
+                        T a0 = xv[u];
+                        if (pr.detrend) a0 = (T)((double)a0 - (t0 + t1 * (double)sjv[u]));
+                        v = mk<T>(a0 * wv[u], (T)0);
+                        if (g.blue_n) v = cmulc(v, reinterpret_cast<const C2<T>*>(g.blue_c)[p]);
+                    }
+                    tile[t * g.seq_stride + phys(p, g.pad_shift)] = v;
+                }
+            }
+            loaded = true;
+        }
         if (!FIRST && g.in_tiled && !(g.dbg & 4)) {  // one contiguous block: element e of the tile is element e of the block
             const int tsh = 31 - __builtin_clz((unsigned)g.T);
             const C2<T>* __restrict__ blk = gin + o0 * g.til_slab + (q0 >> tsh) * g.til_stride;
@@ -780,7 +829,79 @@ __global__ void __launch_bounds__(1024) tile_fft_kernel(TileGeom g, Prologue pr,
         // ------------------------------------------------------------------ store
         const int nl = g.blue_n ? g.blue_n : g.n;  // logical transform length
         bool stored = false;
-        if (FINAL && g.lean_final && hist == nullptr && ep.out != nullptr && !(g.dbg & 2)) {
+        if (!FINAL && (g.lean_col & 2) && !(g.dbg & 2)) {
+            // four-step first pass, store: W2[o][k n2 + q] = F[k] W_N^(q k); the lane's column q is fixed
+            const int tsh = 31 - __builtin_clz((unsigned)g.T);
+            const int t = tid & (g.T - 1);
+            const long long q = q0 + t;
+            const bool ok = t < tv;
+            const unsigned a = ((unsigned)q / (unsigned)g.tw_qdiv) % (unsigned)g.tw_qmod;
+            const C2<T>* __restrict__ big = reinterpret_cast<const C2<T>*>(g.tw_big);
+            C2<T>* __restrict__ dstc = gout + o0 * g.out_so + q * g.out_sq;
+            const C2<T>* s = tile + t * g.seq_stride;
+            const int kstep = nthreads >> tsh;
+            constexpr int VS = 4;
+            for (int k0 = tid >> tsh; k0 < nl; k0 += VS * kstep) {
+                C2<T> FF[VS], WW[VS];
+#pragma unroll
+                for (int u = 0; u < VS; ++u) {
+                    const int k = k0 + u * kstep;
+                    FF[u] = mk<T>((T)0, (T)0); WW[u] = mk<T>((T)1, (T)0);
+                    if (k < nl && ok) {
+                        const int pk = g.blue_n ? k : (revl ? (int)revl[k] : (int)g.rev[k]);
+                        FF[u] = s[phys(pk, g.pad_shift)];
+                        WW[u] = big[(long long)a * k];
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < VS; ++u) {
+                    const int k = k0 + u * kstep;
+                    if (k < nl && ok) dstc[(long long)k * g.out_sp] = cmul(FF[u], WW[u]);
+                }
+            }
+            stored = true;
+        }
+        if (FINAL && g.lean_final == 2 && hist == nullptr && ep.out != nullptr && !(g.dbg & 2)) {
+            // last pass of a four-step transform along x (1-D): kx = q + p_mul k with the lane's q fixed; no mirror (the
+            // four-step path transforms real input as complex), row = slab
+            const int tsh = 31 - __builtin_clz((unsigned)g.T);
+            const int t = tid & (g.T - 1);
+            const int kq = (int)(q0 + t) * (int)ep.q_mul, pm = (int)ep.p_mul;
+            const bool ok = t < tv;
+            const bool cplx = ep.mode == 0;
+            const C2<T>* __restrict__ phx = reinterpret_cast<const C2<T>*>(ep.ph_x);
+            const long long row_off = eb0 * ep.slab_stride;
+            const C2<T>* s = tile + t * g.seq_stride;
+            const int kstep = nthreads >> tsh;
+            constexpr int VL = 4;
+            for (int k0 = tid >> tsh; k0 < nl; k0 += VL * kstep) {
+                C2<T> FF[VL], PH[VL];
+#pragma unroll
+                for (int u = 0; u < VL; ++u) {
+                    const int k = k0 + u * kstep;
+                    FF[u] = mk<T>((T)0, (T)0); PH[u] = mk<T>((T)1, (T)0);
+                    if (k < nl && ok) {
+                        const int pk = g.blue_n ? k : (revl ? (int)revl[k] : (int)g.rev[k]);
+                        FF[u] = s[phys(pk, g.pad_shift)];
+                        if (cplx && phx) PH[u] = phx[kq + pm * k];
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < VL; ++u) {
+                    const int k = k0 + u * kstep;
+                    if (k >= nl || !ok) continue;
+                    const int kx = kq + pm * k;
+                    if (kx >= ep.nx_out) continue;
+                    T sc = (T)ep.scale;
+                    if (ep.realdim_x2 && !(kx == 0 || ((ep.nx & 1) == 0 && kx == ep.nx / 2))) sc *= (T)2;
+                    const long long off = row_off + shift_dst(kx, ep.nx, ep.shift_x);
+                    if (cplx) reinterpret_cast<C2<T>*>(ep.out)[off] = cscale(cmul(FF[u], PH[u]), sc);
+                    else reinterpret_cast<T*>(ep.out)[off] = (FF[u].re * FF[u].re + FF[u].im * FF[u].im) * sc;
+                }
+            }
+            stored = true;
+        }
+        if (FINAL && g.lean_final == 1 && hist == nullptr && ep.out != nullptr && !(g.dbg & 2)) {
             // lean epilogue of a plain column pass (xrft.py:446-472, 740-748): T is a power of two dividing the block size,
             // so a lane keeps its column for the whole tile -- column index, shifted destination column, mirror column,
             // x phase factors and the scale are per-lane constants; per sample: one LDS read, the y factors, two stores.

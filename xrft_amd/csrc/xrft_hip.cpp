@@ -294,7 +294,7 @@ TileChoice choose_tile(long long n_logical, size_t csize, bool col, long long av
     c.T = (int)T;
     long long th = (T * n + 15) / 16;
     th = ((th + 63) / 64) * 64;
-    c.threads = (int)std::min<long long>(1024, std::max<long long>(64, th));
+    c.threads = (int)std::min<long long>(csize == 16 ? 512 : 1024, std::max<long long>(64, th));  // float64: 256 VGPRs per lane
     c.lds = (((size_t)T * per + 15) & ~(size_t)15) + hist_bytes;
     return c;
 }
@@ -508,6 +508,10 @@ struct Builder {
             a.g.out_so = d.nx; a.g.out_sq = 1; a.g.out_sp = n2;
             a.g.tw_big = big->p; a.g.tw_bigN = d.nx; a.g.tw_qdiv = 1; a.g.tw_qmod = n2;
             a.out_kind = B_W2;
+            if (ca.T <= 64 && (ca.T & (ca.T - 1)) == 0 && a.threads % ca.T == 0 && env_ll("XRFTHIP_LEAN_COL", 1)) {
+                a.g.lean_col = 2;
+                if (d.ndim == 1 && real_in && !(d.flags & (XRFTHIP_FLIP_X | XRFTHIP_C2R_X | XRFTHIP_INVERSE))) a.g.lean_col |= 1;
+            }
             out.push_back(a);
         }
         {
@@ -529,6 +533,9 @@ struct Builder {
                 fill_epilogue(b, raw, 0, 1);
                 b.ep.q_mul = 1;  // kx = k1 + n1 * k2
                 b.ep.p_mul = n1;
+                if ((b.ep.mode == 0 || b.ep.mode == 1) && !b.ep.conj_out && !b.ep.real_out && !b.ep.mirror && cb.T <= 64 &&
+                    (cb.T & (cb.T - 1)) == 0 && b.threads % cb.T == 0 && env_ll("XRFTHIP_LEAN_FINAL", 1))
+                    b.g.lean_final = 2;
             } else {
                 b.g.out_so = d.nx; b.g.out_sq = 1; b.g.out_sp = n1;
                 b.out_kind = B_W;
@@ -655,7 +662,7 @@ void set_kernel_attrs_once() {
     if (done) return;
     done = true;
     const int m = (int)kLdsMax;
-#define SETA(TT, A, B, C) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&tile_fft_kernel<TT, A, B, C>), hipFuncAttributeMaxDynamicSharedMemorySize, m)
+#define SETA(TT, A, B, C) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&tile_fft_kernel<TT, A, B, C, sizeof(TT) == 8 ? 512 : 1024>), hipFuncAttributeMaxDynamicSharedMemorySize, m)
 #define SETALL(TT) SETA(TT, false, false, false); SETA(TT, false, false, true); SETA(TT, false, true, false); SETA(TT, false, true, true); \
                    SETA(TT, true, false, false); SETA(TT, true, false, true); SETA(TT, true, true, false); SETA(TT, true, true, true)
     SETALL(float);
@@ -675,7 +682,10 @@ void set_kernel_attrs_once() {
 template <typename T>
 void launch_tile(const Pass& ps, int grid, hipStream_t st) {
     const dim3 g((unsigned)grid), b((unsigned)ps.threads);
-#define L_(A, B, C) do { auto k = &tile_fft_kernel<T, A, B, C>; XRFT_LAUNCH(k, g, b, ps.lds, st, ps.g, ps.pr, ps.ep); } while (0)
+    // float64 plans run at most 512 threads per block (choose_tile) on the instantiation with 256 VGPRs per lane; float32
+    // keeps the 128-VGPR one (its small tiles want four workgroups per CU)
+#define L_(A, B, C) do { if constexpr (sizeof(T) == 8) { auto k = &tile_fft_kernel<T, A, B, C, 512>; XRFT_LAUNCH(k, g, b, ps.lds, st, ps.g, ps.pr, ps.ep); } \
+                         else { auto k = &tile_fft_kernel<T, A, B, C, 1024>; XRFT_LAUNCH(k, g, b, ps.lds, st, ps.g, ps.pr, ps.ep); } } while (0)
     const int sel = (ps.first ? 4 : 0) | (ps.final_ ? 2 : 0) | (ps.generic ? 1 : 0);
     switch (sel) {
         case 0: L_(false, false, false); break;
