@@ -29,3 +29,6 @@ for (nt, n) in ((16, 4096), (64, 2048), (128, 1024)):
     prof(f"iso cross hann ({nt},{n},{n})", lambda: xrft.isotropic_cross_spectrum(d1, d2, dim=["y", "x"], window="hann"), nt)
     del a, d1, b, d2
     torch.cuda.empty_cache()
+a = torch.randn((16, 4096, 4096), dtype=torch.float32, device="cuda"); c = {"y": np.arange(4096.), "x": np.arange(4096.)}
+d1 = xrft.DataArray(a, ("t", "y", "x"), c)
+prof("PS real_dim=x linear+hann (16,4096,4096)", lambda: xrft.power_spectrum(d1, dim=["y"], real_dim="x", detrend="linear", window="hann"), 16)

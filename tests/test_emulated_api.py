@@ -200,6 +200,25 @@ def test_fastp2_complex_fft(ny, nx, kw):
     api._plan_cache.clear()
 
 
+@pytest.mark.parametrize("ny,nx", [(1024, 1024), (1024, 2048)])
+def test_fastp2_real_dim(ny, nx):
+    """real_dim: the half spectrum leaves the specialised kernels as it is (no mirror), kept bins count twice."""
+    import xrft_amd as xa
+    from oracle import xrft_oracle as o
+
+    da, od = _p2_fields(ny, nx, 2, 31, x0=1.5)
+    db, ob = _p2_fields(ny, nx, 2, 32, x0=1.5)
+    for fn, ofn, args, oargs in (
+            (xa.power_spectrum, o.power_spectrum, (da,), (od,)),
+            (xa.fft, o.fft, (da,), (od,)),
+            (xa.cross_spectrum, o.cross_spectrum, (da, db), (od, ob))):
+        for kw in (dict(detrend="linear", window="hann"), dict()):
+            got = fn(*args, dim=["y"], real_dim="x", **kw)
+            assert any("[fastp2]" in p.describe() for p in api._plan_cache.values())
+            cases.check(got, ofn(*oargs, dim=["y"], real_dim="x", **kw), 3e-4)
+            api._plan_cache.clear()
+
+
 @pytest.mark.parametrize("ny,nx,kw", [
     (1024, 1024, dict(detrend="linear", window="hann")),
     (2048, 1024, dict(true_phase=False)),

@@ -387,3 +387,17 @@ def test_bluestein_lengths(dtype):
 @pytest.mark.parametrize("dtype", ["float64", "float32"])
 def test_composite_radix_lengths(dtype):
     cases.run_composite_lengths(dtype)
+
+
+@pytest.mark.parametrize("ny,nx", [(1024, 1024), (2048, 4096), (4096, 2048)])
+def test_fastp2_real_dim(ny, nx):
+    """real_dim on the specialised path: half spectra (no mirror written), kept bins doubled in the spectra."""
+    import xrft_amd as xa
+
+    da, od = _p2_pair(ny, nx, 2, 41, x0=1.5)
+    db, ob = _p2_pair(ny, nx, 2, 42, x0=1.5)
+    for fn, ofn, args, oargs in ((xa.power_spectrum, o.power_spectrum, (da,), (od,)), (xa.fft, o.fft, (da,), (od,)),
+                                 (xa.cross_spectrum, o.cross_spectrum, (da, db), (od, ob))):
+        got = fn(*args, dim=["y"], real_dim="x", detrend="linear", window="hann")
+        _assert_fast()
+        cases.check(got, ofn(*oargs, dim=["y"], real_dim="x", detrend="linear", window="hann"), 3e-4)

@@ -97,6 +97,8 @@ struct FastP2 {  // parameters shared by the passes
     int detrend;             // 0 none, 1 constant, 2 linear
     int nslab;
     int shift_y, shift_x;    // 0 or n/2
+    int half;                // real_dim: only kx = 0..nx/2 is stored, rows of nx/2 + 1 samples, no mirror (xrft.py:400-404)
+    int realdim2;            // ... and 0 < kx < nx/2 counts twice (xrft.py:673-682)
     float scale;
 };
 
@@ -430,6 +432,17 @@ __global__ void __launch_bounds__(256) fastp2_untile_kernel(FastP2 p) {
         d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
     }
     __syncthreads();
+    if (p.half) {  // rows of nx/2 + 1 samples: an odd row length, so plain 4-byte stores (still whole lines per wave)
+        const int w = nxh + 1;
+        float* __restrict__ outh = p.out + (size_t)slab * ny * w;
+        for (int e = tid; e < 8 * w; e += 256) {
+            const int r = e / w, kx = e - r * w, ky = kb * 8 + r;
+            float v = rows[r * ld + kx];
+            if (p.realdim2 && kx != 0 && kx != nxh) v *= 2.0f;
+            outh[(size_t)((ky + p.shift_y) & my) * w + kx] = v;
+        }
+        return;
+    }
     float* __restrict__ out = p.out + (size_t)slab * ny * nx;
     const int sx = p.shift_x;
     for (int r = 0; r < 8; ++r) {
@@ -473,6 +486,17 @@ __global__ void __launch_bounds__(256) fastp2_untile_c_kernel(FastP2 p) {
         d[0] = mk<float>(v.x, v.y); d[1] = mk<float>(v.z, v.w);
     }
     __syncthreads();
+    if (p.half) {
+        const int w = nxh + 1;
+        cf* __restrict__ outh = reinterpret_cast<cf*>(p.out) + (size_t)slab * ny * w;
+        for (int e = tid; e < 4 * w; e += 256) {
+            const int r = e / w, kx = e - r * w, ky = kb * 8 + half * 4 + r;
+            cf v = cmul(cmul(rows[r * ld + kx], p.ph_y[ky]), p.ph_x[kx]);
+            if (p.realdim2 && kx != 0 && kx != nxh) v = cscale(v, 2.0f);
+            outh[(size_t)((ky + p.shift_y) & my) * w + kx] = v;
+        }
+        return;
+    }
     cf* __restrict__ out = reinterpret_cast<cf*>(p.out) + (size_t)slab * ny * nx;
     const int sx = p.shift_x;
     for (int r = 0; r < 4; ++r) {

@@ -925,7 +925,8 @@ static int run_fast4096(const xrfthip_plan* P, const float* in, const float* in1
         p.in = in + (size_t)g0 * slab_pts;
         p.w = reinterpret_cast<cf*>(ws + P->off_w);
         p.pt = (!power || want_out) ? reinterpret_cast<float*>(ws + P->off_pt) : nullptr;
-        p.out = !want_out ? nullptr : power ? (float*)out + (size_t)g0 * slab_pts : (float*)((cf*)out + (size_t)g0 * slab_pts);
+        const size_t out_pts = (size_t)d.ny * ((d.flags & XRFTHIP_HALF_X) ? d.nx / 2 + 1 : d.nx);
+        p.out = !want_out ? nullptr : power ? (float*)out + (size_t)g0 * out_pts : (float*)((cf*)out + (size_t)g0 * out_pts);
         p.ph_y = reinterpret_cast<const cf*>(P->fph[0].p);
         p.ph_x = reinterpret_cast<const cf*>(P->fph[1].p);
         p.tcodes = reinterpret_cast<const unsigned*>(P->tcodes.p);
@@ -946,6 +947,8 @@ static int run_fast4096(const xrfthip_plan* P, const float* in, const float* in1
         p.shift_y = (d.flags & XRFTHIP_SHIFT_Y) ? (int)(d.ny / 2) : 0;
         p.shift_x = (d.flags & XRFTHIP_SHIFT_X) ? (int)(d.nx / 2) : 0;
         p.scale = (float)d.scale;
+        p.half = (d.flags & XRFTHIP_HALF_X) ? 1 : 0;
+        p.realdim2 = (d.flags & XRFTHIP_REALDIM_X2) ? 1 : 0;
         fast_launch_rows(P, p, gc, st);
         if (power) {
             if (iso_on) fast_launch_cols<1, true>(P, p, gc, st); else fast_launch_cols<1, false>(P, p, gc, st);
@@ -1092,10 +1095,12 @@ int xrfthip_plan_create(xrfthip_plan** plan, const xrfthip_desc* desc) {
     auto fast_len = [](long long n) { return n == 1024 || n == 2048 || n == 4096; };
     {
         const uint32_t shifts = XRFTHIP_SHIFT_Y | XRFTHIP_SHIFT_X, ish = XRFTHIP_ISHIFT_Y | XRFTHIP_ISHIFT_X, isof = XRFTHIP_ISO | XRFTHIP_NO_SPECTRUM_OUT;
-        const uint32_t allowed = d.out_mode == XRFTHIP_OUT_POWER ? (shifts | isof) : d.out_mode == XRFTHIP_OUT_COMPLEX ? (shifts | ish)
-                                 : d.out_mode == XRFTHIP_OUT_CROSS ? (shifts | ish | isof) : 0u;
+        const uint32_t halff = XRFTHIP_HALF_X | XRFTHIP_REALDIM_X2;  // real_dim: half output, no mirror
+        const uint32_t allowed = d.out_mode == XRFTHIP_OUT_POWER ? (shifts | isof | halff) : d.out_mode == XRFTHIP_OUT_COMPLEX ? (shifts | ish | XRFTHIP_HALF_X)
+                                 : d.out_mode == XRFTHIP_OUT_CROSS ? (shifts | ish | isof | halff) : 0u;
         P->fast4096 = d.ndim == 2 && fast_len(d.ny) && fast_len(d.nx) && d.dtype == XRFTHIP_F32 && d.out_mode != XRFTHIP_OUT_PHASE &&
-                      !(d.flags & ~allowed) && !env_ll("XRFTHIP_NO_FAST", 0);
+                      !(d.flags & ~allowed) && !((d.flags & halff) && (d.flags & XRFTHIP_ISO)) && !((d.flags & XRFTHIP_HALF_X) && (d.flags & XRFTHIP_SHIFT_X)) &&
+                      !env_ll("XRFTHIP_NO_FAST", 0);
     }
     if (P->fast4096) {
         const int tpu = fast_cols_gy(d.ny, (d.flags & XRFTHIP_ISO) != 0) / 4;  // tiles one column workgroup covers
