@@ -18,7 +18,7 @@ def prof(name, fn, nslab):
     p = plan.read_profile(); plan.set_profiling(False)
     tot = sum(ms for c, ms in p.values()) / 3 * 1e3 / nslab
     print(f"{name:34s}", " | ".join(f"{k} {ms/3*1e3/nslab:.1f}" for k, (c, ms) in p.items()), f"|| kernels {tot:.1f} us/slab, wall {wall*1e6/nslab:.1f} us/slab")
-for (nt, n) in ((16, 4096), (64, 2048), (128, 1024)):
+for (nt, n) in ((16, 4096), (64, 2048), (128, 1024), (512, 512), (2048, 256)):
     a = torch.randn((nt, n, n), dtype=torch.float32, device="cuda"); c = {"y": np.arange(float(n)), "x": np.arange(float(n))}
     d1 = xrft.DataArray(a, ("t", "y", "x"), c)
     prof(f"PS linear+hann ({nt},{n},{n})", lambda: xrft.power_spectrum(d1, dim=["y", "x"], detrend="linear", window="hann"), nt)

@@ -119,6 +119,10 @@ def test_unsupported_length_is_loud():
     (2048, 2048, 1, True, None, "hann"),
     (1024, 4096, 1, True, "linear", "hann"),
     (4096, 1024, 1, False, "linear", "hann"),
+    (256, 256, 5, True, "linear", "hann"),
+    (512, 256, 3, True, "linear", "hamming"),
+    (256, 1024, 2, False, "constant", None),
+    (512, 512, 2, True, None, "hann"),
 ])
 def test_fastp2_path(ny, nx, nt, shift, det, win):
     """The specialised power-of-two float32 power-spectrum kernels (fastp2.h) against numpy in float64."""
@@ -153,7 +157,8 @@ def test_fastp2_path(ny, nx, nt, shift, det, win):
 
 
 @pytest.mark.parametrize("ny,nx,nt,det,win,truncate", [(1024, 1024, 3, "linear", "hann", True), (1024, 2048, 2, None, None, False),
-                                                     (2048, 1024, 1, "constant", "hann", True)])
+                                                     (2048, 1024, 1, "constant", "hann", True), (256, 256, 4, "linear", "hann", True),
+                                                     (512, 256, 3, None, "hann", False)])
 def test_fastp2_isotropic(ny, nx, nt, det, win, truncate):
     """isotropic_power_spectrum through the specialised kernels: radial sums taken inside the column pass."""
     import xrft_amd as xa
@@ -187,6 +192,8 @@ def _p2_fields(ny, nx, nt, seed, dx=1.0, x0=0.0):
     (1024, 1024, dict(detrend="linear", window="hann")),                      # true_phase=True: ifftshift sign + phase tables
     (1024, 2048, dict(true_phase=False, detrend="constant")),
     (2048, 1024, dict(shift=False, window="hamming", true_phase=True)),
+    (256, 512, dict(detrend="linear", window="hann")),
+    (512, 256, dict(true_phase=False)),
 ])
 def test_fastp2_complex_fft(ny, nx, kw):
     """xrft.fft of a real float32 slab through the specialised kernels (complex result, Hermitian half mirrored)."""
@@ -200,7 +207,7 @@ def test_fastp2_complex_fft(ny, nx, kw):
     api._plan_cache.clear()
 
 
-@pytest.mark.parametrize("ny,nx", [(1024, 1024), (1024, 2048)])
+@pytest.mark.parametrize("ny,nx", [(1024, 1024), (1024, 2048), (256, 512)])
 def test_fastp2_real_dim(ny, nx):
     """real_dim: the half spectrum leaves the specialised kernels as it is (no mirror), kept bins count twice."""
     import xrft_amd as xa
@@ -222,6 +229,8 @@ def test_fastp2_real_dim(ny, nx):
 @pytest.mark.parametrize("ny,nx,kw", [
     (1024, 1024, dict(detrend="linear", window="hann")),
     (2048, 1024, dict(true_phase=False)),
+    (256, 256, dict(detrend="linear", window="hann")),
+    (512, 512, dict()),
 ])
 def test_fastp2_cross_spectrum(ny, nx, kw):
     import xrft_amd as xa
@@ -238,6 +247,8 @@ def test_fastp2_cross_spectrum(ny, nx, kw):
 @pytest.mark.parametrize("ny,nx,kw", [
     (1024, 1024, dict(detrend="linear", window="hann", truncate=True)),
     (1024, 2048, dict(window="hann", truncate=False)),
+    (256, 512, dict(detrend="linear", window="hann", truncate=True)),
+    (512, 512, dict(truncate=True)),
 ])
 def test_fastp2_isotropic_cross(ny, nx, kw):
     import xrft_amd as xa

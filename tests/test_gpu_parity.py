@@ -157,6 +157,10 @@ def test_config3_ps_4096_f32_vs_oracle():
     (2048, 1024, 2, None, None, True),
     (4096, 1024, 2, "linear", None, True),
     (1024, 4096, 2, "linear", "hann", False),
+    (256, 256, 7, "linear", "hann", True),
+    (512, 512, 5, "linear", "hann", True),
+    (256, 2048, 3, "constant", None, False),
+    (512, 256, 3, None, "hamming", True),
 ])
 def test_fastp2_shapes_vs_oracle(ny, nx, nt, det, win, shift):
     """Every power-of-two shape the specialised kernels take (fastp2.h) against the oracle, several slabs."""
@@ -178,7 +182,7 @@ def test_fastp2_shapes_vs_oracle(ny, nx, nt, det, win, shift):
         assert np.abs(g[t] - r[t]).sum() / np.abs(r[t]).sum() < 1e-4
 
 
-@pytest.mark.parametrize("ny,nx,nt,det,win", [(1024, 1024, 5, "linear", "hann"), (2048, 2048, 3, "linear", "hann"),
+@pytest.mark.parametrize("ny,nx,nt,det,win", [(256, 256, 9, "linear", "hann"), (512, 256, 4, None, "hann"), (1024, 1024, 5, "linear", "hann"), (2048, 2048, 3, "linear", "hann"),
                                             (2048, 1024, 2, None, None), (4096, 4096, 2, "linear", "hann")])
 def test_fastp2_isotropic_vs_oracle(ny, nx, nt, det, win):
     """isotropic_power_spectrum with the radial sums taken inside the specialised column pass (no full spectrum written)."""
@@ -218,6 +222,8 @@ def _assert_fast():
     (1024, 2048, 2, dict(true_phase=False, detrend="constant")),
     (2048, 1024, 2, dict(shift=False, window="hamming")),
     (4096, 4096, 1, dict(detrend="linear", window="hann")),
+    (256, 512, 4, dict(detrend="linear", window="hann")),
+    (512, 256, 4, dict(true_phase=False)),
 ])
 def test_fastp2_complex_fft_vs_oracle(ny, nx, nt, kw):
     """xrft.fft of real float32 power-of-two slabs on the specialised path (true-phase factors, ifftshift sign, mirror)."""
@@ -234,6 +240,8 @@ def test_fastp2_complex_fft_vs_oracle(ny, nx, nt, kw):
     (2048, 2048, 2, dict(window="hann")),
     (2048, 1024, 2, dict(true_phase=False, detrend="constant")),
     (4096, 4096, 1, dict(detrend="linear", window="hann")),
+    (256, 256, 6, dict(detrend="linear", window="hann")),
+    (512, 512, 3, dict(window="hann")),
 ])
 def test_fastp2_cross_vs_oracle(ny, nx, nt, kw):
     import xrft_amd as xa

@@ -1,4 +1,4 @@
-// fastp2.h -- the specialised kernels for 2-D float32 power spectra whose two transform lengths are 1024, 2048 or
+// fastp2.h -- the specialised kernels for 2-D float32 spectra whose two transform lengths are 256, 512, 1024, 2048 or
 // 4096 (BASELINE.json's headline shape (nt, 4096, 4096) and the other power-of-two slabs), with detrend + window
 // (xrft.power_spectrum, reference xrft/xrft.py:685-750 -> fft :307-476).
 //
@@ -9,7 +9,7 @@
 //     half spectrum in a tiled layout W[slab][tile = kx/4][i/4][kx%4][i%4] (4 columns x 4 rows x 8 B = one line), which
 //     the column pass reads as contiguous blocks; the column pass stores |F|^2 line-tiled and a streaming kernel
 //     produces the row-major, shifted, mirrored output.
-// Core: an N-point complex FFT (N = 256 R3, R3 = 4, 8, 16) by N/16 threads, 16 points per thread held in registers,
+// Core: an N-point complex FFT (N = 256 R3, R3 = 1, 2, 4, 8, 16; R3 = 1 keeps the exchange and skips the butterfly) by N/16 threads, 16 points per thread held in registers,
 // radix 16 x 16 x R3 (decimation in frequency) with two padded LDS exchanges; twiddles W^(u k), k = 1..15, are
 // generated in registers from one table load W^u by a depth-4 product tree (no strided table gathers).
 #pragma once
@@ -32,7 +32,7 @@ template <typename T> __device__ __forceinline__ void twiddle16(C2<T>* a, C2<T> 
 }
 
 template <int N> struct P2 {
-    static_assert(N == 1024 || N == 2048 || N == 4096, "radix 16 x 16 x {4, 8, 16}");
+    static_assert(N == 256 || N == 512 || N == 1024 || N == 2048 || N == 4096, "radix 16 x 16 x {1, 2, 4, 8, 16}");
     static constexpr int NT = N / 16;    // threads per sequence
     static constexpr int R3 = N / 256;   // last radix
     static constexpr int NB = 16 / R3;   // last-pass butterflies per thread

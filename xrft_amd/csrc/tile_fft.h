@@ -169,6 +169,7 @@ template <typename T> __device__ __forceinline__ void dft9(C2<T>* a) {
 }
 
 template <typename T, int R> __device__ __forceinline__ void dft_r(C2<T>* a) {
+    if (R == 1) return;
     if (R == 2) dft2(a[0], a[1]);
     else if (R == 3) dft3(a);
     else if (R == 4) dft4(a);

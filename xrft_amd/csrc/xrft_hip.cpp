@@ -671,7 +671,9 @@ void set_kernel_attrs_once() {
 #undef SETA
 #define SETF(K) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&K), hipFuncAttributeMaxDynamicSharedMemorySize, m)
     SETF((fastp2_rows_kernel<4096, 512>)); SETF((fastp2_rows_kernel<2048, 512>)); SETF((fastp2_rows_kernel<1024, 256>));
-#define SETC(M, I, T1) SETF((fastp2_cols_kernel<4096, 1024, M, I>)); SETF((fastp2_cols_kernel<2048, 1024, M, I>)); SETF((fastp2_cols_kernel<1024, T1, M, I>))
+    SETF((fastp2_rows_kernel<512, 256>)); SETF((fastp2_rows_kernel<256, 256>));
+#define SETC(M, I, T1) SETF((fastp2_cols_kernel<4096, 1024, M, I>)); SETF((fastp2_cols_kernel<2048, 1024, M, I>)); SETF((fastp2_cols_kernel<1024, T1, M, I>)); \
+                       SETF((fastp2_cols_kernel<512, 512, M, I>)); SETF((fastp2_cols_kernel<256, 256, M, I>))
     SETC(1, false, 1024); SETC(1, true, 768); SETC(0, false, 1024); SETC(2, false, 1024); SETC(2, true, 768);
     SETF((fastp2_cols_kernel<1024, 768, 0, false>));
 #undef SETC
@@ -825,13 +827,13 @@ static int fast4096_window_spectra(xrfthip_plan* P) {
     return rc;
 }
 
-static int fast_rows_threads(long long nx) { return nx == 1024 ? 256 : 512; }
+static int fast_rows_threads(long long nx) { return nx <= 1024 ? 256 : 512; }
 static size_t fast_rows_lds(long long nx) {
     const int thr = fast_rows_threads(nx), gx = thr / (int)(nx / 16), lb = 2 * gx / 4, ntile = (int)(nx / 8 + 1);
     return std::max<size_t>((size_t)gx * (nx + 256), (size_t)ntile * lb * 16) * sizeof(cf);
 }
 // the 1024-point column pass fills the whole LDS with 16 columns: with a histogram it runs 12 columns (768 threads)
-static int fast_cols_threads(long long ny, bool iso) { return (iso && ny == 1024) ? 768 : 1024; }
+static int fast_cols_threads(long long ny, bool iso) { return ny == 256 ? 256 : ny == 512 ? 512 : (iso && ny == 1024) ? 768 : 1024; }
 static int fast_cols_gy(long long ny, bool iso) { return fast_cols_threads(ny, iso) / (int)(ny / 16); }
 static size_t fast_cols_lds(long long ny, bool iso) { return (size_t)fast_cols_gy(ny, iso) * (ny + 256) * sizeof(cf); }
 
@@ -880,7 +882,9 @@ static void fast_launch_rows(const xrfthip_plan* P, const FastP2& p, long long g
     const size_t lds = fast_rows_lds(d.nx);
     if (d.nx == 4096) { auto k = &fastp2_rows_kernel<4096, 512>; XRFT_LAUNCH(k, grid, blk, lds, st, p); }
     else if (d.nx == 2048) { auto k = &fastp2_rows_kernel<2048, 512>; XRFT_LAUNCH(k, grid, blk, lds, st, p); }
-    else { auto k = &fastp2_rows_kernel<1024, 256>; XRFT_LAUNCH(k, grid, blk, lds, st, p); }
+    else if (d.nx == 1024) { auto k = &fastp2_rows_kernel<1024, 256>; XRFT_LAUNCH(k, grid, blk, lds, st, p); }
+    else if (d.nx == 512) { auto k = &fastp2_rows_kernel<512, 256>; XRFT_LAUNCH(k, grid, blk, lds, st, p); }
+    else { auto k = &fastp2_rows_kernel<256, 256>; XRFT_LAUNCH(k, grid, blk, lds, st, p); }
     prof_end(rec, st);
     if (d.detrend) {
         rec = prof_begin(P, "fastp2_fit", st);
@@ -904,6 +908,8 @@ static void fast_launch_cols(const xrfthip_plan* P, const FastP2& p, long long g
 #define COLS_(NN, TT) do { auto k = &fastp2_cols_kernel<NN, TT, MODE, ISO>; XRFT_LAUNCH(k, dim3((unsigned)grid), dim3((unsigned)cthr), lds, st, p); } while (0)
     if (d.ny == 4096) COLS_(4096, 1024);
     else if (d.ny == 2048) COLS_(2048, 1024);
+    else if (d.ny == 512) COLS_(512, 512);
+    else if (d.ny == 256) COLS_(256, 256);
     else if (cthr == 768) { if constexpr (ISO || MODE == 0) COLS_(1024, 768); }  // (the field-0 pass of an isotropic cross spectrum)
     else { if constexpr (!ISO) COLS_(1024, 1024); }
 #undef COLS_
@@ -1092,7 +1098,7 @@ int xrfthip_plan_create(xrfthip_plan** plan, const xrfthip_desc* desc) {
         if (c.T == 0 || n_try >= env_ll("XRFTHIP_X_FOURSTEP_MIN", 1LL << 40)) P->width = d.nx;
     }
     P->mirror = !cplx_in && !(d.flags & XRFTHIP_HALF_X) && P->width == d.nx / 2 + 1 && d.nx > 1;
-    auto fast_len = [](long long n) { return n == 1024 || n == 2048 || n == 4096; };
+    auto fast_len = [](long long n) { return n == 256 || n == 512 || n == 1024 || n == 2048 || n == 4096; };
     {
         const uint32_t shifts = XRFTHIP_SHIFT_Y | XRFTHIP_SHIFT_X, ish = XRFTHIP_ISHIFT_Y | XRFTHIP_ISHIFT_X, isof = XRFTHIP_ISO | XRFTHIP_NO_SPECTRUM_OUT;
         const uint32_t halff = XRFTHIP_HALF_X | XRFTHIP_REALDIM_X2;  // real_dim: half output, no mirror
