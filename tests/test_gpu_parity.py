@@ -409,3 +409,11 @@ def test_fastp2_real_dim(ny, nx):
         got = fn(*args, dim=["y"], real_dim="x", detrend="linear", window="hann")
         _assert_fast()
         cases.check(got, ofn(*oargs, dim=["y"], real_dim="x", detrend="linear", window="hann"), 3e-4)
+
+
+@pytest.mark.parametrize("seed", range(120))
+def test_random_differential(seed):
+    """The seeded random option / shape combinations of tests/test_random_differential.py on the real library."""
+    from test_random_differential import run_random
+
+    run_random(seed)

@@ -1,0 +1,111 @@
+"""Seeded random differential test: product API (kernels on the CPU emulator) against the oracle over random shapes, dtypes
+and option combinations -- every prologue / epilogue switch of the generic tile kernel in combinations the hand-written
+cases do not enumerate."""
+import os
+import sys
+import warnings
+
+import numpy as np
+import pytest
+
+sys.path.insert(0, os.path.join(os.path.dirname(__file__), "emu"))
+import build_emu  # noqa: E402
+
+from xrft_amd import _lib, api  # noqa: E402
+from oracle import xrft_oracle as o  # noqa: E402
+
+import cases  # noqa: E402
+
+warnings.simplefilter("ignore")
+
+SIZES = [1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 12, 15, 16, 18, 20, 21, 24, 25, 27, 30, 32, 33, 36, 40, 45, 48, 49, 60, 64, 77, 90, 96, 131]
+WINDOWS = [None, "hann", "hamming", "blackman", "boxcar", "tukey"]
+
+
+@pytest.fixture(scope="module", autouse=True)
+def emulated_library():
+    api._plan_cache.clear()
+    _lib._load_for_testing(build_emu.build())
+    yield
+    api._plan_cache.clear()
+    _lib._state.update(dll=None, path=None, device="cuda")
+
+
+def _draw(rng):
+    two_d = rng.random() < 0.6
+    dtype = rng.choice(["float64", "float32", "complex128", "complex64"], p=[0.35, 0.35, 0.15, 0.15])
+    nb = int(rng.integers(1, 4))
+    ny = int(rng.choice(SIZES[2:])) if two_d else None
+    nx = int(rng.choice(SIZES[2:]))
+    shape = (nb, ny, nx) if two_d else (nb, nx)
+    v = rng.standard_normal(shape)
+    if dtype.startswith("complex"):
+        v = v + 1j * rng.standard_normal(shape)
+    v = v + 0.05 * np.arange(nx)[None, ...] if not two_d else v + 0.05 * np.arange(nx)[None, None, :] - 0.03 * np.arange(ny)[None, :, None]
+    v = v.astype(dtype)
+    dims = ("t", "y", "x") if two_d else ("t", "x")
+    coords = {"t": np.arange(nb), "x": np.arange(nx) * float(rng.choice([0.25, 1.0, 3.0])) + float(rng.choice([0.0, -4.0, 2.5]))}
+    if two_d:
+        coords["y"] = np.arange(ny) * float(rng.choice([0.5, 1.0, 2.0])) + float(rng.choice([0.0, 1.0]))
+    if rng.random() < 0.15:  # descending coordinate (flip under true_phase)
+        coords["x"] = coords["x"][::-1].copy()
+    kw = {}
+    tdims = ["y", "x"] if two_d else ["x"]
+    if two_d and rng.random() < 0.25:
+        tdims = [str(rng.choice(["y", "x"]))]
+    kw["detrend"] = rng.choice([None, "constant", "linear"])
+    kw["window"] = rng.choice(WINDOWS)
+    kw["shift"] = bool(rng.random() < 0.7)
+    real_ok = not dtype.startswith("complex")
+    real_dim = None
+    if real_ok and rng.random() < 0.3:
+        real_dim = tdims[-1]
+    return v, dims, coords, tdims, real_dim, kw, dtype
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("XRFT_RANDOM_CASES", "70"))))
+def test_random_case(seed):
+    run_random(seed)
+
+
+def run_random(seed):
+    """One random case (also run on the GPU by tests/test_gpu_parity.py)."""
+    import xrft_amd as xa
+
+    rng = np.random.default_rng(1000 + seed)
+    v, dims, coords, tdims, real_dim, kw, dtype = _draw(rng)
+    tol = cases.TOL[dtype]
+    da, od = cases.pair(v, dims, coords)
+    kind = rng.choice(["fft", "ps", "cs", "roundtrip"])
+    if kw["detrend"] == "linear" and len(tdims) == 1 and kw["window"] is None and kind == "ps":
+        pass
+    try:
+        if kind == "fft":
+            tp = bool(rng.random() < 0.5)
+            ref = o.fft(od, dim=tdims, real_dim=real_dim, true_phase=tp, **kw)
+            got = xa.fft(da, dim=tdims, real_dim=real_dim, true_phase=tp, **kw)
+        elif kind == "ps":
+            sc = str(rng.choice(["density", "spectrum"]))
+            wc = bool(kw["window"] is not None and rng.random() < 0.5)
+            ref = o.power_spectrum(od, dim=tdims, real_dim=real_dim, scaling=sc, window_correction=wc, **kw)
+            got = xa.power_spectrum(da, dim=tdims, real_dim=real_dim, scaling=sc, window_correction=wc, **kw)
+        elif kind == "cs":
+            w = (np.roll(v, 1, axis=-1) * 0.5 + 0.1).astype(dtype)
+            db, ob = cases.pair(w, dims, coords)
+            if "x" in coords and coords["x"][0] > coords["x"][-1] and kw["window"] is not None:
+                kw["window"] = None
+            ref = o.cross_spectrum(od, ob, dim=tdims, real_dim=real_dim, **kw)
+            got = xa.cross_spectrum(da, db, dim=tdims, real_dim=real_dim, **kw)
+        else:
+            F, Fo = xa.fft(da, dim=tdims), o.fft(od, dim=tdims)
+            fd = ["freq_" + d for d in tdims]
+            ref = o.ifft(Fo, dim=fd)
+            got = xa.ifft(F, dim=fd)
+    except (ValueError, NotImplementedError) as e:  # both sides must refuse alike
+        with pytest.raises(type(e)):
+            {"fft": lambda: xa.fft(da, dim=tdims, real_dim=real_dim, **kw),
+             "ps": lambda: xa.power_spectrum(da, dim=tdims, real_dim=real_dim, **kw),
+             "cs": lambda: xa.cross_spectrum(da, da, dim=tdims, real_dim=real_dim, **kw),
+             "roundtrip": lambda: xa.ifft(xa.fft(da, dim=tdims), dim=["freq_" + d for d in tdims])}[kind]()
+        return
+    cases.check(got, ref, tol)
