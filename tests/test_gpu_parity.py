@@ -417,3 +417,10 @@ def test_random_differential(seed):
     from test_random_differential import run_random
 
     run_random(seed)
+
+
+@pytest.mark.parametrize("seed", range(60))
+def test_random_fastp2_differential(seed):
+    from test_random_differential import run_random_fast
+
+    run_random_fast(seed)

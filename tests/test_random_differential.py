@@ -109,3 +109,48 @@ def run_random(seed):
              "roundtrip": lambda: xa.ifft(xa.fft(da, dim=tdims), dim=["freq_" + d for d in tdims])}[kind]()
         return
     cases.check(got, ref, tol)
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("XRFT_RANDOM_FAST_CASES", "24"))))
+def test_random_fastp2_case(seed):
+    run_random_fast(seed)
+
+
+def run_random_fast(seed):
+    """Random mode / option combinations on the shapes the specialised kernels take (256 and 512 keep the emulator quick)."""
+    import xrft_amd as xa
+
+    rng = np.random.default_rng(5000 + seed)
+    ny, nx = int(rng.choice([256, 512])), int(rng.choice([256, 512]))
+    nb = int(rng.integers(1, 4))
+    v = rng.standard_normal((nb, ny, nx)).astype(np.float32)
+    v += (0.01 * np.arange(ny, dtype=np.float32))[None, :, None] + (-0.02 * np.arange(nx, dtype=np.float32) + 3)[None, None, :]
+    v *= (1 + np.arange(nb, dtype=np.float32))[:, None, None]
+    c = {"t": np.arange(nb), "y": np.arange(ny) * float(rng.choice([0.5, 1.0])) + float(rng.choice([0.0, 2.0])),
+         "x": np.arange(nx) * float(rng.choice([0.25, 1.0])) - float(rng.choice([0.0, 3.0]))}
+    da, od = cases.pair(v, ("t", "y", "x"), c)
+    w = rng.standard_normal((nb, ny, nx)).astype(np.float32)
+    db, ob = cases.pair(w, ("t", "y", "x"), c)
+    kw = dict(detrend=rng.choice([None, "constant", "linear"]), window=rng.choice([None, "hann", "hamming"]))
+    kind = str(rng.choice(["ps", "fft", "cs", "iso", "isocs", "ps_real", "fft_real"]))
+    shift = bool(rng.random() < 0.7)
+    tp = bool(rng.random() < 0.5)
+    api._plan_cache.clear()
+    if kind == "ps":
+        sc = str(rng.choice(["density", "spectrum"]))
+        got, ref = xa.power_spectrum(da, dim=["y", "x"], shift=shift, scaling=sc, **kw), o.power_spectrum(od, dim=["y", "x"], shift=shift, scaling=sc, **kw)
+    elif kind == "fft":
+        got, ref = xa.fft(da, dim=["y", "x"], shift=shift, true_phase=tp, **kw), o.fft(od, dim=["y", "x"], shift=shift, true_phase=tp, **kw)
+    elif kind == "cs":
+        got, ref = xa.cross_spectrum(da, db, dim=["y", "x"], shift=shift, true_phase=tp, **kw), o.cross_spectrum(od, ob, dim=["y", "x"], shift=shift, true_phase=tp, **kw)
+    elif kind == "iso":
+        tr = bool(rng.random() < 0.5)
+        got, ref = xa.isotropic_power_spectrum(da, dim=["y", "x"], truncate=tr, **kw), o.isotropic_power_spectrum(od, dim=["y", "x"], truncate=tr, **kw)
+    elif kind == "isocs":
+        got, ref = xa.isotropic_cross_spectrum(da, db, dim=["y", "x"], truncate=True, **kw), o.isotropic_cross_spectrum(od, ob, dim=["y", "x"], truncate=True, **kw)
+    elif kind == "ps_real":
+        got, ref = xa.power_spectrum(da, dim=["y"], real_dim="x", **kw), o.power_spectrum(od, dim=["y"], real_dim="x", **kw)
+    else:
+        got, ref = xa.fft(da, dim=["y"], real_dim="x", true_phase=tp, **kw), o.fft(od, dim=["y"], real_dim="x", true_phase=tp, **kw)
+    assert any("[fastp2]" in p.describe() for p in api._plan_cache.values()), kind
+    cases.check(got, ref, 3e-4)
