@@ -46,7 +46,9 @@ __device__ __forceinline__ int nat16(int k) { return k + (k >> 4); }  // natural
 // N-point forward FFT by an N/16-thread group.  In: a[q] = x[u + NT q].  Out: a[b R3 + k3] = X[k1 + 16 k2 + 256 k3] with
 // k1 = pr >> 4, k2 = pr & 15, pr = u + NT b  (b < 16 / R3).  `lds` = this group's P2<N>::LDS elements; every thread of
 // the workgroup must call it (it contains __syncthreads()); the buffer may be reused after the trailing barrier.
-template <int N> __device__ __forceinline__ void fft_p2_group(cf* a, int u, cf* lds, const cf* __restrict__ tw) {
+// tw2: LDS table of the second stage's factors, tw2[k * R3 + v] = W_(N/16)^(v k) (15 LDS reads instead of a 56-instruction
+// product tree per thread; the passes are VALU-bound, the LDS pipe is 15 % busy)
+template <int N> __device__ __forceinline__ void fft_p2_group(cf* a, int u, cf* lds, const cf* __restrict__ tw, const cf* tw2) {
     typedef P2<N> G;
     dft16(a);
     twiddle16(a, tw[u]);  // W_N^(u k)
@@ -58,7 +60,14 @@ template <int N> __device__ __forceinline__ void fft_p2_group(cf* a, int u, cf* 
     for (int q = 0; q < 16; ++q) a[q] = lds[k1 * G::S1 + v + G::R3 * q];
     __syncthreads();
     dft16(a);
-    twiddle16(a, tw[16 * v]);  // W_(N/16)^(v k)
+    if (G::R3 > 1) {
+        if (tw2) {
+#pragma unroll
+            for (int k = 1; k < 16; ++k) a[k] = cmul(a[k], tw2[k * G::R3 + v]);  // W_(N/16)^(v k)
+        } else {
+            twiddle16(a, tw[16 * v]);
+        }
+    }
 #pragma unroll
     for (int k = 0; k < 16; ++k) lds[k1 * G::S2 + k * G::RP + v] = a[k];
     __syncthreads();
@@ -71,6 +80,15 @@ template <int N> __device__ __forceinline__ void fft_p2_group(cf* a, int u, cf* 
         dft_r<float, G::R3>(a + b * G::R3);
     }
     __syncthreads();
+}
+
+// fill the stage-2 table (16 * R3 entries) from the W_N^k table; visible after the next barrier
+template <int N> __device__ __forceinline__ void fill_tw2(cf* tw2, const cf* __restrict__ tw, int tid, int nthreads) {
+    typedef P2<N> G;
+    for (int e = tid; e < 16 * G::R3; e += nthreads) {
+        const int k = e / G::R3, v = e % G::R3;
+        tw2[e] = tw[16 * v * k];  // W_N^(16 v k), 16 v k < N
+    }
 }
 
 struct FastP2 {  // parameters shared by the passes
@@ -119,6 +137,9 @@ __global__ void __launch_bounds__(THR) fastp2_rows_kernel(FastP2 p) {
     const int slab = blockIdx.x / wpr, wrow = blockIdx.x % wpr;
     const int rA = RW * wrow + 2 * g, rB = rA + 1;
     cf* mine = lds + g * G::LDS;
+    constexpr int FFTW = GX * G::LDS, STGW = NTILE * LB * 16;
+    cf* tw2 = lds + (FFTW > STGW ? FFTW : STGW);
+    fill_tw2<NX>(tw2, p.tw_x, tid, THR);
     const float* __restrict__ srcA = p.in + ((size_t)slab * p.ny + rA) * NX;
     const float* __restrict__ srcB = srcA + NX;
     const float wA = p.win_y[rA], wB = p.win_y[rB];
@@ -190,7 +211,7 @@ __global__ void __launch_bounds__(THR) fastp2_rows_kernel(FastP2 p) {
         const float vb = fmaf(-sBl, jf, fmaf(-sBh, jf, xb[q] - tBh) - tBl);
         a[q] = mk<float>(va * (wx[q] * wA), vb * (wx[q] * wB));
     }
-    fft_p2_group<NX>(a, u, mine, p.tw_x);
+    fft_p2_group<NX>(a, u, mine, p.tw_x, tw2);
 #pragma unroll
     for (int b = 0; b < G::NB; ++b) {
         const int pr = u + NT * b;
@@ -269,6 +290,9 @@ __global__ void __launch_bounds__(THR) fastp2_cols_kernel(FastP2 p) {
     const size_t lane_off = (size_t)(g >> 2) * NY * 4 + (u >> 2) * 16 + (g & 3) * 4 + (u & 3);
     // radial sums (xrft.py:895-906): per-workgroup float64 histogram behind the FFT buffers, flushed when the slab changes
     double* hist = reinterpret_cast<double*>(lds + GY * G::LDS);
+    // the column pass keeps the product tree for its second-stage twiddles: with one workgroup per CU the 15 extra LDS reads
+    // cost more (+1 us / slab measured) than the 56 VALU instructions they replace; the row pass gains 1.2 us from the table
+    const cf* tw2 = nullptr;
     int cur_slab = -1;
     constexpr int HW = MODE == 2 ? 2 : 1;  // doubles per bin
     if (ISO) for (int i = tid; i < p.nbins * HW; i += THR) hist[i] = 0.0;  // ordered before the first add by the FFT's barriers
@@ -301,7 +325,7 @@ __global__ void __launch_bounds__(THR) fastp2_cols_kernel(FastP2 p) {
                 a[q].im = fmaf(al, w0.im, fmaf(ga, w1.im, a[q].im));
             }
         }
-        fft_p2_group<NY>(a, u, mine, p.tw_y);
+        fft_p2_group<NY>(a, u, mine, p.tw_y, tw2);
         if constexpr (MODE == 1) {
             if (ISO) {  // value at (ky, kx) goes to its bin, and once more to the bin of (-ky, -kx) (Hermitian mirror of a real field)
                 const unsigned* __restrict__ tc = p.tcodes + ((size_t)unit * 16 * GY + g) * NT + u;

@@ -830,7 +830,7 @@ static int fast4096_window_spectra(xrfthip_plan* P) {
 static int fast_rows_threads(long long nx) { return nx <= 1024 ? 256 : 512; }
 static size_t fast_rows_lds(long long nx) {
     const int thr = fast_rows_threads(nx), gx = thr / (int)(nx / 16), lb = 2 * gx / 4, ntile = (int)(nx / 8 + 1);
-    return std::max<size_t>((size_t)gx * (nx + 256), (size_t)ntile * lb * 16) * sizeof(cf);
+    return (std::max<size_t>((size_t)gx * (nx + 256), (size_t)ntile * lb * 16) + 16 * (size_t)(nx / 256)) * sizeof(cf);  // + stage-2 twiddles
 }
 // the 1024-point column pass fills the whole LDS with 16 columns: with a histogram it runs 12 columns (768 threads)
 static int fast_cols_threads(long long ny, bool iso) { return ny == 256 ? 256 : ny == 512 ? 512 : (iso && ny == 1024) ? 768 : 1024; }
