@@ -478,15 +478,20 @@ __device__ void run_pass_generic(C2<T>* tile, const TileGeom& g, int R, int L, i
 // ------------------------------------------------------------------------------------------------
 // MAXT: the largest block the instantiation is launched with -- 512 leaves the register allocator 256 VGPRs per lane
 // (the float64 radix-16 butterfly alone holds 64), 1024 caps it at 128
-template <typename T, bool FIRST, bool FINAL, bool GENERIC, int MAXT>
+// PATH: 0 = every loader and epilogue (the general instantiation).  1..4 = instantiations that contain only the lean code
+// of one pass kind, chosen by the host when all of its preconditions hold at plan time -- smaller code, no spills, deeper
+// load batches:  1 row first pass (lean row loader; generic store)   2 column last pass (tiled loader, lean epilogue)
+//                3 four-step first pass (lean column loader + store)  4 four-step last pass along x (lean epilogue)
+template <typename T, bool FIRST, bool FINAL, bool GENERIC, int MAXT, int PATH>
 __global__ void __launch_bounds__(MAXT) tile_fft_kernel(TileGeom g, Prologue pr, Epilogue ep) {
+    constexpr bool ALL = PATH == 0;
     XRFT_DYN_SMEM(smem_raw);
     C2<T>* tile = reinterpret_cast<C2<T>*>(smem_raw);
     const int tid = threadIdx.x, nthreads = blockDim.x;
     double* hist = nullptr;
     long long hist_slab = -1;
     int hist_len = 0;
-    if (FINAL && ep.iso) {
+    if (ALL && FINAL && ep.iso) {
         size_t off = (size_t)g.T * g.seq_stride * sizeof(C2<T>);
         off = (off + 15) & ~(size_t)15;
         hist = reinterpret_cast<double*>(smem_raw + off);
@@ -501,7 +506,7 @@ __global__ void __launch_bounds__(MAXT) tile_fft_kernel(TileGeom g, Prologue pr,
     if (g.tw_lds || g.rev_lds) {
         size_t off = (size_t)g.T * g.seq_stride * sizeof(C2<T>);
         off = (off + 15) & ~(size_t)15;
-        if (FINAL && ep.iso) off += (size_t)ep.nbins * (ep.mode == 2 ? 16 : 8);
+        if (ALL && FINAL && ep.iso) off += (size_t)ep.nbins * (ep.mode == 2 ? 16 : 8);
         off = (off + 15) & ~(size_t)15;
         if (g.tw_lds) {
             twl = reinterpret_cast<C2<T>*>(smem_raw + off);
@@ -551,7 +556,7 @@ __global__ void __launch_bounds__(MAXT) tile_fft_kernel(TileGeom g, Prologue pr,
         // base of the row in the (tiled) intermediate -- is computed once per tile by T lanes and read back from LDS
         struct RowC { long long base, obase; double t0, t1, wy, pad_; };
         RowC* rc = reinterpret_cast<RowC*>(smem_raw + (g.rowc_off > 0 ? g.rowc_off : 0));
-        if (FIRST && g.rowc_off > 0) {
+        if ((ALL || PATH == 1) && FIRST && g.rowc_off > 0) {
             for (int rt = tid; rt < g.T; rt += nthreads) {
                 unsigned ii = (unsigned)(pi0 + rt), db = 0;
                 const unsigned rws = (unsigned)pr.rows;
@@ -568,7 +573,7 @@ __global__ void __launch_bounds__(MAXT) tile_fft_kernel(TileGeom g, Prologue pr,
             }
             __syncthreads();
         }
-        if (FIRST && g.rowc_off > 0 && pr.ph_y == nullptr && pr.ph_x == nullptr && !(g.dbg & 4)) {
+        if ((PATH == 1) || (ALL && FIRST && g.rowc_off > 0 && pr.ph_y == nullptr && pr.ph_x == nullptr && !(g.dbg & 4))) {
             // lean loader for rows of real samples (xrft.py:425-442 without flips / input phases): per sample one
             // address, the trend FMA in float64, the x window
             const T* __restrict__ src = reinterpret_cast<const T*>(pr.in);
@@ -624,7 +629,7 @@ __global__ void __launch_bounds__(MAXT) tile_fft_kernel(TileGeom g, Prologue pr,
         }
         // U independent elements per thread and trip: all their global loads are in flight before the first LDS store
         constexpr int U = 4;
-        if (FIRST && (g.lean_col & 1) && pr.ph_x == nullptr && !(g.dbg & 4)) {
+        if ((PATH == 3) || (ALL && FIRST && (g.lean_col & 1) && pr.ph_x == nullptr && !(g.dbg & 4))) {
             // four-step first pass over a real 1-D series: the tile is T consecutive columns q of the row viewed as
             // [n1][n2]; a lane keeps its column, per sample: j = p n2 + q, one load, trend, window
             const int tsh = 31 - __builtin_clz((unsigned)g.T);
@@ -669,7 +674,7 @@ __global__ void __launch_bounds__(MAXT) tile_fft_kernel(TileGeom g, Prologue pr,
             }
             loaded = true;
         }
-        if (!FIRST && g.in_tiled && !(g.dbg & 4)) {  // one contiguous block: element e of the tile is element e of the block
+        if ((PATH == 2) || (ALL && !FIRST && g.in_tiled && !(g.dbg & 4))) {  // one contiguous block: element e of the tile is element e of the block
             const int tsh = 31 - __builtin_clz((unsigned)g.T);
             const C2<T>* __restrict__ blk = gin + o0 * g.til_slab + (q0 >> tsh) * g.til_stride;
             const int nlog = g.blue_n ? g.blue_n : g.n;
@@ -702,6 +707,7 @@ __global__ void __launch_bounds__(MAXT) tile_fft_kernel(TileGeom g, Prologue pr,
             }
             loaded = true;
         }
+        if constexpr (ALL || PATH == 4)
         for (int e0 = tid; e0 < ((loaded || (g.dbg & 4)) ? 0 : total_in); e0 += U * nthreads) {
             C2<T> vv[U];
             int dst[U];
@@ -830,7 +836,7 @@ __global__ void __launch_bounds__(MAXT) tile_fft_kernel(TileGeom g, Prologue pr,
         // ------------------------------------------------------------------ store
         const int nl = g.blue_n ? g.blue_n : g.n;  // logical transform length
         bool stored = false;
-        if (!FINAL && (g.lean_col & 2) && !(g.dbg & 2)) {
+        if ((PATH == 3) || (ALL && !FINAL && (g.lean_col & 2) && !(g.dbg & 2))) {
             // four-step first pass, store: W2[o][k n2 + q] = F[k] W_N^(q k); the lane's column q is fixed
             const int tsh = 31 - __builtin_clz((unsigned)g.T);
             const int t = tid & (g.T - 1);
@@ -862,7 +868,7 @@ __global__ void __launch_bounds__(MAXT) tile_fft_kernel(TileGeom g, Prologue pr,
             }
             stored = true;
         }
-        if (FINAL && g.lean_final == 2 && hist == nullptr && ep.out != nullptr && !(g.dbg & 2)) {
+        if ((PATH == 4) || (ALL && FINAL && g.lean_final == 2 && hist == nullptr && ep.out != nullptr && !(g.dbg & 2))) {
             // last pass of a four-step transform along x (1-D): kx = q + p_mul k with the lane's q fixed; no mirror (the
             // four-step path transforms real input as complex), row = slab
             const int tsh = 31 - __builtin_clz((unsigned)g.T);
@@ -902,7 +908,7 @@ __global__ void __launch_bounds__(MAXT) tile_fft_kernel(TileGeom g, Prologue pr,
             }
             stored = true;
         }
-        if (FINAL && g.lean_final == 1 && hist == nullptr && ep.out != nullptr && !(g.dbg & 2)) {
+        if ((PATH == 2) || (ALL && FINAL && g.lean_final == 1 && hist == nullptr && ep.out != nullptr && !(g.dbg & 2))) {
             // lean epilogue of a plain column pass (xrft.py:446-472, 740-748): T is a power of two dividing the block size,
             // so a lane keeps its column for the whole tile -- column index, shifted destination column, mirror column,
             // x phase factors and the scale are per-lane constants; per sample: one LDS read, the y factors, two stores.
@@ -964,6 +970,7 @@ __global__ void __launch_bounds__(MAXT) tile_fft_kernel(TileGeom g, Prologue pr,
         const float inv_no = 1.0f / (float)g.n_out;
         // V independent results per thread and trip: table lookups and LDS reads of all of them overlap
         constexpr int V = 4;
+        if constexpr (ALL || PATH == 1)
         for (int e0 = tid; e0 < ((stored || (g.dbg & 2)) ? 0 : total_out); e0 += V * nthreads) {
             C2<T> FF[V];
             int tt[V], kk[V];

@@ -73,6 +73,7 @@ struct Pass {
     Prologue pr{};
     Epilogue ep{};
     bool first = false, final_ = false, generic = false;
+    int path = 0;  // tile_fft_kernel PATH: 0 = general instantiation, 1..4 = lean single-purpose ones
     int threads = 256;
     size_t lds = 0;
     int in_kind = B_NONE, out_kind = B_NONE;
@@ -643,6 +644,18 @@ struct Builder {
                 out[0].g.til_ny = out[1].g.til_ny = (int)P.d.ny;
             }
         }
+        // single-purpose kernel instantiations where every precondition of a lean path is known now
+        if (env_ll("XRFTHIP_PATHS", 1) && !env_ll("XRFTHIP_DBG", 0)) {
+            const xrfthip_desc& d = P.d;
+            const bool no_iso_out = !(d.flags & (XRFTHIP_ISO | XRFTHIP_NO_SPECTRUM_OUT)), no_phase_in = !(d.flags & XRFTHIP_PHASE_IN);
+            for (Pass& ps : out) {
+                if (ps.generic) continue;
+                if (ps.first && ps.g.tile_axis == 0 && ps.g.rowc_off > 0 && no_phase_in && (!ps.final_ || no_iso_out)) ps.path = 1;
+                else if (!ps.first && ps.final_ && ps.g.in_tiled && ps.g.lean_final == 1 && (raw || no_iso_out)) ps.path = 2;
+                else if (ps.first && !ps.final_ && ps.g.lean_col == 3 && no_phase_in) ps.path = 3;
+                else if (!ps.first && ps.final_ && ps.g.lean_final == 2 && (raw || no_iso_out)) ps.path = 4;
+            }
+        }
         return XRFTHIP_OK;
     }
 };
@@ -662,7 +675,13 @@ void set_kernel_attrs_once() {
     if (done) return;
     done = true;
     const int m = (int)kLdsMax;
-#define SETA(TT, A, B, C) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&tile_fft_kernel<TT, A, B, C, sizeof(TT) == 8 ? 512 : 1024>), hipFuncAttributeMaxDynamicSharedMemorySize, m)
+#define SETA(TT, A, B, C) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&tile_fft_kernel<TT, A, B, C, sizeof(TT) == 8 ? 512 : 1024, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, m)
+#define SETP(TT, A, B, PP) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&tile_fft_kernel<TT, A, B, false, sizeof(TT) == 8 ? 512 : 1024, PP>), hipFuncAttributeMaxDynamicSharedMemorySize, m)
+#define SETPATHS(TT) SETP(TT, true, false, 1); SETP(TT, true, true, 1); SETP(TT, false, true, 2); SETP(TT, true, false, 3); SETP(TT, false, true, 4)
+    SETPATHS(float);
+    SETPATHS(double);
+#undef SETPATHS
+#undef SETP
 #define SETALL(TT) SETA(TT, false, false, false); SETA(TT, false, false, true); SETA(TT, false, true, false); SETA(TT, false, true, true); \
                    SETA(TT, true, false, false); SETA(TT, true, false, true); SETA(TT, true, true, false); SETA(TT, true, true, true)
     SETALL(float);
@@ -686,8 +705,17 @@ void launch_tile(const Pass& ps, int grid, hipStream_t st) {
     const dim3 g((unsigned)grid), b((unsigned)ps.threads);
     // float64 plans run at most 512 threads per block (choose_tile) on the instantiation with 256 VGPRs per lane; float32
     // keeps the 128-VGPR one (its small tiles want four workgroups per CU)
-#define L_(A, B, C) do { if constexpr (sizeof(T) == 8) { auto k = &tile_fft_kernel<T, A, B, C, 512>; XRFT_LAUNCH(k, g, b, ps.lds, st, ps.g, ps.pr, ps.ep); } \
-                         else { auto k = &tile_fft_kernel<T, A, B, C, 1024>; XRFT_LAUNCH(k, g, b, ps.lds, st, ps.g, ps.pr, ps.ep); } } while (0)
+    constexpr int MT = sizeof(T) == 8 ? 512 : 1024;
+#define LP_(A, B, PP) do { auto k = &tile_fft_kernel<T, A, B, false, MT, PP>; XRFT_LAUNCH(k, g, b, ps.lds, st, ps.g, ps.pr, ps.ep); } while (0)
+    if (ps.path && !ps.generic) {  // single-purpose instantiations (preconditions checked when the plan was built)
+        if (ps.path == 1 && ps.first && !ps.final_) { LP_(true, false, 1); return; }
+        if (ps.path == 1 && ps.first && ps.final_) { LP_(true, true, 1); return; }
+        if (ps.path == 2 && !ps.first && ps.final_) { LP_(false, true, 2); return; }
+        if (ps.path == 3 && ps.first && !ps.final_) { LP_(true, false, 3); return; }
+        if (ps.path == 4 && !ps.first && ps.final_) { LP_(false, true, 4); return; }
+    }
+#undef LP_
+#define L_(A, B, C) do { auto k = &tile_fft_kernel<T, A, B, C, MT, 0>; XRFT_LAUNCH(k, g, b, ps.lds, st, ps.g, ps.pr, ps.ep); } while (0)
     const int sel = (ps.first ? 4 : 0) | (ps.final_ ? 2 : 0) | (ps.generic ? 1 : 0);
     switch (sel) {
         case 0: L_(false, false, false); break;
