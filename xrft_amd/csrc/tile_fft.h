@@ -581,7 +581,7 @@ __global__ void __launch_bounds__(MAXT) tile_fft_kernel(TileGeom g, Prologue pr,
             const C2<T>* __restrict__ chirp = reinterpret_cast<const C2<T>*>(g.blue_c);
             const int nx = pr.nx, hx = pr.ishift_x ? nx / 2 : 0, nlog = g.blue_n ? g.blue_n : g.n;
             const bool det = pr.detrend != 0, r2c = g.r2c != 0;
-            constexpr int UR = 4;
+            constexpr int UR = ALL ? 4 : (sizeof(T) == 4 ? 8 : 4);
             for (int e0 = tid; e0 < total_in; e0 += UR * nthreads) {
                 T x0[UR], x1[UR], w0[UR], w1[UR];
                 int dst[UR], sj0[UR], sj1[UR], tt[UR], pp[UR];
@@ -847,7 +847,7 @@ __global__ void __launch_bounds__(MAXT) tile_fft_kernel(TileGeom g, Prologue pr,
             C2<T>* __restrict__ dstc = gout + o0 * g.out_so + q * g.out_sq;
             const C2<T>* s = tile + t * g.seq_stride;
             const int kstep = nthreads >> tsh;
-            constexpr int VS = 4;
+            constexpr int VS = ALL ? 4 : 8;  // (16 spills in the 128-VGPR float32 instantiation)
             for (int k0 = tid >> tsh; k0 < nl; k0 += VS * kstep) {
                 C2<T> FF[VS], WW[VS];
 #pragma unroll
@@ -880,7 +880,7 @@ __global__ void __launch_bounds__(MAXT) tile_fft_kernel(TileGeom g, Prologue pr,
             const long long row_off = eb0 * ep.slab_stride;
             const C2<T>* s = tile + t * g.seq_stride;
             const int kstep = nthreads >> tsh;
-            constexpr int VL = 4;
+            constexpr int VL = ALL ? 4 : 8;
             for (int k0 = tid >> tsh; k0 < nl; k0 += VL * kstep) {
                 C2<T> FF[VL], PH[VL];
 #pragma unroll
@@ -932,7 +932,7 @@ __global__ void __launch_bounds__(MAXT) tile_fft_kernel(TileGeom g, Prologue pr,
             const long long slab_off = eb0 * ep.slab_stride;
             const C2<T>* s = tile + t * g.seq_stride;
             const int kstep = nthreads >> tsh;
-            constexpr int VL = 4;
+            constexpr int VL = ALL ? 4 : 8;
             for (int k0 = tid >> tsh; k0 < nl; k0 += VL * kstep) {
                 C2<T> FF[VL];
 #pragma unroll
