@@ -285,3 +285,34 @@ def test_cross_phase(dtype):
 @pytest.mark.parametrize("dtype", ["float64", "float32"])
 def test_chunks_to_segments(dtype):
     cases.run_segment_cases(dtype)
+
+
+def test_concurrent_callers_share_a_plan():
+    """The API functions are pure, like the reference's: several threads may call them at once (dask-style workers).  The
+    plan cache is locked and one plan enqueues one call at a time with a workspace per stream."""
+    import threading
+
+    import xrft_amd as xa
+
+    rng = np.random.default_rng(3)
+    c = {"t": np.arange(2), "y": np.arange(24) * 1.0, "x": np.arange(40) * 0.5}
+    inputs = [rng.standard_normal((2, 24, 40)) for _ in range(4)]
+    want = [xa.power_spectrum(xa.DataArray(v, ("t", "y", "x"), c), dim=["y", "x"], detrend="linear", window="hann").values for v in inputs]
+    got = [None] * 4
+    errs = []
+
+    def work(i):
+        try:
+            for _ in range(5):
+                got[i] = xa.power_spectrum(xa.DataArray(inputs[i], ("t", "y", "x"), c), dim=["y", "x"], detrend="linear", window="hann").values
+        except Exception as e:  # pragma: no cover
+            errs.append(e)
+
+    th = [threading.Thread(target=work, args=(i,)) for i in range(4)]
+    for t_ in th:
+        t_.start()
+    for t_ in th:
+        t_.join()
+    assert not errs
+    for g_, w_ in zip(got, want):
+        np.testing.assert_allclose(g_, w_, rtol=1e-12)  # (the detrend sums are accumulated with atomics: order varies)

@@ -14,6 +14,7 @@ Deviations from the reference, all documented in DESIGN.md:
 """
 from __future__ import annotations
 
+import threading
 import warnings
 from collections import OrderedDict
 
@@ -176,6 +177,7 @@ def _to_device(data):
 
 _plan_cache: "OrderedDict[tuple, engine.SpectralPlan]" = OrderedDict()
 _PLAN_CACHE_SIZE = 16
+_plan_lock = threading.RLock()  # the functions are pure like the reference's: callable from several (dask-style) worker threads
 
 
 def _akey(a):
@@ -186,14 +188,15 @@ def _get_plan(binmap_key=None, **kw):
     # the bin map can be 16M entries: it is identified by the key of the (cached) host computation, not by its bytes
     key = tuple((k, (binmap_key if k == "binmap" else _akey(v)) if isinstance(v, np.ndarray) else v)
                 for k, v in sorted(kw.items()))
-    p = _plan_cache.get(key)
-    if p is None:
-        p = engine.SpectralPlan(**kw)
-        _plan_cache[key] = p
-        while len(_plan_cache) > _PLAN_CACHE_SIZE:
-            _plan_cache.popitem(last=False)
-    else:
-        _plan_cache.move_to_end(key)
+    with _plan_lock:
+        p = _plan_cache.get(key)
+        if p is None:
+            p = engine.SpectralPlan(**kw)
+            _plan_cache[key] = p
+            while len(_plan_cache) > _PLAN_CACHE_SIZE:
+                _plan_cache.popitem(last=False)
+        else:
+            _plan_cache.move_to_end(key)
     return p
 
 
@@ -857,14 +860,16 @@ def _radial_bins(k, l, nfactor):
     and nfactor, and costs seconds of host time at 4096^2, so it is cached (the reference recomputes it per call).
     """
     key = (k.size, l.size, hash(np.ascontiguousarray(k).tobytes()), hash(np.ascontiguousarray(l).tobytes()), nfactor)
-    hit = _bins_cache.get(key)
-    if hit is not None:
-        _bins_cache.move_to_end(key)
-        return hit
+    with _plan_lock:
+        hit = _bins_cache.get(key)
+        if hit is not None:
+            _bins_cache.move_to_end(key)
+            return hit
     res = _radial_bins_uncached(k, l, nfactor) + (key,)
-    _bins_cache[key] = res
-    while len(_bins_cache) > 8:
-        _bins_cache.popitem(last=False)
+    with _plan_lock:
+        _bins_cache[key] = res
+        while len(_bins_cache) > 8:
+            _bins_cache.popitem(last=False)
     return res
 
 

@@ -6,6 +6,7 @@ arithmetic step runs inside libxrft_hip.so.
 from __future__ import annotations
 
 import ctypes as C
+import threading
 
 import numpy as np
 import torch
@@ -61,7 +62,8 @@ class SpectralPlan:
                 raise ValueError(f"bin map shape {bm.shape} != {(self.ny, self.nx_out)}")
             _lib.check(self._dll.xrfthip_plan_set_binmap(self._h, bm.ctypes.data_as(C.c_void_p), self.ny,
                                                          self.nx_out, self.nbins))
-        self._ws = None
+        self._ws = {}  # (device, stream) -> workspace: two streams never share scratch memory
+        self._lock = threading.Lock()  # the C plan lays out its workspace lazily inside exec: one enqueue at a time
 
     def __del__(self):
         try:
@@ -117,11 +119,15 @@ class SpectralPlan:
                               dtype=torch.complex128 if self.out_mode == _lib.OUT_CROSS else torch.float64)
         if self.batch == 0:  # nothing to transform: empty outputs, no device call
             return (out if want_out else None), iso
-        nws = self.workspace_bytes
-        if self._ws is None or self._ws.numel() < nws or self._ws.device != dev:
-            self._ws = torch.empty(max(nws, 256), dtype=torch.uint8, device=dev)
-        _lib.check(self._dll.xrfthip_exec(self._h, _ptr(in0), _ptr(in1), _ptr(out if want_out else None), _ptr(iso),
-                                          _ptr(self._ws), self._ws.numel(), _stream_handle(in0)))
+        stream = _stream_handle(in0)
+        with self._lock:
+            nws = self.workspace_bytes
+            key = (str(dev), stream.value)
+            ws = self._ws.get(key)
+            if ws is None or ws.numel() < nws:
+                ws = self._ws[key] = torch.empty(max(nws, 256), dtype=torch.uint8, device=dev)
+            _lib.check(self._dll.xrfthip_exec(self._h, _ptr(in0), _ptr(in1), _ptr(out if want_out else None), _ptr(iso),
+                                              _ptr(ws), ws.numel(), stream))
         return (out if want_out else None), iso
 
 
