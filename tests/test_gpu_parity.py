@@ -424,3 +424,36 @@ def test_random_fastp2_differential(seed):
     from test_random_differential import run_random_fast
 
     run_random_fast(seed)
+
+
+def test_concurrent_threads_and_streams():
+    """Four host threads, each on its own HIP stream, share one cached plan (a workspace per stream, one enqueue at a time)."""
+    import threading
+
+    import xrft_amd as xa
+
+    rng = np.random.default_rng(3)
+    c = {"t": np.arange(4), "y": np.arange(512) * 1.0, "x": np.arange(512) * 0.5}
+    inputs = [torch.from_numpy(rng.standard_normal((4, 512, 512)).astype(np.float32)).cuda() for _ in range(4)]
+    want = [xa.power_spectrum(xa.DataArray(v, ("t", "y", "x"), c), dim=["y", "x"], detrend="linear", window="hann").values for v in inputs]
+    got, errs = [None] * 4, []
+
+    def work(i):
+        try:
+            s = torch.cuda.Stream()
+            with torch.cuda.stream(s):
+                for _ in range(10):
+                    r = xa.power_spectrum(xa.DataArray(inputs[i], ("t", "y", "x"), c), dim=["y", "x"], detrend="linear", window="hann")
+                s.synchronize()
+                got[i] = r.values
+        except Exception as e:  # pragma: no cover
+            errs.append(repr(e))
+
+    th = [threading.Thread(target=work, args=(i,)) for i in range(4)]
+    for t_ in th:
+        t_.start()
+    for t_ in th:
+        t_.join()
+    assert not errs, errs
+    for g_, w_ in zip(got, want):
+        np.testing.assert_allclose(g_, w_, rtol=1e-5, atol=1e-6 * float(np.abs(w_).max()))
