@@ -41,7 +41,35 @@ _real_flag_warning = ("`real` flag will be deprecated in future version of xrft.
 # ------------------------------------------------------------------------------------------------------
 # coordinate helpers (host, float64) -- xrft.py:139-155, 195-234, 269-304
 # ------------------------------------------------------------------------------------------------------
+# Host work that depends only on (length, spacing) or on a coordinate vector is memoised: the reference recomputes it on
+# every call, here it would be most of the ~0.25 ms a call costs on the host (what small problems are made of).
+_memo = {}
+
+
+def _memoised(key, fn):
+    with _plan_lock:
+        hit = _memo.get(key)
+    if hit is None:
+        hit = fn()
+        with _plan_lock:
+            if len(_memo) > 512:
+                _memo.clear()
+            _memo[key] = hit
+    return hit
+
+
+def _ro(a):
+    a = np.asarray(a)
+    a.setflags(write=False)
+    return a
+
+
 def _freq(N, delta_x, real, shift):
+    key = ("freq", tuple(int(n) for n in N), tuple(float(d) for d in delta_x), real is not None, bool(shift))
+    return list(_memoised(key, lambda: tuple(_ro(k) for k in _freq_uncached(N, delta_x, real, shift))))
+
+
+def _freq_uncached(N, delta_x, real, shift):
     if real is None:
         fftfreq = [np.fft.fftfreq] * len(N)
     else:
@@ -139,6 +167,12 @@ def _move_to_end(lst, el):
 
 
 def _window_vector(window_type, n):
+    if isinstance(window_type, str) and window_type in _WINDOW_NAMES:
+        return _memoised(("window", window_type, int(n)), lambda: _ro(_window_vector_uncached(window_type, n)))
+    return _window_vector_uncached(window_type, n)
+
+
+def _window_vector_uncached(window_type, n):
     if window_type is True:  # xrft.py:42-47
         window_type = "hann"
         warnings.warn("Please provide the name of window adhering to scipy.signal.windows. The boolean option "
@@ -241,8 +275,16 @@ def _analyze(da, spacing_tol, dim, real_dim, shift, detrend, window, true_phase,
             raise ValueError(f"The input array contains coordinate variable(s) ({bad}) whose dims include the "
                              f"transform dimension(s) `{d}`. Please drop these coordinates (`.drop({bad}`) "
                              "before invoking xrft.")
-    c.delta_x = [_get_coordinate_spacing(da[d].values, spacing_tol, d) for d in dim]  # xrft.py:422
-    c.lag_x = [_lag_coord(da[d].values) for d in dim]  # xrft.py:423
+    def _coord_info(d):  # spacing check + lag of one coordinate vector, memoised on its bytes
+        cv = np.asarray(da[d].values)
+        if cv.dtype.kind not in "fiu" or not isinstance(spacing_tol, (int, float)):  # (a bad spacing_tol must fail in numpy, as in the reference)
+            return _get_coordinate_spacing(cv, spacing_tol, d), _lag_coord(cv)
+        key = ("coord", cv.dtype.str, cv.size, hash(np.ascontiguousarray(cv).tobytes()), float(spacing_tol))
+        return _memoised(key, lambda: (_get_coordinate_spacing(cv, spacing_tol, d), _lag_coord(cv)))
+
+    info = [_coord_info(d) for d in dim]
+    c.delta_x = [i[0] for i in info]  # xrft.py:422
+    c.lag_x = [i[1] for i in info]  # xrft.py:423
     if detrend not in (None, "constant", "linear"):  # detrend.py:46-50
         raise NotImplementedError("%s is not a valid detrending option. Valid options are: 'constant','linear', "
                                   "or None." % detrend)
