@@ -44,6 +44,16 @@ _real_flag_warning = ("`real` flag will be deprecated in future version of xrft.
 # Host work that depends only on (length, spacing) or on a coordinate vector is memoised: the reference recomputes it on
 # every call, here it would be most of the ~0.25 ms a call costs on the host (what small problems are made of).
 _memo = {}
+_memo_ids = {}  # id(memoised vector) -> its key: plans are keyed by it instead of by a hash of 32 KB of window samples
+
+try:  # bytes -> 64-bit digest at ~10 GB/s (python's own bytes hash does 2 GB/s: 16 us per 4096-point coordinate)
+    import xxhash
+
+    def _digest(arr):
+        return xxhash.xxh3_64_intdigest(np.ascontiguousarray(arr))
+except Exception:  # pragma: no cover
+    def _digest(arr):
+        return hash(np.ascontiguousarray(arr).tobytes())
 
 
 def _memoised(key, fn):
@@ -54,7 +64,10 @@ def _memoised(key, fn):
         with _plan_lock:
             if len(_memo) > 512:
                 _memo.clear()
+                _memo_ids.clear()
             _memo[key] = hit
+            if isinstance(hit, np.ndarray):
+                _memo_ids[id(hit)] = key
     return hit
 
 
@@ -215,7 +228,10 @@ _plan_lock = threading.RLock()  # the functions are pure like the reference's: c
 
 
 def _akey(a):
-    return None if a is None else hash(np.ascontiguousarray(a).tobytes())
+    if a is None:
+        return None
+    k = _memo_ids.get(id(a))  # a memoised window vector: identified by (name, n)
+    return k if k is not None else _digest(a)
 
 
 def _get_plan(binmap_key=None, **kw):
@@ -279,7 +295,7 @@ def _analyze(da, spacing_tol, dim, real_dim, shift, detrend, window, true_phase,
         cv = np.asarray(da[d].values)
         if cv.dtype.kind not in "fiu" or not isinstance(spacing_tol, (int, float)):  # (a bad spacing_tol must fail in numpy, as in the reference)
             return _get_coordinate_spacing(cv, spacing_tol, d), _lag_coord(cv)
-        key = ("coord", cv.dtype.str, cv.size, hash(np.ascontiguousarray(cv).tobytes()), float(spacing_tol))
+        key = ("coord", cv.dtype.str, cv.size, _digest(cv), float(spacing_tol))
         return _memoised(key, lambda: (_get_coordinate_spacing(cv, spacing_tol, d), _lag_coord(cv)))
 
     info = [_coord_info(d) for d in dim]
@@ -901,7 +917,7 @@ def _radial_bins(k, l, nfactor):
     ``numpy_groupies.aggregate(func="mean", fill_value=0)``.  The result depends only on the two frequency vectors
     and nfactor, and costs seconds of host time at 4096^2, so it is cached (the reference recomputes it per call).
     """
-    key = (k.size, l.size, hash(np.ascontiguousarray(k).tobytes()), hash(np.ascontiguousarray(l).tobytes()), nfactor)
+    key = (k.size, l.size, _digest(k), _digest(l), nfactor)
     with _plan_lock:
         hit = _bins_cache.get(key)
         if hit is not None:
