@@ -42,7 +42,7 @@ extern "C" {
 typedef enum xrfthip_status {
     XRFTHIP_OK = 0,
     XRFTHIP_BAD_ARG = -1,
-    XRFTHIP_UNSUPPORTED_LENGTH = -2, /* a prime factor above XRFTHIP_MAX_RADIX whose Bluestein transform (2^k >= 2n-1) does not fit the LDS */
+    XRFTHIP_UNSUPPORTED_LENGTH = -2, /* a prime factor above XRFTHIP_MAX_RADIX whose Bluestein transform (2^a 3^b 5^c >= 2n-1) does not fit the LDS */
     XRFTHIP_WORKSPACE_TOO_SMALL = -3,
     XRFTHIP_HIP_ERROR = -4, /* see xrfthip_last_hip_error() */
     XRFTHIP_ALLOC_FAILED = -5,

@@ -430,7 +430,7 @@ def run_bluestein_cases(dtype):
     """Lengths with a prime factor above 128 (chirp-z inside the tile kernel); numpy's pocketfft takes any length."""
     tol = TOL[dtype]
     rng = np.random.default_rng(131)
-    for n in (131, 257, 262, 1801):
+    for n in (131, 257, 262, 1801, 4099):
         v = rng.standard_normal((3, n)).astype(dtype) + 0.01 * np.arange(n, dtype=dtype)[None]
         da, od = pair(v, ("t", "x"), {"t": np.arange(3), "x": np.arange(n) * 0.5 + 2.0})
         for kw in (dict(), dict(detrend="linear", window="hann"), dict(true_phase=False, shift=False)):

@@ -412,8 +412,7 @@ __device__ __forceinline__ void run_pass(C2<T>* tile, const TileGeom& g, int L, 
     }
 }
 
-// exact inverse of run_pass up to the factor R (used by the Bluestein convolution, whose transform length is a power of
-// two): undo the twiddles with their conjugates, then the unnormalised inverse butterfly
+// exact inverse of run_pass up to the factor R (used by the Bluestein convolution, whose transform length is 2^a 3^b 5^c): undo the twiddles with their conjugates, then the unnormalised inverse butterfly
 template <typename T, int R, typename TWP>
 __device__ __forceinline__ void run_pass_inv(C2<T>* tile, const TileGeom& g, int L, int tid, int nthreads, TWP tw) {
     const int m = L / R;
@@ -810,15 +809,29 @@ __global__ void __launch_bounds__(MAXT) tile_fft_kernel(TileGeom g, Prologue pr,
                     const C2<T>* tw = twl;
                     switch (R) {
                         case 2: run_pass_inv<T, 2>(tile, g, Li, tid, nthreads, tw); break;
+                        case 3: run_pass_inv<T, 3>(tile, g, Li, tid, nthreads, tw); break;
                         case 4: run_pass_inv<T, 4>(tile, g, Li, tid, nthreads, tw); break;
+                        case 5: run_pass_inv<T, 5>(tile, g, Li, tid, nthreads, tw); break;
+                        case 6: run_pass_inv<T, 6>(tile, g, Li, tid, nthreads, tw); break;
                         case 8: run_pass_inv<T, 8>(tile, g, Li, tid, nthreads, tw); break;
+                        case 9: run_pass_inv<T, 9>(tile, g, Li, tid, nthreads, tw); break;
+                        case 10: run_pass_inv<T, 10>(tile, g, Li, tid, nthreads, tw); break;
+                        case 12: run_pass_inv<T, 12>(tile, g, Li, tid, nthreads, tw); break;
+                        case 15: run_pass_inv<T, 15>(tile, g, Li, tid, nthreads, tw); break;
                         default: run_pass_inv<T, 16>(tile, g, Li, tid, nthreads, tw); break;
                     }
                 } else {
                     switch (R) {
                         case 2: run_pass_inv<T, 2>(tile, g, Li, tid, nthreads, twg); break;
+                        case 3: run_pass_inv<T, 3>(tile, g, Li, tid, nthreads, twg); break;
                         case 4: run_pass_inv<T, 4>(tile, g, Li, tid, nthreads, twg); break;
+                        case 5: run_pass_inv<T, 5>(tile, g, Li, tid, nthreads, twg); break;
+                        case 6: run_pass_inv<T, 6>(tile, g, Li, tid, nthreads, twg); break;
                         case 8: run_pass_inv<T, 8>(tile, g, Li, tid, nthreads, twg); break;
+                        case 9: run_pass_inv<T, 9>(tile, g, Li, tid, nthreads, twg); break;
+                        case 10: run_pass_inv<T, 10>(tile, g, Li, tid, nthreads, twg); break;
+                        case 12: run_pass_inv<T, 12>(tile, g, Li, tid, nthreads, twg); break;
+                        case 15: run_pass_inv<T, 15>(tile, g, Li, tid, nthreads, twg); break;
                         default: run_pass_inv<T, 16>(tile, g, Li, tid, nthreads, twg); break;
                     }
                 }

@@ -60,7 +60,7 @@ struct FftTables {  // per FFT length, in the plan's precision
     std::vector<int> radix;
     bool generic = false;
     DevBuf tw, rev;
-    // Bluestein (a prime factor above XRFTHIP_MAX_RADIX): the LDS transform has blue_m = 2^k >= 2n-1 points;
+    // Bluestein (a prime factor above XRFTHIP_MAX_RADIX): the LDS transform has blue_m = 2^a 3^b 5^c >= 2n-1 points;
     // blue_c[k] = exp(+i pi k^2 / n), blue_b = FFT_m(chirp kernel) / m in the order the DIF passes leave it
     int blue_m = 0;
     DevBuf blue_c, blue_b;
@@ -136,15 +136,48 @@ int factorize(long long n, std::vector<int>& out, bool& generic) {
     return XRFTHIP_OK;
 }
 
+// host-side forward FFT (float64) of any length whose prime factors are small: recursive decimation in time over the
+// smallest factor (used once per plan for the Bluestein kernel's spectrum)
+static void host_fft_rec(const double* xr, const double* xi, size_t n, size_t stride, double* yr, double* yi) {
+    if (n == 1) { yr[0] = xr[0]; yi[0] = xi[0]; return; }
+    size_t p = 2;
+    while (n % p) ++p;
+    const size_t m = n / p;
+    std::vector<double> tr(n), ti(n);
+    for (size_t r = 0; r < p; ++r) host_fft_rec(xr + r * stride, xi + r * stride, m, stride * p, tr.data() + r * m, ti.data() + r * m);
+    const long double w0 = -2.0L * 3.14159265358979323846264338327950288L / (long double)n;
+    for (size_t k = 0; k < n; ++k) {
+        long double ar = 0.0L, ai = 0.0L;
+        const size_t km = k % m;
+        for (size_t r = 0; r < p; ++r) {
+            const long double a = w0 * (long double)((r * k) % n);
+            const long double c = cosl(a), s = sinl(a);
+            ar += c * tr[r * m + km] - s * ti[r * m + km];
+            ai += c * ti[r * m + km] + s * tr[r * m + km];
+        }
+        yr[k] = (double)ar; yi[k] = (double)ai;
+    }
+}
+static void host_fft_smooth(std::vector<double>& re, std::vector<double>& im) {
+    std::vector<double> yr(re.size()), yi(re.size());
+    host_fft_rec(re.data(), im.data(), re.size(), 1, yr.data(), yi.data());
+    re.swap(yr); im.swap(yi);
+}
+
 // length of the transform actually run in LDS for an n-point sequence: n, or the Bluestein length when n has a prime
 // factor the radix passes do not take
 long long lds_fft_len(long long n) {
     std::vector<int> r;
     bool g;
     if (n < 2 || factorize(n, r, g) == XRFTHIP_OK) return n;
-    long long m = 1;
-    while (m < 2 * n - 1) m *= 2;
-    return m;
+    // Bluestein: the smallest 2^a 3^b 5^c >= 2n - 1 (a power of two can be almost twice as long and then misses the LDS)
+    for (long long m = 2 * n - 1;; ++m) {
+        long long q = m;
+        while (q % 2 == 0) q /= 2;
+        while (q % 3 == 0) q /= 3;
+        while (q % 5 == 0) q /= 5;
+        if (q == 1) return m;
+    }
 }
 
 // host-side radix-2 FFT (float64) for the two 4096-point window spectra the fused detrend needs
@@ -208,7 +241,7 @@ int build_tables(FftTables& t, int n_logical) {
             br[(size_t)k] = (double)cr; bi[(size_t)k] = (double)ci;
             if (k) { br[(size_t)(n - k)] = (double)cr; bi[(size_t)(n - k)] = (double)ci; }
         }
-        host_fft_pow2(br, bi);
+        host_fft_smooth(br, bi);
         std::vector<C2<T>> bh((size_t)n);
         for (int k = 0; k < n; ++k) {
             bh[(size_t)rev[(size_t)k]].re = (T)(br[(size_t)k] / n);
