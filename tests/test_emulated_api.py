@@ -207,6 +207,29 @@ def test_fastp2_complex_fft(ny, nx, kw):
     api._plan_cache.clear()
 
 
+@pytest.mark.parametrize("ny,nx,kw", [(256, 512, dict(window="hann", detrend="linear")), (512, 256, dict(true_phase=False)),
+                                       (256, 256, dict(real_dim="x", dim=["y"]))])
+def test_fastp2_cross_phase(ny, nx, kw):
+    """cross_phase: the specialised cross pipeline with the angle taken in the untile pass."""
+    import xrft_amd as xa
+    from oracle import xrft_oracle as o
+
+    da, od = _p2_fields(ny, nx, 2, 41, x0=2.0)
+    db, ob = _p2_fields(ny, nx, 2, 42, x0=-1.0)
+    kw = dict(kw)
+    dim = kw.pop("dim", ["y", "x"])
+    got = xa.cross_phase(da, db, dim=dim, **kw)
+    assert any("[fastp2]" in p.describe() for p in api._plan_cache.values())
+    ref = o.cross_phase(od, ob, dim=dim, **kw)
+    assert got.dims == ref.dims and got.values.shape == ref.values.shape
+    d = np.angle(np.exp(1j * (got.values.astype(np.float64) - ref.values)))
+    # the angle of a near-zero cross spectrum amplifies rounding: compare where the cross spectrum is not tiny
+    cs = np.abs(o.cross_spectrum(od, ob, dim=dim, **kw).values)
+    ok = cs > 1e-3 * cs.max()
+    assert np.abs(d[ok]).max() < 5e-3, np.abs(d[ok]).max()
+    api._plan_cache.clear()
+
+
 @pytest.mark.parametrize("ny,nx", [(1024, 1024), (1024, 2048), (256, 512)])
 def test_fastp2_real_dim(ny, nx):
     """real_dim: the half spectrum leaves the specialised kernels as it is (no mirror), kept bins count twice."""

@@ -457,3 +457,21 @@ def test_concurrent_threads_and_streams():
     assert not errs, errs
     for g_, w_ in zip(got, want):
         np.testing.assert_allclose(g_, w_, rtol=1e-5, atol=1e-6 * float(np.abs(w_).max()))
+
+
+@pytest.mark.parametrize("ny,nx,kw", [(1024, 1024, dict(window="hann", detrend="linear")), (2048, 512, dict(true_phase=False)),
+                                       (256, 256, dict(real_dim="x", dim=["y"]))])
+def test_fastp2_cross_phase(ny, nx, kw):
+    import xrft_amd as xa
+
+    da, od = _p2_pair(ny, nx, 2, 51, x0=2.0)
+    db, ob = _p2_pair(ny, nx, 2, 52, x0=-1.0)
+    kw = dict(kw)
+    dim = kw.pop("dim", ["y", "x"])
+    got = xa.cross_phase(da, db, dim=dim, **kw)
+    _assert_fast()
+    ref = o.cross_phase(od, ob, dim=dim, **kw)
+    d = np.angle(np.exp(1j * (got.values.astype(np.float64) - ref.values)))
+    cs = np.abs(o.cross_spectrum(od, ob, dim=dim, **kw).values)
+    ok = cs > 1e-3 * cs.max()
+    assert np.abs(d[ok]).max() < 5e-3

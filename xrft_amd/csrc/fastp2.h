@@ -13,6 +13,7 @@
 // radix 16 x 16 x R3 (decimation in frequency) with two padded LDS exchanges; twiddles W^(u k), k = 1..15, are
 // generated in registers from one table load W^u by a depth-4 product tree (no strided table gathers).
 #pragma once
+#include <type_traits>
 #include "aux_kernels.h"
 
 namespace xrft {
@@ -117,6 +118,7 @@ struct FastP2 {  // parameters shared by the passes
     int shift_y, shift_x;    // 0 or n/2
     int half;                // real_dim: only kx = 0..nx/2 is stored, rows of nx/2 + 1 samples, no mirror (xrft.py:400-404)
     int realdim2;            // ... and 0 < kx < nx/2 counts twice (xrft.py:673-682)
+    int phase_out;           // cross_phase (xrft.py:838-874): the untile pass writes arg(F0 conj(F1) * phase) as float32
     float scale;
 };
 
@@ -495,7 +497,10 @@ __global__ void __launch_bounds__(256) fastp2_untile_kernel(FastP2 p) {
 // intermediate, still full 128-byte lines); the mirror half is the conjugate; the true-phase factors
 // exp(-i 2 pi k lag) (xrft.py:462-469) are applied here, to direct and mirrored samples alike.
 // ------------------------------------------------------------------------------------------------
+template <bool ANGLE>
 __global__ void __launch_bounds__(256) fastp2_untile_c_kernel(FastP2 p) {
+    typedef typename std::conditional<ANGLE, float, cf>::type OutT;  // one angle, or the complex sample
+    auto fin = [](cf v) -> OutT { if constexpr (ANGLE) return (float)atan2((double)v.im, (double)v.re); else return v; };
     XRFT_DYN_SMEM(smem_raw);
     cf* rows = reinterpret_cast<cf*>(smem_raw);
     const int tid = threadIdx.x;
@@ -512,36 +517,37 @@ __global__ void __launch_bounds__(256) fastp2_untile_c_kernel(FastP2 p) {
     __syncthreads();
     if (p.half) {
         const int w = nxh + 1;
-        cf* __restrict__ outh = reinterpret_cast<cf*>(p.out) + (size_t)slab * ny * w;
+        OutT* __restrict__ outh = reinterpret_cast<OutT*>(p.out) + (size_t)slab * ny * w;
         for (int e = tid; e < 4 * w; e += 256) {
             const int r = e / w, kx = e - r * w, ky = kb * 8 + half * 4 + r;
             cf v = cmul(cmul(rows[r * ld + kx], p.ph_y[ky]), p.ph_x[kx]);
             if (p.realdim2 && kx != 0 && kx != nxh) v = cscale(v, 2.0f);
-            outh[(size_t)((ky + p.shift_y) & my) * w + kx] = v;
+            outh[(size_t)((ky + p.shift_y) & my) * w + kx] = fin(v);
         }
         return;
     }
-    cf* __restrict__ out = reinterpret_cast<cf*>(p.out) + (size_t)slab * ny * nx;
+    OutT* __restrict__ out = reinterpret_cast<OutT*>(p.out) + (size_t)slab * ny * nx;
     const int sx = p.shift_x;
     for (int r = 0; r < 4; ++r) {
         const int ky = kb * 8 + half * 4 + r, nky = (ny - ky) & my;
         const cf* row = rows + r * ld;
         const cf py = p.ph_y[ky], pmy = p.ph_y[nky];
-        cf* drow = out + (size_t)((ky + p.shift_y) & my) * nx;
-        cf* mrow = out + (size_t)((nky + p.shift_y) & my) * nx;
-        for (int m = tid; m < (nxh >> 1); m += 256) {  // direct, kx = 2m, 2m+1: one aligned 16-byte store
+        OutT* drow = out + (size_t)((ky + p.shift_y) & my) * nx;
+        OutT* mrow = out + (size_t)((nky + p.shift_y) & my) * nx;
+        struct alignas(2 * sizeof(OutT)) Pair { OutT a, b; };  // two neighbours: one aligned store
+        for (int m = tid; m < (nxh >> 1); m += 256) {  // direct, kx = 2m, 2m+1
             const cf v0 = cmul(cmul(row[2 * m], py), p.ph_x[2 * m]), v1 = cmul(cmul(row[2 * m + 1], py), p.ph_x[2 * m + 1]);
-            F4 o; o.x = v0.re; o.y = v0.im; o.z = v1.re; o.w = v1.im;
-            *reinterpret_cast<F4*>(drow + ((2 * m + sx) & mx)) = o;
+            Pair o; o.a = fin(v0); o.b = fin(v1);
+            *reinterpret_cast<Pair*>(drow + ((2 * m + sx) & mx)) = o;
         }
-        if (tid == 0) drow[(nxh + sx) & mx] = cmul(cmul(row[nxh], py), p.ph_x[nxh]);
+        if (tid == 0) drow[(nxh + sx) & mx] = fin(cmul(cmul(row[nxh], py), p.ph_x[nxh]));
         for (int m = tid; m < (nxh >> 1) - 1; m += 256) {  // mirror of kx = 2m+2, 2m+1 at columns nx - kx: again an aligned pair
             const cf v2 = cmul(cmul(cconj(row[2 * m + 2]), pmy), p.ph_x[nx - (2 * m + 2)]);
             const cf v1 = cmul(cmul(cconj(row[2 * m + 1]), pmy), p.ph_x[nx - (2 * m + 1)]);
-            F4 o; o.x = v2.re; o.y = v2.im; o.z = v1.re; o.w = v1.im;
-            *reinterpret_cast<F4*>(mrow + ((nx - (2 * m + 2) + sx) & mx)) = o;
+            Pair o; o.a = fin(v2); o.b = fin(v1);
+            *reinterpret_cast<Pair*>(mrow + ((nx - (2 * m + 2) + sx) & mx)) = o;
         }
-        if (tid == 0) { const int kx = nxh - 1; mrow[(nx - kx + sx) & mx] = cmul(cmul(cconj(row[kx]), pmy), p.ph_x[nx - kx]); }
+        if (tid == 0) { const int kx = nxh - 1; mrow[(nx - kx + sx) & mx] = fin(cmul(cmul(cconj(row[kx]), pmy), p.ph_x[nx - kx])); }
     }
 }
 

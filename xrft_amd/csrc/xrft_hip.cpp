@@ -729,7 +729,7 @@ void set_kernel_attrs_once() {
     SETC(1, false, 1024); SETC(1, true, 768); SETC(0, false, 1024); SETC(2, false, 1024); SETC(2, true, 768);
     SETF((fastp2_cols_kernel<1024, 768, 0, false>));
 #undef SETC
-    SETF(fastp2_untile_kernel); SETF(fastp2_untile_c_kernel);
+    SETF(fastp2_untile_kernel); SETF(fastp2_untile_c_kernel<false>); SETF(fastp2_untile_c_kernel<true>);
 #undef SETF
 }
 
@@ -985,7 +985,8 @@ static int run_fast4096(const xrfthip_plan* P, const float* in, const float* in1
     const size_t slab_pts = (size_t)d.ny * d.nx;
     const bool want_out = !(d.flags & XRFTHIP_NO_SPECTRUM_OUT);
     const bool iso_on = (d.flags & XRFTHIP_ISO) != 0;
-    const bool power = d.out_mode == XRFTHIP_OUT_POWER, cross = d.out_mode == XRFTHIP_OUT_CROSS;
+    const bool power = d.out_mode == XRFTHIP_OUT_POWER, angle = d.out_mode == XRFTHIP_OUT_PHASE;
+    const bool cross = d.out_mode == XRFTHIP_OUT_CROSS || angle;
     for (long long g0 = 0; g0 < d.batch; g0 += P->G) {
         const long long gc = std::min<long long>(P->G, d.batch - g0);
         FastP2 p{};
@@ -993,7 +994,8 @@ static int run_fast4096(const xrfthip_plan* P, const float* in, const float* in1
         p.w = reinterpret_cast<cf*>(ws + P->off_w);
         p.pt = (!power || want_out) ? reinterpret_cast<float*>(ws + P->off_pt) : nullptr;
         const size_t out_pts = (size_t)d.ny * ((d.flags & XRFTHIP_HALF_X) ? d.nx / 2 + 1 : d.nx);
-        p.out = !want_out ? nullptr : power ? (float*)out + (size_t)g0 * out_pts : (float*)((cf*)out + (size_t)g0 * out_pts);
+        p.out = !want_out ? nullptr : (power || angle) ? (float*)out + (size_t)g0 * out_pts : (float*)((cf*)out + (size_t)g0 * out_pts);
+        p.phase_out = angle ? 1 : 0;
         p.ph_y = reinterpret_cast<const cf*>(P->fph[0].p);
         p.ph_x = reinterpret_cast<const cf*>(P->fph[1].p);
         p.tcodes = reinterpret_cast<const unsigned*>(P->tcodes.p);
@@ -1034,8 +1036,11 @@ static int run_fast4096(const xrfthip_plan* P, const float* in, const float* in1
             if (power) {
                 auto ku = &fastp2_untile_kernel;
                 XRFT_LAUNCH(ku, dim3((unsigned)((d.ny / 8) * gc)), dim3(256), (size_t)8 * (d.nx / 2 + 4) * sizeof(float), st, p);
+            } else if (angle) {
+                auto ku = &fastp2_untile_c_kernel<true>;
+                XRFT_LAUNCH(ku, dim3((unsigned)((d.ny / 4) * gc)), dim3(256), (size_t)4 * (d.nx / 2 + 4) * sizeof(cf), st, p);
             } else {
-                auto ku = &fastp2_untile_c_kernel;
+                auto ku = &fastp2_untile_c_kernel<false>;
                 XRFT_LAUNCH(ku, dim3((unsigned)((d.ny / 4) * gc)), dim3(256), (size_t)4 * (d.nx / 2 + 4) * sizeof(cf), st, p);
             }
             prof_end(rec, st);
@@ -1164,8 +1169,8 @@ int xrfthip_plan_create(xrfthip_plan** plan, const xrfthip_desc* desc) {
         const uint32_t shifts = XRFTHIP_SHIFT_Y | XRFTHIP_SHIFT_X, ish = XRFTHIP_ISHIFT_Y | XRFTHIP_ISHIFT_X, isof = XRFTHIP_ISO | XRFTHIP_NO_SPECTRUM_OUT;
         const uint32_t halff = XRFTHIP_HALF_X | XRFTHIP_REALDIM_X2;  // real_dim: half output, no mirror
         const uint32_t allowed = d.out_mode == XRFTHIP_OUT_POWER ? (shifts | isof | halff) : d.out_mode == XRFTHIP_OUT_COMPLEX ? (shifts | ish | XRFTHIP_HALF_X)
-                                 : d.out_mode == XRFTHIP_OUT_CROSS ? (shifts | ish | isof | halff) : 0u;
-        P->fast4096 = d.ndim == 2 && fast_len(d.ny) && fast_len(d.nx) && d.dtype == XRFTHIP_F32 && d.out_mode != XRFTHIP_OUT_PHASE &&
+                                 : d.out_mode == XRFTHIP_OUT_CROSS ? (shifts | ish | isof | halff) : d.out_mode == XRFTHIP_OUT_PHASE ? (shifts | ish | XRFTHIP_HALF_X) : 0u;
+        P->fast4096 = d.ndim == 2 && fast_len(d.ny) && fast_len(d.nx) && d.dtype == XRFTHIP_F32 &&
                       !(d.flags & ~allowed) && !((d.flags & halff) && (d.flags & XRFTHIP_ISO)) && !((d.flags & XRFTHIP_HALF_X) && (d.flags & XRFTHIP_SHIFT_X)) &&
                       !env_ll("XRFTHIP_NO_FAST", 0);
     }
