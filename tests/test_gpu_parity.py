@@ -475,3 +475,18 @@ def test_fastp2_cross_phase(ny, nx, kw):
     cs = np.abs(o.cross_spectrum(od, ob, dim=dim, **kw).values)
     ok = cs > 1e-3 * cs.max()
     assert np.abs(d[ok]).max() < 5e-3
+
+
+def test_huge_batch_of_short_series():
+    """70 000 independent 16-point series in one call: more slabs than one grid dimension holds (65 535)."""
+    import xrft_amd as xa
+
+    rng = np.random.default_rng(8)
+    v = rng.standard_normal((70000, 16)).astype(np.float64) + 0.1 * np.arange(16)
+    c = {"t": np.arange(70000), "x": np.arange(16) * 0.5}
+    got = xa.power_spectrum(_da(v, ("t", "x"), c), dim="x", detrend="linear", window="hann")
+    ref = o.power_spectrum(o.OArr(v, ("t", "x"), c), dim="x", detrend="linear", window="hann")
+    cases.check(got, ref, 1e-10)
+    got = xa.detrend(_da(v, ("t", "x"), c), "x", "linear")
+    ref = o.detrend(o.OArr(v, ("t", "x"), c), "x", "linear")
+    assert np.abs(got.values - ref.values).max() < 1e-10

@@ -849,13 +849,16 @@ static int run_moments(const xrfthip_plan* P, const void* in, long long g0, long
     const xrfthip_desc& d = P->d;
     const long long total = d.ny * d.nx;
     long long chunks = std::max<long long>(1, std::min<long long>(d.ny, std::max<long long>(1, (2048 + gc - 1) / gc)));
-    const dim3 grid((unsigned)chunks, (unsigned)gc), block(256);
     const size_t esz = P->cplx_in ? P->csize : P->rsize;
-    const void* src = (const char*)in + (size_t)g0 * total * esz;
     const size_t lds = 6 * 256 * sizeof(double);
     xrfthip_plan::ProfRec* rec = prof_begin(P, "moments", st);
-    if (P->cplx_in) { auto k = &slab_moments_kernel<T, true>; XRFT_LAUNCH(k, grid, block, lds, st, src, (long long)d.ny, (long long)d.nx, total, (long long)d.nx, acc + g0 * 6); }
-    else { auto k = &slab_moments_kernel<T, false>; XRFT_LAUNCH(k, grid, block, lds, st, src, (long long)d.ny, (long long)d.nx, total, (long long)d.nx, acc + g0 * 6); }
+    for (long long b0 = 0; b0 < gc; b0 += 32768) {  // grid.y is limited to 65535 blocks
+        const long long bc = std::min<long long>(32768, gc - b0);
+        const dim3 grid((unsigned)chunks, (unsigned)bc), block(256);
+        const void* src = (const char*)in + (size_t)(g0 + b0) * total * esz;
+        if (P->cplx_in) { auto k = &slab_moments_kernel<T, true>; XRFT_LAUNCH(k, grid, block, lds, st, src, (long long)d.ny, (long long)d.nx, total, (long long)d.nx, acc + (g0 + b0) * 6); }
+        else { auto k = &slab_moments_kernel<T, false>; XRFT_LAUNCH(k, grid, block, lds, st, src, (long long)d.ny, (long long)d.nx, total, (long long)d.nx, acc + (g0 + b0) * 6); }
+    }
     prof_end(rec, st);
     rec = prof_begin(P, "finalize_coef", st);
     auto kf = &finalize_coef_kernel;
