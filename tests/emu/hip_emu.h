@@ -13,6 +13,7 @@
 #include <sys/mman.h>
 #include <ucontext.h>
 
+#include <algorithm>
 #include <atomic>
 #include <cmath>
 #include <cstdint>
@@ -179,6 +180,11 @@ inline T atomic_add(T* p, T v) {
 #define blockDim (emu::tls()->blockDim)
 #define gridDim (emu::tls()->gridDim)
 #define __syncthreads() emu::barrier()
+
+inline float __uint_as_float(unsigned v) { float f; memcpy(&f, &v, 4); return f; }
+inline unsigned __float_as_uint(float f) { unsigned v; memcpy(&v, &f, 4); return v; }
+using std::max;
+using std::min;
 
 inline double atomicAdd(double* p, double v) { return emu::atomic_add(p, v); }
 inline float atomicAdd(float* p, float v) { return emu::atomic_add(p, v); }

@@ -152,5 +152,5 @@ def run_random_fast(seed):
         got, ref = xa.power_spectrum(da, dim=["y"], real_dim="x", **kw), o.power_spectrum(od, dim=["y"], real_dim="x", **kw)
     else:
         got, ref = xa.fft(da, dim=["y"], real_dim="x", true_phase=tp, **kw), o.fft(od, dim=["y"], real_dim="x", true_phase=tp, **kw)
-    assert any("[fastp2]" in p.describe() for p in api._plan_cache.values()), kind
+    assert any("[fast" in p.describe() for p in api._plan_cache.values()), kind
     cases.check(got, ref, 3e-4)

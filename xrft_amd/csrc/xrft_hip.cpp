@@ -21,6 +21,7 @@
 #include "../../include/xrft_hip.h"
 #include "aux_kernels.h"
 #include "fastp2.h"
+#include "fasty.h"
 #include "tile_fft.h"
 
 using namespace xrft;
@@ -291,6 +292,12 @@ struct xrfthip_plan {
     bool fph_dirty = true;
     bool what_dirty = true;
     std::vector<double> host_win_x;
+    // two-pass "y first" pipeline for full power spectra (fasty.h): columns -> [fit] -> rows, no untile pass
+    bool yfirst = false;
+    int y_nrow_pad = 0;  // rows ky = 0..ny/2 of the intermediate, rounded up to what one row workgroup covers
+    DevBuf ywhat0, ywhat1, ytcodes;
+    std::vector<double> host_win_y;
+    bool ywhat_dirty = true;
     // optional per-pass event timing (bench only)
     bool prof = false;
     struct ProfRec { std::string label; hipEvent_t a, b; };
@@ -730,6 +737,9 @@ void set_kernel_attrs_once() {
     SETF((fastp2_cols_kernel<1024, 768, 0, false>));
 #undef SETC
     SETF(fastp2_untile_kernel); SETF(fastp2_untile_c_kernel<false>); SETF(fastp2_untile_c_kernel<true>);
+#define SETY(NN) SETF(fasty_cols_kernel<NN>); SETF((fasty_rows_kernel<NN, false>)); SETF((fasty_rows_kernel<NN, true>))
+    SETY(4096); SETY(2048); SETY(1024); SETY(512); SETY(256);
+#undef SETY
 #undef SETF
 }
 
@@ -799,8 +809,9 @@ static void layout_workspace(xrfthip_plan* P) {
     const bool fast = fast_on(P);
     long long G = d.slabs_per_group > 0 ? d.slabs_per_group : env_ll("XRFTHIP_GROUP", 0);
     size_t slab_w = (size_t)d.ny * std::max(P->width, P->w_cols) * P->csize;
+    const bool yf = fast && P->yfirst;
     if (fast) {
-        slab_w = (size_t)P->fast_ntile_pad * d.ny * 4 * sizeof(cf);
+        slab_w = yf ? (size_t)P->y_nrow_pad * d.nx * sizeof(cf) : (size_t)P->fast_ntile_pad * d.ny * 4 * sizeof(cf);
         if (G <= 0) G = env_ll("XRFTHIP_FAST_GROUP", std::max<long long>(1, (32LL * 4096 * 4096) / (d.ny * d.nx)));  // measured 8: 197, 16: 210, 32: 214 GFFT/s (tails and launch gaps amortise)
     }
     if (G <= 0) {
@@ -820,13 +831,14 @@ static void layout_workspace(xrfthip_plan* P) {
     P->off_w = off; if (need_w) off = al(off + (size_t)G * slab_w);
     P->off_w2 = off; if (need_w2) off = al(off + (size_t)G * d.ny * d.nx * P->csize);
     P->off_f0 = off; if (nf == 2 && !fast) off = al(off + (size_t)G * slab_w);
-    if (fast) {  // line-tiled result: float (power; not needed without a spectrum output) or complex (fft, cross)
+    if (fast && !yf) {  // line-tiled result: float (power; not needed without a spectrum output) or complex (fft, cross)
         const bool pw = d.out_mode == XRFTHIP_OUT_POWER;
         P->off_pt = off;
         if (!pw || !(d.flags & XRFTHIP_NO_SPECTRUM_OUT)) off = al(off + (size_t)G * (d.ny / 8) * P->fast_ntile_pad * 8 * sizeof(F4) * (pw ? 1 : 2));
     }
-    P->off_rowfit = off; if (fast) off = al(off + (size_t)G * d.ny * 2 * sizeof(double));
-    P->off_corr = off; if (fast) off = al(off + (size_t)G * d.ny * 2 * sizeof(float));
+    const size_t nfit = (size_t)(yf ? d.nx : d.ny);  // per-row fits (x first) or per-column fits (y first)
+    P->off_rowfit = off; if (fast) off = al(off + (size_t)G * nfit * 2 * sizeof(double));
+    P->off_corr = off; if (fast) off = al(off + (size_t)G * nfit * 2 * sizeof(float));
     P->ws_bytes = off;
 }
 
@@ -1053,6 +1065,139 @@ static int run_fast4096(const xrfthip_plan* P, const float* in, const float* in1
     return XRFTHIP_OK;
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// two-pass "y first" pipeline (fasty.h): full float32 power spectra of power-of-two slabs
+// ---------------------------------------------------------------------------------------------------------------
+struct YGeomRt { int thr, gxy, cw, rk, lbs; size_t lds; };
+template <int NY> static YGeomRt ycols_geom_t() {
+    typedef YCols<NY> Y;
+    return {Y::THR, Y::GY, Y::CW, Y::RK, Y::LBS, (size_t)(Y::GY * YLds<NY, Y::GY>::GSTR + 16 * P2<NY>::R3) * sizeof(cf)};
+}
+template <int NX> static YGeomRt yrows_geom_t() {
+    typedef YRows<NX> R;
+    return {R::THR, R::GX, 0, R::RPU, 0, (size_t)(R::GX * YLds<NX, R::GX>::GSTR + 16 * P2<NX>::R3) * sizeof(cf)};
+}
+static YGeomRt ycols_geom(long long ny) {
+    switch (ny) { case 4096: return ycols_geom_t<4096>(); case 2048: return ycols_geom_t<2048>(); case 1024: return ycols_geom_t<1024>();
+                  case 512: return ycols_geom_t<512>(); default: return ycols_geom_t<256>(); }
+}
+static YGeomRt yrows_geom(long long nx) {  // .rk = rows per workgroup
+    switch (nx) { case 4096: return yrows_geom_t<4096>(); case 2048: return yrows_geom_t<2048>(); case 1024: return yrows_geom_t<1024>();
+                  case 512: return yrows_geom_t<512>(); default: return yrows_geom_t<256>(); }
+}
+static int ilog2i(int v) { int l = 0; while ((1 << l) < v) ++l; return l; }
+
+// FFT_y(wy) and FFT_y(wy (i - ibar)) for ky < nrow_pad (zero beyond ny/2): what pass 2 needs to add the residual trend back
+static int fasty_window_spectra(xrfthip_plan* P) {
+    const int ny = (int)P->d.ny, nyh = ny / 2;
+    std::vector<double> r0((size_t)ny), i0((size_t)ny, 0.0), r1((size_t)ny), i1((size_t)ny, 0.0);
+    for (int i = 0; i < ny; ++i) {
+        const double w = P->host_win_y.empty() ? 1.0 : P->host_win_y[(size_t)i];
+        r0[(size_t)i] = w;
+        r1[(size_t)i] = w * ((double)i - 0.5 * (ny - 1));
+    }
+    host_fft_pow2(r0, i0);
+    host_fft_pow2(r1, i1);
+    const int nent = P->y_nrow_pad;
+    std::vector<cf> h0((size_t)nent), h1((size_t)nent);
+    for (int k = 0; k < nent; ++k) {
+        h0[(size_t)k].re = k <= nyh ? (float)r0[(size_t)k] : 0.f; h0[(size_t)k].im = k <= nyh ? (float)i0[(size_t)k] : 0.f;
+        h1[(size_t)k].re = k <= nyh ? (float)r1[(size_t)k] : 0.f; h1[(size_t)k].im = k <= nyh ? (float)i1[(size_t)k] : 0.f;
+    }
+    int rc = P->ywhat0.upload(h0.data(), h0.size() * sizeof(cf));
+    if (!rc) rc = P->ywhat1.upload(h1.data(), h1.size() * sizeof(cf));
+    if (!rc) P->ywhat_dirty = false;
+    return rc;
+}
+
+// the bin map re-ordered the way pass 2 holds its results (fasty_rows_kernel): [unit][e (32)][tid], e < 16: transform A
+// (row ky0 + g), else B (row ky0 + GX + g); value = (bin of (ky, kx) + 1) | (bin of the mirror (-ky, -kx) + 1) << 16
+static int fasty_build_tcodes(xrfthip_plan* P, const int32_t* bm) {
+    const int ny = (int)P->d.ny, nx = (int)P->d.nx, nyh = ny / 2, nt = nx / 16, r3 = nx / 256;
+    const YGeomRt R = yrows_geom(nx);
+    const int gx = R.gxy, rpu = R.rk, thr = R.thr, units = P->y_nrow_pad / rpu;
+    std::vector<uint32_t> t((size_t)units * 32 * thr, 0u);
+    for (int un = 0; un < units; ++un)
+        for (int e = 0; e < 32; ++e)
+            for (int tid = 0; tid < thr; ++tid) {
+                const int g = tid % gx, u = tid / gx;
+                const int ky = un * rpu + (e < 16 ? g : gx + g);
+                if (ky > nyh) continue;
+                const int el = e & 15, bb = el / r3, k3 = el % r3, pr = u + nt * bb, kx = (pr >> 4) + 16 * (pr & 15) + 256 * k3;
+                uint32_t v = 0;
+                const int32_t cd = bm[(size_t)ky * nx + kx];
+                if (cd >= 0) v |= (uint32_t)(cd + 1);
+                if (ky != 0 && ky != nyh) {
+                    const int32_t cm = bm[(size_t)(ny - ky) * nx + ((nx - kx) & (nx - 1))];
+                    if (cm >= 0) v |= (uint32_t)(cm + 1) << 16;
+                }
+                t[((size_t)un * 32 + e) * thr + tid] = v;
+            }
+    return P->ytcodes.upload(t.data(), t.size() * sizeof(uint32_t));
+}
+
+static bool fasty_on(const xrfthip_plan* P) { return P->yfirst && fast_on(P); }
+
+static int run_fasty(const xrfthip_plan* P, const float* in, void* out, double* iso, char* ws, hipStream_t st) {
+    const xrfthip_desc& d = P->d;
+    const size_t slab_pts = (size_t)d.ny * d.nx;
+    const bool want_out = !(d.flags & XRFTHIP_NO_SPECTRUM_OUT);
+    const bool iso_on = (d.flags & XRFTHIP_ISO) != 0;
+    const YGeomRt C = ycols_geom(d.ny), R = yrows_geom(d.nx);
+    for (long long g0 = 0; g0 < d.batch; g0 += P->G) {
+        const long long gc = std::min<long long>(P->G, d.batch - g0);
+        FastY p{};
+        p.in = in + (size_t)g0 * slab_pts;
+        p.w2 = reinterpret_cast<cf*>(ws + P->off_w);
+        p.out = want_out ? (float*)out + (size_t)g0 * slab_pts : nullptr;
+        p.tw_x = reinterpret_cast<const cf*>(P->tw_fx.p);
+        p.tw_y = reinterpret_cast<const cf*>(P->tw_fy.p);
+        p.win_y = reinterpret_cast<const float*>(P->win[0].p ? P->win[0].p : P->ones4096.p);
+        p.win_x = reinterpret_cast<const float*>(P->win[1].p ? P->win[1].p : P->ones4096.p);
+        p.colfit = reinterpret_cast<double*>(ws + P->off_rowfit);
+        p.corr = reinterpret_cast<const float*>(ws + P->off_corr);
+        p.what0 = reinterpret_cast<const cf*>(P->ywhat0.p);
+        p.what1 = reinterpret_cast<const cf*>(P->ywhat1.p);
+        p.tcodes = reinterpret_cast<const unsigned*>(P->ytcodes.p);
+        p.iso = iso_on ? iso + (size_t)g0 * P->nbins : nullptr;
+        p.nbins = P->nbins;
+        p.ny = (int)d.ny; p.nx = (int)d.nx;
+        p.nrow_pad = P->y_nrow_pad;
+        p.l_cw = ilog2i(C.cw); p.l_rk = ilog2i(C.rk); p.l_2gy = ilog2i(2 * C.gxy);
+        p.detrend = d.detrend;
+        p.nslab = (int)gc;
+        p.shift_y = (d.flags & XRFTHIP_SHIFT_Y) ? (int)(d.ny / 2) : 0;
+        p.shift_x = (d.flags & XRFTHIP_SHIFT_X) ? (int)(d.nx / 2) : 0;
+        p.scale = (float)d.scale;
+        xrfthip_plan::ProfRec* rec = prof_begin(P, "fasty_cols", st);
+        {
+            const dim3 grid((unsigned)(gc * (d.nx / C.cw))), blk((unsigned)C.thr);
+#define YC_(NN) do { auto k = &fasty_cols_kernel<NN>; XRFT_LAUNCH(k, grid, blk, C.lds, st, p); } while (0)
+            if (d.ny == 4096) YC_(4096); else if (d.ny == 2048) YC_(2048); else if (d.ny == 1024) YC_(1024); else if (d.ny == 512) YC_(512); else YC_(256);
+#undef YC_
+        }
+        prof_end(rec, st);
+        if (d.detrend) {  // the x-first path's fit kernel with the axes swapped: plane from the per-column fits
+            rec = prof_begin(P, "fasty_fit", st);
+            auto kf = &fastp2_fit_kernel;
+            XRFT_LAUNCH(kf, dim3((unsigned)gc), dim3(256), 3 * 256 * sizeof(double), st, (const double*)p.colfit, p.win_x, const_cast<float*>(p.corr), (int)d.nx, (int)d.detrend);
+            prof_end(rec, st);
+        }
+        rec = prof_begin(P, "fasty_rows", st);
+        {
+            const dim3 grid((unsigned)(gc * (P->y_nrow_pad / R.rk))), blk((unsigned)R.thr);
+            const size_t lds = R.lds + (iso_on ? (size_t)P->nbins * sizeof(double) : 0);
+#define YR_(NN) do { if (iso_on) { auto k = &fasty_rows_kernel<NN, true>; XRFT_LAUNCH(k, grid, blk, lds, st, p); } \
+                     else { auto k = &fasty_rows_kernel<NN, false>; XRFT_LAUNCH(k, grid, blk, lds, st, p); } } while (0)
+            if (d.nx == 4096) YR_(4096); else if (d.nx == 2048) YR_(2048); else if (d.nx == 1024) YR_(1024); else if (d.nx == 512) YR_(512); else YR_(256);
+#undef YR_
+        }
+        prof_end(rec, st);
+        HIP_TRY(hipGetLastError());
+    }
+    return XRFTHIP_OK;
+}
+
 template <typename T>
 static int run_pipeline(const xrfthip_plan* P, const std::vector<Pass>& passes, const void* in, void* out, double* iso,
                         char* ws, const double* coef, long long g0, long long gc, hipStream_t st) {
@@ -1181,6 +1326,12 @@ int xrfthip_plan_create(xrfthip_plan** plan, const xrfthip_desc* desc) {
         const int tpu = fast_cols_gy(d.ny, (d.flags & XRFTHIP_ISO) != 0) / 4;  // tiles one column workgroup covers
         P->fast_ntile = (int)(d.nx / 8 + 1);
         P->fast_ntile_pad = (P->fast_ntile + tpu - 1) / tpu * tpu;
+        // full power spectra take the two-pass y-first pipeline (fasty.h); half / complex / cross results keep the x-first one
+        P->yfirst = d.out_mode == XRFTHIP_OUT_POWER && !(d.flags & (XRFTHIP_HALF_X | XRFTHIP_REALDIM_X2)) && env_ll("XRFTHIP_YFIRST", 1) != 0;
+        if (P->yfirst) {
+            const int rpu = yrows_geom(d.nx).rk;
+            P->y_nrow_pad = (int)((d.ny / 2 + 1 + rpu - 1) / rpu * rpu);
+        }
         int rc4 = build_twiddle<float>(P->tw_fx, d.nx, d.nx);
         if (!rc4) rc4 = build_twiddle<float>(P->tw_fy, d.ny, d.ny);
         std::vector<float> ones((size_t)std::max(d.ny, d.nx), 1.0f);
@@ -1208,6 +1359,9 @@ int xrfthip_plan_set_window(xrfthip_plan* plan, int axis, const double* h_window
     if (axis == 1) {
         plan->host_win_x.assign(h_window ? h_window : nullptr, h_window ? h_window + n : nullptr);
         plan->what_dirty = true;
+    } else {
+        plan->host_win_y.assign(h_window ? h_window : nullptr, h_window ? h_window + n : nullptr);
+        plan->ywhat_dirty = true;
     }
     return upload_real_table(plan, plan->win[axis], h_window, n, 0);
 }
@@ -1269,7 +1423,11 @@ int xrfthip_plan_set_binmap(xrfthip_plan* plan, const int32_t* h_binmap, int64_t
     if (plan->fast4096) {
         int rcf = XRFTHIP_OK;
         const size_t hist_bytes = (size_t)nbins * sizeof(double) * (plan->d.out_mode == XRFTHIP_OUT_CROSS ? 2 : 1);
-        if (nbins > 65534 || fast_cols_lds(plan->d.ny, true) + hist_bytes > kLdsMax) plan->fast4096 = false;  // the histogram sits behind the column pass's FFT buffers
+        if (plan->yfirst) {
+            if (nbins > 65534 || yrows_geom(plan->d.nx).lds + hist_bytes > kLdsMax) plan->fast4096 = false;
+            else rcf = fasty_build_tcodes(plan, h_binmap);
+        }
+        else if (nbins > 65534 || fast_cols_lds(plan->d.ny, true) + hist_bytes > kLdsMax) plan->fast4096 = false;  // the histogram sits behind the column pass's FFT buffers
         else rcf = fast_build_tcodes(plan, h_binmap);
         if (rcf) return rcf;
     }
@@ -1320,7 +1478,12 @@ int xrfthip_plan_describe(const xrfthip_plan* plan, char* buf, size_t buflen) {
     appendf(s, "xrfthip plan: ndim=%d batch=%lld ny=%lld nx=%lld dtype=%d mode=%d detrend=%d flags=0x%x width=%lld nx_out=%lld mirror=%d group=%d ws=%zuB\n",
             d.ndim, (long long)d.batch, (long long)d.ny, (long long)d.nx, d.dtype, d.out_mode, d.detrend, d.flags,
             plan->width, plan->nx_out, (int)plan->mirror, plan->G, plan->ws_bytes);
-    if (fast_on(plan)) {
+    if (fasty_on(plan)) {
+        const YGeomRt C = ycols_geom(plan->d.ny), R = yrows_geom(plan->d.nx);
+        appendf(s, "  [fasty] cols: %d thr, %d x 2 packed column pairs (FFT%lld r16x16x%lld, column-local detrend fused), %d columns/unit, lds=%zuB -> W2[slab][%d/%d][nx/%d][2][%d][%d] -> rows: %d thr, %d rows/unit (FFT%lld r16x16x%lld), lds=%zuB, |F|^2 + fftshift + mirror rows\n",
+                C.thr, C.gxy, (long long)plan->d.ny, (long long)plan->d.ny / 256, C.cw, C.lds, plan->y_nrow_pad, C.rk, C.cw, C.rk, 2 * C.gxy,
+                R.thr, R.rk, (long long)plan->d.nx, (long long)plan->d.nx / 256, R.lds);
+    } else if (fast_on(plan)) {
         const long long nx = plan->d.nx, ny = plan->d.ny;
         appendf(s, "  [fastp2] rows: %d thr (row-local detrend fused), %dx(2 real rows -> 1 complex FFT%lld r16x16x%lld), lds=%zuB, tiled W[slab][%d][%lld][4] -> cols: %lld columns/unit (FFT%lld r16x16x%lld), lds=%zuB, persistent, line-tiled |F|^2 -> untile+shift+mirror: 256 thr, 8 rows\n",
                 fast_rows_threads(nx), fast_rows_threads(nx) / (int)(nx / 16), nx, nx / 256, fast_rows_lds(nx), plan->fast_ntile_pad, ny,
@@ -1356,6 +1519,10 @@ int xrfthip_exec(const xrfthip_plan* plan, const void* d_in0, const void* d_in1,
     double* coef = (double*)(ws + P->off_coef);
     if (det) HIP_TRY(hipMemsetAsync(acc, 0, (size_t)d.batch * 6 * sizeof(double) * (cross ? 2 : 1), st));
     if (iso) HIP_TRY(hipMemsetAsync(d_iso, 0, (size_t)d.batch * P->nbins * (cross ? 16 : 8), st));
+    if (fasty_on(P)) {
+        if (P->ywhat_dirty) { int rcw = fasty_window_spectra(const_cast<xrfthip_plan*>(P)); if (rcw) return rcw; }
+        return run_fasty(P, (const float*)d_in0, out, (double*)d_iso, ws, st);
+    }
     if (fast_on(P)) {
         if (P->what_dirty) { int rcw = fast4096_window_spectra(const_cast<xrfthip_plan*>(P)); if (rcw) return rcw; }
         if (P->fph_dirty && d.out_mode != XRFTHIP_OUT_POWER) { int rcp = fast_phase_tables(const_cast<xrfthip_plan*>(P)); if (rcp) return rcp; }
