@@ -4,7 +4,8 @@ import os, sys, time, warnings
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 import xrft_amd as xrft
-from xrft_amd import api
+from xrft_amd import api, _lib
+if os.environ.get("XRFT_LIB"): _lib.load(os.environ["XRFT_LIB"])  # an ablation build (scripts/build_ablate_yf.sh)
 warnings.simplefilter("ignore")
 nt, n = int(os.environ.get("NT", 32)), int(os.environ.get("N", 4096))
 a = torch.randn((nt, n, n), dtype=torch.float32, device="cuda"); c = {"y": np.arange(float(n)), "x": np.arange(float(n))}

@@ -10,13 +10,14 @@
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
+typedef float v4f __attribute__((ext_vector_type(4)));
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); exit(1);} } while (0)
 
 constexpr int NY = 4096, NX = 4096, NPAIR = NY / 4 + 1;  // ky = 0..ny/2 in pairs: 1025
 constexpr size_t W2_SLAB = (size_t)NPAIR * (NX / 8) * 8 /*float4 per line*/;  // float4 units
 
 // COLS in {8, 16, 32}; 1024 threads; lane = (u, g): g = tid % (COLS/4) fastest
-template <int COLS, bool XCD>
+template <int COLS, bool XCD, bool NTL = false>
 __global__ void __launch_bounds__(1024) k_pass1(const float* __restrict__ in, float4* __restrict__ w2, int nslab) {
     constexpr int LPR = COLS / 4, RPR = 1024 / LPR, NQ = NY / RPR, UPS = NX / COLS;
     extern __shared__ float lds_fp[];  // the real kernel's LDS footprint decides how the two passes can share a CU
@@ -35,7 +36,9 @@ __global__ void __launch_bounds__(1024) k_pass1(const float* __restrict__ in, fl
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll 16
     for (int q = 0; q < NQ; ++q) {
-        const float4 v = *reinterpret_cast<const float4*>(src + (size_t)(u + RPR * q) * NX);
+        const float4* ap = reinterpret_cast<const float4*>(src + (size_t)(u + RPR * q) * NX);
+        float4 v;
+        if (NTL) { const v4f t = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(ap)); v = make_float4(t.x, t.y, t.z, t.w); } else v = *ap;
         acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
     }
     // COLS/8 lines (128 B = 8 float4) per pair, adjacent in memory
@@ -48,6 +51,7 @@ __global__ void __launch_bounds__(1024) k_pass1(const float* __restrict__ in, fl
 }
 
 // 512 threads; unit = one row pair p < ny/4 of one slab: 64-KB contiguous read, four 16-KB rows written
+template <bool NTS = false, bool NTLD = false>
 __global__ void __launch_bounds__(512) k_pass2(const float4* __restrict__ w2, float* __restrict__ out, int nslab) {
     extern __shared__ float lds_fp[];
     if (nslab < 0) lds_fp[threadIdx.x] = 0.f;
@@ -56,7 +60,10 @@ __global__ void __launch_bounds__(512) k_pass2(const float4* __restrict__ w2, fl
     const float4* src = w2 + (size_t)slab * W2_SLAB + (size_t)p * (NX / 8) * 8;
     float4 v[8];
 #pragma unroll
-    for (int r = 0; r < 8; ++r) v[r] = src[tid + 512 * r];
+    for (int r = 0; r < 8; ++r) {
+        if (NTLD) { const v4f t = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(src + tid + 512 * r)); v[r] = make_float4(t.x, t.y, t.z, t.w); }
+        else v[r] = src[tid + 512 * r];
+    }
     float4 s = v[0];
 #pragma unroll
     for (int r = 1; r < 8; ++r) { s.x += v[r].x; s.y += v[r].y; s.z += v[r].z; s.w += v[r].w; }
@@ -66,8 +73,8 @@ __global__ void __launch_bounds__(512) k_pass2(const float4* __restrict__ w2, fl
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         float4* d = reinterpret_cast<float4*>(o + (size_t)rows[r] * NX);
-        d[tid] = s;
-        d[tid + 512] = v[r];
+        if (NTS) { v4f t0 = {s.x, s.y, s.z, s.w}, t1 = {v[r].x, v[r].y, v[r].z, v[r].w}; __builtin_nontemporal_store(t0, reinterpret_cast<v4f*>(d + tid)); __builtin_nontemporal_store(t1, reinterpret_cast<v4f*>(d + tid + 512)); }
+        else { d[tid] = s; d[tid + 512] = v[r]; }
     }
 }
 
@@ -104,11 +111,11 @@ int main() {
     } while (0)
     P1(8, false); P1(8, true); P1(16, false); P1(16, true); P1(32, false); P1(32, true);
     {
-        float t = timeit([&] { k_pass2<<<NS * (NY / 4), 512>>>(w2, out, NS); }, 5);
+        float t = timeit([&] { k_pass2<false><<<NS * (NY / 4), 512>>>(w2, out, NS); }, 5);
         printf("pass2 (64-KB pair read, 4 rows written): %6.1f us / slab  (%.0f GB/s r+w)\n", t * 1e3 / NS, (in_mb + w2_mb) * NS / t / 1e3);
     }
     {   // both passes back to back per group of 32 slabs, as the plan would launch them
-        float t = timeit([&] { k_pass1<16, true><<<NS * (NX / 16), 1024>>>(in, w2, NS); k_pass2<<<NS * (NY / 4), 512>>>(w2, out, NS); }, 5);
+        float t = timeit([&] { k_pass1<16, true><<<NS * (NX / 16), 1024>>>(in, w2, NS); k_pass2<false><<<NS * (NY / 4), 512>>>(w2, out, NS); }, 5);
         printf("pass1(16, xcd) + pass2: %6.1f us / slab\n", t * 1e3 / NS);
     }
     // ---- the same two passes software-pipelined on two streams: pass 1 of group k+1 runs beside pass 2 of group k, the
@@ -116,7 +123,7 @@ int main() {
     {
         const size_t L1 = 139264, L2 = 71680;
         CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_pass1<16, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)L1));
-        CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_pass2), hipFuncAttributeMaxDynamicSharedMemorySize, (int)L2));
+        CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_pass2<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)L2));
         hipStream_t s1, s2; CK(hipStreamCreate(&s1)); CK(hipStreamCreate(&s2));
         for (int withlds = 0; withlds < 2; ++withlds)
         for (int G : {1, 2, 4, 8}) for (int R : {2, 3}) {
@@ -133,7 +140,7 @@ int main() {
                     k_pass1<16, true><<<G * (NX / 16), 1024, l1, s1>>>(in + (size_t)s0 * NY * NX, w2 + (size_t)slot * G * W2_SLAB, G);
                     CK(hipEventRecord(done1[k], s1));
                     CK(hipStreamWaitEvent(s2, done1[k], 0));
-                    k_pass2<<<G * (NY / 4), 512, l2, s2>>>(w2 + (size_t)slot * G * W2_SLAB, out + (size_t)s0 * NY * NX, G);
+                    k_pass2<false><<<G * (NY / 4), 512, l2, s2>>>(w2 + (size_t)slot * G * W2_SLAB, out + (size_t)s0 * NY * NX, G);
                     CK(hipEventRecord(done2[k], s2));
                 }
                 CK(hipStreamSynchronize(s1)); CK(hipStreamSynchronize(s2));
@@ -154,12 +161,27 @@ int main() {
         float t = timeit([&] {
             for (int s0 = 0; s0 < NS; s0 += G) {
                 k_pass1<16, true><<<G * (NX / 16), 1024>>>(in + (size_t)s0 * NY * NX, w2, G);
-                k_pass2<<<G * (NY / 4), 512>>>(w2, out + (size_t)s0 * NY * NX, G);
+                k_pass2<false><<<G * (NY / 4), 512>>>(w2, out + (size_t)s0 * NY * NX, G);
             } }, 5);
         float t1 = timeit([&] { for (int s0 = 0; s0 < NS; s0 += G) k_pass1<16, true><<<G * (NX / 16), 1024>>>(in + (size_t)s0 * NY * NX, w2, G); }, 5);
-        float t2 = timeit([&] { for (int s0 = 0; s0 < NS; s0 += G) k_pass2<<<G * (NY / 4), 512>>>(w2, out + (size_t)s0 * NY * NX, G); }, 5);
+        float t2 = timeit([&] { for (int s0 = 0; s0 < NS; s0 += G) k_pass2<false><<<G * (NY / 4), 512>>>(w2, out + (size_t)s0 * NY * NX, G); }, 5);
         printf("one stream, group %2d (W2 %4.0f MB re-used): %6.1f us / slab;  pass1 alone %5.1f, pass2 alone %5.1f\n", G, G * w2_mb, t * 1e3 / NS, t1 * 1e3 / NS, t2 * 1e3 / NS);
     }
+    // ---- non-temporal variants (what leaves the intermediate in the Infinity Cache?): A = nt stores of the output only,
+    // B = A + nt loads of the intermediate in pass 2, C = B + nt loads of the input in pass 1
+#define NTV(NAME, L1, S2, L2) \
+    for (int G : {1, 2, 3, 4, 6, 8, 16, 32}) { \
+        float t = timeit([&] { \
+            for (int s0 = 0; s0 + G <= NS; s0 += G) { \
+                k_pass1<16, true, L1><<<G * (NX / 16), 1024>>>(in + (size_t)s0 * NY * NX, w2, G); \
+                k_pass2<S2, L2><<<G * (NY / 4), 512>>>(w2, out + (size_t)s0 * NY * NX, G); \
+            } }, 5); \
+        printf("%s, one stream, group %2d (W2 %4.0f MB re-used): %6.1f us / slab\n", NAME, G, G * w2_mb, t * 1e3 / (NS / G * G)); \
+    }
+    NTV("plain", false, false, false)
+    NTV("A (nt out)", false, true, false)
+    NTV("B (nt out, nt W2 loads)", false, true, true)
+    NTV("C (all nt)", true, true, true)
     // ---- copies between two small buffers that stay in the Infinity Cache: is read + write faster there than from HBM?
     for (size_t mb : {8, 16, 32, 64, 128, 512}) {
         const size_t n = (mb << 20) / 16;

@@ -53,6 +53,7 @@ struct Fiber {
 struct BlockCtx {
     dim3 blockIdx, blockDim, gridDim;
     unsigned char* smem;
+    double* shfl;  // one slot per thread: cross-lane exchange of the emulated __shfl_xor
     ucontext_t sched;
     Fiber* cur;
     const std::function<void()>* body;
@@ -83,7 +84,9 @@ inline void barrier() {
 struct Worker {
     std::vector<Fiber> fibers;
     std::vector<unsigned char> smem;
+    std::vector<double> shfl;
     void ensure(size_t n) {
+        if (shfl.size() < n) shfl.resize(n);
         while (fibers.size() < n) {
             Fiber f;
             f.stack = mmap(nullptr, kStack, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS | MAP_NORESERVE, -1, 0);
@@ -101,6 +104,7 @@ struct Worker {
         ctx.blockIdx = bidx; ctx.blockDim = block; ctx.gridDim = grid;
         ctx.smem = (unsigned char*)(((uintptr_t)smem.data() + 63) & ~(uintptr_t)63);
         ctx.body = &body;
+        ctx.shfl = shfl.data();
         tls() = &ctx;
         size_t t = 0;
         for (unsigned z = 0; z < block.z; ++z)
@@ -181,6 +185,16 @@ inline T atomic_add(T* p, T v) {
 #define gridDim (emu::tls()->gridDim)
 #define __syncthreads() emu::barrier()
 
+// wave-level exchange (64 lanes): EVERY thread of the workgroup must call it (it contains two barriers)
+inline double __shfl_xor(double v, int mask) {
+    emu::BlockCtx* b = emu::tls();
+    const unsigned t = b->cur->tid.x;
+    b->shfl[t] = v;
+    emu::barrier();
+    const double r = b->shfl[t ^ (unsigned)mask];
+    emu::barrier();
+    return r;
+}
 inline float __uint_as_float(unsigned v) { float f; memcpy(&f, &v, 4); return f; }
 inline unsigned __float_as_uint(float f) { unsigned v; memcpy(&v, &f, 4); return v; }
 using std::max;

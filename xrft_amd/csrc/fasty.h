@@ -26,6 +26,17 @@
 
 namespace xrft {
 
+// 16-byte store that is not kept in L2 / the Infinity Cache
+__device__ __forceinline__ void xrft_store_nt(float* dst, F4 v) {
+#ifdef XRFT_EMULATE
+    *reinterpret_cast<F4*>(dst) = v;
+#else
+    typedef float v4f __attribute__((ext_vector_type(4)));
+    v4f t = {v.x, v.y, v.z, v.w};
+    __builtin_nontemporal_store(t, reinterpret_cast<v4f*>(dst));
+#endif
+}
+
 struct FastY {
     const float* in;         // [slab][ny][nx] float32
     cf* w2;                  // intermediate, see above
@@ -34,8 +45,8 @@ struct FastY {
     const cf* tw_y;          // W_ny^k
     const float* win_y;      // never null (ones when there is no window)
     const float* win_x;
-    double* colfit;          // [slab][nx][2]: per-column mean and slope found by pass 1 (detrend != none), float64
-    const float* corr;       // [slab][nx][2]: wx[x] * (column fit - plane fit) as (offset, slope), from fastp2_fit_kernel
+    double* colfit;          // [slab][nx][4]: per column sum d, sum (i - ibar) d (exact), and the line pass 1 subtracted as (value at ibar, slope)
+    const float* corr;       // [slab][nx][2]: wx[x] * (subtracted line - plane fit) as (offset at ibar, slope), from fasty_fit_kernel
     const cf* what0;         // FFT_y(wy)[ky], ky < nrow_pad (zero beyond ny/2)
     const cf* what1;         // FFT_y(wy * (i - (ny-1)/2))[ky]
     const unsigned* tcodes;  // radial bins in pass 2's register order: (direct + 1) | (mirror + 1) << 16
@@ -147,7 +158,7 @@ template <int N> __device__ __forceinline__ int held_k(int u, int bb, int k3) {
 // A and +2, +3 into transform B (one float4 per row), splits the half spectra and stores them as 16-byte (column pair)
 // pieces: 8 consecutive lanes fill one 128-byte line of W2.          detrend/window: xrft.py:425-433
 // ------------------------------------------------------------------------------------------------
-template <int NY>
+template <int NY, bool DET>
 __global__ void __launch_bounds__(YCols<NY>::THR, YCols<NY>::THR / 128) fasty_cols_kernel(FastY p) {
     typedef P2<NY> G;
     typedef YCols<NY> Y;
@@ -174,97 +185,108 @@ __global__ void __launch_bounds__(YCols<NY>::THR, YCols<NY>::THR / 128) fasty_co
     // uniform 64-bit base + one 32-bit per-lane byte offset (a slab is < 4 GB): scalar-base loads, no 64-bit address per row
     const char* __restrict__ src = reinterpret_cast<const char*>(p.in + (size_t)slab * NY * p.nx + (size_t)xb * Y::CW);
     const unsigned off0 = ((unsigned)u * (unsigned)p.nx + 4u * (unsigned)g) * 4u, rstep = (unsigned)NT * (unsigned)p.nx * 4u;
+    const F4 wx = *reinterpret_cast<const F4*>(p.win_x + x0);
+    // ---- detrend, fused, nothing on the critical path.  The plane of xrft/detrend.py:100-113 needs sums over the whole
+    // slab, which exist only after this pass.  What is subtracted HERE, in y-space, only has to take the bulk of the trend
+    // out (so that nothing cancels catastrophically in float32) and to be one line T + S i per column: it is an estimate
+    // from KREF rows at the top and at the bottom of the column, which every thread of the group loads itself (the same
+    // addresses in all lanes of a wave: one transaction) BEFORE its own 16 rows, so that the constants are ready when the
+    // rows arrive.  Pass 2 adds the difference to the true plane back in the spectral domain,
+    // wx[x] (alpha_x What0[ky] + gamma_x What1[ky]) with What0 = FFT(wy), What1 = FFT(wy (i - ibar)), from the exact column sums
+    // (sum d, sum (i - ibar) d) that this kernel produces on the side: float32 over a thread's 16 rows, float64 wave
+    // shuffles, one small LDS table that is summed AFTER the transforms -- no barrier of its own.
+    // (A three-level LDS reduction in front of the transforms, with the rows held in registers meanwhile, cost 7 of 36 us
+    // per slab, most of it through the 17 VGPRs it made the kernel spill: 36 MB of scratch traffic per slab.)
+    constexpr double IBAR = 0.5 * (NY - 1);
+    constexpr int KREF = 2, NW = THR / 64;
+    double* part = reinterpret_cast<double*>(tw2 + 16 * G::R3);  // [wave][g][8]
+    float T[4] = {0.f, 0.f, 0.f, 0.f}, S[4] = {0.f, 0.f, 0.f, 0.f};
+    F4 rt[KREF], rb[KREF];
+    if (DET) {
+        const unsigned offg = 16u * (unsigned)g, rowb = (unsigned)p.nx * 4u;
+#pragma unroll
+        for (int k = 0; k < KREF; ++k) {
+            rt[k] = *reinterpret_cast<const F4*>(src + (offg + rowb * (unsigned)k));
+            rb[k] = *reinterpret_cast<const F4*>(src + (offg + rowb * (unsigned)(NY - KREF + k)));
+        }
+    }
     F4 raw[16];
 #pragma unroll
     for (int q = 0; q < 16; ++q) raw[q] = *reinterpret_cast<const F4*>(src + (off0 + rstep * (unsigned)q));
-    const F4 wx = *reinterpret_cast<const F4*>(p.win_x + x0);
-    // ---- detrend, fused (cf. fastp2_rows_kernel with the axes swapped): every column's own least-squares line
-    // m + s (i - ibar) is found here and subtracted in y-space; the plane of xrft/detrend.py:100-113 differs from it by a
-    // noise-sized (offset, slope) pair per column, which pass 2 adds back in the spectral domain:
-    // wx[x] * (alpha_x What0[ky] + gamma_x What1[ky]),  What0 = FFT(wy), What1 = FFT(wy (i - ibar)).  float64 sums.
-    constexpr double IBAR = 0.5 * (NY - 1);
-    float th[4] = {0.f, 0.f, 0.f, 0.f}, tl[4] = {0.f, 0.f, 0.f, 0.f}, sh[4] = {0.f, 0.f, 0.f, 0.f}, sl[4] = {0.f, 0.f, 0.f, 0.f};
-    if (p.detrend && !(XRFT_YDBG & 16)) {
-        struct alignas(16) D8 { double s0[4], s1[4]; };
-        // a thread's 16 rows are summed in float32 (16 terms: ~1e-7 relative, random over the NT threads of a column), the
-        // rest of the reduction runs in float64.  sum (i - ibar) d over i = u + NT q is (u - ibar) S0 + NT sum q d.
-        // (float64 from the first term costs 64 conversions per thread and 128 live VGPRs when the scheduler hoists them.)
-        float f0[4] = {0.f, 0.f, 0.f, 0.f}, f1[4] = {0.f, 0.f, 0.f, 0.f};
+    if (DET) {
+        float mt[4] = {0.f, 0.f, 0.f, 0.f}, mb[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int q = 0; q < 16; ++q) {
+        for (int k = 0; k < KREF; ++k) {
+            mt[0] += rt[k].x; mt[1] += rt[k].y; mt[2] += rt[k].z; mt[3] += rt[k].w;
+            mb[0] += rb[k].x; mb[1] += rb[k].y; mb[2] += rb[k].z; mb[3] += rb[k].w;
+        }
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const float top = mt[c] * (1.0f / KREF), bot = mb[c] * (1.0f / KREF);  // means at i = (KREF-1)/2 and ny-1-(KREF-1)/2
+            const float Se = p.detrend == 2 ? (bot - top) * (1.0f / (NY - KREF)) : 0.f;
+            const float Te = p.detrend == 2 ? top - Se * (0.5f * (KREF - 1)) : 0.5f * (top + bot);  // value of the line at i = 0
+            // The line is OUR choice (pass 2 corrects whatever is subtracted here), so both coefficients are rounded to one
+            // coarse power-of-two grid 2^(e-20), 2^e <= |T| + |S| ny < 2^(e+1) (adding and subtracting C = 1.5 * 2^(e+3)
+            // rounds to that grid): T + S i is then exact in float32 for every row, and x - (T + S i) has a single rounding,
+            // relative to the already noise-sized result (a plain float32 evaluation of the trend leaves 6e-4 of max in the
+            // ky = 0 bins, cf. fastp2_rows_kernel).  The slope keeps >= 9 bits: the residual line stays < 0.1 % of the trend.
+            const float mag = fabsf(Te) + fabsf(Se) * (float)NY;
+            const float C = __uint_as_float((__float_as_uint(mag) & 0x7f800000u) + (3u << 23)) * 1.5f;
+            T[c] = (Te + C) - C; S[c] = (Se + C) - C;
+        }
+        if (u == 0) {  // what is subtracted, as (offset at ibar, slope)
+            double* cfp = p.colfit + ((size_t)slab * p.nx + x0) * 4;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) { cfp[4 * c + 2] = (double)T[c] + (double)S[c] * IBAR; cfp[4 * c + 3] = (double)S[c]; }
+        }
+    }
+    cf a[16], b[16];
+    float f0[4] = {0.f, 0.f, 0.f, 0.f}, f1[4] = {0.f, 0.f, 0.f, 0.f};  // exact column sums, float32 over this thread's rows
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+        const float fi = (float)(u + NT * q);
+        const float wy = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(p.win_y) + (unsigned)(u + NT * q) * 4u);
+        if (DET) {
             const float fq = (float)q;
             f0[0] += raw[q].x; f1[0] = fmaf(fq, raw[q].x, f1[0]);
             f0[1] += raw[q].y; f1[1] = fmaf(fq, raw[q].y, f1[1]);
             f0[2] += raw[q].z; f1[2] = fmaf(fq, raw[q].z, f1[2]);
             f0[3] += raw[q].w; f1[3] = fmaf(fq, raw[q].w, f1[3]);
         }
-        D8 t;
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            t.s0[c] = (double)f0[c];
-            t.s1[c] = fma((double)u - IBAR, (double)f0[c], (double)NT * (double)f1[c]);
-        }
-        // three levels through LDS (the scratch aliases the still unused FFT buffers), every access unit-stride over the
-        // lanes: (1) red[c][tid], c = 8 sums; (2) 8 J GY threads (c, jj, g) add NT / J entries each; (3) everyone adds the
-        // J partial sums of its group
-        constexpr int J = 8 * 4 * GY <= THR ? 4 : THR / (8 * GY), RS = THR + 8;  // the pad spreads the 8 rows over the banks
-        double* red = reinterpret_cast<double*>(lds);
-        double* mid = red + 8 * RS;
-#pragma unroll
-        for (int c = 0; c < 4; ++c) { red[c * RS + tid] = t.s0[c]; red[(4 + c) * RS + tid] = t.s1[c]; }
-        __syncthreads();
-        if (tid < 8 * J * GY) {
-            const int c = tid / (J * GY), r = tid % (J * GY);
-            double acc = 0.0;
-#pragma unroll 8
-            for (int k = 0; k < NT / J; ++k) acc += red[c * RS + k * (J * GY) + r];
-            mid[tid] = acc;
-        }
-        __syncthreads();
-        D8 tot;
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            tot.s0[c] = 0.0; tot.s1[c] = 0.0;
-#pragma unroll
-            for (int jj = 0; jj < J; ++jj) { tot.s0[c] += mid[c * (J * GY) + jj * GY + g]; tot.s1[c] += mid[(4 + c) * (J * GY) + jj * GY + g]; }
-        }
-        constexpr double inv_n = 1.0 / NY, inv_sii = 12.0 / ((double)NY * ((double)NY * NY - 1.0));  // sum (i - ibar)^2 = n (n^2 - 1) / 12
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            const double md = tot.s0[c] * inv_n, sd = p.detrend == 2 ? tot.s1[c] * inv_sii : 0.0;
-            if (u == 0) {
-                double* cfp = p.colfit + ((size_t)slab * p.nx + x0 + c) * 2;
-                cfp[0] = md; cfp[1] = sd;
-            }
-            // local trend (m - s ibar) + s i, subtracted in float32 with hi/lo splits whose hi parts lie on a coarse
-            // power-of-two grid: x - th and the FMA with the exact product sh * i are error-free, the lo parts are
-            // applied to the already noise-sized value (see fastp2_rows_kernel: 1e-6 of max instead of 6e-4)
-            const float mf = (float)md, sf = (float)sd;  // the float32 values are what gets subtracted
-            const double tt = (double)mf - (double)sf * IBAR;
-            // grid 2^(e-20), 2^e <= |t| + |s| ny < 2^(e+1): adding and subtracting C = 1.5 * 2^(e+3) rounds to that grid
-            const float mag = fabsf((float)tt) + fabsf(sf) * (float)NY;
-            const float C = __uint_as_float((__float_as_uint(mag) & 0x7f800000u) + (3u << 23)) * 1.5f;
-            const float thc = ((float)tt + C) - C, shc = (sf + C) - C;
-            th[c] = thc; tl[c] = (float)(tt - (double)thc); sh[c] = shc; sl[c] = sf - shc;
-        }
-        __syncthreads();  // the reduction scratch aliases the FFT buffer written next
-    }
-    cf a[16], b[16];
-#pragma unroll
-    for (int q = 0; q < 16; ++q) {
-        const float fi = (float)(u + NT * q);
-        const float wy = p.win_y[u + NT * q];
-        const float v0 = fmaf(-sl[0], fi, fmaf(-sh[0], fi, raw[q].x - th[0]) - tl[0]);
-        const float v1 = fmaf(-sl[1], fi, fmaf(-sh[1], fi, raw[q].y - th[1]) - tl[1]);
-        const float v2 = fmaf(-sl[2], fi, fmaf(-sh[2], fi, raw[q].z - th[2]) - tl[2]);
-        const float v3 = fmaf(-sl[3], fi, fmaf(-sh[3], fi, raw[q].w - th[3]) - tl[3]);
+        const float v0 = DET ? raw[q].x - fmaf(S[0], fi, T[0]) : raw[q].x;
+        const float v1 = DET ? raw[q].y - fmaf(S[1], fi, T[1]) : raw[q].y;
+        const float v2 = DET ? raw[q].z - fmaf(S[2], fi, T[2]) : raw[q].z;
+        const float v3 = DET ? raw[q].w - fmaf(S[3], fi, T[3]) : raw[q].w;
         a[q] = mk<float>(v0 * (wy * wx.x), v1 * (wy * wx.y));
         b[q] = mk<float>(v2 * (wy * wx.z), v3 * (wy * wx.w));
     }
+    if (DET) {
+        double v[8];  // sum (i - ibar) d over i = u + NT q is (u - ibar) S0 + NT sum q d
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            v[c] = (double)f0[c];
+            v[4 + c] = fma((double)u - IBAR, (double)f0[c], (double)NT * (double)f1[c]);
+        }
+#pragma unroll
+        for (int m = GY; m < 64; m <<= 1)
+#pragma unroll
+            for (int c = 0; c < 8; ++c) v[c] += __shfl_xor(v[c], m);
+        if ((tid & 63) < GY) {  // the lane with the wave's first u: lane = g
+#pragma unroll
+            for (int c = 0; c < 8; ++c) part[((tid >> 6) * GY + g) * 8 + c] = v[c];
+        }
+    }
     if (!(XRFT_YDBG & 32)) fft_p2_pair<NY>(a, b, u, mine, p.tw_y, tw2);
+    if (DET && tid < 8 * GY) {  // the transforms' barriers have made every wave's partial sums visible
+        const int c = tid / GY, gg = tid % GY;
+        double acc = 0.0;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) acc += part[(w * GY + gg) * 8 + c];
+        p.colfit[((size_t)slab * p.nx + xb * Y::CW + 4 * gg + (c & 3)) * 4 + (c >> 2)] = acc;
+    }
     // split the packed transforms: Ra[k] = (Z[k] + conj Z[N-k]) / 2, Rb[k] = (Z[k] - conj Z[N-k]) / (2i), k = u + NT q (q < 8)
     // and k = NY/2; (Ra, Rb) = two adjacent columns = one 16-byte store; lanes (u..u+RK-1, all g) complete a line
-    cf* __restrict__ w2s = p.w2 + (size_t)slab * p.nrow_pad * p.nx;
+    char* __restrict__ w2s = reinterpret_cast<char*>(p.w2 + (size_t)slab * p.nrow_pad * p.nx);
 #pragma unroll
     for (int set = 0; set < 2; ++set) {
         const cf* z = set == 0 ? a : b;
@@ -280,9 +302,9 @@ __global__ void __launch_bounds__(YCols<NY>::THR, YCols<NY>::THR / 128) fasty_co
                 const cf zk = mine[nat16(k & (NY - 1))];
                 const cf zc = cconj(mine[nat16((NY - k) & (NY - 1))]);
                 const cf ra = cscale(zk + zc, 0.5f), rb = cscale(mul_mi(zk - zc), 0.5f);
-                const size_t off = ((((size_t)(k / Y::RK) * nxb + xb) * 2 + set) * Y::LBS) + (k % Y::RK) * (2 * GY) + 2 * g;
+                const unsigned off = ((((unsigned)(k / Y::RK) * (unsigned)nxb + (unsigned)xb) * 2u + set) * Y::LBS) + (k % Y::RK) * (2 * GY) + 2 * g;
                 F4 o; o.x = ra.re; o.y = ra.im; o.z = rb.re; o.w = rb.im;
-                if (!(XRFT_YDBG & 64) || o.x == 1.2345f) *reinterpret_cast<F4*>(w2s + off) = o;
+                if (!(XRFT_YDBG & 64) || o.x == 1.2345f) *reinterpret_cast<F4*>(w2s + off * 8u) = o;
             }
         }
         if (set == 0) __syncthreads();
@@ -304,10 +326,11 @@ template <int NX> struct YRows {
     static constexpr int RS = NX + NX / 16;  // floats per staged row (nat16 padding)
 };
 
-__device__ __forceinline__ size_t w2_offset(const FastY& p, int ky, int x) {
-    const int nxb = p.nx >> p.l_cw;
-    const size_t blk = ((size_t)(ky >> p.l_rk) * nxb + (x >> p.l_cw)) * 2 + ((x >> 1) & 1);
-    return (blk << (p.l_rk + p.l_2gy)) + ((ky & ((1 << p.l_rk) - 1)) << p.l_2gy) + (((x & ((1 << p.l_cw) - 1)) >> 2) << 1) + (x & 1);
+// element offset of (ky, x) inside one slab of W2 (< 2^24 elements)
+__device__ __forceinline__ unsigned w2_offset(const FastY& p, int ky, int x) {
+    const unsigned nxb = (unsigned)p.nx >> p.l_cw;
+    const unsigned blk = (((unsigned)ky >> p.l_rk) * nxb + ((unsigned)x >> p.l_cw)) * 2u + (((unsigned)x >> 1) & 1u);
+    return (blk << (p.l_rk + p.l_2gy)) + (((unsigned)ky & ((1u << p.l_rk) - 1u)) << p.l_2gy) + ((((unsigned)x & ((1u << p.l_cw) - 1u)) >> 2) << 1) + ((unsigned)x & 1u);
 }
 
 template <int NX, bool ISO>
@@ -329,20 +352,37 @@ __global__ void __launch_bounds__(YRows<NX>::THR, YRows<NX>::THR / 128) fasty_ro
     const int nyh = p.ny >> 1;
     // rows beyond ny/2 (padding of the last unit) are computed on row ny/2's data and never stored or binned
     const int kyA = min(ky0 + g, nyh), kyB = min(ky0 + GX + g, nyh);
-    const cf* __restrict__ w2s = p.w2 + (size_t)slab * p.nrow_pad * NX;
-    cf a[16], b[16];
+    // uniform 64-bit bases + 32-bit per-lane byte offsets (scalar-base loads).  The residual-trend pairs go first: 16 loads
+    // in flight beside the 32 of the rows (issued after them they came in four serialised batches: +4.5 us per slab)
+    const char* __restrict__ w2s = reinterpret_cast<const char*>(p.w2 + (size_t)slab * p.nrow_pad * NX);
+    const char* __restrict__ crb = reinterpret_cast<const char*>(p.corr + (size_t)slab * NX * 2);
+    const bool addback = p.detrend && !(XRFT_YDBG & 1);
+    cf cr[16];
+    if (addback) {
 #pragma unroll
-    for (int q = 0; q < 16; ++q) {
-        const int x = u + NT * q;
-        a[q] = w2s[w2_offset(p, kyA, x)];
-        b[q] = w2s[w2_offset(p, kyB, x)];
+        for (int q = 0; q < 16; ++q) cr[q] = *reinterpret_cast<const cf*>(crb + (unsigned)(u + NT * q) * 8u);
     }
-    if (p.detrend && !(XRFT_YDBG & 1)) {  // add back wx[x] * (column fit - plane fit) in the spectral domain (see fasty_cols_kernel)
-        const cf a0 = p.what0[kyA], a1 = p.what1[kyA], b0 = p.what0[kyB], b1 = p.what1[kyB];
-        const float* __restrict__ cr = p.corr + ((size_t)slab * NX + u) * 2;
+    const unsigned offA = w2_offset(p, kyA, u) * 8u, offB = w2_offset(p, kyB, u) * 8u;
+    cf a[16], b[16];
+    if (NT >= (1 << p.l_cw)) {  // x = u + NT q advances by whole column blocks: constant stride
+        const unsigned qstr = (unsigned)(((NT >> p.l_cw) * 2) << (p.l_rk + p.l_2gy)) * 8u;
 #pragma unroll
         for (int q = 0; q < 16; ++q) {
-            const float al = (XRFT_YDBG & 2) ? a0.re : cr[2 * NT * q], ga = (XRFT_YDBG & 2) ? a0.im : cr[2 * NT * q + 1];
+            a[q] = *reinterpret_cast<const cf*>(w2s + (offA + qstr * (unsigned)q));
+            b[q] = *reinterpret_cast<const cf*>(w2s + (offB + qstr * (unsigned)q));
+        }
+    } else {
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            a[q] = *reinterpret_cast<const cf*>(w2s + w2_offset(p, kyA, u + NT * q) * 8u);
+            b[q] = *reinterpret_cast<const cf*>(w2s + w2_offset(p, kyB, u + NT * q) * 8u);
+        }
+    }
+    if (addback) {  // add back wx[x] * (column fit - plane fit) in the spectral domain (see fasty_cols_kernel)
+        const cf a0 = p.what0[kyA], a1 = p.what1[kyA], b0 = p.what0[kyB], b1 = p.what1[kyB];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const float al = cr[q].re, ga = cr[q].im;
             a[q].re = fmaf(al, a0.re, fmaf(ga, a1.re, a[q].re));
             a[q].im = fmaf(al, a0.im, fmaf(ga, a1.im, a[q].im));
             b[q].re = fmaf(al, b0.re, fmaf(ga, b1.re, b[q].re));
@@ -396,7 +436,9 @@ __global__ void __launch_bounds__(YRows<NX>::THR, YRows<NX>::THR / 128) fasty_ro
                 v.x = row[nat16(kx)]; v.y = row[nat16((kx - 1) & mx)]; v.z = row[nat16((kx - 2) & mx)]; v.w = row[nat16((kx - 3) & mx)];
             }
             const int orow = mir ? ((p.ny - ky) + p.shift_y) & my : (ky + p.shift_y) & my;
-            if (!(XRFT_YDBG & 8) || v.x == 1.2345f) *reinterpret_cast<F4*>(outs + (size_t)orow * NX + c) = v;
+            // non-temporal: the result is not read again, and keeping it out of the caches leaves the Infinity Cache to the
+            // intermediate (scripts/ubench/yfirst.hip: 45.8 vs 50.9 us per slab for the two passes at 2 slabs per group)
+            if (!(XRFT_YDBG & 8) || v.x == 1.2345f) xrft_store_nt(outs + (size_t)orow * NX + c, v);
         }
     }
     if (ISO) {
@@ -405,6 +447,41 @@ __global__ void __launch_bounds__(YRows<NX>::THR, YRows<NX>::THR / 128) fasty_ro
             const double v = hist[i];
             if (v != 0.0) atomicAdd(&p.iso[(size_t)slab * p.nbins + i], v);
         }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// plane fit from the per-column sums (one 256-thread block per slab, float64, fixed summation order): column means
+// m_x = sum d / ny and slopes s_x = sum (i - ibar) d / sum (i - ibar)^2; a = mean(m_x), b = slope of m_x over x, c = mean(s_x)
+// (the centred regressors of a full grid are orthogonal, so this IS the least-squares plane of xrft/detrend.py:100-113).
+// Output: corr[x] = wx[x] * (line pass 1 subtracted - plane) as (offset at ibar, slope).
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) fasty_fit_kernel(const double* colfit, const float* win_x, float* corr, int nx, int ny, int detrend) {
+    XRFT_DYN_SMEM(smem_raw);
+    double* red = reinterpret_cast<double*>(smem_raw);
+    const int slab = blockIdx.x, tid = threadIdx.x;
+    const double* cf4 = colfit + (size_t)slab * nx * 4;
+    const double xbar = 0.5 * (nx - 1), sxx = (double)nx * ((double)nx * nx - 1.0) / 12.0;
+    const double inv_n = 1.0 / ny, inv_sii = 12.0 / ((double)ny * ((double)ny * ny - 1.0));
+    double s[3] = {0.0, 0.0, 0.0};
+    for (int x = tid; x < nx; x += 256) {
+        const double m = cf4[4 * x] * inv_n, sl = cf4[4 * x + 1] * inv_sii;
+        s[0] += m;
+        s[1] += ((double)x - xbar) * m;
+        s[2] += sl;
+    }
+    block_sum<3>(s, red);
+    __syncthreads();
+    if (tid == 0) { red[0] = s[0]; red[1] = s[1]; red[2] = s[2]; }
+    __syncthreads();
+    const double a = red[0] / nx;
+    const double b = detrend == 2 ? red[1] / sxx : 0.0;
+    const double c = detrend == 2 ? red[2] / nx : 0.0;
+    float* out = corr + (size_t)slab * nx * 2;
+    for (int x = tid; x < nx; x += 256) {
+        const double wx = win_x[x];
+        out[2 * x] = (float)(wx * (cf4[4 * x + 2] - a - b * ((double)x - xbar)));
+        out[2 * x + 1] = (float)(wx * (cf4[4 * x + 3] - c));
     }
 }
 

@@ -737,7 +737,7 @@ void set_kernel_attrs_once() {
     SETF((fastp2_cols_kernel<1024, 768, 0, false>));
 #undef SETC
     SETF(fastp2_untile_kernel); SETF(fastp2_untile_c_kernel<false>); SETF(fastp2_untile_c_kernel<true>);
-#define SETY(NN) SETF(fasty_cols_kernel<NN>); SETF((fasty_rows_kernel<NN, false>)); SETF((fasty_rows_kernel<NN, true>))
+#define SETY(NN) SETF((fasty_cols_kernel<NN, false>)); SETF((fasty_cols_kernel<NN, true>)); SETF((fasty_rows_kernel<NN, false>)); SETF((fasty_rows_kernel<NN, true>))
     SETY(4096); SETY(2048); SETY(1024); SETY(512); SETY(256);
 #undef SETY
 #undef SETF
@@ -836,7 +836,7 @@ static void layout_workspace(xrfthip_plan* P) {
         P->off_pt = off;
         if (!pw || !(d.flags & XRFTHIP_NO_SPECTRUM_OUT)) off = al(off + (size_t)G * (d.ny / 8) * P->fast_ntile_pad * 8 * sizeof(F4) * (pw ? 1 : 2));
     }
-    const size_t nfit = (size_t)(yf ? d.nx : d.ny);  // per-row fits (x first) or per-column fits (y first)
+    const size_t nfit = (size_t)(yf ? 2 * d.nx : d.ny);  // per-row fits (x first) or per-column sums + subtracted lines (y first)
     P->off_rowfit = off; if (fast) off = al(off + (size_t)G * nfit * 2 * sizeof(double));
     P->off_corr = off; if (fast) off = al(off + (size_t)G * nfit * 2 * sizeof(float));
     P->ws_bytes = off;
@@ -1071,7 +1071,7 @@ static int run_fast4096(const xrfthip_plan* P, const float* in, const float* in1
 struct YGeomRt { int thr, gxy, cw, rk, lbs; size_t lds; };
 template <int NY> static YGeomRt ycols_geom_t() {
     typedef YCols<NY> Y;
-    return {Y::THR, Y::GY, Y::CW, Y::RK, Y::LBS, (size_t)(Y::GY * YLds<NY, Y::GY>::GSTR + 16 * P2<NY>::R3) * sizeof(cf)};
+    return {Y::THR, Y::GY, Y::CW, Y::RK, Y::LBS, (size_t)(Y::GY * YLds<NY, Y::GY>::GSTR + 16 * P2<NY>::R3) * sizeof(cf) + (size_t)(Y::THR / 64) * Y::GY * 8 * sizeof(double)};
 }
 template <int NX> static YGeomRt yrows_geom_t() {
     typedef YRows<NX> R;
@@ -1106,6 +1106,7 @@ static int fasty_window_spectra(xrfthip_plan* P) {
     }
     int rc = P->ywhat0.upload(h0.data(), h0.size() * sizeof(cf));
     if (!rc) rc = P->ywhat1.upload(h1.data(), h1.size() * sizeof(cf));
+
     if (!rc) P->ywhat_dirty = false;
     return rc;
 }
@@ -1172,15 +1173,16 @@ static int run_fasty(const xrfthip_plan* P, const float* in, void* out, double* 
         xrfthip_plan::ProfRec* rec = prof_begin(P, "fasty_cols", st);
         {
             const dim3 grid((unsigned)(gc * (d.nx / C.cw))), blk((unsigned)C.thr);
-#define YC_(NN) do { auto k = &fasty_cols_kernel<NN>; XRFT_LAUNCH(k, grid, blk, C.lds, st, p); } while (0)
+#define YC_(NN) do { if (d.detrend) { auto k = &fasty_cols_kernel<NN, true>; XRFT_LAUNCH(k, grid, blk, C.lds, st, p); } \
+                     else { auto k = &fasty_cols_kernel<NN, false>; XRFT_LAUNCH(k, grid, blk, C.lds, st, p); } } while (0)
             if (d.ny == 4096) YC_(4096); else if (d.ny == 2048) YC_(2048); else if (d.ny == 1024) YC_(1024); else if (d.ny == 512) YC_(512); else YC_(256);
 #undef YC_
         }
         prof_end(rec, st);
-        if (d.detrend) {  // the x-first path's fit kernel with the axes swapped: plane from the per-column fits
+        if (d.detrend) {  // plane from the per-column sums -> what pass 2 has to add back
             rec = prof_begin(P, "fasty_fit", st);
-            auto kf = &fastp2_fit_kernel;
-            XRFT_LAUNCH(kf, dim3((unsigned)gc), dim3(256), 3 * 256 * sizeof(double), st, (const double*)p.colfit, p.win_x, const_cast<float*>(p.corr), (int)d.nx, (int)d.detrend);
+            auto kf = &fasty_fit_kernel;
+            XRFT_LAUNCH(kf, dim3((unsigned)gc), dim3(256), 3 * 256 * sizeof(double), st, (const double*)p.colfit, p.win_x, const_cast<float*>(p.corr), (int)d.nx, (int)d.ny, (int)d.detrend);
             prof_end(rec, st);
         }
         rec = prof_begin(P, "fasty_rows", st);
