@@ -11,10 +11,12 @@ resident in HBM.  Batches shard over ranks as independent time slabs (weak scali
 no data-path collective.  value = GFFT/s = 1e-9 * (points transformed by all ranks) / (max-over-ranks wall time).
 
 Extra objects on the JSON line:
-  roofline     : the dominant kernel (longest total time): achieved = 8 B/point (4 B read + 4 B
-                 written per input point) * points per launch / average launch duration, durations from HIP events
-                 recorded by the library on the launch stream inside the timed region (xrfthip_plan_set_profiling).
-                 "path" repeats the computation for the whole call (all kernels + gaps).
+  roofline     : achieved = 8 B/point (4 B read + 4 B written per input point) * points per step / wall
+                 time of the step (all kernels + gaps), frac = achieved / 8 TB/s.  "kernel" holds the same figure for the
+                 longest kernel alone (its launch's points / its average launch duration, from HIP events recorded by
+                 the library on the launch stream inside the timed region, xrfthip_plan_set_profiling); "traffic" the
+                 HBM bytes of one step measured with rocprofv3 PMC counters (profiles/r02_traffic.json);
+                 "two_pass_ceiling" what the memory system allows any out-of-cache two-pass 2-D FFT (measured skeletons).
   cpu_baseline : the CPU oracle (numpy/scipy restatement of the reference; the reference itself needs xarray,
                  which the image lacks) timed on a bounded sample of the same workload, 1 thread.
 """
@@ -67,7 +69,8 @@ def main():
     ap.add_argument("--ny", type=int, default=4096)
     ap.add_argument("--nx", type=int, default=4096)
     ap.add_argument("--cpu-slabs", type=int, default=10, help="slabs timed through the CPU oracle on one thread (0 = skip)")
-    ap.add_argument("--cpu-pool", type=int, default=16, help="worker processes for the all-cores CPU figure, one slab each (0 = skip)")
+    ap.add_argument("--cpu-pool", type=int, default=-1, help="worker processes for the all-cores CPU figure, one slab each "
+                    "(-1 = as many as host cores, slabs and memory allow; 0 = skip)")
     ap.add_argument("--no-profile", action="store_true", help="do not record per-kernel HIP events")
     args = ap.parse_args()
 
@@ -147,7 +150,8 @@ def main():
 
     out = None
     if rank == 0:
-        # ---- roofline of the dominant kernel
+        # ---- roofline: achieved = algorithmic bytes / wall of the whole hot path; the dominant kernel's own
+        # figure (algorithmic bytes of its launch / its average launch duration) is kept beside it as `kernel`
         roof = None
         if prof:
             kern = {k: v for k, v in prof.items()}
@@ -156,28 +160,35 @@ def main():
             avg_s = 1e-3 * total_ms / launches
             launches_per_step = launches / args.steps
             pts_per_launch = float(nt) * ny * nx / launches_per_step
-            achieved = BYTES_PER_POINT * pts_per_launch / avg_s
+            k_achieved = BYTES_PER_POINT * pts_per_launch / avg_s
             kernel_ms = sum(v[1] for v in kern.values()) / args.steps
-            # HBM traffic of the dominant kernel from the committed PMC profile of this same command (rocprofv3 cannot run
-            # inside the timed process): bytes per slab x slabs per launch
+            path_achieved = BYTES_PER_POINT * value * 1e9 / world  # B/s per GPU
+            # HBM traffic of one step from the committed PMC profile of this same command (rocprofv3 cannot run inside the
+            # timed process): measured bytes per slab, all kernels, x slabs per step
             traffic = None
+            tnote = None
+            ceiling = None
             try:
-                with open(os.path.join(REPO, "profiles", "r01_traffic.json")) as fh:
+                with open(os.path.join(REPO, "profiles", "r02_traffic.json")) as fh:
                     tj = json.load(fh)
-                traffic = tj["kernels"][dom]["hbm_bytes_per_slab"] * (pts_per_launch / (ny * nx))
+                traffic = tj["path_hbm_bytes_per_slab"] * nt
+                tnote = tj.get("note")
+                ceiling = tj.get("two_pass_ceiling")
             except Exception:
                 traffic = None
             roof = {
-                "bound": "hbm", "kernel": dom, "achieved": round(achieved / 1e9, 2), "peak": HBM_PEAK / 1e9,
-                "unit": "GB/s", "frac": round(achieved / HBM_PEAK, 4), "traffic": traffic,
-                "traffic_note": "HBM bytes per launch from profiles/r01_traffic.json (rocprofv3 --pmc FETCH_SIZE x2 + "
-                                "WRITE_SIZE, separate passes); algorithmic bytes per launch = 8 B x points_per_launch",
-                "avg_launch_us": round(avg_s * 1e6, 2), "points_per_launch": pts_per_launch,
+                "bound": "hbm", "achieved": round(path_achieved / 1e9, 2), "peak": HBM_PEAK / 1e9, "unit": "GB/s",
+                "frac": round(path_achieved / HBM_PEAK, 4),
+                "definition": "algorithmic bytes (8 B per input point: 4 read + 4 written) of one step / wall time of the step, per GPU",
+                "traffic": traffic, "traffic_note": tnote,
+                "kernel": {"name": dom, "avg_launch_us": round(avg_s * 1e6, 2), "points_per_launch": pts_per_launch,
+                           "achieved": round(k_achieved / 1e9, 2), "frac": round(k_achieved / HBM_PEAK, 4),
+                           "definition": "algorithmic bytes of the slabs one launch of the longest kernel processes / its average "
+                                         "launch duration (HIP events on the launch stream inside the timed region)"},
                 "bytes_per_point": BYTES_PER_POINT,
                 "kernels_ms_per_step": {k: round(v[1] / args.steps, 3) for k, v in kern.items()},
-                "path": {"achieved": round(BYTES_PER_POINT * value, 2), "unit": "GB/s",
-                         "frac": round(BYTES_PER_POINT * value * 1e9 / HBM_PEAK / world, 4),
-                         "sum_kernels_ms_per_step": round(kernel_ms, 3)},
+                "sum_kernels_ms_per_step": round(kernel_ms, 3),
+                "two_pass_ceiling": ceiling,
             }
         # ---- CPU baseline (the oracle on a bounded sample, 1 thread) + parity of the same slabs
         cpu = None
@@ -206,7 +217,16 @@ def main():
                              f"{tc:.1f} s; host has {os.cpu_count()} cores"}
             got = ps.data[:ns].cpu().numpy()
             parity = float(np.abs(got - ref.values).max() / np.abs(ref.values).max())
-            npool = min(args.cpu_pool, os.cpu_count() or 1, nt)
+            # one slab per worker (what dask chunks {time: 1} would give the reference): as many workers as cores, slabs in the
+            # workload and memory allow (a slab's plane fit holds ~2.5 GB of float64 temporaries)
+            ncores = os.cpu_count() or 1
+            want = ncores if args.cpu_pool < 0 else args.cpu_pool
+            try:
+                import psutil
+                mem_cap = max(1, int(psutil.virtual_memory().available * 0.6 / 3.0e9))
+            except Exception:  # pragma: no cover
+                mem_cap = 16
+            npool = min(want, ncores, nt, mem_cap)
             if npool > 1:  # the same work spread over host cores, one slab per process (the reference would need dask for this)
                 import multiprocessing as mp
 
@@ -218,7 +238,8 @@ def main():
                         pool.map(_cpu_pool_slab, [(slabs[i], (coords["y"], coords["x"])) for i in range(npool)], chunksize=1)
                         tp = time.perf_counter() - t0
                     cpu["all_cores"] = {"value": round(1e-9 * npool * ny * nx / tp, 6), "unit": "GFFT/s", "cores": npool,
-                                        "sample": f"{npool} slabs, one per worker process (1 thread each), {tp:.1f} s"}
+                                        "sample": f"{npool} slabs, one per worker process (1 thread each), {tp:.1f} s; workers = "
+                                                  f"min(host cores {ncores}, slabs in the workload {nt}, memory cap {mem_cap})"}
                 except Exception as e:  # pragma: no cover
                     cpu["all_cores"] = {"error": repr(e)}
         out = {

@@ -304,7 +304,9 @@ __global__ void __launch_bounds__(YCols<NY>::THR, YCols<NY>::THR / 128) fasty_co
                 const cf ra = cscale(zk + zc, 0.5f), rb = cscale(mul_mi(zk - zc), 0.5f);
                 const unsigned off = ((((unsigned)(k / Y::RK) * (unsigned)nxb + (unsigned)xb) * 2u + set) * Y::LBS) + (k % Y::RK) * (2 * GY) + 2 * g;
                 F4 o; o.x = ra.re; o.y = ra.im; o.z = rb.re; o.w = rb.im;
-                if (!(XRFT_YDBG & 64) || o.x == 1.2345f) *reinterpret_cast<F4*>(w2s + off * 8u) = o;
+                // non-temporal: the next reader is another kernel, a whole group of slabs later; kept out of L2 the lines leave
+                // it to the input, whose 128-byte lines are shared by four workgroups (PMC: 1.34x over-fetch with plain stores)
+                if (!(XRFT_YDBG & 64) || o.x == 1.2345f) xrft_store_nt(reinterpret_cast<float*>(w2s + off * 8u), o);
             }
         }
         if (set == 0) __syncthreads();

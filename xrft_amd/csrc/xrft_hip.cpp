@@ -1139,62 +1139,79 @@ static int fasty_build_tcodes(xrfthip_plan* P, const int32_t* bm) {
 
 static bool fasty_on(const xrfthip_plan* P) { return P->yfirst && fast_on(P); }
 
-static int run_fasty(const xrfthip_plan* P, const float* in, void* out, double* iso, char* ws, hipStream_t st) {
+static void fasty_launch_cols(const xrfthip_plan* P, const FastY& p, long long gc, hipStream_t st, bool prof) {
+    const xrfthip_desc& d = P->d;
+    const YGeomRt C = ycols_geom(d.ny);
+    xrfthip_plan::ProfRec* rec = prof ? prof_begin(P, "fasty_cols", st) : nullptr;
+    const dim3 grid((unsigned)(gc * (d.nx / C.cw))), blk((unsigned)C.thr);
+#define YC_(NN) do { if (d.detrend) { auto k = &fasty_cols_kernel<NN, true>; XRFT_LAUNCH(k, grid, blk, C.lds, st, p); } \
+                     else { auto k = &fasty_cols_kernel<NN, false>; XRFT_LAUNCH(k, grid, blk, C.lds, st, p); } } while (0)
+    if (d.ny == 4096) YC_(4096); else if (d.ny == 2048) YC_(2048); else if (d.ny == 1024) YC_(1024); else if (d.ny == 512) YC_(512); else YC_(256);
+#undef YC_
+    prof_end(rec, st);
+    if (d.detrend) {  // plane from the per-column sums -> what pass 2 has to add back
+        rec = prof ? prof_begin(P, "fasty_fit", st) : nullptr;
+        auto kf = &fasty_fit_kernel;
+        XRFT_LAUNCH(kf, dim3((unsigned)gc), dim3(256), 3 * 256 * sizeof(double), st, (const double*)p.colfit, p.win_x, const_cast<float*>(p.corr), (int)d.nx, (int)d.ny, (int)d.detrend);
+        prof_end(rec, st);
+    }
+}
+
+static void fasty_launch_rows(const xrfthip_plan* P, const FastY& p, long long gc, hipStream_t st, bool prof) {
+    const xrfthip_desc& d = P->d;
+    const YGeomRt R = yrows_geom(d.nx);
+    const bool iso_on = (d.flags & XRFTHIP_ISO) != 0;
+    xrfthip_plan::ProfRec* rec = prof ? prof_begin(P, "fasty_rows", st) : nullptr;
+    const dim3 grid((unsigned)(gc * (P->y_nrow_pad / R.rk))), blk((unsigned)R.thr);
+    const size_t lds = R.lds + (iso_on ? (size_t)P->nbins * sizeof(double) : 0);
+#define YR_(NN) do { if (iso_on) { auto k = &fasty_rows_kernel<NN, true>; XRFT_LAUNCH(k, grid, blk, lds, st, p); } \
+                     else { auto k = &fasty_rows_kernel<NN, false>; XRFT_LAUNCH(k, grid, blk, lds, st, p); } } while (0)
+    if (d.nx == 4096) YR_(4096); else if (d.nx == 2048) YR_(2048); else if (d.nx == 1024) YR_(1024); else if (d.nx == 512) YR_(512); else YR_(256);
+#undef YR_
+    prof_end(rec, st);
+}
+
+// parameter block of one group of slabs [g0, g0 + gc): the intermediate and the fit tables sit in ring slot `slot` (of slot_slabs slabs each)
+static FastY fasty_params(const xrfthip_plan* P, const float* in, void* out, double* iso, char* ws, long long g0, long long gc, int slot, long long slot_slabs) {
     const xrfthip_desc& d = P->d;
     const size_t slab_pts = (size_t)d.ny * d.nx;
     const bool want_out = !(d.flags & XRFTHIP_NO_SPECTRUM_OUT);
     const bool iso_on = (d.flags & XRFTHIP_ISO) != 0;
-    const YGeomRt C = ycols_geom(d.ny), R = yrows_geom(d.nx);
+    const YGeomRt C = ycols_geom(d.ny);
+    const size_t s0 = (size_t)slot * slot_slabs;  // first slab of the slot inside the workspace arrays
+    FastY p{};
+    p.in = in + (size_t)g0 * slab_pts;
+    p.w2 = reinterpret_cast<cf*>(ws + P->off_w) + s0 * (size_t)P->y_nrow_pad * d.nx;
+    p.out = want_out ? (float*)out + (size_t)g0 * slab_pts : nullptr;
+    p.tw_x = reinterpret_cast<const cf*>(P->tw_fx.p);
+    p.tw_y = reinterpret_cast<const cf*>(P->tw_fy.p);
+    p.win_y = reinterpret_cast<const float*>(P->win[0].p ? P->win[0].p : P->ones4096.p);
+    p.win_x = reinterpret_cast<const float*>(P->win[1].p ? P->win[1].p : P->ones4096.p);
+    p.colfit = reinterpret_cast<double*>(ws + P->off_rowfit) + s0 * (size_t)d.nx * 4;
+    p.corr = reinterpret_cast<const float*>(ws + P->off_corr) + s0 * (size_t)d.nx * 2;
+    p.what0 = reinterpret_cast<const cf*>(P->ywhat0.p);
+    p.what1 = reinterpret_cast<const cf*>(P->ywhat1.p);
+    p.tcodes = reinterpret_cast<const unsigned*>(P->ytcodes.p);
+    p.iso = iso_on ? iso + (size_t)g0 * P->nbins : nullptr;
+    p.nbins = P->nbins;
+    p.ny = (int)d.ny; p.nx = (int)d.nx;
+    p.nrow_pad = P->y_nrow_pad;
+    p.l_cw = ilog2i(C.cw); p.l_rk = ilog2i(C.rk); p.l_2gy = ilog2i(2 * C.gxy);
+    p.detrend = d.detrend;
+    p.nslab = (int)gc;
+    p.shift_y = (d.flags & XRFTHIP_SHIFT_Y) ? (int)(d.ny / 2) : 0;
+    p.shift_x = (d.flags & XRFTHIP_SHIFT_X) ? (int)(d.nx / 2) : 0;
+    p.scale = (float)d.scale;
+    return p;
+}
+
+static int run_fasty(const xrfthip_plan* P, const float* in, void* out, double* iso, char* ws, hipStream_t st) {
+    const xrfthip_desc& d = P->d;
     for (long long g0 = 0; g0 < d.batch; g0 += P->G) {
         const long long gc = std::min<long long>(P->G, d.batch - g0);
-        FastY p{};
-        p.in = in + (size_t)g0 * slab_pts;
-        p.w2 = reinterpret_cast<cf*>(ws + P->off_w);
-        p.out = want_out ? (float*)out + (size_t)g0 * slab_pts : nullptr;
-        p.tw_x = reinterpret_cast<const cf*>(P->tw_fx.p);
-        p.tw_y = reinterpret_cast<const cf*>(P->tw_fy.p);
-        p.win_y = reinterpret_cast<const float*>(P->win[0].p ? P->win[0].p : P->ones4096.p);
-        p.win_x = reinterpret_cast<const float*>(P->win[1].p ? P->win[1].p : P->ones4096.p);
-        p.colfit = reinterpret_cast<double*>(ws + P->off_rowfit);
-        p.corr = reinterpret_cast<const float*>(ws + P->off_corr);
-        p.what0 = reinterpret_cast<const cf*>(P->ywhat0.p);
-        p.what1 = reinterpret_cast<const cf*>(P->ywhat1.p);
-        p.tcodes = reinterpret_cast<const unsigned*>(P->ytcodes.p);
-        p.iso = iso_on ? iso + (size_t)g0 * P->nbins : nullptr;
-        p.nbins = P->nbins;
-        p.ny = (int)d.ny; p.nx = (int)d.nx;
-        p.nrow_pad = P->y_nrow_pad;
-        p.l_cw = ilog2i(C.cw); p.l_rk = ilog2i(C.rk); p.l_2gy = ilog2i(2 * C.gxy);
-        p.detrend = d.detrend;
-        p.nslab = (int)gc;
-        p.shift_y = (d.flags & XRFTHIP_SHIFT_Y) ? (int)(d.ny / 2) : 0;
-        p.shift_x = (d.flags & XRFTHIP_SHIFT_X) ? (int)(d.nx / 2) : 0;
-        p.scale = (float)d.scale;
-        xrfthip_plan::ProfRec* rec = prof_begin(P, "fasty_cols", st);
-        {
-            const dim3 grid((unsigned)(gc * (d.nx / C.cw))), blk((unsigned)C.thr);
-#define YC_(NN) do { if (d.detrend) { auto k = &fasty_cols_kernel<NN, true>; XRFT_LAUNCH(k, grid, blk, C.lds, st, p); } \
-                     else { auto k = &fasty_cols_kernel<NN, false>; XRFT_LAUNCH(k, grid, blk, C.lds, st, p); } } while (0)
-            if (d.ny == 4096) YC_(4096); else if (d.ny == 2048) YC_(2048); else if (d.ny == 1024) YC_(1024); else if (d.ny == 512) YC_(512); else YC_(256);
-#undef YC_
-        }
-        prof_end(rec, st);
-        if (d.detrend) {  // plane from the per-column sums -> what pass 2 has to add back
-            rec = prof_begin(P, "fasty_fit", st);
-            auto kf = &fasty_fit_kernel;
-            XRFT_LAUNCH(kf, dim3((unsigned)gc), dim3(256), 3 * 256 * sizeof(double), st, (const double*)p.colfit, p.win_x, const_cast<float*>(p.corr), (int)d.nx, (int)d.ny, (int)d.detrend);
-            prof_end(rec, st);
-        }
-        rec = prof_begin(P, "fasty_rows", st);
-        {
-            const dim3 grid((unsigned)(gc * (P->y_nrow_pad / R.rk))), blk((unsigned)R.thr);
-            const size_t lds = R.lds + (iso_on ? (size_t)P->nbins * sizeof(double) : 0);
-#define YR_(NN) do { if (iso_on) { auto k = &fasty_rows_kernel<NN, true>; XRFT_LAUNCH(k, grid, blk, lds, st, p); } \
-                     else { auto k = &fasty_rows_kernel<NN, false>; XRFT_LAUNCH(k, grid, blk, lds, st, p); } } while (0)
-            if (d.nx == 4096) YR_(4096); else if (d.nx == 2048) YR_(2048); else if (d.nx == 1024) YR_(1024); else if (d.nx == 512) YR_(512); else YR_(256);
-#undef YR_
-        }
-        prof_end(rec, st);
+        const FastY p = fasty_params(P, in, out, iso, ws, g0, gc, 0, P->G);
+        fasty_launch_cols(P, p, gc, st, true);
+        fasty_launch_rows(P, p, gc, st, true);
         HIP_TRY(hipGetLastError());
     }
     return XRFTHIP_OK;
