@@ -21,8 +21,13 @@
  *     every `h_*` pointer is a HOST pointer, copied during the call;
  *   - arrays are C-contiguous [batch][ny][nx] (ny == 1 for 1-D transforms); the transform runs over the
  *     last `ndim` axes; `batch` slabs are independent;
- *   - xrfthip_exec never allocates, never synchronises, and enqueues everything on `stream`
- *     (a hipStream_t passed as void*; NULL = the default stream);
+ *   - a plan is immutable once created and its tables are set: xrfthip_plan_create and the xrfthip_plan_set_* calls build
+ *     every device table and the workspace layout (allocations, blocking copies, environment lookups happen THERE);
+ *     xrfthip_exec takes the plan as const, never allocates, never copies from the host, never synchronises, reads no
+ *     environment variable and enqueues everything on `stream` (a hipStream_t passed as void*; NULL = the default
+ *     stream).  It can be captured into a hipGraph from its first call, and one plan can be executed from several
+ *     threads at once, each with its own stream and workspace (exception: a plan with profiling switched on records
+ *     events into itself and is not re-entrant);
  *   - all functions return 0 on success or a negative xrfthip_status; nothing throws or aborts.
  *
  * Python binding: xrft_amd/_lib.py (ctypes).  A reference-side binding sketch is in INTEGRATION.md.
@@ -86,6 +91,11 @@ typedef enum xrfthip_detrend_kind {
 #define XRFTHIP_INVERSE 0x400u   /* ifftn: conj(FFT(conj(z))); the caller folds 1/prod(N) into `scale` */
 #define XRFTHIP_C2R_X 0x800u     /* irfftn: d_in0 is [batch][ny][nx/2+1] complex, Hermitian-extended on the fly; d_out is REAL [batch][ny][nx] */
 #define XRFTHIP_PHASE_IN 0x1000u /* the phase tables multiply the INPUT (indexed by source position) instead of the output (xrft.py:574-576) */
+/* Transform along a middle (or the first) axis in place, no transposed copy (the reference transforms any axes of the array
+ * where they lie, xrft.py:395-409): with ndim = 2 the array is [batch][ny][nx] and ONLY y is transformed, once per (slab,
+ * column); nx is the product of the trailing axes.  Detrending and the window act along y (one line / mean per column);
+ * the *_X flags, HALF_X, ISO and C2R_X do not apply.  Output [batch][ny][nx] in the same layout. */
+#define XRFTHIP_AXIS_Y 0x2000u
 
 typedef struct xrfthip_desc {
     uint32_t struct_size; /* = sizeof(xrfthip_desc) */

@@ -339,3 +339,44 @@ def test_concurrent_callers_share_a_plan():
     assert not errs
     for g_, w_ in zip(got, want):
         np.testing.assert_allclose(g_, w_, rtol=1e-12)  # (the detrend sums are accumulated with atomics: order varies)
+
+
+@pytest.mark.parametrize("dtype", ["float64", "float32", "complex128"])
+def test_inplace_middle_and_first_axis(dtype):
+    """Single-axis transforms along a middle / the first axis take the XRFTHIP_AXIS_Y plan (no transposed copy): fft, power
+    and cross spectra with per-column detrend and window, against the oracle."""
+    import xrft_amd as xa
+    from oracle import xrft_oracle as o
+
+    rng = np.random.default_rng(1)
+    v = rng.standard_normal((6, 20, 12))
+    if dtype.startswith("complex"):
+        v = v + 1j * rng.standard_normal(v.shape)
+    v = v.astype(dtype)
+    c = {"t": np.arange(6) * 2.0, "y": np.arange(20) * 0.5, "x": np.arange(12) * 0.25 + 1}
+    da, od = cases.pair(v, ("t", "y", "x"), c)
+    tol = 1e-5 if dtype == "float32" else 1e-10
+    for dim in ("y", "t"):
+        for det, win in ((None, None), ("linear", "hann"), ("constant", None)):
+            cases.check(xa.fft(da, dim=[dim], detrend=det, window=win), o.fft(od, dim=[dim], detrend=det, window=win), tol)
+            assert "y:col-only" in next(reversed(api._plan_cache.values())).describe()
+            cases.check(xa.power_spectrum(da, dim=[dim], detrend=det, window=win), o.power_spectrum(od, dim=[dim], detrend=det, window=win), tol)
+    da2, od2 = cases.pair((v * 2 + 1).astype(dtype), ("t", "y", "x"), c)
+    cases.check(xa.cross_spectrum(da, da2, dim=["y"], window="hann"), o.cross_spectrum(od, od2, dim=["y"], window="hann"), tol)
+    cases.check(xa.fft(da, dim=["y"], true_phase=False, shift=False), o.fft(od, dim=["y"], true_phase=False, shift=False), tol)
+
+
+def test_torch_conj_and_neg_views_are_resolved():
+    """torch's lazy conjugate / negative bits are materialised before the raw pointer reaches the library (x.conj(), x.mH)."""
+    import torch
+
+    import xrft_amd as xa
+
+    rng = np.random.default_rng(2)
+    z = rng.standard_normal((3, 16, 24)) + 1j * rng.standard_normal((3, 16, 24))
+    c = {"t": np.arange(3), "y": np.arange(16.0), "x": np.arange(24.0)}
+    tz = torch.from_numpy(z)
+    for view, ref in ((torch.conj(tz), np.conj(z)), (torch.conj(tz).imag, -z.imag), (-tz.real, -z.real)):
+        got = xa.fft(xa.DataArray(view, ("t", "y", "x"), c), dim=["y", "x"], true_phase=False, true_amplitude=False, shift=False)
+        want = np.fft.fftn(ref, axes=(1, 2))
+        assert np.abs(got.values - want).max() / np.abs(want).max() < 1e-12

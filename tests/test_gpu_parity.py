@@ -490,3 +490,134 @@ def test_huge_batch_of_short_series():
     got = xa.detrend(_da(v, ("t", "x"), c), "x", "linear")
     ref = o.detrend(o.OArr(v, ("t", "x"), c), "x", "linear")
     assert np.abs(got.values - ref.values).max() < 1e-10
+
+
+# ------------------------------------------------------------------------------------------------------
+# the C-ABI contract of include/xrft_hip.h: plans are immutable after creation, xrfthip_exec neither allocates nor
+# synchronises (graph-capturable from its first call), is re-entrant across threads, and transforms a middle / first
+# axis where it lies
+# ------------------------------------------------------------------------------------------------------
+def _fresh_plan(shape, dtype, **kw):
+    from xrft_amd import _lib, engine
+
+    nt, ny, nx = shape
+    return engine.SpectralPlan(ndim=2, batch=nt, ny=ny, nx=nx, dtype=dtype, out_mode=_lib.OUT_POWER,
+                               detrend=_lib.DETREND_LINEAR, flags=_lib.SHIFT_Y | _lib.SHIFT_X, scale=1.0, **kw)
+
+
+@pytest.mark.parametrize("shape,dtype", [((2, 256, 512), "float32"), ((3, 96, 80), "float64"), ((2, 50, 72), "float32")])
+def test_exec_is_graph_capturable_on_its_first_call(shape, dtype):
+    """xrfthip_exec of a plan that has never run is captured into a HIP graph (no allocation, no blocking copy, no
+    synchronisation inside), then replayed on two different inputs."""
+    import scipy.signal as sps
+
+    from xrft_amd import engine
+
+    tdt = getattr(torch, dtype)
+    nt, ny, nx = shape
+    plan = _fresh_plan(shape, tdt, window_y=sps.windows.hann(ny, sym=False), window_x=sps.windows.hann(nx, sym=False))
+    rng = np.random.default_rng(7)
+    data = [(rng.standard_normal(shape) + 0.01 * np.arange(nx)).astype(dtype) for _ in range(2)]
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        x = torch.zeros(shape, dtype=tdt, device="cuda")
+        out = torch.empty(shape, dtype=tdt, device="cuda")
+        engine._workspace(x.device, engine._stream_handle(x), plan.workspace_bytes)  # scratch exists before the capture
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, stream=s):
+        plan.execute(x, out=out)  # the plan's FIRST execution happens inside the capture
+    for v in data:
+        x.copy_(torch.from_numpy(v))
+        torch.cuda.synchronize()
+        g.replay()
+        torch.cuda.synchronize()
+        got = out.cpu().numpy().astype(np.float64)
+        # reference: the same plan executed eagerly (bit-for-bit: same kernels, same order)
+        eager, _ = plan.execute(torch.from_numpy(v).cuda())
+        torch.cuda.synchronize()
+        assert np.array_equal(got, eager.cpu().numpy().astype(np.float64))
+        # and the oracle's numbers: |fft2(w (d - plane))|^2, fftshifted
+        w = np.outer(sps.windows.hann(ny, sym=False), sps.windows.hann(nx, sym=False))
+        want = np.stack([np.fft.fftshift(np.abs(np.fft.fft2(o._detrend_2d_ufunc(vv.astype(np.float64)) * w)) ** 2) for vv in v])
+        assert np.abs(got - want).max() / want.max() < (1e-4 if dtype == "float32" else 1e-10)
+
+
+def test_one_plan_from_four_threads_without_a_lock():
+    """One immutable plan, four threads, each with its own stream, scratch and output, calling xrfthip_exec through
+    ctypes directly (no engine.py lock): every result equals the single-threaded one bit for bit."""
+    import ctypes as C
+    import threading
+
+    import scipy.signal as sps
+
+    from xrft_amd import _lib
+
+    shape = (4, 512, 256)
+    plan = _fresh_plan(shape, torch.float32, window_y=sps.windows.hann(512, sym=False), window_x=sps.windows.hann(256, sym=False))
+    dll = _lib.load()
+    rng = np.random.default_rng(11)
+    xs = [torch.from_numpy(rng.standard_normal(shape).astype(np.float32)).cuda() for _ in range(4)]
+    want = [plan.execute(x)[0].clone() for x in xs]
+    torch.cuda.synchronize()
+    nws = plan.workspace_bytes
+    outs = [torch.empty(shape, dtype=torch.float32, device="cuda") for _ in range(4)]
+    wss = [torch.empty(nws, dtype=torch.uint8, device="cuda") for _ in range(4)]
+    streams = [torch.cuda.Stream() for _ in range(4)]
+    torch.cuda.synchronize()
+    errs = []
+
+    def work(i):
+        try:
+            for _ in range(25):
+                rc = dll.xrfthip_exec(plan._h, C.c_void_p(xs[i].data_ptr()), C.c_void_p(0), C.c_void_p(outs[i].data_ptr()), C.c_void_p(0),
+                                      C.c_void_p(wss[i].data_ptr()), nws, C.c_void_p(streams[i].cuda_stream))
+                assert rc == 0, rc
+            streams[i].synchronize()
+        except Exception as e:  # pragma: no cover
+            errs.append(e)
+
+    th = [threading.Thread(target=work, args=(i,)) for i in range(4)]
+    for t_ in th:
+        t_.start()
+    for t_ in th:
+        t_.join()
+    torch.cuda.synchronize()
+    assert not errs, errs
+    for a, b in zip(outs, want):
+        assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("dim", ["y", "t"])
+@pytest.mark.parametrize("dtype", ["float32", "float64", "complex64"])
+def test_middle_and_first_axis_without_copies(dim, dtype):
+    """A transform along a middle or the first axis runs where the axis lies (XRFTHIP_AXIS_Y): no transposed copy of the
+    input or of the result -- the only device memory the call allocates is its result."""
+    import xrft_amd as xa
+    from xrft_amd import api
+
+    shape = (48, 200, 384)
+    rng = np.random.default_rng(5)
+    v = rng.standard_normal(shape)
+    if dtype.startswith("complex"):
+        v = v + 1j * rng.standard_normal(shape)
+    v = v.astype(dtype)
+    c = {"t": np.arange(shape[0]) * 2.0, "y": np.arange(shape[1]) * 0.5, "x": np.arange(shape[2]) * 0.25}
+    x = torch.from_numpy(v).cuda()
+    da = xa.DataArray(x, ("t", "y", "x"), c)
+    kw = dict(dim=[dim], detrend="linear", window="hann")
+    res = xa.fft(da, **kw)  # plan, tables and scratch exist after this call
+    assert "y:col-only" in next(reversed(api._plan_cache.values())).describe()
+    del res
+    torch.cuda.synchronize()
+    torch.cuda.reset_peak_memory_stats()
+    before = torch.cuda.memory_allocated()
+    res = xa.fft(da, **kw)
+    torch.cuda.synchronize()
+    peak = torch.cuda.max_memory_allocated() - before
+    out_bytes = res.data.numel() * res.data.element_size()
+    assert peak <= out_bytes + (1 << 20), (peak, out_bytes)  # a transposed copy of the input or the result would show here
+    ref = o.fft(o.OArr(v, ("t", "y", "x"), c), **kw)
+    cases.check(res, ref, 2e-4 if dtype in ("float32", "complex64") else 1e-10)
+    ps = xa.power_spectrum(da, **kw)
+    cases.check(ps, o.power_spectrum(o.OArr(v, ("t", "y", "x"), c), **kw), 2e-4 if dtype in ("float32", "complex64") else 1e-10)

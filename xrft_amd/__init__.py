@@ -9,7 +9,7 @@ There is no CPU fallback: the compute entry points raise ``XrftHipUnavailable`` 
 """
 from ._lib import XrftHipError, XrftHipUnavailable  # noqa: F401
 from .labeled import Coordinate, DataArray  # noqa: F401
-from .api import (cross_phase, cross_spectrum, detrend, dft, fft, fit_loglog, idft, ifft,  # noqa: F401
+from .api import (clear_plan_cache, cross_phase, cross_spectrum, detrend, dft, fft, fit_loglog, idft, ifft,  # noqa: F401
                   isotropic_cross_spectrum, isotropic_power_spectrum, isotropize, power_spectrum)
 from .padding import get_spacing, pad, unpad  # noqa: F401
 
@@ -17,4 +17,4 @@ __version__ = "0.1.0"
 __all__ = ["DataArray", "Coordinate", "fft", "ifft", "dft", "idft", "detrend", "power_spectrum", "cross_spectrum",
            "cross_phase", "isotropize",
            "isotropic_power_spectrum", "isotropic_cross_spectrum", "fit_loglog", "pad", "unpad", "get_spacing", "XrftHipError",
-           "XrftHipUnavailable"]
+           "XrftHipUnavailable", "clear_plan_cache"]

@@ -27,7 +27,7 @@ from pandas.api.types import is_datetime64_any_dtype, is_numeric_dtype
 from . import _lib, engine
 from .labeled import Coordinate, DataArray, from_any, to_like
 
-__all__ = ["fft", "ifft", "dft", "idft", "detrend", "power_spectrum", "cross_spectrum", "cross_phase", "isotropize",
+__all__ = ["clear_plan_cache", "fft", "ifft", "dft", "idft", "detrend", "power_spectrum", "cross_spectrum", "cross_phase", "isotropize",
            "isotropic_power_spectrum", "isotropic_cross_spectrum", "fit_loglog"]
 
 _WINDOW_NAMES = [  # xrft.py:48-72
@@ -205,7 +205,8 @@ _TORCH_OK = (torch.float32, torch.float64, torch.complex64, torch.complex128)
 def _to_device(data):
     dev = _lib.device()
     if isinstance(data, torch.Tensor):
-        t = data
+        # the C library reads raw memory: materialise torch's lazy conjugate / negative views (x.conj(), x.mH)
+        t = data.resolve_conj().resolve_neg()
     else:
         a = np.asarray(data)
         if a.dtype == np.float16:
@@ -248,6 +249,13 @@ def _get_plan(binmap_key=None, **kw):
         else:
             _plan_cache.move_to_end(key)
     return p
+
+
+def clear_plan_cache():
+    """Drop every cached plan (device tables) and the shared scratch buffers."""
+    with _plan_lock:
+        _plan_cache.clear()
+    engine.clear_workspaces()
 
 
 class _Ctx:
@@ -372,13 +380,15 @@ def _arrange(c, da):
 
 
 def _label_output(c, da, out_t, other, extra_cattrs=None, drop_transform=False):
-    """Wrap the engine output (other..., ky, kx) as a DataArray in the reference's dim order (xrft.py:451-476)."""
+    """Wrap the engine output (other..., ky, kx) as a DataArray in the reference's dim order (xrft.py:451-476).
+    ``other is None``: the output already has the input's dim order (in-place axis transform)."""
     tdims = ([c.ydim] if c.ydim is not None else []) + [c.xdim]
-    cur = other + [c.swap[d] for d in tdims]
     final = [c.swap.get(d, d) for d in c.rawdims]
-    out_t = out_t.reshape([da.sizes[d] for d in other] + list(out_t.shape[-len(tdims):]))
-    if cur != final:
-        out_t = out_t.permute([cur.index(d) for d in final])
+    if other is not None:
+        cur = other + [c.swap[d] for d in tdims]
+        out_t = out_t.reshape([da.sizes[d] for d in other] + list(out_t.shape[-len(tdims):]))
+        if cur != final:
+            out_t = out_t.permute([cur.index(d) for d in final])
     coords = {k: v for k, v in da.coords.items() if k not in c.dim}
     for name, cv in c.new_coords.items():
         attrs = dict(cv.attrs)
@@ -388,7 +398,59 @@ def _label_output(c, da, out_t, other, extra_cattrs=None, drop_transform=False):
     return DataArray(out_t, final, coords, None, None)
 
 
+def _inplace_axis(c, da, iso):
+    """Axis number k if the call is a single-axis transform along a middle or first axis that the engine can do where the
+    axis lies (XRFTHIP_AXIS_Y: the array is (batch, n, inner) with no transposed copy, like the reference, xrft.py:395-409)."""
+    if len(c.dim) != 1 or c.real_dim is not None or iso is not None:
+        return None
+    k = da.get_axis_num(c.xdim)
+    return k if k != len(da.dims) - 1 else None
+
+
+def _execute_axis_y(c, da, mode, scale, k, da2=None, c2=None):
+    """Single transform axis k < last: (batch, ny, nx) = (prod(shape[:k]), shape[k], prod(shape[k+1:])), y transformed in
+    place.  Returns the output tensor in the ORIGINAL dim order, or None if the plan cannot be built (column too long
+    for one LDS tile): the caller then takes the transposing path."""
+    t = _to_device(da.data).contiguous()  # C-contiguous input: no copy
+    shape = list(t.shape)
+    ny = shape[k]
+    nx = int(np.prod(shape[k + 1:], dtype=np.int64))
+    batch = int(np.prod(shape[:k], dtype=np.int64))
+    flags, win, ph = _flags_tables(c, da, None if c2 is None else c2.lag_x)
+    if mode == _lib.OUT_POWER:
+        ph = {"y": None, "x": None}
+    yflags = _lib.AXIS_Y
+    for fx, fy in ((_lib.SHIFT_X, _lib.SHIFT_Y), (_lib.ISHIFT_X, _lib.ISHIFT_Y), (_lib.FLIP_X, _lib.FLIP_Y)):
+        if flags & fx:
+            yflags |= fy
+    t2 = None
+    if da2 is not None:
+        if c2.reversed[0] != c.reversed[0] and c.true_phase:
+            return None
+        t2 = _to_device(da2.data).contiguous()
+        if tuple(da2.dims) != tuple(da.dims) or t2.shape != t.shape:
+            raise ValueError("The two datasets have different dimensions")
+        if t2.dtype != t.dtype:
+            dt = torch.promote_types(t.dtype, t2.dtype)
+            t, t2 = t.to(dt), t2.to(dt)
+    kw = dict(ndim=2, batch=batch, ny=ny, nx=nx, dtype=t.dtype, out_mode=mode, detrend=c.detrend, flags=yflags,
+              scale=float(scale), window_y=win["x"], window_x=None, phase_y=ph["x"], phase_x=None)
+    try:
+        plan = _get_plan(**kw)
+    except _lib.XrftHipError as e:
+        if e.status == _lib.UNSUPPORTED_LENGTH:
+            return None
+        raise
+    out, _ = plan.execute(t.reshape(batch, ny, nx), None if t2 is None else t2.reshape(batch, ny, nx))
+    return out.reshape(shape)
+
+
 def _execute(c, da, mode, scale, da2=None, c2=None, iso=None, extra_flags=0):
+    k = _inplace_axis(c, da, iso) if extra_flags == 0 else None
+    if k is not None:
+        out = _execute_axis_y(c, da, mode, scale, k, da2, c2)
+        if out is not None:
+            return out, None, None  # other = None: the output has the input's dim order
     t, other = _arrange(c, da)
     ndim = len(c.dim)
     nx = da.sizes[c.xdim]

@@ -23,8 +23,9 @@ __device__ __forceinline__ void block_sum(double* v, double* red /* >= NV*blockD
         for (int k = 0; k < NV; ++k) v[k] = red[k * n];
 }
 
-// acc[slab][6] += { sum x.re, sum x.im, sum (i-ibar) x.re, .. .im, sum (j-jbar) x.re, .. .im }
-// grid = (chunks, batch); every block reduces a contiguous run of rows of one slab.
+// part[slab][chunk][6] = { sum x.re, sum x.im, sum (i-ibar) x.re, .. .im, sum (j-jbar) x.re, .. .im } over the rows dealt to
+// block `chunk` of the slab; grid = (chunks, batch).  The finalize kernel adds the chunks in order: no atomics, the result
+// does not depend on the order in which blocks finish (bit-identical from run to run).
 template <typename T, bool CPLX>
 __global__ void __launch_bounds__(256) slab_moments_kernel(const void* in, long long ny, long long nx, long long slab_stride,
                                                           long long row_stride, double* acc) {
@@ -56,31 +57,58 @@ __global__ void __launch_bounds__(256) slab_moments_kernel(const void* in, long 
     }
     block_sum<6>(s, red);
     if (threadIdx.x == 0)
-        for (int k = 0; k < 6; ++k)
-            if (s[k] != 0.0) atomicAdd(&acc[b * 6 + k], s[k]);
+        for (int k = 0; k < 6; ++k) acc[(b * gridDim.x + blockIdx.x) * 6 + k] = s[k];
 }
 
 // One thread per slab.  Least squares on a full regular grid: the centred regressors (i-ibar), (j-jbar) are
 // orthogonal to each other and to 1, so the plane fit of detrend.py:100-113 (normal equations on [1, i+1, j+1])
 // and the line fit of scipy.signal.detrend (detrend.py:64-71) reduce to three independent ratios.
-__global__ void finalize_coef_kernel(const double* acc, double* coef, long long batch, long long ny, long long nx, int kind) {
+__global__ void finalize_coef_kernel(const double* part, double* coef, long long batch, long long ny, long long nx, int kind, int nchunk) {
     const long long b = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= batch) return;
+    double acc[6] = {0, 0, 0, 0, 0, 0};
+    for (int ch = 0; ch < nchunk; ++ch)
+        for (int k = 0; k < 6; ++k) acc[k] += part[(b * nchunk + ch) * 6 + k];
     const double n = (double)ny * (double)nx;
     const double ibar = 0.5 * (double)(ny - 1), jbar = 0.5 * (double)(nx - 1);
     const double sii = (double)nx * (double)ny * ((double)ny * (double)ny - 1.0) / 12.0;
     const double sjj = (double)ny * (double)nx * ((double)nx * (double)nx - 1.0) / 12.0;
     for (int c = 0; c < 2; ++c) {
-        const double mean = acc[b * 6 + c] / n;
+        const double mean = acc[c] / n;
         double c1 = 0.0, c2 = 0.0;
         if (kind == 2) {
-            if (ny > 1) c1 = acc[b * 6 + 2 + c] / sii;
-            if (nx > 1) c2 = acc[b * 6 + 4 + c] / sjj;
+            if (ny > 1) c1 = acc[2 + c] / sii;
+            if (nx > 1) c2 = acc[4 + c] / sjj;
         }
         coef[b * 6 + c] = mean - c1 * ibar - c2 * jbar;
         coef[b * 6 + 2 + c] = c1;
         coef[b * 6 + 4 + c] = c2;
     }
+}
+
+// XRFTHIP_AXIS_Y: one least-squares line per COLUMN of [slab][ny][nx] (scipy.signal.detrend along y, xrft/detrend.py:64-71,
+// or the column mean, :54-55).  One thread per column (lanes run along x: coalesced), rows in order: deterministic.
+// coef[(slab * nx + j) * 6] = { c0.re, c0.im, c1.re, c1.im, 0, 0 }, trend = c0 + c1 * i.
+template <typename T, bool CPLX>
+__global__ void __launch_bounds__(256) column_fit_kernel(const void* in, long long ny, long long nx, double* coef, int kind) {
+    const long long b = blockIdx.y, j = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= nx) return;
+    const double ibar = 0.5 * (double)(ny - 1);
+    double s0r = 0, s0i = 0, s1r = 0, s1i = 0;
+    for (long long i = 0; i < ny; ++i) {
+        const long long off = (b * ny + i) * nx + j;
+        double xr, xi = 0.0;
+        if (CPLX) { const C2<T> v = reinterpret_cast<const C2<T>*>(in)[off]; xr = (double)v.re; xi = (double)v.im; }
+        else xr = (double)reinterpret_cast<const T*>(in)[off];
+        const double di = (double)i - ibar;
+        s0r += xr; s1r = fma(di, xr, s1r);
+        if (CPLX) { s0i += xi; s1i = fma(di, xi, s1i); }
+    }
+    const double sii = (double)ny * ((double)ny * (double)ny - 1.0) / 12.0;
+    const double c1r = (kind == 2 && ny > 1) ? s1r / sii : 0.0, c1i = (kind == 2 && ny > 1) ? s1i / sii : 0.0;
+    double* c = coef + (b * nx + j) * 6;
+    c[0] = s0r / (double)ny - c1r * ibar; c[1] = s0i / (double)ny - c1i * ibar;
+    c[2] = c1r; c[3] = c1i; c[4] = 0.0; c[5] = 0.0;
 }
 
 template <typename T, bool CPLX>
@@ -140,23 +168,25 @@ __global__ void __launch_bounds__(256) block3_moments_kernel(const void* in, lon
         s[4] += ((double)j - jbar) * q0r; s[5] += ((double)j - jbar) * q0i;
     }
     block_sum<8>(s, red);
-    if (threadIdx.x == 0)
-        for (int k = 0; k < 8; ++k)
-            if (s[k] != 0.0) atomicAdd(&acc[b * 8 + k], s[k]);
+    if (threadIdx.x == 0)  // per-chunk partial sums, added in order by the finalize kernel (deterministic)
+        for (int k = 0; k < 8; ++k) acc[(b * gridDim.x + blockIdx.x) * 8 + k] = s[k];
 }
 
 // the centred regressors of a full grid are mutually orthogonal: four independent ratios (constant: only the mean)
-__global__ void finalize_coef3_kernel(const double* acc, double* coef, long long batch, long long n0, long long n1, long long n2, int kind) {
+__global__ void finalize_coef3_kernel(const double* part, double* coef, long long batch, long long n0, long long n1, long long n2, int kind, int nchunk) {
     const long long b = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= batch) return;
+    double acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int ch = 0; ch < nchunk; ++ch)
+        for (int k = 0; k < 8; ++k) acc[k] += part[(b * nchunk + ch) * 8 + k];
     const double n = (double)n0 * (double)n1 * (double)n2;
     const double bar[3] = {0.5 * (double)(n0 - 1), 0.5 * (double)(n1 - 1), 0.5 * (double)(n2 - 1)};
     const double len[3] = {(double)n0, (double)n1, (double)n2};
     for (int c = 0; c < 2; ++c) {
-        double c0 = acc[b * 8 + c] / n;
+        double c0 = acc[c] / n;
         for (int a = 0; a < 3; ++a) {
             double sl = 0.0;
-            if (kind == 2 && len[a] > 1.0) sl = acc[b * 8 + 2 + 2 * a + c] / (n * (len[a] * len[a] - 1.0) / 12.0);
+            if (kind == 2 && len[a] > 1.0) sl = acc[2 + 2 * a + c] / (n * (len[a] * len[a] - 1.0) / 12.0);
             coef[b * 8 + 2 + 2 * a + c] = sl;
             c0 -= sl * bar[a];
         }

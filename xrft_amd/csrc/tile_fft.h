@@ -250,6 +250,8 @@ struct Prologue {  // first pass: xrft.py:425-442
     const void* ph_x;
     int conj_in;         // conjugate after the phase multiply (ifft = conj(FFT(conj z)) / N)
     int herm_nxh;        // > 0: the source row holds only kx = 0..herm_nxh-1; kx >= herm_nxh is conj(src[-ky][nx-kx]) (irfftn)
+    int p_is_row;        // XRFTHIP_AXIS_Y: the pass transforms y of [slab][ny][nx] in place: point p is the row i, q the column j,
+                         // and the trend coefficients are per column: coef[(slab * nx + j) * 6]
 };
 
 struct Epilogue {  // last pass: xrft.py:446-472, 740-748, 825-833, 993-1004
@@ -311,7 +313,7 @@ __device__ __forceinline__ C2<T> fetch_src(const Prologue& pr, long long b, int 
     if (pr.in_complex) v = reinterpret_cast<const C2<T>*>(pr.in)[off];
     else v = mk<T>(reinterpret_cast<const T*>(pr.in)[off], (T)0);
     if (pr.detrend) {
-        const double* c = pr.coef + b * 6;
+        const double* c = pr.coef + (pr.p_is_row ? b * pr.nx + sj : b) * 6;
         v.re = (T)((double)v.re - (c[0] + c[2] * si + c[4] * sj));
         if (pr.in_complex) v.im = (T)((double)v.im - (c[1] + c[3] * si + c[5] * sj));
     }
@@ -734,7 +736,7 @@ __global__ void __launch_bounds__(MAXT) tile_fft_kernel(TileGeom g, Prologue pr,
                                 const C2<T> x1 = fetch_src<T>(pr, b, i, 2 * p + 1);
                                 v = mk<T>(x0.re, x1.re);
                             } else {
-                                v = fetch_src<T>(pr, b, i, (int)(p * pr.j_mul_p + q * pr.j_mul_q));
+                                v = pr.p_is_row ? fetch_src<T>(pr, b, p, (int)q) : fetch_src<T>(pr, b, i, (int)(p * pr.j_mul_p + q * pr.j_mul_q));
                             }
                         } else {
                             v = gin[o * g.in_so + q * g.in_sq + (long long)p * g.in_sp];

@@ -275,6 +275,7 @@ struct xrfthip_plan {
     long long nxh = 0, width = 0, nx_out = 0, w_cols = 0;  // w_cols: columns of the row->column intermediate incl. tile padding
     bool mirror = false;
     int G = 1;
+    int mom_chunks = 1;  // blocks per slab of the moments pass (partial sums added in order: deterministic)
     std::map<int, FftTables> tables;
     std::vector<DevBuf*> extra;  // r2c / four-step twiddles
     DevBuf win[2], phase[2], binmap;
@@ -289,16 +290,15 @@ struct xrfthip_plan {
     int fast_ntile = 0, fast_ntile_pad = 0;
     DevBuf tw_fx, tw_fy, ones4096, what0, what1, tcodes, fph[2];
     std::vector<double> host_phase[2];  // complex, as handed to xrfthip_plan_set_phase (empty = none)
-    bool fph_dirty = true;
-    bool what_dirty = true;
     std::vector<double> host_win_x;
     // two-pass "y first" pipeline for full power spectra (fasty.h): columns -> [fit] -> rows, no untile pass
     bool yfirst = false;
     int y_nrow_pad = 0;  // rows ky = 0..ny/2 of the intermediate, rounded up to what one row workgroup covers
     DevBuf ywhat0, ywhat1, ytcodes;
     std::vector<double> host_win_y;
-    bool ywhat_dirty = true;
-    // optional per-pass event timing (bench only)
+    // tuning knobs from the environment, read once when the plan is created (never in xrfthip_exec)
+    long long tune_group = 0, tune_fast_group = 0, tune_group_bytes = 512LL << 20, tune_cols_grid = 256, tune_max_grid = 8192;
+    // optional per-pass event timing (bench only; a plan with profiling on is not re-entrant)
     bool prof = false;
     struct ProfRec { std::string label; hipEvent_t a, b; };
     std::vector<ProfRec> prof_recs;
@@ -666,7 +666,33 @@ struct Builder {
         return XRFTHIP_OK;
     }
 
+    // XRFTHIP_AXIS_Y: one column pass that is first AND final -- reads the caller's [slab][ny][nx] array with the prologue
+    // (point p = row, q = column) and writes the result in the same layout
+    int build_yonly(std::vector<Pass>& out, bool raw) {
+        const xrfthip_desc& d = P.d;
+        TileChoice c = choose_tile(d.ny, P.csize, true, d.nx, 0);
+        if (c.T == 0) return XRFTHIP_UNSUPPORTED_LENGTH;  // (longer columns: transpose on the caller's side and use a 1-D plan)
+        Pass ps;
+        ps.label = "y:col-only";
+        int rc = set_fft(ps, (int)d.ny);
+        if (rc) return rc;
+        apply_tile(ps, c);
+        ps.g.n_out = (int)d.ny;
+        ps.g.tile_axis = 1;
+        ps.g.in_fast = 1;
+        ps.g.out_fast = 1;
+        ps.g.inner = d.nx;
+        ps.g.tiles_per_outer = (d.nx + c.T - 1) / c.T;
+        ps.outer_per_slab = 1;
+        fill_prologue(ps, 1, 0, 0);
+        ps.pr.p_is_row = 1;
+        fill_epilogue(ps, raw, 1, 1);
+        out.push_back(ps);
+        return XRFTHIP_OK;
+    }
+
     int build_pipeline(std::vector<Pass>& out, bool raw) {
+        if (P.d.flags & XRFTHIP_AXIS_Y) return build_yonly(out, raw);
         int rc = build_x(out, raw);
         if (rc) return rc;
         if (P.d.ndim == 2) rc = build_y(out, raw);
@@ -807,16 +833,16 @@ static bool fast_on(const xrfthip_plan* P);
 static void layout_workspace(xrfthip_plan* P) {
     const xrfthip_desc& d = P->d;
     const bool fast = fast_on(P);
-    long long G = d.slabs_per_group > 0 ? d.slabs_per_group : env_ll("XRFTHIP_GROUP", 0);
+    long long G = d.slabs_per_group > 0 ? d.slabs_per_group : P->tune_group;
     size_t slab_w = (size_t)d.ny * std::max(P->width, P->w_cols) * P->csize;
     const bool yf = fast && P->yfirst;
     if (fast) {
         slab_w = yf ? (size_t)P->y_nrow_pad * d.nx * sizeof(cf) : (size_t)P->fast_ntile_pad * d.ny * 4 * sizeof(cf);
-        if (G <= 0) G = env_ll("XRFTHIP_FAST_GROUP", std::max<long long>(1, (32LL * 4096 * 4096) / (d.ny * d.nx)));  // measured 8: 197, 16: 210, 32: 214 GFFT/s (tails and launch gaps amortise)
+        if (G <= 0) G = P->tune_fast_group > 0 ? P->tune_fast_group : std::max<long long>(1, (32LL * 4096 * 4096) / (d.ny * d.nx));  // measured 8: 197, 16: 210, 32: 214 GFFT/s (tails and launch gaps amortise)
     }
     if (G <= 0) {
         // the Infinity Cache adds no bandwidth, so groups are sized for launch efficiency, not residency
-        const size_t target = (size_t)env_ll("XRFTHIP_GROUP_BYTES", 512LL << 20);
+        const size_t target = (size_t)P->tune_group_bytes;
         G = (long long)std::max<size_t>(1, target / std::max<size_t>(slab_w, 1));
     }
     G = std::max<long long>(1, std::min<long long>(G, std::max<long long>(d.batch, 1)));
@@ -824,8 +850,10 @@ static void layout_workspace(xrfthip_plan* P) {
     auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
     const int nf = (d.out_mode == XRFTHIP_OUT_CROSS || d.out_mode == XRFTHIP_OUT_PHASE) ? 2 : 1;
     size_t off = 0;
-    P->off_acc = off; off = al(off + (size_t)d.batch * 6 * sizeof(double) * nf);
-    P->off_coef = off; off = al(off + (size_t)d.batch * 6 * sizeof(double) * nf);
+    const size_t ncoef = (size_t)d.batch * ((d.flags & XRFTHIP_AXIS_Y) ? (size_t)d.nx : 1);  // trend per slab, or per column
+    P->mom_chunks = (int)std::max<long long>(1, std::min<long long>(d.ny, (2048 + G - 1) / G));
+    P->off_acc = off; off = al(off + (size_t)G * P->mom_chunks * 6 * sizeof(double) * nf);  // per-chunk partial sums of ONE group of slabs
+    P->off_coef = off; off = al(off + ncoef * 6 * sizeof(double) * nf);
     bool need_w = d.ndim == 2, need_w2 = false;
     for (const Pass& p : P->passes) { if (p.out_kind == B_W2) need_w2 = true; if (p.out_kind == B_W) need_w = true; }
     P->off_w = off; if (need_w) off = al(off + (size_t)G * slab_w);
@@ -860,21 +888,35 @@ template <typename T>
 static int run_moments(const xrfthip_plan* P, const void* in, long long g0, long long gc, double* acc, double* coef, hipStream_t st) {
     const xrfthip_desc& d = P->d;
     const long long total = d.ny * d.nx;
-    long long chunks = std::max<long long>(1, std::min<long long>(d.ny, std::max<long long>(1, (2048 + gc - 1) / gc)));
+    const long long chunks = P->mom_chunks;
     const size_t esz = P->cplx_in ? P->csize : P->rsize;
+    if (d.flags & XRFTHIP_AXIS_Y) {  // one line (or mean) per column, straight into the coefficient table
+        xrfthip_plan::ProfRec* recc = prof_begin(P, "column_fit", st);
+        for (long long b0 = 0; b0 < gc; b0 += 32768) {
+            const long long bc = std::min<long long>(32768, gc - b0);
+            const dim3 grid((unsigned)((d.nx + 255) / 256), (unsigned)bc), block(256);
+            const void* src = (const char*)in + (size_t)(g0 + b0) * total * esz;
+            double* cdst = coef + (g0 + b0) * d.nx * 6;
+            if (P->cplx_in) { auto k = &column_fit_kernel<T, true>; XRFT_LAUNCH(k, grid, block, 0, st, src, (long long)d.ny, (long long)d.nx, cdst, (int)d.detrend); }
+            else { auto k = &column_fit_kernel<T, false>; XRFT_LAUNCH(k, grid, block, 0, st, src, (long long)d.ny, (long long)d.nx, cdst, (int)d.detrend); }
+        }
+        prof_end(recc, st);
+        HIP_TRY(hipGetLastError());
+        return XRFTHIP_OK;
+    }
     const size_t lds = 6 * 256 * sizeof(double);
     xrfthip_plan::ProfRec* rec = prof_begin(P, "moments", st);
     for (long long b0 = 0; b0 < gc; b0 += 32768) {  // grid.y is limited to 65535 blocks
         const long long bc = std::min<long long>(32768, gc - b0);
         const dim3 grid((unsigned)chunks, (unsigned)bc), block(256);
         const void* src = (const char*)in + (size_t)(g0 + b0) * total * esz;
-        if (P->cplx_in) { auto k = &slab_moments_kernel<T, true>; XRFT_LAUNCH(k, grid, block, lds, st, src, (long long)d.ny, (long long)d.nx, total, (long long)d.nx, acc + (g0 + b0) * 6); }
-        else { auto k = &slab_moments_kernel<T, false>; XRFT_LAUNCH(k, grid, block, lds, st, src, (long long)d.ny, (long long)d.nx, total, (long long)d.nx, acc + (g0 + b0) * 6); }
+        if (P->cplx_in) { auto k = &slab_moments_kernel<T, true>; XRFT_LAUNCH(k, grid, block, lds, st, src, (long long)d.ny, (long long)d.nx, total, (long long)d.nx, acc + b0 * chunks * 6); }
+        else { auto k = &slab_moments_kernel<T, false>; XRFT_LAUNCH(k, grid, block, lds, st, src, (long long)d.ny, (long long)d.nx, total, (long long)d.nx, acc + b0 * chunks * 6); }
     }
     prof_end(rec, st);
     rec = prof_begin(P, "finalize_coef", st);
     auto kf = &finalize_coef_kernel;
-    XRFT_LAUNCH(kf, dim3((unsigned)((gc + 63) / 64)), dim3(64), 0, st, (const double*)(acc + g0 * 6), coef + g0 * 6, gc, (long long)d.ny, (long long)d.nx, (int)d.detrend);
+    XRFT_LAUNCH(kf, dim3((unsigned)((gc + 63) / 64)), dim3(64), 0, st, (const double*)acc, coef + g0 * 6, gc, (long long)d.ny, (long long)d.nx, (int)d.detrend, (int)chunks);
     prof_end(rec, st);
     HIP_TRY(hipGetLastError());
     return XRFTHIP_OK;
@@ -899,7 +941,6 @@ static int fast4096_window_spectra(xrfthip_plan* P) {
     }
     int rc = P->what0.upload(h0.data(), h0.size() * sizeof(cf));
     if (!rc) rc = P->what1.upload(h1.data(), h1.size() * sizeof(cf));
-    if (!rc) P->what_dirty = false;
     return rc;
 }
 
@@ -931,7 +972,6 @@ static int fast_phase_tables(xrfthip_plan* P) {
         int rc = P->fph[ax].upload(t.data(), t.size() * sizeof(cf));
         if (rc) return rc;
     }
-    P->fph_dirty = false;
     return XRFTHIP_OK;
 }
 
@@ -978,7 +1018,7 @@ static void fast_launch_cols(const xrfthip_plan* P, const FastP2& p, long long g
     const long long tpu = fast_cols_gy(d.ny, iso_plan) / 4;
     const int cthr = fast_cols_threads(d.ny, iso_plan);
     const long long nunits = gc * (P->fast_ntile_pad / tpu);
-    long long grid = std::min<long long>(env_ll("XRFTHIP_FAST_COLS_GRID", kCUs), ((nunits + 63) / 64) * 64);
+    long long grid = std::min<long long>(P->tune_cols_grid, ((nunits + 63) / 64) * 64);
     grid = std::max<long long>(64, (grid / 64) * 64);
     const size_t lds = fast_cols_lds(d.ny, iso_plan) + (ISO ? (size_t)P->nbins * sizeof(double) * (MODE == 2 ? 2 : 1) : 0);
 #define COLS_(NN, TT) do { auto k = &fastp2_cols_kernel<NN, TT, MODE, ISO>; XRFT_LAUNCH(k, dim3((unsigned)grid), dim3((unsigned)cthr), lds, st, p); } while (0)
@@ -1107,7 +1147,6 @@ static int fasty_window_spectra(xrfthip_plan* P) {
     int rc = P->ywhat0.upload(h0.data(), h0.size() * sizeof(cf));
     if (!rc) rc = P->ywhat1.upload(h1.data(), h1.size() * sizeof(cf));
 
-    if (!rc) P->ywhat_dirty = false;
     return rc;
 }
 
@@ -1217,6 +1256,23 @@ static int run_fasty(const xrfthip_plan* P, const float* in, void* out, double* 
     return XRFTHIP_OK;
 }
 
+// Everything xrfthip_exec needs beyond the caller's buffers is built HERE, when the plan is created or one of its tables is
+// set: window spectra and phase tables of the specialised paths (device allocations + blocking copies) and the workspace
+// layout.  xrfthip_exec itself takes the plan as const: no allocation, no copy, no synchronisation, no getenv.
+static int finalize_plan(xrfthip_plan* P) {
+    if (P->fast4096) {
+        int rc = XRFTHIP_OK;
+        if (P->yfirst) rc = fasty_window_spectra(P);
+        else {
+            rc = fast4096_window_spectra(P);
+            if (!rc && P->d.out_mode != XRFTHIP_OUT_POWER) rc = fast_phase_tables(P);
+        }
+        if (rc) return rc;
+    }
+    layout_workspace(P);
+    return XRFTHIP_OK;
+}
+
 template <typename T>
 static int run_pipeline(const xrfthip_plan* P, const std::vector<Pass>& passes, const void* in, void* out, double* iso,
                         char* ws, const double* coef, long long g0, long long gc, hipStream_t st) {
@@ -1238,7 +1294,7 @@ static int run_pipeline(const xrfthip_plan* P, const std::vector<Pass>& passes, 
             p.pr.in = (const char*)in + (size_t)g0 * d.ny * ((d.flags & XRFTHIP_C2R_X) ? d.nx / 2 + 1 : d.nx) * in_esz;
             p.pr.win_y = P->win[0].p;
             p.pr.win_x = P->win[1].p;
-            p.pr.coef = coef ? coef + g0 * 6 : nullptr;
+            p.pr.coef = coef ? coef + g0 * ((d.flags & XRFTHIP_AXIS_Y) ? d.nx : 1) * 6 : nullptr;
             if (!coef) p.pr.detrend = 0;
             if (d.flags & XRFTHIP_PHASE_IN) { p.pr.ph_y = P->phase[0].p; p.pr.ph_x = P->phase[1].p; }
         } else {
@@ -1263,7 +1319,7 @@ static int run_pipeline(const xrfthip_plan* P, const std::vector<Pass>& passes, 
             p.g.out = buf(p.out_kind);
         }
         if (p.g.n_tiles <= 0) continue;
-        const int grid = (int)std::min<long long>(p.g.n_tiles, env_ll("XRFTHIP_MAX_GRID", 8 * kCUs * 4));
+        const int grid = (int)std::min<long long>(p.g.n_tiles, P->tune_max_grid);
         xrfthip_plan::ProfRec* rec = prof_begin(P, p.label, st);
         launch_tile<T>(p, grid, st);
         prof_end(rec, st);
@@ -1312,10 +1368,17 @@ int xrfthip_plan_create(xrfthip_plan** plan, const xrfthip_desc* desc) {
     if ((d.flags & XRFTHIP_ISO) && (d.ndim != 2 || d.out_mode == XRFTHIP_OUT_COMPLEX)) return XRFTHIP_BAD_ARG;
     if ((d.flags & XRFTHIP_NO_SPECTRUM_OUT) && !(d.flags & XRFTHIP_ISO)) return XRFTHIP_BAD_ARG;
     if (d.ndim == 1 && (d.flags & (XRFTHIP_SHIFT_Y | XRFTHIP_ISHIFT_Y | XRFTHIP_FLIP_Y))) return XRFTHIP_BAD_ARG;
+    if ((d.flags & XRFTHIP_AXIS_Y) && (d.ndim != 2 || (d.flags & (XRFTHIP_SHIFT_X | XRFTHIP_ISHIFT_X | XRFTHIP_FLIP_X | XRFTHIP_HALF_X | XRFTHIP_REALDIM_X2 |
+                                                                    XRFTHIP_ISO | XRFTHIP_NO_SPECTRUM_OUT | XRFTHIP_C2R_X | XRFTHIP_PHASE_IN)))) return XRFTHIP_BAD_ARG;
 
     xrfthip_plan* P = new (std::nothrow) xrfthip_plan();
     if (!P) return XRFTHIP_ALLOC_FAILED;
     P->d = d;
+    P->tune_group = env_ll("XRFTHIP_GROUP", 0);
+    P->tune_fast_group = env_ll("XRFTHIP_FAST_GROUP", 0);
+    P->tune_group_bytes = env_ll("XRFTHIP_GROUP_BYTES", 512LL << 20);
+    P->tune_cols_grid = env_ll("XRFTHIP_FAST_COLS_GRID", kCUs);
+    P->tune_max_grid = env_ll("XRFTHIP_MAX_GRID", 8 * kCUs * 4);
     P->cplx_in = cplx_in;
     P->dbl = d.dtype == XRFTHIP_F64 || d.dtype == XRFTHIP_C128;
     P->rsize = P->dbl ? 8 : 4;
@@ -1325,12 +1388,13 @@ int xrfthip_plan_create(xrfthip_plan** plan, const xrfthip_desc* desc) {
     // width of the intermediate: the half spectrum for real input, unless the row does not fit one LDS tile
     // (four-step along x computes every kx) -- decided inside build_x through P->width.
     P->width = P->nxh;
-    if (!cplx_in) {
+    if (d.flags & XRFTHIP_AXIS_Y) P->width = d.nx;  // x is not transformed: every column is its own sequence
+    else if (!cplx_in) {
         const long long n_try = (d.nx % 2 == 0 && d.nx >= 2) ? d.nx / 2 : d.nx;
         TileChoice c = choose_tile(n_try, P->csize, false, 1LL << 40, 0);
         if (c.T == 0 || n_try >= env_ll("XRFTHIP_X_FOURSTEP_MIN", 1LL << 40)) P->width = d.nx;
     }
-    P->mirror = !cplx_in && !(d.flags & XRFTHIP_HALF_X) && P->width == d.nx / 2 + 1 && d.nx > 1;
+    P->mirror = !cplx_in && !(d.flags & (XRFTHIP_HALF_X | XRFTHIP_AXIS_Y)) && P->width == d.nx / 2 + 1 && d.nx > 1;
     auto fast_len = [](long long n) { return n == 256 || n == 512 || n == 1024 || n == 2048 || n == 4096; };
     {
         const uint32_t shifts = XRFTHIP_SHIFT_Y | XRFTHIP_SHIFT_X, ish = XRFTHIP_ISHIFT_Y | XRFTHIP_ISHIFT_X, isof = XRFTHIP_ISO | XRFTHIP_NO_SPECTRUM_OUT;
@@ -1362,6 +1426,7 @@ int xrfthip_plan_create(xrfthip_plan** plan, const xrfthip_desc* desc) {
     // (re)built in xrfthip_plan_set_binmap.  Build now for everything else.
     int rc = XRFTHIP_OK;
     if (!(d.flags & XRFTHIP_ISO)) rc = P->dbl ? build_plan_t<double>(*P) : build_plan_t<float>(*P);
+    if (!rc) rc = finalize_plan(P);
     if (rc) { delete P; return rc; }
     *plan = P;
     return XRFTHIP_OK;
@@ -1375,14 +1440,11 @@ int xrfthip_plan_destroy(xrfthip_plan* plan) {
 int xrfthip_plan_set_window(xrfthip_plan* plan, int axis, const double* h_window, int64_t n) {
     if (!plan || axis < 0 || axis > 1) return XRFTHIP_BAD_ARG;
     if (h_window && n != (axis == 0 ? plan->d.ny : plan->d.nx)) return XRFTHIP_BAD_ARG;
-    if (axis == 1) {
-        plan->host_win_x.assign(h_window ? h_window : nullptr, h_window ? h_window + n : nullptr);
-        plan->what_dirty = true;
-    } else {
-        plan->host_win_y.assign(h_window ? h_window : nullptr, h_window ? h_window + n : nullptr);
-        plan->ywhat_dirty = true;
-    }
-    return upload_real_table(plan, plan->win[axis], h_window, n, 0);
+    if (axis == 1) plan->host_win_x.assign(h_window ? h_window : nullptr, h_window ? h_window + n : nullptr);
+    else plan->host_win_y.assign(h_window ? h_window : nullptr, h_window ? h_window + n : nullptr);
+    int rc = upload_real_table(plan, plan->win[axis], h_window, n, 0);
+    if (!rc) rc = finalize_plan(plan);
+    return rc;
 }
 
 int xrfthip_plan_set_phase(xrfthip_plan* plan, int axis, const double* h_phase, int64_t n) {
@@ -1391,8 +1453,9 @@ int xrfthip_plan_set_phase(xrfthip_plan* plan, int axis, const double* h_phase, 
     const int64_t want = axis == 0 ? plan->d.ny : ((plan->d.flags & XRFTHIP_C2R_X) ? plan->d.nx / 2 + 1 : plan->d.nx);
     if (h_phase && n != want) return XRFTHIP_BAD_ARG;
     plan->host_phase[axis].assign(h_phase ? h_phase : nullptr, h_phase ? h_phase + 2 * n : nullptr);
-    plan->fph_dirty = true;
-    return upload_real_table(plan, plan->phase[axis], h_phase, n, 1);
+    int rc = upload_real_table(plan, plan->phase[axis], h_phase, n, 1);
+    if (!rc) rc = finalize_plan(plan);  // (a non-trivial phase can take an isotropic cross spectrum off the specialised path: new layout)
+    return rc;
 }
 
 // the bin map re-ordered the way the column pass holds its results (fastp2_cols_kernel): [unit][slot][column][u],
@@ -1452,7 +1515,9 @@ int xrfthip_plan_set_binmap(xrfthip_plan* plan, const int32_t* h_binmap, int64_t
     }
     plan->passes.clear();
     plan->passes_f0.clear();
-    return plan->dbl ? build_plan_t<double>(*plan) : build_plan_t<float>(*plan);
+    int rcb = plan->dbl ? build_plan_t<double>(*plan) : build_plan_t<float>(*plan);
+    if (!rcb) rcb = finalize_plan(plan);
+    return rcb;
 }
 
 int xrfthip_plan_set_profiling(xrfthip_plan* plan, int enable) {
@@ -1485,13 +1550,11 @@ int xrfthip_plan_profile_read(xrfthip_plan* plan, char* buf, size_t buflen) {
 
 size_t xrfthip_workspace_bytes(const xrfthip_plan* plan) {
     if (!plan) return 0;
-    layout_workspace(const_cast<xrfthip_plan*>(plan));
     return plan->ws_bytes;
 }
 
 int xrfthip_plan_describe(const xrfthip_plan* plan, char* buf, size_t buflen) {
     if (!plan || !buf || !buflen) return XRFTHIP_BAD_ARG;
-    layout_workspace(const_cast<xrfthip_plan*>(plan));
     std::string s;
     const xrfthip_desc& d = plan->d;
     appendf(s, "xrfthip plan: ndim=%d batch=%lld ny=%lld nx=%lld dtype=%d mode=%d detrend=%d flags=0x%x width=%lld nx_out=%lld mirror=%d group=%d ws=%zuB\n",
@@ -1527,7 +1590,6 @@ int xrfthip_exec(const xrfthip_plan* plan, const void* d_in0, const void* d_in1,
     if (!d_out && !(d.flags & XRFTHIP_NO_SPECTRUM_OUT)) return XRFTHIP_BAD_ARG;
     if (iso && (!d_iso || !P->binmap.p)) return d_iso ? XRFTHIP_MISSING_TABLE : XRFTHIP_BAD_ARG;
     if (P->passes.empty()) return XRFTHIP_MISSING_TABLE;
-    layout_workspace(const_cast<xrfthip_plan*>(P));
     if (ws_bytes < P->ws_bytes || (!d_workspace && P->ws_bytes)) return XRFTHIP_WORKSPACE_TOO_SMALL;
     if (d.batch == 0) return XRFTHIP_OK;
     hipStream_t st = (hipStream_t)stream;
@@ -1536,15 +1598,11 @@ int xrfthip_exec(const xrfthip_plan* plan, const void* d_in0, const void* d_in1,
     const bool det = d.detrend != XRFTHIP_DETREND_NONE;
     double* acc = (double*)(ws + P->off_acc);
     double* coef = (double*)(ws + P->off_coef);
-    if (det) HIP_TRY(hipMemsetAsync(acc, 0, (size_t)d.batch * 6 * sizeof(double) * (cross ? 2 : 1), st));
     if (iso) HIP_TRY(hipMemsetAsync(d_iso, 0, (size_t)d.batch * P->nbins * (cross ? 16 : 8), st));
     if (fasty_on(P)) {
-        if (P->ywhat_dirty) { int rcw = fasty_window_spectra(const_cast<xrfthip_plan*>(P)); if (rcw) return rcw; }
         return run_fasty(P, (const float*)d_in0, out, (double*)d_iso, ws, st);
     }
     if (fast_on(P)) {
-        if (P->what_dirty) { int rcw = fast4096_window_spectra(const_cast<xrfthip_plan*>(P)); if (rcw) return rcw; }
-        if (P->fph_dirty && d.out_mode != XRFTHIP_OUT_POWER) { int rcp = fast_phase_tables(const_cast<xrfthip_plan*>(P)); if (rcp) return rcp; }
         return run_fast4096(P, (const float*)d_in0, (const float*)d_in1, out, (double*)d_iso, ws, st);
     }
     for (long long g0 = 0; g0 < d.batch; g0 += P->G) {
@@ -1560,8 +1618,8 @@ int xrfthip_exec(const xrfthip_plan* plan, const void* d_in0, const void* d_in1,
             if (rc) return rc;
         }
         const void* in_main = cross ? d_in1 : d_in0;
-        double* acc_m = cross ? acc + d.batch * 6 : acc;
-        double* coef_m = cross ? coef + d.batch * 6 : coef;
+        double* acc_m = cross ? acc + (size_t)P->G * P->mom_chunks * 6 : acc;
+        double* coef_m = cross ? coef + d.batch * ((d.flags & XRFTHIP_AXIS_Y) ? d.nx : 1) * 6 : coef;
         if (det) {
             rc = P->dbl ? run_moments<double>(P, in_main, g0, gc, acc_m, coef_m, st) : run_moments<float>(P, in_main, g0, gc, acc_m, coef_m, st);
             if (rc) return rc;
@@ -1573,7 +1631,9 @@ int xrfthip_exec(const xrfthip_plan* plan, const void* d_in0, const void* d_in1,
     return XRFTHIP_OK;
 }
 
-size_t xrfthip_detrend_workspace_bytes(int64_t batch) { return ((size_t)std::max<int64_t>(batch, 1) * 16 * sizeof(double) + 255) & ~(size_t)255; }
+// per-chunk partial sums of at most 32768 slabs at a time (slabs x chunks <= 32768, 8 sums each) + 8 coefficients per slab
+static constexpr long long kDetrendPart = 32768;
+size_t xrfthip_detrend_workspace_bytes(int64_t batch) { return ((size_t)(kDetrendPart + std::max<int64_t>(batch, 1)) * 8 * sizeof(double) + 255) & ~(size_t)255; }
 
 int xrfthip_detrend(int32_t dtype, int32_t ndim, int64_t batch, int64_t ny, int64_t nx, int32_t detrend_type,
                     const void* d_in, void* d_out, void* d_workspace, size_t ws_bytes, void* stream) {
@@ -1584,23 +1644,22 @@ int xrfthip_detrend(int32_t dtype, int32_t ndim, int64_t batch, int64_t ny, int6
     if (batch == 0) return XRFTHIP_OK;
     hipStream_t st = (hipStream_t)stream;
     double* acc = (double*)d_workspace;
-    double* coef = acc + batch * 6;
-    HIP_TRY(hipMemsetAsync(acc, 0, (size_t)batch * 6 * sizeof(double), st));
+    double* coef = acc + kDetrendPart * 8;
     const bool dbl = dtype == XRFTHIP_F64 || dtype == XRFTHIP_C128, cplx = dtype >= XRFTHIP_C64;
     const long long total = ny * nx;
-    const long long chunks = std::max<long long>(1, std::min<long long>(ny, 64));
     const size_t esz = (dbl ? 8 : 4) * (cplx ? 2 : 1);
     for (long long b0 = 0; b0 < batch; b0 += 32768) {  // grid.y limit
         const long long bc = std::min<long long>(32768, batch - b0);
+        const long long chunks = std::max<long long>(1, std::min<long long>(std::min<long long>(ny, 64), kDetrendPart / bc));
         const dim3 grid((unsigned)chunks, (unsigned)bc), block(256);
         const void* src = (const char*)d_in + (size_t)b0 * total * esz;
         void* dst = (char*)d_out + (size_t)b0 * total * esz;
         const size_t lds = 6 * 256 * sizeof(double);
-#define MOM(TT, CC) do { auto k = &slab_moments_kernel<TT, CC>; XRFT_LAUNCH(k, grid, block, lds, st, src, (long long)ny, (long long)nx, total, (long long)nx, acc + b0 * 6); } while (0)
+#define MOM(TT, CC) do { auto k = &slab_moments_kernel<TT, CC>; XRFT_LAUNCH(k, grid, block, lds, st, src, (long long)ny, (long long)nx, total, (long long)nx, acc); } while (0)
         if (dbl) { if (cplx) MOM(double, true); else MOM(double, false); } else { if (cplx) MOM(float, true); else MOM(float, false); }
 #undef MOM
         auto kf = &finalize_coef_kernel;
-        XRFT_LAUNCH(kf, dim3((unsigned)((bc + 63) / 64)), dim3(64), 0, st, (const double*)(acc + b0 * 6), coef + b0 * 6, bc, (long long)ny, (long long)nx, (int)detrend_type);
+        XRFT_LAUNCH(kf, dim3((unsigned)((bc + 63) / 64)), dim3(64), 0, st, (const double*)acc, coef + b0 * 6, bc, (long long)ny, (long long)nx, (int)detrend_type, (int)chunks);
         const long long gx = std::max<long long>(1, std::min<long long>(2048, (total + 255) / 256));
         const dim3 grid2((unsigned)gx, (unsigned)bc);
 #define APP(TT, CC) do { auto k = &detrend_apply_kernel<TT, CC>; XRFT_LAUNCH(k, grid2, block, 0, st, src, dst, (long long)ny, (long long)nx, (const double*)(coef + b0 * 6)); } while (0)
@@ -1619,23 +1678,22 @@ int xrfthip_detrend3(int32_t dtype, int64_t batch, int64_t n0, int64_t n1, int64
     if (batch == 0) return XRFTHIP_OK;
     hipStream_t st = (hipStream_t)stream;
     double* acc = (double*)d_workspace;
-    double* coef = acc + batch * 8;
-    HIP_TRY(hipMemsetAsync(acc, 0, (size_t)batch * 8 * sizeof(double), st));
+    double* coef = acc + kDetrendPart * 8;
     const bool dbl = dtype == XRFTHIP_F64 || dtype == XRFTHIP_C128, cplx = dtype >= XRFTHIP_C64;
     const long long rows = n0 * n1, total = rows * n2;
     const size_t esz = (dbl ? 8 : 4) * (cplx ? 2 : 1);
     for (long long b0 = 0; b0 < batch; b0 += 32768) {  // grid.y limit
         const long long bc = std::min<long long>(32768, batch - b0);
-        const long long gx = std::max<long long>(1, std::min<long long>(rows, std::max<long long>(8, 4096 / bc)));
+        const long long gx = std::max<long long>(1, std::min<long long>(rows, std::min<long long>(4096, kDetrendPart / bc)));
         const dim3 grid((unsigned)gx, (unsigned)bc), block(256);
         const void* src = (const char*)d_in + (size_t)b0 * total * esz;
         void* dst = (char*)d_out + (size_t)b0 * total * esz;
         const size_t lds = 8 * 256 * sizeof(double);
-#define MOM(TT, CC) do { auto k = &block3_moments_kernel<TT, CC>; XRFT_LAUNCH(k, grid, block, lds, st, src, (long long)n0, (long long)n1, (long long)n2, acc + b0 * 8); } while (0)
+#define MOM(TT, CC) do { auto k = &block3_moments_kernel<TT, CC>; XRFT_LAUNCH(k, grid, block, lds, st, src, (long long)n0, (long long)n1, (long long)n2, acc); } while (0)
         if (dbl) { if (cplx) MOM(double, true); else MOM(double, false); } else { if (cplx) MOM(float, true); else MOM(float, false); }
 #undef MOM
         auto kf = &finalize_coef3_kernel;
-        XRFT_LAUNCH(kf, dim3((unsigned)((bc + 63) / 64)), dim3(64), 0, st, (const double*)(acc + b0 * 8), coef + b0 * 8, bc, (long long)n0, (long long)n1, (long long)n2, (int)detrend_type);
+        XRFT_LAUNCH(kf, dim3((unsigned)((bc + 63) / 64)), dim3(64), 0, st, (const double*)acc, coef + b0 * 8, bc, (long long)n0, (long long)n1, (long long)n2, (int)detrend_type, (int)gx);
         const dim3 grid2((unsigned)std::max<long long>(1, std::min<long long>(rows, 4096)), (unsigned)bc);
 #define APP(TT, CC) do { auto k = &detrend3_apply_kernel<TT, CC>; XRFT_LAUNCH(k, grid2, block, 0, st, src, dst, (long long)n0, (long long)n1, (long long)n2, (const double*)(coef + b0 * 8)); } while (0)
         if (dbl) { if (cplx) APP(double, true); else APP(double, false); } else { if (cplx) APP(float, true); else APP(float, false); }

@@ -62,8 +62,6 @@ class SpectralPlan:
                 raise ValueError(f"bin map shape {bm.shape} != {(self.ny, self.nx_out)}")
             _lib.check(self._dll.xrfthip_plan_set_binmap(self._h, bm.ctypes.data_as(C.c_void_p), self.ny,
                                                          self.nx_out, self.nbins))
-        self._ws = {}  # (device, stream) -> workspace: two streams never share scratch memory
-        self._lock = threading.Lock()  # the C plan lays out its workspace lazily inside exec: one enqueue at a time
 
     def __del__(self):
         try:
@@ -120,15 +118,47 @@ class SpectralPlan:
         if self.batch == 0:  # nothing to transform: empty outputs, no device call
             return (out if want_out else None), iso
         stream = _stream_handle(in0)
-        with self._lock:
-            nws = self.workspace_bytes
-            key = (str(dev), stream.value)
-            ws = self._ws.get(key)
-            if ws is None or ws.numel() < nws:
-                ws = self._ws[key] = torch.empty(max(nws, 256), dtype=torch.uint8, device=dev)
+        # The C plan is immutable after creation, so nothing plan-wide is locked: threads on different streams enqueue
+        # concurrently.  Callers that share a stream share its scratch buffer: their enqueues (a short sequence of kernel
+        # launches each) must not interleave, hence one lock per (device, stream).
+        ws, lock = _workspace(dev, stream, self.workspace_bytes)
+        with lock:
+            ws, _ = _workspace(dev, stream, self.workspace_bytes)  # (another thread may have grown it meanwhile)
             _lib.check(self._dll.xrfthip_exec(self._h, _ptr(in0), _ptr(in1), _ptr(out if want_out else None), _ptr(iso),
                                               _ptr(ws), ws.numel(), stream))
         return (out if want_out else None), iso
+
+
+# One grow-only scratch buffer per (device, stream), shared by every plan: work on one stream is ordered, so plans never
+# overlap in it; two streams never share scratch memory.  (A workspace per plan pinned several GB per cached plan.)
+_WS = {}
+_WS_LOCKS = {}
+_WS_RETIRED = []  # outgrown buffers: kept until clear_workspaces() -- kernels enqueued earlier may still be using them
+_WS_LOCK = threading.Lock()
+
+
+def _workspace(dev, stream, nbytes):
+    key = (str(dev), stream.value)
+    with _WS_LOCK:
+        ws = _WS.get(key)
+        if ws is None or ws.numel() < nbytes:
+            if ws is not None:
+                _WS_RETIRED.append(ws)
+            ws = _WS[key] = torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=dev)
+        lock = _WS_LOCKS.get(key)
+        if lock is None:
+            lock = _WS_LOCKS[key] = threading.Lock()
+        return ws, lock
+
+
+def clear_workspaces():
+    """Release the shared scratch buffers (synchronises the devices first)."""
+    with _WS_LOCK:
+        if _WS or _WS_RETIRED:
+            if _lib.device() == "cuda" and torch.cuda.is_available():
+                torch.cuda.synchronize()
+            _WS.clear()
+            _WS_RETIRED.clear()
 
 
 def detrend(x, ndim, kind):
