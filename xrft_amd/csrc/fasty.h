@@ -40,13 +40,17 @@ __device__ __forceinline__ void xrft_store_nt(float* dst, F4 v) {
 struct FastY {
     const float* in;         // [slab][ny][nx] float32
     cf* w2;                  // intermediate, see above
-    float* out;              // [slab][ny][nx] float32 power spectrum (may be null with ISO)
+    const cf* w2b;           // cross spectra: the intermediate of field 1 (pass 2 only)
+    void* out;               // [slab][ny][nx]: float32 power / phase, or complex64 (may be null with ISO)
     const cf* tw_x;          // W_nx^k
     const cf* tw_y;          // W_ny^k
     const float* win_y;      // never null (ones when there is no window)
     const float* win_x;
     double* colfit;          // [slab][nx][4]: per column sum d, sum (i - ibar) d (exact), and the line pass 1 subtracted as (value at ibar, slope)
     const float* corr;       // [slab][nx][2]: wx[x] * (subtracted line - plane fit) as (offset at ibar, slope), from fasty_fit_kernel
+    const float* corr_b;     // ... of field 1 (cross spectra)
+    const cf* ph_y;          // complex modes: true-phase factor per unshifted ky (times (-1)^ky for an ifftshifted input), never null
+    const cf* ph_x;
     const cf* what0;         // FFT_y(wy)[ky], ky < nrow_pad (zero beyond ny/2)
     const cf* what1;         // FFT_y(wy * (i - (ny-1)/2))[ky]
     const unsigned* tcodes;  // radial bins in pass 2's register order: (direct + 1) | (mirror + 1) << 16
@@ -335,11 +339,25 @@ __device__ __forceinline__ unsigned w2_offset(const FastY& p, int ky, int x) {
     return (blk << (p.l_rk + p.l_2gy)) + (((unsigned)ky & ((1u << p.l_rk) - 1u)) << p.l_2gy) + ((((unsigned)x & ((1u << p.l_cw) - 1u)) >> 2) << 1) + ((unsigned)x & 1u);
 }
 
-template <int NX, bool ISO>
+// 16-byte non-temporal store of two complex samples
+__device__ __forceinline__ void xrft_store_nt2(cf* dst, cf v0, cf v1) {
+    F4 o; o.x = v0.re; o.y = v0.im; o.z = v1.re; o.w = v1.im;
+    xrft_store_nt(reinterpret_cast<float*>(dst), o);
+}
+
+// MODE = xrfthip_out_mode: 1 power (two rows of one field per thread), 0 complex (fft; the same, staged in two rounds),
+// 2 cross / 3 cross phase (transform A = the row of field 0, transform B = the same row of field 1: F0 conj(F1) is formed in
+// registers, so a cross spectrum costs ONE column pass per field and one row pass -- xrft.py:825).  The complex results
+// carry the true-phase factors exp(-i 2 pi k lag) (xrft.py:462-469), indexed by unshifted frequency, applied in the store
+// loop to direct and mirrored samples alike (an ifftshifted input is the sign (-1)^k folded into the tables).
+template <int NX, int MODE, bool ISO>
 __global__ void __launch_bounds__(YRows<NX>::THR, YRows<NX>::THR / 128) fasty_rows_kernel(FastY p) {
+    static_assert(MODE == 1 || MODE == 2 || !ISO, "radial sums exist for power and cross spectra");
     typedef P2<NX> G;
     typedef YRows<NX> R;
-    constexpr int NT = G::NT, GX = R::GX, THR = R::THR, RPU = R::RPU, GSTR = YLds<NX, GX>::GSTR;
+    constexpr bool TWO = MODE >= 2;  // two fields
+    constexpr int NT = G::NT, GX = R::GX, THR = R::THR, RPU = TWO ? GX : 2 * GX, GSTR = YLds<NX, GX>::GSTR;
+    constexpr int HW = MODE == 2 ? 2 : 1;  // doubles per radial bin
     XRFT_DYN_SMEM(smem_raw);
     cf* lds = reinterpret_cast<cf*>(smem_raw);
     float* stg = reinterpret_cast<float*>(smem_raw);
@@ -348,15 +366,16 @@ __global__ void __launch_bounds__(YRows<NX>::THR, YRows<NX>::THR / 128) fasty_ro
     cf* tw2 = lds + GX * GSTR;
     double* hist = reinterpret_cast<double*>(tw2 + 16 * G::R3);
     fill_tw2<NX>(tw2, p.tw_x, tid, THR);
-    if (ISO) for (int i = tid; i < p.nbins; i += THR) hist[i] = 0.0;  // ordered before the first add by the FFT's barriers
+    if (ISO) for (int i = tid; i < p.nbins * HW; i += THR) hist[i] = 0.0;  // ordered before the first add by the FFT's barriers
     const int upr = p.nrow_pad / RPU;  // units per slab
     const int slab = blockIdx.x / upr, unit = blockIdx.x % upr, ky0 = unit * RPU;
     const int nyh = p.ny >> 1;
     // rows beyond ny/2 (padding of the last unit) are computed on row ny/2's data and never stored or binned
-    const int kyA = min(ky0 + g, nyh), kyB = min(ky0 + GX + g, nyh);
+    const int kyA = min(ky0 + g, nyh), kyB = TWO ? kyA : min(ky0 + GX + g, nyh);
     // uniform 64-bit bases + 32-bit per-lane byte offsets (scalar-base loads).  The residual-trend pairs go first: 16 loads
     // in flight beside the 32 of the rows (issued after them they came in four serialised batches: +4.5 us per slab)
     const char* __restrict__ w2s = reinterpret_cast<const char*>(p.w2 + (size_t)slab * p.nrow_pad * NX);
+    const char* __restrict__ w2t = TWO ? reinterpret_cast<const char*>(p.w2b + (size_t)slab * p.nrow_pad * NX) : w2s;
     const char* __restrict__ crb = reinterpret_cast<const char*>(p.corr + (size_t)slab * NX * 2);
     const bool addback = p.detrend && !(XRFT_YDBG & 1);
     cf cr[16];
@@ -371,43 +390,68 @@ __global__ void __launch_bounds__(YRows<NX>::THR, YRows<NX>::THR / 128) fasty_ro
 #pragma unroll
         for (int q = 0; q < 16; ++q) {
             a[q] = *reinterpret_cast<const cf*>(w2s + (offA + qstr * (unsigned)q));
-            b[q] = *reinterpret_cast<const cf*>(w2s + (offB + qstr * (unsigned)q));
+            b[q] = *reinterpret_cast<const cf*>(w2t + (offB + qstr * (unsigned)q));
         }
     } else {
 #pragma unroll
         for (int q = 0; q < 16; ++q) {
             a[q] = *reinterpret_cast<const cf*>(w2s + w2_offset(p, kyA, u + NT * q) * 8u);
-            b[q] = *reinterpret_cast<const cf*>(w2s + w2_offset(p, kyB, u + NT * q) * 8u);
+            b[q] = *reinterpret_cast<const cf*>(w2t + w2_offset(p, kyB, u + NT * q) * 8u);
         }
     }
-    if (addback) {  // add back wx[x] * (column fit - plane fit) in the spectral domain (see fasty_cols_kernel)
+    if (addback) {  // add back wx[x] * (subtracted line - plane fit) in the spectral domain (see fasty_cols_kernel)
         const cf a0 = p.what0[kyA], a1 = p.what1[kyA], b0 = p.what0[kyB], b1 = p.what1[kyB];
 #pragma unroll
         for (int q = 0; q < 16; ++q) {
             const float al = cr[q].re, ga = cr[q].im;
             a[q].re = fmaf(al, a0.re, fmaf(ga, a1.re, a[q].re));
             a[q].im = fmaf(al, a0.im, fmaf(ga, a1.im, a[q].im));
-            b[q].re = fmaf(al, b0.re, fmaf(ga, b1.re, b[q].re));
-            b[q].im = fmaf(al, b0.im, fmaf(ga, b1.im, b[q].im));
+            if (!TWO) {
+                b[q].re = fmaf(al, b0.re, fmaf(ga, b1.re, b[q].re));
+                b[q].im = fmaf(al, b0.im, fmaf(ga, b1.im, b[q].im));
+            }
         }
-    }
-    if (!(XRFT_YDBG & 4)) fft_p2_pair<NX>(a, b, u, mine, p.tw_x, tw2);
-    if (ISO) {  // value at (ky, kx) goes to its bin, and once more to the bin of (-ky, -kx)
-        const unsigned* __restrict__ tc = p.tcodes + ((size_t)unit * 32) * THR + tid;
+        if (TWO) {  // the second field has its own residual trend (these loads are not hidden: a cross spectrum with detrending pays for them)
+            const char* __restrict__ crc = reinterpret_cast<const char*>(p.corr_b + (size_t)slab * NX * 2);
 #pragma unroll
-        for (int e = 0; e < 32; ++e) {
-            const cf v = e < 16 ? a[e] : b[e - 16];
-            const unsigned code = tc[(size_t)e * THR];
-            const float pw = (v.re * v.re + v.im * v.im) * p.scale;
-            const unsigned cd = code & 0xffffu, cm = code >> 16;
-            if (cd == cm) { if (cd) atomicAdd(&hist[cd - 1], 2.0 * (double)pw); }
-            else {
-                if (cd) atomicAdd(&hist[cd - 1], (double)pw);
-                if (cm) atomicAdd(&hist[cm - 1], (double)pw);
+            for (int q = 0; q < 16; ++q) cr[q] = *reinterpret_cast<const cf*>(crc + (unsigned)(u + NT * q) * 8u);
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                b[q].re = fmaf(cr[q].re, b0.re, fmaf(cr[q].im, b1.re, b[q].re));
+                b[q].im = fmaf(cr[q].re, b0.im, fmaf(cr[q].im, b1.im, b[q].im));
             }
         }
     }
-    if (p.out != nullptr) {
+    if (!(XRFT_YDBG & 4)) fft_p2_pair<NX>(a, b, u, mine, p.tw_x, tw2);
+    if (TWO) {  // F0 conj(F1) * scale, in place of transform A (xrft.py:825)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) a[e] = cscale(cmulc(a[e], b[e]), p.scale);
+    }
+    if (ISO) {  // value at (ky, kx) goes to its bin, and once more (conjugated) to the bin of (-ky, -kx)
+        const unsigned* __restrict__ tc = p.tcodes + ((size_t)unit * (TWO ? 16 : 32)) * THR + tid;
+#pragma unroll
+        for (int e = 0; e < (TWO ? 16 : 32); ++e) {
+            const cf v = e < 16 ? a[e] : b[e - 16];
+            const unsigned code = tc[(size_t)e * THR];
+            const unsigned cd = code & 0xffffu, cm = code >> 16;
+            if (MODE == 1) {
+                const float pw = (v.re * v.re + v.im * v.im) * p.scale;
+                if (cd == cm) { if (cd) atomicAdd(&hist[cd - 1], 2.0 * (double)pw); }
+                else {
+                    if (cd) atomicAdd(&hist[cd - 1], (double)pw);
+                    if (cm) atomicAdd(&hist[cm - 1], (double)pw);
+                }
+            } else {
+                if (cd == cm) { if (cd) atomicAdd(&hist[2 * (cd - 1)], 2.0 * (double)v.re); }  // V + conj V
+                else {
+                    if (cd) { atomicAdd(&hist[2 * (cd - 1)], (double)v.re); atomicAdd(&hist[2 * (cd - 1) + 1], (double)v.im); }
+                    if (cm) { atomicAdd(&hist[2 * (cm - 1)], (double)v.re); atomicAdd(&hist[2 * (cm - 1) + 1], -(double)v.im); }
+                }
+            }
+        }
+    }
+    const int mx = NX - 1, my = p.ny - 1, sx = p.shift_x;
+    if (MODE == 1 && p.out != nullptr) {
         // power, staged row-major [row][kx] in natural order with the conflict-free 17/16 padding
 #pragma unroll
         for (int bb = 0; bb < G::NB; ++bb)
@@ -420,8 +464,7 @@ __global__ void __launch_bounds__(YRows<NX>::THR, YRows<NX>::THR / 128) fasty_ro
             }
         __syncthreads();
         // every staged row leaves twice: rotated (direct) and reversed + rotated (mirror); 16-byte stores, whole rows
-        float* __restrict__ outs = p.out + (size_t)slab * p.ny * NX;
-        const int mx = NX - 1, my = p.ny - 1, sx = p.shift_x;
+        float* __restrict__ outs = reinterpret_cast<float*>(p.out) + (size_t)slab * p.ny * NX;
         constexpr int CPR = NX / 4;  // float4 chunks per row
         for (int e = tid; e < RPU * 2 * CPR; e += THR) {
             const int chunk = e % CPR, rr = e / CPR, r = rr >> 1, mir = rr & 1;
@@ -443,11 +486,53 @@ __global__ void __launch_bounds__(YRows<NX>::THR, YRows<NX>::THR / 128) fasty_ro
             if (!(XRFT_YDBG & 8) || v.x == 1.2345f) xrft_store_nt(outs + (size_t)orow * NX + c, v);
         }
     }
+    if (MODE != 1 && p.out != nullptr) {
+        // complex results: GX rows at a time staged in natural order (a round fills the transforms' LDS exactly); the complex
+        // spectrum of one field takes two rounds (transform A's rows, then B's)
+        cf* cstg = lds;
+        constexpr int RSC = NX + NX / 16, NROUND = TWO ? 1 : 2, CPR = NX / 2;  // pairs of samples per row
+        typedef typename std::conditional<MODE == 3, float, cf>::type OutT;
+        OutT* __restrict__ outs = reinterpret_cast<OutT*>(p.out) + (size_t)slab * p.ny * NX;
+#pragma unroll
+        for (int round = 0; round < NROUND; ++round) {
+            if (round) __syncthreads();
+            const float sc = TWO ? 1.0f : p.scale;
+#pragma unroll
+            for (int bb = 0; bb < G::NB; ++bb)
+#pragma unroll
+                for (int k3 = 0; k3 < G::R3; ++k3)
+                    cstg[g * RSC + nat16(held_k<NX>(u, bb, k3))] = cscale(round ? b[bb * G::R3 + k3] : a[bb * G::R3 + k3], sc);
+            __syncthreads();
+            for (int e = tid; e < GX * 2 * CPR; e += THR) {
+                const int chunk = e % CPR, rr = e / CPR, r = rr >> 1, mir = rr & 1;
+                const int ky = ky0 + round * GX + r;
+                if (ky > nyh || (mir && (ky == 0 || ky == nyh))) continue;
+                const cf* row = cstg + r * RSC;
+                const int c = 2 * chunk;
+                const int fx0 = (c - sx) & mx, fx1 = (c + 1 - sx) & mx;  // unshifted frequency indices of the two output columns
+                const int fy = mir ? (p.ny - ky) & my : ky;
+                cf v0, v1;
+                if (!mir) { v0 = row[nat16(fx0)]; v1 = row[nat16(fx1)]; }
+                else { v0 = cconj(row[nat16((NX - fx0) & mx)]); v1 = cconj(row[nat16((NX - fx1) & mx)]); }  // F(-k) = conj F(k)
+                const cf py = p.ph_y[fy];
+                v0 = cmul(v0, cmul(py, p.ph_x[fx0]));
+                v1 = cmul(v1, cmul(py, p.ph_x[fx1]));
+                const size_t o = (size_t)((fy + p.shift_y) & my) * NX + c;
+                if (MODE == 3) {  // cross phase (xrft.py:838-874)
+                    struct alignas(8) P2f { float x, y; } ang;
+                    ang.x = (float)atan2((double)v0.im, (double)v0.re); ang.y = (float)atan2((double)v1.im, (double)v1.re);
+                    *reinterpret_cast<P2f*>(reinterpret_cast<float*>(outs) + o) = ang;
+                } else {
+                    xrft_store_nt2(reinterpret_cast<cf*>(outs) + o, v0, v1);
+                }
+            }
+        }
+    }
     if (ISO) {
         __syncthreads();
-        for (int i = tid; i < p.nbins; i += THR) {
+        for (int i = tid; i < p.nbins * HW; i += THR) {
             const double v = hist[i];
-            if (v != 0.0) atomicAdd(&p.iso[(size_t)slab * p.nbins + i], v);
+            if (v != 0.0) atomicAdd(&p.iso[(size_t)slab * p.nbins * HW + i], v);
         }
     }
 }

@@ -763,7 +763,8 @@ void set_kernel_attrs_once() {
     SETF((fastp2_cols_kernel<1024, 768, 0, false>));
 #undef SETC
     SETF(fastp2_untile_kernel); SETF(fastp2_untile_c_kernel<false>); SETF(fastp2_untile_c_kernel<true>);
-#define SETY(NN) SETF((fasty_cols_kernel<NN, false>)); SETF((fasty_cols_kernel<NN, true>)); SETF((fasty_rows_kernel<NN, false>)); SETF((fasty_rows_kernel<NN, true>))
+#define SETY(NN) SETF((fasty_cols_kernel<NN, false>)); SETF((fasty_cols_kernel<NN, true>)); SETF((fasty_rows_kernel<NN, 1, false>)); SETF((fasty_rows_kernel<NN, 1, true>)); \
+                 SETF((fasty_rows_kernel<NN, 0, false>)); SETF((fasty_rows_kernel<NN, 2, false>)); SETF((fasty_rows_kernel<NN, 2, true>)); SETF((fasty_rows_kernel<NN, 3, false>))
     SETY(4096); SETY(2048); SETY(1024); SETY(512); SETY(256);
 #undef SETY
 #undef SETF
@@ -856,7 +857,7 @@ static void layout_workspace(xrfthip_plan* P) {
     P->off_coef = off; off = al(off + ncoef * 6 * sizeof(double) * nf);
     bool need_w = d.ndim == 2, need_w2 = false;
     for (const Pass& p : P->passes) { if (p.out_kind == B_W2) need_w2 = true; if (p.out_kind == B_W) need_w = true; }
-    P->off_w = off; if (need_w) off = al(off + (size_t)G * slab_w);
+    P->off_w = off; if (need_w) off = al(off + (size_t)G * slab_w * (yf ? nf : 1));  // (y first: field 1's intermediate follows field 0's)
     P->off_w2 = off; if (need_w2) off = al(off + (size_t)G * d.ny * d.nx * P->csize);
     P->off_f0 = off; if (nf == 2 && !fast) off = al(off + (size_t)G * slab_w);
     if (fast && !yf) {  // line-tiled result: float (power; not needed without a spectrum output) or complex (fft, cross)
@@ -865,8 +866,8 @@ static void layout_workspace(xrfthip_plan* P) {
         if (!pw || !(d.flags & XRFTHIP_NO_SPECTRUM_OUT)) off = al(off + (size_t)G * (d.ny / 8) * P->fast_ntile_pad * 8 * sizeof(F4) * (pw ? 1 : 2));
     }
     const size_t nfit = (size_t)(yf ? 2 * d.nx : d.ny);  // per-row fits (x first) or per-column sums + subtracted lines (y first)
-    P->off_rowfit = off; if (fast) off = al(off + (size_t)G * nfit * 2 * sizeof(double));
-    P->off_corr = off; if (fast) off = al(off + (size_t)G * nfit * 2 * sizeof(float));
+    P->off_rowfit = off; if (fast) off = al(off + (size_t)G * nfit * 2 * sizeof(double) * (yf ? nf : 1));
+    P->off_corr = off; if (fast) off = al(off + (size_t)G * nfit * 2 * sizeof(float) * (yf ? nf : 1));
     P->ws_bytes = off;
 }
 
@@ -1155,10 +1156,11 @@ static int fasty_window_spectra(xrfthip_plan* P) {
 static int fasty_build_tcodes(xrfthip_plan* P, const int32_t* bm) {
     const int ny = (int)P->d.ny, nx = (int)P->d.nx, nyh = ny / 2, nt = nx / 16, r3 = nx / 256;
     const YGeomRt R = yrows_geom(nx);
-    const int gx = R.gxy, rpu = R.rk, thr = R.thr, units = P->y_nrow_pad / rpu;
-    std::vector<uint32_t> t((size_t)units * 32 * thr, 0u);
+    const bool two = P->d.out_mode == XRFTHIP_OUT_CROSS;  // transform B is field 1: only transform A's slots carry results
+    const int gx = R.gxy, rpu = two ? R.gxy : R.rk, thr = R.thr, units = P->y_nrow_pad / rpu, ne = two ? 16 : 32;
+    std::vector<uint32_t> t((size_t)units * ne * thr, 0u);
     for (int un = 0; un < units; ++un)
-        for (int e = 0; e < 32; ++e)
+        for (int e = 0; e < ne; ++e)
             for (int tid = 0; tid < thr; ++tid) {
                 const int g = tid % gx, u = tid / gx;
                 const int ky = un * rpu + (e < 16 ? g : gx + g);
@@ -1171,7 +1173,7 @@ static int fasty_build_tcodes(xrfthip_plan* P, const int32_t* bm) {
                     const int32_t cm = bm[(size_t)(ny - ky) * nx + ((nx - kx) & (nx - 1))];
                     if (cm >= 0) v |= (uint32_t)(cm + 1) << 16;
                 }
-                t[((size_t)un * 32 + e) * thr + tid] = v;
+                t[((size_t)un * ne + e) * thr + tid] = v;
             }
     return P->ytcodes.upload(t.data(), t.size() * sizeof(uint32_t));
 }
@@ -1200,11 +1202,16 @@ static void fasty_launch_rows(const xrfthip_plan* P, const FastY& p, long long g
     const xrfthip_desc& d = P->d;
     const YGeomRt R = yrows_geom(d.nx);
     const bool iso_on = (d.flags & XRFTHIP_ISO) != 0;
+    const bool two = d.out_mode == XRFTHIP_OUT_CROSS || d.out_mode == XRFTHIP_OUT_PHASE;
     xrfthip_plan::ProfRec* rec = prof ? prof_begin(P, "fasty_rows", st) : nullptr;
-    const dim3 grid((unsigned)(gc * (P->y_nrow_pad / R.rk))), blk((unsigned)R.thr);
-    const size_t lds = R.lds + (iso_on ? (size_t)P->nbins * sizeof(double) : 0);
-#define YR_(NN) do { if (iso_on) { auto k = &fasty_rows_kernel<NN, true>; XRFT_LAUNCH(k, grid, blk, lds, st, p); } \
-                     else { auto k = &fasty_rows_kernel<NN, false>; XRFT_LAUNCH(k, grid, blk, lds, st, p); } } while (0)
+    const int rpu = two ? R.gxy : R.rk;  // a cross spectrum spends both transforms of a thread on one row (field 0, field 1)
+    const dim3 grid((unsigned)(gc * (P->y_nrow_pad / rpu))), blk((unsigned)R.thr);
+    const size_t lds = R.lds + (iso_on ? (size_t)P->nbins * sizeof(double) * (d.out_mode == XRFTHIP_OUT_CROSS ? 2 : 1) : 0);
+#define YR_(NN) do { \
+        if (d.out_mode == XRFTHIP_OUT_POWER) { if (iso_on) { auto k = &fasty_rows_kernel<NN, 1, true>; XRFT_LAUNCH(k, grid, blk, lds, st, p); } else { auto k = &fasty_rows_kernel<NN, 1, false>; XRFT_LAUNCH(k, grid, blk, lds, st, p); } } \
+        else if (d.out_mode == XRFTHIP_OUT_CROSS) { if (iso_on) { auto k = &fasty_rows_kernel<NN, 2, true>; XRFT_LAUNCH(k, grid, blk, lds, st, p); } else { auto k = &fasty_rows_kernel<NN, 2, false>; XRFT_LAUNCH(k, grid, blk, lds, st, p); } } \
+        else if (d.out_mode == XRFTHIP_OUT_PHASE) { auto k = &fasty_rows_kernel<NN, 3, false>; XRFT_LAUNCH(k, grid, blk, lds, st, p); } \
+        else { auto k = &fasty_rows_kernel<NN, 0, false>; XRFT_LAUNCH(k, grid, blk, lds, st, p); } } while (0)
     if (d.nx == 4096) YR_(4096); else if (d.nx == 2048) YR_(2048); else if (d.nx == 1024) YR_(1024); else if (d.nx == 512) YR_(512); else YR_(256);
 #undef YR_
     prof_end(rec, st);
@@ -1212,6 +1219,7 @@ static void fasty_launch_rows(const xrfthip_plan* P, const FastY& p, long long g
 
 // parameter block of one group of slabs [g0, g0 + gc): the intermediate and the fit tables sit in ring slot `slot` (of slot_slabs slabs each)
 static FastY fasty_params(const xrfthip_plan* P, const float* in, void* out, double* iso, char* ws, long long g0, long long gc, int slot, long long slot_slabs) {
+    // (slot 0 = field 0 / the only field, slot 1 = field 1 of a cross spectrum: its own intermediate and fit tables)
     const xrfthip_desc& d = P->d;
     const size_t slab_pts = (size_t)d.ny * d.nx;
     const bool want_out = !(d.flags & XRFTHIP_NO_SPECTRUM_OUT);
@@ -1221,7 +1229,10 @@ static FastY fasty_params(const xrfthip_plan* P, const float* in, void* out, dou
     FastY p{};
     p.in = in + (size_t)g0 * slab_pts;
     p.w2 = reinterpret_cast<cf*>(ws + P->off_w) + s0 * (size_t)P->y_nrow_pad * d.nx;
-    p.out = want_out ? (float*)out + (size_t)g0 * slab_pts : nullptr;
+    const size_t out_esz = (d.out_mode == XRFTHIP_OUT_POWER || d.out_mode == XRFTHIP_OUT_PHASE) ? sizeof(float) : sizeof(cf);
+    p.out = want_out ? (char*)out + (size_t)g0 * slab_pts * out_esz : nullptr;
+    p.ph_y = reinterpret_cast<const cf*>(P->fph[0].p);
+    p.ph_x = reinterpret_cast<const cf*>(P->fph[1].p);
     p.tw_x = reinterpret_cast<const cf*>(P->tw_fx.p);
     p.tw_y = reinterpret_cast<const cf*>(P->tw_fy.p);
     p.win_y = reinterpret_cast<const float*>(P->win[0].p ? P->win[0].p : P->ones4096.p);
@@ -1231,7 +1242,7 @@ static FastY fasty_params(const xrfthip_plan* P, const float* in, void* out, dou
     p.what0 = reinterpret_cast<const cf*>(P->ywhat0.p);
     p.what1 = reinterpret_cast<const cf*>(P->ywhat1.p);
     p.tcodes = reinterpret_cast<const unsigned*>(P->ytcodes.p);
-    p.iso = iso_on ? iso + (size_t)g0 * P->nbins : nullptr;
+    p.iso = iso_on ? iso + (size_t)g0 * P->nbins * (d.out_mode == XRFTHIP_OUT_CROSS ? 2 : 1) : nullptr;
     p.nbins = P->nbins;
     p.ny = (int)d.ny; p.nx = (int)d.nx;
     p.nrow_pad = P->y_nrow_pad;
@@ -1244,12 +1255,19 @@ static FastY fasty_params(const xrfthip_plan* P, const float* in, void* out, dou
     return p;
 }
 
-static int run_fasty(const xrfthip_plan* P, const float* in, void* out, double* iso, char* ws, hipStream_t st) {
+static int run_fasty(const xrfthip_plan* P, const float* in, const float* in1, void* out, double* iso, char* ws, hipStream_t st) {
     const xrfthip_desc& d = P->d;
+    const bool two = d.out_mode == XRFTHIP_OUT_CROSS || d.out_mode == XRFTHIP_OUT_PHASE;
     for (long long g0 = 0; g0 < d.batch; g0 += P->G) {
         const long long gc = std::min<long long>(P->G, d.batch - g0);
-        const FastY p = fasty_params(P, in, out, iso, ws, g0, gc, 0, P->G);
+        FastY p = fasty_params(P, in, out, iso, ws, g0, gc, 0, P->G);
         fasty_launch_cols(P, p, gc, st, true);
+        if (two) {  // field 1 through the same column pass into its own intermediate; the row pass reads both
+            const FastY p1 = fasty_params(P, in1, out, iso, ws, g0, gc, 1, P->G);
+            fasty_launch_cols(P, p1, gc, st, true);
+            p.w2b = p1.w2;
+            p.corr_b = p1.corr;
+        }
         fasty_launch_rows(P, p, gc, st, true);
         HIP_TRY(hipGetLastError());
     }
@@ -1262,8 +1280,10 @@ static int run_fasty(const xrfthip_plan* P, const float* in, void* out, double* 
 static int finalize_plan(xrfthip_plan* P) {
     if (P->fast4096) {
         int rc = XRFTHIP_OK;
-        if (P->yfirst) rc = fasty_window_spectra(P);
-        else {
+        if (P->yfirst) {
+            rc = fasty_window_spectra(P);
+            if (!rc && P->d.out_mode != XRFTHIP_OUT_POWER) rc = fast_phase_tables(P);
+        } else {
             rc = fast4096_window_spectra(P);
             if (!rc && P->d.out_mode != XRFTHIP_OUT_POWER) rc = fast_phase_tables(P);
         }
@@ -1410,7 +1430,7 @@ int xrfthip_plan_create(xrfthip_plan** plan, const xrfthip_desc* desc) {
         P->fast_ntile = (int)(d.nx / 8 + 1);
         P->fast_ntile_pad = (P->fast_ntile + tpu - 1) / tpu * tpu;
         // full power spectra take the two-pass y-first pipeline (fasty.h); half / complex / cross results keep the x-first one
-        P->yfirst = d.out_mode == XRFTHIP_OUT_POWER && !(d.flags & (XRFTHIP_HALF_X | XRFTHIP_REALDIM_X2)) && env_ll("XRFTHIP_YFIRST", 1) != 0;
+        P->yfirst = !(d.flags & (XRFTHIP_HALF_X | XRFTHIP_REALDIM_X2)) && env_ll("XRFTHIP_YFIRST", 1) != 0;
         if (P->yfirst) {
             const int rpu = yrows_geom(d.nx).rk;
             P->y_nrow_pad = (int)((d.ny / 2 + 1 + rpu - 1) / rpu * rpu);
@@ -1600,7 +1620,7 @@ int xrfthip_exec(const xrfthip_plan* plan, const void* d_in0, const void* d_in1,
     double* coef = (double*)(ws + P->off_coef);
     if (iso) HIP_TRY(hipMemsetAsync(d_iso, 0, (size_t)d.batch * P->nbins * (cross ? 16 : 8), st));
     if (fasty_on(P)) {
-        return run_fasty(P, (const float*)d_in0, out, (double*)d_iso, ws, st);
+        return run_fasty(P, (const float*)d_in0, (const float*)d_in1, out, (double*)d_iso, ws, st);
     }
     if (fast_on(P)) {
         return run_fast4096(P, (const float*)d_in0, (const float*)d_in1, out, (double*)d_iso, ws, st);
