@@ -82,8 +82,8 @@ typedef enum xrfthip_detrend_kind {
 #define XRFTHIP_SHIFT_X 0x004u  /* fftshift the output along x */
 #define XRFTHIP_ISHIFT_Y 0x008u /* ifftshift the input along y (true_phase, xrft.py:440) */
 #define XRFTHIP_ISHIFT_X 0x010u /* ifftshift the input along x */
-#define XRFTHIP_FLIP_Y 0x020u   /* np.flip the input along y before the ifftshift (descending coordinate) */
-#define XRFTHIP_FLIP_X 0x040u   /* np.flip the input along x */
+#define XRFTHIP_FLIP_Y 0x020u   /* np.flip the input along y before the ifftshift (descending coordinate); CROSS/PHASE: field 1 (d_in1) */
+#define XRFTHIP_FLIP_X 0x040u   /* np.flip the input along x; CROSS/PHASE: field 1 */
 #define XRFTHIP_REALDIM_X2 0x080u /* with HALF_X and POWER|CROSS: multiply by [1,2,...,2,(1)] (xrft.py:673-682) */
 #define XRFTHIP_ISO 0x100u      /* radial bin-sum of the POWER|CROSS result into d_iso (needs a bin map) */
 #define XRFTHIP_NO_SPECTRUM_OUT 0x200u /* with ISO: do not write the full spectrum (d_out may be NULL) */
@@ -96,6 +96,10 @@ typedef enum xrfthip_detrend_kind {
  * column); nx is the product of the trailing axes.  Detrending and the window act along y (one line / mean per column);
  * the *_X flags, HALF_X, ISO and C2R_X do not apply.  Output [batch][ny][nx] in the same layout. */
 #define XRFTHIP_AXIS_Y 0x2000u
+/* CROSS/PHASE: the reference flips each field by its own coordinate (xrft.py:436-441): these flip field 0 (d_in0), FLIP_Y /
+ * FLIP_X flip field 1 (d_in1).  The window always multiplies in the source order, before the flip (xrft.py:425-441). */
+#define XRFTHIP_FLIP0_Y 0x4000u
+#define XRFTHIP_FLIP0_X 0x8000u
 
 typedef struct xrfthip_desc {
     uint32_t struct_size; /* = sizeof(xrfthip_desc) */

@@ -39,11 +39,9 @@ def check(got, ref, tol):
         if d in ref.coords:
             gv = np.asarray(got[d].values)
             rv = np.asarray(ref.coord(d))
-            if rv.dtype.kind in "fc":
-                np.testing.assert_allclose(gv.astype(np.float64), rv.astype(np.float64), rtol=1e-13, atol=0,
-                                           equal_nan=True)
-            else:
-                assert np.array_equal(gv, rv)
+            # frequency / bin-centre coordinates are host float64 arithmetic on both sides: bit for bit
+            assert gv.shape == rv.shape and gv.dtype == rv.dtype, (d, gv.dtype, rv.dtype)
+            assert np.array_equal(gv, rv, equal_nan=rv.dtype.kind in "fc"), d
             ra = ref.coord_attrs.get(d, {})
             for k, v in ra.items():
                 assert k in got[d].attrs, (d, k)
@@ -185,6 +183,20 @@ def run_cross_case(kind, dtype, seed=1):
         kw = dict(dim=["y"], real_dim="x", detrend="linear")
     elif kind == "one_dim":
         kw = dict(dim=["x"], window="hann", window_correction=True)
+    elif kind in ("opposite_x", "opposite_y_mid_axis"):
+        # the two fields' coordinates run in opposite directions: the reference flips each by its own coordinate, after the
+        # window (xrft.py:425-441) -- per-field flip flags in the engine (XRFTHIP_FLIP0_* / XRFTHIP_FLIP_*)
+        c3 = dict(c2)
+        if kind == "opposite_x":
+            c3["x"] = c2["x"][::-1].copy()
+            kw = dict(dim=["y", "x"], window="hann", detrend="linear")
+        else:
+            c3["y"] = c2["y"][::-1].copy()
+            kw = dict(dim=["y"], window="hann")
+        db, ob = pair(b, D3, c3)
+        e1 = check(xa.cross_spectrum(da, db, **kw), o.cross_spectrum(od, ob, **kw), TOL[dtype])
+        e2 = check(xa.cross_spectrum(db, da, **kw), o.cross_spectrum(ob, od, **kw), TOL[dtype])
+        return max(e1, e2)
     elif kind == "iso":
         got = xa.isotropic_cross_spectrum(da, db, dim=["y", "x"], window="hann", detrend="linear")
         ref = o.isotropic_cross_spectrum(od, ob, dim=["y", "x"], window="hann", detrend="linear")
@@ -194,7 +206,7 @@ def run_cross_case(kind, dtype, seed=1):
     return check(xa.cross_spectrum(da, db, **kw), o.cross_spectrum(od, ob, **kw), TOL[dtype])
 
 
-CROSS_KINDS = ["true_phase_window", "nophase_spectrum", "real_dim", "one_dim", "iso"]
+CROSS_KINDS = ["true_phase_window", "nophase_spectrum", "real_dim", "one_dim", "iso", "opposite_x", "opposite_y_mid_axis"]
 
 
 # ---- true-phase cases with descending / offset coordinates --------------------------------------------

@@ -122,6 +122,46 @@ def gen_reference_misc():
     print("reference-generated: ref_misc.npz")
 
 
+def gen_reference_bins():
+    """Radial bin maps (ref_bins.npz): the reference's own expressions of xrft.py:975-981 and :921-923 evaluated with the
+    installed pandas, pushed through the reference's ``_binned_agg`` (xrft.py:877-907) whose numpy_groupies.aggregate call is
+    intercepted by a recorder: what is stored are the integer bin indices the reference hands to the aggregation, for the
+    frequency grids the reference's ``_freq`` produces.  (numpy_groupies itself is not installed: the aggregate's
+    arithmetic -- a per-bin sum / mean -- is not pinned here.)"""
+    import pandas as pd
+
+    rx, _ = import_reference()
+    rec = {}
+    ng = types.ModuleType("numpy_groupies")
+
+    def aggregate(idx, a, func=None, size=None, fill_value=0, dtype=None, axis=-1):
+        rec["idx"], rec["size"], rec["func"] = np.array(idx), int(size), func
+        return np.zeros(a.shape[:-1] + (size,))
+
+    ng.aggregate = aggregate
+    sys.modules["numpy_groupies"] = ng
+    out = {}
+    cases = []
+    for j, (N, dx, nfactor) in enumerate([((16, 32), (1.0, 1.0), 4), ((512, 512), (1.0, 1.0), 4), ((720, 1440), (0.25, 0.25), 4),
+                                           ((256, 256), (2.0, 0.5), 2)]):
+        ll, kk = rx._freq(list(N), list(dx), None, True)  # freq_y (fftdim[0]), freq_x (fftdim[1]), shifted
+        nbins = int(min(kk.size, ll.size) / nfactor)  # xrft.py:977-979
+        freq_r = np.sqrt(kk[:, None] ** 2 + ll[None, :] ** 2)  # xrft.py:980 (xarray broadcasting of k (dim fftdim[1]) and l)
+        binned = pd.cut(np.ravel(freq_r), nbins)  # xrft.py:921
+        indices = binned.codes.reshape(freq_r.shape)  # xrft.py:923
+        rx._binned_agg(freq_r, indices, binned.categories.size, func="mean", fill_value=0, dtype=None)
+        assert rec["size"] == binned.categories.size and rec["idx"].size == freq_r.size
+        out[f"k_{j}"], out[f"l_{j}"] = kk, ll
+        out[f"codes_{j}"] = rec["idx"].reshape(freq_r.shape).astype(np.int16)
+        out[f"left_{j}"] = np.array([iv.left for iv in binned.categories])
+        out[f"right_{j}"] = np.array([iv.right for iv in binned.categories])
+        cases.append((N[0], N[1], dx[0], dx[1], nfactor, nbins))
+    out["cases"] = np.array(cases, dtype=np.float64)
+    np.savez_compressed(os.path.join(HERE, "ref_bins.npz"), **out)
+    del sys.modules["numpy_groupies"]
+    print("reference-generated: ref_bins.npz")
+
+
 def gen_oracle_cases():
     from oracle import xrft_oracle as o
     import warnings
@@ -196,6 +236,9 @@ def gen_oracle_cases():
     print("oracle-generated: case_ps2d_f64.npz, case_ps2d_f32_real.npz, case_cs2d.npz, case_iso.npz, case_dft1d_f32.npz")
 
 
+if __name__ == "__main__" and "--bins-only" in sys.argv:
+    gen_reference_bins()
+    sys.exit(0)
 if __name__ == "__main__" and "--misc-only" in sys.argv:
     gen_reference_misc()
     sys.exit(0)
@@ -207,4 +250,5 @@ if __name__ == "__main__":
         print("no /root/reference: skipping reference-generated files")
     if os.path.isdir("/root/reference/xrft"):
         gen_reference_misc()
+        gen_reference_bins()
     gen_oracle_cases()

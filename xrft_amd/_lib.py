@@ -19,7 +19,8 @@ HALF_X, SHIFT_Y, SHIFT_X, ISHIFT_Y, ISHIFT_X, FLIP_Y, FLIP_X = 0x1, 0x2, 0x4, 0x
 REALDIM_X2, ISO, NO_SPECTRUM_OUT = 0x80, 0x100, 0x200
 INVERSE, C2R_X, PHASE_IN = 0x400, 0x800, 0x1000
 UNSUPPORTED_LENGTH = -2  # xrfthip_status
-AXIS_Y = 0x2000  # transform y of [batch][ny][nx] in place (a middle or first axis of the array), no transposed copy
+AXIS_Y = 0x2000
+FLIP0_Y, FLIP0_X = 0x4000, 0x8000  # cross spectra: flip field 0 (FLIP_Y / FLIP_X then flip field 1)  # transform y of [batch][ny][nx] in place (a middle or first axis of the array), no transposed copy
 
 EXPORTS = [
     "xrfthip_version", "xrfthip_strerror", "xrfthip_last_hip_error", "xrfthip_plan_create",

@@ -339,8 +339,9 @@ def _analyze(da, spacing_tol, dim, real_dim, shift, detrend, window, true_phase,
     return c
 
 
-def _flags_tables(c, da, other_lag=None):
-    """Engine flags, window vectors and phase tables per device axis (y, x)."""
+def _flags_tables(c, da, other_lag=None, other_reversed=None):
+    """Engine flags, window vectors and phase tables per device axis (y, x).  ``other_reversed``: cross spectra -- the
+    reference flips each field by its own coordinate (xrft.py:436-441): ``c`` is field 0 (FLIP0_*), the other field 1."""
     flags = 0
     win = {"y": None, "x": None}
     ph = {"y": None, "x": None}
@@ -350,8 +351,14 @@ def _flags_tables(c, da, other_lag=None):
             flags |= _lib.SHIFT_X if ax == "x" else _lib.SHIFT_Y
         if c.true_phase:
             flags |= _lib.ISHIFT_X if ax == "x" else _lib.ISHIFT_Y
-            if c.reversed[i]:
-                flags |= _lib.FLIP_X if ax == "x" else _lib.FLIP_Y
+            if other_reversed is None:
+                if c.reversed[i]:
+                    flags |= _lib.FLIP_X if ax == "x" else _lib.FLIP_Y
+            else:
+                if c.reversed[i]:
+                    flags |= _lib.FLIP0_X if ax == "x" else _lib.FLIP0_Y
+                if other_reversed[i]:
+                    flags |= _lib.FLIP_X if ax == "x" else _lib.FLIP_Y
             # xrft.py:462-469 -- indexed by unshifted frequency; the real axis uses rfftfreq on its kept half
             n = c.N[i]
             f = np.fft.fftfreq(n, c.delta_x[i])
@@ -416,17 +423,15 @@ def _execute_axis_y(c, da, mode, scale, k, da2=None, c2=None):
     ny = shape[k]
     nx = int(np.prod(shape[k + 1:], dtype=np.int64))
     batch = int(np.prod(shape[:k], dtype=np.int64))
-    flags, win, ph = _flags_tables(c, da, None if c2 is None else c2.lag_x)
+    flags, win, ph = _flags_tables(c, da, None if c2 is None else c2.lag_x, None if c2 is None else c2.reversed)
     if mode == _lib.OUT_POWER:
         ph = {"y": None, "x": None}
     yflags = _lib.AXIS_Y
-    for fx, fy in ((_lib.SHIFT_X, _lib.SHIFT_Y), (_lib.ISHIFT_X, _lib.ISHIFT_Y), (_lib.FLIP_X, _lib.FLIP_Y)):
+    for fx, fy in ((_lib.SHIFT_X, _lib.SHIFT_Y), (_lib.ISHIFT_X, _lib.ISHIFT_Y), (_lib.FLIP_X, _lib.FLIP_Y), (_lib.FLIP0_X, _lib.FLIP0_Y)):
         if flags & fx:
             yflags |= fy
     t2 = None
     if da2 is not None:
-        if c2.reversed[0] != c.reversed[0] and c.true_phase:
-            return None
         t2 = _to_device(da2.data).contiguous()
         if tuple(da2.dims) != tuple(da.dims) or t2.shape != t.shape:
             raise ValueError("The two datasets have different dimensions")
@@ -456,7 +461,7 @@ def _execute(c, da, mode, scale, da2=None, c2=None, iso=None, extra_flags=0):
     nx = da.sizes[c.xdim]
     ny = da.sizes[c.ydim] if c.ydim is not None else 1
     batch = t.numel() // max(ny * nx, 1)
-    flags, win, ph = _flags_tables(c, da, None if c2 is None else c2.lag_x)
+    flags, win, ph = _flags_tables(c, da, None if c2 is None else c2.lag_x, None if c2 is None else c2.reversed)
     if mode == _lib.OUT_POWER:
         ph = {"y": None, "x": None}
     flags |= extra_flags
@@ -468,15 +473,6 @@ def _execute(c, da, mode, scale, da2=None, c2=None, iso=None, extra_flags=0):
         if t2.dtype != t.dtype:
             dt = torch.promote_types(t.dtype, t2.dtype)
             t, t2 = t.to(dt), t2.to(dt)
-        for i, d in enumerate(c.dim):
-            if c.true_phase and c.reversed[i] != c2.reversed[i]:
-                # The engine flips both fields alike (xrft.py:436-441 flips each by its own coordinate).  Pre-flip
-                # the second field; only exact when no (flip-asymmetric, sym=False) window is applied.
-                if c.windows is not None:
-                    raise NotImplementedError("cross_spectrum of fields whose coordinates run in opposite "
-                                              "directions combined with a window is not supported")
-                axis = t2.dim() - 1 if d == c.xdim else t2.dim() - 2
-                t2 = torch.flip(t2, dims=[axis]).contiguous()
     kw = dict(ndim=ndim, batch=batch, ny=ny, nx=nx, dtype=t.dtype, out_mode=mode, detrend=c.detrend, flags=flags,
               scale=float(scale), window_y=win["y"], window_x=win["x"], phase_y=ph["y"], phase_x=ph["x"])
     bkey = None
@@ -972,20 +968,20 @@ def cross_phase(da1, da2, dim=None, true_phase=True, **kwargs):
 _bins_cache: "OrderedDict[tuple, tuple]" = OrderedDict()
 
 
-def _radial_bins(k, l, nfactor):
+def _radial_bins(k, l, nfactor, ref_order=None):
     """Bin codes and per-bin mean radius for the grid sqrt(k^2 + l^2), dims (k, l)  (xrft.py:975-981, 910-923).
 
     ``pd.cut`` on the float64 radii, exactly the reference's expression; the per-bin mean replaces
     ``numpy_groupies.aggregate(func="mean", fill_value=0)``.  The result depends only on the two frequency vectors
     and nfactor, and costs seconds of host time at 4096^2, so it is cached (the reference recomputes it per call).
     """
-    key = (k.size, l.size, _digest(k), _digest(l), nfactor)
+    key = (k.size, l.size, _digest(k), _digest(l), nfactor, ref_order)
     with _plan_lock:
         hit = _bins_cache.get(key)
         if hit is not None:
             _bins_cache.move_to_end(key)
             return hit
-    res = _radial_bins_uncached(k, l, nfactor) + (key,)
+    res = _radial_bins_uncached(k, l, nfactor, ref_order) + (key,)
     with _plan_lock:
         _bins_cache[key] = res
         while len(_bins_cache) > 8:
@@ -993,17 +989,28 @@ def _radial_bins(k, l, nfactor):
     return res
 
 
-def _radial_bins_uncached(k, l, nfactor):
+def _radial_bins_uncached(k, l, nfactor, ref_order=None):
     N = [k.size, l.size]
     nbins = int(min(N) / nfactor)
     freq_r = np.sqrt(k[:, None] ** 2 + l[None, :] ** 2)
     binned = pd.cut(np.ravel(freq_r), nbins)
     codes = binned.codes.reshape(freq_r.shape)
     nb = binned.categories.size
-    valid = codes >= 0
-    cnt = np.bincount(codes[valid], minlength=nb)
-    s = np.bincount(codes[valid], weights=freq_r[valid], minlength=nb)
-    kr = np.where(cnt > 0, s / np.maximum(cnt, 1), 0.0)
+    cr, fr = codes, freq_r
+    if ref_order is not None:
+        # The bin-centre coordinate is a per-bin MEAN: its last bits depend on the order of the sum.  The reference sums
+        # over the (fftdim[1], fftdim[0]) grid of the SHIFTED coordinates (xrft.py:980-981); visit the same cells in the
+        # same order (the codes and radii themselves are order-independent).
+        shift_k, shift_l, transpose = ref_order
+        ik = np.fft.fftshift(np.arange(k.size)) if shift_k else np.arange(k.size)
+        il = np.fft.fftshift(np.arange(l.size)) if shift_l else np.arange(l.size)
+        cr, fr = codes[np.ix_(ik, il)], freq_r[np.ix_(ik, il)]
+        if transpose:
+            cr, fr = cr.T, fr.T
+    valid = cr >= 0
+    cnt = np.bincount(cr[valid], minlength=nb)
+    s_ = np.bincount(cr[valid], weights=fr[valid], minlength=nb)
+    kr = np.where(cnt > 0, s_ / np.maximum(cnt, 1), 0.0)
     return codes.astype(np.int32), kr, nb
 
 
@@ -1068,9 +1075,9 @@ def _iso_spectrum(da, da2, spacing_tol, dim, shift, detrend_, scaling, window, w
     kx = c.k_unshifted[c.dim.index(c.xdim)]
     kk = c.new_coords[fftdim[1]].values
     ll = c.new_coords[fftdim[0]].values
-    codes_yx, kr, nb, bkey = _radial_bins(ky, kx, nfactor)
-    # reference bins over (fftdim[1], fftdim[0]); the edges depend only on min/max of the same set of radii,
-    # and kr (a per-bin mean of the same multiset) is identical up to summation order
+    # reference bins over (fftdim[1], fftdim[0]) of the shifted coordinates: the edges depend only on min/max of the same set
+    # of radii; kr (a per-bin mean of the same multiset) is summed in the reference's cell order to match it bit for bit
+    codes_yx, kr, nb, bkey = _radial_bins(ky, kx, nfactor, (bool(c.shift), bool(c.shift), fftdim[1] == c.swap[c.xdim]))
     iso_cfg = {"binmap": codes_yx, "nbins": nb, "binmap_key": bkey}
     da = c.da
     out, iso, other = _execute(c, da, mode, scale, da2=None if c2 is None else c2.da, c2=c2, iso=iso_cfg,

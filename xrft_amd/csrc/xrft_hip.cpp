@@ -354,7 +354,10 @@ bool split_two(long long n, long long& n1, long long& n2) {
 template <typename T>
 struct Builder {
     xrfthip_plan& P;
+    bool cur_raw = false;  // building the field-0 pipeline of a cross spectrum: its own flip flags (xrft.py:436-441 flips each field by its own coordinate)
     explicit Builder(xrfthip_plan& p) : P(p) {}
+    bool flip_x() const { return (P.d.flags & (cur_raw ? XRFTHIP_FLIP0_X : XRFTHIP_FLIP_X)) != 0; }
+    bool flip_y() const { return (P.d.flags & (cur_raw ? XRFTHIP_FLIP0_Y : XRFTHIP_FLIP_Y)) != 0; }
 
     int tables_for(int n, FftTables** out) {
         auto it = P.tables.find(n);
@@ -413,9 +416,9 @@ struct Builder {
         pr.j_mul_q = jmq;
         pr.ny = (int)d.ny;
         pr.nx = (int)d.nx;
-        pr.flip_y = !!(d.flags & XRFTHIP_FLIP_Y);
+        pr.flip_y = flip_y();
         pr.ishift_y = !!(d.flags & XRFTHIP_ISHIFT_Y);
-        pr.flip_x = !!(d.flags & XRFTHIP_FLIP_X);
+        pr.flip_x = flip_x();
         pr.ishift_x = !!(d.flags & XRFTHIP_ISHIFT_X);
         pr.slab_stride = d.ny * d.nx;
         pr.row_stride = d.nx;
@@ -506,7 +509,7 @@ struct Builder {
             ps.g.tiles_per_outer = 1;
             ps.outer_per_slab = rows;
             fill_prologue(ps, rows, 1, 0);
-            if (real_in && !(d.flags & (XRFTHIP_FLIP_X | XRFTHIP_C2R_X | XRFTHIP_INVERSE)) && env_ll("XRFTHIP_LEAN_ROWS", 1) &&
+            if (real_in && !flip_x() && !(d.flags & (XRFTHIP_C2R_X | XRFTHIP_INVERSE)) && env_ll("XRFTHIP_LEAN_ROWS", 1) &&
                 ps.lds + 48 * (size_t)c.T + 32 <= kLdsMax) {  // lean row loader: per-row constants behind everything else
                 ps.g.rowc_off = (int)((ps.lds + 15) & ~(size_t)15);
                 ps.lds = (size_t)ps.g.rowc_off + 48 * (size_t)c.T;
@@ -551,7 +554,7 @@ struct Builder {
             a.out_kind = B_W2;
             if (ca.T <= 64 && (ca.T & (ca.T - 1)) == 0 && a.threads % ca.T == 0 && env_ll("XRFTHIP_LEAN_COL", 1)) {
                 a.g.lean_col = 2;
-                if (d.ndim == 1 && real_in && !(d.flags & (XRFTHIP_FLIP_X | XRFTHIP_C2R_X | XRFTHIP_INVERSE))) a.g.lean_col |= 1;
+                if (d.ndim == 1 && real_in && !flip_x() && !(d.flags & (XRFTHIP_C2R_X | XRFTHIP_INVERSE))) a.g.lean_col |= 1;
             }
             out.push_back(a);
         }
@@ -692,6 +695,7 @@ struct Builder {
     }
 
     int build_pipeline(std::vector<Pass>& out, bool raw) {
+        cur_raw = raw;
         if (P.d.flags & XRFTHIP_AXIS_Y) return build_yonly(out, raw);
         int rc = build_x(out, raw);
         if (rc) return rc;
@@ -1388,7 +1392,9 @@ int xrfthip_plan_create(xrfthip_plan** plan, const xrfthip_desc* desc) {
     if ((d.flags & XRFTHIP_ISO) && (d.ndim != 2 || d.out_mode == XRFTHIP_OUT_COMPLEX)) return XRFTHIP_BAD_ARG;
     if ((d.flags & XRFTHIP_NO_SPECTRUM_OUT) && !(d.flags & XRFTHIP_ISO)) return XRFTHIP_BAD_ARG;
     if (d.ndim == 1 && (d.flags & (XRFTHIP_SHIFT_Y | XRFTHIP_ISHIFT_Y | XRFTHIP_FLIP_Y))) return XRFTHIP_BAD_ARG;
-    if ((d.flags & XRFTHIP_AXIS_Y) && (d.ndim != 2 || (d.flags & (XRFTHIP_SHIFT_X | XRFTHIP_ISHIFT_X | XRFTHIP_FLIP_X | XRFTHIP_HALF_X | XRFTHIP_REALDIM_X2 |
+    if ((d.flags & (XRFTHIP_FLIP0_Y | XRFTHIP_FLIP0_X)) && d.out_mode != XRFTHIP_OUT_CROSS && d.out_mode != XRFTHIP_OUT_PHASE) return XRFTHIP_BAD_ARG;
+    if ((d.flags & XRFTHIP_FLIP0_Y) && d.ndim == 1) return XRFTHIP_BAD_ARG;
+    if ((d.flags & XRFTHIP_AXIS_Y) && (d.ndim != 2 || (d.flags & XRFTHIP_FLIP0_X) || (d.flags & (XRFTHIP_SHIFT_X | XRFTHIP_ISHIFT_X | XRFTHIP_FLIP_X | XRFTHIP_HALF_X | XRFTHIP_REALDIM_X2 |
                                                                     XRFTHIP_ISO | XRFTHIP_NO_SPECTRUM_OUT | XRFTHIP_C2R_X | XRFTHIP_PHASE_IN)))) return XRFTHIP_BAD_ARG;
 
     xrfthip_plan* P = new (std::nothrow) xrfthip_plan();
