@@ -60,7 +60,7 @@ def _cpu_pool_slab(arg):
     return float(r.values[0, 0, 0])
 
 
-def main():
+def main(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
@@ -72,7 +72,13 @@ def main():
     ap.add_argument("--cpu-pool", type=int, default=-1, help="worker processes for the all-cores CPU figure, one slab each "
                     "(-1 = as many as host cores, slabs and memory allow; 0 = skip)")
     ap.add_argument("--no-profile", action="store_true", help="do not record per-kernel HIP events")
-    args = ap.parse_args()
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
+                    help="weak: --nt slabs PER GPU (default); strong: --nt slabs in total, contiguous blocks per rank")
+    ap.add_argument("--workload", choices=["ps", "c4"], default="ps",
+                    help="ps: BASELINE.json configs[2] (power_spectrum, the headline metric); c4: configs[3] -- cross_spectrum + "
+                         "isotropic_cross_spectrum of two fields per rank, the isotropic result all-gathered over RCCL")
+    ap.add_argument("--emulate", action="store_true", help=argparse.SUPPRESS)  # tests/test_bench_ranks_cpu.py: gloo + the emulated library
+    args = ap.parse_args(argv)
 
     import numpy as np
     import torch
@@ -82,40 +88,78 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     dist = None
+    emu = args.emulate
     if world > 1:
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        torch.cuda.set_device(local)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if emu:
+            dist.init_process_group("gloo")
+        else:
+            torch.cuda.set_device(local)
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
     assert world == max(args.gpus, 1), f"--gpus {args.gpus} but WORLD_SIZE={world}"
-    dev = torch.device("cuda", local)
-    torch.cuda.set_device(dev)
+    dev = torch.device("cpu") if emu else torch.device("cuda", local)
+    if not emu:
+        torch.cuda.set_device(dev)
 
     import xrft_amd as xrft
     from xrft_amd import _lib, api
+    from xrft_amd import dist as xdist
 
-    _lib.load()  # no fallback: raises if the HIP library is missing
-    nt, ny, nx = args.nt, args.ny, args.nx
+    if emu:  # CPU test of the rank logic only (never a measurement): the emulated build of the same C ABI
+        sys.path.insert(0, os.path.join(REPO, "tests", "emu"))
+        import build_emu
+
+        _lib._load_for_testing(build_emu.build())
+    else:
+        _lib.load()  # no fallback: raises if the HIP library is missing
+    ny, nx = args.ny, args.nx
+    if args.workload == "c4" and (args.ny, args.nx) == (4096, 4096):
+        ny = nx = 2048  # BASELINE.json configs[3]
+    # slabs of this rank: weak = --nt each; strong = contiguous block of --nt in total (never splits a slab)
+    if args.scaling == "strong":
+        lo, hi = xdist.shard_bounds(args.nt, rank, world)
+        nt, nt_total = hi - lo, args.nt
+    else:
+        nt, nt_total = args.nt, args.nt * world
 
     # ---- synthetic cube generated on the device: N(0,1) + plane + offset so that the linear detrend works
     gen = torch.Generator(device=dev)
-    gen.manual_seed(20260927 + 1000 * 3 + rank)
+    gen.manual_seed(20260927 + 1000 * (3 if args.workload == "ps" else 4) + rank)
     x = torch.randn((nt, ny, nx), dtype=torch.float32, device=dev, generator=gen)
     x += (0.01 * torch.arange(ny, device=dev, dtype=torch.float32))[None, :, None]
     x += (-0.02 * torch.arange(nx, device=dev, dtype=torch.float32) + 3.0)[None, None, :]
     coords = {"time": np.arange(nt), "y": np.arange(ny, dtype=np.float64), "x": np.arange(nx, dtype=np.float64)}
     da = xrft.DataArray(x, ("time", "y", "x"), coords)
+    collective = None
+    if args.workload == "c4":
+        x2 = 0.5 * x + torch.randn((nt, ny, nx), dtype=torch.float32, device=dev, generator=gen)
+        db = xrft.DataArray(x2, ("time", "y", "x"), coords)
 
-    def step():
-        return xrft.power_spectrum(da, dim=["y", "x"], detrend="linear", window="hann")
+    if args.workload == "ps":
+        def step():
+            return xrft.power_spectrum(da, dim=["y", "x"], detrend="linear", window="hann")
+    else:
+        nbins = min(ny, nx) // 4
+        collective = {"op": "all_gather", "backend": "gloo" if emu else "nccl (RCCL over xGMI)",
+                      "bytes_per_rank": int(-(-nt_total // world) * nbins * 16), "per_step": 1}
+
+        def step():  # BASELINE.json configs[3]: cross spectrum (stays sharded) + isotropic cross spectrum (gathered)
+            cs = xrft.cross_spectrum(da, db, dim=["y", "x"], window="hann")
+            ics = xrft.isotropic_cross_spectrum(da, db, dim=["y", "x"], window="hann")
+            if dist is not None:
+                ics = xdist.all_gather_batch(ics, "time", nt_total)
+            return cs, ics
 
     def barrier():
-        torch.cuda.synchronize(dev)
+        if not emu:
+            torch.cuda.synchronize(dev)
         if dist is not None:
             dist.barrier()
-        torch.cuda.synchronize(dev)
+        if not emu:
+            torch.cuda.synchronize(dev)
 
     # setup (not a step): prime torch's caching allocator so that no hipMalloc of a 4 GiB output lands in the timed
     # region -- a step holds the previous result while the next one is produced, i.e. two output blocks are live
@@ -144,7 +188,7 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax.item())
 
-    points_per_step = float(nt) * ny * nx * world
+    points_per_step = float(nt_total) * ny * nx  # points of ONE field transformed by all ranks per step
     value = 1e-9 * points_per_step * args.steps / dt
     ms_per_step = 1e3 * dt / args.steps
 
@@ -159,10 +203,13 @@ def main():
             launches, total_ms = kern[dom]
             avg_s = 1e-3 * total_ms / launches
             launches_per_step = launches / args.steps
-            pts_per_launch = float(nt) * ny * nx / launches_per_step
-            k_achieved = BYTES_PER_POINT * pts_per_launch / avg_s
+            # c4: two float32 fields in, one complex64 cross spectrum out per point (16 B/point); the
+            # isotropic call reads the two fields again (8 B/point, its output is negligible)
+            bpp = BYTES_PER_POINT if args.workload == "ps" else 16.0 + 8.0
+            pts_per_launch = float(nt) * ny * nx / max(launches_per_step, 1e-9)
+            k_achieved = bpp * pts_per_launch / avg_s
             kernel_ms = sum(v[1] for v in kern.values()) / args.steps
-            path_achieved = BYTES_PER_POINT * value * 1e9 / world  # B/s per GPU
+            path_achieved = bpp * value * 1e9 / world  # B/s per GPU
             # HBM traffic of one step from the committed PMC profile of this same command (rocprofv3 cannot run inside the
             # timed process): measured bytes per slab, all kernels, x slabs per step
             traffic = None
@@ -171,7 +218,7 @@ def main():
             try:
                 with open(os.path.join(REPO, "profiles", "r02_traffic.json")) as fh:
                     tj = json.load(fh)
-                traffic = tj["path_hbm_bytes_per_slab"] * nt
+                traffic = tj["path_hbm_bytes_per_slab"] * nt if args.workload == "ps" and (ny, nx) == (4096, 4096) else None
                 tnote = tj.get("note")
                 ceiling = tj.get("two_pass_ceiling")
             except Exception:
@@ -179,13 +226,16 @@ def main():
             roof = {
                 "bound": "hbm", "achieved": round(path_achieved / 1e9, 2), "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                 "frac": round(path_achieved / HBM_PEAK, 4),
-                "definition": "algorithmic bytes (8 B per input point: 4 read + 4 written) of one step / wall time of the step, per GPU",
+                "definition": ("algorithmic bytes (8 B per input point: 4 read + 4 written) of one step / wall time of the step, per GPU"
+                               if args.workload == "ps" else
+                               "algorithmic bytes (cross spectrum 16 B + isotropic cross spectrum 8 B per point of one field) of one "
+                               "step / wall time of the step, per GPU"),
                 "traffic": traffic, "traffic_note": tnote,
                 "kernel": {"name": dom, "avg_launch_us": round(avg_s * 1e6, 2), "points_per_launch": pts_per_launch,
                            "achieved": round(k_achieved / 1e9, 2), "frac": round(k_achieved / HBM_PEAK, 4),
                            "definition": "algorithmic bytes of the slabs one launch of the longest kernel processes / its average "
                                          "launch duration (HIP events on the launch stream inside the timed region)"},
-                "bytes_per_point": BYTES_PER_POINT,
+                "bytes_per_point": bpp,
                 "kernels_ms_per_step": {k: round(v[1] / args.steps, 3) for k, v in kern.items()},
                 "sum_kernels_ms_per_step": round(kernel_ms, 3),
                 "two_pass_ceiling": ceiling,
@@ -193,7 +243,7 @@ def main():
         # ---- CPU baseline (the oracle on a bounded sample, 1 thread) + parity of the same slabs
         cpu = None
         parity = None
-        if args.cpu_slabs > 0 and world == 1:
+        if args.cpu_slabs > 0 and world == 1 and args.workload == "ps" and not emu:
             from oracle import xrft_oracle as oracle
 
             try:
@@ -242,16 +292,26 @@ def main():
                                                   f"min(host cores {ncores}, slabs in the workload {nt}, memory cap {mem_cap})"}
                 except Exception as e:  # pragma: no cover
                     cpu["all_cores"] = {"error": repr(e)}
+        if args.workload == "ps":
+            wl = (f"xrft.power_spectrum dim=[y,x] detrend=linear window=hann on ({nt},{ny},{nx}) float32 per GPU "
+                  f"(BASELINE.json configs[2])")
+            metric = f"2-D power_spectrum GFFT/s (nt,{ny},{nx}) fp32"
+            par = f"time-slab shards x{world}, no collective"
+        else:
+            wl = (f"xrft.cross_spectrum + xrft.isotropic_cross_spectrum window=hann on two ({nt},{ny},{nx}) float32 fields per GPU "
+                  f"(BASELINE.json configs[3]); GFFT/s counts the points of one field")
+            metric = f"2-D cross_spectrum + isotropic_cross_spectrum GFFT/s (nt,{ny},{nx}) fp32"
+            par = f"time-slab shards x{world}; full cross spectra stay sharded, one all_gather of the ({nt_total}, {min(ny, nx) // 4}) isotropic result per step"
         out = {
-            "metric": "2-D power_spectrum GFFT/s (nt,4096,4096) fp32", "value": round(value, 3), "unit": "GFFT/s",
+            "metric": metric, "value": round(value, 3), "unit": "GFFT/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"xrft.power_spectrum dim=[y,x] detrend=linear window=hann on ({nt},{ny},{nx}) "
-                                   f"float32 per GPU (BASELINE.json configs[2])",
-                       "nt_per_gpu": nt, "ny": ny, "nx": nx, "parallelism": f"time-slab shards x{world}, no collective",
-                       "slabs_per_s": round(nt * world * args.steps / dt, 2)},
+            "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": wl, "nt_per_gpu": nt, "nt_total": nt_total, "ny": ny, "nx": nx, "parallelism": par,
+                       "collective": collective, "slabs_per_s": round(nt_total * args.steps / dt, 2)},
             "roofline": roof, "cpu_baseline": cpu, "parity_max_rel_err_vs_oracle": parity,
         }
+        if emu:
+            out["data"] = "synthetic (EMULATED library on CPU: rank-logic test, not a measurement)"
         if plan is not None:
             out["plan"] = plan.describe().strip().split("\n")
     if dist is not None:
@@ -259,6 +319,7 @@ def main():
         dist.destroy_process_group()
     if rank == 0:
         print(json.dumps(out), flush=True)
+    return out
 
 
 if __name__ == "__main__":

@@ -1,0 +1,56 @@
+"""bench.py's rank logic (sharding for weak / strong scaling, barriers, max-over-ranks timing, the c4 workload's all_gather)
+run as two gloo processes on the CPU with the emulated library and tiny shapes -- so that the first real multi-GPU run
+is not the first run of this code.  Nothing here is a measurement."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(HERE)
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _run(world, extra):
+    sys.path.insert(0, os.path.join(HERE, "emu"))
+    import build_emu
+
+    build_emu.build()  # once, before the ranks race for it
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(REPO, "bench.py"), "--gpus", str(world), "--steps", "2", "--warmup", "1",
+           "--ny", "256", "--nx", "256", "--emulate", "--cpu-slabs", "0"] + extra
+    env = dict(os.environ, OMP_NUM_THREADS="1", XRFT_EMU_THREADS="2")
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=REPO)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]  # rank 0 prints ONE JSON line
+    return json.loads(lines[0])
+
+
+@pytest.mark.parametrize("scaling", ["weak", "strong"])
+def test_bench_two_ranks_power_spectrum(scaling):
+    out = _run(2, ["--nt", "3", "--scaling", scaling])
+    assert out["n_gpus"] == 2 and out["scaling"] == scaling and out["unit"] == "GFFT/s" and out["value"] > 0
+    cfg = out["config"]
+    if scaling == "weak":
+        assert cfg["nt_per_gpu"] == 3 and cfg["nt_total"] == 6
+    else:
+        assert cfg["nt_total"] == 3 and cfg["nt_per_gpu"] == 2  # rank 0 owns slabs [0, 2)
+    assert out["roofline"]["achieved"] >= 0 and "fasty_cols" in out["roofline"]["kernels_ms_per_step"]
+
+
+def test_bench_two_ranks_c4_all_gather():
+    out = _run(2, ["--nt", "2", "--workload", "c4"])
+    assert out["n_gpus"] == 2 and "cross_spectrum" in out["metric"]
+    col = out["config"]["collective"]
+    assert col["op"] == "all_gather" and col["bytes_per_rank"] == 2 * 64 * 16  # (nt/world, nbins = 256/4) complex128 per rank
