@@ -172,6 +172,18 @@ int xrfthip_detrend3(int32_t dtype, int64_t batch, int64_t n0, int64_t n1, int64
  * d_a[e] * conj(d_b[e]) * scale (complex).  dtype = XRFTHIP_C64 | XRFTHIP_C128 (type of d_a / d_b). */
 int xrfthip_spectrum_tail(int32_t dtype, int64_t n, const void* d_a, const void* d_b, void* d_out, double scale, void* stream);
 
+/* The same over [outer][na][inner] with the real-dim factor [1, 2, ..., 2, (1 if last_is_one)] along axis `na` (xrft.py:673-682):
+ * the kept half of a real transform counts twice, except k = 0 and, for an even length, the Nyquist sample. */
+int xrfthip_spectrum_tail_axis(int32_t dtype, int64_t outer, int64_t na, int64_t inner, int32_t last_is_one, const void* d_a, const void* d_b,
+                               void* d_out, double scale, void* stream);
+
+/* out[o][i][j] = in[o][src(i)][j] over [outer][n_out][inner] (source [outer][n_in][inner]), elem_bytes = 4 | 8 | 16:
+ * src(i) = d_index[i] (device int64[n_out]) or, with d_index NULL, (i - roll) mod n_in (numpy.roll: n_out == n_in).
+ * The fftshift / ifftshift of the backend module (xrft.py:446-447, 617-621) and the gather of spectra that are not stored
+ * in fftshift order (xrft.ifft).  d_out must not alias d_in. */
+int xrfthip_gather_axis(int32_t elem_bytes, int64_t outer, int64_t n_out, int64_t inner, int64_t n_in, const int64_t* d_index, int64_t roll,
+                        const void* d_in, void* d_out, void* stream);
+
 /* Stand-alone radial bin-sum of an existing spectrum (xrft.isotropize, xrft.py:948-1010):
  * d_in [batch][ny][nx] (dtype F32|F64|C64|C128), d_binmap device int32 [ny][nx], d_iso float64|complex128
  * [batch][nbins] (zeroed by the call). */

@@ -380,3 +380,13 @@ def test_torch_conj_and_neg_views_are_resolved():
         got = xa.fft(xa.DataArray(view, ("t", "y", "x"), c), dim=["y", "x"], true_phase=False, true_amplitude=False, shift=False)
         want = np.fft.fftn(ref, axes=(1, 2))
         assert np.abs(got.values - want).max() / np.abs(want).max() < 1e-12
+
+
+def test_fftmod_backend_object():
+    """xrft_amd.fftmod -- the module the reference's `_fft_module` seam can return (xrft.py:32-36): fftn / rfftn / ifftn /
+    irfftn / fftshift / ifftshift with the reference's call shapes against numpy.fft."""
+    import fftmod_cases
+
+    from xrft_amd import fftmod
+
+    assert fftmod_cases.run_all(fftmod) < 2e-5

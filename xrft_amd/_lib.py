@@ -26,7 +26,7 @@ EXPORTS = [
     "xrfthip_version", "xrfthip_strerror", "xrfthip_last_hip_error", "xrfthip_plan_create",
     "xrfthip_plan_destroy", "xrfthip_plan_set_window", "xrfthip_plan_set_phase", "xrfthip_plan_set_binmap",
     "xrfthip_plan_set_profiling", "xrfthip_plan_profile_read", "xrfthip_workspace_bytes", "xrfthip_plan_describe", "xrfthip_exec", "xrfthip_detrend_workspace_bytes",
-    "xrfthip_detrend", "xrfthip_detrend3", "xrfthip_spectrum_tail", "xrfthip_isotropize",
+    "xrfthip_detrend", "xrfthip_detrend3", "xrfthip_spectrum_tail", "xrfthip_spectrum_tail_axis", "xrfthip_gather_axis", "xrfthip_isotropize",
 ]
 
 
@@ -71,6 +71,8 @@ def _bind(dll):
     dll.xrfthip_detrend.argtypes = [i32, i32, i64, i64, i64, i32, vp, vp, vp, sz, vp]
     dll.xrfthip_detrend3.argtypes = [i32, i64, i64, i64, i64, i32, vp, vp, vp, sz, vp]
     dll.xrfthip_spectrum_tail.argtypes = [i32, i64, vp, vp, vp, C.c_double, vp]
+    dll.xrfthip_spectrum_tail_axis.argtypes = [i32, i64, i64, i64, i32, vp, vp, vp, C.c_double, vp]
+    dll.xrfthip_gather_axis.argtypes = [i32, i64, i64, i64, i64, vp, i64, vp, vp, vp]
     dll.xrfthip_isotropize.argtypes = [i32, i64, i64, i64, vp, vp, i32, vp, vp]
     for name in EXPORTS:
         getattr(dll, name)  # AttributeError here = the .so does not export what the header declares

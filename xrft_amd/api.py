@@ -582,16 +582,10 @@ def _spectrum_nd(da, da2, dims, real_dim, scaling, window_correction, true_phase
         if b.dtype != a.dtype:
             dt = torch.promote_types(a.dtype, b.dtype)
             a, b = a.to(dt), b.to(dt)
-    out = engine.spectrum_tail(a, b, scale)
     if real_dim is not None:  # xrft.py:673-682: the kept half of the real axis counts twice, except k = 0 and Nyquist
-        nreal = da.sizes[real_dim]
-        fac = np.full(out.shape[f1.get_axis_num(new[-1])], 2.0)
-        fac[0] = 1.0
-        if nreal % 2 == 0:
-            fac[-1] = 1.0
-        shp = [1] * out.ndim
-        shp[f1.get_axis_num(new[-1])] = fac.size
-        out = out * torch.from_numpy(fac).to(device=out.device, dtype=out.real.dtype if out.is_complex() else out.dtype).reshape(shp)
+        out = engine.spectrum_tail_axis(a, b, scale, f1.get_axis_num(new[-1]), da.sizes[real_dim] % 2 == 0)
+    else:
+        out = engine.spectrum_tail(a, b, scale)
     return DataArray(out, f1.dims, f1.coords, None, None)
 
 
@@ -743,8 +737,7 @@ def ifft(daft, spacing_tol=1e-3, dim=None, real_dim=None, shift=True, true_phase
         p = phase[d]
         if isinstance(m, np.ndarray):  # gather to the unshifted layout on the device; the phase follows the data
             axis = t.dim() - 1 if ax == "x" else t.dim() - 2
-            idx = torch.from_numpy(m.astype(np.int64)).to(t.device)
-            t = torch.index_select(t, axis, idx)
+            t = engine.gather_axis(t, axis, index=m)
             p = None if p is None else p[m]
         elif m == "ishift":
             flags |= _lib.ISHIFT_X if ax == "x" else _lib.ISHIFT_Y
@@ -786,7 +779,7 @@ def ifft(daft, spacing_tol=1e-3, dim=None, real_dim=None, shift=True, true_phase
     out, _ = plan.execute(t)
     out = out.reshape([daft.sizes[d] for d in other] + list(out.shape[-len(tdims):]))
     for ax, sh in post_roll:
-        out = torch.roll(out, shifts=sh, dims=out.dim() - 1 if ax == "x" else out.dim() - 2)
+        out = engine.gather_axis(out, out.dim() - 1 if ax == "x" else out.dim() - 2, roll=sh)
     cur = other + [swap[d] for d in tdims]
     final = [swap.get(d, d) for d in rawdims]
     if cur != final:
@@ -1043,7 +1036,7 @@ def isotropize(ps, fftdim, nfactor=4, truncate=True, complx=False):
     bm = torch.from_numpy(np.ascontiguousarray(codes)).to(t.device)
     iso = engine.isotropize(t, bm, nb)
     iso = iso.reshape([ps.sizes[d] for d in other] + [nb])
-    vals = iso.cpu().numpy()
+    vals = iso.cpu().numpy() if truncate else iso  # (truncate: dropna inspects the data values, xrft.py:1007-1008)
     kr, vals = _finish_iso(kr, k, l, truncate, vals)
     coords = {c: v for c, v in ps.coords.items() if not (set(v.dims) & set(fftdim))}
     coords["freq_r"] = Coordinate(("freq_r",), kr, None, "freq_r")
@@ -1082,7 +1075,9 @@ def _iso_spectrum(da, da2, spacing_tol, dim, shift, detrend_, scaling, window, w
     da = c.da
     out, iso, other = _execute(c, da, mode, scale, da2=None if c2 is None else c2.da, c2=c2, iso=iso_cfg,
                                extra_flags=flags | _lib.ISO | _lib.NO_SPECTRUM_OUT)
-    vals = iso.reshape([da.sizes[d] for d in other] + [nb]).cpu().numpy()
+    vals = iso.reshape([da.sizes[d] for d in other] + [nb])
+    if truncate:  # dropna inspects the DATA values (xrft.py:1007-1008): the only case that needs them on the host
+        vals = vals.cpu().numpy()
     kr, vals = _finish_iso(kr, kk, ll, truncate, vals)
     coords = {cn: cv for cn, cv in da.coords.items() if not (set(cv.dims) & set(dim))}
     coords["freq_r"] = Coordinate(("freq_r",), kr, None, "freq_r")

@@ -227,6 +227,35 @@ __global__ void __launch_bounds__(256) spectrum_tail_kernel(const C2<T>* a, cons
     }
 }
 
+// the same with the real-dim factor [1, 2, ..., 2, (1 if the real axis is even)] along one axis of [outer][na][inner] (xrft.py:673-682)
+template <typename T, bool CROSS>
+__global__ void __launch_bounds__(256) spectrum_tail_axis_kernel(const C2<T>* a, const C2<T>* b, void* out, long long n, double scale,
+                                                                 long long na, long long inner, int last_is_one) {
+    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (long long)gridDim.x * blockDim.x) {
+        const long long k = (e / inner) % na;
+        const T f = (T)((k == 0 || (last_is_one && k == na - 1)) ? scale : 2.0 * scale);
+        const C2<T> x = a[e];
+        if (CROSS) reinterpret_cast<C2<T>*>(out)[e] = cscale(cmulc(x, b[e]), f);
+        else reinterpret_cast<T*>(out)[e] = (x.re * x.re + x.im * x.im) * f;
+    }
+}
+
+// out[o][i][j] = in[o][src(i)][j] over [outer][n_out][inner]; src(i) = index[i], or (i - roll) mod n_in (numpy.roll) -- the
+// fftshift / ifftshift of the backend object (xrft.py:446-447, 617-621) and the re-ordering of spectra that are not stored
+// in fftshift order (xrft.ifft).  E = element type by size (4, 8, 16 bytes).
+template <typename E>
+__global__ void __launch_bounds__(256) gather_axis_kernel(const E* in, E* out, long long outer, long long n_out, long long inner, long long n_in,
+                                                          const long long* index, long long roll) {
+    const long long total = outer * n_out * inner;
+    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
+        const long long j = e % inner, r = e / inner, i = r % n_out, o = r / n_out;
+        long long si;
+        if (index) si = index[i];
+        else { si = (i - roll) % n_in; if (si < 0) si += n_in; }
+        out[e] = in[(o * n_in + si) * inner + j];
+    }
+}
+
 // iso[slab][bin] += in[slab][e] for bin = binmap[e] >= 0 ; LDS-privatised histogram, one flush per block.
 template <typename T, bool CPLX>
 __global__ void __launch_bounds__(256) radial_binsum_kernel(const void* in, const int* binmap, long long total, int nbins, double* iso) {

@@ -1742,6 +1742,37 @@ int xrfthip_spectrum_tail(int32_t dtype, int64_t n, const void* d_a, const void*
     return XRFTHIP_OK;
 }
 
+int xrfthip_spectrum_tail_axis(int32_t dtype, int64_t outer, int64_t na, int64_t inner, int32_t last_is_one, const void* d_a, const void* d_b,
+                               void* d_out, double scale, void* stream) {
+    if (!d_a || !d_out || outer < 0 || na < 1 || inner < 1 || (dtype != XRFTHIP_C64 && dtype != XRFTHIP_C128)) return XRFTHIP_BAD_ARG;
+    const long long n = (long long)outer * na * inner;
+    if (n == 0) return XRFTHIP_OK;
+    hipStream_t st = (hipStream_t)stream;
+    const dim3 grid((unsigned)std::max<long long>(1, std::min<long long>(16384, (n + 255) / 256))), block(256);
+#define TAIL(TT, CC) do { auto k = &spectrum_tail_axis_kernel<TT, CC>; XRFT_LAUNCH(k, grid, block, 0, st, (const C2<TT>*)d_a, (const C2<TT>*)d_b, d_out, n, scale, (long long)na, (long long)inner, (int)last_is_one); } while (0)
+    if (dtype == XRFTHIP_C128) { if (d_b) TAIL(double, true); else TAIL(double, false); }
+    else { if (d_b) TAIL(float, true); else TAIL(float, false); }
+#undef TAIL
+    HIP_TRY(hipGetLastError());
+    return XRFTHIP_OK;
+}
+
+int xrfthip_gather_axis(int32_t elem_bytes, int64_t outer, int64_t n_out, int64_t inner, int64_t n_in, const int64_t* d_index, int64_t roll,
+                        const void* d_in, void* d_out, void* stream) {
+    if (!d_in || !d_out || d_in == d_out || outer < 0 || n_out < 0 || inner < 0 || n_in < 1) return XRFTHIP_BAD_ARG;
+    if (elem_bytes != 4 && elem_bytes != 8 && elem_bytes != 16) return XRFTHIP_BAD_ARG;
+    const long long n = (long long)outer * n_out * inner;
+    if (n == 0) return XRFTHIP_OK;
+    hipStream_t st = (hipStream_t)stream;
+    const dim3 grid((unsigned)std::max<long long>(1, std::min<long long>(16384, (n + 255) / 256))), block(256);
+    struct alignas(16) E16 { double a, b; };
+#define GA(EE) do { auto k = &gather_axis_kernel<EE>; XRFT_LAUNCH(k, grid, block, 0, st, (const EE*)d_in, (EE*)d_out, (long long)outer, (long long)n_out, (long long)inner, (long long)n_in, (const long long*)d_index, (long long)roll); } while (0)
+    if (elem_bytes == 4) GA(float); else if (elem_bytes == 8) GA(double); else GA(E16);
+#undef GA
+    HIP_TRY(hipGetLastError());
+    return XRFTHIP_OK;
+}
+
 int xrfthip_isotropize(int32_t dtype, int64_t batch, int64_t ny, int64_t nx, const void* d_in,
                        const int32_t* d_binmap, int32_t nbins, void* d_iso, void* stream) {
     if (!d_in || !d_binmap || !d_iso || dtype < XRFTHIP_F32 || dtype > XRFTHIP_C128 || batch < 0 || ny < 1 || nx < 1) return XRFTHIP_BAD_ARG;

@@ -198,6 +198,44 @@ def spectrum_tail(a, b, scale):
     return out
 
 
+def spectrum_tail_axis(a, b, scale, axis, last_is_one):
+    """spectrum_tail with the real-dim factor [1, 2, ..., 2, (1)] along ``axis`` (xrft.py:673-682)."""
+    dll = _lib.load()
+    if not a.is_complex() or not a.is_contiguous() or (b is not None and (b.dtype != a.dtype or b.shape != a.shape or not b.is_contiguous())):
+        raise ValueError("spectrum_tail_axis needs contiguous complex tensors of one shape and dtype")
+    real_dt = torch.float32 if a.dtype == torch.complex64 else torch.float64
+    out = torch.empty(a.shape, dtype=a.dtype if b is not None else real_dt, device=a.device)
+    axis = axis % a.dim()
+    outer = int(np.prod(a.shape[:axis], dtype=np.int64))
+    inner = int(np.prod(a.shape[axis + 1:], dtype=np.int64))
+    _lib.check(dll.xrfthip_spectrum_tail_axis(_DTYPES[a.dtype], outer, a.shape[axis], inner, int(bool(last_is_one)), _ptr(a), _ptr(b),
+                                              _ptr(out), float(scale), _stream_handle(a)))
+    return out
+
+
+def gather_axis(x, axis, index=None, roll=0):
+    """``x`` re-ordered along ``axis``: out[..., i, ...] = x[..., index[i], ...] (``index``: host int array) or numpy.roll by
+    ``roll``.  A device copy kernel (xrfthip_gather_axis): no torch arithmetic."""
+    dll = _lib.load()
+    if not x.is_contiguous():
+        x = x.contiguous()
+    axis = axis % x.dim()
+    n_in = x.shape[axis]
+    outer = int(np.prod(x.shape[:axis], dtype=np.int64))
+    inner = int(np.prod(x.shape[axis + 1:], dtype=np.int64))
+    idx = None
+    n_out = n_in
+    if index is not None:
+        idx = torch.from_numpy(np.ascontiguousarray(index, dtype=np.int64)).to(x.device)
+        n_out = idx.numel()
+    shape = list(x.shape)
+    shape[axis] = n_out
+    out = torch.empty(shape, dtype=x.dtype, device=x.device)
+    _lib.check(dll.xrfthip_gather_axis(x.element_size(), outer, n_out, inner, n_in, _ptr(idx), int(roll), _ptr(x), _ptr(out),
+                                       _stream_handle(x)))
+    return out
+
+
 def isotropize(x, binmap_dev, nbins):
     """Radial bin-sum of the last two axes of ``x`` with a device int32 bin map (xrft/xrft.py:993-1004)."""
     dll = _lib.load()
