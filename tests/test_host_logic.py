@@ -118,3 +118,17 @@ def test_radial_bins_match_pandas_cut():
     assert nb == 4 and np.array_equal(codes.ravel(), ref.codes)
     for b in range(4):
         np.testing.assert_allclose(kr[b], r.ravel()[ref.codes == b].mean(), rtol=1e-14)
+
+
+def test_xarray_chunks_become_metadata():
+    """A dask-chunked xarray input keeps its chunk layout (chunks_to_segments and the multi-chunk refusal depend on it)."""
+    xr = pytest.importorskip("xarray")
+    pytest.importorskip("dask")
+    import xrft_amd as xa
+    from xrft_amd.labeled import DataArray
+
+    x = xr.DataArray(np.arange(24.0).reshape(2, 12), dims=("t", "x"), coords={"x": np.arange(12.0)}).chunk({"x": 4})
+    d = DataArray.from_xarray(x)
+    assert d._chunks == {"t": (2,), "x": (4, 4, 4)}
+    with pytest.raises(ValueError):
+        xa.fft(x, dim=["x"])

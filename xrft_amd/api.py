@@ -479,7 +479,18 @@ def _execute(c, da, mode, scale, da2=None, c2=None, iso=None, extra_flags=0):
     if iso is not None:
         kw.update(binmap=iso["binmap"], nbins=iso["nbins"])
         bkey = iso.get("binmap_key")
-    plan = _get_plan(binmap_key=bkey, **kw)
+    try:
+        plan = _get_plan(binmap_key=bkey, **kw)
+    except _lib.XrftHipError as e:
+        if e.status != _lib.UNSUPPORTED_LENGTH:
+            raise
+        # numpy.fft takes any length; here a prime factor above 128 goes through Bluestein inside one LDS tile, which bounds
+        # the length (2 n - 1 rounded up to 2^a 3^b 5^c complex samples must fit 160 KB)
+        lens = {d: da.sizes[d] for d in c.dim}
+        lim = 8800 if t.dtype in (torch.float32, torch.complex64) else 4400
+        raise ValueError(f"transform length(s) {lens} not supported on the device: a length with a prime factor above 128 must be "
+                         f"<= ~{lim} samples for {str(t.dtype).replace('torch.', '')} data (Bluestein inside one LDS tile); pad or "
+                         f"crop the axis (e.g. xrft_amd.pad) to a 2^a 3^b 5^c 7^d-smooth length") from e
     out, iso_out = plan.execute(t, t2)
     return out, iso_out, other
 

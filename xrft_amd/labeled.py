@@ -260,7 +260,12 @@ class DataArray:
     @classmethod
     def from_xarray(cls, xda):
         coords = {k: (tuple(v.dims), np.asarray(v.values), dict(v.attrs)) for k, v in xda.coords.items()}
-        return cls(np.asarray(xda.values), tuple(xda.dims), coords, xda.name, dict(xda.attrs))
+        out = cls(np.asarray(xda.values), tuple(xda.dims), coords, xda.name, dict(xda.attrs))
+        # a dask-chunked source keeps its chunk layout as metadata: chunks_to_segments (xrft.py:106-136) and the refusal to
+        # transform across chunk boundaries (xrft.py:279) depend on it, the data themselves sit in one buffer
+        if getattr(xda, "chunks", None) is not None:
+            out._chunks = {d: tuple(int(n) for n in ch) for d, ch in zip(xda.dims, xda.chunks)}
+        return out
 
 
 def is_xarray(obj):
