@@ -478,3 +478,33 @@ def run_composite_lengths(dtype):
     da, od = pair(v, ("t", "y", "x"), {"t": np.arange(2), "y": np.arange(90) * 0.25, "x": np.arange(120) * 0.25})
     check(xa.power_spectrum(da, dim=["y", "x"], detrend="constant", window="hann"),
           o.power_spectrum(od, dim=["y", "x"], detrend="constant", window="hann"), tol)
+
+
+# ---- long 1-D real float32 sequences: the two y-first passes as the two steps of a four-step transform (fasty.h, FS) ----
+def run_fourstep_1d(n=65536, nt=3):
+    """xrft.fft / dft / power_spectrum along one long axis (BASELINE.json configs[1] is (1024, 65536)): plain, shifted or not,
+    true phase, detrended; a window takes the generic path.  The float32 reference detrends in float32 (scipy), which costs
+    it 5e-5 on a 65536-point line: the detrended cases are held against the oracle on float64 input."""
+    rng = np.random.default_rng(31)
+    v = (rng.standard_normal((nt, n)) + 2.0 + 1e-4 * np.arange(n)).astype("float32")
+    c = {"t": np.arange(nt), "x": np.arange(n) * 0.25 + 5.0}
+    da, od = pair(v, ("t", "x"), c)
+    od64 = o.OArr(v.astype("float64"), ("t", "x"), c)
+    worst = 0.0
+    for kw in (dict(), dict(true_phase=False, shift=False), dict(true_amplitude=False, shift=False)):
+        worst = max(worst, check(xa.fft(da, dim=["x"], **kw), o.fft(od, dim=["x"], **kw), 3e-6))
+    assert "four-step]" in next(reversed(xa.api._plan_cache.values())).describe()
+    worst = max(worst, check(xa.dft(da, dim="x"), o.dft(od, dim="x"), 3e-6))
+    for kw in (dict(), dict(scaling="spectrum", shift=False)):
+        worst = max(worst, check(xa.power_spectrum(da, dim=["x"], **kw), o.power_spectrum(od, dim=["x"], **kw), 3e-6))
+    for det in ("constant", "linear"):
+        g = xa.fft(da, dim=["x"], detrend=det)
+        r = o.fft(od64, dim=["x"], detrend=det)
+        err = float(np.abs(g.values - r.values).max() / np.abs(r.values).max())
+        assert err < 5e-6, (det, err)
+        g = xa.power_spectrum(da, dim=["x"], detrend=det)
+        r = o.power_spectrum(od64, dim=["x"], detrend=det)
+        assert float(np.abs(g.values - r.values).max() / np.abs(r.values).max()) < 5e-6
+    worst = max(worst, check(xa.power_spectrum(da, dim=["x"], window="hann"), o.power_spectrum(od, dim=["x"], window="hann"), 3e-6))
+    assert "four-step]" not in next(reversed(xa.api._plan_cache.values())).describe()  # (a window: the generic four-step passes)
+    return worst

@@ -390,3 +390,8 @@ def test_fftmod_backend_object():
     from xrft_amd import fftmod
 
     assert fftmod_cases.run_all(fftmod) < 2e-5
+
+
+@pytest.mark.parametrize("n", [65536, 262144])
+def test_fourstep_1d_fast_path(n):
+    cases.run_fourstep_1d(n, nt=2)

@@ -707,6 +707,11 @@ def test_middle_and_first_axis_without_copies(dim, dtype):
     cases.check(ps, o.power_spectrum(o.OArr(v, ("t", "y", "x"), c), **kw), 2e-4 if dtype in ("float32", "complex64") else 1e-10)
 
 
+@pytest.mark.parametrize("n", [65536, 131072, 1048576])
+def test_fourstep_1d_fast_path(n):
+    cases.run_fourstep_1d(n, nt=3)
+
+
 def test_fftmod_backend_object_on_gpu():
     """The backend module of the reference's `_fft_module` seam (xrft.py:32-36, :398-404, :439-447, :612-621) on the device:
     device tensors in, device tensors out, numpy.fft semantics; plus the reference-sized call fftn((8, 1024, 1024), axes=[1, 2])."""

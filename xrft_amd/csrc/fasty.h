@@ -50,7 +50,9 @@ struct FastY {
     const float* corr;       // [slab][nx][2]: wx[x] * (subtracted line - plane fit) as (offset at ibar, slope), from fasty_fit_kernel
     const float* corr_b;     // ... of field 1 (cross spectra)
     const cf* ph_y;          // complex modes: true-phase factor per unshifted ky (times (-1)^ky for an ifftshifted input), never null
-    const cf* ph_x;
+    const cf* ph_x;          // (four-step 1-D: one table over the whole sequence, indexed by the unshifted sample index)
+    const cf* tw_big;        // four-step 1-D: W_N^j, j < N / 2
+    int ph_on;               // 0: every phase factor is 1 (true_phase off, no ifftshift): the tables are not read
     const cf* what0;         // FFT_y(wy)[ky], ky < nrow_pad (zero beyond ny/2)
     const cf* what1;         // FFT_y(wy * (i - (ny-1)/2))[ky]
     const unsigned* tcodes;  // radial bins in pass 2's register order: (direct + 1) | (mirror + 1) << 16
@@ -350,9 +352,17 @@ __device__ __forceinline__ void xrft_store_nt2(cf* dst, cf v0, cf v1) {
 // registers, so a cross spectrum costs ONE column pass per field and one row pass -- xrft.py:825).  The complex results
 // carry the true-phase factors exp(-i 2 pi k lag) (xrft.py:462-469), indexed by unshifted frequency, applied in the store
 // loop to direct and mirrored samples alike (an ifftshifted input is the sign (-1)^k folded into the tables).
-template <int NX, int MODE, bool ISO>
+//
+// FS ("four-step"): the slab is ONE long real sequence of N = ny * nx samples, n = nx i1 + i2, and the two passes are the two
+// steps of its 1-D transform X[k1 + ny k2] = sum_i2 W_N^(i2 k1) W_nx^(i2 k2) [ sum_i1 x[nx i1 + i2] W_ny^(i1 k1) ]: pass 1 is
+// unchanged (columns = the inner sums, half spectrum k1 <= ny/2 of a real sequence), this pass multiplies row k1 by
+// W_N^(i2 k1) before its transform and stores TRANSPOSED: the unit's rows k1 are consecutive output samples for a given k2
+// (2 GX * 4 or GX * 8 bytes contiguous); the Hermitian mirror X[N - k] = conj X[k] is the reversed run.  (xrft.dft / fft /
+// power_spectrum along one long axis, BASELINE.json configs[1]: 1-D (1024, 65536) float32.)
+template <int NX, int MODE, bool ISO, bool FS = false>
 __global__ void __launch_bounds__(YRows<NX>::THR, YRows<NX>::THR / 128) fasty_rows_kernel(FastY p) {
     static_assert(MODE == 1 || MODE == 2 || !ISO, "radial sums exist for power and cross spectra");
+    static_assert(!FS || (MODE <= 1 && !ISO), "the four-step form serves fft and power_spectrum");
     typedef P2<NX> G;
     typedef YRows<NX> R;
     constexpr bool TWO = MODE >= 2;  // two fields
@@ -422,6 +432,13 @@ __global__ void __launch_bounds__(YRows<NX>::THR, YRows<NX>::THR / 128) fasty_ro
             }
         }
     }
+    if (FS) {  // x W_N^(i2 k1), i2 = u + NT q: W^(k1 u) (W^(k1 NT))^q -- two table loads and a product tree per row
+        const cf ba = p.tw_big[kyA * u], sa = p.tw_big[kyA * NT], bb_ = p.tw_big[kyB * u], sb = p.tw_big[kyB * NT];
+        twiddle16(a, sa);
+        twiddle16(b, sb);
+#pragma unroll
+        for (int q = 0; q < 16; ++q) { a[q] = cmul(a[q], ba); b[q] = cmul(b[q], bb_); }
+    }
     if (!(XRFT_YDBG & 4)) fft_p2_pair<NX>(a, b, u, mine, p.tw_x, tw2);
     if (TWO) {  // F0 conj(F1) * scale, in place of transform A (xrft.py:825)
 #pragma unroll
@@ -452,17 +469,30 @@ __global__ void __launch_bounds__(YRows<NX>::THR, YRows<NX>::THR / 128) fasty_ro
     }
     const int mx = NX - 1, my = p.ny - 1, sx = p.shift_x;
     if (MODE == 1 && p.out != nullptr) {
-        // power, staged row-major [row][kx] in natural order with the conflict-free 17/16 padding
+        // power, staged row-major [row][kx] in natural order with the conflict-free 17/16 padding (FS: + 1, the transposed
+        // read-out runs down the rows)
+        constexpr int RSP = R::RS + (FS ? 1 : 0);
 #pragma unroll
         for (int bb = 0; bb < G::NB; ++bb)
 #pragma unroll
             for (int k3 = 0; k3 < G::R3; ++k3) {
                 const int s = nat16(held_k<NX>(u, bb, k3));
                 const cf va = a[bb * G::R3 + k3], vb = b[bb * G::R3 + k3];
-                stg[g * R::RS + s] = (va.re * va.re + va.im * va.im) * p.scale;
-                stg[(GX + g) * R::RS + s] = (vb.re * vb.re + vb.im * vb.im) * p.scale;
+                stg[g * RSP + s] = (va.re * va.re + va.im * va.im) * p.scale;
+                stg[(GX + g) * RSP + s] = (vb.re * vb.re + vb.im * vb.im) * p.scale;
             }
         __syncthreads();
+        if (FS) {  // sample k = k1 + ny k2 (fftshift: k2 + nx/2): the unit's RPU rows are consecutive samples
+            float* __restrict__ o1 = reinterpret_cast<float*>(p.out) + (size_t)slab * p.ny * NX;
+            for (int e = tid; e < RPU * NX * 2; e += THR) {
+                const int r = e % RPU, rest = e / RPU, mir = rest & 1, k2 = rest >> 1;
+                const int k1 = ky0 + r;
+                if (k1 > nyh || (mir && (k1 == 0 || k1 == nyh))) continue;
+                const float v = stg[r * RSP + nat16(k2)];
+                const int o1k = mir ? p.ny - k1 : k1, o2k = mir ? (NX - 1 - k2) : k2;  // X[N - k]: (ny - k1) + ny (nx - 1 - k2)
+                o1[(size_t)((o2k + sx) & mx) * p.ny + o1k] = v;
+            }
+        } else {
         // every staged row leaves twice: rotated (direct) and reversed + rotated (mirror); 16-byte stores, whole rows
         float* __restrict__ outs = reinterpret_cast<float*>(p.out) + (size_t)slab * p.ny * NX;
         constexpr int CPR = NX / 4;  // float4 chunks per row
@@ -485,12 +515,13 @@ __global__ void __launch_bounds__(YRows<NX>::THR, YRows<NX>::THR / 128) fasty_ro
             // intermediate (scripts/ubench/yfirst.hip: 45.8 vs 50.9 us per slab for the two passes at 2 slabs per group)
             if (!(XRFT_YDBG & 8) || v.x == 1.2345f) xrft_store_nt(outs + (size_t)orow * NX + c, v);
         }
+        }
     }
     if (MODE != 1 && p.out != nullptr) {
         // complex results: GX rows at a time staged in natural order (a round fills the transforms' LDS exactly); the complex
         // spectrum of one field takes two rounds (transform A's rows, then B's)
         cf* cstg = lds;
-        constexpr int RSC = NX + NX / 16, NROUND = TWO ? 1 : 2, CPR = NX / 2;  // pairs of samples per row
+        constexpr int RSC = NX + NX / 16 + (FS ? 1 : 0), NROUND = TWO ? 1 : 2, CPR = NX / 2;  // pairs of samples per row
         typedef typename std::conditional<MODE == 3, float, cf>::type OutT;
         OutT* __restrict__ outs = reinterpret_cast<OutT*>(p.out) + (size_t)slab * p.ny * NX;
 #pragma unroll
@@ -503,6 +534,20 @@ __global__ void __launch_bounds__(YRows<NX>::THR, YRows<NX>::THR / 128) fasty_ro
                 for (int k3 = 0; k3 < G::R3; ++k3)
                     cstg[g * RSC + nat16(held_k<NX>(u, bb, k3))] = cscale(round ? b[bb * G::R3 + k3] : a[bb * G::R3 + k3], sc);
             __syncthreads();
+            if (FS) {  // transposed: sample k = k1 + ny k2; the true-phase table is indexed by the unshifted sample index
+                cf* __restrict__ o1 = reinterpret_cast<cf*>(p.out) + (size_t)slab * p.ny * NX;
+                for (int e = tid; e < GX * NX * 2; e += THR) {
+                    const int r = e % GX, rest = e / GX, mir = rest & 1, k2 = rest >> 1;
+                    const int k1 = ky0 + round * GX + r;
+                    if (k1 > nyh || (mir && (k1 == 0 || k1 == nyh))) continue;
+                    cf v = cstg[r * RSC + nat16(k2)];
+                    if (mir) v = cconj(v);
+                    const int o1k = mir ? p.ny - k1 : k1, o2k = mir ? (NX - 1 - k2) : k2;
+                    if (p.ph_on) v = cmul(v, p.ph_x[o2k * p.ny + o1k]);
+                    o1[(size_t)((o2k + sx) & mx) * p.ny + o1k] = v;
+                }
+                continue;
+            }
             for (int e = tid; e < GX * 2 * CPR; e += THR) {
                 const int chunk = e % CPR, rr = e / CPR, r = rr >> 1, mir = rr & 1;
                 const int ky = ky0 + round * GX + r;
@@ -514,9 +559,11 @@ __global__ void __launch_bounds__(YRows<NX>::THR, YRows<NX>::THR / 128) fasty_ro
                 cf v0, v1;
                 if (!mir) { v0 = row[nat16(fx0)]; v1 = row[nat16(fx1)]; }
                 else { v0 = cconj(row[nat16((NX - fx0) & mx)]); v1 = cconj(row[nat16((NX - fx1) & mx)]); }  // F(-k) = conj F(k)
-                const cf py = p.ph_y[fy];
-                v0 = cmul(v0, cmul(py, p.ph_x[fx0]));
-                v1 = cmul(v1, cmul(py, p.ph_x[fx1]));
+                if (p.ph_on) {
+                    const cf py = p.ph_y[fy];
+                    v0 = cmul(v0, cmul(py, p.ph_x[fx0]));
+                    v1 = cmul(v1, cmul(py, p.ph_x[fx1]));
+                }
                 const size_t o = (size_t)((fy + p.shift_y) & my) * NX + c;
                 if (MODE == 3) {  // cross phase (xrft.py:838-874)
                     struct alignas(8) P2f { float x, y; } ang;
@@ -569,6 +616,37 @@ __global__ void __launch_bounds__(256) fasty_fit_kernel(const double* colfit, co
         const double wx = win_x[x];
         out[2 * x] = (float)(wx * (cf4[4 * x + 2] - a - b * ((double)x - xbar)));
         out[2 * x + 1] = (float)(wx * (cf4[4 * x + 3] - c));
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// four-step 1-D: the trend of the WHOLE sequence (mean, or the least-squares line a + b (n - nbar), scipy.signal.detrend,
+// xrft/detrend.py:64-71) from the per-column sums of its [ny][nx] view, n = nx i1 + i2:
+//   sum d = sum_x S0[x],   sum (n - nbar) d = sum_x ( nx (S1[x] + ibar S0[x]) + x S0[x] ) - nbar sum d
+// Along column x the line is [a + b (x - nbar + nx ibar)] + (b nx) (i1 - ibar): corr[x] = subtracted line - that (no window).
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) fasty_fit1d_kernel(const double* colfit, float* corr, int nx, int ny, int detrend) {
+    XRFT_DYN_SMEM(smem_raw);
+    double* red = reinterpret_cast<double*>(smem_raw);
+    const int slab = blockIdx.x, tid = threadIdx.x;
+    const double* cf4 = colfit + (size_t)slab * nx * 4;
+    const double N = (double)nx * (double)ny, nbar = 0.5 * (N - 1.0), ibar = 0.5 * (ny - 1);
+    double s[3] = {0.0, 0.0, 0.0};
+    for (int x = tid; x < nx; x += 256) {
+        const double s0 = cf4[4 * x], s1 = cf4[4 * x + 1];
+        s[0] += s0;
+        s[1] += (double)nx * (s1 + ibar * s0) + (double)x * s0;
+    }
+    block_sum<3>(s, red);
+    __syncthreads();
+    if (tid == 0) { red[0] = s[0]; red[1] = s[1]; }
+    __syncthreads();
+    const double a = red[0] / N;
+    const double b = detrend == 2 ? (red[1] - nbar * red[0]) / (N * (N * N - 1.0) / 12.0) : 0.0;
+    float* out = corr + (size_t)slab * nx * 2;
+    for (int x = tid; x < nx; x += 256) {
+        out[2 * x] = (float)(cf4[4 * x + 2] - (a + b * ((double)x - nbar + (double)nx * ibar)));
+        out[2 * x + 1] = (float)(cf4[4 * x + 3] - b * (double)nx);
     }
 }
 

@@ -293,6 +293,12 @@ struct xrfthip_plan {
     std::vector<double> host_win_x;
     // two-pass "y first" pipeline for full power spectra (fasty.h): columns -> [fit] -> rows, no untile pass
     bool yfirst = false;
+    // ... and, as the two steps of a four-step transform, one long real sequence per slab: N = yny * ynx samples viewed as
+    // a [yny][ynx] slab (fasty.h, FS).  yny / ynx are d.ny / d.nx for the 2-D plans.
+    bool fast1d = false;
+    bool fph_on = false;  // some entry of the combined phase tables (fph) differs from 1
+    long long yny = 0, ynx = 0;
+    DevBuf tw_big1d;
     int y_nrow_pad = 0;  // rows ky = 0..ny/2 of the intermediate, rounded up to what one row workgroup covers
     DevBuf ywhat0, ywhat1, ytcodes;
     std::vector<double> host_win_y;
@@ -771,6 +777,7 @@ void set_kernel_attrs_once() {
                  SETF((fasty_rows_kernel<NN, 0, false>)); SETF((fasty_rows_kernel<NN, 2, false>)); SETF((fasty_rows_kernel<NN, 2, true>)); SETF((fasty_rows_kernel<NN, 3, false>))
     SETY(4096); SETY(2048); SETY(1024); SETY(512); SETY(256);
 #undef SETY
+    SETF((fasty_rows_kernel<256, 0, false, true>)); SETF((fasty_rows_kernel<256, 1, false, true>));
 #undef SETF
 }
 
@@ -842,7 +849,7 @@ static void layout_workspace(xrfthip_plan* P) {
     size_t slab_w = (size_t)d.ny * std::max(P->width, P->w_cols) * P->csize;
     const bool yf = fast && P->yfirst;
     if (fast) {
-        slab_w = yf ? (size_t)P->y_nrow_pad * d.nx * sizeof(cf) : (size_t)P->fast_ntile_pad * d.ny * 4 * sizeof(cf);
+        slab_w = yf ? (size_t)P->y_nrow_pad * P->ynx * sizeof(cf) : (size_t)P->fast_ntile_pad * d.ny * 4 * sizeof(cf);
         if (G <= 0) G = P->tune_fast_group > 0 ? P->tune_fast_group : std::max<long long>(1, (32LL * 4096 * 4096) / (d.ny * d.nx));  // measured 8: 197, 16: 210, 32: 214 GFFT/s (tails and launch gaps amortise)
     }
     if (G <= 0) {
@@ -859,7 +866,7 @@ static void layout_workspace(xrfthip_plan* P) {
     P->mom_chunks = (int)std::max<long long>(1, std::min<long long>(d.ny, (2048 + G - 1) / G));
     P->off_acc = off; off = al(off + (size_t)G * P->mom_chunks * 6 * sizeof(double) * nf);  // per-chunk partial sums of ONE group of slabs
     P->off_coef = off; off = al(off + ncoef * 6 * sizeof(double) * nf);
-    bool need_w = d.ndim == 2, need_w2 = false;
+    bool need_w = d.ndim == 2 || yf, need_w2 = false;
     for (const Pass& p : P->passes) { if (p.out_kind == B_W2) need_w2 = true; if (p.out_kind == B_W) need_w = true; }
     P->off_w = off; if (need_w) off = al(off + (size_t)G * slab_w * (yf ? nf : 1));  // (y first: field 1's intermediate follows field 0's)
     P->off_w2 = off; if (need_w2) off = al(off + (size_t)G * d.ny * d.nx * P->csize);
@@ -869,7 +876,7 @@ static void layout_workspace(xrfthip_plan* P) {
         P->off_pt = off;
         if (!pw || !(d.flags & XRFTHIP_NO_SPECTRUM_OUT)) off = al(off + (size_t)G * (d.ny / 8) * P->fast_ntile_pad * 8 * sizeof(F4) * (pw ? 1 : 2));
     }
-    const size_t nfit = (size_t)(yf ? 2 * d.nx : d.ny);  // per-row fits (x first) or per-column sums + subtracted lines (y first)
+    const size_t nfit = (size_t)(yf ? 2 * P->ynx : d.ny);  // per-row fits (x first) or per-column sums + subtracted lines (y first)
     P->off_rowfit = off; if (fast) off = al(off + (size_t)G * nfit * 2 * sizeof(double) * (yf ? nf : 1));
     P->off_corr = off; if (fast) off = al(off + (size_t)G * nfit * 2 * sizeof(float) * (yf ? nf : 1));
     P->ws_bytes = off;
@@ -964,6 +971,7 @@ static size_t fast_cols_lds(long long ny, bool iso) { return (size_t)fast_cols_g
 // (rolling the input by n/2 -- xrft.py:436-441 -- is that sign in the spectrum; in a cross spectrum the two signs cancel)
 static int fast_phase_tables(xrfthip_plan* P) {
     const xrfthip_desc& d = P->d;
+    P->fph_on = false;
     for (int ax = 0; ax < 2; ++ax) {
         const long long n = ax == 0 ? d.ny : d.nx;
         const bool sign = d.out_mode == XRFTHIP_OUT_COMPLEX && (d.flags & (ax == 0 ? XRFTHIP_ISHIFT_Y : XRFTHIP_ISHIFT_X));
@@ -973,6 +981,7 @@ static int fast_phase_tables(xrfthip_plan* P) {
             if (!P->host_phase[ax].empty()) { re = P->host_phase[ax][(size_t)(2 * k)]; im = P->host_phase[ax][(size_t)(2 * k + 1)]; }
             if (sign && (k & 1)) { re = -re; im = -im; }
             t[(size_t)k].re = (float)re; t[(size_t)k].im = (float)im;
+            if (t[(size_t)k].re != 1.0f || t[(size_t)k].im != 0.0f) P->fph_on = true;
         }
         int rc = P->fph[ax].upload(t.data(), t.size() * sizeof(cf));
         if (rc) return rc;
@@ -990,6 +999,7 @@ static bool phase_nontrivial(const xrfthip_plan* P) {
 // the specialised path is taken unless an isotropic cross spectrum carries a true-phase factor that is not 1 (two
 // fields with different lags): its radial sums would need the factor per sample inside the column pass
 static bool fast_on(const xrfthip_plan* P) {
+    if (P->fast1d) return P->win[1].p == nullptr;  // the four-step form has no place for a (non-separable) window
     if (!P->fast4096) return false;
     if (P->d.out_mode == XRFTHIP_OUT_CROSS && (P->d.flags & XRFTHIP_ISO) && phase_nontrivial(P)) return false;
     return true;
@@ -1134,7 +1144,7 @@ static int ilog2i(int v) { int l = 0; while ((1 << l) < v) ++l; return l; }
 
 // FFT_y(wy) and FFT_y(wy (i - ibar)) for ky < nrow_pad (zero beyond ny/2): what pass 2 needs to add the residual trend back
 static int fasty_window_spectra(xrfthip_plan* P) {
-    const int ny = (int)P->d.ny, nyh = ny / 2;
+    const int ny = (int)P->yny, nyh = ny / 2;
     std::vector<double> r0((size_t)ny), i0((size_t)ny, 0.0), r1((size_t)ny), i1((size_t)ny, 0.0);
     for (int i = 0; i < ny; ++i) {
         const double w = P->host_win_y.empty() ? 1.0 : P->host_win_y[(size_t)i];
@@ -1158,7 +1168,7 @@ static int fasty_window_spectra(xrfthip_plan* P) {
 // the bin map re-ordered the way pass 2 holds its results (fasty_rows_kernel): [unit][e (32)][tid], e < 16: transform A
 // (row ky0 + g), else B (row ky0 + GX + g); value = (bin of (ky, kx) + 1) | (bin of the mirror (-ky, -kx) + 1) << 16
 static int fasty_build_tcodes(xrfthip_plan* P, const int32_t* bm) {
-    const int ny = (int)P->d.ny, nx = (int)P->d.nx, nyh = ny / 2, nt = nx / 16, r3 = nx / 256;
+    const int ny = (int)P->yny, nx = (int)P->ynx, nyh = ny / 2, nt = nx / 16, r3 = nx / 256;
     const YGeomRt R = yrows_geom(nx);
     const bool two = P->d.out_mode == XRFTHIP_OUT_CROSS;  // transform B is field 1: only transform A's slots carry results
     const int gx = R.gxy, rpu = two ? R.gxy : R.rk, thr = R.thr, units = P->y_nrow_pad / rpu, ne = two ? 16 : 32;
@@ -1186,25 +1196,25 @@ static bool fasty_on(const xrfthip_plan* P) { return P->yfirst && fast_on(P); }
 
 static void fasty_launch_cols(const xrfthip_plan* P, const FastY& p, long long gc, hipStream_t st, bool prof) {
     const xrfthip_desc& d = P->d;
-    const YGeomRt C = ycols_geom(d.ny);
+    const YGeomRt C = ycols_geom(P->yny);
     xrfthip_plan::ProfRec* rec = prof ? prof_begin(P, "fasty_cols", st) : nullptr;
-    const dim3 grid((unsigned)(gc * (d.nx / C.cw))), blk((unsigned)C.thr);
+    const dim3 grid((unsigned)(gc * (P->ynx / C.cw))), blk((unsigned)C.thr);
 #define YC_(NN) do { if (d.detrend) { auto k = &fasty_cols_kernel<NN, true>; XRFT_LAUNCH(k, grid, blk, C.lds, st, p); } \
                      else { auto k = &fasty_cols_kernel<NN, false>; XRFT_LAUNCH(k, grid, blk, C.lds, st, p); } } while (0)
-    if (d.ny == 4096) YC_(4096); else if (d.ny == 2048) YC_(2048); else if (d.ny == 1024) YC_(1024); else if (d.ny == 512) YC_(512); else YC_(256);
+    if (P->yny == 4096) YC_(4096); else if (P->yny == 2048) YC_(2048); else if (P->yny == 1024) YC_(1024); else if (P->yny == 512) YC_(512); else YC_(256);
 #undef YC_
     prof_end(rec, st);
-    if (d.detrend) {  // plane from the per-column sums -> what pass 2 has to add back
+    if (d.detrend) {  // plane (2-D) or line through the whole sequence (four-step 1-D) from the per-column sums -> what pass 2 has to add back
         rec = prof ? prof_begin(P, "fasty_fit", st) : nullptr;
-        auto kf = &fasty_fit_kernel;
-        XRFT_LAUNCH(kf, dim3((unsigned)gc), dim3(256), 3 * 256 * sizeof(double), st, (const double*)p.colfit, p.win_x, const_cast<float*>(p.corr), (int)d.nx, (int)d.ny, (int)d.detrend);
+        if (P->fast1d) { auto kf = &fasty_fit1d_kernel; XRFT_LAUNCH(kf, dim3((unsigned)gc), dim3(256), 3 * 256 * sizeof(double), st, (const double*)p.colfit, const_cast<float*>(p.corr), (int)P->ynx, (int)P->yny, (int)d.detrend); }
+        else { auto kf = &fasty_fit_kernel; XRFT_LAUNCH(kf, dim3((unsigned)gc), dim3(256), 3 * 256 * sizeof(double), st, (const double*)p.colfit, p.win_x, const_cast<float*>(p.corr), (int)P->ynx, (int)P->yny, (int)d.detrend); }
         prof_end(rec, st);
     }
 }
 
 static void fasty_launch_rows(const xrfthip_plan* P, const FastY& p, long long gc, hipStream_t st, bool prof) {
     const xrfthip_desc& d = P->d;
-    const YGeomRt R = yrows_geom(d.nx);
+    const YGeomRt R = yrows_geom(P->ynx);
     const bool iso_on = (d.flags & XRFTHIP_ISO) != 0;
     const bool two = d.out_mode == XRFTHIP_OUT_CROSS || d.out_mode == XRFTHIP_OUT_PHASE;
     xrfthip_plan::ProfRec* rec = prof ? prof_begin(P, "fasty_rows", st) : nullptr;
@@ -1216,7 +1226,11 @@ static void fasty_launch_rows(const xrfthip_plan* P, const FastY& p, long long g
         else if (d.out_mode == XRFTHIP_OUT_CROSS) { if (iso_on) { auto k = &fasty_rows_kernel<NN, 2, true>; XRFT_LAUNCH(k, grid, blk, lds, st, p); } else { auto k = &fasty_rows_kernel<NN, 2, false>; XRFT_LAUNCH(k, grid, blk, lds, st, p); } } \
         else if (d.out_mode == XRFTHIP_OUT_PHASE) { auto k = &fasty_rows_kernel<NN, 3, false>; XRFT_LAUNCH(k, grid, blk, lds, st, p); } \
         else { auto k = &fasty_rows_kernel<NN, 0, false>; XRFT_LAUNCH(k, grid, blk, lds, st, p); } } while (0)
-    if (d.nx == 4096) YR_(4096); else if (d.nx == 2048) YR_(2048); else if (d.nx == 1024) YR_(1024); else if (d.nx == 512) YR_(512); else YR_(256);
+    if (P->fast1d) {  // four-step 1-D: rows of 256 samples, transposed stores
+        if (d.out_mode == XRFTHIP_OUT_POWER) { auto k = &fasty_rows_kernel<256, 1, false, true>; XRFT_LAUNCH(k, grid, blk, lds, st, p); }
+        else { auto k = &fasty_rows_kernel<256, 0, false, true>; XRFT_LAUNCH(k, grid, blk, lds, st, p); }
+    }
+    else if (P->ynx == 4096) YR_(4096); else if (P->ynx == 2048) YR_(2048); else if (P->ynx == 1024) YR_(1024); else if (P->ynx == 512) YR_(512); else YR_(256);
 #undef YR_
     prof_end(rec, st);
 }
@@ -1225,36 +1239,39 @@ static void fasty_launch_rows(const xrfthip_plan* P, const FastY& p, long long g
 static FastY fasty_params(const xrfthip_plan* P, const float* in, void* out, double* iso, char* ws, long long g0, long long gc, int slot, long long slot_slabs) {
     // (slot 0 = field 0 / the only field, slot 1 = field 1 of a cross spectrum: its own intermediate and fit tables)
     const xrfthip_desc& d = P->d;
-    const size_t slab_pts = (size_t)d.ny * d.nx;
+    const size_t slab_pts = (size_t)P->yny * P->ynx;
     const bool want_out = !(d.flags & XRFTHIP_NO_SPECTRUM_OUT);
     const bool iso_on = (d.flags & XRFTHIP_ISO) != 0;
-    const YGeomRt C = ycols_geom(d.ny);
+    const YGeomRt C = ycols_geom(P->yny);
     const size_t s0 = (size_t)slot * slot_slabs;  // first slab of the slot inside the workspace arrays
     FastY p{};
     p.in = in + (size_t)g0 * slab_pts;
-    p.w2 = reinterpret_cast<cf*>(ws + P->off_w) + s0 * (size_t)P->y_nrow_pad * d.nx;
+    p.w2 = reinterpret_cast<cf*>(ws + P->off_w) + s0 * (size_t)P->y_nrow_pad * P->ynx;
     const size_t out_esz = (d.out_mode == XRFTHIP_OUT_POWER || d.out_mode == XRFTHIP_OUT_PHASE) ? sizeof(float) : sizeof(cf);
     p.out = want_out ? (char*)out + (size_t)g0 * slab_pts * out_esz : nullptr;
     p.ph_y = reinterpret_cast<const cf*>(P->fph[0].p);
     p.ph_x = reinterpret_cast<const cf*>(P->fph[1].p);
+    p.tw_big = reinterpret_cast<const cf*>(P->tw_big1d.p);
+    p.ph_on = P->fph_on ? 1 : 0;
     p.tw_x = reinterpret_cast<const cf*>(P->tw_fx.p);
     p.tw_y = reinterpret_cast<const cf*>(P->tw_fy.p);
     p.win_y = reinterpret_cast<const float*>(P->win[0].p ? P->win[0].p : P->ones4096.p);
     p.win_x = reinterpret_cast<const float*>(P->win[1].p ? P->win[1].p : P->ones4096.p);
-    p.colfit = reinterpret_cast<double*>(ws + P->off_rowfit) + s0 * (size_t)d.nx * 4;
-    p.corr = reinterpret_cast<const float*>(ws + P->off_corr) + s0 * (size_t)d.nx * 2;
+    p.colfit = reinterpret_cast<double*>(ws + P->off_rowfit) + s0 * (size_t)P->ynx * 4;
+    p.corr = reinterpret_cast<const float*>(ws + P->off_corr) + s0 * (size_t)P->ynx * 2;
     p.what0 = reinterpret_cast<const cf*>(P->ywhat0.p);
     p.what1 = reinterpret_cast<const cf*>(P->ywhat1.p);
     p.tcodes = reinterpret_cast<const unsigned*>(P->ytcodes.p);
     p.iso = iso_on ? iso + (size_t)g0 * P->nbins * (d.out_mode == XRFTHIP_OUT_CROSS ? 2 : 1) : nullptr;
     p.nbins = P->nbins;
-    p.ny = (int)d.ny; p.nx = (int)d.nx;
+    p.ny = (int)P->yny; p.nx = (int)P->ynx;
     p.nrow_pad = P->y_nrow_pad;
     p.l_cw = ilog2i(C.cw); p.l_rk = ilog2i(C.rk); p.l_2gy = ilog2i(2 * C.gxy);
     p.detrend = d.detrend;
     p.nslab = (int)gc;
-    p.shift_y = (d.flags & XRFTHIP_SHIFT_Y) ? (int)(d.ny / 2) : 0;
-    p.shift_x = (d.flags & XRFTHIP_SHIFT_X) ? (int)(d.nx / 2) : 0;
+    p.shift_y = (d.flags & XRFTHIP_SHIFT_Y) ? (int)(P->yny / 2) : 0;
+    p.shift_x = (d.flags & XRFTHIP_SHIFT_X) ? (int)(P->ynx / 2) : 0;  // (four-step 1-D: the shift by N/2 samples is k2 + nx/2)
+    if (P->fast1d) p.win_y = p.win_x = reinterpret_cast<const float*>(P->ones4096.p);  // (no window on this path)
     p.scale = (float)d.scale;
     return p;
 }
@@ -1282,7 +1299,11 @@ static int run_fasty(const xrfthip_plan* P, const float* in, const float* in1, v
 // set: window spectra and phase tables of the specialised paths (device allocations + blocking copies) and the workspace
 // layout.  xrfthip_exec itself takes the plan as const: no allocation, no copy, no synchronisation, no getenv.
 static int finalize_plan(xrfthip_plan* P) {
-    if (P->fast4096) {
+    if (P->fast1d) {
+        int rc = fasty_window_spectra(P);
+        if (!rc && P->d.out_mode != XRFTHIP_OUT_POWER) rc = fast_phase_tables(P);
+        if (rc) return rc;
+    } else if (P->fast4096) {
         int rc = XRFTHIP_OK;
         if (P->yfirst) {
             rc = fasty_window_spectra(P);
@@ -1438,6 +1459,7 @@ int xrfthip_plan_create(xrfthip_plan** plan, const xrfthip_desc* desc) {
         // full power spectra take the two-pass y-first pipeline (fasty.h); half / complex / cross results keep the x-first one
         P->yfirst = !(d.flags & (XRFTHIP_HALF_X | XRFTHIP_REALDIM_X2)) && env_ll("XRFTHIP_YFIRST", 1) != 0;
         if (P->yfirst) {
+            P->yny = d.ny; P->ynx = d.nx;
             const int rpu = yrows_geom(d.nx).rk;
             P->y_nrow_pad = (int)((d.ny / 2 + 1 + rpu - 1) / rpu * rpu);
         }
@@ -1446,6 +1468,26 @@ int xrfthip_plan_create(xrfthip_plan** plan, const xrfthip_desc* desc) {
         std::vector<float> ones((size_t)std::max(d.ny, d.nx), 1.0f);
         if (!rc4) rc4 = P->ones4096.upload(ones.data(), ones.size() * sizeof(float));
         if (rc4) { delete P; return rc4; }
+    }
+    {   // one long real float32 sequence per slab, N = n1 * 256 samples (2^16 .. 2^20): the two passes of the y-first pipeline are
+        // the two steps of its four-step transform (fasty.h, FS)
+        const long long n1 = d.nx / 256;
+        const bool pow2 = d.nx >= 65536 && d.nx <= (1LL << 20) && (d.nx & (d.nx - 1)) == 0;
+        const uint32_t ok1 = XRFTHIP_SHIFT_X | (d.out_mode == XRFTHIP_OUT_COMPLEX ? XRFTHIP_ISHIFT_X : 0u);
+        P->fast1d = d.ndim == 1 && pow2 && d.dtype == XRFTHIP_F32 && (d.out_mode == XRFTHIP_OUT_COMPLEX || d.out_mode == XRFTHIP_OUT_POWER) &&
+                    !(d.flags & ~ok1) && !env_ll("XRFTHIP_NO_FAST", 0) && env_ll("XRFTHIP_FAST1D", 1) != 0;
+        if (P->fast1d) {
+            P->yfirst = true;
+            P->yny = n1; P->ynx = 256;
+            const int rpu = yrows_geom(256).rk;
+            P->y_nrow_pad = (int)((n1 / 2 + 1 + rpu - 1) / rpu * rpu);
+            int rc1 = build_twiddle<float>(P->tw_fx, 256, 256);
+            if (!rc1) rc1 = build_twiddle<float>(P->tw_fy, n1, n1);
+            if (!rc1) rc1 = build_twiddle<float>(P->tw_big1d, d.nx, d.nx / 2 + 1);
+            std::vector<float> ones((size_t)std::max<long long>(n1, 256), 1.0f);
+            if (!rc1) rc1 = P->ones4096.upload(ones.data(), ones.size() * sizeof(float));
+            if (rc1) { delete P; return rc1; }
+        }
     }
     set_kernel_attrs_once();
     // nbins must be known before tiles are sized (the LDS histogram shares the tile's allocation): ISO plans are
@@ -1587,7 +1629,9 @@ int xrfthip_plan_describe(const xrfthip_plan* plan, char* buf, size_t buflen) {
             d.ndim, (long long)d.batch, (long long)d.ny, (long long)d.nx, d.dtype, d.out_mode, d.detrend, d.flags,
             plan->width, plan->nx_out, (int)plan->mirror, plan->G, plan->ws_bytes);
     if (fasty_on(plan)) {
-        const YGeomRt C = ycols_geom(plan->d.ny), R = yrows_geom(plan->d.nx);
+        const YGeomRt C = ycols_geom(plan->yny), R = yrows_geom(plan->ynx);
+        if (plan->fast1d) appendf(s, "  [fasty four-step] %lld samples = [%lld][%lld]: columns = step 1 (half spectrum k1 <= %lld), rows x W_N^(i2 k1) = step 2, transposed stores + Hermitian mirror\n",
+                                  (long long)plan->d.nx, (long long)plan->yny, (long long)plan->ynx, (long long)plan->yny / 2);
         appendf(s, "  [fasty] cols: %d thr, %d x 2 packed column pairs (FFT%lld r16x16x%lld, column-local detrend fused), %d columns/unit, lds=%zuB -> W2[slab][%d/%d][nx/%d][2][%d][%d] -> rows: %d thr, %d rows/unit (FFT%lld r16x16x%lld), lds=%zuB, |F|^2 + fftshift + mirror rows\n",
                 C.thr, C.gxy, (long long)plan->d.ny, (long long)plan->d.ny / 256, C.cw, C.lds, plan->y_nrow_pad, C.rk, C.cw, C.rk, 2 * C.gxy,
                 R.thr, R.rk, (long long)plan->d.nx, (long long)plan->d.nx / 256, R.lds);
