@@ -501,10 +501,10 @@ def run_fourstep_1d(n=65536, nt=3):
         g = xa.fft(da, dim=["x"], detrend=det)
         r = o.fft(od64, dim=["x"], detrend=det)
         err = float(np.abs(g.values - r.values).max() / np.abs(r.values).max())
-        assert err < 5e-6, (det, err)
+        assert err < 2e-5, (det, err)  # (the trend reaches 100x the noise at 2^20 samples: float32 input)
         g = xa.power_spectrum(da, dim=["x"], detrend=det)
         r = o.power_spectrum(od64, dim=["x"], detrend=det)
-        assert float(np.abs(g.values - r.values).max() / np.abs(r.values).max()) < 5e-6
+        assert float(np.abs(g.values - r.values).max() / np.abs(r.values).max()) < 2e-5
     worst = max(worst, check(xa.power_spectrum(da, dim=["x"], window="hann"), o.power_spectrum(od, dim=["x"], window="hann"), 3e-6))
     assert "four-step]" not in next(reversed(xa.api._plan_cache.values())).describe()  # (a window: the generic four-step passes)
     return worst
