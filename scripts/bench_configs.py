@@ -1,14 +1,16 @@
 #!/usr/bin/env python3
-"""Throughput of the other BASELINE.json configurations (parity-test cases, not the bench line) at reduced batch sizes,
-to document where the generic kernels stand.  Run on the GPU box: python scripts/bench_configs.py"""
+"""Throughput + roofline of the BASELINE.json configurations other than the bench line (parity-test cases) on one MI355X.
+GFFT/s = points of one field / wall time; roofline = SURVEY.md 8(d) algorithmic bytes per point / wall / 8 TB/s.
+Run on the GPU box: python scripts/bench_configs.py > gpurun_out/r02/bench_configs.txt"""
 import os, sys, time, warnings
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 import xrft_amd as xrft
+from xrft_amd import api
 warnings.simplefilter("ignore")
 dev = "cuda"
 
-def timeit(fn, reps=3):
+def timeit(fn, reps=5):
     fn(); fn(); torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(reps):
@@ -20,31 +22,51 @@ def cube(shape, dtype):
     return torch.randn(shape, dtype=dtype, device=dev)
 
 rows = []
-# C1: PS (4,256,256) f64
+def add(name, pts, bpp, t):
+    path = next(reversed(api._plan_cache.values())).describe().strip().split("\n")[1].strip().split("]")[0] + "]"
+    rows.append((name, pts / t / 1e9, t, bpp, bpp * pts / t / 8e12, path))
+
+# C1: PS (4,256,256) f64 (the reference's CPU-runnable case; one call is host-time bound here)
 x = cube((4, 256, 256), torch.float64); c = {"t": np.arange(4), "y": np.arange(256.), "x": np.arange(256.)}
 da = xrft.DataArray(x, ("t", "y", "x"), c)
-t = timeit(lambda: xrft.power_spectrum(da, dim=["y", "x"], detrend="linear", window="hann")); rows.append(("C1 PS (4,256,256) f64", x.numel() / t / 1e9, t))
+add("C1 PS (4,256,256) f64 linear+hann", x.numel(), 16, timeit(lambda: xrft.power_spectrum(da, dim=["y", "x"], detrend="linear", window="hann")))
 # C2: dft 1-D (1024, 65536) f32
 x = cube((1024, 65536), torch.float32); da = xrft.DataArray(x, ("t", "x"), {"x": np.arange(65536) * 0.5})
-t = timeit(lambda: xrft.dft(da, dim="x")); rows.append(("C2 dft 1-D (1024,65536) f32", x.numel() / t / 1e9, t))
-# C3 variants on the generic path
-x = cube((8, 4096, 4096), torch.float32); c = {"y": np.arange(4096.), "x": np.arange(4096.)}
+add("C2 dft 1-D (1024,65536) f32", x.numel(), 12, timeit(lambda: xrft.dft(da, dim="x")))
+add("   power_spectrum 1-D (1024,65536) f32", x.numel(), 8, timeit(lambda: xrft.power_spectrum(da, dim="x")))
+add("   power_spectrum 1-D linear+hann (generic passes)", x.numel(), 8, timeit(lambda: xrft.power_spectrum(da, dim="x", detrend="linear", window="hann")))
+del x, da
+# C3 variants
+x = cube((32, 4096, 4096), torch.float32); c = {"y": np.arange(4096.), "x": np.arange(4096.)}
 da = xrft.DataArray(x, ("t", "y", "x"), c)
-t = timeit(lambda: xrft.power_spectrum(da, dim=["y", "x"], detrend="linear", window="hann")); rows.append(("C3 PS (8,4096,4096) f32 [fastp2]", x.numel() / t / 1e9, t))
-t = timeit(lambda: xrft.fft(da, dim=["y", "x"], detrend="linear", window="hann")); rows.append(("   fft complex out (8,4096,4096) f32 [fastp2]", x.numel() / t / 1e9, t))
-t = timeit(lambda: xrft.isotropic_power_spectrum(da, dim=["y", "x"], detrend="linear", window="hann")); rows.append(("   isotropic PS (8,4096,4096) f32 [fastp2]", x.numel() / t / 1e9, t))
-# C4: cross + isotropic on two (16,2048,2048) f32
-a = cube((16, 2048, 2048), torch.float32); b = cube((16, 2048, 2048), torch.float32); c = {"y": np.arange(2048.), "x": np.arange(2048.)}
+add("C3 PS (32,4096,4096) f32 linear+hann", x.numel(), 8, timeit(lambda: xrft.power_spectrum(da, dim=["y", "x"], detrend="linear", window="hann")))
+add("   isotropic PS (32,4096,4096) f32", x.numel(), 4, timeit(lambda: xrft.isotropic_power_spectrum(da, dim=["y", "x"], detrend="linear", window="hann")))
+add("   PS real_dim=x (32,4096,4096) f32 [x-first path]", x.numel(), 6, timeit(lambda: xrft.power_spectrum(da, dim=["y"], real_dim="x", detrend="linear", window="hann")))
+da8 = xrft.DataArray(x[:16].contiguous(), ("t", "y", "x"), c)
+add("   fft complex out (16,4096,4096) f32", da8.data.numel(), 12, timeit(lambda: xrft.fft(da8, dim=["y", "x"], detrend="linear", window="hann")))
+del x, da, da8
+# C4: cross + isotropic on two (64,2048,2048) f32 (one GPU's share of nt = 512 over 8 GPUs)
+a = cube((64, 2048, 2048), torch.float32); b = cube((64, 2048, 2048), torch.float32); c = {"y": np.arange(2048.), "x": np.arange(2048.)}
 d1 = xrft.DataArray(a, ("t", "y", "x"), c); d2 = xrft.DataArray(b, ("t", "y", "x"), c)
-t = timeit(lambda: xrft.cross_spectrum(d1, d2, dim=["y", "x"], window="hann")); rows.append(("C4 cross_spectrum 2x(16,2048,2048) f32", a.numel() / t / 1e9, t))
-t = timeit(lambda: xrft.isotropic_cross_spectrum(d1, d2, dim=["y", "x"], window="hann")); rows.append(("C4 isotropic_cross_spectrum", a.numel() / t / 1e9, t))
-t = timeit(lambda: xrft.isotropic_power_spectrum(d1, dim=["y", "x"], window="hann")); rows.append(("C4 isotropic_power_spectrum", a.numel() / t / 1e9, t))
-t = timeit(lambda: xrft.power_spectrum(d1, dim=["y", "x"], detrend="linear", window="hann")); rows.append(("   PS (16,2048,2048) f32 [fastp2]", a.numel() / t / 1e9, t))
-x = cube((64, 1024, 1024), torch.float32); c = {"y": np.arange(1024.), "x": np.arange(1024.)}
-da = xrft.DataArray(x, ("t", "y", "x"), c)
-t = timeit(lambda: xrft.power_spectrum(da, dim=["y", "x"], detrend="linear", window="hann")); rows.append(("   PS (64,1024,1024) f32 [fastp2]", x.numel() / t / 1e9, t))
+add("C4 cross_spectrum 2x(64,2048,2048) f32 hann", a.numel(), 16, timeit(lambda: xrft.cross_spectrum(d1, d2, dim=["y", "x"], window="hann")))
+add("C4 isotropic_cross_spectrum", a.numel(), 8, timeit(lambda: xrft.isotropic_cross_spectrum(d1, d2, dim=["y", "x"], window="hann")))
+add("C4 isotropic_power_spectrum", a.numel(), 4, timeit(lambda: xrft.isotropic_power_spectrum(d1, dim=["y", "x"], window="hann")))
+add("   PS (64,2048,2048) f32 linear+hann", a.numel(), 8, timeit(lambda: xrft.power_spectrum(d1, dim=["y", "x"], detrend="linear", window="hann")))
+del a, b, d1, d2
+for n, nt in ((1024, 256), (512, 1024), (256, 4096)):
+    x = cube((nt, n, n), torch.float32); c = {"y": np.arange(float(n)), "x": np.arange(float(n))}
+    da = xrft.DataArray(x, ("t", "y", "x"), c)
+    add(f"   PS ({nt},{n},{n}) f32 linear+hann", x.numel(), 8, timeit(lambda: xrft.power_spectrum(da, dim=["y", "x"], detrend="linear", window="hann")))
+    del x, da
 # C5: PS (64,1440,720) f64
 x = cube((64, 1440, 720), torch.float64); da = xrft.DataArray(x, ("t", "lat", "lon"), {"lat": np.arange(1440) * .25, "lon": np.arange(720) * .25})
-t = timeit(lambda: xrft.power_spectrum(da, dim=["lat", "lon"], detrend="constant", window="hann")); rows.append(("C5 PS (64,1440,720) f64", x.numel() / t / 1e9, t))
-for name, g, t in rows:
-    print(f"{name:50s} {g:8.2f} GFFT/s   {t*1e3:8.2f} ms")
+add("C5 PS (64,1440,720) f64 linear+hann", x.numel(), 16, timeit(lambda: xrft.power_spectrum(da, dim=["lat", "lon"], detrend="linear", window="hann")))
+add("   same, detrend=None", x.numel(), 16, timeit(lambda: xrft.power_spectrum(da, dim=["lat", "lon"], window="hann")))
+da32 = xrft.DataArray(x.float(), da.dims, da.coords)
+add("   same shape, float32, linear+hann", x.numel(), 8, timeit(lambda: xrft.power_spectrum(da32, dim=["lat", "lon"], detrend="linear", window="hann")))
+# a middle axis in place (XRFTHIP_AXIS_Y)
+x = cube((64, 1024, 2048), torch.float32); da = xrft.DataArray(x, ("t", "y", "x"), {"y": np.arange(1024.), "x": np.arange(2048.)})
+add("fft along the MIDDLE axis (64,1024,2048) f32, no copies", x.numel(), 12, timeit(lambda: xrft.fft(da, dim=["y"])))
+print(f"{'workload':58s} {'GFFT/s':>8s} {'ms':>9s} {'B/pt':>5s} {'frac of 8 TB/s':>15s}  path")
+for name, g, t, bpp, frac, path in rows:
+    print(f"{name:58s} {g:8.2f} {t*1e3:9.3f} {bpp:5.0f} {frac:15.3f}  {path}")
