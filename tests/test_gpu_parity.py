@@ -344,6 +344,10 @@ def test_config4_full_size_16x2048x2048():
     ips = xa.isotropic_power_spectrum(da, dim=["y", "x"], window="hann")
     ps = xa.power_spectrum(da, dim=["y", "x"], window="hann")
     np.testing.assert_allclose(ips.values.sum(axis=-1), ps.data.double().sum(dim=(1, 2)).cpu().numpy(), rtol=1e-5)
+    # the radial sums are bit-reproducible (integer fixed-point adds per workgroup, partial sums reduced in order)
+    for _ in range(3):
+        assert np.array_equal(xa.isotropic_cross_spectrum(da, db, dim=["y", "x"], window="hann").values, ics.values)
+        assert np.array_equal(xa.isotropic_power_spectrum(da, dim=["y", "x"], window="hann").values, ips.values)
 
 
 def test_config5_full_size_64x1440x720_f64_linear():

@@ -56,7 +56,8 @@ struct FastY {
     const cf* what0;         // FFT_y(wy)[ky], ky < nrow_pad (zero beyond ny/2)
     const cf* what1;         // FFT_y(wy * (i - (ny-1)/2))[ky]
     const unsigned* tcodes;  // radial bins in pass 2's register order: (direct + 1) | (mirror + 1) << 16
-    double* iso;             // [slab][nbins] per-bin sums (ISO), zeroed by the caller
+    double* iso;             // [slab][nbins] per-bin sums (ISO)
+    double* iso_part;        // [slab][row workgroup][nbins (x2 complex)]: per-workgroup partial sums, reduced in order
     int nbins;
     int ny, nx;
     int nrow_pad;            // rows of W2 per slab
@@ -341,6 +342,18 @@ __device__ __forceinline__ unsigned w2_offset(const FastY& p, int ky, int x) {
     return (blk << (p.l_rk + p.l_2gy)) + (((unsigned)ky & ((1u << p.l_rk) - 1u)) << p.l_2gy) + ((((unsigned)x & ((1u << p.l_cw) - 1u)) >> 2) << 1) + ((unsigned)x & 1u);
 }
 
+// float -> int64 fixed point with 40 fractional bits below 2^(eb - 127), eb = biased exponent of a bound |v| < 2^(eb - 126):
+// integer arithmetic only (no float64 <-> int64 conversions, which gfx950 emulates); truncates below 2^-40 of the bound
+__device__ __forceinline__ long long fixed40(float v, int eb) {
+    const unsigned bits = __float_as_uint(v);
+    const int ex = (int)((bits >> 23) & 0xffu);
+    if (ex == 0) return 0;  // zero / denormal
+    long long m = (long long)((bits & 0x7fffffu) | 0x800000u);  // 24-bit mantissa: |v| = m 2^(ex - 150)
+    const int sh = ex - eb + 17;                                // q = |v| 2^(40 + 127 - eb) = m 2^(ex - eb + 17), sh <= 17
+    m = sh >= 0 ? (m << sh) : (sh > -40 ? (m >> (-sh)) : 0);
+    return (bits >> 31) ? -m : m;
+}
+
 // 16-byte non-temporal store of two complex samples
 __device__ __forceinline__ void xrft_store_nt2(cf* dst, cf v0, cf v1) {
     F4 o; o.x = v0.re; o.y = v0.im; o.z = v1.re; o.w = v1.im;
@@ -374,9 +387,11 @@ __global__ void __launch_bounds__(YRows<NX>::THR, YRows<NX>::THR / 128) fasty_ro
     const int tid = threadIdx.x, g = tid % GX, u = tid / GX;
     cf* mine = lds + g * GSTR;
     cf* tw2 = lds + GX * GSTR;
-    double* hist = reinterpret_cast<double*>(tw2 + 16 * G::R3);
+    // radial-sum tables, ALIASED onto the transforms' LDS (they live only between the last transform barrier and the staging
+    // of the result: a separate 12-20 KB would cost the second workgroup per CU)
+    unsigned long long* acc = reinterpret_cast<unsigned long long*>(lds);          // [nbins][HW] int64 fixed-point sums
+    unsigned* bmax = reinterpret_cast<unsigned*>(acc + (ISO ? p.nbins * HW : 0));  // [nbins] float bits of the largest magnitude
     fill_tw2<NX>(tw2, p.tw_x, tid, THR);
-    if (ISO) for (int i = tid; i < p.nbins * HW; i += THR) hist[i] = 0.0;  // ordered before the first add by the FFT's barriers
     const int upr = p.nrow_pad / RPU;  // units per slab
     const int slab = blockIdx.x / upr, unit = blockIdx.x % upr, ky0 = unit * RPU;
     const int nyh = p.ny >> 1;
@@ -444,28 +459,52 @@ __global__ void __launch_bounds__(YRows<NX>::THR, YRows<NX>::THR / 128) fasty_ro
 #pragma unroll
         for (int e = 0; e < 16; ++e) a[e] = cscale(cmulc(a[e], b[e]), p.scale);
     }
-    if (ISO) {  // value at (ky, kx) goes to its bin, and once more (conjugated) to the bin of (-ky, -kx)
+    if (ISO) {
+        // Radial sums (xrft.py:895-906), bit-reproducible: floating-point atomics would make the sum depend on the order in
+        // which waves arrive.  Two passes over this workgroup's values: (1) the largest magnitude per bin (atomicMax on the
+        // float bits: order-independent), (2) every value converted to int64 fixed point 40 bits below its bin's maximum
+        // and added with INTEGER atomics (exact, order-independent; the inputs carry 24 bits).  The workgroup's per-bin
+        // sums go to a partial table that fasty_iso_reduce_kernel adds in unit order.  A value at (ky, kx) goes to its bin
+        // and once more (conjugated) to the bin of (-ky, -kx).
         const unsigned* __restrict__ tc = p.tcodes + ((size_t)unit * (TWO ? 16 : 32)) * THR + tid;
+        unsigned codes[TWO ? 16 : 32];
+#pragma unroll
+        for (int e = 0; e < (TWO ? 16 : 32); ++e) codes[e] = tc[(size_t)e * THR];
+        for (int i = tid; i < p.nbins * HW; i += THR) acc[i] = 0ull;  // (the transforms' trailing barrier has passed: their LDS is free)
+        for (int i = tid; i < p.nbins; i += THR) bmax[i] = 0u;
+        __syncthreads();
 #pragma unroll
         for (int e = 0; e < (TWO ? 16 : 32); ++e) {
             const cf v = e < 16 ? a[e] : b[e - 16];
-            const unsigned code = tc[(size_t)e * THR];
-            const unsigned cd = code & 0xffffu, cm = code >> 16;
-            if (MODE == 1) {
-                const float pw = (v.re * v.re + v.im * v.im) * p.scale;
-                if (cd == cm) { if (cd) atomicAdd(&hist[cd - 1], 2.0 * (double)pw); }
-                else {
-                    if (cd) atomicAdd(&hist[cd - 1], (double)pw);
-                    if (cm) atomicAdd(&hist[cm - 1], (double)pw);
-                }
-            } else {
-                if (cd == cm) { if (cd) atomicAdd(&hist[2 * (cd - 1)], 2.0 * (double)v.re); }  // V + conj V
-                else {
-                    if (cd) { atomicAdd(&hist[2 * (cd - 1)], (double)v.re); atomicAdd(&hist[2 * (cd - 1) + 1], (double)v.im); }
-                    if (cm) { atomicAdd(&hist[2 * (cm - 1)], (double)v.re); atomicAdd(&hist[2 * (cm - 1) + 1], -(double)v.im); }
-                }
+            const float mag = MODE == 1 ? (v.re * v.re + v.im * v.im) * p.scale : fabsf(v.re) + fabsf(v.im);
+            const unsigned cd = codes[e] & 0xffffu, cm = codes[e] >> 16, mb = __float_as_uint(fabsf(mag));
+            if (cd) atomicMax(&bmax[cd - 1], mb);
+            if (cm && cm != cd) atomicMax(&bmax[cm - 1], mb);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int e = 0; e < (TWO ? 16 : 32); ++e) {
+            const cf v = e < 16 ? a[e] : b[e - 16];
+            const unsigned cd = codes[e] & 0xffffu, cm = codes[e] >> 16;
+            if (!cd && !cm) continue;
+            const float re = MODE == 1 ? (v.re * v.re + v.im * v.im) * p.scale : v.re, im = v.im;
+            if (cd) {
+                const int eb = (int)(bmax[cd - 1] >> 23);
+                atomicAdd(&acc[HW * (cd - 1)], (unsigned long long)(fixed40(re, eb) * (cd == cm ? 2 : 1)));
+                if (MODE == 2 && cd != cm) atomicAdd(&acc[2 * (cd - 1) + 1], (unsigned long long)fixed40(im, eb));  // (cd == cm: V + conj V is real)
+            }
+            if (cm && cm != cd) {
+                const int eb = (int)(bmax[cm - 1] >> 23);
+                atomicAdd(&acc[HW * (cm - 1)], (unsigned long long)fixed40(re, eb));
+                if (MODE == 2) atomicAdd(&acc[2 * (cm - 1) + 1], (unsigned long long)fixed40(-im, eb));
             }
         }
+        __syncthreads();
+        // this workgroup's sums, back in floating point (exact: < 2^53), into its row of the partial table
+        double* __restrict__ part = p.iso_part + ((size_t)slab * upr + unit) * p.nbins * HW;
+        for (int i = tid; i < p.nbins * HW; i += THR)
+            part[i] = ldexp((double)(long long)acc[i], (int)(bmax[i / HW] >> 23) - 127 - 40);
+        __syncthreads();  // the staging below re-uses this LDS
     }
     const int mx = NX - 1, my = p.ny - 1, sx = p.shift_x;
     if (MODE == 1 && p.out != nullptr) {
@@ -575,13 +614,23 @@ __global__ void __launch_bounds__(YRows<NX>::THR, YRows<NX>::THR / 128) fasty_ro
             }
         }
     }
-    if (ISO) {
-        __syncthreads();
-        for (int i = tid; i < p.nbins * HW; i += THR) {
-            const double v = hist[i];
-            if (v != 0.0) atomicAdd(&p.iso[(size_t)slab * p.nbins * HW + i], v);
-        }
+}
+
+// iso[slab][bin] = sum over the row workgroups of the slab in a FIXED order (bit-reproducible): 256 threads = 4 segments of
+// units x 64 bins; every segment adds its units in order, the four segment sums are combined in order
+__global__ void __launch_bounds__(256) fasty_iso_reduce_kernel(const double* __restrict__ part, double* __restrict__ iso, int upr, int nb) {
+    XRFT_DYN_SMEM(smem_raw);
+    double (*seg)[64] = reinterpret_cast<double (*)[64]>(smem_raw);  // [4][64]
+    const int lane = threadIdx.x & 63, sg = threadIdx.x >> 6, i = blockIdx.x * 64 + lane, slab = blockIdx.y;
+    const int per = (upr + 3) / 4, u0 = sg * per, u1 = min(upr, u0 + per);
+    double s = 0.0;
+    if (i < nb) {
+        const double* src = part + (size_t)slab * upr * nb + i;
+        for (int un = u0; un < u1; ++un) s += src[(size_t)un * nb];
     }
+    seg[sg][lane] = s;
+    __syncthreads();
+    if (sg == 0 && i < nb) iso[(size_t)slab * nb + i] = ((seg[0][lane] + seg[1][lane]) + seg[2][lane]) + seg[3][lane];
 }
 
 // ------------------------------------------------------------------------------------------------

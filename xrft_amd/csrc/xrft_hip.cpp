@@ -283,7 +283,7 @@ struct xrfthip_plan {
     std::vector<Pass> passes;     // main pipeline (field 1 for CROSS)
     std::vector<Pass> passes_f0;  // CROSS: field 0 -> raw F0 buffer
     // workspace layout (byte offsets)
-    size_t off_acc = 0, off_coef = 0, off_w = 0, off_w2 = 0, off_f0 = 0, off_pt = 0, off_rowfit = 0, off_corr = 0, ws_bytes = 0;
+    size_t off_acc = 0, off_coef = 0, off_w = 0, off_w2 = 0, off_f0 = 0, off_pt = 0, off_rowfit = 0, off_corr = 0, off_isopart = 0, ws_bytes = 0;
     std::string desc_text;
     // specialised path for float32 power spectra of power-of-two slabs, 1024..4096 per axis (fastp2.h)
     bool fast4096 = false;  // (the flag keeps its first name: the headline shape is where the path started)
@@ -879,6 +879,13 @@ static void layout_workspace(xrfthip_plan* P) {
     const size_t nfit = (size_t)(yf ? 2 * P->ynx : d.ny);  // per-row fits (x first) or per-column sums + subtracted lines (y first)
     P->off_rowfit = off; if (fast) off = al(off + (size_t)G * nfit * 2 * sizeof(double) * (yf ? nf : 1));
     P->off_corr = off; if (fast) off = al(off + (size_t)G * nfit * 2 * sizeof(float) * (yf ? nf : 1));
+    P->off_isopart = off;
+    if (yf && (d.flags & XRFTHIP_ISO)) {  // per-workgroup partial radial sums of one group of slabs (reduced in order)
+        const bool two = d.out_mode == XRFTHIP_OUT_CROSS;
+        const long long gx = (P->ynx >= 2048 ? 512 : 256) / (P->ynx / 16);  // YRows<NX>::GX
+        const size_t upr = (size_t)P->y_nrow_pad / (two ? gx : 2 * gx);
+        off = al(off + (size_t)G * upr * P->nbins * (two ? 2 : 1) * sizeof(double));
+    }
     P->ws_bytes = off;
 }
 
@@ -1220,7 +1227,8 @@ static void fasty_launch_rows(const xrfthip_plan* P, const FastY& p, long long g
     xrfthip_plan::ProfRec* rec = prof ? prof_begin(P, "fasty_rows", st) : nullptr;
     const int rpu = two ? R.gxy : R.rk;  // a cross spectrum spends both transforms of a thread on one row (field 0, field 1)
     const dim3 grid((unsigned)(gc * (P->y_nrow_pad / rpu))), blk((unsigned)R.thr);
-    const size_t lds = R.lds + (iso_on ? (size_t)P->nbins * sizeof(double) * (d.out_mode == XRFTHIP_OUT_CROSS ? 2 : 1) : 0);
+    const int hw = d.out_mode == XRFTHIP_OUT_CROSS ? 2 : 1;
+    const size_t lds = R.lds;  // (the radial-sum tables alias the transforms' LDS)
 #define YR_(NN) do { \
         if (d.out_mode == XRFTHIP_OUT_POWER) { if (iso_on) { auto k = &fasty_rows_kernel<NN, 1, true>; XRFT_LAUNCH(k, grid, blk, lds, st, p); } else { auto k = &fasty_rows_kernel<NN, 1, false>; XRFT_LAUNCH(k, grid, blk, lds, st, p); } } \
         else if (d.out_mode == XRFTHIP_OUT_CROSS) { if (iso_on) { auto k = &fasty_rows_kernel<NN, 2, true>; XRFT_LAUNCH(k, grid, blk, lds, st, p); } else { auto k = &fasty_rows_kernel<NN, 2, false>; XRFT_LAUNCH(k, grid, blk, lds, st, p); } } \
@@ -1233,6 +1241,13 @@ static void fasty_launch_rows(const xrfthip_plan* P, const FastY& p, long long g
     else if (P->ynx == 4096) YR_(4096); else if (P->ynx == 2048) YR_(2048); else if (P->ynx == 1024) YR_(1024); else if (P->ynx == 512) YR_(512); else YR_(256);
 #undef YR_
     prof_end(rec, st);
+    if (iso_on) {  // the row workgroups' partial sums, added in order
+        rec = prof ? prof_begin(P, "fasty_iso_reduce", st) : nullptr;
+        const int nb = P->nbins * hw, upr = P->y_nrow_pad / rpu;
+        auto kr = &fasty_iso_reduce_kernel;
+        XRFT_LAUNCH(kr, dim3((unsigned)((nb + 63) / 64), (unsigned)gc), dim3(256), 4 * 64 * sizeof(double), st, (const double*)p.iso_part, p.iso, upr, nb);
+        prof_end(rec, st);
+    }
 }
 
 // parameter block of one group of slabs [g0, g0 + gc): the intermediate and the fit tables sit in ring slot `slot` (of slot_slabs slabs each)
@@ -1264,6 +1279,7 @@ static FastY fasty_params(const xrfthip_plan* P, const float* in, void* out, dou
     p.tcodes = reinterpret_cast<const unsigned*>(P->ytcodes.p);
     p.iso = iso_on ? iso + (size_t)g0 * P->nbins * (d.out_mode == XRFTHIP_OUT_CROSS ? 2 : 1) : nullptr;
     p.nbins = P->nbins;
+    p.iso_part = reinterpret_cast<double*>(ws + P->off_isopart);
     p.ny = (int)P->yny; p.nx = (int)P->ynx;
     p.nrow_pad = P->y_nrow_pad;
     p.l_cw = ilog2i(C.cw); p.l_rk = ilog2i(C.rk); p.l_2gy = ilog2i(2 * C.gxy);
@@ -1574,7 +1590,7 @@ int xrfthip_plan_set_binmap(xrfthip_plan* plan, const int32_t* h_binmap, int64_t
         int rcf = XRFTHIP_OK;
         const size_t hist_bytes = (size_t)nbins * sizeof(double) * (plan->d.out_mode == XRFTHIP_OUT_CROSS ? 2 : 1);
         if (plan->yfirst) {
-            if (nbins > 65534 || yrows_geom(plan->d.nx).lds + hist_bytes > kLdsMax) plan->fast4096 = false;
+            if (nbins > 65534 || hist_bytes + (size_t)nbins * 4 + 64 > yrows_geom(plan->d.nx).lds) plan->fast4096 = false;  // (the tables alias the transforms' LDS)
             else rcf = fasty_build_tcodes(plan, h_binmap);
         }
         else if (nbins > 65534 || fast_cols_lds(plan->d.ny, true) + hist_bytes > kLdsMax) plan->fast4096 = false;  // the histogram sits behind the column pass's FFT buffers
