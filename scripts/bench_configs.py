@@ -41,7 +41,7 @@ x = cube((32, 4096, 4096), torch.float32); c = {"y": np.arange(4096.), "x": np.a
 da = xrft.DataArray(x, ("t", "y", "x"), c)
 add("C3 PS (32,4096,4096) f32 linear+hann", x.numel(), 8, timeit(lambda: xrft.power_spectrum(da, dim=["y", "x"], detrend="linear", window="hann")))
 add("   isotropic PS (32,4096,4096) f32", x.numel(), 4, timeit(lambda: xrft.isotropic_power_spectrum(da, dim=["y", "x"], detrend="linear", window="hann")))
-add("   PS real_dim=x (32,4096,4096) f32 [x-first path]", x.numel(), 6, timeit(lambda: xrft.power_spectrum(da, dim=["y"], real_dim="x", detrend="linear", window="hann")))
+add("   PS real_dim=x (32,4096,4096) f32 (half output)", x.numel(), 6, timeit(lambda: xrft.power_spectrum(da, dim=["y"], real_dim="x", detrend="linear", window="hann")))
 da8 = xrft.DataArray(x[:16].contiguous(), ("t", "y", "x"), c)
 add("   fft complex out (16,4096,4096) f32", da8.data.numel(), 12, timeit(lambda: xrft.fft(da8, dim=["y", "x"], detrend="linear", window="hann")))
 del x, da, da8

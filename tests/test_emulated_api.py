@@ -125,7 +125,7 @@ def test_unsupported_length_is_loud():
     (512, 512, 2, True, None, "hann"),
 ])
 def test_fastp2_path(ny, nx, nt, shift, det, win):
-    """The specialised power-of-two float32 power-spectrum kernels (fastp2.h) against numpy in float64."""
+    """The specialised power-of-two float32 power-spectrum kernels (fasty.h) against numpy in float64."""
     import scipy.signal as sps
     import xrft_amd as xa
 

@@ -163,7 +163,7 @@ def test_config3_ps_4096_f32_vs_oracle():
     (512, 256, 3, None, "hamming", True),
 ])
 def test_fastp2_shapes_vs_oracle(ny, nx, nt, det, win, shift):
-    """Every power-of-two shape the specialised kernels take (fastp2.h) against the oracle, several slabs."""
+    """Every power-of-two shape the specialised kernels take (fasty.h) against the oracle, several slabs."""
     import xrft_amd as xa
     from xrft_amd import api
 

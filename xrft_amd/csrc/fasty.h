@@ -53,6 +53,8 @@ struct FastY {
     const cf* ph_x;          // (four-step 1-D: one table over the whole sequence, indexed by the unshifted sample index)
     const cf* tw_big;        // four-step 1-D: W_N^j, j < N / 2
     int ph_on;               // 0: every phase factor is 1 (true_phase off, no ifftshift): the tables are not read
+    int half;                // real_dim: only kx = 0..nx/2 is stored, rows of nx/2 + 1 samples, unshifted (xrft.py:400-404)
+    int realdim2;            // ... and 0 < kx < nx/2 counts twice (xrft.py:673-682)
     const cf* what0;         // FFT_y(wy)[ky], ky < nrow_pad (zero beyond ny/2)
     const cf* what1;         // FFT_y(wy * (i - (ny-1)/2))[ky]
     const unsigned* tcodes;  // radial bins in pass 2's register order: (direct + 1) | (mirror + 1) << 16
@@ -531,6 +533,17 @@ __global__ void __launch_bounds__(YRows<NX>::THR, YRows<NX>::THR / 128) fasty_ro
                 const int o1k = mir ? p.ny - k1 : k1, o2k = mir ? (NX - 1 - k2) : k2;  // X[N - k]: (ny - k1) + ny (nx - 1 - k2)
                 o1[(size_t)((o2k + sx) & mx) * p.ny + o1k] = v;
             }
+        } else if (p.half) {  // rows of nx/2 + 1 samples (an odd length: 4-byte stores, still whole lines per wave); row -ky reads the row backwards
+            constexpr int W = NX / 2 + 1;
+            float* __restrict__ oh = reinterpret_cast<float*>(p.out) + (size_t)slab * p.ny * W;
+            for (int e = tid; e < RPU * 2 * W; e += THR) {
+                const int kx = e % W, rr = e / W, r = rr >> 1, mir = rr & 1;
+                const int ky = ky0 + r;
+                if (ky > nyh || (mir && (ky == 0 || ky == nyh))) continue;
+                float v = stg[r * RSP + nat16(mir ? (NX - kx) & mx : kx)];
+                if (p.realdim2 && kx != 0 && kx != NX / 2) v *= 2.0f;
+                oh[(size_t)(mir ? p.ny - ky : ky) * W + kx] = v;
+            }
         } else {
         // every staged row leaves twice: rotated (direct) and reversed + rotated (mirror); 16-byte stores, whole rows
         float* __restrict__ outs = reinterpret_cast<float*>(p.out) + (size_t)slab * p.ny * NX;
@@ -584,6 +597,23 @@ __global__ void __launch_bounds__(YRows<NX>::THR, YRows<NX>::THR / 128) fasty_ro
                     const int o1k = mir ? p.ny - k1 : k1, o2k = mir ? (NX - 1 - k2) : k2;
                     if (p.ph_on) v = cmul(v, p.ph_x[o2k * p.ny + o1k]);
                     o1[(size_t)((o2k + sx) & mx) * p.ny + o1k] = v;
+                }
+                continue;
+            }
+            if (p.half) {  // kx = 0..nx/2 only, unshifted; F(-ky, kx) = conj F(ky, -kx)
+                constexpr int W = NX / 2 + 1;
+                for (int e = tid; e < GX * 2 * W; e += THR) {
+                    const int kx = e % W, rr = e / W, r = rr >> 1, mir = rr & 1;
+                    const int ky = ky0 + round * GX + r;
+                    if (ky > nyh || (mir && (ky == 0 || ky == nyh))) continue;
+                    cf v = cstg[r * RSC + nat16(mir ? (NX - kx) & mx : kx)];
+                    if (mir) v = cconj(v);
+                    const int fy = mir ? p.ny - ky : ky;
+                    if (p.ph_on) v = cmul(v, cmul(p.ph_y[fy], p.ph_x[kx]));
+                    if (p.realdim2 && kx != 0 && kx != NX / 2) v = cscale(v, 2.0f);
+                    const size_t o = ((size_t)slab * p.ny + fy) * W + kx;
+                    if (MODE == 3) reinterpret_cast<float*>(p.out)[o] = (float)atan2((double)v.im, (double)v.re);
+                    else reinterpret_cast<cf*>(p.out)[o] = v;
                 }
                 continue;
             }

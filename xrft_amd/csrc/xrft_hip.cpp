@@ -285,12 +285,10 @@ struct xrfthip_plan {
     // workspace layout (byte offsets)
     size_t off_acc = 0, off_coef = 0, off_w = 0, off_w2 = 0, off_f0 = 0, off_pt = 0, off_rowfit = 0, off_corr = 0, off_isopart = 0, ws_bytes = 0;
     std::string desc_text;
-    // specialised path for float32 power spectra of power-of-two slabs, 1024..4096 per axis (fastp2.h)
+    // specialised path for real float32 slabs whose two lengths are 256 .. 4096 powers of two (fasty.h)
     bool fast4096 = false;  // (the flag keeps its first name: the headline shape is where the path started)
-    int fast_ntile = 0, fast_ntile_pad = 0;
-    DevBuf tw_fx, tw_fy, ones4096, what0, what1, tcodes, fph[2];
+    DevBuf tw_fx, tw_fy, ones4096, fph[2];
     std::vector<double> host_phase[2];  // complex, as handed to xrfthip_plan_set_phase (empty = none)
-    std::vector<double> host_win_x;
     // two-pass "y first" pipeline for full power spectra (fasty.h): columns -> [fit] -> rows, no untile pass
     bool yfirst = false;
     // ... and, as the two steps of a four-step transform, one long real sequence per slab: N = yny * ynx samples viewed as
@@ -765,14 +763,6 @@ void set_kernel_attrs_once() {
 #undef SETALL
 #undef SETA
 #define SETF(K) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&K), hipFuncAttributeMaxDynamicSharedMemorySize, m)
-    SETF((fastp2_rows_kernel<4096, 512>)); SETF((fastp2_rows_kernel<2048, 512>)); SETF((fastp2_rows_kernel<1024, 256>));
-    SETF((fastp2_rows_kernel<512, 256>)); SETF((fastp2_rows_kernel<256, 256>));
-#define SETC(M, I, T1) SETF((fastp2_cols_kernel<4096, 1024, M, I>)); SETF((fastp2_cols_kernel<2048, 1024, M, I>)); SETF((fastp2_cols_kernel<1024, T1, M, I>)); \
-                       SETF((fastp2_cols_kernel<512, 512, M, I>)); SETF((fastp2_cols_kernel<256, 256, M, I>))
-    SETC(1, false, 1024); SETC(1, true, 768); SETC(0, false, 1024); SETC(2, false, 1024); SETC(2, true, 768);
-    SETF((fastp2_cols_kernel<1024, 768, 0, false>));
-#undef SETC
-    SETF(fastp2_untile_kernel); SETF(fastp2_untile_c_kernel<false>); SETF(fastp2_untile_c_kernel<true>);
 #define SETY(NN) SETF((fasty_cols_kernel<NN, false>)); SETF((fasty_cols_kernel<NN, true>)); SETF((fasty_rows_kernel<NN, 1, false>)); SETF((fasty_rows_kernel<NN, 1, true>)); \
                  SETF((fasty_rows_kernel<NN, 0, false>)); SETF((fasty_rows_kernel<NN, 2, false>)); SETF((fasty_rows_kernel<NN, 2, true>)); SETF((fasty_rows_kernel<NN, 3, false>))
     SETY(4096); SETY(2048); SETY(1024); SETY(512); SETY(256);
@@ -849,7 +839,7 @@ static void layout_workspace(xrfthip_plan* P) {
     size_t slab_w = (size_t)d.ny * std::max(P->width, P->w_cols) * P->csize;
     const bool yf = fast && P->yfirst;
     if (fast) {
-        slab_w = yf ? (size_t)P->y_nrow_pad * P->ynx * sizeof(cf) : (size_t)P->fast_ntile_pad * d.ny * 4 * sizeof(cf);
+        slab_w = (size_t)P->y_nrow_pad * P->ynx * sizeof(cf);
         if (G <= 0) G = P->tune_fast_group > 0 ? P->tune_fast_group : std::max<long long>(1, (32LL * 4096 * 4096) / (d.ny * d.nx));  // measured 8: 197, 16: 210, 32: 214 GFFT/s (tails and launch gaps amortise)
     }
     if (G <= 0) {
@@ -871,12 +861,7 @@ static void layout_workspace(xrfthip_plan* P) {
     P->off_w = off; if (need_w) off = al(off + (size_t)G * slab_w * (yf ? nf : 1));  // (y first: field 1's intermediate follows field 0's)
     P->off_w2 = off; if (need_w2) off = al(off + (size_t)G * d.ny * d.nx * P->csize);
     P->off_f0 = off; if (nf == 2 && !fast) off = al(off + (size_t)G * slab_w);
-    if (fast && !yf) {  // line-tiled result: float (power; not needed without a spectrum output) or complex (fft, cross)
-        const bool pw = d.out_mode == XRFTHIP_OUT_POWER;
-        P->off_pt = off;
-        if (!pw || !(d.flags & XRFTHIP_NO_SPECTRUM_OUT)) off = al(off + (size_t)G * (d.ny / 8) * P->fast_ntile_pad * 8 * sizeof(F4) * (pw ? 1 : 2));
-    }
-    const size_t nfit = (size_t)(yf ? 2 * P->ynx : d.ny);  // per-row fits (x first) or per-column sums + subtracted lines (y first)
+    const size_t nfit = (size_t)(yf ? 2 * P->ynx : d.ny);  // per-column sums + subtracted lines
     P->off_rowfit = off; if (fast) off = al(off + (size_t)G * nfit * 2 * sizeof(double) * (yf ? nf : 1));
     P->off_corr = off; if (fast) off = al(off + (size_t)G * nfit * 2 * sizeof(float) * (yf ? nf : 1));
     P->off_isopart = off;
@@ -942,38 +927,6 @@ static int run_moments(const xrfthip_plan* P, const void* in, long long g0, long
 }
 
 
-static int fast4096_window_spectra(xrfthip_plan* P) {
-    const int nx = (int)P->d.nx, nxh = nx / 2;
-    std::vector<double> r0((size_t)nx), i0((size_t)nx, 0.0), r1((size_t)nx), i1((size_t)nx, 0.0);
-    for (int j = 0; j < nx; ++j) {
-        const double w = P->host_win_x.empty() ? 1.0 : P->host_win_x[(size_t)j];
-        r0[(size_t)j] = w;
-        r1[(size_t)j] = w * ((double)j - 0.5 * (nx - 1));
-    }
-    host_fft_pow2(r0, i0);
-    host_fft_pow2(r1, i1);
-    const int nent = 4 * P->fast_ntile_pad;
-    std::vector<cf> h0((size_t)nent), h1((size_t)nent);
-    for (int k = 0; k < nent; ++k) {
-        h0[(size_t)k].re = k <= nxh ? (float)r0[(size_t)k] : 0.f; h0[(size_t)k].im = k <= nxh ? (float)i0[(size_t)k] : 0.f;
-        h1[(size_t)k].re = k <= nxh ? (float)r1[(size_t)k] : 0.f; h1[(size_t)k].im = k <= nxh ? (float)i1[(size_t)k] : 0.f;
-    }
-    int rc = P->what0.upload(h0.data(), h0.size() * sizeof(cf));
-    if (!rc) rc = P->what1.upload(h1.data(), h1.size() * sizeof(cf));
-    return rc;
-}
-
-static int fast_rows_threads(long long nx) { return nx <= 1024 ? 256 : 512; }
-static size_t fast_rows_lds(long long nx) {
-    const int thr = fast_rows_threads(nx), gx = thr / (int)(nx / 16), lb = 2 * gx / 4, ntile = (int)(nx / 8 + 1);
-    return (std::max<size_t>((size_t)gx * (nx + 256), (size_t)ntile * lb * 16) + 16 * (size_t)(nx / 256)) * sizeof(cf);  // + stage-2 twiddles
-}
-// the 1024-point column pass fills the whole LDS with 16 columns: with a histogram it runs 12 columns (768 threads)
-static int fast_cols_threads(long long ny, bool iso) { return ny == 256 ? 256 : ny == 512 ? 512 : (iso && ny == 1024) ? 768 : 1024; }
-static int fast_cols_gy(long long ny, bool iso) { return fast_cols_threads(ny, iso) / (int)(ny / 16); }
-static size_t fast_cols_lds(long long ny, bool iso) { return (size_t)fast_cols_gy(ny, iso) * (ny + 256) * sizeof(cf); }
-
-// float32 power spectrum of a power-of-two slab: row pass (detrend fused) -> [plane fit] -> column pass -> untile, per group of slabs
 // combined per-axis factors of the complex modes: the true-phase table (or 1) times (-1)^k for an ifftshifted input
 // (rolling the input by n/2 -- xrft.py:436-441 -- is that sign in the spectrum; in a cross spectrum the two signs cancel)
 static int fast_phase_tables(xrfthip_plan* P) {
@@ -1010,121 +963,6 @@ static bool fast_on(const xrfthip_plan* P) {
     if (!P->fast4096) return false;
     if (P->d.out_mode == XRFTHIP_OUT_CROSS && (P->d.flags & XRFTHIP_ISO) && phase_nontrivial(P)) return false;
     return true;
-}
-
-static void fast_launch_rows(const xrfthip_plan* P, const FastP2& p, long long gc, hipStream_t st) {
-    const xrfthip_desc& d = P->d;
-    xrfthip_plan::ProfRec* rec = prof_begin(P, "fastp2_rows", st);
-    const int thr = fast_rows_threads(d.nx), rw = 2 * thr / (int)(d.nx / 16);
-    const dim3 grid((unsigned)(gc * (d.ny / rw))), blk((unsigned)thr);
-    const size_t lds = fast_rows_lds(d.nx);
-    if (d.nx == 4096) { auto k = &fastp2_rows_kernel<4096, 512>; XRFT_LAUNCH(k, grid, blk, lds, st, p); }
-    else if (d.nx == 2048) { auto k = &fastp2_rows_kernel<2048, 512>; XRFT_LAUNCH(k, grid, blk, lds, st, p); }
-    else if (d.nx == 1024) { auto k = &fastp2_rows_kernel<1024, 256>; XRFT_LAUNCH(k, grid, blk, lds, st, p); }
-    else if (d.nx == 512) { auto k = &fastp2_rows_kernel<512, 256>; XRFT_LAUNCH(k, grid, blk, lds, st, p); }
-    else { auto k = &fastp2_rows_kernel<256, 256>; XRFT_LAUNCH(k, grid, blk, lds, st, p); }
-    prof_end(rec, st);
-    if (d.detrend) {
-        rec = prof_begin(P, "fastp2_fit", st);
-        auto kf = &fastp2_fit_kernel;
-        XRFT_LAUNCH(kf, dim3((unsigned)gc), dim3(256), 3 * 256 * sizeof(double), st, (const double*)p.rowfit, p.win_y, const_cast<float*>(p.corr), (int)d.ny, (int)d.detrend);
-        prof_end(rec, st);
-    }
-}
-
-template <int MODE, bool ISO>
-static void fast_launch_cols(const xrfthip_plan* P, const FastP2& p, long long gc, hipStream_t st) {
-    const xrfthip_desc& d = P->d;
-    const bool iso_plan = (d.flags & XRFTHIP_ISO) != 0;  // decides the unit size (plan-wide: the tile padding depends on it)
-    xrfthip_plan::ProfRec* rec = prof_begin(P, MODE == 0 && d.out_mode == XRFTHIP_OUT_CROSS ? "fastp2_cols_f0" : "fastp2_cols", st);
-    const long long tpu = fast_cols_gy(d.ny, iso_plan) / 4;
-    const int cthr = fast_cols_threads(d.ny, iso_plan);
-    const long long nunits = gc * (P->fast_ntile_pad / tpu);
-    long long grid = std::min<long long>(P->tune_cols_grid, ((nunits + 63) / 64) * 64);
-    grid = std::max<long long>(64, (grid / 64) * 64);
-    const size_t lds = fast_cols_lds(d.ny, iso_plan) + (ISO ? (size_t)P->nbins * sizeof(double) * (MODE == 2 ? 2 : 1) : 0);
-#define COLS_(NN, TT) do { auto k = &fastp2_cols_kernel<NN, TT, MODE, ISO>; XRFT_LAUNCH(k, dim3((unsigned)grid), dim3((unsigned)cthr), lds, st, p); } while (0)
-    if (d.ny == 4096) COLS_(4096, 1024);
-    else if (d.ny == 2048) COLS_(2048, 1024);
-    else if (d.ny == 512) COLS_(512, 512);
-    else if (d.ny == 256) COLS_(256, 256);
-    else if (cthr == 768) { if constexpr (ISO || MODE == 0) COLS_(1024, 768); }  // (the field-0 pass of an isotropic cross spectrum)
-    else { if constexpr (!ISO) COLS_(1024, 1024); }
-#undef COLS_
-    prof_end(rec, st);
-}
-
-// float32 spectra of a power-of-two slab, per group of slabs:  rows (detrend fused) -> [plane fit] -> columns -> untile.
-// A cross spectrum runs rows + columns for field 0 (complex, left line-tiled), then rows + columns for field 1, whose
-// column pass multiplies in place.
-static int run_fast4096(const xrfthip_plan* P, const float* in, const float* in1, void* out, double* iso, char* ws, hipStream_t st) {
-    const xrfthip_desc& d = P->d;
-    const size_t slab_pts = (size_t)d.ny * d.nx;
-    const bool want_out = !(d.flags & XRFTHIP_NO_SPECTRUM_OUT);
-    const bool iso_on = (d.flags & XRFTHIP_ISO) != 0;
-    const bool power = d.out_mode == XRFTHIP_OUT_POWER, angle = d.out_mode == XRFTHIP_OUT_PHASE;
-    const bool cross = d.out_mode == XRFTHIP_OUT_CROSS || angle;
-    for (long long g0 = 0; g0 < d.batch; g0 += P->G) {
-        const long long gc = std::min<long long>(P->G, d.batch - g0);
-        FastP2 p{};
-        p.in = in + (size_t)g0 * slab_pts;
-        p.w = reinterpret_cast<cf*>(ws + P->off_w);
-        p.pt = (!power || want_out) ? reinterpret_cast<float*>(ws + P->off_pt) : nullptr;
-        const size_t out_pts = (size_t)d.ny * ((d.flags & XRFTHIP_HALF_X) ? d.nx / 2 + 1 : d.nx);
-        p.out = !want_out ? nullptr : (power || angle) ? (float*)out + (size_t)g0 * out_pts : (float*)((cf*)out + (size_t)g0 * out_pts);
-        p.phase_out = angle ? 1 : 0;
-        p.ph_y = reinterpret_cast<const cf*>(P->fph[0].p);
-        p.ph_x = reinterpret_cast<const cf*>(P->fph[1].p);
-        p.tcodes = reinterpret_cast<const unsigned*>(P->tcodes.p);
-        p.iso = iso_on ? iso + (size_t)g0 * P->nbins * (cross ? 2 : 1) : nullptr;
-        p.nbins = P->nbins;
-        p.tw_x = reinterpret_cast<const cf*>(P->tw_fx.p);
-        p.tw_y = reinterpret_cast<const cf*>(P->tw_fy.p);
-        p.win_y = reinterpret_cast<const float*>(P->win[0].p ? P->win[0].p : P->ones4096.p);
-        p.win_x = reinterpret_cast<const float*>(P->win[1].p ? P->win[1].p : P->ones4096.p);
-        p.rowfit = reinterpret_cast<double*>(ws + P->off_rowfit);
-        p.corr = reinterpret_cast<const float*>(ws + P->off_corr);
-        p.what0 = reinterpret_cast<const cf*>(P->what0.p);
-        p.what1 = reinterpret_cast<const cf*>(P->what1.p);
-        p.ny = (int)d.ny; p.nx = (int)d.nx;
-        p.ntile = P->fast_ntile; p.ntile_pad = P->fast_ntile_pad;
-        p.detrend = d.detrend;
-        p.nslab = (int)gc;
-        p.shift_y = (d.flags & XRFTHIP_SHIFT_Y) ? (int)(d.ny / 2) : 0;
-        p.shift_x = (d.flags & XRFTHIP_SHIFT_X) ? (int)(d.nx / 2) : 0;
-        p.scale = (float)d.scale;
-        p.half = (d.flags & XRFTHIP_HALF_X) ? 1 : 0;
-        p.realdim2 = (d.flags & XRFTHIP_REALDIM_X2) ? 1 : 0;
-        fast_launch_rows(P, p, gc, st);
-        if (power) {
-            if (iso_on) fast_launch_cols<1, true>(P, p, gc, st); else fast_launch_cols<1, false>(P, p, gc, st);
-        } else if (!cross) {
-            fast_launch_cols<0, false>(P, p, gc, st);
-        } else {
-            FastP2 p0 = p;
-            p0.scale = 1.0f;
-            fast_launch_cols<0, false>(P, p0, gc, st);
-            p.in = in1 + (size_t)g0 * slab_pts;
-            fast_launch_rows(P, p, gc, st);
-            if (iso_on) fast_launch_cols<2, true>(P, p, gc, st); else fast_launch_cols<2, false>(P, p, gc, st);
-        }
-        if (want_out) {
-            xrfthip_plan::ProfRec* rec = prof_begin(P, "fastp2_untile", st);
-            if (power) {
-                auto ku = &fastp2_untile_kernel;
-                XRFT_LAUNCH(ku, dim3((unsigned)((d.ny / 8) * gc)), dim3(256), (size_t)8 * (d.nx / 2 + 4) * sizeof(float), st, p);
-            } else if (angle) {
-                auto ku = &fastp2_untile_c_kernel<true>;
-                XRFT_LAUNCH(ku, dim3((unsigned)((d.ny / 4) * gc)), dim3(256), (size_t)4 * (d.nx / 2 + 4) * sizeof(cf), st, p);
-            } else {
-                auto ku = &fastp2_untile_c_kernel<false>;
-                XRFT_LAUNCH(ku, dim3((unsigned)((d.ny / 4) * gc)), dim3(256), (size_t)4 * (d.nx / 2 + 4) * sizeof(cf), st, p);
-            }
-            prof_end(rec, st);
-        }
-        HIP_TRY(hipGetLastError());
-    }
-    return XRFTHIP_OK;
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -1263,7 +1101,10 @@ static FastY fasty_params(const xrfthip_plan* P, const float* in, void* out, dou
     p.in = in + (size_t)g0 * slab_pts;
     p.w2 = reinterpret_cast<cf*>(ws + P->off_w) + s0 * (size_t)P->y_nrow_pad * P->ynx;
     const size_t out_esz = (d.out_mode == XRFTHIP_OUT_POWER || d.out_mode == XRFTHIP_OUT_PHASE) ? sizeof(float) : sizeof(cf);
-    p.out = want_out ? (char*)out + (size_t)g0 * slab_pts * out_esz : nullptr;
+    const size_t out_pts = (size_t)P->yny * ((d.flags & XRFTHIP_HALF_X) ? P->ynx / 2 + 1 : P->ynx);
+    p.out = want_out ? (char*)out + (size_t)g0 * out_pts * out_esz : nullptr;
+    p.half = (d.flags & XRFTHIP_HALF_X) ? 1 : 0;
+    p.realdim2 = (d.flags & XRFTHIP_REALDIM_X2) ? 1 : 0;
     p.ph_y = reinterpret_cast<const cf*>(P->fph[0].p);
     p.ph_x = reinterpret_cast<const cf*>(P->fph[1].p);
     p.tw_big = reinterpret_cast<const cf*>(P->tw_big1d.p);
@@ -1323,9 +1164,6 @@ static int finalize_plan(xrfthip_plan* P) {
         int rc = XRFTHIP_OK;
         if (P->yfirst) {
             rc = fasty_window_spectra(P);
-            if (!rc && P->d.out_mode != XRFTHIP_OUT_POWER) rc = fast_phase_tables(P);
-        } else {
-            rc = fast4096_window_spectra(P);
             if (!rc && P->d.out_mode != XRFTHIP_OUT_POWER) rc = fast_phase_tables(P);
         }
         if (rc) return rc;
@@ -1469,11 +1307,8 @@ int xrfthip_plan_create(xrfthip_plan** plan, const xrfthip_desc* desc) {
                       !env_ll("XRFTHIP_NO_FAST", 0);
     }
     if (P->fast4096) {
-        const int tpu = fast_cols_gy(d.ny, (d.flags & XRFTHIP_ISO) != 0) / 4;  // tiles one column workgroup covers
-        P->fast_ntile = (int)(d.nx / 8 + 1);
-        P->fast_ntile_pad = (P->fast_ntile + tpu - 1) / tpu * tpu;
-        // full power spectra take the two-pass y-first pipeline (fasty.h); half / complex / cross results keep the x-first one
-        P->yfirst = !(d.flags & (XRFTHIP_HALF_X | XRFTHIP_REALDIM_X2)) && env_ll("XRFTHIP_YFIRST", 1) != 0;
+        // every mode of these slabs takes the two-pass y-first pipeline (fasty.h)
+        P->yfirst = true;
         if (P->yfirst) {
             P->yny = d.ny; P->ynx = d.nx;
             const int rpu = yrows_geom(d.nx).rk;
@@ -1524,8 +1359,7 @@ int xrfthip_plan_destroy(xrfthip_plan* plan) {
 int xrfthip_plan_set_window(xrfthip_plan* plan, int axis, const double* h_window, int64_t n) {
     if (!plan || axis < 0 || axis > 1) return XRFTHIP_BAD_ARG;
     if (h_window && n != (axis == 0 ? plan->d.ny : plan->d.nx)) return XRFTHIP_BAD_ARG;
-    if (axis == 1) plan->host_win_x.assign(h_window ? h_window : nullptr, h_window ? h_window + n : nullptr);
-    else plan->host_win_y.assign(h_window ? h_window : nullptr, h_window ? h_window + n : nullptr);
+    if (axis == 0) plan->host_win_y.assign(h_window ? h_window : nullptr, h_window ? h_window + n : nullptr);
     int rc = upload_real_table(plan, plan->win[axis], h_window, n, 0);
     if (!rc) rc = finalize_plan(plan);
     return rc;
@@ -1542,44 +1376,6 @@ int xrfthip_plan_set_phase(xrfthip_plan* plan, int axis, const double* h_phase, 
     return rc;
 }
 
-// the bin map re-ordered the way the column pass holds its results (fastp2_cols_kernel): [unit][slot][column][u],
-// value = (bin of (ky, kx) + 1) | (bin of the Hermitian mirror (-ky, -kx) + 1) << 16, 0 = not counted
-static int fast_build_tcodes(xrfthip_plan* P, const int32_t* bm) {
-    const int ny = (int)P->d.ny, nx = (int)P->d.nx, nt = ny / 16, r3 = ny / 256, gy = fast_cols_gy(ny, true), tpu = gy / 4;
-    const int units = P->fast_ntile_pad / tpu;
-    const long long w = P->nx_out;
-    auto code = [&](int ky, int kx) -> uint32_t {
-        uint32_t v = 0;
-        if (kx <= nx / 2) {
-            const int32_t cd = bm[(size_t)ky * w + kx];
-            if (cd >= 0) v |= (uint32_t)(cd + 1);
-            if (kx > 0 && kx < nx - kx) {
-                const int32_t cm = bm[(size_t)(ky == 0 ? 0 : ny - ky) * w + (nx - kx)];
-                if (cm >= 0) v |= (uint32_t)(cm + 1) << 16;
-            }
-        }
-        return v;
-    };
-    std::vector<uint32_t> t((size_t)units * 16 * gy * nt);
-    if (P->d.out_mode == XRFTHIP_OUT_CROSS) {  // the cross pass bins in its store loop: [unit][item = tile * ny + ky][column of the tile]
-        for (int un = 0; un < units; ++un)
-            for (int wt = 0; wt < tpu; ++wt)
-                for (int ky = 0; ky < ny; ++ky)
-                    for (int c = 0; c < 4; ++c) t[(((size_t)un * tpu + wt) * ny + ky) * 4 + c] = code(ky, 4 * (un * tpu + wt) + c);
-    } else {
-        for (int un = 0; un < units; ++un)
-            for (int sl = 0; sl < 16; ++sl) {
-                const int b = sl / r3, k3 = sl % r3;
-                for (int g = 0; g < gy; ++g)
-                    for (int u = 0; u < nt; ++u) {
-                        const int pr = u + nt * b, ky = (pr >> 4) + 16 * (pr & 15) + 256 * k3;
-                        t[(((size_t)un * 16 + sl) * gy + g) * nt + u] = code(ky, 4 * un * tpu + g);
-                    }
-            }
-    }
-    return P->tcodes.upload(t.data(), t.size() * sizeof(uint32_t));
-}
-
 int xrfthip_plan_set_binmap(xrfthip_plan* plan, const int32_t* h_binmap, int64_t ny, int64_t nx_out, int32_t nbins) {
     if (!plan || !h_binmap || !(plan->d.flags & XRFTHIP_ISO)) return XRFTHIP_BAD_ARG;
     if (ny != plan->d.ny || nx_out != plan->nx_out || nbins < 1 || nbins > 4096) return XRFTHIP_BAD_ARG;
@@ -1593,8 +1389,6 @@ int xrfthip_plan_set_binmap(xrfthip_plan* plan, const int32_t* h_binmap, int64_t
             if (nbins > 65534 || hist_bytes + (size_t)nbins * 4 + 64 > yrows_geom(plan->d.nx).lds) plan->fast4096 = false;  // (the tables alias the transforms' LDS)
             else rcf = fasty_build_tcodes(plan, h_binmap);
         }
-        else if (nbins > 65534 || fast_cols_lds(plan->d.ny, true) + hist_bytes > kLdsMax) plan->fast4096 = false;  // the histogram sits behind the column pass's FFT buffers
-        else rcf = fast_build_tcodes(plan, h_binmap);
         if (rcf) return rcf;
     }
     plan->passes.clear();
@@ -1651,11 +1445,6 @@ int xrfthip_plan_describe(const xrfthip_plan* plan, char* buf, size_t buflen) {
         appendf(s, "  [fasty] cols: %d thr, %d x 2 packed column pairs (FFT%lld r16x16x%lld, column-local detrend fused), %d columns/unit, lds=%zuB -> W2[slab][%d/%d][nx/%d][2][%d][%d] -> rows: %d thr, %d rows/unit (FFT%lld r16x16x%lld), lds=%zuB, |F|^2 + fftshift + mirror rows\n",
                 C.thr, C.gxy, (long long)plan->d.ny, (long long)plan->d.ny / 256, C.cw, C.lds, plan->y_nrow_pad, C.rk, C.cw, C.rk, 2 * C.gxy,
                 R.thr, R.rk, (long long)plan->d.nx, (long long)plan->d.nx / 256, R.lds);
-    } else if (fast_on(plan)) {
-        const long long nx = plan->d.nx, ny = plan->d.ny;
-        appendf(s, "  [fastp2] rows: %d thr (row-local detrend fused), %dx(2 real rows -> 1 complex FFT%lld r16x16x%lld), lds=%zuB, tiled W[slab][%d][%lld][4] -> cols: %lld columns/unit (FFT%lld r16x16x%lld), lds=%zuB, persistent, line-tiled |F|^2 -> untile+shift+mirror: 256 thr, 8 rows\n",
-                fast_rows_threads(nx), fast_rows_threads(nx) / (int)(nx / 16), nx, nx / 256, fast_rows_lds(nx), plan->fast_ntile_pad, ny,
-                (long long)fast_cols_gy(ny, (plan->d.flags & XRFTHIP_ISO) != 0), ny, ny / 256, fast_cols_lds(ny, (plan->d.flags & XRFTHIP_ISO) != 0));
     }
     describe_passes(s, plan->passes_f0, "f0");
     describe_passes(s, plan->passes, "main");
@@ -1687,9 +1476,6 @@ int xrfthip_exec(const xrfthip_plan* plan, const void* d_in0, const void* d_in1,
     if (iso) HIP_TRY(hipMemsetAsync(d_iso, 0, (size_t)d.batch * P->nbins * (cross ? 16 : 8), st));
     if (fasty_on(P)) {
         return run_fasty(P, (const float*)d_in0, (const float*)d_in1, out, (double*)d_iso, ws, st);
-    }
-    if (fast_on(P)) {
-        return run_fast4096(P, (const float*)d_in0, (const float*)d_in1, out, (double*)d_iso, ws, st);
     }
     for (long long g0 = 0; g0 < d.batch; g0 += P->G) {
         const long long gc = std::min<long long>(P->G, d.batch - g0);
