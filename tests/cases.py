@@ -508,3 +508,48 @@ def run_fourstep_1d(n=65536, nt=3):
     worst = max(worst, check(xa.power_spectrum(da, dim=["x"], window="hann"), o.power_spectrum(od, dim=["x"], window="hann"), 3e-6))
     assert "four-step]" not in next(reversed(xa.api._plan_cache.values())).describe()  # (a window: the generic four-step passes)
     return worst
+
+
+def run_fastm_cases(shape=(2, 360, 360), full=True, cross=True):
+    """float64 slabs on the regular lat/lon lengths (360 / 720 / 1440; BASELINE.json configs[4] is (64, 1440, 720) with a linear
+    detrend and a Hann window): the mixed-radix y-first kernels (csrc/fastm.h) against the oracle -- power spectra with every
+    detrend / window / shift combination, the complex spectrum with true phase on offset coordinates, cross spectrum, cross phase."""
+    rng = np.random.default_rng(41)
+    tol = TOL["float64"]
+    a = _cube(rng, shape, "float64")
+    c1 = _coords3(shape, y0=1.0, x0=-3.0)
+    da, od = pair(a, D3, c1)
+    worst = 0.0
+
+    def on_fastm():
+        return "[fastm]" in next(reversed(xa.api._plan_cache.values())).describe()
+
+    worst = max(worst, check(xa.power_spectrum(da, dim=["y", "x"], detrend="linear", window="hann"),
+                             o.power_spectrum(od, dim=["y", "x"], detrend="linear", window="hann"), tol))
+    assert on_fastm()
+    if not full:
+        return worst
+    for kw in (dict(), dict(detrend="constant", window="hamming", scaling="spectrum", window_correction=True), dict(detrend="linear"),
+               dict(shift=False, window="bartlett", density=False)):
+        worst = max(worst, check(xa.power_spectrum(da, dim=["y", "x"], **kw), o.power_spectrum(od, dim=["y", "x"], **kw), tol))
+        assert on_fastm()
+    for kw in (dict(), dict(shift=False, true_phase=False, true_amplitude=False), dict(detrend="linear", window="hann")):
+        worst = max(worst, check(xa.fft(da, dim=["y", "x"], **kw), o.fft(od, dim=["y", "x"], **kw), tol))
+        assert on_fastm()
+    if not cross:  # (1440 x 1440: one row pair per workgroup leaves no room for the second field -- the generic kernels take it)
+        return worst
+    b = _cube(rng, shape, "float64")
+    db, ob = pair(b, D3, _coords3(shape, y0=-2.5, x0=4.0))
+    for kw in (dict(window="hann", detrend="linear"), dict(true_phase=False, scaling="spectrum", shift=False)):
+        worst = max(worst, check(xa.cross_spectrum(da, db, dim=["y", "x"], **kw), o.cross_spectrum(od, ob, dim=["y", "x"], **kw), tol))
+        assert on_fastm()
+    g = xa.cross_phase(da, db, dim=["y", "x"], detrend="constant")
+    r = o.cross_phase(od, ob, dim=["y", "x"], detrend="constant")
+    dphi = np.abs(np.angle(np.exp(1j * (g.values - r.values))))
+    mag = np.abs(o.cross_spectrum(od, ob, dim=["y", "x"], detrend="constant").values)
+    # (the angle of a near-zero cross spectrum amplifies rounding -- the detrended mean bin is pure rounding, its angle 0 or pi:
+    # the error is held relative to the sample's magnitude, and absolutely wherever the sample is not tiny)
+    big = mag > 1e-6 * mag.max()
+    assert (dphi * mag).max() / mag.max() < 1e-10 and dphi[big].max() < 1e-6, ((dphi * mag).max() / mag.max(), dphi[big].max())
+    assert on_fastm()
+    return worst

@@ -395,3 +395,9 @@ def test_fftmod_backend_object():
 @pytest.mark.parametrize("n", [65536, 262144])
 def test_fourstep_1d_fast_path(n):
     cases.run_fourstep_1d(n, nt=2)
+
+
+@pytest.mark.parametrize("shape,full", [((2, 360, 360), True), ((1, 1440, 720), False), ((1, 720, 1440), False)])
+def test_fastm_float64_latlon_lengths(shape, full):
+    """The mixed-radix float64 y-first kernels (csrc/fastm.h; BASELINE.json configs[4] is (64, 1440, 720) float64)."""
+    cases.run_fastm_cases(shape, full)

@@ -711,6 +711,14 @@ def test_middle_and_first_axis_without_copies(dim, dtype):
     cases.check(ps, o.power_spectrum(o.OArr(v, ("t", "y", "x"), c), **kw), 2e-4 if dtype in ("float32", "complex64") else 1e-10)
 
 
+@pytest.mark.parametrize("shape,cross", [((3, 1440, 720), True), ((2, 720, 1440), True), ((3, 360, 360), True), ((2, 1440, 1440), False),
+                                         ((3, 720, 360), True), ((2, 360, 1440), True)])
+def test_fastm_float64_latlon_lengths(shape, cross):
+    """The mixed-radix float64 y-first kernels (csrc/fastm.h) against the oracle: power spectra (every detrend), fft with true
+    phase, cross spectrum, cross phase."""
+    cases.run_fastm_cases(shape, True, cross)
+
+
 @pytest.mark.parametrize("n", [65536, 131072, 1048576])
 def test_fourstep_1d_fast_path(n):
     cases.run_fourstep_1d(n, nt=3)

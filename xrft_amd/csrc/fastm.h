@@ -1,0 +1,387 @@
+// fastm.h -- the two-pass "y first" pipeline (fasty.h) for slabs whose two lengths are products of three small radices
+// (2^a 3^b 5^c: 360, 720, 1440, ... -- the regular lat/lon grids) and for float64: BASELINE.json configs[4] is
+// power_spectrum of (64, 1440, 720) float64 slabs with a linear detrend and a Hann window.
+//     pass 1  fastm_cols_kernel   FFT along y of the real columns (window fused), half spectra ky = 0..ny/2, exact column sums
+//     [fit]   fastm_fit_kernel    plane from the per-column sums (xrft/detrend.py:100-113)
+//     pass 2  fastm_rows_kernel   trend added back in the spectral domain, FFT along x of rows ky = 0..ny/2, result rows ky AND -ky
+// (xrft.power_spectrum / fft / cross_spectrum / cross_phase, reference xrft/xrft.py:307-476, 685-874.)
+//
+// Same plan as fasty.h -- the last pass owns whole result rows, fftshift is a rotation, the Hermitian mirror a reversed read
+// of a row that is in LDS, detrending costs no pass over the data -- but the transforms are not register-resident: a
+// workgroup stages G sequences in LDS with wide coalesced loads (every load of a thread in flight before the first LDS
+// store), runs three in-place decimation-in-frequency passes with compile-time radices R0 x R1 x R2 (one butterfly per
+// thread and pass: no loops, no index tables), the last of which leaves the spectrum in natural order, and streams the
+// result out of LDS.  The generic tile kernel (tile_fft.h) does the same with run-time geometry; at (1440, 720) float64 it
+// ran 2.5x above the memory floor of both passes with its waves parked half of the time (profiles/r02_pmc_generic_c5_summary.txt).
+//
+// Intermediate W2 (complex T): [slab][ky / RK][x / CW][ky % RK][CW], CW = 2 G columns of one pass-1 workgroup, RK rows per
+// 128-byte line; pass 1 writes whole lines, pass 2 reads RPU (a multiple of RK) consecutive ky = one contiguous block.
+#pragma once
+#include "aux_kernels.h"
+#include "tile_fft.h"
+
+namespace xrft {
+
+template <int N> struct MRad { static constexpr int R0 = 0, R1 = 0, R2 = 0; };
+#define XRFT_MRAD(NN, A, B, C) \
+    template <> struct MRad<NN> { static constexpr int R0 = A, R1 = B, R2 = C; static_assert(A * B * C == NN, "radices"); }
+XRFT_MRAD(360, 6, 6, 10);
+XRFT_MRAD(720, 8, 9, 10);
+XRFT_MRAD(1440, 10, 12, 12);
+#undef XRFT_MRAD
+
+constexpr int mr_max3(int a, int b, int c) { return a > b ? (a > c ? a : c) : (b > c ? b : c); }
+
+// LDS geometry of one N-point sequence.  Positions during the passes: pd(i) = i + i / PDQ (the last pass reads runs of R2
+// with a lane stride of R2: padded to an odd stride), natural-order result: pn(k) = k + k / PNQ (the last pass writes with a
+// lane stride of R0).  STR = 4 (mod 8) elements: the two rows / two sequences that eight lanes touch land on disjoint banks.
+template <typename T, int N> struct MGeom {
+    typedef MRad<N> R;
+    static_assert(R::R0 > 0, "length not in the table");
+    static constexpr int R0 = R::R0, R1 = R::R1, R2 = R::R2;
+    static constexpr int M0 = N / R0;                  // = R1 R2
+    static constexpr int B0 = N / R0, B1 = N / R1, B2 = N / R2;  // butterflies per sequence and pass
+    static constexpr int BMAX = mr_max3(B0, B1, B2);
+    static constexpr int PDQ = (R2 % 2 == 0) ? R2 : (1 << 30);
+    static constexpr int PNQ = (R0 % 2 == 0) ? R0 : (1 << 30);
+    static constexpr int PQ = PDQ < PNQ ? PDQ : PNQ;
+    static constexpr int STR = ((N + N / PQ + 3) / 8) * 8 + 4;  // the smallest s >= N + N / PQ with s = 4 (mod 8)
+    static constexpr size_t CS = 2 * sizeof(T);
+    // sequences per workgroup: as many (a power of two, <= 8) as keep three workgroups on a CU
+    static constexpr int G = (size_t)8 * STR * CS <= 52 * 1024 ? 8 : (size_t)4 * STR * CS <= 52 * 1024 ? 4 : (size_t)2 * STR * CS <= 52 * 1024 ? 2 : 1;
+    static constexpr int THR = ((G * BMAX + 63) / 64) * 64;
+    static constexpr size_t LDS_ROWS = ((size_t)G * STR + M0) * CS;                                    // sequences + pass-1 twiddles
+    static constexpr size_t LDS = LDS_ROWS + (size_t)(THR / 64) * G * 4 * sizeof(double);              // + pass 1's partial column sums
+    static constexpr int WGS = (int)((160 * 1024) / LDS) < 1 ? 1 : (int)((160 * 1024) / LDS);
+    static constexpr int WPS = (WGS * (THR / 64) + 3) / 4 > 8 ? 8 : (WGS * (THR / 64) + 3) / 4;  // waves per SIMD the launch bounds ask for
+    __device__ static __forceinline__ int pd(int i) { return i + i / PDQ; }
+    __device__ static __forceinline__ int pn(int k) { return k + k / PNQ; }
+};
+
+struct FastM {
+    const void* in;      // [slab][ny][nx] real T
+    void* w2;            // intermediate (see above)
+    const void* w2b;     // cross spectra: field 1's intermediate (pass 2 only)
+    void* out;           // [slab][ny][nx]: T (power, phase) or complex T
+    const void* tw_x;    // W_nx^k, k < nx  (complex T)
+    const void* tw_y;
+    const void* win_y;   // T, never null
+    const void* win_x;
+    double* colfit;      // [slab][nx][4]: sum d, sum (i - ibar) d, and the line pass 1 subtracted (0, 0 here)
+    const void* corr;    // [slab][nx] complex T: wx[x] * (subtracted line - plane fit) as (offset at ibar, slope)
+    const void* corr_b;  // ... of field 1
+    const void* ph_y;    // complex modes: combined phase factors per unshifted frequency (complex T), never null
+    const void* ph_x;
+    const void* what0;   // FFT_y(wy)[ky], ky < nrow_pad (complex T)
+    const void* what1;   // FFT_y(wy (i - ibar))[ky]
+    int ph_on;
+    int ny, nx, nrow_pad;
+    int l_cw, l_rk;      // log2 of CW and RK
+    int detrend, nslab, nunits;
+    int shift_y, shift_x;
+    double scale;
+};
+
+// 16-byte store that bypasses the caches' retention (the next reader is another kernel, a whole group of slabs later)
+template <typename T> __device__ __forceinline__ void mr_store16_nt(void* dst, const void* src16) {
+#ifdef XRFT_EMULATE
+    memcpy(dst, src16, 16);
+#else
+    typedef float v4f __attribute__((ext_vector_type(4)));
+    __builtin_nontemporal_store(*reinterpret_cast<const v4f*>(src16), reinterpret_cast<v4f*>(dst));
+#endif
+}
+
+// First pass of sequence t, butterfly j, on operands the thread already holds (a[q] = x[j + q M0], straight from global
+// memory: the sequences are never staged): y_k[j] W_N^(j k) goes to k M0 + j.  w0 = W_N^j (loaded by the caller long before).
+template <typename T, int N>
+__device__ __forceinline__ void mr_pass0(C2<T>* a, C2<T>* s, int j, C2<T> w0) {
+    typedef MGeom<T, N> M;
+    dft_r<T, M::R0>(a);
+    C2<T> w = w0;
+#pragma unroll
+    for (int k = 1; k < M::R0; ++k) {
+        a[k] = cmul(a[k], w);
+        if (k + 1 < M::R0) w = cmul(w, w0);
+    }
+#pragma unroll
+    for (int k = 0; k < M::R0; ++k) s[M::pd(j + k * M::M0)] = a[k];
+}
+
+// The other two passes over the G sequences of a workgroup (sequence t at lds + t STR, positions pd(i); the result is left in
+// natural order at pn(k)).  tw1[j R1 + k] = W_(N/R0)^(j k).  Starts and ends with a barrier.
+template <typename T, int N, int G, int THR>
+__device__ __forceinline__ void mr_fft_tail(C2<T>* lds, int tid, const C2<T>* tw1) {
+    typedef MGeom<T, N> M;
+    constexpr int R0 = M::R0, R1 = M::R1, R2 = M::R2, M0 = M::M0, STR = M::STR;
+    __syncthreads();
+    if (tid < G * M::B1) {  // pass 1: blocks of M0 = R1 R2, butterflies over stride R2
+        const int t = tid / M::B1, gg = tid % M::B1, blk = gg / R2, j = gg % R2, base = blk * M0 + j;
+        C2<T>* s = lds + t * STR;
+        C2<T> a[R1];
+#pragma unroll
+        for (int q = 0; q < R1; ++q) a[q] = s[M::pd(base + q * R2)];
+        dft_r<T, R1>(a);
+#pragma unroll
+        for (int k = 1; k < R1; ++k) a[k] = cmul(a[k], tw1[j * R1 + k]);
+#pragma unroll
+        for (int k = 0; k < R1; ++k) s[M::pd(base + k * R2)] = a[k];
+    }
+    __syncthreads();
+    {   // pass 2: runs of R2; frequency k0 + R0 (k1 + R1 k2) of run k0 R1 + k1 goes to its natural slot (after everyone has read)
+        const bool on = tid < G * M::B2;
+        const int t = tid / M::B2, blk = tid % M::B2, k0 = blk / R1, k1 = blk % R1;
+        C2<T>* s = lds + (on ? t : 0) * STR;
+        C2<T> a[R2];
+        if (on) {
+#pragma unroll
+            for (int q = 0; q < R2; ++q) a[q] = s[M::pd(blk * R2 + q)];
+        }
+        __syncthreads();
+        if (on) {
+            dft_r<T, R2>(a);
+#pragma unroll
+            for (int k2 = 0; k2 < R2; ++k2) s[M::pn(k0 + R0 * (k1 + R1 * k2))] = a[k2];
+        }
+    }
+    __syncthreads();
+}
+
+template <typename T, int N> __device__ __forceinline__ void mr_fill_tw1(C2<T>* tw1, const C2<T>* __restrict__ tw, int tid, int nthreads) {
+    typedef MGeom<T, N> M;
+    for (int e = tid; e < M::M0; e += nthreads) {
+        const int j = e / M::R1, k = e % M::R1;
+        tw1[e] = tw[M::R0 * j * k];  // W_(N/R0)^(j k) = W_N^(R0 j k), j k < M0
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// pass 1: a workgroup owns CW = 2 G adjacent real columns of one slab (lane order (row, g), g fastest: the lanes of a row read
+// 16 G contiguous bytes); columns 2g, 2g+1 are the real and imaginary part of sequence g.     window: xrft.py:96-103, 430-433
+// Detrending (xrft/detrend.py:100-113): the plane needs sums over the whole slab, which exist only after this pass, so the
+// pass transforms the raw windowed data, produces the exact per-column sums (sum d, sum (i - ibar) d) on the side -- float64
+// per thread, wave shuffles, one small LDS table summed after the transforms -- and pass 2 subtracts the plane in the spectral
+// domain: wx[x] (alpha_x What0[ky] + gamma_x What1[ky]).  In float64 nothing cancels visibly (trend / signal of 10^4 costs 13 of
+// 53 bits; the tests hold 1e-10).
+// ------------------------------------------------------------------------------------------------
+template <typename T, int NY, bool DET>
+__global__ void __launch_bounds__((MGeom<T, NY>::THR), (MGeom<T, NY>::WPS)) fastm_cols_kernel(FastM p) {
+    typedef MGeom<T, NY> M;
+    typedef C2<T> CT;
+    constexpr int G = M::G, THR = M::THR, STR = M::STR, CW = 2 * G;
+    static_assert(sizeof(T) == 8, "float64 (the float32 variant packs four columns per load: fasty.h)");
+    static_assert(THR >= G * M::B0 && THR % G == 0, "one first-pass butterfly per thread");
+    XRFT_DYN_SMEM(smem_raw);
+    CT* lds = reinterpret_cast<CT*>(smem_raw);
+    CT* tw1 = lds + G * STR;
+    double* part = reinterpret_cast<double*>(tw1 + M::M0);  // [wave][g][4]
+    const int tid = threadIdx.x, g = tid % G, r0 = tid / G;
+    // unit = (slab, column block).  Workgroups b, b + 8, ... run on one XCD: every XCD gets a contiguous range of units, so
+    // that the workgroups that share the 128-byte lines of the input rows share an L2 (fasty.h; 45.9 vs 27.8 us measured there)
+    const int per = (p.nunits + 7) >> 3, xcd = blockIdx.x & 7, jb = blockIdx.x >> 3;
+    const int unit = xcd * per + jb;
+    if (jb >= per || unit >= p.nunits) return;
+    const int nxb = p.nx / CW, slab = unit / nxb, xb = unit % nxb;
+    mr_fill_tw1<T, NY>(tw1, reinterpret_cast<const CT*>(p.tw_y), tid, THR);
+    // first pass from registers: thread (g, j = r0) loads rows j + q M0, q < R0, of its sequence (lanes (j, g), g fastest: the
+    // lanes of a row read 16 G contiguous bytes) -- all of them in flight at once, none staged in LDS
+    constexpr int R0 = M::R0, M0 = M::M0;
+    const bool on = r0 < M::B0;
+    const int j = on ? r0 : 0;
+    const CT w0 = reinterpret_cast<const CT*>(p.tw_y)[j];
+    const char* __restrict__ src = reinterpret_cast<const char*>(reinterpret_cast<const T*>(p.in) + (size_t)slab * NY * p.nx + (size_t)xb * CW);
+    const unsigned rowb = (unsigned)p.nx * (unsigned)sizeof(T), off0 = (unsigned)j * rowb + (unsigned)g * 16u, rstep = (unsigned)M0 * rowb;
+    const T* __restrict__ wy = reinterpret_cast<const T*>(p.win_y);
+    const CT wx = *reinterpret_cast<const CT*>(reinterpret_cast<const T*>(p.win_x) + xb * CW + 2 * g);
+    CT a[R0];
+    T wyv[R0];
+#pragma unroll
+    for (int q = 0; q < R0; ++q) {
+        a[q] = mk<T>((T)0, (T)0); wyv[q] = (T)0;
+        if (on) {
+            a[q] = *reinterpret_cast<const CT*>(src + (off0 + rstep * (unsigned)q));
+            wyv[q] = wy[j + q * M0];
+        }
+    }
+    constexpr double IBAR = 0.5 * (NY - 1);
+    if (DET) {
+        double s[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int q = 0; q < R0; ++q) {
+            const double ri = (double)(j + q * M0) - IBAR;
+            s[0] += (double)a[q].re; s[1] += (double)a[q].im;
+            s[2] = fma(ri, (double)a[q].re, s[2]); s[3] = fma(ri, (double)a[q].im, s[3]);
+        }
+#pragma unroll
+        for (int m = G; m < 64; m <<= 1)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) s[c] += __shfl_xor(s[c], m);
+        if ((tid & 63) < G) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) part[((tid >> 6) * G + g) * 4 + c] = s[c];
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < R0; ++q) a[q] = mk<T>(a[q].re * (wyv[q] * wx.re), a[q].im * (wyv[q] * wx.im));
+    if (on) mr_pass0<T, NY>(a, lds + g * STR, j, w0);
+    mr_fft_tail<T, NY, G, THR>(lds, tid, tw1);
+    if (DET && tid < 4 * G) {  // (sum d, sum (i - ibar) d, 0, 0) per column
+        const int c = tid / G, gg = tid % G;  // c: 0, 1 = sum d of columns 2gg, 2gg+1; 2, 3 = the first moments
+        double acc = 0.0;
+#pragma unroll
+        for (int w = 0; w < THR / 64; ++w) acc += part[(w * G + gg) * 4 + c];
+        double* cfp = p.colfit + ((size_t)slab * p.nx + xb * CW + 2 * gg + (c & 1)) * 4;
+        cfp[c >> 1] = acc;
+        cfp[2 + (c >> 1)] = 0.0;
+    }
+    // split the packed spectra: Ra[k] = (Z[k] + conj Z[N-k]) / 2, Rb[k] = (Z[k] - conj Z[N-k]) / (2i); (Ra, Rb) = two adjacent
+    // columns = 32 bytes; lanes (ky, g), g fastest: 128 / (32 G) consecutive ky complete a line
+    const int rk = 1 << p.l_rk;
+    char* __restrict__ w2s = reinterpret_cast<char*>(reinterpret_cast<CT*>(p.w2) + (size_t)slab * p.nrow_pad * p.nx);
+    constexpr int NST = (G * (NY / 2 + 1) + THR - 1) / THR;
+#pragma unroll
+    for (int i = 0; i < NST; ++i) {
+        const int k = r0 + i * (THR / G);
+        if (k <= NY / 2) {
+            const CT* z = lds + g * STR;
+            const CT zk = z[M::pn(k)], zc = cconj(z[M::pn(k == 0 ? 0 : NY - k)]);
+            CT o[2];
+            o[0] = cscale(zk + zc, (T)0.5);
+            o[1] = cscale(mul_mi(zk - zc), (T)0.5);
+            const unsigned off = ((((unsigned)(k >> p.l_rk) * (unsigned)nxb + (unsigned)xb) << p.l_rk) + (unsigned)(k & (rk - 1))) * (unsigned)CW + 2u * (unsigned)g;
+            mr_store16_nt<T>(w2s + (size_t)off * sizeof(CT), &o[0]);
+            mr_store16_nt<T>(w2s + (size_t)off * sizeof(CT) + 16, &o[1]);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// pass 2: a workgroup owns RPU consecutive rows ky0.. of W2 (one contiguous block), adds the plane back, transforms along x and
+// writes every row twice: as output row ky (rotated by the fftshift) and, reversed, as row -ky (Hermitian mirror of the
+// spectrum of a real field).  MODE = xrfthip_out_mode: 1 power, 0 complex (fft), 2 cross / 3 cross phase (the first G/2
+// sequences are rows of field 0, the others the same rows of field 1: F0 conj(F1) is formed on the way out).
+//   xrft.py:446-447 (fftshift), :462-469 (true phase), :740-748 / :825-833 (|F|^2, F0 conj F1 and the scalings, in `scale`)
+// ------------------------------------------------------------------------------------------------
+template <typename T, int NX, int MODE>
+__global__ void __launch_bounds__((MGeom<T, NX>::THR), (MGeom<T, NX>::WPS)) fastm_rows_kernel(FastM p) {
+    typedef MGeom<T, NX> M;
+    typedef C2<T> CT;
+    constexpr bool TWO = MODE >= 2;
+    constexpr int G = M::G, THR = M::THR, STR = M::STR, RPU = TWO ? G / 2 : G;
+    static_assert(sizeof(T) == 8, "float64");
+    static_assert(!TWO || G >= 2, "two fields need two sequences");
+    XRFT_DYN_SMEM(smem_raw);
+    CT* lds = reinterpret_cast<CT*>(smem_raw);
+    CT* tw1 = lds + G * STR;
+    const int tid = threadIdx.x;
+    const int upr = p.nrow_pad / RPU, slab = blockIdx.x / upr, unit = blockIdx.x % upr, ky0 = unit * RPU, nyh = p.ny >> 1;
+    mr_fill_tw1<T, NX>(tw1, reinterpret_cast<const CT*>(p.tw_x), tid, THR);
+    // first pass from registers: thread (sequence t, j) loads x = j + q M0, q < R0, of its row.  Lane order (row pair, j, row in
+    // the pair): the RK rows that share the lines of W2 sit in adjacent lanes, so a wave consumes whole lines.
+    constexpr int R0 = M::R0, M0 = M::M0;
+    const int rk = 1 << p.l_rk, cwm = (1 << p.l_cw) - 1;
+    const int pairi = (tid >> p.l_rk) / M::B0, j = (tid >> p.l_rk) % M::B0, t = (pairi << p.l_rk) + (tid & (rk - 1));
+    const bool on = t < G;
+    const int f = TWO && t >= RPU ? 1 : 0, row = t - f * RPU;  // (two fields: sequences RPU.. are the same rows of field 1)
+    const int ky = ky0 + row, kyc = min(ky, nyh);
+    const CT w0 = reinterpret_cast<const CT*>(p.tw_x)[j];
+    const CT* __restrict__ blk = reinterpret_cast<const CT*>(f ? p.w2b : p.w2) + ((size_t)slab * p.nrow_pad + (size_t)((ky >> p.l_rk) << p.l_rk)) * NX;
+    const CT* __restrict__ cr = reinterpret_cast<const CT*>(f ? p.corr_b : p.corr) + (size_t)slab * NX;
+    const bool addback = p.detrend != 0;
+    const bool live = on && ky <= nyh;  // (padding rows of the last unit were never written by pass 1: they stay zero)
+    CT a[R0], c[R0];
+    CT h0 = mk<T>((T)0, (T)0), h1 = h0;
+    if (addback && live) { h0 = reinterpret_cast<const CT*>(p.what0)[kyc]; h1 = reinterpret_cast<const CT*>(p.what1)[kyc]; }
+#pragma unroll
+    for (int q = 0; q < R0; ++q) {
+        a[q] = mk<T>((T)0, (T)0); c[q] = a[q];
+        if (live) {
+            const int x = j + q * M0;
+            // element (ky, x) of the block [x / CW][ky % RK][x % CW]
+            a[q] = blk[((((x >> p.l_cw) << p.l_rk) + (ky & (rk - 1))) << p.l_cw) + (x & cwm)];
+            if (addback) c[q] = cr[x];
+        }
+    }
+    if (addback) {  // + wx[x] (alpha_x What0[ky] + gamma_x What1[ky]): the plane, subtracted in the spectral domain
+#pragma unroll
+        for (int q = 0; q < R0; ++q) {
+            a[q].re = fma(c[q].re, h0.re, fma(c[q].im, h1.re, a[q].re));
+            a[q].im = fma(c[q].re, h0.im, fma(c[q].im, h1.im, a[q].im));
+        }
+    }
+    if (on) mr_pass0<T, NX>(a, lds + t * STR, j, w0);
+    mr_fft_tail<T, NX, G, THR>(lds, tid, tw1);
+    if (p.out == nullptr) return;
+    // ---- the result leaves as whole rows, 16 bytes per lane and store: VW samples
+    typedef typename std::conditional<MODE == 0 || MODE == 2, CT, T>::type OutT;
+    constexpr int VW = 16 / (int)sizeof(OutT), CPR = NX / VW;
+    static_assert(NX % VW == 0, "row length");
+    OutT* __restrict__ outs = reinterpret_cast<OutT*>(p.out) + (size_t)slab * p.ny * NX;
+    const int sx = p.shift_x, sy = p.shift_y;
+    const T sc = (T)p.scale;
+    for (int e = tid; e < RPU * 2 * CPR; e += THR) {
+        const int chunk = e % CPR, rr = e / CPR, r = rr >> 1, mir = rr & 1;
+        const int ky = ky0 + r;
+        if (ky > nyh || (mir && (ky == 0 || 2 * ky == p.ny))) continue;
+        const CT* rowA = lds + r * STR;
+        const CT* rowB = lds + (RPU + r) * STR;  // (TWO)
+        const int fy = mir ? p.ny - ky : ky;
+        int orow = fy + sy; if (orow >= p.ny) orow -= p.ny;
+        const int c = chunk * VW;
+        alignas(16) OutT o[VW];
+        CT py = mk<T>((T)1, (T)0);
+        if (MODE != 1 && p.ph_on) py = reinterpret_cast<const CT*>(p.ph_y)[fy];
+#pragma unroll
+        for (int i = 0; i < VW; ++i) {
+            int fx = c + i - sx; if (fx < 0) fx += NX;      // unshifted frequency of output column c + i
+            int kx = mir ? (fx == 0 ? 0 : NX - fx) : fx;    // F(-ky, fx) = conj F(ky, -fx)
+            CT va = rowA[M::pn(kx)];
+            if (MODE == 1) {
+                reinterpret_cast<T*>(o)[i] = (va.re * va.re + va.im * va.im) * sc;
+            } else {
+                if (TWO) va = cmulc(va, rowB[M::pn(kx)]);  // F0 conj(F1)
+                va = cscale(va, sc);
+                if (mir) va = cconj(va);
+                if (p.ph_on) va = cmul(va, cmul(py, reinterpret_cast<const CT*>(p.ph_x)[fx]));
+                if (MODE == 3) reinterpret_cast<T*>(o)[i] = (T)atan2((double)va.im, (double)va.re);
+                else reinterpret_cast<CT*>(o)[i] = va;
+            }
+        }
+        mr_store16_nt<T>(outs + (size_t)orow * NX + c, o);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// plane fit from the per-column sums (fasty_fit_kernel with the correction in the pipeline's own precision): one 256-thread
+// block per slab, float64, fixed summation order.  corr[x] = wx[x] * (line pass 1 subtracted - plane) as (offset at ibar, slope).
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void __launch_bounds__(256) fastm_fit_kernel(const double* colfit, const T* win_x, C2<T>* corr, int nx, int ny, int detrend) {
+    XRFT_DYN_SMEM(smem_raw);
+    double* red = reinterpret_cast<double*>(smem_raw);
+    const int slab = blockIdx.x, tid = threadIdx.x;
+    const double* cf4 = colfit + (size_t)slab * nx * 4;
+    const double xbar = 0.5 * (nx - 1), sxx = (double)nx * ((double)nx * nx - 1.0) / 12.0;
+    const double inv_n = 1.0 / ny, inv_sii = 12.0 / ((double)ny * ((double)ny * ny - 1.0));
+    double s[3] = {0.0, 0.0, 0.0};
+    for (int x = tid; x < nx; x += 256) {
+        const double m = cf4[4 * x] * inv_n, sl = cf4[4 * x + 1] * inv_sii;
+        s[0] += m;
+        s[1] += ((double)x - xbar) * m;
+        s[2] += sl;
+    }
+    block_sum<3>(s, red);
+    __syncthreads();
+    if (tid == 0) { red[0] = s[0]; red[1] = s[1]; red[2] = s[2]; }
+    __syncthreads();
+    const double a = red[0] / nx;
+    const double b = detrend == 2 ? red[1] / sxx : 0.0;
+    const double c = detrend == 2 ? red[2] / nx : 0.0;
+    C2<T>* out = corr + (size_t)slab * nx;
+    for (int x = tid; x < nx; x += 256) {
+        const double wx = (double)win_x[x];
+        out[x] = mk<T>((T)(wx * (cf4[4 * x + 2] - a - b * ((double)x - xbar))), (T)(wx * (cf4[4 * x + 3] - c)));
+    }
+}
+
+}  // namespace xrft

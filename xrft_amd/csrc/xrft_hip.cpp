@@ -22,6 +22,7 @@
 #include "aux_kernels.h"
 #include "fastp2.h"
 #include "fasty.h"
+#include "fastm.h"
 #include "tile_fft.h"
 
 using namespace xrft;
@@ -294,6 +295,8 @@ struct xrfthip_plan {
     // ... and, as the two steps of a four-step transform, one long real sequence per slab: N = yny * ynx samples viewed as
     // a [yny][ynx] slab (fasty.h, FS).  yny / ynx are d.ny / d.nx for the 2-D plans.
     bool fast1d = false;
+    // ... and its mixed-radix float64 form (fastm.h): lengths 360 / 720 / 1440
+    bool fastm = false;
     bool fph_on = false;  // some entry of the combined phase tables (fph) differs from 1
     long long yny = 0, ynx = 0;
     DevBuf tw_big1d;
@@ -839,7 +842,7 @@ static void layout_workspace(xrfthip_plan* P) {
     size_t slab_w = (size_t)d.ny * std::max(P->width, P->w_cols) * P->csize;
     const bool yf = fast && P->yfirst;
     if (fast) {
-        slab_w = (size_t)P->y_nrow_pad * P->ynx * sizeof(cf);
+        slab_w = (size_t)P->y_nrow_pad * P->ynx * (P->fastm ? P->csize : sizeof(cf));
         if (G <= 0) G = P->tune_fast_group > 0 ? P->tune_fast_group : std::max<long long>(1, (32LL * 4096 * 4096) / (d.ny * d.nx));  // measured 8: 197, 16: 210, 32: 214 GFFT/s (tails and launch gaps amortise)
     }
     if (G <= 0) {
@@ -863,7 +866,7 @@ static void layout_workspace(xrfthip_plan* P) {
     P->off_f0 = off; if (nf == 2 && !fast) off = al(off + (size_t)G * slab_w);
     const size_t nfit = (size_t)(yf ? 2 * P->ynx : d.ny);  // per-column sums + subtracted lines
     P->off_rowfit = off; if (fast) off = al(off + (size_t)G * nfit * 2 * sizeof(double) * (yf ? nf : 1));
-    P->off_corr = off; if (fast) off = al(off + (size_t)G * nfit * 2 * sizeof(float) * (yf ? nf : 1));
+    P->off_corr = off; if (fast) off = al(off + (size_t)G * nfit * 2 * sizeof(float) * (yf ? nf : 1));  // (16 bytes per column: fasty uses 8, fastm's float64 pairs all 16)
     P->off_isopart = off;
     if (yf && (d.flags & XRFTHIP_ISO)) {  // per-workgroup partial radial sums of one group of slabs (reduced in order)
         const bool two = d.out_mode == XRFTHIP_OUT_CROSS;
@@ -936,14 +939,16 @@ static int fast_phase_tables(xrfthip_plan* P) {
         const long long n = ax == 0 ? d.ny : d.nx;
         const bool sign = d.out_mode == XRFTHIP_OUT_COMPLEX && (d.flags & (ax == 0 ? XRFTHIP_ISHIFT_Y : XRFTHIP_ISHIFT_X));
         std::vector<cf> t((size_t)n);
+        std::vector<C2<double>> td(P->fastm ? (size_t)n : 0);
         for (long long k = 0; k < n; ++k) {
             double re = 1.0, im = 0.0;
             if (!P->host_phase[ax].empty()) { re = P->host_phase[ax][(size_t)(2 * k)]; im = P->host_phase[ax][(size_t)(2 * k + 1)]; }
             if (sign && (k & 1)) { re = -re; im = -im; }
             t[(size_t)k].re = (float)re; t[(size_t)k].im = (float)im;
-            if (t[(size_t)k].re != 1.0f || t[(size_t)k].im != 0.0f) P->fph_on = true;
+            if (P->fastm) { td[(size_t)k].re = re; td[(size_t)k].im = im; }
+            if (P->fastm ? (re != 1.0 || im != 0.0) : (t[(size_t)k].re != 1.0f || t[(size_t)k].im != 0.0f)) P->fph_on = true;
         }
-        int rc = P->fph[ax].upload(t.data(), t.size() * sizeof(cf));
+        int rc = P->fastm ? P->fph[ax].upload(td.data(), td.size() * sizeof(C2<double>)) : P->fph[ax].upload(t.data(), t.size() * sizeof(cf));
         if (rc) return rc;
     }
     return XRFTHIP_OK;
@@ -959,6 +964,7 @@ static bool phase_nontrivial(const xrfthip_plan* P) {
 // the specialised path is taken unless an isotropic cross spectrum carries a true-phase factor that is not 1 (two
 // fields with different lags): its radial sums would need the factor per sample inside the column pass
 static bool fast_on(const xrfthip_plan* P) {
+    if (P->fastm) return true;
     if (P->fast1d) return P->win[1].p == nullptr;  // the four-step form has no place for a (non-separable) window
     if (!P->fast4096) return false;
     if (P->d.out_mode == XRFTHIP_OUT_CROSS && (P->d.flags & XRFTHIP_ISO) && phase_nontrivial(P)) return false;
@@ -996,9 +1002,33 @@ static int fasty_window_spectra(xrfthip_plan* P) {
         r0[(size_t)i] = w;
         r1[(size_t)i] = w * ((double)i - 0.5 * (ny - 1));
     }
-    host_fft_pow2(r0, i0);
-    host_fft_pow2(r1, i1);
+    if ((ny & (ny - 1)) == 0) { host_fft_pow2(r0, i0); host_fft_pow2(r1, i1); }
+    else {  // a direct O(n^2) transform with exact twiddle indices (n <= 1440, once per plan)
+        std::vector<long double> cw((size_t)ny), sw((size_t)ny);
+        for (int k = 0; k < ny; ++k) { const long double a = -2.0L * 3.14159265358979323846264338327950288L * (long double)k / (long double)ny; cw[(size_t)k] = cosl(a); sw[(size_t)k] = sinl(a); }
+        std::vector<double> o0r((size_t)ny), o0i((size_t)ny), o1r((size_t)ny), o1i((size_t)ny);
+        for (int k = 0; k <= nyh; ++k) {
+            long double a0 = 0, b0 = 0, a1 = 0, b1 = 0;
+            for (int i = 0; i < ny; ++i) {
+                const size_t m = (size_t)(((long long)i * k) % ny);
+                a0 += r0[(size_t)i] * cw[m]; b0 += r0[(size_t)i] * sw[m];
+                a1 += r1[(size_t)i] * cw[m]; b1 += r1[(size_t)i] * sw[m];
+            }
+            o0r[(size_t)k] = (double)a0; o0i[(size_t)k] = (double)b0; o1r[(size_t)k] = (double)a1; o1i[(size_t)k] = (double)b1;
+        }
+        r0 = o0r; i0 = o0i; r1 = o1r; i1 = o1i;
+    }
     const int nent = P->y_nrow_pad;
+    if (P->fastm) {
+        std::vector<C2<double>> d0((size_t)nent), d1((size_t)nent);
+        for (int k = 0; k < nent; ++k) {
+            d0[(size_t)k].re = k <= nyh ? r0[(size_t)k] : 0.0; d0[(size_t)k].im = k <= nyh ? i0[(size_t)k] : 0.0;
+            d1[(size_t)k].re = k <= nyh ? r1[(size_t)k] : 0.0; d1[(size_t)k].im = k <= nyh ? i1[(size_t)k] : 0.0;
+        }
+        int rcd = P->ywhat0.upload(d0.data(), d0.size() * sizeof(C2<double>));
+        if (!rcd) rcd = P->ywhat1.upload(d1.data(), d1.size() * sizeof(C2<double>));
+        return rcd;
+    }
     std::vector<cf> h0((size_t)nent), h1((size_t)nent);
     for (int k = 0; k < nent; ++k) {
         h0[(size_t)k].re = k <= nyh ? (float)r0[(size_t)k] : 0.f; h0[(size_t)k].im = k <= nyh ? (float)i0[(size_t)k] : 0.f;
@@ -1152,11 +1182,111 @@ static int run_fasty(const xrfthip_plan* P, const float* in, const float* in1, v
     return XRFTHIP_OK;
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// mixed-radix float64 form of the y-first pipeline (fastm.h)
+// ---------------------------------------------------------------------------------------------------------------
+struct MGeomRt { int thr, g; size_t lds_cols, lds_rows; int r0, r1, r2; };
+template <int N> static MGeomRt mgeom_t() {
+    typedef MGeom<double, N> M;
+    return {M::THR, M::G, M::LDS, M::LDS_ROWS, M::R0, M::R1, M::R2};
+}
+static bool fastm_len(long long n) { return n == 360 || n == 720 || n == 1440; }
+static MGeomRt mgeom(long long n) {
+    switch (n) { case 1440: return mgeom_t<1440>(); case 720: return mgeom_t<720>(); default: return mgeom_t<360>(); }
+}
+// layout of the intermediate: CW = 2 G columns of a pass-1 workgroup, RK rows per 128-byte line
+static int fastm_cw(long long ny) { return 2 * mgeom(ny).g; }
+static int fastm_rk(long long ny) { const int cw = fastm_cw(ny); return cw * 16 >= 128 ? 1 : 128 / (cw * 16); }
+static int fastm_rpu(long long nx, bool two) { const int g = mgeom(nx).g; return two ? g / 2 : g; }
+
+static FastM fastm_params(const xrfthip_plan* P, const void* in, void* out, char* ws, long long g0, long long gc, int slot, long long slot_slabs) {
+    const xrfthip_desc& d = P->d;
+    const size_t slab_pts = (size_t)P->yny * P->ynx, s0 = (size_t)slot * slot_slabs;
+    FastM p{};
+    p.in = (const char*)in + (size_t)g0 * slab_pts * sizeof(double);
+    p.w2 = reinterpret_cast<C2<double>*>(ws + P->off_w) + s0 * (size_t)P->y_nrow_pad * P->ynx;
+    const size_t out_esz = (d.out_mode == XRFTHIP_OUT_POWER || d.out_mode == XRFTHIP_OUT_PHASE) ? sizeof(double) : sizeof(C2<double>);
+    p.out = out ? (char*)out + (size_t)g0 * slab_pts * out_esz : nullptr;
+    p.tw_x = P->tw_fx.p; p.tw_y = P->tw_fy.p;
+    p.win_y = P->win[0].p ? P->win[0].p : P->ones4096.p;
+    p.win_x = P->win[1].p ? P->win[1].p : P->ones4096.p;
+    p.colfit = reinterpret_cast<double*>(ws + P->off_rowfit) + s0 * (size_t)P->ynx * 4;
+    p.corr = reinterpret_cast<const C2<double>*>(ws + P->off_corr) + s0 * (size_t)P->ynx;
+    p.ph_y = P->fph[0].p; p.ph_x = P->fph[1].p; p.ph_on = P->fph_on ? 1 : 0;
+    p.what0 = P->ywhat0.p; p.what1 = P->ywhat1.p;
+    p.ny = (int)P->yny; p.nx = (int)P->ynx; p.nrow_pad = P->y_nrow_pad;
+    p.l_cw = ilog2i(fastm_cw(P->yny)); p.l_rk = ilog2i(fastm_rk(P->yny));
+    p.detrend = d.detrend; p.nslab = (int)gc;
+    p.nunits = (int)(gc * (P->ynx / fastm_cw(P->yny)));
+    p.shift_y = (d.flags & XRFTHIP_SHIFT_Y) ? (int)(P->yny / 2) : 0;
+    p.shift_x = (d.flags & XRFTHIP_SHIFT_X) ? (int)(P->ynx / 2) : 0;
+    p.scale = d.scale;
+    return p;
+}
+
+static void fastm_launch_cols(const xrfthip_plan* P, const FastM& p, long long gc, hipStream_t st) {
+    const xrfthip_desc& d = P->d;
+    const MGeomRt C = mgeom(P->yny);
+    xrfthip_plan::ProfRec* rec = prof_begin(P, "fastm_cols", st);
+    const dim3 grid((unsigned)(8 * ((p.nunits + 7) / 8))), blk((unsigned)C.thr);
+#define MC_(NN) do { if (d.detrend) { auto k = &fastm_cols_kernel<double, NN, true>; XRFT_LAUNCH(k, grid, blk, C.lds_cols, st, p); } \
+                     else { auto k = &fastm_cols_kernel<double, NN, false>; XRFT_LAUNCH(k, grid, blk, C.lds_cols, st, p); } } while (0)
+    if (P->yny == 1440) MC_(1440); else if (P->yny == 720) MC_(720); else MC_(360);
+#undef MC_
+    prof_end(rec, st);
+    if (d.detrend) {
+        rec = prof_begin(P, "fastm_fit", st);
+        auto kf = &fastm_fit_kernel<double>;
+        XRFT_LAUNCH(kf, dim3((unsigned)gc), dim3(256), 3 * 256 * sizeof(double), st, (const double*)p.colfit, (const double*)p.win_x,
+                    reinterpret_cast<C2<double>*>(const_cast<void*>(p.corr)), (int)P->ynx, (int)P->yny, (int)d.detrend);
+        prof_end(rec, st);
+    }
+}
+
+static void fastm_launch_rows(const xrfthip_plan* P, const FastM& p, long long gc, hipStream_t st) {
+    const xrfthip_desc& d = P->d;
+    const MGeomRt R = mgeom(P->ynx);
+    const bool two = d.out_mode == XRFTHIP_OUT_CROSS || d.out_mode == XRFTHIP_OUT_PHASE;
+    xrfthip_plan::ProfRec* rec = prof_begin(P, "fastm_rows", st);
+    const dim3 grid((unsigned)(gc * (P->y_nrow_pad / fastm_rpu(P->ynx, two)))), blk((unsigned)R.thr);
+#define MR_(NN) do { \
+        if (d.out_mode == XRFTHIP_OUT_POWER) { auto k = &fastm_rows_kernel<double, NN, 1>; XRFT_LAUNCH(k, grid, blk, R.lds_rows, st, p); } \
+        else if (d.out_mode == XRFTHIP_OUT_CROSS) { auto k = &fastm_rows_kernel<double, NN, 2>; XRFT_LAUNCH(k, grid, blk, R.lds_rows, st, p); } \
+        else if (d.out_mode == XRFTHIP_OUT_PHASE) { auto k = &fastm_rows_kernel<double, NN, 3>; XRFT_LAUNCH(k, grid, blk, R.lds_rows, st, p); } \
+        else { auto k = &fastm_rows_kernel<double, NN, 0>; XRFT_LAUNCH(k, grid, blk, R.lds_rows, st, p); } } while (0)
+    if (P->ynx == 1440) MR_(1440); else if (P->ynx == 720) MR_(720); else MR_(360);
+#undef MR_
+    prof_end(rec, st);
+}
+
+static int run_fastm(const xrfthip_plan* P, const void* in, const void* in1, void* out, char* ws, hipStream_t st) {
+    const xrfthip_desc& d = P->d;
+    const bool two = d.out_mode == XRFTHIP_OUT_CROSS || d.out_mode == XRFTHIP_OUT_PHASE;
+    for (long long g0 = 0; g0 < d.batch; g0 += P->G) {
+        const long long gc = std::min<long long>(P->G, d.batch - g0);
+        FastM p = fastm_params(P, in, out, ws, g0, gc, 0, P->G);
+        fastm_launch_cols(P, p, gc, st);
+        if (two) {
+            const FastM p1 = fastm_params(P, in1, out, ws, g0, gc, 1, P->G);
+            fastm_launch_cols(P, p1, gc, st);
+            p.w2b = p1.w2;
+            p.corr_b = p1.corr;
+        }
+        fastm_launch_rows(P, p, gc, st);
+        HIP_TRY(hipGetLastError());
+    }
+    return XRFTHIP_OK;
+}
+
 // Everything xrfthip_exec needs beyond the caller's buffers is built HERE, when the plan is created or one of its tables is
 // set: window spectra and phase tables of the specialised paths (device allocations + blocking copies) and the workspace
 // layout.  xrfthip_exec itself takes the plan as const: no allocation, no copy, no synchronisation, no getenv.
 static int finalize_plan(xrfthip_plan* P) {
-    if (P->fast1d) {
+    if (P->fastm) {
+        int rc = fasty_window_spectra(P);
+        if (!rc && P->d.out_mode != XRFTHIP_OUT_POWER) rc = fast_phase_tables(P);
+        if (rc) return rc;
+    } else if (P->fast1d) {
         int rc = fasty_window_spectra(P);
         if (!rc && P->d.out_mode != XRFTHIP_OUT_POWER) rc = fast_phase_tables(P);
         if (rc) return rc;
@@ -1340,6 +1470,29 @@ int xrfthip_plan_create(xrfthip_plan** plan, const xrfthip_desc* desc) {
             if (rc1) { delete P; return rc1; }
         }
     }
+    {   // real float64 slabs on the regular lat/lon lengths: the mixed-radix form of the y-first pipeline (fastm.h)
+        const uint32_t shifts = XRFTHIP_SHIFT_Y | XRFTHIP_SHIFT_X, ish = XRFTHIP_ISHIFT_Y | XRFTHIP_ISHIFT_X;
+        const uint32_t allowed = d.out_mode == XRFTHIP_OUT_POWER ? shifts : (d.out_mode == XRFTHIP_OUT_COMPLEX || d.out_mode == XRFTHIP_OUT_CROSS || d.out_mode == XRFTHIP_OUT_PHASE) ? (shifts | ish) : 0u;
+        P->fastm = d.ndim == 2 && d.dtype == XRFTHIP_F64 && fastm_len(d.ny) && fastm_len(d.nx) && !(d.flags & ~allowed) &&
+                   !env_ll("XRFTHIP_NO_FAST", 0) && env_ll("XRFTHIP_FASTM", 1) != 0;
+        if (P->fastm) {
+            const bool two = d.out_mode == XRFTHIP_OUT_CROSS || d.out_mode == XRFTHIP_OUT_PHASE;
+            const int rpu = fastm_rpu(d.nx, two);
+            if (rpu < 1 || rpu % fastm_rk(d.ny) != 0 || d.nx % fastm_cw(d.ny) != 0) P->fastm = false;
+        }
+        if (P->fastm) {
+            const bool two = d.out_mode == XRFTHIP_OUT_CROSS || d.out_mode == XRFTHIP_OUT_PHASE;
+            const int rpu = fastm_rpu(d.nx, two);
+            P->yfirst = true;
+            P->yny = d.ny; P->ynx = d.nx;
+            P->y_nrow_pad = (int)((d.ny / 2 + 1 + rpu - 1) / rpu * rpu);
+            int rcm = build_twiddle<double>(P->tw_fx, d.nx, d.nx);
+            if (!rcm) rcm = build_twiddle<double>(P->tw_fy, d.ny, d.ny);
+            std::vector<double> ones((size_t)std::max(d.ny, d.nx), 1.0);
+            if (!rcm) rcm = P->ones4096.upload(ones.data(), ones.size() * sizeof(double));
+            if (rcm) { delete P; return rcm; }
+        }
+    }
     set_kernel_attrs_once();
     // nbins must be known before tiles are sized (the LDS histogram shares the tile's allocation): ISO plans are
     // (re)built in xrfthip_plan_set_binmap.  Build now for everything else.
@@ -1438,7 +1591,12 @@ int xrfthip_plan_describe(const xrfthip_plan* plan, char* buf, size_t buflen) {
     appendf(s, "xrfthip plan: ndim=%d batch=%lld ny=%lld nx=%lld dtype=%d mode=%d detrend=%d flags=0x%x width=%lld nx_out=%lld mirror=%d group=%d ws=%zuB\n",
             d.ndim, (long long)d.batch, (long long)d.ny, (long long)d.nx, d.dtype, d.out_mode, d.detrend, d.flags,
             plan->width, plan->nx_out, (int)plan->mirror, plan->G, plan->ws_bytes);
-    if (fasty_on(plan)) {
+    if (plan->fastm) {
+        const MGeomRt C = mgeom(plan->yny), R = mgeom(plan->ynx);
+        appendf(s, "  [fastm] cols: %d thr, %d packed column pairs (FFT%lld r%dx%dx%d in LDS), lds=%zuB -> W2[slab][%d/%d][nx/%d][%d][%d] complex128 -> fit -> rows: %d thr, %d rows/unit (FFT%lld r%dx%dx%d), lds=%zuB, trend added back in the spectral domain, fftshift + mirror rows\n",
+                C.thr, C.g, (long long)plan->yny, C.r0, C.r1, C.r2, C.lds_cols, plan->y_nrow_pad, fastm_rk(plan->yny), fastm_cw(plan->yny), fastm_rk(plan->yny), fastm_cw(plan->yny),
+                R.thr, R.g, (long long)plan->ynx, R.r0, R.r1, R.r2, R.lds_rows);
+    } else if (fasty_on(plan)) {
         const YGeomRt C = ycols_geom(plan->yny), R = yrows_geom(plan->ynx);
         if (plan->fast1d) appendf(s, "  [fasty four-step] %lld samples = [%lld][%lld]: columns = step 1 (half spectrum k1 <= %lld), rows x W_N^(i2 k1) = step 2, transposed stores + Hermitian mirror\n",
                                   (long long)plan->d.nx, (long long)plan->yny, (long long)plan->ynx, (long long)plan->yny / 2);
@@ -1474,6 +1632,7 @@ int xrfthip_exec(const xrfthip_plan* plan, const void* d_in0, const void* d_in1,
     double* acc = (double*)(ws + P->off_acc);
     double* coef = (double*)(ws + P->off_coef);
     if (iso) HIP_TRY(hipMemsetAsync(d_iso, 0, (size_t)d.batch * P->nbins * (cross ? 16 : 8), st));
+    if (P->fastm) return run_fastm(P, d_in0, d_in1, out, ws, st);
     if (fasty_on(P)) {
         return run_fasty(P, (const float*)d_in0, (const float*)d_in1, out, (double*)d_iso, ws, st);
     }
