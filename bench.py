@@ -6,6 +6,10 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
+--workload c2 | c4 | c5 runs BASELINE.json configs[1] / [3] / [4] through the same harness (dft along x of (1024, 65536) float32;
+cross_spectrum + isotropic_cross_spectrum of two (nt, 2048, 2048) fields with the all_gather; power_spectrum of (64, 1440, 720)
+float64) -- same JSON line, roofline on that configuration's own algorithmic bytes.
+
 One "step" = one call of ``xrft_amd.power_spectrum`` over the rank's whole (nt, ny, nx) cube, input already
 resident in HBM.  Batches shard over ranks as independent time slabs (weak scaling: nt per GPU is fixed); there is
 no data-path collective.  value = GFFT/s = 1e-9 * (points transformed by all ranks) / (max-over-ranks wall time).
@@ -74,9 +78,10 @@ def main(argv=None):
     ap.add_argument("--no-profile", action="store_true", help="do not record per-kernel HIP events")
     ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
                     help="weak: --nt slabs PER GPU (default); strong: --nt slabs in total, contiguous blocks per rank")
-    ap.add_argument("--workload", choices=["ps", "c4"], default="ps",
-                    help="ps: BASELINE.json configs[2] (power_spectrum, the headline metric); c4: configs[3] -- cross_spectrum + "
-                         "isotropic_cross_spectrum of two fields per rank, the isotropic result all-gathered over RCCL")
+    ap.add_argument("--workload", choices=["ps", "c2", "c4", "c5"], default="ps",
+                    help="ps: BASELINE.json configs[2] (power_spectrum, the headline metric); c2: configs[1] -- dft along x of "
+                         "(1024, 65536) float32; c4: configs[3] -- cross_spectrum + isotropic_cross_spectrum of two fields per rank, the "
+                         "isotropic result all-gathered over RCCL; c5: configs[4] -- power_spectrum of (64, 1440, 720) float64, linear detrend + Hann")
     ap.add_argument("--emulate", action="store_true", help=argparse.SUPPRESS)  # tests/test_bench_ranks_cpu.py: gloo + the emulated library
     args = ap.parse_args(argv)
 
@@ -116,8 +121,16 @@ def main(argv=None):
     else:
         _lib.load()  # no fallback: raises if the HIP library is missing
     ny, nx = args.ny, args.nx
-    if args.workload == "c4" and (args.ny, args.nx) == (4096, 4096):
+    default_shape = (args.ny, args.nx) == (4096, 4096)
+    if args.workload == "c4" and default_shape:
         ny = nx = 2048  # BASELINE.json configs[3]
+    if args.workload == "c5" and default_shape:
+        ny, nx = 1440, 720  # configs[4]
+    if args.workload == "c2":
+        ny, nx = 1, (65536 if default_shape else args.nx)  # configs[1]: (1024, 65536) per GPU, one long axis
+        if args.nt == 64:
+            args.nt = 1024
+    fdt = torch.float64 if args.workload == "c5" else torch.float32
     # slabs of this rank: weak = --nt each; strong = contiguous block of --nt in total (never splits a slab)
     if args.scaling == "strong":
         lo, hi = xdist.shard_bounds(args.nt, rank, world)
@@ -127,20 +140,25 @@ def main(argv=None):
 
     # ---- synthetic cube generated on the device: N(0,1) + plane + offset so that the linear detrend works
     gen = torch.Generator(device=dev)
-    gen.manual_seed(20260927 + 1000 * (3 if args.workload == "ps" else 4) + rank)
-    x = torch.randn((nt, ny, nx), dtype=torch.float32, device=dev, generator=gen)
-    x += (0.01 * torch.arange(ny, device=dev, dtype=torch.float32))[None, :, None]
-    x += (-0.02 * torch.arange(nx, device=dev, dtype=torch.float32) + 3.0)[None, None, :]
+    gen.manual_seed(20260927 + 1000 * {"ps": 3, "c4": 4, "c2": 2, "c5": 5}[args.workload] + rank)
+    x = torch.randn((nt, ny, nx), dtype=fdt, device=dev, generator=gen)
+    x += (0.01 * torch.arange(ny, device=dev, dtype=fdt))[None, :, None]
+    x += (-0.02 * torch.arange(nx, device=dev, dtype=fdt) * (4096.0 / nx) + 3.0)[None, None, :]
     coords = {"time": np.arange(nt), "y": np.arange(ny, dtype=np.float64), "x": np.arange(nx, dtype=np.float64)}
     da = xrft.DataArray(x, ("time", "y", "x"), coords)
+    if args.workload == "c2":
+        da = xrft.DataArray(x.reshape(nt, nx), ("time", "x"), {"time": coords["time"], "x": coords["x"]})
     collective = None
     if args.workload == "c4":
         x2 = 0.5 * x + torch.randn((nt, ny, nx), dtype=torch.float32, device=dev, generator=gen)
         db = xrft.DataArray(x2, ("time", "y", "x"), coords)
 
-    if args.workload == "ps":
+    if args.workload in ("ps", "c5"):
         def step():
             return xrft.power_spectrum(da, dim=["y", "x"], detrend="linear", window="hann")
+    elif args.workload == "c2":
+        def step():
+            return xrft.dft(da, dim="x")
     else:
         nbins = min(ny, nx) // 4
         collective = {"op": "all_gather", "backend": "gloo" if emu else "nccl (RCCL over xGMI)",
@@ -205,7 +223,8 @@ def main(argv=None):
             launches_per_step = launches / args.steps
             # c4: two float32 fields in, one complex64 cross spectrum out per point (16 B/point); the
             # isotropic call reads the two fields again (8 B/point, its output is negligible)
-            bpp = BYTES_PER_POINT if args.workload == "ps" else 16.0 + 8.0
+            # c2: float32 in, complex64 out (12 B/point); c5: float64 in, float64 out (16 B/point)
+            bpp = {"ps": BYTES_PER_POINT, "c4": 16.0 + 8.0, "c2": 12.0, "c5": 16.0}[args.workload]
             pts_per_launch = float(nt) * ny * nx / max(launches_per_step, 1e-9)
             k_achieved = bpp * pts_per_launch / avg_s
             kernel_ms = sum(v[1] for v in kern.values()) / args.steps
@@ -226,10 +245,12 @@ def main(argv=None):
             roof = {
                 "bound": "hbm", "achieved": round(path_achieved / 1e9, 2), "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                 "frac": round(path_achieved / HBM_PEAK, 4),
-                "definition": ("algorithmic bytes (8 B per input point: 4 read + 4 written) of one step / wall time of the step, per GPU"
-                               if args.workload == "ps" else
-                               "algorithmic bytes (cross spectrum 16 B + isotropic cross spectrum 8 B per point of one field) of one "
-                               "step / wall time of the step, per GPU"),
+                "definition": {"ps": "algorithmic bytes (8 B per input point: 4 read + 4 written) of one step / wall time of the step, per GPU",
+                               "c4": "algorithmic bytes (cross spectrum 16 B + isotropic cross spectrum 8 B per point of one field) of one "
+                                     "step / wall time of the step, per GPU",
+                               "c2": "algorithmic bytes (12 B per point: float32 read + complex64 written) of one step / wall time of the step, per GPU",
+                               "c5": "algorithmic bytes (16 B per point: float64 read + float64 written) of one step / wall time of the step, per GPU",
+                               }[args.workload],
                 "traffic": traffic, "traffic_note": tnote,
                 "kernel": {"name": dom, "avg_launch_us": round(avg_s * 1e6, 2), "points_per_launch": pts_per_launch,
                            "achieved": round(k_achieved / 1e9, 2), "frac": round(k_achieved / HBM_PEAK, 4),
@@ -297,6 +318,15 @@ def main(argv=None):
                   f"(BASELINE.json configs[2])")
             metric = f"2-D power_spectrum GFFT/s (nt,{ny},{nx}) fp32"
             par = f"time-slab shards x{world}, no collective"
+        elif args.workload == "c5":
+            wl = (f"xrft.power_spectrum dim=[y,x] detrend=linear window=hann on ({nt},{ny},{nx}) float64 per GPU "
+                  f"(BASELINE.json configs[4])")
+            metric = f"2-D power_spectrum GFFT/s (nt,{ny},{nx}) fp64"
+            par = f"time-slab shards x{world}, no collective"
+        elif args.workload == "c2":
+            wl = f"xrft.dft dim=x on ({nt},{nx}) float32 per GPU (BASELINE.json configs[1])"
+            metric = f"1-D dft GFFT/s (nt,{nx}) fp32"
+            par = f"row shards x{world}, no collective"
         else:
             wl = (f"xrft.cross_spectrum + xrft.isotropic_cross_spectrum window=hann on two ({nt},{ny},{nx}) float32 fields per GPU "
                   f"(BASELINE.json configs[3]); GFFT/s counts the points of one field")
@@ -305,7 +335,7 @@ def main(argv=None):
         out = {
             "metric": metric, "value": round(value, 3), "unit": "GFFT/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
-            "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": "f64" if args.workload == "c5" else "f32", "data": "synthetic",
             "config": {"workload": wl, "nt_per_gpu": nt, "nt_total": nt_total, "ny": ny, "nx": nx, "parallelism": par,
                        "collective": collective, "slabs_per_s": round(nt_total * args.steps / dt, 2)},
             "roofline": roof, "cpu_baseline": cpu, "parity_max_rel_err_vs_oracle": parity,

@@ -7,6 +7,12 @@ export TMPDIR=/tmp
 (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d "$GRAFT_REPO_ROOT/gpurun_out/r02/prof_bench" -o bench -- python3 "$GRAFT_REPO_ROOT/bench.py" --gpus 1 --steps 20 --warmup 5 --cpu-slabs 0 > "$GRAFT_REPO_ROOT/gpurun_out/r02/prof_bench.json" 2> "$GRAFT_REPO_ROOT/gpurun_out/r02/prof_bench.err"; echo "rocprof bench rc=$?")
 f=$(find gpurun_out/r02/prof_bench -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp "$f" gpurun_out/r02/bench_kernel_stats.csv && head -8 "$f" | cut -c1-220
 find gpurun_out/r02/prof_bench -name "*kernel_trace.csv" -size +8M -delete
+# the driver's command as it is, and the other BASELINE.json configurations through the same bench (one JSON line each)
+timeout 600 python3 bench.py --gpus 1 --steps 20 --warmup 5 > gpurun_out/r02/bench_driver_cmd.json 2> gpurun_out/r02/bench_driver_cmd.err; echo "bench rc=$?"
+for w in c2 c4 c5; do
+  timeout 300 python3 bench.py --gpus 1 --steps 10 --warmup 3 --workload $w --cpu-slabs 0 > gpurun_out/r02/bench_$w.json 2> gpurun_out/r02/bench_$w.err; echo "bench $w rc=$?"
+done
+timeout 600 python3 scripts/bench_configs.py > gpurun_out/r02/bench_configs.txt 2>&1; echo "configs rc=$?"
 bash scripts/gpu_pmc_yf.sh r02 sq1 sq2 tcc2 fetch write grbm > gpurun_out/r02/pmc.log 2>&1; tail -2 gpurun_out/r02/pmc.log
 for c in FETCH_SIZE WRITE_SIZE; do
   (cd /tmp && timeout 300 rocprofv3 --kernel-trace --pmc $c --output-format csv -d "$GRAFT_REPO_ROOT/gpurun_out/r02/pmc_ubench_$c" -o u -- "$GRAFT_REPO_ROOT/scripts/ubench/yfirst" > /dev/null 2>&1; echo "ubench $c rc=$?")

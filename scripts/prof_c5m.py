@@ -5,7 +5,8 @@ import os, sys, time, warnings
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 import xrft_amd as xrft
-from xrft_amd import api
+from xrft_amd import api, _lib
+if os.environ.get("XRFT_LIB"): _lib.load(os.environ["XRFT_LIB"])  # an ablation build (scripts/build_ablate_m.sh)
 warnings.simplefilter("ignore")
 def prof(name, fn, units, pts):
     fn(); fn(); torch.cuda.synchronize()
@@ -26,9 +27,10 @@ for shp in shapes:
     y = torch.randn(shp, dtype=torch.float64, device="cuda")
     c = {"lat": np.arange(shp[1]) * .25, "lon": np.arange(shp[2]) * .25}
     da = xrft.DataArray(x, ("t", "lat", "lon"), c); db = xrft.DataArray(y, ("t", "lat", "lon"), c)
-    for det in (None, "linear"):
+    for det in ((None, "linear") if not os.environ.get("ONLY_LINEAR") else ("linear",)):
         pl = prof(f"PS f64 {det} hann {shp}", lambda: xrft.power_spectrum(da, dim=["lat", "lon"], detrend=det, window="hann"), shp[0], x.numel())
     print("   ", pl.describe().strip().split("\n")[1][:300])
+    if os.environ.get("ONLY_LINEAR"): continue
     prof(f"fft f64 linear hann {shp}", lambda: xrft.fft(da, dim=["lat", "lon"], detrend="linear", window="hann"), shp[0], x.numel())
     prof(f"cross f64 linear hann {shp}", lambda: xrft.cross_spectrum(da, db, dim=["lat", "lon"], detrend="linear", window="hann"), shp[0], x.numel())
     del x, y, da, db

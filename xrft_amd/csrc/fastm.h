@@ -82,11 +82,18 @@ struct FastM {
     double scale;
 };
 
+// profiling builds (scripts/build_ablate_m.sh, -DXRFT_MDBG=bits; 0 in the product): 1 = the intermediate is written with plain
+// stores, 2 = the result too
+#ifndef XRFT_MDBG
+#define XRFT_MDBG 0
+#endif
+
 // 16-byte store that bypasses the caches' retention (the next reader is another kernel, a whole group of slabs later)
-template <typename T> __device__ __forceinline__ void mr_store16_nt(void* dst, const void* src16) {
+template <typename T, bool PLAIN = false> __device__ __forceinline__ void mr_store16_nt(void* dst, const void* src16) {
 #ifdef XRFT_EMULATE
     memcpy(dst, src16, 16);
 #else
+    if (PLAIN) { *reinterpret_cast<float4*>(dst) = *reinterpret_cast<const float4*>(src16); return; }
     typedef float v4f __attribute__((ext_vector_type(4)));
     __builtin_nontemporal_store(*reinterpret_cast<const v4f*>(src16), reinterpret_cast<v4f*>(dst));
 #endif
@@ -249,8 +256,8 @@ __global__ void __launch_bounds__((MGeom<T, NY>::THR), (MGeom<T, NY>::WPS)) fast
             o[0] = cscale(zk + zc, (T)0.5);
             o[1] = cscale(mul_mi(zk - zc), (T)0.5);
             const unsigned off = ((((unsigned)(k >> p.l_rk) * (unsigned)nxb + (unsigned)xb) << p.l_rk) + (unsigned)(k & (rk - 1))) * (unsigned)CW + 2u * (unsigned)g;
-            mr_store16_nt<T>(w2s + (size_t)off * sizeof(CT), &o[0]);
-            mr_store16_nt<T>(w2s + (size_t)off * sizeof(CT) + 16, &o[1]);
+            mr_store16_nt<T, (XRFT_MDBG & 1) != 0>(w2s + (size_t)off * sizeof(CT), &o[0]);
+            mr_store16_nt<T, (XRFT_MDBG & 1) != 0>(w2s + (size_t)off * sizeof(CT) + 16, &o[1]);
         }
     }
 }
@@ -347,7 +354,7 @@ __global__ void __launch_bounds__((MGeom<T, NX>::THR), (MGeom<T, NX>::WPS)) fast
                 else reinterpret_cast<CT*>(o)[i] = va;
             }
         }
-        mr_store16_nt<T>(outs + (size_t)orow * NX + c, o);
+        mr_store16_nt<T, (XRFT_MDBG & 2) != 0>(outs + (size_t)orow * NX + c, o);
     }
 }
 

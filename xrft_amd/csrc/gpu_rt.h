@@ -7,13 +7,11 @@
 #include "hip_emu.h"
 #define XRFT_LAUNCH(kernel, grid, block, smem, stream, ...) emu::launch(kernel, grid, block, smem, stream, __VA_ARGS__)
 #define XRFT_DYN_SMEM(name) unsigned char* name = emu::tls()->smem
-#define XRFT_SLEEP_4US() ((void)0)
 #define XRFT_OPAQUE(x) asm volatile("" : "+r"(x))
 #else
 #include <hip/hip_runtime.h>
 #define XRFT_LAUNCH(kernel, grid, block, smem, stream, ...) hipLaunchKernelGGL(kernel, grid, block, smem, stream, __VA_ARGS__)
 #define XRFT_DYN_SMEM(name) extern __shared__ __attribute__((aligned(16))) unsigned char name[]
-#define XRFT_SLEEP_4US() __builtin_amdgcn_s_sleep(127) /* 127 x 64 cycles ~ 3.9 us at 2.1 GHz */
 // make a per-lane value opaque to the optimiser (stops LICM from hoisting everything derived from it out of a
 // persistent loop and then spilling it: measured 500 B/lane of scratch in fast4096_rows_kernel without this)
 #define XRFT_OPAQUE(x) asm volatile("" : "+v"(x))
