@@ -843,7 +843,7 @@ static void layout_workspace(xrfthip_plan* P) {
     const bool yf = fast && P->yfirst;
     if (fast) {
         slab_w = (size_t)P->y_nrow_pad * P->ynx * (P->fastm ? P->csize : sizeof(cf));
-        if (G <= 0) G = P->tune_fast_group > 0 ? P->tune_fast_group : std::max<long long>(1, (32LL * 4096 * 4096) / (d.ny * d.nx));  // measured 8: 197, 16: 210, 32: 214 GFFT/s (tails and launch gaps amortise)
+        if (G <= 0) G = P->tune_fast_group > 0 ? P->tune_fast_group : std::max<long long>(1, (64LL * 4096 * 4096) / (d.ny * d.nx));  // y-first, 4096^2: 16: 62.7, 32: 61.4 us per slab; 32 -> 64: 301-303 -> 306-307 GFFT/s (tails, launch gaps and the plane-fit bubble amortise)
     }
     if (G <= 0) {
         // the Infinity Cache adds no bandwidth, so groups are sized for launch efficiency, not residency
