@@ -185,10 +185,13 @@ int xrfthip_gather_axis(int32_t elem_bytes, int64_t outer, int64_t n_out, int64_
                         const void* d_in, void* d_out, void* stream);
 
 /* Stand-alone radial bin-sum of an existing spectrum (xrft.isotropize, xrft.py:948-1010):
- * d_in [batch][ny][nx] (dtype F32|F64|C64|C128), d_binmap device int32 [ny][nx], d_iso float64|complex128
- * [batch][nbins] (zeroed by the call). */
+ * d_in [batch][ny][nx] (dtype F32|F64|C64|C128), d_binmap device int32 [ny][nx] (bin of each sample, < 0 = none),
+ * d_iso float64|complex128 [batch][nbins] (every entry written).  The sums are bit-reproducible (per-workgroup integer
+ * fixed-point sums, combined in a fixed order); d_workspace holds the per-workgroup tables,
+ * xrfthip_isotropize_workspace_bytes(...) bytes (0 = bad arguments).  Any nbins >= 1. */
+size_t xrfthip_isotropize_workspace_bytes(int32_t dtype, int64_t batch, int64_t ny, int64_t nx, int32_t nbins);
 int xrfthip_isotropize(int32_t dtype, int64_t batch, int64_t ny, int64_t nx, const void* d_in,
-                       const int32_t* d_binmap, int32_t nbins, void* d_iso, void* stream);
+                       const int32_t* d_binmap, int32_t nbins, void* d_iso, void* d_workspace, size_t ws_bytes, void* stream);
 
 #ifdef __cplusplus
 }

@@ -553,3 +553,62 @@ def run_fastm_cases(shape=(2, 360, 360), full=True, cross=True):
     assert (dphi * mag).max() / mag.max() < 1e-10 and dphi[big].max() < 1e-6, ((dphi * mag).max() / mag.max(), dphi[big].max())
     assert on_fastm()
     return worst
+
+
+def run_radial_sum_cases(big=False):
+    """Radial bin sums (xrft.isotropize / isotropic_*_spectrum; reference xrft.py:877-1010) outside the specialised kernels: the
+    stand-alone sum and the generic plans.  Values against numpy.bincount / the oracle, any number of bins (the C ABI used to
+    stop at 4096; the tables of a launch cover a window of bins), and bit-identical repeats (integer fixed-point sums)."""
+    import torch
+
+    from xrft_amd import engine
+
+    rng = np.random.default_rng(51)
+    nb = 7000  # more bins than one launch's LDS window (5461 real / 3276 complex)
+    ny, nx, nt = 48, 160, 3
+    bm = rng.integers(-1, nb, size=(ny, nx)).astype(np.int32)
+    dev = xa.api._to_device(np.zeros(1, dtype=np.float32)).device
+    bmd = torch.from_numpy(bm).to(dev)
+    for dt in ("float32", "float64", "complex64", "complex128"):
+        v = rng.standard_normal((nt, ny, nx)) * np.exp(3.0 * rng.standard_normal((nt, ny, nx)))  # ten decades of dynamic range
+        if dt.startswith("complex"):
+            v = v + 1j * rng.standard_normal((nt, ny, nx))
+        v = v.astype(dt)
+        t = torch.from_numpy(v).to(dev)
+        got = engine.isotropize(t, bmd, nb)
+        again = engine.isotropize(t, bmd, nb)
+        assert torch.equal(got, again), dt
+        g = got.cpu().numpy()
+        ok = bm.ravel() >= 0
+        for b in range(nt):
+            w = v[b].ravel()[ok].astype("complex128" if dt.startswith("complex") else "float64")
+            ref = np.bincount(bm.ravel()[ok], weights=w.real, minlength=nb)
+            if dt.startswith("complex"):
+                ref = ref + 1j * np.bincount(bm.ravel()[ok], weights=w.imag, minlength=nb)
+            mag = np.bincount(bm.ravel()[ok], weights=np.abs(w), minlength=nb)
+            assert np.all(np.abs(g[b] - ref) <= 1e-12 * np.maximum(mag, 1e-300)), (dt, b, np.abs(g[b] - ref).max())
+    # generic plans (float64, lengths the specialised kernels do not take): values vs the oracle, repeats bit for bit
+    shape = (3, 48, 40)
+    a = _cube(rng, shape, "float64")
+    b = _cube(rng, shape, "float64")
+    da, od = pair(a, D3, _coords3(shape))
+    db, ob = pair(b, D3, _coords3(shape))
+    kw = dict(dim=["y", "x"], detrend="linear", window="hann")
+    ips = xa.isotropic_power_spectrum(da, **kw)
+    worst = check(ips, o.isotropic_power_spectrum(od, **kw), TOL["float64"])
+    assert np.array_equal(xa.isotropic_power_spectrum(da, **kw).values, ips.values)
+    ics = xa.isotropic_cross_spectrum(da, db, **kw)
+    worst = max(worst, check(ics, o.isotropic_cross_spectrum(od, ob, **kw), TOL["float64"]))
+    assert np.array_equal(xa.isotropic_cross_spectrum(da, db, **kw).values, ics.values)
+    iso = xa.isotropize(xa.power_spectrum(da, dim=["y", "x"]), ["freq_y", "freq_x"])
+    assert np.array_equal(xa.isotropize(xa.power_spectrum(da, dim=["y", "x"]), ["freq_y", "freq_x"]).values, iso.values)
+    if big:  # more than 4096 radial bins through the public call: nfactor = 1 on a 4400^2 spectrum
+        n = 4400
+        ps = (rng.standard_normal((1, n, n)) ** 2).astype("float32")
+        c = {"t": np.arange(1), "freq_y": np.fft.fftshift(np.fft.fftfreq(n, 0.5)), "freq_x": np.fft.fftshift(np.fft.fftfreq(n, 0.5))}
+        dps, ops = pair(ps, ("t", "freq_y", "freq_x"), c)
+        got = xa.isotropize(dps, ["freq_y", "freq_x"], nfactor=1)
+        ref = o.isotropize(ops, ["freq_y", "freq_x"], nfactor=1)
+        assert got.sizes["freq_r"] == ref.values.shape[-1] > 4000
+        worst = max(worst, check(got, ref, 1e-6))
+    return worst

@@ -195,6 +195,7 @@ inline double __shfl_xor(double v, int mask) {
     emu::barrier();
     return r;
 }
+inline long long __double_as_longlong(double d) { long long v; memcpy(&v, &d, 8); return v; }
 inline float __uint_as_float(unsigned v) { float f; memcpy(&f, &v, 4); return f; }
 inline unsigned __float_as_uint(float f) { unsigned v; memcpy(&v, &f, 4); return v; }
 using std::max;

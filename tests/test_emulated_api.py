@@ -401,3 +401,9 @@ def test_fourstep_1d_fast_path(n):
 def test_fastm_float64_latlon_lengths(shape, full):
     """The mixed-radix float64 y-first kernels (csrc/fastm.h; BASELINE.json configs[4] is (64, 1440, 720) float64)."""
     cases.run_fastm_cases(shape, full)
+
+
+def test_radial_sums_any_nbins_and_bit_identical_repeats():
+    """Stand-alone and generic-plan radial sums: > 4096 bins, values vs numpy / the oracle, repeats bit for bit (the emulator runs
+    the workgroups of a launch on several OS threads, so an order-dependent sum would show)."""
+    cases.run_radial_sum_cases()

@@ -719,6 +719,12 @@ def test_fastm_float64_latlon_lengths(shape, cross):
     cases.run_fastm_cases(shape, True, cross)
 
 
+def test_radial_sums_any_nbins_and_bit_identical_repeats():
+    """Stand-alone and generic-plan radial sums: more than 4096 bins (also through xrft.isotropize, nfactor = 1 on 4400^2), values
+    vs numpy / the oracle, repeats bit for bit."""
+    cases.run_radial_sum_cases(big=True)
+
+
 @pytest.mark.parametrize("n", [65536, 131072, 1048576])
 def test_fourstep_1d_fast_path(n):
     cases.run_fourstep_1d(n, nt=3)

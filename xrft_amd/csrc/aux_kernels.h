@@ -256,35 +256,86 @@ __global__ void __launch_bounds__(256) gather_axis_kernel(const E* in, E* out, l
     }
 }
 
-// iso[slab][bin] += in[slab][e] for bin = binmap[e] >= 0 ; LDS-privatised histogram, one flush per block.
+// Radial bin sums of a stored spectrum (xrft.isotropize, xrft.py:948-1010; _groupby_bins_agg / _binned_agg :877-945),
+// BIT-REPRODUCIBLE: floating-point atomics would make a sum depend on the order in which waves arrive.  A workgroup owns one
+// contiguous chunk of a slab and makes two sweeps over it: (1) the largest exponent per bin (atomicMax on the high word of the
+// float64 magnitude: order-independent), (2) every value converted to int64 fixed point FR bits below its bin's exponent bound
+// and added with INTEGER atomics (exact, order-independent).  The chunk's sums go to part[slab][chunk][bin]; the chunks are
+// added in order by iso_reduce_kernel.  Bins outside [b0, b0 + nb) are skipped (a window of the bins per launch when the
+// tables do not fit the LDS).  The spectrum is stored with rows / columns rotated by sy / sx (fftshift); binmap is indexed by
+// unshifted frequencies.  A chunk holds <= 2^17 elements: |sum| < 2^(FR + 1 + 17) = 2^62.
+constexpr int kIsoFR = 44;
+__device__ __forceinline__ long long iso_fixed(double v, int eb) {
+    const unsigned long long bits = (unsigned long long)__double_as_longlong(v);
+    const int ex = (int)((bits >> 52) & 0x7ffull);
+    if (ex == 0) return 0;  // zero / denormal
+    const long long m = (long long)((bits & 0xfffffffffffffull) | 0x10000000000000ull);  // |v| = m 2^(ex - 1075)
+    const int sh = eb - ex + (52 - kIsoFR);                                               // q = m >> sh, sh >= 8 (ex <= eb)
+    const long long q = sh < 63 ? (m >> sh) : 0;
+    return (bits >> 63) ? -q : q;
+}
+
 template <typename T, bool CPLX>
-__global__ void __launch_bounds__(256) radial_binsum_kernel(const void* in, const int* binmap, long long total, int nbins, double* iso) {
+__global__ void __launch_bounds__(256) radial_binsum_det_kernel(const void* in, const int* __restrict__ binmap, long long total, int nxo, int ny,
+                                                                int sy, int sx, int b0, int nb, int nbins, double* part) {
     XRFT_DYN_SMEM(smem_raw);
-    double* hist = reinterpret_cast<double*>(smem_raw);
-    const int hl = nbins * (CPLX ? 2 : 1);
-    for (int i = threadIdx.x; i < hl; i += blockDim.x) hist[i] = 0.0;
+    constexpr int HW = CPLX ? 2 : 1;
+    unsigned long long* acc = reinterpret_cast<unsigned long long*>(smem_raw);  // [nb][HW]
+    unsigned* bmax = reinterpret_cast<unsigned*>(acc + (size_t)nb * HW);          // [nb]: high word of the largest magnitude
+    for (int i = threadIdx.x; i < nb * HW; i += blockDim.x) acc[i] = 0ull;
+    for (int i = threadIdx.x; i < nb; i += blockDim.x) bmax[i] = 0u;
     __syncthreads();
     const long long b = blockIdx.y;
     const long long per = (total + gridDim.x - 1) / gridDim.x;
     const long long e0 = (long long)blockIdx.x * per;
-    long long e1 = e0 + per;
-    if (e1 > total) e1 = total;
+    const long long e1 = e0 + per < total ? e0 + per : total;
+    const T* __restrict__ src = reinterpret_cast<const T*>(in) + b * total * HW;
+    auto bin_of = [&](long long e) -> int {
+        int r = (int)(e / nxo), c = (int)(e - (long long)r * nxo);
+        r -= sy; if (r < 0) r += ny;
+        c -= sx; if (c < 0) c += nxo;
+        const int bin = binmap[(long long)r * nxo + c] - b0;
+        return (bin >= 0 && bin < nb) ? bin : -1;
+    };
     for (long long e = e0 + threadIdx.x; e < e1; e += blockDim.x) {
-        const int bin = binmap[e];
+        const int bin = bin_of(e);
         if (bin < 0) continue;
+        const double mag = CPLX ? fabs((double)src[2 * e]) + fabs((double)src[2 * e + 1]) : fabs((double)src[e]);
+        atomicMax(&bmax[bin], (unsigned)((unsigned long long)__double_as_longlong(mag) >> 32));
+    }
+    __syncthreads();
+    for (long long e = e0 + threadIdx.x; e < e1; e += blockDim.x) {
+        const int bin = bin_of(e);
+        if (bin < 0) continue;
+        const int eb = (int)(bmax[bin] >> 20);  // biased exponent of the bound: |v| <= mag < 2^(eb - 1022)
         if (CPLX) {
-            const C2<T> v = reinterpret_cast<const C2<T>*>(in)[b * total + e];
-            atomicAdd(&hist[2 * bin], (double)v.re);
-            atomicAdd(&hist[2 * bin + 1], (double)v.im);
+            atomicAdd(&acc[2 * bin], (unsigned long long)iso_fixed((double)src[2 * e], eb));
+            atomicAdd(&acc[2 * bin + 1], (unsigned long long)iso_fixed((double)src[2 * e + 1], eb));
         } else {
-            atomicAdd(&hist[bin], (double)reinterpret_cast<const T*>(in)[b * total + e]);
+            atomicAdd(&acc[bin], (unsigned long long)iso_fixed((double)src[e], eb));
         }
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < hl; i += blockDim.x) {
-        const double v = hist[i];
-        if (v != 0.0) atomicAdd(&iso[b * hl + i], v);
+    double* dst = part + ((size_t)b * gridDim.x + blockIdx.x) * (size_t)nbins * HW + (size_t)b0 * HW;
+    for (int i = threadIdx.x; i < nb * HW; i += blockDim.x)
+        dst[i] = ldexp((double)(long long)acc[i], (int)(bmax[i / HW] >> 20) - 1023 - kIsoFR);
+}
+
+// iso[slab][bin] = sum over the partial tables of the slab's units in a FIXED order (bit-reproducible): 256 threads = 4 segments
+// of units x 64 bins; every segment adds its units in order, the four segment sums are combined in order
+__global__ void __launch_bounds__(256) iso_reduce_kernel(const double* __restrict__ part, double* __restrict__ iso, int upr, int nb) {
+    XRFT_DYN_SMEM(smem_raw);
+    double (*seg)[64] = reinterpret_cast<double (*)[64]>(smem_raw);  // [4][64]
+    const int lane = threadIdx.x & 63, sg = threadIdx.x >> 6, i = blockIdx.x * 64 + lane, slab = blockIdx.y;
+    const int per = (upr + 3) / 4, u0 = sg * per, u1 = min(upr, u0 + per);
+    double s = 0.0;
+    if (i < nb) {
+        const double* src = part + (size_t)slab * upr * nb + i;
+        for (int un = u0; un < u1; ++un) s += src[(size_t)un * nb];
     }
+    seg[sg][lane] = s;
+    __syncthreads();
+    if (sg == 0 && i < nb) iso[(size_t)slab * nb + i] = ((seg[0][lane] + seg[1][lane]) + seg[2][lane]) + seg[3][lane];
 }
 
 }  // namespace xrft

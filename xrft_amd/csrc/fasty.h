@@ -466,7 +466,7 @@ __global__ void __launch_bounds__(YRows<NX>::THR, YRows<NX>::THR / 128) fasty_ro
         // which waves arrive.  Two passes over this workgroup's values: (1) the largest magnitude per bin (atomicMax on the
         // float bits: order-independent), (2) every value converted to int64 fixed point 40 bits below its bin's maximum
         // and added with INTEGER atomics (exact, order-independent; the inputs carry 24 bits).  The workgroup's per-bin
-        // sums go to a partial table that fasty_iso_reduce_kernel adds in unit order.  A value at (ky, kx) goes to its bin
+        // sums go to a partial table that iso_reduce_kernel adds in unit order.  A value at (ky, kx) goes to its bin
         // and once more (conjugated) to the bin of (-ky, -kx).
         const unsigned* __restrict__ tc = p.tcodes + ((size_t)unit * (TWO ? 16 : 32)) * THR + tid;
         unsigned codes[TWO ? 16 : 32];
@@ -644,23 +644,6 @@ __global__ void __launch_bounds__(YRows<NX>::THR, YRows<NX>::THR / 128) fasty_ro
             }
         }
     }
-}
-
-// iso[slab][bin] = sum over the row workgroups of the slab in a FIXED order (bit-reproducible): 256 threads = 4 segments of
-// units x 64 bins; every segment adds its units in order, the four segment sums are combined in order
-__global__ void __launch_bounds__(256) fasty_iso_reduce_kernel(const double* __restrict__ part, double* __restrict__ iso, int upr, int nb) {
-    XRFT_DYN_SMEM(smem_raw);
-    double (*seg)[64] = reinterpret_cast<double (*)[64]>(smem_raw);  // [4][64]
-    const int lane = threadIdx.x & 63, sg = threadIdx.x >> 6, i = blockIdx.x * 64 + lane, slab = blockIdx.y;
-    const int per = (upr + 3) / 4, u0 = sg * per, u1 = min(upr, u0 + per);
-    double s = 0.0;
-    if (i < nb) {
-        const double* src = part + (size_t)slab * upr * nb + i;
-        for (int un = u0; un < u1; ++un) s += src[(size_t)un * nb];
-    }
-    seg[sg][lane] = s;
-    __syncthreads();
-    if (sg == 0 && i < nb) iso[(size_t)slab * nb + i] = ((seg[0][lane] + seg[1][lane]) + seg[2][lane]) + seg[3][lane];
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -6,11 +6,12 @@
 // needed and twice as many sequences fit per tile (better HBM coalescing for strided "column" passes).
 // Everything the reference does around numpy.fft is folded into the first pass' loads (detrend, window,
 // flip, ifftshift -- xrft/xrft.py:425-442) and the last pass' stores (fftshift, true-phase factor, prod(dx),
-// |F|^2 / F conj(G), real-dim doubling, window/density scaling, Hermitian mirror, radial bin-sum --
+// |F|^2 / F conj(G), real-dim doubling, window/density scaling, Hermitian mirror --
 // xrft/xrft.py:446-472, 740-748, 825-833, 993-1004), so intermediates never exist as arrays.
 //
-// The hot shape of BASELINE.json (4096 x 4096 float32) has its own specialised kernels (fft4096.h); this
-// kernel is the fallback for every other shape and the parity reference for the specialised ones.
+// The shapes of BASELINE.json have their own kernels (fasty.h: float32 powers of two; fastm.h: float64 lat/lon lengths); this
+// kernel takes every other shape and is the parity reference for the specialised ones.  Radial bin sums (isotropic spectra,
+// xrft.py:895-906) are a separate, bit-reproducible pass over the stored spectrum (aux_kernels.h, radial_binsum_det_kernel).
 #pragma once
 #include "gpu_rt.h"
 
@@ -271,9 +272,6 @@ struct Epilogue {  // last pass: xrft.py:446-472, 740-748, 825-833, 993-1004
     const void* ph_x;
     const void* other;  // CROSS: raw F0, complex [slab][ny][nxh], unshifted
     long long other_slab_stride, other_row_stride;
-    const int* binmap;  // [ny][nx_out], unshifted indices
-    int nbins;
-    double* iso;  // [slab][nbins] (x2 interleaved for CROSS)
 };
 
 __device__ __forceinline__ int phys(int pos, int sh) { return pos + (pos >> sh); }
@@ -331,7 +329,7 @@ __device__ __forceinline__ C2<T> fetch_src(const Prologue& pr, long long b, int 
 // last-pass store of one frequency sample V = F(b, ky, kx) (unshifted indices)
 // ------------------------------------------------------------------------------------------------
 template <typename T>
-__device__ __forceinline__ void emit(const Epilogue& ep, long long b, int ky, int kx, C2<T> V, bool conj_it, double* hist) {
+__device__ __forceinline__ void emit(const Epilogue& ep, long long b, int ky, int kx, C2<T> V, bool conj_it) {
     // V is F (COMPLEX), or F0 conj(F1) (CROSS), or (|F|^2, 0) (POWER), before phase and scale
     if (conj_it) V.im = -V.im;
     if (ep.mode != 1) {
@@ -348,19 +346,12 @@ __device__ __forceinline__ void emit(const Epilogue& ep, long long b, int ky, in
         else if (ep.mode == 1 || ep.real_out) reinterpret_cast<T*>(ep.out)[off] = V.re;
         else reinterpret_cast<C2<T>*>(ep.out)[off] = V;
     }
-    if (hist) {
-        const int bin = ep.binmap[(long long)ky * ep.nx_out + kx];
-        if (bin >= 0) {
-            if (ep.mode == 2) { atomicAdd(&hist[2 * bin], (double)V.re); atomicAdd(&hist[2 * bin + 1], (double)V.im); }
-            else atomicAdd(&hist[bin], (double)V.re);
-        }
-    }
 }
 
 // (b0, r0) = (o0 / odiv, o0 % odiv) of the tile's first sequence, dt = sequence offset inside the tile: the only division
 // per element is a 32-bit one (64-bit integer division costs >100 instructions on the GPU)
 template <typename T>
-__device__ __forceinline__ void epi_store(const Epilogue& ep, long long b0, int r0, int dt, int q, int p, C2<T> F, double* hist) {
+__device__ __forceinline__ void epi_store(const Epilogue& ep, long long b0, int r0, int dt, int q, int p, C2<T> F) {
     unsigned rr = (unsigned)(r0 + dt), db = 0;
     const unsigned od = (unsigned)ep.odiv;
     if (od == 1) { db = rr; rr = 0; } else { while (rr >= od) { rr -= od; ++db; } }  // r0 < od, dt < T: a step or two
@@ -377,10 +368,10 @@ __device__ __forceinline__ void epi_store(const Epilogue& ep, long long b0, int 
         const C2<T> G = reinterpret_cast<const C2<T>*>(ep.other)[b * ep.other_slab_stride + (long long)ky * ep.other_row_stride + kx];
         V = cmulc(G, F);  // F0 * conj(F1): `other` holds field 0, this pass transforms field 1
     }
-    emit<T>(ep, b, ky, kx, V, false, hist);
+    emit<T>(ep, b, ky, kx, V, false);
     if (ep.mirror && kx > 0 && kx < ep.nx - kx) {
         const int my = ky == 0 ? 0 : ep.ny - ky;
-        emit<T>(ep, b, my, ep.nx - kx, V, true, hist);
+        emit<T>(ep, b, my, ep.nx - kx, V, true);
     }
 }
 
@@ -489,16 +480,6 @@ __global__ void __launch_bounds__(MAXT) tile_fft_kernel(TileGeom g, Prologue pr,
     XRFT_DYN_SMEM(smem_raw);
     C2<T>* tile = reinterpret_cast<C2<T>*>(smem_raw);
     const int tid = threadIdx.x, nthreads = blockDim.x;
-    double* hist = nullptr;
-    long long hist_slab = -1;
-    int hist_len = 0;
-    if (ALL && FINAL && ep.iso) {
-        size_t off = (size_t)g.T * g.seq_stride * sizeof(C2<T>);
-        off = (off + 15) & ~(size_t)15;
-        hist = reinterpret_cast<double*>(smem_raw + off);
-        hist_len = ep.nbins * (ep.mode == 2 ? 2 : 1);
-        for (int i = tid; i < hist_len; i += nthreads) hist[i] = 0.0;
-    }
     const C2<T>* __restrict__ gin = reinterpret_cast<const C2<T>*>(g.in);
     C2<T>* __restrict__ gout = reinterpret_cast<C2<T>*>(g.out);
     const C2<T>* __restrict__ twg = reinterpret_cast<const C2<T>*>(g.tw);
@@ -507,7 +488,6 @@ __global__ void __launch_bounds__(MAXT) tile_fft_kernel(TileGeom g, Prologue pr,
     if (g.tw_lds || g.rev_lds) {
         size_t off = (size_t)g.T * g.seq_stride * sizeof(C2<T>);
         off = (off + 15) & ~(size_t)15;
-        if (ALL && FINAL && ep.iso) off += (size_t)ep.nbins * (ep.mode == 2 ? 16 : 8);
         off = (off + 15) & ~(size_t)15;
         if (g.tw_lds) {
             twl = reinterpret_cast<C2<T>*>(smem_raw + off);
@@ -537,18 +517,6 @@ __global__ void __launch_bounds__(MAXT) tile_fft_kernel(TileGeom g, Prologue pr,
         int pi0 = 0, er0 = 0;
         if (FIRST) { pb0 = o0 / pr.rows; pi0 = (int)(o0 - pb0 * pr.rows); }
         if (FINAL) { eb0 = o0 / ep.odiv; er0 = (int)(o0 - eb0 * ep.odiv); }
-        if (hist) {  // flush the LDS histogram when this block moves on to another slab
-            const long long slab = eb0;
-            if (hist_slab >= 0 && slab != hist_slab) {
-                __syncthreads();
-                for (int i = tid; i < hist_len; i += nthreads) {
-                    double v = hist[i];
-                    if (v != 0.0) atomicAdd(&ep.iso[hist_slab * hist_len + i], v);
-                    hist[i] = 0.0;
-                }
-            }
-            hist_slab = slab;
-        }
         // ------------------------------------------------------------------ load
         const int total_in = g.T * g.n;
         const float inv_n = 1.0f / (float)g.n, inv_T = 1.0f / (float)g.T;
@@ -883,7 +851,7 @@ __global__ void __launch_bounds__(MAXT) tile_fft_kernel(TileGeom g, Prologue pr,
             }
             stored = true;
         }
-        if ((PATH == 4) || (ALL && FINAL && g.lean_final == 2 && hist == nullptr && ep.out != nullptr && !(g.dbg & 2))) {
+        if ((PATH == 4) || (ALL && FINAL && g.lean_final == 2 && ep.out != nullptr && !(g.dbg & 2))) {
             // last pass of a four-step transform along x (1-D): kx = q + p_mul k with the lane's q fixed; no mirror (the
             // four-step path transforms real input as complex), row = slab
             const int tsh = 31 - __builtin_clz((unsigned)g.T);
@@ -923,7 +891,7 @@ __global__ void __launch_bounds__(MAXT) tile_fft_kernel(TileGeom g, Prologue pr,
             }
             stored = true;
         }
-        if ((PATH == 2) || (ALL && FINAL && g.lean_final == 1 && hist == nullptr && ep.out != nullptr && !(g.dbg & 2))) {
+        if ((PATH == 2) || (ALL && FINAL && g.lean_final == 1 && ep.out != nullptr && !(g.dbg & 2))) {
             // lean epilogue of a plain column pass (xrft.py:446-472, 740-748): T is a power of two dividing the block size,
             // so a lane keeps its column for the whole tile -- column index, shifted destination column, mirror column,
             // x phase factors and the scale are per-lane constants; per sample: one LDS read, the y factors, two stores.
@@ -1027,7 +995,7 @@ __global__ void __launch_bounds__(MAXT) tile_fft_kernel(TileGeom g, Prologue pr,
                 const long long o = g.tile_axis == 0 ? o0 + t : o0;
                 const long long q = g.tile_axis == 0 ? 0 : q0 + t;
                 if (FINAL) {
-                    epi_store<T>(ep, eb0, er0, g.tile_axis == 0 ? t : 0, (int)q, k, F, hist);
+                    epi_store<T>(ep, eb0, er0, g.tile_axis == 0 ? t : 0, (int)q, k, F);
                 } else {
                     if (g.tw_big) {
                         const unsigned a = ((unsigned)q / (unsigned)g.tw_qdiv) % (unsigned)g.tw_qmod;
@@ -1043,13 +1011,6 @@ __global__ void __launch_bounds__(MAXT) tile_fft_kernel(TileGeom g, Prologue pr,
             }
         }
         __syncthreads();
-    }
-    if (hist && hist_slab >= 0) {
-        __syncthreads();
-        for (int i = tid; i < hist_len; i += nthreads) {
-            double v = hist[i];
-            if (v != 0.0) atomicAdd(&ep.iso[hist_slab * hist_len + i], v);
-        }
     }
 }
 

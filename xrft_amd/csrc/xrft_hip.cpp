@@ -284,7 +284,8 @@ struct xrfthip_plan {
     std::vector<Pass> passes;     // main pipeline (field 1 for CROSS)
     std::vector<Pass> passes_f0;  // CROSS: field 0 -> raw F0 buffer
     // workspace layout (byte offsets)
-    size_t off_acc = 0, off_coef = 0, off_w = 0, off_w2 = 0, off_f0 = 0, off_pt = 0, off_rowfit = 0, off_corr = 0, off_isopart = 0, ws_bytes = 0;
+    size_t off_acc = 0, off_coef = 0, off_w = 0, off_w2 = 0, off_f0 = 0, off_pt = 0, off_rowfit = 0, off_corr = 0, off_isopart = 0, off_isotmp = 0, ws_bytes = 0;
+    int iso_chunks = 1;  // workgroups per slab of the generic radial-sum pass (partial sums added in order)
     std::string desc_text;
     // specialised path for real float32 slabs whose two lengths are 256 .. 4096 powers of two (fasty.h)
     bool fast4096 = false;  // (the flag keeps its first name: the headline shape is where the path started)
@@ -477,10 +478,7 @@ struct Builder {
         ps.final_ = true;
     }
 
-    size_t hist_bytes(bool raw) const {
-        if (raw || !(P.d.flags & XRFTHIP_ISO)) return 0;
-        return (size_t)P.nbins * (P.d.out_mode == XRFTHIP_OUT_CROSS ? 16 : 8);
-    }
+    size_t hist_bytes(bool) const { return 0; }  // (radial sums are a pass of their own over the stored spectrum: run_radial_sums)
 
     // ---------------------------------------------------------------- x passes (along the contiguous axis)
     // rows_per_slab = ny (2-D) or 1 (1-D).  `last`: the x transform is the whole transform (1-D).
@@ -835,6 +833,42 @@ static int upload_real_table(xrfthip_plan* P, DevBuf& buf, const double* h, int6
 
 static bool fast_on(const xrfthip_plan* P);
 
+// workgroups per slab of radial_binsum_det_kernel: chunks of <= 2^17 elements (its int64 sums hold 2^17 values), at most 128
+static int iso_chunk_count(long long total) {
+    long long c = std::max<long long>(1, std::min<long long>(128, total / 16384));
+    while ((total + c - 1) / c > (1LL << 17)) ++c;
+    return (int)c;
+}
+// bins per launch: the int64 sums and the exponent table of a window of bins share 64 KB of LDS
+static int iso_bin_window(bool cplx) { return (int)((64 * 1024) / (cplx ? 20 : 12)); }
+
+// radial sums of `bc` stored spectra [bc][ny][nxo] (rows / columns rotated by sy / sx) -> iso[bc][nbins (x2)], bit-reproducible
+static int run_radial_sums(int32_t dtype, const void* spec, const int32_t* d_binmap, long long bc, long long ny, long long nxo, int sy, int sx,
+                           int nbins, int chunks, double* part, double* iso, hipStream_t st) {
+    const bool dbl = dtype == XRFTHIP_F64 || dtype == XRFTHIP_C128, cplx = dtype >= XRFTHIP_C64;
+    const int hw = cplx ? 2 : 1, win = iso_bin_window(cplx);
+    const long long total = ny * nxo;
+    const size_t esz = (dbl ? 8 : 4) * (size_t)hw;
+    for (long long s0 = 0; s0 < bc; s0 += 32768) {  // grid.y limit
+        const long long sc = std::min<long long>(32768, bc - s0);
+        const void* src = (const char*)spec + (size_t)s0 * total * esz;
+        double* pdst = part + (size_t)s0 * chunks * nbins * hw;
+        for (int b0 = 0; b0 < nbins; b0 += win) {
+            const int nb = std::min(win, nbins - b0);
+            const dim3 grid((unsigned)chunks, (unsigned)sc), block(256);
+            const size_t lds = (size_t)nb * (cplx ? 20 : 12);
+#define ISO_(TT, CC) do { auto k = &radial_binsum_det_kernel<TT, CC>; XRFT_LAUNCH(k, grid, block, lds, st, src, (const int*)d_binmap, total, (int)nxo, (int)ny, sy, sx, b0, nb, nbins, pdst); } while (0)
+            if (dbl) { if (cplx) ISO_(double, true); else ISO_(double, false); } else { if (cplx) ISO_(float, true); else ISO_(float, false); }
+#undef ISO_
+        }
+        auto kr = &iso_reduce_kernel;
+        XRFT_LAUNCH(kr, dim3((unsigned)((nbins * hw + 63) / 64), (unsigned)sc), dim3(256), 4 * 64 * sizeof(double), st, (const double*)pdst,
+                    iso + (size_t)s0 * nbins * hw, chunks, nbins * hw);
+    }
+    HIP_TRY(hipGetLastError());
+    return XRFTHIP_OK;
+}
+
 static void layout_workspace(xrfthip_plan* P) {
     const xrfthip_desc& d = P->d;
     const bool fast = fast_on(P);
@@ -873,6 +907,16 @@ static void layout_workspace(xrfthip_plan* P) {
         const long long gx = (P->ynx >= 2048 ? 512 : 256) / (P->ynx / 16);  // YRows<NX>::GX
         const size_t upr = (size_t)P->y_nrow_pad / (two ? gx : 2 * gx);
         off = al(off + (size_t)G * upr * P->nbins * (two ? 2 : 1) * sizeof(double));
+    }
+    P->off_isotmp = off;
+    if (!fast && (d.flags & XRFTHIP_ISO)) {  // generic kernels: the spectrum is stored (into the caller's array, or here), then summed
+        const bool two = d.out_mode == XRFTHIP_OUT_CROSS;
+        const size_t out_esz = two ? P->csize : P->rsize;
+        const long long total = d.ny * P->nx_out;
+        P->iso_chunks = iso_chunk_count(total);
+        if (d.flags & XRFTHIP_NO_SPECTRUM_OUT) off = al(off + (size_t)G * total * out_esz);
+        P->off_isopart = off;
+        off = al(off + (size_t)G * P->iso_chunks * std::max(P->nbins, 1) * (two ? 2 : 1) * sizeof(double));
     }
     P->ws_bytes = off;
 }
@@ -1112,7 +1156,7 @@ static void fasty_launch_rows(const xrfthip_plan* P, const FastY& p, long long g
     if (iso_on) {  // the row workgroups' partial sums, added in order
         rec = prof ? prof_begin(P, "fasty_iso_reduce", st) : nullptr;
         const int nb = P->nbins * hw, upr = P->y_nrow_pad / rpu;
-        auto kr = &fasty_iso_reduce_kernel;
+        auto kr = &iso_reduce_kernel;
         XRFT_LAUNCH(kr, dim3((unsigned)((nb + 63) / 64), (unsigned)gc), dim3(256), 4 * 64 * sizeof(double), st, (const double*)p.iso_part, p.iso, upr, nb);
         prof_end(rec, st);
     }
@@ -1307,6 +1351,7 @@ static int run_pipeline(const xrfthip_plan* P, const std::vector<Pass>& passes, 
                         char* ws, const double* coef, long long g0, long long gc, hipStream_t st) {
     const xrfthip_desc& d = P->d;
     const size_t in_esz = P->cplx_in ? P->csize : P->rsize;
+    const void* iso_src = nullptr;
     for (const Pass& p0 : passes) {
         Pass p = p0;
         p.g.n_outer = p.outer_per_slab * gc;
@@ -1332,17 +1377,13 @@ static int run_pipeline(const xrfthip_plan* P, const std::vector<Pass>& passes, 
         if (p.final_) {
             if (p.out_kind == B_F0) {
                 p.ep.out = buf(B_F0);
-                p.ep.iso = nullptr;
             } else {
                 const size_t out_esz = (d.out_mode == XRFTHIP_OUT_POWER || d.out_mode == XRFTHIP_OUT_PHASE || (d.flags & XRFTHIP_C2R_X)) ? P->rsize : P->csize;
                 p.ep.out = out ? (char*)out + (size_t)g0 * d.ny * P->nx_out * out_esz : nullptr;
+                if ((d.flags & XRFTHIP_ISO) && iso && !out) p.ep.out = ws + P->off_isotmp;  // isotropic spectra: the full spectrum of this group lives in the workspace
+                iso_src = p.ep.out;
                 if (!(d.flags & XRFTHIP_PHASE_IN)) { p.ep.ph_y = P->phase[0].p; p.ep.ph_x = P->phase[1].p; }
                 p.ep.other = (d.out_mode == XRFTHIP_OUT_CROSS || d.out_mode == XRFTHIP_OUT_PHASE) ? buf(B_F0) : nullptr;
-                if (d.flags & XRFTHIP_ISO) {
-                    p.ep.binmap = (const int*)P->binmap.p;
-                    p.ep.nbins = P->nbins;
-                    p.ep.iso = iso + (size_t)g0 * P->nbins * (d.out_mode == XRFTHIP_OUT_CROSS ? 2 : 1);
-                }
             }
         } else {
             p.g.out = buf(p.out_kind);
@@ -1353,6 +1394,16 @@ static int run_pipeline(const xrfthip_plan* P, const std::vector<Pass>& passes, 
         launch_tile<T>(p, grid, st);
         prof_end(rec, st);
         HIP_TRY(hipGetLastError());
+    }
+    if ((d.flags & XRFTHIP_ISO) && iso && iso_src) {  // radial sums of the stored spectrum (xrft.py:895-906), bit-reproducible
+        const bool two = d.out_mode == XRFTHIP_OUT_CROSS;
+        const int32_t sdt = two ? (P->dbl ? XRFTHIP_C128 : XRFTHIP_C64) : (P->dbl ? XRFTHIP_F64 : XRFTHIP_F32);
+        xrfthip_plan::ProfRec* rec = prof_begin(P, "radial_sums", st);
+        const int rc = run_radial_sums(sdt, iso_src, (const int32_t*)P->binmap.p, gc, d.ny, P->nx_out, (d.flags & XRFTHIP_SHIFT_Y) ? (int)(d.ny / 2) : 0,
+                                       (d.flags & XRFTHIP_SHIFT_X) ? (int)(d.nx / 2) : 0, P->nbins, P->iso_chunks, reinterpret_cast<double*>(ws + P->off_isopart),
+                                       iso + (size_t)g0 * P->nbins * (two ? 2 : 1), st);
+        prof_end(rec, st);
+        if (rc) return rc;
     }
     return XRFTHIP_OK;
 }
@@ -1531,7 +1582,7 @@ int xrfthip_plan_set_phase(xrfthip_plan* plan, int axis, const double* h_phase, 
 
 int xrfthip_plan_set_binmap(xrfthip_plan* plan, const int32_t* h_binmap, int64_t ny, int64_t nx_out, int32_t nbins) {
     if (!plan || !h_binmap || !(plan->d.flags & XRFTHIP_ISO)) return XRFTHIP_BAD_ARG;
-    if (ny != plan->d.ny || nx_out != plan->nx_out || nbins < 1 || nbins > 4096) return XRFTHIP_BAD_ARG;
+    if (ny != plan->d.ny || nx_out != plan->nx_out || nbins < 1) return XRFTHIP_BAD_ARG;
     int rc = plan->binmap.upload(h_binmap, (size_t)ny * nx_out * sizeof(int32_t));
     if (rc) return rc;
     plan->nbins = nbins;
@@ -1778,29 +1829,17 @@ int xrfthip_gather_axis(int32_t elem_bytes, int64_t outer, int64_t n_out, int64_
     return XRFTHIP_OK;
 }
 
+size_t xrfthip_isotropize_workspace_bytes(int32_t dtype, int64_t batch, int64_t ny, int64_t nx, int32_t nbins) {
+    if (dtype < XRFTHIP_F32 || dtype > XRFTHIP_C128 || batch < 0 || ny < 1 || nx < 1 || nbins < 1) return 0;
+    return (size_t)batch * iso_chunk_count(ny * nx) * nbins * (dtype >= XRFTHIP_C64 ? 2 : 1) * sizeof(double);
+}
+
 int xrfthip_isotropize(int32_t dtype, int64_t batch, int64_t ny, int64_t nx, const void* d_in,
-                       const int32_t* d_binmap, int32_t nbins, void* d_iso, void* stream) {
-    if (!d_in || !d_binmap || !d_iso || dtype < XRFTHIP_F32 || dtype > XRFTHIP_C128 || batch < 0 || ny < 1 || nx < 1) return XRFTHIP_BAD_ARG;
-    if (nbins < 1 || nbins > 4096) return XRFTHIP_BAD_ARG;
-    hipStream_t st = (hipStream_t)stream;
-    const bool dbl = dtype == XRFTHIP_F64 || dtype == XRFTHIP_C128, cplx = dtype >= XRFTHIP_C64;
-    HIP_TRY(hipMemsetAsync(d_iso, 0, (size_t)batch * nbins * (cplx ? 16 : 8), st));
+                       const int32_t* d_binmap, int32_t nbins, void* d_iso, void* d_workspace, size_t ws_bytes, void* stream) {
+    if (!d_in || !d_binmap || !d_iso || dtype < XRFTHIP_F32 || dtype > XRFTHIP_C128 || batch < 0 || ny < 1 || nx < 1 || nbins < 1) return XRFTHIP_BAD_ARG;
     if (batch == 0) return XRFTHIP_OK;
-    const long long total = ny * nx;
-    const long long chunks = std::max<long long>(1, std::min<long long>(512, total / (256 * 16)));
-    const size_t esz = (dbl ? 8 : 4) * (cplx ? 2 : 1);
-    const size_t lds = (size_t)nbins * (cplx ? 16 : 8);
-    for (long long b0 = 0; b0 < batch; b0 += 32768) {
-        const long long bc = std::min<long long>(32768, batch - b0);
-        const dim3 grid((unsigned)chunks, (unsigned)bc), block(256);
-        const void* src = (const char*)d_in + (size_t)b0 * total * esz;
-        double* dst = (double*)d_iso + (size_t)b0 * nbins * (cplx ? 2 : 1);
-#define ISO_(TT, CC) do { auto k = &radial_binsum_kernel<TT, CC>; XRFT_LAUNCH(k, grid, block, lds, st, src, (const int*)d_binmap, total, (int)nbins, dst); } while (0)
-        if (dbl) { if (cplx) ISO_(double, true); else ISO_(double, false); } else { if (cplx) ISO_(float, true); else ISO_(float, false); }
-#undef ISO_
-        HIP_TRY(hipGetLastError());
-    }
-    return XRFTHIP_OK;
+    if (!d_workspace || ws_bytes < xrfthip_isotropize_workspace_bytes(dtype, batch, ny, nx, nbins)) return XRFTHIP_WORKSPACE_TOO_SMALL;
+    return run_radial_sums(dtype, d_in, d_binmap, batch, ny, nx, 0, 0, nbins, iso_chunk_count(ny * nx), (double*)d_workspace, (double*)d_iso, (hipStream_t)stream);
 }
 
 }  // extern "C"

@@ -243,6 +243,8 @@ def isotropize(x, binmap_dev, nbins):
     batch = x.numel() // max(ny * nx, 1)
     cplx = x.is_complex()
     iso = torch.empty((batch, nbins), dtype=torch.complex128 if cplx else torch.float64, device=x.device)
-    _lib.check(dll.xrfthip_isotropize(_DTYPES[x.dtype], batch, ny, nx, _ptr(x), _ptr(binmap_dev), nbins, _ptr(iso),
+    nws = int(dll.xrfthip_isotropize_workspace_bytes(_DTYPES[x.dtype], batch, ny, nx, nbins))
+    ws = torch.empty(max(nws, 16), dtype=torch.uint8, device=x.device)  # per-workgroup partial sums (added in a fixed order: bit-reproducible)
+    _lib.check(dll.xrfthip_isotropize(_DTYPES[x.dtype], batch, ny, nx, _ptr(x), _ptr(binmap_dev), nbins, _ptr(iso), _ptr(ws), nws,
                                       _stream_handle(x)))
     return iso
