@@ -7,7 +7,7 @@
         bench.py --gpus N --steps K --warmup W
 
 --workload c2 | c4 | c5 runs BASELINE.json configs[1] / [3] / [4] through the same harness (dft along x of (1024, 65536) float32;
-cross_spectrum + isotropic_cross_spectrum of two (nt, 2048, 2048) fields with the all_gather; power_spectrum of (64, 1440, 720)
+cross_spectrum + isotropic_power_spectrum of two (nt, 2048, 2048) fields with the all_gathers; power_spectrum of (64, 1440, 720)
 float64) -- same JSON line, roofline on that configuration's own algorithmic bytes.
 
 One "step" = one call of ``xrft_amd.power_spectrum`` over the rank's whole (nt, ny, nx) cube, input already
@@ -80,8 +80,8 @@ def main(argv=None):
                     help="weak: --nt slabs PER GPU (default); strong: --nt slabs in total, contiguous blocks per rank")
     ap.add_argument("--workload", choices=["ps", "c2", "c4", "c5"], default="ps",
                     help="ps: BASELINE.json configs[2] (power_spectrum, the headline metric); c2: configs[1] -- dft along x of "
-                         "(1024, 65536) float32; c4: configs[3] -- cross_spectrum + isotropic_cross_spectrum of two fields per rank, the "
-                         "isotropic result all-gathered over RCCL; c5: configs[4] -- power_spectrum of (64, 1440, 720) float64, linear detrend + Hann")
+                         "(1024, 65536) float32; c4: configs[3] -- cross_spectrum + isotropic_power_spectrum of two fields per rank, the "
+                         "isotropic results all-gathered over RCCL; c5: configs[4] -- power_spectrum of (64, 1440, 720) float64, linear detrend + Hann")
     ap.add_argument("--emulate", action="store_true", help=argparse.SUPPRESS)  # tests/test_bench_ranks_cpu.py: gloo + the emulated library
     args = ap.parse_args(argv)
 
@@ -162,14 +162,16 @@ def main(argv=None):
     else:
         nbins = min(ny, nx) // 4
         collective = {"op": "all_gather", "backend": "gloo" if emu else "nccl (RCCL over xGMI)",
-                      "bytes_per_rank": int(-(-nt_total // world) * nbins * 16), "per_step": 1}
+                      "bytes_per_rank": int(-(-nt_total // world) * nbins * 16), "per_step": 2}
 
-        def step():  # BASELINE.json configs[3]: cross spectrum (stays sharded) + isotropic cross spectrum (gathered)
+        def step():  # BASELINE.json configs[3]: cross spectrum (stays sharded) + isotropic power spectra of the two fields (gathered)
             cs = xrft.cross_spectrum(da, db, dim=["y", "x"], window="hann")
-            ics = xrft.isotropic_cross_spectrum(da, db, dim=["y", "x"], window="hann")
+            ia = xrft.isotropic_power_spectrum(da, dim=["y", "x"], window="hann")
+            ib = xrft.isotropic_power_spectrum(db, dim=["y", "x"], window="hann")
             if dist is not None:
-                ics = xdist.all_gather_batch(ics, "time", nt_total)
-            return cs, ics
+                ia = xdist.all_gather_batch(ia, "time", nt_total)
+                ib = xdist.all_gather_batch(ib, "time", nt_total)
+            return cs, ia, ib
 
     def barrier():
         if not emu:
@@ -221,14 +223,14 @@ def main(argv=None):
             launches, total_ms = kern[dom]
             avg_s = 1e-3 * total_ms / launches
             launches_per_step = launches / args.steps
-            # c4: two float32 fields in, one complex64 cross spectrum out per point (16 B/point); the
-            # isotropic call reads the two fields again (8 B/point, its output is negligible)
+            # c4: two float32 fields in, one complex64 cross spectrum out per point (16 B/point); the two
+            # isotropic calls read the two fields again (4 B/point each, their output is negligible)
             # c2: float32 in, complex64 out (12 B/point); c5: float64 in, float64 out (16 B/point)
             bpp = {"ps": BYTES_PER_POINT, "c4": 16.0 + 8.0, "c2": 12.0, "c5": 16.0}[args.workload]
             pts_per_launch = float(nt) * ny * nx / max(launches_per_step, 1e-9)
-            # the HIP events cover the LAST plan of the step: the whole step for ps / c2 / c5, the isotropic call (two fields
-            # read, nothing but the radial sums written: 8 B per point of one field) for c4
-            bpp_prof = 8.0 if args.workload == "c4" else bpp
+            # the HIP events cover the LAST plan of the step: the whole step for ps / c2 / c5, one isotropic_power_spectrum call
+            # (one field read, nothing but the radial sums written: 4 B per point) for c4
+            bpp_prof = 4.0 if args.workload == "c4" else bpp
             k_achieved = bpp_prof * pts_per_launch / avg_s
             kernel_ms = sum(v[1] for v in kern.values()) / args.steps
             path_achieved = bpp * value * 1e9 / world  # B/s per GPU
@@ -249,7 +251,7 @@ def main(argv=None):
                 "bound": "hbm", "achieved": round(path_achieved / 1e9, 2), "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                 "frac": round(path_achieved / HBM_PEAK, 4),
                 "definition": {"ps": "algorithmic bytes (8 B per input point: 4 read + 4 written) of one step / wall time of the step, per GPU",
-                               "c4": "algorithmic bytes (cross spectrum 16 B + isotropic cross spectrum 8 B per point of one field) of one "
+                               "c4": "algorithmic bytes (cross spectrum 16 B + two isotropic power spectra 2 x 4 B per point of one field) of one "
                                      "step / wall time of the step, per GPU",
                                "c2": "algorithmic bytes (12 B per point: float32 read + complex64 written) of one step / wall time of the step, per GPU",
                                "c5": "algorithmic bytes (16 B per point: float64 read + float64 written) of one step / wall time of the step, per GPU",
@@ -259,8 +261,8 @@ def main(argv=None):
                            "achieved": round(k_achieved / 1e9, 2), "frac": round(k_achieved / HBM_PEAK, 4),
                            "definition": "algorithmic bytes of the slabs one launch of the longest kernel processes / its average "
                                          "launch duration (HIP events on the launch stream inside the timed region)"
-                                         + (" -- of the isotropic_cross_spectrum call, the plan the events are recorded on: 8 B per point of one field, "
-                                            "one column-pass launch per field" if args.workload == "c4" else "")},
+                                         + (" -- of one isotropic_power_spectrum call, the plan the events are recorded on: 4 B per point"
+                                            if args.workload == "c4" else "")},
                 "bytes_per_point": bpp,
                 "kernels_ms_per_step": {k: round(v[1] / args.steps, 3) for k, v in kern.items()},
                 "sum_kernels_ms_per_step": round(kernel_ms, 3),
@@ -333,10 +335,10 @@ def main(argv=None):
             metric = f"1-D dft GFFT/s (nt,{nx}) fp32"
             par = f"row shards x{world}, no collective"
         else:
-            wl = (f"xrft.cross_spectrum + xrft.isotropic_cross_spectrum window=hann on two ({nt},{ny},{nx}) float32 fields per GPU "
-                  f"(BASELINE.json configs[3]); GFFT/s counts the points of one field")
-            metric = f"2-D cross_spectrum + isotropic_cross_spectrum GFFT/s (nt,{ny},{nx}) fp32"
-            par = f"time-slab shards x{world}; full cross spectra stay sharded, one all_gather of the ({nt_total}, {min(ny, nx) // 4}) isotropic result per step"
+            wl = (f"xrft.cross_spectrum + xrft.isotropic_power_spectrum (of each field) window=hann on two ({nt},{ny},{nx}) float32 fields "
+                  f"per GPU (BASELINE.json configs[3]); GFFT/s counts the points of one field")
+            metric = f"2-D cross_spectrum + isotropic_power_spectrum GFFT/s (nt,{ny},{nx}) fp32"
+            par = f"time-slab shards x{world}; full cross spectra stay sharded, one all_gather of the ({nt_total}, {min(ny, nx) // 4}) isotropic result per field and step"
         out = {
             "metric": metric, "value": round(value, 3), "unit": "GFFT/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),

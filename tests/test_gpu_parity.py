@@ -514,6 +514,13 @@ def test_random_fastp2_differential(seed):
     run_random_fast(seed)
 
 
+@pytest.mark.parametrize("seed", range(40))
+def test_random_fastm_differential(seed):
+    from test_random_differential import run_random_fastm
+
+    run_random_fastm(seed)
+
+
 def test_concurrent_threads_and_streams():
     """Four host threads, each on its own HIP stream, share one cached plan (a workspace per stream, one enqueue at a time)."""
     import threading
