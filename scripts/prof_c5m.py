@@ -32,6 +32,7 @@ for shp in shapes:
     print("   ", pl.describe().strip().split("\n")[1][:300])
     if os.environ.get("ONLY_LINEAR"): continue
     prof(f"fft f64 linear hann {shp}", lambda: xrft.fft(da, dim=["lat", "lon"], detrend="linear", window="hann"), shp[0], x.numel())
+    prof(f"isotropic PS f64 linear hann {shp}", lambda: xrft.isotropic_power_spectrum(da, dim=["lat", "lon"], detrend="linear", window="hann"), shp[0], x.numel())
     prof(f"cross f64 linear hann {shp}", lambda: xrft.cross_spectrum(da, db, dim=["lat", "lon"], detrend="linear", window="hann"), shp[0], x.numel())
     del x, y, da, db
     torch.cuda.empty_cache()

@@ -543,6 +543,16 @@ def run_fastm_cases(shape=(2, 360, 360), full=True, cross=True):
     for kw in (dict(window="hann", detrend="linear"), dict(true_phase=False, scaling="spectrum", shift=False)):
         worst = max(worst, check(xa.cross_spectrum(da, db, dim=["y", "x"], **kw), o.cross_spectrum(od, ob, dim=["y", "x"], **kw), tol))
         assert on_fastm()
+    # isotropic spectra (doc/MITgcm_example.ipynb: isotropic_powerspectrum with detrend='linear', window=True): the spectrum is
+    # stored by the same kernels and summed by the bit-reproducible radial pass
+    kwi = dict(dim=["y", "x"], detrend="linear", window="hann")
+    ips = xa.isotropic_power_spectrum(da, **kwi)
+    assert on_fastm()
+    worst = max(worst, check(ips, o.isotropic_power_spectrum(od, **kwi), tol))
+    assert np.array_equal(xa.isotropic_power_spectrum(da, **kwi).values, ips.values)
+    ics = xa.isotropic_cross_spectrum(da, db, **kwi)
+    assert on_fastm()
+    worst = max(worst, check(ics, o.isotropic_cross_spectrum(od, ob, **kwi), tol))
     g = xa.cross_phase(da, db, dim=["y", "x"], detrend="constant")
     r = o.cross_phase(od, ob, dim=["y", "x"], detrend="constant")
     dphi = np.abs(np.angle(np.exp(1j * (g.values - r.values))))

@@ -263,7 +263,7 @@ __global__ void __launch_bounds__(256) gather_axis_kernel(const E* in, E* out, l
 // and added with INTEGER atomics (exact, order-independent).  The chunk's sums go to part[slab][chunk][bin]; the chunks are
 // added in order by iso_reduce_kernel.  Bins outside [b0, b0 + nb) are skipped (a window of the bins per launch when the
 // tables do not fit the LDS).  The spectrum is stored with rows / columns rotated by sy / sx (fftshift); binmap is indexed by
-// unshifted frequencies.  A chunk holds <= 2^17 elements: |sum| < 2^(FR + 1 + 17) = 2^62.
+// unshifted frequencies.  A chunk holds <= 2^17 elements: |sum| < 2^(FR + 1 + 17) = 2^62 (also summed over the copies).
 constexpr int kIsoFR = 44;
 __device__ __forceinline__ long long iso_fixed(double v, int eb) {
     const unsigned long long bits = (unsigned long long)__double_as_longlong(v);
@@ -275,50 +275,85 @@ __device__ __forceinline__ long long iso_fixed(double v, int eb) {
     return (bits >> 63) ? -q : q;
 }
 
+// Neighbouring samples of a row mostly fall into the same radial bin (a 64-lane wave touches ~4 bins at 1440 x 720: 16-way
+// serialised LDS atomics), so the tables exist in `ncopy` copies (a power of two, as many as fit 64 KB), lane l uses copy
+// l % ncopy; the copies' maxima are merged before the second sweep, their (exact, integer) sums after it.
 template <typename T, bool CPLX>
 __global__ void __launch_bounds__(256) radial_binsum_det_kernel(const void* in, const int* __restrict__ binmap, long long total, int nxo, int ny,
-                                                                int sy, int sx, int b0, int nb, int nbins, double* part) {
+                                                                int sy, int sx, int b0, int nb, int nbins, int ncopy, double* part) {
     XRFT_DYN_SMEM(smem_raw);
     constexpr int HW = CPLX ? 2 : 1;
-    unsigned long long* acc = reinterpret_cast<unsigned long long*>(smem_raw);  // [nb][HW]
-    unsigned* bmax = reinterpret_cast<unsigned*>(acc + (size_t)nb * HW);          // [nb]: high word of the largest magnitude
-    for (int i = threadIdx.x; i < nb * HW; i += blockDim.x) acc[i] = 0ull;
-    for (int i = threadIdx.x; i < nb; i += blockDim.x) bmax[i] = 0u;
+    unsigned long long* acc_all = reinterpret_cast<unsigned long long*>(smem_raw);       // [ncopy][nb][HW]
+    unsigned* bmax_all = reinterpret_cast<unsigned*>(acc_all + (size_t)ncopy * nb * HW);  // [ncopy][nb]: high word of the largest magnitude
+    for (int i = threadIdx.x; i < ncopy * nb * HW; i += blockDim.x) acc_all[i] = 0ull;
+    for (int i = threadIdx.x; i < ncopy * nb; i += blockDim.x) bmax_all[i] = 0u;
+    const int cp = (int)(threadIdx.x & (unsigned)(ncopy - 1));
+    unsigned long long* acc = acc_all + (size_t)cp * nb * HW;
+    unsigned* bmax = bmax_all + (size_t)cp * nb;
     __syncthreads();
     const long long b = blockIdx.y;
     const long long per = (total + gridDim.x - 1) / gridDim.x;
     const long long e0 = (long long)blockIdx.x * per;
     const long long e1 = e0 + per < total ? e0 + per : total;
     const T* __restrict__ src = reinterpret_cast<const T*>(in) + b * total * HW;
-    auto bin_of = [&](long long e) -> int {
-        int r = (int)(e / nxo), c = (int)(e - (long long)r * nxo);
+    // (row, column) of the thread's first sample by one division, then advanced by the block size: no division per sample
+    const long long ef = e0 + threadIdx.x;
+    const int rf = (int)(ef / nxo), cf = (int)(ef - (long long)rf * nxo), step_r = (int)(blockDim.x / nxo), step_c = (int)(blockDim.x % nxo);
+    auto bin_at = [&](int r, int c) -> int {  // r, c: storage position; the map is indexed by unshifted frequencies
         r -= sy; if (r < 0) r += ny;
         c -= sx; if (c < 0) c += nxo;
         const int bin = binmap[(long long)r * nxo + c] - b0;
         return (bin >= 0 && bin < nb) ? bin : -1;
     };
-    for (long long e = e0 + threadIdx.x; e < e1; e += blockDim.x) {
-        const int bin = bin_of(e);
-        if (bin < 0) continue;
-        const double mag = CPLX ? fabs((double)src[2 * e]) + fabs((double)src[2 * e + 1]) : fabs((double)src[e]);
-        atomicMax(&bmax[bin], (unsigned)((unsigned long long)__double_as_longlong(mag) >> 32));
-    }
-    __syncthreads();
-    for (long long e = e0 + threadIdx.x; e < e1; e += blockDim.x) {
-        const int bin = bin_of(e);
-        if (bin < 0) continue;
-        const int eb = (int)(bmax[bin] >> 20);  // biased exponent of the bound: |v| <= mag < 2^(eb - 1022)
-        if (CPLX) {
-            atomicAdd(&acc[2 * bin], (unsigned long long)iso_fixed((double)src[2 * e], eb));
-            atomicAdd(&acc[2 * bin + 1], (unsigned long long)iso_fixed((double)src[2 * e + 1], eb));
-        } else {
-            atomicAdd(&acc[bin], (unsigned long long)iso_fixed((double)src[e], eb));
+    // both sweeps in batches of U samples per thread: the U bin-map loads and the U value loads of a batch are independent and in
+    // flight together (one sample at a time, map load -> value load, the kernel was latency-bound: 5.5 us per 1440 x 720 slab)
+    constexpr int U = 8;
+    for (int sweep = 0; sweep < 2; ++sweep) {
+        int r = rf, c = cf;
+        for (long long eb0 = ef; eb0 < e1; eb0 += (long long)U * blockDim.x) {
+            int bins[U];
+            double vr[U], vi[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const long long e = eb0 + (long long)u * blockDim.x;
+                bins[u] = -1; vr[u] = 0.0; vi[u] = 0.0;
+                if (e < e1) {
+                    bins[u] = bin_at(r, c);
+                    if (CPLX) { vr[u] = (double)src[2 * e]; vi[u] = (double)src[2 * e + 1]; } else vr[u] = (double)src[e];
+                }
+                r += step_r; c += step_c;
+                if (c >= nxo) { c -= nxo; ++r; }
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int bin = bins[u];
+                if (bin < 0) continue;
+                if (sweep == 0) {
+                    const double mag = CPLX ? fabs(vr[u]) + fabs(vi[u]) : fabs(vr[u]);
+                    atomicMax(&bmax[bin], (unsigned)((unsigned long long)__double_as_longlong(mag) >> 32));
+                } else {
+                    const int eb = (int)(bmax_all[bin] >> 20);  // biased exponent of the bound: |v| <= mag < 2^(eb - 1022)
+                    atomicAdd(&acc[HW * bin], (unsigned long long)iso_fixed(vr[u], eb));
+                    if (CPLX) atomicAdd(&acc[2 * bin + 1], (unsigned long long)iso_fixed(vi[u], eb));
+                }
+            }
+        }
+        __syncthreads();
+        if (sweep == 0 && ncopy > 1) {  // one bound per bin for every copy: the maximum over the copies, kept in copy 0
+            for (int i = threadIdx.x; i < nb; i += blockDim.x) {
+                unsigned m = bmax_all[i];
+                for (int k = 1; k < ncopy; ++k) m = max(m, bmax_all[(size_t)k * nb + i]);
+                bmax_all[i] = m;
+            }
+            __syncthreads();
         }
     }
-    __syncthreads();
     double* dst = part + ((size_t)b * gridDim.x + blockIdx.x) * (size_t)nbins * HW + (size_t)b0 * HW;
-    for (int i = threadIdx.x; i < nb * HW; i += blockDim.x)
-        dst[i] = ldexp((double)(long long)acc[i], (int)(bmax[i / HW] >> 20) - 1023 - kIsoFR);
+    for (int i = threadIdx.x; i < nb * HW; i += blockDim.x) {
+        long long sum = 0;
+        for (int k = 0; k < ncopy; ++k) sum += (long long)acc_all[(size_t)k * nb * HW + i];
+        dst[i] = ldexp((double)sum, (int)(bmax_all[i / HW] >> 20) - 1023 - kIsoFR);
+    }
 }
 
 // iso[slab][bin] = sum over the partial tables of the slab's units in a FIXED order (bit-reproducible): 256 threads = 4 segments

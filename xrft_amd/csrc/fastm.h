@@ -74,6 +74,9 @@ struct FastM {
     const void* ph_x;
     const void* what0;   // FFT_y(wy)[ky], ky < nrow_pad (complex T)
     const void* what1;   // FFT_y(wy (i - ibar))[ky]
+    const int* binmap;   // radial sums fused into pass 2 (ISO): bin of (ky, kx), unshifted indices, [ny][nx]; < 0 = none
+    double* iso_part;    // [slab][row workgroup][nbins (x2 complex)]: per-workgroup sums, reduced in order by iso_reduce_kernel
+    int nbins, iso_ncopy;
     int ph_on;
     int ny, nx, nrow_pad;
     int l_cw, l_rk;      // log2 of CW and RK
@@ -269,8 +272,10 @@ __global__ void __launch_bounds__((MGeom<T, NY>::THR), (MGeom<T, NY>::WPS)) fast
 // sequences are rows of field 0, the others the same rows of field 1: F0 conj(F1) is formed on the way out).
 //   xrft.py:446-447 (fftshift), :462-469 (true phase), :740-748 / :825-833 (|F|^2, F0 conj F1 and the scalings, in `scale`)
 // ------------------------------------------------------------------------------------------------
-template <typename T, int NX, int MODE>
+//   xrft.py:895-906 (ISO: radial sums, here bit-reproducible: per-bin exponent bound by atomicMax, int64 fixed-point adds; aux_kernels.h)
+template <typename T, int NX, int MODE, bool ISO = false>
 __global__ void __launch_bounds__((MGeom<T, NX>::THR), (MGeom<T, NX>::WPS)) fastm_rows_kernel(FastM p) {
+    static_assert(!ISO || MODE == 1 || MODE == 2, "radial sums exist for power and cross spectra");
     typedef MGeom<T, NX> M;
     typedef C2<T> CT;
     constexpr bool TWO = MODE >= 2;
@@ -318,14 +323,91 @@ __global__ void __launch_bounds__((MGeom<T, NX>::THR), (MGeom<T, NX>::WPS)) fast
     }
     if (on) mr_pass0<T, NX>(a, lds + t * STR, j, w0);
     mr_fft_tail<T, NX, G, THR>(lds, tid, tw1);
+    const int sx = p.shift_x, sy = p.shift_y;
+    const T sc = (T)p.scale;
+    if (ISO) {
+        // Radial sums of this workgroup's samples -- rows ky0.. and their Hermitian mirrors -- straight from the spectra in LDS: two
+        // sweeps (largest exponent per bin, then integer fixed-point adds: exact, so the order in which lanes arrive does not
+        // matter), the sums go to this workgroup's row of the partial table.  The tables sit behind the twiddle table.
+        constexpr int HW = MODE == 2 ? 2 : 1, NIT = (RPU * NX + THR - 1) / THR;
+        const int nc = p.iso_ncopy, nbn = p.nbins;  // copies of the tables (lane l uses copy l % nc: neighbouring samples share bins)
+        unsigned long long* acc_all = reinterpret_cast<unsigned long long*>(tw1 + M::M0);  // [nc][nbins][HW]
+        unsigned* bmax_all = reinterpret_cast<unsigned*>(acc_all + (size_t)nc * nbn * HW);   // [nc][nbins]
+        unsigned long long* acc = acc_all + (size_t)(tid & (nc - 1)) * nbn * HW;
+        unsigned* bmax = bmax_all + (size_t)(tid & (nc - 1)) * nbn;
+        for (int i = tid; i < nc * nbn * HW; i += THR) acc_all[i] = 0ull;
+        for (int i = tid; i < nc * nbn; i += THR) bmax_all[i] = 0u;
+        // a thread's samples: (row r, kx) and its mirror (-ky, -kx); their bins first, all loads in flight together
+        int bd[NIT], bm[NIT];
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int e = tid + it * THR, r = e / NX, kx = e % NX, ky = ky0 + r;
+            bd[it] = -1; bm[it] = -1;
+            if (e < RPU * NX && ky <= nyh) {
+                bd[it] = p.binmap[(size_t)ky * NX + kx];
+                if (ky != 0 && 2 * ky != p.ny) bm[it] = p.binmap[(size_t)(p.ny - ky) * NX + (kx == 0 ? 0 : NX - kx)];
+            }
+        }
+        __syncthreads();
+        for (int sweep = 0; sweep < 2; ++sweep) {
+#pragma unroll
+            for (int it = 0; it < NIT; ++it) {
+                if (bd[it] < 0 && bm[it] < 0) continue;
+                const int e = tid + it * THR, r = e / NX, kx = e % NX, ky = ky0 + r;
+                CT va = lds[r * STR + M::pn(kx)];
+                double dr, di = 0.0, mr = 0.0, mi = 0.0;  // direct and mirrored value
+                if (MODE == 1) {
+                    dr = (double)((va.re * va.re + va.im * va.im) * sc);
+                    mr = dr;
+                } else {
+                    va = cscale(cmulc(va, lds[(RPU + r) * STR + M::pn(kx)]), sc);
+                    CT vm = cconj(va);
+                    if (p.ph_on) {
+                        va = cmul(va, cmul(reinterpret_cast<const CT*>(p.ph_y)[ky], reinterpret_cast<const CT*>(p.ph_x)[kx]));
+                        vm = cmul(vm, cmul(reinterpret_cast<const CT*>(p.ph_y)[ky == 0 ? 0 : p.ny - ky], reinterpret_cast<const CT*>(p.ph_x)[kx == 0 ? 0 : NX - kx]));
+                    }
+                    dr = (double)va.re; di = (double)va.im; mr = (double)vm.re; mi = (double)vm.im;
+                }
+                const bool same = MODE == 1 && bd[it] == bm[it];  // (a power spectrum's two samples are equal: one add of twice the value)
+                if (sweep == 0) {
+                    if (bd[it] >= 0) atomicMax(&bmax[bd[it]], (unsigned)((unsigned long long)__double_as_longlong(fabs(dr) + fabs(di)) >> 32));
+                    if (bm[it] >= 0 && !same) atomicMax(&bmax[bm[it]], (unsigned)((unsigned long long)__double_as_longlong(fabs(mr) + fabs(mi)) >> 32));
+                } else {
+                    if (bd[it] >= 0) {
+                        const int eb = (int)(bmax_all[bd[it]] >> 20);
+                        atomicAdd(&acc[HW * bd[it]], (unsigned long long)(iso_fixed(dr, eb) * (same ? 2 : 1)));
+                        if (MODE == 2) atomicAdd(&acc[2 * bd[it] + 1], (unsigned long long)iso_fixed(di, eb));
+                    }
+                    if (bm[it] >= 0 && !same) {
+                        const int eb = (int)(bmax_all[bm[it]] >> 20);
+                        atomicAdd(&acc[HW * bm[it]], (unsigned long long)iso_fixed(mr, eb));
+                        if (MODE == 2) atomicAdd(&acc[2 * bm[it] + 1], (unsigned long long)iso_fixed(mi, eb));
+                    }
+                }
+            }
+            __syncthreads();
+            if (sweep == 0) {  // one bound per bin: the maximum over the copies, kept in copy 0
+                for (int i = tid; i < nbn; i += THR) {
+                    unsigned m = bmax_all[i];
+                    for (int k = 1; k < nc; ++k) m = max(m, bmax_all[(size_t)k * nbn + i]);
+                    bmax_all[i] = m;
+                }
+                __syncthreads();
+            }
+        }
+        double* __restrict__ part = p.iso_part + ((size_t)slab * upr + unit) * nbn * HW;
+        for (int i = tid; i < nbn * HW; i += THR) {
+            long long sum = 0;
+            for (int k = 0; k < nc; ++k) sum += (long long)acc_all[(size_t)k * nbn * HW + i];
+            part[i] = ldexp((double)sum, (int)(bmax_all[i / HW] >> 20) - 1023 - kIsoFR);
+        }
+    }
     if (p.out == nullptr) return;
     // ---- the result leaves as whole rows, 16 bytes per lane and store: VW samples
     typedef typename std::conditional<MODE == 0 || MODE == 2, CT, T>::type OutT;
     constexpr int VW = 16 / (int)sizeof(OutT), CPR = NX / VW;
     static_assert(NX % VW == 0, "row length");
     OutT* __restrict__ outs = reinterpret_cast<OutT*>(p.out) + (size_t)slab * p.ny * NX;
-    const int sx = p.shift_x, sy = p.shift_y;
-    const T sc = (T)p.scale;
     for (int e = tid; e < RPU * 2 * CPR; e += THR) {
         const int chunk = e % CPR, rr = e / CPR, r = rr >> 1, mir = rr & 1;
         const int ky = ky0 + r;

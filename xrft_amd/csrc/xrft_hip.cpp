@@ -832,6 +832,8 @@ static int upload_real_table(xrfthip_plan* P, DevBuf& buf, const double* h, int6
 }
 
 static bool fast_on(const xrfthip_plan* P);
+static bool fastm_iso_fused(const xrfthip_plan* P);
+static int fastm_rpu(long long nx, bool two);
 
 // workgroups per slab of radial_binsum_det_kernel: chunks of <= 2^17 elements (its int64 sums hold 2^17 values), at most 128
 static int iso_chunk_count(long long total) {
@@ -856,8 +858,10 @@ static int run_radial_sums(int32_t dtype, const void* spec, const int32_t* d_bin
         for (int b0 = 0; b0 < nbins; b0 += win) {
             const int nb = std::min(win, nbins - b0);
             const dim3 grid((unsigned)chunks, (unsigned)sc), block(256);
-            const size_t lds = (size_t)nb * (cplx ? 20 : 12);
-#define ISO_(TT, CC) do { auto k = &radial_binsum_det_kernel<TT, CC>; XRFT_LAUNCH(k, grid, block, lds, st, src, (const int*)d_binmap, total, (int)nxo, (int)ny, sy, sx, b0, nb, nbins, pdst); } while (0)
+            int ncopy = 1;  // copies of the tables (lanes spread over them: neighbouring samples share bins), as many as fit 32 KB
+            while (ncopy < 8 && (size_t)nb * (cplx ? 20 : 12) * (2 * ncopy) <= 32 * 1024) ncopy *= 2;
+            const size_t lds = (size_t)nb * (cplx ? 20 : 12) * ncopy;
+#define ISO_(TT, CC) do { auto k = &radial_binsum_det_kernel<TT, CC>; XRFT_LAUNCH(k, grid, block, lds, st, src, (const int*)d_binmap, total, (int)nxo, (int)ny, sy, sx, b0, nb, nbins, ncopy, pdst); } while (0)
             if (dbl) { if (cplx) ISO_(double, true); else ISO_(double, false); } else { if (cplx) ISO_(float, true); else ISO_(float, false); }
 #undef ISO_
         }
@@ -902,14 +906,18 @@ static void layout_workspace(xrfthip_plan* P) {
     P->off_rowfit = off; if (fast) off = al(off + (size_t)G * nfit * 2 * sizeof(double) * (yf ? nf : 1));
     P->off_corr = off; if (fast) off = al(off + (size_t)G * nfit * 2 * sizeof(float) * (yf ? nf : 1));  // (16 bytes per column: fasty uses 8, fastm's float64 pairs all 16)
     P->off_isopart = off;
-    if (yf && (d.flags & XRFTHIP_ISO)) {  // per-workgroup partial radial sums of one group of slabs (reduced in order)
+    if (yf && !P->fastm && (d.flags & XRFTHIP_ISO)) {  // per-workgroup partial radial sums of one group of slabs (reduced in order)
         const bool two = d.out_mode == XRFTHIP_OUT_CROSS;
         const long long gx = (P->ynx >= 2048 ? 512 : 256) / (P->ynx / 16);  // YRows<NX>::GX
         const size_t upr = (size_t)P->y_nrow_pad / (two ? gx : 2 * gx);
         off = al(off + (size_t)G * upr * P->nbins * (two ? 2 : 1) * sizeof(double));
     }
     P->off_isotmp = off;
-    if (!fast && (d.flags & XRFTHIP_ISO)) {  // generic kernels: the spectrum is stored (into the caller's array, or here), then summed
+    if (fastm_iso_fused(P)) {  // fastm with the radial sums inside pass 2: one partial table per row workgroup
+        const bool two = d.out_mode == XRFTHIP_OUT_CROSS;
+        P->off_isopart = off;
+        off = al(off + (size_t)G * (P->y_nrow_pad / fastm_rpu(P->ynx, two)) * P->nbins * (two ? 2 : 1) * sizeof(double));
+    } else if ((!fast || P->fastm) && (d.flags & XRFTHIP_ISO)) {  // generic and fastm kernels: the spectrum is stored (into the caller's array, or here), then summed
         const bool two = d.out_mode == XRFTHIP_OUT_CROSS;
         const size_t out_esz = two ? P->csize : P->rsize;
         const long long total = d.ny * P->nx_out;
@@ -1243,6 +1251,22 @@ static int fastm_cw(long long ny) { return 2 * mgeom(ny).g; }
 static int fastm_rk(long long ny) { const int cw = fastm_cw(ny); return cw * 16 >= 128 ? 1 : 128 / (cw * 16); }
 static int fastm_rpu(long long nx, bool two) { const int g = mgeom(nx).g; return two ? g / 2 : g; }
 
+// radial sums inside pass 2 when the per-bin tables fit behind the transforms' LDS (64 KB of dynamic LDS per workgroup); otherwise
+// the spectrum is stored and summed by run_radial_sums
+static bool fastm_iso_fused(const xrfthip_plan* P) {
+    if (!P->fastm || !(P->d.flags & XRFTHIP_ISO) || P->nbins < 1) return false;
+    const bool cx = P->d.out_mode == XRFTHIP_OUT_CROSS;
+    return mgeom(P->ynx).lds_rows + (size_t)P->nbins * (cx ? 20 : 12) <= 64 * 1024;
+}
+
+// copies of the per-bin tables in pass 2 (a power of two <= 8, whatever fits the 64 KB)
+static int fastm_iso_ncopy(const xrfthip_plan* P) {
+    const size_t per = (size_t)P->nbins * (P->d.out_mode == XRFTHIP_OUT_CROSS ? 20 : 12), room = 64 * 1024 - mgeom(P->ynx).lds_rows;
+    int nc = 1;
+    while (nc < 8 && per * (size_t)(2 * nc) <= room) nc *= 2;
+    return nc;
+}
+
 static FastM fastm_params(const xrfthip_plan* P, const void* in, void* out, char* ws, long long g0, long long gc, int slot, long long slot_slabs) {
     const xrfthip_desc& d = P->d;
     const size_t slab_pts = (size_t)P->yny * P->ynx, s0 = (size_t)slot * slot_slabs;
@@ -1258,6 +1282,8 @@ static FastM fastm_params(const xrfthip_plan* P, const void* in, void* out, char
     p.corr = reinterpret_cast<const C2<double>*>(ws + P->off_corr) + s0 * (size_t)P->ynx;
     p.ph_y = P->fph[0].p; p.ph_x = P->fph[1].p; p.ph_on = P->fph_on ? 1 : 0;
     p.what0 = P->ywhat0.p; p.what1 = P->ywhat1.p;
+    p.binmap = (const int*)P->binmap.p; p.nbins = P->nbins; p.iso_ncopy = P->nbins > 0 ? fastm_iso_ncopy(P) : 1;
+    p.iso_part = reinterpret_cast<double*>(ws + P->off_isopart);
     p.ny = (int)P->yny; p.nx = (int)P->ynx; p.nrow_pad = P->y_nrow_pad;
     p.l_cw = ilog2i(fastm_cw(P->yny)); p.l_rk = ilog2i(fastm_rk(P->yny));
     p.detrend = d.detrend; p.nslab = (int)gc;
@@ -1293,9 +1319,11 @@ static void fastm_launch_rows(const xrfthip_plan* P, const FastM& p, long long g
     const bool two = d.out_mode == XRFTHIP_OUT_CROSS || d.out_mode == XRFTHIP_OUT_PHASE;
     xrfthip_plan::ProfRec* rec = prof_begin(P, "fastm_rows", st);
     const dim3 grid((unsigned)(gc * (P->y_nrow_pad / fastm_rpu(P->ynx, two)))), blk((unsigned)R.thr);
+    const bool fused = fastm_iso_fused(P);
+    const size_t lds_iso = R.lds_rows + (size_t)P->nbins * (d.out_mode == XRFTHIP_OUT_CROSS ? 20 : 12) * (size_t)p.iso_ncopy;
 #define MR_(NN) do { \
-        if (d.out_mode == XRFTHIP_OUT_POWER) { auto k = &fastm_rows_kernel<double, NN, 1>; XRFT_LAUNCH(k, grid, blk, R.lds_rows, st, p); } \
-        else if (d.out_mode == XRFTHIP_OUT_CROSS) { auto k = &fastm_rows_kernel<double, NN, 2>; XRFT_LAUNCH(k, grid, blk, R.lds_rows, st, p); } \
+        if (d.out_mode == XRFTHIP_OUT_POWER) { if (fused) { auto k = &fastm_rows_kernel<double, NN, 1, true>; XRFT_LAUNCH(k, grid, blk, lds_iso, st, p); } else { auto k = &fastm_rows_kernel<double, NN, 1>; XRFT_LAUNCH(k, grid, blk, R.lds_rows, st, p); } } \
+        else if (d.out_mode == XRFTHIP_OUT_CROSS) { if (fused) { auto k = &fastm_rows_kernel<double, NN, 2, true>; XRFT_LAUNCH(k, grid, blk, lds_iso, st, p); } else { auto k = &fastm_rows_kernel<double, NN, 2>; XRFT_LAUNCH(k, grid, blk, R.lds_rows, st, p); } } \
         else if (d.out_mode == XRFTHIP_OUT_PHASE) { auto k = &fastm_rows_kernel<double, NN, 3>; XRFT_LAUNCH(k, grid, blk, R.lds_rows, st, p); } \
         else { auto k = &fastm_rows_kernel<double, NN, 0>; XRFT_LAUNCH(k, grid, blk, R.lds_rows, st, p); } } while (0)
     if (P->ynx == 1440) MR_(1440); else if (P->ynx == 720) MR_(720); else MR_(360);
@@ -1303,12 +1331,15 @@ static void fastm_launch_rows(const xrfthip_plan* P, const FastM& p, long long g
     prof_end(rec, st);
 }
 
-static int run_fastm(const xrfthip_plan* P, const void* in, const void* in1, void* out, char* ws, hipStream_t st) {
+static int run_fastm(const xrfthip_plan* P, const void* in, const void* in1, void* out, double* iso, char* ws, hipStream_t st) {
     const xrfthip_desc& d = P->d;
     const bool two = d.out_mode == XRFTHIP_OUT_CROSS || d.out_mode == XRFTHIP_OUT_PHASE;
+    const bool iso_on = (d.flags & XRFTHIP_ISO) != 0;
     for (long long g0 = 0; g0 < d.batch; g0 += P->G) {
         const long long gc = std::min<long long>(P->G, d.batch - g0);
         FastM p = fastm_params(P, in, out, ws, g0, gc, 0, P->G);
+        const bool fused = fastm_iso_fused(P);
+        if (iso_on && !out && !fused) p.out = ws + P->off_isotmp;  // radial sums from the stored spectrum: the group's spectrum lives in the workspace
         fastm_launch_cols(P, p, gc, st);
         if (two) {
             const FastM p1 = fastm_params(P, in1, out, ws, g0, gc, 1, P->G);
@@ -1318,6 +1349,22 @@ static int run_fastm(const xrfthip_plan* P, const void* in, const void* in1, voi
         }
         fastm_launch_rows(P, p, gc, st);
         HIP_TRY(hipGetLastError());
+        if (iso_on && fused) {  // the row workgroups' partial sums, added in order
+            const int hw = d.out_mode == XRFTHIP_OUT_CROSS ? 2 : 1, nb = P->nbins * hw, upr = P->y_nrow_pad / fastm_rpu(P->ynx, two);
+            xrfthip_plan::ProfRec* rec = prof_begin(P, "iso_reduce", st);
+            auto kr = &iso_reduce_kernel;
+            XRFT_LAUNCH(kr, dim3((unsigned)((nb + 63) / 64), (unsigned)gc), dim3(256), 4 * 64 * sizeof(double), st, (const double*)p.iso_part,
+                        iso + (size_t)g0 * nb, upr, nb);
+            prof_end(rec, st);
+            HIP_TRY(hipGetLastError());
+        } else if (iso_on) {  // radial sums of the stored spectrum (xrft.py:895-906), bit-reproducible
+            const bool cx = d.out_mode == XRFTHIP_OUT_CROSS;
+            xrfthip_plan::ProfRec* rec = prof_begin(P, "radial_sums", st);
+            const int rc = run_radial_sums(cx ? XRFTHIP_C128 : XRFTHIP_F64, p.out, (const int32_t*)P->binmap.p, gc, d.ny, d.nx, p.shift_y, p.shift_x, P->nbins,
+                                           P->iso_chunks, reinterpret_cast<double*>(ws + P->off_isopart), iso + (size_t)g0 * P->nbins * (cx ? 2 : 1), st);
+            prof_end(rec, st);
+            if (rc) return rc;
+        }
     }
     return XRFTHIP_OK;
 }
@@ -1523,7 +1570,9 @@ int xrfthip_plan_create(xrfthip_plan** plan, const xrfthip_desc* desc) {
     }
     {   // real float64 slabs on the regular lat/lon lengths: the mixed-radix form of the y-first pipeline (fastm.h)
         const uint32_t shifts = XRFTHIP_SHIFT_Y | XRFTHIP_SHIFT_X, ish = XRFTHIP_ISHIFT_Y | XRFTHIP_ISHIFT_X;
-        const uint32_t allowed = d.out_mode == XRFTHIP_OUT_POWER ? shifts : (d.out_mode == XRFTHIP_OUT_COMPLEX || d.out_mode == XRFTHIP_OUT_CROSS || d.out_mode == XRFTHIP_OUT_PHASE) ? (shifts | ish) : 0u;
+        const uint32_t isof = XRFTHIP_ISO | XRFTHIP_NO_SPECTRUM_OUT;  // radial sums: a bit-reproducible pass over the stored spectrum (run_radial_sums)
+        const uint32_t allowed = d.out_mode == XRFTHIP_OUT_POWER ? (shifts | isof) : d.out_mode == XRFTHIP_OUT_CROSS ? (shifts | ish | isof)
+                                 : (d.out_mode == XRFTHIP_OUT_COMPLEX || d.out_mode == XRFTHIP_OUT_PHASE) ? (shifts | ish) : 0u;
         P->fastm = d.ndim == 2 && d.dtype == XRFTHIP_F64 && fastm_len(d.ny) && fastm_len(d.nx) && !(d.flags & ~allowed) &&
                    !env_ll("XRFTHIP_NO_FAST", 0) && env_ll("XRFTHIP_FASTM", 1) != 0;
         if (P->fastm) {
@@ -1683,7 +1732,7 @@ int xrfthip_exec(const xrfthip_plan* plan, const void* d_in0, const void* d_in1,
     double* acc = (double*)(ws + P->off_acc);
     double* coef = (double*)(ws + P->off_coef);
     if (iso) HIP_TRY(hipMemsetAsync(d_iso, 0, (size_t)d.batch * P->nbins * (cross ? 16 : 8), st));
-    if (P->fastm) return run_fastm(P, d_in0, d_in1, out, ws, st);
+    if (P->fastm) return run_fastm(P, d_in0, d_in1, out, (double*)d_iso, ws, st);
     if (fasty_on(P)) {
         return run_fasty(P, (const float*)d_in0, (const float*)d_in1, out, (double*)d_iso, ws, st);
     }
