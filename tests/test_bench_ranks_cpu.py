@@ -54,3 +54,10 @@ def test_bench_two_ranks_c4_all_gather():
     assert out["n_gpus"] == 2 and "cross_spectrum" in out["metric"]
     col = out["config"]["collective"]
     assert col["op"] == "all_gather" and col["bytes_per_rank"] == 2 * 64 * 16  # (nt/world, nbins = 256/4) complex128 per rank
+
+
+def test_bench_two_ranks_c5_float64():
+    """BASELINE.json configs[4] through the harness (float64, the mixed-radix kernels), two ranks, strong scaling."""
+    out = _run(2, ["--nt", "3", "--workload", "c5", "--ny", "360", "--nx", "360", "--scaling", "strong"])
+    assert out["n_gpus"] == 2 and out["dtype"] == "f64" and "fp64" in out["metric"] and out["config"]["nt_total"] == 3
+    assert "fastm_cols" in out["roofline"]["kernels_ms_per_step"] and out["roofline"]["bytes_per_point"] == 16.0

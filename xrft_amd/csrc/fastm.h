@@ -48,7 +48,10 @@ template <typename T, int N> struct MGeom {
     static constexpr int STR = ((N + N / PQ + 3) / 8) * 8 + 4;  // the smallest s >= N + N / PQ with s = 4 (mod 8)
     static constexpr size_t CS = 2 * sizeof(T);
     // sequences per workgroup: as many (a power of two, <= 8) as keep three workgroups on a CU
-    static constexpr int G = (size_t)8 * STR * CS <= 52 * 1024 ? 8 : (size_t)4 * STR * CS <= 52 * 1024 ? 4 : (size_t)2 * STR * CS <= 52 * 1024 ? 2 : 1;
+#ifndef XRFT_M_LDSCAP
+#define XRFT_M_LDSCAP (52 * 1024)
+#endif
+    static constexpr int G = (size_t)8 * STR * CS <= XRFT_M_LDSCAP ? 8 : (size_t)4 * STR * CS <= XRFT_M_LDSCAP ? 4 : (size_t)2 * STR * CS <= XRFT_M_LDSCAP ? 2 : 1;
     static constexpr int THR = ((G * BMAX + 63) / 64) * 64;
     static constexpr size_t LDS_ROWS = ((size_t)G * STR + M0) * CS;                                    // sequences + pass-1 twiddles
     static constexpr size_t LDS = LDS_ROWS + (size_t)(THR / 64) * G * 4 * sizeof(double);              // + pass 1's partial column sums
@@ -86,7 +89,7 @@ struct FastM {
 };
 
 // profiling builds (scripts/build_ablate_m.sh, -DXRFT_MDBG=bits; 0 in the product): 1 = the intermediate is written with plain
-// stores, 2 = the result too
+// stores, 2 = the result too, 4 = no transforms (passes skipped), 8 = no stores, 16 = no loads of the sequences
 #ifndef XRFT_MDBG
 #define XRFT_MDBG 0
 #endif
@@ -209,7 +212,7 @@ __global__ void __launch_bounds__((MGeom<T, NY>::THR), (MGeom<T, NY>::WPS)) fast
     for (int q = 0; q < R0; ++q) {
         a[q] = mk<T>((T)0, (T)0); wyv[q] = (T)0;
         if (on) {
-            a[q] = *reinterpret_cast<const CT*>(src + (off0 + rstep * (unsigned)q));
+            if (!(XRFT_MDBG & 16)) a[q] = *reinterpret_cast<const CT*>(src + (off0 + rstep * (unsigned)q));
             wyv[q] = wy[j + q * M0];
         }
     }
@@ -233,8 +236,13 @@ __global__ void __launch_bounds__((MGeom<T, NY>::THR), (MGeom<T, NY>::WPS)) fast
     }
 #pragma unroll
     for (int q = 0; q < R0; ++q) a[q] = mk<T>(a[q].re * (wyv[q] * wx.re), a[q].im * (wyv[q] * wx.im));
-    if (on) mr_pass0<T, NY>(a, lds + g * STR, j, w0);
-    mr_fft_tail<T, NY, G, THR>(lds, tid, tw1);
+    if (XRFT_MDBG & 4) {
+        if (on) for (int q = 0; q < R0; ++q) lds[g * STR + M::pn(j + q * M0)] = a[q];
+        __syncthreads();
+    } else {
+        if (on) mr_pass0<T, NY>(a, lds + g * STR, j, w0);
+        mr_fft_tail<T, NY, G, THR>(lds, tid, tw1);
+    }
     if (DET && tid < 4 * G) {  // (sum d, sum (i - ibar) d, 0, 0) per column
         const int c = tid / G, gg = tid % G;  // c: 0, 1 = sum d of columns 2gg, 2gg+1; 2, 3 = the first moments
         double acc = 0.0;
@@ -244,23 +252,22 @@ __global__ void __launch_bounds__((MGeom<T, NY>::THR), (MGeom<T, NY>::WPS)) fast
         cfp[c >> 1] = acc;
         cfp[2 + (c >> 1)] = 0.0;
     }
-    // split the packed spectra: Ra[k] = (Z[k] + conj Z[N-k]) / 2, Rb[k] = (Z[k] - conj Z[N-k]) / (2i); (Ra, Rb) = two adjacent
-    // columns = 32 bytes; lanes (ky, g), g fastest: 128 / (32 G) consecutive ky complete a line
+    // split the packed spectra: Ra[k] = (Z[k] + conj Z[N-k]) / 2, Rb[k] = (Z[k] - conj Z[N-k]) / (2i) = the spectra of columns 2g and
+    // 2g+1.  One 16-byte value per lane, lanes (ky, column): CW consecutive lanes write the CW columns of a row, RK rows
+    // complete a 128-byte line -- every store instruction writes whole lines.  (Two stores per lane -- Ra then Rb, each instruction
+    // half of every 32-byte sector -- ran the stores at 2.8 TB/s: 2.99 us per slab alone, profiles/r02_experiments.txt.)
     const int rk = 1 << p.l_rk;
     char* __restrict__ w2s = reinterpret_cast<char*>(reinterpret_cast<CT*>(p.w2) + (size_t)slab * p.nrow_pad * p.nx);
-    constexpr int NST = (G * (NY / 2 + 1) + THR - 1) / THR;
+    constexpr int NST = (CW * (NY / 2 + 1) + THR - 1) / THR;
 #pragma unroll
     for (int i = 0; i < NST; ++i) {
-        const int k = r0 + i * (THR / G);
+        const int l = tid + i * THR, col = l % CW, k = l / CW;
         if (k <= NY / 2) {
-            const CT* z = lds + g * STR;
+            const CT* z = lds + (col >> 1) * STR;
             const CT zk = z[M::pn(k)], zc = cconj(z[M::pn(k == 0 ? 0 : NY - k)]);
-            CT o[2];
-            o[0] = cscale(zk + zc, (T)0.5);
-            o[1] = cscale(mul_mi(zk - zc), (T)0.5);
-            const unsigned off = ((((unsigned)(k >> p.l_rk) * (unsigned)nxb + (unsigned)xb) << p.l_rk) + (unsigned)(k & (rk - 1))) * (unsigned)CW + 2u * (unsigned)g;
-            mr_store16_nt<T, (XRFT_MDBG & 1) != 0>(w2s + (size_t)off * sizeof(CT), &o[0]);
-            mr_store16_nt<T, (XRFT_MDBG & 1) != 0>(w2s + (size_t)off * sizeof(CT) + 16, &o[1]);
+            const CT o = (col & 1) ? cscale(mul_mi(zk - zc), (T)0.5) : cscale(zk + zc, (T)0.5);
+            const unsigned off = ((((unsigned)(k >> p.l_rk) * (unsigned)nxb + (unsigned)xb) << p.l_rk) + (unsigned)(k & (rk - 1))) * (unsigned)CW + (unsigned)col;
+            if (!(XRFT_MDBG & 8) || o.re == (T)1.2345) mr_store16_nt<T, (XRFT_MDBG & 1) != 0>(w2s + (size_t)off * sizeof(CT), &o);
         }
     }
 }
@@ -310,7 +317,7 @@ __global__ void __launch_bounds__((MGeom<T, NX>::THR), (MGeom<T, NX>::WPS)) fast
         if (live) {
             const int x = j + q * M0;
             // element (ky, x) of the block [x / CW][ky % RK][x % CW]
-            a[q] = blk[((((x >> p.l_cw) << p.l_rk) + (ky & (rk - 1))) << p.l_cw) + (x & cwm)];
+            if (!(XRFT_MDBG & 16)) a[q] = blk[((((x >> p.l_cw) << p.l_rk) + (ky & (rk - 1))) << p.l_cw) + (x & cwm)];
             if (addback) c[q] = cr[x];
         }
     }
@@ -321,8 +328,13 @@ __global__ void __launch_bounds__((MGeom<T, NX>::THR), (MGeom<T, NX>::WPS)) fast
             a[q].im = fma(c[q].re, h0.im, fma(c[q].im, h1.im, a[q].im));
         }
     }
-    if (on) mr_pass0<T, NX>(a, lds + t * STR, j, w0);
-    mr_fft_tail<T, NX, G, THR>(lds, tid, tw1);
+    if (XRFT_MDBG & 4) {
+        if (on) for (int q = 0; q < R0; ++q) lds[t * STR + M::pn(j + q * M0)] = a[q];
+        __syncthreads();
+    } else {
+        if (on) mr_pass0<T, NX>(a, lds + t * STR, j, w0);
+        mr_fft_tail<T, NX, G, THR>(lds, tid, tw1);
+    }
     const int sx = p.shift_x, sy = p.shift_y;
     const T sc = (T)p.scale;
     if (ISO) {
@@ -436,7 +448,7 @@ __global__ void __launch_bounds__((MGeom<T, NX>::THR), (MGeom<T, NX>::WPS)) fast
                 else reinterpret_cast<CT*>(o)[i] = va;
             }
         }
-        mr_store16_nt<T, (XRFT_MDBG & 2) != 0>(outs + (size_t)orow * NX + c, o);
+        if (!(XRFT_MDBG & 8) || reinterpret_cast<T*>(o)[0] == (T)1.2345) mr_store16_nt<T, (XRFT_MDBG & 2) != 0>(outs + (size_t)orow * NX + c, o);
     }
 }
 

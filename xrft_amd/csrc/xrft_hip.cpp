@@ -1299,8 +1299,13 @@ static void fastm_launch_cols(const xrfthip_plan* P, const FastM& p, long long g
     const MGeomRt C = mgeom(P->yny);
     xrfthip_plan::ProfRec* rec = prof_begin(P, "fastm_cols", st);
     const dim3 grid((unsigned)(8 * ((p.nunits + 7) / 8))), blk((unsigned)C.thr);
-#define MC_(NN) do { if (d.detrend) { auto k = &fastm_cols_kernel<double, NN, true>; XRFT_LAUNCH(k, grid, blk, C.lds_cols, st, p); } \
-                     else { auto k = &fastm_cols_kernel<double, NN, false>; XRFT_LAUNCH(k, grid, blk, C.lds_cols, st, p); } } while (0)
+#ifdef XRFT_M_BIGLDS  /* profiling builds with more than 64 KB of LDS per workgroup */
+#define MBIG_(k, n) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(n))
+#else
+#define MBIG_(k, n) ((void)0)
+#endif
+#define MC_(NN) do { if (d.detrend) { auto k = &fastm_cols_kernel<double, NN, true>; MBIG_(k, C.lds_cols); XRFT_LAUNCH(k, grid, blk, C.lds_cols, st, p); } \
+                     else { auto k = &fastm_cols_kernel<double, NN, false>; MBIG_(k, C.lds_cols); XRFT_LAUNCH(k, grid, blk, C.lds_cols, st, p); } } while (0)
     if (P->yny == 1440) MC_(1440); else if (P->yny == 720) MC_(720); else MC_(360);
 #undef MC_
     prof_end(rec, st);
@@ -1322,7 +1327,7 @@ static void fastm_launch_rows(const xrfthip_plan* P, const FastM& p, long long g
     const bool fused = fastm_iso_fused(P);
     const size_t lds_iso = R.lds_rows + (size_t)P->nbins * (d.out_mode == XRFTHIP_OUT_CROSS ? 20 : 12) * (size_t)p.iso_ncopy;
 #define MR_(NN) do { \
-        if (d.out_mode == XRFTHIP_OUT_POWER) { if (fused) { auto k = &fastm_rows_kernel<double, NN, 1, true>; XRFT_LAUNCH(k, grid, blk, lds_iso, st, p); } else { auto k = &fastm_rows_kernel<double, NN, 1>; XRFT_LAUNCH(k, grid, blk, R.lds_rows, st, p); } } \
+        if (d.out_mode == XRFTHIP_OUT_POWER) { if (fused) { auto k = &fastm_rows_kernel<double, NN, 1, true>; XRFT_LAUNCH(k, grid, blk, lds_iso, st, p); } else { auto k = &fastm_rows_kernel<double, NN, 1>; MBIG_(k, R.lds_rows); XRFT_LAUNCH(k, grid, blk, R.lds_rows, st, p); } } \
         else if (d.out_mode == XRFTHIP_OUT_CROSS) { if (fused) { auto k = &fastm_rows_kernel<double, NN, 2, true>; XRFT_LAUNCH(k, grid, blk, lds_iso, st, p); } else { auto k = &fastm_rows_kernel<double, NN, 2>; XRFT_LAUNCH(k, grid, blk, R.lds_rows, st, p); } } \
         else if (d.out_mode == XRFTHIP_OUT_PHASE) { auto k = &fastm_rows_kernel<double, NN, 3>; XRFT_LAUNCH(k, grid, blk, R.lds_rows, st, p); } \
         else { auto k = &fastm_rows_kernel<double, NN, 0>; XRFT_LAUNCH(k, grid, blk, R.lds_rows, st, p); } } while (0)
