@@ -57,6 +57,19 @@ template <typename T, int N> struct MGeom {
     static constexpr size_t LDS = LDS_ROWS + (size_t)(THR / 64) * G * 4 * sizeof(double);              // + pass 1's partial column sums
     static constexpr int WGS = (int)((160 * 1024) / LDS) < 1 ? 1 : (int)((160 * 1024) / LDS);
     static constexpr int WPS = (WGS * (THR / 64) + 3) / 4 > 8 ? 8 : (WGS * (THR / 64) + 3) / 4;  // waves per SIMD the launch bounds ask for
+    // pass 2, one field: sequences (= rows) per workgroup, its threads, LDS and launch bound.  Half of pass 1's (but whole lines of
+    // W2: >= 2 rows): its reads and writes are contiguous whatever the count, and six small workgroups per CU interleave their
+    // load / transform / store phases better than three (C5 row pass 4.22 -> 3.74 us per slab)
+#ifndef XRFT_M_ROWS_SHIFT
+#define XRFT_M_ROWS_SHIFT 1
+#endif
+    static constexpr int GR1 = (G >> XRFT_M_ROWS_SHIFT) < 2 ? (G < 2 ? G : 2) : (G >> XRFT_M_ROWS_SHIFT);
+    template <int GG> struct Rows {
+        static constexpr int THR = ((GG * BMAX + 63) / 64) * 64;
+        static constexpr size_t LDS = ((size_t)GG * STR + M0) * CS;
+        static constexpr int WGS = (int)((160 * 1024) / LDS) < 1 ? 1 : ((int)((160 * 1024) / LDS) > 8 ? 8 : (int)((160 * 1024) / LDS));
+        static constexpr int WPS = (WGS * (THR / 64) + 3) / 4 > 8 ? 8 : (WGS * (THR / 64) + 3) / 4;
+    };
     __device__ static __forceinline__ int pd(int i) { return i + i / PDQ; }
     __device__ static __forceinline__ int pn(int k) { return k + k / PNQ; }
 };
@@ -280,13 +293,16 @@ __global__ void __launch_bounds__((MGeom<T, NY>::THR), (MGeom<T, NY>::WPS)) fast
 //   xrft.py:446-447 (fftshift), :462-469 (true phase), :740-748 / :825-833 (|F|^2, F0 conj F1 and the scalings, in `scale`)
 // ------------------------------------------------------------------------------------------------
 //   xrft.py:895-906 (ISO: radial sums, here bit-reproducible: per-bin exponent bound by atomicMax, int64 fixed-point adds; aux_kernels.h)
+// (two fields, or radial sums -- whose tables and partial-sum rows are per workgroup --: pass 1's count)
+template <typename T, int NX, int MODE, bool ISO> struct MRowsG { static constexpr int G = (MODE >= 2 || ISO) ? MGeom<T, NX>::G : MGeom<T, NX>::GR1; };
+
 template <typename T, int NX, int MODE, bool ISO = false>
-__global__ void __launch_bounds__((MGeom<T, NX>::THR), (MGeom<T, NX>::WPS)) fastm_rows_kernel(FastM p) {
+__global__ void __launch_bounds__((MGeom<T, NX>::template Rows<MRowsG<T, NX, MODE, ISO>::G>::THR), (MGeom<T, NX>::template Rows<MRowsG<T, NX, MODE, ISO>::G>::WPS)) fastm_rows_kernel(FastM p) {
     static_assert(!ISO || MODE == 1 || MODE == 2, "radial sums exist for power and cross spectra");
     typedef MGeom<T, NX> M;
     typedef C2<T> CT;
     constexpr bool TWO = MODE >= 2;
-    constexpr int G = M::G, THR = M::THR, STR = M::STR, RPU = TWO ? G / 2 : G;
+    constexpr int G = MRowsG<T, NX, MODE, ISO>::G, THR = M::template Rows<G>::THR, STR = M::STR, RPU = TWO ? G / 2 : G;
     static_assert(sizeof(T) == 8, "float64");
     static_assert(!TWO || G >= 2, "two fields need two sequences");
     XRFT_DYN_SMEM(smem_raw);

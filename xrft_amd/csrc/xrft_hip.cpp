@@ -833,7 +833,7 @@ static int upload_real_table(xrfthip_plan* P, DevBuf& buf, const double* h, int6
 
 static bool fast_on(const xrfthip_plan* P);
 static bool fastm_iso_fused(const xrfthip_plan* P);
-static int fastm_rpu(long long nx, bool two);
+static int fastm_rows_rpu(const xrfthip_plan* P);
 
 // workgroups per slab of radial_binsum_det_kernel: chunks of <= 2^17 elements (its int64 sums hold 2^17 values), at most 128
 static int iso_chunk_count(long long total) {
@@ -916,7 +916,7 @@ static void layout_workspace(xrfthip_plan* P) {
     if (fastm_iso_fused(P)) {  // fastm with the radial sums inside pass 2: one partial table per row workgroup
         const bool two = d.out_mode == XRFTHIP_OUT_CROSS;
         P->off_isopart = off;
-        off = al(off + (size_t)G * (P->y_nrow_pad / fastm_rpu(P->ynx, two)) * P->nbins * (two ? 2 : 1) * sizeof(double));
+        off = al(off + (size_t)G * (P->y_nrow_pad / fastm_rows_rpu(P)) * P->nbins * (two ? 2 : 1) * sizeof(double));
     } else if ((!fast || P->fastm) && (d.flags & XRFTHIP_ISO)) {  // generic and fastm kernels: the spectrum is stored (into the caller's array, or here), then summed
         const bool two = d.out_mode == XRFTHIP_OUT_CROSS;
         const size_t out_esz = two ? P->csize : P->rsize;
@@ -1237,10 +1237,11 @@ static int run_fasty(const xrfthip_plan* P, const float* in, const float* in1, v
 // ---------------------------------------------------------------------------------------------------------------
 // mixed-radix float64 form of the y-first pipeline (fastm.h)
 // ---------------------------------------------------------------------------------------------------------------
-struct MGeomRt { int thr, g; size_t lds_cols, lds_rows; int r0, r1, r2; };
+struct MGeomRt { int thr, g; size_t lds_cols, lds_rows; int r0, r1, r2; int thr_r1, g_r1; size_t lds_r1; };  // *_r1: pass 2 of one field
 template <int N> static MGeomRt mgeom_t() {
     typedef MGeom<double, N> M;
-    return {M::THR, M::G, M::LDS, M::LDS_ROWS, M::R0, M::R1, M::R2};
+    typedef typename M::template Rows<M::GR1> R1;
+    return {M::THR, M::G, M::LDS, M::LDS_ROWS, M::R0, M::R1, M::R2, R1::THR, M::GR1, R1::LDS};
 }
 static bool fastm_len(long long n) { return n == 360 || n == 720 || n == 1440; }
 static MGeomRt mgeom(long long n) {
@@ -1249,22 +1250,33 @@ static MGeomRt mgeom(long long n) {
 // layout of the intermediate: CW = 2 G columns of a pass-1 workgroup, RK rows per 128-byte line
 static int fastm_cw(long long ny) { return 2 * mgeom(ny).g; }
 static int fastm_rk(long long ny) { const int cw = fastm_cw(ny); return cw * 16 >= 128 ? 1 : 128 / (cw * 16); }
-static int fastm_rpu(long long nx, bool two) { const int g = mgeom(nx).g; return two ? g / 2 : g; }
+static int fastm_rpu(long long nx, bool two) { const MGeomRt r = mgeom(nx); return two ? r.g / 2 : r.g_r1; }  // rows per pass-2 workgroup (radial sums fused: fastm_rows_rpu)
 
 // radial sums inside pass 2 when the per-bin tables fit behind the transforms' LDS (64 KB of dynamic LDS per workgroup); otherwise
 // the spectrum is stored and summed by run_radial_sums
 static bool fastm_iso_fused(const xrfthip_plan* P) {
     if (!P->fastm || !(P->d.flags & XRFTHIP_ISO) || P->nbins < 1) return false;
     const bool cx = P->d.out_mode == XRFTHIP_OUT_CROSS;
-    return mgeom(P->ynx).lds_rows + (size_t)P->nbins * (cx ? 20 : 12) <= 64 * 1024;
+    const MGeomRt R = mgeom(P->ynx);
+    return R.lds_rows + (size_t)P->nbins * (cx ? 20 : 12) <= 64 * 1024;
 }
 
 // copies of the per-bin tables in pass 2 (a power of two <= 8, whatever fits the 64 KB)
 static int fastm_iso_ncopy(const xrfthip_plan* P) {
-    const size_t per = (size_t)P->nbins * (P->d.out_mode == XRFTHIP_OUT_CROSS ? 20 : 12), room = 64 * 1024 - mgeom(P->ynx).lds_rows;
+    const bool cx = P->d.out_mode == XRFTHIP_OUT_CROSS;
+    const MGeomRt R = mgeom(P->ynx);
+    const size_t per = (size_t)P->nbins * (cx ? 20 : 12), room = 64 * 1024 - R.lds_rows;
     int nc = 1;
     while (nc < 8 && per * (size_t)(2 * nc) <= room) nc *= 2;
     return nc;
+}
+
+// rows per pass-2 workgroup of this plan: two fields share a workgroup's sequences; with the radial sums fused the one-field kernel
+// keeps pass 1's sequence count (MRowsG in fastm.h)
+static int fastm_rows_rpu(const xrfthip_plan* P) {
+    const bool two = P->d.out_mode == XRFTHIP_OUT_CROSS || P->d.out_mode == XRFTHIP_OUT_PHASE;
+    const MGeomRt r = mgeom(P->ynx);
+    return two ? r.g / 2 : (fastm_iso_fused(P) ? r.g : r.g_r1);
 }
 
 static FastM fastm_params(const xrfthip_plan* P, const void* in, void* out, char* ws, long long g0, long long gc, int slot, long long slot_slabs) {
@@ -1323,14 +1335,15 @@ static void fastm_launch_rows(const xrfthip_plan* P, const FastM& p, long long g
     const MGeomRt R = mgeom(P->ynx);
     const bool two = d.out_mode == XRFTHIP_OUT_CROSS || d.out_mode == XRFTHIP_OUT_PHASE;
     xrfthip_plan::ProfRec* rec = prof_begin(P, "fastm_rows", st);
-    const dim3 grid((unsigned)(gc * (P->y_nrow_pad / fastm_rpu(P->ynx, two)))), blk((unsigned)R.thr);
-    const bool fused = fastm_iso_fused(P);
-    const size_t lds_iso = R.lds_rows + (size_t)P->nbins * (d.out_mode == XRFTHIP_OUT_CROSS ? 20 : 12) * (size_t)p.iso_ncopy;
+    const bool fused = fastm_iso_fused(P), full = two || fused;  // (full: pass 1's sequence count per workgroup)
+    const dim3 grid((unsigned)(gc * (P->y_nrow_pad / fastm_rows_rpu(P)))), blk((unsigned)(full ? R.thr : R.thr_r1));
+    const size_t lds_rows = full ? R.lds_rows : R.lds_r1;
+    const size_t lds_iso = lds_rows + (size_t)P->nbins * (d.out_mode == XRFTHIP_OUT_CROSS ? 20 : 12) * (size_t)p.iso_ncopy;
 #define MR_(NN) do { \
-        if (d.out_mode == XRFTHIP_OUT_POWER) { if (fused) { auto k = &fastm_rows_kernel<double, NN, 1, true>; XRFT_LAUNCH(k, grid, blk, lds_iso, st, p); } else { auto k = &fastm_rows_kernel<double, NN, 1>; MBIG_(k, R.lds_rows); XRFT_LAUNCH(k, grid, blk, R.lds_rows, st, p); } } \
+        if (d.out_mode == XRFTHIP_OUT_POWER) { if (fused) { auto k = &fastm_rows_kernel<double, NN, 1, true>; XRFT_LAUNCH(k, grid, blk, lds_iso, st, p); } else { auto k = &fastm_rows_kernel<double, NN, 1>; MBIG_(k, lds_rows); XRFT_LAUNCH(k, grid, blk, lds_rows, st, p); } } \
         else if (d.out_mode == XRFTHIP_OUT_CROSS) { if (fused) { auto k = &fastm_rows_kernel<double, NN, 2, true>; XRFT_LAUNCH(k, grid, blk, lds_iso, st, p); } else { auto k = &fastm_rows_kernel<double, NN, 2>; XRFT_LAUNCH(k, grid, blk, R.lds_rows, st, p); } } \
         else if (d.out_mode == XRFTHIP_OUT_PHASE) { auto k = &fastm_rows_kernel<double, NN, 3>; XRFT_LAUNCH(k, grid, blk, R.lds_rows, st, p); } \
-        else { auto k = &fastm_rows_kernel<double, NN, 0>; XRFT_LAUNCH(k, grid, blk, R.lds_rows, st, p); } } while (0)
+        else { auto k = &fastm_rows_kernel<double, NN, 0>; XRFT_LAUNCH(k, grid, blk, lds_rows, st, p); } } while (0)
     if (P->ynx == 1440) MR_(1440); else if (P->ynx == 720) MR_(720); else MR_(360);
 #undef MR_
     prof_end(rec, st);
@@ -1355,7 +1368,7 @@ static int run_fastm(const xrfthip_plan* P, const void* in, const void* in1, voi
         fastm_launch_rows(P, p, gc, st);
         HIP_TRY(hipGetLastError());
         if (iso_on && fused) {  // the row workgroups' partial sums, added in order
-            const int hw = d.out_mode == XRFTHIP_OUT_CROSS ? 2 : 1, nb = P->nbins * hw, upr = P->y_nrow_pad / fastm_rpu(P->ynx, two);
+            const int hw = d.out_mode == XRFTHIP_OUT_CROSS ? 2 : 1, nb = P->nbins * hw, upr = P->y_nrow_pad / fastm_rows_rpu(P);
             xrfthip_plan::ProfRec* rec = prof_begin(P, "iso_reduce", st);
             auto kr = &iso_reduce_kernel;
             XRFT_LAUNCH(kr, dim3((unsigned)((nb + 63) / 64), (unsigned)gc), dim3(256), 4 * 64 * sizeof(double), st, (const double*)p.iso_part,
@@ -1587,7 +1600,7 @@ int xrfthip_plan_create(xrfthip_plan** plan, const xrfthip_desc* desc) {
         }
         if (P->fastm) {
             const bool two = d.out_mode == XRFTHIP_OUT_CROSS || d.out_mode == XRFTHIP_OUT_PHASE;
-            const int rpu = fastm_rpu(d.nx, two);
+            const int rpu = two ? fastm_rpu(d.nx, true) : mgeom(d.nx).g;  // (the largest count a row kernel of this plan may use)
             P->yfirst = true;
             P->yny = d.ny; P->ynx = d.nx;
             P->y_nrow_pad = (int)((d.ny / 2 + 1 + rpu - 1) / rpu * rpu);
@@ -1700,7 +1713,7 @@ int xrfthip_plan_describe(const xrfthip_plan* plan, char* buf, size_t buflen) {
         const MGeomRt C = mgeom(plan->yny), R = mgeom(plan->ynx);
         appendf(s, "  [fastm] cols: %d thr, %d packed column pairs (FFT%lld r%dx%dx%d in LDS), lds=%zuB -> W2[slab][%d/%d][nx/%d][%d][%d] complex128 -> fit -> rows: %d thr, %d rows/unit (FFT%lld r%dx%dx%d), lds=%zuB, trend added back in the spectral domain, fftshift + mirror rows\n",
                 C.thr, C.g, (long long)plan->yny, C.r0, C.r1, C.r2, C.lds_cols, plan->y_nrow_pad, fastm_rk(plan->yny), fastm_cw(plan->yny), fastm_rk(plan->yny), fastm_cw(plan->yny),
-                R.thr, R.g, (long long)plan->ynx, R.r0, R.r1, R.r2, R.lds_rows);
+                R.thr_r1, R.g_r1, (long long)plan->ynx, R.r0, R.r1, R.r2, R.lds_r1);
     } else if (fasty_on(plan)) {
         const YGeomRt C = ycols_geom(plan->yny), R = yrows_geom(plan->ynx);
         if (plan->fast1d) appendf(s, "  [fasty four-step] %lld samples = [%lld][%lld]: columns = step 1 (half spectrum k1 <= %lld), rows x W_N^(i2 k1) = step 2, transposed stores + Hermitian mirror\n",
