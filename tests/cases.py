@@ -543,6 +543,13 @@ def run_fastm_cases(shape=(2, 360, 360), full=True, cross=True):
     for kw in (dict(window="hann", detrend="linear"), dict(true_phase=False, scaling="spectrum", shift=False)):
         worst = max(worst, check(xa.cross_spectrum(da, db, dim=["y", "x"], **kw), o.cross_spectrum(od, ob, dim=["y", "x"], **kw), tol))
         assert on_fastm()
+    # real_dim: half output along x (rows of nx/2 + 1 samples)
+    for fn, ofn, kwr in ((xa.power_spectrum, o.power_spectrum, dict(detrend="linear", window="hann")), (xa.fft, o.fft, dict(detrend="constant")),
+                         (xa.power_spectrum, o.power_spectrum, dict(shift=False, scaling="spectrum"))):
+        worst = max(worst, check(fn(da, dim=["y"], real_dim="x", **kwr), ofn(od, dim=["y"], real_dim="x", **kwr), tol))
+        assert on_fastm()
+    worst = max(worst, check(xa.cross_spectrum(da, db, dim=["y"], real_dim="x", window="hann"), o.cross_spectrum(od, ob, dim=["y"], real_dim="x", window="hann"), tol))
+    assert on_fastm()
     # isotropic spectra (doc/MITgcm_example.ipynb: isotropic_powerspectrum with detrend='linear', window=True): the spectrum is
     # stored by the same kernels and summed by the bit-reproducible radial pass
     kwi = dict(dim=["y", "x"], detrend="linear", window="hann")

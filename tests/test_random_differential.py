@@ -158,7 +158,7 @@ def run_random_fast(seed):
 
 def run_random_fastm(seed, lengths=(360, 720, 1440)):
     """Random mode / option combinations in float64 on the lat/lon lengths of csrc/fastm.h (BASELINE.json configs[4] is
-    (64, 1440, 720)); modes the mixed-radix kernels do not take (real_dim, a flipped axis) must come out
+    (64, 1440, 720)); modes the mixed-radix kernels do not take (a flipped axis) must come out
     right through the generic ones."""
     import xrft_amd as xa
 
@@ -193,7 +193,7 @@ def run_random_fastm(seed, lengths=(360, 720, 1440)):
     on = any("[fastm]" in p.describe() for p in api._plan_cache.values())
     two_rows = not (kind == "cs" and ny == 1440 and nx == 1440)  # (one row pair per workgroup: no room for the second field)
     flipped = desc and tp and kind in ("fft", "cs")  # (the reference flips only under true_phase, xrft.py:436-441; power spectra never)
-    assert on == (kind in ("ps", "fft", "cs", "iso") and not flipped and two_rows), (kind, desc, tp, ny, nx, on)
+    assert on == (not flipped and two_rows), (kind, desc, tp, ny, nx, on)
     cases.check(got, ref, 1e-10)
 
 

@@ -93,6 +93,8 @@ struct FastM {
     const int* binmap;   // radial sums fused into pass 2 (ISO): bin of (ky, kx), unshifted indices, [ny][nx]; < 0 = none
     double* iso_part;    // [slab][row workgroup][nbins (x2 complex)]: per-workgroup sums, reduced in order by iso_reduce_kernel
     int nbins, iso_ncopy;
+    int half;            // real_dim: only kx = 0..nx/2 is stored, rows of nx/2 + 1 samples, unshifted along x (xrft.py:400-404)
+    int realdim2;        // ... and 0 < kx < nx/2 counts twice (xrft.py:673-682)
     int ph_on;
     int ny, nx, nrow_pad;
     int l_cw, l_rk;      // log2 of CW and RK
@@ -435,6 +437,30 @@ __global__ void __launch_bounds__((MGeom<T, NX>::template Rows<MRowsG<T, NX, MOD
     typedef typename std::conditional<MODE == 0 || MODE == 2, CT, T>::type OutT;
     constexpr int VW = 16 / (int)sizeof(OutT), CPR = NX / VW;
     static_assert(NX % VW == 0, "row length");
+    if (p.half) {  // rows of nx/2 + 1 samples (an odd length: one sample per lane and store, still whole lines per wave); F(-ky, kx) = conj F(ky, -kx)
+        constexpr int W = NX / 2 + 1;
+        OutT* __restrict__ oh = reinterpret_cast<OutT*>(p.out) + (size_t)slab * p.ny * W;
+        for (int e = tid; e < RPU * 2 * W; e += THR) {
+            const int fx = e % W, rr = e / W, r = rr >> 1, mir = rr & 1, ky = ky0 + r;
+            if (ky > nyh || (mir && (ky == 0 || 2 * ky == p.ny))) continue;
+            const int fy = mir ? p.ny - ky : ky, kx = mir ? (fx == 0 ? 0 : NX - fx) : fx;
+            int orow = fy + sy; if (orow >= p.ny) orow -= p.ny;
+            const T f2 = (p.realdim2 && fx != 0 && 2 * fx != NX) ? (T)2 : (T)1;
+            CT va = lds[r * STR + M::pn(kx)];
+            OutT* dst = oh + (size_t)orow * W + fx;
+            if (MODE == 1) {
+                *reinterpret_cast<T*>(dst) = (va.re * va.re + va.im * va.im) * (sc * f2);
+            } else {
+                if (TWO) va = cmulc(va, lds[(RPU + r) * STR + M::pn(kx)]);
+                va = cscale(va, sc * f2);
+                if (mir) va = cconj(va);
+                if (p.ph_on) va = cmul(va, cmul(reinterpret_cast<const CT*>(p.ph_y)[fy], reinterpret_cast<const CT*>(p.ph_x)[fx]));
+                if (MODE == 3) *reinterpret_cast<T*>(dst) = (T)atan2((double)va.im, (double)va.re);
+                else *reinterpret_cast<CT*>(dst) = va;
+            }
+        }
+        return;
+    }
     OutT* __restrict__ outs = reinterpret_cast<OutT*>(p.out) + (size_t)slab * p.ny * NX;
     for (int e = tid; e < RPU * 2 * CPR; e += THR) {
         const int chunk = e % CPR, rr = e / CPR, r = rr >> 1, mir = rr & 1;

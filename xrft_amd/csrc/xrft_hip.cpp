@@ -1286,7 +1286,10 @@ static FastM fastm_params(const xrfthip_plan* P, const void* in, void* out, char
     p.in = (const char*)in + (size_t)g0 * slab_pts * sizeof(double);
     p.w2 = reinterpret_cast<C2<double>*>(ws + P->off_w) + s0 * (size_t)P->y_nrow_pad * P->ynx;
     const size_t out_esz = (d.out_mode == XRFTHIP_OUT_POWER || d.out_mode == XRFTHIP_OUT_PHASE) ? sizeof(double) : sizeof(C2<double>);
-    p.out = out ? (char*)out + (size_t)g0 * slab_pts * out_esz : nullptr;
+    const size_t out_pts = (size_t)P->yny * ((d.flags & XRFTHIP_HALF_X) ? P->ynx / 2 + 1 : P->ynx);
+    p.out = out ? (char*)out + (size_t)g0 * out_pts * out_esz : nullptr;
+    p.half = (d.flags & XRFTHIP_HALF_X) ? 1 : 0;
+    p.realdim2 = (d.flags & XRFTHIP_REALDIM_X2) ? 1 : 0;
     p.tw_x = P->tw_fx.p; p.tw_y = P->tw_fy.p;
     p.win_y = P->win[0].p ? P->win[0].p : P->ones4096.p;
     p.win_x = P->win[1].p ? P->win[1].p : P->ones4096.p;
@@ -1588,10 +1591,12 @@ int xrfthip_plan_create(xrfthip_plan** plan, const xrfthip_desc* desc) {
     }
     {   // real float64 slabs on the regular lat/lon lengths: the mixed-radix form of the y-first pipeline (fastm.h)
         const uint32_t shifts = XRFTHIP_SHIFT_Y | XRFTHIP_SHIFT_X, ish = XRFTHIP_ISHIFT_Y | XRFTHIP_ISHIFT_X;
-        const uint32_t isof = XRFTHIP_ISO | XRFTHIP_NO_SPECTRUM_OUT;  // radial sums: a bit-reproducible pass over the stored spectrum (run_radial_sums)
-        const uint32_t allowed = d.out_mode == XRFTHIP_OUT_POWER ? (shifts | isof) : d.out_mode == XRFTHIP_OUT_CROSS ? (shifts | ish | isof)
-                                 : (d.out_mode == XRFTHIP_OUT_COMPLEX || d.out_mode == XRFTHIP_OUT_PHASE) ? (shifts | ish) : 0u;
-        P->fastm = d.ndim == 2 && d.dtype == XRFTHIP_F64 && fastm_len(d.ny) && fastm_len(d.nx) && !(d.flags & ~allowed) &&
+        const uint32_t isof = XRFTHIP_ISO | XRFTHIP_NO_SPECTRUM_OUT;  // radial sums: fused into pass 2, or a pass over the stored spectrum (run_radial_sums)
+        const uint32_t halff = XRFTHIP_HALF_X | XRFTHIP_REALDIM_X2;     // real_dim: half output, no mirror columns
+        const uint32_t allowed = d.out_mode == XRFTHIP_OUT_POWER ? (shifts | isof | halff) : d.out_mode == XRFTHIP_OUT_CROSS ? (shifts | ish | isof | halff)
+                                 : (d.out_mode == XRFTHIP_OUT_COMPLEX || d.out_mode == XRFTHIP_OUT_PHASE) ? (shifts | ish | XRFTHIP_HALF_X) : 0u;
+        const bool half_ok = !((d.flags & halff) && (d.flags & XRFTHIP_ISO)) && !((d.flags & XRFTHIP_HALF_X) && (d.flags & XRFTHIP_SHIFT_X));
+        P->fastm = half_ok && d.ndim == 2 && d.dtype == XRFTHIP_F64 && fastm_len(d.ny) && fastm_len(d.nx) && !(d.flags & ~allowed) &&
                    !env_ll("XRFTHIP_NO_FAST", 0) && env_ll("XRFTHIP_FASTM", 1) != 0;
         if (P->fastm) {
             const bool two = d.out_mode == XRFTHIP_OUT_CROSS || d.out_mode == XRFTHIP_OUT_PHASE;
