@@ -23,16 +23,17 @@ def prof(name, fn, units, pts):
     return plan
 shapes = [(64, 1440, 720)] + ([(64, 720, 1440), (32, 1440, 1440), (256, 360, 360)] if len(sys.argv) > 1 else [])
 for shp in shapes:
-    x = torch.randn(shp, dtype=torch.float64, device="cuda")
-    y = torch.randn(shp, dtype=torch.float64, device="cuda")
+    fdt = torch.float32 if os.environ.get("C5_F32") else torch.float64
+    x = torch.randn(shp, dtype=fdt, device="cuda")
+    y = torch.randn(shp, dtype=fdt, device="cuda")
     c = {"lat": np.arange(shp[1]) * .25, "lon": np.arange(shp[2]) * .25}
     da = xrft.DataArray(x, ("t", "lat", "lon"), c); db = xrft.DataArray(y, ("t", "lat", "lon"), c)
     for det in ((None, "linear") if not os.environ.get("ONLY_LINEAR") else ("linear",)):
-        pl = prof(f"PS f64 {det} hann {shp}", lambda: xrft.power_spectrum(da, dim=["lat", "lon"], detrend=det, window="hann"), shp[0], x.numel())
+        pl = prof(f"PS {'f32' if os.environ.get('C5_F32') else 'f64'} {det} hann {shp}", lambda: xrft.power_spectrum(da, dim=["lat", "lon"], detrend=det, window="hann"), shp[0], x.numel())
     print("   ", pl.describe().strip().split("\n")[1][:300])
     if os.environ.get("ONLY_LINEAR"): continue
-    prof(f"fft f64 linear hann {shp}", lambda: xrft.fft(da, dim=["lat", "lon"], detrend="linear", window="hann"), shp[0], x.numel())
-    prof(f"isotropic PS f64 linear hann {shp}", lambda: xrft.isotropic_power_spectrum(da, dim=["lat", "lon"], detrend="linear", window="hann"), shp[0], x.numel())
-    prof(f"cross f64 linear hann {shp}", lambda: xrft.cross_spectrum(da, db, dim=["lat", "lon"], detrend="linear", window="hann"), shp[0], x.numel())
+    prof(f"fft {'f32' if os.environ.get('C5_F32') else 'f64'} linear hann {shp}", lambda: xrft.fft(da, dim=["lat", "lon"], detrend="linear", window="hann"), shp[0], x.numel())
+    prof(f"isotropic PS {'f32' if os.environ.get('C5_F32') else 'f64'} linear hann {shp}", lambda: xrft.isotropic_power_spectrum(da, dim=["lat", "lon"], detrend="linear", window="hann"), shp[0], x.numel())
+    prof(f"cross {'f32' if os.environ.get('C5_F32') else 'f64'} linear hann {shp}", lambda: xrft.cross_spectrum(da, db, dim=["lat", "lon"], detrend="linear", window="hann"), shp[0], x.numel())
     del x, y, da, db
     torch.cuda.empty_cache()

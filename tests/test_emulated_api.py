@@ -397,10 +397,11 @@ def test_fourstep_1d_fast_path(n):
     cases.run_fourstep_1d(n, nt=2)
 
 
-@pytest.mark.parametrize("shape,full", [((2, 360, 360), True), ((1, 1440, 720), False), ((1, 720, 1440), False)])
-def test_fastm_float64_latlon_lengths(shape, full):
-    """The mixed-radix float64 y-first kernels (csrc/fastm.h; BASELINE.json configs[4] is (64, 1440, 720) float64)."""
-    cases.run_fastm_cases(shape, full)
+@pytest.mark.parametrize("shape,full,dtype", [((2, 360, 360), True, "float64"), ((1, 1440, 720), False, "float64"), ((1, 720, 1440), False, "float64"),
+                                               ((2, 360, 360), True, "float32"), ((1, 720, 1440), False, "float32"), ((1, 1440, 720), False, "float32")])
+def test_fastm_latlon_lengths(shape, full, dtype):
+    """The mixed-radix y-first kernels (csrc/fastm.h; BASELINE.json configs[4] is (64, 1440, 720) float64)."""
+    cases.run_fastm_cases(shape, full, True, dtype)
 
 
 def test_radial_sums_any_nbins_and_bit_identical_repeats():

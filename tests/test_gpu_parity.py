@@ -514,11 +514,11 @@ def test_random_fastp2_differential(seed):
     run_random_fast(seed)
 
 
-@pytest.mark.parametrize("seed", range(40))
+@pytest.mark.parametrize("seed", range(48))
 def test_random_fastm_differential(seed):
     from test_random_differential import run_random_fastm
 
-    run_random_fastm(seed)
+    run_random_fastm(seed, dtype="float64" if seed % 3 else "float32")
 
 
 def test_concurrent_threads_and_streams():
@@ -720,10 +720,11 @@ def test_middle_and_first_axis_without_copies(dim, dtype):
 
 @pytest.mark.parametrize("shape,cross", [((3, 1440, 720), True), ((2, 720, 1440), True), ((3, 360, 360), True), ((2, 1440, 1440), False),
                                          ((3, 720, 360), True), ((2, 360, 1440), True)])
-def test_fastm_float64_latlon_lengths(shape, cross):
-    """The mixed-radix float64 y-first kernels (csrc/fastm.h) against the oracle: power spectra (every detrend), fft with true
-    phase, cross spectrum, cross phase."""
-    cases.run_fastm_cases(shape, True, cross)
+@pytest.mark.parametrize("dtype", ["float64", "float32"])
+def test_fastm_latlon_lengths(shape, cross, dtype):
+    """The mixed-radix y-first kernels (csrc/fastm.h) against the oracle: power spectra (every detrend), fft with true phase, half
+    output, isotropic spectra, cross spectrum, cross phase."""
+    cases.run_fastm_cases(shape, True, cross, dtype)
 
 
 def test_radial_sums_any_nbins_and_bit_identical_repeats():

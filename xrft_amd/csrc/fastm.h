@@ -47,16 +47,17 @@ template <typename T, int N> struct MGeom {
     static constexpr int PQ = PDQ < PNQ ? PDQ : PNQ;
     static constexpr int STR = ((N + N / PQ + 3) / 8) * 8 + 4;  // the smallest s >= N + N / PQ with s = 4 (mod 8)
     static constexpr size_t CS = 2 * sizeof(T);
-    // sequences per workgroup: as many (a power of two, <= 8) as keep three workgroups on a CU
+    // sequences per workgroup: as many (a power of two) as keep three workgroups on a CU
 #ifndef XRFT_M_LDSCAP
 #define XRFT_M_LDSCAP (52 * 1024)
 #endif
-    static constexpr int G = (size_t)8 * STR * CS <= XRFT_M_LDSCAP ? 8 : (size_t)4 * STR * CS <= XRFT_M_LDSCAP ? 4 : (size_t)2 * STR * CS <= XRFT_M_LDSCAP ? 2 : 1;
+    // (at most 4: 8 columns per workgroup divide every length of the table; and at most 640 threads: one butterfly per thread and pass)
+    static constexpr int G = ((size_t)4 * STR * CS <= XRFT_M_LDSCAP && 4 * BMAX <= 640) ? 4 : (size_t)2 * STR * CS <= XRFT_M_LDSCAP ? 2 : 1;
     static constexpr int THR = ((G * BMAX + 63) / 64) * 64;
     static constexpr size_t LDS_ROWS = ((size_t)G * STR + M0) * CS;                                    // sequences + pass-1 twiddles
     static constexpr size_t LDS = LDS_ROWS + (size_t)(THR / 64) * G * 4 * sizeof(double);              // + pass 1's partial column sums
     static constexpr int WGS = (int)((160 * 1024) / LDS) < 1 ? 1 : (int)((160 * 1024) / LDS);
-    static constexpr int WPS = (WGS * (THR / 64) + 3) / 4 > 8 ? 8 : (WGS * (THR / 64) + 3) / 4;  // waves per SIMD the launch bounds ask for
+    static constexpr int WPS = (WGS * (THR / 64) + 3) / 4 > 5 ? 5 : (WGS * (THR / 64) + 3) / 4;  // waves per SIMD the launch bounds ask for (>= 102 VGPRs)
     // pass 2, one field: sequences (= rows) per workgroup, its threads, LDS and launch bound.  Half of pass 1's (but whole lines of
     // W2: >= 2 rows): its reads and writes are contiguous whatever the count, and six small workgroups per CU interleave their
     // load / transform / store phases better than three (C5 row pass 4.22 -> 3.74 us per slab)
@@ -68,7 +69,7 @@ template <typename T, int N> struct MGeom {
         static constexpr int THR = ((GG * BMAX + 63) / 64) * 64;
         static constexpr size_t LDS = ((size_t)GG * STR + M0) * CS;
         static constexpr int WGS = (int)((160 * 1024) / LDS) < 1 ? 1 : ((int)((160 * 1024) / LDS) > 8 ? 8 : (int)((160 * 1024) / LDS));
-        static constexpr int WPS = (WGS * (THR / 64) + 3) / 4 > 8 ? 8 : (WGS * (THR / 64) + 3) / 4;
+        static constexpr int WPS = (WGS * (THR / 64) + 3) / 4 > 5 ? 5 : (WGS * (THR / 64) + 3) / 4;
     };
     __device__ static __forceinline__ int pd(int i) { return i + i / PDQ; }
     __device__ static __forceinline__ int pn(int k) { return k + k / PNQ; }
@@ -117,6 +118,18 @@ template <typename T, bool PLAIN = false> __device__ __forceinline__ void mr_sto
     if (PLAIN) { *reinterpret_cast<float4*>(dst) = *reinterpret_cast<const float4*>(src16); return; }
     typedef float v4f __attribute__((ext_vector_type(4)));
     __builtin_nontemporal_store(*reinterpret_cast<const v4f*>(src16), reinterpret_cast<v4f*>(dst));
+#endif
+}
+
+// one complex value (16 bytes float64, 8 bytes float32), non-temporal
+template <typename T, bool PLAIN = false> __device__ __forceinline__ void mr_store_ct_nt(void* dst, const C2<T>& v) {
+    if (sizeof(T) == 8) { mr_store16_nt<T, PLAIN>(dst, &v); return; }
+#ifdef XRFT_EMULATE
+    memcpy(dst, &v, sizeof(v));
+#else
+    if (PLAIN) { *reinterpret_cast<C2<T>*>(dst) = v; return; }
+    typedef float v2f __attribute__((ext_vector_type(2)));
+    __builtin_nontemporal_store(*reinterpret_cast<const v2f*>(&v), reinterpret_cast<v2f*>(dst));
 #endif
 }
 
@@ -197,7 +210,6 @@ __global__ void __launch_bounds__((MGeom<T, NY>::THR), (MGeom<T, NY>::WPS)) fast
     typedef MGeom<T, NY> M;
     typedef C2<T> CT;
     constexpr int G = M::G, THR = M::THR, STR = M::STR, CW = 2 * G;
-    static_assert(sizeof(T) == 8, "float64 (the float32 variant packs four columns per load: fasty.h)");
     static_assert(THR >= G * M::B0 && THR % G == 0, "one first-pass butterfly per thread");
     XRFT_DYN_SMEM(smem_raw);
     CT* lds = reinterpret_cast<CT*>(smem_raw);
@@ -218,11 +230,25 @@ __global__ void __launch_bounds__((MGeom<T, NY>::THR), (MGeom<T, NY>::WPS)) fast
     const int j = on ? r0 : 0;
     const CT w0 = reinterpret_cast<const CT*>(p.tw_y)[j];
     const char* __restrict__ src = reinterpret_cast<const char*>(reinterpret_cast<const T*>(p.in) + (size_t)slab * NY * p.nx + (size_t)xb * CW);
-    const unsigned rowb = (unsigned)p.nx * (unsigned)sizeof(T), off0 = (unsigned)j * rowb + (unsigned)g * 16u, rstep = (unsigned)M0 * rowb;
+    const unsigned rowb = (unsigned)p.nx * (unsigned)sizeof(T), off0 = (unsigned)j * rowb + (unsigned)g * (unsigned)sizeof(CT), rstep = (unsigned)M0 * rowb;
     const T* __restrict__ wy = reinterpret_cast<const T*>(p.win_y);
     const CT wx = *reinterpret_cast<const CT*>(reinterpret_cast<const T*>(p.win_x) + xb * CW + 2 * g);
     CT a[R0];
     T wyv[R0];
+    // float32: what is subtracted HERE, in y-space, only has to take the bulk of the trend out so that nothing cancels in float32 --
+    // a line per column estimated from KREF rows at the top and at the bottom (every thread of the sequence loads them itself:
+    // the same addresses in all lanes), rounded to a power-of-two grid on which T + S i is exact (fasty.h); pass 2 corrects
+    // whatever was subtracted.  float64 subtracts nothing.
+    constexpr bool PRE = DET && sizeof(T) == 4;
+    constexpr int KREF = 2;
+    CT rt[KREF], rb[KREF];
+    if (PRE) {
+#pragma unroll
+        for (int k = 0; k < KREF; ++k) {
+            rt[k] = *reinterpret_cast<const CT*>(src + ((unsigned)g * (unsigned)sizeof(CT) + rowb * (unsigned)k));
+            rb[k] = *reinterpret_cast<const CT*>(src + ((unsigned)g * (unsigned)sizeof(CT) + rowb * (unsigned)(NY - KREF + k)));
+        }
+    }
 #pragma unroll
     for (int q = 0; q < R0; ++q) {
         a[q] = mk<T>((T)0, (T)0); wyv[q] = (T)0;
@@ -232,6 +258,26 @@ __global__ void __launch_bounds__((MGeom<T, NY>::THR), (MGeom<T, NY>::WPS)) fast
         }
     }
     constexpr double IBAR = 0.5 * (NY - 1);
+    float Tl[2] = {0.f, 0.f}, Sl[2] = {0.f, 0.f};
+    if (PRE) {
+        float mt[2] = {0.f, 0.f}, mb[2] = {0.f, 0.f};
+#pragma unroll
+        for (int k = 0; k < KREF; ++k) { mt[0] += (float)rt[k].re; mt[1] += (float)rt[k].im; mb[0] += (float)rb[k].re; mb[1] += (float)rb[k].im; }
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            const float top = mt[c] * (1.0f / KREF), bot = mb[c] * (1.0f / KREF);  // means at i = (KREF-1)/2 and ny-1-(KREF-1)/2
+            const float Se = p.detrend == 2 ? (bot - top) * (1.0f / (NY - KREF)) : 0.f;
+            const float Te = p.detrend == 2 ? top - Se * (0.5f * (KREF - 1)) : 0.5f * (top + bot);
+            const float mag = fabsf(Te) + fabsf(Se) * (float)NY;
+            const float C = __uint_as_float((__float_as_uint(mag) & 0x7f800000u) + (3u << 23)) * 1.5f;  // rounds to 2^(e-20), 2^e <= mag
+            Tl[c] = (Te + C) - C; Sl[c] = (Se + C) - C;
+        }
+        if (r0 == 0) {  // what is subtracted, as (offset at ibar, slope)
+            double* cfp = p.colfit + ((size_t)slab * p.nx + xb * CW + 2 * g) * 4;
+#pragma unroll
+            for (int c = 0; c < 2; ++c) { cfp[4 * c + 2] = (double)Tl[c] + (double)Sl[c] * IBAR; cfp[4 * c + 3] = (double)Sl[c]; }
+        }
+    }
     if (DET) {
         double s[4] = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
@@ -250,7 +296,13 @@ __global__ void __launch_bounds__((MGeom<T, NY>::THR), (MGeom<T, NY>::WPS)) fast
         }
     }
 #pragma unroll
-    for (int q = 0; q < R0; ++q) a[q] = mk<T>(a[q].re * (wyv[q] * wx.re), a[q].im * (wyv[q] * wx.im));
+    for (int q = 0; q < R0; ++q) {
+        if (PRE) {
+            const float fi = (float)(j + q * M0);
+            a[q] = mk<T>((T)((float)a[q].re - fmaf(Sl[0], fi, Tl[0])), (T)((float)a[q].im - fmaf(Sl[1], fi, Tl[1])));
+        }
+        a[q] = mk<T>(a[q].re * (wyv[q] * wx.re), a[q].im * (wyv[q] * wx.im));
+    }
     if (XRFT_MDBG & 4) {
         if (on) for (int q = 0; q < R0; ++q) lds[g * STR + M::pn(j + q * M0)] = a[q];
         __syncthreads();
@@ -265,7 +317,7 @@ __global__ void __launch_bounds__((MGeom<T, NY>::THR), (MGeom<T, NY>::WPS)) fast
         for (int w = 0; w < THR / 64; ++w) acc += part[(w * G + gg) * 4 + c];
         double* cfp = p.colfit + ((size_t)slab * p.nx + xb * CW + 2 * gg + (c & 1)) * 4;
         cfp[c >> 1] = acc;
-        cfp[2 + (c >> 1)] = 0.0;
+        if (!PRE) cfp[2 + (c >> 1)] = 0.0;
     }
     // split the packed spectra: Ra[k] = (Z[k] + conj Z[N-k]) / 2, Rb[k] = (Z[k] - conj Z[N-k]) / (2i) = the spectra of columns 2g and
     // 2g+1.  One 16-byte value per lane, lanes (ky, column): CW consecutive lanes write the CW columns of a row, RK rows
@@ -282,7 +334,7 @@ __global__ void __launch_bounds__((MGeom<T, NY>::THR), (MGeom<T, NY>::WPS)) fast
             const CT zk = z[M::pn(k)], zc = cconj(z[M::pn(k == 0 ? 0 : NY - k)]);
             const CT o = (col & 1) ? cscale(mul_mi(zk - zc), (T)0.5) : cscale(zk + zc, (T)0.5);
             const unsigned off = ((((unsigned)(k >> p.l_rk) * (unsigned)nxb + (unsigned)xb) << p.l_rk) + (unsigned)(k & (rk - 1))) * (unsigned)CW + (unsigned)col;
-            if (!(XRFT_MDBG & 8) || o.re == (T)1.2345) mr_store16_nt<T, (XRFT_MDBG & 1) != 0>(w2s + (size_t)off * sizeof(CT), &o);
+            if (!(XRFT_MDBG & 8) || o.re == (T)1.2345) mr_store_ct_nt<T, (XRFT_MDBG & 1) != 0>(w2s + (size_t)off * sizeof(CT), o);
         }
     }
 }
@@ -305,7 +357,6 @@ __global__ void __launch_bounds__((MGeom<T, NX>::template Rows<MRowsG<T, NX, MOD
     typedef C2<T> CT;
     constexpr bool TWO = MODE >= 2;
     constexpr int G = MRowsG<T, NX, MODE, ISO>::G, THR = M::template Rows<G>::THR, STR = M::STR, RPU = TWO ? G / 2 : G;
-    static_assert(sizeof(T) == 8, "float64");
     static_assert(!TWO || G >= 2, "two fields need two sequences");
     XRFT_DYN_SMEM(smem_raw);
     CT* lds = reinterpret_cast<CT*>(smem_raw);

@@ -991,16 +991,17 @@ static int fast_phase_tables(xrfthip_plan* P) {
         const long long n = ax == 0 ? d.ny : d.nx;
         const bool sign = d.out_mode == XRFTHIP_OUT_COMPLEX && (d.flags & (ax == 0 ? XRFTHIP_ISHIFT_Y : XRFTHIP_ISHIFT_X));
         std::vector<cf> t((size_t)n);
-        std::vector<C2<double>> td(P->fastm ? (size_t)n : 0);
+        const bool dtab = P->fastm && P->dbl;
+        std::vector<C2<double>> td(dtab ? (size_t)n : 0);
         for (long long k = 0; k < n; ++k) {
             double re = 1.0, im = 0.0;
             if (!P->host_phase[ax].empty()) { re = P->host_phase[ax][(size_t)(2 * k)]; im = P->host_phase[ax][(size_t)(2 * k + 1)]; }
             if (sign && (k & 1)) { re = -re; im = -im; }
             t[(size_t)k].re = (float)re; t[(size_t)k].im = (float)im;
-            if (P->fastm) { td[(size_t)k].re = re; td[(size_t)k].im = im; }
-            if (P->fastm ? (re != 1.0 || im != 0.0) : (t[(size_t)k].re != 1.0f || t[(size_t)k].im != 0.0f)) P->fph_on = true;
+            if (dtab) { td[(size_t)k].re = re; td[(size_t)k].im = im; }
+            if (dtab ? (re != 1.0 || im != 0.0) : (t[(size_t)k].re != 1.0f || t[(size_t)k].im != 0.0f)) P->fph_on = true;
         }
-        int rc = P->fastm ? P->fph[ax].upload(td.data(), td.size() * sizeof(C2<double>)) : P->fph[ax].upload(t.data(), t.size() * sizeof(cf));
+        int rc = dtab ? P->fph[ax].upload(td.data(), td.size() * sizeof(C2<double>)) : P->fph[ax].upload(t.data(), t.size() * sizeof(cf));
         if (rc) return rc;
     }
     return XRFTHIP_OK;
@@ -1071,7 +1072,7 @@ static int fasty_window_spectra(xrfthip_plan* P) {
         r0 = o0r; i0 = o0i; r1 = o1r; i1 = o1i;
     }
     const int nent = P->y_nrow_pad;
-    if (P->fastm) {
+    if (P->fastm && P->dbl) {
         std::vector<C2<double>> d0((size_t)nent), d1((size_t)nent);
         for (int k = 0; k < nent; ++k) {
             d0[(size_t)k].re = k <= nyh ? r0[(size_t)k] : 0.0; d0[(size_t)k].im = k <= nyh ? i0[(size_t)k] : 0.0;
@@ -1238,33 +1239,34 @@ static int run_fasty(const xrfthip_plan* P, const float* in, const float* in1, v
 // mixed-radix float64 form of the y-first pipeline (fastm.h)
 // ---------------------------------------------------------------------------------------------------------------
 struct MGeomRt { int thr, g; size_t lds_cols, lds_rows; int r0, r1, r2; int thr_r1, g_r1; size_t lds_r1; };  // *_r1: pass 2 of one field
-template <int N> static MGeomRt mgeom_t() {
-    typedef MGeom<double, N> M;
+template <typename T, int N> static MGeomRt mgeom_t() {
+    typedef MGeom<T, N> M;
     typedef typename M::template Rows<M::GR1> R1;
     return {M::THR, M::G, M::LDS, M::LDS_ROWS, M::R0, M::R1, M::R2, R1::THR, M::GR1, R1::LDS};
 }
 static bool fastm_len(long long n) { return n == 360 || n == 720 || n == 1440; }
-static MGeomRt mgeom(long long n) {
-    switch (n) { case 1440: return mgeom_t<1440>(); case 720: return mgeom_t<720>(); default: return mgeom_t<360>(); }
+static MGeomRt mgeom(long long n, bool dbl) {
+    if (dbl) switch (n) { case 1440: return mgeom_t<double, 1440>(); case 720: return mgeom_t<double, 720>(); default: return mgeom_t<double, 360>(); }
+    switch (n) { case 1440: return mgeom_t<float, 1440>(); case 720: return mgeom_t<float, 720>(); default: return mgeom_t<float, 360>(); }
 }
 // layout of the intermediate: CW = 2 G columns of a pass-1 workgroup, RK rows per 128-byte line
-static int fastm_cw(long long ny) { return 2 * mgeom(ny).g; }
-static int fastm_rk(long long ny) { const int cw = fastm_cw(ny); return cw * 16 >= 128 ? 1 : 128 / (cw * 16); }
-static int fastm_rpu(long long nx, bool two) { const MGeomRt r = mgeom(nx); return two ? r.g / 2 : r.g_r1; }  // rows per pass-2 workgroup (radial sums fused: fastm_rows_rpu)
+static int fastm_cw(long long ny, bool dbl) { return 2 * mgeom(ny, dbl).g; }
+static int fastm_rk(long long ny, bool dbl) { const int lb = fastm_cw(ny, dbl) * (dbl ? 16 : 8); return lb >= 128 ? 1 : 128 / lb; }
+static int fastm_rpu(long long nx, bool two, bool dbl) { const MGeomRt r = mgeom(nx, dbl); return two ? r.g / 2 : r.g_r1; }  // 
 
 // radial sums inside pass 2 when the per-bin tables fit behind the transforms' LDS (64 KB of dynamic LDS per workgroup); otherwise
 // the spectrum is stored and summed by run_radial_sums
 static bool fastm_iso_fused(const xrfthip_plan* P) {
     if (!P->fastm || !(P->d.flags & XRFTHIP_ISO) || P->nbins < 1) return false;
     const bool cx = P->d.out_mode == XRFTHIP_OUT_CROSS;
-    const MGeomRt R = mgeom(P->ynx);
+    const MGeomRt R = mgeom(P->ynx, P->dbl);
     return R.lds_rows + (size_t)P->nbins * (cx ? 20 : 12) <= 64 * 1024;
 }
 
 // copies of the per-bin tables in pass 2 (a power of two <= 8, whatever fits the 64 KB)
 static int fastm_iso_ncopy(const xrfthip_plan* P) {
     const bool cx = P->d.out_mode == XRFTHIP_OUT_CROSS;
-    const MGeomRt R = mgeom(P->ynx);
+    const MGeomRt R = mgeom(P->ynx, P->dbl);
     const size_t per = (size_t)P->nbins * (cx ? 20 : 12), room = 64 * 1024 - R.lds_rows;
     int nc = 1;
     while (nc < 8 && per * (size_t)(2 * nc) <= room) nc *= 2;
@@ -1275,7 +1277,7 @@ static int fastm_iso_ncopy(const xrfthip_plan* P) {
 // keeps pass 1's sequence count (MRowsG in fastm.h)
 static int fastm_rows_rpu(const xrfthip_plan* P) {
     const bool two = P->d.out_mode == XRFTHIP_OUT_CROSS || P->d.out_mode == XRFTHIP_OUT_PHASE;
-    const MGeomRt r = mgeom(P->ynx);
+    const MGeomRt r = mgeom(P->ynx, P->dbl);
     return two ? r.g / 2 : (fastm_iso_fused(P) ? r.g : r.g_r1);
 }
 
@@ -1283,9 +1285,9 @@ static FastM fastm_params(const xrfthip_plan* P, const void* in, void* out, char
     const xrfthip_desc& d = P->d;
     const size_t slab_pts = (size_t)P->yny * P->ynx, s0 = (size_t)slot * slot_slabs;
     FastM p{};
-    p.in = (const char*)in + (size_t)g0 * slab_pts * sizeof(double);
-    p.w2 = reinterpret_cast<C2<double>*>(ws + P->off_w) + s0 * (size_t)P->y_nrow_pad * P->ynx;
-    const size_t out_esz = (d.out_mode == XRFTHIP_OUT_POWER || d.out_mode == XRFTHIP_OUT_PHASE) ? sizeof(double) : sizeof(C2<double>);
+    p.in = (const char*)in + (size_t)g0 * slab_pts * P->rsize;
+    p.w2 = ws + P->off_w + s0 * (size_t)P->y_nrow_pad * P->ynx * P->csize;
+    const size_t out_esz = (d.out_mode == XRFTHIP_OUT_POWER || d.out_mode == XRFTHIP_OUT_PHASE) ? P->rsize : P->csize;
     const size_t out_pts = (size_t)P->yny * ((d.flags & XRFTHIP_HALF_X) ? P->ynx / 2 + 1 : P->ynx);
     p.out = out ? (char*)out + (size_t)g0 * out_pts * out_esz : nullptr;
     p.half = (d.flags & XRFTHIP_HALF_X) ? 1 : 0;
@@ -1294,15 +1296,15 @@ static FastM fastm_params(const xrfthip_plan* P, const void* in, void* out, char
     p.win_y = P->win[0].p ? P->win[0].p : P->ones4096.p;
     p.win_x = P->win[1].p ? P->win[1].p : P->ones4096.p;
     p.colfit = reinterpret_cast<double*>(ws + P->off_rowfit) + s0 * (size_t)P->ynx * 4;
-    p.corr = reinterpret_cast<const C2<double>*>(ws + P->off_corr) + s0 * (size_t)P->ynx;
+    p.corr = ws + P->off_corr + s0 * (size_t)P->ynx * P->csize;
     p.ph_y = P->fph[0].p; p.ph_x = P->fph[1].p; p.ph_on = P->fph_on ? 1 : 0;
     p.what0 = P->ywhat0.p; p.what1 = P->ywhat1.p;
     p.binmap = (const int*)P->binmap.p; p.nbins = P->nbins; p.iso_ncopy = P->nbins > 0 ? fastm_iso_ncopy(P) : 1;
     p.iso_part = reinterpret_cast<double*>(ws + P->off_isopart);
     p.ny = (int)P->yny; p.nx = (int)P->ynx; p.nrow_pad = P->y_nrow_pad;
-    p.l_cw = ilog2i(fastm_cw(P->yny)); p.l_rk = ilog2i(fastm_rk(P->yny));
+    p.l_cw = ilog2i(fastm_cw(P->yny, P->dbl)); p.l_rk = ilog2i(fastm_rk(P->yny, P->dbl));
     p.detrend = d.detrend; p.nslab = (int)gc;
-    p.nunits = (int)(gc * (P->ynx / fastm_cw(P->yny)));
+    p.nunits = (int)(gc * (P->ynx / fastm_cw(P->yny, P->dbl)));
     p.shift_y = (d.flags & XRFTHIP_SHIFT_Y) ? (int)(P->yny / 2) : 0;
     p.shift_x = (d.flags & XRFTHIP_SHIFT_X) ? (int)(P->ynx / 2) : 0;
     p.scale = d.scale;
@@ -1311,7 +1313,7 @@ static FastM fastm_params(const xrfthip_plan* P, const void* in, void* out, char
 
 static void fastm_launch_cols(const xrfthip_plan* P, const FastM& p, long long gc, hipStream_t st) {
     const xrfthip_desc& d = P->d;
-    const MGeomRt C = mgeom(P->yny);
+    const MGeomRt C = mgeom(P->yny, P->dbl);
     xrfthip_plan::ProfRec* rec = prof_begin(P, "fastm_cols", st);
     const dim3 grid((unsigned)(8 * ((p.nunits + 7) / 8))), blk((unsigned)C.thr);
 #ifdef XRFT_M_BIGLDS  /* profiling builds with more than 64 KB of LDS per workgroup */
@@ -1319,35 +1321,43 @@ static void fastm_launch_cols(const xrfthip_plan* P, const FastM& p, long long g
 #else
 #define MBIG_(k, n) ((void)0)
 #endif
-#define MC_(NN) do { if (d.detrend) { auto k = &fastm_cols_kernel<double, NN, true>; MBIG_(k, C.lds_cols); XRFT_LAUNCH(k, grid, blk, C.lds_cols, st, p); } \
-                     else { auto k = &fastm_cols_kernel<double, NN, false>; MBIG_(k, C.lds_cols); XRFT_LAUNCH(k, grid, blk, C.lds_cols, st, p); } } while (0)
-    if (P->yny == 1440) MC_(1440); else if (P->yny == 720) MC_(720); else MC_(360);
+#define MC_(TT, NN) do { if (d.detrend) { auto k = &fastm_cols_kernel<TT, NN, true>; MBIG_(k, C.lds_cols); XRFT_LAUNCH(k, grid, blk, C.lds_cols, st, p); } \
+                         else { auto k = &fastm_cols_kernel<TT, NN, false>; MBIG_(k, C.lds_cols); XRFT_LAUNCH(k, grid, blk, C.lds_cols, st, p); } } while (0)
+    if (P->dbl) { if (P->yny == 1440) MC_(double, 1440); else if (P->yny == 720) MC_(double, 720); else MC_(double, 360); }
+    else { if (P->yny == 1440) MC_(float, 1440); else if (P->yny == 720) MC_(float, 720); else MC_(float, 360); }
 #undef MC_
     prof_end(rec, st);
     if (d.detrend) {
         rec = prof_begin(P, "fastm_fit", st);
-        auto kf = &fastm_fit_kernel<double>;
-        XRFT_LAUNCH(kf, dim3((unsigned)gc), dim3(256), 3 * 256 * sizeof(double), st, (const double*)p.colfit, (const double*)p.win_x,
-                    reinterpret_cast<C2<double>*>(const_cast<void*>(p.corr)), (int)P->ynx, (int)P->yny, (int)d.detrend);
+        if (P->dbl) {
+            auto kf = &fastm_fit_kernel<double>;
+            XRFT_LAUNCH(kf, dim3((unsigned)gc), dim3(256), 3 * 256 * sizeof(double), st, (const double*)p.colfit, (const double*)p.win_x,
+                        reinterpret_cast<C2<double>*>(const_cast<void*>(p.corr)), (int)P->ynx, (int)P->yny, (int)d.detrend);
+        } else {
+            auto kf = &fastm_fit_kernel<float>;
+            XRFT_LAUNCH(kf, dim3((unsigned)gc), dim3(256), 3 * 256 * sizeof(double), st, (const double*)p.colfit, (const float*)p.win_x,
+                        reinterpret_cast<C2<float>*>(const_cast<void*>(p.corr)), (int)P->ynx, (int)P->yny, (int)d.detrend);
+        }
         prof_end(rec, st);
     }
 }
 
 static void fastm_launch_rows(const xrfthip_plan* P, const FastM& p, long long gc, hipStream_t st) {
     const xrfthip_desc& d = P->d;
-    const MGeomRt R = mgeom(P->ynx);
+    const MGeomRt R = mgeom(P->ynx, P->dbl);
     const bool two = d.out_mode == XRFTHIP_OUT_CROSS || d.out_mode == XRFTHIP_OUT_PHASE;
     xrfthip_plan::ProfRec* rec = prof_begin(P, "fastm_rows", st);
     const bool fused = fastm_iso_fused(P), full = two || fused;  // (full: pass 1's sequence count per workgroup)
     const dim3 grid((unsigned)(gc * (P->y_nrow_pad / fastm_rows_rpu(P)))), blk((unsigned)(full ? R.thr : R.thr_r1));
     const size_t lds_rows = full ? R.lds_rows : R.lds_r1;
     const size_t lds_iso = lds_rows + (size_t)P->nbins * (d.out_mode == XRFTHIP_OUT_CROSS ? 20 : 12) * (size_t)p.iso_ncopy;
-#define MR_(NN) do { \
-        if (d.out_mode == XRFTHIP_OUT_POWER) { if (fused) { auto k = &fastm_rows_kernel<double, NN, 1, true>; XRFT_LAUNCH(k, grid, blk, lds_iso, st, p); } else { auto k = &fastm_rows_kernel<double, NN, 1>; MBIG_(k, lds_rows); XRFT_LAUNCH(k, grid, blk, lds_rows, st, p); } } \
-        else if (d.out_mode == XRFTHIP_OUT_CROSS) { if (fused) { auto k = &fastm_rows_kernel<double, NN, 2, true>; XRFT_LAUNCH(k, grid, blk, lds_iso, st, p); } else { auto k = &fastm_rows_kernel<double, NN, 2>; XRFT_LAUNCH(k, grid, blk, R.lds_rows, st, p); } } \
-        else if (d.out_mode == XRFTHIP_OUT_PHASE) { auto k = &fastm_rows_kernel<double, NN, 3>; XRFT_LAUNCH(k, grid, blk, R.lds_rows, st, p); } \
-        else { auto k = &fastm_rows_kernel<double, NN, 0>; XRFT_LAUNCH(k, grid, blk, lds_rows, st, p); } } while (0)
-    if (P->ynx == 1440) MR_(1440); else if (P->ynx == 720) MR_(720); else MR_(360);
+#define MR_(TT, NN) do { \
+        if (d.out_mode == XRFTHIP_OUT_POWER) { if (fused) { auto k = &fastm_rows_kernel<TT, NN, 1, true>; XRFT_LAUNCH(k, grid, blk, lds_iso, st, p); } else { auto k = &fastm_rows_kernel<TT, NN, 1>; MBIG_(k, lds_rows); XRFT_LAUNCH(k, grid, blk, lds_rows, st, p); } } \
+        else if (d.out_mode == XRFTHIP_OUT_CROSS) { if (fused) { auto k = &fastm_rows_kernel<TT, NN, 2, true>; XRFT_LAUNCH(k, grid, blk, lds_iso, st, p); } else { auto k = &fastm_rows_kernel<TT, NN, 2>; XRFT_LAUNCH(k, grid, blk, R.lds_rows, st, p); } } \
+        else if (d.out_mode == XRFTHIP_OUT_PHASE) { auto k = &fastm_rows_kernel<TT, NN, 3>; XRFT_LAUNCH(k, grid, blk, R.lds_rows, st, p); } \
+        else { auto k = &fastm_rows_kernel<TT, NN, 0>; XRFT_LAUNCH(k, grid, blk, lds_rows, st, p); } } while (0)
+    if (P->dbl) { if (P->ynx == 1440) MR_(double, 1440); else if (P->ynx == 720) MR_(double, 720); else MR_(double, 360); }
+    else { if (P->ynx == 1440) MR_(float, 1440); else if (P->ynx == 720) MR_(float, 720); else MR_(float, 360); }
 #undef MR_
     prof_end(rec, st);
 }
@@ -1381,7 +1391,7 @@ static int run_fastm(const xrfthip_plan* P, const void* in, const void* in1, voi
         } else if (iso_on) {  // radial sums of the stored spectrum (xrft.py:895-906), bit-reproducible
             const bool cx = d.out_mode == XRFTHIP_OUT_CROSS;
             xrfthip_plan::ProfRec* rec = prof_begin(P, "radial_sums", st);
-            const int rc = run_radial_sums(cx ? XRFTHIP_C128 : XRFTHIP_F64, p.out, (const int32_t*)P->binmap.p, gc, d.ny, d.nx, p.shift_y, p.shift_x, P->nbins,
+            const int rc = run_radial_sums(cx ? (P->dbl ? XRFTHIP_C128 : XRFTHIP_C64) : (P->dbl ? XRFTHIP_F64 : XRFTHIP_F32), p.out, (const int32_t*)P->binmap.p, gc, d.ny, d.nx, p.shift_y, p.shift_x, P->nbins,
                                            P->iso_chunks, reinterpret_cast<double*>(ws + P->off_isopart), iso + (size_t)g0 * P->nbins * (cx ? 2 : 1), st);
             prof_end(rec, st);
             if (rc) return rc;
@@ -1596,23 +1606,24 @@ int xrfthip_plan_create(xrfthip_plan** plan, const xrfthip_desc* desc) {
         const uint32_t allowed = d.out_mode == XRFTHIP_OUT_POWER ? (shifts | isof | halff) : d.out_mode == XRFTHIP_OUT_CROSS ? (shifts | ish | isof | halff)
                                  : (d.out_mode == XRFTHIP_OUT_COMPLEX || d.out_mode == XRFTHIP_OUT_PHASE) ? (shifts | ish | XRFTHIP_HALF_X) : 0u;
         const bool half_ok = !((d.flags & halff) && (d.flags & XRFTHIP_ISO)) && !((d.flags & XRFTHIP_HALF_X) && (d.flags & XRFTHIP_SHIFT_X));
-        P->fastm = half_ok && d.ndim == 2 && d.dtype == XRFTHIP_F64 && fastm_len(d.ny) && fastm_len(d.nx) && !(d.flags & ~allowed) &&
+        P->fastm = half_ok && d.ndim == 2 && (d.dtype == XRFTHIP_F64 || d.dtype == XRFTHIP_F32) && fastm_len(d.ny) && fastm_len(d.nx) && !(d.flags & ~allowed) &&
                    !env_ll("XRFTHIP_NO_FAST", 0) && env_ll("XRFTHIP_FASTM", 1) != 0;
         if (P->fastm) {
             const bool two = d.out_mode == XRFTHIP_OUT_CROSS || d.out_mode == XRFTHIP_OUT_PHASE;
-            const int rpu = fastm_rpu(d.nx, two);
-            if (rpu < 1 || rpu % fastm_rk(d.ny) != 0 || d.nx % fastm_cw(d.ny) != 0) P->fastm = false;
+            const int rpu = fastm_rpu(d.nx, two, P->dbl);
+            if (rpu < 1 || rpu % fastm_rk(d.ny, P->dbl) != 0 || d.nx % fastm_cw(d.ny, P->dbl) != 0) P->fastm = false;
         }
         if (P->fastm) {
             const bool two = d.out_mode == XRFTHIP_OUT_CROSS || d.out_mode == XRFTHIP_OUT_PHASE;
-            const int rpu = two ? fastm_rpu(d.nx, true) : mgeom(d.nx).g;  // (the largest count a row kernel of this plan may use)
+            const int rpu = two ? fastm_rpu(d.nx, true, P->dbl) : mgeom(d.nx, P->dbl).g;  // (the largest count a row kernel of this plan may use)
             P->yfirst = true;
             P->yny = d.ny; P->ynx = d.nx;
             P->y_nrow_pad = (int)((d.ny / 2 + 1 + rpu - 1) / rpu * rpu);
-            int rcm = build_twiddle<double>(P->tw_fx, d.nx, d.nx);
-            if (!rcm) rcm = build_twiddle<double>(P->tw_fy, d.ny, d.ny);
+            int rcm = P->dbl ? build_twiddle<double>(P->tw_fx, d.nx, d.nx) : build_twiddle<float>(P->tw_fx, d.nx, d.nx);
+            if (!rcm) rcm = P->dbl ? build_twiddle<double>(P->tw_fy, d.ny, d.ny) : build_twiddle<float>(P->tw_fy, d.ny, d.ny);
             std::vector<double> ones((size_t)std::max(d.ny, d.nx), 1.0);
-            if (!rcm) rcm = P->ones4096.upload(ones.data(), ones.size() * sizeof(double));
+            std::vector<float> onesf((size_t)std::max(d.ny, d.nx), 1.0f);
+            if (!rcm) rcm = P->dbl ? P->ones4096.upload(ones.data(), ones.size() * sizeof(double)) : P->ones4096.upload(onesf.data(), onesf.size() * sizeof(float));
             if (rcm) { delete P; return rcm; }
         }
     }
@@ -1715,9 +1726,9 @@ int xrfthip_plan_describe(const xrfthip_plan* plan, char* buf, size_t buflen) {
             d.ndim, (long long)d.batch, (long long)d.ny, (long long)d.nx, d.dtype, d.out_mode, d.detrend, d.flags,
             plan->width, plan->nx_out, (int)plan->mirror, plan->G, plan->ws_bytes);
     if (plan->fastm) {
-        const MGeomRt C = mgeom(plan->yny), R = mgeom(plan->ynx);
-        appendf(s, "  [fastm] cols: %d thr, %d packed column pairs (FFT%lld r%dx%dx%d in LDS), lds=%zuB -> W2[slab][%d/%d][nx/%d][%d][%d] complex128 -> fit -> rows: %d thr, %d rows/unit (FFT%lld r%dx%dx%d), lds=%zuB, trend added back in the spectral domain, fftshift + mirror rows\n",
-                C.thr, C.g, (long long)plan->yny, C.r0, C.r1, C.r2, C.lds_cols, plan->y_nrow_pad, fastm_rk(plan->yny), fastm_cw(plan->yny), fastm_rk(plan->yny), fastm_cw(plan->yny),
+        const MGeomRt C = mgeom(plan->yny, plan->dbl), R = mgeom(plan->ynx, plan->dbl);
+        appendf(s, "  [fastm] cols: %d thr, %d packed column pairs (FFT%lld r%dx%dx%d in LDS), lds=%zuB -> W2[slab][%d/%d][nx/%d][%d][%d] complex -> fit -> rows: %d thr, %d rows/unit (FFT%lld r%dx%dx%d), lds=%zuB, trend added back in the spectral domain, fftshift + mirror rows\n",
+                C.thr, C.g, (long long)plan->yny, C.r0, C.r1, C.r2, C.lds_cols, plan->y_nrow_pad, fastm_rk(plan->yny, plan->dbl), fastm_cw(plan->yny, plan->dbl), fastm_rk(plan->yny, plan->dbl), fastm_cw(plan->yny, plan->dbl),
                 R.thr_r1, R.g_r1, (long long)plan->ynx, R.r0, R.r1, R.r2, R.lds_r1);
     } else if (fasty_on(plan)) {
         const YGeomRt C = ycols_geom(plan->yny), R = yrows_geom(plan->ynx);
