@@ -1,5 +1,5 @@
 // fastm.h -- the two-pass "y first" pipeline (fasty.h) for slabs whose two lengths are products of three small radices
-// (2^a 3^b 5^c: 360, 720, 1440, ... -- the regular lat/lon grids) and for float64: BASELINE.json configs[4] is
+// (2^a 3^b 5^c: 180 ... 1440 -- the regular lat/lon grids -- in float64 and float32; 256 / 512 / 1024 in float64): BASELINE.json configs[4] is
 // power_spectrum of (64, 1440, 720) float64 slabs with a linear detrend and a Hann window.
 //     pass 1  fastm_cols_kernel   FFT along y of the real columns (window fused), half spectra ky = 0..ny/2, exact column sums
 //     [fit]   fastm_fit_kernel    plane from the per-column sums (xrft/detrend.py:100-113)
@@ -25,10 +25,20 @@ namespace xrft {
 template <int N> struct MRad { static constexpr int R0 = 0, R1 = 0, R2 = 0; };
 #define XRFT_MRAD(NN, A, B, C) \
     template <> struct MRad<NN> { static constexpr int R0 = A, R1 = B, R2 = C; static_assert(A * B * C == NN, "radices"); }
+XRFT_MRAD(180, 5, 6, 6);
+XRFT_MRAD(240, 5, 6, 8);
 XRFT_MRAD(360, 6, 6, 10);
+XRFT_MRAD(480, 6, 8, 10);
 XRFT_MRAD(720, 8, 9, 10);
+XRFT_MRAD(960, 8, 10, 12);
 XRFT_MRAD(1440, 10, 12, 12);
+XRFT_MRAD(256, 4, 8, 8);   // (powers of two: float64 only -- float32 has the register-resident kernels of fasty.h)
+XRFT_MRAD(512, 8, 8, 8);
+XRFT_MRAD(1024, 8, 8, 16);
 #undef XRFT_MRAD
+// the lengths the host dispatches on: X(N) for every entry
+#define XRFT_M_LATLON(X) X(180) X(240) X(360) X(480) X(720) X(960) X(1440)
+#define XRFT_M_POW2(X) X(256) X(512) X(1024)
 
 constexpr int mr_max3(int a, int b, int c) { return a > b ? (a > c ? a : c) : (b > c ? b : c); }
 

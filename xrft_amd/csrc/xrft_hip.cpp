@@ -1244,10 +1244,23 @@ template <typename T, int N> static MGeomRt mgeom_t() {
     typedef typename M::template Rows<M::GR1> R1;
     return {M::THR, M::G, M::LDS, M::LDS_ROWS, M::R0, M::R1, M::R2, R1::THR, M::GR1, R1::LDS};
 }
-static bool fastm_len(long long n) { return n == 360 || n == 720 || n == 1440; }
+static bool fastm_len(long long n, bool dbl) {
+#define X_(NN) if (n == NN) return true;
+    XRFT_M_LATLON(X_)
+    if (dbl) { XRFT_M_POW2(X_) }
+#undef X_
+    return false;
+}
 static MGeomRt mgeom(long long n, bool dbl) {
-    if (dbl) switch (n) { case 1440: return mgeom_t<double, 1440>(); case 720: return mgeom_t<double, 720>(); default: return mgeom_t<double, 360>(); }
-    switch (n) { case 1440: return mgeom_t<float, 1440>(); case 720: return mgeom_t<float, 720>(); default: return mgeom_t<float, 360>(); }
+    if (dbl) {
+#define X_(NN) if (n == NN) return mgeom_t<double, NN>();
+        XRFT_M_LATLON(X_) XRFT_M_POW2(X_)
+#undef X_
+    }
+#define X_(NN) if (n == NN) return mgeom_t<float, NN>();
+    XRFT_M_LATLON(X_)
+#undef X_
+    return mgeom_t<float, 360>();
 }
 // layout of the intermediate: CW = 2 G columns of a pass-1 workgroup, RK rows per 128-byte line
 static int fastm_cw(long long ny, bool dbl) { return 2 * mgeom(ny, dbl).g; }
@@ -1323,8 +1336,11 @@ static void fastm_launch_cols(const xrfthip_plan* P, const FastM& p, long long g
 #endif
 #define MC_(TT, NN) do { if (d.detrend) { auto k = &fastm_cols_kernel<TT, NN, true>; MBIG_(k, C.lds_cols); XRFT_LAUNCH(k, grid, blk, C.lds_cols, st, p); } \
                          else { auto k = &fastm_cols_kernel<TT, NN, false>; MBIG_(k, C.lds_cols); XRFT_LAUNCH(k, grid, blk, C.lds_cols, st, p); } } while (0)
-    if (P->dbl) { if (P->yny == 1440) MC_(double, 1440); else if (P->yny == 720) MC_(double, 720); else MC_(double, 360); }
-    else { if (P->yny == 1440) MC_(float, 1440); else if (P->yny == 720) MC_(float, 720); else MC_(float, 360); }
+#define XD_(NN) if (P->yny == NN) MC_(double, NN);
+#define XF_(NN) if (P->yny == NN) MC_(float, NN);
+    if (P->dbl) { XRFT_M_LATLON(XD_) XRFT_M_POW2(XD_) } else { XRFT_M_LATLON(XF_) }
+#undef XD_
+#undef XF_
 #undef MC_
     prof_end(rec, st);
     if (d.detrend) {
@@ -1356,8 +1372,11 @@ static void fastm_launch_rows(const xrfthip_plan* P, const FastM& p, long long g
         else if (d.out_mode == XRFTHIP_OUT_CROSS) { if (fused) { auto k = &fastm_rows_kernel<TT, NN, 2, true>; XRFT_LAUNCH(k, grid, blk, lds_iso, st, p); } else { auto k = &fastm_rows_kernel<TT, NN, 2>; XRFT_LAUNCH(k, grid, blk, R.lds_rows, st, p); } } \
         else if (d.out_mode == XRFTHIP_OUT_PHASE) { auto k = &fastm_rows_kernel<TT, NN, 3>; XRFT_LAUNCH(k, grid, blk, R.lds_rows, st, p); } \
         else { auto k = &fastm_rows_kernel<TT, NN, 0>; XRFT_LAUNCH(k, grid, blk, lds_rows, st, p); } } while (0)
-    if (P->dbl) { if (P->ynx == 1440) MR_(double, 1440); else if (P->ynx == 720) MR_(double, 720); else MR_(double, 360); }
-    else { if (P->ynx == 1440) MR_(float, 1440); else if (P->ynx == 720) MR_(float, 720); else MR_(float, 360); }
+#define XD_(NN) if (P->ynx == NN) MR_(double, NN);
+#define XF_(NN) if (P->ynx == NN) MR_(float, NN);
+    if (P->dbl) { XRFT_M_LATLON(XD_) XRFT_M_POW2(XD_) } else { XRFT_M_LATLON(XF_) }
+#undef XD_
+#undef XF_
 #undef MR_
     prof_end(rec, st);
 }
@@ -1606,7 +1625,7 @@ int xrfthip_plan_create(xrfthip_plan** plan, const xrfthip_desc* desc) {
         const uint32_t allowed = d.out_mode == XRFTHIP_OUT_POWER ? (shifts | isof | halff) : d.out_mode == XRFTHIP_OUT_CROSS ? (shifts | ish | isof | halff)
                                  : (d.out_mode == XRFTHIP_OUT_COMPLEX || d.out_mode == XRFTHIP_OUT_PHASE) ? (shifts | ish | XRFTHIP_HALF_X) : 0u;
         const bool half_ok = !((d.flags & halff) && (d.flags & XRFTHIP_ISO)) && !((d.flags & XRFTHIP_HALF_X) && (d.flags & XRFTHIP_SHIFT_X));
-        P->fastm = half_ok && d.ndim == 2 && (d.dtype == XRFTHIP_F64 || d.dtype == XRFTHIP_F32) && fastm_len(d.ny) && fastm_len(d.nx) && !(d.flags & ~allowed) &&
+        P->fastm = half_ok && d.ndim == 2 && (d.dtype == XRFTHIP_F64 || d.dtype == XRFTHIP_F32) && !P->fast4096 && fastm_len(d.ny, P->dbl) && fastm_len(d.nx, P->dbl) && !(d.flags & ~allowed) &&
                    !env_ll("XRFTHIP_NO_FAST", 0) && env_ll("XRFTHIP_FASTM", 1) != 0;
         if (P->fastm) {
             const bool two = d.out_mode == XRFTHIP_OUT_CROSS || d.out_mode == XRFTHIP_OUT_PHASE;
