@@ -64,6 +64,11 @@ add("C5 PS (64,1440,720) f64 linear+hann", x.numel(), 16, timeit(lambda: xrft.po
 add("   same, detrend=None", x.numel(), 16, timeit(lambda: xrft.power_spectrum(da, dim=["lat", "lon"], window="hann")))
 da32 = xrft.DataArray(x.float(), da.dims, da.coords)
 add("   same shape, float32, linear+hann", x.numel(), 8, timeit(lambda: xrft.power_spectrum(da32, dim=["lat", "lon"], detrend="linear", window="hann")))
+add("   isotropic PS (64,1440,720) f64 linear+hann", x.numel(), 8, timeit(lambda: xrft.isotropic_power_spectrum(da, dim=["lat", "lon"], detrend="linear", window="hann")))
+add("   dft complex out (64,1440,720) f64 linear+hann", x.numel(), 24, timeit(lambda: xrft.dft(da, dim=["lat", "lon"], detrend="linear", window="hann")))
+y64 = cube((64, 1440, 720), torch.float64); db = xrft.DataArray(y64, da.dims, da.coords)
+add("   cross_spectrum 2x(64,1440,720) f64 linear+hann", x.numel(), 32, timeit(lambda: xrft.cross_spectrum(da, db, dim=["lat", "lon"], detrend="linear", window="hann")))
+del y64, db
 # a middle axis in place (XRFTHIP_AXIS_Y)
 x = cube((64, 1024, 2048), torch.float32); da = xrft.DataArray(x, ("t", "y", "x"), {"y": np.arange(1024.), "x": np.arange(2048.)})
 add("fft along the MIDDLE axis (64,1024,2048) f32, no copies", x.numel(), 12, timeit(lambda: xrft.fft(da, dim=["y"])))
