@@ -329,10 +329,14 @@ __global__ void __launch_bounds__(YCols<NY>::THR, YCols<NY>::THR / 128) fasty_co
 // output row -ky (Hermitian mirror of the spectrum of a real field); ky = 0 and ny/2 are their own mirrors.
 //   xrft.py:446-447 (fftshift), :740-748 (|F|^2 and the scalings, folded into `scale`), :895-906 (ISO: radial sums)
 // ------------------------------------------------------------------------------------------------
-template <int NX> struct YRows {
-    static constexpr int THR = NX >= 2048 ? 512 : 256;
+// Small workgroups -- 128 threads up to 1024-point rows, 256 at 2048: twice as many per CU as with 256 / 512 -- interleave their
+// load / transform / store phases better: row pass -19 % at 256 (PS (4096, 256, 256) 256 -> 286 GFFT/s), -6 ... -8 % at 512, 1024,
+// 2048.  Not at 4096 (one sequence pair per 256-thread workgroup: 24.1 -> 32.5 us), and not in the four-step form, whose
+// transposed runs are one sample per row of the unit: 32 rows = a whole line (dft (1024, 65536): 170 vs 156 GFFT/s).
+template <int NX, bool FS = false> struct YRows {
+    static constexpr int THR = NX >= 4096 ? 512 : NX >= 2048 ? 256 : ((NX == 256 && FS) ? 256 : 128);
     static constexpr int NT = NX / 16;
-    static constexpr int GX = THR / NT;  // 2, 4, 4, 8, 16
+    static constexpr int GX = THR / NT;  // sequences (pairs of rows) in lockstep: 8, 4, 2, 2, 2 (four-step: 16)
     static constexpr int RPU = 2 * GX;   // rows per workgroup
     static constexpr int RS = NX + NX / 16;  // floats per staged row (nat16 padding)
 };
@@ -375,11 +379,11 @@ __device__ __forceinline__ void xrft_store_nt2(cf* dst, cf v0, cf v1) {
 // (2 GX * 4 or GX * 8 bytes contiguous); the Hermitian mirror X[N - k] = conj X[k] is the reversed run.  (xrft.dft / fft /
 // power_spectrum along one long axis, BASELINE.json configs[1]: 1-D (1024, 65536) float32.)
 template <int NX, int MODE, bool ISO, bool FS = false>
-__global__ void __launch_bounds__(YRows<NX>::THR, YRows<NX>::THR / 128) fasty_rows_kernel(FastY p) {
+__global__ void __launch_bounds__((YRows<NX, FS>::THR), (YRows<NX, FS>::THR / 128 < 1 ? 1 : YRows<NX, FS>::THR / 128)) fasty_rows_kernel(FastY p) {
     static_assert(MODE == 1 || MODE == 2 || !ISO, "radial sums exist for power and cross spectra");
     static_assert(!FS || (MODE <= 1 && !ISO), "the four-step form serves fft and power_spectrum");
     typedef P2<NX> G;
-    typedef YRows<NX> R;
+    typedef YRows<NX, FS> R;
     constexpr bool TWO = MODE >= 2;  // two fields
     constexpr int NT = G::NT, GX = R::GX, THR = R::THR, RPU = TWO ? GX : 2 * GX, GSTR = YLds<NX, GX>::GSTR;
     constexpr int HW = MODE == 2 ? 2 : 1;  // doubles per radial bin

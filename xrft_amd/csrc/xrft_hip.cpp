@@ -833,6 +833,7 @@ static int upload_real_table(xrfthip_plan* P, DevBuf& buf, const double* h, int6
 
 static bool fast_on(const xrfthip_plan* P);
 static bool fastm_iso_fused(const xrfthip_plan* P);
+static long long fasty_rows_gx(const xrfthip_plan* P);
 static int fastm_rows_rpu(const xrfthip_plan* P);
 
 // workgroups per slab of radial_binsum_det_kernel: chunks of <= 2^17 elements (its int64 sums hold 2^17 values), at most 128
@@ -908,7 +909,7 @@ static void layout_workspace(xrfthip_plan* P) {
     P->off_isopart = off;
     if (yf && !P->fastm && (d.flags & XRFTHIP_ISO)) {  // per-workgroup partial radial sums of one group of slabs (reduced in order)
         const bool two = d.out_mode == XRFTHIP_OUT_CROSS;
-        const long long gx = (P->ynx >= 2048 ? 512 : 256) / (P->ynx / 16);  // YRows<NX>::GX
+        const long long gx = fasty_rows_gx(P);  // YRows<NX>::GX
         const size_t upr = (size_t)P->y_nrow_pad / (two ? gx : 2 * gx);
         off = al(off + (size_t)G * upr * P->nbins * (two ? 2 : 1) * sizeof(double));
     }
@@ -1032,18 +1033,20 @@ template <int NY> static YGeomRt ycols_geom_t() {
     typedef YCols<NY> Y;
     return {Y::THR, Y::GY, Y::CW, Y::RK, Y::LBS, (size_t)(Y::GY * YLds<NY, Y::GY>::GSTR + 16 * P2<NY>::R3) * sizeof(cf) + (size_t)(Y::THR / 64) * Y::GY * 8 * sizeof(double)};
 }
-template <int NX> static YGeomRt yrows_geom_t() {
-    typedef YRows<NX> R;
+template <int NX, bool FS = false> static YGeomRt yrows_geom_t() {
+    typedef YRows<NX, FS> R;
     return {R::THR, R::GX, 0, R::RPU, 0, (size_t)(R::GX * YLds<NX, R::GX>::GSTR + 16 * P2<NX>::R3) * sizeof(cf)};
 }
 static YGeomRt ycols_geom(long long ny) {
     switch (ny) { case 4096: return ycols_geom_t<4096>(); case 2048: return ycols_geom_t<2048>(); case 1024: return ycols_geom_t<1024>();
                   case 512: return ycols_geom_t<512>(); default: return ycols_geom_t<256>(); }
 }
-static YGeomRt yrows_geom(long long nx) {  // .rk = rows per workgroup
+static YGeomRt yrows_geom(long long nx, bool fs = false) {  // .rk = rows per workgroup; fs: the four-step 1-D form (256-point rows)
+    if (fs) return yrows_geom_t<256, true>();
     switch (nx) { case 4096: return yrows_geom_t<4096>(); case 2048: return yrows_geom_t<2048>(); case 1024: return yrows_geom_t<1024>();
                   case 512: return yrows_geom_t<512>(); default: return yrows_geom_t<256>(); }
 }
+static long long fasty_rows_gx(const xrfthip_plan* P) { return yrows_geom(P->ynx, P->fast1d).gxy; }
 static int ilog2i(int v) { int l = 0; while ((1 << l) < v) ++l; return l; }
 
 // FFT_y(wy) and FFT_y(wy (i - ibar)) for ky < nrow_pad (zero beyond ny/2): what pass 2 needs to add the residual trend back
@@ -1142,7 +1145,7 @@ static void fasty_launch_cols(const xrfthip_plan* P, const FastY& p, long long g
 
 static void fasty_launch_rows(const xrfthip_plan* P, const FastY& p, long long gc, hipStream_t st, bool prof) {
     const xrfthip_desc& d = P->d;
-    const YGeomRt R = yrows_geom(P->ynx);
+    const YGeomRt R = yrows_geom(P->ynx, P->fast1d);
     const bool iso_on = (d.flags & XRFTHIP_ISO) != 0;
     const bool two = d.out_mode == XRFTHIP_OUT_CROSS || d.out_mode == XRFTHIP_OUT_PHASE;
     xrfthip_plan::ProfRec* rec = prof ? prof_begin(P, "fasty_rows", st) : nullptr;
@@ -1608,7 +1611,7 @@ int xrfthip_plan_create(xrfthip_plan** plan, const xrfthip_desc* desc) {
         if (P->fast1d) {
             P->yfirst = true;
             P->yny = n1; P->ynx = 256;
-            const int rpu = yrows_geom(256).rk;
+            const int rpu = yrows_geom(256, true).rk;
             P->y_nrow_pad = (int)((n1 / 2 + 1 + rpu - 1) / rpu * rpu);
             int rc1 = build_twiddle<float>(P->tw_fx, 256, 256);
             if (!rc1) rc1 = build_twiddle<float>(P->tw_fy, n1, n1);
@@ -1750,7 +1753,7 @@ int xrfthip_plan_describe(const xrfthip_plan* plan, char* buf, size_t buflen) {
                 C.thr, C.g, (long long)plan->yny, C.r0, C.r1, C.r2, C.lds_cols, plan->y_nrow_pad, fastm_rk(plan->yny, plan->dbl), fastm_cw(plan->yny, plan->dbl), fastm_rk(plan->yny, plan->dbl), fastm_cw(plan->yny, plan->dbl),
                 R.thr_r1, R.g_r1, (long long)plan->ynx, R.r0, R.r1, R.r2, R.lds_r1);
     } else if (fasty_on(plan)) {
-        const YGeomRt C = ycols_geom(plan->yny), R = yrows_geom(plan->ynx);
+        const YGeomRt C = ycols_geom(plan->yny), R = yrows_geom(plan->ynx, plan->fast1d);
         if (plan->fast1d) appendf(s, "  [fasty four-step] %lld samples = [%lld][%lld]: columns = step 1 (half spectrum k1 <= %lld), rows x W_N^(i2 k1) = step 2, transposed stores + Hermitian mirror\n",
                                   (long long)plan->d.nx, (long long)plan->yny, (long long)plan->ynx, (long long)plan->yny / 2);
         appendf(s, "  [fasty] cols: %d thr, %d x 2 packed column pairs (FFT%lld r16x16x%lld, column-local detrend fused), %d columns/unit, lds=%zuB -> W2[slab][%d/%d][nx/%d][2][%d][%d] -> rows: %d thr, %d rows/unit (FFT%lld r16x16x%lld), lds=%zuB, |F|^2 + fftshift + mirror rows\n",
