@@ -630,3 +630,29 @@ def run_radial_sum_cases(big=False):
         assert got.sizes["freq_r"] == ref.values.shape[-1] > 4000
         worst = max(worst, check(got, ref, 1e-6))
     return worst
+
+
+def run_yonly_fast_cases(shape=(3, 360, 40), dtype="float64"):
+    """One transform axis that is not the contiguous one (spectra along "time" of a (batch, time, space) array), lengths of the
+    fastm table: csrc/fastm.h fastm_yonly_kernel against the oracle -- fft (true phase on an offset, also ifftshifted,
+    coordinate), power spectrum, every detrend along the axis, window, shift."""
+    rng = np.random.default_rng(61)
+    tol = TOL[dtype]
+    a = _cube(rng, shape, dtype)
+    da, od = pair(a, D3, _coords3(shape, y0=2.5, x0=-1.0))
+    worst = 0.0
+
+    def on_fast():
+        return "[fastm y-only]" in next(reversed(xa.api._plan_cache.values())).describe()
+
+    for kw in (dict(), dict(detrend="linear", window="hann"), dict(detrend="constant", shift=False), dict(true_phase=False, true_amplitude=False, window="hamming")):
+        worst = max(worst, check(xa.fft(da, dim=["y"], **kw), o.fft(od, dim=["y"], **kw), tol))
+        assert on_fast(), kw
+    for kw in (dict(detrend="linear", window="hann"), dict(shift=False, scaling="spectrum", detrend="constant"), dict()):
+        worst = max(worst, check(xa.power_spectrum(da, dim=["y"], **kw), o.power_spectrum(od, dim=["y"], **kw), tol))
+        assert on_fast(), kw
+    # the first axis of a 3-D array: batch = 1, inner = ny * nx
+    worst = max(worst, check(xa.power_spectrum(da.transpose("y", "time", "x"), dim=["y"], detrend="linear", window="hann"),
+                             o.power_spectrum(od.transpose("y", "time", "x"), dim=["y"], detrend="linear", window="hann"), tol))
+    assert on_fast()
+    return worst

@@ -729,6 +729,15 @@ def test_fastm_latlon_lengths(shape, cross, dtype):
     cases.run_fastm_cases(shape, True, cross, dtype)
 
 
+@pytest.mark.parametrize("shape,dtype", [((5, 360, 256), "float64"), ((3, 256, 512), "float32"), ((2, 1024, 2048), "float64"), ((2, 2048, 1024), "float32"),
+                                         ((3, 1440, 64), "float64"), ((4, 240, 96), "float32"), ((2, 960, 128), "float32"), ((2, 512, 264), "float64"),
+                                         ((3, 100, 64), "float64"), ((2, 1000, 256), "float32"), ((2, 128, 136), "float32"), ((2, 1200, 64), "float64"),
+                                         ((2, 200, 40), "float32"), ((2, 400, 48), "float64"), ((2, 500, 72), "float32"), ((2, 600, 88), "float64"), ((2, 800, 16), "float32")])
+def test_one_axis_not_contiguous_fast_kernel(shape, dtype):
+    """fastm_yonly_kernel (csrc/fastm.h): fft / power_spectrum along a middle or first axis, in place in memory order."""
+    cases.run_yonly_fast_cases(shape, dtype)
+
+
 def test_radial_sums_any_nbins_and_bit_identical_repeats():
     """Stand-alone and generic-plan radial sums: more than 4096 bins (also through xrft.isotropize, nfactor = 1 on 4400^2), values
     vs numpy / the oracle, repeats bit for bit."""

@@ -35,10 +35,22 @@ XRFT_MRAD(1440, 10, 12, 12);
 XRFT_MRAD(256, 4, 8, 8);   // (powers of two: float64 only -- float32 has the register-resident kernels of fasty.h)
 XRFT_MRAD(512, 8, 8, 8);
 XRFT_MRAD(1024, 8, 8, 16);
+XRFT_MRAD(2048, 8, 16, 16);  // (float32, one transform axis only)
+// lengths of time-like axes, one transform axis only (fastm_yonly_kernel)
+XRFT_MRAD(100, 4, 5, 5);
+XRFT_MRAD(128, 4, 4, 8);
+XRFT_MRAD(200, 5, 5, 8);
+XRFT_MRAD(400, 5, 8, 10);
+XRFT_MRAD(500, 5, 10, 10);
+XRFT_MRAD(600, 6, 10, 10);
+XRFT_MRAD(800, 8, 10, 10);
+XRFT_MRAD(1000, 10, 10, 10);
+XRFT_MRAD(1200, 10, 10, 12);
 #undef XRFT_MRAD
 // the lengths the host dispatches on: X(N) for every entry
 #define XRFT_M_LATLON(X) X(180) X(240) X(360) X(480) X(720) X(960) X(1440)
 #define XRFT_M_POW2(X) X(256) X(512) X(1024)
+#define XRFT_M_YONLY(X) X(100) X(128) X(200) X(400) X(500) X(600) X(800) X(1000) X(1200)
 
 constexpr int mr_max3(int a, int b, int c) { return a > b ? (a > c ? a : c) : (b > c ? b : c); }
 
@@ -345,6 +357,115 @@ __global__ void __launch_bounds__((MGeom<T, NY>::THR), (MGeom<T, NY>::WPS)) fast
             const CT o = (col & 1) ? cscale(mul_mi(zk - zc), (T)0.5) : cscale(zk + zc, (T)0.5);
             const unsigned off = ((((unsigned)(k >> p.l_rk) * (unsigned)nxb + (unsigned)xb) << p.l_rk) + (unsigned)(k & (rk - 1))) * (unsigned)CW + (unsigned)col;
             if (!(XRFT_MDBG & 8) || o.re == (T)1.2345) mr_store_ct_nt<T, (XRFT_MDBG & 1) != 0>(w2s + (size_t)off * sizeof(CT), o);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// One transform axis that is NOT the contiguous one (XRFTHIP_AXIS_Y: xrft.fft / power_spectrum along "time" of a
+// (..., time, ...) array, in place in memory order -- the reference's most common call): pass 1 alone IS the transform.  A
+// workgroup owns CW adjacent columns of one slab [ny][nx] exactly as fastm_cols_kernel does; the whole column is inside the
+// workgroup, so the per-column detrend of the reference (scipy.signal.detrend along the axis, xrft/detrend.py:54-71) is exact
+// and local: column sums -> wave shuffles -> LDS -> every thread subtracts its columns' mean / least-squares line in float64
+// from the samples it holds, then windows them.  The spectrum of every column leaves as rows ky and -ky (conjugate) of the
+// caller's [ny][nx] result, rotated by the fftshift: |F|^2 scale (MODE 1) or F scale phase[ky] (MODE 0; the phase table carries
+// the true-phase factor and the (-1)^k of an ifftshifted input).  xrft.py:425-447, 462-469, 740-748.
+// ------------------------------------------------------------------------------------------------
+template <typename T, int NY, bool DET, int MODE>
+__global__ void __launch_bounds__((MGeom<T, NY>::THR), (MGeom<T, NY>::WPS)) fastm_yonly_kernel(FastM p) {
+    typedef MGeom<T, NY> M;
+    typedef C2<T> CT;
+    constexpr int G = M::G, THR = M::THR, STR = M::STR, CW = 2 * G, R0 = M::R0, M0 = M::M0;
+    XRFT_DYN_SMEM(smem_raw);
+    CT* lds = reinterpret_cast<CT*>(smem_raw);
+    CT* tw1 = lds + G * STR;
+    double* part = reinterpret_cast<double*>(tw1 + M::M0);  // [wave][g][4]
+    const int tid = threadIdx.x, g = tid % G, r0 = tid / G;
+    const int per = (p.nunits + 7) >> 3, xcd = blockIdx.x & 7, jb = blockIdx.x >> 3;
+    const int unit = xcd * per + jb;
+    if (jb >= per || unit >= p.nunits) return;
+    const int nxb = p.nx / CW, slab = unit / nxb, xb = unit % nxb;
+    mr_fill_tw1<T, NY>(tw1, reinterpret_cast<const CT*>(p.tw_y), tid, THR);
+    const bool on = r0 < M::B0;
+    const int j = on ? r0 : 0;
+    const CT w0 = reinterpret_cast<const CT*>(p.tw_y)[j];
+    const char* __restrict__ src = reinterpret_cast<const char*>(reinterpret_cast<const T*>(p.in) + (size_t)slab * NY * p.nx + (size_t)xb * CW);
+    const unsigned rowb = (unsigned)p.nx * (unsigned)sizeof(T), off0 = (unsigned)j * rowb + (unsigned)g * (unsigned)sizeof(CT), rstep = (unsigned)M0 * rowb;
+    const T* __restrict__ wy = reinterpret_cast<const T*>(p.win_y);
+    CT a[R0];
+    T wyv[R0];
+#pragma unroll
+    for (int q = 0; q < R0; ++q) {
+        a[q] = mk<T>((T)0, (T)0); wyv[q] = (T)0;
+        if (on) {
+            a[q] = *reinterpret_cast<const CT*>(src + (off0 + rstep * (unsigned)q));
+            wyv[q] = wy[j + q * M0];
+        }
+    }
+    constexpr double IBAR = 0.5 * (NY - 1);
+    if (DET) {
+        double s[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int q = 0; q < R0; ++q) {
+            const double ri = (double)(j + q * M0) - IBAR;
+            s[0] += (double)a[q].re; s[1] += (double)a[q].im;
+            s[2] = fma(ri, (double)a[q].re, s[2]); s[3] = fma(ri, (double)a[q].im, s[3]);
+        }
+#pragma unroll
+        for (int m = G; m < 64; m <<= 1)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) s[c] += __shfl_xor(s[c], m);
+        if ((tid & 63) < G) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) part[((tid >> 6) * G + g) * 4 + c] = s[c];
+        }
+        __syncthreads();
+        double tot[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int w = 0; w < THR / 64; ++w)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) tot[c] += part[(w * G + g) * 4 + c];
+        // mean, and the slope of the least-squares line through (i - ibar): sum (i - ibar)^2 = n (n^2 - 1) / 12
+        constexpr double INV_N = 1.0 / NY, INV_SII = 12.0 / ((double)NY * ((double)NY * NY - 1.0));
+        const double m0 = tot[0] * INV_N, m1 = tot[1] * INV_N;
+        const double sl0 = p.detrend == 2 ? tot[2] * INV_SII : 0.0, sl1 = p.detrend == 2 ? tot[3] * INV_SII : 0.0;
+#pragma unroll
+        for (int q = 0; q < R0; ++q) {
+            const double ri = (double)(j + q * M0) - IBAR;
+            a[q] = mk<T>((T)((double)a[q].re - fma(sl0, ri, m0)), (T)((double)a[q].im - fma(sl1, ri, m1)));
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < R0; ++q) a[q] = cscale(a[q], wyv[q]);
+    if (on) mr_pass0<T, NY>(a, lds + g * STR, j, w0);
+    mr_fft_tail<T, NY, G, THR>(lds, tid, tw1);
+    // split the packed spectra (fastm_cols_kernel) and store rows ky and -ky of the result; lanes (ky, column), column fastest
+    typedef typename std::conditional<MODE == 0, CT, T>::type OutT;
+    OutT* __restrict__ outs = reinterpret_cast<OutT*>(p.out) + (size_t)slab * NY * p.nx + (size_t)xb * CW;
+    const T sc = (T)p.scale;
+    constexpr int NST = (CW * (NY / 2 + 1) + THR - 1) / THR;
+#pragma unroll
+    for (int i = 0; i < NST; ++i) {
+        const int l = tid + i * THR, col = l % CW, k = l / CW;
+        if (k <= NY / 2) {
+            const CT* z = lds + (col >> 1) * STR;
+            const CT zk = z[M::pn(k)], zc = cconj(z[M::pn(k == 0 ? 0 : NY - k)]);
+            CT o = (col & 1) ? cscale(mul_mi(zk - zc), (T)0.5) : cscale(zk + zc, (T)0.5);
+            const int km = k == 0 ? 0 : NY - k;
+            int rd = k + p.shift_y; if (rd >= NY) rd -= NY;
+            int rm = km + p.shift_y; if (rm >= NY) rm -= NY;
+            const bool mirror = k != 0 && 2 * k != NY;
+            if (MODE == 1) {
+                const T v = (o.re * o.re + o.im * o.im) * sc;
+                reinterpret_cast<T*>(outs)[(size_t)rd * p.nx + col] = v;
+                if (mirror) reinterpret_cast<T*>(outs)[(size_t)rm * p.nx + col] = v;
+            } else {
+                o = cscale(o, sc);
+                CT om = cconj(o);
+                if (p.ph_on) { o = cmul(o, reinterpret_cast<const CT*>(p.ph_y)[k]); om = cmul(om, reinterpret_cast<const CT*>(p.ph_y)[km]); }
+                reinterpret_cast<CT*>(outs)[(size_t)rd * p.nx + col] = o;
+                if (mirror) reinterpret_cast<CT*>(outs)[(size_t)rm * p.nx + col] = om;
+            }
         }
     }
 }

@@ -298,6 +298,8 @@ struct xrfthip_plan {
     bool fast1d = false;
     // ... and its mixed-radix float64 form (fastm.h): lengths 360 / 720 / 1440
     bool fastm = false;
+    // ... and pass 1 alone for ONE transform axis that is not the contiguous one (XRFTHIP_AXIS_Y, fastm_yonly_kernel)
+    bool fastmy = false;
     bool fph_on = false;  // some entry of the combined phase tables (fph) differs from 1
     long long yny = 0, ynx = 0;
     DevBuf tw_big1d;
@@ -992,7 +994,7 @@ static int fast_phase_tables(xrfthip_plan* P) {
         const long long n = ax == 0 ? d.ny : d.nx;
         const bool sign = d.out_mode == XRFTHIP_OUT_COMPLEX && (d.flags & (ax == 0 ? XRFTHIP_ISHIFT_Y : XRFTHIP_ISHIFT_X));
         std::vector<cf> t((size_t)n);
-        const bool dtab = P->fastm && P->dbl;
+        const bool dtab = (P->fastm || P->fastmy) && P->dbl;
         std::vector<C2<double>> td(dtab ? (size_t)n : 0);
         for (long long k = 0; k < n; ++k) {
             double re = 1.0, im = 0.0;
@@ -1422,11 +1424,62 @@ static int run_fastm(const xrfthip_plan* P, const void* in, const void* in1, voi
     return XRFTHIP_OK;
 }
 
+// one transform axis, not the contiguous one: pass 1 alone (fastm_yonly_kernel)
+static bool fastmy_len(long long n, bool dbl) {
+#define X_(NN) if (n == NN) return true;
+    XRFT_M_LATLON(X_) XRFT_M_POW2(X_) XRFT_M_YONLY(X_)
+#undef X_
+    return !dbl && n == 2048;
+}
+static MGeomRt mygeom(long long n, bool dbl) {
+    if (!dbl) {
+#define X_(NN) if (n == NN) return mgeom_t<float, NN>();
+        XRFT_M_POW2(X_) XRFT_M_YONLY(X_) X_(2048)
+#undef X_
+    } else {
+#define X_(NN) if (n == NN) return mgeom_t<double, NN>();
+        XRFT_M_YONLY(X_)
+#undef X_
+    }
+    return mgeom(n, dbl);
+}
+static int run_fastmy(const xrfthip_plan* P, const void* in, void* out, hipStream_t st) {
+    const xrfthip_desc& d = P->d;
+    const MGeomRt C = mygeom(d.ny, P->dbl);
+    FastM p{};
+    p.in = in; p.out = out;
+    p.tw_y = P->tw_fy.p;
+    p.win_y = P->win[0].p ? P->win[0].p : P->ones4096.p;
+    p.ph_y = P->fph[0].p; p.ph_on = P->fph_on ? 1 : 0;
+    p.ny = (int)d.ny; p.nx = (int)d.nx;
+    p.detrend = d.detrend; p.nslab = (int)d.batch;
+    p.nunits = (int)(d.batch * (d.nx / (2 * C.g)));
+    p.shift_y = (d.flags & XRFTHIP_SHIFT_Y) ? (int)(d.ny / 2) : 0;
+    p.scale = d.scale;
+    xrfthip_plan::ProfRec* rec = prof_begin(P, "fastm_yonly", st);
+    const dim3 grid((unsigned)(8 * ((p.nunits + 7) / 8))), blk((unsigned)C.thr);
+    const bool pw = d.out_mode == XRFTHIP_OUT_POWER;
+#define MY_(TT, NN) do { \
+        if (d.detrend) { if (pw) { auto k = &fastm_yonly_kernel<TT, NN, true, 1>; XRFT_LAUNCH(k, grid, blk, C.lds_cols, st, p); } else { auto k = &fastm_yonly_kernel<TT, NN, true, 0>; XRFT_LAUNCH(k, grid, blk, C.lds_cols, st, p); } } \
+        else { if (pw) { auto k = &fastm_yonly_kernel<TT, NN, false, 1>; XRFT_LAUNCH(k, grid, blk, C.lds_cols, st, p); } else { auto k = &fastm_yonly_kernel<TT, NN, false, 0>; XRFT_LAUNCH(k, grid, blk, C.lds_cols, st, p); } } } while (0)
+#define XD_(NN) if (d.ny == NN) MY_(double, NN);
+#define XF_(NN) if (d.ny == NN) MY_(float, NN);
+    if (P->dbl) { XRFT_M_LATLON(XD_) XRFT_M_POW2(XD_) XRFT_M_YONLY(XD_) } else { XRFT_M_LATLON(XF_) XRFT_M_POW2(XF_) XRFT_M_YONLY(XF_) XF_(2048) }
+#undef XD_
+#undef XF_
+#undef MY_
+    prof_end(rec, st);
+    HIP_TRY(hipGetLastError());
+    return XRFTHIP_OK;
+}
+
 // Everything xrfthip_exec needs beyond the caller's buffers is built HERE, when the plan is created or one of its tables is
 // set: window spectra and phase tables of the specialised paths (device allocations + blocking copies) and the workspace
 // layout.  xrfthip_exec itself takes the plan as const: no allocation, no copy, no synchronisation, no getenv.
 static int finalize_plan(xrfthip_plan* P) {
-    if (P->fastm) {
+    if (P->fastmy) {
+        if (P->d.out_mode != XRFTHIP_OUT_POWER) { const int rc = fast_phase_tables(P); if (rc) return rc; }
+    } else if (P->fastm) {
         int rc = fasty_window_spectra(P);
         if (!rc && P->d.out_mode != XRFTHIP_OUT_POWER) rc = fast_phase_tables(P);
         if (rc) return rc;
@@ -1649,6 +1702,20 @@ int xrfthip_plan_create(xrfthip_plan** plan, const xrfthip_desc* desc) {
             if (rcm) { delete P; return rcm; }
         }
     }
+    {   // one transform axis that is not the contiguous one, real input: pass 1 of the same kernels is the whole transform
+        const uint32_t allowed = XRFTHIP_AXIS_Y | XRFTHIP_SHIFT_Y | (d.out_mode == XRFTHIP_OUT_COMPLEX ? XRFTHIP_ISHIFT_Y : 0u);
+        P->fastmy = (d.flags & XRFTHIP_AXIS_Y) && d.ndim == 2 && !cplx_in && (d.dtype == XRFTHIP_F64 || d.dtype == XRFTHIP_F32) &&
+                    (d.out_mode == XRFTHIP_OUT_COMPLEX || d.out_mode == XRFTHIP_OUT_POWER) && !(d.flags & ~allowed) && fastmy_len(d.ny, P->dbl) &&
+                    d.batch * d.nx < (1LL << 30) && !env_ll("XRFTHIP_NO_FAST", 0) && env_ll("XRFTHIP_FASTM", 1) != 0;
+        if (P->fastmy && d.nx % (2 * mygeom(d.ny, P->dbl).g) != 0) P->fastmy = false;
+        if (P->fastmy) {
+            int rcm = P->dbl ? build_twiddle<double>(P->tw_fy, d.ny, d.ny) : build_twiddle<float>(P->tw_fy, d.ny, d.ny);
+            std::vector<double> ones((size_t)d.ny, 1.0);
+            std::vector<float> onesf((size_t)d.ny, 1.0f);
+            if (!rcm) rcm = P->dbl ? P->ones4096.upload(ones.data(), ones.size() * sizeof(double)) : P->ones4096.upload(onesf.data(), onesf.size() * sizeof(float));
+            if (rcm) { delete P; return rcm; }
+        }
+    }
     set_kernel_attrs_once();
     // nbins must be known before tiles are sized (the LDS histogram shares the tile's allocation): ISO plans are
     // (re)built in xrfthip_plan_set_binmap.  Build now for everything else.
@@ -1747,7 +1814,11 @@ int xrfthip_plan_describe(const xrfthip_plan* plan, char* buf, size_t buflen) {
     appendf(s, "xrfthip plan: ndim=%d batch=%lld ny=%lld nx=%lld dtype=%d mode=%d detrend=%d flags=0x%x width=%lld nx_out=%lld mirror=%d group=%d ws=%zuB\n",
             d.ndim, (long long)d.batch, (long long)d.ny, (long long)d.nx, d.dtype, d.out_mode, d.detrend, d.flags,
             plan->width, plan->nx_out, (int)plan->mirror, plan->G, plan->ws_bytes);
-    if (plan->fastm) {
+    if (plan->fastmy) {
+        const MGeomRt C = mygeom(plan->d.ny, plan->dbl);
+        appendf(s, "  [fastm y-only] %d thr, %d packed column pairs (FFT%lld r%dx%dx%d in LDS), lds=%zuB: per-column detrend + window + transform + both halves of the spectrum in one pass, in place in memory order\n",
+                C.thr, C.g, (long long)plan->d.ny, C.r0, C.r1, C.r2, C.lds_cols);
+    } else if (plan->fastm) {
         const MGeomRt C = mgeom(plan->yny, plan->dbl), R = mgeom(plan->ynx, plan->dbl);
         appendf(s, "  [fastm] cols: %d thr, %d packed column pairs (FFT%lld r%dx%dx%d in LDS), lds=%zuB -> W2[slab][%d/%d][nx/%d][%d][%d] complex -> fit -> rows: %d thr, %d rows/unit (FFT%lld r%dx%dx%d), lds=%zuB, trend added back in the spectral domain, fftshift + mirror rows\n",
                 C.thr, C.g, (long long)plan->yny, C.r0, C.r1, C.r2, C.lds_cols, plan->y_nrow_pad, fastm_rk(plan->yny, plan->dbl), fastm_cw(plan->yny, plan->dbl), fastm_rk(plan->yny, plan->dbl), fastm_cw(plan->yny, plan->dbl),
@@ -1788,6 +1859,7 @@ int xrfthip_exec(const xrfthip_plan* plan, const void* d_in0, const void* d_in1,
     double* acc = (double*)(ws + P->off_acc);
     double* coef = (double*)(ws + P->off_coef);
     if (iso) HIP_TRY(hipMemsetAsync(d_iso, 0, (size_t)d.batch * P->nbins * (cross ? 16 : 8), st));
+    if (P->fastmy) return run_fastmy(P, d_in0, out, st);
     if (P->fastm) return run_fastm(P, d_in0, d_in1, out, (double*)d_iso, ws, st);
     if (fasty_on(P)) {
         return run_fasty(P, (const float*)d_in0, (const float*)d_in1, out, (double*)d_iso, ws, st);
