@@ -166,20 +166,34 @@ static void host_fft_smooth(std::vector<double>& re, std::vector<double>& im) {
     re.swap(yr); im.swap(yi);
 }
 
-// length of the transform actually run in LDS for an n-point sequence: n, or the Bluestein length when n has a prime
-// factor the radix passes do not take
-long long lds_fft_len(long long n) {
+// length of the transform actually run in LDS for an n-point sequence: n, or the Bluestein length m = 2^a 3^b 5^c >= 2n - 1 (a
+// power of two can be almost twice as long and then misses the LDS) when n has a prime factor the radix passes do not take
+// -- or take badly: a prime above kGenericMax = 6 runs through the O(r^2) butterfly with its operands in scratch memory
+// ((64, 721, 1440) float32, 721 = 7 x 103: 22.3 ms in the column pass, 2.9 GFFT/s -> 54.7 through Bluestein; 1001 = 7 x 11 x 13: 13 ->
+// 26; a lone factor 7 breaks even), so it goes to Bluestein as long as four sequences of m points fit the LDS
+// (scripts/prof_primes.py, prof_primes2.py).
+long long lds_fft_len(long long n, size_t csize) {
     std::vector<int> r;
     bool g;
-    if (n < 2 || factorize(n, r, g) == XRFTHIP_OK) return n;
-    // Bluestein: the smallest 2^a 3^b 5^c >= 2n - 1 (a power of two can be almost twice as long and then misses the LDS)
-    for (long long m = 2 * n - 1;; ++m) {
+    if (n < 2) return n;
+    const bool ok = factorize(n, r, g) == XRFTHIP_OK;
+    static const long long kGenericMax = env_ll("XRFTHIP_GENERIC_MAX", 6);
+    if (ok) {
+        int lp = 1;
+        for (int f : r) lp = std::max(lp, f);  // (composite radices are <= 16)
+        if (lp <= kGenericMax) return n;
+    }
+    long long m = 2 * n - 1;
+    for (;; ++m) {
         long long q = m;
         while (q % 2 == 0) q /= 2;
         while (q % 3 == 0) q /= 3;
         while (q % 5 == 0) q /= 5;
-        if (q == 1) return m;
+        if (q == 1) break;
     }
+    if (!ok) return m;
+    const size_t per = (size_t)(m + m / 16 + 2) * csize;
+    return 4 * per <= kLdsMax ? m : n;
 }
 
 // host-side radix-2 FFT (float64) for the two 4096-point window spectra the fused detrend needs
@@ -207,7 +221,7 @@ static void host_fft_pow2(std::vector<double>& re, std::vector<double>& im) {
 template <typename T>
 int build_tables(FftTables& t, int n_logical) {
     t.n = n_logical;
-    const int n = (int)lds_fft_len(n_logical);
+    const int n = (int)lds_fft_len(n_logical, 2 * sizeof(T));
     t.blue_m = n != n_logical ? n : 0;
     int rc = factorize(n, t.radix, t.generic);
     if (rc) return rc;
@@ -323,7 +337,7 @@ struct TileChoice { int T, threads, seq_stride, pad_shift; size_t lds; };
 // pick sequences-per-tile for an n-point FFT; `col`: the tile axis is the contiguous one in memory, so T*csize
 // bytes per row segment should reach a 128-byte line.  Returns T = 0 if one sequence does not fit in LDS.
 TileChoice choose_tile(long long n_logical, size_t csize, bool col, long long avail, size_t hist_bytes) {
-    const long long n = lds_fft_len(n_logical);
+    const long long n = lds_fft_len(n_logical, csize);
     TileChoice c{};
     c.pad_shift = csize == 8 ? 4 : 3;
     long long ss = n + (n >> c.pad_shift) + 1;
