@@ -471,6 +471,103 @@ __global__ void __launch_bounds__((MGeom<T, NY>::THR), (MGeom<T, NY>::WPS)) fast
 }
 
 // ------------------------------------------------------------------------------------------------
+// One transform axis that IS the contiguous one, short rows (ndim = 1: xrft.fft / power_spectrum along the last axis of
+// (..., n) arrays, n in the table): the same transform with ROWS packed in pairs -- rows 2g, 2g+1 of the workgroup's 2 G rows are
+// the real and imaginary part of sequence g.  Per-row detrend (mean / least-squares line along the row, scipy.signal.detrend,
+// xrft/detrend.py:54-71) from the sums of the samples the threads hold, as in fastm_yonly_kernel; window; three passes; each
+// row's spectrum (all n frequencies, or n/2 + 1 with real_dim) leaves rotated by the fftshift, contiguous along k.
+// ------------------------------------------------------------------------------------------------
+template <typename T, int N, bool DET, int MODE>
+__global__ void __launch_bounds__((MGeom<T, N>::THR), (MGeom<T, N>::WPS)) fastm_xonly_kernel(FastM p) {
+    typedef MGeom<T, N> M;
+    typedef C2<T> CT;
+    constexpr int G = M::G, THR = M::THR, STR = M::STR, R0 = M::R0, M0 = M::M0;
+    XRFT_DYN_SMEM(smem_raw);
+    CT* lds = reinterpret_cast<CT*>(smem_raw);
+    CT* tw1 = lds + G * STR;
+    double* part = reinterpret_cast<double*>(tw1 + M::M0);  // [wave][g][4]
+    const int tid = threadIdx.x, g = tid % G, r0 = tid / G;
+    const long long row0 = (long long)blockIdx.x * (2 * G), nrows = p.nslab;  // (nslab: rows in all)
+    mr_fill_tw1<T, N>(tw1, reinterpret_cast<const CT*>(p.tw_x), tid, THR);
+    const bool on = r0 < M::B0;
+    const int j = on ? r0 : 0;
+    const CT w0 = reinterpret_cast<const CT*>(p.tw_x)[j];
+    const long long ra = row0 + 2 * g, rb = ra + 1;
+    const bool ha = on && ra < nrows, hb = on && rb < nrows;
+    const T* __restrict__ sa = reinterpret_cast<const T*>(p.in) + (size_t)(ha ? ra : 0) * N;
+    const T* __restrict__ sb = reinterpret_cast<const T*>(p.in) + (size_t)(hb ? rb : 0) * N;
+    const T* __restrict__ wx = reinterpret_cast<const T*>(p.win_x);
+    CT a[R0];
+    T wv[R0];
+#pragma unroll
+    for (int q = 0; q < R0; ++q) {
+        const int x = j + q * M0;
+        a[q] = mk<T>(ha ? sa[x] : (T)0, hb ? sb[x] : (T)0);
+        wv[q] = wx[x];
+    }
+    constexpr double XBAR = 0.5 * (N - 1);
+    if (DET) {
+        double s[4] = {0.0, 0.0, 0.0, 0.0};
+        if (on) {
+#pragma unroll
+            for (int q = 0; q < R0; ++q) {
+                const double ri = (double)(j + q * M0) - XBAR;
+                s[0] += (double)a[q].re; s[1] += (double)a[q].im;
+                s[2] = fma(ri, (double)a[q].re, s[2]); s[3] = fma(ri, (double)a[q].im, s[3]);
+            }
+        }
+#pragma unroll
+        for (int m = G; m < 64; m <<= 1)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) s[c] += __shfl_xor(s[c], m);
+        if ((tid & 63) < G) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) part[((tid >> 6) * G + g) * 4 + c] = s[c];
+        }
+        __syncthreads();
+        double tot[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int w = 0; w < THR / 64; ++w)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) tot[c] += part[(w * G + g) * 4 + c];
+        constexpr double INV_N = 1.0 / N, INV_SII = 12.0 / ((double)N * ((double)N * N - 1.0));
+        const double m0 = tot[0] * INV_N, m1 = tot[1] * INV_N;
+        const double sl0 = p.detrend == 2 ? tot[2] * INV_SII : 0.0, sl1 = p.detrend == 2 ? tot[3] * INV_SII : 0.0;
+#pragma unroll
+        for (int q = 0; q < R0; ++q) {
+            const double ri = (double)(j + q * M0) - XBAR;
+            a[q] = mk<T>((T)((double)a[q].re - fma(sl0, ri, m0)), (T)((double)a[q].im - fma(sl1, ri, m1)));
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < R0; ++q) a[q] = cscale(a[q], wv[q]);
+    if (on) mr_pass0<T, N>(a, lds + g * STR, j, w0);
+    mr_fft_tail<T, N, G, THR>(lds, tid, tw1);
+    // split and store: lanes run along k of one row
+    typedef typename std::conditional<MODE == 0, CT, T>::type OutT;
+    const int W = p.half ? N / 2 + 1 : N;
+    const T sc = (T)p.scale;
+    for (int e = tid; e < 2 * G * W; e += THR) {
+        const int t = e / W, k = e - t * W;
+        const long long row = row0 + t;
+        if (row >= nrows) break;  // (t grows with e)
+        const CT* z = lds + (t >> 1) * STR;
+        const CT zk = z[M::pn(k)], zc = cconj(z[M::pn(k == 0 ? 0 : N - k)]);
+        CT o = (t & 1) ? cscale(mul_mi(zk - zc), (T)0.5) : cscale(zk + zc, (T)0.5);
+        int oc = k + p.shift_x; if (oc >= N) oc -= N;  // (half output: shift_x = 0)
+        const T f = (p.realdim2 && k != 0 && 2 * k != N) ? sc * (T)2 : sc;
+        OutT* dst = reinterpret_cast<OutT*>(p.out) + (size_t)row * W + oc;
+        if (MODE == 1) {
+            *reinterpret_cast<T*>(dst) = (o.re * o.re + o.im * o.im) * f;
+        } else {
+            o = cscale(o, f);
+            if (p.ph_on) o = cmul(o, reinterpret_cast<const CT*>(p.ph_x)[k]);
+            *reinterpret_cast<CT*>(dst) = o;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // pass 2: a workgroup owns RPU consecutive rows ky0.. of W2 (one contiguous block), adds the plane back, transforms along x and
 // writes every row twice: as output row ky (rotated by the fftshift) and, reversed, as row -ky (Hermitian mirror of the
 // spectrum of a real field).  MODE = xrfthip_out_mode: 1 power, 0 complex (fft), 2 cross / 3 cross phase (the first G/2

@@ -178,11 +178,7 @@ long long lds_fft_len(long long n, size_t csize) {
     if (n < 2) return n;
     const bool ok = factorize(n, r, g) == XRFTHIP_OK;
     static const long long kGenericMax = env_ll("XRFTHIP_GENERIC_MAX", 6);
-    if (ok) {
-        int lp = 1;
-        for (int f : r) lp = std::max(lp, f);  // (composite radices are <= 16)
-        if (lp <= kGenericMax) return n;
-    }
+    if (ok && (!g || r[0] <= kGenericMax)) return n;  // (g: a prime factor other than 2, 3, 5; those come first in r, largest first)
     long long m = 2 * n - 1;
     for (;; ++m) {
         long long q = m;
@@ -314,6 +310,8 @@ struct xrfthip_plan {
     bool fastm = false;
     // ... and pass 1 alone for ONE transform axis that is not the contiguous one (XRFTHIP_AXIS_Y, fastm_yonly_kernel)
     bool fastmy = false;
+    // ... and the same transform over short contiguous rows packed in pairs (ndim = 1, fastm_xonly_kernel)
+    bool fastmx = false;
     bool fph_on = false;  // some entry of the combined phase tables (fph) differs from 1
     long long yny = 0, ynx = 0;
     DevBuf tw_big1d;
@@ -1008,7 +1006,7 @@ static int fast_phase_tables(xrfthip_plan* P) {
         const long long n = ax == 0 ? d.ny : d.nx;
         const bool sign = d.out_mode == XRFTHIP_OUT_COMPLEX && (d.flags & (ax == 0 ? XRFTHIP_ISHIFT_Y : XRFTHIP_ISHIFT_X));
         std::vector<cf> t((size_t)n);
-        const bool dtab = (P->fastm || P->fastmy) && P->dbl;
+        const bool dtab = (P->fastm || P->fastmy || P->fastmx) && P->dbl;
         std::vector<C2<double>> td(dtab ? (size_t)n : 0);
         for (long long k = 0; k < n; ++k) {
             double re = 1.0, im = 0.0;
@@ -1487,11 +1485,45 @@ static int run_fastmy(const xrfthip_plan* P, const void* in, void* out, hipStrea
     return XRFTHIP_OK;
 }
 
+// one transform axis, the contiguous one, short rows: rows packed in pairs (fastm_xonly_kernel)
+static int run_fastmx(const xrfthip_plan* P, const void* in, void* out, hipStream_t st) {
+    const xrfthip_desc& d = P->d;
+    const MGeomRt C = mygeom(d.nx, P->dbl);
+    FastM p{};
+    p.in = in; p.out = out;
+    p.tw_x = P->tw_fx.p;
+    p.win_x = P->win[1].p ? P->win[1].p : P->ones4096.p;
+    p.ph_x = P->fph[1].p; p.ph_on = P->fph_on ? 1 : 0;
+    p.ny = 1; p.nx = (int)d.nx;
+    p.detrend = d.detrend; p.nslab = (int)d.batch;
+    p.half = (d.flags & XRFTHIP_HALF_X) ? 1 : 0;
+    p.realdim2 = (d.flags & XRFTHIP_REALDIM_X2) ? 1 : 0;
+    p.shift_x = (d.flags & XRFTHIP_SHIFT_X) ? (int)(d.nx / 2) : 0;
+    p.scale = d.scale;
+    xrfthip_plan::ProfRec* rec = prof_begin(P, "fastm_xonly", st);
+    const dim3 grid((unsigned)((d.batch + 2 * C.g - 1) / (2 * C.g))), blk((unsigned)C.thr);
+    const bool pw = d.out_mode == XRFTHIP_OUT_POWER;
+#define MX_(TT, NN) do { \
+        if (d.detrend) { if (pw) { auto k = &fastm_xonly_kernel<TT, NN, true, 1>; XRFT_LAUNCH(k, grid, blk, C.lds_cols, st, p); } else { auto k = &fastm_xonly_kernel<TT, NN, true, 0>; XRFT_LAUNCH(k, grid, blk, C.lds_cols, st, p); } } \
+        else { if (pw) { auto k = &fastm_xonly_kernel<TT, NN, false, 1>; XRFT_LAUNCH(k, grid, blk, C.lds_cols, st, p); } else { auto k = &fastm_xonly_kernel<TT, NN, false, 0>; XRFT_LAUNCH(k, grid, blk, C.lds_cols, st, p); } } } while (0)
+#define XD_(NN) if (d.nx == NN) MX_(double, NN);
+#define XF_(NN) if (d.nx == NN) MX_(float, NN);
+    if (P->dbl) { XRFT_M_LATLON(XD_) XRFT_M_POW2(XD_) XRFT_M_YONLY(XD_) } else { XRFT_M_LATLON(XF_) XRFT_M_POW2(XF_) XRFT_M_YONLY(XF_) XF_(2048) }
+#undef XD_
+#undef XF_
+#undef MX_
+    prof_end(rec, st);
+    HIP_TRY(hipGetLastError());
+    return XRFTHIP_OK;
+}
+
 // Everything xrfthip_exec needs beyond the caller's buffers is built HERE, when the plan is created or one of its tables is
 // set: window spectra and phase tables of the specialised paths (device allocations + blocking copies) and the workspace
 // layout.  xrfthip_exec itself takes the plan as const: no allocation, no copy, no synchronisation, no getenv.
 static int finalize_plan(xrfthip_plan* P) {
-    if (P->fastmy) {
+    if (P->fastmx) {
+        if (P->d.out_mode != XRFTHIP_OUT_POWER) { const int rc = fast_phase_tables(P); if (rc) return rc; }
+    } else if (P->fastmy) {
         if (P->d.out_mode != XRFTHIP_OUT_POWER) { const int rc = fast_phase_tables(P); if (rc) return rc; }
     } else if (P->fastm) {
         int rc = fasty_window_spectra(P);
@@ -1730,6 +1762,19 @@ int xrfthip_plan_create(xrfthip_plan** plan, const xrfthip_desc* desc) {
             if (rcm) { delete P; return rcm; }
         }
     }
+    {   // one short transform axis, the contiguous one, real input: rows packed in pairs through the same three passes
+        const uint32_t allowed = XRFTHIP_SHIFT_X | XRFTHIP_HALF_X | XRFTHIP_REALDIM_X2 | (d.out_mode == XRFTHIP_OUT_COMPLEX ? XRFTHIP_ISHIFT_X : 0u);
+        P->fastmx = d.ndim == 1 && !cplx_in && (d.dtype == XRFTHIP_F64 || d.dtype == XRFTHIP_F32) && (d.out_mode == XRFTHIP_OUT_COMPLEX || d.out_mode == XRFTHIP_OUT_POWER) &&
+                    !(d.flags & ~allowed) && !((d.flags & XRFTHIP_HALF_X) && (d.flags & XRFTHIP_SHIFT_X)) && !((d.flags & XRFTHIP_REALDIM_X2) && !(d.flags & XRFTHIP_HALF_X)) &&
+                    fastmy_len(d.nx, P->dbl) && d.batch < (1LL << 31) - 16 && !env_ll("XRFTHIP_NO_FAST", 0) && env_ll("XRFTHIP_FASTM", 1) != 0;
+        if (P->fastmx) {
+            int rcm = P->dbl ? build_twiddle<double>(P->tw_fx, d.nx, d.nx) : build_twiddle<float>(P->tw_fx, d.nx, d.nx);
+            std::vector<double> ones((size_t)d.nx, 1.0);
+            std::vector<float> onesf((size_t)d.nx, 1.0f);
+            if (!rcm) rcm = P->dbl ? P->ones4096.upload(ones.data(), ones.size() * sizeof(double)) : P->ones4096.upload(onesf.data(), onesf.size() * sizeof(float));
+            if (rcm) { delete P; return rcm; }
+        }
+    }
     set_kernel_attrs_once();
     // nbins must be known before tiles are sized (the LDS histogram shares the tile's allocation): ISO plans are
     // (re)built in xrfthip_plan_set_binmap.  Build now for everything else.
@@ -1828,7 +1873,11 @@ int xrfthip_plan_describe(const xrfthip_plan* plan, char* buf, size_t buflen) {
     appendf(s, "xrfthip plan: ndim=%d batch=%lld ny=%lld nx=%lld dtype=%d mode=%d detrend=%d flags=0x%x width=%lld nx_out=%lld mirror=%d group=%d ws=%zuB\n",
             d.ndim, (long long)d.batch, (long long)d.ny, (long long)d.nx, d.dtype, d.out_mode, d.detrend, d.flags,
             plan->width, plan->nx_out, (int)plan->mirror, plan->G, plan->ws_bytes);
-    if (plan->fastmy) {
+    if (plan->fastmx) {
+        const MGeomRt C = mygeom(plan->d.nx, plan->dbl);
+        appendf(s, "  [fastm x-only] %d thr, %d row pairs per workgroup (FFT%lld r%dx%dx%d in LDS), lds=%zuB: per-row detrend + window + transform + full (or half) spectrum in one pass\n",
+                C.thr, C.g, (long long)plan->d.nx, C.r0, C.r1, C.r2, C.lds_cols);
+    } else if (plan->fastmy) {
         const MGeomRt C = mygeom(plan->d.ny, plan->dbl);
         appendf(s, "  [fastm y-only] %d thr, %d packed column pairs (FFT%lld r%dx%dx%d in LDS), lds=%zuB: per-column detrend + window + transform + both halves of the spectrum in one pass, in place in memory order\n",
                 C.thr, C.g, (long long)plan->d.ny, C.r0, C.r1, C.r2, C.lds_cols);
@@ -1873,6 +1922,7 @@ int xrfthip_exec(const xrfthip_plan* plan, const void* d_in0, const void* d_in1,
     double* acc = (double*)(ws + P->off_acc);
     double* coef = (double*)(ws + P->off_coef);
     if (iso) HIP_TRY(hipMemsetAsync(d_iso, 0, (size_t)d.batch * P->nbins * (cross ? 16 : 8), st));
+    if (P->fastmx) return run_fastmx(P, d_in0, out, st);
     if (P->fastmy) return run_fastmy(P, d_in0, out, st);
     if (P->fastm) return run_fastm(P, d_in0, d_in1, out, (double*)d_iso, ws, st);
     if (fasty_on(P)) {
