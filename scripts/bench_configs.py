@@ -72,6 +72,16 @@ del y64, db
 # a middle axis in place (XRFTHIP_AXIS_Y)
 x = cube((64, 1024, 2048), torch.float32); da = xrft.DataArray(x, ("t", "y", "x"), {"y": np.arange(1024.), "x": np.arange(2048.)})
 add("fft along the MIDDLE axis (64,1024,2048) f32, no copies", x.numel(), 12, timeit(lambda: xrft.fft(da, dim=["y"])))
+add("   power_spectrum along it, linear+hann", x.numel(), 8, timeit(lambda: xrft.power_spectrum(da, dim=["y"], detrend="linear", window="hann")))
+x = cube((64, 1000, 2048), torch.float64); da = xrft.DataArray(x, ("t", "y", "x"), {"y": np.arange(1000.), "x": np.arange(2048.)})
+add("   the same, (64,1000,2048) f64", x.numel(), 16, timeit(lambda: xrft.power_spectrum(da, dim=["y"], detrend="linear", window="hann")))
+# short contiguous axis (ndim = 1)
+x = cube((131072, 1024), torch.float32); da = xrft.DataArray(x, ("t", "x"), {"x": np.arange(1024.)})
+add("power_spectrum 1-D (131072,1024) f32 linear+hann", x.numel(), 8, timeit(lambda: xrft.power_spectrum(da, dim=["x"], detrend="linear", window="hann")))
+add("   fft 1-D (131072,1024) f32", x.numel(), 12, timeit(lambda: xrft.fft(da, dim=["x"])))
+# a length with large prime factors: the ERA5 grid (721 = 7 x 103 latitudes) -- Bluestein in the column tile
+x = cube((64, 721, 1440), torch.float32); da = xrft.DataArray(x, ("t", "lat", "lon"), {"lat": np.arange(721) * .25, "lon": np.arange(1440) * .25})
+add("PS (64,721,1440) f32 linear+hann (ERA5 grid)", x.numel(), 8, timeit(lambda: xrft.power_spectrum(da, dim=["lat", "lon"], detrend="linear", window="hann")))
 print(f"{'workload':58s} {'GFFT/s':>8s} {'ms':>9s} {'B/pt':>5s} {'frac of 8 TB/s':>15s}  path")
 for name, g, t, bpp, frac, path in rows:
     print(f"{name:58s} {g:8.2f} {t*1e3:9.3f} {bpp:5.0f} {frac:15.3f}  {path}")
