@@ -35,7 +35,8 @@ XRFT_MRAD(1440, 10, 12, 12);
 XRFT_MRAD(256, 4, 8, 8);   // (powers of two: float64 only -- float32 has the register-resident kernels of fasty.h)
 XRFT_MRAD(512, 8, 8, 8);
 XRFT_MRAD(1024, 8, 8, 16);
-XRFT_MRAD(2048, 8, 16, 16);  // (float32, one transform axis only)
+XRFT_MRAD(2048, 8, 16, 16);  // (one transform axis only: float32; float64 along the contiguous axis)
+XRFT_MRAD(4096, 16, 16, 16); // (one transform axis, the contiguous one: a single pair of rows per workgroup)
 // lengths of time-like axes, one transform axis only (fastm_yonly_kernel)
 XRFT_MRAD(100, 4, 5, 5);
 XRFT_MRAD(128, 4, 4, 8);

@@ -764,6 +764,11 @@ void set_kernel_attrs_once() {
     if (done) return;
     done = true;
     const int m = (int)kLdsMax;
+    // (the one fastm instantiation above 64 KB of dynamic LDS: 4096-point float64 rows, one pair per workgroup)
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&fastm_xonly_kernel<double, 4096, true, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, m);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&fastm_xonly_kernel<double, 4096, true, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, m);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&fastm_xonly_kernel<double, 4096, false, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, m);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&fastm_xonly_kernel<double, 4096, false, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, m);
 #define SETA(TT, A, B, C) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&tile_fft_kernel<TT, A, B, C, sizeof(TT) == 8 ? 512 : 1024, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, m)
 #define SETP(TT, A, B, PP) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&tile_fft_kernel<TT, A, B, false, sizeof(TT) == 8 ? 512 : 1024, PP>), hipFuncAttributeMaxDynamicSharedMemorySize, m)
 #define SETPATHS(TT) SETP(TT, true, false, 1); SETP(TT, true, true, 1); SETP(TT, false, true, 2); SETP(TT, true, false, 3); SETP(TT, false, true, 4)
@@ -1485,10 +1490,17 @@ static int run_fastmy(const xrfthip_plan* P, const void* in, void* out, hipStrea
     return XRFTHIP_OK;
 }
 
-// one transform axis, the contiguous one, short rows: rows packed in pairs (fastm_xonly_kernel)
+// one transform axis, the contiguous one, short rows: rows packed in pairs (fastm_xonly_kernel).  Rows are contiguous whatever the
+// number of sequences per workgroup, so the lengths that leave room for one pair only (4096; 2048 in float64) are taken too.
+static bool fastmx_len(long long n, bool dbl) { return fastmy_len(n, dbl) || n == 4096 || (dbl && n == 2048); }
+static MGeomRt mxgeom(long long n, bool dbl) {
+    if (n == 4096) return dbl ? mgeom_t<double, 4096>() : mgeom_t<float, 4096>();
+    if (dbl && n == 2048) return mgeom_t<double, 2048>();
+    return mygeom(n, dbl);
+}
 static int run_fastmx(const xrfthip_plan* P, const void* in, void* out, hipStream_t st) {
     const xrfthip_desc& d = P->d;
-    const MGeomRt C = mygeom(d.nx, P->dbl);
+    const MGeomRt C = mxgeom(d.nx, P->dbl);
     FastM p{};
     p.in = in; p.out = out;
     p.tw_x = P->tw_fx.p;
@@ -1508,7 +1520,7 @@ static int run_fastmx(const xrfthip_plan* P, const void* in, void* out, hipStrea
         else { if (pw) { auto k = &fastm_xonly_kernel<TT, NN, false, 1>; XRFT_LAUNCH(k, grid, blk, C.lds_cols, st, p); } else { auto k = &fastm_xonly_kernel<TT, NN, false, 0>; XRFT_LAUNCH(k, grid, blk, C.lds_cols, st, p); } } } while (0)
 #define XD_(NN) if (d.nx == NN) MX_(double, NN);
 #define XF_(NN) if (d.nx == NN) MX_(float, NN);
-    if (P->dbl) { XRFT_M_LATLON(XD_) XRFT_M_POW2(XD_) XRFT_M_YONLY(XD_) } else { XRFT_M_LATLON(XF_) XRFT_M_POW2(XF_) XRFT_M_YONLY(XF_) XF_(2048) }
+    if (P->dbl) { XRFT_M_LATLON(XD_) XRFT_M_POW2(XD_) XRFT_M_YONLY(XD_) XD_(2048) XD_(4096) } else { XRFT_M_LATLON(XF_) XRFT_M_POW2(XF_) XRFT_M_YONLY(XF_) XF_(2048) XF_(4096) }
 #undef XD_
 #undef XF_
 #undef MX_
@@ -1766,7 +1778,7 @@ int xrfthip_plan_create(xrfthip_plan** plan, const xrfthip_desc* desc) {
         const uint32_t allowed = XRFTHIP_SHIFT_X | XRFTHIP_HALF_X | XRFTHIP_REALDIM_X2 | (d.out_mode == XRFTHIP_OUT_COMPLEX ? XRFTHIP_ISHIFT_X : 0u);
         P->fastmx = d.ndim == 1 && !cplx_in && (d.dtype == XRFTHIP_F64 || d.dtype == XRFTHIP_F32) && (d.out_mode == XRFTHIP_OUT_COMPLEX || d.out_mode == XRFTHIP_OUT_POWER) &&
                     !(d.flags & ~allowed) && !((d.flags & XRFTHIP_HALF_X) && (d.flags & XRFTHIP_SHIFT_X)) && !((d.flags & XRFTHIP_REALDIM_X2) && !(d.flags & XRFTHIP_HALF_X)) &&
-                    fastmy_len(d.nx, P->dbl) && d.batch < (1LL << 31) - 16 && !env_ll("XRFTHIP_NO_FAST", 0) && env_ll("XRFTHIP_FASTM", 1) != 0;
+                    fastmx_len(d.nx, P->dbl) && d.batch < (1LL << 31) - 16 && !env_ll("XRFTHIP_NO_FAST", 0) && env_ll("XRFTHIP_FASTM", 1) != 0;
         if (P->fastmx) {
             int rcm = P->dbl ? build_twiddle<double>(P->tw_fx, d.nx, d.nx) : build_twiddle<float>(P->tw_fx, d.nx, d.nx);
             std::vector<double> ones((size_t)d.nx, 1.0);
@@ -1874,7 +1886,7 @@ int xrfthip_plan_describe(const xrfthip_plan* plan, char* buf, size_t buflen) {
             d.ndim, (long long)d.batch, (long long)d.ny, (long long)d.nx, d.dtype, d.out_mode, d.detrend, d.flags,
             plan->width, plan->nx_out, (int)plan->mirror, plan->G, plan->ws_bytes);
     if (plan->fastmx) {
-        const MGeomRt C = mygeom(plan->d.nx, plan->dbl);
+        const MGeomRt C = mxgeom(plan->d.nx, plan->dbl);
         appendf(s, "  [fastm x-only] %d thr, %d row pairs per workgroup (FFT%lld r%dx%dx%d in LDS), lds=%zuB: per-row detrend + window + transform + full (or half) spectrum in one pass\n",
                 C.thr, C.g, (long long)plan->d.nx, C.r0, C.r1, C.r2, C.lds_cols);
     } else if (plan->fastmy) {
