@@ -651,6 +651,19 @@ def run_yonly_fast_cases(shape=(3, 360, 40), dtype="float64"):
     for kw in (dict(detrend="linear", window="hann"), dict(shift=False, scaling="spectrum", detrend="constant"), dict()):
         worst = max(worst, check(xa.power_spectrum(da, dim=["y"], **kw), o.power_spectrum(od, dim=["y"], **kw), tol))
         assert on_fast(), kw
+    # two fields: cross spectrum and cross phase along the axis (a column of each field = the two halves of one packed sequence)
+    b = _cube(rng, shape, dtype)
+    db, ob = pair(b, D3, _coords3(shape, y0=-1.5, x0=-1.0))
+    for kw in (dict(detrend="linear", window="hann"), dict(true_phase=False, shift=False, scaling="spectrum")):
+        worst = max(worst, check(xa.cross_spectrum(da, db, dim=["y"], **kw), o.cross_spectrum(od, ob, dim=["y"], **kw), tol))
+        assert on_fast(), kw
+    g = xa.cross_phase(da, db, dim=["y"], detrend="constant")
+    r = o.cross_phase(od, ob, dim=["y"], detrend="constant")
+    assert on_fast()
+    dphi = np.abs(np.angle(np.exp(1j * (g.values - r.values))))
+    mag = np.abs(o.cross_spectrum(od, ob, dim=["y"], detrend="constant").values)
+    lim = 1e-10 if dtype == "float64" else 3e-4
+    assert (dphi * mag).max() / mag.max() < lim, (dphi * mag).max() / mag.max()
     # the first axis of a 3-D array: batch = 1, inner = ny * nx
     worst = max(worst, check(xa.power_spectrum(da.transpose("y", "time", "x"), dim=["y"], detrend="linear", window="hann"),
                              o.power_spectrum(od.transpose("y", "time", "x"), dim=["y"], detrend="linear", window="hann"), tol))
@@ -682,4 +695,17 @@ def run_xonly_fast_cases(shape=(5, 360), dtype="float64"):
     for kw in (dict(detrend="linear", window="hann"), dict(shift=False, scaling="spectrum", detrend="constant"), dict(real_dim="x", window="hann"), dict()):
         worst = max(worst, check(xa.power_spectrum(da, dim=["x"], **kw), o.power_spectrum(od, dim=["x"], **kw), tol))
         assert on_fast(), kw
+    w = (rng.standard_normal(shape) - 1.0).astype(dtype)
+    c2 = dict(c); c2["x"] = c["x"] + 1.25
+    db, ob = pair(w, dims, c2)
+    for kw in (dict(detrend="linear", window="hann"), dict(true_phase=False, shift=False), dict(real_dim="x", detrend="constant")):
+        worst = max(worst, check(xa.cross_spectrum(da, db, dim=["x"], **kw), o.cross_spectrum(od, ob, dim=["x"], **kw), tol))
+        assert on_fast(), kw
+    g = xa.cross_phase(da, db, dim=["x"], window="hann")
+    r = o.cross_phase(od, ob, dim=["x"], window="hann")
+    assert on_fast()
+    dphi = np.abs(np.angle(np.exp(1j * (g.values - r.values))))
+    mag = np.abs(o.cross_spectrum(od, ob, dim=["x"], window="hann").values)
+    lim = 1e-10 if dtype == "float64" else 3e-4
+    assert (dphi * mag).max() / mag.max() < lim, (dphi * mag).max() / mag.max()
     return worst

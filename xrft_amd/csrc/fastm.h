@@ -100,6 +100,7 @@ template <typename T, int N> struct MGeom {
 
 struct FastM {
     const void* in;      // [slab][ny][nx] real T
+    const void* in_b;    // one-axis cross spectra / phases: the second field (same layout)
     void* w2;            // intermediate (see above)
     const void* w2b;     // cross spectra: field 1's intermediate (pass 2 only)
     void* out;           // [slab][ny][nx]: T (power, phase) or complex T
@@ -117,6 +118,7 @@ struct FastM {
     const int* binmap;   // radial sums fused into pass 2 (ISO): bin of (ky, kx), unshifted indices, [ny][nx]; < 0 = none
     double* iso_part;    // [slab][row workgroup][nbins (x2 complex)]: per-workgroup sums, reduced in order by iso_reduce_kernel
     int nbins, iso_ncopy;
+    int angle;           // one-axis two-field kernels: store the cross PHASE (float) instead of the cross spectrum (xrft.py:838-874)
     int half;            // real_dim: only kx = 0..nx/2 is stored, rows of nx/2 + 1 samples, unshifted along x (xrft.py:400-404)
     int realdim2;        // ... and 0 < kx < nx/2 counts twice (xrft.py:673-682)
     int ph_on;
@@ -372,11 +374,15 @@ __global__ void __launch_bounds__((MGeom<T, NY>::THR), (MGeom<T, NY>::WPS)) fast
 // caller's [ny][nx] result, rotated by the fftshift: |F|^2 scale (MODE 1) or F scale phase[ky] (MODE 0; the phase table carries
 // the true-phase factor and the (-1)^k of an ifftshifted input).  xrft.py:425-447, 462-469, 740-748.
 // ------------------------------------------------------------------------------------------------
-template <typename T, int NY, bool DET, int MODE>
+// (MODE 0 complex, 1 power, 2 two fields: cross spectrum, or its phase with p.angle; the detrend is a run-time switch: fewer
+// instantiations -- 20 lengths x 2 precisions x 3 modes)
+template <typename T, int NY, int MODE>
 __global__ void __launch_bounds__((MGeom<T, NY>::THR), (MGeom<T, NY>::WPS)) fastm_yonly_kernel(FastM p) {
     typedef MGeom<T, NY> M;
     typedef C2<T> CT;
-    constexpr int G = M::G, THR = M::THR, STR = M::STR, CW = 2 * G, R0 = M::R0, M0 = M::M0;
+    constexpr bool TWO = MODE >= 2;
+    const bool DET = p.detrend != 0;  // cross spectrum / cross phase: column c of field 0 and of field 1 are the two halves of sequence c
+    constexpr int G = M::G, THR = M::THR, STR = M::STR, CW = TWO ? G : 2 * G, R0 = M::R0, M0 = M::M0;
     XRFT_DYN_SMEM(smem_raw);
     CT* lds = reinterpret_cast<CT*>(smem_raw);
     CT* tw1 = lds + G * STR;
@@ -391,7 +397,8 @@ __global__ void __launch_bounds__((MGeom<T, NY>::THR), (MGeom<T, NY>::WPS)) fast
     const int j = on ? r0 : 0;
     const CT w0 = reinterpret_cast<const CT*>(p.tw_y)[j];
     const char* __restrict__ src = reinterpret_cast<const char*>(reinterpret_cast<const T*>(p.in) + (size_t)slab * NY * p.nx + (size_t)xb * CW);
-    const unsigned rowb = (unsigned)p.nx * (unsigned)sizeof(T), off0 = (unsigned)j * rowb + (unsigned)g * (unsigned)sizeof(CT), rstep = (unsigned)M0 * rowb;
+    const char* __restrict__ srcb = reinterpret_cast<const char*>(reinterpret_cast<const T*>(TWO ? p.in_b : p.in) + (size_t)slab * NY * p.nx + (size_t)xb * CW);
+    const unsigned rowb = (unsigned)p.nx * (unsigned)sizeof(T), off0 = (unsigned)j * rowb + (unsigned)g * (unsigned)(TWO ? sizeof(T) : sizeof(CT)), rstep = (unsigned)M0 * rowb;
     const T* __restrict__ wy = reinterpret_cast<const T*>(p.win_y);
     CT a[R0];
     T wyv[R0];
@@ -399,7 +406,8 @@ __global__ void __launch_bounds__((MGeom<T, NY>::THR), (MGeom<T, NY>::WPS)) fast
     for (int q = 0; q < R0; ++q) {
         a[q] = mk<T>((T)0, (T)0); wyv[q] = (T)0;
         if (on) {
-            a[q] = *reinterpret_cast<const CT*>(src + (off0 + rstep * (unsigned)q));
+            if (TWO) a[q] = mk<T>(*reinterpret_cast<const T*>(src + (off0 + rstep * (unsigned)q)), *reinterpret_cast<const T*>(srcb + (off0 + rstep * (unsigned)q)));
+            else a[q] = *reinterpret_cast<const CT*>(src + (off0 + rstep * (unsigned)q));
             wyv[q] = wy[j + q * M0];
         }
     }
@@ -441,17 +449,18 @@ __global__ void __launch_bounds__((MGeom<T, NY>::THR), (MGeom<T, NY>::WPS)) fast
     if (on) mr_pass0<T, NY>(a, lds + g * STR, j, w0);
     mr_fft_tail<T, NY, G, THR>(lds, tid, tw1);
     // split the packed spectra (fastm_cols_kernel) and store rows ky and -ky of the result; lanes (ky, column), column fastest
-    typedef typename std::conditional<MODE == 0, CT, T>::type OutT;
-    OutT* __restrict__ outs = reinterpret_cast<OutT*>(p.out) + (size_t)slab * NY * p.nx + (size_t)xb * CW;
+    char* __restrict__ outs = reinterpret_cast<char*>(p.out) + ((size_t)slab * NY * p.nx + (size_t)xb * CW) * ((MODE == 1 || (MODE == 2 && p.angle)) ? sizeof(T) : sizeof(CT));
     const T sc = (T)p.scale;
     constexpr int NST = (CW * (NY / 2 + 1) + THR - 1) / THR;
 #pragma unroll
     for (int i = 0; i < NST; ++i) {
         const int l = tid + i * THR, col = l % CW, k = l / CW;
         if (k <= NY / 2) {
-            const CT* z = lds + (col >> 1) * STR;
+            const CT* z = lds + (TWO ? col : (col >> 1)) * STR;
             const CT zk = z[M::pn(k)], zc = cconj(z[M::pn(k == 0 ? 0 : NY - k)]);
-            CT o = (col & 1) ? cscale(mul_mi(zk - zc), (T)0.5) : cscale(zk + zc, (T)0.5);
+            CT o;
+            if (TWO) o = cmulc(cscale(zk + zc, (T)0.5), cscale(mul_mi(zk - zc), (T)0.5));  // F0 conj(F1) of this column (xrft.py:825)
+            else o = (col & 1) ? cscale(mul_mi(zk - zc), (T)0.5) : cscale(zk + zc, (T)0.5);
             const int km = k == 0 ? 0 : NY - k;
             int rd = k + p.shift_y; if (rd >= NY) rd -= NY;
             int rm = km + p.shift_y; if (rm >= NY) rm -= NY;
@@ -464,8 +473,13 @@ __global__ void __launch_bounds__((MGeom<T, NY>::THR), (MGeom<T, NY>::WPS)) fast
                 o = cscale(o, sc);
                 CT om = cconj(o);
                 if (p.ph_on) { o = cmul(o, reinterpret_cast<const CT*>(p.ph_y)[k]); om = cmul(om, reinterpret_cast<const CT*>(p.ph_y)[km]); }
-                reinterpret_cast<CT*>(outs)[(size_t)rd * p.nx + col] = o;
-                if (mirror) reinterpret_cast<CT*>(outs)[(size_t)rm * p.nx + col] = om;
+                if (MODE == 2 && p.angle) {  // cross phase (xrft.py:838-874)
+                    reinterpret_cast<T*>(outs)[(size_t)rd * p.nx + col] = (T)atan2((double)o.im, (double)o.re);
+                    if (mirror) reinterpret_cast<T*>(outs)[(size_t)rm * p.nx + col] = (T)atan2((double)om.im, (double)om.re);
+                } else {
+                    reinterpret_cast<CT*>(outs)[(size_t)rd * p.nx + col] = o;
+                    if (mirror) reinterpret_cast<CT*>(outs)[(size_t)rm * p.nx + col] = om;
+                }
             }
         }
     }
@@ -478,25 +492,27 @@ __global__ void __launch_bounds__((MGeom<T, NY>::THR), (MGeom<T, NY>::WPS)) fast
 // xrft/detrend.py:54-71) from the sums of the samples the threads hold, as in fastm_yonly_kernel; window; three passes; each
 // row's spectrum (all n frequencies, or n/2 + 1 with real_dim) leaves rotated by the fftshift, contiguous along k.
 // ------------------------------------------------------------------------------------------------
-template <typename T, int N, bool DET, int MODE>
+template <typename T, int N, int MODE>
 __global__ void __launch_bounds__((MGeom<T, N>::THR), (MGeom<T, N>::WPS)) fastm_xonly_kernel(FastM p) {
     typedef MGeom<T, N> M;
     typedef C2<T> CT;
-    constexpr int G = M::G, THR = M::THR, STR = M::STR, R0 = M::R0, M0 = M::M0;
+    constexpr bool TWO = MODE >= 2;
+    const bool DET = p.detrend != 0;  // cross spectrum / cross phase: row r of field 0 and of field 1 are the two halves of a sequence
+    constexpr int G = M::G, THR = M::THR, STR = M::STR, R0 = M::R0, M0 = M::M0, RPW = TWO ? G : 2 * G;  // rows per workgroup
     XRFT_DYN_SMEM(smem_raw);
     CT* lds = reinterpret_cast<CT*>(smem_raw);
     CT* tw1 = lds + G * STR;
     double* part = reinterpret_cast<double*>(tw1 + M::M0);  // [wave][g][4]
     const int tid = threadIdx.x, g = tid % G, r0 = tid / G;
-    const long long row0 = (long long)blockIdx.x * (2 * G), nrows = p.nslab;  // (nslab: rows in all)
+    const long long row0 = (long long)blockIdx.x * RPW, nrows = p.nslab;  // (nslab: rows in all)
     mr_fill_tw1<T, N>(tw1, reinterpret_cast<const CT*>(p.tw_x), tid, THR);
     const bool on = r0 < M::B0;
     const int j = on ? r0 : 0;
     const CT w0 = reinterpret_cast<const CT*>(p.tw_x)[j];
-    const long long ra = row0 + 2 * g, rb = ra + 1;
+    const long long ra = TWO ? row0 + g : row0 + 2 * g, rb = TWO ? ra : ra + 1;
     const bool ha = on && ra < nrows, hb = on && rb < nrows;
     const T* __restrict__ sa = reinterpret_cast<const T*>(p.in) + (size_t)(ha ? ra : 0) * N;
-    const T* __restrict__ sb = reinterpret_cast<const T*>(p.in) + (size_t)(hb ? rb : 0) * N;
+    const T* __restrict__ sb = reinterpret_cast<const T*>(TWO ? p.in_b : p.in) + (size_t)(hb ? rb : 0) * N;
     const T* __restrict__ wx = reinterpret_cast<const T*>(p.win_x);
     CT a[R0];
     T wv[R0];
@@ -545,25 +561,28 @@ __global__ void __launch_bounds__((MGeom<T, N>::THR), (MGeom<T, N>::WPS)) fastm_
     if (on) mr_pass0<T, N>(a, lds + g * STR, j, w0);
     mr_fft_tail<T, N, G, THR>(lds, tid, tw1);
     // split and store: lanes run along k of one row
-    typedef typename std::conditional<MODE == 0, CT, T>::type OutT;
+    const bool real_out = MODE == 1 || (MODE == 2 && p.angle);
     const int W = p.half ? N / 2 + 1 : N;
     const T sc = (T)p.scale;
-    for (int e = tid; e < 2 * G * W; e += THR) {
+    for (int e = tid; e < RPW * W; e += THR) {
         const int t = e / W, k = e - t * W;
         const long long row = row0 + t;
         if (row >= nrows) break;  // (t grows with e)
-        const CT* z = lds + (t >> 1) * STR;
+        const CT* z = lds + (TWO ? t : (t >> 1)) * STR;
         const CT zk = z[M::pn(k)], zc = cconj(z[M::pn(k == 0 ? 0 : N - k)]);
-        CT o = (t & 1) ? cscale(mul_mi(zk - zc), (T)0.5) : cscale(zk + zc, (T)0.5);
+        CT o;
+        if (TWO) o = cmulc(cscale(zk + zc, (T)0.5), cscale(mul_mi(zk - zc), (T)0.5));  // F0 conj(F1) of this row (xrft.py:825)
+        else o = (t & 1) ? cscale(mul_mi(zk - zc), (T)0.5) : cscale(zk + zc, (T)0.5);
         int oc = k + p.shift_x; if (oc >= N) oc -= N;  // (half output: shift_x = 0)
         const T f = (p.realdim2 && k != 0 && 2 * k != N) ? sc * (T)2 : sc;
-        OutT* dst = reinterpret_cast<OutT*>(p.out) + (size_t)row * W + oc;
+        char* dst = reinterpret_cast<char*>(p.out) + ((size_t)row * W + oc) * (real_out ? sizeof(T) : sizeof(CT));
         if (MODE == 1) {
             *reinterpret_cast<T*>(dst) = (o.re * o.re + o.im * o.im) * f;
         } else {
             o = cscale(o, f);
             if (p.ph_on) o = cmul(o, reinterpret_cast<const CT*>(p.ph_x)[k]);
-            *reinterpret_cast<CT*>(dst) = o;
+            if (MODE == 2 && p.angle) *reinterpret_cast<T*>(dst) = (T)atan2((double)o.im, (double)o.re);
+            else *reinterpret_cast<CT*>(dst) = o;
         }
     }
 }

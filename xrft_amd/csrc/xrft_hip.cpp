@@ -765,10 +765,9 @@ void set_kernel_attrs_once() {
     done = true;
     const int m = (int)kLdsMax;
     // (the one fastm instantiation above 64 KB of dynamic LDS: 4096-point float64 rows, one pair per workgroup)
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&fastm_xonly_kernel<double, 4096, true, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, m);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&fastm_xonly_kernel<double, 4096, true, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, m);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&fastm_xonly_kernel<double, 4096, false, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, m);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&fastm_xonly_kernel<double, 4096, false, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, m);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&fastm_xonly_kernel<double, 4096, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, m);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&fastm_xonly_kernel<double, 4096, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, m);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&fastm_xonly_kernel<double, 4096, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, m);
 #define SETA(TT, A, B, C) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&tile_fft_kernel<TT, A, B, C, sizeof(TT) == 8 ? 512 : 1024, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, m)
 #define SETP(TT, A, B, PP) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&tile_fft_kernel<TT, A, B, false, sizeof(TT) == 8 ? 512 : 1024, PP>), hipFuncAttributeMaxDynamicSharedMemorySize, m)
 #define SETPATHS(TT) SETP(TT, true, false, 1); SETP(TT, true, true, 1); SETP(TT, false, true, 2); SETP(TT, true, false, 3); SETP(TT, false, true, 4)
@@ -1460,31 +1459,33 @@ static MGeomRt mygeom(long long n, bool dbl) {
     }
     return mgeom(n, dbl);
 }
-static int run_fastmy(const xrfthip_plan* P, const void* in, void* out, hipStream_t st) {
+static int run_fastmy(const xrfthip_plan* P, const void* in, const void* in1, void* out, hipStream_t st) {
     const xrfthip_desc& d = P->d;
     const MGeomRt C = mygeom(d.ny, P->dbl);
+    const bool two = d.out_mode == XRFTHIP_OUT_CROSS || d.out_mode == XRFTHIP_OUT_PHASE;
     FastM p{};
-    p.in = in; p.out = out;
+    p.in = in; p.in_b = in1; p.out = out;
+    p.angle = d.out_mode == XRFTHIP_OUT_PHASE ? 1 : 0;
     p.tw_y = P->tw_fy.p;
     p.win_y = P->win[0].p ? P->win[0].p : P->ones4096.p;
     p.ph_y = P->fph[0].p; p.ph_on = P->fph_on ? 1 : 0;
     p.ny = (int)d.ny; p.nx = (int)d.nx;
     p.detrend = d.detrend; p.nslab = (int)d.batch;
-    p.nunits = (int)(d.batch * (d.nx / (2 * C.g)));
+    p.nunits = (int)(d.batch * (d.nx / (two ? C.g : 2 * C.g)));
     p.shift_y = (d.flags & XRFTHIP_SHIFT_Y) ? (int)(d.ny / 2) : 0;
     p.scale = d.scale;
     xrfthip_plan::ProfRec* rec = prof_begin(P, "fastm_yonly", st);
     const dim3 grid((unsigned)(8 * ((p.nunits + 7) / 8))), blk((unsigned)C.thr);
-    const bool pw = d.out_mode == XRFTHIP_OUT_POWER;
+#define MYL_(TT, NN, MM) do { auto k = &fastm_yonly_kernel<TT, NN, MM>; XRFT_LAUNCH(k, grid, blk, C.lds_cols, st, p); } while (0)
 #define MY_(TT, NN) do { \
-        if (d.detrend) { if (pw) { auto k = &fastm_yonly_kernel<TT, NN, true, 1>; XRFT_LAUNCH(k, grid, blk, C.lds_cols, st, p); } else { auto k = &fastm_yonly_kernel<TT, NN, true, 0>; XRFT_LAUNCH(k, grid, blk, C.lds_cols, st, p); } } \
-        else { if (pw) { auto k = &fastm_yonly_kernel<TT, NN, false, 1>; XRFT_LAUNCH(k, grid, blk, C.lds_cols, st, p); } else { auto k = &fastm_yonly_kernel<TT, NN, false, 0>; XRFT_LAUNCH(k, grid, blk, C.lds_cols, st, p); } } } while (0)
+        if (d.out_mode == XRFTHIP_OUT_POWER) MYL_(TT, NN, 1); else if (two) MYL_(TT, NN, 2); else MYL_(TT, NN, 0); } while (0)
 #define XD_(NN) if (d.ny == NN) MY_(double, NN);
 #define XF_(NN) if (d.ny == NN) MY_(float, NN);
     if (P->dbl) { XRFT_M_LATLON(XD_) XRFT_M_POW2(XD_) XRFT_M_YONLY(XD_) } else { XRFT_M_LATLON(XF_) XRFT_M_POW2(XF_) XRFT_M_YONLY(XF_) XF_(2048) }
 #undef XD_
 #undef XF_
 #undef MY_
+#undef MYL_
     prof_end(rec, st);
     HIP_TRY(hipGetLastError());
     return XRFTHIP_OK;
@@ -1498,11 +1499,13 @@ static MGeomRt mxgeom(long long n, bool dbl) {
     if (dbl && n == 2048) return mgeom_t<double, 2048>();
     return mygeom(n, dbl);
 }
-static int run_fastmx(const xrfthip_plan* P, const void* in, void* out, hipStream_t st) {
+static int run_fastmx(const xrfthip_plan* P, const void* in, const void* in1, void* out, hipStream_t st) {
     const xrfthip_desc& d = P->d;
     const MGeomRt C = mxgeom(d.nx, P->dbl);
+    const bool two = d.out_mode == XRFTHIP_OUT_CROSS || d.out_mode == XRFTHIP_OUT_PHASE;
     FastM p{};
-    p.in = in; p.out = out;
+    p.in = in; p.in_b = in1; p.out = out;
+    p.angle = d.out_mode == XRFTHIP_OUT_PHASE ? 1 : 0;
     p.tw_x = P->tw_fx.p;
     p.win_x = P->win[1].p ? P->win[1].p : P->ones4096.p;
     p.ph_x = P->fph[1].p; p.ph_on = P->fph_on ? 1 : 0;
@@ -1513,17 +1516,18 @@ static int run_fastmx(const xrfthip_plan* P, const void* in, void* out, hipStrea
     p.shift_x = (d.flags & XRFTHIP_SHIFT_X) ? (int)(d.nx / 2) : 0;
     p.scale = d.scale;
     xrfthip_plan::ProfRec* rec = prof_begin(P, "fastm_xonly", st);
-    const dim3 grid((unsigned)((d.batch + 2 * C.g - 1) / (2 * C.g))), blk((unsigned)C.thr);
-    const bool pw = d.out_mode == XRFTHIP_OUT_POWER;
+    const int rpw = two ? C.g : 2 * C.g;
+    const dim3 grid((unsigned)((d.batch + rpw - 1) / rpw)), blk((unsigned)C.thr);
+#define MXL_(TT, NN, MM) do { auto k = &fastm_xonly_kernel<TT, NN, MM>; XRFT_LAUNCH(k, grid, blk, C.lds_cols, st, p); } while (0)
 #define MX_(TT, NN) do { \
-        if (d.detrend) { if (pw) { auto k = &fastm_xonly_kernel<TT, NN, true, 1>; XRFT_LAUNCH(k, grid, blk, C.lds_cols, st, p); } else { auto k = &fastm_xonly_kernel<TT, NN, true, 0>; XRFT_LAUNCH(k, grid, blk, C.lds_cols, st, p); } } \
-        else { if (pw) { auto k = &fastm_xonly_kernel<TT, NN, false, 1>; XRFT_LAUNCH(k, grid, blk, C.lds_cols, st, p); } else { auto k = &fastm_xonly_kernel<TT, NN, false, 0>; XRFT_LAUNCH(k, grid, blk, C.lds_cols, st, p); } } } while (0)
+        if (d.out_mode == XRFTHIP_OUT_POWER) MXL_(TT, NN, 1); else if (two) MXL_(TT, NN, 2); else MXL_(TT, NN, 0); } while (0)
 #define XD_(NN) if (d.nx == NN) MX_(double, NN);
 #define XF_(NN) if (d.nx == NN) MX_(float, NN);
     if (P->dbl) { XRFT_M_LATLON(XD_) XRFT_M_POW2(XD_) XRFT_M_YONLY(XD_) XD_(2048) XD_(4096) } else { XRFT_M_LATLON(XF_) XRFT_M_POW2(XF_) XRFT_M_YONLY(XF_) XF_(2048) XF_(4096) }
 #undef XD_
 #undef XF_
 #undef MX_
+#undef MXL_
     prof_end(rec, st);
     HIP_TRY(hipGetLastError());
     return XRFTHIP_OK;
@@ -1761,11 +1765,12 @@ int xrfthip_plan_create(xrfthip_plan** plan, const xrfthip_desc* desc) {
         }
     }
     {   // one transform axis that is not the contiguous one, real input: pass 1 of the same kernels is the whole transform
-        const uint32_t allowed = XRFTHIP_AXIS_Y | XRFTHIP_SHIFT_Y | (d.out_mode == XRFTHIP_OUT_COMPLEX ? XRFTHIP_ISHIFT_Y : 0u);
+        const bool two = d.out_mode == XRFTHIP_OUT_CROSS || d.out_mode == XRFTHIP_OUT_PHASE;
+        const uint32_t allowed = XRFTHIP_AXIS_Y | XRFTHIP_SHIFT_Y | (d.out_mode != XRFTHIP_OUT_POWER ? XRFTHIP_ISHIFT_Y : 0u);
         P->fastmy = (d.flags & XRFTHIP_AXIS_Y) && d.ndim == 2 && !cplx_in && (d.dtype == XRFTHIP_F64 || d.dtype == XRFTHIP_F32) &&
-                    (d.out_mode == XRFTHIP_OUT_COMPLEX || d.out_mode == XRFTHIP_OUT_POWER) && !(d.flags & ~allowed) && fastmy_len(d.ny, P->dbl) &&
+                    (d.out_mode == XRFTHIP_OUT_COMPLEX || d.out_mode == XRFTHIP_OUT_POWER || two) && !(d.flags & ~allowed) && fastmy_len(d.ny, P->dbl) &&
                     d.batch * d.nx < (1LL << 30) && !env_ll("XRFTHIP_NO_FAST", 0) && env_ll("XRFTHIP_FASTM", 1) != 0;
-        if (P->fastmy && d.nx % (2 * mygeom(d.ny, P->dbl).g) != 0) P->fastmy = false;
+        if (P->fastmy && d.nx % ((two ? 1 : 2) * mygeom(d.ny, P->dbl).g) != 0) P->fastmy = false;
         if (P->fastmy) {
             int rcm = P->dbl ? build_twiddle<double>(P->tw_fy, d.ny, d.ny) : build_twiddle<float>(P->tw_fy, d.ny, d.ny);
             std::vector<double> ones((size_t)d.ny, 1.0);
@@ -1775,8 +1780,9 @@ int xrfthip_plan_create(xrfthip_plan** plan, const xrfthip_desc* desc) {
         }
     }
     {   // one short transform axis, the contiguous one, real input: rows packed in pairs through the same three passes
-        const uint32_t allowed = XRFTHIP_SHIFT_X | XRFTHIP_HALF_X | XRFTHIP_REALDIM_X2 | (d.out_mode == XRFTHIP_OUT_COMPLEX ? XRFTHIP_ISHIFT_X : 0u);
-        P->fastmx = d.ndim == 1 && !cplx_in && (d.dtype == XRFTHIP_F64 || d.dtype == XRFTHIP_F32) && (d.out_mode == XRFTHIP_OUT_COMPLEX || d.out_mode == XRFTHIP_OUT_POWER) &&
+        const bool two = d.out_mode == XRFTHIP_OUT_CROSS || d.out_mode == XRFTHIP_OUT_PHASE;
+        const uint32_t allowed = XRFTHIP_SHIFT_X | XRFTHIP_HALF_X | (d.out_mode != XRFTHIP_OUT_PHASE ? XRFTHIP_REALDIM_X2 : 0u) | (d.out_mode != XRFTHIP_OUT_POWER ? XRFTHIP_ISHIFT_X : 0u);
+        P->fastmx = d.ndim == 1 && !cplx_in && (d.dtype == XRFTHIP_F64 || d.dtype == XRFTHIP_F32) && (d.out_mode == XRFTHIP_OUT_COMPLEX || d.out_mode == XRFTHIP_OUT_POWER || two) &&
                     !(d.flags & ~allowed) && !((d.flags & XRFTHIP_HALF_X) && (d.flags & XRFTHIP_SHIFT_X)) && !((d.flags & XRFTHIP_REALDIM_X2) && !(d.flags & XRFTHIP_HALF_X)) &&
                     fastmx_len(d.nx, P->dbl) && d.batch < (1LL << 31) - 16 && !env_ll("XRFTHIP_NO_FAST", 0) && env_ll("XRFTHIP_FASTM", 1) != 0;
         if (P->fastmx) {
@@ -1934,8 +1940,8 @@ int xrfthip_exec(const xrfthip_plan* plan, const void* d_in0, const void* d_in1,
     double* acc = (double*)(ws + P->off_acc);
     double* coef = (double*)(ws + P->off_coef);
     if (iso) HIP_TRY(hipMemsetAsync(d_iso, 0, (size_t)d.batch * P->nbins * (cross ? 16 : 8), st));
-    if (P->fastmx) return run_fastmx(P, d_in0, out, st);
-    if (P->fastmy) return run_fastmy(P, d_in0, out, st);
+    if (P->fastmx) return run_fastmx(P, d_in0, d_in1, out, st);
+    if (P->fastmy) return run_fastmy(P, d_in0, d_in1, out, st);
     if (P->fastm) return run_fastm(P, d_in0, d_in1, out, (double*)d_iso, ws, st);
     if (fasty_on(P)) {
         return run_fasty(P, (const float*)d_in0, (const float*)d_in1, out, (double*)d_iso, ws, st);
