@@ -22,7 +22,7 @@ def build(force=False):
     if not force and not needs_build():
         return OUT
     os.makedirs(os.path.dirname(OUT), exist_ok=True)
-    cmd = ["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-DXRFT_EMULATE", f"-I{HERE}", f"-I{SRC}",
+    cmd = ["g++", "-O1", "-std=c++17", "-fPIC", "-shared", "-DXRFT_EMULATE", f"-I{HERE}", f"-I{SRC}",
            os.path.join(SRC, "xrft_hip.cpp"), "-o", OUT, "-lpthread"]
     subprocess.run(cmd, check=True)
     return OUT
