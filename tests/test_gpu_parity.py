@@ -600,7 +600,7 @@ def _fresh_plan(shape, dtype, **kw):
                                detrend=_lib.DETREND_LINEAR, flags=_lib.SHIFT_Y | _lib.SHIFT_X, scale=1.0, **kw)
 
 
-@pytest.mark.parametrize("shape,dtype", [((2, 256, 512), "float32"), ((3, 96, 80), "float64"), ((2, 50, 72), "float32")])
+@pytest.mark.parametrize("shape,dtype", [((2, 256, 512), "float32"), ((3, 96, 80), "float64"), ((2, 50, 72), "float32"), ((2, 360, 720), "float64"), ((3, 720, 360), "float32")])
 def test_exec_is_graph_capturable_on_its_first_call(shape, dtype):
     """xrfthip_exec of a plan that has never run is captured into a HIP graph (no allocation, no blocking copy, no
     synchronisation inside), then replayed on two different inputs."""
