@@ -651,6 +651,15 @@ def run_yonly_fast_cases(shape=(3, 360, 40), dtype="float64"):
     for kw in (dict(detrend="linear", window="hann"), dict(shift=False, scaling="spectrum", detrend="constant"), dict()):
         worst = max(worst, check(xa.power_spectrum(da, dim=["y"], **kw), o.power_spectrum(od, dim=["y"], **kw), tol))
         assert on_fast(), kw
+    # complex input (the later stages of N-D transforms): one sequence per column
+    cdt = "complex128" if dtype == "float64" else "complex64"
+    z = (a + 1j * _cube(rng, shape, dtype)).astype(cdt)
+    dz, oz = pair(z, D3, _coords3(shape, y0=2.5, x0=-1.0))
+    for kw in (dict(), dict(detrend="linear", window="hann", shift=False)):
+        worst = max(worst, check(xa.fft(dz, dim=["y"], **kw), o.fft(oz, dim=["y"], **kw), tol))
+        assert on_fast(), kw
+    worst = max(worst, check(xa.power_spectrum(dz, dim=["y"], detrend="constant"), o.power_spectrum(oz, dim=["y"], detrend="constant"), tol))
+    assert on_fast()
     # two fields: cross spectrum and cross phase along the axis (a column of each field = the two halves of one packed sequence)
     b = _cube(rng, shape, dtype)
     db, ob = pair(b, D3, _coords3(shape, y0=-1.5, x0=-1.0))
@@ -695,6 +704,14 @@ def run_xonly_fast_cases(shape=(5, 360), dtype="float64"):
     for kw in (dict(detrend="linear", window="hann"), dict(shift=False, scaling="spectrum", detrend="constant"), dict(real_dim="x", window="hann"), dict()):
         worst = max(worst, check(xa.power_spectrum(da, dim=["x"], **kw), o.power_spectrum(od, dim=["x"], **kw), tol))
         assert on_fast(), kw
+    cdt = "complex128" if dtype == "float64" else "complex64"
+    z = (v + 1j * rng.standard_normal(shape)).astype(cdt)
+    dz, oz = pair(z, dims, c)
+    for kw in (dict(), dict(detrend="linear", window="hann", shift=False)):
+        worst = max(worst, check(xa.fft(dz, dim=["x"], **kw), o.fft(oz, dim=["x"], **kw), tol))
+        assert on_fast(), kw
+    worst = max(worst, check(xa.power_spectrum(dz, dim=["x"], detrend="constant"), o.power_spectrum(oz, dim=["x"], detrend="constant"), tol))
+    assert on_fast()
     w = (rng.standard_normal(shape) - 1.0).astype(dtype)
     c2 = dict(c); c2["x"] = c["x"] + 1.25
     db, ob = pair(w, dims, c2)

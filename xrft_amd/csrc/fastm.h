@@ -18,6 +18,7 @@
 // 128-byte line; pass 1 writes whole lines, pass 2 reads RPU (a multiple of RK) consecutive ky = one contiguous block.
 #pragma once
 #include "aux_kernels.h"
+#include "fasty.h"  // ilog2c
 #include "tile_fft.h"
 
 namespace xrft {
@@ -118,6 +119,7 @@ struct FastM {
     const int* binmap;   // radial sums fused into pass 2 (ISO): bin of (ky, kx), unshifted indices, [ny][nx]; < 0 = none
     double* iso_part;    // [slab][row workgroup][nbins (x2 complex)]: per-workgroup sums, reduced in order by iso_reduce_kernel
     int nbins, iso_ncopy;
+    int cin;             // one-axis kernels: the input is COMPLEX (one sequence per column / row, no packing): the later stages of N-D transforms
     int angle;           // one-axis two-field kernels: store the cross PHASE (float) instead of the cross spectrum (xrft.py:838-874)
     int half;            // real_dim: only kx = 0..nx/2 is stored, rows of nx/2 + 1 samples, unshifted along x (xrft.py:400-404)
     int realdim2;        // ... and 0 < kx < nx/2 counts twice (xrft.py:673-682)
@@ -382,7 +384,9 @@ __global__ void __launch_bounds__((MGeom<T, NY>::THR), (MGeom<T, NY>::WPS)) fast
     typedef C2<T> CT;
     constexpr bool TWO = MODE >= 2;
     const bool DET = p.detrend != 0;  // cross spectrum / cross phase: column c of field 0 and of field 1 are the two halves of sequence c
-    constexpr int G = M::G, THR = M::THR, STR = M::STR, CW = TWO ? G : 2 * G, R0 = M::R0, M0 = M::M0;
+    constexpr int G = M::G, THR = M::THR, STR = M::STR, R0 = M::R0, M0 = M::M0;
+    const bool CIN = !TWO && p.cin != 0;          // complex input: column c IS sequence c
+    const int CW = (TWO || CIN) ? G : 2 * G;     // columns per workgroup
     XRFT_DYN_SMEM(smem_raw);
     CT* lds = reinterpret_cast<CT*>(smem_raw);
     CT* tw1 = lds + G * STR;
@@ -396,9 +400,10 @@ __global__ void __launch_bounds__((MGeom<T, NY>::THR), (MGeom<T, NY>::WPS)) fast
     const bool on = r0 < M::B0;
     const int j = on ? r0 : 0;
     const CT w0 = reinterpret_cast<const CT*>(p.tw_y)[j];
-    const char* __restrict__ src = reinterpret_cast<const char*>(reinterpret_cast<const T*>(p.in) + (size_t)slab * NY * p.nx + (size_t)xb * CW);
-    const char* __restrict__ srcb = reinterpret_cast<const char*>(reinterpret_cast<const T*>(TWO ? p.in_b : p.in) + (size_t)slab * NY * p.nx + (size_t)xb * CW);
-    const unsigned rowb = (unsigned)p.nx * (unsigned)sizeof(T), off0 = (unsigned)j * rowb + (unsigned)g * (unsigned)(TWO ? sizeof(T) : sizeof(CT)), rstep = (unsigned)M0 * rowb;
+    const size_t esz = CIN ? sizeof(CT) : sizeof(T);  // bytes per input element
+    const char* __restrict__ src = reinterpret_cast<const char*>(p.in) + ((size_t)slab * NY * p.nx + (size_t)xb * CW) * esz;
+    const char* __restrict__ srcb = reinterpret_cast<const char*>(TWO ? p.in_b : p.in) + ((size_t)slab * NY * p.nx + (size_t)xb * CW) * esz;
+    const unsigned rowb = (unsigned)p.nx * (unsigned)esz, off0 = (unsigned)j * rowb + (unsigned)g * (unsigned)(TWO ? sizeof(T) : sizeof(CT)), rstep = (unsigned)M0 * rowb;
     const T* __restrict__ wy = reinterpret_cast<const T*>(p.win_y);
     CT a[R0];
     T wyv[R0];
@@ -451,10 +456,25 @@ __global__ void __launch_bounds__((MGeom<T, NY>::THR), (MGeom<T, NY>::WPS)) fast
     // split the packed spectra (fastm_cols_kernel) and store rows ky and -ky of the result; lanes (ky, column), column fastest
     char* __restrict__ outs = reinterpret_cast<char*>(p.out) + ((size_t)slab * NY * p.nx + (size_t)xb * CW) * ((MODE == 1 || (MODE == 2 && p.angle)) ? sizeof(T) : sizeof(CT));
     const T sc = (T)p.scale;
-    constexpr int NST = (CW * (NY / 2 + 1) + THR - 1) / THR;
+    if (CIN) {  // every frequency of every column, no mirror
+        for (int l = tid; l < CW * NY; l += THR) {
+            const int col = l % CW, k = l / CW;
+            CT o = lds[col * STR + M::pn(k)];
+            int rd = k + p.shift_y; if (rd >= NY) rd -= NY;
+            if (MODE == 1) reinterpret_cast<T*>(outs)[(size_t)rd * p.nx + col] = (o.re * o.re + o.im * o.im) * sc;
+            else {
+                o = cscale(o, sc);
+                if (p.ph_on) o = cmul(o, reinterpret_cast<const CT*>(p.ph_y)[k]);
+                reinterpret_cast<CT*>(outs)[(size_t)rd * p.nx + col] = o;
+            }
+        }
+        return;
+    }
+    constexpr int NST = (2 * G * (NY / 2 + 1) + THR - 1) / THR;
+    const int cwsh = CW == G ? ilog2c(G) : ilog2c(2 * G);  // (CW is a power of two)
 #pragma unroll
     for (int i = 0; i < NST; ++i) {
-        const int l = tid + i * THR, col = l % CW, k = l / CW;
+        const int l = tid + i * THR, col = l & (CW - 1), k = l >> cwsh;
         if (k <= NY / 2) {
             const CT* z = lds + (TWO ? col : (col >> 1)) * STR;
             const CT zk = z[M::pn(k)], zc = cconj(z[M::pn(k == 0 ? 0 : NY - k)]);
@@ -498,7 +518,9 @@ __global__ void __launch_bounds__((MGeom<T, N>::THR), (MGeom<T, N>::WPS)) fastm_
     typedef C2<T> CT;
     constexpr bool TWO = MODE >= 2;
     const bool DET = p.detrend != 0;  // cross spectrum / cross phase: row r of field 0 and of field 1 are the two halves of a sequence
-    constexpr int G = M::G, THR = M::THR, STR = M::STR, R0 = M::R0, M0 = M::M0, RPW = TWO ? G : 2 * G;  // rows per workgroup
+    constexpr int G = M::G, THR = M::THR, STR = M::STR, R0 = M::R0, M0 = M::M0;
+    const bool CIN = !TWO && p.cin != 0;           // complex input: row r IS sequence r
+    const int RPW = (TWO || CIN) ? G : 2 * G;     // rows per workgroup
     XRFT_DYN_SMEM(smem_raw);
     CT* lds = reinterpret_cast<CT*>(smem_raw);
     CT* tw1 = lds + G * STR;
@@ -509,8 +531,9 @@ __global__ void __launch_bounds__((MGeom<T, N>::THR), (MGeom<T, N>::WPS)) fastm_
     const bool on = r0 < M::B0;
     const int j = on ? r0 : 0;
     const CT w0 = reinterpret_cast<const CT*>(p.tw_x)[j];
-    const long long ra = TWO ? row0 + g : row0 + 2 * g, rb = TWO ? ra : ra + 1;
+    const long long ra = (TWO || CIN) ? row0 + g : row0 + 2 * g, rb = (TWO || CIN) ? ra : ra + 1;
     const bool ha = on && ra < nrows, hb = on && rb < nrows;
+    const CT* __restrict__ sc_in = reinterpret_cast<const CT*>(p.in) + (size_t)(ha ? ra : 0) * N;  // (complex input)
     const T* __restrict__ sa = reinterpret_cast<const T*>(p.in) + (size_t)(ha ? ra : 0) * N;
     const T* __restrict__ sb = reinterpret_cast<const T*>(TWO ? p.in_b : p.in) + (size_t)(hb ? rb : 0) * N;
     const T* __restrict__ wx = reinterpret_cast<const T*>(p.win_x);
@@ -519,7 +542,8 @@ __global__ void __launch_bounds__((MGeom<T, N>::THR), (MGeom<T, N>::WPS)) fastm_
 #pragma unroll
     for (int q = 0; q < R0; ++q) {
         const int x = j + q * M0;
-        a[q] = mk<T>(ha ? sa[x] : (T)0, hb ? sb[x] : (T)0);
+        if (CIN) a[q] = ha ? sc_in[x] : mk<T>((T)0, (T)0);
+        else a[q] = mk<T>(ha ? sa[x] : (T)0, hb ? sb[x] : (T)0);
         wv[q] = wx[x];
     }
     constexpr double XBAR = 0.5 * (N - 1);
@@ -568,10 +592,11 @@ __global__ void __launch_bounds__((MGeom<T, N>::THR), (MGeom<T, N>::WPS)) fastm_
         const int t = e / W, k = e - t * W;
         const long long row = row0 + t;
         if (row >= nrows) break;  // (t grows with e)
-        const CT* z = lds + (TWO ? t : (t >> 1)) * STR;
+        const CT* z = lds + ((TWO || CIN) ? t : (t >> 1)) * STR;
         const CT zk = z[M::pn(k)], zc = cconj(z[M::pn(k == 0 ? 0 : N - k)]);
         CT o;
-        if (TWO) o = cmulc(cscale(zk + zc, (T)0.5), cscale(mul_mi(zk - zc), (T)0.5));  // F0 conj(F1) of this row (xrft.py:825)
+        if (CIN) o = zk;
+        else if (TWO) o = cmulc(cscale(zk + zc, (T)0.5), cscale(mul_mi(zk - zc), (T)0.5));  // F0 conj(F1) of this row (xrft.py:825)
         else o = (t & 1) ? cscale(mul_mi(zk - zc), (T)0.5) : cscale(zk + zc, (T)0.5);
         int oc = k + p.shift_x; if (oc >= N) oc -= N;  // (half output: shift_x = 0)
         const T f = (p.realdim2 && k != 0 && 2 * k != N) ? sc * (T)2 : sc;

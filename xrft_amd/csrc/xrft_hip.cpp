@@ -1471,7 +1471,8 @@ static int run_fastmy(const xrfthip_plan* P, const void* in, const void* in1, vo
     p.ph_y = P->fph[0].p; p.ph_on = P->fph_on ? 1 : 0;
     p.ny = (int)d.ny; p.nx = (int)d.nx;
     p.detrend = d.detrend; p.nslab = (int)d.batch;
-    p.nunits = (int)(d.batch * (d.nx / (two ? C.g : 2 * C.g)));
+    p.cin = P->cplx_in ? 1 : 0;
+    p.nunits = (int)(d.batch * (d.nx / ((two || P->cplx_in) ? C.g : 2 * C.g)));
     p.shift_y = (d.flags & XRFTHIP_SHIFT_Y) ? (int)(d.ny / 2) : 0;
     p.scale = d.scale;
     xrfthip_plan::ProfRec* rec = prof_begin(P, "fastm_yonly", st);
@@ -1516,7 +1517,8 @@ static int run_fastmx(const xrfthip_plan* P, const void* in, const void* in1, vo
     p.shift_x = (d.flags & XRFTHIP_SHIFT_X) ? (int)(d.nx / 2) : 0;
     p.scale = d.scale;
     xrfthip_plan::ProfRec* rec = prof_begin(P, "fastm_xonly", st);
-    const int rpw = two ? C.g : 2 * C.g;
+    p.cin = P->cplx_in ? 1 : 0;
+    const int rpw = (two || P->cplx_in) ? C.g : 2 * C.g;
     const dim3 grid((unsigned)((d.batch + rpw - 1) / rpw)), blk((unsigned)C.thr);
 #define MXL_(TT, NN, MM) do { auto k = &fastm_xonly_kernel<TT, NN, MM>; XRFT_LAUNCH(k, grid, blk, C.lds_cols, st, p); } while (0)
 #define MX_(TT, NN) do { \
@@ -1767,10 +1769,10 @@ int xrfthip_plan_create(xrfthip_plan** plan, const xrfthip_desc* desc) {
     {   // one transform axis that is not the contiguous one, real input: pass 1 of the same kernels is the whole transform
         const bool two = d.out_mode == XRFTHIP_OUT_CROSS || d.out_mode == XRFTHIP_OUT_PHASE;
         const uint32_t allowed = XRFTHIP_AXIS_Y | XRFTHIP_SHIFT_Y | (d.out_mode != XRFTHIP_OUT_POWER ? XRFTHIP_ISHIFT_Y : 0u);
-        P->fastmy = (d.flags & XRFTHIP_AXIS_Y) && d.ndim == 2 && !cplx_in && (d.dtype == XRFTHIP_F64 || d.dtype == XRFTHIP_F32) &&
+        P->fastmy = (d.flags & XRFTHIP_AXIS_Y) && d.ndim == 2 && (!cplx_in || !two) &&
                     (d.out_mode == XRFTHIP_OUT_COMPLEX || d.out_mode == XRFTHIP_OUT_POWER || two) && !(d.flags & ~allowed) && fastmy_len(d.ny, P->dbl) &&
                     d.batch * d.nx < (1LL << 30) && !env_ll("XRFTHIP_NO_FAST", 0) && env_ll("XRFTHIP_FASTM", 1) != 0;
-        if (P->fastmy && d.nx % ((two ? 1 : 2) * mygeom(d.ny, P->dbl).g) != 0) P->fastmy = false;
+        if (P->fastmy && d.nx % (((two || cplx_in) ? 1 : 2) * mygeom(d.ny, P->dbl).g) != 0) P->fastmy = false;
         if (P->fastmy) {
             int rcm = P->dbl ? build_twiddle<double>(P->tw_fy, d.ny, d.ny) : build_twiddle<float>(P->tw_fy, d.ny, d.ny);
             std::vector<double> ones((size_t)d.ny, 1.0);
@@ -1782,7 +1784,7 @@ int xrfthip_plan_create(xrfthip_plan** plan, const xrfthip_desc* desc) {
     {   // one short transform axis, the contiguous one, real input: rows packed in pairs through the same three passes
         const bool two = d.out_mode == XRFTHIP_OUT_CROSS || d.out_mode == XRFTHIP_OUT_PHASE;
         const uint32_t allowed = XRFTHIP_SHIFT_X | XRFTHIP_HALF_X | (d.out_mode != XRFTHIP_OUT_PHASE ? XRFTHIP_REALDIM_X2 : 0u) | (d.out_mode != XRFTHIP_OUT_POWER ? XRFTHIP_ISHIFT_X : 0u);
-        P->fastmx = d.ndim == 1 && !cplx_in && (d.dtype == XRFTHIP_F64 || d.dtype == XRFTHIP_F32) && (d.out_mode == XRFTHIP_OUT_COMPLEX || d.out_mode == XRFTHIP_OUT_POWER || two) &&
+        P->fastmx = d.ndim == 1 && (!cplx_in || (!two && !(d.flags & (XRFTHIP_HALF_X | XRFTHIP_REALDIM_X2)))) && (d.out_mode == XRFTHIP_OUT_COMPLEX || d.out_mode == XRFTHIP_OUT_POWER || two) &&
                     !(d.flags & ~allowed) && !((d.flags & XRFTHIP_HALF_X) && (d.flags & XRFTHIP_SHIFT_X)) && !((d.flags & XRFTHIP_REALDIM_X2) && !(d.flags & XRFTHIP_HALF_X)) &&
                     fastmx_len(d.nx, P->dbl) && d.batch < (1LL << 31) - 16 && !env_ll("XRFTHIP_NO_FAST", 0) && env_ll("XRFTHIP_FASTM", 1) != 0;
         if (P->fastmx) {
