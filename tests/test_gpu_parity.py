@@ -746,6 +746,25 @@ def test_short_contiguous_axis_fast_kernel(shape, dtype):
     cases.run_xonly_fast_cases(shape, dtype)
 
 
+def test_one_axis_kernel_slab_beyond_4GB():
+    """A (time, space) array whose ONE slab is 4.6 GB (the axis is the first one, everything behind it is the row): the one-pass
+    kernel addresses it with 64-bit offsets.  power_spectrum along time, linear detrend + Hann; the oracle on three blocks of columns."""
+    import xrft_amd as xa
+
+    ny, nx = 1024, 1_120_000
+    g = torch.Generator(device="cuda").manual_seed(77)
+    x = torch.randn((ny, nx), dtype=torch.float32, device="cuda", generator=g)
+    x += (0.01 * torch.arange(ny, device="cuda", dtype=torch.float32))[:, None]
+    c = {"time": np.arange(ny) * 0.5, "x": np.arange(nx) * 1.0}
+    ps = xa.power_spectrum(xa.DataArray(x, ("time", "x"), c), dim=["time"], detrend="linear", window="hann")
+    assert "[fastm y-only]" in next(reversed(xa.api._plan_cache.values())).describe()
+    for lo in (0, nx // 2 + 3, nx - 64):
+        sub = x[:, lo:lo + 64].cpu().numpy()
+        ref = o.power_spectrum(o.OArr(sub, ("time", "x"), {"time": c["time"], "x": c["x"][lo:lo + 64]}), dim=["time"], detrend="linear", window="hann")
+        got = ps.data[:, lo:lo + 64].cpu().numpy()
+        assert np.abs(got - ref.values).max() / np.abs(ref.values).max() < 3e-4, lo
+
+
 def test_radial_sums_any_nbins_and_bit_identical_repeats():
     """Stand-alone and generic-plan radial sums: more than 4096 bins (also through xrft.isotropize, nfactor = 1 on 4400^2), values
     vs numpy / the oracle, repeats bit for bit."""

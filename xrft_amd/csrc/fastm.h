@@ -403,7 +403,8 @@ __global__ void __launch_bounds__((MGeom<T, NY>::THR), (MGeom<T, NY>::WPS)) fast
     const size_t esz = CIN ? sizeof(CT) : sizeof(T);  // bytes per input element
     const char* __restrict__ src = reinterpret_cast<const char*>(p.in) + ((size_t)slab * NY * p.nx + (size_t)xb * CW) * esz;
     const char* __restrict__ srcb = reinterpret_cast<const char*>(TWO ? p.in_b : p.in) + ((size_t)slab * NY * p.nx + (size_t)xb * CW) * esz;
-    const unsigned rowb = (unsigned)p.nx * (unsigned)esz, off0 = (unsigned)j * rowb + (unsigned)g * (unsigned)(TWO ? sizeof(T) : sizeof(CT)), rstep = (unsigned)M0 * rowb;
+    // (64-bit offsets: nx is everything behind the axis -- a (time, y, x) cube is ONE slab of ny * nx elements, far beyond 4 GB)
+    const size_t rowb = (size_t)p.nx * esz, off0 = (size_t)j * rowb + (size_t)g * (TWO ? sizeof(T) : sizeof(CT)), rstep = (size_t)M0 * rowb;
     const T* __restrict__ wy = reinterpret_cast<const T*>(p.win_y);
     CT a[R0];
     T wyv[R0];
@@ -411,8 +412,8 @@ __global__ void __launch_bounds__((MGeom<T, NY>::THR), (MGeom<T, NY>::WPS)) fast
     for (int q = 0; q < R0; ++q) {
         a[q] = mk<T>((T)0, (T)0); wyv[q] = (T)0;
         if (on) {
-            if (TWO) a[q] = mk<T>(*reinterpret_cast<const T*>(src + (off0 + rstep * (unsigned)q)), *reinterpret_cast<const T*>(srcb + (off0 + rstep * (unsigned)q)));
-            else a[q] = *reinterpret_cast<const CT*>(src + (off0 + rstep * (unsigned)q));
+            if (TWO) a[q] = mk<T>(*reinterpret_cast<const T*>(src + (off0 + rstep * (size_t)q)), *reinterpret_cast<const T*>(srcb + (off0 + rstep * (size_t)q)));
+            else a[q] = *reinterpret_cast<const CT*>(src + (off0 + rstep * (size_t)q));
             wyv[q] = wy[j + q * M0];
         }
     }
