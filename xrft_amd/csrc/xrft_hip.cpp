@@ -972,11 +972,11 @@ static int run_moments(const xrfthip_plan* P, const void* in, long long g0, long
         xrfthip_plan::ProfRec* recc = prof_begin(P, "column_fit", st);
         for (long long b0 = 0; b0 < gc; b0 += 32768) {
             const long long bc = std::min<long long>(32768, gc - b0);
-            const dim3 grid((unsigned)((d.nx + 255) / 256), (unsigned)bc), block(256);
+            const dim3 grid((unsigned)((d.nx + 63) / 64), (unsigned)bc), block(256);  // (64 columns x 4 row parts per workgroup)
             const void* src = (const char*)in + (size_t)(g0 + b0) * total * esz;
             double* cdst = coef + (g0 + b0) * d.nx * 6;
-            if (P->cplx_in) { auto k = &column_fit_kernel<T, true>; XRFT_LAUNCH(k, grid, block, 0, st, src, (long long)d.ny, (long long)d.nx, cdst, (int)d.detrend); }
-            else { auto k = &column_fit_kernel<T, false>; XRFT_LAUNCH(k, grid, block, 0, st, src, (long long)d.ny, (long long)d.nx, cdst, (int)d.detrend); }
+            if (P->cplx_in) { auto k = &column_fit_kernel<T, true>; XRFT_LAUNCH(k, grid, block, 4 * 4 * 64 * sizeof(double), st, src, (long long)d.ny, (long long)d.nx, cdst, (int)d.detrend); }
+            else { auto k = &column_fit_kernel<T, false>; XRFT_LAUNCH(k, grid, block, 4 * 4 * 64 * sizeof(double), st, src, (long long)d.ny, (long long)d.nx, cdst, (int)d.detrend); }
         }
         prof_end(recc, st);
         HIP_TRY(hipGetLastError());
