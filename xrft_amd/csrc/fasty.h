@@ -398,9 +398,13 @@ __global__ void __launch_bounds__((YRows<NX, FS>::THR), (YRows<NX, FS>::THR / 12
     unsigned long long* acc = reinterpret_cast<unsigned long long*>(lds);          // [nbins][HW] int64 fixed-point sums
     unsigned* bmax = reinterpret_cast<unsigned*>(acc + (ISO ? p.nbins * HW : 0));  // [nbins] float bits of the largest magnitude
     fill_tw2<NX>(tw2, p.tw_x, tid, THR);
-    const int upr = p.nrow_pad / RPU;  // units per slab
-    const int slab = blockIdx.x / upr, unit = blockIdx.x % upr, ky0 = unit * RPU;
     const int nyh = p.ny >> 1;
+    // FS: rows 0 .. ny/2 - 1 fill whole units; the Nyquist rows (k1 = ny/2) of GX consecutive slabs share one extra unit (transform A
+    // of group g = slab s0 + g; B idles) instead of a fifth unit per slab with one live row in 32 (dft (1024, 65536): +12 %)
+    const int upr = FS ? nyh / RPU : p.nrow_pad / RPU;  // units per slab
+    const bool nyq = FS && (int)blockIdx.x >= p.nslab * upr;
+    const int s0 = nyq ? ((int)blockIdx.x - p.nslab * upr) * GX : 0;
+    const int slab = nyq ? min(s0 + g, p.nslab - 1) : (int)blockIdx.x / upr, unit = nyq ? 0 : (int)blockIdx.x % upr, ky0 = nyq ? nyh : unit * RPU;
     // rows beyond ny/2 (padding of the last unit) are computed on row ny/2's data and never stored or binned
     const int kyA = min(ky0 + g, nyh), kyB = TWO ? kyA : min(ky0 + GX + g, nyh);
     // uniform 64-bit bases + 32-bit per-lane byte offsets (scalar-base loads).  The residual-trend pairs go first: 16 loads
@@ -528,14 +532,14 @@ __global__ void __launch_bounds__((YRows<NX, FS>::THR), (YRows<NX, FS>::THR / 12
             }
         __syncthreads();
         if (FS) {  // sample k = k1 + ny k2 (fftshift: k2 + nx/2): the unit's RPU rows are consecutive samples
-            float* __restrict__ o1 = reinterpret_cast<float*>(p.out) + (size_t)slab * p.ny * NX;
+            float* __restrict__ ob = reinterpret_cast<float*>(p.out);
             for (int e = tid; e < RPU * NX * 2; e += THR) {
                 const int r = e % RPU, rest = e / RPU, mir = rest & 1, k2 = rest >> 1;
-                const int k1 = ky0 + r;
-                if (k1 > nyh || (mir && (k1 == 0 || k1 == nyh))) continue;
+                const int k1 = nyq ? nyh : ky0 + r;
+                if (nyq ? (r >= GX || s0 + r >= p.nslab || mir) : (mir && k1 == 0)) continue;  // (Nyquist unit: row r = slab s0 + r)
                 const float v = stg[r * RSP + nat16(k2)];
                 const int o1k = mir ? p.ny - k1 : k1, o2k = mir ? (NX - 1 - k2) : k2;  // X[N - k]: (ny - k1) + ny (nx - 1 - k2)
-                o1[(size_t)((o2k + sx) & mx) * p.ny + o1k] = v;
+                ob[(size_t)(nyq ? s0 + r : slab) * p.ny * NX + (size_t)((o2k + sx) & mx) * p.ny + o1k] = v;
             }
         } else if (p.half) {  // rows of nx/2 + 1 samples (an odd length: 4-byte stores, still whole lines per wave); row -ky reads the row backwards
             constexpr int W = NX / 2 + 1;
@@ -591,16 +595,16 @@ __global__ void __launch_bounds__((YRows<NX, FS>::THR), (YRows<NX, FS>::THR / 12
                     cstg[g * RSC + nat16(held_k<NX>(u, bb, k3))] = cscale(round ? b[bb * G::R3 + k3] : a[bb * G::R3 + k3], sc);
             __syncthreads();
             if (FS) {  // transposed: sample k = k1 + ny k2; the true-phase table is indexed by the unshifted sample index
-                cf* __restrict__ o1 = reinterpret_cast<cf*>(p.out) + (size_t)slab * p.ny * NX;
+                cf* __restrict__ ob = reinterpret_cast<cf*>(p.out);
                 for (int e = tid; e < GX * NX * 2; e += THR) {
                     const int r = e % GX, rest = e / GX, mir = rest & 1, k2 = rest >> 1;
-                    const int k1 = ky0 + round * GX + r;
-                    if (k1 > nyh || (mir && (k1 == 0 || k1 == nyh))) continue;
+                    const int k1 = nyq ? nyh : ky0 + round * GX + r;
+                    if (nyq ? (round != 0 || s0 + r >= p.nslab || mir) : (mir && k1 == 0)) continue;  // (Nyquist unit: row r = slab s0 + r, transform A only)
                     cf v = cstg[r * RSC + nat16(k2)];
                     if (mir) v = cconj(v);
                     const int o1k = mir ? p.ny - k1 : k1, o2k = mir ? (NX - 1 - k2) : k2;
                     if (p.ph_on) v = cmul(v, p.ph_x[o2k * p.ny + o1k]);
-                    o1[(size_t)((o2k + sx) & mx) * p.ny + o1k] = v;
+                    ob[(size_t)(nyq ? s0 + r : slab) * p.ny * NX + (size_t)((o2k + sx) & mx) * p.ny + o1k] = v;
                 }
                 continue;
             }

@@ -1168,7 +1168,8 @@ static void fasty_launch_rows(const xrfthip_plan* P, const FastY& p, long long g
     const bool two = d.out_mode == XRFTHIP_OUT_CROSS || d.out_mode == XRFTHIP_OUT_PHASE;
     xrfthip_plan::ProfRec* rec = prof ? prof_begin(P, "fasty_rows", st) : nullptr;
     const int rpu = two ? R.gxy : R.rk;  // a cross spectrum spends both transforms of a thread on one row (field 0, field 1)
-    const dim3 grid((unsigned)(gc * (P->y_nrow_pad / rpu))), blk((unsigned)R.thr);
+    // (four-step: rows 0 .. ny/2 - 1 in whole units, the Nyquist rows of R.gxy consecutive slabs in one extra unit each)
+    const dim3 grid((unsigned)(P->fast1d ? gc * ((P->yny / 2) / rpu) + (gc + R.gxy - 1) / R.gxy : gc * (P->y_nrow_pad / rpu))), blk((unsigned)R.thr);
     const int hw = d.out_mode == XRFTHIP_OUT_CROSS ? 2 : 1;
     const size_t lds = R.lds;  // (the radial-sum tables alias the transforms' LDS)
 #define YR_(NN) do { \
