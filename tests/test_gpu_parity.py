@@ -521,6 +521,13 @@ def test_random_fastm_differential(seed):
     run_random_fastm(seed, dtype="float64" if seed % 3 else "float32")
 
 
+@pytest.mark.parametrize("seed", range(60))
+def test_random_one_axis_differential(seed):
+    from test_random_differential import run_random_one_axis
+
+    run_random_one_axis(seed)
+
+
 def test_concurrent_threads_and_streams():
     """Four host threads, each on its own HIP stream, share one cached plan (a workspace per stream, one enqueue at a time)."""
     import threading

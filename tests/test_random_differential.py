@@ -202,3 +202,52 @@ def run_random_fastm(seed, lengths=(180, 240, 360, 480, 720, 960, 1440), dtype="
 @pytest.mark.parametrize("seed", range(int(os.environ.get("XRFT_RANDOM_FASTM_CASES", "12"))))
 def test_random_fastm_case(seed):
     run_random_fastm(seed, lengths=(360,), dtype="float64" if seed % 2 == 0 else "float32")
+
+
+_ONE_AXIS_LENGTHS = (100, 128, 180, 200, 240, 256, 360, 400, 480, 500, 512, 600, 720, 800, 960, 1000, 1024, 1200, 1440, 2048, 4096)
+
+
+def run_random_one_axis(seed):
+    """Random one-axis calls on the lengths of the fastm table (csrc/fastm.h: fastm_yonly_kernel / fastm_xonly_kernel): which axis,
+    batch and inner sizes (odd ones fall back to the generic kernels), precision, real / complex input, fft / power spectrum /
+    cross spectrum / real_dim, detrend, window, shift, true phase -- whatever kernel serves the call, the oracle's numbers."""
+    import xrft_amd as xa
+
+    rng = np.random.default_rng(9000 + seed)
+    n = int(rng.choice(_ONE_AXIS_LENGTHS))
+    dtype = str(rng.choice(["float64", "float32"]))
+    last = bool(rng.random() < 0.4)  # the transform axis is the contiguous one
+    nb = int(rng.integers(1, 6))
+    inner = int(rng.choice([8, 16, 24, 40, 7, 12])) if not last else 1
+    shape = (nb, int(rng.integers(1, 5)), n) if last else (nb, n, inner)
+    dims = ("t", "y", "x")
+    ax = "x" if last else "y"
+    v = rng.standard_normal(shape) + 1.5 + 2.0 * np.arange(n).reshape((1, 1, n) if last else (1, n, 1)) / n
+    cplx = bool(rng.random() < 0.2)
+    if cplx:
+        v = v + 1j * rng.standard_normal(shape)
+    v = v.astype(("complex128" if dtype == "float64" else "complex64") if cplx else dtype)
+    c = {"t": np.arange(shape[0]), "y": np.arange(shape[1]) * 0.5 + float(rng.choice([0.0, 3.0])), "x": np.arange(shape[2]) * 0.25 - float(rng.choice([0.0, 2.0]))}
+    da, od = cases.pair(v, dims, c)
+    kw = dict(detrend=rng.choice([None, "constant", "linear"]), window=rng.choice([None, "hann", "hamming"]))
+    kind = str(rng.choice(["fft", "ps", "cs", "ps_real"] if not cplx else ["fft", "ps"]))
+    shift = bool(rng.random() < 0.7)
+    tp = bool(rng.random() < 0.5)
+    api._plan_cache.clear()
+    if kind == "fft":
+        got, ref = xa.fft(da, dim=[ax], shift=shift, true_phase=tp, **kw), o.fft(od, dim=[ax], shift=shift, true_phase=tp, **kw)
+    elif kind == "ps":
+        got, ref = xa.power_spectrum(da, dim=[ax], shift=shift, **kw), o.power_spectrum(od, dim=[ax], shift=shift, **kw)
+    elif kind == "cs":
+        w = rng.standard_normal(shape).astype(dtype)
+        db, ob = cases.pair(w, dims, c)
+        got, ref = xa.cross_spectrum(da, db, dim=[ax], shift=shift, true_phase=tp, **kw), o.cross_spectrum(od, ob, dim=[ax], shift=shift, true_phase=tp, **kw)
+    else:
+        got, ref = xa.power_spectrum(da, dim=[ax], real_dim=ax, **kw), o.power_spectrum(od, dim=[ax], real_dim=ax, **kw)
+    cases.check(got, ref, 1e-10 if dtype == "float64" else 3e-4)
+    return any("[fastm " in p.describe() for p in api._plan_cache.values())
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("XRFT_RANDOM_ONE_AXIS_CASES", "16"))))
+def test_random_one_axis_case(seed):
+    run_random_one_axis(seed)
