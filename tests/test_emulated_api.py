@@ -414,7 +414,8 @@ def test_radial_sums_any_nbins_and_bit_identical_repeats():
 
 @pytest.mark.parametrize("shape,dtype", [((3, 360, 40), "float64"), ((2, 256, 24), "float32"), ((2, 1024, 16), "float64"), ((1, 2048, 8), "float32"),
                                          ((2, 1440, 8), "float64"), ((2, 240, 32), "float32"), ((3, 100, 16), "float64"), ((2, 1000, 8), "float32"),
-                                         ((2, 128, 40), "float32"), ((2, 1200, 8), "float64"), ((2, 500, 24), "float64"), ((2, 800, 16), "float32")])
+                                         ((2, 128, 40), "float32"), ((2, 1200, 8), "float64"), ((2, 500, 24), "float64"), ((2, 800, 16), "float32"),
+                                         ((1, 4096, 8), "float32"), ((1, 2048, 4), "float64")])
 def test_one_axis_not_contiguous_fast_kernel(shape, dtype):
     """fastm_yonly_kernel (csrc/fastm.h): fft / power_spectrum along a middle or first axis, in place in memory order."""
     cases.run_yonly_fast_cases(shape, dtype)

@@ -739,7 +739,8 @@ def test_fastm_latlon_lengths(shape, cross, dtype):
 @pytest.mark.parametrize("shape,dtype", [((5, 360, 256), "float64"), ((3, 256, 512), "float32"), ((2, 1024, 2048), "float64"), ((2, 2048, 1024), "float32"),
                                          ((3, 1440, 64), "float64"), ((4, 240, 96), "float32"), ((2, 960, 128), "float32"), ((2, 512, 264), "float64"),
                                          ((3, 100, 64), "float64"), ((2, 1000, 256), "float32"), ((2, 128, 136), "float32"), ((2, 1200, 64), "float64"),
-                                         ((2, 200, 40), "float32"), ((2, 400, 48), "float64"), ((2, 500, 72), "float32"), ((2, 600, 88), "float64"), ((2, 800, 16), "float32")])
+                                         ((2, 200, 40), "float32"), ((2, 400, 48), "float64"), ((2, 500, 72), "float32"), ((2, 600, 88), "float64"), ((2, 800, 16), "float32"),
+                                         ((2, 4096, 64), "float32"), ((2, 2048, 36), "float64"), ((1, 4096, 12), "float64")])
 def test_one_axis_not_contiguous_fast_kernel(shape, dtype):
     """fastm_yonly_kernel (csrc/fastm.h): fft / power_spectrum along a middle or first axis, in place in memory order."""
     cases.run_yonly_fast_cases(shape, dtype)

@@ -59,7 +59,9 @@ constexpr int mr_max3(int a, int b, int c) { return a > b ? (a > c ? a : c) : (b
 // LDS geometry of one N-point sequence.  Positions during the passes: pd(i) = i + i / PDQ (the last pass reads runs of R2
 // with a lane stride of R2: padded to an odd stride), natural-order result: pn(k) = k + k / PNQ (the last pass writes with a
 // lane stride of R0).  STR = 4 (mod 8) elements: the two rows / two sequences that eight lanes touch land on disjoint banks.
-template <typename T, int N> struct MGeom {
+// (GOV > 0 overrides the number of sequences per workgroup: the y-only kernel at 4096 / 2048 points needs two -- four columns --
+// whatever the LDS they take)
+template <typename T, int N, int GOV = 0> struct MGeom {
     typedef MRad<N> R;
     static_assert(R::R0 > 0, "length not in the table");
     static constexpr int R0 = R::R0, R1 = R::R1, R2 = R::R2;
@@ -76,7 +78,8 @@ template <typename T, int N> struct MGeom {
 #define XRFT_M_LDSCAP (52 * 1024)
 #endif
     // (at most 4: 8 columns per workgroup divide every length of the table; and at most 640 threads: one butterfly per thread and pass)
-    static constexpr int G = ((size_t)4 * STR * CS <= XRFT_M_LDSCAP && 4 * BMAX <= 640) ? 4 : (size_t)2 * STR * CS <= XRFT_M_LDSCAP ? 2 : 1;
+    static constexpr int G0 = ((size_t)4 * STR * CS <= XRFT_M_LDSCAP && 4 * BMAX <= 640) ? 4 : (size_t)2 * STR * CS <= XRFT_M_LDSCAP ? 2 : 1;
+    static constexpr int G = GOV > 0 ? GOV : G0;
     static constexpr int THR = ((G * BMAX + 63) / 64) * 64;
     static constexpr size_t LDS_ROWS = ((size_t)G * STR + M0) * CS;                                    // sequences + pass-1 twiddles
     static constexpr size_t LDS = LDS_ROWS + (size_t)(THR / 64) * G * 4 * sizeof(double);              // + pass 1's partial column sums
@@ -378,9 +381,12 @@ __global__ void __launch_bounds__((MGeom<T, NY>::THR), (MGeom<T, NY>::WPS)) fast
 // ------------------------------------------------------------------------------------------------
 // (MODE 0 complex, 1 power, 2 two fields: cross spectrum, or its phase with p.angle; the detrend is a run-time switch: fewer
 // instantiations -- 20 lengths x 2 precisions x 3 modes)
+// (a workgroup needs at least two sequences = four real columns here: 4096 points, and 2048 in float64, get them by override)
+template <typename T, int NY> struct MYGeom { typedef MGeom<T, NY, (MGeom<T, NY>::G0 < 2 ? 2 : 0)> type; };
+
 template <typename T, int NY, int MODE>
-__global__ void __launch_bounds__((MGeom<T, NY>::THR), (MGeom<T, NY>::WPS)) fastm_yonly_kernel(FastM p) {
-    typedef MGeom<T, NY> M;
+__global__ void __launch_bounds__((MYGeom<T, NY>::type::THR), (MYGeom<T, NY>::type::WPS)) fastm_yonly_kernel(FastM p) {
+    typedef typename MYGeom<T, NY>::type M;
     typedef C2<T> CT;
     constexpr bool TWO = MODE >= 2;
     const bool DET = p.detrend != 0;  // cross spectrum / cross phase: column c of field 0 and of field 1 are the two halves of sequence c

@@ -765,6 +765,11 @@ void set_kernel_attrs_once() {
     done = true;
     const int m = (int)kLdsMax;
     // (the one fastm instantiation above 64 KB of dynamic LDS: 4096-point float64 rows, one pair per workgroup)
+#define YA_(TT, NN) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&fastm_yonly_kernel<TT, NN, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, m); \
+                    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&fastm_yonly_kernel<TT, NN, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, m); \
+                    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&fastm_yonly_kernel<TT, NN, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, m)
+    YA_(float, 4096); YA_(double, 2048); YA_(double, 4096);
+#undef YA_
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&fastm_xonly_kernel<double, 4096, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, m);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&fastm_xonly_kernel<double, 4096, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, m);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&fastm_xonly_kernel<double, 4096, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, m);
@@ -1446,9 +1451,15 @@ static bool fastmy_len(long long n, bool dbl) {
 #define X_(NN) if (n == NN) return true;
     XRFT_M_LATLON(X_) XRFT_M_POW2(X_) XRFT_M_YONLY(X_)
 #undef X_
-    return !dbl && n == 2048;
+    return n == 2048 || n == 4096;
+}
+template <typename T, int N> static MGeomRt mygeom_t() {  // (the y-only kernel's own geometry: at least two sequences per workgroup)
+    typedef typename MYGeom<T, N>::type M;
+    return {M::THR, M::G, M::LDS, M::LDS_ROWS, M::R0, M::R1, M::R2, 0, 0, 0};
 }
 static MGeomRt mygeom(long long n, bool dbl) {
+    if (n == 4096) return dbl ? mygeom_t<double, 4096>() : mygeom_t<float, 4096>();
+    if (n == 2048 && dbl) return mygeom_t<double, 2048>();
     if (!dbl) {
 #define X_(NN) if (n == NN) return mgeom_t<float, NN>();
         XRFT_M_POW2(X_) XRFT_M_YONLY(X_) X_(2048)
@@ -1483,7 +1494,7 @@ static int run_fastmy(const xrfthip_plan* P, const void* in, const void* in1, vo
         if (d.out_mode == XRFTHIP_OUT_POWER) MYL_(TT, NN, 1); else if (two) MYL_(TT, NN, 2); else MYL_(TT, NN, 0); } while (0)
 #define XD_(NN) if (d.ny == NN) MY_(double, NN);
 #define XF_(NN) if (d.ny == NN) MY_(float, NN);
-    if (P->dbl) { XRFT_M_LATLON(XD_) XRFT_M_POW2(XD_) XRFT_M_YONLY(XD_) } else { XRFT_M_LATLON(XF_) XRFT_M_POW2(XF_) XRFT_M_YONLY(XF_) XF_(2048) }
+    if (P->dbl) { XRFT_M_LATLON(XD_) XRFT_M_POW2(XD_) XRFT_M_YONLY(XD_) XD_(2048) XD_(4096) } else { XRFT_M_LATLON(XF_) XRFT_M_POW2(XF_) XRFT_M_YONLY(XF_) XF_(2048) XF_(4096) }
 #undef XD_
 #undef XF_
 #undef MY_
@@ -1495,7 +1506,7 @@ static int run_fastmy(const xrfthip_plan* P, const void* in, const void* in1, vo
 
 // one transform axis, the contiguous one, short rows: rows packed in pairs (fastm_xonly_kernel).  Rows are contiguous whatever the
 // number of sequences per workgroup, so the lengths that leave room for one pair only (4096; 2048 in float64) are taken too.
-static bool fastmx_len(long long n, bool dbl) { return fastmy_len(n, dbl) || n == 4096 || (dbl && n == 2048); }
+static bool fastmx_len(long long n, bool dbl) { return fastmy_len(n, dbl); }
 static MGeomRt mxgeom(long long n, bool dbl) {
     if (n == 4096) return dbl ? mgeom_t<double, 4096>() : mgeom_t<float, 4096>();
     if (dbl && n == 2048) return mgeom_t<double, 2048>();
