@@ -1,18 +1,25 @@
-// fastm.h -- the two-pass "y first" pipeline (fasty.h) for slabs whose two lengths are products of three small radices
-// (2^a 3^b 5^c: 180 ... 1440 -- the regular lat/lon grids -- in float64 and float32; 256 / 512 / 1024 in float64): BASELINE.json configs[4] is
-// power_spectrum of (64, 1440, 720) float64 slabs with a linear detrend and a Hann window.
-//     pass 1  fastm_cols_kernel   FFT along y of the real columns (window fused), half spectra ky = 0..ny/2, exact column sums
-//     [fit]   fastm_fit_kernel    plane from the per-column sums (xrft/detrend.py:100-113)
-//     pass 2  fastm_rows_kernel   trend added back in the spectral domain, FFT along x of rows ky = 0..ny/2, result rows ky AND -ky
-// (xrft.power_spectrum / fft / cross_spectrum / cross_phase, reference xrft/xrft.py:307-476, 685-874.)
+// fastm.h -- transforms whose length is a product of three small radices, held in LDS: the float64 / float32 kernels beside the
+// register-resident float32 power-of-two ones of fasty.h.
+//
+// (1) The two-pass "y first" pipeline (fasty.h) for real slabs whose two lengths are in the table -- the regular lat/lon grids
+//     180 ... 1440 in both precisions, 256 / 512 / 1024 in float64.  BASELINE.json configs[4] is power_spectrum of
+//     (64, 1440, 720) float64 slabs with a linear detrend and a Hann window.
+//       pass 1  fastm_cols_kernel   FFT along y of the real columns (window fused), half spectra ky = 0..ny/2, exact column sums
+//       [fit]   fastm_fit_kernel    plane from the per-column sums (xrft/detrend.py:100-113)
+//       pass 2  fastm_rows_kernel   trend added back in the spectral domain, FFT along x of rows ky = 0..ny/2, result rows ky AND -ky;
+//                                   power / complex / cross spectrum / cross phase, full or half (real_dim) rows, radial sums
+//     (xrft.power_spectrum / fft / cross_spectrum / cross_phase / isotropic_*, reference xrft/xrft.py:307-476, 685-1187.)
+// (2) ONE transform axis in ONE pass: fastm_yonly_kernel (an axis that is not the contiguous one: XRFTHIP_AXIS_Y) and
+//     fastm_xonly_kernel (short contiguous rows, packed in pairs), real or complex input, one or two fields, with the
+//     reference's per-sequence detrend done inside the workgroup.
 //
 // Same plan as fasty.h -- the last pass owns whole result rows, fftshift is a rotation, the Hermitian mirror a reversed read
-// of a row that is in LDS, detrending costs no pass over the data -- but the transforms are not register-resident: a
-// workgroup stages G sequences in LDS with wide coalesced loads (every load of a thread in flight before the first LDS
-// store), runs three in-place decimation-in-frequency passes with compile-time radices R0 x R1 x R2 (one butterfly per
-// thread and pass: no loops, no index tables), the last of which leaves the spectrum in natural order, and streams the
-// result out of LDS.  The generic tile kernel (tile_fft.h) does the same with run-time geometry; at (1440, 720) float64 it
-// ran 2.5x above the memory floor of both passes with its waves parked half of the time (profiles/r02_pmc_generic_c5_summary.txt).
+// of a row that is in LDS, detrending costs no pass over the data -- but the transforms are not register-resident: the first
+// pass runs on operands loaded straight from global memory (every load of a thread in flight at once), then two more in-place
+// decimation-in-frequency passes through LDS with compile-time radices R0 x R1 x R2 (one butterfly per thread and pass: no
+// loops, no index tables), the last of which leaves the spectrum in natural order, and the result streams out of LDS.
+// The generic tile kernel (tile_fft.h) does the same with run-time geometry; at (1440, 720) float64 it ran 2.5x above the
+// memory floor of both passes with its waves parked half of the time (profiles/r02_pmc_generic_c5_summary.txt).
 //
 // Intermediate W2 (complex T): [slab][ky / RK][x / CW][ky % RK][CW], CW = 2 G columns of one pass-1 workgroup, RK rows per
 // 128-byte line; pass 1 writes whole lines, pass 2 reads RPU (a multiple of RK) consecutive ky = one contiguous block.
@@ -36,8 +43,8 @@ XRFT_MRAD(1440, 10, 12, 12);
 XRFT_MRAD(256, 4, 8, 8);   // (powers of two: float64 only -- float32 has the register-resident kernels of fasty.h)
 XRFT_MRAD(512, 8, 8, 8);
 XRFT_MRAD(1024, 8, 8, 16);
-XRFT_MRAD(2048, 8, 16, 16);  // (one transform axis only: float32; float64 along the contiguous axis)
-XRFT_MRAD(4096, 16, 16, 16); // (one transform axis, the contiguous one: a single pair of rows per workgroup)
+XRFT_MRAD(2048, 8, 16, 16);  // (one transform axis only)
+XRFT_MRAD(4096, 16, 16, 16); // (one transform axis only)
 // lengths of time-like axes, one transform axis only (fastm_yonly_kernel)
 XRFT_MRAD(100, 4, 5, 5);
 XRFT_MRAD(128, 4, 4, 8);
