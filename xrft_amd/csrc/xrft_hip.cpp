@@ -1,11 +1,14 @@
 // xrft_hip.cpp -- plan builder, pass scheduler and the C ABI of libxrft_hip.so (see include/xrft_hip.h).
 //
-// A plan is a short list of kernel launches ("passes") per group of slabs:
-//     [slab_moments -> finalize_coef]  ->  x pass(es)  ->  y pass(es)
-// The x pass reads the user's array (detrend / window / flip / ifftshift fused into its loads) and the last
-// pass writes the user's output (fftshift / phase / scaling / |F|^2 / cross / mirror / radial bin-sum fused
-// into its stores).  The only intermediate is the half-spectrum of ONE group of slabs, sized to stay inside
-// the 256 MiB Infinity Cache, re-used for every group.  Nothing here allocates or synchronises in exec.
+// A plan is a short list of kernel launches per group of slabs, chosen when the plan is created (xrfthip_plan_describe says which):
+//   * generic passes (tile_fft.h), any shape:   [slab_moments -> finalize_coef]  ->  x pass(es)  ->  y pass(es)  [-> radial sums]
+//     The x pass reads the user's array (detrend / window / flip / ifftshift fused into its loads) and the last pass writes the
+//     user's output (fftshift / phase / scaling / |F|^2 / cross / mirror fused into its stores); the only intermediate is the
+//     half spectrum of ONE group of slabs, re-used for every group.
+//   * the two-pass y-first pipelines: fasty.h (real float32, powers of two 256 .. 4096; the four-step form for long 1-D
+//     sequences) and fastm.h (real float64 / float32 on the lat/lon lengths): columns -> plane fit -> rows;
+//   * one-pass kernels for ONE transform axis whose length is in the fastm table (fastm_yonly_kernel / fastm_xonly_kernel).
+// Nothing here allocates or synchronises in exec.
 #include <algorithm>
 #include <functional>
 #include <cmath>
