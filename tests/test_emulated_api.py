@@ -400,7 +400,8 @@ def test_fourstep_1d_fast_path(n):
 @pytest.mark.parametrize("shape,full,dtype", [((2, 360, 360), True, "float64"), ((1, 1440, 720), False, "float64"), ((1, 720, 1440), False, "float64"),
                                                ((2, 360, 360), True, "float32"), ((1, 720, 1440), False, "float32"), ((1, 1440, 720), False, "float32"),
                                                ((2, 180, 360), True, "float64"), ((2, 240, 480), False, "float32"), ((1, 960, 480), False, "float64"),
-                                               ((2, 256, 256), True, "float64"), ((1, 1024, 512), False, "float64"), ((1, 480, 960), False, "float32")])
+                                               ((2, 256, 256), True, "float64"), ((1, 1024, 512), False, "float64"), ((1, 480, 960), False, "float32"),
+                                               ((1, 1000, 1000), False, "float32"), ((1, 500, 1200), False, "float64")])
 def test_fastm_latlon_lengths(shape, full, dtype):
     """The mixed-radix y-first kernels (csrc/fastm.h; BASELINE.json configs[4] is (64, 1440, 720) float64)."""
     cases.run_fastm_cases(shape, full, True, dtype)

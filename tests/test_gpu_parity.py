@@ -729,7 +729,7 @@ def test_middle_and_first_axis_without_copies(dim, dtype):
                                                                               ((3, 720, 360), True), ((2, 360, 1440), True), ((3, 180, 360), True), ((2, 960, 480), True),
                                                                               ((3, 240, 720), True)] for d_ in ("float64", "float32")
                                                if not (s_ == (2, 1440, 1440) and d_ == "float32")]
-                         + [((2, 1440, 1440), True, "float32"), ((3, 256, 256), True, "float64"), ((2, 1024, 512), True, "float64"), ((2, 512, 1024), True, "float64")])
+                         + [((2, 1440, 1440), True, "float32"), ((2, 1000, 1000), True, "float32"), ((2, 500, 1200), True, "float64"), ((2, 1200, 1000), False, "float64"), ((3, 256, 256), True, "float64"), ((2, 1024, 512), True, "float64"), ((2, 512, 1024), True, "float64")])
 def test_fastm_latlon_lengths(shape, cross, dtype):
     """The mixed-radix y-first kernels (csrc/fastm.h) against the oracle: power spectra (every detrend), fft with true phase, half
     output, isotropic spectra, cross spectrum, cross phase."""

@@ -156,7 +156,7 @@ def run_random_fast(seed):
     cases.check(got, ref, 3e-4)
 
 
-def run_random_fastm(seed, lengths=(180, 240, 360, 480, 720, 960, 1440), dtype="float64"):
+def run_random_fastm(seed, lengths=(180, 240, 360, 480, 500, 720, 960, 1000, 1200, 1440), dtype="float64"):
     """Random mode / option combinations in float64 / float32 on the lat/lon lengths of csrc/fastm.h (BASELINE.json configs[4] is
     (64, 1440, 720)); modes the mixed-radix kernels do not take (a flipped axis) must come out
     right through the generic ones."""
@@ -191,8 +191,8 @@ def run_random_fastm(seed, lengths=(180, 240, 360, 480, 720, 960, 1440), dtype="
     else:
         got, ref = xa.power_spectrum(da, dim=["y"], real_dim="x", **kw), o.power_spectrum(od, dim=["y"], real_dim="x", **kw)
     on = any("[fastm]" in p.describe() for p in api._plan_cache.values())
-    two_rows = not (kind == "cs" and nx in (960, 1440) and dtype == "float64" and ny in (960, 1440))  # (one row pair per workgroup, two rows per line: no room for the second field)
-    cw = 4 if (dtype == "float64" and ny in (960, 1440)) else 8  # columns per pass-1 workgroup
+    two_rows = not (kind == "cs" and nx in (960, 1000, 1200, 1440) and dtype == "float64" and ny in (960, 1000, 1200, 1440))  # (one row pair per workgroup, two rows per line: no room for the second field)
+    cw = 4 if (dtype == "float64" and ny in (960, 1000, 1200, 1440)) else 8  # columns per pass-1 workgroup
     two_rows = two_rows and nx % cw == 0
     flipped = desc and tp and kind in ("fft", "cs")  # (the reference flips only under true_phase, xrft.py:436-441; power spectra never)
     assert on == (not flipped and two_rows), (kind, desc, tp, ny, nx, on)

@@ -57,9 +57,9 @@ XRFT_MRAD(1000, 10, 10, 10);
 XRFT_MRAD(1200, 10, 10, 12);
 #undef XRFT_MRAD
 // the lengths the host dispatches on: X(N) for every entry
-#define XRFT_M_LATLON(X) X(180) X(240) X(360) X(480) X(720) X(960) X(1440)
+#define XRFT_M_LATLON(X) X(180) X(240) X(360) X(480) X(500) X(720) X(960) X(1000) X(1200) X(1440)  /* both axes of a slab: the lat/lon lengths + 500, 1000, 1200 */
 #define XRFT_M_POW2(X) X(256) X(512) X(1024)
-#define XRFT_M_YONLY(X) X(100) X(128) X(200) X(400) X(500) X(600) X(800) X(1000) X(1200)
+#define XRFT_M_YONLY(X) X(100) X(128) X(200) X(400) X(600) X(800)
 
 constexpr int mr_max3(int a, int b, int c) { return a > b ? (a > c ? a : c) : (b > c ? b : c); }
 
