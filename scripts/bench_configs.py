@@ -75,10 +75,14 @@ add("fft along the MIDDLE axis (64,1024,2048) f32, no copies", x.numel(), 12, ti
 add("   power_spectrum along it, linear+hann", x.numel(), 8, timeit(lambda: xrft.power_spectrum(da, dim=["y"], detrend="linear", window="hann")))
 x = cube((64, 1000, 2048), torch.float64); da = xrft.DataArray(x, ("t", "y", "x"), {"y": np.arange(1000.), "x": np.arange(2048.)})
 add("   the same, (64,1000,2048) f64", x.numel(), 16, timeit(lambda: xrft.power_spectrum(da, dim=["y"], detrend="linear", window="hann")))
+x = cube((16, 4096, 2048), torch.float32); da = xrft.DataArray(x, ("t", "y", "x"), {"y": np.arange(4096.), "x": np.arange(2048.)})
+add("   power_spectrum along a 4096-point middle axis (16,4096,2048) f32", x.numel(), 8, timeit(lambda: xrft.power_spectrum(da, dim=["y"], detrend="linear", window="hann")))
 # short contiguous axis (ndim = 1)
 x = cube((131072, 1024), torch.float32); da = xrft.DataArray(x, ("t", "x"), {"x": np.arange(1024.)})
 add("power_spectrum 1-D (131072,1024) f32 linear+hann", x.numel(), 8, timeit(lambda: xrft.power_spectrum(da, dim=["x"], detrend="linear", window="hann")))
 add("   fft 1-D (131072,1024) f32", x.numel(), 12, timeit(lambda: xrft.fft(da, dim=["x"])))
+x = cube((64, 1000, 1000), torch.float32); da = xrft.DataArray(x, ("t", "y", "x"), {"y": np.arange(1000.), "x": np.arange(1000.)})
+add("PS (64,1000,1000) f32 linear+hann", x.numel(), 8, timeit(lambda: xrft.power_spectrum(da, dim=["y", "x"], detrend="linear", window="hann")))
 # a length with large prime factors: the ERA5 grid (721 = 7 x 103 latitudes) -- Bluestein in the column tile
 x = cube((64, 721, 1440), torch.float32); da = xrft.DataArray(x, ("t", "lat", "lon"), {"lat": np.arange(721) * .25, "lon": np.arange(1440) * .25})
 add("PS (64,721,1440) f32 linear+hann (ERA5 grid)", x.numel(), 8, timeit(lambda: xrft.power_spectrum(da, dim=["lat", "lon"], detrend="linear", window="hann")))
