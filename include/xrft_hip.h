@@ -184,6 +184,12 @@ int xrfthip_spectrum_tail_axis(int32_t dtype, int64_t outer, int64_t na, int64_t
 int xrfthip_gather_axis(int32_t elem_bytes, int64_t outer, int64_t n_out, int64_t inner, int64_t n_in, const int64_t* d_index, int64_t roll,
                         const void* d_in, void* d_out, void* stream);
 
+/* d_out[b][j] = (j < n_in ? d_in[b][j] : 0) * d_table[j], j < n_out: zero padding or truncation with a pointwise complex factor.
+ * dtype of d_in F32|F64|C64|C128; d_table (min(n_in, n_out) entries) and d_out complex of that precision.  The pointwise steps of Bluestein's algorithm
+ * through global memory, for lengths with a prime factor > XRFTHIP_MAX_RADIX that exceed the in-tile bound
+ * (numpy.fft takes any length: xrft.py:398-447). */
+int xrfthip_table_mul(int32_t dtype, int64_t batch, int64_t n_in, int64_t n_out, const void* d_in, const void* d_table, void* d_out, void* stream);
+
 /* Stand-alone radial bin-sum of an existing spectrum (xrft.isotropize, xrft.py:948-1010):
  * d_in [batch][ny][nx] (dtype F32|F64|C64|C128), d_binmap device int32 [ny][nx] (bin of each sample, < 0 = none),
  * d_iso float64|complex128 [batch][nbins] (every entry written).  The sums are bit-reproducible (per-workgroup integer

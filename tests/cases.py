@@ -744,3 +744,34 @@ def run_xonly_fast_cases(shape=(5, 360), dtype="float64"):
     lim = 1e-10 if dtype == "float64" else 3e-4
     assert (dphi * mag).max() / mag.max() < lim, (dphi * mag).max() / mag.max()
     return worst
+
+
+def run_long_prime_cases(lengths=((9001, "float64"), (10007, "float32"), (9001, "complex128"))):
+    """One transform axis (the last) whose length has a prime factor above 128 and is too long for Bluestein inside one LDS tile:
+    Bluestein through global memory (api._bluestein_1d: xrfthip_table_mul around two smooth-length plans).  numpy.fft takes any
+    length (xrft.py:398-447): fft with every option, power spectrum, real_dim, a descending coordinate."""
+    rng = np.random.default_rng(81)
+    worst = 0.0
+    for n, dt in lengths:
+        v = rng.standard_normal((3, n)) + 0.5 + 2.0 * np.arange(n) / n
+        if dt.startswith("complex"):
+            v = v + 1j * rng.standard_normal((3, n))
+        v = v.astype(dt)
+        c = {"t": np.arange(3), "x": np.arange(n) * 0.5 - 11.0}
+        da, od = pair(v, ("t", "x"), c)
+        tol = TOL[dt]
+        for kw in (dict(), dict(detrend="linear", window="hann"), dict(shift=False, true_phase=False)):
+            worst = max(worst, check(xa.fft(da, dim=["x"], **kw), o.fft(od, dim=["x"], **kw), tol))
+        worst = max(worst, check(xa.power_spectrum(da, dim=["x"], detrend="constant", window="hann"),
+                                 o.power_spectrum(od, dim=["x"], detrend="constant", window="hann"), tol))
+        if not dt.startswith("complex"):
+            worst = max(worst, check(xa.power_spectrum(da, dim=["x"], real_dim="x"), o.power_spectrum(od, dim=["x"], real_dim="x"), tol))
+            worst = max(worst, check(xa.fft(da, dim=["x"], real_dim="x", detrend="linear"), o.fft(od, dim=["x"], real_dim="x", detrend="linear"), tol))
+        c2 = dict(c)
+        c2["x"] = c["x"][::-1].copy()
+        da2, od2 = pair(v, ("t", "x"), c2)
+        worst = max(worst, check(xa.fft(da2, dim=["x"], window="hann"), o.fft(od2, dim=["x"], window="hann"), tol))
+        for kw in (dict(), dict(true_phase=False, shift=False)):  # and back: the inverse transform with conjugated chirps
+            F, Fo = xa.fft(da, dim=["x"], **kw), o.fft(od, dim=["x"], **kw)
+            worst = max(worst, check(xa.ifft(F, dim=["freq_x"], **kw), o.ifft(Fo, dim=["freq_x"], **kw), tol))
+    return worst

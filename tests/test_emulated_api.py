@@ -103,11 +103,18 @@ def test_groups_and_batches(monkeypatch):
 
 
 def test_unsupported_length_is_loud():
+    """Two transform axes, one of them a prime whose Bluestein transform does not fit the LDS: the C ABI returns
+    XRFTHIP_UNSUPPORTED_LENGTH and the call names the axis, the length and the bound.  (ONE such axis, the last, goes through
+    Bluestein in global memory: test_long_prime_lengths_through_global_bluestein.)"""
     import xrft_amd as xa
 
-    da = xa.DataArray(np.zeros((2, 10007)), ("t", "x"))  # a prime whose Bluestein transform (32768 points) does not fit the LDS
-    with pytest.raises(ValueError, match="10007"):  # names the axis, the length and the bound (the C ABI returns XRFTHIP_UNSUPPORTED_LENGTH)
-        xa.fft(da, dim="x")
+    da = xa.DataArray(np.zeros((2, 4, 10007)), ("t", "y", "x"))
+    with pytest.raises(ValueError, match="10007"):
+        xa.fft(da, dim=["y", "x"])
+
+
+def test_long_prime_lengths_through_global_bluestein():
+    cases.run_long_prime_cases()
 
 
 @pytest.mark.parametrize("ny,nx,nt,shift,det,win", [

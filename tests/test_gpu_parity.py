@@ -773,6 +773,11 @@ def test_one_axis_kernel_slab_beyond_4GB():
         assert np.abs(got - ref.values).max() / np.abs(ref.values).max() < 3e-4, lo
 
 
+def test_long_prime_lengths_through_global_bluestein():
+    """Lengths with a prime factor above 128 beyond the in-tile Bluestein (12 289 was the only failure of the random sweeps)."""
+    cases.run_long_prime_cases(((12289, "float64"), (12289, "float32"), (10007, "complex64"), (100003, "float64")))
+
+
 def test_radial_sums_any_nbins_and_bit_identical_repeats():
     """Stand-alone and generic-plan radial sums: more than 4096 bins (also through xrft.isotropize, nfactor = 1 on 4400^2), values
     vs numpy / the oracle, repeats bit for bit."""

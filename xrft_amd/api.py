@@ -486,6 +486,8 @@ def _execute(c, da, mode, scale, da2=None, c2=None, iso=None, extra_flags=0):
             raise
         # numpy.fft takes any length; here a prime factor above 128 goes through Bluestein inside one LDS tile, which bounds
         # the length (2 n - 1 rounded up to 2^a 3^b 5^c complex samples must fit 160 KB)
+        if ndim == 1 and iso is None and t2 is None and mode in (_lib.OUT_COMPLEX, _lib.OUT_POWER) and not (flags & (_lib.INVERSE | _lib.C2R_X | _lib.PHASE_IN)):
+            return _bluestein_1d(t, nx, mode, c.detrend, flags, scale, win["x"], ph["x"]), None, other
         lens = {d: da.sizes[d] for d in c.dim}
         lim = 8800 if t.dtype in (torch.float32, torch.complex64) else 4400
         raise ValueError(f"transform length(s) {lens} not supported on the device: a length with a prime factor above 128 must be "
@@ -493,6 +495,100 @@ def _execute(c, da, mode, scale, da2=None, c2=None, iso=None, extra_flags=0):
                          f"crop the axis (e.g. xrft_amd.pad) to a 2^a 3^b 5^c 7^d-smooth length") from e
     out, iso_out = plan.execute(t, t2)
     return out, iso_out, other
+
+
+# ------------------------------------------------------------------------------------------------------
+# Bluestein's algorithm through global memory: one transform axis (the last) whose length has a prime factor above 128 and exceeds
+# what the in-tile Bluestein of the C ABI holds (numpy.fft takes any length, xrft.py:398-447).
+#   X[k] = conj(c[k]) sum_j (x[j] conj(c[j])) c[k - j],   c[j] = exp(i pi j^2 / n)
+# = chirp multiply with zero padding to a 2^a 3^b 5^c length m >= 2n - 1, a forward plan, the product with FFT_m(c wrapped) / m,
+# an inverse plan, chirp multiply with truncation -- three table-multiply launches (xrfthip_table_mul) around two existing plans;
+# detrend, window, flips and shifts, true-phase factors, scaling and |F|^2 are the same device calls the other paths use.
+# ------------------------------------------------------------------------------------------------------
+_BLUE_TABLES = {}
+
+
+def _blue_tables(n, cdt, dev, inverse=False):
+    key = (n, str(cdt), str(dev), inverse)
+    tb = _BLUE_TABLES.get(key)
+    if tb is None:
+        m = 2 * n - 1
+        while True:
+            q = m
+            for p in (2, 3, 5):
+                while q % p == 0:
+                    q //= p
+            if q == 1:
+                break
+            m += 1
+        j = np.arange(n, dtype=np.int64)
+        ang = np.pi * ((j * j) % (2 * n)).astype(np.float64) / n  # j^2 mod 2n: exact phases for long sequences
+        chirp = np.exp((-1j if inverse else 1j) * ang)             # c[j] (conjugated for the inverse transform)
+        b = np.zeros(m, dtype=np.complex128)
+        b[:n] = chirp
+        b[m - n + 1:] = chirp[1:][::-1]                            # c[-j] = c[j], wrapped
+        bhat = np.fft.fft(b) / m                                   # (host, once per length)
+        tb = (m, torch.from_numpy(np.conj(chirp)).to(cdt).to(dev), torch.from_numpy(bhat).to(cdt).to(dev))
+        if len(_BLUE_TABLES) > 8:
+            _BLUE_TABLES.clear()
+        _BLUE_TABLES[key] = tb
+    return tb
+
+
+def _bluestein_1d(t, n, mode, detrend_kind, flags, scale, win, ph, phase_in=None):
+    """The 1-D plan's result for t[..., n] (real or complex) without a 1-D plan of length n.  With XRFTHIP_INVERSE in ``flags`` the
+    unnormalised inverse transform (the same pipeline with conjugated chirps); ``phase_in`` multiplies the INPUT, indexed by source
+    position (XRFTHIP_PHASE_IN, xrft.py:574-576)."""
+    shape = list(t.shape)
+    x = t.reshape(-1, n).contiguous()
+    real_in = not x.is_complex()
+    cdt = torch.complex64 if x.dtype in (torch.float32, torch.complex64) else torch.complex128
+    if detrend_kind != _lib.DETREND_NONE:  # per row, before the window (xrft.py:425-433)
+        x = engine.detrend(x, 1, detrend_kind)
+    idx = np.arange(n)
+    if flags & _lib.FLIP_X:      # np.flip, then ifftshift (xrft.py:436-441)
+        idx = idx[::-1]
+    if flags & _lib.ISHIFT_X:
+        idx = np.roll(idx, -(n // 2))
+    if (flags & (_lib.FLIP_X | _lib.ISHIFT_X)):
+        x = engine.gather_axis(x, 1, index=idx)
+    m, cconj_chirp, bhat = _blue_tables(n, cdt, x.device, inverse=bool(flags & _lib.INVERSE))
+    tab = cconj_chirp
+    if phase_in is not None:
+        tab = tab * torch.from_numpy(np.ascontiguousarray(np.asarray(phase_in, dtype=np.complex128)[idx])).to(cdt).to(tab.device)
+    if win is not None:  # the window rides on the first chirp multiply (it multiplies the samples where they lie AFTER flip / shift:
+        w = np.asarray(win, dtype=np.float64)[idx]  # the reference windows first, then flips: window of the source sample)
+        tab = tab * torch.from_numpy(np.ascontiguousarray(w)).to(tab.real.dtype).to(tab.device)
+    a = engine.table_mul(x, tab.contiguous(), m)
+    fwd = _get_plan(ndim=1, batch=a.shape[0], ny=1, nx=m, dtype=a.dtype, out_mode=_lib.OUT_COMPLEX, detrend=_lib.DETREND_NONE, flags=0, scale=1.0,
+                    window_y=None, window_x=None, phase_y=None, phase_x=None)
+    A, _ = fwd.execute(a.reshape(a.shape[0], 1, m))
+    C = engine.table_mul(A.reshape(-1, m), bhat, m)
+    inv = _get_plan(ndim=1, batch=a.shape[0], ny=1, nx=m, dtype=a.dtype, out_mode=_lib.OUT_COMPLEX, detrend=_lib.DETREND_NONE, flags=_lib.INVERSE, scale=1.0,
+                    window_y=None, window_x=None, phase_y=None, phase_x=None)
+    cc, _ = inv.execute(C.reshape(-1, 1, m))
+    half = bool(flags & _lib.HALF_X)
+    n_out = n // 2 + 1 if half else n
+    fac = np.ones(n_out, dtype=np.complex128)
+    if mode == _lib.OUT_COMPLEX:
+        fac = fac * float(scale)
+        if ph is not None:
+            fac = fac * np.asarray(ph, dtype=np.complex128)[:n_out]
+    tab2 = cconj_chirp[:n_out] * torch.from_numpy(fac).to(cdt).to(x.device)
+    X = engine.table_mul(cc.reshape(-1, m), tab2.contiguous(), n_out)  # F[k] (x phase x scale), k < n_out
+    if mode == _lib.OUT_POWER:
+        if flags & _lib.REALDIM_X2:
+            X = engine.spectrum_tail_axis(X, None, float(scale), 1, n % 2 == 0)
+        else:
+            X = engine.spectrum_tail(X, None, float(scale))
+    elif flags & _lib.REALDIM_X2:
+        d2 = np.full(n_out, 2.0); d2[0] = 1.0
+        if n % 2 == 0:
+            d2[-1] = 1.0
+        X = engine.table_mul(X, torch.from_numpy(d2.astype(np.complex128)).to(cdt).to(x.device), n_out)
+    if flags & _lib.SHIFT_X:
+        X = engine.gather_axis(X, 1, roll=n // 2)
+    return X.reshape(shape[:-1] + [n_out])
 
 
 # ------------------------------------------------------------------------------------------------------
@@ -784,10 +880,19 @@ def ifft(daft, spacing_tol=1e-3, dim=None, real_dim=None, shift=True, true_phase
     scale = 1.0 / nprod
     if true_amplitude:  # xrft.py:641-642
         scale = scale / np.prod([float(new_coords[swap[d]].attrs["spacing"]) for d in dim])
-    plan = _get_plan(ndim=len(dim), batch=batch, ny=ny, nx=nx, dtype=t.dtype, out_mode=_lib.OUT_COMPLEX,
-                     detrend=_lib.DETREND_NONE, flags=flags, scale=float(scale), window_y=None, window_x=None,
-                     phase_y=ph["y"], phase_x=ph["x"])
-    out, _ = plan.execute(t)
+    try:
+        plan = _get_plan(ndim=len(dim), batch=batch, ny=ny, nx=nx, dtype=t.dtype, out_mode=_lib.OUT_COMPLEX,
+                         detrend=_lib.DETREND_NONE, flags=flags, scale=float(scale), window_y=None, window_x=None,
+                         phase_y=ph["y"], phase_x=ph["x"])
+        out, _ = plan.execute(t)
+    except _lib.XrftHipError as e:
+        if e.status != _lib.UNSUPPORTED_LENGTH:
+            raise
+        if len(dim) != 1 or real_dim is not None:
+            lim = 8800 if t.dtype == torch.complex64 else 4400
+            raise ValueError(f"transform length(s) {dict(zip(dim, N))} not supported on the device: a length with a prime factor above 128 must "
+                             f"be <= ~{lim} samples (Bluestein inside one LDS tile) unless it is the only transform axis") from e
+        out = _bluestein_1d(t, nx, _lib.OUT_COMPLEX, _lib.DETREND_NONE, flags & ~_lib.PHASE_IN, float(scale), None, None, phase_in=ph["x"])
     out = out.reshape([daft.sizes[d] for d in other] + list(out.shape[-len(tdims):]))
     for ax, sh in post_roll:
         out = engine.gather_axis(out, out.dim() - 1 if ax == "x" else out.dim() - 2, roll=sh)

@@ -280,6 +280,24 @@ __global__ void __launch_bounds__(256) gather_axis_kernel(const E* in, E* out, l
     }
 }
 
+// out[b][j] = (j < n_in ? in[b][j] : 0) * table[j], j < n_out: the pointwise steps of Bluestein's algorithm run through global
+// memory (chirp multiply with zero padding, product with the chirp's spectrum, chirp multiply with truncation) for lengths whose
+// in-tile Bluestein does not fit the LDS.  `in` real (CIN = false) or complex, table and out complex.
+template <typename T, bool CIN>
+__global__ void __launch_bounds__(256) table_mul_kernel(const void* in, const C2<T>* __restrict__ table, C2<T>* __restrict__ out, long long batch, long long n_in, long long n_out) {
+    const long long total = batch * n_out;
+    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
+        const long long b = e / n_out, j = e - b * n_out;
+        C2<T> v = mk<T>((T)0, (T)0);
+        if (j < n_in) {  // (the table has min(n_in, n_out) entries)
+            if (CIN) v = reinterpret_cast<const C2<T>*>(in)[b * n_in + j];
+            else v = mk<T>(reinterpret_cast<const T*>(in)[b * n_in + j], (T)0);
+            v = cmul(v, table[j]);
+        }
+        out[e] = v;
+    }
+}
+
 // Radial bin sums of a stored spectrum (xrft.isotropize, xrft.py:948-1010; _groupby_bins_agg / _binned_agg :877-945),
 // BIT-REPRODUCIBLE: floating-point atomics would make a sum depend on the order in which waves arrive.  A workgroup owns one
 // contiguous chunk of a slab and makes two sweeps over it: (1) the largest exponent per bin (atomicMax on the high word of the

@@ -2105,6 +2105,19 @@ int xrfthip_gather_axis(int32_t elem_bytes, int64_t outer, int64_t n_out, int64_
     return XRFTHIP_OK;
 }
 
+int xrfthip_table_mul(int32_t dtype, int64_t batch, int64_t n_in, int64_t n_out, const void* d_in, const void* d_table, void* d_out, void* stream) {
+    if (!d_in || !d_table || !d_out || dtype < XRFTHIP_F32 || dtype > XRFTHIP_C128 || batch < 0 || n_in < 1 || n_out < 1) return XRFTHIP_BAD_ARG;
+    if (batch == 0) return XRFTHIP_OK;
+    hipStream_t st = (hipStream_t)stream;
+    const long long total = batch * n_out;
+    const dim3 grid((unsigned)std::min<long long>((total + 255) / 256, 8LL * kCUs * 8)), block(256);
+#define TM_(TT, CC) do { auto k = &table_mul_kernel<TT, CC>; XRFT_LAUNCH(k, grid, block, 0, st, d_in, (const C2<TT>*)d_table, (C2<TT>*)d_out, (long long)batch, (long long)n_in, (long long)n_out); } while (0)
+    if (dtype == XRFTHIP_F32) TM_(float, false); else if (dtype == XRFTHIP_F64) TM_(double, false); else if (dtype == XRFTHIP_C64) TM_(float, true); else TM_(double, true);
+#undef TM_
+    HIP_TRY(hipGetLastError());
+    return XRFTHIP_OK;
+}
+
 size_t xrfthip_isotropize_workspace_bytes(int32_t dtype, int64_t batch, int64_t ny, int64_t nx, int32_t nbins) {
     if (dtype < XRFTHIP_F32 || dtype > XRFTHIP_C128 || batch < 0 || ny < 1 || nx < 1 || nbins < 1) return 0;
     return (size_t)batch * iso_chunk_count(ny * nx) * nbins * (dtype >= XRFTHIP_C64 ? 2 : 1) * sizeof(double);

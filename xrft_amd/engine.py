@@ -236,6 +236,21 @@ def gather_axis(x, axis, index=None, roll=0):
     return out
 
 
+def table_mul(x, table, n_out):
+    """out[..., j] = (j < n ? x[..., j] : 0) * table[j], j < n_out, complex result: zero padding / truncation with a pointwise factor
+    (the pointwise steps of Bluestein's algorithm through global memory)."""
+    dll = _lib.load()
+    x = x.contiguous()
+    n_in = x.shape[-1]
+    batch = x.numel() // max(n_in, 1)
+    cdt = torch.complex64 if x.dtype in (torch.float32, torch.complex64) else torch.complex128
+    if table.dtype != cdt or table.numel() < min(n_in, n_out) or not table.is_contiguous():
+        raise ValueError("table_mul needs a contiguous complex table of the data's precision with min(n, n_out) entries")
+    out = torch.empty(list(x.shape[:-1]) + [n_out], dtype=cdt, device=x.device)
+    _lib.check(dll.xrfthip_table_mul(_DTYPES[x.dtype], batch, n_in, n_out, _ptr(x), _ptr(table), _ptr(out), _stream_handle(x)))
+    return out
+
+
 def isotropize(x, binmap_dev, nbins):
     """Radial bin-sum of the last two axes of ``x`` with a device int32 bin map (xrft/xrft.py:993-1004)."""
     dll = _lib.load()
