@@ -491,8 +491,8 @@ def _execute(c, da, mode, scale, da2=None, c2=None, iso=None, extra_flags=0):
         lens = {d: da.sizes[d] for d in c.dim}
         lim = 8800 if t.dtype in (torch.float32, torch.complex64) else 4400
         raise ValueError(f"transform length(s) {lens} not supported on the device: a length with a prime factor above 128 must be "
-                         f"<= ~{lim} samples for {str(t.dtype).replace('torch.', '')} data (Bluestein inside one LDS tile); pad or "
-                         f"crop the axis (e.g. xrft_amd.pad) to a 2^a 3^b 5^c 7^d-smooth length") from e
+                         f"<= ~{lim} samples for {str(t.dtype).replace('torch.', '')} data (Bluestein inside one LDS tile) unless it is the only "
+                         f"transform axis; transform the axes one at a time, or pad / crop the axis (e.g. xrft_amd.pad) to a smooth length") from e
     out, iso_out = plan.execute(t, t2)
     return out, iso_out, other
 
