@@ -103,14 +103,15 @@ def test_groups_and_batches(monkeypatch):
 
 
 def test_unsupported_length_is_loud():
-    """Two transform axes, one of them a prime whose Bluestein transform does not fit the LDS: the C ABI returns
-    XRFTHIP_UNSUPPORTED_LENGTH and the call names the axis, the length and the bound.  (ONE such axis, the last, goes through
-    Bluestein in global memory: test_long_prime_lengths_through_global_bluestein.)"""
+    """What the device cannot do fails loudly, never silently on a CPU: a fused isotropic spectrum over an axis whose length has a
+    prime factor above 128 and exceeds Bluestein inside one LDS tile (the C ABI returns XRFTHIP_UNSUPPORTED_LENGTH; the call names
+    the axis, the length and the bound).  fft / power_spectrum / cross_spectrum take such lengths: one axis through Bluestein in
+    global memory, two axes one at a time (test_long_prime_lengths_through_global_bluestein)."""
     import xrft_amd as xa
 
-    da = xa.DataArray(np.zeros((2, 4, 10007)), ("t", "y", "x"))
+    da = xa.DataArray(np.zeros((2, 8, 10007)), ("t", "y", "x"), {"t": np.arange(2), "y": np.arange(8) * 1.0, "x": np.arange(10007) * 1.0})
     with pytest.raises(ValueError, match="10007"):
-        xa.fft(da, dim=["y", "x"])
+        xa.isotropic_power_spectrum(da, dim=["y", "x"])
 
 
 def test_long_prime_lengths_through_global_bluestein():

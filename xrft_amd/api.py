@@ -490,7 +490,7 @@ def _execute(c, da, mode, scale, da2=None, c2=None, iso=None, extra_flags=0):
             return _bluestein_1d(t, nx, mode, c.detrend, flags, scale, win["x"], ph["x"]), None, other
         lens = {d: da.sizes[d] for d in c.dim}
         lim = 8800 if t.dtype in (torch.float32, torch.complex64) else 4400
-        raise ValueError(f"transform length(s) {lens} not supported on the device: a length with a prime factor above 128 must be "
+        raise _UnsupportedLength(f"transform length(s) {lens} not supported on the device: a length with a prime factor above 128 must be "
                          f"<= ~{lim} samples for {str(t.dtype).replace('torch.', '')} data (Bluestein inside one LDS tile) unless it is the only "
                          f"transform axis; transform the axes one at a time, or pad / crop the axis (e.g. xrft_amd.pad) to a smooth length") from e
     out, iso_out = plan.execute(t, t2)
@@ -505,6 +505,10 @@ def _execute(c, da, mode, scale, da2=None, c2=None, iso=None, extra_flags=0):
 # an inverse plan, chirp multiply with truncation -- three table-multiply launches (xrfthip_table_mul) around two existing plans;
 # detrend, window, flips and shifts, true-phase factors, scaling and |F|^2 are the same device calls the other paths use.
 # ------------------------------------------------------------------------------------------------------
+class _UnsupportedLength(ValueError):
+    """A two-axis plan could not be built for these lengths: the callers transform the axes one at a time instead."""
+
+
 _BLUE_TABLES = {}
 
 
@@ -617,8 +621,15 @@ def _nd_dims(da, dim, real_dim, real):
     return dims
 
 
+def _two_dims(da, dim, real_dim, real):
+    """The normalised list of two transform dims (the real one last), for the one-axis-at-a-time fallback."""
+    dims = list(da.dims) if dim is None else ([dim] if isinstance(dim, str) else list(dim))
+    rd = real if real is not None else real_dim
+    return _move_to_end(dims, rd) if rd is not None else dims
+
+
 def _fft_nd(da, dims, spacing_tol, real_dim, shift, detrend_, window, true_phase, true_amplitude, chunks_to_segments,
-            prefix):
+            prefix, one_at_a_time=False):
     if chunks_to_segments:
         raise NotImplementedError("chunks_to_segments is implemented for one or two transform dimensions.")
     if detrend_ not in (None, "constant", "linear"):
@@ -629,18 +640,19 @@ def _fft_nd(da, dims, spacing_tol, real_dim, shift, detrend_, window, true_phase
         cur = from_any(detrend(cur, dims, detrend_))
     with warnings.catch_warnings():
         warnings.simplefilter("ignore", FutureWarning)
-        cur = fft(cur, spacing_tol=spacing_tol, dim=dims[-2:], real_dim=real_dim, shift=shift, detrend=None,
+        g = 1 if one_at_a_time else 2  # (one axis per stage: a length no two-axis plan takes goes through the one-axis paths, which take any)
+        cur = fft(cur, spacing_tol=spacing_tol, dim=dims[-g:], real_dim=real_dim, shift=shift, detrend=None,
                   window=window, true_phase=true_phase, true_amplitude=true_amplitude, prefix=prefix)
-        rest = dims[:-2]
+        rest = dims[:-g]
         sh = False if real_dim is not None else shift  # xrft.py:403: a real transform switches every shift off
         while rest:
-            grp, rest = rest[-2:], rest[:-2]
+            grp, rest = rest[-g:], rest[:-g]
             cur = fft(cur, spacing_tol=spacing_tol, dim=grp, shift=sh, detrend=None, window=window,
                       true_phase=true_phase, true_amplitude=true_amplitude, prefix=prefix)
     return cur
 
 
-def _spectrum_nd(da, da2, dims, real_dim, scaling, window_correction, true_phase, kwargs):
+def _spectrum_nd(da, da2, dims, real_dim, scaling, window_correction, true_phase, kwargs, one_at_a_time=False):
     """power_spectrum / cross_spectrum over more than two axes: N-D transform(s), then the elementwise tail."""
     if "density" in kwargs:
         scaling = "density" if kwargs.pop("density") else "false_density"
@@ -654,11 +666,11 @@ def _spectrum_nd(da, da2, dims, real_dim, scaling, window_correction, true_phase
         raise TypeError(f"fft() got an unexpected keyword argument {sorted(unknown)[0]!r}")
     kw.update({k: v for k, v in kwargs.items() if k != "real"})
     f1 = _fft_nd(da, dims, kw["spacing_tol"], real_dim, kw["shift"], kw["detrend"], kw["window"], true_phase, True,
-                 kw["chunks_to_segments"], kw["prefix"])
+                 kw["chunks_to_segments"], kw["prefix"], one_at_a_time)
     f2 = None
     if da2 is not None:
         f2 = _fft_nd(da2, dims, kw["spacing_tol"], real_dim, kw["shift"], kw["detrend"], kw["window"], true_phase, True,
-                     kw["chunks_to_segments"], kw["prefix"])
+                     kw["chunks_to_segments"], kw["prefix"], one_at_a_time)
         if tuple(f1.dims) != tuple(f2.dims):
             raise ValueError("The two datasets have different dimensions")
     pf = kw["prefix"]
@@ -709,9 +721,15 @@ def fft(da, spacing_tol=1e-3, dim=None, real_dim=None, shift=True, detrend=None,
         return to_like(_fft_nd(da, nd, spacing_tol, real_dim if real is None else real, shift, detrend, window,
                                true_phase, true_amplitude, chunks_to_segments, prefix), src)
     c = _analyze(da, spacing_tol, dim, real_dim, shift, detrend, window, true_phase, chunks_to_segments, prefix, real)
-    da = c.da
     scale = np.prod(c.delta_x) if true_amplitude else 1.0  # xrft.py:471-472
-    out, _, other = _execute(c, da, _lib.OUT_COMPLEX, scale)
+    try:
+        out, _, other = _execute(c, c.da, _lib.OUT_COMPLEX, scale)
+    except _UnsupportedLength:
+        if chunks_to_segments:
+            raise
+        return to_like(_fft_nd(da, _two_dims(da, dim, real_dim, real), spacing_tol, real_dim if real is None else real, shift, detrend, window,
+                               true_phase, true_amplitude, False, prefix, one_at_a_time=True), src)
+    da = c.da
     extra = None
     if c.true_phase:  # xrft.py:469
         extra = {c.swap[d]: {"direct_lag": lag} for d, lag in zip(c.dim, c.lag_x)}
@@ -1031,7 +1049,11 @@ def power_spectrum(da, dim=None, real_dim=None, scaling="density", window_correc
     if nd is not None:
         return to_like(_spectrum_nd(da, None, nd, real_dim, scaling, window_correction, False, dict(kwargs)), src)
     c, _, mode, scale, flags = _spectrum(da, None, dim, real_dim, scaling, window_correction, False, dict(kwargs))
-    out, _, other = _execute(c, c.da, mode, scale, extra_flags=flags)
+    try:
+        out, _, other = _execute(c, c.da, mode, scale, extra_flags=flags)
+    except _UnsupportedLength:
+        return to_like(_spectrum_nd(da, None, _two_dims(da, dim, real_dim, kwargs.get("real")), real_dim, scaling, window_correction, False,
+                                    dict(kwargs), one_at_a_time=True), src)
     return to_like(_label_output(c, c.da, out, other), src)
 
 
@@ -1044,7 +1066,11 @@ def cross_spectrum(da1, da2, dim=None, real_dim=None, scaling="density", window_
     if nd is not None:
         return to_like(_spectrum_nd(da1, da2, nd, real_dim, scaling, window_correction, true_phase, dict(kwargs)), src)
     c, c2, mode, scale, flags = _spectrum(da1, da2, dim, real_dim, scaling, window_correction, true_phase, dict(kwargs))
-    return to_like(_cross_result(c, c2, mode, scale, flags), src)
+    try:
+        return to_like(_cross_result(c, c2, mode, scale, flags), src)
+    except _UnsupportedLength:
+        return to_like(_spectrum_nd(da1, da2, _two_dims(da1, dim, real_dim, kwargs.get("real")), real_dim, scaling, window_correction, true_phase,
+                                    dict(kwargs), one_at_a_time=True), src)
 
 
 def _cross_result(c, c2, mode, scale, flags):
