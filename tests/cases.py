@@ -790,4 +790,9 @@ def run_long_prime_cases(lengths=((9001, "float64"), (10007, "float32"), (9001, 
             b = _cube(rng, shape, dt)
             db3, ob3 = pair(b, D3, _coords3(shape, y0=1.0))
             worst = max(worst, check(xa.cross_spectrum(da3, db3, dim=["y", "x"], window="hann"), o.cross_spectrum(od3, ob3, dim=["y", "x"], window="hann"), tol))
+            # isotropic spectra: the full spectrum, then isotropize -- what the reference does literally (xrft.py:1085-1095)
+            kwi = dict(dim=["y", "x"], detrend="linear", window="hann", truncate=True)
+            worst = max(worst, check(xa.isotropic_power_spectrum(da3, **kwi), o.isotropic_power_spectrum(od3, **kwi), tol2))
+            worst = max(worst, check(xa.isotropic_cross_spectrum(da3, db3, dim=["y", "x"], window="hann"),
+                                     o.isotropic_cross_spectrum(od3, ob3, dim=["y", "x"], window="hann"), tol2))
     return worst

@@ -102,16 +102,17 @@ def test_groups_and_batches(monkeypatch):
     api._plan_cache.clear()
 
 
-def test_unsupported_length_is_loud():
-    """What the device cannot do fails loudly, never silently on a CPU: a fused isotropic spectrum over an axis whose length has a
-    prime factor above 128 and exceeds Bluestein inside one LDS tile (the C ABI returns XRFTHIP_UNSUPPORTED_LENGTH; the call names
-    the axis, the length and the bound).  fft / power_spectrum / cross_spectrum take such lengths: one axis through Bluestein in
-    global memory, two axes one at a time (test_long_prime_lengths_through_global_bluestein)."""
-    import xrft_amd as xa
+def test_unsupported_length_is_loud_at_the_c_abi():
+    """A plan the kernels cannot serve -- two transform axes, one a prime whose Bluestein transform does not fit the LDS -- is refused
+    by xrfthip_plan_create with XRFTHIP_UNSUPPORTED_LENGTH (never computed some other way behind the caller's back); the Python
+    layer then transforms the axes one at a time (test_long_prime_lengths_through_global_bluestein)."""
+    import torch
 
-    da = xa.DataArray(np.zeros((2, 8, 10007)), ("t", "y", "x"), {"t": np.arange(2), "y": np.arange(8) * 1.0, "x": np.arange(10007) * 1.0})
-    with pytest.raises(ValueError, match="10007"):
-        xa.isotropic_power_spectrum(da, dim=["y", "x"])
+    from xrft_amd import engine
+
+    with pytest.raises(_lib.XrftHipError) as ei:
+        engine.SpectralPlan(ndim=2, batch=2, ny=8, nx=10007, dtype=torch.float64, out_mode=_lib.OUT_POWER, detrend=_lib.DETREND_NONE, flags=0, scale=1.0)
+    assert ei.value.status == _lib.UNSUPPORTED_LENGTH
 
 
 def test_long_prime_lengths_through_global_bluestein():

@@ -1214,9 +1214,20 @@ def _iso_spectrum(da, da2, spacing_tol, dim, shift, detrend_, scaling, window, w
     # of radii; kr (a per-bin mean of the same multiset) is summed in the reference's cell order to match it bit for bit
     codes_yx, kr, nb, bkey = _radial_bins(ky, kx, nfactor, (bool(c.shift), bool(c.shift), fftdim[1] == c.swap[c.xdim]))
     iso_cfg = {"binmap": codes_yx, "nbins": nb, "binmap_key": bkey}
+    da_in = da
     da = c.da
-    out, iso, other = _execute(c, da, mode, scale, da2=None if c2 is None else c2.da, c2=c2, iso=iso_cfg,
-                               extra_flags=flags | _lib.ISO | _lib.NO_SPECTRUM_OUT)
+    try:
+        out, iso, other = _execute(c, da, mode, scale, da2=None if c2 is None else c2.da, c2=c2, iso=iso_cfg,
+                                   extra_flags=flags | _lib.ISO | _lib.NO_SPECTRUM_OUT)
+    except _UnsupportedLength:
+        # no two-axis plan for these lengths: what the reference does literally (xrft.py:1085-1095, 1177-1187) -- the full spectrum
+        # (its axes transformed one at a time), then isotropize
+        skw = dict(dim=dim, real_dim=real_dim, scaling=scaling, window_correction=window_correction, **kw)
+        if da2 is None:
+            full = power_spectrum(da_in, **skw)
+        else:
+            full = cross_spectrum(da_in, da2, true_phase=true_phase, **skw)
+        return from_any(isotropize(full, fftdim, nfactor=nfactor, truncate=truncate, complx=da2 is not None))
     vals = iso.reshape([da.sizes[d] for d in other] + [nb])
     if truncate:  # dropna inspects the DATA values (xrft.py:1007-1008): the only case that needs them on the host
         vals = vals.cpu().numpy()
