@@ -776,6 +776,9 @@ def run_long_prime_cases(lengths=((9001, "float64"), (10007, "float32"), (9001, 
             worst = max(worst, check(xa.ifft(F, dim=["freq_x"], **kw), o.ifft(Fo, dim=["freq_x"], **kw), tol))
         if dt.startswith("complex"):
             continue
+        # the half spectrum back to 2 (n // 2) real samples (irfft; 2 x 5003 points for n = 10007: Bluestein again)
+        F, Fo = xa.fft(da, dim=["x"], real_dim="x"), o.fft(od, dim=["x"], real_dim="x")
+        worst = max(worst, check(xa.ifft(F, dim=["freq_x"], real_dim="freq_x"), o.ifft(Fo, dim=["freq_x"], real_dim="freq_x"), tol))
         # two transform axes, one of them such a length (either position): no two-axis plan exists, the axes go one at a time
         tol2 = max(tol, 1e-8)  # (the cube's trend grows with the index: 10^3 times the noise at 10^5 samples -- the plane fit's own rounding)
         for shape in ((2, 6, n), (2, n, 6)):

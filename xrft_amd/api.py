@@ -906,11 +906,25 @@ def ifft(daft, spacing_tol=1e-3, dim=None, real_dim=None, shift=True, true_phase
     except _lib.XrftHipError as e:
         if e.status != _lib.UNSUPPORTED_LENGTH:
             raise
-        if len(dim) != 1 or real_dim is not None:
+        if len(dim) == 1 and real_dim is not None and not (flags & (_lib.FLIP_X | _lib.ISHIFT_X)):
+            # irfft of a long prime length: x[j] = Re sum_k Y[k] e^(+2 pi i jk / n) with Y = the stored half spectrum, its interior
+            # samples doubled, zero beyond n/2 -- the zero padding and the factors ride on a table multiply, then the inverse Bluestein
+            # pipeline; the real part is a device gather over the (re, im) pairs
+            cdt = t.dtype
+            two = np.full(nx_in, 2.0)
+            two[0] = 1.0
+            if nx % 2 == 0:
+                two[-1] = 1.0
+            fac = two.astype(np.complex128) if ph["x"] is None else two * np.asarray(ph["x"], dtype=np.complex128)
+            y = engine.table_mul(t.reshape(-1, nx_in), torch.from_numpy(fac).to(cdt).to(t.device), nx)
+            z = _bluestein_1d(y, nx, _lib.OUT_COMPLEX, _lib.DETREND_NONE, flags & ~(_lib.PHASE_IN | _lib.C2R_X), float(scale), None, None)
+            out = engine.gather_axis(torch.view_as_real(z.contiguous()), 2, index=np.array([0])).reshape(list(t.shape[:-1]) + [nx])
+        elif len(dim) != 1 or real_dim is not None:
             lim = 8800 if t.dtype == torch.complex64 else 4400
             raise ValueError(f"transform length(s) {dict(zip(dim, N))} not supported on the device: a length with a prime factor above 128 must "
                              f"be <= ~{lim} samples (Bluestein inside one LDS tile) unless it is the only transform axis") from e
-        out = _bluestein_1d(t, nx, _lib.OUT_COMPLEX, _lib.DETREND_NONE, flags & ~_lib.PHASE_IN, float(scale), None, None, phase_in=ph["x"])
+        else:
+            out = _bluestein_1d(t, nx, _lib.OUT_COMPLEX, _lib.DETREND_NONE, flags & ~_lib.PHASE_IN, float(scale), None, None, phase_in=ph["x"])
     out = out.reshape([daft.sizes[d] for d in other] + list(out.shape[-len(tdims):]))
     for ax, sh in post_roll:
         out = engine.gather_axis(out, out.dim() - 1 if ax == "x" else out.dim() - 2, roll=sh)
