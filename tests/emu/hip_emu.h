@@ -197,6 +197,7 @@ inline double __shfl_xor(double v, int mask) {
 }
 inline long long __double_as_longlong(double d) { long long v; memcpy(&v, &d, 8); return v; }
 inline float __uint_as_float(unsigned v) { float f; memcpy(&f, &v, 4); return f; }
+inline double __longlong_as_double(long long v) { double d; memcpy(&d, &v, 8); return d; }
 inline unsigned __float_as_uint(float f) { unsigned v; memcpy(&v, &f, 4); return v; }
 using std::max;
 using std::min;
@@ -206,6 +207,7 @@ inline float atomicAdd(float* p, float v) { return emu::atomic_add(p, v); }
 inline int atomicAdd(int* p, int v) { return __atomic_fetch_add(p, v, __ATOMIC_RELAXED); }
 inline unsigned atomicAdd(unsigned* p, unsigned v) { return __atomic_fetch_add(p, v, __ATOMIC_RELAXED); }
 inline unsigned long long atomicAdd(unsigned long long* p, unsigned long long v) { return __atomic_fetch_add(p, v, __ATOMIC_RELAXED); }
+inline unsigned atomicOr(unsigned* p, unsigned v) { return __atomic_fetch_or(p, v, __ATOMIC_RELAXED); }
 inline unsigned atomicMax(unsigned* p, unsigned v) {
     unsigned old = __atomic_load_n(p, __ATOMIC_RELAXED);
     while (old < v && !__atomic_compare_exchange_n(p, &old, v, false, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) {}

@@ -307,14 +307,29 @@ __global__ void __launch_bounds__(256) table_mul_kernel(const void* in, const C2
 // tables do not fit the LDS).  The spectrum is stored with rows / columns rotated by sy / sx (fftshift); binmap is indexed by
 // unshifted frequencies.  A chunk holds <= 2^17 elements: |sum| < 2^(FR + 1 + 17) = 2^62 (also summed over the copies).
 constexpr int kIsoFR = 44;
+// rounds to nearest (a truncating shift biases a sum of positive powers by up to 2^-45 of the bin's bound per sample);
+// non-finite values give 0 here: they are recorded in the bin's flag word instead (iso_nonfinite_flags)
 __device__ __forceinline__ long long iso_fixed(double v, int eb) {
     const unsigned long long bits = (unsigned long long)__double_as_longlong(v);
     const int ex = (int)((bits >> 52) & 0x7ffull);
-    if (ex == 0) return 0;  // zero / denormal
+    if (ex == 0 || ex == 0x7ff) return 0;  // zero / denormal; inf / nan
     const long long m = (long long)((bits & 0xfffffffffffffull) | 0x10000000000000ull);  // |v| = m 2^(ex - 1075)
     const int sh = eb - ex + (52 - kIsoFR);                                               // q = m >> sh, sh >= 8 (ex <= eb)
-    const long long q = sh < 63 ? (m >> sh) : 0;
+    const long long q = sh < 62 ? ((m + (1ll << (sh - 1))) >> sh) : 0;
     return (bits >> 63) ? -q : q;
+}
+// what a non-finite sample does to an IEEE sum: bit 0 +inf seen, bit 1 -inf seen, bit 2 nan seen (0 for a finite value)
+__device__ __forceinline__ unsigned iso_nonfinite_flags(double v) {
+    const unsigned long long bits = (unsigned long long)__double_as_longlong(v);
+    if (((bits >> 52) & 0x7ffull) != 0x7ffull) return 0u;
+    if (bits & 0xfffffffffffffull) return 4u;
+    return (bits >> 63) ? 2u : 1u;
+}
+// the finite part of a sum combined with the flags of its non-finite members, as IEEE addition would have given it
+__device__ __forceinline__ double iso_apply_flags(double finite_sum, unsigned fl) {
+    if (fl == 0u) return finite_sum;
+    if ((fl & 4u) || (fl & 3u) == 3u) return __longlong_as_double(0x7ff8000000000000ll);
+    return __longlong_as_double((fl & 1u) ? 0x7ff0000000000000ll : (long long)0xfff0000000000000ull);
 }
 
 // Neighbouring samples of a row mostly fall into the same radial bin (a 64-lane wave touches ~4 bins at 1440 x 720: 16-way
@@ -326,9 +341,11 @@ __global__ void __launch_bounds__(256) radial_binsum_det_kernel(const void* in, 
     XRFT_DYN_SMEM(smem_raw);
     constexpr int HW = CPLX ? 2 : 1;
     unsigned long long* acc_all = reinterpret_cast<unsigned long long*>(smem_raw);       // [ncopy][nb][HW]
-    unsigned* bmax_all = reinterpret_cast<unsigned*>(acc_all + (size_t)ncopy * nb * HW);  // [ncopy][nb]: high word of the largest magnitude
+    unsigned* bmax_all = reinterpret_cast<unsigned*>(acc_all + (size_t)ncopy * nb * HW);  // [ncopy][nb]: high word of the largest FINITE magnitude
+    unsigned* nfl = bmax_all + (size_t)ncopy * nb;                                        // [nb]: non-finite members (3 bits per component), one copy: rare
     for (int i = threadIdx.x; i < ncopy * nb * HW; i += blockDim.x) acc_all[i] = 0ull;
     for (int i = threadIdx.x; i < ncopy * nb; i += blockDim.x) bmax_all[i] = 0u;
+    for (int i = threadIdx.x; i < nb; i += blockDim.x) nfl[i] = 0u;
     const int cp = (int)(threadIdx.x & (unsigned)(ncopy - 1));
     unsigned long long* acc = acc_all + (size_t)cp * nb * HW;
     unsigned* bmax = bmax_all + (size_t)cp * nb;
@@ -371,8 +388,12 @@ __global__ void __launch_bounds__(256) radial_binsum_det_kernel(const void* in, 
                 const int bin = bins[u];
                 if (bin < 0) continue;
                 if (sweep == 0) {
-                    const double mag = CPLX ? fabs(vr[u]) + fabs(vi[u]) : fabs(vr[u]);
-                    atomicMax(&bmax[bin], (unsigned)((unsigned long long)__double_as_longlong(mag) >> 32));
+                    // inf / nan members do not set the scale of the bin's finite sum: they go to the flag word and are put back
+                    // at the end the way IEEE addition treats them (xrft.py:895-906 sums in floating point: a NaN poisons its bin)
+                    const unsigned fl = iso_nonfinite_flags(vr[u]) | (CPLX ? iso_nonfinite_flags(vi[u]) << 3 : 0u);
+                    if (fl) atomicOr(&nfl[bin], fl);
+                    const double mr = (fl & 7u) ? 0.0 : fabs(vr[u]), mi = (!CPLX || (fl >> 3)) ? 0.0 : fabs(vi[u]);
+                    atomicMax(&bmax[bin], (unsigned)((unsigned long long)__double_as_longlong(mr + mi) >> 32));
                 } else {
                     const int eb = (int)(bmax_all[bin] >> 20);  // biased exponent of the bound: |v| <= mag < 2^(eb - 1022)
                     atomicAdd(&acc[HW * bin], (unsigned long long)iso_fixed(vr[u], eb));
@@ -394,7 +415,7 @@ __global__ void __launch_bounds__(256) radial_binsum_det_kernel(const void* in, 
     for (int i = threadIdx.x; i < nb * HW; i += blockDim.x) {
         long long sum = 0;
         for (int k = 0; k < ncopy; ++k) sum += (long long)acc_all[(size_t)k * nb * HW + i];
-        dst[i] = ldexp((double)sum, (int)(bmax_all[i / HW] >> 20) - 1023 - kIsoFR);
+        dst[i] = iso_apply_flags(ldexp((double)sum, (int)(bmax_all[i / HW] >> 20) - 1023 - kIsoFR), (nfl[i / HW] >> (3 * (i % HW))) & 7u);
     }
 }
 

@@ -869,7 +869,7 @@ static int iso_chunk_count(long long total) {
     return (int)c;
 }
 // bins per launch: the int64 sums and the exponent table of a window of bins share 64 KB of LDS
-static int iso_bin_window(bool cplx) { return (int)((64 * 1024) / (cplx ? 20 : 12)); }
+static int iso_bin_window(bool cplx) { return (int)((64 * 1024) / (cplx ? 24 : 16)); }  // (+ 4 bytes per bin: the non-finite flags)
 
 // radial sums of `bc` stored spectra [bc][ny][nxo] (rows / columns rotated by sy / sx) -> iso[bc][nbins (x2)], bit-reproducible
 static int run_radial_sums(int32_t dtype, const void* spec, const int32_t* d_binmap, long long bc, long long ny, long long nxo, int sy, int sx,
@@ -887,7 +887,7 @@ static int run_radial_sums(int32_t dtype, const void* spec, const int32_t* d_bin
             const dim3 grid((unsigned)chunks, (unsigned)sc), block(256);
             int ncopy = 1;  // copies of the tables (lanes spread over them: neighbouring samples share bins), as many as fit 32 KB
             while (ncopy < 8 && (size_t)nb * (cplx ? 20 : 12) * (2 * ncopy) <= 32 * 1024) ncopy *= 2;
-            const size_t lds = (size_t)nb * (cplx ? 20 : 12) * ncopy;
+            const size_t lds = (size_t)nb * (cplx ? 20 : 12) * ncopy + (size_t)nb * 4;
 #define ISO_(TT, CC) do { auto k = &radial_binsum_det_kernel<TT, CC>; XRFT_LAUNCH(k, grid, block, lds, st, src, (const int*)d_binmap, total, (int)nxo, (int)ny, sy, sx, b0, nb, nbins, ncopy, pdst); } while (0)
             if (dbl) { if (cplx) ISO_(double, true); else ISO_(double, false); } else { if (cplx) ISO_(float, true); else ISO_(float, false); }
 #undef ISO_
