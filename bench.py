@@ -19,8 +19,9 @@ Extra objects on the JSON line:
                  time of the step (all kernels + gaps), frac = achieved / 8 TB/s.  "kernel" holds the same figure for the
                  longest kernel alone (its launch's points / its average launch duration, from HIP events recorded by
                  the library on the launch stream inside the timed region, xrfthip_plan_set_profiling); "traffic" the
-                 HBM bytes of one step measured with rocprofv3 PMC counters (profiles/r02_traffic.json);
-                 "two_pass_ceiling" what the memory system allows any out-of-cache two-pass 2-D FFT (measured skeletons).
+                 HBM bytes of one step measured with rocprofv3 PMC counters (profiles/r03_traffic.json, used only when its
+                 stamp matches the SHA-1 of xrft_amd/csrc; null otherwise); "two_pass_floor" what the memory system allows the
+                 two passes' access patterns with no arithmetic (scripts/ubench/fused.hip, profiles/r03_ubench_fused.txt).
   cpu_baseline : the CPU oracle (numpy/scipy restatement of the reference; the reference itself needs xarray,
                  which the image lacks) timed on a bounded sample of the same workload, 1 thread.
 """
@@ -64,7 +65,7 @@ def _cpu_pool_slab(arg):
     return float(r.values[0, 0, 0])
 
 
-def main(argv=None):
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
@@ -82,9 +83,60 @@ def main(argv=None):
                     help="ps: BASELINE.json configs[2] (power_spectrum, the headline metric); c2: configs[1] -- dft along x of "
                          "(1024, 65536) float32; c4: configs[3] -- cross_spectrum + isotropic_power_spectrum of two fields per rank, the "
                          "isotropic results all-gathered over RCCL; c5: configs[4] -- power_spectrum of (64, 1440, 720) float64, linear detrend + Hann")
-    ap.add_argument("--emulate", action="store_true", help=argparse.SUPPRESS)  # tests/test_bench_ranks_cpu.py: gloo + the emulated library
-    args = ap.parse_args(argv)
+    return ap.parse_args(argv)
 
+
+class GpuEnv:
+    """Where the bench runs: one MI355X per rank, RCCL ("nccl") between ranks, the HIP library or nothing.  The only environment
+    this script knows; tests/bench_ranks_harness.py drives run() with its own (gloo, CPU tensors, the emulated test build) to
+    exercise the rank logic without a GPU."""
+    backend = "nccl"
+    backend_label = "nccl (RCCL over xGMI)"
+    data_label = "synthetic"
+    measures = True
+
+    def device(self, local):
+        import torch
+
+        dev = torch.device("cuda", local)
+        torch.cuda.set_device(dev)
+        return dev
+
+    def init_process_group(self, dist, local):
+        import torch
+
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+
+    def sync(self, dev):
+        import torch
+
+        torch.cuda.synchronize(dev)
+
+    def load_library(self):
+        from xrft_amd import _lib
+
+        _lib.load()  # no fallback: raises if the HIP library is missing
+
+
+def csrc_sha1():
+    """SHA-1 over the library's sources (file names + contents, sorted): what a committed traffic profile is stamped with."""
+    import hashlib
+
+    h = hashlib.sha1()
+    d = os.path.join(REPO, "xrft_amd", "csrc")
+    for name in sorted(os.listdir(d)):
+        h.update(name.encode())
+        with open(os.path.join(d, name), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()
+
+
+def main(argv=None):
+    return run(parse_args(argv), GpuEnv())
+
+
+def run(args, env):
     import numpy as np
     import torch
 
@@ -93,33 +145,21 @@ def main(argv=None):
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     dist = None
-    emu = args.emulate
     if world > 1:
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        if emu:
-            dist.init_process_group("gloo")
-        else:
-            torch.cuda.set_device(local)
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        env.init_process_group(dist, local)
     assert world == max(args.gpus, 1), f"--gpus {args.gpus} but WORLD_SIZE={world}"
-    dev = torch.device("cpu") if emu else torch.device("cuda", local)
-    if not emu:
-        torch.cuda.set_device(dev)
+    dev = env.device(local)
 
     import xrft_amd as xrft
-    from xrft_amd import _lib, api
+    from xrft_amd import api
     from xrft_amd import dist as xdist
 
-    if emu:  # CPU test of the rank logic only (never a measurement): the emulated build of the same C ABI
-        sys.path.insert(0, os.path.join(REPO, "tests", "emu"))
-        import build_emu
-
-        _lib._load_for_testing(build_emu.build())
-    else:
-        _lib.load()  # no fallback: raises if the HIP library is missing
+    env.load_library()
+    ranks_reported = dist.get_world_size() if dist is not None else 1  # what the process group (RCCL on GPUs) says, not the env
     ny, nx = args.ny, args.nx
     default_shape = (args.ny, args.nx) == (4096, 4096)
     if args.workload == "c4" and default_shape:
@@ -161,7 +201,7 @@ def main(argv=None):
             return xrft.dft(da, dim="x")
     else:
         nbins = min(ny, nx) // 4
-        collective = {"op": "all_gather", "backend": "gloo" if emu else "nccl (RCCL over xGMI)",
+        collective = {"op": "all_gather", "backend": env.backend_label,
                       "bytes_per_rank": int(-(-nt_total // world) * nbins * 16), "per_step": 2}
 
         def step():  # BASELINE.json configs[3]: cross spectrum (stays sharded) + isotropic power spectra of the two fields (gathered)
@@ -174,12 +214,10 @@ def main(argv=None):
             return cs, ia, ib
 
     def barrier():
-        if not emu:
-            torch.cuda.synchronize(dev)
+        env.sync(dev)
         if dist is not None:
             dist.barrier()
-        if not emu:
-            torch.cuda.synchronize(dev)
+        env.sync(dev)
 
     # setup (not a step): prime torch's caching allocator so that no hipMalloc of a 4 GiB output lands in the timed
     # region -- a step holds the previous result while the next one is produced, i.e. two output blocks are live
@@ -234,19 +272,25 @@ def main(argv=None):
             k_achieved = bpp_prof * pts_per_launch / avg_s
             kernel_ms = sum(v[1] for v in kern.values()) / args.steps
             path_achieved = bpp * value * 1e9 / world  # B/s per GPU
-            # HBM traffic of one step from the committed PMC profile of this same command (rocprofv3 cannot run inside the
-            # timed process): measured bytes per slab, all kernels, x slabs per step
+            # HBM traffic of one step: rocprofv3 cannot run inside the timed process, so the figure comes from the committed PMC
+            # profile of this same command (scripts/gpu_profile_r03.sh, --nt 64) -- and only if that profile was taken on the
+            # kernels that just ran: it is stamped with the SHA-1 of xrft_amd/csrc, a mismatch leaves traffic null
             traffic = None
             tnote = None
             ceiling = None
             try:
-                with open(os.path.join(REPO, "profiles", "r02_traffic.json")) as fh:
+                with open(os.path.join(REPO, "profiles", "r03_traffic.json")) as fh:
                     tj = json.load(fh)
-                traffic = tj["path_hbm_bytes_per_slab"] * nt if args.workload == "ps" and (ny, nx) == (4096, 4096) else None
-                tnote = tj.get("note")
-                ceiling = tj.get("two_pass_ceiling")
-            except Exception:
-                traffic = None
+                ceiling = tj.get("two_pass_floor")
+                if args.workload == "ps" and (ny, nx) == (4096, 4096):
+                    if tj.get("csrc_sha1") == csrc_sha1():
+                        traffic = tj["path_hbm_bytes_per_slab"] * nt
+                        tnote = tj.get("note")
+                    else:
+                        tnote = ("profiles/r03_traffic.json was measured on other kernel sources (csrc SHA-1 "
+                                 f"{str(tj.get('csrc_sha1'))[:12]} != {csrc_sha1()[:12]}): re-run scripts/gpu_profile_r03.sh")
+            except Exception as e:
+                tnote = f"no traffic profile: {e!r}"
             roof = {
                 "bound": "hbm", "achieved": round(path_achieved / 1e9, 2), "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                 "frac": round(path_achieved / HBM_PEAK, 4),
@@ -266,12 +310,12 @@ def main(argv=None):
                 "bytes_per_point": bpp,
                 "kernels_ms_per_step": {k: round(v[1] / args.steps, 3) for k, v in kern.items()},
                 "sum_kernels_ms_per_step": round(kernel_ms, 3),
-                "two_pass_ceiling": ceiling,
+                "two_pass_floor": ceiling,
             }
         # ---- CPU baseline (the oracle on a bounded sample, 1 thread) + parity of the same slabs
         cpu = None
         parity = None
-        if args.cpu_slabs > 0 and world == 1 and args.workload == "ps" and not emu:
+        if args.cpu_slabs > 0 and world == 1 and args.workload == "ps" and env.measures:
             from oracle import xrft_oracle as oracle
 
             try:
@@ -342,13 +386,12 @@ def main(argv=None):
         out = {
             "metric": metric, "value": round(value, 3), "unit": "GFFT/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
-            "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": "f64" if args.workload == "c5" else "f32", "data": "synthetic",
+            "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": "f64" if args.workload == "c5" else "f32", "data": env.data_label,
             "config": {"workload": wl, "nt_per_gpu": nt, "nt_total": nt_total, "ny": ny, "nx": nx, "parallelism": par,
-                       "collective": collective, "slabs_per_s": round(nt_total * args.steps / dt, 2)},
+                       "collective": collective, "slabs_per_s": round(nt_total * args.steps / dt, 2),
+                       "ranks_in_process_group": ranks_reported, "process_group_backend": env.backend if dist is not None else None},
             "roofline": roof, "cpu_baseline": cpu, "parity_max_rel_err_vs_oracle": parity,
         }
-        if emu:
-            out["data"] = "synthetic (EMULATED library on CPU: rank-logic test, not a measurement)"
         if plan is not None:
             out["plan"] = plan.describe().strip().split("\n")
     if dist is not None:

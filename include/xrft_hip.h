@@ -190,6 +190,12 @@ int xrfthip_gather_axis(int32_t elem_bytes, int64_t outer, int64_t n_out, int64_
  * (numpy.fft takes any length: xrft.py:398-447). */
 int xrfthip_table_mul(int32_t dtype, int64_t batch, int64_t n_in, int64_t n_out, const void* d_in, const void* d_table, void* d_out, void* stream);
 
+/* d_out[o][i] = scale * sum_k d_in[o][k][i] over [outer][n][inner] -> [outer][inner], same dtype (F32|F64|C64|C128), accumulated in float64
+ * in the order k = 0, 1, ...: the sum / mean over a batch dimension (scale = 1 / n), bit-reproducible.  What the reference's users do with
+ * batches of isotropic spectra (`iso_ps.mean("time")`, xrft/tests/test_xrft.py:1011-1013) and, with scale = 1 / (slabs of ALL ranks), the
+ * local term of the multi-GPU batch mean (xrft_amd/dist.py: one all_reduce(SUM) of nbins values finishes it). */
+int xrfthip_reduce_axis(int32_t dtype, int64_t outer, int64_t n, int64_t inner, const void* d_in, void* d_out, double scale, void* stream);
+
 /* Stand-alone radial bin-sum of an existing spectrum (xrft.isotropize, xrft.py:948-1010):
  * d_in [batch][ny][nx] (dtype F32|F64|C64|C128), d_binmap device int32 [ny][nx] (bin of each sample, < 0 = none),
  * d_iso float64|complex128 [batch][nbins] (every entry written).  The sums are bit-reproducible (per-workgroup integer

@@ -1,5 +1,5 @@
 #!/bin/bash
-# PMC counter passes for the bench workload (--nt 8). Usage: gpu_pmc_yf.sh <tag> [passes...]
+# PMC counter passes for the bench workload (--nt ${PMC_NT:-64}: the bench batch). Usage: gpu_pmc_yf.sh <tag> [passes...]
 cd "$GRAFT_REPO_ROOT" || exit 1
 TAG=${1:-r02}; shift
 PASSES=${@:-sq1 sq2 fetch write grbm}
@@ -8,7 +8,7 @@ export TMPDIR=/tmp
 cd /tmp
 run() {
   name=$1; shift
-  timeout 600 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d "$GRAFT_REPO_ROOT/gpurun_out/pmc_$TAG/$name" -o p -- python "$GRAFT_REPO_ROOT/bench.py" --steps 1 --warmup 1 --nt 8 --cpu-slabs 0 --no-profile > "$GRAFT_REPO_ROOT/gpurun_out/pmc_$TAG/$name.log" 2>&1
+  timeout 600 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d "$GRAFT_REPO_ROOT/gpurun_out/pmc_$TAG/$name" -o p -- python "$GRAFT_REPO_ROOT/bench.py" --steps 1 --warmup 1 --nt ${PMC_NT:-64} --cpu-slabs 0 --no-profile > "$GRAFT_REPO_ROOT/gpurun_out/pmc_$TAG/$name.log" 2>&1
   echo "pass $name rc=$?"
 }
 for p in $PASSES; do

@@ -1,6 +1,7 @@
 """bench.py's rank logic (sharding for weak / strong scaling, barriers, max-over-ranks timing, the c4 workload's all_gather)
-run as two gloo processes on the CPU with the emulated library and tiny shapes -- so that the first real multi-GPU run
-is not the first run of this code.  Nothing here is a measurement."""
+run as two gloo processes on the CPU with the emulated library and tiny shapes (tests/bench_ranks_harness.py hands bench.run()
+a CPU environment; bench.py has no such switch) -- so that the first real multi-GPU run is not the first run of this code.
+Nothing here is a measurement."""
 import json
 import os
 import socket
@@ -27,8 +28,8 @@ def _run(world, extra):
 
     build_emu.build()  # once, before the ranks race for it
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
-           "--master-port", str(_free_port()), os.path.join(REPO, "bench.py"), "--gpus", str(world), "--steps", "2", "--warmup", "1",
-           "--ny", "256", "--nx", "256", "--emulate", "--cpu-slabs", "0"] + extra
+           "--master-port", str(_free_port()), os.path.join(HERE, "bench_ranks_harness.py"), "--gpus", str(world), "--steps", "2", "--warmup", "1",
+           "--ny", "256", "--nx", "256", "--cpu-slabs", "0"] + extra
     env = dict(os.environ, OMP_NUM_THREADS="1", XRFT_EMU_THREADS="2")
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=REPO)
     assert r.returncode == 0, r.stderr[-3000:]
@@ -41,6 +42,7 @@ def _run(world, extra):
 def test_bench_two_ranks_power_spectrum(scaling):
     out = _run(2, ["--nt", "3", "--scaling", scaling])
     assert out["n_gpus"] == 2 and out["scaling"] == scaling and out["unit"] == "GFFT/s" and out["value"] > 0
+    assert out["config"]["ranks_in_process_group"] == 2 and "EMULATED" in out["data"]
     cfg = out["config"]
     if scaling == "weak":
         assert cfg["nt_per_gpu"] == 3 and cfg["nt_total"] == 6
@@ -61,3 +63,9 @@ def test_bench_two_ranks_c5_float64():
     out = _run(2, ["--nt", "3", "--workload", "c5", "--ny", "360", "--nx", "360", "--scaling", "strong"])
     assert out["n_gpus"] == 2 and out["dtype"] == "f64" and "fp64" in out["metric"] and out["config"]["nt_total"] == 3
     assert "fastm_cols" in out["roofline"]["kernels_ms_per_step"] and out["roofline"]["bytes_per_point"] == 16.0
+
+
+def test_bench_has_no_emulator_switch():
+    """bench.py measures on the GPU or not at all: no flag, environment variable or import reaches the emulated test build."""
+    src = open(os.path.join(REPO, "bench.py")).read()
+    assert "--emulate" not in src and "_load_for_testing" not in src and "build_emu" not in src

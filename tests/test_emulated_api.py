@@ -436,3 +436,14 @@ def test_one_axis_not_contiguous_fast_kernel(shape, dtype):
 def test_short_contiguous_axis_fast_kernel(shape, dtype):
     """fastm_xonly_kernel (csrc/fastm.h): fft / power_spectrum along the last axis, rows packed in pairs."""
     cases.run_xonly_fast_cases(shape, dtype)
+
+
+@pytest.mark.parametrize("n", [256, 360])
+def test_adversarial_detrend_float32(n):
+    """Outliers in the rows the float32 kernels estimate the trend from, offsets / trends far above the signal, constant
+    columns (fasty.h at 256, fastm.h float32 at 360): every norm of cases.check, per bin down to 1e-6 of the peak."""
+    cases.run_adversarial_detrend(n)
+
+
+def test_reduce_axis_kernel():
+    cases.run_reduce_axis_cases()

@@ -150,6 +150,18 @@ def test_config3_ps_4096_f32_vs_oracle():
     assert np.abs(g - r).sum() / np.abs(r).sum() < 1e-4
 
 
+@pytest.mark.parametrize("n", [256, 360, 1024, 1440])
+def test_adversarial_detrend_float32(n):
+    """Outliers in the rows the float32 kernels estimate the trend from, offsets / trends 1e4 ... 1e6 times the signal, constant
+    columns, steps (fasty.h: 256, 1024; fastm.h float32: 360, 1440): max norm, L1 norm and every bin above 1e-6 of the peak."""
+    cases.run_adversarial_detrend(n)
+
+
+def test_adversarial_detrend_float32_headline_shape():
+    """The same at 4096^2 (the oracle's plane fit takes ~8 s per slab: three fields, linear detrend + Hann)."""
+    cases.run_adversarial_detrend(4096, detrends=("linear",), only=("spikes_in_the_quarter_rows", "offset_1e6", "trend_1e4_times_noise"))
+
+
 @pytest.mark.parametrize("ny,nx,nt,det,win,shift", [
     (1024, 1024, 5, "linear", "hann", True),
     (2048, 2048, 3, "linear", "hann", True),
@@ -804,3 +816,53 @@ def test_fftmod_backend_object_on_gpu():
     assert np.abs(f[:2].cpu().numpy() - want).max() / np.abs(want).max() < 1e-5
     back = fftmod.irfftn(fftmod.rfftn(x, axes=[1, 2]), axes=[1, 2])
     assert float((back - x).abs().max()) < 1e-4
+
+
+def test_reduce_axis_kernel():
+    cases.run_reduce_axis_cases()
+
+
+def test_collective_leg_on_one_gpu_through_rccl():
+    """The collective leg of SURVEY.md 8e on the device: a world_size-1 "nccl" group (= RCCL on ROCm) is initialised and the
+    isotropic block goes through xrft_amd.dist -- all_gather of float64 and of complex128 (through its real view) device tensors,
+    the batch mean as one library kernel + all_reduce -- so that the first multi-GPU run is not the first RCCL init."""
+    import socket
+
+    import torch.distributed as dist
+
+    import xrft_amd as xa
+    from xrft_amd import dist as xd
+
+    created = False
+    if not dist.is_initialized():
+        s = socket.socket()
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+        s.close()
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+        created = True
+    try:
+        assert dist.get_backend() == "nccl" and dist.get_world_size() == 1
+        nt, n = 6, 256
+        g = torch.Generator(device="cuda").manual_seed(301)
+        a = torch.randn((nt, n, n), dtype=torch.float32, device="cuda", generator=g)
+        b = 0.5 * a + torch.randn((nt, n, n), dtype=torch.float32, device="cuda", generator=g)
+        c = {"time": np.arange(nt), "y": np.arange(n) * 0.5, "x": np.arange(n) * 0.5}
+        da, db = xa.DataArray(a, ("time", "y", "x"), c), xa.DataArray(b, ("time", "y", "x"), c)
+        ips = xa.isotropic_power_spectrum(xd.shard(da, "time"), dim=["y", "x"], detrend="linear", window="hann")
+        ics = xa.isotropic_cross_spectrum(xd.shard(da, "time"), xd.shard(db, "time"), dim=["y", "x"], window="hann")
+        assert ips.data.is_cuda and ics.data.is_cuda and ics.data.dtype == torch.complex128
+        gp = xd.all_gather_batch(ips, "time", nt)
+        gc = xd.all_gather_batch(ics, "time", nt)
+        assert gp.data.is_cuda and torch.equal(gp.data, ips.data) and torch.equal(gc.data, ics.data)
+        mp_ = xd.batch_mean_allreduce(ips, "time", nt)
+        mc = xd.batch_mean_allreduce(ics, "time", nt)
+        assert mp_.data.is_cuda and mp_.dims == ("freq_r",)
+        np.testing.assert_allclose(mp_.values, ips.values.mean(axis=0), rtol=1e-13)
+        np.testing.assert_allclose(mc.values, ics.values.mean(axis=0), rtol=1e-12)
+        ref = o.isotropic_power_spectrum(o.OArr(a.cpu().numpy(), ("time", "y", "x"), c), dim=["y", "x"], detrend="linear", window="hann")
+        assert np.abs(mp_.values - ref.values.mean(axis=0)).max() / np.abs(ref.values).max() < 3e-4
+    finally:
+        if created:
+            dist.destroy_process_group()

@@ -19,15 +19,15 @@ HALF_X, SHIFT_Y, SHIFT_X, ISHIFT_Y, ISHIFT_X, FLIP_Y, FLIP_X = 0x1, 0x2, 0x4, 0x
 REALDIM_X2, ISO, NO_SPECTRUM_OUT = 0x80, 0x100, 0x200
 INVERSE, C2R_X, PHASE_IN = 0x400, 0x800, 0x1000
 UNSUPPORTED_LENGTH = -2  # xrfthip_status
-AXIS_Y = 0x2000
-FLIP0_Y, FLIP0_X = 0x4000, 0x8000  # cross spectra: flip field 0 (FLIP_Y / FLIP_X then flip field 1)  # transform y of [batch][ny][nx] in place (a middle or first axis of the array), no transposed copy
+AXIS_Y = 0x2000  # transform y of [batch][ny][nx] in place (a middle or first axis of the array), no transposed copy
+FLIP0_Y, FLIP0_X = 0x4000, 0x8000  # cross spectra: flip field 0 (FLIP_Y / FLIP_X then flip field 1)
 
 EXPORTS = [
     "xrfthip_version", "xrfthip_strerror", "xrfthip_last_hip_error", "xrfthip_plan_create",
     "xrfthip_plan_destroy", "xrfthip_plan_set_window", "xrfthip_plan_set_phase", "xrfthip_plan_set_binmap",
     "xrfthip_plan_set_profiling", "xrfthip_plan_profile_read", "xrfthip_workspace_bytes", "xrfthip_plan_describe", "xrfthip_exec", "xrfthip_detrend_workspace_bytes",
     "xrfthip_detrend", "xrfthip_detrend3", "xrfthip_spectrum_tail", "xrfthip_spectrum_tail_axis", "xrfthip_gather_axis", "xrfthip_isotropize",
-    "xrfthip_isotropize_workspace_bytes", "xrfthip_table_mul",
+    "xrfthip_isotropize_workspace_bytes", "xrfthip_table_mul", "xrfthip_reduce_axis",
 ]
 
 
@@ -75,6 +75,7 @@ def _bind(dll):
     dll.xrfthip_spectrum_tail_axis.argtypes = [i32, i64, i64, i64, i32, vp, vp, vp, C.c_double, vp]
     dll.xrfthip_gather_axis.argtypes = [i32, i64, i64, i64, i64, vp, i64, vp, vp, vp]
     dll.xrfthip_table_mul.argtypes = [i32, i64, i64, i64, vp, vp, vp, vp]
+    dll.xrfthip_reduce_axis.argtypes = [i32, i64, i64, i64, vp, vp, C.c_double, vp]
     dll.xrfthip_isotropize_workspace_bytes.restype = sz
     dll.xrfthip_isotropize_workspace_bytes.argtypes = [i32, i64, i64, i64, i32]
     dll.xrfthip_isotropize.argtypes = [i32, i64, i64, i64, vp, vp, i32, vp, vp, sz, vp]

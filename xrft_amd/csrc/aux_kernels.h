@@ -298,6 +298,21 @@ __global__ void __launch_bounds__(256) table_mul_kernel(const void* in, const C2
     }
 }
 
+// out[o][i] = scale * sum_k in[o][k][i] over [outer][n][inner] (complex data: inner counts real components), the terms added in
+// the order k = 0, 1, ... in float64: a mean / sum over a batch dimension whose result does not depend on how the launch was
+// scheduled (the reference's users average isotropic spectra over the batch: xrft/tests/test_xrft.py:1011-1013, `.mean("d0")`).
+template <typename T>
+__global__ void __launch_bounds__(256) reduce_axis_kernel(const T* __restrict__ in, T* __restrict__ out, long long outer, long long n, long long inner, double scale) {
+    const long long total = outer * inner;
+    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
+        const long long o = e / inner, i = e - o * inner;
+        const T* src = in + o * n * inner + i;
+        double acc = 0.0;
+        for (long long k = 0; k < n; ++k) acc += (double)src[k * inner];
+        out[e] = (T)(acc * scale);
+    }
+}
+
 // Radial bin sums of a stored spectrum (xrft.isotropize, xrft.py:948-1010; _groupby_bins_agg / _binned_agg :877-945),
 // BIT-REPRODUCIBLE: floating-point atomics would make a sum depend on the order in which waves arrive.  A workgroup owns one
 // contiguous chunk of a slab and makes two sweeps over it: (1) the largest exponent per bin (atomicMax on the high word of the

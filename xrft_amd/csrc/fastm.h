@@ -273,17 +273,17 @@ __global__ void __launch_bounds__((MGeom<T, NY>::THR), (MGeom<T, NY>::WPS)) fast
     CT a[R0];
     T wyv[R0];
     // float32: what is subtracted HERE, in y-space, only has to take the bulk of the trend out so that nothing cancels in float32 --
-    // a line per column estimated from KREF rows at the top and at the bottom (every thread of the sequence loads them itself:
-    // the same addresses in all lanes), rounded to a power-of-two grid on which T + S i is exact (fasty.h); pass 2 corrects
-    // whatever was subtracted.  float64 subtracts nothing.
+    // a line per column estimated from the medians of the KREF adjacent rows around ny/4 and around 3 ny/4 (away from the edges,
+    // robust to a spike in one row; every thread of the sequence loads them itself: the same addresses in all lanes), rounded to
+    // a power-of-two grid on which T + S i is exact (fasty.h); pass 2 corrects whatever was subtracted.  float64 subtracts nothing.
     constexpr bool PRE = DET && sizeof(T) == 4;
-    constexpr int KREF = 2;
+    constexpr int KREF = 3, ITOP = NY / 4, IBOT = 3 * NY / 4;
     CT rt[KREF], rb[KREF];
     if (PRE) {
 #pragma unroll
         for (int k = 0; k < KREF; ++k) {
-            rt[k] = *reinterpret_cast<const CT*>(src + ((unsigned)g * (unsigned)sizeof(CT) + rowb * (unsigned)k));
-            rb[k] = *reinterpret_cast<const CT*>(src + ((unsigned)g * (unsigned)sizeof(CT) + rowb * (unsigned)(NY - KREF + k)));
+            rt[k] = *reinterpret_cast<const CT*>(src + ((unsigned)g * (unsigned)sizeof(CT) + rowb * (unsigned)(ITOP - 1 + k)));
+            rb[k] = *reinterpret_cast<const CT*>(src + ((unsigned)g * (unsigned)sizeof(CT) + rowb * (unsigned)(IBOT - 1 + k)));
         }
     }
 #pragma unroll
@@ -297,14 +297,14 @@ __global__ void __launch_bounds__((MGeom<T, NY>::THR), (MGeom<T, NY>::WPS)) fast
     constexpr double IBAR = 0.5 * (NY - 1);
     float Tl[2] = {0.f, 0.f}, Sl[2] = {0.f, 0.f};
     if (PRE) {
-        float mt[2] = {0.f, 0.f}, mb[2] = {0.f, 0.f};
-#pragma unroll
-        for (int k = 0; k < KREF; ++k) { mt[0] += (float)rt[k].re; mt[1] += (float)rt[k].im; mb[0] += (float)rb[k].re; mb[1] += (float)rb[k].im; }
+        auto med3 = [](float x, float y, float z) { return fmaxf(fminf(x, y), fminf(fmaxf(x, y), z)); };
+        const float mt[2] = {med3((float)rt[0].re, (float)rt[1].re, (float)rt[2].re), med3((float)rt[0].im, (float)rt[1].im, (float)rt[2].im)};
+        const float mb[2] = {med3((float)rb[0].re, (float)rb[1].re, (float)rb[2].re), med3((float)rb[0].im, (float)rb[1].im, (float)rb[2].im)};
 #pragma unroll
         for (int c = 0; c < 2; ++c) {
-            const float top = mt[c] * (1.0f / KREF), bot = mb[c] * (1.0f / KREF);  // means at i = (KREF-1)/2 and ny-1-(KREF-1)/2
-            const float Se = p.detrend == 2 ? (bot - top) * (1.0f / (NY - KREF)) : 0.f;
-            const float Te = p.detrend == 2 ? top - Se * (0.5f * (KREF - 1)) : 0.5f * (top + bot);
+            const float top = mt[c], bot = mb[c];  // the column near i = ITOP and i = IBOT
+            const float Se = p.detrend == 2 ? (bot - top) * (1.0f / (IBOT - ITOP)) : 0.f;
+            const float Te = p.detrend == 2 ? top - Se * (float)ITOP : 0.5f * (top + bot);
             const float mag = fabsf(Te) + fabsf(Se) * (float)NY;
             const float C = __uint_as_float((__float_as_uint(mag) & 0x7f800000u) + (3u << 23)) * 1.5f;  // rounds to 2^(e-20), 2^e <= mag
             Tl[c] = (Te + C) - C; Sl[c] = (Se + C) - C;

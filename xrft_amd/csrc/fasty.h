@@ -37,6 +37,65 @@ __device__ __forceinline__ void xrft_store_nt(float* dst, F4 v) {
 #endif
 }
 
+// FastY::tune (XRFTHIP_YTUNE, read once at plan creation): cache policies of the four streams and a start stagger, kept as knobs
+// because the right setting is a property of the memory system, measured (scripts/tune_yf.py -> profiles/r03_tune_yf.txt):
+//   bits 0-1  pass 1, stores of the intermediate: 0 non-temporal, 1 plain, 2 write-through (sc1)
+//   bit  2    pass 1, loads of the input non-temporal
+//   bit  3    pass 2, loads of the intermediate non-temporal
+//   bit  4    pass 2, stores of the result plain instead of non-temporal
+//   bits 8-15 the second workgroup of every CU (blocks 256..511 of a launch) starts n x 3.4 us late: the two residents of a CU
+//             then run their load / transform / store phases out of step for the whole launch
+// The product build compiles the default in (a run-time policy in the store loops costs the column kernel a spilled register);
+// scripts/build_tune_yf.sh builds a second library with -DXRFT_YTUNE_RT whose kernels read FastY::tune, for scripts/tune_yf.py.
+constexpr long long kYTuneDefault = 0;
+#ifdef XRFT_YTUNE_RT
+#define XRFT_YTUNE(p) ((p).tune)
+#else
+#define XRFT_YTUNE(p) ((int)kYTuneDefault)
+#endif
+
+// 16-byte store with a run-time cache policy: 0 non-temporal, 1 plain, 2 write-through to memory (sc1)
+__device__ __forceinline__ void xrft_store_pol(float* dst, F4 v, int pol) {
+#ifdef XRFT_EMULATE
+    *reinterpret_cast<F4*>(dst) = v;
+#else
+    typedef float v4f __attribute__((ext_vector_type(4)));
+    const v4f t = {v.x, v.y, v.z, v.w};
+    if (pol == 0) __builtin_nontemporal_store(t, reinterpret_cast<v4f*>(dst));
+    else if (pol == 1) *reinterpret_cast<v4f*>(dst) = t;
+    else __builtin_amdgcn_raw_buffer_store_b128(t, __builtin_amdgcn_make_buffer_rsrc(dst, 0, 16, 0x00020000), 0, 0, 16);
+#endif
+}
+__device__ __forceinline__ F4 xrft_load_pol(const char* src, bool nt) {
+#ifdef XRFT_EMULATE
+    return *reinterpret_cast<const F4*>(src);
+#else
+    typedef float v4f __attribute__((ext_vector_type(4)));
+    if (!nt) return *reinterpret_cast<const F4*>(src);
+    const v4f t = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(src));
+    F4 r; r.x = t.x; r.y = t.y; r.z = t.z; r.w = t.w;
+    return r;
+#endif
+}
+__device__ __forceinline__ cf xrft_load8_pol(const char* src, bool nt) {
+#ifdef XRFT_EMULATE
+    return *reinterpret_cast<const cf*>(src);
+#else
+    typedef float v2f __attribute__((ext_vector_type(2)));
+    if (!nt) return *reinterpret_cast<const cf*>(src);
+    const v2f t = __builtin_nontemporal_load(reinterpret_cast<const v2f*>(src));
+    return mk<float>(t.x, t.y);
+#endif
+}
+// start stagger (FastY::tune bits 8-15): blocks 256..511 = the second resident of every CU at launch start
+__device__ __forceinline__ void xrft_stagger(int tune) {
+#ifndef XRFT_EMULATE
+    const int n = (tune >> 8) & 0xff;
+    if (n && blockIdx.x >= 256u && blockIdx.x < 512u)
+        for (int i = 0; i < n; ++i) __builtin_amdgcn_s_sleep(127);
+#endif
+}
+
 struct FastY {
     const float* in;         // [slab][ny][nx] float32
     cf* w2;                  // intermediate, see above
@@ -46,7 +105,7 @@ struct FastY {
     const cf* tw_y;          // W_ny^k
     const float* win_y;      // never null (ones when there is no window)
     const float* win_x;
-    double* colfit;          // [slab][nx][4]: per column sum d, sum (i - ibar) d (exact), and the line pass 1 subtracted as (value at ibar, slope)
+    double* colfit;          // [slab][nx][4]: per column sum r, sum (i - ibar) r of the residual r = d - line, and the line pass 1 subtracted as (value at ibar, slope)
     const float* corr;       // [slab][nx][2]: wx[x] * (subtracted line - plane fit) as (offset at ibar, slope), from fasty_fit_kernel
     const float* corr_b;     // ... of field 1 (cross spectra)
     const cf* ph_y;          // complex modes: true-phase factor per unshifted ky (times (-1)^ky for an ifftshifted input), never null
@@ -57,7 +116,7 @@ struct FastY {
     int realdim2;            // ... and 0 < kx < nx/2 counts twice (xrft.py:673-682)
     const cf* what0;         // FFT_y(wy)[ky], ky < nrow_pad (zero beyond ny/2)
     const cf* what1;         // FFT_y(wy * (i - (ny-1)/2))[ky]
-    const unsigned* tcodes;  // radial bins in pass 2's register order: (direct + 1) | (mirror + 1) << 16
+    const unsigned* tcodes;  // radial bins [ky < nrow_pad][kx] in natural order: (direct + 1) | (mirror + 1) << 16 (0: not binned)
     double* iso;             // [slab][nbins] per-bin sums (ISO)
     double* iso_part;        // [slab][row workgroup][nbins (x2 complex)]: per-workgroup partial sums, reduced in order
     int nbins;
@@ -68,6 +127,7 @@ struct FastY {
     int nslab;
     int shift_y, shift_x;    // 0 or n/2
     float scale;
+    int tune;                // see kYTuneDefault
 };
 
 // phase-ablation bits for profiling builds (scripts/gpu_ablate_yf.sh compiles variants with -DXRFT_YDBG=bits); 0 in the product
@@ -177,6 +237,7 @@ __global__ void __launch_bounds__(YCols<NY>::THR, YCols<NY>::THR / 128) fasty_co
     const int tid = threadIdx.x, g = tid % GY, u = tid / GY;
     cf* mine = lds + g * GSTR;
     cf* tw2 = lds + GY * GSTR;
+    xrft_stagger(XRFT_YTUNE(p));
     fill_tw2<NY>(tw2, p.tw_y, tid, THR);
     // unit = (slab, column block).  Blocks b, b+8, b+16, ... run on one XCD (round-robin dispatch): give each XCD a
     // contiguous range of column blocks, so that the workgroups sharing a 128-byte line of the input share an L2.
@@ -198,7 +259,7 @@ __global__ void __launch_bounds__(YCols<NY>::THR, YCols<NY>::THR / 128) fasty_co
     // ---- detrend, fused, nothing on the critical path.  The plane of xrft/detrend.py:100-113 needs sums over the whole
     // slab, which exist only after this pass.  What is subtracted HERE, in y-space, only has to take the bulk of the trend
     // out (so that nothing cancels catastrophically in float32) and to be one line T + S i per column: it is an estimate
-    // from KREF rows at the top and at the bottom of the column, which every thread of the group loads itself (the same
+    // from a few reference rows of the column (below), which every thread of the group loads itself (the same
     // addresses in all lanes of a wave: one transaction) BEFORE its own 16 rows, so that the constants are ready when the
     // rows arrive.  Pass 2 adds the difference to the true plane back in the spectral domain,
     // wx[x] (alpha_x What0[ky] + gamma_x What1[ky]) with What0 = FFT(wy), What1 = FFT(wy (i - ibar)), from the exact column sums
@@ -207,33 +268,34 @@ __global__ void __launch_bounds__(YCols<NY>::THR, YCols<NY>::THR / 128) fasty_co
     // (A three-level LDS reduction in front of the transforms, with the rows held in registers meanwhile, cost 7 of 36 us
     // per slab, most of it through the 17 VGPRs it made the kernel spill: 36 MB of scratch traffic per slab.)
     constexpr double IBAR = 0.5 * (NY - 1);
-    constexpr int KREF = 2, NW = THR / 64;
+    // reference rows: KREF ADJACENT rows around ny/4 and around 3 ny/4, the per-column MEDIAN of each triple.  Away from the edges
+    // (where real fields carry their artefacts: coast lines, padding, tapering) and robust to a spike in any single row: what the
+    // estimate misses costs float32 digits in the ky = 0, +-1 bins, where pass 2 has to cancel it (round 2 took the mean of rows
+    // 0, 1 and ny-2, ny-1: 1e3-spikes there left 4e-3 relative errors in bins 1e-6 of the peak, tests/cases.py adversarial fields)
+    constexpr int KREF = 3, NW = THR / 64, ITOP = NY / 4, IBOT = 3 * NY / 4;
     double* part = reinterpret_cast<double*>(tw2 + 16 * G::R3);  // [wave][g][8]
-    float T[4] = {0.f, 0.f, 0.f, 0.f}, S[4] = {0.f, 0.f, 0.f, 0.f};
+    float T[4] = {0.f, 0.f, 0.f, 0.f}, S[4] = {0.f, 0.f, 0.f, 0.f}, S2[4] = {0.f, 0.f, 0.f, 0.f};
     F4 rt[KREF], rb[KREF];
     if (DET) {
         const unsigned offg = 16u * (unsigned)g, rowb = (unsigned)p.nx * 4u;
 #pragma unroll
         for (int k = 0; k < KREF; ++k) {
-            rt[k] = *reinterpret_cast<const F4*>(src + (offg + rowb * (unsigned)k));
-            rb[k] = *reinterpret_cast<const F4*>(src + (offg + rowb * (unsigned)(NY - KREF + k)));
+            rt[k] = *reinterpret_cast<const F4*>(src + (offg + rowb * (unsigned)(ITOP - 1 + k)));
+            rb[k] = *reinterpret_cast<const F4*>(src + (offg + rowb * (unsigned)(IBOT - 1 + k)));
         }
     }
     F4 raw[16];
 #pragma unroll
-    for (int q = 0; q < 16; ++q) raw[q] = *reinterpret_cast<const F4*>(src + (off0 + rstep * (unsigned)q));
+    for (int q = 0; q < 16; ++q) raw[q] = xrft_load_pol(src + (off0 + rstep * (unsigned)q), (XRFT_YTUNE(p) & 4) != 0);
     if (DET) {
-        float mt[4] = {0.f, 0.f, 0.f, 0.f}, mb[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int k = 0; k < KREF; ++k) {
-            mt[0] += rt[k].x; mt[1] += rt[k].y; mt[2] += rt[k].z; mt[3] += rt[k].w;
-            mb[0] += rb[k].x; mb[1] += rb[k].y; mb[2] += rb[k].z; mb[3] += rb[k].w;
-        }
+        auto med3 = [](float x, float y, float z) { return fmaxf(fminf(x, y), fminf(fmaxf(x, y), z)); };
+        const float mt[4] = {med3(rt[0].x, rt[1].x, rt[2].x), med3(rt[0].y, rt[1].y, rt[2].y), med3(rt[0].z, rt[1].z, rt[2].z), med3(rt[0].w, rt[1].w, rt[2].w)};
+        const float mb[4] = {med3(rb[0].x, rb[1].x, rb[2].x), med3(rb[0].y, rb[1].y, rb[2].y), med3(rb[0].z, rb[1].z, rb[2].z), med3(rb[0].w, rb[1].w, rb[2].w)};
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
-            const float top = mt[c] * (1.0f / KREF), bot = mb[c] * (1.0f / KREF);  // means at i = (KREF-1)/2 and ny-1-(KREF-1)/2
-            const float Se = p.detrend == 2 ? (bot - top) * (1.0f / (NY - KREF)) : 0.f;
-            const float Te = p.detrend == 2 ? top - Se * (0.5f * (KREF - 1)) : 0.5f * (top + bot);  // value of the line at i = 0
+            const float top = mt[c], bot = mb[c];  // the column near i = ITOP and i = IBOT
+            const float Se = p.detrend == 2 ? (bot - top) * (1.0f / (IBOT - ITOP)) : 0.f;
+            const float Te = p.detrend == 2 ? top - Se * (float)ITOP : 0.5f * (top + bot);  // value of the line at i = 0
             // The line is OUR choice (pass 2 corrects whatever is subtracted here), so both coefficients are rounded to one
             // coarse power-of-two grid 2^(e-20), 2^e <= |T| + |S| ny < 2^(e+1) (adding and subtracting C = 1.5 * 2^(e+3)
             // rounds to that grid): T + S i is then exact in float32 for every row, and x - (T + S i) has a single rounding,
@@ -242,39 +304,55 @@ __global__ void __launch_bounds__(YCols<NY>::THR, YCols<NY>::THR / 128) fasty_co
             const float mag = fabsf(Te) + fabsf(Se) * (float)NY;
             const float C = __uint_as_float((__float_as_uint(mag) & 0x7f800000u) + (3u << 23)) * 1.5f;
             T[c] = (Te + C) - C; S[c] = (Se + C) - C;
+            // The grid leaves the slope 8-9 bits: a residual line of up to 0.4 % of the trend (16 x the noise under a trend 1e4 x
+            // the noise at ny = 4096, which cost the ky = +-1 bins 2.5e-3 of relative error).  What the grid dropped of the slope,
+            // S2 = Se - S (exact: the two are within a factor two), leaves in a fused multiply-add, (x - L1(i)) - S2 i: the product
+            // is exact inside the fma and the one rounding is at the size of the result, so the line subtracted is exactly
+            // T + (S + S2) i with the slope at full precision (the offset's grid error is 2^-21 of the trend: nothing).
+            S2[c] = Se - S[c];
         }
         if (u == 0) {  // what is subtracted, as (offset at ibar, slope)
             double* cfp = p.colfit + ((size_t)slab * p.nx + x0) * 4;
 #pragma unroll
-            for (int c = 0; c < 4; ++c) { cfp[4 * c + 2] = (double)T[c] + (double)S[c] * IBAR; cfp[4 * c + 3] = (double)S[c]; }
+            for (int c = 0; c < 4; ++c) {
+                cfp[4 * c + 2] = (double)T[c] + ((double)S[c] + (double)S2[c]) * IBAR;
+                cfp[4 * c + 3] = (double)S[c] + (double)S2[c];
+            }
         }
     }
     cf a[16], b[16];
-    float f0[4] = {0.f, 0.f, 0.f, 0.f}, f1[4] = {0.f, 0.f, 0.f, 0.f};  // exact column sums, float32 over this thread's rows
+    // column sums of the RESIDUAL d - (T + S i), float32 over this thread's rows: the residual is noise-sized, so nothing is lost
+    // (sums of the raw samples lose the mean of a column to rounding once an offset or trend is >~ 1e4 times the signal: with
+    // 1e6 + N(0, 1) the 16-row partial sums sit at 2^24 and the ky = 0 row came out 90 % wrong); fasty_fit_kernel adds the
+    // subtracted line back in float64
+    float f0[4] = {0.f, 0.f, 0.f, 0.f}, f1[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int q = 0; q < 16; ++q) {
         const float fi = (float)(u + NT * q);
         const float wy = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(p.win_y) + (unsigned)(u + NT * q) * 4u);
+        const float v0 = DET ? fmaf(-S2[0], fi, raw[q].x - fmaf(S[0], fi, T[0])) : raw[q].x;
+        const float v1 = DET ? fmaf(-S2[1], fi, raw[q].y - fmaf(S[1], fi, T[1])) : raw[q].y;
+        const float v2 = DET ? fmaf(-S2[2], fi, raw[q].z - fmaf(S[2], fi, T[2])) : raw[q].z;
+        const float v3 = DET ? fmaf(-S2[3], fi, raw[q].w - fmaf(S[3], fi, T[3])) : raw[q].w;
         if (DET) {
             const float fq = (float)q;
-            f0[0] += raw[q].x; f1[0] = fmaf(fq, raw[q].x, f1[0]);
-            f0[1] += raw[q].y; f1[1] = fmaf(fq, raw[q].y, f1[1]);
-            f0[2] += raw[q].z; f1[2] = fmaf(fq, raw[q].z, f1[2]);
-            f0[3] += raw[q].w; f1[3] = fmaf(fq, raw[q].w, f1[3]);
+            f0[0] += v0; f1[0] = fmaf(fq, v0, f1[0]);
+            f0[1] += v1; f1[1] = fmaf(fq, v1, f1[1]);
+            f0[2] += v2; f1[2] = fmaf(fq, v2, f1[2]);
+            f0[3] += v3; f1[3] = fmaf(fq, v3, f1[3]);
         }
-        const float v0 = DET ? raw[q].x - fmaf(S[0], fi, T[0]) : raw[q].x;
-        const float v1 = DET ? raw[q].y - fmaf(S[1], fi, T[1]) : raw[q].y;
-        const float v2 = DET ? raw[q].z - fmaf(S[2], fi, T[2]) : raw[q].z;
-        const float v3 = DET ? raw[q].w - fmaf(S[3], fi, T[3]) : raw[q].w;
         a[q] = mk<float>(v0 * (wy * wx.x), v1 * (wy * wx.y));
         b[q] = mk<float>(v2 * (wy * wx.z), v3 * (wy * wx.w));
     }
     if (DET) {
-        double v[8];  // sum (i - ibar) d over i = u + NT q is (u - ibar) S0 + NT sum q d
+        // sum (i - ibar) r over i = u + NT q is (u - ibar) S0 + NT sum q r.  float32 through the wave (the sums are of noise-sized
+        // residuals: 1e-7 of the noise is lost; as float64 -- needed when these were sums of the raw samples -- the eight values
+        // were sixteen registers beside the two transforms' sixty-four and spilled), float64 from the per-wave table on
+        float v[8];
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
-            v[c] = (double)f0[c];
-            v[4 + c] = fma((double)u - IBAR, (double)f0[c], (double)NT * (double)f1[c]);
+            v[c] = f0[c];
+            v[4 + c] = fmaf((float)u - (float)IBAR, f0[c], (float)NT * f1[c]);
         }
 #pragma unroll
         for (int m = GY; m < 64; m <<= 1)
@@ -282,12 +360,16 @@ __global__ void __launch_bounds__(YCols<NY>::THR, YCols<NY>::THR / 128) fasty_co
             for (int c = 0; c < 8; ++c) v[c] += __shfl_xor(v[c], m);
         if ((tid & 63) < GY) {  // the lane with the wave's first u: lane = g
 #pragma unroll
-            for (int c = 0; c < 8; ++c) part[((tid >> 6) * GY + g) * 8 + c] = v[c];
+            for (int c = 0; c < 8; ++c) part[((tid >> 6) * GY + g) * 8 + c] = (double)v[c];
         }
     }
     if (!(XRFT_YDBG & 32)) fft_p2_pair<NY>(a, b, u, mine, p.tw_y, tw2);
-    if (DET && tid < 8 * GY) {  // the transforms' barriers have made every wave's partial sums visible
-        const int c = tid / GY, gg = tid % GY;
+    // (the lane indices are re-derived from an opaque copy of the thread index: carried from the top of the kernel through the
+    // transforms they were spilled -- 3 dwords per lane = 3 MB of scratch traffic per 4096^2 slab each way)
+    int tid2 = threadIdx.x;
+    XRFT_OPAQUE(tid2);
+    if (DET && tid2 < 8 * GY) {  // the transforms' barriers have made every wave's partial sums visible
+        const int c = tid2 / GY, gg = tid2 % GY;
         double acc = 0.0;
 #pragma unroll
         for (int w = 0; w < NW; ++w) acc += part[(w * GY + gg) * 8 + c];
@@ -296,26 +378,28 @@ __global__ void __launch_bounds__(YCols<NY>::THR, YCols<NY>::THR / 128) fasty_co
     // split the packed transforms: Ra[k] = (Z[k] + conj Z[N-k]) / 2, Rb[k] = (Z[k] - conj Z[N-k]) / (2i), k = u + NT q (q < 8)
     // and k = NY/2; (Ra, Rb) = two adjacent columns = one 16-byte store; lanes (u..u+RK-1, all g) complete a line
     char* __restrict__ w2s = reinterpret_cast<char*>(p.w2 + (size_t)slab * p.nrow_pad * p.nx);
+    const int g2 = tid2 % GY, u2 = tid2 / GY;
+    cf* mine2 = lds + g2 * GSTR;
 #pragma unroll
     for (int set = 0; set < 2; ++set) {
         const cf* z = set == 0 ? a : b;
 #pragma unroll
         for (int bb = 0; bb < G::NB; ++bb)
 #pragma unroll
-            for (int k3 = 0; k3 < G::R3; ++k3) mine[nat16(held_k<NY>(u, bb, k3))] = z[bb * G::R3 + k3];
+            for (int k3 = 0; k3 < G::R3; ++k3) mine2[nat16(held_k<NY>(u2, bb, k3))] = z[bb * G::R3 + k3];
         __syncthreads();
 #pragma unroll
         for (int q = 0; q < 9; ++q) {
-            const int k = u + NT * q;
-            if (q < 8 || u == 0) {
-                const cf zk = mine[nat16(k & (NY - 1))];
-                const cf zc = cconj(mine[nat16((NY - k) & (NY - 1))]);
+            const int k = u2 + NT * q;
+            if (q < 8 || u2 == 0) {
+                const cf zk = mine2[nat16(k & (NY - 1))];
+                const cf zc = cconj(mine2[nat16((NY - k) & (NY - 1))]);
                 const cf ra = cscale(zk + zc, 0.5f), rb = cscale(mul_mi(zk - zc), 0.5f);
-                const unsigned off = ((((unsigned)(k / Y::RK) * (unsigned)nxb + (unsigned)xb) * 2u + set) * Y::LBS) + (k % Y::RK) * (2 * GY) + 2 * g;
+                const unsigned off = ((((unsigned)(k / Y::RK) * (unsigned)nxb + (unsigned)xb) * 2u + set) * Y::LBS) + (k % Y::RK) * (2 * GY) + 2 * g2;
                 F4 o; o.x = ra.re; o.y = ra.im; o.z = rb.re; o.w = rb.im;
                 // non-temporal: the next reader is another kernel, a whole group of slabs later; kept out of L2 the lines leave
                 // it to the input, whose 128-byte lines are shared by four workgroups (PMC: 1.34x over-fetch with plain stores)
-                if (!(XRFT_YDBG & 64) || o.x == 1.2345f) xrft_store_nt(reinterpret_cast<float*>(w2s + off * 8u), o);
+                if (!(XRFT_YDBG & 64) || o.x == 1.2345f) xrft_store_pol(reinterpret_cast<float*>(w2s + off * 8u), o, XRFT_YTUNE(p) & 3);
             }
         }
         if (set == 0) __syncthreads();
@@ -349,14 +433,14 @@ __device__ __forceinline__ unsigned w2_offset(const FastY& p, int ky, int x) {
 }
 
 // float -> int64 fixed point with 40 fractional bits below 2^(eb - 127), eb = biased exponent of a bound |v| < 2^(eb - 126):
-// integer arithmetic only (no float64 <-> int64 conversions, which gfx950 emulates); truncates below 2^-40 of the bound
+// integer arithmetic only (no float64 <-> int64 conversions, which gfx950 emulates); rounds to nearest at 2^-40 of the bound
 __device__ __forceinline__ long long fixed40(float v, int eb) {
     const unsigned bits = __float_as_uint(v);
     const int ex = (int)((bits >> 23) & 0xffu);
     if (ex == 0) return 0;  // zero / denormal
     long long m = (long long)((bits & 0x7fffffu) | 0x800000u);  // 24-bit mantissa: |v| = m 2^(ex - 150)
     const int sh = ex - eb + 17;                                // q = |v| 2^(40 + 127 - eb) = m 2^(ex - eb + 17), sh <= 17
-    m = sh >= 0 ? (m << sh) : (sh > -40 ? (m >> (-sh)) : 0);
+    m = sh >= 0 ? (m << sh) : (sh > -25 ? ((m + (1ll << (-sh - 1))) >> (-sh)) : 0);  // (rounds to nearest; below half a unit: 0)
     return (bits >> 31) ? -m : m;
 }
 
@@ -393,10 +477,8 @@ __global__ void __launch_bounds__((YRows<NX, FS>::THR), (YRows<NX, FS>::THR / 12
     const int tid = threadIdx.x, g = tid % GX, u = tid / GX;
     cf* mine = lds + g * GSTR;
     cf* tw2 = lds + GX * GSTR;
-    // radial-sum tables, ALIASED onto the transforms' LDS (they live only between the last transform barrier and the staging
-    // of the result: a separate 12-20 KB would cost the second workgroup per CU)
-    unsigned long long* acc = reinterpret_cast<unsigned long long*>(lds);          // [nbins][HW] int64 fixed-point sums
-    unsigned* bmax = reinterpret_cast<unsigned*>(acc + (ISO ? p.nbins * HW : 0));  // [nbins] float bits of the largest magnitude
+    // (the radial-sum tables alias the transforms' LDS: a separate 12-20 KB would cost the second workgroup per CU)
+    xrft_stagger(XRFT_YTUNE(p));
     fill_tw2<NX>(tw2, p.tw_x, tid, THR);
     const int nyh = p.ny >> 1;
     // FS: rows 0 .. ny/2 - 1 fill whole units; the Nyquist rows (k1 = ny/2) of GX consecutive slabs share one extra unit (transform A
@@ -420,12 +502,13 @@ __global__ void __launch_bounds__((YRows<NX, FS>::THR), (YRows<NX, FS>::THR / 12
     }
     const unsigned offA = w2_offset(p, kyA, u) * 8u, offB = w2_offset(p, kyB, u) * 8u;
     cf a[16], b[16];
+    const bool ntw = (XRFT_YTUNE(p) & 8) != 0;
     if (NT >= (1 << p.l_cw)) {  // x = u + NT q advances by whole column blocks: constant stride
         const unsigned qstr = (unsigned)(((NT >> p.l_cw) * 2) << (p.l_rk + p.l_2gy)) * 8u;
 #pragma unroll
         for (int q = 0; q < 16; ++q) {
-            a[q] = *reinterpret_cast<const cf*>(w2s + (offA + qstr * (unsigned)q));
-            b[q] = *reinterpret_cast<const cf*>(w2t + (offB + qstr * (unsigned)q));
+            a[q] = xrft_load8_pol(w2s + (offA + qstr * (unsigned)q), ntw);
+            b[q] = xrft_load8_pol(w2t + (offB + qstr * (unsigned)q), ntw);
         }
     } else {
 #pragma unroll
@@ -469,58 +552,208 @@ __global__ void __launch_bounds__((YRows<NX, FS>::THR), (YRows<NX, FS>::THR / 12
 #pragma unroll
         for (int e = 0; e < 16; ++e) a[e] = cscale(cmulc(a[e], b[e]), p.scale);
     }
-    if (ISO) {
-        // Radial sums (xrft.py:895-906), bit-reproducible: floating-point atomics would make the sum depend on the order in
-        // which waves arrive.  Two passes over this workgroup's values: (1) the largest magnitude per bin (atomicMax on the
-        // float bits: order-independent), (2) every value converted to int64 fixed point 40 bits below its bin's maximum
-        // and added with INTEGER atomics (exact, order-independent; the inputs carry 24 bits).  The workgroup's per-bin
-        // sums go to a partial table that iso_reduce_kernel adds in unit order.  A value at (ky, kx) goes to its bin
-        // and once more (conjugated) to the bin of (-ky, -kx).
-        const unsigned* __restrict__ tc = p.tcodes + ((size_t)unit * (TWO ? 16 : 32)) * THR + tid;
-        unsigned codes[TWO ? 16 : 32];
-#pragma unroll
-        for (int e = 0; e < (TWO ? 16 : 32); ++e) codes[e] = tc[(size_t)e * THR];
-        for (int i = tid; i < p.nbins * HW; i += THR) acc[i] = 0ull;  // (the transforms' trailing barrier has passed: their LDS is free)
-        for (int i = tid; i < p.nbins; i += THR) bmax[i] = 0u;
-        __syncthreads();
-#pragma unroll
-        for (int e = 0; e < (TWO ? 16 : 32); ++e) {
-            const cf v = e < 16 ? a[e] : b[e - 16];
-            const float mag = MODE == 1 ? (v.re * v.re + v.im * v.im) * p.scale : fabsf(v.re) + fabsf(v.im);
-            const unsigned cd = codes[e] & 0xffffu, cm = codes[e] >> 16, mb = __float_as_uint(fabsf(mag));
-            if (cd) atomicMax(&bmax[cd - 1], mb);
-            if (cm && cm != cd) atomicMax(&bmax[cm - 1], mb);
-        }
-        __syncthreads();
-#pragma unroll
-        for (int e = 0; e < (TWO ? 16 : 32); ++e) {
-            const cf v = e < 16 ? a[e] : b[e - 16];
-            const unsigned cd = codes[e] & 0xffffu, cm = codes[e] >> 16;
-            if (!cd && !cm) continue;
-            const float re = MODE == 1 ? (v.re * v.re + v.im * v.im) * p.scale : v.re, im = v.im;
-            if (cd) {
-                const int eb = (int)(bmax[cd - 1] >> 23);
-                atomicAdd(&acc[HW * (cd - 1)], (unsigned long long)(fixed40(re, eb) * (cd == cm ? 2 : 1)));
-                if (MODE == 2 && cd != cm) atomicAdd(&acc[2 * (cd - 1) + 1], (unsigned long long)fixed40(im, eb));  // (cd == cm: V + conj V is real)
-            }
-            if (cm && cm != cd) {
-                const int eb = (int)(bmax[cm - 1] >> 23);
-                atomicAdd(&acc[HW * (cm - 1)], (unsigned long long)fixed40(re, eb));
-                if (MODE == 2) atomicAdd(&acc[2 * (cm - 1) + 1], (unsigned long long)fixed40(-im, eb));
-            }
-        }
-        __syncthreads();
-        // this workgroup's sums, back in floating point (exact: < 2^53), into its row of the partial table
-        double* __restrict__ part = p.iso_part + ((size_t)slab * upr + unit) * p.nbins * HW;
-        for (int i = tid; i < p.nbins * HW; i += THR)
-            part[i] = ldexp((double)(long long)acc[i], (int)(bmax[i / HW] >> 23) - 127 - 40);
-        __syncthreads();  // the staging below re-uses this LDS
-    }
     const int mx = NX - 1, my = p.ny - 1, sx = p.shift_x;
+    // ---- store loops.  Power rows staged as floats at sbase[rl * RSP + nat16(kx)] (rl < nrows) are the unit's rows r0 .. r0 + nrows - 1;
+    // every valid row leaves twice: rotated (direct) and reversed + rotated (mirror); 16-byte stores, whole rows
+    constexpr int RSP = R::RS + (FS ? 1 : 0);
+    auto store_power = [&](const float* sbase, int r0, int nrows) {
+        if (p.half) {  // rows of nx/2 + 1 samples (an odd length: 4-byte stores, still whole lines per wave); row -ky reads the row backwards
+            constexpr int W = NX / 2 + 1;
+            float* __restrict__ oh = reinterpret_cast<float*>(p.out) + (size_t)slab * p.ny * W;
+            for (int e = tid; e < nrows * 2 * W; e += THR) {
+                const int kx = e % W, rr = e / W, rl = rr >> 1, mir = rr & 1;
+                const int ky = ky0 + r0 + rl;
+                if (ky > nyh || (mir && (ky == 0 || ky == nyh))) continue;
+                float v = sbase[rl * RSP + nat16(mir ? (NX - kx) & mx : kx)];
+                if (p.realdim2 && kx != 0 && kx != NX / 2) v *= 2.0f;
+                oh[(size_t)(mir ? p.ny - ky : ky) * W + kx] = v;
+            }
+            return;
+        }
+        float* __restrict__ outs = reinterpret_cast<float*>(p.out) + (size_t)slab * p.ny * NX;
+        constexpr int CPR = NX / 4;  // float4 chunks per row
+        for (int e = tid; e < nrows * 2 * CPR; e += THR) {
+            const int chunk = e % CPR, rr = e / CPR, rl = rr >> 1, mir = rr & 1;
+            const int ky = ky0 + r0 + rl;
+            if (ky > nyh || (mir && (ky == 0 || ky == nyh))) continue;
+            const float* row = sbase + rl * RSP;
+            const int c = 4 * chunk;
+            F4 v;
+            if (!mir) {
+                const int kx = (c - sx) & mx;
+                v.x = row[nat16(kx)]; v.y = row[nat16(kx + 1)]; v.z = row[nat16(kx + 2)]; v.w = row[nat16(kx + 3)];
+            } else {  // output column c holds kx = (nx - (c - sx)) mod nx
+                const int kx = (NX - c + sx) & mx;
+                v.x = row[nat16(kx)]; v.y = row[nat16((kx - 1) & mx)]; v.z = row[nat16((kx - 2) & mx)]; v.w = row[nat16((kx - 3) & mx)];
+            }
+            const int orow = mir ? ((p.ny - ky) + p.shift_y) & my : (ky + p.shift_y) & my;
+            // non-temporal: the result is not read again, and keeping it out of the caches leaves the Infinity Cache to the
+            // intermediate (scripts/ubench/yfirst.hip: 45.8 vs 50.9 us per slab for the two passes at 2 slabs per group)
+            if (!(XRFT_YDBG & 8) || v.x == 1.2345f) xrft_store_pol(outs + (size_t)orow * NX + c, v, (XRFT_YTUNE(p) >> 4) & 1 ? 1 : 0);
+        }
+    };
+    // complex rows staged at cbase[rl * RSC + nat16(kx)] (natural order) = the unit's rows r0 .. r0 + nrows - 1 (not the four-step form)
+    constexpr int RSC = NX + NX / 16 + (FS ? 1 : 0);
+    auto store_complex = [&](const cf* cbase, int r0, int nrows) {
+        if (p.half) {  // kx = 0..nx/2 only, unshifted; F(-ky, kx) = conj F(ky, -kx)
+            constexpr int W = NX / 2 + 1;
+            for (int e = tid; e < nrows * 2 * W; e += THR) {
+                const int kx = e % W, rr = e / W, rl = rr >> 1, mir = rr & 1;
+                const int ky = ky0 + r0 + rl;
+                if (ky > nyh || (mir && (ky == 0 || ky == nyh))) continue;
+                cf v = cbase[rl * RSC + nat16(mir ? (NX - kx) & mx : kx)];
+                if (mir) v = cconj(v);
+                const int fy = mir ? p.ny - ky : ky;
+                if (p.ph_on) v = cmul(v, cmul(p.ph_y[fy], p.ph_x[kx]));
+                if (p.realdim2 && kx != 0 && kx != NX / 2) v = cscale(v, 2.0f);
+                const size_t o = ((size_t)slab * p.ny + fy) * W + kx;
+                if (MODE == 3) reinterpret_cast<float*>(p.out)[o] = (float)atan2((double)v.im, (double)v.re);
+                else reinterpret_cast<cf*>(p.out)[o] = v;
+            }
+            return;
+        }
+        typedef typename std::conditional<MODE == 3, float, cf>::type OutT;
+        OutT* __restrict__ outs = reinterpret_cast<OutT*>(p.out) + (size_t)slab * p.ny * NX;
+        constexpr int CPR = NX / 2;  // pairs of samples per row
+        for (int e = tid; e < nrows * 2 * CPR; e += THR) {
+            const int chunk = e % CPR, rr = e / CPR, rl = rr >> 1, mir = rr & 1;
+            const int ky = ky0 + r0 + rl;
+            if (ky > nyh || (mir && (ky == 0 || ky == nyh))) continue;
+            const cf* row = cbase + rl * RSC;
+            const int c = 2 * chunk;
+            const int fx0 = (c - sx) & mx, fx1 = (c + 1 - sx) & mx;  // unshifted frequency indices of the two output columns
+            const int fy = mir ? (p.ny - ky) & my : ky;
+            cf v0, v1;
+            if (!mir) { v0 = row[nat16(fx0)]; v1 = row[nat16(fx1)]; }
+            else { v0 = cconj(row[nat16((NX - fx0) & mx)]); v1 = cconj(row[nat16((NX - fx1) & mx)]); }  // F(-k) = conj F(k)
+            if (p.ph_on) {
+                const cf py = p.ph_y[fy];
+                v0 = cmul(v0, cmul(py, p.ph_x[fx0]));
+                v1 = cmul(v1, cmul(py, p.ph_x[fx1]));
+            }
+            const size_t o = (size_t)((fy + p.shift_y) & my) * NX + c;
+            if (MODE == 3) {  // cross phase (xrft.py:838-874)
+                struct alignas(8) P2f { float x, y; } ang;
+                ang.x = (float)atan2((double)v0.im, (double)v0.re); ang.y = (float)atan2((double)v1.im, (double)v1.re);
+                *reinterpret_cast<P2f*>(reinterpret_cast<float*>(outs) + o) = ang;
+            } else {
+                xrft_store_nt2(reinterpret_cast<cf*>(outs) + o, v0, v1);
+            }
+        }
+    };
+    if constexpr (ISO) {
+        // Radial sums (xrft.py:895-906), bit-reproducible: floating-point atomics would make a sum depend on the order in which waves
+        // arrive.  The results are staged in LDS in natural order, half of the workgroup's rows per round (the other half of the
+        // transforms' LDS holds the tables), and a thread owns L CONSECUTIVE kx of one row: neighbouring samples mostly share a
+        // radial bin, so the thread reduces RUNS of equal (bin, mirror bin) pairs in registers (float32 adds in sample order: as
+        // reproducible as the transform itself) and touches the tables once per run, and the lanes of a wave (L samples apart)
+        // mostly hit different bins.  (In register order -- a thread's samples 16 apart, its
+        // neighbours' 1 apart -- every sample was its own atomic and a wave collided in a handful of bins: 33 us per 4096^2 slab
+        // with nothing stored, profiles/r02_bench_configs.txt.)  Two sweeps per round: (1) the largest run sum per bin (atomicMax
+        // on the float bits: order-independent), (2) every run sum converted to int64 fixed point 40 bits below its bin's maximum
+        // and added with INTEGER atomics (exact, order-independent).  A value at (ky, kx) goes to its bin and once more (conjugated) to the
+        // bin of (-ky, -kx).  The workgroup's per-bin sums go to a partial table that iso_reduce_kernel adds in unit order.
+        constexpr int NR = MODE == 1 ? GX : GX / 2;    // rows per round
+        constexpr int L = NR * NX / THR;                // 16 (power), 8 (cross) consecutive samples per thread
+        constexpr int RSI = MODE == 1 ? RSP : 2 * RSC;  // floats per staged row
+        static_assert(GX >= 2 && L * THR == NR * NX && (16 % L) == 0, "radial-sum geometry");
+        double* __restrict__ part = p.iso_part + ((size_t)slab * upr + unit) * p.nbins * HW;
+        const int rl = tid / (NX / L), kx0 = (tid % (NX / L)) * L;
+#pragma unroll
+        for (int rd = 0; rd < 2; ++rd) {  // (unrolled: transform A's registers are dead in round 2)
+            float* sreg = stg + (rd ? NR * RSI : 0);
+            unsigned long long* acc = reinterpret_cast<unsigned long long*>(stg + (rd ? 0 : NR * RSI));  // [nbins][HW] int64 fixed-point sums
+            unsigned* bmax = reinterpret_cast<unsigned*>(acc + p.nbins * HW);                              // [nbins] float bits of the largest magnitude
+            if (MODE == 1) {
+#pragma unroll
+                for (int bb = 0; bb < G::NB; ++bb)
+#pragma unroll
+                    for (int k3 = 0; k3 < G::R3; ++k3) {
+                        const cf v = rd ? b[bb * G::R3 + k3] : a[bb * G::R3 + k3];
+                        sreg[g * RSP + nat16(held_k<NX>(u, bb, k3))] = (v.re * v.re + v.im * v.im) * p.scale;
+                    }
+            } else if (g / NR == rd) {
+                cf* creg = reinterpret_cast<cf*>(sreg);
+#pragma unroll
+                for (int bb = 0; bb < G::NB; ++bb)
+#pragma unroll
+                    for (int k3 = 0; k3 < G::R3; ++k3) creg[(g % NR) * RSC + nat16(held_k<NX>(u, bb, k3))] = a[bb * G::R3 + k3];
+            }
+            for (int i = tid; i < p.nbins * HW; i += THR) acc[i] = 0ull;
+            for (int i = tid; i < p.nbins; i += THR) bmax[i] = 0u;
+            // this thread's run of L samples of row ky0 + rd NR + rl: bin codes in natural order, (bin + 1) | (mirror bin + 1) << 16
+            unsigned codes[L];
+            {
+                const unsigned* __restrict__ tc = p.tcodes + (size_t)(ky0 + rd * NR + rl) * NX + kx0;
+#pragma unroll
+                for (int i = 0; i < L; i += 4) {
+                    const uint4 c4 = *reinterpret_cast<const uint4*>(tc + i);
+                    codes[i] = c4.x; codes[i + 1] = c4.y; codes[i + 2] = c4.z; codes[i + 3] = c4.w;
+                }
+            }
+            __syncthreads();
+            // sweep 1: the thread adds up each run of equal codes (float32, in sample order: a fixed order), keeps the sum at the
+            // run's last sample, and records its magnitude in the bins it goes to (one atomicMax per run and bin)
+            const float* src = sreg + rl * RSI + (MODE == 1 ? 1 : 2) * nat16(kx0);
+            float rsr[L], rsi[MODE == 2 ? L : 1];
+            {
+                float sr = 0.f, si = 0.f;
+#pragma unroll
+                for (int i = 0; i < L; ++i) {
+                    if (MODE == 1) sr += src[i];
+                    else { sr += src[2 * i]; si += src[2 * i + 1]; }
+                    rsr[i] = sr;
+                    if (MODE == 2) rsi[i] = si;
+                    const bool last = i == L - 1 || codes[i + 1] != codes[i];
+                    if (last) {
+                        const unsigned cd = codes[i] & 0xffffu, cm = codes[i] >> 16, m = __float_as_uint(fabsf(sr) + fabsf(si));
+                        if (cd) atomicMax(&bmax[cd - 1], m);
+                        if (cm && cm != cd) atomicMax(&bmax[cm - 1], m);
+                        sr = 0.f; si = 0.f;
+                    }
+                }
+            }
+            __syncthreads();
+            // sweep 2: every run sum converted to int64 fixed point 40 bits below its bin's largest and added with an INTEGER atomic
+            // (exact: the order in which lanes arrive does not matter)
+#pragma unroll
+            for (int i = 0; i < L; ++i) {
+                const bool last = i == L - 1 || codes[i + 1] != codes[i];
+                if (last) {
+                    const unsigned cd = codes[i] & 0xffffu, cm = codes[i] >> 16;
+                    const float re = rsr[i], im = MODE == 2 ? rsi[MODE == 2 ? i : 0] : 0.f;
+                    if (cd) {
+                        const int eb = (int)(bmax[cd - 1] >> 23);
+                        atomicAdd(&acc[HW * (cd - 1)], (unsigned long long)(fixed40(re, eb) * (cd == cm ? 2 : 1)));
+                        if (MODE == 2 && cd != cm) atomicAdd(&acc[2 * (cd - 1) + 1], (unsigned long long)fixed40(im, eb));  // (cd == cm: V + conj V is real)
+                    }
+                    if (cm && cm != cd) {
+                        const int eb = (int)(bmax[cm - 1] >> 23);
+                        atomicAdd(&acc[HW * (cm - 1)], (unsigned long long)fixed40(re, eb));
+                        if (MODE == 2) atomicAdd(&acc[2 * (cm - 1) + 1], (unsigned long long)fixed40(-im, eb));
+                    }
+                }
+            }
+            __syncthreads();
+            // this round's sums, back in floating point, into the workgroup's row of the partial table (the same thread adds round 2
+            // to what it wrote in round 1: a fixed order).  A bin with an inf / nan member is +inf (power) or nan, as IEEE sums are.
+            for (int i = tid; i < p.nbins * HW; i += THR) {
+                const unsigned bm = bmax[i / HW];
+                double v = ldexp((double)(long long)acc[i], (int)(bm >> 23) - 127 - 40);
+                if ((bm >> 23) == 0xffu) v = __longlong_as_double((MODE == 1 && bm == 0x7f800000u) ? 0x7ff0000000000000ll : 0x7ff8000000000000ll);
+                part[i] = rd ? part[i] + v : v;
+            }
+            if (p.out != nullptr) {
+                if (MODE == 1) store_power(sreg, rd * NR, NR);
+                else store_complex(reinterpret_cast<const cf*>(sreg), rd * NR, NR);
+            }
+            __syncthreads();  // the next round's tables overwrite this round's staging
+        }
+        return;
+    }
     if (MODE == 1 && p.out != nullptr) {
         // power, staged row-major [row][kx] in natural order with the conflict-free 17/16 padding (FS: + 1, the transposed
         // read-out runs down the rows)
-        constexpr int RSP = R::RS + (FS ? 1 : 0);
 #pragma unroll
         for (int bb = 0; bb < G::NB; ++bb)
 #pragma unroll
@@ -541,49 +774,15 @@ __global__ void __launch_bounds__((YRows<NX, FS>::THR), (YRows<NX, FS>::THR / 12
                 const int o1k = mir ? p.ny - k1 : k1, o2k = mir ? (NX - 1 - k2) : k2;  // X[N - k]: (ny - k1) + ny (nx - 1 - k2)
                 ob[(size_t)(nyq ? s0 + r : slab) * p.ny * NX + (size_t)((o2k + sx) & mx) * p.ny + o1k] = v;
             }
-        } else if (p.half) {  // rows of nx/2 + 1 samples (an odd length: 4-byte stores, still whole lines per wave); row -ky reads the row backwards
-            constexpr int W = NX / 2 + 1;
-            float* __restrict__ oh = reinterpret_cast<float*>(p.out) + (size_t)slab * p.ny * W;
-            for (int e = tid; e < RPU * 2 * W; e += THR) {
-                const int kx = e % W, rr = e / W, r = rr >> 1, mir = rr & 1;
-                const int ky = ky0 + r;
-                if (ky > nyh || (mir && (ky == 0 || ky == nyh))) continue;
-                float v = stg[r * RSP + nat16(mir ? (NX - kx) & mx : kx)];
-                if (p.realdim2 && kx != 0 && kx != NX / 2) v *= 2.0f;
-                oh[(size_t)(mir ? p.ny - ky : ky) * W + kx] = v;
-            }
         } else {
-        // every staged row leaves twice: rotated (direct) and reversed + rotated (mirror); 16-byte stores, whole rows
-        float* __restrict__ outs = reinterpret_cast<float*>(p.out) + (size_t)slab * p.ny * NX;
-        constexpr int CPR = NX / 4;  // float4 chunks per row
-        for (int e = tid; e < RPU * 2 * CPR; e += THR) {
-            const int chunk = e % CPR, rr = e / CPR, r = rr >> 1, mir = rr & 1;
-            const int ky = ky0 + r;
-            if (ky > nyh || (mir && (ky == 0 || ky == nyh))) continue;
-            const float* row = stg + r * R::RS;
-            const int c = 4 * chunk;
-            F4 v;
-            if (!mir) {
-                const int kx = (c - sx) & mx;
-                v.x = row[nat16(kx)]; v.y = row[nat16(kx + 1)]; v.z = row[nat16(kx + 2)]; v.w = row[nat16(kx + 3)];
-            } else {  // output column c holds kx = (nx - (c - sx)) mod nx
-                const int kx = (NX - c + sx) & mx;
-                v.x = row[nat16(kx)]; v.y = row[nat16((kx - 1) & mx)]; v.z = row[nat16((kx - 2) & mx)]; v.w = row[nat16((kx - 3) & mx)];
-            }
-            const int orow = mir ? ((p.ny - ky) + p.shift_y) & my : (ky + p.shift_y) & my;
-            // non-temporal: the result is not read again, and keeping it out of the caches leaves the Infinity Cache to the
-            // intermediate (scripts/ubench/yfirst.hip: 45.8 vs 50.9 us per slab for the two passes at 2 slabs per group)
-            if (!(XRFT_YDBG & 8) || v.x == 1.2345f) xrft_store_nt(outs + (size_t)orow * NX + c, v);
-        }
+            store_power(stg, 0, RPU);
         }
     }
     if (MODE != 1 && p.out != nullptr) {
         // complex results: GX rows at a time staged in natural order (a round fills the transforms' LDS exactly); the complex
         // spectrum of one field takes two rounds (transform A's rows, then B's)
         cf* cstg = lds;
-        constexpr int RSC = NX + NX / 16 + (FS ? 1 : 0), NROUND = TWO ? 1 : 2, CPR = NX / 2;  // pairs of samples per row
-        typedef typename std::conditional<MODE == 3, float, cf>::type OutT;
-        OutT* __restrict__ outs = reinterpret_cast<OutT*>(p.out) + (size_t)slab * p.ny * NX;
+        constexpr int NROUND = TWO ? 1 : 2;
 #pragma unroll
         for (int round = 0; round < NROUND; ++round) {
             if (round) __syncthreads();
@@ -608,48 +807,7 @@ __global__ void __launch_bounds__((YRows<NX, FS>::THR), (YRows<NX, FS>::THR / 12
                 }
                 continue;
             }
-            if (p.half) {  // kx = 0..nx/2 only, unshifted; F(-ky, kx) = conj F(ky, -kx)
-                constexpr int W = NX / 2 + 1;
-                for (int e = tid; e < GX * 2 * W; e += THR) {
-                    const int kx = e % W, rr = e / W, r = rr >> 1, mir = rr & 1;
-                    const int ky = ky0 + round * GX + r;
-                    if (ky > nyh || (mir && (ky == 0 || ky == nyh))) continue;
-                    cf v = cstg[r * RSC + nat16(mir ? (NX - kx) & mx : kx)];
-                    if (mir) v = cconj(v);
-                    const int fy = mir ? p.ny - ky : ky;
-                    if (p.ph_on) v = cmul(v, cmul(p.ph_y[fy], p.ph_x[kx]));
-                    if (p.realdim2 && kx != 0 && kx != NX / 2) v = cscale(v, 2.0f);
-                    const size_t o = ((size_t)slab * p.ny + fy) * W + kx;
-                    if (MODE == 3) reinterpret_cast<float*>(p.out)[o] = (float)atan2((double)v.im, (double)v.re);
-                    else reinterpret_cast<cf*>(p.out)[o] = v;
-                }
-                continue;
-            }
-            for (int e = tid; e < GX * 2 * CPR; e += THR) {
-                const int chunk = e % CPR, rr = e / CPR, r = rr >> 1, mir = rr & 1;
-                const int ky = ky0 + round * GX + r;
-                if (ky > nyh || (mir && (ky == 0 || ky == nyh))) continue;
-                const cf* row = cstg + r * RSC;
-                const int c = 2 * chunk;
-                const int fx0 = (c - sx) & mx, fx1 = (c + 1 - sx) & mx;  // unshifted frequency indices of the two output columns
-                const int fy = mir ? (p.ny - ky) & my : ky;
-                cf v0, v1;
-                if (!mir) { v0 = row[nat16(fx0)]; v1 = row[nat16(fx1)]; }
-                else { v0 = cconj(row[nat16((NX - fx0) & mx)]); v1 = cconj(row[nat16((NX - fx1) & mx)]); }  // F(-k) = conj F(k)
-                if (p.ph_on) {
-                    const cf py = p.ph_y[fy];
-                    v0 = cmul(v0, cmul(py, p.ph_x[fx0]));
-                    v1 = cmul(v1, cmul(py, p.ph_x[fx1]));
-                }
-                const size_t o = (size_t)((fy + p.shift_y) & my) * NX + c;
-                if (MODE == 3) {  // cross phase (xrft.py:838-874)
-                    struct alignas(8) P2f { float x, y; } ang;
-                    ang.x = (float)atan2((double)v0.im, (double)v0.re); ang.y = (float)atan2((double)v1.im, (double)v1.re);
-                    *reinterpret_cast<P2f*>(reinterpret_cast<float*>(outs) + o) = ang;
-                } else {
-                    xrft_store_nt2(reinterpret_cast<cf*>(outs) + o, v0, v1);
-                }
-            }
+            store_complex(cstg, round * GX, GX);
         }
     }
 }
@@ -669,7 +827,7 @@ __global__ void __launch_bounds__(256) fasty_fit_kernel(const double* colfit, co
     const double inv_n = 1.0 / ny, inv_sii = 12.0 / ((double)ny * ((double)ny * ny - 1.0));
     double s[3] = {0.0, 0.0, 0.0};
     for (int x = tid; x < nx; x += 256) {
-        const double m = cf4[4 * x] * inv_n, sl = cf4[4 * x + 1] * inv_sii;
+        const double m = cf4[4 * x] * inv_n + cf4[4 * x + 2], sl = cf4[4 * x + 1] * inv_sii + cf4[4 * x + 3];  // (residual sums + the subtracted line)
         s[0] += m;
         s[1] += ((double)x - xbar) * m;
         s[2] += sl;
@@ -700,10 +858,10 @@ __global__ void __launch_bounds__(256) fasty_fit1d_kernel(const double* colfit, 
     double* red = reinterpret_cast<double*>(smem_raw);
     const int slab = blockIdx.x, tid = threadIdx.x;
     const double* cf4 = colfit + (size_t)slab * nx * 4;
-    const double N = (double)nx * (double)ny, nbar = 0.5 * (N - 1.0), ibar = 0.5 * (ny - 1);
+    const double N = (double)nx * (double)ny, nbar = 0.5 * (N - 1.0), ibar = 0.5 * (ny - 1), sii = (double)ny * ((double)ny * ny - 1.0) / 12.0;
     double s[3] = {0.0, 0.0, 0.0};
     for (int x = tid; x < nx; x += 256) {
-        const double s0 = cf4[4 * x], s1 = cf4[4 * x + 1];
+        const double s0 = cf4[4 * x] + (double)ny * cf4[4 * x + 2], s1 = cf4[4 * x + 1] + cf4[4 * x + 3] * sii;  // (residual sums + the subtracted line)
         s[0] += s0;
         s[1] += (double)nx * (s1 + ibar * s0) + (double)x * s0;
     }

@@ -323,6 +323,7 @@ struct xrfthip_plan {
     std::vector<double> host_win_y;
     // tuning knobs from the environment, read once when the plan is created (never in xrfthip_exec)
     long long tune_group = 0, tune_fast_group = 0, tune_group_bytes = 512LL << 20, tune_cols_grid = 256, tune_max_grid = 8192;
+    long long tune_y = 0;  // XRFTHIP_YTUNE: cache policies / start stagger of the y-first float32 kernels (FastY::tune), fixed at plan creation
     // optional per-pass event timing (bench only; a plan with profiling on is not re-entrant)
     bool prof = false;
     struct ProfRec { std::string label; hipEvent_t a, b; };
@@ -860,6 +861,7 @@ static int upload_real_table(xrfthip_plan* P, DevBuf& buf, const double* h, int6
 static bool fast_on(const xrfthip_plan* P);
 static bool fastm_iso_fused(const xrfthip_plan* P);
 static long long fasty_rows_gx(const xrfthip_plan* P);
+static bool fasty_iso_tables_fit(const xrfthip_plan* P, int nbins);
 static int fastm_rows_rpu(const xrfthip_plan* P);
 
 // workgroups per slab of radial_binsum_det_kernel: chunks of <= 2^17 elements (its int64 sums hold 2^17 values), at most 128
@@ -1122,31 +1124,30 @@ static int fasty_window_spectra(xrfthip_plan* P) {
     return rc;
 }
 
-// the bin map re-ordered the way pass 2 holds its results (fasty_rows_kernel): [unit][e (32)][tid], e < 16: transform A
-// (row ky0 + g), else B (row ky0 + GX + g); value = (bin of (ky, kx) + 1) | (bin of the mirror (-ky, -kx) + 1) << 16
+// the bin map as pass 2 reads it (fasty_rows_kernel): [ky < nrow_pad][kx] in natural order,
+// value = (bin of (ky, kx) + 1) | (bin of the mirror (-ky, -kx) + 1) << 16; rows beyond ny/2 and unbinned samples are 0
 static int fasty_build_tcodes(xrfthip_plan* P, const int32_t* bm) {
-    const int ny = (int)P->yny, nx = (int)P->ynx, nyh = ny / 2, nt = nx / 16, r3 = nx / 256;
-    const YGeomRt R = yrows_geom(nx);
-    const bool two = P->d.out_mode == XRFTHIP_OUT_CROSS;  // transform B is field 1: only transform A's slots carry results
-    const int gx = R.gxy, rpu = two ? R.gxy : R.rk, thr = R.thr, units = P->y_nrow_pad / rpu, ne = two ? 16 : 32;
-    std::vector<uint32_t> t((size_t)units * ne * thr, 0u);
-    for (int un = 0; un < units; ++un)
-        for (int e = 0; e < ne; ++e)
-            for (int tid = 0; tid < thr; ++tid) {
-                const int g = tid % gx, u = tid / gx;
-                const int ky = un * rpu + (e < 16 ? g : gx + g);
-                if (ky > nyh) continue;
-                const int el = e & 15, bb = el / r3, k3 = el % r3, pr = u + nt * bb, kx = (pr >> 4) + 16 * (pr & 15) + 256 * k3;
-                uint32_t v = 0;
-                const int32_t cd = bm[(size_t)ky * nx + kx];
-                if (cd >= 0) v |= (uint32_t)(cd + 1);
-                if (ky != 0 && ky != nyh) {
-                    const int32_t cm = bm[(size_t)(ny - ky) * nx + ((nx - kx) & (nx - 1))];
-                    if (cm >= 0) v |= (uint32_t)(cm + 1) << 16;
-                }
-                t[((size_t)un * ne + e) * thr + tid] = v;
+    const int ny = (int)P->yny, nx = (int)P->ynx, nyh = ny / 2;
+    std::vector<uint32_t> t((size_t)P->y_nrow_pad * nx, 0u);
+    for (int ky = 0; ky <= nyh; ++ky)
+        for (int kx = 0; kx < nx; ++kx) {
+            uint32_t v = 0;
+            const int32_t cd = bm[(size_t)ky * nx + kx];
+            if (cd >= 0) v |= (uint32_t)(cd + 1);
+            if (ky != 0 && ky != nyh) {
+                const int32_t cm = bm[(size_t)(ny - ky) * nx + ((nx - kx) & (nx - 1))];
+                if (cm >= 0) v |= (uint32_t)(cm + 1) << 16;
             }
+            t[(size_t)ky * nx + kx] = v;
+        }
     return P->ytcodes.upload(t.data(), t.size() * sizeof(uint32_t));
+}
+// the radial-sum tables of one round share the transforms' LDS with the staged half of the workgroup's rows: they must fit the other half
+static bool fasty_iso_tables_fit(const xrfthip_plan* P, int nbins) {
+    const YGeomRt R = yrows_geom(P->ynx);
+    const size_t half = (size_t)R.gxy * (size_t)(P->ynx + P->ynx / 16) * 4;  // GX rows of floats = GX / 2 rows of complex
+    const size_t hw = P->d.out_mode == XRFTHIP_OUT_CROSS ? 2 : 1;
+    return nbins <= 65534 && (size_t)nbins * (8 * hw + 4) <= half;
 }
 
 static bool fasty_on(const xrfthip_plan* P) { return P->yfirst && fast_on(P); }
@@ -1243,6 +1244,7 @@ static FastY fasty_params(const xrfthip_plan* P, const float* in, void* out, dou
     p.shift_x = (d.flags & XRFTHIP_SHIFT_X) ? (int)(P->ynx / 2) : 0;  // (four-step 1-D: the shift by N/2 samples is k2 + nx/2)
     if (P->fast1d) p.win_y = p.win_x = reinterpret_cast<const float*>(P->ones4096.p);  // (no window on this path)
     p.scale = (float)d.scale;
+    p.tune = (int)P->tune_y;
     return p;
 }
 
@@ -1690,6 +1692,7 @@ int xrfthip_plan_create(xrfthip_plan** plan, const xrfthip_desc* desc) {
     P->d = d;
     P->tune_group = env_ll("XRFTHIP_GROUP", 0);
     P->tune_fast_group = env_ll("XRFTHIP_FAST_GROUP", 0);
+    P->tune_y = env_ll("XRFTHIP_YTUNE", kYTuneDefault);
     P->tune_group_bytes = env_ll("XRFTHIP_GROUP_BYTES", 512LL << 20);
     P->tune_cols_grid = env_ll("XRFTHIP_FAST_COLS_GRID", kCUs);
     P->tune_max_grid = env_ll("XRFTHIP_MAX_GRID", 8 * kCUs * 4);
@@ -1854,9 +1857,8 @@ int xrfthip_plan_set_binmap(xrfthip_plan* plan, const int32_t* h_binmap, int64_t
     plan->nbins = nbins;
     if (plan->fast4096) {
         int rcf = XRFTHIP_OK;
-        const size_t hist_bytes = (size_t)nbins * sizeof(double) * (plan->d.out_mode == XRFTHIP_OUT_CROSS ? 2 : 1);
         if (plan->yfirst) {
-            if (nbins > 65534 || hist_bytes + (size_t)nbins * 4 + 64 > yrows_geom(plan->d.nx).lds) plan->fast4096 = false;  // (the tables alias the transforms' LDS)
+            if (!fasty_iso_tables_fit(plan, nbins)) plan->fast4096 = false;  // (the tables alias half of the transforms' LDS)
             else rcf = fasty_build_tcodes(plan, h_binmap);
         }
         if (rcf) return rcf;
@@ -2114,6 +2116,18 @@ int xrfthip_table_mul(int32_t dtype, int64_t batch, int64_t n_in, int64_t n_out,
 #define TM_(TT, CC) do { auto k = &table_mul_kernel<TT, CC>; XRFT_LAUNCH(k, grid, block, 0, st, d_in, (const C2<TT>*)d_table, (C2<TT>*)d_out, (long long)batch, (long long)n_in, (long long)n_out); } while (0)
     if (dtype == XRFTHIP_F32) TM_(float, false); else if (dtype == XRFTHIP_F64) TM_(double, false); else if (dtype == XRFTHIP_C64) TM_(float, true); else TM_(double, true);
 #undef TM_
+    HIP_TRY(hipGetLastError());
+    return XRFTHIP_OK;
+}
+
+int xrfthip_reduce_axis(int32_t dtype, int64_t outer, int64_t n, int64_t inner, const void* d_in, void* d_out, double scale, void* stream) {
+    if (!d_in || !d_out || dtype < XRFTHIP_F32 || dtype > XRFTHIP_C128 || outer < 0 || n < 1 || inner < 0) return XRFTHIP_BAD_ARG;
+    if (outer == 0 || inner == 0) return XRFTHIP_OK;
+    hipStream_t st = (hipStream_t)stream;
+    const long long in2 = inner * (dtype >= XRFTHIP_C64 ? 2 : 1), total = outer * in2;  // complex data: two real components per sample
+    const dim3 grid((unsigned)std::min<long long>((total + 255) / 256, 8LL * kCUs * 8)), block(256);
+    if (dtype == XRFTHIP_F32 || dtype == XRFTHIP_C64) { auto k = &reduce_axis_kernel<float>; XRFT_LAUNCH(k, grid, block, 0, st, (const float*)d_in, (float*)d_out, (long long)outer, (long long)n, in2, scale); }
+    else { auto k = &reduce_axis_kernel<double>; XRFT_LAUNCH(k, grid, block, 0, st, (const double*)d_in, (double*)d_out, (long long)outer, (long long)n, in2, scale); }
     HIP_TRY(hipGetLastError());
     return XRFTHIP_OK;
 }

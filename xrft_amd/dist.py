@@ -60,15 +60,20 @@ def all_gather_batch(local, dim, total, group=None):
 
 
 def batch_mean_allreduce(local, dim, total, group=None):
-    """Mean over the sharded batch dimension: local sum -> all_reduce(SUM) -> / total (nbins values per rank)."""
+    """Mean over the sharded batch dimension: every rank's slabs are summed and scaled by 1 / total in ONE library kernel
+    (xrfthip_reduce_axis: float64 accumulation in slab order, bit-reproducible per rank), then one all_reduce(SUM) of the nbins
+    values per rank finishes the mean -- no torch arithmetic on the data path (test_xrft.py:1011-1013)."""
+    from . import engine
+
     ax = local.get_axis_num(dim)
     t = local.data if isinstance(local.data, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(local.data))
     if dist.get_backend(group) == "nccl" and not t.is_cuda:
         t = t.cuda()
-    s = t.sum(dim=ax)
-    buf = torch.view_as_real(s).contiguous() if s.is_complex() else s.contiguous()
+    if t.device.type != engine.device_type():
+        t = t.to(engine.device_type())
+    s = engine.reduce_axis(t, ax, 1.0 / float(total))
+    buf = torch.view_as_real(s) if s.is_complex() else s
     dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=group)
-    s = torch.view_as_complex(buf) if s.is_complex() else buf
     dims = [d for d in local.dims if d != dim]
     coords = {k: c for k, c in local.coords.items() if dim not in c.dims}
-    return DataArray(s / float(total), dims, coords, local.name, local.attrs)
+    return DataArray(s, dims, coords, local.name, local.attrs)

@@ -251,6 +251,26 @@ def table_mul(x, table, n_out):
     return out
 
 
+def device_type():
+    """torch device type the bound library computes on ('cuda'; 'cpu' only for the emulated test build)."""
+    return _lib.device()
+
+
+def reduce_axis(x, axis, scale=1.0):
+    """scale * sum of ``x`` over ``axis`` (a device kernel, float64 accumulation in index order: bit-reproducible); the mean over a
+    batch dimension with scale = 1 / n (the reference's users average isotropic spectra over the batch, test_xrft.py:1011-1013)."""
+    dll = _lib.load()
+    if x.dtype not in _DTYPES:
+        raise TypeError(f"reduce_axis: unsupported dtype {x.dtype}")
+    x = x.contiguous()
+    axis = axis % x.dim()
+    outer = int(np.prod(x.shape[:axis], dtype=np.int64))
+    inner = int(np.prod(x.shape[axis + 1:], dtype=np.int64))
+    out = torch.empty(list(x.shape[:axis]) + list(x.shape[axis + 1:]), dtype=x.dtype, device=x.device)
+    _lib.check(dll.xrfthip_reduce_axis(_DTYPES[x.dtype], outer, x.shape[axis], inner, _ptr(x), _ptr(out), float(scale), _stream_handle(x)))
+    return out
+
+
 def isotropize(x, binmap_dev, nbins):
     """Radial bin-sum of the last two axes of ``x`` with a device int32 bin map (xrft/xrft.py:993-1004)."""
     dll = _lib.load()

@@ -200,26 +200,32 @@ class DataArray:
                 dims.pop(ax)
         return DataArray(data, dims, coords, self.name, self.attrs)
 
-    def mean(self, dim=None):
-        """Mean over ``dim`` (name or list of names; all dims if None) -- host-side convenience for tests/examples."""
-        v = self.values
-        if dim is None:
-            return DataArray(v.mean(), (), None, self.name, self.attrs)
-        dims = [dim] if isinstance(dim, str) else list(dim)
-        ax = tuple(self.get_axis_num(d) for d in dims)
+    def _reduce(self, dim, mean):
+        dims = list(self.dims) if dim is None else ([dim] if isinstance(dim, str) else list(dim))
         keep = [d for d in self.dims if d not in dims]
         coords = {k: c for k, c in self.coords.items() if not (set(c.dims) & set(dims))}
-        return DataArray(v.mean(axis=ax), keep, coords, self.name, self.attrs)
+        data = self.data
+        if _is_torch(data) and data.device.type != "cpu":
+            # device data stay on the device: one library kernel per reduced dim (xrfthip_reduce_axis: float64 accumulation in
+            # index order, bit-reproducible) -- e.g. the batch mean of isotropic spectra, test_xrft.py:1011-1013
+            from . import engine
+
+            cur = list(self.dims)
+            for d in dims:
+                ax = cur.index(d)
+                data = engine.reduce_axis(data, ax, 1.0 / data.shape[ax] if mean else 1.0)
+                cur.pop(ax)
+            return DataArray(data, keep, coords, self.name, self.attrs)
+        v = self.values
+        ax = tuple(self.get_axis_num(d) for d in dims)
+        return DataArray(v.mean(axis=ax) if mean else v.sum(axis=ax), keep, coords, self.name, self.attrs)
+
+    def mean(self, dim=None):
+        """Mean over ``dim`` (name or list of names; all dims if None), as xarray's ``.mean(dim)``."""
+        return self._reduce(dim, True)
 
     def sum(self, dim=None):
-        v = self.values
-        if dim is None:
-            return DataArray(v.sum(), (), None, self.name, self.attrs)
-        dims = [dim] if isinstance(dim, str) else list(dim)
-        ax = tuple(self.get_axis_num(d) for d in dims)
-        keep = [d for d in self.dims if d not in dims]
-        coords = {k: c for k, c in self.coords.items() if not (set(c.dims) & set(dims))}
-        return DataArray(v.sum(axis=ax), keep, coords, self.name, self.attrs)
+        return self._reduce(dim, False)
 
     # ---------------------------------------------------------------- chunk metadata (stands in for dask chunking)
     @property
