@@ -42,7 +42,7 @@
 extern "C" {
 #endif
 
-#define XRFTHIP_VERSION 100 /* 0.1.0 */
+#define XRFTHIP_VERSION 101 /* 0.1.1: xrfthip_desc.inner, xrfthip_reduce_axis, xrfthip_detrend_inner */
 
 typedef enum xrfthip_status {
     XRFTHIP_OK = 0,
@@ -114,6 +114,14 @@ typedef struct xrfthip_desc {
     double scale;            /* COMPLEX: multiplies F (prod(dx) for true_amplitude); POWER/CROSS: multiplies the product */
     int32_t slabs_per_group; /* 0 = auto: slabs pushed through all passes together (keeps the intermediate in MALL) */
     int32_t reserved;
+    /* Layout with the independent elements INNERMOST: with inner > 1 the arrays are [batch][ny][nx][inner] and the transform runs over
+     * (ny, nx) for every (batch, inner) element -- two ADJACENT transform axes anywhere in a C-contiguous array (the reference transforms
+     * any axes where they lie, xrft/xrft.py:395-409), e.g. dim = ["y", "x"] of a (y, x, time) array: batch = 1, inner = nt.  No transposed
+     * copy is made: x is transformed where it lies ([batch ny][nx][inner], as XRFTHIP_AXIS_Y does for one axis), then y
+     * ([batch][ny][nx inner]); a detrend runs first as a pass of its own.  ndim = 2, out_mode COMPLEX | POWER, flags SHIFT_* /
+     * ISHIFT_* / FLIP_*; windows, phases and `scale` as usual.  0 or 1 = the trailing-axes layout.  A descriptor with the
+     * struct_size of the version without this field is accepted (inner = 1). */
+    int64_t inner;
 } xrfthip_desc;
 
 typedef struct xrfthip_plan xrfthip_plan;
@@ -161,6 +169,13 @@ int xrfthip_exec(const xrfthip_plan* plan, const void* d_in0, const void* d_in1,
 size_t xrfthip_detrend_workspace_bytes(int64_t batch);
 int xrfthip_detrend(int32_t dtype, int32_t ndim, int64_t batch, int64_t ny, int64_t nx, int32_t detrend_type,
                     const void* d_in, void* d_out, void* d_workspace, size_t ws_bytes, void* stream);
+
+/* The same with the independent elements innermost: [batch][ny][nx][inner], mean or least-squares plane over (ny, nx) for every
+ * (batch, inner) element (ndim = 2), or line over nx of [batch][nx][inner] (ndim = 1, ny = 1) -- xrft.detrend over adjacent axes that
+ * are not the trailing ones, without a transposed copy.  d_workspace: >= xrfthip_detrend_inner_workspace_bytes(dtype, batch, inner). */
+size_t xrfthip_detrend_inner_workspace_bytes(int32_t dtype, int64_t batch, int64_t inner);
+int xrfthip_detrend_inner(int32_t dtype, int32_t ndim, int64_t batch, int64_t ny, int64_t nx, int64_t inner, int32_t detrend_type,
+                          const void* d_in, void* d_out, void* d_workspace, size_t ws_bytes, void* stream);
 
 /* The same over the last THREE axes (n0, n1, n2) of [batch][n0][n1][n2]: mean, or the least-squares hyperplane
  * a0 + a1 i + a2 j + a3 k of xrft/detrend.py:116-138 (_detrend_3d_ufunc).  Same workspace size as xrfthip_detrend. */

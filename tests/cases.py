@@ -22,7 +22,13 @@ TOL = {"float64": 1e-10, "float32": 3e-4, "complex128": 1e-10, "complex64": 3e-4
 
 
 def pair(data, dims, coords=None):
-    return xa.DataArray(data, dims, coords), o.OArr(data, dims, coords)
+    """The product's array and the oracle's, from the same samples.  float32 / complex64 samples go to the oracle as float64 /
+    complex128 (the same values): the yardstick of the float32 path is what the reference's algorithm gives in exact-enough
+    arithmetic, not the reference's own float32 rounding (its float32 `da - da.mean()` and scipy detrend leave up to 5e-3 of
+    relative error in bins 1e-6 of the peak -- tests/cases.py fine_errors -- which would otherwise be charged to the product)."""
+    a = np.asarray(data)
+    ref = a.astype(np.float64) if a.dtype == np.float32 else (a.astype(np.complex128) if a.dtype == np.complex64 else a)
+    return xa.DataArray(data, dims, coords), o.OArr(ref, dims, coords)
 
 
 def rel_err(got, ref):
@@ -73,7 +79,8 @@ def check(got, ref, tol, bin_rel=BIN_REL):
     assert err < tol, f"rel err {err:.3e} >= {tol:.1e}"
     if tol > 1e-8:  # float32 tolerances: the finer norms
         binrel, l1 = fine_errors(got.values, ref.values)
-        assert l1 < tol, f"L1 err {l1:.3e} >= {tol:.1e}"
+        l1_tol = max(tol, TOL["float32"])  # (callers that hold the max norm tighter than 3e-4 do so on spectra led by one huge bin)
+        assert l1 < l1_tol, f"L1 err {l1:.3e} >= {l1_tol:.1e}"
         assert binrel < bin_rel, f"worst per-bin rel err {binrel:.3e} >= {bin_rel:.1e}"
     return err
 
@@ -719,7 +726,7 @@ def check_values(got, ref, tol):
     err = float(np.abs(g - r).max() / max(float(np.abs(r).max()), 1e-300))
     assert g.shape == r.shape and err < tol, f"rel err {err:.3e} >= {tol:.1e}"
     binrel, l1 = fine_errors(g, r)
-    assert l1 < tol and binrel < BIN_REL, f"L1 err {l1:.3e} (< {tol:.1e}), worst per-bin rel err {binrel:.3e} (< {BIN_REL:.1e})"
+    assert l1 < max(tol, TOL["float32"]) and binrel < BIN_REL, f"L1 err {l1:.3e} (< {max(tol, TOL['float32']):.1e}), worst per-bin rel err {binrel:.3e} (< {BIN_REL:.1e})"
     return err
 
 
@@ -910,3 +917,52 @@ def run_reduce_axis_cases():
     assert m.dims == ("freq_r",) and np.array_equal(m["freq_r"].values, np.arange(9) * 0.1)
     npt.assert_allclose(m.values, da.values.mean(axis=0), rtol=1e-13)
     npt.assert_allclose(da.sum("freq_r").values, da.values.sum(axis=1), rtol=1e-13)
+
+
+def run_inner_layout_cases(dtype="float64", shape=(24, 20, 6)):
+    """Two ADJACENT transform axes that are not the trailing ones -- dim = ["y", "x"] of a (y, x, t) array, (t, y, x, z), the two in
+    either order -- through the engine's inner layout (xrfthip_desc.inner: x where it lies, then y, a detrend pass first; no
+    transposed copies) against the oracle; and xrft.detrend over such axes (xrfthip_detrend_inner).  xrft.py:395-409."""
+    rng = np.random.default_rng(97)
+    tol = TOL[dtype]
+    ny, nx, nt = shape
+    ii, jj = np.meshgrid(np.arange(ny), np.arange(nx), indexing="ij")
+    v = (rng.standard_normal(shape) + (0.05 * ii - 0.03 * jj + 2.0)[:, :, None] * (1.0 + np.arange(nt))[None, None, :]).astype(dtype)
+    c = {"y": np.arange(ny) * 0.5 + 1.0, "x": np.arange(nx) * 2.0 - 3.0, "t": np.arange(nt)}
+    da, od = pair(v, ("y", "x", "t"), c)
+    worst = 0.0
+
+    def on_inner():
+        return "[inner layout]" in next(reversed(xa.api._plan_cache.values())).describe()
+
+    for kw in (dict(), dict(detrend="linear", window="hann"), dict(detrend="constant", shift=False, true_phase=False), dict(window="hamming", true_amplitude=False)):
+        worst = max(worst, check(xa.fft(da, dim=["y", "x"], **kw), o.fft(od, dim=["y", "x"], **kw), tol))
+        assert on_inner(), kw
+    for kw in (dict(detrend="linear", window="hann"), dict(scaling="spectrum", shift=False), dict(detrend="constant", window="hann", window_correction=True)):
+        worst = max(worst, check(xa.power_spectrum(da, dim=["y", "x"], **kw), o.power_spectrum(od, dim=["y", "x"], **kw), tol))
+        assert on_inner(), kw
+    # the same axes named in the other order: the plan's first axis is the one that comes first in memory
+    worst = max(worst, check(xa.fft(da, dim=["x", "y"], detrend="linear", window="hann"), o.fft(od, dim=["x", "y"], detrend="linear", window="hann"), tol))
+    assert on_inner()
+    worst = max(worst, check(xa.power_spectrum(da, dim=["x", "y"], window="hann"), o.power_spectrum(od, dim=["x", "y"], window="hann"), tol))
+    # a descending coordinate (flip) and complex input
+    c2 = dict(c); c2["x"] = c["x"][::-1].copy()
+    da2, od2 = pair(v, ("y", "x", "t"), c2)
+    worst = max(worst, check(xa.fft(da2, dim=["y", "x"], window="hann"), o.fft(od2, dim=["y", "x"], window="hann"), tol))
+    assert on_inner()
+    z = (v + 1j * rng.standard_normal(shape)).astype("complex128" if dtype == "float64" else "complex64")
+    dz, oz = pair(z, ("y", "x", "t"), c)
+    worst = max(worst, check(xa.fft(dz, dim=["y", "x"], detrend="constant"), o.fft(oz, dim=["y", "x"], detrend="constant"), tol))
+    assert on_inner()
+    # leading AND trailing dims
+    w = rng.standard_normal((3, 12, 10, 4)).astype(dtype)
+    c4 = {"t": np.arange(3), "y": np.arange(12) * 1.0, "x": np.arange(10) * 0.25, "z": np.arange(4)}
+    d4, o4 = pair(w, ("t", "y", "x", "z"), c4)
+    worst = max(worst, check(xa.power_spectrum(d4, dim=["y", "x"], detrend="linear", window="hann"), o.power_spectrum(o4, dim=["y", "x"], detrend="linear", window="hann"), tol))
+    assert on_inner()
+    # stand-alone detrend where the axes lie
+    for det in ("constant", "linear"):
+        worst = max(worst, check(xa.detrend(da, ["y", "x"], det), o.detrend(od, ["y", "x"], det).transpose("y", "x", "t"), tol))
+        worst = max(worst, check(xa.detrend(d4, ["y", "x"], det), o.detrend(o4, ["y", "x"], det).transpose("t", "y", "x", "z"), tol))
+        worst = max(worst, check(xa.detrend(d4, "y", det), o.detrend(o4, "y", det).transpose("t", "y", "x", "z"), tol))
+    return worst

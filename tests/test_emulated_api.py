@@ -447,3 +447,22 @@ def test_adversarial_detrend_float32(n):
 
 def test_reduce_axis_kernel():
     cases.run_reduce_axis_cases()
+
+
+@pytest.mark.parametrize("dtype", ["float64", "float32"])
+def test_two_adjacent_axes_that_are_not_the_trailing_ones(dtype):
+    cases.run_inner_layout_cases(dtype)
+
+
+def test_huge_slab_along_a_first_axis_takes_the_transposing_path():
+    """a cube whose [n][inner] slab exceeds 2^31 elements cannot be indexed by the one-axis plans; plan creation is
+    refused (XRFTHIP_BAD_ARG) and the API must not hand that error to the caller -- it never asks for such a plan."""
+    import ctypes as C
+
+    dll = _lib.load()
+    for batch, ny, nx in ((1, 4096, 2048 * 2048), (1, 365, 1440 * 721 * 8), (2, 30, 1 << 27)):
+        d = _lib.Desc(C.sizeof(_lib.Desc), 2, batch, ny, nx, _lib.F32, _lib.OUT_COMPLEX, 0, _lib.AXIS_Y, 1.0, 0, 0, 1)
+        h = C.c_void_p(0)
+        assert dll.xrfthip_plan_create(C.byref(h), C.byref(d)) == -1
+    src = open(os.path.join(os.path.dirname(api.__file__), "api.py")).read()
+    assert "ny * nx > (1 << 31) - 1" in src  # _execute_axis_y returns None (-> _arrange) before asking for the plan

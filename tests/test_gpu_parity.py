@@ -866,3 +866,41 @@ def test_collective_leg_on_one_gpu_through_rccl():
     finally:
         if created:
             dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("dtype", ["float64", "float32"])
+def test_two_adjacent_axes_that_are_not_the_trailing_ones(dtype):
+    cases.run_inner_layout_cases(dtype)
+    cases.run_inner_layout_cases(dtype, shape=(360, 256, 12))
+
+
+@pytest.mark.parametrize("dtype", ["float32", "float64"])
+def test_two_axes_with_the_batch_innermost_without_copies(dtype):
+    """dim = ["y", "x"] of a (y, x, t) array -- the batch INNERMOST -- runs where the axes lie (xrfthip_desc.inner; the reference
+    transforms any axes in place, xrft.py:395-409): after the first call (plan, tables, scratch) the only device memory a call
+    allocates is its result -- no transposed copy of the input or of the result, no torch permute -- and the result has the
+    input's layout."""
+    import xrft_amd as xa
+    from xrft_amd import api
+
+    shape = (256, 240, 48)
+    rng = np.random.default_rng(6)
+    v = (rng.standard_normal(shape) + 0.01 * np.arange(shape[0])[:, None, None]).astype(dtype)
+    c = {"y": np.arange(shape[0]) * 0.5, "x": np.arange(shape[1]) * 0.25, "t": np.arange(shape[2]) * 2.0}
+    x = torch.from_numpy(v).cuda()
+    da = xa.DataArray(x, ("y", "x", "t"), c)
+    kw = dict(dim=["y", "x"], detrend="linear", window="hann")
+    for fn, ofn in ((xa.power_spectrum, o.power_spectrum), (xa.fft, o.fft)):
+        res = fn(da, **kw)
+        assert "[inner layout]" in next(reversed(api._plan_cache.values())).describe()
+        del res
+        torch.cuda.synchronize()
+        torch.cuda.reset_peak_memory_stats()
+        before = torch.cuda.memory_allocated()
+        res = fn(da, **kw)
+        torch.cuda.synchronize()
+        peak = torch.cuda.max_memory_allocated() - before
+        out_bytes = res.data.numel() * res.data.element_size()
+        assert peak <= out_bytes + (1 << 20), (peak, out_bytes)
+        assert res.data.is_contiguous() and tuple(res.dims) == ("freq_y", "freq_x", "t")
+        cases.check(res, ofn(o.OArr(v.astype(np.float64), ("y", "x", "t"), c), **kw), 2e-4 if dtype == "float32" else 1e-10)

@@ -27,7 +27,7 @@ EXPORTS = [
     "xrfthip_plan_destroy", "xrfthip_plan_set_window", "xrfthip_plan_set_phase", "xrfthip_plan_set_binmap",
     "xrfthip_plan_set_profiling", "xrfthip_plan_profile_read", "xrfthip_workspace_bytes", "xrfthip_plan_describe", "xrfthip_exec", "xrfthip_detrend_workspace_bytes",
     "xrfthip_detrend", "xrfthip_detrend3", "xrfthip_spectrum_tail", "xrfthip_spectrum_tail_axis", "xrfthip_gather_axis", "xrfthip_isotropize",
-    "xrfthip_isotropize_workspace_bytes", "xrfthip_table_mul", "xrfthip_reduce_axis",
+    "xrfthip_isotropize_workspace_bytes", "xrfthip_table_mul", "xrfthip_reduce_axis", "xrfthip_detrend_inner_workspace_bytes", "xrfthip_detrend_inner",
 ]
 
 
@@ -47,6 +47,7 @@ class Desc(C.Structure):
         ("struct_size", C.c_uint32), ("ndim", C.c_int32), ("batch", C.c_int64), ("ny", C.c_int64),
         ("nx", C.c_int64), ("dtype", C.c_int32), ("out_mode", C.c_int32), ("detrend", C.c_int32),
         ("flags", C.c_uint32), ("scale", C.c_double), ("slabs_per_group", C.c_int32), ("reserved", C.c_int32),
+        ("inner", C.c_int64),  # > 1: arrays are [batch][ny][nx][inner], two adjacent transform axes with the independent elements innermost
     ]
 
 
@@ -76,6 +77,9 @@ def _bind(dll):
     dll.xrfthip_gather_axis.argtypes = [i32, i64, i64, i64, i64, vp, i64, vp, vp, vp]
     dll.xrfthip_table_mul.argtypes = [i32, i64, i64, i64, vp, vp, vp, vp]
     dll.xrfthip_reduce_axis.argtypes = [i32, i64, i64, i64, vp, vp, C.c_double, vp]
+    dll.xrfthip_detrend_inner_workspace_bytes.restype = sz
+    dll.xrfthip_detrend_inner_workspace_bytes.argtypes = [i32, i64, i64]
+    dll.xrfthip_detrend_inner.argtypes = [i32, i32, i64, i64, i64, i64, i32, vp, vp, vp, sz, vp]
     dll.xrfthip_isotropize_workspace_bytes.restype = sz
     dll.xrfthip_isotropize_workspace_bytes.argtypes = [i32, i64, i64, i64, i32]
     dll.xrfthip_isotropize.argtypes = [i32, i64, i64, i64, vp, vp, i32, vp, vp, sz, vp]

@@ -440,6 +440,8 @@ def _execute_axis_y(c, da, mode, scale, k, da2=None, c2=None):
             t, t2 = t.to(dt), t2.to(dt)
     kw = dict(ndim=2, batch=batch, ny=ny, nx=nx, dtype=t.dtype, out_mode=mode, detrend=c.detrend, flags=yflags,
               scale=float(scale), window_y=win["x"], window_x=None, phase_y=ph["x"], phase_x=None)
+    if ny * nx > (1 << 31) - 1 or nx > (1 << 30) or ny > (1 << 30):
+        return None  # the engine indexes a slab with 32 bits: a cube this large along a first / middle axis takes the transposing path
     try:
         plan = _get_plan(**kw)
     except _lib.XrftHipError as e:
@@ -450,12 +452,61 @@ def _execute_axis_y(c, da, mode, scale, k, da2=None, c2=None):
     return out.reshape(shape)
 
 
+def _swap_xy(flags):
+    """The per-axis flag bits with the roles of x and y exchanged."""
+    out = flags & ~(_lib.SHIFT_X | _lib.SHIFT_Y | _lib.ISHIFT_X | _lib.ISHIFT_Y | _lib.FLIP_X | _lib.FLIP_Y)
+    for fx, fy in ((_lib.SHIFT_X, _lib.SHIFT_Y), (_lib.ISHIFT_X, _lib.ISHIFT_Y), (_lib.FLIP_X, _lib.FLIP_Y)):
+        if flags & fx:
+            out |= fy
+        if flags & fy:
+            out |= fx
+    return out
+
+
+def _execute_inner(c, da, mode, scale):
+    """Two ADJACENT transform axes that are not the trailing ones, e.g. dim = ["y", "x"] of a (y, x, time) array: the engine's
+    inner layout [batch][n0][n1][inner] (xrfthip_desc.inner) transforms them where they lie, as the reference does
+    (xrft.py:395-409) -- no transposed copy of the input or of the result.  Returns the result in the input's dim order, or None
+    when the call is not of this kind (the caller then takes the transposing path)."""
+    if len(c.dim) != 2 or c.real_dim is not None or mode not in (_lib.OUT_COMPLEX, _lib.OUT_POWER):
+        return None
+    p, q = da.get_axis_num(c.ydim), da.get_axis_num(c.xdim)
+    first, second = min(p, q), max(p, q)
+    if second != first + 1 or second == len(da.dims) - 1:
+        return None
+    t = _to_device(da.data).contiguous()  # C-contiguous input: no copy
+    shape = list(t.shape)
+    inner = int(np.prod(shape[second + 1:], dtype=np.int64))
+    batch = int(np.prod(shape[:first], dtype=np.int64))
+    if inner < 2 or inner * shape[second] > (1 << 30):
+        return None
+    flags, win, ph = _flags_tables(c, da)
+    if mode == _lib.OUT_POWER:
+        ph = {"y": None, "x": None}
+    if p > q:  # the array holds (x, y): the plan's first axis is the one that comes first in memory
+        flags, win, ph = _swap_xy(flags), {"y": win["x"], "x": win["y"]}, {"y": ph["x"], "x": ph["y"]}
+    kw = dict(ndim=2, batch=batch, ny=shape[first], nx=shape[second], inner=inner, dtype=t.dtype, out_mode=mode, detrend=c.detrend, flags=flags,
+              scale=float(scale), window_y=win["y"], window_x=win["x"], phase_y=ph["y"], phase_x=ph["x"])
+    try:
+        plan = _get_plan(**kw)
+    except _lib.XrftHipError as e:
+        if e.status in (_lib.UNSUPPORTED_LENGTH, -1):  # a length or extent the one-axis plans do not take: the transposing path
+            return None
+        raise
+    out, _ = plan.execute(t)
+    return out.reshape(shape)
+
+
 def _execute(c, da, mode, scale, da2=None, c2=None, iso=None, extra_flags=0):
     k = _inplace_axis(c, da, iso) if extra_flags == 0 else None
     if k is not None:
         out = _execute_axis_y(c, da, mode, scale, k, da2, c2)
         if out is not None:
             return out, None, None  # other = None: the output has the input's dim order
+    if extra_flags == 0 and iso is None and da2 is None:
+        out = _execute_inner(c, da, mode, scale)
+        if out is not None:
+            return out, None, None
     t, other = _arrange(c, da)
     ndim = len(c.dim)
     nx = da.sizes[c.xdim]
@@ -968,10 +1019,16 @@ def detrend(da, dim, detrend_type="constant"):
     dim = [d for _, d in sorted(zip(axes, dim))]  # memory order: the fit does not depend on the order of the axes
     other = [d for d in da.dims if d not in dim]
     order = other + dim
+    kind = _lib.DETREND_CONSTANT if detrend_type == "constant" else _lib.DETREND_LINEAR
+    ax_sorted = sorted(axes)
+    if (len(dim) <= 2 and ax_sorted[-1] != len(da.dims) - 1 and ax_sorted == list(range(ax_sorted[0], ax_sorted[0] + len(dim)))
+            and int(np.prod(t.shape[ax_sorted[-1] + 1:], dtype=np.int64)) > 1):
+        # one or two adjacent axes that are not the trailing ones: detrended where they lie (xrfthip_detrend_inner), no transposed copies
+        out = engine.detrend_inner(t.contiguous(), ax_sorted[0], len(dim), kind)
+        return to_like(DataArray(out, da.dims, da.coords, da.name, da.attrs), src)
     if tuple(order) != tuple(da.dims):
         t = t.permute([da.get_axis_num(d) for d in order])
     t = t.contiguous()
-    kind = _lib.DETREND_CONSTANT if detrend_type == "constant" else _lib.DETREND_LINEAR
     if len(dim) > 3 or (len(dim) == 3 and detrend_type == "constant"):
         # the mean over any number of trailing axes is the mean of the flattened block
         nblk = int(np.prod([da.sizes[d] for d in dim]))

@@ -298,6 +298,69 @@ __global__ void __launch_bounds__(256) table_mul_kernel(const void* in, const C2
     }
 }
 
+// Detrending with the independent elements INNERMOST: data [batch][ny][nx][inner2] (inner2 counts real components: 2 per complex
+// sample), one mean / least-squares plane over (ny, nx) per (batch, inner2) element (xrft/detrend.py:54-55, 100-113 for two adjacent
+// axes that are not the trailing ones).  A workgroup = IB consecutive inner2 indices (lanes: contiguous) x XS columns; rows are dealt
+// round-robin to the gridDim.x chunks of a slab; part[b][chunk][i2][3] = { sum d, sum (i - ibar) d, sum (j - jbar) d }, added in
+// chunk order by plane_inner_finalize_kernel (no atomics: bit-reproducible).
+constexpr int kInnerIB = 32, kInnerXS = 8;
+template <typename T>
+__global__ void __launch_bounds__(kInnerIB * kInnerXS) plane_inner_moments_kernel(const T* __restrict__ in, long long ny, long long nx, long long inner2, double* part) {
+    XRFT_DYN_SMEM(smem_raw);
+    double (*red)[3][kInnerIB] = reinterpret_cast<double (*)[3][kInnerIB]>(smem_raw);  // [XS][3][IB]
+    const int li = threadIdx.x % kInnerIB, xs = threadIdx.x / kInnerIB;
+    const long long i2 = (long long)blockIdx.y * kInnerIB + li, b = blockIdx.z;
+    const double ibar = 0.5 * (double)(ny - 1), jbar = 0.5 * (double)(nx - 1);
+    double s0 = 0.0, si = 0.0, sj = 0.0;
+    if (i2 < inner2) {
+        for (long long i = blockIdx.x; i < ny; i += gridDim.x) {
+            const T* row = in + ((b * ny + i) * nx) * inner2 + i2;
+            double r0 = 0.0, rj = 0.0;
+            for (long long j = xs; j < nx; j += kInnerXS) {
+                const double v = (double)row[j * inner2];
+                r0 += v;
+                rj = fma((double)j - jbar, v, rj);
+            }
+            s0 += r0; sj += rj;
+            si = fma((double)i - ibar, r0, si);
+        }
+    }
+    red[xs][0][li] = s0; red[xs][1][li] = si; red[xs][2][li] = sj;
+    __syncthreads();
+    if (xs == 0 && i2 < inner2) {
+        for (int k = 1; k < kInnerXS; ++k) { s0 += red[k][0][li]; si += red[k][1][li]; sj += red[k][2][li]; }
+        double* dst = part + ((b * gridDim.x + blockIdx.x) * inner2 + i2) * 3;
+        dst[0] = s0; dst[1] = si; dst[2] = sj;
+    }
+}
+// coef[b][i2] = { c0, c1, c2 }: trend = c0 + c1 i + c2 j (kind 1: the mean)
+__global__ void plane_inner_finalize_kernel(const double* part, double* coef, long long batch, long long ny, long long nx, long long inner2, int nchunk, int kind) {
+    const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= batch * inner2) return;
+    const long long b = e / inner2, i2 = e - b * inner2;
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0;
+    for (int ch = 0; ch < nchunk; ++ch) {
+        const double* src = part + ((b * nchunk + ch) * inner2 + i2) * 3;
+        a0 += src[0]; a1 += src[1]; a2 += src[2];
+    }
+    const double n = (double)ny * (double)nx, ibar = 0.5 * (double)(ny - 1), jbar = 0.5 * (double)(nx - 1);
+    const double sii = (double)nx * (double)ny * ((double)ny * (double)ny - 1.0) / 12.0, sjj = (double)ny * (double)nx * ((double)nx * (double)nx - 1.0) / 12.0;
+    double c1 = 0.0, c2 = 0.0;
+    if (kind == 2) { if (ny > 1) c1 = a1 / sii; if (nx > 1) c2 = a2 / sjj; }
+    coef[e * 3] = a0 / n - c1 * ibar - c2 * jbar;
+    coef[e * 3 + 1] = c1;
+    coef[e * 3 + 2] = c2;
+}
+template <typename T>
+__global__ void __launch_bounds__(256) plane_inner_apply_kernel(const T* __restrict__ in, T* __restrict__ out, const double* __restrict__ coef, long long batch, long long ny, long long nx, long long inner2) {
+    const long long total = batch * ny * nx * inner2;
+    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
+        const long long i2 = e % inner2, r = e / inner2, j = r % nx, r2 = r / nx, i = r2 % ny, b = r2 / ny;
+        const double* c = coef + (b * inner2 + i2) * 3;
+        out[e] = (T)((double)in[e] - (c[0] + c[1] * (double)i + c[2] * (double)j));
+    }
+}
+
 // out[o][i] = scale * sum_k in[o][k][i] over [outer][n][inner] (complex data: inner counts real components), the terms added in
 // the order k = 0, 1, ... in float64: a mean / sum over a batch dimension whose result does not depend on how the launch was
 // scheduled (the reference's users average isotropic spectra over the batch: xrft/tests/test_xrft.py:1011-1013, `.mean("d0")`).

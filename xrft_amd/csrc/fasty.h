@@ -683,7 +683,10 @@ __global__ void __launch_bounds__((YRows<NX, FS>::THR), (YRows<NX, FS>::THR / 12
             for (int i = tid; i < p.nbins; i += THR) bmax[i] = 0u;
             // this thread's run of L samples of row ky0 + rd NR + rl: bin codes in natural order, (bin + 1) | (mirror bin + 1) << 16
             unsigned codes[L];
-            {
+            if (XRFT_YTUNE(p) & (1 << 16)) {  // (ablation, tuning build: no bin-code loads)
+#pragma unroll
+                for (int i = 0; i < L; ++i) codes[i] = (unsigned)(1 + ((kx0 + i) >> 2)) * 0x10001u;
+            } else {
                 const unsigned* __restrict__ tc = p.tcodes + (size_t)(ky0 + rd * NR + rl) * NX + kx0;
 #pragma unroll
                 for (int i = 0; i < L; i += 4) {
@@ -696,7 +699,7 @@ __global__ void __launch_bounds__((YRows<NX, FS>::THR), (YRows<NX, FS>::THR / 12
             // run's last sample, and records its magnitude in the bins it goes to (one atomicMax per run and bin)
             const float* src = sreg + rl * RSI + (MODE == 1 ? 1 : 2) * nat16(kx0);
             float rsr[L], rsi[MODE == 2 ? L : 1];
-            {
+            if (!(XRFT_YTUNE(p) & (1 << 17))) {
                 float sr = 0.f, si = 0.f;
 #pragma unroll
                 for (int i = 0; i < L; ++i) {
@@ -716,6 +719,7 @@ __global__ void __launch_bounds__((YRows<NX, FS>::THR), (YRows<NX, FS>::THR / 12
             __syncthreads();
             // sweep 2: every run sum converted to int64 fixed point 40 bits below its bin's largest and added with an INTEGER atomic
             // (exact: the order in which lanes arrive does not matter)
+            if (!(XRFT_YTUNE(p) & (1 << 17)))
 #pragma unroll
             for (int i = 0; i < L; ++i) {
                 const bool last = i == L - 1 || codes[i + 1] != codes[i];
@@ -737,6 +741,7 @@ __global__ void __launch_bounds__((YRows<NX, FS>::THR), (YRows<NX, FS>::THR / 12
             __syncthreads();
             // this round's sums, back in floating point, into the workgroup's row of the partial table (the same thread adds round 2
             // to what it wrote in round 1: a fixed order).  A bin with an inf / nan member is +inf (power) or nan, as IEEE sums are.
+            if (!(XRFT_YTUNE(p) & (1 << 18)))
             for (int i = tid; i < p.nbins * HW; i += THR) {
                 const unsigned bm = bmax[i / HW];
                 double v = ldexp((double)(long long)acc[i], (int)(bm >> 23) - 127 - 40);

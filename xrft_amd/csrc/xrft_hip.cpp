@@ -15,6 +15,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
+#include <cstddef>
 #include <cstring>
 #include <map>
 #include <new>
@@ -329,7 +330,14 @@ struct xrfthip_plan {
     struct ProfRec { std::string label; hipEvent_t a, b; };
     std::vector<ProfRec> prof_recs;
     void prof_clear() { for (auto& r : prof_recs) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); } prof_recs.clear(); }
-    ~xrfthip_plan() { for (auto* b : extra) delete b; prof_clear(); }
+    // xrfthip_desc.inner > 1: [batch][ny][nx][inner], two adjacent transform axes with the independent elements innermost.  A
+    // composite of two in-place one-axis plans (XRFTHIP_AXIS_Y): sub_x transforms x of [batch ny][nx][inner], sub_y transforms y of
+    // [batch][ny][nx inner]; a detrend runs first as a pass of its own (plane_inner_* kernels).  No transposed copy anywhere.
+    long long inner = 1;
+    xrfthip_plan* sub_x = nullptr;
+    xrfthip_plan* sub_y = nullptr;
+    size_t off_sub = 0, off_det = 0, off_mid = 0, off_dws = 0;
+    ~xrfthip_plan() { for (auto* b : extra) delete b; prof_clear(); delete sub_x; delete sub_y; }
 };
 
 namespace {
@@ -1664,9 +1672,76 @@ const char* xrfthip_strerror(int status) {
 
 int xrfthip_last_hip_error(void) { return g_last_hip_error; }
 
+static size_t detrend_inner_ws(bool cplx, long long batch, long long inner);
+static int run_detrend_inner(int32_t dtype, int32_t ndim, long long batch, long long ny, long long nx, long long inner, int32_t kind, const void* in, void* out,
+                             char* ws, hipStream_t st);
+
+// composite plan for xrfthip_desc.inner > 1 (see xrfthip_plan::inner)
+static int create_inner_plan(xrfthip_plan** plan, const xrfthip_desc& d) {
+    const uint32_t ok = XRFTHIP_SHIFT_Y | XRFTHIP_SHIFT_X | XRFTHIP_ISHIFT_Y | XRFTHIP_ISHIFT_X | XRFTHIP_FLIP_Y | XRFTHIP_FLIP_X;
+    if (d.ndim != 2 || (d.flags & ~ok) || (d.out_mode != XRFTHIP_OUT_COMPLEX && d.out_mode != XRFTHIP_OUT_POWER)) return XRFTHIP_BAD_ARG;
+    if (d.inner > (1LL << 30) || d.nx * d.inner > (1LL << 30)) return XRFTHIP_BAD_ARG;
+    xrfthip_plan* P = new (std::nothrow) xrfthip_plan();
+    if (!P) return XRFTHIP_ALLOC_FAILED;
+    P->d = d;
+    P->inner = d.inner;
+    P->dbl = d.dtype == XRFTHIP_F64 || d.dtype == XRFTHIP_C128;
+    P->cplx_in = d.dtype >= XRFTHIP_C64;
+    P->rsize = P->dbl ? 8 : 4;
+    P->csize = 2 * P->rsize;
+    P->nx_out = d.nx;
+    xrfthip_desc dx = d, dy = d;
+    dx.inner = dy.inner = 1;
+    dx.detrend = dy.detrend = XRFTHIP_DETREND_NONE;
+    // x where it lies: [batch ny][nx][inner], the per-axis flags of x become the y flags of the one-axis plan
+    dx.batch = d.batch * d.ny; dx.ny = d.nx; dx.nx = d.inner;
+    dx.out_mode = XRFTHIP_OUT_COMPLEX; dx.scale = 1.0;
+    dx.flags = XRFTHIP_AXIS_Y | ((d.flags & XRFTHIP_SHIFT_X) ? XRFTHIP_SHIFT_Y : 0u) | ((d.flags & XRFTHIP_ISHIFT_X) ? XRFTHIP_ISHIFT_Y : 0u) |
+               ((d.flags & XRFTHIP_FLIP_X) ? XRFTHIP_FLIP_Y : 0u);
+    // then y: [batch][ny][nx inner], complex input, the requested result and scale
+    dy.batch = d.batch; dy.ny = d.ny; dy.nx = d.nx * d.inner;
+    dy.dtype = P->dbl ? XRFTHIP_C128 : XRFTHIP_C64;
+    dy.flags = XRFTHIP_AXIS_Y | (d.flags & (XRFTHIP_SHIFT_Y | XRFTHIP_ISHIFT_Y | XRFTHIP_FLIP_Y));
+    int rc = xrfthip_plan_create(&P->sub_x, &dx);
+    if (!rc) rc = xrfthip_plan_create(&P->sub_y, &dy);
+    if (rc) { delete P; return rc; }
+    auto al = [](size_t v) { return (v + 255) & ~(size_t)255; };
+    const size_t pts = (size_t)d.batch * d.ny * d.nx * d.inner;
+    size_t off = 0;
+    P->off_sub = off; off = al(off + std::max(P->sub_x->ws_bytes, P->sub_y->ws_bytes));
+    P->off_mid = off; off = al(off + pts * P->csize);                                        // the x-transformed field (complex)
+    if (d.detrend) {
+        P->off_det = off; off = al(off + pts * (P->cplx_in ? P->csize : P->rsize));         // the detrended copy of the input
+        P->off_dws = off; off = al(off + detrend_inner_ws(P->cplx_in, d.batch, d.inner));
+    }
+    P->ws_bytes = off;
+    *plan = P;
+    return XRFTHIP_OK;
+}
+
+static int run_inner_plan(const xrfthip_plan* P, const void* in, void* out, char* ws, hipStream_t st) {
+    const xrfthip_desc& d = P->d;
+    const void* cur = in;
+    if (d.detrend) {
+        int rc = run_detrend_inner(d.dtype, 2, d.batch, d.ny, d.nx, d.inner, d.detrend, in, ws + P->off_det, ws + P->off_dws, st);
+        if (rc) return rc;
+        cur = ws + P->off_det;
+    }
+    int rc = xrfthip_exec(P->sub_x, cur, nullptr, ws + P->off_mid, nullptr, ws + P->off_sub, P->sub_x->ws_bytes, st);
+    if (!rc) rc = xrfthip_exec(P->sub_y, ws + P->off_mid, nullptr, out, nullptr, ws + P->off_sub, P->sub_y->ws_bytes, st);
+    return rc;
+}
+
 int xrfthip_plan_create(xrfthip_plan** plan, const xrfthip_desc* desc) {
-    if (!plan || !desc || desc->struct_size != sizeof(xrfthip_desc)) return XRFTHIP_BAD_ARG;
-    const xrfthip_desc& d = *desc;
+    // (a descriptor of the version before `inner` was appended is accepted: inner = 1)
+    constexpr uint32_t kOldDescSize = (uint32_t)offsetof(xrfthip_desc, inner);
+    if (!plan || !desc || (desc->struct_size != sizeof(xrfthip_desc) && desc->struct_size != kOldDescSize)) return XRFTHIP_BAD_ARG;
+    xrfthip_desc dcopy{};
+    memcpy(&dcopy, desc, desc->struct_size);
+    dcopy.struct_size = sizeof(xrfthip_desc);
+    if (dcopy.inner < 0) return XRFTHIP_BAD_ARG;
+    if (dcopy.inner == 0) dcopy.inner = 1;
+    const xrfthip_desc& d = dcopy;
     if (d.ndim != 1 && d.ndim != 2) return XRFTHIP_BAD_ARG;
     if (d.batch < 0 || d.nx < 1 || d.ny < 1 || (d.ndim == 1 && d.ny != 1)) return XRFTHIP_BAD_ARG;
     if (d.nx > (1LL << 30) || d.ny > (1LL << 30) || d.nx * d.ny > (1LL << 31) - 1) return XRFTHIP_BAD_ARG;  // per-element index math is 32-bit
@@ -1686,6 +1761,8 @@ int xrfthip_plan_create(xrfthip_plan** plan, const xrfthip_desc* desc) {
     if ((d.flags & XRFTHIP_FLIP0_Y) && d.ndim == 1) return XRFTHIP_BAD_ARG;
     if ((d.flags & XRFTHIP_AXIS_Y) && (d.ndim != 2 || (d.flags & XRFTHIP_FLIP0_X) || (d.flags & (XRFTHIP_SHIFT_X | XRFTHIP_ISHIFT_X | XRFTHIP_FLIP_X | XRFTHIP_HALF_X | XRFTHIP_REALDIM_X2 |
                                                                     XRFTHIP_ISO | XRFTHIP_NO_SPECTRUM_OUT | XRFTHIP_C2R_X | XRFTHIP_PHASE_IN)))) return XRFTHIP_BAD_ARG;
+
+    if (d.inner > 1) return create_inner_plan(plan, d);
 
     xrfthip_plan* P = new (std::nothrow) xrfthip_plan();
     if (!P) return XRFTHIP_ALLOC_FAILED;
@@ -1832,6 +1909,7 @@ int xrfthip_plan_destroy(xrfthip_plan* plan) {
 int xrfthip_plan_set_window(xrfthip_plan* plan, int axis, const double* h_window, int64_t n) {
     if (!plan || axis < 0 || axis > 1) return XRFTHIP_BAD_ARG;
     if (h_window && n != (axis == 0 ? plan->d.ny : plan->d.nx)) return XRFTHIP_BAD_ARG;
+    if (plan->inner > 1) return xrfthip_plan_set_window(axis == 0 ? plan->sub_y : plan->sub_x, 0, h_window, n);  // (each one-axis plan transforms its "y")
     if (axis == 0) plan->host_win_y.assign(h_window ? h_window : nullptr, h_window ? h_window + n : nullptr);
     int rc = upload_real_table(plan, plan->win[axis], h_window, n, 0);
     if (!rc) rc = finalize_plan(plan);
@@ -1843,6 +1921,7 @@ int xrfthip_plan_set_phase(xrfthip_plan* plan, int axis, const double* h_phase, 
     // an input phase of a c2r transform covers the stored half of the x axis only
     const int64_t want = axis == 0 ? plan->d.ny : ((plan->d.flags & XRFTHIP_C2R_X) ? plan->d.nx / 2 + 1 : plan->d.nx);
     if (h_phase && n != want) return XRFTHIP_BAD_ARG;
+    if (plan->inner > 1) return xrfthip_plan_set_phase(axis == 0 ? plan->sub_y : plan->sub_x, 0, h_phase, n);
     plan->host_phase[axis].assign(h_phase ? h_phase : nullptr, h_phase ? h_phase + 2 * n : nullptr);
     int rc = upload_real_table(plan, plan->phase[axis], h_phase, n, 1);
     if (!rc) rc = finalize_plan(plan);  // (a non-trivial phase can take an isotropic cross spectrum off the specialised path: new layout)
@@ -1872,6 +1951,7 @@ int xrfthip_plan_set_binmap(xrfthip_plan* plan, const int32_t* h_binmap, int64_t
 
 int xrfthip_plan_set_profiling(xrfthip_plan* plan, int enable) {
     if (!plan) return XRFTHIP_BAD_ARG;
+    if (plan->inner > 1) { const int rc = xrfthip_plan_set_profiling(plan->sub_x, enable); return rc ? rc : xrfthip_plan_set_profiling(plan->sub_y, enable); }
     plan->prof_clear();
     plan->prof_recs.reserve(1 << 16);  // prof_begin hands out pointers into this vector
     plan->prof = enable != 0;
@@ -1880,6 +1960,12 @@ int xrfthip_plan_set_profiling(xrfthip_plan* plan, int enable) {
 
 int xrfthip_plan_profile_read(xrfthip_plan* plan, char* buf, size_t buflen) {
     if (!plan || !buf || !buflen) return XRFTHIP_BAD_ARG;
+    if (plan->inner > 1) {  // the two one-axis plans' records, one after the other
+        const int n1 = xrfthip_plan_profile_read(plan->sub_x, buf, buflen);
+        if (n1 < 0) return n1;
+        const int n2 = xrfthip_plan_profile_read(plan->sub_y, buf + n1, buflen - (size_t)n1);
+        return n2 < 0 ? n2 : n1 + n2;
+    }
     std::vector<std::string> order;
     std::map<std::string, std::pair<long long, double>> agg;
     for (auto& r : plan->prof_recs) {
@@ -1907,6 +1993,21 @@ int xrfthip_plan_describe(const xrfthip_plan* plan, char* buf, size_t buflen) {
     if (!plan || !buf || !buflen) return XRFTHIP_BAD_ARG;
     std::string s;
     const xrfthip_desc& d = plan->d;
+    if (plan->inner > 1) {
+        appendf(s, "xrfthip plan: [batch %lld][ny %lld][nx %lld][inner %lld] dtype=%d mode=%d detrend=%d flags=0x%x ws=%zuB\n  [inner layout] no transposed copy: %sx where it lies, then y\n",
+                (long long)d.batch, (long long)d.ny, (long long)d.nx, (long long)plan->inner, d.dtype, d.out_mode, d.detrend, d.flags, plan->ws_bytes,
+                d.detrend ? "detrend pass (plane per (batch, inner) element), " : "");
+        for (const xrfthip_plan* sp : {plan->sub_x, plan->sub_y}) {
+            std::vector<char> tmp(4096);
+            xrfthip_plan_describe(sp, tmp.data(), tmp.size());
+            s += "  ";
+            for (const char* c = tmp.data(); *c; ++c) { s += *c; if (*c == '\n' && c[1]) s += "  "; }
+        }
+        const size_t n = std::min(buflen - 1, s.size());
+        memcpy(buf, s.data(), n);
+        buf[n] = 0;
+        return (int)n;
+    }
     appendf(s, "xrfthip plan: ndim=%d batch=%lld ny=%lld nx=%lld dtype=%d mode=%d detrend=%d flags=0x%x width=%lld nx_out=%lld mirror=%d group=%d ws=%zuB\n",
             d.ndim, (long long)d.batch, (long long)d.ny, (long long)d.nx, d.dtype, d.out_mode, d.detrend, d.flags,
             plan->width, plan->nx_out, (int)plan->mirror, plan->G, plan->ws_bytes);
@@ -1949,6 +2050,10 @@ int xrfthip_exec(const xrfthip_plan* plan, const void* d_in0, const void* d_in1,
     if (cross && !d_in1) return XRFTHIP_BAD_ARG;
     if (!d_out && !(d.flags & XRFTHIP_NO_SPECTRUM_OUT)) return XRFTHIP_BAD_ARG;
     if (iso && (!d_iso || !P->binmap.p)) return d_iso ? XRFTHIP_MISSING_TABLE : XRFTHIP_BAD_ARG;
+    if (P->inner > 1) {
+        if (ws_bytes < P->ws_bytes || !d_workspace) return XRFTHIP_WORKSPACE_TOO_SMALL;
+        return d.batch == 0 ? XRFTHIP_OK : run_inner_plan(P, d_in0, d_out, (char*)d_workspace, (hipStream_t)stream);
+    }
     if (P->passes.empty()) return XRFTHIP_MISSING_TABLE;
     if (ws_bytes < P->ws_bytes || (!d_workspace && P->ws_bytes)) return XRFTHIP_WORKSPACE_TOO_SMALL;
     if (d.batch == 0) return XRFTHIP_OK;
@@ -2118,6 +2223,53 @@ int xrfthip_table_mul(int32_t dtype, int64_t batch, int64_t n_in, int64_t n_out,
 #undef TM_
     HIP_TRY(hipGetLastError());
     return XRFTHIP_OK;
+}
+
+static int inner_chunks(long long ny) { return (int)std::max<long long>(1, std::min<long long>(64, ny / 4)); }
+static size_t detrend_inner_ws(bool cplx, long long batch, long long inner) {
+    const size_t i2 = (size_t)inner * (cplx ? 2 : 1);
+    return (((size_t)std::max<long long>(batch, 1) * i2 * 3 * sizeof(double) * (64 + 1)) + 255) & ~(size_t)255;  // <= 64 chunks of partial sums + the coefficients
+}
+static int run_detrend_inner(int32_t dtype, int32_t ndim, long long batch, long long ny, long long nx, long long inner, int32_t kind, const void* in, void* out,
+                             char* ws, hipStream_t st) {
+    (void)ndim;
+    const bool dbl = dtype == XRFTHIP_F64 || dtype == XRFTHIP_C128, cplx = dtype >= XRFTHIP_C64;
+    const long long i2 = inner * (cplx ? 2 : 1);
+    const int nch = inner_chunks(ny);
+    double* part = reinterpret_cast<double*>(ws);
+    double* coef = part + (size_t)batch * 64 * i2 * 3;
+    for (long long b0 = 0; b0 < batch; b0 += 65535) {  // grid.z limit
+        const long long bc = std::min<long long>(65535, batch - b0);
+        const dim3 grid((unsigned)nch, (unsigned)((i2 + kInnerIB - 1) / kInnerIB), (unsigned)bc), block(kInnerIB * kInnerXS);
+        const size_t lds = (size_t)kInnerXS * 3 * kInnerIB * sizeof(double), eoff = (size_t)b0 * ny * nx * i2;
+        if (dbl) { auto k = &plane_inner_moments_kernel<double>; XRFT_LAUNCH(k, grid, block, lds, st, (const double*)in + eoff, (long long)ny, (long long)nx, i2, part + (size_t)b0 * nch * i2 * 3); }
+        else { auto k = &plane_inner_moments_kernel<float>; XRFT_LAUNCH(k, grid, block, lds, st, (const float*)in + eoff, (long long)ny, (long long)nx, i2, part + (size_t)b0 * nch * i2 * 3); }
+    }
+    {
+        auto k = &plane_inner_finalize_kernel;
+        XRFT_LAUNCH(k, dim3((unsigned)((batch * i2 + 255) / 256)), dim3(256), 0, st, (const double*)part, coef, (long long)batch, (long long)ny, (long long)nx, i2, nch, (int)kind);
+    }
+    const long long total = batch * ny * nx * i2;
+    const dim3 grid((unsigned)std::min<long long>((total + 255) / 256, 8LL * kCUs * 8)), block(256);
+    if (dbl) { auto k = &plane_inner_apply_kernel<double>; XRFT_LAUNCH(k, grid, block, 0, st, (const double*)in, (double*)out, (const double*)coef, (long long)batch, (long long)ny, (long long)nx, i2); }
+    else { auto k = &plane_inner_apply_kernel<float>; XRFT_LAUNCH(k, grid, block, 0, st, (const float*)in, (float*)out, (const double*)coef, (long long)batch, (long long)ny, (long long)nx, i2); }
+    HIP_TRY(hipGetLastError());
+    return XRFTHIP_OK;
+}
+
+size_t xrfthip_detrend_inner_workspace_bytes(int32_t dtype, int64_t batch, int64_t inner) {
+    if (dtype < XRFTHIP_F32 || dtype > XRFTHIP_C128 || batch < 0 || inner < 1) return 0;
+    return detrend_inner_ws(dtype >= XRFTHIP_C64, batch, inner);
+}
+
+int xrfthip_detrend_inner(int32_t dtype, int32_t ndim, int64_t batch, int64_t ny, int64_t nx, int64_t inner, int32_t detrend_type,
+                          const void* d_in, void* d_out, void* d_workspace, size_t ws_bytes, void* stream) {
+    if (!d_in || !d_out || dtype < XRFTHIP_F32 || dtype > XRFTHIP_C128 || batch < 0 || ny < 1 || nx < 1 || inner < 1) return XRFTHIP_BAD_ARG;
+    if ((ndim != 1 && ndim != 2) || (ndim == 1 && ny != 1)) return XRFTHIP_BAD_ARG;
+    if (detrend_type != XRFTHIP_DETREND_CONSTANT && detrend_type != XRFTHIP_DETREND_LINEAR) return XRFTHIP_BAD_ARG;
+    if (!d_workspace || ws_bytes < xrfthip_detrend_inner_workspace_bytes(dtype, batch, inner)) return XRFTHIP_WORKSPACE_TOO_SMALL;
+    if (batch == 0) return XRFTHIP_OK;
+    return run_detrend_inner(dtype, ndim, batch, ny, nx, inner, detrend_type, d_in, d_out, (char*)d_workspace, (hipStream_t)stream);
 }
 
 int xrfthip_reduce_axis(int32_t dtype, int64_t outer, int64_t n, int64_t inner, const void* d_in, void* d_out, double scale, void* stream) {

@@ -36,7 +36,7 @@ class SpectralPlan:
 
     def __init__(self, ndim, batch, ny, nx, dtype, out_mode=_lib.OUT_COMPLEX, detrend=_lib.DETREND_NONE, flags=0,
                  scale=1.0, window_y=None, window_x=None, phase_y=None, phase_x=None, binmap=None, nbins=0,
-                 slabs_per_group=0):
+                 slabs_per_group=0, inner=1):
         self._dll = _lib.load()
         self._h = C.c_void_p(0)
         if dtype not in _DTYPES:
@@ -45,8 +45,9 @@ class SpectralPlan:
         self.dtype, self.out_mode, self.flags = dtype, int(out_mode), int(flags)
         self.nx_out = self.nx // 2 + 1 if (flags & _lib.HALF_X) else self.nx
         self.nbins = int(nbins)
+        self.inner = max(int(inner), 1)  # > 1: (batch, ny, nx, inner) arrays, the transform axes are not the trailing ones
         d = _lib.Desc(C.sizeof(_lib.Desc), self.ndim, self.batch, self.ny, self.nx, _DTYPES[dtype], self.out_mode,
-                      int(detrend), self.flags, float(scale), int(slabs_per_group), 0)
+                      int(detrend), self.flags, float(scale), int(slabs_per_group), 0, self.inner)
         _lib.check(self._dll.xrfthip_plan_create(C.byref(self._h), C.byref(d)))
         for axis, w in ((0, window_y), (1, window_x)):
             if w is not None:
@@ -104,14 +105,15 @@ class SpectralPlan:
         Returns (out, iso); either may be None depending on the flags."""
         dev = in0.device
         nx_in = self.nx // 2 + 1 if (self.flags & _lib.C2R_X) else self.nx
-        if in0.dtype != self.dtype or not in0.is_contiguous() or in0.numel() != self.batch * self.ny * nx_in:
+        if in0.dtype != self.dtype or not in0.is_contiguous() or in0.numel() != self.batch * self.ny * nx_in * self.inner:
             raise ValueError("in0 does not match the plan (dtype / contiguity / size)")
         if self.out_mode in (_lib.OUT_CROSS, _lib.OUT_PHASE):
             if in1 is None or in1.dtype != self.dtype or not in1.is_contiguous() or in1.numel() != in0.numel():
                 raise ValueError("in1 does not match the plan")
         want_out = not (self.flags & _lib.NO_SPECTRUM_OUT)
         if want_out and out is None:
-            out = torch.empty((self.batch, self.ny, self.nx_out), dtype=self.out_dtype(), device=dev)
+            shape = (self.batch, self.ny, self.nx_out) + ((self.inner,) if self.inner > 1 else ())
+            out = torch.empty(shape, dtype=self.out_dtype(), device=dev)
         if self.flags & _lib.ISO and iso is None:
             iso = torch.empty((self.batch, self.nbins), device=dev,
                               dtype=torch.complex128 if self.out_mode == _lib.OUT_CROSS else torch.float64)
@@ -183,6 +185,23 @@ def detrend(x, ndim, kind):
     ws = torch.empty(nws, dtype=torch.uint8, device=x.device)
     _lib.check(dll.xrfthip_detrend(_DTYPES[x.dtype], ndim, batch, ny, nx, kind, _ptr(x), _ptr(out), _ptr(ws), nws,
                                    _stream_handle(x)))
+    return out
+
+
+def detrend_inner(x, axis0, naxes, kind):
+    """Stand-alone detrend over ``naxes`` (1|2) ADJACENT axes starting at ``axis0`` of a contiguous tensor, whatever follows them
+    (xrft.detrend over axes that are not the trailing ones: no transposed copy; xrft/detrend.py:54-55, 64-71, 100-113)."""
+    dll = _lib.load()
+    if x.dtype not in _DTYPES or not x.is_contiguous():
+        raise ValueError("detrend needs a contiguous float/complex tensor")
+    batch = int(np.prod(x.shape[:axis0], dtype=np.int64))
+    ny = x.shape[axis0] if naxes == 2 else 1
+    nx = x.shape[axis0 + naxes - 1]
+    inner = int(np.prod(x.shape[axis0 + naxes:], dtype=np.int64))
+    out = torch.empty_like(x)
+    nws = int(dll.xrfthip_detrend_inner_workspace_bytes(_DTYPES[x.dtype], batch, inner))
+    ws = torch.empty(max(nws, 16), dtype=torch.uint8, device=x.device)
+    _lib.check(dll.xrfthip_detrend_inner(_DTYPES[x.dtype], naxes, batch, ny, nx, inner, kind, _ptr(x), _ptr(out), _ptr(ws), nws, _stream_handle(x)))
     return out
 
 

@@ -53,13 +53,16 @@ def _c2c_one(t, ax, inverse):
         return out.reshape(shape)
     batch = int(np.prod(shape[:ax], dtype=np.int64))
     inner = int(np.prod(shape[ax + 1:], dtype=np.int64))
-    try:
-        plan = _get_plan(ndim=2, batch=batch, ny=n, nx=inner, dtype=t.dtype, out_mode=_lib.OUT_COMPLEX, detrend=_lib.DETREND_NONE,
-                         flags=flags | _lib.AXIS_Y, scale=scale, window_y=None, window_x=None, phase_y=None, phase_x=None)
-    except _lib.XrftHipError as e:
-        if e.status != _lib.UNSUPPORTED_LENGTH:
-            raise
-        # a column too long for one LDS tile: transposed copy, 1-D plan (four-step inside), copy back
+    plan = None
+    if n * inner <= (1 << 31) - 1 and inner <= (1 << 30):  # (the engine indexes one [n][inner] slab with 32 bits)
+        try:
+            plan = _get_plan(ndim=2, batch=batch, ny=n, nx=inner, dtype=t.dtype, out_mode=_lib.OUT_COMPLEX, detrend=_lib.DETREND_NONE,
+                             flags=flags | _lib.AXIS_Y, scale=scale, window_y=None, window_x=None, phase_y=None, phase_x=None)
+        except _lib.XrftHipError as e:
+            if e.status != _lib.UNSUPPORTED_LENGTH:
+                raise
+    if plan is None:
+        # a column too long for one LDS tile, or a slab beyond 2^31 elements: transposed copy, 1-D plan (four-step inside), copy back
         tt = t.movedim(ax, -1).contiguous()
         return _c2c_one(tt, tt.dim() - 1, inverse).movedim(-1, ax).contiguous()
     out, _ = plan.execute(t.reshape(batch, n, inner))
