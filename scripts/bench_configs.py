@@ -83,6 +83,16 @@ add("power_spectrum 1-D (131072,1024) f32 linear+hann", x.numel(), 8, timeit(lam
 add("   fft 1-D (131072,1024) f32", x.numel(), 12, timeit(lambda: xrft.fft(da, dim=["x"])))
 x = cube((64, 1000, 1000), torch.float32); da = xrft.DataArray(x, ("t", "y", "x"), {"y": np.arange(1000.), "x": np.arange(1000.)})
 add("PS (64,1000,1000) f32 linear+hann", x.numel(), 8, timeit(lambda: xrft.power_spectrum(da, dim=["y", "x"], detrend="linear", window="hann")))
+# lengths that joined the mixed-radix table in round 3 (the generic tile kernels before: (64,2000,2000) f32 95, (16,3000,3000) f64 34 GFFT/s)
+for shape, dt in (((64, 2000, 2000), torch.float32), ((16, 3000, 3000), torch.float32), ((16, 3000, 3000), torch.float64), ((16, 1800, 3600), torch.float32), ((32, 1800, 900), torch.float64), ((32, 2000, 2000), torch.float64)):
+    x = cube(shape, dt); da = xrft.DataArray(x, ("t", "y", "x"), {"y": np.arange(float(shape[1])), "x": np.arange(float(shape[2]))})
+    add(f"PS {shape} {'f32' if dt == torch.float32 else 'f64'} linear+hann", x.numel(), 8 if dt == torch.float32 else 16, timeit(lambda: xrft.power_spectrum(da, dim=["y", "x"], detrend="linear", window="hann")))
+    del x, da
+# two adjacent axes with the batch INNERMOST (xrfthip_desc.inner): no transposed copies
+x = cube((1024, 1024, 64), torch.float32); da = xrft.DataArray(x, ("y", "x", "t"), {"y": np.arange(1024.), "x": np.arange(1024.)})
+add("PS over (y, x) of a (1024,1024,64) f32 (y, x, t) array, linear+hann", x.numel(), 8, timeit(lambda: xrft.power_spectrum(da, dim=["y", "x"], detrend="linear", window="hann")))
+add("   fft (complex) of the same, no detrend", x.numel(), 12, timeit(lambda: xrft.fft(da, dim=["y", "x"])))
+del x, da
 # a length with large prime factors: the ERA5 grid (721 = 7 x 103 latitudes) -- Bluestein in the column tile
 x = cube((64, 721, 1440), torch.float32); da = xrft.DataArray(x, ("t", "lat", "lon"), {"lat": np.arange(721) * .25, "lon": np.arange(1440) * .25})
 add("PS (64,721,1440) f32 linear+hann (ERA5 grid)", x.numel(), 8, timeit(lambda: xrft.power_spectrum(da, dim=["lat", "lon"], detrend="linear", window="hann")))

@@ -688,6 +688,22 @@ def run_radial_sum_cases(big=False):
                 ref = ref + 1j * np.bincount(bm.ravel()[ok], weights=w.imag, minlength=nb)
             mag = np.bincount(bm.ravel()[ok], weights=np.abs(w), minlength=nb)
             assert np.all(np.abs(g[b] - ref) <= 1e-12 * np.maximum(mag, 1e-300)), (dt, b, np.abs(g[b] - ref).max())
+    # inf / nan members are what they are in a floating-point sum (the fixed-point tables used to turn a NaN into +inf):
+    # nan poisons its bin, +inf alone gives +inf, +inf and -inf give nan; the other bins and slabs stay exact
+    for dt in ("float32", "float64", "complex128"):
+        v = rng.standard_normal((2, ny, nx)).astype(dt)
+        bm2 = (np.arange(ny * nx).reshape(ny, nx) % 50).astype(np.int32)
+        v[0, 0, 3] = np.nan; v[0, 0, 4] = np.inf; v[0, 0, 5] = -np.inf; v[0, 0, 6] = np.inf; v[0, 1, 6] = -np.inf
+        if dt == "complex128":
+            v[1, 0, 7] = complex(1.0, np.inf)
+        g = engine.isotropize(torch.from_numpy(v).to(dev), torch.from_numpy(bm2).to(dev), 50).cpu().numpy()
+        with np.errstate(invalid="ignore"):
+            vv = v.astype("complex128" if dt.startswith("complex") else "float64")
+            ref = np.stack([np.array([vv[b].ravel()[bm2.ravel() == k].sum() for k in range(50)]) for b in range(2)])
+        assert np.array_equal(np.isnan(g.real), np.isnan(ref.real)) and np.array_equal(np.isnan(g.imag), np.isnan(ref.imag)), dt
+        assert np.array_equal(np.isinf(g), np.isinf(ref)) and np.array_equal(np.sign(g.real[np.isinf(g.real)]), np.sign(ref.real[np.isinf(ref.real)])), dt
+        fin = np.isfinite(ref)
+        npt.assert_allclose(g[fin], ref[fin], rtol=1e-10, atol=1e-10)
     # generic plans (float64, lengths the specialised kernels do not take): values vs the oracle, repeats bit for bit
     shape = (3, 48, 40)
     a = _cube(rng, shape, "float64")
@@ -966,3 +982,69 @@ def run_inner_layout_cases(dtype="float64", shape=(24, 20, 6)):
         worst = max(worst, check(xa.detrend(d4, ["y", "x"], det), o.detrend(o4, ["y", "x"], det).transpose("t", "y", "x", "z"), tol))
         worst = max(worst, check(xa.detrend(d4, "y", det), o.detrend(o4, "y", det).transpose("t", "y", "x", "z"), tol))
     return worst
+
+
+def run_fused_radial_code_forms(n=256):
+    """The fused radial sums of the y-first float32 kernels (csrc/fasty.h): a radial bin map (what isotropic_*_spectrum hands
+    over) is summed by a per-bin gather with no atomics; any other map through int64 fixed-point tables, its codes compact (first bin
+    + step mask per 16 samples) or full (4 bytes per sample).  All three against numpy.bincount of the stored spectrum, through the C ABI's plan; a NaN in the data poisons its slab's bins, as a
+    floating-point sum would."""
+    import torch
+
+    from xrft_amd import _lib, engine
+
+    rng = np.random.default_rng(131)
+    dev = xa.api._to_device(np.zeros(1, dtype=np.float32)).device
+    nt, nb = 3, n // 4
+    v = rng.standard_normal((nt, n, n)).astype(np.float32)
+    t = torch.from_numpy(v).to(dev)
+    f = np.fft.fftfreq(n)
+    kr = np.sqrt(f[:, None] ** 2 + f[None, :] ** 2)
+    radial = np.minimum((kr / kr.max() * nb).astype(np.int32), nb - 1)
+    anymap = rng.integers(-1, nb, size=(n, n)).astype(np.int32)
+    import os
+
+    for name, bm, want, gather in (("radial", radial, "per-bin gather", "1"), ("radial", radial, "bin codes: compact", "0"), ("random", anymap, "bin codes: full", "1")):
+        os.environ["XRFTHIP_ISO_GATHER"] = gather  # (read once, when a plan is created)
+        for mode in (_lib.OUT_POWER, _lib.OUT_CROSS):
+            plan = engine.SpectralPlan(2, nt, n, n, torch.float32, out_mode=mode, flags=_lib.ISO, scale=1.0, binmap=bm, nbins=nb)
+            assert want in plan.describe(), (name, plan.describe())
+            t2 = torch.from_numpy(np.roll(v, 3, axis=2).copy()).to(dev) if mode == _lib.OUT_CROSS else None
+            out, iso = plan.execute(t, t2)
+            out2, iso2 = plan.execute(t, t2)
+            assert torch.equal(iso, iso2)
+            spec = out.cpu().numpy().astype(np.complex128 if mode == _lib.OUT_CROSS else np.float64)
+            ok = bm.ravel() >= 0
+            for b in range(nt):
+                w = spec[b].ravel()[ok]
+                ref = np.bincount(bm.ravel()[ok], weights=w.real, minlength=nb).astype(np.complex128)
+                if mode == _lib.OUT_CROSS:
+                    ref = ref + 1j * np.bincount(bm.ravel()[ok], weights=w.imag, minlength=nb)
+                mag = np.bincount(bm.ravel()[ok], weights=np.abs(w), minlength=nb)
+                got = iso.cpu().numpy()[b]
+                assert np.all(np.abs(got - (ref if mode == _lib.OUT_CROSS else ref.real)) <= 2e-6 * np.maximum(mag, 1e-300)), (name, mode, b)
+        # a NaN sample: every bin of that slab is NaN (the transform spreads it), the other slabs are untouched
+        vn = v.copy(); vn[1, 5, 7] = np.nan
+        plan = engine.SpectralPlan(2, nt, n, n, torch.float32, out_mode=_lib.OUT_POWER, flags=_lib.ISO | _lib.NO_SPECTRUM_OUT, scale=1.0, binmap=bm, nbins=nb)
+        _, iso = plan.execute(torch.from_numpy(vn).to(dev))
+        g = iso.cpu().numpy()
+        used = np.bincount(bm.ravel()[bm.ravel() >= 0], minlength=nb) > 0
+        assert np.all(np.isnan(g[1][used])) and np.all(np.isfinite(g[0])) and np.all(np.isfinite(g[2])), name
+    os.environ.pop("XRFTHIP_ISO_GATHER", None)
+
+
+def run_nan_in_isotropic_spectra():
+    """A NaN sample poisons its own slab's isotropic spectrum and nothing else, on every path that takes radial sums (the
+    reference sums in floating point, xrft.py:895-906; ADVICE r2: fixed-point tables gave +inf or 0): fasty.h (256^2 float32),
+    fastm.h fused (360^2 float64), the generic plans + the stand-alone pass (48 x 40 float64)."""
+    rng = np.random.default_rng(141)
+    for shape, dt in (((3, 256, 256), "float32"), ((3, 360, 360), "float64"), ((3, 48, 40), "float64")):
+        v = rng.standard_normal(shape).astype(dt)
+        v[1, 5, 7] = np.nan
+        c = _coords3(shape)
+        da = xa.DataArray(v, D3, c)
+        for fn in (lambda: xa.isotropic_power_spectrum(da, dim=["y", "x"], window="hann"),
+                   lambda: xa.isotropic_cross_spectrum(da, xa.DataArray(np.roll(v, 2, axis=2).copy(), D3, c), dim=["y", "x"], window="hann")):
+            g = np.asarray(fn().values)
+            assert np.all(np.isnan(g[1])), (shape, dt)
+            assert np.all(np.isfinite(g[0])) and np.all(np.isfinite(g[2])), (shape, dt)

@@ -198,6 +198,7 @@ inline double __shfl_xor(double v, int mask) {
 inline long long __double_as_longlong(double d) { long long v; memcpy(&v, &d, 8); return v; }
 inline float __uint_as_float(unsigned v) { float f; memcpy(&f, &v, 4); return f; }
 struct alignas(16) uint4 { unsigned x, y, z, w; };
+inline int __popc(unsigned v) { return __builtin_popcount(v); }
 inline double __longlong_as_double(long long v) { double d; memcpy(&d, &v, 8); return d; }
 inline unsigned __float_as_uint(float f) { unsigned v; memcpy(&v, &f, 4); return v; }
 using std::max;

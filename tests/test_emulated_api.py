@@ -466,3 +466,28 @@ def test_huge_slab_along_a_first_axis_takes_the_transposing_path():
         assert dll.xrfthip_plan_create(C.byref(h), C.byref(d)) == -1
     src = open(os.path.join(os.path.dirname(api.__file__), "api.py")).read()
     assert "ny * nx > (1 << 31) - 1" in src  # _execute_axis_y returns None (-> _arrange) before asking for the plan
+
+
+def test_fused_radial_sums_compact_and_full_bin_codes():
+    cases.run_fused_radial_code_forms(256)
+
+
+def test_nan_poisons_its_own_slab_only():
+    cases.run_nan_in_isotropic_spectra()
+
+
+@pytest.mark.parametrize("shape,full,dtype", [((1, 900, 900), False, "float64"), ((1, 2000, 1500), False, "float32"), ((1, 1800, 900), False, "float64"), ((1, 900, 2000), False, "float64"),
+                                               ((1, 3000, 900), False, "float32"), ((1, 1500, 3600), False, "float32")])
+def test_fastm_round3_lengths(shape, full, dtype):
+    """900, 1500, 1800, 2000 (both precisions; 2000 = 10 x 10 x 20, the radix-20 Good-Thomas butterfly), 3000 and 3600 (float32)."""
+    cases.run_fastm_cases(shape, full, True, dtype)
+
+
+@pytest.mark.parametrize("shape,dtype", [((1, 2000, 8), "float64"), ((2, 3000, 8), "float32"), ((1, 1800, 4), "float64"), ((1, 3600, 8), "float32"), ((2, 900, 16), "float32"), ((1, 1500, 8), "float64")])
+def test_one_axis_round3_lengths(shape, dtype):
+    cases.run_yonly_fast_cases(shape, dtype)
+
+
+@pytest.mark.parametrize("shape,dtype", [((3, 2000), "float32"), ((2, 3000), "float32"), ((2, 1800), "float64"), ((3, 3600), "float32"), ((2, 900), "float64"), ((3, 1500), "float32")])
+def test_short_axis_round3_lengths(shape, dtype):
+    cases.run_xonly_fast_cases(shape, dtype)

@@ -904,3 +904,12 @@ def test_two_axes_with_the_batch_innermost_without_copies(dtype):
         assert peak <= out_bytes + (1 << 20), (peak, out_bytes)
         assert res.data.is_contiguous() and tuple(res.dims) == ("freq_y", "freq_x", "t")
         cases.check(res, ofn(o.OArr(v.astype(np.float64), ("y", "x", "t"), c), **kw), 2e-4 if dtype == "float32" else 1e-10)
+
+
+def test_fused_radial_sums_compact_and_full_bin_codes():
+    cases.run_fused_radial_code_forms(256)
+    cases.run_fused_radial_code_forms(2048)
+
+
+def test_nan_poisons_its_own_slab_only():
+    cases.run_nan_in_isotropic_spectra()

@@ -351,13 +351,21 @@ __global__ void plane_inner_finalize_kernel(const double* part, double* coef, lo
     coef[e * 3 + 1] = c1;
     coef[e * 3 + 2] = c2;
 }
+// (a workgroup walks whole rows (b, i): 32-bit index arithmetic inside the row -- one 64-bit division per element ran at 1 TB/s)
 template <typename T>
 __global__ void __launch_bounds__(256) plane_inner_apply_kernel(const T* __restrict__ in, T* __restrict__ out, const double* __restrict__ coef, long long batch, long long ny, long long nx, long long inner2) {
-    const long long total = batch * ny * nx * inner2;
-    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
-        const long long i2 = e % inner2, r = e / inner2, j = r % nx, r2 = r / nx, i = r2 % ny, b = r2 / ny;
-        const double* c = coef + (b * inner2 + i2) * 3;
-        out[e] = (T)((double)in[e] - (c[0] + c[1] * (double)i + c[2] * (double)j));
+    const unsigned rowlen = (unsigned)(nx * inner2), in2 = (unsigned)inner2;
+    for (long long r = blockIdx.x; r < batch * ny; r += gridDim.x) {
+        const long long b = r / ny;
+        const double fi = (double)(r - b * ny);
+        const double* cb = coef + b * inner2 * 3;
+        const T* src = in + r * rowlen;
+        T* dst = out + r * rowlen;
+        for (unsigned e = threadIdx.x; e < rowlen; e += 256) {
+            const unsigned j = e / in2, i2 = e - j * in2;
+            const double* c = cb + (size_t)i2 * 3;
+            dst[e] = (T)((double)src[e] - (c[0] + c[1] * fi + c[2] * (double)j));
+        }
     }
 }
 
@@ -507,7 +515,15 @@ __global__ void __launch_bounds__(256) iso_reduce_kernel(const double* __restric
     double s = 0.0;
     if (i < nb) {
         const double* src = part + (size_t)slab * upr * nb + i;
-        for (int un = u0; un < u1; ++un) s += src[(size_t)un * nb];
+        int un = u0;
+        for (; un + 8 <= u1; un += 8) {  // eight loads in flight, added in unit order (one at a time the kernel was latency-bound: 2 us per 4096^2 slab)
+            double v[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v[k] = src[(size_t)(un + k) * nb];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) s += v[k];
+        }
+        for (; un < u1; ++un) s += src[(size_t)un * nb];
     }
     seg[sg][lane] = s;
     __syncthreads();

@@ -40,6 +40,12 @@ XRFT_MRAD(480, 6, 8, 10);
 XRFT_MRAD(720, 8, 9, 10);
 XRFT_MRAD(960, 8, 10, 12);
 XRFT_MRAD(1440, 10, 12, 12);
+XRFT_MRAD(900, 9, 10, 10);    // (round 3: lengths the generic tile kernels ran 3-5x slower -- 0.1-degree grids 3600 x 1800, and 1500 / 2000 / 3000)
+XRFT_MRAD(1500, 10, 10, 15);
+XRFT_MRAD(1800, 10, 12, 15);
+XRFT_MRAD(2000, 10, 10, 20);
+XRFT_MRAD(3000, 10, 15, 20);
+XRFT_MRAD(3600, 15, 15, 16);
 XRFT_MRAD(256, 4, 8, 8);   // (powers of two: float64 only -- float32 has the register-resident kernels of fasty.h)
 XRFT_MRAD(512, 8, 8, 8);
 XRFT_MRAD(1024, 8, 8, 16);
@@ -57,7 +63,8 @@ XRFT_MRAD(1000, 10, 10, 10);
 XRFT_MRAD(1200, 10, 10, 12);
 #undef XRFT_MRAD
 // the lengths the host dispatches on: X(N) for every entry
-#define XRFT_M_LATLON(X) X(180) X(240) X(360) X(480) X(500) X(720) X(960) X(1000) X(1200) X(1440)  /* both axes of a slab: the lat/lon lengths + 500, 1000, 1200 */
+#define XRFT_M_LATLON(X) X(180) X(240) X(360) X(480) X(500) X(720) X(900) X(960) X(1000) X(1200) X(1440) X(1500) X(1800) X(2000)  /* both axes of a slab: the lat/lon lengths + 500, 1000, 1200, 1500, 2000 */
+#define XRFT_M_F32ONLY(X) X(3000) X(3600)  /* float32 only: a pair of complex128 sequences of this length does not fit the LDS beside a second workgroup */
 #define XRFT_M_POW2(X) X(256) X(512) X(1024)
 #define XRFT_M_YONLY(X) X(100) X(128) X(200) X(400) X(600) X(800)
 
@@ -82,7 +89,7 @@ template <typename T, int N, int GOV = 0> struct MGeom {
     static constexpr size_t CS = 2 * sizeof(T);
     // sequences per workgroup: as many (a power of two) as keep three workgroups on a CU
 #ifndef XRFT_M_LDSCAP
-#define XRFT_M_LDSCAP (52 * 1024)
+#define XRFT_M_LDSCAP (N >= 1800 ? 78 * 1024 : 52 * 1024)  /* three workgroups per CU; two for the long sequences (a pair of 2000-point complex128 sequences is 70 KB) */
 #endif
     // (at most 4: 8 columns per workgroup divide every length of the table; and at most 640 threads: one butterfly per thread and pass)
     static constexpr int G0 = ((size_t)4 * STR * CS <= XRFT_M_LDSCAP && 4 * BMAX <= 640) ? 4 : (size_t)2 * STR * CS <= XRFT_M_LDSCAP ? 2 : 1;
@@ -767,7 +774,11 @@ __global__ void __launch_bounds__((MGeom<T, NX>::template Rows<MRowsG<T, NX, MOD
         for (int i = tid; i < nbn * HW; i += THR) {
             long long sum = 0;
             for (int k = 0; k < nc; ++k) sum += (long long)acc_all[(size_t)k * nbn * HW + i];
-            part[i] = ldexp((double)sum, (int)(bmax_all[i / HW] >> 20) - 1023 - kIsoFR);
+            const unsigned bm = bmax_all[i / HW];
+            double v = ldexp((double)sum, (int)(bm >> 20) - 1023 - kIsoFR);
+            // a bin with an inf / nan member is +inf (a power spectrum whose only offenders are +inf) or nan, as the IEEE sum is
+            if ((bm >> 20) == 0x7ffu) v = __longlong_as_double((MODE == 1 && bm == 0x7ff00000u) ? 0x7ff0000000000000ll : 0x7ff8000000000000ll);
+            part[i] = v;
         }
     }
     if (p.out == nullptr) return;

@@ -116,7 +116,10 @@ struct FastY {
     int realdim2;            // ... and 0 < kx < nx/2 counts twice (xrft.py:673-682)
     const cf* what0;         // FFT_y(wy)[ky], ky < nrow_pad (zero beyond ny/2)
     const cf* what1;         // FFT_y(wy * (i - (ny-1)/2))[ky]
-    const unsigned* tcodes;  // radial bins [ky < nrow_pad][kx] in natural order: (direct + 1) | (mirror + 1) << 16 (0: not binned)
+    const unsigned* tcodes;  // radial bins [ky < nrow_pad][kx] in natural order: (direct + 1) | (mirror + 1) << 16 (0: not binned);
+                             // tcodes_compact: [ky][kx / 16]: (first sample's bin + 1) | step mask << 16 (see fasty_rows_kernel)
+    int tcodes_compact;
+    const unsigned short* tfirst;  // radial map: [ky < nrow_pad][nbins + 1], the smallest |kx| of a row whose bin is >= b (null: any map, the atomic tables)
     double* iso;             // [slab][nbins] per-bin sums (ISO)
     double* iso_part;        // [slab][row workgroup][nbins (x2 complex)]: per-workgroup partial sums, reduced in order
     int nbins;
@@ -642,6 +645,88 @@ __global__ void __launch_bounds__((YRows<NX, FS>::THR), (YRows<NX, FS>::THR / 12
         }
     };
     if constexpr (ISO) {
+        if (p.tfirst != nullptr) {
+            // Radial sums (xrft.py:895-906) of a RADIAL bin map -- along a row the bin depends on |kx| only and never decreases
+            // with it, and the Hermitian twin (-ky, -kx) of a sample falls into the sample's bin (verified on the host,
+            // fasty_build_tcodes) -- with no atomic at all: the bins of a row are contiguous ranges of kx on either side of
+            // kx = 0.  (1) Every 16-sample segment of the staged rows is reduced in place: the sum of each run of equal bins
+            // lands on the run's last sample (float32 adds in sample order; the run ends come from a 16-bit step mask).
+            // (2) The owner of a bin walks its two kx ranges in every row, one staged value per segment it touches, and adds them
+            // in float64 in a fixed order: bit-reproducible, nothing to zero, no per-bin exponent pass, inf / nan propagate as in
+            // any floating-point sum.  (Atomics -- int64 fixed point, the only way to make them order-independent -- cost 10 of
+            // the row pass's 30 us per 4096^2 slab even issued once per run: profiles/r03_tune_iso.txt.)
+            constexpr int NRW = MODE == 1 ? 2 * GX : GX;      // staged rows
+            constexpr int RSI = MODE == 1 ? RSP : 2 * RSC;    // floats per staged row
+            constexpr int CPS = MODE == 1 ? 1 : 2;            // floats per sample
+            constexpr int SPR = NX / 16;                      // segments per row
+            if (MODE == 1) {
+#pragma unroll
+                for (int bb = 0; bb < G::NB; ++bb)
+#pragma unroll
+                    for (int k3 = 0; k3 < G::R3; ++k3) {
+                        const int sl = nat16(held_k<NX>(u, bb, k3));
+                        const cf va = a[bb * G::R3 + k3], vb = b[bb * G::R3 + k3];
+                        stg[g * RSP + sl] = (va.re * va.re + va.im * va.im) * p.scale;
+                        stg[(GX + g) * RSP + sl] = (vb.re * vb.re + vb.im * vb.im) * p.scale;
+                    }
+            } else {
+#pragma unroll
+                for (int bb = 0; bb < G::NB; ++bb)
+#pragma unroll
+                    for (int k3 = 0; k3 < G::R3; ++k3) lds[g * RSC + nat16(held_k<NX>(u, bb, k3))] = a[bb * G::R3 + k3];
+            }
+            __syncthreads();
+            if (p.out != nullptr) {  // the spectrum leaves first: step (1) overwrites the staged samples
+                if (MODE == 1) store_power(stg, 0, NRW); else store_complex(lds, 0, NRW);
+                __syncthreads();
+            }
+            for (int sg = tid; sg < NRW * SPR; sg += THR) {
+                const int row = sg / SPR, s16 = sg % SPR, ky = ky0 + row;
+                if (ky > nyh) continue;
+                const unsigned mask = p.tcodes[(size_t)ky * SPR + s16] >> 16;  // bit i: the bin changes between samples i - 1 and i
+                float* q = stg + row * RSI + CPS * (17 * s16);                  // nat16(16 s16) = 17 s16: the segment is contiguous
+                float sr = 0.f, si = 0.f;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    sr += q[CPS * i];
+                    if (MODE == 2) si += q[2 * i + 1];
+                    if (i == 15 || ((mask >> (i + 1)) & 1u)) {
+                        q[CPS * i] = sr;
+                        if (MODE == 2) q[2 * i + 1] = si;
+                        sr = 0.f; si = 0.f;
+                    }
+                }
+            }
+            __syncthreads();
+            double* __restrict__ part = p.iso_part + ((size_t)slab * upr + unit) * p.nbins * HW;
+            for (int bn = tid; bn < p.nbins; bn += THR) {
+                double sre = 0.0, sim = 0.0;
+                for (int row = 0; row < NRW; ++row) {
+                    const int ky = ky0 + row;
+                    if (ky > nyh) break;
+                    const unsigned short* __restrict__ fr = p.tfirst + (size_t)ky * (p.nbins + 1) + bn;
+                    const int s = fr[0], e = fr[1];  // the bin holds |kx| = s .. e - 1 of this row
+                    const bool twin = ky != 0 && ky != nyh;
+                    const float* rowp = stg + row * RSI;
+                    auto take = [&](int pp) {
+                        const float* v = rowp + CPS * nat16(pp);
+                        if (MODE == 1) sre += (double)v[0] * (twin ? 2.0 : 1.0);
+                        else if (twin) sre += 2.0 * (double)v[0];           // V + conj V
+                        else { sre += (double)v[0]; sim += (double)v[1]; }
+                    };
+                    const int e1 = min(e, NX / 2);  // kx = |kx| = s .. e1 - 1
+                    for (int seg = s >> 4; 16 * seg < e1 && s < e1; ++seg) take(min(e1, 16 * (seg + 1)) - 1);
+                    const int ms = max(s, 1), me = min(e, NX / 2 + 1);  // kx = nx - |kx|, |kx| = ms .. me - 1
+                    if (ms < me) {
+                        const int lo = NX - (me - 1), hi1 = NX - ms + 1;
+                        for (int seg = lo >> 4; 16 * seg < hi1; ++seg) take(min(hi1, 16 * (seg + 1)) - 1);
+                    }
+                }
+                part[bn * HW] = sre;
+                if (MODE == 2) part[2 * bn + 1] = sim;
+            }
+            return;
+        }
         // Radial sums (xrft.py:895-906), bit-reproducible: floating-point atomics would make a sum depend on the order in which waves
         // arrive.  The results are staged in LDS in natural order, half of the workgroup's rows per round (the other half of the
         // transforms' LDS holds the tables), and a thread owns L CONSECUTIVE kx of one row: neighbouring samples mostly share a
@@ -683,11 +768,28 @@ __global__ void __launch_bounds__((YRows<NX, FS>::THR), (YRows<NX, FS>::THR / 12
             for (int i = tid; i < p.nbins; i += THR) bmax[i] = 0u;
             // this thread's run of L samples of row ky0 + rd NR + rl: bin codes in natural order, (bin + 1) | (mirror bin + 1) << 16
             unsigned codes[L];
+            const int kyr = ky0 + rd * NR + rl;
             if (XRFT_YTUNE(p) & (1 << 16)) {  // (ablation, tuning build: no bin-code loads)
 #pragma unroll
                 for (int i = 0; i < L; ++i) codes[i] = (unsigned)(1 + ((kx0 + i) >> 2)) * 0x10001u;
+            } else if (p.tcodes_compact) {
+                // A radial bin map is monotone along a half row and moves by at most one bin per sample: 16 samples = the first
+                // one's bin and a mask of the steps (built and verified on the host, fasty_build_tcodes).  4 bytes per 16 samples
+                // instead of 64: the full table (33.6 MB at 4096^2, read once per slab -- loads do not stay in the Infinity Cache --
+                // cost 7.3 of the row pass's 29.6 us, profiles/r03_tune_iso.txt) becomes 2 MB that live in L2.  The mirror sample
+                // (-ky, -kx) is in the same bin (verified too) except on the rows ky = 0 and ny/2, which are their own mirrors.
+                const unsigned w = p.tcodes[(size_t)kyr * (NX / 16) + (kx0 >> 4)];
+                const unsigned first = w & 0xffffu, mask = w >> 16;
+                const bool up = kx0 < NX / 2, twin = kyr != 0 && kyr != nyh;
+#pragma unroll
+                for (int i = 0; i < L; ++i) {
+                    const int pos = (kx0 & 15) + i;  // position inside the 16-sample segment
+                    const unsigned steps = (unsigned)__popc(mask & ((2u << pos) - 1u));
+                    const unsigned cd = first ? (up ? first + steps : first - steps) : 0u;
+                    codes[i] = cd | (twin ? cd << 16 : 0u);
+                }
             } else {
-                const unsigned* __restrict__ tc = p.tcodes + (size_t)(ky0 + rd * NR + rl) * NX + kx0;
+                const unsigned* __restrict__ tc = p.tcodes + (size_t)kyr * NX + kx0;
 #pragma unroll
                 for (int i = 0; i < L; i += 4) {
                     const uint4 c4 = *reinterpret_cast<const uint4*>(tc + i);

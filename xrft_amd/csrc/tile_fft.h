@@ -121,7 +121,7 @@ template <typename T> __device__ __forceinline__ void dft16(C2<T>* a) {
 
 template <typename T, int R> __device__ __forceinline__ void dft_r(C2<T>* a);
 
-// Composite radices with coprime factors (6, 10, 12, 15) by the prime-factor (Good-Thomas) mapping: no twiddles at all,
+// Composite radices with coprime factors (6, 10, 12, 15, 20) by the prime-factor (Good-Thomas) mapping: no twiddles at all,
 //   n = (B n1 + A n2) mod AB,   k = k1 mod A, k = k2 mod B (CRT);  every index is a compile-time constant.
 constexpr int xrft_modinv(int a, int m) { for (int x = 1; x < m; ++x) if ((a * x) % m == 1) return x; return 0; }
 template <typename T, int A, int B> __device__ __forceinline__ void dft_pfa(C2<T>* a) {
@@ -182,6 +182,7 @@ template <typename T, int R> __device__ __forceinline__ void dft_r(C2<T>* a) {
     else if (R == 12) dft_pfa<T, 4, 3>(a);
     else if (R == 15) dft_pfa<T, 3, 5>(a);
     else if (R == 16) dft16(a);
+    else if (R == 20) dft_pfa<T, 4, 5>(a);
 }
 
 // ------------------------------------------------------------------------------------------------

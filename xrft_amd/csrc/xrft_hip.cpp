@@ -321,6 +321,9 @@ struct xrfthip_plan {
     DevBuf tw_big1d;
     int y_nrow_pad = 0;  // rows ky = 0..ny/2 of the intermediate, rounded up to what one row workgroup covers
     DevBuf ywhat0, ywhat1, ytcodes;
+    DevBuf ytfirst;
+    bool ytfirst_on = false;       // ... and a radial map's: the radial sums are gathered per bin without atomics (fasty_build_tcodes)
+    bool ytcodes_compact = false;  // the bin map has a radial map's structure: 4 bytes per 16 samples (fasty_build_tcodes)
     std::vector<double> host_win_y;
     // tuning knobs from the environment, read once when the plan is created (never in xrfthip_exec)
     long long tune_group = 0, tune_fast_group = 0, tune_group_bytes = 512LL << 20, tune_cols_grid = 256, tune_max_grid = 8192;
@@ -1132,10 +1135,74 @@ static int fasty_window_spectra(xrfthip_plan* P) {
     return rc;
 }
 
-// the bin map as pass 2 reads it (fasty_rows_kernel): [ky < nrow_pad][kx] in natural order,
-// value = (bin of (ky, kx) + 1) | (bin of the mirror (-ky, -kx) + 1) << 16; rows beyond ny/2 and unbinned samples are 0
+// the bin map as pass 2 reads it (fasty_rows_kernel).  Full form: [ky < nrow_pad][kx] in natural order,
+// value = (bin of (ky, kx) + 1) | (bin of the mirror (-ky, -kx) + 1) << 16; rows beyond ny/2 and unbinned samples are 0.
+// Compact form, when the map has the structure of a radial one (every sample of rows 0 .. ny/2 binned; along a half row the bin
+// never decreases / never increases and moves by at most one per sample; the mirror sample is in the same bin except on the
+// self-mirrored rows 0 and ny/2): [ky][kx / 16] = (first sample's bin + 1) | step mask << 16 -- 1/16 of the bytes.
 static int fasty_build_tcodes(xrfthip_plan* P, const int32_t* bm) {
     const int ny = (int)P->yny, nx = (int)P->ynx, nyh = ny / 2;
+    bool compact = env_ll("XRFTHIP_ISO_COMPACT", 1) != 0 && nx % 32 == 0;
+    for (int ky = 0; ky <= nyh && compact; ++ky)
+        for (int kx = 0; kx < nx; ++kx) {
+            const int32_t cd = bm[(size_t)ky * nx + kx];
+            if (cd < 0 || cd > 65533) { compact = false; break; }
+            if (ky != 0 && ky != nyh && bm[(size_t)(ny - ky) * nx + ((nx - kx) & (nx - 1))] != cd) { compact = false; break; }
+            if (kx & 15) {  // inside a segment: a step of 0 or one bin in the half row's direction
+                const int32_t step = cd - bm[(size_t)ky * nx + kx - 1];
+                if (step != 0 && step != (kx < nx / 2 ? 1 : -1)) { compact = false; break; }
+            }
+        }
+    P->ytcodes_compact = compact;
+    // ... and the form the atomic-free gather needs (fasty_rows_kernel): along a row the bin depends on |kx| only and never
+    // decreases with it (a radial map), every sample is binned, a sample's Hermitian twin shares its bin: first[ky][b] = the
+    // smallest |kx| <= nx/2 whose bin is >= b (nx/2 + 1 if none), b = 0 .. nbins
+    bool radial = env_ll("XRFTHIP_ISO_GATHER", 1) != 0 && nx % 32 == 0 && P->nbins < 65535 && nx / 2 + 1 < 65535;
+    for (int ky = 0; ky <= nyh && radial; ++ky) {
+        const int32_t* r = bm + (size_t)ky * nx;
+        for (int m = 0; m <= nx / 2; ++m) {
+            const int32_t c = r[m];
+            if (c < 0 || c >= P->nbins || (m > 0 && c < r[m - 1]) || (m > 0 && m < nx / 2 && r[nx - m] != c)) { radial = false; break; }
+            if (ky != 0 && ky != nyh && (bm[(size_t)(ny - ky) * nx + ((nx - m) & (nx - 1))] != c || bm[(size_t)(ny - ky) * nx + m] != c)) { radial = false; break; }
+        }
+    }
+    P->ytfirst_on = radial;
+    if (radial) {
+        std::vector<uint16_t> f((size_t)P->y_nrow_pad * (P->nbins + 1), (uint16_t)(nx / 2 + 1));
+        for (int ky = 0; ky <= nyh; ++ky) {
+            const int32_t* r = bm + (size_t)ky * nx;
+            uint16_t* dst = f.data() + (size_t)ky * (P->nbins + 1);
+            int m = 0;
+            for (int b = 0; b <= P->nbins; ++b) {
+                while (m <= nx / 2 && r[m] < b) ++m;
+                dst[b] = (uint16_t)m;
+            }
+        }
+        const int rcf = P->ytfirst.upload(f.data(), f.size() * sizeof(uint16_t));
+        if (rcf) return rcf;
+        // the step masks of the 16-sample segments (any step size: the gather needs the run ends only)
+        std::vector<uint32_t> t((size_t)P->y_nrow_pad * (nx / 16), 0u);
+        for (int ky = 0; ky <= nyh; ++ky)
+            for (int s0 = 0; s0 < nx; s0 += 16) {
+                uint32_t w = (uint32_t)(std::min<int32_t>(bm[(size_t)ky * nx + s0], 65533) + 1);
+                for (int i = 1; i < 16; ++i)
+                    if (bm[(size_t)ky * nx + s0 + i] != bm[(size_t)ky * nx + s0 + i - 1]) w |= 1u << (16 + i);
+                t[(size_t)ky * (nx / 16) + s0 / 16] = w;
+            }
+        P->ytcodes_compact = true;  // (the table has the compact form; the gather reads its masks only)
+        return P->ytcodes.upload(t.data(), t.size() * sizeof(uint32_t));
+    }
+    if (compact) {
+        std::vector<uint32_t> t((size_t)P->y_nrow_pad * (nx / 16), 0u);
+        for (int ky = 0; ky <= nyh; ++ky)
+            for (int s0 = 0; s0 < nx; s0 += 16) {
+                uint32_t w = (uint32_t)(bm[(size_t)ky * nx + s0] + 1);
+                for (int i = 1; i < 16; ++i)
+                    if (bm[(size_t)ky * nx + s0 + i] != bm[(size_t)ky * nx + s0 + i - 1]) w |= 1u << (16 + i);
+                t[(size_t)ky * (nx / 16) + s0 / 16] = w;
+            }
+        return P->ytcodes.upload(t.data(), t.size() * sizeof(uint32_t));
+    }
     std::vector<uint32_t> t((size_t)P->y_nrow_pad * nx, 0u);
     for (int ky = 0; ky <= nyh; ++ky)
         for (int kx = 0; kx < nx; ++kx) {
@@ -1240,6 +1307,8 @@ static FastY fasty_params(const xrfthip_plan* P, const float* in, void* out, dou
     p.what0 = reinterpret_cast<const cf*>(P->ywhat0.p);
     p.what1 = reinterpret_cast<const cf*>(P->ywhat1.p);
     p.tcodes = reinterpret_cast<const unsigned*>(P->ytcodes.p);
+    p.tcodes_compact = P->ytcodes_compact ? 1 : 0;
+    p.tfirst = P->ytfirst_on ? reinterpret_cast<const unsigned short*>(P->ytfirst.p) : nullptr;
     p.iso = iso_on ? iso + (size_t)g0 * P->nbins * (d.out_mode == XRFTHIP_OUT_CROSS ? 2 : 1) : nullptr;
     p.nbins = P->nbins;
     p.iso_part = reinterpret_cast<double*>(ws + P->off_isopart);
@@ -1287,7 +1356,7 @@ template <typename T, int N> static MGeomRt mgeom_t() {
 static bool fastm_len(long long n, bool dbl) {
 #define X_(NN) if (n == NN) return true;
     XRFT_M_LATLON(X_)
-    if (dbl) { XRFT_M_POW2(X_) }
+    if (dbl) { XRFT_M_POW2(X_) } else { XRFT_M_F32ONLY(X_) }
 #undef X_
     return false;
 }
@@ -1298,7 +1367,7 @@ static MGeomRt mgeom(long long n, bool dbl) {
 #undef X_
     }
 #define X_(NN) if (n == NN) return mgeom_t<float, NN>();
-    XRFT_M_LATLON(X_)
+    XRFT_M_LATLON(X_) XRFT_M_F32ONLY(X_)
 #undef X_
     return mgeom_t<float, 360>();
 }
@@ -1306,6 +1375,9 @@ static MGeomRt mgeom(long long n, bool dbl) {
 static int fastm_cw(long long ny, bool dbl) { return 2 * mgeom(ny, dbl).g; }
 static int fastm_rk(long long ny, bool dbl) { const int lb = fastm_cw(ny, dbl) * (dbl ? 16 : 8); return lb >= 128 ? 1 : 128 / lb; }
 static int fastm_rpu(long long nx, bool two, bool dbl) { const MGeomRt r = mgeom(nx, dbl); return two ? r.g / 2 : r.g_r1; }  // 
+// rows per line of the intermediate for a (ny, nx) plan: a whole 128-byte line of pass 1's CW columns, but never more rows than
+// one pass-2 workgroup owns (long float32 sequences: two per workgroup = 4 columns = 32 bytes per row, pass 2 takes 2 rows -> 64-byte pieces)
+static int fastm_rk2(long long ny, long long nx, bool two, bool dbl) { return std::max(1, std::min(fastm_rk(ny, dbl), fastm_rpu(nx, two, dbl))); }
 
 // radial sums inside pass 2 when the per-bin tables fit behind the transforms' LDS (64 KB of dynamic LDS per workgroup); otherwise
 // the spectrum is stored and summed by run_radial_sums
@@ -1355,7 +1427,7 @@ static FastM fastm_params(const xrfthip_plan* P, const void* in, void* out, char
     p.binmap = (const int*)P->binmap.p; p.nbins = P->nbins; p.iso_ncopy = P->nbins > 0 ? fastm_iso_ncopy(P) : 1;
     p.iso_part = reinterpret_cast<double*>(ws + P->off_isopart);
     p.ny = (int)P->yny; p.nx = (int)P->ynx; p.nrow_pad = P->y_nrow_pad;
-    p.l_cw = ilog2i(fastm_cw(P->yny, P->dbl)); p.l_rk = ilog2i(fastm_rk(P->yny, P->dbl));
+    p.l_cw = ilog2i(fastm_cw(P->yny, P->dbl)); p.l_rk = ilog2i(fastm_rk2(P->yny, P->ynx, P->d.out_mode == XRFTHIP_OUT_CROSS || P->d.out_mode == XRFTHIP_OUT_PHASE, P->dbl));
     p.detrend = d.detrend; p.nslab = (int)gc;
     p.nunits = (int)(gc * (P->ynx / fastm_cw(P->yny, P->dbl)));
     p.shift_y = (d.flags & XRFTHIP_SHIFT_Y) ? (int)(P->yny / 2) : 0;
@@ -1378,7 +1450,7 @@ static void fastm_launch_cols(const xrfthip_plan* P, const FastM& p, long long g
                          else { auto k = &fastm_cols_kernel<TT, NN, false>; MBIG_(k, C.lds_cols); XRFT_LAUNCH(k, grid, blk, C.lds_cols, st, p); } } while (0)
 #define XD_(NN) if (P->yny == NN) MC_(double, NN);
 #define XF_(NN) if (P->yny == NN) MC_(float, NN);
-    if (P->dbl) { XRFT_M_LATLON(XD_) XRFT_M_POW2(XD_) } else { XRFT_M_LATLON(XF_) }
+    if (P->dbl) { XRFT_M_LATLON(XD_) XRFT_M_POW2(XD_) } else { XRFT_M_LATLON(XF_) XRFT_M_F32ONLY(XF_) }
 #undef XD_
 #undef XF_
 #undef MC_
@@ -1414,7 +1486,7 @@ static void fastm_launch_rows(const xrfthip_plan* P, const FastM& p, long long g
         else { auto k = &fastm_rows_kernel<TT, NN, 0>; XRFT_LAUNCH(k, grid, blk, lds_rows, st, p); } } while (0)
 #define XD_(NN) if (P->ynx == NN) MR_(double, NN);
 #define XF_(NN) if (P->ynx == NN) MR_(float, NN);
-    if (P->dbl) { XRFT_M_LATLON(XD_) XRFT_M_POW2(XD_) } else { XRFT_M_LATLON(XF_) }
+    if (P->dbl) { XRFT_M_LATLON(XD_) XRFT_M_POW2(XD_) } else { XRFT_M_LATLON(XF_) XRFT_M_F32ONLY(XF_) }
 #undef XD_
 #undef XF_
 #undef MR_
@@ -1463,6 +1535,7 @@ static int run_fastm(const xrfthip_plan* P, const void* in, const void* in1, voi
 static bool fastmy_len(long long n, bool dbl) {
 #define X_(NN) if (n == NN) return true;
     XRFT_M_LATLON(X_) XRFT_M_POW2(X_) XRFT_M_YONLY(X_)
+    if (!dbl) { XRFT_M_F32ONLY(X_) }
 #undef X_
     return n == 2048 || n == 4096;
 }
@@ -1507,7 +1580,7 @@ static int run_fastmy(const xrfthip_plan* P, const void* in, const void* in1, vo
         if (d.out_mode == XRFTHIP_OUT_POWER) MYL_(TT, NN, 1); else if (two) MYL_(TT, NN, 2); else MYL_(TT, NN, 0); } while (0)
 #define XD_(NN) if (d.ny == NN) MY_(double, NN);
 #define XF_(NN) if (d.ny == NN) MY_(float, NN);
-    if (P->dbl) { XRFT_M_LATLON(XD_) XRFT_M_POW2(XD_) XRFT_M_YONLY(XD_) XD_(2048) XD_(4096) } else { XRFT_M_LATLON(XF_) XRFT_M_POW2(XF_) XRFT_M_YONLY(XF_) XF_(2048) XF_(4096) }
+    if (P->dbl) { XRFT_M_LATLON(XD_) XRFT_M_POW2(XD_) XRFT_M_YONLY(XD_) XD_(2048) XD_(4096) } else { XRFT_M_LATLON(XF_) XRFT_M_F32ONLY(XF_) XRFT_M_POW2(XF_) XRFT_M_YONLY(XF_) XF_(2048) XF_(4096) }
 #undef XD_
 #undef XF_
 #undef MY_
@@ -1550,7 +1623,7 @@ static int run_fastmx(const xrfthip_plan* P, const void* in, const void* in1, vo
         if (d.out_mode == XRFTHIP_OUT_POWER) MXL_(TT, NN, 1); else if (two) MXL_(TT, NN, 2); else MXL_(TT, NN, 0); } while (0)
 #define XD_(NN) if (d.nx == NN) MX_(double, NN);
 #define XF_(NN) if (d.nx == NN) MX_(float, NN);
-    if (P->dbl) { XRFT_M_LATLON(XD_) XRFT_M_POW2(XD_) XRFT_M_YONLY(XD_) XD_(2048) XD_(4096) } else { XRFT_M_LATLON(XF_) XRFT_M_POW2(XF_) XRFT_M_YONLY(XF_) XF_(2048) XF_(4096) }
+    if (P->dbl) { XRFT_M_LATLON(XD_) XRFT_M_POW2(XD_) XRFT_M_YONLY(XD_) XD_(2048) XD_(4096) } else { XRFT_M_LATLON(XF_) XRFT_M_F32ONLY(XF_) XRFT_M_POW2(XF_) XRFT_M_YONLY(XF_) XF_(2048) XF_(4096) }
 #undef XD_
 #undef XF_
 #undef MX_
@@ -1845,7 +1918,7 @@ int xrfthip_plan_create(xrfthip_plan** plan, const xrfthip_desc* desc) {
         if (P->fastm) {
             const bool two = d.out_mode == XRFTHIP_OUT_CROSS || d.out_mode == XRFTHIP_OUT_PHASE;
             const int rpu = fastm_rpu(d.nx, two, P->dbl);
-            if (rpu < 1 || rpu % fastm_rk(d.ny, P->dbl) != 0 || d.nx % fastm_cw(d.ny, P->dbl) != 0) P->fastm = false;
+            if (rpu < 1 || rpu % fastm_rk2(d.ny, d.nx, two, P->dbl) != 0 || d.nx % fastm_cw(d.ny, P->dbl) != 0) P->fastm = false;
         }
         if (P->fastm) {
             const bool two = d.out_mode == XRFTHIP_OUT_CROSS || d.out_mode == XRFTHIP_OUT_PHASE;
@@ -1937,8 +2010,8 @@ int xrfthip_plan_set_binmap(xrfthip_plan* plan, const int32_t* h_binmap, int64_t
     if (plan->fast4096) {
         int rcf = XRFTHIP_OK;
         if (plan->yfirst) {
-            if (!fasty_iso_tables_fit(plan, nbins)) plan->fast4096 = false;  // (the tables alias half of the transforms' LDS)
-            else rcf = fasty_build_tcodes(plan, h_binmap);
+            rcf = fasty_build_tcodes(plan, h_binmap);
+            if (!rcf && !plan->ytfirst_on && !fasty_iso_tables_fit(plan, nbins)) plan->fast4096 = false;  // (any map: the atomic tables alias half of the transforms' LDS)
         }
         if (rcf) return rcf;
     }
@@ -2022,7 +2095,7 @@ int xrfthip_plan_describe(const xrfthip_plan* plan, char* buf, size_t buflen) {
     } else if (plan->fastm) {
         const MGeomRt C = mgeom(plan->yny, plan->dbl), R = mgeom(plan->ynx, plan->dbl);
         appendf(s, "  [fastm] cols: %d thr, %d packed column pairs (FFT%lld r%dx%dx%d in LDS), lds=%zuB -> W2[slab][%d/%d][nx/%d][%d][%d] complex -> fit -> rows: %d thr, %d rows/unit (FFT%lld r%dx%dx%d), lds=%zuB, trend added back in the spectral domain, fftshift + mirror rows\n",
-                C.thr, C.g, (long long)plan->yny, C.r0, C.r1, C.r2, C.lds_cols, plan->y_nrow_pad, fastm_rk(plan->yny, plan->dbl), fastm_cw(plan->yny, plan->dbl), fastm_rk(plan->yny, plan->dbl), fastm_cw(plan->yny, plan->dbl),
+                C.thr, C.g, (long long)plan->yny, C.r0, C.r1, C.r2, C.lds_cols, plan->y_nrow_pad, fastm_rk2(plan->yny, plan->ynx, plan->d.out_mode >= XRFTHIP_OUT_CROSS, plan->dbl), fastm_cw(plan->yny, plan->dbl), fastm_rk2(plan->yny, plan->ynx, plan->d.out_mode >= XRFTHIP_OUT_CROSS, plan->dbl), fastm_cw(plan->yny, plan->dbl),
                 R.thr_r1, R.g_r1, (long long)plan->ynx, R.r0, R.r1, R.r2, R.lds_r1);
     } else if (fasty_on(plan)) {
         const YGeomRt C = ycols_geom(plan->yny), R = yrows_geom(plan->ynx, plan->fast1d);
@@ -2031,6 +2104,9 @@ int xrfthip_plan_describe(const xrfthip_plan* plan, char* buf, size_t buflen) {
         appendf(s, "  [fasty] cols: %d thr, %d x 2 packed column pairs (FFT%lld r16x16x%lld, column-local detrend fused), %d columns/unit, lds=%zuB -> W2[slab][%d/%d][nx/%d][2][%d][%d] -> rows: %d thr, %d rows/unit (FFT%lld r16x16x%lld), lds=%zuB, |F|^2 + fftshift + mirror rows\n",
                 C.thr, C.gxy, (long long)plan->d.ny, (long long)plan->d.ny / 256, C.cw, C.lds, plan->y_nrow_pad, C.rk, C.cw, C.rk, 2 * C.gxy,
                 R.thr, R.rk, (long long)plan->d.nx, (long long)plan->d.nx / 256, R.lds);
+        if ((plan->d.flags & XRFTHIP_ISO) && plan->ytcodes.p)
+            appendf(s, "  [fasty radial sums] fused into the row pass (runs of equal bins from the staged rows, int64 fixed-point tables), bin codes: %s\n",
+                    plan->ytfirst_on ? "radial map: per-bin gather, no atomics" : plan->ytcodes_compact ? "compact (radial map: first bin + step mask per 16 samples)" : "full (4 bytes per sample)");
     }
     describe_passes(s, plan->passes_f0, "f0");
     describe_passes(s, plan->passes, "main");
@@ -2225,19 +2301,23 @@ int xrfthip_table_mul(int32_t dtype, int64_t batch, int64_t n_in, int64_t n_out,
     return XRFTHIP_OK;
 }
 
-static int inner_chunks(long long ny) { return (int)std::max<long long>(1, std::min<long long>(64, ny / 4)); }
+static constexpr int kInnerMaxChunks = 256;
+static int inner_chunks(long long ny, long long batch, long long i2) {  // enough workgroups to fill the chip (a (y, x, t) array is ONE slab)
+    const long long tiles = std::max<long long>(1, batch * ((i2 + kInnerIB - 1) / kInnerIB));
+    return (int)std::max<long long>(1, std::min<long long>(std::min<long long>(kInnerMaxChunks, ny), (2048 + tiles - 1) / tiles));
+}
 static size_t detrend_inner_ws(bool cplx, long long batch, long long inner) {
     const size_t i2 = (size_t)inner * (cplx ? 2 : 1);
-    return (((size_t)std::max<long long>(batch, 1) * i2 * 3 * sizeof(double) * (64 + 1)) + 255) & ~(size_t)255;  // <= 64 chunks of partial sums + the coefficients
+    return (((size_t)std::max<long long>(batch, 1) * i2 * 3 * sizeof(double) * (kInnerMaxChunks + 1)) + 255) & ~(size_t)255;  // <= 256 chunks of partial sums + the coefficients
 }
 static int run_detrend_inner(int32_t dtype, int32_t ndim, long long batch, long long ny, long long nx, long long inner, int32_t kind, const void* in, void* out,
                              char* ws, hipStream_t st) {
     (void)ndim;
     const bool dbl = dtype == XRFTHIP_F64 || dtype == XRFTHIP_C128, cplx = dtype >= XRFTHIP_C64;
     const long long i2 = inner * (cplx ? 2 : 1);
-    const int nch = inner_chunks(ny);
+    const int nch = inner_chunks(ny, batch, i2);
     double* part = reinterpret_cast<double*>(ws);
-    double* coef = part + (size_t)batch * 64 * i2 * 3;
+    double* coef = part + (size_t)batch * kInnerMaxChunks * i2 * 3;
     for (long long b0 = 0; b0 < batch; b0 += 65535) {  // grid.z limit
         const long long bc = std::min<long long>(65535, batch - b0);
         const dim3 grid((unsigned)nch, (unsigned)((i2 + kInnerIB - 1) / kInnerIB), (unsigned)bc), block(kInnerIB * kInnerXS);
@@ -2249,8 +2329,7 @@ static int run_detrend_inner(int32_t dtype, int32_t ndim, long long batch, long 
         auto k = &plane_inner_finalize_kernel;
         XRFT_LAUNCH(k, dim3((unsigned)((batch * i2 + 255) / 256)), dim3(256), 0, st, (const double*)part, coef, (long long)batch, (long long)ny, (long long)nx, i2, nch, (int)kind);
     }
-    const long long total = batch * ny * nx * i2;
-    const dim3 grid((unsigned)std::min<long long>((total + 255) / 256, 8LL * kCUs * 8)), block(256);
+    const dim3 grid((unsigned)std::min<long long>(batch * ny, 8LL * kCUs * 4)), block(256);
     if (dbl) { auto k = &plane_inner_apply_kernel<double>; XRFT_LAUNCH(k, grid, block, 0, st, (const double*)in, (double*)out, (const double*)coef, (long long)batch, (long long)ny, (long long)nx, i2); }
     else { auto k = &plane_inner_apply_kernel<float>; XRFT_LAUNCH(k, grid, block, 0, st, (const float*)in, (float*)out, (const double*)coef, (long long)batch, (long long)ny, (long long)nx, i2); }
     HIP_TRY(hipGetLastError());
