@@ -187,6 +187,10 @@ int xrfthip_detrend3(int32_t dtype, int64_t batch, int64_t n0, int64_t n1, int64
  * d_a[e] * conj(d_b[e]) * scale (complex).  dtype = XRFTHIP_C64 | XRFTHIP_C128 (type of d_a / d_b). */
 int xrfthip_spectrum_tail(int32_t dtype, int64_t n, const void* d_a, const void* d_b, void* d_out, double scale, void* stream);
 
+/* d_out[e] = arg(d_a[e]) in [-pi, pi], real of the same precision (dtype = XRFTHIP_C64 | XRFTHIP_C128): numpy.angle of a stored cross
+ * spectrum, for xrft.cross_phase (xrft.py:838-874) on calls whose cross spectrum is composed of several plans. */
+int xrfthip_angle(int32_t dtype, int64_t n, const void* d_a, void* d_out, void* stream);
+
 /* The same over [outer][na][inner] with the real-dim factor [1, 2, ..., 2, (1 if last_is_one)] along axis `na` (xrft.py:673-682):
  * the kept half of a real transform counts twice, except k = 0 and, for an even length, the Nyquist sample. */
 int xrfthip_spectrum_tail_axis(int32_t dtype, int64_t outer, int64_t na, int64_t inner, int32_t last_is_one, const void* d_a, const void* d_b,

@@ -900,6 +900,13 @@ def run_long_prime_cases(lengths=((9001, "float64"), (10007, "float32"), (9001, 
             b = _cube(rng, shape, dt)
             db3, ob3 = pair(b, D3, _coords3(shape, y0=1.0))
             worst = max(worst, check(xa.cross_spectrum(da3, db3, dim=["y", "x"], window="hann"), o.cross_spectrum(od3, ob3, dim=["y", "x"], window="hann"), tol, br))
+            # ... and the calls ADVICE r2 found raising: the inverse over both axes, and the cross phase (the angle of the composed cross spectrum)
+            F3, Fo3 = xa.fft(da3, dim=["y", "x"]), o.fft(od3, dim=["y", "x"])
+            worst = max(worst, check(xa.ifft(F3, dim=["freq_y", "freq_x"]), o.ifft(Fo3, dim=["freq_y", "freq_x"]), tol, br))
+            gph = xa.cross_phase(da3, db3, dim=["y", "x"], window="hann")
+            rcs = o.cross_spectrum(od3, ob3, dim=["y", "x"], window="hann")
+            dphi = np.abs(np.angle(np.exp(1j * (np.asarray(gph.values, dtype=np.float64) - np.angle(rcs.values)))))
+            assert (dphi * np.abs(rcs.values)).max() / np.abs(rcs.values).max() < (1e-9 if dt == "float64" else 3e-4)
             # isotropic spectra: the full spectrum, then isotropize -- what the reference does literally (xrft.py:1085-1095)
             kwi = dict(dim=["y", "x"], detrend="linear", window="hann", truncate=True)
             worst = max(worst, check(xa.isotropic_power_spectrum(da3, **kwi), o.isotropic_power_spectrum(od3, **kwi), tol2, br))

@@ -23,6 +23,13 @@ CALLS = [
     ("irfftn", "complex", (3, 16, 13), [1, 2]),
     ("irfftn", "complex", (4, 16), [1]),
     ("irfftn", "complex", (5, 12, 5), [0, 2]),
+    # lengths with a prime factor too large for one LDS tile (numpy.fft takes any length): Bluestein through global memory
+    ("fftn", "complex", (2, 9001), [1]),
+    ("fftn", "real", (2, 6, 9001), [1, 2]),
+    ("ifftn", "complex", (2, 9001, 4), [1]),
+    ("fftn", "complex", (9001, 3), [0]),
+    ("rfftn", "real", (2, 9001), [1]),
+    ("rfftn", "real", (2, 6, 9001), [1, 2]),
 ]
 
 

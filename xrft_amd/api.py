@@ -255,6 +255,7 @@ def clear_plan_cache():
     """Drop every cached plan (device tables) and the shared scratch buffers."""
     with _plan_lock:
         _plan_cache.clear()
+        _BLUE_TABLES.clear()
     engine.clear_workspaces()
 
 
@@ -564,8 +565,11 @@ _BLUE_TABLES = {}
 
 
 def _blue_tables(n, cdt, dev, inverse=False):
+    """(m, conj chirp as a HOST complex128 vector, FFT_m(chirp) / m on the device) of Bluestein's algorithm for length n, cached.
+    The chirp's spectrum is taken by the engine's own length-m plan in complex128 (no numpy.fft in the product path)."""
     key = (n, str(cdt), str(dev), inverse)
-    tb = _BLUE_TABLES.get(key)
+    with _plan_lock:
+        tb = _BLUE_TABLES.get(key)
     if tb is None:
         m = 2 * n - 1
         while True:
@@ -582,11 +586,14 @@ def _blue_tables(n, cdt, dev, inverse=False):
         b = np.zeros(m, dtype=np.complex128)
         b[:n] = chirp
         b[m - n + 1:] = chirp[1:][::-1]                            # c[-j] = c[j], wrapped
-        bhat = np.fft.fft(b) / m                                   # (host, once per length)
-        tb = (m, torch.from_numpy(np.conj(chirp)).to(cdt).to(dev), torch.from_numpy(bhat).to(cdt).to(dev))
-        if len(_BLUE_TABLES) > 8:
-            _BLUE_TABLES.clear()
-        _BLUE_TABLES[key] = tb
+        plan = _get_plan(ndim=1, batch=1, ny=1, nx=m, dtype=torch.complex128, out_mode=_lib.OUT_COMPLEX, detrend=_lib.DETREND_NONE, flags=0,
+                         scale=1.0 / m, window_y=None, window_x=None, phase_y=None, phase_x=None)
+        bhat, _ = plan.execute(torch.from_numpy(b).to(dev).reshape(1, 1, m))
+        tb = (m, np.conj(chirp), bhat.reshape(m).to(cdt))  # (one precision change of a table, once per length)
+        with _plan_lock:
+            if len(_BLUE_TABLES) > 8:
+                _BLUE_TABLES.clear()
+            _BLUE_TABLES[key] = tb
     return tb
 
 
@@ -608,12 +615,13 @@ def _bluestein_1d(t, n, mode, detrend_kind, flags, scale, win, ph, phase_in=None
     if (flags & (_lib.FLIP_X | _lib.ISHIFT_X)):
         x = engine.gather_axis(x, 1, index=idx)
     m, cconj_chirp, bhat = _blue_tables(n, cdt, x.device, inverse=bool(flags & _lib.INVERSE))
-    tab = cconj_chirp
+    # the pointwise tables are composed on the host (length-n vectors, like the window vectors) and uploaded: no torch arithmetic
+    tab_h = cconj_chirp
     if phase_in is not None:
-        tab = tab * torch.from_numpy(np.ascontiguousarray(np.asarray(phase_in, dtype=np.complex128)[idx])).to(cdt).to(tab.device)
+        tab_h = tab_h * np.asarray(phase_in, dtype=np.complex128)[idx]
     if win is not None:  # the window rides on the first chirp multiply (it multiplies the samples where they lie AFTER flip / shift:
-        w = np.asarray(win, dtype=np.float64)[idx]  # the reference windows first, then flips: window of the source sample)
-        tab = tab * torch.from_numpy(np.ascontiguousarray(w)).to(tab.real.dtype).to(tab.device)
+        tab_h = tab_h * np.asarray(win, dtype=np.float64)[idx]  # the reference windows first, then flips: window of the source sample)
+    tab = torch.from_numpy(np.ascontiguousarray(tab_h.astype(np.complex64 if cdt == torch.complex64 else np.complex128))).to(x.device)
     a = engine.table_mul(x, tab.contiguous(), m)
     fwd = _get_plan(ndim=1, batch=a.shape[0], ny=1, nx=m, dtype=a.dtype, out_mode=_lib.OUT_COMPLEX, detrend=_lib.DETREND_NONE, flags=0, scale=1.0,
                     window_y=None, window_x=None, phase_y=None, phase_x=None)
@@ -629,8 +637,8 @@ def _bluestein_1d(t, n, mode, detrend_kind, flags, scale, win, ph, phase_in=None
         fac = fac * float(scale)
         if ph is not None:
             fac = fac * np.asarray(ph, dtype=np.complex128)[:n_out]
-    tab2 = cconj_chirp[:n_out] * torch.from_numpy(fac).to(cdt).to(x.device)
-    X = engine.table_mul(cc.reshape(-1, m), tab2.contiguous(), n_out)  # F[k] (x phase x scale), k < n_out
+    tab2 = torch.from_numpy(np.ascontiguousarray((cconj_chirp[:n_out] * fac).astype(np.complex64 if cdt == torch.complex64 else np.complex128))).to(x.device)
+    X = engine.table_mul(cc.reshape(-1, m), tab2, n_out)  # F[k] (x phase x scale), k < n_out
     if mode == _lib.OUT_POWER:
         if flags & _lib.REALDIM_X2:
             X = engine.spectrum_tail_axis(X, None, float(scale), 1, n % 2 == 0)
@@ -640,7 +648,7 @@ def _bluestein_1d(t, n, mode, detrend_kind, flags, scale, win, ph, phase_in=None
         d2 = np.full(n_out, 2.0); d2[0] = 1.0
         if n % 2 == 0:
             d2[-1] = 1.0
-        X = engine.table_mul(X, torch.from_numpy(d2.astype(np.complex128)).to(cdt).to(x.device), n_out)
+        X = engine.table_mul(X, torch.from_numpy(d2.astype(np.complex64 if cdt == torch.complex64 else np.complex128)).to(x.device), n_out)
     if flags & _lib.SHIFT_X:
         X = engine.gather_axis(X, 1, roll=n // 2)
     return X.reshape(shape[:-1] + [n_out])
@@ -970,6 +978,17 @@ def ifft(daft, spacing_tol=1e-3, dim=None, real_dim=None, shift=True, true_phase
             y = engine.table_mul(t.reshape(-1, nx_in), torch.from_numpy(fac).to(cdt).to(t.device), nx)
             z = _bluestein_1d(y, nx, _lib.OUT_COMPLEX, _lib.DETREND_NONE, flags & ~(_lib.PHASE_IN | _lib.C2R_X), float(scale), None, None)
             out = engine.gather_axis(torch.view_as_real(z.contiguous()), 2, index=np.array([0])).reshape(list(t.shape[:-1]) + [nx])
+        elif len(dim) == 2 and not chunks_to_segments:
+            # two axes, one of them a length no two-axis plan takes: ifftn is separable (xrft.py:612-621) -- one axis at a time, the
+            # real dimension (whose c2r step must come last) at the end; each stage has its own way round (Bluestein through global memory)
+            lag_of = dict(zip(dim, lag))
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore")
+                cur = ifft(from_any(src), spacing_tol=spacing_tol, dim=[dim[0]], shift=shift, true_phase=true_phase, true_amplitude=true_amplitude,
+                           prefix=prefix, lag=[lag_of[dim[0]]])
+                cur = ifft(cur, spacing_tol=spacing_tol, dim=[dim[1]], real_dim=real_dim, shift=shift, true_phase=true_phase,
+                           true_amplitude=true_amplitude, prefix=prefix, lag=[lag_of[dim[1]]])
+            return to_like(from_any(cur), src)
         elif len(dim) != 1 or real_dim is not None:
             lim = 8800 if t.dtype == torch.complex64 else 4400
             raise ValueError(f"transform length(s) {dict(zip(dim, N))} not supported on the device: a length with a prime factor above 128 must "
@@ -1162,7 +1181,14 @@ def cross_phase(da1, da2, dim=None, true_phase=True, **kwargs):
     scaling = kw.pop("scaling", "density")
     window_correction = kw.pop("window_correction", False)
     c, c2, mode, scale, flags = _spectrum(da1, da2, dim, real_dim, scaling, window_correction, true_phase, kw)
-    cp = _cross_result(c, c2, _lib.OUT_PHASE, abs(scale) if scale != 0 else 1.0, flags & ~_lib.REALDIM_X2)
+    try:
+        cp = _cross_result(c, c2, _lib.OUT_PHASE, abs(scale) if scale != 0 else 1.0, flags & ~_lib.REALDIM_X2)
+    except _UnsupportedLength:
+        # a length no fused plan takes (numpy.fft takes any): the angle of the cross spectrum, which has its own way round
+        # (one axis at a time, Bluestein through global memory) -- what the reference does literally (xrft.py:871-874)
+        cs = from_any(cross_spectrum(da1, da2, dim=dim, real_dim=real_dim, scaling=scaling, window_correction=window_correction,
+                                     true_phase=true_phase, **kw))
+        cp = DataArray(engine.angle(_to_device(cs.data)), cs.dims, cs.coords, None, None)
     if da1.name and da2.name:
         cp.name = "{}_{}_phase".format(da1.name, da2.name)
     return to_like(cp, src)

@@ -369,6 +369,14 @@ __global__ void __launch_bounds__(256) plane_inner_apply_kernel(const T* __restr
     }
 }
 
+// out[e] = arg(a[e]) in [-pi, pi] (numpy.angle of a stored cross spectrum: xrft.cross_phase, xrft/xrft.py:838-874, where the fused
+// plans cannot take the phase in their epilogue)
+template <typename T>
+__global__ void __launch_bounds__(256) angle_kernel(const C2<T>* __restrict__ a, T* __restrict__ out, long long n) {
+    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (long long)gridDim.x * blockDim.x)
+        out[e] = (T)atan2((double)a[e].im, (double)a[e].re);
+}
+
 // out[o][i] = scale * sum_k in[o][k][i] over [outer][n][inner] (complex data: inner counts real components), the terms added in
 // the order k = 0, 1, ... in float64: a mean / sum over a batch dimension whose result does not depend on how the launch was
 // scheduled (the reference's users average isotropic spectra over the batch: xrft/tests/test_xrft.py:1011-1013, `.mean("d0")`).

@@ -54,16 +54,17 @@ constexpr long long kYTuneDefault = 0;
 #define XRFT_YTUNE(p) ((int)kYTuneDefault)
 #endif
 
-// 16-byte store with a run-time cache policy: 0 non-temporal, 1 plain, 2 write-through to memory (sc1)
-__device__ __forceinline__ void xrft_store_pol(float* dst, F4 v, int pol) {
+// 16-byte store at base + off with a run-time cache policy: 0 non-temporal, 1 plain, 2 write-through to memory (sc1; `base` must be
+// wave-uniform: it becomes the buffer descriptor -- a per-lane base is a 64-iteration waterfall loop, 154 us per slab)
+__device__ __forceinline__ void xrft_store_pol(char* base, unsigned off, F4 v, int pol) {
 #ifdef XRFT_EMULATE
-    *reinterpret_cast<F4*>(dst) = v;
+    *reinterpret_cast<F4*>(base + off) = v;
 #else
     typedef float v4f __attribute__((ext_vector_type(4)));
     const v4f t = {v.x, v.y, v.z, v.w};
-    if (pol == 0) __builtin_nontemporal_store(t, reinterpret_cast<v4f*>(dst));
-    else if (pol == 1) *reinterpret_cast<v4f*>(dst) = t;
-    else __builtin_amdgcn_raw_buffer_store_b128(t, __builtin_amdgcn_make_buffer_rsrc(dst, 0, 16, 0x00020000), 0, 0, 16);
+    if (pol == 0) __builtin_nontemporal_store(t, reinterpret_cast<v4f*>(base + off));
+    else if (pol == 1) *reinterpret_cast<v4f*>(base + off) = t;
+    else __builtin_amdgcn_raw_buffer_store_b128(t, __builtin_amdgcn_make_buffer_rsrc(base, 0, 0x7fffffff, 0x00020000), (int)off, 0, 16);
 #endif
 }
 __device__ __forceinline__ F4 xrft_load_pol(const char* src, bool nt) {
@@ -402,7 +403,7 @@ __global__ void __launch_bounds__(YCols<NY>::THR, YCols<NY>::THR / 128) fasty_co
                 F4 o; o.x = ra.re; o.y = ra.im; o.z = rb.re; o.w = rb.im;
                 // non-temporal: the next reader is another kernel, a whole group of slabs later; kept out of L2 the lines leave
                 // it to the input, whose 128-byte lines are shared by four workgroups (PMC: 1.34x over-fetch with plain stores)
-                if (!(XRFT_YDBG & 64) || o.x == 1.2345f) xrft_store_pol(reinterpret_cast<float*>(w2s + off * 8u), o, XRFT_YTUNE(p) & 3);
+                if (!(XRFT_YDBG & 64) || o.x == 1.2345f) xrft_store_pol(w2s, off * 8u, o, XRFT_YTUNE(p) & 3);
             }
         }
         if (set == 0) __syncthreads();
@@ -592,7 +593,7 @@ __global__ void __launch_bounds__((YRows<NX, FS>::THR), (YRows<NX, FS>::THR / 12
             const int orow = mir ? ((p.ny - ky) + p.shift_y) & my : (ky + p.shift_y) & my;
             // non-temporal: the result is not read again, and keeping it out of the caches leaves the Infinity Cache to the
             // intermediate (scripts/ubench/yfirst.hip: 45.8 vs 50.9 us per slab for the two passes at 2 slabs per group)
-            if (!(XRFT_YDBG & 8) || v.x == 1.2345f) xrft_store_pol(outs + (size_t)orow * NX + c, v, (XRFT_YTUNE(p) >> 4) & 1 ? 1 : 0);
+            if (!(XRFT_YDBG & 8) || v.x == 1.2345f) xrft_store_pol(reinterpret_cast<char*>(outs), (unsigned)(((size_t)orow * NX + c) * 4u), v, (XRFT_YTUNE(p) >> 4) & 1 ? 1 : 0);
         }
     };
     // complex rows staged at cbase[rl * RSC + nat16(kx)] (natural order) = the unit's rows r0 .. r0 + nrows - 1 (not the four-step form)

@@ -2257,6 +2257,17 @@ int xrfthip_spectrum_tail(int32_t dtype, int64_t n, const void* d_a, const void*
     return XRFTHIP_OK;
 }
 
+int xrfthip_angle(int32_t dtype, int64_t n, const void* d_a, void* d_out, void* stream) {
+    if (!d_a || !d_out || n < 0 || (dtype != XRFTHIP_C64 && dtype != XRFTHIP_C128)) return XRFTHIP_BAD_ARG;
+    if (n == 0) return XRFTHIP_OK;
+    hipStream_t st = (hipStream_t)stream;
+    const dim3 grid((unsigned)std::max<long long>(1, std::min<long long>(16384, (n + 255) / 256))), block(256);
+    if (dtype == XRFTHIP_C128) { auto k = &angle_kernel<double>; XRFT_LAUNCH(k, grid, block, 0, st, (const C2<double>*)d_a, (double*)d_out, (long long)n); }
+    else { auto k = &angle_kernel<float>; XRFT_LAUNCH(k, grid, block, 0, st, (const C2<float>*)d_a, (float*)d_out, (long long)n); }
+    HIP_TRY(hipGetLastError());
+    return XRFTHIP_OK;
+}
+
 int xrfthip_spectrum_tail_axis(int32_t dtype, int64_t outer, int64_t na, int64_t inner, int32_t last_is_one, const void* d_a, const void* d_b,
                                void* d_out, double scale, void* stream) {
     if (!d_a || !d_out || outer < 0 || na < 1 || inner < 1 || (dtype != XRFTHIP_C64 && dtype != XRFTHIP_C128)) return XRFTHIP_BAD_ARG;

@@ -135,18 +135,26 @@ class SpectralPlan:
 # overlap in it; two streams never share scratch memory.  (A workspace per plan pinned several GB per cached plan.)
 _WS = {}
 _WS_LOCKS = {}
-_WS_RETIRED = []  # outgrown buffers: kept until clear_workspaces() -- kernels enqueued earlier may still be using them
+_WS_RETIRED = []  # (buffer, event) of outgrown buffers: kernels enqueued earlier may still be using them until the event has passed
 _WS_LOCK = threading.Lock()
 
 
 def _workspace(dev, stream, nbytes):
     key = (str(dev), stream.value)
     with _WS_LOCK:
+        # outgrown buffers go once the work that may still use them has finished (an event recorded on their stream when they retired)
+        _WS_RETIRED[:] = [(b, ev) for b, ev in _WS_RETIRED if ev is not None and not ev.query()]
         ws = _WS.get(key)
         if ws is None or ws.numel() < nbytes:
+            want = max(int(nbytes), 256)
             if ws is not None:
-                _WS_RETIRED.append(ws)
-            ws = _WS[key] = torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=dev)
+                want = max(want, int(1.5 * ws.numel()))  # geometric growth: a session whose plans grow step by step re-allocates O(log) times
+                ev = None
+                if dev.type == "cuda":
+                    ev = torch.cuda.Event()
+                    ev.record(torch.cuda.current_stream(dev))
+                    _WS_RETIRED.append((ws, ev))
+            ws = _WS[key] = torch.empty(want, dtype=torch.uint8, device=dev)
         lock = _WS_LOCKS.get(key)
         if lock is None:
             lock = _WS_LOCKS[key] = threading.Lock()
@@ -214,6 +222,17 @@ def spectrum_tail(a, b, scale):
     out = torch.empty(a.shape, dtype=a.dtype if b is not None else real_dt, device=a.device)
     _lib.check(dll.xrfthip_spectrum_tail(_DTYPES[a.dtype], a.numel(), _ptr(a), _ptr(b), _ptr(out), float(scale),
                                          _stream_handle(a)))
+    return out
+
+
+def angle(a):
+    """arg(a) in [-pi, pi] of a contiguous complex tensor (numpy.angle; xrft.cross_phase on composed cross spectra)."""
+    dll = _lib.load()
+    if not a.is_complex():
+        raise ValueError("angle needs a complex tensor")
+    a = a.contiguous()
+    out = torch.empty(a.shape, dtype=torch.float32 if a.dtype == torch.complex64 else torch.float64, device=a.device)
+    _lib.check(dll.xrfthip_angle(_DTYPES[a.dtype], a.numel(), _ptr(a), _ptr(out), _stream_handle(a)))
     return out
 
 

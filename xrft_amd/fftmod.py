@@ -19,7 +19,7 @@ import numpy as np
 import torch
 
 from . import _lib, engine
-from .api import _get_plan, _to_device
+from .api import _bluestein_1d, _get_plan, _to_device
 
 __all__ = ["fftn", "ifftn", "rfftn", "irfftn", "fftshift", "ifftshift"]
 
@@ -47,8 +47,14 @@ def _c2c_one(t, ax, inverse):
     flags = _lib.INVERSE if inverse else 0
     if ax == t.dim() - 1:
         batch = t.numel() // max(n, 1)
-        plan = _get_plan(ndim=1, batch=batch, ny=1, nx=n, dtype=t.dtype, out_mode=_lib.OUT_COMPLEX, detrend=_lib.DETREND_NONE,
-                         flags=flags, scale=scale, window_y=None, window_x=None, phase_y=None, phase_x=None)
+        try:
+            plan = _get_plan(ndim=1, batch=batch, ny=1, nx=n, dtype=t.dtype, out_mode=_lib.OUT_COMPLEX, detrend=_lib.DETREND_NONE,
+                             flags=flags, scale=scale, window_y=None, window_x=None, phase_y=None, phase_x=None)
+        except _lib.XrftHipError as e:
+            if e.status != _lib.UNSUPPORTED_LENGTH:
+                raise
+            # numpy.fft takes any length: a prime factor too large for one LDS tile goes through Bluestein in global memory
+            return _bluestein_1d(t, n, _lib.OUT_COMPLEX, _lib.DETREND_NONE, flags, scale, None, None).reshape(shape)
         out, _ = plan.execute(t.reshape(batch, 1, n))
         return out.reshape(shape)
     batch = int(np.prod(shape[:ax], dtype=np.int64))
@@ -72,6 +78,15 @@ def _c2c_one(t, ax, inverse):
 def _c2c_last2(t, inverse):
     ny, nx = t.shape[-2], t.shape[-1]
     batch = t.numel() // max(ny * nx, 1)
+    try:
+        return _c2c_last2_plan(t, inverse, ny, nx, batch)
+    except _lib.XrftHipError as e:
+        if e.status != _lib.UNSUPPORTED_LENGTH:
+            raise
+        return _c2c_one(_c2c_one(t, t.dim() - 1, inverse), t.dim() - 2, inverse)  # separable: one axis at a time
+
+
+def _c2c_last2_plan(t, inverse, ny, nx, batch):
     plan = _get_plan(ndim=2, batch=batch, ny=ny, nx=nx, dtype=t.dtype, out_mode=_lib.OUT_COMPLEX, detrend=_lib.DETREND_NONE,
                      flags=_lib.INVERSE if inverse else 0, scale=1.0 / (ny * nx) if inverse else 1.0, window_y=None, window_x=None,
                      phase_y=None, phase_x=None)
@@ -104,8 +119,13 @@ def fftn(a, s=None, axes=None, norm=None):
         nx = t.shape[-1]
         ny = t.shape[-2] if len(axes) == 2 else 1
         batch = t.numel() // max(ny * nx, 1)
-        plan = _get_plan(ndim=len(axes), batch=batch, ny=ny, nx=nx, dtype=t.dtype, out_mode=_lib.OUT_COMPLEX,
-                         detrend=_lib.DETREND_NONE, flags=0, scale=1.0, window_y=None, window_x=None, phase_y=None, phase_x=None)
+        try:
+            plan = _get_plan(ndim=len(axes), batch=batch, ny=ny, nx=nx, dtype=t.dtype, out_mode=_lib.OUT_COMPLEX,
+                             detrend=_lib.DETREND_NONE, flags=0, scale=1.0, window_y=None, window_x=None, phase_y=None, phase_x=None)
+        except _lib.XrftHipError as e:
+            if e.status != _lib.UNSUPPORTED_LENGTH:
+                raise
+            return _c2c(t, axes, False)  # a length no fused plan takes: one axis at a time, Bluestein through global memory
         out, _ = plan.execute(t.reshape(batch, ny, nx))
         return out.reshape(t.shape)
     return _c2c(t, axes, False)
@@ -136,19 +156,30 @@ def rfftn(a, s=None, axes=None, norm=None):
     t = t.contiguous()
     nx = t.shape[-1]
     rest = axes[:-1]
+    plan2 = None
     if rest and sorted(rest)[-1] == t.dim() - 2:  # fused two-axis half-spectrum plan over the trailing pair
         ny = t.shape[-2]
         batch = t.numel() // max(ny * nx, 1)
-        plan = _get_plan(ndim=2, batch=batch, ny=ny, nx=nx, dtype=t.dtype, out_mode=_lib.OUT_COMPLEX, detrend=_lib.DETREND_NONE,
-                         flags=_lib.HALF_X, scale=1.0, window_y=None, window_x=None, phase_y=None, phase_x=None)
-        out, _ = plan.execute(t.reshape(batch, ny, nx))
+        try:
+            plan2 = _get_plan(ndim=2, batch=batch, ny=ny, nx=nx, dtype=t.dtype, out_mode=_lib.OUT_COMPLEX, detrend=_lib.DETREND_NONE,
+                              flags=_lib.HALF_X, scale=1.0, window_y=None, window_x=None, phase_y=None, phase_x=None)
+        except _lib.XrftHipError as e:
+            if e.status != _lib.UNSUPPORTED_LENGTH:
+                raise
+    if plan2 is not None:
+        out, _ = plan2.execute(t.reshape(batch, ny, nx))
         out = out.reshape(list(t.shape[:-1]) + [nx // 2 + 1])
         rest = [ax for ax in rest if ax != t.dim() - 2]
     else:
         batch = t.numel() // max(nx, 1)
-        plan = _get_plan(ndim=1, batch=batch, ny=1, nx=nx, dtype=t.dtype, out_mode=_lib.OUT_COMPLEX, detrend=_lib.DETREND_NONE,
-                         flags=_lib.HALF_X, scale=1.0, window_y=None, window_x=None, phase_y=None, phase_x=None)
-        out, _ = plan.execute(t.reshape(batch, 1, nx))
+        try:
+            plan = _get_plan(ndim=1, batch=batch, ny=1, nx=nx, dtype=t.dtype, out_mode=_lib.OUT_COMPLEX, detrend=_lib.DETREND_NONE,
+                             flags=_lib.HALF_X, scale=1.0, window_y=None, window_x=None, phase_y=None, phase_x=None)
+            out, _ = plan.execute(t.reshape(batch, 1, nx))
+        except _lib.XrftHipError as e:
+            if e.status != _lib.UNSUPPORTED_LENGTH:
+                raise
+            out = _bluestein_1d(t, nx, _lib.OUT_COMPLEX, _lib.DETREND_NONE, _lib.HALF_X, 1.0, None, None)  # (any length, as numpy.fft)
         out = out.reshape(list(t.shape[:-1]) + [nx // 2 + 1])
     for ax in sorted(rest, reverse=True):
         out = _c2c_one(out, ax, False)
