@@ -542,8 +542,22 @@ def run_fourstep_1d(n=65536, nt=3):
         g = xa.power_spectrum(da, dim=["x"], detrend=det)
         r = o.power_spectrum(od64, dim=["x"], detrend=det)
         assert float(np.abs(g.values - r.values).max() / np.abs(r.values).max()) < 2e-5
-    worst = max(worst, check(xa.power_spectrum(da, dim=["x"], window="hann"), o.power_spectrum(od, dim=["x"], window="hann"), 3e-6))
-    assert "four-step]" not in next(reversed(xa.api._plan_cache.values())).describe()  # (a window: the generic four-step passes)
+    # a window of the whole sequence is not separable over the [n1][256] view: it rides on a slab-shaped table, and the transforms
+    # that carry the residual trend back are per column (fasty.h, W2D) -- still the two four-step kernels (round 2: generic passes)
+    for kw in (dict(window="hann"), dict(window="hann", detrend="linear"), dict(window="hamming", detrend="constant", shift=False)):
+        g = xa.power_spectrum(da, dim=["x"], **kw)
+        assert "four-step]" in next(reversed(xa.api._plan_cache.values())).describe(), kw
+        r = o.power_spectrum(od64, dim=["x"], **kw)
+        e = float(np.abs(g.values - r.values).max() / np.abs(r.values).max())
+        binrel, l1 = fine_errors(g.values, r.values)
+        assert e < 2e-5 and l1 < 3e-4 and binrel < BIN_REL, (kw, e, binrel, l1)
+        worst = max(worst, e)
+    for kw in (dict(window="hann", detrend="linear"), dict(window="blackman", true_phase=False, shift=False)):
+        g = xa.fft(da, dim=["x"], **kw)
+        assert "four-step]" in next(reversed(xa.api._plan_cache.values())).describe(), kw
+        r = o.fft(od64, dim=["x"], **kw)
+        e = float(np.abs(g.values - r.values).max() / np.abs(r.values).max())
+        assert e < 2e-5, (kw, e)
     return worst
 
 

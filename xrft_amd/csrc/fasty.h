@@ -106,6 +106,7 @@ struct FastY {
     const cf* tw_y;          // W_ny^k
     const float* win_y;      // never null (ones when there is no window)
     const float* win_x;
+    const float* win2d;      // four-step 1-D with a window: w[n] laid out like the slab, [ny][nx] (else unused)
     double* colfit;          // [slab][nx][4]: per column sum r, sum (i - ibar) r of the residual r = d - line, and the line pass 1 subtracted as (value at ibar, slope)
     const float* corr;       // [slab][nx][2]: wx[x] * (subtracted line - plane fit) as (offset at ibar, slope), from fasty_fit_kernel
     const float* corr_b;     // ... of field 1 (cross spectra)
@@ -231,7 +232,9 @@ template <int N> __device__ __forceinline__ int held_k(int u, int bb, int k3) {
 // A and +2, +3 into transform B (one float4 per row), splits the half spectra and stores them as 16-byte (column pair)
 // pieces: 8 consecutive lanes fill one 128-byte line of W2.          detrend/window: xrft.py:425-433
 // ------------------------------------------------------------------------------------------------
-template <int NY, bool DET>
+// W2D (four-step 1-D with a window): the window of a long sequence is not separable over its [ny][nx] view, so it comes from a
+// table laid out like the slab, read at the samples' own offsets (w[nx i1 + i2]; shared by every slab: L2-resident).
+template <int NY, bool DET, bool W2D = false>
 __global__ void __launch_bounds__(YCols<NY>::THR, YCols<NY>::THR / 128) fasty_cols_kernel(FastY p) {
     typedef P2<NY> G;
     typedef YCols<NY> Y;
@@ -259,7 +262,9 @@ __global__ void __launch_bounds__(YCols<NY>::THR, YCols<NY>::THR / 128) fasty_co
     // uniform 64-bit base + one 32-bit per-lane byte offset (a slab is < 4 GB): scalar-base loads, no 64-bit address per row
     const char* __restrict__ src = reinterpret_cast<const char*>(p.in + (size_t)slab * NY * p.nx + (size_t)xb * Y::CW);
     const unsigned off0 = ((unsigned)u * (unsigned)p.nx + 4u * (unsigned)g) * 4u, rstep = (unsigned)NT * (unsigned)p.nx * 4u;
-    const F4 wx = *reinterpret_cast<const F4*>(p.win_x + x0);
+    F4 wx = {1.f, 1.f, 1.f, 1.f};
+    if (!W2D) wx = *reinterpret_cast<const F4*>(p.win_x + x0);
+    const char* __restrict__ wsrc = reinterpret_cast<const char*>(p.win2d + (size_t)xb * Y::CW);
     // ---- detrend, fused, nothing on the critical path.  The plane of xrft/detrend.py:100-113 needs sums over the whole
     // slab, which exist only after this pass.  What is subtracted HERE, in y-space, only has to take the bulk of the trend
     // out (so that nothing cancels catastrophically in float32) and to be one line T + S i per column: it is an estimate
@@ -333,7 +338,8 @@ __global__ void __launch_bounds__(YCols<NY>::THR, YCols<NY>::THR / 128) fasty_co
 #pragma unroll
     for (int q = 0; q < 16; ++q) {
         const float fi = (float)(u + NT * q);
-        const float wy = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(p.win_y) + (unsigned)(u + NT * q) * 4u);
+        float wy = 1.f;
+        if (!W2D) wy = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(p.win_y) + (unsigned)(u + NT * q) * 4u);
         const float v0 = DET ? fmaf(-S2[0], fi, raw[q].x - fmaf(S[0], fi, T[0])) : raw[q].x;
         const float v1 = DET ? fmaf(-S2[1], fi, raw[q].y - fmaf(S[1], fi, T[1])) : raw[q].y;
         const float v2 = DET ? fmaf(-S2[2], fi, raw[q].z - fmaf(S[2], fi, T[2])) : raw[q].z;
@@ -345,8 +351,15 @@ __global__ void __launch_bounds__(YCols<NY>::THR, YCols<NY>::THR / 128) fasty_co
             f0[2] += v2; f1[2] = fmaf(fq, v2, f1[2]);
             f0[3] += v3; f1[3] = fmaf(fq, v3, f1[3]);
         }
-        a[q] = mk<float>(v0 * (wy * wx.x), v1 * (wy * wx.y));
-        b[q] = mk<float>(v2 * (wy * wx.z), v3 * (wy * wx.w));
+        if (W2D) {
+            if ((q & 3) == 0) asm volatile("" ::: "memory");  // window loads in batches of four rows (all sixteen hoisted: 40 spilled registers at 4096)
+            const F4 ww = *reinterpret_cast<const F4*>(wsrc + (off0 + rstep * (unsigned)q));
+            a[q] = mk<float>(v0 * ww.x, v1 * ww.y);
+            b[q] = mk<float>(v2 * ww.z, v3 * ww.w);
+        } else {
+            a[q] = mk<float>(v0 * (wy * wx.x), v1 * (wy * wx.y));
+            b[q] = mk<float>(v2 * (wy * wx.z), v3 * (wy * wx.w));
+        }
     }
     if (DET) {
         // sum (i - ibar) r over i = u + NT q is (u - ibar) S0 + NT sum q r.  float32 through the wave (the sums are of noise-sized
@@ -466,8 +479,9 @@ __device__ __forceinline__ void xrft_store_nt2(cf* dst, cf v0, cf v1) {
 // W_N^(i2 k1) before its transform and stores TRANSPOSED: the unit's rows k1 are consecutive output samples for a given k2
 // (2 GX * 4 or GX * 8 bytes contiguous); the Hermitian mirror X[N - k] = conj X[k] is the reversed run.  (xrft.dft / fft /
 // power_spectrum along one long axis, BASELINE.json configs[1]: 1-D (1024, 65536) float32.)
-template <int NX, int MODE, bool ISO, bool FS = false>
+template <int NX, int MODE, bool ISO, bool FS = false, bool W2D = false>
 __global__ void __launch_bounds__((YRows<NX, FS>::THR), (YRows<NX, FS>::THR / 128 < 1 ? 1 : YRows<NX, FS>::THR / 128)) fasty_rows_kernel(FastY p) {
+    static_assert(!W2D || FS, "the slab-shaped window belongs to the four-step form");
     static_assert(MODE == 1 || MODE == 2 || !ISO, "radial sums exist for power and cross spectra");
     static_assert(!FS || (MODE <= 1 && !ISO), "the four-step form serves fft and power_spectrum");
     typedef P2<NX> G;
@@ -521,7 +535,21 @@ __global__ void __launch_bounds__((YRows<NX, FS>::THR), (YRows<NX, FS>::THR / 12
             b[q] = *reinterpret_cast<const cf*>(w2t + w2_offset(p, kyB, u + NT * q) * 8u);
         }
     }
-    if (addback) {  // add back wx[x] * (subtracted line - plane fit) in the spectral domain (see fasty_cols_kernel)
+    if (addback && W2D) {
+        // four-step with a window: column x of the [ny][nx] view has its own window w[nx i1 + x], so the transforms of the window
+        // (and of the window times i1 - ibar) that carry the residual line back are tables over (x, k1): [x][k1 < nrow_pad]
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const float al = cr[q].re, ga = cr[q].im;
+            const cf* w0 = p.what0 + (size_t)(u + NT * q) * p.nrow_pad;
+            const cf* w1 = p.what1 + (size_t)(u + NT * q) * p.nrow_pad;
+            const cf a0 = w0[kyA], a1 = w1[kyA], b0 = w0[kyB], b1 = w1[kyB];
+            a[q].re = fmaf(al, a0.re, fmaf(ga, a1.re, a[q].re));
+            a[q].im = fmaf(al, a0.im, fmaf(ga, a1.im, a[q].im));
+            b[q].re = fmaf(al, b0.re, fmaf(ga, b1.re, b[q].re));
+            b[q].im = fmaf(al, b0.im, fmaf(ga, b1.im, b[q].im));
+        }
+    } else if (addback) {  // add back wx[x] * (subtracted line - plane fit) in the spectral domain (see fasty_cols_kernel)
         const cf a0 = p.what0[kyA], a1 = p.what1[kyA], b0 = p.what0[kyB], b1 = p.what1[kyB];
 #pragma unroll
         for (int q = 0; q < 16; ++q) {

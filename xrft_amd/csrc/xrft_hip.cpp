@@ -325,6 +325,9 @@ struct xrfthip_plan {
     bool ytfirst_on = false;       // ... and a radial map's: the radial sums are gathered per bin without atomics (fasty_build_tcodes)
     bool ytcodes_compact = false;  // the bin map has a radial map's structure: 4 bytes per 16 samples (fasty_build_tcodes)
     std::vector<double> host_win_y;
+    std::vector<double> host_win_x;  // (four-step 1-D: the window of the whole sequence)
+    DevBuf win2d;                    // ... as float32, laid out like the slab [yny][ynx]
+    bool fast1d_win = false;         // the four-step plan carries a window: slab-shaped window table, per-column window spectra
     // tuning knobs from the environment, read once when the plan is created (never in xrfthip_exec)
     long long tune_group = 0, tune_fast_group = 0, tune_group_bytes = 512LL << 20, tune_cols_grid = 256, tune_max_grid = 8192;
     long long tune_y = 0;  // XRFTHIP_YTUNE: cache policies / start stagger of the y-first float32 kernels (FastY::tune), fixed at plan creation
@@ -802,11 +805,12 @@ void set_kernel_attrs_once() {
 #undef SETALL
 #undef SETA
 #define SETF(K) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&K), hipFuncAttributeMaxDynamicSharedMemorySize, m)
-#define SETY(NN) SETF((fasty_cols_kernel<NN, false>)); SETF((fasty_cols_kernel<NN, true>)); SETF((fasty_rows_kernel<NN, 1, false>)); SETF((fasty_rows_kernel<NN, 1, true>)); \
+#define SETY(NN) SETF((fasty_cols_kernel<NN, false>)); SETF((fasty_cols_kernel<NN, true>)); SETF((fasty_cols_kernel<NN, false, true>)); SETF((fasty_cols_kernel<NN, true, true>)); SETF((fasty_rows_kernel<NN, 1, false>)); SETF((fasty_rows_kernel<NN, 1, true>)); \
                  SETF((fasty_rows_kernel<NN, 0, false>)); SETF((fasty_rows_kernel<NN, 2, false>)); SETF((fasty_rows_kernel<NN, 2, true>)); SETF((fasty_rows_kernel<NN, 3, false>))
     SETY(4096); SETY(2048); SETY(1024); SETY(512); SETY(256);
 #undef SETY
     SETF((fasty_rows_kernel<256, 0, false, true>)); SETF((fasty_rows_kernel<256, 1, false, true>));
+    SETF((fasty_rows_kernel<256, 0, false, true, true>)); SETF((fasty_rows_kernel<256, 1, false, true, true>));
 #undef SETF
 }
 
@@ -1058,7 +1062,7 @@ static bool phase_nontrivial(const xrfthip_plan* P) {
 // fields with different lags): its radial sums would need the factor per sample inside the column pass
 static bool fast_on(const xrfthip_plan* P) {
     if (P->fastm) return true;
-    if (P->fast1d) return P->win[1].p == nullptr;  // the four-step form has no place for a (non-separable) window
+    if (P->fast1d) return true;  // (a window rides on a slab-shaped table: fasty_window_spectra_1d)
     if (!P->fast4096) return false;
     if (P->d.out_mode == XRFTHIP_OUT_CROSS && (P->d.flags & XRFTHIP_ISO) && phase_nontrivial(P)) return false;
     return true;
@@ -1087,6 +1091,39 @@ static YGeomRt yrows_geom(long long nx, bool fs = false) {  // .rk = rows per wo
 }
 static long long fasty_rows_gx(const xrfthip_plan* P) { return yrows_geom(P->ynx, P->fast1d).gxy; }
 static int ilog2i(int v) { int l = 0; while ((1 << l) < v) ++l; return l; }
+
+// Four-step 1-D with a window w[n], n = nx i1 + i2: the slab-shaped float32 window table pass 1 reads, and -- column i2 of the view has
+// its own window w[nx i1 + i2] -- the per-column transforms FFT_i1(w) and FFT_i1(w (i1 - ibar)) as tables [i2][k1 < nrow_pad] that carry
+// the residual line back in pass 2 (fasty_rows_kernel, W2D).  Host, once per plan: nx transforms of ny points each.
+static int fasty_window_spectra_1d(xrfthip_plan* P) {
+    const int ny = (int)P->yny, nx = (int)P->ynx, nyh = ny / 2, nent = P->y_nrow_pad;
+    const std::vector<double>& w = P->host_win_x;
+    if ((long long)w.size() != (long long)ny * nx) return XRFTHIP_BAD_ARG;
+    std::vector<float> wf(w.size());
+    for (size_t i = 0; i < w.size(); ++i) wf[i] = (float)w[i];
+    int rc = P->win2d.upload(wf.data(), wf.size() * sizeof(float));
+    if (rc) return rc;
+    std::vector<cf> h0((size_t)nx * nent), h1((size_t)nx * nent);
+    std::vector<double> r0((size_t)ny), i0((size_t)ny), r1((size_t)ny), i1((size_t)ny);
+    for (int x = 0; x < nx; ++x) {
+        for (int i = 0; i < ny; ++i) {
+            const double wv = w[(size_t)i * nx + x];
+            r0[(size_t)i] = wv; i0[(size_t)i] = 0.0;
+            r1[(size_t)i] = wv * ((double)i - 0.5 * (ny - 1)); i1[(size_t)i] = 0.0;
+        }
+        host_fft_pow2(r0, i0);
+        host_fft_pow2(r1, i1);
+        for (int k = 0; k < nent; ++k) {
+            cf a, b;
+            a.re = k <= nyh ? (float)r0[(size_t)k] : 0.f; a.im = k <= nyh ? (float)i0[(size_t)k] : 0.f;
+            b.re = k <= nyh ? (float)r1[(size_t)k] : 0.f; b.im = k <= nyh ? (float)i1[(size_t)k] : 0.f;
+            h0[(size_t)x * nent + k] = a; h1[(size_t)x * nent + k] = b;
+        }
+    }
+    rc = P->ywhat0.upload(h0.data(), h0.size() * sizeof(cf));
+    if (!rc) rc = P->ywhat1.upload(h1.data(), h1.size() * sizeof(cf));
+    return rc;
+}
 
 // FFT_y(wy) and FFT_y(wy (i - ibar)) for ky < nrow_pad (zero beyond ny/2): what pass 2 needs to add the residual trend back
 static int fasty_window_spectra(xrfthip_plan* P) {
@@ -1234,8 +1271,14 @@ static void fasty_launch_cols(const xrfthip_plan* P, const FastY& p, long long g
     const dim3 grid((unsigned)(gc * (P->ynx / C.cw))), blk((unsigned)C.thr);
 #define YC_(NN) do { if (d.detrend) { auto k = &fasty_cols_kernel<NN, true>; XRFT_LAUNCH(k, grid, blk, C.lds, st, p); } \
                      else { auto k = &fasty_cols_kernel<NN, false>; XRFT_LAUNCH(k, grid, blk, C.lds, st, p); } } while (0)
-    if (P->yny == 4096) YC_(4096); else if (P->yny == 2048) YC_(2048); else if (P->yny == 1024) YC_(1024); else if (P->yny == 512) YC_(512); else YC_(256);
+#define YCW_(NN) do { if (d.detrend) { auto k = &fasty_cols_kernel<NN, true, true>; XRFT_LAUNCH(k, grid, blk, C.lds, st, p); } \
+                      else { auto k = &fasty_cols_kernel<NN, false, true>; XRFT_LAUNCH(k, grid, blk, C.lds, st, p); } } while (0)
+    if (P->fast1d_win) {  // four-step 1-D with a window: the slab-shaped window table
+        if (P->yny == 4096) YCW_(4096); else if (P->yny == 2048) YCW_(2048); else if (P->yny == 1024) YCW_(1024); else if (P->yny == 512) YCW_(512); else YCW_(256);
+    }
+    else if (P->yny == 4096) YC_(4096); else if (P->yny == 2048) YC_(2048); else if (P->yny == 1024) YC_(1024); else if (P->yny == 512) YC_(512); else YC_(256);
 #undef YC_
+#undef YCW_
     prof_end(rec, st);
     if (d.detrend) {  // plane (2-D) or line through the whole sequence (four-step 1-D) from the per-column sums -> what pass 2 has to add back
         rec = prof ? prof_begin(P, "fasty_fit", st) : nullptr;
@@ -1262,7 +1305,11 @@ static void fasty_launch_rows(const xrfthip_plan* P, const FastY& p, long long g
         else if (d.out_mode == XRFTHIP_OUT_PHASE) { auto k = &fasty_rows_kernel<NN, 3, false>; XRFT_LAUNCH(k, grid, blk, lds, st, p); } \
         else { auto k = &fasty_rows_kernel<NN, 0, false>; XRFT_LAUNCH(k, grid, blk, lds, st, p); } } while (0)
     if (P->fast1d) {  // four-step 1-D: rows of 256 samples, transposed stores
-        if (d.out_mode == XRFTHIP_OUT_POWER) { auto k = &fasty_rows_kernel<256, 1, false, true>; XRFT_LAUNCH(k, grid, blk, lds, st, p); }
+        if (P->fast1d_win) {
+            if (d.out_mode == XRFTHIP_OUT_POWER) { auto k = &fasty_rows_kernel<256, 1, false, true, true>; XRFT_LAUNCH(k, grid, blk, lds, st, p); }
+            else { auto k = &fasty_rows_kernel<256, 0, false, true, true>; XRFT_LAUNCH(k, grid, blk, lds, st, p); }
+        }
+        else if (d.out_mode == XRFTHIP_OUT_POWER) { auto k = &fasty_rows_kernel<256, 1, false, true>; XRFT_LAUNCH(k, grid, blk, lds, st, p); }
         else { auto k = &fasty_rows_kernel<256, 0, false, true>; XRFT_LAUNCH(k, grid, blk, lds, st, p); }
     }
     else if (P->ynx == 4096) YR_(4096); else if (P->ynx == 2048) YR_(2048); else if (P->ynx == 1024) YR_(1024); else if (P->ynx == 512) YR_(512); else YR_(256);
@@ -1319,7 +1366,8 @@ static FastY fasty_params(const xrfthip_plan* P, const float* in, void* out, dou
     p.nslab = (int)gc;
     p.shift_y = (d.flags & XRFTHIP_SHIFT_Y) ? (int)(P->yny / 2) : 0;
     p.shift_x = (d.flags & XRFTHIP_SHIFT_X) ? (int)(P->ynx / 2) : 0;  // (four-step 1-D: the shift by N/2 samples is k2 + nx/2)
-    if (P->fast1d) p.win_y = p.win_x = reinterpret_cast<const float*>(P->ones4096.p);  // (no window on this path)
+    if (P->fast1d) p.win_y = p.win_x = reinterpret_cast<const float*>(P->ones4096.p);  // (a window of the whole sequence: win2d)
+    p.win2d = reinterpret_cast<const float*>(P->fast1d_win ? P->win2d.p : nullptr);
     p.scale = (float)d.scale;
     p.tune = (int)P->tune_y;
     return p;
@@ -1646,7 +1694,8 @@ static int finalize_plan(xrfthip_plan* P) {
         if (!rc && P->d.out_mode != XRFTHIP_OUT_POWER) rc = fast_phase_tables(P);
         if (rc) return rc;
     } else if (P->fast1d) {
-        int rc = fasty_window_spectra(P);
+        P->fast1d_win = !P->host_win_x.empty();
+        int rc = P->fast1d_win ? fasty_window_spectra_1d(P) : fasty_window_spectra(P);
         if (!rc && P->d.out_mode != XRFTHIP_OUT_POWER) rc = fast_phase_tables(P);
         if (rc) return rc;
     } else if (P->fast4096) {
@@ -1984,6 +2033,7 @@ int xrfthip_plan_set_window(xrfthip_plan* plan, int axis, const double* h_window
     if (h_window && n != (axis == 0 ? plan->d.ny : plan->d.nx)) return XRFTHIP_BAD_ARG;
     if (plan->inner > 1) return xrfthip_plan_set_window(axis == 0 ? plan->sub_y : plan->sub_x, 0, h_window, n);  // (each one-axis plan transforms its "y")
     if (axis == 0) plan->host_win_y.assign(h_window ? h_window : nullptr, h_window ? h_window + n : nullptr);
+    else plan->host_win_x.assign(h_window ? h_window : nullptr, h_window ? h_window + n : nullptr);
     int rc = upload_real_table(plan, plan->win[axis], h_window, n, 0);
     if (!rc) rc = finalize_plan(plan);
     return rc;
