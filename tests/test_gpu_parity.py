@@ -327,12 +327,12 @@ def test_config2_full_size_1024x65536():
     assert torch.equal(xa.dft(da, dim="x").data, got.data)
 
 
-def test_config4_full_size_16x2048x2048():
-    """C4 on one GPU's share (16 of 512 slabs per rank at 8 GPUs... here 16): cross_spectrum + isotropic spectra of two
-    (16, 2048, 2048) float32 fields -- oracle on 2 slabs, Hermitian symmetry and radial sum conservation on all."""
+def test_config4_full_size_64x2048x2048():
+    """C4 on one GPU's share (nt = 512 over 8 GPUs = 64 slab pairs per rank): cross_spectrum + isotropic spectra of two
+    (64, 2048, 2048) float32 fields -- oracle on 2 slabs, Hermitian symmetry and radial sum conservation on all 64."""
     import xrft_amd as xa
 
-    nt, n = 16, 2048
+    nt, n = 64, 2048
     g = torch.Generator(device="cuda").manual_seed(204)
     a = torch.randn((nt, n, n), dtype=torch.float32, device="cuda", generator=g)
     b = 0.5 * a + torch.randn((nt, n, n), dtype=torch.float32, device="cuda", generator=g)
