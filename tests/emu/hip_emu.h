@@ -195,6 +195,15 @@ inline double __shfl_xor(double v, int mask) {
     emu::barrier();
     return r;
 }
+inline double __shfl_down(double v, unsigned delta, int width = 64) {
+    emu::BlockCtx* b = emu::tls();
+    const unsigned t = b->cur->tid.x;
+    b->shfl[t] = v;
+    emu::barrier();
+    const double r = ((t % (unsigned)width) + delta < (unsigned)width) ? b->shfl[t + delta] : v;
+    emu::barrier();
+    return r;
+}
 inline long long __double_as_longlong(double d) { long long v; memcpy(&v, &d, 8); return v; }
 inline float __uint_as_float(unsigned v) { float f; memcpy(&f, &v, 4); return f; }
 struct alignas(16) uint4 { unsigned x, y, z, w; };
