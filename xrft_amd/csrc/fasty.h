@@ -729,8 +729,9 @@ __global__ void __launch_bounds__((YRows<NX, FS>::THR), (YRows<NX, FS>::THR / 12
             __syncthreads();
             double* __restrict__ part = p.iso_part + ((size_t)slab * upr + unit) * p.nbins * HW;
             // task = (bin, row): NRW adjacent lanes share a bin, one row each, and their sums meet in lane order by shuffles (a bin
-            // per thread left the one thread whose bin hugs |k| = ky -- ranges of up to 300 samples in every row -- working alone:
-            // 23.1 -> us per 4096^2 slab)
+            // per thread leaves the one thread whose bin hugs |k| = ky -- ranges of up to 300 samples in every row -- working
+            // alone; measured, the two forms run alike: 23.1 / 24.1 us per 4096^2 slab, the tail is not what is left above the
+            // 17.4 us of the row pass without radial sums)
             static_assert((NRW & (NRW - 1)) == 0 && NRW <= 64 && THR % NRW == 0, "rows per workgroup");
             const int row = tid % NRW, ky = ky0 + row;
             const bool live = ky <= nyh, twin = ky != 0 && ky != nyh;
