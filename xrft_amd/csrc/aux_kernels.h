@@ -515,11 +515,21 @@ __global__ void __launch_bounds__(256) radial_binsum_det_kernel(const void* in, 
 
 // iso[slab][bin] = sum over the partial tables of the slab's units in a FIXED order (bit-reproducible): 256 threads = 4 segments
 // of units x 64 bins; every segment adds its units in order, the four segment sums are combined in order
-__global__ void __launch_bounds__(256) iso_reduce_kernel(const double* __restrict__ part, double* __restrict__ iso, int upr, int nb) {
+__global__ void __launch_bounds__(256) iso_reduce_kernel(const double* __restrict__ part, double* __restrict__ iso, int upr, int nb,
+                                                         const unsigned* __restrict__ tunits, int hw) {
     XRFT_DYN_SMEM(smem_raw);
     double (*seg)[64] = reinterpret_cast<double (*)[64]>(smem_raw);  // [4][64]
     const int lane = threadIdx.x & 63, sg = threadIdx.x >> 6, i = blockIdx.x * 64 + lane, slab = blockIdx.y;
-    const int per = (upr + 3) / 4, u0 = sg * per, u1 = min(upr, u0 + per);
+    // tunits (may be null): only the units tunits[bin] & 0xffff .. (tunits[bin] >> 16) - 1 wrote this bin (the gather of
+    // fasty_rows_kernel leaves out the bins a unit's rows do not reach)
+    int ulo = 0, uhi = upr;
+    if (tunits && i < nb) { const unsigned w = tunits[i / hw]; ulo = (int)(w & 0xffffu); uhi = (int)(w >> 16); }
+    // the 64 bins of a wave walk ONE range of units -- the union of theirs (neighbouring bins' ranges nearly coincide) -- so that a
+    // load is 64 adjacent doubles of one unit's table; a lane skips the units outside its own range (nothing was written there)
+    int wlo = (tunits && i >= nb) ? upr : ulo, whi = (tunits && i >= nb) ? 0 : uhi;
+#pragma unroll
+    for (int m = 1; m < 64; m <<= 1) { wlo = min(wlo, (int)__shfl_xor((double)wlo, m)); whi = max(whi, (int)__shfl_xor((double)whi, m)); }
+    const int per = (max(whi - wlo, 0) + 3) / 4, u0 = wlo + sg * per, u1 = min(whi, u0 + per);
     double s = 0.0;
     if (i < nb) {
         const double* src = part + (size_t)slab * upr * nb + i;
@@ -527,11 +537,11 @@ __global__ void __launch_bounds__(256) iso_reduce_kernel(const double* __restric
         for (; un + 8 <= u1; un += 8) {  // eight loads in flight, added in unit order (one at a time the kernel was latency-bound: 2 us per 4096^2 slab)
             double v[8];
 #pragma unroll
-            for (int k = 0; k < 8; ++k) v[k] = src[(size_t)(un + k) * nb];
+            for (int k = 0; k < 8; ++k) v[k] = (un + k >= ulo && un + k < uhi) ? src[(size_t)(un + k) * nb] : 0.0;
 #pragma unroll
             for (int k = 0; k < 8; ++k) s += v[k];
         }
-        for (; un < u1; ++un) s += src[(size_t)un * nb];
+        for (; un < u1; ++un) s += (un >= ulo && un < uhi) ? src[(size_t)un * nb] : 0.0;
     }
     seg[sg][lane] = s;
     __syncthreads();

@@ -121,6 +121,7 @@ struct FastY {
     const unsigned* tcodes;  // radial bins [ky < nrow_pad][kx] in natural order: (direct + 1) | (mirror + 1) << 16 (0: not binned);
                              // tcodes_compact: [ky][kx / 16]: (first sample's bin + 1) | step mask << 16 (see fasty_rows_kernel)
     int tcodes_compact;
+    const unsigned* twin;          // radial map: [unit] first bin | (last bin + 1) << 16 of the unit's rows: bins outside it are neither gathered, written nor reduced
     const unsigned short* tfirst;  // radial map: [ky < nrow_pad][nbins + 1], the smallest |kx| of a row whose bin is >= b (null: any map, the atomic tables)
     double* iso;             // [slab][nbins] per-bin sums (ISO)
     double* iso_part;        // [slab][row workgroup][nbins (x2 complex)]: per-workgroup partial sums, reduced in order
@@ -714,16 +715,29 @@ __global__ void __launch_bounds__((YRows<NX, FS>::THR), (YRows<NX, FS>::THR / 12
                 if (ky > nyh) continue;
                 const unsigned mask = p.tcodes[(size_t)ky * SPR + s16] >> 16;  // bit i: the bin changes between samples i - 1 and i
                 float* q = stg + row * RSI + CPS * (17 * s16);                  // nat16(16 s16) = 17 s16: the segment is contiguous
+                // all 16 samples first, the running sums in registers, every position written back (only the run ends are read again):
+                // no branch and ONE trip to the LDS -- a read, a conditional write and a wait per sample was a chain of 16 LDS latencies
+                // per segment, 128 per thread, most of what the radial sums added to the row pass
+                float vr[16], vi[MODE == 2 ? 16 : 1];
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    vr[i] = q[CPS * i];
+                    if (MODE == 2) vi[MODE == 2 ? i : 0] = q[2 * i + 1];
+                }
                 float sr = 0.f, si = 0.f;
 #pragma unroll
                 for (int i = 0; i < 16; ++i) {
-                    sr += q[CPS * i];
-                    if (MODE == 2) si += q[2 * i + 1];
-                    if (i == 15 || ((mask >> (i + 1)) & 1u)) {
-                        q[CPS * i] = sr;
-                        if (MODE == 2) q[2 * i + 1] = si;
-                        sr = 0.f; si = 0.f;
-                    }
+                    sr += vr[i];
+                    vr[i] = sr;
+                    if (MODE == 2) { si += vi[MODE == 2 ? i : 0]; vi[MODE == 2 ? i : 0] = si; }
+                    const bool end = ((mask >> (i + 1)) & 1u) != 0u;
+                    sr = end ? 0.f : sr;
+                    si = end ? 0.f : si;
+                }
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    q[CPS * i] = vr[i];
+                    if (MODE == 2) q[2 * i + 1] = vi[MODE == 2 ? i : 0];
                 }
             }
             __syncthreads();
@@ -736,12 +750,24 @@ __global__ void __launch_bounds__((YRows<NX, FS>::THR), (YRows<NX, FS>::THR / 12
             const int row = tid % NRW, ky = ky0 + row;
             const bool live = ky <= nyh, twin = ky != 0 && ky != nyh;
             const float* rowp = stg + row * RSI;
-            for (int b0 = 0; b0 < p.nbins; b0 += THR / NRW) {
+            // only the bins the unit's rows reach, |k| = ky0 dky .. |(ky0 + NRW - 1, nx/2)| (p.twin, from the map itself): 46 % of them
+            // on average -- the range table and the partial sums of all bins for every 4 rows of a 4096^2 slab were 25 MB of traffic
+            // beside the 67 MB of the rows
+            const unsigned bw = p.twin[unit];
+            const int blo = (int)(bw & 0xffffu), bhi = (int)(bw >> 16);
+            auto range_of = [&](int bn_) -> unsigned {
+                if (!(live && bn_ < bhi)) return 0u;
+                const unsigned short* __restrict__ fr = p.tfirst + (size_t)ky * (p.nbins + 1) + bn_;
+                return (unsigned)fr[0] | ((unsigned)fr[1] << 16);
+            };
+            unsigned nxt = range_of(blo + tid / NRW);
+            for (int b0 = blo; b0 < bhi; b0 += THR / NRW) {
                 const int bn = b0 + tid / NRW;
                 double sre = 0.0, sim = 0.0;
-                if (live && bn < p.nbins) {
-                    const unsigned short* __restrict__ fr = p.tfirst + (size_t)ky * (p.nbins + 1) + bn;
-                    const int s = fr[0], e = fr[1];  // the bin holds |kx| = s .. e - 1 of this row
+                const unsigned cur = nxt;
+                nxt = range_of(bn + THR / NRW);  // (the next bin's range is in flight behind this bin's sums: one L2 round trip per bin otherwise)
+                if (live && bn < bhi) {
+                    const int s = (int)(cur & 0xffffu), e = (int)(cur >> 16);  // the bin holds |kx| = s .. e - 1 of this row
                     auto take = [&](int pp) {
                         const float* v = rowp + CPS * nat16(pp);
                         if (MODE == 1) sre += (double)v[0];
@@ -761,7 +787,7 @@ __global__ void __launch_bounds__((YRows<NX, FS>::THR), (YRows<NX, FS>::THR / 12
                     sre += __shfl_down(sre, m, NRW);
                     if (MODE == 2) sim += __shfl_down(sim, m, NRW);
                 }
-                if (row == 0 && bn < p.nbins) {
+                if (row == 0 && bn < bhi) {
                     part[bn * HW] = sre;
                     if (MODE == 2) part[2 * bn + 1] = sim;
                 }

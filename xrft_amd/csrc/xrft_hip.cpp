@@ -321,7 +321,7 @@ struct xrfthip_plan {
     DevBuf tw_big1d;
     int y_nrow_pad = 0;  // rows ky = 0..ny/2 of the intermediate, rounded up to what one row workgroup covers
     DevBuf ywhat0, ywhat1, ytcodes;
-    DevBuf ytfirst;
+    DevBuf ytfirst, ytwin, ytunits;  // (ytwin: the bins each unit of rows reaches; ytunits: the units that reach each bin)
     bool ytfirst_on = false;       // ... and a radial map's: the radial sums are gathered per bin without atomics (fasty_build_tcodes)
     bool ytcodes_compact = false;  // the bin map has a radial map's structure: 4 bytes per 16 samples (fasty_build_tcodes)
     std::vector<double> host_win_y;
@@ -911,7 +911,7 @@ static int run_radial_sums(int32_t dtype, const void* spec, const int32_t* d_bin
         }
         auto kr = &iso_reduce_kernel;
         XRFT_LAUNCH(kr, dim3((unsigned)((nbins * hw + 63) / 64), (unsigned)sc), dim3(256), 4 * 64 * sizeof(double), st, (const double*)pdst,
-                    iso + (size_t)s0 * nbins * hw, chunks, nbins * hw);
+                    iso + (size_t)s0 * nbins * hw, chunks, nbins * hw, (const unsigned*)nullptr, hw);
     }
     HIP_TRY(hipGetLastError());
     return XRFTHIP_OK;
@@ -1215,7 +1215,41 @@ static int fasty_build_tcodes(xrfthip_plan* P, const int32_t* bm) {
                 dst[b] = (uint16_t)m;
             }
         }
-        const int rcf = P->ytfirst.upload(f.data(), f.size() * sizeof(uint16_t));
+        int rcf = P->ytfirst.upload(f.data(), f.size() * sizeof(uint16_t));
+        if (rcf) return rcf;
+        // the bins a unit of rows (one workgroup of pass 2) reaches: along a half row the bin never decreases, so row ky holds the
+        // bins r[0] .. r[nx/2]; the unit gathers, writes and has reduced the union over its rows only
+        const bool two = P->d.out_mode == XRFTHIP_OUT_CROSS;
+        const YGeomRt R = yrows_geom(P->ynx, false);
+        const int rpu = two ? R.gxy : R.rk, units = P->y_nrow_pad / rpu;  // (as fasty_launch_rows)
+        std::vector<uint32_t> w((size_t)units);
+        for (int un = 0; un < units; ++un) {
+            int lo = P->nbins, hi = 0;
+            for (int ky = un * rpu; ky < (un + 1) * rpu && ky <= nyh; ++ky) {
+                lo = std::min<int>(lo, bm[(size_t)ky * nx]);
+                hi = std::max<int>(hi, bm[(size_t)ky * nx + nx / 2] + 1);
+            }
+            if (lo > hi) lo = hi = 0;  // (a unit of padding rows only)
+            w[(size_t)un] = (uint32_t)lo | (uint32_t)hi << 16;
+        }
+        // ... and the units that reach a bin: a contiguous range when the windows move monotonically with ky (a radial map's do;
+        // otherwise every unit keeps all bins)
+        bool mono = units < 65535;
+        for (int un = 1; un < units && mono; ++un) {
+            if ((w[(size_t)un] >> 16) == 0) continue;  // (padding rows only)
+            mono = (w[(size_t)un] & 0xffffu) >= (w[(size_t)un - 1] & 0xffffu) && (w[(size_t)un] >> 16) >= (w[(size_t)un - 1] >> 16);
+        }
+        if (!mono) std::fill(w.begin(), w.end(), (uint32_t)P->nbins << 16);
+        std::vector<uint32_t> tu((size_t)P->nbins, 0u);
+        for (int b = 0; b < P->nbins; ++b) {
+            int ulo = units, uhi = 0;
+            for (int un = 0; un < units; ++un)
+                if ((int)(w[(size_t)un] & 0xffffu) <= b && b < (int)(w[(size_t)un] >> 16)) { ulo = std::min(ulo, un); uhi = std::max(uhi, un + 1); }
+            if (ulo > uhi) ulo = uhi = 0;
+            tu[(size_t)b] = (uint32_t)ulo | (uint32_t)uhi << 16;
+        }
+        rcf = P->ytwin.upload(w.data(), w.size() * sizeof(uint32_t));
+        if (!rcf) rcf = P->ytunits.upload(tu.data(), tu.size() * sizeof(uint32_t));
         if (rcf) return rcf;
         // the step masks of the 16-sample segments (any step size: the gather needs the run ends only)
         std::vector<uint32_t> t((size_t)P->y_nrow_pad * (nx / 16), 0u);
@@ -1319,7 +1353,7 @@ static void fasty_launch_rows(const xrfthip_plan* P, const FastY& p, long long g
         rec = prof ? prof_begin(P, "fasty_iso_reduce", st) : nullptr;
         const int nb = P->nbins * hw, upr = P->y_nrow_pad / rpu;
         auto kr = &iso_reduce_kernel;
-        XRFT_LAUNCH(kr, dim3((unsigned)((nb + 63) / 64), (unsigned)gc), dim3(256), 4 * 64 * sizeof(double), st, (const double*)p.iso_part, p.iso, upr, nb);
+        XRFT_LAUNCH(kr, dim3((unsigned)((nb + 63) / 64), (unsigned)gc), dim3(256), 4 * 64 * sizeof(double), st, (const double*)p.iso_part, p.iso, upr, nb, P->ytfirst_on ? reinterpret_cast<const unsigned*>(P->ytunits.p) : nullptr, hw);
         prof_end(rec, st);
     }
 }
@@ -1356,6 +1390,7 @@ static FastY fasty_params(const xrfthip_plan* P, const float* in, void* out, dou
     p.tcodes = reinterpret_cast<const unsigned*>(P->ytcodes.p);
     p.tcodes_compact = P->ytcodes_compact ? 1 : 0;
     p.tfirst = P->ytfirst_on ? reinterpret_cast<const unsigned short*>(P->ytfirst.p) : nullptr;
+    p.twin = P->ytfirst_on ? reinterpret_cast<const unsigned*>(P->ytwin.p) : nullptr;
     p.iso = iso_on ? iso + (size_t)g0 * P->nbins * (d.out_mode == XRFTHIP_OUT_CROSS ? 2 : 1) : nullptr;
     p.nbins = P->nbins;
     p.iso_part = reinterpret_cast<double*>(ws + P->off_isopart);
@@ -1564,7 +1599,7 @@ static int run_fastm(const xrfthip_plan* P, const void* in, const void* in1, voi
             xrfthip_plan::ProfRec* rec = prof_begin(P, "iso_reduce", st);
             auto kr = &iso_reduce_kernel;
             XRFT_LAUNCH(kr, dim3((unsigned)((nb + 63) / 64), (unsigned)gc), dim3(256), 4 * 64 * sizeof(double), st, (const double*)p.iso_part,
-                        iso + (size_t)g0 * nb, upr, nb);
+                        iso + (size_t)g0 * nb, upr, nb, (const unsigned*)nullptr, hw);
             prof_end(rec, st);
             HIP_TRY(hipGetLastError());
         } else if (iso_on) {  // radial sums of the stored spectrum (xrft.py:895-906), bit-reproducible
