@@ -81,6 +81,10 @@ add("   power_spectrum along a 4096-point middle axis (16,4096,2048) f32", x.num
 x = cube((131072, 1024), torch.float32); da = xrft.DataArray(x, ("t", "x"), {"x": np.arange(1024.)})
 add("power_spectrum 1-D (131072,1024) f32 linear+hann", x.numel(), 8, timeit(lambda: xrft.power_spectrum(da, dim=["x"], detrend="linear", window="hann")))
 add("   fft 1-D (131072,1024) f32", x.numel(), 12, timeit(lambda: xrft.fft(da, dim=["x"])))
+del x, da
+x = cube((32768, 4096), torch.float32); da = xrft.DataArray(x, ("t", "x"), {"x": np.arange(4096.)})
+add("   power_spectrum 1-D (32768,4096) f32 linear+hann (round 2: 89-92, generic passes)", x.numel(), 8, timeit(lambda: xrft.power_spectrum(da, dim=["x"], detrend="linear", window="hann")))
+add("   fft 1-D (32768,4096) f32", x.numel(), 12, timeit(lambda: xrft.fft(da, dim=["x"])))
 x = cube((64, 1000, 1000), torch.float32); da = xrft.DataArray(x, ("t", "y", "x"), {"y": np.arange(1000.), "x": np.arange(1000.)})
 add("PS (64,1000,1000) f32 linear+hann", x.numel(), 8, timeit(lambda: xrft.power_spectrum(da, dim=["y", "x"], detrend="linear", window="hann")))
 # lengths that joined the mixed-radix table in round 3 (the generic tile kernels before: (64,2000,2000) f32 95, (16,3000,3000) f64 34 GFFT/s)

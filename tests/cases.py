@@ -1054,6 +1054,56 @@ def run_fused_radial_code_forms(n=256):
     os.environ.pop("XRFTHIP_ISO_GATHER", None)
 
 
+def run_fastm_radial_code_forms(ny=360, nx=240, dtype="float64"):
+    """The fused radial sums of the mixed-radix kernels (csrc/fastm.h): a radial bin map is gathered per bin from the spectra in LDS with no
+    atomics, any other map (and a radial one with XRFTHIP_ISO_GATHER=0) goes through the int64 fixed-point tables.  Both against
+    numpy.bincount of the stored spectrum through the C ABI's plan, power and cross spectra, repeats bit for bit; a NaN poisons its own slab only."""
+    import os
+
+    import torch
+
+    from xrft_amd import _lib, engine
+
+    rng = np.random.default_rng(137)
+    dev = xa.api._to_device(np.zeros(1, dtype=np.float32)).device
+    tdt = torch.float64 if dtype == "float64" else torch.float32
+    nt, nb = 3, min(ny, nx) // 4
+    v = rng.standard_normal((nt, ny, nx)).astype(dtype)
+    t = torch.from_numpy(v).to(dev)
+    kr = np.sqrt((np.fft.fftfreq(ny) * 1.3)[:, None] ** 2 + np.fft.fftfreq(nx)[None, :] ** 2)
+    radial = np.minimum((kr / kr.max() * nb).astype(np.int32), nb - 1)
+    anymap = rng.integers(-1, nb, size=(ny, nx)).astype(np.int32)
+    tol = 1e-12 if dtype == "float64" else 2e-6
+    try:
+        for name, bm, want, gather in (("radial", radial, "per-bin gather", "1"), ("radial", radial, "fixed-point tables", "0"), ("random", anymap, "fixed-point tables", "1")):
+            os.environ["XRFTHIP_ISO_GATHER"] = gather  # (read when the bin map is set)
+            for mode in (_lib.OUT_POWER, _lib.OUT_CROSS):
+                plan = engine.SpectralPlan(2, nt, ny, nx, tdt, out_mode=mode, flags=_lib.ISO, scale=1.0, binmap=bm, nbins=nb)
+                assert "[fastm radial sums]" in plan.describe() and want in plan.describe(), (name, plan.describe())
+                t2 = torch.from_numpy(np.roll(v, 3, axis=2).copy()).to(dev) if mode == _lib.OUT_CROSS else None
+                out, iso = plan.execute(t, t2)
+                out2, iso2 = plan.execute(t, t2)
+                assert torch.equal(iso, iso2)
+                spec = out.cpu().numpy().astype(np.complex128 if mode == _lib.OUT_CROSS else np.float64)
+                ok = bm.ravel() >= 0
+                for b in range(nt):
+                    w = spec[b].ravel()[ok]
+                    ref = np.bincount(bm.ravel()[ok], weights=w.real, minlength=nb).astype(np.complex128)
+                    if mode == _lib.OUT_CROSS:
+                        ref = ref + 1j * np.bincount(bm.ravel()[ok], weights=w.imag, minlength=nb)
+                    mag = np.bincount(bm.ravel()[ok], weights=np.abs(w), minlength=nb)
+                    got = iso.cpu().numpy()[b]
+                    assert np.all(np.abs(got - (ref if mode == _lib.OUT_CROSS else ref.real)) <= tol * np.maximum(mag, 1e-300)), (name, mode, b)
+            vn = v.copy(); vn[1, 5, 7] = np.nan
+            plan = engine.SpectralPlan(2, nt, ny, nx, tdt, out_mode=_lib.OUT_POWER, flags=_lib.ISO | _lib.NO_SPECTRUM_OUT, scale=1.0, binmap=bm, nbins=nb)
+            _, iso = plan.execute(torch.from_numpy(vn).to(dev))
+            g = iso.cpu().numpy()
+            used = np.bincount(bm.ravel()[bm.ravel() >= 0], minlength=nb) > 0
+            assert np.all(np.isnan(g[1][used])) and np.all(np.isfinite(g[0])) and np.all(np.isfinite(g[2])), name
+    finally:
+        os.environ.pop("XRFTHIP_ISO_GATHER", None)
+
+
 def run_nan_in_isotropic_spectra():
     """A NaN sample poisons its own slab's isotropic spectrum and nothing else, on every path that takes radial sums (the
     reference sums in floating point, xrft.py:895-906; ADVICE r2: fixed-point tables gave +inf or 0): fasty.h (256^2 float32),

@@ -472,6 +472,11 @@ def test_fused_radial_sums_compact_and_full_bin_codes():
     cases.run_fused_radial_code_forms(256)
 
 
+@pytest.mark.parametrize("ny,nx,dtype", [(360, 240, "float64"), (240, 480, "float32")])
+def test_fastm_radial_sums_gather_and_tables(ny, nx, dtype):
+    cases.run_fastm_radial_code_forms(ny, nx, dtype)
+
+
 def test_nan_poisons_its_own_slab_only():
     cases.run_nan_in_isotropic_spectra()
 

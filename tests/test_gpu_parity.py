@@ -427,6 +427,39 @@ def test_full_size_properties_4096():
     assert float(num / fs.abs().max()) < 1e-5
 
 
+def test_batch_beyond_2p32_elements():
+    """(264, 4096, 4096) float32 = 4.43e9 samples (17.7 GB in, 17.7 GB out) in ONE call: element offsets beyond 2^32 in the input, the
+    output and the radial-sum tables.  The batch repeats 8 distinct slabs, so every slab's spectrum must equal, bit for bit, the
+    spectrum of its first copy -- which test_config3 / test_full_size_properties hold against the oracle."""
+    import xrft_amd as xa
+
+    free, _total = torch.cuda.mem_get_info()
+    if free < 60 * 2 ** 30:
+        pytest.skip("needs 60 GB of free device memory")
+    nt, ny, nx, rep = 264, 4096, 4096, 8
+    g = torch.Generator(device="cuda").manual_seed(21)
+    base = torch.randn((rep, ny, nx), dtype=torch.float32, device="cuda", generator=g)
+    base += (0.01 * torch.arange(ny, device="cuda"))[None, :, None] + 3.0
+    x = base.repeat(nt // rep, 1, 1)
+    assert x.numel() > 2 ** 32 and x.is_contiguous()
+    c = {"time": np.arange(nt), "y": np.arange(ny, dtype=np.float64), "x": np.arange(nx, dtype=np.float64)}
+    da = xa.DataArray(x, ("time", "y", "x"), c)
+    ps = xa.power_spectrum(da, dim=["y", "x"], detrend="linear", window="hann")
+    assert ps.data.shape == (nt, ny, nx)
+    first = ps.data[:rep]
+    small = xa.power_spectrum(xa.DataArray(base, ("time", "y", "x"), dict(c, time=np.arange(rep))), dim=["y", "x"], detrend="linear", window="hann")
+    assert torch.equal(first, small.data)
+    for k in range(rep, nt, rep):
+        assert torch.equal(ps.data[k:k + rep], first), k
+    del ps, small
+    torch.cuda.empty_cache()
+    iso = xa.isotropic_power_spectrum(da, dim=["y", "x"], detrend="linear", window="hann")
+    v = iso.data if isinstance(iso.data, torch.Tensor) else torch.from_numpy(np.asarray(iso.values))
+    assert torch.isfinite(v).all()
+    for k in range(rep, nt, rep):
+        assert torch.equal(v[k:k + rep], v[:rep]), k
+
+
 def test_isotropic_slope_minus3():
     """test_xrft.py:995-1031: isotropic PS of a synthetic red-noise field has slope -3 (N = 512)."""
     import xrft_amd as xa
@@ -909,6 +942,11 @@ def test_two_axes_with_the_batch_innermost_without_copies(dtype):
 def test_fused_radial_sums_compact_and_full_bin_codes():
     cases.run_fused_radial_code_forms(256)
     cases.run_fused_radial_code_forms(2048)
+
+
+@pytest.mark.parametrize("ny,nx,dtype", [(360, 240, "float64"), (240, 480, "float32")])
+def test_fastm_radial_sums_gather_and_tables(ny, nx, dtype):
+    cases.run_fastm_radial_code_forms(ny, nx, dtype)
 
 
 def test_nan_poisons_its_own_slab_only():

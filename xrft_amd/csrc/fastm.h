@@ -135,6 +135,8 @@ struct FastM {
     const void* what1;   // FFT_y(wy (i - ibar))[ky]
     const int* binmap;   // radial sums fused into pass 2 (ISO): bin of (ky, kx), unshifted indices, [ny][nx]; < 0 = none
     double* iso_part;    // [slab][row workgroup][nbins (x2 complex)]: per-workgroup sums, reduced in order by iso_reduce_kernel
+    const unsigned short* tfirst;  // radial bin map: [ky <= ny/2][nbins + 1], the smallest |kx| <= nx/2 of a row whose bin is >= b (null: any map, the atomic tables)
+    const unsigned* twin;          // ... [unit of rows] first bin | (last bin + 1) << 16 its rows reach
     int nbins, iso_ncopy;
     int cin;             // one-axis kernels: the input is COMPLEX (one sequence per column / row, no packing): the later stages of N-D transforms
     int angle;           // one-axis two-field kernels: store the cross PHASE (float) instead of the cross spectrum (xrft.py:838-874)
@@ -642,7 +644,9 @@ __global__ void __launch_bounds__((MGeom<T, N>::THR), (MGeom<T, N>::WPS)) fastm_
 // ------------------------------------------------------------------------------------------------
 //   xrft.py:895-906 (ISO: radial sums, here bit-reproducible: per-bin exponent bound by atomicMax, int64 fixed-point adds; aux_kernels.h)
 // (two fields, or radial sums -- whose tables and partial-sum rows are per workgroup --: pass 1's count)
-template <typename T, int NX, int MODE, bool ISO> struct MRowsG { static constexpr int G = (MODE >= 2 || ISO) ? MGeom<T, NX>::G : MGeom<T, NX>::GR1; };
+// (round 3: the kernels with the radial sums fused take the small one-field workgroup too -- a radial map's sums are gathered without tables,
+// nothing is amortised over the rows of a workgroup any more)
+template <typename T, int NX, int MODE, bool ISO> struct MRowsG { static constexpr int G = MODE >= 2 ? MGeom<T, NX>::G : MGeom<T, NX>::GR1; };
 
 template <typename T, int NX, int MODE, bool ISO = false>
 __global__ void __launch_bounds__((MGeom<T, NX>::template Rows<MRowsG<T, NX, MODE, ISO>::G>::THR), (MGeom<T, NX>::template Rows<MRowsG<T, NX, MODE, ISO>::G>::WPS)) fastm_rows_kernel(FastM p) {
@@ -705,6 +709,39 @@ __global__ void __launch_bounds__((MGeom<T, NX>::template Rows<MRowsG<T, NX, MOD
         // sweeps (largest exponent per bin, then integer fixed-point adds: exact, so the order in which lanes arrive does not
         // matter), the sums go to this workgroup's row of the partial table.  The tables sit behind the twiddle table.
         constexpr int HW = MODE == 2 ? 2 : 1, NIT = (RPU * NX + THR - 1) / THR;
+        if (p.tfirst != nullptr) {
+            // A RADIAL bin map (verified on the host, fastm_build_tfirst: along a row the bin depends on |kx| only and never decreases
+            // with it, every sample is binned, the Hermitian twin of a sample shares its bin) needs no atomics and no tables: the
+            // bins of a row are contiguous ranges of kx on either side of kx = 0.  A thread owns a bin and adds its samples of the
+            // unit's rows in float64 in a fixed order (rows in order, kx = |kx| ascending then kx = nx - |kx|): bit-reproducible,
+            // inf / nan propagate as in any sum.  Only the bins the unit's rows reach are visited (p.twin), written and reduced.
+            const unsigned bw = p.twin[unit];
+            const int blo = (int)(bw & 0xffffu), bhi = (int)(bw >> 16);
+            constexpr int H = NX / 2, HM = (NX - 1) / 2;  // |kx| = 0 .. H; kx = nx - |kx| exists for |kx| = 1 .. HM
+            double* __restrict__ part = p.iso_part + ((size_t)slab * upr + unit) * p.nbins * HW;
+            for (int bn = blo + tid; bn < bhi; bn += THR) {
+                double sre = 0.0, sim = 0.0;
+#pragma unroll
+                for (int r = 0; r < RPU; ++r) {
+                    const int kyr = ky0 + r;
+                    if (kyr > nyh) break;
+                    const unsigned short* __restrict__ fr = p.tfirst + (size_t)kyr * (p.nbins + 1) + bn;
+                    const int s = fr[0], e = fr[1];  // the bin holds |kx| = s .. e - 1 of this row
+                    double rr = 0.0, ri = 0.0;
+                    auto take = [&](int kx) {
+                        const CT va = lds[r * STR + M::pn(kx)];
+                        if (MODE == 1) rr += (double)((va.re * va.re + va.im * va.im) * sc);
+                        else { const CT v = cscale(cmulc(va, lds[(RPU + r) * STR + M::pn(kx)]), sc); rr += (double)v.re; ri += (double)v.im; }
+                    };
+                    for (int m = s; m < min(e, H + 1); ++m) take(m);
+                    for (int m = max(s, 1); m < min(e, HM + 1); ++m) take(NX - m);
+                    if (kyr != 0 && 2 * kyr != p.ny) { rr *= 2.0; ri = 0.0; }  // + the twin row (-ky): V + conj V
+                    sre += rr; sim += ri;
+                }
+                part[bn * HW] = sre;
+                if (MODE == 2) part[2 * bn + 1] = sim;
+            }
+        } else {
         const int nc = p.iso_ncopy, nbn = p.nbins;  // copies of the tables (lane l uses copy l % nc: neighbouring samples share bins)
         unsigned long long* acc_all = reinterpret_cast<unsigned long long*>(tw1 + M::M0);  // [nc][nbins][HW]
         unsigned* bmax_all = reinterpret_cast<unsigned*>(acc_all + (size_t)nc * nbn * HW);   // [nc][nbins]
@@ -779,6 +816,7 @@ __global__ void __launch_bounds__((MGeom<T, NX>::template Rows<MRowsG<T, NX, MOD
             // a bin with an inf / nan member is +inf (a power spectrum whose only offenders are +inf) or nan, as the IEEE sum is
             if ((bm >> 20) == 0x7ffu) v = __longlong_as_double((MODE == 1 && bm == 0x7ff00000u) ? 0x7ff0000000000000ll : 0x7ff8000000000000ll);
             part[i] = v;
+        }
         }
     }
     if (p.out == nullptr) return;

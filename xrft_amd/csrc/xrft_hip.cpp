@@ -875,9 +875,11 @@ static int upload_real_table(xrfthip_plan* P, DevBuf& buf, const double* h, int6
 
 static bool fast_on(const xrfthip_plan* P);
 static bool fastm_iso_fused(const xrfthip_plan* P);
+static bool fastm_iso_gather(const xrfthip_plan* P);
 static long long fasty_rows_gx(const xrfthip_plan* P);
 static bool fasty_iso_tables_fit(const xrfthip_plan* P, int nbins);
 static int fastm_rows_rpu(const xrfthip_plan* P);
+static int fastm_gather_rpu(const xrfthip_plan* P);
 
 // workgroups per slab of radial_binsum_det_kernel: chunks of <= 2^17 elements (its int64 sums hold 2^17 values), at most 128
 static int iso_chunk_count(long long total) {
@@ -1172,6 +1174,74 @@ static int fasty_window_spectra(xrfthip_plan* P) {
     return rc;
 }
 
+// The bins a unit of rows (one workgroup of pass 2) reaches, and the units that reach a bin, of a RADIAL bin map (along a half row the
+// bin never decreases: row ky holds the bins r[0] .. r[nx/2]): the unit gathers, writes and has reduced the union over its rows only.
+static int build_unit_windows(xrfthip_plan* P, const int32_t* bm, int rpu) {
+    const int nx = (int)P->ynx, nyh = (int)P->yny / 2, units = P->y_nrow_pad / rpu;
+    int rcf = XRFTHIP_OK;
+    std::vector<uint32_t> w((size_t)units);
+    for (int un = 0; un < units; ++un) {
+        int lo = P->nbins, hi = 0;
+        for (int ky = un * rpu; ky < (un + 1) * rpu && ky <= nyh; ++ky) {
+            lo = std::min<int>(lo, bm[(size_t)ky * nx]);
+            hi = std::max<int>(hi, bm[(size_t)ky * nx + nx / 2] + 1);
+        }
+        if (lo > hi) lo = hi = 0;  // (a unit of padding rows only)
+        w[(size_t)un] = (uint32_t)lo | (uint32_t)hi << 16;
+    }
+    // ... and the units that reach a bin: a contiguous range when the windows move monotonically with ky (a radial map's do;
+    // otherwise every unit keeps all bins)
+    bool mono = units < 65535;
+    for (int un = 1; un < units && mono; ++un) {
+        if ((w[(size_t)un] >> 16) == 0) continue;  // (padding rows only)
+        mono = (w[(size_t)un] & 0xffffu) >= (w[(size_t)un - 1] & 0xffffu) && (w[(size_t)un] >> 16) >= (w[(size_t)un - 1] >> 16);
+    }
+    if (!mono) std::fill(w.begin(), w.end(), (uint32_t)P->nbins << 16);
+    std::vector<uint32_t> tu((size_t)P->nbins, 0u);
+    for (int b = 0; b < P->nbins; ++b) {
+        int ulo = units, uhi = 0;
+        for (int un = 0; un < units; ++un)
+            if ((int)(w[(size_t)un] & 0xffffu) <= b && b < (int)(w[(size_t)un] >> 16)) { ulo = std::min(ulo, un); uhi = std::max(uhi, un + 1); }
+        if (ulo > uhi) ulo = uhi = 0;
+        tu[(size_t)b] = (uint32_t)ulo | (uint32_t)uhi << 16;
+    }
+    rcf = P->ytwin.upload(w.data(), w.size() * sizeof(uint32_t));
+    if (!rcf) rcf = P->ytunits.upload(tu.data(), tu.size() * sizeof(uint32_t));
+    return rcf;
+}
+
+// fastm: is the bin map a radial one (see fastm_rows_kernel, ISO)?  If so: first[ky][b] = the smallest |kx| <= nx/2 whose bin is >= b
+// (nx/2 + 1 if none), b = 0 .. nbins, and the unit windows.  Any nx (the lengths of the table are even; odd ones would work).
+static int fastm_build_tfirst(xrfthip_plan* P, const int32_t* bm) {
+    const int ny = (int)P->yny, nx = (int)P->ynx, nyh = ny / 2, H = nx / 2, HM = (nx - 1) / 2;
+    bool radial = env_ll("XRFTHIP_ISO_GATHER", 1) != 0 && P->nbins < 65535 && H + 1 < 65535;
+    for (int ky = 0; ky <= nyh && radial; ++ky) {
+        const int32_t* r = bm + (size_t)ky * nx;
+        const bool twin = ky != 0 && 2 * ky != ny;
+        const int32_t* t = bm + (size_t)(twin ? ny - ky : ky) * nx;
+        for (int m = 0; m <= H; ++m) {
+            const int32_t c = r[m];
+            if (c < 0 || c >= P->nbins || (m > 0 && c < r[m - 1]) || (m >= 1 && m <= HM && r[nx - m] != c)) { radial = false; break; }
+            if (twin && (t[m] != c || t[(nx - m) % nx] != c)) { radial = false; break; }
+        }
+    }
+    P->ytfirst_on = radial;
+    if (!radial) return XRFTHIP_OK;
+    std::vector<uint16_t> f((size_t)(nyh + 1) * (P->nbins + 1), (uint16_t)(H + 1));
+    for (int ky = 0; ky <= nyh; ++ky) {
+        const int32_t* r = bm + (size_t)ky * nx;
+        uint16_t* dst = f.data() + (size_t)ky * (P->nbins + 1);
+        int m = 0;
+        for (int b = 0; b <= P->nbins; ++b) {
+            while (m <= H && r[m] < b) ++m;
+            dst[b] = (uint16_t)m;
+        }
+    }
+    int rc = P->ytfirst.upload(f.data(), f.size() * sizeof(uint16_t));
+    if (!rc) rc = build_unit_windows(P, bm, fastm_gather_rpu(P));
+    return rc;
+}
+
 // the bin map as pass 2 reads it (fasty_rows_kernel).  Full form: [ky < nrow_pad][kx] in natural order,
 // value = (bin of (ky, kx) + 1) | (bin of the mirror (-ky, -kx) + 1) << 16; rows beyond ny/2 and unbinned samples are 0.
 // Compact form, when the map has the structure of a radial one (every sample of rows 0 .. ny/2 binned; along a half row the bin
@@ -1217,39 +1287,9 @@ static int fasty_build_tcodes(xrfthip_plan* P, const int32_t* bm) {
         }
         int rcf = P->ytfirst.upload(f.data(), f.size() * sizeof(uint16_t));
         if (rcf) return rcf;
-        // the bins a unit of rows (one workgroup of pass 2) reaches: along a half row the bin never decreases, so row ky holds the
-        // bins r[0] .. r[nx/2]; the unit gathers, writes and has reduced the union over its rows only
         const bool two = P->d.out_mode == XRFTHIP_OUT_CROSS;
         const YGeomRt R = yrows_geom(P->ynx, false);
-        const int rpu = two ? R.gxy : R.rk, units = P->y_nrow_pad / rpu;  // (as fasty_launch_rows)
-        std::vector<uint32_t> w((size_t)units);
-        for (int un = 0; un < units; ++un) {
-            int lo = P->nbins, hi = 0;
-            for (int ky = un * rpu; ky < (un + 1) * rpu && ky <= nyh; ++ky) {
-                lo = std::min<int>(lo, bm[(size_t)ky * nx]);
-                hi = std::max<int>(hi, bm[(size_t)ky * nx + nx / 2] + 1);
-            }
-            if (lo > hi) lo = hi = 0;  // (a unit of padding rows only)
-            w[(size_t)un] = (uint32_t)lo | (uint32_t)hi << 16;
-        }
-        // ... and the units that reach a bin: a contiguous range when the windows move monotonically with ky (a radial map's do;
-        // otherwise every unit keeps all bins)
-        bool mono = units < 65535;
-        for (int un = 1; un < units && mono; ++un) {
-            if ((w[(size_t)un] >> 16) == 0) continue;  // (padding rows only)
-            mono = (w[(size_t)un] & 0xffffu) >= (w[(size_t)un - 1] & 0xffffu) && (w[(size_t)un] >> 16) >= (w[(size_t)un - 1] >> 16);
-        }
-        if (!mono) std::fill(w.begin(), w.end(), (uint32_t)P->nbins << 16);
-        std::vector<uint32_t> tu((size_t)P->nbins, 0u);
-        for (int b = 0; b < P->nbins; ++b) {
-            int ulo = units, uhi = 0;
-            for (int un = 0; un < units; ++un)
-                if ((int)(w[(size_t)un] & 0xffffu) <= b && b < (int)(w[(size_t)un] >> 16)) { ulo = std::min(ulo, un); uhi = std::max(uhi, un + 1); }
-            if (ulo > uhi) ulo = uhi = 0;
-            tu[(size_t)b] = (uint32_t)ulo | (uint32_t)uhi << 16;
-        }
-        rcf = P->ytwin.upload(w.data(), w.size() * sizeof(uint32_t));
-        if (!rcf) rcf = P->ytunits.upload(tu.data(), tu.size() * sizeof(uint32_t));
+        rcf = build_unit_windows(P, bm, two ? R.gxy : R.rk);  // (rows per unit as fasty_launch_rows)
         if (rcf) return rcf;
         // the step masks of the 16-sample segments (any step size: the gather needs the run ends only)
         std::vector<uint32_t> t((size_t)P->y_nrow_pad * (nx / 16), 0u);
@@ -1464,29 +1504,36 @@ static int fastm_rk2(long long ny, long long nx, bool two, bool dbl) { return st
 
 // radial sums inside pass 2 when the per-bin tables fit behind the transforms' LDS (64 KB of dynamic LDS per workgroup); otherwise
 // the spectrum is stored and summed by run_radial_sums
+// a radial bin map (fastm_build_tfirst) is gathered per bin without atomics or tables; a cross spectrum with a true-phase factor keeps
+// the general path (the factor of a sample and of its Hermitian twin differ)
+static bool fastm_iso_gather(const xrfthip_plan* P) {
+    return P->fastm && (P->d.flags & XRFTHIP_ISO) && P->nbins >= 1 && P->ytfirst_on && !(P->d.out_mode == XRFTHIP_OUT_CROSS && P->fph_on);
+}
 static bool fastm_iso_fused(const xrfthip_plan* P) {
     if (!P->fastm || !(P->d.flags & XRFTHIP_ISO) || P->nbins < 1) return false;
+    if (fastm_iso_gather(P)) return true;
     const bool cx = P->d.out_mode == XRFTHIP_OUT_CROSS;
     const MGeomRt R = mgeom(P->ynx, P->dbl);
-    return R.lds_rows + (size_t)P->nbins * (cx ? 20 : 12) <= 64 * 1024;
+    return (cx ? R.lds_rows : R.lds_r1) + (size_t)P->nbins * (cx ? 20 : 12) <= 64 * 1024;
 }
 
 // copies of the per-bin tables in pass 2 (a power of two <= 8, whatever fits the 64 KB)
 static int fastm_iso_ncopy(const xrfthip_plan* P) {
+    if (fastm_iso_gather(P)) return 1;
     const bool cx = P->d.out_mode == XRFTHIP_OUT_CROSS;
     const MGeomRt R = mgeom(P->ynx, P->dbl);
-    const size_t per = (size_t)P->nbins * (cx ? 20 : 12), room = 64 * 1024 - R.lds_rows;
+    const size_t per = (size_t)P->nbins * (cx ? 20 : 12), room = 64 * 1024 - (cx ? R.lds_rows : R.lds_r1);
     int nc = 1;
     while (nc < 8 && per * (size_t)(2 * nc) <= room) nc *= 2;
     return nc;
 }
 
-// rows per pass-2 workgroup of this plan: two fields share a workgroup's sequences; with the radial sums fused the one-field kernel
-// keeps pass 1's sequence count (MRowsG in fastm.h)
+// rows per pass-2 workgroup of this plan: two fields share a workgroup's sequences (MRowsG in fastm.h)
+static int fastm_gather_rpu(const xrfthip_plan* P) { return fastm_rows_rpu(P); }
 static int fastm_rows_rpu(const xrfthip_plan* P) {
     const bool two = P->d.out_mode == XRFTHIP_OUT_CROSS || P->d.out_mode == XRFTHIP_OUT_PHASE;
     const MGeomRt r = mgeom(P->ynx, P->dbl);
-    return two ? r.g / 2 : (fastm_iso_fused(P) ? r.g : r.g_r1);
+    return two ? r.g / 2 : r.g_r1;
 }
 
 static FastM fastm_params(const xrfthip_plan* P, const void* in, void* out, char* ws, long long g0, long long gc, int slot, long long slot_slabs) {
@@ -1509,6 +1556,9 @@ static FastM fastm_params(const xrfthip_plan* P, const void* in, void* out, char
     p.what0 = P->ywhat0.p; p.what1 = P->ywhat1.p;
     p.binmap = (const int*)P->binmap.p; p.nbins = P->nbins; p.iso_ncopy = P->nbins > 0 ? fastm_iso_ncopy(P) : 1;
     p.iso_part = reinterpret_cast<double*>(ws + P->off_isopart);
+    const bool gather = fastm_iso_gather(P);
+    p.tfirst = gather ? reinterpret_cast<const unsigned short*>(P->ytfirst.p) : nullptr;
+    p.twin = gather ? reinterpret_cast<const unsigned*>(P->ytwin.p) : nullptr;
     p.ny = (int)P->yny; p.nx = (int)P->ynx; p.nrow_pad = P->y_nrow_pad;
     p.l_cw = ilog2i(fastm_cw(P->yny, P->dbl)); p.l_rk = ilog2i(fastm_rk2(P->yny, P->ynx, P->d.out_mode == XRFTHIP_OUT_CROSS || P->d.out_mode == XRFTHIP_OUT_PHASE, P->dbl));
     p.detrend = d.detrend; p.nslab = (int)gc;
@@ -1558,10 +1608,10 @@ static void fastm_launch_rows(const xrfthip_plan* P, const FastM& p, long long g
     const MGeomRt R = mgeom(P->ynx, P->dbl);
     const bool two = d.out_mode == XRFTHIP_OUT_CROSS || d.out_mode == XRFTHIP_OUT_PHASE;
     xrfthip_plan::ProfRec* rec = prof_begin(P, "fastm_rows", st);
-    const bool fused = fastm_iso_fused(P), full = two || fused;  // (full: pass 1's sequence count per workgroup)
+    const bool fused = fastm_iso_fused(P), full = two;  // (full: pass 1's sequence count per workgroup)
     const dim3 grid((unsigned)(gc * (P->y_nrow_pad / fastm_rows_rpu(P)))), blk((unsigned)(full ? R.thr : R.thr_r1));
     const size_t lds_rows = full ? R.lds_rows : R.lds_r1;
-    const size_t lds_iso = lds_rows + (size_t)P->nbins * (d.out_mode == XRFTHIP_OUT_CROSS ? 20 : 12) * (size_t)p.iso_ncopy;
+    const size_t lds_iso = p.tfirst ? lds_rows : lds_rows + (size_t)P->nbins * (d.out_mode == XRFTHIP_OUT_CROSS ? 20 : 12) * (size_t)p.iso_ncopy;  // (the gather needs no tables)
 #define MR_(TT, NN) do { \
         if (d.out_mode == XRFTHIP_OUT_POWER) { if (fused) { auto k = &fastm_rows_kernel<TT, NN, 1, true>; XRFT_LAUNCH(k, grid, blk, lds_iso, st, p); } else { auto k = &fastm_rows_kernel<TT, NN, 1>; MBIG_(k, lds_rows); XRFT_LAUNCH(k, grid, blk, lds_rows, st, p); } } \
         else if (d.out_mode == XRFTHIP_OUT_CROSS) { if (fused) { auto k = &fastm_rows_kernel<TT, NN, 2, true>; XRFT_LAUNCH(k, grid, blk, lds_iso, st, p); } else { auto k = &fastm_rows_kernel<TT, NN, 2>; XRFT_LAUNCH(k, grid, blk, R.lds_rows, st, p); } } \
@@ -1599,7 +1649,7 @@ static int run_fastm(const xrfthip_plan* P, const void* in, const void* in1, voi
             xrfthip_plan::ProfRec* rec = prof_begin(P, "iso_reduce", st);
             auto kr = &iso_reduce_kernel;
             XRFT_LAUNCH(kr, dim3((unsigned)((nb + 63) / 64), (unsigned)gc), dim3(256), 4 * 64 * sizeof(double), st, (const double*)p.iso_part,
-                        iso + (size_t)g0 * nb, upr, nb, (const unsigned*)nullptr, hw);
+                        iso + (size_t)g0 * nb, upr, nb, p.tfirst ? reinterpret_cast<const unsigned*>(P->ytunits.p) : nullptr, hw);
             prof_end(rec, st);
             HIP_TRY(hipGetLastError());
         } else if (iso_on) {  // radial sums of the stored spectrum (xrft.py:895-906), bit-reproducible
@@ -2100,6 +2150,10 @@ int xrfthip_plan_set_binmap(xrfthip_plan* plan, const int32_t* h_binmap, int64_t
         }
         if (rcf) return rcf;
     }
+    if (plan->fastm) {  // a radial map: the fused radial sums are gathered per bin (fastm_rows_kernel)
+        const int rcf = fastm_build_tfirst(plan, h_binmap);
+        if (rcf) return rcf;
+    }
     plan->passes.clear();
     plan->passes_f0.clear();
     int rcb = plan->dbl ? build_plan_t<double>(*plan) : build_plan_t<float>(*plan);
@@ -2182,6 +2236,10 @@ int xrfthip_plan_describe(const xrfthip_plan* plan, char* buf, size_t buflen) {
         appendf(s, "  [fastm] cols: %d thr, %d packed column pairs (FFT%lld r%dx%dx%d in LDS), lds=%zuB -> W2[slab][%d/%d][nx/%d][%d][%d] complex -> fit -> rows: %d thr, %d rows/unit (FFT%lld r%dx%dx%d), lds=%zuB, trend added back in the spectral domain, fftshift + mirror rows\n",
                 C.thr, C.g, (long long)plan->yny, C.r0, C.r1, C.r2, C.lds_cols, plan->y_nrow_pad, fastm_rk2(plan->yny, plan->ynx, plan->d.out_mode >= XRFTHIP_OUT_CROSS, plan->dbl), fastm_cw(plan->yny, plan->dbl), fastm_rk2(plan->yny, plan->ynx, plan->d.out_mode >= XRFTHIP_OUT_CROSS, plan->dbl), fastm_cw(plan->yny, plan->dbl),
                 R.thr_r1, R.g_r1, (long long)plan->ynx, R.r0, R.r1, R.r2, R.lds_r1);
+        if ((plan->d.flags & XRFTHIP_ISO) && plan->nbins > 0)
+            appendf(s, "  [fastm radial sums] %s\n", fastm_iso_gather(plan) ? "fused into the row pass: radial map, per-bin gather from the spectra in LDS, no atomics"
+                                                   : fastm_iso_fused(plan) ? "fused into the row pass: int64 fixed-point tables behind the transforms' LDS"
+                                                                           : "a pass over the stored spectrum (the tables do not fit beside the transforms)");
     } else if (fasty_on(plan)) {
         const YGeomRt C = ycols_geom(plan->yny), R = yrows_geom(plan->ynx, plan->fast1d);
         if (plan->fast1d) appendf(s, "  [fasty four-step] %lld samples = [%lld][%lld]: columns = step 1 (half spectrum k1 <= %lld), rows x W_N^(i2 k1) = step 2, transposed stores + Hermitian mirror\n",
