@@ -41,6 +41,12 @@ def show(label, tune):
 
 
 show("default: nt W2 stores, plain loads, nt result stores", 0)
+if os.environ.get("ONLY_MAP"):
+    for _ in range(2):
+        show("sharers of a line 16 workgroups apart (two per CU in the first round)", 1 << 19)
+        show("sharers of a line: pairs 32 apart", 2 << 19)
+        show("default again", 0)
+    sys.exit(0)
 show("W2 stores plain", 1)
 show("W2 stores write-through (sc1)", 2)
 show("input loads nt", 4)
@@ -51,4 +57,6 @@ show("W2 stores sc1 + input loads nt", 2 + 4)
 for n in (1, 2, 3, 4, 5, 6, 8):
     show(f"stagger {n} x 3.4 us", n << 8)
 show("stagger 4 + W2 stores sc1", (4 << 8) + 2)
+show("sharers of a line 16 workgroups apart (two per CU in the first round)", 1 << 19)
+show("sharers of a line: pairs 32 apart", 2 << 19)
 show("default again", 0)

@@ -254,7 +254,13 @@ __global__ void __launch_bounds__(YCols<NY>::THR, YCols<NY>::THR / 128) fasty_co
     if ((nxb & 7) == 0) {
         const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3, per = nxb >> 3;
         slab = j / per;
-        xb = xcd * per + j % per;
+        int jj = j % per;
+        // (tuning build: where the four sharers of a line go.  Workgroups k and k + 32 of an XCD land on one CU in the first round of
+        // a launch -- scripts/ubench/cuid.hip -- so sharers 16 or 32 apart share an L1 while they stay in step)
+        const int mp = (XRFT_YTUNE(p) >> 19) & 3;
+        if (mp == 1 && (per & 3) == 0) jj = (jj % (per >> 2)) * 4 + jj / (per >> 2);
+        else if (mp == 2 && per == 64) jj = ((jj & 31) >> 1) * 4 + (jj & 1) * 2 + (jj >> 5);
+        xb = xcd * per + jj;
     } else {
         slab = blockIdx.x / nxb;
         xb = blockIdx.x % nxb;
