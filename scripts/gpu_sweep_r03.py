@@ -7,34 +7,35 @@ sys.path.insert(0, REPO); sys.path.insert(0, os.path.join(REPO, "tests"))
 warnings.simplefilter("ignore")
 from test_random_differential import run_random_fastm, run_random_fast, run_random, run_random_one_axis
 bad = 0
+ONLY = os.environ.get("SWEEP_ONLY", "")  # e.g. "fast": that family alone
 NEW = (900, 1500, 1800, 2000, 360, 720, 1000)
-for seed in range(3000, 3120):
+for seed in (range(3000, 3120) if ONLY in ("", "fastm") else ()):
     for dt in ("float64", "float32"):
         try:
             run_random_fastm(seed, lengths=NEW + ((3000, 3600) if dt == "float32" else ()), dtype=dt)
         except Exception as e:
             bad += 1
             print("FAIL fastm-new", seed, dt, repr(e)[:300], flush=True)
-for seed in range(100, 250):
+for seed in (range(100, 250) if ONLY in ("", "fastm") else ()):
     for dt in ("float64", "float32"):
         try:
             run_random_fastm(seed, dtype=dt)
         except Exception as e:
             bad += 1
             print("FAIL fastm", seed, dt, repr(e)[:300], flush=True)
-for seed in range(100, 400):
+for seed in (range(100, 400) if ONLY in ("", "fast") else ()):
     try:
         run_random_fast(seed)
     except Exception as e:
         bad += 1
         print("FAIL fast", seed, repr(e)[:300], flush=True)
-for seed in range(1000, 1300):
+for seed in (range(1000, 1300) if ONLY in ("", "one-axis") else ()):
     try:
         run_random_one_axis(seed)
     except Exception as e:
         bad += 1
         print("FAIL one-axis", seed, repr(e)[:300], flush=True)
-for seed in range(500, 650):
+for seed in (range(500, 650) if ONLY in ("", "generic") else ()):
     try:
         run_random(seed)
     except Exception as e:

@@ -147,7 +147,8 @@ def run_random_fast(seed):
         tr = bool(rng.random() < 0.5)
         got, ref = xa.isotropic_power_spectrum(da, dim=["y", "x"], truncate=tr, **kw), o.isotropic_power_spectrum(od, dim=["y", "x"], truncate=tr, **kw)
     elif kind == "isocs":
-        got, ref = xa.isotropic_cross_spectrum(da, db, dim=["y", "x"], truncate=True, **kw), o.isotropic_cross_spectrum(od, ob, dim=["y", "x"], truncate=True, **kw)
+        tr = bool(rng.random() < 0.5)
+        got, ref = xa.isotropic_cross_spectrum(da, db, dim=["y", "x"], truncate=tr, **kw), o.isotropic_cross_spectrum(od, ob, dim=["y", "x"], truncate=tr, **kw)
     elif kind == "ps_real":
         got, ref = xa.power_spectrum(da, dim=["y"], real_dim="x", **kw), o.power_spectrum(od, dim=["y"], real_dim="x", **kw)
     else:
@@ -175,9 +176,10 @@ def run_random_fastm(seed, lengths=(180, 240, 360, 480, 500, 720, 960, 1000, 120
     w = rng.standard_normal((nb, ny, nx)).astype(dtype)
     db, ob = cases.pair(w, ("t", "y", "x"), c)
     kw = dict(detrend=rng.choice([None, "constant", "linear"]), window=rng.choice([None, "hann", "hamming"]))
-    kind = str(rng.choice(["ps", "ps", "fft", "cs", "iso", "ps_real"]))
+    kind = str(rng.choice(["ps", "ps", "fft", "cs", "iso", "isocs", "ps_real"]))
     shift = bool(rng.random() < 0.7)
     tp = bool(rng.random() < 0.5)
+    tr = bool(rng.random() < 0.5)  # (truncate=False: every sample binned, a radial map: the per-bin gather; True: unbinned corners, the tables)
     api._plan_cache.clear()
     if kind == "ps":
         sc = str(rng.choice(["density", "spectrum"]))
@@ -187,7 +189,9 @@ def run_random_fastm(seed, lengths=(180, 240, 360, 480, 500, 720, 960, 1000, 120
     elif kind == "cs":
         got, ref = xa.cross_spectrum(da, db, dim=["y", "x"], shift=shift, true_phase=tp, **kw), o.cross_spectrum(od, ob, dim=["y", "x"], shift=shift, true_phase=tp, **kw)
     elif kind == "iso":
-        got, ref = xa.isotropic_power_spectrum(da, dim=["y", "x"], truncate=True, **kw), o.isotropic_power_spectrum(od, dim=["y", "x"], truncate=True, **kw)
+        got, ref = xa.isotropic_power_spectrum(da, dim=["y", "x"], truncate=tr, **kw), o.isotropic_power_spectrum(od, dim=["y", "x"], truncate=tr, **kw)
+    elif kind == "isocs":
+        got, ref = xa.isotropic_cross_spectrum(da, db, dim=["y", "x"], truncate=tr, true_phase=tp, **kw), o.isotropic_cross_spectrum(od, ob, dim=["y", "x"], truncate=tr, true_phase=tp, **kw)
     else:
         got, ref = xa.power_spectrum(da, dim=["y"], real_dim="x", **kw), o.power_spectrum(od, dim=["y"], real_dim="x", **kw)
     on = any("[fastm]" in p.describe() for p in api._plan_cache.values())
