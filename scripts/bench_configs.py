@@ -88,7 +88,7 @@ add("   fft 1-D (32768,4096) f32", x.numel(), 12, timeit(lambda: xrft.fft(da, di
 x = cube((64, 1000, 1000), torch.float32); da = xrft.DataArray(x, ("t", "y", "x"), {"y": np.arange(1000.), "x": np.arange(1000.)})
 add("PS (64,1000,1000) f32 linear+hann", x.numel(), 8, timeit(lambda: xrft.power_spectrum(da, dim=["y", "x"], detrend="linear", window="hann")))
 # lengths that joined the mixed-radix table in round 3 (the generic tile kernels before: (64,2000,2000) f32 95, (16,3000,3000) f64 34 GFFT/s)
-for shape, dt in (((64, 2000, 2000), torch.float32), ((16, 3000, 3000), torch.float32), ((16, 3000, 3000), torch.float64), ((16, 1800, 3600), torch.float32), ((32, 1800, 900), torch.float64), ((32, 2000, 2000), torch.float64)):
+for shape, dt in (((64, 1280, 2560), torch.float32), ((16, 2160, 4320), torch.float32), ((32, 1080, 2160), torch.float64), ((32, 1440, 2880), torch.float32), ((64, 640, 1280), torch.float64), ((64, 2000, 2000), torch.float32), ((16, 3000, 3000), torch.float32), ((16, 3000, 3000), torch.float64), ((16, 1800, 3600), torch.float32), ((32, 1800, 900), torch.float64), ((32, 2000, 2000), torch.float64)):
     x = cube(shape, dt); da = xrft.DataArray(x, ("t", "y", "x"), {"y": np.arange(float(shape[1])), "x": np.arange(float(shape[2]))})
     add(f"PS {shape} {'f32' if dt == torch.float32 else 'f64'} linear+hann", x.numel(), 8 if dt == torch.float32 else 16, timeit(lambda: xrft.power_spectrum(da, dim=["y", "x"], detrend="linear", window="hann")))
     del x, da

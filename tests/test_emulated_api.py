@@ -488,6 +488,24 @@ def test_fastm_round3_lengths(shape, full, dtype):
     cases.run_fastm_cases(shape, full, True, dtype)
 
 
+@pytest.mark.parametrize("shape,full,dtype", [((1, 1080, 540), False, "float64"), ((1, 640, 320), True, "float32"), ((1, 1280, 640), False, "float64"), ((1, 2160, 1080), False, "float32"),
+                                               ((1, 2160, 540), False, "float64"), ((1, 2560, 1280), False, "float32"), ((1, 2880, 1440), False, "float32"), ((1, 2160, 4320), False, "float32")])
+def test_fastm_grid_lengths(shape, full, dtype):
+    """Gaussian grids (320 x 160 ... 2560 x 1280) and the 1/3 ... 1/12-degree lat/lon grids (1080 x 540 ... 4320 x 2160; 4320 = 15 x 16 x 18,
+    the radix-18 Good-Thomas butterfly; 2560, 2880, 4320 in float32 only)."""
+    cases.run_fastm_cases(shape, full, True, dtype)
+
+
+@pytest.mark.parametrize("shape,dtype", [((1, 2160, 8), "float64"), ((2, 4320, 8), "float32"), ((2, 540, 16), "float32"), ((1, 1280, 8), "float64")])
+def test_one_axis_grid_lengths(shape, dtype):
+    cases.run_yonly_fast_cases(shape, dtype)
+
+
+@pytest.mark.parametrize("shape,dtype", [((3, 2160), "float32"), ((2, 4320), "float32"), ((2, 1080), "float64"), ((3, 320), "float32")])
+def test_short_axis_grid_lengths(shape, dtype):
+    cases.run_xonly_fast_cases(shape, dtype)
+
+
 @pytest.mark.parametrize("shape,dtype", [((1, 2000, 8), "float64"), ((2, 3000, 8), "float32"), ((1, 1800, 4), "float64"), ((1, 3600, 8), "float32"), ((2, 900, 16), "float32"), ((1, 1500, 8), "float64")])
 def test_one_axis_round3_lengths(shape, dtype):
     cases.run_yonly_fast_cases(shape, dtype)

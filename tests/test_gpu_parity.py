@@ -781,6 +781,25 @@ def test_fastm_latlon_lengths(shape, cross, dtype):
     cases.run_fastm_cases(shape, True, cross, dtype)
 
 
+@pytest.mark.parametrize("shape,cross,dtype", [((2, 1080, 540), True, "float64"), ((3, 640, 320), True, "float32"), ((2, 1280, 640), True, "float64"), ((2, 2160, 1080), True, "float32"),
+                                                ((2, 2160, 1080), True, "float64"), ((2, 2560, 1280), True, "float32"), ((2, 2880, 1440), True, "float32"), ((2, 2160, 4320), False, "float32"),
+                                                ((2, 4320, 2160), True, "float32"), ((3, 320, 640), True, "float64"), ((2, 540, 1080), True, "float32")])
+def test_fastm_grid_lengths(shape, cross, dtype):
+    """Gaussian grids (320 x 160 ... 2560 x 1280) and the 1/3 ... 1/12-degree lat/lon grids (1080 x 540 ... 4320 x 2160; 4320 = 15 x 16 x 18,
+    the radix-18 Good-Thomas butterfly; 2560, 2880, 4320 in float32 only)."""
+    cases.run_fastm_cases(shape, True, cross, dtype)
+
+
+@pytest.mark.parametrize("shape,dtype", [((2, 2160, 64), "float64"), ((2, 4320, 40), "float32"), ((3, 540, 72), "float32"), ((2, 1280, 48), "float64"), ((2, 2880, 24), "float32"), ((2, 320, 136), "float64")])
+def test_one_axis_grid_lengths(shape, dtype):
+    cases.run_yonly_fast_cases(shape, dtype)
+
+
+@pytest.mark.parametrize("shape,dtype", [((33, 2160), "float32"), ((17, 4320), "float32"), ((65, 1080), "float64"), ((130, 320), "float32"), ((9, 2560), "float32"), ((12, 2160), "float64")])
+def test_short_axis_grid_lengths(shape, dtype):
+    cases.run_xonly_fast_cases(shape, dtype)
+
+
 @pytest.mark.parametrize("shape,dtype", [((5, 360, 256), "float64"), ((3, 256, 512), "float32"), ((2, 1024, 2048), "float64"), ((2, 2048, 1024), "float32"),
                                          ((3, 1440, 64), "float64"), ((4, 240, 96), "float32"), ((2, 960, 128), "float32"), ((2, 512, 264), "float64"),
                                          ((3, 100, 64), "float64"), ((2, 1000, 256), "float32"), ((2, 128, 136), "float32"), ((2, 1200, 64), "float64"),

@@ -46,6 +46,15 @@ XRFT_MRAD(1800, 10, 12, 15);
 XRFT_MRAD(2000, 10, 10, 20);
 XRFT_MRAD(3000, 10, 15, 20);
 XRFT_MRAD(3600, 15, 15, 16);
+XRFT_MRAD(320, 5, 8, 8);      // (Gaussian grids N80 ... N640: 320 x 160, 640 x 320, 1280 x 640, 2560 x 1280; 1/3, 1/6, 1/8, 1/12-degree grids: 1080 x 540, 2160 x 1080, 2880 x 1440, 4320 x 2160)
+XRFT_MRAD(540, 6, 9, 10);
+XRFT_MRAD(640, 8, 8, 10);
+XRFT_MRAD(1080, 9, 10, 12);
+XRFT_MRAD(1280, 8, 10, 16);
+XRFT_MRAD(2160, 12, 12, 15);
+XRFT_MRAD(2560, 10, 16, 16);
+XRFT_MRAD(2880, 12, 15, 16);
+XRFT_MRAD(4320, 15, 16, 18);
 XRFT_MRAD(256, 4, 8, 8);   // (powers of two: float64 only -- float32 has the register-resident kernels of fasty.h)
 XRFT_MRAD(512, 8, 8, 8);
 XRFT_MRAD(1024, 8, 8, 16);
@@ -63,8 +72,8 @@ XRFT_MRAD(1000, 10, 10, 10);
 XRFT_MRAD(1200, 10, 10, 12);
 #undef XRFT_MRAD
 // the lengths the host dispatches on: X(N) for every entry
-#define XRFT_M_LATLON(X) X(180) X(240) X(360) X(480) X(500) X(720) X(900) X(960) X(1000) X(1200) X(1440) X(1500) X(1800) X(2000)  /* both axes of a slab: the lat/lon lengths + 500, 1000, 1200, 1500, 2000 */
-#define XRFT_M_F32ONLY(X) X(3000) X(3600)  /* float32 only: a pair of complex128 sequences of this length does not fit the LDS beside a second workgroup */
+#define XRFT_M_LATLON(X) X(180) X(240) X(320) X(360) X(480) X(500) X(540) X(640) X(720) X(900) X(960) X(1000) X(1080) X(1200) X(1280) X(1440) X(1500) X(1800) X(2000) X(2160)  /* both axes of a slab: the lat/lon and Gaussian-grid lengths + 500, 1000, 1200, 1500, 2000 */
+#define XRFT_M_F32ONLY(X) X(2560) X(2880) X(3000) X(3600) X(4320)  /* float32 only: a pair of complex128 sequences of this length does not fit the LDS beside a second workgroup */
 #define XRFT_M_POW2(X) X(256) X(512) X(1024)
 #define XRFT_M_YONLY(X) X(100) X(128) X(200) X(400) X(600) X(800)
 
@@ -712,34 +721,44 @@ __global__ void __launch_bounds__((MGeom<T, NX>::template Rows<MRowsG<T, NX, MOD
         if (p.tfirst != nullptr) {
             // A RADIAL bin map (verified on the host, fastm_build_tfirst: along a row the bin depends on |kx| only and never decreases
             // with it, every sample is binned, the Hermitian twin of a sample shares its bin) needs no atomics and no tables: the
-            // bins of a row are contiguous ranges of kx on either side of kx = 0.  A thread owns a bin and adds its samples of the
-            // unit's rows in float64 in a fixed order (rows in order, kx = |kx| ascending then kx = nx - |kx|): bit-reproducible,
-            // inf / nan propagate as in any sum.  Only the bins the unit's rows reach are visited (p.twin), written and reduced.
+            // bins of a row are contiguous ranges of kx on either side of kx = 0.  The samples of a bin are added in float64 in a fixed
+            // order (each range in ascending |kx|, the ranges by a shuffle tree): bit-reproducible, inf / nan propagate as in any sum.
+            // Only the bins the unit's rows reach are visited (p.twin), written and reduced.
             const unsigned bw = p.twin[unit];
             const int blo = (int)(bw & 0xffffu), bhi = (int)(bw >> 16);
             constexpr int H = NX / 2, HM = (NX - 1) / 2;  // |kx| = 0 .. H; kx = nx - |kx| exists for |kx| = 1 .. HM
+            // task = (bin, row, side of kx = 0): 2 RPU adjacent lanes share a bin and their sums meet in lane order by shuffles (a thread per
+            // bin left most of the workgroup idle behind chains of LDS round trips: the row pass with the radial sums ran 25 % behind the one
+            // that stores the spectrum)
+            constexpr int TPB = 2 * RPU;
+            static_assert((TPB & (TPB - 1)) == 0 && TPB <= 64 && THR % TPB == 0, "tasks per bin");
+            const int sub = tid % TPB, r = sub >> 1, side = sub & 1, kyr = ky0 + r;
+            const bool rlive = kyr <= nyh, twin = kyr != 0 && 2 * kyr != p.ny;
             double* __restrict__ part = p.iso_part + ((size_t)slab * upr + unit) * p.nbins * HW;
-            for (int bn = blo + tid; bn < bhi; bn += THR) {
-                double sre = 0.0, sim = 0.0;
-#pragma unroll
-                for (int r = 0; r < RPU; ++r) {
-                    const int kyr = ky0 + r;
-                    if (kyr > nyh) break;
+            for (int b0 = blo; b0 < bhi; b0 += THR / TPB) {
+                const int bn = b0 + tid / TPB;
+                double rr = 0.0, ri = 0.0;
+                if (rlive && bn < bhi) {
                     const unsigned short* __restrict__ fr = p.tfirst + (size_t)kyr * (p.nbins + 1) + bn;
                     const int s = fr[0], e = fr[1];  // the bin holds |kx| = s .. e - 1 of this row
-                    double rr = 0.0, ri = 0.0;
                     auto take = [&](int kx) {
                         const CT va = lds[r * STR + M::pn(kx)];
                         if (MODE == 1) rr += (double)((va.re * va.re + va.im * va.im) * sc);
                         else { const CT v = cscale(cmulc(va, lds[(RPU + r) * STR + M::pn(kx)]), sc); rr += (double)v.re; ri += (double)v.im; }
                     };
-                    for (int m = s; m < min(e, H + 1); ++m) take(m);
-                    for (int m = max(s, 1); m < min(e, HM + 1); ++m) take(NX - m);
-                    if (kyr != 0 && 2 * kyr != p.ny) { rr *= 2.0; ri = 0.0; }  // + the twin row (-ky): V + conj V
-                    sre += rr; sim += ri;
+                    if (side == 0) { for (int m = s; m < min(e, H + 1); ++m) take(m); }
+                    else { for (int m = max(s, 1); m < min(e, HM + 1); ++m) take(NX - m); }
+                    if (twin) { rr *= 2.0; ri = 0.0; }  // + the twin row (-ky): V + conj V
                 }
-                part[bn * HW] = sre;
-                if (MODE == 2) part[2 * bn + 1] = sim;
+#pragma unroll
+                for (int m = 1; m < TPB; m <<= 1) {  // (row, side) in a fixed tree order
+                    rr += __shfl_down(rr, m, TPB);
+                    if (MODE == 2) ri += __shfl_down(ri, m, TPB);
+                }
+                if (sub == 0 && bn < bhi) {
+                    part[bn * HW] = rr;
+                    if (MODE == 2) part[2 * bn + 1] = ri;
+                }
             }
         } else {
         const int nc = p.iso_ncopy, nbn = p.nbins;  // copies of the tables (lane l uses copy l % nc: neighbouring samples share bins)

@@ -182,6 +182,7 @@ template <typename T, int R> __device__ __forceinline__ void dft_r(C2<T>* a) {
     else if (R == 12) dft_pfa<T, 4, 3>(a);
     else if (R == 15) dft_pfa<T, 3, 5>(a);
     else if (R == 16) dft16(a);
+    else if (R == 18) dft_pfa<T, 2, 9>(a);
     else if (R == 20) dft_pfa<T, 4, 5>(a);
 }
 
