@@ -489,10 +489,12 @@ def test_fastm_round3_lengths(shape, full, dtype):
 
 
 @pytest.mark.parametrize("shape,full,dtype", [((1, 1080, 540), False, "float64"), ((1, 640, 320), True, "float32"), ((1, 1280, 640), False, "float64"), ((1, 2160, 1080), False, "float32"),
-                                               ((1, 2160, 540), False, "float64"), ((1, 2560, 1280), False, "float32"), ((1, 2880, 1440), False, "float32"), ((1, 2160, 4320), False, "float32")])
+                                               ((1, 2160, 540), False, "float64"), ((1, 2560, 1280), False, "float32"), ((1, 2880, 1440), False, "float32"), ((1, 2160, 4320), False, "float32"),
+                                               ((1, 2000, 1000), False, "float32"), ((1, 1800, 960), False, "float32"), ((1, 2160, 900), False, "float32")])
 def test_fastm_grid_lengths(shape, full, dtype):
     """Gaussian grids (320 x 160 ... 2560 x 1280) and the 1/3 ... 1/12-degree lat/lon grids (1080 x 540 ... 4320 x 2160; 4320 = 15 x 16 x 18,
-    the radix-18 Good-Thomas butterfly; 2560, 2880, 4320 in float32 only)."""
+    the radix-18 Good-Thomas butterfly; 2560, 2880, 4320 in float32 only).  1800 / 2000 / 2160 rows in float32: pass 1 with four sequences per workgroup when
+    the row length divides into 8-column blocks (1000, 960, 1080, 4320), with two otherwise (900)."""
     cases.run_fastm_cases(shape, full, True, dtype)
 
 

@@ -783,7 +783,8 @@ def test_fastm_latlon_lengths(shape, cross, dtype):
 
 @pytest.mark.parametrize("shape,cross,dtype", [((2, 1080, 540), True, "float64"), ((3, 640, 320), True, "float32"), ((2, 1280, 640), True, "float64"), ((2, 2160, 1080), True, "float32"),
                                                 ((2, 2160, 1080), True, "float64"), ((2, 2560, 1280), True, "float32"), ((2, 2880, 1440), True, "float32"), ((2, 2160, 4320), False, "float32"),
-                                                ((2, 4320, 2160), True, "float32"), ((3, 320, 640), True, "float64"), ((2, 540, 1080), True, "float32")])
+                                                ((2, 4320, 2160), True, "float32"), ((3, 320, 640), True, "float64"), ((2, 540, 1080), True, "float32"),
+                                                ((2, 2000, 2000), True, "float32"), ((2, 1800, 3600), True, "float32"), ((2, 2000, 1500), True, "float32"), ((2, 1800, 900), True, "float32"), ((2, 2160, 1000), True, "float32")])
 def test_fastm_grid_lengths(shape, cross, dtype):
     """Gaussian grids (320 x 160 ... 2560 x 1280) and the 1/3 ... 1/12-degree lat/lon grids (1080 x 540 ... 4320 x 2160; 4320 = 15 x 16 x 18,
     the radix-18 Good-Thomas butterfly; 2560, 2880, 4320 in float32 only)."""

@@ -75,6 +75,7 @@ XRFT_MRAD(1200, 10, 10, 12);
 #define XRFT_M_LATLON(X) X(180) X(240) X(320) X(360) X(480) X(500) X(540) X(640) X(720) X(900) X(960) X(1000) X(1080) X(1200) X(1280) X(1440) X(1500) X(1800) X(2000) X(2160)  /* both axes of a slab: the lat/lon and Gaussian-grid lengths + 500, 1000, 1200, 1500, 2000 */
 #define XRFT_M_F32ONLY(X) X(2560) X(2880) X(3000) X(3600) X(4320)  /* float32 only: a pair of complex128 sequences of this length does not fit the LDS beside a second workgroup */
 #define XRFT_M_POW2(X) X(256) X(512) X(1024)
+#define XRFT_M_WIDE32(X) X(1800) X(2000) X(2160)  /* float32: pass 1 also exists with four sequences per workgroup (832 threads at most) */
 #define XRFT_M_YONLY(X) X(100) X(128) X(200) X(400) X(600) X(800)
 
 constexpr int mr_max3(int a, int b, int c) { return a > b ? (a > c ? a : c) : (b > c ? b : c); }
@@ -100,8 +101,13 @@ template <typename T, int N, int GOV = 0> struct MGeom {
 #ifndef XRFT_M_LDSCAP
 #define XRFT_M_LDSCAP (N >= 1800 ? 78 * 1024 : 52 * 1024)  /* three workgroups per CU; two for the long sequences (a pair of 2000-point complex128 sequences is 70 KB) */
 #endif
-    // (at most 4: 8 columns per workgroup divide every length of the table; and at most 640 threads: one butterfly per thread and pass)
-    static constexpr int G0 = ((size_t)4 * STR * CS <= XRFT_M_LDSCAP && 4 * BMAX <= 640) ? 4 : (size_t)2 * STR * CS <= XRFT_M_LDSCAP ? 2 : 1;
+    // (at most 4: 8 columns per workgroup divide every length of the table; and at most XRFT_M_MAXTHR threads: one butterfly per thread and pass.
+    // 640 until the lengths 1800 ... 2160 joined: four float32 sequences of them fit the LDS, and 16-byte row segments -- two sequences --
+    // load at half the rate of 32-byte ones: (64, 2000, 2000) float32 pass 1 12.5 us per slab for 6 us of bytes)
+#ifndef XRFT_M_MAXTHR
+#define XRFT_M_MAXTHR 640
+#endif
+    static constexpr int G0 = ((size_t)4 * STR * CS <= XRFT_M_LDSCAP && 4 * BMAX <= XRFT_M_MAXTHR) ? 4 : (size_t)2 * STR * CS <= XRFT_M_LDSCAP ? 2 : 1;
     static constexpr int G = GOV > 0 ? GOV : G0;
     static constexpr int THR = ((G * BMAX + 63) / 64) * 64;
     static constexpr size_t LDS_ROWS = ((size_t)G * STR + M0) * CS;                                    // sequences + pass-1 twiddles
@@ -260,9 +266,12 @@ template <typename T, int N> __device__ __forceinline__ void mr_fill_tw1(C2<T>* 
 // domain: wx[x] (alpha_x What0[ky] + gamma_x What1[ky]).  In float64 nothing cancels visibly (trend / signal of 10^4 costs 13 of
 // 53 bits; the tests hold 1e-10).
 // ------------------------------------------------------------------------------------------------
-template <typename T, int NY, bool DET>
-__global__ void __launch_bounds__((MGeom<T, NY>::THR), (MGeom<T, NY>::WPS)) fastm_cols_kernel(FastM p) {
-    typedef MGeom<T, NY> M;
+// GOV = 4 (float32, 1800 / 2000 / 2160 rows: XRFT_M_WIDE32): four sequences = 8 real columns = 32-byte row segments where the default
+// geometry (at most 640 threads) takes two -- 16-byte segments load at half the rate: (64, 2000, 2000) float32 12.5 us per slab for 6 us of
+// bytes.  Taken when the row length divides into 8-column blocks; the intermediate's layout follows (FastM::l_cw, l_rk).
+template <typename T, int NY, bool DET, int GOV = 0>
+__global__ void __launch_bounds__((MGeom<T, NY, GOV>::THR), (MGeom<T, NY, GOV>::WPS)) fastm_cols_kernel(FastM p) {
+    typedef MGeom<T, NY, GOV> M;
     typedef C2<T> CT;
     constexpr int G = M::G, THR = M::THR, STR = M::STR, CW = 2 * G;
     static_assert(THR >= G * M::B0 && THR % G == 0, "one first-pass butterfly per thread");

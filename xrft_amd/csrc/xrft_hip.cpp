@@ -1471,8 +1471,8 @@ static int run_fasty(const xrfthip_plan* P, const float* in, const float* in1, v
 // mixed-radix float64 form of the y-first pipeline (fastm.h)
 // ---------------------------------------------------------------------------------------------------------------
 struct MGeomRt { int thr, g; size_t lds_cols, lds_rows; int r0, r1, r2; int thr_r1, g_r1; size_t lds_r1; };  // *_r1: pass 2 of one field
-template <typename T, int N> static MGeomRt mgeom_t() {
-    typedef MGeom<T, N> M;
+template <typename T, int N, int GOV = 0> static MGeomRt mgeom_t() {
+    typedef MGeom<T, N, GOV> M;
     typedef typename M::template Rows<M::GR1> R1;
     return {M::THR, M::G, M::LDS, M::LDS_ROWS, M::R0, M::R1, M::R2, R1::THR, M::GR1, R1::LDS};
 }
@@ -1494,13 +1494,29 @@ static MGeomRt mgeom(long long n, bool dbl) {
 #undef X_
     return mgeom_t<float, 360>();
 }
+// pass 1 with four float32 sequences per workgroup (fastm_cols_kernel, GOV = 4) when the rows divide into its 8-column blocks
+static bool fastm_wide(long long ny, long long nx, bool dbl) {
+    if (dbl || (nx & 7) != 0) return false;
+#define X_(NN) if (ny == NN) return true;
+    XRFT_M_WIDE32(X_)
+#undef X_
+    return false;
+}
+static MGeomRt mgeom_cols(long long ny, long long nx, bool dbl) {  // geometry of pass 1 of an (ny, nx) slab
+    if (fastm_wide(ny, nx, dbl)) {
+#define X_(NN) if (ny == NN) return mgeom_t<float, NN, 4>();
+        XRFT_M_WIDE32(X_)
+#undef X_
+    }
+    return mgeom(ny, dbl);
+}
 // layout of the intermediate: CW = 2 G columns of a pass-1 workgroup, RK rows per 128-byte line
-static int fastm_cw(long long ny, bool dbl) { return 2 * mgeom(ny, dbl).g; }
-static int fastm_rk(long long ny, bool dbl) { const int lb = fastm_cw(ny, dbl) * (dbl ? 16 : 8); return lb >= 128 ? 1 : 128 / lb; }
+static int fastm_cw(long long ny, long long nx, bool dbl) { return 2 * mgeom_cols(ny, nx, dbl).g; }
+static int fastm_rk(long long ny, long long nx, bool dbl) { const int lb = fastm_cw(ny, nx, dbl) * (dbl ? 16 : 8); return lb >= 128 ? 1 : 128 / lb; }
 static int fastm_rpu(long long nx, bool two, bool dbl) { const MGeomRt r = mgeom(nx, dbl); return two ? r.g / 2 : r.g_r1; }  // 
 // rows per line of the intermediate for a (ny, nx) plan: a whole 128-byte line of pass 1's CW columns, but never more rows than
 // one pass-2 workgroup owns (long float32 sequences: two per workgroup = 4 columns = 32 bytes per row, pass 2 takes 2 rows -> 64-byte pieces)
-static int fastm_rk2(long long ny, long long nx, bool two, bool dbl) { return std::max(1, std::min(fastm_rk(ny, dbl), fastm_rpu(nx, two, dbl))); }
+static int fastm_rk2(long long ny, long long nx, bool two, bool dbl) { return std::max(1, std::min(fastm_rk(ny, nx, dbl), fastm_rpu(nx, two, dbl))); }
 
 // radial sums inside pass 2 when the per-bin tables fit behind the transforms' LDS (64 KB of dynamic LDS per workgroup); otherwise
 // the spectrum is stored and summed by run_radial_sums
@@ -1560,9 +1576,9 @@ static FastM fastm_params(const xrfthip_plan* P, const void* in, void* out, char
     p.tfirst = gather ? reinterpret_cast<const unsigned short*>(P->ytfirst.p) : nullptr;
     p.twin = gather ? reinterpret_cast<const unsigned*>(P->ytwin.p) : nullptr;
     p.ny = (int)P->yny; p.nx = (int)P->ynx; p.nrow_pad = P->y_nrow_pad;
-    p.l_cw = ilog2i(fastm_cw(P->yny, P->dbl)); p.l_rk = ilog2i(fastm_rk2(P->yny, P->ynx, P->d.out_mode == XRFTHIP_OUT_CROSS || P->d.out_mode == XRFTHIP_OUT_PHASE, P->dbl));
+    p.l_cw = ilog2i(fastm_cw(P->yny, P->ynx, P->dbl)); p.l_rk = ilog2i(fastm_rk2(P->yny, P->ynx, P->d.out_mode == XRFTHIP_OUT_CROSS || P->d.out_mode == XRFTHIP_OUT_PHASE, P->dbl));
     p.detrend = d.detrend; p.nslab = (int)gc;
-    p.nunits = (int)(gc * (P->ynx / fastm_cw(P->yny, P->dbl)));
+    p.nunits = (int)(gc * (P->ynx / fastm_cw(P->yny, P->ynx, P->dbl)));
     p.shift_y = (d.flags & XRFTHIP_SHIFT_Y) ? (int)(P->yny / 2) : 0;
     p.shift_x = (d.flags & XRFTHIP_SHIFT_X) ? (int)(P->ynx / 2) : 0;
     p.scale = d.scale;
@@ -1571,7 +1587,8 @@ static FastM fastm_params(const xrfthip_plan* P, const void* in, void* out, char
 
 static void fastm_launch_cols(const xrfthip_plan* P, const FastM& p, long long gc, hipStream_t st) {
     const xrfthip_desc& d = P->d;
-    const MGeomRt C = mgeom(P->yny, P->dbl);
+    const MGeomRt C = mgeom_cols(P->yny, P->ynx, P->dbl);
+    const bool wide = fastm_wide(P->yny, P->ynx, P->dbl);
     xrfthip_plan::ProfRec* rec = prof_begin(P, "fastm_cols", st);
     const dim3 grid((unsigned)(8 * ((p.nunits + 7) / 8))), blk((unsigned)C.thr);
 #ifdef XRFT_M_BIGLDS  /* profiling builds with more than 64 KB of LDS per workgroup */
@@ -1583,7 +1600,11 @@ static void fastm_launch_cols(const xrfthip_plan* P, const FastM& p, long long g
                          else { auto k = &fastm_cols_kernel<TT, NN, false>; MBIG_(k, C.lds_cols); XRFT_LAUNCH(k, grid, blk, C.lds_cols, st, p); } } while (0)
 #define XD_(NN) if (P->yny == NN) MC_(double, NN);
 #define XF_(NN) if (P->yny == NN) MC_(float, NN);
-    if (P->dbl) { XRFT_M_LATLON(XD_) XRFT_M_POW2(XD_) } else { XRFT_M_LATLON(XF_) XRFT_M_F32ONLY(XF_) }
+#define MCW_(NN) if (P->yny == NN) do { if (d.detrend) { auto k = &fastm_cols_kernel<float, NN, true, 4>; MBIG_(k, C.lds_cols); XRFT_LAUNCH(k, grid, blk, C.lds_cols, st, p); } \
+                                            else { auto k = &fastm_cols_kernel<float, NN, false, 4>; MBIG_(k, C.lds_cols); XRFT_LAUNCH(k, grid, blk, C.lds_cols, st, p); } } while (0);
+    if (wide) { XRFT_M_WIDE32(MCW_) }
+    else if (P->dbl) { XRFT_M_LATLON(XD_) XRFT_M_POW2(XD_) } else { XRFT_M_LATLON(XF_) XRFT_M_F32ONLY(XF_) }
+#undef MCW_
 #undef XD_
 #undef XF_
 #undef MC_
@@ -2052,7 +2073,7 @@ int xrfthip_plan_create(xrfthip_plan** plan, const xrfthip_desc* desc) {
         if (P->fastm) {
             const bool two = d.out_mode == XRFTHIP_OUT_CROSS || d.out_mode == XRFTHIP_OUT_PHASE;
             const int rpu = fastm_rpu(d.nx, two, P->dbl);
-            if (rpu < 1 || rpu % fastm_rk2(d.ny, d.nx, two, P->dbl) != 0 || d.nx % fastm_cw(d.ny, P->dbl) != 0) P->fastm = false;
+            if (rpu < 1 || rpu % fastm_rk2(d.ny, d.nx, two, P->dbl) != 0 || d.nx % fastm_cw(d.ny, d.nx, P->dbl) != 0) P->fastm = false;
         }
         if (P->fastm) {
             const bool two = d.out_mode == XRFTHIP_OUT_CROSS || d.out_mode == XRFTHIP_OUT_PHASE;
@@ -2232,9 +2253,9 @@ int xrfthip_plan_describe(const xrfthip_plan* plan, char* buf, size_t buflen) {
         appendf(s, "  [fastm y-only] %d thr, %d packed column pairs (FFT%lld r%dx%dx%d in LDS), lds=%zuB: per-column detrend + window + transform + both halves of the spectrum in one pass, in place in memory order\n",
                 C.thr, C.g, (long long)plan->d.ny, C.r0, C.r1, C.r2, C.lds_cols);
     } else if (plan->fastm) {
-        const MGeomRt C = mgeom(plan->yny, plan->dbl), R = mgeom(plan->ynx, plan->dbl);
+        const MGeomRt C = mgeom_cols(plan->yny, plan->ynx, plan->dbl), R = mgeom(plan->ynx, plan->dbl);
         appendf(s, "  [fastm] cols: %d thr, %d packed column pairs (FFT%lld r%dx%dx%d in LDS), lds=%zuB -> W2[slab][%d/%d][nx/%d][%d][%d] complex -> fit -> rows: %d thr, %d rows/unit (FFT%lld r%dx%dx%d), lds=%zuB, trend added back in the spectral domain, fftshift + mirror rows\n",
-                C.thr, C.g, (long long)plan->yny, C.r0, C.r1, C.r2, C.lds_cols, plan->y_nrow_pad, fastm_rk2(plan->yny, plan->ynx, plan->d.out_mode >= XRFTHIP_OUT_CROSS, plan->dbl), fastm_cw(plan->yny, plan->dbl), fastm_rk2(plan->yny, plan->ynx, plan->d.out_mode >= XRFTHIP_OUT_CROSS, plan->dbl), fastm_cw(plan->yny, plan->dbl),
+                C.thr, C.g, (long long)plan->yny, C.r0, C.r1, C.r2, C.lds_cols, plan->y_nrow_pad, fastm_rk2(plan->yny, plan->ynx, plan->d.out_mode >= XRFTHIP_OUT_CROSS, plan->dbl), fastm_cw(plan->yny, plan->ynx, plan->dbl), fastm_rk2(plan->yny, plan->ynx, plan->d.out_mode >= XRFTHIP_OUT_CROSS, plan->dbl), fastm_cw(plan->yny, plan->ynx, plan->dbl),
                 R.thr_r1, R.g_r1, (long long)plan->ynx, R.r0, R.r1, R.r2, R.lds_r1);
         if ((plan->d.flags & XRFTHIP_ISO) && plan->nbins > 0)
             appendf(s, "  [fastm radial sums] %s\n", fastm_iso_gather(plan) ? "fused into the row pass: radial map, per-bin gather from the spectra in LDS, no atomics"
