@@ -1002,6 +1002,13 @@ def run_inner_layout_cases(dtype="float64", shape=(24, 20, 6)):
         worst = max(worst, check(xa.detrend(da, ["y", "x"], det), o.detrend(od, ["y", "x"], det).transpose("y", "x", "t"), tol))
         worst = max(worst, check(xa.detrend(d4, ["y", "x"], det), o.detrend(o4, ["y", "x"], det).transpose("t", "y", "x", "z"), tol))
         worst = max(worst, check(xa.detrend(d4, "y", det), o.detrend(o4, "y", det).transpose("t", "y", "x", "z"), tol))
+    # many independent elements (the per-element coefficients no longer fit the LDS of the pass that subtracts the planes), rows of a
+    # length the 256-element stride does not divide, more than one leading batch element
+    wb = (rng.standard_normal((2, 7, 5, 1801)) + 0.3 * np.arange(7)[None, :, None, None] - 0.2 * np.arange(5)[None, None, :, None] + 4.0).astype(dtype)
+    cb = {"t": np.arange(2), "y": np.arange(7) * 1.0, "x": np.arange(5) * 1.0, "z": np.arange(1801)}
+    db_, ob_ = pair(wb, ("t", "y", "x", "z"), cb)
+    for det in ("constant", "linear"):
+        worst = max(worst, check(xa.detrend(db_, ["y", "x"], det), o.detrend(ob_, ["y", "x"], det).transpose("t", "y", "x", "z"), tol))
     return worst
 
 

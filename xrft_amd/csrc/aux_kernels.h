@@ -303,32 +303,43 @@ __global__ void __launch_bounds__(256) table_mul_kernel(const void* in, const C2
 // axes that are not the trailing ones).  A workgroup = IB consecutive inner2 indices (lanes: contiguous) x XS columns; rows are dealt
 // round-robin to the gridDim.x chunks of a slab; part[b][chunk][i2][3] = { sum d, sum (i - ibar) d, sum (j - jbar) d }, added in
 // chunk order by plane_inner_finalize_kernel (no atomics: bit-reproducible).
-constexpr int kInnerIB = 32, kInnerXS = 8;
+// (round 3: ib = min(inner2, 1024) lanes across the inner index and xs = 1024 / ib column slots, chosen at launch -- fixed at 32 x 8, a
+// 16-element inner dimension left half of every wave idle on 64-byte pieces: 0.86 ms for a 268-MB array)
+constexpr int kInnerThreads = 1024;  // (a (y, x, t) array with few inner elements is ONE tile: at most kInnerMaxChunks = 256 workgroups share it, so they are large)
 template <typename T>
-__global__ void __launch_bounds__(kInnerIB * kInnerXS) plane_inner_moments_kernel(const T* __restrict__ in, long long ny, long long nx, long long inner2, double* part) {
+__global__ void __launch_bounds__(kInnerThreads) plane_inner_moments_kernel(const T* __restrict__ in, long long ny, long long nx, long long inner2, double* part, int ib, int xsn) {
     XRFT_DYN_SMEM(smem_raw);
-    double (*red)[3][kInnerIB] = reinterpret_cast<double (*)[3][kInnerIB]>(smem_raw);  // [XS][3][IB]
-    const int li = threadIdx.x % kInnerIB, xs = threadIdx.x / kInnerIB;
-    const long long i2 = (long long)blockIdx.y * kInnerIB + li, b = blockIdx.z;
+    double* red = reinterpret_cast<double*>(smem_raw);  // [xsn][3][ib]
+    const int li = threadIdx.x % ib, xs = threadIdx.x / ib;
+    const long long i2 = (long long)blockIdx.y * ib + li, b = blockIdx.z;
     const double ibar = 0.5 * (double)(ny - 1), jbar = 0.5 * (double)(nx - 1);
+    const bool live = xs < xsn && i2 < inner2;
     double s0 = 0.0, si = 0.0, sj = 0.0;
-    if (i2 < inner2) {
+    if (live) {
         for (long long i = blockIdx.x; i < ny; i += gridDim.x) {
             const T* row = in + ((b * ny + i) * nx) * inner2 + i2;
-            double r0 = 0.0, rj = 0.0;
-            for (long long j = xs; j < nx; j += kInnerXS) {
-                const double v = (double)row[j * inner2];
-                r0 += v;
-                rj = fma((double)j - jbar, v, rj);
+            // four independent loads per trip (one load in flight per thread ran the pass at a fifth of the copy rate); the four partial
+            // sums are combined in a fixed order
+            double r0[4] = {0.0, 0.0, 0.0, 0.0}, rj[4] = {0.0, 0.0, 0.0, 0.0};
+            for (long long j0 = xs; j0 < nx; j0 += 4 * xsn) {
+                T v[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) { const long long j = j0 + (long long)u * xsn; v[u] = j < nx ? row[j * inner2] : (T)0; }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    r0[u] += (double)v[u];
+                    rj[u] = fma((double)(j0 + (long long)u * xsn) - jbar, (double)v[u], rj[u]);
+                }
             }
-            s0 += r0; sj += rj;
-            si = fma((double)i - ibar, r0, si);
+            const double r0s = (r0[0] + r0[1]) + (r0[2] + r0[3]), rjs = (rj[0] + rj[1]) + (rj[2] + rj[3]);
+            s0 += r0s; sj += rjs;
+            si = fma((double)i - ibar, r0s, si);
         }
     }
-    red[xs][0][li] = s0; red[xs][1][li] = si; red[xs][2][li] = sj;
+    if (xs < xsn) { red[(xs * 3 + 0) * ib + li] = s0; red[(xs * 3 + 1) * ib + li] = si; red[(xs * 3 + 2) * ib + li] = sj; }
     __syncthreads();
     if (xs == 0 && i2 < inner2) {
-        for (int k = 1; k < kInnerXS; ++k) { s0 += red[k][0][li]; si += red[k][1][li]; sj += red[k][2][li]; }
+        for (int k = 1; k < xsn; ++k) { s0 += red[(k * 3 + 0) * ib + li]; si += red[(k * 3 + 1) * ib + li]; sj += red[(k * 3 + 2) * ib + li]; }
         double* dst = part + ((b * gridDim.x + blockIdx.x) * inner2 + i2) * 3;
         dst[0] = s0; dst[1] = si; dst[2] = sj;
     }
@@ -351,20 +362,51 @@ __global__ void plane_inner_finalize_kernel(const double* part, double* coef, lo
     coef[e * 3 + 1] = c1;
     coef[e * 3 + 2] = c2;
 }
-// (a workgroup walks whole rows (b, i): 32-bit index arithmetic inside the row -- one 64-bit division per element ran at 1 TB/s)
+// A workgroup walks a CONTIGUOUS range of rows (b, i); the coefficients of the batch element it is in sit in LDS (three float64 per inner
+// index: read from memory per element they were six times the data), a thread's position (j, i2) advances by additions (no division per
+// element), four loads in flight per thread.  lds_coef = 0: inner2 too large for the LDS, the coefficients come from memory.
 template <typename T>
-__global__ void __launch_bounds__(256) plane_inner_apply_kernel(const T* __restrict__ in, T* __restrict__ out, const double* __restrict__ coef, long long batch, long long ny, long long nx, long long inner2) {
+__global__ void __launch_bounds__(256) plane_inner_apply_kernel(const T* __restrict__ in, T* __restrict__ out, const double* __restrict__ coef, long long batch, long long ny, long long nx, long long inner2, int lds_coef) {
+    XRFT_DYN_SMEM(smem_raw);
+    double* cl = reinterpret_cast<double*>(smem_raw);  // [inner2][3]
     const unsigned rowlen = (unsigned)(nx * inner2), in2 = (unsigned)inner2;
-    for (long long r = blockIdx.x; r < batch * ny; r += gridDim.x) {
+    const long long rows = batch * ny, per = (rows + gridDim.x - 1) / gridDim.x;
+    const long long r_lo = (long long)blockIdx.x * per, r_hi = r_lo + per < rows ? r_lo + per : rows;
+    const unsigned dj = 256u / in2, di = 256u % in2;  // a step of 256 elements in (j, i2)
+    long long bcur = -1;
+    for (long long r = r_lo; r < r_hi; ++r) {
         const long long b = r / ny;
         const double fi = (double)(r - b * ny);
         const double* cb = coef + b * inner2 * 3;
+        if (lds_coef && b != bcur) {
+            __syncthreads();  // (the previous batch element's rows are done with the table)
+            for (unsigned k = threadIdx.x; k < 3u * in2; k += 256) cl[k] = cb[k];
+            __syncthreads();
+            bcur = b;
+        }
+        const double* ct = lds_coef ? cl : cb;
         const T* src = in + r * rowlen;
         T* dst = out + r * rowlen;
-        for (unsigned e = threadIdx.x; e < rowlen; e += 256) {
-            const unsigned j = e / in2, i2 = e - j * in2;
-            const double* c = cb + (size_t)i2 * 3;
-            dst[e] = (T)((double)src[e] - (c[0] + c[1] * fi + c[2] * (double)j));
+        unsigned j = threadIdx.x / in2, i2 = threadIdx.x - j * in2;
+        for (unsigned e0 = threadIdx.x; e0 < rowlen; e0 += 4 * 256) {
+            T v[4];
+            unsigned jj[4], ii[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const unsigned e = e0 + u * 256;
+                jj[u] = j; ii[u] = i2;
+                v[u] = e < rowlen ? src[e] : (T)0;
+                j += dj; i2 += di;
+                if (i2 >= in2) { i2 -= in2; ++j; }
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const unsigned e = e0 + u * 256;
+                if (e < rowlen) {
+                    const double* c = ct + (size_t)ii[u] * 3;
+                    dst[e] = (T)((double)v[u] - (c[0] + c[1] * fi + c[2] * (double)jj[u]));
+                }
+            }
         }
     }
 }

@@ -2478,7 +2478,7 @@ int xrfthip_table_mul(int32_t dtype, int64_t batch, int64_t n_in, int64_t n_out,
 
 static constexpr int kInnerMaxChunks = 256;
 static int inner_chunks(long long ny, long long batch, long long i2) {  // enough workgroups to fill the chip (a (y, x, t) array is ONE slab)
-    const long long tiles = std::max<long long>(1, batch * ((i2 + kInnerIB - 1) / kInnerIB));
+    const long long tiles = std::max<long long>(1, batch * ((i2 + kInnerThreads - 1) / kInnerThreads));
     return (int)std::max<long long>(1, std::min<long long>(std::min<long long>(kInnerMaxChunks, ny), (2048 + tiles - 1) / tiles));
 }
 static size_t detrend_inner_ws(bool cplx, long long batch, long long inner) {
@@ -2495,18 +2495,21 @@ static int run_detrend_inner(int32_t dtype, int32_t ndim, long long batch, long 
     double* coef = part + (size_t)batch * kInnerMaxChunks * i2 * 3;
     for (long long b0 = 0; b0 < batch; b0 += 65535) {  // grid.z limit
         const long long bc = std::min<long long>(65535, batch - b0);
-        const dim3 grid((unsigned)nch, (unsigned)((i2 + kInnerIB - 1) / kInnerIB), (unsigned)bc), block(kInnerIB * kInnerXS);
-        const size_t lds = (size_t)kInnerXS * 3 * kInnerIB * sizeof(double), eoff = (size_t)b0 * ny * nx * i2;
-        if (dbl) { auto k = &plane_inner_moments_kernel<double>; XRFT_LAUNCH(k, grid, block, lds, st, (const double*)in + eoff, (long long)ny, (long long)nx, i2, part + (size_t)b0 * nch * i2 * 3); }
-        else { auto k = &plane_inner_moments_kernel<float>; XRFT_LAUNCH(k, grid, block, lds, st, (const float*)in + eoff, (long long)ny, (long long)nx, i2, part + (size_t)b0 * nch * i2 * 3); }
+        const int ib = (int)std::min<long long>(i2, kInnerThreads), xsn = kInnerThreads / ib;  // lanes across the inner index x column slots
+        const dim3 grid((unsigned)nch, (unsigned)((i2 + ib - 1) / ib), (unsigned)bc), block(kInnerThreads);
+        const size_t lds = (size_t)xsn * 3 * ib * sizeof(double), eoff = (size_t)b0 * ny * nx * i2;
+        if (dbl) { auto k = &plane_inner_moments_kernel<double>; XRFT_LAUNCH(k, grid, block, lds, st, (const double*)in + eoff, (long long)ny, (long long)nx, i2, part + (size_t)b0 * nch * i2 * 3, ib, xsn); }
+        else { auto k = &plane_inner_moments_kernel<float>; XRFT_LAUNCH(k, grid, block, lds, st, (const float*)in + eoff, (long long)ny, (long long)nx, i2, part + (size_t)b0 * nch * i2 * 3, ib, xsn); }
     }
     {
         auto k = &plane_inner_finalize_kernel;
         XRFT_LAUNCH(k, dim3((unsigned)((batch * i2 + 255) / 256)), dim3(256), 0, st, (const double*)part, coef, (long long)batch, (long long)ny, (long long)nx, i2, nch, (int)kind);
     }
     const dim3 grid((unsigned)std::min<long long>(batch * ny, 8LL * kCUs * 4)), block(256);
-    if (dbl) { auto k = &plane_inner_apply_kernel<double>; XRFT_LAUNCH(k, grid, block, 0, st, (const double*)in, (double*)out, (const double*)coef, (long long)batch, (long long)ny, (long long)nx, i2); }
-    else { auto k = &plane_inner_apply_kernel<float>; XRFT_LAUNCH(k, grid, block, 0, st, (const float*)in, (float*)out, (const double*)coef, (long long)batch, (long long)ny, (long long)nx, i2); }
+    const size_t clds = (size_t)i2 * 3 * sizeof(double);  // the coefficients of one batch element in LDS (four workgroups per CU at 40 KB)
+    const int lds_coef = clds <= 40 * 1024 ? 1 : 0;
+    if (dbl) { auto k = &plane_inner_apply_kernel<double>; XRFT_LAUNCH(k, grid, block, lds_coef ? clds : 0, st, (const double*)in, (double*)out, (const double*)coef, (long long)batch, (long long)ny, (long long)nx, i2, lds_coef); }
+    else { auto k = &plane_inner_apply_kernel<float>; XRFT_LAUNCH(k, grid, block, lds_coef ? clds : 0, st, (const float*)in, (float*)out, (const double*)coef, (long long)batch, (long long)ny, (long long)nx, i2, lds_coef); }
     HIP_TRY(hipGetLastError());
     return XRFTHIP_OK;
 }
