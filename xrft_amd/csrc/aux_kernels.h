@@ -63,7 +63,7 @@ __global__ void __launch_bounds__(256) slab_moments_kernel(const void* in, long 
 // One thread per slab.  Least squares on a full regular grid: the centred regressors (i-ibar), (j-jbar) are
 // orthogonal to each other and to 1, so the plane fit of detrend.py:100-113 (normal equations on [1, i+1, j+1])
 // and the line fit of scipy.signal.detrend (detrend.py:64-71) reduce to three independent ratios.
-__global__ void finalize_coef_kernel(const double* part, double* coef, long long batch, long long ny, long long nx, int kind, int nchunk) {
+static __global__ void finalize_coef_kernel(const double* part, double* coef, long long batch, long long ny, long long nx, int kind, int nchunk) {
     const long long b = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= batch) return;
     double acc[6] = {0, 0, 0, 0, 0, 0};
@@ -197,7 +197,7 @@ __global__ void __launch_bounds__(256) block3_moments_kernel(const void* in, lon
 }
 
 // the centred regressors of a full grid are mutually orthogonal: four independent ratios (constant: only the mean)
-__global__ void finalize_coef3_kernel(const double* part, double* coef, long long batch, long long n0, long long n1, long long n2, int kind, int nchunk) {
+static __global__ void finalize_coef3_kernel(const double* part, double* coef, long long batch, long long n0, long long n1, long long n2, int kind, int nchunk) {
     const long long b = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= batch) return;
     double acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -345,7 +345,7 @@ __global__ void __launch_bounds__(kInnerThreads) plane_inner_moments_kernel(cons
     }
 }
 // coef[b][i2] = { c0, c1, c2 }: trend = c0 + c1 i + c2 j (kind 1: the mean)
-__global__ void plane_inner_finalize_kernel(const double* part, double* coef, long long batch, long long ny, long long nx, long long inner2, int nchunk, int kind) {
+static __global__ void plane_inner_finalize_kernel(const double* part, double* coef, long long batch, long long ny, long long nx, long long inner2, int nchunk, int kind) {
     const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= batch * inner2) return;
     const long long b = e / inner2, i2 = e - b * inner2;
@@ -557,7 +557,7 @@ __global__ void __launch_bounds__(256) radial_binsum_det_kernel(const void* in, 
 
 // iso[slab][bin] = sum over the partial tables of the slab's units in a FIXED order (bit-reproducible): 256 threads = 4 segments
 // of units x 64 bins; every segment adds its units in order, the four segment sums are combined in order
-__global__ void __launch_bounds__(256) iso_reduce_kernel(const double* __restrict__ part, double* __restrict__ iso, int upr, int nb,
+static __global__ void __launch_bounds__(256) iso_reduce_kernel(const double* __restrict__ part, double* __restrict__ iso, int upr, int nb,
                                                          const unsigned* __restrict__ tunits, int hw) {
     XRFT_DYN_SMEM(smem_raw);
     double (*seg)[64] = reinterpret_cast<double (*)[64]>(smem_raw);  // [4][64]

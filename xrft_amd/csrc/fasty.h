@@ -998,7 +998,7 @@ __global__ void __launch_bounds__((YRows<NX, FS>::THR), (YRows<NX, FS>::THR / 12
 // (the centred regressors of a full grid are orthogonal, so this IS the least-squares plane of xrft/detrend.py:100-113).
 // Output: corr[x] = wx[x] * (line pass 1 subtracted - plane) as (offset at ibar, slope).
 // ------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) fasty_fit_kernel(const double* colfit, const float* win_x, float* corr, int nx, int ny, int detrend) {
+static __global__ void __launch_bounds__(256) fasty_fit_kernel(const double* colfit, const float* win_x, float* corr, int nx, int ny, int detrend) {
     XRFT_DYN_SMEM(smem_raw);
     double* red = reinterpret_cast<double*>(smem_raw);
     const int slab = blockIdx.x, tid = threadIdx.x;
@@ -1033,7 +1033,7 @@ __global__ void __launch_bounds__(256) fasty_fit_kernel(const double* colfit, co
 //   sum d = sum_x S0[x],   sum (n - nbar) d = sum_x ( nx (S1[x] + ibar S0[x]) + x S0[x] ) - nbar sum d
 // Along column x the line is [a + b (x - nbar + nx ibar)] + (b nx) (i1 - ibar): corr[x] = subtracted line - that (no window).
 // ------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) fasty_fit1d_kernel(const double* colfit, float* corr, int nx, int ny, int detrend) {
+static __global__ void __launch_bounds__(256) fasty_fit1d_kernel(const double* colfit, float* corr, int nx, int ny, int detrend) {
     XRFT_DYN_SMEM(smem_raw);
     double* red = reinterpret_cast<double*>(smem_raw);
     const int slab = blockIdx.x, tid = threadIdx.x;

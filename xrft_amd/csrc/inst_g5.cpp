@@ -1,0 +1,9 @@
+// inst_g5.cpp -- the kernel instantiations of group 5 of instances.h (one of the translation units libxrft_hip.so is built from)
+#include "gpu_rt.h"
+#include "fasty.h"
+#include "fastm.h"
+namespace xrft {
+#define XRFT_KW template __global__
+#define XRFT_KI_GROUP 5
+#include "instances.h"
+}

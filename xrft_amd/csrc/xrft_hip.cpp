@@ -28,6 +28,13 @@
 #include "fasty.h"
 #include "fastm.h"
 #include "tile_fft.h"
+#ifdef XRFT_SPLIT_TUS  /* the library built from several translation units: the fasty / fastm kernels are instantiated in inst_g*.cpp */
+namespace xrft {
+#define XRFT_KW extern template __global__
+#include "instances.h"
+#undef XRFT_KW
+}
+#endif
 
 using namespace xrft;
 
