@@ -490,7 +490,9 @@ def test_fastm_round3_lengths(shape, full, dtype):
 
 @pytest.mark.parametrize("shape,full,dtype", [((1, 1080, 540), False, "float64"), ((1, 640, 320), True, "float32"), ((1, 1280, 640), False, "float64"), ((1, 2160, 1080), False, "float32"),
                                                ((1, 2160, 540), False, "float64"), ((1, 2560, 1280), False, "float32"), ((1, 2880, 1440), False, "float32"), ((1, 2160, 4320), False, "float32"),
-                                               ((1, 2000, 1000), False, "float32"), ((1, 1800, 960), False, "float32"), ((1, 2160, 900), False, "float32")])
+                                               ((1, 2000, 1000), False, "float32"), ((1, 1800, 960), False, "float32"), ((1, 2160, 900), False, "float32"),
+                                               ((1, 768, 384), False, "float64"), ((1, 1536, 768), False, "float32"), ((1, 1600, 1600), False, "float32"), ((1, 1920, 1080), False, "float64"),
+                                               ((1, 1080, 1920), False, "float32"), ((1, 2400, 1200), False, "float32"), ((1, 3072, 1536), False, "float32"), ((1, 2160, 3840), False, "float32"), ((2, 192, 384), True, "float64")])
 def test_fastm_grid_lengths(shape, full, dtype):
     """Gaussian grids (320 x 160 ... 2560 x 1280) and the 1/3 ... 1/12-degree lat/lon grids (1080 x 540 ... 4320 x 2160; 4320 = 15 x 16 x 18,
     the radix-18 Good-Thomas butterfly; 2560, 2880, 4320 in float32 only).  1800 / 2000 / 2160 rows in float32: pass 1 with four sequences per workgroup when
@@ -498,12 +500,12 @@ def test_fastm_grid_lengths(shape, full, dtype):
     cases.run_fastm_cases(shape, full, True, dtype)
 
 
-@pytest.mark.parametrize("shape,dtype", [((1, 2160, 8), "float64"), ((2, 4320, 8), "float32"), ((2, 540, 16), "float32"), ((1, 1280, 8), "float64")])
+@pytest.mark.parametrize("shape,dtype", [((1, 2160, 8), "float64"), ((2, 4320, 8), "float32"), ((2, 540, 16), "float32"), ((1, 1280, 8), "float64"), ((1, 1920, 8), "float64"), ((2, 3840, 8), "float32"), ((2, 768, 16), "float32"), ((1, 1536, 8), "float32")])
 def test_one_axis_grid_lengths(shape, dtype):
     cases.run_yonly_fast_cases(shape, dtype)
 
 
-@pytest.mark.parametrize("shape,dtype", [((3, 2160), "float32"), ((2, 4320), "float32"), ((2, 1080), "float64"), ((3, 320), "float32")])
+@pytest.mark.parametrize("shape,dtype", [((3, 2160), "float32"), ((2, 4320), "float32"), ((2, 1080), "float64"), ((3, 320), "float32"), ((3, 3840), "float32"), ((2, 1920), "float64"), ((3, 384), "float32"), ((2, 1600), "float32")])
 def test_short_axis_grid_lengths(shape, dtype):
     cases.run_xonly_fast_cases(shape, dtype)
 

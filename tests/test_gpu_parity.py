@@ -784,19 +784,21 @@ def test_fastm_latlon_lengths(shape, cross, dtype):
 @pytest.mark.parametrize("shape,cross,dtype", [((2, 1080, 540), True, "float64"), ((3, 640, 320), True, "float32"), ((2, 1280, 640), True, "float64"), ((2, 2160, 1080), True, "float32"),
                                                 ((2, 2160, 1080), True, "float64"), ((2, 2560, 1280), True, "float32"), ((2, 2880, 1440), True, "float32"), ((2, 2160, 4320), False, "float32"),
                                                 ((2, 4320, 2160), True, "float32"), ((3, 320, 640), True, "float64"), ((2, 540, 1080), True, "float32"),
-                                                ((2, 2000, 2000), True, "float32"), ((2, 1800, 3600), True, "float32"), ((2, 2000, 1500), True, "float32"), ((2, 1800, 900), True, "float32"), ((2, 2160, 1000), True, "float32")])
+                                                ((2, 2000, 2000), True, "float32"), ((2, 1800, 3600), True, "float32"), ((2, 2000, 1500), True, "float32"), ((2, 1800, 900), True, "float32"), ((2, 2160, 1000), True, "float32"),
+                                                ((3, 768, 384), True, "float64"), ((2, 1536, 768), True, "float32"), ((2, 1600, 1600), True, "float32"), ((2, 1920, 1080), True, "float64"), ((2, 1080, 1920), True, "float32"),
+                                                ((2, 2400, 1200), True, "float32"), ((2, 3072, 1536), True, "float32"), ((2, 2160, 3840), True, "float32"), ((2, 3840, 2160), True, "float32"), ((3, 192, 384), True, "float64")])
 def test_fastm_grid_lengths(shape, cross, dtype):
     """Gaussian grids (320 x 160 ... 2560 x 1280) and the 1/3 ... 1/12-degree lat/lon grids (1080 x 540 ... 4320 x 2160; 4320 = 15 x 16 x 18,
     the radix-18 Good-Thomas butterfly; 2560, 2880, 4320 in float32 only)."""
     cases.run_fastm_cases(shape, True, cross, dtype)
 
 
-@pytest.mark.parametrize("shape,dtype", [((2, 2160, 64), "float64"), ((2, 4320, 40), "float32"), ((3, 540, 72), "float32"), ((2, 1280, 48), "float64"), ((2, 2880, 24), "float32"), ((2, 320, 136), "float64")])
+@pytest.mark.parametrize("shape,dtype", [((2, 2160, 64), "float64"), ((2, 4320, 40), "float32"), ((3, 540, 72), "float32"), ((2, 1280, 48), "float64"), ((2, 2880, 24), "float32"), ((2, 320, 136), "float64"), ((2, 1920, 40), "float64"), ((2, 3840, 24), "float32"), ((2, 768, 72), "float32"), ((2, 3072, 16), "float32")])
 def test_one_axis_grid_lengths(shape, dtype):
     cases.run_yonly_fast_cases(shape, dtype)
 
 
-@pytest.mark.parametrize("shape,dtype", [((33, 2160), "float32"), ((17, 4320), "float32"), ((65, 1080), "float64"), ((130, 320), "float32"), ((9, 2560), "float32"), ((12, 2160), "float64")])
+@pytest.mark.parametrize("shape,dtype", [((33, 2160), "float32"), ((17, 4320), "float32"), ((65, 1080), "float64"), ((130, 320), "float32"), ((9, 2560), "float32"), ((12, 2160), "float64"), ((11, 3840), "float32"), ((14, 1920), "float64"), ((40, 384), "float32"), ((21, 1600), "float32"), ((13, 2400), "float32")])
 def test_short_axis_grid_lengths(shape, dtype):
     cases.run_xonly_fast_cases(shape, dtype)
 

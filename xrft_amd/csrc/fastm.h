@@ -55,6 +55,15 @@ XRFT_MRAD(2160, 12, 12, 15);
 XRFT_MRAD(2560, 10, 16, 16);
 XRFT_MRAD(2880, 12, 15, 16);
 XRFT_MRAD(4320, 15, 16, 18);
+XRFT_MRAD(192, 4, 6, 8);      // (3 x 2^k: the Gaussian grids T63 ... T511 and their halves -- 192 x 96, 384 x 192, 768 x 384, 1536 x 768; TL799: 1600 x 800; HD / 4K frames: 1920 x 1080, 3840 x 2160)
+XRFT_MRAD(384, 6, 8, 8);
+XRFT_MRAD(768, 8, 8, 12);
+XRFT_MRAD(1536, 8, 12, 16);
+XRFT_MRAD(1600, 10, 10, 16);
+XRFT_MRAD(1920, 10, 12, 16);
+XRFT_MRAD(2400, 10, 12, 20);
+XRFT_MRAD(3072, 12, 16, 16);
+XRFT_MRAD(3840, 15, 16, 16);
 XRFT_MRAD(256, 4, 8, 8);   // (powers of two: float64 only -- float32 has the register-resident kernels of fasty.h)
 XRFT_MRAD(512, 8, 8, 8);
 XRFT_MRAD(1024, 8, 8, 16);
@@ -72,8 +81,8 @@ XRFT_MRAD(1000, 10, 10, 10);
 XRFT_MRAD(1200, 10, 10, 12);
 #undef XRFT_MRAD
 // the lengths the host dispatches on: X(N) for every entry
-#define XRFT_M_LATLON(X) X(180) X(240) X(320) X(360) X(480) X(500) X(540) X(640) X(720) X(900) X(960) X(1000) X(1080) X(1200) X(1280) X(1440) X(1500) X(1800) X(2000) X(2160)  /* both axes of a slab: the lat/lon and Gaussian-grid lengths + 500, 1000, 1200, 1500, 2000 */
-#define XRFT_M_F32ONLY(X) X(2560) X(2880) X(3000) X(3600) X(4320)  /* float32 only: a pair of complex128 sequences of this length does not fit the LDS beside a second workgroup */
+#define XRFT_M_LATLON(X) X(180) X(192) X(240) X(320) X(360) X(384) X(480) X(500) X(540) X(640) X(720) X(768) X(900) X(960) X(1000) X(1080) X(1200) X(1280) X(1440) X(1500) X(1800) X(1920) X(2000) X(2160)  /* both axes of a slab: the lat/lon and Gaussian-grid lengths + 500, 1000, 1200, 1500, 2000 */
+#define XRFT_M_F32ONLY(X) X(1536) X(1600) X(2400) X(2560) X(2880) X(3000) X(3072) X(3600) X(3840) X(4320)  /* float32 only: a pair of complex128 sequences of this length does not fit the LDS beside a second workgroup */
 #define XRFT_M_POW2(X) X(256) X(512) X(1024)
 #define XRFT_M_WIDE32(X) X(1800) X(2000) X(2160)  /* float32: pass 1 also exists with four sequences per workgroup (832 threads at most) */
 #define XRFT_M_YONLY(X) X(100) X(128) X(200) X(400) X(600) X(800)
