@@ -5,10 +5,11 @@
     python bench.py --gpus 1 --steps K --warmup W
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W        (no launcher: the script starts its N ranks itself, same JSON line)
 
 --workload c2 | c4 | c5 runs BASELINE.json configs[1] / [3] / [4] through the same harness (dft along x of (1024, 65536) float32;
-cross_spectrum + isotropic_power_spectrum of two (nt, 2048, 2048) fields with the all_gathers; power_spectrum of (64, 1440, 720)
-float64) -- same JSON line, roofline on that configuration's own algorithmic bytes.
+cross_spectrum + isotropic_power_spectrum of two (nt, 2048, 2048) fields with the all_gathers; power_spectrum of (450, 1440, 720)
+float64, the per-GPU share of the configuration's 3600 slabs) -- same JSON line, roofline on that configuration's own algorithmic bytes.
 
 One "step" = one call of ``xrft_amd.power_spectrum`` over the rank's whole (nt, ny, nx) cube, input already
 resident in HBM.  Batches shard over ranks as independent time slabs (weak scaling: nt per GPU is fixed); there is
@@ -20,8 +21,10 @@ Extra objects on the JSON line:
                  longest kernel alone (its launch's points / its average launch duration, from HIP events recorded by
                  the library on the launch stream inside the timed region, xrfthip_plan_set_profiling); "traffic" the
                  HBM bytes of one step measured with rocprofv3 PMC counters (profiles/r03_traffic.json, used only when its
-                 stamp matches the SHA-1 of xrft_amd/csrc; null otherwise); "two_pass_floor" what the memory system allows the
-                 two passes' access patterns with no arithmetic (scripts/ubench/fused.hip, profiles/r03_ubench_fused.txt).
+                 stamp matches the SHA-1 of xrft_amd/csrc; null otherwise); "claimed_floor" is NOT a measurement of this run: the
+                 builder's claim of what the two passes' access patterns cost with no arithmetic (scripts/ubench/fused.hip as
+                 timed in profiles/r03_ubench_fused.txt), carried with the SHA-1 of that skeleton's source and of the kernel
+                 sources it was shaped after, and dropped (null) once either no longer matches the tree.
   cpu_baseline : the CPU oracle (numpy/scipy restatement of the reference; the reference itself needs xarray,
                  which the image lacks) timed on a bounded sample of the same workload, 1 thread.
 """
@@ -82,8 +85,10 @@ def parse_args(argv=None):
     ap.add_argument("--workload", choices=["ps", "c2", "c4", "c5"], default="ps",
                     help="ps: BASELINE.json configs[2] (power_spectrum, the headline metric); c2: configs[1] -- dft along x of "
                          "(1024, 65536) float32; c4: configs[3] -- cross_spectrum + isotropic_power_spectrum of two fields per rank, the "
-                         "isotropic results all-gathered over RCCL; c5: configs[4] -- power_spectrum of (64, 1440, 720) float64, linear detrend + Hann")
-    return ap.parse_args(argv)
+                         "isotropic results all-gathered over RCCL; c5: configs[4] -- power_spectrum of (450, 1440, 720) float64 per GPU (3600 / 8), linear detrend + Hann")
+    args = ap.parse_args(argv)
+    args.argv = list(sys.argv[1:] if argv is None else argv)
+    return args
 
 
 class GpuEnv:
@@ -94,6 +99,12 @@ class GpuEnv:
     backend_label = "nccl (RCCL over xGMI)"
     data_label = "synthetic"
     measures = True
+    script = os.path.abspath(__file__)  # what launch_ranks() starts once per rank
+
+    def visible_devices(self):
+        import torch
+
+        return torch.cuda.device_count()
 
     def device(self, local):
         import torch
@@ -132,8 +143,45 @@ def csrc_sha1():
     return h.hexdigest()
 
 
+def _free_port():
+    import socket
+
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def launch_ranks(args, env):
+    """`python bench.py --gpus N` with no launcher around it (no WORLD_SIZE in the environment): start the N ranks here, one
+    process per GPU under torch.distributed.run on 127.0.0.1 (rank -> GPU by LOCAL_RANK in run()), and hand their exit status
+    back.  Rank 0 of the children prints the ONE JSON line on this process's stdout.  Fewer than N visible devices is an
+    error, said before anything is started."""
+    import subprocess
+
+    have = env.visible_devices()
+    if have < args.gpus:
+        sys.stderr.write(f"bench.py: --gpus {args.gpus} but only {have} device(s) visible "
+                         f"(HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES = {os.environ.get('HIP_VISIBLE_DEVICES')!r} / "
+                         f"{os.environ.get('ROCR_VISIBLE_DEVICES')!r}); not starting any rank\n")
+        return 3
+    child_env = dict(os.environ)
+    child_env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # the host driver supports dmabuf IPC only (RCCL over xGMI needs it)
+    child_env.setdefault("OMP_NUM_THREADS", "1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), env.script] + list(args.argv)
+    r = subprocess.run(cmd, env=child_env)
+    if r.returncode != 0:
+        sys.stderr.write(f"bench.py: the {args.gpus}-rank run failed (exit status {r.returncode}): {' '.join(cmd)}\n")
+    return r.returncode
+
+
 def main(argv=None):
-    return run(parse_args(argv), GpuEnv())
+    out = run(parse_args(argv), GpuEnv())
+    if isinstance(out, int):  # the exit status of a self-launched multi-rank run
+        sys.exit(out)
+    return out
 
 
 def run(args, env):
@@ -141,6 +189,8 @@ def run(args, env):
     import torch
 
     warnings.simplefilter("ignore")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return launch_ranks(args, env)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -151,7 +201,10 @@ def run(args, env):
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         env.init_process_group(dist, local)
-    assert world == max(args.gpus, 1), f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    if world != max(args.gpus, 1):
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
+    if dist is not None and dist.get_world_size() != world:
+        raise SystemExit(f"bench.py: the process group reports {dist.get_world_size()} ranks, WORLD_SIZE={world}")
     dev = env.device(local)
 
     import xrft_amd as xrft
@@ -166,6 +219,8 @@ def run(args, env):
         ny = nx = 2048  # BASELINE.json configs[3]
     if args.workload == "c5" and default_shape:
         ny, nx = 1440, 720  # configs[4]
+        if args.nt == 64 and args.scaling == "weak":
+            args.nt = 450  # the configuration's per-GPU share: 3600 slabs over 8 GPUs (3.7 GB in, 3.7 GB out)
     if args.workload == "c2":
         ny, nx = 1, (65536 if default_shape else args.nx)  # configs[1]: (1024, 65536) per GPU, one long axis
         if args.nt == 64:
@@ -281,8 +336,17 @@ def run(args, env):
             try:
                 with open(os.path.join(REPO, "profiles", "r03_traffic.json")) as fh:
                     tj = json.load(fh)
-                ceiling = tj.get("two_pass_floor")
                 if args.workload == "ps" and (ny, nx) == (4096, 4096):
+                    ceiling = tj.get("claimed_floor") or tj.get("two_pass_floor")
+                    if ceiling is not None:  # a claim, not a measurement of this run: it travels with the skeleton's source hash
+                        import hashlib
+
+                        with open(os.path.join(REPO, "scripts", "ubench", "fused.hip"), "rb") as fh:
+                            sha = hashlib.sha1(fh.read()).hexdigest()
+                        ceiling = dict(ceiling, claim="builder's claim from a committed skeleton timing, not measured in this run",
+                                       ubench_sha1=sha)
+                        if tj.get("ubench_sha1") not in (None, sha):
+                            ceiling = None  # the skeleton changed since it was timed
                     if tj.get("csrc_sha1") == csrc_sha1():
                         traffic = tj["path_hbm_bytes_per_slab"] * nt
                         tnote = tj.get("note")
@@ -310,7 +374,7 @@ def run(args, env):
                 "bytes_per_point": bpp,
                 "kernels_ms_per_step": {k: round(v[1] / args.steps, 3) for k, v in kern.items()},
                 "sum_kernels_ms_per_step": round(kernel_ms, 3),
-                "two_pass_floor": ceiling,
+                "claimed_floor": ceiling,
             }
         # ---- CPU baseline (the oracle on a bounded sample, 1 thread) + parity of the same slabs
         cpu = None

@@ -18,6 +18,10 @@ class EmulatedEnv:
     backend_label = "gloo"
     data_label = "synthetic (EMULATED library on CPU: rank-logic test, not a measurement)"
     measures = False
+    script = os.path.abspath(__file__)
+
+    def visible_devices(self):
+        return int(os.environ.get("XRFT_EMU_DEVICES", "8"))  # the harness pretends to a node's worth of devices
 
     def device(self, local):
         import torch
@@ -38,4 +42,6 @@ class EmulatedEnv:
 
 
 if __name__ == "__main__":
-    bench.run(bench.parse_args(sys.argv[1:]), EmulatedEnv())
+    out = bench.run(bench.parse_args(sys.argv[1:]), EmulatedEnv())
+    if isinstance(out, int):
+        sys.exit(out)

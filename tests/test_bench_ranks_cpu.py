@@ -22,16 +22,25 @@ def _free_port():
     return p
 
 
-def _run(world, extra):
+def _run(world, extra, launcher=True, environ=None, expect_status=0):
     sys.path.insert(0, os.path.join(HERE, "emu"))
     import build_emu
 
     build_emu.build()  # once, before the ranks race for it
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
-           "--master-port", str(_free_port()), os.path.join(HERE, "bench_ranks_harness.py"), "--gpus", str(world), "--steps", "2", "--warmup", "1",
-           "--ny", "256", "--nx", "256", "--cpu-slabs", "0"] + extra
+    cmd = [sys.executable]
+    if launcher:  # the driver's form: torch.distributed.run around the script
+        cmd += ["-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
+                "--master-port", str(_free_port())]
+    cmd += [os.path.join(HERE, "bench_ranks_harness.py"), "--gpus", str(world), "--steps", "2", "--warmup", "1",
+            "--ny", "256", "--nx", "256", "--cpu-slabs", "0"] + extra
     env = dict(os.environ, OMP_NUM_THREADS="1", XRFT_EMU_THREADS="2")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    env.update(environ or {})
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=REPO)
+    if expect_status:
+        assert r.returncode == expect_status, (r.returncode, r.stderr[-3000:])
+        return r
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, r.stdout[-2000:]  # rank 0 prints ONE JSON line
@@ -63,6 +72,20 @@ def test_bench_two_ranks_c5_float64():
     out = _run(2, ["--nt", "3", "--workload", "c5", "--ny", "360", "--nx", "360", "--scaling", "strong"])
     assert out["n_gpus"] == 2 and out["dtype"] == "f64" and "fp64" in out["metric"] and out["config"]["nt_total"] == 3
     assert "fastm_cols" in out["roofline"]["kernels_ms_per_step"] and out["roofline"]["bytes_per_point"] == 16.0
+
+
+def test_bench_plain_command_starts_its_own_ranks():
+    """`python bench.py --gpus 2` with no launcher around it (how the driver starts the 1-GPU bench): the script starts its two
+    ranks itself, the process group reports two, ONE JSON line comes out."""
+    out = _run(2, ["--nt", "3"], launcher=False)
+    assert out["n_gpus"] == 2 and out["config"]["ranks_in_process_group"] == 2 and out["config"]["nt_total"] == 6
+    assert out["config"]["process_group_backend"] == "gloo" and out["value"] > 0
+
+
+def test_bench_plain_command_refuses_more_ranks_than_devices():
+    """Fewer visible devices than --gpus: a clear message and a non-zero status before any rank is started."""
+    r = _run(4, ["--nt", "2"], launcher=False, environ={"XRFT_EMU_DEVICES": "2"}, expect_status=3)
+    assert "only 2 device(s) visible" in r.stderr and not [l for l in r.stdout.splitlines() if l.startswith("{")]
 
 
 def test_bench_has_no_emulator_switch():
