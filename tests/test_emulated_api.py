@@ -468,6 +468,34 @@ def test_huge_slab_along_a_first_axis_takes_the_transposing_path():
     assert "ny * nx > (1 << 31) - 1" in src  # _execute_axis_y returns None (-> _arrange) before asking for the plan
 
 
+def test_detrend_inner_scratch_is_bounded_and_extents_are_checked():
+    """the partial sums of xrfthip_detrend_inner are sized by the chunks a (batch, inner) pair can use (they were 257 chunks'
+    worth always: 6.4 GB for detrend(da, 'time') on a 1440 x 720 grid, 103 GB at 4096^2), extents beyond the 32-bit positions are refused
+    with BAD_ARG (never truncated), and the API takes the transposing path for them."""
+    import torch
+
+    dll = _lib.load()
+    for inner in (1440 * 720, 2048 * 2048, 4096 * 4096):
+        nws = dll.xrfthip_detrend_inner_workspace_bytes(_lib.F32, 1, inner)
+        assert 0 < nws <= inner * 24 * 4 + 256, (inner, nws)   # <= 3 chunks of three float64 sums per element + the coefficients
+    assert dll.xrfthip_detrend_inner_workspace_bytes(_lib.F32, 1, 16) == ((16 * 24 * 257 + 255) // 256) * 256  # a short inner extent keeps its 256 chunks
+    x = torch.zeros(16)
+    assert dll.xrfthip_detrend_inner(_lib.F32, 1, 1, 1, 1000, (1 << 30) + 1, _lib.DETREND_LINEAR, x.data_ptr(), x.data_ptr(), x.data_ptr(), 1 << 62, None) == -1
+    from xrft_amd import engine
+
+    class _Fake:  # a tensor-like with the extents only
+        dtype = torch.float32
+        shape = (1000, (1 << 30) + 1)
+        def is_contiguous(self): return True
+    assert engine.detrend_inner(_Fake(), 0, 1, _lib.DETREND_LINEAR) is None
+    # a long inner extent with few samples per element still runs where it lies and matches numpy
+    rng = np.random.default_rng(5)
+    v = rng.standard_normal((6, 40, 70)) + np.arange(6)[:, None, None] * 0.3
+    got = api.detrend(api.DataArray(v, ("t", "y", "x"), {}), "t", "linear")
+    import scipy.signal as sps
+    assert np.abs(np.asarray(got.values) - sps.detrend(v, axis=0)).max() < 1e-12
+
+
 def test_fused_radial_sums_compact_and_full_bin_codes():
     cases.run_fused_radial_code_forms(256)
 

@@ -479,7 +479,9 @@ def _execute_inner(c, da, mode, scale):
     shape = list(t.shape)
     inner = int(np.prod(shape[second + 1:], dtype=np.int64))
     batch = int(np.prod(shape[:first], dtype=np.int64))
-    if inner < 2 or inner * shape[second] > (1 << 30):
+    # the extents the composite plan carries in 32 bits (create_inner_plan; the one-axis stages): known limits are checked HERE,
+    # so that a BAD_ARG from the library means a bug in the descriptor and is raised, not hidden behind the transposing path
+    if inner < 2 or inner * shape[second] > (1 << 30) or shape[first] * shape[second] * inner > (1 << 31) - 1:
         return None
     flags, win, ph = _flags_tables(c, da)
     if mode == _lib.OUT_POWER:
@@ -491,7 +493,7 @@ def _execute_inner(c, da, mode, scale):
     try:
         plan = _get_plan(**kw)
     except _lib.XrftHipError as e:
-        if e.status in (_lib.UNSUPPORTED_LENGTH, -1):  # a length or extent the one-axis plans do not take: the transposing path
+        if e.status == _lib.UNSUPPORTED_LENGTH:  # a length the one-axis plans do not take: the transposing path
             return None
         raise
     out, _ = plan.execute(t)
@@ -1043,8 +1045,10 @@ def detrend(da, dim, detrend_type="constant"):
     if (len(dim) <= 2 and ax_sorted[-1] != len(da.dims) - 1 and ax_sorted == list(range(ax_sorted[0], ax_sorted[0] + len(dim)))
             and int(np.prod(t.shape[ax_sorted[-1] + 1:], dtype=np.int64)) > 1):
         # one or two adjacent axes that are not the trailing ones: detrended where they lie (xrfthip_detrend_inner), no transposed copies
+        # -- unless the extents exceed what the library carries in 32 bits, or its scratch would outgrow the array (None: transposing path)
         out = engine.detrend_inner(t.contiguous(), ax_sorted[0], len(dim), kind)
-        return to_like(DataArray(out, da.dims, da.coords, da.name, da.attrs), src)
+        if out is not None:
+            return to_like(DataArray(out, da.dims, da.coords, da.name, da.attrs), src)
     if tuple(order) != tuple(da.dims):
         t = t.permute([da.get_axis_num(d) for d in order])
     t = t.contiguous()

@@ -301,7 +301,7 @@ __global__ void __launch_bounds__(256) table_mul_kernel(const void* in, const C2
 // Detrending with the independent elements INNERMOST: data [batch][ny][nx][inner2] (inner2 counts real components: 2 per complex
 // sample), one mean / least-squares plane over (ny, nx) per (batch, inner2) element (xrft/detrend.py:54-55, 100-113 for two adjacent
 // axes that are not the trailing ones).  A workgroup = IB consecutive inner2 indices (lanes: contiguous) x XS columns; rows are dealt
-// round-robin to the gridDim.x chunks of a slab; part[b][chunk][i2][3] = { sum d, sum (i - ibar) d, sum (j - jbar) d }, added in
+// round-robin to the gridDim.y chunks of a slab; part[b][chunk][i2][3] = { sum d, sum (i - ibar) d, sum (j - jbar) d }, added in
 // chunk order by plane_inner_finalize_kernel (no atomics: bit-reproducible).
 // (round 3: ib = min(inner2, 1024) lanes across the inner index and xs = 1024 / ib column slots, chosen at launch -- fixed at 32 x 8, a
 // 16-element inner dimension left half of every wave idle on 64-byte pieces: 0.86 ms for a 268-MB array)
@@ -311,12 +311,12 @@ __global__ void __launch_bounds__(kInnerThreads) plane_inner_moments_kernel(cons
     XRFT_DYN_SMEM(smem_raw);
     double* red = reinterpret_cast<double*>(smem_raw);  // [xsn][3][ib]
     const int li = threadIdx.x % ib, xs = threadIdx.x / ib;
-    const long long i2 = (long long)blockIdx.y * ib + li, b = blockIdx.z;
+    const long long i2 = (long long)blockIdx.x * ib + li, b = blockIdx.z;  // grid = (tiles of the inner index, row chunks, batch)
     const double ibar = 0.5 * (double)(ny - 1), jbar = 0.5 * (double)(nx - 1);
     const bool live = xs < xsn && i2 < inner2;
     double s0 = 0.0, si = 0.0, sj = 0.0;
     if (live) {
-        for (long long i = blockIdx.x; i < ny; i += gridDim.x) {
+        for (long long i = blockIdx.y; i < ny; i += gridDim.y) {
             const T* row = in + ((b * ny + i) * nx) * inner2 + i2;
             // four independent loads per trip (one load in flight per thread ran the pass at a fifth of the copy rate); the four partial
             // sums are combined in a fixed order
@@ -340,7 +340,7 @@ __global__ void __launch_bounds__(kInnerThreads) plane_inner_moments_kernel(cons
     __syncthreads();
     if (xs == 0 && i2 < inner2) {
         for (int k = 1; k < xsn; ++k) { s0 += red[(k * 3 + 0) * ib + li]; si += red[(k * 3 + 1) * ib + li]; sj += red[(k * 3 + 2) * ib + li]; }
-        double* dst = part + ((b * gridDim.x + blockIdx.x) * inner2 + i2) * 3;
+        double* dst = part + ((b * gridDim.y + blockIdx.y) * inner2 + i2) * 3;
         dst[0] = s0; dst[1] = si; dst[2] = sj;
     }
 }
@@ -369,7 +369,8 @@ template <typename T>
 __global__ void __launch_bounds__(256) plane_inner_apply_kernel(const T* __restrict__ in, T* __restrict__ out, const double* __restrict__ coef, long long batch, long long ny, long long nx, long long inner2, int lds_coef) {
     XRFT_DYN_SMEM(smem_raw);
     double* cl = reinterpret_cast<double*>(smem_raw);  // [inner2][3]
-    const unsigned rowlen = (unsigned)(nx * inner2), in2 = (unsigned)inner2;
+    const long long rowlen = nx * inner2;  // (beyond 2^32 for a long inner extent: detrend along time of a (1000, 4096, 2048) array)
+    const unsigned in2 = (unsigned)inner2;
     const long long rows = batch * ny, per = (rows + gridDim.x - 1) / gridDim.x;
     const long long r_lo = (long long)blockIdx.x * per, r_hi = r_lo + per < rows ? r_lo + per : rows;
     const unsigned dj = 256u / in2, di = 256u % in2;  // a step of 256 elements in (j, i2)
@@ -388,12 +389,12 @@ __global__ void __launch_bounds__(256) plane_inner_apply_kernel(const T* __restr
         const T* src = in + r * rowlen;
         T* dst = out + r * rowlen;
         unsigned j = threadIdx.x / in2, i2 = threadIdx.x - j * in2;
-        for (unsigned e0 = threadIdx.x; e0 < rowlen; e0 += 4 * 256) {
+        for (long long e0 = threadIdx.x; e0 < rowlen; e0 += 4 * 256) {
             T v[4];
             unsigned jj[4], ii[4];
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
-                const unsigned e = e0 + u * 256;
+                const long long e = e0 + u * 256;
                 jj[u] = j; ii[u] = i2;
                 v[u] = e < rowlen ? src[e] : (T)0;
                 j += dj; i2 += di;
@@ -401,7 +402,7 @@ __global__ void __launch_bounds__(256) plane_inner_apply_kernel(const T* __restr
             }
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
-                const unsigned e = e0 + u * 256;
+                const long long e = e0 + u * 256;
                 if (e < rowlen) {
                     const double* c = ct + (size_t)ii[u] * 3;
                     dst[e] = (T)((double)v[u] - (c[0] + c[1] * fi + c[2] * (double)jj[u]));

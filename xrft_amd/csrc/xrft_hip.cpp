@@ -2484,13 +2484,17 @@ int xrfthip_table_mul(int32_t dtype, int64_t batch, int64_t n_in, int64_t n_out,
 }
 
 static constexpr int kInnerMaxChunks = 256;
-static int inner_chunks(long long ny, long long batch, long long i2) {  // enough workgroups to fill the chip (a (y, x, t) array is ONE slab)
+// Row chunks per (batch, inner tile): enough workgroups to fill the chip (a (y, x, t) array is ONE slab), never more than the rows.  The cap
+// depends only on (batch, inner) -- what the workspace query knows -- and falls to 1 as soon as the tiles alone fill the chip, so the partial
+// sums stay a few MB whatever the inner extent (they were 257 chunks' worth always: 6168 bytes per inner element, 103 GB for a 4096^2 grid).
+static int inner_chunk_cap(long long batch, long long i2) {
     const long long tiles = std::max<long long>(1, batch * ((i2 + kInnerThreads - 1) / kInnerThreads));
-    return (int)std::max<long long>(1, std::min<long long>(std::min<long long>(kInnerMaxChunks, ny), (2048 + tiles - 1) / tiles));
+    return (int)std::max<long long>(1, std::min<long long>(kInnerMaxChunks, (2048 + tiles - 1) / tiles));
 }
+static int inner_chunks(long long ny, long long batch, long long i2) { return (int)std::max<long long>(1, std::min<long long>(inner_chunk_cap(batch, i2), ny)); }
 static size_t detrend_inner_ws(bool cplx, long long batch, long long inner) {
     const size_t i2 = (size_t)inner * (cplx ? 2 : 1);
-    return (((size_t)std::max<long long>(batch, 1) * i2 * 3 * sizeof(double) * (kInnerMaxChunks + 1)) + 255) & ~(size_t)255;  // <= 256 chunks of partial sums + the coefficients
+    return (((size_t)std::max<long long>(batch, 1) * i2 * 3 * sizeof(double) * ((size_t)inner_chunk_cap(batch, (long long)i2) + 1)) + 255) & ~(size_t)255;  // partial sums of <= cap chunks + the coefficients
 }
 static int run_detrend_inner(int32_t dtype, int32_t ndim, long long batch, long long ny, long long nx, long long inner, int32_t kind, const void* in, void* out,
                              char* ws, hipStream_t st) {
@@ -2499,11 +2503,11 @@ static int run_detrend_inner(int32_t dtype, int32_t ndim, long long batch, long 
     const long long i2 = inner * (cplx ? 2 : 1);
     const int nch = inner_chunks(ny, batch, i2);
     double* part = reinterpret_cast<double*>(ws);
-    double* coef = part + (size_t)batch * kInnerMaxChunks * i2 * 3;
+    double* coef = part + (size_t)batch * inner_chunk_cap(batch, i2) * i2 * 3;
     for (long long b0 = 0; b0 < batch; b0 += 65535) {  // grid.z limit
         const long long bc = std::min<long long>(65535, batch - b0);
         const int ib = (int)std::min<long long>(i2, kInnerThreads), xsn = kInnerThreads / ib;  // lanes across the inner index x column slots
-        const dim3 grid((unsigned)nch, (unsigned)((i2 + ib - 1) / ib), (unsigned)bc), block(kInnerThreads);
+        const dim3 grid((unsigned)((i2 + ib - 1) / ib), (unsigned)nch, (unsigned)bc), block(kInnerThreads);  // (tiles of the inner index on grid.x: no 65535 limit)
         const size_t lds = (size_t)xsn * 3 * ib * sizeof(double), eoff = (size_t)b0 * ny * nx * i2;
         if (dbl) { auto k = &plane_inner_moments_kernel<double>; XRFT_LAUNCH(k, grid, block, lds, st, (const double*)in + eoff, (long long)ny, (long long)nx, i2, part + (size_t)b0 * nch * i2 * 3, ib, xsn); }
         else { auto k = &plane_inner_moments_kernel<float>; XRFT_LAUNCH(k, grid, block, lds, st, (const float*)in + eoff, (long long)ny, (long long)nx, i2, part + (size_t)b0 * nch * i2 * 3, ib, xsn); }
@@ -2531,6 +2535,7 @@ int xrfthip_detrend_inner(int32_t dtype, int32_t ndim, int64_t batch, int64_t ny
     if (!d_in || !d_out || dtype < XRFTHIP_F32 || dtype > XRFTHIP_C128 || batch < 0 || ny < 1 || nx < 1 || inner < 1) return XRFTHIP_BAD_ARG;
     if ((ndim != 1 && ndim != 2) || (ndim == 1 && ny != 1)) return XRFTHIP_BAD_ARG;
     if (detrend_type != XRFTHIP_DETREND_CONSTANT && detrend_type != XRFTHIP_DETREND_LINEAR) return XRFTHIP_BAD_ARG;
+    if (inner > (1LL << 30) || nx > (1LL << 31) - 1 || ny > (1LL << 31) - 1) return XRFTHIP_BAD_ARG;  // (a row's length nx * inner is carried in 64 bits, the positions within it in 32)
     if (!d_workspace || ws_bytes < xrfthip_detrend_inner_workspace_bytes(dtype, batch, inner)) return XRFTHIP_WORKSPACE_TOO_SMALL;
     if (batch == 0) return XRFTHIP_OK;
     return run_detrend_inner(dtype, ndim, batch, ny, nx, inner, detrend_type, d_in, d_out, (char*)d_workspace, (hipStream_t)stream);

@@ -69,9 +69,14 @@ def batch_mean_allreduce(local, dim, total, group=None):
     t = local.data if isinstance(local.data, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(local.data))
     if dist.get_backend(group) == "nccl" and not t.is_cuda:
         t = t.cuda()
-    if t.device.type != engine.device_type():
-        t = t.to(engine.device_type())
-    s = engine.reduce_axis(t, ax, 1.0 / float(total))
+    if (t.is_floating_point() or t.is_complex()) and t.device.type == engine.device_type() and t.shape[ax] > 0:
+        s = engine.reduce_axis(t, ax, 1.0 / float(total))
+    else:
+        # host-resident data under a CPU backend (they stay where the process group can reduce them), integer / bool data, an empty
+        # shard: the local term on the host, same order and accumulation type (float64, slab order) as the library kernel
+        acc = torch.complex128 if t.is_complex() else torch.float64
+        s = t.to(acc).cumsum(ax).select(ax, -1) if t.shape[ax] > 0 else torch.zeros(t.shape[:ax] + t.shape[ax + 1:], dtype=acc, device=t.device)
+        s = (s * (1.0 / float(total))).to(t.dtype if (t.is_floating_point() or t.is_complex()) else torch.float64).contiguous()
     buf = torch.view_as_real(s) if s.is_complex() else s
     dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=group)
     dims = [d for d in local.dims if d != dim]

@@ -123,9 +123,10 @@ class SpectralPlan:
         # The C plan is immutable after creation, so nothing plan-wide is locked: threads on different streams enqueue
         # concurrently.  Callers that share a stream share its scratch buffer: their enqueues (a short sequence of kernel
         # launches each) must not interleave, hence one lock per (device, stream).
-        ws, lock = _workspace(dev, stream, self.workspace_bytes)
-        with lock:
-            ws, _ = _workspace(dev, stream, self.workspace_bytes)  # (another thread may have grown it meanwhile)
+        with _stream_lock(dev, stream):
+            # grown (and the outgrown buffer retired) only HERE, under the stream's lock: no other thread is between its look-up and
+            # its enqueue on this stream, so the event recorded at retirement really follows every use of the old buffer
+            ws = _workspace(dev, stream, self.workspace_bytes)
             _lib.check(self._dll.xrfthip_exec(self._h, _ptr(in0), _ptr(in1), _ptr(out if want_out else None), _ptr(iso),
                                               _ptr(ws), ws.numel(), stream))
         return (out if want_out else None), iso
@@ -139,7 +140,17 @@ _WS_RETIRED = []  # (buffer, event) of outgrown buffers: kernels enqueued earlie
 _WS_LOCK = threading.Lock()
 
 
+def _stream_lock(dev, stream):
+    key = (str(dev), stream.value)
+    with _WS_LOCK:
+        lock = _WS_LOCKS.get(key)
+        if lock is None:
+            lock = _WS_LOCKS[key] = threading.Lock()
+        return lock
+
+
 def _workspace(dev, stream, nbytes):
+    """The stream's scratch buffer, grown if needed.  Call with _stream_lock(dev, stream) held."""
     key = (str(dev), stream.value)
     with _WS_LOCK:
         # outgrown buffers go once the work that may still use them has finished (an event recorded on their stream when they retired)
@@ -155,10 +166,7 @@ def _workspace(dev, stream, nbytes):
                     ev.record(torch.cuda.current_stream(dev))
                     _WS_RETIRED.append((ws, ev))
             ws = _WS[key] = torch.empty(want, dtype=torch.uint8, device=dev)
-        lock = _WS_LOCKS.get(key)
-        if lock is None:
-            lock = _WS_LOCKS[key] = threading.Lock()
-        return ws, lock
+        return ws
 
 
 def clear_workspaces():
@@ -206,8 +214,12 @@ def detrend_inner(x, axis0, naxes, kind):
     ny = x.shape[axis0] if naxes == 2 else 1
     nx = x.shape[axis0 + naxes - 1]
     inner = int(np.prod(x.shape[axis0 + naxes:], dtype=np.int64))
-    out = torch.empty_like(x)
+    if inner > (1 << 30) or nx > (1 << 31) - 1 or ny > (1 << 31) - 1:
+        return None  # beyond the extents xrfthip_detrend_inner takes (it would say BAD_ARG): the caller transposes
     nws = int(dll.xrfthip_detrend_inner_workspace_bytes(_DTYPES[x.dtype], batch, inner))
+    if nws > max(x.numel() * x.element_size(), 64 << 20):
+        return None  # a few samples per element: the partial sums would outgrow the array
+    out = torch.empty_like(x)
     ws = torch.empty(max(nws, 16), dtype=torch.uint8, device=x.device)
     _lib.check(dll.xrfthip_detrend_inner(_DTYPES[x.dtype], naxes, batch, ny, nx, inner, kind, _ptr(x), _ptr(out), _ptr(ws), nws, _stream_handle(x)))
     return out

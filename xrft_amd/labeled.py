@@ -205,8 +205,9 @@ class DataArray:
         keep = [d for d in self.dims if d not in dims]
         coords = {k: c for k, c in self.coords.items() if not (set(c.dims) & set(dims))}
         data = self.data
-        if _is_torch(data) and data.device.type != "cpu":
-            # device data stay on the device: one library kernel per reduced dim (xrfthip_reduce_axis: float64 accumulation in
+        if (_is_torch(data) and data.device.type != "cpu" and (data.is_floating_point() or data.is_complex())
+                and all(self.sizes[d] > 0 for d in dims)):
+            # floating-point device data stay on the device: one library kernel per reduced dim (xrfthip_reduce_axis: float64 accumulation in
             # index order, bit-reproducible) -- e.g. the batch mean of isotropic spectra, test_xrft.py:1011-1013
             from . import engine
 
