@@ -528,9 +528,21 @@ def run_fourstep_1d(n=65536, nt=3):
     da, od = pair(v, ("t", "x"), c)
     od64 = o.OArr(v.astype("float64"), ("t", "x"), c)
     worst = 0.0
+    # 65536 samples = one row per workgroup, in registers, ONE pass (csrc/fastr.h); longer rows: the two four-step passes (fasty.h)
+    tag = "[fastr]" if n == 65536 else "four-step]"
     for kw in (dict(), dict(true_phase=False, shift=False), dict(true_amplitude=False, shift=False)):
         worst = max(worst, check(xa.fft(da, dim=["x"], **kw), o.fft(od, dim=["x"], **kw), 3e-6))
-    assert "four-step]" in next(reversed(xa.api._plan_cache.values())).describe()
+    assert tag in next(reversed(xa.api._plan_cache.values())).describe()
+    if n == 65536:  # real_dim: the half spectrum k = 0..n/2, its power spectrum counted twice inside (xrft.py:400-404, 673-682)
+        for kw in (dict(), dict(true_phase=False)):
+            worst = max(worst, check(xa.fft(da, dim=["x"], real_dim="x", **kw), o.fft(od, dim=["x"], real_dim="x", **kw), 3e-6))
+            assert tag in next(reversed(xa.api._plan_cache.values())).describe()
+        worst = max(worst, check(xa.power_spectrum(da, dim=["x"], real_dim="x"), o.power_spectrum(od, dim=["x"], real_dim="x"), 3e-6))
+        assert tag in next(reversed(xa.api._plan_cache.values())).describe()
+        g = xa.power_spectrum(da, dim=["x"], real_dim="x", detrend="linear", window="hann")
+        assert tag in next(reversed(xa.api._plan_cache.values())).describe()
+        r = o.power_spectrum(od64, dim=["x"], real_dim="x", detrend="linear", window="hann")
+        assert float(np.abs(g.values - r.values).max() / np.abs(r.values).max()) < 2e-5
     worst = max(worst, check(xa.dft(da, dim="x"), o.dft(od, dim="x"), 3e-6))
     for kw in (dict(), dict(scaling="spectrum", shift=False)):
         worst = max(worst, check(xa.power_spectrum(da, dim=["x"], **kw), o.power_spectrum(od, dim=["x"], **kw), 3e-6))
@@ -546,7 +558,7 @@ def run_fourstep_1d(n=65536, nt=3):
     # that carry the residual trend back are per column (fasty.h, W2D) -- still the two four-step kernels (round 2: generic passes)
     for kw in (dict(window="hann"), dict(window="hann", detrend="linear"), dict(window="hamming", detrend="constant", shift=False)):
         g = xa.power_spectrum(da, dim=["x"], **kw)
-        assert "four-step]" in next(reversed(xa.api._plan_cache.values())).describe(), kw
+        assert tag in next(reversed(xa.api._plan_cache.values())).describe(), kw
         r = o.power_spectrum(od64, dim=["x"], **kw)
         e = float(np.abs(g.values - r.values).max() / np.abs(r.values).max())
         binrel, l1 = fine_errors(g.values, r.values)
@@ -554,7 +566,7 @@ def run_fourstep_1d(n=65536, nt=3):
         worst = max(worst, e)
     for kw in (dict(window="hann", detrend="linear"), dict(window="blackman", true_phase=False, shift=False)):
         g = xa.fft(da, dim=["x"], **kw)
-        assert "four-step]" in next(reversed(xa.api._plan_cache.values())).describe(), kw
+        assert tag in next(reversed(xa.api._plan_cache.values())).describe(), kw
         r = o.fft(od64, dim=["x"], **kw)
         e = float(np.abs(g.values - r.values).max() / np.abs(r.values).max())
         assert e < 2e-5, (kw, e)

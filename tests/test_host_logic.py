@@ -132,3 +132,32 @@ def test_xarray_chunks_become_metadata():
     assert d._chunks == {"t": (2,), "x": (4, 4, 4)}
     with pytest.raises(ValueError):
         xa.fft(x, dim=["x"])
+
+
+def test_coordinates_are_owned_and_read_only_and_the_analysis_is_remembered_per_label_set():
+    """Round 4 (host overhead per call): coordinate vectors are owned read-only copies (xarray's dimension coordinates are immutable
+    indexes, too), so api._analyze may remember what it derived from a labelled array by the identity of its labels; new labels -- a
+    replaced coordinate, other arguments -- are analysed (and validated) afresh."""
+    x = np.arange(16) * 0.5
+    da = xa.DataArray(np.zeros((2, 16)), ("t", "x"), {"t": np.arange(2), "x": x})
+    x[3] = 99.0                                   # the caller's array is not the coordinate
+    assert da["x"].values[3] == 1.5 and not da["x"].values.flags.writeable
+    with pytest.raises(ValueError):
+        da["x"].values[3] = 7.0
+    c1 = api._analyze(da, 1e-3, ["x"], None, True, None, None, True, False, "freq_", None)
+    c2 = api._analyze(da, 1e-3, ["x"], None, True, None, None, True, False, "freq_", None)
+    assert c1.k[0] is c2.k[0] and c2.da is da and c1._x is c2._x   # the stored context, re-bound to the array
+    assert da._memo[1] and all(v.da is None for v in da._memo[1].values())  # (no reference cycle through the array)
+    c3 = api._analyze(da, 1e-3, ["x"], None, False, None, None, True, False, "freq_", None)
+    assert c3.shift is False and not np.array_equal(c3.k[0], c1.k[0])
+    # the same array object with a coordinate replaced by an unevenly spaced one: validated again, and refused
+    bad = np.arange(16) * 0.5
+    bad[5] += 0.2
+    da.coords["x"] = xa.Coordinate(("x",), bad, None, "x")
+    with pytest.raises(ValueError, match="not evenly spaced"):
+        api._analyze(da, 1e-3, ["x"], None, True, None, None, True, False, "freq_", None)
+    # a list-valued window argument cannot key the memo: analysed every time, same answer
+    da2 = xa.DataArray(np.zeros((2, 16)), ("t", "x"), {"t": np.arange(2), "x": np.arange(16) * 0.5})
+    f1 = api._flags_tables(api._analyze(da2, 1e-3, ["x"], None, True, None, None, True, False, "freq_", None), da2)
+    f2 = api._flags_tables(api._analyze(da2, 1e-3, ["x"], None, True, None, None, True, False, "freq_", None), da2)
+    assert f1[0] == f2[0] and f1[2]["x"] is f2[2]["x"] and not f1[2]["x"].flags.writeable  # the phase table: built once

@@ -27,6 +27,7 @@
 #include "fastp2.h"
 #include "fasty.h"
 #include "fastm.h"
+#include "fastr.h"
 #include "tile_fft.h"
 #ifdef XRFT_SPLIT_TUS  /* the library built from several translation units: the fasty / fastm kernels are instantiated in inst_g*.cpp */
 namespace xrft {
@@ -323,6 +324,10 @@ struct xrfthip_plan {
     bool fastmy = false;
     // ... and the same transform over short contiguous rows packed in pairs (ndim = 1, fastm_xonly_kernel)
     bool fastmx = false;
+    // ... and ONE pass for a long real float32 row that fits the registers of a CU: 65536 samples per workgroup (fastr.h)
+    bool fastr = false;
+    DevBuf tw_rm, tw_rs, tw_rn;   // W_M^p (p < 1024), W_1024^n (n < 32), W_N^p (p < 1024)
+    long long tune_rgrid = 0;     // XRFTHIP_FASTR_GRID: workgroups of the launch (0 = one per row; else a resident set walking the rows)
     bool fph_on = false;  // some entry of the combined phase tables (fph) differs from 1
     long long yny = 0, ynx = 0;
     DevBuf tw_big1d;
@@ -812,6 +817,7 @@ void set_kernel_attrs_once() {
 #undef SETALL
 #undef SETA
 #define SETF(K) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&K), hipFuncAttributeMaxDynamicSharedMemorySize, m)
+    SETF((fastr_kernel<0, false>)); SETF((fastr_kernel<0, true>)); SETF((fastr_kernel<1, false>)); SETF((fastr_kernel<1, true>));
 #define SETY(NN) SETF((fasty_cols_kernel<NN, false>)); SETF((fasty_cols_kernel<NN, true>)); SETF((fasty_cols_kernel<NN, false, true>)); SETF((fasty_cols_kernel<NN, true, true>)); SETF((fasty_rows_kernel<NN, 1, false>)); SETF((fasty_rows_kernel<NN, 1, true>)); \
                  SETF((fasty_rows_kernel<NN, 0, false>)); SETF((fasty_rows_kernel<NN, 2, false>)); SETF((fasty_rows_kernel<NN, 2, true>)); SETF((fasty_rows_kernel<NN, 3, false>))
     SETY(4096); SETY(2048); SETY(1024); SETY(512); SETY(256);
@@ -928,6 +934,7 @@ static int run_radial_sums(int32_t dtype, const void* spec, const int32_t* d_bin
 
 static void layout_workspace(xrfthip_plan* P) {
     const xrfthip_desc& d = P->d;
+    if (P->fastr) { P->G = (int)std::max<long long>(1, std::min<long long>(d.batch, 1 << 30)); P->ws_bytes = 0; return; }  // one pass, registers + LDS: no intermediate
     const bool fast = fast_on(P);
     long long G = d.slabs_per_group > 0 ? d.slabs_per_group : P->tune_group;
     size_t slab_w = (size_t)d.ny * std::max(P->width, P->w_cols) * P->csize;
@@ -1794,11 +1801,39 @@ static int run_fastmx(const xrfthip_plan* P, const void* in, const void* in1, vo
     return XRFTHIP_OK;
 }
 
+// one pass over 65536-sample float32 rows (fastr.h): a 1024-thread workgroup per row, or a resident set walking the rows
+static int run_fastr(const xrfthip_plan* P, const void* in, void* out, hipStream_t st) {
+    const xrfthip_desc& d = P->d;
+    FastR p{};
+    p.in = (const float*)in; p.out = out;
+    p.tw_m = (const cf*)P->tw_rm.p; p.tw_s = (const cf*)P->tw_rs.p; p.tw_n = (const cf*)P->tw_rn.p;
+    p.win = (const float*)P->win[1].p;
+    p.ph = (const cf*)P->fph[1].p; p.ph_on = (d.out_mode == XRFTHIP_OUT_COMPLEX && P->fph_on) ? 1 : 0;
+    p.nrows = d.batch;
+    p.detrend = d.detrend;
+    p.half = (d.flags & XRFTHIP_HALF_X) ? 1 : 0;
+    p.realdim2 = (d.flags & XRFTHIP_REALDIM_X2) ? 1 : 0;
+    p.shift = (d.flags & XRFTHIP_SHIFT_X) ? 1 : 0;
+    p.scale = (float)d.scale;
+    const long long g = P->tune_rgrid > 0 ? std::min<long long>(P->tune_rgrid, d.batch) : d.batch;
+    const dim3 grid((unsigned)std::min<long long>(g, 0x7fffffffLL)), blk(kFastRThreads);
+    xrfthip_plan::ProfRec* rec = prof_begin(P, "fastr_row", st);
+    const bool pw = d.out_mode == XRFTHIP_OUT_POWER;
+#define RL_(MM, HH) do { auto k = &fastr_kernel<MM, HH>; XRFT_LAUNCH(k, grid, blk, kFastRLds, st, p); } while (0)
+    if (pw) { if (p.half) RL_(1, true); else RL_(1, false); } else { if (p.half) RL_(0, true); else RL_(0, false); }
+#undef RL_
+    prof_end(rec, st);
+    HIP_TRY(hipGetLastError());
+    return XRFTHIP_OK;
+}
+
 // Everything xrfthip_exec needs beyond the caller's buffers is built HERE, when the plan is created or one of its tables is
 // set: window spectra and phase tables of the specialised paths (device allocations + blocking copies) and the workspace
 // layout.  xrfthip_exec itself takes the plan as const: no allocation, no copy, no synchronisation, no getenv.
 static int finalize_plan(xrfthip_plan* P) {
-    if (P->fastmx) {
+    if (P->fastr) {
+        if (P->d.out_mode != XRFTHIP_OUT_POWER) { const int rc = fast_phase_tables(P); if (rc) return rc; }
+    } else if (P->fastmx) {
         if (P->d.out_mode != XRFTHIP_OUT_POWER) { const int rc = fast_phase_tables(P); if (rc) return rc; }
     } else if (P->fastmy) {
         if (P->d.out_mode != XRFTHIP_OUT_POWER) { const int rc = fast_phase_tables(P); if (rc) return rc; }
@@ -2048,12 +2083,25 @@ int xrfthip_plan_create(xrfthip_plan** plan, const xrfthip_desc* desc) {
         if (!rc4) rc4 = P->ones4096.upload(ones.data(), ones.size() * sizeof(float));
         if (rc4) { delete P; return rc4; }
     }
+    {   // one real float32 row of 65536 samples per workgroup, transformed in registers in ONE pass (fastr.h): 12 bytes per sample through
+        // memory where the four-step form below moves 28
+        const uint32_t okr = XRFTHIP_SHIFT_X | XRFTHIP_HALF_X | (d.out_mode == XRFTHIP_OUT_POWER ? XRFTHIP_REALDIM_X2 : 0u) | (d.out_mode == XRFTHIP_OUT_COMPLEX ? XRFTHIP_ISHIFT_X : 0u);
+        P->fastr = d.ndim == 1 && d.nx == 65536 && d.dtype == XRFTHIP_F32 && (d.out_mode == XRFTHIP_OUT_COMPLEX || d.out_mode == XRFTHIP_OUT_POWER) &&
+                   !(d.flags & ~okr) && !((d.flags & XRFTHIP_HALF_X) && (d.flags & XRFTHIP_SHIFT_X)) && !env_ll("XRFTHIP_NO_FAST", 0) && env_ll("XRFTHIP_FASTR", 1) != 0;
+        if (P->fastr) {
+            P->tune_rgrid = env_ll("XRFTHIP_FASTR_GRID", 0);
+            int rcr = build_twiddle<float>(P->tw_rm, d.nx / 2, 1024);
+            if (!rcr) rcr = build_twiddle<float>(P->tw_rs, 1024, 32);
+            if (!rcr) rcr = build_twiddle<float>(P->tw_rn, d.nx, 1024);
+            if (rcr) { delete P; return rcr; }
+        }
+    }
     {   // one long real float32 sequence per slab, N = n1 * 256 samples (2^16 .. 2^20): the two passes of the y-first pipeline are
         // the two steps of its four-step transform (fasty.h, FS)
         const long long n1 = d.nx / 256;
         const bool pow2 = d.nx >= 65536 && d.nx <= (1LL << 20) && (d.nx & (d.nx - 1)) == 0;
         const uint32_t ok1 = XRFTHIP_SHIFT_X | (d.out_mode == XRFTHIP_OUT_COMPLEX ? XRFTHIP_ISHIFT_X : 0u);
-        P->fast1d = d.ndim == 1 && pow2 && d.dtype == XRFTHIP_F32 && (d.out_mode == XRFTHIP_OUT_COMPLEX || d.out_mode == XRFTHIP_OUT_POWER) &&
+        P->fast1d = !P->fastr && d.ndim == 1 && pow2 && d.dtype == XRFTHIP_F32 && (d.out_mode == XRFTHIP_OUT_COMPLEX || d.out_mode == XRFTHIP_OUT_POWER) &&
                     !(d.flags & ~ok1) && !env_ll("XRFTHIP_NO_FAST", 0) && env_ll("XRFTHIP_FAST1D", 1) != 0;
         if (P->fast1d) {
             P->yfirst = true;
@@ -2251,7 +2299,13 @@ int xrfthip_plan_describe(const xrfthip_plan* plan, char* buf, size_t buflen) {
     appendf(s, "xrfthip plan: ndim=%d batch=%lld ny=%lld nx=%lld dtype=%d mode=%d detrend=%d flags=0x%x width=%lld nx_out=%lld mirror=%d group=%d ws=%zuB\n",
             d.ndim, (long long)d.batch, (long long)d.ny, (long long)d.nx, d.dtype, d.out_mode, d.detrend, d.flags,
             plan->width, plan->nx_out, (int)plan->mirror, plan->G, plan->ws_bytes);
-    if (plan->fastmx) {
+    if (plan->fastr) {
+        appendf(s, "  [fastr] one pass, one %d-thread workgroup per %lld-sample row (grid %lld): the packed %lld-point complex transform in registers (32 per thread, "
+                   "r32x32x32, two LDS exchanges in halves), real split through the LDS, lds=%zuB; per-row detrend + window + full (or half) spectrum; "
+                   "12 algorithmic bytes per sample through memory\n",
+                kFastRThreads, (long long)plan->d.nx, plan->tune_rgrid > 0 ? std::min<long long>(plan->tune_rgrid, plan->d.batch) : (long long)plan->d.batch,
+                (long long)plan->d.nx / 2, kFastRLds);
+    } else if (plan->fastmx) {
         const MGeomRt C = mxgeom(plan->d.nx, plan->dbl);
         appendf(s, "  [fastm x-only] %d thr, %d row pairs per workgroup (FFT%lld r%dx%dx%d in LDS), lds=%zuB: per-row detrend + window + transform + full (or half) spectrum in one pass\n",
                 C.thr, C.g, (long long)plan->d.nx, C.r0, C.r1, C.r2, C.lds_cols);
@@ -2311,6 +2365,7 @@ int xrfthip_exec(const xrfthip_plan* plan, const void* d_in0, const void* d_in1,
     double* acc = (double*)(ws + P->off_acc);
     double* coef = (double*)(ws + P->off_coef);
     if (iso) HIP_TRY(hipMemsetAsync(d_iso, 0, (size_t)d.batch * P->nbins * (cross ? 16 : 8), st));
+    if (P->fastr) return run_fastr(P, d_in0, out, st);
     if (P->fastmx) return run_fastmx(P, d_in0, d_in1, out, st);
     if (P->fastmy) return run_fastmy(P, d_in0, d_in1, out, st);
     if (P->fastm) return run_fastm(P, d_in0, d_in1, out, (double*)d_iso, ws, st);

@@ -23,7 +23,14 @@ class Coordinate:
 
     def __init__(self, dims, values, attrs=None, name=None):
         self.dims = (dims,) if isinstance(dims, str) else tuple(dims)
-        self.values = np.asarray(values)
+        # The values are an owned, read-only array (xarray keeps its dimension coordinates in immutable indexes, too): what the API
+        # derives from a coordinate vector (spacing check, lag, digest) can then be remembered by the array's identity instead of
+        # being re-derived from its bytes on every call.  An array that already is an owned read-only one is shared, not copied.
+        a = values if isinstance(values, np.ndarray) else np.asarray(values)
+        if a.flags.writeable or not a.flags.owndata:
+            a = np.array(a, copy=True)
+            a.setflags(write=False)
+        self.values = a
         self.attrs = dict(attrs or {})
         self.name = name
 
@@ -73,6 +80,7 @@ class DataArray:
         self.name = name
         self.attrs = dict(attrs or {})
         self._chunks = None  # {dim: tuple of chunk lengths}: metadata only (see .chunk)
+        self._memo = None    # what the API derived from this array's labels on earlier calls (xrft_amd/api.py:_analyze), with its guard
         self.coords = {}
         if coords is not None:
             if isinstance(coords, dict):
