@@ -43,6 +43,8 @@ __device__ __forceinline__ void xrft_store_nt(float* dst, F4 v) {
 //   bit  2    pass 1, loads of the input non-temporal
 //   bit  3    pass 2, loads of the intermediate non-temporal
 //   bit  4    pass 2, stores of the result plain instead of non-temporal
+//   bit  21   pass 1: the workgroups that share the input's 128-byte lines (consecutive column blocks of one XCD) meet on a counter
+//             before they load, with a time-out (round 4: does the 1.45x input over-fetch go away when the sharers load together?)
 //   bits 8-15 the second workgroup of every CU (blocks 256..511 of a launch) starts n x 3.4 us late: the two residents of a CU
 //             then run their load / transform / store phases out of step for the whole launch
 // The product build compiles the default in (a run-time policy in the store loops costs the column kernel a spilled register);
@@ -134,6 +136,7 @@ struct FastY {
     int shift_y, shift_x;    // 0 or n/2
     float scale;
     int tune;                // see kYTuneDefault
+    unsigned* rdv;           // tune bit 21: one arrival counter per (slab, group of the column blocks that share the input's 128-byte lines), zeroed per launch
 };
 
 // phase-ablation bits for profiling builds (scripts/gpu_ablate_yf.sh compiles variants with -DXRFT_YDBG=bits); 0 in the product
@@ -264,6 +267,24 @@ __global__ void __launch_bounds__(YCols<NY>::THR, YCols<NY>::THR / 128) fasty_co
     } else {
         slab = blockIdx.x / nxb;
         xb = blockIdx.x % nxb;
+    }
+    if ((XRFT_YTUNE(p) >> 21) & 1) {
+#ifndef XRFT_EMULATE
+        // rendezvous of the sharers of a line group: 128 / (4 CW) column blocks, consecutive on one XCD (dispatched in order: at most
+        // one group is partially resident, so the wait cannot deadlock; the time-out is a belt)
+        constexpr int SH = 128 / (4 * Y::CW) > 1 ? 128 / (4 * Y::CW) : 1;
+        if (SH > 1) {
+            if (tid == 0) {
+                unsigned* ctr = p.rdv + (size_t)slab * (nxb / SH) + xb / SH;
+                __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                for (int it = 0; it < 4000; ++it) {
+                    if (__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= (unsigned)SH) break;
+                    __builtin_amdgcn_s_sleep(2);
+                }
+            }
+            __syncthreads();
+        }
+#endif
     }
     const int x0 = xb * Y::CW + 4 * g;
     // uniform 64-bit base + one 32-bit per-lane byte offset (a slab is < 4 GB): scalar-base loads, no 64-bit address per row

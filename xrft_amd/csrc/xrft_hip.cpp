@@ -306,7 +306,7 @@ struct xrfthip_plan {
     std::vector<Pass> passes;     // main pipeline (field 1 for CROSS)
     std::vector<Pass> passes_f0;  // CROSS: field 0 -> raw F0 buffer
     // workspace layout (byte offsets)
-    size_t off_acc = 0, off_coef = 0, off_w = 0, off_w2 = 0, off_f0 = 0, off_pt = 0, off_rowfit = 0, off_corr = 0, off_isopart = 0, off_isotmp = 0, ws_bytes = 0;
+    size_t off_acc = 0, off_coef = 0, off_w = 0, off_w2 = 0, off_f0 = 0, off_pt = 0, off_rowfit = 0, off_corr = 0, off_isopart = 0, off_isotmp = 0, off_rdv = 0, ws_bytes = 0;
     int iso_chunks = 1;  // workgroups per slab of the generic radial-sum pass (partial sums added in order)
     std::string desc_text;
     // specialised path for real float32 slabs whose two lengths are 256 .. 4096 powers of two (fasty.h)
@@ -972,6 +972,8 @@ static void layout_workspace(xrfthip_plan* P) {
         const size_t upr = (size_t)P->y_nrow_pad / (two ? gx : 2 * gx);
         off = al(off + (size_t)G * upr * P->nbins * (two ? 2 : 1) * sizeof(double));
     }
+    P->off_rdv = off;
+    if (yf && !P->fastm && ((P->tune_y >> 21) & 1)) off = al(off + (size_t)G * (size_t)std::max<long long>(P->ynx / 8, 1) * sizeof(unsigned));  // (tuning: rendezvous counters of pass 1)
     P->off_isotmp = off;
     if (fastm_iso_fused(P)) {  // fastm with the radial sums inside pass 2: one partial table per row workgroup
         const bool two = d.out_mode == XRFTHIP_OUT_CROSS;
@@ -1468,6 +1470,10 @@ static int run_fasty(const xrfthip_plan* P, const float* in, const float* in1, v
     for (long long g0 = 0; g0 < d.batch; g0 += P->G) {
         const long long gc = std::min<long long>(P->G, d.batch - g0);
         FastY p = fasty_params(P, in, out, iso, ws, g0, gc, 0, P->G);
+        if ((P->tune_y >> 21) & 1) {
+            p.rdv = reinterpret_cast<unsigned*>(ws + P->off_rdv);
+            HIP_TRY(hipMemsetAsync(p.rdv, 0, (size_t)gc * (size_t)std::max<long long>(P->ynx / 8, 1) * sizeof(unsigned), st));
+        }
         fasty_launch_cols(P, p, gc, st, true);
         if (two) {  // field 1 through the same column pass into its own intermediate; the row pass reads both
             const FastY p1 = fasty_params(P, in1, out, iso, ws, g0, gc, 1, P->G);
