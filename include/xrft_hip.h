@@ -42,7 +42,7 @@
 extern "C" {
 #endif
 
-#define XRFTHIP_VERSION 101 /* 0.1.1: xrfthip_desc.inner, xrfthip_reduce_axis, xrfthip_detrend_inner */
+#define XRFTHIP_VERSION 102 /* 0.1.2: xrfthip_plan_uses_bluestein, xrfthip_convert (0.1.1: xrfthip_desc.inner, xrfthip_reduce_axis, xrfthip_detrend_inner) */
 
 typedef enum xrfthip_status {
     XRFTHIP_OK = 0,
@@ -149,6 +149,11 @@ int xrfthip_plan_set_binmap(xrfthip_plan* plan, const int32_t* h_binmap, int64_t
 int xrfthip_plan_set_profiling(xrfthip_plan* plan, int enable);
 int xrfthip_plan_profile_read(xrfthip_plan* plan, char* buf, size_t buflen);
 
+/* 1 if a pass of the plan runs Bluestein's algorithm (a transform length with a prime factor that has no butterfly: numpy.fft takes
+ * any length, xrft.py:439-444), else 0.  In float32 the chirp convolution leaves an error of a few 1e-7 of the spectrum's PEAK in every bin;
+ * callers that hold small bins to 1e-3 run such plans in float64 (xrft_amd/engine.py does, with xrfthip_convert at both ends). */
+int xrfthip_plan_uses_bluestein(const xrfthip_plan* plan);
+
 size_t xrfthip_workspace_bytes(const xrfthip_plan* plan);
 /* human-readable pass list (kernel, tile, grid, LDS) for logs and DESIGN.md; returns bytes written */
 int xrfthip_plan_describe(const xrfthip_plan* plan, char* buf, size_t buflen);
@@ -208,6 +213,10 @@ int xrfthip_gather_axis(int32_t elem_bytes, int64_t outer, int64_t n_out, int64_
  * through global memory, for lengths with a prime factor > XRFTHIP_MAX_RADIX that exceed the in-tile bound
  * (numpy.fft takes any length: xrft.py:398-447). */
 int xrfthip_table_mul(int32_t dtype, int64_t batch, int64_t n_in, int64_t n_out, const void* d_in, const void* d_table, void* d_out, void* stream);
+
+/* d_out[e] = (precision of dtype_out) d_in[e], e < n: F32 <-> F64 or C64 <-> C128 (n counts real or complex elements of dtype_in's kind).
+ * The precision change around float32 plans that run in float64 (Bluestein lengths, see xrfthip_plan_uses_bluestein). */
+int xrfthip_convert(int32_t dtype_in, int32_t dtype_out, int64_t n, const void* d_in, void* d_out, void* stream);
 
 /* d_out[o][i] = scale * sum_k d_in[o][k][i] over [outer][n][inner] -> [outer][inner], same dtype (F32|F64|C64|C128), accumulated in float64
  * in the order k = 0, 1, ...: the sum / mean over a batch dimension (scale = 1 / n), bit-reproducible.  What the reference's users do with

@@ -28,6 +28,7 @@ EXPORTS = [
     "xrfthip_plan_set_profiling", "xrfthip_plan_profile_read", "xrfthip_workspace_bytes", "xrfthip_plan_describe", "xrfthip_exec", "xrfthip_detrend_workspace_bytes",
     "xrfthip_detrend", "xrfthip_detrend3", "xrfthip_spectrum_tail", "xrfthip_spectrum_tail_axis", "xrfthip_gather_axis", "xrfthip_isotropize",
     "xrfthip_isotropize_workspace_bytes", "xrfthip_table_mul", "xrfthip_reduce_axis", "xrfthip_detrend_inner_workspace_bytes", "xrfthip_detrend_inner", "xrfthip_angle",
+    "xrfthip_plan_uses_bluestein", "xrfthip_convert",
 ]
 
 
@@ -78,6 +79,8 @@ def _bind(dll):
     dll.xrfthip_table_mul.argtypes = [i32, i64, i64, i64, vp, vp, vp, vp]
     dll.xrfthip_reduce_axis.argtypes = [i32, i64, i64, i64, vp, vp, C.c_double, vp]
     dll.xrfthip_angle.argtypes = [i32, i64, vp, vp, vp]
+    dll.xrfthip_plan_uses_bluestein.argtypes = [vp]
+    dll.xrfthip_convert.argtypes = [i32, i32, i64, vp, vp, vp]
     dll.xrfthip_detrend_inner_workspace_bytes.restype = sz
     dll.xrfthip_detrend_inner_workspace_bytes.argtypes = [i32, i64, i64]
     dll.xrfthip_detrend_inner.argtypes = [i32, i32, i64, i64, i64, i64, i32, vp, vp, vp, sz, vp]

@@ -637,6 +637,25 @@ def _execute(c, da, mode, scale, da2=None, c2=None, iso=None, extra_flags=0):
 # an inverse plan, chirp multiply with truncation -- three table-multiply launches (xrfthip_table_mul) around two existing plans;
 # detrend, window, flips and shifts, true-phase factors, scaling and |F|^2 are the same device calls the other paths use.
 # ------------------------------------------------------------------------------------------------------
+def _wide(da):
+    """float32 data of a call that is composed of several device passes around a Bluestein axis (no two-axis plan exists for a long
+    prime length): the whole composition runs in float64 -- detrending pass, chirp convolution, the other axis -- between two precision
+    changes, so that its small bins hold the 1e-3 every fused path holds (stored float32 intermediates cost them 1.3e-3)."""
+    t = _to_device(da.data)
+    if t.dtype not in (torch.float32, torch.complex64):
+        return da, False
+    w = engine.convert(t.contiguous(), torch.float64 if t.dtype == torch.float32 else torch.complex128)
+    return DataArray(w, da.dims, da.coords, da.name, da.attrs), True
+
+
+def _narrow(res, was_wide):
+    if not was_wide or not isinstance(res.data, torch.Tensor) or res.data.dtype not in (torch.float64, torch.complex128):
+        return res
+    d = res.data
+    n = engine.convert(d.contiguous(), torch.float32 if d.dtype == torch.float64 else torch.complex64)
+    return DataArray(n, res.dims, res.coords, res.name, res.attrs)
+
+
 class _UnsupportedLength(ValueError):
     """A two-axis plan could not be built for these lengths: the callers transform the axes one at a time instead."""
 
@@ -680,7 +699,12 @@ def _blue_tables(n, cdt, dev, inverse=False):
 def _bluestein_1d(t, n, mode, detrend_kind, flags, scale, win, ph, phase_in=None):
     """The 1-D plan's result for t[..., n] (real or complex) without a 1-D plan of length n.  With XRFTHIP_INVERSE in ``flags`` the
     unnormalised inverse transform (the same pipeline with conjugated chirps); ``phase_in`` multiplies the INPUT, indexed by source
-    position (XRFTHIP_PHASE_IN, xrft.py:574-576)."""
+    position (XRFTHIP_PHASE_IN, xrft.py:574-576).  float32 data run in float64 between two precision changes (engine.convert), as the
+    in-tile Bluestein plans do (engine.SpectralPlan): in float32 the chirp convolution costs the small bins their 1e-3."""
+    if t.dtype in (torch.float32, torch.complex64):
+        X = _bluestein_1d(engine.convert(t, torch.float64 if t.dtype == torch.float32 else torch.complex128), n, mode, detrend_kind, flags,
+                          scale, win, ph, phase_in)
+        return engine.convert(X, torch.float32 if X.dtype == torch.float64 else torch.complex64)
     shape = list(t.shape)
     x = t.reshape(-1, n).contiguous()
     real_in = not x.is_complex()
@@ -866,8 +890,9 @@ def fft(da, spacing_tol=1e-3, dim=None, real_dim=None, shift=True, detrend=None,
     except _UnsupportedLength:
         if chunks_to_segments:
             raise
-        return to_like(_fft_nd(da, _two_dims(da, dim, real_dim, real), spacing_tol, real_dim if real is None else real, shift, detrend, window,
-                               true_phase, true_amplitude, False, prefix, one_at_a_time=True), src)
+        daw, wide = _wide(da)
+        return to_like(_narrow(_fft_nd(daw, _two_dims(da, dim, real_dim, real), spacing_tol, real_dim if real is None else real, shift, detrend, window,
+                                       true_phase, true_amplitude, False, prefix, one_at_a_time=True), wide), src)
     da = c.da
     extra = None
     if c.true_phase:  # xrft.py:469
@@ -1224,8 +1249,9 @@ def power_spectrum(da, dim=None, real_dim=None, scaling="density", window_correc
     try:
         out, _, other = _execute(c, c.da, mode, scale, extra_flags=flags)
     except _UnsupportedLength:
-        return to_like(_spectrum_nd(da, None, _two_dims(da, dim, real_dim, kwargs.get("real")), real_dim, scaling, window_correction, False,
-                                    dict(kwargs), one_at_a_time=True), src)
+        daw, wide = _wide(da)
+        return to_like(_narrow(_spectrum_nd(daw, None, _two_dims(da, dim, real_dim, kwargs.get("real")), real_dim, scaling, window_correction, False,
+                                            dict(kwargs), one_at_a_time=True), wide), src)
     return to_like(_label_output(c, c.da, out, other), src)
 
 
@@ -1241,8 +1267,10 @@ def cross_spectrum(da1, da2, dim=None, real_dim=None, scaling="density", window_
     try:
         return to_like(_cross_result(c, c2, mode, scale, flags), src)
     except _UnsupportedLength:
-        return to_like(_spectrum_nd(da1, da2, _two_dims(da1, dim, real_dim, kwargs.get("real")), real_dim, scaling, window_correction, true_phase,
-                                    dict(kwargs), one_at_a_time=True), src)
+        d1w, wide = _wide(da1)
+        d2w, _ = _wide(da2)
+        return to_like(_narrow(_spectrum_nd(d1w, d2w, _two_dims(da1, dim, real_dim, kwargs.get("real")), real_dim, scaling, window_correction, true_phase,
+                                            dict(kwargs), one_at_a_time=True), wide), src)
 
 
 def _cross_result(c, c2, mode, scale, flags):

@@ -412,6 +412,12 @@ __global__ void __launch_bounds__(256) plane_inner_apply_kernel(const T* __restr
     }
 }
 
+// out[e] = (B) in[e]: float32 <-> float64 (complex data: twice the elements)
+template <typename A, typename B>
+__global__ void __launch_bounds__(256) convert_kernel(const A* __restrict__ in, B* __restrict__ out, long long n) {
+    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (long long)gridDim.x * blockDim.x) out[e] = (B)in[e];
+}
+
 // out[e] = arg(a[e]) in [-pi, pi] (numpy.angle of a stored cross spectrum: xrft.cross_phase, xrft/xrft.py:838-874, where the fused
 // plans cannot take the phase in their epilogue)
 template <typename T>

@@ -2278,6 +2278,15 @@ int xrfthip_plan_profile_read(xrfthip_plan* plan, char* buf, size_t buflen) {
     return (int)n;
 }
 
+int xrfthip_plan_uses_bluestein(const xrfthip_plan* plan) {
+    if (!plan) return 0;
+    if (plan->inner > 1) return xrfthip_plan_uses_bluestein(plan->sub_x) || xrfthip_plan_uses_bluestein(plan->sub_y);
+    if (plan->fastr || plan->fastmx || plan->fastmy || plan->fastm || plan->fast1d || plan->fast4096) return 0;  // (the generic passes of such a plan never run)
+    for (const Pass& ps : plan->passes) if (ps.g.blue_n > 0) return 1;
+    for (const Pass& ps : plan->passes_f0) if (ps.g.blue_n > 0) return 1;
+    return 0;
+}
+
 size_t xrfthip_workspace_bytes(const xrfthip_plan* plan) {
     if (!plan) return 0;
     return plan->ws_bytes;
@@ -2600,6 +2609,20 @@ int xrfthip_detrend_inner(int32_t dtype, int32_t ndim, int64_t batch, int64_t ny
     if (!d_workspace || ws_bytes < xrfthip_detrend_inner_workspace_bytes(dtype, batch, inner)) return XRFTHIP_WORKSPACE_TOO_SMALL;
     if (batch == 0) return XRFTHIP_OK;
     return run_detrend_inner(dtype, ndim, batch, ny, nx, inner, detrend_type, d_in, d_out, (char*)d_workspace, (hipStream_t)stream);
+}
+
+int xrfthip_convert(int32_t dtype_in, int32_t dtype_out, int64_t n, const void* d_in, void* d_out, void* stream) {
+    if (!d_in || !d_out || n < 0) return XRFTHIP_BAD_ARG;
+    const bool up = (dtype_in == XRFTHIP_F32 && dtype_out == XRFTHIP_F64) || (dtype_in == XRFTHIP_C64 && dtype_out == XRFTHIP_C128);
+    const bool down = (dtype_in == XRFTHIP_F64 && dtype_out == XRFTHIP_F32) || (dtype_in == XRFTHIP_C128 && dtype_out == XRFTHIP_C64);
+    if (!up && !down) return XRFTHIP_BAD_ARG;
+    const long long cnt = n * (dtype_in >= XRFTHIP_C64 ? 2 : 1);
+    if (cnt == 0) return XRFTHIP_OK;
+    const dim3 grid((unsigned)std::min<long long>((cnt + 255) / 256, 8LL * kCUs * 4)), block(256);
+    if (up) { auto k = &convert_kernel<float, double>; XRFT_LAUNCH(k, grid, block, 0, (hipStream_t)stream, (const float*)d_in, (double*)d_out, cnt); }
+    else { auto k = &convert_kernel<double, float>; XRFT_LAUNCH(k, grid, block, 0, (hipStream_t)stream, (const double*)d_in, (float*)d_out, cnt); }
+    HIP_TRY(hipGetLastError());
+    return XRFTHIP_OK;
 }
 
 int xrfthip_reduce_axis(int32_t dtype, int64_t outer, int64_t n, int64_t inner, const void* d_in, void* d_out, double scale, void* stream) {

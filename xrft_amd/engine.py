@@ -39,6 +39,7 @@ class SpectralPlan:
                  slabs_per_group=0, inner=1):
         self._dll = _lib.load()
         self._h = C.c_void_p(0)
+        self._twin = None
         if dtype not in _DTYPES:
             raise TypeError(f"unsupported dtype {dtype}")
         self.ndim, self.batch, self.ny, self.nx = int(ndim), int(batch), int(ny), int(nx)
@@ -63,6 +64,14 @@ class SpectralPlan:
                 raise ValueError(f"bin map shape {bm.shape} != {(self.ny, self.nx_out)}")
             _lib.check(self._dll.xrfthip_plan_set_binmap(self._h, bm.ctypes.data_as(C.c_void_p), self.ny,
                                                          self.nx_out, self.nbins))
+        if dtype in _WIDER and self._dll.xrfthip_plan_uses_bluestein(self._h):
+            # float32 data on a length that takes Bluestein's algorithm: the chirp convolution (two long transforms and three pointwise
+            # products) leaves an error of a few 1e-7 of the spectrum's PEAK in every bin -- 1e-3 relative in the bins 1e-3 of the
+            # peak.  Such plans run in float64 between two precision changes (xrfthip_convert); float32 in, float32 out as ever.
+            # (A length whose float64 chirp transform does not fit the tile raises UNSUPPORTED_LENGTH here, and the callers go
+            # through global memory as they do for float64 data.)
+            self._twin = SpectralPlan(ndim, batch, ny, nx, _WIDER[dtype], out_mode, detrend, flags, scale, window_y, window_x, phase_y, phase_x,
+                                      binmap, nbins, slabs_per_group, inner)
 
     def __del__(self):
         try:
@@ -77,6 +86,8 @@ class SpectralPlan:
         return int(self._dll.xrfthip_workspace_bytes(self._h))
 
     def describe(self):
+        if self._twin is not None:
+            return "[float32 data, run in float64: Bluestein length]\n" + self._twin.describe()
         buf = C.create_string_buffer(8192)
         self._dll.xrfthip_plan_describe(self._h, buf, len(buf))
         return buf.value.decode()
@@ -118,6 +129,11 @@ class SpectralPlan:
             iso = torch.empty((self.batch, self.nbins), device=dev,
                               dtype=torch.complex128 if self.out_mode == _lib.OUT_CROSS else torch.float64)
         if self.batch == 0:  # nothing to transform: empty outputs, no device call
+            return (out if want_out else None), iso
+        if self._twin is not None:
+            o64, iso = self._twin.execute(convert(in0, _WIDER[in0.dtype]), None if in1 is None else convert(in1, _WIDER[in1.dtype]), None, iso)
+            if o64 is not None:
+                convert(o64, self.out_dtype(), out.reshape(o64.shape))
             return (out if want_out else None), iso
         stream = _stream_handle(in0)
         # The C plan is immutable after creation, so nothing plan-wide is locked: threads on different streams enqueue
@@ -222,6 +238,24 @@ def detrend_inner(x, axis0, naxes, kind):
     out = torch.empty_like(x)
     ws = torch.empty(max(nws, 16), dtype=torch.uint8, device=x.device)
     _lib.check(dll.xrfthip_detrend_inner(_DTYPES[x.dtype], naxes, batch, ny, nx, inner, kind, _ptr(x), _ptr(out), _ptr(ws), nws, _stream_handle(x)))
+    return out
+
+
+_WIDER = {torch.float32: torch.float64, torch.complex64: torch.complex128}
+_NARROWER = {v: k for k, v in _WIDER.items()}
+
+
+def convert(x, dtype, out=None):
+    """``x`` in the other precision (float32 <-> float64, complex64 <-> complex128) by the library's own kernel (xrfthip_convert)."""
+    dll = _lib.load()
+    if _WIDER.get(x.dtype) is not dtype and _NARROWER.get(x.dtype) is not dtype:
+        raise TypeError(f"convert: {x.dtype} -> {dtype}")
+    x = x.contiguous()
+    if out is None:
+        out = torch.empty(x.shape, dtype=dtype, device=x.device)
+    elif out.dtype is not dtype or out.numel() != x.numel() or not out.is_contiguous():
+        raise ValueError("convert: out does not match")
+    _lib.check(dll.xrfthip_convert(_DTYPES[x.dtype], _DTYPES[dtype], x.numel(), _ptr(x), _ptr(out), _stream_handle(x)))
     return out
 
 
