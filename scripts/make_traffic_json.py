@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""profiles/r03_traffic.json from the FETCH_SIZE / WRITE_SIZE passes of scripts/gpu_pmc_yf.sh (bench.py --nt <n> --steps 1).
+"""profiles/r0N_traffic.json from the FETCH_SIZE / WRITE_SIZE passes of scripts/gpu_pmc_yf.sh (bench.py --nt <n> --steps 1).
 usage: make_traffic_json.py gpurun_out/pmc_<tag> <slabs per profiled launch> [fused-skeleton result file] > profiles/r03_traffic.json
 The file is stamped with the SHA-1 of xrft_amd/csrc (bench.csrc_sha1): bench.py reports `traffic` only when the stamp matches
 the sources it runs.
@@ -16,7 +16,7 @@ for f in glob.glob(os.path.join(root, "*", "**", "*counter_collection.csv"), rec
     with open(f) as fh:
         for row in csv.DictReader(fh):
             k = row.get("Kernel_Name", "")
-            m = re.search(r"xrft::(fast[py2]*_\w+?)_kernel", k)
+            m = re.search(r"xrft::(fast[pyr2]*_\w+?)_kernel", k) or re.search(r"xrft::(fastr)_kernel", k)
             if m and row["Counter_Name"] in ("FETCH_SIZE", "WRITE_SIZE"):
                 agg[m.group(1)][row["Counter_Name"]].append(float(row["Counter_Value"]))
 out = {"csrc_sha1": bench.csrc_sha1(),
@@ -33,8 +33,13 @@ for k, c in sorted(agg.items()):
                          "write_bytes_per_slab": int(ws * 1024 / nslab), "hbm_bytes_per_slab": int(b), "launches": len(c["FETCH_SIZE"])}
     tot += b
 out["path_hbm_bytes_per_slab"] = int(tot)
-out["algorithmic_bytes_per_slab"] = 4096 * 4096 * 8
-out["two_pass_minimum_bytes_per_slab"] = 4096 * 4096 * 4 * 2 + 2 * 2052 * 4096 * 8  # in + out + the half-spectrum intermediate written and read once
+if os.environ.get("TRAFFIC_WORKLOAD", "ps") == "c2":  # (1024, 65536) float32 -> complex64: a "slab" is one row
+    out["algorithmic_bytes_per_slab"] = 65536 * 12
+    out["hbm_bytes_per_point"] = round(tot / 65536, 3)
+    out["algorithmic_bytes_per_point"] = 12
+else:
+    out["algorithmic_bytes_per_slab"] = 4096 * 4096 * 8
+    out["two_pass_minimum_bytes_per_slab"] = 4096 * 4096 * 4 * 2 + 2 * 2052 * 4096 * 8  # in + out + the half-spectrum intermediate written and read once
 if len(sys.argv) > 3:  # what the memory system allows the two passes' access patterns with no arithmetic (scripts/ubench/fused.hip)
     txt = open(sys.argv[3]).read()
     best = None
@@ -43,7 +48,10 @@ if len(sys.argv) > 3:  # what the memory system allows the two passes' access pa
         if best is None or us < best[0]:
             best = (us, float(m.group(5)), float(m.group(6)), m.group(1))
     if best:
-        out["two_pass_floor"] = {"us_per_slab": best[0], "cols_us": best[1], "rows_us": best[2], "GFFT_per_s": round(4096 * 4096 / best[0] / 1e3, 1),
+        import hashlib
+        with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "ubench", "fused.hip"), "rb") as fh:
+            out["ubench_sha1"] = hashlib.sha1(fh.read()).hexdigest()
+        out["claimed_floor"] = {"us_per_slab": best[0], "cols_us": best[1], "rows_us": best[2], "GFFT_per_s": round(4096 * 4096 / best[0] / 1e3, 1),
                                  "frac_of_8TBps_on_algorithmic_bytes": round(4096 * 4096 * 8 / (best[0] * 1e-6) / 8e12, 3),
                                  "source": "scripts/ubench/fused.hip, 'two launches' (profiles/r03_ubench_fused.txt): the real kernels' workgroup shape, LDS footprint and "
                                            "access patterns (32-byte row segments in, 16-byte pieces of 128-byte lines out; one contiguous 128-KB block in, eight output rows "

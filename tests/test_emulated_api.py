@@ -7,6 +7,7 @@ import sys
 
 import numpy as np
 import pytest
+import torch
 
 sys.path.insert(0, os.path.join(os.path.dirname(__file__), "emu"))
 import build_emu  # noqa: E402
@@ -113,6 +114,28 @@ def test_unsupported_length_is_loud_at_the_c_abi():
     with pytest.raises(_lib.XrftHipError) as ei:
         engine.SpectralPlan(ndim=2, batch=2, ny=8, nx=10007, dtype=torch.float64, out_mode=_lib.OUT_POWER, detrend=_lib.DETREND_NONE, flags=0, scale=1.0)
     assert ei.value.status == _lib.UNSUPPORTED_LENGTH
+
+
+def test_bluestein_precision_policy():
+    """float32 data on a Bluestein length run in float64 by default (the per-bin bound of every other path); the policy switch keeps
+    float32 arithmetic -- twice as fast, max-norm bound only."""
+    import xrft_amd as xa
+    rng = np.random.default_rng(3)
+    v = rng.standard_normal((2, 262)).astype("float32")
+    da = xa.DataArray(v, ("t", "x"), {"t": np.arange(2), "x": np.arange(262) * 1.0})
+    ref = np.fft.fftshift(np.fft.fft(v.astype("float64"), axis=1), axes=1)
+    assert xa.bluestein_in_float64() is True
+    g64 = xa.fft(da, dim="x", true_phase=False, true_amplitude=False)
+    assert "run in float64" in next(reversed(api._plan_cache.values())).describe() and g64.data.dtype == torch.complex64
+    try:
+        xa.bluestein_in_float64(False)
+        g32 = xa.fft(da, dim="x", true_phase=False, true_amplitude=False)
+        assert "run in float64" not in next(reversed(api._plan_cache.values())).describe() and g32.data.dtype == torch.complex64
+    finally:
+        xa.bluestein_in_float64(True)
+    e64 = np.abs(g64.values - ref).max() / np.abs(ref).max()
+    e32 = np.abs(g32.values - ref).max() / np.abs(ref).max()
+    assert e64 < 2e-7 and e64 <= e32 < 1e-5, (e64, e32)
 
 
 def test_long_prime_lengths_through_global_bluestein():

@@ -254,8 +254,8 @@ def _akey(a):
 
 def _get_plan(binmap_key=None, **kw):
     # the bin map can be 16M entries: it is identified by the key of the (cached) host computation, not by its bytes
-    key = tuple((k, (binmap_key if k == "binmap" else _akey(v)) if isinstance(v, np.ndarray) else v)
-                for k, v in sorted(kw.items()))
+    key = (engine.bluestein_in_float64(),) + tuple((k, (binmap_key if k == "binmap" else _akey(v)) if isinstance(v, np.ndarray) else v)
+                                                   for k, v in sorted(kw.items()))
     with _plan_lock:
         p = _plan_cache.get(key)
         if p is None:
@@ -642,7 +642,7 @@ def _wide(da):
     prime length): the whole composition runs in float64 -- detrending pass, chirp convolution, the other axis -- between two precision
     changes, so that its small bins hold the 1e-3 every fused path holds (stored float32 intermediates cost them 1.3e-3)."""
     t = _to_device(da.data)
-    if t.dtype not in (torch.float32, torch.complex64):
+    if t.dtype not in (torch.float32, torch.complex64) or not engine.bluestein_in_float64():
         return da, False
     w = engine.convert(t.contiguous(), torch.float64 if t.dtype == torch.float32 else torch.complex128)
     return DataArray(w, da.dims, da.coords, da.name, da.attrs), True
@@ -701,7 +701,7 @@ def _bluestein_1d(t, n, mode, detrend_kind, flags, scale, win, ph, phase_in=None
     unnormalised inverse transform (the same pipeline with conjugated chirps); ``phase_in`` multiplies the INPUT, indexed by source
     position (XRFTHIP_PHASE_IN, xrft.py:574-576).  float32 data run in float64 between two precision changes (engine.convert), as the
     in-tile Bluestein plans do (engine.SpectralPlan): in float32 the chirp convolution costs the small bins their 1e-3."""
-    if t.dtype in (torch.float32, torch.complex64):
+    if t.dtype in (torch.float32, torch.complex64) and engine.bluestein_in_float64():
         X = _bluestein_1d(engine.convert(t, torch.float64 if t.dtype == torch.float32 else torch.complex128), n, mode, detrend_kind, flags,
                           scale, win, ph, phase_in)
         return engine.convert(X, torch.float32 if X.dtype == torch.float64 else torch.complex64)

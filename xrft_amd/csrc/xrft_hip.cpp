@@ -327,7 +327,7 @@ struct xrfthip_plan {
     // ... and ONE pass for a long real float32 row that fits the registers of a CU: 65536 samples per workgroup (fastr.h)
     bool fastr = false;
     DevBuf tw_rm, tw_rs, tw_rn;   // W_M^p (p < 1024), W_1024^n (n < 32), W_N^p (p < 1024)
-    long long tune_rgrid = 0;     // XRFTHIP_FASTR_GRID: workgroups of the launch (0 = one per row; else a resident set walking the rows)
+    long long tune_rgrid = 0;     // XRFTHIP_FASTR_GRID: workgroups of the launch (0 = one per row; default: a resident set of one per CU walking the rows)
     bool fph_on = false;  // some entry of the combined phase tables (fph) differs from 1
     long long yny = 0, ynx = 0;
     DevBuf tw_big1d;
@@ -2095,7 +2095,7 @@ int xrfthip_plan_create(xrfthip_plan** plan, const xrfthip_desc* desc) {
         P->fastr = d.ndim == 1 && d.nx == 65536 && d.dtype == XRFTHIP_F32 && (d.out_mode == XRFTHIP_OUT_COMPLEX || d.out_mode == XRFTHIP_OUT_POWER) &&
                    !(d.flags & ~okr) && !((d.flags & XRFTHIP_HALF_X) && (d.flags & XRFTHIP_SHIFT_X)) && !env_ll("XRFTHIP_NO_FAST", 0) && env_ll("XRFTHIP_FASTR", 1) != 0;
         if (P->fastr) {
-            P->tune_rgrid = env_ll("XRFTHIP_FASTR_GRID", 0);
+            P->tune_rgrid = env_ll("XRFTHIP_FASTR_GRID", kCUs);  // one resident workgroup per CU walks the rows (measured: 359 vs 344 GFFT/s for a workgroup per row, profiles/r04_fastr.txt)
             int rcr = build_twiddle<float>(P->tw_rm, d.nx / 2, 1024);
             if (!rcr) rcr = build_twiddle<float>(P->tw_rs, 1024, 32);
             if (!rcr) rcr = build_twiddle<float>(P->tw_rn, d.nx, 1024);

@@ -6,6 +6,7 @@ arithmetic step runs inside libxrft_hip.so.
 from __future__ import annotations
 
 import ctypes as C
+import os
 import threading
 
 import numpy as np
@@ -64,7 +65,7 @@ class SpectralPlan:
                 raise ValueError(f"bin map shape {bm.shape} != {(self.ny, self.nx_out)}")
             _lib.check(self._dll.xrfthip_plan_set_binmap(self._h, bm.ctypes.data_as(C.c_void_p), self.ny,
                                                          self.nx_out, self.nbins))
-        if dtype in _WIDER and self._dll.xrfthip_plan_uses_bluestein(self._h):
+        if dtype in _WIDER and bluestein_in_float64() and self._dll.xrfthip_plan_uses_bluestein(self._h):
             # float32 data on a length that takes Bluestein's algorithm: the chirp convolution (two long transforms and three pointwise
             # products) leaves an error of a few 1e-7 of the spectrum's PEAK in every bin -- 1e-3 relative in the bins 1e-3 of the
             # peak.  Such plans run in float64 between two precision changes (xrfthip_convert); float32 in, float32 out as ever.
@@ -239,6 +240,20 @@ def detrend_inner(x, axis0, naxes, kind):
     ws = torch.empty(max(nws, 16), dtype=torch.uint8, device=x.device)
     _lib.check(dll.xrfthip_detrend_inner(_DTYPES[x.dtype], naxes, batch, ny, nx, inner, kind, _ptr(x), _ptr(out), _ptr(ws), nws, _stream_handle(x)))
     return out
+
+
+_BLUESTEIN_F64 = [os.environ.get("XRFT_AMD_BLUESTEIN", "float64").lower() not in ("float32", "f32", "fast")]
+
+
+def bluestein_in_float64(enable=None):
+    """float32 data on a transform length that takes Bluestein's algorithm (a prime factor with no butterfly: the ERA5 grid's 721 =
+    7 x 103 latitudes) run in float64 between two precision changes -- the default: in float32 the chirp convolution leaves every bin
+    an error of a few 1e-7 of the spectrum's PEAK, up to 4e-3 relative in the bins 1e-3 of the peak (the far end of a red spectrum).
+    ``bluestein_in_float64(False)`` (or XRFT_AMD_BLUESTEIN=float32 in the environment) keeps float32 arithmetic: about twice as fast on
+    such lengths ((64, 721, 1440): 56 against 26 GFFT/s), the max-norm bound of 1e-3 still holds.  Returns the setting."""
+    if enable is not None:
+        _BLUESTEIN_F64[0] = bool(enable)
+    return _BLUESTEIN_F64[0]
 
 
 _WIDER = {torch.float32: torch.float64, torch.complex64: torch.complex128}
