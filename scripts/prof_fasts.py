@@ -1,0 +1,42 @@
+#!/usr/bin/env python3
+"""The one-pass 256 x 256 slab kernel (csrc/fasts.h) against the two-pass pipeline (XRFTHIP_FASTS=0) on (4096, 256, 256) float32 power
+spectra: per-kernel HIP-event time and wall time per call; resident workgroups vs one per slab."""
+import os, sys, time, warnings
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+import xrft_amd as xrft
+from xrft_amd import api
+warnings.simplefilter("ignore")
+NT = int(os.environ.get("NT", "4096"))
+
+
+def prof(name, fn, pts, reps=10):
+    fn(); fn(); torch.cuda.synchronize()
+    plan = [p for p in api._plan_cache.values()][-1]
+    t0 = time.perf_counter()
+    for _ in range(reps): fn()
+    torch.cuda.synchronize(); wall = (time.perf_counter() - t0) / reps
+    plan.set_profiling(True)
+    for _ in range(reps): fn()
+    torch.cuda.synchronize()
+    p = plan.read_profile(); plan.set_profiling(False)
+    ks = " | ".join(f"{k} {ms / c * 1e3:.1f} us" for k, (c, ms) in p.items())
+    print(f"{name:50s} {ks} || wall {wall * 1e6:.1f} us = {pts / wall / 1e9:.1f} GFFT/s", flush=True)
+
+
+x = torch.randn((NT, 256, 256), dtype=torch.float32, device="cuda") + 2.0
+da = xrft.DataArray(x, ("t", "y", "x"), {"y": np.arange(256.), "x": np.arange(256.)})
+pts = x.numel()
+res = {}
+for label, env in (("fasts, one resident workgroup per CU", {"XRFTHIP_FASTS": "1", "XRFTHIP_FASTS_GRID": "256"}),
+                   ("fasts, one workgroup per slab", {"XRFTHIP_FASTS": "1", "XRFTHIP_FASTS_GRID": "0"}),
+                   ("two passes (fasty)", {"XRFTHIP_FASTS": "0"})):
+    os.environ.update(env); api._plan_cache.clear()
+    print("---", label, flush=True)
+    prof("power_spectrum linear + hann", lambda: xrft.power_spectrum(da, dim=["y", "x"], detrend="linear", window="hann"), pts)
+    prof("power_spectrum, no detrend, no window", lambda: xrft.power_spectrum(da, dim=["y", "x"]), pts)
+    prof("power_spectrum constant + hamming, shift=False", lambda: xrft.power_spectrum(da, dim=["y", "x"], detrend="constant", window="hamming", shift=False), pts)
+    res[label] = xrft.power_spectrum(da, dim=["y", "x"], detrend="linear", window="hann").data[:64].clone()
+ks = list(res)
+print("resident == per-slab launch, bit for bit:", bool(torch.equal(res[ks[0]], res[ks[1]])))
+print("max |fasts - fasty| / max:", float((res[ks[0]] - res[ks[2]]).abs().max() / res[ks[2]].abs().max()))

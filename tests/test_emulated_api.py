@@ -151,7 +151,10 @@ def test_long_prime_lengths_through_global_bluestein():
     (2048, 2048, 1, True, None, "hann"),
     (1024, 4096, 1, True, "linear", "hann"),
     (4096, 1024, 1, False, "linear", "hann"),
-    (256, 256, 5, True, "linear", "hann"),
+    (256, 256, 5, True, "linear", "hann"),      # (256 x 256: one slab per workgroup, one pass -- csrc/fasts.h)
+    (256, 256, 2, False, None, None),
+    (256, 256, 3, True, "constant", "hamming"),
+    (256, 256, 2, False, "linear", None),
     (512, 256, 3, True, "linear", "hamming"),
     (256, 1024, 2, False, "constant", None),
     (512, 512, 2, True, None, "hann"),

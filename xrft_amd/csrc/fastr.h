@@ -214,7 +214,10 @@ __global__ void __launch_bounds__(kFastRThreads) fastr_kernel(FastR p) {
             __syncthreads();
             double t0 = 0.0, t1 = 0.0;  // (`red` is next written a row later, behind the barriers of the exchanges)
 #pragma unroll
-            for (int w = 0; w < T / 64; ++w) { t0 += red[2 * w]; t1 += red[2 * w + 1]; }
+            for (int w = 0; w < T / 64; ++w) {
+                t0 += red[2 * w]; t1 += red[2 * w + 1];
+                if ((w & 3) == 3) fastr_sched_fence();  // (four waves' sums at a time: all 32 values at once are 64 registers beside the row's 64)
+            }
             constexpr double INV_N = 1.0 / N, INV_SII = 12.0 / ((double)N * ((double)N * N - 1.0));
             const double slope = p.detrend == 2 ? t1 * INV_SII : 0.0;
             const double l0 = fma(slope, c0, t0 * INV_N), dl = 2048.0 * slope;  // the line at sample 2 n_j: l0 + dl j

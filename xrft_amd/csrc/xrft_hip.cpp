@@ -23,11 +23,15 @@
 #include <vector>
 
 #include "../../include/xrft_hip.h"
+#ifndef XRFT_EMULATE
+#include <hip/hip_ext.h>
+#endif
 #include "aux_kernels.h"
 #include "fastp2.h"
 #include "fasty.h"
 #include "fastm.h"
 #include "fastr.h"
+#include "fasts.h"
 #include "tile_fft.h"
 #ifdef XRFT_SPLIT_TUS  /* the library built from several translation units: the fasty / fastm kernels are instantiated in inst_g*.cpp */
 namespace xrft {
@@ -324,6 +328,10 @@ struct xrfthip_plan {
     bool fastmy = false;
     // ... and the same transform over short contiguous rows packed in pairs (ndim = 1, fastm_xonly_kernel)
     bool fastmx = false;
+    // ... and ONE pass for a small real float32 slab that fits the registers of a CU: 256 x 256 power spectra (fasts.h)
+    bool fasts = false;
+    DevBuf tw_s256;
+    long long tune_sgrid = 0;     // XRFTHIP_FASTS_GRID: workgroups of the launch (0 = one per slab; default: one resident workgroup per CU)
     // ... and ONE pass for a long real float32 row that fits the registers of a CU: 65536 samples per workgroup (fastr.h)
     bool fastr = false;
     DevBuf tw_rm, tw_rs, tw_rn;   // W_M^p (p < 1024), W_1024^n (n < 32), W_N^p (p < 1024)
@@ -817,6 +825,7 @@ void set_kernel_attrs_once() {
 #undef SETALL
 #undef SETA
 #define SETF(K) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&K), hipFuncAttributeMaxDynamicSharedMemorySize, m)
+    SETF(fasts_power_kernel);
     SETF((fastr_kernel<0, false>)); SETF((fastr_kernel<0, true>)); SETF((fastr_kernel<1, false>)); SETF((fastr_kernel<1, true>));
 #define SETY(NN) SETF((fasty_cols_kernel<NN, false>)); SETF((fasty_cols_kernel<NN, true>)); SETF((fasty_cols_kernel<NN, false, true>)); SETF((fasty_cols_kernel<NN, true, true>)); SETF((fasty_rows_kernel<NN, 1, false>)); SETF((fasty_rows_kernel<NN, 1, true>)); \
                  SETF((fasty_rows_kernel<NN, 0, false>)); SETF((fasty_rows_kernel<NN, 2, false>)); SETF((fasty_rows_kernel<NN, 2, true>)); SETF((fasty_rows_kernel<NN, 3, false>))
@@ -934,7 +943,7 @@ static int run_radial_sums(int32_t dtype, const void* spec, const int32_t* d_bin
 
 static void layout_workspace(xrfthip_plan* P) {
     const xrfthip_desc& d = P->d;
-    if (P->fastr) { P->G = (int)std::max<long long>(1, std::min<long long>(d.batch, 1 << 30)); P->ws_bytes = 0; return; }  // one pass, registers + LDS: no intermediate
+    if (P->fastr || P->fasts) { P->G = (int)std::max<long long>(1, std::min<long long>(d.batch, 1 << 30)); P->ws_bytes = 0; return; }  // one pass, registers + LDS: no intermediate
     const bool fast = fast_on(P);
     long long G = d.slabs_per_group > 0 ? d.slabs_per_group : P->tune_group;
     size_t slab_w = (size_t)d.ny * std::max(P->width, P->w_cols) * P->csize;
@@ -1807,6 +1816,30 @@ static int run_fastmx(const xrfthip_plan* P, const void* in, const void* in1, vo
     return XRFTHIP_OK;
 }
 
+// one pass over 256 x 256 float32 slabs (fasts.h): a resident 1024-thread workgroup per CU walks the slabs
+static int run_fasts(const xrfthip_plan* P, const void* in, void* out, hipStream_t st) {
+    const xrfthip_desc& d = P->d;
+    FastS p{};
+    p.in = (const float*)in; p.out = (float*)out;
+    p.tw = (const cf*)P->tw_s256.p;
+    const bool win = P->win[0].p || P->win[1].p;
+    p.win_y = win ? (const float*)(P->win[0].p ? P->win[0].p : P->ones4096.p) : nullptr;
+    p.win_x = win ? (const float*)(P->win[1].p ? P->win[1].p : P->ones4096.p) : nullptr;
+    p.nslabs = d.batch;
+    p.detrend = d.detrend;
+    p.shift_y = (d.flags & XRFTHIP_SHIFT_Y) ? 128 : 0;
+    p.shift_x = (d.flags & XRFTHIP_SHIFT_X) ? 128 : 0;
+    p.scale = (float)d.scale;
+    const long long g = P->tune_sgrid > 0 ? std::min<long long>(P->tune_sgrid, d.batch) : d.batch;
+    const dim3 grid((unsigned)std::min<long long>(g, 0x7fffffffLL)), blk(kFastSThreads);
+    xrfthip_plan::ProfRec* rec = prof_begin(P, "fasts_slab", st);
+    auto k = &fasts_power_kernel;
+    XRFT_LAUNCH(k, grid, blk, kFastSLds, st, p);
+    prof_end(rec, st);
+    HIP_TRY(hipGetLastError());
+    return XRFTHIP_OK;
+}
+
 // one pass over 65536-sample float32 rows (fastr.h): a 1024-thread workgroup per row, or a resident set walking the rows
 static int run_fastr(const xrfthip_plan* P, const void* in, void* out, hipStream_t st) {
     const xrfthip_desc& d = P->d;
@@ -1823,12 +1856,25 @@ static int run_fastr(const xrfthip_plan* P, const void* in, void* out, hipStream
     p.scale = (float)d.scale;
     const long long g = P->tune_rgrid > 0 ? std::min<long long>(P->tune_rgrid, d.batch) : d.batch;
     const dim3 grid((unsigned)std::min<long long>(g, 0x7fffffffLL)), blk(kFastRThreads);
-    xrfthip_plan::ProfRec* rec = prof_begin(P, "fastr_row", st);
     const bool pw = d.out_mode == XRFTHIP_OUT_POWER;
+    // profiling (bench.py's roofline.kernel): the start / stop timestamps ride on the kernel's own dispatch packet (hipExtLaunchKernelGGL)
+    // instead of two event records around it -- barrier packets either side of a 0.18-ms kernel cost the C2 bench line 50 us per step
+    hipEvent_t ea = nullptr, eb = nullptr;
+#ifndef XRFT_EMULATE
+    if (P->prof && P->prof_recs.size() + 1 < P->prof_recs.capacity() && hipEventCreate(&ea) == hipSuccess) {
+        if (hipEventCreate(&eb) != hipSuccess) { (void)hipEventDestroy(ea); ea = nullptr; }
+    }
+#define RL_(MM, HH) do { auto k = &fastr_kernel<MM, HH>; if (ea) hipExtLaunchKernelGGL(k, grid, blk, kFastRLds, st, ea, eb, 0, p); else XRFT_LAUNCH(k, grid, blk, kFastRLds, st, p); } while (0)
+#else
 #define RL_(MM, HH) do { auto k = &fastr_kernel<MM, HH>; XRFT_LAUNCH(k, grid, blk, kFastRLds, st, p); } while (0)
+#endif
     if (pw) { if (p.half) RL_(1, true); else RL_(1, false); } else { if (p.half) RL_(0, true); else RL_(0, false); }
 #undef RL_
-    prof_end(rec, st);
+    if (ea) {
+        xrfthip_plan::ProfRec r;
+        r.label = "fastr_row"; r.a = ea; r.b = eb;
+        const_cast<xrfthip_plan*>(P)->prof_recs.push_back(r);
+    }
     HIP_TRY(hipGetLastError());
     return XRFTHIP_OK;
 }
@@ -1837,7 +1883,9 @@ static int run_fastr(const xrfthip_plan* P, const void* in, void* out, hipStream
 // set: window spectra and phase tables of the specialised paths (device allocations + blocking copies) and the workspace
 // layout.  xrfthip_exec itself takes the plan as const: no allocation, no copy, no synchronisation, no getenv.
 static int finalize_plan(xrfthip_plan* P) {
-    if (P->fastr) {
+    if (P->fasts) {
+        // (nothing to build: the windows are the plan's own tables)
+    } else if (P->fastr) {
         if (P->d.out_mode != XRFTHIP_OUT_POWER) { const int rc = fast_phase_tables(P); if (rc) return rc; }
     } else if (P->fastmx) {
         if (P->d.out_mode != XRFTHIP_OUT_POWER) { const int rc = fast_phase_tables(P); if (rc) return rc; }
@@ -2075,6 +2123,17 @@ int xrfthip_plan_create(xrfthip_plan** plan, const xrfthip_desc* desc) {
                       !(d.flags & ~allowed) && !((d.flags & halff) && (d.flags & XRFTHIP_ISO)) && !((d.flags & XRFTHIP_HALF_X) && (d.flags & XRFTHIP_SHIFT_X)) &&
                       !env_ll("XRFTHIP_NO_FAST", 0);
     }
+    // a 256 x 256 float32 slab fits the registers of one CU: full power spectra in ONE pass (fasts.h)
+    P->fasts = P->fast4096 && d.ny == 256 && d.nx == 256 && d.out_mode == XRFTHIP_OUT_POWER && !(d.flags & ~(XRFTHIP_SHIFT_Y | XRFTHIP_SHIFT_X)) &&
+               env_ll("XRFTHIP_FASTS", 1) != 0;
+    if (P->fasts) {
+        P->fast4096 = false;
+        P->tune_sgrid = env_ll("XRFTHIP_FASTS_GRID", kCUs);
+        std::vector<float> ones((size_t)256, 1.0f);
+        int rcs = build_twiddle<float>(P->tw_s256, 256, 256);
+        if (!rcs) rcs = P->ones4096.upload(ones.data(), ones.size() * sizeof(float));
+        if (rcs) { delete P; return rcs; }
+    }
     if (P->fast4096) {
         // every mode of these slabs takes the two-pass y-first pipeline (fasty.h)
         P->yfirst = true;
@@ -2281,7 +2340,7 @@ int xrfthip_plan_profile_read(xrfthip_plan* plan, char* buf, size_t buflen) {
 int xrfthip_plan_uses_bluestein(const xrfthip_plan* plan) {
     if (!plan) return 0;
     if (plan->inner > 1) return xrfthip_plan_uses_bluestein(plan->sub_x) || xrfthip_plan_uses_bluestein(plan->sub_y);
-    if (plan->fastr || plan->fastmx || plan->fastmy || plan->fastm || plan->fast1d || plan->fast4096) return 0;  // (the generic passes of such a plan never run)
+    if (plan->fasts || plan->fastr || plan->fastmx || plan->fastmy || plan->fastm || plan->fast1d || plan->fast4096) return 0;  // (the generic passes of such a plan never run)
     for (const Pass& ps : plan->passes) if (ps.g.blue_n > 0) return 1;
     for (const Pass& ps : plan->passes_f0) if (ps.g.blue_n > 0) return 1;
     return 0;
@@ -2314,7 +2373,12 @@ int xrfthip_plan_describe(const xrfthip_plan* plan, char* buf, size_t buflen) {
     appendf(s, "xrfthip plan: ndim=%d batch=%lld ny=%lld nx=%lld dtype=%d mode=%d detrend=%d flags=0x%x width=%lld nx_out=%lld mirror=%d group=%d ws=%zuB\n",
             d.ndim, (long long)d.batch, (long long)d.ny, (long long)d.nx, d.dtype, d.out_mode, d.detrend, d.flags,
             plan->width, plan->nx_out, (int)plan->mirror, plan->G, plan->ws_bytes);
-    if (plan->fastr) {
+    if (plan->fasts) {
+        appendf(s, "  [fasts] one pass, one %d-thread workgroup per 256 x 256 slab (grid %lld): the packed columns' transform, their split and the rows' transform in "
+                   "registers (32 complex per thread, r32x8 per axis, three LDS exchanges in halves), exact plane detrend in the workgroup, |F|^2 rows staged in "
+                   "LDS and written whole with the fftshift and the Hermitian mirror, lds=%zuB; 8 algorithmic bytes per sample through memory\n",
+                kFastSThreads, plan->tune_sgrid > 0 ? std::min<long long>(plan->tune_sgrid, plan->d.batch) : (long long)plan->d.batch, kFastSLds);
+    } else if (plan->fastr) {
         appendf(s, "  [fastr] one pass, one %d-thread workgroup per %lld-sample row (grid %lld): the packed %lld-point complex transform in registers (32 per thread, "
                    "r32x32x32, two LDS exchanges in halves), real split through the LDS, lds=%zuB; per-row detrend + window + full (or half) spectrum; "
                    "12 algorithmic bytes per sample through memory\n",
@@ -2380,6 +2444,7 @@ int xrfthip_exec(const xrfthip_plan* plan, const void* d_in0, const void* d_in1,
     double* acc = (double*)(ws + P->off_acc);
     double* coef = (double*)(ws + P->off_coef);
     if (iso) HIP_TRY(hipMemsetAsync(d_iso, 0, (size_t)d.batch * P->nbins * (cross ? 16 : 8), st));
+    if (P->fasts) return run_fasts(P, d_in0, out, st);
     if (P->fastr) return run_fastr(P, d_in0, out, st);
     if (P->fastmx) return run_fastmx(P, d_in0, d_in1, out, st);
     if (P->fastmy) return run_fastmy(P, d_in0, d_in1, out, st);
