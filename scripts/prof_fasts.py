@@ -24,19 +24,22 @@ def prof(name, fn, pts, reps=10):
     print(f"{name:50s} {ks} || wall {wall * 1e6:.1f} us = {pts / wall / 1e9:.1f} GFFT/s", flush=True)
 
 
-x = torch.randn((NT, 256, 256), dtype=torch.float32, device="cuda") + 2.0
-da = xrft.DataArray(x, ("t", "y", "x"), {"y": np.arange(256.), "x": np.arange(256.)})
-pts = x.numel()
-res = {}
-for label, env in (("fasts, one resident workgroup per CU", {"XRFTHIP_FASTS": "1", "XRFTHIP_FASTS_GRID": "256"}),
-                   ("fasts, one workgroup per slab", {"XRFTHIP_FASTS": "1", "XRFTHIP_FASTS_GRID": "0"}),
-                   ("two passes (fasty)", {"XRFTHIP_FASTS": "0"})):
-    os.environ.update(env); api._plan_cache.clear()
-    print("---", label, flush=True)
-    prof("power_spectrum linear + hann", lambda: xrft.power_spectrum(da, dim=["y", "x"], detrend="linear", window="hann"), pts)
-    prof("power_spectrum, no detrend, no window", lambda: xrft.power_spectrum(da, dim=["y", "x"]), pts)
-    prof("power_spectrum constant + hamming, shift=False", lambda: xrft.power_spectrum(da, dim=["y", "x"], detrend="constant", window="hamming", shift=False), pts)
-    res[label] = xrft.power_spectrum(da, dim=["y", "x"], detrend="linear", window="hann").data[:64].clone()
-ks = list(res)
-print("resident == per-slab launch, bit for bit:", bool(torch.equal(res[ks[0]], res[ks[1]])))
-print("max |fasts - fasty| / max:", float((res[ks[0]] - res[ks[2]]).abs().max() / res[ks[2]].abs().max()))
+for ny, nx in ((256, 256), (128, 128), (64, 64), (128, 256), (256, 64)):
+    nt = (NT * 256 * 256) // (ny * nx)
+    x = torch.randn((nt, ny, nx), dtype=torch.float32, device="cuda") + 2.0
+    da = xrft.DataArray(x, ("t", "y", "x"), {"y": np.arange(float(ny)), "x": np.arange(float(nx))})
+    pts = x.numel()
+    res = {}
+    print(f"=== ({nt}, {ny}, {nx}) float32", flush=True)
+    for label, env in (("fasts, resident workgroups", {"XRFTHIP_FASTS": "1", "XRFTHIP_FASTS_GRID": "-1"}),
+                       ("fasts, one workgroup per slab", {"XRFTHIP_FASTS": "1", "XRFTHIP_FASTS_GRID": "0"}),
+                       ("without (two passes: fasty at 256 x 256, the generic tile kernels below)", {"XRFTHIP_FASTS": "0"})):
+        os.environ.update(env); api._plan_cache.clear()
+        print("---", label, flush=True)
+        prof("power_spectrum linear + hann", lambda: xrft.power_spectrum(da, dim=["y", "x"], detrend="linear", window="hann"), pts)
+        prof("power_spectrum, no detrend, no window", lambda: xrft.power_spectrum(da, dim=["y", "x"]), pts)
+        res[label] = xrft.power_spectrum(da, dim=["y", "x"], detrend="linear", window="hann").data[:64].clone()
+    ks = list(res)
+    print("resident == per-slab launch, bit for bit:", bool(torch.equal(res[ks[0]], res[ks[1]])),
+          "| max |fasts - the other path| / max:", float((res[ks[0]] - res[ks[2]]).abs().max() / res[ks[2]].abs().max()), flush=True)
+    del x, da, res

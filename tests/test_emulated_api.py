@@ -155,6 +155,15 @@ def test_long_prime_lengths_through_global_bluestein():
     (256, 256, 2, False, None, None),
     (256, 256, 3, True, "constant", "hamming"),
     (256, 256, 2, False, "linear", None),
+    (128, 128, 3, True, "linear", "hann"),      # (64 | 128 | 256 points per axis: the same kernel, smaller workgroups)
+    (64, 64, 5, True, "linear", "hann"),
+    (64, 64, 2, False, None, None),
+    (128, 256, 2, True, "constant", "hamming"),
+    (256, 64, 2, False, "linear", "hann"),
+    (64, 128, 3, True, "linear", None),
+    (128, 64, 2, True, None, "hann"),
+    (256, 128, 2, True, "linear", "hann"),
+    (64, 256, 2, True, "linear", "hann"),
     (512, 256, 3, True, "linear", "hamming"),
     (256, 1024, 2, False, "constant", None),
     (512, 512, 2, True, None, "hann"),

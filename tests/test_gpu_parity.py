@@ -173,6 +173,20 @@ def test_adversarial_detrend_float32_headline_shape():
     (512, 512, 5, "linear", "hann", True),
     (256, 2048, 3, "constant", None, False),
     (512, 256, 3, None, "hamming", True),
+    # one slab per workgroup, ONE pass (csrc/fasts.h): 64 | 128 | 256 points per axis, every workgroup size and the rectangular ones
+    (256, 256, 300, "linear", "hann", True),    # (more slabs than resident workgroups: the slab loop)
+    (256, 256, 3, None, None, False),
+    (256, 256, 5, "constant", "hamming", True),
+    (128, 128, 900, "linear", "hann", True),
+    (128, 128, 4, None, None, False),
+    (64, 64, 3300, "linear", "hann", True),
+    (64, 64, 5, "constant", None, False),
+    (128, 256, 5, "linear", "hann", True),
+    (256, 128, 5, "linear", "hamming", False),
+    (64, 256, 6, "linear", "hann", True),
+    (256, 64, 6, None, "hann", True),
+    (64, 128, 7, "linear", None, True),
+    (128, 64, 7, "constant", "hann", False),
 ])
 def test_fastp2_shapes_vs_oracle(ny, nx, nt, det, win, shift):
     """Every power-of-two shape the specialised kernels take (fasty.h) against the oracle, several slabs."""

@@ -330,8 +330,8 @@ struct xrfthip_plan {
     bool fastmx = false;
     // ... and ONE pass for a small real float32 slab that fits the registers of a CU: 256 x 256 power spectra (fasts.h)
     bool fasts = false;
-    DevBuf tw_s256;
-    long long tune_sgrid = 0;     // XRFTHIP_FASTS_GRID: workgroups of the launch (0 = one per slab; default: one resident workgroup per CU)
+    DevBuf tw_sy, tw_sx;
+    long long tune_sgrid = -1;    // XRFTHIP_FASTS_GRID: workgroups of the launch (0 = one per slab, the default; else a resident set walking the slabs)
     // ... and ONE pass for a long real float32 row that fits the registers of a CU: 65536 samples per workgroup (fastr.h)
     bool fastr = false;
     DevBuf tw_rm, tw_rs, tw_rn;   // W_M^p (p < 1024), W_1024^n (n < 32), W_N^p (p < 1024)
@@ -825,7 +825,8 @@ void set_kernel_attrs_once() {
 #undef SETALL
 #undef SETA
 #define SETF(K) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&K), hipFuncAttributeMaxDynamicSharedMemorySize, m)
-    SETF(fasts_power_kernel);
+    SETF((fasts_power_kernel<8, 8>));  // (the only one above 64 KB of dynamic LDS)
+    SETF((fasts_power_kernel<8, 4>)); SETF((fasts_power_kernel<4, 8>));
     SETF((fastr_kernel<0, false>)); SETF((fastr_kernel<0, true>)); SETF((fastr_kernel<1, false>)); SETF((fastr_kernel<1, true>));
 #define SETY(NN) SETF((fasty_cols_kernel<NN, false>)); SETF((fasty_cols_kernel<NN, true>)); SETF((fasty_cols_kernel<NN, false, true>)); SETF((fasty_cols_kernel<NN, true, true>)); SETF((fasty_rows_kernel<NN, 1, false>)); SETF((fasty_rows_kernel<NN, 1, true>)); \
                  SETF((fasty_rows_kernel<NN, 0, false>)); SETF((fasty_rows_kernel<NN, 2, false>)); SETF((fasty_rows_kernel<NN, 2, true>)); SETF((fasty_rows_kernel<NN, 3, false>))
@@ -1816,25 +1817,42 @@ static int run_fastmx(const xrfthip_plan* P, const void* in, const void* in1, vo
     return XRFTHIP_OK;
 }
 
-// one pass over 256 x 256 float32 slabs (fasts.h): a resident 1024-thread workgroup per CU walks the slabs
+// one pass over small float32 slabs (fasts.h): resident workgroups walk the slabs
+struct SGeomRt { int thr; size_t lds; int per_cu; };
+template <int RY, int RX> static SGeomRt sgeom_t() {
+    typedef SGeom<RY, RX> G;
+    const int by_lds = (int)((160 * 1024) / G::LDS);
+    return {G::T, G::LDS, std::max(1, std::min(by_lds, (int)G::PER_CU))};
+}
+static SGeomRt sgeom(long long ny, long long nx) {
+#define SG_(A, B) if (ny == 32 * A && nx == 32 * B) return sgeom_t<A, B>();
+    SG_(2, 2) SG_(2, 4) SG_(2, 8) SG_(4, 2) SG_(4, 4) SG_(4, 8) SG_(8, 2) SG_(8, 4) SG_(8, 8)
+#undef SG_
+    return {0, 0, 0};
+}
 static int run_fasts(const xrfthip_plan* P, const void* in, void* out, hipStream_t st) {
     const xrfthip_desc& d = P->d;
     FastS p{};
     p.in = (const float*)in; p.out = (float*)out;
-    p.tw = (const cf*)P->tw_s256.p;
+    p.tw_y = (const cf*)P->tw_sy.p; p.tw_x = (const cf*)P->tw_sx.p;
     const bool win = P->win[0].p || P->win[1].p;
     p.win_y = win ? (const float*)(P->win[0].p ? P->win[0].p : P->ones4096.p) : nullptr;
     p.win_x = win ? (const float*)(P->win[1].p ? P->win[1].p : P->ones4096.p) : nullptr;
     p.nslabs = d.batch;
     p.detrend = d.detrend;
-    p.shift_y = (d.flags & XRFTHIP_SHIFT_Y) ? 128 : 0;
-    p.shift_x = (d.flags & XRFTHIP_SHIFT_X) ? 128 : 0;
+    p.shift_y = (d.flags & XRFTHIP_SHIFT_Y) ? (int)(d.ny / 2) : 0;
+    p.shift_x = (d.flags & XRFTHIP_SHIFT_X) ? (int)(d.nx / 2) : 0;
     p.scale = (float)d.scale;
-    const long long g = P->tune_sgrid > 0 ? std::min<long long>(P->tune_sgrid, d.batch) : d.batch;
-    const dim3 grid((unsigned)std::min<long long>(g, 0x7fffffffLL)), blk(kFastSThreads);
+    const SGeomRt G = sgeom(d.ny, d.nx);
+    // one workgroup per slab by default: measured against the resident set (kCUs x per_cu workgroups walking the slabs), (16384, 128, 128)
+    // linear + Hann 531 vs 425 GFFT/s, (65536, 64, 64) 577 vs 497, 256 x 256 even (profiles/r04_fasts.txt)
+    const long long res = P->tune_sgrid < 0 ? 0 : P->tune_sgrid;
+    const long long g = res > 0 ? std::min<long long>(res, d.batch) : d.batch;
+    const dim3 grid((unsigned)std::min<long long>(g, 0x7fffffffLL)), blk((unsigned)G.thr);
     xrfthip_plan::ProfRec* rec = prof_begin(P, "fasts_slab", st);
-    auto k = &fasts_power_kernel;
-    XRFT_LAUNCH(k, grid, blk, kFastSLds, st, p);
+#define SL_(A, B) if (d.ny == 32 * A && d.nx == 32 * B) { auto k = &fasts_power_kernel<A, B>; XRFT_LAUNCH(k, grid, blk, G.lds, st, p); }
+    SL_(2, 2) SL_(2, 4) SL_(2, 8) SL_(4, 2) SL_(4, 4) SL_(4, 8) SL_(8, 2) SL_(8, 4) SL_(8, 8)
+#undef SL_
     prof_end(rec, st);
     HIP_TRY(hipGetLastError());
     return XRFTHIP_OK;
@@ -2123,14 +2141,18 @@ int xrfthip_plan_create(xrfthip_plan** plan, const xrfthip_desc* desc) {
                       !(d.flags & ~allowed) && !((d.flags & halff) && (d.flags & XRFTHIP_ISO)) && !((d.flags & XRFTHIP_HALF_X) && (d.flags & XRFTHIP_SHIFT_X)) &&
                       !env_ll("XRFTHIP_NO_FAST", 0);
     }
-    // a 256 x 256 float32 slab fits the registers of one CU: full power spectra in ONE pass (fasts.h)
-    P->fasts = P->fast4096 && d.ny == 256 && d.nx == 256 && d.out_mode == XRFTHIP_OUT_POWER && !(d.flags & ~(XRFTHIP_SHIFT_Y | XRFTHIP_SHIFT_X)) &&
-               env_ll("XRFTHIP_FASTS", 1) != 0;
+    // a small float32 slab (64 | 128 | 256 points per axis) fits the registers of one workgroup: full power spectra in ONE pass (fasts.h)
+    {
+        auto small_len = [](long long n) { return n == 64 || n == 128 || n == 256; };
+        P->fasts = d.ndim == 2 && d.dtype == XRFTHIP_F32 && small_len(d.ny) && small_len(d.nx) && d.out_mode == XRFTHIP_OUT_POWER &&
+                   !(d.flags & ~(XRFTHIP_SHIFT_Y | XRFTHIP_SHIFT_X)) && !env_ll("XRFTHIP_NO_FAST", 0) && env_ll("XRFTHIP_FASTS", 1) != 0;
+    }
     if (P->fasts) {
         P->fast4096 = false;
-        P->tune_sgrid = env_ll("XRFTHIP_FASTS_GRID", kCUs);
+        P->tune_sgrid = env_ll("XRFTHIP_FASTS_GRID", -1);
         std::vector<float> ones((size_t)256, 1.0f);
-        int rcs = build_twiddle<float>(P->tw_s256, 256, 256);
+        int rcs = build_twiddle<float>(P->tw_sy, d.ny, d.ny);
+        if (!rcs) rcs = build_twiddle<float>(P->tw_sx, d.nx, d.nx);
         if (!rcs) rcs = P->ones4096.upload(ones.data(), ones.size() * sizeof(float));
         if (rcs) { delete P; return rcs; }
     }
@@ -2374,10 +2396,11 @@ int xrfthip_plan_describe(const xrfthip_plan* plan, char* buf, size_t buflen) {
             d.ndim, (long long)d.batch, (long long)d.ny, (long long)d.nx, d.dtype, d.out_mode, d.detrend, d.flags,
             plan->width, plan->nx_out, (int)plan->mirror, plan->G, plan->ws_bytes);
     if (plan->fasts) {
-        appendf(s, "  [fasts] one pass, one %d-thread workgroup per 256 x 256 slab (grid %lld): the packed columns' transform, their split and the rows' transform in "
-                   "registers (32 complex per thread, r32x8 per axis, three LDS exchanges in halves), exact plane detrend in the workgroup, |F|^2 rows staged in "
-                   "LDS and written whole with the fftshift and the Hermitian mirror, lds=%zuB; 8 algorithmic bytes per sample through memory\n",
-                kFastSThreads, plan->tune_sgrid > 0 ? std::min<long long>(plan->tune_sgrid, plan->d.batch) : (long long)plan->d.batch, kFastSLds);
+        const SGeomRt G = sgeom(plan->d.ny, plan->d.nx);
+        appendf(s, "  [fasts] one pass, one %d-thread workgroup per %lld x %lld slab (%d fit a CU): the packed columns' transform, their split and the rows' "
+                   "transform in registers (32 complex per thread, r32x%lld / r32x%lld, three LDS exchanges in halves), exact plane detrend in the workgroup, |F|^2 "
+                   "rows staged in LDS and written whole with the fftshift and the Hermitian mirror, lds=%zuB; 8 algorithmic bytes per sample through memory\n",
+                G.thr, (long long)plan->d.ny, (long long)plan->d.nx, G.per_cu, (long long)plan->d.ny / 32, (long long)plan->d.nx / 32, G.lds);
     } else if (plan->fastr) {
         appendf(s, "  [fastr] one pass, one %d-thread workgroup per %lld-sample row (grid %lld): the packed %lld-point complex transform in registers (32 per thread, "
                    "r32x32x32, two LDS exchanges in halves), real split through the LDS, lds=%zuB; per-row detrend + window + full (or half) spectrum; "
