@@ -1049,7 +1049,9 @@ def run_fused_radial_code_forms(n=256):
         os.environ["XRFTHIP_ISO_GATHER"] = gather  # (read once, when a plan is created)
         for mode in (_lib.OUT_POWER, _lib.OUT_CROSS):
             plan = engine.SpectralPlan(2, nt, n, n, torch.float32, out_mode=mode, flags=_lib.ISO, scale=1.0, binmap=bm, nbins=nb)
-            assert want in plan.describe(), (name, plan.describe())
+            # (a radial map of a power spectrum of slabs up to 256 x 256 is summed inside the one-pass kernel, csrc/fasts.h; any other map
+            # and the cross spectra take the two-pass kernels this test is about)
+            assert ("[fasts]" if (n <= 256 and mode == _lib.OUT_POWER and name == "radial") else want) in plan.describe(), (name, plan.describe())
             t2 = torch.from_numpy(np.roll(v, 3, axis=2).copy()).to(dev) if mode == _lib.OUT_CROSS else None
             out, iso = plan.execute(t, t2)
             out2, iso2 = plan.execute(t, t2)

@@ -57,7 +57,7 @@ def test_bench_two_ranks_power_spectrum(scaling):
         assert cfg["nt_per_gpu"] == 3 and cfg["nt_total"] == 6
     else:
         assert cfg["nt_total"] == 3 and cfg["nt_per_gpu"] == 2  # rank 0 owns slabs [0, 2)
-    assert out["roofline"]["achieved"] >= 0 and "fasty_cols" in out["roofline"]["kernels_ms_per_step"]
+    assert out["roofline"]["achieved"] >= 0 and "fasts_slab" in out["roofline"]["kernels_ms_per_step"]  # (256 x 256 slabs: the one-pass kernel)
 
 
 def test_bench_two_ranks_c4_all_gather():

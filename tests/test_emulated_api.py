@@ -202,7 +202,11 @@ def test_fastp2_path(ny, nx, nt, shift, det, win):
 
 @pytest.mark.parametrize("ny,nx,nt,det,win,truncate", [(1024, 1024, 3, "linear", "hann", True), (1024, 2048, 2, None, None, False),
                                                      (2048, 1024, 1, "constant", "hann", True), (256, 256, 4, "linear", "hann", True),
-                                                     (512, 256, 3, None, "hann", False)])
+                                                     (512, 256, 3, None, "hann", False),
+                                                     # one slab per workgroup (csrc/fasts.h): the radial sums from the staged rows
+                                                     (256, 256, 2, None, None, False), (128, 128, 5, "linear", "hann", True),
+                                                     (64, 64, 9, "linear", "hann", False), (128, 256, 3, "constant", "hamming", True),
+                                                     (256, 64, 3, "linear", "hann", False), (64, 128, 4, None, "hann", True)])
 def test_fastp2_isotropic(ny, nx, nt, det, win, truncate):
     """isotropic_power_spectrum through the specialised kernels: radial sums taken inside the column pass."""
     import xrft_amd as xa
@@ -215,6 +219,8 @@ def test_fastp2_isotropic(ny, nx, nt, det, win, truncate):
     c = {"t": np.arange(nt), "y": np.arange(ny) * 1.0, "x": np.arange(nx) * 1.0}
     got = xa.isotropic_power_spectrum(xa.DataArray(v, ("t", "y", "x"), c), dim=["y", "x"], detrend=det, window=win, truncate=truncate)
     assert any("[fast" in p.describe() for p in api._plan_cache.values())
+    if max(ny, nx) <= 256:
+        assert any("[fasts]" in p.describe() for p in api._plan_cache.values())
     ref = o.isotropic_power_spectrum(o.OArr(v, ("t", "y", "x"), c), dim=["y", "x"], detrend=det, window=win, truncate=truncate)
     cases.check(got, ref, 3e-4)
     api._plan_cache.clear()
@@ -533,6 +539,7 @@ def test_detrend_inner_scratch_is_bounded_and_extents_are_checked():
 
 def test_fused_radial_sums_compact_and_full_bin_codes():
     cases.run_fused_radial_code_forms(256)
+    cases.run_fused_radial_code_forms(512)
 
 
 @pytest.mark.parametrize("ny,nx,dtype", [(360, 240, "float64"), (240, 480, "float32")])

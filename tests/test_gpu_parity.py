@@ -209,7 +209,10 @@ def test_fastp2_shapes_vs_oracle(ny, nx, nt, det, win, shift):
 
 
 @pytest.mark.parametrize("ny,nx,nt,det,win", [(256, 256, 9, "linear", "hann"), (512, 256, 4, None, "hann"), (1024, 1024, 5, "linear", "hann"), (2048, 2048, 3, "linear", "hann"),
-                                            (2048, 1024, 2, None, None), (4096, 4096, 2, "linear", "hann")])
+                                            (2048, 1024, 2, None, None), (4096, 4096, 2, "linear", "hann"),
+                                            # one slab per workgroup (csrc/fasts.h): radial sums from the staged rows
+                                            (256, 256, 300, None, None), (128, 128, 700, "linear", "hann"), (64, 64, 2000, "linear", "hann"),
+                                            (128, 256, 6, "constant", "hamming"), (256, 64, 6, "linear", "hann"), (64, 128, 5, None, "hann")])
 def test_fastp2_isotropic_vs_oracle(ny, nx, nt, det, win):
     """isotropic_power_spectrum with the radial sums taken inside the specialised column pass (no full spectrum written)."""
     import xrft_amd as xa

@@ -36,6 +36,11 @@ struct FastS {
     int detrend;        // 0 none, 1 constant, 2 linear (plane)
     int shift_y, shift_x;  // 0 or N/2
     float scale;
+    // radial sums (xrft.isotropize, xrft/xrft.py:895-906, 993-1004) of a RADIAL bin map, taken from the staged rows: no partial tables, no
+    // atomics, one float64 sum per bin in a fixed order
+    double* iso;                   // [slabs][nbins]
+    const unsigned short* tfirst;  // [NY/2 + 1][nbins + 1]: the smallest |kx| <= NX/2 of row ky whose bin is >= b (NX/2 + 1 if none)
+    int nbins;                     // <= threads of the workgroup
 };
 
 constexpr size_t fasts_max(size_t a, size_t b) { return a > b ? a : b; }
@@ -52,6 +57,8 @@ template <int RY, int RX> struct SGeom {
     static constexpr size_t E1 = (size_t)NXP * P1 * 8, E2 = (size_t)NROW * PX * 8, E3 = (size_t)(NROW / 2) * P3 * 8, EF = (size_t)(NROW + 1) * PF * 4;
     static constexpr size_t LDS_MAIN = (fasts_max(fasts_max(E1, E2), fasts_max(E3, EF)) + 15) & ~(size_t)15;
     static constexpr size_t LDS = LDS_MAIN + (size_t)NW * 3 * 8;  // + the detrend sums per wave
+    static constexpr size_t EFA = (EF + 15) & ~(size_t)15;        // radial sums: the per-chunk partial sums (one float64 per thread) behind the staged rows
+    static constexpr size_t LDS_ISO = fasts_max(LDS_MAIN, EFA + (size_t)T * 8) + (size_t)NW * 3 * 8;
     // waves per SIMD asked of the compiler: 4 (128 registers) where two workgroups per CU need it (512 threads) and at 1024 threads; the small
     // workgroups take the 152 registers the kernel wants without spilling and run three waves per SIMD
     static constexpr int WPS = T >= 512 ? 4 : 3;
@@ -117,7 +124,8 @@ template <int R> __device__ __forceinline__ void fasts_split(cf* b, int c) {
     }
 }
 
-template <int RY, int RX>
+// ISO: 0 the power spectrum; 1 the spectrum and its radial sums; 2 the radial sums only (XRFTHIP_NO_SPECTRUM_OUT)
+template <int RY, int RX, int ISO = 0>
 __global__ void __launch_bounds__((SGeom<RY, RX>::T), (SGeom<RY, RX>::WPS)) fasts_power_kernel(FastS p) {
     typedef SGeom<RY, RX> G;
     constexpr int NY = G::NY, NX = G::NX, T = G::T, NXP = G::NXP, NROW = G::NROW, KGY = G::KGY, KGX = G::KGX;
@@ -125,7 +133,7 @@ __global__ void __launch_bounds__((SGeom<RY, RX>::T), (SGeom<RY, RX>::WPS)) fast
     XRFT_DYN_SMEM(smem_raw);
     cf* L = reinterpret_cast<cf*>(smem_raw);
     float* Lf = reinterpret_cast<float*>(smem_raw);
-    double* red = reinterpret_cast<double*>(smem_raw + G::LDS_MAIN);  // [waves][3]
+    double* red = reinterpret_cast<double*>(smem_raw + (ISO ? G::LDS_ISO : G::LDS) - (size_t)G::NW * 3 * 8);  // [waves][3]
     for (long long slab = blockIdx.x; slab < p.nslabs; slab += gridDim.x) {
         int tid = threadIdx.x;
         XRFT_OPAQUE(tid);  // (nothing derived from the thread index is hoisted out of the slab loop and spilled: fastr.h)
@@ -291,6 +299,38 @@ __global__ void __launch_bounds__((SGeom<RY, RX>::T), (SGeom<RY, RX>::WPS)) fast
                     }
         }
         __syncthreads();
+        if (ISO) {
+            // Radial sums straight from the staged rows.  In row ky the bin b of a radial map covers |kx| in [first[ky][b], first[ky][b + 1]):
+            // the samples kx = |kx| and kx = NX - |kx|; a row 0 < ky < NY/2 counts twice (its Hermitian twin -ky has the same power and bins).
+            // Task = (bin, chunk of rows): float64 sums in sample order, then the chunks of a bin in chunk order: bit-reproducible.
+            const int nb = p.nbins;
+            int rcn = T / nb;
+            rcn = rcn < 1 ? 1 : (rcn > NROW + 1 ? NROW + 1 : rcn);
+            double* part = reinterpret_cast<double*>(smem_raw + G::EFA);  // [rcn][nb]
+            if (tid < nb * rcn) {
+                const int bn = tid % nb, rc = tid / nb;
+                double acc = 0.0;
+                for (int ky = rc; ky <= NROW; ky += rcn) {
+                    const unsigned short* __restrict__ fr = p.tfirst + (size_t)ky * (nb + 1) + bn;
+                    const int s = fr[0], e = fr[1];
+                    const float* r = Lf + ky * PF;
+                    double rs = 0.0;
+                    const int e1 = e < NX / 2 + 1 ? e : NX / 2 + 1;
+                    for (int m = s; m < e1; ++m) rs += (double)r[m];                       // kx = m
+                    const int ms = s > 1 ? s : 1, me = e < NX / 2 ? e : NX / 2;
+                    for (int m = ms; m < me; ++m) rs += (double)r[NX - m];                 // kx = NX - m
+                    acc += (ky != 0 && ky != NROW) ? 2.0 * rs : rs;
+                }
+                part[rc * nb + bn] = acc;
+            }
+            __syncthreads();
+            if (tid < nb) {
+                double tot = 0.0;
+                for (int rc = 0; rc < rcn; ++rc) tot += part[rc * nb + tid];
+                p.iso[(size_t)slab * nb + tid] = tot;
+            }
+            if (ISO == 2) continue;  // (the next slab's first exchange starts with a barrier)
+        }
         // ---- every output row whole: row ky (<= NY/2) rotated by the fftshift, row NY - ky reversed (F[-ky][-kx] = conj F[ky][kx])
         float* __restrict__ o = p.out + (size_t)slab * NY * NX;
         for (int e = tid; e < NY * NX / 4; e += T) {

@@ -330,7 +330,7 @@ struct xrfthip_plan {
     bool fastmx = false;
     // ... and ONE pass for a small real float32 slab that fits the registers of a CU: 256 x 256 power spectra (fasts.h)
     bool fasts = false;
-    DevBuf tw_sy, tw_sx;
+    DevBuf tw_sy, tw_sx, s_tfirst;
     long long tune_sgrid = -1;    // XRFTHIP_FASTS_GRID: workgroups of the launch (0 = one per slab, the default; else a resident set walking the slabs)
     // ... and ONE pass for a long real float32 row that fits the registers of a CU: 65536 samples per workgroup (fastr.h)
     bool fastr = false;
@@ -825,8 +825,9 @@ void set_kernel_attrs_once() {
 #undef SETALL
 #undef SETA
 #define SETF(K) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&K), hipFuncAttributeMaxDynamicSharedMemorySize, m)
-    SETF((fasts_power_kernel<8, 8>));  // (the only one above 64 KB of dynamic LDS)
-    SETF((fasts_power_kernel<8, 4>)); SETF((fasts_power_kernel<4, 8>));
+    SETF((fasts_power_kernel<8, 8, 0>)); SETF((fasts_power_kernel<8, 8, 1>)); SETF((fasts_power_kernel<8, 8, 2>));  // (above 64 KB of dynamic LDS)
+    SETF((fasts_power_kernel<8, 4, 0>)); SETF((fasts_power_kernel<8, 4, 1>)); SETF((fasts_power_kernel<8, 4, 2>));
+    SETF((fasts_power_kernel<4, 8, 0>)); SETF((fasts_power_kernel<4, 8, 1>)); SETF((fasts_power_kernel<4, 8, 2>));
     SETF((fastr_kernel<0, false>)); SETF((fastr_kernel<0, true>)); SETF((fastr_kernel<1, false>)); SETF((fastr_kernel<1, true>));
 #define SETY(NN) SETF((fasty_cols_kernel<NN, false>)); SETF((fasty_cols_kernel<NN, true>)); SETF((fasty_cols_kernel<NN, false, true>)); SETF((fasty_cols_kernel<NN, true, true>)); SETF((fasty_rows_kernel<NN, 1, false>)); SETF((fasty_rows_kernel<NN, 1, true>)); \
                  SETF((fasty_rows_kernel<NN, 0, false>)); SETF((fasty_rows_kernel<NN, 2, false>)); SETF((fasty_rows_kernel<NN, 2, true>)); SETF((fasty_rows_kernel<NN, 3, false>))
@@ -1818,19 +1819,48 @@ static int run_fastmx(const xrfthip_plan* P, const void* in, const void* in1, vo
 }
 
 // one pass over small float32 slabs (fasts.h): resident workgroups walk the slabs
-struct SGeomRt { int thr; size_t lds; int per_cu; };
+struct SGeomRt { int thr; size_t lds; int per_cu; size_t lds_iso; };
 template <int RY, int RX> static SGeomRt sgeom_t() {
     typedef SGeom<RY, RX> G;
     const int by_lds = (int)((160 * 1024) / G::LDS);
-    return {G::T, G::LDS, std::max(1, std::min(by_lds, (int)G::PER_CU))};
+    return {G::T, G::LDS, std::max(1, std::min(by_lds, (int)G::PER_CU)), G::LDS_ISO};
 }
 static SGeomRt sgeom(long long ny, long long nx) {
 #define SG_(A, B) if (ny == 32 * A && nx == 32 * B) return sgeom_t<A, B>();
     SG_(2, 2) SG_(2, 4) SG_(2, 8) SG_(4, 2) SG_(4, 4) SG_(4, 8) SG_(8, 2) SG_(8, 4) SG_(8, 8)
 #undef SG_
-    return {0, 0, 0};
+    return {0, 0, 0, 0};
 }
-static int run_fasts(const xrfthip_plan* P, const void* in, void* out, hipStream_t st) {
+// fasts: is the bin map a radial one (see fasts_power_kernel, ISO)?  If so: first[ky][b] = the smallest |kx| <= nx/2 of row ky whose bin is
+// >= b (nx/2 + 1 if none), ky <= ny/2, b = 0 .. nbins.  Otherwise the plan leaves the one-pass path.
+static int fasts_build_tfirst(xrfthip_plan* P, const int32_t* bm) {
+    const int ny = (int)P->d.ny, nx = (int)P->d.nx, nyh = ny / 2, H = nx / 2;
+    bool radial = P->nbins <= sgeom(ny, nx).thr && P->nbins >= 1;
+    for (int ky = 0; ky <= nyh && radial; ++ky) {
+        const int32_t* r = bm + (size_t)ky * nx;
+        const bool twin = ky != 0 && 2 * ky != ny;
+        const int32_t* t = bm + (size_t)(twin ? ny - ky : ky) * nx;
+        for (int m = 0; m <= H; ++m) {
+            const int32_t c = r[m];
+            if (c < 0 || c >= P->nbins || (m > 0 && c < r[m - 1]) || (m >= 1 && m < H && r[nx - m] != c)) { radial = false; break; }
+            if (twin && (t[m] != c || t[(nx - m) % nx] != c)) { radial = false; break; }
+        }
+    }
+    if (!radial) { P->fasts = false; return XRFTHIP_OK; }
+    std::vector<uint16_t> f((size_t)(nyh + 1) * (P->nbins + 1), (uint16_t)(H + 1));
+    for (int ky = 0; ky <= nyh; ++ky) {
+        const int32_t* r = bm + (size_t)ky * nx;
+        uint16_t* dst = f.data() + (size_t)ky * (P->nbins + 1);
+        int m = 0;
+        for (int b = 0; b <= P->nbins; ++b) {
+            while (m <= H && r[m] < b) ++m;
+            dst[b] = (uint16_t)m;
+        }
+    }
+    return P->s_tfirst.upload(f.data(), f.size() * sizeof(uint16_t));
+}
+
+static int run_fasts(const xrfthip_plan* P, const void* in, void* out, double* iso, hipStream_t st) {
     const xrfthip_desc& d = P->d;
     FastS p{};
     p.in = (const float*)in; p.out = (float*)out;
@@ -1850,7 +1880,12 @@ static int run_fasts(const xrfthip_plan* P, const void* in, void* out, hipStream
     const long long g = res > 0 ? std::min<long long>(res, d.batch) : d.batch;
     const dim3 grid((unsigned)std::min<long long>(g, 0x7fffffffLL)), blk((unsigned)G.thr);
     xrfthip_plan::ProfRec* rec = prof_begin(P, "fasts_slab", st);
-#define SL_(A, B) if (d.ny == 32 * A && d.nx == 32 * B) { auto k = &fasts_power_kernel<A, B>; XRFT_LAUNCH(k, grid, blk, G.lds, st, p); }
+    const int isom = (d.flags & XRFTHIP_ISO) ? ((d.flags & XRFTHIP_NO_SPECTRUM_OUT) ? 2 : 1) : 0;
+    p.iso = iso; p.tfirst = (const unsigned short*)P->s_tfirst.p; p.nbins = P->nbins;
+#define SL_(A, B) if (d.ny == 32 * A && d.nx == 32 * B) { \
+        if (isom == 0) { auto k = &fasts_power_kernel<A, B, 0>; XRFT_LAUNCH(k, grid, blk, G.lds, st, p); } \
+        else if (isom == 1) { auto k = &fasts_power_kernel<A, B, 1>; XRFT_LAUNCH(k, grid, blk, G.lds_iso, st, p); } \
+        else { auto k = &fasts_power_kernel<A, B, 2>; XRFT_LAUNCH(k, grid, blk, G.lds_iso, st, p); } }
     SL_(2, 2) SL_(2, 4) SL_(2, 8) SL_(4, 2) SL_(4, 4) SL_(4, 8) SL_(8, 2) SL_(8, 4) SL_(8, 8)
 #undef SL_
     prof_end(rec, st);
@@ -2145,10 +2180,10 @@ int xrfthip_plan_create(xrfthip_plan** plan, const xrfthip_desc* desc) {
     {
         auto small_len = [](long long n) { return n == 64 || n == 128 || n == 256; };
         P->fasts = d.ndim == 2 && d.dtype == XRFTHIP_F32 && small_len(d.ny) && small_len(d.nx) && d.out_mode == XRFTHIP_OUT_POWER &&
-                   !(d.flags & ~(XRFTHIP_SHIFT_Y | XRFTHIP_SHIFT_X)) && !env_ll("XRFTHIP_NO_FAST", 0) && env_ll("XRFTHIP_FASTS", 1) != 0;
+                   !(d.flags & ~(XRFTHIP_SHIFT_Y | XRFTHIP_SHIFT_X | XRFTHIP_ISO | XRFTHIP_NO_SPECTRUM_OUT)) && !env_ll("XRFTHIP_NO_FAST", 0) && env_ll("XRFTHIP_FASTS", 1) != 0;
     }
-    if (P->fasts) {
-        P->fast4096 = false;
+    if (P->fasts) {  // (takes precedence over the two-pass pipeline wherever the plan is looked at; an isotropic plan whose bin map turns out
+                     // not to be a radial one falls back to it: xrfthip_plan_set_binmap)
         P->tune_sgrid = env_ll("XRFTHIP_FASTS_GRID", -1);
         std::vector<float> ones((size_t)256, 1.0f);
         int rcs = build_twiddle<float>(P->tw_sy, d.ny, d.ny);
@@ -2305,7 +2340,11 @@ int xrfthip_plan_set_binmap(xrfthip_plan* plan, const int32_t* h_binmap, int64_t
     int rc = plan->binmap.upload(h_binmap, (size_t)ny * nx_out * sizeof(int32_t));
     if (rc) return rc;
     plan->nbins = nbins;
-    if (plan->fast4096) {
+    if (plan->fasts) {  // a radial map within the workgroup's reach: the sums are taken from the staged rows (fasts.h); else the other paths
+        const int rcs = fasts_build_tfirst(plan, h_binmap);
+        if (rcs) return rcs;
+    }
+    if (plan->fast4096 && !plan->fasts) {
         int rcf = XRFTHIP_OK;
         if (plan->yfirst) {
             rcf = fasty_build_tcodes(plan, h_binmap);
@@ -2467,7 +2506,7 @@ int xrfthip_exec(const xrfthip_plan* plan, const void* d_in0, const void* d_in1,
     double* acc = (double*)(ws + P->off_acc);
     double* coef = (double*)(ws + P->off_coef);
     if (iso) HIP_TRY(hipMemsetAsync(d_iso, 0, (size_t)d.batch * P->nbins * (cross ? 16 : 8), st));
-    if (P->fasts) return run_fasts(P, d_in0, out, st);
+    if (P->fasts) return run_fasts(P, d_in0, out, (double*)d_iso, st);
     if (P->fastr) return run_fastr(P, d_in0, out, st);
     if (P->fastmx) return run_fastmx(P, d_in0, d_in1, out, st);
     if (P->fastmy) return run_fastmy(P, d_in0, d_in1, out, st);
