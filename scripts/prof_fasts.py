@@ -39,6 +39,7 @@ for ny, nx in ((256, 256), (128, 128), (64, 64), (128, 256), (256, 64)):
         prof("power_spectrum linear + hann", lambda: xrft.power_spectrum(da, dim=["y", "x"], detrend="linear", window="hann"), pts)
         prof("power_spectrum, no detrend, no window", lambda: xrft.power_spectrum(da, dim=["y", "x"]), pts)
         if "per slab" not in label:
+            prof("fft (complex result) linear + hann", lambda: xrft.fft(da, dim=["y", "x"], detrend="linear", window="hann"), pts)
             prof("isotropic_power_spectrum linear + hann", lambda: xrft.isotropic_power_spectrum(da, dim=["y", "x"], detrend="linear", window="hann"), pts)
         res[label] = xrft.power_spectrum(da, dim=["y", "x"], detrend="linear", window="hann").data[:64].clone()
     ks = list(res)

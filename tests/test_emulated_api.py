@@ -244,6 +244,14 @@ def _p2_fields(ny, nx, nt, seed, dx=1.0, x0=0.0):
     (2048, 1024, dict(shift=False, window="hamming", true_phase=True)),
     (256, 512, dict(detrend="linear", window="hann")),
     (512, 256, dict(true_phase=False)),
+    # one slab per workgroup (csrc/fasts.h): complex rows staged in halves, the mirror rows conjugated
+    (256, 256, dict(detrend="linear", window="hann")),
+    (256, 256, dict(true_phase=False, shift=False)),
+    (128, 128, dict(detrend="linear", window="hann")),
+    (64, 64, dict(true_phase=False, detrend="constant")),
+    (128, 256, dict(shift=False, window="hamming")),
+    (256, 64, dict(detrend="linear", window="hann")),
+    (64, 128, dict(true_phase=False)),
 ])
 def test_fastp2_complex_fft(ny, nx, kw):
     """xrft.fft of a real float32 slab through the specialised kernels (complex result, Hermitian half mirrored)."""
@@ -253,6 +261,8 @@ def test_fastp2_complex_fft(ny, nx, kw):
     da, od = _p2_fields(ny, nx, 2, 11, x0=3.0)
     got = xa.fft(da, dim=["y", "x"], **kw)
     assert any("[fast" in p.describe() for p in api._plan_cache.values())
+    if max(ny, nx) <= 256:
+        assert any("[fasts]" in p.describe() for p in api._plan_cache.values())
     cases.check(got, o.fft(od, dim=["y", "x"], **kw), 3e-4)
     api._plan_cache.clear()
 

@@ -253,6 +253,14 @@ def _assert_fast():
     (4096, 4096, 1, dict(detrend="linear", window="hann")),
     (256, 512, 4, dict(detrend="linear", window="hann")),
     (512, 256, 4, dict(true_phase=False)),
+    # one slab per workgroup (csrc/fasts.h)
+    (256, 256, 300, dict(detrend="linear", window="hann")),
+    (256, 256, 3, dict(true_phase=False, shift=False)),
+    (128, 128, 700, dict(detrend="linear", window="hann")),
+    (64, 64, 2500, dict(true_phase=False, detrend="constant")),
+    (128, 256, 5, dict(shift=False, window="hamming")),
+    (256, 64, 5, dict(detrend="linear", window="hann")),
+    (64, 128, 5, dict(true_phase=False)),
 ])
 def test_fastp2_complex_fft_vs_oracle(ny, nx, nt, kw):
     """xrft.fft of real float32 power-of-two slabs on the specialised path (true-phase factors, ifftshift sign, mirror)."""

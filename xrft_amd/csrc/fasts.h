@@ -41,6 +41,11 @@ struct FastS {
     double* iso;                   // [slabs][nbins]
     const unsigned short* tfirst;  // [NY/2 + 1][nbins + 1]: the smallest |kx| <= NX/2 of row ky whose bin is >= b (NX/2 + 1 if none)
     int nbins;                     // <= threads of the workgroup
+    // complex output (xrft.fft / dft): F scale x the true-phase factors, indexed by unshifted frequency (xrft.py:462-469; an ifftshifted input
+    // is the sign (-1)^k folded into the tables)
+    const cf* ph_y;
+    const cf* ph_x;
+    int ph_on;
 };
 
 constexpr size_t fasts_max(size_t a, size_t b) { return a > b ? a : b; }
@@ -55,7 +60,8 @@ template <int RY, int RX> struct SGeom {
     static constexpr int P3 = 33 * RX;            // exchange 3: elements per row
     static constexpr int PF = NX + 1;             // staged float rows
     static constexpr size_t E1 = (size_t)NXP * P1 * 8, E2 = (size_t)NROW * PX * 8, E3 = (size_t)(NROW / 2) * P3 * 8, EF = (size_t)(NROW + 1) * PF * 4;
-    static constexpr size_t LDS_MAIN = (fasts_max(fasts_max(E1, E2), fasts_max(E3, EF)) + 15) & ~(size_t)15;
+    static constexpr size_t EC = (size_t)(NROW / 2 + 1) * PF * 8;  // complex output: half of the rows (+ the Nyquist row) staged at a time
+    static constexpr size_t LDS_MAIN = (fasts_max(fasts_max(fasts_max(E1, E2), fasts_max(E3, EF)), EC) + 15) & ~(size_t)15;
     static constexpr size_t LDS = LDS_MAIN + (size_t)NW * 3 * 8;  // + the detrend sums per wave
     static constexpr size_t EFA = (EF + 15) & ~(size_t)15;        // radial sums: the per-chunk partial sums (one float64 per thread) behind the staged rows
     static constexpr size_t LDS_ISO = fasts_max(LDS_MAIN, EFA + (size_t)T * 8) + (size_t)NW * 3 * 8;
@@ -124,9 +130,11 @@ template <int R> __device__ __forceinline__ void fasts_split(cf* b, int c) {
     }
 }
 
-// ISO: 0 the power spectrum; 1 the spectrum and its radial sums; 2 the radial sums only (XRFTHIP_NO_SPECTRUM_OUT)
-template <int RY, int RX, int ISO = 0>
+// ISO: 0 the power spectrum; 1 the spectrum and its radial sums; 2 the radial sums only (XRFTHIP_NO_SPECTRUM_OUT).  MODE 1: power spectrum;
+// 0: the complex spectrum (xrft.fft / dft; ISO = 0)
+template <int RY, int RX, int ISO = 0, int MODE = 1>
 __global__ void __launch_bounds__((SGeom<RY, RX>::T), (SGeom<RY, RX>::WPS)) fasts_power_kernel(FastS p) {
+    static_assert(MODE == 1 || ISO == 0, "radial sums are of power spectra");
     typedef SGeom<RY, RX> G;
     constexpr int NY = G::NY, NX = G::NX, T = G::T, NXP = G::NXP, NROW = G::NROW, KGY = G::KGY, KGX = G::KGX;
     constexpr int P1 = G::P1, PX = G::PX, P3 = G::P3, PF = G::PF, HY = RY / 2, HX = RX / 2;
@@ -265,6 +273,67 @@ __global__ void __launch_bounds__((SGeom<RY, RX>::T), (SGeom<RY, RX>::WPS)) fast
         // ---- x, stage 2: DFT_RX over x0 -> kx2: b[(4 g + w) RX + kx2] = F[row][kx1 + 32 kx2]; the packed row 0 is split (rows 0 and NY/2)
         fasts_dft_r<RX>(b);
         if (row == 0) fasts_split<RX>(b, cx);
+        if (MODE == 0) {
+            // ---- complex output: F scale staged as complex rows, half of the rows at a time (rows [NROW/2 h, NROW/2 h + NROW/2) in slots
+            // 0 .. NROW/2 - 1; the Nyquist row NY/2, which the threads of row 0 hold, in slot NROW/2 of half 0), then every output row whole:
+            // row ky rotated by the fftshift, row NY - ky reversed and conjugated (F[-ky][-kx] = conj F[ky][kx]), x the phase factors
+            cf* __restrict__ oc = reinterpret_cast<cf*>(p.out) + (size_t)slab * NY * NX;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                __syncthreads();
+                if (row / (NROW / 2) == h) {
+                    if (row != 0) {
+                        cf* dst = L + (row % (NROW / 2)) * PF;
+#pragma unroll
+                        for (int g = 0; g < KGX; ++g)
+#pragma unroll
+                            for (int w = 0; w < 4; ++w)
+#pragma unroll
+                                for (int k2 = 0; k2 < RX; ++k2) dst[fasts_k1(cx * KGX + g, w) + 32 * k2] = cscale(b[(4 * g + w) * RX + k2], p.scale);
+                    } else {
+#pragma unroll
+                        for (int g = 0; g < KGX; ++g)
+#pragma unroll
+                            for (int w = 0; w < 4; ++w)
+#pragma unroll
+                                for (int k2 = 0; k2 < HX; ++k2) {
+                                    const int idx = fasts_k1(cx * KGX + g, w) + 32 * k2;
+                                    const cf e = cscale(b[(4 * g + w) * RX + k2], p.scale), o = cscale(b[(4 * g + (w ^ 1)) * RX + RX - 1 - k2], p.scale);
+                                    cf* r0 = L;                     // row 0
+                                    cf* rn = L + (NROW / 2) * PF;   // row NY/2
+                                    if (idx == 0) {  // e = F[0][0] + i F[0][NX/2], o = F[NY/2][0] + i F[NY/2][NX/2] (four real samples)
+                                        r0[0] = mk<float>(e.re, 0.f); r0[NX / 2] = mk<float>(e.im, 0.f);
+                                        rn[0] = mk<float>(o.re, 0.f); rn[NX / 2] = mk<float>(o.im, 0.f);
+                                    } else {         // rows 0 and NY/2 of a real field's spectrum are Hermitian in kx
+                                        r0[idx] = e; r0[NX - idx] = cconj(e);
+                                        rn[idx] = o; rn[NX - idx] = cconj(o);
+                                    }
+                                }
+                    }
+                }
+                __syncthreads();
+                constexpr int NSL = NROW / 2 + 1;  // slots (the last one only in half 0)
+                for (int e = tid; e < NSL * 2 * (NX / 2); e += T) {
+                    const int ch = e % (NX / 2), rr = e / (NX / 2), sl = rr >> 1, mir = rr & 1;
+                    const int ky = sl == NROW / 2 ? NROW : sl + h * (NROW / 2);
+                    if ((sl == NROW / 2 && h == 1) || (mir && (ky == 0 || ky == NROW))) continue;
+                    const cf* r = L + sl * PF;
+                    const int c0 = 2 * ch;                                              // output columns c0, c0 + 1
+                    const int fx0 = (c0 - p.shift_x) & (NX - 1), fx1 = (c0 + 1 - p.shift_x) & (NX - 1);  // their unshifted frequency indices
+                    const int fy = mir ? NY - ky : ky;
+                    cf v0, v1;
+                    if (!mir) { v0 = r[fx0]; v1 = r[fx1]; }
+                    else { v0 = cconj(r[(NX - fx0) & (NX - 1)]); v1 = cconj(r[(NX - fx1) & (NX - 1)]); }
+                    if (p.ph_on) {
+                        const cf py = p.ph_y[fy];
+                        v0 = cmul(v0, cmul(py, p.ph_x[fx0]));
+                        v1 = cmul(v1, cmul(py, p.ph_x[fx1]));
+                    }
+                    xrft_store_nt2(oc + (size_t)((fy + p.shift_y) & (NY - 1)) * NX + c0, v0, v1);
+                }
+            }
+            continue;
+        }
         // ---- |F|^2 scale, staged as float rows: row r (0 <= r <= NY/2) at r PF + kx
         __syncthreads();
         if (row != 0) {

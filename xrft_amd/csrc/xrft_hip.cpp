@@ -825,6 +825,7 @@ void set_kernel_attrs_once() {
 #undef SETALL
 #undef SETA
 #define SETF(K) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&K), hipFuncAttributeMaxDynamicSharedMemorySize, m)
+    SETF((fasts_power_kernel<8, 8, 0, 0>)); SETF((fasts_power_kernel<8, 4, 0, 0>)); SETF((fasts_power_kernel<4, 8, 0, 0>));
     SETF((fasts_power_kernel<8, 8, 0>)); SETF((fasts_power_kernel<8, 8, 1>)); SETF((fasts_power_kernel<8, 8, 2>));  // (above 64 KB of dynamic LDS)
     SETF((fasts_power_kernel<8, 4, 0>)); SETF((fasts_power_kernel<8, 4, 1>)); SETF((fasts_power_kernel<8, 4, 2>));
     SETF((fasts_power_kernel<4, 8, 0>)); SETF((fasts_power_kernel<4, 8, 1>)); SETF((fasts_power_kernel<4, 8, 2>));
@@ -1882,8 +1883,11 @@ static int run_fasts(const xrfthip_plan* P, const void* in, void* out, double* i
     xrfthip_plan::ProfRec* rec = prof_begin(P, "fasts_slab", st);
     const int isom = (d.flags & XRFTHIP_ISO) ? ((d.flags & XRFTHIP_NO_SPECTRUM_OUT) ? 2 : 1) : 0;
     p.iso = iso; p.tfirst = (const unsigned short*)P->s_tfirst.p; p.nbins = P->nbins;
+    const bool cplx = d.out_mode == XRFTHIP_OUT_COMPLEX;
+    p.ph_y = (const cf*)P->fph[0].p; p.ph_x = (const cf*)P->fph[1].p; p.ph_on = (cplx && P->fph_on) ? 1 : 0;
 #define SL_(A, B) if (d.ny == 32 * A && d.nx == 32 * B) { \
-        if (isom == 0) { auto k = &fasts_power_kernel<A, B, 0>; XRFT_LAUNCH(k, grid, blk, G.lds, st, p); } \
+        if (cplx) { auto k = &fasts_power_kernel<A, B, 0, 0>; XRFT_LAUNCH(k, grid, blk, G.lds, st, p); } \
+        else if (isom == 0) { auto k = &fasts_power_kernel<A, B, 0>; XRFT_LAUNCH(k, grid, blk, G.lds, st, p); } \
         else if (isom == 1) { auto k = &fasts_power_kernel<A, B, 1>; XRFT_LAUNCH(k, grid, blk, G.lds_iso, st, p); } \
         else { auto k = &fasts_power_kernel<A, B, 2>; XRFT_LAUNCH(k, grid, blk, G.lds_iso, st, p); } }
     SL_(2, 2) SL_(2, 4) SL_(2, 8) SL_(4, 2) SL_(4, 4) SL_(4, 8) SL_(8, 2) SL_(8, 4) SL_(8, 8)
@@ -1937,7 +1941,7 @@ static int run_fastr(const xrfthip_plan* P, const void* in, void* out, hipStream
 // layout.  xrfthip_exec itself takes the plan as const: no allocation, no copy, no synchronisation, no getenv.
 static int finalize_plan(xrfthip_plan* P) {
     if (P->fasts) {
-        // (nothing to build: the windows are the plan's own tables)
+        if (P->d.out_mode != XRFTHIP_OUT_POWER) { const int rc = fast_phase_tables(P); if (rc) return rc; }
     } else if (P->fastr) {
         if (P->d.out_mode != XRFTHIP_OUT_POWER) { const int rc = fast_phase_tables(P); if (rc) return rc; }
     } else if (P->fastmx) {
@@ -2179,8 +2183,9 @@ int xrfthip_plan_create(xrfthip_plan** plan, const xrfthip_desc* desc) {
     // a small float32 slab (64 | 128 | 256 points per axis) fits the registers of one workgroup: full power spectra in ONE pass (fasts.h)
     {
         auto small_len = [](long long n) { return n == 64 || n == 128 || n == 256; };
-        P->fasts = d.ndim == 2 && d.dtype == XRFTHIP_F32 && small_len(d.ny) && small_len(d.nx) && d.out_mode == XRFTHIP_OUT_POWER &&
-                   !(d.flags & ~(XRFTHIP_SHIFT_Y | XRFTHIP_SHIFT_X | XRFTHIP_ISO | XRFTHIP_NO_SPECTRUM_OUT)) && !env_ll("XRFTHIP_NO_FAST", 0) && env_ll("XRFTHIP_FASTS", 1) != 0;
+        const uint32_t oks = XRFTHIP_SHIFT_Y | XRFTHIP_SHIFT_X | (d.out_mode == XRFTHIP_OUT_POWER ? (XRFTHIP_ISO | XRFTHIP_NO_SPECTRUM_OUT) : (XRFTHIP_ISHIFT_Y | XRFTHIP_ISHIFT_X));
+        P->fasts = d.ndim == 2 && d.dtype == XRFTHIP_F32 && small_len(d.ny) && small_len(d.nx) && (d.out_mode == XRFTHIP_OUT_POWER || d.out_mode == XRFTHIP_OUT_COMPLEX) &&
+                   !(d.flags & ~oks) && !env_ll("XRFTHIP_NO_FAST", 0) && env_ll("XRFTHIP_FASTS", 1) != 0;
     }
     if (P->fasts) {  // (takes precedence over the two-pass pipeline wherever the plan is looked at; an isotropic plan whose bin map turns out
                      // not to be a radial one falls back to it: xrfthip_plan_set_binmap)
