@@ -529,12 +529,12 @@ def run_fourstep_1d(n=65536, nt=3):
     da, od = pair(v, ("t", "x"), c)
     od64 = o.OArr(v.astype("float64"), ("t", "x"), c)
     worst = 0.0
-    # 65536 samples = one row per workgroup, in registers, ONE pass (csrc/fastr.h); longer rows: the two four-step passes (fasty.h)
-    tag = "[fastr]" if n == 65536 else "four-step]"
+    # 8192 ... 65536 samples = one row per workgroup, in registers, ONE pass (csrc/fastr.h); longer rows: the two four-step passes (fasty.h)
+    tag = "[fastr]" if n <= 65536 else "four-step]"
     for kw in (dict(), dict(true_phase=False, shift=False), dict(true_amplitude=False, shift=False)):
         worst = max(worst, check(xa.fft(da, dim=["x"], **kw), o.fft(od, dim=["x"], **kw), 3e-6))
     assert tag in next(reversed(xa.api._plan_cache.values())).describe()
-    if n == 65536:  # real_dim: the half spectrum k = 0..n/2, its power spectrum counted twice inside (xrft.py:400-404, 673-682)
+    if n <= 65536:  # real_dim: the half spectrum k = 0..n/2, its power spectrum counted twice inside (xrft.py:400-404, 673-682)
         for kw in (dict(), dict(true_phase=False)):
             worst = max(worst, check(xa.fft(da, dim=["x"], real_dim="x", **kw), o.fft(od, dim=["x"], real_dim="x", **kw), 3e-6))
             assert tag in next(reversed(xa.api._plan_cache.values())).describe()

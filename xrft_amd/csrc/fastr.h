@@ -308,4 +308,189 @@ __global__ void __launch_bounds__(kFastRThreads) fastr_kernel(FastR p) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------------------------------
+// The same for rows of N = 8192, 16384, 32768 samples: M = N / 2 = 32 R2 R3 packed points on T = R2 R3 = 128, 256, 512 threads, 32 per thread
+// (R2, R3 = 16, 8 | 16, 16 | 32, 16).  The whole row fits the LDS, so every exchange is ONE trip (all write, barrier, all read), and 4 / 2 / 1
+// workgroups share a CU (35 / 70 / 135 KB of LDS): below 32768 samples a CU's rows overlap their load, transform and store phases.
+//   stage 1   thread p = a + R3 b holds n = p + T j, j < 32:      DFT32 over j -> k1,  x W_M^(p k1)
+//   exchange  (a + R3 b | k1) -> (a + R3 c | s, b),  k1 = c + R2 s, s < 32 / R2           element (k1, p) at k1 (T + R3 mod 32) + p
+//   stage 2   DFT_R2 over b -> k2,  x W_T^(a k2)                                           [u = s R2 + k2]
+//   exchange  (a + R3 c | u) -> (d + R3 c | t, a),  u = d + R3 t, t < 32 / R3             element (u, a + R3 c) at u (T + 1) + a + R3 c
+//   stage 3   DFT_R3 over a -> k3:  Z[k], k = k1 + 32 (k2 + R2 k3)
+//   split     Z in natural order through the LDS (k + k / 32); thread v takes k = v + T m, m < 32, and its partner M - k:
+//             X[k] = A - i W_N^k B,  X[k + M] = A + i W_N^k B,  W_N^k = W_N^v W_64^m  (N / T = 64 for every size) -- lane-contiguous stores.
+// Every access is an 8-byte one with a lane stride that is conflict-free (1 element; T + R3 or T + 1 elements between the classes that share a
+// 32-lane group), except the natural-order writes of the last trip (2-way).
+// ------------------------------------------------------------------------------------------------------------------------------------------
+template <int R2, int R3> struct R2Geom {
+    static_assert((R2 == 32 && R3 == 16) || (R2 == 16 && R3 == 16) || (R2 == 16 && R3 == 8), "32768, 16384 or 8192 samples");
+    static constexpr int T = R2 * R3, M = 32 * T, N = 2 * M;
+    static constexpr int K2 = 32 / R2, K3 = 32 / R3;
+    static constexpr int S1 = T + (R3 % 32), S2 = T + 1;
+    static constexpr size_t LDS_MAIN = (size_t)(32 * S1 > M + M / 32 ? 32 * S1 : M + M / 32) * 8;
+    static constexpr int NW = T / 64;
+    static constexpr size_t LDS = LDS_MAIN + (size_t)NW * 2 * 8;
+    static constexpr int WPS = 4;  // (113-123 registers, none spilled: four waves per SIMD)
+};
+
+template <int R2, int R3, int MODE, bool HALF>
+__global__ void __launch_bounds__((R2Geom<R2, R3>::T), (R2Geom<R2, R3>::WPS)) fastr2_kernel(FastR p) {
+    typedef R2Geom<R2, R3> G;
+    constexpr int T = G::T, M = G::M, N = G::N, K2 = G::K2, K3 = G::K3, S1 = G::S1, S2 = G::S2;
+    constexpr float C64[32] = {
+        1.0000000000f, 0.9951847267f, 0.9807852804f, 0.9569403357f, 0.9238795325f, 0.8819212643f, 0.8314696123f, 0.7730104534f, 0.7071067812f,
+        0.6343932842f, 0.5555702330f, 0.4713967368f, 0.3826834324f, 0.2902846773f, 0.1950903220f, 0.0980171403f, 0.0000000000f, -0.0980171403f,
+        -0.1950903220f, -0.2902846773f, -0.3826834324f, -0.4713967368f, -0.5555702330f, -0.6343932842f, -0.7071067812f, -0.7730104534f,
+        -0.8314696123f, -0.8819212643f, -0.9238795325f, -0.9569403357f, -0.9807852804f, -0.9951847267f};
+    constexpr float S64[32] = {
+        0.0000000000f, -0.0980171403f, -0.1950903220f, -0.2902846773f, -0.3826834324f, -0.4713967368f, -0.5555702330f, -0.6343932842f,
+        -0.7071067812f, -0.7730104534f, -0.8314696123f, -0.8819212643f, -0.9238795325f, -0.9569403357f, -0.9807852804f, -0.9951847267f,
+        -1.0000000000f, -0.9951847267f, -0.9807852804f, -0.9569403357f, -0.9238795325f, -0.8819212643f, -0.8314696123f, -0.7730104534f,
+        -0.7071067812f, -0.6343932842f, -0.5555702330f, -0.4713967368f, -0.3826834324f, -0.2902846773f, -0.1950903220f, -0.0980171403f};
+    XRFT_DYN_SMEM(smem_raw);
+    cf* L = reinterpret_cast<cf*>(smem_raw);
+    double* red = reinterpret_cast<double*>(smem_raw + G::LDS_MAIN);  // [waves][2]
+    for (long long row = blockIdx.x; row < p.nrows; row += gridDim.x) {
+        int tid = threadIdx.x;
+        XRFT_OPAQUE(tid);
+        const cf* __restrict__ src = reinterpret_cast<const cf*>(p.in + (size_t)row * N) + tid;
+        cf a[32];
+#pragma unroll
+        for (int j = 0; j < 32; ++j) a[j] = src[j * T];  // z[n], n = tid + T j: samples 2n, 2n + 1
+        if (p.detrend) {  // (as in fastr_kernel: c_j = 2 n_j - ibar = c_0 + 2 T j)
+            constexpr double IBAR = 0.5 * (N - 1);
+            const double c0 = (double)(2 * tid) - IBAR;
+            double U = 0.0, V = 0.0, I = 0.0;
+#pragma unroll
+            for (int j = 0; j < 32; ++j) {
+                const double u = (double)a[j].re + (double)a[j].im;
+                U += u;
+                V = fma((double)j, u, V);
+                I += (double)a[j].im;
+            }
+            double s0 = U, s1 = fma(c0, U, fma((double)(2 * T), V, I));
+#pragma unroll
+            for (int m = 1; m < 64; m <<= 1) { s0 += __shfl_xor(s0, m); s1 += __shfl_xor(s1, m); }
+            if ((tid & 63) == 0) { red[(tid >> 6) * 2] = s0; red[(tid >> 6) * 2 + 1] = s1; }
+            __syncthreads();
+            double t0 = 0.0, t1 = 0.0;
+#pragma unroll
+            for (int w = 0; w < G::NW; ++w) { t0 += red[2 * w]; t1 += red[2 * w + 1]; }
+            constexpr double INV_N = 1.0 / N, INV_SII = 12.0 / ((double)N * ((double)N * N - 1.0));
+            const double slope = p.detrend == 2 ? t1 * INV_SII : 0.0;
+            const double l0 = fma(slope, c0, t0 * INV_N), dl = (double)(2 * T) * slope;
+#pragma unroll
+            for (int j = 0; j < 32; ++j) {
+                XRFT_OPAQUE(a[j].re); XRFT_OPAQUE(a[j].im);
+                const double lj = fma(dl, (double)j, l0);
+                a[j] = mk<float>((float)((double)a[j].re - lj), (float)((double)a[j].im - (lj + slope)));
+            }
+        }
+        if (p.win) {
+            const cf* __restrict__ wsrc = reinterpret_cast<const cf*>(p.win) + tid;
+#pragma unroll
+            for (int g = 0; g < 2; ++g) {
+                cf w[16];
+#pragma unroll
+                for (int j = 0; j < 16; ++j) w[j] = wsrc[(16 * g + j) * T];
+#pragma unroll
+                for (int j = 0; j < 16; ++j) a[16 * g + j] = mk<float>(a[16 * g + j].re * w[j].re, a[16 * g + j].im * w[j].im);
+                fastr_sched_fence();
+            }
+        }
+        // ---- stage 1
+        dft32f(a);
+        twiddle32f(a, p.tw_m[tid]);
+        // ---- exchange 1
+        const int aa = tid % R3, cc = tid / R3;  // before: (a, b); after: (a, c)
+        __syncthreads();
+#pragma unroll
+        for (int k1 = 0; k1 < 32; ++k1) L[k1 * S1 + tid] = a[k1];
+        __syncthreads();
+#pragma unroll
+        for (int s = 0; s < K2; ++s)
+#pragma unroll
+            for (int b = 0; b < R2; ++b) a[s * R2 + b] = L[(cc + R2 * s) * S1 + aa + R3 * b];
+        // ---- stage 2: DFT_R2 over b, x W_T^(a k2)
+        {
+            const cf wt = p.tw_s[aa];  // W_T^a
+            if (R2 == 32) { dft32f(a); twiddle32f(a, wt); }
+            else {
+#pragma unroll
+                for (int s = 0; s < K2; ++s) { dft16<float>(a + 16 * s); twiddle16<float>(a + 16 * s, wt); }
+            }
+        }
+        // ---- exchange 2
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < 32; ++u) L[u * S2 + tid] = a[u];
+        __syncthreads();
+        const int dd = tid % R3;  // after: (d, c), the same c
+#pragma unroll
+        for (int t = 0; t < K3; ++t)
+#pragma unroll
+            for (int e = 0; e < R3; ++e) a[t * R3 + e] = L[(dd + R3 * t) * S2 + e + R3 * cc];
+        // ---- stage 3: DFT_R3 over a -> k3
+#pragma unroll
+        for (int t = 0; t < K3; ++t) dft_r<float, R3>(a + R3 * t);
+        // ---- Z in natural order: register (t, k3) is k = k1 + 32 (k2 + R2 k3), u = d + R3 t = s R2 + k2, k1 = c + R2 s
+        __syncthreads();
+#pragma unroll
+        for (int t = 0; t < K3; ++t) {
+            const int u = dd + R3 * t, s2 = u / R2, k2 = u % R2, k1 = cc + R2 * s2;
+#pragma unroll
+            for (int k3 = 0; k3 < R3; ++k3) {
+                const int k = k1 + 32 * (k2 + R2 * k3);
+                L[k + (k >> 5)] = a[t * R3 + k3];
+            }
+        }
+        __syncthreads();
+        // ---- split + store: thread v takes k = v + T m
+        constexpr int W = HALF ? M + 1 : N;
+        const size_t orow = (size_t)row * W;
+        const int pos0 = tid + ((p.shift && !HALF) ? M : 0), pos1 = tid + (p.shift ? 0 : M);
+        const float sc = MODE == 1 ? 0.25f * p.scale : 0.5f * p.scale;
+        const cf wn = p.tw_n[tid];
+        const int km0 = (M - tid) & (M - 1);  // partner of m = 0; of m: km0 - T m (mod M)
+#pragma unroll
+        for (int g = 0; g < 8; ++g) {  // batches of 4
+            cf z[4], zm[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int m = 4 * g + q, k = tid + T * m, km = (km0 - T * m) & (M - 1);
+                z[q] = L[k + (k >> 5)];
+                zm[q] = L[km + (km >> 5)];
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int m = 4 * g + q;
+                const cf A = mk<float>(z[q].re + zm[q].re, z[q].im - zm[q].im), B = mk<float>(z[q].re - zm[q].re, z[q].im + zm[q].im);  // 2A, 2B
+                const cf w = m == 0 ? wn : cmul(wn, mk<float>(C64[m], S64[m]));  // W_N^k = W_N^tid W_64^m
+                const cf wb = cmul(w, B);
+                const cf t = mk<float>(-wb.im, wb.re);  // i W B
+                cf x0 = mk<float>(A.re - t.re, A.im - t.im), x1 = mk<float>(A.re + t.re, A.im + t.im);  // 2 X[k], 2 X[k + M]
+                if (MODE == 1) {
+                    float* o = reinterpret_cast<float*>(p.out) + orow;
+                    const float f = (HALF && p.realdim2 && (m != 0 || tid != 0)) ? 2.0f * sc : sc;
+                    fastr_store4(o + pos0 + T * m, (x0.re * x0.re + x0.im * x0.im) * f);
+                    if (!HALF) fastr_store4(o + pos1 + T * m, (x1.re * x1.re + x1.im * x1.im) * sc);
+                    else if (m == 0) { if (tid == 0) fastr_store4(o + M, (x1.re * x1.re + x1.im * x1.im) * sc); }
+                } else {
+                    x0 = cscale(x0, sc); x1 = cscale(x1, sc);
+                    cf* o = reinterpret_cast<cf*>(p.out) + orow;
+                    if (p.ph_on) {
+                        const int k = tid + T * m;
+                        x0 = cmul(x0, p.ph[k]);
+                        if (!HALF) x1 = cmul(x1, p.ph[k + M]);
+                    }
+                    fastr_store8(o + pos0 + T * m, x0);
+                    if (!HALF) fastr_store8(o + pos1 + T * m, x1);
+                    else if (m == 0) { if (tid == 0) fastr_store8(o + M, p.ph_on ? cmul(x1, p.ph[M]) : x1); }
+                }
+            }
+            fastr_sched_fence();
+        }
+    }
+}
+
 }  // namespace xrft

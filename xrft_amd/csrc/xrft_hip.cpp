@@ -830,6 +830,8 @@ void set_kernel_attrs_once() {
     SETF((fasts_power_kernel<8, 4, 0>)); SETF((fasts_power_kernel<8, 4, 1>)); SETF((fasts_power_kernel<8, 4, 2>));
     SETF((fasts_power_kernel<4, 8, 0>)); SETF((fasts_power_kernel<4, 8, 1>)); SETF((fasts_power_kernel<4, 8, 2>));
     SETF((fastr_kernel<0, false>)); SETF((fastr_kernel<0, true>)); SETF((fastr_kernel<1, false>)); SETF((fastr_kernel<1, true>));
+    SETF((fastr2_kernel<32, 16, 0, false>)); SETF((fastr2_kernel<32, 16, 0, true>)); SETF((fastr2_kernel<32, 16, 1, false>)); SETF((fastr2_kernel<32, 16, 1, true>));
+    SETF((fastr2_kernel<16, 16, 0, false>)); SETF((fastr2_kernel<16, 16, 0, true>)); SETF((fastr2_kernel<16, 16, 1, false>)); SETF((fastr2_kernel<16, 16, 1, true>));
 #define SETY(NN) SETF((fasty_cols_kernel<NN, false>)); SETF((fasty_cols_kernel<NN, true>)); SETF((fasty_cols_kernel<NN, false, true>)); SETF((fasty_cols_kernel<NN, true, true>)); SETF((fasty_rows_kernel<NN, 1, false>)); SETF((fasty_rows_kernel<NN, 1, true>)); \
                  SETF((fasty_rows_kernel<NN, 0, false>)); SETF((fasty_rows_kernel<NN, 2, false>)); SETF((fasty_rows_kernel<NN, 2, true>)); SETF((fasty_rows_kernel<NN, 3, false>))
     SETY(4096); SETY(2048); SETY(1024); SETY(512); SETY(256);
@@ -1912,7 +1914,7 @@ static int run_fastr(const xrfthip_plan* P, const void* in, void* out, hipStream
     p.shift = (d.flags & XRFTHIP_SHIFT_X) ? 1 : 0;
     p.scale = (float)d.scale;
     const long long g = P->tune_rgrid > 0 ? std::min<long long>(P->tune_rgrid, d.batch) : d.batch;
-    const dim3 grid((unsigned)std::min<long long>(g, 0x7fffffffLL)), blk(kFastRThreads);
+    const dim3 grid((unsigned)std::min<long long>(g, 0x7fffffffLL)), blk((unsigned)(d.nx / 64));
     const bool pw = d.out_mode == XRFTHIP_OUT_POWER;
     // profiling (bench.py's roofline.kernel): the start / stop timestamps ride on the kernel's own dispatch packet (hipExtLaunchKernelGGL)
     // instead of two event records around it -- barrier packets either side of a 0.18-ms kernel cost the C2 bench line 50 us per step
@@ -1921,12 +1923,18 @@ static int run_fastr(const xrfthip_plan* P, const void* in, void* out, hipStream
     if (P->prof && P->prof_recs.size() + 1 < P->prof_recs.capacity() && hipEventCreate(&ea) == hipSuccess) {
         if (hipEventCreate(&eb) != hipSuccess) { (void)hipEventDestroy(ea); ea = nullptr; }
     }
-#define RL_(MM, HH) do { auto k = &fastr_kernel<MM, HH>; if (ea) hipExtLaunchKernelGGL(k, grid, blk, kFastRLds, st, ea, eb, 0, p); else XRFT_LAUNCH(k, grid, blk, kFastRLds, st, p); } while (0)
+#define RK_(KK, LL) do { auto k = &KK; if (ea) hipExtLaunchKernelGGL(k, grid, blk, LL, st, ea, eb, 0, p); else XRFT_LAUNCH(k, grid, blk, LL, st, p); } while (0)
 #else
-#define RL_(MM, HH) do { auto k = &fastr_kernel<MM, HH>; XRFT_LAUNCH(k, grid, blk, kFastRLds, st, p); } while (0)
+#define RK_(KK, LL) do { auto k = &KK; XRFT_LAUNCH(k, grid, blk, LL, st, p); } while (0)
 #endif
+#define RL_(MM, HH) do { \
+        if (d.nx == 65536) RK_((fastr_kernel<MM, HH>), kFastRLds); \
+        else if (d.nx == 32768) RK_((fastr2_kernel<32, 16, MM, HH>), (R2Geom<32, 16>::LDS)); \
+        else if (d.nx == 16384) RK_((fastr2_kernel<16, 16, MM, HH>), (R2Geom<16, 16>::LDS)); \
+        else RK_((fastr2_kernel<16, 8, MM, HH>), (R2Geom<16, 8>::LDS)); } while (0)
     if (pw) { if (p.half) RL_(1, true); else RL_(1, false); } else { if (p.half) RL_(0, true); else RL_(0, false); }
 #undef RL_
+#undef RK_
     if (ea) {
         xrfthip_plan::ProfRec r;
         r.label = "fastr_row"; r.a = ea; r.b = eb;
@@ -2213,13 +2221,16 @@ int xrfthip_plan_create(xrfthip_plan** plan, const xrfthip_desc* desc) {
     {   // one real float32 row of 65536 samples per workgroup, transformed in registers in ONE pass (fastr.h): 12 bytes per sample through
         // memory where the four-step form below moves 28
         const uint32_t okr = XRFTHIP_SHIFT_X | XRFTHIP_HALF_X | (d.out_mode == XRFTHIP_OUT_POWER ? XRFTHIP_REALDIM_X2 : 0u) | (d.out_mode == XRFTHIP_OUT_COMPLEX ? XRFTHIP_ISHIFT_X : 0u);
-        P->fastr = d.ndim == 1 && d.nx == 65536 && d.dtype == XRFTHIP_F32 && (d.out_mode == XRFTHIP_OUT_COMPLEX || d.out_mode == XRFTHIP_OUT_POWER) &&
+        P->fastr = d.ndim == 1 && (d.nx == 65536 || d.nx == 32768 || d.nx == 16384 || d.nx == 8192) && d.dtype == XRFTHIP_F32 && (d.out_mode == XRFTHIP_OUT_COMPLEX || d.out_mode == XRFTHIP_OUT_POWER) &&
                    !(d.flags & ~okr) && !((d.flags & XRFTHIP_HALF_X) && (d.flags & XRFTHIP_SHIFT_X)) && !env_ll("XRFTHIP_NO_FAST", 0) && env_ll("XRFTHIP_FASTR", 1) != 0;
         if (P->fastr) {
-            P->tune_rgrid = env_ll("XRFTHIP_FASTR_GRID", kCUs);  // one resident workgroup per CU walks the rows (measured: 359 vs 344 GFFT/s for a workgroup per row, profiles/r04_fastr.txt)
-            int rcr = build_twiddle<float>(P->tw_rm, d.nx / 2, 1024);
-            if (!rcr) rcr = build_twiddle<float>(P->tw_rs, 1024, 32);
-            if (!rcr) rcr = build_twiddle<float>(P->tw_rn, d.nx, 1024);
+            // 65536 samples: one resident workgroup per CU walks the rows (measured: 359 vs 344 GFFT/s for a workgroup per row, profiles/r04_fastr.txt);
+            // the shorter rows (several workgroups per CU): a workgroup per row
+            P->tune_rgrid = env_ll("XRFTHIP_FASTR_GRID", d.nx == 65536 ? kCUs : 0);
+            const long long thr = d.nx / 64;  // threads per row: 32 packed complex values each
+            int rcr = build_twiddle<float>(P->tw_rm, d.nx / 2, thr);
+            if (!rcr) rcr = build_twiddle<float>(P->tw_rs, thr, 32);
+            if (!rcr) rcr = build_twiddle<float>(P->tw_rn, d.nx, thr);
             if (rcr) { delete P; return rcr; }
         }
     }
@@ -2446,11 +2457,13 @@ int xrfthip_plan_describe(const xrfthip_plan* plan, char* buf, size_t buflen) {
                    "rows staged in LDS and written whole with the fftshift and the Hermitian mirror, lds=%zuB; 8 algorithmic bytes per sample through memory\n",
                 G.thr, (long long)plan->d.ny, (long long)plan->d.nx, G.per_cu, (long long)plan->d.ny / 32, (long long)plan->d.nx / 32, G.lds);
     } else if (plan->fastr) {
-        appendf(s, "  [fastr] one pass, one %d-thread workgroup per %lld-sample row (grid %lld): the packed %lld-point complex transform in registers (32 per thread, "
-                   "r32x32x32, two LDS exchanges in halves), real split through the LDS, lds=%zuB; per-row detrend + window + full (or half) spectrum; "
+        const long long nxr = plan->d.nx;
+        appendf(s, "  [fastr] one pass, one %lld-thread workgroup per %lld-sample row (grid %lld): the packed %lld-point complex transform in registers (32 per thread, "
+                   "r32x%dx%d, LDS exchanges%s), real split through the LDS, lds=%zuB; per-row detrend + window + full (or half) spectrum; "
                    "12 algorithmic bytes per sample through memory\n",
-                kFastRThreads, (long long)plan->d.nx, plan->tune_rgrid > 0 ? std::min<long long>(plan->tune_rgrid, plan->d.batch) : (long long)plan->d.batch,
-                (long long)plan->d.nx / 2, kFastRLds);
+                nxr / 64, nxr, plan->tune_rgrid > 0 ? std::min<long long>(plan->tune_rgrid, plan->d.batch) : (long long)plan->d.batch, nxr / 2,
+                nxr >= 32768 ? 32 : 16, nxr == 65536 ? 32 : nxr == 8192 ? 8 : 16, nxr == 65536 ? " in halves" : "",
+                nxr == 65536 ? kFastRLds : nxr == 32768 ? R2Geom<32, 16>::LDS : nxr == 16384 ? R2Geom<16, 16>::LDS : R2Geom<16, 8>::LDS);
     } else if (plan->fastmx) {
         const MGeomRt C = mxgeom(plan->d.nx, plan->dbl);
         appendf(s, "  [fastm x-only] %d thr, %d row pairs per workgroup (FFT%lld r%dx%dx%d in LDS), lds=%zuB: per-row detrend + window + transform + full (or half) spectrum in one pass\n",
