@@ -23,7 +23,7 @@ def prof(name, fn, pts, reps=10):
     print(f"{name:46s} {ks} || wall {wall * 1e6:.1f} us = {pts / wall / 1e9:.1f} GFFT/s", flush=True)
 
 
-for n in (8192, 16384, 32768, 65536):
+for n in (4096, 8192, 16384, 32768, 65536):
     nt = (1 << 26) // n
     y = torch.randn((nt, n), dtype=torch.float32, device="cuda") + 3.0
     db = xrft.DataArray(y, ("t", "x"), {"x": np.arange(n) * 0.5 + 7.0})

@@ -452,7 +452,7 @@ def test_fftmod_backend_object():
     assert fftmod_cases.run_all(fftmod) < 2e-5
 
 
-@pytest.mark.parametrize("n", [8192, 16384, 32768, 65536, 262144])
+@pytest.mark.parametrize("n", [4096, 8192, 16384, 32768, 65536, 262144])
 def test_fourstep_1d_fast_path(n):
     cases.run_fourstep_1d(n, nt=2)
 

@@ -878,7 +878,7 @@ def test_radial_sums_any_nbins_and_bit_identical_repeats():
     cases.run_radial_sum_cases(big=True)
 
 
-@pytest.mark.parametrize("n", [8192, 16384, 32768, 65536, 131072, 1048576])
+@pytest.mark.parametrize("n", [4096, 8192, 16384, 32768, 65536, 131072, 1048576])
 def test_fourstep_1d_fast_path(n):
     cases.run_fourstep_1d(n, nt=3)
 

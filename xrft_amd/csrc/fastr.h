@@ -323,12 +323,12 @@ __global__ void __launch_bounds__(kFastRThreads) fastr_kernel(FastR p) {
 // 32-lane group), except the natural-order writes of the last trip (2-way).
 // ------------------------------------------------------------------------------------------------------------------------------------------
 template <int R2, int R3> struct R2Geom {
-    static_assert((R2 == 32 && R3 == 16) || (R2 == 16 && R3 == 16) || (R2 == 16 && R3 == 8), "32768, 16384 or 8192 samples");
+    static_assert((R2 == 32 && R3 == 16) || (R2 == 16 && R3 == 16) || (R2 == 16 && R3 == 8) || (R2 == 8 && R3 == 8), "32768, 16384, 8192 or 4096 samples");
     static constexpr int T = R2 * R3, M = 32 * T, N = 2 * M;
     static constexpr int K2 = 32 / R2, K3 = 32 / R3;
     static constexpr int S1 = T + (R3 % 32), S2 = T + 1;
     static constexpr size_t LDS_MAIN = (size_t)(32 * S1 > M + M / 32 ? 32 * S1 : M + M / 32) * 8;
-    static constexpr int NW = T / 64;
+    static constexpr int NW = T / 64;  // (>= 1: a 4096-sample row is one wave)
     static constexpr size_t LDS = LDS_MAIN + (size_t)NW * 2 * 8;
     static constexpr int WPS = 4;  // (113-123 registers, none spilled: four waves per SIMD)
 };
@@ -415,9 +415,18 @@ __global__ void __launch_bounds__((R2Geom<R2, R3>::T), (R2Geom<R2, R3>::WPS)) fa
         {
             const cf wt = p.tw_s[aa];  // W_T^a
             if (R2 == 32) { dft32f(a); twiddle32f(a, wt); }
-            else {
+            else if (R2 == 16) {
 #pragma unroll
                 for (int s = 0; s < K2; ++s) { dft16<float>(a + 16 * s); twiddle16<float>(a + 16 * s, wt); }
+            } else {
+                const cf w2 = cmul(wt, wt), w3 = cmul(w2, wt), w4 = cmul(w2, w2), w5 = cmul(w4, wt), w6 = cmul(w4, w2), w7 = cmul(w4, w3);
+#pragma unroll
+                for (int s = 0; s < K2; ++s) {
+                    cf* g = a + 8 * s;
+                    dft8<float>(g);
+                    g[1] = cmul(g[1], wt); g[2] = cmul(g[2], w2); g[3] = cmul(g[3], w3); g[4] = cmul(g[4], w4);
+                    g[5] = cmul(g[5], w5); g[6] = cmul(g[6], w6); g[7] = cmul(g[7], w7);
+                }
             }
         }
         // ---- exchange 2

@@ -1931,7 +1931,8 @@ static int run_fastr(const xrfthip_plan* P, const void* in, void* out, hipStream
         if (d.nx == 65536) RK_((fastr_kernel<MM, HH>), kFastRLds); \
         else if (d.nx == 32768) RK_((fastr2_kernel<32, 16, MM, HH>), (R2Geom<32, 16>::LDS)); \
         else if (d.nx == 16384) RK_((fastr2_kernel<16, 16, MM, HH>), (R2Geom<16, 16>::LDS)); \
-        else RK_((fastr2_kernel<16, 8, MM, HH>), (R2Geom<16, 8>::LDS)); } while (0)
+        else if (d.nx == 8192) RK_((fastr2_kernel<16, 8, MM, HH>), (R2Geom<16, 8>::LDS)); \
+        else RK_((fastr2_kernel<8, 8, MM, HH>), (R2Geom<8, 8>::LDS)); } while (0)
     if (pw) { if (p.half) RL_(1, true); else RL_(1, false); } else { if (p.half) RL_(0, true); else RL_(0, false); }
 #undef RL_
 #undef RK_
@@ -2221,7 +2222,7 @@ int xrfthip_plan_create(xrfthip_plan** plan, const xrfthip_desc* desc) {
     {   // one real float32 row of 65536 samples per workgroup, transformed in registers in ONE pass (fastr.h): 12 bytes per sample through
         // memory where the four-step form below moves 28
         const uint32_t okr = XRFTHIP_SHIFT_X | XRFTHIP_HALF_X | (d.out_mode == XRFTHIP_OUT_POWER ? XRFTHIP_REALDIM_X2 : 0u) | (d.out_mode == XRFTHIP_OUT_COMPLEX ? XRFTHIP_ISHIFT_X : 0u);
-        P->fastr = d.ndim == 1 && (d.nx == 65536 || d.nx == 32768 || d.nx == 16384 || d.nx == 8192) && d.dtype == XRFTHIP_F32 && (d.out_mode == XRFTHIP_OUT_COMPLEX || d.out_mode == XRFTHIP_OUT_POWER) &&
+        P->fastr = d.ndim == 1 && (d.nx == 65536 || d.nx == 32768 || d.nx == 16384 || d.nx == 8192 || d.nx == 4096) && d.dtype == XRFTHIP_F32 && (d.out_mode == XRFTHIP_OUT_COMPLEX || d.out_mode == XRFTHIP_OUT_POWER) &&
                    !(d.flags & ~okr) && !((d.flags & XRFTHIP_HALF_X) && (d.flags & XRFTHIP_SHIFT_X)) && !env_ll("XRFTHIP_NO_FAST", 0) && env_ll("XRFTHIP_FASTR", 1) != 0;
         if (P->fastr) {
             // 65536 samples: one resident workgroup per CU walks the rows (measured: 359 vs 344 GFFT/s for a workgroup per row, profiles/r04_fastr.txt);
@@ -2300,7 +2301,7 @@ int xrfthip_plan_create(xrfthip_plan** plan, const xrfthip_desc* desc) {
     {   // one short transform axis, the contiguous one, real input: rows packed in pairs through the same three passes
         const bool two = d.out_mode == XRFTHIP_OUT_CROSS || d.out_mode == XRFTHIP_OUT_PHASE;
         const uint32_t allowed = XRFTHIP_SHIFT_X | XRFTHIP_HALF_X | (d.out_mode != XRFTHIP_OUT_PHASE ? XRFTHIP_REALDIM_X2 : 0u) | (d.out_mode != XRFTHIP_OUT_POWER ? XRFTHIP_ISHIFT_X : 0u);
-        P->fastmx = d.ndim == 1 && (!cplx_in || (!two && !(d.flags & (XRFTHIP_HALF_X | XRFTHIP_REALDIM_X2)))) && (d.out_mode == XRFTHIP_OUT_COMPLEX || d.out_mode == XRFTHIP_OUT_POWER || two) &&
+        P->fastmx = !P->fastr && d.ndim == 1 && (!cplx_in || (!two && !(d.flags & (XRFTHIP_HALF_X | XRFTHIP_REALDIM_X2)))) && (d.out_mode == XRFTHIP_OUT_COMPLEX || d.out_mode == XRFTHIP_OUT_POWER || two) &&
                     !(d.flags & ~allowed) && !((d.flags & XRFTHIP_HALF_X) && (d.flags & XRFTHIP_SHIFT_X)) && !((d.flags & XRFTHIP_REALDIM_X2) && !(d.flags & XRFTHIP_HALF_X)) &&
                     fastmx_len(d.nx, P->dbl) && d.batch < (1LL << 31) - 16 && !env_ll("XRFTHIP_NO_FAST", 0) && env_ll("XRFTHIP_FASTM", 1) != 0;
         if (P->fastmx) {
@@ -2462,8 +2463,8 @@ int xrfthip_plan_describe(const xrfthip_plan* plan, char* buf, size_t buflen) {
                    "r32x%dx%d, LDS exchanges%s), real split through the LDS, lds=%zuB; per-row detrend + window + full (or half) spectrum; "
                    "12 algorithmic bytes per sample through memory\n",
                 nxr / 64, nxr, plan->tune_rgrid > 0 ? std::min<long long>(plan->tune_rgrid, plan->d.batch) : (long long)plan->d.batch, nxr / 2,
-                nxr >= 32768 ? 32 : 16, nxr == 65536 ? 32 : nxr == 8192 ? 8 : 16, nxr == 65536 ? " in halves" : "",
-                nxr == 65536 ? kFastRLds : nxr == 32768 ? R2Geom<32, 16>::LDS : nxr == 16384 ? R2Geom<16, 16>::LDS : R2Geom<16, 8>::LDS);
+                nxr >= 32768 ? 32 : nxr == 4096 ? 8 : 16, nxr == 65536 ? 32 : nxr <= 8192 ? 8 : 16, nxr == 65536 ? " in halves" : "",
+                nxr == 65536 ? kFastRLds : nxr == 32768 ? R2Geom<32, 16>::LDS : nxr == 16384 ? R2Geom<16, 16>::LDS : nxr == 8192 ? R2Geom<16, 8>::LDS : R2Geom<8, 8>::LDS);
     } else if (plan->fastmx) {
         const MGeomRt C = mxgeom(plan->d.nx, plan->dbl);
         appendf(s, "  [fastm x-only] %d thr, %d row pairs per workgroup (FFT%lld r%dx%dx%d in LDS), lds=%zuB: per-row detrend + window + transform + full (or half) spectrum in one pass\n",
