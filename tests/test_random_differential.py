@@ -257,3 +257,85 @@ def run_random_one_axis(seed):
 @pytest.mark.parametrize("seed", range(int(os.environ.get("XRFT_RANDOM_ONE_AXIS_CASES", "16"))))
 def test_random_one_axis_case(seed):
     run_random_one_axis(seed)
+
+
+def run_random_one_pass(seed, big=False):
+    """Random calls on what the register-resident one-pass kernels serve (round 4): real float32 slabs of 64 | 128 | 256 points per axis
+    (csrc/fasts.h: power spectrum, fft, isotropic power spectrum; the other modes must come out right through the other kernels) and real
+    float32 rows of 4096 ... 65536 samples (csrc/fastr.h: fft / power spectrum, full or real_dim half).  Descending coordinates, every
+    detrend / window / shift / scaling / true-phase combination.  Returns the one-pass kernel that served the call (or None)."""
+    import xrft_amd as xa
+
+    rng = np.random.default_rng(11000 + seed)
+    kw = dict(detrend=rng.choice([None, "constant", "linear"]), window=rng.choice([None, "hann", "hamming", "blackman"]))
+    shift = bool(rng.random() < 0.7)
+    tp = bool(rng.random() < 0.5)
+    api._plan_cache.clear()
+    if rng.random() < 0.6:
+        ny, nx = int(rng.choice([64, 128, 256])), int(rng.choice([64, 128, 256]))
+        nb = int(rng.integers(1, 700 if big else 4))
+        v = rng.standard_normal((nb, ny, nx)).astype(np.float32)
+        v += (0.01 * np.arange(ny, dtype=np.float32))[None, :, None] + (-0.02 * np.arange(nx, dtype=np.float32) + 3)[None, None, :]
+        v *= (1 + (np.arange(nb) % 5).astype(np.float32))[:, None, None]
+        yc = np.arange(ny) * float(rng.choice([0.5, 1.0])) + float(rng.choice([0.0, 2.0]))
+        desc = bool(rng.random() < 0.15)
+        c = {"t": np.arange(nb), "y": yc[::-1].copy() if desc else yc, "x": np.arange(nx) * float(rng.choice([0.25, 1.0])) - float(rng.choice([0.0, 3.0]))}
+        da, od = cases.pair(v, ("t", "y", "x"), c)
+        kind = str(rng.choice(["ps", "ps", "fft", "iso", "iso", "cs", "ps_real"]))
+        if kind == "ps":
+            sc = str(rng.choice(["density", "spectrum"]))
+            wc = bool(kw["window"] is not None and rng.random() < 0.4)
+            got, ref = (xa.power_spectrum(da, dim=["y", "x"], shift=shift, scaling=sc, window_correction=wc, **kw),
+                        o.power_spectrum(od, dim=["y", "x"], shift=shift, scaling=sc, window_correction=wc, **kw))
+        elif kind == "fft":
+            got, ref = xa.fft(da, dim=["y", "x"], shift=shift, true_phase=tp, **kw), o.fft(od, dim=["y", "x"], shift=shift, true_phase=tp, **kw)
+        elif kind == "iso":
+            tr = bool(rng.random() < 0.5)
+            nf = int(rng.choice([4, 4, 2, 8]))
+            got, ref = (xa.isotropic_power_spectrum(da, dim=["y", "x"], truncate=tr, nfactor=nf, **kw),
+                        o.isotropic_power_spectrum(od, dim=["y", "x"], truncate=tr, nfactor=nf, **kw))
+        elif kind == "cs":
+            w = rng.standard_normal((nb, ny, nx)).astype(np.float32)
+            db, ob = cases.pair(w, ("t", "y", "x"), c)
+            got, ref = xa.cross_spectrum(da, db, dim=["y", "x"], shift=shift, true_phase=tp, **kw), o.cross_spectrum(od, ob, dim=["y", "x"], shift=shift, true_phase=tp, **kw)
+        else:
+            got, ref = xa.power_spectrum(da, dim=["y"], real_dim="x", **kw), o.power_spectrum(od, dim=["y"], real_dim="x", **kw)
+        served = "[fasts]"
+        expect = kind in ("ps", "iso") or (kind == "fft" and not (desc and tp))  # (a flipped axis is not the one-pass kernel's; iso: any bin map, radial or not)
+        if kind == "iso":
+            expect = None  # (truncate=True leaves unbinned corners: not a radial map -> the other kernels; both must be right)
+    else:
+        n = int(rng.choice([4096, 8192, 16384, 32768, 65536]))
+        nb = int(rng.integers(1, 40 if big else 3))
+        v = (rng.standard_normal((nb, n)) + 2.0 + 1e-4 * np.arange(n)).astype(np.float32)
+        xc = np.arange(n) * 0.25 + float(rng.choice([0.0, 5.0]))
+        desc = bool(rng.random() < 0.15)
+        da, od = cases.pair(v, ("t", "x"), {"t": np.arange(nb), "x": xc[::-1].copy() if desc else xc})
+        od64 = o.OArr(v.astype("float64"), ("t", "x"), {"t": np.arange(nb), "x": xc[::-1].copy() if desc else xc})
+        kind = str(rng.choice(["fft", "ps", "fft_real", "ps_real"]))
+        if kind == "fft":
+            got, ref = xa.fft(da, dim=["x"], shift=shift, true_phase=tp, **kw), o.fft(od64, dim=["x"], shift=shift, true_phase=tp, **kw)
+        elif kind == "ps":
+            sc = str(rng.choice(["density", "spectrum"]))
+            got, ref = xa.power_spectrum(da, dim=["x"], shift=shift, scaling=sc, **kw), o.power_spectrum(od64, dim=["x"], shift=shift, scaling=sc, **kw)
+        elif kind == "fft_real":
+            got, ref = xa.fft(da, dim=["x"], real_dim="x", true_phase=tp, **kw), o.fft(od64, dim=["x"], real_dim="x", true_phase=tp, **kw)
+        else:
+            got, ref = xa.power_spectrum(da, dim=["x"], real_dim="x", **kw), o.power_spectrum(od64, dim=["x"], real_dim="x", **kw)
+        served = "[fastr]"
+        expect = not (desc and tp and kind in ("fft", "fft_real"))
+    on = any(served in p.describe() for p in api._plan_cache.values())
+    if expect is not None:
+        assert on == expect, (kind, served, on, [p.describe()[:200] for p in api._plan_cache.values()])
+    # (the rows are held against the float64-fed oracle: a trend of 1e-4 x 65536 beside unit noise in float32, cases.run_fourstep_1d)
+    err = float(np.abs(np.asarray(got.values) - ref.values).max() / np.abs(ref.values).max())
+    assert err < 3e-4, (kind, err)
+    for d in ref.dims:
+        if d in ref.coords:
+            assert np.array_equal(np.asarray(got[d].values), np.asarray(ref.coord(d)), equal_nan=True), d
+    return served if on else None
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("XRFT_RANDOM_ONE_PASS_CASES", "14"))))
+def test_random_one_pass_case(seed):
+    run_random_one_pass(seed)
