@@ -1,0 +1,40 @@
+"""Small real slabs that are not 64 | 128 | 256 points per axis: the one-pass LDS kernel (csrc/fastg.h) against the two-pass generic kernels
+(XRFTHIP_FASTG=0), and the workgroup size (XRFTHIP_FASTG_THREADS).  Run on the GPU box: python scripts/prof_small_np2.py"""
+import os, sys, time, warnings
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+import xrft_amd as xrft
+from xrft_amd import api
+warnings.simplefilter("ignore")
+
+
+def t(fn, reps=5):
+    fn(); fn(); torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps): fn()
+    torch.cuda.synchronize(); return (time.perf_counter() - t0) / reps
+
+
+shapes = ((14400, 50, 50, torch.float32), (14400, 50, 50, torch.float64), (8192, 96, 96, torch.float32), (4096, 100, 100, torch.float32), (4096, 100, 100, torch.float64),
+          (2048, 150, 150, torch.float32), (1024, 192, 192, torch.float32), (2048, 120, 240, torch.float32), (4096, 128, 128, torch.float64), (8192, 64, 64, torch.float64),
+          (4096, 90, 180, torch.float32), (8192, 60, 60, torch.float32), (8192, 80, 80, torch.float64), (1024, 180, 180, torch.float32), (2048, 144, 96, torch.float64))
+for nt, ny, nx, dt in shapes:
+    x = torch.randn((nt, ny, nx), dtype=dt, device="cuda")
+    da = xrft.DataArray(x, ("t", "y", "x"), {"y": np.arange(float(ny)), "x": np.arange(float(nx))})
+    line = f"({nt},{ny},{nx}) {str(dt)[6:]}:"
+    for label, env in (("two-pass", {"XRFTHIP_FASTG": "0"}), ("fastg", {}), ("128thr", {"XRFTHIP_FASTG_THREADS": "128"}),
+                       ("256thr", {"XRFTHIP_FASTG_THREADS": "256"}), ("512thr", {"XRFTHIP_FASTG_THREADS": "512"}), ("1024thr", {"XRFTHIP_FASTG_THREADS": "1024"})):
+        for k in ("XRFTHIP_FASTG", "XRFTHIP_FASTG_THREADS"):
+            os.environ.pop(k, None)
+        os.environ.update(env)
+        api._plan_cache.clear()
+        w = t(lambda: xrft.power_spectrum(da, dim=["y", "x"], detrend="linear", window="hann"))
+        on = "[fastg]" in next(reversed(api._plan_cache.values())).describe()
+        line += f" {label}{'*' if on else ''} {x.numel()/w/1e9:6.1f}"
+        if label == "fastg" and not on:
+            break
+    for k in ("XRFTHIP_FASTG", "XRFTHIP_FASTG_THREADS"):
+        os.environ.pop(k, None)
+    api._plan_cache.clear()
+    w2 = t(lambda: xrft.fft(da, dim=["y", "x"], detrend="linear", window="hann"))
+    print(line + f" | fft {x.numel()/w2/1e9:6.1f} GFFT/s", flush=True)

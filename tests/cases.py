@@ -1077,6 +1077,34 @@ def run_fused_radial_code_forms(n=256):
     os.environ.pop("XRFTHIP_ISO_GATHER", None)
 
 
+def run_fastg_cases(shape=(3, 50, 50), dtype="float32", full=True):
+    """Small real slabs of any smooth shape (50 x 50 boxes -- the reference's documented workload --, 96 x 96, 100 x 100, odd row counts), both
+    precisions: the LDS-resident one-pass kernel with run-time radices (csrc/fastg.h) against the oracle -- power spectra with every detrend /
+    window / shift combination, the complex spectrum with and without the true phase (an odd ny makes the ifftshift a rotation, not (-1)^k)."""
+    rng = np.random.default_rng(53)
+    tol = TOL[dtype]
+    a = _cube(rng, shape, dtype)
+    da, od = pair(a, D3, _coords3(shape, y0=1.0, x0=-3.0))
+    worst = 0.0
+
+    def on_fastg():
+        return "[fastg]" in next(reversed(xa.api._plan_cache.values())).describe()
+
+    worst = max(worst, check(xa.power_spectrum(da, dim=["y", "x"], detrend="linear", window="hann"),
+                             o.power_spectrum(od, dim=["y", "x"], detrend="linear", window="hann"), tol))
+    assert on_fastg()
+    if not full:
+        return worst
+    for kw in (dict(), dict(detrend="constant", window="hamming", scaling="spectrum", window_correction=True), dict(detrend="linear"),
+               dict(shift=False, window="bartlett", density=False)):
+        worst = max(worst, check(xa.power_spectrum(da, dim=["y", "x"], **kw), o.power_spectrum(od, dim=["y", "x"], **kw), tol))
+        assert on_fastg()
+    for kw in (dict(), dict(true_phase=False), dict(shift=False, true_phase=False, true_amplitude=False), dict(detrend="linear", window="hann")):
+        worst = max(worst, check(xa.fft(da, dim=["y", "x"], **kw), o.fft(od, dim=["y", "x"], **kw), tol))
+        assert on_fastg()
+    return worst
+
+
 def run_fastm_radial_code_forms(ny=360, nx=240, dtype="float64"):
     """The fused radial sums of the mixed-radix kernels (csrc/fastm.h): a radial bin map is gathered per bin from the spectra in LDS with no
     atomics, any other map (and a radial one with XRFTHIP_ISO_GATHER=0) goes through the int64 fixed-point tables.  Both against

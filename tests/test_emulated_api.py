@@ -598,3 +598,10 @@ def test_one_axis_round3_lengths(shape, dtype):
 @pytest.mark.parametrize("shape,dtype", [((3, 2000), "float32"), ((2, 3000), "float32"), ((2, 1800), "float64"), ((3, 3600), "float32"), ((2, 900), "float64"), ((3, 1500), "float32")])
 def test_short_axis_round3_lengths(shape, dtype):
     cases.run_xonly_fast_cases(shape, dtype)
+
+
+@pytest.mark.parametrize("shape,dtype,full", [((3, 50, 50), "float32", True), ((2, 50, 50), "float64", True), ((2, 27, 96), "float32", True), ((1, 100, 100), "float64", False),
+                                              ((2, 45, 30), "float64", True), ((1, 96, 96), "float32", False), ((1, 120, 60), "float32", False)])
+def test_small_slabs_of_any_smooth_shape_in_one_pass(shape, dtype, full):
+    """fastg.h: lengths as data (run-time radices), both precisions; (2, 27, 96) is the odd-ny true-phase case the random sweep found."""
+    cases.run_fastg_cases(shape, dtype, full)

@@ -1000,3 +1000,11 @@ def test_fastm_radial_sums_gather_and_tables(ny, nx, dtype):
 
 def test_nan_poisons_its_own_slab_only():
     cases.run_nan_in_isotropic_spectra()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape,dtype", [((300, 50, 50), "float32"), ((300, 50, 50), "float64"), ((5, 27, 96), "float32"), ((64, 100, 100), "float32"), ((64, 100, 100), "float64"),
+                                         ((7, 45, 30), "float64"), ((33, 96, 96), "float32"), ((9, 120, 60), "float32"), ((3, 128, 128), "float64"), ((5, 80, 160), "float32")])
+def test_small_slabs_of_any_smooth_shape_in_one_pass(shape, dtype):
+    """fastg.h against the oracle: the reference's documented workload (thousands of 50 x 50 boxes) and its neighbours, both precisions."""
+    cases.run_fastg_cases(shape, dtype, True)

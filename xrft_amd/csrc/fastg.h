@@ -1,0 +1,241 @@
+// fastg.h -- ONE pass over a small real slab of ANY smooth shape, either precision: the whole 2-D transform of a slab inside the LDS of one
+// workgroup, the lengths as DATA (run-time radices), not as template arguments (xrft.power_spectrum / fft over the last two axes of
+// (nt, ny, nx) arrays: reference xrft/xrft.py:307-476, 685-750, detrend.py:100-113 -- the reference's documented workload is thousands of
+// 50 x 50 boxes).
+//
+// Where fasts.h (float32, 64 | 128 | 256 points per axis) keeps a slab in registers with compile-time radices, this kernel keeps the slab's
+// half spectrum -- ny rows of nx/2 + 1 complex values -- in LDS and runs the radix passes of tile_fft.h over it with the radices of a
+// parameter block: any ny, nx = 2^a 3^b 5^c (nx even) whose half spectrum fits the LDS (19 000 complex64 / 9 500 complex128 values:
+// 50 x 50, 96 x 96, 100 x 100, 120 x 240, 150 x 150, 180 x 90; in float64 also 64 ... 128 points per axis).  Before it these shapes took the
+// generic tile kernels in two passes through memory with a moments pass in front (50-115 GFFT/s in float32, 40-60 in float64).
+//
+//   load      the slab, rows packed in pairs of samples z[i][m] = x[i][2m] + i x[i][2m+1], into LDS (coalesced); the exact plane of
+//             detrend='linear' from three float64 sums over the workgroup (fixed order), subtracted, the window multiplied, in a second sweep
+//   x         the radix passes of length n = nx/2 over the ny rows (tile_fft.h run_pass: decimation in frequency, digit-reversed result),
+//             then the unpack of the packed rows in place: X[k] = E + W_nx^k O, X[n - k] = conj(E - W_nx^k O) at the positions of Z[k], Z[n - k];
+//             X[n] in column n
+//   y         the radix passes of length ny over the n + 1 columns (lanes along the columns: contiguous)
+//   out       every output sample in output order (coalesced stores): its source (ky, kx) or the Hermitian twin (-ky, -kx), looked up through
+//             the digit-reversal tables of the two axes; |F|^2 scale, or F scale x the true-phase factors (conjugated for the twin)
+#pragma once
+#include "tile_fft.h"
+#include "fastr.h"  // fastr_store4 / fastr_store8
+
+namespace xrft {
+
+constexpr int kFastGMaxPasses = 8;
+constexpr int kFastGWaves = 16;  // at most: 1024 threads in float32, 512 in float64 (its radix-16 butterflies want more than 128 registers)
+template <typename T> constexpr int fastg_max_threads() { return sizeof(T) == 4 ? 1024 : 512; }
+
+struct FastG {
+    const void* in;     // [slabs][ny][nx] real T
+    void* out;          // [slabs][ny][nx] real T (power) or complex T
+    long long nslabs;
+    int ny, nx, n, rs;  // n = nx / 2; rs = LDS row stride in complex elements (>= n + 1)
+    int nrx, nry;
+    int rx[kFastGMaxPasses], ry[kFastGMaxPasses];
+    const void* tw_x;   // W_n^k,  k < n   (complex T)
+    const void* tw_y;   // W_ny^k, k < ny
+    const void* tw_r;   // W_nx^k, k <= n
+    const unsigned* rev_x;  // position of frequency k after the passes of length n
+    const unsigned* rev_y;  // ... of length ny
+    const void* win_y;  // T, or null (then win_x is null, too)
+    const void* win_x;
+    const void* ph_y;   // complex mode: true-phase factors by unshifted frequency index (complex T)
+    const void* ph_x;
+    int ph_on;
+    int detrend;        // 0 none, 1 constant, 2 linear (plane)
+    int shift_y, shift_x;  // 0 or n/2 (the fftshift offsets, xrft.py:446-447)
+    double scale;
+};
+
+// one radix pass over the COLUMNS of the tile: sequences of length len, element stride rs, ncols of them; lanes run along the columns
+template <typename T, int R>
+__device__ __forceinline__ void fastg_pass_cols(C2<T>* tile, int ncols, int len, int rs, int L, int tid, int nthreads, const C2<T>* __restrict__ tw) {
+    const int m = L / R, per = len / R, nb = ncols * per, twstep = len / L;
+    const float inv_c = 1.0f / (float)ncols, inv_m = 1.0f / (float)m;
+    for (int w = tid; w < nb; w += nthreads) {
+        const int gg = fdiv(w, inv_c), c = w - gg * ncols;
+        const int blk = fdiv(gg, inv_m), j = gg - blk * m;
+        C2<T>* s = tile + c + (blk * L + j) * rs;
+        C2<T> a[R];
+#pragma unroll
+        for (int q = 0; q < R; ++q) a[q] = s[q * m * rs];
+        dft_r<T, R>(a);
+        if (m > 1) {
+#pragma unroll
+            for (int k = 1; k < R; ++k) a[k] = cmul(a[k], tw[j * k * twstep]);
+        }
+#pragma unroll
+        for (int k = 0; k < R; ++k) s[k * m * rs] = a[k];
+    }
+}
+
+template <typename T>
+__device__ __forceinline__ void fastg_rows_pass(C2<T>* tile, const TileGeom& g, int R, int L, int tid, int nthr, const C2<T>* tw) {
+    switch (R) {
+        case 2: run_pass<T, 2>(tile, g, L, tid, nthr, tw); break;
+        case 3: run_pass<T, 3>(tile, g, L, tid, nthr, tw); break;
+        case 4: run_pass<T, 4>(tile, g, L, tid, nthr, tw); break;
+        case 5: run_pass<T, 5>(tile, g, L, tid, nthr, tw); break;
+        case 6: run_pass<T, 6>(tile, g, L, tid, nthr, tw); break;
+        case 8: run_pass<T, 8>(tile, g, L, tid, nthr, tw); break;
+        case 9: run_pass<T, 9>(tile, g, L, tid, nthr, tw); break;
+        case 10: run_pass<T, 10>(tile, g, L, tid, nthr, tw); break;
+        case 12: run_pass<T, 12>(tile, g, L, tid, nthr, tw); break;
+        case 15: run_pass<T, 15>(tile, g, L, tid, nthr, tw); break;
+        default: run_pass<T, 16>(tile, g, L, tid, nthr, tw); break;
+    }
+}
+template <typename T>
+__device__ __forceinline__ void fastg_cols_pass(C2<T>* tile, int ncols, int len, int rs, int R, int L, int tid, int nthr, const C2<T>* tw) {
+    switch (R) {
+        case 2: fastg_pass_cols<T, 2>(tile, ncols, len, rs, L, tid, nthr, tw); break;
+        case 3: fastg_pass_cols<T, 3>(tile, ncols, len, rs, L, tid, nthr, tw); break;
+        case 4: fastg_pass_cols<T, 4>(tile, ncols, len, rs, L, tid, nthr, tw); break;
+        case 5: fastg_pass_cols<T, 5>(tile, ncols, len, rs, L, tid, nthr, tw); break;
+        case 6: fastg_pass_cols<T, 6>(tile, ncols, len, rs, L, tid, nthr, tw); break;
+        case 8: fastg_pass_cols<T, 8>(tile, ncols, len, rs, L, tid, nthr, tw); break;
+        case 9: fastg_pass_cols<T, 9>(tile, ncols, len, rs, L, tid, nthr, tw); break;
+        case 10: fastg_pass_cols<T, 10>(tile, ncols, len, rs, L, tid, nthr, tw); break;
+        case 12: fastg_pass_cols<T, 12>(tile, ncols, len, rs, L, tid, nthr, tw); break;
+        case 15: fastg_pass_cols<T, 15>(tile, ncols, len, rs, L, tid, nthr, tw); break;
+        default: fastg_pass_cols<T, 16>(tile, ncols, len, rs, L, tid, nthr, tw); break;
+    }
+}
+
+// MODE 1: power spectrum (real T out), 0: complex spectrum
+template <typename T, int MODE>
+__global__ void __launch_bounds__(fastg_max_threads<T>()) fastg_kernel(FastG p) {
+    typedef C2<T> CT;
+    XRFT_DYN_SMEM(smem_raw);
+    CT* tile = reinterpret_cast<CT*>(smem_raw);
+    const int tid = threadIdx.x, nthr = blockDim.x, ny = p.ny, nx = p.nx, n = p.n, rs = p.rs;
+    // behind the tile: the tables of the plan, staged once per workgroup (the passes' twiddles and the digit-reversal look-ups of the unpack and
+    // of the output loop sit on every inner loop's critical path: from global memory each was an L2 round trip), and the plane's wave sums
+    unsigned char* tb = smem_raw + (((size_t)ny * rs * sizeof(CT) + 15) & ~(size_t)15);
+    CT* twx = reinterpret_cast<CT*>(tb); tb += (size_t)n * sizeof(CT);
+    CT* twy = reinterpret_cast<CT*>(tb); tb += (size_t)ny * sizeof(CT);
+    CT* twr = reinterpret_cast<CT*>(tb); tb += (size_t)(n + 1) * sizeof(CT);
+    double* red = reinterpret_cast<double*>(tb); tb += kFastGWaves * 3 * sizeof(double);  // [waves][3]
+    unsigned short* revx = reinterpret_cast<unsigned short*>(tb); tb += (((size_t)n * 2 + 3) & ~(size_t)3);
+    unsigned short* revy = reinterpret_cast<unsigned short*>(tb);
+    for (int k = tid; k < n; k += nthr) { twx[k] = reinterpret_cast<const CT*>(p.tw_x)[k]; revx[k] = (unsigned short)p.rev_x[k]; }
+    for (int k = tid; k < ny; k += nthr) { twy[k] = reinterpret_cast<const CT*>(p.tw_y)[k]; revy[k] = (unsigned short)p.rev_y[k]; }
+    for (int k = tid; k <= n; k += nthr) twr[k] = reinterpret_cast<const CT*>(p.tw_r)[k];
+    const float inv_n = 1.0f / (float)n, inv_nx = 1.0f / (float)nx;
+    TileGeom g{};
+    g.n = n; g.T = ny; g.seq_stride = rs; g.pad_shift = 30;
+    for (long long slab = blockIdx.x; slab < p.nslabs; slab += gridDim.x) {
+        const CT* __restrict__ src = reinterpret_cast<const CT*>(reinterpret_cast<const T*>(p.in) + (size_t)slab * ny * nx);
+        const int npk = ny * n;  // packed samples
+        __syncthreads();         // (the previous slab's output loop is done with the tile; the tables are in place)
+        // ---- load; the plane's sums on the way (float64 per thread, then the threads in a fixed order)
+        double s0 = 0.0, si = 0.0, sj = 0.0;
+        const double ibar = 0.5 * (ny - 1), jbar = 0.5 * (nx - 1);
+        for (int e = tid; e < npk; e += nthr) {
+            const int i = fdiv(e, inv_n), m = e - i * n;
+            const CT z = src[e];
+            tile[i * rs + m] = z;
+            if (p.detrend) {
+                const double u = (double)z.re + (double)z.im;
+                s0 += u;
+                si = fma((double)i - ibar, u, si);
+                sj += ((double)(2 * m) - jbar) * u + (double)z.im;
+            }
+        }
+        if (p.detrend || p.win_y) {
+            double c0 = 0.0, c1 = 0.0, c2 = 0.0;
+            if (p.detrend) {  // wave shuffles, then the waves' sums in wave order
+#pragma unroll
+                for (int m = 1; m < 64; m <<= 1) { s0 += __shfl_xor(s0, m); si += __shfl_xor(si, m); sj += __shfl_xor(sj, m); }
+                if ((tid & 63) == 0) { red[(tid >> 6) * 3] = s0; red[(tid >> 6) * 3 + 1] = si; red[(tid >> 6) * 3 + 2] = sj; }
+                __syncthreads();
+                double t0 = 0.0, t1 = 0.0, t2 = 0.0;
+                for (int w = 0; w < (nthr >> 6); ++w) { t0 += red[3 * w]; t1 += red[3 * w + 1]; t2 += red[3 * w + 2]; }
+                const double npts = (double)ny * (double)nx;
+                c0 = t0 / npts;
+                if (p.detrend == 2) {
+                    if (ny > 1) c1 = t1 * 12.0 / (npts * ((double)ny * ny - 1.0));
+                    if (nx > 1) c2 = t2 * 12.0 / (npts * ((double)nx * nx - 1.0));
+                }
+            } else {
+                __syncthreads();
+            }
+            const T* __restrict__ wy = reinterpret_cast<const T*>(p.win_y);
+            const T* __restrict__ wx = reinterpret_cast<const T*>(p.win_x);
+            for (int e = tid; e < npk; e += nthr) {  // (each thread revisits the elements it loaded)
+                const int i = fdiv(e, inv_n), m = e - i * n;
+                CT z = tile[i * rs + m];
+                if (p.detrend) {
+                    const double l = c0 + c1 * ((double)i - ibar) + c2 * ((double)(2 * m) - jbar);
+                    z = mk<T>((T)((double)z.re - l), (T)((double)z.im - (l + c2)));
+                }
+                if (wy) { const T w = wy[i]; z = mk<T>(z.re * (w * wx[2 * m]), z.im * (w * wx[2 * m + 1])); }
+                tile[i * rs + m] = z;
+            }
+        }
+        __syncthreads();
+        // ---- x: the passes of length n over the rows
+        {
+            int L = n;
+            for (int ps = 0; ps < p.nrx; ++ps) {
+                fastg_rows_pass<T>(tile, g, p.rx[ps], L, tid, nthr, twx);
+                L /= p.rx[ps];
+                __syncthreads();
+            }
+        }
+        // ---- unpack the packed rows in place: pairs (k, n - k), k <= n / 2; X[n] goes to column n
+        {
+            const int hp = n / 2 + 1, nb = ny * hp;
+            const float inv_hp = 1.0f / (float)hp;
+            for (int w = tid; w < nb; w += nthr) {
+                const int i = fdiv(w, inv_hp), k = w - i * hp;
+                CT* row = tile + i * rs;
+                const int pk = (int)revx[k], pm = (int)revx[k == 0 ? 0 : n - k];
+                const CT zk = row[pk], zm = row[pm];
+                const CT E = mk<T>((T)0.5 * (zk.re + zm.re), (T)0.5 * (zk.im - zm.im));   // (Zk + conj Zm) / 2
+                const CT O = mk<T>((T)0.5 * (zk.im + zm.im), (T)0.5 * (zm.re - zk.re));   // -i (Zk - conj Zm) / 2
+                const CT t = cmul(twr[k], O);
+                if (k == 0) {
+                    row[pk] = mk<T>(E.re + t.re, (T)0);    // X[0]  = Re Z0 + Im Z0
+                    row[n] = mk<T>(E.re - t.re, (T)0);     // X[n]  = Re Z0 - Im Z0
+                } else {
+                    row[pk] = mk<T>(E.re + t.re, E.im + t.im);        // X[k]
+                    if (pm != pk) row[pm] = mk<T>(E.re - t.re, -(E.im - t.im));  // X[n - k] = conj(E - t)
+                }
+            }
+        }
+        __syncthreads();
+        // ---- y: the passes of length ny over the n + 1 columns
+        {
+            int L = ny;
+            for (int ps = 0; ps < p.nry; ++ps) {
+                fastg_cols_pass<T>(tile, n + 1, ny, rs, p.ry[ps], L, tid, nthr, twy);
+                L /= p.ry[ps];
+                __syncthreads();
+            }
+        }
+        // ---- out, in output order: (orow, ocol) <- F[ky][kx], or conj F[-ky][-kx] for kx > n (a real field's spectrum is Hermitian)
+        const int tot = ny * nx;
+        const T sc = (T)p.scale;
+        for (int e = tid; e < tot; e += nthr) {
+            const int orow = fdiv(e, inv_nx), ocol = e - orow * nx;
+            int ky = orow - p.shift_y; if (ky < 0) ky += ny;
+            int kx = ocol - p.shift_x; if (kx < 0) kx += nx;
+            const bool mir = kx > n;
+            const int sy = mir ? (ky == 0 ? 0 : ny - ky) : ky, sx = mir ? nx - kx : kx;
+            const CT v = tile[(int)revy[sy] * rs + (sx == n ? n : (int)revx[sx])];
+            if (MODE == 1) {
+                const T pw = (v.re * v.re + v.im * v.im) * sc;
+                reinterpret_cast<T*>(p.out)[(size_t)slab * tot + e] = pw;
+            } else {
+                CT o = mk<T>(v.re * sc, (mir ? -v.im : v.im) * sc);
+                if (p.ph_on) o = cmul(o, cmul(reinterpret_cast<const CT*>(p.ph_y)[ky], reinterpret_cast<const CT*>(p.ph_x)[kx]));
+                reinterpret_cast<CT*>(p.out)[(size_t)slab * tot + e] = o;
+            }
+        }
+    }
+}
+
+}  // namespace xrft

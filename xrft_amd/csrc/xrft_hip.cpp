@@ -33,6 +33,7 @@
 #include "fastr.h"
 #include "fasts.h"
 #include "tile_fft.h"
+#include "fastg.h"
 #ifdef XRFT_SPLIT_TUS  /* the library built from several translation units: the fasty / fastm kernels are instantiated in inst_g*.cpp */
 namespace xrft {
 #define XRFT_KW extern template __global__
@@ -328,6 +329,12 @@ struct xrfthip_plan {
     bool fastmy = false;
     // ... and the same transform over short contiguous rows packed in pairs (ndim = 1, fastm_xonly_kernel)
     bool fastmx = false;
+    // ... and ONE pass for a small real slab of any smooth shape, either precision, held in LDS with run-time radices (fastg.h)
+    bool fastg = false;
+    std::vector<int> g_rx, g_ry;
+    DevBuf g_twx, g_twy, g_twr, g_revx, g_revy;
+    int g_rs = 0;
+    size_t g_lds = 0;
     // ... and ONE pass for a small real float32 slab that fits the registers of a CU: 256 x 256 power spectra (fasts.h)
     bool fasts = false;
     DevBuf tw_sy, tw_sx, s_tfirst;
@@ -825,6 +832,7 @@ void set_kernel_attrs_once() {
 #undef SETALL
 #undef SETA
 #define SETF(K) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&K), hipFuncAttributeMaxDynamicSharedMemorySize, m)
+    SETF((fastg_kernel<float, 0>)); SETF((fastg_kernel<float, 1>)); SETF((fastg_kernel<double, 0>)); SETF((fastg_kernel<double, 1>));
     SETF((fasts_power_kernel<8, 8, 0, 0>)); SETF((fasts_power_kernel<8, 4, 0, 0>)); SETF((fasts_power_kernel<4, 8, 0, 0>));
     SETF((fasts_power_kernel<8, 8, 0>)); SETF((fasts_power_kernel<8, 8, 1>)); SETF((fasts_power_kernel<8, 8, 2>));  // (above 64 KB of dynamic LDS)
     SETF((fasts_power_kernel<8, 4, 0>)); SETF((fasts_power_kernel<8, 4, 1>)); SETF((fasts_power_kernel<8, 4, 2>));
@@ -948,7 +956,7 @@ static int run_radial_sums(int32_t dtype, const void* spec, const int32_t* d_bin
 
 static void layout_workspace(xrfthip_plan* P) {
     const xrfthip_desc& d = P->d;
-    if (P->fastr || P->fasts) { P->G = (int)std::max<long long>(1, std::min<long long>(d.batch, 1 << 30)); P->ws_bytes = 0; return; }  // one pass, registers + LDS: no intermediate
+    if (P->fastr || P->fasts || P->fastg) { P->G = (int)std::max<long long>(1, std::min<long long>(d.batch, 1 << 30)); P->ws_bytes = 0; return; }  // one pass, registers + LDS: no intermediate
     const bool fast = fast_on(P);
     long long G = d.slabs_per_group > 0 ? d.slabs_per_group : P->tune_group;
     size_t slab_w = (size_t)d.ny * std::max(P->width, P->w_cols) * P->csize;
@@ -1067,12 +1075,17 @@ static int fast_phase_tables(xrfthip_plan* P) {
         const long long n = ax == 0 ? d.ny : d.nx;
         const bool sign = d.out_mode == XRFTHIP_OUT_COMPLEX && (d.flags & (ax == 0 ? XRFTHIP_ISHIFT_Y : XRFTHIP_ISHIFT_X));
         std::vector<cf> t((size_t)n);
-        const bool dtab = (P->fastm || P->fastmy || P->fastmx) && P->dbl;
+        const bool dtab = (P->fastm || P->fastmy || P->fastmx || P->fastg) && P->dbl;
         std::vector<C2<double>> td(dtab ? (size_t)n : 0);
         for (long long k = 0; k < n; ++k) {
             double re = 1.0, im = 0.0;
             if (!P->host_phase[ax].empty()) { re = P->host_phase[ax][(size_t)(2 * k)]; im = P->host_phase[ax][(size_t)(2 * k + 1)]; }
-            if (sign && (k & 1)) { re = -re; im = -im; }
+            if (sign && !(n & 1)) { if (k & 1) { re = -re; im = -im; } }
+            else if (sign) {  // an odd length (fastg.h takes them): the ifftshift is a rotation by n // 2 samples, X'[k] = X[k] exp(+2 pi i (n // 2) k / n)
+                const long double a = 2.0L * 3.14159265358979323846264338327950288L * (long double)((k * (n / 2)) % n) / (long double)n;
+                const double cr = (double)cosl(a), ci = (double)sinl(a), r2 = re * cr - im * ci, i2 = re * ci + im * cr;
+                re = r2; im = i2;
+            }
             t[(size_t)k].re = (float)re; t[(size_t)k].im = (float)im;
             if (dtab) { td[(size_t)k].re = re; td[(size_t)k].im = im; }
             if (dtab ? (re != 1.0 || im != 0.0) : (t[(size_t)k].re != 1.0f || t[(size_t)k].im != 0.0f)) P->fph_on = true;
@@ -1821,6 +1834,101 @@ static int run_fastmx(const xrfthip_plan* P, const void* in, const void* in1, vo
     return XRFTHIP_OK;
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// one pass over small slabs of any smooth shape (fastg.h): the lengths as data
+// ---------------------------------------------------------------------------------------------------------------
+static int fastg_rev(const std::vector<int>& radix, int n, DevBuf& buf) {  // rev[k] = position of frequency k after the DIF passes (as build_tables)
+    std::vector<unsigned> rev((size_t)std::max(n, 1));
+    for (int pos = 0; pos < n; ++pos) {
+        long long L = n, rem = pos, k = 0, mult = 1;
+        for (int r : radix) {
+            const long long m = L / r;
+            k += (rem / m) * mult;
+            rem %= m;
+            mult *= r;
+            L = m;
+        }
+        rev[(size_t)k] = (unsigned)pos;
+    }
+    return buf.upload(rev.data(), rev.size() * sizeof(unsigned));
+}
+template <typename T> static int fastg_setup_t(xrfthip_plan* P) {
+    const xrfthip_desc& d = P->d;
+    const int n = (int)(d.nx / 2), ny = (int)d.ny;
+    int rc = build_twiddle<T>(P->g_twx, n, n);
+    if (!rc) rc = build_twiddle<T>(P->g_twy, ny, ny);
+    if (!rc) rc = build_twiddle<T>(P->g_twr, d.nx, n + 1);
+    if (!rc) rc = fastg_rev(P->g_rx, n, P->g_revx);
+    if (!rc) rc = fastg_rev(P->g_ry, ny, P->g_revy);
+    return rc;
+}
+static bool fastg_try(xrfthip_plan* P) {  // can the slab's half spectrum live in the LDS of one workgroup, and are both lengths smooth?
+    const xrfthip_desc& d = P->d;
+    if (d.ndim != 2 || P->cplx_in || (d.nx & 1) || d.nx < 4 || d.ny < 2 || d.nx > 4096 || d.ny > 4096) return false;
+    const int n = (int)(d.nx / 2), ny = (int)d.ny;
+    int rs = n + 1;
+    if (!(rs & 1)) ++rs;  // an odd row stride: the rows' passes and the gather of the output loop spread over the banks
+    const size_t lds = (((size_t)ny * rs * P->csize + 15) & ~(size_t)15) + (size_t)(n + ny + n + 1) * P->csize + kFastGWaves * 3 * sizeof(double) +
+                       (((size_t)n * 2 + 3) & ~(size_t)3) + (size_t)ny * 2 + 16;  // the tile + the plan's tables + the wave sums
+    if (lds > 150 * 1024) return false;
+    bool gx = false, gy = false;
+    std::vector<int> rx, ry;
+    if (n == 1) rx.clear(); else if (factorize(n, rx, gx) || gx) return false;
+    if (factorize(ny, ry, gy) || gy) return false;
+    if ((int)rx.size() > kFastGMaxPasses || (int)ry.size() > kFastGMaxPasses) return false;
+    for (int r : rx) if (r > 16) return false;
+    for (int r : ry) if (r > 16) return false;
+    P->g_rx = rx; P->g_ry = ry; P->g_rs = rs; P->g_lds = lds;
+    return true;
+}
+// threads per slab.  The passes are chains of LDS round trips, so it is the number of waves in flight on a CU that sets the rate, and that is
+// bounded twice: by the registers (float32: 105 -> 4 waves per SIMD, 16 per CU; float64: 153 -> 3 and 12) and by how many slabs' LDS a CU holds.
+// Take the workgroup of 1, 2, 4, 8 or 16 waves (whole waves per SIMD, or the second workgroup does not fit beside the first) that keeps most
+// waves resident, the smaller one on a tie: a 50 x 50 slab is a 128-thread workgroup, eight to a CU; 96 x 96: 256 threads, four to a CU;
+// 150 x 150 fills the LDS alone and brings 1024 threads (512 in float64).  Measured: profiles/r04_small_slabs.txt
+static long long fastg_threads(const xrfthip_plan* P) {
+    const long long maxthr = P->dbl ? fastg_max_threads<double>() : fastg_max_threads<float>();
+    const long long forced = env_ll("XRFTHIP_FASTG_THREADS", 0);
+    if (forced >= 64 && forced <= maxthr && forced % 64 == 0) return forced;
+    const long long cu_waves = P->dbl ? 12 : 16, by_lds = std::max<long long>(1, std::min<long long>(32, (long long)(kLdsMax / std::max<size_t>(1, P->g_lds))));
+    long long best = 1, best_res = 0;
+    for (long long w = 1; w * 64 <= maxthr; w *= 2) {
+        const long long res = std::min(by_lds, cu_waves / w) * w;
+        if (res > best_res) { best = w; best_res = res; }
+    }
+    return best * 64;
+}
+
+static int run_fastg(const xrfthip_plan* P, const void* in, void* out, hipStream_t st) {
+    const xrfthip_desc& d = P->d;
+    FastG p{};
+    p.in = in; p.out = out; p.nslabs = d.batch;
+    p.ny = (int)d.ny; p.nx = (int)d.nx; p.n = (int)(d.nx / 2); p.rs = P->g_rs;
+    p.nrx = (int)P->g_rx.size(); p.nry = (int)P->g_ry.size();
+    for (int i = 0; i < p.nrx; ++i) p.rx[i] = P->g_rx[(size_t)i];
+    for (int i = 0; i < p.nry; ++i) p.ry[i] = P->g_ry[(size_t)i];
+    p.tw_x = P->g_twx.p; p.tw_y = P->g_twy.p; p.tw_r = P->g_twr.p;
+    p.rev_x = (const unsigned*)P->g_revx.p; p.rev_y = (const unsigned*)P->g_revy.p;
+    const bool win = P->win[0].p || P->win[1].p;
+    p.win_y = win ? (P->win[0].p ? P->win[0].p : P->ones4096.p) : nullptr;
+    p.win_x = win ? (P->win[1].p ? P->win[1].p : P->ones4096.p) : nullptr;
+    const bool cplx = d.out_mode == XRFTHIP_OUT_COMPLEX;
+    p.ph_y = P->fph[0].p; p.ph_x = P->fph[1].p; p.ph_on = (cplx && P->fph_on) ? 1 : 0;
+    p.detrend = d.detrend;
+    p.shift_y = (d.flags & XRFTHIP_SHIFT_Y) ? (int)(d.ny / 2) : 0;
+    p.shift_x = (d.flags & XRFTHIP_SHIFT_X) ? (int)(d.nx / 2) : 0;
+    p.scale = d.scale;
+    const long long thr = fastg_threads(P);
+    const dim3 grid((unsigned)std::min<long long>(d.batch, 0x7fffffffLL)), blk((unsigned)thr);
+    xrfthip_plan::ProfRec* rec = prof_begin(P, "fastg_slab", st);
+#define GL_(TT, MM) do { auto k = &fastg_kernel<TT, MM>; XRFT_LAUNCH(k, grid, blk, P->g_lds, st, p); } while (0)
+    if (P->dbl) { if (cplx) GL_(double, 0); else GL_(double, 1); } else { if (cplx) GL_(float, 0); else GL_(float, 1); }
+#undef GL_
+    prof_end(rec, st);
+    HIP_TRY(hipGetLastError());
+    return XRFTHIP_OK;
+}
+
 // one pass over small float32 slabs (fasts.h): resident workgroups walk the slabs
 struct SGeomRt { int thr; size_t lds; int per_cu; size_t lds_iso; };
 template <int RY, int RX> static SGeomRt sgeom_t() {
@@ -1949,7 +2057,9 @@ static int run_fastr(const xrfthip_plan* P, const void* in, void* out, hipStream
 // set: window spectra and phase tables of the specialised paths (device allocations + blocking copies) and the workspace
 // layout.  xrfthip_exec itself takes the plan as const: no allocation, no copy, no synchronisation, no getenv.
 static int finalize_plan(xrfthip_plan* P) {
-    if (P->fasts) {
+    if (P->fastg) {
+        if (P->d.out_mode != XRFTHIP_OUT_POWER) { const int rc = fast_phase_tables(P); if (rc) return rc; }
+    } else if (P->fasts) {
         if (P->d.out_mode != XRFTHIP_OUT_POWER) { const int rc = fast_phase_tables(P); if (rc) return rc; }
     } else if (P->fastr) {
         if (P->d.out_mode != XRFTHIP_OUT_POWER) { const int rc = fast_phase_tables(P); if (rc) return rc; }
@@ -2312,6 +2422,18 @@ int xrfthip_plan_create(xrfthip_plan** plan, const xrfthip_desc* desc) {
             if (rcm) { delete P; return rcm; }
         }
     }
+    {   // a small slab of any smooth shape, either precision, that none of the specialised kernels above takes: one pass in LDS (fastg.h)
+        const uint32_t okg = XRFTHIP_SHIFT_Y | XRFTHIP_SHIFT_X | (d.out_mode == XRFTHIP_OUT_COMPLEX ? (XRFTHIP_ISHIFT_Y | XRFTHIP_ISHIFT_X) : 0u);
+        P->fastg = !P->fasts && !P->fast4096 && !P->fastm && (d.out_mode == XRFTHIP_OUT_POWER || d.out_mode == XRFTHIP_OUT_COMPLEX) && !(d.flags & ~okg) &&
+                   !env_ll("XRFTHIP_NO_FAST", 0) && env_ll("XRFTHIP_FASTG", 1) != 0 && fastg_try(P);
+        if (P->fastg) {
+            int rcg = P->dbl ? fastg_setup_t<double>(P) : fastg_setup_t<float>(P);
+            std::vector<double> ones((size_t)std::max(d.ny, d.nx), 1.0);
+            std::vector<float> onesf((size_t)std::max(d.ny, d.nx), 1.0f);
+            if (!rcg) rcg = P->dbl ? P->ones4096.upload(ones.data(), ones.size() * sizeof(double)) : P->ones4096.upload(onesf.data(), onesf.size() * sizeof(float));
+            if (rcg) { delete P; return rcg; }
+        }
+    }
     set_kernel_attrs_once();
     // nbins must be known before tiles are sized (the LDS histogram shares the tile's allocation): ISO plans are
     // (re)built in xrfthip_plan_set_binmap.  Build now for everything else.
@@ -2418,7 +2540,7 @@ int xrfthip_plan_profile_read(xrfthip_plan* plan, char* buf, size_t buflen) {
 int xrfthip_plan_uses_bluestein(const xrfthip_plan* plan) {
     if (!plan) return 0;
     if (plan->inner > 1) return xrfthip_plan_uses_bluestein(plan->sub_x) || xrfthip_plan_uses_bluestein(plan->sub_y);
-    if (plan->fasts || plan->fastr || plan->fastmx || plan->fastmy || plan->fastm || plan->fast1d || plan->fast4096) return 0;  // (the generic passes of such a plan never run)
+    if (plan->fastg || plan->fasts || plan->fastr || plan->fastmx || plan->fastmy || plan->fastm || plan->fast1d || plan->fast4096) return 0;  // (the generic passes of such a plan never run)
     for (const Pass& ps : plan->passes) if (ps.g.blue_n > 0) return 1;
     for (const Pass& ps : plan->passes_f0) if (ps.g.blue_n > 0) return 1;
     return 0;
@@ -2451,7 +2573,16 @@ int xrfthip_plan_describe(const xrfthip_plan* plan, char* buf, size_t buflen) {
     appendf(s, "xrfthip plan: ndim=%d batch=%lld ny=%lld nx=%lld dtype=%d mode=%d detrend=%d flags=0x%x width=%lld nx_out=%lld mirror=%d group=%d ws=%zuB\n",
             d.ndim, (long long)d.batch, (long long)d.ny, (long long)d.nx, d.dtype, d.out_mode, d.detrend, d.flags,
             plan->width, plan->nx_out, (int)plan->mirror, plan->G, plan->ws_bytes);
-    if (plan->fasts) {
+    if (plan->fastg) {
+        std::string rxs, rys;
+        for (int r : plan->g_rx) rxs += (rxs.empty() ? "" : "x") + std::to_string(r);
+        for (int r : plan->g_ry) rys += (rys.empty() ? "" : "x") + std::to_string(r);
+        appendf(s, "  [fastg] one pass, one %d-thread workgroup per %lld x %lld slab: the half spectrum (%lld rows of %lld + 1 complex) in LDS, radices from the plan "
+                   "(x: %lld = %s on packed rows, y: %lld = %s), exact plane detrend in the workgroup, output gathered in output order through the digit-reversal "
+                   "tables, lds=%zuB\n",
+                (int)fastg_threads(plan), (long long)plan->d.ny, (long long)plan->d.nx, (long long)plan->d.ny, (long long)plan->d.nx / 2, (long long)plan->d.nx / 2,
+                rxs.empty() ? "1" : rxs.c_str(), (long long)plan->d.ny, rys.c_str(), plan->g_lds);
+    } else if (plan->fasts) {
         const SGeomRt G = sgeom(plan->d.ny, plan->d.nx);
         appendf(s, "  [fasts] one pass, one %d-thread workgroup per %lld x %lld slab (%d fit a CU): the packed columns' transform, their split and the rows' "
                    "transform in registers (32 complex per thread, r32x%lld / r32x%lld, three LDS exchanges in halves), exact plane detrend in the workgroup, |F|^2 "
@@ -2525,6 +2656,7 @@ int xrfthip_exec(const xrfthip_plan* plan, const void* d_in0, const void* d_in1,
     double* acc = (double*)(ws + P->off_acc);
     double* coef = (double*)(ws + P->off_coef);
     if (iso) HIP_TRY(hipMemsetAsync(d_iso, 0, (size_t)d.batch * P->nbins * (cross ? 16 : 8), st));
+    if (P->fastg) return run_fastg(P, d_in0, out, st);
     if (P->fasts) return run_fasts(P, d_in0, out, (double*)d_iso, st);
     if (P->fastr) return run_fastr(P, d_in0, out, st);
     if (P->fastmx) return run_fastmx(P, d_in0, d_in1, out, st);
