@@ -18,14 +18,37 @@ def needs_build():
     return any(os.path.getmtime(d) > t for d in deps)
 
 
+# the same translation units as the gfx950 build (__graft_entry__.py): xrft_hip.cpp with the fasty / fastm kernels `extern template`, and the
+# instantiation groups, one g++ process each
+UNITS = [("xrft_hip.cpp", ["-DXRFT_SPLIT_TUS"])] + [(f"inst_g{g}.cpp", []) for g in (4, 5, 3, 1, 2)]
+
+
 def build(force=False):
     if not force and not needs_build():
         return OUT
-    os.makedirs(os.path.dirname(OUT), exist_ok=True)
-    cmd = ["g++", "-O1", "-std=c++17", "-fPIC", "-shared", "-DXRFT_EMULATE", f"-I{HERE}", f"-I{SRC}",
-           os.path.join(SRC, "xrft_hip.cpp"), "-o", OUT, "-lpthread"]
-    subprocess.run(cmd, check=True)
+    obj_dir = os.path.join(os.path.dirname(OUT), "obj")
+    os.makedirs(obj_dir, exist_ok=True)
+    import fcntl
+
+    with open(os.path.join(os.path.dirname(OUT), ".lock"), "w") as lock:  # xdist workers and spawned ranks: one builds, the others wait and find it built
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        if force or needs_build():
+            _compile(obj_dir)
     return OUT
+
+
+def _compile(obj_dir):
+    procs = []
+    for src, extra in UNITS:
+        obj = os.path.join(obj_dir, os.path.splitext(src)[0] + ".o")
+        cmd = ["g++", "-O1", "-std=c++17", "-fPIC", "-DXRFT_EMULATE", f"-I{HERE}", f"-I{SRC}"] + extra + ["-c", os.path.join(SRC, src), "-o", obj]
+        procs.append((src, obj, subprocess.Popen(cmd)))
+    failed = [src for src, _obj, pr in procs if pr.wait() != 0]
+    if failed:
+        raise RuntimeError(f"g++ failed on {failed}")
+    tmp = OUT + f".{os.getpid()}.tmp"  # (the library appears whole or not at all)
+    subprocess.run(["g++", "-shared", "-fPIC"] + [obj for _src, obj, _pr in procs] + ["-Wl,-z,defs", "-o", tmp, "-lpthread"], check=True)
+    os.replace(tmp, OUT)
 
 
 if __name__ == "__main__":
