@@ -99,10 +99,7 @@ add("   fft (complex) of the same, no detrend", x.numel(), 12, timeit(lambda: xr
 del x, da
 # a length with large prime factors: the ERA5 grid (721 = 7 x 103 latitudes) -- Bluestein in the column tile
 x = cube((64, 721, 1440), torch.float32); da = xrft.DataArray(x, ("t", "lat", "lon"), {"lat": np.arange(721) * .25, "lon": np.arange(1440) * .25})
-add("PS (64,721,1440) f32 linear+hann (ERA5 grid; Bluestein lengths run in float64: the default)", x.numel(), 8, timeit(lambda: xrft.power_spectrum(da, dim=["lat", "lon"], detrend="linear", window="hann")))
-xrft.bluestein_in_float64(False)
-add("   the same with xrft_amd.bluestein_in_float64(False): float32 arithmetic, max-norm bound only", x.numel(), 8, timeit(lambda: xrft.power_spectrum(da, dim=["lat", "lon"], detrend="linear", window="hann")))
-xrft.bluestein_in_float64(True)
+add("PS (64,721,1440) f32 linear+hann (ERA5 grid; Bluestein inside the column tile, float32)", x.numel(), 8, timeit(lambda: xrft.power_spectrum(da, dim=["lat", "lon"], detrend="linear", window="hann")))
 print(f"{'workload':58s} {'GFFT/s':>8s} {'ms':>9s} {'B/pt':>5s} {'frac of 8 TB/s':>15s}  path")
 for name, g, t, bpp, frac, path in rows:
     print(f"{name:58s} {g:8.2f} {t*1e3:9.3f} {bpp:5.0f} {frac:15.3f}  {path}")

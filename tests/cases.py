@@ -475,9 +475,8 @@ def run_pad_cases():
 def run_bluestein_cases(dtype):
     """Lengths with a prime factor above 128 (chirp-z inside the tile kernel); numpy's pocketfft takes any length."""
     tol = TOL[dtype]
-    # float32 chirp-z: a result is a difference of convolution terms the size of the spectrum's peak, so in float32 the bins 1e-3 of the
-    # peak of the UN-detrended cases (a trend 10-40 x the noise) carried a few 1e-3 of relative error (round 3: a 4e-3 exception here);
-    # since round 4 float32 data on such lengths run in float64 between two precision changes: the per-bin bound of every other path
+    # float32 chirp-z inside the tile: round 3 carried a 4e-3 per-bin exception here; measured since (profiles/r04_bluestein_f32.txt) these
+    # cases hold 6e-5 in float32 arithmetic, ERA5-like slabs 1.2e-4: the per-bin bound of every other path
     br = BIN_REL
     rng = np.random.default_rng(131)
     for n in (131, 257, 262, 1801, 4099):

@@ -699,8 +699,9 @@ def _blue_tables(n, cdt, dev, inverse=False):
 def _bluestein_1d(t, n, mode, detrend_kind, flags, scale, win, ph, phase_in=None):
     """The 1-D plan's result for t[..., n] (real or complex) without a 1-D plan of length n.  With XRFTHIP_INVERSE in ``flags`` the
     unnormalised inverse transform (the same pipeline with conjugated chirps); ``phase_in`` multiplies the INPUT, indexed by source
-    position (XRFTHIP_PHASE_IN, xrft.py:574-576).  float32 data run in float64 between two precision changes (engine.convert), as the
-    in-tile Bluestein plans do (engine.SpectralPlan): in float32 the chirp convolution costs the small bins their 1e-3."""
+    position (XRFTHIP_PHASE_IN, xrft.py:574-576).  float32 data run in float64 between two precision changes (engine.convert;
+    engine.bluestein_in_float64): stored float32 intermediates between the five passes cost the small bins their 1e-3.  (Bluestein
+    inside one tile of the C ABI's plans stays in float32: 1.2e-4 per bin.)"""
     if t.dtype in (torch.float32, torch.complex64) and engine.bluestein_in_float64():
         X = _bluestein_1d(engine.convert(t, torch.float64 if t.dtype == torch.float32 else torch.complex128), n, mode, detrend_kind, flags,
                           scale, win, ph, phase_in)

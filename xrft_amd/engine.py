@@ -40,7 +40,6 @@ class SpectralPlan:
                  slabs_per_group=0, inner=1):
         self._dll = _lib.load()
         self._h = C.c_void_p(0)
-        self._twin = None
         if dtype not in _DTYPES:
             raise TypeError(f"unsupported dtype {dtype}")
         self.ndim, self.batch, self.ny, self.nx = int(ndim), int(batch), int(ny), int(nx)
@@ -65,14 +64,6 @@ class SpectralPlan:
                 raise ValueError(f"bin map shape {bm.shape} != {(self.ny, self.nx_out)}")
             _lib.check(self._dll.xrfthip_plan_set_binmap(self._h, bm.ctypes.data_as(C.c_void_p), self.ny,
                                                          self.nx_out, self.nbins))
-        if dtype in _WIDER and bluestein_in_float64() and self._dll.xrfthip_plan_uses_bluestein(self._h):
-            # float32 data on a length that takes Bluestein's algorithm: the chirp convolution (two long transforms and three pointwise
-            # products) leaves an error of a few 1e-7 of the spectrum's PEAK in every bin -- 1e-3 relative in the bins 1e-3 of the
-            # peak.  Such plans run in float64 between two precision changes (xrfthip_convert); float32 in, float32 out as ever.
-            # (A length whose float64 chirp transform does not fit the tile raises UNSUPPORTED_LENGTH here, and the callers go
-            # through global memory as they do for float64 data.)
-            self._twin = SpectralPlan(ndim, batch, ny, nx, _WIDER[dtype], out_mode, detrend, flags, scale, window_y, window_x, phase_y, phase_x,
-                                      binmap, nbins, slabs_per_group, inner)
 
     def __del__(self):
         try:
@@ -87,11 +78,13 @@ class SpectralPlan:
         return int(self._dll.xrfthip_workspace_bytes(self._h))
 
     def describe(self):
-        if self._twin is not None:
-            return "[float32 data, run in float64: Bluestein length]\n" + self._twin.describe()
         buf = C.create_string_buffer(8192)
         self._dll.xrfthip_plan_describe(self._h, buf, len(buf))
         return buf.value.decode()
+
+    def uses_bluestein(self):
+        """True when an axis of the plan runs Bluestein's algorithm inside the tile kernels (a prime factor with no butterfly)."""
+        return bool(self._dll.xrfthip_plan_uses_bluestein(self._h))
 
     def set_profiling(self, enable=True):
         _lib.check(self._dll.xrfthip_plan_set_profiling(self._h, int(bool(enable))))
@@ -130,11 +123,6 @@ class SpectralPlan:
             iso = torch.empty((self.batch, self.nbins), device=dev,
                               dtype=torch.complex128 if self.out_mode == _lib.OUT_CROSS else torch.float64)
         if self.batch == 0:  # nothing to transform: empty outputs, no device call
-            return (out if want_out else None), iso
-        if self._twin is not None:
-            o64, iso = self._twin.execute(convert(in0, _WIDER[in0.dtype]), None if in1 is None else convert(in1, _WIDER[in1.dtype]), None, iso)
-            if o64 is not None:
-                convert(o64, self.out_dtype(), out.reshape(o64.shape))
             return (out if want_out else None), iso
         stream = _stream_handle(in0)
         # The C plan is immutable after creation, so nothing plan-wide is locked: threads on different streams enqueue
@@ -246,11 +234,13 @@ _BLUESTEIN_F64 = [os.environ.get("XRFT_AMD_BLUESTEIN", "float64").lower() not in
 
 
 def bluestein_in_float64(enable=None):
-    """float32 data on a transform length that takes Bluestein's algorithm (a prime factor with no butterfly: the ERA5 grid's 721 =
-    7 x 103 latitudes) run in float64 between two precision changes -- the default: in float32 the chirp convolution leaves every bin
-    an error of a few 1e-7 of the spectrum's PEAK, up to 4e-3 relative in the bins 1e-3 of the peak (the far end of a red spectrum).
-    ``bluestein_in_float64(False)`` (or XRFT_AMD_BLUESTEIN=float32 in the environment) keeps float32 arithmetic: about twice as fast on
-    such lengths ((64, 721, 1440): 56 against 26 GFFT/s), the max-norm bound of 1e-3 still holds.  Returns the setting."""
+    """float32 data on a transform length too long for Bluestein's algorithm inside one LDS tile (a prime factor above 128 and more than
+    ~8800 samples: api._bluestein_1d, three table products around two long plans through global memory) run in float64 between two
+    precision changes -- the default: with float32 intermediates stored between the passes, the composition leaves the bins 1e-3 of
+    the spectrum's peak 1.3e-3 of relative error, above the 1e-3 every other path holds.  ``bluestein_in_float64(False)`` (or
+    XRFT_AMD_BLUESTEIN=float32 in the environment) keeps float32 arithmetic there: the max-norm bound of 1e-3 still holds.
+    Bluestein lengths INSIDE a tile (the ERA5 grid's 721 = 7 x 103 latitudes) stay in float32 either way: measured on the GPU they hold
+    1.2e-4 per bin (profiles/r04_bluestein_f32.txt).  Returns the setting."""
     if enable is not None:
         _BLUESTEIN_F64[0] = bool(enable)
     return _BLUESTEIN_F64[0]
