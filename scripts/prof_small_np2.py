@@ -37,4 +37,10 @@ for nt, ny, nx, dt in shapes:
         os.environ.pop(k, None)
     api._plan_cache.clear()
     w2 = t(lambda: xrft.fft(da, dim=["y", "x"], detrend="linear", window="hann"))
-    print(line + f" | fft {x.numel()/w2/1e9:6.1f} GFFT/s", flush=True)
+    w3 = t(lambda: xrft.isotropic_power_spectrum(da, dim=["y", "x"], detrend="linear", window="hann"))
+    os.environ["XRFTHIP_FASTG"] = "0"
+    api._plan_cache.clear()
+    w4 = t(lambda: xrft.isotropic_power_spectrum(da, dim=["y", "x"], detrend="linear", window="hann"))
+    os.environ.pop("XRFTHIP_FASTG", None)
+    api._plan_cache.clear()
+    print(line + f" | fft {x.numel()/w2/1e9:6.1f} | isotropic PS {x.numel()/w3/1e9:6.1f} (two-pass {x.numel()/w4/1e9:6.1f}) GFFT/s", flush=True)

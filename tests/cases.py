@@ -1101,6 +1101,40 @@ def run_fastg_cases(shape=(3, 50, 50), dtype="float32", full=True):
     for kw in (dict(), dict(true_phase=False), dict(shift=False, true_phase=False, true_amplitude=False), dict(detrend="linear", window="hann")):
         worst = max(worst, check(xa.fft(da, dim=["y", "x"], **kw), o.fft(od, dim=["y", "x"], **kw), tol))
         assert on_fastg()
+    # the radial sums inside the same pass (xrft.py:895-906, 1013-1095): per-bin position lists, any bin map
+    for kw in (dict(detrend="linear", window="hann"), dict(truncate=True), dict(detrend="constant", window="hamming", nfactor=2)):
+        worst = max(worst, check(xa.isotropic_power_spectrum(da, dim=["y", "x"], **kw), o.isotropic_power_spectrum(od, dim=["y", "x"], **kw), max(tol, 1e-9)))
+        assert any("[fastg]" in p.describe() and "radial sums" in p.describe() for p in xa.api._plan_cache.values())
+    import torch
+
+    from xrft_amd import _lib, engine
+
+    nt, ny, nx = shape
+    nb = max(2, min(ny, nx) // 4)
+    tdt = torch.float64 if dtype == "float64" else torch.float32
+    t = xa.api._to_device(np.ascontiguousarray(a))
+    anymap = rng.integers(-1, nb, size=(ny, nx)).astype(np.int32)
+    for flags in (_lib.ISO, _lib.ISO | _lib.NO_SPECTRUM_OUT):
+        plan = engine.SpectralPlan(2, nt, ny, nx, tdt, out_mode=_lib.OUT_POWER, flags=flags, scale=0.5, binmap=anymap, nbins=nb)
+        assert "[fastg]" in plan.describe()
+        out, iso = plan.execute(t)
+        _, iso2 = plan.execute(t)
+        assert torch.equal(iso, iso2)  # no atomics: the same bits
+        if out is not None:
+            spec = out.cpu().numpy().astype(np.float64)
+            ok = anymap.ravel() >= 0
+            for b in range(nt):
+                ref = np.bincount(anymap.ravel()[ok], weights=spec[b].ravel()[ok], minlength=nb)
+                assert np.all(np.abs(iso.cpu().numpy()[b] - ref) <= (1e-13 if dtype == "float64" else 2e-6) * np.maximum(ref, 1e-300))
+            keep = iso
+        else:
+            assert torch.equal(iso, keep)
+    vn = np.array(a, copy=True)
+    vn[nt - 1, 1, 2] = np.nan  # poisons its own slab only
+    plan = engine.SpectralPlan(2, nt, ny, nx, tdt, out_mode=_lib.OUT_POWER, flags=_lib.ISO | _lib.NO_SPECTRUM_OUT, scale=1.0, binmap=anymap, nbins=nb)
+    g = plan.execute(xa.api._to_device(vn))[1].cpu().numpy()
+    used = np.bincount(anymap.ravel()[anymap.ravel() >= 0], minlength=nb) > 0
+    assert np.all(np.isnan(g[nt - 1][used])) and (nt == 1 or np.all(np.isfinite(g[: nt - 1])))
     return worst
 
 

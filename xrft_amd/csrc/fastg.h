@@ -47,6 +47,12 @@ struct FastG {
     int detrend;        // 0 none, 1 constant, 2 linear (plane)
     int shift_y, shift_x;  // 0 or n/2 (the fftshift offsets, xrft.py:446-447)
     double scale;
+    // radial sums (xrft.isotropic_power_spectrum, xrft.py:895-906): per bin the LDS positions of its samples (any bin map; a sample of the
+    // right half plane is its Hermitian twin's position), [nbins + 1] starts into the list; iso[slab][nbins].  out may then be null.
+    const unsigned short* iso_pos;
+    const unsigned* iso_start;
+    double* iso;
+    int nbins;
 };
 
 // one radix pass over the COLUMNS of the tile: sequences of length len, element stride rs, ncols of them; lanes run along the columns
@@ -219,6 +225,23 @@ __global__ void __launch_bounds__(fastg_max_threads<T>()) fastg_kernel(FastG p) 
         // ---- out, in output order: (orow, ocol) <- F[ky][kx], or conj F[-ky][-kx] for kx > n (a real field's spectrum is Hermitian)
         const int tot = ny * nx;
         const T sc = (T)p.scale;
+        if (MODE == 1 && p.iso != nullptr) {
+            // a bin per wave: lane l adds the samples l, l + 64, ... of the bin's list in float64, the lanes meet in a fixed shuffle tree -- no
+            // atomics, the same bits every time; a nan / inf stays in its bin
+            const int lane = tid & 63, nw = nthr >> 6;
+            for (int b = tid >> 6; b < p.nbins; b += nw) {
+                const unsigned q0 = p.iso_start[b], q1 = p.iso_start[b + 1];
+                double acc = 0.0;
+                for (unsigned q = q0 + (unsigned)lane; q < q1; q += 64u) {
+                    const CT v = tile[p.iso_pos[q]];
+                    acc += (double)((v.re * v.re + v.im * v.im) * sc);
+                }
+#pragma unroll
+                for (int m = 1; m < 64; m <<= 1) acc += __shfl_xor(acc, m);
+                if (lane == 0) p.iso[(size_t)slab * p.nbins + b] = acc;
+            }
+            if (p.out == nullptr) continue;
+        }
         for (int e = tid; e < tot; e += nthr) {
             const int orow = fdiv(e, inv_nx), ocol = e - orow * nx;
             int ky = orow - p.shift_y; if (ky < 0) ky += ny;

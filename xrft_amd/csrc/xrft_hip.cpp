@@ -332,7 +332,8 @@ struct xrfthip_plan {
     // ... and ONE pass for a small real slab of any smooth shape, either precision, held in LDS with run-time radices (fastg.h)
     bool fastg = false;
     std::vector<int> g_rx, g_ry;
-    DevBuf g_twx, g_twy, g_twr, g_revx, g_revy;
+    DevBuf g_twx, g_twy, g_twr, g_revx, g_revy, g_isopos, g_isostart;
+    std::vector<unsigned> g_hrevx, g_hrevy;  // (host copies: the radial-sum lists are built from them when the bin map arrives)
     int g_rs = 0;
     size_t g_lds = 0;
     // ... and ONE pass for a small real float32 slab that fits the registers of a CU: 256 x 256 power spectra (fasts.h)
@@ -1059,7 +1060,7 @@ static int run_moments(const xrfthip_plan* P, const void* in, long long g0, long
     prof_end(rec, st);
     rec = prof_begin(P, "finalize_coef", st);
     auto kf = &finalize_coef_kernel;
-    XRFT_LAUNCH(kf, dim3((unsigned)((gc + 63) / 64)), dim3(64), 0, st, (const double*)acc, coef + g0 * 6, gc, (long long)d.ny, (long long)d.nx, (int)d.detrend, (int)chunks);
+    XRFT_LAUNCH(kf, dim3((unsigned)gc), dim3(64), 0, st, (const double*)acc, coef + g0 * 6, gc, (long long)d.ny, (long long)d.nx, (int)d.detrend, (int)chunks);
     prof_end(rec, st);
     HIP_TRY(hipGetLastError());
     return XRFTHIP_OK;
@@ -1837,7 +1838,7 @@ static int run_fastmx(const xrfthip_plan* P, const void* in, const void* in1, vo
 // ---------------------------------------------------------------------------------------------------------------
 // one pass over small slabs of any smooth shape (fastg.h): the lengths as data
 // ---------------------------------------------------------------------------------------------------------------
-static int fastg_rev(const std::vector<int>& radix, int n, DevBuf& buf) {  // rev[k] = position of frequency k after the DIF passes (as build_tables)
+static int fastg_rev(const std::vector<int>& radix, int n, DevBuf& buf, std::vector<unsigned>& host) {  // rev[k] = position of frequency k after the DIF passes (as build_tables)
     std::vector<unsigned> rev((size_t)std::max(n, 1));
     for (int pos = 0; pos < n; ++pos) {
         long long L = n, rem = pos, k = 0, mult = 1;
@@ -1850,6 +1851,7 @@ static int fastg_rev(const std::vector<int>& radix, int n, DevBuf& buf) {  // re
         }
         rev[(size_t)k] = (unsigned)pos;
     }
+    host = rev;
     return buf.upload(rev.data(), rev.size() * sizeof(unsigned));
 }
 template <typename T> static int fastg_setup_t(xrfthip_plan* P) {
@@ -1858,8 +1860,8 @@ template <typename T> static int fastg_setup_t(xrfthip_plan* P) {
     int rc = build_twiddle<T>(P->g_twx, n, n);
     if (!rc) rc = build_twiddle<T>(P->g_twy, ny, ny);
     if (!rc) rc = build_twiddle<T>(P->g_twr, d.nx, n + 1);
-    if (!rc) rc = fastg_rev(P->g_rx, n, P->g_revx);
-    if (!rc) rc = fastg_rev(P->g_ry, ny, P->g_revy);
+    if (!rc) rc = fastg_rev(P->g_rx, n, P->g_revx, P->g_hrevx);
+    if (!rc) rc = fastg_rev(P->g_ry, ny, P->g_revy, P->g_hrevy);
     return rc;
 }
 static bool fastg_try(xrfthip_plan* P) {  // can the slab's half spectrum live in the LDS of one workgroup, and are both lengths smooth?
@@ -1881,6 +1883,29 @@ static bool fastg_try(xrfthip_plan* P) {  // can the slab's half spectrum live i
     P->g_rx = rx; P->g_ry = ry; P->g_rs = rs; P->g_lds = lds;
     return true;
 }
+// fastg radial sums: per bin the LDS positions of its samples, in (ky, kx) order -- any bin map (a sample with kx > nx/2 lives at its Hermitian twin's
+// position: |F|^2 is the same)
+static int fastg_build_iso(xrfthip_plan* P, const int32_t* bm) {
+    const int ny = (int)P->d.ny, nx = (int)P->d.nx, n = nx / 2, rs = P->g_rs, nb = P->nbins;
+    if ((size_t)ny * rs > 65535u || nb < 1) { P->fastg = false; return XRFTHIP_OK; }  // (16-bit positions; the other paths take the plan)
+    std::vector<unsigned> start((size_t)nb + 1, 0u);
+    for (size_t e = 0; e < (size_t)ny * nx; ++e) if (bm[e] >= 0 && bm[e] < nb) ++start[(size_t)bm[e] + 1];
+    for (int b = 0; b < nb; ++b) start[(size_t)b + 1] += start[(size_t)b];
+    std::vector<unsigned> fill(start.begin(), start.end() - 1);
+    std::vector<uint16_t> pos(std::max<size_t>(1, start[(size_t)nb]));
+    for (int ky = 0; ky < ny; ++ky)
+        for (int kx = 0; kx < nx; ++kx) {
+            const int32_t c = bm[(size_t)ky * nx + kx];
+            if (c < 0 || c >= nb) continue;
+            const bool mir = kx > n;
+            const int sy = mir ? (ky == 0 ? 0 : ny - ky) : ky, sx = mir ? nx - kx : kx;
+            pos[fill[(size_t)c]++] = (uint16_t)(P->g_hrevy[(size_t)sy] * (unsigned)rs + (sx == n ? (unsigned)n : P->g_hrevx[(size_t)sx]));
+        }
+    int rc = P->g_isopos.upload(pos.data(), pos.size() * sizeof(uint16_t));
+    if (!rc) rc = P->g_isostart.upload(start.data(), start.size() * sizeof(unsigned));
+    return rc;
+}
+
 // threads per slab.  The passes are chains of LDS round trips, so it is the number of waves in flight on a CU that sets the rate, and that is
 // bounded twice: by the registers (float32: 105 -> 4 waves per SIMD, 16 per CU; float64: 153 -> 3 and 12) and by how many slabs' LDS a CU holds.
 // Take the workgroup of 1, 2, 4, 8 or 16 waves (whole waves per SIMD, or the second workgroup does not fit beside the first) that keeps most
@@ -1899,7 +1924,7 @@ static long long fastg_threads(const xrfthip_plan* P) {
     return best * 64;
 }
 
-static int run_fastg(const xrfthip_plan* P, const void* in, void* out, hipStream_t st) {
+static int run_fastg(const xrfthip_plan* P, const void* in, void* out, double* iso, hipStream_t st) {
     const xrfthip_desc& d = P->d;
     FastG p{};
     p.in = in; p.out = out; p.nslabs = d.batch;
@@ -1909,6 +1934,12 @@ static int run_fastg(const xrfthip_plan* P, const void* in, void* out, hipStream
     for (int i = 0; i < p.nry; ++i) p.ry[i] = P->g_ry[(size_t)i];
     p.tw_x = P->g_twx.p; p.tw_y = P->g_twy.p; p.tw_r = P->g_twr.p;
     p.rev_x = (const unsigned*)P->g_revx.p; p.rev_y = (const unsigned*)P->g_revy.p;
+    if (d.flags & XRFTHIP_ISO) {
+        p.iso = iso; p.nbins = P->nbins;
+        p.iso_pos = (const unsigned short*)P->g_isopos.p; p.iso_start = (const unsigned*)P->g_isostart.p;
+        if (d.flags & XRFTHIP_NO_SPECTRUM_OUT) out = nullptr;
+        p.out = out;
+    }
     const bool win = P->win[0].p || P->win[1].p;
     p.win_y = win ? (P->win[0].p ? P->win[0].p : P->ones4096.p) : nullptr;
     p.win_x = win ? (P->win[1].p ? P->win[1].p : P->ones4096.p) : nullptr;
@@ -2423,7 +2454,7 @@ int xrfthip_plan_create(xrfthip_plan** plan, const xrfthip_desc* desc) {
         }
     }
     {   // a small slab of any smooth shape, either precision, that none of the specialised kernels above takes: one pass in LDS (fastg.h)
-        const uint32_t okg = XRFTHIP_SHIFT_Y | XRFTHIP_SHIFT_X | (d.out_mode == XRFTHIP_OUT_COMPLEX ? (XRFTHIP_ISHIFT_Y | XRFTHIP_ISHIFT_X) : 0u);
+        const uint32_t okg = XRFTHIP_SHIFT_Y | XRFTHIP_SHIFT_X | (d.out_mode == XRFTHIP_OUT_COMPLEX ? (XRFTHIP_ISHIFT_Y | XRFTHIP_ISHIFT_X) : (XRFTHIP_ISO | XRFTHIP_NO_SPECTRUM_OUT));
         P->fastg = !P->fasts && !P->fast4096 && !P->fastm && (d.out_mode == XRFTHIP_OUT_POWER || d.out_mode == XRFTHIP_OUT_COMPLEX) && !(d.flags & ~okg) &&
                    !env_ll("XRFTHIP_NO_FAST", 0) && env_ll("XRFTHIP_FASTG", 1) != 0 && fastg_try(P);
         if (P->fastg) {
@@ -2481,6 +2512,10 @@ int xrfthip_plan_set_binmap(xrfthip_plan* plan, const int32_t* h_binmap, int64_t
     plan->nbins = nbins;
     if (plan->fasts) {  // a radial map within the workgroup's reach: the sums are taken from the staged rows (fasts.h); else the other paths
         const int rcs = fasts_build_tfirst(plan, h_binmap);
+        if (rcs) return rcs;
+    }
+    if (plan->fastg) {  // any map: per-bin position lists (fastg.h)
+        const int rcs = fastg_build_iso(plan, h_binmap);
         if (rcs) return rcs;
     }
     if (plan->fast4096 && !plan->fasts) {
@@ -2582,6 +2617,9 @@ int xrfthip_plan_describe(const xrfthip_plan* plan, char* buf, size_t buflen) {
                    "tables, lds=%zuB\n",
                 (int)fastg_threads(plan), (long long)plan->d.ny, (long long)plan->d.nx, (long long)plan->d.ny, (long long)plan->d.nx / 2, (long long)plan->d.nx / 2,
                 rxs.empty() ? "1" : rxs.c_str(), (long long)plan->d.ny, rys.c_str(), plan->g_lds);
+        if (plan->d.flags & XRFTHIP_ISO)
+            appendf(s, "  [fastg radial sums] in the same pass: per bin the LDS positions of its samples (any bin map), a bin per wave, float64, a fixed shuffle tree -- no atomics%s\n",
+                    (plan->d.flags & XRFTHIP_NO_SPECTRUM_OUT) ? "; the spectrum is not stored" : "");
     } else if (plan->fasts) {
         const SGeomRt G = sgeom(plan->d.ny, plan->d.nx);
         appendf(s, "  [fasts] one pass, one %d-thread workgroup per %lld x %lld slab (%d fit a CU): the packed columns' transform, their split and the rows' "
@@ -2656,7 +2694,7 @@ int xrfthip_exec(const xrfthip_plan* plan, const void* d_in0, const void* d_in1,
     double* acc = (double*)(ws + P->off_acc);
     double* coef = (double*)(ws + P->off_coef);
     if (iso) HIP_TRY(hipMemsetAsync(d_iso, 0, (size_t)d.batch * P->nbins * (cross ? 16 : 8), st));
-    if (P->fastg) return run_fastg(P, d_in0, out, st);
+    if (P->fastg) return run_fastg(P, d_in0, out, (double*)d_iso, st);
     if (P->fasts) return run_fasts(P, d_in0, out, (double*)d_iso, st);
     if (P->fastr) return run_fastr(P, d_in0, out, st);
     if (P->fastmx) return run_fastmx(P, d_in0, d_in1, out, st);
@@ -2719,7 +2757,7 @@ int xrfthip_detrend(int32_t dtype, int32_t ndim, int64_t batch, int64_t ny, int6
         if (dbl) { if (cplx) MOM(double, true); else MOM(double, false); } else { if (cplx) MOM(float, true); else MOM(float, false); }
 #undef MOM
         auto kf = &finalize_coef_kernel;
-        XRFT_LAUNCH(kf, dim3((unsigned)((bc + 63) / 64)), dim3(64), 0, st, (const double*)acc, coef + b0 * 6, bc, (long long)ny, (long long)nx, (int)detrend_type, (int)chunks);
+        XRFT_LAUNCH(kf, dim3((unsigned)bc), dim3(64), 0, st, (const double*)acc, coef + b0 * 6, bc, (long long)ny, (long long)nx, (int)detrend_type, (int)chunks);
         const long long gx = std::max<long long>(1, std::min<long long>(2048, (total + 255) / 256));
         const dim3 grid2((unsigned)gx, (unsigned)bc);
 #define APP(TT, CC) do { auto k = &detrend_apply_kernel<TT, CC>; XRFT_LAUNCH(k, grid2, block, 0, st, src, dst, (long long)ny, (long long)nx, (const double*)(coef + b0 * 6)); } while (0)
