@@ -7,8 +7,7 @@ import xrft_amd as xrft
 from xrft_amd import api
 warnings.simplefilter("ignore")
 
-shapes = [(16, 3000, 3000, "float64"), (64, 721, 1440, "float32"), (16, 2200, 2200, "float32"), (16, 1100, 1100, "float64"), (32, 1000, 1000, "float32"), (16, 2500, 1250, "float32"),
-          (32, 750, 1500, "float64"), (16, 1215, 1215, "float32")]
+shapes = [(16, 3000, 3000, "float64"), (16, 2500, 1250, "float32"), (32, 750, 1500, "float64"), (16, 1215, 1215, "float32")]
 for nt, ny, nx, dt in shapes:
     x = torch.randn((nt, ny, nx), dtype=getattr(torch, dt), device="cuda")
     da = xrft.DataArray(x, ("t", "y", "x"), {"y": np.arange(float(ny)), "x": np.arange(float(nx))})

@@ -600,6 +600,14 @@ def test_random_one_axis_differential(seed):
     run_random_one_axis(seed)
 
 
+@pytest.mark.parametrize("seed", range(100))
+def test_random_small_slab_differential(seed):
+    """Random small slabs of any smooth shape, both precisions, up to 39 slabs per call: the one-pass kernels (fastg.h / fasts.h)."""
+    from test_random_differential import run_random_small_slab
+
+    run_random_small_slab(1000 + seed)
+
+
 def test_concurrent_threads_and_streams():
     """Four host threads, each on its own HIP stream, share one cached plan (a workspace per stream, one enqueue at a time)."""
     import threading

@@ -157,6 +157,66 @@ def run_random_fast(seed):
     cases.check(got, ref, 3e-4)
 
 
+def _smooth_lengths(lo, hi, even=False):
+    out = []
+    for n in range(lo, hi + 1):
+        m = n
+        for f in (2, 3, 5):
+            while m % f == 0:
+                m //= f
+        if m == 1 and (not even or n % 2 == 0):
+            out.append(n)
+    return out
+
+
+def run_random_small_slab(seed, max_points=19000):
+    """Random small real slabs of any smooth shape (the half spectrum fits one workgroup's LDS), both precisions, many slabs per call: the
+    one-pass kernel with run-time radices (csrc/fastg.h; 64 | 128 | 256 points per axis in float32: csrc/fasts.h) -- power / complex /
+    isotropic spectra with random options against the oracle.  Returns the tag of the kernel that served the call."""
+    import xrft_amd as xa
+
+    rng = np.random.default_rng(9000 + seed)
+    dtype = str(rng.choice(["float32", "float64"]))
+    cap = max_points if dtype == "float32" else max_points // 2
+    while True:
+        ny = int(rng.choice(_smooth_lengths(2, 200)))
+        nx = int(rng.choice(_smooth_lengths(4, 300, even=True)))
+        if ny * (nx // 2 + 2) <= cap - 300:
+            break
+    nb = int(rng.integers(1, 40))
+    v = rng.standard_normal((nb, ny, nx))
+    v += (0.01 * np.arange(ny))[None, :, None] + (-0.02 * np.arange(nx) + 3)[None, None, :]
+    v *= (1 + (np.arange(nb) % 5))[:, None, None]
+    v = v.astype(dtype)
+    c = {"t": np.arange(nb), "y": np.arange(ny) * float(rng.choice([0.5, 1.0])) + float(rng.choice([0.0, 2.0])),
+         "x": np.arange(nx) * float(rng.choice([0.25, 1.0])) - float(rng.choice([0.0, 3.0]))}
+    da, od = cases.pair(v, ("t", "y", "x"), c)
+    kw = dict(detrend=rng.choice([None, "constant", "linear"]), window=rng.choice([None, "hann", "hamming"]))
+    kind = str(rng.choice(["ps", "ps", "fft", "iso"]))
+    shift = bool(rng.random() < 0.7)
+    tp = bool(rng.random() < 0.5)
+    api._plan_cache.clear()
+    if kind == "ps":
+        sc = str(rng.choice(["density", "spectrum"]))
+        got, ref = xa.power_spectrum(da, dim=["y", "x"], shift=shift, scaling=sc, **kw), o.power_spectrum(od, dim=["y", "x"], shift=shift, scaling=sc, **kw)
+    elif kind == "fft":
+        got, ref = xa.fft(da, dim=["y", "x"], shift=shift, true_phase=tp, **kw), o.fft(od, dim=["y", "x"], shift=shift, true_phase=tp, **kw)
+    else:
+        if min(ny, nx) < 8:
+            kw["nfactor"] = 1
+        tr = bool(rng.random() < 0.5)
+        got, ref = xa.isotropic_power_spectrum(da, dim=["y", "x"], truncate=tr, **kw), o.isotropic_power_spectrum(od, dim=["y", "x"], truncate=tr, **kw)
+    tags = [t for t in ("[fastg]", "[fasts]", "[fastm]") if any(t in p.describe() for p in api._plan_cache.values())]
+    assert tags, (kind, ny, nx, dtype, [p.describe() for p in api._plan_cache.values()])
+    cases.check(got, ref, max(cases.TOL[dtype], 1e-9))
+    return tags[0]
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("XRFT_RANDOM_SMALL_SLAB_CASES", "30"))))
+def test_random_small_slab_case(seed):
+    run_random_small_slab(seed)
+
+
 def run_random_fastm(seed, lengths=(180, 240, 360, 480, 500, 720, 960, 1000, 1200, 1440), dtype="float64"):
     """Random mode / option combinations in float64 / float32 on the lat/lon lengths of csrc/fastm.h (BASELINE.json configs[4] is
     (64, 1440, 720)); modes the mixed-radix kernels do not take (a flipped axis) must come out
