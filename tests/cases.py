@@ -1101,8 +1101,16 @@ def run_fastg_cases(shape=(3, 50, 50), dtype="float32", full=True):
     for kw in (dict(), dict(true_phase=False), dict(shift=False, true_phase=False, true_amplitude=False), dict(detrend="linear", window="hann")):
         worst = max(worst, check(xa.fft(da, dim=["y", "x"], **kw), o.fft(od, dim=["y", "x"], **kw), tol))
         assert on_fastg()
+    # real_dim: the half spectrum along x, unshifted, the doubled interior columns of a power spectrum (xrft.py:400-404, 673-682)
+    for kw in (dict(), dict(detrend="linear", window="hann"), dict(scaling="spectrum", detrend="constant")):
+        worst = max(worst, check(xa.power_spectrum(da, dim=["y"], real_dim="x", **kw), o.power_spectrum(od, dim=["y"], real_dim="x", **kw), tol))
+        assert on_fastg()
+    for kw in (dict(), dict(true_phase=False, detrend="linear", window="hann")):
+        worst = max(worst, check(xa.fft(da, dim=["y"], real_dim="x", **kw), o.fft(od, dim=["y"], real_dim="x", **kw), tol))
+        assert on_fastg()
     # the radial sums inside the same pass (xrft.py:895-906, 1013-1095): per-bin position lists, any bin map
     for kw in (dict(detrend="linear", window="hann"), dict(truncate=True), dict(detrend="constant", window="hamming", nfactor=2)):
+        xa.api._plan_cache.clear()
         worst = max(worst, check(xa.isotropic_power_spectrum(da, dim=["y", "x"], **kw), o.isotropic_power_spectrum(od, dim=["y", "x"], **kw), max(tol, 1e-9)))
         assert any("[fastg]" in p.describe() and "radial sums" in p.describe() for p in xa.api._plan_cache.values())
     import torch

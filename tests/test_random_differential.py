@@ -181,7 +181,7 @@ def run_random_small_slab(seed, max_points=19000):
     while True:
         ny = int(rng.choice(_smooth_lengths(2, 200)))
         nx = int(rng.choice(_smooth_lengths(4, 300, even=True)))
-        if ny * (nx // 2 + 2) <= cap - 300:
+        if ny * (nx // 2 + 2) + 2 * (nx + ny) <= cap - 300:  # (the tile, the tables and the windows in 150 KB of LDS)
             break
     nb = int(rng.integers(1, 40))
     v = rng.standard_normal((nb, ny, nx))
@@ -192,7 +192,7 @@ def run_random_small_slab(seed, max_points=19000):
          "x": np.arange(nx) * float(rng.choice([0.25, 1.0])) - float(rng.choice([0.0, 3.0]))}
     da, od = cases.pair(v, ("t", "y", "x"), c)
     kw = dict(detrend=rng.choice([None, "constant", "linear"]), window=rng.choice([None, "hann", "hamming"]))
-    kind = str(rng.choice(["ps", "ps", "fft", "iso"]))
+    kind = str(rng.choice(["ps", "ps", "fft", "iso", "ps_real", "fft_real"]))
     shift = bool(rng.random() < 0.7)
     tp = bool(rng.random() < 0.5)
     api._plan_cache.clear()
@@ -201,6 +201,10 @@ def run_random_small_slab(seed, max_points=19000):
         got, ref = xa.power_spectrum(da, dim=["y", "x"], shift=shift, scaling=sc, **kw), o.power_spectrum(od, dim=["y", "x"], shift=shift, scaling=sc, **kw)
     elif kind == "fft":
         got, ref = xa.fft(da, dim=["y", "x"], shift=shift, true_phase=tp, **kw), o.fft(od, dim=["y", "x"], shift=shift, true_phase=tp, **kw)
+    elif kind == "ps_real":
+        got, ref = xa.power_spectrum(da, dim=["y"], real_dim="x", **kw), o.power_spectrum(od, dim=["y"], real_dim="x", **kw)
+    elif kind == "fft_real":
+        got, ref = xa.fft(da, dim=["y"], real_dim="x", true_phase=tp, **kw), o.fft(od, dim=["y"], real_dim="x", true_phase=tp, **kw)
     else:
         if min(ny, nx) < 8:
             kw["nfactor"] = 1

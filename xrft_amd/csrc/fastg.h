@@ -46,6 +46,8 @@ struct FastG {
     int ph_on;
     int detrend;        // 0 none, 1 constant, 2 linear (plane)
     int shift_y, shift_x;  // 0 or n/2 (the fftshift offsets, xrft.py:446-447)
+    int half;              // real_dim: only kx = 0..nx/2 is stored, rows of nx/2 + 1 samples, unshifted (xrft.py:400-404)
+    int realdim2;          // ... and 0 < kx < nx/2 counts twice (xrft.py:673-682)
     double scale;
     // radial sums (xrft.isotropic_power_spectrum, xrft.py:895-906): per bin the LDS positions of its samples (any bin map; a sample of the
     // right half plane is its Hermitian twin's position), [nbins + 1] starts into the list; iso[slab][nbins].  out may then be null.
@@ -124,8 +126,14 @@ __global__ void __launch_bounds__(fastg_max_threads<T>()) fastg_kernel(FastG p) 
     CT* twy = reinterpret_cast<CT*>(tb); tb += (size_t)ny * sizeof(CT);
     CT* twr = reinterpret_cast<CT*>(tb); tb += (size_t)(n + 1) * sizeof(CT);
     double* red = reinterpret_cast<double*>(tb); tb += kFastGWaves * 3 * sizeof(double);  // [waves][3]
+    T* wys = reinterpret_cast<T*>(tb); tb += (size_t)ny * sizeof(T);  // the windows (with a window; else unused)
+    T* wxs = reinterpret_cast<T*>(tb); tb += (size_t)nx * sizeof(T);
     unsigned short* revx = reinterpret_cast<unsigned short*>(tb); tb += (((size_t)n * 2 + 3) & ~(size_t)3);
     unsigned short* revy = reinterpret_cast<unsigned short*>(tb);
+    if (p.win_y) {
+        for (int k = tid; k < ny; k += nthr) wys[k] = reinterpret_cast<const T*>(p.win_y)[k];
+        for (int k = tid; k < nx; k += nthr) wxs[k] = reinterpret_cast<const T*>(p.win_x)[k];
+    }
     for (int k = tid; k < n; k += nthr) { twx[k] = reinterpret_cast<const CT*>(p.tw_x)[k]; revx[k] = (unsigned short)p.rev_x[k]; }
     for (int k = tid; k < ny; k += nthr) { twy[k] = reinterpret_cast<const CT*>(p.tw_y)[k]; revy[k] = (unsigned short)p.rev_y[k]; }
     for (int k = tid; k <= n; k += nthr) twr[k] = reinterpret_cast<const CT*>(p.tw_r)[k];
@@ -168,8 +176,8 @@ __global__ void __launch_bounds__(fastg_max_threads<T>()) fastg_kernel(FastG p) 
             } else {
                 __syncthreads();
             }
-            const T* __restrict__ wy = reinterpret_cast<const T*>(p.win_y);
-            const T* __restrict__ wx = reinterpret_cast<const T*>(p.win_x);
+            const T* wy = p.win_y ? wys : nullptr;
+            const T* wx = wxs;
             for (int e = tid; e < npk; e += nthr) {  // (each thread revisits the elements it loaded)
                 const int i = fdiv(e, inv_n), m = e - i * n;
                 CT z = tile[i * rs + m];
@@ -241,6 +249,24 @@ __global__ void __launch_bounds__(fastg_max_threads<T>()) fastg_kernel(FastG p) 
                 if (lane == 0) p.iso[(size_t)slab * p.nbins + b] = acc;
             }
             if (p.out == nullptr) continue;
+        }
+        if (p.half) {  // rows of n + 1 samples, kx = 0 .. n as they lie in the tile: no twin, no shift
+            const int W = n + 1, toth = ny * W;
+            const float inv_w = 1.0f / (float)W;
+            for (int e = tid; e < toth; e += nthr) {
+                const int ky = fdiv(e, inv_w), kx = e - ky * W;
+                const CT v = tile[(int)revy[ky] * rs + (kx == n ? n : (int)revx[kx])];
+                if (MODE == 1) {
+                    T pw = (v.re * v.re + v.im * v.im) * sc;
+                    if (p.realdim2 && kx != 0 && kx != n) pw *= (T)2;
+                    reinterpret_cast<T*>(p.out)[(size_t)slab * toth + e] = pw;
+                } else {
+                    CT o = mk<T>(v.re * sc, v.im * sc);
+                    if (p.ph_on) o = cmul(o, cmul(reinterpret_cast<const CT*>(p.ph_y)[ky], reinterpret_cast<const CT*>(p.ph_x)[kx]));
+                    reinterpret_cast<CT*>(p.out)[(size_t)slab * toth + e] = o;
+                }
+            }
+            continue;
         }
         for (int e = tid; e < tot; e += nthr) {
             const int orow = fdiv(e, inv_nx), ocol = e - orow * nx;

@@ -1871,8 +1871,8 @@ static bool fastg_try(xrfthip_plan* P) {  // can the slab's half spectrum live i
     int rs = n + 1;
     if (!(rs & 1)) ++rs;  // an odd row stride: the rows' passes and the gather of the output loop spread over the banks
     const size_t lds = (((size_t)ny * rs * P->csize + 15) & ~(size_t)15) + (size_t)(n + ny + n + 1) * P->csize + kFastGWaves * 3 * sizeof(double) +
-                       (((size_t)n * 2 + 3) & ~(size_t)3) + (size_t)ny * 2 + 16;  // the tile + the plan's tables + the wave sums
-    if (lds > 150 * 1024) return false;
+                       (size_t)(ny + d.nx) * P->rsize + (((size_t)n * 2 + 3) & ~(size_t)3) + (size_t)ny * 2 + 16;  // the tile + the plan's tables, the windows + the wave sums
+    if (lds > kLdsMax - 1024) return false;
     bool gx = false, gy = false;
     std::vector<int> rx, ry;
     if (n == 1) rx.clear(); else if (factorize(n, rx, gx) || gx) return false;
@@ -1948,6 +1948,8 @@ static int run_fastg(const xrfthip_plan* P, const void* in, void* out, double* i
     p.detrend = d.detrend;
     p.shift_y = (d.flags & XRFTHIP_SHIFT_Y) ? (int)(d.ny / 2) : 0;
     p.shift_x = (d.flags & XRFTHIP_SHIFT_X) ? (int)(d.nx / 2) : 0;
+    p.half = (d.flags & XRFTHIP_HALF_X) ? 1 : 0;
+    p.realdim2 = (d.flags & XRFTHIP_REALDIM_X2) ? 1 : 0;
     p.scale = d.scale;
     const long long thr = fastg_threads(P);
     const dim3 grid((unsigned)std::min<long long>(d.batch, 0x7fffffffLL)), blk((unsigned)thr);
@@ -2454,8 +2456,10 @@ int xrfthip_plan_create(xrfthip_plan** plan, const xrfthip_desc* desc) {
         }
     }
     {   // a small slab of any smooth shape, either precision, that none of the specialised kernels above takes: one pass in LDS (fastg.h)
-        const uint32_t okg = XRFTHIP_SHIFT_Y | XRFTHIP_SHIFT_X | (d.out_mode == XRFTHIP_OUT_COMPLEX ? (XRFTHIP_ISHIFT_Y | XRFTHIP_ISHIFT_X) : (XRFTHIP_ISO | XRFTHIP_NO_SPECTRUM_OUT));
+        const uint32_t okg = XRFTHIP_SHIFT_Y | XRFTHIP_SHIFT_X | XRFTHIP_HALF_X |
+                             (d.out_mode == XRFTHIP_OUT_COMPLEX ? (XRFTHIP_ISHIFT_Y | XRFTHIP_ISHIFT_X) : (XRFTHIP_ISO | XRFTHIP_NO_SPECTRUM_OUT | XRFTHIP_REALDIM_X2));
         P->fastg = !P->fasts && !P->fast4096 && !P->fastm && (d.out_mode == XRFTHIP_OUT_POWER || d.out_mode == XRFTHIP_OUT_COMPLEX) && !(d.flags & ~okg) &&
+                   !((d.flags & XRFTHIP_HALF_X) && (d.flags & (XRFTHIP_ISO | XRFTHIP_SHIFT_X | XRFTHIP_SHIFT_Y))) &&
                    !env_ll("XRFTHIP_NO_FAST", 0) && env_ll("XRFTHIP_FASTG", 1) != 0 && fastg_try(P);
         if (P->fastg) {
             int rcg = P->dbl ? fastg_setup_t<double>(P) : fastg_setup_t<float>(P);
