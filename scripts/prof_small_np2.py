@@ -17,7 +17,8 @@ def t(fn, reps=5):
 
 shapes = ((14400, 50, 50, torch.float32), (14400, 50, 50, torch.float64), (8192, 96, 96, torch.float32), (4096, 100, 100, torch.float32), (4096, 100, 100, torch.float64),
           (2048, 150, 150, torch.float32), (1024, 192, 192, torch.float32), (2048, 120, 240, torch.float32), (4096, 128, 128, torch.float64), (8192, 64, 64, torch.float64),
-          (4096, 90, 180, torch.float32), (8192, 60, 60, torch.float32), (8192, 80, 80, torch.float64), (1024, 180, 180, torch.float32), (2048, 144, 96, torch.float64))
+          (4096, 90, 180, torch.float32), (8192, 60, 60, torch.float32), (8192, 80, 80, torch.float64), (1024, 180, 180, torch.float32), (2048, 144, 96, torch.float64),
+          (14400, 45, 45, torch.float32), (4096, 75, 75, torch.float32), (4096, 81, 81, torch.float64), (2048, 125, 125, torch.float32))
 for nt, ny, nx, dt in shapes:
     x = torch.randn((nt, ny, nx), dtype=dt, device="cuda")
     da = xrft.DataArray(x, ("t", "y", "x"), {"y": np.arange(float(ny)), "x": np.arange(float(nx))})

@@ -609,7 +609,9 @@ def test_short_axis_round3_lengths(shape, dtype):
 
 
 @pytest.mark.parametrize("shape,dtype,full", [((3, 50, 50), "float32", True), ((2, 50, 50), "float64", True), ((2, 27, 96), "float32", True), ((1, 100, 100), "float64", False),
-                                              ((2, 45, 30), "float64", True), ((1, 96, 96), "float32", False), ((1, 120, 60), "float32", False)])
+                                              ((2, 45, 30), "float64", True), ((1, 96, 96), "float32", False), ((1, 120, 60), "float32", False),
+                                              ((3, 45, 45), "float32", True), ((2, 50, 75), "float64", True), ((2, 27, 81), "float32", True), ((1, 125, 125), "float32", False)])
 def test_small_slabs_of_any_smooth_shape_in_one_pass(shape, dtype, full):
-    """fastg.h: lengths as data (run-time radices), both precisions; (2, 27, 96) is the odd-ny true-phase case the random sweep found."""
+    """fastg.h: lengths as data (run-time radices), both precisions; (2, 27, 96) is the odd-ny true-phase case the random sweep found; an odd nx
+    (45 x 45, 75-sample rows, 125 x 125) runs its rows as complex sequences, the whole spectrum in the tile."""
     cases.run_fastg_cases(shape, dtype, full)

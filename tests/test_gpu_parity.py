@@ -1012,7 +1012,8 @@ def test_nan_poisons_its_own_slab_only():
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("shape,dtype", [((300, 50, 50), "float32"), ((300, 50, 50), "float64"), ((5, 27, 96), "float32"), ((64, 100, 100), "float32"), ((64, 100, 100), "float64"),
-                                         ((7, 45, 30), "float64"), ((33, 96, 96), "float32"), ((9, 120, 60), "float32"), ((3, 128, 128), "float64"), ((5, 80, 160), "float32")])
+                                         ((7, 45, 30), "float64"), ((33, 96, 96), "float32"), ((9, 120, 60), "float32"), ((3, 128, 128), "float64"), ((5, 80, 160), "float32"),
+                                         ((300, 45, 45), "float32"), ((70, 75, 75), "float64"), ((40, 81, 81), "float32"), ((17, 125, 125), "float32"), ((5, 50, 75), "float64")])
 def test_small_slabs_of_any_smooth_shape_in_one_pass(shape, dtype):
     """fastg.h against the oracle: the reference's documented workload (thousands of 50 x 50 boxes) and its neighbours, both precisions."""
     cases.run_fastg_cases(shape, dtype, True)

@@ -31,7 +31,8 @@ struct FastG {
     const void* in;     // [slabs][ny][nx] real T
     void* out;          // [slabs][ny][nx] real T (power) or complex T
     long long nslabs;
-    int ny, nx, n, rs;  // n = nx / 2; rs = LDS row stride in complex elements (>= n + 1)
+    int ny, nx, n, rs;  // n = nx / 2 (packed rows) or nx (an odd nx: the rows as complex sequences, imaginary parts zero); rs = LDS row stride in complex elements (>= n + 1 | nx)
+    int packed;         // nx even: rows packed in pairs of samples, the half spectrum in the tile; else the whole spectrum
     int nrx, nry;
     int rx[kFastGMaxPasses], ry[kFastGMaxPasses];
     const void* tw_x;   // W_n^k,  k < n   (complex T)
@@ -119,6 +120,8 @@ __global__ void __launch_bounds__(fastg_max_threads<T>()) fastg_kernel(FastG p) 
     XRFT_DYN_SMEM(smem_raw);
     CT* tile = reinterpret_cast<CT*>(smem_raw);
     const int tid = threadIdx.x, nthr = blockDim.x, ny = p.ny, nx = p.nx, n = p.n, rs = p.rs;
+    const bool packed = p.packed != 0;
+    const int ncol = packed ? n + 1 : nx;  // columns of the tile after the x transforms
     // behind the tile: the tables of the plan, staged once per workgroup (the passes' twiddles and the digit-reversal look-ups of the unpack and
     // of the output loop sit on every inner loop's critical path: from global memory each was an L2 round trip), and the plane's wave sums
     unsigned char* tb = smem_raw + (((size_t)ny * rs * sizeof(CT) + 15) & ~(size_t)15);
@@ -136,7 +139,7 @@ __global__ void __launch_bounds__(fastg_max_threads<T>()) fastg_kernel(FastG p) 
     }
     for (int k = tid; k < n; k += nthr) { twx[k] = reinterpret_cast<const CT*>(p.tw_x)[k]; revx[k] = (unsigned short)p.rev_x[k]; }
     for (int k = tid; k < ny; k += nthr) { twy[k] = reinterpret_cast<const CT*>(p.tw_y)[k]; revy[k] = (unsigned short)p.rev_y[k]; }
-    for (int k = tid; k <= n; k += nthr) twr[k] = reinterpret_cast<const CT*>(p.tw_r)[k];
+    if (packed) for (int k = tid; k <= n; k += nthr) twr[k] = reinterpret_cast<const CT*>(p.tw_r)[k];
     const float inv_n = 1.0f / (float)n, inv_nx = 1.0f / (float)nx;
     TileGeom g{};
     g.n = n; g.T = ny; g.seq_stride = rs; g.pad_shift = 30;
@@ -147,15 +150,29 @@ __global__ void __launch_bounds__(fastg_max_threads<T>()) fastg_kernel(FastG p) 
         // ---- load; the plane's sums on the way (float64 per thread, then the threads in a fixed order)
         double s0 = 0.0, si = 0.0, sj = 0.0;
         const double ibar = 0.5 * (ny - 1), jbar = 0.5 * (nx - 1);
-        for (int e = tid; e < npk; e += nthr) {
-            const int i = fdiv(e, inv_n), m = e - i * n;
-            const CT z = src[e];
-            tile[i * rs + m] = z;
-            if (p.detrend) {
-                const double u = (double)z.re + (double)z.im;
-                s0 += u;
-                si = fma((double)i - ibar, u, si);
-                sj += ((double)(2 * m) - jbar) * u + (double)z.im;
+        if (packed) {
+            for (int e = tid; e < npk; e += nthr) {
+                const int i = fdiv(e, inv_n), m = e - i * n;
+                const CT z = src[e];
+                tile[i * rs + m] = z;
+                if (p.detrend) {
+                    const double u = (double)z.re + (double)z.im;
+                    s0 += u;
+                    si = fma((double)i - ibar, u, si);
+                    sj += ((double)(2 * m) - jbar) * u + (double)z.im;
+                }
+            }
+        } else {  // (npk = ny nx real samples)
+            const T* __restrict__ srcr = reinterpret_cast<const T*>(src);
+            for (int e = tid; e < npk; e += nthr) {
+                const int i = fdiv(e, inv_n), m = e - i * n;
+                const T v = srcr[e];
+                tile[i * rs + m] = mk<T>(v, (T)0);
+                if (p.detrend) {
+                    s0 += (double)v;
+                    si = fma((double)i - ibar, (double)v, si);
+                    sj = fma((double)m - jbar, (double)v, sj);
+                }
             }
         }
         if (p.detrend || p.win_y) {
@@ -181,11 +198,16 @@ __global__ void __launch_bounds__(fastg_max_threads<T>()) fastg_kernel(FastG p) 
             for (int e = tid; e < npk; e += nthr) {  // (each thread revisits the elements it loaded)
                 const int i = fdiv(e, inv_n), m = e - i * n;
                 CT z = tile[i * rs + m];
-                if (p.detrend) {
-                    const double l = c0 + c1 * ((double)i - ibar) + c2 * ((double)(2 * m) - jbar);
-                    z = mk<T>((T)((double)z.re - l), (T)((double)z.im - (l + c2)));
+                if (packed) {
+                    if (p.detrend) {
+                        const double l = c0 + c1 * ((double)i - ibar) + c2 * ((double)(2 * m) - jbar);
+                        z = mk<T>((T)((double)z.re - l), (T)((double)z.im - (l + c2)));
+                    }
+                    if (wy) { const T w = wy[i]; z = mk<T>(z.re * (w * wx[2 * m]), z.im * (w * wx[2 * m + 1])); }
+                } else {
+                    if (p.detrend) z.re = (T)((double)z.re - (c0 + c1 * ((double)i - ibar) + c2 * ((double)m - jbar)));
+                    if (wy) z.re *= wy[i] * wx[m];
                 }
-                if (wy) { const T w = wy[i]; z = mk<T>(z.re * (w * wx[2 * m]), z.im * (w * wx[2 * m + 1])); }
                 tile[i * rs + m] = z;
             }
         }
@@ -200,7 +222,7 @@ __global__ void __launch_bounds__(fastg_max_threads<T>()) fastg_kernel(FastG p) 
             }
         }
         // ---- unpack the packed rows in place: pairs (k, n - k), k <= n / 2; X[n] goes to column n
-        {
+        if (packed) {
             const int hp = n / 2 + 1, nb = ny * hp;
             const float inv_hp = 1.0f / (float)hp;
             for (int w = tid; w < nb; w += nthr) {
@@ -225,7 +247,7 @@ __global__ void __launch_bounds__(fastg_max_threads<T>()) fastg_kernel(FastG p) 
         {
             int L = ny;
             for (int ps = 0; ps < p.nry; ++ps) {
-                fastg_cols_pass<T>(tile, n + 1, ny, rs, p.ry[ps], L, tid, nthr, twy);
+                fastg_cols_pass<T>(tile, ncol, ny, rs, p.ry[ps], L, tid, nthr, twy);
                 L /= p.ry[ps];
                 __syncthreads();
             }
@@ -251,14 +273,14 @@ __global__ void __launch_bounds__(fastg_max_threads<T>()) fastg_kernel(FastG p) 
             if (p.out == nullptr) continue;
         }
         if (p.half) {  // rows of n + 1 samples, kx = 0 .. n as they lie in the tile: no twin, no shift
-            const int W = n + 1, toth = ny * W;
+            const int W = nx / 2 + 1, toth = ny * W;
             const float inv_w = 1.0f / (float)W;
             for (int e = tid; e < toth; e += nthr) {
                 const int ky = fdiv(e, inv_w), kx = e - ky * W;
-                const CT v = tile[(int)revy[ky] * rs + (kx == n ? n : (int)revx[kx])];
+                const CT v = tile[(int)revy[ky] * rs + ((packed && kx == n) ? n : (int)revx[kx])];
                 if (MODE == 1) {
                     T pw = (v.re * v.re + v.im * v.im) * sc;
-                    if (p.realdim2 && kx != 0 && kx != n) pw *= (T)2;
+                    if (p.realdim2 && kx != 0 && 2 * kx != nx) pw *= (T)2;
                     reinterpret_cast<T*>(p.out)[(size_t)slab * toth + e] = pw;
                 } else {
                     CT o = mk<T>(v.re * sc, v.im * sc);
@@ -272,9 +294,9 @@ __global__ void __launch_bounds__(fastg_max_threads<T>()) fastg_kernel(FastG p) 
             const int orow = fdiv(e, inv_nx), ocol = e - orow * nx;
             int ky = orow - p.shift_y; if (ky < 0) ky += ny;
             int kx = ocol - p.shift_x; if (kx < 0) kx += nx;
-            const bool mir = kx > n;
+            const bool mir = packed && kx > n;
             const int sy = mir ? (ky == 0 ? 0 : ny - ky) : ky, sx = mir ? nx - kx : kx;
-            const CT v = tile[(int)revy[sy] * rs + (sx == n ? n : (int)revx[sx])];
+            const CT v = tile[(int)revy[sy] * rs + ((packed && sx == n) ? n : (int)revx[sx])];
             if (MODE == 1) {
                 const T pw = (v.re * v.re + v.im * v.im) * sc;
                 reinterpret_cast<T*>(p.out)[(size_t)slab * tot + e] = pw;

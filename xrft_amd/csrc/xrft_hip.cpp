@@ -334,7 +334,8 @@ struct xrfthip_plan {
     std::vector<int> g_rx, g_ry;
     DevBuf g_twx, g_twy, g_twr, g_revx, g_revy, g_isopos, g_isostart;
     std::vector<unsigned> g_hrevx, g_hrevy;  // (host copies: the radial-sum lists are built from them when the bin map arrives)
-    int g_rs = 0;
+    int g_rs = 0, g_n = 0;  // LDS row stride; length of the x transforms: nx / 2 (rows packed in pairs of samples) or nx (an odd nx)
+    bool g_packed = true;
     size_t g_lds = 0;
     // ... and ONE pass for a small real float32 slab that fits the registers of a CU: 256 x 256 power spectra (fasts.h)
     bool fasts = false;
@@ -1856,19 +1857,22 @@ static int fastg_rev(const std::vector<int>& radix, int n, DevBuf& buf, std::vec
 }
 template <typename T> static int fastg_setup_t(xrfthip_plan* P) {
     const xrfthip_desc& d = P->d;
-    const int n = (int)(d.nx / 2), ny = (int)d.ny;
+    const int n = P->g_n, ny = (int)d.ny;
     int rc = build_twiddle<T>(P->g_twx, n, n);
     if (!rc) rc = build_twiddle<T>(P->g_twy, ny, ny);
-    if (!rc) rc = build_twiddle<T>(P->g_twr, d.nx, n + 1);
+    if (!rc && P->g_packed) rc = build_twiddle<T>(P->g_twr, d.nx, n + 1);
     if (!rc) rc = fastg_rev(P->g_rx, n, P->g_revx, P->g_hrevx);
     if (!rc) rc = fastg_rev(P->g_ry, ny, P->g_revy, P->g_hrevy);
     return rc;
 }
 static bool fastg_try(xrfthip_plan* P) {  // can the slab's half spectrum live in the LDS of one workgroup, and are both lengths smooth?
     const xrfthip_desc& d = P->d;
-    if (d.ndim != 2 || P->cplx_in || (d.nx & 1) || d.nx < 4 || d.ny < 2 || d.nx > 4096 || d.ny > 4096) return false;
-    const int n = (int)(d.nx / 2), ny = (int)d.ny;
-    int rs = n + 1;
+    if (d.ndim != 2 || P->cplx_in || d.nx < 3 || d.ny < 2 || d.nx > 4096 || d.ny > 4096) return false;
+    // an even nx: the rows packed in pairs of samples, the half spectrum (nx / 2 + 1 columns) in the tile; an odd nx: the rows as complex sequences with
+    // zero imaginary parts, the whole spectrum in the tile (twice the LDS and the x passes' work: 75 x 75, 81 x 81, 125 x 125 boxes)
+    const bool packed = !(d.nx & 1);
+    const int n = packed ? (int)(d.nx / 2) : (int)d.nx, ny = (int)d.ny;
+    int rs = packed ? n + 1 : n;
     if (!(rs & 1)) ++rs;  // an odd row stride: the rows' passes and the gather of the output loop spread over the banks
     const size_t lds = (((size_t)ny * rs * P->csize + 15) & ~(size_t)15) + (size_t)(n + ny + n + 1) * P->csize + kFastGWaves * 3 * sizeof(double) +
                        (size_t)(ny + d.nx) * P->rsize + (((size_t)n * 2 + 3) & ~(size_t)3) + (size_t)ny * 2 + 16;  // the tile + the plan's tables, the windows + the wave sums
@@ -1880,13 +1884,14 @@ static bool fastg_try(xrfthip_plan* P) {  // can the slab's half spectrum live i
     if ((int)rx.size() > kFastGMaxPasses || (int)ry.size() > kFastGMaxPasses) return false;
     for (int r : rx) if (r > 16) return false;
     for (int r : ry) if (r > 16) return false;
-    P->g_rx = rx; P->g_ry = ry; P->g_rs = rs; P->g_lds = lds;
+    P->g_rx = rx; P->g_ry = ry; P->g_rs = rs; P->g_lds = lds; P->g_n = n; P->g_packed = packed;
     return true;
 }
 // fastg radial sums: per bin the LDS positions of its samples, in (ky, kx) order -- any bin map (a sample with kx > nx/2 lives at its Hermitian twin's
 // position: |F|^2 is the same)
 static int fastg_build_iso(xrfthip_plan* P, const int32_t* bm) {
-    const int ny = (int)P->d.ny, nx = (int)P->d.nx, n = nx / 2, rs = P->g_rs, nb = P->nbins;
+    const int ny = (int)P->d.ny, nx = (int)P->d.nx, n = P->g_n, rs = P->g_rs, nb = P->nbins;
+    const bool packed = P->g_packed;
     if ((size_t)ny * rs > 65535u || nb < 1) { P->fastg = false; return XRFTHIP_OK; }  // (16-bit positions; the other paths take the plan)
     std::vector<unsigned> start((size_t)nb + 1, 0u);
     for (size_t e = 0; e < (size_t)ny * nx; ++e) if (bm[e] >= 0 && bm[e] < nb) ++start[(size_t)bm[e] + 1];
@@ -1897,9 +1902,9 @@ static int fastg_build_iso(xrfthip_plan* P, const int32_t* bm) {
         for (int kx = 0; kx < nx; ++kx) {
             const int32_t c = bm[(size_t)ky * nx + kx];
             if (c < 0 || c >= nb) continue;
-            const bool mir = kx > n;
+            const bool mir = packed && kx > n;
             const int sy = mir ? (ky == 0 ? 0 : ny - ky) : ky, sx = mir ? nx - kx : kx;
-            pos[fill[(size_t)c]++] = (uint16_t)(P->g_hrevy[(size_t)sy] * (unsigned)rs + (sx == n ? (unsigned)n : P->g_hrevx[(size_t)sx]));
+            pos[fill[(size_t)c]++] = (uint16_t)(P->g_hrevy[(size_t)sy] * (unsigned)rs + ((packed && sx == n) ? (unsigned)n : P->g_hrevx[(size_t)sx]));
         }
     int rc = P->g_isopos.upload(pos.data(), pos.size() * sizeof(uint16_t));
     if (!rc) rc = P->g_isostart.upload(start.data(), start.size() * sizeof(unsigned));
@@ -1928,7 +1933,7 @@ static int run_fastg(const xrfthip_plan* P, const void* in, void* out, double* i
     const xrfthip_desc& d = P->d;
     FastG p{};
     p.in = in; p.out = out; p.nslabs = d.batch;
-    p.ny = (int)d.ny; p.nx = (int)d.nx; p.n = (int)(d.nx / 2); p.rs = P->g_rs;
+    p.ny = (int)d.ny; p.nx = (int)d.nx; p.n = P->g_n; p.rs = P->g_rs; p.packed = P->g_packed ? 1 : 0;
     p.nrx = (int)P->g_rx.size(); p.nry = (int)P->g_ry.size();
     for (int i = 0; i < p.nrx; ++i) p.rx[i] = P->g_rx[(size_t)i];
     for (int i = 0; i < p.nry; ++i) p.ry[i] = P->g_ry[(size_t)i];
@@ -2616,11 +2621,18 @@ int xrfthip_plan_describe(const xrfthip_plan* plan, char* buf, size_t buflen) {
         std::string rxs, rys;
         for (int r : plan->g_rx) rxs += (rxs.empty() ? "" : "x") + std::to_string(r);
         for (int r : plan->g_ry) rys += (rys.empty() ? "" : "x") + std::to_string(r);
-        appendf(s, "  [fastg] one pass, one %d-thread workgroup per %lld x %lld slab: the half spectrum (%lld rows of %lld + 1 complex) in LDS, radices from the plan "
-                   "(x: %lld = %s on packed rows, y: %lld = %s), exact plane detrend in the workgroup, output gathered in output order through the digit-reversal "
-                   "tables, lds=%zuB\n",
-                (int)fastg_threads(plan), (long long)plan->d.ny, (long long)plan->d.nx, (long long)plan->d.ny, (long long)plan->d.nx / 2, (long long)plan->d.nx / 2,
-                rxs.empty() ? "1" : rxs.c_str(), (long long)plan->d.ny, rys.c_str(), plan->g_lds);
+        if (plan->g_packed)
+            appendf(s, "  [fastg] one pass, one %d-thread workgroup per %lld x %lld slab: the half spectrum (%lld rows of %lld + 1 complex) in LDS, radices from the plan "
+                       "(x: %lld = %s on packed rows, y: %lld = %s), exact plane detrend in the workgroup, output gathered in output order through the digit-reversal "
+                       "tables, lds=%zuB\n",
+                    (int)fastg_threads(plan), (long long)plan->d.ny, (long long)plan->d.nx, (long long)plan->d.ny, (long long)plan->d.nx / 2, (long long)plan->d.nx / 2,
+                    rxs.empty() ? "1" : rxs.c_str(), (long long)plan->d.ny, rys.c_str(), plan->g_lds);
+        else
+            appendf(s, "  [fastg] one pass, one %d-thread workgroup per %lld x %lld slab (an odd row length: the rows as complex sequences): the spectrum (%lld rows of %lld complex) "
+                       "in LDS, radices from the plan (x: %lld = %s, y: %lld = %s), exact plane detrend in the workgroup, output gathered in output order through the "
+                       "digit-reversal tables, lds=%zuB\n",
+                    (int)fastg_threads(plan), (long long)plan->d.ny, (long long)plan->d.nx, (long long)plan->d.ny, (long long)plan->d.nx, (long long)plan->d.nx,
+                    rxs.c_str(), (long long)plan->d.ny, rys.c_str(), plan->g_lds);
         if (plan->d.flags & XRFTHIP_ISO)
             appendf(s, "  [fastg radial sums] in the same pass: per bin the LDS positions of its samples (any bin map), a bin per wave, float64, a fixed shuffle tree -- no atomics%s\n",
                     (plan->d.flags & XRFTHIP_NO_SPECTRUM_OUT) ? "; the spectrum is not stored" : "");
