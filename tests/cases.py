@@ -1101,6 +1101,13 @@ def run_fastg_cases(shape=(3, 50, 50), dtype="float32", full=True):
     for kw in (dict(), dict(true_phase=False), dict(shift=False, true_phase=False, true_amplitude=False), dict(detrend="linear", window="hann")):
         worst = max(worst, check(xa.fft(da, dim=["y", "x"], **kw), o.fft(od, dim=["y", "x"], **kw), tol))
         assert on_fastg()
+    # cross spectrum of two fields (xrft.py:753-835): both tiles in the workgroup's LDS when they fit, F0 conj(F1) on the way out
+    b = (np.roll(a, 2, axis=-1) * 0.5 + _cube(rng, shape, dtype, trend=False) * 0.3).astype(dtype)
+    db, ob = pair(b, D3, _coords3(shape, y0=1.5, x0=-2.0))  # (other origins: a true-phase factor that is not 1)
+    two_fit = 2 * shape[1] * (shape[2] // 2 + 2 if shape[2] % 2 == 0 else shape[2] + 1) * (8 if dtype == "float32" else 16) < 140 * 1024
+    for kw in (dict(), dict(true_phase=False, detrend="linear", window="hann"), dict(shift=False, scaling="spectrum", detrend="constant")):
+        worst = max(worst, check(xa.cross_spectrum(da, db, dim=["y", "x"], **kw), o.cross_spectrum(od, ob, dim=["y", "x"], **kw), tol))
+        assert on_fastg() or not two_fit
     # real_dim: the half spectrum along x, unshifted, the doubled interior columns of a power spectrum (xrft.py:400-404, 673-682)
     for kw in (dict(), dict(detrend="linear", window="hann"), dict(scaling="spectrum", detrend="constant")):
         worst = max(worst, check(xa.power_spectrum(da, dim=["y"], real_dim="x", **kw), o.power_spectrum(od, dim=["y"], real_dim="x", **kw), tol))

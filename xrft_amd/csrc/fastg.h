@@ -29,6 +29,7 @@ template <typename T> constexpr int fastg_max_threads() { return sizeof(T) == 4 
 
 struct FastG {
     const void* in;     // [slabs][ny][nx] real T
+    const void* in_b;   // cross spectrum: the second field (same layout); the result is F(in) conj F(in_b) (xrft.py:825)
     void* out;          // [slabs][ny][nx] real T (power) or complex T
     long long nslabs;
     int ny, nx, n, rs;  // n = nx / 2 (packed rows) or nx (an odd nx: the rows as complex sequences, imaginary parts zero); rs = LDS row stride in complex elements (>= n + 1 | nx)
@@ -113,18 +114,19 @@ __device__ __forceinline__ void fastg_cols_pass(C2<T>* tile, int ncols, int len,
     }
 }
 
-// MODE 1: power spectrum (real T out), 0: complex spectrum
+// MODE 1: power spectrum (real T out), 0: complex spectrum, 2: cross spectrum of two fields (two tiles in LDS, complex out)
 template <typename T, int MODE>
 __global__ void __launch_bounds__(fastg_max_threads<T>()) fastg_kernel(FastG p) {
     typedef C2<T> CT;
     XRFT_DYN_SMEM(smem_raw);
-    CT* tile = reinterpret_cast<CT*>(smem_raw);
+    CT* tile0 = reinterpret_cast<CT*>(smem_raw);
+    constexpr int NF = MODE == 2 ? 2 : 1;  // fields = tiles
     const int tid = threadIdx.x, nthr = blockDim.x, ny = p.ny, nx = p.nx, n = p.n, rs = p.rs;
     const bool packed = p.packed != 0;
     const int ncol = packed ? n + 1 : nx;  // columns of the tile after the x transforms
     // behind the tile: the tables of the plan, staged once per workgroup (the passes' twiddles and the digit-reversal look-ups of the unpack and
     // of the output loop sit on every inner loop's critical path: from global memory each was an L2 round trip), and the plane's wave sums
-    unsigned char* tb = smem_raw + (((size_t)ny * rs * sizeof(CT) + 15) & ~(size_t)15);
+    unsigned char* tb = smem_raw + (((size_t)NF * ny * rs * sizeof(CT) + 15) & ~(size_t)15);
     CT* twx = reinterpret_cast<CT*>(tb); tb += (size_t)n * sizeof(CT);
     CT* twy = reinterpret_cast<CT*>(tb); tb += (size_t)ny * sizeof(CT);
     CT* twr = reinterpret_cast<CT*>(tb); tb += (size_t)(n + 1) * sizeof(CT);
@@ -144,9 +146,12 @@ __global__ void __launch_bounds__(fastg_max_threads<T>()) fastg_kernel(FastG p) 
     TileGeom g{};
     g.n = n; g.T = ny; g.seq_stride = rs; g.pad_shift = 30;
     for (long long slab = blockIdx.x; slab < p.nslabs; slab += gridDim.x) {
-        const CT* __restrict__ src = reinterpret_cast<const CT*>(reinterpret_cast<const T*>(p.in) + (size_t)slab * ny * nx);
-        const int npk = ny * n;  // packed samples
-        __syncthreads();         // (the previous slab's output loop is done with the tile; the tables are in place)
+      const int npk = ny * n;  // packed samples
+      __syncthreads();         // (the previous slab's output loop is done with the tile; the tables are in place)
+#pragma unroll 1
+      for (int f = 0; f < NF; ++f) {  // (a cross spectrum: field 0 into tile 0, field 1 into tile 1, the same code)
+        CT* tile = tile0 + f * (ny * rs);
+        const CT* __restrict__ src = reinterpret_cast<const CT*>(reinterpret_cast<const T*>(f ? p.in_b : p.in) + (size_t)slab * ny * nx);
         // ---- load; the plane's sums on the way (float64 per thread, then the threads in a fixed order)
         double s0 = 0.0, si = 0.0, sj = 0.0;
         const double ibar = 0.5 * (ny - 1), jbar = 0.5 * (nx - 1);
@@ -252,6 +257,11 @@ __global__ void __launch_bounds__(fastg_max_threads<T>()) fastg_kernel(FastG p) 
                 __syncthreads();
             }
         }
+      }
+      {
+        CT* tile = tile0;
+        const CT* tileb = tile0 + ny * rs;  // (MODE 2)
+        (void)tileb;
         // ---- out, in output order: (orow, ocol) <- F[ky][kx], or conj F[-ky][-kx] for kx > n (a real field's spectrum is Hermitian)
         const int tot = ny * nx;
         const T sc = (T)p.scale;
@@ -277,13 +287,16 @@ __global__ void __launch_bounds__(fastg_max_threads<T>()) fastg_kernel(FastG p) 
             const float inv_w = 1.0f / (float)W;
             for (int e = tid; e < toth; e += nthr) {
                 const int ky = fdiv(e, inv_w), kx = e - ky * W;
-                const CT v = tile[(int)revy[ky] * rs + ((packed && kx == n) ? n : (int)revx[kx])];
+                const int ps_ = (int)revy[ky] * rs + ((packed && kx == n) ? n : (int)revx[kx]);
+                CT v = tile[ps_];
+                if (MODE == 2) v = cmulc(v, tileb[ps_]);  // F0 conj(F1)
                 if (MODE == 1) {
                     T pw = (v.re * v.re + v.im * v.im) * sc;
                     if (p.realdim2 && kx != 0 && 2 * kx != nx) pw *= (T)2;
                     reinterpret_cast<T*>(p.out)[(size_t)slab * toth + e] = pw;
                 } else {
                     CT o = mk<T>(v.re * sc, v.im * sc);
+                    if (MODE == 2 && p.realdim2 && kx != 0 && 2 * kx != nx) o = mk<T>(o.re * (T)2, o.im * (T)2);
                     if (p.ph_on) o = cmul(o, cmul(reinterpret_cast<const CT*>(p.ph_y)[ky], reinterpret_cast<const CT*>(p.ph_x)[kx]));
                     reinterpret_cast<CT*>(p.out)[(size_t)slab * toth + e] = o;
                 }
@@ -296,7 +309,9 @@ __global__ void __launch_bounds__(fastg_max_threads<T>()) fastg_kernel(FastG p) 
             int kx = ocol - p.shift_x; if (kx < 0) kx += nx;
             const bool mir = packed && kx > n;
             const int sy = mir ? (ky == 0 ? 0 : ny - ky) : ky, sx = mir ? nx - kx : kx;
-            const CT v = tile[(int)revy[sy] * rs + ((packed && sx == n) ? n : (int)revx[sx])];
+            const int ps_ = (int)revy[sy] * rs + ((packed && sx == n) ? n : (int)revx[sx]);
+            CT v = tile[ps_];
+            if (MODE == 2) v = cmulc(v, tileb[ps_]);  // F0 conj(F1); its Hermitian twin is the conjugate, like a spectrum's
             if (MODE == 1) {
                 const T pw = (v.re * v.re + v.im * v.im) * sc;
                 reinterpret_cast<T*>(p.out)[(size_t)slab * tot + e] = pw;
@@ -306,6 +321,7 @@ __global__ void __launch_bounds__(fastg_max_threads<T>()) fastg_kernel(FastG p) 
                 reinterpret_cast<CT*>(p.out)[(size_t)slab * tot + e] = o;
             }
         }
+      }
     }
 }
 

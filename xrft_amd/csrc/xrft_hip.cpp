@@ -835,6 +835,7 @@ void set_kernel_attrs_once() {
 #undef SETA
 #define SETF(K) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&K), hipFuncAttributeMaxDynamicSharedMemorySize, m)
     SETF((fastg_kernel<float, 0>)); SETF((fastg_kernel<float, 1>)); SETF((fastg_kernel<double, 0>)); SETF((fastg_kernel<double, 1>));
+    SETF((fastg_kernel<float, 2>)); SETF((fastg_kernel<double, 2>));
     SETF((fasts_power_kernel<8, 8, 0, 0>)); SETF((fasts_power_kernel<8, 4, 0, 0>)); SETF((fasts_power_kernel<4, 8, 0, 0>));
     SETF((fasts_power_kernel<8, 8, 0>)); SETF((fasts_power_kernel<8, 8, 1>)); SETF((fasts_power_kernel<8, 8, 2>));  // (above 64 KB of dynamic LDS)
     SETF((fasts_power_kernel<8, 4, 0>)); SETF((fasts_power_kernel<8, 4, 1>)); SETF((fasts_power_kernel<8, 4, 2>));
@@ -1874,7 +1875,8 @@ static bool fastg_try(xrfthip_plan* P) {  // can the slab's half spectrum live i
     const int n = packed ? (int)(d.nx / 2) : (int)d.nx, ny = (int)d.ny;
     int rs = packed ? n + 1 : n;
     if (!(rs & 1)) ++rs;  // an odd row stride: the rows' passes and the gather of the output loop spread over the banks
-    const size_t lds = (((size_t)ny * rs * P->csize + 15) & ~(size_t)15) + (size_t)(n + ny + n + 1) * P->csize + kFastGWaves * 3 * sizeof(double) +
+    const size_t nf = d.out_mode == XRFTHIP_OUT_CROSS ? 2 : 1;  // a cross spectrum holds both fields' tiles
+    const size_t lds = (((size_t)nf * ny * rs * P->csize + 15) & ~(size_t)15) + (size_t)(n + ny + n + 1) * P->csize + kFastGWaves * 3 * sizeof(double) +
                        (size_t)(ny + d.nx) * P->rsize + (((size_t)n * 2 + 3) & ~(size_t)3) + (size_t)ny * 2 + 16;  // the tile + the plan's tables, the windows + the wave sums
     if (lds > kLdsMax - 1024) return false;
     bool gx = false, gy = false;
@@ -1929,10 +1931,10 @@ static long long fastg_threads(const xrfthip_plan* P) {
     return best * 64;
 }
 
-static int run_fastg(const xrfthip_plan* P, const void* in, void* out, double* iso, hipStream_t st) {
+static int run_fastg(const xrfthip_plan* P, const void* in, const void* in_b, void* out, double* iso, hipStream_t st) {
     const xrfthip_desc& d = P->d;
     FastG p{};
-    p.in = in; p.out = out; p.nslabs = d.batch;
+    p.in = in; p.in_b = in_b; p.out = out; p.nslabs = d.batch;
     p.ny = (int)d.ny; p.nx = (int)d.nx; p.n = P->g_n; p.rs = P->g_rs; p.packed = P->g_packed ? 1 : 0;
     p.nrx = (int)P->g_rx.size(); p.nry = (int)P->g_ry.size();
     for (int i = 0; i < p.nrx; ++i) p.rx[i] = P->g_rx[(size_t)i];
@@ -1948,8 +1950,8 @@ static int run_fastg(const xrfthip_plan* P, const void* in, void* out, double* i
     const bool win = P->win[0].p || P->win[1].p;
     p.win_y = win ? (P->win[0].p ? P->win[0].p : P->ones4096.p) : nullptr;
     p.win_x = win ? (P->win[1].p ? P->win[1].p : P->ones4096.p) : nullptr;
-    const bool cplx = d.out_mode == XRFTHIP_OUT_COMPLEX;
-    p.ph_y = P->fph[0].p; p.ph_x = P->fph[1].p; p.ph_on = (cplx && P->fph_on) ? 1 : 0;
+    const bool cplx = d.out_mode == XRFTHIP_OUT_COMPLEX, cross = d.out_mode == XRFTHIP_OUT_CROSS;
+    p.ph_y = P->fph[0].p; p.ph_x = P->fph[1].p; p.ph_on = ((cplx || cross) && P->fph_on) ? 1 : 0;
     p.detrend = d.detrend;
     p.shift_y = (d.flags & XRFTHIP_SHIFT_Y) ? (int)(d.ny / 2) : 0;
     p.shift_x = (d.flags & XRFTHIP_SHIFT_X) ? (int)(d.nx / 2) : 0;
@@ -1960,7 +1962,8 @@ static int run_fastg(const xrfthip_plan* P, const void* in, void* out, double* i
     const dim3 grid((unsigned)std::min<long long>(d.batch, 0x7fffffffLL)), blk((unsigned)thr);
     xrfthip_plan::ProfRec* rec = prof_begin(P, "fastg_slab", st);
 #define GL_(TT, MM) do { auto k = &fastg_kernel<TT, MM>; XRFT_LAUNCH(k, grid, blk, P->g_lds, st, p); } while (0)
-    if (P->dbl) { if (cplx) GL_(double, 0); else GL_(double, 1); } else { if (cplx) GL_(float, 0); else GL_(float, 1); }
+    if (P->dbl) { if (cross) GL_(double, 2); else if (cplx) GL_(double, 0); else GL_(double, 1); }
+    else { if (cross) GL_(float, 2); else if (cplx) GL_(float, 0); else GL_(float, 1); }
 #undef GL_
     prof_end(rec, st);
     HIP_TRY(hipGetLastError());
@@ -2462,8 +2465,10 @@ int xrfthip_plan_create(xrfthip_plan** plan, const xrfthip_desc* desc) {
     }
     {   // a small slab of any smooth shape, either precision, that none of the specialised kernels above takes: one pass in LDS (fastg.h)
         const uint32_t okg = XRFTHIP_SHIFT_Y | XRFTHIP_SHIFT_X | XRFTHIP_HALF_X |
-                             (d.out_mode == XRFTHIP_OUT_COMPLEX ? (XRFTHIP_ISHIFT_Y | XRFTHIP_ISHIFT_X) : (XRFTHIP_ISO | XRFTHIP_NO_SPECTRUM_OUT | XRFTHIP_REALDIM_X2));
-        P->fastg = !P->fasts && !P->fast4096 && !P->fastm && (d.out_mode == XRFTHIP_OUT_POWER || d.out_mode == XRFTHIP_OUT_COMPLEX) && !(d.flags & ~okg) &&
+                             (d.out_mode == XRFTHIP_OUT_COMPLEX ? (XRFTHIP_ISHIFT_Y | XRFTHIP_ISHIFT_X)
+                              : d.out_mode == XRFTHIP_OUT_CROSS ? (XRFTHIP_ISHIFT_Y | XRFTHIP_ISHIFT_X | XRFTHIP_REALDIM_X2)  // (no radial sums, no flipped field: the other paths)
+                              : (XRFTHIP_ISO | XRFTHIP_NO_SPECTRUM_OUT | XRFTHIP_REALDIM_X2));
+        P->fastg = !P->fasts && !P->fast4096 && !P->fastm && (d.out_mode == XRFTHIP_OUT_POWER || d.out_mode == XRFTHIP_OUT_COMPLEX || d.out_mode == XRFTHIP_OUT_CROSS) && !(d.flags & ~okg) &&
                    !((d.flags & XRFTHIP_HALF_X) && (d.flags & (XRFTHIP_ISO | XRFTHIP_SHIFT_X | XRFTHIP_SHIFT_Y))) &&
                    !env_ll("XRFTHIP_NO_FAST", 0) && env_ll("XRFTHIP_FASTG", 1) != 0 && fastg_try(P);
         if (P->fastg) {
@@ -2633,6 +2638,8 @@ int xrfthip_plan_describe(const xrfthip_plan* plan, char* buf, size_t buflen) {
                        "digit-reversal tables, lds=%zuB\n",
                     (int)fastg_threads(plan), (long long)plan->d.ny, (long long)plan->d.nx, (long long)plan->d.ny, (long long)plan->d.nx, (long long)plan->d.nx,
                     rxs.c_str(), (long long)plan->d.ny, rys.c_str(), plan->g_lds);
+        if (plan->d.out_mode == XRFTHIP_OUT_CROSS)
+            appendf(s, "  [fastg cross spectrum] both fields' tiles in the workgroup's LDS, F0 conj(F1) on the way out\n");
         if (plan->d.flags & XRFTHIP_ISO)
             appendf(s, "  [fastg radial sums] in the same pass: per bin the LDS positions of its samples (any bin map), a bin per wave, float64, a fixed shuffle tree -- no atomics%s\n",
                     (plan->d.flags & XRFTHIP_NO_SPECTRUM_OUT) ? "; the spectrum is not stored" : "");
@@ -2710,7 +2717,7 @@ int xrfthip_exec(const xrfthip_plan* plan, const void* d_in0, const void* d_in1,
     double* acc = (double*)(ws + P->off_acc);
     double* coef = (double*)(ws + P->off_coef);
     if (iso) HIP_TRY(hipMemsetAsync(d_iso, 0, (size_t)d.batch * P->nbins * (cross ? 16 : 8), st));
-    if (P->fastg) return run_fastg(P, d_in0, out, (double*)d_iso, st);
+    if (P->fastg) return run_fastg(P, d_in0, d_in1, out, (double*)d_iso, st);
     if (P->fasts) return run_fasts(P, d_in0, out, (double*)d_iso, st);
     if (P->fastr) return run_fastr(P, d_in0, out, st);
     if (P->fastmx) return run_fastmx(P, d_in0, d_in1, out, st);
