@@ -42,10 +42,12 @@ for nt, ny, nx, dt in shapes:
     db = xrft.DataArray(torch.roll(x, 3, dims=2) * 0.5, ("t", "y", "x"), {"y": np.arange(float(ny)), "x": np.arange(float(nx))})
     w5 = t(lambda: xrft.cross_spectrum(da, db, dim=["y", "x"], detrend="linear", window="hann"))
     on5 = any("[fastg cross" in p.describe() for p in api._plan_cache.values())
+    w7 = t(lambda: xrft.isotropic_cross_spectrum(da, db, dim=["y", "x"], detrend="linear", window="hann"))
     os.environ["XRFTHIP_FASTG"] = "0"
     api._plan_cache.clear()
     w4 = t(lambda: xrft.isotropic_power_spectrum(da, dim=["y", "x"], detrend="linear", window="hann"))
     w6 = t(lambda: xrft.cross_spectrum(da, db, dim=["y", "x"], detrend="linear", window="hann"))
+    w8 = t(lambda: xrft.isotropic_cross_spectrum(da, db, dim=["y", "x"], detrend="linear", window="hann"))
     os.environ.pop("XRFTHIP_FASTG", None)
     api._plan_cache.clear()
-    print(line + f" | fft {x.numel()/w2/1e9:6.1f} | isotropic PS {x.numel()/w3/1e9:6.1f} (two-pass {x.numel()/w4/1e9:6.1f}) | cross spectrum{'*' if on5 else ''} {x.numel()/w5/1e9:6.1f} (two-pass {x.numel()/w6/1e9:6.1f}) GFFT/s", flush=True)
+    print(line + f" | fft {x.numel()/w2/1e9:6.1f} | isotropic PS {x.numel()/w3/1e9:6.1f} (two-pass {x.numel()/w4/1e9:6.1f}) | cross spectrum{'*' if on5 else ''} {x.numel()/w5/1e9:6.1f} (two-pass {x.numel()/w6/1e9:6.1f}) | isotropic cross {x.numel()/w7/1e9:6.1f} (two-pass {x.numel()/w8/1e9:6.1f}) GFFT/s", flush=True)

@@ -1120,6 +1120,14 @@ def run_fastg_cases(shape=(3, 50, 50), dtype="float32", full=True):
         xa.api._plan_cache.clear()
         worst = max(worst, check(xa.isotropic_power_spectrum(da, dim=["y", "x"], **kw), o.isotropic_power_spectrum(od, dim=["y", "x"], **kw), max(tol, 1e-9)))
         assert any("[fastg]" in p.describe() and "radial sums" in p.describe() for p in xa.api._plan_cache.values())
+    # ... and of a cross spectrum (complex sums; a sample of the right half plane is the conjugate of the stored product); two fields with different
+    # origins carry a true-phase factor per sample: the other paths, the same numbers
+    dc, oc = pair(b, D3, _coords3(shape, y0=1.0, x0=-3.0))
+    for other, oth_o, fused in ((dc, oc, True), (db, ob, False)):
+        for kw in (dict(detrend="linear", window="hann"), dict(truncate=True)):
+            xa.api._plan_cache.clear()
+            worst = max(worst, check(xa.isotropic_cross_spectrum(da, other, dim=["y", "x"], **kw), o.isotropic_cross_spectrum(od, oth_o, dim=["y", "x"], **kw), max(tol, 1e-9)))
+            assert (not fused) or (not two_fit) or any("[fastg cross" in p.describe() and "radial sums" in p.describe() for p in xa.api._plan_cache.values())
     import torch
 
     from xrft_amd import _lib, engine
@@ -1129,6 +1137,19 @@ def run_fastg_cases(shape=(3, 50, 50), dtype="float32", full=True):
     tdt = torch.float64 if dtype == "float64" else torch.float32
     t = xa.api._to_device(np.ascontiguousarray(a))
     anymap = rng.integers(-1, nb, size=(ny, nx)).astype(np.int32)
+    if two_fit:  # the C ABI's plan: complex sums of any bin map against numpy.bincount of the stored cross spectrum
+        t2 = xa.api._to_device(np.ascontiguousarray(b))
+        plan = engine.SpectralPlan(2, nt, ny, nx, tdt, out_mode=_lib.OUT_CROSS, flags=_lib.ISO, scale=0.5, binmap=anymap, nbins=nb)
+        assert "[fastg cross" in plan.describe()
+        out, iso = plan.execute(t, t2)
+        assert torch.equal(iso, plan.execute(t, t2)[1])
+        spec = out.cpu().numpy().astype(np.complex128)
+        ok = anymap.ravel() >= 0
+        for bb in range(nt):
+            w = spec[bb].ravel()[ok]
+            ref = np.bincount(anymap.ravel()[ok], weights=w.real, minlength=nb) + 1j * np.bincount(anymap.ravel()[ok], weights=w.imag, minlength=nb)
+            mag = np.bincount(anymap.ravel()[ok], weights=np.abs(w), minlength=nb)
+            assert np.all(np.abs(iso.cpu().numpy()[bb] - ref) <= (1e-13 if dtype == "float64" else 2e-6) * np.maximum(mag, 1e-300))
     for flags in (_lib.ISO, _lib.ISO | _lib.NO_SPECTRUM_OUT):
         plan = engine.SpectralPlan(2, nt, ny, nx, tdt, out_mode=_lib.OUT_POWER, flags=flags, scale=0.5, binmap=anymap, nbins=nb)
         assert "[fastg]" in plan.describe()

@@ -193,15 +193,21 @@ def run_random_small_slab(seed, max_points=19000):
          "x": np.arange(nx) * float(rng.choice([0.25, 1.0])) - float(rng.choice([0.0, 3.0]))}
     da, od = cases.pair(v, ("t", "y", "x"), c)
     kw = dict(detrend=rng.choice([None, "constant", "linear"]), window=rng.choice([None, "hann", "hamming"]))
-    kind = str(rng.choice(["ps", "ps", "fft", "iso", "ps_real", "fft_real", "cs"]))
+    kind = str(rng.choice(["ps", "ps", "fft", "iso", "ps_real", "fft_real", "cs", "isocs"]))
     shift = bool(rng.random() < 0.7)
     tp = bool(rng.random() < 0.5)
     api._plan_cache.clear()
-    if kind == "cs":
+    if kind in ("cs", "isocs"):
         w = (np.roll(v, 1, axis=-1) * 0.5 + 0.1 + 0.2 * rng.standard_normal(v.shape)).astype(dtype)
-        c2 = dict(c, x=c["x"] + float(rng.choice([0.0, 1.0])))
+        c2 = dict(c, x=c["x"] + float(rng.choice([0.0, 0.0, 1.0])))
         db, ob = cases.pair(w, ("t", "y", "x"), c2)
-        got, ref = xa.cross_spectrum(da, db, dim=["y", "x"], shift=shift, true_phase=tp, **kw), o.cross_spectrum(od, ob, dim=["y", "x"], shift=shift, true_phase=tp, **kw)
+        if kind == "cs":
+            got, ref = xa.cross_spectrum(da, db, dim=["y", "x"], shift=shift, true_phase=tp, **kw), o.cross_spectrum(od, ob, dim=["y", "x"], shift=shift, true_phase=tp, **kw)
+        else:
+            if min(ny, nx) < 8:
+                kw["nfactor"] = 1
+            tr = bool(rng.random() < 0.5)
+            got, ref = xa.isotropic_cross_spectrum(da, db, dim=["y", "x"], truncate=tr, **kw), o.isotropic_cross_spectrum(od, ob, dim=["y", "x"], truncate=tr, **kw)
         cases.check(got, ref, max(cases.TOL[dtype], 1e-9))
         return next((t for t in ("[fastg]", "[fasts]", "[fastm]", "[main]") if any(t in p.describe() for p in api._plan_cache.values())), None)
     if kind == "ps":

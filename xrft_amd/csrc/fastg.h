@@ -265,20 +265,31 @@ __global__ void __launch_bounds__(fastg_max_threads<T>()) fastg_kernel(FastG p) 
         // ---- out, in output order: (orow, ocol) <- F[ky][kx], or conj F[-ky][-kx] for kx > n (a real field's spectrum is Hermitian)
         const int tot = ny * nx;
         const T sc = (T)p.scale;
-        if (MODE == 1 && p.iso != nullptr) {
+        if (MODE != 0 && p.iso != nullptr) {
             // a bin per wave: lane l adds the samples l, l + 64, ... of the bin's list in float64, the lanes meet in a fixed shuffle tree -- no
-            // atomics, the same bits every time; a nan / inf stays in its bin
+            // atomics, the same bits every time; a nan / inf stays in its bin.  A cross spectrum's sums are complex; bit 15 of a position: the sample
+            // is the Hermitian twin of the stored one (the conjugate)
             const int lane = tid & 63, nw = nthr >> 6;
             for (int b = tid >> 6; b < p.nbins; b += nw) {
                 const unsigned q0 = p.iso_start[b], q1 = p.iso_start[b + 1];
-                double acc = 0.0;
+                double acc = 0.0, aci = 0.0;
                 for (unsigned q = q0 + (unsigned)lane; q < q1; q += 64u) {
-                    const CT v = tile[p.iso_pos[q]];
-                    acc += (double)((v.re * v.re + v.im * v.im) * sc);
+                    const unsigned pq = p.iso_pos[q];
+                    if (MODE == 2) {
+                        const CT v = cmulc(tile[pq & 0x7fffu], tileb[pq & 0x7fffu]);
+                        acc += (double)(v.re * sc);
+                        aci += (double)(((pq & 0x8000u) ? -v.im : v.im) * sc);
+                    } else {
+                        const CT v = tile[pq];
+                        acc += (double)((v.re * v.re + v.im * v.im) * sc);
+                    }
                 }
 #pragma unroll
-                for (int m = 1; m < 64; m <<= 1) acc += __shfl_xor(acc, m);
-                if (lane == 0) p.iso[(size_t)slab * p.nbins + b] = acc;
+                for (int m = 1; m < 64; m <<= 1) { acc += __shfl_xor(acc, m); if (MODE == 2) aci += __shfl_xor(aci, m); }
+                if (lane == 0) {
+                    if (MODE == 2) { p.iso[((size_t)slab * p.nbins + b) * 2] = acc; p.iso[((size_t)slab * p.nbins + b) * 2 + 1] = aci; }
+                    else p.iso[(size_t)slab * p.nbins + b] = acc;
+                }
             }
             if (p.out == nullptr) continue;
         }

@@ -1894,7 +1894,8 @@ static bool fastg_try(xrfthip_plan* P) {  // can the slab's half spectrum live i
 static int fastg_build_iso(xrfthip_plan* P, const int32_t* bm) {
     const int ny = (int)P->d.ny, nx = (int)P->d.nx, n = P->g_n, rs = P->g_rs, nb = P->nbins;
     const bool packed = P->g_packed;
-    if ((size_t)ny * rs > 65535u || nb < 1) { P->fastg = false; return XRFTHIP_OK; }  // (16-bit positions; the other paths take the plan)
+    const bool cross = P->d.out_mode == XRFTHIP_OUT_CROSS;  // (bit 15 of a position: the sample is the conjugate of the stored product)
+    if ((size_t)ny * rs > (cross ? 32767u : 65535u) || nb < 1) { P->fastg = false; return XRFTHIP_OK; }  // (16-bit positions; the other paths take the plan)
     std::vector<unsigned> start((size_t)nb + 1, 0u);
     for (size_t e = 0; e < (size_t)ny * nx; ++e) if (bm[e] >= 0 && bm[e] < nb) ++start[(size_t)bm[e] + 1];
     for (int b = 0; b < nb; ++b) start[(size_t)b + 1] += start[(size_t)b];
@@ -1906,7 +1907,7 @@ static int fastg_build_iso(xrfthip_plan* P, const int32_t* bm) {
             if (c < 0 || c >= nb) continue;
             const bool mir = packed && kx > n;
             const int sy = mir ? (ky == 0 ? 0 : ny - ky) : ky, sx = mir ? nx - kx : kx;
-            pos[fill[(size_t)c]++] = (uint16_t)(P->g_hrevy[(size_t)sy] * (unsigned)rs + ((packed && sx == n) ? (unsigned)n : P->g_hrevx[(size_t)sx]));
+            pos[fill[(size_t)c]++] = (uint16_t)((P->g_hrevy[(size_t)sy] * (unsigned)rs + ((packed && sx == n) ? (unsigned)n : P->g_hrevx[(size_t)sx])) | ((cross && mir) ? 0x8000u : 0u));
         }
     int rc = P->g_isopos.upload(pos.data(), pos.size() * sizeof(uint16_t));
     if (!rc) rc = P->g_isostart.upload(start.data(), start.size() * sizeof(unsigned));
@@ -2098,6 +2099,8 @@ static int run_fastr(const xrfthip_plan* P, const void* in, void* out, hipStream
 // set: window spectra and phase tables of the specialised paths (device allocations + blocking copies) and the workspace
 // layout.  xrfthip_exec itself takes the plan as const: no allocation, no copy, no synchronisation, no getenv.
 static int finalize_plan(xrfthip_plan* P) {
+    // the radial sums of a cross spectrum with a true-phase factor that is not 1 (two fields with different lags) need the factor per sample: the other paths
+    if (P->fastg && P->d.out_mode == XRFTHIP_OUT_CROSS && (P->d.flags & XRFTHIP_ISO) && phase_nontrivial(P)) P->fastg = false;
     if (P->fastg) {
         if (P->d.out_mode != XRFTHIP_OUT_POWER) { const int rc = fast_phase_tables(P); if (rc) return rc; }
     } else if (P->fasts) {
@@ -2466,7 +2469,7 @@ int xrfthip_plan_create(xrfthip_plan** plan, const xrfthip_desc* desc) {
     {   // a small slab of any smooth shape, either precision, that none of the specialised kernels above takes: one pass in LDS (fastg.h)
         const uint32_t okg = XRFTHIP_SHIFT_Y | XRFTHIP_SHIFT_X | XRFTHIP_HALF_X |
                              (d.out_mode == XRFTHIP_OUT_COMPLEX ? (XRFTHIP_ISHIFT_Y | XRFTHIP_ISHIFT_X)
-                              : d.out_mode == XRFTHIP_OUT_CROSS ? (XRFTHIP_ISHIFT_Y | XRFTHIP_ISHIFT_X | XRFTHIP_REALDIM_X2)  // (no radial sums, no flipped field: the other paths)
+                              : d.out_mode == XRFTHIP_OUT_CROSS ? (XRFTHIP_ISHIFT_Y | XRFTHIP_ISHIFT_X | XRFTHIP_REALDIM_X2 | XRFTHIP_ISO | XRFTHIP_NO_SPECTRUM_OUT)  // (no flipped field: the other paths)
                               : (XRFTHIP_ISO | XRFTHIP_NO_SPECTRUM_OUT | XRFTHIP_REALDIM_X2));
         P->fastg = !P->fasts && !P->fast4096 && !P->fastm && (d.out_mode == XRFTHIP_OUT_POWER || d.out_mode == XRFTHIP_OUT_COMPLEX || d.out_mode == XRFTHIP_OUT_CROSS) && !(d.flags & ~okg) &&
                    !((d.flags & XRFTHIP_HALF_X) && (d.flags & (XRFTHIP_ISO | XRFTHIP_SHIFT_X | XRFTHIP_SHIFT_Y))) &&
