@@ -772,6 +772,37 @@ def check_values(got, ref, tol):
     return err
 
 
+def run_yonly_any_length_cases(shape=(3, 96, 40), dtype="float32"):
+    """One transform axis that is not the contiguous one on ANY smooth length (the reference's `dim="time"` calls on lengths outside fastm.h's table:
+    48, 96, 120, 150, 250, 1250, odd lengths): csrc/fastg.h fastgy_kernel (run-time radices, two real columns per complex sequence) against the oracle --
+    fft (true phase on an offset coordinate, also ifftshifted), power spectrum, every per-column detrend, window, shift; a column count that does not fill
+    the last workgroup; the first axis of a 3-D array."""
+    rng = np.random.default_rng(67)
+    tol = TOL[dtype]
+    a = _cube(rng, shape, dtype)
+    da, od = pair(a, D3, _coords3(shape, y0=2.5, x0=-1.0))
+    od_det = od if dtype == "float64" else o.OArr(a.astype("float64"), D3, _coords3(shape, y0=2.5, x0=-1.0))  # (as run_yonly_fast_cases)
+    worst = 0.0
+
+    def on_fast():
+        return "[fastg y-only]" in next(reversed(xa.api._plan_cache.values())).describe()
+
+    for kw in (dict(), dict(detrend="linear", window="hann"), dict(detrend="constant", shift=False), dict(true_phase=False, true_amplitude=False, window="hamming")):
+        worst = max(worst, check_values(xa.fft(da, dim=["y"], **kw), o.fft(od_det if "detrend" in kw else od, dim=["y"], **kw), tol))
+        assert on_fast(), kw
+    for kw in (dict(detrend="linear", window="hann"), dict(shift=False, scaling="spectrum", detrend="constant"), dict()):
+        worst = max(worst, check_values(xa.power_spectrum(da, dim=["y"], **kw), o.power_spectrum(od_det if "detrend" in kw else od, dim=["y"], **kw), tol))
+        assert on_fast(), kw
+    # the same samples with the transform axis FIRST, (time, y, x): columns = y x
+    at = np.ascontiguousarray(a.transpose(1, 0, 2))
+    ct = {"time": np.arange(shape[1]) * 0.5 + 2.5, "y": np.arange(shape[0]) * 1.0, "x": np.arange(shape[2]) * 2.0}
+    dt_, ot_ = pair(at, D3, ct)
+    ot_det = ot_ if dtype == "float64" else o.OArr(at.astype("float64"), D3, ct)
+    worst = max(worst, check_values(xa.power_spectrum(dt_, dim=["time"], detrend="linear", window="hann"), o.power_spectrum(ot_det, dim=["time"], detrend="linear", window="hann"), tol))
+    assert on_fast()
+    return worst
+
+
 def run_yonly_fast_cases(shape=(3, 360, 40), dtype="float64"):
     """One transform axis that is not the contiguous one (spectra along "time" of a (batch, time, space) array), lengths of the
     fastm table: csrc/fastm.h fastm_yonly_kernel against the oracle -- fft (true phase on an offset, also ifftshifted,

@@ -615,3 +615,10 @@ def test_small_slabs_of_any_smooth_shape_in_one_pass(shape, dtype, full):
     """fastg.h: lengths as data (run-time radices), both precisions; (2, 27, 96) is the odd-ny true-phase case the random sweep found; an odd nx
     (45 x 45, 75-sample rows, 125 x 125) runs its rows as complex sequences, the whole spectrum in the tile."""
     cases.run_fastg_cases(shape, dtype, full)
+
+
+@pytest.mark.parametrize("shape,dtype", [((3, 96, 40), "float32"), ((2, 250, 36), "float64"), ((2, 45, 22), "float32"), ((1, 1250, 8), "float32"), ((2, 120, 50), "float64"),
+                                         ((30, 48, 6), "float32"), ((2, 27, 130), "float64"), ((4, 150, 2), "float32")])
+def test_one_axis_not_contiguous_any_smooth_length(shape, dtype):
+    """fastg.h, fastgy_kernel: `dim="time"` calls on lengths outside the mixed-radix table."""
+    cases.run_yonly_any_length_cases(shape, dtype)

@@ -336,4 +336,127 @@ __global__ void __launch_bounds__(fastg_max_threads<T>()) fastg_kernel(FastG p) 
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------------------------------
+// ONE transform axis that is NOT the contiguous one -- xrft.fft / power_spectrum along "time" of a (time, y, x) array, the reference's most
+// common call (xrft.py:395-409) -- on ANY smooth length, lengths as data: XRFTHIP_AXIS_Y, [batch][ny][nx] real T, y transformed where it lies.
+// (The lengths of fastm.h's table have fastm_yonly_kernel; every other one took the generic column tiles at 0.3-0.5 TB/s.)
+//
+// A workgroup owns C = 2 G adjacent real columns of one batch element: columns 2g, 2g + 1 are the real and imaginary part of sequence g, the tile is
+// [ny][G] complex with the lanes along g (every load, LDS access and store of a wave is contiguous).  Per-column mean / least-squares line
+// (xrft/detrend.py:54-71) from float64 sums -- row groups of threads, partial sums in LDS, added in group order -- subtracted and the window multiplied
+// in place; the radix passes along y with the radices of the parameter block; the two columns' spectra A[k] = (Z[k] + conj Z[-k]) / 2,
+// B[k] = (Z[k] - conj Z[-k]) / 2i are split on the way out, every output row whole: |F|^2 scale or F scale x the true-phase factor, fftshift as a
+// rotation of the rows.
+struct FastGY {
+    const void* in;    // [batch][ny][nx] real T
+    void* out;         // [batch][ny][nx] real T (power) or complex T
+    long long nunits;  // batch x column blocks
+    int ny, nx, nblk;  // nblk = ceil(nx / (2 G))
+    int G, lg;         // complex sequences per workgroup (a power of two), its log2
+    int nry, ry[kFastGMaxPasses];
+    const void* tw_y;  // W_ny^k (complex T)
+    const unsigned* rev_y;
+    const void* win_y; // T, or null
+    const void* ph_y;  // complex mode: combined phase factors by unshifted frequency (complex T)
+    int ph_on, detrend, shift_y;
+    double scale;
+};
+
+// MODE 1: power spectrum (real T out), 0: complex spectrum
+template <typename T, int MODE>
+__global__ void __launch_bounds__(256) fastgy_kernel(FastGY p) {
+    typedef C2<T> CT;
+    XRFT_DYN_SMEM(smem_raw);
+    CT* tile = reinterpret_cast<CT*>(smem_raw);
+    const int tid = threadIdx.x, nthr = blockDim.x, ny = p.ny, nx = p.nx, G = p.G, lg = p.lg, C = 2 * G;
+    unsigned char* tb = smem_raw + (((size_t)ny * G * sizeof(CT) + 15) & ~(size_t)15);
+    CT* twy = reinterpret_cast<CT*>(tb); tb += (size_t)ny * sizeof(CT);
+    double* part = reinterpret_cast<double*>(tb); tb += (size_t)nthr * 4 * sizeof(double);  // [row group][g][4]
+    double* coef = reinterpret_cast<double*>(tb); tb += (size_t)G * 4 * sizeof(double);     // [g][mean re, slope re, mean im, slope im]
+    T* wys = reinterpret_cast<T*>(tb); tb += (size_t)ny * sizeof(T);
+    unsigned short* revy = reinterpret_cast<unsigned short*>(tb);
+    for (int k = tid; k < ny; k += nthr) {
+        twy[k] = reinterpret_cast<const CT*>(p.tw_y)[k];
+        revy[k] = (unsigned short)p.rev_y[k];
+        if (p.win_y) wys[k] = reinterpret_cast<const T*>(p.win_y)[k];
+    }
+    const int g = tid & (G - 1), rq = tid >> lg, RQ = nthr >> lg;  // (lane along the sequences, row group)
+    const T sc = (T)p.scale;
+    const double ibar = 0.5 * (ny - 1);
+    for (long long unit = blockIdx.x; unit < p.nunits; unit += gridDim.x) {
+        const long long b = unit / p.nblk;
+        const int c0 = (int)(unit - b * p.nblk) * C;
+        const bool live = c0 + 2 * g < nx;  // (nx is even: a pair of columns is whole or absent)
+        const T* __restrict__ src = reinterpret_cast<const T*>(p.in) + (size_t)b * ny * nx + c0 + 2 * g;
+        __syncthreads();  // (the previous unit's output loop is done with the tile; the tables are in place)
+        // ---- load (rows rq, rq + RQ, ... of sequence g); without a detrend the window rides along
+        double s[4] = {0.0, 0.0, 0.0, 0.0};
+        for (int i = rq; i < ny; i += RQ) {
+            CT z = live ? *reinterpret_cast<const CT*>(src + (size_t)i * nx) : mk<T>((T)0, (T)0);
+            if (p.detrend) {
+                const double ri = (double)i - ibar;
+                s[0] += (double)z.re; s[2] += (double)z.im;
+                s[1] = fma(ri, (double)z.re, s[1]); s[3] = fma(ri, (double)z.im, s[3]);
+            } else if (p.win_y) {
+                const T w = reinterpret_cast<const T*>(p.win_y)[i];
+                z = mk<T>(z.re * w, z.im * w);
+            }
+            tile[i * G + g] = z;
+        }
+        if (p.detrend) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) part[(rq * G + g) * 4 + c] = s[c];
+            __syncthreads();
+            if (tid < G) {  // the row groups' sums in group order; mean and slope of the two columns of sequence tid
+                double a[4] = {0.0, 0.0, 0.0, 0.0};
+                for (int r = 0; r < RQ; ++r)
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) a[c] += part[(r * G + tid) * 4 + c];
+                const double sii = (double)ny * ((double)ny * (double)ny - 1.0) / 12.0;
+                const bool lin = p.detrend == 2 && ny > 1;
+                coef[tid * 4 + 0] = a[0] / (double)ny; coef[tid * 4 + 1] = lin ? a[1] / sii : 0.0;
+                coef[tid * 4 + 2] = a[2] / (double)ny; coef[tid * 4 + 3] = lin ? a[3] / sii : 0.0;
+            }
+            __syncthreads();
+            const double m0 = coef[g * 4], b0 = coef[g * 4 + 1], m1 = coef[g * 4 + 2], b1 = coef[g * 4 + 3];
+            for (int i = rq; i < ny; i += RQ) {  // (each thread revisits the elements it loaded)
+                CT z = tile[i * G + g];
+                const double ri = (double)i - ibar;
+                z = mk<T>((T)((double)z.re - fma(b0, ri, m0)), (T)((double)z.im - fma(b1, ri, m1)));
+                if (p.win_y) { const T w = wys[i]; z = mk<T>(z.re * w, z.im * w); }
+                tile[i * G + g] = z;
+            }
+        }
+        __syncthreads();
+        // ---- the passes of length ny over the G sequences (lanes along the sequences)
+        {
+            int L = ny;
+            for (int ps = 0; ps < p.nry; ++ps) {
+                fastg_cols_pass<T>(tile, G, ny, G, p.ry[ps], L, tid, nthr, twy);
+                L /= p.ry[ps];
+                __syncthreads();
+            }
+        }
+        // ---- out: row orow of the C columns = frequency k of the two spectra packed in every sequence
+        const int tot = ny << (lg + 1);
+        for (int e = tid; e < tot; e += nthr) {
+            const int orow = e >> (lg + 1), c = e & (C - 1), col = c0 + c;
+            if (col >= nx) continue;
+            int k = orow - p.shift_y; if (k < 0) k += ny;
+            const int km = k == 0 ? 0 : ny - k;
+            const CT zk = tile[(int)revy[k] * G + (c >> 1)], zm = tile[(int)revy[km] * G + (c >> 1)];
+            const CT v = (c & 1) ? mk<T>((T)0.5 * (zk.im + zm.im), (T)0.5 * (zm.re - zk.re))   // (Zk - conj Zm) / 2i
+                                 : mk<T>((T)0.5 * (zk.re + zm.re), (T)0.5 * (zk.im - zm.im));  // (Zk + conj Zm) / 2
+            const size_t o = ((size_t)b * ny + orow) * nx + col;
+            if (MODE == 1) {
+                reinterpret_cast<T*>(p.out)[o] = (v.re * v.re + v.im * v.im) * sc;
+            } else {
+                CT w = mk<T>(v.re * sc, v.im * sc);
+                if (p.ph_on) w = cmul(w, reinterpret_cast<const CT*>(p.ph_y)[k]);
+                reinterpret_cast<CT*>(p.out)[o] = w;
+            }
+        }
+    }
+}
+
 }  // namespace xrft

@@ -206,7 +206,10 @@ long long lds_fft_len(long long n, size_t csize) {
     }
     if (!ok) return m;
     const size_t per = (size_t)(m + m / 16 + 2) * csize;
-    return 4 * per <= kLdsMax ? m : n;
+    // (a factor above 13 through the O(r^2) butterfly is hopeless -- 1460 = 2 x 2 x 5 x 73 daily samples of four years, float64: 1.0 GFFT/s along the time axis --:
+    // Bluestein even when only one or two sequences of m points fit the tile)
+    const size_t seqs = r[0] > 13 ? 1 : 4;
+    return seqs * per + 4096 <= kLdsMax ? m : n;
 }
 
 // host-side radix-2 FFT (float64) for the two 4096-point window spectra the fused detrend needs
@@ -336,6 +339,10 @@ struct xrfthip_plan {
     std::vector<unsigned> g_hrevx, g_hrevy;  // (host copies: the radial-sum lists are built from them when the bin map arrives)
     int g_rs = 0, g_n = 0;  // LDS row stride; length of the x transforms: nx / 2 (rows packed in pairs of samples) or nx (an odd nx)
     bool g_packed = true;
+    // ... and ONE pass for one transform axis that is not the contiguous one (XRFTHIP_AXIS_Y), any smooth length, real input (fastg.h: fastgy_kernel)
+    bool fastgy = false;
+    int gy_G = 0, gy_thr = 0;
+    size_t gy_lds = 0;
     size_t g_lds = 0;
     // ... and ONE pass for a small real float32 slab that fits the registers of a CU: 256 x 256 power spectra (fasts.h)
     bool fasts = false;
@@ -836,6 +843,7 @@ void set_kernel_attrs_once() {
 #define SETF(K) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&K), hipFuncAttributeMaxDynamicSharedMemorySize, m)
     SETF((fastg_kernel<float, 0>)); SETF((fastg_kernel<float, 1>)); SETF((fastg_kernel<double, 0>)); SETF((fastg_kernel<double, 1>));
     SETF((fastg_kernel<float, 2>)); SETF((fastg_kernel<double, 2>));
+    SETF((fastgy_kernel<float, 0>)); SETF((fastgy_kernel<float, 1>)); SETF((fastgy_kernel<double, 0>)); SETF((fastgy_kernel<double, 1>));
     SETF((fasts_power_kernel<8, 8, 0, 0>)); SETF((fasts_power_kernel<8, 4, 0, 0>)); SETF((fasts_power_kernel<4, 8, 0, 0>));
     SETF((fasts_power_kernel<8, 8, 0>)); SETF((fasts_power_kernel<8, 8, 1>)); SETF((fasts_power_kernel<8, 8, 2>));  // (above 64 KB of dynamic LDS)
     SETF((fasts_power_kernel<8, 4, 0>)); SETF((fasts_power_kernel<8, 4, 1>)); SETF((fasts_power_kernel<8, 4, 2>));
@@ -959,7 +967,7 @@ static int run_radial_sums(int32_t dtype, const void* spec, const int32_t* d_bin
 
 static void layout_workspace(xrfthip_plan* P) {
     const xrfthip_desc& d = P->d;
-    if (P->fastr || P->fasts || P->fastg) { P->G = (int)std::max<long long>(1, std::min<long long>(d.batch, 1 << 30)); P->ws_bytes = 0; return; }  // one pass, registers + LDS: no intermediate
+    if (P->fastr || P->fasts || P->fastg || P->fastgy) { P->G = (int)std::max<long long>(1, std::min<long long>(d.batch, 1 << 30)); P->ws_bytes = 0; return; }  // one pass, registers + LDS: no intermediate
     const bool fast = fast_on(P);
     long long G = d.slabs_per_group > 0 ? d.slabs_per_group : P->tune_group;
     size_t slab_w = (size_t)d.ny * std::max(P->width, P->w_cols) * P->csize;
@@ -1078,7 +1086,7 @@ static int fast_phase_tables(xrfthip_plan* P) {
         const long long n = ax == 0 ? d.ny : d.nx;
         const bool sign = d.out_mode == XRFTHIP_OUT_COMPLEX && (d.flags & (ax == 0 ? XRFTHIP_ISHIFT_Y : XRFTHIP_ISHIFT_X));
         std::vector<cf> t((size_t)n);
-        const bool dtab = (P->fastm || P->fastmy || P->fastmx || P->fastg) && P->dbl;
+        const bool dtab = (P->fastm || P->fastmy || P->fastmx || P->fastg || P->fastgy) && P->dbl;
         std::vector<C2<double>> td(dtab ? (size_t)n : 0);
         for (long long k = 0; k < n; ++k) {
             double re = 1.0, im = 0.0;
@@ -1914,6 +1922,56 @@ static int fastg_build_iso(xrfthip_plan* P, const int32_t* bm) {
     return rc;
 }
 
+// one transform axis that is not the contiguous one, any smooth length (fastg.h: fastgy_kernel): G complex sequences = 2 G real columns per workgroup,
+// the widest power of two (<= 128 bytes of a row) whose tile leaves three workgroups on a CU, or the widest that fits at all
+static bool fastgy_try(xrfthip_plan* P) {
+    const xrfthip_desc& d = P->d;
+    if (d.ndim != 2 || P->cplx_in || (d.nx & 1) || d.ny < 2 || d.ny > 4096 || d.batch * ((d.nx + 3) / 4) >= (1LL << 31)) return false;
+    bool gy = false;
+    std::vector<int> ry;
+    if (factorize(d.ny, ry, gy) || gy || (int)ry.size() > kFastGMaxPasses) return false;
+    for (int r : ry) if (r > 16) return false;
+    const int thr = 256;
+    auto lds_of = [&](int G) {
+        return (((size_t)d.ny * G * P->csize + 15) & ~(size_t)15) + (size_t)d.ny * P->csize + (size_t)thr * 4 * sizeof(double) + (size_t)G * 4 * sizeof(double) +
+               (size_t)d.ny * P->rsize + (size_t)d.ny * 2 + 16;
+    };
+    const int gmax = (int)(128 / P->csize);  // 128 bytes of a row: 16 float32 pairs, 8 float64 pairs
+    int G = 0;
+    for (int cand = gmax; cand >= gmax / 4 && cand >= 1 && !G; cand >>= 1) if (lds_of(cand) <= 78 * 1024) G = cand;   // two or more workgroups per CU, 32 bytes of a row at least
+    for (int cand = gmax; cand >= 1 && !G; cand >>= 1) if (lds_of(cand) <= kLdsMax - 1024) G = cand;                  // ... or whatever fits
+    const long long forced = env_ll("XRFTHIP_FASTGY_G", 0);
+    if (forced >= 1 && forced <= gmax && !(forced & (forced - 1)) && lds_of((int)forced) <= kLdsMax - 1024) G = (int)forced;
+    if (!G) return false;
+    P->g_ry = ry; P->gy_G = G; P->gy_thr = thr; P->gy_lds = lds_of(G);
+    return true;
+}
+static int run_fastgy(const xrfthip_plan* P, const void* in, void* out, hipStream_t st) {
+    const xrfthip_desc& d = P->d;
+    FastGY p{};
+    p.in = in; p.out = out;
+    p.ny = (int)d.ny; p.nx = (int)d.nx; p.G = P->gy_G; p.lg = ilog2i(P->gy_G);
+    p.nblk = (int)((d.nx + 2 * P->gy_G - 1) / (2 * P->gy_G));
+    p.nunits = d.batch * p.nblk;
+    p.nry = (int)P->g_ry.size();
+    for (int i = 0; i < p.nry; ++i) p.ry[i] = P->g_ry[(size_t)i];
+    p.tw_y = P->g_twy.p; p.rev_y = (const unsigned*)P->g_revy.p;
+    p.win_y = P->win[0].p;
+    p.ph_y = P->fph[0].p; p.ph_on = (d.out_mode == XRFTHIP_OUT_COMPLEX && P->fph_on) ? 1 : 0;
+    p.detrend = d.detrend;
+    p.shift_y = (d.flags & XRFTHIP_SHIFT_Y) ? (int)(d.ny / 2) : 0;
+    p.scale = d.scale;
+    const dim3 grid((unsigned)std::min<long long>(p.nunits, 0x7fffffffLL)), blk((unsigned)P->gy_thr);
+    xrfthip_plan::ProfRec* rec = prof_begin(P, "fastg_yonly", st);
+#define GY_(TT, MM) do { auto k = &fastgy_kernel<TT, MM>; XRFT_LAUNCH(k, grid, blk, P->gy_lds, st, p); } while (0)
+    const bool cplx = d.out_mode == XRFTHIP_OUT_COMPLEX;
+    if (P->dbl) { if (cplx) GY_(double, 0); else GY_(double, 1); } else { if (cplx) GY_(float, 0); else GY_(float, 1); }
+#undef GY_
+    prof_end(rec, st);
+    HIP_TRY(hipGetLastError());
+    return XRFTHIP_OK;
+}
+
 // threads per slab.  The passes are chains of LDS round trips, so it is the number of waves in flight on a CU that sets the rate, and that is
 // bounded twice: by the registers (float32: 105 -> 4 waves per SIMD, 16 per CU; float64: 153 -> 3 and 12) and by how many slabs' LDS a CU holds.
 // Take the workgroup of 1, 2, 4, 8 or 16 waves (whole waves per SIMD, or the second workgroup does not fit beside the first) that keeps most
@@ -2101,7 +2159,7 @@ static int run_fastr(const xrfthip_plan* P, const void* in, void* out, hipStream
 static int finalize_plan(xrfthip_plan* P) {
     // the radial sums of a cross spectrum with a true-phase factor that is not 1 (two fields with different lags) need the factor per sample: the other paths
     if (P->fastg && P->d.out_mode == XRFTHIP_OUT_CROSS && (P->d.flags & XRFTHIP_ISO) && phase_nontrivial(P)) P->fastg = false;
-    if (P->fastg) {
+    if (P->fastg || P->fastgy) {
         if (P->d.out_mode != XRFTHIP_OUT_POWER) { const int rc = fast_phase_tables(P); if (rc) return rc; }
     } else if (P->fasts) {
         if (P->d.out_mode != XRFTHIP_OUT_POWER) { const int rc = fast_phase_tables(P); if (rc) return rc; }
@@ -2452,6 +2510,16 @@ int xrfthip_plan_create(xrfthip_plan** plan, const xrfthip_desc* desc) {
             if (rcm) { delete P; return rcm; }
         }
     }
+    {   // ... on any other smooth length: one pass in LDS with the radices as data (fastg.h: fastgy_kernel)
+        const uint32_t allowed = XRFTHIP_AXIS_Y | XRFTHIP_SHIFT_Y | (d.out_mode == XRFTHIP_OUT_COMPLEX ? XRFTHIP_ISHIFT_Y : 0u);
+        P->fastgy = !P->fastmy && (d.flags & XRFTHIP_AXIS_Y) && (d.out_mode == XRFTHIP_OUT_COMPLEX || d.out_mode == XRFTHIP_OUT_POWER) && !(d.flags & ~allowed) &&
+                    !env_ll("XRFTHIP_NO_FAST", 0) && env_ll("XRFTHIP_FASTG", 1) != 0 && fastgy_try(P);
+        if (P->fastgy) {
+            int rcg = P->dbl ? build_twiddle<double>(P->g_twy, d.ny, d.ny) : build_twiddle<float>(P->g_twy, d.ny, d.ny);
+            if (!rcg) rcg = fastg_rev(P->g_ry, (int)d.ny, P->g_revy, P->g_hrevy);
+            if (rcg) { delete P; return rcg; }
+        }
+    }
     {   // one short transform axis, the contiguous one, real input: rows packed in pairs through the same three passes
         const bool two = d.out_mode == XRFTHIP_OUT_CROSS || d.out_mode == XRFTHIP_OUT_PHASE;
         const uint32_t allowed = XRFTHIP_SHIFT_X | XRFTHIP_HALF_X | (d.out_mode != XRFTHIP_OUT_PHASE ? XRFTHIP_REALDIM_X2 : 0u) | (d.out_mode != XRFTHIP_OUT_POWER ? XRFTHIP_ISHIFT_X : 0u);
@@ -2592,7 +2660,7 @@ int xrfthip_plan_profile_read(xrfthip_plan* plan, char* buf, size_t buflen) {
 int xrfthip_plan_uses_bluestein(const xrfthip_plan* plan) {
     if (!plan) return 0;
     if (plan->inner > 1) return xrfthip_plan_uses_bluestein(plan->sub_x) || xrfthip_plan_uses_bluestein(plan->sub_y);
-    if (plan->fastg || plan->fasts || plan->fastr || plan->fastmx || plan->fastmy || plan->fastm || plan->fast1d || plan->fast4096) return 0;  // (the generic passes of such a plan never run)
+    if (plan->fastg || plan->fastgy || plan->fasts || plan->fastr || plan->fastmx || plan->fastmy || plan->fastm || plan->fast1d || plan->fast4096) return 0;  // (the generic passes of such a plan never run)
     for (const Pass& ps : plan->passes) if (ps.g.blue_n > 0) return 1;
     for (const Pass& ps : plan->passes_f0) if (ps.g.blue_n > 0) return 1;
     return 0;
@@ -2664,6 +2732,12 @@ int xrfthip_plan_describe(const xrfthip_plan* plan, char* buf, size_t buflen) {
         const MGeomRt C = mxgeom(plan->d.nx, plan->dbl);
         appendf(s, "  [fastm x-only] %d thr, %d row pairs per workgroup (FFT%lld r%dx%dx%d in LDS), lds=%zuB: per-row detrend + window + transform + full (or half) spectrum in one pass\n",
                 C.thr, C.g, (long long)plan->d.nx, C.r0, C.r1, C.r2, C.lds_cols);
+    } else if (plan->fastgy) {
+        std::string rys;
+        for (int r : plan->g_ry) rys += (rys.empty() ? "" : "x") + std::to_string(r);
+        appendf(s, "  [fastg y-only] one pass, %d thr, %d packed column pairs per workgroup (%d bytes of a row), the radices from the plan (y: %lld = %s in LDS), lds=%zuB: "
+                   "per-column detrend + window + transform + both columns' spectra, in place in memory order\n",
+                plan->gy_thr, plan->gy_G, (int)(2 * plan->gy_G * plan->rsize), (long long)plan->d.ny, rys.c_str(), plan->gy_lds);
     } else if (plan->fastmy) {
         const MGeomRt C = mygeom(plan->d.ny, plan->dbl);
         appendf(s, "  [fastm y-only] %d thr, %d packed column pairs (FFT%lld r%dx%dx%d in LDS), lds=%zuB: per-column detrend + window + transform + both halves of the spectrum in one pass, in place in memory order\n",
@@ -2724,6 +2798,7 @@ int xrfthip_exec(const xrfthip_plan* plan, const void* d_in0, const void* d_in1,
     if (P->fasts) return run_fasts(P, d_in0, out, (double*)d_iso, st);
     if (P->fastr) return run_fastr(P, d_in0, out, st);
     if (P->fastmx) return run_fastmx(P, d_in0, d_in1, out, st);
+    if (P->fastgy) return run_fastgy(P, d_in0, out, st);
     if (P->fastmy) return run_fastmy(P, d_in0, d_in1, out, st);
     if (P->fastm) return run_fastm(P, d_in0, d_in1, out, (double*)d_iso, ws, st);
     if (fasty_on(P)) {
