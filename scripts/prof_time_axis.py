@@ -11,7 +11,7 @@ def t(fn, reps=5):
     for _ in range(reps): fn()
     torch.cuda.synchronize(); return (time.perf_counter() - t0) / reps
 for nt, ny, nx, dt in ((96, 512, 512, "float32"), (120, 512, 512, "float32"), (250, 512, 512, "float32"), (360, 512, 512, "float32"), (500, 256, 512, "float64"), (250, 256, 512, "float64"),
-                       (730, 256, 256, "float32"), (1250, 256, 256, "float32"), (1460, 128, 256, "float64"), (3000, 128, 128, "float32"), (48, 1024, 1024, "float32"), (150, 512, 512, "float64")):
+                       (730, 256, 256, "float32"), (1250, 256, 256, "float32"), (1460, 128, 256, "float64"), (3000, 128, 128, "float32"), (48, 1024, 1024, "float32"), (150, 512, 512, "float64"), (365, 512, 512, "float32"), (365, 256, 512, "float64"), (8760, 64, 64, "float32")):
     x = torch.randn((nt, ny, nx), dtype=getattr(torch, dt), device="cuda")
     da = xrft.DataArray(x, ("time", "y", "x"), {"time": np.arange(float(nt))})
     api._plan_cache.clear()

@@ -618,7 +618,9 @@ def test_small_slabs_of_any_smooth_shape_in_one_pass(shape, dtype, full):
 
 
 @pytest.mark.parametrize("shape,dtype", [((3, 96, 40), "float32"), ((2, 250, 36), "float64"), ((2, 45, 22), "float32"), ((1, 1250, 8), "float32"), ((2, 120, 50), "float64"),
-                                         ((30, 48, 6), "float32"), ((2, 27, 130), "float64"), ((4, 150, 2), "float32")])
+                                         ((30, 48, 6), "float32"), ((2, 27, 130), "float64"), ((4, 150, 2), "float32"),
+                                         # a prime factor with no butterfly: Bluestein inside the tile (365 = 5 x 73 days, 730, 77 = 7 x 11, 131)
+                                         ((2, 365, 20), "float32"), ((1, 730, 10), "float64"), ((3, 77, 34), "float64"), ((2, 131, 18), "float32")])
 def test_one_axis_not_contiguous_any_smooth_length(shape, dtype):
     """fastg.h, fastgy_kernel: `dim="time"` calls on lengths outside the mixed-radix table."""
     cases.run_yonly_any_length_cases(shape, dtype)

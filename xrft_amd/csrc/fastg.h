@@ -81,6 +81,45 @@ __device__ __forceinline__ void fastg_pass_cols(C2<T>* tile, int ncols, int len,
     }
 }
 
+// exact inverse of fastg_pass_cols up to the factor R (the Bluestein convolution of fastgy_kernel): undo the twiddles with their conjugates, then the
+// unnormalised inverse butterfly (as run_pass_inv of tile_fft.h)
+template <typename T, int R>
+__device__ __forceinline__ void fastg_pass_cols_inv(C2<T>* tile, int ncols, int len, int rs, int L, int tid, int nthreads, const C2<T>* __restrict__ tw) {
+    const int m = L / R, per = len / R, nb = ncols * per, twstep = len / L;
+    const float inv_c = 1.0f / (float)ncols, inv_m = 1.0f / (float)m;
+    for (int w = tid; w < nb; w += nthreads) {
+        const int gg = fdiv(w, inv_c), c = w - gg * ncols;
+        const int blk = fdiv(gg, inv_m), j = gg - blk * m;
+        C2<T>* s = tile + c + (blk * L + j) * rs;
+        C2<T> a[R];
+#pragma unroll
+        for (int k = 0; k < R; ++k) a[k] = cconj(s[k * m * rs]);
+        if (m > 1) {
+#pragma unroll
+            for (int k = 1; k < R; ++k) a[k] = cmul(a[k], tw[j * k * twstep]);  // conj(a conj(w)) = conj(a) w
+        }
+        dft_r<T, R>(a);
+#pragma unroll
+        for (int q = 0; q < R; ++q) s[q * m * rs] = cconj(a[q]);
+    }
+}
+template <typename T>
+__device__ __forceinline__ void fastg_cols_pass_inv(C2<T>* tile, int ncols, int len, int rs, int R, int L, int tid, int nthr, const C2<T>* tw) {
+    switch (R) {
+        case 2: fastg_pass_cols_inv<T, 2>(tile, ncols, len, rs, L, tid, nthr, tw); break;
+        case 3: fastg_pass_cols_inv<T, 3>(tile, ncols, len, rs, L, tid, nthr, tw); break;
+        case 4: fastg_pass_cols_inv<T, 4>(tile, ncols, len, rs, L, tid, nthr, tw); break;
+        case 5: fastg_pass_cols_inv<T, 5>(tile, ncols, len, rs, L, tid, nthr, tw); break;
+        case 6: fastg_pass_cols_inv<T, 6>(tile, ncols, len, rs, L, tid, nthr, tw); break;
+        case 8: fastg_pass_cols_inv<T, 8>(tile, ncols, len, rs, L, tid, nthr, tw); break;
+        case 9: fastg_pass_cols_inv<T, 9>(tile, ncols, len, rs, L, tid, nthr, tw); break;
+        case 10: fastg_pass_cols_inv<T, 10>(tile, ncols, len, rs, L, tid, nthr, tw); break;
+        case 12: fastg_pass_cols_inv<T, 12>(tile, ncols, len, rs, L, tid, nthr, tw); break;
+        case 15: fastg_pass_cols_inv<T, 15>(tile, ncols, len, rs, L, tid, nthr, tw); break;
+        default: fastg_pass_cols_inv<T, 16>(tile, ncols, len, rs, L, tid, nthr, tw); break;
+    }
+}
+
 template <typename T>
 __device__ __forceinline__ void fastg_rows_pass(C2<T>* tile, const TileGeom& g, int R, int L, int tid, int nthr, const C2<T>* tw) {
     switch (R) {
@@ -360,24 +399,35 @@ struct FastGY {
     const void* ph_y;  // complex mode: combined phase factors by unshifted frequency (complex T)
     int ph_on, detrend, shift_y;
     double scale;
+    // a length with a prime factor that has no butterfly (365 = 5 x 73 daily samples of a year, 730, 1460): Bluestein inside the tile -- the passes run
+    // on blue_m = 2^a 3^b 5^c >= 2 ny - 1 rows (ry, tw_y belong to blue_m; rev_y is unused: the result comes out in natural order):
+    //   x[i] conj(c[i]) zero-padded -> forward passes -> * blue_b -> inverse passes -> * conj(c[k]),  c[k] = exp(i pi k^2 / ny)
+    int blue_m;
+    const void* blue_c;  // c[k], k < ny (complex T)
+    const void* blue_b;  // FFT_m(chirp kernel) / m at the row the forward passes leave each frequency
+    int tw_lds;          // the twiddles of the passes are staged in LDS (always, unless a Bluestein tile leaves no room)
 };
 
-// MODE 1: power spectrum (real T out), 0: complex spectrum
-template <typename T, int MODE>
+// MODE 1: power spectrum (real T out), 0: complex spectrum; BLUE: the Bluestein form (its inverse passes cost the plain form 25 registers: a kernel of its own)
+template <typename T, int MODE, bool BLUE>
 __global__ void __launch_bounds__(256) fastgy_kernel(FastGY p) {
     typedef C2<T> CT;
     XRFT_DYN_SMEM(smem_raw);
     CT* tile = reinterpret_cast<CT*>(smem_raw);
     const int tid = threadIdx.x, nthr = blockDim.x, ny = p.ny, nx = p.nx, G = p.G, lg = p.lg, C = 2 * G;
-    unsigned char* tb = smem_raw + (((size_t)ny * G * sizeof(CT) + 15) & ~(size_t)15);
-    CT* twy = reinterpret_cast<CT*>(tb); tb += (size_t)ny * sizeof(CT);
+    const int nrow = BLUE ? p.blue_m : ny;  // rows of the tile = length of the passes
+    unsigned char* tb = smem_raw + (((size_t)nrow * G * sizeof(CT) + 15) & ~(size_t)15);
     double* part = reinterpret_cast<double*>(tb); tb += (size_t)nthr * 4 * sizeof(double);  // [row group][g][4]
     double* coef = reinterpret_cast<double*>(tb); tb += (size_t)G * 4 * sizeof(double);     // [g][mean re, slope re, mean im, slope im]
+    const bool twin_lds = !BLUE || p.tw_lds;  // (the plain form always)
+    CT* twl = reinterpret_cast<CT*>(tb); tb += twin_lds ? (size_t)nrow * sizeof(CT) : 0;
     T* wys = reinterpret_cast<T*>(tb); tb += (size_t)ny * sizeof(T);
     unsigned short* revy = reinterpret_cast<unsigned short*>(tb);
+    const CT* twy = twl;
+    if (BLUE && !p.tw_lds) twy = reinterpret_cast<const CT*>(p.tw_y);
+    if (twin_lds) for (int k = tid; k < nrow; k += nthr) twl[k] = reinterpret_cast<const CT*>(p.tw_y)[k];
     for (int k = tid; k < ny; k += nthr) {
-        twy[k] = reinterpret_cast<const CT*>(p.tw_y)[k];
-        revy[k] = (unsigned short)p.rev_y[k];
+        if (!BLUE) revy[k] = (unsigned short)p.rev_y[k];
         if (p.win_y) wys[k] = reinterpret_cast<const T*>(p.win_y)[k];
     }
     const int g = tid & (G - 1), rq = tid >> lg, RQ = nthr >> lg;  // (lane along the sequences, row group)
@@ -427,15 +477,33 @@ __global__ void __launch_bounds__(256) fastgy_kernel(FastGY p) {
                 tile[i * G + g] = z;
             }
         }
+        if (BLUE) {  // x conj(c), zero padding up to blue_m rows
+            const CT* __restrict__ ch = reinterpret_cast<const CT*>(p.blue_c);
+            for (int i = rq; i < nrow; i += RQ) tile[i * G + g] = i < ny ? cmulc(tile[i * G + g], ch[i]) : mk<T>((T)0, (T)0);
+        }
         __syncthreads();
-        // ---- the passes of length ny over the G sequences (lanes along the sequences)
+        // ---- the passes of length ny (blue_m) over the G sequences (lanes along the sequences)
         {
-            int L = ny;
+            int L = nrow;
             for (int ps = 0; ps < p.nry; ++ps) {
-                fastg_cols_pass<T>(tile, G, ny, G, p.ry[ps], L, tid, nthr, twy);
+                fastg_cols_pass<T>(tile, G, nrow, G, p.ry[ps], L, tid, nthr, twy);
                 L /= p.ry[ps];
                 __syncthreads();
             }
+        }
+        if (BLUE) {  // circular convolution with the chirp: * B, the inverse passes in reverse order, * conj(c): Z[k] at row k
+            const CT* __restrict__ bh = reinterpret_cast<const CT*>(p.blue_b);
+            const CT* __restrict__ ch = reinterpret_cast<const CT*>(p.blue_c);
+            for (int i = rq; i < nrow; i += RQ) tile[i * G + g] = cmul(tile[i * G + g], bh[i]);
+            __syncthreads();
+            int Li = 1;
+            for (int ip = p.nry - 1; ip >= 0; --ip) {
+                Li *= p.ry[ip];
+                fastg_cols_pass_inv<T>(tile, G, nrow, G, p.ry[ip], Li, tid, nthr, twy);
+                __syncthreads();
+            }
+            for (int i = rq; i < ny; i += RQ) tile[i * G + g] = cmulc(tile[i * G + g], ch[i]);
+            __syncthreads();
         }
         // ---- out: row orow of the C columns = frequency k of the two spectra packed in every sequence
         const int tot = ny << (lg + 1);
@@ -444,7 +512,7 @@ __global__ void __launch_bounds__(256) fastgy_kernel(FastGY p) {
             if (col >= nx) continue;
             int k = orow - p.shift_y; if (k < 0) k += ny;
             const int km = k == 0 ? 0 : ny - k;
-            const CT zk = tile[(int)revy[k] * G + (c >> 1)], zm = tile[(int)revy[km] * G + (c >> 1)];
+            const CT zk = tile[(BLUE ? k : (int)revy[k]) * G + (c >> 1)], zm = tile[(BLUE ? km : (int)revy[km]) * G + (c >> 1)];
             const CT v = (c & 1) ? mk<T>((T)0.5 * (zk.im + zm.im), (T)0.5 * (zm.re - zk.re))   // (Zk - conj Zm) / 2i
                                  : mk<T>((T)0.5 * (zk.re + zm.re), (T)0.5 * (zk.im - zm.im));  // (Zk + conj Zm) / 2
             const size_t o = ((size_t)b * ny + orow) * nx + col;

@@ -341,8 +341,10 @@ struct xrfthip_plan {
     bool g_packed = true;
     // ... and ONE pass for one transform axis that is not the contiguous one (XRFTHIP_AXIS_Y), any smooth length, real input (fastg.h: fastgy_kernel)
     bool fastgy = false;
-    int gy_G = 0, gy_thr = 0;
+    int gy_G = 0, gy_thr = 0, gy_blue_m = 0;  // gy_blue_m: Bluestein inside the tile on blue_m rows (a prime factor of ny with no butterfly)
+    bool gy_tw_lds = true;
     size_t gy_lds = 0;
+    DevBuf gy_bluec, gy_blueb;
     size_t g_lds = 0;
     // ... and ONE pass for a small real float32 slab that fits the registers of a CU: 256 x 256 power spectra (fasts.h)
     bool fasts = false;
@@ -843,7 +845,8 @@ void set_kernel_attrs_once() {
 #define SETF(K) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&K), hipFuncAttributeMaxDynamicSharedMemorySize, m)
     SETF((fastg_kernel<float, 0>)); SETF((fastg_kernel<float, 1>)); SETF((fastg_kernel<double, 0>)); SETF((fastg_kernel<double, 1>));
     SETF((fastg_kernel<float, 2>)); SETF((fastg_kernel<double, 2>));
-    SETF((fastgy_kernel<float, 0>)); SETF((fastgy_kernel<float, 1>)); SETF((fastgy_kernel<double, 0>)); SETF((fastgy_kernel<double, 1>));
+    SETF((fastgy_kernel<float, 0, false>)); SETF((fastgy_kernel<float, 1, false>)); SETF((fastgy_kernel<double, 0, false>)); SETF((fastgy_kernel<double, 1, false>));
+    SETF((fastgy_kernel<float, 0, true>)); SETF((fastgy_kernel<float, 1, true>)); SETF((fastgy_kernel<double, 0, true>)); SETF((fastgy_kernel<double, 1, true>));
     SETF((fasts_power_kernel<8, 8, 0, 0>)); SETF((fasts_power_kernel<8, 4, 0, 0>)); SETF((fasts_power_kernel<4, 8, 0, 0>));
     SETF((fasts_power_kernel<8, 8, 0>)); SETF((fasts_power_kernel<8, 8, 1>)); SETF((fasts_power_kernel<8, 8, 2>));  // (above 64 KB of dynamic LDS)
     SETF((fasts_power_kernel<8, 4, 0>)); SETF((fasts_power_kernel<8, 4, 1>)); SETF((fasts_power_kernel<8, 4, 2>));
@@ -1926,25 +1929,68 @@ static int fastg_build_iso(xrfthip_plan* P, const int32_t* bm) {
 // the widest power of two (<= 128 bytes of a row) whose tile leaves three workgroups on a CU, or the widest that fits at all
 static bool fastgy_try(xrfthip_plan* P) {
     const xrfthip_desc& d = P->d;
-    if (d.ndim != 2 || P->cplx_in || (d.nx & 1) || d.ny < 2 || d.ny > 4096 || d.batch * ((d.nx + 3) / 4) >= (1LL << 31)) return false;
+    if (d.ndim != 2 || P->cplx_in || (d.nx & 1) || d.ny < 2 || d.ny > 16384 || d.batch * ((d.nx + 3) / 4) >= (1LL << 31)) return false;
     bool gy = false;
     std::vector<int> ry;
-    if (factorize(d.ny, ry, gy) || gy || (int)ry.size() > kFastGMaxPasses) return false;
+    long long m = d.ny;  // rows of the tile = length of the passes: ny, or the Bluestein length when a prime factor of ny has no butterfly
+    int blue_m = 0;
+    if (factorize(d.ny, ry, gy) || gy) {
+        for (m = 2 * d.ny - 1;; ++m) {
+            long long q = m;
+            while (q % 2 == 0) q /= 2;
+            while (q % 3 == 0) q /= 3;
+            while (q % 5 == 0) q /= 5;
+            if (q == 1) break;
+        }
+        if (m > 65535 || factorize(m, ry, gy) || gy) return false;
+        blue_m = (int)m;
+    }
+    if ((int)ry.size() > kFastGMaxPasses) return false;
     for (int r : ry) if (r > 16) return false;
+    if (d.ny > 4096 && !blue_m) return false;
     const int thr = 256;
-    auto lds_of = [&](int G) {
-        return (((size_t)d.ny * G * P->csize + 15) & ~(size_t)15) + (size_t)d.ny * P->csize + (size_t)thr * 4 * sizeof(double) + (size_t)G * 4 * sizeof(double) +
+    auto lds_of = [&](int G, bool tw_lds) {
+        return (((size_t)m * G * P->csize + 15) & ~(size_t)15) + (tw_lds ? (size_t)m * P->csize : 0) + (size_t)thr * 4 * sizeof(double) + (size_t)G * 4 * sizeof(double) +
                (size_t)d.ny * P->rsize + (size_t)d.ny * 2 + 16;
     };
     const int gmax = (int)(128 / P->csize);  // 128 bytes of a row: 16 float32 pairs, 8 float64 pairs
     int G = 0;
-    for (int cand = gmax; cand >= gmax / 4 && cand >= 1 && !G; cand >>= 1) if (lds_of(cand) <= 78 * 1024) G = cand;   // two or more workgroups per CU, 32 bytes of a row at least
-    for (int cand = gmax; cand >= 1 && !G; cand >>= 1) if (lds_of(cand) <= kLdsMax - 1024) G = cand;                  // ... or whatever fits
+    bool tw_lds = true;
+    for (int cand = gmax; cand >= gmax / 4 && cand >= 1 && !G; cand >>= 1) if (lds_of(cand, true) <= 78 * 1024) G = cand;   // two or more workgroups per CU, 32 bytes of a row at least
+    for (int cand = gmax; cand >= 1 && !G; cand >>= 1) if (lds_of(cand, true) <= kLdsMax - 1024) G = cand;                  // ... or whatever fits
+    if (!G && blue_m) {  // (a Bluestein tile that leaves no room for the twiddles: they come from memory)
+        tw_lds = false;
+        for (int cand = gmax; cand >= 1 && !G; cand >>= 1) if (lds_of(cand, false) <= kLdsMax - 1024) G = cand;
+    }
     const long long forced = env_ll("XRFTHIP_FASTGY_G", 0);
-    if (forced >= 1 && forced <= gmax && !(forced & (forced - 1)) && lds_of((int)forced) <= kLdsMax - 1024) G = (int)forced;
+    if (forced >= 1 && forced <= gmax && !(forced & (forced - 1)) && lds_of((int)forced, tw_lds) <= kLdsMax - 1024) G = (int)forced;
     if (!G) return false;
-    P->g_ry = ry; P->gy_G = G; P->gy_thr = thr; P->gy_lds = lds_of(G);
+    P->g_ry = ry; P->gy_G = G; P->gy_thr = thr; P->gy_lds = lds_of(G, tw_lds); P->gy_blue_m = blue_m; P->gy_tw_lds = tw_lds;
     return true;
+}
+// the tables of the Bluestein form: c[k] = exp(i pi k^2 / n), k < n, and FFT_m(chirp kernel) / m at the row the forward passes leave each frequency
+template <typename T> static int fastgy_blue_tables(xrfthip_plan* P) {
+    const long long N = P->d.ny;
+    const int m = P->gy_blue_m;
+    const long double pi = 3.14159265358979323846264338327950288L;
+    std::vector<C2<T>> c((size_t)N);
+    std::vector<double> br((size_t)m, 0.0), bi((size_t)m, 0.0);
+    for (long long k = 0; k < N; ++k) {
+        const long double a = pi * (long double)((k * k) % (2 * N)) / (long double)N;  // k^2 mod 2N keeps the angle small
+        const long double cr = cosl(a), ci = sinl(a);
+        c[(size_t)k].re = (T)cr; c[(size_t)k].im = (T)ci;
+        br[(size_t)k] = (double)cr; bi[(size_t)k] = (double)ci;
+        if (k) { br[(size_t)(m - k)] = (double)cr; bi[(size_t)(m - k)] = (double)ci; }
+    }
+    host_fft_smooth(br, bi);
+    std::vector<C2<T>> bh((size_t)m);
+    for (int k = 0; k < m; ++k) {
+        bh[(size_t)P->g_hrevy[(size_t)k]].re = (T)(br[(size_t)k] / m);
+        bh[(size_t)P->g_hrevy[(size_t)k]].im = (T)(bi[(size_t)k] / m);
+    }
+    int rc = P->gy_bluec.upload(c.data(), c.size() * sizeof(C2<T>));
+    if (!rc) rc = P->gy_blueb.upload(bh.data(), bh.size() * sizeof(C2<T>));
+    return rc;
 }
 static int run_fastgy(const xrfthip_plan* P, const void* in, void* out, hipStream_t st) {
     const xrfthip_desc& d = P->d;
@@ -1956,6 +2002,7 @@ static int run_fastgy(const xrfthip_plan* P, const void* in, void* out, hipStrea
     p.nry = (int)P->g_ry.size();
     for (int i = 0; i < p.nry; ++i) p.ry[i] = P->g_ry[(size_t)i];
     p.tw_y = P->g_twy.p; p.rev_y = (const unsigned*)P->g_revy.p;
+    p.blue_m = P->gy_blue_m; p.blue_c = P->gy_bluec.p; p.blue_b = P->gy_blueb.p; p.tw_lds = P->gy_tw_lds ? 1 : 0;
     p.win_y = P->win[0].p;
     p.ph_y = P->fph[0].p; p.ph_on = (d.out_mode == XRFTHIP_OUT_COMPLEX && P->fph_on) ? 1 : 0;
     p.detrend = d.detrend;
@@ -1963,7 +2010,8 @@ static int run_fastgy(const xrfthip_plan* P, const void* in, void* out, hipStrea
     p.scale = d.scale;
     const dim3 grid((unsigned)std::min<long long>(p.nunits, 0x7fffffffLL)), blk((unsigned)P->gy_thr);
     xrfthip_plan::ProfRec* rec = prof_begin(P, "fastg_yonly", st);
-#define GY_(TT, MM) do { auto k = &fastgy_kernel<TT, MM>; XRFT_LAUNCH(k, grid, blk, P->gy_lds, st, p); } while (0)
+#define GY_(TT, MM) do { if (P->gy_blue_m) { auto k = &fastgy_kernel<TT, MM, true>; XRFT_LAUNCH(k, grid, blk, P->gy_lds, st, p); } \
+                         else { auto k = &fastgy_kernel<TT, MM, false>; XRFT_LAUNCH(k, grid, blk, P->gy_lds, st, p); } } while (0)
     const bool cplx = d.out_mode == XRFTHIP_OUT_COMPLEX;
     if (P->dbl) { if (cplx) GY_(double, 0); else GY_(double, 1); } else { if (cplx) GY_(float, 0); else GY_(float, 1); }
 #undef GY_
@@ -2515,8 +2563,10 @@ int xrfthip_plan_create(xrfthip_plan** plan, const xrfthip_desc* desc) {
         P->fastgy = !P->fastmy && (d.flags & XRFTHIP_AXIS_Y) && (d.out_mode == XRFTHIP_OUT_COMPLEX || d.out_mode == XRFTHIP_OUT_POWER) && !(d.flags & ~allowed) &&
                     !env_ll("XRFTHIP_NO_FAST", 0) && env_ll("XRFTHIP_FASTG", 1) != 0 && fastgy_try(P);
         if (P->fastgy) {
-            int rcg = P->dbl ? build_twiddle<double>(P->g_twy, d.ny, d.ny) : build_twiddle<float>(P->g_twy, d.ny, d.ny);
-            if (!rcg) rcg = fastg_rev(P->g_ry, (int)d.ny, P->g_revy, P->g_hrevy);
+            const long long m = P->gy_blue_m ? P->gy_blue_m : d.ny;  // length of the passes
+            int rcg = P->dbl ? build_twiddle<double>(P->g_twy, m, m) : build_twiddle<float>(P->g_twy, m, m);
+            if (!rcg) rcg = fastg_rev(P->g_ry, (int)m, P->g_revy, P->g_hrevy);
+            if (!rcg && P->gy_blue_m) rcg = P->dbl ? fastgy_blue_tables<double>(P) : fastgy_blue_tables<float>(P);
             if (rcg) { delete P; return rcg; }
         }
     }
@@ -2660,7 +2710,8 @@ int xrfthip_plan_profile_read(xrfthip_plan* plan, char* buf, size_t buflen) {
 int xrfthip_plan_uses_bluestein(const xrfthip_plan* plan) {
     if (!plan) return 0;
     if (plan->inner > 1) return xrfthip_plan_uses_bluestein(plan->sub_x) || xrfthip_plan_uses_bluestein(plan->sub_y);
-    if (plan->fastg || plan->fastgy || plan->fasts || plan->fastr || plan->fastmx || plan->fastmy || plan->fastm || plan->fast1d || plan->fast4096) return 0;  // (the generic passes of such a plan never run)
+    if (plan->fastgy) return plan->gy_blue_m > 0;
+    if (plan->fastg || plan->fasts || plan->fastr || plan->fastmx || plan->fastmy || plan->fastm || plan->fast1d || plan->fast4096) return 0;  // (the generic passes of such a plan never run)
     for (const Pass& ps : plan->passes) if (ps.g.blue_n > 0) return 1;
     for (const Pass& ps : plan->passes_f0) if (ps.g.blue_n > 0) return 1;
     return 0;
@@ -2737,7 +2788,10 @@ int xrfthip_plan_describe(const xrfthip_plan* plan, char* buf, size_t buflen) {
         for (int r : plan->g_ry) rys += (rys.empty() ? "" : "x") + std::to_string(r);
         appendf(s, "  [fastg y-only] one pass, %d thr, %d packed column pairs per workgroup (%d bytes of a row), the radices from the plan (y: %lld = %s in LDS), lds=%zuB: "
                    "per-column detrend + window + transform + both columns' spectra, in place in memory order\n",
-                plan->gy_thr, plan->gy_G, (int)(2 * plan->gy_G * plan->rsize), (long long)plan->d.ny, rys.c_str(), plan->gy_lds);
+                plan->gy_thr, plan->gy_G, (int)(2 * plan->gy_G * plan->rsize), (long long)(plan->gy_blue_m ? plan->gy_blue_m : plan->d.ny), rys.c_str(), plan->gy_lds);
+        if (plan->gy_blue_m)
+            appendf(s, "  [fastg y-only Bluestein] %lld points as a circular convolution of %d inside the tile (chirp products, forward and inverse passes)%s\n",
+                    (long long)plan->d.ny, plan->gy_blue_m, plan->gy_tw_lds ? "" : "; twiddles from memory");
     } else if (plan->fastmy) {
         const MGeomRt C = mygeom(plan->d.ny, plan->dbl);
         appendf(s, "  [fastm y-only] %d thr, %d packed column pairs (FFT%lld r%dx%dx%d in LDS), lds=%zuB: per-column detrend + window + transform + both halves of the spectrum in one pass, in place in memory order\n",
