@@ -859,6 +859,33 @@ def run_yonly_fast_cases(shape=(3, 360, 40), dtype="float64"):
     return worst
 
 
+def run_rows_any_length_cases(shape=(37, 250), dtype="float32"):
+    """One transform axis, the contiguous one, on ANY smooth length outside the tables (96, 250, 750, 1250, 6000, odd 125 / 243 / 729): csrc/fastg.h on groups of
+    rows (run-time radices, a mean / line per row in the workgroup; the last group short) against the oracle -- fft with true phase, real_dim (half
+    output), power spectrum, every detrend, window, shift."""
+    rng = np.random.default_rng(73)
+    tol = TOL[dtype]
+    n = shape[-1]
+    v = (rng.standard_normal(shape) + 2.0 + 3.0 * np.arange(n) / n).astype(dtype)
+    dims = ("a", "b", "x")[-len(shape):]
+    c = {d: np.arange(s) for d, s in zip(dims[:-1], shape[:-1])}
+    c["x"] = np.arange(n) * 0.5 - 7.0
+    da, od = pair(v, dims, c)
+    worst = 0.0
+
+    def on_fast():
+        return "[fastg rows]" in next(reversed(xa.api._plan_cache.values())).describe()
+
+    for kw in (dict(), dict(detrend="linear", window="hann"), dict(detrend="constant", shift=False), dict(true_phase=False, true_amplitude=False, window="hamming"),
+               dict(real_dim="x", detrend="linear")):
+        worst = max(worst, check(xa.fft(da, dim=["x"], **kw), o.fft(od, dim=["x"], **kw), tol))
+        assert on_fast(), kw
+    for kw in (dict(detrend="linear", window="hann"), dict(shift=False, scaling="spectrum", detrend="constant"), dict(real_dim="x", window="hann"), dict()):
+        worst = max(worst, check(xa.power_spectrum(da, dim=["x"], **kw), o.power_spectrum(od, dim=["x"], **kw), tol))
+        assert on_fast(), kw
+    return worst
+
+
 def run_xonly_fast_cases(shape=(5, 360), dtype="float64"):
     """One short transform axis, the contiguous one (spectra along the last axis of (..., n) arrays, n in the fastm table):
     csrc/fastm.h fastm_xonly_kernel (rows packed in pairs; an odd number of rows leaves the last pair half empty) against the

@@ -624,3 +624,10 @@ def test_small_slabs_of_any_smooth_shape_in_one_pass(shape, dtype, full):
 def test_one_axis_not_contiguous_any_smooth_length(shape, dtype):
     """fastg.h, fastgy_kernel: `dim="time"` calls on lengths outside the mixed-radix table."""
     cases.run_yonly_any_length_cases(shape, dtype)
+
+
+@pytest.mark.parametrize("shape,dtype", [((37, 250), "float32"), ((5, 96), "float64"), ((3, 4, 125), "float32"), ((2, 750), "float64"), ((300, 50), "float32"), ((2, 2250), "float32"),
+                                         ((7, 243), "float64"), ((1, 1250), "float32")])
+def test_last_axis_any_smooth_length(shape, dtype):
+    """fastg.h on groups of rows: 1-D spectra along the contiguous axis on lengths outside the tables."""
+    cases.run_rows_any_length_cases(shape, dtype)

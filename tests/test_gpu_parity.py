@@ -1025,3 +1025,10 @@ def test_small_slabs_of_any_smooth_shape_in_one_pass(shape, dtype):
 def test_one_axis_not_contiguous_any_smooth_length(shape, dtype):
     """fastg.h, fastgy_kernel: `dim="time"` calls on lengths outside the mixed-radix table."""
     cases.run_yonly_any_length_cases(shape, dtype)
+
+
+@pytest.mark.parametrize("shape,dtype", [((3700, 250), "float32"), ((501, 96), "float64"), ((30, 40, 125), "float32"), ((200, 750), "float64"), ((30001, 50), "float32"), ((20, 2250), "float32"),
+                                         ((700, 243), "float64"), ((100, 1250), "float32"), ((64, 1250), "float64"), ((9, 2700), "float32")])
+def test_last_axis_any_smooth_length(shape, dtype):
+    """fastg.h on groups of rows: 1-D spectra along the contiguous axis on lengths outside the tables."""
+    cases.run_rows_any_length_cases(shape, dtype)

@@ -34,6 +34,10 @@ struct FastG {
     long long nslabs;
     int ny, nx, n, rs;  // n = nx / 2 (packed rows) or nx (an odd nx: the rows as complex sequences, imaginary parts zero); rs = LDS row stride in complex elements (>= n + 1 | nx)
     int packed;         // nx even: rows packed in pairs of samples, the half spectrum in the tile; else the whole spectrum
+    int one_d;          // a 1-D transform along x of `nrows` rows, ny of them per workgroup: no y passes (nry = 0, rev_y the identity), a mean / line per ROW
+    int lpr;            // ... lanes that share a row in the per-row sums (a power of two <= 64)
+    int nred;           // doubles of the sums' scratch: 3 per wave (plane), 2 per row (one_d)
+    long long nrows;
     int nrx, nry;
     int rx[kFastGMaxPasses], ry[kFastGMaxPasses];
     const void* tw_x;   // W_n^k,  k < n   (complex T)
@@ -155,7 +159,7 @@ __device__ __forceinline__ void fastg_cols_pass(C2<T>* tile, int ncols, int len,
 
 // MODE 1: power spectrum (real T out), 0: complex spectrum, 2: cross spectrum of two fields (two tiles in LDS, complex out)
 template <typename T, int MODE>
-__global__ void __launch_bounds__(fastg_max_threads<T>()) fastg_kernel(FastG p) {
+__global__ void __launch_bounds__(fastg_max_threads<T>(), (sizeof(T) == 4 ? 4 : 3)) fastg_kernel(FastG p) {  // (float64: three waves per SIMD = 168 registers)
     typedef C2<T> CT;
     XRFT_DYN_SMEM(smem_raw);
     CT* tile0 = reinterpret_cast<CT*>(smem_raw);
@@ -169,7 +173,7 @@ __global__ void __launch_bounds__(fastg_max_threads<T>()) fastg_kernel(FastG p) 
     CT* twx = reinterpret_cast<CT*>(tb); tb += (size_t)n * sizeof(CT);
     CT* twy = reinterpret_cast<CT*>(tb); tb += (size_t)ny * sizeof(CT);
     CT* twr = reinterpret_cast<CT*>(tb); tb += (size_t)(n + 1) * sizeof(CT);
-    double* red = reinterpret_cast<double*>(tb); tb += kFastGWaves * 3 * sizeof(double);  // [waves][3]
+    double* red = reinterpret_cast<double*>(tb); tb += (size_t)p.nred * sizeof(double);  // [waves][3]; one_d: [row][2]
     T* wys = reinterpret_cast<T*>(tb); tb += (size_t)ny * sizeof(T);  // the windows (with a window; else unused)
     T* wxs = reinterpret_cast<T*>(tb); tb += (size_t)nx * sizeof(T);
     unsigned short* revx = reinterpret_cast<unsigned short*>(tb); tb += (((size_t)n * 2 + 3) & ~(size_t)3);
@@ -185,7 +189,9 @@ __global__ void __launch_bounds__(fastg_max_threads<T>()) fastg_kernel(FastG p) 
     TileGeom g{};
     g.n = n; g.T = ny; g.seq_stride = rs; g.pad_shift = 30;
     for (long long slab = blockIdx.x; slab < p.nslabs; slab += gridDim.x) {
-      const int npk = ny * n;  // packed samples
+      // one_d: the "slab" is a group of ny ROWS of a 1-D transform along x (no y passes; the last group may be short)
+      const int nyv = p.one_d ? (int)(p.nrows - slab * ny < (long long)ny ? p.nrows - slab * ny : (long long)ny) : ny;
+      const int npk = nyv * n;  // packed samples
       __syncthreads();         // (the previous slab's output loop is done with the tile; the tables are in place)
 #pragma unroll 1
       for (int f = 0; f < NF; ++f) {  // (a cross spectrum: field 0 into tile 0, field 1 into tile 1, the same code)
@@ -193,13 +199,14 @@ __global__ void __launch_bounds__(fastg_max_threads<T>()) fastg_kernel(FastG p) 
         const CT* __restrict__ src = reinterpret_cast<const CT*>(reinterpret_cast<const T*>(f ? p.in_b : p.in) + (size_t)slab * ny * nx);
         // ---- load; the plane's sums on the way (float64 per thread, then the threads in a fixed order)
         double s0 = 0.0, si = 0.0, sj = 0.0;
+        const bool plane = p.detrend && !p.one_d;  // (the slab's plane; a 1-D transform fits a line per row below)
         const double ibar = 0.5 * (ny - 1), jbar = 0.5 * (nx - 1);
         if (packed) {
             for (int e = tid; e < npk; e += nthr) {
                 const int i = fdiv(e, inv_n), m = e - i * n;
                 const CT z = src[e];
                 tile[i * rs + m] = z;
-                if (p.detrend) {
+                if (plane) {
                     const double u = (double)z.re + (double)z.im;
                     s0 += u;
                     si = fma((double)i - ibar, u, si);
@@ -212,14 +219,56 @@ __global__ void __launch_bounds__(fastg_max_threads<T>()) fastg_kernel(FastG p) 
                 const int i = fdiv(e, inv_n), m = e - i * n;
                 const T v = srcr[e];
                 tile[i * rs + m] = mk<T>(v, (T)0);
-                if (p.detrend) {
+                if (plane) {
                     s0 += (double)v;
                     si = fma((double)i - ibar, (double)v, si);
                     sj = fma((double)m - jbar, (double)v, sj);
                 }
             }
         }
-        if (p.detrend || p.win_y) {
+        if (p.one_d && (p.detrend || p.win_y)) {
+            // per-row mean / least-squares line (scipy.signal.detrend along x, xrft/detrend.py:54-71): lpr lanes share a row (a power of two <= 64, so a
+            // row's lanes sit in one wave), the lanes' float64 sums meet in a fixed shuffle tree; the rows in rounds
+            __syncthreads();
+            const int lpr = p.lpr, lane = tid & (lpr - 1);
+            if (p.detrend) {
+                const double sjj = (double)nx * ((double)nx * (double)nx - 1.0) / 12.0;
+                for (int r0 = 0; r0 < nyv; r0 += nthr / lpr) {  // (every thread takes every round: the shuffles are wave-wide)
+                    const int row = r0 + tid / lpr;
+                    double a0 = 0.0, a1 = 0.0;
+                    for (int m = lane; m < n && row < nyv; m += lpr) {
+                        const CT z = tile[row * rs + m];
+                        if (packed) {
+                            a0 += (double)z.re + (double)z.im;
+                            a1 += ((double)(2 * m) - jbar) * ((double)z.re + (double)z.im) + (double)z.im;
+                        } else {
+                            a0 += (double)z.re;
+                            a1 = fma((double)m - jbar, (double)z.re, a1);
+                        }
+                    }
+                    for (int mm = 1; mm < lpr; mm <<= 1) { a0 += __shfl_xor(a0, mm); a1 += __shfl_xor(a1, mm); }
+                    if (lane == 0 && row < nyv) { red[2 * row] = a0 / (double)nx; red[2 * row + 1] = (p.detrend == 2 && nx > 1) ? a1 / sjj : 0.0; }
+                }
+                __syncthreads();
+            }
+            const T* wx = wxs;
+            for (int e = tid; e < npk; e += nthr) {
+                const int i = fdiv(e, inv_n), m = e - i * n;
+                CT z = tile[i * rs + m];
+                const double c0 = p.detrend ? red[2 * i] : 0.0, c2 = p.detrend ? red[2 * i + 1] : 0.0;
+                if (packed) {
+                    if (p.detrend) {
+                        const double l = c0 + c2 * ((double)(2 * m) - jbar);
+                        z = mk<T>((T)((double)z.re - l), (T)((double)z.im - (l + c2)));
+                    }
+                    if (p.win_y) z = mk<T>(z.re * wx[2 * m], z.im * wx[2 * m + 1]);
+                } else {
+                    if (p.detrend) z.re = (T)((double)z.re - (c0 + c2 * ((double)m - jbar)));
+                    if (p.win_y) z.re *= wx[m];
+                }
+                tile[i * rs + m] = z;
+            }
+        } else if (p.detrend || p.win_y) {
             double c0 = 0.0, c1 = 0.0, c2 = 0.0;
             if (p.detrend) {  // wave shuffles, then the waves' sums in wave order
 #pragma unroll
@@ -267,7 +316,7 @@ __global__ void __launch_bounds__(fastg_max_threads<T>()) fastg_kernel(FastG p) 
         }
         // ---- unpack the packed rows in place: pairs (k, n - k), k <= n / 2; X[n] goes to column n
         if (packed) {
-            const int hp = n / 2 + 1, nb = ny * hp;
+            const int hp = n / 2 + 1, nb = nyv * hp;
             const float inv_hp = 1.0f / (float)hp;
             for (int w = tid; w < nb; w += nthr) {
                 const int i = fdiv(w, inv_hp), k = w - i * hp;
@@ -302,7 +351,8 @@ __global__ void __launch_bounds__(fastg_max_threads<T>()) fastg_kernel(FastG p) 
         const CT* tileb = tile0 + ny * rs;  // (MODE 2)
         (void)tileb;
         // ---- out, in output order: (orow, ocol) <- F[ky][kx], or conj F[-ky][-kx] for kx > n (a real field's spectrum is Hermitian)
-        const int tot = ny * nx;
+        const int tot = nyv * nx;
+        const size_t obase = (size_t)slab * ((size_t)ny * (p.half ? nx / 2 + 1 : nx));
         const T sc = (T)p.scale;
         if (MODE != 0 && p.iso != nullptr) {
             // a bin per wave: lane l adds the samples l, l + 64, ... of the bin's list in float64, the lanes meet in a fixed shuffle tree -- no
@@ -333,7 +383,7 @@ __global__ void __launch_bounds__(fastg_max_threads<T>()) fastg_kernel(FastG p) 
             if (p.out == nullptr) continue;
         }
         if (p.half) {  // rows of n + 1 samples, kx = 0 .. n as they lie in the tile: no twin, no shift
-            const int W = nx / 2 + 1, toth = ny * W;
+            const int W = nx / 2 + 1, toth = nyv * W;
             const float inv_w = 1.0f / (float)W;
             for (int e = tid; e < toth; e += nthr) {
                 const int ky = fdiv(e, inv_w), kx = e - ky * W;
@@ -343,12 +393,12 @@ __global__ void __launch_bounds__(fastg_max_threads<T>()) fastg_kernel(FastG p) 
                 if (MODE == 1) {
                     T pw = (v.re * v.re + v.im * v.im) * sc;
                     if (p.realdim2 && kx != 0 && 2 * kx != nx) pw *= (T)2;
-                    reinterpret_cast<T*>(p.out)[(size_t)slab * toth + e] = pw;
+                    reinterpret_cast<T*>(p.out)[obase + e] = pw;
                 } else {
                     CT o = mk<T>(v.re * sc, v.im * sc);
                     if (MODE == 2 && p.realdim2 && kx != 0 && 2 * kx != nx) o = mk<T>(o.re * (T)2, o.im * (T)2);
-                    if (p.ph_on) o = cmul(o, cmul(reinterpret_cast<const CT*>(p.ph_y)[ky], reinterpret_cast<const CT*>(p.ph_x)[kx]));
-                    reinterpret_cast<CT*>(p.out)[(size_t)slab * toth + e] = o;
+                    if (p.ph_on) o = cmul(o, p.one_d ? reinterpret_cast<const CT*>(p.ph_x)[kx] : cmul(reinterpret_cast<const CT*>(p.ph_y)[ky], reinterpret_cast<const CT*>(p.ph_x)[kx]));
+                    reinterpret_cast<CT*>(p.out)[obase + e] = o;
                 }
             }
             continue;
@@ -358,17 +408,17 @@ __global__ void __launch_bounds__(fastg_max_threads<T>()) fastg_kernel(FastG p) 
             int ky = orow - p.shift_y; if (ky < 0) ky += ny;
             int kx = ocol - p.shift_x; if (kx < 0) kx += nx;
             const bool mir = packed && kx > n;
-            const int sy = mir ? (ky == 0 ? 0 : ny - ky) : ky, sx = mir ? nx - kx : kx;
+            const int sy = (mir && !p.one_d) ? (ky == 0 ? 0 : ny - ky) : ky, sx = mir ? nx - kx : kx;  // (one_d: a row's twin is in the row)
             const int ps_ = (int)revy[sy] * rs + ((packed && sx == n) ? n : (int)revx[sx]);
             CT v = tile[ps_];
             if (MODE == 2) v = cmulc(v, tileb[ps_]);  // F0 conj(F1); its Hermitian twin is the conjugate, like a spectrum's
             if (MODE == 1) {
                 const T pw = (v.re * v.re + v.im * v.im) * sc;
-                reinterpret_cast<T*>(p.out)[(size_t)slab * tot + e] = pw;
+                reinterpret_cast<T*>(p.out)[obase + e] = pw;
             } else {
                 CT o = mk<T>(v.re * sc, (mir ? -v.im : v.im) * sc);
-                if (p.ph_on) o = cmul(o, cmul(reinterpret_cast<const CT*>(p.ph_y)[ky], reinterpret_cast<const CT*>(p.ph_x)[kx]));
-                reinterpret_cast<CT*>(p.out)[(size_t)slab * tot + e] = o;
+                if (p.ph_on) o = cmul(o, p.one_d ? reinterpret_cast<const CT*>(p.ph_x)[kx] : cmul(reinterpret_cast<const CT*>(p.ph_y)[ky], reinterpret_cast<const CT*>(p.ph_x)[kx]));
+                reinterpret_cast<CT*>(p.out)[obase + e] = o;
             }
         }
       }

@@ -337,6 +337,8 @@ struct xrfthip_plan {
     std::vector<int> g_rx, g_ry;
     DevBuf g_twx, g_twy, g_twr, g_revx, g_revy, g_isopos, g_isostart;
     std::vector<unsigned> g_hrevx, g_hrevy;  // (host copies: the radial-sum lists are built from them when the bin map arrives)
+    bool g_one_d = false;  // ... the same kernel on groups of g_rows ROWS of a 1-D transform along x (no y passes, a mean / line per row)
+    int g_rows = 0, g_lpr = 1, g_nred = 0;
     int g_rs = 0, g_n = 0;  // LDS row stride; length of the x transforms: nx / 2 (rows packed in pairs of samples) or nx (an odd nx)
     bool g_packed = true;
     // ... and ONE pass for one transform axis that is not the contiguous one (XRFTHIP_AXIS_Y), any smooth length, real input (fastg.h: fastgy_kernel)
@@ -1854,6 +1856,7 @@ static int run_fastmx(const xrfthip_plan* P, const void* in, const void* in1, vo
 static int fastg_rev(const std::vector<int>& radix, int n, DevBuf& buf, std::vector<unsigned>& host) {  // rev[k] = position of frequency k after the DIF passes (as build_tables)
     std::vector<unsigned> rev((size_t)std::max(n, 1));
     for (int pos = 0; pos < n; ++pos) {
+        if (radix.empty()) { rev[(size_t)pos] = (unsigned)pos; continue; }  // (no passes: the identity)
         long long L = n, rem = pos, k = 0, mult = 1;
         for (int r : radix) {
             const long long m = L / r;
@@ -1869,35 +1872,45 @@ static int fastg_rev(const std::vector<int>& radix, int n, DevBuf& buf, std::vec
 }
 template <typename T> static int fastg_setup_t(xrfthip_plan* P) {
     const xrfthip_desc& d = P->d;
-    const int n = P->g_n, ny = (int)d.ny;
+    const int n = P->g_n, ny = P->g_one_d ? P->g_rows : (int)d.ny;
     int rc = build_twiddle<T>(P->g_twx, n, n);
     if (!rc) rc = build_twiddle<T>(P->g_twy, ny, ny);
     if (!rc && P->g_packed) rc = build_twiddle<T>(P->g_twr, d.nx, n + 1);
     if (!rc) rc = fastg_rev(P->g_rx, n, P->g_revx, P->g_hrevx);
-    if (!rc) rc = fastg_rev(P->g_ry, ny, P->g_revy, P->g_hrevy);
+    if (!rc) rc = fastg_rev(P->g_ry, ny, P->g_revy, P->g_hrevy);  // (no passes: the identity)
     return rc;
 }
 static bool fastg_try(xrfthip_plan* P) {  // can the slab's half spectrum live in the LDS of one workgroup, and are both lengths smooth?
     const xrfthip_desc& d = P->d;
-    if (d.ndim != 2 || P->cplx_in || d.nx < 3 || d.ny < 2 || d.nx > 4096 || d.ny > 4096) return false;
+    const bool one_d = d.ndim == 1;
+    if ((d.ndim != 2 && !one_d) || P->cplx_in || d.nx < 3 || (!one_d && d.ny < 2) || d.nx > (one_d ? 16384 : 4096) || d.ny > 4096) return false;
     // an even nx: the rows packed in pairs of samples, the half spectrum (nx / 2 + 1 columns) in the tile; an odd nx: the rows as complex sequences with
     // zero imaginary parts, the whole spectrum in the tile (twice the LDS and the x passes' work: 75 x 75, 81 x 81, 125 x 125 boxes)
     const bool packed = !(d.nx & 1);
-    const int n = packed ? (int)(d.nx / 2) : (int)d.nx, ny = (int)d.ny;
+    const int n = packed ? (int)(d.nx / 2) : (int)d.nx;
     int rs = packed ? n + 1 : n;
     if (!(rs & 1)) ++rs;  // an odd row stride: the rows' passes and the gather of the output loop spread over the banks
+    // a 1-D transform along x: groups of rows as "slabs" without y passes -- as many rows as make a tile of ~24 KB (several workgroups per CU), 1 ... 256
+    int ny = (int)d.ny;
+    if (one_d) {
+        ny = (int)std::max<long long>(1, std::min<long long>(256, (24 * 1024) / ((long long)rs * (long long)P->csize)));
+        if (ny < 2) return false;  // (one long row per workgroup: the row tiles of the generic passes do as well -- (8192, 3000) float64 65 vs 46 GFFT/s)
+        ny = (int)std::min<long long>(ny, std::max<long long>(1, d.batch));
+    }
     const size_t nf = d.out_mode == XRFTHIP_OUT_CROSS ? 2 : 1;  // a cross spectrum holds both fields' tiles
-    const size_t lds = (((size_t)nf * ny * rs * P->csize + 15) & ~(size_t)15) + (size_t)(n + ny + n + 1) * P->csize + kFastGWaves * 3 * sizeof(double) +
+    const int nred = one_d ? std::max(2 * ny, kFastGWaves * 3) : kFastGWaves * 3;
+    const size_t lds = (((size_t)nf * ny * rs * P->csize + 15) & ~(size_t)15) + (size_t)(n + ny + n + 1) * P->csize + (size_t)nred * sizeof(double) +
                        (size_t)(ny + d.nx) * P->rsize + (((size_t)n * 2 + 3) & ~(size_t)3) + (size_t)ny * 2 + 16;  // the tile + the plan's tables, the windows + the wave sums
     if (lds > kLdsMax - 1024) return false;
     bool gx = false, gy = false;
     std::vector<int> rx, ry;
     if (n == 1) rx.clear(); else if (factorize(n, rx, gx) || gx) return false;
-    if (factorize(ny, ry, gy) || gy) return false;
+    if (!one_d && (factorize(ny, ry, gy) || gy)) return false;
     if ((int)rx.size() > kFastGMaxPasses || (int)ry.size() > kFastGMaxPasses) return false;
     for (int r : rx) if (r > 16) return false;
     for (int r : ry) if (r > 16) return false;
     P->g_rx = rx; P->g_ry = ry; P->g_rs = rs; P->g_lds = lds; P->g_n = n; P->g_packed = packed;
+    P->g_one_d = one_d; P->g_rows = ny; P->g_nred = nred;
     return true;
 }
 // fastg radial sums: per bin the LDS positions of its samples, in (ky, kx) order -- any bin map (a sample with kx > nx/2 lives at its Hermitian twin's
@@ -2042,7 +2055,9 @@ static int run_fastg(const xrfthip_plan* P, const void* in, const void* in_b, vo
     const xrfthip_desc& d = P->d;
     FastG p{};
     p.in = in; p.in_b = in_b; p.out = out; p.nslabs = d.batch;
-    p.ny = (int)d.ny; p.nx = (int)d.nx; p.n = P->g_n; p.rs = P->g_rs; p.packed = P->g_packed ? 1 : 0;
+    p.ny = P->g_one_d ? P->g_rows : (int)d.ny; p.nx = (int)d.nx; p.n = P->g_n; p.rs = P->g_rs; p.packed = P->g_packed ? 1 : 0;
+    p.one_d = P->g_one_d ? 1 : 0; p.nrows = d.batch; p.nred = P->g_nred;
+    if (P->g_one_d) p.nslabs = (d.batch + P->g_rows - 1) / P->g_rows;
     p.nrx = (int)P->g_rx.size(); p.nry = (int)P->g_ry.size();
     for (int i = 0; i < p.nrx; ++i) p.rx[i] = P->g_rx[(size_t)i];
     for (int i = 0; i < p.nry; ++i) p.ry[i] = P->g_ry[(size_t)i];
@@ -2066,8 +2081,13 @@ static int run_fastg(const xrfthip_plan* P, const void* in, const void* in_b, vo
     p.realdim2 = (d.flags & XRFTHIP_REALDIM_X2) ? 1 : 0;
     p.scale = d.scale;
     const long long thr = fastg_threads(P);
-    const dim3 grid((unsigned)std::min<long long>(d.batch, 0x7fffffffLL)), blk((unsigned)thr);
-    xrfthip_plan::ProfRec* rec = prof_begin(P, "fastg_slab", st);
+    {   // (one_d) lanes that share a row in the per-row sums: a power of two, <= 64, <= threads / rows
+        int lpr = 1;
+        while (lpr * 2 <= 64 && (long long)lpr * 2 * p.ny <= thr) lpr *= 2;
+        p.lpr = lpr;
+    }
+    const dim3 grid((unsigned)std::min<long long>(p.nslabs, 0x7fffffffLL)), blk((unsigned)thr);
+    xrfthip_plan::ProfRec* rec = prof_begin(P, P->g_one_d ? "fastg_rows" : "fastg_slab", st);
 #define GL_(TT, MM) do { auto k = &fastg_kernel<TT, MM>; XRFT_LAUNCH(k, grid, blk, P->g_lds, st, p); } while (0)
     if (P->dbl) { if (cross) GL_(double, 2); else if (cplx) GL_(double, 0); else GL_(double, 1); }
     else { if (cross) GL_(float, 2); else if (cplx) GL_(float, 0); else GL_(float, 1); }
@@ -2589,13 +2609,15 @@ int xrfthip_plan_create(xrfthip_plan** plan, const xrfthip_desc* desc) {
                              (d.out_mode == XRFTHIP_OUT_COMPLEX ? (XRFTHIP_ISHIFT_Y | XRFTHIP_ISHIFT_X)
                               : d.out_mode == XRFTHIP_OUT_CROSS ? (XRFTHIP_ISHIFT_Y | XRFTHIP_ISHIFT_X | XRFTHIP_REALDIM_X2 | XRFTHIP_ISO | XRFTHIP_NO_SPECTRUM_OUT)  // (no flipped field: the other paths)
                               : (XRFTHIP_ISO | XRFTHIP_NO_SPECTRUM_OUT | XRFTHIP_REALDIM_X2));
-        P->fastg = !P->fasts && !P->fast4096 && !P->fastm && (d.out_mode == XRFTHIP_OUT_POWER || d.out_mode == XRFTHIP_OUT_COMPLEX || d.out_mode == XRFTHIP_OUT_CROSS) && !(d.flags & ~okg) &&
+        // (a 1-D transform along x that neither the register kernels nor the table lengths take: the same kernel on groups of rows)
+        const bool one_ok = d.ndim != 1 || (!P->fastr && !P->fastmx && !P->fast1d && d.out_mode != XRFTHIP_OUT_CROSS && !(d.flags & (XRFTHIP_ISO | XRFTHIP_SHIFT_Y | XRFTHIP_ISHIFT_Y)));
+        P->fastg = one_ok && !P->fasts && !P->fast4096 && !P->fastm && (d.out_mode == XRFTHIP_OUT_POWER || d.out_mode == XRFTHIP_OUT_COMPLEX || d.out_mode == XRFTHIP_OUT_CROSS) && !(d.flags & ~okg) &&
                    !((d.flags & XRFTHIP_HALF_X) && (d.flags & (XRFTHIP_ISO | XRFTHIP_SHIFT_X | XRFTHIP_SHIFT_Y))) &&
                    !env_ll("XRFTHIP_NO_FAST", 0) && env_ll("XRFTHIP_FASTG", 1) != 0 && fastg_try(P);
         if (P->fastg) {
             int rcg = P->dbl ? fastg_setup_t<double>(P) : fastg_setup_t<float>(P);
-            std::vector<double> ones((size_t)std::max(d.ny, d.nx), 1.0);
-            std::vector<float> onesf((size_t)std::max(d.ny, d.nx), 1.0f);
+            std::vector<double> ones((size_t)std::max<long long>(std::max(d.ny, d.nx), P->g_rows), 1.0);
+            std::vector<float> onesf(ones.size(), 1.0f);
             if (!rcg) rcg = P->dbl ? P->ones4096.upload(ones.data(), ones.size() * sizeof(double)) : P->ones4096.upload(onesf.data(), onesf.size() * sizeof(float));
             if (rcg) { delete P; return rcg; }
         }
@@ -2748,7 +2770,12 @@ int xrfthip_plan_describe(const xrfthip_plan* plan, char* buf, size_t buflen) {
         std::string rxs, rys;
         for (int r : plan->g_rx) rxs += (rxs.empty() ? "" : "x") + std::to_string(r);
         for (int r : plan->g_ry) rys += (rys.empty() ? "" : "x") + std::to_string(r);
-        if (plan->g_packed)
+        if (plan->g_one_d)
+            appendf(s, "  [fastg rows] one pass, one %d-thread workgroup per %d rows of %lld samples%s: in LDS, radices from the plan (x: %d = %s), a mean / line per row in the "
+                       "workgroup, output gathered in output order through the digit-reversal table, lds=%zuB\n",
+                    (int)fastg_threads(plan), plan->g_rows, (long long)plan->d.nx, plan->g_packed ? " packed in pairs" : " (an odd length: complex sequences)", plan->g_n,
+                    rxs.empty() ? "1" : rxs.c_str(), plan->g_lds);
+        else if (plan->g_packed)
             appendf(s, "  [fastg] one pass, one %d-thread workgroup per %lld x %lld slab: the half spectrum (%lld rows of %lld + 1 complex) in LDS, radices from the plan "
                        "(x: %lld = %s on packed rows, y: %lld = %s), exact plane detrend in the workgroup, output gathered in output order through the digit-reversal "
                        "tables, lds=%zuB\n",
