@@ -793,6 +793,17 @@ def run_yonly_any_length_cases(shape=(3, 96, 40), dtype="float32"):
     for kw in (dict(detrend="linear", window="hann"), dict(shift=False, scaling="spectrum", detrend="constant"), dict()):
         worst = max(worst, check_values(xa.power_spectrum(da, dim=["y"], **kw), o.power_spectrum(od_det if "detrend" in kw else od, dim=["y"], **kw), tol))
         assert on_fast(), kw
+    # complex input (the later stages of N-D transforms, xrft.fft of complex data): one sequence per column, any column count
+    cdt = "complex128" if dtype == "float64" else "complex64"
+    z = (a + 1j * _cube(rng, shape, dtype)).astype(cdt)[:, :, : max(1, shape[2] - 1)]  # (an odd column count where the shape allows)
+    cz = _coords3((shape[0], shape[1], z.shape[2]), y0=2.5, x0=-1.0)
+    dz, oz = pair(z, D3, cz)
+    oz_det = oz if dtype == "float64" else o.OArr(z.astype("complex128"), D3, cz)
+    for kw in (dict(), dict(detrend="linear", window="hann", shift=False)):
+        worst = max(worst, check_values(xa.fft(dz, dim=["y"], **kw), o.fft(oz_det if "detrend" in kw else oz, dim=["y"], **kw), tol))
+        assert on_fast(), kw
+    worst = max(worst, check_values(xa.power_spectrum(dz, dim=["y"], detrend="constant"), o.power_spectrum(oz_det, dim=["y"], detrend="constant"), tol))
+    assert on_fast()
     # the same samples with the transform axis FIRST, (time, y, x): columns = y x
     at = np.ascontiguousarray(a.transpose(1, 0, 2))
     ct = {"time": np.arange(shape[1]) * 0.5 + 2.5, "y": np.arange(shape[0]) * 1.0, "x": np.arange(shape[2]) * 2.0}

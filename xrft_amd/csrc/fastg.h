@@ -456,6 +456,7 @@ struct FastGY {
     const void* blue_c;  // c[k], k < ny (complex T)
     const void* blue_b;  // FFT_m(chirp kernel) / m at the row the forward passes leave each frequency
     int tw_lds;          // the twiddles of the passes are staged in LDS (always, unless a Bluestein tile leaves no room)
+    int cin;             // the input is COMPLEX T (the later stages of N-D transforms, xrft.fft of complex data): one sequence per column, G columns per workgroup, no split
 };
 
 // MODE 1: power spectrum (real T out), 0: complex spectrum; BLUE: the Bluestein form (its inverse passes cost the plain form 25 registers: a kernel of its own)
@@ -464,7 +465,8 @@ __global__ void __launch_bounds__(256) fastgy_kernel(FastGY p) {
     typedef C2<T> CT;
     XRFT_DYN_SMEM(smem_raw);
     CT* tile = reinterpret_cast<CT*>(smem_raw);
-    const int tid = threadIdx.x, nthr = blockDim.x, ny = p.ny, nx = p.nx, G = p.G, lg = p.lg, C = 2 * G;
+    const int tid = threadIdx.x, nthr = blockDim.x, ny = p.ny, nx = p.nx, G = p.G, lg = p.lg;
+    int C = 2 * G;  // columns of a unit
     const int nrow = BLUE ? p.blue_m : ny;  // rows of the tile = length of the passes
     unsigned char* tb = smem_raw + (((size_t)nrow * G * sizeof(CT) + 15) & ~(size_t)15);
     double* part = reinterpret_cast<double*>(tb); tb += (size_t)nthr * 4 * sizeof(double);  // [row group][g][4]
@@ -481,18 +483,21 @@ __global__ void __launch_bounds__(256) fastgy_kernel(FastGY p) {
         if (p.win_y) wys[k] = reinterpret_cast<const T*>(p.win_y)[k];
     }
     const int g = tid & (G - 1), rq = tid >> lg, RQ = nthr >> lg;  // (lane along the sequences, row group)
+    const int cpg = p.cin ? 1 : 2, lc = p.cin ? lg : lg + 1;        // real columns per sequence; log2 of the columns of a unit
+    C = G * cpg;
     const T sc = (T)p.scale;
     const double ibar = 0.5 * (ny - 1);
     for (long long unit = blockIdx.x; unit < p.nunits; unit += gridDim.x) {
         const long long b = unit / p.nblk;
         const int c0 = (int)(unit - b * p.nblk) * C;
-        const bool live = c0 + 2 * g < nx;  // (nx is even: a pair of columns is whole or absent)
-        const T* __restrict__ src = reinterpret_cast<const T*>(p.in) + (size_t)b * ny * nx + c0 + 2 * g;
+        const bool live = c0 + cpg * g < nx;  // (real input: nx is even, a pair of columns is whole or absent)
+        const T* __restrict__ src = reinterpret_cast<const T*>(p.in) + ((size_t)b * ny * nx + c0 + cpg * g) * (p.cin ? 2 : 1);
+        const size_t rowstep = (size_t)nx * (p.cin ? 2 : 1);  // (in T elements)
         __syncthreads();  // (the previous unit's output loop is done with the tile; the tables are in place)
         // ---- load (rows rq, rq + RQ, ... of sequence g); without a detrend the window rides along
         double s[4] = {0.0, 0.0, 0.0, 0.0};
         for (int i = rq; i < ny; i += RQ) {
-            CT z = live ? *reinterpret_cast<const CT*>(src + (size_t)i * nx) : mk<T>((T)0, (T)0);
+            CT z = live ? *reinterpret_cast<const CT*>(src + (size_t)i * rowstep) : mk<T>((T)0, (T)0);
             if (p.detrend) {
                 const double ri = (double)i - ibar;
                 s[0] += (double)z.re; s[2] += (double)z.im;
@@ -556,15 +561,20 @@ __global__ void __launch_bounds__(256) fastgy_kernel(FastGY p) {
             __syncthreads();
         }
         // ---- out: row orow of the C columns = frequency k of the two spectra packed in every sequence
-        const int tot = ny << (lg + 1);
+        const int tot = ny << lc;
         for (int e = tid; e < tot; e += nthr) {
-            const int orow = e >> (lg + 1), c = e & (C - 1), col = c0 + c;
+            const int orow = e >> lc, c = e & (C - 1), col = c0 + c;
             if (col >= nx) continue;
             int k = orow - p.shift_y; if (k < 0) k += ny;
             const int km = k == 0 ? 0 : ny - k;
-            const CT zk = tile[(BLUE ? k : (int)revy[k]) * G + (c >> 1)], zm = tile[(BLUE ? km : (int)revy[km]) * G + (c >> 1)];
-            const CT v = (c & 1) ? mk<T>((T)0.5 * (zk.im + zm.im), (T)0.5 * (zm.re - zk.re))   // (Zk - conj Zm) / 2i
-                                 : mk<T>((T)0.5 * (zk.re + zm.re), (T)0.5 * (zk.im - zm.im));  // (Zk + conj Zm) / 2
+            CT v;
+            if (p.cin) {
+                v = tile[(BLUE ? k : (int)revy[k]) * G + c];
+            } else {
+                const CT zk = tile[(BLUE ? k : (int)revy[k]) * G + (c >> 1)], zm = tile[(BLUE ? km : (int)revy[km]) * G + (c >> 1)];
+                v = (c & 1) ? mk<T>((T)0.5 * (zk.im + zm.im), (T)0.5 * (zm.re - zk.re))   // (Zk - conj Zm) / 2i
+                            : mk<T>((T)0.5 * (zk.re + zm.re), (T)0.5 * (zk.im - zm.im));  // (Zk + conj Zm) / 2
+            }
             const size_t o = ((size_t)b * ny + orow) * nx + col;
             if (MODE == 1) {
                 reinterpret_cast<T*>(p.out)[o] = (v.re * v.re + v.im * v.im) * sc;

@@ -1942,7 +1942,7 @@ static int fastg_build_iso(xrfthip_plan* P, const int32_t* bm) {
 // the widest power of two (<= 128 bytes of a row) whose tile leaves three workgroups on a CU, or the widest that fits at all
 static bool fastgy_try(xrfthip_plan* P) {
     const xrfthip_desc& d = P->d;
-    if (d.ndim != 2 || P->cplx_in || (d.nx & 1) || d.ny < 2 || d.ny > 16384 || d.batch * ((d.nx + 3) / 4) >= (1LL << 31)) return false;
+    if (d.ndim != 2 || (!P->cplx_in && (d.nx & 1)) || d.ny < 2 || d.ny > 16384 || d.batch * ((d.nx + 3) / 4) >= (1LL << 31)) return false;
     bool gy = false;
     std::vector<int> ry;
     long long m = d.ny;  // rows of the tile = length of the passes: ny, or the Bluestein length when a prime factor of ny has no butterfly
@@ -2010,7 +2010,9 @@ static int run_fastgy(const xrfthip_plan* P, const void* in, void* out, hipStrea
     FastGY p{};
     p.in = in; p.out = out;
     p.ny = (int)d.ny; p.nx = (int)d.nx; p.G = P->gy_G; p.lg = ilog2i(P->gy_G);
-    p.nblk = (int)((d.nx + 2 * P->gy_G - 1) / (2 * P->gy_G));
+    p.cin = P->cplx_in ? 1 : 0;
+    const int ucols = (P->cplx_in ? 1 : 2) * P->gy_G;  // columns of a unit
+    p.nblk = (int)((d.nx + ucols - 1) / ucols);
     p.nunits = d.batch * p.nblk;
     p.nry = (int)P->g_ry.size();
     for (int i = 0; i < p.nry; ++i) p.ry[i] = P->g_ry[(size_t)i];
