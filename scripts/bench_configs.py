@@ -108,6 +108,28 @@ del x, da
 # a length with large prime factors: the ERA5 grid (721 = 7 x 103 latitudes) -- Bluestein in the column tile
 x = cube((64, 721, 1440), torch.float32); da = xrft.DataArray(x, ("t", "lat", "lon"), {"lat": np.arange(721) * .25, "lon": np.arange(1440) * .25})
 add("PS (64,721,1440) f32 linear+hann (ERA5 grid; Bluestein inside the column tile, float32)", x.numel(), 8, timeit(lambda: xrft.power_spectrum(da, dim=["lat", "lon"], detrend="linear", window="hann")))
+del x, da
+# round 4: lengths as data (csrc/fastg.h) -- small slabs of any smooth shape, one transform axis on any smooth length
+for shape, dt in (((14400, 50, 50), torch.float32), ((14400, 50, 50), torch.float64), ((8192, 96, 96), torch.float32), ((14400, 45, 45), torch.float32), ((2048, 150, 150), torch.float32)):
+    x = cube(shape, dt); da = xrft.DataArray(x, ("t", "y", "x"), {"y": np.arange(float(shape[1])), "x": np.arange(float(shape[2]))})
+    tag, bpp = ("f32" if dt == torch.float32 else "f64"), (8 if dt == torch.float32 else 16)
+    add(f"PS {shape} {tag} linear+hann (small boxes, one pass)", x.numel(), bpp, timeit(lambda: xrft.power_spectrum(da, dim=["y", "x"], detrend="linear", window="hann")))
+    if shape[1] == 50:
+        add(f"   isotropic PS {shape} {tag}", x.numel(), bpp // 2, timeit(lambda: xrft.isotropic_power_spectrum(da, dim=["y", "x"], detrend="linear", window="hann")))
+        db = xrft.DataArray(torch.roll(x, 3, dims=2) * 0.5, ("t", "y", "x"), {"y": np.arange(float(shape[1])), "x": np.arange(float(shape[2]))})
+        add(f"   cross_spectrum 2x{shape} {tag}", x.numel(), 2 * bpp, timeit(lambda: xrft.cross_spectrum(da, db, dim=["y", "x"], detrend="linear", window="hann")))
+        del db
+    del x, da
+for shape, dt in (((96, 512, 512), torch.float32), ((250, 512, 512), torch.float32), ((250, 256, 512), torch.float64), ((365, 512, 512), torch.float32), ((1460, 128, 256), torch.float64)):
+    x = cube(shape, dt); da = xrft.DataArray(x, ("time", "y", "x"), {"time": np.arange(float(shape[0]))})
+    tag, bpp = ("f32" if dt == torch.float32 else "f64"), (8 if dt == torch.float32 else 16)
+    add(f"power_spectrum along time of (time, y, x) = {shape} {tag}, linear+hann", x.numel(), bpp, timeit(lambda: xrft.power_spectrum(da, dim="time", detrend="linear", window="hann")))
+    del x, da
+for shape, dt in (((131072, 250), torch.float32), ((65536, 96), torch.float32), ((65536, 50), torch.float64)):
+    x = cube(shape, dt); da = xrft.DataArray(x, ("t", "x"), {"x": np.arange(float(shape[1]))})
+    tag, bpp = ("f32" if dt == torch.float32 else "f64"), (8 if dt == torch.float32 else 16)
+    add(f"power_spectrum 1-D {shape} {tag} linear+hann (a length outside the tables)", x.numel(), bpp, timeit(lambda: xrft.power_spectrum(da, dim="x", detrend="linear", window="hann")))
+    del x, da
 print(f"{'workload':58s} {'GFFT/s':>8s} {'ms':>9s} {'B/pt':>5s} {'frac of 8 TB/s':>15s}  path")
 for name, g, t, bpp, frac, path in rows:
     print(f"{name:58s} {g:8.2f} {t*1e3:9.3f} {bpp:5.0f} {frac:15.3f}  {path}")
