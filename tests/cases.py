@@ -804,6 +804,24 @@ def run_yonly_any_length_cases(shape=(3, 96, 40), dtype="float32"):
         assert on_fast(), kw
     worst = max(worst, check_values(xa.power_spectrum(dz, dim=["y"], detrend="constant"), o.power_spectrum(oz_det, dim=["y"], detrend="constant"), tol))
     assert on_fast()
+    # two fields: cross spectrum and cross phase along the axis (a column of each field = the two halves of one packed sequence; any column count)
+    b2 = _cube(rng, shape, dtype)[:, :, : max(1, shape[2] - 1)]
+    a2 = a[:, :, : b2.shape[2]]
+    c2a, c2b = _coords3(a2.shape, y0=2.5, x0=-1.0), _coords3(a2.shape, y0=-1.5, x0=-1.0)
+    d2a, o2a = pair(a2, D3, c2a)
+    d2b, o2b = pair(b2, D3, c2b)
+    o2a_det = o2a if dtype == "float64" else o.OArr(a2.astype("float64"), D3, c2a)
+    o2b_det = o2b if dtype == "float64" else o.OArr(b2.astype("float64"), D3, c2b)
+    for kw in (dict(detrend="linear", window="hann"), dict(true_phase=False, shift=False, scaling="spectrum")):
+        det = "detrend" in kw
+        worst = max(worst, check_values(xa.cross_spectrum(d2a, d2b, dim=["y"], **kw), o.cross_spectrum(o2a_det if det else o2a, o2b_det if det else o2b, dim=["y"], **kw), tol))
+        assert on_fast(), kw
+    gph = xa.cross_phase(d2a, d2b, dim=["y"], detrend="constant")
+    rph = o.cross_phase(o2a, o2b, dim=["y"], detrend="constant")
+    assert on_fast()
+    dphi = np.abs(np.angle(np.exp(1j * (gph.values - rph.values))))
+    mag = np.abs(o.cross_spectrum(o2a, o2b, dim=["y"], detrend="constant").values)
+    assert (dphi * mag).max() / mag.max() < (1e-10 if dtype == "float64" else 3e-4), (dphi * mag).max() / mag.max()
     # the same samples with the transform axis FIRST, (time, y, x): columns = y x
     at = np.ascontiguousarray(a.transpose(1, 0, 2))
     ct = {"time": np.arange(shape[1]) * 0.5 + 2.5, "y": np.arange(shape[0]) * 1.0, "x": np.arange(shape[2]) * 2.0}

@@ -457,6 +457,8 @@ struct FastGY {
     const void* blue_b;  // FFT_m(chirp kernel) / m at the row the forward passes leave each frequency
     int tw_lds;          // the twiddles of the passes are staged in LDS (always, unless a Bluestein tile leaves no room)
     int cin;             // the input is COMPLEX T (the later stages of N-D transforms, xrft.fft of complex data): one sequence per column, G columns per workgroup, no split
+    const void* in_b;    // two real fields (cross spectrum / cross phase along the axis, xrft.py:753-874): column c of `in` and of `in_b` are the real and the
+    int two, angle;      // imaginary part of sequence c -- G columns per workgroup; the result is F(in) conj F(in_b) (MODE 0), or its phase as real T (angle)
 };
 
 // MODE 1: power spectrum (real T out), 0: complex spectrum; BLUE: the Bluestein form (its inverse passes cost the plain form 25 registers: a kernel of its own)
@@ -483,7 +485,8 @@ __global__ void __launch_bounds__(256) fastgy_kernel(FastGY p) {
         if (p.win_y) wys[k] = reinterpret_cast<const T*>(p.win_y)[k];
     }
     const int g = tid & (G - 1), rq = tid >> lg, RQ = nthr >> lg;  // (lane along the sequences, row group)
-    const int cpg = p.cin ? 1 : 2, lc = p.cin ? lg : lg + 1;        // real columns per sequence; log2 of the columns of a unit
+    const bool one_col = p.cin || p.two;                            // a sequence is ONE column (complex input, or a column of each of two fields)
+    const int cpg = one_col ? 1 : 2, lc = one_col ? lg : lg + 1;    // columns per sequence; log2 of the columns of a unit
     C = G * cpg;
     const T sc = (T)p.scale;
     const double ibar = 0.5 * (ny - 1);
@@ -497,7 +500,11 @@ __global__ void __launch_bounds__(256) fastgy_kernel(FastGY p) {
         // ---- load (rows rq, rq + RQ, ... of sequence g); without a detrend the window rides along
         double s[4] = {0.0, 0.0, 0.0, 0.0};
         for (int i = rq; i < ny; i += RQ) {
-            CT z = live ? *reinterpret_cast<const CT*>(src + (size_t)i * rowstep) : mk<T>((T)0, (T)0);
+            CT z = mk<T>((T)0, (T)0);
+            if (live) {
+                if (p.two) z = mk<T>(src[(size_t)i * rowstep], (reinterpret_cast<const T*>(p.in_b) + ((size_t)b * ny * nx + c0 + g))[(size_t)i * rowstep]);
+                else z = *reinterpret_cast<const CT*>(src + (size_t)i * rowstep);
+            }
             if (p.detrend) {
                 const double ri = (double)i - ibar;
                 s[0] += (double)z.re; s[2] += (double)z.im;
@@ -570,6 +577,9 @@ __global__ void __launch_bounds__(256) fastgy_kernel(FastGY p) {
             CT v;
             if (p.cin) {
                 v = tile[(BLUE ? k : (int)revy[k]) * G + c];
+            } else if (p.two) {  // A = (Zk + conj Zm) / 2, B = (Zk - conj Zm) / 2i: A conj(B)
+                const CT zk = tile[(BLUE ? k : (int)revy[k]) * G + c], zm = tile[(BLUE ? km : (int)revy[km]) * G + c];
+                v = cmulc(mk<T>((T)0.5 * (zk.re + zm.re), (T)0.5 * (zk.im - zm.im)), mk<T>((T)0.5 * (zk.im + zm.im), (T)0.5 * (zm.re - zk.re)));
             } else {
                 const CT zk = tile[(BLUE ? k : (int)revy[k]) * G + (c >> 1)], zm = tile[(BLUE ? km : (int)revy[km]) * G + (c >> 1)];
                 v = (c & 1) ? mk<T>((T)0.5 * (zk.im + zm.im), (T)0.5 * (zm.re - zk.re))   // (Zk - conj Zm) / 2i
@@ -581,7 +591,8 @@ __global__ void __launch_bounds__(256) fastgy_kernel(FastGY p) {
             } else {
                 CT w = mk<T>(v.re * sc, v.im * sc);
                 if (p.ph_on) w = cmul(w, reinterpret_cast<const CT*>(p.ph_y)[k]);
-                reinterpret_cast<CT*>(p.out)[o] = w;
+                if (p.angle) reinterpret_cast<T*>(p.out)[o] = (T)atan2((double)w.im, (double)w.re);  // cross phase (xrft.py:838-874)
+                else reinterpret_cast<CT*>(p.out)[o] = w;
             }
         }
     }

@@ -1942,7 +1942,8 @@ static int fastg_build_iso(xrfthip_plan* P, const int32_t* bm) {
 // the widest power of two (<= 128 bytes of a row) whose tile leaves three workgroups on a CU, or the widest that fits at all
 static bool fastgy_try(xrfthip_plan* P) {
     const xrfthip_desc& d = P->d;
-    if (d.ndim != 2 || (!P->cplx_in && (d.nx & 1)) || d.ny < 2 || d.ny > 16384 || d.batch * ((d.nx + 3) / 4) >= (1LL << 31)) return false;
+    const bool two_f = d.out_mode == XRFTHIP_OUT_CROSS || d.out_mode == XRFTHIP_OUT_PHASE;
+    if (d.ndim != 2 || (!P->cplx_in && !two_f && (d.nx & 1)) || d.ny < 2 || d.ny > 16384 || d.batch * ((d.nx + 3) / 4) >= (1LL << 31)) return false;
     bool gy = false;
     std::vector<int> ry;
     long long m = d.ny;  // rows of the tile = length of the passes: ny, or the Bluestein length when a prime factor of ny has no butterfly
@@ -2005,13 +2006,15 @@ template <typename T> static int fastgy_blue_tables(xrfthip_plan* P) {
     if (!rc) rc = P->gy_blueb.upload(bh.data(), bh.size() * sizeof(C2<T>));
     return rc;
 }
-static int run_fastgy(const xrfthip_plan* P, const void* in, void* out, hipStream_t st) {
+static int run_fastgy(const xrfthip_plan* P, const void* in, const void* in_b, void* out, hipStream_t st) {
     const xrfthip_desc& d = P->d;
     FastGY p{};
     p.in = in; p.out = out;
+    const bool two = d.out_mode == XRFTHIP_OUT_CROSS || d.out_mode == XRFTHIP_OUT_PHASE;
+    p.in_b = in_b; p.two = two ? 1 : 0; p.angle = d.out_mode == XRFTHIP_OUT_PHASE ? 1 : 0;
     p.ny = (int)d.ny; p.nx = (int)d.nx; p.G = P->gy_G; p.lg = ilog2i(P->gy_G);
     p.cin = P->cplx_in ? 1 : 0;
-    const int ucols = (P->cplx_in ? 1 : 2) * P->gy_G;  // columns of a unit
+    const int ucols = ((P->cplx_in || two) ? 1 : 2) * P->gy_G;  // columns of a unit
     p.nblk = (int)((d.nx + ucols - 1) / ucols);
     p.nunits = d.batch * p.nblk;
     p.nry = (int)P->g_ry.size();
@@ -2019,7 +2022,7 @@ static int run_fastgy(const xrfthip_plan* P, const void* in, void* out, hipStrea
     p.tw_y = P->g_twy.p; p.rev_y = (const unsigned*)P->g_revy.p;
     p.blue_m = P->gy_blue_m; p.blue_c = P->gy_bluec.p; p.blue_b = P->gy_blueb.p; p.tw_lds = P->gy_tw_lds ? 1 : 0;
     p.win_y = P->win[0].p;
-    p.ph_y = P->fph[0].p; p.ph_on = (d.out_mode == XRFTHIP_OUT_COMPLEX && P->fph_on) ? 1 : 0;
+    p.ph_y = P->fph[0].p; p.ph_on = (d.out_mode != XRFTHIP_OUT_POWER && P->fph_on) ? 1 : 0;
     p.detrend = d.detrend;
     p.shift_y = (d.flags & XRFTHIP_SHIFT_Y) ? (int)(d.ny / 2) : 0;
     p.scale = d.scale;
@@ -2027,7 +2030,7 @@ static int run_fastgy(const xrfthip_plan* P, const void* in, void* out, hipStrea
     xrfthip_plan::ProfRec* rec = prof_begin(P, "fastg_yonly", st);
 #define GY_(TT, MM) do { if (P->gy_blue_m) { auto k = &fastgy_kernel<TT, MM, true>; XRFT_LAUNCH(k, grid, blk, P->gy_lds, st, p); } \
                          else { auto k = &fastgy_kernel<TT, MM, false>; XRFT_LAUNCH(k, grid, blk, P->gy_lds, st, p); } } while (0)
-    const bool cplx = d.out_mode == XRFTHIP_OUT_COMPLEX;
+    const bool cplx = d.out_mode != XRFTHIP_OUT_POWER;  // (complex spectrum, cross spectrum, cross phase: MODE 0)
     if (P->dbl) { if (cplx) GY_(double, 0); else GY_(double, 1); } else { if (cplx) GY_(float, 0); else GY_(float, 1); }
 #undef GY_
     prof_end(rec, st);
@@ -2581,8 +2584,9 @@ int xrfthip_plan_create(xrfthip_plan** plan, const xrfthip_desc* desc) {
         }
     }
     {   // ... on any other smooth length: one pass in LDS with the radices as data (fastg.h: fastgy_kernel)
-        const uint32_t allowed = XRFTHIP_AXIS_Y | XRFTHIP_SHIFT_Y | (d.out_mode == XRFTHIP_OUT_COMPLEX ? XRFTHIP_ISHIFT_Y : 0u);
-        P->fastgy = !P->fastmy && (d.flags & XRFTHIP_AXIS_Y) && (d.out_mode == XRFTHIP_OUT_COMPLEX || d.out_mode == XRFTHIP_OUT_POWER) && !(d.flags & ~allowed) &&
+        const bool two = d.out_mode == XRFTHIP_OUT_CROSS || d.out_mode == XRFTHIP_OUT_PHASE;  // (two REAL fields: a column of each = one packed sequence; no flipped field)
+        const uint32_t allowed = XRFTHIP_AXIS_Y | XRFTHIP_SHIFT_Y | (d.out_mode != XRFTHIP_OUT_POWER ? XRFTHIP_ISHIFT_Y : 0u);
+        P->fastgy = !P->fastmy && (d.flags & XRFTHIP_AXIS_Y) && (d.out_mode == XRFTHIP_OUT_COMPLEX || d.out_mode == XRFTHIP_OUT_POWER || (two && !cplx_in)) && !(d.flags & ~allowed) &&
                     !env_ll("XRFTHIP_NO_FAST", 0) && env_ll("XRFTHIP_FASTG", 1) != 0 && fastgy_try(P);
         if (P->fastgy) {
             const long long m = P->gy_blue_m ? P->gy_blue_m : d.ny;  // length of the passes
@@ -2881,7 +2885,7 @@ int xrfthip_exec(const xrfthip_plan* plan, const void* d_in0, const void* d_in1,
     if (P->fasts) return run_fasts(P, d_in0, out, (double*)d_iso, st);
     if (P->fastr) return run_fastr(P, d_in0, out, st);
     if (P->fastmx) return run_fastmx(P, d_in0, d_in1, out, st);
-    if (P->fastgy) return run_fastgy(P, d_in0, out, st);
+    if (P->fastgy) return run_fastgy(P, d_in0, d_in1, out, st);
     if (P->fastmy) return run_fastmy(P, d_in0, d_in1, out, st);
     if (P->fastm) return run_fastm(P, d_in0, d_in1, out, (double*)d_iso, ws, st);
     if (fasty_on(P)) {
