@@ -5,7 +5,7 @@
 //
 // Where fasts.h (float32, 64 | 128 | 256 points per axis) keeps a slab in registers with compile-time radices, this kernel keeps the slab's
 // half spectrum -- ny rows of nx/2 + 1 complex values -- in LDS and runs the radix passes of tile_fft.h over it with the radices of a
-// parameter block: any ny, nx = 2^a 3^b 5^c (nx even) whose half spectrum fits the LDS (19 000 complex64 / 9 500 complex128 values:
+// parameter block: any ny, nx = 2^a 3^b 5^c whose half spectrum fits the LDS (19 500 complex64 / 9 700 complex128 values:
 // 50 x 50, 96 x 96, 100 x 100, 120 x 240, 150 x 150, 180 x 90; in float64 also 64 ... 128 points per axis).  Before it these shapes took the
 // generic tile kernels in two passes through memory with a moments pass in front (50-115 GFFT/s in float32, 40-60 in float64).
 //
@@ -17,6 +17,12 @@
 //   y         the radix passes of length ny over the n + 1 columns (lanes along the columns: contiguous)
 //   out       every output sample in output order (coalesced stores): its source (ky, kx) or the Hermitian twin (-ky, -kx), looked up through
 //             the digit-reversal tables of the two axes; |F|^2 scale, or F scale x the true-phase factors (conjugated for the twin)
+//
+// The same kernel, by parameter: an ODD nx (rows as complex sequences, the whole spectrum in the tile); real_dim (the half spectrum as it lies);
+// the radial sums of isotropic_power_spectrum / isotropic_cross_spectrum (per-bin lists of LDS positions, any bin map, no atomics); MODE 2, the cross
+// spectrum of two fields (two tiles); `one_d`, 1-D transforms along x on groups of rows (no y passes, a mean / line per row).
+// fastgy_kernel (below): ONE transform axis that is NOT the contiguous one on any smooth length -- real columns packed in pairs, complex columns, two
+// real fields; Bluestein inside the tile for a prime factor that has no butterfly.
 #pragma once
 #include "tile_fft.h"
 #include "fastr.h"  // fastr_store4 / fastr_store8
