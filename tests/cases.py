@@ -912,6 +912,13 @@ def run_rows_any_length_cases(shape=(37, 250), dtype="float32"):
     for kw in (dict(detrend="linear", window="hann"), dict(shift=False, scaling="spectrum", detrend="constant"), dict(real_dim="x", window="hann"), dict()):
         worst = max(worst, check(xa.power_spectrum(da, dim=["x"], **kw), o.power_spectrum(od, dim=["x"], **kw), tol))
         assert on_fast(), kw
+    # two fields: the cross spectrum along the axis (both fields' rows in the workgroup's LDS)
+    w = (rng.standard_normal(shape) - 1.0).astype(dtype)
+    c2 = dict(c); c2["x"] = c["x"] + 1.25
+    db, ob = pair(w, dims, c2)
+    for kw in (dict(detrend="linear", window="hann"), dict(true_phase=False, shift=False), dict(real_dim="x", detrend="constant")):
+        worst = max(worst, check(xa.cross_spectrum(da, db, dim=["x"], **kw), o.cross_spectrum(od, ob, dim=["x"], **kw), tol))
+        assert on_fast(), kw
     return worst
 
 

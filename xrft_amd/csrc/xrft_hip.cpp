@@ -2616,7 +2616,7 @@ int xrfthip_plan_create(xrfthip_plan** plan, const xrfthip_desc* desc) {
                               : d.out_mode == XRFTHIP_OUT_CROSS ? (XRFTHIP_ISHIFT_Y | XRFTHIP_ISHIFT_X | XRFTHIP_REALDIM_X2 | XRFTHIP_ISO | XRFTHIP_NO_SPECTRUM_OUT)  // (no flipped field: the other paths)
                               : (XRFTHIP_ISO | XRFTHIP_NO_SPECTRUM_OUT | XRFTHIP_REALDIM_X2));
         // (a 1-D transform along x that neither the register kernels nor the table lengths take: the same kernel on groups of rows)
-        const bool one_ok = d.ndim != 1 || (!P->fastr && !P->fastmx && !P->fast1d && d.out_mode != XRFTHIP_OUT_CROSS && !(d.flags & (XRFTHIP_ISO | XRFTHIP_SHIFT_Y | XRFTHIP_ISHIFT_Y)));
+        const bool one_ok = d.ndim != 1 || (!P->fastr && !P->fastmx && !P->fast1d && !(d.flags & (XRFTHIP_ISO | XRFTHIP_SHIFT_Y | XRFTHIP_ISHIFT_Y)));
         P->fastg = one_ok && !P->fasts && !P->fast4096 && !P->fastm && (d.out_mode == XRFTHIP_OUT_POWER || d.out_mode == XRFTHIP_OUT_COMPLEX || d.out_mode == XRFTHIP_OUT_CROSS) && !(d.flags & ~okg) &&
                    !((d.flags & XRFTHIP_HALF_X) && (d.flags & (XRFTHIP_ISO | XRFTHIP_SHIFT_X | XRFTHIP_SHIFT_Y))) &&
                    !env_ll("XRFTHIP_NO_FAST", 0) && env_ll("XRFTHIP_FASTG", 1) != 0 && fastg_try(P);
