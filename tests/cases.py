@@ -804,6 +804,15 @@ def run_yonly_any_length_cases(shape=(3, 96, 40), dtype="float32"):
         assert on_fast(), kw
     worst = max(worst, check_values(xa.power_spectrum(dz, dim=["y"], detrend="constant"), o.power_spectrum(oz_det, dim=["y"], detrend="constant"), tol))
     assert on_fast()
+    # and back: xrft.ifft along the axis where it lies (conj in, conj out, the fftshifted input rotated on load, the lag's phase on the input)
+    import warnings
+
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        for kw in (dict(), dict(true_phase=False, shift=False), dict(true_phase=False), dict(shift=False)):
+            F, Fo = xa.fft(da, dim=["y"], **kw), o.fft(od, dim=["y"], **kw)
+            worst = max(worst, check_values(xa.ifft(F, dim=["freq_y"], **kw), o.ifft(Fo, dim=["freq_y"], **kw), tol))
+            assert on_fast(), kw
     # two fields: cross spectrum and cross phase along the axis (a column of each field = the two halves of one packed sequence; any column count)
     b2 = _cube(rng, shape, dtype)[:, :, : max(1, shape[2] - 1)]
     a2 = a[:, :, : b2.shape[2]]
@@ -885,6 +894,33 @@ def run_yonly_fast_cases(shape=(3, 360, 40), dtype="float64"):
     worst = max(worst, check(xa.power_spectrum(da.transpose("y", "time", "x"), dim=["y"], detrend="linear", window="hann"),
                              o.power_spectrum(od_det.transpose("y", "time", "x"), dim=["y"], detrend="linear", window="hann"), tol))
     assert on_fast()
+    return worst
+
+
+def run_inverse_one_pass_cases(shape=(2, 360, 250), dtype="float64"):
+    """xrft.ifft (xrft.py:479-646) on the one-pass kernels of csrc/fastg.h: a two-axis inverse transform as two one-axis stages (y where it lies, then the rows),
+    one axis along a first / middle axis with no transposed copy, along the contiguous axis, small slabs in one pass -- every true_phase / shift combination,
+    against the oracle."""
+    import warnings
+
+    rng = np.random.default_rng(79)
+    tol = TOL[dtype]
+    a = _cube(rng, shape, dtype)
+    da, od = pair(a, D3, _coords3(shape, y0=1.0, x0=-3.0))
+    worst = 0.0
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        for kw in (dict(), dict(true_phase=False, shift=False), dict(true_phase=False), dict(shift=False)):
+            F, Fo = xa.fft(da, dim=["y", "x"], **kw), o.fft(od, dim=["y", "x"], **kw)
+            xa.api._plan_cache.clear()
+            worst = max(worst, check_values(xa.ifft(F, dim=["freq_y", "freq_x"], **kw), o.ifft(Fo, dim=["freq_y", "freq_x"], **kw), tol))
+            tags = [p.describe() for p in xa.api._plan_cache.values()]
+            assert any("[fastg y-only]" in t for t in tags) and any("[fastg rows]" in t for t in tags) or any("[fastg] one pass" in t for t in tags), tags
+            for d, tag in (("y", "[fastg y-only]"), ("x", "[fastg rows]")):
+                F1, F1o = xa.fft(da, dim=[d], **kw), o.fft(od, dim=[d], **kw)
+                xa.api._plan_cache.clear()
+                worst = max(worst, check_values(xa.ifft(F1, dim=["freq_" + d], **kw), o.ifft(F1o, dim=["freq_" + d], **kw), tol))
+                assert any(tag in p.describe() for p in xa.api._plan_cache.values()), (d, kw)
     return worst
 
 

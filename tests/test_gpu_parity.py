@@ -1032,3 +1032,9 @@ def test_one_axis_not_contiguous_any_smooth_length(shape, dtype):
 def test_last_axis_any_smooth_length(shape, dtype):
     """fastg.h on groups of rows: 1-D spectra along the contiguous axis on lengths outside the tables."""
     cases.run_rows_any_length_cases(shape, dtype)
+
+
+@pytest.mark.parametrize("shape,dtype", [((4, 360, 250), "float64"), ((3, 1024, 1024), "float32"), ((5, 243, 125), "float32"), ((30, 50, 50), "float64"), ((2, 1440, 720), "float64")])
+def test_inverse_transforms_on_the_one_pass_kernels(shape, dtype):
+    """xrft.ifft over two axes as two one-pass stages, over one axis where it lies, small slabs in one pass (csrc/fastg.h)."""
+    cases.run_inverse_one_pass_cases(shape, dtype)

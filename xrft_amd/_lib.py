@@ -18,7 +18,8 @@ DETREND_NONE, DETREND_CONSTANT, DETREND_LINEAR = 0, 1, 2
 HALF_X, SHIFT_Y, SHIFT_X, ISHIFT_Y, ISHIFT_X, FLIP_Y, FLIP_X = 0x1, 0x2, 0x4, 0x8, 0x10, 0x20, 0x40
 REALDIM_X2, ISO, NO_SPECTRUM_OUT = 0x80, 0x100, 0x200
 INVERSE, C2R_X, PHASE_IN = 0x400, 0x800, 0x1000
-UNSUPPORTED_LENGTH = -2  # xrfthip_status
+BAD_ARG = -1  # xrfthip_status
+UNSUPPORTED_LENGTH = -2
 AXIS_Y = 0x2000  # transform y of [batch][ny][nx] in place (a middle or first axis of the array), no transposed copy
 FLIP0_Y, FLIP0_X = 0x4000, 0x8000  # cross spectra: flip field 0 (FLIP_Y / FLIP_X then flip field 1)
 

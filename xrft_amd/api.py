@@ -1014,6 +1014,14 @@ def ifft(daft, spacing_tol=1e-3, dim=None, real_dim=None, shift=True, true_phase
     t = _to_device(daft.data)
     if not t.is_complex():
         t = t.to(torch.complex64 if t.dtype == torch.float32 else torch.complex128)
+    if len(dim) == 1 and real_dim is None and daft.get_axis_num(xdim) != len(daft.dims) - 1 and maps[xdim] in ("none", "ishift"):
+        # one inverse transform along a first / middle axis: where the axis lies (XRFTHIP_AXIS_Y), no transposed copies -- as the forward call
+        out = _ifft_axis_y(t, daft.get_axis_num(xdim), maps[xdim], phase[xdim], true_phase, shift, true_amplitude, new_coords[swap[xdim]])
+        if out is not None:
+            coords = {kname: v for kname, v in daft.coords.items() if kname not in dim}
+            cv = new_coords[swap[xdim]]
+            coords[swap[xdim]] = Coordinate(cv.dims, cv.values + lag[0], cv.attrs, swap[xdim])
+            return to_like(DataArray(out, [swap.get(d, d) for d in rawdims], coords, None, None), src)
     tdims = ([ydim] if ydim is not None else []) + [xdim]
     other = [d for d in daft.dims if d not in tdims]
     order_dims = other + tdims
@@ -1064,10 +1072,14 @@ def ifft(daft, spacing_tol=1e-3, dim=None, real_dim=None, shift=True, true_phase
     if true_amplitude:  # xrft.py:641-642
         scale = scale / np.prod([float(new_coords[swap[d]].attrs["spacing"]) for d in dim])
     try:
-        plan = _get_plan(ndim=len(dim), batch=batch, ny=ny, nx=nx, dtype=t.dtype, out_mode=_lib.OUT_COMPLEX,
-                         detrend=_lib.DETREND_NONE, flags=flags, scale=float(scale), window_y=None, window_x=None,
-                         phase_y=ph["y"], phase_x=ph["x"])
-        out, _ = plan.execute(t)
+        out = None
+        if len(dim) == 2 and real_dim is None and not (flags & (_lib.FLIP_X | _lib.FLIP_Y)):
+            out = _ifft_two_stages(t, batch, ny, nx, flags, float(scale), ph)
+        if out is None:
+            plan = _get_plan(ndim=len(dim), batch=batch, ny=ny, nx=nx, dtype=t.dtype, out_mode=_lib.OUT_COMPLEX,
+                             detrend=_lib.DETREND_NONE, flags=flags, scale=float(scale), window_y=None, window_x=None,
+                             phase_y=ph["y"], phase_x=ph["x"])
+            out, _ = plan.execute(t)
     except _lib.XrftHipError as e:
         if e.status != _lib.UNSUPPORTED_LENGTH:
             raise
@@ -1113,6 +1125,73 @@ def ifft(daft, spacing_tol=1e-3, dim=None, real_dim=None, shift=True, true_phase
         cv = new_coords[swap[d]]
         coords[swap[d]] = Coordinate(cv.dims, cv.values + l, cv.attrs, swap[d])
     return to_like(DataArray(out, final, coords, None, None), src)
+
+
+def _ifft_two_stages(t, batch, ny, nx, flags, scale, ph):
+    """A two-axis inverse transform of complex (batch, ny, nx) data as two one-axis passes -- ifftn is separable (xrft.py:612-621) --: y where it lies
+    (XRFTHIP_AXIS_Y), then x along the rows.  Only when BOTH stages run on one-pass kernels (csrc/fastg.h) and the two-axis plan would not: the generic two-axis
+    passes take 30 GFFT/s, the two stages 100 each.  Returns None otherwise (the caller builds the two-axis plan)."""
+    if ny * nx > (1 << 31) - 1 or batch * ny * nx == 0:
+        return None
+    fy = _lib.AXIS_Y | _lib.INVERSE | (flags & (_lib.ISHIFT_Y | _lib.SHIFT_Y)) | (_lib.PHASE_IN if ph["y"] is not None else 0)
+    fx = _lib.INVERSE | (flags & (_lib.ISHIFT_X | _lib.SHIFT_X)) | (_lib.PHASE_IN if ph["x"] is not None else 0)
+    try:
+        whole = _get_plan(ndim=2, batch=batch, ny=ny, nx=nx, dtype=t.dtype, out_mode=_lib.OUT_COMPLEX, detrend=_lib.DETREND_NONE, flags=flags, scale=scale,
+                          window_y=None, window_x=None, phase_y=ph["y"], phase_x=ph["x"])
+        if "[fast" in whole.describe():
+            return None  # (a small slab: one pass over both axes)
+        py = _get_plan(ndim=2, batch=batch, ny=ny, nx=nx, dtype=t.dtype, out_mode=_lib.OUT_COMPLEX, detrend=_lib.DETREND_NONE, flags=fy, scale=1.0 / float(ny),
+                       window_y=None, window_x=None, phase_y=ph["y"], phase_x=None)
+        px = _get_plan(ndim=1, batch=batch * ny, ny=1, nx=nx, dtype=t.dtype, out_mode=_lib.OUT_COMPLEX, detrend=_lib.DETREND_NONE, flags=fx, scale=scale * float(ny),
+                       window_y=None, window_x=None, phase_y=None, phase_x=ph["x"])
+    except _lib.XrftHipError as e:
+        if e.status in (_lib.UNSUPPORTED_LENGTH, _lib.BAD_ARG):
+            return None
+        raise
+    if "[fastg" not in py.describe() or "[fastg" not in px.describe():
+        return None
+    mid, _ = py.execute(t.reshape(batch, ny, nx))
+    out, _ = px.execute(mid.reshape(batch * ny, 1, nx))
+    return out.reshape(t.shape)
+
+
+def _ifft_axis_y(t, k, imap, phase, true_phase, shift, true_amplitude, new_coord):
+    """ifft along axis k < last of the C-contiguous tensor ``t`` where the axis lies: (batch, n, inner) with XRFTHIP_AXIS_Y | XRFTHIP_INVERSE; None when no such
+    plan exists (the caller takes the transposing path).  The shifts as in ``ifft``: an fftshifted input is rotated on load, the output is fftshifted with the true
+    phase and shift, rolled afterwards in the one remaining case (xrft.py:612-621)."""
+    t = t.contiguous()
+    shape = list(t.shape)
+    n = shape[k]
+    inner = int(np.prod(shape[k + 1:], dtype=np.int64))
+    batch = int(np.prod(shape[:k], dtype=np.int64))
+    if n * inner > (1 << 31) - 1 or inner > (1 << 30) or batch * n * inner == 0:
+        return None
+    flags = _lib.AXIS_Y | _lib.INVERSE
+    if imap == "ishift":
+        flags |= _lib.ISHIFT_Y
+    if phase is not None:
+        flags |= _lib.PHASE_IN
+    roll = 0
+    if true_phase:
+        if shift:
+            flags |= _lib.SHIFT_Y
+    elif not shift:
+        roll = -(n // 2)  # only the ifftshift of the output remains
+    scale = 1.0 / float(n)
+    if true_amplitude:
+        scale = scale / float(new_coord.attrs["spacing"])
+    try:
+        plan = _get_plan(ndim=2, batch=batch, ny=n, nx=inner, dtype=t.dtype, out_mode=_lib.OUT_COMPLEX, detrend=_lib.DETREND_NONE, flags=flags,
+                         scale=float(scale), window_y=None, window_x=None, phase_y=phase, phase_x=None)
+    except _lib.XrftHipError as e:
+        if e.status in (_lib.UNSUPPORTED_LENGTH, _lib.BAD_ARG):
+            return None
+        raise
+    out, _ = plan.execute(t.reshape(batch, n, inner))
+    out = out.reshape(shape)
+    if roll:
+        out = engine.gather_axis(out, k, roll=roll)
+    return out
 
 
 def idft(daft, dim=None, true_phase=False, true_amplitude=False, **kwargs):

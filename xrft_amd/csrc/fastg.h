@@ -44,6 +44,10 @@ struct FastG {
     int lpr;            // ... lanes that share a row in the per-row sums (a power of two <= 64)
     int nred;           // doubles of the sums' scratch: 3 per wave (plane), 2 per row (one_d)
     long long nrows;
+    // complex input (xrft.fft of complex data, and every inverse transform: xrft.ifft, xrft.py:479-646): [slabs][ny][nx] complex T, the whole spectrum in the tile
+    // (packed = 0), no detrend.  inv: conj(FFT(conj(z))); ishy / ishx: sample (i, m) of the tile is source (i + ishy, m + ishx) mod (ny, nx) -- the ifftshift of an
+    // fftshifted spectrum; ph_in: the phase tables multiply the INPUT at its source position (the lag's phase, xrft.py:574-576)
+    int cin, inv, ishy, ishx, ph_in;
     int nrx, nry;
     int rx[kFastGMaxPasses], ry[kFastGMaxPasses];
     const void* tw_x;   // W_n^k,  k < n   (complex T)
@@ -202,7 +206,8 @@ __global__ void __launch_bounds__(fastg_max_threads<T>(), (sizeof(T) == 4 ? 4 : 
 #pragma unroll 1
       for (int f = 0; f < NF; ++f) {  // (a cross spectrum: field 0 into tile 0, field 1 into tile 1, the same code)
         CT* tile = tile0 + f * (ny * rs);
-        const CT* __restrict__ src = reinterpret_cast<const CT*>(reinterpret_cast<const T*>(f ? p.in_b : p.in) + (size_t)slab * ny * nx);
+        const CT* __restrict__ src = p.cin ? reinterpret_cast<const CT*>(p.in) + (size_t)slab * ny * nx  // (complex samples)
+                                           : reinterpret_cast<const CT*>(reinterpret_cast<const T*>(f ? p.in_b : p.in) + (size_t)slab * ny * nx);
         // ---- load; the plane's sums on the way (float64 per thread, then the threads in a fixed order)
         double s0 = 0.0, si = 0.0, sj = 0.0;
         const bool plane = p.detrend && !p.one_d;  // (the slab's plane; a 1-D transform fits a line per row below)
@@ -219,6 +224,19 @@ __global__ void __launch_bounds__(fastg_max_threads<T>(), (sizeof(T) == 4 ? 4 : 
                     sj += ((double)(2 * m) - jbar) * u + (double)z.im;
                 }
             }
+        } else if (p.cin) {  // (npk = ny nx complex samples)
+            const CT* __restrict__ wyc = reinterpret_cast<const CT*>(p.ph_y);
+            const CT* __restrict__ wxc = reinterpret_cast<const CT*>(p.ph_x);
+            for (int e = tid; e < npk; e += nthr) {
+                const int i = fdiv(e, inv_n), m = e - i * n;
+                int is = i + p.ishy; if (is >= ny) is -= ny;
+                int ms = m + p.ishx; if (ms >= nx) ms -= nx;
+                CT z = src[(size_t)is * nx + ms];
+                if (p.ph_in) z = cmul(z, p.one_d ? wxc[ms] : cmul(wyc[is], wxc[ms]));
+                if (p.inv) z.im = -z.im;
+                if (p.win_y) { const T w = (p.one_d ? (T)1 : wys[i]) * wxs[m]; z = mk<T>(z.re * w, z.im * w); }
+                tile[i * rs + m] = z;
+            }
         } else {  // (npk = ny nx real samples)
             const T* __restrict__ srcr = reinterpret_cast<const T*>(src);
             for (int e = tid; e < npk; e += nthr) {
@@ -232,7 +250,9 @@ __global__ void __launch_bounds__(fastg_max_threads<T>(), (sizeof(T) == 4 ? 4 : 
                 }
             }
         }
-        if (p.one_d && (p.detrend || p.win_y)) {
+        if (p.cin) {
+            // (complex input: the window rode on the load, there is no detrend)
+        } else if (p.one_d && (p.detrend || p.win_y)) {
             // per-row mean / least-squares line (scipy.signal.detrend along x, xrft/detrend.py:54-71): lpr lanes share a row (a power of two <= 64, so a
             // row's lanes sit in one wave), the lanes' float64 sums meet in a fixed shuffle tree; the rows in rounds
             __syncthreads();
@@ -422,7 +442,7 @@ __global__ void __launch_bounds__(fastg_max_threads<T>(), (sizeof(T) == 4 ? 4 : 
                 const T pw = (v.re * v.re + v.im * v.im) * sc;
                 reinterpret_cast<T*>(p.out)[obase + e] = pw;
             } else {
-                CT o = mk<T>(v.re * sc, (mir ? -v.im : v.im) * sc);
+                CT o = mk<T>(v.re * sc, ((mir != (p.inv != 0)) ? -v.im : v.im) * sc);  // (the twin's conjugate; an inverse transform's conj out)
                 if (p.ph_on) o = cmul(o, p.one_d ? reinterpret_cast<const CT*>(p.ph_x)[kx] : cmul(reinterpret_cast<const CT*>(p.ph_y)[ky], reinterpret_cast<const CT*>(p.ph_x)[kx]));
                 reinterpret_cast<CT*>(p.out)[obase + e] = o;
             }
@@ -465,6 +485,9 @@ struct FastGY {
     int cin;             // the input is COMPLEX T (the later stages of N-D transforms, xrft.fft of complex data): one sequence per column, G columns per workgroup, no split
     const void* in_b;    // two real fields (cross spectrum / cross phase along the axis, xrft.py:753-874): column c of `in` and of `in_b` are the real and the
     int two, angle;      // imaginary part of sequence c -- G columns per workgroup; the result is F(in) conj F(in_b) (MODE 0), or its phase as real T (angle)
+    // inverse transforms (xrft.ifft along the axis, xrft.py:479-646; complex input): conj(FFT(conj(z))); row i of the tile is source row i + ishift_in (mod ny:
+    // the ifftshift of an fftshifted spectrum), ph_in: ph_y multiplies the INPUT at its source position (the lag's phase, xrft.py:574-576)
+    int inv, ishift_in, ph_in;
 };
 
 // MODE 1: power spectrum (real T out), 0: complex spectrum; BLUE: the Bluestein form (its inverse passes cost the plain form 25 registers: a kernel of its own)
@@ -507,10 +530,13 @@ __global__ void __launch_bounds__(256) fastgy_kernel(FastGY p) {
         double s[4] = {0.0, 0.0, 0.0, 0.0};
         for (int i = rq; i < ny; i += RQ) {
             CT z = mk<T>((T)0, (T)0);
+            int is = i + p.ishift_in; if (is >= ny) is -= ny;  // (source row)
             if (live) {
-                if (p.two) z = mk<T>(src[(size_t)i * rowstep], (reinterpret_cast<const T*>(p.in_b) + ((size_t)b * ny * nx + c0 + g))[(size_t)i * rowstep]);
-                else z = *reinterpret_cast<const CT*>(src + (size_t)i * rowstep);
+                if (p.two) z = mk<T>(src[(size_t)is * rowstep], (reinterpret_cast<const T*>(p.in_b) + ((size_t)b * ny * nx + c0 + g))[(size_t)is * rowstep]);
+                else z = *reinterpret_cast<const CT*>(src + (size_t)is * rowstep);
             }
+            if (p.ph_in) z = cmul(z, reinterpret_cast<const CT*>(p.ph_y)[is]);
+            if (p.inv) z.im = -z.im;
             if (p.detrend) {
                 const double ri = (double)i - ibar;
                 s[0] += (double)z.re; s[2] += (double)z.im;
@@ -583,6 +609,7 @@ __global__ void __launch_bounds__(256) fastgy_kernel(FastGY p) {
             CT v;
             if (p.cin) {
                 v = tile[(BLUE ? k : (int)revy[k]) * G + c];
+                if (p.inv) v.im = -v.im;
             } else if (p.two) {  // A = (Zk + conj Zm) / 2, B = (Zk - conj Zm) / 2i: A conj(B)
                 const CT zk = tile[(BLUE ? k : (int)revy[k]) * G + c], zm = tile[(BLUE ? km : (int)revy[km]) * G + c];
                 v = cmulc(mk<T>((T)0.5 * (zk.re + zm.re), (T)0.5 * (zk.im - zm.im)), mk<T>((T)0.5 * (zk.im + zm.im), (T)0.5 * (zm.re - zk.re)));

@@ -1089,7 +1089,7 @@ static int fast_phase_tables(xrfthip_plan* P) {
     P->fph_on = false;
     for (int ax = 0; ax < 2; ++ax) {
         const long long n = ax == 0 ? d.ny : d.nx;
-        const bool sign = d.out_mode == XRFTHIP_OUT_COMPLEX && (d.flags & (ax == 0 ? XRFTHIP_ISHIFT_Y : XRFTHIP_ISHIFT_X));
+        const bool sign = d.out_mode == XRFTHIP_OUT_COMPLEX && !(d.flags & XRFTHIP_INVERSE) && (d.flags & (ax == 0 ? XRFTHIP_ISHIFT_Y : XRFTHIP_ISHIFT_X));  // (an inverse plan rotates its input)
         std::vector<cf> t((size_t)n);
         const bool dtab = (P->fastm || P->fastmy || P->fastmx || P->fastg || P->fastgy) && P->dbl;
         std::vector<C2<double>> td(dtab ? (size_t)n : 0);
@@ -1883,10 +1883,10 @@ template <typename T> static int fastg_setup_t(xrfthip_plan* P) {
 static bool fastg_try(xrfthip_plan* P) {  // can the slab's half spectrum live in the LDS of one workgroup, and are both lengths smooth?
     const xrfthip_desc& d = P->d;
     const bool one_d = d.ndim == 1;
-    if ((d.ndim != 2 && !one_d) || P->cplx_in || d.nx < 3 || (!one_d && d.ny < 2) || d.nx > (one_d ? 16384 : 4096) || d.ny > 4096) return false;
+    if ((d.ndim != 2 && !one_d) || d.nx < 3 || (!one_d && d.ny < 2) || d.nx > (one_d ? 16384 : 4096) || d.ny > 4096) return false;
     // an even nx: the rows packed in pairs of samples, the half spectrum (nx / 2 + 1 columns) in the tile; an odd nx: the rows as complex sequences with
     // zero imaginary parts, the whole spectrum in the tile (twice the LDS and the x passes' work: 75 x 75, 81 x 81, 125 x 125 boxes)
-    const bool packed = !(d.nx & 1);
+    const bool packed = !(d.nx & 1) && !P->cplx_in;  // (complex input: every row a complex sequence, the whole spectrum in the tile)
     const int n = packed ? (int)(d.nx / 2) : (int)d.nx;
     int rs = packed ? n + 1 : n;
     if (!(rs & 1)) ++rs;  // an odd row stride: the rows' passes and the gather of the output loop spread over the banks
@@ -2022,7 +2022,10 @@ static int run_fastgy(const xrfthip_plan* P, const void* in, const void* in_b, v
     p.tw_y = P->g_twy.p; p.rev_y = (const unsigned*)P->g_revy.p;
     p.blue_m = P->gy_blue_m; p.blue_c = P->gy_bluec.p; p.blue_b = P->gy_blueb.p; p.tw_lds = P->gy_tw_lds ? 1 : 0;
     p.win_y = P->win[0].p;
-    p.ph_y = P->fph[0].p; p.ph_on = (d.out_mode != XRFTHIP_OUT_POWER && P->fph_on) ? 1 : 0;
+    p.ph_y = P->fph[0].p; p.ph_on = (d.out_mode != XRFTHIP_OUT_POWER && P->fph_on && !(d.flags & XRFTHIP_PHASE_IN)) ? 1 : 0;
+    p.inv = (d.flags & XRFTHIP_INVERSE) ? 1 : 0;
+    p.ishift_in = ((d.flags & XRFTHIP_INVERSE) && (d.flags & XRFTHIP_ISHIFT_Y)) ? (int)(d.ny / 2) : 0;
+    p.ph_in = ((d.flags & XRFTHIP_PHASE_IN) && P->fph_on) ? 1 : 0;
     p.detrend = d.detrend;
     p.shift_y = (d.flags & XRFTHIP_SHIFT_Y) ? (int)(d.ny / 2) : 0;
     p.scale = d.scale;
@@ -2062,6 +2065,11 @@ static int run_fastg(const xrfthip_plan* P, const void* in, const void* in_b, vo
     p.in = in; p.in_b = in_b; p.out = out; p.nslabs = d.batch;
     p.ny = P->g_one_d ? P->g_rows : (int)d.ny; p.nx = (int)d.nx; p.n = P->g_n; p.rs = P->g_rs; p.packed = P->g_packed ? 1 : 0;
     p.one_d = P->g_one_d ? 1 : 0; p.nrows = d.batch; p.nred = P->g_nred;
+    p.cin = P->cplx_in ? 1 : 0;
+    p.inv = (d.flags & XRFTHIP_INVERSE) ? 1 : 0;
+    p.ishy = ((d.flags & XRFTHIP_INVERSE) && (d.flags & XRFTHIP_ISHIFT_Y)) ? (int)(d.ny / 2) : 0;  // (an inverse plan rotates its fftshifted input; a forward plan folds the shift into the phase)
+    p.ishx = ((d.flags & XRFTHIP_INVERSE) && (d.flags & XRFTHIP_ISHIFT_X)) ? (int)(d.nx / 2) : 0;
+    p.ph_in = ((d.flags & XRFTHIP_PHASE_IN) && P->fph_on) ? 1 : 0;
     if (P->g_one_d) p.nslabs = (d.batch + P->g_rows - 1) / P->g_rows;
     p.nrx = (int)P->g_rx.size(); p.nry = (int)P->g_ry.size();
     for (int i = 0; i < p.nrx; ++i) p.rx[i] = P->g_rx[(size_t)i];
@@ -2078,7 +2086,7 @@ static int run_fastg(const xrfthip_plan* P, const void* in, const void* in_b, vo
     p.win_y = win ? (P->win[0].p ? P->win[0].p : P->ones4096.p) : nullptr;
     p.win_x = win ? (P->win[1].p ? P->win[1].p : P->ones4096.p) : nullptr;
     const bool cplx = d.out_mode == XRFTHIP_OUT_COMPLEX, cross = d.out_mode == XRFTHIP_OUT_CROSS;
-    p.ph_y = P->fph[0].p; p.ph_x = P->fph[1].p; p.ph_on = ((cplx || cross) && P->fph_on) ? 1 : 0;
+    p.ph_y = P->fph[0].p; p.ph_x = P->fph[1].p; p.ph_on = ((cplx || cross) && P->fph_on && !(d.flags & XRFTHIP_PHASE_IN)) ? 1 : 0;
     p.detrend = d.detrend;
     p.shift_y = (d.flags & XRFTHIP_SHIFT_Y) ? (int)(d.ny / 2) : 0;
     p.shift_x = (d.flags & XRFTHIP_SHIFT_X) ? (int)(d.nx / 2) : 0;
@@ -2435,7 +2443,7 @@ int xrfthip_plan_create(xrfthip_plan** plan, const xrfthip_desc* desc) {
     if ((d.flags & (XRFTHIP_FLIP0_Y | XRFTHIP_FLIP0_X)) && d.out_mode != XRFTHIP_OUT_CROSS && d.out_mode != XRFTHIP_OUT_PHASE) return XRFTHIP_BAD_ARG;
     if ((d.flags & XRFTHIP_FLIP0_Y) && d.ndim == 1) return XRFTHIP_BAD_ARG;
     if ((d.flags & XRFTHIP_AXIS_Y) && (d.ndim != 2 || (d.flags & XRFTHIP_FLIP0_X) || (d.flags & (XRFTHIP_SHIFT_X | XRFTHIP_ISHIFT_X | XRFTHIP_FLIP_X | XRFTHIP_HALF_X | XRFTHIP_REALDIM_X2 |
-                                                                    XRFTHIP_ISO | XRFTHIP_NO_SPECTRUM_OUT | XRFTHIP_C2R_X | XRFTHIP_PHASE_IN)))) return XRFTHIP_BAD_ARG;
+                                                                    XRFTHIP_ISO | XRFTHIP_NO_SPECTRUM_OUT | XRFTHIP_C2R_X)))) return XRFTHIP_BAD_ARG;  // (PHASE_IN: only where fastgy takes the plan, below)
 
     if (d.inner > 1) return create_inner_plan(plan, d);
 
@@ -2585,7 +2593,8 @@ int xrfthip_plan_create(xrfthip_plan** plan, const xrfthip_desc* desc) {
     }
     {   // ... on any other smooth length: one pass in LDS with the radices as data (fastg.h: fastgy_kernel)
         const bool two = d.out_mode == XRFTHIP_OUT_CROSS || d.out_mode == XRFTHIP_OUT_PHASE;  // (two REAL fields: a column of each = one packed sequence; no flipped field)
-        const uint32_t allowed = XRFTHIP_AXIS_Y | XRFTHIP_SHIFT_Y | (d.out_mode != XRFTHIP_OUT_POWER ? XRFTHIP_ISHIFT_Y : 0u);
+        const uint32_t allowed = XRFTHIP_AXIS_Y | XRFTHIP_SHIFT_Y | (d.out_mode != XRFTHIP_OUT_POWER ? XRFTHIP_ISHIFT_Y : 0u) |
+                                 ((cplx_in && d.out_mode == XRFTHIP_OUT_COMPLEX) ? (XRFTHIP_INVERSE | XRFTHIP_PHASE_IN) : 0u);  // (xrft.ifft along the axis: conj in, conj out, the input rotated)
         P->fastgy = !P->fastmy && (d.flags & XRFTHIP_AXIS_Y) && (d.out_mode == XRFTHIP_OUT_COMPLEX || d.out_mode == XRFTHIP_OUT_POWER || (two && !cplx_in)) && !(d.flags & ~allowed) &&
                     !env_ll("XRFTHIP_NO_FAST", 0) && env_ll("XRFTHIP_FASTG", 1) != 0 && fastgy_try(P);
         if (P->fastgy) {
@@ -2611,13 +2620,15 @@ int xrfthip_plan_create(xrfthip_plan** plan, const xrfthip_desc* desc) {
         }
     }
     {   // a small slab of any smooth shape, either precision, that none of the specialised kernels above takes: one pass in LDS (fastg.h)
-        const uint32_t okg = XRFTHIP_SHIFT_Y | XRFTHIP_SHIFT_X | XRFTHIP_HALF_X |
+        // complex input (fft of complex data, every inverse transform): power / complex, no detrend, no real_dim, no radial sums
+        const bool cin_ok = !cplx_in || ((d.out_mode == XRFTHIP_OUT_POWER || d.out_mode == XRFTHIP_OUT_COMPLEX) && !d.detrend && !(d.flags & (XRFTHIP_HALF_X | XRFTHIP_REALDIM_X2 | XRFTHIP_ISO | XRFTHIP_C2R_X)));
+        const uint32_t okg = XRFTHIP_SHIFT_Y | XRFTHIP_SHIFT_X | XRFTHIP_HALF_X | ((cplx_in && d.out_mode == XRFTHIP_OUT_COMPLEX) ? (XRFTHIP_INVERSE | XRFTHIP_PHASE_IN) : 0u) |
                              (d.out_mode == XRFTHIP_OUT_COMPLEX ? (XRFTHIP_ISHIFT_Y | XRFTHIP_ISHIFT_X)
                               : d.out_mode == XRFTHIP_OUT_CROSS ? (XRFTHIP_ISHIFT_Y | XRFTHIP_ISHIFT_X | XRFTHIP_REALDIM_X2 | XRFTHIP_ISO | XRFTHIP_NO_SPECTRUM_OUT)  // (no flipped field: the other paths)
                               : (XRFTHIP_ISO | XRFTHIP_NO_SPECTRUM_OUT | XRFTHIP_REALDIM_X2));
         // (a 1-D transform along x that neither the register kernels nor the table lengths take: the same kernel on groups of rows)
         const bool one_ok = d.ndim != 1 || (!P->fastr && !P->fastmx && !P->fast1d && !(d.flags & (XRFTHIP_ISO | XRFTHIP_SHIFT_Y | XRFTHIP_ISHIFT_Y)));
-        P->fastg = one_ok && !P->fasts && !P->fast4096 && !P->fastm && (d.out_mode == XRFTHIP_OUT_POWER || d.out_mode == XRFTHIP_OUT_COMPLEX || d.out_mode == XRFTHIP_OUT_CROSS) && !(d.flags & ~okg) &&
+        P->fastg = one_ok && cin_ok && !P->fasts && !P->fast4096 && !P->fastm && (d.out_mode == XRFTHIP_OUT_POWER || d.out_mode == XRFTHIP_OUT_COMPLEX || d.out_mode == XRFTHIP_OUT_CROSS) && !(d.flags & ~okg) &&
                    !((d.flags & XRFTHIP_HALF_X) && (d.flags & (XRFTHIP_ISO | XRFTHIP_SHIFT_X | XRFTHIP_SHIFT_Y))) &&
                    !env_ll("XRFTHIP_NO_FAST", 0) && env_ll("XRFTHIP_FASTG", 1) != 0 && fastg_try(P);
         if (P->fastg) {
@@ -2628,6 +2639,7 @@ int xrfthip_plan_create(xrfthip_plan** plan, const xrfthip_desc* desc) {
             if (rcg) { delete P; return rcg; }
         }
     }
+    if ((d.flags & XRFTHIP_AXIS_Y) && (d.flags & XRFTHIP_PHASE_IN) && !P->fastgy) { delete P; return XRFTHIP_BAD_ARG; }  // (the generic column tiles have no input phase)
     set_kernel_attrs_once();
     // nbins must be known before tiles are sized (the LDS histogram shares the tile's allocation): ISO plans are
     // (re)built in xrfthip_plan_set_binmap.  Build now for everything else.
@@ -2779,7 +2791,7 @@ int xrfthip_plan_describe(const xrfthip_plan* plan, char* buf, size_t buflen) {
         if (plan->g_one_d)
             appendf(s, "  [fastg rows] one pass, one %d-thread workgroup per %d rows of %lld samples%s: in LDS, radices from the plan (x: %d = %s), a mean / line per row in the "
                        "workgroup, output gathered in output order through the digit-reversal table, lds=%zuB\n",
-                    (int)fastg_threads(plan), plan->g_rows, (long long)plan->d.nx, plan->g_packed ? " packed in pairs" : " (an odd length: complex sequences)", plan->g_n,
+                    (int)fastg_threads(plan), plan->g_rows, (long long)plan->d.nx, plan->g_packed ? " packed in pairs" : plan->cplx_in ? " (complex input)" : " (an odd length: complex sequences)", plan->g_n,
                     rxs.empty() ? "1" : rxs.c_str(), plan->g_lds);
         else if (plan->g_packed)
             appendf(s, "  [fastg] one pass, one %d-thread workgroup per %lld x %lld slab: the half spectrum (%lld rows of %lld + 1 complex) in LDS, radices from the plan "
@@ -2788,7 +2800,7 @@ int xrfthip_plan_describe(const xrfthip_plan* plan, char* buf, size_t buflen) {
                     (int)fastg_threads(plan), (long long)plan->d.ny, (long long)plan->d.nx, (long long)plan->d.ny, (long long)plan->d.nx / 2, (long long)plan->d.nx / 2,
                     rxs.empty() ? "1" : rxs.c_str(), (long long)plan->d.ny, rys.c_str(), plan->g_lds);
         else
-            appendf(s, "  [fastg] one pass, one %d-thread workgroup per %lld x %lld slab (an odd row length: the rows as complex sequences): the spectrum (%lld rows of %lld complex) "
+            appendf(s, "  [fastg] one pass, one %d-thread workgroup per %lld x %lld slab (complex input or an odd row length: the rows as complex sequences): the spectrum (%lld rows of %lld complex) "
                        "in LDS, radices from the plan (x: %lld = %s, y: %lld = %s), exact plane detrend in the workgroup, output gathered in output order through the "
                        "digit-reversal tables, lds=%zuB\n",
                     (int)fastg_threads(plan), (long long)plan->d.ny, (long long)plan->d.nx, (long long)plan->d.ny, (long long)plan->d.nx, (long long)plan->d.nx,
@@ -2819,9 +2831,12 @@ int xrfthip_plan_describe(const xrfthip_plan* plan, char* buf, size_t buflen) {
     } else if (plan->fastgy) {
         std::string rys;
         for (int r : plan->g_ry) rys += (rys.empty() ? "" : "x") + std::to_string(r);
-        appendf(s, "  [fastg y-only] one pass, %d thr, %d packed column pairs per workgroup (%d bytes of a row), the radices from the plan (y: %lld = %s in LDS), lds=%zuB: "
-                   "per-column detrend + window + transform + both columns' spectra, in place in memory order\n",
-                plan->gy_thr, plan->gy_G, (int)(2 * plan->gy_G * plan->rsize), (long long)(plan->gy_blue_m ? plan->gy_blue_m : plan->d.ny), rys.c_str(), plan->gy_lds);
+        const bool onecol = plan->cplx_in || plan->d.out_mode == XRFTHIP_OUT_CROSS || plan->d.out_mode == XRFTHIP_OUT_PHASE;
+        appendf(s, "  [fastg y-only] one pass, %d thr, %d %s per workgroup (%d bytes of a row), the radices from the plan (y: %lld = %s in LDS), lds=%zuB: "
+                   "per-column detrend + window + transform%s, in place in memory order%s\n",
+                plan->gy_thr, plan->gy_G, plan->cplx_in ? "complex columns" : onecol ? "columns of each of the two fields" : "packed column pairs",
+                (int)((plan->cplx_in ? plan->csize : onecol ? plan->rsize : 2 * plan->rsize) * (size_t)plan->gy_G), (long long)(plan->gy_blue_m ? plan->gy_blue_m : plan->d.ny), rys.c_str(), plan->gy_lds,
+                onecol ? "" : " + both columns' spectra", (plan->d.flags & XRFTHIP_INVERSE) ? "; inverse (conj in, conj out)" : "");
         if (plan->gy_blue_m)
             appendf(s, "  [fastg y-only Bluestein] %lld points as a circular convolution of %d inside the tile (chirp products, forward and inverse passes)%s\n",
                     (long long)plan->d.ny, plan->gy_blue_m, plan->gy_tw_lds ? "" : "; twiddles from memory");
