@@ -921,6 +921,13 @@ def run_inverse_one_pass_cases(shape=(2, 360, 250), dtype="float64"):
                 xa.api._plan_cache.clear()
                 worst = max(worst, check_values(xa.ifft(F1, dim=["freq_" + d], **kw), o.ifft(F1o, dim=["freq_" + d], **kw), tol))
                 assert any(tag in p.describe() for p in xa.api._plan_cache.values()), (d, kw)
+            if shape[2] % 2 == 0:  # the half spectrum back to real samples (irfft / irfftn, real_dim): along the rows, and over two axes where the slab fits a workgroup
+                Fr, Fro = xa.fft(da, dim=["x"], real_dim="x", **kw), o.fft(od, dim=["x"], real_dim="x", **kw)
+                xa.api._plan_cache.clear()
+                worst = max(worst, check_values(xa.ifft(Fr, dim=["freq_x"], real_dim="freq_x", **kw), o.ifft(Fro, dim=["freq_x"], real_dim="freq_x", **kw), tol))
+                assert any("[fastg rows]" in p.describe() for p in xa.api._plan_cache.values()), kw
+                Fr2, Fr2o = xa.fft(da, dim=["y"], real_dim="x", **kw), o.fft(od, dim=["y"], real_dim="x", **kw)
+                worst = max(worst, check_values(xa.ifft(Fr2, dim=["freq_y"], real_dim="freq_x", **kw), o.ifft(Fr2o, dim=["freq_y"], real_dim="freq_x", **kw), tol))
     return worst
 
 

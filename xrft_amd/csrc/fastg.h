@@ -48,6 +48,11 @@ struct FastG {
     // (packed = 0), no detrend.  inv: conj(FFT(conj(z))); ishy / ishx: sample (i, m) of the tile is source (i + ishy, m + ishx) mod (ny, nx) -- the ifftshift of an
     // fftshifted spectrum; ph_in: the phase tables multiply the INPUT at its source position (the lag's phase, xrft.py:574-576)
     int cin, inv, ishy, ishx, ph_in;
+    // irfftn (XRFTHIP_C2R_X, xrft.ifft with real_dim): the input is the HALF spectrum [slabs][ny][nx/2 + 1] complex T, the output REAL [slabs][ny][nx] T (MODE 1).
+    // conj(X) phase is loaded into the packed geometry, the y passes run FIRST (on the nx/2 + 1 columns), every row is re-packed in place --
+    // W[k] = T[k] + conj T[n-k] - i (T[k] - conj T[n-k]) W_nx^k = conj Z[k], Z the spectrum of z[m] = x[2m] + i x[2m+1] -- the x passes, and
+    // x[2m] = Re R[m], x[2m+1] = -Im R[m] on the way out
+    int c2r;
     int nrx, nry;
     int rx[kFastGMaxPasses], ry[kFastGMaxPasses];
     const void* tw_x;   // W_n^k,  k < n   (complex T)
@@ -168,7 +173,8 @@ __device__ __forceinline__ void fastg_cols_pass(C2<T>* tile, int ncols, int len,
 }
 
 // MODE 1: power spectrum (real T out), 0: complex spectrum, 2: cross spectrum of two fields (two tiles in LDS, complex out)
-template <typename T, int MODE>
+// CIN: the complex-input forms (cin, inverse, c2r) -- kernels of their own: their branches cost the real-input forms registers
+template <typename T, int MODE, bool CIN>
 __global__ void __launch_bounds__(fastg_max_threads<T>(), (sizeof(T) == 4 ? 4 : 3)) fastg_kernel(FastG p) {  // (float64: three waves per SIMD = 168 registers)
     typedef C2<T> CT;
     XRFT_DYN_SMEM(smem_raw);
@@ -206,13 +212,51 @@ __global__ void __launch_bounds__(fastg_max_threads<T>(), (sizeof(T) == 4 ? 4 : 
 #pragma unroll 1
       for (int f = 0; f < NF; ++f) {  // (a cross spectrum: field 0 into tile 0, field 1 into tile 1, the same code)
         CT* tile = tile0 + f * (ny * rs);
-        const CT* __restrict__ src = p.cin ? reinterpret_cast<const CT*>(p.in) + (size_t)slab * ny * nx  // (complex samples)
+        const CT* __restrict__ src = (CIN && p.c2r) ? reinterpret_cast<const CT*>(p.in) + (size_t)slab * ny * (n + 1)  // (half spectra)
+                                   : (CIN && p.cin) ? reinterpret_cast<const CT*>(p.in) + (size_t)slab * ny * nx  // (complex samples)
                                            : reinterpret_cast<const CT*>(reinterpret_cast<const T*>(f ? p.in_b : p.in) + (size_t)slab * ny * nx);
         // ---- load; the plane's sums on the way (float64 per thread, then the threads in a fixed order)
         double s0 = 0.0, si = 0.0, sj = 0.0;
         const bool plane = p.detrend && !p.one_d;  // (the slab's plane; a 1-D transform fits a line per row below)
         const double ibar = 0.5 * (ny - 1), jbar = 0.5 * (nx - 1);
-        if (packed) {
+        if ((CIN && p.c2r)) {  // (nyv (n + 1) complex samples of the half spectrum, conjugated: the inverse transform is conj(FFT(conj .)))
+            const CT* __restrict__ wyc = reinterpret_cast<const CT*>(p.ph_y);
+            const CT* __restrict__ wxc = reinterpret_cast<const CT*>(p.ph_x);
+            const int hw = n + 1, toth = nyv * hw;
+            const float inv_hw = 1.0f / (float)hw;
+            for (int e = tid; e < toth; e += nthr) {
+                const int i = fdiv(e, inv_hw), k = e - i * hw;
+                int is = i + p.ishy; if (is >= ny) is -= ny;
+                CT z = src[(size_t)is * hw + k];
+                if ((CIN && p.ph_in)) z = cmul(z, p.one_d ? wxc[k] : cmul(wyc[is], wxc[k]));
+                tile[i * rs + k] = mk<T>(z.re, -z.im);
+            }
+            if (!p.one_d) {  // the y passes first: every row must be the half spectrum of a real sequence before its c2r step
+                __syncthreads();
+                int L = ny;
+                for (int ps = 0; ps < p.nry; ++ps) {
+                    fastg_cols_pass<T>(tile, ncol, ny, rs, p.ry[ps], L, tid, nthr, twy);
+                    L /= p.ry[ps];
+                    __syncthreads();
+                }
+            } else {
+                __syncthreads();
+            }
+            // re-pack the rows in place: pairs (k, n - k), k <= n / 2
+            const int hp = n / 2 + 1, nb = nyv * hp;
+            const float inv_hp = 1.0f / (float)hp;
+            for (int w = tid; w < nb; w += nthr) {
+                const int i = fdiv(w, inv_hp), k = w - i * hp, km = n - k;
+                CT* row = tile + i * rs;
+                CT tk = row[k], tm = row[km];
+                if (k == 0) { tk.im = (T)0; tm.im = (T)0; }  // (numpy's irfft takes the real parts of the zero-frequency and Nyquist samples of a spectrum that is not a real sequence's)
+                // W[k] = tk + conj tm - i (tk - conj tm) w_k,  W[n-k] = tm + conj tk - i (tm - conj tk) w_(n-k)
+                const CT d1 = mk<T>(tk.re - tm.re, tk.im + tm.im), d2 = mk<T>(tm.re - tk.re, tm.im + tk.im);
+                const CT p1 = cmul(d1, twr[k]), p2 = cmul(d2, twr[km]);
+                row[k] = mk<T>(tk.re + tm.re + p1.im, tk.im - tm.im - p1.re);  // (-i (a + i b) = b - i a)
+                if (km != k && km != n) row[km] = mk<T>(tm.re + tk.re + p2.im, tm.im - tk.im - p2.re);
+            }
+        } else if (packed) {
             for (int e = tid; e < npk; e += nthr) {
                 const int i = fdiv(e, inv_n), m = e - i * n;
                 const CT z = src[e];
@@ -224,7 +268,7 @@ __global__ void __launch_bounds__(fastg_max_threads<T>(), (sizeof(T) == 4 ? 4 : 
                     sj += ((double)(2 * m) - jbar) * u + (double)z.im;
                 }
             }
-        } else if (p.cin) {  // (npk = ny nx complex samples)
+        } else if ((CIN && p.cin)) {  // (npk = ny nx complex samples)
             const CT* __restrict__ wyc = reinterpret_cast<const CT*>(p.ph_y);
             const CT* __restrict__ wxc = reinterpret_cast<const CT*>(p.ph_x);
             for (int e = tid; e < npk; e += nthr) {
@@ -232,8 +276,8 @@ __global__ void __launch_bounds__(fastg_max_threads<T>(), (sizeof(T) == 4 ? 4 : 
                 int is = i + p.ishy; if (is >= ny) is -= ny;
                 int ms = m + p.ishx; if (ms >= nx) ms -= nx;
                 CT z = src[(size_t)is * nx + ms];
-                if (p.ph_in) z = cmul(z, p.one_d ? wxc[ms] : cmul(wyc[is], wxc[ms]));
-                if (p.inv) z.im = -z.im;
+                if ((CIN && p.ph_in)) z = cmul(z, p.one_d ? wxc[ms] : cmul(wyc[is], wxc[ms]));
+                if ((CIN && p.inv)) z.im = -z.im;
                 if (p.win_y) { const T w = (p.one_d ? (T)1 : wys[i]) * wxs[m]; z = mk<T>(z.re * w, z.im * w); }
                 tile[i * rs + m] = z;
             }
@@ -250,7 +294,7 @@ __global__ void __launch_bounds__(fastg_max_threads<T>(), (sizeof(T) == 4 ? 4 : 
                 }
             }
         }
-        if (p.cin) {
+        if ((CIN && p.cin) || (CIN && p.c2r)) {
             // (complex input: the window rode on the load, there is no detrend)
         } else if (p.one_d && (p.detrend || p.win_y)) {
             // per-row mean / least-squares line (scipy.signal.detrend along x, xrft/detrend.py:54-71): lpr lanes share a row (a power of two <= 64, so a
@@ -341,7 +385,7 @@ __global__ void __launch_bounds__(fastg_max_threads<T>(), (sizeof(T) == 4 ? 4 : 
             }
         }
         // ---- unpack the packed rows in place: pairs (k, n - k), k <= n / 2; X[n] goes to column n
-        if (packed) {
+        if (packed && !(CIN && p.c2r)) {
             const int hp = n / 2 + 1, nb = nyv * hp;
             const float inv_hp = 1.0f / (float)hp;
             for (int w = tid; w < nb; w += nthr) {
@@ -363,7 +407,7 @@ __global__ void __launch_bounds__(fastg_max_threads<T>(), (sizeof(T) == 4 ? 4 : 
         }
         __syncthreads();
         // ---- y: the passes of length ny over the n + 1 columns
-        {
+        if (!(CIN && p.c2r)) {
             int L = ny;
             for (int ps = 0; ps < p.nry; ++ps) {
                 fastg_cols_pass<T>(tile, ncol, ny, rs, p.ry[ps], L, tid, nthr, twy);
@@ -408,6 +452,17 @@ __global__ void __launch_bounds__(fastg_max_threads<T>(), (sizeof(T) == 4 ? 4 : 
             }
             if (p.out == nullptr) continue;
         }
+        if (MODE == 1 && (CIN && p.c2r)) {  // real samples in output order: x[2m] = Re R[m], x[2m+1] = -Im R[m], R[m] at the digit-reversed position of m in its row
+#pragma unroll 2
+            for (int e = tid; e < tot; e += nthr) {
+                const int orow = fdiv(e, inv_nx), ocol = e - orow * nx;
+                int i = orow - p.shift_y; if (i < 0) i += ny;
+                int j = ocol - p.shift_x; if (j < 0) j += nx;
+                const CT r = tile[(int)revy[i] * rs + (int)revx[j >> 1]];
+                reinterpret_cast<T*>(p.out)[obase + e] = ((j & 1) ? -r.im : r.re) * sc;
+            }
+            continue;
+        }
         if (p.half) {  // rows of n + 1 samples, kx = 0 .. n as they lie in the tile: no twin, no shift
             const int W = nx / 2 + 1, toth = nyv * W;
             const float inv_w = 1.0f / (float)W;
@@ -442,7 +497,7 @@ __global__ void __launch_bounds__(fastg_max_threads<T>(), (sizeof(T) == 4 ? 4 : 
                 const T pw = (v.re * v.re + v.im * v.im) * sc;
                 reinterpret_cast<T*>(p.out)[obase + e] = pw;
             } else {
-                CT o = mk<T>(v.re * sc, ((mir != (p.inv != 0)) ? -v.im : v.im) * sc);  // (the twin's conjugate; an inverse transform's conj out)
+                CT o = mk<T>(v.re * sc, ((mir != ((CIN && p.inv) != 0)) ? -v.im : v.im) * sc);  // (the twin's conjugate; an inverse transform's conj out)
                 if (p.ph_on) o = cmul(o, p.one_d ? reinterpret_cast<const CT*>(p.ph_x)[kx] : cmul(reinterpret_cast<const CT*>(p.ph_y)[ky], reinterpret_cast<const CT*>(p.ph_x)[kx]));
                 reinterpret_cast<CT*>(p.out)[obase + e] = o;
             }

@@ -845,8 +845,9 @@ void set_kernel_attrs_once() {
 #undef SETALL
 #undef SETA
 #define SETF(K) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&K), hipFuncAttributeMaxDynamicSharedMemorySize, m)
-    SETF((fastg_kernel<float, 0>)); SETF((fastg_kernel<float, 1>)); SETF((fastg_kernel<double, 0>)); SETF((fastg_kernel<double, 1>));
-    SETF((fastg_kernel<float, 2>)); SETF((fastg_kernel<double, 2>));
+    SETF((fastg_kernel<float, 0, false>)); SETF((fastg_kernel<float, 1, false>)); SETF((fastg_kernel<double, 0, false>)); SETF((fastg_kernel<double, 1, false>));
+    SETF((fastg_kernel<float, 2, false>)); SETF((fastg_kernel<double, 2, false>));
+    SETF((fastg_kernel<float, 0, true>)); SETF((fastg_kernel<float, 1, true>)); SETF((fastg_kernel<double, 0, true>)); SETF((fastg_kernel<double, 1, true>));
     SETF((fastgy_kernel<float, 0, false>)); SETF((fastgy_kernel<float, 1, false>)); SETF((fastgy_kernel<double, 0, false>)); SETF((fastgy_kernel<double, 1, false>));
     SETF((fastgy_kernel<float, 0, true>)); SETF((fastgy_kernel<float, 1, true>)); SETF((fastgy_kernel<double, 0, true>)); SETF((fastgy_kernel<double, 1, true>));
     SETF((fasts_power_kernel<8, 8, 0, 0>)); SETF((fasts_power_kernel<8, 4, 0, 0>)); SETF((fasts_power_kernel<4, 8, 0, 0>));
@@ -1095,7 +1096,7 @@ static int fast_phase_tables(xrfthip_plan* P) {
         std::vector<C2<double>> td(dtab ? (size_t)n : 0);
         for (long long k = 0; k < n; ++k) {
             double re = 1.0, im = 0.0;
-            if (!P->host_phase[ax].empty()) { re = P->host_phase[ax][(size_t)(2 * k)]; im = P->host_phase[ax][(size_t)(2 * k + 1)]; }
+            if ((size_t)(2 * k + 1) < P->host_phase[ax].size()) { re = P->host_phase[ax][(size_t)(2 * k)]; im = P->host_phase[ax][(size_t)(2 * k + 1)]; }  // (a C2R_X plan: nx/2 + 1 entries on axis 1)
             if (sign && !(n & 1)) { if (k & 1) { re = -re; im = -im; } }
             else if (sign) {  // an odd length (fastg.h takes them): the ifftshift is a rotation by n // 2 samples, X'[k] = X[k] exp(+2 pi i (n // 2) k / n)
                 const long double a = 2.0L * 3.14159265358979323846264338327950288L * (long double)((k * (n / 2)) % n) / (long double)n;
@@ -1886,7 +1887,8 @@ static bool fastg_try(xrfthip_plan* P) {  // can the slab's half spectrum live i
     if ((d.ndim != 2 && !one_d) || d.nx < 3 || (!one_d && d.ny < 2) || d.nx > (one_d ? 16384 : 4096) || d.ny > 4096) return false;
     // an even nx: the rows packed in pairs of samples, the half spectrum (nx / 2 + 1 columns) in the tile; an odd nx: the rows as complex sequences with
     // zero imaginary parts, the whole spectrum in the tile (twice the LDS and the x passes' work: 75 x 75, 81 x 81, 125 x 125 boxes)
-    const bool packed = !(d.nx & 1) && !P->cplx_in;  // (complex input: every row a complex sequence, the whole spectrum in the tile)
+    const bool c2r = (d.flags & XRFTHIP_C2R_X) != 0;  // (irfftn: the half spectrum in, the packed geometry)
+    const bool packed = !(d.nx & 1) && (!P->cplx_in || c2r);  // (complex input: every row a complex sequence, the whole spectrum in the tile)
     const int n = packed ? (int)(d.nx / 2) : (int)d.nx;
     int rs = packed ? n + 1 : n;
     if (!(rs & 1)) ++rs;  // an odd row stride: the rows' passes and the gather of the output loop spread over the banks
@@ -2070,6 +2072,7 @@ static int run_fastg(const xrfthip_plan* P, const void* in, const void* in_b, vo
     p.ishy = ((d.flags & XRFTHIP_INVERSE) && (d.flags & XRFTHIP_ISHIFT_Y)) ? (int)(d.ny / 2) : 0;  // (an inverse plan rotates its fftshifted input; a forward plan folds the shift into the phase)
     p.ishx = ((d.flags & XRFTHIP_INVERSE) && (d.flags & XRFTHIP_ISHIFT_X)) ? (int)(d.nx / 2) : 0;
     p.ph_in = ((d.flags & XRFTHIP_PHASE_IN) && P->fph_on) ? 1 : 0;
+    p.c2r = (d.flags & XRFTHIP_C2R_X) ? 1 : 0;
     if (P->g_one_d) p.nslabs = (d.batch + P->g_rows - 1) / P->g_rows;
     p.nrx = (int)P->g_rx.size(); p.nry = (int)P->g_ry.size();
     for (int i = 0; i < p.nrx; ++i) p.rx[i] = P->g_rx[(size_t)i];
@@ -2101,9 +2104,11 @@ static int run_fastg(const xrfthip_plan* P, const void* in, const void* in_b, vo
     }
     const dim3 grid((unsigned)std::min<long long>(p.nslabs, 0x7fffffffLL)), blk((unsigned)thr);
     xrfthip_plan::ProfRec* rec = prof_begin(P, P->g_one_d ? "fastg_rows" : "fastg_slab", st);
-#define GL_(TT, MM) do { auto k = &fastg_kernel<TT, MM>; XRFT_LAUNCH(k, grid, blk, P->g_lds, st, p); } while (0)
-    if (P->dbl) { if (cross) GL_(double, 2); else if (cplx) GL_(double, 0); else GL_(double, 1); }
-    else { if (cross) GL_(float, 2); else if (cplx) GL_(float, 0); else GL_(float, 1); }
+#define GL_(TT, MM) do { if (P->cplx_in) { auto k = &fastg_kernel<TT, (MM == 2 ? 1 : MM), true>; XRFT_LAUNCH(k, grid, blk, P->g_lds, st, p); } \
+                         else { auto k = &fastg_kernel<TT, MM, false>; XRFT_LAUNCH(k, grid, blk, P->g_lds, st, p); } } while (0)
+    const bool real_out = d.out_mode == XRFTHIP_OUT_POWER || (d.flags & XRFTHIP_C2R_X);  // (MODE 1: |F|^2, or the real samples of an irfftn)
+    if (P->dbl) { if (cross) GL_(double, 2); else if (!real_out) GL_(double, 0); else GL_(double, 1); }
+    else { if (cross) GL_(float, 2); else if (!real_out) GL_(float, 0); else GL_(float, 1); }
 #undef GL_
     prof_end(rec, st);
     HIP_TRY(hipGetLastError());
@@ -2621,8 +2626,9 @@ int xrfthip_plan_create(xrfthip_plan** plan, const xrfthip_desc* desc) {
     }
     {   // a small slab of any smooth shape, either precision, that none of the specialised kernels above takes: one pass in LDS (fastg.h)
         // complex input (fft of complex data, every inverse transform): power / complex, no detrend, no real_dim, no radial sums
-        const bool cin_ok = !cplx_in || ((d.out_mode == XRFTHIP_OUT_POWER || d.out_mode == XRFTHIP_OUT_COMPLEX) && !d.detrend && !(d.flags & (XRFTHIP_HALF_X | XRFTHIP_REALDIM_X2 | XRFTHIP_ISO | XRFTHIP_C2R_X)));
-        const uint32_t okg = XRFTHIP_SHIFT_Y | XRFTHIP_SHIFT_X | XRFTHIP_HALF_X | ((cplx_in && d.out_mode == XRFTHIP_OUT_COMPLEX) ? (XRFTHIP_INVERSE | XRFTHIP_PHASE_IN) : 0u) |
+        const bool cin_ok = !cplx_in || ((d.out_mode == XRFTHIP_OUT_POWER || d.out_mode == XRFTHIP_OUT_COMPLEX) && !d.detrend && !(d.flags & (XRFTHIP_HALF_X | XRFTHIP_REALDIM_X2 | XRFTHIP_ISO)) &&
+                                         (!(d.flags & XRFTHIP_C2R_X) || !(d.nx & 1)));
+        const uint32_t okg = XRFTHIP_SHIFT_Y | XRFTHIP_SHIFT_X | XRFTHIP_HALF_X | ((cplx_in && d.out_mode == XRFTHIP_OUT_COMPLEX) ? (XRFTHIP_INVERSE | XRFTHIP_PHASE_IN | XRFTHIP_C2R_X) : 0u) |
                              (d.out_mode == XRFTHIP_OUT_COMPLEX ? (XRFTHIP_ISHIFT_Y | XRFTHIP_ISHIFT_X)
                               : d.out_mode == XRFTHIP_OUT_CROSS ? (XRFTHIP_ISHIFT_Y | XRFTHIP_ISHIFT_X | XRFTHIP_REALDIM_X2 | XRFTHIP_ISO | XRFTHIP_NO_SPECTRUM_OUT)  // (no flipped field: the other paths)
                               : (XRFTHIP_ISO | XRFTHIP_NO_SPECTRUM_OUT | XRFTHIP_REALDIM_X2));
