@@ -26,7 +26,7 @@ for shape, dt in (((64, 1024, 1024), "float32"), ((16, 4096, 4096), "float32"), 
     w = t(lambda: xrft.ifft(Fr, dim=["freq_y"], real_dim="freq_x"))
     print(f"   half spectrum back to real (real_dim): {x.numel()/w/1e9:6.1f} GFFT/s | " + " + ".join(p.describe().split("\n")[1].strip()[:48] for p in api._plan_cache.values()), flush=True)
     del x, da, F, Fr
-for shape, dt in (((1024, 65536), "float32"), ((131072, 1024), "float32"), ((131072, 250), "float32")):
+for shape, dt in (((1024, 65536), "float32"), ((131072, 1024), "float32"), ((131072, 250), "float32"), ((16384, 4096), "float32"), ((8192, 6000), "float32"), ((8192, 3000), "float64")):
     x = torch.randn(shape, dtype=getattr(torch, dt), device="cuda")
     da = xrft.DataArray(x, ("t", "x"), {"x": np.arange(float(shape[1]))})
     F = xrft.fft(da, dim=["x"])

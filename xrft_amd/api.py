@@ -1148,7 +1148,13 @@ def _ifft_two_stages(t, batch, ny, nx, flags, scale, ph):
         if e.status in (_lib.UNSUPPORTED_LENGTH, _lib.BAD_ARG):
             return None
         raise
-    if "[fastg" not in py.describe() or "[fastg" not in px.describe():
+    # ... and run well: four complex columns or more per workgroup along y (32-byte row segments at least), two rows or more per workgroup along x (one long
+    # row per workgroup runs at half the rate: (16, 4096, 4096) 24 GFFT/s in two such stages against 30 on the two-axis plan)
+    import re
+
+    my = re.search(r"\[fastg y-only\] one pass, \d+ thr, (\d+) complex columns", py.describe())
+    mx = re.search(r"\[fastg rows\] one pass, one \d+-thread workgroup per (\d+) rows", px.describe())
+    if my is None or mx is None or int(my.group(1)) < 4 or int(mx.group(1)) < 2:
         return None
     mid, _ = py.execute(t.reshape(batch, ny, nx))
     out, _ = px.execute(mid.reshape(batch * ny, 1, nx))

@@ -1896,7 +1896,8 @@ static bool fastg_try(xrfthip_plan* P) {  // can the slab's half spectrum live i
     int ny = (int)d.ny;
     if (one_d) {
         ny = (int)std::max<long long>(1, std::min<long long>(256, (24 * 1024) / ((long long)rs * (long long)P->csize)));
-        if (ny < 2) return false;  // (one long row per workgroup: the row tiles of the generic passes do as well -- (8192, 3000) float64 65 vs 46 GFFT/s)
+        if (ny < 2 && !P->cplx_in) return false;  // (one long real row per workgroup: the row tiles of the generic passes do as well -- (8192, 3000) float64 65 vs 46 GFFT/s;
+                                                  //  complex rows -- inverse transforms -- run 40 GFFT/s there: taken)
         ny = (int)std::min<long long>(ny, std::max<long long>(1, d.batch));
     }
     const size_t nf = d.out_mode == XRFTHIP_OUT_CROSS ? 2 : 1;  // a cross spectrum holds both fields' tiles
