@@ -94,7 +94,10 @@ typedef enum xrfthip_detrend_kind {
 /* Transform along a middle (or the first) axis in place, no transposed copy (the reference transforms any axes of the array
  * where they lie, xrft.py:395-409): with ndim = 2 the array is [batch][ny][nx] and ONLY y is transformed, once per (slab,
  * column); nx is the product of the trailing axes.  Detrending and the window act along y (one line / mean per column);
- * the *_X flags, HALF_X, ISO and C2R_X do not apply.  Output [batch][ny][nx] in the same layout. */
+ * the *_X flags, HALF_X, ISO and C2R_X do not apply.  Output [batch][ny][nx] in the same layout.
+ * Inverse transforms along the axis (xrft.ifft of one first / middle axis, xrft.py:479-646): XRFTHIP_INVERSE with complex input; ISHIFT_Y then
+ * rotates the fftshifted INPUT rows, SHIFT_Y the output; XRFTHIP_PHASE_IN (the lag's phase on the input, axis 0 table) is accepted where a one-pass
+ * kernel takes the plan (any smooth ny that fits a tile, Bluestein lengths included) and XRFTHIP_BAD_ARG otherwise -- the caller then transposes. */
 #define XRFTHIP_AXIS_Y 0x2000u
 /* CROSS/PHASE: the reference flips each field by its own coordinate (xrft.py:436-441): these flip field 0 (d_in0), FLIP_Y /
  * FLIP_X flip field 1 (d_in1).  The window always multiplies in the source order, before the flip (xrft.py:425-441). */
