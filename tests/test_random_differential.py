@@ -417,3 +417,102 @@ def run_random_one_pass(seed, big=False):
 @pytest.mark.parametrize("seed", range(int(os.environ.get("XRFT_RANDOM_ONE_PASS_CASES", "14"))))
 def test_random_one_pass_case(seed):
     run_random_one_pass(seed)
+
+
+_ANY_AXIS_LENGTHS = [6, 12, 27, 45, 48, 50, 75, 96, 120, 125, 150, 243, 250, 77, 131, 146, 365]  # (smooth, odd, and with prime factors that take Bluestein)
+
+
+def run_random_any_axis(seed):
+    """Random one-axis calls on lengths OUTSIDE the mixed-radix table -- smooth, odd, Bluestein -- along a first / middle / last axis, real or complex input, fft /
+    power spectrum / cross spectrum / real_dim / ifft of the call's own spectrum: the lengths-as-data kernels of csrc/fastg.h (fastgy_kernel, fastg on groups of
+    rows) or whatever else serves the call, against the oracle."""
+    import warnings
+
+    import xrft_amd as xa
+
+    rng = np.random.default_rng(11000 + seed)
+    n = int(rng.choice(_ANY_AXIS_LENGTHS))
+    dtype = str(rng.choice(["float64", "float32"]))
+    where = int(rng.integers(0, 3))  # the transform axis
+    sizes = [int(rng.choice([1, 2, 3, 5])), int(rng.choice([2, 4, 6, 7])), int(rng.choice([2, 8, 10, 13]))]
+    sizes[where] = n
+    shape = tuple(sizes)
+    dims = ("t", "y", "x")
+    ax = dims[where]
+    rs = [1, 1, 1]
+    rs[where] = n
+    v = rng.standard_normal(shape) + 1.5 + 2.0 * np.arange(n).reshape(rs) / n
+    cplx = bool(rng.random() < 0.25)
+    if cplx:
+        v = v + 1j * rng.standard_normal(shape)
+    v = v.astype(("complex128" if dtype == "float64" else "complex64") if cplx else dtype)
+    c = {d: np.arange(s) * float(rng.choice([0.5, 1.0])) + float(rng.choice([0.0, 3.0])) for d, s in zip(dims, shape)}
+    da, od = cases.pair(v, dims, c)
+    kw = dict(detrend=rng.choice([None, "constant", "linear"]), window=rng.choice([None, "hann", "hamming"]))
+    kind = str(rng.choice(["fft", "ps", "cs", "ps_real", "inverse"] if not cplx else ["fft", "ps", "inverse"]))
+    shift = bool(rng.random() < 0.7)
+    tp = bool(rng.random() < 0.5)
+    tol = 1e-10 if dtype == "float64" else 3e-4
+    api._plan_cache.clear()
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        if kind == "fft":
+            got, ref = xa.fft(da, dim=[ax], shift=shift, true_phase=tp, **kw), o.fft(od, dim=[ax], shift=shift, true_phase=tp, **kw)
+        elif kind == "ps":
+            got, ref = xa.power_spectrum(da, dim=[ax], shift=shift, **kw), o.power_spectrum(od, dim=[ax], shift=shift, **kw)
+        elif kind == "cs":
+            w = rng.standard_normal(shape).astype(dtype)
+            db, ob = cases.pair(w, dims, c)
+            got, ref = xa.cross_spectrum(da, db, dim=[ax], shift=shift, true_phase=tp, **kw), o.cross_spectrum(od, ob, dim=[ax], shift=shift, true_phase=tp, **kw)
+        elif kind == "ps_real":
+            got, ref = xa.power_spectrum(da, dim=[ax], real_dim=ax, **kw), o.power_spectrum(od, dim=[ax], real_dim=ax, **kw)
+        else:
+            F, Fo = xa.fft(da, dim=[ax], shift=shift, true_phase=tp), o.fft(od, dim=[ax], shift=shift, true_phase=tp)
+            got, ref = xa.ifft(F, dim=["freq_" + ax], shift=shift, true_phase=tp), o.ifft(Fo, dim=["freq_" + ax], shift=shift, true_phase=tp)
+    if dtype == "float64" or kind == "inverse" or cplx or kw["detrend"] is None:
+        cases.check(got, ref, tol)
+    else:  # (float32 with a detrend: the oracle on the float64 copy of the samples, as everywhere -- cases.pair)
+        cases.check(got, ref, tol)
+    return [t for t in ("[fastg y-only]", "[fastg rows]", "[fastm ", "[main]") if any(t in p.describe() for p in api._plan_cache.values())]
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("XRFT_RANDOM_ANY_AXIS_CASES", "48"))))
+def test_random_any_axis_case(seed):
+    run_random_any_axis(seed)
+
+
+def run_random_inverse(seed):
+    """Random inverse transforms over two axes (xrft.ifft of the call's own xrft.fft, with and without real_dim) on small and medium slabs of any smooth shape:
+    one pass, two one-pass stages, or the generic passes -- against the oracle."""
+    import warnings
+
+    import xrft_amd as xa
+
+    rng = np.random.default_rng(13000 + seed)
+    dtype = str(rng.choice(["float64", "float32"]))
+    ny = int(rng.choice(_smooth_lengths(2, 150)))
+    nx = int(rng.choice(_smooth_lengths(4, 200, even=bool(rng.random() < 0.7))))
+    nb = int(rng.integers(1, 5))
+    v = (rng.standard_normal((nb, ny, nx)) + 0.5).astype(dtype)
+    c = {"t": np.arange(nb), "y": np.arange(ny) * float(rng.choice([0.5, 1.0])) + float(rng.choice([0.0, 2.0])),
+         "x": np.arange(nx) * float(rng.choice([0.25, 1.0])) - float(rng.choice([0.0, 3.0]))}
+    da, od = cases.pair(v, ("t", "y", "x"), c)
+    shift = bool(rng.random() < 0.7)
+    tp = bool(rng.random() < 0.5)
+    real = bool(rng.random() < 0.4) and nx % 2 == 0
+    api._plan_cache.clear()
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        if real:
+            F, Fo = xa.fft(da, dim=["y"], real_dim="x", shift=shift, true_phase=tp), o.fft(od, dim=["y"], real_dim="x", shift=shift, true_phase=tp)
+            got, ref = xa.ifft(F, dim=["freq_y"], real_dim="freq_x", shift=shift, true_phase=tp), o.ifft(Fo, dim=["freq_y"], real_dim="freq_x", shift=shift, true_phase=tp)
+        else:
+            F, Fo = xa.fft(da, dim=["y", "x"], shift=shift, true_phase=tp), o.fft(od, dim=["y", "x"], shift=shift, true_phase=tp)
+            got, ref = xa.ifft(F, dim=["freq_y", "freq_x"], shift=shift, true_phase=tp), o.ifft(Fo, dim=["freq_y", "freq_x"], shift=shift, true_phase=tp)
+    cases.check(got, ref, 1e-10 if dtype == "float64" else 3e-4)
+    return [t for t in ("[fastg] one pass", "[fastg y-only]", "[fastg rows]") if any(t in p.describe() for p in api._plan_cache.values())]
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("XRFT_RANDOM_INVERSE_CASES", "32"))))
+def test_random_inverse_case(seed):
+    run_random_inverse(seed)
