@@ -1073,7 +1073,7 @@ def ifft(daft, spacing_tol=1e-3, dim=None, real_dim=None, shift=True, true_phase
         scale = scale / np.prod([float(new_coords[swap[d]].attrs["spacing"]) for d in dim])
     try:
         out = None
-        if len(dim) == 2 and real_dim is None and not (flags & (_lib.FLIP_X | _lib.FLIP_Y)):
+        if len(dim) == 2 and not (flags & (_lib.FLIP_X | _lib.FLIP_Y)):
             out = _ifft_two_stages(t, batch, ny, nx, flags, float(scale), ph)
         if out is None:
             plan = _get_plan(ndim=len(dim), batch=batch, ny=ny, nx=nx, dtype=t.dtype, out_mode=_lib.OUT_COMPLEX,
@@ -1128,19 +1128,22 @@ def ifft(daft, spacing_tol=1e-3, dim=None, real_dim=None, shift=True, true_phase
 
 
 def _ifft_two_stages(t, batch, ny, nx, flags, scale, ph):
-    """A two-axis inverse transform of complex (batch, ny, nx) data as two one-axis passes -- ifftn is separable (xrft.py:612-621) --: y where it lies
-    (XRFTHIP_AXIS_Y), then x along the rows.  Only when BOTH stages run on one-pass kernels (csrc/fastg.h) and the two-axis plan would not: the generic two-axis
-    passes take 30 GFFT/s, the two stages 100 each.  Returns None otherwise (the caller builds the two-axis plan)."""
+    """A two-axis inverse transform of (batch, ny, nx) complex data -- or of (batch, ny, nx / 2 + 1) half spectra with XRFTHIP_C2R_X in ``flags`` -- as two one-axis
+    passes: ifftn / irfftn are separable (xrft.py:612-621), y where it lies (XRFTHIP_AXIS_Y) on the stored columns, then x along the rows (the c2r step last).
+    Only when BOTH stages run well on one-pass kernels (csrc/fastg.h) and the two-axis plan would not: the generic two-axis passes take 30-38 GFFT/s, the stages 100
+    each.  Returns None otherwise (the caller builds the two-axis plan)."""
+    c2r = bool(flags & _lib.C2R_X)
+    nxs = nx // 2 + 1 if c2r else nx  # stored columns
     if ny * nx > (1 << 31) - 1 or batch * ny * nx == 0:
         return None
     fy = _lib.AXIS_Y | _lib.INVERSE | (flags & (_lib.ISHIFT_Y | _lib.SHIFT_Y)) | (_lib.PHASE_IN if ph["y"] is not None else 0)
-    fx = _lib.INVERSE | (flags & (_lib.ISHIFT_X | _lib.SHIFT_X)) | (_lib.PHASE_IN if ph["x"] is not None else 0)
+    fx = _lib.INVERSE | (flags & (_lib.ISHIFT_X | _lib.SHIFT_X | _lib.C2R_X)) | (_lib.PHASE_IN if ph["x"] is not None else 0)
     try:
         whole = _get_plan(ndim=2, batch=batch, ny=ny, nx=nx, dtype=t.dtype, out_mode=_lib.OUT_COMPLEX, detrend=_lib.DETREND_NONE, flags=flags, scale=scale,
                           window_y=None, window_x=None, phase_y=ph["y"], phase_x=ph["x"])
         if "[fast" in whole.describe():
             return None  # (a small slab: one pass over both axes)
-        py = _get_plan(ndim=2, batch=batch, ny=ny, nx=nx, dtype=t.dtype, out_mode=_lib.OUT_COMPLEX, detrend=_lib.DETREND_NONE, flags=fy, scale=1.0 / float(ny),
+        py = _get_plan(ndim=2, batch=batch, ny=ny, nx=nxs, dtype=t.dtype, out_mode=_lib.OUT_COMPLEX, detrend=_lib.DETREND_NONE, flags=fy, scale=1.0 / float(ny),
                        window_y=None, window_x=None, phase_y=ph["y"], phase_x=None)
         px = _get_plan(ndim=1, batch=batch * ny, ny=1, nx=nx, dtype=t.dtype, out_mode=_lib.OUT_COMPLEX, detrend=_lib.DETREND_NONE, flags=fx, scale=scale * float(ny),
                        window_y=None, window_x=None, phase_y=None, phase_x=ph["x"])
@@ -1156,9 +1159,9 @@ def _ifft_two_stages(t, batch, ny, nx, flags, scale, ph):
     mx = re.search(r"\[fastg rows\] one pass, one \d+-thread workgroup per (\d+) rows", px.describe())
     if my is None or mx is None or int(my.group(1)) < 4 or int(mx.group(1)) < 2:
         return None
-    mid, _ = py.execute(t.reshape(batch, ny, nx))
-    out, _ = px.execute(mid.reshape(batch * ny, 1, nx))
-    return out.reshape(t.shape)
+    mid, _ = py.execute(t.reshape(batch, ny, nxs))
+    out, _ = px.execute(mid.reshape(batch * ny, 1, nxs))
+    return out.reshape(list(t.shape[:-1]) + [nx])
 
 
 def _ifft_axis_y(t, k, imap, phase, true_phase, shift, true_amplitude, new_coord):
