@@ -1141,6 +1141,15 @@ def _ifft_two_stages(t, batch, ny, nx, flags, scale, ph):
     try:
         whole = _get_plan(ndim=2, batch=batch, ny=ny, nx=nx, dtype=t.dtype, out_mode=_lib.OUT_COMPLEX, detrend=_lib.DETREND_NONE, flags=flags, scale=scale,
                           window_y=None, window_x=None, phase_y=ph["y"], phase_x=ph["x"])
+        dec = getattr(whole, "_two_stage", None)  # (decided once per cached two-axis plan: describe() and the stage plans cost a call their host time)
+        if dec is False:
+            return None
+        if dec is not None:
+            py, px = dec
+            mid, _ = py.execute(t.reshape(batch, ny, nxs))
+            out, _ = px.execute(mid.reshape(batch * ny, 1, nxs))
+            return out.reshape(list(t.shape[:-1]) + [nx])
+        whole._two_stage = False
         if "[fast" in whole.describe():
             return None  # (a small slab: one pass over both axes)
         py = _get_plan(ndim=2, batch=batch, ny=ny, nx=nxs, dtype=t.dtype, out_mode=_lib.OUT_COMPLEX, detrend=_lib.DETREND_NONE, flags=fy, scale=1.0 / float(ny),
@@ -1159,6 +1168,7 @@ def _ifft_two_stages(t, batch, ny, nx, flags, scale, ph):
     mx = re.search(r"\[fastg rows\] one pass, one \d+-thread workgroup per (\d+) rows", px.describe())
     if my is None or mx is None or int(my.group(1)) < 4 or int(mx.group(1)) < 2:
         return None
+    whole._two_stage = (py, px)
     mid, _ = py.execute(t.reshape(batch, ny, nxs))
     out, _ = px.execute(mid.reshape(batch * ny, 1, nxs))
     return out.reshape(list(t.shape[:-1]) + [nx])
