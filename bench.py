@@ -68,12 +68,29 @@ def _cpu_pool_slab(arg):
     return float(r.values[0, 0, 0])
 
 
+def own_share(name, workload, ny, nx, pts_per_launch, avg_s):
+    """The dominant kernel's OWN compulsory bytes per input point (not the whole path's): a column pass reads the input and writes the
+    half-spectrum intermediate ((ny/2 + 1) complex rows), a row pass reads that intermediate and writes the result."""
+    esz = 8.0 if workload == "c5" else 4.0  # bytes of a real sample
+    half = 2.0 * esz * (ny // 2 + 1) / max(ny, 1)  # intermediate, bytes per input point
+    if "cols" in name:
+        b, what = esz + half, "input read + half-spectrum intermediate written"
+    elif "rows" in name:
+        outb = {"ps": esz, "c5": esz, "c4": 0.0, "c2": 2 * esz}.get(workload, esz)
+        b, what = half + outb, "half-spectrum intermediate read + result written"
+    else:  # a one-pass kernel: the path's bytes ARE its own
+        b = {"ps": 2 * esz, "c5": 2 * esz, "c2": 3 * esz, "c4": esz}.get(workload, 2 * esz)
+        what = "input read + result written (one pass)"
+    ach = b * pts_per_launch / avg_s
+    return {"bytes_per_point": round(b, 3), "what": what, "achieved": round(ach / 1e9, 2), "frac": round(ach / HBM_PEAK, 4)}
+
+
 def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--nt", type=int, default=64, help="time slabs per GPU")
+    ap.add_argument("--nt", type=int, default=None, help="time slabs per GPU (default: 64; c5: 450 = 3600 / 8 under weak scaling; c2: 1024 rows)")
     ap.add_argument("--ny", type=int, default=4096)
     ap.add_argument("--nx", type=int, default=4096)
     ap.add_argument("--cpu-slabs", type=int, default=10, help="slabs timed through the CPU oracle on one thread (0 = skip)")
@@ -219,12 +236,14 @@ def run(args, env):
         ny = nx = 2048  # BASELINE.json configs[3]
     if args.workload == "c5" and default_shape:
         ny, nx = 1440, 720  # configs[4]
-        if args.nt == 64 and args.scaling == "weak":
+        if args.nt is None and args.scaling == "weak":
             args.nt = 450  # the configuration's per-GPU share: 3600 slabs over 8 GPUs (3.7 GB in, 3.7 GB out)
     if args.workload == "c2":
         ny, nx = 1, (65536 if default_shape else args.nx)  # configs[1]: (1024, 65536) per GPU, one long axis
-        if args.nt == 64:
+        if args.nt is None:
             args.nt = 1024
+    if args.nt is None:  # (an explicit --nt is always what runs)
+        args.nt = 64
     fdt = torch.float64 if args.workload == "c5" else torch.float32
     # slabs of this rank: weak = --nt each; strong = contiguous block of --nt in total (never splits a slab)
     if args.scaling == "strong":
@@ -379,8 +398,12 @@ def run(args, env):
                 "traffic": traffic, "traffic_note": tnote,
                 "kernel": {"name": dom, "avg_launch_us": round(avg_s * 1e6, 2), "points_per_launch": pts_per_launch,
                            "achieved": round(k_achieved / 1e9, 2), "frac": round(k_achieved / HBM_PEAK, 4),
-                           "definition": "algorithmic bytes of the slabs one launch of the longest kernel processes / its average "
-                                         "launch duration (HIP events on the launch stream inside the timed region)"
+                           # what THIS kernel itself must move (a pass of a two-pass transform reads or writes the intermediate, too): the
+                           # figure to hold against the copy rate; `frac` above prices the whole path's bytes against one pass's time
+                           "own": own_share(dom, args.workload, ny, nx, pts_per_launch, avg_s),
+                           "definition": "algorithmic bytes OF THE WHOLE PATH for the slabs one launch of the longest kernel processes / its average "
+                                         "launch duration (HIP events on the launch stream inside the timed region); `own` = the bytes this "
+                                         "kernel alone has to move (input or intermediate read + intermediate or result written)"
                                          + (" -- of one isotropic_power_spectrum call, the plan the events are recorded on: 4 B per point"
                                             if args.workload == "c4" else "")},
                 "bytes_per_point": bpp,

@@ -62,7 +62,6 @@ def test_golden_ps2d(golden_dir):
 def test_four_step_paths(monkeypatch):
     """Force the four-step decompositions (normally only used when a sequence does not fit one LDS tile)."""
     import xrft_amd as xa
-    from oracle import xrft_oracle as o
 
     rng = np.random.default_rng(5)
     monkeypatch.setenv("XRFTHIP_X_FOURSTEP_MIN", "2")
@@ -637,3 +636,37 @@ def test_last_axis_any_smooth_length(shape, dtype):
 def test_inverse_transforms_on_the_one_pass_kernels(shape, dtype):
     """xrft.ifft over two axes as two one-pass stages, over one axis where it lies, small slabs in one pass (csrc/fastg.h)."""
     cases.run_inverse_one_pass_cases(shape, dtype)
+
+
+@pytest.mark.parametrize("axis", [0, 1])
+def test_ifft_with_a_permuted_frequency_coordinate_on_a_non_last_axis(axis):
+    """xrft.ifft sorts by the coordinate first (xrft.py:598), so an arbitrarily permuted frequency axis is legal; on a first / middle
+    axis the index map is an array, which the one-axis fast path must not compare with a string."""
+    import warnings
+
+    import xrft_amd as xa
+
+    rng = np.random.default_rng(5)
+    shape = (6, 10, 8)
+    dims = ("t", "y", "x")
+    d = dims[axis]
+    v = rng.standard_normal(shape)
+    c = {"t": np.arange(6) * 2.0, "y": np.arange(10) * 0.5 - 1.0, "x": np.arange(8) * 0.25}
+    da, _od = cases.pair(v, dims, c)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        F = xa.fft(da, dim=[d])
+        perm = rng.permutation(shape[axis])
+        assert not np.array_equal(np.sort(perm), perm) and not np.array_equal(perm[::-1], np.arange(len(perm)))
+        fd = "freq_" + d
+        idx = [slice(None)] * 3
+        idx[axis] = perm
+        fc = {k: np.asarray(F[k].values) for k in F.dims}
+        fc[fd] = fc[fd][perm]
+        lagattr = dict(F[fd].attrs)
+        Fp = xa.DataArray(np.ascontiguousarray(np.asarray(F.values)[tuple(idx)]), F.dims, {k: xa.Coordinate((k,), fc[k], lagattr if k == fd else {}, k) for k in F.dims})
+        back = xa.ifft(Fp, dim=[fd])
+        ref = xa.ifft(F, dim=[fd])  # the same spectrum in sorted order
+        assert np.abs(np.asarray(back.values) - np.asarray(ref.values)).max() < 1e-12
+        assert np.abs(np.asarray(back.values).real - v).max() < 1e-10
+        assert np.array_equal(back[d].values, ref[d].values)

@@ -161,3 +161,26 @@ def test_coordinates_are_owned_and_read_only_and_the_analysis_is_remembered_per_
     f1 = api._flags_tables(api._analyze(da2, 1e-3, ["x"], None, True, None, None, True, False, "freq_", None), da2)
     f2 = api._flags_tables(api._analyze(da2, 1e-3, ["x"], None, True, None, None, True, False, "freq_", None), da2)
     assert f1[0] == f2[0] and f1[2]["x"] is f2[2]["x"] and not f1[2]["x"].flags.writeable  # the phase table: built once
+
+
+def test_label_memo_is_keyed_by_tokens_not_by_object_identity():
+    """what the API remembers about a labelled array is keyed by a per-assignment token of each coordinate (never reused, unlike id()),
+    nothing is remembered once a coordinate array is writeable again, and a read-only VIEW of a writeable base is digested by content."""
+    import xrft_amd as xa
+    from xrft_amd import api
+
+    da = xa.DataArray(np.zeros((4, 8)), ("t", "x"), {"t": np.arange(4), "x": np.arange(8) * 0.5})
+    g0 = api._label_guard(da)
+    assert g0 is not None and api._label_guard(da) == g0
+    tok = da.coords["x"]._token
+    da.coords["x"].values = np.arange(8) * 0.25  # a new coordinate vector: a new token, read-only again
+    assert da.coords["x"]._token != tok and not da.coords["x"].values.flags.writeable
+    assert api._label_guard(da) != g0
+    da.coords["x"].values.setflags(write=True)    # re-opened for in-place edits: nothing may be remembered
+    assert api._label_guard(da) is None
+    base = np.arange(8.0)
+    view = base[:]
+    view.setflags(write=False)
+    k1 = api._akey(view)
+    base[3] = 99.0
+    assert api._akey(view) != k1

@@ -238,7 +238,7 @@ def _akey(a):
     k = _memo_ids.get(id(a))  # a memoised window vector: identified by (name, n)
     if k is not None:
         return k
-    if a.flags.writeable:
+    if a.flags.writeable or not a.flags.owndata or a.base is not None:  # (a read-only VIEW of a writeable base can change under its id)
         return _digest(a)
     with _plan_lock:
         e = _digest_ids.get(id(a))
@@ -281,10 +281,16 @@ class _Ctx:
 
 
 def _label_guard(da):
-    """What the host analysis of a labelled array depends on, by identity: coordinate vectors are owned read-only arrays
-    (labeled.Coordinate), so the same objects mean the same labels."""
-    return (da.dims, da.shape, tuple((k, id(v), id(v.values)) for k, v in da.coords.items()),
-            None if not da._chunks else tuple(sorted(da._chunks.items())))
+    """What the host analysis of a labelled array depends on: coordinate vectors are owned read-only arrays with a token that is
+    issued once per assignment of ``Coordinate.values`` and never reused (labeled.Coordinate), so the same tokens mean the same
+    labels.  None: do not remember anything (a coordinate array was made writeable again)."""
+    toks = []
+    for k, v in da.coords.items():
+        vals = v.values
+        if vals.flags.writeable:  # (someone re-opened the array for writing: its content is no longer pinned by the token)
+            return None
+        toks.append((k, v._token))
+    return (da.dims, da.shape, tuple(toks), None if not da._chunks else tuple(sorted(da._chunks.items())))
 
 
 def _analyze(da, spacing_tol, dim, real_dim, shift, detrend, window, true_phase, chunks_to_segments, prefix, real):
@@ -303,6 +309,9 @@ def _analyze(da, spacing_tol, dim, real_dim, shift, detrend, window, true_phase,
             mkey = None
     if mkey is not None:
         guard = _label_guard(da)
+        if guard is None:
+            mkey = None
+    if mkey is not None:
         memo = da._memo
         if memo is not None and memo[0] == guard:
             hit = memo[1].get(mkey)
@@ -1014,7 +1023,7 @@ def ifft(daft, spacing_tol=1e-3, dim=None, real_dim=None, shift=True, true_phase
     t = _to_device(daft.data)
     if not t.is_complex():
         t = t.to(torch.complex64 if t.dtype == torch.float32 else torch.complex128)
-    if len(dim) == 1 and real_dim is None and daft.get_axis_num(xdim) != len(daft.dims) - 1 and maps[xdim] in ("none", "ishift"):
+    if len(dim) == 1 and real_dim is None and daft.get_axis_num(xdim) != len(daft.dims) - 1 and isinstance(maps[xdim], str) and maps[xdim] in ("none", "ishift"):
         # one inverse transform along a first / middle axis: where the axis lies (XRFTHIP_AXIS_Y), no transposed copies -- as the forward call
         out = _ifft_axis_y(t, daft.get_axis_num(xdim), maps[xdim], phase[xdim], true_phase, shift, true_amplitude, new_coords[swap[xdim]])
         if out is not None:
@@ -1366,10 +1375,10 @@ def cross_spectrum(da1, da2, dim=None, real_dim=None, scaling="density", window_
     try:
         return to_like(_cross_result(c, c2, mode, scale, flags), src)
     except _UnsupportedLength:
-        d1w, wide = _wide(da1)
-        d2w, _ = _wide(da2)
+        d1w, wide1 = _wide(da1)
+        d2w, wide2 = _wide(da2)  # (narrowed back only when BOTH were widened: float32 x float64 stays the promoted complex128, whatever the order)
         return to_like(_narrow(_spectrum_nd(d1w, d2w, _two_dims(da1, dim, real_dim, kwargs.get("real")), real_dim, scaling, window_correction, true_phase,
-                                            dict(kwargs), one_at_a_time=True), wide), src)
+                                            dict(kwargs), one_at_a_time=True), wide1 and wide2), src)
 
 
 def _cross_result(c, c2, mode, scale, flags):

@@ -10,12 +10,17 @@ and hand the same type back (see ``from_any`` / ``to_like``).
 """
 from __future__ import annotations
 
+import itertools
+
 import numpy as np
 
 try:  # torch is the device-memory carrier; the container itself also works with plain numpy
     import torch
 except Exception:  # pragma: no cover
     torch = None
+
+
+_coord_tokens = itertools.count(1)
 
 
 class Coordinate:
@@ -26,13 +31,24 @@ class Coordinate:
         # The values are an owned, read-only array (xarray keeps its dimension coordinates in immutable indexes, too): what the API
         # derives from a coordinate vector (spacing check, lag, digest) can then be remembered by the array's identity instead of
         # being re-derived from its bytes on every call.  An array that already is an owned read-only one is shared, not copied.
-        a = values if isinstance(values, np.ndarray) else np.asarray(values)
-        if a.flags.writeable or not a.flags.owndata:
-            a = np.array(a, copy=True)
-            a.setflags(write=False)
-        self.values = a
+        # NOTE for callers: ``coord.values`` is read-only (assign a new array to ``coord.values`` to change a coordinate; in-place edits raise).
+        self.values = values
         self.attrs = dict(attrs or {})
         self.name = name
+
+    @property
+    def values(self):
+        return self._values
+
+    @values.setter
+    def values(self, values):
+        a = values if isinstance(values, np.ndarray) else np.asarray(values)
+        if a.flags.writeable or not a.flags.owndata or a.base is not None:
+            a = np.array(a, copy=True)
+            a.setflags(write=False)
+        self._values = a
+        # a token that is never reused (``id()`` of a freed object is): what the API remembers about this coordinate is keyed by it
+        self._token = next(_coord_tokens)
 
     # numpy interop so that ``npt.assert_allclose(ft["freq_x"], expected)`` works as with xarray
     def __array__(self, dtype=None, copy=None):
