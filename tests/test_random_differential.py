@@ -288,6 +288,88 @@ def test_random_fastm_case(seed):
     run_random_fastm(seed, lengths=(360,), dtype="float64" if seed % 2 == 0 else "float32")
 
 
+def smooth_lengths(lo, hi, primes=(2, 3, 5, 7, 11, 13)):
+    """Every n in [lo, hi] whose prime factors are all in `primes` (the butterflies of csrc/fastn.h)."""
+    out = []
+    for n in range(lo, hi + 1):
+        m = n
+        for q in primes:
+            while m % q == 0:
+                m //= q
+        if m == 1:
+            out.append(n)
+    return out
+
+
+def run_random_fastn(seed, lo=16, hi=200, dtype="float64", blue_p=0.15):
+    """Random mode / option combinations on slabs whose lengths are NOT in any table: csrc/fastn.h, the y-first two-pass pipeline with the lengths
+    as data (run-time radices incl. 7 / 11 / 13, odd lengths, ragged column blocks; now and then a column length with a large prime factor:
+    the chirp convolution inside the tile).  A flipped axis must come out right through the generic passes."""
+    import xrft_amd as xa
+
+    rng = np.random.default_rng(9000 + seed)
+    lens = smooth_lengths(lo, hi)
+    ny, nx = int(rng.choice(lens)), int(rng.choice(lens))
+    blue = bool(rng.random() < blue_p)
+    if blue:  # a length the butterflies do not factor (a prime factor >= 17)
+        cand = [n for n in range(lo, hi + 1) if n not in set(lens)]
+        ny = int(rng.choice(cand))
+    nb = int(rng.integers(1, 4))
+    v = rng.standard_normal((nb, ny, nx)).astype(dtype)
+    v += ((0.01 * np.arange(ny))[None, :, None] + (-0.02 * np.arange(nx) + 3)[None, None, :]).astype(dtype)
+    v *= (1 + np.arange(nb, dtype=dtype))[:, None, None]
+    desc = bool(rng.random() < 0.1)
+    yc = np.arange(ny) * float(rng.choice([0.5, 1.0])) + float(rng.choice([0.0, 2.0]))
+    c = {"t": np.arange(nb), "y": yc[::-1].copy() if desc else yc, "x": np.arange(nx) * float(rng.choice([0.25, 1.0])) - float(rng.choice([0.0, 3.0]))}
+    da, od = cases.pair(v, ("t", "y", "x"), c)
+    w = rng.standard_normal((nb, ny, nx)).astype(dtype)
+    db, ob = cases.pair(w, ("t", "y", "x"), c)
+    kw = dict(detrend=rng.choice([None, "constant", "linear"]), window=rng.choice([None, "hann", "hamming"]))
+    kind = str(rng.choice(["ps", "ps", "fft", "cs", "iso", "isocs", "ps_real", "phase"]))
+    shift = bool(rng.random() < 0.7)
+    tp = bool(rng.random() < 0.5)
+    tr = bool(rng.random() < 0.3)
+    api._plan_cache.clear()
+    if kind == "ps":
+        sc = str(rng.choice(["density", "spectrum"]))
+        got, ref = xa.power_spectrum(da, dim=["y", "x"], shift=shift, scaling=sc, **kw), o.power_spectrum(od, dim=["y", "x"], shift=shift, scaling=sc, **kw)
+    elif kind == "fft":
+        got, ref = xa.fft(da, dim=["y", "x"], shift=shift, true_phase=tp, **kw), o.fft(od, dim=["y", "x"], shift=shift, true_phase=tp, **kw)
+    elif kind == "cs":
+        got, ref = xa.cross_spectrum(da, db, dim=["y", "x"], shift=shift, true_phase=tp, **kw), o.cross_spectrum(od, ob, dim=["y", "x"], shift=shift, true_phase=tp, **kw)
+    elif kind == "phase":
+        got, ref = xa.cross_phase(da, db, dim=["y", "x"], shift=shift, true_phase=tp, **kw), o.cross_phase(od, ob, dim=["y", "x"], shift=shift, true_phase=tp, **kw)
+    elif kind == "iso":
+        got, ref = xa.isotropic_power_spectrum(da, dim=["y", "x"], truncate=tr, **kw), o.isotropic_power_spectrum(od, dim=["y", "x"], truncate=tr, **kw)
+    elif kind == "isocs":
+        got, ref = xa.isotropic_cross_spectrum(da, db, dim=["y", "x"], truncate=tr, true_phase=tp, **kw), o.isotropic_cross_spectrum(od, ob, dim=["y", "x"], truncate=tr, true_phase=tp, **kw)
+    else:
+        got, ref = xa.power_spectrum(da, dim=["y"], real_dim="x", **kw), o.power_spectrum(od, dim=["y"], real_dim="x", **kw)
+    tags = [p.describe() for p in api._plan_cache.values()]
+    on = any("[fastn]" in t for t in tags)
+    flipped = desc and tp and kind in ("fft", "cs", "phase", "isocs")
+    assert not (on and flipped), (kind, desc, tp, ny, nx, on)
+    if kind == "ps" and not any("[fastg" in t or "[fasts" in t or "[fastm]" in t or "[fasty" in t for t in tags):
+        assert on, (kind, ny, nx, dtype, tags)  # (a plain power spectrum of a slab no other specialised kernel takes is always served here)
+    if kind == "phase":  # (the angle of a near-zero cross spectrum amplifies rounding: compare where the product is not small)
+        assert tuple(got.dims) == tuple(ref.dims)
+        cs = o.cross_spectrum(od, ob, dim=["y", "x"], shift=shift, true_phase=tp, **kw).values
+        big = np.abs(cs) > 1e-3 * np.abs(cs).max()
+        dphi = np.angle(np.exp(1j * (np.asarray(got.values) - ref.values)))
+        assert np.abs(dphi[big]).max() < (1e-7 if dtype == "float64" else 2e-2), np.abs(dphi[big]).max()
+    else:
+        cases.check(got, ref, 1e-10 if dtype == "float64" else 3e-4)
+    return "fastn" if on else "other"
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("XRFT_RANDOM_FASTN_CASES", "24"))))
+def test_random_fastn_case(seed, monkeypatch):
+    """csrc/fastn.h on the emulator: small slabs are kept off the one-pass kernel (XRFTHIP_FASTG=0) so that the two-pass pipeline with run-time
+    radices serves them."""
+    monkeypatch.setenv("XRFTHIP_FASTG", "0")
+    run_random_fastn(seed, lo=16, hi=130, dtype="float64" if seed % 2 == 0 else "float32")
+
+
 _ONE_AXIS_LENGTHS = (100, 128, 180, 200, 240, 256, 360, 400, 480, 500, 512, 600, 720, 800, 960, 1000, 1024, 1200, 1440, 2048, 4096)
 
 

@@ -66,4 +66,12 @@ XRFT_M_LATLON(XRFT_KI_M1F_) XRFT_M_F32ONLY(XRFT_KI_M1F_) XRFT_M_POW2(XRFT_KI_M1F
 #undef XRFT_KI_M1D_
 #undef XRFT_KI_M1F_
 #endif
+#if XRFT_KI_ON(6)  // ---- fastn.h: the y-first pipeline with the lengths as data
+#define XRFT_KI_N_(TT) \
+    XRFT_KW void fastn_cols_kernel<TT, false>(FastN); XRFT_KW void fastn_cols_kernel<TT, true>(FastN); \
+    XRFT_KW void fastn_rows_kernel<TT, 0, false>(FastN); XRFT_KW void fastn_rows_kernel<TT, 1, false>(FastN); XRFT_KW void fastn_rows_kernel<TT, 1, true>(FastN); \
+    XRFT_KW void fastn_rows_kernel<TT, 2, false>(FastN); XRFT_KW void fastn_rows_kernel<TT, 2, true>(FastN); XRFT_KW void fastn_rows_kernel<TT, 3, false>(FastN);
+XRFT_KI_N_(float) XRFT_KI_N_(double)
+#undef XRFT_KI_N_
+#endif
 #undef XRFT_KI_ON

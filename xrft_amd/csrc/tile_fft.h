@@ -169,6 +169,47 @@ template <typename T> __device__ __forceinline__ void dft9(C2<T>* a) {
     }
 }
 
+// odd primes 7, 11, 13 (numpy's pocketfft has hard-coded passes for 7 and 11): with s_k = a[k] + a[P-k], d_k = a[k] - a[P-k],
+//   X[m], X[P-m] = (a0 + sum_k cos(2 pi m k / P) s_k) -/+ i (sum_k sin(2 pi m k / P) d_k)  --  H^2 real x complex products each, H = (P - 1) / 2.
+// Every table index is a compile-time constant after unrolling.
+template <typename T, int P> struct PrimeTab;
+template <typename T> struct PrimeTab<T, 7> {
+    static __device__ __forceinline__ T c(int k) { const T t[3] = {(T)0.623489801858733530525, (T)-0.2225209339563144042889, (T)-0.9009688679024191262361}; return t[k - 1]; }
+    static __device__ __forceinline__ T s(int k) { const T t[3] = {(T)0.7818314824680298087084, (T)0.9749279121818236070181, (T)0.4338837391175581204758}; return t[k - 1]; }
+};
+template <typename T> struct PrimeTab<T, 11> {
+    static __device__ __forceinline__ T c(int k) { const T t[5] = {(T)0.8412535328311811688618, (T)0.4154150130018864255293, (T)-0.1423148382732851404438, (T)-0.6548607339452850640569, (T)-0.9594929736144973898904}; return t[k - 1]; }
+    static __device__ __forceinline__ T s(int k) { const T t[5] = {(T)0.5406408174555975821076, (T)0.9096319953545183714117, (T)0.9898214418809327323761, (T)0.755749574354258283774, (T)0.2817325568414296977114}; return t[k - 1]; }
+};
+template <typename T> struct PrimeTab<T, 13> {
+    static __device__ __forceinline__ T c(int k) { const T t[6] = {(T)0.8854560256532098959004, (T)0.5680647467311558025118, (T)0.1205366802553230533491, (T)-0.3546048870425356259696, (T)-0.7485107481711010986346, (T)-0.970941817426052027157}; return t[k - 1]; }
+    static __device__ __forceinline__ T s(int k) { const T t[6] = {(T)0.464723172043768545656, (T)0.8229838658936563945796, (T)0.9927088740980539928008, (T)0.9350162426854148234398, (T)0.6631226582407952023768, (T)0.2393156642875577671488}; return t[k - 1]; }
+};
+template <typename T, int P> __device__ __forceinline__ void dft_prime(C2<T>* a) {
+    constexpr int H = (P - 1) / 2;
+    C2<T> sm[H], df[H];
+#pragma unroll
+    for (int k = 1; k <= H; ++k) { sm[k - 1] = a[k] + a[P - k]; df[k - 1] = a[k] - a[P - k]; }
+    const C2<T> a0 = a[0];
+    C2<T> tot = a0;
+#pragma unroll
+    for (int k = 0; k < H; ++k) tot = tot + sm[k];
+    a[0] = tot;
+#pragma unroll
+    for (int m = 1; m <= H; ++m) {
+        C2<T> A = a0, B = mk<T>((T)0, (T)0);
+#pragma unroll
+        for (int k = 1; k <= H; ++k) {
+            const int mk_ = (m * k) % P, idx = mk_ <= H ? mk_ : P - mk_;   // cos is even, sin odd around P / 2
+            const T cc = PrimeTab<T, P>::c(idx), ss = mk_ <= H ? PrimeTab<T, P>::s(idx) : -PrimeTab<T, P>::s(idx);
+            A = mk<T>(A.re + cc * sm[k - 1].re, A.im + cc * sm[k - 1].im);
+            B = mk<T>(B.re + ss * df[k - 1].re, B.im + ss * df[k - 1].im);
+        }
+        a[m] = A + mul_mi(B);       // A - i B
+        a[P - m] = A + mul_pi(B);   // A + i B
+    }
+}
+
 template <typename T, int R> __device__ __forceinline__ void dft_r(C2<T>* a) {
     if (R == 1) return;
     if (R == 2) dft2(a[0], a[1]);
@@ -176,10 +217,14 @@ template <typename T, int R> __device__ __forceinline__ void dft_r(C2<T>* a) {
     else if (R == 4) dft4(a);
     else if (R == 5) dft5(a);
     else if (R == 6) dft_pfa<T, 2, 3>(a);
+    else if (R == 7) dft_prime<T, 7>(a);
     else if (R == 8) dft8(a);
     else if (R == 9) dft9(a);
     else if (R == 10) dft_pfa<T, 2, 5>(a);
+    else if (R == 11) dft_prime<T, 11>(a);
     else if (R == 12) dft_pfa<T, 4, 3>(a);
+    else if (R == 13) dft_prime<T, 13>(a);
+    else if (R == 14) dft_pfa<T, 2, 7>(a);
     else if (R == 15) dft_pfa<T, 3, 5>(a);
     else if (R == 16) dft16(a);
     else if (R == 18) dft_pfa<T, 2, 9>(a);

@@ -30,6 +30,7 @@
 #include "fastp2.h"
 #include "fasty.h"
 #include "fastm.h"
+#include "fastn.h"
 #include "fastr.h"
 #include "fasts.h"
 #include "tile_fft.h"
@@ -328,6 +329,15 @@ struct xrfthip_plan {
     bool fast1d = false;
     // ... and its mixed-radix float64 form (fastm.h): lengths 360 / 720 / 1440
     bool fastm = false;
+    // ... and the same pipeline with the LENGTHS AS DATA (fastn.h): either pass (or both) of a `fastm` plan may be the run-time-radix kernel -- every
+    // length that is a product of the butterflies 2 ... 20 (7, 11, 13 included), and for the columns any other length through a chirp convolution
+    bool fastn = false;
+    struct NSide { bool rt = false; NGeo geo{}; size_t lds = 0; DevBuf twm; };
+    NSide n_c, n_r;                 // pass 1 (columns, length ny) and pass 2 (rows, length nx)
+    int n_cw = 0, n_rk = 1, n_rpu = 0, n_nxb = 0;  // the intermediate's layout: columns per block, rows per line; rows per pass-2 workgroup; column blocks per row
+    long long y_pitch = 0;          // complex elements per row of the intermediate (ynx, or n_nxb * n_cw when the last column block is ragged)
+    int n_blue_m = 0;               // pass 1 through a chirp convolution of this length
+    DevBuf n_bluec, n_blueb;
     // ... and pass 1 alone for ONE transform axis that is not the contiguous one (XRFTHIP_AXIS_Y, fastm_yonly_kernel)
     bool fastmy = false;
     // ... and the same transform over short contiguous rows packed in pairs (ndim = 1, fastm_xonly_kernel)
@@ -850,6 +860,11 @@ void set_kernel_attrs_once() {
     SETF((fastg_kernel<float, 0, true>)); SETF((fastg_kernel<float, 1, true>)); SETF((fastg_kernel<double, 0, true>)); SETF((fastg_kernel<double, 1, true>));
     SETF((fastgy_kernel<float, 0, false>)); SETF((fastgy_kernel<float, 1, false>)); SETF((fastgy_kernel<double, 0, false>)); SETF((fastgy_kernel<double, 1, false>));
     SETF((fastgy_kernel<float, 0, true>)); SETF((fastgy_kernel<float, 1, true>)); SETF((fastgy_kernel<double, 0, true>)); SETF((fastgy_kernel<double, 1, true>));
+    SETF((fastn_cols_kernel<float, false>)); SETF((fastn_cols_kernel<float, true>)); SETF((fastn_cols_kernel<double, false>)); SETF((fastn_cols_kernel<double, true>));
+#define SETN(TT) SETF((fastn_rows_kernel<TT, 0, false>)); SETF((fastn_rows_kernel<TT, 1, false>)); SETF((fastn_rows_kernel<TT, 1, true>)); SETF((fastn_rows_kernel<TT, 2, false>)); \
+                 SETF((fastn_rows_kernel<TT, 2, true>)); SETF((fastn_rows_kernel<TT, 3, false>))
+    SETN(float); SETN(double);
+#undef SETN
     SETF((fasts_power_kernel<8, 8, 0, 0>)); SETF((fasts_power_kernel<8, 4, 0, 0>)); SETF((fasts_power_kernel<4, 8, 0, 0>));
     SETF((fasts_power_kernel<8, 8, 0>)); SETF((fasts_power_kernel<8, 8, 1>)); SETF((fasts_power_kernel<8, 8, 2>));  // (above 64 KB of dynamic LDS)
     SETF((fasts_power_kernel<8, 4, 0>)); SETF((fasts_power_kernel<8, 4, 1>)); SETF((fasts_power_kernel<8, 4, 2>));
@@ -979,7 +994,7 @@ static void layout_workspace(xrfthip_plan* P) {
     size_t slab_w = (size_t)d.ny * std::max(P->width, P->w_cols) * P->csize;
     const bool yf = fast && P->yfirst;
     if (fast) {
-        slab_w = (size_t)P->y_nrow_pad * P->ynx * (P->fastm ? P->csize : sizeof(cf));
+        slab_w = (size_t)P->y_nrow_pad * (size_t)(P->y_pitch > 0 ? P->y_pitch : P->ynx) * (P->fastm ? P->csize : sizeof(cf));
         if (G <= 0) G = P->tune_fast_group > 0 ? P->tune_fast_group : std::max<long long>(1, (64LL * 4096 * 4096) / (d.ny * d.nx));  // y-first, 4096^2: 16: 62.7, 32: 61.4 us per slab; 32 -> 64: 301-303 -> 306-307 GFFT/s (tails, launch gaps and the plane-fit bubble amortise)
     }
     if (G <= 0) {
@@ -1581,6 +1596,11 @@ static int fastm_rpu(long long nx, bool two, bool dbl) { const MGeomRt r = mgeom
 // rows per line of the intermediate for a (ny, nx) plan: a whole 128-byte line of pass 1's CW columns, but never more rows than
 // one pass-2 workgroup owns (long float32 sequences: two per workgroup = 4 columns = 32 bytes per row, pass 2 takes 2 rows -> 64-byte pieces)
 static int fastm_rk2(long long ny, long long nx, bool two, bool dbl) { return std::max(1, std::min(fastm_rk(ny, nx, dbl), fastm_rpu(nx, two, dbl))); }
+// ... of a plan: the table's geometry, or what fastn_setup chose when either pass runs on the run-time-radix kernels (fastn.h)
+static bool plan_two(const xrfthip_plan* P) { return P->d.out_mode == XRFTHIP_OUT_CROSS || P->d.out_mode == XRFTHIP_OUT_PHASE; }
+static int plan_cw(const xrfthip_plan* P) { return P->fastn ? P->n_cw : fastm_cw(P->yny, P->ynx, P->dbl); }
+static int plan_rk2(const xrfthip_plan* P) { return P->fastn ? P->n_rk : fastm_rk2(P->yny, P->ynx, plan_two(P), P->dbl); }
+static int plan_nxb(const xrfthip_plan* P) { return P->fastn ? P->n_nxb : (int)(P->ynx / fastm_cw(P->yny, P->ynx, P->dbl)); }
 
 // radial sums inside pass 2 when the per-bin tables fit behind the transforms' LDS (64 KB of dynamic LDS per workgroup); otherwise
 // the spectrum is stored and summed by run_radial_sums
@@ -1592,6 +1612,7 @@ static bool fastm_iso_gather(const xrfthip_plan* P) {
 static bool fastm_iso_fused(const xrfthip_plan* P) {
     if (!P->fastm || !(P->d.flags & XRFTHIP_ISO) || P->nbins < 1) return false;
     if (fastm_iso_gather(P)) return true;
+    if (P->fastn && P->n_r.rt) return false;  // (the run-time-radix row kernel fuses the gather of a radial map only: any other map is summed from the stored spectrum)
     const bool cx = P->d.out_mode == XRFTHIP_OUT_CROSS;
     const MGeomRt R = mgeom(P->ynx, P->dbl);
     return (cx ? R.lds_rows : R.lds_r1) + (size_t)P->nbins * (cx ? 20 : 12) <= 64 * 1024;
@@ -1611,9 +1632,255 @@ static int fastm_iso_ncopy(const xrfthip_plan* P) {
 // rows per pass-2 workgroup of this plan: two fields share a workgroup's sequences (MRowsG in fastm.h)
 static int fastm_gather_rpu(const xrfthip_plan* P) { return fastm_rows_rpu(P); }
 static int fastm_rows_rpu(const xrfthip_plan* P) {
+    if (P->fastn) return P->n_rpu;
     const bool two = P->d.out_mode == XRFTHIP_OUT_CROSS || P->d.out_mode == XRFTHIP_OUT_PHASE;
     const MGeomRt r = mgeom(P->ynx, P->dbl);
     return two ? r.g / 2 : r.g_r1;
+}
+
+
+// ---------------------------------------------------------------------------------------------------------------
+// the same pipeline with the lengths as data (fastn.h)
+// ---------------------------------------------------------------------------------------------------------------
+// n as a product of 2 .. kNMaxPass butterflies of fastn.h's set: the fewest passes, then the smallest largest radix (registers; threads per pass), then the
+// smallest sum; ascending, so that the last pass -- one butterfly per thread -- has the fewest butterflies.  False: n has another prime factor, or too many passes.
+static bool fastn_factor(long long n, int maxr, std::vector<int>& out, int need_last = 0) {  // need_last: the largest radix must reach it (the last pass: one butterfly per thread)
+    static const int R[] = {20, 18, 16, 15, 14, 13, 12, 11, 10, 9, 8, 7, 6, 5, 4, 3, 2};
+    static const int PR[] = {2, 3, 5, 7, 11, 13};
+    int ex[6] = {0, 0, 0, 0, 0, 0};
+    long long m = n;
+    for (int i = 0; i < 6; ++i) while (m % PR[i] == 0) { ++ex[i]; m /= PR[i]; }
+    if (m != 1 || n < 4) return false;
+    int re[17][6];
+    for (int i = 0; i < 17; ++i) { int v = R[i]; for (int k = 0; k < 6; ++k) { re[i][k] = 0; while (v % PR[k] == 0) { ++re[i][k]; v /= PR[k]; } } }
+    std::vector<int> best, cur;
+    auto better = [](const std::vector<int>& a, const std::vector<int>& b) {  // (a complete, b the incumbent)
+        if (b.empty()) return true;
+        if (a.size() != b.size()) return a.size() < b.size();
+        const int ma = *std::max_element(a.begin(), a.end()), mb = *std::max_element(b.begin(), b.end());
+        if (ma != mb) return ma < mb;
+        int sa = 0, sb = 0; for (int v : a) sa += v; for (int v : b) sb += v;
+        return sa < sb;
+    };
+    std::function<void(int)> dfs = [&](int from) {
+        bool done = true;
+        for (int k = 0; k < 6; ++k) if (ex[k]) done = false;
+        if (done) { if (cur.size() >= 2 && cur[0] >= need_last && better(cur, best)) best = cur; return; }
+        if ((int)cur.size() >= kNMaxPass || (!best.empty() && cur.size() + 1 > best.size()) || (!cur.empty() && cur[0] < need_last)) return;  // (non-increasing: cur[0] is the largest)
+        for (int i = from; i < 17; ++i) {  // non-increasing radices: each multiset once
+            if (R[i] > maxr) continue;
+            bool fits = true;
+            for (int k = 0; k < 6; ++k) if (re[i][k] > ex[k]) fits = false;
+            if (!fits) continue;
+            for (int k = 0; k < 6; ++k) ex[k] -= re[i][k];
+            cur.push_back(R[i]);
+            dfs(i);
+            cur.pop_back();
+            for (int k = 0; k < 6; ++k) ex[k] += re[i][k];
+        }
+    };
+    dfs(0);
+    if (best.empty()) return false;
+    std::sort(best.begin(), best.end());
+    out = best;
+    return true;
+}
+
+// the geometry of one n-point transform held in LDS with g sequences per workgroup (fastn.h, NGeo); blue: the Bluestein plan's natural layout is its intermediate layout
+static void fastn_geom(long long n, const std::vector<int>& rad, int g, int maxthr, bool blue, NGeo& o) {
+    o = NGeo{};
+    o.n = (int)n; o.np = (int)rad.size();
+    long long L = n;
+    for (int p = 0; p < o.np; ++p) { o.r[p] = rad[(size_t)p]; o.inv_r[p] = 1.0f / (float)rad[(size_t)p]; o.m[p] = (int)(L / rad[(size_t)p]); L /= rad[(size_t)p]; }
+    const int rl = o.r[o.np - 1], pdq = (rl % 2 == 0) ? rl : 0;
+    int pnq = (o.r[0] % 2 == 0) ? o.r[0] : 0;
+    if (blue) pnq = pdq;
+    o.inv_pdq = pdq ? 1.0f / (float)pdq : 0.0f;
+    o.inv_pnq = pnq ? 1.0f / (float)pnq : 0.0f;
+    o.pn_r0 = (pnq != 0 && pnq == o.r[0]) ? 1 : 0;
+    for (int p = 0; p < o.np; ++p) o.step[p] = o.m[p] + ((pdq && p + 1 < o.np) ? o.m[p] / pdq : 0);
+    o.wlast = 1;
+    for (int p = 1; p + 1 < o.np; ++p) o.wlast *= o.r[p];
+    int acc = 0;
+    for (int p = 1; p + 1 < o.np; ++p) { o.two[p] = acc; acc += o.m[p] * o.r[p]; }
+    o.twn = acc;
+    const long long span = n + std::max<long long>(pdq ? n / pdq : 0, pnq ? n / pnq : 0) + 1;
+    o.str = (int)(((span + 3) / 8) * 8 + 4);  // the smallest s >= span with s = 4 (mod 8): sequences eight lanes touch land on disjoint banks (fastm.h)
+    o.g = g; o.lg = ilog2i(g);
+    long long bmax = 0;
+    for (int p = 0; p < o.np; ++p) bmax = std::max<long long>(bmax, n / o.r[p]);
+    long long thr = std::min<long long>(maxthr, ((g * bmax + 63) / 64) * 64);
+    thr = std::max<long long>(thr, ((g * (n / rl) + 63) / 64) * 64);  // (the last pass: one butterfly per thread)
+    o.thr = (int)thr;
+}
+
+template <typename T> static int fastn_upload_twm(const NGeo& g, DevBuf& buf) {  // W_{L_p}^(j k) at [two[p] + j r[p] + k], p = 1 .. np - 2
+    std::vector<C2<T>> t((size_t)std::max(g.twn, 1));
+    const long double pi2 = 2.0L * 3.14159265358979323846264338327950288L;
+    for (int p = 1; p + 1 < g.np; ++p) {
+        const int Lp = g.m[p] * g.r[p];
+        for (int j = 0; j < g.m[p]; ++j)
+            for (int k = 0; k < g.r[p]; ++k) {
+                const long double a = -pi2 * (long double)(((long long)j * k) % Lp) / (long double)Lp;
+                t[(size_t)(g.two[p] + j * g.r[p] + k)].re = (T)cosl(a);
+                t[(size_t)(g.two[p] + j * g.r[p] + k)].im = (T)sinl(a);
+            }
+    }
+    return buf.upload(t.data(), t.size() * sizeof(C2<T>));
+}
+
+// Bluestein tables of pass 1: c[k] = exp(i pi k^2 / n), k < n, and FFT_m(chirp) / m in natural order
+template <typename T> static int fastn_blue_tables(xrfthip_plan* P) {
+    const long long N = P->d.ny;
+    const int m = P->n_blue_m;
+    const long double pi = 3.14159265358979323846264338327950288L;
+    std::vector<C2<T>> c((size_t)N), bh((size_t)m);
+    std::vector<double> br((size_t)m, 0.0), bi((size_t)m, 0.0);
+    for (long long k = 0; k < N; ++k) {
+        const long double a = pi * (long double)((k * k) % (2 * N)) / (long double)N;
+        const long double cr = cosl(a), ci = sinl(a);
+        c[(size_t)k].re = (T)cr; c[(size_t)k].im = (T)ci;
+        br[(size_t)k] = (double)cr; bi[(size_t)k] = (double)ci;
+        if (k) { br[(size_t)(m - k)] = (double)cr; bi[(size_t)(m - k)] = (double)ci; }
+    }
+    host_fft_smooth(br, bi);
+    for (int k = 0; k < m; ++k) { bh[(size_t)k].re = (T)(br[(size_t)k] / m); bh[(size_t)k].im = (T)(bi[(size_t)k] / m); }
+    int rc = P->n_bluec.upload(c.data(), c.size() * sizeof(C2<T>));
+    if (!rc) rc = P->n_blueb.upload(bh.data(), bh.size() * sizeof(C2<T>));
+    return rc;
+}
+
+static size_t fastn_lds(const NGeo& g, size_t csize, bool cols) {
+    return ((size_t)g.g * g.str + g.twn) * csize + (cols ? (size_t)(g.thr / 64) * g.g * 4 * sizeof(double) : 0);
+}
+
+// Decide which kernel runs each pass of a y-first plan on (ny, nx) and the layout of the intermediate between them.  Returns false when the plan stays
+// with the other paths (a length the butterflies do not factor and the chirp convolution does not fit, sequences that do not fit the LDS).
+static bool fastn_setup(xrfthip_plan* P) {
+    const xrfthip_desc& d = P->d;
+    const bool dbl = P->dbl, two = plan_two(P);
+    const size_t cs = P->csize;
+    const int maxthr = dbl ? fastn_max_threads<double>() : fastn_max_threads<float>();
+    const int maxr = (int)env_ll("XRFTHIP_FASTN_MAXR", dbl ? fastn_max_radix<double>() : fastn_max_radix<float>());
+    if (d.ny < 16 || d.nx < 16 || d.ny > 16384 || d.nx > 16384 || (unsigned long long)d.ny * (unsigned long long)d.nx * P->rsize >= (1ULL << 32)) return false;
+    const bool tab_ok = env_ll("XRFTHIP_FASTN_TABLES", 1) != 0;  // (0: the run-time-radix kernels even where the table has the length -- measurements)
+    bool cols_rt = !(tab_ok && fastm_len(d.ny, dbl)), rows_rt = !(tab_ok && fastm_len(d.nx, dbl));
+    if (!cols_rt && !rows_rt) return false;  // (plain fastm)
+    if (!cols_rt && d.nx % fastm_cw(d.ny, d.nx, dbl) != 0) cols_rt = true;  // (the table's column kernel wants whole column blocks)
+    // ---- rows (length nx)
+    std::vector<int> rx, ry;
+    int rpu = 0;
+    NGeo gr{};
+    auto need_last = [&](long long g, long long n) { return (int)((g * n + maxthr - 1) / maxthr); };  // one last-pass butterfly per thread: g n / r_last <= maxthr
+    if (rows_rt) {
+        if (!fastn_factor(d.nx, maxr, rx)) return false;
+        // rows per workgroup: reads and writes are contiguous whatever the count, and many small workgroups interleave their phases best (fastm.h): the
+        // count that leaves 6, else 3, 2, 1 workgroups on a CU -- but two rows at least while they fit, so that W2's lines hold two rows' pieces
+        const long long forced = env_ll("XRFTHIP_FASTN_RPU", 0);
+        static const size_t caps[] = {26 * 1024, 52 * 1024, 78 * 1024, 156 * 1024};
+        for (int ci = 0; ci < 4 && !rpu; ++ci)
+            for (int cand = 4; cand >= 1 && !rpu; cand >>= 1) {
+                if (ci < 3 && cand > 2) continue;
+                if (forced && cand != forced) continue;
+                NGeo t{};
+                if (!fastn_factor(d.nx, maxr, rx, need_last(two ? 2 * cand : cand, d.nx))) continue;
+                fastn_geom(d.nx, rx, two ? 2 * cand : cand, maxthr, false, t);
+                if ((long long)t.g * (d.nx / t.r[t.np - 1]) > maxthr) continue;
+                if (fastn_lds(t, cs, false) <= caps[ci] && 2 * cand <= 64) { rpu = cand; gr = t; }
+            }
+        if (!rpu) return false;
+    } else {
+        rpu = fastm_rpu(d.nx, two, dbl);
+        if (rpu < 1) return false;
+    }
+    // ---- columns (length ny, or the chirp convolution's m)
+    int cw = 0, blue_m = 0;
+    NGeo gc{};
+    if (cols_rt) {
+        long long mlen = d.ny;
+        if (!fastn_factor(d.ny, maxr, ry)) {
+            // a prime factor without a butterfly: x conj(c) zero-padded to m >= 2 ny - 1 -> FFT_m -> * FFT_m(chirp) / m -> inverse FFT_m -> * conj(c).  The m with the
+            // fewest passes within 12 % of the smallest candidate
+            std::vector<int> best;
+            long long bm = 0;
+            for (long long m = 2 * d.ny - 1; m <= (2 * d.ny - 1) * 9 / 8 + 16; ++m) {
+                std::vector<int> t;
+                if (!fastn_factor(m, std::min(maxr, 16), t)) continue;
+                if (best.empty() || t.size() < best.size()) { best = t; bm = m; }
+            }
+            if (best.empty()) return false;
+            ry = best; mlen = bm; blue_m = (int)bm;
+        }
+        const int gmax = dbl ? 4 : 8, gpref = dbl ? 2 : 4;  // (32-byte row segments at least where they fit: 16-byte segments load at half the rate, fastm.h)
+        const long long forced = env_ll("XRFTHIP_FASTN_GC", 0);
+        static const size_t caps[] = {52 * 1024, 78 * 1024, 156 * 1024};
+        int G = 0;
+        for (int ci = 0; ci < 3 && !G; ++ci)
+            for (int cand = gmax; cand >= 1 && !G; cand >>= 1) {
+                if (forced && cand != forced) continue;
+                if (ci < 2 && cand < gpref && !forced) continue;
+                if (!rows_rt && d.nx % (2 * cand) != 0) continue;  // (the table's row kernel reads an unpadded intermediate)
+                if (2LL * cand > d.nx + 1) continue;
+                NGeo t{};
+                if (!fastn_factor(mlen, blue_m ? std::min(maxr, 16) : maxr, ry, need_last(cand, mlen))) continue;
+                fastn_geom(mlen, ry, cand, maxthr, blue_m != 0, t);
+                if ((long long)t.g * (mlen / t.r[t.np - 1]) > maxthr) continue;
+                if (fastn_lds(t, cs, true) <= caps[ci]) { G = cand; gc = t; }
+            }
+        if (!G) return false;
+        cw = 2 * G;
+    } else {
+        cw = fastm_cw(d.ny, d.nx, dbl);
+    }
+    const int nxb = (int)((d.nx + cw - 1) / cw);
+    const long long pitch = (long long)nxb * cw;
+    if (!rows_rt && pitch != d.nx) return false;
+    int rk = (int)std::max<long long>(1, std::min<long long>((long long)(128 / (cw * cs)), rpu));
+    if (rpu % rk != 0) return false;
+    P->fastn = true;
+    P->n_c.rt = cols_rt; P->n_c.geo = gc; P->n_c.lds = cols_rt ? fastn_lds(gc, cs, true) : 0;
+    P->n_r.rt = rows_rt; P->n_r.geo = gr; P->n_r.lds = rows_rt ? fastn_lds(gr, cs, false) : 0;
+    P->n_cw = cw; P->n_rk = rk; P->n_rpu = rpu; P->n_nxb = nxb; P->y_pitch = pitch; P->n_blue_m = blue_m;
+    return true;
+}
+
+static FastN fastn_wrap(const xrfthip_plan* P, const FastM& m, bool cols) {
+    FastN n{};
+    n.f = m;
+    n.g = cols ? P->n_c.geo : P->n_r.geo;
+    n.twm = cols ? P->n_c.twm.p : P->n_r.twm.p;
+    n.pitch = (int)P->y_pitch; n.nxb = P->n_nxb;
+    n.pair_ok = (P->ynx % 2 == 0) ? 1 : 0;
+    n.blue_c = P->n_bluec.p; n.blue_b = P->n_blueb.p;
+    const bool cplx_out = P->d.out_mode == XRFTHIP_OUT_COMPLEX || P->d.out_mode == XRFTHIP_OUT_CROSS;
+    const int vw = (int)(16 / (cplx_out ? P->csize : P->rsize));
+    n.vec_ok = (P->ynx % vw == 0) ? 1 : 0;
+    n.rpu = P->n_rpu;
+    return n;
+}
+
+static void fastn_launch_cols(const xrfthip_plan* P, const FastM& m, hipStream_t st) {
+    const FastN n = fastn_wrap(P, m, true);
+    const dim3 grid((unsigned)(8 * ((m.nunits + 7) / 8))), blk((unsigned)n.g.thr);
+    const size_t lds = P->n_c.lds;
+#define NC_(TT) do { if (P->n_blue_m) { auto k = &fastn_cols_kernel<TT, true>; XRFT_LAUNCH(k, grid, blk, lds, st, n); } \
+                     else { auto k = &fastn_cols_kernel<TT, false>; XRFT_LAUNCH(k, grid, blk, lds, st, n); } } while (0)
+    if (P->dbl) NC_(double); else NC_(float);
+#undef NC_
+}
+
+static void fastn_launch_rows(const xrfthip_plan* P, const FastM& m, long long gc, bool fused, hipStream_t st) {
+    const FastN n = fastn_wrap(P, m, false);
+    const xrfthip_desc& d = P->d;
+    const dim3 grid((unsigned)(gc * (P->y_nrow_pad / P->n_rpu))), blk((unsigned)n.g.thr);
+    const size_t lds = P->n_r.lds;
+#define NR_(TT) do { \
+        if (d.out_mode == XRFTHIP_OUT_POWER) { if (fused) { auto k = &fastn_rows_kernel<TT, 1, true>; XRFT_LAUNCH(k, grid, blk, lds, st, n); } else { auto k = &fastn_rows_kernel<TT, 1, false>; XRFT_LAUNCH(k, grid, blk, lds, st, n); } } \
+        else if (d.out_mode == XRFTHIP_OUT_CROSS) { if (fused) { auto k = &fastn_rows_kernel<TT, 2, true>; XRFT_LAUNCH(k, grid, blk, lds, st, n); } else { auto k = &fastn_rows_kernel<TT, 2, false>; XRFT_LAUNCH(k, grid, blk, lds, st, n); } } \
+        else if (d.out_mode == XRFTHIP_OUT_PHASE) { auto k = &fastn_rows_kernel<TT, 3, false>; XRFT_LAUNCH(k, grid, blk, lds, st, n); } \
+        else { auto k = &fastn_rows_kernel<TT, 0, false>; XRFT_LAUNCH(k, grid, blk, lds, st, n); } } while (0)
+    if (P->dbl) NR_(double); else NR_(float);
+#undef NR_
 }
 
 static FastM fastm_params(const xrfthip_plan* P, const void* in, void* out, char* ws, long long g0, long long gc, int slot, long long slot_slabs) {
@@ -1621,7 +1888,7 @@ static FastM fastm_params(const xrfthip_plan* P, const void* in, void* out, char
     const size_t slab_pts = (size_t)P->yny * P->ynx, s0 = (size_t)slot * slot_slabs;
     FastM p{};
     p.in = (const char*)in + (size_t)g0 * slab_pts * P->rsize;
-    p.w2 = ws + P->off_w + s0 * (size_t)P->y_nrow_pad * P->ynx * P->csize;
+    p.w2 = ws + P->off_w + s0 * (size_t)P->y_nrow_pad * (size_t)P->y_pitch * P->csize;
     const size_t out_esz = (d.out_mode == XRFTHIP_OUT_POWER || d.out_mode == XRFTHIP_OUT_PHASE) ? P->rsize : P->csize;
     const size_t out_pts = (size_t)P->yny * ((d.flags & XRFTHIP_HALF_X) ? P->ynx / 2 + 1 : P->ynx);
     p.out = out ? (char*)out + (size_t)g0 * out_pts * out_esz : nullptr;
@@ -1640,9 +1907,9 @@ static FastM fastm_params(const xrfthip_plan* P, const void* in, void* out, char
     p.tfirst = gather ? reinterpret_cast<const unsigned short*>(P->ytfirst.p) : nullptr;
     p.twin = gather ? reinterpret_cast<const unsigned*>(P->ytwin.p) : nullptr;
     p.ny = (int)P->yny; p.nx = (int)P->ynx; p.nrow_pad = P->y_nrow_pad;
-    p.l_cw = ilog2i(fastm_cw(P->yny, P->ynx, P->dbl)); p.l_rk = ilog2i(fastm_rk2(P->yny, P->ynx, P->d.out_mode == XRFTHIP_OUT_CROSS || P->d.out_mode == XRFTHIP_OUT_PHASE, P->dbl));
+    p.l_cw = ilog2i(plan_cw(P)); p.l_rk = ilog2i(plan_rk2(P));
     p.detrend = d.detrend; p.nslab = (int)gc;
-    p.nunits = (int)(gc * (P->ynx / fastm_cw(P->yny, P->ynx, P->dbl)));
+    p.nunits = (int)(gc * plan_nxb(P));
     p.shift_y = (d.flags & XRFTHIP_SHIFT_Y) ? (int)(P->yny / 2) : 0;
     p.shift_x = (d.flags & XRFTHIP_SHIFT_X) ? (int)(P->ynx / 2) : 0;
     p.scale = d.scale;
@@ -1653,7 +1920,9 @@ static void fastm_launch_cols(const xrfthip_plan* P, const FastM& p, long long g
     const xrfthip_desc& d = P->d;
     const MGeomRt C = mgeom_cols(P->yny, P->ynx, P->dbl);
     const bool wide = fastm_wide(P->yny, P->ynx, P->dbl);
-    xrfthip_plan::ProfRec* rec = prof_begin(P, "fastm_cols", st);
+    const bool rt = P->fastn && P->n_c.rt;  // (the run-time-radix kernel: fastn.h)
+    xrfthip_plan::ProfRec* rec = prof_begin(P, rt ? "fastn_cols" : "fastm_cols", st);
+    if (rt) fastn_launch_cols(P, p, st);
     const dim3 grid((unsigned)(8 * ((p.nunits + 7) / 8))), blk((unsigned)C.thr);
 #ifdef XRFT_M_BIGLDS  /* profiling builds with more than 64 KB of LDS per workgroup */
 #define MBIG_(k, n) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(n))
@@ -1666,7 +1935,8 @@ static void fastm_launch_cols(const xrfthip_plan* P, const FastM& p, long long g
 #define XF_(NN) if (P->yny == NN) MC_(float, NN);
 #define MCW_(NN) if (P->yny == NN) do { if (d.detrend) { auto k = &fastm_cols_kernel<float, NN, true, 4>; MBIG_(k, C.lds_cols); XRFT_LAUNCH(k, grid, blk, C.lds_cols, st, p); } \
                                             else { auto k = &fastm_cols_kernel<float, NN, false, 4>; MBIG_(k, C.lds_cols); XRFT_LAUNCH(k, grid, blk, C.lds_cols, st, p); } } while (0);
-    if (wide) { XRFT_M_WIDE32(MCW_) }
+    if (rt) {}
+    else if (wide) { XRFT_M_WIDE32(MCW_) }
     else if (P->dbl) { XRFT_M_LATLON(XD_) XRFT_M_POW2(XD_) } else { XRFT_M_LATLON(XF_) XRFT_M_F32ONLY(XF_) }
 #undef MCW_
 #undef XD_
@@ -1692,8 +1962,10 @@ static void fastm_launch_rows(const xrfthip_plan* P, const FastM& p, long long g
     const xrfthip_desc& d = P->d;
     const MGeomRt R = mgeom(P->ynx, P->dbl);
     const bool two = d.out_mode == XRFTHIP_OUT_CROSS || d.out_mode == XRFTHIP_OUT_PHASE;
-    xrfthip_plan::ProfRec* rec = prof_begin(P, "fastm_rows", st);
+    const bool rt = P->fastn && P->n_r.rt;  // (the run-time-radix kernel: fastn.h)
+    xrfthip_plan::ProfRec* rec = prof_begin(P, rt ? "fastn_rows" : "fastm_rows", st);
     const bool fused = fastm_iso_fused(P), full = two;  // (full: pass 1's sequence count per workgroup)
+    if (rt) { fastn_launch_rows(P, p, gc, fused, st); prof_end(rec, st); return; }
     const dim3 grid((unsigned)(gc * (P->y_nrow_pad / fastm_rows_rpu(P)))), blk((unsigned)(full ? R.thr : R.thr_r1));
     const size_t lds_rows = full ? R.lds_rows : R.lds_r1;
     const size_t lds_iso = p.tfirst ? lds_rows : lds_rows + (size_t)P->nbins * (d.out_mode == XRFTHIP_OUT_CROSS ? 20 : 12) * (size_t)p.iso_ncopy;  // (the gather needs no tables)
@@ -2572,7 +2844,7 @@ int xrfthip_plan_create(xrfthip_plan** plan, const xrfthip_desc* desc) {
             const bool two = d.out_mode == XRFTHIP_OUT_CROSS || d.out_mode == XRFTHIP_OUT_PHASE;
             const int rpu = two ? fastm_rpu(d.nx, true, P->dbl) : mgeom(d.nx, P->dbl).g;  // (the largest count a row kernel of this plan may use)
             P->yfirst = true;
-            P->yny = d.ny; P->ynx = d.nx;
+            P->yny = d.ny; P->ynx = d.nx; P->y_pitch = d.nx;
             P->y_nrow_pad = (int)((d.ny / 2 + 1 + rpu - 1) / rpu * rpu);
             int rcm = P->dbl ? build_twiddle<double>(P->tw_fx, d.nx, d.nx) : build_twiddle<float>(P->tw_fx, d.nx, d.nx);
             if (!rcm) rcm = P->dbl ? build_twiddle<double>(P->tw_fy, d.ny, d.ny) : build_twiddle<float>(P->tw_fy, d.ny, d.ny);
@@ -2644,6 +2916,35 @@ int xrfthip_plan_create(xrfthip_plan** plan, const xrfthip_desc* desc) {
             std::vector<float> onesf(ones.size(), 1.0f);
             if (!rcg) rcg = P->dbl ? P->ones4096.upload(ones.data(), ones.size() * sizeof(double)) : P->ones4096.upload(onesf.data(), onesf.size() * sizeof(float));
             if (rcg) { delete P; return rcg; }
+        }
+    }
+    {   // every other large real slab whose lengths the butterflies factor (the columns: any length, through a chirp convolution): the y-first pipeline with the
+        // lengths as data (fastn.h) -- either pass may still be the table kernel of fastm.h when its length is in the table
+        const uint32_t shifts = XRFTHIP_SHIFT_Y | XRFTHIP_SHIFT_X, ish = XRFTHIP_ISHIFT_Y | XRFTHIP_ISHIFT_X;
+        const uint32_t isof = XRFTHIP_ISO | XRFTHIP_NO_SPECTRUM_OUT, halff = XRFTHIP_HALF_X | XRFTHIP_REALDIM_X2;
+        const uint32_t allowed = d.out_mode == XRFTHIP_OUT_POWER ? (shifts | isof | halff) : d.out_mode == XRFTHIP_OUT_CROSS ? (shifts | ish | isof | halff)
+                                 : (d.out_mode == XRFTHIP_OUT_COMPLEX || d.out_mode == XRFTHIP_OUT_PHASE) ? (shifts | ish | XRFTHIP_HALF_X) : 0u;
+        const bool half_ok = !((d.flags & halff) && (d.flags & XRFTHIP_ISO)) && !((d.flags & XRFTHIP_HALF_X) && (d.flags & XRFTHIP_SHIFT_X));
+        const bool cand = half_ok && d.ndim == 2 && (d.dtype == XRFTHIP_F64 || d.dtype == XRFTHIP_F32) && !P->fast4096 && !P->fastm && !P->fastg && !P->fasts && !(d.flags & ~allowed) &&
+                          !env_ll("XRFTHIP_NO_FAST", 0) && env_ll("XRFTHIP_FASTN", 1) != 0;
+        if (cand) {
+            P->yny = d.ny; P->ynx = d.nx;
+            if (fastn_setup(P)) {
+                P->fastm = true; P->yfirst = true;
+                const bool two = plan_two(P);
+                const int rpu = P->n_r.rt ? P->n_rpu : (two ? fastm_rpu(d.nx, true, P->dbl) : mgeom(d.nx, P->dbl).g);  // (the largest count a row kernel of this plan may use)
+                P->y_nrow_pad = (int)((d.ny / 2 + 1 + rpu - 1) / rpu * rpu);
+                const long long ylen = P->n_blue_m ? P->n_blue_m : d.ny;
+                int rcn = P->dbl ? build_twiddle<double>(P->tw_fx, d.nx, d.nx) : build_twiddle<float>(P->tw_fx, d.nx, d.nx);
+                if (!rcn) rcn = P->dbl ? build_twiddle<double>(P->tw_fy, ylen, ylen) : build_twiddle<float>(P->tw_fy, ylen, ylen);
+                std::vector<double> ones((size_t)std::max(d.ny, d.nx), 1.0);
+                std::vector<float> onesf((size_t)std::max(d.ny, d.nx), 1.0f);
+                if (!rcn) rcn = P->dbl ? P->ones4096.upload(ones.data(), ones.size() * sizeof(double)) : P->ones4096.upload(onesf.data(), onesf.size() * sizeof(float));
+                if (!rcn && P->n_c.rt) rcn = P->dbl ? fastn_upload_twm<double>(P->n_c.geo, P->n_c.twm) : fastn_upload_twm<float>(P->n_c.geo, P->n_c.twm);
+                if (!rcn && P->n_r.rt) rcn = P->dbl ? fastn_upload_twm<double>(P->n_r.geo, P->n_r.twm) : fastn_upload_twm<float>(P->n_r.geo, P->n_r.twm);
+                if (!rcn && P->n_blue_m) rcn = P->dbl ? fastn_blue_tables<double>(P) : fastn_blue_tables<float>(P);
+                if (rcn) { delete P; return rcn; }
+            }
         }
     }
     if ((d.flags & XRFTHIP_AXIS_Y) && (d.flags & XRFTHIP_PHASE_IN) && !P->fastgy) { delete P; return XRFTHIP_BAD_ARG; }  // (the generic column tiles have no input phase)
@@ -2758,6 +3059,7 @@ int xrfthip_plan_uses_bluestein(const xrfthip_plan* plan) {
     if (!plan) return 0;
     if (plan->inner > 1) return xrfthip_plan_uses_bluestein(plan->sub_x) || xrfthip_plan_uses_bluestein(plan->sub_y);
     if (plan->fastgy) return plan->gy_blue_m > 0;
+    if (plan->fastn) return plan->n_blue_m > 0;
     if (plan->fastg || plan->fasts || plan->fastr || plan->fastmx || plan->fastmy || plan->fastm || plan->fast1d || plan->fast4096) return 0;  // (the generic passes of such a plan never run)
     for (const Pass& ps : plan->passes) if (ps.g.blue_n > 0) return 1;
     for (const Pass& ps : plan->passes_f0) if (ps.g.blue_n > 0) return 1;
@@ -2851,6 +3153,32 @@ int xrfthip_plan_describe(const xrfthip_plan* plan, char* buf, size_t buflen) {
         const MGeomRt C = mygeom(plan->d.ny, plan->dbl);
         appendf(s, "  [fastm y-only] %d thr, %d packed column pairs (FFT%lld r%dx%dx%d in LDS), lds=%zuB: per-column detrend + window + transform + both halves of the spectrum in one pass, in place in memory order\n",
                 C.thr, C.g, (long long)plan->d.ny, C.r0, C.r1, C.r2, C.lds_cols);
+    } else if (plan->fastm && plan->fastn) {
+        auto rads = [](const NGeo& g) { std::string t; for (int i = 0; i < g.np; ++i) t += (i ? "x" : "") + std::to_string(g.r[i]); return t; };
+        std::string cs_, rs_;
+        if (plan->n_c.rt) {
+            const NGeo& g = plan->n_c.geo;
+            appendf(cs_, "lengths as data, %d thr, %d packed column pairs (FFT%d r%s in LDS%s), lds=%zuB", g.thr, g.g, g.n, rads(g).c_str(),
+                    plan->n_blue_m ? ": a chirp convolution" : "", plan->n_c.lds);
+        } else {
+            const MGeomRt C = mgeom_cols(plan->yny, plan->ynx, plan->dbl);
+            appendf(cs_, "table kernel, %d thr, %d packed column pairs (FFT%lld r%dx%dx%d)", C.thr, C.g, (long long)plan->yny, C.r0, C.r1, C.r2);
+        }
+        if (plan->n_r.rt) {
+            const NGeo& g = plan->n_r.geo;
+            appendf(rs_, "lengths as data, %d thr, %d rows/unit (FFT%d r%s), lds=%zuB", g.thr, plan->n_rpu, g.n, rads(g).c_str(), plan->n_r.lds);
+        } else {
+            const MGeomRt R = mgeom(plan->ynx, plan->dbl);
+            appendf(rs_, "table kernel, %d thr, %d rows/unit (FFT%lld r%dx%dx%d)", R.thr_r1, plan->n_rpu, (long long)plan->ynx, R.r0, R.r1, R.r2);
+        }
+        appendf(s, "  [fastn] cols: %s -> W2[slab][%d/%d][%d][%d][%d] complex -> fit -> rows: %s, trend added back in the spectral domain, fftshift + mirror rows\n",
+                cs_.c_str(), plan->y_nrow_pad, plan->n_rk, plan->n_nxb, plan->n_rk, plan->n_cw, rs_.c_str());
+        if (plan->n_blue_m)
+            appendf(s, "  [fastn Bluestein] the %lld-point columns as a circular convolution of %d inside the tile (chirp products, two forward transforms)\n", (long long)plan->yny, plan->n_blue_m);
+        if ((plan->d.flags & XRFTHIP_ISO) && plan->nbins > 0)
+            appendf(s, "  [fastn radial sums] %s\n", fastm_iso_gather(plan) ? "fused into the row pass: radial map, per-bin gather from the spectra in LDS, no atomics"
+                                                   : fastm_iso_fused(plan) ? "fused into the row pass: int64 fixed-point tables behind the transforms' LDS"
+                                                                           : "a pass over the stored spectrum");
     } else if (plan->fastm) {
         const MGeomRt C = mgeom_cols(plan->yny, plan->ynx, plan->dbl), R = mgeom(plan->ynx, plan->dbl);
         appendf(s, "  [fastm] cols: %d thr, %d packed column pairs (FFT%lld r%dx%dx%d in LDS), lds=%zuB -> W2[slab][%d/%d][nx/%d][%d][%d] complex -> fit -> rows: %d thr, %d rows/unit (FFT%lld r%dx%dx%d), lds=%zuB, trend added back in the spectral domain, fftshift + mirror rows\n",
