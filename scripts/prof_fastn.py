@@ -53,31 +53,36 @@ def one(nt, ny, nx, dt, env=None, profile=False, parity=False, fn=xrft.power_spe
             if v is None: os.environ.pop(k, None)
             else: os.environ[k] = v
 
-targets = [(64, 721, 1440, "float32"), (16, 3000, 3000, "float64"), (16, 2200, 2200, "float32"), (16, 1215, 1215, "float32"), (32, 750, 1500, "float64")]
-print("== targets, default geometry, per-kernel times, parity")
-for t in targets:
-    one(*t, profile=True, parity=True)
-print("== the generic passes on the same shapes (XRFTHIP_FASTN=0)")
-for t in targets:
-    one(*t, env={"XRFTHIP_FASTN": 0})
-print("== geometry knobs")
-for t in targets:
-    for gc in (1, 2, 4, 8):
-        one(*t, env={"XRFTHIP_FASTN_GC": gc})
-    for rpu in (1, 2, 4):
-        one(*t, env={"XRFTHIP_FASTN_RPU": rpu})
-if not quick:
-    print("== run-time radices against the table kernels on table shapes")
-    for t in [(64, 1440, 720, "float64"), (64, 1440, 720, "float32"), (32, 1000, 1000, "float32"), (64, 2000, 2000, "float32"), (16, 3000, 3000, "float32"), (32, 2000, 2000, "float64"),
-              (64, 360, 720, "float64"), (16, 2160, 4320, "float32"), (64, 1024, 1024, "float64")]:
-        one(*t)
-        one(*t, env={"XRFTHIP_FASTN_TABLES": 0}, profile=True)
-    print("== other shapes off the tables")
-    for t in [(16, 2500, 1250, "float32"), (16, 4800, 4800, "float32"), (16, 2187, 2187, "float32"), (16, 2401, 2401, "float32"), (32, 1001, 1001, "float32"), (32, 1331, 1331, "float64"),
-              (16, 1536, 3072, "float64"), (64, 700, 1400, "float32"), (64, 343, 686, "float64"), (8, 4096, 4096, "float64"), (32, 1999, 1000, "float32"), (32, 1013, 1024, "float64")]:
+def main():
+    targets = [(64, 721, 1440, "float32"), (16, 3000, 3000, "float64"), (16, 2200, 2200, "float32"), (16, 1215, 1215, "float32"), (32, 750, 1500, "float64")]
+    print("== targets, default geometry, per-kernel times, parity")
+    for t in targets:
         one(*t, profile=True, parity=True)
-    print("== modes on (16, 2200, 2200) float32 and (32, 750, 1500) float64")
-    for t in [(16, 2200, 2200, "float32"), (32, 750, 1500, "float64")]:
-        one(*t, fn=xrft.fft, parity=True, detrend="linear", window="hann")
-        one(*t, fn=xrft.isotropic_power_spectrum, parity=True, detrend="linear", window="hann")
-        one(*t, fn=xrft.power_spectrum, parity=True, real_dim="x", detrend="constant")
+    print("== the generic passes on the same shapes (XRFTHIP_FASTN=0)")
+    for t in targets:
+        one(*t, env={"XRFTHIP_FASTN": 0})
+    print("== geometry knobs")
+    for t in targets:
+        for gc in (1, 2, 4, 8):
+            one(*t, env={"XRFTHIP_FASTN_GC": gc})
+        for rpu in (1, 2, 4):
+            one(*t, env={"XRFTHIP_FASTN_RPU": rpu})
+    if not quick:
+        print("== run-time radices against the table kernels on table shapes")
+        for t in [(64, 1440, 720, "float64"), (64, 1440, 720, "float32"), (32, 1000, 1000, "float32"), (64, 2000, 2000, "float32"), (16, 3000, 3000, "float32"), (32, 2000, 2000, "float64"),
+                  (64, 360, 720, "float64"), (16, 2160, 4320, "float32"), (64, 1024, 1024, "float64")]:
+            one(*t)
+            one(*t, env={"XRFTHIP_FASTN_TABLES": 0}, profile=True)
+        print("== other shapes off the tables")
+        for t in [(16, 2500, 1250, "float32"), (16, 4800, 4800, "float32"), (16, 2187, 2187, "float32"), (16, 2401, 2401, "float32"), (32, 1001, 1001, "float32"), (32, 1331, 1331, "float64"),
+                  (16, 1536, 3072, "float64"), (64, 700, 1400, "float32"), (64, 343, 686, "float64"), (8, 4096, 4096, "float64"), (32, 1999, 1000, "float32"), (32, 1013, 1024, "float64")]:
+            one(*t, profile=True, parity=True)
+        print("== modes on (16, 2200, 2200) float32 and (32, 750, 1500) float64")
+        for t in [(16, 2200, 2200, "float32"), (32, 750, 1500, "float64")]:
+            one(*t, fn=xrft.fft, parity=True, detrend="linear", window="hann")
+            one(*t, fn=xrft.isotropic_power_spectrum, parity=True, detrend="linear", window="hann")
+            one(*t, fn=xrft.power_spectrum, parity=True, real_dim="x", detrend="constant")
+
+
+if __name__ == "__main__":
+    main()

@@ -897,6 +897,51 @@ def run_yonly_fast_cases(shape=(3, 360, 40), dtype="float64"):
     return worst
 
 
+def run_fastn_cases(shape=(2, 1215, 700), dtype="float32", cross=True):
+    """csrc/fastn.h -- the y-first two-pass pipeline with the LENGTHS AS DATA (run-time radices 2 ... 20 incl. 7 / 11 / 13, odd lengths, ragged column blocks,
+    the chirp convolution for a column length with a large prime factor) -- against the oracle, every mode that the table kernels of fastm.h take."""
+    rng = np.random.default_rng(91)
+    tol = TOL[dtype]
+    a = _cube(rng, shape, dtype)
+    da, od = pair(a, D3, _coords3(shape, y0=1.0, x0=-3.0))
+    worst = 0.0
+
+    def on_fast():
+        return any("[fastn]" in p.describe() for p in xa.api._plan_cache.values())
+
+    for kw in (dict(detrend="linear", window="hann"), dict(detrend="constant", shift=False, scaling="spectrum"), dict(window="hamming", window_correction=True), dict()):
+        xa.api._plan_cache.clear()
+        worst = max(worst, check(xa.power_spectrum(da, dim=["y", "x"], **kw), o.power_spectrum(od, dim=["y", "x"], **kw), tol))
+        assert on_fast(), (shape, kw, [p.describe() for p in xa.api._plan_cache.values()])
+    xa.api._plan_cache.clear()
+    worst = max(worst, check(xa.power_spectrum(da, dim=["y"], real_dim="x", detrend="linear"), o.power_spectrum(od, dim=["y"], real_dim="x", detrend="linear"), tol))
+    assert on_fast()
+    for kw in (dict(detrend="linear", window="hann"), dict(true_phase=False, shift=False), dict(real_dim="x", detrend="constant")):
+        xa.api._plan_cache.clear()
+        dims = ["y"] if "real_dim" in kw else ["y", "x"]
+        worst = max(worst, check(xa.fft(da, dim=dims, **kw), o.fft(od, dim=dims, **kw), tol))
+        assert on_fast(), kw
+    for kw in (dict(detrend="linear", window="hann"), dict(truncate=True)):
+        xa.api._plan_cache.clear()
+        r1 = xa.isotropic_power_spectrum(da, dim=["y", "x"], **kw)
+        worst = max(worst, check(r1, o.isotropic_power_spectrum(od, dim=["y", "x"], **kw), tol))
+        assert on_fast(), kw
+        assert np.array_equal(np.asarray(xa.isotropic_power_spectrum(da, dim=["y", "x"], **kw).values), np.asarray(r1.values))  # bit-identical repeats
+    if cross:
+        b = _cube(rng, shape, dtype, trend=False)
+        c2 = _coords3(shape, y0=2.5, x0=1.0)
+        db, ob = pair(b, D3, c2)
+        for kw in (dict(detrend="linear", window="hann"), dict(true_phase=False)):
+            xa.api._plan_cache.clear()
+            worst = max(worst, check(xa.cross_spectrum(da, db, dim=["y", "x"], **kw), o.cross_spectrum(od, ob, dim=["y", "x"], **kw), tol))
+            assert on_fast(), kw
+        xa.api._plan_cache.clear()
+        db0, ob0 = pair(b, D3, _coords3(shape, y0=1.0, x0=-3.0))
+        worst = max(worst, check(xa.isotropic_cross_spectrum(da, db0, dim=["y", "x"], window="hann"), o.isotropic_cross_spectrum(od, ob0, dim=["y", "x"], window="hann"), tol))
+        assert on_fast()
+    return worst
+
+
 def run_inverse_one_pass_cases(shape=(2, 360, 250), dtype="float64"):
     """xrft.ifft (xrft.py:479-646) on the one-pass kernels of csrc/fastg.h: a two-axis inverse transform as two one-axis stages (y where it lies, then the rows),
     one axis along a first / middle axis with no transposed copy, along the contiguous axis, small slabs in one pass -- every true_phase / shift combination,

@@ -670,3 +670,11 @@ def test_ifft_with_a_permuted_frequency_coordinate_on_a_non_last_axis(axis):
         assert np.abs(np.asarray(back.values) - np.asarray(ref.values)).max() < 1e-12
         assert np.abs(np.asarray(back.values).real - v).max() < 1e-10
         assert np.array_equal(back[d].values, ref[d].values)
+
+
+@pytest.mark.parametrize("shape,dtype", [((2, 77, 90), "float64"), ((2, 63, 55), "float32"), ((1, 46, 60), "float32"), ((1, 243, 50), "float64"), ((2, 180, 84), "float64")])
+def test_two_pass_pipeline_with_the_lengths_as_data(shape, dtype, monkeypatch):
+    """csrc/fastn.h on the emulator (small slabs kept off the one-pass kernel): run-time radices incl. 7 / 11, odd lengths, the chirp convolution (46 = 2 x 23),
+    4 passes (243), a table length on one side (180)."""
+    monkeypatch.setenv("XRFTHIP_FASTG", "0")
+    cases.run_fastn_cases(shape, dtype)

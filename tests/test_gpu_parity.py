@@ -1038,3 +1038,21 @@ def test_last_axis_any_smooth_length(shape, dtype):
 def test_inverse_transforms_on_the_one_pass_kernels(shape, dtype):
     """xrft.ifft over two axes as two one-pass stages, over one axis where it lies, small slabs in one pass (csrc/fastg.h)."""
     cases.run_inverse_one_pass_cases(shape, dtype)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape,dtype", [((2, 1215, 700), "float32"), ((2, 721, 1440), "float32"), ((1, 3000, 3000), "float64"), ((2, 2200, 1100), "float32"), ((2, 750, 1500), "float64"),
+                                         ((2, 1001, 343), "float64"), ((1, 2187, 625), "float32"), ((2, 343, 1331), "float32"), ((1, 4800, 1250), "float32"), ((2, 1013, 768), "float64"),
+                                         ((1, 2401, 1440), "float64"), ((3, 675, 945), "float32")])
+def test_large_slabs_off_the_tables_with_the_lengths_as_data(shape, dtype):
+    """csrc/fastn.h: both passes with run-time radices (7 / 11 / 13 butterflies, odd lengths, 4+ passes), mixed with a table kernel on one side, and the chirp
+    convolution for the columns (721 = 7 x 103, 1013 prime)."""
+    cases.run_fastn_cases(shape, dtype, cross=shape[1] * shape[2] <= 2_500_000)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", range(40))
+def test_random_fastn_differential(seed):
+    from test_random_differential import run_random_fastn
+
+    run_random_fastn(seed, lo=200, hi=1600, dtype="float64" if seed % 2 == 0 else "float32")

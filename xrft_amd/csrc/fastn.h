@@ -45,7 +45,8 @@ struct NGeo {
 
 struct FastN {
     FastM f;              // the pipeline's parameter block exactly as the table kernels take it (incl. the intermediate's layout l_cw, l_rk)
-    NGeo g;               // the transform of THIS pass
+    const NGeo* g;        // the transform of THIS pass (device memory, uploaded once per plan: a by-value copy in the kernel arguments is dynamically
+                          // indexed by the pass number, which made the compiler park the whole argument block in scratch memory)
     const void* twm;      // twiddles of the middle passes, [g.twn] complex T (staged in LDS)
     int pitch;            // complex elements per row of the intermediate: nxb column blocks of CW columns (a ragged last block is padded)
     int nxb;
@@ -54,17 +55,19 @@ struct FastN {
     const void* blue_b;   // FFT_m(chirp) / m in natural order
     int vec_ok;           // pass 2: the rows leave 16 bytes per lane (the row length divides)
     int rpu;              // pass 2: rows ky per workgroup (two fields: g.g = 2 rpu sequences)
+    int dbg;              // ablation switches of the measuring scripts (XRFTHIP_FASTN_DBG; 0 in production): 1 no LDS passes, 2 no stores, 4 no first pass
 };
 
 __device__ __forceinline__ int n_pad(int i, float inv) { return i + (int)(((float)i + 0.5f) * inv); }  // i + i / q, inv = 1 / q (or 0)
 
+// (CAP: the largest radix the enclosing kernel variant carries -- 16 or 20: the 18- and 20-point butterflies cost the others ~20 registers)
 #define XRFT_N_SWITCH(RR, F_)                                                                                                         \
     switch (RR) {                                                                                                                     \
         case 2: F_(2); break; case 3: F_(3); break; case 4: F_(4); break; case 5: F_(5); break; case 6: F_(6); break;                 \
-        case 7: F_(7); break; case 8: F_(8); break; case 9: F_(9); break; case 10: F_(10); break; case 11: F_(11); break;             \
-        case 12: F_(12); break; case 13: F_(13); break; case 14: F_(14); break; case 15: F_(15); break;                               \
-        case 18: if (sizeof(T) == 4) { F_(18); } break; case 20: if (sizeof(T) == 4) { F_(20); } break;                               \
-        default: F_(16); break;                                                                                                       \
+        case 7: F_(7); break; case 8: F_(8); break; case 9: F_(9); break; case 10: F_(10); break; case 11: if (CAP >= 11) { F_(11); } break;             \
+        case 12: if (CAP >= 12) { F_(12); } break; case 13: if (CAP >= 13) { F_(13); } break; case 14: if (CAP >= 14) { F_(14); } break; case 15: if (CAP >= 15) { F_(15); } break;                               \
+        case 18: if (sizeof(T) == 4 && CAP >= 18) { F_(18); } break; case 20: if (sizeof(T) == 4 && CAP >= 20) { F_(20); } break;                               \
+        default: if (CAP >= 16) { F_(16); } break;                                                                                                       \
     }
 // (float64: radices up to 16 -- the 18- and 20-point butterflies want more than the 168 registers that leave three waves on a SIMD)
 template <typename T> constexpr int fastn_max_radix() { return sizeof(T) == 4 ? 20 : 16; }
@@ -79,8 +82,8 @@ template <typename T, int R> __device__ __forceinline__ void n_chain(C2<T>* a, C
     }
 }
 
-// Pass p < np - 1 over the G sequences of a workgroup, in place in the intermediate layout (sequence t at lds + t str).  p == 0 (the second
-// transform of a Bluestein convolution: operands in LDS) takes its twiddles as powers of twg[j] = W_n^j, the others from the staged table.
+// Pass p < np - 1 over the G sequences of a workgroup, in place in the intermediate layout (sequence t at lds + t str).  p == 0 (the transforms of a
+// Bluestein convolution: operands in LDS) takes its twiddles as powers of W_n^j, staged at two[0]; the others W_{L_p}^(j k) from the staged table.
 template <typename T, int R>
 __device__ __forceinline__ void n_pass_mid(C2<T>* lds, const NGeo& g, int p, int tid, int nthr, const C2<T>* twl, const C2<T>* __restrict__ twg) {
     const int m = g.m[p], L = m * R, bps = g.n / R, nb = bps << g.lg, st = g.step[p];
@@ -93,7 +96,7 @@ __device__ __forceinline__ void n_pass_mid(C2<T>* lds, const NGeo& g, int p, int
 #pragma unroll
         for (int q = 0; q < R; ++q) a[q] = s[q * st];
         dft_r<T, R>(a);
-        if (p == 0) n_chain<T, R>(a, twg[j]);
+        if (p == 0) n_chain<T, R>(a, twp[j]);  // (a Bluestein plan: W_n^j staged at two[0])
         else {
 #pragma unroll
             for (int k = 1; k < R; ++k) a[k] = cmul(a[k], twp[j * R + k]);
@@ -138,7 +141,7 @@ __device__ __forceinline__ void n_pass_last(C2<T>* lds, const NGeo& g, int tid) 
 }
 
 // passes 1 .. np - 1 (the first one has put its results into LDS); ends with the result in natural order, after a barrier
-template <typename T>
+template <typename T, int CAP>
 __device__ __forceinline__ void n_fft_tail(C2<T>* lds, const NGeo& g, int tid, int nthr, const C2<T>* twl) {
     for (int p = 1; p + 1 < g.np; ++p) {
         __syncthreads();
@@ -217,10 +220,10 @@ __device__ __forceinline__ void n_first_cols(NColsCtx<T>& c, const NGeo& g, C2<T
     for (int k = 0; k < R; ++k) s[k * st] = a[k];
 }
 
-template <typename T, bool BLUE>
+template <typename T, bool BLUE, int CAP>
 __global__ void __launch_bounds__(fastn_max_threads<T>(), (sizeof(T) == 4 ? 4 : 3)) fastn_cols_kernel(FastN P) {
     typedef C2<T> CT;
-    const NGeo& g = P.g;
+    const NGeo& g = *P.g;
     const FastM& p = P.f;
     XRFT_DYN_SMEM(smem_raw);
     CT* lds = reinterpret_cast<CT*>(smem_raw);
@@ -279,13 +282,52 @@ __global__ void __launch_bounds__(fastn_max_threads<T>(), (sizeof(T) == 4 ? 4 : 
         if (c.has0) { cfp[2] = (double)c.Tl[0] + (double)c.Sl[0] * c.ibar; cfp[3] = (double)c.Sl[0]; }
         if (c.has1) { cfp[6] = (double)c.Tl[1] + (double)c.Sl[1] * c.ibar; cfp[7] = (double)c.Sl[1]; }
     }
-    // first pass from registers: rows j + q M0, q < r[0], of the thread's column pair -- all of a butterfly's loads in flight at once, never staged
-    {
+    if (BLUE) {
+        // Bluestein: the column pair's ny rows are staged in LDS -- detrended, windowed, times conj(c[i]) -- behind them zeros up to the convolution
+        // length, and ALL passes run from LDS (the natural layout of a Bluestein plan is its intermediate layout).  U rows per thread in flight.
+        CT* seq = lds + gi * g.str;
+        const CT* __restrict__ ch = reinterpret_cast<const CT*>(P.blue_c);
+        constexpr int U = 4;
+        for (int i0 = r0; i0 < ny && !(P.dbg & 4); i0 += U * RQ) {
+            CT v[U], cc_[U];
+            T wv[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int ic = min(i0 + u * RQ, ny - 1);
+                v[u] = n_load_pair<T>(c, c.coff + c.rowb * (unsigned)ic);
+                wv[u] = c.wy[ic];
+                cc_[u] = ch[ic];
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int i = i0 + u * RQ;
+                if (i < ny) {
+                    if (c.det) {
+                        const double ri = (double)i - c.ibar;
+                        c.s[0] += (double)v[u].re; c.s[1] += (double)v[u].im;
+                        c.s[2] = fma(ri, (double)v[u].re, c.s[2]); c.s[3] = fma(ri, (double)v[u].im, c.s[3]);
+                    }
+                    CT z = v[u];
+                    if (c.pre) {
+                        const float fi = (float)i;
+                        z = mk<T>((T)((float)z.re - fmaf(c.Sl[0], fi, c.Tl[0])), (T)((float)z.im - fmaf(c.Sl[1], fi, c.Tl[1])));
+                    }
+                    z = mk<T>(z.re * (wv[u] * c.wx.re), z.im * (wv[u] * c.wx.im));
+                    seq[n_pad(i, g.inv_pdq)] = cmulc(z, cc_[u]);
+                }
+            }
+        }
+        for (int i = ny + r0; i < g.n; i += RQ) seq[n_pad(i, g.inv_pdq)] = mk<T>((T)0, (T)0);
+        __syncthreads();
+#define NB_(RR) n_pass_mid<T, RR>(lds, g, 0, tid, nthr, twl, nullptr)
+        if (!(P.dbg & 1)) { XRFT_N_SWITCH(g.r[0], NB_) }
+#undef NB_
+    } else {
         CT* seq = lds + gi * g.str;
         const CT* __restrict__ tw = reinterpret_cast<const CT*>(p.tw_y);
         const int M0 = g.m[0];
-        for (int j = r0; j < M0; j += RQ) {
-#define NF_(RR) n_first_cols<T, RR, BLUE>(c, g, seq, j, tw)
+        for (int j = r0; j < M0 && !(P.dbg & 4); j += RQ) {
+#define NF_(RR) n_first_cols<T, RR, false>(c, g, seq, j, tw)
             XRFT_N_SWITCH(g.r[0], NF_)
 #undef NF_
         }
@@ -300,8 +342,8 @@ __global__ void __launch_bounds__(fastn_max_threads<T>(), (sizeof(T) == 4 ? 4 : 
             for (int cc = 0; cc < 4; ++cc) part[((tid >> 6) * G + gi) * 4 + cc] = c.s[cc];
         }
     }
-    n_fft_tail<T>(lds, g, tid, nthr, twl);
-    if (BLUE) {
+    if (!(P.dbg & 1)) n_fft_tail<T, CAP>(lds, g, tid, nthr, twl); else __syncthreads();
+    if (BLUE && !(P.dbg & 1)) {
         // circular convolution with the chirp: Z1 B, conjugated (the inverse transform is conj FFT conj; 1 / m rides on B), a second forward transform
         // whose first pass finds its operands in LDS -- the Bluestein plan's natural layout IS its intermediate layout --, and Z[k] = conj(res[k] c[k])
         const CT* __restrict__ bh = reinterpret_cast<const CT*>(P.blue_b);
@@ -314,10 +356,10 @@ __global__ void __launch_bounds__(fastn_max_threads<T>(), (sizeof(T) == 4 ? 4 : 
             *z = mk<T>(v.re, -v.im);
         }
         __syncthreads();
-#define NB_(RR) n_pass_mid<T, RR>(lds, g, 0, tid, nthr, twl, reinterpret_cast<const CT*>(p.tw_y))
+#define NB_(RR) n_pass_mid<T, RR>(lds, g, 0, tid, nthr, twl, nullptr)
         XRFT_N_SWITCH(g.r[0], NB_)
 #undef NB_
-        n_fft_tail<T>(lds, g, tid, nthr, twl);
+        n_fft_tail<T, CAP>(lds, g, tid, nthr, twl);
     }
     if (c.det && tid < 4 * G) {  // (sum d, sum (i - ibar) d) per column, the waves' partial sums in wave order
         const int cc = tid >> g.lg, gg = tid & (G - 1);  // cc: 0, 1 = sum d of columns 2gg, 2gg+1; 2, 3 = the first moments
@@ -334,7 +376,7 @@ __global__ void __launch_bounds__(fastn_max_threads<T>(), (sizeof(T) == 4 ? 4 : 
     // CW columns of a row, RK rows complete a line of the intermediate
     const int rk = 1 << p.l_rk, lcw = g.lg + 1;
     char* __restrict__ w2s = reinterpret_cast<char*>(reinterpret_cast<CT*>(p.w2) + (size_t)slab * p.nrow_pad * P.pitch);
-    const int nst = CW * (nyh + 1);
+    const int nst = (P.dbg & 2) ? 0 : CW * (nyh + 1);
     for (int l = tid; l < nst; l += nthr) {
         const int col = l & (CW - 1), k = l >> lcw, km = k == 0 ? 0 : ny - k;
         const CT* z = lds + (col >> 1) * g.str;
@@ -361,7 +403,7 @@ __global__ void __launch_bounds__(fastn_max_threads<T>(), (sizeof(T) == 4 ? 4 : 
 template <typename T, int R>
 __device__ __forceinline__ void n_first_rows(const FastN& P, C2<T>* lds, int w, int ky0, int slab, bool two) {
     typedef C2<T> CT;
-    const NGeo& g = P.g;
+    const NGeo& g = *P.g;
     const FastM& p = P.f;
     const int M0 = g.m[0], rk = 1 << p.l_rk, cwm = (1 << p.l_cw) - 1, nyh = p.ny >> 1;
     const int xq = w >> p.l_rk, pairi = fdiv(xq, 1.0f / (float)M0), j = xq - pairi * M0, t = (pairi << p.l_rk) + (w & (rk - 1));
@@ -398,30 +440,36 @@ __device__ __forceinline__ void n_first_rows(const FastN& P, C2<T>* lds, int w, 
     for (int k = 0; k < R; ++k) s[k * st] = a[k];
 }
 
-template <typename T, int MODE, bool ISO>
+template <typename T, int MODE, bool ISO, int CAP>
 __global__ void __launch_bounds__(fastn_max_threads<T>(), (sizeof(T) == 4 ? 4 : 3)) fastn_rows_kernel(FastN P) {
     static_assert(!ISO || MODE == 1 || MODE == 2, "radial sums exist for power and cross spectra");
     typedef C2<T> CT;
     constexpr bool TWO = MODE >= 2;
-    const NGeo& g = P.g;
+    const NGeo& g = *P.g;
     const FastM& p = P.f;
     XRFT_DYN_SMEM(smem_raw);
     CT* lds = reinterpret_cast<CT*>(smem_raw);
     CT* twl = lds + g.g * g.str;
     const int tid = threadIdx.x, nthr = g.thr, NX = p.nx, STR = g.str, RPU = P.rpu;
     const int upr = p.nrow_pad / RPU, slab = blockIdx.x / upr, unit = blockIdx.x - slab * upr, ky0 = unit * RPU, nyh = p.ny >> 1;
-    for (int e = tid; e < g.twn; e += nthr) twl[e] = reinterpret_cast<const CT*>(P.twm)[e];
+    constexpr int NTW = 2;  // (the middle passes' twiddles: loaded now, parked in registers, written to LDS behind the first pass -- no load waits for another)
+    CT twr[NTW];
+#pragma unroll
+    for (int i = 0; i < NTW; ++i) { const int e = tid + i * nthr; twr[i] = e < g.twn ? reinterpret_cast<const CT*>(P.twm)[e] : mk<T>((T)0, (T)0); }
     // first pass from registers: item (sequence t, butterfly j) loads x = j + q M0, q < r[0], of its row.  Item order (row pair, j, row in the pair):
     // the RK rows that share the lines of W2 sit in adjacent lanes, so a wave consumes whole lines
     {
         const int nit = g.m[0] << g.lg;
-        for (int w = tid; w < nit; w += nthr) {
+        for (int w = tid; w < nit && !(P.dbg & 4); w += nthr) {
 #define NF_(RR) n_first_rows<T, RR>(P, lds, w, ky0, slab, TWO)
             XRFT_N_SWITCH(g.r[0], NF_)
 #undef NF_
         }
     }
-    n_fft_tail<T>(lds, g, tid, nthr, twl);
+#pragma unroll
+    for (int i = 0; i < NTW; ++i) { const int e = tid + i * nthr; if (e < g.twn) twl[e] = twr[i]; }
+    for (int e = tid + NTW * nthr; e < g.twn; e += nthr) twl[e] = reinterpret_cast<const CT*>(P.twm)[e];
+    if (!(P.dbg & 1)) n_fft_tail<T, CAP>(lds, g, tid, nthr, twl); else __syncthreads();
     const int sx = p.shift_x, sy = p.shift_y;
     const T sc = (T)p.scale;
     const float ipn = g.inv_pnq;
@@ -463,7 +511,7 @@ __global__ void __launch_bounds__(fastn_max_threads<T>(), (sizeof(T) == 4 ? 4 : 
             }
         }
     }
-    if (p.out == nullptr) return;
+    if (p.out == nullptr || (P.dbg & 2)) return;
     typedef typename std::conditional<MODE == 0 || MODE == 2, CT, T>::type OutT;
     constexpr int VW = 16 / (int)sizeof(OutT);
     if (p.half || !P.vec_ok) {

@@ -66,12 +66,17 @@ XRFT_M_LATLON(XRFT_KI_M1F_) XRFT_M_F32ONLY(XRFT_KI_M1F_) XRFT_M_POW2(XRFT_KI_M1F
 #undef XRFT_KI_M1D_
 #undef XRFT_KI_M1F_
 #endif
-#if XRFT_KI_ON(6)  // ---- fastn.h: the y-first pipeline with the lengths as data
-#define XRFT_KI_N_(TT) \
-    XRFT_KW void fastn_cols_kernel<TT, false>(FastN); XRFT_KW void fastn_cols_kernel<TT, true>(FastN); \
-    XRFT_KW void fastn_rows_kernel<TT, 0, false>(FastN); XRFT_KW void fastn_rows_kernel<TT, 1, false>(FastN); XRFT_KW void fastn_rows_kernel<TT, 1, true>(FastN); \
-    XRFT_KW void fastn_rows_kernel<TT, 2, false>(FastN); XRFT_KW void fastn_rows_kernel<TT, 2, true>(FastN); XRFT_KW void fastn_rows_kernel<TT, 3, false>(FastN);
-XRFT_KI_N_(float) XRFT_KI_N_(double)
+#if XRFT_KI_ON(6) || XRFT_KI_ON(7)  // ---- fastn.h: the y-first pipeline with the lengths as data (float32: group 6, float64: group 7); CAP = the largest radix a variant carries
+#define XRFT_KI_N_(TT, CC) \
+    XRFT_KW void fastn_cols_kernel<TT, false, CC>(FastN); XRFT_KW void fastn_cols_kernel<TT, true, CC>(FastN); \
+    XRFT_KW void fastn_rows_kernel<TT, 0, false, CC>(FastN); XRFT_KW void fastn_rows_kernel<TT, 1, false, CC>(FastN); XRFT_KW void fastn_rows_kernel<TT, 1, true, CC>(FastN); \
+    XRFT_KW void fastn_rows_kernel<TT, 2, false, CC>(FastN); XRFT_KW void fastn_rows_kernel<TT, 2, true, CC>(FastN); XRFT_KW void fastn_rows_kernel<TT, 3, false, CC>(FastN);
+#if XRFT_KI_ON(6)
+XRFT_KI_N_(float, 16) XRFT_KI_N_(float, 20)
+#endif
+#if XRFT_KI_ON(7)
+XRFT_KI_N_(double, 16)
+#endif
 #undef XRFT_KI_N_
 #endif
 #undef XRFT_KI_ON

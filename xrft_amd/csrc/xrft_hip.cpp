@@ -332,7 +332,7 @@ struct xrfthip_plan {
     // ... and the same pipeline with the LENGTHS AS DATA (fastn.h): either pass (or both) of a `fastm` plan may be the run-time-radix kernel -- every
     // length that is a product of the butterflies 2 ... 20 (7, 11, 13 included), and for the columns any other length through a chirp convolution
     bool fastn = false;
-    struct NSide { bool rt = false; NGeo geo{}; size_t lds = 0; DevBuf twm; };
+    struct NSide { bool rt = false; NGeo geo{}; size_t lds = 0; DevBuf twm, geo_dev; };
     NSide n_c, n_r;                 // pass 1 (columns, length ny) and pass 2 (rows, length nx)
     int n_cw = 0, n_rk = 1, n_rpu = 0, n_nxb = 0;  // the intermediate's layout: columns per block, rows per line; rows per pass-2 workgroup; column blocks per row
     long long y_pitch = 0;          // complex elements per row of the intermediate (ynx, or n_nxb * n_cw when the last column block is ragged)
@@ -860,10 +860,10 @@ void set_kernel_attrs_once() {
     SETF((fastg_kernel<float, 0, true>)); SETF((fastg_kernel<float, 1, true>)); SETF((fastg_kernel<double, 0, true>)); SETF((fastg_kernel<double, 1, true>));
     SETF((fastgy_kernel<float, 0, false>)); SETF((fastgy_kernel<float, 1, false>)); SETF((fastgy_kernel<double, 0, false>)); SETF((fastgy_kernel<double, 1, false>));
     SETF((fastgy_kernel<float, 0, true>)); SETF((fastgy_kernel<float, 1, true>)); SETF((fastgy_kernel<double, 0, true>)); SETF((fastgy_kernel<double, 1, true>));
-    SETF((fastn_cols_kernel<float, false>)); SETF((fastn_cols_kernel<float, true>)); SETF((fastn_cols_kernel<double, false>)); SETF((fastn_cols_kernel<double, true>));
-#define SETN(TT) SETF((fastn_rows_kernel<TT, 0, false>)); SETF((fastn_rows_kernel<TT, 1, false>)); SETF((fastn_rows_kernel<TT, 1, true>)); SETF((fastn_rows_kernel<TT, 2, false>)); \
-                 SETF((fastn_rows_kernel<TT, 2, true>)); SETF((fastn_rows_kernel<TT, 3, false>))
-    SETN(float); SETN(double);
+#define SETN(TT, CC) SETF((fastn_cols_kernel<TT, false, CC>)); SETF((fastn_cols_kernel<TT, true, CC>)); \
+                     SETF((fastn_rows_kernel<TT, 0, false, CC>)); SETF((fastn_rows_kernel<TT, 1, false, CC>)); SETF((fastn_rows_kernel<TT, 1, true, CC>)); SETF((fastn_rows_kernel<TT, 2, false, CC>)); \
+                     SETF((fastn_rows_kernel<TT, 2, true, CC>)); SETF((fastn_rows_kernel<TT, 3, false, CC>))
+    SETN(float, 16); SETN(float, 20); SETN(double, 16);
 #undef SETN
     SETF((fasts_power_kernel<8, 8, 0, 0>)); SETF((fasts_power_kernel<8, 4, 0, 0>)); SETF((fasts_power_kernel<4, 8, 0, 0>));
     SETF((fasts_power_kernel<8, 8, 0>)); SETF((fasts_power_kernel<8, 8, 1>)); SETF((fasts_power_kernel<8, 8, 2>));  // (above 64 KB of dynamic LDS)
@@ -1687,7 +1687,7 @@ static bool fastn_factor(long long n, int maxr, std::vector<int>& out, int need_
 }
 
 // the geometry of one n-point transform held in LDS with g sequences per workgroup (fastn.h, NGeo); blue: the Bluestein plan's natural layout is its intermediate layout
-static void fastn_geom(long long n, const std::vector<int>& rad, int g, int maxthr, bool blue, NGeo& o) {
+static void fastn_geom(long long n, const std::vector<int>& rad, int g, int maxthr, bool blue, NGeo& o, int thr_force = 0, int thr_pref = 0) {
     o = NGeo{};
     o.n = (int)n; o.np = (int)rad.size();
     long long L = n;
@@ -1703,20 +1703,37 @@ static void fastn_geom(long long n, const std::vector<int>& rad, int g, int maxt
     for (int p = 1; p + 1 < o.np; ++p) o.wlast *= o.r[p];
     int acc = 0;
     for (int p = 1; p + 1 < o.np; ++p) { o.two[p] = acc; acc += o.m[p] * o.r[p]; }
+    if (blue) { o.two[0] = acc; acc += o.m[0]; }  // (W_n^j, j < m[0]: the first pass of a Bluestein plan runs from LDS, too)
     o.twn = acc;
     const long long span = n + std::max<long long>(pdq ? n / pdq : 0, pnq ? n / pnq : 0) + 1;
     o.str = (int)(((span + 3) / 8) * 8 + 4);  // the smallest s >= span with s = 4 (mod 8): sequences eight lanes touch land on disjoint banks (fastm.h)
     o.g = g; o.lg = ilog2i(g);
     long long bmax = 0;
     for (int p = 0; p < o.np; ++p) bmax = std::max<long long>(bmax, n / o.r[p]);
-    long long thr = std::min<long long>(maxthr, ((g * bmax + 63) / 64) * 64);
-    thr = std::max<long long>(thr, ((g * (n / rl) + 63) / 64) * 64);  // (the last pass: one butterfly per thread)
+    long long thr = 0;
+    // Measured (profiles/r05_fastn_threads.txt): what counts is how many workgroups a CU keeps resident, and that is set by the registers (128 per
+    // lane in float32 -> 16 waves per CU, 168 in float64 -> 12), so the thread count is a divisor of that budget -- 512 (columns) / 256 (rows) in
+    // float32, 192 in float64 -- and a thread loops over its butterflies; 576- or 320-thread workgroups (one butterfly per thread) leave a CU half empty
+    (void)bmax;
+    const long long lower = ((g * (n / rl) + 63) / 64) * 64;  // (the last pass: one butterfly per thread)
+    static const int kGoodF[] = {256, 512, 1024}, kGoodD[] = {192, 256, 384, 512};
+    thr = 0;
+    const int want = thr_force > 0 ? thr_force : thr_pref;
+    if (maxthr > 512) { for (int t : kGoodF) if (!thr && t >= lower && t >= want) thr = t; }
+    else { for (int t : kGoodD) if (!thr && t >= lower && t >= want) thr = t; }
+    if (!thr) thr = std::min<long long>(maxthr, std::max<long long>(lower, want));
+    if (thr_force > 0) thr = std::max<long long>(lower, std::min<long long>(maxthr, ((thr_force + 63) / 64) * 64));
     o.thr = (int)thr;
 }
 
-template <typename T> static int fastn_upload_twm(const NGeo& g, DevBuf& buf) {  // W_{L_p}^(j k) at [two[p] + j r[p] + k], p = 1 .. np - 2
+template <typename T> static int fastn_upload_twm(const NGeo& g, DevBuf& buf, bool blue = false) {  // W_{L_p}^(j k) at [two[p] + j r[p] + k], p = 1 .. np - 2
     std::vector<C2<T>> t((size_t)std::max(g.twn, 1));
     const long double pi2 = 2.0L * 3.14159265358979323846264338327950288L;
+    if (blue)
+        for (int j = 0; j < g.m[0]; ++j) {
+            const long double a = -pi2 * (long double)j / (long double)g.n;
+            t[(size_t)(g.two[0] + j)].re = (T)cosl(a); t[(size_t)(g.two[0] + j)].im = (T)sinl(a);
+        }
     for (int p = 1; p + 1 < g.np; ++p) {
         const int Lp = g.m[p] * g.r[p];
         for (int j = 0; j < g.m[p]; ++j)
@@ -1777,14 +1794,15 @@ static bool fastn_setup(xrfthip_plan* P) {
         // rows per workgroup: reads and writes are contiguous whatever the count, and many small workgroups interleave their phases best (fastm.h): the
         // count that leaves 6, else 3, 2, 1 workgroups on a CU -- but two rows at least while they fit, so that W2's lines hold two rows' pieces
         const long long forced = env_ll("XRFTHIP_FASTN_RPU", 0);
-        static const size_t caps[] = {26 * 1024, 52 * 1024, 78 * 1024, 156 * 1024};
-        for (int ci = 0; ci < 4 && !rpu; ++ci)
-            for (int cand = 4; cand >= 1 && !rpu; cand >>= 1) {
-                if (ci < 3 && cand > 2) continue;
+        // (measured, profiles/r05_fastn_threads.txt: two rows per workgroup -- whole 128-byte lines of W2 -- beat one and four at every size, even where
+        // two rows leave a single workgroup on a CU: (16, 3000, 3000) float64 78 against 66 GFFT/s)
+        static const size_t caps[] = {156 * 1024};
+        for (int ci = 0; ci < 1 && !rpu; ++ci)
+            for (int cand = forced ? 4 : 2; cand >= 1 && !rpu; cand >>= 1) {
                 if (forced && cand != forced) continue;
                 NGeo t{};
                 if (!fastn_factor(d.nx, maxr, rx, need_last(two ? 2 * cand : cand, d.nx))) continue;
-                fastn_geom(d.nx, rx, two ? 2 * cand : cand, maxthr, false, t);
+                fastn_geom(d.nx, rx, two ? 2 * cand : cand, maxthr, false, t, (int)env_ll("XRFTHIP_FASTN_TR", 0), dbl ? 192 : 256);
                 if ((long long)t.g * (d.nx / t.r[t.np - 1]) > maxthr) continue;
                 if (fastn_lds(t, cs, false) <= caps[ci] && 2 * cand <= 64) { rpu = cand; gr = t; }
             }
@@ -1803,10 +1821,16 @@ static bool fastn_setup(xrfthip_plan* P) {
             // fewest passes within 12 % of the smallest candidate
             std::vector<int> best;
             long long bm = 0;
+            double bcost = 0.0;
+            // (arithmetic of an r-point butterfly per point, roughly: the prime butterflies 7 / 11 / 13 are O(r^2))
+            static const double kFlop[21] = {0, 0, 2, 5, 4, 8, 8, 15, 8, 10, 12, 24, 11, 28, 19, 15, 11, 0, 14, 0, 15};
             for (long long m = 2 * d.ny - 1; m <= (2 * d.ny - 1) * 9 / 8 + 16; ++m) {
                 std::vector<int> t;
                 if (!fastn_factor(m, std::min(maxr, 16), t)) continue;
-                if (best.empty() || t.size() < best.size()) { best = t; bm = m; }
+                double c = 0.0;
+                for (int r : t) c += 12.0 + kFlop[r];  // (a trip through LDS + the butterfly, per point and pass)
+                c *= (double)m;
+                if (best.empty() || t.size() < best.size() || (t.size() == best.size() && c < bcost)) { best = t; bm = m; bcost = c; }
             }
             if (best.empty()) return false;
             ry = best; mlen = bm; blue_m = (int)bm;
@@ -1823,7 +1847,7 @@ static bool fastn_setup(xrfthip_plan* P) {
                 if (2LL * cand > d.nx + 1) continue;
                 NGeo t{};
                 if (!fastn_factor(mlen, blue_m ? std::min(maxr, 16) : maxr, ry, need_last(cand, mlen))) continue;
-                fastn_geom(mlen, ry, cand, maxthr, blue_m != 0, t);
+                fastn_geom(mlen, ry, cand, maxthr, blue_m != 0, t, (int)env_ll("XRFTHIP_FASTN_TC", 0), dbl ? 192 : 512);
                 if ((long long)t.g * (mlen / t.r[t.np - 1]) > maxthr) continue;
                 if (fastn_lds(t, cs, true) <= caps[ci]) { G = cand; gc = t; }
             }
@@ -1847,7 +1871,7 @@ static bool fastn_setup(xrfthip_plan* P) {
 static FastN fastn_wrap(const xrfthip_plan* P, const FastM& m, bool cols) {
     FastN n{};
     n.f = m;
-    n.g = cols ? P->n_c.geo : P->n_r.geo;
+    n.g = reinterpret_cast<const NGeo*>(cols ? P->n_c.geo_dev.p : P->n_r.geo_dev.p);
     n.twm = cols ? P->n_c.twm.p : P->n_r.twm.p;
     n.pitch = (int)P->y_pitch; n.nxb = P->n_nxb;
     n.pair_ok = (P->ynx % 2 == 0) ? 1 : 0;
@@ -1856,30 +1880,37 @@ static FastN fastn_wrap(const xrfthip_plan* P, const FastM& m, bool cols) {
     const int vw = (int)(16 / (cplx_out ? P->csize : P->rsize));
     n.vec_ok = (P->ynx % vw == 0) ? 1 : 0;
     n.rpu = P->n_rpu;
+    n.dbg = (int)env_ll("XRFTHIP_FASTN_DBG", 0);
     return n;
 }
 
 static void fastn_launch_cols(const xrfthip_plan* P, const FastM& m, hipStream_t st) {
     const FastN n = fastn_wrap(P, m, true);
-    const dim3 grid((unsigned)(8 * ((m.nunits + 7) / 8))), blk((unsigned)n.g.thr);
+    const NGeo& hg = P->n_c.geo;
+    const dim3 grid((unsigned)(8 * ((m.nunits + 7) / 8))), blk((unsigned)hg.thr);
     const size_t lds = P->n_c.lds;
-#define NC_(TT) do { if (P->n_blue_m) { auto k = &fastn_cols_kernel<TT, true>; XRFT_LAUNCH(k, grid, blk, lds, st, n); } \
-                     else { auto k = &fastn_cols_kernel<TT, false>; XRFT_LAUNCH(k, grid, blk, lds, st, n); } } while (0)
-    if (P->dbl) NC_(double); else NC_(float);
+    int maxrad = 0;
+    for (int i = 0; i < hg.np; ++i) maxrad = std::max(maxrad, hg.r[i]);
+#define NC_(TT, CC) do { if (P->n_blue_m) { auto k = &fastn_cols_kernel<TT, true, CC>; XRFT_LAUNCH(k, grid, blk, lds, st, n); } \
+                         else { auto k = &fastn_cols_kernel<TT, false, CC>; XRFT_LAUNCH(k, grid, blk, lds, st, n); } } while (0)
+    if (P->dbl) NC_(double, 16); else if (maxrad > 16) NC_(float, 20); else NC_(float, 16);
 #undef NC_
 }
 
 static void fastn_launch_rows(const xrfthip_plan* P, const FastM& m, long long gc, bool fused, hipStream_t st) {
     const FastN n = fastn_wrap(P, m, false);
     const xrfthip_desc& d = P->d;
-    const dim3 grid((unsigned)(gc * (P->y_nrow_pad / P->n_rpu))), blk((unsigned)n.g.thr);
+    const NGeo& hg = P->n_r.geo;
+    const dim3 grid((unsigned)(gc * (P->y_nrow_pad / P->n_rpu))), blk((unsigned)hg.thr);
     const size_t lds = P->n_r.lds;
-#define NR_(TT) do { \
-        if (d.out_mode == XRFTHIP_OUT_POWER) { if (fused) { auto k = &fastn_rows_kernel<TT, 1, true>; XRFT_LAUNCH(k, grid, blk, lds, st, n); } else { auto k = &fastn_rows_kernel<TT, 1, false>; XRFT_LAUNCH(k, grid, blk, lds, st, n); } } \
-        else if (d.out_mode == XRFTHIP_OUT_CROSS) { if (fused) { auto k = &fastn_rows_kernel<TT, 2, true>; XRFT_LAUNCH(k, grid, blk, lds, st, n); } else { auto k = &fastn_rows_kernel<TT, 2, false>; XRFT_LAUNCH(k, grid, blk, lds, st, n); } } \
-        else if (d.out_mode == XRFTHIP_OUT_PHASE) { auto k = &fastn_rows_kernel<TT, 3, false>; XRFT_LAUNCH(k, grid, blk, lds, st, n); } \
-        else { auto k = &fastn_rows_kernel<TT, 0, false>; XRFT_LAUNCH(k, grid, blk, lds, st, n); } } while (0)
-    if (P->dbl) NR_(double); else NR_(float);
+    int maxrad = 0;
+    for (int i = 0; i < hg.np; ++i) maxrad = std::max(maxrad, hg.r[i]);
+#define NR_(TT, CC) do { \
+        if (d.out_mode == XRFTHIP_OUT_POWER) { if (fused) { auto k = &fastn_rows_kernel<TT, 1, true, CC>; XRFT_LAUNCH(k, grid, blk, lds, st, n); } else { auto k = &fastn_rows_kernel<TT, 1, false, CC>; XRFT_LAUNCH(k, grid, blk, lds, st, n); } } \
+        else if (d.out_mode == XRFTHIP_OUT_CROSS) { if (fused) { auto k = &fastn_rows_kernel<TT, 2, true, CC>; XRFT_LAUNCH(k, grid, blk, lds, st, n); } else { auto k = &fastn_rows_kernel<TT, 2, false, CC>; XRFT_LAUNCH(k, grid, blk, lds, st, n); } } \
+        else if (d.out_mode == XRFTHIP_OUT_PHASE) { auto k = &fastn_rows_kernel<TT, 3, false, CC>; XRFT_LAUNCH(k, grid, blk, lds, st, n); } \
+        else { auto k = &fastn_rows_kernel<TT, 0, false, CC>; XRFT_LAUNCH(k, grid, blk, lds, st, n); } } while (0)
+    if (P->dbl) NR_(double, 16); else if (maxrad > 16) NR_(float, 20); else NR_(float, 16);
 #undef NR_
 }
 
@@ -2834,7 +2865,7 @@ int xrfthip_plan_create(xrfthip_plan** plan, const xrfthip_desc* desc) {
                                  : (d.out_mode == XRFTHIP_OUT_COMPLEX || d.out_mode == XRFTHIP_OUT_PHASE) ? (shifts | ish | XRFTHIP_HALF_X) : 0u;
         const bool half_ok = !((d.flags & halff) && (d.flags & XRFTHIP_ISO)) && !((d.flags & XRFTHIP_HALF_X) && (d.flags & XRFTHIP_SHIFT_X));
         P->fastm = half_ok && d.ndim == 2 && (d.dtype == XRFTHIP_F64 || d.dtype == XRFTHIP_F32) && !P->fast4096 && fastm_len(d.ny, P->dbl) && fastm_len(d.nx, P->dbl) && !(d.flags & ~allowed) &&
-                   !env_ll("XRFTHIP_NO_FAST", 0) && env_ll("XRFTHIP_FASTM", 1) != 0;
+                   !env_ll("XRFTHIP_NO_FAST", 0) && env_ll("XRFTHIP_FASTM", 1) != 0 && env_ll("XRFTHIP_FASTN_TABLES", 1) != 0;
         if (P->fastm) {
             const bool two = d.out_mode == XRFTHIP_OUT_CROSS || d.out_mode == XRFTHIP_OUT_PHASE;
             const int rpu = fastm_rpu(d.nx, two, P->dbl);
@@ -2940,9 +2971,11 @@ int xrfthip_plan_create(xrfthip_plan** plan, const xrfthip_desc* desc) {
                 std::vector<double> ones((size_t)std::max(d.ny, d.nx), 1.0);
                 std::vector<float> onesf((size_t)std::max(d.ny, d.nx), 1.0f);
                 if (!rcn) rcn = P->dbl ? P->ones4096.upload(ones.data(), ones.size() * sizeof(double)) : P->ones4096.upload(onesf.data(), onesf.size() * sizeof(float));
-                if (!rcn && P->n_c.rt) rcn = P->dbl ? fastn_upload_twm<double>(P->n_c.geo, P->n_c.twm) : fastn_upload_twm<float>(P->n_c.geo, P->n_c.twm);
+                if (!rcn && P->n_c.rt) rcn = P->dbl ? fastn_upload_twm<double>(P->n_c.geo, P->n_c.twm, P->n_blue_m != 0) : fastn_upload_twm<float>(P->n_c.geo, P->n_c.twm, P->n_blue_m != 0);
                 if (!rcn && P->n_r.rt) rcn = P->dbl ? fastn_upload_twm<double>(P->n_r.geo, P->n_r.twm) : fastn_upload_twm<float>(P->n_r.geo, P->n_r.twm);
                 if (!rcn && P->n_blue_m) rcn = P->dbl ? fastn_blue_tables<double>(P) : fastn_blue_tables<float>(P);
+                if (!rcn && P->n_c.rt) rcn = P->n_c.geo_dev.upload(&P->n_c.geo, sizeof(NGeo));
+                if (!rcn && P->n_r.rt) rcn = P->n_r.geo_dev.upload(&P->n_r.geo, sizeof(NGeo));
                 if (rcn) { delete P; return rcn; }
             }
         }
