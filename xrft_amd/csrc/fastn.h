@@ -43,9 +43,20 @@ struct NGeo {
     int wlast;                // r[1] .. r[np-2]: the weight of the last pass's output index in `rest`
 };
 
+// The geometry is read through the CONSTANT address space: uniform, read-only for the kernel's lifetime, so every field is a scalar load (s_load, scalar
+// cache) -- through a plain global pointer the compiler cannot rule out aliasing with the kernel's own stores and fetches each field with a vector load, an
+// L2 round trip on the critical path between two barriers (measured: 2-3 x the table kernels' VMEM read instructions, SQ busy cycles 2 x).
+#ifdef XRFT_EMULATE
+typedef const NGeo* NGeoPtr;
+typedef const NGeo& NGeoRef;
+#else
+typedef const NGeo __attribute__((address_space(4)))* NGeoPtr;
+typedef const NGeo __attribute__((address_space(4)))& NGeoRef;
+#endif
+
 struct FastN {
     FastM f;              // the pipeline's parameter block exactly as the table kernels take it (incl. the intermediate's layout l_cw, l_rk)
-    const NGeo* g;        // the transform of THIS pass (device memory, uploaded once per plan: a by-value copy in the kernel arguments is dynamically
+    NGeoPtr g;            // the transform of THIS pass (device memory, uploaded once per plan: a by-value copy in the kernel arguments is dynamically
                           // indexed by the pass number, which made the compiler park the whole argument block in scratch memory)
     const void* twm;      // twiddles of the middle passes, [g.twn] complex T (staged in LDS)
     int pitch;            // complex elements per row of the intermediate: nxb column blocks of CW columns (a ragged last block is padded)
@@ -85,7 +96,7 @@ template <typename T, int R> __device__ __forceinline__ void n_chain(C2<T>* a, C
 // Pass p < np - 1 over the G sequences of a workgroup, in place in the intermediate layout (sequence t at lds + t str).  p == 0 (the transforms of a
 // Bluestein convolution: operands in LDS) takes its twiddles as powers of W_n^j, staged at two[0]; the others W_{L_p}^(j k) from the staged table.
 template <typename T, int R>
-__device__ __forceinline__ void n_pass_mid(C2<T>* lds, const NGeo& g, int p, int tid, int nthr, const C2<T>* twl, const C2<T>* __restrict__ twg) {
+__device__ __forceinline__ void n_pass_mid(C2<T>* lds, NGeoRef g, int p, int tid, int nthr, const C2<T>* twl, const C2<T>* __restrict__ twg) {
     const int m = g.m[p], L = m * R, bps = g.n / R, nb = bps << g.lg, st = g.step[p];
     const float inv_bps = 1.0f / (float)bps, inv_m = 1.0f / (float)m;
     const C2<T>* twp = twl + g.two[p];
@@ -110,7 +121,7 @@ __device__ __forceinline__ void n_pass_mid(C2<T>* lds, const NGeo& g, int p, int
 // anyone writes.  Run blk = ((k_0 r_1 + k_1) r_2 + ...) + k_{np-2} holds the frequencies k_0 + r_0 (k_1 + r_1 (k_2 + ... + r_{np-2} k_{np-1})).
 // Starts and ends with a barrier.
 template <typename T, int R>
-__device__ __forceinline__ void n_pass_last(C2<T>* lds, const NGeo& g, int tid) {
+__device__ __forceinline__ void n_pass_last(C2<T>* lds, NGeoRef g, int tid) {
     const int bps = g.n / R, nb = bps << g.lg;
     const bool on = tid < nb;
     const int t = on ? fdiv(tid, 1.0f / (float)bps) : 0, blk = on ? tid - t * bps : 0;
@@ -142,7 +153,7 @@ __device__ __forceinline__ void n_pass_last(C2<T>* lds, const NGeo& g, int tid) 
 
 // passes 1 .. np - 1 (the first one has put its results into LDS); ends with the result in natural order, after a barrier
 template <typename T, int CAP>
-__device__ __forceinline__ void n_fft_tail(C2<T>* lds, const NGeo& g, int tid, int nthr, const C2<T>* twl) {
+__device__ __forceinline__ void n_fft_tail(C2<T>* lds, NGeoRef g, int tid, int nthr, const C2<T>* twl) {
     for (int p = 1; p + 1 < g.np; ++p) {
         __syncthreads();
 #define NM_(RR) n_pass_mid<T, RR>(lds, g, p, tid, nthr, twl, nullptr)
@@ -162,6 +173,7 @@ template <typename T> struct NColsCtx {
     const char* src;     // the slab's column block (bytes)
     unsigned rowb;       // bytes per row
     unsigned coff;       // byte offset of this thread's column pair in a row
+    unsigned coff1;      // ... of its second column (an odd nx: two loads)
     bool pair_ok, has0, has1;
     const T* wy;
     C2<T> wx;
@@ -173,13 +185,16 @@ template <typename T> struct NColsCtx {
     int ny;
 };
 
-template <typename T> __device__ __forceinline__ C2<T> n_load_pair(const NColsCtx<T>& c, unsigned off) {
-    if (c.pair_ok) return *reinterpret_cast<const C2<T>*>(c.src + off);
-    return mk<T>(c.has0 ? *reinterpret_cast<const T*>(c.src + off) : (T)0, c.has1 ? *reinterpret_cast<const T*>(c.src + off + (unsigned)sizeof(T)) : (T)0);
+// UNCONDITIONAL loads (a per-lane branch around a load makes the compiler wait for each one, and all of a butterfly's loads must be in flight together):
+// an even nx makes every column pair one aligned 2 T-wide load; an odd nx (pair_ok = 0, a UNIFORM switch) two T-wide loads.  A column beyond the ragged
+// edge re-reads column 0 and is zeroed by its window factor (c.wx).
+template <typename T> __device__ __forceinline__ C2<T> n_load_pair(const NColsCtx<T>& c, unsigned rowoff) {
+    if (c.pair_ok) return *reinterpret_cast<const C2<T>*>(c.src + (rowoff + c.coff));
+    return mk<T>(*reinterpret_cast<const T*>(c.src + (rowoff + c.coff)), *reinterpret_cast<const T*>(c.src + (rowoff + c.coff1)));
 }
 
 template <typename T, int R, bool BLUE>
-__device__ __forceinline__ void n_first_cols(NColsCtx<T>& c, const NGeo& g, C2<T>* seq, int j, const C2<T>* __restrict__ tw) {
+__device__ __forceinline__ void n_first_cols(NColsCtx<T>& c, NGeoRef g, C2<T>* seq, int j, const C2<T>* __restrict__ tw) {
     typedef C2<T> CT;
     const int M0 = g.m[0];
     CT a[R];
@@ -190,7 +205,7 @@ __device__ __forceinline__ void n_first_cols(NColsCtx<T>& c, const NGeo& g, C2<T
         const int row = j + q * M0;
         a[q] = mk<T>((T)0, (T)0); wyv[q] = (T)0;
         if (!BLUE || row < c.ny) {
-            a[q] = n_load_pair<T>(c, c.coff + c.rowb * (unsigned)row);
+            a[q] = n_load_pair<T>(c, c.rowb * (unsigned)row);
             wyv[q] = c.wy[row];
         }
     }
@@ -223,7 +238,7 @@ __device__ __forceinline__ void n_first_cols(NColsCtx<T>& c, const NGeo& g, C2<T
 template <typename T, bool BLUE, int CAP>
 __global__ void __launch_bounds__(fastn_max_threads<T>(), (sizeof(T) == 4 ? 4 : 3)) fastn_cols_kernel(FastN P) {
     typedef C2<T> CT;
-    const NGeo& g = *P.g;
+    NGeoRef g = *P.g;
     const FastM& p = P.f;
     XRFT_DYN_SMEM(smem_raw);
     CT* lds = reinterpret_cast<CT*>(smem_raw);
@@ -242,10 +257,16 @@ __global__ void __launch_bounds__(fastn_max_threads<T>(), (sizeof(T) == 4 ? 4 : 
     c.src = reinterpret_cast<const char*>(reinterpret_cast<const T*>(p.in) + (size_t)slab * ny * nx + (size_t)xb * CW);
     c.rowb = (unsigned)nx * (unsigned)sizeof(T);
     c.coff = (unsigned)gi * (unsigned)sizeof(CT);
-    c.pair_ok = P.pair_ok != 0; c.has0 = col0 < nx; c.has1 = col0 + 1 < nx;
-    if (c.pair_ok && !c.has0) { c.pair_ok = false; }  // (a pair beyond the ragged edge: zeros)
+    c.pair_ok = P.pair_ok != 0;  // (uniform)
+    c.has0 = col0 < nx; c.has1 = col0 + 1 < nx;
+    c.coff1 = c.has1 ? c.coff + (unsigned)sizeof(T) : 0u;
+    if (!c.has0) c.coff = 0;  // (a column beyond the ragged edge: column 0 again, times a zero window)
     c.wy = reinterpret_cast<const T*>(p.win_y);
-    c.wx = mk<T>(c.has0 ? reinterpret_cast<const T*>(p.win_x)[col0] : (T)0, c.has1 ? reinterpret_cast<const T*>(p.win_x)[col0 + 1] : (T)0);
+    {
+        const T* __restrict__ wxp = reinterpret_cast<const T*>(p.win_x);
+        const T w0 = wxp[min(col0, nx - 1)], w1 = wxp[min(col0 + 1, nx - 1)];
+        c.wx = mk<T>(c.has0 ? w0 : (T)0, c.has1 ? w1 : (T)0);
+    }
     c.det = p.detrend != 0;
     c.pre = c.det && sizeof(T) == 4;
     c.ibar = 0.5 * (ny - 1);
@@ -261,8 +282,8 @@ __global__ void __launch_bounds__(fastn_max_threads<T>(), (sizeof(T) == 4 ? 4 : 
         CT rt[3], rb[3];
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
-            rt[k] = n_load_pair<T>(c, c.coff + c.rowb * (unsigned)(ITOP - 1 + k));
-            rb[k] = n_load_pair<T>(c, c.coff + c.rowb * (unsigned)(IBOT - 1 + k));
+            rt[k] = n_load_pair<T>(c, c.rowb * (unsigned)(ITOP - 1 + k));
+            rb[k] = n_load_pair<T>(c, c.rowb * (unsigned)(IBOT - 1 + k));
         }
         auto med3 = [](float x, float y, float z) { return fmaxf(fminf(x, y), fminf(fmaxf(x, y), z)); };
         const float mt[2] = {med3((float)rt[0].re, (float)rt[1].re, (float)rt[2].re), med3((float)rt[0].im, (float)rt[1].im, (float)rt[2].im)};
@@ -294,7 +315,7 @@ __global__ void __launch_bounds__(fastn_max_threads<T>(), (sizeof(T) == 4 ? 4 : 
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 const int ic = min(i0 + u * RQ, ny - 1);
-                v[u] = n_load_pair<T>(c, c.coff + c.rowb * (unsigned)ic);
+                v[u] = n_load_pair<T>(c, c.rowb * (unsigned)ic);
                 wv[u] = c.wy[ic];
                 cc_[u] = ch[ic];
             }
@@ -403,7 +424,7 @@ __global__ void __launch_bounds__(fastn_max_threads<T>(), (sizeof(T) == 4 ? 4 : 
 template <typename T, int R>
 __device__ __forceinline__ void n_first_rows(const FastN& P, C2<T>* lds, int w, int ky0, int slab, bool two) {
     typedef C2<T> CT;
-    const NGeo& g = *P.g;
+    NGeoRef g = *P.g;
     const FastM& p = P.f;
     const int M0 = g.m[0], rk = 1 << p.l_rk, cwm = (1 << p.l_cw) - 1, nyh = p.ny >> 1;
     const int xq = w >> p.l_rk, pairi = fdiv(xq, 1.0f / (float)M0), j = xq - pairi * M0, t = (pairi << p.l_rk) + (w & (rk - 1));
@@ -445,7 +466,7 @@ __global__ void __launch_bounds__(fastn_max_threads<T>(), (sizeof(T) == 4 ? 4 : 
     static_assert(!ISO || MODE == 1 || MODE == 2, "radial sums exist for power and cross spectra");
     typedef C2<T> CT;
     constexpr bool TWO = MODE >= 2;
-    const NGeo& g = *P.g;
+    NGeoRef g = *P.g;
     const FastM& p = P.f;
     XRFT_DYN_SMEM(smem_raw);
     CT* lds = reinterpret_cast<CT*>(smem_raw);

@@ -1871,7 +1871,7 @@ static bool fastn_setup(xrfthip_plan* P) {
 static FastN fastn_wrap(const xrfthip_plan* P, const FastM& m, bool cols) {
     FastN n{};
     n.f = m;
-    n.g = reinterpret_cast<const NGeo*>(cols ? P->n_c.geo_dev.p : P->n_r.geo_dev.p);
+    n.g = (NGeoPtr)(cols ? P->n_c.geo_dev.p : P->n_r.geo_dev.p);
     n.twm = cols ? P->n_c.twm.p : P->n_r.twm.p;
     n.pitch = (int)P->y_pitch; n.nxb = P->n_nxb;
     n.pair_ok = (P->ynx % 2 == 0) ? 1 : 0;
