@@ -349,8 +349,9 @@ def run_random_fastn(seed, lo=16, hi=200, dtype="float64", blue_p=0.15):
     on = any("[fastn]" in t for t in tags)
     flipped = desc and tp and kind in ("fft", "cs", "phase", "isocs")
     assert not (on and flipped), (kind, desc, tp, ny, nx, on)
-    if kind == "ps" and not any("[fastg" in t or "[fasts" in t or "[fastm]" in t or "[fasty" in t for t in tags):
-        assert on, (kind, ny, nx, dtype, tags)  # (a plain power spectrum of a slab no other specialised kernel takes is always served here)
+    if kind == "ps" and not blue and not any("[fastg" in t or "[fasts" in t or "[fastm]" in t or "[fasty" in t for t in tags):
+        assert on, (kind, ny, nx, dtype, tags)  # (a plain power spectrum of a slab no other specialised kernel takes is always served here; a chirp
+        #                                          convolution of 2 ny points that does not fit the LDS stays with the generic passes)
     if kind == "phase":  # (the angle of a near-zero cross spectrum amplifies rounding: compare where the product is not small)
         assert tuple(got.dims) == tuple(ref.dims)
         cs = o.cross_spectrum(od, ob, dim=["y", "x"], shift=shift, true_phase=tp, **kw).values

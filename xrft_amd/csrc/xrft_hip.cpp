@@ -1711,18 +1711,9 @@ static void fastn_geom(long long n, const std::vector<int>& rad, int g, int maxt
     long long bmax = 0;
     for (int p = 0; p < o.np; ++p) bmax = std::max<long long>(bmax, n / o.r[p]);
     long long thr = 0;
-    // Measured (profiles/r05_fastn_threads.txt): what counts is how many workgroups a CU keeps resident, and that is set by the registers (128 per
-    // lane in float32 -> 16 waves per CU, 168 in float64 -> 12), so the thread count is a divisor of that budget -- 512 (columns) / 256 (rows) in
-    // float32, 192 in float64 -- and a thread loops over its butterflies; 576- or 320-thread workgroups (one butterfly per thread) leave a CU half empty
-    (void)bmax;
+    (void)bmax; (void)thr_pref;
     const long long lower = ((g * (n / rl) + 63) / 64) * 64;  // (the last pass: one butterfly per thread)
-    static const int kGoodF[] = {256, 512, 1024}, kGoodD[] = {192, 256, 384, 512};
-    thr = 0;
-    const int want = thr_force > 0 ? thr_force : thr_pref;
-    if (maxthr > 512) { for (int t : kGoodF) if (!thr && t >= lower && t >= want) thr = t; }
-    else { for (int t : kGoodD) if (!thr && t >= lower && t >= want) thr = t; }
-    if (!thr) thr = std::min<long long>(maxthr, std::max<long long>(lower, want));
-    if (thr_force > 0) thr = std::max<long long>(lower, std::min<long long>(maxthr, ((thr_force + 63) / 64) * 64));
+    thr = std::max<long long>(lower, std::min<long long>(maxthr, ((std::max(thr_force, 64) + 63) / 64) * 64));
     o.thr = (int)thr;
 }
 
@@ -1771,6 +1762,27 @@ static size_t fastn_lds(const NGeo& g, size_t csize, bool cols) {
     return ((size_t)g.g * g.str + g.twn) * csize + (cols ? (size_t)(g.thr / 64) * g.g * 4 * sizeof(double) : 0);
 }
 
+// Radices and thread count of one transform with g sequences per workgroup.  What counts is how many workgroups a CU keeps resident, and that is set by the
+// registers (128 per lane in float32 -> 16 waves per CU, 168 in float64 -> 12): the thread count is a divisor of that budget -- 512 (columns) / 256 (rows) in
+// float32, 192 / 256 / 384 in float64; 576- or 320-thread workgroups leave a CU half empty (profiles/r05_fastn_threads.txt) -- and the factorisation is the one
+// with the fewest passes whose LAST radix is large enough for one last-pass butterfly per thread at that count (a thread loops over the other passes' butterflies).
+static bool fastn_pick(long long n, int g, bool blue, bool dbl, bool cols, int maxr, int thr_force, NGeo& out) {
+    const int maxthr = dbl ? fastn_max_threads<double>() : fastn_max_threads<float>();
+    std::vector<int> base, r;
+    if (!fastn_factor(n, maxr, base)) return false;
+    static const int kD[] = {192, 256, 384, 512, 0}, kFC[] = {512, 1024, 0, 0, 0}, kFR[] = {256, 512, 1024, 0, 0};
+    const int* targets = dbl ? kD : cols ? kFC : kFR;
+    for (int extra = 0; extra <= 1; ++extra)
+        for (int i = 0; i < 5 && (thr_force > 0 ? i < 1 : targets[i] != 0); ++i) {
+            const int t = thr_force > 0 ? std::min(maxthr, ((thr_force + 63) / 64) * 64) : targets[i];
+            const int need = (int)((g * n + t - 1) / t);
+            if (need > maxr || !fastn_factor(n, maxr, r, need) || r.size() > base.size() + (size_t)extra) continue;
+            fastn_geom(n, r, g, maxthr, blue, out, t);
+            return true;
+        }
+    return false;
+}
+
 // Decide which kernel runs each pass of a y-first plan on (ny, nx) and the layout of the intermediate between them.  Returns false when the plan stays
 // with the other paths (a length the butterflies do not factor and the chirp convolution does not fit, sequences that do not fit the LDS).
 static bool fastn_setup(xrfthip_plan* P) {
@@ -1788,7 +1800,6 @@ static bool fastn_setup(xrfthip_plan* P) {
     std::vector<int> rx, ry;
     int rpu = 0;
     NGeo gr{};
-    auto need_last = [&](long long g, long long n) { return (int)((g * n + maxthr - 1) / maxthr); };  // one last-pass butterfly per thread: g n / r_last <= maxthr
     if (rows_rt) {
         if (!fastn_factor(d.nx, maxr, rx)) return false;
         // rows per workgroup: reads and writes are contiguous whatever the count, and many small workgroups interleave their phases best (fastm.h): the
@@ -1801,8 +1812,7 @@ static bool fastn_setup(xrfthip_plan* P) {
             for (int cand = forced ? 4 : 2; cand >= 1 && !rpu; cand >>= 1) {
                 if (forced && cand != forced) continue;
                 NGeo t{};
-                if (!fastn_factor(d.nx, maxr, rx, need_last(two ? 2 * cand : cand, d.nx))) continue;
-                fastn_geom(d.nx, rx, two ? 2 * cand : cand, maxthr, false, t, (int)env_ll("XRFTHIP_FASTN_TR", 0), dbl ? 192 : 256);
+                if (!fastn_pick(d.nx, two ? 2 * cand : cand, false, dbl, false, maxr, (int)env_ll("XRFTHIP_FASTN_TR", 0), t)) continue;
                 if ((long long)t.g * (d.nx / t.r[t.np - 1]) > maxthr) continue;
                 if (fastn_lds(t, cs, false) <= caps[ci] && 2 * cand <= 64) { rpu = cand; gr = t; }
             }
@@ -1846,8 +1856,7 @@ static bool fastn_setup(xrfthip_plan* P) {
                 if (!rows_rt && d.nx % (2 * cand) != 0) continue;  // (the table's row kernel reads an unpadded intermediate)
                 if (2LL * cand > d.nx + 1) continue;
                 NGeo t{};
-                if (!fastn_factor(mlen, blue_m ? std::min(maxr, 16) : maxr, ry, need_last(cand, mlen))) continue;
-                fastn_geom(mlen, ry, cand, maxthr, blue_m != 0, t, (int)env_ll("XRFTHIP_FASTN_TC", 0), dbl ? 192 : 512);
+                if (!fastn_pick(mlen, cand, blue_m != 0, dbl, true, blue_m ? std::min(maxr, 16) : maxr, (int)env_ll("XRFTHIP_FASTN_TC", 0), t)) continue;
                 if ((long long)t.g * (mlen / t.r[t.np - 1]) > maxthr) continue;
                 if (fastn_lds(t, cs, true) <= caps[ci]) { G = cand; gc = t; }
             }
