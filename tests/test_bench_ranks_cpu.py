@@ -82,6 +82,23 @@ def test_bench_plain_command_starts_its_own_ranks():
     assert out["config"]["process_group_backend"] == "gloo" and out["value"] > 0
 
 
+def test_bench_plain_c4_command_gathers_identical_isotropic_blocks():
+    """`python bench.py --gpus 2 --workload c4` as the driver would type it (no launcher): two ranks in the process group, the isotropic blocks all-gathered
+    over the group are the same bytes on both ranks and hold every rank's slabs."""
+    out = _run(2, ["--nt", "2", "--workload", "c4"], launcher=False)
+    assert out["n_gpus"] == 2 and out["config"]["ranks_in_process_group"] == 2 and out["scaling"] == "weak"
+    col = out["config"]["collective"]
+    assert col["op"] == "all_gather" and col["identical_on_all_ranks"] is True
+    assert col["gathered_shape"] == [4, 64] and out["config"]["shard_sizes"] == [2, 2]  # (nt_total, nbins = 256 / 4)
+
+
+def test_bench_plain_c5_command_strong_scaling_shards():
+    """`python bench.py --gpus 2 --workload c5 --scaling strong` (no launcher): contiguous blocks of the total, never a split slab."""
+    out = _run(2, ["--nt", "5", "--workload", "c5", "--ny", "360", "--nx", "360", "--scaling", "strong"], launcher=False)
+    assert out["n_gpus"] == 2 and out["config"]["ranks_in_process_group"] == 2 and out["scaling"] == "strong" and out["dtype"] == "f64"
+    assert out["config"]["shard_sizes"] == [3, 2] and out["config"]["nt_total"] == 5 and out["config"]["nt_per_gpu"] == 3
+
+
 def test_bench_plain_command_refuses_more_ranks_than_devices():
     """Fewer visible devices than --gpus: a clear message and a non-zero status before any rank is started."""
     r = _run(4, ["--nt", "2"], launcher=False, environ={"XRFT_EMU_DEVICES": "2"}, expect_status=3)
