@@ -147,10 +147,14 @@ __device__ __forceinline__ void fastg_rows_pass(C2<T>* tile, const TileGeom& g, 
         case 4: run_pass<T, 4>(tile, g, L, tid, nthr, tw); break;
         case 5: run_pass<T, 5>(tile, g, L, tid, nthr, tw); break;
         case 6: run_pass<T, 6>(tile, g, L, tid, nthr, tw); break;
+        case 7: run_pass<T, 7>(tile, g, L, tid, nthr, tw); break;
         case 8: run_pass<T, 8>(tile, g, L, tid, nthr, tw); break;
         case 9: run_pass<T, 9>(tile, g, L, tid, nthr, tw); break;
         case 10: run_pass<T, 10>(tile, g, L, tid, nthr, tw); break;
+        case 11: run_pass<T, 11>(tile, g, L, tid, nthr, tw); break;
         case 12: run_pass<T, 12>(tile, g, L, tid, nthr, tw); break;
+        case 13: run_pass<T, 13>(tile, g, L, tid, nthr, tw); break;
+        case 14: run_pass<T, 14>(tile, g, L, tid, nthr, tw); break;
         case 15: run_pass<T, 15>(tile, g, L, tid, nthr, tw); break;
         default: run_pass<T, 16>(tile, g, L, tid, nthr, tw); break;
     }
@@ -163,10 +167,14 @@ __device__ __forceinline__ void fastg_cols_pass(C2<T>* tile, int ncols, int len,
         case 4: fastg_pass_cols<T, 4>(tile, ncols, len, rs, L, tid, nthr, tw); break;
         case 5: fastg_pass_cols<T, 5>(tile, ncols, len, rs, L, tid, nthr, tw); break;
         case 6: fastg_pass_cols<T, 6>(tile, ncols, len, rs, L, tid, nthr, tw); break;
+        case 7: fastg_pass_cols<T, 7>(tile, ncols, len, rs, L, tid, nthr, tw); break;
         case 8: fastg_pass_cols<T, 8>(tile, ncols, len, rs, L, tid, nthr, tw); break;
         case 9: fastg_pass_cols<T, 9>(tile, ncols, len, rs, L, tid, nthr, tw); break;
         case 10: fastg_pass_cols<T, 10>(tile, ncols, len, rs, L, tid, nthr, tw); break;
+        case 11: fastg_pass_cols<T, 11>(tile, ncols, len, rs, L, tid, nthr, tw); break;
         case 12: fastg_pass_cols<T, 12>(tile, ncols, len, rs, L, tid, nthr, tw); break;
+        case 13: fastg_pass_cols<T, 13>(tile, ncols, len, rs, L, tid, nthr, tw); break;
+        case 14: fastg_pass_cols<T, 14>(tile, ncols, len, rs, L, tid, nthr, tw); break;
         case 15: fastg_pass_cols<T, 15>(tile, ncols, len, rs, L, tid, nthr, tw); break;
         default: fastg_pass_cols<T, 16>(tile, ncols, len, rs, L, tid, nthr, tw); break;
     }

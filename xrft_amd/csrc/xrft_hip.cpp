@@ -1766,20 +1766,33 @@ static size_t fastn_lds(const NGeo& g, size_t csize, bool cols) {
 // registers (128 per lane in float32 -> 16 waves per CU, 168 in float64 -> 12): the thread count is a divisor of that budget -- 512 (columns) / 256 (rows) in
 // float32, 192 / 256 / 384 in float64; 576- or 320-thread workgroups leave a CU half empty (profiles/r05_fastn_threads.txt) -- and the factorisation is the one
 // with the fewest passes whose LAST radix is large enough for one last-pass butterfly per thread at that count (a thread loops over the other passes' butterflies).
+static size_t fastn_lds(const NGeo& g, size_t csize, bool cols);
 static bool fastn_pick(long long n, int g, bool blue, bool dbl, bool cols, int maxr, int thr_force, NGeo& out) {
     const int maxthr = dbl ? fastn_max_threads<double>() : fastn_max_threads<float>();
     std::vector<int> base, r;
     if (!fastn_factor(n, maxr, base)) return false;
-    static const int kD[] = {192, 256, 384, 512, 0}, kFC[] = {512, 1024, 0, 0, 0}, kFR[] = {256, 512, 1024, 0, 0};
-    const int* targets = dbl ? kD : cols ? kFC : kFR;
-    for (int extra = 0; extra <= 1; ++extra)
+    static const int kD[] = {192, 256, 384, 512, 0}, kFC[] = {512, 256, 1024, 0, 0}, kFR[] = {256, 512, 1024, 0, 0};
+    const int* targets = dbl ? kD : (cols && !blue) ? kFC : kFR;  // (a chirp convolution: the smaller workgroup, more of them)
+    const int budget = dbl ? 12 : 16;  // waves a CU keeps resident at the kernels' register counts
+    for (int extra = 0; extra <= 1; ++extra) {
+        int best_res = -1;
         for (int i = 0; i < 5 && (thr_force > 0 ? i < 1 : targets[i] != 0); ++i) {
             const int t = thr_force > 0 ? std::min(maxthr, ((thr_force + 63) / 64) * 64) : targets[i];
             const int need = (int)((g * n + t - 1) / t);
             if (need > maxr || !fastn_factor(n, maxr, r, need) || r.size() > base.size() + (size_t)extra) continue;
-            fastn_geom(n, r, g, maxthr, blue, out, t);
-            return true;
+            NGeo cand{};
+            fastn_geom(n, r, g, maxthr, blue, cand, t);
+            const size_t lds = fastn_lds(cand, dbl ? 16 : 8, cols);
+            if (lds > 156 * 1024) continue;
+            const int w = cand.thr / 64, res = std::min<int>(budget / w, (int)((160 * 1024) / lds)) * w;  // resident waves per CU
+            // float64: the size that keeps the most waves resident ((64, 1440, 720): 256 threads, three workgroups by LDS, 5.4 us against 6.6 with 192); float32:
+            // the first size that works -- 512 (columns) / 256 (rows): beyond that a workgroup that owns the CU's LDS alone only gets slower (2200-point
+            // columns: 512 threads 137 GFFT/s, 1024 threads 122)
+            if (res > best_res) { best_res = res; out = cand; }
+            if (!dbl) break;
         }
+        if (best_res >= 0) return true;
+    }
     return false;
 }
 
@@ -1847,12 +1860,18 @@ static bool fastn_setup(xrfthip_plan* P) {
         }
         const int gmax = dbl ? 4 : 8, gpref = dbl ? 2 : 4;  // (32-byte row segments at least where they fit: 16-byte segments load at half the rate, fastm.h)
         const long long forced = env_ll("XRFTHIP_FASTN_GC", 0);
-        static const size_t caps[] = {52 * 1024, 78 * 1024, 156 * 1024};
+        // sequences per workgroup: the widest row segments (32 bytes at least where they fit: 16-byte segments load at half the rate, fastm.h) that leave three,
+        // else two, else one workgroup on a CU; a chirp convolution -- bound by its 16 trips through the LDS, not by its loads -- the narrowest
+        // instead: more, smaller workgroups interleave better ((64, 721, 1440): 2 pairs x 256 threads 99 GFFT/s, 4 x 512 80; profiles/r05_fastn_knobs.txt)
         int G = 0;
+        static const size_t caps[] = {52 * 1024, 78 * 1024, 156 * 1024};
+        static const int kBlueOrder[] = {2, 4, 1, 8}, kOrder[] = {8, 4, 2, 1};
         for (int ci = 0; ci < 3 && !G; ++ci)
-            for (int cand = gmax; cand >= 1 && !G; cand >>= 1) {
+            for (int oi = 0; oi < 4 && !G; ++oi) {
+                const int cand = blue_m ? kBlueOrder[oi] : kOrder[oi];
+                if (cand > gmax) continue;
                 if (forced && cand != forced) continue;
-                if (ci < 2 && cand < gpref && !forced) continue;
+                if (ci < 2 && cand < gpref && !forced && !blue_m) continue;
                 if (!rows_rt && d.nx % (2 * cand) != 0) continue;  // (the table's row kernel reads an unpadded intermediate)
                 if (2LL * cand > d.nx + 1) continue;
                 NGeo t{};
@@ -2193,6 +2212,15 @@ template <typename T> static int fastg_setup_t(xrfthip_plan* P) {
     if (!rc) rc = fastg_rev(P->g_ry, ny, P->g_revy, P->g_hrevy);  // (no passes: the identity)
     return rc;
 }
+// the radices of one axis of the lengths-as-data one-pass kernels (fastg.h): the 2^a 3^b 5^c choice of `factorize` where the length is that smooth (unchanged
+// plans), else -- prime factors 7, 11, 13: weekly data, 77, 91, 364 = 52 weeks, 1001 -- the butterflies of tile_fft.h's dft_prime (numpy's pocketfft
+// hard-codes 7 and 11).  False: another prime factor.
+static bool fastg_factor(long long n, std::vector<int>& out) {
+    bool gen = false;
+    if (factorize(n, out, gen) == XRFTHIP_OK && !gen) return true;
+    if (n == 7 || n == 11 || n == 13 || n == 14) { out.assign(1, (int)n); return true; }
+    return fastn_factor(n, 16, out);
+}
 static bool fastg_try(xrfthip_plan* P) {  // can the slab's half spectrum live in the LDS of one workgroup, and are both lengths smooth?
     const xrfthip_desc& d = P->d;
     const bool one_d = d.ndim == 1;
@@ -2219,8 +2247,9 @@ static bool fastg_try(xrfthip_plan* P) {  // can the slab's half spectrum live i
     if (lds > kLdsMax - 1024) return false;
     bool gx = false, gy = false;
     std::vector<int> rx, ry;
-    if (n == 1) rx.clear(); else if (factorize(n, rx, gx) || gx) return false;
-    if (!one_d && (factorize(ny, ry, gy) || gy)) return false;
+    (void)gx; (void)gy;
+    if (n == 1) rx.clear(); else if (!fastg_factor(n, rx)) return false;
+    if (!one_d && !fastg_factor(ny, ry)) return false;
     if ((int)rx.size() > kFastGMaxPasses || (int)ry.size() > kFastGMaxPasses) return false;
     for (int r : rx) if (r > 16) return false;
     for (int r : ry) if (r > 16) return false;
@@ -2263,7 +2292,7 @@ static bool fastgy_try(xrfthip_plan* P) {
     std::vector<int> ry;
     long long m = d.ny;  // rows of the tile = length of the passes: ny, or the Bluestein length when a prime factor of ny has no butterfly
     int blue_m = 0;
-    if (factorize(d.ny, ry, gy) || gy) {
+    if (!fastg_factor(d.ny, ry)) {
         for (m = 2 * d.ny - 1;; ++m) {
             long long q = m;
             while (q % 2 == 0) q /= 2;
