@@ -62,6 +62,7 @@ def test_golden_ps2d(golden_dir):
 def test_four_step_paths(monkeypatch):
     """Force the four-step decompositions (normally only used when a sequence does not fit one LDS tile)."""
     import xrft_amd as xa
+    from oracle import xrft_oracle as o
 
     rng = np.random.default_rng(5)
     monkeypatch.setenv("XRFTHIP_X_FOURSTEP_MIN", "2")

@@ -82,7 +82,8 @@ XRFT_MRAD(1200, 10, 10, 12);
 #undef XRFT_MRAD
 // the lengths the host dispatches on: X(N) for every entry
 #define XRFT_M_LATLON(X) X(180) X(192) X(240) X(320) X(360) X(384) X(480) X(500) X(540) X(640) X(720) X(768) X(900) X(960) X(1000) X(1080) X(1200) X(1280) X(1440) X(1500) X(1800) X(1920) X(2000) X(2160)  /* both axes of a slab: the lat/lon and Gaussian-grid lengths + 500, 1000, 1200, 1500, 2000 */
-#define XRFT_M_F32ONLY(X) X(1536) X(1600) X(2400) X(2560) X(2880) X(3000) X(3072) X(3600) X(3840) X(4320)  /* float32 only: a pair of complex128 sequences of this length does not fit the LDS beside a second workgroup */
+#define XRFT_M_F32ONLY(X) X(1536) X(1600) X(2400) X(2560) X(2880) X(3072) X(3840)  /* float32 only: a pair of complex128 sequences of this length does not fit the LDS beside a second workgroup */
+#define XRFT_M_F32_1AX(X) X(3000) X(3600) X(4320)  /* float32, ONE transform axis only: as both axes of a slab these lengths left the table in round 5 -- the lengths-as-data pipeline (fastn.h) runs them within 10 % (profiles/r05_fastn_vs_table.txt: 150 / 162, 162 / 176, 137 / 131 GFFT/s) */
 #define XRFT_M_POW2(X) X(256) X(512) X(1024)
 #define XRFT_M_WIDE32(X) X(1800) X(2000) X(2160)  /* float32: pass 1 also exists with four sequences per workgroup (832 threads at most) */
 #define XRFT_M_YONLY(X) X(100) X(128) X(200) X(400) X(600) X(800)

@@ -61,21 +61,21 @@ XRFT_M_LATLON(XRFT_KI_MRF_) XRFT_M_F32ONLY(XRFT_KI_MRF_)
 #define XRFT_KI_M1D_(NN) XRFT_KI_M1_(double, NN)
 #define XRFT_KI_M1F_(NN) XRFT_KI_M1_(float, NN)
 XRFT_M_LATLON(XRFT_KI_M1D_) XRFT_M_POW2(XRFT_KI_M1D_) XRFT_M_YONLY(XRFT_KI_M1D_) XRFT_KI_M1D_(2048) XRFT_KI_M1D_(4096)
-XRFT_M_LATLON(XRFT_KI_M1F_) XRFT_M_F32ONLY(XRFT_KI_M1F_) XRFT_M_POW2(XRFT_KI_M1F_) XRFT_M_YONLY(XRFT_KI_M1F_) XRFT_KI_M1F_(2048) XRFT_KI_M1F_(4096)
+XRFT_M_LATLON(XRFT_KI_M1F_) XRFT_M_F32ONLY(XRFT_KI_M1F_) XRFT_M_F32_1AX(XRFT_KI_M1F_) XRFT_M_POW2(XRFT_KI_M1F_) XRFT_M_YONLY(XRFT_KI_M1F_) XRFT_KI_M1F_(2048) XRFT_KI_M1F_(4096)
 #undef XRFT_KI_M1_
 #undef XRFT_KI_M1D_
 #undef XRFT_KI_M1F_
 #endif
 #if XRFT_KI_ON(6) || XRFT_KI_ON(7)  // ---- fastn.h: the y-first pipeline with the lengths as data (float32: group 6, float64: group 7); CAP = the largest radix a variant carries
 #define XRFT_KI_N_(TT, CC) \
-    XRFT_KW void fastn_cols_kernel<TT, false, CC>(FastN); XRFT_KW void fastn_cols_kernel<TT, true, CC>(FastN); \
+    XRFT_KW void fastn_cols_kernel<TT, false, CC>(FastN); \
     XRFT_KW void fastn_rows_kernel<TT, 0, false, CC>(FastN); XRFT_KW void fastn_rows_kernel<TT, 1, false, CC>(FastN); XRFT_KW void fastn_rows_kernel<TT, 1, true, CC>(FastN); \
     XRFT_KW void fastn_rows_kernel<TT, 2, false, CC>(FastN); XRFT_KW void fastn_rows_kernel<TT, 2, true, CC>(FastN); XRFT_KW void fastn_rows_kernel<TT, 3, false, CC>(FastN);
 #if XRFT_KI_ON(6)
-XRFT_KI_N_(float, 16) XRFT_KI_N_(float, 20)
+XRFT_KI_N_(float, 16) XRFT_KI_N_(float, 20) XRFT_KW void fastn_cols_kernel<float, true, 16>(FastN);  /* (the chirp-convolution columns: radices up to 16) */
 #endif
 #if XRFT_KI_ON(7)
-XRFT_KI_N_(double, 16)
+XRFT_KI_N_(double, 16) XRFT_KW void fastn_cols_kernel<double, true, 16>(FastN);
 #endif
 #undef XRFT_KI_N_
 #endif

@@ -860,7 +860,7 @@ void set_kernel_attrs_once() {
     SETF((fastg_kernel<float, 0, true>)); SETF((fastg_kernel<float, 1, true>)); SETF((fastg_kernel<double, 0, true>)); SETF((fastg_kernel<double, 1, true>));
     SETF((fastgy_kernel<float, 0, false>)); SETF((fastgy_kernel<float, 1, false>)); SETF((fastgy_kernel<double, 0, false>)); SETF((fastgy_kernel<double, 1, false>));
     SETF((fastgy_kernel<float, 0, true>)); SETF((fastgy_kernel<float, 1, true>)); SETF((fastgy_kernel<double, 0, true>)); SETF((fastgy_kernel<double, 1, true>));
-#define SETN(TT, CC) SETF((fastn_cols_kernel<TT, false, CC>)); SETF((fastn_cols_kernel<TT, true, CC>)); \
+#define SETN(TT, CC) SETF((fastn_cols_kernel<TT, false, CC>)); SETF((fastn_cols_kernel<TT, true, 16>)); \
                      SETF((fastn_rows_kernel<TT, 0, false, CC>)); SETF((fastn_rows_kernel<TT, 1, false, CC>)); SETF((fastn_rows_kernel<TT, 1, true, CC>)); SETF((fastn_rows_kernel<TT, 2, false, CC>)); \
                      SETF((fastn_rows_kernel<TT, 2, true, CC>)); SETF((fastn_rows_kernel<TT, 3, false, CC>))
     SETN(float, 16); SETN(float, 20); SETN(double, 16);
@@ -1569,7 +1569,7 @@ static MGeomRt mgeom(long long n, bool dbl) {
 #undef X_
     }
 #define X_(NN) if (n == NN) return mgeom_t<float, NN>();
-    XRFT_M_LATLON(X_) XRFT_M_F32ONLY(X_)
+    XRFT_M_LATLON(X_) XRFT_M_F32ONLY(X_) XRFT_M_F32_1AX(X_)
 #undef X_
     return mgeom_t<float, 360>();
 }
@@ -1919,7 +1919,7 @@ static void fastn_launch_cols(const xrfthip_plan* P, const FastM& m, hipStream_t
     const size_t lds = P->n_c.lds;
     int maxrad = 0;
     for (int i = 0; i < hg.np; ++i) maxrad = std::max(maxrad, hg.r[i]);
-#define NC_(TT, CC) do { if (P->n_blue_m) { auto k = &fastn_cols_kernel<TT, true, CC>; XRFT_LAUNCH(k, grid, blk, lds, st, n); } \
+#define NC_(TT, CC) do { if (P->n_blue_m) { auto k = &fastn_cols_kernel<TT, true, 16>; XRFT_LAUNCH(k, grid, blk, lds, st, n); } /* (a chirp convolution's radices stop at 16) */ \
                          else { auto k = &fastn_cols_kernel<TT, false, CC>; XRFT_LAUNCH(k, grid, blk, lds, st, n); } } while (0)
     if (P->dbl) NC_(double, 16); else if (maxrad > 16) NC_(float, 20); else NC_(float, 16);
 #undef NC_
@@ -2084,7 +2084,7 @@ static int run_fastm(const xrfthip_plan* P, const void* in, const void* in1, voi
 static bool fastmy_len(long long n, bool dbl) {
 #define X_(NN) if (n == NN) return true;
     XRFT_M_LATLON(X_) XRFT_M_POW2(X_) XRFT_M_YONLY(X_)
-    if (!dbl) { XRFT_M_F32ONLY(X_) }
+    if (!dbl) { XRFT_M_F32ONLY(X_) XRFT_M_F32_1AX(X_) }
 #undef X_
     return n == 2048 || n == 4096;
 }
@@ -2129,7 +2129,7 @@ static int run_fastmy(const xrfthip_plan* P, const void* in, const void* in1, vo
         if (d.out_mode == XRFTHIP_OUT_POWER) MYL_(TT, NN, 1); else if (two) MYL_(TT, NN, 2); else MYL_(TT, NN, 0); } while (0)
 #define XD_(NN) if (d.ny == NN) MY_(double, NN);
 #define XF_(NN) if (d.ny == NN) MY_(float, NN);
-    if (P->dbl) { XRFT_M_LATLON(XD_) XRFT_M_POW2(XD_) XRFT_M_YONLY(XD_) XD_(2048) XD_(4096) } else { XRFT_M_LATLON(XF_) XRFT_M_F32ONLY(XF_) XRFT_M_POW2(XF_) XRFT_M_YONLY(XF_) XF_(2048) XF_(4096) }
+    if (P->dbl) { XRFT_M_LATLON(XD_) XRFT_M_POW2(XD_) XRFT_M_YONLY(XD_) XD_(2048) XD_(4096) } else { XRFT_M_LATLON(XF_) XRFT_M_F32ONLY(XF_) XRFT_M_F32_1AX(XF_) XRFT_M_POW2(XF_) XRFT_M_YONLY(XF_) XF_(2048) XF_(4096) }
 #undef XD_
 #undef XF_
 #undef MY_
@@ -2172,7 +2172,7 @@ static int run_fastmx(const xrfthip_plan* P, const void* in, const void* in1, vo
         if (d.out_mode == XRFTHIP_OUT_POWER) MXL_(TT, NN, 1); else if (two) MXL_(TT, NN, 2); else MXL_(TT, NN, 0); } while (0)
 #define XD_(NN) if (d.nx == NN) MX_(double, NN);
 #define XF_(NN) if (d.nx == NN) MX_(float, NN);
-    if (P->dbl) { XRFT_M_LATLON(XD_) XRFT_M_POW2(XD_) XRFT_M_YONLY(XD_) XD_(2048) XD_(4096) } else { XRFT_M_LATLON(XF_) XRFT_M_F32ONLY(XF_) XRFT_M_POW2(XF_) XRFT_M_YONLY(XF_) XF_(2048) XF_(4096) }
+    if (P->dbl) { XRFT_M_LATLON(XD_) XRFT_M_POW2(XD_) XRFT_M_YONLY(XD_) XD_(2048) XD_(4096) } else { XRFT_M_LATLON(XF_) XRFT_M_F32ONLY(XF_) XRFT_M_F32_1AX(XF_) XRFT_M_POW2(XF_) XRFT_M_YONLY(XF_) XF_(2048) XF_(4096) }
 #undef XD_
 #undef XF_
 #undef MX_
