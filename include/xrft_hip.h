@@ -42,7 +42,7 @@
 extern "C" {
 #endif
 
-#define XRFTHIP_VERSION 102 /* 0.1.2: xrfthip_plan_uses_bluestein, xrfthip_convert (0.1.1: xrfthip_desc.inner, xrfthip_reduce_axis, xrfthip_detrend_inner) */
+#define XRFTHIP_VERSION 103 /* 0.1.3: xrfthip_desc.mid (two transform axes anywhere in a C-contiguous array); 0.1.2: xrfthip_plan_uses_bluestein, xrfthip_convert (0.1.1: xrfthip_desc.inner, xrfthip_reduce_axis, xrfthip_detrend_inner) */
 
 typedef enum xrfthip_status {
     XRFTHIP_OK = 0,
@@ -125,6 +125,13 @@ typedef struct xrfthip_desc {
      * ISHIFT_* / FLIP_*; windows, phases and `scale` as usual.  0 or 1 = the trailing-axes layout.  A descriptor with the
      * struct_size of the version without this field is accepted (inner = 1). */
     int64_t inner;
+    /* ... and `mid` independent elements BETWEEN the two transform axes (ABI 0.1.3): with inner > 1 or mid > 1 the arrays are
+     * [batch][ny][mid][nx][inner] -- batch = the product of the extents in front of the first transform axis, mid of those between the two, inner of those
+     * behind the second -- which is every way two transform axes can lie in a C-contiguous array of any rank (xrft/xrft.py:395-409 transforms any axes where
+     * they lie): dim = ["t", "x"] of a (t, y, x) array is batch = 1, ny = nt, mid = ny, nx = nx, inner = 1.  Same plan as `inner` alone: x where it lies, then y
+     * where it lies, a detrend (one plane over (ny, nx) per (batch, mid, inner) element) first as a pass of its own; no transposed copy.  0 or 1 = none.
+     * Descriptors with the struct_size of the versions without `mid` / without `inner` are accepted. */
+    int64_t mid;
 } xrfthip_desc;
 
 typedef struct xrfthip_plan xrfthip_plan;

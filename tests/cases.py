@@ -1152,6 +1152,48 @@ def run_reduce_axis_cases():
     npt.assert_allclose(da.sum("freq_r").values, da.values.sum(axis=1), rtol=1e-13)
 
 
+def run_mid_layout_cases(dtype="float64", shape=(24, 5, 20)):
+    """Two transform axes that are NOT adjacent -- dim = ["t", "x"] of a (t, y, x) array, (a, t, y, x, i) with dims in front of, between and behind them --
+    where they lie (xrfthip_desc.mid: [batch][n0][mid][n1][inner], a plane detrend per (batch, mid, inner) element first; no transposed copies) against
+    the oracle.  xrft.py:395-409."""
+    rng = np.random.default_rng(98)
+    tol = TOL[dtype]
+    nt, ny, nx = shape
+    ii, jj = np.meshgrid(np.arange(nt), np.arange(nx), indexing="ij")
+    v = (rng.standard_normal(shape) + (0.05 * ii - 0.03 * jj + 2.0)[:, None, :] * (1.0 + np.arange(ny))[None, :, None]).astype(dtype)
+    c = {"t": np.arange(nt) * 0.5 + 1.0, "y": np.arange(ny), "x": np.arange(nx) * 2.0 - 3.0}
+    da, od = pair(v, ("t", "y", "x"), c)
+    worst = 0.0
+
+    def on_inner():
+        d_ = next(reversed(xa.api._plan_cache.values())).describe()
+        return "[inner layout]" in d_ and "[mid %d]" % ny in d_
+
+    for kw in (dict(), dict(detrend="linear", window="hann"), dict(detrend="constant", shift=False, true_phase=False), dict(window="hamming", true_amplitude=False)):
+        worst = max(worst, check(xa.fft(da, dim=["t", "x"], **kw), o.fft(od, dim=["t", "x"], **kw), tol))
+        assert on_inner(), kw
+    for kw in (dict(detrend="linear", window="hann"), dict(scaling="spectrum", shift=False), dict(detrend="constant", window="hann", window_correction=True)):
+        worst = max(worst, check(xa.power_spectrum(da, dim=["t", "x"], **kw), o.power_spectrum(od, dim=["t", "x"], **kw), tol))
+        assert on_inner(), kw
+    worst = max(worst, check(xa.fft(da, dim=["x", "t"], detrend="linear", window="hann"), o.fft(od, dim=["x", "t"], detrend="linear", window="hann"), tol))
+    assert on_inner()
+    c2 = dict(c); c2["t"] = c["t"][::-1].copy()  # a descending coordinate (flip)
+    da2, od2 = pair(v, ("t", "y", "x"), c2)
+    worst = max(worst, check(xa.fft(da2, dim=["t", "x"], window="hann"), o.fft(od2, dim=["t", "x"], window="hann"), tol))
+    z = (v + 1j * rng.standard_normal(shape)).astype("complex128" if dtype == "float64" else "complex64")
+    dz, oz = pair(z, ("t", "y", "x"), c)
+    worst = max(worst, check(xa.fft(dz, dim=["t", "x"], detrend="constant"), o.fft(oz, dim=["t", "x"], detrend="constant"), tol))
+    assert on_inner()
+    # dims in front of, between and behind the two axes
+    w = rng.standard_normal((2, 12, 3, 10, 4)).astype(dtype)
+    c5 = {"a": np.arange(2), "t": np.arange(12) * 1.0, "y": np.arange(3), "x": np.arange(10) * 0.25, "i": np.arange(4)}
+    d5, o5 = pair(w, ("a", "t", "y", "x", "i"), c5)
+    worst = max(worst, check(xa.power_spectrum(d5, dim=["t", "x"], detrend="linear", window="hann"), o.power_spectrum(o5, dim=["t", "x"], detrend="linear", window="hann"), tol))
+    d_ = next(reversed(xa.api._plan_cache.values())).describe()
+    assert "[batch 2][ny 12][mid 3][nx 10][inner 4]" in d_, d_
+    return worst
+
+
 def run_inner_layout_cases(dtype="float64", shape=(24, 20, 6)):
     """Two ADJACENT transform axes that are not the trailing ones -- dim = ["y", "x"] of a (y, x, t) array, (t, y, x, z), the two in
     either order -- through the engine's inner layout (xrfthip_desc.inner: x where it lies, then y, a detrend pass first; no

@@ -679,3 +679,9 @@ def test_two_pass_pipeline_with_the_lengths_as_data(shape, dtype, monkeypatch):
     4 passes (243), a table length on one side (180)."""
     monkeypatch.setenv("XRFTHIP_FASTG", "0")
     cases.run_fastn_cases(shape, dtype)
+
+
+@pytest.mark.parametrize("dtype", ["float64", "float32"])
+def test_two_transform_axes_that_are_not_adjacent(dtype):
+    """xrfthip_desc.mid: dim = ["t", "x"] of (t, y, x) where the axes lie."""
+    cases.run_mid_layout_cases(dtype)

@@ -1056,3 +1056,36 @@ def test_random_fastn_differential(seed):
     from test_random_differential import run_random_fastn
 
     run_random_fastn(seed, lo=200, hi=1600, dtype="float64" if seed % 2 == 0 else "float32")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", ["float32", "float64"])
+def test_two_axes_that_are_not_adjacent_without_copies(dtype):
+    """dim = ["t", "x"] of a (t, y, x) array -- y between the two transform axes -- runs where the axes lie (xrfthip_desc.mid; the reference transforms any
+    axes in place, xrft.py:395-409): after the first call the only device memory a call allocates is its result, and the result has the input's layout."""
+    import xrft_amd as xa
+    from xrft_amd import api
+
+    cases.run_mid_layout_cases(dtype)
+    cases.run_mid_layout_cases(dtype, shape=(360, 12, 250))
+    shape = (256, 48, 240)
+    rng = np.random.default_rng(6)
+    v = (rng.standard_normal(shape) + 0.01 * np.arange(shape[0])[:, None, None]).astype(dtype)
+    c = {"t": np.arange(shape[0]) * 0.5, "y": np.arange(shape[1]) * 2.0, "x": np.arange(shape[2]) * 0.25}
+    x = torch.from_numpy(v).cuda()
+    da = xa.DataArray(x, ("t", "y", "x"), c)
+    kw = dict(dim=["t", "x"], detrend="linear", window="hann")
+    for fn, ofn in ((xa.power_spectrum, o.power_spectrum), (xa.fft, o.fft)):
+        res = fn(da, **kw)
+        assert "[inner layout]" in next(reversed(api._plan_cache.values())).describe()
+        del res
+        torch.cuda.synchronize()
+        torch.cuda.reset_peak_memory_stats()
+        before = torch.cuda.memory_allocated()
+        res = fn(da, **kw)
+        torch.cuda.synchronize()
+        peak = torch.cuda.max_memory_allocated() - before
+        out_bytes = res.data.numel() * res.data.element_size()
+        assert peak <= out_bytes + (1 << 20), (peak, out_bytes)
+        assert res.data.is_contiguous() and tuple(res.dims) == ("freq_t", "y", "freq_x")
+        cases.check(res, ofn(o.OArr(v.astype(np.float64), ("t", "y", "x"), c), **kw), 2e-4 if dtype == "float32" else 1e-10)

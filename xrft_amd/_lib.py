@@ -50,6 +50,7 @@ class Desc(C.Structure):
         ("nx", C.c_int64), ("dtype", C.c_int32), ("out_mode", C.c_int32), ("detrend", C.c_int32),
         ("flags", C.c_uint32), ("scale", C.c_double), ("slabs_per_group", C.c_int32), ("reserved", C.c_int32),
         ("inner", C.c_int64),  # > 1: arrays are [batch][ny][nx][inner], two adjacent transform axes with the independent elements innermost
+        ("mid", C.c_int64),    # > 1: ... and `mid` independent elements between the two transform axes: [batch][ny][mid][nx][inner]
     ]
 
 

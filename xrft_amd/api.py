@@ -552,30 +552,31 @@ def _swap_xy(flags):
 
 
 def _execute_inner(c, da, mode, scale):
-    """Two ADJACENT transform axes that are not the trailing ones, e.g. dim = ["y", "x"] of a (y, x, time) array: the engine's
-    inner layout [batch][n0][n1][inner] (xrfthip_desc.inner) transforms them where they lie, as the reference does
-    (xrft.py:395-409) -- no transposed copy of the input or of the result.  Returns the result in the input's dim order, or None
-    when the call is not of this kind (the caller then takes the transposing path)."""
+    """Two transform axes that are not the trailing pair, wherever they lie -- dim = ["y", "x"] of a (y, x, time) array, dim = ["t", "x"] of a (t, y, x) array:
+    the engine's layout [batch][n0][mid][n1][inner] (xrfthip_desc.inner, .mid: the products of the extents in front of, between and behind the two axes)
+    transforms them where they lie, as the reference does (xrft.py:395-409) -- no transposed copy of the input or of the result.  Returns the result in
+    the input's dim order, or None when the call is not of this kind (the caller then takes the transposing path)."""
     if len(c.dim) != 2 or c.real_dim is not None or mode not in (_lib.OUT_COMPLEX, _lib.OUT_POWER):
         return None
     p, q = da.get_axis_num(c.ydim), da.get_axis_num(c.xdim)
     first, second = min(p, q), max(p, q)
-    if second != first + 1 or second == len(da.dims) - 1:
-        return None
+    if second == first + 1 and second == len(da.dims) - 1:
+        return None  # (the trailing pair: the fused two-axis plans)
     t = _to_device(da.data).contiguous()  # C-contiguous input: no copy
     shape = list(t.shape)
     inner = int(np.prod(shape[second + 1:], dtype=np.int64))
+    mid = int(np.prod(shape[first + 1:second], dtype=np.int64))
     batch = int(np.prod(shape[:first], dtype=np.int64))
     # the extents the composite plan carries in 32 bits (create_inner_plan; the one-axis stages): known limits are checked HERE,
     # so that a BAD_ARG from the library means a bug in the descriptor and is raised, not hidden behind the transposing path
-    if inner < 2 or inner * shape[second] > (1 << 30) or shape[first] * shape[second] * inner > (1 << 31) - 1:
+    if (inner < 2 and mid < 2) or mid * inner * shape[second] > (1 << 30) or shape[first] * shape[second] * inner * mid > (1 << 31) - 1 or (c.detrend and mid > 1 and batch * mid > 65535):
         return None
     flags, win, ph = _flags_tables(c, da)
     if mode == _lib.OUT_POWER:
         ph = {"y": None, "x": None}
     if p > q:  # the array holds (x, y): the plan's first axis is the one that comes first in memory
         flags, win, ph = _swap_xy(flags), {"y": win["x"], "x": win["y"]}, {"y": ph["x"], "x": ph["y"]}
-    kw = dict(ndim=2, batch=batch, ny=shape[first], nx=shape[second], inner=inner, dtype=t.dtype, out_mode=mode, detrend=c.detrend, flags=flags,
+    kw = dict(ndim=2, batch=batch, ny=shape[first], nx=shape[second], inner=inner, mid=mid, dtype=t.dtype, out_mode=mode, detrend=c.detrend, flags=flags,
               scale=float(scale), window_y=win["y"], window_x=win["x"], phase_y=ph["y"], phase_x=ph["x"])
     try:
         plan = _get_plan(**kw)

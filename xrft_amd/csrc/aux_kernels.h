@@ -327,7 +327,7 @@ __global__ void __launch_bounds__(256) table_mul_kernel(const void* in, const C2
 // 16-element inner dimension left half of every wave idle on 64-byte pieces: 0.86 ms for a 268-MB array)
 constexpr int kInnerThreads = 1024;  // (a (y, x, t) array with few inner elements is ONE tile: at most kInnerMaxChunks = 256 workgroups share it, so they are large)
 template <typename T>
-__global__ void __launch_bounds__(kInnerThreads) plane_inner_moments_kernel(const T* __restrict__ in, long long ny, long long nx, long long inner2, double* part, int ib, int xsn) {
+__global__ void __launch_bounds__(kInnerThreads) plane_inner_moments_kernel(const T* __restrict__ in, long long ny, long long nx, long long inner2, double* part, int ib, int xsn, long long mid) {
     XRFT_DYN_SMEM(smem_raw);
     double* red = reinterpret_cast<double*>(smem_raw);  // [xsn][3][ib]
     const int li = threadIdx.x % ib, xs = threadIdx.x / ib;
@@ -337,7 +337,8 @@ __global__ void __launch_bounds__(kInnerThreads) plane_inner_moments_kernel(cons
     double s0 = 0.0, si = 0.0, sj = 0.0;
     if (live) {
         for (long long i = blockIdx.y; i < ny; i += gridDim.y) {
-            const T* row = in + ((b * ny + i) * nx) * inner2 + i2;
+            // (mid > 1: [batch / mid][ny][mid][nx][inner2] -- the independent elements between the two axes; element b = (outer, m))
+            const T* row = in + ((((b / mid) * ny + i) * mid + b % mid) * nx) * inner2 + i2;
             // four independent loads per trip (one load in flight per thread ran the pass at a fifth of the copy rate); the four partial
             // sums are combined in a fixed order
             double r0[4] = {0.0, 0.0, 0.0, 0.0}, rj[4] = {0.0, 0.0, 0.0, 0.0};
@@ -386,7 +387,7 @@ static __global__ void plane_inner_finalize_kernel(const double* part, double* c
 // index: read from memory per element they were six times the data), a thread's position (j, i2) advances by additions (no division per
 // element), four loads in flight per thread.  lds_coef = 0: inner2 too large for the LDS, the coefficients come from memory.
 template <typename T>
-__global__ void __launch_bounds__(256) plane_inner_apply_kernel(const T* __restrict__ in, T* __restrict__ out, const double* __restrict__ coef, long long batch, long long ny, long long nx, long long inner2, int lds_coef) {
+__global__ void __launch_bounds__(256) plane_inner_apply_kernel(const T* __restrict__ in, T* __restrict__ out, const double* __restrict__ coef, long long batch, long long ny, long long nx, long long inner2, int lds_coef, long long mid) {
     XRFT_DYN_SMEM(smem_raw);
     double* cl = reinterpret_cast<double*>(smem_raw);  // [inner2][3]
     const long long rowlen = nx * inner2;  // (beyond 2^32 for a long inner extent: detrend along time of a (1000, 4096, 2048) array)
@@ -395,9 +396,10 @@ __global__ void __launch_bounds__(256) plane_inner_apply_kernel(const T* __restr
     const long long r_lo = (long long)blockIdx.x * per, r_hi = r_lo + per < rows ? r_lo + per : rows;
     const unsigned dj = 256u / in2, di = 256u % in2;  // a step of 256 elements in (j, i2)
     long long bcur = -1;
-    for (long long r = r_lo; r < r_hi; ++r) {
-        const long long b = r / ny;
-        const double fi = (double)(r - b * ny);
+    for (long long r = r_lo; r < r_hi; ++r) {  // memory rows: (outer, i, m) with mid > 1 (batch counts (outer, m) pairs), else (b, i)
+        const long long rq = r / mid, m_ = r - rq * mid, bo = rq / ny;
+        const long long b = bo * mid + m_;
+        const double fi = (double)(rq - bo * ny);
         const double* cb = coef + b * inner2 * 3;
         if (lds_coef && b != bcur) {
             __syncthreads();  // (the previous batch element's rows are done with the table)

@@ -389,7 +389,8 @@ struct xrfthip_plan {
     // xrfthip_desc.inner > 1: [batch][ny][nx][inner], two adjacent transform axes with the independent elements innermost.  A
     // composite of two in-place one-axis plans (XRFTHIP_AXIS_Y): sub_x transforms x of [batch ny][nx][inner], sub_y transforms y of
     // [batch][ny][nx inner]; a detrend runs first as a pass of its own (plane_inner_* kernels).  No transposed copy anywhere.
-    long long inner = 1;
+    long long inner = 1, mid = 1;
+    bool sub_x_1d = false;  // the x stage is a 1-D plan (nothing behind x: inner = 1), its axis is 1
     xrfthip_plan* sub_x = nullptr;
     xrfthip_plan* sub_y = nullptr;
     size_t off_sub = 0, off_det = 0, off_mid = 0, off_dws = 0;
@@ -2704,45 +2705,52 @@ int xrfthip_last_hip_error(void) { return g_last_hip_error; }
 
 static size_t detrend_inner_ws(bool cplx, long long batch, long long inner);
 static int run_detrend_inner(int32_t dtype, int32_t ndim, long long batch, long long ny, long long nx, long long inner, int32_t kind, const void* in, void* out,
-                             char* ws, hipStream_t st);
+                             char* ws, hipStream_t st, long long mid = 1);
 
 // composite plan for xrfthip_desc.inner > 1 (see xrfthip_plan::inner)
 static int create_inner_plan(xrfthip_plan** plan, const xrfthip_desc& d) {
     const uint32_t ok = XRFTHIP_SHIFT_Y | XRFTHIP_SHIFT_X | XRFTHIP_ISHIFT_Y | XRFTHIP_ISHIFT_X | XRFTHIP_FLIP_Y | XRFTHIP_FLIP_X;
     if (d.ndim != 2 || (d.flags & ~ok) || (d.out_mode != XRFTHIP_OUT_COMPLEX && d.out_mode != XRFTHIP_OUT_POWER)) return XRFTHIP_BAD_ARG;
-    if (d.inner > (1LL << 30) || d.nx * d.inner > (1LL << 30)) return XRFTHIP_BAD_ARG;
+    if (d.inner > (1LL << 30) || d.mid > (1LL << 30) || d.nx * d.inner > (1LL << 30) || d.mid * d.nx * d.inner > (1LL << 30) || d.batch * d.mid > (1LL << 40)) return XRFTHIP_BAD_ARG;
     xrfthip_plan* P = new (std::nothrow) xrfthip_plan();
     if (!P) return XRFTHIP_ALLOC_FAILED;
     P->d = d;
-    P->inner = d.inner;
+    P->inner = d.inner; P->mid = d.mid;
     P->dbl = d.dtype == XRFTHIP_F64 || d.dtype == XRFTHIP_C128;
     P->cplx_in = d.dtype >= XRFTHIP_C64;
     P->rsize = P->dbl ? 8 : 4;
     P->csize = 2 * P->rsize;
     P->nx_out = d.nx;
     xrfthip_desc dx = d, dy = d;
-    dx.inner = dy.inner = 1;
+    dx.inner = dy.inner = 1; dx.mid = dy.mid = 1;
     dx.detrend = dy.detrend = XRFTHIP_DETREND_NONE;
-    // x where it lies: [batch ny][nx][inner], the per-axis flags of x become the y flags of the one-axis plan
-    dx.batch = d.batch * d.ny; dx.ny = d.nx; dx.nx = d.inner;
     dx.out_mode = XRFTHIP_OUT_COMPLEX; dx.scale = 1.0;
-    dx.flags = XRFTHIP_AXIS_Y | ((d.flags & XRFTHIP_SHIFT_X) ? XRFTHIP_SHIFT_Y : 0u) | ((d.flags & XRFTHIP_ISHIFT_X) ? XRFTHIP_ISHIFT_Y : 0u) |
-               ((d.flags & XRFTHIP_FLIP_X) ? XRFTHIP_FLIP_Y : 0u);
-    // then y: [batch][ny][nx inner], complex input, the requested result and scale
-    dy.batch = d.batch; dy.ny = d.ny; dy.nx = d.nx * d.inner;
+    if (d.inner > 1) {
+        // x where it lies: [batch ny mid][nx][inner], the per-axis flags of x become the y flags of the one-axis plan
+        dx.batch = d.batch * d.ny * d.mid; dx.ny = d.nx; dx.nx = d.inner;
+        dx.flags = XRFTHIP_AXIS_Y | ((d.flags & XRFTHIP_SHIFT_X) ? XRFTHIP_SHIFT_Y : 0u) | ((d.flags & XRFTHIP_ISHIFT_X) ? XRFTHIP_ISHIFT_Y : 0u) |
+                   ((d.flags & XRFTHIP_FLIP_X) ? XRFTHIP_FLIP_Y : 0u);
+    } else {
+        // nothing behind x (two transform axes with `mid` elements between them, x the contiguous one): a 1-D plan over the rows [batch ny mid][nx]
+        P->sub_x_1d = true;
+        dx.ndim = 1; dx.batch = d.batch * d.ny * d.mid; dx.ny = 1; dx.nx = d.nx;
+        dx.flags = d.flags & (XRFTHIP_SHIFT_X | XRFTHIP_ISHIFT_X | XRFTHIP_FLIP_X);
+    }
+    // then y: [batch][ny][mid nx inner], complex input, the requested result and scale
+    dy.batch = d.batch; dy.ny = d.ny; dy.nx = d.mid * d.nx * d.inner;
     dy.dtype = P->dbl ? XRFTHIP_C128 : XRFTHIP_C64;
     dy.flags = XRFTHIP_AXIS_Y | (d.flags & (XRFTHIP_SHIFT_Y | XRFTHIP_ISHIFT_Y | XRFTHIP_FLIP_Y));
     int rc = xrfthip_plan_create(&P->sub_x, &dx);
     if (!rc) rc = xrfthip_plan_create(&P->sub_y, &dy);
     if (rc) { delete P; return rc; }
     auto al = [](size_t v) { return (v + 255) & ~(size_t)255; };
-    const size_t pts = (size_t)d.batch * d.ny * d.nx * d.inner;
+    const size_t pts = (size_t)d.batch * d.ny * d.mid * d.nx * d.inner;
     size_t off = 0;
     P->off_sub = off; off = al(off + std::max(P->sub_x->ws_bytes, P->sub_y->ws_bytes));
     P->off_mid = off; off = al(off + pts * P->csize);                                        // the x-transformed field (complex)
     if (d.detrend) {
         P->off_det = off; off = al(off + pts * (P->cplx_in ? P->csize : P->rsize));         // the detrended copy of the input
-        P->off_dws = off; off = al(off + detrend_inner_ws(P->cplx_in, d.batch, d.inner));
+        P->off_dws = off; off = al(off + detrend_inner_ws(P->cplx_in, d.batch * d.mid, d.inner));
     }
     P->ws_bytes = off;
     *plan = P;
@@ -2753,7 +2761,7 @@ static int run_inner_plan(const xrfthip_plan* P, const void* in, void* out, char
     const xrfthip_desc& d = P->d;
     const void* cur = in;
     if (d.detrend) {
-        int rc = run_detrend_inner(d.dtype, 2, d.batch, d.ny, d.nx, d.inner, d.detrend, in, ws + P->off_det, ws + P->off_dws, st);
+        int rc = run_detrend_inner(d.dtype, 2, d.batch * d.mid, d.ny, d.nx, d.inner, d.detrend, in, ws + P->off_det, ws + P->off_dws, st, d.mid);
         if (rc) return rc;
         cur = ws + P->off_det;
     }
@@ -2764,13 +2772,14 @@ static int run_inner_plan(const xrfthip_plan* P, const void* in, void* out, char
 
 int xrfthip_plan_create(xrfthip_plan** plan, const xrfthip_desc* desc) {
     // (a descriptor of the version before `inner` was appended is accepted: inner = 1)
-    constexpr uint32_t kOldDescSize = (uint32_t)offsetof(xrfthip_desc, inner);
-    if (!plan || !desc || (desc->struct_size != sizeof(xrfthip_desc) && desc->struct_size != kOldDescSize)) return XRFTHIP_BAD_ARG;
+    constexpr uint32_t kOldDescSize = (uint32_t)offsetof(xrfthip_desc, inner), kOldDescSize2 = (uint32_t)offsetof(xrfthip_desc, mid);
+    if (!plan || !desc || (desc->struct_size != sizeof(xrfthip_desc) && desc->struct_size != kOldDescSize && desc->struct_size != kOldDescSize2)) return XRFTHIP_BAD_ARG;
     xrfthip_desc dcopy{};
     memcpy(&dcopy, desc, desc->struct_size);
     dcopy.struct_size = sizeof(xrfthip_desc);
-    if (dcopy.inner < 0) return XRFTHIP_BAD_ARG;
+    if (dcopy.inner < 0 || dcopy.mid < 0) return XRFTHIP_BAD_ARG;
     if (dcopy.inner == 0) dcopy.inner = 1;
+    if (dcopy.mid == 0) dcopy.mid = 1;
     const xrfthip_desc& d = dcopy;
     if (d.ndim != 1 && d.ndim != 2) return XRFTHIP_BAD_ARG;
     if (d.batch < 0 || d.nx < 1 || d.ny < 1 || (d.ndim == 1 && d.ny != 1)) return XRFTHIP_BAD_ARG;
@@ -2792,7 +2801,7 @@ int xrfthip_plan_create(xrfthip_plan** plan, const xrfthip_desc* desc) {
     if ((d.flags & XRFTHIP_AXIS_Y) && (d.ndim != 2 || (d.flags & XRFTHIP_FLIP0_X) || (d.flags & (XRFTHIP_SHIFT_X | XRFTHIP_ISHIFT_X | XRFTHIP_FLIP_X | XRFTHIP_HALF_X | XRFTHIP_REALDIM_X2 |
                                                                     XRFTHIP_ISO | XRFTHIP_NO_SPECTRUM_OUT | XRFTHIP_C2R_X)))) return XRFTHIP_BAD_ARG;  // (PHASE_IN: only where fastgy takes the plan, below)
 
-    if (d.inner > 1) return create_inner_plan(plan, d);
+    if (d.inner > 1 || d.mid > 1) return create_inner_plan(plan, d);
 
     xrfthip_plan* P = new (std::nothrow) xrfthip_plan();
     if (!P) return XRFTHIP_ALLOC_FAILED;
@@ -3038,7 +3047,7 @@ int xrfthip_plan_destroy(xrfthip_plan* plan) {
 int xrfthip_plan_set_window(xrfthip_plan* plan, int axis, const double* h_window, int64_t n) {
     if (!plan || axis < 0 || axis > 1) return XRFTHIP_BAD_ARG;
     if (h_window && n != (axis == 0 ? plan->d.ny : plan->d.nx)) return XRFTHIP_BAD_ARG;
-    if (plan->inner > 1) return xrfthip_plan_set_window(axis == 0 ? plan->sub_y : plan->sub_x, 0, h_window, n);  // (each one-axis plan transforms its "y")
+    if (plan->sub_x) return xrfthip_plan_set_window(axis == 0 ? plan->sub_y : plan->sub_x, (axis == 1 && plan->sub_x_1d) ? 1 : 0, h_window, n);  // (each one-axis plan transforms its "y"; a 1-D x stage its x)
     if (axis == 0) plan->host_win_y.assign(h_window ? h_window : nullptr, h_window ? h_window + n : nullptr);
     else plan->host_win_x.assign(h_window ? h_window : nullptr, h_window ? h_window + n : nullptr);
     int rc = upload_real_table(plan, plan->win[axis], h_window, n, 0);
@@ -3051,7 +3060,7 @@ int xrfthip_plan_set_phase(xrfthip_plan* plan, int axis, const double* h_phase, 
     // an input phase of a c2r transform covers the stored half of the x axis only
     const int64_t want = axis == 0 ? plan->d.ny : ((plan->d.flags & XRFTHIP_C2R_X) ? plan->d.nx / 2 + 1 : plan->d.nx);
     if (h_phase && n != want) return XRFTHIP_BAD_ARG;
-    if (plan->inner > 1) return xrfthip_plan_set_phase(axis == 0 ? plan->sub_y : plan->sub_x, 0, h_phase, n);
+    if (plan->sub_x) return xrfthip_plan_set_phase(axis == 0 ? plan->sub_y : plan->sub_x, (axis == 1 && plan->sub_x_1d) ? 1 : 0, h_phase, n);
     plan->host_phase[axis].assign(h_phase ? h_phase : nullptr, h_phase ? h_phase + 2 * n : nullptr);
     int rc = upload_real_table(plan, plan->phase[axis], h_phase, n, 1);
     if (!rc) rc = finalize_plan(plan);  // (a non-trivial phase can take an isotropic cross spectrum off the specialised path: new layout)
@@ -3093,7 +3102,7 @@ int xrfthip_plan_set_binmap(xrfthip_plan* plan, const int32_t* h_binmap, int64_t
 
 int xrfthip_plan_set_profiling(xrfthip_plan* plan, int enable) {
     if (!plan) return XRFTHIP_BAD_ARG;
-    if (plan->inner > 1) { const int rc = xrfthip_plan_set_profiling(plan->sub_x, enable); return rc ? rc : xrfthip_plan_set_profiling(plan->sub_y, enable); }
+    if (plan->sub_x) { const int rc = xrfthip_plan_set_profiling(plan->sub_x, enable); return rc ? rc : xrfthip_plan_set_profiling(plan->sub_y, enable); }
     plan->prof_clear();
     plan->prof_recs.reserve(1 << 16);  // prof_begin hands out pointers into this vector
     plan->prof = enable != 0;
@@ -3102,7 +3111,7 @@ int xrfthip_plan_set_profiling(xrfthip_plan* plan, int enable) {
 
 int xrfthip_plan_profile_read(xrfthip_plan* plan, char* buf, size_t buflen) {
     if (!plan || !buf || !buflen) return XRFTHIP_BAD_ARG;
-    if (plan->inner > 1) {  // the two one-axis plans' records, one after the other
+    if (plan->sub_x) {  // the two one-axis plans' records, one after the other
         const int n1 = xrfthip_plan_profile_read(plan->sub_x, buf, buflen);
         if (n1 < 0) return n1;
         const int n2 = xrfthip_plan_profile_read(plan->sub_y, buf + n1, buflen - (size_t)n1);
@@ -3128,7 +3137,7 @@ int xrfthip_plan_profile_read(xrfthip_plan* plan, char* buf, size_t buflen) {
 
 int xrfthip_plan_uses_bluestein(const xrfthip_plan* plan) {
     if (!plan) return 0;
-    if (plan->inner > 1) return xrfthip_plan_uses_bluestein(plan->sub_x) || xrfthip_plan_uses_bluestein(plan->sub_y);
+    if (plan->sub_x) return xrfthip_plan_uses_bluestein(plan->sub_x) || xrfthip_plan_uses_bluestein(plan->sub_y);
     if (plan->fastgy) return plan->gy_blue_m > 0;
     if (plan->fastn) return plan->n_blue_m > 0;
     if (plan->fastg || plan->fasts || plan->fastr || plan->fastmx || plan->fastmy || plan->fastm || plan->fast1d || plan->fast4096) return 0;  // (the generic passes of such a plan never run)
@@ -3146,9 +3155,9 @@ int xrfthip_plan_describe(const xrfthip_plan* plan, char* buf, size_t buflen) {
     if (!plan || !buf || !buflen) return XRFTHIP_BAD_ARG;
     std::string s;
     const xrfthip_desc& d = plan->d;
-    if (plan->inner > 1) {
-        appendf(s, "xrfthip plan: [batch %lld][ny %lld][nx %lld][inner %lld] dtype=%d mode=%d detrend=%d flags=0x%x ws=%zuB\n  [inner layout] no transposed copy: %sx where it lies, then y\n",
-                (long long)d.batch, (long long)d.ny, (long long)d.nx, (long long)plan->inner, d.dtype, d.out_mode, d.detrend, d.flags, plan->ws_bytes,
+    if (plan->sub_x) {
+        appendf(s, "xrfthip plan: [batch %lld][ny %lld][mid %lld][nx %lld][inner %lld] dtype=%d mode=%d detrend=%d flags=0x%x ws=%zuB\n  [inner layout] no transposed copy: %sx where it lies, then y\n",
+                (long long)d.batch, (long long)d.ny, (long long)plan->mid, (long long)d.nx, (long long)plan->inner, d.dtype, d.out_mode, d.detrend, d.flags, plan->ws_bytes,
                 d.detrend ? "detrend pass (plane per (batch, inner) element), " : "");
         for (const xrfthip_plan* sp : {plan->sub_x, plan->sub_y}) {
             std::vector<char> tmp(4096);
@@ -3288,7 +3297,7 @@ int xrfthip_exec(const xrfthip_plan* plan, const void* d_in0, const void* d_in1,
     if (cross && !d_in1) return XRFTHIP_BAD_ARG;
     if (!d_out && !(d.flags & XRFTHIP_NO_SPECTRUM_OUT)) return XRFTHIP_BAD_ARG;
     if (iso && (!d_iso || !P->binmap.p)) return d_iso ? XRFTHIP_MISSING_TABLE : XRFTHIP_BAD_ARG;
-    if (P->inner > 1) {
+    if (P->sub_x) {
         if (ws_bytes < P->ws_bytes || !d_workspace) return XRFTHIP_WORKSPACE_TOO_SMALL;
         return d.batch == 0 ? XRFTHIP_OK : run_inner_plan(P, d_in0, d_out, (char*)d_workspace, (hipStream_t)stream);
     }
@@ -3492,7 +3501,7 @@ static size_t detrend_inner_ws(bool cplx, long long batch, long long inner) {
     return (((size_t)std::max<long long>(batch, 1) * i2 * 3 * sizeof(double) * ((size_t)inner_chunk_cap(batch, (long long)i2) + 1)) + 255) & ~(size_t)255;  // partial sums of <= cap chunks + the coefficients
 }
 static int run_detrend_inner(int32_t dtype, int32_t ndim, long long batch, long long ny, long long nx, long long inner, int32_t kind, const void* in, void* out,
-                             char* ws, hipStream_t st) {
+                             char* ws, hipStream_t st, long long mid) {  // (batch counts (outer, mid) pairs: [batch / mid][ny][mid][nx][inner])
     (void)ndim;
     const bool dbl = dtype == XRFTHIP_F64 || dtype == XRFTHIP_C128, cplx = dtype >= XRFTHIP_C64;
     const long long i2 = inner * (cplx ? 2 : 1);
@@ -3503,9 +3512,10 @@ static int run_detrend_inner(int32_t dtype, int32_t ndim, long long batch, long 
         const long long bc = std::min<long long>(65535, batch - b0);
         const int ib = (int)std::min<long long>(i2, kInnerThreads), xsn = kInnerThreads / ib;  // lanes across the inner index x column slots
         const dim3 grid((unsigned)((i2 + ib - 1) / ib), (unsigned)nch, (unsigned)bc), block(kInnerThreads);  // (tiles of the inner index on grid.x: no 65535 limit)
+        if (mid > 1 && batch > 65535) return XRFTHIP_BAD_ARG;  // (one launch covers all (outer, mid) pairs: the element offsets are not a multiple of a batch block)
         const size_t lds = (size_t)xsn * 3 * ib * sizeof(double), eoff = (size_t)b0 * ny * nx * i2;
-        if (dbl) { auto k = &plane_inner_moments_kernel<double>; XRFT_LAUNCH(k, grid, block, lds, st, (const double*)in + eoff, (long long)ny, (long long)nx, i2, part + (size_t)b0 * nch * i2 * 3, ib, xsn); }
-        else { auto k = &plane_inner_moments_kernel<float>; XRFT_LAUNCH(k, grid, block, lds, st, (const float*)in + eoff, (long long)ny, (long long)nx, i2, part + (size_t)b0 * nch * i2 * 3, ib, xsn); }
+        if (dbl) { auto k = &plane_inner_moments_kernel<double>; XRFT_LAUNCH(k, grid, block, lds, st, (const double*)in + eoff, (long long)ny, (long long)nx, i2, part + (size_t)b0 * nch * i2 * 3, ib, xsn, mid); }
+        else { auto k = &plane_inner_moments_kernel<float>; XRFT_LAUNCH(k, grid, block, lds, st, (const float*)in + eoff, (long long)ny, (long long)nx, i2, part + (size_t)b0 * nch * i2 * 3, ib, xsn, mid); }
     }
     {
         auto k = &plane_inner_finalize_kernel;
@@ -3514,8 +3524,8 @@ static int run_detrend_inner(int32_t dtype, int32_t ndim, long long batch, long 
     const dim3 grid((unsigned)std::min<long long>(batch * ny, 8LL * kCUs * 4)), block(256);
     const size_t clds = (size_t)i2 * 3 * sizeof(double);  // the coefficients of one batch element in LDS (four workgroups per CU at 40 KB)
     const int lds_coef = clds <= 40 * 1024 ? 1 : 0;
-    if (dbl) { auto k = &plane_inner_apply_kernel<double>; XRFT_LAUNCH(k, grid, block, lds_coef ? clds : 0, st, (const double*)in, (double*)out, (const double*)coef, (long long)batch, (long long)ny, (long long)nx, i2, lds_coef); }
-    else { auto k = &plane_inner_apply_kernel<float>; XRFT_LAUNCH(k, grid, block, lds_coef ? clds : 0, st, (const float*)in, (float*)out, (const double*)coef, (long long)batch, (long long)ny, (long long)nx, i2, lds_coef); }
+    if (dbl) { auto k = &plane_inner_apply_kernel<double>; XRFT_LAUNCH(k, grid, block, lds_coef ? clds : 0, st, (const double*)in, (double*)out, (const double*)coef, (long long)batch, (long long)ny, (long long)nx, i2, lds_coef, mid); }
+    else { auto k = &plane_inner_apply_kernel<float>; XRFT_LAUNCH(k, grid, block, lds_coef ? clds : 0, st, (const float*)in, (float*)out, (const double*)coef, (long long)batch, (long long)ny, (long long)nx, i2, lds_coef, mid); }
     HIP_TRY(hipGetLastError());
     return XRFTHIP_OK;
 }

@@ -37,7 +37,7 @@ class SpectralPlan:
 
     def __init__(self, ndim, batch, ny, nx, dtype, out_mode=_lib.OUT_COMPLEX, detrend=_lib.DETREND_NONE, flags=0,
                  scale=1.0, window_y=None, window_x=None, phase_y=None, phase_x=None, binmap=None, nbins=0,
-                 slabs_per_group=0, inner=1):
+                 slabs_per_group=0, inner=1, mid=1):
         self._dll = _lib.load()
         self._h = C.c_void_p(0)
         if dtype not in _DTYPES:
@@ -47,8 +47,9 @@ class SpectralPlan:
         self.nx_out = self.nx // 2 + 1 if (flags & _lib.HALF_X) else self.nx
         self.nbins = int(nbins)
         self.inner = max(int(inner), 1)  # > 1: (batch, ny, nx, inner) arrays, the transform axes are not the trailing ones
+        self.mid = max(int(mid), 1)      # > 1: (batch, ny, mid, nx, inner): independent elements between the two transform axes
         d = _lib.Desc(C.sizeof(_lib.Desc), self.ndim, self.batch, self.ny, self.nx, _DTYPES[dtype], self.out_mode,
-                      int(detrend), self.flags, float(scale), int(slabs_per_group), 0, self.inner)
+                      int(detrend), self.flags, float(scale), int(slabs_per_group), 0, self.inner, self.mid)
         _lib.check(self._dll.xrfthip_plan_create(C.byref(self._h), C.byref(d)))
         for axis, w in ((0, window_y), (1, window_x)):
             if w is not None:
@@ -110,7 +111,7 @@ class SpectralPlan:
         Returns (out, iso); either may be None depending on the flags."""
         dev = in0.device
         nx_in = self.nx // 2 + 1 if (self.flags & _lib.C2R_X) else self.nx
-        if in0.dtype != self.dtype or not in0.is_contiguous() or in0.numel() != self.batch * self.ny * nx_in * self.inner:
+        if in0.dtype != self.dtype or not in0.is_contiguous() or in0.numel() != self.batch * self.ny * nx_in * self.inner * self.mid:
             raise ValueError("in0 does not match the plan (dtype / contiguity / size)")
         if self.out_mode in (_lib.OUT_CROSS, _lib.OUT_PHASE):
             if in1 is None or in1.dtype != self.dtype or not in1.is_contiguous() or in1.numel() != in0.numel():
@@ -118,6 +119,8 @@ class SpectralPlan:
         want_out = not (self.flags & _lib.NO_SPECTRUM_OUT)
         if want_out and out is None:
             shape = (self.batch, self.ny, self.nx_out) + ((self.inner,) if self.inner > 1 else ())
+            if self.mid > 1:
+                shape = (self.batch, self.ny, self.mid, self.nx_out, self.inner)
             out = torch.empty(shape, dtype=self.out_dtype(), device=dev)
         if self.flags & _lib.ISO and iso is None:
             iso = torch.empty((self.batch, self.nbins), device=dev,
