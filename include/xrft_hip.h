@@ -164,6 +164,25 @@ int xrfthip_plan_profile_read(xrfthip_plan* plan, char* buf, size_t buflen);
  * callers that hold small bins to 1e-3 run such plans in float64 (xrft_amd/engine.py does, with xrfthip_convert at both ends). */
 int xrfthip_plan_uses_bluestein(const xrfthip_plan* plan);
 
+/* Which kernel family serves the plan (decided when it is created; what xrfthip_plan_describe prints, as numbers -- callers that compose plans decide on
+ * these, not on the text): *kind = xrfthip_kernel_kind, *per_workgroup = the independent sequences (columns, rows or slabs) one workgroup transforms
+ * (0 where that is not a property of the plan).  ABI 0.1.3. */
+typedef enum xrfthip_kernel_kind {
+    XRFTHIP_K_GENERIC = 0,    /* tile_fft.h passes */
+    XRFTHIP_K_FASTY = 1,      /* two-pass float32 powers of two (and the four-step 1-D form) */
+    XRFTHIP_K_FASTM = 2,      /* two-pass table lengths */
+    XRFTHIP_K_FASTN = 3,      /* two-pass, lengths as data (either pass may be a table kernel) */
+    XRFTHIP_K_FASTM_Y = 4,    /* one axis, not the contiguous one, table lengths */
+    XRFTHIP_K_FASTM_X = 5,    /* rows, table lengths */
+    XRFTHIP_K_FASTG_Y = 6,    /* one axis, not the contiguous one, lengths as data */
+    XRFTHIP_K_FASTG_ROWS = 7, /* groups of rows, lengths as data */
+    XRFTHIP_K_FASTG = 8,      /* one pass over a small slab, lengths as data */
+    XRFTHIP_K_FASTS = 9,      /* one pass over a small float32 slab in registers */
+    XRFTHIP_K_FASTR = 10,     /* one pass over a long float32 row in registers */
+    XRFTHIP_K_COMPOSITE = 11  /* xrfthip_desc.inner / .mid: two one-axis plans */
+} xrfthip_kernel_kind;
+int xrfthip_plan_kernel_info(const xrfthip_plan* plan, int32_t* kind, int32_t* per_workgroup);
+
 size_t xrfthip_workspace_bytes(const xrfthip_plan* plan);
 /* human-readable pass list (kernel, tile, grid, LDS) for logs and DESIGN.md; returns bytes written */
 int xrfthip_plan_describe(const xrfthip_plan* plan, char* buf, size_t buflen);

@@ -22,6 +22,8 @@ BAD_ARG = -1  # xrfthip_status
 UNSUPPORTED_LENGTH = -2
 AXIS_Y = 0x2000  # transform y of [batch][ny][nx] in place (a middle or first axis of the array), no transposed copy
 FLIP0_Y, FLIP0_X = 0x4000, 0x8000  # cross spectra: flip field 0 (FLIP_Y / FLIP_X then flip field 1)
+# xrfthip_kernel_kind (xrfthip_plan_kernel_info)
+K_GENERIC, K_FASTY, K_FASTM, K_FASTN, K_FASTM_Y, K_FASTM_X, K_FASTG_Y, K_FASTG_ROWS, K_FASTG, K_FASTS, K_FASTR, K_COMPOSITE = range(12)
 
 EXPORTS = [
     "xrfthip_version", "xrfthip_strerror", "xrfthip_last_hip_error", "xrfthip_plan_create",
@@ -29,7 +31,7 @@ EXPORTS = [
     "xrfthip_plan_set_profiling", "xrfthip_plan_profile_read", "xrfthip_workspace_bytes", "xrfthip_plan_describe", "xrfthip_exec", "xrfthip_detrend_workspace_bytes",
     "xrfthip_detrend", "xrfthip_detrend3", "xrfthip_spectrum_tail", "xrfthip_spectrum_tail_axis", "xrfthip_gather_axis", "xrfthip_isotropize",
     "xrfthip_isotropize_workspace_bytes", "xrfthip_table_mul", "xrfthip_reduce_axis", "xrfthip_detrend_inner_workspace_bytes", "xrfthip_detrend_inner", "xrfthip_angle",
-    "xrfthip_plan_uses_bluestein", "xrfthip_convert",
+    "xrfthip_plan_uses_bluestein", "xrfthip_convert", "xrfthip_plan_kernel_info",
 ]
 
 
@@ -82,6 +84,7 @@ def _bind(dll):
     dll.xrfthip_reduce_axis.argtypes = [i32, i64, i64, i64, vp, vp, C.c_double, vp]
     dll.xrfthip_angle.argtypes = [i32, i64, vp, vp, vp]
     dll.xrfthip_plan_uses_bluestein.argtypes = [vp]
+    dll.xrfthip_plan_kernel_info.argtypes = [vp, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
     dll.xrfthip_convert.argtypes = [i32, i32, i64, vp, vp, vp]
     dll.xrfthip_detrend_inner_workspace_bytes.restype = sz
     dll.xrfthip_detrend_inner_workspace_bytes.argtypes = [i32, i64, i64]

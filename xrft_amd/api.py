@@ -268,11 +268,15 @@ def _get_plan(binmap_key=None, **kw):
     return p
 
 
+_TWO_STAGE = {}  # _ifft_two_stages: (shape, flags, tables) -> False | (y-stage plan, x-stage plan)
+
+
 def clear_plan_cache():
     """Drop every cached plan (device tables) and the shared scratch buffers."""
     with _plan_lock:
         _plan_cache.clear()
         _BLUE_TABLES.clear()
+        _TWO_STAGE.clear()
     engine.clear_workspaces()
 
 
@@ -1148,37 +1152,39 @@ def _ifft_two_stages(t, batch, ny, nx, flags, scale, ph):
         return None
     fy = _lib.AXIS_Y | _lib.INVERSE | (flags & (_lib.ISHIFT_Y | _lib.SHIFT_Y)) | (_lib.PHASE_IN if ph["y"] is not None else 0)
     fx = _lib.INVERSE | (flags & (_lib.ISHIFT_X | _lib.SHIFT_X | _lib.C2R_X)) | (_lib.PHASE_IN if ph["x"] is not None else 0)
-    try:
-        whole = _get_plan(ndim=2, batch=batch, ny=ny, nx=nx, dtype=t.dtype, out_mode=_lib.OUT_COMPLEX, detrend=_lib.DETREND_NONE, flags=flags, scale=scale,
-                          window_y=None, window_x=None, phase_y=ph["y"], phase_x=ph["x"])
-        dec = getattr(whole, "_two_stage", None)  # (decided once per cached two-axis plan: describe() and the stage plans cost a call their host time)
+    # the decision is taken once per shape / flag / phase-table set and remembered here (not as an attribute hung on a cached plan)
+    dkey = (batch, ny, nx, str(t.dtype), int(flags), float(scale), _akey(ph["y"]), _akey(ph["x"]), engine.bluestein_in_float64())
+    with _plan_lock:
+        dec = _TWO_STAGE.get(dkey)
+    if dec is False:
+        return None
+    if dec is None:
+        try:
+            py = _get_plan(ndim=2, batch=batch, ny=ny, nx=nxs, dtype=t.dtype, out_mode=_lib.OUT_COMPLEX, detrend=_lib.DETREND_NONE, flags=fy, scale=1.0 / float(ny),
+                           window_y=None, window_x=None, phase_y=ph["y"], phase_x=None)
+            px = _get_plan(ndim=1, batch=batch * ny, ny=1, nx=nx, dtype=t.dtype, out_mode=_lib.OUT_COMPLEX, detrend=_lib.DETREND_NONE, flags=fx, scale=scale * float(ny),
+                           window_y=None, window_x=None, phase_y=None, phase_x=ph["x"])
+            # ... and run well: four complex columns or more per workgroup along y (32-byte row segments at least), two rows or more per workgroup along x (one long
+            # row per workgroup runs at half the rate: (16, 4096, 4096) 24 GFFT/s in two such stages against 30 on the two-axis plan).  Decided on the kernel
+            # kinds the C ABI reports (xrfthip_plan_kernel_info), not on the text of describe()
+            (ky, cy), (kx, rx) = py.kernel_info(), px.kernel_info()
+            good = ky in (_lib.K_FASTG_Y, _lib.K_FASTM_Y) and cy >= 4 and kx in (_lib.K_FASTG_ROWS, _lib.K_FASTM_X) and rx >= 2
+            if good and ny * nxs <= 20000:  # (a slab this small may run in ONE pass over both axes: only then is the two-axis plan built to ask)
+                whole = _get_plan(ndim=2, batch=batch, ny=ny, nx=nx, dtype=t.dtype, out_mode=_lib.OUT_COMPLEX, detrend=_lib.DETREND_NONE, flags=flags, scale=scale,
+                                  window_y=None, window_x=None, phase_y=ph["y"], phase_x=ph["x"])
+                good = whole.kernel_info()[0] == _lib.K_GENERIC
+        except _lib.XrftHipError as e:
+            if e.status not in (_lib.UNSUPPORTED_LENGTH, _lib.BAD_ARG):
+                raise
+            good = False
+        dec = (py, px) if good else False
+        with _plan_lock:
+            if len(_TWO_STAGE) > 256:
+                _TWO_STAGE.clear()
+            _TWO_STAGE[dkey] = dec
         if dec is False:
             return None
-        if dec is not None:
-            py, px = dec
-            mid, _ = py.execute(t.reshape(batch, ny, nxs))
-            out, _ = px.execute(mid.reshape(batch * ny, 1, nxs))
-            return out.reshape(list(t.shape[:-1]) + [nx])
-        whole._two_stage = False
-        if "[fast" in whole.describe():
-            return None  # (a small slab: one pass over both axes)
-        py = _get_plan(ndim=2, batch=batch, ny=ny, nx=nxs, dtype=t.dtype, out_mode=_lib.OUT_COMPLEX, detrend=_lib.DETREND_NONE, flags=fy, scale=1.0 / float(ny),
-                       window_y=None, window_x=None, phase_y=ph["y"], phase_x=None)
-        px = _get_plan(ndim=1, batch=batch * ny, ny=1, nx=nx, dtype=t.dtype, out_mode=_lib.OUT_COMPLEX, detrend=_lib.DETREND_NONE, flags=fx, scale=scale * float(ny),
-                       window_y=None, window_x=None, phase_y=None, phase_x=ph["x"])
-    except _lib.XrftHipError as e:
-        if e.status in (_lib.UNSUPPORTED_LENGTH, _lib.BAD_ARG):
-            return None
-        raise
-    # ... and run well: four complex columns or more per workgroup along y (32-byte row segments at least), two rows or more per workgroup along x (one long
-    # row per workgroup runs at half the rate: (16, 4096, 4096) 24 GFFT/s in two such stages against 30 on the two-axis plan)
-    import re
-
-    my = re.search(r"\[fastg y-only\] one pass, \d+ thr, (\d+) complex columns", py.describe())
-    mx = re.search(r"\[fastg rows\] one pass, one \d+-thread workgroup per (\d+) rows", px.describe())
-    if my is None or mx is None or int(my.group(1)) < 4 or int(mx.group(1)) < 2:
-        return None
-    whole._two_stage = (py, px)
+    py, px = dec
     mid, _ = py.execute(t.reshape(batch, ny, nxs))
     out, _ = px.execute(mid.reshape(batch * ny, 1, nxs))
     return out.reshape(list(t.shape[:-1]) + [nx])

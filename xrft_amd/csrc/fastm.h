@@ -168,6 +168,8 @@ struct FastM {
     int half;            // real_dim: only kx = 0..nx/2 is stored, rows of nx/2 + 1 samples, unshifted along x (xrft.py:400-404)
     int realdim2;        // ... and 0 < kx < nx/2 counts twice (xrft.py:673-682)
     int ph_on;
+    int inv, ishift_in, ph_in;  // x-only kernel, complex input: an inverse transform (xrft.ifft along the contiguous axis, xrft.py:479-646) = conj(FFT(conj z)); source sample
+                                // (x + ishift_in) mod n feeds position x (the ifftshift of an fftshifted spectrum); ph_x multiplies the INPUT at its source position (the lag's phase, :574-576)
     int ny, nx, nrow_pad;
     int l_cw, l_rk;      // log2 of CW and RK
     int detrend, nslab, nunits;
@@ -463,7 +465,13 @@ __global__ void __launch_bounds__((MYGeom<T, NY>::type::THR), (MYGeom<T, NY>::ty
         a[q] = mk<T>((T)0, (T)0); wyv[q] = (T)0;
         if (on) {
             if (TWO) a[q] = mk<T>(*reinterpret_cast<const T*>(src + (off0 + rstep * (size_t)q)), *reinterpret_cast<const T*>(srcb + (off0 + rstep * (size_t)q)));
-            else a[q] = *reinterpret_cast<const CT*>(src + (off0 + rstep * (size_t)q));
+            else if (CIN && (p.inv | p.ishift_in | p.ph_in)) {  // an inverse transform along the axis (xrft.ifft, xrft.py:479-646): the fftshifted input rotated, the lag's phase on the input, conj in
+                int rs = j + q * M0 + p.ishift_in; if (rs >= NY) rs -= NY;
+                CT z = *reinterpret_cast<const CT*>(src + ((size_t)rs * rowb + (size_t)g * sizeof(CT)));
+                if (p.ph_in) z = cmul(z, reinterpret_cast<const CT*>(p.ph_y)[rs]);
+                if (p.inv) z.im = -z.im;
+                a[q] = z;
+            } else a[q] = *reinterpret_cast<const CT*>(src + (off0 + rstep * (size_t)q));
             wyv[q] = wy[j + q * M0];
         }
     }
@@ -511,6 +519,7 @@ __global__ void __launch_bounds__((MYGeom<T, NY>::type::THR), (MYGeom<T, NY>::ty
         for (int l = tid; l < CW * NY; l += THR) {
             const int col = l % CW, k = l / CW;
             CT o = lds[col * STR + M::pn(k)];
+            if (p.inv) o.im = -o.im;
             int rd = k + p.shift_y; if (rd >= NY) rd -= NY;
             if (MODE == 1) reinterpret_cast<T*>(outs)[(size_t)rd * p.nx + col] = (o.re * o.re + o.im * o.im) * sc;
             else {
@@ -593,8 +602,13 @@ __global__ void __launch_bounds__((MGeom<T, N>::THR), (MGeom<T, N>::WPS)) fastm_
 #pragma unroll
     for (int q = 0; q < R0; ++q) {
         const int x = j + q * M0;
-        if (CIN) a[q] = ha ? sc_in[x] : mk<T>((T)0, (T)0);
-        else a[q] = mk<T>(ha ? sa[x] : (T)0, hb ? sb[x] : (T)0);
+        if (CIN) {
+            int xs = x + p.ishift_in; if (xs >= N) xs -= N;
+            CT z = ha ? sc_in[xs] : mk<T>((T)0, (T)0);
+            if (p.ph_in) z = cmul(z, reinterpret_cast<const CT*>(p.ph_x)[xs]);
+            if (p.inv) z.im = -z.im;
+            a[q] = z;
+        } else a[q] = mk<T>(ha ? sa[x] : (T)0, hb ? sb[x] : (T)0);
         wv[q] = wx[x];
     }
     constexpr double XBAR = 0.5 * (N - 1);
@@ -646,7 +660,7 @@ __global__ void __launch_bounds__((MGeom<T, N>::THR), (MGeom<T, N>::WPS)) fastm_
         const CT* z = lds + ((TWO || CIN) ? t : (t >> 1)) * STR;
         const CT zk = z[M::pn(k)], zc = cconj(z[M::pn(k == 0 ? 0 : N - k)]);
         CT o;
-        if (CIN) o = zk;
+        if (CIN) { o = zk; if (p.inv) o.im = -o.im; }
         else if (TWO) o = cmulc(cscale(zk + zc, (T)0.5), cscale(mul_mi(zk - zc), (T)0.5));  // F0 conj(F1) of this row (xrft.py:825)
         else o = (t & 1) ? cscale(mul_mi(zk - zc), (T)0.5) : cscale(zk + zc, (T)0.5);
         int oc = k + p.shift_x; if (oc >= N) oc -= N;  // (half output: shift_x = 0)

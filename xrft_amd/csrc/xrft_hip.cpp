@@ -2116,7 +2116,10 @@ static int run_fastmy(const xrfthip_plan* P, const void* in, const void* in1, vo
     p.angle = d.out_mode == XRFTHIP_OUT_PHASE ? 1 : 0;
     p.tw_y = P->tw_fy.p;
     p.win_y = P->win[0].p ? P->win[0].p : P->ones4096.p;
-    p.ph_y = P->fph[0].p; p.ph_on = P->fph_on ? 1 : 0;
+    p.ph_y = P->fph[0].p; p.ph_on = (P->fph_on && !(d.flags & XRFTHIP_PHASE_IN)) ? 1 : 0;
+    p.inv = (d.flags & XRFTHIP_INVERSE) ? 1 : 0;
+    p.ishift_in = ((d.flags & XRFTHIP_INVERSE) && (d.flags & XRFTHIP_ISHIFT_Y)) ? (int)(d.ny / 2) : 0;
+    p.ph_in = ((d.flags & XRFTHIP_PHASE_IN) && P->fph_on) ? 1 : 0;
     p.ny = (int)d.ny; p.nx = (int)d.nx;
     p.detrend = d.detrend; p.nslab = (int)d.batch;
     p.cin = P->cplx_in ? 1 : 0;
@@ -2157,7 +2160,10 @@ static int run_fastmx(const xrfthip_plan* P, const void* in, const void* in1, vo
     p.angle = d.out_mode == XRFTHIP_OUT_PHASE ? 1 : 0;
     p.tw_x = P->tw_fx.p;
     p.win_x = P->win[1].p ? P->win[1].p : P->ones4096.p;
-    p.ph_x = P->fph[1].p; p.ph_on = P->fph_on ? 1 : 0;
+    p.ph_x = P->fph[1].p; p.ph_on = (P->fph_on && !(d.flags & XRFTHIP_PHASE_IN)) ? 1 : 0;
+    p.inv = (d.flags & XRFTHIP_INVERSE) ? 1 : 0;
+    p.ishift_in = ((d.flags & XRFTHIP_INVERSE) && (d.flags & XRFTHIP_ISHIFT_X)) ? (int)(d.nx / 2) : 0;
+    p.ph_in = ((d.flags & XRFTHIP_PHASE_IN) && P->fph_on) ? 1 : 0;
     p.ny = 1; p.nx = (int)d.nx;
     p.detrend = d.detrend; p.nslab = (int)d.batch;
     p.half = (d.flags & XRFTHIP_HALF_X) ? 1 : 0;
@@ -2934,7 +2940,8 @@ int xrfthip_plan_create(xrfthip_plan** plan, const xrfthip_desc* desc) {
     }
     {   // one transform axis that is not the contiguous one, real input: pass 1 of the same kernels is the whole transform
         const bool two = d.out_mode == XRFTHIP_OUT_CROSS || d.out_mode == XRFTHIP_OUT_PHASE;
-        const uint32_t allowed = XRFTHIP_AXIS_Y | XRFTHIP_SHIFT_Y | (d.out_mode != XRFTHIP_OUT_POWER ? XRFTHIP_ISHIFT_Y : 0u);
+        const uint32_t allowed = XRFTHIP_AXIS_Y | XRFTHIP_SHIFT_Y | (d.out_mode != XRFTHIP_OUT_POWER ? XRFTHIP_ISHIFT_Y : 0u) |
+                                 ((cplx_in && d.out_mode == XRFTHIP_OUT_COMPLEX) ? (XRFTHIP_INVERSE | XRFTHIP_PHASE_IN) : 0u);  // (xrft.ifft along the axis)
         P->fastmy = (d.flags & XRFTHIP_AXIS_Y) && d.ndim == 2 && (!cplx_in || !two) &&
                     (d.out_mode == XRFTHIP_OUT_COMPLEX || d.out_mode == XRFTHIP_OUT_POWER || two) && !(d.flags & ~allowed) && fastmy_len(d.ny, P->dbl) &&
                     d.batch * d.nx < (1LL << 30) && !env_ll("XRFTHIP_NO_FAST", 0) && env_ll("XRFTHIP_FASTM", 1) != 0;
@@ -2963,7 +2970,8 @@ int xrfthip_plan_create(xrfthip_plan** plan, const xrfthip_desc* desc) {
     }
     {   // one short transform axis, the contiguous one, real input: rows packed in pairs through the same three passes
         const bool two = d.out_mode == XRFTHIP_OUT_CROSS || d.out_mode == XRFTHIP_OUT_PHASE;
-        const uint32_t allowed = XRFTHIP_SHIFT_X | XRFTHIP_HALF_X | (d.out_mode != XRFTHIP_OUT_PHASE ? XRFTHIP_REALDIM_X2 : 0u) | (d.out_mode != XRFTHIP_OUT_POWER ? XRFTHIP_ISHIFT_X : 0u);
+        const uint32_t allowed = XRFTHIP_SHIFT_X | XRFTHIP_HALF_X | (d.out_mode != XRFTHIP_OUT_PHASE ? XRFTHIP_REALDIM_X2 : 0u) | (d.out_mode != XRFTHIP_OUT_POWER ? XRFTHIP_ISHIFT_X : 0u) |
+                                 ((cplx_in && d.out_mode == XRFTHIP_OUT_COMPLEX) ? (XRFTHIP_INVERSE | XRFTHIP_PHASE_IN) : 0u);  // (xrft.ifft along the contiguous axis: conj in, conj out, the input rotated)
         P->fastmx = !P->fastr && d.ndim == 1 && (!cplx_in || (!two && !(d.flags & (XRFTHIP_HALF_X | XRFTHIP_REALDIM_X2)))) && (d.out_mode == XRFTHIP_OUT_COMPLEX || d.out_mode == XRFTHIP_OUT_POWER || two) &&
                     !(d.flags & ~allowed) && !((d.flags & XRFTHIP_HALF_X) && (d.flags & XRFTHIP_SHIFT_X)) && !((d.flags & XRFTHIP_REALDIM_X2) && !(d.flags & XRFTHIP_HALF_X)) &&
                     fastmx_len(d.nx, P->dbl) && d.batch < (1LL << 31) - 16 && !env_ll("XRFTHIP_NO_FAST", 0) && env_ll("XRFTHIP_FASTM", 1) != 0;
@@ -3027,7 +3035,7 @@ int xrfthip_plan_create(xrfthip_plan** plan, const xrfthip_desc* desc) {
             }
         }
     }
-    if ((d.flags & XRFTHIP_AXIS_Y) && (d.flags & XRFTHIP_PHASE_IN) && !P->fastgy) { delete P; return XRFTHIP_BAD_ARG; }  // (the generic column tiles have no input phase)
+    if ((d.flags & XRFTHIP_AXIS_Y) && (d.flags & XRFTHIP_PHASE_IN) && !P->fastgy && !P->fastmy) { delete P; return XRFTHIP_BAD_ARG; }  // (the generic column tiles have no input phase)
     set_kernel_attrs_once();
     // nbins must be known before tiles are sized (the LDS histogram shares the tile's allocation): ISO plans are
     // (re)built in xrfthip_plan_set_binmap.  Build now for everything else.
@@ -3144,6 +3152,24 @@ int xrfthip_plan_uses_bluestein(const xrfthip_plan* plan) {
     for (const Pass& ps : plan->passes) if (ps.g.blue_n > 0) return 1;
     for (const Pass& ps : plan->passes_f0) if (ps.g.blue_n > 0) return 1;
     return 0;
+}
+
+int xrfthip_plan_kernel_info(const xrfthip_plan* plan, int32_t* kind, int32_t* per_workgroup) {
+    if (!plan || !kind || !per_workgroup) return XRFTHIP_BAD_ARG;
+    const xrfthip_plan* P = plan;
+    const bool two = P->d.out_mode == XRFTHIP_OUT_CROSS || P->d.out_mode == XRFTHIP_OUT_PHASE;
+    int k = XRFTHIP_K_GENERIC, n = 0;
+    if (P->sub_x) k = XRFTHIP_K_COMPOSITE;
+    else if (P->fastg) { k = P->g_one_d ? XRFTHIP_K_FASTG_ROWS : XRFTHIP_K_FASTG; n = P->g_one_d ? P->g_rows : 1; }
+    else if (P->fasts) { k = XRFTHIP_K_FASTS; n = 1; }
+    else if (P->fastr) { k = XRFTHIP_K_FASTR; n = 1; }
+    else if (P->fastmx) { k = XRFTHIP_K_FASTM_X; const MGeomRt C = mxgeom(P->d.nx, P->dbl); n = (two || P->cplx_in) ? C.g : 2 * C.g; }
+    else if (P->fastgy) { k = XRFTHIP_K_FASTG_Y; n = ((P->cplx_in || two) ? 1 : 2) * P->gy_G; }
+    else if (P->fastmy) { k = XRFTHIP_K_FASTM_Y; const MGeomRt C = mygeom(P->d.ny, P->dbl); n = ((P->cplx_in || two) ? 1 : 2) * C.g; }
+    else if (P->fastm) { k = P->fastn ? XRFTHIP_K_FASTN : XRFTHIP_K_FASTM; n = plan_cw(P); }
+    else if (fasty_on(P)) { k = XRFTHIP_K_FASTY; n = 0; }
+    *kind = k; *per_workgroup = n;
+    return XRFTHIP_OK;
 }
 
 size_t xrfthip_workspace_bytes(const xrfthip_plan* plan) {

@@ -83,6 +83,12 @@ class SpectralPlan:
         self._dll.xrfthip_plan_describe(self._h, buf, len(buf))
         return buf.value.decode()
 
+    def kernel_info(self):
+        """(kernel kind, independent sequences per workgroup) of the plan: ``_lib.K_*`` -- what ``describe()`` prints, as numbers."""
+        k, n = C.c_int32(0), C.c_int32(0)
+        _lib.check(self._dll.xrfthip_plan_kernel_info(self._h, C.byref(k), C.byref(n)))
+        return int(k.value), int(n.value)
+
     def uses_bluestein(self):
         """True when an axis of the plan runs Bluestein's algorithm inside the tile kernels (a prime factor with no butterfly)."""
         return bool(self._dll.xrfthip_plan_uses_bluestein(self._h))
