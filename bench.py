@@ -20,7 +20,7 @@ Extra objects on the JSON line:
                  time of the step (all kernels + gaps), frac = achieved / 8 TB/s.  "kernel" holds the same figure for the
                  longest kernel alone (its launch's points / its average launch duration, from HIP events recorded by
                  the library on the launch stream inside the timed region, xrfthip_plan_set_profiling); "traffic" the
-                 HBM bytes of one step measured with rocprofv3 PMC counters (profiles/r04_traffic.json, used only when its
+                 HBM bytes of one step measured with rocprofv3 PMC counters (profiles/r05_traffic.json, used only when its
                  stamp matches the SHA-1 of xrft_amd/csrc; null otherwise); "claimed_floor" is NOT a measurement of this run: the
                  builder's claim of what the two passes' access patterns cost with no arithmetic (scripts/ubench/fused.hip as
                  timed in profiles/r03_ubench_fused.txt), carried with the SHA-1 of that skeleton's source and of the kernel
@@ -367,13 +367,13 @@ def run(args, env):
             kernel_ms = sum(v[1] for v in kern.values()) / args.steps
             path_achieved = bpp * value * 1e9 / world  # B/s per GPU
             # HBM traffic of one step: rocprofv3 cannot run inside the timed process, so the figure comes from the committed PMC
-            # profile of this same command (scripts/gpu_profile_r04.sh, --nt 64) -- and only if that profile was taken on the
+            # profile of this same command (scripts/gpu_profile_r05.sh, --nt 64) -- and only if that profile was taken on the
             # kernels that just ran: it is stamped with the SHA-1 of xrft_amd/csrc, a mismatch leaves traffic null
             traffic = None
             tnote = None
             ceiling = None
             try:
-                tname = "r04_traffic_c2.json" if args.workload == "c2" else "r04_traffic.json"
+                tname = "r05_traffic_c2.json" if args.workload == "c2" else "r05_traffic.json"
                 with open(os.path.join(REPO, "profiles", tname)) as fh:
                     tj = json.load(fh)
                 if args.workload == "c2" and nx == 65536:
@@ -382,7 +382,7 @@ def run(args, env):
                         tnote = tj.get("note")
                     else:
                         tnote = (f"profiles/{tname} was measured on other kernel sources (csrc SHA-1 "
-                                 f"{str(tj.get('csrc_sha1'))[:12]} != {csrc_sha1()[:12]}): re-run scripts/gpu_profile_r04.sh")
+                                 f"{str(tj.get('csrc_sha1'))[:12]} != {csrc_sha1()[:12]}): re-run scripts/gpu_profile_r05.sh")
                 if args.workload == "ps" and (ny, nx) == (4096, 4096):
                     ceiling = tj.get("claimed_floor") or tj.get("two_pass_floor")
                     if ceiling is not None:  # a claim, not a measurement of this run: it travels with the skeleton's source hash
@@ -399,7 +399,7 @@ def run(args, env):
                         tnote = tj.get("note")
                     else:
                         tnote = (f"profiles/{tname} was measured on other kernel sources (csrc SHA-1 "
-                                 f"{str(tj.get('csrc_sha1'))[:12]} != {csrc_sha1()[:12]}): re-run scripts/gpu_profile_r04.sh")
+                                 f"{str(tj.get('csrc_sha1'))[:12]} != {csrc_sha1()[:12]}): re-run scripts/gpu_profile_r05.sh")
             except Exception as e:
                 tnote = f"no traffic profile: {e!r}"
             roof = {
