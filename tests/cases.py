@@ -1250,6 +1250,34 @@ def run_inner_layout_cases(dtype="float64", shape=(24, 20, 6)):
     return worst
 
 
+def run_fused_inner_cases(dtype="float64", shapes=((24, 20, 6), (16, 48, 3), (36, 30, 17), (40, 16, 33), (2, 28, 18, 5), (20, 24, 8), (2, 32, 16, 12))):
+    """dim = ["y", "x"] of a real (..., y, x, t) array with both lengths >= 16 and smooth: the engine's two FUSED passes over the inner layout (csrc/fastn.h:
+    fastn_cols_kernel on the [ny][nx t] view, fastn_fit_inner_kernel, fastn_irows_kernel; describe() says [fastn fused]) against the oracle -- odd and even
+    element counts, a ragged last element block, a leading batch, every option the path takes.  xrft.py:395-409, 421-447."""
+    rng = np.random.default_rng(5)
+    tol = TOL[dtype]
+    worst = 0.0
+    for shape in shapes:
+        ny, nx, nt = shape[-3:]
+        ii, jj = np.meshgrid(np.arange(ny), np.arange(nx), indexing="ij")
+        v = (rng.standard_normal(shape) + (0.05 * ii - 0.03 * jj + 2.0)[:, :, None] * (1.0 + np.arange(nt))[None, None, :]).astype(dtype)
+        dims = ("y", "x", "t") if len(shape) == 3 else ("b", "y", "x", "t")
+        c = {"y": np.arange(ny) * 0.5 + 1.0, "x": np.arange(nx) * 2.0 - 3.0, "t": np.arange(nt)}
+        if len(shape) == 4:
+            c["b"] = np.arange(shape[0])
+        da, od = pair(v, dims, c)
+        for kw in (dict(), dict(detrend="linear", window="hann"), dict(detrend="constant", shift=False, true_phase=False), dict(window="hamming", true_amplitude=False)):
+            worst = max(worst, check(xa.fft(da, dim=["y", "x"], **kw), o.fft(od, dim=["y", "x"], **kw), tol))
+            d = next(reversed(xa.api._plan_cache.values())).describe()
+            assert "[fastn fused]" in d and "[inner layout]" in d, (shape, kw, d)
+        for kw in (dict(detrend="linear", window="hann"), dict(scaling="spectrum", shift=False), dict(detrend="constant", window="hann", window_correction=True)):
+            worst = max(worst, check(xa.power_spectrum(da, dim=["y", "x"], **kw), o.power_spectrum(od, dim=["y", "x"], **kw), tol))
+            assert "[fastn fused]" in next(reversed(xa.api._plan_cache.values())).describe(), (shape, kw)
+        # the axes named in the other order; a length with a factor the butterflies do not hold falls back to the composite of one-axis plans
+        worst = max(worst, check(xa.power_spectrum(da, dim=["x", "y"], window="hann"), o.power_spectrum(od, dim=["x", "y"], window="hann"), tol))
+    return worst
+
+
 def run_fused_radial_code_forms(n=256):
     """The fused radial sums of the y-first float32 kernels (csrc/fasty.h): a radial bin map (what isotropic_*_spectrum hands
     over) is summed by a per-bin gather with no atomics; any other map through int64 fixed-point tables, its codes compact (first bin

@@ -602,4 +602,178 @@ __global__ void __launch_bounds__(fastn_max_threads<T>(), (sizeof(T) == 4 ? 4 : 
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Two ADJACENT transform axes with the independent elements INNERMOST -- dim = ["y", "x"] of a (y, x, time) array, xrfthip_desc.inner:
+// [batch][ny][nx][inner] -- as the same two passes (round 5; before: a detrend pass and two one-axis plans, 32 bytes per sample through memory):
+//   pass 1  fastn_cols_kernel on the [ny][nx inner] view: every (x, e) is a column, two adjacent ones (e, e + 1) a packed sequence; the window along x rides on a
+//           table expanded to the view's columns; the per-column sums are those of the (x, e) columns
+//   [fit]   fastn_fit_inner_kernel: one plane per (slab, e) from its nx column sums
+//   pass 2  fastn_irows_kernel: a workgroup owns GE consecutive e of ONE row ky of the intermediate -- GE complex sequences of nx points, x strided by `inner` --
+//           adds the plane back, transforms along x and writes (ky, kx, e) and its Hermitian twin (-ky, -kx, e) as runs of GE elements where they lie.
+// 16 algorithmic-plus-intermediate bytes per sample instead of 32; no transposed copy.      (xrft/xrft.py:395-409: any axes where they lie)
+// ------------------------------------------------------------------------------------------------
+struct FastNI {
+    const void* w2;      // [slab][ky / RK][c / CW][ky % RK][CW] complex T, c = x inner + e (pitch columns per row)
+    const void* corr;    // [slab][nx inner] complex T: wx (subtracted line - plane) as (offset at ibar, slope)
+    const void* what0;   // FFT_y(wy)[ky], FFT_y(wy (i - ibar))[ky]
+    const void* what1;
+    const void* tw_x;    // W_nx^k
+    const void* twm;     // staged twiddles of the middle passes
+    NGeoPtr g;           // the nx-point transform, g.g = GE sequences per workgroup
+    const void* ph_y;    // complex mode: combined phase factors per unshifted frequency
+    const void* ph_x;
+    void* out;           // [slab][ny][nx][inner]: T (power) or complex T
+    int ph_on, vec, dbg; // vec: the result is written in 16-byte pieces; dbg: ablations for measurements (1 no LDS passes, 2 no stores, 4 no loads)
+    int ny, nx, inner, nrow_pad, pitch, l_cw, l_rk, detrend, shift_y, shift_x, neb, nunits;
+    double scale;
+};
+
+template <typename T, int R>
+__device__ __forceinline__ void n_first_irows(const FastNI& p, NGeoRef g, C2<T>* lds, int w, int ky, int slab, int e0) {
+    typedef C2<T> CT;
+    const int M0 = g.m[0], rk = 1 << p.l_rk, cwm = (1 << p.l_cw) - 1;
+    const int ge = w & (g.g - 1), j = w >> g.lg, e = min(e0 + ge, p.inner - 1);  // (a ragged last block re-reads the last element; never stored)
+    const CT w0 = reinterpret_cast<const CT*>(p.tw_x)[j];
+    const CT* __restrict__ blk = reinterpret_cast<const CT*>(p.w2) + ((size_t)slab * p.nrow_pad + (size_t)((ky >> p.l_rk) << p.l_rk)) * p.pitch;
+    const CT* __restrict__ cr = reinterpret_cast<const CT*>(p.corr) + (size_t)slab * p.nx * p.inner;
+    const bool addback = p.detrend != 0;
+    CT a[R], c[R];
+    CT h0 = mk<T>((T)0, (T)0), h1 = h0;
+    if (addback) { h0 = reinterpret_cast<const CT*>(p.what0)[ky]; h1 = reinterpret_cast<const CT*>(p.what1)[ky]; }
+#pragma unroll
+    for (int q = 0; q < R; ++q) {
+        const int col = (j + q * M0) * p.inner + e;
+        if (p.dbg & 4) { a[q] = mk<T>((T)col, (T)ky); c[q] = a[q]; continue; }
+        a[q] = blk[((((col >> p.l_cw) << p.l_rk) + (ky & (rk - 1))) << p.l_cw) + (col & cwm)];
+        c[q] = addback ? cr[col] : mk<T>((T)0, (T)0);
+    }
+    if (addback) {
+#pragma unroll
+        for (int q = 0; q < R; ++q) {
+            a[q].re = fma(c[q].re, h0.re, fma(c[q].im, h1.re, a[q].re));
+            a[q].im = fma(c[q].re, h0.im, fma(c[q].im, h1.im, a[q].im));
+        }
+    }
+    dft_r<T, R>(a);
+    n_chain<T, R>(a, w0);
+    CT* s = lds + ge * g.str + n_pad(j, g.inv_pdq);
+    const int st = g.step[0];
+#pragma unroll
+    for (int k = 0; k < R; ++k) s[k * st] = a[k];
+}
+
+// MODE 0: complex spectrum, 1: power spectrum
+template <typename T, int MODE, int CAP>
+__global__ void __launch_bounds__(fastn_max_threads<T>(), (sizeof(T) == 4 ? 4 : 3)) fastn_irows_kernel(FastNI p) {
+    typedef C2<T> CT;
+    NGeoRef g = *p.g;
+    XRFT_DYN_SMEM(smem_raw);
+    CT* lds = reinterpret_cast<CT*>(smem_raw);
+    CT* twl = lds + g.g * g.str;
+    const int tid = threadIdx.x, nthr = g.thr, GE = g.g, NX = p.nx, nyh = p.ny >> 1;
+    // unit = (slab, ky, block of GE elements e); every XCD gets a contiguous range of units: the workgroups that fill the 128-byte lines of a result row share an L2
+    const int per = (p.nunits + 7) >> 3, xcd = blockIdx.x & 7, jb = blockIdx.x >> 3;
+    const int unit = xcd * per + jb;
+    if (jb >= per || unit >= p.nunits) return;
+    const int ups = (nyh + 1) * p.neb, slab = unit / ups, rem = unit - slab * ups, ky = rem / p.neb, e0 = (rem - ky * p.neb) * GE;
+    for (int e = tid; e < g.twn; e += nthr) twl[e] = reinterpret_cast<const CT*>(p.twm)[e];
+    {
+        const int nit = g.m[0] << g.lg;
+        for (int w = tid; w < nit; w += nthr) {
+#define NF_(RR) n_first_irows<T, RR>(p, g, lds, w, ky, slab, e0)
+            XRFT_N_SWITCH(g.r[0], NF_)
+#undef NF_
+        }
+    }
+    if (!(p.dbg & 1)) n_fft_tail<T, CAP>(lds, g, tid, nthr, twl); else __syncthreads();
+    const int sx = p.shift_x, sy = p.shift_y;
+    const T sc = (T)p.scale;
+    const float ipn = g.inv_pnq, inv_nx = 1.0f / (float)NX;
+    if ((p.dbg & 2) && lds[tid].re != (T)1.2345) return;
+    const bool twin = ky != 0 && 2 * ky != p.ny;
+    const int tot = (NX << g.lg) * (twin ? 2 : 1);
+    typedef typename std::conditional<MODE == 0, CT, T>::type OutT;
+    OutT* __restrict__ outs = reinterpret_cast<OutT*>(p.out) + (size_t)slab * p.ny * NX * p.inner;
+    if (p.vec) {  // 16-byte pieces of the result: VW consecutive elements e per thread (the host checked inner % VW == 0 and GE % VW == 0)
+        constexpr int VW = 16 / (int)sizeof(OutT), LV = VW == 4 ? 2 : VW == 2 ? 1 : 0;
+        const int lgq = g.lg - LV, totv = tot >> LV;
+        for (int idx = tid; idx < totv; idx += nthr) {
+            const int ge = (idx & ((1 << lgq) - 1)) << LV, rest = idx >> lgq, mir = fdiv(rest, inv_nx), oc = rest - mir * NX, e = e0 + ge;
+            if (e >= p.inner) continue;
+            int fx = oc - sx; if (fx < 0) fx += NX;
+            const int kx = mir ? (fx == 0 ? 0 : NX - fx) : fx;
+            const int fy = mir ? p.ny - ky : ky;
+            int orow = fy + sy; if (orow >= p.ny) orow -= p.ny;
+            const CT* src = lds + ge * g.str + n_pad(kx, ipn);
+            OutT o[VW];
+            CT ph = mk<T>((T)1, (T)0);
+            if (MODE == 0 && p.ph_on) ph = cmul(reinterpret_cast<const CT*>(p.ph_y)[fy], reinterpret_cast<const CT*>(p.ph_x)[fx]);
+#pragma unroll
+            for (int i = 0; i < VW; ++i) {
+                CT v = src[i * g.str];
+                if (MODE == 1) {
+                    *reinterpret_cast<T*>(&o[i]) = (v.re * v.re + v.im * v.im) * sc;
+                } else {
+                    v = cscale(v, sc);
+                    if (mir) v = cconj(v);
+                    if (p.ph_on) v = cmul(v, ph);
+                    *reinterpret_cast<CT*>(&o[i]) = v;
+                }
+            }
+            mr_store16_nt<T, true>(outs + ((size_t)orow * NX + oc) * p.inner + e, o);  // (a plain store: the pieces of a 128-byte line come from several workgroups and meet in the L2; non-temporal pieces go to memory one by one, 652 us against 244)
+        }
+        return;
+    }
+    for (int idx = tid; idx < tot; idx += nthr) {
+        const int ge = idx & (GE - 1), rest = idx >> g.lg, mir = fdiv(rest, inv_nx), oc = rest - mir * NX, e = e0 + ge;
+        if (e >= p.inner) continue;
+        int fx = oc - sx; if (fx < 0) fx += NX;                 // unshifted frequency of output column oc
+        const int kx = mir ? (fx == 0 ? 0 : NX - fx) : fx;      // F(-ky, fx) = conj F(ky, -fx)
+        const int fy = mir ? p.ny - ky : ky;
+        int orow = fy + sy; if (orow >= p.ny) orow -= p.ny;
+        CT v = lds[ge * g.str + n_pad(kx, ipn)];
+        OutT* dst = outs + ((size_t)orow * NX + oc) * p.inner + e;
+        if (MODE == 1) {
+            *reinterpret_cast<T*>(dst) = (v.re * v.re + v.im * v.im) * sc;
+        } else {
+            v = cscale(v, sc);
+            if (mir) v = cconj(v);
+            if (p.ph_on) v = cmul(v, cmul(reinterpret_cast<const CT*>(p.ph_y)[fy], reinterpret_cast<const CT*>(p.ph_x)[fx]));
+            *reinterpret_cast<CT*>(dst) = v;
+        }
+    }
+}
+
+// one plane per (slab, e) from the sums of its nx columns (fastm_fit_kernel with the columns of an element `inner` apart): one 256-thread block each
+template <typename T>
+__global__ void __launch_bounds__(256) fastn_fit_inner_kernel(const double* colfit, const T* win_x_exp, C2<T>* corr, int nx, int inner, int ny, int detrend) {
+    XRFT_DYN_SMEM(smem_raw);
+    double* red = reinterpret_cast<double*>(smem_raw);
+    const int slab = blockIdx.x / inner, e = blockIdx.x - slab * inner, tid = threadIdx.x;
+    const double* cf4 = colfit + (size_t)slab * nx * inner * 4;
+    const double xbar = 0.5 * (nx - 1), sxx = (double)nx * ((double)nx * nx - 1.0) / 12.0;
+    const double inv_n = 1.0 / ny, inv_sii = 12.0 / ((double)ny * ((double)ny * ny - 1.0));
+    double s[3] = {0.0, 0.0, 0.0};
+    for (int x = tid; x < nx; x += 256) {
+        const size_t c = (size_t)x * inner + e;
+        const double m = cf4[4 * c] * inv_n, sl = cf4[4 * c + 1] * inv_sii;
+        s[0] += m;
+        s[1] += ((double)x - xbar) * m;
+        s[2] += sl;
+    }
+    block_sum<3>(s, red);
+    __syncthreads();
+    if (tid == 0) { red[0] = s[0]; red[1] = s[1]; red[2] = s[2]; }
+    __syncthreads();
+    const double a = red[0] / nx;
+    const double b = (detrend == 2 && nx > 1) ? red[1] / sxx : 0.0;
+    const double cc = detrend == 2 ? red[2] / nx : 0.0;
+    C2<T>* out = corr + (size_t)slab * nx * inner;
+    for (int x = tid; x < nx; x += 256) {
+        const size_t c = (size_t)x * inner + e;
+        const double wx = (double)win_x_exp[c];
+        out[c] = mk<T>((T)(wx * (cf4[4 * c + 2] - a - b * ((double)x - xbar))), (T)(wx * (cf4[4 * c + 3] - cc)));
+    }
+}
+
 }  // namespace xrft

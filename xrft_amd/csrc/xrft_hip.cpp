@@ -338,6 +338,10 @@ struct xrfthip_plan {
     long long y_pitch = 0;          // complex elements per row of the intermediate (ynx, or n_nxb * n_cw when the last column block is ragged)
     int n_blue_m = 0;               // pass 1 through a chirp convolution of this length
     DevBuf n_bluec, n_blueb;
+    // ... and xrfthip_desc.inner > 1 (two adjacent transform axes, the independent elements innermost) as the same two passes (fastn.h: fastn_cols_kernel on the
+    // [ny][nx inner] view, fastn_fit_inner_kernel, fastn_irows_kernel).  n_c: the ny-point columns of the view; n_r: GE sequences of nx points per row workgroup
+    bool fusedi = false;
+    DevBuf winx_exp;                // the window along x expanded to the view's columns (never null: ones)
     // ... and pass 1 alone for ONE transform axis that is not the contiguous one (XRFTHIP_AXIS_Y, fastm_yonly_kernel)
     bool fastmy = false;
     // ... and the same transform over short contiguous rows packed in pairs (ndim = 1, fastm_xonly_kernel)
@@ -865,6 +869,8 @@ void set_kernel_attrs_once() {
                      SETF((fastn_rows_kernel<TT, 0, false, CC>)); SETF((fastn_rows_kernel<TT, 1, false, CC>)); SETF((fastn_rows_kernel<TT, 1, true, CC>)); SETF((fastn_rows_kernel<TT, 2, false, CC>)); \
                      SETF((fastn_rows_kernel<TT, 2, true, CC>)); SETF((fastn_rows_kernel<TT, 3, false, CC>))
     SETN(float, 16); SETN(float, 20); SETN(double, 16);
+    SETF((fastn_irows_kernel<float, 0, 16>)); SETF((fastn_irows_kernel<float, 1, 16>)); SETF((fastn_irows_kernel<float, 0, 20>)); SETF((fastn_irows_kernel<float, 1, 20>));
+    SETF((fastn_irows_kernel<double, 0, 16>)); SETF((fastn_irows_kernel<double, 1, 16>));
 #undef SETN
     SETF((fasts_power_kernel<8, 8, 0, 0>)); SETF((fasts_power_kernel<8, 4, 0, 0>)); SETF((fasts_power_kernel<4, 8, 0, 0>));
     SETF((fasts_power_kernel<8, 8, 0>)); SETF((fasts_power_kernel<8, 8, 1>)); SETF((fasts_power_kernel<8, 8, 2>));  // (above 64 KB of dynamic LDS)
@@ -1108,7 +1114,7 @@ static int fast_phase_tables(xrfthip_plan* P) {
         const long long n = ax == 0 ? d.ny : d.nx;
         const bool sign = d.out_mode == XRFTHIP_OUT_COMPLEX && !(d.flags & XRFTHIP_INVERSE) && (d.flags & (ax == 0 ? XRFTHIP_ISHIFT_Y : XRFTHIP_ISHIFT_X));  // (an inverse plan rotates its input)
         std::vector<cf> t((size_t)n);
-        const bool dtab = (P->fastm || P->fastmy || P->fastmx || P->fastg || P->fastgy) && P->dbl;
+        const bool dtab = (P->fastm || P->fastmy || P->fastmx || P->fastg || P->fastgy || P->fusedi) && P->dbl;
         std::vector<C2<double>> td(dtab ? (size_t)n : 0);
         for (long long k = 0; k < n; ++k) {
             double re = 1.0, im = 0.0;
@@ -1229,7 +1235,7 @@ static int fasty_window_spectra(xrfthip_plan* P) {
         r0 = o0r; i0 = o0i; r1 = o1r; i1 = o1i;
     }
     const int nent = P->y_nrow_pad;
-    if (P->fastm && P->dbl) {
+    if ((P->fastm || P->fusedi) && P->dbl) {
         std::vector<C2<double>> d0((size_t)nent), d1((size_t)nent);
         for (int k = 0; k < nent; ++k) {
             d0[(size_t)k].re = k <= nyh ? r0[(size_t)k] : 0.0; d0[(size_t)k].im = k <= nyh ? i0[(size_t)k] : 0.0;
@@ -2591,7 +2597,9 @@ static int run_fastr(const xrfthip_plan* P, const void* in, void* out, hipStream
 // Everything xrfthip_exec needs beyond the caller's buffers is built HERE, when the plan is created or one of its tables is
 // set: window spectra and phase tables of the specialised paths (device allocations + blocking copies) and the workspace
 // layout.  xrfthip_exec itself takes the plan as const: no allocation, no copy, no synchronisation, no getenv.
+extern "C" { static int fusedi_tables(xrfthip_plan* P); }
 static int finalize_plan(xrfthip_plan* P) {
+    if (P->fusedi) return fusedi_tables(P);  // (its workspace layout does not depend on the tables)
     // the radial sums of a cross spectrum with a true-phase factor that is not 1 (two fields with different lags) need the factor per sample: the other paths
     if (P->fastg && P->d.out_mode == XRFTHIP_OUT_CROSS && (P->d.flags & XRFTHIP_ISO) && phase_nontrivial(P)) P->fastg = false;
     if (P->fastg || P->fastgy) {
@@ -2713,8 +2721,164 @@ static size_t detrend_inner_ws(bool cplx, long long batch, long long inner);
 static int run_detrend_inner(int32_t dtype, int32_t ndim, long long batch, long long ny, long long nx, long long inner, int32_t kind, const void* in, void* out,
                              char* ws, hipStream_t st, long long mid = 1);
 
+// ---------------------------------------------------------------------------------------------------------------
+// xrfthip_desc.inner > 1 as two fused passes (fastn.h, round 5): 16 bytes per sample through memory where the composite of two one-axis plans moves 32
+// ---------------------------------------------------------------------------------------------------------------
+static int fusedi_tables(xrfthip_plan* P) {  // what depends on the windows / phases: called from finalize_plan
+    const xrfthip_desc& d = P->d;
+    const long long ncol = d.nx * d.inner;
+    std::vector<double> wexp((size_t)ncol);
+    for (long long x = 0; x < d.nx; ++x) {
+        const double w = P->host_win_x.empty() ? 1.0 : P->host_win_x[(size_t)x];
+        for (long long e = 0; e < d.inner; ++e) wexp[(size_t)(x * d.inner + e)] = w;
+    }
+    int rc = upload_real_table(P, P->winx_exp, wexp.data(), ncol, 0);
+    if (!rc) rc = fasty_window_spectra(P);
+    if (!rc && d.out_mode != XRFTHIP_OUT_POWER) rc = fast_phase_tables(P);
+    return rc;
+}
+
+static xrfthip_plan* create_fused_inner(const xrfthip_desc& d) {
+    if (env_ll("XRFTHIP_NO_FAST", 0) || !env_ll("XRFTHIP_FASTN", 1) || !env_ll("XRFTHIP_FUSED_INNER", 1)) return nullptr;
+    if (d.ndim != 2 || d.mid > 1 || d.inner < 2 || (d.dtype != XRFTHIP_F32 && d.dtype != XRFTHIP_F64)) return nullptr;
+    if (d.out_mode != XRFTHIP_OUT_COMPLEX && d.out_mode != XRFTHIP_OUT_POWER) return nullptr;
+    const uint32_t ok = XRFTHIP_SHIFT_Y | XRFTHIP_SHIFT_X | (d.out_mode == XRFTHIP_OUT_COMPLEX ? (XRFTHIP_ISHIFT_Y | XRFTHIP_ISHIFT_X) : 0u);
+    if (d.flags & ~ok) return nullptr;  // (a flipped axis: the composite of one-axis plans)
+    const bool dbl = d.dtype == XRFTHIP_F64;
+    const size_t rs = dbl ? 8 : 4, cs = 2 * rs;
+    const long long ncol = d.nx * d.inner;
+    if (d.ny < 16 || d.nx < 16 || d.ny > 8192 || d.nx > 8192 || ncol > (1LL << 26) || (unsigned long long)d.ny * (unsigned long long)ncol * rs >= (1ULL << 32)) return nullptr;
+    const int maxthr = dbl ? fastn_max_threads<double>() : fastn_max_threads<float>();
+    const int maxr = dbl ? fastn_max_radix<double>() : fastn_max_radix<float>();
+    // pass 1: ny-point columns of the [ny][nx inner] view, the widest column blocks that leave three, two, one workgroup on a CU
+    NGeo gc{}, gr{};
+    int G = 0, GE = 0;
+    // Both passes here are "column" passes (the sequences of pass 2 lie `inner` apart): the widest block of sequences that leaves two workgroups on a CU, then one --
+    // 64-byte pieces of every line where the LDS allows ((1024, 1024, 64) float32: 8 column pairs 187 us against 273 with 4 and three workgroups; 8 elements
+    // per row workgroup 231 us against 290; profiles/r05_inner_knobs.txt)
+    static const size_t caps[] = {78 * 1024, 156 * 1024, 156 * 1024};
+    const int f_gc = (int)env_ll("XRFTHIP_FI_GC", 0), f_ge = (int)env_ll("XRFTHIP_FI_GE", 0), f_tc = (int)env_ll("XRFTHIP_FI_TC", 0), f_tr = (int)env_ll("XRFTHIP_FI_TR", 0);  // (measurements)
+    for (int ci = 0; ci < 3 && !G; ++ci)
+        for (int cand = f_gc ? f_gc : (dbl ? 4 : 8); cand >= 1 && !G; cand >>= 1) {
+            NGeo t{};
+            // (float64: 256 threads -- (1024, 1024, 32): 176 us against 235 with the 384 that keep the most waves resident)
+            const int tc = f_tc ? f_tc : dbl ? 256 : 0;
+            if (!(tc && fastn_pick(d.ny, cand, false, dbl, true, maxr, tc, t)) && !fastn_pick(d.ny, cand, false, dbl, true, maxr, 0, t)) continue;
+            if ((long long)t.g * (d.ny / t.r[t.np - 1]) > maxthr) continue;
+            if (fastn_lds(t, cs, true) <= (f_gc ? caps[2] : caps[ci])) { G = cand; gc = t; }
+        }
+    // pass 2: GE sequences (consecutive inner elements) of nx points: 64-byte runs of the result where the LDS allows
+    for (int ci = 0; ci < 3 && !GE; ++ci)
+        for (int cand = f_ge ? f_ge : (dbl ? 4 : 8); cand >= 1 && !GE; cand >>= 1) {
+            if (cand > 2 * d.inner) continue;
+            NGeo t{};
+            // (float32: 512 threads where a workgroup holds eight sequences, 231 us against 292 with 256; float64: 256, 182 us against 249 with 384)
+            const int tr = f_tr ? f_tr : dbl ? 256 : ((long long)cand * d.nx >= 4096) ? 512 : 0;
+            if (!(tr && fastn_pick(d.nx, cand, false, dbl, false, maxr, tr, t)) && !fastn_pick(d.nx, cand, false, dbl, false, maxr, 0, t)) continue;
+            if ((long long)t.g * (d.nx / t.r[t.np - 1]) > maxthr) continue;
+            if (fastn_lds(t, cs, false) <= (f_ge ? caps[2] : caps[ci])) { GE = cand; gr = t; }
+        }
+    if (!G || !GE) return nullptr;
+    xrfthip_plan* P = new (std::nothrow) xrfthip_plan();
+    if (!P) return nullptr;
+    P->d = d;
+    P->fusedi = true;
+    P->inner = d.inner; P->mid = 1;
+    P->dbl = dbl; P->cplx_in = false; P->rsize = rs; P->csize = cs;
+    P->nx_out = d.nx;
+    P->yny = d.ny; P->ynx = ncol;  // (the view pass 1 transforms)
+    P->n_c.rt = true; P->n_c.geo = gc; P->n_c.lds = fastn_lds(gc, cs, true);
+    P->n_r.rt = true; P->n_r.geo = gr; P->n_r.lds = fastn_lds(gr, cs, false);
+    P->n_cw = 2 * G; P->n_nxb = (int)((ncol + P->n_cw - 1) / P->n_cw); P->y_pitch = (long long)P->n_nxb * P->n_cw;
+    P->n_rk = (int)std::max<long long>(1, (long long)(128 / (P->n_cw * cs)));
+    P->n_rpu = 1;
+    P->y_nrow_pad = (int)((d.ny / 2 + 1 + P->n_rk - 1) / P->n_rk * P->n_rk);
+    int rc = dbl ? build_twiddle<double>(P->tw_fx, d.nx, d.nx) : build_twiddle<float>(P->tw_fx, d.nx, d.nx);
+    if (!rc) rc = dbl ? build_twiddle<double>(P->tw_fy, d.ny, d.ny) : build_twiddle<float>(P->tw_fy, d.ny, d.ny);
+    std::vector<double> ones((size_t)std::max<long long>(d.ny, ncol), 1.0);
+    if (!rc) rc = upload_real_table(P, P->ones4096, ones.data(), (int64_t)ones.size(), 0);
+    if (!rc) rc = dbl ? fastn_upload_twm<double>(gc, P->n_c.twm) : fastn_upload_twm<float>(gc, P->n_c.twm);
+    if (!rc) rc = dbl ? fastn_upload_twm<double>(gr, P->n_r.twm) : fastn_upload_twm<float>(gr, P->n_r.twm);
+    if (!rc) rc = P->n_c.geo_dev.upload(&P->n_c.geo, sizeof(NGeo));
+    if (!rc) rc = P->n_r.geo_dev.upload(&P->n_r.geo, sizeof(NGeo));
+    if (!rc) rc = fusedi_tables(P);
+    if (rc) { delete P; return nullptr; }
+    // workspace: the intermediate of one group of slabs, the column sums, the plane corrections
+    auto al = [](size_t v) { return (v + 255) & ~(size_t)255; };
+    const size_t slab_w = (size_t)P->y_nrow_pad * (size_t)P->y_pitch * cs;
+    long long Gs = d.slabs_per_group > 0 ? d.slabs_per_group : (long long)std::max<size_t>(1, ((size_t)512 << 20) / std::max<size_t>(slab_w, 1));
+    Gs = std::max<long long>(1, std::min<long long>(Gs, std::max<long long>(d.batch, 1)));
+    P->G = (int)Gs;
+    size_t off = 0;
+    P->off_w = off; off = al(off + (size_t)Gs * slab_w);
+    P->off_rowfit = off; off = al(off + (size_t)Gs * ncol * 4 * sizeof(double));
+    P->off_corr = off; off = al(off + (size_t)Gs * ncol * cs);
+    P->ws_bytes = off;
+    return P;
+}
+
+static int run_fused_inner(const xrfthip_plan* P, const void* in, void* out, char* ws, hipStream_t st) {
+    const xrfthip_desc& d = P->d;
+    const long long ncol = d.nx * d.inner;
+    const size_t out_esz = d.out_mode == XRFTHIP_OUT_POWER ? P->rsize : P->csize;
+    for (long long g0 = 0; g0 < d.batch; g0 += P->G) {
+        const long long gc = std::min<long long>(P->G, d.batch - g0);
+        FastM m{};
+        m.in = (const char*)in + (size_t)g0 * d.ny * ncol * P->rsize;
+        m.w2 = ws + P->off_w;
+        m.tw_y = P->tw_fy.p;
+        m.win_y = P->win[0].p ? P->win[0].p : P->ones4096.p;
+        m.win_x = P->winx_exp.p;
+        m.colfit = reinterpret_cast<double*>(ws + P->off_rowfit);
+        m.ny = (int)d.ny; m.nx = (int)ncol; m.nrow_pad = P->y_nrow_pad;
+        m.l_cw = ilog2i(P->n_cw); m.l_rk = ilog2i(P->n_rk);
+        m.detrend = d.detrend; m.nslab = (int)gc; m.nunits = (int)(gc * P->n_nxb);
+        xrfthip_plan::ProfRec* rec = prof_begin(P, "fastn_cols", st);
+        fastn_launch_cols(P, m, st);
+        prof_end(rec, st);
+        if (d.detrend) {
+            rec = prof_begin(P, "fastn_fit_inner", st);
+            const dim3 grid((unsigned)(gc * d.inner)), blk(256);
+            if (P->dbl) { auto k = &fastn_fit_inner_kernel<double>; XRFT_LAUNCH(k, grid, blk, 3 * 256 * sizeof(double), st, (const double*)m.colfit, (const double*)m.win_x, reinterpret_cast<C2<double>*>(ws + P->off_corr), (int)d.nx, (int)d.inner, (int)d.ny, (int)d.detrend); }
+            else { auto k = &fastn_fit_inner_kernel<float>; XRFT_LAUNCH(k, grid, blk, 3 * 256 * sizeof(double), st, (const double*)m.colfit, (const float*)m.win_x, reinterpret_cast<C2<float>*>(ws + P->off_corr), (int)d.nx, (int)d.inner, (int)d.ny, (int)d.detrend); }
+            prof_end(rec, st);
+        }
+        FastNI r{};
+        r.w2 = m.w2; r.corr = ws + P->off_corr; r.what0 = P->ywhat0.p; r.what1 = P->ywhat1.p;
+        r.tw_x = P->tw_fx.p; r.twm = P->n_r.twm.p; r.g = (NGeoPtr)P->n_r.geo_dev.p;
+        r.ph_y = P->fph[0].p; r.ph_x = P->fph[1].p; r.ph_on = (d.out_mode != XRFTHIP_OUT_POWER && P->fph_on) ? 1 : 0;
+        r.out = (char*)out + (size_t)g0 * d.ny * ncol * out_esz;
+        r.ny = (int)d.ny; r.nx = (int)d.nx; r.inner = (int)d.inner; r.nrow_pad = P->y_nrow_pad; r.pitch = (int)P->y_pitch;
+        r.l_cw = m.l_cw; r.l_rk = m.l_rk; r.detrend = d.detrend;
+        r.shift_y = (d.flags & XRFTHIP_SHIFT_Y) ? (int)(d.ny / 2) : 0;
+        r.shift_x = (d.flags & XRFTHIP_SHIFT_X) ? (int)(d.nx / 2) : 0;
+        const NGeo& hg = P->n_r.geo;
+        {
+            const int vw = (int)(16 / out_esz);
+            r.vec = (vw == 1 || (d.inner % vw == 0 && hg.g % vw == 0)) ? 1 : 0;
+            if (!env_ll("XRFTHIP_FI_VEC", 1)) r.vec = 0;
+            r.dbg = (int)env_ll("XRFTHIP_FI_DBG", 0);
+        }
+        r.neb = (int)((d.inner + hg.g - 1) / hg.g);
+        r.nunits = (int)(gc * (d.ny / 2 + 1) * r.neb);
+        r.scale = d.scale;
+        int maxrad = 0;
+        for (int i = 0; i < hg.np; ++i) maxrad = std::max(maxrad, hg.r[i]);
+        const dim3 grid((unsigned)(8 * ((r.nunits + 7) / 8))), blk((unsigned)hg.thr);
+        rec = prof_begin(P, "fastn_irows", st);
+#define NI_(TT, CC) do { if (d.out_mode == XRFTHIP_OUT_POWER) { auto k = &fastn_irows_kernel<TT, 1, CC>; XRFT_LAUNCH(k, grid, blk, P->n_r.lds, st, r); } \
+                         else { auto k = &fastn_irows_kernel<TT, 0, CC>; XRFT_LAUNCH(k, grid, blk, P->n_r.lds, st, r); } } while (0)
+        if (P->dbl) NI_(double, 16); else if (maxrad > 16) NI_(float, 20); else NI_(float, 16);
+#undef NI_
+        prof_end(rec, st);
+        HIP_TRY(hipGetLastError());
+    }
+    return XRFTHIP_OK;
+}
+
 // composite plan for xrfthip_desc.inner > 1 (see xrfthip_plan::inner)
 static int create_inner_plan(xrfthip_plan** plan, const xrfthip_desc& d) {
+    if (xrfthip_plan* F = create_fused_inner(d)) { *plan = F; return XRFTHIP_OK; }
     const uint32_t ok = XRFTHIP_SHIFT_Y | XRFTHIP_SHIFT_X | XRFTHIP_ISHIFT_Y | XRFTHIP_ISHIFT_X | XRFTHIP_FLIP_Y | XRFTHIP_FLIP_X;
     if (d.ndim != 2 || (d.flags & ~ok) || (d.out_mode != XRFTHIP_OUT_COMPLEX && d.out_mode != XRFTHIP_OUT_POWER)) return XRFTHIP_BAD_ARG;
     if (d.inner > (1LL << 30) || d.mid > (1LL << 30) || d.nx * d.inner > (1LL << 30) || d.mid * d.nx * d.inner > (1LL << 30) || d.batch * d.mid > (1LL << 40)) return XRFTHIP_BAD_ARG;
@@ -3148,6 +3312,7 @@ int xrfthip_plan_uses_bluestein(const xrfthip_plan* plan) {
     if (plan->sub_x) return xrfthip_plan_uses_bluestein(plan->sub_x) || xrfthip_plan_uses_bluestein(plan->sub_y);
     if (plan->fastgy) return plan->gy_blue_m > 0;
     if (plan->fastn) return plan->n_blue_m > 0;
+    if (plan->fusedi) return 0;
     if (plan->fastg || plan->fasts || plan->fastr || plan->fastmx || plan->fastmy || plan->fastm || plan->fast1d || plan->fast4096) return 0;  // (the generic passes of such a plan never run)
     for (const Pass& ps : plan->passes) if (ps.g.blue_n > 0) return 1;
     for (const Pass& ps : plan->passes_f0) if (ps.g.blue_n > 0) return 1;
@@ -3160,6 +3325,7 @@ int xrfthip_plan_kernel_info(const xrfthip_plan* plan, int32_t* kind, int32_t* p
     const bool two = P->d.out_mode == XRFTHIP_OUT_CROSS || P->d.out_mode == XRFTHIP_OUT_PHASE;
     int k = XRFTHIP_K_GENERIC, n = 0;
     if (P->sub_x) k = XRFTHIP_K_COMPOSITE;
+    else if (P->fusedi) { k = XRFTHIP_K_FASTN; n = P->n_cw; }
     else if (P->fastg) { k = P->g_one_d ? XRFTHIP_K_FASTG_ROWS : XRFTHIP_K_FASTG; n = P->g_one_d ? P->g_rows : 1; }
     else if (P->fasts) { k = XRFTHIP_K_FASTS; n = 1; }
     else if (P->fastr) { k = XRFTHIP_K_FASTR; n = 1; }
@@ -3181,6 +3347,20 @@ int xrfthip_plan_describe(const xrfthip_plan* plan, char* buf, size_t buflen) {
     if (!plan || !buf || !buflen) return XRFTHIP_BAD_ARG;
     std::string s;
     const xrfthip_desc& d = plan->d;
+    if (plan->fusedi) {
+        auto rads = [](const NGeo& g) { std::string t; for (int i = 0; i < g.np; ++i) t += (i ? "x" : "") + std::to_string(g.r[i]); return t; };
+        const NGeo &gc = plan->n_c.geo, &gr = plan->n_r.geo;
+        appendf(s, "xrfthip plan: [batch %lld][ny %lld][nx %lld][inner %lld] dtype=%d mode=%d detrend=%d flags=0x%x ws=%zuB\n"
+                   "  [inner layout] [fastn fused] two passes where the axes lie, no transposed copy: cols: the [ny][nx inner] view, %d thr, %d packed column pairs (FFT%d r%s), lds=%zuB -> "
+                   "W2[slab][%d/%d][%d][%d][%d] complex -> fit per (slab, inner element) -> rows: %d thr, %d inner elements of one row ky per workgroup (FFT%d r%s), lds=%zuB, plane added "
+                   "back in the spectral domain, (ky, kx, e) and its Hermitian twin stored as runs of %d elements\n",
+                (long long)d.batch, (long long)d.ny, (long long)d.nx, (long long)plan->inner, d.dtype, d.out_mode, d.detrend, d.flags, plan->ws_bytes,
+                gc.thr, gc.g, gc.n, rads(gc).c_str(), plan->n_c.lds, plan->y_nrow_pad, plan->n_rk, plan->n_nxb, plan->n_rk, plan->n_cw, gr.thr, gr.g, gr.n, rads(gr).c_str(), plan->n_r.lds, gr.g);
+        const size_t n = std::min(buflen - 1, s.size());
+        memcpy(buf, s.data(), n);
+        buf[n] = 0;
+        return (int)n;
+    }
     if (plan->sub_x) {
         appendf(s, "xrfthip plan: [batch %lld][ny %lld][mid %lld][nx %lld][inner %lld] dtype=%d mode=%d detrend=%d flags=0x%x ws=%zuB\n  [inner layout] no transposed copy: %sx where it lies, then y\n",
                 (long long)d.batch, (long long)d.ny, (long long)plan->mid, (long long)d.nx, (long long)plan->inner, d.dtype, d.out_mode, d.detrend, d.flags, plan->ws_bytes,
@@ -3323,6 +3503,10 @@ int xrfthip_exec(const xrfthip_plan* plan, const void* d_in0, const void* d_in1,
     if (cross && !d_in1) return XRFTHIP_BAD_ARG;
     if (!d_out && !(d.flags & XRFTHIP_NO_SPECTRUM_OUT)) return XRFTHIP_BAD_ARG;
     if (iso && (!d_iso || !P->binmap.p)) return d_iso ? XRFTHIP_MISSING_TABLE : XRFTHIP_BAD_ARG;
+    if (P->fusedi) {
+        if (ws_bytes < P->ws_bytes || !d_workspace) return XRFTHIP_WORKSPACE_TOO_SMALL;
+        return d.batch == 0 ? XRFTHIP_OK : run_fused_inner(P, d_in0, d_out, (char*)d_workspace, (hipStream_t)stream);
+    }
     if (P->sub_x) {
         if (ws_bytes < P->ws_bytes || !d_workspace) return XRFTHIP_WORKSPACE_TOO_SMALL;
         return d.batch == 0 ? XRFTHIP_OK : run_inner_plan(P, d_in0, d_out, (char*)d_workspace, (hipStream_t)stream);
