@@ -625,10 +625,16 @@ def test_small_slabs_of_any_smooth_shape_in_one_pass(shape, dtype, full):
 @pytest.mark.parametrize("shape,dtype", [((3, 96, 40), "float32"), ((2, 250, 36), "float64"), ((2, 45, 22), "float32"), ((1, 1250, 8), "float32"), ((2, 120, 50), "float64"),
                                          ((30, 48, 6), "float32"), ((2, 27, 130), "float64"), ((4, 150, 2), "float32"),
                                          # a prime factor with no butterfly: Bluestein inside the tile (365 = 5 x 73 days, 730, 77 = 7 x 11, 131)
-                                         ((2, 365, 20), "float32"), ((1, 730, 10), "float64"), ((3, 77, 34), "float64"), ((2, 131, 18), "float32")])
+                                         ((2, 365, 20), "float32"), ((1, 730, 10), "float64"), ((3, 77, 34), "float64"), ((2, 131, 18), "float32"), ((1, 262, 10), "float64"),
+                                         # round 5: ONE prime 17 ... 127 with a smooth p - 1 (73: a year of days; 61: a leap year; 29: radix 7 in the inverse passes; 97 alone): the
+                                         # prime-factor form with Rader's algorithm along the prime
+                                         ((2, 366, 12), "float64"), ((2, 97, 10), "float32"), ((1, 1460, 6), "float32"), ((2, 58, 14), "float64")])
 def test_one_axis_not_contiguous_any_smooth_length(shape, dtype):
     """fastg.h, fastgy_kernel: `dim="time"` calls on lengths outside the mixed-radix table."""
     cases.run_yonly_any_length_cases(shape, dtype)
+    d = next(reversed(api._plan_cache.values())).describe()
+    n = shape[1]
+    assert ("Rader" in d) == (n in (365, 730, 366, 97, 1460, 58)) and ("Bluestein" in d) == (n in (131, 262)), d
 
 
 @pytest.mark.parametrize("shape,dtype", [((37, 250), "float32"), ((5, 96), "float64"), ((3, 4, 125), "float32"), ((2, 750), "float64"), ((300, 50), "float32"), ((2, 2250), "float32"),

@@ -1027,7 +1027,8 @@ def test_small_slabs_of_any_smooth_shape_in_one_pass(shape, dtype):
 
 @pytest.mark.parametrize("shape,dtype", [((3, 96, 4000), "float32"), ((2, 250, 3600), "float64"), ((5, 45, 2222), "float32"), ((1, 1250, 1024), "float32"), ((2, 120, 5000), "float64"),
                                          ((30, 48, 600), "float32"), ((2, 27, 1300), "float64"), ((4, 150, 2), "float32"), ((2, 2500, 256), "float32"), ((1, 3000, 64), "float64"),
-                                         ((2, 365, 2000), "float32"), ((1, 730, 1000), "float64"), ((3, 77, 340), "float64"), ((2, 131, 1800), "float32"), ((1, 1460, 512), "float64"), ((1, 3650, 128), "float32")])
+                                         ((2, 365, 2000), "float32"), ((1, 730, 1000), "float64"), ((3, 77, 340), "float64"), ((2, 131, 1800), "float32"), ((1, 1460, 512), "float64"), ((1, 3650, 128), "float32"),
+                                         ((2, 366, 1200), "float64"), ((2, 97, 1000), "float32"), ((1, 1460, 600), "float32"), ((2, 58, 1400), "float64"), ((1, 262, 1000), "float64"), ((1, 2920, 256), "float32")])
 def test_one_axis_not_contiguous_any_smooth_length(shape, dtype):
     """fastg.h, fastgy_kernel: `dim="time"` calls on lengths outside the mixed-radix table."""
     cases.run_yonly_any_length_cases(shape, dtype)

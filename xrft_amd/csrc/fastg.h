@@ -130,10 +130,14 @@ __device__ __forceinline__ void fastg_cols_pass_inv(C2<T>* tile, int ncols, int 
         case 4: fastg_pass_cols_inv<T, 4>(tile, ncols, len, rs, L, tid, nthr, tw); break;
         case 5: fastg_pass_cols_inv<T, 5>(tile, ncols, len, rs, L, tid, nthr, tw); break;
         case 6: fastg_pass_cols_inv<T, 6>(tile, ncols, len, rs, L, tid, nthr, tw); break;
+        case 7: fastg_pass_cols_inv<T, 7>(tile, ncols, len, rs, L, tid, nthr, tw); break;
         case 8: fastg_pass_cols_inv<T, 8>(tile, ncols, len, rs, L, tid, nthr, tw); break;
         case 9: fastg_pass_cols_inv<T, 9>(tile, ncols, len, rs, L, tid, nthr, tw); break;
         case 10: fastg_pass_cols_inv<T, 10>(tile, ncols, len, rs, L, tid, nthr, tw); break;
+        case 11: fastg_pass_cols_inv<T, 11>(tile, ncols, len, rs, L, tid, nthr, tw); break;
         case 12: fastg_pass_cols_inv<T, 12>(tile, ncols, len, rs, L, tid, nthr, tw); break;
+        case 13: fastg_pass_cols_inv<T, 13>(tile, ncols, len, rs, L, tid, nthr, tw); break;
+        case 14: fastg_pass_cols_inv<T, 14>(tile, ncols, len, rs, L, tid, nthr, tw); break;
         case 15: fastg_pass_cols_inv<T, 15>(tile, ncols, len, rs, L, tid, nthr, tw); break;
         default: fastg_pass_cols_inv<T, 16>(tile, ncols, len, rs, L, tid, nthr, tw); break;
     }
@@ -551,11 +555,24 @@ struct FastGY {
     // inverse transforms (xrft.ifft along the axis, xrft.py:479-646; complex input): conj(FFT(conj(z))); row i of the tile is source row i + ishift_in (mod ny:
     // the ifftshift of an fftshifted spectrum), ph_in: ph_y multiplies the INPUT at its source position (the lag's phase, xrft.py:574-576)
     int inv, ishift_in, ph_in;
+    // ny = q p, p ONE prime 17 ... 127 with a smooth p - 1, q smooth and prime to p (365 = 5 x 73 days, 1460 = 20 x 73 six-hourly samples, 366 = 6 x 61):
+    // the prime-factor form -- input row i = n1 p + n2 q (mod ny), frequency k = (k mod q, k mod p): a q x p transform with no twiddles between the two
+    // dimensions -- with RADER's algorithm along p: the tile is [p][q][G], block j < p - 1 holds n2 = g^-j (g a generator of the units mod p), block
+    // p - 1 holds n2 = 0;  ry/tw_y (W_ny) run along q inside every block (the tail passes of a length-ny transform), then along j over the first p - 1
+    // blocks: rp forward passes (tw_p = W_(p-1)) -> * rad_b, the sum of the p - 1 samples and the n2 = 0 sample exchanged at frequency 0 -> the inverse
+    // passes: X[k1][g^k] at block k, X[k1][0] at block p - 1.  perm_in[i] = row of input i; rev_y[k] = row of frequency k.  ~2.4 transforms of the
+    // length where the chirp convolution takes two of 2.1 x the length: (1460, 128, 256) float64 16 -> GFFT/s, see DESIGN.md.
+    int rad_p, rad_q, nrp, rp[kFastGMaxPasses];
+    const void* tw_p;            // W_(p-1)^k (complex T)
+    const void* rad_b;           // FFT_(p-1)(W_p^(g^m)) / (p - 1) at the row the forward passes leave each frequency (complex T)
+    const unsigned* perm_in;
 };
 
-// MODE 1: power spectrum (real T out), 0: complex spectrum; BLUE: the Bluestein form (its inverse passes cost the plain form 25 registers: a kernel of its own)
-template <typename T, int MODE, bool BLUE>
+// MODE 1: power spectrum (real T out), 0: complex spectrum; FORM 1: the Bluestein form (its inverse passes cost the plain form 25 registers: a kernel of its own),
+// FORM 2: the prime-factor form with Rader's algorithm along the prime
+template <typename T, int MODE, int FORM>
 __global__ void __launch_bounds__(256) fastgy_kernel(FastGY p) {
+    constexpr bool BLUE = FORM == 1, RADER = FORM == 2;
     typedef C2<T> CT;
     XRFT_DYN_SMEM(smem_raw);
     CT* tile = reinterpret_cast<CT*>(smem_raw);
@@ -568,7 +585,14 @@ __global__ void __launch_bounds__(256) fastgy_kernel(FastGY p) {
     const bool twin_lds = !BLUE || p.tw_lds;  // (the plain form always)
     CT* twl = reinterpret_cast<CT*>(tb); tb += twin_lds ? (size_t)nrow * sizeof(CT) : 0;
     T* wys = reinterpret_cast<T*>(tb); tb += (size_t)ny * sizeof(T);
-    unsigned short* revy = reinterpret_cast<unsigned short*>(tb);
+    unsigned short* revy = reinterpret_cast<unsigned short*>(tb); tb += (size_t)ny * 2;
+    tb += (size_t)(-(reinterpret_cast<intptr_t>(tb) - reinterpret_cast<intptr_t>(smem_raw))) & 15;  // (what follows holds complex values: 16-byte aligned)
+    unsigned short* pin = reinterpret_cast<unsigned short*>(tb); tb += RADER ? (((size_t)ny * 2 + 15) & ~(size_t)15) : 0;
+    CT* twp = reinterpret_cast<CT*>(tb);  // (RADER: W_(p-1))
+    if (RADER) {
+        for (int k = tid; k < ny; k += nthr) pin[k] = (unsigned short)p.perm_in[k];
+        for (int k = tid; k < p.rad_p - 1; k += nthr) twp[k] = reinterpret_cast<const CT*>(p.tw_p)[k];
+    }
     const CT* twy = twl;
     if (BLUE && !p.tw_lds) twy = reinterpret_cast<const CT*>(p.tw_y);
     if (twin_lds) for (int k = tid; k < nrow; k += nthr) twl[k] = reinterpret_cast<const CT*>(p.tw_y)[k];
@@ -608,7 +632,7 @@ __global__ void __launch_bounds__(256) fastgy_kernel(FastGY p) {
                 const T w = reinterpret_cast<const T*>(p.win_y)[i];
                 z = mk<T>(z.re * w, z.im * w);
             }
-            tile[i * G + g] = z;
+            tile[(RADER ? (int)pin[i] : i) * G + g] = z;
         }
         if (p.detrend) {
 #pragma unroll
@@ -627,11 +651,12 @@ __global__ void __launch_bounds__(256) fastgy_kernel(FastGY p) {
             __syncthreads();
             const double m0 = coef[g * 4], b0 = coef[g * 4 + 1], m1 = coef[g * 4 + 2], b1 = coef[g * 4 + 3];
             for (int i = rq; i < ny; i += RQ) {  // (each thread revisits the elements it loaded)
-                CT z = tile[i * G + g];
+                const int slot = (RADER ? (int)pin[i] : i) * G + g;
+                CT z = tile[slot];
                 const double ri = (double)i - ibar;
                 z = mk<T>((T)((double)z.re - fma(b0, ri, m0)), (T)((double)z.im - fma(b1, ri, m1)));
                 if (p.win_y) { const T w = wys[i]; z = mk<T>(z.re * w, z.im * w); }
-                tile[i * G + g] = z;
+                tile[slot] = z;
             }
         }
         if (BLUE) {  // x conj(c), zero padding up to blue_m rows
@@ -639,9 +664,9 @@ __global__ void __launch_bounds__(256) fastgy_kernel(FastGY p) {
             for (int i = rq; i < nrow; i += RQ) tile[i * G + g] = i < ny ? cmulc(tile[i * G + g], ch[i]) : mk<T>((T)0, (T)0);
         }
         __syncthreads();
-        // ---- the passes of length ny (blue_m) over the G sequences (lanes along the sequences)
+        // ---- the passes of length ny (blue_m) over the G sequences (lanes along the sequences); RADER: along q inside every block of q rows
         {
-            int L = nrow;
+            int L = RADER ? p.rad_q : nrow;
             for (int ps = 0; ps < p.nry; ++ps) {
                 fastg_cols_pass<T>(tile, G, nrow, G, p.ry[ps], L, tid, nthr, twy);
                 L /= p.ry[ps];
@@ -661,6 +686,36 @@ __global__ void __launch_bounds__(256) fastgy_kernel(FastGY p) {
             }
             for (int i = rq; i < ny; i += RQ) tile[i * G + g] = cmulc(tile[i * G + g], ch[i]);
             __syncthreads();
+        }
+        if (RADER) {  // along the prime: a cyclic convolution of the p - 1 blocks with n2 != 0 (q G sequences side by side, element stride q G)
+            const int P1 = p.rad_p - 1, qg = p.rad_q * G;
+            const CT* __restrict__ bh = reinterpret_cast<const CT*>(p.rad_b);
+            int L = P1;
+            for (int ps = 0; ps < p.nrp; ++ps) {
+                fastg_cols_pass<T>(tile, qg, P1, qg, p.rp[ps], L, tid, nthr, twp);
+                L /= p.rp[ps];
+                __syncthreads();
+            }
+            const float inv_qg = 1.0f / (float)qg;
+            for (int e = tid; e < P1 * qg; e += nthr) {
+                const int jr = fdiv(e, inv_qg);
+                CT a = tile[e];
+                const CT prod = cmul(a, bh[jr]);
+                if (jr == 0) {  // frequency 0 of the convolution = the sum of the samples with n2 != 0: X[.][0] = x0 + sum, and x0 joins every other frequency
+                    const int zc = P1 * qg + e;
+                    const CT z = tile[zc];
+                    tile[zc] = mk<T>(z.re + a.re, z.im + a.im);
+                    a = mk<T>(prod.re + z.re, prod.im + z.im);
+                } else a = prod;
+                tile[e] = a;
+            }
+            __syncthreads();
+            int Li = 1;
+            for (int ip = p.nrp - 1; ip >= 0; --ip) {
+                Li *= p.rp[ip];
+                fastg_cols_pass_inv<T>(tile, qg, P1, qg, p.rp[ip], Li, tid, nthr, twp);
+                __syncthreads();
+            }
         }
         // ---- out: row orow of the C columns = frequency k of the two spectra packed in every sequence
         const int tot = ny << lc;

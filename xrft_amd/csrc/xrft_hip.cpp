@@ -358,6 +358,9 @@ struct xrfthip_plan {
     // ... and ONE pass for one transform axis that is not the contiguous one (XRFTHIP_AXIS_Y), any smooth length, real input (fastg.h: fastgy_kernel)
     bool fastgy = false;
     int gy_G = 0, gy_thr = 0, gy_blue_m = 0;  // gy_blue_m: Bluestein inside the tile on blue_m rows (a prime factor of ny with no butterfly)
+    int gy_rad_p = 0;                         // ... or, ny = q p with ONE such prime p <= 127 and p - 1 smooth: the prime-factor form with Rader's algorithm along p
+    std::vector<int> gy_rp;                   // the radices of p - 1
+    DevBuf gy_twp, gy_radb, gy_permin;
     bool gy_tw_lds = true;
     size_t gy_lds = 0;
     DevBuf gy_bluec, gy_blueb;
@@ -863,8 +866,9 @@ void set_kernel_attrs_once() {
     SETF((fastg_kernel<float, 0, false>)); SETF((fastg_kernel<float, 1, false>)); SETF((fastg_kernel<double, 0, false>)); SETF((fastg_kernel<double, 1, false>));
     SETF((fastg_kernel<float, 2, false>)); SETF((fastg_kernel<double, 2, false>));
     SETF((fastg_kernel<float, 0, true>)); SETF((fastg_kernel<float, 1, true>)); SETF((fastg_kernel<double, 0, true>)); SETF((fastg_kernel<double, 1, true>));
-    SETF((fastgy_kernel<float, 0, false>)); SETF((fastgy_kernel<float, 1, false>)); SETF((fastgy_kernel<double, 0, false>)); SETF((fastgy_kernel<double, 1, false>));
-    SETF((fastgy_kernel<float, 0, true>)); SETF((fastgy_kernel<float, 1, true>)); SETF((fastgy_kernel<double, 0, true>)); SETF((fastgy_kernel<double, 1, true>));
+    SETF((fastgy_kernel<float, 0, 0>)); SETF((fastgy_kernel<float, 1, 0>)); SETF((fastgy_kernel<double, 0, 0>)); SETF((fastgy_kernel<double, 1, 0>));
+    SETF((fastgy_kernel<float, 0, 1>)); SETF((fastgy_kernel<float, 1, 1>)); SETF((fastgy_kernel<double, 0, 1>)); SETF((fastgy_kernel<double, 1, 1>));
+    SETF((fastgy_kernel<float, 0, 2>)); SETF((fastgy_kernel<float, 1, 2>)); SETF((fastgy_kernel<double, 0, 2>)); SETF((fastgy_kernel<double, 1, 2>));
 #define SETN(TT, CC) SETF((fastn_cols_kernel<TT, false, CC>)); SETF((fastn_cols_kernel<TT, true, 16>)); \
                      SETF((fastn_rows_kernel<TT, 0, false, CC>)); SETF((fastn_rows_kernel<TT, 1, false, CC>)); SETF((fastn_rows_kernel<TT, 1, true, CC>)); SETF((fastn_rows_kernel<TT, 2, false, CC>)); \
                      SETF((fastn_rows_kernel<TT, 2, true, CC>)); SETF((fastn_rows_kernel<TT, 3, false, CC>))
@@ -2297,15 +2301,39 @@ static int fastg_build_iso(xrfthip_plan* P, const int32_t* bm) {
 
 // one transform axis that is not the contiguous one, any smooth length (fastg.h: fastgy_kernel): G complex sequences = 2 G real columns per workgroup,
 // the widest power of two (<= 128 bytes of a row) whose tile leaves three workgroups on a CU, or the widest that fits at all
+// n = q p, p ONE prime 17 ... 127 whose p - 1 the butterflies factor, q smooth and prime to p: the prime-factor form with Rader's algorithm along p (fastg.h)
+static bool rader_split(long long n, int& p_out, std::vector<int>& rq, std::vector<int>& rp) {
+    if (!env_ll("XRFTHIP_RADER", 1)) return false;
+    for (int p = 17; p <= 127; ++p) {
+        bool prime = true;
+        for (int f = 2; f * f <= p; ++f) if (p % f == 0) { prime = false; break; }
+        if (!prime || n % p) continue;
+        const long long q = n / p;
+        if (q % p == 0) return false;  // (p^2)
+        rq.clear(); rp.clear();
+        if (q > 1 && !fastg_factor(q, rq)) return false;  // (a second prime without a butterfly)
+        if (!fastg_factor(p - 1, rp)) return false;
+        for (int r : rq) if (r > 16) return false;
+        for (int r : rp) if (r > 16) return false;
+        if ((int)rq.size() > kFastGMaxPasses || (int)rp.size() > kFastGMaxPasses) return false;
+        p_out = p;
+        return true;
+    }
+    return false;
+}
+
 static bool fastgy_try(xrfthip_plan* P) {
     const xrfthip_desc& d = P->d;
     const bool two_f = d.out_mode == XRFTHIP_OUT_CROSS || d.out_mode == XRFTHIP_OUT_PHASE;
     if (d.ndim != 2 || (!P->cplx_in && !two_f && (d.nx & 1)) || d.ny < 2 || d.ny > 16384 || d.batch * ((d.nx + 3) / 4) >= (1LL << 31)) return false;
     bool gy = false;
-    std::vector<int> ry;
+    std::vector<int> ry, rp;
     long long m = d.ny;  // rows of the tile = length of the passes: ny, or the Bluestein length when a prime factor of ny has no butterfly
-    int blue_m = 0;
-    if (!fastg_factor(d.ny, ry)) {
+    int blue_m = 0, rad_p = 0;
+    if (!fastg_factor(d.ny, ry) && d.ny <= 4096 && rader_split(d.ny, rad_p, ry, rp)) {
+        // (ry: the radices of q; the tile holds ny rows)
+    } else if (!fastg_factor(d.ny, ry)) {
+        rad_p = 0;
         for (m = 2 * d.ny - 1;; ++m) {
             long long q = m;
             while (q % 2 == 0) q /= 2;
@@ -2322,7 +2350,7 @@ static bool fastgy_try(xrfthip_plan* P) {
     const int thr = 256;
     auto lds_of = [&](int G, bool tw_lds) {
         return (((size_t)m * G * P->csize + 15) & ~(size_t)15) + (tw_lds ? (size_t)m * P->csize : 0) + (size_t)thr * 4 * sizeof(double) + (size_t)G * 4 * sizeof(double) +
-               (size_t)d.ny * P->rsize + (size_t)d.ny * 2 + 16;
+               (size_t)d.ny * P->rsize + (size_t)d.ny * 2 + 16 + (rad_p ? (((size_t)d.ny * 2 + 15) & ~(size_t)15) + (size_t)rad_p * P->csize + 16 : 0);
     };
     const int gmax = (int)(128 / P->csize);  // 128 bytes of a row: 16 float32 pairs, 8 float64 pairs
     int G = 0;
@@ -2337,7 +2365,61 @@ static bool fastgy_try(xrfthip_plan* P) {
     if (forced >= 1 && forced <= gmax && !(forced & (forced - 1)) && lds_of((int)forced, tw_lds) <= kLdsMax - 1024) G = (int)forced;
     if (!G) return false;
     P->g_ry = ry; P->gy_G = G; P->gy_thr = thr; P->gy_lds = lds_of(G, tw_lds); P->gy_blue_m = blue_m; P->gy_tw_lds = tw_lds;
+    P->gy_rad_p = rad_p; P->gy_rp = rp;
     return true;
+}
+// the tables of the prime-factor / Rader form (fastg.h, FastGY::rad_p): the row of every input sample and of every frequency, W_(p-1), the transformed kernel
+template <typename T> static int fastgy_rader_tables(xrfthip_plan* P) {
+    const int n = (int)P->d.ny, p = P->gy_rad_p, q = n / p, P1 = p - 1;
+    auto powmod = [](long long b, long long e, long long m) { long long r = 1; b %= m; while (e > 0) { if (e & 1) r = r * b % m; b = b * b % m; e >>= 1; } return r; };
+    int g = 0;  // the smallest generator of the units mod p
+    for (int c = 2; c < p && !g; ++c) {
+        bool ok = true;
+        for (int f = 2; f <= P1 && ok; ++f) if (P1 % f == 0) { bool pf = true; for (int t = 2; t * t <= f; ++t) if (f % t == 0) pf = false; if (pf && powmod(c, P1 / f, p) == 1) ok = false; }
+        if (ok) g = c;
+    }
+    if (!g) return XRFTHIP_BAD_ARG;
+    std::vector<int> dlog((size_t)p, 0), gpow((size_t)P1);
+    { long long v = 1; for (int m = 0; m < P1; ++m) { gpow[(size_t)m] = (int)v; dlog[(size_t)v] = m; v = v * g % p; } }
+    // digit reversals of the passes along q and along p - 1
+    std::vector<unsigned> revq, revp;
+    DevBuf scratch;
+    int rc = fastg_rev(P->g_ry, q, scratch, revq);
+    if (!rc) rc = fastg_rev(P->gy_rp, P1, scratch, revp);
+    if (rc) return rc;
+    // inverses for the index maps: i = n1 p + n2 q (mod n) -> n1 = i p^-1 (mod q), n2 = i q^-1 (mod p)
+    long long pinv_q = 0, qinv_p = 0;
+    for (int t = 0; t < q; ++t) if ((long long)t * p % q == 1 % q) { pinv_q = t; break; }
+    for (int t = 0; t < p; ++t) if ((long long)t * q % p == 1) { qinv_p = t; break; }
+    std::vector<unsigned> pin((size_t)n), pout((size_t)n);
+    for (int i = 0; i < n; ++i) {
+        const int n1 = q > 1 ? (int)((long long)i * pinv_q % q) : 0, n2 = (int)((long long)i * qinv_p % p);
+        const int j = n2 == 0 ? P1 : (P1 - dlog[(size_t)n2]) % P1;  // g^-j = n2
+        pin[(size_t)i] = (unsigned)(j * q + n1);
+    }
+    for (int k = 0; k < n; ++k) {
+        const int k1 = k % q, k2 = k % p;
+        const int blk = k2 == 0 ? P1 : dlog[(size_t)k2];  // the inverse passes leave X[.][g^k] at block k
+        pout[(size_t)k] = (unsigned)(blk * q + (int)revq[(size_t)k1]);
+    }
+    // B = FFT_(p-1)(b) / (p - 1), b[m] = W_p^(g^m), by the definition in long double
+    const long double pi2 = 2.0L * 3.14159265358979323846264338327950288L;
+    std::vector<C2<T>> bh((size_t)P1);
+    for (int f = 0; f < P1; ++f) {
+        long double sr = 0, si = 0;
+        for (int m = 0; m < P1; ++m) {
+            const long double a = -pi2 * ((long double)gpow[(size_t)m] / (long double)p + (long double)((long long)f * m % P1) / (long double)P1);
+            sr += cosl(a); si += sinl(a);
+        }
+        bh[(size_t)revp[(size_t)f]].re = (T)(sr / P1);
+        bh[(size_t)revp[(size_t)f]].im = (T)(si / P1);
+    }
+    P->g_hrevy = pout;
+    rc = P->g_revy.upload(pout.data(), pout.size() * sizeof(unsigned));
+    if (!rc) rc = P->gy_permin.upload(pin.data(), pin.size() * sizeof(unsigned));
+    if (!rc) rc = P->gy_radb.upload(bh.data(), bh.size() * sizeof(C2<T>));
+    if (!rc) rc = build_twiddle<T>(P->gy_twp, P1, P1);
+    return rc;
 }
 // the tables of the Bluestein form: c[k] = exp(i pi k^2 / n), k < n, and FFT_m(chirp kernel) / m at the row the forward passes leave each frequency
 template <typename T> static int fastgy_blue_tables(xrfthip_plan* P) {
@@ -2378,6 +2460,10 @@ static int run_fastgy(const xrfthip_plan* P, const void* in, const void* in_b, v
     for (int i = 0; i < p.nry; ++i) p.ry[i] = P->g_ry[(size_t)i];
     p.tw_y = P->g_twy.p; p.rev_y = (const unsigned*)P->g_revy.p;
     p.blue_m = P->gy_blue_m; p.blue_c = P->gy_bluec.p; p.blue_b = P->gy_blueb.p; p.tw_lds = P->gy_tw_lds ? 1 : 0;
+    p.rad_p = P->gy_rad_p; p.rad_q = P->gy_rad_p ? (int)(d.ny / P->gy_rad_p) : 0;
+    p.nrp = (int)P->gy_rp.size();
+    for (int i = 0; i < p.nrp; ++i) p.rp[i] = P->gy_rp[(size_t)i];
+    p.tw_p = P->gy_twp.p; p.rad_b = P->gy_radb.p; p.perm_in = (const unsigned*)P->gy_permin.p;
     p.win_y = P->win[0].p;
     p.ph_y = P->fph[0].p; p.ph_on = (d.out_mode != XRFTHIP_OUT_POWER && P->fph_on && !(d.flags & XRFTHIP_PHASE_IN)) ? 1 : 0;
     p.inv = (d.flags & XRFTHIP_INVERSE) ? 1 : 0;
@@ -2388,8 +2474,9 @@ static int run_fastgy(const xrfthip_plan* P, const void* in, const void* in_b, v
     p.scale = d.scale;
     const dim3 grid((unsigned)std::min<long long>(p.nunits, 0x7fffffffLL)), blk((unsigned)P->gy_thr);
     xrfthip_plan::ProfRec* rec = prof_begin(P, "fastg_yonly", st);
-#define GY_(TT, MM) do { if (P->gy_blue_m) { auto k = &fastgy_kernel<TT, MM, true>; XRFT_LAUNCH(k, grid, blk, P->gy_lds, st, p); } \
-                         else { auto k = &fastgy_kernel<TT, MM, false>; XRFT_LAUNCH(k, grid, blk, P->gy_lds, st, p); } } while (0)
+#define GY_(TT, MM) do { if (P->gy_blue_m) { auto k = &fastgy_kernel<TT, MM, 1>; XRFT_LAUNCH(k, grid, blk, P->gy_lds, st, p); } \
+                         else if (P->gy_rad_p) { auto k = &fastgy_kernel<TT, MM, 2>; XRFT_LAUNCH(k, grid, blk, P->gy_lds, st, p); } \
+                         else { auto k = &fastgy_kernel<TT, MM, 0>; XRFT_LAUNCH(k, grid, blk, P->gy_lds, st, p); } } while (0)
     const bool cplx = d.out_mode != XRFTHIP_OUT_POWER;  // (complex spectrum, cross spectrum, cross phase: MODE 0)
     if (P->dbl) { if (cplx) GY_(double, 0); else GY_(double, 1); } else { if (cplx) GY_(float, 0); else GY_(float, 1); }
 #undef GY_
@@ -3127,7 +3214,8 @@ int xrfthip_plan_create(xrfthip_plan** plan, const xrfthip_desc* desc) {
         if (P->fastgy) {
             const long long m = P->gy_blue_m ? P->gy_blue_m : d.ny;  // length of the passes
             int rcg = P->dbl ? build_twiddle<double>(P->g_twy, m, m) : build_twiddle<float>(P->g_twy, m, m);
-            if (!rcg) rcg = fastg_rev(P->g_ry, (int)m, P->g_revy, P->g_hrevy);
+            if (!rcg && !P->gy_rad_p) rcg = fastg_rev(P->g_ry, (int)m, P->g_revy, P->g_hrevy);
+            if (!rcg && P->gy_rad_p) rcg = P->dbl ? fastgy_rader_tables<double>(P) : fastgy_rader_tables<float>(P);
             if (!rcg && P->gy_blue_m) rcg = P->dbl ? fastgy_blue_tables<double>(P) : fastgy_blue_tables<float>(P);
             if (rcg) { delete P; return rcg; }
         }
@@ -3432,6 +3520,13 @@ int xrfthip_plan_describe(const xrfthip_plan* plan, char* buf, size_t buflen) {
                 plan->gy_thr, plan->gy_G, plan->cplx_in ? "complex columns" : onecol ? "columns of each of the two fields" : "packed column pairs",
                 (int)((plan->cplx_in ? plan->csize : onecol ? plan->rsize : 2 * plan->rsize) * (size_t)plan->gy_G), (long long)(plan->gy_blue_m ? plan->gy_blue_m : plan->d.ny), rys.c_str(), plan->gy_lds,
                 onecol ? "" : " + both columns' spectra", (plan->d.flags & XRFTHIP_INVERSE) ? "; inverse (conj in, conj out)" : "");
+        if (plan->gy_rad_p) {
+            std::string rps;
+            for (int r : plan->gy_rp) rps += (rps.empty() ? "" : "x") + std::to_string(r);
+            appendf(s, "  [fastg y-only Rader] %lld = %lld x %d: the prime-factor form, no twiddles between the two dimensions; along the prime %d a cyclic convolution of %d = %s points "
+                       "(forward passes, * the transformed kernel, inverse passes) inside the tile\n",
+                    (long long)plan->d.ny, (long long)(plan->d.ny / plan->gy_rad_p), plan->gy_rad_p, plan->gy_rad_p, plan->gy_rad_p - 1, rps.c_str());
+        }
         if (plan->gy_blue_m)
             appendf(s, "  [fastg y-only Bluestein] %lld points as a circular convolution of %d inside the tile (chirp products, forward and inverse passes)%s\n",
                     (long long)plan->d.ny, plan->gy_blue_m, plan->gy_tw_lds ? "" : "; twiddles from memory");
