@@ -1050,7 +1050,9 @@ def test_inverse_transforms_on_the_one_pass_kernels(shape, dtype):
 @pytest.mark.gpu
 @pytest.mark.parametrize("shape,dtype", [((2, 1215, 700), "float32"), ((2, 721, 1440), "float32"), ((1, 3000, 3000), "float64"), ((2, 2200, 1100), "float32"), ((2, 750, 1500), "float64"),
                                          ((2, 1001, 343), "float64"), ((1, 2187, 625), "float32"), ((2, 343, 1331), "float32"), ((1, 4800, 1250), "float32"), ((2, 1013, 768), "float64"),
-                                         ((1, 2401, 1440), "float64"), ((3, 675, 945), "float32")])
+                                         ((1, 2401, 1440), "float64"), ((3, 675, 945), "float32"),
+                                         # the Rader columns (721 = 7 x 103 in float32: the 17-point butterfly; float64 keeps the chirp convolution), 365 = 5 x 73, 1460
+                                         ((2, 721, 1440), "float64"), ((2, 365, 720), "float64"), ((2, 1460, 600), "float32"), ((2, 1098, 540), "float32")])
 def test_large_slabs_off_the_tables_with_the_lengths_as_data(shape, dtype):
     """csrc/fastn.h: both passes with run-time radices (7 / 11 / 13 butterflies, odd lengths, 4+ passes), mixed with a table kernel on one side, and the chirp
     convolution for the columns (721 = 7 x 103, 1013 prime)."""

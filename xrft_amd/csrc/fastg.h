@@ -122,8 +122,63 @@ __device__ __forceinline__ void fastg_pass_cols_inv(C2<T>* tile, int ncols, int 
         for (int q = 0; q < R; ++q) s[q * m * rs] = cconj(a[q]);
     }
 }
-template <typename T>
+// The middle of Rader's convolution in ONE trip through the LDS: the LAST forward pass, the product by the transformed kernel and the FIRST inverse pass all work on
+// the same blocks of R consecutive rows, without twiddles (two trips and two barriers less than pass, product, pass); and the two frequency-0 exchanges of the algorithm: row 0 holds the sum S of the samples with n2 != 0,
+// block zoff the sample z with n2 = 0: X[.][0] = z + S goes to zoff, S B[0] + z (z reaches every other output) into the convolution.
+template <typename T, int R>
+__device__ __forceinline__ void fastg_pass_cols_inv_first(C2<T>* tile, int ncols, int len, int rs, int tid, int nthreads, const C2<T>* __restrict__ bh, int zoff) {
+    const int per = len / R, nb = ncols * per;
+    const float inv_c = 1.0f / (float)ncols;
+    for (int w = tid; w < nb; w += nthreads) {
+        const int blk = fdiv(w, inv_c), c = w - blk * ncols;
+        C2<T>* s = tile + c + (blk * R) * rs;
+        C2<T> a[R];
+#pragma unroll
+        for (int k = 0; k < R; ++k) a[k] = s[k * rs];
+        dft_r<T, R>(a);  // (the LAST forward pass works on the same blocks of R rows, without twiddles: it runs here, in registers)
+        if (blk == 0) {
+            const C2<T> S = a[0], z = tile[zoff + c];
+            tile[zoff + c] = mk<T>(z.re + S.re, z.im + S.im);
+            a[0] = cmul(S, bh[0]);
+            a[0] = mk<T>(a[0].re + z.re, a[0].im + z.im);
+#pragma unroll
+            for (int k = 1; k < R; ++k) a[k] = cmul(a[k], bh[k]);
+        } else {
+#pragma unroll
+            for (int k = 0; k < R; ++k) a[k] = cmul(a[k], bh[blk * R + k]);
+        }
+#pragma unroll
+        for (int k = 0; k < R; ++k) a[k] = cconj(a[k]);
+        dft_r<T, R>(a);
+#pragma unroll
+        for (int q = 0; q < R; ++q) s[q * rs] = cconj(a[q]);
+    }
+}
+template <typename T, bool X17 = false>
+__device__ __forceinline__ void fastg_cols_pass_inv_first(C2<T>* tile, int ncols, int len, int rs, int R, int tid, int nthr, const C2<T>* bh, int zoff) {
+    if (X17 && R == 17) { fastg_pass_cols_inv_first<T, X17 ? 17 : 2>(tile, ncols, len, rs, tid, nthr, bh, zoff); return; }
+    switch (R) {
+        case 2: fastg_pass_cols_inv_first<T, 2>(tile, ncols, len, rs, tid, nthr, bh, zoff); break;
+        case 3: fastg_pass_cols_inv_first<T, 3>(tile, ncols, len, rs, tid, nthr, bh, zoff); break;
+        case 4: fastg_pass_cols_inv_first<T, 4>(tile, ncols, len, rs, tid, nthr, bh, zoff); break;
+        case 5: fastg_pass_cols_inv_first<T, 5>(tile, ncols, len, rs, tid, nthr, bh, zoff); break;
+        case 6: fastg_pass_cols_inv_first<T, 6>(tile, ncols, len, rs, tid, nthr, bh, zoff); break;
+        case 7: fastg_pass_cols_inv_first<T, 7>(tile, ncols, len, rs, tid, nthr, bh, zoff); break;
+        case 8: fastg_pass_cols_inv_first<T, 8>(tile, ncols, len, rs, tid, nthr, bh, zoff); break;
+        case 9: fastg_pass_cols_inv_first<T, 9>(tile, ncols, len, rs, tid, nthr, bh, zoff); break;
+        case 10: fastg_pass_cols_inv_first<T, 10>(tile, ncols, len, rs, tid, nthr, bh, zoff); break;
+        case 11: fastg_pass_cols_inv_first<T, 11>(tile, ncols, len, rs, tid, nthr, bh, zoff); break;
+        case 12: fastg_pass_cols_inv_first<T, 12>(tile, ncols, len, rs, tid, nthr, bh, zoff); break;
+        case 13: fastg_pass_cols_inv_first<T, 13>(tile, ncols, len, rs, tid, nthr, bh, zoff); break;
+        case 14: fastg_pass_cols_inv_first<T, 14>(tile, ncols, len, rs, tid, nthr, bh, zoff); break;
+        case 15: fastg_pass_cols_inv_first<T, 15>(tile, ncols, len, rs, tid, nthr, bh, zoff); break;
+        default: fastg_pass_cols_inv_first<T, 16>(tile, ncols, len, rs, tid, nthr, bh, zoff); break;
+    }
+}
+
+template <typename T, bool X17 = false>  // (X17: the 17-point butterfly, too -- the float32 Rader forms only: it would cost every other kernel registers)
 __device__ __forceinline__ void fastg_cols_pass_inv(C2<T>* tile, int ncols, int len, int rs, int R, int L, int tid, int nthr, const C2<T>* tw) {
+    if (X17 && R == 17) { fastg_pass_cols_inv<T, X17 ? 17 : 2>(tile, ncols, len, rs, L, tid, nthr, tw); return; }
     switch (R) {
         case 2: fastg_pass_cols_inv<T, 2>(tile, ncols, len, rs, L, tid, nthr, tw); break;
         case 3: fastg_pass_cols_inv<T, 3>(tile, ncols, len, rs, L, tid, nthr, tw); break;
@@ -163,8 +218,9 @@ __device__ __forceinline__ void fastg_rows_pass(C2<T>* tile, const TileGeom& g, 
         default: run_pass<T, 16>(tile, g, L, tid, nthr, tw); break;
     }
 }
-template <typename T>
+template <typename T, bool X17 = false>
 __device__ __forceinline__ void fastg_cols_pass(C2<T>* tile, int ncols, int len, int rs, int R, int L, int tid, int nthr, const C2<T>* tw) {
+    if (X17 && R == 17) { fastg_pass_cols<T, X17 ? 17 : 2>(tile, ncols, len, rs, L, tid, nthr, tw); return; }
     switch (R) {
         case 2: fastg_pass_cols<T, 2>(tile, ncols, len, rs, L, tid, nthr, tw); break;
         case 3: fastg_pass_cols<T, 3>(tile, ncols, len, rs, L, tid, nthr, tw); break;
@@ -691,29 +747,19 @@ __global__ void __launch_bounds__(256) fastgy_kernel(FastGY p) {
             const int P1 = p.rad_p - 1, qg = p.rad_q * G;
             const CT* __restrict__ bh = reinterpret_cast<const CT*>(p.rad_b);
             int L = P1;
-            for (int ps = 0; ps < p.nrp; ++ps) {
-                fastg_cols_pass<T>(tile, qg, P1, qg, p.rp[ps], L, tid, nthr, twp);
+            for (int ps = 0; ps + 1 < p.nrp; ++ps) {
+                fastg_cols_pass<T, sizeof(T) == 4>(tile, qg, P1, qg, p.rp[ps], L, tid, nthr, twp);
                 L /= p.rp[ps];
                 __syncthreads();
             }
-            const float inv_qg = 1.0f / (float)qg;
-            for (int e = tid; e < P1 * qg; e += nthr) {
-                const int jr = fdiv(e, inv_qg);
-                CT a = tile[e];
-                const CT prod = cmul(a, bh[jr]);
-                if (jr == 0) {  // frequency 0 of the convolution = the sum of the samples with n2 != 0: X[.][0] = x0 + sum, and x0 joins every other frequency
-                    const int zc = P1 * qg + e;
-                    const CT z = tile[zc];
-                    tile[zc] = mk<T>(z.re + a.re, z.im + a.im);
-                    a = mk<T>(prod.re + z.re, prod.im + z.im);
-                } else a = prod;
-                tile[e] = a;
-            }
+            // the last forward pass, * the transformed kernel, the frequency-0 exchanges and the first inverse pass in one (frequency 0 of the convolution = the sum of the samples with
+            // n2 != 0: X[.][0] = x0 + sum, and x0 joins every other frequency)
+            fastg_cols_pass_inv_first<T, sizeof(T) == 4>(tile, qg, P1, qg, p.rp[p.nrp - 1], tid, nthr, bh, P1 * qg);
             __syncthreads();
-            int Li = 1;
-            for (int ip = p.nrp - 1; ip >= 0; --ip) {
+            int Li = p.rp[p.nrp - 1];
+            for (int ip = p.nrp - 2; ip >= 0; --ip) {
                 Li *= p.rp[ip];
-                fastg_cols_pass_inv<T>(tile, qg, P1, qg, p.rp[ip], Li, tid, nthr, twp);
+                fastg_cols_pass_inv<T, sizeof(T) == 4>(tile, qg, P1, qg, p.rp[ip], Li, tid, nthr, twp);
                 __syncthreads();
             }
         }

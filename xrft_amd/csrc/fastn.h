@@ -19,6 +19,7 @@
 // is the contract between them.
 #pragma once
 #include "fastm.h"
+#include "fastg.h"  // (the column passes of the Rader form)
 
 namespace xrft {
 
@@ -54,6 +55,19 @@ typedef const NGeo __attribute__((address_space(4)))* NGeoPtr;
 typedef const NGeo __attribute__((address_space(4)))& NGeoRef;
 #endif
 
+// the prime-factor / Rader form of pass 1 (fastg.h, FastGY::rad_p: ny = q p, ONE prime p with a smooth p - 1): its radices, in device memory like NGeo
+struct RGeo {
+    int p, q, nrq, nrp;
+    int rq[kNMaxPass + 2], rp[kNMaxPass + 2];
+};
+#ifdef XRFT_EMULATE
+typedef const RGeo* RGeoPtr;
+typedef const RGeo& RGeoRef;
+#else
+typedef const RGeo __attribute__((address_space(4)))* RGeoPtr;
+typedef const RGeo __attribute__((address_space(4)))& RGeoRef;
+#endif
+
 struct FastN {
     FastM f;              // the pipeline's parameter block exactly as the table kernels take it (incl. the intermediate's layout l_cw, l_rk)
     NGeoPtr g;            // the transform of THIS pass (device memory, uploaded once per plan: a by-value copy in the kernel arguments is dynamically
@@ -67,6 +81,11 @@ struct FastN {
     int vec_ok;           // pass 2: the rows leave 16 bytes per lane (the row length divides)
     int rpu;              // pass 2: rows ky per workgroup (two fields: g.g = 2 rpu sequences)
     int dbg;              // ablation switches of the measuring scripts (XRFTHIP_FASTN_DBG; 0 in production): 1 no LDS passes, 2 no stores, 4 no first pass
+    // pass 1, the Rader form (FORM 2): g.n = f.ny, g.str = f.ny (the tile is [ny][G], lanes along the sequences), twm = W_ny then W_(p-1)
+    RGeoPtr rg;
+    const unsigned short* rad_pin;   // row of input sample i
+    const unsigned short* rad_pout;  // row of frequency k
+    const void* rad_b;               // FFT_(p-1)(W_p^(g^m)) / (p - 1) at the row the forward passes leave each frequency
 };
 
 __device__ __forceinline__ int n_pad(int i, float inv) { return i + (int)(((float)i + 0.5f) * inv); }  // i + i / q, inv = 1 / q (or 0)
@@ -235,8 +254,10 @@ __device__ __forceinline__ void n_first_cols(NColsCtx<T>& c, NGeoRef g, C2<T>* s
     for (int k = 0; k < R; ++k) s[k * st] = a[k];
 }
 
-template <typename T, bool BLUE, int CAP>
+// FORM 0: the radix passes; 1: Bluestein's chirp convolution; 2: the prime-factor form with Rader's algorithm along the prime (fastg.h)
+template <typename T, int FORM, int CAP>
 __global__ void __launch_bounds__(fastn_max_threads<T>(), (sizeof(T) == 4 ? 4 : 3)) fastn_cols_kernel(FastN P) {
+    constexpr bool BLUE = FORM == 1, RADER = FORM == 2;
     typedef C2<T> CT;
     NGeoRef g = *P.g;
     const FastM& p = P.f;
@@ -251,7 +272,8 @@ __global__ void __launch_bounds__(fastn_max_threads<T>(), (sizeof(T) == 4 ? 4 : 
     const int unit = xcd * per + jb;
     if (jb >= per || unit >= p.nunits) return;
     const int nxb = P.nxb, slab = unit / nxb, xb = unit - slab * nxb;
-    for (int e = tid; e < g.twn; e += nthr) twl[e] = reinterpret_cast<const CT*>(P.twm)[e];
+    unsigned short* pin = reinterpret_cast<unsigned short*>(part + (nthr >> 6) * G * 4);
+    unsigned short* pout = pin + ((ny + 7) & ~7);
     const int col0 = xb * CW + 2 * gi;  // this thread's column pair
     NColsCtx<T> c;
     c.src = reinterpret_cast<const char*>(reinterpret_cast<const T*>(p.in) + (size_t)slab * ny * nx + (size_t)xb * CW);
@@ -285,6 +307,9 @@ __global__ void __launch_bounds__(fastn_max_threads<T>(), (sizeof(T) == 4 ? 4 : 
             rt[k] = n_load_pair<T>(c, c.rowb * (unsigned)(ITOP - 1 + k));
             rb[k] = n_load_pair<T>(c, c.rowb * (unsigned)(IBOT - 1 + k));
         }
+        // (the tables are staged while these six rows are in flight: one memory latency, not two, before the first pass)
+        for (int e = tid; e < g.twn; e += nthr) twl[e] = reinterpret_cast<const CT*>(P.twm)[e];
+        if (RADER) for (int e = tid; e < ny; e += nthr) { pin[e] = P.rad_pin[e]; pout[e] = P.rad_pout[e]; }
         auto med3 = [](float x, float y, float z) { return fmaxf(fminf(x, y), fminf(fmaxf(x, y), z)); };
         const float mt[2] = {med3((float)rt[0].re, (float)rt[1].re, (float)rt[2].re), med3((float)rt[0].im, (float)rt[1].im, (float)rt[2].im)};
         const float mb[2] = {med3((float)rb[0].re, (float)rb[1].re, (float)rb[2].re), med3((float)rb[0].im, (float)rb[1].im, (float)rb[2].im)};
@@ -297,18 +322,23 @@ __global__ void __launch_bounds__(fastn_max_threads<T>(), (sizeof(T) == 4 ? 4 : 
             const float C = __uint_as_float((__float_as_uint(mag) & 0x7f800000u) + (3u << 23)) * 1.5f;  // rounds to 2^(e-20), 2^e <= mag
             c.Tl[cc] = (Te + C) - C; c.Sl[cc] = (Se + C) - C;
         }
+    } else {
+        for (int e = tid; e < g.twn; e += nthr) twl[e] = reinterpret_cast<const CT*>(P.twm)[e];
+        if (RADER) for (int e = tid; e < ny; e += nthr) { pin[e] = P.rad_pin[e]; pout[e] = P.rad_pout[e]; }
     }
     if (c.det && r0 == 0) {  // what is subtracted, as (offset at ibar, slope)
         double* cfp = p.colfit + ((size_t)slab * nx + col0) * 4;
         if (c.has0) { cfp[2] = (double)c.Tl[0] + (double)c.Sl[0] * c.ibar; cfp[3] = (double)c.Sl[0]; }
         if (c.has1) { cfp[6] = (double)c.Tl[1] + (double)c.Sl[1] * c.ibar; cfp[7] = (double)c.Sl[1]; }
     }
-    if (BLUE) {
+    if (RADER) __syncthreads();  // (the row tables)
+    if (BLUE || RADER) {
         // Bluestein: the column pair's ny rows are staged in LDS -- detrended, windowed, times conj(c[i]) -- behind them zeros up to the convolution
         // length, and ALL passes run from LDS (the natural layout of a Bluestein plan is its intermediate layout).  U rows per thread in flight.
+        // Rader: the rows are staged at the rows of the prime-factor / generator order, tile [ny][G].
         CT* seq = lds + gi * g.str;
         const CT* __restrict__ ch = reinterpret_cast<const CT*>(P.blue_c);
-        constexpr int U = 4;
+        constexpr int U = 4;  // (eight in flight: no faster, profiles/r05_rader_cols.txt)
         for (int i0 = r0; i0 < ny && !(P.dbg & 4); i0 += U * RQ) {
             CT v[U], cc_[U];
             T wv[U];
@@ -317,7 +347,7 @@ __global__ void __launch_bounds__(fastn_max_threads<T>(), (sizeof(T) == 4 ? 4 : 
                 const int ic = min(i0 + u * RQ, ny - 1);
                 v[u] = n_load_pair<T>(c, c.rowb * (unsigned)ic);
                 wv[u] = c.wy[ic];
-                cc_[u] = ch[ic];
+                if (BLUE) cc_[u] = ch[ic];
             }
 #pragma unroll
             for (int u = 0; u < U; ++u) {
@@ -334,15 +364,18 @@ __global__ void __launch_bounds__(fastn_max_threads<T>(), (sizeof(T) == 4 ? 4 : 
                         z = mk<T>((T)((float)z.re - fmaf(c.Sl[0], fi, c.Tl[0])), (T)((float)z.im - fmaf(c.Sl[1], fi, c.Tl[1])));
                     }
                     z = mk<T>(z.re * (wv[u] * c.wx.re), z.im * (wv[u] * c.wx.im));
-                    seq[n_pad(i, g.inv_pdq)] = cmulc(z, cc_[u]);
+                    if (BLUE) seq[n_pad(i, g.inv_pdq)] = cmulc(z, cc_[u]);
+                    else lds[(int)pin[i] * G + gi] = z;
                 }
             }
         }
-        for (int i = ny + r0; i < g.n; i += RQ) seq[n_pad(i, g.inv_pdq)] = mk<T>((T)0, (T)0);
-        __syncthreads();
+        if (BLUE) {
+            for (int i = ny + r0; i < g.n; i += RQ) seq[n_pad(i, g.inv_pdq)] = mk<T>((T)0, (T)0);
+            __syncthreads();
 #define NB_(RR) n_pass_mid<T, RR>(lds, g, 0, tid, nthr, twl, nullptr)
-        if (!(P.dbg & 1)) { XRFT_N_SWITCH(g.r[0], NB_) }
+            if (!(P.dbg & 1)) { XRFT_N_SWITCH(g.r[0], NB_) }
 #undef NB_
+        }
     } else {
         CT* seq = lds + gi * g.str;
         const CT* __restrict__ tw = reinterpret_cast<const CT*>(p.tw_y);
@@ -363,7 +396,37 @@ __global__ void __launch_bounds__(fastn_max_threads<T>(), (sizeof(T) == 4 ? 4 : 
             for (int cc = 0; cc < 4; ++cc) part[((tid >> 6) * G + gi) * 4 + cc] = c.s[cc];
         }
     }
-    if (!(P.dbg & 1)) n_fft_tail<T, CAP>(lds, g, tid, nthr, twl); else __syncthreads();
+    if (RADER && (P.dbg & 1)) __syncthreads();
+    else if (RADER) {
+        // along q inside every block of q rows (the tail passes of a length-ny transform), then Rader's cyclic convolution of p - 1 points across the first
+        // p - 1 blocks (q G sequences side by side): forward passes, * the transformed kernel with the two frequency-0 exchanges, inverse passes (fastg.h)
+        constexpr bool X17 = sizeof(T) == 4;
+        RGeoRef rg = *P.rg;
+        const CT* twp = twl + ny;
+        __syncthreads();
+        int L = rg.q;
+        for (int ps = 0; ps < rg.nrq; ++ps) {
+            fastg_cols_pass<T>(lds, G, ny, G, rg.rq[ps], L, tid, nthr, twl);
+            L /= rg.rq[ps];
+            __syncthreads();
+        }
+        const int P1 = rg.p - 1, qg = rg.q * G;
+        L = P1;
+        for (int ps = 0; ps + 1 < rg.nrp; ++ps) {  // (the last forward pass runs inside fastg_cols_pass_inv_first)
+            fastg_cols_pass<T, X17>(lds, qg, P1, qg, rg.rp[ps], L, tid, nthr, twp);
+            L /= rg.rp[ps];
+            __syncthreads();
+        }
+        const CT* __restrict__ bh = reinterpret_cast<const CT*>(P.rad_b);
+        fastg_cols_pass_inv_first<T, X17>(lds, qg, P1, qg, rg.rp[rg.nrp - 1], tid, nthr, bh, P1 * qg);
+        __syncthreads();
+        int Li = rg.rp[rg.nrp - 1];
+        for (int ip = rg.nrp - 2; ip >= 0; --ip) {
+            Li *= rg.rp[ip];
+            fastg_cols_pass_inv<T, X17>(lds, qg, P1, qg, rg.rp[ip], Li, tid, nthr, twp);
+            __syncthreads();
+        }
+    } else if (!(P.dbg & 1)) n_fft_tail<T, CAP>(lds, g, tid, nthr, twl); else __syncthreads();
     if (BLUE && !(P.dbg & 1)) {
         // circular convolution with the chirp: Z1 B, conjugated (the inverse transform is conj FFT conj; 1 / m rides on B), a second forward transform
         // whose first pass finds its operands in LDS -- the Bluestein plan's natural layout IS its intermediate layout --, and Z[k] = conj(res[k] c[k])
@@ -401,7 +464,9 @@ __global__ void __launch_bounds__(fastn_max_threads<T>(), (sizeof(T) == 4 ? 4 : 
     for (int l = tid; l < nst; l += nthr) {
         const int col = l & (CW - 1), k = l >> lcw, km = k == 0 ? 0 : ny - k;
         const CT* z = lds + (col >> 1) * g.str;
-        CT zk = z[n_pad(k, g.inv_pnq)], zc = z[n_pad(km, g.inv_pnq)];
+        CT zk, zc;
+        if (RADER) { zk = lds[(int)pout[k] * G + (col >> 1)]; zc = lds[(int)pout[km] * G + (col >> 1)]; }
+        else { zk = z[n_pad(k, g.inv_pnq)]; zc = z[n_pad(km, g.inv_pnq)]; }
         if (BLUE) {
             zk = cmul(zk, reinterpret_cast<const CT*>(P.blue_c)[k]); zk.im = -zk.im;
             zc = cmul(zc, reinterpret_cast<const CT*>(P.blue_c)[km]);  // conj(conj(res c)) = res c

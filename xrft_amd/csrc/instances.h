@@ -68,16 +68,16 @@ XRFT_M_LATLON(XRFT_KI_M1F_) XRFT_M_F32ONLY(XRFT_KI_M1F_) XRFT_M_F32_1AX(XRFT_KI_
 #endif
 #if XRFT_KI_ON(6) || XRFT_KI_ON(7)  // ---- fastn.h: the y-first pipeline with the lengths as data (float32: group 6, float64: group 7); CAP = the largest radix a variant carries
 #define XRFT_KI_N_(TT, CC) \
-    XRFT_KW void fastn_cols_kernel<TT, false, CC>(FastN); \
+    XRFT_KW void fastn_cols_kernel<TT, 0, CC>(FastN); \
     XRFT_KW void fastn_rows_kernel<TT, 0, false, CC>(FastN); XRFT_KW void fastn_rows_kernel<TT, 1, false, CC>(FastN); XRFT_KW void fastn_rows_kernel<TT, 1, true, CC>(FastN); \
     XRFT_KW void fastn_rows_kernel<TT, 2, false, CC>(FastN); XRFT_KW void fastn_rows_kernel<TT, 2, true, CC>(FastN); XRFT_KW void fastn_rows_kernel<TT, 3, false, CC>(FastN);
 #if XRFT_KI_ON(6)
-XRFT_KI_N_(float, 16) XRFT_KI_N_(float, 20) XRFT_KW void fastn_cols_kernel<float, true, 16>(FastN);  /* (the chirp-convolution columns: radices up to 16) */
+XRFT_KI_N_(float, 16) XRFT_KI_N_(float, 20) XRFT_KW void fastn_cols_kernel<float, 1, 16>(FastN); XRFT_KW void fastn_cols_kernel<float, 2, 16>(FastN);  /* (the chirp-convolution and the Rader columns: radices up to 16) */
 XRFT_KW void fastn_irows_kernel<float, 0, 16>(FastNI); XRFT_KW void fastn_irows_kernel<float, 1, 16>(FastNI); XRFT_KW void fastn_irows_kernel<float, 0, 20>(FastNI); XRFT_KW void fastn_irows_kernel<float, 1, 20>(FastNI);
 XRFT_KW void fastn_fit_inner_kernel<float>(const double*, const float*, C2<float>*, int, int, int, int);
 #endif
 #if XRFT_KI_ON(7)
-XRFT_KI_N_(double, 16) XRFT_KW void fastn_cols_kernel<double, true, 16>(FastN);
+XRFT_KI_N_(double, 16) XRFT_KW void fastn_cols_kernel<double, 1, 16>(FastN); XRFT_KW void fastn_cols_kernel<double, 2, 16>(FastN);
 XRFT_KW void fastn_irows_kernel<double, 0, 16>(FastNI); XRFT_KW void fastn_irows_kernel<double, 1, 16>(FastNI);
 XRFT_KW void fastn_fit_inner_kernel<double>(const double*, const double*, C2<double>*, int, int, int, int);
 #endif

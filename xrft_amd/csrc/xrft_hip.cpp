@@ -338,6 +338,9 @@ struct xrfthip_plan {
     long long y_pitch = 0;          // complex elements per row of the intermediate (ynx, or n_nxb * n_cw when the last column block is ragged)
     int n_blue_m = 0;               // pass 1 through a chirp convolution of this length
     DevBuf n_bluec, n_blueb;
+    int n_rad_p = 0;                // ... or, ny = q p with ONE prime 17 ... 127 whose p - 1 the butterflies factor: the prime-factor form with Rader's algorithm along p
+    std::vector<int> n_rq, n_rp;    // the radices of q and of p - 1
+    DevBuf n_rgeo, n_radpin, n_radpout, n_radb;
     // ... and xrfthip_desc.inner > 1 (two adjacent transform axes, the independent elements innermost) as the same two passes (fastn.h: fastn_cols_kernel on the
     // [ny][nx inner] view, fastn_fit_inner_kernel, fastn_irows_kernel).  n_c: the ny-point columns of the view; n_r: GE sequences of nx points per row workgroup
     bool fusedi = false;
@@ -869,7 +872,7 @@ void set_kernel_attrs_once() {
     SETF((fastgy_kernel<float, 0, 0>)); SETF((fastgy_kernel<float, 1, 0>)); SETF((fastgy_kernel<double, 0, 0>)); SETF((fastgy_kernel<double, 1, 0>));
     SETF((fastgy_kernel<float, 0, 1>)); SETF((fastgy_kernel<float, 1, 1>)); SETF((fastgy_kernel<double, 0, 1>)); SETF((fastgy_kernel<double, 1, 1>));
     SETF((fastgy_kernel<float, 0, 2>)); SETF((fastgy_kernel<float, 1, 2>)); SETF((fastgy_kernel<double, 0, 2>)); SETF((fastgy_kernel<double, 1, 2>));
-#define SETN(TT, CC) SETF((fastn_cols_kernel<TT, false, CC>)); SETF((fastn_cols_kernel<TT, true, 16>)); \
+#define SETN(TT, CC) SETF((fastn_cols_kernel<TT, 0, CC>)); SETF((fastn_cols_kernel<TT, 1, 16>)); SETF((fastn_cols_kernel<TT, 2, 16>)); \
                      SETF((fastn_rows_kernel<TT, 0, false, CC>)); SETF((fastn_rows_kernel<TT, 1, false, CC>)); SETF((fastn_rows_kernel<TT, 1, true, CC>)); SETF((fastn_rows_kernel<TT, 2, false, CC>)); \
                      SETF((fastn_rows_kernel<TT, 2, true, CC>)); SETF((fastn_rows_kernel<TT, 3, false, CC>))
     SETN(float, 16); SETN(float, 20); SETN(double, 16);
@@ -1807,6 +1810,7 @@ static bool fastn_pick(long long n, int g, bool blue, bool dbl, bool cols, int m
     return false;
 }
 
+static bool rader_split(long long n, bool dbl, int& p_out, std::vector<int>& rq, std::vector<int>& rp);
 // Decide which kernel runs each pass of a y-first plan on (ny, nx) and the layout of the intermediate between them.  Returns false when the plan stays
 // with the other paths (a length the butterflies do not factor and the chirp convolution does not fit, sequences that do not fit the LDS).
 static bool fastn_setup(xrfthip_plan* P) {
@@ -1846,11 +1850,42 @@ static bool fastn_setup(xrfthip_plan* P) {
         if (rpu < 1) return false;
     }
     // ---- columns (length ny, or the chirp convolution's m)
-    int cw = 0, blue_m = 0;
+    int cw = 0, blue_m = 0, rad_p = 0;
+    std::vector<int> rq, rp;
     NGeo gc{};
     if (cols_rt) {
         long long mlen = d.ny;
-        if (!fastn_factor(d.ny, maxr, ry)) {
+        if (!fastn_factor(d.ny, maxr, ry) && d.ny <= 8192 && env_ll("XRFTHIP_FASTN_RADER", 1) && rader_split(d.ny, dbl, rad_p, rq, rp)) {
+            // ONE prime factor 17 ... 127 with a smooth p - 1 (721 = 7 x 103 latitudes, 365 = 5 x 73): the prime-factor form with Rader's algorithm along the prime
+            // inside the column tile (fastg.h, fastn_cols_kernel<T, 2, 16>): the tile is [ny][G], no padding; ~2.4 transforms of the length in LDS where the chirp
+            // convolution takes two of 2.1 x the length.  Column pairs per workgroup and threads as for the chirp convolution: small workgroups, several per CU
+            const int gmax_r = dbl ? 4 : 8;
+            int G = 0;
+            NGeo t{};
+            const long long forced = env_ll("XRFTHIP_FASTN_GC", 0), thr_f = env_ll("XRFTHIP_FASTN_TC", 0);
+            // (measured, profiles/r05_rader_cols.txt: the widest block of ~3000 ... 6000 points -- (365, 720) float32 8 pairs 65 us against 87 with 4, 721 points 4 pairs,
+            // 1460 points 4 pairs and 512 threads 379 us against 430 with 256; float64 (365, 720) 4 pairs 112 us against 167 with 2)
+            static const int kOrd[] = {8, 4, 2, 1};
+            static const size_t caps[] = {52 * 1024, 78 * 1024, 156 * 1024};
+            for (int ci = 0; ci < 3 && !G; ++ci)
+                for (int oi = 0; oi < 4 && !G; ++oi) {
+                    const int cand = kOrd[oi];
+                    if (cand > gmax_r || (forced && cand != forced)) continue;
+                    if (!forced && cand > 1 && (long long)cand * d.ny > 6000) continue;
+                    if (!rows_rt && d.nx % (2 * cand) != 0) continue;
+                    if (2LL * cand > d.nx + 1) continue;
+                    NGeo c{};
+                    c.n = (int)d.ny; c.np = 0; c.g = cand; c.lg = ilog2i(cand); c.str = (int)d.ny; c.twn = (int)d.ny + rad_p - 1;
+                    c.thr = thr_f ? (int)std::min<long long>(maxthr, (thr_f + 63) / 64 * 64) : ((long long)cand * d.ny >= 4096 && !dbl) ? 512 : 256;
+                    const size_t lds = fastn_lds(c, cs, true) + 2 * (((size_t)d.ny + 7) & ~(size_t)7) * 2;
+                    if (lds <= caps[ci]) { G = cand; t = c; }
+                }
+            if (G) {
+                gc = t; cw = 2 * G;
+            } else rad_p = 0;
+        }
+        if (rad_p) {
+        } else if (!fastn_factor(d.ny, maxr, ry)) {
             // a prime factor without a butterfly: x conj(c) zero-padded to m >= 2 ny - 1 -> FFT_m -> * FFT_m(chirp) / m -> inverse FFT_m -> * conj(c).  The m with the
             // fewest passes within 12 % of the smallest candidate
             std::vector<int> best;
@@ -1890,8 +1925,8 @@ static bool fastn_setup(xrfthip_plan* P) {
                 if ((long long)t.g * (mlen / t.r[t.np - 1]) > maxthr) continue;
                 if (fastn_lds(t, cs, true) <= caps[ci]) { G = cand; gc = t; }
             }
-        if (!G) return false;
-        cw = 2 * G;
+        if (!G && !rad_p) return false;
+        if (!rad_p) cw = 2 * G;
     } else {
         cw = fastm_cw(d.ny, d.nx, dbl);
     }
@@ -1901,7 +1936,8 @@ static bool fastn_setup(xrfthip_plan* P) {
     int rk = (int)std::max<long long>(1, std::min<long long>((long long)(128 / (cw * cs)), rpu));
     if (rpu % rk != 0) return false;
     P->fastn = true;
-    P->n_c.rt = cols_rt; P->n_c.geo = gc; P->n_c.lds = cols_rt ? fastn_lds(gc, cs, true) : 0;
+    P->n_c.rt = cols_rt; P->n_c.geo = gc; P->n_c.lds = cols_rt ? fastn_lds(gc, cs, true) + (rad_p ? 2 * (((size_t)d.ny + 7) & ~(size_t)7) * 2 : 0) : 0;
+    P->n_rad_p = rad_p; P->n_rq = rq; P->n_rp = rp;
     P->n_r.rt = rows_rt; P->n_r.geo = gr; P->n_r.lds = rows_rt ? fastn_lds(gr, cs, false) : 0;
     P->n_cw = cw; P->n_rk = rk; P->n_rpu = rpu; P->n_nxb = nxb; P->y_pitch = pitch; P->n_blue_m = blue_m;
     return true;
@@ -1915,6 +1951,7 @@ static FastN fastn_wrap(const xrfthip_plan* P, const FastM& m, bool cols) {
     n.pitch = (int)P->y_pitch; n.nxb = P->n_nxb;
     n.pair_ok = (P->ynx % 2 == 0) ? 1 : 0;
     n.blue_c = P->n_bluec.p; n.blue_b = P->n_blueb.p;
+    n.rg = (RGeoPtr)P->n_rgeo.p; n.rad_pin = (const unsigned short*)P->n_radpin.p; n.rad_pout = (const unsigned short*)P->n_radpout.p; n.rad_b = P->n_radb.p;
     const bool cplx_out = P->d.out_mode == XRFTHIP_OUT_COMPLEX || P->d.out_mode == XRFTHIP_OUT_CROSS;
     const int vw = (int)(16 / (cplx_out ? P->csize : P->rsize));
     n.vec_ok = (P->ynx % vw == 0) ? 1 : 0;
@@ -1930,8 +1967,9 @@ static void fastn_launch_cols(const xrfthip_plan* P, const FastM& m, hipStream_t
     const size_t lds = P->n_c.lds;
     int maxrad = 0;
     for (int i = 0; i < hg.np; ++i) maxrad = std::max(maxrad, hg.r[i]);
-#define NC_(TT, CC) do { if (P->n_blue_m) { auto k = &fastn_cols_kernel<TT, true, 16>; XRFT_LAUNCH(k, grid, blk, lds, st, n); } /* (a chirp convolution's radices stop at 16) */ \
-                         else { auto k = &fastn_cols_kernel<TT, false, CC>; XRFT_LAUNCH(k, grid, blk, lds, st, n); } } while (0)
+#define NC_(TT, CC) do { if (P->n_blue_m) { auto k = &fastn_cols_kernel<TT, 1, 16>; XRFT_LAUNCH(k, grid, blk, lds, st, n); } /* (a chirp convolution's radices stop at 16) */ \
+                         else if (P->n_rad_p) { auto k = &fastn_cols_kernel<TT, 2, 16>; XRFT_LAUNCH(k, grid, blk, lds, st, n); } \
+                         else { auto k = &fastn_cols_kernel<TT, 0, CC>; XRFT_LAUNCH(k, grid, blk, lds, st, n); } } while (0)
     if (P->dbl) NC_(double, 16); else if (maxrad > 16) NC_(float, 20); else NC_(float, 16);
 #undef NC_
 }
@@ -2302,7 +2340,7 @@ static int fastg_build_iso(xrfthip_plan* P, const int32_t* bm) {
 // one transform axis that is not the contiguous one, any smooth length (fastg.h: fastgy_kernel): G complex sequences = 2 G real columns per workgroup,
 // the widest power of two (<= 128 bytes of a row) whose tile leaves three workgroups on a CU, or the widest that fits at all
 // n = q p, p ONE prime 17 ... 127 whose p - 1 the butterflies factor, q smooth and prime to p: the prime-factor form with Rader's algorithm along p (fastg.h)
-static bool rader_split(long long n, int& p_out, std::vector<int>& rq, std::vector<int>& rp) {
+static bool rader_split(long long n, bool dbl, int& p_out, std::vector<int>& rq, std::vector<int>& rp) {
     if (!env_ll("XRFTHIP_RADER", 1)) return false;
     for (int p = 17; p <= 127; ++p) {
         bool prime = true;
@@ -2312,9 +2350,14 @@ static bool rader_split(long long n, int& p_out, std::vector<int>& rq, std::vect
         if (q % p == 0) return false;  // (p^2)
         rq.clear(); rp.clear();
         if (q > 1 && !fastg_factor(q, rq)) return false;  // (a second prime without a butterfly)
-        if (!fastg_factor(p - 1, rp)) return false;
+        if (!fastg_factor(p - 1, rp)) {
+            // 103 - 1 = 6 x 17 (the ERA5 grid's 721 = 7 x 103 latitudes): the 17-point butterfly, float32 only (its registers)
+            if (dbl || (p - 1) % 17 || !fastg_factor((p - 1) / 17, rp)) return false;
+            rp.push_back(17);
+        }
         for (int r : rq) if (r > 16) return false;
-        for (int r : rp) if (r > 16) return false;
+        for (int r : rp) if (r > 17) return false;
+        if ((int)rq.size() > kNMaxPass || (int)rp.size() > kNMaxPass) return false;
         if ((int)rq.size() > kFastGMaxPasses || (int)rp.size() > kFastGMaxPasses) return false;
         p_out = p;
         return true;
@@ -2330,7 +2373,7 @@ static bool fastgy_try(xrfthip_plan* P) {
     std::vector<int> ry, rp;
     long long m = d.ny;  // rows of the tile = length of the passes: ny, or the Bluestein length when a prime factor of ny has no butterfly
     int blue_m = 0, rad_p = 0;
-    if (!fastg_factor(d.ny, ry) && d.ny <= 4096 && rader_split(d.ny, rad_p, ry, rp)) {
+    if (!fastg_factor(d.ny, ry) && d.ny <= 4096 && rader_split(d.ny, P->dbl, rad_p, ry, rp)) {
         // (ry: the radices of q; the tile holds ny rows)
     } else if (!fastg_factor(d.ny, ry)) {
         rad_p = 0;
@@ -2368,9 +2411,10 @@ static bool fastgy_try(xrfthip_plan* P) {
     P->gy_rad_p = rad_p; P->gy_rp = rp;
     return true;
 }
-// the tables of the prime-factor / Rader form (fastg.h, FastGY::rad_p): the row of every input sample and of every frequency, W_(p-1), the transformed kernel
-template <typename T> static int fastgy_rader_tables(xrfthip_plan* P) {
-    const int n = (int)P->d.ny, p = P->gy_rad_p, q = n / p, P1 = p - 1;
+// the tables of the prime-factor / Rader form (fastg.h, FastGY::rad_p): the row of every input sample and of every frequency, the transformed kernel
+// B = FFT_(p-1)(W_p^(g^m)) / (p - 1) at the row the forward passes (radices rp) leave each frequency
+static int rader_maps(int n, int p, const std::vector<int>& rq_, const std::vector<int>& rp_, std::vector<unsigned>& pin, std::vector<unsigned>& pout, std::vector<double>& bre, std::vector<double>& bim) {
+    const int q = n / p, P1 = p - 1;
     auto powmod = [](long long b, long long e, long long m) { long long r = 1; b %= m; while (e > 0) { if (e & 1) r = r * b % m; b = b * b % m; e >>= 1; } return r; };
     int g = 0;  // the smallest generator of the units mod p
     for (int c = 2; c < p && !g; ++c) {
@@ -2384,14 +2428,14 @@ template <typename T> static int fastgy_rader_tables(xrfthip_plan* P) {
     // digit reversals of the passes along q and along p - 1
     std::vector<unsigned> revq, revp;
     DevBuf scratch;
-    int rc = fastg_rev(P->g_ry, q, scratch, revq);
-    if (!rc) rc = fastg_rev(P->gy_rp, P1, scratch, revp);
+    int rc = fastg_rev(rq_, q, scratch, revq);
+    if (!rc) rc = fastg_rev(rp_, P1, scratch, revp);
     if (rc) return rc;
     // inverses for the index maps: i = n1 p + n2 q (mod n) -> n1 = i p^-1 (mod q), n2 = i q^-1 (mod p)
     long long pinv_q = 0, qinv_p = 0;
     for (int t = 0; t < q; ++t) if ((long long)t * p % q == 1 % q) { pinv_q = t; break; }
     for (int t = 0; t < p; ++t) if ((long long)t * q % p == 1) { qinv_p = t; break; }
-    std::vector<unsigned> pin((size_t)n), pout((size_t)n);
+    pin.assign((size_t)n, 0u); pout.assign((size_t)n, 0u);
     for (int i = 0; i < n; ++i) {
         const int n1 = q > 1 ? (int)((long long)i * pinv_q % q) : 0, n2 = (int)((long long)i * qinv_p % p);
         const int j = n2 == 0 ? P1 : (P1 - dlog[(size_t)n2]) % P1;  // g^-j = n2
@@ -2402,23 +2446,57 @@ template <typename T> static int fastgy_rader_tables(xrfthip_plan* P) {
         const int blk = k2 == 0 ? P1 : dlog[(size_t)k2];  // the inverse passes leave X[.][g^k] at block k
         pout[(size_t)k] = (unsigned)(blk * q + (int)revq[(size_t)k1]);
     }
-    // B = FFT_(p-1)(b) / (p - 1), b[m] = W_p^(g^m), by the definition in long double
     const long double pi2 = 2.0L * 3.14159265358979323846264338327950288L;
-    std::vector<C2<T>> bh((size_t)P1);
-    for (int f = 0; f < P1; ++f) {
+    bre.assign((size_t)P1, 0.0); bim.assign((size_t)P1, 0.0);
+    for (int f = 0; f < P1; ++f) {  // by the definition, in long double
         long double sr = 0, si = 0;
         for (int m = 0; m < P1; ++m) {
             const long double a = -pi2 * ((long double)gpow[(size_t)m] / (long double)p + (long double)((long long)f * m % P1) / (long double)P1);
             sr += cosl(a); si += sinl(a);
         }
-        bh[(size_t)revp[(size_t)f]].re = (T)(sr / P1);
-        bh[(size_t)revp[(size_t)f]].im = (T)(si / P1);
+        bre[(size_t)revp[(size_t)f]] = (double)(sr / P1);
+        bim[(size_t)revp[(size_t)f]] = (double)(si / P1);
     }
+    return XRFTHIP_OK;
+}
+template <typename T> static int fastgy_rader_tables(xrfthip_plan* P) {
+    const int n = (int)P->d.ny, p = P->gy_rad_p, P1 = p - 1;
+    std::vector<unsigned> pin, pout;
+    std::vector<double> bre, bim;
+    int rc = rader_maps(n, p, P->g_ry, P->gy_rp, pin, pout, bre, bim);
+    if (rc) return rc;
+    std::vector<C2<T>> bh((size_t)P1);
+    for (int f = 0; f < P1; ++f) { bh[(size_t)f].re = (T)bre[(size_t)f]; bh[(size_t)f].im = (T)bim[(size_t)f]; }
     P->g_hrevy = pout;
     rc = P->g_revy.upload(pout.data(), pout.size() * sizeof(unsigned));
     if (!rc) rc = P->gy_permin.upload(pin.data(), pin.size() * sizeof(unsigned));
     if (!rc) rc = P->gy_radb.upload(bh.data(), bh.size() * sizeof(C2<T>));
     if (!rc) rc = build_twiddle<T>(P->gy_twp, P1, P1);
+    return rc;
+}
+// ... of the two-pass pipeline's column kernel (fastn.h, fastn_cols_kernel<T, 2, 16>): 16-bit row tables, W_ny then W_(p-1) in one staged table
+template <typename T> static int fastn_rader_tables(xrfthip_plan* P) {
+    const int n = (int)P->d.ny, p = P->n_rad_p, P1 = p - 1;
+    std::vector<unsigned> pin, pout;
+    std::vector<double> bre, bim;
+    int rc = rader_maps(n, p, P->n_rq, P->n_rp, pin, pout, bre, bim);
+    if (rc) return rc;
+    std::vector<C2<T>> bh((size_t)P1), tw((size_t)n + P1);
+    for (int f = 0; f < P1; ++f) { bh[(size_t)f].re = (T)bre[(size_t)f]; bh[(size_t)f].im = (T)bim[(size_t)f]; }
+    const long double pi2 = 2.0L * 3.14159265358979323846264338327950288L;
+    for (int k = 0; k < n; ++k) { const long double a = -pi2 * (long double)k / (long double)n; tw[(size_t)k].re = (T)cosl(a); tw[(size_t)k].im = (T)sinl(a); }
+    for (int k = 0; k < P1; ++k) { const long double a = -pi2 * (long double)k / (long double)P1; tw[(size_t)n + k].re = (T)cosl(a); tw[(size_t)n + k].im = (T)sinl(a); }
+    std::vector<uint16_t> pi16((size_t)n), po16((size_t)n);
+    for (int i = 0; i < n; ++i) { pi16[(size_t)i] = (uint16_t)pin[(size_t)i]; po16[(size_t)i] = (uint16_t)pout[(size_t)i]; }
+    RGeo rg{};
+    rg.p = p; rg.q = n / p; rg.nrq = (int)P->n_rq.size(); rg.nrp = (int)P->n_rp.size();
+    for (int i = 0; i < rg.nrq; ++i) rg.rq[i] = P->n_rq[(size_t)i];
+    for (int i = 0; i < rg.nrp; ++i) rg.rp[i] = P->n_rp[(size_t)i];
+    rc = P->n_c.twm.upload(tw.data(), tw.size() * sizeof(C2<T>));
+    if (!rc) rc = P->n_radpin.upload(pi16.data(), pi16.size() * sizeof(uint16_t));
+    if (!rc) rc = P->n_radpout.upload(po16.data(), po16.size() * sizeof(uint16_t));
+    if (!rc) rc = P->n_radb.upload(bh.data(), bh.size() * sizeof(C2<T>));
+    if (!rc) rc = P->n_rgeo.upload(&rg, sizeof(RGeo));
     return rc;
 }
 // the tables of the Bluestein form: c[k] = exp(i pi k^2 / n), k < n, and FFT_m(chirp kernel) / m at the row the forward passes leave each frequency
@@ -3278,7 +3356,8 @@ int xrfthip_plan_create(xrfthip_plan** plan, const xrfthip_desc* desc) {
                 std::vector<double> ones((size_t)std::max(d.ny, d.nx), 1.0);
                 std::vector<float> onesf((size_t)std::max(d.ny, d.nx), 1.0f);
                 if (!rcn) rcn = P->dbl ? P->ones4096.upload(ones.data(), ones.size() * sizeof(double)) : P->ones4096.upload(onesf.data(), onesf.size() * sizeof(float));
-                if (!rcn && P->n_c.rt) rcn = P->dbl ? fastn_upload_twm<double>(P->n_c.geo, P->n_c.twm, P->n_blue_m != 0) : fastn_upload_twm<float>(P->n_c.geo, P->n_c.twm, P->n_blue_m != 0);
+                if (!rcn && P->n_c.rt && P->n_rad_p) rcn = P->dbl ? fastn_rader_tables<double>(P) : fastn_rader_tables<float>(P);
+                else if (!rcn && P->n_c.rt) rcn = P->dbl ? fastn_upload_twm<double>(P->n_c.geo, P->n_c.twm, P->n_blue_m != 0) : fastn_upload_twm<float>(P->n_c.geo, P->n_c.twm, P->n_blue_m != 0);
                 if (!rcn && P->n_r.rt) rcn = P->dbl ? fastn_upload_twm<double>(P->n_r.geo, P->n_r.twm) : fastn_upload_twm<float>(P->n_r.geo, P->n_r.twm);
                 if (!rcn && P->n_blue_m) rcn = P->dbl ? fastn_blue_tables<double>(P) : fastn_blue_tables<float>(P);
                 if (!rcn && P->n_c.rt) rcn = P->n_c.geo_dev.upload(&P->n_c.geo, sizeof(NGeo));
@@ -3539,6 +3618,13 @@ int xrfthip_plan_describe(const xrfthip_plan* plan, char* buf, size_t buflen) {
         std::string cs_, rs_;
         if (plan->n_c.rt) {
             const NGeo& g = plan->n_c.geo;
+            if (plan->n_rad_p) {
+                std::string a, b;
+                for (int r : plan->n_rq) a += (a.empty() ? "" : "x") + std::to_string(r);
+                for (int r : plan->n_rp) b += (b.empty() ? "" : "x") + std::to_string(r);
+                appendf(cs_, "lengths as data, %d thr, %d packed column pairs (FFT%d = %d r%s x prime %d: the prime-factor form, Rader's cyclic convolution of %d = %s points along the prime, in LDS), lds=%zuB",
+                        g.thr, g.g, g.n, g.n / plan->n_rad_p, a.c_str(), plan->n_rad_p, plan->n_rad_p - 1, b.c_str(), plan->n_c.lds);
+            } else
             appendf(cs_, "lengths as data, %d thr, %d packed column pairs (FFT%d r%s in LDS%s), lds=%zuB", g.thr, g.g, g.n, rads(g).c_str(),
                     plan->n_blue_m ? ": a chirp convolution" : "", plan->n_c.lds);
         } else {
