@@ -687,13 +687,12 @@ def test_ifft_with_a_permuted_frequency_coordinate_on_a_non_last_axis(axis):
 @pytest.mark.parametrize("shape,dtype", [((2, 77, 90), "float64"), ((2, 63, 55), "float32"), ((1, 46, 60), "float32"), ((1, 243, 50), "float64"), ((2, 180, 84), "float64"),
                                          ((1, 94, 60), "float32"), ((2, 146, 44), "float64"), ((1, 206, 40), "float32"), ((1, 206, 40), "float64")])
 def test_two_pass_pipeline_with_the_lengths_as_data(shape, dtype, monkeypatch):
-    """csrc/fastn.h on the emulator (small slabs kept off the one-pass kernel): run-time radices incl. 7 / 11, odd lengths, the chirp convolution (94 = 2 x 47; 206 = 2 x 103
-    in float64), 4 passes (243), a table length on one side (180); the Rader columns (46 = 2 x 23, 146 = 2 x 73, 206 = 2 x 103 in float32: the 17-point butterfly)."""
+    """csrc/fastn.h on the emulator (small slabs kept off the one-pass kernel): run-time radices incl. 7 / 11, odd lengths, the chirp convolution (94 = 2 x 47),
+    4 passes (243), a table length on one side (180); the Rader columns (46 = 2 x 23, 146 = 2 x 73, 206 = 2 x 103: the 17-point butterfly)."""
     monkeypatch.setenv("XRFTHIP_FASTG", "0")
     cases.run_fastn_cases(shape, dtype)
     d = " ".join(p.describe() for p in api._plan_cache.values())
-    rader = shape[1] in (46, 146) or (shape[1] == 206 and dtype == "float32")
-    assert ("Rader" in d) == rader and ("chirp" in d) == (shape[1] == 94 or (shape[1] == 206 and dtype == "float64")), d
+    assert ("Rader" in d) == (shape[1] in (46, 146, 206)) and ("chirp" in d) == (shape[1] == 94), d
 
 
 @pytest.mark.parametrize("dtype", ["float64", "float32"])

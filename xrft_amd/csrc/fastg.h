@@ -176,7 +176,7 @@ __device__ __forceinline__ void fastg_cols_pass_inv_first(C2<T>* tile, int ncols
     }
 }
 
-template <typename T, bool X17 = false>  // (X17: the 17-point butterfly, too -- the float32 Rader forms only: it would cost every other kernel registers)
+template <typename T, bool X17 = false>  // (X17: the 17-point butterfly, too -- the Rader forms only: it would cost every other kernel registers)
 __device__ __forceinline__ void fastg_cols_pass_inv(C2<T>* tile, int ncols, int len, int rs, int R, int L, int tid, int nthr, const C2<T>* tw) {
     if (X17 && R == 17) { fastg_pass_cols_inv<T, X17 ? 17 : 2>(tile, ncols, len, rs, L, tid, nthr, tw); return; }
     switch (R) {
@@ -748,18 +748,18 @@ __global__ void __launch_bounds__(256) fastgy_kernel(FastGY p) {
             const CT* __restrict__ bh = reinterpret_cast<const CT*>(p.rad_b);
             int L = P1;
             for (int ps = 0; ps + 1 < p.nrp; ++ps) {
-                fastg_cols_pass<T, sizeof(T) == 4>(tile, qg, P1, qg, p.rp[ps], L, tid, nthr, twp);
+                fastg_cols_pass<T, true>(tile, qg, P1, qg, p.rp[ps], L, tid, nthr, twp);
                 L /= p.rp[ps];
                 __syncthreads();
             }
             // the last forward pass, * the transformed kernel, the frequency-0 exchanges and the first inverse pass in one (frequency 0 of the convolution = the sum of the samples with
             // n2 != 0: X[.][0] = x0 + sum, and x0 joins every other frequency)
-            fastg_cols_pass_inv_first<T, sizeof(T) == 4>(tile, qg, P1, qg, p.rp[p.nrp - 1], tid, nthr, bh, P1 * qg);
+            fastg_cols_pass_inv_first<T, true>(tile, qg, P1, qg, p.rp[p.nrp - 1], tid, nthr, bh, P1 * qg);
             __syncthreads();
             int Li = p.rp[p.nrp - 1];
             for (int ip = p.nrp - 2; ip >= 0; --ip) {
                 Li *= p.rp[ip];
-                fastg_cols_pass_inv<T, sizeof(T) == 4>(tile, qg, P1, qg, p.rp[ip], Li, tid, nthr, twp);
+                fastg_cols_pass_inv<T, true>(tile, qg, P1, qg, p.rp[ip], Li, tid, nthr, twp);
                 __syncthreads();
             }
         }

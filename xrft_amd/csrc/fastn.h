@@ -400,7 +400,7 @@ __global__ void __launch_bounds__(fastn_max_threads<T>(), (sizeof(T) == 4 ? 4 : 
     else if (RADER) {
         // along q inside every block of q rows (the tail passes of a length-ny transform), then Rader's cyclic convolution of p - 1 points across the first
         // p - 1 blocks (q G sequences side by side): forward passes, * the transformed kernel with the two frequency-0 exchanges, inverse passes (fastg.h)
-        constexpr bool X17 = sizeof(T) == 4;
+        constexpr bool X17 = true;
         RGeoRef rg = *P.rg;
         const CT* twp = twl + ny;
         __syncthreads();

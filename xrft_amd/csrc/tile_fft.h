@@ -185,7 +185,7 @@ template <typename T> struct PrimeTab<T, 13> {
     static __device__ __forceinline__ T c(int k) { const T t[6] = {(T)0.8854560256532098959004, (T)0.5680647467311558025118, (T)0.1205366802553230533491, (T)-0.3546048870425356259696, (T)-0.7485107481711010986346, (T)-0.970941817426052027157}; return t[k - 1]; }
     static __device__ __forceinline__ T s(int k) { const T t[6] = {(T)0.464723172043768545656, (T)0.8229838658936563945796, (T)0.9927088740980539928008, (T)0.9350162426854148234398, (T)0.6631226582407952023768, (T)0.2393156642875577671488}; return t[k - 1]; }
 };
-template <typename T> struct PrimeTab<T, 17> {  // (round 5: 102 = 6 x 17 -- Rader's convolution for the 103 of the ERA5 grid's 721 = 7 x 103 latitudes; float32 kernels only)
+template <typename T> struct PrimeTab<T, 17> {  // (round 5: 102 = 6 x 17 -- Rader's convolution for the 103 of the ERA5 grid's 721 = 7 x 103 latitudes; the Rader forms only)
     static __device__ __forceinline__ T c(int k) { const T t[8] = {(T)0.9324722294043558045731, (T)0.7390089172206591159245, (T)0.4457383557765382673965, (T)0.09226835946330199523965, (T)-0.2736629900720828635391, (T)-0.6026346363792563891786, (T)-0.8502171357296141521341, (T)-0.9829730996839017782819}; return t[k - 1]; }
     static __device__ __forceinline__ T s(int k) { const T t[8] = {(T)0.3612416661871529487447, (T)0.6736956436465572117127, (T)0.895163291355062322067, (T)0.9957341762950345218712, (T)0.9618256431728190704088, (T)0.7980172272802395033328, (T)0.5264321628773558002446, (T)0.1837495178165703315744}; return t[k - 1]; }
 };

@@ -2351,8 +2351,9 @@ static bool rader_split(long long n, bool dbl, int& p_out, std::vector<int>& rq,
         rq.clear(); rp.clear();
         if (q > 1 && !fastg_factor(q, rq)) return false;  // (a second prime without a butterfly)
         if (!fastg_factor(p - 1, rp)) {
-            // 103 - 1 = 6 x 17 (the ERA5 grid's 721 = 7 x 103 latitudes): the 17-point butterfly, float32 only (its registers)
-            if (dbl || (p - 1) % 17 || !fastg_factor((p - 1) / 17, rp)) return false;
+            // 103 - 1 = 6 x 17 (the ERA5 grid's 721 = 7 x 103 latitudes): the 17-point butterfly, which only the Rader forms carry (float64: 6 spilled registers)
+            (void)dbl;
+            if ((p - 1) % 17 || !fastg_factor((p - 1) / 17, rp)) return false;
             rp.push_back(17);
         }
         for (int r : rq) if (r > 16) return false;
