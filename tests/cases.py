@@ -1011,6 +1011,65 @@ def run_rows_any_length_cases(shape=(37, 250), dtype="float32"):
     return worst
 
 
+def run_rows_rader_cases(shape=(37, 365), dtype="float32"):
+    """One transform axis, the contiguous one, on a length with ONE prime factor 17 ... 127 (365 = 5 x 73 daily samples of (station, time) rows, 730, 1460, 366): the
+    prime-factor / Rader form of csrc/fastg.h's fastgy_kernel with the lanes along the samples (FORM 3) against the oracle -- fft (true phase, ifftshift), power spectrum,
+    every detrend, window, shift; an odd number of rows (the last sequence holds one row); complex rows; xrft.ifft; the cross spectrum and cross phase of two fields.
+    real_dim (half output) stays on the generic passes: checked for parity only."""
+    import warnings
+
+    rng = np.random.default_rng(79)
+    tol = TOL[dtype]
+    n = shape[-1]
+    v = (rng.standard_normal(shape) + 2.0 + 3.0 * np.arange(n) / n).astype(dtype)
+    dims = ("a", "b", "x")[-len(shape):]
+    c = {d: np.arange(s) for d, s in zip(dims[:-1], shape[:-1])}
+    c["x"] = np.arange(n) * 0.5 - 7.0
+    da, od = pair(v, dims, c)
+    od_det = od if dtype == "float64" else o.OArr(v.astype("float64"), dims, c)
+    worst = 0.0
+
+    def on_fast():
+        return "[fastg rows Rader]" in next(reversed(xa.api._plan_cache.values())).describe()
+
+    for kw in (dict(), dict(detrend="linear", window="hann"), dict(detrend="constant", shift=False), dict(true_phase=False, true_amplitude=False, window="hamming")):
+        worst = max(worst, check_values(xa.fft(da, dim=["x"], **kw), o.fft(od_det if "detrend" in kw else od, dim=["x"], **kw), tol))
+        assert on_fast(), kw
+    for kw in (dict(detrend="linear", window="hann"), dict(shift=False, scaling="spectrum", detrend="constant"), dict()):
+        worst = max(worst, check_values(xa.power_spectrum(da, dim=["x"], **kw), o.power_spectrum(od_det if "detrend" in kw else od, dim=["x"], **kw), tol))
+        assert on_fast(), kw
+    worst = max(worst, check(xa.power_spectrum(da, dim=["x"], real_dim="x", window="hann"), o.power_spectrum(od, dim=["x"], real_dim="x", window="hann"), tol))
+    # complex rows, and back
+    cdt = "complex128" if dtype == "float64" else "complex64"
+    z = (v + 1j * rng.standard_normal(shape)).astype(cdt)
+    dz, oz = pair(z, dims, c)
+    oz_det = oz if dtype == "float64" else o.OArr(z.astype("complex128"), dims, c)
+    for kw in (dict(), dict(detrend="linear", window="hann", shift=False)):
+        worst = max(worst, check_values(xa.fft(dz, dim=["x"], **kw), o.fft(oz_det if "detrend" in kw else oz, dim=["x"], **kw), tol))
+        assert on_fast(), kw
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        for kw in (dict(), dict(true_phase=False, shift=False), dict(true_phase=False), dict(shift=False)):
+            F, Fo = xa.fft(da, dim=["x"], **kw), o.fft(od, dim=["x"], **kw)
+            worst = max(worst, check_values(xa.ifft(F, dim=["freq_x"], **kw), o.ifft(Fo, dim=["freq_x"], **kw), tol))
+            assert on_fast(), kw
+    # two fields
+    w = (rng.standard_normal(shape) - 1.0).astype(dtype)
+    c2 = dict(c); c2["x"] = c["x"] + 1.25
+    db, ob = pair(w, dims, c2)
+    ob_det = ob if dtype == "float64" else o.OArr(w.astype("float64"), dims, c2)
+    for kw in (dict(detrend="linear", window="hann"), dict(true_phase=False, shift=False)):
+        det = "detrend" in kw
+        worst = max(worst, check_values(xa.cross_spectrum(da, db, dim=["x"], **kw), o.cross_spectrum(od_det if det else od, ob_det if det else ob, dim=["x"], **kw), tol))
+        assert on_fast(), kw
+    ph, pho = xa.cross_phase(da, db, dim=["x"]), o.cross_phase(od, ob, dim=["x"])
+    assert on_fast()
+    dphi = np.angle(np.exp(1j * (np.asarray(ph.values, dtype="float64") - np.asarray(pho.values, dtype="float64"))))
+    amp = np.abs(np.asarray(o.cross_spectrum(od, ob, dim=["x"], true_phase=True).values))
+    assert np.abs(dphi[amp > 1e-3 * amp.max()]).max() < (1e-9 if dtype == "float64" else 2e-3)
+    return worst
+
+
 def run_xonly_fast_cases(shape=(5, 360), dtype="float64"):
     """One short transform axis, the contiguous one (spectra along the last axis of (..., n) arrays, n in the fastm table):
     csrc/fastm.h fastm_xonly_kernel (rows packed in pairs; an odd number of rows leaves the last pair half empty) against the

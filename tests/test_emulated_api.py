@@ -644,6 +644,12 @@ def test_last_axis_any_smooth_length(shape, dtype):
     cases.run_rows_any_length_cases(shape, dtype)
 
 
+@pytest.mark.parametrize("shape,dtype", [((37, 365), "float32"), ((5, 730), "float64"), ((3, 4, 146), "float32"), ((2, 1460), "float64"), ((9, 97), "float64"), ((33, 58), "float32")])
+def test_last_axis_with_one_awkward_prime(shape, dtype):
+    """fastg.h, fastgy_kernel FORM 3: 1-D spectra along the contiguous axis on 365 / 730 / 1460 / 146 / 97 / 58-sample rows (Rader's algorithm along the prime)."""
+    cases.run_rows_rader_cases(shape, dtype)
+
+
 @pytest.mark.parametrize("shape,dtype", [((2, 360, 250), "float64"), ((1, 300, 512), "float32"), ((2, 243, 125), "float32"), ((3, 50, 50), "float64")])
 def test_inverse_transforms_on_the_one_pass_kernels(shape, dtype):
     """xrft.ifft over two axes as two one-pass stages, over one axis where it lies, small slabs in one pass (csrc/fastg.h)."""

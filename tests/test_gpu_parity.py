@@ -1041,6 +1041,14 @@ def test_last_axis_any_smooth_length(shape, dtype):
     cases.run_rows_any_length_cases(shape, dtype)
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape,dtype", [((3701, 365), "float32"), ((500, 730), "float64"), ((30, 41, 146), "float32"), ((200, 1460), "float64"), ((901, 97), "float64"), ((3333, 58), "float32"),
+                                         ((64, 2920), "float32"), ((777, 366), "float64")])
+def test_last_axis_with_one_awkward_prime(shape, dtype):
+    """fastg.h, fastgy_kernel FORM 3: 1-D spectra along the contiguous axis on 365 / 730 / 1460 / 2920 / 366-sample rows (Rader's algorithm along the prime)."""
+    cases.run_rows_rader_cases(shape, dtype)
+
+
 @pytest.mark.parametrize("shape,dtype", [((4, 360, 250), "float64"), ((3, 1024, 1024), "float32"), ((5, 243, 125), "float32"), ((30, 50, 50), "float64"), ((2, 1440, 720), "float64")])
 def test_inverse_transforms_on_the_one_pass_kernels(shape, dtype):
     """xrft.ifft over two axes as two one-pass stages, over one axis where it lies, small slabs in one pass (csrc/fastg.h)."""

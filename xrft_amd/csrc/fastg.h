@@ -79,9 +79,10 @@ struct FastG {
 };
 
 // one radix pass over the COLUMNS of the tile: sequences of length len, element stride rs, ncols of them; lanes run along the columns
+// (tws: the stride of W^(j k) in `tw` when that is not len / L -- the passes along q of the prime-factor form run on blocks of a length-n tile with a table of W_q alone)
 template <typename T, int R>
-__device__ __forceinline__ void fastg_pass_cols(C2<T>* tile, int ncols, int len, int rs, int L, int tid, int nthreads, const C2<T>* __restrict__ tw) {
-    const int m = L / R, per = len / R, nb = ncols * per, twstep = len / L;
+__device__ __forceinline__ void fastg_pass_cols(C2<T>* tile, int ncols, int len, int rs, int L, int tid, int nthreads, const C2<T>* __restrict__ tw, int tws = 0) {
+    const int m = L / R, per = len / R, nb = ncols * per, twstep = tws ? tws : len / L;
     const float inv_c = 1.0f / (float)ncols, inv_m = 1.0f / (float)m;
     for (int w = tid; w < nb; w += nthreads) {
         const int gg = fdiv(w, inv_c), c = w - gg * ncols;
@@ -219,24 +220,24 @@ __device__ __forceinline__ void fastg_rows_pass(C2<T>* tile, const TileGeom& g, 
     }
 }
 template <typename T, bool X17 = false>
-__device__ __forceinline__ void fastg_cols_pass(C2<T>* tile, int ncols, int len, int rs, int R, int L, int tid, int nthr, const C2<T>* tw) {
-    if (X17 && R == 17) { fastg_pass_cols<T, X17 ? 17 : 2>(tile, ncols, len, rs, L, tid, nthr, tw); return; }
+__device__ __forceinline__ void fastg_cols_pass(C2<T>* tile, int ncols, int len, int rs, int R, int L, int tid, int nthr, const C2<T>* tw, int tws = 0) {
+    if (X17 && R == 17) { fastg_pass_cols<T, X17 ? 17 : 2>(tile, ncols, len, rs, L, tid, nthr, tw, tws); return; }
     switch (R) {
-        case 2: fastg_pass_cols<T, 2>(tile, ncols, len, rs, L, tid, nthr, tw); break;
-        case 3: fastg_pass_cols<T, 3>(tile, ncols, len, rs, L, tid, nthr, tw); break;
-        case 4: fastg_pass_cols<T, 4>(tile, ncols, len, rs, L, tid, nthr, tw); break;
-        case 5: fastg_pass_cols<T, 5>(tile, ncols, len, rs, L, tid, nthr, tw); break;
-        case 6: fastg_pass_cols<T, 6>(tile, ncols, len, rs, L, tid, nthr, tw); break;
-        case 7: fastg_pass_cols<T, 7>(tile, ncols, len, rs, L, tid, nthr, tw); break;
-        case 8: fastg_pass_cols<T, 8>(tile, ncols, len, rs, L, tid, nthr, tw); break;
-        case 9: fastg_pass_cols<T, 9>(tile, ncols, len, rs, L, tid, nthr, tw); break;
-        case 10: fastg_pass_cols<T, 10>(tile, ncols, len, rs, L, tid, nthr, tw); break;
-        case 11: fastg_pass_cols<T, 11>(tile, ncols, len, rs, L, tid, nthr, tw); break;
-        case 12: fastg_pass_cols<T, 12>(tile, ncols, len, rs, L, tid, nthr, tw); break;
-        case 13: fastg_pass_cols<T, 13>(tile, ncols, len, rs, L, tid, nthr, tw); break;
-        case 14: fastg_pass_cols<T, 14>(tile, ncols, len, rs, L, tid, nthr, tw); break;
-        case 15: fastg_pass_cols<T, 15>(tile, ncols, len, rs, L, tid, nthr, tw); break;
-        default: fastg_pass_cols<T, 16>(tile, ncols, len, rs, L, tid, nthr, tw); break;
+        case 2: fastg_pass_cols<T, 2>(tile, ncols, len, rs, L, tid, nthr, tw, tws); break;
+        case 3: fastg_pass_cols<T, 3>(tile, ncols, len, rs, L, tid, nthr, tw, tws); break;
+        case 4: fastg_pass_cols<T, 4>(tile, ncols, len, rs, L, tid, nthr, tw, tws); break;
+        case 5: fastg_pass_cols<T, 5>(tile, ncols, len, rs, L, tid, nthr, tw, tws); break;
+        case 6: fastg_pass_cols<T, 6>(tile, ncols, len, rs, L, tid, nthr, tw, tws); break;
+        case 7: fastg_pass_cols<T, 7>(tile, ncols, len, rs, L, tid, nthr, tw, tws); break;
+        case 8: fastg_pass_cols<T, 8>(tile, ncols, len, rs, L, tid, nthr, tw, tws); break;
+        case 9: fastg_pass_cols<T, 9>(tile, ncols, len, rs, L, tid, nthr, tw, tws); break;
+        case 10: fastg_pass_cols<T, 10>(tile, ncols, len, rs, L, tid, nthr, tw, tws); break;
+        case 11: fastg_pass_cols<T, 11>(tile, ncols, len, rs, L, tid, nthr, tw, tws); break;
+        case 12: fastg_pass_cols<T, 12>(tile, ncols, len, rs, L, tid, nthr, tw, tws); break;
+        case 13: fastg_pass_cols<T, 13>(tile, ncols, len, rs, L, tid, nthr, tw, tws); break;
+        case 14: fastg_pass_cols<T, 14>(tile, ncols, len, rs, L, tid, nthr, tw, tws); break;
+        case 15: fastg_pass_cols<T, 15>(tile, ncols, len, rs, L, tid, nthr, tw, tws); break;
+        default: fastg_pass_cols<T, 16>(tile, ncols, len, rs, L, tid, nthr, tw, tws); break;
     }
 }
 
@@ -625,21 +626,23 @@ struct FastGY {
 };
 
 // MODE 1: power spectrum (real T out), 0: complex spectrum; FORM 1: the Bluestein form (its inverse passes cost the plain form 25 registers: a kernel of its own),
-// FORM 2: the prime-factor form with Rader's algorithm along the prime
+// FORM 2: the prime-factor form with Rader's algorithm along the prime; FORM 3: the same along the CONTIGUOUS axis -- [rows][ny samples], a sequence = two rows (1-D spectra of
+// (station, time) series on 365 / 730 / 1460 samples): the lanes of the load and of the output loop run along the samples, the tile's rows are one sequence wider (odd stride)
 template <typename T, int MODE, int FORM>
-__global__ void __launch_bounds__(256) fastgy_kernel(FastGY p) {
-    constexpr bool BLUE = FORM == 1, RADER = FORM == 2;
+__global__ void __launch_bounds__(256, (sizeof(T) == 4 ? 3 : 2)) fastgy_kernel(FastGY p) {  // (two waves per SIMD at least: the float64 Rader forms wanted 256 + registers -- one wave, 76 -> 46 GFFT/s)
+    constexpr bool BLUE = FORM == 1, RADER = FORM >= 2, ROWS = FORM == 3;
     typedef C2<T> CT;
     XRFT_DYN_SMEM(smem_raw);
     CT* tile = reinterpret_cast<CT*>(smem_raw);
     const int tid = threadIdx.x, nthr = blockDim.x, ny = p.ny, nx = p.nx, G = p.G, lg = p.lg;
     int C = 2 * G;  // columns of a unit
+    const int GS = ROWS ? G + 1 : G;        // sequences of a tile row incl. padding (ROWS: an odd stride -- consecutive lanes hold consecutive samples of ONE sequence)
     const int nrow = BLUE ? p.blue_m : ny;  // rows of the tile = length of the passes
-    unsigned char* tb = smem_raw + (((size_t)nrow * G * sizeof(CT) + 15) & ~(size_t)15);
+    unsigned char* tb = smem_raw + (((size_t)nrow * GS * sizeof(CT) + 15) & ~(size_t)15);
     double* part = reinterpret_cast<double*>(tb); tb += (size_t)nthr * 4 * sizeof(double);  // [row group][g][4]
     double* coef = reinterpret_cast<double*>(tb); tb += (size_t)G * 4 * sizeof(double);     // [g][mean re, slope re, mean im, slope im]
     const bool twin_lds = !BLUE || p.tw_lds;  // (the plain form always)
-    CT* twl = reinterpret_cast<CT*>(tb); tb += twin_lds ? (size_t)nrow * sizeof(CT) : 0;
+    CT* twl = reinterpret_cast<CT*>(tb); tb += twin_lds ? (size_t)(RADER ? p.rad_q : nrow) * sizeof(CT) : 0;  // (RADER: W_q alone, W_ny^(k p))
     T* wys = reinterpret_cast<T*>(tb); tb += (size_t)ny * sizeof(T);
     unsigned short* revy = reinterpret_cast<unsigned short*>(tb); tb += (size_t)ny * 2;
     tb += (size_t)(-(reinterpret_cast<intptr_t>(tb) - reinterpret_cast<intptr_t>(smem_raw))) & 15;  // (what follows holds complex values: 16-byte aligned)
@@ -651,12 +654,15 @@ __global__ void __launch_bounds__(256) fastgy_kernel(FastGY p) {
     }
     const CT* twy = twl;
     if (BLUE && !p.tw_lds) twy = reinterpret_cast<const CT*>(p.tw_y);
-    if (twin_lds) for (int k = tid; k < nrow; k += nthr) twl[k] = reinterpret_cast<const CT*>(p.tw_y)[k];
+    if (RADER) { for (int k = tid; k < p.rad_q; k += nthr) twl[k] = reinterpret_cast<const CT*>(p.tw_y)[k * p.rad_p]; }
+    else if (twin_lds) for (int k = tid; k < nrow; k += nthr) twl[k] = reinterpret_cast<const CT*>(p.tw_y)[k];
     for (int k = tid; k < ny; k += nthr) {
         if (!BLUE) revy[k] = (unsigned short)p.rev_y[k];
         if (p.win_y) wys[k] = reinterpret_cast<const T*>(p.win_y)[k];
     }
-    const int g = tid & (G - 1), rq = tid >> lg, RQ = nthr >> lg;  // (lane along the sequences, row group)
+    const int RQ = nthr >> lg;
+    // (lane along the sequences, row group; ROWS: lanes along the samples of a sequence -- they are contiguous in memory)
+    const int g = ROWS ? tid / RQ : tid & (G - 1), rq = ROWS ? tid - g * RQ : tid >> lg;
     const bool one_col = p.cin || p.two;                            // a sequence is ONE column (complex input, or a column of each of two fields)
     const int cpg = one_col ? 1 : 2, lc = one_col ? lg : lg + 1;    // columns per sequence; log2 of the columns of a unit
     C = G * cpg;
@@ -666,8 +672,10 @@ __global__ void __launch_bounds__(256) fastgy_kernel(FastGY p) {
         const long long b = unit / p.nblk;
         const int c0 = (int)(unit - b * p.nblk) * C;
         const bool live = c0 + cpg * g < nx;  // (real input: nx is even, a pair of columns is whole or absent)
-        const T* __restrict__ src = reinterpret_cast<const T*>(p.in) + ((size_t)b * ny * nx + c0 + cpg * g) * (p.cin ? 2 : 1);
-        const size_t rowstep = (size_t)nx * (p.cin ? 2 : 1);  // (in T elements)
+        const bool live1 = !ROWS || one_col || c0 + cpg * g + 1 < nx;  // (ROWS: an odd number of rows leaves the last sequence one row)
+        // ROWS: [nx rows][ny samples], the transform axis is the contiguous one; "column" c of the unit is row c0 + c
+        const T* __restrict__ src = reinterpret_cast<const T*>(p.in) + (ROWS ? (size_t)(c0 + cpg * g) * ny : (size_t)b * ny * nx + c0 + cpg * g) * (p.cin ? 2 : 1);
+        const size_t rowstep = ROWS ? (size_t)(p.cin ? 2 : 1) : (size_t)nx * (p.cin ? 2 : 1);  // (in T elements)
         __syncthreads();  // (the previous unit's output loop is done with the tile; the tables are in place)
         // ---- load (rows rq, rq + RQ, ... of sequence g); without a detrend the window rides along
         double s[4] = {0.0, 0.0, 0.0, 0.0};
@@ -675,7 +683,8 @@ __global__ void __launch_bounds__(256) fastgy_kernel(FastGY p) {
             CT z = mk<T>((T)0, (T)0);
             int is = i + p.ishift_in; if (is >= ny) is -= ny;  // (source row)
             if (live) {
-                if (p.two) z = mk<T>(src[(size_t)is * rowstep], (reinterpret_cast<const T*>(p.in_b) + ((size_t)b * ny * nx + c0 + g))[(size_t)is * rowstep]);
+                if (p.two) z = mk<T>(src[(size_t)is * rowstep], (reinterpret_cast<const T*>(p.in_b) + (ROWS ? (size_t)(c0 + g) * ny : (size_t)b * ny * nx + c0 + g))[(size_t)is * rowstep]);
+                else if (ROWS && !p.cin) z = mk<T>(src[is], live1 ? src[(size_t)ny + is] : (T)0);  // (the two rows of the sequence)
                 else z = *reinterpret_cast<const CT*>(src + (size_t)is * rowstep);
             }
             if (p.ph_in) z = cmul(z, reinterpret_cast<const CT*>(p.ph_y)[is]);
@@ -688,7 +697,7 @@ __global__ void __launch_bounds__(256) fastgy_kernel(FastGY p) {
                 const T w = reinterpret_cast<const T*>(p.win_y)[i];
                 z = mk<T>(z.re * w, z.im * w);
             }
-            tile[(RADER ? (int)pin[i] : i) * G + g] = z;
+            tile[(RADER ? (int)pin[i] : i) * GS + g] = z;
         }
         if (p.detrend) {
 #pragma unroll
@@ -707,7 +716,7 @@ __global__ void __launch_bounds__(256) fastgy_kernel(FastGY p) {
             __syncthreads();
             const double m0 = coef[g * 4], b0 = coef[g * 4 + 1], m1 = coef[g * 4 + 2], b1 = coef[g * 4 + 3];
             for (int i = rq; i < ny; i += RQ) {  // (each thread revisits the elements it loaded)
-                const int slot = (RADER ? (int)pin[i] : i) * G + g;
+                const int slot = (RADER ? (int)pin[i] : i) * GS + g;
                 CT z = tile[slot];
                 const double ri = (double)i - ibar;
                 z = mk<T>((T)((double)z.re - fma(b0, ri, m0)), (T)((double)z.im - fma(b1, ri, m1)));
@@ -724,7 +733,7 @@ __global__ void __launch_bounds__(256) fastgy_kernel(FastGY p) {
         {
             int L = RADER ? p.rad_q : nrow;
             for (int ps = 0; ps < p.nry; ++ps) {
-                fastg_cols_pass<T>(tile, G, nrow, G, p.ry[ps], L, tid, nthr, twy);
+                fastg_cols_pass<T>(tile, G, nrow, GS, p.ry[ps], L, tid, nthr, twy, RADER ? p.rad_q / L : 0);
                 L /= p.ry[ps];
                 __syncthreads();
             }
@@ -744,45 +753,49 @@ __global__ void __launch_bounds__(256) fastgy_kernel(FastGY p) {
             __syncthreads();
         }
         if (RADER) {  // along the prime: a cyclic convolution of the p - 1 blocks with n2 != 0 (q G sequences side by side, element stride q G)
-            const int P1 = p.rad_p - 1, qg = p.rad_q * G;
+            const int P1 = p.rad_p - 1, qg = p.rad_q * GS;
             const CT* __restrict__ bh = reinterpret_cast<const CT*>(p.rad_b);
             int L = P1;
             for (int ps = 0; ps + 1 < p.nrp; ++ps) {
-                fastg_cols_pass<T, true>(tile, qg, P1, qg, p.rp[ps], L, tid, nthr, twp);
+                fastg_cols_pass<T, sizeof(T) == 4>(tile, qg, P1, qg, p.rp[ps], L, tid, nthr, twp);
                 L /= p.rp[ps];
                 __syncthreads();
             }
             // the last forward pass, * the transformed kernel, the frequency-0 exchanges and the first inverse pass in one (frequency 0 of the convolution = the sum of the samples with
             // n2 != 0: X[.][0] = x0 + sum, and x0 joins every other frequency)
-            fastg_cols_pass_inv_first<T, true>(tile, qg, P1, qg, p.rp[p.nrp - 1], tid, nthr, bh, P1 * qg);
+            fastg_cols_pass_inv_first<T, sizeof(T) == 4>(tile, qg, P1, qg, p.rp[p.nrp - 1], tid, nthr, bh, P1 * qg);
             __syncthreads();
             int Li = p.rp[p.nrp - 1];
             for (int ip = p.nrp - 2; ip >= 0; --ip) {
                 Li *= p.rp[ip];
-                fastg_cols_pass_inv<T, true>(tile, qg, P1, qg, p.rp[ip], Li, tid, nthr, twp);
+                fastg_cols_pass_inv<T, sizeof(T) == 4>(tile, qg, P1, qg, p.rp[ip], Li, tid, nthr, twp);
                 __syncthreads();
             }
         }
         // ---- out: row orow of the C columns = frequency k of the two spectra packed in every sequence
         const int tot = ny << lc;
+        const float inv_ny = 1.0f / (float)ny;
         for (int e = tid; e < tot; e += nthr) {
-            const int orow = e >> lc, c = e & (C - 1), col = c0 + c;
+            int orow, c;
+            if (ROWS) { c = fdiv(e, inv_ny); orow = e - c * ny; }  // (lanes along the frequencies of one row: contiguous stores)
+            else { orow = e >> lc; c = e & (C - 1); }
+            const int col = c0 + c;
             if (col >= nx) continue;
             int k = orow - p.shift_y; if (k < 0) k += ny;
             const int km = k == 0 ? 0 : ny - k;
             CT v;
             if (p.cin) {
-                v = tile[(BLUE ? k : (int)revy[k]) * G + c];
+                v = tile[(BLUE ? k : (int)revy[k]) * GS + c];
                 if (p.inv) v.im = -v.im;
             } else if (p.two) {  // A = (Zk + conj Zm) / 2, B = (Zk - conj Zm) / 2i: A conj(B)
-                const CT zk = tile[(BLUE ? k : (int)revy[k]) * G + c], zm = tile[(BLUE ? km : (int)revy[km]) * G + c];
+                const CT zk = tile[(BLUE ? k : (int)revy[k]) * GS + c], zm = tile[(BLUE ? km : (int)revy[km]) * GS + c];
                 v = cmulc(mk<T>((T)0.5 * (zk.re + zm.re), (T)0.5 * (zk.im - zm.im)), mk<T>((T)0.5 * (zk.im + zm.im), (T)0.5 * (zm.re - zk.re)));
             } else {
-                const CT zk = tile[(BLUE ? k : (int)revy[k]) * G + (c >> 1)], zm = tile[(BLUE ? km : (int)revy[km]) * G + (c >> 1)];
+                const CT zk = tile[(BLUE ? k : (int)revy[k]) * GS + (c >> 1)], zm = tile[(BLUE ? km : (int)revy[km]) * GS + (c >> 1)];
                 v = (c & 1) ? mk<T>((T)0.5 * (zk.im + zm.im), (T)0.5 * (zm.re - zk.re))   // (Zk - conj Zm) / 2i
                             : mk<T>((T)0.5 * (zk.re + zm.re), (T)0.5 * (zk.im - zm.im));  // (Zk + conj Zm) / 2
             }
-            const size_t o = ((size_t)b * ny + orow) * nx + col;
+            const size_t o = ROWS ? (size_t)col * ny + orow : ((size_t)b * ny + orow) * nx + col;
             if (MODE == 1) {
                 reinterpret_cast<T*>(p.out)[o] = (v.re * v.re + v.im * v.im) * sc;
             } else {

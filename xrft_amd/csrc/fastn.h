@@ -81,7 +81,7 @@ struct FastN {
     int vec_ok;           // pass 2: the rows leave 16 bytes per lane (the row length divides)
     int rpu;              // pass 2: rows ky per workgroup (two fields: g.g = 2 rpu sequences)
     int dbg;              // ablation switches of the measuring scripts (XRFTHIP_FASTN_DBG; 0 in production): 1 no LDS passes, 2 no stores, 4 no first pass
-    // pass 1, the Rader form (FORM 2): g.n = f.ny, g.str = f.ny (the tile is [ny][G], lanes along the sequences), twm = W_ny then W_(p-1)
+    // pass 1, the Rader form (FORM 2): g.n = f.ny, g.str = f.ny (the tile is [ny][G], lanes along the sequences), twm = W_q then W_(p-1)
     RGeoPtr rg;
     const unsigned short* rad_pin;   // row of input sample i
     const unsigned short* rad_pout;  // row of frequency k
@@ -402,11 +402,11 @@ __global__ void __launch_bounds__(fastn_max_threads<T>(), (sizeof(T) == 4 ? 4 : 
         // p - 1 blocks (q G sequences side by side): forward passes, * the transformed kernel with the two frequency-0 exchanges, inverse passes (fastg.h)
         constexpr bool X17 = true;
         RGeoRef rg = *P.rg;
-        const CT* twp = twl + ny;
+        const CT* twp = twl + rg.q;  // (the staged table: W_q, then W_(p-1))
         __syncthreads();
         int L = rg.q;
         for (int ps = 0; ps < rg.nrq; ++ps) {
-            fastg_cols_pass<T>(lds, G, ny, G, rg.rq[ps], L, tid, nthr, twl);
+            fastg_cols_pass<T>(lds, G, ny, G, rg.rq[ps], L, tid, nthr, twl, rg.q / L);
             L /= rg.rq[ps];
             __syncthreads();
         }

@@ -362,6 +362,8 @@ struct xrfthip_plan {
     bool fastgy = false;
     int gy_G = 0, gy_thr = 0, gy_blue_m = 0;  // gy_blue_m: Bluestein inside the tile on blue_m rows (a prime factor of ny with no butterfly)
     int gy_rad_p = 0;                         // ... or, ny = q p with ONE such prime p <= 127 and p - 1 smooth: the prime-factor form with Rader's algorithm along p
+    bool gy_rows = false;                     // ... the same form along the CONTIGUOUS axis of a 1-D plan ([batch rows][nx samples]; fastgy_kernel FORM 3): gy_n = nx
+    long long gy_n = 0;                       // the transform length of a fastgy plan
     std::vector<int> gy_rp;                   // the radices of p - 1
     DevBuf gy_twp, gy_radb, gy_permin;
     bool gy_tw_lds = true;
@@ -872,6 +874,7 @@ void set_kernel_attrs_once() {
     SETF((fastgy_kernel<float, 0, 0>)); SETF((fastgy_kernel<float, 1, 0>)); SETF((fastgy_kernel<double, 0, 0>)); SETF((fastgy_kernel<double, 1, 0>));
     SETF((fastgy_kernel<float, 0, 1>)); SETF((fastgy_kernel<float, 1, 1>)); SETF((fastgy_kernel<double, 0, 1>)); SETF((fastgy_kernel<double, 1, 1>));
     SETF((fastgy_kernel<float, 0, 2>)); SETF((fastgy_kernel<float, 1, 2>)); SETF((fastgy_kernel<double, 0, 2>)); SETF((fastgy_kernel<double, 1, 2>));
+    SETF((fastgy_kernel<float, 0, 3>)); SETF((fastgy_kernel<float, 1, 3>)); SETF((fastgy_kernel<double, 0, 3>)); SETF((fastgy_kernel<double, 1, 3>));
 #define SETN(TT, CC) SETF((fastn_cols_kernel<TT, 0, CC>)); SETF((fastn_cols_kernel<TT, 1, 16>)); SETF((fastn_cols_kernel<TT, 2, 16>)); \
                      SETF((fastn_rows_kernel<TT, 0, false, CC>)); SETF((fastn_rows_kernel<TT, 1, false, CC>)); SETF((fastn_rows_kernel<TT, 1, true, CC>)); SETF((fastn_rows_kernel<TT, 2, false, CC>)); \
                      SETF((fastn_rows_kernel<TT, 2, true, CC>)); SETF((fastn_rows_kernel<TT, 3, false, CC>))
@@ -1810,7 +1813,7 @@ static bool fastn_pick(long long n, int g, bool blue, bool dbl, bool cols, int m
     return false;
 }
 
-static bool rader_split(long long n, bool dbl, int& p_out, std::vector<int>& rq, std::vector<int>& rp);
+static bool rader_split(long long n, bool allow17, int& p_out, std::vector<int>& rq, std::vector<int>& rp);
 // Decide which kernel runs each pass of a y-first plan on (ny, nx) and the layout of the intermediate between them.  Returns false when the plan stays
 // with the other paths (a length the butterflies do not factor and the chirp convolution does not fit, sequences that do not fit the LDS).
 static bool fastn_setup(xrfthip_plan* P) {
@@ -1855,7 +1858,7 @@ static bool fastn_setup(xrfthip_plan* P) {
     NGeo gc{};
     if (cols_rt) {
         long long mlen = d.ny;
-        if (!fastn_factor(d.ny, maxr, ry) && d.ny <= 8192 && env_ll("XRFTHIP_FASTN_RADER", 1) && rader_split(d.ny, dbl, rad_p, rq, rp)) {
+        if (!fastn_factor(d.ny, maxr, ry) && d.ny <= 8192 && env_ll("XRFTHIP_FASTN_RADER", 1) && rader_split(d.ny, true, rad_p, rq, rp)) {
             // ONE prime factor 17 ... 127 with a smooth p - 1 (721 = 7 x 103 latitudes, 365 = 5 x 73): the prime-factor form with Rader's algorithm along the prime
             // inside the column tile (fastg.h, fastn_cols_kernel<T, 2, 16>): the tile is [ny][G], no padding; ~2.4 transforms of the length in LDS where the chirp
             // convolution takes two of 2.1 x the length.  Column pairs per workgroup and threads as for the chirp convolution: small workgroups, several per CU
@@ -1875,7 +1878,7 @@ static bool fastn_setup(xrfthip_plan* P) {
                     if (!rows_rt && d.nx % (2 * cand) != 0) continue;
                     if (2LL * cand > d.nx + 1) continue;
                     NGeo c{};
-                    c.n = (int)d.ny; c.np = 0; c.g = cand; c.lg = ilog2i(cand); c.str = (int)d.ny; c.twn = (int)d.ny + rad_p - 1;
+                    c.n = (int)d.ny; c.np = 0; c.g = cand; c.lg = ilog2i(cand); c.str = (int)d.ny; c.twn = (int)(d.ny / rad_p) + rad_p - 1;
                     c.thr = thr_f ? (int)std::min<long long>(maxthr, (thr_f + 63) / 64 * 64) : ((long long)cand * d.ny >= 4096 && !dbl) ? 512 : 256;
                     const size_t lds = fastn_lds(c, cs, true) + 2 * (((size_t)d.ny + 7) & ~(size_t)7) * 2;
                     if (lds <= caps[ci]) { G = cand; t = c; }
@@ -2340,7 +2343,7 @@ static int fastg_build_iso(xrfthip_plan* P, const int32_t* bm) {
 // one transform axis that is not the contiguous one, any smooth length (fastg.h: fastgy_kernel): G complex sequences = 2 G real columns per workgroup,
 // the widest power of two (<= 128 bytes of a row) whose tile leaves three workgroups on a CU, or the widest that fits at all
 // n = q p, p ONE prime 17 ... 127 whose p - 1 the butterflies factor, q smooth and prime to p: the prime-factor form with Rader's algorithm along p (fastg.h)
-static bool rader_split(long long n, bool dbl, int& p_out, std::vector<int>& rq, std::vector<int>& rp) {
+static bool rader_split(long long n, bool allow17, int& p_out, std::vector<int>& rq, std::vector<int>& rp) {
     if (!env_ll("XRFTHIP_RADER", 1)) return false;
     for (int p = 17; p <= 127; ++p) {
         bool prime = true;
@@ -2351,9 +2354,9 @@ static bool rader_split(long long n, bool dbl, int& p_out, std::vector<int>& rq,
         rq.clear(); rp.clear();
         if (q > 1 && !fastg_factor(q, rq)) return false;  // (a second prime without a butterfly)
         if (!fastg_factor(p - 1, rp)) {
-            // 103 - 1 = 6 x 17 (the ERA5 grid's 721 = 7 x 103 latitudes): the 17-point butterfly, which only the Rader forms carry (float64: 6 spilled registers)
-            (void)dbl;
-            if ((p - 1) % 17 || !fastg_factor((p - 1) / 17, rp)) return false;
+            // 103 - 1 = 6 x 17 (the ERA5 grid's 721 = 7 x 103 latitudes): the 17-point butterfly, which only the Rader forms carry -- the two-pass pipeline's columns in both
+            // precisions (float64: 6 spilled registers), the one-axis kernel in float32 only (float64: 256 registers, one wave per SIMD; measured 76 -> 46 GFFT/s)
+            if (!allow17 || (p - 1) % 17 || !fastg_factor((p - 1) / 17, rp)) return false;
             rp.push_back(17);
         }
         for (int r : rq) if (r > 16) return false;
@@ -2366,16 +2369,20 @@ static bool rader_split(long long n, bool dbl, int& p_out, std::vector<int>& rq,
     return false;
 }
 
-static bool fastgy_try(xrfthip_plan* P) {
+static bool fastgy_try(xrfthip_plan* P, bool rows = false) {
     const xrfthip_desc& d = P->d;
     const bool two_f = d.out_mode == XRFTHIP_OUT_CROSS || d.out_mode == XRFTHIP_OUT_PHASE;
-    if (d.ndim != 2 || (!P->cplx_in && !two_f && (d.nx & 1)) || d.ny < 2 || d.ny > 16384 || d.batch * ((d.nx + 3) / 4) >= (1LL << 31)) return false;
+    const long long N = rows ? d.nx : d.ny;  // the transform length
+    if (rows) { if (d.ndim != 1 || d.nx < 17 || d.nx > 4096 || d.batch >= (1LL << 31)) return false; }
+    else if (d.ndim != 2 || (!P->cplx_in && !two_f && (d.nx & 1)) || d.ny < 2 || d.ny > 16384 || d.batch * ((d.nx + 3) / 4) >= (1LL << 31)) return false;
     bool gy = false;
     std::vector<int> ry, rp;
-    long long m = d.ny;  // rows of the tile = length of the passes: ny, or the Bluestein length when a prime factor of ny has no butterfly
+    long long m = N;  // rows of the tile = length of the passes: ny, or the Bluestein length when a prime factor of ny has no butterfly
     int blue_m = 0, rad_p = 0;
-    if (!fastg_factor(d.ny, ry) && d.ny <= 4096 && rader_split(d.ny, P->dbl, rad_p, ry, rp)) {
+    if (!fastg_factor(N, ry) && N <= 4096 && rader_split(N, !P->dbl, rad_p, ry, rp)) {
         // (ry: the radices of q; the tile holds ny rows)
+    } else if (rows) {
+        return false;  // (the contiguous axis: smooth lengths have fastg_kernel's row groups, the others the generic passes)
     } else if (!fastg_factor(d.ny, ry)) {
         rad_p = 0;
         for (m = 2 * d.ny - 1;; ++m) {
@@ -2393,8 +2400,8 @@ static bool fastgy_try(xrfthip_plan* P) {
     if (d.ny > 4096 && !blue_m) return false;
     const int thr = 256;
     auto lds_of = [&](int G, bool tw_lds) {
-        return (((size_t)m * G * P->csize + 15) & ~(size_t)15) + (tw_lds ? (size_t)m * P->csize : 0) + (size_t)thr * 4 * sizeof(double) + (size_t)G * 4 * sizeof(double) +
-               (size_t)d.ny * P->rsize + (size_t)d.ny * 2 + 16 + (rad_p ? (((size_t)d.ny * 2 + 15) & ~(size_t)15) + (size_t)rad_p * P->csize + 16 : 0);
+        return (((size_t)m * (rows ? G + 1 : G) * P->csize + 15) & ~(size_t)15) + (tw_lds ? (size_t)(rad_p ? m / rad_p : m) * P->csize : 0) + (size_t)thr * 4 * sizeof(double) + (size_t)G * 4 * sizeof(double) +
+               (size_t)N * P->rsize + (size_t)N * 2 + 16 + (rad_p ? (((size_t)N * 2 + 15) & ~(size_t)15) + (size_t)rad_p * P->csize + 16 : 0);
     };
     const int gmax = (int)(128 / P->csize);  // 128 bytes of a row: 16 float32 pairs, 8 float64 pairs
     int G = 0;
@@ -2409,7 +2416,7 @@ static bool fastgy_try(xrfthip_plan* P) {
     if (forced >= 1 && forced <= gmax && !(forced & (forced - 1)) && lds_of((int)forced, tw_lds) <= kLdsMax - 1024) G = (int)forced;
     if (!G) return false;
     P->g_ry = ry; P->gy_G = G; P->gy_thr = thr; P->gy_lds = lds_of(G, tw_lds); P->gy_blue_m = blue_m; P->gy_tw_lds = tw_lds;
-    P->gy_rad_p = rad_p; P->gy_rp = rp;
+    P->gy_rad_p = rad_p; P->gy_rp = rp; P->gy_rows = rows; P->gy_n = N;
     return true;
 }
 // the tables of the prime-factor / Rader form (fastg.h, FastGY::rad_p): the row of every input sample and of every frequency, the transformed kernel
@@ -2461,7 +2468,7 @@ static int rader_maps(int n, int p, const std::vector<int>& rq_, const std::vect
     return XRFTHIP_OK;
 }
 template <typename T> static int fastgy_rader_tables(xrfthip_plan* P) {
-    const int n = (int)P->d.ny, p = P->gy_rad_p, P1 = p - 1;
+    const int n = (int)P->gy_n, p = P->gy_rad_p, P1 = p - 1;
     std::vector<unsigned> pin, pout;
     std::vector<double> bre, bim;
     int rc = rader_maps(n, p, P->g_ry, P->gy_rp, pin, pout, bre, bim);
@@ -2475,18 +2482,19 @@ template <typename T> static int fastgy_rader_tables(xrfthip_plan* P) {
     if (!rc) rc = build_twiddle<T>(P->gy_twp, P1, P1);
     return rc;
 }
-// ... of the two-pass pipeline's column kernel (fastn.h, fastn_cols_kernel<T, 2, 16>): 16-bit row tables, W_ny then W_(p-1) in one staged table
+// ... of the two-pass pipeline's column kernel (fastn.h, fastn_cols_kernel<T, 2, 16>): 16-bit row tables, W_q then W_(p-1) in one staged table
 template <typename T> static int fastn_rader_tables(xrfthip_plan* P) {
     const int n = (int)P->d.ny, p = P->n_rad_p, P1 = p - 1;
     std::vector<unsigned> pin, pout;
     std::vector<double> bre, bim;
     int rc = rader_maps(n, p, P->n_rq, P->n_rp, pin, pout, bre, bim);
     if (rc) return rc;
-    std::vector<C2<T>> bh((size_t)P1), tw((size_t)n + P1);
+    const int q = n / p;
+    std::vector<C2<T>> bh((size_t)P1), tw((size_t)q + P1);
     for (int f = 0; f < P1; ++f) { bh[(size_t)f].re = (T)bre[(size_t)f]; bh[(size_t)f].im = (T)bim[(size_t)f]; }
     const long double pi2 = 2.0L * 3.14159265358979323846264338327950288L;
-    for (int k = 0; k < n; ++k) { const long double a = -pi2 * (long double)k / (long double)n; tw[(size_t)k].re = (T)cosl(a); tw[(size_t)k].im = (T)sinl(a); }
-    for (int k = 0; k < P1; ++k) { const long double a = -pi2 * (long double)k / (long double)P1; tw[(size_t)n + k].re = (T)cosl(a); tw[(size_t)n + k].im = (T)sinl(a); }
+    for (int k = 0; k < q; ++k) { const long double a = -pi2 * (long double)k / (long double)q; tw[(size_t)k].re = (T)cosl(a); tw[(size_t)k].im = (T)sinl(a); }
+    for (int k = 0; k < P1; ++k) { const long double a = -pi2 * (long double)k / (long double)P1; tw[(size_t)q + k].re = (T)cosl(a); tw[(size_t)q + k].im = (T)sinl(a); }
     std::vector<uint16_t> pi16((size_t)n), po16((size_t)n);
     for (int i = 0; i < n; ++i) { pi16[(size_t)i] = (uint16_t)pin[(size_t)i]; po16[(size_t)i] = (uint16_t)pout[(size_t)i]; }
     RGeo rg{};
@@ -2530,30 +2538,33 @@ static int run_fastgy(const xrfthip_plan* P, const void* in, const void* in_b, v
     p.in = in; p.out = out;
     const bool two = d.out_mode == XRFTHIP_OUT_CROSS || d.out_mode == XRFTHIP_OUT_PHASE;
     p.in_b = in_b; p.two = two ? 1 : 0; p.angle = d.out_mode == XRFTHIP_OUT_PHASE ? 1 : 0;
-    p.ny = (int)d.ny; p.nx = (int)d.nx; p.G = P->gy_G; p.lg = ilog2i(P->gy_G);
+    const bool rows = P->gy_rows;  // (the contiguous axis of a 1-D plan: "columns" are the batch's rows)
+    const int ax = rows ? 1 : 0;
+    p.ny = (int)P->gy_n; p.nx = rows ? (int)d.batch : (int)d.nx; p.G = P->gy_G; p.lg = ilog2i(P->gy_G);
     p.cin = P->cplx_in ? 1 : 0;
     const int ucols = ((P->cplx_in || two) ? 1 : 2) * P->gy_G;  // columns of a unit
-    p.nblk = (int)((d.nx + ucols - 1) / ucols);
-    p.nunits = d.batch * p.nblk;
+    p.nblk = (int)((p.nx + ucols - 1) / ucols);
+    p.nunits = rows ? (long long)p.nblk : d.batch * p.nblk;
     p.nry = (int)P->g_ry.size();
     for (int i = 0; i < p.nry; ++i) p.ry[i] = P->g_ry[(size_t)i];
     p.tw_y = P->g_twy.p; p.rev_y = (const unsigned*)P->g_revy.p;
     p.blue_m = P->gy_blue_m; p.blue_c = P->gy_bluec.p; p.blue_b = P->gy_blueb.p; p.tw_lds = P->gy_tw_lds ? 1 : 0;
-    p.rad_p = P->gy_rad_p; p.rad_q = P->gy_rad_p ? (int)(d.ny / P->gy_rad_p) : 0;
+    p.rad_p = P->gy_rad_p; p.rad_q = P->gy_rad_p ? (int)(P->gy_n / P->gy_rad_p) : 0;
     p.nrp = (int)P->gy_rp.size();
     for (int i = 0; i < p.nrp; ++i) p.rp[i] = P->gy_rp[(size_t)i];
     p.tw_p = P->gy_twp.p; p.rad_b = P->gy_radb.p; p.perm_in = (const unsigned*)P->gy_permin.p;
-    p.win_y = P->win[0].p;
-    p.ph_y = P->fph[0].p; p.ph_on = (d.out_mode != XRFTHIP_OUT_POWER && P->fph_on && !(d.flags & XRFTHIP_PHASE_IN)) ? 1 : 0;
+    p.win_y = P->win[ax].p;
+    p.ph_y = P->fph[ax].p; p.ph_on = (d.out_mode != XRFTHIP_OUT_POWER && P->fph_on && !(d.flags & XRFTHIP_PHASE_IN)) ? 1 : 0;
     p.inv = (d.flags & XRFTHIP_INVERSE) ? 1 : 0;
-    p.ishift_in = ((d.flags & XRFTHIP_INVERSE) && (d.flags & XRFTHIP_ISHIFT_Y)) ? (int)(d.ny / 2) : 0;
+    p.ishift_in = ((d.flags & XRFTHIP_INVERSE) && (d.flags & (rows ? XRFTHIP_ISHIFT_X : XRFTHIP_ISHIFT_Y))) ? (int)(P->gy_n / 2) : 0;
     p.ph_in = ((d.flags & XRFTHIP_PHASE_IN) && P->fph_on) ? 1 : 0;
     p.detrend = d.detrend;
-    p.shift_y = (d.flags & XRFTHIP_SHIFT_Y) ? (int)(d.ny / 2) : 0;
+    p.shift_y = (d.flags & (rows ? XRFTHIP_SHIFT_X : XRFTHIP_SHIFT_Y)) ? (int)(P->gy_n / 2) : 0;
     p.scale = d.scale;
     const dim3 grid((unsigned)std::min<long long>(p.nunits, 0x7fffffffLL)), blk((unsigned)P->gy_thr);
-    xrfthip_plan::ProfRec* rec = prof_begin(P, "fastg_yonly", st);
+    xrfthip_plan::ProfRec* rec = prof_begin(P, rows ? "fastg_rows_rader" : "fastg_yonly", st);
 #define GY_(TT, MM) do { if (P->gy_blue_m) { auto k = &fastgy_kernel<TT, MM, 1>; XRFT_LAUNCH(k, grid, blk, P->gy_lds, st, p); } \
+                         else if (P->gy_rows) { auto k = &fastgy_kernel<TT, MM, 3>; XRFT_LAUNCH(k, grid, blk, P->gy_lds, st, p); } \
                          else if (P->gy_rad_p) { auto k = &fastgy_kernel<TT, MM, 2>; XRFT_LAUNCH(k, grid, blk, P->gy_lds, st, p); } \
                          else { auto k = &fastgy_kernel<TT, MM, 0>; XRFT_LAUNCH(k, grid, blk, P->gy_lds, st, p); } } while (0)
     const bool cplx = d.out_mode != XRFTHIP_OUT_POWER;  // (complex spectrum, cross spectrum, cross phase: MODE 0)
@@ -3299,6 +3310,19 @@ int xrfthip_plan_create(xrfthip_plan** plan, const xrfthip_desc* desc) {
             if (rcg) { delete P; return rcg; }
         }
     }
+    {   // ... and along the CONTIGUOUS axis of a 1-D plan when the length holds ONE prime 17 ... 127 (365 / 730 / 1460-sample (station, time) rows): the same kernel's
+        // prime-factor / Rader form with the lanes along the samples (fastg.h, FORM 3); every other 1-D length has its kernels below
+        const bool two = d.out_mode == XRFTHIP_OUT_CROSS || d.out_mode == XRFTHIP_OUT_PHASE;
+        const uint32_t allowed = XRFTHIP_SHIFT_X | (d.out_mode != XRFTHIP_OUT_POWER ? XRFTHIP_ISHIFT_X : 0u) |
+                                 ((cplx_in && d.out_mode == XRFTHIP_OUT_COMPLEX) ? (XRFTHIP_INVERSE | XRFTHIP_PHASE_IN) : 0u);
+        if (!P->fastgy && d.ndim == 1 && (d.out_mode == XRFTHIP_OUT_COMPLEX || d.out_mode == XRFTHIP_OUT_POWER || (two && !cplx_in)) && !(d.flags & ~allowed) &&
+            !env_ll("XRFTHIP_NO_FAST", 0) && env_ll("XRFTHIP_FASTG", 1) != 0 && fastgy_try(P, true)) {
+            P->fastgy = true;
+            int rcg = P->dbl ? build_twiddle<double>(P->g_twy, d.nx, d.nx) : build_twiddle<float>(P->g_twy, d.nx, d.nx);
+            if (!rcg) rcg = P->dbl ? fastgy_rader_tables<double>(P) : fastgy_rader_tables<float>(P);
+            if (rcg) { delete P; return rcg; }
+        }
+    }
     {   // one short transform axis, the contiguous one, real input: rows packed in pairs through the same three passes
         const bool two = d.out_mode == XRFTHIP_OUT_CROSS || d.out_mode == XRFTHIP_OUT_PHASE;
         const uint32_t allowed = XRFTHIP_SHIFT_X | XRFTHIP_HALF_X | (d.out_mode != XRFTHIP_OUT_PHASE ? XRFTHIP_REALDIM_X2 : 0u) | (d.out_mode != XRFTHIP_OUT_POWER ? XRFTHIP_ISHIFT_X : 0u) |
@@ -3498,7 +3522,7 @@ int xrfthip_plan_kernel_info(const xrfthip_plan* plan, int32_t* kind, int32_t* p
     else if (P->fasts) { k = XRFTHIP_K_FASTS; n = 1; }
     else if (P->fastr) { k = XRFTHIP_K_FASTR; n = 1; }
     else if (P->fastmx) { k = XRFTHIP_K_FASTM_X; const MGeomRt C = mxgeom(P->d.nx, P->dbl); n = (two || P->cplx_in) ? C.g : 2 * C.g; }
-    else if (P->fastgy) { k = XRFTHIP_K_FASTG_Y; n = ((P->cplx_in || two) ? 1 : 2) * P->gy_G; }
+    else if (P->fastgy) { k = P->gy_rows ? XRFTHIP_K_FASTG_ROWS : XRFTHIP_K_FASTG_Y; n = ((P->cplx_in || two) ? 1 : 2) * P->gy_G; }
     else if (P->fastmy) { k = XRFTHIP_K_FASTM_Y; const MGeomRt C = mygeom(P->d.ny, P->dbl); n = ((P->cplx_in || two) ? 1 : 2) * C.g; }
     else if (P->fastm) { k = P->fastn ? XRFTHIP_K_FASTN : XRFTHIP_K_FASTM; n = plan_cw(P); }
     else if (fasty_on(P)) { k = XRFTHIP_K_FASTY; n = 0; }
@@ -3595,6 +3619,10 @@ int xrfthip_plan_describe(const xrfthip_plan* plan, char* buf, size_t buflen) {
         std::string rys;
         for (int r : plan->g_ry) rys += (rys.empty() ? "" : "x") + std::to_string(r);
         const bool onecol = plan->cplx_in || plan->d.out_mode == XRFTHIP_OUT_CROSS || plan->d.out_mode == XRFTHIP_OUT_PHASE;
+        if (plan->gy_rows)
+            appendf(s, "  [fastg rows Rader] one pass along the contiguous axis, %d thr, %d sequences (%s) per workgroup, lanes along the samples, lds=%zuB: per-row detrend + window + transform%s\n",
+                    plan->gy_thr, plan->gy_G, plan->cplx_in ? "complex rows" : onecol ? "a row of each of the two fields" : "pairs of rows", plan->gy_lds, (plan->d.flags & XRFTHIP_INVERSE) ? "; inverse (conj in, conj out)" : "");
+        else
         appendf(s, "  [fastg y-only] one pass, %d thr, %d %s per workgroup (%d bytes of a row), the radices from the plan (y: %lld = %s in LDS), lds=%zuB: "
                    "per-column detrend + window + transform%s, in place in memory order%s\n",
                 plan->gy_thr, plan->gy_G, plan->cplx_in ? "complex columns" : onecol ? "columns of each of the two fields" : "packed column pairs",
@@ -3603,9 +3631,9 @@ int xrfthip_plan_describe(const xrfthip_plan* plan, char* buf, size_t buflen) {
         if (plan->gy_rad_p) {
             std::string rps;
             for (int r : plan->gy_rp) rps += (rps.empty() ? "" : "x") + std::to_string(r);
-            appendf(s, "  [fastg y-only Rader] %lld = %lld x %d: the prime-factor form, no twiddles between the two dimensions; along the prime %d a cyclic convolution of %d = %s points "
-                       "(forward passes, * the transformed kernel, inverse passes) inside the tile\n",
-                    (long long)plan->d.ny, (long long)(plan->d.ny / plan->gy_rad_p), plan->gy_rad_p, plan->gy_rad_p, plan->gy_rad_p - 1, rps.c_str());
+            appendf(s, "  [fastg %s Rader] %lld = %lld x %d: the prime-factor form, no twiddles between the two dimensions; along the prime %d a cyclic convolution of %d = %s points "
+                       "(forward passes, * the transformed kernel, inverse passes) inside the tile\n", plan->gy_rows ? "rows:" : "y-only",
+                    (long long)plan->gy_n, (long long)(plan->gy_n / plan->gy_rad_p), plan->gy_rad_p, plan->gy_rad_p, plan->gy_rad_p - 1, rps.c_str());
         }
         if (plan->gy_blue_m)
             appendf(s, "  [fastg y-only Bluestein] %lld points as a circular convolution of %d inside the tile (chirp products, forward and inverse passes)%s\n",
