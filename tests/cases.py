@@ -1337,6 +1337,35 @@ def run_fused_inner_cases(dtype="float64", shapes=((24, 20, 6), (16, 48, 3), (36
     return worst
 
 
+def run_fused_mid_cases(dtype="float64", shapes=((24, 5, 20), (16, 3, 48), (36, 7, 30), (2, 28, 4, 18), (40, 2, 16), (146, 3, 24))):
+    """dim = ["t", "x"] of a real (..., t, y, x) array -- wavenumber-frequency spectra of (time, lat, lon) fields, the two transform axes NOT adjacent -- as the engine's two
+    FUSED passes (csrc/fastn.h: fastn_cols_kernel on the [nt][ny nx] view, a plane per (slab, y), fastn_irows_kernel with the lanes along x; describe() says [fastn fused])
+    against the oracle.  xrft.py:395-409, 421-447."""
+    rng = np.random.default_rng(6)
+    tol = TOL[dtype]
+    worst = 0.0
+    for shape in shapes:
+        nt, ny, nx = shape[-3:]
+        ii, jj = np.meshgrid(np.arange(nt), np.arange(nx), indexing="ij")
+        # (a trend per y element of 1 ... 2 times the base plane, at most ~40 x the noise: the residual's relative error grows with trend / noise -- the plane fit's own
+        # conditioning, the same in the oracle)
+        v = (rng.standard_normal(shape) + (0.05 * ii - 0.03 * jj + 2.0)[:, None, :] * (min(1.0, 500.0 / nt) * (1.0 + np.arange(ny) / ny))[None, :, None]).astype(dtype)
+        dims = ("t", "y", "x") if len(shape) == 3 else ("b", "t", "y", "x")
+        c = {"t": np.arange(nt) * 0.5 + 1.0, "y": np.arange(ny), "x": np.arange(nx) * 2.0 - 3.0}
+        if len(shape) == 4:
+            c["b"] = np.arange(shape[0])
+        da, od = pair(v, dims, c)
+        for kw in (dict(), dict(detrend="linear", window="hann"), dict(detrend="constant", shift=False, true_phase=False), dict(window="hamming", true_amplitude=False)):
+            worst = max(worst, check(xa.fft(da, dim=["t", "x"], **kw), o.fft(od, dim=["t", "x"], **kw), tol))
+            d = next(reversed(xa.api._plan_cache.values())).describe()
+            assert "[fastn fused]" in d and "[mid %d]" % ny in d, (shape, kw, d)
+        for kw in (dict(detrend="linear", window="hann"), dict(scaling="spectrum", shift=False), dict(detrend="constant", window="hann", window_correction=True)):
+            worst = max(worst, check(xa.power_spectrum(da, dim=["t", "x"], **kw), o.power_spectrum(od, dim=["t", "x"], **kw), tol))
+            assert "[fastn fused]" in next(reversed(xa.api._plan_cache.values())).describe(), (shape, kw)
+        worst = max(worst, check(xa.power_spectrum(da, dim=["x", "t"], window="hann"), o.power_spectrum(od, dim=["x", "t"], window="hann"), tol))
+    return worst
+
+
 def run_fused_radial_code_forms(n=256):
     """The fused radial sums of the y-first float32 kernels (csrc/fasty.h): a radial bin map (what isotropic_*_spectrum hands
     over) is summed by a per-bin gather with no atomics; any other map through int64 fixed-point tables, its codes compact (first bin

@@ -518,6 +518,11 @@ def test_inner_layout_as_two_fused_passes(dtype):
     cases.run_fused_inner_cases(dtype)
 
 
+@pytest.mark.parametrize("dtype", ["float64", "float32"])
+def test_two_axes_that_are_not_adjacent_as_two_fused_passes(dtype):
+    cases.run_fused_mid_cases(dtype)
+
+
 def test_huge_slab_along_a_first_axis_takes_the_transposing_path():
     """a cube whose [n][inner] slab exceeds 2^31 elements cannot be indexed by the one-axis plans; plan creation is
     refused (XRFTHIP_BAD_ARG) and the API must not hand that error to the caller -- it never asks for such a plan."""

@@ -970,6 +970,12 @@ def test_inner_layout_as_two_fused_passes(dtype):
     cases.run_fused_inner_cases(dtype, shapes=((360, 256, 12), (250, 1000, 7), (2, 512, 384, 64), (1215, 90, 21)))
 
 
+@pytest.mark.parametrize("dtype", ["float64", "float32"])
+def test_two_axes_that_are_not_adjacent_as_two_fused_passes(dtype):
+    cases.run_fused_mid_cases(dtype)
+    cases.run_fused_mid_cases(dtype, shapes=((360, 12, 250), (1440, 73, 144), (2, 250, 9, 1000), (512, 3, 384), (365, 37, 72), (1460, 19, 144)))
+
+
 @pytest.mark.parametrize("dtype", ["float32", "float64"])
 def test_two_axes_with_the_batch_innermost_without_copies(dtype):
     """dim = ["y", "x"] of a (y, x, t) array -- the batch INNERMOST -- runs where the axes lie (xrfthip_desc.inner; the reference

@@ -690,6 +690,9 @@ struct FastNI {
     void* out;           // [slab][ny][nx][inner]: T (power) or complex T
     int ph_on, vec, dbg; // vec: the result is written in 16-byte pieces; dbg: ablations for measurements (1 no LDS passes, 2 no stores, 4 no loads)
     int ny, nx, inner, nrow_pad, pitch, l_cw, l_rk, detrend, shift_y, shift_x, neb, nunits;
+    // `inner` = the independent elements e of a row; sample (x, e) is column x sx + e se of the view -- the elements INNERMOST ([ny][nx][inner]: sx = inner, se = 1) or
+    // BETWEEN the two axes ([ny][mid][nx], dim = ["time", "lon"] of a (time, lat, lon) array: sx = 1, se = nx; `midlay`: the lanes then run along x, not along e)
+    int sx, se, midlay;
     double scale;
 };
 
@@ -697,7 +700,10 @@ template <typename T, int R>
 __device__ __forceinline__ void n_first_irows(const FastNI& p, NGeoRef g, C2<T>* lds, int w, int ky, int slab, int e0) {
     typedef C2<T> CT;
     const int M0 = g.m[0], rk = 1 << p.l_rk, cwm = (1 << p.l_cw) - 1;
-    const int ge = w & (g.g - 1), j = w >> g.lg, e = min(e0 + ge, p.inner - 1);  // (a ragged last block re-reads the last element; never stored)
+    int ge, j;
+    if (p.midlay) { ge = w / M0; j = w - ge * M0; }  // (lanes along x: the samples of a sequence are contiguous)
+    else { ge = w & (g.g - 1); j = w >> g.lg; }
+    const int e = min(e0 + ge, p.inner - 1);  // (a ragged last block re-reads the last element; never stored)
     const CT w0 = reinterpret_cast<const CT*>(p.tw_x)[j];
     const CT* __restrict__ blk = reinterpret_cast<const CT*>(p.w2) + ((size_t)slab * p.nrow_pad + (size_t)((ky >> p.l_rk) << p.l_rk)) * p.pitch;
     const CT* __restrict__ cr = reinterpret_cast<const CT*>(p.corr) + (size_t)slab * p.nx * p.inner;
@@ -707,7 +713,7 @@ __device__ __forceinline__ void n_first_irows(const FastNI& p, NGeoRef g, C2<T>*
     if (addback) { h0 = reinterpret_cast<const CT*>(p.what0)[ky]; h1 = reinterpret_cast<const CT*>(p.what1)[ky]; }
 #pragma unroll
     for (int q = 0; q < R; ++q) {
-        const int col = (j + q * M0) * p.inner + e;
+        const int col = (j + q * M0) * p.sx + e * p.se;
         if (p.dbg & 4) { a[q] = mk<T>((T)col, (T)ky); c[q] = a[q]; continue; }
         a[q] = blk[((((col >> p.l_cw) << p.l_rk) + (ky & (rk - 1))) << p.l_cw) + (col & cwm)];
         c[q] = addback ? cr[col] : mk<T>((T)0, (T)0);
@@ -789,15 +795,19 @@ __global__ void __launch_bounds__(fastn_max_threads<T>(), (sizeof(T) == 4 ? 4 : 
         }
         return;
     }
+    const size_t osx = p.midlay ? 1 : (size_t)p.inner, ose = p.midlay ? (size_t)NX : 1;  // the result's strides along kx and along e
     for (int idx = tid; idx < tot; idx += nthr) {
-        const int ge = idx & (GE - 1), rest = idx >> g.lg, mir = fdiv(rest, inv_nx), oc = rest - mir * NX, e = e0 + ge;
+        int ge, mir, oc;
+        if (p.midlay) { const int rest = fdiv(idx, inv_nx); oc = idx - rest * NX; mir = rest >> g.lg; ge = rest & (GE - 1); }  // (lanes along kx: contiguous stores)
+        else { ge = idx & (GE - 1); const int rest = idx >> g.lg; mir = fdiv(rest, inv_nx); oc = rest - mir * NX; }
+        const int e = e0 + ge;
         if (e >= p.inner) continue;
         int fx = oc - sx; if (fx < 0) fx += NX;                 // unshifted frequency of output column oc
         const int kx = mir ? (fx == 0 ? 0 : NX - fx) : fx;      // F(-ky, fx) = conj F(ky, -fx)
         const int fy = mir ? p.ny - ky : ky;
         int orow = fy + sy; if (orow >= p.ny) orow -= p.ny;
         CT v = lds[ge * g.str + n_pad(kx, ipn)];
-        OutT* dst = outs + ((size_t)orow * NX + oc) * p.inner + e;
+        OutT* dst = outs + (size_t)orow * NX * p.inner + (size_t)oc * osx + (size_t)e * ose;
         if (MODE == 1) {
             *reinterpret_cast<T*>(dst) = (v.re * v.re + v.im * v.im) * sc;
         } else {
@@ -809,9 +819,9 @@ __global__ void __launch_bounds__(fastn_max_threads<T>(), (sizeof(T) == 4 ? 4 : 
     }
 }
 
-// one plane per (slab, e) from the sums of its nx columns (fastm_fit_kernel with the columns of an element `inner` apart): one 256-thread block each
+// one plane per (slab, e) from the sums of its nx columns (fastm_fit_kernel with the columns of an element sx apart, the elements se): one 256-thread block each
 template <typename T>
-__global__ void __launch_bounds__(256) fastn_fit_inner_kernel(const double* colfit, const T* win_x_exp, C2<T>* corr, int nx, int inner, int ny, int detrend) {
+__global__ void __launch_bounds__(256) fastn_fit_inner_kernel(const double* colfit, const T* win_x_exp, C2<T>* corr, int nx, int inner, int ny, int detrend, int sx, int se) {
     XRFT_DYN_SMEM(smem_raw);
     double* red = reinterpret_cast<double*>(smem_raw);
     const int slab = blockIdx.x / inner, e = blockIdx.x - slab * inner, tid = threadIdx.x;
@@ -820,7 +830,7 @@ __global__ void __launch_bounds__(256) fastn_fit_inner_kernel(const double* colf
     const double inv_n = 1.0 / ny, inv_sii = 12.0 / ((double)ny * ((double)ny * ny - 1.0));
     double s[3] = {0.0, 0.0, 0.0};
     for (int x = tid; x < nx; x += 256) {
-        const size_t c = (size_t)x * inner + e;
+        const size_t c = (size_t)x * sx + (size_t)e * se;
         const double m = cf4[4 * c] * inv_n, sl = cf4[4 * c + 1] * inv_sii;
         s[0] += m;
         s[1] += ((double)x - xbar) * m;
@@ -835,7 +845,7 @@ __global__ void __launch_bounds__(256) fastn_fit_inner_kernel(const double* colf
     const double cc = detrend == 2 ? red[2] / nx : 0.0;
     C2<T>* out = corr + (size_t)slab * nx * inner;
     for (int x = tid; x < nx; x += 256) {
-        const size_t c = (size_t)x * inner + e;
+        const size_t c = (size_t)x * sx + (size_t)e * se;
         const double wx = (double)win_x_exp[c];
         out[c] = mk<T>((T)(wx * (cf4[4 * c + 2] - a - b * ((double)x - xbar))), (T)(wx * (cf4[4 * c + 3] - cc)));
     }

@@ -2903,11 +2903,12 @@ static int run_detrend_inner(int32_t dtype, int32_t ndim, long long batch, long 
 // ---------------------------------------------------------------------------------------------------------------
 static int fusedi_tables(xrfthip_plan* P) {  // what depends on the windows / phases: called from finalize_plan
     const xrfthip_desc& d = P->d;
-    const long long ncol = d.nx * d.inner;
+    const long long ne = std::max<long long>(d.inner, std::max<long long>(d.mid, 1)), ncol = d.nx * ne;
+    const long long sx = d.mid > 1 ? 1 : d.inner, se = d.mid > 1 ? d.nx : 1;
     std::vector<double> wexp((size_t)ncol);
     for (long long x = 0; x < d.nx; ++x) {
         const double w = P->host_win_x.empty() ? 1.0 : P->host_win_x[(size_t)x];
-        for (long long e = 0; e < d.inner; ++e) wexp[(size_t)(x * d.inner + e)] = w;
+        for (long long e = 0; e < ne; ++e) wexp[(size_t)(x * sx + e * se)] = w;
     }
     int rc = upload_real_table(P, P->winx_exp, wexp.data(), ncol, 0);
     if (!rc) rc = fasty_window_spectra(P);
@@ -2917,13 +2918,16 @@ static int fusedi_tables(xrfthip_plan* P) {  // what depends on the windows / ph
 
 static xrfthip_plan* create_fused_inner(const xrfthip_desc& d) {
     if (env_ll("XRFTHIP_NO_FAST", 0) || !env_ll("XRFTHIP_FASTN", 1) || !env_ll("XRFTHIP_FUSED_INNER", 1)) return nullptr;
-    if (d.ndim != 2 || d.mid > 1 || d.inner < 2 || (d.dtype != XRFTHIP_F32 && d.dtype != XRFTHIP_F64)) return nullptr;
+    // (the independent elements innermost, or between the two axes -- not both)
+    if (d.ndim != 2 || !((d.mid <= 1 && d.inner >= 2) || (d.mid >= 2 && d.inner <= 1)) || (d.dtype != XRFTHIP_F32 && d.dtype != XRFTHIP_F64)) return nullptr;
+    const bool midlay = d.mid >= 2;
+    const long long ne = midlay ? d.mid : d.inner;
     if (d.out_mode != XRFTHIP_OUT_COMPLEX && d.out_mode != XRFTHIP_OUT_POWER) return nullptr;
     const uint32_t ok = XRFTHIP_SHIFT_Y | XRFTHIP_SHIFT_X | (d.out_mode == XRFTHIP_OUT_COMPLEX ? (XRFTHIP_ISHIFT_Y | XRFTHIP_ISHIFT_X) : 0u);
     if (d.flags & ~ok) return nullptr;  // (a flipped axis: the composite of one-axis plans)
     const bool dbl = d.dtype == XRFTHIP_F64;
     const size_t rs = dbl ? 8 : 4, cs = 2 * rs;
-    const long long ncol = d.nx * d.inner;
+    const long long ncol = d.nx * ne;
     if (d.ny < 16 || d.nx < 16 || d.ny > 8192 || d.nx > 8192 || ncol > (1LL << 26) || (unsigned long long)d.ny * (unsigned long long)ncol * rs >= (1ULL << 32)) return nullptr;
     const int maxthr = dbl ? fastn_max_threads<double>() : fastn_max_threads<float>();
     const int maxr = dbl ? fastn_max_radix<double>() : fastn_max_radix<float>();
@@ -2944,10 +2948,27 @@ static xrfthip_plan* create_fused_inner(const xrfthip_desc& d) {
             if ((long long)t.g * (d.ny / t.r[t.np - 1]) > maxthr) continue;
             if (fastn_lds(t, cs, true) <= (f_gc ? caps[2] : caps[ci])) { G = cand; gc = t; }
         }
+    // ... or, a length with ONE prime 17 ... 127 (1460 = 20 x 73 six-hourly samples of a year along "time"): the Rader columns (fastn_cols_kernel<T, 2, 16>), as fastn_setup
+    int rad_p = 0;
+    std::vector<int> rad_rq, rad_rp;
+    if (!G && !f_gc && d.ny <= 8192 && env_ll("XRFTHIP_FASTN_RADER", 1) && rader_split(d.ny, true, rad_p, rad_rq, rad_rp)) {
+        for (int cand = dbl ? 4 : 8; cand >= 1 && !G; cand >>= 1) {
+            if (cand > 1 && (long long)cand * d.ny > 6000) continue;
+            NGeo c{};
+            c.n = (int)d.ny; c.np = 0; c.g = cand; c.lg = ilog2i(cand); c.str = (int)d.ny; c.twn = (int)(d.ny / rad_p) + rad_p - 1;
+            c.thr = ((long long)cand * d.ny >= 4096 && !dbl) ? 512 : 256;
+            if (fastn_lds(c, cs, true) + 2 * (((size_t)d.ny + 7) & ~(size_t)7) * 2 <= 156 * 1024) { G = cand; gc = c; }
+        }
+        if (!G) rad_p = 0;
+    }
     // pass 2: GE sequences (consecutive inner elements) of nx points: 64-byte runs of the result where the LDS allows
+    // (midlay: the sequences are contiguous rows -- as many as make ~4096 (float64: 2048) points, two at least: (1440, 73, 144) with two 144-point rows per workgroup
+    // ran 26 000 tiny workgroups, 115 us)
+    int ge_mid = 2;
+    while (ge_mid < 32 && (long long)ge_mid * 2 * d.nx <= (dbl ? 2048 : 4096)) ge_mid *= 2;
     for (int ci = 0; ci < 3 && !GE; ++ci)
-        for (int cand = f_ge ? f_ge : (dbl ? 4 : 8); cand >= 1 && !GE; cand >>= 1) {
-            if (cand > 2 * d.inner) continue;
+        for (int cand = f_ge ? f_ge : midlay ? ge_mid : (dbl ? 4 : 8); cand >= 1 && !GE; cand >>= 1) {
+            if (cand > 2 * ne) continue;
             NGeo t{};
             // (float32: 512 threads where a workgroup holds eight sequences, 231 us against 292 with 256; float64: 256, 182 us against 249 with 384)
             const int tr = f_tr ? f_tr : dbl ? 256 : ((long long)cand * d.nx >= 4096) ? 512 : 0;
@@ -2960,11 +2981,12 @@ static xrfthip_plan* create_fused_inner(const xrfthip_desc& d) {
     if (!P) return nullptr;
     P->d = d;
     P->fusedi = true;
-    P->inner = d.inner; P->mid = 1;
+    P->inner = d.inner > 1 ? d.inner : 1; P->mid = midlay ? d.mid : 1;
     P->dbl = dbl; P->cplx_in = false; P->rsize = rs; P->csize = cs;
     P->nx_out = d.nx;
     P->yny = d.ny; P->ynx = ncol;  // (the view pass 1 transforms)
-    P->n_c.rt = true; P->n_c.geo = gc; P->n_c.lds = fastn_lds(gc, cs, true);
+    P->n_c.rt = true; P->n_c.geo = gc; P->n_c.lds = fastn_lds(gc, cs, true) + (rad_p ? 2 * (((size_t)d.ny + 7) & ~(size_t)7) * 2 : 0);
+    P->n_rad_p = rad_p; P->n_rq = rad_rq; P->n_rp = rad_rp;
     P->n_r.rt = true; P->n_r.geo = gr; P->n_r.lds = fastn_lds(gr, cs, false);
     P->n_cw = 2 * G; P->n_nxb = (int)((ncol + P->n_cw - 1) / P->n_cw); P->y_pitch = (long long)P->n_nxb * P->n_cw;
     P->n_rk = (int)std::max<long long>(1, (long long)(128 / (P->n_cw * cs)));
@@ -2974,7 +2996,8 @@ static xrfthip_plan* create_fused_inner(const xrfthip_desc& d) {
     if (!rc) rc = dbl ? build_twiddle<double>(P->tw_fy, d.ny, d.ny) : build_twiddle<float>(P->tw_fy, d.ny, d.ny);
     std::vector<double> ones((size_t)std::max<long long>(d.ny, ncol), 1.0);
     if (!rc) rc = upload_real_table(P, P->ones4096, ones.data(), (int64_t)ones.size(), 0);
-    if (!rc) rc = dbl ? fastn_upload_twm<double>(gc, P->n_c.twm) : fastn_upload_twm<float>(gc, P->n_c.twm);
+    if (!rc && rad_p) rc = dbl ? fastn_rader_tables<double>(P) : fastn_rader_tables<float>(P);
+    else if (!rc) rc = dbl ? fastn_upload_twm<double>(gc, P->n_c.twm) : fastn_upload_twm<float>(gc, P->n_c.twm);
     if (!rc) rc = dbl ? fastn_upload_twm<double>(gr, P->n_r.twm) : fastn_upload_twm<float>(gr, P->n_r.twm);
     if (!rc) rc = P->n_c.geo_dev.upload(&P->n_c.geo, sizeof(NGeo));
     if (!rc) rc = P->n_r.geo_dev.upload(&P->n_r.geo, sizeof(NGeo));
@@ -2996,7 +3019,9 @@ static xrfthip_plan* create_fused_inner(const xrfthip_desc& d) {
 
 static int run_fused_inner(const xrfthip_plan* P, const void* in, void* out, char* ws, hipStream_t st) {
     const xrfthip_desc& d = P->d;
-    const long long ncol = d.nx * d.inner;
+    const bool midlay = d.mid >= 2;
+    const long long ne = midlay ? d.mid : d.inner, ncol = d.nx * ne;
+    const int sx = midlay ? 1 : (int)d.inner, se = midlay ? (int)d.nx : 1;
     const size_t out_esz = d.out_mode == XRFTHIP_OUT_POWER ? P->rsize : P->csize;
     for (long long g0 = 0; g0 < d.batch; g0 += P->G) {
         const long long gc = std::min<long long>(P->G, d.batch - g0);
@@ -3015,9 +3040,9 @@ static int run_fused_inner(const xrfthip_plan* P, const void* in, void* out, cha
         prof_end(rec, st);
         if (d.detrend) {
             rec = prof_begin(P, "fastn_fit_inner", st);
-            const dim3 grid((unsigned)(gc * d.inner)), blk(256);
-            if (P->dbl) { auto k = &fastn_fit_inner_kernel<double>; XRFT_LAUNCH(k, grid, blk, 3 * 256 * sizeof(double), st, (const double*)m.colfit, (const double*)m.win_x, reinterpret_cast<C2<double>*>(ws + P->off_corr), (int)d.nx, (int)d.inner, (int)d.ny, (int)d.detrend); }
-            else { auto k = &fastn_fit_inner_kernel<float>; XRFT_LAUNCH(k, grid, blk, 3 * 256 * sizeof(double), st, (const double*)m.colfit, (const float*)m.win_x, reinterpret_cast<C2<float>*>(ws + P->off_corr), (int)d.nx, (int)d.inner, (int)d.ny, (int)d.detrend); }
+            const dim3 grid((unsigned)(gc * ne)), blk(256);
+            if (P->dbl) { auto k = &fastn_fit_inner_kernel<double>; XRFT_LAUNCH(k, grid, blk, 3 * 256 * sizeof(double), st, (const double*)m.colfit, (const double*)m.win_x, reinterpret_cast<C2<double>*>(ws + P->off_corr), (int)d.nx, (int)ne, (int)d.ny, (int)d.detrend, sx, se); }
+            else { auto k = &fastn_fit_inner_kernel<float>; XRFT_LAUNCH(k, grid, blk, 3 * 256 * sizeof(double), st, (const double*)m.colfit, (const float*)m.win_x, reinterpret_cast<C2<float>*>(ws + P->off_corr), (int)d.nx, (int)ne, (int)d.ny, (int)d.detrend, sx, se); }
             prof_end(rec, st);
         }
         FastNI r{};
@@ -3025,18 +3050,18 @@ static int run_fused_inner(const xrfthip_plan* P, const void* in, void* out, cha
         r.tw_x = P->tw_fx.p; r.twm = P->n_r.twm.p; r.g = (NGeoPtr)P->n_r.geo_dev.p;
         r.ph_y = P->fph[0].p; r.ph_x = P->fph[1].p; r.ph_on = (d.out_mode != XRFTHIP_OUT_POWER && P->fph_on) ? 1 : 0;
         r.out = (char*)out + (size_t)g0 * d.ny * ncol * out_esz;
-        r.ny = (int)d.ny; r.nx = (int)d.nx; r.inner = (int)d.inner; r.nrow_pad = P->y_nrow_pad; r.pitch = (int)P->y_pitch;
+        r.ny = (int)d.ny; r.nx = (int)d.nx; r.inner = (int)ne; r.sx = sx; r.se = se; r.midlay = midlay ? 1 : 0; r.nrow_pad = P->y_nrow_pad; r.pitch = (int)P->y_pitch;
         r.l_cw = m.l_cw; r.l_rk = m.l_rk; r.detrend = d.detrend;
         r.shift_y = (d.flags & XRFTHIP_SHIFT_Y) ? (int)(d.ny / 2) : 0;
         r.shift_x = (d.flags & XRFTHIP_SHIFT_X) ? (int)(d.nx / 2) : 0;
         const NGeo& hg = P->n_r.geo;
         {
             const int vw = (int)(16 / out_esz);
-            r.vec = (vw == 1 || (d.inner % vw == 0 && hg.g % vw == 0)) ? 1 : 0;
+            r.vec = (!midlay && (vw == 1 || (d.inner % vw == 0 && hg.g % vw == 0))) ? 1 : 0;
             if (!env_ll("XRFTHIP_FI_VEC", 1)) r.vec = 0;
             r.dbg = (int)env_ll("XRFTHIP_FI_DBG", 0);
         }
-        r.neb = (int)((d.inner + hg.g - 1) / hg.g);
+        r.neb = (int)((ne + hg.g - 1) / hg.g);
         r.nunits = (int)(gc * (d.ny / 2 + 1) * r.neb);
         r.scale = d.scale;
         int maxrad = 0;
@@ -3542,12 +3567,12 @@ int xrfthip_plan_describe(const xrfthip_plan* plan, char* buf, size_t buflen) {
     if (plan->fusedi) {
         auto rads = [](const NGeo& g) { std::string t; for (int i = 0; i < g.np; ++i) t += (i ? "x" : "") + std::to_string(g.r[i]); return t; };
         const NGeo &gc = plan->n_c.geo, &gr = plan->n_r.geo;
-        appendf(s, "xrfthip plan: [batch %lld][ny %lld][nx %lld][inner %lld] dtype=%d mode=%d detrend=%d flags=0x%x ws=%zuB\n"
-                   "  [inner layout] [fastn fused] two passes where the axes lie, no transposed copy: cols: the [ny][nx inner] view, %d thr, %d packed column pairs (FFT%d r%s), lds=%zuB -> "
-                   "W2[slab][%d/%d][%d][%d][%d] complex -> fit per (slab, inner element) -> rows: %d thr, %d inner elements of one row ky per workgroup (FFT%d r%s), lds=%zuB, plane added "
+        appendf(s, "xrfthip plan: [batch %lld][ny %lld][mid %lld][nx %lld][inner %lld] dtype=%d mode=%d detrend=%d flags=0x%x ws=%zuB\n"
+                   "  [inner layout] [fastn fused] two passes where the axes lie, no transposed copy: cols: the [ny][mid nx inner] view, %d thr, %d packed column pairs (FFT%d r%s), lds=%zuB -> "
+                   "W2[slab][%d/%d][%d][%d][%d] complex -> fit per (slab, inner element) -> rows: %d thr, %d independent elements of one row ky per workgroup (FFT%d r%s), lds=%zuB, plane added "
                    "back in the spectral domain, (ky, kx, e) and its Hermitian twin stored as runs of %d elements\n",
-                (long long)d.batch, (long long)d.ny, (long long)d.nx, (long long)plan->inner, d.dtype, d.out_mode, d.detrend, d.flags, plan->ws_bytes,
-                gc.thr, gc.g, gc.n, rads(gc).c_str(), plan->n_c.lds, plan->y_nrow_pad, plan->n_rk, plan->n_nxb, plan->n_rk, plan->n_cw, gr.thr, gr.g, gr.n, rads(gr).c_str(), plan->n_r.lds, gr.g);
+                (long long)d.batch, (long long)d.ny, (long long)plan->mid, (long long)d.nx, (long long)plan->inner, d.dtype, d.out_mode, d.detrend, d.flags, plan->ws_bytes,
+                gc.thr, gc.g, gc.n, plan->n_rad_p ? ("Rader, prime " + std::to_string(plan->n_rad_p)).c_str() : rads(gc).c_str(), plan->n_c.lds, plan->y_nrow_pad, plan->n_rk, plan->n_nxb, plan->n_rk, plan->n_cw, gr.thr, gr.g, gr.n, rads(gr).c_str(), plan->n_r.lds, gr.g);
         const size_t n = std::min(buflen - 1, s.size());
         memcpy(buf, s.data(), n);
         buf[n] = 0;
