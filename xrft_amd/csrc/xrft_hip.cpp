@@ -1838,12 +1838,22 @@ static bool fastn_setup(xrfthip_plan* P) {
         const long long forced = env_ll("XRFTHIP_FASTN_RPU", 0);
         // (measured, profiles/r05_fastn_threads.txt: two rows per workgroup -- whole 128-byte lines of W2 -- beat one and four at every size, even where
         // two rows leave a single workgroup on a CU: (16, 3000, 3000) float64 78 against 66 GFFT/s)
+        // SHORT rows (nx <= 512: the 73 x 144, 37 x 72, 145 x 192 grids that the Rader columns brought here): two 144-point rows are a 288-point workgroup, 150 000 of
+        // them per call -- as many rows as make ~1152 points (8 at most), and one thread per ~9 points: (4096, 73, 144) float32 rows 287 -> 86 us, (16384, 37, 72)
+        // 507 -> 106 (profiles/r05_small_awkward.txt)
+        int rpu_short = 2, thr_short = 0;
+        if (d.nx <= 512 && !two) {
+            while (rpu_short < 8 && (long long)rpu_short * 2 * d.nx <= 1152) rpu_short *= 2;
+            const long long pts = (long long)rpu_short * d.nx;
+            thr_short = pts < 1024 ? 64 : pts < 2304 ? 128 : 0;
+        }
         static const size_t caps[] = {156 * 1024};
         for (int ci = 0; ci < 1 && !rpu; ++ci)
-            for (int cand = forced ? 4 : 2; cand >= 1 && !rpu; cand >>= 1) {
+            for (int cand = forced ? 16 : rpu_short; cand >= 1 && !rpu; cand >>= 1) {
                 if (forced && cand != forced) continue;
                 NGeo t{};
-                if (!fastn_pick(d.nx, two ? 2 * cand : cand, false, dbl, false, maxr, (int)env_ll("XRFTHIP_FASTN_TR", 0), t)) continue;
+                const int tr_env = (int)env_ll("XRFTHIP_FASTN_TR", 0), tr = tr_env ? tr_env : (cand == rpu_short && !forced) ? thr_short : 0;
+                if (!(tr && fastn_pick(d.nx, two ? 2 * cand : cand, false, dbl, false, maxr, tr, t)) && !fastn_pick(d.nx, two ? 2 * cand : cand, false, dbl, false, maxr, tr_env, t)) continue;
                 if ((long long)t.g * (d.nx / t.r[t.np - 1]) > maxthr) continue;
                 if (fastn_lds(t, cs, false) <= caps[ci] && 2 * cand <= 64) { rpu = cand; gr = t; }
             }
@@ -1879,7 +1889,9 @@ static bool fastn_setup(xrfthip_plan* P) {
                     if (2LL * cand > d.nx + 1) continue;
                     NGeo c{};
                     c.n = (int)d.ny; c.np = 0; c.g = cand; c.lg = ilog2i(cand); c.str = (int)d.ny; c.twn = (int)(d.ny / rad_p) + rad_p - 1;
-                    c.thr = thr_f ? (int)std::min<long long>(maxthr, (thr_f + 63) / 64 * 64) : ((long long)cand * d.ny >= 4096 && !dbl) ? 512 : 256;
+                    // (threads by the points of a workgroup: 73 x 8 pairs on 64 threads 163 us against 327 on 256 -- a single wave has no barriers to wait at)
+                    const long long pts = (long long)cand * d.ny;
+                    c.thr = thr_f ? (int)std::min<long long>(maxthr, (thr_f + 63) / 64 * 64) : pts <= 1536 ? 64 : pts <= 2560 ? 128 : (pts >= 4096 && !dbl) ? 512 : 256;
                     const size_t lds = fastn_lds(c, cs, true) + 2 * (((size_t)d.ny + 7) & ~(size_t)7) * 2;
                     if (lds <= caps[ci]) { G = cand; t = c; }
                 }
@@ -2956,7 +2968,8 @@ static xrfthip_plan* create_fused_inner(const xrfthip_desc& d) {
             if (cand > 1 && (long long)cand * d.ny > 6000) continue;
             NGeo c{};
             c.n = (int)d.ny; c.np = 0; c.g = cand; c.lg = ilog2i(cand); c.str = (int)d.ny; c.twn = (int)(d.ny / rad_p) + rad_p - 1;
-            c.thr = ((long long)cand * d.ny >= 4096 && !dbl) ? 512 : 256;
+            const long long pts = (long long)cand * d.ny;
+            c.thr = pts <= 1536 ? 64 : pts <= 2560 ? 128 : (pts >= 4096 && !dbl) ? 512 : 256;
             if (fastn_lds(c, cs, true) + 2 * (((size_t)d.ny + 7) & ~(size_t)7) * 2 <= 156 * 1024) { G = cand; gc = c; }
         }
         if (!G) rad_p = 0;
