@@ -1936,7 +1936,14 @@ static bool fastn_setup(xrfthip_plan* P) {
                 if (!rows_rt && d.nx % (2 * cand) != 0) continue;  // (the table's row kernel reads an unpadded intermediate)
                 if (2LL * cand > d.nx + 1) continue;
                 NGeo t{};
-                if (!fastn_pick(mlen, cand, blue_m != 0, dbl, true, blue_m ? std::min(maxr, 16) : maxr, (int)env_ll("XRFTHIP_FASTN_TC", 0), t)) continue;
+                // threads by the points of the column block: SHORT columns ((512, 100, 2000): 8 pairs = 800 points) on the 512 threads of the large slabs leave most
+                // waves idle at every barrier -- 64 threads 275 us against 728, (1024, 98, 1000) 336 against 1295; 2000 ... 4000 points: 256 (profiles/r05_short_cols.txt)
+                const long long pts = (long long)cand * mlen;
+                const int tc_env = (int)env_ll("XRFTHIP_FASTN_TC", 0);
+                // (float64: 64 threads up to 768 points, 128 up to 2048 -- (128, 500, 1500) 473 us against 575 with 192, (128, 250, 3000) 406 against 521)
+                const int tc = tc_env ? tc_env : blue_m ? 0 : pts <= (dbl ? 768 : 1536) ? 64 : (dbl && pts <= 2048) ? 128 : (!dbl && pts < 4096) ? 256 : 0;
+                const int mr = blue_m ? std::min(maxr, 16) : maxr;
+                if (!(tc && fastn_pick(mlen, cand, blue_m != 0, dbl, true, mr, tc, t)) && !fastn_pick(mlen, cand, blue_m != 0, dbl, true, mr, tc_env, t)) continue;
                 if ((long long)t.g * (mlen / t.r[t.np - 1]) > maxthr) continue;
                 if (fastn_lds(t, cs, true) <= caps[ci]) { G = cand; gc = t; }
             }
@@ -2955,7 +2962,8 @@ static xrfthip_plan* create_fused_inner(const xrfthip_desc& d) {
         for (int cand = f_gc ? f_gc : (dbl ? 4 : 8); cand >= 1 && !G; cand >>= 1) {
             NGeo t{};
             // (float64: 256 threads -- (1024, 1024, 32): 176 us against 235 with the 384 that keep the most waves resident)
-            const int tc = f_tc ? f_tc : dbl ? 256 : 0;
+            const long long pts = (long long)cand * d.ny;  // (short columns: fastn_setup's rule)
+            const int tc = f_tc ? f_tc : pts <= (dbl ? 768 : 1536) ? 64 : dbl ? (pts <= 2048 ? 128 : 256) : pts < 4096 ? 256 : 0;
             if (!(tc && fastn_pick(d.ny, cand, false, dbl, true, maxr, tc, t)) && !fastn_pick(d.ny, cand, false, dbl, true, maxr, 0, t)) continue;
             if ((long long)t.g * (d.ny / t.r[t.np - 1]) > maxthr) continue;
             if (fastn_lds(t, cs, true) <= (f_gc ? caps[2] : caps[ci])) { G = cand; gc = t; }
