@@ -2417,8 +2417,16 @@ static bool fastgy_try(xrfthip_plan* P, bool rows = false) {
     if ((int)ry.size() > kFastGMaxPasses) return false;
     for (int r : ry) if (r > 16) return false;
     if (d.ny > 4096 && !blue_m) return false;
-    const int thr = 256;
+    // threads by the points of the tile: a short axis on 256 threads leaves most waves idle at every barrier -- (48, 1024, 1024) float32 on one wave 236 GFFT/s against
+    // 160, (96, 512, 512) on two 243 against 217, float64 126 against 98; from ~2400 points on: 256 (profiles/r05_gy_threads.txt)
+    const long long thr_env = env_ll("XRFTHIP_FASTGY_THR", 0);
+    auto thr_of = [&](int G) {
+        if (thr_env) return (int)std::min<long long>(256, std::max<long long>(64, thr_env / 64 * 64));
+        const long long pts = (long long)G * m;
+        return P->dbl ? (pts <= 512 ? 64 : pts <= 1024 ? 128 : 256) : (pts <= 1024 ? 64 : pts <= 2048 ? 128 : 256);
+    };
     auto lds_of = [&](int G, bool tw_lds) {
+        const int thr = thr_of(G);
         return (((size_t)m * (rows ? G + 1 : G) * P->csize + 15) & ~(size_t)15) + (tw_lds ? (size_t)(rad_p ? m / rad_p : m) * P->csize : 0) + (size_t)thr * 4 * sizeof(double) + (size_t)G * 4 * sizeof(double) +
                (size_t)N * P->rsize + (size_t)N * 2 + 16 + (rad_p ? (((size_t)N * 2 + 15) & ~(size_t)15) + (size_t)rad_p * P->csize + 16 : 0);
     };
@@ -2434,7 +2442,7 @@ static bool fastgy_try(xrfthip_plan* P, bool rows = false) {
     const long long forced = env_ll("XRFTHIP_FASTGY_G", 0);
     if (forced >= 1 && forced <= gmax && !(forced & (forced - 1)) && lds_of((int)forced, tw_lds) <= kLdsMax - 1024) G = (int)forced;
     if (!G) return false;
-    P->g_ry = ry; P->gy_G = G; P->gy_thr = thr; P->gy_lds = lds_of(G, tw_lds); P->gy_blue_m = blue_m; P->gy_tw_lds = tw_lds;
+    P->g_ry = ry; P->gy_G = G; P->gy_thr = thr_of(G); P->gy_lds = lds_of(G, tw_lds); P->gy_blue_m = blue_m; P->gy_tw_lds = tw_lds;
     P->gy_rad_p = rad_p; P->gy_rp = rp; P->gy_rows = rows; P->gy_n = N;
     return true;
 }
