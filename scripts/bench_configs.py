@@ -105,9 +105,9 @@ x = cube((1024, 1024, 64), torch.float32); da = xrft.DataArray(x, ("y", "x", "t"
 add("PS over (y, x) of a (1024,1024,64) f32 (y, x, t) array, linear+hann", x.numel(), 8, timeit(lambda: xrft.power_spectrum(da, dim=["y", "x"], detrend="linear", window="hann")))
 add("   fft (complex) of the same, no detrend", x.numel(), 12, timeit(lambda: xrft.fft(da, dim=["y", "x"])))
 del x, da
-# a length with large prime factors: the ERA5 grid (721 = 7 x 103 latitudes) -- Bluestein in the column tile
+# a length with one awkward prime: the ERA5 grid (721 = 7 x 103 latitudes) -- the prime-factor form with Rader's algorithm in the column tile (round 5)
 x = cube((64, 721, 1440), torch.float32); da = xrft.DataArray(x, ("t", "lat", "lon"), {"lat": np.arange(721) * .25, "lon": np.arange(1440) * .25})
-add("PS (64,721,1440) f32 linear+hann (ERA5 grid; Bluestein inside the column tile, float32)", x.numel(), 8, timeit(lambda: xrft.power_spectrum(da, dim=["lat", "lon"], detrend="linear", window="hann")))
+add("PS (64,721,1440) f32 linear+hann (ERA5 grid, 721 = 7 x 103: Rader columns)", x.numel(), 8, timeit(lambda: xrft.power_spectrum(da, dim=["lat", "lon"], detrend="linear", window="hann")))
 del x, da
 # round 4: lengths as data (csrc/fastg.h) -- small slabs of any smooth shape, one transform axis on any smooth length
 for shape, dt in (((14400, 50, 50), torch.float32), ((14400, 50, 50), torch.float64), ((8192, 96, 96), torch.float32), ((14400, 45, 45), torch.float32), ((2048, 150, 150), torch.float32)):
@@ -129,6 +129,22 @@ for shape, dt in (((131072, 250), torch.float32), ((65536, 96), torch.float32), 
     x = cube(shape, dt); da = xrft.DataArray(x, ("t", "x"), {"x": np.arange(float(shape[1]))})
     tag, bpp = ("f32" if dt == torch.float32 else "f64"), (8 if dt == torch.float32 else 16)
     add(f"power_spectrum 1-D {shape} {tag} linear+hann (a length outside the tables)", x.numel(), bpp, timeit(lambda: xrft.power_spectrum(da, dim="x", detrend="linear", window="hann")))
+    del x, da
+# round 5: the calendar's primes along the contiguous axis, small grids with an awkward prime, short columns, non-adjacent axes
+for shape, dt in (((131072, 365), torch.float32), ((32768, 1460), torch.float64)):
+    x = cube(shape, dt); da = xrft.DataArray(x, ("s", "time"), {"time": np.arange(float(shape[1]))})
+    tag, bpp = ("f32" if dt == torch.float32 else "f64"), (8 if dt == torch.float32 else 16)
+    add(f"power_spectrum 1-D {shape} {tag} linear+hann (365 = 5 x 73: Rader along the contiguous axis)", x.numel(), bpp, timeit(lambda: xrft.power_spectrum(da, dim="time", detrend="linear", window="hann")))
+    del x, da
+for shape, dt in (((4096, 73, 144), torch.float32), ((16384, 37, 72), torch.float32), ((512, 100, 2000), torch.float32), ((64, 721, 1440), torch.float64)):
+    x = cube(shape, dt); da = xrft.DataArray(x, ("t", "lat", "lon"), {"lat": np.arange(float(shape[1])), "lon": np.arange(float(shape[2]))})
+    tag, bpp = ("f32" if dt == torch.float32 else "f64"), (8 if dt == torch.float32 else 16)
+    add(f"PS {shape} {tag} linear+hann", x.numel(), bpp, timeit(lambda: xrft.power_spectrum(da, dim=["lat", "lon"], detrend="linear", window="hann")))
+    del x, da
+for shape, dt in (((1460, 73, 144), torch.float32), ((1024, 64, 512), torch.float32), ((720, 91, 360), torch.float64)):
+    x = cube(shape, dt); da = xrft.DataArray(x, ("time", "lat", "lon"), {"time": np.arange(float(shape[0])), "lon": np.arange(float(shape[2])) * 2.5})
+    tag, bpp = ("f32" if dt == torch.float32 else "f64"), (8 if dt == torch.float32 else 16)
+    add(f"PS over (time, lon) of (time, lat, lon) = {shape} {tag}, linear+hann (non-adjacent axes, fused)", x.numel(), bpp, timeit(lambda: xrft.power_spectrum(da, dim=["time", "lon"], detrend="linear", window="hann")))
     del x, da
 print(f"{'workload':58s} {'GFFT/s':>8s} {'ms':>9s} {'B/pt':>5s} {'frac of 8 TB/s':>15s}  path")
 for name, g, t, bpp, frac, path in rows:
