@@ -2993,14 +2993,17 @@ static xrfthip_plan* create_fused_inner(const xrfthip_desc& d) {
     // pass 2: GE sequences (consecutive inner elements) of nx points: 64-byte runs of the result where the LDS allows
     // (midlay: the sequences are contiguous rows -- as many as make ~4096 (float64: 2048) points, two at least: (1440, 73, 144) with two 144-point rows per workgroup
     // ran 26 000 tiny workgroups, 115 us)
+    // (the elements innermost: 8 (float64: 4) -- 64-byte pieces; SHORT sequences, 16 of them while that is <= 4096 points: (73, 144, 1460) float32 rows 51 -> 42 us,
+    // (72, 144, 1440) float64 116 -> 71, (256, 256, 512) 102 -> 73; at 512 points 16 elements were slower than 8.  profiles/r05_inner_small.txt)
+    const int ge_in = (16LL * d.nx <= 4096) ? 16 : (dbl ? 4 : 8);
     int ge_mid = 2;
     while (ge_mid < 32 && (long long)ge_mid * 2 * d.nx <= (dbl ? 2048 : 4096)) ge_mid *= 2;
     for (int ci = 0; ci < 3 && !GE; ++ci)
-        for (int cand = f_ge ? f_ge : midlay ? ge_mid : (dbl ? 4 : 8); cand >= 1 && !GE; cand >>= 1) {
+        for (int cand = f_ge ? f_ge : midlay ? ge_mid : ge_in; cand >= 1 && !GE; cand >>= 1) {
             if (cand > 2 * ne) continue;
             NGeo t{};
             // (float32: 512 threads where a workgroup holds eight sequences, 231 us against 292 with 256; float64: 256, 182 us against 249 with 384)
-            const int tr = f_tr ? f_tr : dbl ? 256 : ((long long)cand * d.nx >= 4096) ? 512 : 0;
+            const int tr = f_tr ? f_tr : dbl ? 256 : ((long long)cand * d.nx > 4096) ? 512 : 0;
             if (!(tr && fastn_pick(d.nx, cand, false, dbl, false, maxr, tr, t)) && !fastn_pick(d.nx, cand, false, dbl, false, maxr, 0, t)) continue;
             if ((long long)t.g * (d.nx / t.r[t.np - 1]) > maxthr) continue;
             if (fastn_lds(t, cs, false) <= (f_ge ? caps[2] : caps[ci])) { GE = cand; gr = t; }
