@@ -1929,7 +1929,11 @@ static bool fastn_setup(xrfthip_plan* P) {
         static const int kBlueOrder[] = {2, 4, 1, 8}, kOrder[] = {8, 4, 2, 1};
         for (int ci = 0; ci < 3 && !G; ++ci)
             for (int oi = 0; oi < 4 && !G; ++oi) {
-                const int cand = blue_m ? kBlueOrder[oi] : kOrder[oi];
+                // (a SHORT chirp convolution -- 94 x 192, 181 x 360, 241 x 480 grids: m < 1024 -- takes the widest block of <= 2048 points like everything else here:
+                // (2048, 94, 192) 8 pairs on 128 threads 197 us against 617 with 2 on 256, (1024, 181, 360) 496 against 935; profiles/r05_chirp_small.txt)
+                const bool blue_short = blue_m && mlen < 1024 && !dbl;
+                const int cand = (blue_m && !blue_short) ? kBlueOrder[oi] : kOrder[oi];
+                if (blue_short && !forced && cand > 1 && (long long)cand * mlen > 2048) continue;
                 if (cand > gmax) continue;
                 if (forced && cand != forced) continue;
                 if (ci < 2 && cand < gpref && !forced && !blue_m) continue;
@@ -1941,7 +1945,8 @@ static bool fastn_setup(xrfthip_plan* P) {
                 const long long pts = (long long)cand * mlen;
                 const int tc_env = (int)env_ll("XRFTHIP_FASTN_TC", 0);
                 // (float64: 64 threads up to 768 points, 128 up to 2048 -- (128, 500, 1500) 473 us against 575 with 192, (128, 250, 3000) 406 against 521)
-                const int tc = tc_env ? tc_env : blue_m ? 0 : pts <= (dbl ? 768 : 1536) ? 64 : (dbl && pts <= 2048) ? 128 : (!dbl && pts < 4096) ? 256 : 0;
+                const int tc = tc_env ? tc_env : blue_short ? (pts <= 1024 ? 64 : pts <= 2560 ? 128 : 256) : blue_m ? 0
+                               : pts <= (dbl ? 768 : 1536) ? 64 : (dbl && pts <= 2048) ? 128 : (!dbl && pts < 4096) ? 256 : 0;
                 const int mr = blue_m ? std::min(maxr, 16) : maxr;
                 if (!(tc && fastn_pick(mlen, cand, blue_m != 0, dbl, true, mr, tc, t)) && !fastn_pick(mlen, cand, blue_m != 0, dbl, true, mr, tc_env, t)) continue;
                 if ((long long)t.g * (mlen / t.r[t.np - 1]) > maxthr) continue;
