@@ -1948,7 +1948,10 @@ static bool fastn_setup(xrfthip_plan* P) {
                 const int tc = tc_env ? tc_env : blue_short ? (pts <= 1024 ? 64 : pts <= 2560 ? 128 : 256) : blue_m ? 0
                                : pts <= (dbl ? 768 : 1536) ? 64 : (dbl && pts <= 2048) ? 128 : (!dbl && pts < 4096) ? 256 : 0;
                 const int mr = blue_m ? std::min(maxr, 16) : maxr;
-                if (!(tc && fastn_pick(mlen, cand, blue_m != 0, dbl, true, mr, tc, t)) && !fastn_pick(mlen, cand, blue_m != 0, dbl, true, mr, tc_env, t)) continue;
+                // (the last pass wants one butterfly per thread: where the count is too small for the radices at hand, the next one up)
+                bool picked = false;
+                for (int tt = tc; tt && tt <= 256 && !picked && !tc_env; tt *= 2) picked = fastn_pick(mlen, cand, blue_m != 0, dbl, true, mr, tt, t);
+                if (!picked && !fastn_pick(mlen, cand, blue_m != 0, dbl, true, mr, tc_env, t)) continue;
                 if ((long long)t.g * (mlen / t.r[t.np - 1]) > maxthr) continue;
                 if (fastn_lds(t, cs, true) <= caps[ci]) { G = cand; gc = t; }
             }
@@ -2977,7 +2980,9 @@ static xrfthip_plan* create_fused_inner(const xrfthip_desc& d) {
             // (float64: 256 threads -- (1024, 1024, 32): 176 us against 235 with the 384 that keep the most waves resident)
             const long long pts = (long long)cand * d.ny;  // (short columns: fastn_setup's rule)
             const int tc = f_tc ? f_tc : pts <= (dbl ? 768 : 1536) ? 64 : dbl ? (pts <= 2048 ? 128 : 256) : pts < 4096 ? 256 : 0;
-            if (!(tc && fastn_pick(d.ny, cand, false, dbl, true, maxr, tc, t)) && !fastn_pick(d.ny, cand, false, dbl, true, maxr, 0, t)) continue;
+            bool picked = false;
+            for (int tt = tc; tt && tt <= 256 && !picked && !f_tc; tt *= 2) picked = fastn_pick(d.ny, cand, false, dbl, true, maxr, tt, t);
+            if (!picked && !fastn_pick(d.ny, cand, false, dbl, true, maxr, f_tc, t)) continue;
             if ((long long)t.g * (d.ny / t.r[t.np - 1]) > maxthr) continue;
             if (fastn_lds(t, cs, true) <= (f_gc ? caps[2] : caps[ci])) { G = cand; gc = t; }
         }
