@@ -344,6 +344,7 @@ struct xrfthip_plan {
     // ... and xrfthip_desc.inner > 1 (two adjacent transform axes, the independent elements innermost) as the same two passes (fastn.h: fastn_cols_kernel on the
     // [ny][nx inner] view, fastn_fit_inner_kernel, fastn_irows_kernel).  n_c: the ny-point columns of the view; n_r: GE sequences of nx points per row workgroup
     bool fusedi = false;
+    int n_dbg = 0, fi_dbg = 0, fi_vec = 1;  // the measuring scripts' ablation switches (XRFTHIP_FASTN_DBG / _FI_DBG / _FI_VEC), read when the plan is made: xrfthip_exec reads no environment
     DevBuf winx_exp;                // the window along x expanded to the view's columns (never null: ones)
     // ... and pass 1 alone for ONE transform axis that is not the contiguous one (XRFTHIP_AXIS_Y, fastm_yonly_kernel)
     bool fastmy = false;
@@ -1968,6 +1969,7 @@ static bool fastn_setup(xrfthip_plan* P) {
     P->fastn = true;
     P->n_c.rt = cols_rt; P->n_c.geo = gc; P->n_c.lds = cols_rt ? fastn_lds(gc, cs, true) + (rad_p ? 2 * (((size_t)d.ny + 7) & ~(size_t)7) * 2 : 0) : 0;
     P->n_rad_p = rad_p; P->n_rq = rq; P->n_rp = rp;
+    P->n_dbg = (int)env_ll("XRFTHIP_FASTN_DBG", 0);
     P->n_r.rt = rows_rt; P->n_r.geo = gr; P->n_r.lds = rows_rt ? fastn_lds(gr, cs, false) : 0;
     P->n_cw = cw; P->n_rk = rk; P->n_rpu = rpu; P->n_nxb = nxb; P->y_pitch = pitch; P->n_blue_m = blue_m;
     return true;
@@ -1986,7 +1988,7 @@ static FastN fastn_wrap(const xrfthip_plan* P, const FastM& m, bool cols) {
     const int vw = (int)(16 / (cplx_out ? P->csize : P->rsize));
     n.vec_ok = (P->ynx % vw == 0) ? 1 : 0;
     n.rpu = P->n_rpu;
-    n.dbg = (int)env_ll("XRFTHIP_FASTN_DBG", 0);
+    n.dbg = P->n_dbg;
     return n;
 }
 
@@ -3029,6 +3031,7 @@ static xrfthip_plan* create_fused_inner(const xrfthip_desc& d) {
     P->yny = d.ny; P->ynx = ncol;  // (the view pass 1 transforms)
     P->n_c.rt = true; P->n_c.geo = gc; P->n_c.lds = fastn_lds(gc, cs, true) + (rad_p ? 2 * (((size_t)d.ny + 7) & ~(size_t)7) * 2 : 0);
     P->n_rad_p = rad_p; P->n_rq = rad_rq; P->n_rp = rad_rp;
+    P->n_dbg = (int)env_ll("XRFTHIP_FASTN_DBG", 0); P->fi_dbg = (int)env_ll("XRFTHIP_FI_DBG", 0); P->fi_vec = env_ll("XRFTHIP_FI_VEC", 1) ? 1 : 0;
     P->n_r.rt = true; P->n_r.geo = gr; P->n_r.lds = fastn_lds(gr, cs, false);
     P->n_cw = 2 * G; P->n_nxb = (int)((ncol + P->n_cw - 1) / P->n_cw); P->y_pitch = (long long)P->n_nxb * P->n_cw;
     P->n_rk = (int)std::max<long long>(1, (long long)(128 / (P->n_cw * cs)));
@@ -3100,8 +3103,8 @@ static int run_fused_inner(const xrfthip_plan* P, const void* in, void* out, cha
         {
             const int vw = (int)(16 / out_esz);
             r.vec = (!midlay && (vw == 1 || (d.inner % vw == 0 && hg.g % vw == 0))) ? 1 : 0;
-            if (!env_ll("XRFTHIP_FI_VEC", 1)) r.vec = 0;
-            r.dbg = (int)env_ll("XRFTHIP_FI_DBG", 0);
+            if (!P->fi_vec) r.vec = 0;
+            r.dbg = P->fi_dbg;
         }
         r.neb = (int)((ne + hg.g - 1) / hg.g);
         r.nunits = (int)(gc * (d.ny / 2 + 1) * r.neb);
