@@ -502,7 +502,8 @@ def test_random_one_pass_case(seed):
     run_random_one_pass(seed)
 
 
-_ANY_AXIS_LENGTHS = [6, 12, 27, 45, 48, 50, 75, 96, 120, 125, 150, 243, 250, 77, 131, 146, 365]  # (smooth, odd, and with prime factors that take Bluestein)
+# (smooth, odd, with prime factors that take Bluestein -- 131, 94 = 2 x 47, 262 -- and ONE prime 17 ... 127 with a smooth p - 1: the Rader forms -- 146, 365, 366, 73, 97, 58, 68, 206)
+_ANY_AXIS_LENGTHS = [6, 12, 27, 45, 48, 50, 75, 96, 120, 125, 150, 243, 250, 77, 131, 146, 365, 366, 73, 97, 58, 68, 94, 262, 206]
 
 
 def run_random_any_axis(seed):
