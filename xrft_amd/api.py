@@ -14,6 +14,7 @@ Deviations from the reference, all documented in DESIGN.md:
 """
 from __future__ import annotations
 
+import math
 import threading
 import warnings
 from collections import OrderedDict
@@ -865,7 +866,7 @@ def _spectrum_nd(da, da2, dims, real_dim, scaling, window_correction, true_phase
                 scale /= float(np.prod([v.mean() for v in vecs])) ** 2
             else:
                 raise ValueError("Unknown {} scaling flag".format(scaling))
-        fs = float(np.prod([float(f1[n].attrs["spacing"]) for n in new]))
+        fs = float(math.prod([float(f1[n].attrs["spacing"]) for n in new]))
         if scaling == "density":
             scale *= fs
         elif scaling == "spectrum":
@@ -899,7 +900,7 @@ def fft(da, spacing_tol=1e-3, dim=None, real_dim=None, shift=True, detrend=None,
         return to_like(_fft_nd(da, nd, spacing_tol, real_dim if real is None else real, shift, detrend, window,
                                true_phase, true_amplitude, chunks_to_segments, prefix), src)
     c = _analyze(da, spacing_tol, dim, real_dim, shift, detrend, window, true_phase, chunks_to_segments, prefix, real)
-    scale = np.prod(c.delta_x) if true_amplitude else 1.0  # xrft.py:471-472
+    scale = math.prod(c.delta_x) if true_amplitude else 1.0  # xrft.py:471-472 (math.prod: the same left-to-right product as np.prod of a short list, a tenth of its call time)
     try:
         out, _, other = _execute(c, c.da, _lib.OUT_COMPLEX, scale)
     except _UnsupportedLength:
@@ -1084,7 +1085,7 @@ def ifft(daft, spacing_tol=1e-3, dim=None, real_dim=None, shift=True, true_phase
     nprod = float(nx) * float(ny)
     scale = 1.0 / nprod
     if true_amplitude:  # xrft.py:641-642
-        scale = scale / np.prod([float(new_coords[swap[d]].attrs["spacing"]) for d in dim])
+        scale = scale / math.prod([float(new_coords[swap[d]].attrs["spacing"]) for d in dim])
     try:
         out = None
         if len(dim) == 2 and not (flags & (_lib.FLIP_X | _lib.FLIP_Y)):
@@ -1299,7 +1300,7 @@ def _window_correction_factor(c, scaling, window):
 
 def _psd_scaling_factor(c, scaling):
     """xrft.py:663-670."""
-    fs = np.prod([float(c.new_coords[c.swap[d]].attrs["spacing"]) for d in c.dim])
+    fs = math.prod([float(c.new_coords[c.swap[d]].attrs["spacing"]) for d in c.dim])
     if scaling == "density":
         return fs
     elif scaling == "spectrum":
@@ -1339,7 +1340,7 @@ def _spectrum(da, da2, dim, real_dim, scaling, window_correction, true_phase, kw
     c = _analyze(da, kw["spacing_tol"], dim, real_dim, kw["shift"], kw["detrend"], kw["window"], true_phase,
                  kw["chunks_to_segments"], kw["prefix"], kw["real"])
     c2 = None
-    amp = np.prod(c.delta_x) ** 2
+    amp = math.prod(c.delta_x) ** 2
     if da2 is not None:
         c2 = _analyze(da2, kw["spacing_tol"], dim, real_dim, kw["shift"], kw["detrend"], kw["window"], true_phase,
                       kw["chunks_to_segments"], kw["prefix"], kw["real"])
@@ -1347,7 +1348,7 @@ def _spectrum(da, da2, dim, real_dim, scaling, window_correction, true_phase, kw
             raise ValueError("The two datasets have different dimensions")
         if c.N != c2.N or not np.allclose(c.delta_x, c2.delta_x, rtol=1e-12):
             raise ValueError("The two datasets have different frequency coordinates (size or spacing)")
-        amp = np.prod(c.delta_x) * np.prod(c2.delta_x)
+        amp = math.prod(c.delta_x) * math.prod(c2.delta_x)
     scale = _spectrum_scale(c, amp, scaling, window_correction, kw["window"])
     flags = _lib.REALDIM_X2 if c.real_dim is not None else 0  # xrft.py:742-743
     mode = _lib.OUT_POWER if da2 is None else _lib.OUT_CROSS
