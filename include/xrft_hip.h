@@ -42,7 +42,7 @@
 extern "C" {
 #endif
 
-#define XRFTHIP_VERSION 103 /* 0.1.3: xrfthip_desc.mid (two transform axes anywhere in a C-contiguous array); 0.1.2: xrfthip_plan_uses_bluestein, xrfthip_convert (0.1.1: xrfthip_desc.inner, xrfthip_reduce_axis, xrfthip_detrend_inner) */
+#define XRFTHIP_VERSION 104 /* 0.1.4: XRFTHIP_AXIS_Y with XRFTHIP_HALF_X / REALDIM_X2 (real_dim along the one transformed axis); 0.1.3: xrfthip_desc.mid (two transform axes anywhere in a C-contiguous array); 0.1.2: xrfthip_plan_uses_bluestein, xrfthip_convert (0.1.1: xrfthip_desc.inner, xrfthip_reduce_axis, xrfthip_detrend_inner) */
 
 typedef enum xrfthip_status {
     XRFTHIP_OK = 0,
@@ -94,10 +94,13 @@ typedef enum xrfthip_detrend_kind {
 /* Transform along a middle (or the first) axis in place, no transposed copy (the reference transforms any axes of the array
  * where they lie, xrft.py:395-409): with ndim = 2 the array is [batch][ny][nx] and ONLY y is transformed, once per (slab,
  * column); nx is the product of the trailing axes.  Detrending and the window act along y (one line / mean per column);
- * the *_X flags, HALF_X, ISO and C2R_X do not apply.  Output [batch][ny][nx] in the same layout.
+ * the *_X flags, ISO and C2R_X do not apply (HALF_X / REALDIM_X2: see below).  Output [batch][ny][nx] in the same layout.
  * Inverse transforms along the axis (xrft.ifft of one first / middle axis, xrft.py:479-646): XRFTHIP_INVERSE with complex input; ISHIFT_Y then
  * rotates the fftshifted INPUT rows, SHIFT_Y the output; XRFTHIP_PHASE_IN (the lag's phase on the input, axis 0 table) is accepted where a one-pass
- * kernel takes the plan (any smooth ny that fits a tile, Bluestein lengths included) and XRFTHIP_BAD_ARG otherwise -- the caller then transposes. */
+ * kernel takes the plan (any smooth ny that fits a tile, Bluestein lengths included) and XRFTHIP_BAD_ARG otherwise -- the caller then transposes.
+ * real_dim along the axis (0.1.4; xrft.py:400-404, 673-682): XRFTHIP_HALF_X with AXIS_Y keeps k = 0 .. ny/2 of the ONE transformed axis -- output
+ * [batch][ny/2 + 1][nx], unshifted, real input, no SHIFT_Y / FLIP_Y / INVERSE -- and REALDIM_X2 counts 0 < k < ny/2 twice; accepted where a one-pass
+ * kernel takes the plan, XRFTHIP_UNSUPPORTED_LENGTH otherwise (the caller transposes). */
 #define XRFTHIP_AXIS_Y 0x2000u
 /* CROSS/PHASE: the reference flips each field by its own coordinate (xrft.py:436-441): these flip field 0 (d_in0), FLIP_Y /
  * FLIP_X flip field 1 (d_in1).  The window always multiplies in the source order, before the flip (xrft.py:425-441). */

@@ -794,6 +794,12 @@ def run_yonly_any_length_cases(shape=(3, 96, 40), dtype="float32"):
     for kw in (dict(detrend="linear", window="hann"), dict(shift=False, scaling="spectrum", detrend="constant"), dict()):
         worst = max(worst, check_values(xa.power_spectrum(da, dim=["y"], **kw), o.power_spectrum(od_det if "detrend" in kw else od, dim=["y"], **kw), tol))
         assert on_fast(), kw
+    # real_dim along the axis (ABI 0.1.4: the half output of the one-pass kernels -- no transposed copy; xrft.py:400-404, 673-682)
+    for kw in (dict(detrend="linear", window="hann"), dict(scaling="spectrum", detrend="constant"), dict()):
+        worst = max(worst, check_values(xa.power_spectrum(da, dim=["y"], real_dim="y", **kw), o.power_spectrum(od_det if "detrend" in kw else od, dim=["y"], real_dim="y", **kw), tol))
+        assert on_fast(), kw
+    worst = max(worst, check_values(xa.fft(da, dim=["y"], real_dim="y", detrend="linear", true_phase=False), o.fft(od_det, dim=["y"], real_dim="y", detrend="linear", true_phase=False), tol))
+    assert on_fast()
     # complex input (the later stages of N-D transforms, xrft.fft of complex data): one sequence per column, any column count
     cdt = "complex128" if dtype == "float64" else "complex64"
     z = (a + 1j * _cube(rng, shape, dtype)).astype(cdt)[:, :, : max(1, shape[2] - 1)]  # (an odd column count where the shape allows)
@@ -866,6 +872,12 @@ def run_yonly_fast_cases(shape=(3, 360, 40), dtype="float64"):
     for kw in (dict(detrend="linear", window="hann"), dict(shift=False, scaling="spectrum", detrend="constant"), dict()):
         worst = max(worst, check_values(xa.power_spectrum(da, dim=["y"], **kw), o.power_spectrum(od_det if "detrend" in kw else od, dim=["y"], **kw), tol))
         assert on_fast(), kw
+    # real_dim along the axis (ABI 0.1.4: the half output, no transposed copy; xrft.py:400-404, 673-682)
+    for kw in (dict(detrend="linear", window="hann"), dict(scaling="spectrum", detrend="constant"), dict()):
+        worst = max(worst, check_values(xa.power_spectrum(da, dim=["y"], real_dim="y", **kw), o.power_spectrum(od_det if "detrend" in kw else od, dim=["y"], real_dim="y", **kw), tol))
+        assert on_fast(), kw
+    worst = max(worst, check_values(xa.fft(da, dim=["y"], real_dim="y", detrend="linear"), o.fft(od_det, dim=["y"], real_dim="y", detrend="linear"), tol))
+    assert on_fast()
     # complex input (the later stages of N-D transforms): one sequence per column
     cdt = "complex128" if dtype == "float64" else "complex64"
     z = (a + 1j * _cube(rng, shape, dtype)).astype(cdt)
@@ -1015,7 +1027,7 @@ def run_rows_rader_cases(shape=(37, 365), dtype="float32"):
     """One transform axis, the contiguous one, on a length with ONE prime factor 17 ... 127 (365 = 5 x 73 daily samples of (station, time) rows, 730, 1460, 366): the
     prime-factor / Rader form of csrc/fastg.h's fastgy_kernel with the lanes along the samples (FORM 3) against the oracle -- fft (true phase, ifftshift), power spectrum,
     every detrend, window, shift; an odd number of rows (the last sequence holds one row); complex rows; xrft.ifft; the cross spectrum and cross phase of two fields.
-    real_dim (half output) stays on the generic passes: checked for parity only."""
+    real_dim (half output) included."""
     import warnings
 
     rng = np.random.default_rng(79)
@@ -1039,6 +1051,9 @@ def run_rows_rader_cases(shape=(37, 365), dtype="float32"):
         worst = max(worst, check_values(xa.power_spectrum(da, dim=["x"], **kw), o.power_spectrum(od_det if "detrend" in kw else od, dim=["x"], **kw), tol))
         assert on_fast(), kw
     worst = max(worst, check(xa.power_spectrum(da, dim=["x"], real_dim="x", window="hann"), o.power_spectrum(od, dim=["x"], real_dim="x", window="hann"), tol))
+    assert on_fast()  # (the half output, ABI 0.1.4)
+    worst = max(worst, check_values(xa.fft(da, dim=["x"], real_dim="x", detrend="linear"), o.fft(od_det, dim=["x"], real_dim="x", detrend="linear"), tol))
+    assert on_fast()
     # complex rows, and back
     cdt = "complex128" if dtype == "float64" else "complex64"
     z = (v + 1j * rng.standard_normal(shape)).astype(cdt)

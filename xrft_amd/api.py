@@ -501,13 +501,13 @@ def _label_output(c, da, out_t, other, extra_cattrs=None, drop_transform=False):
 def _inplace_axis(c, da, iso):
     """Axis number k if the call is a single-axis transform along a middle or first axis that the engine can do where the
     axis lies (XRFTHIP_AXIS_Y: the array is (batch, n, inner) with no transposed copy, like the reference, xrft.py:395-409)."""
-    if len(c.dim) != 1 or c.real_dim is not None or iso is not None:
+    if len(c.dim) != 1 or iso is not None:  # (real_dim along the axis: the half output of the one-pass kernels, ABI 0.1.4)
         return None
     k = da.get_axis_num(c.xdim)
     return k if k != len(da.dims) - 1 else None
 
 
-def _execute_axis_y(c, da, mode, scale, k, da2=None, c2=None):
+def _execute_axis_y(c, da, mode, scale, k, da2=None, c2=None, extra_flags=0):
     """Single transform axis k < last: (batch, ny, nx) = (prod(shape[:k]), shape[k], prod(shape[k+1:])), y transformed in
     place.  Returns the output tensor in the ORIGINAL dim order, or None if the plan cannot be built (column too long
     for one LDS tile): the caller then takes the transposing path."""
@@ -519,7 +519,9 @@ def _execute_axis_y(c, da, mode, scale, k, da2=None, c2=None):
     flags, win, ph = _flags_tables(c, da, None if c2 is None else c2.lag_x, None if c2 is None else c2.reversed)
     if mode == _lib.OUT_POWER:
         ph = {"y": None, "x": None}
-    yflags = _lib.AXIS_Y
+    yflags = _lib.AXIS_Y | (flags & _lib.HALF_X) | extra_flags  # (HALF_X / REALDIM_X2 with AXIS_Y: along the transformed axis)
+    if (yflags & _lib.HALF_X) and (t.is_complex() or (flags & (_lib.FLIP_X | _lib.FLIP0_X))):
+        return None  # (the half output exists for real input in coordinate order only: the transposing path)
     for fx, fy in ((_lib.SHIFT_X, _lib.SHIFT_Y), (_lib.ISHIFT_X, _lib.ISHIFT_Y), (_lib.FLIP_X, _lib.FLIP_Y), (_lib.FLIP0_X, _lib.FLIP0_Y)):
         if flags & fx:
             yflags |= fy
@@ -542,6 +544,7 @@ def _execute_axis_y(c, da, mode, scale, k, da2=None, c2=None):
             return None
         raise
     out, _ = plan.execute(t.reshape(batch, ny, nx), None if t2 is None else t2.reshape(batch, ny, nx))
+    shape[k] = plan.ny_out
     return out.reshape(shape)
 
 
@@ -594,9 +597,9 @@ def _execute_inner(c, da, mode, scale):
 
 
 def _execute(c, da, mode, scale, da2=None, c2=None, iso=None, extra_flags=0):
-    k = _inplace_axis(c, da, iso) if extra_flags == 0 else None
+    k = _inplace_axis(c, da, iso) if (extra_flags & ~_lib.REALDIM_X2) == 0 else None
     if k is not None:
-        out = _execute_axis_y(c, da, mode, scale, k, da2, c2)
+        out = _execute_axis_y(c, da, mode, scale, k, da2, c2, extra_flags)
         if out is not None:
             return out, None, None  # other = None: the output has the input's dim order
     if extra_flags == 0 and iso is None and da2 is None:

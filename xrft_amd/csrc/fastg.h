@@ -619,6 +619,7 @@ struct FastGY {
     // blocks: rp forward passes (tw_p = W_(p-1)) -> * rad_b, the sum of the p - 1 samples and the n2 = 0 sample exchanged at frequency 0 -> the inverse
     // passes: X[k1][g^k] at block k, X[k1][0] at block p - 1.  perm_in[i] = row of input i; rev_y[k] = row of frequency k.  ~2.4 transforms of the
     // length where the chirp convolution takes two of 2.1 x the length: (1460, 128, 256) float64 16 -> 59 GFFT/s.
+    int half, realdim2;  // real_dim along the axis (xrft.py:400-404, 673-682): only k = 0 .. ny/2 is stored (ny/2 + 1 rows, unshifted); 0 < k < ny/2 counts twice
     int rad_p, rad_q, nrp, rp[kFastGMaxPasses];
     const void* tw_p;            // W_(p-1)^k (complex T)
     const void* rad_b;           // FFT_(p-1)(W_p^(g^m)) / (p - 1) at the row the forward passes leave each frequency (complex T)
@@ -773,11 +774,12 @@ __global__ void __launch_bounds__(256, (sizeof(T) == 4 ? 3 : 2)) fastgy_kernel(F
             }
         }
         // ---- out: row orow of the C columns = frequency k of the two spectra packed in every sequence
-        const int tot = ny << lc;
-        const float inv_ny = 1.0f / (float)ny;
+        const int nyo = p.half ? (ny >> 1) + 1 : ny;  // rows of the result
+        const int tot = nyo << lc;
+        const float inv_ny = 1.0f / (float)nyo;
         for (int e = tid; e < tot; e += nthr) {
             int orow, c;
-            if (ROWS) { c = fdiv(e, inv_ny); orow = e - c * ny; }  // (lanes along the frequencies of one row: contiguous stores)
+            if (ROWS) { c = fdiv(e, inv_ny); orow = e - c * nyo; }  // (lanes along the frequencies of one row: contiguous stores)
             else { orow = e >> lc; c = e & (C - 1); }
             const int col = c0 + c;
             if (col >= nx) continue;
@@ -795,11 +797,12 @@ __global__ void __launch_bounds__(256, (sizeof(T) == 4 ? 3 : 2)) fastgy_kernel(F
                 v = (c & 1) ? mk<T>((T)0.5 * (zk.im + zm.im), (T)0.5 * (zm.re - zk.re))   // (Zk - conj Zm) / 2i
                             : mk<T>((T)0.5 * (zk.re + zm.re), (T)0.5 * (zk.im - zm.im));  // (Zk + conj Zm) / 2
             }
-            const size_t o = ROWS ? (size_t)col * ny + orow : ((size_t)b * ny + orow) * nx + col;
+            const size_t o = ROWS ? (size_t)col * nyo + orow : ((size_t)b * nyo + orow) * nx + col;
+            const T sck = (p.realdim2 && k != 0 && 2 * k != ny) ? sc + sc : sc;
             if (MODE == 1) {
-                reinterpret_cast<T*>(p.out)[o] = (v.re * v.re + v.im * v.im) * sc;
+                reinterpret_cast<T*>(p.out)[o] = (v.re * v.re + v.im * v.im) * sck;
             } else {
-                CT w = mk<T>(v.re * sc, v.im * sc);
+                CT w = mk<T>(v.re * sck, v.im * sck);
                 if (p.ph_on) w = cmul(w, reinterpret_cast<const CT*>(p.ph_y)[k]);
                 if (p.angle) reinterpret_cast<T*>(p.out)[o] = (T)atan2((double)w.im, (double)w.re);  // cross phase (xrft.py:838-874)
                 else reinterpret_cast<CT*>(p.out)[o] = w;

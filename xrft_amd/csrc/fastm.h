@@ -513,7 +513,9 @@ __global__ void __launch_bounds__((MYGeom<T, NY>::type::THR), (MYGeom<T, NY>::ty
     if (on) mr_pass0<T, NY>(a, lds + g * STR, j, w0);
     mr_fft_tail<T, NY, G, THR>(lds, tid, tw1);
     // split the packed spectra (fastm_cols_kernel) and store rows ky and -ky of the result; lanes (ky, column), column fastest
-    char* __restrict__ outs = reinterpret_cast<char*>(p.out) + ((size_t)slab * NY * p.nx + (size_t)xb * CW) * ((MODE == 1 || (MODE == 2 && p.angle)) ? sizeof(T) : sizeof(CT));
+    // (p.half -- real_dim along this axis, xrft.py:400-404: only k = 0 .. NY/2 is stored, NY/2 + 1 rows per slab, unshifted; p.realdim2: 0 < k < NY/2 counts twice, xrft.py:673-682)
+    const int orows = p.half ? NY / 2 + 1 : NY;
+    char* __restrict__ outs = reinterpret_cast<char*>(p.out) + ((size_t)slab * orows * p.nx + (size_t)xb * CW) * ((MODE == 1 || (MODE == 2 && p.angle)) ? sizeof(T) : sizeof(CT));
     const T sc = (T)p.scale;
     if (CIN) {  // every frequency of every column, no mirror
         for (int l = tid; l < CW * NY; l += THR) {
@@ -544,13 +546,14 @@ __global__ void __launch_bounds__((MYGeom<T, NY>::type::THR), (MYGeom<T, NY>::ty
             const int km = k == 0 ? 0 : NY - k;
             int rd = k + p.shift_y; if (rd >= NY) rd -= NY;
             int rm = km + p.shift_y; if (rm >= NY) rm -= NY;
-            const bool mirror = k != 0 && 2 * k != NY;
+            const bool interior = k != 0 && 2 * k != NY, mirror = interior && !p.half;
+            const T sck = (p.realdim2 && interior) ? sc + sc : sc;
             if (MODE == 1) {
-                const T v = (o.re * o.re + o.im * o.im) * sc;
+                const T v = (o.re * o.re + o.im * o.im) * sck;
                 reinterpret_cast<T*>(outs)[(size_t)rd * p.nx + col] = v;
                 if (mirror) reinterpret_cast<T*>(outs)[(size_t)rm * p.nx + col] = v;
             } else {
-                o = cscale(o, sc);
+                o = cscale(o, sck);
                 CT om = cconj(o);
                 if (p.ph_on) { o = cmul(o, reinterpret_cast<const CT*>(p.ph_y)[k]); om = cmul(om, reinterpret_cast<const CT*>(p.ph_y)[km]); }
                 if (MODE == 2 && p.angle) {  // cross phase (xrft.py:838-874)

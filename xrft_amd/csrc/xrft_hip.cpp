@@ -2205,6 +2205,7 @@ static int run_fastmy(const xrfthip_plan* P, const void* in, const void* in1, vo
     p.cin = P->cplx_in ? 1 : 0;
     p.nunits = (int)(d.batch * (d.nx / ((two || P->cplx_in) ? C.g : 2 * C.g)));
     p.shift_y = (d.flags & XRFTHIP_SHIFT_Y) ? (int)(d.ny / 2) : 0;
+    p.half = (d.flags & XRFTHIP_HALF_X) ? 1 : 0; p.realdim2 = (d.flags & XRFTHIP_REALDIM_X2) ? 1 : 0;
     p.scale = d.scale;
     xrfthip_plan::ProfRec* rec = prof_begin(P, "fastm_yonly", st);
     const dim3 grid((unsigned)(8 * ((p.nunits + 7) / 8))), blk((unsigned)C.thr);
@@ -2596,6 +2597,7 @@ static int run_fastgy(const xrfthip_plan* P, const void* in, const void* in_b, v
     p.ishift_in = ((d.flags & XRFTHIP_INVERSE) && (d.flags & (rows ? XRFTHIP_ISHIFT_X : XRFTHIP_ISHIFT_Y))) ? (int)(P->gy_n / 2) : 0;
     p.ph_in = ((d.flags & XRFTHIP_PHASE_IN) && P->fph_on) ? 1 : 0;
     p.detrend = d.detrend;
+    p.half = (d.flags & XRFTHIP_HALF_X) ? 1 : 0; p.realdim2 = (d.flags & XRFTHIP_REALDIM_X2) ? 1 : 0;
     p.shift_y = (d.flags & (rows ? XRFTHIP_SHIFT_X : XRFTHIP_SHIFT_Y)) ? (int)(P->gy_n / 2) : 0;
     p.scale = d.scale;
     const dim3 grid((unsigned)std::min<long long>(p.nunits, 0x7fffffffLL)), blk((unsigned)P->gy_thr);
@@ -3215,8 +3217,11 @@ int xrfthip_plan_create(xrfthip_plan** plan, const xrfthip_desc* desc) {
     if (d.ndim == 1 && (d.flags & (XRFTHIP_SHIFT_Y | XRFTHIP_ISHIFT_Y | XRFTHIP_FLIP_Y))) return XRFTHIP_BAD_ARG;
     if ((d.flags & (XRFTHIP_FLIP0_Y | XRFTHIP_FLIP0_X)) && d.out_mode != XRFTHIP_OUT_CROSS && d.out_mode != XRFTHIP_OUT_PHASE) return XRFTHIP_BAD_ARG;
     if ((d.flags & XRFTHIP_FLIP0_Y) && d.ndim == 1) return XRFTHIP_BAD_ARG;
-    if ((d.flags & XRFTHIP_AXIS_Y) && (d.ndim != 2 || (d.flags & XRFTHIP_FLIP0_X) || (d.flags & (XRFTHIP_SHIFT_X | XRFTHIP_ISHIFT_X | XRFTHIP_FLIP_X | XRFTHIP_HALF_X | XRFTHIP_REALDIM_X2 |
+    if ((d.flags & XRFTHIP_AXIS_Y) && (d.ndim != 2 || (d.flags & XRFTHIP_FLIP0_X) || (d.flags & (XRFTHIP_SHIFT_X | XRFTHIP_ISHIFT_X | XRFTHIP_FLIP_X |
                                                                     XRFTHIP_ISO | XRFTHIP_NO_SPECTRUM_OUT | XRFTHIP_C2R_X)))) return XRFTHIP_BAD_ARG;  // (PHASE_IN: only where fastgy takes the plan, below)
+    // AXIS_Y with HALF_X / REALDIM_X2 (ABI 0.1.4): real_dim along the ONE transformed axis -- ny / 2 + 1 rows per slab, unshifted; the one-pass kernels only (below)
+    if ((d.flags & XRFTHIP_AXIS_Y) && (d.flags & (XRFTHIP_HALF_X | XRFTHIP_REALDIM_X2)) &&
+        (cplx_in || !(d.flags & XRFTHIP_HALF_X) || (d.flags & (XRFTHIP_SHIFT_Y | XRFTHIP_FLIP_Y | XRFTHIP_INVERSE)))) return XRFTHIP_BAD_ARG;
 
     if (d.inner > 1 || d.mid > 1) return create_inner_plan(plan, d);
 
@@ -3234,7 +3239,7 @@ int xrfthip_plan_create(xrfthip_plan** plan, const xrfthip_desc* desc) {
     P->rsize = P->dbl ? 8 : 4;
     P->csize = 2 * P->rsize;
     P->nxh = cplx_in ? d.nx : d.nx / 2 + 1;
-    P->nx_out = (d.flags & XRFTHIP_HALF_X) ? d.nx / 2 + 1 : d.nx;
+    P->nx_out = ((d.flags & XRFTHIP_HALF_X) && !(d.flags & XRFTHIP_AXIS_Y)) ? d.nx / 2 + 1 : d.nx;  // (AXIS_Y: the half is along y)
     // width of the intermediate: the half spectrum for real input, unless the row does not fit one LDS tile
     // (four-step along x computes every kx) -- decided inside build_x through P->width.
     P->width = P->nxh;
@@ -3352,7 +3357,8 @@ int xrfthip_plan_create(xrfthip_plan** plan, const xrfthip_desc* desc) {
     {   // one transform axis that is not the contiguous one, real input: pass 1 of the same kernels is the whole transform
         const bool two = d.out_mode == XRFTHIP_OUT_CROSS || d.out_mode == XRFTHIP_OUT_PHASE;
         const uint32_t allowed = XRFTHIP_AXIS_Y | XRFTHIP_SHIFT_Y | (d.out_mode != XRFTHIP_OUT_POWER ? XRFTHIP_ISHIFT_Y : 0u) |
-                                 ((cplx_in && d.out_mode == XRFTHIP_OUT_COMPLEX) ? (XRFTHIP_INVERSE | XRFTHIP_PHASE_IN) : 0u);  // (xrft.ifft along the axis)
+                                 ((cplx_in && d.out_mode == XRFTHIP_OUT_COMPLEX) ? (XRFTHIP_INVERSE | XRFTHIP_PHASE_IN) : 0u) |  // (xrft.ifft along the axis)
+                                 (!cplx_in ? (XRFTHIP_HALF_X | (d.out_mode != XRFTHIP_OUT_PHASE ? XRFTHIP_REALDIM_X2 : 0u)) : 0u);  // (real_dim along the axis: half output)
         P->fastmy = (d.flags & XRFTHIP_AXIS_Y) && d.ndim == 2 && (!cplx_in || !two) &&
                     (d.out_mode == XRFTHIP_OUT_COMPLEX || d.out_mode == XRFTHIP_OUT_POWER || two) && !(d.flags & ~allowed) && fastmy_len(d.ny, P->dbl) &&
                     d.batch * d.nx < (1LL << 30) && !env_ll("XRFTHIP_NO_FAST", 0) && env_ll("XRFTHIP_FASTM", 1) != 0;
@@ -3368,7 +3374,8 @@ int xrfthip_plan_create(xrfthip_plan** plan, const xrfthip_desc* desc) {
     {   // ... on any other smooth length: one pass in LDS with the radices as data (fastg.h: fastgy_kernel)
         const bool two = d.out_mode == XRFTHIP_OUT_CROSS || d.out_mode == XRFTHIP_OUT_PHASE;  // (two REAL fields: a column of each = one packed sequence; no flipped field)
         const uint32_t allowed = XRFTHIP_AXIS_Y | XRFTHIP_SHIFT_Y | (d.out_mode != XRFTHIP_OUT_POWER ? XRFTHIP_ISHIFT_Y : 0u) |
-                                 ((cplx_in && d.out_mode == XRFTHIP_OUT_COMPLEX) ? (XRFTHIP_INVERSE | XRFTHIP_PHASE_IN) : 0u);  // (xrft.ifft along the axis: conj in, conj out, the input rotated)
+                                 ((cplx_in && d.out_mode == XRFTHIP_OUT_COMPLEX) ? (XRFTHIP_INVERSE | XRFTHIP_PHASE_IN) : 0u) |  // (xrft.ifft along the axis: conj in, conj out, the input rotated)
+                                 (!cplx_in ? (XRFTHIP_HALF_X | (d.out_mode != XRFTHIP_OUT_PHASE ? XRFTHIP_REALDIM_X2 : 0u)) : 0u);
         P->fastgy = !P->fastmy && (d.flags & XRFTHIP_AXIS_Y) && (d.out_mode == XRFTHIP_OUT_COMPLEX || d.out_mode == XRFTHIP_OUT_POWER || (two && !cplx_in)) && !(d.flags & ~allowed) &&
                     !env_ll("XRFTHIP_NO_FAST", 0) && env_ll("XRFTHIP_FASTG", 1) != 0 && fastgy_try(P);
         if (P->fastgy) {
@@ -3384,8 +3391,10 @@ int xrfthip_plan_create(xrfthip_plan** plan, const xrfthip_desc* desc) {
         // prime-factor / Rader form with the lanes along the samples (fastg.h, FORM 3); every other 1-D length has its kernels below
         const bool two = d.out_mode == XRFTHIP_OUT_CROSS || d.out_mode == XRFTHIP_OUT_PHASE;
         const uint32_t allowed = XRFTHIP_SHIFT_X | (d.out_mode != XRFTHIP_OUT_POWER ? XRFTHIP_ISHIFT_X : 0u) |
-                                 ((cplx_in && d.out_mode == XRFTHIP_OUT_COMPLEX) ? (XRFTHIP_INVERSE | XRFTHIP_PHASE_IN) : 0u);
-        if (!P->fastgy && d.ndim == 1 && (d.out_mode == XRFTHIP_OUT_COMPLEX || d.out_mode == XRFTHIP_OUT_POWER || (two && !cplx_in)) && !(d.flags & ~allowed) &&
+                                 ((cplx_in && d.out_mode == XRFTHIP_OUT_COMPLEX) ? (XRFTHIP_INVERSE | XRFTHIP_PHASE_IN) : 0u) |
+                                 (!cplx_in ? (XRFTHIP_HALF_X | (d.out_mode != XRFTHIP_OUT_PHASE ? XRFTHIP_REALDIM_X2 : 0u)) : 0u);
+        const bool half_ok = !((d.flags & XRFTHIP_HALF_X) && (d.flags & XRFTHIP_SHIFT_X)) && !((d.flags & XRFTHIP_REALDIM_X2) && !(d.flags & XRFTHIP_HALF_X));
+        if (half_ok && !P->fastgy && d.ndim == 1 && (d.out_mode == XRFTHIP_OUT_COMPLEX || d.out_mode == XRFTHIP_OUT_POWER || (two && !cplx_in)) && !(d.flags & ~allowed) &&
             !env_ll("XRFTHIP_NO_FAST", 0) && env_ll("XRFTHIP_FASTG", 1) != 0 && fastgy_try(P, true)) {
             P->fastgy = true;
             int rcg = P->dbl ? build_twiddle<double>(P->g_twy, d.nx, d.nx) : build_twiddle<float>(P->g_twy, d.nx, d.nx);
@@ -3462,6 +3471,7 @@ int xrfthip_plan_create(xrfthip_plan** plan, const xrfthip_desc* desc) {
         }
     }
     if ((d.flags & XRFTHIP_AXIS_Y) && (d.flags & XRFTHIP_PHASE_IN) && !P->fastgy && !P->fastmy) { delete P; return XRFTHIP_BAD_ARG; }  // (the generic column tiles have no input phase)
+    if ((d.flags & XRFTHIP_AXIS_Y) && (d.flags & XRFTHIP_HALF_X) && !P->fastgy && !P->fastmy) { delete P; return XRFTHIP_UNSUPPORTED_LENGTH; }  // (... and no half output: the caller transposes)
     set_kernel_attrs_once();
     // nbins must be known before tiles are sized (the LDS histogram shares the tile's allocation): ISO plans are
     // (re)built in xrfthip_plan_set_binmap.  Build now for everything else.

@@ -44,7 +44,9 @@ class SpectralPlan:
             raise TypeError(f"unsupported dtype {dtype}")
         self.ndim, self.batch, self.ny, self.nx = int(ndim), int(batch), int(ny), int(nx)
         self.dtype, self.out_mode, self.flags = dtype, int(out_mode), int(flags)
-        self.nx_out = self.nx // 2 + 1 if (flags & _lib.HALF_X) else self.nx
+        half_y = bool(flags & _lib.HALF_X) and bool(flags & _lib.AXIS_Y)  # (ABI 0.1.4: real_dim along the ONE transformed axis of an AXIS_Y plan)
+        self.nx_out = self.nx // 2 + 1 if ((flags & _lib.HALF_X) and not half_y) else self.nx
+        self.ny_out = self.ny // 2 + 1 if half_y else self.ny
         self.nbins = int(nbins)
         self.inner = max(int(inner), 1)  # > 1: (batch, ny, nx, inner) arrays, the transform axes are not the trailing ones
         self.mid = max(int(mid), 1)      # > 1: (batch, ny, mid, nx, inner): independent elements between the two transform axes
@@ -124,7 +126,7 @@ class SpectralPlan:
                 raise ValueError("in1 does not match the plan")
         want_out = not (self.flags & _lib.NO_SPECTRUM_OUT)
         if want_out and out is None:
-            shape = (self.batch, self.ny, self.nx_out) + ((self.inner,) if self.inner > 1 else ())
+            shape = (self.batch, self.ny_out, self.nx_out) + ((self.inner,) if self.inner > 1 else ())
             if self.mid > 1:
                 shape = (self.batch, self.ny, self.mid, self.nx_out, self.inner)
             out = torch.empty(shape, dtype=self.out_dtype(), device=dev)
