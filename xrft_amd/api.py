@@ -489,13 +489,15 @@ def _label_output(c, da, out_t, other, extra_cattrs=None, drop_transform=False):
         out_t = out_t.reshape([da.sizes[d] for d in other] + list(out_t.shape[-len(tdims):]))
         if cur != final:
             out_t = out_t.permute([cur.index(d) for d in final])
-    coords = {k: v for k, v in da.coords.items() if k not in c.dim}
+    coords = {k: v._clone(k) for k, v in da.coords.items() if k not in c.dim}  # (own objects over the input's immutable values)
     for name, cv in c.new_coords.items():
         attrs = dict(cv.attrs)
         if extra_cattrs and name in extra_cattrs:
             attrs.update(extra_cattrs[name])
         coords[name] = Coordinate(cv.dims, cv.values, attrs, name)
-    return DataArray(out_t, final, coords, None, None)
+    if any(d in c.dim for k, v in da.coords.items() if k not in c.dim for d in v.dims):
+        return DataArray(out_t, final, coords, None, None)  # (a kept coordinate that spans a transformed dim: the validating constructor's error, as before)
+    return DataArray._trusted(out_t, final, coords)
 
 
 def _inplace_axis(c, da, iso):

@@ -50,6 +50,16 @@ class Coordinate:
         # a token that is never reused (``id()`` of a freed object is): what the API remembers about this coordinate is keyed by it
         self._token = next(_coord_tokens)
 
+    def _clone(self, name=None):
+        """Another Coordinate object over the same (immutable) values, with the same token -- what they stand for is the same -- and its own attrs."""
+        c = Coordinate.__new__(Coordinate)
+        c.dims = self.dims
+        c._values = self._values
+        c._token = self._token
+        c.attrs = dict(self.attrs)
+        c.name = self.name if name is None else name
+        return c
+
     # numpy interop so that ``npt.assert_allclose(ft["freq_x"], expected)`` works as with xarray
     def __array__(self, dtype=None, copy=None):
         return np.asarray(self.values, dtype=dtype)
@@ -111,6 +121,20 @@ class DataArray:
                     raise ValueError(f"coordinate {k} has dimension {d} which is not a dimension of the array")
                 if self.shape[self.dims.index(d)] != n:
                     raise ValueError(f"coordinate {k} length {n} conflicts with dimension {d}")
+
+    @classmethod
+    def _trusted(cls, data, dims, coords):
+        """A result the library itself has just labelled: ``coords`` are Coordinate objects under their own names whose lengths match ``data`` by construction,
+        non-transform coordinates are the input's own (immutable) objects -- no copies, no checks (xrft_amd/api.py:_label_output; ~10 us of a 40-us call)."""
+        self = cls.__new__(cls)
+        self.data = data
+        self.dims = tuple(dims)
+        self.name = None
+        self.attrs = {}
+        self._chunks = None
+        self._memo = None
+        self.coords = coords
+        return self
 
     @staticmethod
     def _as_coord(name, v):
