@@ -523,6 +523,39 @@ def test_two_axes_that_are_not_adjacent_as_two_fused_passes(dtype):
     cases.run_fused_mid_cases(dtype)
 
 
+def test_real_dim_along_one_axis_is_a_half_output_plan_or_a_refusal():
+    """ABI 0.1.4: XRFTHIP_AXIS_Y with HALF_X (and REALDIM_X2) = real_dim along the ONE transformed axis, served by the one-pass kernels only.  A shift, a flip,
+    complex input or REALDIM_X2 without HALF_X is a bad descriptor; a length no one-pass kernel takes is XRFTHIP_UNSUPPORTED_LENGTH -- and the API then
+    transposes, with the reference's numbers either way."""
+    import xrft_amd as xa
+    from oracle import xrft_oracle as o
+    from xrft_amd import engine
+
+    def make(**kw):
+        base = dict(ndim=2, batch=2, ny=96, nx=8, dtype=torch.float64, out_mode=_lib.OUT_POWER, detrend=0, flags=_lib.AXIS_Y | _lib.HALF_X, scale=1.0)
+        base.update(kw)
+        return engine.SpectralPlan(**base)
+
+    p = make()
+    assert (p.ny_out, p.nx_out) == (49, 8) and "[fastg y-only]" in p.describe()
+    for bad in (dict(flags=_lib.AXIS_Y | _lib.HALF_X | _lib.SHIFT_Y), dict(flags=_lib.AXIS_Y | _lib.REALDIM_X2), dict(dtype=torch.complex128, out_mode=_lib.OUT_COMPLEX),
+                dict(flags=_lib.AXIS_Y | _lib.HALF_X | _lib.FLIP_Y, out_mode=_lib.OUT_COMPLEX)):
+        with pytest.raises(_lib.XrftHipError) as ei:
+            make(**bad)
+        assert ei.value.status == _lib.BAD_ARG, bad
+    with pytest.raises(_lib.XrftHipError) as ei:
+        make(ny=10007)  # (a prime beyond the tile: no one-pass kernel)
+    assert ei.value.status == _lib.UNSUPPORTED_LENGTH
+    rng = np.random.default_rng(3)
+    for n, desc in ((96, False), (10007, False), (96, True)):
+        v = rng.standard_normal((n, 2, 2))
+        t = np.arange(n) * 0.5
+        da = xa.DataArray(v, ("t", "y", "x"), {"t": t[::-1].copy() if desc else t})
+        od = o.OArr(v, ("t", "y", "x"), {"t": t[::-1].copy() if desc else t})
+        cases.check(xa.power_spectrum(da, dim="t", real_dim="t", detrend="constant"), o.power_spectrum(od, dim="t", real_dim="t", detrend="constant"), 1e-10)
+        cases.check(xa.fft(da, dim="t", real_dim="t"), o.fft(od, dim="t", real_dim="t"), 1e-10)
+
+
 def test_huge_slab_along_a_first_axis_takes_the_transposing_path():
     """a cube whose [n][inner] slab exceeds 2^31 elements cannot be indexed by the one-axis plans; plan creation is
     refused (XRFTHIP_BAD_ARG) and the API must not hand that error to the caller -- it never asks for such a plan."""
