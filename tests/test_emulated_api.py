@@ -147,7 +147,7 @@ def test_bluestein_precision_policy():
 
 
 def test_long_prime_lengths_through_global_bluestein():
-    cases.run_long_prime_cases(lengths=((9001, "float64"), (10007, "float32")))  # (complex input of such a length: the GPU suite)
+    cases.run_long_prime_cases(lengths=((9001, "float64"),))  # (float32 and complex input of such lengths: the GPU suite; the float32 policy: test_bluestein_precision_policy)
 
 
 @pytest.mark.parametrize("ny,nx,nt,shift,det,win", [
