@@ -1075,6 +1075,14 @@ def test_large_slabs_off_the_tables_with_the_lengths_as_data(shape, dtype):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("seed", range(40))
+def test_random_fused_layout_differential(seed):
+    from test_random_differential import run_random_fused_layout
+
+    run_random_fused_layout(32000 + seed, lo=16, hi=1500)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", range(40))
 def test_random_fastn_differential(seed):
     from test_random_differential import run_random_fastn
 

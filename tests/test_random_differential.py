@@ -363,6 +363,53 @@ def run_random_fastn(seed, lo=16, hi=200, dtype="float64", blue_p=0.15):
     return "fastn" if on else "other"
 
 
+def run_random_fused_layout(seed, lo=16, hi=160):
+    """Random power spectra / ffts over two transform axes that are NOT the trailing pair -- the independent elements innermost ((y, x, t) arrays) or between
+    the axes ((y, t, x): dim = ["time", "lon"] of (time, lat, lon)) -- on random smooth / Rader lengths, element counts, leading batches, options, either order
+    of the dims: the engine's two fused passes (csrc/fastn.h: fastn_cols_kernel, fastn_fit_inner_kernel, fastn_irows_kernel) or the composite of one-axis
+    plans, against the oracle.  Returns "fused" | "other"."""
+    import xrft_amd as xa
+
+    rng = np.random.default_rng(seed)
+    lens = smooth_lengths(lo, hi) + [n for n in (34, 51, 57, 58, 68, 73, 97, 146) if lo <= n <= hi]
+    ny, nx = int(rng.choice(lens)), int(rng.choice(lens))
+    ne = int(rng.choice([1, 2, 3, 4, 5, 7, 8, 12, 16, 17, 33]))
+    lay = str(rng.choice(["inner", "mid"]))
+    if ne == 1 and lay == "inner":
+        ne = 6
+    nb = int(rng.choice([0, 0, 2, 3]))
+    dtype = str(rng.choice(["float64", "float32"]))
+    shape, dims = ((ny, nx, ne), ("y", "x", "t")) if lay == "inner" else ((ny, ne, nx), ("y", "t", "x"))
+    if nb:
+        shape, dims = (nb,) + shape, ("b",) + dims
+    v = rng.standard_normal(shape)
+    for d, n, sl in (("y", ny, 0.02), ("x", nx, -0.03)):
+        sh = [1] * len(shape)
+        sh[dims.index(d)] = n
+        v = v + sl * np.arange(n).reshape(sh)
+    v = (v + 1.0).astype(dtype)
+    c = {d: np.arange(n) * float(rng.choice([0.5, 1.0, 2.0])) + float(rng.choice([0.0, 1.0, -3.0])) for d, n in zip(dims, shape)}
+    da, od = cases.pair(v, dims, c)
+    kw = dict(detrend=rng.choice([None, "constant", "linear"]), window=rng.choice([None, "hann", "hamming"]))
+    dd = ["y", "x"] if rng.random() < 0.7 else ["x", "y"]
+    shift = bool(rng.random() < 0.7)
+    api._plan_cache.clear()
+    if rng.random() < 0.6:
+        sc = str(rng.choice(["density", "spectrum"]))
+        got, ref = xa.power_spectrum(da, dim=dd, shift=shift, scaling=sc, **kw), o.power_spectrum(od, dim=dd, shift=shift, scaling=sc, **kw)
+    else:
+        tp = bool(rng.random() < 0.5)
+        got, ref = xa.fft(da, dim=dd, shift=shift, true_phase=tp, **kw), o.fft(od, dim=dd, shift=shift, true_phase=tp, **kw)
+    tol = (1e-10 if dtype == "float64" else 3e-4) * (10 if kw["detrend"] == "linear" else 1)  # (a plane fit on a trend of 5 x the noise: the residual's conditioning)
+    cases.check(got, ref, tol)
+    return "fused" if any("[fastn fused]" in p.describe() for p in api._plan_cache.values()) else "other"
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("XRFT_RANDOM_FUSED_CASES", "24"))))
+def test_random_fused_layout_case(seed):
+    run_random_fused_layout(31000 + seed)
+
+
 @pytest.mark.parametrize("seed", range(int(os.environ.get("XRFT_RANDOM_FASTN_CASES", "24"))))
 def test_random_fastn_case(seed, monkeypatch):
     """csrc/fastn.h on the emulator: small slabs are kept off the one-pass kernel (XRFTHIP_FASTG=0) so that the two-pass pipeline with run-time
