@@ -42,7 +42,7 @@
 extern "C" {
 #endif
 
-#define XRFTHIP_VERSION 104 /* 0.1.4: XRFTHIP_AXIS_Y with XRFTHIP_HALF_X / REALDIM_X2 (real_dim along the one transformed axis); 0.1.3: xrfthip_desc.mid (two transform axes anywhere in a C-contiguous array); 0.1.2: xrfthip_plan_uses_bluestein, xrfthip_convert (0.1.1: xrfthip_desc.inner, xrfthip_reduce_axis, xrfthip_detrend_inner) */
+#define XRFTHIP_VERSION 105 /* 0.1.5: xrfthip_selftest_floor; 0.1.4: XRFTHIP_AXIS_Y with XRFTHIP_HALF_X / REALDIM_X2 (real_dim along the one transformed axis); 0.1.3: xrfthip_desc.mid (two transform axes anywhere in a C-contiguous array); 0.1.2: xrfthip_plan_uses_bluestein, xrfthip_convert (0.1.1: xrfthip_desc.inner, xrfthip_reduce_axis, xrfthip_detrend_inner) */
 
 typedef enum xrfthip_status {
     XRFTHIP_OK = 0,
@@ -255,6 +255,13 @@ int xrfthip_convert(int32_t dtype_in, int32_t dtype_out, int64_t n, const void* 
  * batches of isotropic spectra (`iso_ps.mean("time")`, xrft/tests/test_xrft.py:1011-1013) and, with scale = 1 / (slabs of ALL ranks), the
  * local term of the multi-GPU batch mean (xrft_amd/dist.py: one all_reduce(SUM) of nbins values finishes it). */
 int xrfthip_reduce_axis(int32_t dtype, int64_t outer, int64_t n, int64_t inner, const void* d_in, void* d_out, double scale, void* stream);
+
+/* The memory floor of the headline path (BASELINE.json configs[2]: xrft.power_spectrum of 4096 x 4096 float32 slabs, xrft/xrft.py:685-750),
+ * measured on the spot: the access patterns of the two passes with the transforms removed (csrc/selftest.h), and a plain copy.
+ * `reps` timed rounds after one warm-up; us[0..2] = microseconds per slab of the copy (nslab x 64 MB read + written), the column-pass
+ * skeleton and the row-pass skeleton.  d_in: [nslab][4096][4096] float32; d_w2: scratch, nslab * 2052 * 4096 * 8 bytes; d_out:
+ * [nslab][4096][4096] float32, overwritten.  Synchronises the stream: a measurement for bench.py, not part of the hot path. */
+int xrfthip_selftest_floor(const void* d_in, void* d_w2, void* d_out, int64_t nslab, int32_t reps, double* us, void* stream);
 
 /* Stand-alone radial bin-sum of an existing spectrum (xrft.isotropize, xrft.py:948-1010):
  * d_in [batch][ny][nx] (dtype F32|F64|C64|C128), d_binmap device int32 [ny][nx] (bin of each sample, < 0 = none),

@@ -31,7 +31,7 @@ EXPORTS = [
     "xrfthip_plan_set_profiling", "xrfthip_plan_profile_read", "xrfthip_workspace_bytes", "xrfthip_plan_describe", "xrfthip_exec", "xrfthip_detrend_workspace_bytes",
     "xrfthip_detrend", "xrfthip_detrend3", "xrfthip_spectrum_tail", "xrfthip_spectrum_tail_axis", "xrfthip_gather_axis", "xrfthip_isotropize",
     "xrfthip_isotropize_workspace_bytes", "xrfthip_table_mul", "xrfthip_reduce_axis", "xrfthip_detrend_inner_workspace_bytes", "xrfthip_detrend_inner", "xrfthip_angle",
-    "xrfthip_plan_uses_bluestein", "xrfthip_convert", "xrfthip_plan_kernel_info",
+    "xrfthip_plan_uses_bluestein", "xrfthip_convert", "xrfthip_plan_kernel_info", "xrfthip_selftest_floor",
 ]
 
 
@@ -92,6 +92,7 @@ def _bind(dll):
     dll.xrfthip_isotropize_workspace_bytes.restype = sz
     dll.xrfthip_isotropize_workspace_bytes.argtypes = [i32, i64, i64, i64, i32]
     dll.xrfthip_isotropize.argtypes = [i32, i64, i64, i64, vp, vp, i32, vp, vp, sz, vp]
+    dll.xrfthip_selftest_floor.argtypes = [vp, vp, vp, i64, i32, C.POINTER(C.c_double), vp]
     for name in EXPORTS:
         getattr(dll, name)  # AttributeError here = the .so does not export what the header declares
     return dll

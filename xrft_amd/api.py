@@ -14,6 +14,7 @@ Deviations from the reference, all documented in DESIGN.md:
 """
 from __future__ import annotations
 
+import collections
 import math
 import threading
 import warnings
@@ -269,7 +270,8 @@ def _get_plan(binmap_key=None, **kw):
     return p
 
 
-_TWO_STAGE = {}  # _ifft_two_stages: (shape, flags, tables) -> False | (y-stage plan, x-stage plan)
+_TWO_STAGE = collections.OrderedDict()  # _ifft_two_stages: (shape, flags, tables) -> bool, a small LRU of DECISIONS (the stage plans live in _plan_cache only:
+_TWO_STAGE_SIZE = 32                   # its LRU governs their lifetime and their device tables)
 
 
 def clear_plan_cache():
@@ -294,7 +296,11 @@ def _label_guard(da):
         vals = v.values
         if vals.flags.writeable:  # (someone re-opened the array for writing: its content is no longer pinned by the token)
             return None
-        toks.append((k, v._token))
+        # ... plus a cheap fingerprint of the content (size, first, second and last sample: origin, spacing, extent): an array re-opened for
+        # writing, changed and closed again between two calls keeps its token, and a deep copy shares it while owning another array
+        n = vals.size
+        fp = (n,) if n == 0 or vals.dtype.kind not in "fiuMm" else (n, vals.flat[0].item(), vals.flat[min(1, n - 1)].item(), vals.flat[n - 1].item())
+        toks.append((k, v._token, fp))
     return (da.dims, da.shape, tuple(toks), None if not da._chunks else tuple(sorted(da._chunks.items())))
 
 
@@ -579,7 +585,7 @@ def _execute_inner(c, da, mode, scale):
     batch = int(np.prod(shape[:first], dtype=np.int64))
     # the extents the composite plan carries in 32 bits (create_inner_plan; the one-axis stages): known limits are checked HERE,
     # so that a BAD_ARG from the library means a bug in the descriptor and is raised, not hidden behind the transposing path
-    if (inner < 2 and mid < 2) or mid * inner * shape[second] > (1 << 30) or shape[first] * shape[second] * inner * mid > (1 << 31) - 1 or (c.detrend and mid > 1 and batch * mid > 65535):
+    if (inner < 2 and mid < 2) or mid * inner * shape[second] > (1 << 30) or shape[first] * shape[second] * inner * mid > (1 << 31) - 1:
         return None
     flags, win, ph = _flags_tables(c, da)
     if mode == _lib.OUT_POWER:
@@ -1160,16 +1166,22 @@ def _ifft_two_stages(t, batch, ny, nx, flags, scale, ph):
     fx = _lib.INVERSE | (flags & (_lib.ISHIFT_X | _lib.SHIFT_X | _lib.C2R_X)) | (_lib.PHASE_IN if ph["x"] is not None else 0)
     # the decision is taken once per shape / flag / phase-table set and remembered here (not as an attribute hung on a cached plan)
     dkey = (batch, ny, nx, str(t.dtype), int(flags), float(scale), _akey(ph["y"]), _akey(ph["x"]), engine.bluestein_in_float64())
+    def stage_plans():
+        py_ = _get_plan(ndim=2, batch=batch, ny=ny, nx=nxs, dtype=t.dtype, out_mode=_lib.OUT_COMPLEX, detrend=_lib.DETREND_NONE, flags=fy, scale=1.0 / float(ny),
+                        window_y=None, window_x=None, phase_y=ph["y"], phase_x=None)
+        px_ = _get_plan(ndim=1, batch=batch * ny, ny=1, nx=nx, dtype=t.dtype, out_mode=_lib.OUT_COMPLEX, detrend=_lib.DETREND_NONE, flags=fx, scale=scale * float(ny),
+                        window_y=None, window_x=None, phase_y=None, phase_x=ph["x"])
+        return py_, px_
+
     with _plan_lock:
         dec = _TWO_STAGE.get(dkey)
+        if dec is not None:
+            _TWO_STAGE.move_to_end(dkey)
     if dec is False:
         return None
     if dec is None:
         try:
-            py = _get_plan(ndim=2, batch=batch, ny=ny, nx=nxs, dtype=t.dtype, out_mode=_lib.OUT_COMPLEX, detrend=_lib.DETREND_NONE, flags=fy, scale=1.0 / float(ny),
-                           window_y=None, window_x=None, phase_y=ph["y"], phase_x=None)
-            px = _get_plan(ndim=1, batch=batch * ny, ny=1, nx=nx, dtype=t.dtype, out_mode=_lib.OUT_COMPLEX, detrend=_lib.DETREND_NONE, flags=fx, scale=scale * float(ny),
-                           window_y=None, window_x=None, phase_y=None, phase_x=ph["x"])
+            py, px = stage_plans()
             # ... and run well: four complex columns or more per workgroup along y (32-byte row segments at least), two rows or more per workgroup along x (one long
             # row per workgroup runs at half the rate: (16, 4096, 4096) 24 GFFT/s in two such stages against 30 on the two-axis plan).  Decided on the kernel
             # kinds the C ABI reports (xrfthip_plan_kernel_info), not on the text of describe()
@@ -1184,14 +1196,14 @@ def _ifft_two_stages(t, batch, ny, nx, flags, scale, ph):
             if e.status not in (_lib.UNSUPPORTED_LENGTH, _lib.BAD_ARG):
                 raise
             good = False
-        dec = (py, px) if good else False
+        dec = bool(good)
         with _plan_lock:
-            if len(_TWO_STAGE) > 256:
-                _TWO_STAGE.clear()
             _TWO_STAGE[dkey] = dec
+            while len(_TWO_STAGE) > _TWO_STAGE_SIZE:
+                _TWO_STAGE.popitem(last=False)
         if dec is False:
             return None
-    py, px = dec
+    py, px = stage_plans()  # (through _plan_cache every call: evicted plans are rebuilt, none is kept alive from here)
     mid, _ = py.execute(t.reshape(batch, ny, nxs))
     out, _ = px.execute(mid.reshape(batch * ny, 1, nxs))
     return out.reshape(list(t.shape[:-1]) + [nx])

@@ -327,11 +327,11 @@ __global__ void __launch_bounds__(256) table_mul_kernel(const void* in, const C2
 // 16-element inner dimension left half of every wave idle on 64-byte pieces: 0.86 ms for a 268-MB array)
 constexpr int kInnerThreads = 1024;  // (a (y, x, t) array with few inner elements is ONE tile: at most kInnerMaxChunks = 256 workgroups share it, so they are large)
 template <typename T>
-__global__ void __launch_bounds__(kInnerThreads) plane_inner_moments_kernel(const T* __restrict__ in, long long ny, long long nx, long long inner2, double* part, int ib, int xsn, long long mid) {
+__global__ void __launch_bounds__(kInnerThreads) plane_inner_moments_kernel(const T* __restrict__ in, long long ny, long long nx, long long inner2, double* part, int ib, int xsn, long long mid, long long b0) {
     XRFT_DYN_SMEM(smem_raw);
     double* red = reinterpret_cast<double*>(smem_raw);  // [xsn][3][ib]
     const int li = threadIdx.x % ib, xs = threadIdx.x / ib;
-    const long long i2 = (long long)blockIdx.x * ib + li, b = blockIdx.z;  // grid = (tiles of the inner index, row chunks, batch)
+    const long long i2 = (long long)blockIdx.x * ib + li, b = b0 + blockIdx.z;  // grid = (tiles of the inner index, row chunks, batch elements b0 .. of this launch)
     const double ibar = 0.5 * (double)(ny - 1), jbar = 0.5 * (double)(nx - 1);
     const bool live = xs < xsn && i2 < inner2;
     double s0 = 0.0, si = 0.0, sj = 0.0;

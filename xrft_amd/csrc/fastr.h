@@ -43,6 +43,7 @@ struct FastR {
     int realdim2;      // ... and 0 < k < N/2 counts twice (xrft.py:673-682)
     int shift;         // fftshift of the output (xrft.py:446-447)
     float scale;       // complex: multiplies X; power: multiplies |X|^2
+    int stagger;       // fastr_kernel: start delay of workgroup class c = (block / 8) % classes, c x (stagger & 0xff) x 3.4 us; classes = stagger >> 8 (0: none)
 };
 
 constexpr int kFastRThreads = 1024;
@@ -183,6 +184,15 @@ __global__ void __launch_bounds__(kFastRThreads) fastr_kernel(FastR p) {
     XRFT_DYN_SMEM(smem_raw);
     cf* L = reinterpret_cast<cf*>(smem_raw);
     double* red = reinterpret_cast<double*>(smem_raw + (size_t)kFastRLdsElems * 8);  // [16 waves][2]
+#ifndef XRFT_EMULATE
+    // One workgroup owns a CU and walks its rows load -> transform -> store with nothing overlapped, and all CUs start together: the chip
+    // alternates between memory phases (every CU loading or storing) and a phase in which every CU computes and the memory idles.  Classes of
+    // workgroups that start a fraction of a row period apart keep the memory busy while the others transform.
+    if ((p.stagger >> 8) > 1) {
+        const int cls = (int)((blockIdx.x >> 3) % (unsigned)(p.stagger >> 8)), n = cls * (p.stagger & 0xff);
+        for (int i = 0; i < n; ++i) __builtin_amdgcn_s_sleep(127);
+    }
+#endif
     for (long long row = blockIdx.x; row < p.nrows; row += gridDim.x) {
         // (everything derived from the thread index is re-derived per row from an opaque copy: hoisted out of the loop, the 62 twiddle
         // powers and the store offsets were 165 spilled registers)

@@ -136,6 +136,7 @@ struct FastY {
     int shift_y, shift_x;    // 0 or n/2
     float scale;
     int tune;                // see kYTuneDefault
+    long long* tim;          // fasty_isorows_kernel<.., TIM>: [workgroup][8] shader-clock sums of its phases (profiling build only; null otherwise)
     unsigned* rdv;           // tune bit 21: one arrival counter per (slab, group of the column blocks that share the input's 128-byte lines), zeroed per launch
 };
 
@@ -146,7 +147,11 @@ struct FastY {
 
 // geometry of pass 1 for NY-point columns
 template <int NY> struct YCols {
+#ifdef XRFT_YCOLS_WIDE  // (round-6 experiment, scripts/prof.py cols-wide: a 1024-thread workgroup owns 16 columns of a 4096-point slab -- 64-byte row segments, two sharers per input line instead of four)
+    static constexpr int THR = NY >= 4096 ? 1024 : NY >= 2048 ? 512 : 256;
+#else
     static constexpr int THR = NY >= 2048 ? 512 : 256;
+#endif
     static constexpr int NT = NY / 16;
     static constexpr int GY = THR / NT;              // lockstep transform pairs per workgroup: 2, 4, 4, 8, 16
     static constexpr int CW = 4 * GY;                // real columns per workgroup
@@ -168,10 +173,10 @@ template <int N, int GX> struct YLds {
 // that one transform is parked in LDS whenever the other is inside a butterfly (a butterfly needs 32 temporaries on top
 // of its 32 data registers: with both transforms live the kernel would not fit 128 VGPRs).  In / out conventions per
 // transform as fft_p2_group.
-template <int N> __device__ __forceinline__ void fft_p2_pair(cf* a, cf* b, int u, cf* lds, const cf* __restrict__ tw, const cf* tw2) {
+// (fft_p2_pair_w: the first-stage twiddle W_N^u handed in -- a persistent workgroup loads it once)
+template <int N> __device__ __forceinline__ void fft_p2_pair_w(cf* a, cf* b, int u, cf* lds, const cf w1, const cf* tw2) {
     typedef P2<N> G;
     const int k1 = u / G::R3, v = u % G::R3;
-    const cf w1 = tw[u];  // W_N^u
     dft16(a);
     twiddle16(a, w1);
 #pragma unroll
@@ -225,6 +230,10 @@ template <int N> __device__ __forceinline__ void fft_p2_pair(cf* a, cf* b, int u
     __syncthreads();
 }
 
+template <int N> __device__ __forceinline__ void fft_p2_pair(cf* a, cf* b, int u, cf* lds, const cf* __restrict__ tw, const cf* tw2) {
+    fft_p2_pair_w<N>(a, b, u, lds, tw[u], tw2);  // W_N^u
+}
+
 // slot of frequency k held as element (bb, k3) by thread u after fft_p2_group / fft_p2_pair
 template <int N> __device__ __forceinline__ int held_k(int u, int bb, int k3) {
     const int pr = u + P2<N>::NT * bb;
@@ -239,7 +248,7 @@ template <int N> __device__ __forceinline__ int held_k(int u, int bb, int k3) {
 // W2D (four-step 1-D with a window): the window of a long sequence is not separable over its [ny][nx] view, so it comes from a
 // table laid out like the slab, read at the samples' own offsets (w[nx i1 + i2]; shared by every slab: L2-resident).
 template <int NY, bool DET, bool W2D = false>
-__global__ void __launch_bounds__(YCols<NY>::THR, YCols<NY>::THR / 128) fasty_cols_kernel(FastY p) {
+__global__ void __launch_bounds__(YCols<NY>::THR, (YCols<NY>::THR >= 512 ? 4 : YCols<NY>::THR / 128)) fasty_cols_kernel(FastY p) {
     typedef P2<NY> G;
     typedef YCols<NY> Y;
     constexpr int NT = G::NT, GY = Y::GY, THR = Y::THR, GSTR = YLds<NY, GY>::GSTR;

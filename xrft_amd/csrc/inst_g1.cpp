@@ -1,6 +1,7 @@
 // inst_g1.cpp -- the kernel instantiations of group 1 of instances.h (one of the translation units libxrft_hip.so is built from)
 #include "gpu_rt.h"
 #include "fasty.h"
+#include "fasty_iso.h"
 #include "fastm.h"
 namespace xrft {
 #define XRFT_KW template __global__

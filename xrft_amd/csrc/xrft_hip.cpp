@@ -18,6 +18,7 @@
 #include <cstddef>
 #include <cstring>
 #include <map>
+#include <mutex>
 #include <new>
 #include <string>
 #include <vector>
@@ -29,6 +30,8 @@
 #include "aux_kernels.h"
 #include "fastp2.h"
 #include "fasty.h"
+#include "fasty_iso.h"
+#include "selftest.h"
 #include "fastm.h"
 #include "fastn.h"
 #include "fastr.h"
@@ -378,6 +381,7 @@ struct xrfthip_plan {
     // ... and ONE pass for a long real float32 row that fits the registers of a CU: 65536 samples per workgroup (fastr.h)
     bool fastr = false;
     DevBuf tw_rm, tw_rs, tw_rn;   // W_M^p (p < 1024), W_1024^n (n < 32), W_N^p (p < 1024)
+    long long tune_rstagger = 0;  // XRFTHIP_FASTR_STAGGER: classes << 8 | units of 3.4 us between the start of consecutive classes of workgroups (FastR::stagger)
     long long tune_rgrid = 0;     // XRFTHIP_FASTR_GRID: workgroups of the launch (0 = one per row; default: a resident set of one per CU walking the rows)
     bool fph_on = false;  // some entry of the combined phase tables (fph) differs from 1
     long long yny = 0, ynx = 0;
@@ -394,6 +398,9 @@ struct xrfthip_plan {
     // tuning knobs from the environment, read once when the plan is created (never in xrfthip_exec)
     long long tune_group = 0, tune_fast_group = 0, tune_group_bytes = 512LL << 20, tune_cols_grid = 256, tune_max_grid = 8192;
     long long tune_y = 0;  // XRFTHIP_YTUNE: cache policies / start stagger of the y-first float32 kernels (FastY::tune), fixed at plan creation
+    long long tune_isorows = 1;  // XRFTHIP_ISOROWS: 1 (default) the persistent radial-sum row kernel (fasty_iso.h) when nothing but the sums leaves pass 2; 0 fasty_rows_kernel;
+                                 // 2 its profiling build (per-phase shader-clock sums printed after every launch: scripts/prof.py iso-phases -- synchronises, never in the product)
+    mutable DevBuf iso_tim;      // ... whose counters live here
     // optional per-pass event timing (bench only; a plan with profiling on is not re-entrant)
     bool prof = false;
     struct ProfRec { std::string label; hipEvent_t a, b; };
@@ -894,6 +901,9 @@ void set_kernel_attrs_once() {
                  SETF((fasty_rows_kernel<NN, 0, false>)); SETF((fasty_rows_kernel<NN, 2, false>)); SETF((fasty_rows_kernel<NN, 2, true>)); SETF((fasty_rows_kernel<NN, 3, false>))
     SETY(4096); SETY(2048); SETY(1024); SETY(512); SETY(256);
 #undef SETY
+#define SETI(NN) SETF((fasty_isorows_kernel<NN, 1, false>)); SETF((fasty_isorows_kernel<NN, 2, false>)); SETF((fasty_isorows_kernel<NN, 1, true>)); SETF((fasty_isorows_kernel<NN, 2, true>))
+    SETI(4096); SETI(2048); SETI(1024);
+#undef SETI
     SETF((fasty_rows_kernel<256, 0, false, true>)); SETF((fasty_rows_kernel<256, 1, false, true>));
     SETF((fasty_rows_kernel<256, 0, false, true, true>)); SETF((fasty_rows_kernel<256, 1, false, true, true>));
 #undef SETF
@@ -1431,6 +1441,23 @@ static bool fasty_iso_tables_fit(const xrfthip_plan* P, int nbins) {
 
 static bool fasty_on(const xrfthip_plan* P) { return P->yfirst && fast_on(P); }
 
+// Workgroups of `kernel` the whole device holds at once (a persistent launch's grid): the occupancy calculator's count per CU times the CUs,
+// asked once per kernel.
+static long long resident_workgroups(const void* kernel, int threads, size_t lds) {
+    static std::mutex mu;
+    static std::map<const void*, long long> memo;
+    std::lock_guard<std::mutex> lock(mu);
+    auto it = memo.find(kernel);
+    if (it != memo.end()) return it->second;
+    int per_cu = 0, cus = 0, dev = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, threads, lds) != hipSuccess || per_cu < 1) per_cu = 1;
+    (void)hipGetDevice(&dev);
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1) cus = 256;
+    const long long n = (long long)per_cu * cus;
+    memo[kernel] = n;
+    return n;
+}
+
 static void fasty_launch_cols(const xrfthip_plan* P, const FastY& p, long long gc, hipStream_t st, bool prof) {
     const xrfthip_desc& d = P->d;
     const YGeomRt C = ycols_geom(P->yny);
@@ -1466,6 +1493,37 @@ static void fasty_launch_rows(const xrfthip_plan* P, const FastY& p, long long g
     const dim3 grid((unsigned)(P->fast1d ? gc * ((P->yny / 2) / rpu) + (gc + R.gxy - 1) / R.gxy : gc * (P->y_nrow_pad / rpu))), blk((unsigned)R.thr);
     const int hw = d.out_mode == XRFTHIP_OUT_CROSS ? 2 : 1;
     const size_t lds = R.lds;  // (the radial-sum tables alias the transforms' LDS)
+    // nothing but the radial sums of a radial map leaves the pass: the persistent kernel of fasty_iso.h (as many workgroups as the chip holds)
+    if (iso_on && p.out == nullptr && p.tfirst != nullptr && !P->fast1d && P->tune_isorows != 0 && P->ynx >= 1024 &&
+        (d.out_mode == XRFTHIP_OUT_POWER || d.out_mode == XRFTHIP_OUT_CROSS)) {
+        const long long total = gc * (P->y_nrow_pad / rpu);
+        const bool tim = P->tune_isorows == 2;
+        FastY q = p;
+        void (*kern)(FastY) = nullptr;
+#define YI_(NN) kern = d.out_mode == XRFTHIP_OUT_POWER ? (tim ? &fasty_isorows_kernel<NN, 1, true> : &fasty_isorows_kernel<NN, 1, false>) \
+                                                       : (tim ? &fasty_isorows_kernel<NN, 2, true> : &fasty_isorows_kernel<NN, 2, false>)
+        if (P->ynx == 4096) YI_(4096); else if (P->ynx == 2048) YI_(2048); else YI_(1024);
+#undef YI_
+        const long long slots = resident_workgroups(reinterpret_cast<const void*>(kern), R.thr, lds);
+        const unsigned nblk = (unsigned)std::min<long long>(total, slots);
+        if (tim) {
+            std::vector<long long> z((size_t)nblk * 8, 0);
+            if (P->iso_tim.upload(z.data(), z.size() * sizeof(long long)) == XRFTHIP_OK) q.tim = reinterpret_cast<long long*>(P->iso_tim.p);
+        }
+        XRFT_LAUNCH(kern, dim3(nblk), blk, lds, st, q);
+        prof_end(rec, st);
+        if (tim && q.tim) {
+            (void)hipStreamSynchronize(st);
+            std::vector<long long> h((size_t)nblk * 8, 0);
+            (void)hipMemcpy(h.data(), q.tim, h.size() * sizeof(long long), hipMemcpyDeviceToHost);
+            double acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            for (unsigned b = 0; b < nblk; ++b) for (int i = 0; i < 8; ++i) acc[i] += (double)h[(size_t)b * 8 + i];
+            const double units = std::max(acc[7], 1.0);
+            std::fprintf(stderr, "[xrfthip isorows nx=%lld mode=%d] %u workgroups, %.0f units; shader-clock cycles per unit: wait+addback %.0f | fft %.0f | tables+stage %.0f | "
+                         "segments %.0f | gather %.0f | total %.0f\n", (long long)P->ynx, (int)d.out_mode, nblk, units, acc[0] / units, acc[1] / units, acc[2] / units, acc[3] / units, acc[4] / units,
+                         (acc[0] + acc[1] + acc[2] + acc[3] + acc[4]) / units);
+        }
+    } else {
 #define YR_(NN) do { \
         if (d.out_mode == XRFTHIP_OUT_POWER) { if (iso_on) { auto k = &fasty_rows_kernel<NN, 1, true>; XRFT_LAUNCH(k, grid, blk, lds, st, p); } else { auto k = &fasty_rows_kernel<NN, 1, false>; XRFT_LAUNCH(k, grid, blk, lds, st, p); } } \
         else if (d.out_mode == XRFTHIP_OUT_CROSS) { if (iso_on) { auto k = &fasty_rows_kernel<NN, 2, true>; XRFT_LAUNCH(k, grid, blk, lds, st, p); } else { auto k = &fasty_rows_kernel<NN, 2, false>; XRFT_LAUNCH(k, grid, blk, lds, st, p); } } \
@@ -1482,6 +1540,7 @@ static void fasty_launch_rows(const xrfthip_plan* P, const FastY& p, long long g
     else if (P->ynx == 4096) YR_(4096); else if (P->ynx == 2048) YR_(2048); else if (P->ynx == 1024) YR_(1024); else if (P->ynx == 512) YR_(512); else YR_(256);
 #undef YR_
     prof_end(rec, st);
+    }
     if (iso_on) {  // the row workgroups' partial sums, added in order
         rec = prof ? prof_begin(P, "fasty_iso_reduce", st) : nullptr;
         const int nb = P->nbins * hw, upr = P->y_nrow_pad / rpu;
@@ -2778,6 +2837,7 @@ static int run_fastr(const xrfthip_plan* P, const void* in, void* out, hipStream
     p.realdim2 = (d.flags & XRFTHIP_REALDIM_X2) ? 1 : 0;
     p.shift = (d.flags & XRFTHIP_SHIFT_X) ? 1 : 0;
     p.scale = (float)d.scale;
+    p.stagger = (int)P->tune_rstagger;
     const long long g = P->tune_rgrid > 0 ? std::min<long long>(P->tune_rgrid, d.batch) : d.batch;
     const dim3 grid((unsigned)std::min<long long>(g, 0x7fffffffLL)), blk((unsigned)(d.nx / 64));
     const bool pw = d.out_mode == XRFTHIP_OUT_POWER;
@@ -3231,6 +3291,7 @@ int xrfthip_plan_create(xrfthip_plan** plan, const xrfthip_desc* desc) {
     P->tune_group = env_ll("XRFTHIP_GROUP", 0);
     P->tune_fast_group = env_ll("XRFTHIP_FAST_GROUP", 0);
     P->tune_y = env_ll("XRFTHIP_YTUNE", kYTuneDefault);
+    P->tune_isorows = env_ll("XRFTHIP_ISOROWS", 1);
     P->tune_group_bytes = env_ll("XRFTHIP_GROUP_BYTES", 512LL << 20);
     P->tune_cols_grid = env_ll("XRFTHIP_FAST_COLS_GRID", kCUs);
     P->tune_max_grid = env_ll("XRFTHIP_MAX_GRID", 8 * kCUs * 4);
@@ -3299,6 +3360,7 @@ int xrfthip_plan_create(xrfthip_plan** plan, const xrfthip_desc* desc) {
             // 65536 samples: one resident workgroup per CU walks the rows (measured: 359 vs 344 GFFT/s for a workgroup per row, profiles/r04_fastr.txt);
             // the shorter rows (several workgroups per CU): a workgroup per row
             P->tune_rgrid = env_ll("XRFTHIP_FASTR_GRID", d.nx == 65536 ? kCUs : 0);
+            P->tune_rstagger = d.nx == 65536 ? env_ll("XRFTHIP_FASTR_STAGGER", 0) : 0;
             const long long thr = d.nx / 64;  // threads per row: 32 packed complex values each
             int rcr = build_twiddle<float>(P->tw_rm, d.nx / 2, thr);
             if (!rcr) rcr = build_twiddle<float>(P->tw_rs, thr, 32);
@@ -3361,6 +3423,7 @@ int xrfthip_plan_create(xrfthip_plan** plan, const xrfthip_desc* desc) {
                                  (!cplx_in ? (XRFTHIP_HALF_X | (d.out_mode != XRFTHIP_OUT_PHASE ? XRFTHIP_REALDIM_X2 : 0u)) : 0u);  // (real_dim along the axis: half output)
         P->fastmy = (d.flags & XRFTHIP_AXIS_Y) && d.ndim == 2 && (!cplx_in || !two) &&
                     (d.out_mode == XRFTHIP_OUT_COMPLEX || d.out_mode == XRFTHIP_OUT_POWER || two) && !(d.flags & ~allowed) && fastmy_len(d.ny, P->dbl) &&
+                    !((d.flags & XRFTHIP_HALF_X) && (d.flags & XRFTHIP_SHIFT_Y)) &&  // (the half output is unshifted: also refused by xrfthip_plan_create, kept here so the two cannot drift apart)
                     d.batch * d.nx < (1LL << 30) && !env_ll("XRFTHIP_NO_FAST", 0) && env_ll("XRFTHIP_FASTM", 1) != 0;
         if (P->fastmy && d.nx % (((two || cplx_in) ? 1 : 2) * mygeom(d.ny, P->dbl).g) != 0) P->fastmy = false;
         if (P->fastmy) {
@@ -3377,6 +3440,7 @@ int xrfthip_plan_create(xrfthip_plan** plan, const xrfthip_desc* desc) {
                                  ((cplx_in && d.out_mode == XRFTHIP_OUT_COMPLEX) ? (XRFTHIP_INVERSE | XRFTHIP_PHASE_IN) : 0u) |  // (xrft.ifft along the axis: conj in, conj out, the input rotated)
                                  (!cplx_in ? (XRFTHIP_HALF_X | (d.out_mode != XRFTHIP_OUT_PHASE ? XRFTHIP_REALDIM_X2 : 0u)) : 0u);
         P->fastgy = !P->fastmy && (d.flags & XRFTHIP_AXIS_Y) && (d.out_mode == XRFTHIP_OUT_COMPLEX || d.out_mode == XRFTHIP_OUT_POWER || (two && !cplx_in)) && !(d.flags & ~allowed) &&
+                    !((d.flags & XRFTHIP_HALF_X) && (d.flags & XRFTHIP_SHIFT_Y)) &&
                     !env_ll("XRFTHIP_NO_FAST", 0) && env_ll("XRFTHIP_FASTG", 1) != 0 && fastgy_try(P);
         if (P->fastgy) {
             const long long m = P->gy_blue_m ? P->gy_blue_m : d.ny;  // length of the passes
@@ -3542,6 +3606,48 @@ int xrfthip_plan_set_binmap(xrfthip_plan* plan, const int32_t* h_binmap, int64_t
     int rcb = plan->dbl ? build_plan_t<double>(*plan) : build_plan_t<float>(*plan);
     if (!rcb) rcb = finalize_plan(plan);
     return rcb;
+}
+
+// The memory floor of the headline path, measured here and now (selftest.h): `reps` rounds of [pass-1 skeleton, pass-2 skeleton] over
+// `nslab` 4096 x 4096 float32 slabs and `reps` plain copies of the same input, HIP events on `stream` around every launch.
+// Synchronises (it is a measurement, not part of the hot path).  d_in: nslab x 4096 x 4096 float32; d_w2: nslab x 2052 x 4096 complex64
+// (scratch); d_out: nslab x 4096 x 4096 float32 (overwritten).  us[0..2] = average microseconds PER SLAB of the copy, the column
+// skeleton and the row skeleton.
+int xrfthip_selftest_floor(const void* d_in, void* d_w2, void* d_out, int64_t nslab, int32_t reps, double* us, void* stream) {
+    if (!d_in || !d_w2 || !d_out || !us || nslab < 1 || nslab > 4096 || reps < 1 || reps > 1000) return XRFTHIP_BAD_ARG;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    set_kernel_attrs_once();
+    const size_t lds_c = ycols_geom(4096).lds, lds_r = yrows_geom(4096).lds;
+    const int m = (int)kLdsMax;
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&selftest_cols_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, m);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&selftest_rows_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, m);
+    hipEvent_t ev[4];
+    for (auto& e : ev) HIP_TRY(hipEventCreate(&e));
+    double acc[3] = {0.0, 0.0, 0.0};
+    const size_t n16 = (size_t)nslab * 4096 * 4096 / 4;
+    int rc = XRFTHIP_OK;
+    for (int r = -1; r < reps && rc == XRFTHIP_OK; ++r) {  // (round -1: warm-up, not counted)
+        auto kc = &selftest_copy_kernel;
+        auto k1 = &selftest_cols_kernel;
+        auto k2 = &selftest_rows_kernel;
+        (void)hipEventRecord(ev[0], st);
+        XRFT_LAUNCH(kc, dim3(2048), dim3(256), 0, st, reinterpret_cast<const F4*>(d_in), reinterpret_cast<F4*>(d_out), n16);
+        (void)hipEventRecord(ev[1], st);
+        XRFT_LAUNCH(k1, dim3((unsigned)(nslab * (4096 / SelfGeom::CW))), dim3(512), lds_c, st, reinterpret_cast<const float*>(d_in), reinterpret_cast<cf*>(d_w2), (int)nslab);
+        (void)hipEventRecord(ev[2], st);
+        XRFT_LAUNCH(k2, dim3((unsigned)(nslab * (SelfGeom::NROW_PAD / SelfGeom::RPU))), dim3(512), lds_r, st, reinterpret_cast<const cf*>(d_w2), reinterpret_cast<float*>(d_out), (int)nslab);
+        (void)hipEventRecord(ev[3], st);
+        if (hipEventSynchronize(ev[3]) != hipSuccess || hipGetLastError() != hipSuccess) { rc = XRFTHIP_HIP_ERROR; break; }
+        if (r < 0) continue;
+        for (int i = 0; i < 3; ++i) {
+            float ms = 0.f;
+            (void)hipEventElapsedTime(&ms, ev[i], ev[i + 1]);
+            acc[i] += (double)ms;
+        }
+    }
+    for (auto& e : ev) (void)hipEventDestroy(e);
+    for (int i = 0; i < 3; ++i) us[i] = acc[i] * 1e3 / ((double)reps * (double)nslab);
+    return rc;
 }
 
 int xrfthip_plan_set_profiling(xrfthip_plan* plan, int enable) {
@@ -4012,10 +4118,10 @@ static int run_detrend_inner(int32_t dtype, int32_t ndim, long long batch, long 
         const long long bc = std::min<long long>(65535, batch - b0);
         const int ib = (int)std::min<long long>(i2, kInnerThreads), xsn = kInnerThreads / ib;  // lanes across the inner index x column slots
         const dim3 grid((unsigned)((i2 + ib - 1) / ib), (unsigned)nch, (unsigned)bc), block(kInnerThreads);  // (tiles of the inner index on grid.x: no 65535 limit)
-        if (mid > 1 && batch > 65535) return XRFTHIP_BAD_ARG;  // (one launch covers all (outer, mid) pairs: the element offsets are not a multiple of a batch block)
-        const size_t lds = (size_t)xsn * 3 * ib * sizeof(double), eoff = (size_t)b0 * ny * nx * i2;
-        if (dbl) { auto k = &plane_inner_moments_kernel<double>; XRFT_LAUNCH(k, grid, block, lds, st, (const double*)in + eoff, (long long)ny, (long long)nx, i2, part + (size_t)b0 * nch * i2 * 3, ib, xsn, mid); }
-        else { auto k = &plane_inner_moments_kernel<float>; XRFT_LAUNCH(k, grid, block, lds, st, (const float*)in + eoff, (long long)ny, (long long)nx, i2, part + (size_t)b0 * nch * i2 * 3, ib, xsn, mid); }
+        // (the kernel takes the first (outer, mid) pair of the launch and addresses from the array's base: with mid > 1 a block of pairs is not a contiguous piece)
+        const size_t lds = (size_t)xsn * 3 * ib * sizeof(double);
+        if (dbl) { auto k = &plane_inner_moments_kernel<double>; XRFT_LAUNCH(k, grid, block, lds, st, (const double*)in, (long long)ny, (long long)nx, i2, part, ib, xsn, mid, b0); }
+        else { auto k = &plane_inner_moments_kernel<float>; XRFT_LAUNCH(k, grid, block, lds, st, (const float*)in, (long long)ny, (long long)nx, i2, part, ib, xsn, mid, b0); }
     }
     {
         auto k = &plane_inner_finalize_kernel;
