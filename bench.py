@@ -99,7 +99,7 @@ def parse_args(argv=None):
                     "(-1 = as many as host cores, slabs and memory allow; 0 = skip)")
     ap.add_argument("--no-profile", action="store_true", help="do not record per-kernel HIP events")
     ap.add_argument("--no-extra", action="store_true", help="skip the short c2 / c4 / c5 legs that follow the headline at N = 1 (`extra_workloads`)")
-    ap.add_argument("--extra-steps", type=int, default=5, help="timed steps of each extra leg")
+    ap.add_argument("--extra-steps", type=int, default=10, help="timed steps of each extra leg")
     ap.add_argument("--no-floor", action="store_true", help="skip the library's memory-floor self-test (`roofline.measured_floor`)")
     ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
                     help="weak: --nt slabs PER GPU (default); strong: --nt slabs in total, contiguous blocks per rank")
@@ -534,7 +534,7 @@ def extra_leg(name, args, env, dev):
 
     api.clear_plan_cache()
     wl = Workload(name, args, env, dev, 0, 1, None, default_sizes=True)
-    steps = args.extra_steps
+    steps = max(args.extra_steps, 50) if name == "c2" else args.extra_steps  # (c2's step is one 0.18-ms kernel: the barrier + synchronize bracket of a timed region is 0.4 ms)
     dt, prof, res, plan = wl.measure(steps, 1, True)
     value = 1e-9 * wl.points_per_step * steps / dt
     leg = {"metric": wl.metric, "value": round(value, 3), "unit": "GFFT/s", "steps": steps, "warmup": 1,

@@ -8,7 +8,7 @@ export TMPDIR=/tmp
 cd /tmp
 run() {
   name=$1; shift
-  timeout 600 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d "$GRAFT_REPO_ROOT/gpurun_out/pmc_$TAG/$name" -o p -- python "$GRAFT_REPO_ROOT/bench.py" --steps 1 --warmup 1 --nt ${PMC_NT:-64} --cpu-slabs 0 --no-profile > "$GRAFT_REPO_ROOT/gpurun_out/pmc_$TAG/$name.log" 2>&1
+  timeout 600 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d "$GRAFT_REPO_ROOT/gpurun_out/pmc_$TAG/$name" -o p -- python "$GRAFT_REPO_ROOT/bench.py" --steps 1 --warmup 1 --nt ${PMC_NT:-64} --cpu-slabs 0 --no-profile --no-extra --no-floor > "$GRAFT_REPO_ROOT/gpurun_out/pmc_$TAG/$name.log" 2>&1
   echo "pass $name rc=$?"
 }
 for p in $PASSES; do

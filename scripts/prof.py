@@ -152,6 +152,30 @@ def cmd_iso(a):
         torch.cuda.empty_cache()
 
 
+def cmd_isoq(a):
+    """the new row kernel only (XRFTHIP_ISOROWS=1), then its phase clocks (=2), under whatever XRFTHIP_YTUNE the caller set: tuning sweeps"""
+    setup(a.lib, a.env)
+    import torch
+
+    import xrft_amd as xrft
+    from xrft_amd import api
+
+    for name, n, nt, two in (("iso PS 4096^2", 4096, 32, False), ("iso PS 2048^2", 2048, 64, False), ("iso CS 2048^2", 2048, 64, True)):
+        d1, d2 = make((nt, n, n), "float32", two)
+        fn = (lambda: xrft.isotropic_cross_spectrum(d1, d2, dim=["y", "x"], window="hann")) if two else (lambda: xrft.isotropic_power_spectrum(d1, dim=["y", "x"], window="hann"))
+        os.environ["XRFTHIP_ISOROWS"] = "1"
+        api.clear_plan_cache()
+        wall, kern, _plan = timed(fn, nt, a.reps)
+        line(name, wall, kern, n * n)
+        os.environ["XRFTHIP_ISOROWS"] = "2"
+        api.clear_plan_cache()
+        fn(); torch.cuda.synchronize()
+        os.environ["XRFTHIP_ISOROWS"] = "1"
+        api.clear_plan_cache()
+        del d1, d2
+        torch.cuda.empty_cache()
+
+
 def cmd_headline(a):
     setup(a.lib, a.env)
     import numpy as np
@@ -187,7 +211,7 @@ def cmd_c2(a):
 def main():
     ap = argparse.ArgumentParser()
     sub = ap.add_subparsers(dest="cmd", required=True)
-    for name in ("call", "iso", "headline", "c2"):
+    for name in ("call", "iso", "isoq", "headline", "c2"):
         sp = sub.add_parser(name)
         sp.add_argument("--lib", default=None)
         sp.add_argument("--env", action="append", default=[])
@@ -199,7 +223,7 @@ def main():
         if name == "headline":
             sp.add_argument("--nt", type=int, default=64)
     a = ap.parse_args()
-    {"call": cmd_call, "iso": cmd_iso, "headline": cmd_headline, "c2": cmd_c2}[a.cmd](a)
+    {"call": cmd_call, "iso": cmd_iso, "isoq": cmd_isoq, "headline": cmd_headline, "c2": cmd_c2}[a.cmd](a)
 
 
 if __name__ == "__main__":

@@ -1187,7 +1187,7 @@ def _ifft_two_stages(t, batch, ny, nx, flags, scale, ph):
             # kinds the C ABI reports (xrfthip_plan_kernel_info), not on the text of describe()
             (ky, cy), (kx, rx) = py.kernel_info(), px.kernel_info()
             seg = cy * t.element_size()  # bytes of a row one column workgroup reads
-            good = ((ky == _lib.K_FASTG_Y and seg >= 32) or (ky == _lib.K_FASTM_Y and seg >= 16)) and kx in (_lib.K_FASTG_ROWS, _lib.K_FASTM_X) and rx >= 2
+            good = ((ky == _lib.K_FASTG_Y and seg >= 32) or (ky == _lib.K_FASTM_Y and seg >= 16)) and ((kx in (_lib.K_FASTG_ROWS, _lib.K_FASTM_X) and rx >= 2) or kx == _lib.K_FASTR)  # (K_FASTR: complex rows in registers, csrc/fastr.h fastc_kernel)
             if good and ny * nxs <= 20000:  # (a slab this small may run in ONE pass over both axes: only then is the two-axis plan built to ask)
                 whole = _get_plan(ndim=2, batch=batch, ny=ny, nx=nx, dtype=t.dtype, out_mode=_lib.OUT_COMPLEX, detrend=_lib.DETREND_NONE, flags=flags, scale=scale,
                                   window_y=None, window_x=None, phase_y=ph["y"], phase_x=ph["x"])

@@ -43,6 +43,9 @@ struct FastR {
     int realdim2;      // ... and 0 < k < N/2 counts twice (xrft.py:673-682)
     int shift;         // fftshift of the output (xrft.py:446-447)
     float scale;       // complex: multiplies X; power: multiplies |X|^2
+    int inv;           // fastc_kernel (complex rows): the inverse transform -- conjugate in, conjugate out (xrft.ifft, xrft.py:586-621)
+    int ishift;        // ... its input is rotated by n/2 on load (an fftshifted spectrum: xrft.py:612-617)
+    int ph_in;         // ... `ph` multiplies the INPUT samples (by source index) instead of the output (the true-phase factor of xrft.ifft, xrft.py:596-606)
     int stagger;       // fastr_kernel: start delay of workgroup class c = (block / 8) % classes, c x (stagger & 0xff) x 3.4 us; classes = stagger >> 8 (0: none)
 };
 
@@ -505,6 +508,147 @@ __global__ void __launch_bounds__((R2Geom<R2, R3>::T), (R2Geom<R2, R3>::WPS)) fa
                     fastr_store8(o + pos0 + T * m, x0);
                     if (!HALF) fastr_store8(o + pos1 + T * m, x1);
                     else if (m == 0) { if (tid == 0) fastr_store8(o + M, p.ph_on ? cmul(x1, p.ph[M]) : x1); }
+                }
+            }
+            fastr_sched_fence();
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------------------------------------
+// COMPLEX rows of M = 2048 | 4096 | 8192 | 16384 points in ONE pass (xrft.ifft / xrft.fft of complex data along the contiguous axis, xrft.py:586-621,
+// :439-447): the transform core of fastr2_kernel on the row itself -- no packing in front, no split behind.  T = M / 32 threads hold the row
+// (32 complex values each), three stages through two LDS exchanges, Z in natural order through the LDS, 8-byte lane-contiguous stores.
+//   load    z[n] at n = tid + T j; an fftshifted input is the register rotation j -> j + 16 (n + M/2 = tid + T (j + 16)); the true-phase
+//           factor of an inverse transform multiplies the SOURCE sample (ph_in); the inverse conjugates on the way in and on the way out
+//   store   Z[k] * scale (times the output phase table, unshifted k) at (k + shift) mod M: k = v + T m -> the rotation m -> m + 16
+// 16 bytes per point through memory (8 read + 8 written); the LDS-resident fastm_xonly_kernel it replaces on these lengths ran them at
+// 2.4 TB/s (ifft (16384, 4096): 149 GFFT/s, profiles/r05_inverse.txt).   MODE 0: complex result, 1: |Z|^2 (power spectrum of complex rows)
+// ------------------------------------------------------------------------------------------------------------------------------------------
+template <int R2, int R3, int MODE>
+__global__ void __launch_bounds__((R2Geom<R2, R3>::T), (R2Geom<R2, R3>::WPS)) fastc_kernel(FastR p) {
+    typedef R2Geom<R2, R3> G;
+    constexpr int T = G::T, M = G::M, K2 = G::K2, K3 = G::K3, S1 = G::S1, S2 = G::S2;
+    XRFT_DYN_SMEM(smem_raw);
+    cf* L = reinterpret_cast<cf*>(smem_raw);
+    for (long long row = blockIdx.x; row < p.nrows; row += gridDim.x) {
+        int tid = threadIdx.x;
+        XRFT_OPAQUE(tid);
+        const cf* __restrict__ src = reinterpret_cast<const cf*>(p.in) + (size_t)row * M + tid;
+        const int rot = p.ishift ? 16 : 0;
+        cf a[32];
+        if (p.ishift) {
+#pragma unroll
+            for (int j = 0; j < 32; ++j) a[j] = src[((j + 16) & 31) * T];
+        } else {
+#pragma unroll
+            for (int j = 0; j < 32; ++j) a[j] = src[j * T];
+        }
+        if (p.ph_in) {  // two batches of 16 factors beside the 64 registers of the row
+#pragma unroll
+            for (int g = 0; g < 2; ++g) {
+                cf f[16];
+#pragma unroll
+                for (int j = 0; j < 16; ++j) f[j] = p.ph[tid + T * ((16 * g + j + rot) & 31)];
+#pragma unroll
+                for (int j = 0; j < 16; ++j) a[16 * g + j] = cmul(a[16 * g + j], f[j]);
+                fastr_sched_fence();
+            }
+        }
+        if (p.win) {  // a real window over the M samples
+#pragma unroll
+            for (int g = 0; g < 2; ++g) {
+                float w[16];
+#pragma unroll
+                for (int j = 0; j < 16; ++j) w[j] = p.win[tid + T * (16 * g + j)];  // (indexed by the transform's sample index, as fastm_xonly_kernel)
+#pragma unroll
+                for (int j = 0; j < 16; ++j) a[16 * g + j] = cscale(a[16 * g + j], w[j]);
+                fastr_sched_fence();
+            }
+        }
+        if (p.inv) {
+#pragma unroll
+            for (int j = 0; j < 32; ++j) a[j].im = -a[j].im;
+        }
+        // ---- stage 1
+        dft32f(a);
+        twiddle32f(a, p.tw_m[tid]);
+        // ---- exchange 1
+        const int aa = tid % R3, cc = tid / R3;
+        __syncthreads();
+#pragma unroll
+        for (int k1 = 0; k1 < 32; ++k1) L[k1 * S1 + tid] = a[k1];
+        __syncthreads();
+#pragma unroll
+        for (int s = 0; s < K2; ++s)
+#pragma unroll
+            for (int b = 0; b < R2; ++b) a[s * R2 + b] = L[(cc + R2 * s) * S1 + aa + R3 * b];
+        // ---- stage 2: DFT_R2 over b, x W_T^(a k2)
+        {
+            const cf wt = p.tw_s[aa];
+            if (R2 == 32) { dft32f(a); twiddle32f(a, wt); }
+            else if (R2 == 16) {
+#pragma unroll
+                for (int s = 0; s < K2; ++s) { dft16<float>(a + 16 * s); twiddle16<float>(a + 16 * s, wt); }
+            } else {
+                const cf w2 = cmul(wt, wt), w3 = cmul(w2, wt), w4 = cmul(w2, w2), w5 = cmul(w4, wt), w6 = cmul(w4, w2), w7 = cmul(w4, w3);
+#pragma unroll
+                for (int s = 0; s < K2; ++s) {
+                    cf* g = a + 8 * s;
+                    dft8<float>(g);
+                    g[1] = cmul(g[1], wt); g[2] = cmul(g[2], w2); g[3] = cmul(g[3], w3); g[4] = cmul(g[4], w4);
+                    g[5] = cmul(g[5], w5); g[6] = cmul(g[6], w6); g[7] = cmul(g[7], w7);
+                }
+            }
+        }
+        // ---- exchange 2
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < 32; ++u) L[u * S2 + tid] = a[u];
+        __syncthreads();
+        const int dd = tid % R3;
+#pragma unroll
+        for (int t = 0; t < K3; ++t)
+#pragma unroll
+            for (int e = 0; e < R3; ++e) a[t * R3 + e] = L[(dd + R3 * t) * S2 + e + R3 * cc];
+        // ---- stage 3
+#pragma unroll
+        for (int t = 0; t < K3; ++t) dft_r<float, R3>(a + R3 * t);
+        // ---- Z in natural order: register (t, k3) is k = k1 + 32 (k2 + R2 k3), u = d + R3 t = s R2 + k2, k1 = c + R2 s
+        __syncthreads();
+#pragma unroll
+        for (int t = 0; t < K3; ++t) {
+            const int u = dd + R3 * t, s2 = u / R2, k2 = u % R2, k1 = cc + R2 * s2;
+#pragma unroll
+            for (int k3 = 0; k3 < R3; ++k3) {
+                const int k = k1 + 32 * (k2 + R2 * k3);
+                L[k + (k >> 5)] = a[t * R3 + k3];
+            }
+        }
+        __syncthreads();
+        // ---- store: thread v takes k = v + T m at (k + shift) mod M = v + T ((m + 16) mod 32)
+        const size_t orow = (size_t)row * M;
+        const int orot = p.shift ? 16 : 0;
+        const float sc = p.scale;
+#pragma unroll
+        for (int g = 0; g < 8; ++g) {  // batches of 4
+            cf z[4], f[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int k = tid + T * (4 * g + q);
+                z[q] = L[k + (k >> 5)];
+                if (MODE == 0 && p.ph_on) f[q] = p.ph[k];
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int m = 4 * g + q, pos = tid + T * ((m + orot) & 31);
+                if (MODE == 1) {
+                    fastr_store4(reinterpret_cast<float*>(p.out) + orow + pos, (z[q].re * z[q].re + z[q].im * z[q].im) * sc);
+                } else {
+                    cf o = cscale(z[q], sc);
+                    if (p.inv) o.im = -o.im;
+                    if (p.ph_on) o = cmul(o, f[q]);
+                    fastr_store8(reinterpret_cast<cf*>(p.out) + orow + pos, o);
                 }
             }
             fastr_sched_fence();

@@ -504,6 +504,142 @@ __device__ __forceinline__ void xrft_store_nt2(cf* dst, cf v0, cf v1) {
     xrft_store_nt(reinterpret_cast<float*>(dst), o);
 }
 
+// an unaligned 32-bit read of two adjacent 16-bit table entries (one global_load_dword on gfx950)
+struct __attribute__((packed, aligned(2))) U16Pair { unsigned v; };
+
+
+// Sum of the NRW (2 .. 16, a power of two) adjacent lanes that hold the rows of one bin, valid in the FIRST lane of the group, in the fixed
+// tree order ((r0 + r1) + (r2 + r3)) + ... -- what `v += __shfl_down(v, 1, NRW); v += __shfl_down(v, 2, NRW); ...` yields there.
+// DPP row shifts (lane i reads lane i + m of its row of 16): no trip through the LDS crossbar.
+template <int NRW> __device__ __forceinline__ double quad_rows_sum(double v) {
+    static_assert(NRW == 2 || NRW == 4 || NRW == 8 || NRW == 16, "the rows of a bin are adjacent lanes of one DPP row");
+#ifdef XRFT_EMULATE
+#pragma unroll
+    for (int m = 1; m < NRW; m <<= 1) v += __shfl_down(v, m, NRW);
+    return v;
+#else
+    auto from = [](double x, auto ctrl) -> double {  // (lanes whose source falls off the row read 0: never the group's first lane)
+        const long long b = __double_as_longlong(x);
+        const int lo = __builtin_amdgcn_update_dpp(0, (int)(b & 0xffffffffll), decltype(ctrl)::value, 0xf, 0xf, false);
+        const int hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), decltype(ctrl)::value, 0xf, 0xf, false);
+        return __longlong_as_double(((long long)hi << 32) | (unsigned)lo);
+    };
+    v += from(v, std::integral_constant<int, 0x101>());                 // row_shl:1
+    if (NRW >= 4) v += from(v, std::integral_constant<int, 0x102>());   // row_shl:2
+    if (NRW >= 8) v += from(v, std::integral_constant<int, 0x104>());   // row_shl:4
+    if (NRW >= 16) v += from(v, std::integral_constant<int, 0x108>());  // row_shl:8
+    return v;
+#endif
+}
+
+// ------------------------------------------------------------------------------------------------
+// The per-bin gather of the radial sums (xrft.py:895-906) from rows staged in LDS, shared by fasty_rows_kernel<.., ISO> and
+// fasty_isorows_kernel (fasty_iso.h).  Step (1) of those kernels left the sum of every run of equal bins of a 16-sample segment on
+// the run's last sample; here the owner of a (bin, row) walks the bin's two kx ranges of that row, one staged value per segment it
+// touches, and adds them in float64 in a fixed order (+kx side by rising segment, then the -kx side); the NRW rows of a bin are
+// adjacent lanes of a quad and meet in lane order.  The phase is a chain of LDS latencies, not of work (measured with the profiling
+// build of fasty_isorows_kernel: 7900 shader cycles per unit of four 4096-sample rows with a branch and a wait per read, 5600 so):
+// the first two segments of either side of KB sweeps are read up front with UNCONDITIONAL, masked reads (a bin narrower than 16
+// samples touches no more), the few lanes whose bin hugs |k| = ky walk on four reads per trip, and the rows of a bin are added by DPP
+// quad permutes instead of trips through the LDS crossbar.
+//   rowp: this lane's staged row; rg[k]: the |kx| range s | e << 16 of bin blo + (k0 + k) BPI + blane in this row, k < kn <= KB
+// ------------------------------------------------------------------------------------------------
+template <int NX, int CPS>
+__device__ __forceinline__ void radial_walk(const float* rowp, int seg0, int lim, double& sre, double& sim) {
+    constexpr bool TWO = CPS == 2;
+    for (int seg = seg0; 16 * seg < lim; seg += 4) {
+        float w[4][CPS];
+        int wo[4];
+        unsigned wk[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const bool on = 16 * (seg + j) < lim;
+            wo[j] = CPS * nat16(on ? min(lim, 16 * (seg + j + 1)) - 1 : 0);
+            wk[j] = on ? 0xffffffffu : 0u;
+            XRFT_OPAQUE(wk[j]);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int c = 0; c < CPS; ++c) w[j][c] = rowp[wo[j] + c];
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int c = 0; c < CPS; ++c) w[j][c] = __uint_as_float(__float_as_uint(w[j][c]) & wk[j]);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            sre += (double)w[j][0];
+            if (TWO) sim += (double)w[j][CPS - 1];
+        }
+    }
+}
+
+template <int NX, int NRW, int CPS, int BPI, int KB>
+__device__ __forceinline__ void radial_gather_batch(const float* rowp, int row, bool live, bool twin, int blo, int bhi, int k0, int kn, const unsigned* rg,
+                                                int blane, double* __restrict__ part, bool store) {
+    constexpr bool TWO = CPS == 2;
+    constexpr int HW = TWO ? 2 : 1;
+    auto walk = [&](int seg0, int lim, double& sre, double& sim) { radial_walk<NX, CPS>(rowp, seg0, lim, sre, sim); };
+    float pv[KB][4][CPS];
+    int pa[KB][4];        // the walk beyond the two segments read up front: first segment / limit, either side
+    int po[KB][4];        // float offsets of the four reads
+    unsigned keep[KB][4];  // all ones: the read counts
+#pragma unroll
+    for (int k = 0; k < KB; ++k) {
+        const int bn = blo + (k0 + k) * BPI + blane;
+        const bool on = k < kn && live && bn < bhi;
+        const int s_ = (int)(rg[k] & 0xffffu), e_ = (int)(rg[k] >> 16);
+        const int e1 = min(e_, NX / 2);                               // +side: kx = s .. e1 - 1
+        const int ms = max(s_, 1), me = min(e_, NX / 2 + 1);          // -side: kx = nx - |kx|, |kx| = ms .. me - 1
+        const int lo = NX - (me - 1), hi1 = NX - ms + 1;
+        const int sp = s_ >> 4, sm = lo >> 4;
+        const bool vp0 = on && s_ < e1, vp1 = vp0 && 16 * (sp + 1) < e1;
+        const bool vm0 = on && ms < me, vm1 = vm0 && 16 * (sm + 1) < hi1;
+        const bool vv[4] = {vp0, vp1, vm0, vm1};
+        const int aa[4] = {min(e1, 16 * (sp + 1)) - 1, min(e1, 16 * (sp + 2)) - 1, min(hi1, 16 * (sm + 1)) - 1, min(hi1, 16 * (sm + 2)) - 1};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            // UNCONDITIONAL reads of valid slots, masked afterwards (a select on the loaded value is turned back into a branch around
+            // the read: twelve serialised LDS round trips per batch; the opaque mask keeps the `and` from being folded into a select)
+            po[k][j] = CPS * nat16(vv[j] ? aa[j] : 0);
+            keep[k][j] = vv[j] ? 0xffffffffu : 0u;
+            XRFT_OPAQUE(keep[k][j]);
+        }
+        pa[k][0] = vp1 ? sp + 2 : NX; pa[k][1] = e1; pa[k][2] = vm1 ? sm + 2 : NX; pa[k][3] = hi1;
+    }
+#pragma unroll
+    for (int k = 0; k < KB; ++k)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int c = 0; c < CPS; ++c) pv[k][j][c] = rowp[po[k][j] + c];
+#pragma unroll
+    for (int k = 0; k < KB; ++k)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int c = 0; c < CPS; ++c) pv[k][j][c] = __uint_as_float(__float_as_uint(pv[k][j][c]) & keep[k][j]);
+#pragma unroll
+    for (int k = 0; k < KB; ++k) {
+        if (k >= kn) continue;
+        const int bn = blo + (k0 + k) * BPI + blane;
+        double sre = 0.0, sim = 0.0;
+        sre += (double)pv[k][0][0]; if (TWO) sim += (double)pv[k][0][CPS - 1];
+        sre += (double)pv[k][1][0]; if (TWO) sim += (double)pv[k][1][CPS - 1];
+        walk(pa[k][0], pa[k][1], sre, sim);
+        sre += (double)pv[k][2][0]; if (TWO) sim += (double)pv[k][2][CPS - 1];
+        sre += (double)pv[k][3][0]; if (TWO) sim += (double)pv[k][3][CPS - 1];
+        walk(pa[k][2], pa[k][3], sre, sim);
+        if (twin) { sre *= 2.0; sim = 0.0; }  // V + conj V (a power spectrum's two samples are equal)
+        sre = quad_rows_sum<NRW>(sre);  // rows 0 .. NRW - 1 in a fixed tree order: (r0 + r1) + (r2 + r3)
+        if (TWO) sim = quad_rows_sum<NRW>(sim);
+        if (row == 0 && bn < bhi && store) {
+            part[bn * HW] = sre;
+            if (TWO) part[2 * bn + (TWO ? 1 : 0)] = sim;
+        }
+    }
+}
+
 // MODE = xrfthip_out_mode: 1 power (two rows of one field per thread), 0 complex (fft; the same, staged in two rounds),
 // 2 cross / 3 cross phase (transform A = the row of field 0, transform B = the same row of field 1: F0 conj(F1) is formed in
 // registers, so a cross spectrum costs ONE column pass per field and one row pass -- xrft.py:825).  The complex results
@@ -517,7 +653,7 @@ __device__ __forceinline__ void xrft_store_nt2(cf* dst, cf v0, cf v1) {
 // (2 GX * 4 or GX * 8 bytes contiguous); the Hermitian mirror X[N - k] = conj X[k] is the reversed run.  (xrft.dft / fft /
 // power_spectrum along one long axis, BASELINE.json configs[1]: 1-D (1024, 65536) float32.)
 template <int NX, int MODE, bool ISO, bool FS = false, bool W2D = false>
-__global__ void __launch_bounds__((YRows<NX, FS>::THR), (YRows<NX, FS>::THR / 128 < 1 ? 1 : YRows<NX, FS>::THR / 128)) fasty_rows_kernel(FastY p) {
+__global__ void __launch_bounds__((YRows<NX, FS>::THR), ((ISO && YRows<NX, FS>::THR >= 256) ? 4 : YRows<NX, FS>::THR / 128 < 1 ? 1 : YRows<NX, FS>::THR / 128)) fasty_rows_kernel(FastY p) {
     static_assert(!W2D || FS, "the slab-shaped window belongs to the four-step form");
     static_assert(MODE == 1 || MODE == 2 || !ISO, "radial sums exist for power and cross spectra");
     static_assert(!FS || (MODE <= 1 && !ISO), "the four-step form serves fft and power_spectrum");
@@ -778,12 +914,11 @@ __global__ void __launch_bounds__((YRows<NX, FS>::THR), (YRows<NX, FS>::THR / 12
             }
             __syncthreads();
             double* __restrict__ part = p.iso_part + ((size_t)slab * upr + unit) * p.nbins * HW;
-            // task = (bin, row): NRW adjacent lanes share a bin, one row each, and their sums meet in lane order by shuffles (a bin
-            // per thread leaves the one thread whose bin hugs |k| = ky -- ranges of up to 300 samples in every row -- working
-            // alone; measured, the two forms run alike: 23.1 / 24.1 us per 4096^2 slab, the tail is not what is left above the
-            // 17.4 us of the row pass without radial sums)
-            static_assert((NRW & (NRW - 1)) == 0 && NRW <= 64 && THR % NRW == 0, "rows per workgroup");
-            const int row = tid % NRW, ky = ky0 + row;
+            // task = (bin, row): NRW adjacent lanes share a bin, one row each, and their sums meet in lane order (a bin per thread leaves the
+            // one thread whose bin hugs |k| = ky -- ranges of up to 300 samples in every row -- working alone); radial_gather_batch above
+            static_assert((NRW & (NRW - 1)) == 0 && NRW <= 16 && THR % NRW == 0, "rows per workgroup");
+            constexpr int BPI = THR / NRW, KB = MODE == 2 ? 2 : 3;
+            const int row = tid % NRW, ky = ky0 + row, blane = tid / NRW;
             const bool live = ky <= nyh, twin = ky != 0 && ky != nyh;
             const float* rowp = stg + row * RSI;
             // only the bins the unit's rows reach, |k| = ky0 dky .. |(ky0 + NRW - 1, nx/2)| (p.twin, from the map itself): 46 % of them
@@ -791,42 +926,26 @@ __global__ void __launch_bounds__((YRows<NX, FS>::THR), (YRows<NX, FS>::THR / 12
             // beside the 67 MB of the rows
             const unsigned bw = p.twin[unit];
             const int blo = (int)(bw & 0xffffu), bhi = (int)(bw >> 16);
-            auto range_of = [&](int bn_) -> unsigned {
+            const unsigned short* __restrict__ frow = p.tfirst + (size_t)min(ky, nyh) * (p.nbins + 1);
+            auto range_of = [&](int bn_) -> unsigned {  // the bin holds |kx| = s .. e - 1 of this row: s | e << 16
                 if (!(live && bn_ < bhi)) return 0u;
-                const unsigned short* __restrict__ fr = p.tfirst + (size_t)ky * (p.nbins + 1) + bn_;
-                return (unsigned)fr[0] | ((unsigned)fr[1] << 16);
+#ifdef XRFT_EMULATE
+                return (unsigned)frow[bn_] | ((unsigned)frow[bn_ + 1] << 16);
+#else
+                return reinterpret_cast<const U16Pair*>(frow + bn_)->v;
+#endif
             };
-            unsigned nxt = range_of(blo + tid / NRW);
-            for (int b0 = blo; b0 < bhi; b0 += THR / NRW) {
-                const int bn = b0 + tid / NRW;
-                double sre = 0.0, sim = 0.0;
-                const unsigned cur = nxt;
-                nxt = range_of(bn + THR / NRW);  // (the next bin's range is in flight behind this bin's sums: one L2 round trip per bin otherwise)
-                if (live && bn < bhi) {
-                    const int s = (int)(cur & 0xffffu), e = (int)(cur >> 16);  // the bin holds |kx| = s .. e - 1 of this row
-                    auto take = [&](int pp) {
-                        const float* v = rowp + CPS * nat16(pp);
-                        if (MODE == 1) sre += (double)v[0];
-                        else { sre += (double)v[0]; sim += (double)v[1]; }
-                    };
-                    const int e1 = min(e, NX / 2);  // kx = |kx| = s .. e1 - 1
-                    for (int seg = s >> 4; 16 * seg < e1 && s < e1; ++seg) take(min(e1, 16 * (seg + 1)) - 1);
-                    const int ms = max(s, 1), me = min(e, NX / 2 + 1);  // kx = nx - |kx|, |kx| = ms .. me - 1
-                    if (ms < me) {
-                        const int lo = NX - (me - 1), hi1 = NX - ms + 1;
-                        for (int seg = lo >> 4; 16 * seg < hi1; ++seg) take(min(hi1, 16 * (seg + 1)) - 1);
-                    }
-                    if (twin) { sre *= 2.0; sim = 0.0; }  // V + conj V (a power spectrum's two samples are equal)
-                }
+            const int nsw = (bhi - blo + BPI - 1) / BPI;  // sweeps of this unit (uniform)
+            unsigned rg[KB], rn[KB];
 #pragma unroll
-                for (int m = 1; m < NRW; m <<= 1) {  // rows 0 .. NRW - 1 in a fixed tree order
-                    sre += __shfl_down(sre, m, NRW);
-                    if (MODE == 2) sim += __shfl_down(sim, m, NRW);
+            for (int k = 0; k < KB; ++k) rn[k] = range_of(blo + k * BPI + blane);
+            for (int k0 = 0; k0 < nsw; k0 += KB) {
+#pragma unroll
+                for (int k = 0; k < KB; ++k) {
+                    rg[k] = rn[k];
+                    rn[k] = range_of(blo + (k0 + KB + k) * BPI + blane);  // (the next batch's ranges are in flight behind this batch's sums)
                 }
-                if (row == 0 && bn < bhi) {
-                    part[bn * HW] = sre;
-                    if (MODE == 2) part[2 * bn + 1] = sim;
-                }
+                radial_gather_batch<NX, NRW, CPS, BPI, KB>(rowp, row, live, twin, blo, bhi, k0, min(nsw - k0, KB), rg, blane, part, true);
             }
             return;
         }

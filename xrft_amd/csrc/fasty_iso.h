@@ -17,9 +17,6 @@
 
 namespace xrft {
 
-// an unaligned 32-bit read of two adjacent 16-bit table entries (one global_load_dword on gfx950)
-struct __attribute__((packed, aligned(2))) U16Pair { unsigned v; };
-
 #ifndef XRFT_EMULATE
 #define XRFT_ISO_CLOCK() ((long long)__builtin_readcyclecounter())
 #else
@@ -41,6 +38,7 @@ __global__ void __launch_bounds__((YRows<NX, false>::THR), 4) fasty_isorows_kern
     constexpr int RSP = R::RS, RSC = NX + NX / 16, RSI = TWO ? 2 * RSC : RSP;  // floats per staged row
     constexpr int NSEG = NRW * SPR / THR;  // 16-sample segments per thread: 2 (power), 1 (cross)
     constexpr int BPI = THR / NRW;         // bins per sweep of the gather (NRW adjacent lanes share a bin, one row each)
+    constexpr int KB = TWO ? 2 : 3;        // sweeps of the gather in flight together (their staged values live beside the prefetched rows: 4 CPS floats each)
     constexpr int KPRE = 6;                // sweeps whose |kx| ranges are requested in front of the prefetch (nfactor = 4: at most 6)
     static_assert(NSEG * THR == NRW * SPR && NSEG >= 1 && (NRW & (NRW - 1)) == 0 && NRW <= 64 && THR % NRW == 0, "radial-sum geometry");
     static_assert((size_t)NRW * RSI * sizeof(float) <= (size_t)GX * GSTR * sizeof(cf), "the staged rows alias the transforms' LDS and leave the twiddle table alone");
@@ -84,8 +82,14 @@ __global__ void __launch_bounds__((YRows<NX, false>::THR), 4) fasty_isorows_kern
 
     int un = (int)blockIdx.x;
     if (un >= total) return;
+#ifndef XRFT_EMULATE
+    // (tuning, XRFTHIP_YTUNE bits 8-15: the k-th resident of a CU -- blocks 256 k .. 256 k + 255 of the launch -- starts k n microseconds late, so
+    // that the residents of a CU run their transform and radial-sum phases out of step for the whole launch: the workgroups are persistent)
+    for (int i = 0, n = (int)(blockIdx.x >> 8) * ((p.tune >> 8) & 0xff); i < n; ++i) __builtin_amdgcn_s_sleep(32);
+#endif
+    const int tn = p.tune >> 24;  // (tuning bits 24-27: 1 prefetch in front of the radial sums instead of behind them, 2 no prefetch, 4 no partial stores, 8 no gather)
     if (TIM) tlast = XRFT_ISO_CLOCK();
-    load_rows(un, (int)threadIdx.x % GX, (int)threadIdx.x / GX);
+    if (!(tn & 2)) load_rows(un, (int)threadIdx.x % GX, (int)threadIdx.x / GX);
     for (;;) {
         // (every phase re-derives its lane indices from an opaque copy of the thread index: hoisted out of the persistent loop by the
         // optimiser, the addresses of all phases stayed live through the transforms -- 141 spilled registers)
@@ -95,6 +99,34 @@ __global__ void __launch_bounds__((YRows<NX, false>::THR), 4) fasty_isorows_kern
         cf* mine = lds + g * GSTR;
         const int slab = un / upr, unit = un % upr, ky0 = unit * NRW;
         const int kyA = min(ky0 + g, nyh), kyB = TWO ? kyA : min(ky0 + GX + g, nyh);
+        if (tn & 2) load_rows(un, g, u);
+        // ---- what the radial sums of THIS unit read from global memory, requested at the top of the unit: the transforms cover the L2 round
+        // trip, and the next unit's rows queue BEHIND these (loads return in order: a table load behind the prefetch would wait for all of it)
+        int tid2 = threadIdx.x;
+        XRFT_OPAQUE(tid2);
+        const int row = tid2 % NRW, ky = ky0 + row;
+        const bool live = ky <= nyh, twin = ky != 0 && ky != nyh;
+        unsigned masks[NSEG];
+#pragma unroll
+        for (int s = 0; s < NSEG; ++s) {
+            const int sg = tid2 + s * THR, srow = sg / SPR, s16 = sg % SPR;
+            masks[s] = p.tcodes[(size_t)min(ky0 + srow, nyh) * SPR + s16] >> 16;  // bit i: the bin changes between samples i - 1 and i
+        }
+        // only the bins the unit's rows reach, |k| = ky0 dky .. |(ky0 + NRW - 1, nx/2)| (p.twin, from the map itself)
+        const unsigned bw = p.twin[unit];
+        const int blo = (int)(bw & 0xffffu), bhi = (int)(bw >> 16);
+        const unsigned short* __restrict__ frow = p.tfirst + (size_t)min(ky, nyh) * (p.nbins + 1);
+        auto range_of = [&](int bn_) -> unsigned {  // the bin holds |kx| = s .. e - 1 of this row: s | e << 16
+            if (!(live && bn_ < bhi)) return 0u;
+#ifdef XRFT_EMULATE
+            return (unsigned)frow[bn_] | ((unsigned)frow[bn_ + 1] << 16);
+#else
+            return reinterpret_cast<const U16Pair*>(frow + bn_)->v;
+#endif
+        };
+        unsigned rng[KPRE];
+#pragma unroll
+        for (int k = 0; k < KPRE; ++k) rng[k] = range_of(blo + k * BPI + tid2 / NRW);
         if (addback) {  // add back wx[x] * (subtracted line - plane fit) in the spectral domain (see fasty_cols_kernel)
             const char* __restrict__ crb = reinterpret_cast<const char*>(p.corr + (size_t)slab * NX * 2);
             cf cr[16];
@@ -128,33 +160,6 @@ __global__ void __launch_bounds__((YRows<NX, false>::THR), 4) fasty_isorows_kern
         XRFT_OPAQUE(w1l.im);
         fft_p2_pair_w<NX>(a, b, u, mine, w1l, tw2);
         lap(1, false);
-        // ---- what the radial sums of THIS unit read from global memory, requested now: the staging below covers part of the L2 round
-        // trip, and the next unit's rows must queue BEHIND these (loads return in order)
-        int tid2 = threadIdx.x;
-        XRFT_OPAQUE(tid2);
-        const int row = tid2 % NRW, ky = ky0 + row;
-        const bool live = ky <= nyh, twin = ky != 0 && ky != nyh;
-        unsigned masks[NSEG];
-#pragma unroll
-        for (int s = 0; s < NSEG; ++s) {
-            const int sg = tid2 + s * THR, srow = sg / SPR, s16 = sg % SPR;
-            masks[s] = p.tcodes[(size_t)min(ky0 + srow, nyh) * SPR + s16] >> 16;  // bit i: the bin changes between samples i - 1 and i
-        }
-        // only the bins the unit's rows reach, |k| = ky0 dky .. |(ky0 + NRW - 1, nx/2)| (p.twin, from the map itself)
-        const unsigned bw = p.twin[unit];
-        const int blo = (int)(bw & 0xffffu), bhi = (int)(bw >> 16);
-        const unsigned short* __restrict__ frow = p.tfirst + (size_t)min(ky, nyh) * (p.nbins + 1);
-        auto range_of = [&](int bn_) -> unsigned {  // the bin holds |kx| = s .. e - 1 of this row: s | e << 16
-            if (!(live && bn_ < bhi)) return 0u;
-#ifdef XRFT_EMULATE
-            return (unsigned)frow[bn_] | ((unsigned)frow[bn_ + 1] << 16);
-#else
-            return reinterpret_cast<const U16Pair*>(frow + bn_)->v;
-#endif
-        };
-        unsigned rng[KPRE];
-#pragma unroll
-        for (int k = 0; k < KPRE; ++k) rng[k] = range_of(blo + k * BPI + tid2 / NRW);
         // ---- stage |F|^2 * scale (power) / F0 conj(F1) * scale (cross) in natural order with the conflict-free 17/16 padding
         const int g2 = tid2 % GX, u2 = tid2 / GX;
         if (!TWO) {
@@ -179,11 +184,12 @@ __global__ void __launch_bounds__((YRows<NX, false>::THR), 4) fasty_isorows_kern
         lap(2, true);  // (profiling build: the table loads are waited for here, in front of the prefetch)
         const int nun = un + (int)gridDim.x;
         const bool more = nun < total;
-        if (more) {
+        if (more && (tn & 1)) {  // (tuning: the prefetch in front of the radial sums -- its 32 loads per wave block the issue for 4000 cycles there: 21.4 against 19.2 us per 4096^2 slab)
             int tid3 = threadIdx.x;
             XRFT_OPAQUE(tid3);
             load_rows(nun, tid3 % GX, tid3 / GX);
         }
+        lap(3, false);  // (the prefetch is issued)
         int tid4 = threadIdx.x;
         XRFT_OPAQUE(tid4);
         // (1) every 16-sample segment reduced in place: the sum of each run of equal bins lands on the run's last sample (float32 adds
@@ -217,50 +223,42 @@ __global__ void __launch_bounds__((YRows<NX, false>::THR), 4) fasty_isorows_kern
                 }
             }
         }
+        lap(4, false);
         __syncthreads();
-        lap(3, false);
-        // (2) the owner of a (bin, row) walks the bin's two kx ranges of that row, one staged value per segment it touches, and adds
-        // them in float64 in a fixed order; the NRW rows of a bin meet in lane order by shuffles
+        lap(5, false);  // (what the slowest wave of the workgroup kept this one waiting)
+        // (2) the owner of a (bin, row) walks the bin's two kx ranges of that row, one staged value per segment it touches, and adds them in
+        // float64 in a fixed order (+kx side by rising segment, then the -kx side); the NRW rows of a bin meet in lane order.  The phase is a
+        // chain of LDS latencies, not of work: the first two segments of either side of ALL sweeps are read up front, branch-free (a bin
+        // narrower than 16 samples touches no more; the few lanes whose bin hugs |k| = ky walk on in a loop), and the rows of a bin are
+        // adjacent lanes of a quad, added by DPP moves instead of trips through the LDS crossbar.
         double* __restrict__ part = p.iso_part + ((size_t)slab * upr + unit) * p.nbins * HW;
         const float* rowp = stg + row * RSI;
-        auto gather = [&](int bn, unsigned cur) {
-            double sre = 0.0, sim = 0.0;
-            if (live && bn < bhi) {
-                const int s = (int)(cur & 0xffffu), e = (int)(cur >> 16);
-                auto take = [&](int pp) {
-                    const float* v = rowp + CPS * nat16(pp);
-                    sre += (double)v[0];
-                    if (TWO) sim += (double)v[TWO ? 1 : 0];
-                };
-                const int e1 = min(e, NX / 2);  // kx = |kx| = s .. e1 - 1
-                for (int seg = s >> 4; 16 * seg < e1 && s < e1; ++seg) take(min(e1, 16 * (seg + 1)) - 1);
-                const int ms = max(s, 1), me = min(e, NX / 2 + 1);  // kx = nx - |kx|, |kx| = ms .. me - 1
-                if (ms < me) {
-                    const int lo = NX - (me - 1), hi1 = NX - ms + 1;
-                    for (int seg = lo >> 4; 16 * seg < hi1; ++seg) take(min(hi1, 16 * (seg + 1)) - 1);
-                }
-                if (twin) { sre *= 2.0; sim = 0.0; }  // V + conj V (a power spectrum's two samples are equal)
-            }
-#pragma unroll
-            for (int m = 1; m < NRW; m <<= 1) {  // rows 0 .. NRW - 1 in a fixed tree order
-                sre += __shfl_down(sre, m, NRW);
-                if (TWO) sim += __shfl_down(sim, m, NRW);
-            }
-            if (row == 0 && bn < bhi) {
-                part[bn * HW] = sre;
-                if (TWO) part[2 * bn + (TWO ? 1 : 0)] = sim;
-            }
+        const int blane = tid4 / NRW;
+        auto sweeps = [&](const int k0, const int kn, const unsigned* rg) {
+            radial_gather_batch<NX, NRW, CPS, BPI, KB>(rowp, row, live, twin, blo, bhi, k0, kn, rg, blane, part, !(tn & 4));
         };
+        {
+            const int nsw = (tn & 8) ? 0 : (bhi - blo + BPI - 1) / BPI;  // sweeps of this unit (uniform)
 #pragma unroll
-        for (int k = 0; k < KPRE; ++k)
-            if (blo + k * BPI < bhi) gather(blo + k * BPI + tid4 / NRW, rng[k]);
-        for (int b0 = blo + KPRE * BPI; b0 < bhi; b0 += BPI)  // (a finer bin map than nfactor = 4: these ranges queue behind the prefetch)
-            gather(b0 + tid4 / NRW, range_of(b0 + tid4 / NRW));
+            for (int b = 0; b < KPRE / KB; ++b)
+                if (nsw > b * KB) sweeps(b * KB, min(nsw - b * KB, KB), rng + b * KB);
+            for (int k0 = KPRE; k0 < nsw; k0 += KB) {  // (a finer bin map than nfactor = 4: these ranges queue behind the prefetch)
+                unsigned rg[KB];
+#pragma unroll
+                for (int k = 0; k < KB; ++k) rg[k] = range_of(blo + (k0 + k) * BPI + blane);
+                sweeps(k0, min(nsw - k0, KB), rg);
+            }
+        }
         if (TIM) {
             const long long t = XRFT_ISO_CLOCK();
-            tacc[4] += t - tlast;
+            tacc[6] += t - tlast;
             tlast = t;
             tacc[7] += 1;
+        }
+        if (more && !(tn & 3)) {
+            int tid5 = threadIdx.x;
+            XRFT_OPAQUE(tid5);
+            load_rows(nun, tid5 % GX, tid5 / GX);
         }
         if (!more) break;
         un = nun;

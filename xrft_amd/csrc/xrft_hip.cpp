@@ -380,6 +380,7 @@ struct xrfthip_plan {
     long long tune_sgrid = -1;    // XRFTHIP_FASTS_GRID: workgroups of the launch (0 = one per slab, the default; else a resident set walking the slabs)
     // ... and ONE pass for a long real float32 row that fits the registers of a CU: 65536 samples per workgroup (fastr.h)
     bool fastr = false;
+    bool fastr_cin = false;       // ... its complex-row form: rows of 2048 .. 16384 complex64 points, forward or inverse (fastc_kernel)
     DevBuf tw_rm, tw_rs, tw_rn;   // W_M^p (p < 1024), W_1024^n (n < 32), W_N^p (p < 1024)
     long long tune_rstagger = 0;  // XRFTHIP_FASTR_STAGGER: classes << 8 | units of 3.4 us between the start of consecutive classes of workgroups (FastR::stagger)
     long long tune_rgrid = 0;     // XRFTHIP_FASTR_GRID: workgroups of the launch (0 = one per row; default: a resident set of one per CU walking the rows)
@@ -398,7 +399,7 @@ struct xrfthip_plan {
     // tuning knobs from the environment, read once when the plan is created (never in xrfthip_exec)
     long long tune_group = 0, tune_fast_group = 0, tune_group_bytes = 512LL << 20, tune_cols_grid = 256, tune_max_grid = 8192;
     long long tune_y = 0;  // XRFTHIP_YTUNE: cache policies / start stagger of the y-first float32 kernels (FastY::tune), fixed at plan creation
-    long long tune_isorows = 1;  // XRFTHIP_ISOROWS: 1 (default) the persistent radial-sum row kernel (fasty_iso.h) when nothing but the sums leaves pass 2; 0 fasty_rows_kernel;
+    long long tune_isorows = 0;  // XRFTHIP_ISOROWS: 1 the persistent radial-sum row kernel (fasty_iso.h) when nothing but the sums leaves pass 2; 0 (default) fasty_rows_kernel<.., ISO>;
                                  // 2 its profiling build (per-phase shader-clock sums printed after every launch: scripts/prof.py iso-phases -- synchronises, never in the product)
     mutable DevBuf iso_tim;      // ... whose counters live here
     // optional per-pass event timing (bench only; a plan with profiling on is not re-entrant)
@@ -895,6 +896,8 @@ void set_kernel_attrs_once() {
     SETF((fasts_power_kernel<8, 4, 0>)); SETF((fasts_power_kernel<8, 4, 1>)); SETF((fasts_power_kernel<8, 4, 2>));
     SETF((fasts_power_kernel<4, 8, 0>)); SETF((fasts_power_kernel<4, 8, 1>)); SETF((fasts_power_kernel<4, 8, 2>));
     SETF((fastr_kernel<0, false>)); SETF((fastr_kernel<0, true>)); SETF((fastr_kernel<1, false>)); SETF((fastr_kernel<1, true>));
+    SETF((fastc_kernel<32, 16, 0>)); SETF((fastc_kernel<32, 16, 1>)); SETF((fastc_kernel<16, 16, 0>)); SETF((fastc_kernel<16, 16, 1>));
+    SETF((fastc_kernel<16, 8, 0>)); SETF((fastc_kernel<16, 8, 1>)); SETF((fastc_kernel<8, 8, 0>)); SETF((fastc_kernel<8, 8, 1>));
     SETF((fastr2_kernel<32, 16, 0, false>)); SETF((fastr2_kernel<32, 16, 0, true>)); SETF((fastr2_kernel<32, 16, 1, false>)); SETF((fastr2_kernel<32, 16, 1, true>));
     SETF((fastr2_kernel<16, 16, 0, false>)); SETF((fastr2_kernel<16, 16, 0, true>)); SETF((fastr2_kernel<16, 16, 1, false>)); SETF((fastr2_kernel<16, 16, 1, true>));
 #define SETY(NN) SETF((fasty_cols_kernel<NN, false>)); SETF((fasty_cols_kernel<NN, true>)); SETF((fasty_cols_kernel<NN, false, true>)); SETF((fasty_cols_kernel<NN, true, true>)); SETF((fasty_rows_kernel<NN, 1, false>)); SETF((fasty_rows_kernel<NN, 1, true>)); \
@@ -1494,7 +1497,10 @@ static void fasty_launch_rows(const xrfthip_plan* P, const FastY& p, long long g
     const int hw = d.out_mode == XRFTHIP_OUT_CROSS ? 2 : 1;
     const size_t lds = R.lds;  // (the radial-sum tables alias the transforms' LDS)
     // nothing but the radial sums of a radial map leaves the pass: the persistent kernel of fasty_iso.h (as many workgroups as the chip holds)
-    if (iso_on && p.out == nullptr && p.tfirst != nullptr && !P->fast1d && P->tune_isorows != 0 && P->ynx >= 1024 &&
+    // (measured, profiles/r06_tune_iso.txt: with the pipelined gather in BOTH kernels the workgroup-per-unit kernel is level or ahead -- 19.1 against 19.5 us per 4096^2
+    // slab, 4.87 against 5.26 at 2048^2, 1.21 against 1.20 at 1024^2 -- so the persistent kernel is opt-in: XRFTHIP_ISOROWS=1; =2 its profiling build)
+    const bool iso_persistent = P->tune_isorows == 2 || P->tune_isorows == 1;
+    if (iso_on && p.out == nullptr && p.tfirst != nullptr && !P->fast1d && iso_persistent && P->ynx >= 1024 &&
         (d.out_mode == XRFTHIP_OUT_POWER || d.out_mode == XRFTHIP_OUT_CROSS)) {
         const long long total = gc * (P->y_nrow_pad / rpu);
         const bool tim = P->tune_isorows == 2;
@@ -1519,9 +1525,9 @@ static void fasty_launch_rows(const xrfthip_plan* P, const FastY& p, long long g
             double acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
             for (unsigned b = 0; b < nblk; ++b) for (int i = 0; i < 8; ++i) acc[i] += (double)h[(size_t)b * 8 + i];
             const double units = std::max(acc[7], 1.0);
-            std::fprintf(stderr, "[xrfthip isorows nx=%lld mode=%d] %u workgroups, %.0f units; shader-clock cycles per unit: wait+addback %.0f | fft %.0f | tables+stage %.0f | "
-                         "segments %.0f | gather %.0f | total %.0f\n", (long long)P->ynx, (int)d.out_mode, nblk, units, acc[0] / units, acc[1] / units, acc[2] / units, acc[3] / units, acc[4] / units,
-                         (acc[0] + acc[1] + acc[2] + acc[3] + acc[4]) / units);
+            std::fprintf(stderr, "[xrfthip isorows nx=%lld mode=%d] %u workgroups, %.0f units; shader-clock cycles per unit: wait+tables+addback %.0f | fft %.0f | stage+barrier %.0f | "
+                         "prefetch issue %.0f | segments %.0f | barrier %.0f | gather %.0f | total %.0f\n", (long long)P->ynx, (int)d.out_mode, nblk, units, acc[0] / units, acc[1] / units,
+                         acc[2] / units, acc[3] / units, acc[4] / units, acc[5] / units, acc[6] / units, (acc[0] + acc[1] + acc[2] + acc[3] + acc[4] + acc[5] + acc[6]) / units);
         }
     } else {
 #define YR_(NN) do { \
@@ -2838,8 +2844,14 @@ static int run_fastr(const xrfthip_plan* P, const void* in, void* out, hipStream
     p.shift = (d.flags & XRFTHIP_SHIFT_X) ? 1 : 0;
     p.scale = (float)d.scale;
     p.stagger = (int)P->tune_rstagger;
+    if (P->fastr_cin) {  // (the flags as fastm_xonly_kernel reads them: the input rotated and conjugated for an inverse, the phase table on the input or on the output)
+        p.inv = (d.flags & XRFTHIP_INVERSE) ? 1 : 0;
+        p.ishift = ((d.flags & XRFTHIP_INVERSE) && (d.flags & XRFTHIP_ISHIFT_X)) ? 1 : 0;
+        p.ph_in = ((d.flags & XRFTHIP_PHASE_IN) && P->fph_on) ? 1 : 0;
+        p.ph_on = (d.out_mode == XRFTHIP_OUT_COMPLEX && P->fph_on && !(d.flags & XRFTHIP_PHASE_IN)) ? 1 : 0;
+    }
     const long long g = P->tune_rgrid > 0 ? std::min<long long>(P->tune_rgrid, d.batch) : d.batch;
-    const dim3 grid((unsigned)std::min<long long>(g, 0x7fffffffLL)), blk((unsigned)(d.nx / 64));
+    const dim3 grid((unsigned)std::min<long long>(g, 0x7fffffffLL)), blk((unsigned)(P->fastr_cin ? d.nx / 32 : d.nx / 64));
     const bool pw = d.out_mode == XRFTHIP_OUT_POWER;
     // profiling (bench.py's roofline.kernel): the start / stop timestamps ride on the kernel's own dispatch packet (hipExtLaunchKernelGGL)
     // instead of two event records around it -- barrier packets either side of a 0.18-ms kernel cost the C2 bench line 50 us per step
@@ -2858,7 +2870,14 @@ static int run_fastr(const xrfthip_plan* P, const void* in, void* out, hipStream
         else if (d.nx == 16384) RK_((fastr2_kernel<16, 16, MM, HH>), (R2Geom<16, 16>::LDS)); \
         else if (d.nx == 8192) RK_((fastr2_kernel<16, 8, MM, HH>), (R2Geom<16, 8>::LDS)); \
         else RK_((fastr2_kernel<8, 8, MM, HH>), (R2Geom<8, 8>::LDS)); } while (0)
-    if (pw) { if (p.half) RL_(1, true); else RL_(1, false); } else { if (p.half) RL_(0, true); else RL_(0, false); }
+#define RC_(MM) do { \
+        if (d.nx == 16384) RK_((fastc_kernel<32, 16, MM>), (R2Geom<32, 16>::LDS)); \
+        else if (d.nx == 8192) RK_((fastc_kernel<16, 16, MM>), (R2Geom<16, 16>::LDS)); \
+        else if (d.nx == 4096) RK_((fastc_kernel<16, 8, MM>), (R2Geom<16, 8>::LDS)); \
+        else RK_((fastc_kernel<8, 8, MM>), (R2Geom<8, 8>::LDS)); } while (0)
+    if (P->fastr_cin) { if (pw) RC_(1); else RC_(0); }
+    else if (pw) { if (p.half) RL_(1, true); else RL_(1, false); } else { if (p.half) RL_(0, true); else RL_(0, false); }
+#undef RC_
 #undef RL_
 #undef RK_
     if (ea) {
@@ -3291,7 +3310,7 @@ int xrfthip_plan_create(xrfthip_plan** plan, const xrfthip_desc* desc) {
     P->tune_group = env_ll("XRFTHIP_GROUP", 0);
     P->tune_fast_group = env_ll("XRFTHIP_FAST_GROUP", 0);
     P->tune_y = env_ll("XRFTHIP_YTUNE", kYTuneDefault);
-    P->tune_isorows = env_ll("XRFTHIP_ISOROWS", 1);
+    P->tune_isorows = env_ll("XRFTHIP_ISOROWS", 0);
     P->tune_group_bytes = env_ll("XRFTHIP_GROUP_BYTES", 512LL << 20);
     P->tune_cols_grid = env_ll("XRFTHIP_FAST_COLS_GRID", kCUs);
     P->tune_max_grid = env_ll("XRFTHIP_MAX_GRID", 8 * kCUs * 4);
@@ -3356,11 +3375,25 @@ int xrfthip_plan_create(xrfthip_plan** plan, const xrfthip_desc* desc) {
         const uint32_t okr = XRFTHIP_SHIFT_X | XRFTHIP_HALF_X | (d.out_mode == XRFTHIP_OUT_POWER ? XRFTHIP_REALDIM_X2 : 0u) | (d.out_mode == XRFTHIP_OUT_COMPLEX ? XRFTHIP_ISHIFT_X : 0u);
         P->fastr = d.ndim == 1 && (d.nx == 65536 || d.nx == 32768 || d.nx == 16384 || d.nx == 8192 || d.nx == 4096) && d.dtype == XRFTHIP_F32 && (d.out_mode == XRFTHIP_OUT_COMPLEX || d.out_mode == XRFTHIP_OUT_POWER) &&
                    !(d.flags & ~okr) && !((d.flags & XRFTHIP_HALF_X) && (d.flags & XRFTHIP_SHIFT_X)) && !env_ll("XRFTHIP_NO_FAST", 0) && env_ll("XRFTHIP_FASTR", 1) != 0;
+        // ... and complex rows of 2048 .. 16384 points (xrft.ifft / fft of complex data along the contiguous axis): the same transform without the packing and the split
+        const uint32_t okc = XRFTHIP_SHIFT_X | (d.out_mode == XRFTHIP_OUT_COMPLEX ? (XRFTHIP_ISHIFT_X | XRFTHIP_INVERSE | XRFTHIP_PHASE_IN) : 0u);
+        P->fastr_cin = !P->fastr && d.ndim == 1 && d.dtype == XRFTHIP_C64 && (d.nx == 16384 || d.nx == 8192 || d.nx == 4096 || d.nx == 2048) && !d.detrend &&
+                       (d.out_mode == XRFTHIP_OUT_COMPLEX || d.out_mode == XRFTHIP_OUT_POWER) && !(d.flags & ~okc) && !env_ll("XRFTHIP_NO_FAST", 0) && env_ll("XRFTHIP_FASTC", 1) != 0;
+        if (P->fastr_cin) {
+            P->fastr = true;
+            P->tune_rgrid = env_ll("XRFTHIP_FASTR_GRID", 0);
+            P->tune_rstagger = 0;
+            const long long thr = d.nx / 32;  // threads per row: 32 complex values each
+            int rcr = build_twiddle<float>(P->tw_rm, d.nx, thr);
+            if (!rcr) rcr = build_twiddle<float>(P->tw_rs, thr, 32);
+            if (rcr) { delete P; return rcr; }
+        } else
         if (P->fastr) {
             // 65536 samples: one resident workgroup per CU walks the rows (measured: 359 vs 344 GFFT/s for a workgroup per row, profiles/r04_fastr.txt);
             // the shorter rows (several workgroups per CU): a workgroup per row
             P->tune_rgrid = env_ll("XRFTHIP_FASTR_GRID", d.nx == 65536 ? kCUs : 0);
-            P->tune_rstagger = d.nx == 65536 ? env_ll("XRFTHIP_FASTR_STAGGER", 0) : 0;
+            // two classes of workgroups 10 us apart: dft (1024, 65536) 388 -> 441 GFFT/s, power_spectrum 517 -> 586 (profiles/r06_c2_stagger.txt)
+            P->tune_rstagger = d.nx == 65536 ? env_ll("XRFTHIP_FASTR_STAGGER", (2 << 8) | 3) : 0;
             const long long thr = d.nx / 64;  // threads per row: 32 packed complex values each
             int rcr = build_twiddle<float>(P->tw_rm, d.nx / 2, thr);
             if (!rcr) rcr = build_twiddle<float>(P->tw_rs, thr, 32);
@@ -3789,6 +3822,11 @@ int xrfthip_plan_describe(const xrfthip_plan* plan, char* buf, size_t buflen) {
                    "transform in registers (32 complex per thread, r32x%lld / r32x%lld, three LDS exchanges in halves), exact plane detrend in the workgroup, |F|^2 "
                    "rows staged in LDS and written whole with the fftshift and the Hermitian mirror, lds=%zuB; 8 algorithmic bytes per sample through memory\n",
                 G.thr, (long long)plan->d.ny, (long long)plan->d.nx, G.per_cu, (long long)plan->d.ny / 32, (long long)plan->d.nx / 32, G.lds);
+    } else if (plan->fastr && plan->fastr_cin) {
+        appendf(s, "  [fastr complex rows] one pass, one %lld-thread workgroup per %lld-point complex row: the %s transform in registers (32 per thread, two LDS "
+                   "exchanges), natural order through the LDS, lds=%zuB; 16 algorithmic bytes per point through memory\n",
+                (long long)plan->d.nx / 32, (long long)plan->d.nx, (plan->d.flags & XRFTHIP_INVERSE) ? "inverse" : "forward",
+                plan->d.nx == 16384 ? R2Geom<32, 16>::LDS : plan->d.nx == 8192 ? R2Geom<16, 16>::LDS : plan->d.nx == 4096 ? R2Geom<16, 8>::LDS : R2Geom<8, 8>::LDS);
     } else if (plan->fastr) {
         const long long nxr = plan->d.nx;
         appendf(s, "  [fastr] one pass, one %lld-thread workgroup per %lld-sample row (grid %lld): the packed %lld-point complex transform in registers (32 per thread, "
