@@ -62,7 +62,7 @@ def line(label, wall_us, kern, pts_per_unit):
     print(f"  {label:58s} wall {wall_us:7.2f} us = {pts_per_unit / wall_us / 1e3:6.1f} GFFT/s | {ks}", flush=True)
 
 
-def make(shape, dtype="float32", two=False, trend=True):
+def make(shape, dtype="float32", two=False, trend=True, freq=False):
     import numpy as np
     import torch
 
@@ -70,10 +70,13 @@ def make(shape, dtype="float32", two=False, trend=True):
 
     dt = getattr(torch, dtype)
     x = torch.randn(shape, dtype=dt, device="cuda")
-    if trend and len(shape) == 3:
+    if trend and len(shape) == 3 and not dt.is_complex:
         x += (0.01 * torch.arange(shape[1], device="cuda", dtype=dt))[None, :, None]
     dims = ("t", "y", "x")[-len(shape):]
     c = {d: np.arange(float(n)) for d, n in zip(dims, shape) if d != "t"}
+    if freq:  # the input of an inverse transform: fftshifted frequency coordinates, centred on zero
+        dims = tuple(d if d == "t" else "freq_" + d for d in dims)
+        c = {"freq_" + d: np.fft.fftshift(np.fft.fftfreq(n, 1.0)) for d, n in zip(("t", "y", "x")[-len(shape):], shape) if d != "t"}
     d1 = xrft.DataArray(x, dims, c)
     d2 = xrft.DataArray(torch.randn(shape, dtype=dt, device="cuda"), dims, c) if two else None
     return d1, d2
@@ -103,8 +106,11 @@ def cmd_call(a):
     dtype = parts[-1] if not parts[-1].isdigit() else "float32"
     shape = tuple(int(p) for p in parts if p.isdigit())
     two = a.fn in ("cross_spectrum", "isotropic_cross_spectrum", "cross_phase")
-    d1, d2 = make(shape, dtype, two)
+    inverse = a.fn in ("ifft", "idft")
+    d1, d2 = make(shape, dtype, two, trend=not inverse, freq=inverse)
     kw = parse_kw(a.kw)
+    if inverse and "dim" in kw:
+        kw["dim"] = ["freq_" + d for d in kw["dim"]] if isinstance(kw["dim"], list) else "freq_" + kw["dim"]
     f = getattr(xrft, a.fn)
     fn = (lambda: f(d1, d2, **kw)) if two else (lambda: f(d1, **kw))
     units = shape[0]

@@ -973,8 +973,9 @@ def run_inverse_one_pass_cases(shape=(2, 360, 250), dtype="float64"):
             xa.api._plan_cache.clear()
             worst = max(worst, check_values(xa.ifft(F, dim=["freq_y", "freq_x"], **kw), o.ifft(Fo, dim=["freq_y", "freq_x"], **kw), tol))
             tags = [p.describe() for p in xa.api._plan_cache.values()]
-            assert any("[fastg y-only]" in t or "[fastm y-only]" in t for t in tags) and any("[fastg rows]" in t or "[fastm x-only]" in t for t in tags) or any("[fastg] one pass" in t for t in tags), tags
-            for d, tag in (("y", ("[fastg y-only]", "[fastm y-only]")), ("x", ("[fastg rows]", "[fastm x-only]"))):  # (rows of a table length: the table kernel takes the inverse, too -- round 5)
+            assert (any("[fastg y-only]" in t or "[fastm y-only]" in t for t in tags) and any("[fastg rows]" in t or "[fastm x-only]" in t or "[fasty complex rows]" in t for t in tags)
+                    or any("[fastg] one pass" in t for t in tags) or any("[fasty complex]" in t for t in tags)), tags  # (complex64 power-of-two slabs: csrc/fasty_c2c.h)
+            for d, tag in (("y", ("[fastg y-only]", "[fastm y-only]")), ("x", ("[fastg rows]", "[fastm x-only]", "[fasty complex rows]"))):  # (rows of a table length: the table kernel takes the inverse, too -- round 5)
                 F1, F1o = xa.fft(da, dim=[d], **kw), o.fft(od, dim=[d], **kw)
                 xa.api._plan_cache.clear()
                 worst = max(worst, check_values(xa.ifft(F1, dim=["freq_" + d], **kw), o.ifft(F1o, dim=["freq_" + d], **kw), tol))
@@ -986,6 +987,70 @@ def run_inverse_one_pass_cases(shape=(2, 360, 250), dtype="float64"):
                 assert any("[fastg rows]" in p.describe() for p in xa.api._plan_cache.values()), kw
                 Fr2, Fr2o = xa.fft(da, dim=["y"], real_dim="x", **kw), o.fft(od, dim=["y"], real_dim="x", **kw)
                 worst = max(worst, check_values(xa.ifft(Fr2, dim=["freq_y"], real_dim="freq_x", **kw), o.ifft(Fr2o, dim=["freq_y"], real_dim="freq_x", **kw), tol))
+    return worst
+
+
+def run_complex_rows_cases(n, nt=3, seed=91):
+    """Complex64 rows of n = 2048 .. 16384 points along the contiguous axis in ONE pass (csrc/fastr.h, fastc_kernel): xrft.fft of complex data, xrft.ifft of its
+    spectrum (true phase on / off, shift on / off, explicit lag), power spectrum with a window -- against the oracle (xrft.py:439-447, :586-621)."""
+    rng = np.random.default_rng(seed + n)
+    tol = TOL["complex64"]
+    z = (rng.standard_normal((nt, n)) + 1j * rng.standard_normal((nt, n))).astype(np.complex64)
+    c = {"t": np.arange(nt), "x": np.arange(n) * 0.5 + 3.0}
+    da, od = pair(z, ("t", "x"), c)
+    worst = 0.0
+
+    def tag():
+        return next(reversed(xa.api._plan_cache.values())).describe()
+
+    for kw in (dict(), dict(true_phase=False, true_amplitude=False), dict(shift=False), dict(true_phase=False, shift=False)):
+        F, Fo = xa.fft(da, dim="x", **kw), o.fft(od, dim="x", **kw)
+        assert "complex rows]" in tag(), tag()
+        worst = max(worst, check(F, Fo, tol))
+        ikw = dict(kw)
+        if kw.get("true_phase", True):
+            ikw["lag"] = float(c["x"][n // 2])  # (the lag that makes ifft(fft(z)) the round trip: xrft.py:215-234)
+        G, Go = xa.ifft(F, dim="freq_x", **ikw), o.ifft(Fo, dim="freq_x", **ikw)
+        assert "complex rows]" in tag() and "inverse" in tag(), tag()
+        worst = max(worst, check_values(G, Go, tol))
+        if not kw:  # (the round trip of the default call: true phase, shifted spectrum)
+            assert np.abs(np.asarray(G.values) - z).max() < 100 * tol * np.abs(z).max()
+    P, Po = xa.power_spectrum(da, dim="x", window="hann"), o.power_spectrum(od, dim="x", window="hann")
+    assert "complex rows]" in tag(), tag()
+    worst = max(worst, check(P, Po, tol))
+    return worst
+
+
+def run_complex_two_pass_cases(ny, nx, nt=2, variant=0, seed=97):
+    """Complex64 slabs, both lengths a power of two 256 .. 4096, through the two-pass pipeline of csrc/fasty_c2c.h: xrft.fft of complex data over (y, x) with and
+    without a window, xrft.ifft of its spectrum (the fftshifted input rotated on load, the lag's phase on the input, conjugate in / out), power spectrum --
+    against the oracle (xrft.py:439-447, :586-621), and as a round trip."""
+    rng = np.random.default_rng(seed + ny + 3 * nx)
+    tol = TOL["complex64"]
+    kw = (dict(), dict(true_phase=False, true_amplitude=False), dict(shift=False), dict(true_phase=False, shift=False))[variant % 4]
+    z = (rng.standard_normal((nt, ny, nx)) + 1j * rng.standard_normal((nt, ny, nx))).astype(np.complex64)
+    c = {"t": np.arange(nt), "y": np.arange(ny) * 0.25 - 7.0, "x": np.arange(nx) * 0.5 + 3.0}
+    da, od = pair(z, ("t", "y", "x"), c)
+
+    def tag():
+        return next(reversed(xa.api._plan_cache.values())).describe()
+
+    F, Fo = xa.fft(da, dim=["y", "x"], **kw), o.fft(od, dim=["y", "x"], **kw)
+    assert "[fasty complex]" in tag(), tag()
+    worst = check(F, Fo, tol)
+    Fw, Fwo = xa.fft(da, dim=["y", "x"], window="hann", **kw), o.fft(od, dim=["y", "x"], window="hann", **kw)
+    worst = max(worst, check(Fw, Fwo, tol))
+    ikw = dict(kw)
+    if kw.get("true_phase", True):
+        ikw["lag"] = [float(c["y"][ny // 2]), float(c["x"][nx // 2])]
+    G, Go = xa.ifft(F, dim=["freq_y", "freq_x"], **ikw), o.ifft(Fo, dim=["freq_y", "freq_x"], **ikw)
+    assert "[fasty complex]" in tag() and "inverse" in tag(), tag()
+    worst = max(worst, check_values(G, Go, tol))
+    if not kw:  # (the round trip of the default call: true phase, shifted spectrum)
+        assert np.abs(np.asarray(G.values) - z).max() < 100 * tol * np.abs(z).max()
+    P, Po = xa.power_spectrum(da, dim=["y", "x"]), o.power_spectrum(od, dim=["y", "x"])
+    assert "[fasty complex]" in tag(), tag()
+    worst = max(worst, check(P, Po, tol))
     return worst
 
 

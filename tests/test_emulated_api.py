@@ -743,3 +743,16 @@ def test_two_pass_pipeline_with_the_lengths_as_data(shape, dtype, monkeypatch):
 def test_two_transform_axes_that_are_not_adjacent(dtype):
     """xrfthip_desc.mid: dim = ["t", "x"] of (t, y, x) where the axes lie."""
     cases.run_mid_layout_cases(dtype)
+
+
+@pytest.mark.parametrize("n", [256, 1024, 2048, 4096, 8192, 16384])
+def test_complex_rows_in_one_pass(n):
+    """csrc/fasty_c2c.h (rows of 256 .. 4096 points: the row pass on the input's own rows) and csrc/fastr.h fastc_kernel (8192, 16384) on the emulator: fft / ifft / power
+    spectrum of complex64 rows against the oracle."""
+    cases.run_complex_rows_cases(n, nt=2)
+
+
+@pytest.mark.parametrize("ny,nx,variant", [(256, 256, 0), (512, 256, 1), (256, 1024, 2), (1024, 512, 3), (2048, 256, 0), (256, 4096, 1), (4096, 256, 2)])
+def test_complex_slabs_through_the_two_pass_pipeline(ny, nx, variant):
+    """csrc/fasty_c2c.h on the emulator: fft (with and without a window) / ifft / power spectrum of complex64 slabs, every W2 geometry (ny = 256 .. 4096)."""
+    cases.run_complex_two_pass_cases(ny, nx, nt=2 if ny * nx <= (1 << 19) else 1, variant=variant)

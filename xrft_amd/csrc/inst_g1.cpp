@@ -2,6 +2,7 @@
 #include "gpu_rt.h"
 #include "fasty.h"
 #include "fasty_iso.h"
+#include "fasty_c2c.h"
 #include "fastm.h"
 namespace xrft {
 #define XRFT_KW template __global__

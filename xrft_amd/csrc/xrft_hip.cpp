@@ -31,6 +31,7 @@
 #include "fastp2.h"
 #include "fasty.h"
 #include "fasty_iso.h"
+#include "fasty_c2c.h"
 #include "selftest.h"
 #include "fastm.h"
 #include "fastn.h"
@@ -330,6 +331,7 @@ struct xrfthip_plan {
     // ... and, as the two steps of a four-step transform, one long real sequence per slab: N = yny * ynx samples viewed as
     // a [yny][ynx] slab (fasty.h, FS).  yny / ynx are d.ny / d.nx for the 2-D plans.
     bool fast1d = false;
+    bool fastyc = false;  // ... the same two passes for COMPLEX float32 slabs (fasty_c2c.h): xrft.ifft over two axes, xrft.fft of complex data
     // ... and its mixed-radix float64 form (fastm.h): lengths 360 / 720 / 1440
     bool fastm = false;
     // ... and the same pipeline with the LENGTHS AS DATA (fastn.h): either pass (or both) of a `fastm` plan may be the run-time-radix kernel -- every
@@ -380,6 +382,7 @@ struct xrfthip_plan {
     long long tune_sgrid = -1;    // XRFTHIP_FASTS_GRID: workgroups of the launch (0 = one per slab, the default; else a resident set walking the slabs)
     // ... and ONE pass for a long real float32 row that fits the registers of a CU: 65536 samples per workgroup (fastr.h)
     bool fastr = false;
+    bool fastr_rows = false;      // ... complex rows of 256 .. 4096 points: pass 2 of the complex two-pass pipeline on the rows of the input itself (fastyc_rows_kernel, nrows > 0)
     bool fastr_cin = false;       // ... its complex-row form: rows of 2048 .. 16384 complex64 points, forward or inverse (fastc_kernel)
     DevBuf tw_rm, tw_rs, tw_rn;   // W_M^p (p < 1024), W_1024^n (n < 32), W_N^p (p < 1024)
     long long tune_rstagger = 0;  // XRFTHIP_FASTR_STAGGER: classes << 8 | units of 3.4 us between the start of consecutive classes of workgroups (FastR::stagger)
@@ -904,6 +907,9 @@ void set_kernel_attrs_once() {
                  SETF((fasty_rows_kernel<NN, 0, false>)); SETF((fasty_rows_kernel<NN, 2, false>)); SETF((fasty_rows_kernel<NN, 2, true>)); SETF((fasty_rows_kernel<NN, 3, false>))
     SETY(4096); SETY(2048); SETY(1024); SETY(512); SETY(256);
 #undef SETY
+#define SETC(NN) SETF((fastyc_cols_kernel<NN>)); SETF((fastyc_rows_kernel<NN>))
+    SETC(4096); SETC(2048); SETC(1024); SETC(512); SETC(256);
+#undef SETC
 #define SETI(NN) SETF((fasty_isorows_kernel<NN, 1, false>)); SETF((fasty_isorows_kernel<NN, 2, false>)); SETF((fasty_isorows_kernel<NN, 1, true>)); SETF((fasty_isorows_kernel<NN, 2, true>))
     SETI(4096); SETI(2048); SETI(1024);
 #undef SETI
@@ -1020,6 +1026,14 @@ static int run_radial_sums(int32_t dtype, const void* spec, const int32_t* d_bin
 static void layout_workspace(xrfthip_plan* P) {
     const xrfthip_desc& d = P->d;
     if (P->fastr || P->fasts || P->fastg || P->fastgy) { P->G = (int)std::max<long long>(1, std::min<long long>(d.batch, 1 << 30)); P->ws_bytes = 0; return; }  // one pass, registers + LDS: no intermediate
+    if (P->fastyc) {  // the tiled intermediate of one group of slabs
+        long long G = d.slabs_per_group > 0 ? d.slabs_per_group : (P->tune_fast_group > 0 ? P->tune_fast_group : std::max<long long>(1, (32LL * 4096 * 4096) / (d.ny * d.nx)));
+        G = std::max<long long>(1, std::min<long long>(G, std::max<long long>(d.batch, 1)));
+        P->G = (int)G;
+        P->off_w = 0;
+        P->ws_bytes = (((size_t)G * (size_t)d.ny * (size_t)d.nx * sizeof(cf)) + 255) & ~(size_t)255;
+        return;
+    }
     const bool fast = fast_on(P);
     long long G = d.slabs_per_group > 0 ? d.slabs_per_group : P->tune_group;
     size_t slab_w = (size_t)d.ny * std::max(P->width, P->w_cols) * P->csize;
@@ -1187,6 +1201,10 @@ template <int NY> static YGeomRt ycols_geom_t() {
 template <int NX, bool FS = false> static YGeomRt yrows_geom_t() {
     typedef YRows<NX, FS> R;
     return {R::THR, R::GX, 0, R::RPU, 0, (size_t)(R::GX * YLds<NX, R::GX>::GSTR + 16 * P2<NX>::R3) * sizeof(cf)};
+}
+static int ycols_gstr(long long ny) {  // complex elements of LDS per packed column pair of pass 1 (YLds<NY, GY>::GSTR)
+    switch (ny) { case 4096: return YLds<4096, YCols<4096>::GY>::GSTR; case 2048: return YLds<2048, YCols<2048>::GY>::GSTR; case 1024: return YLds<1024, YCols<1024>::GY>::GSTR;
+                  case 512: return YLds<512, YCols<512>::GY>::GSTR; default: return YLds<256, YCols<256>::GY>::GSTR; }
 }
 static YGeomRt ycols_geom(long long ny) {
     switch (ny) { case 4096: return ycols_geom_t<4096>(); case 2048: return ycols_geom_t<2048>(); case 1024: return ycols_geom_t<1024>();
@@ -2829,9 +2847,87 @@ static int run_fasts(const xrfthip_plan* P, const void* in, void* out, double* i
     return XRFTHIP_OK;
 }
 
+// the two-pass pipeline on complex float32 slabs (fasty_c2c.h): columns -> rows, group by group
+static int run_fastyc(const xrfthip_plan* P, const void* in, void* out, char* ws, hipStream_t st) {
+    const xrfthip_desc& d = P->d;
+    const YGeomRt C = ycols_geom(d.ny), R = yrows_geom(d.nx);
+    const int cw = 2 * C.gxy, rk = std::max(1, 16 / cw);
+    const size_t lds_c = (size_t)(C.gxy * (ycols_gstr(d.ny)) + 16 * (d.ny / 256)) * sizeof(cf);
+    const size_t out_esz = d.out_mode == XRFTHIP_OUT_POWER ? sizeof(float) : sizeof(cf);
+    for (long long g0 = 0; g0 < d.batch; g0 += P->G) {
+        const long long gc = std::min<long long>(P->G, d.batch - g0);
+        FastYC p{};
+        p.in = reinterpret_cast<const cf*>(in) + (size_t)g0 * d.ny * d.nx;
+        p.w2 = reinterpret_cast<cf*>(ws + P->off_w);
+        p.out = (char*)out + (size_t)g0 * d.ny * d.nx * out_esz;
+        p.tw_x = reinterpret_cast<const cf*>(P->tw_fx.p);
+        p.tw_y = reinterpret_cast<const cf*>(P->tw_fy.p);
+        p.win_y = reinterpret_cast<const float*>(P->win[0].p ? P->win[0].p : P->ones4096.p);
+        p.win_x = reinterpret_cast<const float*>(P->win[1].p ? P->win[1].p : P->ones4096.p);
+        p.win_on = (P->win[0].p || P->win[1].p) ? 1 : 0;
+        p.ph_y = reinterpret_cast<const cf*>(P->fph[0].p);
+        p.ph_x = reinterpret_cast<const cf*>(P->fph[1].p);
+        const bool phase = d.out_mode == XRFTHIP_OUT_COMPLEX && P->fph_on;
+        p.ph_in = (phase && (d.flags & XRFTHIP_PHASE_IN)) ? 1 : 0;
+        p.ph_on = (phase && !(d.flags & XRFTHIP_PHASE_IN)) ? 1 : 0;
+        p.inv = (d.flags & XRFTHIP_INVERSE) ? 1 : 0;
+        p.ishift_y = ((d.flags & XRFTHIP_INVERSE) && (d.flags & XRFTHIP_ISHIFT_Y)) ? 1 : 0;  // (a forward plan's ifftshifted input is the sign (-1)^k in the phase tables)
+        p.ishift_x = ((d.flags & XRFTHIP_INVERSE) && (d.flags & XRFTHIP_ISHIFT_X)) ? 1 : 0;
+        p.shift_y = (d.flags & XRFTHIP_SHIFT_Y) ? (int)(d.ny / 2) : 0;
+        p.shift_x = (d.flags & XRFTHIP_SHIFT_X) ? (int)(d.nx / 2) : 0;
+        p.ny = (int)d.ny; p.nx = (int)d.nx; p.nslab = (int)gc;
+        p.l_cw = ilog2i(cw); p.l_rk = ilog2i(rk);
+        p.power = d.out_mode == XRFTHIP_OUT_POWER ? 1 : 0;
+        p.scale = (float)d.scale;
+        xrfthip_plan::ProfRec* rec = prof_begin(P, "fastyc_cols", st);
+        const dim3 gridc((unsigned)(gc * (d.nx / cw))), blkc((unsigned)C.thr);
+#define YCC_(NN) do { auto k = &fastyc_cols_kernel<NN>; XRFT_LAUNCH(k, gridc, blkc, lds_c, st, p); } while (0)
+        if (d.ny == 4096) YCC_(4096); else if (d.ny == 2048) YCC_(2048); else if (d.ny == 1024) YCC_(1024); else if (d.ny == 512) YCC_(512); else YCC_(256);
+#undef YCC_
+        prof_end(rec, st);
+        rec = prof_begin(P, "fastyc_rows", st);
+        const dim3 gridr((unsigned)(gc * (d.ny / R.rk))), blkr((unsigned)R.thr);
+#define YCR_(NN) do { auto k = &fastyc_rows_kernel<NN>; XRFT_LAUNCH(k, gridr, blkr, R.lds, st, p); } while (0)
+        if (d.nx == 4096) YCR_(4096); else if (d.nx == 2048) YCR_(2048); else if (d.nx == 1024) YCR_(1024); else if (d.nx == 512) YCR_(512); else YCR_(256);
+#undef YCR_
+        prof_end(rec, st);
+        HIP_TRY(hipGetLastError());
+    }
+    return XRFTHIP_OK;
+}
+
 // one pass over 65536-sample float32 rows (fastr.h): a 1024-thread workgroup per row, or a resident set walking the rows
 static int run_fastr(const xrfthip_plan* P, const void* in, void* out, hipStream_t st) {
     const xrfthip_desc& d = P->d;
+    if (P->fastr_rows) {  // complex rows of 256 .. 4096 points: the row pass of the complex two-pass pipeline on the input's own rows
+        const YGeomRt R = yrows_geom(d.nx);
+        FastYC p{};
+        p.w2 = reinterpret_cast<cf*>(const_cast<void*>(in));
+        p.out = out;
+        p.tw_x = reinterpret_cast<const cf*>(P->tw_fx.p);
+        p.win_y = p.win_x = reinterpret_cast<const float*>(P->win[1].p ? P->win[1].p : P->ones4096.p);
+        p.win_on = P->win[1].p ? 1 : 0;
+        p.ph_y = p.ph_x = reinterpret_cast<const cf*>(P->fph[1].p);
+        const bool phase = d.out_mode == XRFTHIP_OUT_COMPLEX && P->fph_on;
+        p.ph_in = (phase && (d.flags & XRFTHIP_PHASE_IN)) ? 1 : 0;
+        p.ph_on = (phase && !(d.flags & XRFTHIP_PHASE_IN)) ? 1 : 0;
+        p.inv = (d.flags & XRFTHIP_INVERSE) ? 1 : 0;
+        p.ishift_x = ((d.flags & XRFTHIP_INVERSE) && (d.flags & XRFTHIP_ISHIFT_X)) ? 1 : 0;
+        p.shift_x = (d.flags & XRFTHIP_SHIFT_X) ? (int)(d.nx / 2) : 0;
+        p.ny = R.rk; p.nx = (int)d.nx; p.nslab = 1;  // (ny: one unit of rows -- the kernel addresses by row number)
+        p.l_cw = ilog2i((int)d.nx); p.l_rk = 0;
+        p.power = d.out_mode == XRFTHIP_OUT_POWER ? 1 : 0;
+        p.scale = (float)d.scale;
+        p.nrows = d.batch;
+        xrfthip_plan::ProfRec* rec = prof_begin(P, "fastyc_rows", st);
+        const dim3 gridr((unsigned)((d.batch + R.rk - 1) / R.rk)), blkr((unsigned)R.thr);
+#define YCR_(NN) do { auto k = &fastyc_rows_kernel<NN>; XRFT_LAUNCH(k, gridr, blkr, R.lds, st, p); } while (0)
+        if (d.nx == 4096) YCR_(4096); else if (d.nx == 2048) YCR_(2048); else if (d.nx == 1024) YCR_(1024); else if (d.nx == 512) YCR_(512); else YCR_(256);
+#undef YCR_
+        prof_end(rec, st);
+        HIP_TRY(hipGetLastError());
+        return XRFTHIP_OK;
+    }
     FastR p{};
     p.in = (const float*)in; p.out = out;
     p.tw_m = (const cf*)P->tw_rm.p; p.tw_s = (const cf*)P->tw_rs.p; p.tw_n = (const cf*)P->tw_rn.p;
@@ -2901,7 +2997,7 @@ static int finalize_plan(xrfthip_plan* P) {
         if (P->d.out_mode != XRFTHIP_OUT_POWER) { const int rc = fast_phase_tables(P); if (rc) return rc; }
     } else if (P->fasts) {
         if (P->d.out_mode != XRFTHIP_OUT_POWER) { const int rc = fast_phase_tables(P); if (rc) return rc; }
-    } else if (P->fastr) {
+    } else if (P->fastr || P->fastyc) {
         if (P->d.out_mode != XRFTHIP_OUT_POWER) { const int rc = fast_phase_tables(P); if (rc) return rc; }
     } else if (P->fastmx) {
         if (P->d.out_mode != XRFTHIP_OUT_POWER) { const int rc = fast_phase_tables(P); if (rc) return rc; }
@@ -3340,6 +3436,19 @@ int xrfthip_plan_create(xrfthip_plan** plan, const xrfthip_desc* desc) {
                       !(d.flags & ~allowed) && !((d.flags & halff) && (d.flags & XRFTHIP_ISO)) && !((d.flags & XRFTHIP_HALF_X) && (d.flags & XRFTHIP_SHIFT_X)) &&
                       !env_ll("XRFTHIP_NO_FAST", 0);
     }
+    {   // complex float32 slabs of these lengths: the two-pass pipeline's complex form (fasty_c2c.h)
+        const uint32_t okc = XRFTHIP_SHIFT_Y | XRFTHIP_SHIFT_X | (d.out_mode == XRFTHIP_OUT_COMPLEX ? (XRFTHIP_ISHIFT_Y | XRFTHIP_ISHIFT_X | XRFTHIP_INVERSE | XRFTHIP_PHASE_IN) : 0u);
+        P->fastyc = d.ndim == 2 && d.dtype == XRFTHIP_C64 && fast_len(d.ny) && fast_len(d.nx) && !d.detrend && (d.out_mode == XRFTHIP_OUT_COMPLEX || d.out_mode == XRFTHIP_OUT_POWER) &&
+                    !(d.flags & ~okc) && !env_ll("XRFTHIP_NO_FAST", 0) && env_ll("XRFTHIP_FASTYC", 1) != 0;
+        if (P->fastyc) {
+            std::vector<float> ones((size_t)4096, 1.0f);
+            int rcc = build_twiddle<float>(P->tw_fx, d.nx, d.nx);
+            if (!rcc) rcc = build_twiddle<float>(P->tw_fy, d.ny, d.ny);
+            if (!rcc) rcc = P->ones4096.upload(ones.data(), ones.size() * sizeof(float));
+            if (rcc) { delete P; return rcc; }
+            P->yny = d.ny; P->ynx = d.nx;
+        }
+    }
     // a small float32 slab (64 | 128 | 256 points per axis) fits the registers of one workgroup: full power spectra in ONE pass (fasts.h)
     {
         auto small_len = [](long long n) { return n == 64 || n == 128 || n == 256; };
@@ -3379,6 +3488,17 @@ int xrfthip_plan_create(xrfthip_plan** plan, const xrfthip_desc* desc) {
         const uint32_t okc = XRFTHIP_SHIFT_X | (d.out_mode == XRFTHIP_OUT_COMPLEX ? (XRFTHIP_ISHIFT_X | XRFTHIP_INVERSE | XRFTHIP_PHASE_IN) : 0u);
         P->fastr_cin = !P->fastr && d.ndim == 1 && d.dtype == XRFTHIP_C64 && (d.nx == 16384 || d.nx == 8192 || d.nx == 4096 || d.nx == 2048) && !d.detrend &&
                        (d.out_mode == XRFTHIP_OUT_COMPLEX || d.out_mode == XRFTHIP_OUT_POWER) && !(d.flags & ~okc) && !env_ll("XRFTHIP_NO_FAST", 0) && env_ll("XRFTHIP_FASTC", 1) != 0;
+        // rows of 256 .. 4096 points: two rows per thread through one LDS buffer (the row pass of fasty_c2c.h on the input's own rows; XRFTHIP_CROWS=0: fastc_kernel / fastm_xonly_kernel)
+        P->fastr_rows = !P->fastr && d.ndim == 1 && d.dtype == XRFTHIP_C64 && fast_len(d.nx) && !d.detrend && (d.out_mode == XRFTHIP_OUT_COMPLEX || d.out_mode == XRFTHIP_OUT_POWER) &&
+                        !(d.flags & ~okc) && !env_ll("XRFTHIP_NO_FAST", 0) && env_ll("XRFTHIP_CROWS", 1) != 0;
+        if (P->fastr_rows) {
+            P->fastr = true;
+            P->fastr_cin = false;
+            std::vector<float> ones((size_t)4096, 1.0f);
+            int rcr = build_twiddle<float>(P->tw_fx, d.nx, d.nx);
+            if (!rcr) rcr = P->ones4096.upload(ones.data(), ones.size() * sizeof(float));
+            if (rcr) { delete P; return rcr; }
+        } else
         if (P->fastr_cin) {
             P->fastr = true;
             P->tune_rgrid = env_ll("XRFTHIP_FASTR_GRID", 0);
@@ -3724,7 +3844,7 @@ int xrfthip_plan_uses_bluestein(const xrfthip_plan* plan) {
     if (plan->fastgy) return plan->gy_blue_m > 0;
     if (plan->fastn) return plan->n_blue_m > 0;
     if (plan->fusedi) return 0;
-    if (plan->fastg || plan->fasts || plan->fastr || plan->fastmx || plan->fastmy || plan->fastm || plan->fast1d || plan->fast4096) return 0;  // (the generic passes of such a plan never run)
+    if (plan->fastyc || plan->fastg || plan->fasts || plan->fastr || plan->fastmx || plan->fastmy || plan->fastm || plan->fast1d || plan->fast4096) return 0;  // (the generic passes of such a plan never run)
     for (const Pass& ps : plan->passes) if (ps.g.blue_n > 0) return 1;
     for (const Pass& ps : plan->passes_f0) if (ps.g.blue_n > 0) return 1;
     return 0;
@@ -3739,6 +3859,7 @@ int xrfthip_plan_kernel_info(const xrfthip_plan* plan, int32_t* kind, int32_t* p
     else if (P->fusedi) { k = XRFTHIP_K_FASTN; n = P->n_cw; }
     else if (P->fastg) { k = P->g_one_d ? XRFTHIP_K_FASTG_ROWS : XRFTHIP_K_FASTG; n = P->g_one_d ? P->g_rows : 1; }
     else if (P->fasts) { k = XRFTHIP_K_FASTS; n = 1; }
+    else if (P->fastyc) { k = XRFTHIP_K_FASTY; n = 0; }
     else if (P->fastr) { k = XRFTHIP_K_FASTR; n = 1; }
     else if (P->fastmx) { k = XRFTHIP_K_FASTM_X; const MGeomRt C = mxgeom(P->d.nx, P->dbl); n = (two || P->cplx_in) ? C.g : 2 * C.g; }
     else if (P->fastgy) { k = P->gy_rows ? XRFTHIP_K_FASTG_ROWS : XRFTHIP_K_FASTG_Y; n = ((P->cplx_in || two) ? 1 : 2) * P->gy_G; }
@@ -3822,6 +3943,16 @@ int xrfthip_plan_describe(const xrfthip_plan* plan, char* buf, size_t buflen) {
                    "transform in registers (32 complex per thread, r32x%lld / r32x%lld, three LDS exchanges in halves), exact plane detrend in the workgroup, |F|^2 "
                    "rows staged in LDS and written whole with the fftshift and the Hermitian mirror, lds=%zuB; 8 algorithmic bytes per sample through memory\n",
                 G.thr, (long long)plan->d.ny, (long long)plan->d.nx, G.per_cu, (long long)plan->d.ny / 32, (long long)plan->d.nx / 32, G.lds);
+    } else if (plan->fastyc) {
+        const YGeomRt C = ycols_geom(plan->d.ny), R = yrows_geom(plan->d.nx);
+        appendf(s, "  [fasty complex] cols: %d thr, %d x 2 adjacent complex columns (FFT%lld, %s), %d columns/unit -> W2[slab][%lld/%d][nx/%d][%d][%d] -> rows: %d thr, %d rows/unit "
+                   "(FFT%lld), whole rows out (scale, %sfftshift); 32 B per point through memory\n",
+                C.thr, C.gxy, (long long)plan->d.ny, (plan->d.flags & XRFTHIP_INVERSE) ? "inverse: conjugate in / out" : "forward", 2 * C.gxy, (long long)plan->d.ny,
+                std::max(1, 16 / (2 * C.gxy)), 2 * C.gxy, std::max(1, 16 / (2 * C.gxy)), 2 * C.gxy, R.thr, R.rk, (long long)plan->d.nx, plan->fph_on ? "phase, " : "");
+    } else if (plan->fastr && plan->fastr_rows) {
+        const YGeomRt R = yrows_geom(plan->d.nx);
+        appendf(s, "  [fasty complex rows] one pass: %d thr, %d rows/unit of the row-major input (FFT%lld, %s; two rows per thread through one LDS buffer), whole rows out; "
+                   "16 algorithmic bytes per point through memory\n", R.thr, R.rk, (long long)plan->d.nx, (plan->d.flags & XRFTHIP_INVERSE) ? "inverse" : "forward");
     } else if (plan->fastr && plan->fastr_cin) {
         appendf(s, "  [fastr complex rows] one pass, one %lld-thread workgroup per %lld-point complex row: the %s transform in registers (32 per thread, two LDS "
                    "exchanges), natural order through the LDS, lds=%zuB; 16 algorithmic bytes per point through memory\n",
@@ -3957,6 +4088,7 @@ int xrfthip_exec(const xrfthip_plan* plan, const void* d_in0, const void* d_in1,
     if (iso) HIP_TRY(hipMemsetAsync(d_iso, 0, (size_t)d.batch * P->nbins * (cross ? 16 : 8), st));
     if (P->fastg) return run_fastg(P, d_in0, d_in1, out, (double*)d_iso, st);
     if (P->fasts) return run_fasts(P, d_in0, out, (double*)d_iso, st);
+    if (P->fastyc) return run_fastyc(P, d_in0, out, ws, st);
     if (P->fastr) return run_fastr(P, d_in0, out, st);
     if (P->fastmx) return run_fastmx(P, d_in0, d_in1, out, st);
     if (P->fastgy) return run_fastgy(P, d_in0, d_in1, out, st);
