@@ -4,7 +4,7 @@
 cd "$(dirname "$0")/.." || exit 1
 F="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -fno-slp-vectorize -Wno-unused-result -Ixrft_amd/csrc"
 for u in "$@"; do
-  extra=""; [ "$u" = "xrft_hip" ] && extra="-DXRFT_SPLIT_TUS"
+  extra=""; case "$u" in xrft_hip|host_*|ops) extra="-DXRFT_SPLIT_TUS";; esac
   /opt/rocm/bin/hipcc $F $extra -c xrft_amd/csrc/$u.cpp -o build/obj/$u.o 2>&1 | grep -E "error|Error" ; 
 done
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC build/obj/*.o -Wl,-z,defs -o xrft_amd/libxrft_hip.so && ls -la xrft_amd/libxrft_hip.so

@@ -20,7 +20,8 @@ def needs_build():
 
 # the same translation units as the gfx950 build (__graft_entry__.py): xrft_hip.cpp with the fasty / fastm kernels `extern template`, and the
 # instantiation groups, one g++ process each
-UNITS = [("xrft_hip.cpp", ["-DXRFT_SPLIT_TUS"])] + [(f"inst_g{g}.cpp", []) for g in (6, 7, 4, 5, 3, 1, 2)]
+HOST_UNITS = ["xrft_hip.cpp", "host_fastm.cpp", "host_fastg.cpp", "host_fasty.cpp", "host_rows.cpp", "host_inner.cpp", "ops.cpp"]  # plan builder + C ABI, and one host unit per kernel family
+UNITS = [(u, ["-DXRFT_SPLIT_TUS"]) for u in HOST_UNITS] + [(f"inst_g{g}.cpp", []) for g in (6, 7, 4, 5, 3, 1, 2)]
 
 
 def build(force=False):

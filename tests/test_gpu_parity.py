@@ -37,6 +37,11 @@ def _seeds(short, long_):
     return range(long_ if os.environ.get("XRFT_GPU_SWEEP", "") == "long" else short)
 
 
+def _long_only(*args):
+    """A parameter set that costs the CPU oracle 10-20 s (slabs of 4+ million points through every option): part of the long sweep only."""
+    return pytest.param(*args, marks=pytest.mark.skipif(os.environ.get("XRFT_GPU_SWEEP", "") != "long", reason="XRFT_GPU_SWEEP=long runs the largest shapes"))
+
+
 @pytest.mark.parametrize("name,dtype", cases.all_case_params())
 def test_case(name, dtype):
     cases.run_case(name, dtype)
@@ -823,11 +828,11 @@ def test_fastm_latlon_lengths(shape, cross, dtype):
 
 
 @pytest.mark.parametrize("shape,cross,dtype", [((2, 1080, 540), True, "float64"), ((3, 640, 320), True, "float32"), ((2, 1280, 640), True, "float64"), ((2, 2160, 1080), True, "float32"),
-                                                ((2, 2160, 1080), True, "float64"), ((2, 2560, 1280), True, "float32"), ((2, 2880, 1440), True, "float32"), ((2, 2160, 4320), False, "float32"),
-                                                ((2, 4320, 2160), True, "float32"), ((3, 320, 640), True, "float64"), ((2, 540, 1080), True, "float32"),
-                                                ((2, 2000, 2000), True, "float32"), ((2, 1800, 3600), True, "float32"), ((2, 2000, 1500), True, "float32"), ((2, 1800, 900), True, "float32"), ((2, 2160, 1000), True, "float32"),
+                                                ((2, 2160, 1080), True, "float64"), _long_only((2, 2560, 1280), True, "float32"), _long_only((2, 2880, 1440), True, "float32"), _long_only((2, 2160, 4320), False, "float32"),
+                                                _long_only((2, 4320, 2160), True, "float32"), ((3, 320, 640), True, "float64"), ((2, 540, 1080), True, "float32"),
+                                                ((2, 2000, 2000), True, "float32"), _long_only((2, 1800, 3600), True, "float32"), ((2, 2000, 1500), True, "float32"), ((2, 1800, 900), True, "float32"), ((2, 2160, 1000), True, "float32"),
                                                 ((3, 768, 384), True, "float64"), ((2, 1536, 768), True, "float32"), ((2, 1600, 1600), True, "float32"), ((2, 1920, 1080), True, "float64"), ((2, 1080, 1920), True, "float32"),
-                                                ((2, 2400, 1200), True, "float32"), ((2, 3072, 1536), True, "float32"), ((2, 2160, 3840), True, "float32"), ((2, 3840, 2160), True, "float32"), ((3, 192, 384), True, "float64")])
+                                                ((2, 2400, 1200), True, "float32"), _long_only((2, 3072, 1536), True, "float32"), _long_only((2, 2160, 3840), True, "float32"), _long_only((2, 3840, 2160), True, "float32"), ((3, 192, 384), True, "float64")])
 def test_fastm_grid_lengths(shape, cross, dtype):
     """Gaussian grids (320 x 160 ... 2560 x 1280) and the 1/3 ... 1/12-degree lat/lon grids (1080 x 540 ... 4320 x 2160; 4320 = 15 x 16 x 18,
     the radix-18 Good-Thomas butterfly; 2560, 2880, 4320 in float32 only)."""
