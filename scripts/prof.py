@@ -111,6 +111,15 @@ def cmd_call(a):
     kw = parse_kw(a.kw)
     if inverse and "dim" in kw:
         kw["dim"] = ["freq_" + d for d in kw["dim"]] if isinstance(kw["dim"], list) else "freq_" + kw["dim"]
+    if inverse and kw.get("real_dim"):  # the stored half of the real axis: n/2 + 1 samples at rfftfreq
+        import numpy as np
+        import xrft_amd as xrft_
+        rd = "freq_" + kw["real_dim"]
+        kw["real_dim"] = rd
+        co = {k: v.values for k, v in d1.coords.items()}
+        nh = d1.sizes[rd]
+        co[rd] = np.fft.rfftfreq(2 * (nh - 1), 1.0)
+        d1 = xrft_.DataArray(d1.data, d1.dims, co)
     f = getattr(xrft, a.fn)
     fn = (lambda: f(d1, d2, **kw)) if two else (lambda: f(d1, **kw))
     units = shape[0]

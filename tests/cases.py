@@ -984,7 +984,7 @@ def run_inverse_one_pass_cases(shape=(2, 360, 250), dtype="float64"):
                 Fr, Fro = xa.fft(da, dim=["x"], real_dim="x", **kw), o.fft(od, dim=["x"], real_dim="x", **kw)
                 xa.api._plan_cache.clear()
                 worst = max(worst, check_values(xa.ifft(Fr, dim=["freq_x"], real_dim="freq_x", **kw), o.ifft(Fro, dim=["freq_x"], real_dim="freq_x", **kw), tol))
-                assert any("[fastg rows]" in p.describe() for p in xa.api._plan_cache.values()), kw
+                assert any("[fastg rows]" in p.describe() or "[fasty complex rows]" in p.describe() for p in xa.api._plan_cache.values()), kw  # (float32 rows of 512 .. 4096 samples: the c2r row pass)
                 Fr2, Fr2o = xa.fft(da, dim=["y"], real_dim="x", **kw), o.fft(od, dim=["y"], real_dim="x", **kw)
                 worst = max(worst, check_values(xa.ifft(Fr2, dim=["freq_y"], real_dim="freq_x", **kw), o.ifft(Fr2o, dim=["freq_y"], real_dim="freq_x", **kw), tol))
     return worst
@@ -1051,6 +1051,34 @@ def run_complex_two_pass_cases(ny, nx, nt=2, variant=0, seed=97):
     P, Po = xa.power_spectrum(da, dim=["y", "x"]), o.power_spectrum(od, dim=["y", "x"])
     assert "[fasty complex]" in tag(), tag()
     worst = max(worst, check(P, Po, tol))
+    return worst
+
+
+def run_c2r_two_pass_cases(ny, nx, nt=2, variant=0, seed=101):
+    """xrft.ifft with real_dim (irfftn / irfft, xrft.py:612-616) of float32 half spectra whose lengths are powers of two: the complex two-pass pipeline with the c2r
+    row pass (csrc/fasty_c2c.h fastyc_rows_c2r_kernel: ny = 256 .. 4096, nx = 512 .. 4096), and that row pass alone along the contiguous axis -- against the oracle
+    and as a round trip of the real field."""
+    rng = np.random.default_rng(seed + ny + 5 * nx)
+    tol = TOL["float32"]
+    kw = (dict(), dict(true_phase=False, true_amplitude=False), dict(shift=False), dict(true_phase=False, shift=False))[variant % 4]
+    v = rng.standard_normal((nt, ny, nx)).astype(np.float32)
+    c = {"t": np.arange(nt), "y": np.arange(ny) * 0.25 - 7.0, "x": np.arange(nx) * 0.5 + 3.0}
+    da, od = pair(v, ("t", "y", "x"), c)
+
+    def tag():
+        return next(reversed(xa.api._plan_cache.values())).describe()
+
+    F, Fo = xa.fft(da, dim=["y"], real_dim="x", **kw), o.fft(od, dim=["y"], real_dim="x", **kw)
+    G, Go = xa.ifft(F, dim=["freq_y"], real_dim="freq_x", **kw), o.ifft(Fo, dim=["freq_y"], real_dim="freq_x", **kw)
+    assert "[fasty complex]" in tag() and "real samples" in tag(), tag()
+    assert np.asarray(G.values).dtype == np.float32
+    worst = check_values(G, Go, tol)
+    F1, F1o = xa.fft(da, dim="x", real_dim="x", **kw), o.fft(od, dim="x", real_dim="x", **kw)
+    G1, G1o = xa.ifft(F1, dim="freq_x", real_dim="freq_x", **kw), o.ifft(F1o, dim="freq_x", real_dim="freq_x", **kw)
+    assert "[fasty complex rows]" in tag() and "real samples" in tag(), tag()
+    worst = max(worst, check_values(G1, G1o, tol))
+    if not kw:  # the default call returns the field it started from
+        assert np.abs(np.asarray(G.values) - v).max() < 100 * tol * np.abs(v).max() and np.abs(np.asarray(G1.values) - v).max() < 100 * tol * np.abs(v).max()
     return worst
 
 

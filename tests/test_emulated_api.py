@@ -756,3 +756,9 @@ def test_complex_rows_in_one_pass(n):
 def test_complex_slabs_through_the_two_pass_pipeline(ny, nx, variant):
     """csrc/fasty_c2c.h on the emulator: fft (with and without a window) / ifft / power spectrum of complex64 slabs, every W2 geometry (ny = 256 .. 4096)."""
     cases.run_complex_two_pass_cases(ny, nx, nt=2 if ny * nx <= (1 << 19) else 1, variant=variant)
+
+
+@pytest.mark.parametrize("ny,nx,variant", [(256, 512, 0), (512, 1024, 1), (1024, 4096, 2), (2048, 512, 3), (4096, 1024, 1)])
+def test_half_spectra_back_to_real_fields_through_the_two_pass_pipeline(ny, nx, variant):
+    """csrc/fasty_c2c.h on the emulator: irfftn (the Nyquist column's extra block in pass 1, the c2r row pass) and irfft along the contiguous axis."""
+    cases.run_c2r_two_pass_cases(ny, nx, nt=2 if ny * nx <= (1 << 20) else 1, variant=variant)

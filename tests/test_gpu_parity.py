@@ -1145,3 +1145,10 @@ def test_complex_rows_in_one_pass(n):
 def test_complex_slabs_through_the_two_pass_pipeline(ny, nx, variant):
     """csrc/fasty_c2c.h: two-axis fft / ifft / power spectrum of complex64 slabs (xrft.ifft over two axes, xrft.py:586-621), against the oracle."""
     cases.run_complex_two_pass_cases(ny, nx, nt=3 if ny * nx <= (1 << 22) else 2, variant=variant)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("ny,nx,variant", [(256, 512, 0), (512, 4096, 1), (1024, 1024, 2), (2048, 2048, 3), (4096, 4096, 0), (4096, 512, 1), (256, 4096, 2)])
+def test_half_spectra_back_to_real_fields_through_the_two_pass_pipeline(ny, nx, variant):
+    """csrc/fasty_c2c.h: xrft.ifft with real_dim (irfftn) of float32 half spectra, and irfft along the contiguous axis, against the oracle."""
+    cases.run_c2r_two_pass_cases(ny, nx, nt=3 if ny * nx <= (1 << 22) else 2, variant=variant)

@@ -1160,7 +1160,7 @@ def _ifft_two_stages(t, batch, ny, nx, flags, scale, ph):
     each.  Returns None otherwise (the caller builds the two-axis plan)."""
     c2r = bool(flags & _lib.C2R_X)
     nxs = nx // 2 + 1 if c2r else nx  # stored columns
-    if not c2r and t.dtype == torch.complex64 and ny in (256, 512, 1024, 2048, 4096) and nx in (256, 512, 1024, 2048, 4096):
+    if t.dtype == torch.complex64 and ny in (256, 512, 1024, 2048, 4096) and (nx in (512, 1024, 2048, 4096) if c2r else nx in (256, 512, 1024, 2048, 4096)):
         return None  # (the two-pass pipeline on complex slabs, csrc/fasty_c2c.h: one plan, a tiled intermediate written in whole lines)
     if ny * nx > (1 << 31) - 1 or batch * ny * nx == 0:
         return None

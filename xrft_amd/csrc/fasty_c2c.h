@@ -34,6 +34,12 @@ struct FastYC {
     int l_cw, l_rk;      // log2 of CW, RK (layout of W2, fixed by ny)
     int power;           // |F|^2 * scale as float32 instead of the complex result
     int win_on;          // a window is set (the tables are read)
+    int c2r;             // the half spectrum of a real field back to real samples (irfftn, xrft.py:612-616): the input holds nx/2 + 1 complex columns
+                         // (rows of in_pitch elements), pass 1 transforms them along y -- the nx/2 regular column blocks and ONE extra block for the Nyquist
+                         // column -- and fastyc_rows_c2r_kernel<nx/2> turns every row into nx real samples
+    int in_pitch;        // complex elements per input row (nx; c2r: nx/2 + 1)
+    int w2_nxb;          // column blocks per row block of W2 (nx / CW; c2r: nx/2 / CW + 1)
+    const cf* tw_big;    // c2r: W_nx^k, k < nx/2 / 16 (the split's twiddle of lane u; times W_32^q in registers)
     long long nrows;     // fastyc_rows_kernel alone on ROW-MAJOR complex rows (one transform axis, the contiguous one; `w2` = the input, l_cw = log2 nx, l_rk = 0):
                          // the number of rows (0: pass 2 of the two-pass pipeline); the input-side options of pass 1 then apply to the rows here
     float scale;
@@ -41,7 +47,7 @@ struct FastYC {
 
 // element offset of (ky, x) inside one slab of W2 (< 2^24 elements)
 __device__ __forceinline__ unsigned w2c_offset(const FastYC& p, int ky, int x) {
-    const unsigned nxb = (unsigned)p.nx >> p.l_cw;
+    const unsigned nxb = (unsigned)p.w2_nxb;
     return ((((unsigned)ky >> p.l_rk) * nxb + ((unsigned)x >> p.l_cw)) << (p.l_rk + p.l_cw)) + (((unsigned)ky & ((1u << p.l_rk) - 1u)) << p.l_cw) + ((unsigned)x & ((1u << p.l_cw) - 1u));
 }
 
@@ -63,31 +69,51 @@ __global__ void __launch_bounds__(YCols<NY>::THR, (YCols<NY>::THR >= 512 ? 4 : Y
     fill_tw2<NY>(tw2, p.tw_y, tid, THR);
     // unit = (slab, column block); blocks b, b + 8, ... run on one XCD: each XCD gets a contiguous range of column blocks, so that the
     // workgroups sharing a 128-byte line of the input share an L2 (fasty_cols_kernel)
-    const int nxb = p.nx / CW;
+    const int nxb_full = p.c2r ? (p.nx / 2) / CW : p.nx / CW;  // whole column blocks; c2r: + ONE block whose first column is the Nyquist column
+    const int nxb = p.w2_nxb;
+    const bool tailb = p.c2r && (int)blockIdx.x >= p.nslab * nxb_full;
     int slab, xb;
-    if ((nxb & 7) == 0) {
-        const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3, per = nxb >> 3;
+    if (tailb) {
+        slab = (int)blockIdx.x - p.nslab * nxb_full;
+        xb = nxb_full;
+    } else if ((nxb_full & 7) == 0) {
+        const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3, per = nxb_full >> 3;
         slab = j / per;
         xb = xcd * per + j % per;
     } else {
-        slab = blockIdx.x / nxb;
-        xb = blockIdx.x % nxb;
+        slab = blockIdx.x / nxb_full;
+        xb = blockIdx.x % nxb_full;
     }
     // the block of SOURCE columns (an fftshifted input: rotated by nx/2 = nxb/2 blocks) and the source rows u + NT q (+ ny/2: q + 8)
-    const int xbs = p.ishift_x ? (xb + (nxb >> 1)) % nxb : xb;
+    const int xbs = p.ishift_x ? (xb + (nxb_full >> 1)) % nxb_full : xb;
     const int qrot = p.ishift_y ? 8 : 0;
-    const char* __restrict__ src = reinterpret_cast<const char*>(p.in + (size_t)slab * NY * p.nx + (size_t)xbs * CW);
-    const unsigned off0 = ((unsigned)u * (unsigned)p.nx + 2u * (unsigned)g) * 8u, rstep = (unsigned)NT * (unsigned)p.nx * 8u;
+    const char* __restrict__ src = reinterpret_cast<const char*>(p.in + (size_t)slab * NY * p.in_pitch + (size_t)xbs * CW);
+    const unsigned off0 = ((unsigned)u * (unsigned)p.in_pitch + 2u * (unsigned)g) * 8u, rstep = (unsigned)NT * (unsigned)p.in_pitch * 8u;
     cf a[16], b[16];
+    if (!tailb) {
 #pragma unroll
-    for (int q = 0; q < 16; ++q) {
-        const F4 v = *reinterpret_cast<const F4*>(src + (off0 + rstep * (unsigned)((q + qrot) & 15)));
-        a[q] = mk<float>(v.x, v.y);
-        b[q] = mk<float>(v.z, v.w);
+        for (int q = 0; q < 16; ++q) {
+#ifdef XRFT_EMULATE
+            const float* v = reinterpret_cast<const float*>(src + (off0 + rstep * (unsigned)((q + qrot) & 15)));
+            a[q] = mk<float>(v[0], v[1]);
+            b[q] = mk<float>(v[2], v[3]);
+#else
+            typedef float v4f_a8 __attribute__((ext_vector_type(4), aligned(8)));  // (rows of an odd number of complex values: 8-byte aligned, still one 16-byte load)
+            const v4f_a8 v = *reinterpret_cast<const v4f_a8*>(src + (off0 + rstep * (unsigned)((q + qrot) & 15)));
+            a[q] = mk<float>(v.x, v.y);
+            b[q] = mk<float>(v.z, v.w);
+#endif
+        }
+    } else {  // the Nyquist column alone: transform A of group 0; everything else of the block is zero
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            a[q] = g == 0 ? *reinterpret_cast<const cf*>(src + (off0 + rstep * (unsigned)((q + qrot) & 15))) : mk<float>(0.f, 0.f);
+            b[q] = mk<float>(0.f, 0.f);
+        }
     }
     const int xs0 = xbs * CW + 2 * g;  // source column of transform A
     if (p.ph_in) {  // the lag's phase factor on the source samples: ph_y[row] ph_x[column]
-        const cf pxa = p.ph_x[xs0], pxb = p.ph_x[xs0 + 1];
+        const cf pxa = p.ph_x[tailb ? p.nx / 2 : xs0], pxb = tailb ? mk<float>(1.f, 0.f) : p.ph_x[xs0 + 1];
 #pragma unroll
         for (int q = 0; q < 16; ++q) {
             const cf py = p.ph_y[u + NT * ((q + qrot) & 15)];
@@ -128,7 +154,7 @@ __global__ void __launch_bounds__(YCols<NY>::THR, (YCols<NY>::THR >= 512 ? 4 : Y
 #pragma unroll
         for (int k3 = 0; k3 < G::R3; ++k3) mine2[nat16(held_k<NY>(u2, bb, k3))] = b[bb * G::R3 + k3];
     __syncthreads();
-    char* __restrict__ w2s = reinterpret_cast<char*>(p.w2 + (size_t)slab * NY * p.nx);
+    char* __restrict__ w2s = reinterpret_cast<char*>(p.w2 + (size_t)slab * NY * ((size_t)nxb * CW));
 #pragma unroll
     for (int q = 0; q < 16; ++q) {
         const int k = u2 + NT * q;
@@ -161,7 +187,7 @@ __global__ void __launch_bounds__((YRows<NX>::THR), (YRows<NX>::THR / 128 < 1 ? 
     const int slab = alone ? 0 : (int)blockIdx.x / upr;
     const long long ky0 = alone ? (long long)blockIdx.x * RPU : (long long)(((int)blockIdx.x % upr) * RPU);
     const long long kyA = alone ? min(ky0 + g, p.nrows - 1) : ky0 + g, kyB = alone ? min(ky0 + GX + g, p.nrows - 1) : ky0 + GX + g;
-    const char* __restrict__ w2s = reinterpret_cast<const char*>(p.w2 + (size_t)slab * p.ny * NX);
+    const char* __restrict__ w2s = reinterpret_cast<const char*>(p.w2 + (size_t)slab * p.ny * ((size_t)p.w2_nxb << p.l_cw));
     cf a[16], b[16];
     if (alone) {  // row-major rows: 8 bytes per lane, 64 consecutive lanes = 512 contiguous bytes; the input-side options of pass 1
         const int qrot = p.ishift_x ? 8 : 0;  // an fftshifted input: x + nx/2 = u + NT (q + 8)
@@ -249,6 +275,98 @@ __global__ void __launch_bounds__((YRows<NX>::THR), (YRows<NX>::THR / 128 < 1 ? 
                 v1 = cmul(v1, cmul(py, p.ph_x[fx1]));
             }
             xrft_store_nt2(outs + ((size_t)(alone ? ky : ((ky + p.shift_y) & my)) * NX + c), v0, v1);
+        }
+    }
+}
+
+
+// ------------------------------------------------------------------------------------------------
+// pass 2 of a c2r plan: rows ky of W2 hold X[ky, k], k = 0 .. M (M = nx/2; the Nyquist sample in the extra column block); the row's nx real
+// samples are the packed inverse transform  z[n] = x[2n] + i x[2n+1] = IFFT_M(Z),  Z[k] = E[k] + i O[k],
+//     E[k] = (X[k] + conj X[M-k]) / 2,   O[k] = (X[k] - conj X[M-k]) conj(W_nx^k) / 2,
+// computed as conj(FFT_M(conj Z)): a thread holds k = u + NT q of two rows, fetches the partners X[M - k] itself (they are another lane's
+// samples: a second read of the row, from L2), W_nx^k = W_nx^u W_32^q (nx = 32 NT).  Output: whole rows of nx float32 samples, 16-byte stores.
+// `alone` (nrows > 0): the rows of a row-major half spectrum [rows][M + 1] themselves -- xrft.ifft with real_dim along ONE axis, the contiguous one.
+// ------------------------------------------------------------------------------------------------
+template <int M>
+__global__ void __launch_bounds__((YRows<M>::THR), (YRows<M>::THR / 128 < 1 ? 1 : YRows<M>::THR / 128)) fastyc_rows_c2r_kernel(FastYC p) {
+    typedef P2<M> G;
+    typedef YRows<M> R;
+    constexpr int NT = G::NT, GX = R::GX, THR = R::THR, RPU = 2 * GX, GSTR = YLds<M, GX>::GSTR;
+    constexpr int RSC = M + M / 16;
+    // W_32^q = cos - i sin of 2 pi q / 32
+    constexpr float C32[16] = {1.0f, 0.98078528040323044913f, 0.92387953251128675613f, 0.83146961230254523708f, 0.70710678118654752440f, 0.55557023301960222474f,
+                               0.38268343236508977173f, 0.19509032201612826785f, 0.0f, -0.19509032201612826785f, -0.38268343236508977173f, -0.55557023301960222474f,
+                               -0.70710678118654752440f, -0.83146961230254523708f, -0.92387953251128675613f, -0.98078528040323044913f};
+    constexpr float S32[16] = {0.0f, 0.19509032201612826785f, 0.38268343236508977173f, 0.55557023301960222474f, 0.70710678118654752440f, 0.83146961230254523708f,
+                               0.92387953251128675613f, 0.98078528040323044913f, 1.0f, 0.98078528040323044913f, 0.92387953251128675613f, 0.83146961230254523708f,
+                               0.70710678118654752440f, 0.55557023301960222474f, 0.38268343236508977173f, 0.19509032201612826785f};
+    XRFT_DYN_SMEM(smem_raw);
+    cf* lds = reinterpret_cast<cf*>(smem_raw);
+    const int tid = threadIdx.x, g = tid % GX, u = tid / GX;
+    cf* mine = lds + g * GSTR;
+    cf* tw2 = lds + GX * GSTR;
+    fill_tw2<M>(tw2, p.tw_x, tid, THR);
+    const bool alone = p.nrows > 0;
+    const int upr = p.ny / RPU;
+    const int slab = alone ? 0 : (int)blockIdx.x / upr;
+    const long long ky0 = alone ? (long long)blockIdx.x * RPU : (long long)(((int)blockIdx.x % upr) * RPU);
+    const long long kyr[2] = {alone ? min(ky0 + g, p.nrows - 1) : ky0 + g, alone ? min(ky0 + GX + g, p.nrows - 1) : ky0 + GX + g};
+    const cf wu = p.tw_big[u];  // W_nx^u
+    const cf* __restrict__ w2s = p.w2 + (size_t)slab * p.ny * ((size_t)p.w2_nxb << p.l_cw);
+    // sample (row, k): the tiled intermediate, or the row-major input itself
+    auto at = [&](long long ky, int k) -> cf {
+        if (alone) {
+            cf v = p.w2[(size_t)ky * (M + 1) + k];
+            if (p.ph_in) v = cmul(v, p.ph_x[k]);
+            return v;
+        }
+        return cconj(w2s[w2c_offset(p, (int)ky, k)]);  // (pass 1 of an inverse plan left conj(IFFT_y X): FFT_y of the conjugated input)
+    };
+    cf a[16], b[16];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        cf* z = t ? b : a;
+        cf pr[16];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const int k = u + NT * q, pk = M - k;  // (u = 0, q = 0: the Nyquist sample M)
+            z[q] = at(kyr[t], k);
+            pr[q] = at(kyr[t], pk);
+        }
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const cf x = z[q], pc = cconj(pr[q]);
+            const cf e = mk<float>(x.re + pc.re, x.im + pc.im), d = mk<float>(x.re - pc.re, x.im - pc.im);  // 2E, X - conj P
+            // conj(W_nx^k) = conj(W_nx^u W_32^q)
+            const cf w = cconj(cmul(wu, mk<float>(C32[q], -S32[q])));
+            const cf o = cmul(d, w);                                  // 2 O
+            const cf zz = mk<float>(e.re - o.im, e.im + o.re);        // 2 (E + i O)
+            z[q] = cconj(zz);                                         // the inverse transform as conj(FFT(conj Z))
+        }
+    }
+    fft_p2_pair<M>(a, b, u, mine, p.tw_x, tw2);
+    // GX rows at a time staged in natural order; z[n] = conj(result[n]): x[2n] = re, x[2n + 1] = -im
+    const int mm = M - 1, my = p.ny - 1, sxh = p.shift_x >> 1;  // (the output fftshift by nx/2 samples = M/2 packed values)
+    cf* cstg = lds;
+#pragma unroll
+    for (int round = 0; round < 2; ++round) {
+        if (round) __syncthreads();
+#pragma unroll
+        for (int bb = 0; bb < G::NB; ++bb)
+#pragma unroll
+            for (int k3 = 0; k3 < G::R3; ++k3) cstg[g * RSC + nat16(held_k<M>(u, bb, k3))] = round ? b[bb * G::R3 + k3] : a[bb * G::R3 + k3];
+        __syncthreads();
+        float* __restrict__ outs = reinterpret_cast<float*>(p.out) + (size_t)slab * p.ny * (2 * M);
+        constexpr int CPR = M / 2;  // 16-byte chunks (two packed values = four samples) per row
+        for (int e = tid; e < GX * CPR; e += THR) {
+            const int chunk = e % CPR, rl = e / CPR, n0 = (2 * chunk - sxh) & mm;
+            const long long ky = ky0 + round * GX + rl;
+            if (alone && ky >= p.nrows) break;
+            const cf* row = cstg + rl * RSC;
+            const cf v0 = row[nat16(n0)], v1 = row[nat16((n0 + 1) & mm)];
+            F4 o; o.x = v0.re * p.scale; o.y = -v0.im * p.scale; o.z = v1.re * p.scale; o.w = -v1.im * p.scale;
+            xrft_store_nt(outs + ((size_t)(alone ? ky : ((ky + p.shift_y) & my)) * (2 * M) + 4 * chunk), o);
         }
     }
 }

@@ -506,14 +506,20 @@ int run_fasty(const xrfthip_plan* P, const float* in, const float* in1, void* ou
 // the two-pass pipeline on complex float32 slabs (fasty_c2c.h): columns -> rows, group by group
 int run_fastyc(const xrfthip_plan* P, const void* in, void* out, char* ws, hipStream_t st) {
     const xrfthip_desc& d = P->d;
-    const YGeomRt C = ycols_geom(d.ny), R = yrows_geom(d.nx);
+    const bool c2r = (d.flags & XRFTHIP_C2R_X) != 0;
+    const long long nxt = c2r ? d.nx / 2 : d.nx;  // points of the row transforms
+    const YGeomRt C = ycols_geom(d.ny), R = yrows_geom(nxt);
     const int cw = 2 * C.gxy, rk = std::max(1, 16 / cw);
+    const int nxb_full = (int)(nxt / cw), w2_nxb = nxb_full + (c2r ? 1 : 0);
+    const long long in_pitch = c2r ? d.nx / 2 + 1 : d.nx;
     const size_t lds_c = (size_t)(C.gxy * (ycols_gstr(d.ny)) + 16 * (d.ny / 256)) * sizeof(cf);
-    const size_t out_esz = d.out_mode == XRFTHIP_OUT_POWER ? sizeof(float) : sizeof(cf);
+    const size_t out_esz = (d.out_mode == XRFTHIP_OUT_POWER || c2r) ? sizeof(float) : sizeof(cf);
     for (long long g0 = 0; g0 < d.batch; g0 += P->G) {
         const long long gc = std::min<long long>(P->G, d.batch - g0);
         FastYC p{};
-        p.in = reinterpret_cast<const cf*>(in) + (size_t)g0 * d.ny * d.nx;
+        p.in = reinterpret_cast<const cf*>(in) + (size_t)g0 * d.ny * in_pitch;
+        p.c2r = c2r ? 1 : 0; p.in_pitch = (int)in_pitch; p.w2_nxb = w2_nxb;
+        p.tw_big = reinterpret_cast<const cf*>(P->tw_big1d.p);
         p.w2 = reinterpret_cast<cf*>(ws + P->off_w);
         p.out = (char*)out + (size_t)g0 * d.ny * d.nx * out_esz;
         p.tw_x = reinterpret_cast<const cf*>(P->tw_fx.p);
@@ -536,7 +542,7 @@ int run_fastyc(const xrfthip_plan* P, const void* in, void* out, char* ws, hipSt
         p.power = d.out_mode == XRFTHIP_OUT_POWER ? 1 : 0;
         p.scale = (float)d.scale;
         xrfthip_plan::ProfRec* rec = prof_begin(P, "fastyc_cols", st);
-        const dim3 gridc((unsigned)(gc * (d.nx / cw))), blkc((unsigned)C.thr);
+        const dim3 gridc((unsigned)(gc * nxb_full + (c2r ? gc : 0))), blkc((unsigned)C.thr);
 #define YCC_(NN) do { auto k = &fastyc_cols_kernel<NN>; XRFT_LAUNCH(k, gridc, blkc, lds_c, st, p); } while (0)
         if (d.ny == 4096) YCC_(4096); else if (d.ny == 2048) YCC_(2048); else if (d.ny == 1024) YCC_(1024); else if (d.ny == 512) YCC_(512); else YCC_(256);
 #undef YCC_
@@ -544,8 +550,11 @@ int run_fastyc(const xrfthip_plan* P, const void* in, void* out, char* ws, hipSt
         rec = prof_begin(P, "fastyc_rows", st);
         const dim3 gridr((unsigned)(gc * (d.ny / R.rk))), blkr((unsigned)R.thr);
 #define YCR_(NN) do { auto k = &fastyc_rows_kernel<NN>; XRFT_LAUNCH(k, gridr, blkr, R.lds, st, p); } while (0)
-        if (d.nx == 4096) YCR_(4096); else if (d.nx == 2048) YCR_(2048); else if (d.nx == 1024) YCR_(1024); else if (d.nx == 512) YCR_(512); else YCR_(256);
+#define YC2_(NN) do { auto k = &fastyc_rows_c2r_kernel<NN>; XRFT_LAUNCH(k, gridr, blkr, R.lds, st, p); } while (0)
+        if (c2r) { if (nxt == 2048) YC2_(2048); else if (nxt == 1024) YC2_(1024); else if (nxt == 512) YC2_(512); else YC2_(256); }
+        else if (d.nx == 4096) YCR_(4096); else if (d.nx == 2048) YCR_(2048); else if (d.nx == 1024) YCR_(1024); else if (d.nx == 512) YCR_(512); else YCR_(256);
 #undef YCR_
+#undef YC2_
         prof_end(rec, st);
         HIP_TRY(hipGetLastError());
     }
@@ -563,6 +572,7 @@ void set_attrs_fasty() {
 #undef SETY
 #define SETC(NN) SETF((fastyc_cols_kernel<NN>)); SETF((fastyc_rows_kernel<NN>))
     SETC(4096); SETC(2048); SETC(1024); SETC(512); SETC(256);
+    SETF((fastyc_rows_c2r_kernel<2048>)); SETF((fastyc_rows_c2r_kernel<1024>)); SETF((fastyc_rows_c2r_kernel<512>)); SETF((fastyc_rows_c2r_kernel<256>));
 #undef SETC
 #define SETI(NN) SETF((fasty_isorows_kernel<NN, 1, false>)); SETF((fasty_isorows_kernel<NN, 2, false>)); SETF((fasty_isorows_kernel<NN, 1, true>)); SETF((fasty_isorows_kernel<NN, 2, true>))
     SETI(4096); SETI(2048); SETI(1024);

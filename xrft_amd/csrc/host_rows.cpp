@@ -81,8 +81,12 @@ int run_fasts(const xrfthip_plan* P, const void* in, void* out, double* iso, hip
 int run_fastr(const xrfthip_plan* P, const void* in, void* out, hipStream_t st) {
     const xrfthip_desc& d = P->d;
     if (P->fastr_rows) {  // complex rows of 256 .. 4096 points: the row pass of the complex two-pass pipeline on the input's own rows
-        const YGeomRt R = yrows_geom(d.nx);
+        const bool c2r = (d.flags & XRFTHIP_C2R_X) != 0;
+        const long long nxt = c2r ? d.nx / 2 : d.nx;
+        const YGeomRt R = yrows_geom(nxt);
         FastYC p{};
+        p.c2r = c2r ? 1 : 0; p.in_pitch = (int)(c2r ? nxt + 1 : d.nx); p.w2_nxb = 1;
+        p.tw_big = reinterpret_cast<const cf*>(P->tw_big1d.p);
         p.w2 = reinterpret_cast<cf*>(const_cast<void*>(in));
         p.out = out;
         p.tw_x = reinterpret_cast<const cf*>(P->tw_fx.p);
@@ -96,15 +100,18 @@ int run_fastr(const xrfthip_plan* P, const void* in, void* out, hipStream_t st) 
         p.ishift_x = ((d.flags & XRFTHIP_INVERSE) && (d.flags & XRFTHIP_ISHIFT_X)) ? 1 : 0;
         p.shift_x = (d.flags & XRFTHIP_SHIFT_X) ? (int)(d.nx / 2) : 0;
         p.ny = R.rk; p.nx = (int)d.nx; p.nslab = 1;  // (ny: one unit of rows -- the kernel addresses by row number)
-        p.l_cw = ilog2i((int)d.nx); p.l_rk = 0;
+        p.l_cw = ilog2i((int)nxt); p.l_rk = 0;
         p.power = d.out_mode == XRFTHIP_OUT_POWER ? 1 : 0;
         p.scale = (float)d.scale;
         p.nrows = d.batch;
         xrfthip_plan::ProfRec* rec = prof_begin(P, "fastyc_rows", st);
         const dim3 gridr((unsigned)((d.batch + R.rk - 1) / R.rk)), blkr((unsigned)R.thr);
 #define YCR_(NN) do { auto k = &fastyc_rows_kernel<NN>; XRFT_LAUNCH(k, gridr, blkr, R.lds, st, p); } while (0)
-        if (d.nx == 4096) YCR_(4096); else if (d.nx == 2048) YCR_(2048); else if (d.nx == 1024) YCR_(1024); else if (d.nx == 512) YCR_(512); else YCR_(256);
+#define YC2_(NN) do { auto k = &fastyc_rows_c2r_kernel<NN>; XRFT_LAUNCH(k, gridr, blkr, R.lds, st, p); } while (0)
+        if (c2r) { if (nxt == 2048) YC2_(2048); else if (nxt == 1024) YC2_(1024); else if (nxt == 512) YC2_(512); else YC2_(256); }
+        else if (d.nx == 4096) YCR_(4096); else if (d.nx == 2048) YCR_(2048); else if (d.nx == 1024) YCR_(1024); else if (d.nx == 512) YCR_(512); else YCR_(256);
 #undef YCR_
+#undef YC2_
         prof_end(rec, st);
         HIP_TRY(hipGetLastError());
         return XRFTHIP_OK;

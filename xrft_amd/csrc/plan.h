@@ -1,15 +1,24 @@
 #pragma once
-// xrft_hip.cpp -- plan builder, pass scheduler and the C ABI of libxrft_hip.so (see include/xrft_hip.h).
+// plan.h -- what the host side of libxrft_hip.so shares between its translation units (not part of the C ABI: include/xrft_hip.h is):
+// the plan (struct xrfthip_plan), device tables, the small host helpers, and the declarations of the per-family host functions.
+//
+//   xrft_hip.cpp     the plan builder (xrfthip_plan_create: which kernels serve a descriptor), the generic tile passes (tile_fft.h), workspace
+//                    layout, xrfthip_exec's dispatch, describe / profiling, the C ABI of the plan
+//   host_fasty.cpp   the y-first float32 two-pass pipeline (fasty.h, fasty_iso.h) and its complex form (fasty_c2c.h): tables, launchers
+//   host_fastm.cpp   the mixed-radix pipeline on the lat/lon lengths (fastm.h), its run-time-radix form (fastn.h), the one-axis table kernels
+//   host_fastg.cpp   the one-pass lengths-as-data kernels (fastg.h): small slabs, one axis of any smooth length, Rader / Bluestein tables
+//   host_rows.cpp    the register-resident one-pass kernels: small float32 slabs (fasts.h), long rows and complex rows (fastr.h)
+//   host_inner.cpp   two transform axes that are not the trailing pair (xrfthip_desc.inner / .mid): the fused passes and the composite plan
+//   ops.cpp          the stand-alone operations of the ABI (detrend, spectrum tail, gather, convert, reduce, isotropize, ...)
+//   inst_g1..7.cpp   the explicit instantiations of the fasty / fastm / fastn kernel templates (instances.h)
 //
 // A plan is a short list of kernel launches per group of slabs, chosen when the plan is created (xrfthip_plan_describe says which):
 //   * generic passes (tile_fft.h), any shape:   [slab_moments -> finalize_coef]  ->  x pass(es)  ->  y pass(es)  [-> radial sums]
 //     The x pass reads the user's array (detrend / window / flip / ifftshift fused into its loads) and the last pass writes the
 //     user's output (fftshift / phase / scaling / |F|^2 / cross / mirror fused into its stores); the only intermediate is the
 //     half spectrum of ONE group of slabs, re-used for every group.
-//   * the two-pass y-first pipelines: fasty.h (real float32, powers of two 256 .. 4096; the four-step form for long 1-D
-//     sequences) and fastm.h (real float64 / float32 on the lat/lon lengths): columns -> plane fit -> rows;
-//   * one-pass kernels for ONE transform axis whose length is in the fastm table (fastm_yonly_kernel / fastm_xonly_kernel).
-// Nothing here allocates or synchronises in exec.
+//   * the specialised families above, each with its own launcher (run_fast*).
+// Nothing allocates or synchronises in exec.
 #include <algorithm>
 #include <functional>
 #include <cmath>

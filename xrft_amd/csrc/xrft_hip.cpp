@@ -1,3 +1,4 @@
+// xrft_hip.cpp -- the plan builder, the generic tile passes, and the C ABI of the plan (see plan.h for the map of the host units).
 #include "plan.h"
 
 thread_local int xrfth::g_last_hip_error = 0;
@@ -563,7 +564,9 @@ void layout_workspace(xrfthip_plan* P) {
         G = std::max<long long>(1, std::min<long long>(G, std::max<long long>(d.batch, 1)));
         P->G = (int)G;
         P->off_w = 0;
-        P->ws_bytes = (((size_t)G * (size_t)d.ny * (size_t)d.nx * sizeof(cf)) + 255) & ~(size_t)255;
+        size_t w2_cols = (size_t)d.nx;  // complex columns of the intermediate per row
+        if (d.flags & XRFTHIP_C2R_X) { const size_t cw = 2 * (size_t)ycols_geom(d.ny).gxy; w2_cols = (size_t)d.nx / 2 + cw; }  // (+ the block of the Nyquist column)
+        P->ws_bytes = (((size_t)G * (size_t)d.ny * w2_cols * sizeof(cf)) + 255) & ~(size_t)255;
         return;
     }
     const bool fast = fast_on(P);
@@ -871,12 +874,14 @@ int xrfthip_plan_create(xrfthip_plan** plan, const xrfthip_desc* desc) {
                       !env_ll("XRFTHIP_NO_FAST", 0);
     }
     {   // complex float32 slabs of these lengths: the two-pass pipeline's complex form (fasty_c2c.h)
-        const uint32_t okc = XRFTHIP_SHIFT_Y | XRFTHIP_SHIFT_X | (d.out_mode == XRFTHIP_OUT_COMPLEX ? (XRFTHIP_ISHIFT_Y | XRFTHIP_ISHIFT_X | XRFTHIP_INVERSE | XRFTHIP_PHASE_IN) : 0u);
-        P->fastyc = d.ndim == 2 && d.dtype == XRFTHIP_C64 && fast_len(d.ny) && fast_len(d.nx) && !d.detrend && (d.out_mode == XRFTHIP_OUT_COMPLEX || d.out_mode == XRFTHIP_OUT_POWER) &&
-                    !(d.flags & ~okc) && !env_ll("XRFTHIP_NO_FAST", 0) && env_ll("XRFTHIP_FASTYC", 1) != 0;
+        const uint32_t okc = XRFTHIP_SHIFT_Y | XRFTHIP_SHIFT_X | (d.out_mode == XRFTHIP_OUT_COMPLEX ? (XRFTHIP_ISHIFT_Y | XRFTHIP_ISHIFT_X | XRFTHIP_INVERSE | XRFTHIP_PHASE_IN | XRFTHIP_C2R_X) : 0u);
+        const bool c2r = (d.flags & XRFTHIP_C2R_X) != 0;  // (irfftn: the half spectrum in, nx real samples per row out; the row transforms have nx/2 points)
+        P->fastyc = d.ndim == 2 && d.dtype == XRFTHIP_C64 && fast_len(d.ny) && (c2r ? (d.nx % 2 == 0 && fast_len(d.nx / 2)) : fast_len(d.nx)) && !d.detrend &&
+                    (d.out_mode == XRFTHIP_OUT_COMPLEX || d.out_mode == XRFTHIP_OUT_POWER) && !(d.flags & ~okc) && !env_ll("XRFTHIP_NO_FAST", 0) && env_ll("XRFTHIP_FASTYC", 1) != 0;
         if (P->fastyc) {
             std::vector<float> ones((size_t)4096, 1.0f);
-            int rcc = build_twiddle<float>(P->tw_fx, d.nx, d.nx);
+            int rcc = build_twiddle<float>(P->tw_fx, c2r ? d.nx / 2 : d.nx, c2r ? d.nx / 2 : d.nx);
+            if (!rcc && c2r) rcc = build_twiddle<float>(P->tw_big1d, d.nx, d.nx / 32);  // W_nx^u, u < (nx/2) / 16
             if (!rcc) rcc = build_twiddle<float>(P->tw_fy, d.ny, d.ny);
             if (!rcc) rcc = P->ones4096.upload(ones.data(), ones.size() * sizeof(float));
             if (rcc) { delete P; return rcc; }
@@ -923,13 +928,16 @@ int xrfthip_plan_create(xrfthip_plan** plan, const xrfthip_desc* desc) {
         P->fastr_cin = !P->fastr && d.ndim == 1 && d.dtype == XRFTHIP_C64 && (d.nx == 16384 || d.nx == 8192 || d.nx == 4096 || d.nx == 2048) && !d.detrend &&
                        (d.out_mode == XRFTHIP_OUT_COMPLEX || d.out_mode == XRFTHIP_OUT_POWER) && !(d.flags & ~okc) && !env_ll("XRFTHIP_NO_FAST", 0) && env_ll("XRFTHIP_FASTC", 1) != 0;
         // rows of 256 .. 4096 points: two rows per thread through one LDS buffer (the row pass of fasty_c2c.h on the input's own rows; XRFTHIP_CROWS=0: fastc_kernel / fastm_xonly_kernel)
-        P->fastr_rows = !P->fastr && d.ndim == 1 && d.dtype == XRFTHIP_C64 && fast_len(d.nx) && !d.detrend && (d.out_mode == XRFTHIP_OUT_COMPLEX || d.out_mode == XRFTHIP_OUT_POWER) &&
-                        !(d.flags & ~okc) && !env_ll("XRFTHIP_NO_FAST", 0) && env_ll("XRFTHIP_CROWS", 1) != 0;
+        const bool c2r1 = (d.flags & XRFTHIP_C2R_X) != 0;  // (irfft along the contiguous axis: rows of nx/2 + 1 complex values in, nx real samples out)
+        P->fastr_rows = !P->fastr && d.ndim == 1 && d.dtype == XRFTHIP_C64 && (c2r1 ? (d.nx % 2 == 0 && fast_len(d.nx / 2) && d.out_mode == XRFTHIP_OUT_COMPLEX) : fast_len(d.nx)) && !d.detrend &&
+                        (d.out_mode == XRFTHIP_OUT_COMPLEX || d.out_mode == XRFTHIP_OUT_POWER) && !(d.flags & ~(okc | (d.out_mode == XRFTHIP_OUT_COMPLEX ? XRFTHIP_C2R_X : 0u))) &&
+                        !env_ll("XRFTHIP_NO_FAST", 0) && env_ll("XRFTHIP_CROWS", 1) != 0;
         if (P->fastr_rows) {
             P->fastr = true;
             P->fastr_cin = false;
             std::vector<float> ones((size_t)4096, 1.0f);
-            int rcr = build_twiddle<float>(P->tw_fx, d.nx, d.nx);
+            int rcr = build_twiddle<float>(P->tw_fx, c2r1 ? d.nx / 2 : d.nx, c2r1 ? d.nx / 2 : d.nx);
+            if (!rcr && c2r1) rcr = build_twiddle<float>(P->tw_big1d, d.nx, d.nx / 32);
             if (!rcr) rcr = P->ones4096.upload(ones.data(), ones.size() * sizeof(float));
             if (rcr) { delete P; return rcr; }
         } else
@@ -1379,12 +1387,22 @@ int xrfthip_plan_describe(const xrfthip_plan* plan, char* buf, size_t buflen) {
                 G.thr, (long long)plan->d.ny, (long long)plan->d.nx, G.per_cu, (long long)plan->d.ny / 32, (long long)plan->d.nx / 32, G.lds);
     } else if (plan->fastyc) {
         const YGeomRt C = ycols_geom(plan->d.ny), R = yrows_geom(plan->d.nx);
+        if (plan->d.flags & XRFTHIP_C2R_X) {
+            const YGeomRt R2 = yrows_geom(plan->d.nx / 2);
+            appendf(s, "  [fasty complex] cols: %d thr, %d x 2 adjacent complex columns of the half spectrum (FFT%lld, inverse: conjugate in / out) + one block for the Nyquist column, "
+                       "%d columns/unit -> W2 -> rows: %d thr, %d rows/unit: the half spectrum of a row back to %lld real samples (FFT%lld on the packed row), whole rows out; "
+                       "16 B per point through memory\n", C.thr, C.gxy, (long long)plan->d.ny, 2 * C.gxy, R2.thr, R2.rk, (long long)plan->d.nx, (long long)plan->d.nx / 2);
+        } else
         appendf(s, "  [fasty complex] cols: %d thr, %d x 2 adjacent complex columns (FFT%lld, %s), %d columns/unit -> W2[slab][%lld/%d][nx/%d][%d][%d] -> rows: %d thr, %d rows/unit "
                    "(FFT%lld), whole rows out (scale, %sfftshift); 32 B per point through memory\n",
                 C.thr, C.gxy, (long long)plan->d.ny, (plan->d.flags & XRFTHIP_INVERSE) ? "inverse: conjugate in / out" : "forward", 2 * C.gxy, (long long)plan->d.ny,
                 std::max(1, 16 / (2 * C.gxy)), 2 * C.gxy, std::max(1, 16 / (2 * C.gxy)), 2 * C.gxy, R.thr, R.rk, (long long)plan->d.nx, plan->fph_on ? "phase, " : "");
     } else if (plan->fastr && plan->fastr_rows) {
-        const YGeomRt R = yrows_geom(plan->d.nx);
+        const bool c2r = (plan->d.flags & XRFTHIP_C2R_X) != 0;
+        const YGeomRt R = yrows_geom(c2r ? plan->d.nx / 2 : plan->d.nx);
+        if (c2r) appendf(s, "  [fasty complex rows] one pass: %d thr, %d rows/unit of the row-major half spectrum back to %lld real samples each (FFT%lld on the packed row; two rows per "
+                            "thread through one LDS buffer), whole rows out; 8 algorithmic bytes per sample through memory\n", R.thr, R.rk, (long long)plan->d.nx, (long long)plan->d.nx / 2);
+        else
         appendf(s, "  [fasty complex rows] one pass: %d thr, %d rows/unit of the row-major input (FFT%lld, %s; two rows per thread through one LDS buffer), whole rows out; "
                    "16 algorithmic bytes per point through memory\n", R.thr, R.rk, (long long)plan->d.nx, (plan->d.flags & XRFTHIP_INVERSE) ? "inverse" : "forward");
     } else if (plan->fastr && plan->fastr_cin) {
