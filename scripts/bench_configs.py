@@ -146,6 +146,35 @@ for shape, dt in (((1460, 73, 144), torch.float32), ((1024, 64, 512), torch.floa
     tag, bpp = ("f32" if dt == torch.float32 else "f64"), (8 if dt == torch.float32 else 16)
     add(f"PS over (time, lon) of (time, lat, lon) = {shape} {tag}, linear+hann (non-adjacent axes, fused)", x.numel(), bpp, timeit(lambda: xrft.power_spectrum(da, dim=["time", "lon"], detrend="linear", window="hann")))
     del x, da
+# round 6: inverse transforms and transforms of complex data (csrc/fasty_c2c.h, csrc/fastr.h fastc_kernel); GFFT/s counts the points of the full (real or complex) field
+def spec(shape, real_x=False):
+    """an fftshifted spectrum with centred frequency coordinates (what xrft.fft returns), complex64; real_x: the stored half of the last axis (rfftfreq)"""
+    dims = ("t", "freq_y", "freq_x")[-len(shape):]
+    z = torch.randn(shape, dtype=torch.complex64, device=dev)
+    c = {d: np.fft.fftshift(np.fft.fftfreq(n, 1.0)) for d, n in zip(dims, shape) if d != "t"}
+    if real_x:
+        c["freq_x"] = np.fft.rfftfreq(2 * (shape[-1] - 1), 1.0)
+    return xrft.DataArray(z, dims, c)
+for shape in ((16384, 4096), (131072, 1024), (4096, 16384)):
+    F = spec(shape)
+    add(f"ifft 1-D {shape} complex64", F.data.numel(), 16, timeit(lambda: xrft.ifft(F, dim="freq_x")))
+    del F
+for shape in ((16, 4096, 4096), (64, 2048, 2048), (256, 1024, 1024)):
+    F = spec(shape)
+    add(f"ifft 2-D {shape} complex64", F.data.numel(), 16, timeit(lambda: xrft.ifft(F, dim=["freq_y", "freq_x"])))
+    del F
+for shape in ((16, 4096, 2049), (64, 2048, 1025)):
+    F = spec(shape, real_x=True)
+    nfull = shape[0] * shape[1] * 2 * (shape[2] - 1)
+    add(f"ifft real_dim (irfftn) {shape} complex64 -> real", nfull, 8, timeit(lambda: xrft.ifft(F, dim=["freq_y"], real_dim="freq_x")))
+    del F
+F = spec((16384, 2049), real_x=True)
+add("ifft real_dim 1-D (irfft) (16384, 2049) -> 4096 real samples", 16384 * 4096, 8, timeit(lambda: xrft.ifft(F, dim="freq_x", real_dim="freq_x")))
+del F
+z = torch.randn((16, 4096, 4096), dtype=torch.complex64, device=dev); dz = xrft.DataArray(z, ("t", "y", "x"), {"y": np.arange(4096.), "x": np.arange(4096.)})
+add("fft 2-D of complex data (16,4096,4096) complex64", z.numel(), 16, timeit(lambda: xrft.fft(dz, dim=["y", "x"])))
+add("   power_spectrum of the same", z.numel(), 12, timeit(lambda: xrft.power_spectrum(dz, dim=["y", "x"])))
+del z, dz
 print(f"{'workload':58s} {'GFFT/s':>8s} {'ms':>9s} {'B/pt':>5s} {'frac of 8 TB/s':>15s}  path")
 for name, g, t, bpp, frac, path in rows:
     print(f"{name:58s} {g:8.2f} {t*1e3:9.3f} {bpp:5.0f} {frac:15.3f}  {path}")

@@ -288,8 +288,8 @@ __global__ void __launch_bounds__((YRows<NX>::THR), (YRows<NX>::THR / 128 < 1 ? 
 // samples: a second read of the row, from L2), W_nx^k = W_nx^u W_32^q (nx = 32 NT).  Output: whole rows of nx float32 samples, 16-byte stores.
 // `alone` (nrows > 0): the rows of a row-major half spectrum [rows][M + 1] themselves -- xrft.ifft with real_dim along ONE axis, the contiguous one.
 // ------------------------------------------------------------------------------------------------
-template <int M>
-__global__ void __launch_bounds__((YRows<M>::THR), (YRows<M>::THR / 128 < 1 ? 1 : YRows<M>::THR / 128)) fastyc_rows_c2r_kernel(FastYC p) {
+template <int M, bool ALONE>
+__global__ void __launch_bounds__((YRows<M>::THR), (YRows<M>::THR >= 256 ? 2 : 1)) fastyc_rows_c2r_kernel(FastYC p) {  // (about 150 VGPRs: three waves per SIMD; held to 128 the M = 2048 form spilled 46-112)
     typedef P2<M> G;
     typedef YRows<M> R;
     constexpr int NT = G::NT, GX = R::GX, THR = R::THR, RPU = 2 * GX, GSTR = YLds<M, GX>::GSTR;
@@ -307,43 +307,98 @@ __global__ void __launch_bounds__((YRows<M>::THR), (YRows<M>::THR / 128 < 1 ? 1 
     cf* mine = lds + g * GSTR;
     cf* tw2 = lds + GX * GSTR;
     fill_tw2<M>(tw2, p.tw_x, tid, THR);
-    const bool alone = p.nrows > 0;
+    constexpr bool alone = ALONE;  // (nrows > 0: the rows of the row-major input itself)
     const int upr = p.ny / RPU;
     const int slab = alone ? 0 : (int)blockIdx.x / upr;
     const long long ky0 = alone ? (long long)blockIdx.x * RPU : (long long)(((int)blockIdx.x % upr) * RPU);
     const long long kyr[2] = {alone ? min(ky0 + g, p.nrows - 1) : ky0 + g, alone ? min(ky0 + GX + g, p.nrows - 1) : ky0 + GX + g};
     const cf wu = p.tw_big[u];  // W_nx^u
     const cf* __restrict__ w2s = p.w2 + (size_t)slab * p.ny * ((size_t)p.w2_nxb << p.l_cw);
-    // sample (row, k): the tiled intermediate, or the row-major input itself
-    auto at = [&](long long ky, int k) -> cf {
-        if (alone) {
-            cf v = p.w2[(size_t)ky * (M + 1) + k];
-            if (p.ph_in) v = cmul(v, p.ph_x[k]);
-            return v;
-        }
-        return cconj(w2s[w2c_offset(p, (int)ky, k)]);  // (pass 1 of an inverse plan left conj(IFFT_y X): FFT_y of the conjugated input)
-    };
+    // the rows' samples k = u + NT q once from memory (both rows in flight together; a uniform 64-bit base + 32-bit per-lane byte offsets: scalar-base loads); the
+    // partners X[M - k] are other lanes' samples: they come through the group's LDS buffer (a second read of the row from memory took the pass from 25 to 59 us per
+    // 4096-row slab); the Nyquist sample M rides with lane u = 0
     cf a[16], b[16];
+    cf nyqa = mk<float>(0.f, 0.f), nyqb = nyqa;  // (read by lane u = 0 only; they reach their row through the LDS slot of sample M)
+    if (alone) {  // the row-major input itself: rows of M + 1 complex values
+        const char* __restrict__ base = reinterpret_cast<const char*>(p.w2 + (size_t)ky0 * (M + 1));
+        const unsigned oa = (unsigned)((kyr[0] - ky0) * (M + 1) + u) * 8u, ob = (unsigned)((kyr[1] - ky0) * (M + 1) + u) * 8u;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            a[q] = *reinterpret_cast<const cf*>(base + (oa + (unsigned)(NT * q) * 8u));
+            b[q] = *reinterpret_cast<const cf*>(base + (ob + (unsigned)(NT * q) * 8u));
+        }
+        if (u == 0) { nyqa = *reinterpret_cast<const cf*>(base + (oa + (unsigned)M * 8u)); nyqb = *reinterpret_cast<const cf*>(base + (ob + (unsigned)M * 8u)); }
+        if (p.ph_in) {  // the lag's phase on the source samples, four factors at a time
+#pragma unroll
+            for (int q4 = 0; q4 < 16; q4 += 4) {
+                cf f[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) f[j] = p.ph_x[u + NT * (q4 + j)];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    a[q4 + j] = cmul(a[q4 + j], f[j]);
+                    b[q4 + j] = cmul(b[q4 + j], f[j]);
+                }
+#ifndef XRFT_EMULATE
+                __builtin_amdgcn_sched_barrier(0);
+#endif
+            }
+            if (u == 0) { const cf f = p.ph_x[M]; nyqa = cmul(nyqa, f); nyqb = cmul(nyqb, f); }
+        }
+    } else {  // the tiled intermediate: pass 1 of an inverse plan left conj(IFFT_y X) (FFT_y of the conjugated input)
+        const char* __restrict__ w2c = reinterpret_cast<const char*>(w2s);
+        const unsigned oa = w2c_offset(p, (int)kyr[0], u) * 8u, ob = w2c_offset(p, (int)kyr[1], u) * 8u;
+        if (NT >= (1 << p.l_cw)) {
+            const unsigned qstr = (unsigned)((NT >> p.l_cw) << (p.l_rk + p.l_cw)) * 8u;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                a[q] = cconj(*reinterpret_cast<const cf*>(w2c + (oa + qstr * (unsigned)q)));
+                b[q] = cconj(*reinterpret_cast<const cf*>(w2c + (ob + qstr * (unsigned)q)));
+            }
+        } else {
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                a[q] = cconj(*reinterpret_cast<const cf*>(w2c + w2c_offset(p, (int)kyr[0], u + NT * q) * 8u));
+                b[q] = cconj(*reinterpret_cast<const cf*>(w2c + w2c_offset(p, (int)kyr[1], u + NT * q) * 8u));
+            }
+        }
+        if (u == 0) { nyqa = cconj(w2s[w2c_offset(p, (int)kyr[0], M)]); nyqb = cconj(w2s[w2c_offset(p, (int)kyr[1], M)]); }
+    }
+    __syncthreads();  // (the twiddle table's writers and, in a later use, the buffer's previous readers)
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
         cf* z = t ? b : a;
-        cf pr[16];
+        cf wut = wu;  // (opaque per row: shared between the two rows, the sixteen twiddles W_nx^k stayed live beside both rows' 64 registers -- 112 spilled at M = 2048)
+        XRFT_OPAQUE(wut.re);
+        XRFT_OPAQUE(wut.im);
 #pragma unroll
-        for (int q = 0; q < 16; ++q) {
-            const int k = u + NT * q, pk = M - k;  // (u = 0, q = 0: the Nyquist sample M)
-            z[q] = at(kyr[t], k);
-            pr[q] = at(kyr[t], pk);
-        }
+        for (int q = 0; q < 16; ++q) mine[nat16(u + NT * q)] = z[q];
+        if (u == 0) mine[nat16(M)] = t ? nyqb : nyqa;  // (slot M + M/16: inside the group's buffer of M + 256 elements)
+        __syncthreads();
 #pragma unroll
-        for (int q = 0; q < 16; ++q) {
-            const cf x = z[q], pc = cconj(pr[q]);
-            const cf e = mk<float>(x.re + pc.re, x.im + pc.im), d = mk<float>(x.re - pc.re, x.im - pc.im);  // 2E, X - conj P
-            // conj(W_nx^k) = conj(W_nx^u W_32^q)
-            const cf w = cconj(cmul(wu, mk<float>(C32[q], -S32[q])));
-            const cf o = cmul(d, w);                                  // 2 O
-            const cf zz = mk<float>(e.re - o.im, e.im + o.re);        // 2 (E + i O)
-            z[q] = cconj(zz);                                         // the inverse transform as conj(FFT(conj Z))
+        for (int h = 0; h < 2; ++h) {  // (eight partners at a time: sixteen beside the two rows' 64 registers spilled 38 at M = 2048)
+            cf pr[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int k = u + NT * (8 * h + j);
+                pr[j] = mine[nat16(M - k)];
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int q = 8 * h + j;
+                const cf x = z[q], pc = cconj(pr[j]);
+                const cf e = mk<float>(x.re + pc.re, x.im + pc.im), d = mk<float>(x.re - pc.re, x.im - pc.im);  // 2E, X - conj P
+                // conj(W_nx^k) = conj(W_nx^u W_32^q)
+                const cf w = cconj(cmul(wut, mk<float>(C32[q], -S32[q])));
+                const cf o = cmul(d, w);                                  // 2 O
+                const cf zz = mk<float>(e.re - o.im, e.im + o.re);        // 2 (E + i O)
+                z[q] = cconj(zz);                                         // the inverse transform as conj(FFT(conj Z))
+            }
+#ifndef XRFT_EMULATE
+            __builtin_amdgcn_sched_barrier(0);  // (nothing is scheduled across: the batches' partners and twiddles do not pile up beside the rows' 64 registers)
+#endif
         }
+        __syncthreads();
     }
     fft_p2_pair<M>(a, b, u, mine, p.tw_x, tw2);
     // GX rows at a time staged in natural order; z[n] = conj(result[n]): x[2n] = re, x[2n + 1] = -im

@@ -550,7 +550,7 @@ int run_fastyc(const xrfthip_plan* P, const void* in, void* out, char* ws, hipSt
         rec = prof_begin(P, "fastyc_rows", st);
         const dim3 gridr((unsigned)(gc * (d.ny / R.rk))), blkr((unsigned)R.thr);
 #define YCR_(NN) do { auto k = &fastyc_rows_kernel<NN>; XRFT_LAUNCH(k, gridr, blkr, R.lds, st, p); } while (0)
-#define YC2_(NN) do { auto k = &fastyc_rows_c2r_kernel<NN>; XRFT_LAUNCH(k, gridr, blkr, R.lds, st, p); } while (0)
+#define YC2_(NN) do { auto k = &fastyc_rows_c2r_kernel<NN, false>; XRFT_LAUNCH(k, gridr, blkr, R.lds, st, p); } while (0)
         if (c2r) { if (nxt == 2048) YC2_(2048); else if (nxt == 1024) YC2_(1024); else if (nxt == 512) YC2_(512); else YC2_(256); }
         else if (d.nx == 4096) YCR_(4096); else if (d.nx == 2048) YCR_(2048); else if (d.nx == 1024) YCR_(1024); else if (d.nx == 512) YCR_(512); else YCR_(256);
 #undef YCR_
@@ -572,7 +572,8 @@ void set_attrs_fasty() {
 #undef SETY
 #define SETC(NN) SETF((fastyc_cols_kernel<NN>)); SETF((fastyc_rows_kernel<NN>))
     SETC(4096); SETC(2048); SETC(1024); SETC(512); SETC(256);
-    SETF((fastyc_rows_c2r_kernel<2048>)); SETF((fastyc_rows_c2r_kernel<1024>)); SETF((fastyc_rows_c2r_kernel<512>)); SETF((fastyc_rows_c2r_kernel<256>));
+    SETF((fastyc_rows_c2r_kernel<2048, false>)); SETF((fastyc_rows_c2r_kernel<1024, false>)); SETF((fastyc_rows_c2r_kernel<512, false>)); SETF((fastyc_rows_c2r_kernel<256, false>));
+    SETF((fastyc_rows_c2r_kernel<2048, true>)); SETF((fastyc_rows_c2r_kernel<1024, true>)); SETF((fastyc_rows_c2r_kernel<512, true>)); SETF((fastyc_rows_c2r_kernel<256, true>));
 #undef SETC
 #define SETI(NN) SETF((fasty_isorows_kernel<NN, 1, false>)); SETF((fasty_isorows_kernel<NN, 2, false>)); SETF((fasty_isorows_kernel<NN, 1, true>)); SETF((fasty_isorows_kernel<NN, 2, true>))
     SETI(4096); SETI(2048); SETI(1024);

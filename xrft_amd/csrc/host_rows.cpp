@@ -107,7 +107,7 @@ int run_fastr(const xrfthip_plan* P, const void* in, void* out, hipStream_t st) 
         xrfthip_plan::ProfRec* rec = prof_begin(P, "fastyc_rows", st);
         const dim3 gridr((unsigned)((d.batch + R.rk - 1) / R.rk)), blkr((unsigned)R.thr);
 #define YCR_(NN) do { auto k = &fastyc_rows_kernel<NN>; XRFT_LAUNCH(k, gridr, blkr, R.lds, st, p); } while (0)
-#define YC2_(NN) do { auto k = &fastyc_rows_c2r_kernel<NN>; XRFT_LAUNCH(k, gridr, blkr, R.lds, st, p); } while (0)
+#define YC2_(NN) do { auto k = &fastyc_rows_c2r_kernel<NN, true>; XRFT_LAUNCH(k, gridr, blkr, R.lds, st, p); } while (0)
         if (c2r) { if (nxt == 2048) YC2_(2048); else if (nxt == 1024) YC2_(1024); else if (nxt == 512) YC2_(512); else YC2_(256); }
         else if (d.nx == 4096) YCR_(4096); else if (d.nx == 2048) YCR_(2048); else if (d.nx == 1024) YCR_(1024); else if (d.nx == 512) YCR_(512); else YCR_(256);
 #undef YCR_

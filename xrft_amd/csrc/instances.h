@@ -25,7 +25,9 @@ XRFT_KI_Y_(256) XRFT_KI_Y_(512) XRFT_KI_Y_(1024) XRFT_KI_Y_(2048) XRFT_KI_Y_(409
 #define XRFT_KI_YC_(NN) XRFT_KW void fastyc_cols_kernel<NN>(FastYC); XRFT_KW void fastyc_rows_kernel<NN>(FastYC);
 XRFT_KI_YC_(256) XRFT_KI_YC_(512) XRFT_KI_YC_(1024) XRFT_KI_YC_(2048) XRFT_KI_YC_(4096)
 #undef XRFT_KI_YC_
-XRFT_KW void fastyc_rows_c2r_kernel<256>(FastYC); XRFT_KW void fastyc_rows_c2r_kernel<512>(FastYC); XRFT_KW void fastyc_rows_c2r_kernel<1024>(FastYC); XRFT_KW void fastyc_rows_c2r_kernel<2048>(FastYC);
+#define XRFT_KI_Y2_(NN) XRFT_KW void fastyc_rows_c2r_kernel<NN, false>(FastYC); XRFT_KW void fastyc_rows_c2r_kernel<NN, true>(FastYC);
+XRFT_KI_Y2_(256) XRFT_KI_Y2_(512) XRFT_KI_Y2_(1024) XRFT_KI_Y2_(2048)
+#undef XRFT_KI_Y2_
 #define XRFT_KI_YI_(NN) XRFT_KW void fasty_isorows_kernel<NN, 1, false>(FastY); XRFT_KW void fasty_isorows_kernel<NN, 2, false>(FastY); \
     XRFT_KW void fasty_isorows_kernel<NN, 1, true>(FastY); XRFT_KW void fasty_isorows_kernel<NN, 2, true>(FastY);
 XRFT_KI_YI_(1024) XRFT_KI_YI_(2048) XRFT_KI_YI_(4096)
