@@ -30,5 +30,5 @@ timeout 300 python3 bench.py --gpus 1 --steps 50 --warmup 5 --workload c2 --cpu-
 for w in c4 c5; do
   timeout 300 python3 bench.py --gpus 1 --steps 10 --warmup 3 --workload $w --cpu-slabs 0 > $O/bench_$w.json 2> $O/bench_$w.err; echo "bench $w rc=$?"
 done
-timeout 900 python3 scripts/bench_configs.py > $O/bench_configs.txt 2>&1; echo "configs rc=$?"
+timeout 1500 python3 scripts/bench_configs.py > $O/bench_configs.txt 2>&1; echo "configs rc=$?"
 timeout 300 python3 scripts/host_overhead.py > $O/host_overhead.txt 2>&1; echo "host rc=$?"
