@@ -491,7 +491,8 @@ def test_one_axis_not_contiguous_fast_kernel(shape, dtype):
 
 
 @pytest.mark.parametrize("shape,dtype", [((5, 360), "float64"), ((3, 7, 256), "float32"), ((9, 1000), "float32"), ((2, 1440), "float64"), ((1, 2048), "float32"),
-                                         ((6, 100), "float64"), ((4, 128), "float32"), ((3, 1200), "float64"), ((3, 4096), "float32"), ((2, 2048), "float64")])
+                                         ((6, 100), "float64"), ((4, 128), "float32"), ((3, 1200), "float64"), ((3, 4096), "float32"), ((2, 2048), "float64"),
+                                         ((5, 512), "float32"), ((33, 1024), "float32")])
 def test_short_contiguous_axis_fast_kernel(shape, dtype):
     """fastm_xonly_kernel (csrc/fastm.h): fft / power_spectrum along the last axis, rows packed in pairs."""
     cases.run_xonly_fast_cases(shape, dtype)

@@ -861,7 +861,8 @@ def test_one_axis_not_contiguous_fast_kernel(shape, dtype):
 
 @pytest.mark.parametrize("shape,dtype", [((1001, 360), "float64"), ((64, 33, 256), "float32"), ((999, 1000), "float32"), ((130, 1440), "float64"), ((77, 2048), "float32"),
                                          ((4096, 100), "float64"), ((513, 128), "float32"), ((257, 1200), "float64"), ((300, 1024), "float64"), ((301, 512), "float32"),
-                                         ((50, 720), "float32"), ((51, 960), "float64"), ((1, 480), "float32"), ((37, 4096), "float32"), ((18, 4096), "float64"), ((9, 2048), "float64")])
+                                         ((50, 720), "float32"), ((51, 960), "float64"), ((1, 480), "float32"), ((37, 4096), "float32"), ((18, 4096), "float64"), ((9, 2048), "float64"),
+                                         ((4097, 1024), "float32"), ((1, 512), "float32")])
 def test_short_contiguous_axis_fast_kernel(shape, dtype):
     """fastm_xonly_kernel (csrc/fastm.h): fft / power_spectrum along the last axis, rows packed in pairs."""
     cases.run_xonly_fast_cases(shape, dtype)
