@@ -58,8 +58,10 @@ def timed(fn, units, reps=5, label=""):
 
 
 def line(label, wall_us, kern, pts_per_unit):
-    ks = " ".join(f"{k.replace('fasty_', '').replace('fastm_', 'm.')} {v:6.2f}" for k, v in kern.items())
-    print(f"  {label:58s} wall {wall_us:7.2f} us = {pts_per_unit / wall_us / 1e3:6.1f} GFFT/s | {ks}", flush=True)
+    ks = " ".join(f"{k.replace('fasty_', '').replace('fastm_', 'm.')} {v:6.4g}" for k, v in kern.items())
+    tot = sum(kern.values())  # (the kernels alone, HIP events: what a call costs when the host keeps the queue full)
+    kg = f" = {pts_per_unit / tot / 1e3:6.1f} GFFT/s by the kernels" if tot > 0 else ""
+    print(f"  {label:58s} wall {wall_us:7.4g} us = {pts_per_unit / wall_us / 1e3:6.1f} GFFT/s | {ks}{kg}", flush=True)
 
 
 def make(shape, dtype="float32", two=False, trend=True, freq=False):

@@ -1689,3 +1689,41 @@ def run_nan_in_isotropic_spectra():
             g = np.asarray(fn().values)
             assert np.all(np.isnan(g[1])), (shape, dt)
             assert np.all(np.isfinite(g[0])) and np.all(np.isfinite(g[2])), (shape, dt)
+
+
+def run_small_slab_walk_cases(shapes=((7, 256, 256), (5, 128, 256), (9, 64, 64)), grid="2"):
+    """csrc/fasts.h with a resident set of workgroups walking the slabs (XRFTHIP_FASTS_GRID: what a long batch of 256 x 256 slabs gets by default): every
+    workgroup asks for its next slab while the staged rows of the current one leave.  Power spectrum, its radial sums and the complex form (which does
+    not prefetch) against the oracle, and bit for bit against the one-workgroup-per-slab launch."""
+    import os
+    rng = np.random.default_rng(77)
+    worst = 0.0
+    old = os.environ.get("XRFTHIP_FASTS_GRID")
+    try:
+        for shape in shapes:
+            nt, ny, nx = shape
+            v = (rng.standard_normal(shape) * (1.0 + np.arange(nt))[:, None, None] + 0.02 * np.arange(ny)[None, :, None] - 0.01 * np.arange(nx)[None, None, :] + 2.0).astype("float32")
+            c = {"t": np.arange(nt), "y": np.arange(ny) * 0.5, "x": np.arange(nx) * 0.25}
+            da, od = pair(v, ("t", "y", "x"), c)
+            res = {}
+            for g in ("0", grid):
+                os.environ["XRFTHIP_FASTS_GRID"] = g
+                xa.api.clear_plan_cache()
+                ps = xa.power_spectrum(da, dim=["y", "x"], detrend="linear", window="hann")
+                assert "[fasts]" in next(reversed(xa.api._plan_cache.values())).describe()
+                iso = xa.isotropic_power_spectrum(da, dim=["y", "x"], detrend="constant", window="hann")
+                ft = xa.fft(da, dim=["y", "x"], detrend="linear")
+                res[g] = (np.asarray(ps.values), np.asarray(iso.values), np.asarray(ft.values))
+                if g != "0":
+                    worst = max(worst, check(ps, o.power_spectrum(od, dim=["y", "x"], detrend="linear", window="hann"), 3e-4))
+                    worst = max(worst, check(iso, o.isotropic_power_spectrum(od, dim=["y", "x"], detrend="constant", window="hann"), 3e-4))
+                    worst = max(worst, check(ft, o.fft(od, dim=["y", "x"], detrend="linear"), 3e-4))
+            for a_, b_ in zip(res["0"], res[grid]):
+                assert np.array_equal(a_, b_)
+    finally:
+        if old is None:
+            os.environ.pop("XRFTHIP_FASTS_GRID", None)
+        else:
+            os.environ["XRFTHIP_FASTS_GRID"] = old
+        xa.api.clear_plan_cache()
+    return worst

@@ -763,3 +763,8 @@ def test_complex_slabs_through_the_two_pass_pipeline(ny, nx, variant):
 def test_half_spectra_back_to_real_fields_through_the_two_pass_pipeline(ny, nx, variant):
     """csrc/fasty_c2c.h on the emulator: irfftn (the Nyquist column's extra block in pass 1, the c2r row pass) and irfft along the contiguous axis."""
     cases.run_c2r_two_pass_cases(ny, nx, nt=2 if ny * nx <= (1 << 20) else 1, variant=variant)
+
+
+def test_small_slabs_walked_by_a_resident_set():
+    """csrc/fasts.h: a resident set of workgroups with the next slab's loads in flight beside the stores (the default for long batches of 256 x 256 slabs)."""
+    cases.run_small_slab_walk_cases(shapes=((5, 256, 256), (5, 128, 256), (7, 64, 64)))

@@ -1153,3 +1153,10 @@ def test_complex_slabs_through_the_two_pass_pipeline(ny, nx, variant):
 def test_half_spectra_back_to_real_fields_through_the_two_pass_pipeline(ny, nx, variant):
     """csrc/fasty_c2c.h: xrft.ifft with real_dim (irfftn) of float32 half spectra, and irfft along the contiguous axis, against the oracle."""
     cases.run_c2r_two_pass_cases(ny, nx, nt=3 if ny * nx <= (1 << 22) else 2, variant=variant)
+
+
+def test_small_slabs_walked_by_a_resident_set():
+    """csrc/fasts.h: a resident set of workgroups with the next slab's loads in flight beside the stores; forced grids here, and the default rule of a long batch
+    of 256 x 256 slabs (4 x 256 workgroups' worth) against the first and last slabs of the oracle."""
+    cases.run_small_slab_walk_cases()
+    cases.run_small_slab_walk_cases(shapes=((700, 256, 256),), grid="256")

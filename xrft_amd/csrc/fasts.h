@@ -142,14 +142,77 @@ __global__ void __launch_bounds__((SGeom<RY, RX>::T), (SGeom<RY, RX>::WPS)) fast
     cf* L = reinterpret_cast<cf*>(smem_raw);
     float* Lf = reinterpret_cast<float*>(smem_raw);
     double* red = reinterpret_cast<double*>(smem_raw + (ISO ? G::LDS_ISO : G::LDS) - (size_t)G::NW * 3 * 8);  // [waves][3]
-    for (long long slab = blockIdx.x; slab < p.nslabs; slab += gridDim.x) {
+    // The power-spectrum forms (PRE) leave a slab's staged rows in the LDS and emit them at the TOP of the next trip, behind the loads of the next slab:
+    // a resident set walking the slabs (gridDim.x < nslabs; the default for long batches of 256 x 256 slabs, ONE workgroup per CU) has the 256 KB of loads
+    // in flight beside the 256 KB of stores, and no register value crosses the loop's back edge.  (The complex form stages its result in halves and
+    // emits it in place.)
+    constexpr bool PRE = MODE == 1;
+    // ---- the staged rows of slab `sl` leave: radial sums, then every output row whole
+    auto emit = [&](long long sl) {
+        int tid = threadIdx.x;
+        XRFT_OPAQUE(tid);
+        if (ISO) {
+            // Radial sums straight from the staged rows.  In row ky the bin b of a radial map covers |kx| in [first[ky][b], first[ky][b + 1]):
+            // the samples kx = |kx| and kx = NX - |kx|; a row 0 < ky < NY/2 counts twice (its Hermitian twin -ky has the same power and bins).
+            // Task = (bin, chunk of rows): float64 sums in sample order, then the chunks of a bin in chunk order: bit-reproducible.
+            const int nb = p.nbins;
+            int rcn = T / nb;
+            rcn = rcn < 1 ? 1 : (rcn > NROW + 1 ? NROW + 1 : rcn);
+            double* part = reinterpret_cast<double*>(smem_raw + G::EFA);  // [rcn][nb]
+            if (tid < nb * rcn) {
+                const int bn = tid % nb, rc = tid / nb;
+                double acc = 0.0;
+                for (int ky = rc; ky <= NROW; ky += rcn) {
+                    const unsigned short* __restrict__ fr = p.tfirst + (size_t)ky * (nb + 1) + bn;
+                    const int s = fr[0], e = fr[1];
+                    const float* r = Lf + ky * PF;
+                    double rs = 0.0;
+                    const int e1 = e < NX / 2 + 1 ? e : NX / 2 + 1;
+                    for (int m = s; m < e1; ++m) rs += (double)r[m];                       // kx = m
+                    const int ms = s > 1 ? s : 1, me = e < NX / 2 ? e : NX / 2;
+                    for (int m = ms; m < me; ++m) rs += (double)r[NX - m];                 // kx = NX - m
+                    acc += (ky != 0 && ky != NROW) ? 2.0 * rs : rs;
+                }
+                part[rc * nb + bn] = acc;
+            }
+            __syncthreads();
+            if (tid < nb) {
+                double tot = 0.0;
+                for (int rc = 0; rc < rcn; ++rc) tot += part[rc * nb + tid];
+                p.iso[(size_t)sl * nb + tid] = tot;
+            }
+            if (ISO == 2) return;  // (the next slab's first exchange starts with a barrier)
+        }
+        // ---- every output row whole: row ky (<= NY/2) rotated by the fftshift, row NY - ky reversed (F[-ky][-kx] = conj F[ky][kx])
+        float* __restrict__ o = p.out + (size_t)sl * NY * NX;
+        for (int e = tid; e < NY * NX / 4; e += T) {
+            const int orow = e / (NX / 4), ch = e % (NX / 4);  // output row, float4 chunk
+            const int ky = (orow - p.shift_y) & (NY - 1);      // unshifted frequency index of this output row
+            const bool mir = ky > NY / 2;
+            const float* r = Lf + (mir ? NY - ky : ky) * PF;
+            const int kx0 = (4 * ch - p.shift_x) & (NX - 1);  // unshifted kx of the chunk's first sample
+            F4 v;
+            if (!mir) { v.x = r[kx0]; v.y = r[kx0 + 1]; v.z = r[kx0 + 2]; v.w = r[kx0 + 3]; }
+            else { v.x = r[(NX - kx0) & (NX - 1)]; v.y = r[NX - kx0 - 1]; v.z = r[NX - kx0 - 2]; v.w = r[NX - kx0 - 3]; }
+            xrft_store_nt(o + (size_t)orow * NX + 4 * ch, v);
+        }
+    };
+    bool staged = false;
+    long long prev = 0;
+    for (long long slab = blockIdx.x;; slab += gridDim.x) {
+        const bool have = slab < p.nslabs;
         int tid = threadIdx.x;
         XRFT_OPAQUE(tid);  // (nothing derived from the thread index is hoisted out of the slab loop and spilled: fastr.h)
         const int jp = tid % NXP, i0 = tid / NXP;  // packed column, first row
-        const cf* __restrict__ src = reinterpret_cast<const cf*>(p.in + (size_t)slab * NY * NX) + tid;
         cf a[32], b[32];
+        if (have) {  // rows i0 + RY q, columns 2 jp, 2 jp + 1 (a uniform base + 32-bit offsets: no address pairs in registers)
+            const char* __restrict__ base = reinterpret_cast<const char*>(p.in + (size_t)slab * NY * NX);
+            const unsigned off = (unsigned)tid * 8u;
 #pragma unroll
-        for (int q = 0; q < 32; ++q) a[q] = src[q * T];  // rows i0 + RY q, columns 2 jp, 2 jp + 1
+            for (int q = 0; q < 32; ++q) a[q] = *reinterpret_cast<const cf*>(base + (off + (unsigned)(q * T) * 8u));
+        }
+        if (PRE && staged) emit(prev);
+        if (!have) break;
         if (p.detrend) {
             // S0 = sum x, Si = sum (i - ibar) x, Sj = sum (j - jbar) x over the slab, float64.  With u_q = x[i][2jp] + x[i][2jp+1]:
             //   Si = (i0 - ibar) sum u_q + RY sum q u_q,   Sj = (2 jp - jbar) sum u_q + sum x[i][2jp+1]
@@ -368,51 +431,8 @@ __global__ void __launch_bounds__((SGeom<RY, RX>::T), (SGeom<RY, RX>::WPS)) fast
                     }
         }
         __syncthreads();
-        if (ISO) {
-            // Radial sums straight from the staged rows.  In row ky the bin b of a radial map covers |kx| in [first[ky][b], first[ky][b + 1]):
-            // the samples kx = |kx| and kx = NX - |kx|; a row 0 < ky < NY/2 counts twice (its Hermitian twin -ky has the same power and bins).
-            // Task = (bin, chunk of rows): float64 sums in sample order, then the chunks of a bin in chunk order: bit-reproducible.
-            const int nb = p.nbins;
-            int rcn = T / nb;
-            rcn = rcn < 1 ? 1 : (rcn > NROW + 1 ? NROW + 1 : rcn);
-            double* part = reinterpret_cast<double*>(smem_raw + G::EFA);  // [rcn][nb]
-            if (tid < nb * rcn) {
-                const int bn = tid % nb, rc = tid / nb;
-                double acc = 0.0;
-                for (int ky = rc; ky <= NROW; ky += rcn) {
-                    const unsigned short* __restrict__ fr = p.tfirst + (size_t)ky * (nb + 1) + bn;
-                    const int s = fr[0], e = fr[1];
-                    const float* r = Lf + ky * PF;
-                    double rs = 0.0;
-                    const int e1 = e < NX / 2 + 1 ? e : NX / 2 + 1;
-                    for (int m = s; m < e1; ++m) rs += (double)r[m];                       // kx = m
-                    const int ms = s > 1 ? s : 1, me = e < NX / 2 ? e : NX / 2;
-                    for (int m = ms; m < me; ++m) rs += (double)r[NX - m];                 // kx = NX - m
-                    acc += (ky != 0 && ky != NROW) ? 2.0 * rs : rs;
-                }
-                part[rc * nb + bn] = acc;
-            }
-            __syncthreads();
-            if (tid < nb) {
-                double tot = 0.0;
-                for (int rc = 0; rc < rcn; ++rc) tot += part[rc * nb + tid];
-                p.iso[(size_t)slab * nb + tid] = tot;
-            }
-            if (ISO == 2) continue;  // (the next slab's first exchange starts with a barrier)
-        }
-        // ---- every output row whole: row ky (<= NY/2) rotated by the fftshift, row NY - ky reversed (F[-ky][-kx] = conj F[ky][kx])
-        float* __restrict__ o = p.out + (size_t)slab * NY * NX;
-        for (int e = tid; e < NY * NX / 4; e += T) {
-            const int orow = e / (NX / 4), ch = e % (NX / 4);  // output row, float4 chunk
-            const int ky = (orow - p.shift_y) & (NY - 1);      // unshifted frequency index of this output row
-            const bool mir = ky > NY / 2;
-            const float* r = Lf + (mir ? NY - ky : ky) * PF;
-            const int kx0 = (4 * ch - p.shift_x) & (NX - 1);  // unshifted kx of the chunk's first sample
-            F4 v;
-            if (!mir) { v.x = r[kx0]; v.y = r[kx0 + 1]; v.z = r[kx0 + 2]; v.w = r[kx0 + 3]; }
-            else { v.x = r[(NX - kx0) & (NX - 1)]; v.y = r[NX - kx0 - 1]; v.z = r[NX - kx0 - 2]; v.w = r[NX - kx0 - 3]; }
-            xrft_store_nt(o + (size_t)orow * NX + 4 * ch, v);
-        }
+        staged = true;  // (MODE 1: emitted at the top of the next trip)
+        prev = slab;
     }
 }
 

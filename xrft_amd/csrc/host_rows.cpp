@@ -57,7 +57,10 @@ int run_fasts(const xrfthip_plan* P, const void* in, void* out, double* iso, hip
     const SGeomRt G = sgeom(d.ny, d.nx);
     // one workgroup per slab by default: measured against the resident set (kCUs x per_cu workgroups walking the slabs), (16384, 128, 128)
     // linear + Hann 531 vs 425 GFFT/s, (65536, 64, 64) 577 vs 497, 256 x 256 even (profiles/r04_fasts.txt)
-    const long long res = P->tune_sgrid < 0 ? 0 : P->tune_sgrid;
+    // ... except a 256 x 256 power spectrum (ONE 1024-thread workgroup per CU): a resident set that asks for its next slab while the staged rows of the
+    // current one leave (fasts_power_kernel PRE), when every workgroup has several slabs to walk (profiles/r06_fasts_prefetch.txt)
+    const bool walk = G.thr >= 1024 && d.out_mode == XRFTHIP_OUT_POWER && d.batch >= 4LL * kCUs * G.per_cu;
+    const long long res = P->tune_sgrid < 0 ? (walk ? (long long)kCUs * G.per_cu : 0) : P->tune_sgrid;
     const long long g = res > 0 ? std::min<long long>(res, d.batch) : d.batch;
     const dim3 grid((unsigned)std::min<long long>(g, 0x7fffffffLL)), blk((unsigned)G.thr);
     xrfthip_plan::ProfRec* rec = prof_begin(P, "fasts_slab", st);
