@@ -984,7 +984,14 @@ def run_inverse_one_pass_cases(shape=(2, 360, 250), dtype="float64"):
                 Fr, Fro = xa.fft(da, dim=["x"], real_dim="x", **kw), o.fft(od, dim=["x"], real_dim="x", **kw)
                 xa.api._plan_cache.clear()
                 worst = max(worst, check_values(xa.ifft(Fr, dim=["freq_x"], real_dim="freq_x", **kw), o.ifft(Fro, dim=["freq_x"], real_dim="freq_x", **kw), tol))
-                assert any("[fastg rows]" in p.describe() or "[fasty complex rows]" in p.describe() for p in xa.api._plan_cache.values()), kw  # (float32 rows of 512 .. 4096 samples: the c2r row pass)
+                # (float32 rows of 512 .. 4096 samples: the c2r row pass; a table length: two half rows per transform in fastm_xonly_kernel)
+                assert any("[fastg rows]" in p.describe() or "[fasty complex rows]" in p.describe() or "[fastm x-only]" in p.describe() for p in xa.api._plan_cache.values()), kw
+                if shape[1] == 1440 and shape[2] == 720:  # (the C5 grid back from its half spectra, irfftn: both stages on the table kernels -- 361 complex columns, the last block short)
+                    Fn, Fno = xa.fft(da, dim=["y", "x"], real_dim="x", **kw), o.fft(od, dim=["y", "x"], real_dim="x", **kw)
+                    xa.api._plan_cache.clear()
+                    worst = max(worst, check_values(xa.ifft(Fn, dim=["freq_y", "freq_x"], real_dim="freq_x", **kw), o.ifft(Fno, dim=["freq_y", "freq_x"], real_dim="freq_x", **kw), tol))
+                    tags = [p.describe() for p in xa.api._plan_cache.values()]
+                    assert any("[fastm y-only]" in t for t in tags) and any("[fastm x-only]" in t for t in tags), tags
                 Fr2, Fr2o = xa.fft(da, dim=["y"], real_dim="x", **kw), o.fft(od, dim=["y"], real_dim="x", **kw)
                 worst = max(worst, check_values(xa.ifft(Fr2, dim=["freq_y"], real_dim="freq_x", **kw), o.ifft(Fr2o, dim=["freq_y"], real_dim="freq_x", **kw), tol))
     return worst

@@ -689,7 +689,8 @@ def test_last_axis_with_one_awkward_prime(shape, dtype):
     cases.run_rows_rader_cases(shape, dtype)
 
 
-@pytest.mark.parametrize("shape,dtype", [((2, 360, 250), "float64"), ((1, 300, 512), "float32"), ((2, 243, 125), "float32"), ((3, 50, 50), "float64")])
+@pytest.mark.parametrize("shape,dtype", [((2, 360, 250), "float64"), ((1, 300, 512), "float32"), ((2, 243, 125), "float32"), ((3, 50, 50), "float64"),
+                                         ((1, 1440, 720), "float64"), ((2, 360, 240), "float32")])
 def test_inverse_transforms_on_the_one_pass_kernels(shape, dtype):
     """xrft.ifft over two axes as two one-pass stages, over one axis where it lies, small slabs in one pass (csrc/fastg.h)."""
     cases.run_inverse_one_pass_cases(shape, dtype)

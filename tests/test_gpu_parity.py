@@ -1067,7 +1067,7 @@ def test_last_axis_with_one_awkward_prime(shape, dtype):
     cases.run_rows_rader_cases(shape, dtype)
 
 
-@pytest.mark.parametrize("shape,dtype", [((4, 360, 250), "float64"), ((3, 1024, 1024), "float32"), ((5, 243, 125), "float32"), ((30, 50, 50), "float64"), ((2, 1440, 720), "float64")])
+@pytest.mark.parametrize("shape,dtype", [((4, 360, 250), "float64"), ((3, 1024, 1024), "float32"), ((5, 243, 125), "float32"), ((30, 50, 50), "float64"), ((2, 1440, 720), "float64"), ((5, 360, 240), "float32"), ((3, 1000, 2000), "float64")])
 def test_inverse_transforms_on_the_one_pass_kernels(shape, dtype):
     """xrft.ifft over two axes as two one-pass stages, over one axis where it lies, small slabs in one pass (csrc/fastg.h)."""
     cases.run_inverse_one_pass_cases(shape, dtype)

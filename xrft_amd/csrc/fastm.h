@@ -168,6 +168,7 @@ struct FastM {
     int half;            // real_dim: only kx = 0..nx/2 is stored, rows of nx/2 + 1 samples, unshifted along x (xrft.py:400-404)
     int realdim2;        // ... and 0 < kx < nx/2 counts twice (xrft.py:673-682)
     int ph_on;
+    int c2r;             // x-only kernel: irfft along the contiguous axis (XRFTHIP_C2R_X) -- rows of n/2 + 1 complex values in, n real samples out, TWO rows per transform (C = A + i B)
     int inv, ishift_in, ph_in;  // x-only kernel, complex input: an inverse transform (xrft.ifft along the contiguous axis, xrft.py:479-646) = conj(FFT(conj z)); source sample
                                 // (x + ishift_in) mod n feeds position x (the ifftshift of an fftshifted spectrum); ph_x multiplies the INPUT at its source position (the lag's phase, :574-576)
     int ny, nx, nrow_pad;
@@ -447,8 +448,9 @@ __global__ void __launch_bounds__((MYGeom<T, NY>::type::THR), (MYGeom<T, NY>::ty
     const int per = (p.nunits + 7) >> 3, xcd = blockIdx.x & 7, jb = blockIdx.x >> 3;
     const int unit = xcd * per + jb;
     if (jb >= per || unit >= p.nunits) return;
-    const int nxb = p.nx / CW, slab = unit / nxb, xb = unit % nxb;
+    const int nxb = CIN ? (p.nx + CW - 1) / CW : p.nx / CW, slab = unit / nxb, xb = unit % nxb;  // (complex columns: the last block of a slab may be short)
     mr_fill_tw1<T, NY>(tw1, reinterpret_cast<const CT*>(p.tw_y), tid, THR);
+    const bool colin = !CIN || xb * CW + g < p.nx;
     const bool on = r0 < M::B0;
     const int j = on ? r0 : 0;
     const CT w0 = reinterpret_cast<const CT*>(p.tw_y)[j];
@@ -463,7 +465,7 @@ __global__ void __launch_bounds__((MYGeom<T, NY>::type::THR), (MYGeom<T, NY>::ty
 #pragma unroll
     for (int q = 0; q < R0; ++q) {
         a[q] = mk<T>((T)0, (T)0); wyv[q] = (T)0;
-        if (on) {
+        if (on && colin) {
             if (TWO) a[q] = mk<T>(*reinterpret_cast<const T*>(src + (off0 + rstep * (size_t)q)), *reinterpret_cast<const T*>(srcb + (off0 + rstep * (size_t)q)));
             else if (CIN && (p.inv | p.ishift_in | p.ph_in)) {  // an inverse transform along the axis (xrft.ifft, xrft.py:479-646): the fftshifted input rotated, the lag's phase on the input, conj in
                 int rs = j + q * M0 + p.ishift_in; if (rs >= NY) rs -= NY;
@@ -520,6 +522,7 @@ __global__ void __launch_bounds__((MYGeom<T, NY>::type::THR), (MYGeom<T, NY>::ty
     if (CIN) {  // every frequency of every column, no mirror
         for (int l = tid; l < CW * NY; l += THR) {
             const int col = l % CW, k = l / CW;
+            if (xb * CW + col >= p.nx) continue;
             CT o = lds[col * STR + M::pn(k)];
             if (p.inv) o.im = -o.im;
             int rd = k + p.shift_y; if (rd >= NY) rd -= NY;
@@ -583,7 +586,10 @@ __global__ void __launch_bounds__((MGeom<T, N>::THR), (MGeom<T, N>::WPS)) fastm_
     const bool DET = p.detrend != 0;  // cross spectrum / cross phase: row r of field 0 and of field 1 are the two halves of a sequence
     constexpr int G = M::G, THR = M::THR, STR = M::STR, R0 = M::R0, M0 = M::M0;
     const bool CIN = !TWO && p.cin != 0;           // complex input: row r IS sequence r
-    const int RPW = (TWO || CIN) ? G : 2 * G;     // rows per workgroup
+    // irfft (xrft.ifft with real_dim, xrft.py:612-621): the Hermitian extensions A, B of TWO stored half rows travel as one sequence C = A + i B; its
+    // inverse transform z = conj(FFT(conj C)) holds row a in its real part and row b in its imaginary part
+    const bool C2R = CIN && p.c2r != 0;
+    const int RPW = (TWO || (CIN && !C2R)) ? G : 2 * G;     // rows per workgroup
     XRFT_DYN_SMEM(smem_raw);
     CT* lds = reinterpret_cast<CT*>(smem_raw);
     CT* tw1 = lds + G * STR;
@@ -594,7 +600,7 @@ __global__ void __launch_bounds__((MGeom<T, N>::THR), (MGeom<T, N>::WPS)) fastm_
     const bool on = r0 < M::B0;
     const int j = on ? r0 : 0;
     const CT w0 = reinterpret_cast<const CT*>(p.tw_x)[j];
-    const long long ra = (TWO || CIN) ? row0 + g : row0 + 2 * g, rb = (TWO || CIN) ? ra : ra + 1;
+    const long long ra = (TWO || (CIN && !C2R)) ? row0 + g : row0 + 2 * g, rb = (TWO || (CIN && !C2R)) ? ra : ra + 1;
     const bool ha = on && ra < nrows, hb = on && rb < nrows;
     const CT* __restrict__ sc_in = reinterpret_cast<const CT*>(p.in) + (size_t)(ha ? ra : 0) * N;  // (complex input)
     const T* __restrict__ sa = reinterpret_cast<const T*>(p.in) + (size_t)(ha ? ra : 0) * N;
@@ -605,7 +611,16 @@ __global__ void __launch_bounds__((MGeom<T, N>::THR), (MGeom<T, N>::WPS)) fastm_
 #pragma unroll
     for (int q = 0; q < R0; ++q) {
         const int x = j + q * M0;
-        if (CIN) {
+        if (C2R) {
+            constexpr int HW = N / 2 + 1;
+            const int xs = 2 * x <= N ? x : N - x;  // the stored sample; beyond n/2 its conjugate
+            CT A = ha ? (reinterpret_cast<const CT*>(p.in) + (size_t)ra * HW)[xs] : mk<T>((T)0, (T)0);
+            CT B = hb ? (reinterpret_cast<const CT*>(p.in) + (size_t)rb * HW)[xs] : mk<T>((T)0, (T)0);
+            if (p.ph_in) { const CT f = reinterpret_cast<const CT*>(p.ph_x)[xs]; A = cmul(A, f); B = cmul(B, f); }
+            if (x == 0 || 2 * x == N) { A.im = (T)0; B.im = (T)0; }  // (numpy's irfft takes the real parts of the zero-frequency and Nyquist samples)
+            if (2 * x > N) { A.im = -A.im; B.im = -B.im; }
+            a[q] = mk<T>(A.re - B.im, -(A.im + B.re));  // conj(A + i B)
+        } else if (CIN) {
             int xs = x + p.ishift_in; if (xs >= N) xs -= N;
             CT z = ha ? sc_in[xs] : mk<T>((T)0, (T)0);
             if (p.ph_in) z = cmul(z, reinterpret_cast<const CT*>(p.ph_x)[xs]);
@@ -653,13 +668,19 @@ __global__ void __launch_bounds__((MGeom<T, N>::THR), (MGeom<T, N>::WPS)) fastm_
     if (on) mr_pass0<T, N>(a, lds + g * STR, j, w0);
     mr_fft_tail<T, N, G, THR>(lds, tid, tw1);
     // split and store: lanes run along k of one row
-    const bool real_out = MODE == 1 || (MODE == 2 && p.angle);
+    const bool real_out = MODE == 1 || (MODE == 2 && p.angle) || C2R;
     const int W = p.half ? N / 2 + 1 : N;
     const T sc = (T)p.scale;
     for (int e = tid; e < RPW * W; e += THR) {
         const int t = e / W, k = e - t * W;
         const long long row = row0 + t;
         if (row >= nrows) break;  // (t grows with e)
+        if (C2R) {  // sample k of row t: Re z (the even row of the pair) or Im z = -Im FFT(conj C)
+            const CT zr = lds[(t >> 1) * STR + M::pn(k)];
+            int ocr = k + p.shift_x; if (ocr >= N) ocr -= N;
+            reinterpret_cast<T*>(p.out)[(size_t)row * N + ocr] = ((t & 1) ? -zr.im : zr.re) * sc;
+            continue;
+        }
         const CT* z = lds + ((TWO || CIN) ? t : (t >> 1)) * STR;
         const CT zk = z[M::pn(k)], zc = cconj(z[M::pn(k == 0 ? 0 : N - k)]);
         CT o;

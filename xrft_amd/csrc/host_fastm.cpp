@@ -638,7 +638,7 @@ int run_fastmy(const xrfthip_plan* P, const void* in, const void* in1, void* out
     p.ny = (int)d.ny; p.nx = (int)d.nx;
     p.detrend = d.detrend; p.nslab = (int)d.batch;
     p.cin = P->cplx_in ? 1 : 0;
-    p.nunits = (int)(d.batch * (d.nx / ((two || P->cplx_in) ? C.g : 2 * C.g)));
+    p.nunits = (int)(d.batch * ((P->cplx_in && !two) ? (d.nx + C.g - 1) / C.g : d.nx / (two ? C.g : 2 * C.g)));  // (complex columns: the last block of a slab may be short)
     p.shift_y = (d.flags & XRFTHIP_SHIFT_Y) ? (int)(d.ny / 2) : 0;
     p.half = (d.flags & XRFTHIP_HALF_X) ? 1 : 0; p.realdim2 = (d.flags & XRFTHIP_REALDIM_X2) ? 1 : 0;
     p.scale = d.scale;
@@ -688,7 +688,8 @@ int run_fastmx(const xrfthip_plan* P, const void* in, const void* in1, void* out
     p.scale = d.scale;
     xrfthip_plan::ProfRec* rec = prof_begin(P, "fastm_xonly", st);
     p.cin = P->cplx_in ? 1 : 0;
-    const int rpw = (two || P->cplx_in) ? C.g : 2 * C.g;
+    p.c2r = (P->cplx_in && (d.flags & XRFTHIP_C2R_X)) ? 1 : 0;  // (irfft rows: two half rows per transform)
+    const int rpw = (two || (P->cplx_in && !p.c2r)) ? C.g : 2 * C.g;
     const dim3 grid((unsigned)((d.batch + rpw - 1) / rpw)), blk((unsigned)C.thr);
 #define MXL_(TT, NN, MM) do { auto k = &fastm_xonly_kernel<TT, NN, MM>; XRFT_LAUNCH(k, grid, blk, C.lds_cols, st, p); } while (0)
 #define MX_(TT, NN) do { \

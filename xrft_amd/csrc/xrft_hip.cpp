@@ -1020,7 +1020,7 @@ int xrfthip_plan_create(xrfthip_plan** plan, const xrfthip_desc* desc) {
                     (d.out_mode == XRFTHIP_OUT_COMPLEX || d.out_mode == XRFTHIP_OUT_POWER || two) && !(d.flags & ~allowed) && fastmy_len(d.ny, P->dbl) &&
                     !((d.flags & XRFTHIP_HALF_X) && (d.flags & XRFTHIP_SHIFT_Y)) &&  // (the half output is unshifted: also refused by xrfthip_plan_create, kept here so the two cannot drift apart)
                     d.batch * d.nx < (1LL << 30) && !env_ll("XRFTHIP_NO_FAST", 0) && env_ll("XRFTHIP_FASTM", 1) != 0;
-        if (P->fastmy && d.nx % (((two || cplx_in) ? 1 : 2) * mygeom(d.ny, P->dbl).g) != 0) P->fastmy = false;
+        if (P->fastmy && !(cplx_in && !two) && d.nx % ((two ? 1 : 2) * mygeom(d.ny, P->dbl).g) != 0) P->fastmy = false;  // (complex columns: any count, the last block guarded)
         if (P->fastmy) {
             int rcm = P->dbl ? build_twiddle<double>(P->tw_fy, d.ny, d.ny) : build_twiddle<float>(P->tw_fy, d.ny, d.ny);
             std::vector<double> ones((size_t)d.ny, 1.0);
@@ -1064,7 +1064,7 @@ int xrfthip_plan_create(xrfthip_plan** plan, const xrfthip_desc* desc) {
     {   // one short transform axis, the contiguous one, real input: rows packed in pairs through the same three passes
         const bool two = d.out_mode == XRFTHIP_OUT_CROSS || d.out_mode == XRFTHIP_OUT_PHASE;
         const uint32_t allowed = XRFTHIP_SHIFT_X | XRFTHIP_HALF_X | (d.out_mode != XRFTHIP_OUT_PHASE ? XRFTHIP_REALDIM_X2 : 0u) | (d.out_mode != XRFTHIP_OUT_POWER ? XRFTHIP_ISHIFT_X : 0u) |
-                                 ((cplx_in && d.out_mode == XRFTHIP_OUT_COMPLEX) ? (XRFTHIP_INVERSE | XRFTHIP_PHASE_IN) : 0u);  // (xrft.ifft along the contiguous axis: conj in, conj out, the input rotated)
+                                 ((cplx_in && d.out_mode == XRFTHIP_OUT_COMPLEX) ? (XRFTHIP_INVERSE | XRFTHIP_PHASE_IN | XRFTHIP_C2R_X) : 0u);  // (xrft.ifft along the contiguous axis: conj in, conj out, the input rotated; irfft: two half rows per transform)
         P->fastmx = !P->fastr && d.ndim == 1 && (!cplx_in || (!two && !(d.flags & (XRFTHIP_HALF_X | XRFTHIP_REALDIM_X2)))) && (d.out_mode == XRFTHIP_OUT_COMPLEX || d.out_mode == XRFTHIP_OUT_POWER || two) &&
                     !(d.flags & ~allowed) && !((d.flags & XRFTHIP_HALF_X) && (d.flags & XRFTHIP_SHIFT_X)) && !((d.flags & XRFTHIP_REALDIM_X2) && !(d.flags & XRFTHIP_HALF_X)) &&
                     fastmx_len(d.nx, P->dbl) && d.batch < (1LL << 31) - 16 && !env_ll("XRFTHIP_NO_FAST", 0) && env_ll("XRFTHIP_FASTM", 1) != 0;
@@ -1303,7 +1303,7 @@ int xrfthip_plan_kernel_info(const xrfthip_plan* plan, int32_t* kind, int32_t* p
     else if (P->fasts) { k = XRFTHIP_K_FASTS; n = 1; }
     else if (P->fastyc) { k = XRFTHIP_K_FASTY; n = 0; }
     else if (P->fastr) { k = XRFTHIP_K_FASTR; n = 1; }
-    else if (P->fastmx) { k = XRFTHIP_K_FASTM_X; const MGeomRt C = mxgeom(P->d.nx, P->dbl); n = (two || P->cplx_in) ? C.g : 2 * C.g; }
+    else if (P->fastmx) { k = XRFTHIP_K_FASTM_X; const MGeomRt C = mxgeom(P->d.nx, P->dbl); n = (two || (P->cplx_in && !(P->d.flags & XRFTHIP_C2R_X))) ? C.g : 2 * C.g; }
     else if (P->fastgy) { k = P->gy_rows ? XRFTHIP_K_FASTG_ROWS : XRFTHIP_K_FASTG_Y; n = ((P->cplx_in || two) ? 1 : 2) * P->gy_G; }
     else if (P->fastmy) { k = XRFTHIP_K_FASTM_Y; const MGeomRt C = mygeom(P->d.ny, P->dbl); n = ((P->cplx_in || two) ? 1 : 2) * C.g; }
     else if (P->fastm) { k = P->fastn ? XRFTHIP_K_FASTN : XRFTHIP_K_FASTM; n = plan_cw(P); }
