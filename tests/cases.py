@@ -1734,3 +1734,48 @@ def run_small_slab_walk_cases(shapes=((7, 256, 256), (5, 128, 256), (9, 64, 64))
             os.environ["XRFTHIP_FASTS_GRID"] = old
         xa.api.clear_plan_cache()
     return worst
+
+
+def run_long_rows_resident_cases(n=32768, nt=600):
+    """Rows of 16384 / 32768 float32 samples in a batch long enough for the resident set of csrc/fastr.h (fastr2_kernel: 256 / 512 workgroups walk the rows,
+    classes of workgroups start a few microseconds apart): fft with and without the true phase, dft, power spectrum -- rows from the start, the middle and
+    the end of the batch against the oracle, and every row bit for bit against the one-workgroup-per-row launch (XRFTHIP_FASTR_GRID=0)."""
+    import os
+    rng = np.random.default_rng(n + nt)
+    v = (rng.standard_normal((nt, n)) + 1.0).astype("float32")
+    c = {"t": np.arange(nt), "x": np.arange(n) * 0.5 + 2.0}
+    da, _ = pair(v, ("t", "x"), c)
+    pick = sorted(set([0, 1, 255, 256, 257, 511, 512, nt // 2, nt - 2, nt - 1]) & set(range(nt)))
+    od = o.OArr(v[pick].astype("float64"), ("t", "x"), {"t": np.arange(len(pick)), "x": c["x"]})
+    calls = ((xa.fft, o.fft, dict(dim=["x"])), (xa.fft, o.fft, dict(dim=["x"], true_phase=False, shift=False)), (xa.dft, o.dft, dict(dim="x")),
+             (xa.power_spectrum, o.power_spectrum, dict(dim=["x"], detrend="linear", window="hann")))
+    worst = 0.0
+    old = {k: os.environ.get(k) for k in ("XRFTHIP_FASTR_GRID", "XRFTHIP_FASTR_STAGGER")}
+    try:
+        res = {}
+        for mode in ("default", "per-row"):
+            if mode == "per-row":
+                os.environ["XRFTHIP_FASTR_GRID"] = "0"
+                os.environ["XRFTHIP_FASTR_STAGGER"] = "0"
+            xa.api.clear_plan_cache()
+            res[mode] = []
+            for fn, ofn, kw in calls:
+                g = fn(da, **kw)
+                assert "[fastr]" in next(reversed(xa.api._plan_cache.values())).describe()
+                gv = np.asarray(g.values)
+                res[mode].append(gv)
+                if mode == "default":
+                    r = np.asarray(ofn(od, **kw).values)
+                    err = float(np.abs(gv[pick] - r).max() / np.abs(r).max())
+                    assert err < 2e-5, (kw, err)
+                    worst = max(worst, err)
+        for a_, b_ in zip(res["default"], res["per-row"]):
+            assert np.array_equal(a_, b_)
+    finally:
+        for k, val in old.items():
+            if val is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = val
+        xa.api.clear_plan_cache()
+    return worst

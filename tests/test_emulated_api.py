@@ -769,3 +769,12 @@ def test_half_spectra_back_to_real_fields_through_the_two_pass_pipeline(ny, nx, 
 def test_small_slabs_walked_by_a_resident_set():
     """csrc/fasts.h: a resident set of workgroups with the next slab's loads in flight beside the stores (the default for long batches of 256 x 256 slabs)."""
     cases.run_small_slab_walk_cases(shapes=((5, 256, 256), (5, 128, 256), (7, 64, 64)))
+
+
+def test_long_rows_walked_by_a_resident_set(monkeypatch):
+    """csrc/fastr.h fastr2_kernel with a resident set of workgroups walking the rows (forced small here: the emulator runs one workgroup at a time)."""
+    monkeypatch.setenv("XRFTHIP_FASTR_GRID", "2")
+    monkeypatch.setenv("XRFTHIP_FASTR_STAGGER", "769")
+    api._plan_cache.clear()
+    cases.run_fourstep_1d(16384, nt=5)
+    api._plan_cache.clear()

@@ -1160,3 +1160,9 @@ def test_small_slabs_walked_by_a_resident_set():
     of 256 x 256 slabs (4 x 256 workgroups' worth) against the first and last slabs of the oracle."""
     cases.run_small_slab_walk_cases()
     cases.run_small_slab_walk_cases(shapes=((700, 256, 256),), grid="256")
+
+
+@pytest.mark.parametrize("n,nt", [(32768, 600), (16384, 1100)])
+def test_long_rows_walked_by_a_resident_set(n, nt):
+    """csrc/fastr.h fastr2_kernel on batches long enough for its resident set + start stagger (the default from 2 x 256 rows of 32768 samples / 4 x 256 of 16384)."""
+    cases.run_long_rows_resident_cases(n, nt)

@@ -180,6 +180,16 @@ __device__ __forceinline__ void fastr_emit(const FastR& p, const cf* a, const cf
 }
 
 // MODE 0: complex spectrum (xrft.fft / dft), 1: power spectrum; HALF: real_dim output, k = 0..N/2
+// start delay of workgroup class c = (block / 8) % classes: c x (stagger & 0xff) sleeps of 127 x 64 cycles (~3.4 us each); classes = stagger >> 8
+__device__ __forceinline__ void fastr_stagger(int stagger) {
+#ifndef XRFT_EMULATE
+    if ((stagger >> 8) > 1) {
+        const int cls = (int)((blockIdx.x >> 3) % (unsigned)(stagger >> 8)), n = cls * (stagger & 0xff);
+        for (int i = 0; i < n; ++i) __builtin_amdgcn_s_sleep(127);
+    }
+#endif
+}
+
 template <int MODE, bool HALF>
 __global__ void __launch_bounds__(kFastRThreads) fastr_kernel(FastR p) {
     constexpr int N = 65536, M = N / 2, T = kFastRThreads;
@@ -191,10 +201,7 @@ __global__ void __launch_bounds__(kFastRThreads) fastr_kernel(FastR p) {
     // One workgroup owns a CU and walks its rows load -> transform -> store with nothing overlapped, and all CUs start together: the chip
     // alternates between memory phases (every CU loading or storing) and a phase in which every CU computes and the memory idles.  Classes of
     // workgroups that start a fraction of a row period apart keep the memory busy while the others transform.
-    if ((p.stagger >> 8) > 1) {
-        const int cls = (int)((blockIdx.x >> 3) % (unsigned)(p.stagger >> 8)), n = cls * (p.stagger & 0xff);
-        for (int i = 0; i < n; ++i) __builtin_amdgcn_s_sleep(127);
-    }
+    fastr_stagger(p.stagger);
 #endif
     for (long long row = blockIdx.x; row < p.nrows; row += gridDim.x) {
         // (everything derived from the thread index is re-derived per row from an opaque copy: hoisted out of the loop, the 62 twiddle
@@ -363,6 +370,7 @@ __global__ void __launch_bounds__((R2Geom<R2, R3>::T), (R2Geom<R2, R3>::WPS)) fa
     XRFT_DYN_SMEM(smem_raw);
     cf* L = reinterpret_cast<cf*>(smem_raw);
     double* red = reinterpret_cast<double*>(smem_raw + G::LDS_MAIN);  // [waves][2]
+    fastr_stagger(p.stagger);  // (a resident set walking the rows: XRFTHIP_FASTR_STAGGER / XRFTHIP_FASTR_GRID)
     for (long long row = blockIdx.x; row < p.nrows; row += gridDim.x) {
         int tid = threadIdx.x;
         XRFT_OPAQUE(tid);
@@ -531,6 +539,7 @@ __global__ void __launch_bounds__((R2Geom<R2, R3>::T), (R2Geom<R2, R3>::WPS)) fa
     constexpr int T = G::T, M = G::M, K2 = G::K2, K3 = G::K3, S1 = G::S1, S2 = G::S2;
     XRFT_DYN_SMEM(smem_raw);
     cf* L = reinterpret_cast<cf*>(smem_raw);
+    fastr_stagger(p.stagger);  // (a resident set walking the rows: XRFTHIP_FASTR_STAGGER / XRFTHIP_FASTR_GRID)
     for (long long row = blockIdx.x; row < p.nrows; row += gridDim.x) {
         int tid = threadIdx.x;
         XRFT_OPAQUE(tid);

@@ -138,6 +138,12 @@ int run_fastr(const xrfthip_plan* P, const void* in, void* out, hipStream_t st) 
         p.ph_on = (d.out_mode == XRFTHIP_OUT_COMPLEX && P->fph_on && !(d.flags & XRFTHIP_PHASE_IN)) ? 1 : 0;
     }
     const long long g = P->tune_rgrid > 0 ? std::min<long long>(P->tune_rgrid, d.batch) : d.batch;
+    if (P->tune_rstagger < 0) {
+        // rows of 32768 / 16384 samples on a resident set: three classes of workgroups 3.4 us apart for a complex result (6.8 us when the true-phase table rides
+        // along: fft (2048, 32768) 275 -> 346 GFFT/s, dft 415 -> 435, fft (4096, 16384) 333 -> 356); a power spectrum gains nothing from a stagger
+        const bool cplx = d.out_mode == XRFTHIP_OUT_COMPLEX && !P->fastr_cin;
+        p.stagger = d.batch < 2 * g ? 0 : (cplx && d.nx == 32768) ? ((3 << 8) | (p.ph_on ? 2 : 1)) : (cplx && d.nx == 16384) ? ((3 << 8) | 1) : 0;
+    }
     const dim3 grid((unsigned)std::min<long long>(g, 0x7fffffffLL)), blk((unsigned)(P->fastr_cin ? d.nx / 32 : d.nx / 64));
     const bool pw = d.out_mode == XRFTHIP_OUT_POWER;
     // profiling (bench.py's roofline.kernel): the start / stop timestamps ride on the kernel's own dispatch packet (hipExtLaunchKernelGGL)

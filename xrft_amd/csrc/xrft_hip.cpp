@@ -944,7 +944,7 @@ int xrfthip_plan_create(xrfthip_plan** plan, const xrfthip_desc* desc) {
         if (P->fastr_cin) {
             P->fastr = true;
             P->tune_rgrid = env_ll("XRFTHIP_FASTR_GRID", 0);
-            P->tune_rstagger = 0;
+            P->tune_rstagger = env_ll("XRFTHIP_FASTR_STAGGER", 0);
             const long long thr = d.nx / 32;  // threads per row: 32 complex values each
             int rcr = build_twiddle<float>(P->tw_rm, d.nx, thr);
             if (!rcr) rcr = build_twiddle<float>(P->tw_rs, thr, 32);
@@ -953,9 +953,10 @@ int xrfthip_plan_create(xrfthip_plan** plan, const xrfthip_desc* desc) {
         if (P->fastr) {
             // 65536 samples: one resident workgroup per CU walks the rows (measured: 359 vs 344 GFFT/s for a workgroup per row, profiles/r04_fastr.txt);
             // the shorter rows (several workgroups per CU): a workgroup per row
-            P->tune_rgrid = env_ll("XRFTHIP_FASTR_GRID", d.nx == 65536 ? kCUs : 0);
-            // two classes of workgroups 10 us apart: dft (1024, 65536) 388 -> 441 GFFT/s, power_spectrum 517 -> 586 (profiles/r06_c2_stagger.txt)
-            P->tune_rstagger = d.nx == 65536 ? env_ll("XRFTHIP_FASTR_STAGGER", (2 << 8) | 3) : 0;
+            // 32768 / 16384 samples (one / two workgroups per CU): a resident set, too -- with the start stagger run_fastr picks (profiles/r06_rows_stagger.txt)
+            P->tune_rgrid = env_ll("XRFTHIP_FASTR_GRID", d.nx == 65536 ? kCUs : (d.nx == 32768 && d.batch >= 2 * kCUs) ? kCUs : (d.nx == 16384 && d.out_mode == XRFTHIP_OUT_COMPLEX && d.batch >= 4 * kCUs) ? 2 * kCUs : 0);
+            // two classes of workgroups 10 us apart: dft (1024, 65536) 388 -> 441 GFFT/s, power_spectrum 517 -> 586 (profiles/r06_c2_stagger.txt); -1: run_fastr's rule
+            P->tune_rstagger = env_ll("XRFTHIP_FASTR_STAGGER", d.nx == 65536 ? ((2 << 8) | 3) : -1);
             const long long thr = d.nx / 64;  // threads per row: 32 packed complex values each
             int rcr = build_twiddle<float>(P->tw_rm, d.nx / 2, thr);
             if (!rcr) rcr = build_twiddle<float>(P->tw_rs, thr, 32);
