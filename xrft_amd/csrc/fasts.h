@@ -46,6 +46,7 @@ struct FastS {
     const cf* ph_y;
     const cf* ph_x;
     int ph_on;
+    int stagger;  // a resident set walking the slabs: start delay of workgroup class c = (block / 8) % classes (fastr.h fastr_stagger; XRFTHIP_FASTS_STAGGER)
 };
 
 constexpr size_t fasts_max(size_t a, size_t b) { return a > b ? a : b; }
@@ -197,6 +198,7 @@ __global__ void __launch_bounds__((SGeom<RY, RX>::T), (SGeom<RY, RX>::WPS)) fast
             xrft_store_nt(o + (size_t)orow * NX + 4 * ch, v);
         }
     };
+    fastr_stagger(p.stagger);
     bool staged = false;
     long long prev = 0;
     for (long long slab = blockIdx.x;; slab += gridDim.x) {

@@ -62,6 +62,7 @@ int run_fasts(const xrfthip_plan* P, const void* in, void* out, double* iso, hip
     const bool walk = G.thr >= 1024 && d.out_mode == XRFTHIP_OUT_POWER && d.batch >= 4LL * kCUs * G.per_cu;
     const long long res = P->tune_sgrid < 0 ? (walk ? (long long)kCUs * G.per_cu : 0) : P->tune_sgrid;
     const long long g = res > 0 ? std::min<long long>(res, d.batch) : d.batch;
+    p.stagger = (res > 0 && d.batch >= 2 * g) ? (int)P->tune_sstagger : 0;
     const dim3 grid((unsigned)std::min<long long>(g, 0x7fffffffLL)), blk((unsigned)G.thr);
     xrfthip_plan::ProfRec* rec = prof_begin(P, "fasts_slab", st);
     const int isom = (d.flags & XRFTHIP_ISO) ? ((d.flags & XRFTHIP_NO_SPECTRUM_OUT) ? 2 : 1) : 0;

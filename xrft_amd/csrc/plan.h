@@ -390,6 +390,7 @@ struct xrfthip_plan {
     // ... and ONE pass for a small real float32 slab that fits the registers of a CU: 256 x 256 power spectra (fasts.h)
     bool fasts = false;
     DevBuf tw_sy, tw_sx, s_tfirst;
+    long long tune_sstagger = 0;  // XRFTHIP_FASTS_STAGGER: classes << 8 | steps of 3.4 us between the classes of a resident set of slab workgroups
     long long tune_sgrid = -1;    // XRFTHIP_FASTS_GRID: workgroups of the launch (0 = one per slab, the default; else a resident set walking the slabs)
     // ... and ONE pass for a long real float32 row that fits the registers of a CU: 65536 samples per workgroup (fastr.h)
     bool fastr = false;

@@ -898,6 +898,7 @@ int xrfthip_plan_create(xrfthip_plan** plan, const xrfthip_desc* desc) {
     if (P->fasts) {  // (takes precedence over the two-pass pipeline wherever the plan is looked at; an isotropic plan whose bin map turns out
                      // not to be a radial one falls back to it: xrfthip_plan_set_binmap)
         P->tune_sgrid = env_ll("XRFTHIP_FASTS_GRID", -1);
+        P->tune_sstagger = env_ll("XRFTHIP_FASTS_STAGGER", (3 << 8) | 2);  // (three classes 6.8 us apart: (4096, 256, 256) linear + Hann 310 -> 320 (the walk) -> 328 GFFT/s, profiles/r06_fasts_prefetch.txt)
         std::vector<float> ones((size_t)256, 1.0f);
         int rcs = build_twiddle<float>(P->tw_sy, d.ny, d.ny);
         if (!rcs) rcs = build_twiddle<float>(P->tw_sx, d.nx, d.nx);
