@@ -44,6 +44,11 @@ add("C2 dft 1-D (1024,65536) f32", x.numel(), 12, timeit(lambda: xrft.dft(da, di
 add("   power_spectrum 1-D (1024,65536) f32", x.numel(), 8, timeit(lambda: xrft.power_spectrum(da, dim="x")))
 add("   power_spectrum 1-D linear+hann (window: slab-shaped table)", x.numel(), 8, timeit(lambda: xrft.power_spectrum(da, dim="x", detrend="linear", window="hann")))
 del x, da
+for shape in ((2048, 32768), (4096, 16384), (8192, 8192)):  # (the shorter register-resident rows: a resident set + start stagger on long batches, profiles/r06_rows_stagger.txt)
+    x = cube(shape, torch.float32); da = xrft.DataArray(x, ("t", "x"), {"x": np.arange(shape[1]) * 0.5})
+    add(f"   dft 1-D {shape} f32", x.numel(), 12, timeit(lambda: xrft.dft(da, dim="x")))
+    add(f"   fft 1-D {shape} f32 (true phase)", x.numel(), 12, timeit(lambda: xrft.fft(da, dim="x")))
+    del x, da
 # C3 variants
 x = cube((32, 4096, 4096), torch.float32); c = {"y": np.arange(4096.), "x": np.arange(4096.)}
 da = xrft.DataArray(x, ("t", "y", "x"), c)
@@ -168,6 +173,13 @@ for shape in ((16, 4096, 2049), (64, 2048, 1025)):
     nfull = shape[0] * shape[1] * 2 * (shape[2] - 1)
     add(f"ifft real_dim (irfftn) {shape} complex64 -> real", nfull, 8, timeit(lambda: xrft.ifft(F, dim=["freq_y"], real_dim="freq_x")))
     del F
+def spec128(shape):  # (the stored half spectrum of a float64 field)
+    z = torch.randn(shape, dtype=torch.complex128, device=dev)
+    return xrft.DataArray(z, ("t", "freq_y", "freq_x"), {"freq_y": np.fft.fftshift(np.fft.fftfreq(shape[1], 1.0)), "freq_x": np.fft.rfftfreq(2 * (shape[2] - 1), 1.0)})
+F = spec128((64, 1440, 361))
+add("ifft real_dim (irfftn) (64, 1440, 361) complex128 -> (64, 1440, 720) float64 (the C5 grid back; both stages on the table kernels)", 64 * 1440 * 720, 16,
+    timeit(lambda: xrft.ifft(F, dim=["freq_y"], real_dim="freq_x")))
+del F
 F = spec((16384, 2049), real_x=True)
 add("ifft real_dim 1-D (irfft) (16384, 2049) -> 4096 real samples", 16384 * 4096, 8, timeit(lambda: xrft.ifft(F, dim="freq_x", real_dim="freq_x")))
 del F
