@@ -73,7 +73,12 @@ def batch_mean_allreduce(local, dim, total, group=None):
         s = engine.reduce_axis(t, ax, 1.0 / float(total))
     else:
         # host-resident data under a CPU backend (they stay where the process group can reduce them), integer / bool data, an empty
-        # shard: the local term on the host, same order and accumulation type (float64, slab order) as the library kernel
+        # shard: the local term on the host, same order and accumulation type (float64, slab order) as the library kernel.
+        # Never for floating-point data on a GPU backend: there the library kernel above is the only path (no torch arithmetic
+        # on the product's data path)
+        if dist.get_backend(group) == "nccl" and (t.is_floating_point() or t.is_complex()) and t.shape[ax] > 0:
+            raise RuntimeError("xrft_amd.dist.batch_mean_allreduce: floating-point data under the nccl backend must be reduced by the HIP library "
+                               f"(tensor on {t.device}, library device type {engine.device_type()!r})")
         acc = torch.complex128 if t.is_complex() else torch.float64
         s = t.to(acc).cumsum(ax).select(ax, -1) if t.shape[ax] > 0 else torch.zeros(t.shape[:ax] + t.shape[ax + 1:], dtype=acc, device=t.device)
         s = (s * (1.0 / float(total))).to(t.dtype if (t.is_floating_point() or t.is_complex()) else torch.float64).contiguous()
