@@ -5,7 +5,8 @@ import subprocess
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 REPO = os.path.dirname(os.path.dirname(HERE))
-OUT = os.path.join(HERE, "_build", "libxrft_emu.so")
+ASAN = os.environ.get("XRFT_EMU_ASAN", "0") not in ("", "0")  # scripts/run_emu_asan.sh: the same library under AddressSanitizer, in a directory of its own
+OUT = os.path.join(HERE, "_build_asan" if ASAN else "_build", "libxrft_emu.so")
 SRC = os.path.join(REPO, "xrft_amd", "csrc")
 
 
@@ -42,13 +43,15 @@ def _compile(obj_dir):
     procs = []
     for src, extra in UNITS:
         obj = os.path.join(obj_dir, os.path.splitext(src)[0] + ".o")
-        cmd = ["g++", "-O1", "-std=c++17", "-fPIC", "-DXRFT_EMULATE", f"-I{HERE}", f"-I{SRC}"] + extra + ["-c", os.path.join(SRC, src), "-o", obj]
+        san = ["-fsanitize=address", "-fno-omit-frame-pointer", "-g1", "-DXRFT_EMU_ASAN"] if ASAN else []
+        cmd = ["g++", "-O1", "-std=c++17", "-fPIC", "-DXRFT_EMULATE", f"-I{HERE}", f"-I{SRC}"] + san + extra + ["-c", os.path.join(SRC, src), "-o", obj]
         procs.append((src, obj, subprocess.Popen(cmd)))
     failed = [src for src, _obj, pr in procs if pr.wait() != 0]
     if failed:
         raise RuntimeError(f"g++ failed on {failed}")
     tmp = OUT + f".{os.getpid()}.tmp"  # (the library appears whole or not at all)
-    subprocess.run(["g++", "-shared", "-fPIC"] + [obj for _src, obj, _pr in procs] + ["-Wl,-z,defs", "-o", tmp, "-lpthread"], check=True)
+    # (-z defs cannot hold under the sanitizer: its runtime is resolved from the preloaded libasan)
+    subprocess.run(["g++", "-shared", "-fPIC"] + (["-fsanitize=address"] if ASAN else []) + [obj for _src, obj, _pr in procs] + ([] if ASAN else ["-Wl,-z,defs"]) + ["-o", tmp, "-lpthread"], check=True)
     os.replace(tmp, OUT)
 
 

@@ -99,10 +99,18 @@ struct Worker {
     void run_block(const std::function<void()>& body, dim3 grid, dim3 block, dim3 bidx, size_t smem_bytes) {
         const size_t nt = (size_t)block.x * block.y * block.z;
         ensure(nt);
-        if (smem.size() < smem_bytes + 64) smem.resize(smem_bytes + 64);
         BlockCtx ctx;
         ctx.blockIdx = bidx; ctx.blockDim = block; ctx.gridDim = grid;
+#ifdef XRFT_EMU_ASAN
+        // the AddressSanitizer build (scripts/run_emu_asan.sh): the workgroup's LDS is an allocation of exactly the launch's dynamic size, so that an access
+        // behind it is a heap-buffer-overflow report instead of a read of a previous launch's bytes
+        void* exact = nullptr;
+        if (posix_memalign(&exact, 64, smem_bytes ? smem_bytes : 64) != 0) abort();
+        ctx.smem = (unsigned char*)exact;
+#else
+        if (smem.size() < smem_bytes + 64) smem.resize(smem_bytes + 64);
         ctx.smem = (unsigned char*)(((uintptr_t)smem.data() + 63) & ~(uintptr_t)63);
+#endif
         ctx.body = &body;
         ctx.shfl = shfl.data();
         tls() = &ctx;
@@ -132,6 +140,9 @@ struct Worker {
             if (live == 0) break;
         }
         tls() = nullptr;
+#ifdef XRFT_EMU_ASAN
+        free(exact);
+#endif
     }
 };
 
