@@ -778,3 +778,20 @@ def test_long_rows_walked_by_a_resident_set(monkeypatch):
     api._plan_cache.clear()
     cases.run_fourstep_1d(16384, nt=5)
     api._plan_cache.clear()
+
+
+def test_caller_buffers_are_held_to_the_plan():
+    """engine.SpectralPlan.execute with a caller's `out` / `iso` (graph capture, composed passes): a buffer of the wrong size, dtype or layout is a
+    ValueError before the library sees its pointer (found with scripts/run_emu_asan.sh: a short buffer was a heap overflow in the kernel's stores)."""
+    import torch
+
+    from xrft_amd import engine
+
+    plan = engine.SpectralPlan(2, 2, 64, 64, torch.float32, out_mode=_lib.OUT_POWER, detrend=_lib.DETREND_LINEAR)
+    x = torch.randn(2, 64, 64)
+    good = torch.empty(2, 64, 64)
+    out, _ = plan.execute(x, out=good)
+    assert out is good
+    for bad in (torch.empty(2 * 64 * 64 - 64), torch.empty(2, 64, 64, dtype=torch.float64), torch.empty(2, 64, 128)[:, :, ::2]):
+        with pytest.raises(ValueError):
+            plan.execute(x, out=bad)

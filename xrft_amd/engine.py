@@ -130,9 +130,16 @@ class SpectralPlan:
             if self.mid > 1:
                 shape = (self.batch, self.ny, self.mid, self.nx_out, self.inner)
             out = torch.empty(shape, dtype=self.out_dtype(), device=dev)
+        elif want_out:  # a caller's buffer (graph capture, composed passes): held to the plan before the device sees its pointer
+            need = self.batch * self.ny_out * self.nx_out * self.inner * self.mid
+            if out.dtype != self.out_dtype() or not out.is_contiguous() or out.numel() != need or out.device != dev:
+                raise ValueError(f"out does not match the plan (dtype {self.out_dtype()}, contiguous, {need} elements on {dev})")
+        iso_dtype = torch.complex128 if self.out_mode == _lib.OUT_CROSS else torch.float64
         if self.flags & _lib.ISO and iso is None:
-            iso = torch.empty((self.batch, self.nbins), device=dev,
-                              dtype=torch.complex128 if self.out_mode == _lib.OUT_CROSS else torch.float64)
+            iso = torch.empty((self.batch, self.nbins), device=dev, dtype=iso_dtype)
+        elif self.flags & _lib.ISO:
+            if iso.dtype != iso_dtype or not iso.is_contiguous() or iso.numel() != self.batch * self.nbins or iso.device != dev:
+                raise ValueError(f"iso does not match the plan (dtype {iso_dtype}, contiguous, {self.batch * self.nbins} elements on {dev})")
         if self.batch == 0:  # nothing to transform: empty outputs, no device call
             return (out if want_out else None), iso
         stream = _stream_handle(in0)
