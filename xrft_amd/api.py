@@ -567,14 +567,16 @@ def _swap_xy(flags):
     return out
 
 
-def _execute_inner(c, da, mode, scale):
+def _execute_inner(c, da, mode, scale, extra_flags=0):
     """Two transform axes that are not the trailing pair, wherever they lie -- dim = ["y", "x"] of a (y, x, time) array, dim = ["t", "x"] of a (t, y, x) array:
     the engine's layout [batch][n0][mid][n1][inner] (xrfthip_desc.inner, .mid: the products of the extents in front of, between and behind the two axes)
     transforms them where they lie, as the reference does (xrft.py:395-409) -- no transposed copy of the input or of the result.  Returns the result in
     the input's dim order, or None when the call is not of this kind (the caller then takes the transposing path)."""
-    if len(c.dim) != 2 or c.real_dim is not None or mode not in (_lib.OUT_COMPLEX, _lib.OUT_POWER):
+    if len(c.dim) != 2 or mode not in (_lib.OUT_COMPLEX, _lib.OUT_POWER):
         return None
     p, q = da.get_axis_num(c.ydim), da.get_axis_num(c.xdim)
+    if c.real_dim is not None and p > q:
+        return None  # (real_dim is the axis that comes FIRST in memory: the half output of the fused passes lies along their second axis)
     first, second = min(p, q), max(p, q)
     if second == first + 1 and second == len(da.dims) - 1:
         return None  # (the trailing pair: the fused two-axis plans)
@@ -588,6 +590,7 @@ def _execute_inner(c, da, mode, scale):
     if (inner < 2 and mid < 2) or mid * inner * shape[second] > (1 << 30) or shape[first] * shape[second] * inner * mid > (1 << 31) - 1:
         return None
     flags, win, ph = _flags_tables(c, da)
+    flags |= extra_flags  # (REALDIM_X2: the kept half of the real axis counts twice in a power spectrum)
     if mode == _lib.OUT_POWER:
         ph = {"y": None, "x": None}
     if p > q:  # the array holds (x, y): the plan's first axis is the one that comes first in memory
@@ -601,6 +604,7 @@ def _execute_inner(c, da, mode, scale):
             return None
         raise
     out, _ = plan.execute(t)
+    shape[second] = plan.nx_out  # (real_dim: nx / 2 + 1 samples along the second axis)
     return out.reshape(shape)
 
 
@@ -610,8 +614,8 @@ def _execute(c, da, mode, scale, da2=None, c2=None, iso=None, extra_flags=0):
         out = _execute_axis_y(c, da, mode, scale, k, da2, c2, extra_flags)
         if out is not None:
             return out, None, None  # other = None: the output has the input's dim order
-    if extra_flags == 0 and iso is None and da2 is None:
-        out = _execute_inner(c, da, mode, scale)
+    if (extra_flags & ~_lib.REALDIM_X2) == 0 and iso is None and da2 is None:
+        out = _execute_inner(c, da, mode, scale, extra_flags)
         if out is not None:
             return out, None, None
     t, other = _arrange(c, da)

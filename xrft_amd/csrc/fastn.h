@@ -693,6 +693,8 @@ struct FastNI {
     // `inner` = the independent elements e of a row; sample (x, e) is column x sx + e se of the view -- the elements INNERMOST ([ny][nx][inner]: sx = inner, se = 1) or
     // BETWEEN the two axes ([ny][mid][nx], dim = ["time", "lon"] of a (time, lat, lon) array: sx = 1, se = nx; `midlay`: the lanes then run along x, not along e)
     int sx, se, midlay;
+    // real_dim along the second axis (XRFTHIP_HALF_X, xrft.py:400-404): rows of nx/2 + 1 samples, unshifted along x; realdim2: 0 < kx < nx/2 counts twice (xrft.py:673-682)
+    int half, realdim2;
     double scale;
 };
 
@@ -759,17 +761,19 @@ __global__ void __launch_bounds__(fastn_max_threads<T>(), (sizeof(T) == 4 ? 4 : 
     if (!(p.dbg & 1)) n_fft_tail<T, CAP>(lds, g, tid, nthr, twl); else __syncthreads();
     const int sx = p.shift_x, sy = p.shift_y;
     const T sc = (T)p.scale;
-    const float ipn = g.inv_pnq, inv_nx = 1.0f / (float)NX;
+    // WO: samples of a result row -- every kx, or kx = 0 .. nx/2 as it lies (real_dim; the twin row (-ky) then takes its samples from kx = nx - fx of the same sequences)
+    const int WO = p.half ? NX / 2 + 1 : NX;
+    const float ipn = g.inv_pnq, inv_nx = 1.0f / (float)WO;
     if ((p.dbg & 2) && lds[tid].re != (T)1.2345) return;
     const bool twin = ky != 0 && 2 * ky != p.ny;
-    const int tot = (NX << g.lg) * (twin ? 2 : 1);
+    const int tot = (WO << g.lg) * (twin ? 2 : 1);
     typedef typename std::conditional<MODE == 0, CT, T>::type OutT;
-    OutT* __restrict__ outs = reinterpret_cast<OutT*>(p.out) + (size_t)slab * p.ny * NX * p.inner;
+    OutT* __restrict__ outs = reinterpret_cast<OutT*>(p.out) + (size_t)slab * p.ny * WO * p.inner;
     if (p.vec) {  // 16-byte pieces of the result: VW consecutive elements e per thread (the host checked inner % VW == 0 and GE % VW == 0)
         constexpr int VW = 16 / (int)sizeof(OutT), LV = VW == 4 ? 2 : VW == 2 ? 1 : 0;
         const int lgq = g.lg - LV, totv = tot >> LV;
         for (int idx = tid; idx < totv; idx += nthr) {
-            const int ge = (idx & ((1 << lgq) - 1)) << LV, rest = idx >> lgq, mir = fdiv(rest, inv_nx), oc = rest - mir * NX, e = e0 + ge;
+            const int ge = (idx & ((1 << lgq) - 1)) << LV, rest = idx >> lgq, mir = fdiv(rest, inv_nx), oc = rest - mir * WO, e = e0 + ge;
             if (e >= p.inner) continue;
             int fx = oc - sx; if (fx < 0) fx += NX;
             const int kx = mir ? (fx == 0 ? 0 : NX - fx) : fx;
@@ -777,13 +781,14 @@ __global__ void __launch_bounds__(fastn_max_threads<T>(), (sizeof(T) == 4 ? 4 : 
             int orow = fy + sy; if (orow >= p.ny) orow -= p.ny;
             const CT* src = lds + ge * g.str + n_pad(kx, ipn);
             OutT o[VW];
+            const T scv = (p.realdim2 && fx != 0 && 2 * fx != NX) ? sc + sc : sc;
             CT ph = mk<T>((T)1, (T)0);
             if (MODE == 0 && p.ph_on) ph = cmul(reinterpret_cast<const CT*>(p.ph_y)[fy], reinterpret_cast<const CT*>(p.ph_x)[fx]);
 #pragma unroll
             for (int i = 0; i < VW; ++i) {
                 CT v = src[i * g.str];
                 if (MODE == 1) {
-                    *reinterpret_cast<T*>(&o[i]) = (v.re * v.re + v.im * v.im) * sc;
+                    *reinterpret_cast<T*>(&o[i]) = (v.re * v.re + v.im * v.im) * scv;
                 } else {
                     v = cscale(v, sc);
                     if (mir) v = cconj(v);
@@ -791,15 +796,15 @@ __global__ void __launch_bounds__(fastn_max_threads<T>(), (sizeof(T) == 4 ? 4 : 
                     *reinterpret_cast<CT*>(&o[i]) = v;
                 }
             }
-            mr_store16_nt<T, true>(outs + ((size_t)orow * NX + oc) * p.inner + e, o);  // (a plain store: the pieces of a 128-byte line come from several workgroups and meet in the L2; non-temporal pieces go to memory one by one, 652 us against 244)
+            mr_store16_nt<T, true>(outs + ((size_t)orow * WO + oc) * p.inner + e, o);  // (a plain store: the pieces of a 128-byte line come from several workgroups and meet in the L2; non-temporal pieces go to memory one by one, 652 us against 244)
         }
         return;
     }
-    const size_t osx = p.midlay ? 1 : (size_t)p.inner, ose = p.midlay ? (size_t)NX : 1;  // the result's strides along kx and along e
+    const size_t osx = p.midlay ? 1 : (size_t)p.inner, ose = p.midlay ? (size_t)WO : 1;  // the result's strides along kx and along e
     for (int idx = tid; idx < tot; idx += nthr) {
         int ge, mir, oc;
-        if (p.midlay) { const int rest = fdiv(idx, inv_nx); oc = idx - rest * NX; mir = rest >> g.lg; ge = rest & (GE - 1); }  // (lanes along kx: contiguous stores)
-        else { ge = idx & (GE - 1); const int rest = idx >> g.lg; mir = fdiv(rest, inv_nx); oc = rest - mir * NX; }
+        if (p.midlay) { const int rest = fdiv(idx, inv_nx); oc = idx - rest * WO; mir = rest >> g.lg; ge = rest & (GE - 1); }  // (lanes along kx: contiguous stores)
+        else { ge = idx & (GE - 1); const int rest = idx >> g.lg; mir = fdiv(rest, inv_nx); oc = rest - mir * WO; }
         const int e = e0 + ge;
         if (e >= p.inner) continue;
         int fx = oc - sx; if (fx < 0) fx += NX;                 // unshifted frequency of output column oc
@@ -807,9 +812,9 @@ __global__ void __launch_bounds__(fastn_max_threads<T>(), (sizeof(T) == 4 ? 4 : 
         const int fy = mir ? p.ny - ky : ky;
         int orow = fy + sy; if (orow >= p.ny) orow -= p.ny;
         CT v = lds[ge * g.str + n_pad(kx, ipn)];
-        OutT* dst = outs + (size_t)orow * NX * p.inner + (size_t)oc * osx + (size_t)e * ose;
+        OutT* dst = outs + (size_t)orow * WO * p.inner + (size_t)oc * osx + (size_t)e * ose;
         if (MODE == 1) {
-            *reinterpret_cast<T*>(dst) = (v.re * v.re + v.im * v.im) * sc;
+            *reinterpret_cast<T*>(dst) = (v.re * v.re + v.im * v.im) * ((p.realdim2 && fx != 0 && 2 * fx != NX) ? sc + sc : sc);
         } else {
             v = cscale(v, sc);
             if (mir) v = cconj(v);

@@ -25,8 +25,11 @@ xrfthip_plan* create_fused_inner(const xrfthip_desc& d) {
     const bool midlay = d.mid >= 2;
     const long long ne = midlay ? d.mid : d.inner;
     if (d.out_mode != XRFTHIP_OUT_COMPLEX && d.out_mode != XRFTHIP_OUT_POWER) return nullptr;
-    const uint32_t ok = XRFTHIP_SHIFT_Y | XRFTHIP_SHIFT_X | (d.out_mode == XRFTHIP_OUT_COMPLEX ? (XRFTHIP_ISHIFT_Y | XRFTHIP_ISHIFT_X) : 0u);
+    // (real_dim along the second axis -- HALF_X, the power spectrum's REALDIM_X2: rows of nx/2 + 1 samples out of pass 2, unshifted along x)
+    const uint32_t ok = XRFTHIP_SHIFT_Y | XRFTHIP_SHIFT_X | XRFTHIP_HALF_X | (d.out_mode == XRFTHIP_OUT_COMPLEX ? (XRFTHIP_ISHIFT_Y | XRFTHIP_ISHIFT_X) : XRFTHIP_REALDIM_X2);
     if (d.flags & ~ok) return nullptr;  // (a flipped axis: the composite of one-axis plans)
+    if ((d.flags & XRFTHIP_HALF_X) && ((d.flags & XRFTHIP_SHIFT_X) || (d.nx & 1))) return nullptr;
+    if ((d.flags & XRFTHIP_REALDIM_X2) && !(d.flags & XRFTHIP_HALF_X)) return nullptr;
     const bool dbl = d.dtype == XRFTHIP_F64;
     const size_t rs = dbl ? 8 : 4, cs = 2 * rs;
     const long long ncol = d.nx * ne;
@@ -92,7 +95,7 @@ xrfthip_plan* create_fused_inner(const xrfthip_desc& d) {
     P->fusedi = true;
     P->inner = d.inner > 1 ? d.inner : 1; P->mid = midlay ? d.mid : 1;
     P->dbl = dbl; P->cplx_in = false; P->rsize = rs; P->csize = cs;
-    P->nx_out = d.nx;
+    P->nx_out = (d.flags & XRFTHIP_HALF_X) ? d.nx / 2 + 1 : d.nx;
     P->yny = d.ny; P->ynx = ncol;  // (the view pass 1 transforms)
     P->n_c.rt = true; P->n_c.geo = gc; P->n_c.lds = fastn_lds(gc, cs, true) + (rad_p ? 2 * (((size_t)d.ny + 7) & ~(size_t)7) * 2 : 0);
     P->n_rad_p = rad_p; P->n_rq = rad_rq; P->n_rp = rad_rp;
@@ -159,7 +162,8 @@ int run_fused_inner(const xrfthip_plan* P, const void* in, void* out, char* ws, 
         r.w2 = m.w2; r.corr = ws + P->off_corr; r.what0 = P->ywhat0.p; r.what1 = P->ywhat1.p;
         r.tw_x = P->tw_fx.p; r.twm = P->n_r.twm.p; r.g = (NGeoPtr)P->n_r.geo_dev.p;
         r.ph_y = P->fph[0].p; r.ph_x = P->fph[1].p; r.ph_on = (d.out_mode != XRFTHIP_OUT_POWER && P->fph_on) ? 1 : 0;
-        r.out = (char*)out + (size_t)g0 * d.ny * ncol * out_esz;
+        r.half = (d.flags & XRFTHIP_HALF_X) ? 1 : 0; r.realdim2 = (d.flags & XRFTHIP_REALDIM_X2) ? 1 : 0;
+        r.out = (char*)out + (size_t)g0 * d.ny * (size_t)P->nx_out * ne * out_esz;
         r.ny = (int)d.ny; r.nx = (int)d.nx; r.inner = (int)ne; r.sx = sx; r.se = se; r.midlay = midlay ? 1 : 0; r.nrow_pad = P->y_nrow_pad; r.pitch = (int)P->y_pitch;
         r.l_cw = m.l_cw; r.l_rk = m.l_rk; r.detrend = d.detrend;
         r.shift_y = (d.flags & XRFTHIP_SHIFT_Y) ? (int)(d.ny / 2) : 0;
@@ -191,6 +195,7 @@ int run_fused_inner(const xrfthip_plan* P, const void* in, void* out, char* ws, 
 // composite plan for xrfthip_desc.inner > 1 (see xrfthip_plan::inner)
 int create_inner_plan(xrfthip_plan** plan, const xrfthip_desc& d) {
     if (xrfthip_plan* F = create_fused_inner(d)) { *plan = F; return XRFTHIP_OK; }
+    if (d.flags & (XRFTHIP_HALF_X | XRFTHIP_REALDIM_X2)) return XRFTHIP_UNSUPPORTED_LENGTH;  // (real_dim: the fused passes only; the caller transposes)
     const uint32_t ok = XRFTHIP_SHIFT_Y | XRFTHIP_SHIFT_X | XRFTHIP_ISHIFT_Y | XRFTHIP_ISHIFT_X | XRFTHIP_FLIP_Y | XRFTHIP_FLIP_X;
     if (d.ndim != 2 || (d.flags & ~ok) || (d.out_mode != XRFTHIP_OUT_COMPLEX && d.out_mode != XRFTHIP_OUT_POWER)) return XRFTHIP_BAD_ARG;
     if (d.inner > (1LL << 30) || d.mid > (1LL << 30) || d.nx * d.inner > (1LL << 30) || d.mid * d.nx * d.inner > (1LL << 30) || d.batch * d.mid > (1LL << 40)) return XRFTHIP_BAD_ARG;
