@@ -1450,6 +1450,18 @@ def run_fused_inner_cases(dtype="float64", shapes=((24, 20, 6), (16, 48, 3), (36
             assert "[fastn fused]" in next(reversed(xa.api._plan_cache.values())).describe(), (shape, kw)
         # the axes named in the other order; a length with a factor the butterflies do not hold falls back to the composite of one-axis plans
         worst = max(worst, check(xa.power_spectrum(da, dim=["x", "y"], window="hann"), o.power_spectrum(od, dim=["x", "y"], window="hann"), tol))
+        # the cross spectrum (and the cross phase) of two fields with different coordinate origins where the axes lie (round 6: pass 1 and the plane fit per field, pass 2 on both)
+        w = (rng.standard_normal(shape) - (0.02 * jj + 1.0)[:, :, None]).astype(dtype)
+        c2 = dict(c); c2["x"] = c["x"] + 1.25
+        db, ob = pair(w, dims, c2)
+        for kw in (dict(), dict(detrend="linear", window="hann"), dict(true_phase=False, shift=False), dict(scaling="spectrum", detrend="constant")) + ((dict(real_dim="x", detrend="linear"),) if nx % 2 == 0 else ()):
+            worst = max(worst, check(xa.cross_spectrum(da, db, dim=["y", "x"], **kw), o.cross_spectrum(od, ob, dim=["y", "x"], **kw), tol))
+            assert "[fastn fused]" in next(reversed(xa.api._plan_cache.values())).describe(), (shape, kw)
+        gph, rph = xa.cross_phase(da, db, dim=["y", "x"], window="hann"), o.cross_phase(od, ob, dim=["y", "x"], window="hann")
+        assert "[fastn fused]" in next(reversed(xa.api._plan_cache.values())).describe()
+        mag = np.abs(o.cross_spectrum(od, ob, dim=["y", "x"], window="hann").values)
+        dphi = np.abs(np.angle(np.exp(1j * (np.asarray(gph.values) - np.asarray(rph.values)))))
+        assert (dphi * mag).max() / mag.max() < (1e-10 if dtype == "float64" else 3e-4)
         if nx % 2 == 0:  # real_dim along the second axis (round 6): rows of nx / 2 + 1 samples out of pass 2, the kept half counted twice in a power spectrum -- no transposed copy
             for fn, ofn, kws in ((xa.fft, o.fft, (dict(), dict(detrend="linear", window="hann"), dict(true_phase=False, true_amplitude=False))),
                                  (xa.power_spectrum, o.power_spectrum, (dict(), dict(detrend="linear", window="hann"), dict(scaling="spectrum", detrend="constant")))):
@@ -1485,6 +1497,12 @@ def run_fused_mid_cases(dtype="float64", shapes=((24, 5, 20), (16, 3, 48), (36, 
             worst = max(worst, check(xa.power_spectrum(da, dim=["t", "x"], **kw), o.power_spectrum(od, dim=["t", "x"], **kw), tol))
             assert "[fastn fused]" in next(reversed(xa.api._plan_cache.values())).describe(), (shape, kw)
         worst = max(worst, check(xa.power_spectrum(da, dim=["x", "t"], window="hann"), o.power_spectrum(od, dim=["x", "t"], window="hann"), tol))
+        w = (rng.standard_normal(shape) + 0.5).astype(dtype)  # (two fields: the cross spectrum over the non-adjacent pair)
+        c2 = dict(c); c2["t"] = c["t"] + 0.75
+        db, ob = pair(w, dims, c2)
+        for kw in (dict(), dict(detrend="linear", window="hann"), dict(true_phase=False, shift=False)):
+            worst = max(worst, check(xa.cross_spectrum(da, db, dim=["t", "x"], **kw), o.cross_spectrum(od, ob, dim=["t", "x"], **kw), tol))
+            assert "[fastn fused]" in next(reversed(xa.api._plan_cache.values())).describe(), (shape, kw)
         if nx % 2 == 0:  # real_dim = the contiguous axis of the pair (round 6): the half output of the fused passes
             for fn, ofn, kws in ((xa.fft, o.fft, (dict(), dict(detrend="linear", window="hann"))), (xa.power_spectrum, o.power_spectrum, (dict(), dict(detrend="constant", window="hann")))):
                 for kw in kws:

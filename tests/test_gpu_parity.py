@@ -1021,6 +1021,37 @@ def test_two_axes_with_the_batch_innermost_without_copies(dtype):
         cases.check(res, ofn(o.OArr(v.astype(np.float64), ("y", "x", "t"), c), **kw), 2e-4 if dtype == "float32" else 1e-10)
 
 
+@pytest.mark.parametrize("dtype", ["float32", "float64"])
+def test_cross_spectrum_with_the_batch_innermost_without_copies(dtype):
+    """cross_spectrum over dim = ["y", "x"] of two (y, x, t) arrays runs where the axes lie (the fused passes of csrc/fastn.h on both fields): beyond plan, tables and
+    scratch a call allocates its result only -- no transposed copies of the two inputs -- and the result has the inputs' layout."""
+    import xrft_amd as xa
+    from xrft_amd import api
+
+    shape = (256, 240, 24)
+    rng = np.random.default_rng(8)
+    v = (rng.standard_normal(shape) + 0.01 * np.arange(shape[0])[:, None, None]).astype(dtype)
+    w = (rng.standard_normal(shape) - 0.02 * np.arange(shape[1])[None, :, None]).astype(dtype)
+    c = {"y": np.arange(shape[0]) * 0.5, "x": np.arange(shape[1]) * 0.25, "t": np.arange(shape[2]) * 2.0}
+    c2 = dict(c); c2["x"] = c["x"] + 3.0
+    da, db = xa.DataArray(torch.from_numpy(v).cuda(), ("y", "x", "t"), c), xa.DataArray(torch.from_numpy(w).cuda(), ("y", "x", "t"), c2)
+    for kw in (dict(dim=["y", "x"], detrend="linear", window="hann"), dict(dim=["y", "x"], real_dim="x")):
+        res = xa.cross_spectrum(da, db, **kw)
+        assert "[inner layout]" in next(reversed(api._plan_cache.values())).describe()
+        del res
+        torch.cuda.synchronize()
+        torch.cuda.reset_peak_memory_stats()
+        before = torch.cuda.memory_allocated()
+        res = xa.cross_spectrum(da, db, **kw)
+        torch.cuda.synchronize()
+        peak = torch.cuda.max_memory_allocated() - before
+        out_bytes = res.data.numel() * res.data.element_size()
+        assert peak <= out_bytes + (1 << 20), (peak, out_bytes)
+        assert res.data.is_contiguous() and tuple(res.dims) == ("freq_y", "freq_x", "t")
+        ref = o.cross_spectrum(o.OArr(v.astype(np.float64), ("y", "x", "t"), c), o.OArr(w.astype(np.float64), ("y", "x", "t"), c2), **kw)
+        cases.check(res, ref, 2e-4 if dtype == "float32" else 1e-10)
+
+
 def test_fused_radial_sums_compact_and_full_bin_codes():
     cases.run_fused_radial_code_forms(256)
     cases.run_fused_radial_code_forms(2048)

@@ -567,12 +567,12 @@ def _swap_xy(flags):
     return out
 
 
-def _execute_inner(c, da, mode, scale, extra_flags=0):
+def _execute_inner(c, da, mode, scale, extra_flags=0, da2=None, c2=None):
     """Two transform axes that are not the trailing pair, wherever they lie -- dim = ["y", "x"] of a (y, x, time) array, dim = ["t", "x"] of a (t, y, x) array:
     the engine's layout [batch][n0][mid][n1][inner] (xrfthip_desc.inner, .mid: the products of the extents in front of, between and behind the two axes)
     transforms them where they lie, as the reference does (xrft.py:395-409) -- no transposed copy of the input or of the result.  Returns the result in
     the input's dim order, or None when the call is not of this kind (the caller then takes the transposing path)."""
-    if len(c.dim) != 2 or mode not in (_lib.OUT_COMPLEX, _lib.OUT_POWER):
+    if len(c.dim) != 2 or mode not in (_lib.OUT_COMPLEX, _lib.OUT_POWER, _lib.OUT_CROSS):
         return None
     p, q = da.get_axis_num(c.ydim), da.get_axis_num(c.xdim)
     if c.real_dim is not None and p > q:
@@ -589,7 +589,14 @@ def _execute_inner(c, da, mode, scale, extra_flags=0):
     # so that a BAD_ARG from the library means a bug in the descriptor and is raised, not hidden behind the transposing path
     if (inner < 2 and mid < 2) or mid * inner * shape[second] > (1 << 30) or shape[first] * shape[second] * inner * mid > (1 << 31) - 1:
         return None
-    flags, win, ph = _flags_tables(c, da)
+    t2 = None
+    if mode == _lib.OUT_CROSS:  # (round 6: the cross spectrum of two real fields on the fused passes -- both fields where they lie)
+        if da2 is None or tuple(da2.dims) != tuple(da.dims):
+            return None
+        t2 = _to_device(da2.data).contiguous()
+        if t2.shape != t.shape or t2.dtype != t.dtype or t.is_complex():
+            return None
+    flags, win, ph = _flags_tables(c, da, None if c2 is None else c2.lag_x, None if c2 is None else c2.reversed)
     flags |= extra_flags  # (REALDIM_X2: the kept half of the real axis counts twice in a power spectrum)
     if mode == _lib.OUT_POWER:
         ph = {"y": None, "x": None}
@@ -603,7 +610,7 @@ def _execute_inner(c, da, mode, scale, extra_flags=0):
         if e.status == _lib.UNSUPPORTED_LENGTH:  # a length the one-axis plans do not take: the transposing path
             return None
         raise
-    out, _ = plan.execute(t)
+    out, _ = plan.execute(t, t2)
     shape[second] = plan.nx_out  # (real_dim: nx / 2 + 1 samples along the second axis)
     return out.reshape(shape)
 
@@ -614,10 +621,15 @@ def _execute(c, da, mode, scale, da2=None, c2=None, iso=None, extra_flags=0):
         out = _execute_axis_y(c, da, mode, scale, k, da2, c2, extra_flags)
         if out is not None:
             return out, None, None  # other = None: the output has the input's dim order
-    if (extra_flags & ~_lib.REALDIM_X2) == 0 and iso is None and da2 is None:
-        out = _execute_inner(c, da, mode, scale, extra_flags)
+    if (extra_flags & ~_lib.REALDIM_X2) == 0 and iso is None and (da2 is None or mode == _lib.OUT_CROSS):
+        out = _execute_inner(c, da, mode, scale, extra_flags, da2, c2)
         if out is not None:
             return out, None, None
+    if extra_flags == 0 and iso is None and da2 is not None and mode == _lib.OUT_PHASE:
+        # the cross phase of two fields on non-trailing axes: the fused cross spectrum where the axes lie, then its angle (xrft.py:871-874) -- no transposed copy
+        out = _execute_inner(c, da, _lib.OUT_CROSS, scale, 0, da2, c2)
+        if out is not None:
+            return engine.angle(out), None, None
     t, other = _arrange(c, da)
     ndim = len(c.dim)
     nx = da.sizes[c.xdim]

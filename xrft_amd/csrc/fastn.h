@@ -695,6 +695,10 @@ struct FastNI {
     int sx, se, midlay;
     // real_dim along the second axis (XRFTHIP_HALF_X, xrft.py:400-404): rows of nx/2 + 1 samples, unshifted along x; realdim2: 0 < kx < nx/2 counts twice (xrft.py:673-682)
     int half, realdim2;
+    // MODE 2, the cross spectrum of two fields (xrft.cross_spectrum, xrft.py:825): the workgroup's sequences are GE/2 of field 0 followed by the SAME GE/2 elements of field 1
+    // (its intermediate and plane corrections: w2b, corrb); the result is F0 conj(F1), the twin row its conjugate
+    const void* w2b;
+    const void* corrb;
     double scale;
 };
 
@@ -705,10 +709,12 @@ __device__ __forceinline__ void n_first_irows(const FastNI& p, NGeoRef g, C2<T>*
     int ge, j;
     if (p.midlay) { ge = w / M0; j = w - ge * M0; }  // (lanes along x: the samples of a sequence are contiguous)
     else { ge = w & (g.g - 1); j = w >> g.lg; }
-    const int e = min(e0 + ge, p.inner - 1);  // (a ragged last block re-reads the last element; never stored)
+    const int gh = p.w2b ? (g.g >> 1) : g.g;   // sequences per field
+    const bool fb = ge >= gh;                  // (cross spectrum: the second half of the workgroup's sequences is field 1)
+    const int e = min(e0 + (fb ? ge - gh : ge), p.inner - 1);  // (a ragged last block re-reads the last element; never stored)
     const CT w0 = reinterpret_cast<const CT*>(p.tw_x)[j];
-    const CT* __restrict__ blk = reinterpret_cast<const CT*>(p.w2) + ((size_t)slab * p.nrow_pad + (size_t)((ky >> p.l_rk) << p.l_rk)) * p.pitch;
-    const CT* __restrict__ cr = reinterpret_cast<const CT*>(p.corr) + (size_t)slab * p.nx * p.inner;
+    const CT* __restrict__ blk = reinterpret_cast<const CT*>(fb ? p.w2b : p.w2) + ((size_t)slab * p.nrow_pad + (size_t)((ky >> p.l_rk) << p.l_rk)) * p.pitch;
+    const CT* __restrict__ cr = reinterpret_cast<const CT*>(fb ? p.corrb : p.corr) + (size_t)slab * p.nx * p.inner;
     const bool addback = p.detrend != 0;
     CT a[R], c[R];
     CT h0 = mk<T>((T)0, (T)0), h1 = h0;
@@ -735,7 +741,7 @@ __device__ __forceinline__ void n_first_irows(const FastNI& p, NGeoRef g, C2<T>*
     for (int k = 0; k < R; ++k) s[k * st] = a[k];
 }
 
-// MODE 0: complex spectrum, 1: power spectrum
+// MODE 0: complex spectrum, 1: power spectrum, 2: cross spectrum of two fields (complex)
 template <typename T, int MODE, int CAP>
 __global__ void __launch_bounds__(fastn_max_threads<T>(), (sizeof(T) == 4 ? 4 : 3)) fastn_irows_kernel(FastNI p) {
     typedef C2<T> CT;
@@ -748,7 +754,9 @@ __global__ void __launch_bounds__(fastn_max_threads<T>(), (sizeof(T) == 4 ? 4 : 
     const int per = (p.nunits + 7) >> 3, xcd = blockIdx.x & 7, jb = blockIdx.x >> 3;
     const int unit = xcd * per + jb;
     if (jb >= per || unit >= p.nunits) return;
-    const int ups = (nyh + 1) * p.neb, slab = unit / ups, rem = unit - slab * ups, ky = rem / p.neb, e0 = (rem - ky * p.neb) * GE;
+    constexpr int LX = MODE == 2 ? 1 : 0;  // a cross spectrum's workgroup holds GE >> 1 elements of both fields
+    const int GEO = GE >> LX, lgo = g.lg - LX;  // elements (and their log2) the workgroup writes
+    const int ups = (nyh + 1) * p.neb, slab = unit / ups, rem = unit - slab * ups, ky = rem / p.neb, e0 = (rem - ky * p.neb) * GEO;
     for (int e = tid; e < g.twn; e += nthr) twl[e] = reinterpret_cast<const CT*>(p.twm)[e];
     {
         const int nit = g.m[0] << g.lg;
@@ -766,12 +774,13 @@ __global__ void __launch_bounds__(fastn_max_threads<T>(), (sizeof(T) == 4 ? 4 : 
     const float ipn = g.inv_pnq, inv_nx = 1.0f / (float)WO;
     if ((p.dbg & 2) && lds[tid].re != (T)1.2345) return;
     const bool twin = ky != 0 && 2 * ky != p.ny;
-    const int tot = (WO << g.lg) * (twin ? 2 : 1);
-    typedef typename std::conditional<MODE == 0, CT, T>::type OutT;
+    const int tot = (WO << lgo) * (twin ? 2 : 1);
+    const int fbo = GEO * g.str;  // (MODE 2: field 1's sequence of an element, behind field 0's)
+    typedef typename std::conditional<MODE != 1, CT, T>::type OutT;
     OutT* __restrict__ outs = reinterpret_cast<OutT*>(p.out) + (size_t)slab * p.ny * WO * p.inner;
     if (p.vec) {  // 16-byte pieces of the result: VW consecutive elements e per thread (the host checked inner % VW == 0 and GE % VW == 0)
         constexpr int VW = 16 / (int)sizeof(OutT), LV = VW == 4 ? 2 : VW == 2 ? 1 : 0;
-        const int lgq = g.lg - LV, totv = tot >> LV;
+        const int lgq = lgo - LV, totv = tot >> LV;
         for (int idx = tid; idx < totv; idx += nthr) {
             const int ge = (idx & ((1 << lgq) - 1)) << LV, rest = idx >> lgq, mir = fdiv(rest, inv_nx), oc = rest - mir * WO, e = e0 + ge;
             if (e >= p.inner) continue;
@@ -783,14 +792,15 @@ __global__ void __launch_bounds__(fastn_max_threads<T>(), (sizeof(T) == 4 ? 4 : 
             OutT o[VW];
             const T scv = (p.realdim2 && fx != 0 && 2 * fx != NX) ? sc + sc : sc;
             CT ph = mk<T>((T)1, (T)0);
-            if (MODE == 0 && p.ph_on) ph = cmul(reinterpret_cast<const CT*>(p.ph_y)[fy], reinterpret_cast<const CT*>(p.ph_x)[fx]);
+            if (MODE != 1 && p.ph_on) ph = cmul(reinterpret_cast<const CT*>(p.ph_y)[fy], reinterpret_cast<const CT*>(p.ph_x)[fx]);
 #pragma unroll
             for (int i = 0; i < VW; ++i) {
                 CT v = src[i * g.str];
+                if (MODE == 2) v = cmulc(v, src[i * g.str + fbo]);  // F0 conj(F1)
                 if (MODE == 1) {
                     *reinterpret_cast<T*>(&o[i]) = (v.re * v.re + v.im * v.im) * scv;
                 } else {
-                    v = cscale(v, sc);
+                    v = cscale(v, MODE == 2 ? scv : sc);  // (a cross spectrum's kept half of a real axis counts twice, too: xrft.py:673-682)
                     if (mir) v = cconj(v);
                     if (p.ph_on) v = cmul(v, ph);
                     *reinterpret_cast<CT*>(&o[i]) = v;
@@ -803,8 +813,8 @@ __global__ void __launch_bounds__(fastn_max_threads<T>(), (sizeof(T) == 4 ? 4 : 
     const size_t osx = p.midlay ? 1 : (size_t)p.inner, ose = p.midlay ? (size_t)WO : 1;  // the result's strides along kx and along e
     for (int idx = tid; idx < tot; idx += nthr) {
         int ge, mir, oc;
-        if (p.midlay) { const int rest = fdiv(idx, inv_nx); oc = idx - rest * WO; mir = rest >> g.lg; ge = rest & (GE - 1); }  // (lanes along kx: contiguous stores)
-        else { ge = idx & (GE - 1); const int rest = idx >> g.lg; mir = fdiv(rest, inv_nx); oc = rest - mir * WO; }
+        if (p.midlay) { const int rest = fdiv(idx, inv_nx); oc = idx - rest * WO; mir = rest >> lgo; ge = rest & (GEO - 1); }  // (lanes along kx: contiguous stores)
+        else { ge = idx & (GEO - 1); const int rest = idx >> lgo; mir = fdiv(rest, inv_nx); oc = rest - mir * WO; }
         const int e = e0 + ge;
         if (e >= p.inner) continue;
         int fx = oc - sx; if (fx < 0) fx += NX;                 // unshifted frequency of output column oc
@@ -812,11 +822,12 @@ __global__ void __launch_bounds__(fastn_max_threads<T>(), (sizeof(T) == 4 ? 4 : 
         const int fy = mir ? p.ny - ky : ky;
         int orow = fy + sy; if (orow >= p.ny) orow -= p.ny;
         CT v = lds[ge * g.str + n_pad(kx, ipn)];
+        if (MODE == 2) v = cmulc(v, lds[ge * g.str + fbo + n_pad(kx, ipn)]);  // F0 conj(F1)
         OutT* dst = outs + (size_t)orow * WO * p.inner + (size_t)oc * osx + (size_t)e * ose;
         if (MODE == 1) {
             *reinterpret_cast<T*>(dst) = (v.re * v.re + v.im * v.im) * ((p.realdim2 && fx != 0 && 2 * fx != NX) ? sc + sc : sc);
         } else {
-            v = cscale(v, sc);
+            v = cscale(v, (MODE == 2 && p.realdim2 && fx != 0 && 2 * fx != NX) ? sc + sc : sc);
             if (mir) v = cconj(v);
             if (p.ph_on) v = cmul(v, cmul(reinterpret_cast<const CT*>(p.ph_y)[fy], reinterpret_cast<const CT*>(p.ph_x)[fx]));
             *reinterpret_cast<CT*>(dst) = v;

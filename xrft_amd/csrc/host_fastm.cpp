@@ -730,7 +730,8 @@ void set_attrs_fastm() {
                      SETF((fastn_rows_kernel<TT, 2, true, CC>)); SETF((fastn_rows_kernel<TT, 3, false, CC>))
     SETN(float, 16); SETN(float, 20); SETN(double, 16);
     SETF((fastn_irows_kernel<float, 0, 16>)); SETF((fastn_irows_kernel<float, 1, 16>)); SETF((fastn_irows_kernel<float, 0, 20>)); SETF((fastn_irows_kernel<float, 1, 20>));
-    SETF((fastn_irows_kernel<double, 0, 16>)); SETF((fastn_irows_kernel<double, 1, 16>));
+    SETF((fastn_irows_kernel<double, 0, 16>)); SETF((fastn_irows_kernel<double, 1, 16>)); SETF((fastn_irows_kernel<double, 2, 16>));
+    SETF((fastn_irows_kernel<float, 2, 16>)); SETF((fastn_irows_kernel<float, 2, 20>));
 #undef SETN
 #undef SETF
 }

@@ -24,9 +24,12 @@ xrfthip_plan* create_fused_inner(const xrfthip_desc& d) {
     if (d.ndim != 2 || !((d.mid <= 1 && d.inner >= 2) || (d.mid >= 2 && d.inner <= 1)) || (d.dtype != XRFTHIP_F32 && d.dtype != XRFTHIP_F64)) return nullptr;
     const bool midlay = d.mid >= 2;
     const long long ne = midlay ? d.mid : d.inner;
-    if (d.out_mode != XRFTHIP_OUT_COMPLEX && d.out_mode != XRFTHIP_OUT_POWER) return nullptr;
+    // (the cross spectrum of two real fields, round 6: pass 1 and the plane fit once per field, pass 2 on GE / 2 elements of both)
+    const bool crossm = d.out_mode == XRFTHIP_OUT_CROSS;
+    if (d.out_mode != XRFTHIP_OUT_COMPLEX && d.out_mode != XRFTHIP_OUT_POWER && !crossm) return nullptr;
     // (real_dim along the second axis -- HALF_X, the power spectrum's REALDIM_X2: rows of nx/2 + 1 samples out of pass 2, unshifted along x)
-    const uint32_t ok = XRFTHIP_SHIFT_Y | XRFTHIP_SHIFT_X | XRFTHIP_HALF_X | (d.out_mode == XRFTHIP_OUT_COMPLEX ? (XRFTHIP_ISHIFT_Y | XRFTHIP_ISHIFT_X) : XRFTHIP_REALDIM_X2);
+    const uint32_t ok = XRFTHIP_SHIFT_Y | XRFTHIP_SHIFT_X | XRFTHIP_HALF_X | (d.out_mode != XRFTHIP_OUT_POWER ? (XRFTHIP_ISHIFT_Y | XRFTHIP_ISHIFT_X) : 0u) |
+                        (d.out_mode != XRFTHIP_OUT_COMPLEX ? XRFTHIP_REALDIM_X2 : 0u);
     if (d.flags & ~ok) return nullptr;  // (a flipped axis: the composite of one-axis plans)
     if ((d.flags & XRFTHIP_HALF_X) && ((d.flags & XRFTHIP_SHIFT_X) || (d.nx & 1))) return nullptr;
     if ((d.flags & XRFTHIP_REALDIM_X2) && !(d.flags & XRFTHIP_HALF_X)) return nullptr;
@@ -89,6 +92,7 @@ xrfthip_plan* create_fused_inner(const xrfthip_desc& d) {
             if (fastn_lds(t, cs, false) <= (f_ge ? caps[2] : caps[ci])) { GE = cand; gr = t; }
         }
     if (!G || !GE) return nullptr;
+    if (crossm && GE < 2) return nullptr;  // (both fields of an element share a row workgroup)
     xrfthip_plan* P = new (std::nothrow) xrfthip_plan();
     if (!P) return nullptr;
     P->d = d;
@@ -119,51 +123,60 @@ xrfthip_plan* create_fused_inner(const xrfthip_desc& d) {
     // workspace: the intermediate of one group of slabs, the column sums, the plane corrections
     auto al = [](size_t v) { return (v + 255) & ~(size_t)255; };
     const size_t slab_w = (size_t)P->y_nrow_pad * (size_t)P->y_pitch * cs;
-    long long Gs = d.slabs_per_group > 0 ? d.slabs_per_group : (long long)std::max<size_t>(1, ((size_t)512 << 20) / std::max<size_t>(slab_w, 1));
+    long long Gs = d.slabs_per_group > 0 ? d.slabs_per_group : (long long)std::max<size_t>(1, ((size_t)512 << 20) / std::max<size_t>(slab_w * (crossm ? 2 : 1), 1));
     Gs = std::max<long long>(1, std::min<long long>(Gs, std::max<long long>(d.batch, 1)));
     P->G = (int)Gs;
     size_t off = 0;
-    P->off_w = off; off = al(off + (size_t)Gs * slab_w);
-    P->off_rowfit = off; off = al(off + (size_t)Gs * ncol * 4 * sizeof(double));
-    P->off_corr = off; off = al(off + (size_t)Gs * ncol * cs);
+    const size_t nf = crossm ? 2 : 1;  // fields: field 1's intermediate, sums and corrections lie behind field 0's
+    P->off_w = off; off = al(off + nf * (size_t)Gs * slab_w);
+    P->off_rowfit = off; off = al(off + nf * (size_t)Gs * ncol * 4 * sizeof(double));
+    P->off_corr = off; off = al(off + nf * (size_t)Gs * ncol * cs);
     P->ws_bytes = off;
     return P;
 }
 
-int run_fused_inner(const xrfthip_plan* P, const void* in, void* out, char* ws, hipStream_t st) {
+int run_fused_inner(const xrfthip_plan* P, const void* in, const void* in1, void* out, char* ws, hipStream_t st) {
     const xrfthip_desc& d = P->d;
-    const bool midlay = d.mid >= 2;
+    const bool midlay = d.mid >= 2, crossm = d.out_mode == XRFTHIP_OUT_CROSS;
     const long long ne = midlay ? d.mid : d.inner, ncol = d.nx * ne;
     const int sx = midlay ? 1 : (int)d.inner, se = midlay ? (int)d.nx : 1;
     const size_t out_esz = d.out_mode == XRFTHIP_OUT_POWER ? P->rsize : P->csize;
     for (long long g0 = 0; g0 < d.batch; g0 += P->G) {
         const long long gc = std::min<long long>(P->G, d.batch - g0);
+        const size_t slab_w = (size_t)P->y_nrow_pad * (size_t)P->y_pitch * P->csize;
+        const size_t fw = (size_t)P->G * slab_w, ff = (size_t)P->G * ncol * 4 * sizeof(double), fc = (size_t)P->G * ncol * P->csize;  // field 1 behind field 0 (create_fused_inner)
         FastM m{};
-        m.in = (const char*)in + (size_t)g0 * d.ny * ncol * P->rsize;
-        m.w2 = ws + P->off_w;
+        xrfthip_plan::ProfRec* rec = nullptr;
+      for (int f = 0; f < (crossm ? 2 : 1); ++f) {
+        m = FastM{};
+        m.in = (const char*)(f ? in1 : in) + (size_t)g0 * d.ny * ncol * P->rsize;
+        m.w2 = ws + P->off_w + f * fw;
         m.tw_y = P->tw_fy.p;
         m.win_y = P->win[0].p ? P->win[0].p : P->ones4096.p;
         m.win_x = P->winx_exp.p;
-        m.colfit = reinterpret_cast<double*>(ws + P->off_rowfit);
+        m.colfit = reinterpret_cast<double*>(ws + P->off_rowfit + f * ff);
         m.ny = (int)d.ny; m.nx = (int)ncol; m.nrow_pad = P->y_nrow_pad;
         m.l_cw = ilog2i(P->n_cw); m.l_rk = ilog2i(P->n_rk);
         m.detrend = d.detrend; m.nslab = (int)gc; m.nunits = (int)(gc * P->n_nxb);
-        xrfthip_plan::ProfRec* rec = prof_begin(P, "fastn_cols", st);
+        rec = prof_begin(P, "fastn_cols", st);
         fastn_launch_cols(P, m, st);
         prof_end(rec, st);
         if (d.detrend) {
             rec = prof_begin(P, "fastn_fit_inner", st);
             const dim3 grid((unsigned)(gc * ne)), blk(256);
-            if (P->dbl) { auto k = &fastn_fit_inner_kernel<double>; XRFT_LAUNCH(k, grid, blk, 3 * 256 * sizeof(double), st, (const double*)m.colfit, (const double*)m.win_x, reinterpret_cast<C2<double>*>(ws + P->off_corr), (int)d.nx, (int)ne, (int)d.ny, (int)d.detrend, sx, se); }
-            else { auto k = &fastn_fit_inner_kernel<float>; XRFT_LAUNCH(k, grid, blk, 3 * 256 * sizeof(double), st, (const double*)m.colfit, (const float*)m.win_x, reinterpret_cast<C2<float>*>(ws + P->off_corr), (int)d.nx, (int)ne, (int)d.ny, (int)d.detrend, sx, se); }
+            if (P->dbl) { auto k = &fastn_fit_inner_kernel<double>; XRFT_LAUNCH(k, grid, blk, 3 * 256 * sizeof(double), st, (const double*)m.colfit, (const double*)m.win_x, reinterpret_cast<C2<double>*>(ws + P->off_corr + f * fc), (int)d.nx, (int)ne, (int)d.ny, (int)d.detrend, sx, se); }
+            else { auto k = &fastn_fit_inner_kernel<float>; XRFT_LAUNCH(k, grid, blk, 3 * 256 * sizeof(double), st, (const double*)m.colfit, (const float*)m.win_x, reinterpret_cast<C2<float>*>(ws + P->off_corr + f * fc), (int)d.nx, (int)ne, (int)d.ny, (int)d.detrend, sx, se); }
             prof_end(rec, st);
         }
+      }
         FastNI r{};
-        r.w2 = m.w2; r.corr = ws + P->off_corr; r.what0 = P->ywhat0.p; r.what1 = P->ywhat1.p;
+        r.w2 = ws + P->off_w; r.corr = ws + P->off_corr; r.what0 = P->ywhat0.p; r.what1 = P->ywhat1.p;
+        if (crossm) { r.w2b = ws + P->off_w + fw; r.corrb = ws + P->off_corr + fc; }
         r.tw_x = P->tw_fx.p; r.twm = P->n_r.twm.p; r.g = (NGeoPtr)P->n_r.geo_dev.p;
         r.ph_y = P->fph[0].p; r.ph_x = P->fph[1].p; r.ph_on = (d.out_mode != XRFTHIP_OUT_POWER && P->fph_on) ? 1 : 0;
         r.half = (d.flags & XRFTHIP_HALF_X) ? 1 : 0; r.realdim2 = (d.flags & XRFTHIP_REALDIM_X2) ? 1 : 0;
         r.out = (char*)out + (size_t)g0 * d.ny * (size_t)P->nx_out * ne * out_esz;
+        const int geo = crossm ? P->n_r.geo.g / 2 : P->n_r.geo.g;  // elements a row workgroup writes
         r.ny = (int)d.ny; r.nx = (int)d.nx; r.inner = (int)ne; r.sx = sx; r.se = se; r.midlay = midlay ? 1 : 0; r.nrow_pad = P->y_nrow_pad; r.pitch = (int)P->y_pitch;
         r.l_cw = m.l_cw; r.l_rk = m.l_rk; r.detrend = d.detrend;
         r.shift_y = (d.flags & XRFTHIP_SHIFT_Y) ? (int)(d.ny / 2) : 0;
@@ -171,11 +184,11 @@ int run_fused_inner(const xrfthip_plan* P, const void* in, void* out, char* ws, 
         const NGeo& hg = P->n_r.geo;
         {
             const int vw = (int)(16 / out_esz);
-            r.vec = (!midlay && (vw == 1 || (d.inner % vw == 0 && hg.g % vw == 0))) ? 1 : 0;
+            r.vec = (!midlay && (vw == 1 || (d.inner % vw == 0 && geo % vw == 0))) ? 1 : 0;
             if (!P->fi_vec) r.vec = 0;
             r.dbg = P->fi_dbg;
         }
-        r.neb = (int)((ne + hg.g - 1) / hg.g);
+        r.neb = (int)((ne + geo - 1) / geo);
         r.nunits = (int)(gc * (d.ny / 2 + 1) * r.neb);
         r.scale = d.scale;
         int maxrad = 0;
@@ -183,6 +196,7 @@ int run_fused_inner(const xrfthip_plan* P, const void* in, void* out, char* ws, 
         const dim3 grid((unsigned)(8 * ((r.nunits + 7) / 8))), blk((unsigned)hg.thr);
         rec = prof_begin(P, "fastn_irows", st);
 #define NI_(TT, CC) do { if (d.out_mode == XRFTHIP_OUT_POWER) { auto k = &fastn_irows_kernel<TT, 1, CC>; XRFT_LAUNCH(k, grid, blk, P->n_r.lds, st, r); } \
+                         else if (crossm) { auto k = &fastn_irows_kernel<TT, 2, CC>; XRFT_LAUNCH(k, grid, blk, P->n_r.lds, st, r); } \
                          else { auto k = &fastn_irows_kernel<TT, 0, CC>; XRFT_LAUNCH(k, grid, blk, P->n_r.lds, st, r); } } while (0)
         if (P->dbl) NI_(double, 16); else if (maxrad > 16) NI_(float, 20); else NI_(float, 16);
 #undef NI_
@@ -195,7 +209,7 @@ int run_fused_inner(const xrfthip_plan* P, const void* in, void* out, char* ws, 
 // composite plan for xrfthip_desc.inner > 1 (see xrfthip_plan::inner)
 int create_inner_plan(xrfthip_plan** plan, const xrfthip_desc& d) {
     if (xrfthip_plan* F = create_fused_inner(d)) { *plan = F; return XRFTHIP_OK; }
-    if (d.flags & (XRFTHIP_HALF_X | XRFTHIP_REALDIM_X2)) return XRFTHIP_UNSUPPORTED_LENGTH;  // (real_dim: the fused passes only; the caller transposes)
+    if ((d.flags & (XRFTHIP_HALF_X | XRFTHIP_REALDIM_X2)) || d.out_mode == XRFTHIP_OUT_CROSS) return XRFTHIP_UNSUPPORTED_LENGTH;  // (real_dim, two fields: the fused passes only; the caller transposes)
     const uint32_t ok = XRFTHIP_SHIFT_Y | XRFTHIP_SHIFT_X | XRFTHIP_ISHIFT_Y | XRFTHIP_ISHIFT_X | XRFTHIP_FLIP_Y | XRFTHIP_FLIP_X;
     if (d.ndim != 2 || (d.flags & ~ok) || (d.out_mode != XRFTHIP_OUT_COMPLEX && d.out_mode != XRFTHIP_OUT_POWER)) return XRFTHIP_BAD_ARG;
     if (d.inner > (1LL << 30) || d.mid > (1LL << 30) || d.nx * d.inner > (1LL << 30) || d.mid * d.nx * d.inner > (1LL << 30) || d.batch * d.mid > (1LL << 40)) return XRFTHIP_BAD_ARG;

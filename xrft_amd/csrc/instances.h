@@ -84,11 +84,12 @@ XRFT_M_LATLON(XRFT_KI_M1F_) XRFT_M_F32ONLY(XRFT_KI_M1F_) XRFT_M_F32_1AX(XRFT_KI_
 #if XRFT_KI_ON(6)
 XRFT_KI_N_(float, 16) XRFT_KI_N_(float, 20) XRFT_KW void fastn_cols_kernel<float, 1, 16>(FastN); XRFT_KW void fastn_cols_kernel<float, 2, 16>(FastN);  /* (the chirp-convolution and the Rader columns: radices up to 16) */
 XRFT_KW void fastn_irows_kernel<float, 0, 16>(FastNI); XRFT_KW void fastn_irows_kernel<float, 1, 16>(FastNI); XRFT_KW void fastn_irows_kernel<float, 0, 20>(FastNI); XRFT_KW void fastn_irows_kernel<float, 1, 20>(FastNI);
+XRFT_KW void fastn_irows_kernel<float, 2, 16>(FastNI); XRFT_KW void fastn_irows_kernel<float, 2, 20>(FastNI);
 XRFT_KW void fastn_fit_inner_kernel<float>(const double*, const float*, C2<float>*, int, int, int, int, int, int);
 #endif
 #if XRFT_KI_ON(7)
 XRFT_KI_N_(double, 16) XRFT_KW void fastn_cols_kernel<double, 1, 16>(FastN); XRFT_KW void fastn_cols_kernel<double, 2, 16>(FastN);
-XRFT_KW void fastn_irows_kernel<double, 0, 16>(FastNI); XRFT_KW void fastn_irows_kernel<double, 1, 16>(FastNI);
+XRFT_KW void fastn_irows_kernel<double, 0, 16>(FastNI); XRFT_KW void fastn_irows_kernel<double, 1, 16>(FastNI); XRFT_KW void fastn_irows_kernel<double, 2, 16>(FastNI);
 XRFT_KW void fastn_fit_inner_kernel<double>(const double*, const double*, C2<double>*, int, int, int, int, int, int);
 #endif
 #undef XRFT_KI_N_

@@ -506,7 +506,7 @@ int run_fastr(const xrfthip_plan* P, const void* in, void* out, hipStream_t st);
 int run_fasts(const xrfthip_plan* P, const void* in, void* out, double* iso, hipStream_t st);
 int run_fasty(const xrfthip_plan* P, const float* in, const float* in1, void* out, double* iso, char* ws, hipStream_t st);
 int run_fastyc(const xrfthip_plan* P, const void* in, void* out, char* ws, hipStream_t st);
-int run_fused_inner(const xrfthip_plan* P, const void* in, void* out, char* ws, hipStream_t st);
+int run_fused_inner(const xrfthip_plan* P, const void* in, const void* in1, void* out, char* ws, hipStream_t st);
 int run_inner_plan(const xrfthip_plan* P, const void* in, void* out, char* ws, hipStream_t st);
 int run_radial_sums(int32_t dtype, const void* spec, const int32_t* d_binmap, long long bc, long long ny, long long nxo, int sy, int sx, int nbins, int chunks, double* part, double* iso, hipStream_t st);
 int upload_real_table(xrfthip_plan* P, DevBuf& buf, const double* h, int64_t n, int cplx);

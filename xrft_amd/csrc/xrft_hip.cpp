@@ -1524,7 +1524,7 @@ int xrfthip_exec(const xrfthip_plan* plan, const void* d_in0, const void* d_in1,
     if (iso && (!d_iso || !P->binmap.p)) return d_iso ? XRFTHIP_MISSING_TABLE : XRFTHIP_BAD_ARG;
     if (P->fusedi) {
         if (ws_bytes < P->ws_bytes || !d_workspace) return XRFTHIP_WORKSPACE_TOO_SMALL;
-        return d.batch == 0 ? XRFTHIP_OK : run_fused_inner(P, d_in0, d_out, (char*)d_workspace, (hipStream_t)stream);
+        return d.batch == 0 ? XRFTHIP_OK : run_fused_inner(P, d_in0, d_in1, d_out, (char*)d_workspace, (hipStream_t)stream);
     }
     if (P->sub_x) {
         if (ws_bytes < P->ws_bytes || !d_workspace) return XRFTHIP_WORKSPACE_TOO_SMALL;
