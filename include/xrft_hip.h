@@ -42,7 +42,7 @@
 extern "C" {
 #endif
 
-#define XRFTHIP_VERSION 105 /* 0.1.5: xrfthip_selftest_floor; 0.1.4: XRFTHIP_AXIS_Y with XRFTHIP_HALF_X / REALDIM_X2 (real_dim along the one transformed axis); 0.1.3: xrfthip_desc.mid (two transform axes anywhere in a C-contiguous array); 0.1.2: xrfthip_plan_uses_bluestein, xrfthip_convert (0.1.1: xrfthip_desc.inner, xrfthip_reduce_axis, xrfthip_detrend_inner) */
+#define XRFTHIP_VERSION 106 /* 0.1.6: the inner / mid layouts take OUT_CROSS (two real fields) and XRFTHIP_HALF_X / REALDIM_X2 (real_dim along the second axis) on their fused passes; 0.1.5: xrfthip_selftest_floor; 0.1.4: XRFTHIP_AXIS_Y with XRFTHIP_HALF_X / REALDIM_X2 (real_dim along the one transformed axis); 0.1.3: xrfthip_desc.mid (two transform axes anywhere in a C-contiguous array); 0.1.2: xrfthip_plan_uses_bluestein, xrfthip_convert (0.1.1: xrfthip_desc.inner, xrfthip_reduce_axis, xrfthip_detrend_inner) */
 
 typedef enum xrfthip_status {
     XRFTHIP_OK = 0,
@@ -125,7 +125,9 @@ typedef struct xrfthip_desc {
      * any axes where they lie, xrft/xrft.py:395-409), e.g. dim = ["y", "x"] of a (y, x, time) array: batch = 1, inner = nt.  No transposed
      * copy is made: x is transformed where it lies ([batch ny][nx][inner], as XRFTHIP_AXIS_Y does for one axis), then y
      * ([batch][ny][nx inner]); a detrend runs first as a pass of its own.  ndim = 2, out_mode COMPLEX | POWER, flags SHIFT_* /
-     * ISHIFT_* / FLIP_*; windows, phases and `scale` as usual.  0 or 1 = the trailing-axes layout.  A descriptor with the
+     * ISHIFT_* / FLIP_*; windows, phases and `scale` as usual.  ABI 0.1.6: real input of a smooth shape (the two fused passes) also takes out_mode CROSS
+     * (d_in1 = the second field, same layout) and XRFTHIP_HALF_X / REALDIM_X2 (real_dim along the SECOND transform axis: output [batch][ny][mid][nx/2 + 1][inner],
+     * unshifted); XRFTHIP_UNSUPPORTED_LENGTH where only the composite of one-axis plans exists (the caller transposes).  0 or 1 = the trailing-axes layout.  A descriptor with the
      * struct_size of the version without this field is accepted (inner = 1). */
     int64_t inner;
     /* ... and `mid` independent elements BETWEEN the two transform axes (ABI 0.1.3): with inner > 1 or mid > 1 the arrays are

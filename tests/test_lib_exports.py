@@ -32,7 +32,7 @@ def test_library_builds_loads_and_exports():
     for name in declared_symbols():
         assert hasattr(dll, name), name
     dll.xrfthip_version.restype = ctypes.c_int
-    assert dll.xrfthip_version() == 105  # XRFTHIP_VERSION in include/xrft_hip.h
+    assert dll.xrfthip_version() == 106  # XRFTHIP_VERSION in include/xrft_hip.h
     dll.xrfthip_strerror.restype = ctypes.c_char_p
     assert b"unsupported" in dll.xrfthip_strerror(-2)
 
