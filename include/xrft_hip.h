@@ -106,6 +106,9 @@ typedef enum xrfthip_detrend_kind {
  * FLIP_X flip field 1 (d_in1).  The window always multiplies in the source order, before the flip (xrft.py:425-441). */
 #define XRFTHIP_FLIP0_Y 0x4000u
 #define XRFTHIP_FLIP0_X 0x8000u
+/* inner / mid layouts only (ABI 0.1.6): real_dim along the FIRST of the two transform axes -- ky = 0..ny/2 is stored, output [batch][ny/2 + 1][mid][nx][inner], unshifted;
+ * with REALDIM_X2 and POWER|CROSS 0 < ky < ny/2 counts twice.  Real input, no SHIFT_*, not together with HALF_X. */
+#define XRFTHIP_HALF_Y 0x10000u
 
 typedef struct xrfthip_desc {
     uint32_t struct_size; /* = sizeof(xrfthip_desc) */
@@ -127,7 +130,7 @@ typedef struct xrfthip_desc {
      * ([batch][ny][nx inner]); a detrend runs first as a pass of its own.  ndim = 2, out_mode COMPLEX | POWER, flags SHIFT_* /
      * ISHIFT_* / FLIP_*; windows, phases and `scale` as usual.  ABI 0.1.6: real input of a smooth shape (the two fused passes) also takes out_mode CROSS
      * (d_in1 = the second field, same layout) and XRFTHIP_HALF_X / REALDIM_X2 (real_dim along the SECOND transform axis: output [batch][ny][mid][nx/2 + 1][inner],
-     * unshifted); XRFTHIP_UNSUPPORTED_LENGTH where only the composite of one-axis plans exists (the caller transposes).  0 or 1 = the trailing-axes layout.  A descriptor with the
+     * unshifted) or XRFTHIP_HALF_Y (along the FIRST: [batch][ny/2 + 1][mid][nx][inner]); XRFTHIP_UNSUPPORTED_LENGTH where only the composite of one-axis plans exists (the caller transposes).  0 or 1 = the trailing-axes layout.  A descriptor with the
      * struct_size of the version without this field is accepted (inner = 1). */
     int64_t inner;
     /* ... and `mid` independent elements BETWEEN the two transform axes (ABI 0.1.3): with inner > 1 or mid > 1 the arrays are

@@ -1468,6 +1468,12 @@ def run_fused_inner_cases(dtype="float64", shapes=((24, 20, 6), (16, 48, 3), (36
                 for kw in kws:
                     worst = max(worst, check(fn(da, dim=["y", "x"], real_dim="x", **kw), ofn(od, dim=["y", "x"], real_dim="x", **kw), tol))
                     assert "[fastn fused]" in next(reversed(xa.api._plan_cache.values())).describe(), (shape, kw)
+        if ny % 2 == 0:  # ... and along the axis of the pair that comes FIRST in memory (XRFTHIP_HALF_Y: rows ky = 0 .. ny/2, no twin rows)
+            for fn, ofn, kw in ((xa.fft, o.fft, dict(detrend="linear", window="hann")), (xa.power_spectrum, o.power_spectrum, dict()), (xa.power_spectrum, o.power_spectrum, dict(scaling="spectrum", detrend="constant"))):
+                worst = max(worst, check(fn(da, dim=["x", "y"], real_dim="y", **kw), ofn(od, dim=["x", "y"], real_dim="y", **kw), tol))
+                assert "[fastn fused]" in next(reversed(xa.api._plan_cache.values())).describe(), (shape, kw)
+            worst = max(worst, check(xa.cross_spectrum(da, db, dim=["x", "y"], real_dim="y", detrend="linear"), o.cross_spectrum(od, ob, dim=["x", "y"], real_dim="y", detrend="linear"), tol))
+            assert "[fastn fused]" in next(reversed(xa.api._plan_cache.values())).describe(), shape
     return worst
 
 
@@ -1508,6 +1514,9 @@ def run_fused_mid_cases(dtype="float64", shapes=((24, 5, 20), (16, 3, 48), (36, 
                 for kw in kws:
                     worst = max(worst, check(fn(da, dim=["t", "x"], real_dim="x", **kw), ofn(od, dim=["t", "x"], real_dim="x", **kw), tol))
                     assert "[fastn fused]" in next(reversed(xa.api._plan_cache.values())).describe(), (shape, kw)
+        if nt % 2 == 0:  # real_dim = the FIRST axis of the pair (time): XRFTHIP_HALF_Y
+            worst = max(worst, check(xa.power_spectrum(da, dim=["x", "t"], real_dim="t", detrend="linear", window="hann"), o.power_spectrum(od, dim=["x", "t"], real_dim="t", detrend="linear", window="hann"), tol))
+            assert "[fastn fused]" in next(reversed(xa.api._plan_cache.values())).describe(), shape
     return worst
 
 

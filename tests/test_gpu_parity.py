@@ -1004,8 +1004,9 @@ def test_two_axes_with_the_batch_innermost_without_copies(dtype):
     x = torch.from_numpy(v).cuda()
     da = xa.DataArray(x, ("y", "x", "t"), c)
     kw = dict(dim=["y", "x"], detrend="linear", window="hann")
-    for fn, ofn, rd in ((xa.power_spectrum, o.power_spectrum, None), (xa.fft, o.fft, None), (xa.power_spectrum, o.power_spectrum, "x"), (xa.fft, o.fft, "x")):
-        kw["real_dim"] = rd  # (round 6: real_dim along the second axis -- the half output of the fused passes, no transposed copy either)
+    for fn, ofn, rd in ((xa.power_spectrum, o.power_spectrum, None), (xa.fft, o.fft, None), (xa.power_spectrum, o.power_spectrum, "x"), (xa.fft, o.fft, "x"), (xa.power_spectrum, o.power_spectrum, "y")):
+        kw["real_dim"] = rd  # (round 6: real_dim along either axis of the pair -- the half output of the fused passes, no transposed copy either)
+        kw["dim"] = ["x", "y"] if rd == "y" else ["y", "x"]
         res = fn(da, **kw)
         assert "[inner layout]" in next(reversed(api._plan_cache.values())).describe()
         del res
@@ -1017,7 +1018,8 @@ def test_two_axes_with_the_batch_innermost_without_copies(dtype):
         peak = torch.cuda.max_memory_allocated() - before
         out_bytes = res.data.numel() * res.data.element_size()
         assert peak <= out_bytes + (1 << 20), (peak, out_bytes)
-        assert res.data.is_contiguous() and tuple(res.dims) == ("freq_y", "freq_x", "t") and res.data.shape[1] == (shape[1] // 2 + 1 if rd else shape[1])
+        assert res.data.is_contiguous() and tuple(res.dims) == ("freq_y", "freq_x", "t")
+        assert tuple(res.data.shape[:2]) == (shape[0] // 2 + 1 if rd == "y" else shape[0], shape[1] // 2 + 1 if rd == "x" else shape[1])
         cases.check(res, ofn(o.OArr(v.astype(np.float64), ("y", "x", "t"), c), **kw), 2e-4 if dtype == "float32" else 1e-10)
 
 

@@ -22,6 +22,7 @@ BAD_ARG = -1  # xrfthip_status
 UNSUPPORTED_LENGTH = -2
 AXIS_Y = 0x2000  # transform y of [batch][ny][nx] in place (a middle or first axis of the array), no transposed copy
 FLIP0_Y, FLIP0_X = 0x4000, 0x8000  # cross spectra: flip field 0 (FLIP_Y / FLIP_X then flip field 1)
+HALF_Y = 0x10000  # inner / mid layouts (ABI 0.1.6): real_dim along the FIRST of the two transform axes (ny / 2 + 1 rows out)
 # xrfthip_kernel_kind (xrfthip_plan_kernel_info)
 K_GENERIC, K_FASTY, K_FASTM, K_FASTN, K_FASTM_Y, K_FASTM_X, K_FASTG_Y, K_FASTG_ROWS, K_FASTG, K_FASTS, K_FASTR, K_COMPOSITE = range(12)
 

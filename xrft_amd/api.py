@@ -558,8 +558,8 @@ def _execute_axis_y(c, da, mode, scale, k, da2=None, c2=None, extra_flags=0):
 
 def _swap_xy(flags):
     """The per-axis flag bits with the roles of x and y exchanged."""
-    out = flags & ~(_lib.SHIFT_X | _lib.SHIFT_Y | _lib.ISHIFT_X | _lib.ISHIFT_Y | _lib.FLIP_X | _lib.FLIP_Y)
-    for fx, fy in ((_lib.SHIFT_X, _lib.SHIFT_Y), (_lib.ISHIFT_X, _lib.ISHIFT_Y), (_lib.FLIP_X, _lib.FLIP_Y)):
+    out = flags & ~(_lib.SHIFT_X | _lib.SHIFT_Y | _lib.ISHIFT_X | _lib.ISHIFT_Y | _lib.FLIP_X | _lib.FLIP_Y | _lib.HALF_X | _lib.HALF_Y)
+    for fx, fy in ((_lib.SHIFT_X, _lib.SHIFT_Y), (_lib.ISHIFT_X, _lib.ISHIFT_Y), (_lib.FLIP_X, _lib.FLIP_Y), (_lib.HALF_X, _lib.HALF_Y)):
         if flags & fx:
             out |= fy
         if flags & fy:
@@ -575,8 +575,6 @@ def _execute_inner(c, da, mode, scale, extra_flags=0, da2=None, c2=None):
     if len(c.dim) != 2 or mode not in (_lib.OUT_COMPLEX, _lib.OUT_POWER, _lib.OUT_CROSS):
         return None
     p, q = da.get_axis_num(c.ydim), da.get_axis_num(c.xdim)
-    if c.real_dim is not None and p > q:
-        return None  # (real_dim is the axis that comes FIRST in memory: the half output of the fused passes lies along their second axis)
     first, second = min(p, q), max(p, q)
     if second == first + 1 and second == len(da.dims) - 1:
         return None  # (the trailing pair: the fused two-axis plans)
@@ -611,7 +609,7 @@ def _execute_inner(c, da, mode, scale, extra_flags=0, da2=None, c2=None):
             return None
         raise
     out, _ = plan.execute(t, t2)
-    shape[second] = plan.nx_out  # (real_dim: nx / 2 + 1 samples along the second axis)
+    shape[first], shape[second] = plan.ny_out, plan.nx_out  # (real_dim: n / 2 + 1 samples along that axis -- the second of the pair in memory, or the first: XRFTHIP_HALF_Y)
     return out.reshape(shape)
 
 

@@ -695,6 +695,7 @@ struct FastNI {
     int sx, se, midlay;
     // real_dim along the second axis (XRFTHIP_HALF_X, xrft.py:400-404): rows of nx/2 + 1 samples, unshifted along x; realdim2: 0 < kx < nx/2 counts twice (xrft.py:673-682)
     int half, realdim2;
+    int half_y;          // real_dim along the FIRST axis (XRFTHIP_HALF_Y): rows ky = 0 .. ny/2 only, no twin rows; realdim2 then doubles 0 < ky < ny/2
     // MODE 2, the cross spectrum of two fields (xrft.cross_spectrum, xrft.py:825): the workgroup's sequences are GE/2 of field 0 followed by the SAME GE/2 elements of field 1
     // (its intermediate and plane corrections: w2b, corrb); the result is F0 conj(F1), the twin row its conjugate
     const void* w2b;
@@ -773,11 +774,13 @@ __global__ void __launch_bounds__(fastn_max_threads<T>(), (sizeof(T) == 4 ? 4 : 
     const int WO = p.half ? NX / 2 + 1 : NX;
     const float ipn = g.inv_pnq, inv_nx = 1.0f / (float)WO;
     if ((p.dbg & 2) && lds[tid].re != (T)1.2345) return;
-    const bool twin = ky != 0 && 2 * ky != p.ny;
+    const bool interior_y = ky != 0 && 2 * ky != p.ny, twin = interior_y && !p.half_y;
     const int tot = (WO << lgo) * (twin ? 2 : 1);
+    const int NYO = p.half_y ? nyh + 1 : p.ny;  // rows of a slab of the result
+    const bool dbl_y = p.half_y && p.realdim2 && interior_y;  // (the kept half of the real FIRST axis counts twice)
     const int fbo = GEO * g.str;  // (MODE 2: field 1's sequence of an element, behind field 0's)
     typedef typename std::conditional<MODE != 1, CT, T>::type OutT;
-    OutT* __restrict__ outs = reinterpret_cast<OutT*>(p.out) + (size_t)slab * p.ny * WO * p.inner;
+    OutT* __restrict__ outs = reinterpret_cast<OutT*>(p.out) + (size_t)slab * NYO * WO * p.inner;
     if (p.vec) {  // 16-byte pieces of the result: VW consecutive elements e per thread (the host checked inner % VW == 0 and GE % VW == 0)
         constexpr int VW = 16 / (int)sizeof(OutT), LV = VW == 4 ? 2 : VW == 2 ? 1 : 0;
         const int lgq = lgo - LV, totv = tot >> LV;
@@ -790,7 +793,7 @@ __global__ void __launch_bounds__(fastn_max_threads<T>(), (sizeof(T) == 4 ? 4 : 
             int orow = fy + sy; if (orow >= p.ny) orow -= p.ny;
             const CT* src = lds + ge * g.str + n_pad(kx, ipn);
             OutT o[VW];
-            const T scv = (p.realdim2 && fx != 0 && 2 * fx != NX) ? sc + sc : sc;
+            const T scv = (dbl_y || (!p.half_y && p.realdim2 && fx != 0 && 2 * fx != NX)) ? sc + sc : sc;
             CT ph = mk<T>((T)1, (T)0);
             if (MODE != 1 && p.ph_on) ph = cmul(reinterpret_cast<const CT*>(p.ph_y)[fy], reinterpret_cast<const CT*>(p.ph_x)[fx]);
 #pragma unroll
@@ -825,9 +828,9 @@ __global__ void __launch_bounds__(fastn_max_threads<T>(), (sizeof(T) == 4 ? 4 : 
         if (MODE == 2) v = cmulc(v, lds[ge * g.str + fbo + n_pad(kx, ipn)]);  // F0 conj(F1)
         OutT* dst = outs + (size_t)orow * WO * p.inner + (size_t)oc * osx + (size_t)e * ose;
         if (MODE == 1) {
-            *reinterpret_cast<T*>(dst) = (v.re * v.re + v.im * v.im) * ((p.realdim2 && fx != 0 && 2 * fx != NX) ? sc + sc : sc);
+            *reinterpret_cast<T*>(dst) = (v.re * v.re + v.im * v.im) * ((dbl_y || (!p.half_y && p.realdim2 && fx != 0 && 2 * fx != NX)) ? sc + sc : sc);
         } else {
-            v = cscale(v, (MODE == 2 && p.realdim2 && fx != 0 && 2 * fx != NX) ? sc + sc : sc);
+            v = cscale(v, (MODE == 2 && (dbl_y || (!p.half_y && p.realdim2 && fx != 0 && 2 * fx != NX))) ? sc + sc : sc);
             if (mir) v = cconj(v);
             if (p.ph_on) v = cmul(v, cmul(reinterpret_cast<const CT*>(p.ph_y)[fy], reinterpret_cast<const CT*>(p.ph_x)[fx]));
             *reinterpret_cast<CT*>(dst) = v;

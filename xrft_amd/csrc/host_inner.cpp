@@ -28,11 +28,11 @@ xrfthip_plan* create_fused_inner(const xrfthip_desc& d) {
     const bool crossm = d.out_mode == XRFTHIP_OUT_CROSS;
     if (d.out_mode != XRFTHIP_OUT_COMPLEX && d.out_mode != XRFTHIP_OUT_POWER && !crossm) return nullptr;
     // (real_dim along the second axis -- HALF_X, the power spectrum's REALDIM_X2: rows of nx/2 + 1 samples out of pass 2, unshifted along x)
-    const uint32_t ok = XRFTHIP_SHIFT_Y | XRFTHIP_SHIFT_X | XRFTHIP_HALF_X | (d.out_mode != XRFTHIP_OUT_POWER ? (XRFTHIP_ISHIFT_Y | XRFTHIP_ISHIFT_X) : 0u) |
+    const uint32_t ok = XRFTHIP_SHIFT_Y | XRFTHIP_SHIFT_X | XRFTHIP_HALF_X | XRFTHIP_HALF_Y | (d.out_mode != XRFTHIP_OUT_POWER ? (XRFTHIP_ISHIFT_Y | XRFTHIP_ISHIFT_X) : 0u) |
                         (d.out_mode != XRFTHIP_OUT_COMPLEX ? XRFTHIP_REALDIM_X2 : 0u);
     if (d.flags & ~ok) return nullptr;  // (a flipped axis: the composite of one-axis plans)
     if ((d.flags & XRFTHIP_HALF_X) && ((d.flags & XRFTHIP_SHIFT_X) || (d.nx & 1))) return nullptr;
-    if ((d.flags & XRFTHIP_REALDIM_X2) && !(d.flags & XRFTHIP_HALF_X)) return nullptr;
+    if ((d.flags & XRFTHIP_REALDIM_X2) && !(d.flags & (XRFTHIP_HALF_X | XRFTHIP_HALF_Y))) return nullptr;
     const bool dbl = d.dtype == XRFTHIP_F64;
     const size_t rs = dbl ? 8 : 4, cs = 2 * rs;
     const long long ncol = d.nx * ne;
@@ -175,7 +175,8 @@ int run_fused_inner(const xrfthip_plan* P, const void* in, const void* in1, void
         r.tw_x = P->tw_fx.p; r.twm = P->n_r.twm.p; r.g = (NGeoPtr)P->n_r.geo_dev.p;
         r.ph_y = P->fph[0].p; r.ph_x = P->fph[1].p; r.ph_on = (d.out_mode != XRFTHIP_OUT_POWER && P->fph_on) ? 1 : 0;
         r.half = (d.flags & XRFTHIP_HALF_X) ? 1 : 0; r.realdim2 = (d.flags & XRFTHIP_REALDIM_X2) ? 1 : 0;
-        r.out = (char*)out + (size_t)g0 * d.ny * (size_t)P->nx_out * ne * out_esz;
+        r.half_y = (d.flags & XRFTHIP_HALF_Y) ? 1 : 0;  // (real_dim along the first axis: rows ky = 0 .. ny/2, no twin rows)
+        r.out = (char*)out + (size_t)g0 * (size_t)(r.half_y ? d.ny / 2 + 1 : d.ny) * (size_t)P->nx_out * ne * out_esz;
         const int geo = crossm ? P->n_r.geo.g / 2 : P->n_r.geo.g;  // elements a row workgroup writes
         r.ny = (int)d.ny; r.nx = (int)d.nx; r.inner = (int)ne; r.sx = sx; r.se = se; r.midlay = midlay ? 1 : 0; r.nrow_pad = P->y_nrow_pad; r.pitch = (int)P->y_pitch;
         r.l_cw = m.l_cw; r.l_rk = m.l_rk; r.detrend = d.detrend;
@@ -209,7 +210,7 @@ int run_fused_inner(const xrfthip_plan* P, const void* in, const void* in1, void
 // composite plan for xrfthip_desc.inner > 1 (see xrfthip_plan::inner)
 int create_inner_plan(xrfthip_plan** plan, const xrfthip_desc& d) {
     if (xrfthip_plan* F = create_fused_inner(d)) { *plan = F; return XRFTHIP_OK; }
-    if ((d.flags & (XRFTHIP_HALF_X | XRFTHIP_REALDIM_X2)) || d.out_mode == XRFTHIP_OUT_CROSS) return XRFTHIP_UNSUPPORTED_LENGTH;  // (real_dim, two fields: the fused passes only; the caller transposes)
+    if ((d.flags & (XRFTHIP_HALF_X | XRFTHIP_HALF_Y | XRFTHIP_REALDIM_X2)) || d.out_mode == XRFTHIP_OUT_CROSS) return XRFTHIP_UNSUPPORTED_LENGTH;  // (real_dim, two fields: the fused passes only; the caller transposes)
     const uint32_t ok = XRFTHIP_SHIFT_Y | XRFTHIP_SHIFT_X | XRFTHIP_ISHIFT_Y | XRFTHIP_ISHIFT_X | XRFTHIP_FLIP_Y | XRFTHIP_FLIP_X;
     if (d.ndim != 2 || (d.flags & ~ok) || (d.out_mode != XRFTHIP_OUT_COMPLEX && d.out_mode != XRFTHIP_OUT_POWER)) return XRFTHIP_BAD_ARG;
     if (d.inner > (1LL << 30) || d.mid > (1LL << 30) || d.nx * d.inner > (1LL << 30) || d.mid * d.nx * d.inner > (1LL << 30) || d.batch * d.mid > (1LL << 40)) return XRFTHIP_BAD_ARG;

@@ -823,7 +823,8 @@ int xrfthip_plan_create(xrfthip_plan** plan, const xrfthip_desc* desc) {
     const bool cplx_in = d.dtype >= XRFTHIP_C64;
     if ((d.flags & XRFTHIP_HALF_X) && cplx_in) return XRFTHIP_BAD_ARG;
     if ((d.flags & XRFTHIP_HALF_X) && (d.flags & (XRFTHIP_SHIFT_X | XRFTHIP_SHIFT_Y))) return XRFTHIP_BAD_ARG;  // xrft.py:403
-    if ((d.flags & XRFTHIP_REALDIM_X2) && (!(d.flags & XRFTHIP_HALF_X) || d.out_mode == XRFTHIP_OUT_COMPLEX)) return XRFTHIP_BAD_ARG;
+    if ((d.flags & XRFTHIP_HALF_Y) && (cplx_in || !(d.inner > 1 || d.mid > 1) || (d.ny & 1) || (d.flags & (XRFTHIP_HALF_X | XRFTHIP_SHIFT_X | XRFTHIP_SHIFT_Y | XRFTHIP_AXIS_Y)))) return XRFTHIP_BAD_ARG;
+    if ((d.flags & XRFTHIP_REALDIM_X2) && (!(d.flags & (XRFTHIP_HALF_X | XRFTHIP_HALF_Y)) || d.out_mode == XRFTHIP_OUT_COMPLEX)) return XRFTHIP_BAD_ARG;
     if ((d.flags & XRFTHIP_ISO) && (d.ndim != 2 || d.out_mode == XRFTHIP_OUT_COMPLEX)) return XRFTHIP_BAD_ARG;
     if ((d.flags & XRFTHIP_NO_SPECTRUM_OUT) && !(d.flags & XRFTHIP_ISO)) return XRFTHIP_BAD_ARG;
     if (d.ndim == 1 && (d.flags & (XRFTHIP_SHIFT_Y | XRFTHIP_ISHIFT_Y | XRFTHIP_FLIP_Y))) return XRFTHIP_BAD_ARG;

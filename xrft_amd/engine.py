@@ -44,7 +44,7 @@ class SpectralPlan:
             raise TypeError(f"unsupported dtype {dtype}")
         self.ndim, self.batch, self.ny, self.nx = int(ndim), int(batch), int(ny), int(nx)
         self.dtype, self.out_mode, self.flags = dtype, int(out_mode), int(flags)
-        half_y = bool(flags & _lib.HALF_X) and bool(flags & _lib.AXIS_Y)  # (ABI 0.1.4: real_dim along the ONE transformed axis of an AXIS_Y plan)
+        half_y = (bool(flags & _lib.HALF_X) and bool(flags & _lib.AXIS_Y)) or bool(flags & _lib.HALF_Y)  # (ABI 0.1.4: real_dim along the ONE transformed axis of an AXIS_Y plan; 0.1.6: HALF_Y of the inner / mid layouts)
         self.nx_out = self.nx // 2 + 1 if ((flags & _lib.HALF_X) and not half_y) else self.nx
         self.ny_out = self.ny // 2 + 1 if half_y else self.ny
         self.nbins = int(nbins)
@@ -128,7 +128,7 @@ class SpectralPlan:
         if want_out and out is None:
             shape = (self.batch, self.ny_out, self.nx_out) + ((self.inner,) if self.inner > 1 else ())
             if self.mid > 1:
-                shape = (self.batch, self.ny, self.mid, self.nx_out, self.inner)
+                shape = (self.batch, self.ny_out, self.mid, self.nx_out, self.inner)
             out = torch.empty(shape, dtype=self.out_dtype(), device=dev)
         elif want_out:  # a caller's buffer (graph capture, composed passes): held to the plan before the device sees its pointer
             need = self.batch * self.ny_out * self.nx_out * self.inner * self.mid
