@@ -1817,3 +1817,31 @@ def run_long_rows_resident_cases(n=32768, nt=600):
                 os.environ[k] = val
         xa.api.clear_plan_cache()
     return worst
+
+
+def run_inverse_non_trailing_pairs(cfgs=(((32, 48, 6), ("y", "x", "t"), ["y", "x"], "float32"), ((36, 40, 7), ("y", "x", "t"), ["x", "y"], "float64"),
+                                          ((32, 6, 48), ("t", "y", "x"), ["t", "x"], "float64"), ((2, 24, 20, 3), ("b", "y", "x", "t"), ["y", "x"], "complex128"))):
+    """xrft.ifft over two axes that are not the trailing pair (xrft.py:586-621): ifftn is separable, each axis has a plan that runs where it lies -- one axis at a time,
+    no transposed copy; the result is contiguous in the input's layout.  Every true_phase / shift combination against the oracle."""
+    import warnings
+    rng = np.random.default_rng(17)
+    worst = 0.0
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        for shape, dims, td, dt in cfgs:
+            v = rng.standard_normal(shape)
+            if dt.startswith("complex"):
+                v = v + 1j * rng.standard_normal(shape)
+            v = v.astype(dt)
+            c = {d: np.arange(n) * 0.5 + 1.0 for d, n in zip(dims, shape)}
+            da, od = pair(v, dims, c)
+            tol = 1e-10 if dt in ("float64", "complex128") else 3e-4
+            fd = ["freq_" + d for d in td]
+            for kw in (dict(), dict(true_phase=False, shift=False), dict(shift=False), dict(true_phase=False)):
+                F, Fo = xa.fft(da, dim=td, **kw), o.fft(od, dim=td, **kw)
+                g, r = xa.ifft(F, dim=fd, **kw), o.ifft(Fo, dim=fd, **kw)
+                worst = max(worst, check_values(g, r, tol))
+                assert tuple(g.dims) == tuple(dims)
+                data = g.data
+                assert data.is_contiguous() if hasattr(data, "is_contiguous") else np.asarray(data).flags["C_CONTIGUOUS"]
+    return worst

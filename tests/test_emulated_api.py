@@ -795,3 +795,8 @@ def test_caller_buffers_are_held_to_the_plan():
     for bad in (torch.empty(2 * 64 * 64 - 64), torch.empty(2, 64, 64, dtype=torch.float64), torch.empty(2, 64, 128)[:, :, ::2]):
         with pytest.raises(ValueError):
             plan.execute(x, out=bad)
+
+
+def test_inverse_transform_over_two_axes_that_are_not_the_trailing_pair():
+    """xrft.ifft of (y, x, t) / (t, y, x) spectra over [y, x] / [t, x]: one axis at a time where the axes lie, no transposed copy."""
+    cases.run_inverse_non_trailing_pairs()

@@ -1200,3 +1200,8 @@ def test_small_slabs_walked_by_a_resident_set():
 def test_long_rows_walked_by_a_resident_set(n, nt):
     """csrc/fastr.h fastr2_kernel on batches long enough for its resident set + start stagger (the default from 2 x 256 rows of 32768 samples / 4 x 256 of 16384)."""
     cases.run_long_rows_resident_cases(n, nt)
+
+
+def test_inverse_transform_over_two_axes_that_are_not_the_trailing_pair():
+    """xrft.ifft of (y, x, t) / (t, y, x) spectra over [y, x] / [t, x]: one axis at a time where the axes lie, no transposed copy."""
+    cases.run_inverse_non_trailing_pairs()

@@ -1003,6 +1003,16 @@ def ifft(daft, spacing_tol=1e-3, dim=None, real_dim=None, shift=True, true_phase
                            shift=shift, true_phase=true_phase, true_amplitude=true_amplitude, prefix=prefix,
                            lag=[lag_of[d] for d in grp])
         return to_like(from_any(cur), src)
+    if len(dim) == 2 and real_dim is None and not chunks_to_segments and sorted(daft.get_axis_num(d) for d in dim) != [len(daft.dims) - 2, len(daft.dims) - 1]:
+        # two inverse transform axes that are not the trailing pair: ifftn is separable (xrft.py:612-621) and each axis has a plan that runs where the axis lies
+        # (XRFTHIP_AXIS_Y | XRFTHIP_INVERSE; the contiguous axis: the row kernels) -- one axis at a time, no transposed copy of the spectrum or of the result
+        lag_of = dict(zip(dim, lag))
+        cur = daft
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            for d in sorted(dim, key=daft.get_axis_num):
+                cur = from_any(ifft(cur, spacing_tol=spacing_tol, dim=[d], shift=shift, true_phase=true_phase, true_amplitude=true_amplitude, prefix=prefix, lag=[lag_of[d]]))
+        return to_like(cur, src)
     # input phase factors, indexed by SOURCE position (xrft.py:574-576; applied before any reordering)
     phase = {d: (np.exp(1j * 2.0 * np.pi * np.asarray(daft[d].values, dtype=np.float64) * l) if true_phase else None)
              for d, l in zip(dim, lag)}
