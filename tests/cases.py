@@ -1454,9 +1454,15 @@ def run_fused_inner_cases(dtype="float64", shapes=((24, 20, 6), (16, 48, 3), (36
         w = (rng.standard_normal(shape) - (0.02 * jj + 1.0)[:, :, None]).astype(dtype)
         c2 = dict(c); c2["x"] = c["x"] + 1.25
         db, ob = pair(w, dims, c2)
-        for kw in (dict(), dict(detrend="linear", window="hann"), dict(true_phase=False, shift=False), dict(scaling="spectrum", detrend="constant")) + ((dict(real_dim="x", detrend="linear"),) if nx % 2 == 0 else ()):
+        big = int(np.prod(shape)) > 1500000  # (the large shapes of the GPU suite: one option set per form -- the oracle's float64 passes are the cost)
+        for kw in ((dict(detrend="linear", window="hann"),) if big else (dict(), dict(detrend="linear", window="hann"), dict(true_phase=False, shift=False), dict(scaling="spectrum", detrend="constant")) + ((dict(real_dim="x", detrend="linear"),) if nx % 2 == 0 else ())):
             worst = max(worst, check(xa.cross_spectrum(da, db, dim=["y", "x"], **kw), o.cross_spectrum(od, ob, dim=["y", "x"], **kw), tol))
             assert "[fastn fused]" in next(reversed(xa.api._plan_cache.values())).describe(), (shape, kw)
+        if big:
+            if nx % 2 == 0:
+                worst = max(worst, check(xa.power_spectrum(da, dim=["y", "x"], real_dim="x", detrend="linear", window="hann"), o.power_spectrum(od, dim=["y", "x"], real_dim="x", detrend="linear", window="hann"), tol))
+                assert "[fastn fused]" in next(reversed(xa.api._plan_cache.values())).describe(), shape
+            continue
         gph, rph = xa.cross_phase(da, db, dim=["y", "x"], window="hann"), o.cross_phase(od, ob, dim=["y", "x"], window="hann")
         assert "[fastn fused]" in next(reversed(xa.api._plan_cache.values())).describe()
         mag = np.abs(o.cross_spectrum(od, ob, dim=["y", "x"], window="hann").values)
@@ -1506,9 +1512,12 @@ def run_fused_mid_cases(dtype="float64", shapes=((24, 5, 20), (16, 3, 48), (36, 
         w = (rng.standard_normal(shape) + 0.5).astype(dtype)  # (two fields: the cross spectrum over the non-adjacent pair)
         c2 = dict(c); c2["t"] = c["t"] + 0.75
         db, ob = pair(w, dims, c2)
-        for kw in (dict(), dict(detrend="linear", window="hann"), dict(true_phase=False, shift=False)):
+        big = int(np.prod(shape)) > 1500000
+        for kw in ((dict(detrend="linear", window="hann"),) if big else (dict(), dict(detrend="linear", window="hann"), dict(true_phase=False, shift=False))):
             worst = max(worst, check(xa.cross_spectrum(da, db, dim=["t", "x"], **kw), o.cross_spectrum(od, ob, dim=["t", "x"], **kw), tol))
             assert "[fastn fused]" in next(reversed(xa.api._plan_cache.values())).describe(), (shape, kw)
+        if big:
+            continue
         if nx % 2 == 0:  # real_dim = the contiguous axis of the pair (round 6): the half output of the fused passes
             for fn, ofn, kws in ((xa.fft, o.fft, (dict(), dict(detrend="linear", window="hann"))), (xa.power_spectrum, o.power_spectrum, (dict(), dict(detrend="constant", window="hann")))):
                 for kw in kws:
