@@ -979,7 +979,8 @@ def test_two_adjacent_axes_that_are_not_the_trailing_ones(dtype):
 @pytest.mark.parametrize("dtype", ["float64", "float32"])
 def test_inner_layout_as_two_fused_passes(dtype):
     cases.run_fused_inner_cases(dtype)
-    cases.run_fused_inner_cases(dtype, shapes=((360, 256, 12), (250, 1000, 7), (2, 512, 384, 64), (1215, 90, 21)))
+    # (the 25-M-point shape costs the oracle half a minute per dtype: in the long sweep only)
+    cases.run_fused_inner_cases(dtype, shapes=((360, 256, 12), (250, 1000, 7), (1215, 90, 21)) + (((2, 512, 384, 64),) if os.environ.get("XRFT_GPU_SWEEP") == "long" else ((2, 256, 192, 32),)))
 
 
 @pytest.mark.parametrize("dtype", ["float64", "float32"])
