@@ -747,7 +747,7 @@ def test_two_transform_axes_that_are_not_adjacent(dtype):
     cases.run_mid_layout_cases(dtype)
 
 
-@pytest.mark.parametrize("n", [256, 1024, 2048, 4096, 8192, 16384])
+@pytest.mark.parametrize("n", [256, 1024, 2048, 4096, 8192, 16384, 65536, 262144])
 def test_complex_rows_in_one_pass(n):
     """csrc/fasty_c2c.h (rows of 256 .. 4096 points: the row pass on the input's own rows) and csrc/fastr.h fastc_kernel (8192, 16384) on the emulator: fft / ifft / power
     spectrum of complex64 rows against the oracle."""

@@ -40,6 +40,9 @@ struct FastYC {
     int in_pitch;        // complex elements per input row (nx; c2r: nx/2 + 1)
     int w2_nxb;          // column blocks per row block of W2 (nx / CW; c2r: nx/2 / CW + 1)
     const cf* tw_big;    // c2r: W_nx^k, k < nx/2 / 16 (the split's twiddle of lane u; times W_32^q in registers)
+    int fs;              // "four-step": a slab is ONE complex sequence of N = ny * nx points (xrft.ifft / fft of complex data along one long axis), n = nx i1 + i2:
+                         // pass 1 as it is (the sums over i1), pass 2 multiplies row k1 by W_N^(i2 k1) (tw_big: W_N^j, j < N / 16) before its transform and stores
+                         // TRANSPOSED, X[k1 + ny k2]: the rows of a unit are consecutive samples for a given k2; ph_x of an output phase is indexed by the sample k
     long long nrows;     // fastyc_rows_kernel alone on ROW-MAJOR complex rows (one transform axis, the contiguous one; `w2` = the input, l_cw = log2 nx, l_rk = 0):
                          // the number of rows (0: pass 2 of the two-pass pipeline); the input-side options of pass 1 then apply to the rows here
     float scale;
@@ -233,10 +236,47 @@ __global__ void __launch_bounds__((YRows<NX>::THR), (YRows<NX>::THR / 128 < 1 ? 
             b[q] = *reinterpret_cast<const cf*>(w2s + w2c_offset(p, (int)kyB, u + NT * q) * 8u);
         }
     }
+    if (p.fs) {  // x W_N^(i2 k1), i2 = u + NT q: W^(k1 u) (W^(k1 NT))^q -- two table loads and a product tree per row (k1 u, k1 NT < N / 16)
+        const cf wa = p.tw_big[(int)kyA * u], wb = p.tw_big[(int)kyB * u];
+        twiddle16(a, p.tw_big[(int)kyA * NT]);
+        twiddle16(b, p.tw_big[(int)kyB * NT]);
+#pragma unroll
+        for (int q = 0; q < 16; ++q) { a[q] = cmul(a[q], wa); b[q] = cmul(b[q], wb); }
+    }
     fft_p2_pair<NX>(a, b, u, mine, p.tw_x, tw2);
     // GX rows at a time staged in natural order (a round fills the transforms' LDS exactly): transform A's rows, then B's
     const int mx = NX - 1, my = p.ny - 1, sx = p.shift_x;
     cf* cstg = lds;
+    if (p.fs) {
+        // transposed: sample k = k1 + ny k2 of the sequence (fftshift of the sequence by N/2: k2 + nx/2); the GX rows of a round are GX consecutive samples.
+        // Rows staged one element apart from the natural pitch (RSC + 1: the lanes of a run read GX different banks)
+        constexpr int RSF = RSC + 1;
+        const size_t nseq = (size_t)p.ny * NX;
+#pragma unroll
+        for (int round = 0; round < 2; ++round) {
+            if (round) __syncthreads();
+#pragma unroll
+            for (int bb = 0; bb < G::NB; ++bb)
+#pragma unroll
+                for (int k3 = 0; k3 < G::R3; ++k3) cstg[g * RSF + nat16(held_k<NX>(u, bb, k3))] = round ? b[bb * G::R3 + k3] : a[bb * G::R3 + k3];
+            __syncthreads();
+            const int k1b = (int)ky0 + round * GX;  // first row of the round
+            for (int e = tid; e < GX * NX; e += THR) {
+                const int rl = e % GX, oc = e / GX, k2 = (oc - sx) & mx;  // oc: the position along k2 in the (shifted) result
+                cf v = cstg[rl * RSF + nat16(k2)];
+                const size_t pos = (size_t)slab * nseq + (size_t)oc * p.ny + (size_t)(k1b + rl);
+                if (p.power) {
+                    reinterpret_cast<float*>(p.out)[pos] = (v.re * v.re + v.im * v.im) * p.scale;
+                } else {
+                    v = cscale(v, p.scale);
+                    if (p.inv) v.im = -v.im;
+                    if (p.ph_on) v = cmul(v, p.ph_x[(k1b + rl) + p.ny * k2]);  // (indexed by the unshifted sample index)
+                    reinterpret_cast<cf*>(p.out)[pos] = v;
+                }
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int round = 0; round < 2; ++round) {
         if (round) __syncthreads();

@@ -505,7 +505,10 @@ int run_fasty(const xrfthip_plan* P, const float* in, const float* in1, void* ou
 
 // the two-pass pipeline on complex float32 slabs (fasty_c2c.h): columns -> rows, group by group
 int run_fastyc(const xrfthip_plan* P, const void* in, void* out, char* ws, hipStream_t st) {
-    const xrfthip_desc& d = P->d;
+    const xrfthip_desc& d0 = P->d;
+    // (the four-step form: every batch entry is ONE sequence of d.nx points, transformed as the [d.nx / 256][256] view)
+    struct { long long batch, ny, nx; uint32_t flags; int out_mode; double scale; } d{d0.batch, P->fastyc_fs ? d0.nx / 256 : d0.ny, P->fastyc_fs ? 256 : d0.nx, d0.flags, d0.out_mode, d0.scale};
+    const bool fs = P->fastyc_fs;
     const bool c2r = (d.flags & XRFTHIP_C2R_X) != 0;
     const long long nxt = c2r ? d.nx / 2 : d.nx;  // points of the row transforms
     const YGeomRt C = ycols_geom(d.ny), R = yrows_geom(nxt);
@@ -537,6 +540,13 @@ int run_fastyc(const xrfthip_plan* P, const void* in, void* out, char* ws, hipSt
         p.ishift_x = ((d.flags & XRFTHIP_INVERSE) && (d.flags & XRFTHIP_ISHIFT_X)) ? 1 : 0;
         p.shift_y = (d.flags & XRFTHIP_SHIFT_Y) ? (int)(d.ny / 2) : 0;
         p.shift_x = (d.flags & XRFTHIP_SHIFT_X) ? (int)(d.nx / 2) : 0;
+        if (fs) {
+            p.fs = 1;
+            // the sequence rotated by N / 2 = the view's rows rotated by ny / 2; its fftshift = the row transforms' output rotated by 128; an input phase in its
+            // separable form (finalize_plan), an output phase as the table over the whole sequence
+            p.ishift_y = p.ishift_x; p.ishift_x = 0; p.shift_y = 0;
+            if (p.ph_in) p.ph_x = reinterpret_cast<const cf*>(P->fs_phx.p);
+        }
         p.ny = (int)d.ny; p.nx = (int)d.nx; p.nslab = (int)gc;
         p.l_cw = ilog2i(cw); p.l_rk = ilog2i(rk);
         p.power = d.out_mode == XRFTHIP_OUT_POWER ? 1 : 0;

@@ -395,6 +395,8 @@ struct xrfthip_plan {
     // ... and ONE pass for a long real float32 row that fits the registers of a CU: 65536 samples per workgroup (fastr.h)
     bool fastr = false;
     bool fastr_rows = false;      // ... complex rows of 256 .. 4096 points: pass 2 of the complex two-pass pipeline on the rows of the input itself (fastyc_rows_kernel, nrows > 0)
+    bool fastyc_fs = false;       // fastyc on ONE long complex sequence per batch entry (ndim = 1, 2^16 .. 2^20 points): the [n / 256][256] view, the four-step form of pass 2 (FastYC::fs)
+    DevBuf fs_phx;                // ... the x factor of a separable input phase (PHASE_IN): 256 entries (fph[0]: the factor per row of the view)
     bool fastr_cin = false;       // ... its complex-row form: rows of 2048 .. 16384 complex64 points, forward or inverse (fastc_kernel)
     DevBuf tw_rm, tw_rs, tw_rn;   // W_M^p (p < 1024), W_1024^n (n < 32), W_N^p (p < 1024)
     long long tune_rstagger = 0;  // XRFTHIP_FASTR_STAGGER: classes << 8 | units of 3.4 us between the start of consecutive classes of workgroups (FastR::stagger)

@@ -691,6 +691,38 @@ int finalize_plan(xrfthip_plan* P) {
         if (P->d.out_mode != XRFTHIP_OUT_POWER) { const int rc = fast_phase_tables(P); if (rc) return rc; }
     } else if (P->fastr || P->fastyc) {
         if (P->d.out_mode != XRFTHIP_OUT_POWER) { const int rc = fast_phase_tables(P); if (rc) return rc; }
+        if (P->fastyc_fs) {
+            // a window has no separable form over the view; an input phase (PHASE_IN: the lag's factor on the source samples) must be one -- exp(i theta n) is:
+            // row factor ph[256 i1], column factor ph[i2] / ph[0]; checked, else the generic passes take the plan
+            bool ok = P->host_win_x.empty() && !P->win[1].p;
+            if (ok && (P->d.flags & XRFTHIP_PHASE_IN) && P->fph_on) {
+                const std::vector<double>& h = P->host_phase[1];
+                const long long n = P->d.nx, vy = n / 256;
+                ok = (long long)h.size() >= 2 * n;
+                std::vector<cf> py((size_t)vy), px(256);
+                if (ok) {
+                    const double r0 = h[0], i0 = h[1], m0 = r0 * r0 + i0 * i0;
+                    for (long long i1 = 0; i1 < vy; ++i1) { py[(size_t)i1].re = (float)h[(size_t)(512 * i1)]; py[(size_t)i1].im = (float)h[(size_t)(512 * i1 + 1)]; }
+                    for (int i2 = 0; i2 < 256; ++i2) {  // ph[i2] conj(ph[0]) / |ph[0]|^2
+                        const double re = h[(size_t)(2 * i2)], im = h[(size_t)(2 * i2 + 1)];
+                        px[(size_t)i2].re = (float)((re * r0 + im * i0) / m0); px[(size_t)i2].im = (float)((im * r0 - re * i0) / m0);
+                    }
+                    double worst = 0.0;
+                    for (long long nn = 0; nn < n; nn += 97) {  // (a sample of the products)
+                        const long long i1 = nn / 256; const int i2 = (int)(nn % 256);
+                        const double yr = h[(size_t)(512 * i1)], yi = h[(size_t)(512 * i1 + 1)], xr = (h[(size_t)(2 * i2)] * r0 + h[(size_t)(2 * i2 + 1)] * i0) / m0, xi = (h[(size_t)(2 * i2 + 1)] * r0 - h[(size_t)(2 * i2)] * i0) / m0;
+                        worst = std::max(worst, std::hypot(yr * xr - yi * xi - h[(size_t)(2 * nn)], yr * xi + yi * xr - h[(size_t)(2 * nn + 1)]));
+                    }
+                    ok = worst < 1e-9 && m0 > 0.0;
+                }
+                if (ok) {
+                    int rc = P->fph[0].upload(py.data(), py.size() * sizeof(cf));
+                    if (!rc) rc = P->fs_phx.upload(px.data(), px.size() * sizeof(cf));
+                    if (rc) return rc;
+                }
+            }
+            if (!ok) P->fastyc = P->fastyc_fs = false;  // (the generic four-step passes)
+        }
     } else if (P->fastmx) {
         if (P->d.out_mode != XRFTHIP_OUT_POWER) { const int rc = fast_phase_tables(P); if (rc) return rc; }
     } else if (P->fastmy) {
@@ -887,6 +919,22 @@ int xrfthip_plan_create(xrfthip_plan** plan, const xrfthip_desc* desc) {
             if (!rcc) rcc = P->ones4096.upload(ones.data(), ones.size() * sizeof(float));
             if (rcc) { delete P; return rcc; }
             P->yny = d.ny; P->ynx = d.nx;
+        }
+    }
+    {   // ONE long complex float32 sequence per batch entry, 2^16 .. 2^20 points (xrft.ifft of the spectrum of a long row, fft of complex rows: the inverse twin of
+        // BASELINE config 2): the same two passes on the [n / 256][256] view, pass 2 in its four-step form (before: the generic four-step passes, 49 GFFT/s)
+        const uint32_t okf = XRFTHIP_SHIFT_X | (d.out_mode == XRFTHIP_OUT_COMPLEX ? (XRFTHIP_ISHIFT_X | XRFTHIP_INVERSE | XRFTHIP_PHASE_IN) : 0u);
+        const bool fs = d.ndim == 1 && d.dtype == XRFTHIP_C64 && d.nx >= 65536 && d.nx <= 1048576 && (d.nx & (d.nx - 1)) == 0 && !d.detrend &&
+                        (d.out_mode == XRFTHIP_OUT_COMPLEX || d.out_mode == XRFTHIP_OUT_POWER) && !(d.flags & ~okf) && !env_ll("XRFTHIP_NO_FAST", 0) && env_ll("XRFTHIP_FASTYC", 1) != 0;
+        if (fs) {
+            P->fastyc = P->fastyc_fs = true;
+            std::vector<float> ones((size_t)4096, 1.0f);
+            int rcc = build_twiddle<float>(P->tw_fx, 256, 256);
+            if (!rcc) rcc = build_twiddle<float>(P->tw_big1d, d.nx, d.nx / 16);  // W_N^j, j < N / 16: the four-step twiddles of a row (k1 u, k1 NT)
+            if (!rcc) rcc = build_twiddle<float>(P->tw_fy, d.nx / 256, d.nx / 256);
+            if (!rcc) rcc = P->ones4096.upload(ones.data(), ones.size() * sizeof(float));
+            if (rcc) { delete P; return rcc; }
+            P->yny = d.nx / 256; P->ynx = 256;
         }
     }
     // a small float32 slab (64 | 128 | 256 points per axis) fits the registers of one workgroup: full power spectra in ONE pass (fasts.h)
@@ -1388,6 +1436,12 @@ int xrfthip_plan_describe(const xrfthip_plan* plan, char* buf, size_t buflen) {
                    "transform in registers (32 complex per thread, r32x%lld / r32x%lld, three LDS exchanges in halves), exact plane detrend in the workgroup, |F|^2 "
                    "rows staged in LDS and written whole with the fftshift and the Hermitian mirror, lds=%zuB; 8 algorithmic bytes per sample through memory\n",
                 G.thr, (long long)plan->d.ny, (long long)plan->d.nx, G.per_cu, (long long)plan->d.ny / 32, (long long)plan->d.nx / 32, G.lds);
+    } else if (plan->fastyc && plan->fastyc_fs) {
+        const YGeomRt C = ycols_geom(plan->d.nx / 256), R = yrows_geom(256);
+        appendf(s, "  [fasty complex rows, four-step] two passes over the [%lld][256] view of every %lld-point sequence: cols: %d thr, FFT%lld along the view's rows index (input rotation / lag phase / "
+                   "conjugation on load) -> W2 in whole lines -> rows: %d thr, %d rows/unit x W_N^(i2 k1), FFT256, stored transposed (X[k1 + %lld k2]: runs of %d samples)%s; 32 bytes per point through memory\n",
+                (long long)plan->d.nx / 256, (long long)plan->d.nx, C.thr, (long long)plan->d.nx / 256, R.thr, R.rk, (long long)plan->d.nx / 256, R.rk / 2,
+                (plan->d.flags & XRFTHIP_INVERSE) ? "; inverse: conjugate in / out" : "");
     } else if (plan->fastyc) {
         const YGeomRt C = ycols_geom(plan->d.ny), R = yrows_geom(plan->d.nx);
         if (plan->d.flags & XRFTHIP_C2R_X) {
