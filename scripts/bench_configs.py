@@ -160,7 +160,7 @@ def spec(shape, real_x=False):
     if real_x:
         c["freq_x"] = np.fft.rfftfreq(2 * (shape[-1] - 1), 1.0)
     return xrft.DataArray(z, dims, c)
-for shape in ((16384, 4096), (131072, 1024), (4096, 16384)):
+for shape in ((16384, 4096), (131072, 1024), (4096, 16384), (1024, 65536), (64, 1048576)):  # (65536 points and beyond: the four-step form on fasty_c2c.h)
     F = spec(shape)
     add(f"ifft 1-D {shape} complex64", F.data.numel(), 16, timeit(lambda: xrft.ifft(F, dim="freq_x")))
     del F
