@@ -1170,7 +1170,7 @@ def test_two_axes_that_are_not_adjacent_without_copies(dtype):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("n", [256, 512, 1024, 2048, 4096, 8192, 16384, 65536, 131072, 524288, 1048576])
+@pytest.mark.parametrize("n", [256, 512, 1024, 2048, 4096, 8192, 16384, 65536, _long_only(131072), _long_only(524288), 1048576])
 def test_complex_rows_in_one_pass(n):
     """csrc/fastr.h fastc_kernel: fft / ifft / power spectrum of (37, n) complex64 rows in one pass, against the oracle."""
     cases.run_complex_rows_cases(n, nt=37)
